@@ -1,0 +1,141 @@
+"""Pin the CPU oracle against fixtures produced by the reference's own modules
+(tests/golden/make_golden.py) and against the closed-form properties the reference tests use
+(tests/unit/test_window_engine.py, tests/unit/test_lazy_inference.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mednext_oracle as MO
+from oracle import rsunet_oracle as RO
+from oracle import window_oracle as WO
+
+
+def test_window_grids_match_reference(golden_dir):
+    g = np.load(golden_dir / "window_grids.npz")
+    for i in range(int(g["n"])):
+        img, roi, ov = g[f"img_{i}"], g[f"roi_{i}"], tuple(g[f"ov_{i}"])
+        iv = WO.scan_interval(img, roi, ov)
+        assert tuple(g[f"interval_{i}"]) == iv
+        st = WO.window_starts(img, roi, iv)
+        assert np.array_equal(np.asarray(st, np.int64).reshape(-1, 3), g[f"starts_{i}"])
+    assert len(WO.window_starts((165, 1024, 768), (112,) * 3, WO.scan_interval((165, 1024, 768), (112,) * 3, 0.5))) == 468
+
+
+def test_importance_maps_match_reference(golden_dir):
+    g = np.load(golden_dir / "importance_maps.npz")
+    for mode in ("constant", "bump", "distance_transform"):
+        for roi in ((8, 8, 8), (5, 5, 5), (2, 3, 3), (4, 6, 10)):
+            exp = g[f"{mode}_{'x'.join(map(str, roi))}"]
+            got = WO.importance_map(roi, mode)
+            assert got.shape == exp.shape
+            np.testing.assert_allclose(got, exp, rtol=2e-6, atol=0)
+    big = WO.importance_map((112,) * 3, "bump")
+    np.testing.assert_allclose(big[:, 56, 56], g["bump_112_z"], rtol=2e-6)
+    np.testing.assert_allclose(big[56, 56, :], g["bump_112_x"], rtol=2e-6)
+    np.testing.assert_allclose(big[:4, :4, :4], g["bump_112_corner"], rtol=2e-6)
+    np.testing.assert_allclose(np.array([big[i, i, i] for i in range(112)]), g["bump_112_diag"], rtol=4e-6)
+    # reference test_lazy_inference.py:73-84 known values
+    d = WO.importance_map((5, 5, 5), "distance_transform")
+    assert d[0, 0, 0] == 1 and d[1, 1, 1] == 2 and d[2, 2, 2] == 3 and np.all(d[0] == 1)
+
+
+def test_normalize_matches_reference(golden_dir):
+    g = np.load(golden_dir / "normalize.npz")
+    np.testing.assert_array_equal(WO.normalize_accumulator(g["value"], g["weight"]), g["expected"])
+    got16 = WO.normalize_accumulator(g["value16"], g["weight16"])
+    assert got16.dtype == np.float16
+    np.testing.assert_allclose(got16.astype(np.float32), g["expected16"].astype(np.float32), rtol=1e-3)
+
+
+def test_extract_window_matches_reference(golden_dir):
+    g = np.load(golden_dir / "extract_patch.npz")
+    x = torch.from_numpy(g["x"])
+    for i in range(int(g["n"])):
+        p = WO.extract_window(x, g[f"start_{i}"], g[f"roi_{i}"], str(g[f"mode_{i}"]), 0.25)
+        np.testing.assert_array_equal(p.numpy(), g[f"patch_{i}"])
+
+
+NETS = {
+    "identity": lambda x: x,
+    "patch_mean": lambda x: x + x.mean(dim=(2, 3, 4), keepdim=True),
+    "two_channel": lambda x: torch.cat([x * 0.5 + torch.linspace(0, 1, x.shape[-1]).view(1, 1, 1, 1, -1),
+                                        torch.tanh(x) - 0.25 * x.mean(dim=(2, 3, 4), keepdim=True)], 1),
+}
+
+
+def test_eager_engine_matches_reference(golden_dir):
+    g = np.load(golden_dir / "eager_engine.npz")
+    for name in g["names"]:
+        mode, pmode, net, swb = g[f"{name}__meta"]
+        y = WO.eager_sliding_window(torch.from_numpy(g[f"{name}__x"]), NETS[str(net)],
+                                    roi=tuple(g[f"{name}__roi"]), overlap=tuple(g[f"{name}__ov"]),
+                                    mode=str(mode), sw_batch_size=int(swb), padding_mode=str(pmode))
+        exp = g[f"{name}__y"]
+        assert tuple(y.shape) == exp.shape, name
+        np.testing.assert_allclose(y.numpy(), exp, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(exp).max()), err_msg=name)
+
+
+def test_eager_identity_properties():
+    # reference tests/unit/test_window_engine.py:33-104
+    img = torch.arange(24 ** 3, dtype=torch.float32).reshape(1, 1, 24, 24, 24)
+    for ov in (0.5, 0.0):
+        out = WO.eager_sliding_window(img, lambda x: x, roi=(16,) * 3, overlap=ov, mode="constant", sw_batch_size=4)
+        assert torch.allclose(out, img, atol=1e-4 * 24 ** 3)
+    small = torch.randn(1, 1, 32, 32, 32)
+    for pm in ("constant", "reflect"):
+        out = WO.eager_sliding_window(small, lambda x: x, roi=(64,) * 3, overlap=0.0, mode="constant", padding_mode=pm)
+        assert out.shape == small.shape and torch.allclose(out, small, atol=1e-4)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("c1_group", dict(width=[8, 16], down_factors=[(2, 2, 2)], norm="group", num_groups=8, activation="relu")),
+    ("aniso_inst_elu_ds", dict(width=[6, 8, 12], norm="instance", activation="elu", deep_supervision=True)),
+    ("batch_prelu_2d", dict(width=[4, 8, 8], norm="batch", activation="prelu", depth_2d=1, init=0.1)),
+])
+def test_rsunet_oracle_matches_reference(golden_dir, name, kw):
+    g = np.load(golden_dir / f"rsunet_{name}.npz")
+    st = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd__")}
+    y = RO.forward(st, torch.from_numpy(g["x"]), **kw)
+    if not isinstance(y, dict):
+        y = {"output": y}
+    for k, v in y.items():
+        np.testing.assert_allclose(v.numpy(), g["y__" + k], rtol=1e-5, atol=1e-5)
+
+
+def test_chunk_grid_matches_reference(golden_dir):
+    g = np.load(golden_dir / "chunk_grid.npz")
+    for i in range(int(g["n"])):
+        vol, ch, halo, crop = g[f"vol_{i}"], g[f"chunk_{i}"], g[f"halo_{i}"], g[f"crop_{i}"]
+        in_shape = tuple(int(v) + 2 * int(c) for v, c in zip(vol, crop))
+        rows = []
+        for idx, start, stop in WO.chunk_grid(vol, ch):
+            rs, re, lo, hi = WO.halo_region(start, stop, halo, in_shape, crop)
+            rows.append(list(idx) + list(start) + list(stop) + list(rs) + list(re) + list(lo) + list(hi))
+        assert np.array_equal(np.asarray(rows, np.int64), g[f"rows_{i}"])
+
+
+# ------------------------------------------------------------------ MedNeXt (parity unpinned)
+@pytest.mark.parametrize("size,k,millions", [("S", 3, 5.6), ("B", 3, 10.5), ("M", 3, 17.6), ("L", 3, 61.8),
+                                             ("B", 5, 11.0), ("M", 5, 18.3), ("L", 5, 63.0)])
+def test_mednext_param_counts(size, k, millions):
+    # reference table mednext_models.py:309-312 (one decimal, in millions)
+    s = MO.SIZES[size]
+    n = MO.param_count(MO.init_state(1, 32, 1, s["exp_r"], k, s["block_counts"]))
+    assert abs(n / 1e6 - millions) < 0.06, n
+
+
+def test_mednext_s_k5_param_count():
+    n = MO.param_count(MO.init_state(1, 32, 1, 2, 5, [2] * 9))
+    assert 5.9e6 <= n < 6.0e6     # table says 5.9 M (truncated)
+
+
+def test_mednext_feature_contract():
+    # reference tests/unit/test_mednext_features.py:26-55 (tiny trunk)
+    kw = dict(n_channels=4, exp_r=2, kernel_size=3, block_counts=[1] * 9)
+    st = MO.init_state(1, 4, 3, 2, 3, [1] * 9, deep_supervision=True, seed=1)
+    x = torch.randn(1, 1, 32, 32, 32)
+    f = MO.forward_features(st, x, **kw)
+    assert f.shape == (1, 4, 32, 32, 32)
+    assert torch.allclose(MO.forward_output(st, f), MO.forward(st, x, **kw))
+    outs = MO.forward(st, x, deep_supervision=True, **kw)
+    assert [tuple(o.shape[2:]) for o in outs] == [(32,) * 3, (16,) * 3, (8,) * 3, (4,) * 3, (2,) * 3]
