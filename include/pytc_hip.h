@@ -1,0 +1,175 @@
+/* pytc_hip.h -- C ABI of the MI355X (gfx950) engine for the PyTorch Connectomics hot path.
+ *
+ * Every entry point takes raw device pointers + shapes + a hipStream_t (passed as void*),
+ * launches asynchronously on that stream and returns an int status (0 = ok).  No torch
+ * types, no ownership transfer: the caller allocates every buffer, including workspaces.
+ * Re-entrant per stream; the only global state is a thread-local last-error string.
+ *
+ * The reference (PyTorch Connectomics, 100 % Python) has no FFI of its own for this path:
+ * the boundary is the two Python plug-in interfaces of SURVEY.md section 8(b).  Each entry
+ * below names the reference call site(s) (path:line under /root/reference/connectomics/)
+ * whose arithmetic it replaces; INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Layouts: activations are NDHWC ("channels last 3d"), dtype PYTC_F32 or PYTC_BF16;
+ *          parameters are fp32 in the packed layouts documented per function;
+ *          sliding-window volumes / accumulators are fp32 [C][Z][Y][X] (== NCDHW, N = 1).
+ */
+#ifndef PYTC_HIP_H
+#define PYTC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYTC_ABI_VERSION 1
+
+#define PYTC_OK 0
+#define PYTC_ERR_INVALID 1     /* bad argument (shape, dtype, alignment) */
+#define PYTC_ERR_HIP 2         /* a HIP runtime call / launch failed */
+#define PYTC_ERR_UNSUPPORTED 3 /* valid request this build has no kernel for */
+
+#define PYTC_F32 0
+#define PYTC_BF16 1
+
+/* window "view" bits (test-time-augmentation as index math, inference/tta.py:712-719,1026-1060) */
+#define PYTC_VIEW_FLIP_Z 1
+#define PYTC_VIEW_FLIP_Y 2
+#define PYTC_VIEW_FLIP_X 4
+#define PYTC_VIEW_SWAP_YX 8
+
+/* padding modes of inference/window.py:464-527 */
+#define PYTC_PAD_CONSTANT 0
+#define PYTC_PAD_REFLECT 1
+#define PYTC_PAD_REPLICATE 2
+#define PYTC_PAD_CIRCULAR 3
+
+/* blending-map combine rules (inference/window.py:137-243) */
+#define PYTC_BLEND_PRODUCT 0 /* w = max(max((wz*wy)*wx, FLT_MIN), floor)  (constant / bump) */
+#define PYTC_BLEND_MIN 1     /* w = min(min(wz, wy), wx)                    (distance transform) */
+
+/* activations */
+#define PYTC_ACT_NONE 0
+#define PYTC_ACT_SIGMOID 1
+#define PYTC_ACT_TANH 2
+#define PYTC_ACT_GELU 3
+
+/* pointwise epilogue modes */
+#define PYTC_RES_NONE 0
+#define PYTC_RES_ADD 1        /* y = f(x) + R[row]                     (MedNeXt block / down block) */
+#define PYTC_RES_UPSAMPLE 2   /* MedNeXt up block: front-pad + transposed 1x1 residual + skip     */
+
+int pytc_abi_version(void);
+const char* pytc_last_error(void);
+/* fills cu_count / lds_bytes_per_cu / gcn arch name of `device`; returns status */
+int pytc_device_info(int device, int* cu_count, int* lds_bytes_per_cu, char* arch, int arch_len);
+
+/* ---------------------------------------------------------------- sliding window --------- */
+
+/* Patch gather + boundary pad.  Replaces _extract_padded_patch_batch
+ * (inference/window.py:464-527) and the view flips of inference/tta.py:1021-1030.
+ *   vol    fp32 [C][Z][Y][X] (device)
+ *   starts host int32 [B][3] window origins (may be negative / overhang: padded by pad_mode)
+ *   out    [B][rz][ry][rx][C] in out_dtype
+ * B <= 64. */
+int pytc_gather_windows(const float* vol, int C, int Z, int Y, int X, const int32_t* starts, int B,
+                        int rz, int ry, int rx, int view, int pad_mode, float cval, void* out,
+                        int out_dtype, void* stream);
+
+/* Overlap-add of B window predictions, one launch per window IN ORDER (so the fp32 sum order
+ * is the reference's).  Replaces EagerSlidingWindowEngine._accumulate
+ * (inference/window.py:648-655), lazy.py:1216-1227, tta.py:1161-1186.
+ *   pred   [B][rz][ry][rx][C] in pred_dtype (network output, NDHWC)
+ *   wz/wy/wx fp32 per-axis blending factors (device), combined by `combine`, floored by `floor_w`
+ *   value  fp32 [C][Z][Y][X]  +=  pred * w      weight fp32 [Z][Y][X] += w  (if weight != NULL)
+ * Voxels falling outside [0,Z)x[0,Y)x[0,X) are skipped. */
+int pytc_blend_accumulate(const void* pred, int pred_dtype, int B, const int32_t* starts, int rz,
+                          int ry, int rx, int C, int view, const float* wz, const float* wy,
+                          const float* wx, int combine, float floor_w, float* value, float* weight,
+                          int Z, int Y, int X, void* stream);
+
+/* value[c][i] = act(value[c][i] / max(weight[i], clamp)), in place.  Replaces
+ * normalize_weighted_accumulator (inference/window.py:275-294) + the sigmoid/tanh of
+ * apply_preprocessing (inference/tta.py:312-402). */
+int pytc_blend_finalize(float* value, const float* weight, int C, int64_t nvox, float clamp,
+                        int act, void* stream);
+
+/* out = running ensemble update over TTA views (inference/tta_ensemble.py:85-101):
+ * mode 0 mean: acc += (x - acc) / count ; mode 1 min ; mode 2 max.  n elements fp32. */
+int pytc_ensemble_update(float* acc, const float* x, int64_t n, int mode, int count, void* stream);
+
+/* ---------------------------------------------------------------- depthwise conv ---------- */
+
+/* number of per-sample partial-statistics slots pytc_dwconv3d_fwd / pytc_dwconvT3d_fwd write for
+ * this problem (INPUT dims); -1 when the channel count is unsupported */
+int pytc_dwconv3d_stat_slots(int D, int H, int W, int C, int K, int stride, int dtype, int transposed);
+
+/* Depthwise Conv3d (groups == C), kernel K^3 (3/5/7), padding K/2, stride 1 or 2, fused with the
+ * per-(n,c) sum / sum-of-squares of the OUTPUT that the following GroupNorm(C,C) needs.
+ * Replaces MedNeXtBlock.conv1 (+ first half of .norm) -- external nnunet_mednext, attribute
+ * contract at models/architectures/mednext_models.py:104-117.
+ *   x [N][D][H][W][C]   y [N][Do][Ho][Wo][C]   (dtype)      Do = (D + 2*(K/2) - K)/stride + 1
+ *   w fp32 [K*K*K][C] (tap-major: w[(kz*K+ky)*K+kx][c] = torch_weight[c][0][kz][ky][kx])
+ *   bias fp32 [C] or NULL
+ *   stats fp32 [N][slots][2][C] (sum, sumsq per slot) or NULL */
+int pytc_dwconv3d_fwd(const void* x, void* y, const float* w, const float* bias, float* stats,
+                      int N, int D, int H, int W, int C, int K, int stride, int dtype,
+                      void* stream);
+
+/* Depthwise ConvTranspose3d (groups == C), kernel K^3, stride 2, padding K/2 -> Do = 2D-1.
+ * Replaces MedNeXtUpBlock.conv1.  Output is written into a buffer of spatial size
+ * (2D)x(2H)x(2W) at offset +1 on every axis (the block's later F.pad((1,0,1,0,1,0)) is thereby
+ * free); the front faces of y are NOT touched.  w fp32 [K^3][C] with
+ * w[(kz*K+ky)*K+kx][c] = torch_weight[c][0][kz][ky][kx].  stats as above, over (2D-1)^3. */
+int pytc_dwconvT3d_fwd(const void* x, void* y, const float* w, const float* bias, float* stats,
+                       int N, int D, int H, int W, int C, int K, int dtype, void* stream);
+
+/* Reduce the partial statistics and emit the per-(n,c) affine of GroupNorm(num_groups=C):
+ *   mean = S1/count, var = S2/count - mean^2 (biased), a = gamma * rsqrt(var+eps), b = beta - mean*a
+ *   ab fp32 [N][2][C].  Replaces the statistics half of nn.GroupNorm in MedNeXtBlock.norm. */
+int pytc_groupnorm_finalize(const float* stats, int slots, float count, const float* gamma,
+                            const float* beta, float eps, float* ab, int N, int C, void* stream);
+
+/* ---------------------------------------------------------------- pointwise (1x1x1) ------- */
+
+/* Pack a PyTorch 1x1x1 conv weight [C_out][C_in] (fp32, row major) into the MFMA operand image
+ * the GEMM kernels read.  `packed` must hold pytc_pw_packed_elems(C_out, C_in) elements of
+ * `dtype`.  transposed != 0 means the source is [C_in][C_out] (ConvTranspose3d layout). */
+int64_t pytc_pw_packed_elems(int C_out, int C_in, int dtype);
+int pytc_pw_pack_weight(const float* w, int C_out, int C_in, int transposed, void* packed,
+                        int dtype, void* stream);
+
+/* Generic pointwise convolution  y[r][o] = act( sum_k f(x[src(r)][k]) * W[o][k] + bias[o] ) (+ res)
+ *   f(x) = a[n][k]*x + b[n][k] when ab != NULL (GroupNorm apply), identity otherwise
+ *   rows = N * rows_per_sample; x is [N*rows_per_sample_in][C_in] (in_dtype)
+ *   gather: 0 dense (src(r) = r); 2 = stride-2 spatial subsample of an input grid
+ *           (Di,Hi,Wi) -> (Do,Ho,Wo) = ceil(./2)   (MedNeXtDownBlock.res_conv, k=1 stride 2)
+ *   res_mode PYTC_RES_ADD adds res[r][o] (out dtype layout);
+ *   Replaces stem / conv2 / conv3 / res_conv / out_0 / task-head 1x1 convs
+ *   (mednext_models.py:120,169-173,188; rsunet.py:249,388). */
+typedef struct {
+  const void* x;        /* input activations */
+  const void* w_packed; /* from pytc_pw_pack_weight */
+  const float* bias;    /* [C_out] or NULL */
+  const float* ab;      /* [N][2][C_in] or NULL */
+  const void* res;      /* residual or NULL */
+  void* y;              /* output */
+  int N;                /* samples */
+  int64_t rows_per_sample; /* OUTPUT rows per sample */
+  int C_in, C_out;
+  int in_dtype, out_dtype, w_dtype;
+  int act;              /* PYTC_ACT_* applied before the residual */
+  int res_mode;         /* PYTC_RES_* */
+  int gather;           /* 0 or 2 */
+  int Di, Hi, Wi;       /* input grid (gather == 2) or output grid (RES_UPSAMPLE) */
+  const void* res_low;  /* RES_UPSAMPLE: low-res residual [N][Di/2..][C_out] */
+  const float* res_bias;/* RES_UPSAMPLE: bias of the transposed 1x1 residual conv */
+} pytc_pw_args;
+
+int pytc_pw_conv_fwd(const pytc_pw_args* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYTC_HIP_H */

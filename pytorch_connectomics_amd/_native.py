@@ -1,0 +1,95 @@
+"""ctypes binding of libpytc_hip.so (the C ABI declared in include/pytc_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, a RuntimeError
+is raised.  The library is built in-tree by ``python -m pytorch_connectomics_amd.csrc.build``
+(also run by ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libpytc_hip.so"
+
+F32, BF16 = 0, 1
+OK = 0
+
+VIEW_FLIP_Z, VIEW_FLIP_Y, VIEW_FLIP_X, VIEW_SWAP_YX = 1, 2, 4, 8
+PAD_MODES = {"constant": 0, "reflect": 1, "replicate": 2, "circular": 3}
+BLEND_PRODUCT, BLEND_MIN = 0, 1
+ACT_NONE, ACT_SIGMOID, ACT_TANH, ACT_GELU = 0, 1, 2, 3
+RES_NONE, RES_ADD, RES_UPSAMPLE = 0, 1, 2
+
+
+class PwArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("ab", C.c_void_p),
+        ("res", C.c_void_p), ("y", C.c_void_p),
+        ("N", C.c_int), ("rows_per_sample", C.c_int64),
+        ("C_in", C.c_int), ("C_out", C.c_int),
+        ("in_dtype", C.c_int), ("out_dtype", C.c_int), ("w_dtype", C.c_int),
+        ("act", C.c_int), ("res_mode", C.c_int), ("gather", C.c_int),
+        ("Di", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int),
+        ("res_low", C.c_void_p), ("res_bias", C.c_void_p),
+    ]
+
+
+_SIGS = {
+    "pytc_abi_version": (C.c_int, []),
+    "pytc_last_error": (C.c_char_p, []),
+    "pytc_device_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "pytc_gather_windows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32),
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                      C.c_void_p, C.c_int, C.c_void_p]),
+    "pytc_blend_accumulate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_blend_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
+    "pytc_ensemble_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_dwconv3d_stat_slots": (C.c_int, [C.c_int] * 8),
+    "pytc_dwconv3d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8
+                          + [C.c_void_p]),
+    "pytc_dwconvT3d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7
+                           + [C.c_void_p]),
+    "pytc_groupnorm_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_float,
+                                          C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_pw_packed_elems": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "pytc_pw_pack_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "pytc_pw_conv_fwd": (C.c_int, [C.POINTER(PwArgs), C.c_void_p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names every build of the library must export (checked by the CPU test-suite)."""
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise loudly if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"pytorch_connectomics_amd: HIP library {LIB_PATH} is missing. Build it with "
+            "`python -m pytorch_connectomics_amd.csrc.build` (needs hipcc). There is no CPU fallback.")
+    handle = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in _SIGS.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:  # pragma: no cover
+            raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
+        fn.restype = res
+        fn.argtypes = args
+    if handle.pytc_abi_version() != 1:
+        raise RuntimeError("libpytc_hip.so ABI version mismatch; rebuild the library")
+    _lib = handle
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != OK:
+        msg = lib().pytc_last_error()
+        raise RuntimeError(f"{what} failed (status {status}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,67 @@
+"""Build libpytc_hip.so (all HIP kernels + the C ABI) for gfx950 with hipcc, in-tree.
+
+    python -m pytorch_connectomics_amd.csrc.build [--force]
+
+hipcc cross-compiles without a GPU.  The .so lands in pytorch_connectomics_amd/lib/ (git-ignored,
+but it travels to the GPU box with the gpurun snapshot).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent
+PKG = CSRC.parent
+LIB_DIR = PKG / "lib"
+LIB = LIB_DIR / "libpytc_hip.so"
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+
+
+def _sources():
+    return sorted(CSRC.glob("*.hip"))
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for p in _sources() + sorted(CSRC.glob("*.h")) + [PKG.parent / "include" / "pytc_hip.h"]:
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    LIB_DIR.mkdir(exist_ok=True)
+    obj_dir = LIB_DIR / "obj"
+    obj_dir.mkdir(exist_ok=True)
+    stamp = LIB_DIR / "build.sha256"
+    dig = _digest()
+    if not force and LIB.exists() and stamp.exists() and stamp.read_text().strip() == dig:
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+    def compile_one(src: Path) -> Path:
+        obj = obj_dir / (src.stem + ".o")
+        cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, _sources()))
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(LIB)]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    stamp.write_text(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,339 @@
+// Pointwise (1x1x1) convolutions as MFMA GEMMs in "transposed" form:
+//     Y^T[o][v] = sum_k W[o][k] * X^T[k][v]
+// i.e. the WEIGHTS are the MFMA A operand (M = output channels) and the NDHWC activations are the
+// B operand (K = input channels, N = voxels).  Consequences on gfx950 (wave64):
+//   * a lane's B fragment is EPL consecutive channels of ONE voxel = one 16-byte global load,
+//     a wave's B-fragment load is fully coalesced, no LDS staging, no transposes;
+//   * the accumulator (C/D layout: col = lane&15 -> voxel, row = 4*(lane>>4)+r -> channel) holds
+//     4 consecutive output channels of one voxel per lane = one 8/16-byte NDHWC store.
+// bf16 uses v_mfma_f32_16x16x32_bf16, fp32 uses 4x v_mfma_f32_16x16x4_f32 per 16-wide k-group
+// (exact fp32, used for the tight parity gate).
+#include "pytc_common.h"
+
+namespace pytc {
+
+template <typename TW>
+struct Mma;
+
+template <>
+struct Mma<bf16_t> {
+  static constexpr int EPL = 8;     // fragment elements per lane
+  static constexpr int KSTEP = 32;  // k covered by one fragment set
+  typedef bf16x8_t frag_t;
+  static __device__ __forceinline__ f32x4_t mma(frag_t a, frag_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ frag_t from_floats(const float (&v)[8]) {
+    f32x8_t f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = v[i];
+    return __builtin_convertvector(f, frag_t);
+  }
+};
+
+template <>
+struct Mma<float> {
+  static constexpr int EPL = 4;
+  static constexpr int KSTEP = 16;
+  typedef f32x4_t frag_t;
+  static __device__ __forceinline__ f32x4_t mma(frag_t a, frag_t b, f32x4_t c) {
+    // logical k of (step s, lane group kb) = kb*4 + s : any bijection works as long as A and B agree
+#pragma unroll
+    for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], c, 0, 0, 0);
+    return c;
+  }
+  static __device__ __forceinline__ frag_t from_floats(const float (&v)[4]) {
+    frag_t f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = v[i];
+    return f;
+  }
+};
+
+struct PwParams {
+  const void* x;
+  const void* wp;
+  const float* bias;
+  const float* ab;
+  const void* res;
+  const void* res_low;
+  const float* res_bias;
+  void* y;
+  long rps_out, rps_in;  // rows per sample
+  int N, C_in, C_out, KG, MTt;
+  int act, res_mode, gather;
+  int Di, Hi, Wi;        // gather==2: input grid ; RES_UPSAMPLE: OUTPUT grid
+  int Do, Ho, Wo;        // gather==2: output grid ; RES_UPSAMPLE: low-res grid
+};
+
+template <typename TI, int EPL>
+__device__ __forceinline__ void load_row_frag(const TI* __restrict__ row, int k0, int C_in, bool vec_ok,
+                                              float (&v)[EPL]) {
+  if (vec_ok && k0 + EPL <= C_in) {
+    if constexpr (sizeof(TI) == 4 && EPL == 8) {
+      float t0[4], t1[4];
+      VecIO<float, 4>::load(reinterpret_cast<const float*>(row) + k0, t0);
+      VecIO<float, 4>::load(reinterpret_cast<const float*>(row) + k0 + 4, t1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = t0[i]; v[4 + i] = t1[i]; }
+    } else {
+      VecIO<TI, EPL>::load(row + k0, v);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) v[j] = (k0 + j < C_in) ? to_f32<TI>(row[k0 + j]) : 0.f;
+  }
+}
+
+template <typename TI, typename TW, typename TO, int MT, int NT>
+__global__ void __launch_bounds__(256)
+pw_conv_kernel(PwParams p) {
+  typedef Mma<TW> M;
+  constexpr int EPL = M::EPL;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.z;
+  const int mt0 = blockIdx.y * MT;
+  const long row0 = ((long)blockIdx.x * 4 + wave) * (NT * 16);
+  if (row0 >= p.rps_out) return;
+  const int r = lane & 15, kb = lane >> 4;
+
+  long orow[NT];
+  const TI* xrow[NT];
+  const TI* xn = reinterpret_cast<const TI*>(p.x) + (long)n * p.rps_in * p.C_in;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    long o = row0 + nt * 16 + r;
+    orow[nt] = o;
+    long oc = o < p.rps_out ? o : p.rps_out - 1;
+    long src = oc;
+    if (p.gather == 2) {
+      int ox = (int)(oc % p.Wo);
+      long t = oc / p.Wo;
+      int oy = (int)(t % p.Ho);
+      int oz = (int)(t / p.Ho);
+      src = ((long)(2 * oz) * p.Hi + 2 * oy) * p.Wi + 2 * ox;
+    }
+    xrow[nt] = xn + src * p.C_in;
+  }
+  const bool vec_ok = (p.C_in % EPL) == 0;
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const typename M::frag_t* wp = reinterpret_cast<const typename M::frag_t*>(p.wp);
+  for (int kg = 0; kg < p.KG; ++kg) {
+    const int k0 = kg * M::KSTEP + kb * EPL;
+    float av[EPL], bv[EPL];
+    if (p.ab) {
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        bool ok = k0 + j < p.C_in;
+        av[j] = ok ? p.ab[((long)n * 2 + 0) * p.C_in + k0 + j] : 0.f;
+        bv[j] = ok ? p.ab[((long)n * 2 + 1) * p.C_in + k0 + j] : 0.f;
+      }
+    }
+    typename M::frag_t bf[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float v[EPL];
+      load_row_frag<TI, EPL>(xrow[nt], k0, p.C_in, vec_ok, v);
+      if (p.ab) {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) v[j] = fmaf(v[j], av[j], bv[j]);
+      }
+      bf[nt] = M::from_floats(v);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (mt0 + mt < p.MTt) {
+        typename M::frag_t af = wp[((long)(mt0 + mt) * p.KG + kg) * 64 + lane];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = M::mma(af, bf[nt], acc[mt][nt]);
+      }
+    }
+  }
+
+  // ---- epilogue: lane holds channels o0..o0+3 of voxel orow[nt]
+  TO* yn = reinterpret_cast<TO*>(p.y) + (long)n * p.rps_out * p.C_out;
+  const TO* resn = p.res ? reinterpret_cast<const TO*>(p.res) + (long)n * p.rps_out * p.C_out : nullptr;
+  const bool ovec = (p.C_out % 4) == 0;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int o0 = (mt0 + mt) * 16 + kb * 4;
+    if (o0 >= p.C_out) continue;
+    float bo[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) bo[rr] = (p.bias && o0 + rr < p.C_out) ? p.bias[o0 + rr] : 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (orow[nt] >= p.rps_out) continue;
+      float v[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        float t = acc[mt][nt][rr] + bo[rr];
+        if (p.act == PYTC_ACT_GELU) t = gelu_erf(t);
+        else if (p.act == PYTC_ACT_SIGMOID) t = 1.f / (1.f + expf(-t));
+        else if (p.act == PYTC_ACT_TANH) t = tanhf(t);
+        v[rr] = t;
+      }
+      const long off = orow[nt] * p.C_out + o0;
+      const bool full = ovec && (o0 + 4 <= p.C_out);
+      if (p.res_mode == PYTC_RES_ADD) {
+        float rv[4];
+        if (full) VecIO<TO, 4>::load(resn + off, rv);
+        else {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) rv[rr] = (o0 + rr < p.C_out) ? to_f32<TO>(resn[off + rr]) : 0.f;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) v[rr] += rv[rr];
+      } else if (p.res_mode == PYTC_RES_UPSAMPLE) {
+        // output grid (Di,Hi,Wi); low-res grid (Do,Ho,Wo); see MedNeXtUpBlock restatement
+        int px = (int)(orow[nt] % p.Wi);
+        long t = orow[nt] / p.Wi;
+        int py = (int)(t % p.Hi);
+        int pz = (int)(t / p.Hi);
+        float sk[4];
+        if (full) VecIO<TO, 4>::load(resn + off, sk);
+        else {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) sk[rr] = (o0 + rr < p.C_out) ? to_f32<TO>(resn[off + rr]) : 0.f;
+        }
+        if (px == 0 || py == 0 || pz == 0) {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) v[rr] = sk[rr];
+        } else {
+          int oz = pz - 1, oy = py - 1, ox = px - 1;
+          float rl[4];
+          if (p.res_low && !((oz | oy | ox) & 1)) {
+            const TO* rp = reinterpret_cast<const TO*>(p.res_low) +
+                           (((long)n * p.Do + (oz >> 1)) * p.Ho + (oy >> 1)) * (long)p.Wo * p.C_out +
+                           (long)(ox >> 1) * p.C_out + o0;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) rl[rr] = (o0 + rr < p.C_out) ? to_f32<TO>(rp[rr]) : 0.f;
+          } else {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+              rl[rr] = (p.res_bias && o0 + rr < p.C_out) ? p.res_bias[o0 + rr] : 0.f;
+          }
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) v[rr] = v[rr] + rl[rr] + sk[rr];
+        }
+      }
+      if (full) VecIO<TO, 4>::store(yn + off, v);
+      else {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          if (o0 + rr < p.C_out) yn[off + rr] = from_f32<TO>(v[rr]);
+      }
+    }
+  }
+}
+
+template <typename TW>
+__global__ void __launch_bounds__(256)
+pw_pack_kernel(const float* __restrict__ w, int C_out, int C_in, int transposed, TW* __restrict__ packed,
+               int KG, long total) {
+  typedef Mma<TW> M;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int j = (int)(i % M::EPL);
+  long t = i / M::EPL;
+  int lane = (int)(t % 64);
+  t /= 64;
+  int kg = (int)(t % KG);
+  int mt = (int)(t / KG);
+  int o = mt * 16 + (lane & 15);
+  int k = kg * M::KSTEP + (lane >> 4) * M::EPL + j;
+  float v = 0.f;
+  if (o < C_out && k < C_in) v = transposed ? w[(long)k * C_out + o] : w[(long)o * C_in + k];
+  packed[i] = from_f32<TW>(v);
+}
+
+template <typename TI, typename TW, typename TO, int NT>
+static void launch_pw(const PwParams& p, int MT, hipStream_t s) {
+  long rows_per_block = 4L * NT * 16;
+  dim3 grid((unsigned)((p.rps_out + rows_per_block - 1) / rows_per_block), (unsigned)((p.MTt + MT - 1) / MT),
+            (unsigned)p.N);
+  dim3 block(256);
+  switch (MT) {
+    case 1: hipLaunchKernelGGL((pw_conv_kernel<TI, TW, TO, 1, NT>), grid, block, 0, s, p); break;
+    case 2: hipLaunchKernelGGL((pw_conv_kernel<TI, TW, TO, 2, NT>), grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL((pw_conv_kernel<TI, TW, TO, 4, NT>), grid, block, 0, s, p); break;
+  }
+}
+
+}  // namespace pytc
+
+using namespace pytc;
+
+static int kstep_of(int dtype) { return dtype == PYTC_BF16 ? 32 : 16; }
+
+extern "C" int64_t pytc_pw_packed_elems(int C_out, int C_in, int dtype) {
+  if (C_out < 1 || C_in < 1 || (dtype != PYTC_F32 && dtype != PYTC_BF16)) return -1;
+  int ks = kstep_of(dtype);
+  return (int64_t)((C_out + 15) / 16) * 16 * ((C_in + ks - 1) / ks) * ks;
+}
+
+extern "C" int pytc_pw_pack_weight(const float* w, int C_out, int C_in, int transposed, void* packed, int dtype,
+                                   void* stream) {
+  PYTC_REQUIRE(w && packed && C_out >= 1 && C_in >= 1, "pw_pack_weight: bad arguments");
+  PYTC_REQUIRE(dtype == PYTC_F32 || dtype == PYTC_BF16, "pw_pack_weight: bad dtype");
+  long total = pytc_pw_packed_elems(C_out, C_in, dtype);
+  int KG = (C_in + kstep_of(dtype) - 1) / kstep_of(dtype);
+  dim3 grid(ceil_div(total, 256)), block(256);
+  if (dtype == PYTC_BF16)
+    hipLaunchKernelGGL(pw_pack_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, w, C_out, C_in, transposed,
+                       (bf16_t*)packed, KG, total);
+  else
+    hipLaunchKernelGGL(pw_pack_kernel<float>, grid, block, 0, (hipStream_t)stream, w, C_out, C_in, transposed,
+                       (float*)packed, KG, total);
+  PYTC_LAUNCH_CHECK("pw_pack_weight");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_pw_conv_fwd(const pytc_pw_args* a, void* stream) {
+  PYTC_REQUIRE(a && a->x && a->w_packed && a->y, "pw_conv: null pointer");
+  PYTC_REQUIRE(a->N >= 1 && a->rows_per_sample >= 1 && a->C_in >= 1 && a->C_out >= 1, "pw_conv: bad shape");
+  PYTC_REQUIRE(a->w_dtype == PYTC_F32 || a->w_dtype == PYTC_BF16, "pw_conv: bad w_dtype");
+  PYTC_REQUIRE(a->res_mode == PYTC_RES_NONE || a->res, "pw_conv: residual mode without residual pointer");
+  PwParams p;
+  p.x = a->x; p.wp = a->w_packed; p.bias = a->bias; p.ab = a->ab; p.res = a->res; p.res_low = a->res_low;
+  p.res_bias = a->res_bias; p.y = a->y;
+  p.N = a->N; p.C_in = a->C_in; p.C_out = a->C_out;
+  p.KG = (a->C_in + kstep_of(a->w_dtype) - 1) / kstep_of(a->w_dtype);
+  p.MTt = (a->C_out + 15) / 16;
+  p.act = a->act; p.res_mode = a->res_mode; p.gather = a->gather;
+  p.rps_out = a->rows_per_sample; p.rps_in = a->rows_per_sample;
+  p.Di = a->Di; p.Hi = a->Hi; p.Wi = a->Wi; p.Do = p.Ho = p.Wo = 0;
+  if (a->gather == 2) {
+    PYTC_REQUIRE(a->Di >= 1 && a->Hi >= 1 && a->Wi >= 1, "pw_conv: gather needs the input grid");
+    p.Do = (a->Di - 1) / 2 + 1; p.Ho = (a->Hi - 1) / 2 + 1; p.Wo = (a->Wi - 1) / 2 + 1;
+    PYTC_REQUIRE((long)p.Do * p.Ho * p.Wo == a->rows_per_sample, "pw_conv: gather grid does not match rows");
+    p.rps_in = (long)a->Di * a->Hi * a->Wi;
+  } else {
+    PYTC_REQUIRE(a->gather == 0, "pw_conv: bad gather mode %d", a->gather);
+  }
+  if (a->res_mode == PYTC_RES_UPSAMPLE) {
+    PYTC_REQUIRE(a->gather == 0, "pw_conv: RES_UPSAMPLE cannot be combined with gather");
+    PYTC_REQUIRE((long)a->Di * a->Hi * a->Wi == a->rows_per_sample && !(a->Di & 1) && !(a->Hi & 1) && !(a->Wi & 1),
+                 "pw_conv: RES_UPSAMPLE needs the (even) output grid");
+    p.Do = a->Di / 2; p.Ho = a->Hi / 2; p.Wo = a->Wi / 2;
+  }
+  int MT = p.MTt >= 4 ? 4 : (p.MTt >= 2 ? 2 : 1);
+  hipStream_t s = (hipStream_t)stream;
+  const int ti = a->in_dtype, tw = a->w_dtype, to = a->out_dtype;
+  if (ti == PYTC_F32 && tw == PYTC_F32 && to == PYTC_F32) launch_pw<float, float, float, 4>(p, MT, s);
+  else if (ti == PYTC_BF16 && tw == PYTC_BF16 && to == PYTC_BF16) launch_pw<bf16_t, bf16_t, bf16_t, 4>(p, MT, s);
+  else if (ti == PYTC_BF16 && tw == PYTC_BF16 && to == PYTC_F32) launch_pw<bf16_t, bf16_t, float, 4>(p, MT, s);
+  else if (ti == PYTC_F32 && tw == PYTC_BF16 && to == PYTC_BF16) launch_pw<float, bf16_t, bf16_t, 4>(p, MT, s);
+  else {
+    set_error("pw_conv: unsupported dtype combination in=%d w=%d out=%d", ti, tw, to);
+    return PYTC_ERR_UNSUPPORTED;
+  }
+  PYTC_LAUNCH_CHECK("pw_conv");
+  return PYTC_OK;
+}

@@ -1,0 +1,110 @@
+// Shared device/host helpers for the gfx950 (CDNA4, wave64) kernels of the PyTC hot path.
+// NDHWC activations, fp32 or bf16 storage, fp32 accumulation everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/pytc_hip.h"
+
+namespace pytc {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+constexpr int WAVE = 64;
+
+// ---- last-error plumbing (thread local; the ABI returns an int status) -----------------
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define PYTC_REQUIRE(cond, ...)                     \
+  do {                                              \
+    if (!(cond)) {                                  \
+      pytc::set_error(__VA_ARGS__);                 \
+      return PYTC_ERR_INVALID;                      \
+    }                                               \
+  } while (0)
+
+#define PYTC_LAUNCH_CHECK(name)                                  \
+  do {                                                           \
+    hipError_t e_ = hipGetLastError();                           \
+    if (e_ != hipSuccess) return pytc::hip_fail(e_, name);       \
+  } while (0)
+
+// ---- element traits: T in {float, bf16_t}; vectors of VEC channels --------------------
+template <typename T, int VEC>
+struct VecIO;
+
+template <int VEC>
+struct VecIO<float, VEC> {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  static __device__ __forceinline__ void load(const float* p, float (&v)[VEC]) {
+    vec_t t = *reinterpret_cast<const vec_t*>(p);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = t[i];
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[VEC]) {
+    vec_t t;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) t[i] = v[i];
+    *reinterpret_cast<vec_t*>(p) = t;
+  }
+};
+template <>
+struct VecIO<float, 1> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[1]) { v[0] = *p; }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[1]) { *p = v[0]; }
+};
+
+template <int VEC>
+struct VecIO<bf16_t, VEC> {
+  typedef __bf16 vec_t __attribute__((ext_vector_type(VEC)));
+  typedef float fvec_t __attribute__((ext_vector_type(VEC)));
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[VEC]) {
+    vec_t t = *reinterpret_cast<const vec_t*>(p);
+    fvec_t f = __builtin_convertvector(t, fvec_t);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = f[i];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[VEC]) {
+    fvec_t f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) f[i] = v[i];
+    *reinterpret_cast<vec_t*>(p) = __builtin_convertvector(f, vec_t);
+  }
+};
+template <>
+struct VecIO<bf16_t, 1> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[1]) { v[0] = (float)*p; }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[1]) { *p = (bf16_t)v[0]; }
+};
+
+template <typename T>
+__device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T>
+__device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+// ---- wave64 reductions ------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// exact (erf) GELU, matches torch.nn.functional.gelu(approximate='none')
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace pytc

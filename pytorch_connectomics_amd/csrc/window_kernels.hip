@@ -1,0 +1,224 @@
+// Sliding-window kernels: window gather (+pad, +TTA view), overlap-add blend, finalize,
+// TTA ensemble update.  All HBM-bound elementwise/scatter work: x-fastest thread mapping so
+// that every global access is coalesced; no atomics (one launch per window, stream-ordered,
+// so the fp32 accumulation order is exactly the reference's window order).
+#include "pytc_common.h"
+
+namespace pytc {
+
+struct StartList {
+  int s[64 * 3];
+};
+
+__device__ __forceinline__ int pad_index(int i, int n, int mode, bool& inside) {
+  // returns source index for coordinate i on an axis of length n under `mode`
+  inside = true;
+  if (i >= 0 && i < n) return i;
+  switch (mode) {
+    case PYTC_PAD_REFLECT: {  // torch 'reflect': no edge repeat; caller guarantees pad < n
+      if (n == 1) return 0;
+      int p = 2 * (n - 1);
+      int m = i % p;
+      if (m < 0) m += p;
+      return m < n ? m : p - m;
+    }
+    case PYTC_PAD_REPLICATE:
+      return i < 0 ? 0 : n - 1;
+    case PYTC_PAD_CIRCULAR: {
+      int m = i % n;
+      return m < 0 ? m + n : m;
+    }
+    default:
+      inside = false;
+      return 0;
+  }
+}
+
+// view: out[z,y,x] = win[T(F(z,y,x))], F = per-axis flips, T = optional (y,x) swap
+__device__ __forceinline__ void view_src(int view, int rz, int ry, int rx, int z, int y, int x,
+                                         int& wz, int& wy, int& wx) {
+  int fz = (view & PYTC_VIEW_FLIP_Z) ? rz - 1 - z : z;
+  int fy = (view & PYTC_VIEW_FLIP_Y) ? ry - 1 - y : y;
+  int fx = (view & PYTC_VIEW_FLIP_X) ? rx - 1 - x : x;
+  if (view & PYTC_VIEW_SWAP_YX) {
+    wz = fz; wy = fx; wx = fy;
+  } else {
+    wz = fz; wy = fy; wx = fx;
+  }
+}
+
+template <typename TO>
+__global__ void __launch_bounds__(256)
+gather_windows_kernel(const float* __restrict__ vol, int C, int Z, int Y, int X, StartList st,
+                      int rz, int ry, int rx, int view, int pad_mode, float cval, int pz, int py,
+                      int px, TO* __restrict__ out) {
+  // pz/py/px: per-axis "mode valid" flags (reflect/circular fall back to constant when the pad
+  // would reach the inner extent, window.py:511-518) are resolved on the host per window batch:
+  // here pad_mode already is the effective mode.
+  const int b = blockIdx.z;
+  const long per_win = (long)rz * ry * rx;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per_win) return;
+  int x = (int)(i % rx);
+  long t = i / rx;
+  int y = (int)(t % ry);
+  int z = (int)(t / ry);
+  int wz, wy, wx;
+  view_src(view, rz, ry, rx, z, y, x, wz, wy, wx);
+  int gz = st.s[3 * b + 0] + wz, gy = st.s[3 * b + 1] + wy, gx = st.s[3 * b + 2] + wx;
+  bool iz, iy, ix;
+  int sz = pad_index(gz, Z, pad_mode, iz);
+  int sy = pad_index(gy, Y, pad_mode, iy);
+  int sx = pad_index(gx, X, pad_mode, ix);
+  bool inside = iz && iy && ix;
+  TO* o = out + ((long)b * per_win + i) * C;
+  const long plane = (long)Z * Y * X;
+  long src = ((long)sz * Y + sy) * X + sx;
+  for (int c = 0; c < C; ++c) {
+    float v = inside ? vol[c * plane + src] : cval;
+    o[c] = from_f32<TO>(v);
+  }
+}
+
+template <typename TP>
+__global__ void __launch_bounds__(256)
+blend_accumulate_kernel(const TP* __restrict__ pred, int sz, int sy, int sx, int rz, int ry, int rx,
+                        int C, int view, const float* __restrict__ wzv, const float* __restrict__ wyv,
+                        const float* __restrict__ wxv, int combine, float floor_w,
+                        float* __restrict__ value, float* __restrict__ weight, int Z, int Y, int X) {
+  const long per_win = (long)rz * ry * rx;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per_win) return;
+  int x = (int)(i % rx);
+  long t = i / rx;
+  int y = (int)(t % ry);
+  int z = (int)(t / ry);
+  int wz, wy, wx;
+  view_src(view, rz, ry, rx, z, y, x, wz, wy, wx);
+  int gz = sz + wz, gy = sy + wy, gx = sx + wx;
+  if (gz < 0 || gz >= Z || gy < 0 || gy >= Y || gx < 0 || gx >= X) return;
+  float w;
+  if (combine == PYTC_BLEND_MIN) {
+    w = fminf(fminf(wzv[wz], wyv[wy]), wxv[wx]);
+  } else {
+    // (wz*wy)*wx, each product rounded (axis order of window.py:178-194), then the two floors
+    w = __fmul_rn(__fmul_rn(wzv[wz], wyv[wy]), wxv[wx]);
+    w = fmaxf(w, 1.17549435e-38f);
+    w = fmaxf(w, floor_w);
+  }
+  const long plane = (long)Z * Y * X;
+  long dst = ((long)gz * Y + gy) * X + gx;
+  const TP* p = pred + i * C;
+  for (int c = 0; c < C; ++c) {
+    float pv = to_f32<TP>(p[c]);
+    // separate multiply and add roundings: value += pred * w  (window.py:652-654)
+    value[c * plane + dst] = __fadd_rn(value[c * plane + dst], __fmul_rn(pv, w));
+  }
+  if (weight) weight[dst] = __fadd_rn(weight[dst], w);
+}
+
+__global__ void __launch_bounds__(256)
+blend_finalize_kernel(float* __restrict__ value, const float* __restrict__ weight, int C, long nvox,
+                      float clamp, int act) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < nvox; i += stride) {
+    float d = fmaxf(weight[i], clamp);
+    for (int c = 0; c < C; ++c) {
+      float v = __fdiv_rn(value[c * nvox + i], d);
+      if (act == PYTC_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+      else if (act == PYTC_ACT_TANH) v = tanhf(v);
+      value[c * nvox + i] = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+ensemble_update_kernel(float* __restrict__ acc, const float* __restrict__ x, long n, int mode, int count) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float a = acc[i], v = x[i];
+    if (count <= 1) a = v;
+    else if (mode == 0) a = __fadd_rn(a, __fdiv_rn(__fsub_rn(v, a), (float)count));
+    else if (mode == 1) a = fminf(a, v);
+    else a = fmaxf(a, v);
+    acc[i] = a;
+  }
+}
+
+}  // namespace pytc
+
+using namespace pytc;
+
+extern "C" int pytc_gather_windows(const float* vol, int C, int Z, int Y, int X, const int32_t* starts,
+                                   int B, int rz, int ry, int rx, int view, int pad_mode, float cval,
+                                   void* out, int out_dtype, void* stream) {
+  PYTC_REQUIRE(vol && out && starts, "gather_windows: null pointer");
+  PYTC_REQUIRE(B >= 1 && B <= 64, "gather_windows: B=%d must be in [1,64]", B);
+  PYTC_REQUIRE(C >= 1 && rz > 0 && ry > 0 && rx > 0 && Z > 0 && Y > 0 && X > 0, "gather_windows: bad shape");
+  PYTC_REQUIRE(!(view & PYTC_VIEW_SWAP_YX) || ry == rx, "gather_windows: SWAP_YX needs ry == rx");
+  PYTC_REQUIRE(pad_mode >= 0 && pad_mode <= 3, "gather_windows: bad pad_mode %d", pad_mode);
+  StartList st;
+  memcpy(st.s, starts, sizeof(int) * 3 * B);
+  long per_win = (long)rz * ry * rx;
+  dim3 grid(ceil_div(per_win, 256), 1, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (out_dtype == PYTC_F32)
+    hipLaunchKernelGGL(gather_windows_kernel<float>, grid, block, 0, s, vol, C, Z, Y, X, st, rz, ry, rx, view,
+                       pad_mode, cval, 0, 0, 0, (float*)out);
+  else if (out_dtype == PYTC_BF16)
+    hipLaunchKernelGGL(gather_windows_kernel<bf16_t>, grid, block, 0, s, vol, C, Z, Y, X, st, rz, ry, rx, view,
+                       pad_mode, cval, 0, 0, 0, (bf16_t*)out);
+  else
+    PYTC_REQUIRE(false, "gather_windows: bad out_dtype %d", out_dtype);
+  PYTC_LAUNCH_CHECK("gather_windows");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_blend_accumulate(const void* pred, int pred_dtype, int B, const int32_t* starts, int rz,
+                                     int ry, int rx, int C, int view, const float* wz, const float* wy,
+                                     const float* wx, int combine, float floor_w, float* value,
+                                     float* weight, int Z, int Y, int X, void* stream) {
+  PYTC_REQUIRE(pred && starts && wz && wy && wx && value, "blend_accumulate: null pointer");
+  PYTC_REQUIRE(B >= 1 && C >= 1, "blend_accumulate: bad B/C");
+  PYTC_REQUIRE(!(view & PYTC_VIEW_SWAP_YX) || ry == rx, "blend_accumulate: SWAP_YX needs ry == rx");
+  PYTC_REQUIRE(combine == PYTC_BLEND_PRODUCT || combine == PYTC_BLEND_MIN, "blend_accumulate: bad combine");
+  long per_win = (long)rz * ry * rx;
+  dim3 grid(ceil_div(per_win, 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  for (int b = 0; b < B; ++b) {
+    int sz = starts[3 * b], sy = starts[3 * b + 1], sx = starts[3 * b + 2];
+    if (pred_dtype == PYTC_F32)
+      hipLaunchKernelGGL(blend_accumulate_kernel<float>, grid, block, 0, s,
+                         (const float*)pred + (long)b * per_win * C, sz, sy, sx, rz, ry, rx, C, view, wz, wy, wx,
+                         combine, floor_w, value, weight, Z, Y, X);
+    else if (pred_dtype == PYTC_BF16)
+      hipLaunchKernelGGL(blend_accumulate_kernel<bf16_t>, grid, block, 0, s,
+                         (const bf16_t*)pred + (long)b * per_win * C, sz, sy, sx, rz, ry, rx, C, view, wz, wy, wx,
+                         combine, floor_w, value, weight, Z, Y, X);
+    else
+      PYTC_REQUIRE(false, "blend_accumulate: bad pred_dtype %d", pred_dtype);
+  }
+  PYTC_LAUNCH_CHECK("blend_accumulate");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_blend_finalize(float* value, const float* weight, int C, int64_t nvox, float clamp, int act,
+                                   void* stream) {
+  PYTC_REQUIRE(value && weight && C >= 1 && nvox > 0, "blend_finalize: bad arguments");
+  int blocks = (int)((nvox + 255) / 256 < 8192 ? (nvox + 255) / 256 : 8192);
+  hipLaunchKernelGGL(blend_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, value, weight, C,
+                     (long)nvox, clamp, act);
+  PYTC_LAUNCH_CHECK("blend_finalize");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_ensemble_update(float* acc, const float* x, int64_t n, int mode, int count, void* stream) {
+  PYTC_REQUIRE(acc && x && n > 0 && mode >= 0 && mode <= 2 && count >= 1, "ensemble_update: bad arguments");
+  int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  hipLaunchKernelGGL(ensemble_update_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, acc, x, (long)n, mode,
+                     count);
+  PYTC_LAUNCH_CHECK("ensemble_update");
+  return PYTC_OK;
+}

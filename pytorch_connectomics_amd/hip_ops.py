@@ -1,0 +1,171 @@
+"""Immediate-mode Python wrappers over the C ABI (torch tensors in, raw pointers out).
+
+PyTorch is used here only as the owner of device memory and of the HIP stream; every
+arithmetic op below is a hand-written gfx950 kernel in libpytc_hip.so.  All functions raise
+if handed CPU tensors: there is no CPU path in the product.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _native as nat
+
+_DT = {torch.float32: nat.F32, torch.bfloat16: nat.BF16}
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise TypeError(f"pytorch_connectomics_amd kernels support float32/bfloat16, got {dt}") from None
+
+
+def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA(HIP) tensor: pytorch_connectomics_amd has no CPU path")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return t
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _starts_array(starts: Sequence[Sequence[int]]):
+    flat = [int(v) for s in starts for v in s]
+    return (C.c_int32 * len(flat))(*flat)
+
+
+# ------------------------------------------------------------------ sliding window
+def gather_windows(vol: torch.Tensor, starts, roi, *, view: int = 0, pad_mode: str = "constant",
+                   cval: float = 0.0, out_dtype: torch.dtype = torch.float32,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """vol fp32 (C,Z,Y,X) -> (B, rz, ry, rx, C) window batch (NDHWC)."""
+    _dev(vol, "vol")
+    if vol.dtype != torch.float32 or vol.dim() != 4:
+        raise ValueError("vol must be float32 with shape (C, Z, Y, X)")
+    Cc, Z, Y, X = vol.shape
+    B = len(starts)
+    rz, ry, rx = (int(v) for v in roi)
+    if out is None:
+        out = torch.empty((B, rz, ry, rx, Cc), dtype=out_dtype, device=vol.device)
+    st = _starts_array(starts)
+    for b0 in range(0, B, 64):
+        nb = min(64, B - b0)
+        sub = (C.c_int32 * (3 * nb)).from_buffer(st, 4 * 3 * b0)
+        nat.check(nat.lib().pytc_gather_windows(_p(vol), Cc, Z, Y, X, sub, nb, rz, ry, rx, int(view),
+                                                nat.PAD_MODES[pad_mode], float(cval), _p(out[b0:b0 + nb]),
+                                                dtype_code(out.dtype), _stream()), "gather_windows")
+    return out
+
+
+def blend_accumulate(pred: torch.Tensor, starts, value: torch.Tensor, weight: Optional[torch.Tensor],
+                     wz: torch.Tensor, wy: torch.Tensor, wx: torch.Tensor, *, view: int = 0,
+                     combine: int = nat.BLEND_PRODUCT, floor_w: float = 1e-5) -> None:
+    """pred (B, rz, ry, rx, C) NDHWC; value (C,Z,Y,X) += pred*w; weight (Z,Y,X) += w."""
+    _dev(pred, "pred"); _dev(value, "value")
+    B, rz, ry, rx, Cc = pred.shape
+    if value.dtype != torch.float32 or value.shape[0] != Cc:
+        raise ValueError("value accumulator must be float32 (C, Z, Y, X) with C matching pred")
+    _, Z, Y, X = value.shape
+    st = _starts_array(starts)
+    nat.check(nat.lib().pytc_blend_accumulate(_p(pred), dtype_code(pred.dtype), B, st, rz, ry, rx, Cc, int(view),
+                                              _p(wz), _p(wy), _p(wx), int(combine), float(floor_w), _p(value),
+                                              _p(weight), Z, Y, X, _stream()), "blend_accumulate")
+
+
+def blend_finalize(value: torch.Tensor, weight: torch.Tensor, *, clamp: float = 1e-4, act: int = nat.ACT_NONE) -> None:
+    _dev(value, "value"); _dev(weight, "weight")
+    Cc = value.shape[0]
+    nvox = weight.numel()
+    nat.check(nat.lib().pytc_blend_finalize(_p(value), _p(weight), Cc, nvox, float(clamp), int(act), _stream()),
+              "blend_finalize")
+
+
+def ensemble_update(acc: torch.Tensor, x: torch.Tensor, mode: int, count: int) -> None:
+    _dev(acc, "acc"); _dev(x, "x")
+    nat.check(nat.lib().pytc_ensemble_update(_p(acc), _p(x), acc.numel(), int(mode), int(count), _stream()),
+              "ensemble_update")
+
+
+# ------------------------------------------------------------------ depthwise conv + norm statistics
+def dwconv3d(x: torch.Tensor, w_taps: torch.Tensor, bias: Optional[torch.Tensor], *, K: int, stride: int = 1,
+             stats: bool = True, transposed: bool = False, y: Optional[torch.Tensor] = None):
+    """x (N,D,H,W,C) -> y, stats(N,slots,2,C)|None.  w_taps fp32 (K^3, C)."""
+    _dev(x, "x"); _dev(w_taps, "w_taps")
+    N, D, H, W, Cc = x.shape
+    dt = dtype_code(x.dtype)
+    if transposed:
+        oshape = (N, 2 * D, 2 * H, 2 * W, Cc)
+    else:
+        p = K // 2
+        oshape = (N, (D + 2 * p - K) // stride + 1, (H + 2 * p - K) // stride + 1, (W + 2 * p - K) // stride + 1, Cc)
+    if y is None:
+        y = torch.empty(oshape, dtype=x.dtype, device=x.device)
+    st = None
+    if stats:
+        slots = nat.lib().pytc_dwconv3d_stat_slots(D, H, W, Cc, K, stride, dt, int(transposed))
+        if slots < 0:
+            raise RuntimeError(f"dwconv3d: unsupported channel count {Cc}")
+        st = torch.empty((N, slots, 2, Cc), dtype=torch.float32, device=x.device)
+    if transposed:
+        nat.check(nat.lib().pytc_dwconvT3d_fwd(_p(x), _p(y), _p(w_taps), _p(bias), _p(st), N, D, H, W, Cc, K, dt,
+                                               _stream()), "dwconvT3d_fwd")
+    else:
+        nat.check(nat.lib().pytc_dwconv3d_fwd(_p(x), _p(y), _p(w_taps), _p(bias), _p(st), N, D, H, W, Cc, K, stride,
+                                              dt, _stream()), "dwconv3d_fwd")
+    return y, st
+
+
+def groupnorm_finalize(stats: torch.Tensor, count: float, gamma: Optional[torch.Tensor],
+                       beta: Optional[torch.Tensor], eps: float = 1e-5) -> torch.Tensor:
+    N, slots, _, Cc = stats.shape
+    ab = torch.empty((N, 2, Cc), dtype=torch.float32, device=stats.device)
+    nat.check(nat.lib().pytc_groupnorm_finalize(_p(stats), slots, float(count), _p(gamma), _p(beta), float(eps),
+                                                _p(ab), N, Cc, _stream()), "groupnorm_finalize")
+    return ab
+
+
+# ------------------------------------------------------------------ pointwise convs (MFMA GEMMs)
+def pw_pack_weight(w: torch.Tensor, dtype: torch.dtype, *, transposed: bool = False) -> torch.Tensor:
+    """w fp32 (C_out, C_in) [or (C_in, C_out) when transposed] -> packed MFMA operand image."""
+    _dev(w, "w")
+    if w.dtype != torch.float32 or w.dim() != 2:
+        raise ValueError("pointwise weight must be float32 2-D")
+    c_out, c_in = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+    n = nat.lib().pytc_pw_packed_elems(c_out, c_in, dtype_code(dtype))
+    packed = torch.empty((n,), dtype=dtype, device=w.device)
+    nat.check(nat.lib().pytc_pw_pack_weight(_p(w), c_out, c_in, int(transposed), _p(packed), dtype_code(dtype),
+                                            _stream()), "pw_pack_weight")
+    return packed
+
+
+def pw_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, N: int, rows_per_sample: int,
+            c_in: int, c_out: int, out_dtype: torch.dtype, ab: Optional[torch.Tensor] = None,
+            act: int = nat.ACT_NONE, res: Optional[torch.Tensor] = None, res_mode: int = nat.RES_NONE,
+            gather: int = 0, grid: Sequence[int] = (0, 0, 0), res_low: Optional[torch.Tensor] = None,
+            res_bias: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev(x, "x"); _dev(w_packed, "w_packed")
+    if y is None:
+        y = torch.empty((N, rows_per_sample, c_out), dtype=out_dtype, device=x.device)
+    a = nat.PwArgs()
+    a.x, a.w_packed, a.bias, a.ab, a.res, a.y = (x.data_ptr(), w_packed.data_ptr(),
+                                                 bias.data_ptr() if bias is not None else None,
+                                                 ab.data_ptr() if ab is not None else None,
+                                                 res.data_ptr() if res is not None else None, y.data_ptr())
+    a.N, a.rows_per_sample, a.C_in, a.C_out = N, rows_per_sample, c_in, c_out
+    a.in_dtype, a.out_dtype, a.w_dtype = dtype_code(x.dtype), dtype_code(y.dtype), dtype_code(w_packed.dtype)
+    a.act, a.res_mode, a.gather = act, res_mode, gather
+    a.Di, a.Hi, a.Wi = (int(v) for v in grid)
+    a.res_low = res_low.data_ptr() if res_low is not None else None
+    a.res_bias = res_bias.data_ptr() if res_bias is not None else None
+    nat.check(nat.lib().pytc_pw_conv_fwd(C.byref(a), _stream()), "pw_conv_fwd")
+    return y

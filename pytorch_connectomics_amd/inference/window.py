@@ -1,0 +1,458 @@
+"""Sliding-window inference on the MI355X -- counterpart of the reference's
+connectomics/inference/window.py (same function names, argument meaning and error behaviour).
+
+What is different: the volume, both accumulators and every window stay resident in HBM; patch
+gather, overlap-add and normalisation are hand-written HIP kernels (csrc/window_kernels.hip);
+the 3-D blending map is never materialised (three per-axis vectors, combined in-kernel in the
+reference's rounding order); windows are blended one launch per window in reference order, so
+for identical network outputs the result is bit-identical to the reference engine.
+
+Planner helpers (integers / tiny tables) are plain host code.
+"""
+from __future__ import annotations
+
+import logging
+from collections.abc import Mapping
+from typing import Callable, Optional, Sequence, Tuple, Union
+
+import torch
+
+from .. import _native as nat
+from .. import hip_ops as ops
+
+logger = logging.getLogger(__name__)
+
+_DISTANCE_TRANSFORM_BLEND_MODES = {"distance", "distance_transform", "distance-transform",
+                                   "distance_transform_cdt", "banis", "banis_distance"}
+
+
+def _cfg_value(obj, key: str, default=None):
+    if obj is None:
+        return default
+    if isinstance(obj, Mapping):
+        return obj.get(key, default)
+    return getattr(obj, key, default)
+
+
+def _normalize_blending_mode(mode: str) -> str:
+    return str(mode).strip().lower()
+
+
+def is_distance_transform_blending(mode: str) -> bool:
+    return _normalize_blending_mode(mode) in _DISTANCE_TRANSFORM_BLEND_MODES
+
+
+# --------------------------------------------------------------------------- planner (host ints)
+def compute_scan_interval(image_size: Sequence[int], roi_size: Sequence[int],
+                          num_spatial_dims: int | None = None,
+                          overlap: Union[float, Sequence[float]] = 0.0) -> tuple[int, ...]:
+    """Stride per axis: max(1, round(roi*(1-overlap))) with overlap clamped to [0, 0.99]; the
+    image extent itself when image <= roi (reference window.py:57-89)."""
+    del num_spatial_dims
+    nd = len(roi_size)
+    ovs = [float(overlap[i]) for i in range(nd)] if isinstance(overlap, (list, tuple)) else [float(overlap)] * nd
+    out = []
+    for a in range(nd):
+        roi, img = int(roi_size[a]), int(image_size[a])
+        if img <= roi:
+            out.append(img)
+        else:
+            ov = max(0.0, min(ovs[a], 0.99))
+            out.append(max(1, int(round(roi * (1.0 - ov)))))
+    return tuple(out)
+
+
+def dense_patch_slices(image_size: Sequence[int], roi_size: Sequence[int], scan_interval: Sequence[int],
+                       return_slice: bool = True):
+    """Window origins covering the image, last one per axis snapped to img-roi, first axis
+    outermost (reference window.py:92-134)."""
+    nd = len(roi_size)
+    axes = []
+    for a in range(nd):
+        roi, img = int(roi_size[a]), int(image_size[a])
+        step = max(1, int(scan_interval[a]))
+        if img <= roi:
+            axes.append([0])
+            continue
+        s = list(range(0, img - roi + 1, step))
+        if s[-1] != img - roi:
+            s.append(img - roi)
+        axes.append(s)
+    starts = [()]
+    for s in axes:
+        starts = [p + (v,) for p in starts for v in s]
+    if not return_slice:
+        return starts
+    return [tuple(slice(v, v + int(roi_size[i])) for i, v in enumerate(st)) for st in starts]
+
+
+# --------------------------------------------------------------------------- blending maps
+def _axis_kernels(roi_size: Sequence[int], mode: str, dtype: torch.dtype = torch.float32):
+    """Per-axis factors (CPU tensors) and the in-kernel combine rule.  The bump factors are
+    evaluated with the same torch ops / order as the reference so they are bit-identical."""
+    mode = _normalize_blending_mode(mode)
+    spatial = tuple(int(v) for v in roi_size)
+    if not spatial or any(v <= 0 for v in spatial):
+        raise ValueError(f"roi_size must contain positive values, got {roi_size}.")
+    if mode in _DISTANCE_TRANSFORM_BLEND_MODES:
+        ks = []
+        for n in spatial:
+            c = torch.arange(n, dtype=dtype)
+            ks.append(torch.minimum(c + 1, torch.as_tensor(n, dtype=dtype) - c))
+        return ks, nat.BLEND_MIN
+    if mode == "constant":
+        return [torch.ones(n, dtype=dtype) for n in spatial], nat.BLEND_PRODUCT
+    if mode != "bump":
+        raise ValueError(f"compute_importance_map: unsupported mode {mode!r}; expected 'constant' or 'bump' "
+                         "(use is_distance_transform_blending for the distance-transform path).")
+    tiny = torch.finfo(dtype).tiny
+    ks = []
+    for n in spatial:
+        idx = torch.arange(n, dtype=dtype)
+        u = (idx + 1.0) / (n + 1.0) * 2.0 - 1.0
+        k = torch.exp(-1.0 / (1.0 - u * u).clamp_min(tiny))
+        ks.append(k / k.max().clamp_min(tiny))
+    return ks, nat.BLEND_PRODUCT
+
+
+def _combine_axes(ks, combine, floor: float, device, dtype) -> torch.Tensor:
+    out = None
+    nd = len(ks)
+    for a, k in enumerate(ks):
+        shape = [1] * nd
+        shape[a] = k.numel()
+        kv = k.to(device=device, dtype=dtype).view(shape)
+        if out is None:
+            out = kv
+        else:
+            out = torch.minimum(out, kv) if combine == nat.BLEND_MIN else out * kv
+    out = out.expand([k.numel() for k in ks]).contiguous()
+    if combine == nat.BLEND_PRODUCT:
+        out = out.clamp_min(torch.finfo(dtype).tiny)
+        if floor > 0:
+            out = out.clamp_min(floor)
+    return out
+
+
+def compute_importance_map(roi_size: Sequence[int], *, mode: str = "constant", device="cpu",
+                           dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """'constant' -> ones; 'bump' -> peak-normalised Wu bump, floored at finfo.tiny
+    (reference window.py:137-196).  Utility only: the engine never materialises this map."""
+    mode_n = _normalize_blending_mode(mode)
+    if mode_n not in ("constant", "bump"):
+        raise ValueError(f"compute_importance_map: unsupported mode {mode!r}; expected 'constant' or 'bump' "
+                         "(use is_distance_transform_blending for the distance-transform path).")
+    ks, comb = _axis_kernels(roi_size, mode_n, dtype)
+    if mode_n == "constant":
+        return torch.ones(tuple(int(v) for v in roi_size), device=device, dtype=dtype)
+    return _combine_axes(ks, comb, 0.0, device, dtype)
+
+
+def build_sliding_importance_map(roi_size: Sequence[int], *, mode: str, device, dtype: torch.dtype = torch.float32,
+                                 min_value: float = 1e-5) -> torch.Tensor:
+    """Blending map incl. the distance-transform mode and the 1e-5 floor (reference window.py:199-243)."""
+    ks, comb = _axis_kernels(roi_size, mode, dtype)
+    if comb == nat.BLEND_MIN:
+        return _combine_axes(ks, comb, 0.0, device, dtype)
+    m = _combine_axes(ks, comb, 0.0, device, dtype) if _normalize_blending_mode(mode) != "constant" else \
+        torch.ones(tuple(int(v) for v in roi_size), device=device, dtype=dtype)
+    return m.clamp_min(min_value) if min_value > 0 else m
+
+
+def build_sliding_accumulator_weight_maps(roi_size, *, mode: str, device, value_dtype: torch.dtype):
+    """Value and weight maps are the SAME map (reference window.py:246-272)."""
+    m = build_sliding_importance_map(roi_size, mode=mode, device=device, dtype=value_dtype)
+    return m, m
+
+
+def normalize_weighted_accumulator(value_accumulator: torch.Tensor, weight_accumulator: torch.Tensor) -> torch.Tensor:
+    """In-place value /= clamp_min(weight, 1e-4) on the device (reference window.py:275-294)."""
+    if not value_accumulator.is_cuda:
+        raise RuntimeError("normalize_weighted_accumulator: accumulators live in HBM in this engine "
+                           "(no CPU path)")
+    if value_accumulator.dtype != torch.float32 or weight_accumulator.dtype != torch.float32:
+        raise TypeError("accumulators are float32 in this engine")
+    spatial = weight_accumulator.shape[-3:]
+    v = value_accumulator.view(-1, *spatial)
+    ops.blend_finalize(v, weight_accumulator.view(*spatial), clamp=1e-4, act=nat.ACT_NONE)
+    return value_accumulator
+
+
+def apply_border_mask(importance_map: torch.Tensor, border_mask: Sequence[int]) -> torch.Tensor:
+    """Zero the outer k voxels per axis (reference window.py:297-319)."""
+    if not border_mask or all(int(b) <= 0 for b in border_mask):
+        return importance_map
+    nd = len(border_mask)
+    shape = importance_map.shape[-nd:]
+    for axis, k in enumerate(border_mask):
+        k = int(k)
+        if k <= 0:
+            continue
+        size = int(shape[axis])
+        if 2 * k >= size:
+            raise ValueError(f"inference.sliding_window.border_mask[{axis}]={k} is too large "
+                             f"for window size {size} on that axis.")
+        idx = [slice(None)] * importance_map.ndim
+        pos = importance_map.ndim - nd + axis
+        idx[pos] = slice(0, k)
+        importance_map[tuple(idx)] = 0
+        idx[pos] = slice(size - k, size)
+        importance_map[tuple(idx)] = 0
+    return importance_map
+
+
+# --------------------------------------------------------------------------- config resolution
+_MODEL_OUTPUT_DTYPE_ALIASES = {"float32": torch.float32, "fp32": torch.float32, "float16": torch.float16,
+                               "fp16": torch.float16, "half": torch.float16, "bfloat16": torch.bfloat16,
+                               "bf16": torch.bfloat16}
+
+
+def resolve_model_output_dtype(cfg) -> torch.dtype:
+    raw = _cfg_value(_cfg_value(_cfg_value(cfg, "inference", None), "model", None), "output_dtype", None)
+    if raw is None:
+        return torch.float32
+    name = str(raw).strip().lower().removeprefix("torch.")
+    if name in _MODEL_OUTPUT_DTYPE_ALIASES:
+        return _MODEL_OUTPUT_DTYPE_ALIASES[name]
+    raise ValueError("inference.model.output_dtype must be one of "
+                     f"{sorted(_MODEL_OUTPUT_DTYPE_ALIASES)}, got {raw!r}.")
+
+
+def _sliding_cfg(cfg):
+    inf = getattr(cfg, "inference", None)
+    sw = getattr(inf, "sliding_window", None)
+    return sw if sw is not None else getattr(inf, "window", None)
+
+
+def resolve_border_mask(cfg, spatial_dims: int) -> list[int]:
+    sw = _sliding_cfg(cfg)
+    raw = getattr(sw, "border_mask", None) if sw else None
+    if not raw:
+        return []
+    values = [int(v) for v in raw]
+    if len(values) == 1:
+        values = values * spatial_dims
+    if len(values) != spatial_dims:
+        raise ValueError(f"inference.sliding_window.border_mask must have length 1 or {spatial_dims}, "
+                         f"got {len(values)}.")
+    return values
+
+
+def is_2d_inference_mode(cfg) -> bool:
+    data = getattr(cfg, "data", None)
+    return bool(getattr(getattr(data, "train", None), "do_2d", False)
+                or getattr(getattr(data, "val", None), "do_2d", False))
+
+
+def resolve_inferer_roi_size(cfg) -> Optional[Tuple[int, ...]]:
+    sw = _sliding_cfg(cfg)
+    ws = getattr(sw, "window_size", None) if sw else None
+    if ws:
+        return tuple(int(v) for v in ws)
+    for holder, key in ((getattr(cfg, "model", None), "output_size"),
+                        (getattr(getattr(cfg, "data", None), "data_transform", None), "patch_size")):
+        val = getattr(holder, key, None) if holder is not None else None
+        if val:
+            roi = tuple(int(v) for v in val)
+            if is_2d_inference_mode(cfg) and len(roi) == 2:
+                roi = (1,) + roi
+            return roi
+    return None
+
+
+def resolve_inferer_overlap(cfg, roi_size) -> Union[float, Tuple[float, ...]]:
+    sw = _sliding_cfg(cfg)
+    if sw is None:
+        return 0.5
+    ov = getattr(sw, "overlap", None)
+    if ov is None:
+        return 0.5
+    if isinstance(ov, (list, tuple)):
+        return tuple(float(max(0.0, min(o, 0.99))) for o in ov)
+    return float(max(0.0, min(ov, 0.99)))
+
+
+def _resolve_sliding_window_runtime(cfg, roi_size) -> dict:
+    sw = _sliding_cfg(cfg)
+    dl = getattr(getattr(cfg, "data", None), "dataloader", None)
+    data_bs = getattr(dl, "batch_size", 1) if dl else 1
+    cfg_bs = getattr(sw, "sw_batch_size", None) if sw else None
+
+    def none_if_blank(v):
+        return None if isinstance(v, str) and v.lower() in {"", "none", "null"} else v
+
+    sw_device = none_if_blank(getattr(sw, "sw_device", None) if sw else None)
+    output_device = none_if_blank(getattr(sw, "output_device", None) if sw else None)
+    keep_cpu = bool(getattr(sw, "keep_input_on_cpu", False)) if sw else False
+    if keep_cpu:
+        if sw_device is None and torch.cuda.is_available():
+            sw_device = "cuda"
+        if output_device is None:
+            output_device = "cpu"
+    return {
+        "overlap": resolve_inferer_overlap(cfg, roi_size),
+        "sw_batch_size": max(1, int(cfg_bs if cfg_bs is not None else data_bs)),
+        "mode": _normalize_blending_mode(getattr(sw, "blending", "bump") if sw else "bump"),
+        "padding_mode": getattr(sw, "padding_mode", "constant") if sw else "constant",
+        "cval": float(getattr(sw, "cval", 0.0)) if sw else 0.0,
+        "keep_input_on_cpu": keep_cpu,
+        "sw_device": sw_device,
+        "output_device": output_device,
+    }
+
+
+# --------------------------------------------------------------------------- engine
+def _effective_pad_mode(start, roi, img, padding_mode: str) -> str:
+    """reflect/circular fall back to constant when a pad reaches the in-volume extent
+    (reference window.py:511-518)."""
+    if padding_mode not in ("reflect", "circular"):
+        return padding_mode
+    for a in range(len(roi)):
+        lo, hi = max(0, start[a]), min(img[a], start[a] + roi[a])
+        before, after = max(0, -start[a]), max(0, start[a] + roi[a] - img[a])
+        if before >= hi - lo or after >= hi - lo:
+            return "constant"
+    return padding_mode
+
+
+def _extract_padded_patch_batch(tensor: torch.Tensor, patch_slices, *, roi_size, padding_mode: str, cval: float):
+    """(1,C,*spatial) device tensor -> (B,C,*roi) batch + locations (reference window.py:464-527);
+    gather/pad kernel, result returned in NCDHW for API compatibility."""
+    if tensor.shape[0] != 1:
+        raise ValueError("Patch-first sliding-window TTA currently expects singleton batches. "
+                         f"Got batch size {tensor.shape[0]}.")
+    roi = tuple(int(v) for v in roi_size)
+    locs = [tuple(int(s.start) for s in sl) for sl in patch_slices]
+    vol = tensor[0].float().contiguous()
+    img = tuple(int(v) for v in vol.shape[1:])
+    outs = []
+    for loc in locs:      # pad mode can differ per window (fallback rule)
+        mode = _effective_pad_mode(loc, roi, img, padding_mode)
+        outs.append(ops.gather_windows(vol, [loc], roi, pad_mode=mode, cval=cval))
+    cl = torch.cat(outs, 0)
+    return cl.permute(0, 4, 1, 2, 3).contiguous().to(tensor.dtype), locs
+
+
+class EagerSlidingWindowEngine:
+    """``engine(inputs=(1,C,*spatial), network=fn) -> (1,C_out,*spatial)`` with everything in HBM.
+
+    ``network`` is either a module exposing ``forward_cl`` (channels-last fast path of this
+    package's models) or any callable ``(B,C,*roi) -> (B,C_out,*roi)`` tensor.
+    """
+
+    def __init__(self, *, roi_size, sw_batch_size: int, overlap, mode: str, padding_mode: str, cval: float,
+                 sw_device=None, output_device=None, progress: bool = False) -> None:
+        self.roi_size = tuple(int(v) for v in roi_size)
+        self.sw_batch_size = max(1, int(sw_batch_size))
+        self.overlap = overlap
+        self.mode = _normalize_blending_mode(mode)
+        self.padding_mode = padding_mode
+        self.cval = float(cval)
+        self.sw_device = sw_device
+        self.output_device = output_device
+        self.progress = bool(progress)
+        self._axis_cache = {}
+        self.last_stats = {}
+
+    def _axis_vectors(self, device):
+        key = (self.roi_size, self.mode, str(device))
+        hit = self._axis_cache.get(key)
+        if hit is None:
+            ks, comb = _axis_kernels(self.roi_size, self.mode, torch.float32)
+            hit = ([k.to(device).contiguous() for k in ks], comb)
+            self._axis_cache[key] = hit
+        return hit
+
+    def plan(self, image_size):
+        image_size = tuple(max(int(image_size[i]), self.roi_size[i]) for i in range(len(self.roi_size)))
+        interval = compute_scan_interval(image_size, self.roi_size, overlap=self.overlap)
+        return image_size, dense_patch_slices(image_size, self.roi_size, interval, return_slice=False)
+
+    def _run_network(self, network, batch_cl: torch.Tensor) -> torch.Tensor:
+        """batch (B,rz,ry,rx,C) fp32 -> prediction (B,rz,ry,rx,C_out) fp32/bf16, channels last."""
+        fwd_cl = getattr(network, "forward_cl", None)
+        if fwd_cl is not None:
+            y = fwd_cl(batch_cl)
+        else:
+            x = batch_cl.permute(0, 4, 1, 2, 3)
+            if batch_cl.shape[-1] != 1:
+                x = x.contiguous()
+            y = network(x)
+            if not isinstance(y, torch.Tensor):
+                raise ValueError("EagerSlidingWindowEngine: `network` must return a torch.Tensor; "
+                                 f"got {type(y).__name__}.")
+            if tuple(y.shape[2:]) != self.roi_size:
+                raise ValueError(f"network must preserve the ROI shape {self.roi_size}, got {tuple(y.shape[2:])}")
+            y = y.permute(0, 2, 3, 4, 1).contiguous()
+        if y.dtype not in (torch.float32, torch.bfloat16):
+            y = y.float()
+        return y.contiguous()
+
+    @torch.no_grad()
+    def __call__(self, inputs: torch.Tensor, network: Callable[[torch.Tensor], torch.Tensor]) -> torch.Tensor:
+        nd = len(self.roi_size)
+        if nd != 3:
+            raise NotImplementedError("the MI355X engine handles 3-D ROIs (use roi (1,H,W) for 2-D data)")
+        if inputs.dim() < nd + 2:
+            raise ValueError("EagerSlidingWindowEngine: inputs must have shape (B, C, *spatial); "
+                             f"got shape {tuple(inputs.shape)} for roi_size {self.roi_size}.")
+        if inputs.shape[0] != 1:
+            raise ValueError(f"EagerSlidingWindowEngine currently expects batch size 1; got batch {inputs.shape[0]}.")
+        dev = torch.device(self.sw_device) if self.sw_device else inputs.device
+        if dev.type != "cuda":
+            raise RuntimeError("EagerSlidingWindowEngine (pytorch_connectomics_amd) needs a CUDA(HIP) device: "
+                               "there is no CPU path")
+        vol = inputs[0].to(device=dev, dtype=torch.float32).contiguous()
+        orig = tuple(int(v) for v in vol.shape[1:])
+        # grow-to-roi: windows may overhang the stored volume; the gather kernel fills the
+        # overhang with cval (always constant, reference window.py:583-601)
+        image_size, starts = self.plan(orig)
+        (wz, wy, wx), combine = self._axis_vectors(dev)
+        roi = self.roi_size
+
+        def run(batch_starts):
+            x = ops.gather_windows(vol, batch_starts, roi, pad_mode="constant", cval=self.cval)
+            return self._run_network(network, x)
+
+        probe = run(starts[:1])
+        c_out = int(probe.shape[-1])
+        value = torch.zeros((c_out,) + image_size, dtype=torch.float32, device=dev)
+        weight = torch.zeros(image_size, dtype=torch.float32, device=dev)
+        ops.blend_accumulate(probe, starts[:1], value, weight, wz, wy, wx, combine=combine, floor_w=1e-5)
+        rest = starts[1:]
+        for b0 in range(0, len(rest), self.sw_batch_size):
+            chunk = rest[b0:b0 + self.sw_batch_size]
+            pred = run(chunk)
+            ops.blend_accumulate(pred, chunk, value, weight, wz, wy, wx, combine=combine, floor_w=1e-5)
+        ops.blend_finalize(value, weight, clamp=1e-4, act=nat.ACT_NONE)
+        self.last_stats = {"windows": len(starts), "roi": roi, "image_size": image_size}
+        out = value
+        if image_size != orig:
+            out = out[:, :orig[0], :orig[1], :orig[2]].contiguous()
+        out = out.unsqueeze(0)
+        if self.output_device is not None and torch.device(self.output_device) != out.device:
+            out = out.to(self.output_device)
+        return out
+
+
+def build_sliding_inferer(cfg) -> Optional[EagerSlidingWindowEngine]:
+    """Build the eager engine from cfg.inference.sliding_window (reference window.py:686-732)."""
+    roi_size = resolve_inferer_roi_size(cfg)
+    if roi_size is None:
+        logger.warning("Sliding-window inference disabled: unable to determine ROI size. "
+                       "Set inference.window_size or model.output_size in the config.")
+        return None
+    rt = _resolve_sliding_window_runtime(cfg, roi_size)
+    if resolve_border_mask(cfg, len(roi_size)):
+        logger.warning("inference.sliding_window.border_mask is set but the eager sliding-window engine "
+                       "ignores it; use the lazy sliding-window path to apply border masking.")
+    return EagerSlidingWindowEngine(roi_size=roi_size, sw_batch_size=rt["sw_batch_size"], overlap=rt["overlap"],
+                                    mode=rt["mode"], padding_mode=rt["padding_mode"], cval=rt["cval"],
+                                    sw_device=rt["sw_device"], output_device=rt["output_device"], progress=False)
+
+
+__all__ = ["EagerSlidingWindowEngine", "apply_border_mask", "build_sliding_accumulator_weight_maps",
+           "build_sliding_importance_map", "build_sliding_inferer", "compute_importance_map",
+           "compute_scan_interval", "dense_patch_slices", "is_2d_inference_mode",
+           "is_distance_transform_blending", "normalize_weighted_accumulator", "resolve_border_mask",
+           "resolve_inferer_overlap", "resolve_inferer_roi_size", "resolve_model_output_dtype"]

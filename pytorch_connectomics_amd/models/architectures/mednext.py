@@ -1,0 +1,402 @@
+"""MedNeXt trunk for MI355X -- the counterpart of the third-party ``nnunet_mednext`` package the
+reference imports (connectomics/models/architectures/mednext_models.py:23-32).
+
+Module / parameter names follow the published MedNeXt v1 layout so that reference checkpoints
+(``model.model.stem.weight``, ``...enc_block_0.0.conv1.weight`` ...) load with
+``strict=True``.  The nn.Conv3d / nn.GroupNorm / nn.ConvTranspose3d children are PARAMETER HOLDERS
+only (they also keep torch.optim's "no weight decay on norm modules" grouping working,
+training/optimization/build.py:73-112); ``forward`` never calls them -- it runs the hand-written
+gfx950 kernels of libpytc_hip.so on NDHWC activations:
+
+  block      : dwconv3d (+ per-(n,c) sum/sumsq)  ->  groupnorm_finalize  ->
+               [norm-apply . 1x1 expand . GELU]  ->  [1x1 project + residual]        (MFMA GEMMs)
+  down block : same with stride-2 depthwise conv; residual = strided 1x1 conv (gather GEMM)
+  up block   : depthwise transposed conv written at +1 offset (the F.pad((1,0)*3) is free),
+               residual = transposed 1x1 conv evaluated at low resolution and gathered in the
+               epilogue together with the encoder skip.
+
+There is no CPU path: calling ``forward`` with a CPU tensor raises.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Union
+
+import torch
+import torch.nn as nn
+
+from ... import _native as nat
+from ... import hip_ops as ops
+
+
+def _conv_nd(dim: str):
+    if dim == "3d":
+        return nn.Conv3d, nn.ConvTranspose3d
+    if dim == "2d":
+        return nn.Conv2d, nn.ConvTranspose2d
+    raise ValueError(f"dim must be '2d' or '3d', got {dim!r}")
+
+
+class _ChannelLayerNorm(nn.Module):
+    """channels_first LayerNorm parameter holder (norm_type='layer')."""
+
+    def __init__(self, normalized_shape: int, eps: float = 1e-5):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(normalized_shape))
+        self.eps = eps
+
+
+class MedNeXtBlock(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, exp_r: int = 4, kernel_size: int = 7,
+                 do_res: bool = True, norm_type: str = "group", n_groups: Optional[int] = None,
+                 dim: str = "3d", grn: bool = False):
+        super().__init__()
+        conv, _ = _conv_nd(dim)
+        self.do_res = do_res
+        self.dim = dim
+        self.grn = grn
+        self.conv1 = conv(in_channels, in_channels, kernel_size=kernel_size, stride=1,
+                          padding=kernel_size // 2, groups=in_channels if n_groups is None else n_groups)
+        if norm_type == "group":
+            self.norm = nn.GroupNorm(num_groups=in_channels, num_channels=in_channels)
+        elif norm_type == "layer":
+            self.norm = _ChannelLayerNorm(in_channels)
+        else:
+            raise ValueError(f"norm_type must be 'group' or 'layer', got {norm_type!r}")
+        self.conv2 = conv(in_channels, exp_r * in_channels, kernel_size=1, stride=1, padding=0)
+        self.act = nn.GELU()
+        self.conv3 = conv(exp_r * in_channels, out_channels, kernel_size=1, stride=1, padding=0)
+        if grn:
+            shape = (1, exp_r * in_channels, 1, 1, 1) if dim == "3d" else (1, exp_r * in_channels, 1, 1)
+            self.grn_beta = nn.Parameter(torch.zeros(shape))
+            self.grn_gamma = nn.Parameter(torch.zeros(shape))
+        self.kind = "block"
+
+    def forward(self, x, dummy_tensor=None):  # pragma: no cover - guard only
+        raise RuntimeError("MedNeXt blocks execute through MedNeXt.forward (HIP engine); they are parameter "
+                           "holders and cannot be called directly")
+
+
+class MedNeXtDownBlock(MedNeXtBlock):
+    def __init__(self, in_channels, out_channels, exp_r=4, kernel_size=7, do_res=False, norm_type="group",
+                 dim="3d", grn=False):
+        super().__init__(in_channels, out_channels, exp_r, kernel_size, do_res=False, norm_type=norm_type,
+                         dim=dim, grn=grn)
+        conv, _ = _conv_nd(dim)
+        self.resample_do_res = do_res
+        if do_res:
+            self.res_conv = conv(in_channels, out_channels, kernel_size=1, stride=2)
+        self.conv1 = conv(in_channels, in_channels, kernel_size=kernel_size, stride=2,
+                          padding=kernel_size // 2, groups=in_channels)
+        self.kind = "down"
+
+
+class MedNeXtUpBlock(MedNeXtBlock):
+    def __init__(self, in_channels, out_channels, exp_r=4, kernel_size=7, do_res=False, norm_type="group",
+                 dim="3d", grn=False):
+        super().__init__(in_channels, out_channels, exp_r, kernel_size, do_res=False, norm_type=norm_type,
+                         dim=dim, grn=grn)
+        _, convt = _conv_nd(dim)
+        self.resample_do_res = do_res
+        if do_res:
+            self.res_conv = convt(in_channels, out_channels, kernel_size=1, stride=2)
+        self.conv1 = convt(in_channels, in_channels, kernel_size=kernel_size, stride=2,
+                           padding=kernel_size // 2, groups=in_channels)
+        self.kind = "up"
+
+
+class OutBlock(nn.Module):
+    def __init__(self, in_channels: int, n_classes: int, dim: str = "3d"):
+        super().__init__()
+        _, convt = _conv_nd(dim)
+        self.conv_out = convt(in_channels, n_classes, kernel_size=1)
+
+    def forward(self, x, dummy_tensor=None):  # pragma: no cover - guard only
+        raise RuntimeError("OutBlock executes through MedNeXt.forward (HIP engine)")
+
+
+# --------------------------------------------------------------------------------------------
+class _WeightCache:
+    """Device-side repacked parameters, keyed by (parameter identity, version, compute dtype)."""
+
+    def __init__(self):
+        self._store: Dict = {}
+
+    def get(self, key, params: Sequence[torch.Tensor], make):
+        sig = tuple((p.data_ptr(), p._version) for p in params)
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        with torch.no_grad():
+            val = make()
+        self._store[key] = (sig, val)
+        return val
+
+    def clear(self):
+        self._store.clear()
+
+
+def _f32(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if p is None else p.detach().float().contiguous()
+
+
+class HipBlockOps:
+    """Forward of the three MedNeXt block kinds on NDHWC tensors using libpytc_hip kernels."""
+
+    def __init__(self):
+        self.cache = _WeightCache()
+
+    # ---- parameter repacking (load time / after optimizer steps) -----------------------------
+    def _taps(self, conv: nn.Module):
+        w = conv.weight
+        def make():
+            c = w.shape[0]
+            k = w.shape[-1]
+            return w.detach().float().reshape(c, k ** 3).t().contiguous(), k
+        return self.cache.get(("taps", id(conv)), [w], make)
+
+    def _pw(self, conv: nn.Module, dt: torch.dtype, transposed: bool = False):
+        w = conv.weight
+        def make():
+            w2 = w.detach().float().reshape(w.shape[0], w.shape[1]).contiguous()
+            return ops.pw_pack_weight(w2, dt, transposed=transposed)
+        return self.cache.get(("pw", id(conv), dt), [w], make)
+
+    def _vec(self, owner, name: str, p: Optional[torch.Tensor]):
+        if p is None:
+            return None
+        return self.cache.get(("vec", id(owner), name), [p], lambda: _f32(p).reshape(-1))
+
+    # ---- ops -----------------------------------------------------------------------------------
+    def pointwise(self, x: torch.Tensor, conv: nn.Module, *, out_dtype=None, transposed=False, act=nat.ACT_NONE):
+        """x (N, *spatial, C_in) -> (N, *spatial, C_out) through a 1x1x1 conv module."""
+        N = x.shape[0]
+        spatial = tuple(x.shape[1:-1])
+        rows = 1
+        for s in spatial:
+            rows *= s
+        c_in = x.shape[-1]
+        c_out = conv.weight.shape[1] if transposed else conv.weight.shape[0]
+        dt = x.dtype if x.dtype == torch.bfloat16 else torch.float32
+        wdt = torch.bfloat16 if (dt == torch.bfloat16 or (out_dtype == torch.bfloat16)) else torch.float32
+        wp = self._pw(conv, wdt, transposed)
+        y = ops.pw_conv(x, wp, self._vec(conv, "bias", conv.bias), N=N, rows_per_sample=rows, c_in=c_in,
+                        c_out=c_out, out_dtype=out_dtype or x.dtype, act=act)
+        return y.view(N, *spatial, c_out)
+
+    def block(self, m: MedNeXtBlock, x: torch.Tensor, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if m.grn:
+            raise NotImplementedError("MedNeXt GRN (grn=True) has no HIP kernel yet")
+        if not isinstance(m.norm, nn.GroupNorm):
+            raise NotImplementedError("MedNeXt norm_type='layer' has no HIP kernel yet")
+        if m.dim != "3d":
+            raise NotImplementedError("MedNeXt dim='2d' has no HIP kernel yet")
+        dt = x.dtype
+        N, D, H, W, C = x.shape
+        taps, K = self._taps(m.conv1)
+        b1 = self._vec(m.conv1, "bias", m.conv1.bias)
+        kind = m.kind
+        if kind == "up":
+            t, st = ops.dwconv3d(x, taps, b1, K=K, transposed=True)
+            count = float((2 * D - 1) * (2 * H - 1) * (2 * W - 1))
+        else:
+            t, st = ops.dwconv3d(x, taps, b1, K=K, stride=2 if kind == "down" else 1)
+            count = float(t.shape[1] * t.shape[2] * t.shape[3])
+        ab = ops.groupnorm_finalize(st, count, self._vec(m.norm, "weight", m.norm.weight),
+                                    self._vec(m.norm, "bias", m.norm.bias), m.norm.eps)
+        _, Do, Ho, Wo, _ = t.shape
+        rows = Do * Ho * Wo
+        c_hid = m.conv2.weight.shape[0]
+        c_out = m.conv3.weight.shape[0]
+        h = ops.pw_conv(t, self._pw(m.conv2, dt), self._vec(m.conv2, "bias", m.conv2.bias), N=N,
+                        rows_per_sample=rows, c_in=C, c_out=c_hid, out_dtype=dt, ab=ab, act=nat.ACT_GELU)
+        w3, b3 = self._pw(m.conv3, dt), self._vec(m.conv3, "bias", m.conv3.bias)
+        if kind == "block":
+            y = ops.pw_conv(h, w3, b3, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, out_dtype=dt,
+                            res=x if m.do_res else None, res_mode=nat.RES_ADD if m.do_res else nat.RES_NONE)
+        elif kind == "down":
+            res = None
+            if m.resample_do_res:
+                res = ops.pw_conv(x, self._pw(m.res_conv, dt), self._vec(m.res_conv, "bias", m.res_conv.bias),
+                                  N=N, rows_per_sample=rows, c_in=C, c_out=c_out, out_dtype=dt, gather=2,
+                                  grid=(D, H, W))
+            y = ops.pw_conv(h, w3, b3, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, out_dtype=dt,
+                            res=res, res_mode=nat.RES_ADD if res is not None else nat.RES_NONE)
+        else:  # up: result + padded transposed-1x1 residual + encoder skip, one epilogue
+            if skip is None:
+                skip = torch.zeros((N, Do, Ho, Wo, c_out), dtype=dt, device=x.device)
+            res_low = res_bias = None
+            if m.resample_do_res:
+                res_bias = self._vec(m.res_conv, "bias", m.res_conv.bias)
+                res_low = ops.pw_conv(x, self._pw(m.res_conv, dt, transposed=True), res_bias, N=N,
+                                      rows_per_sample=D * H * W, c_in=C, c_out=c_out, out_dtype=dt)
+            y = ops.pw_conv(h, w3, b3, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, out_dtype=dt,
+                            res=skip, res_mode=nat.RES_UPSAMPLE, grid=(Do, Ho, Wo), res_low=res_low,
+                            res_bias=res_bias)
+        return y.view(N, Do, Ho, Wo, c_out)
+
+
+def resolve_compute_dtype(module_pref: Optional[torch.dtype]) -> torch.dtype:
+    """bf16 storage when requested on the module or under torch.autocast(bfloat16) (the reference's
+    'bf16-mixed' Lightning precision, training/lightning/trainer.py:216-223); fp32 otherwise."""
+    if module_pref is not None:
+        return module_pref
+    if torch.is_autocast_enabled():
+        adt = torch.get_autocast_gpu_dtype()
+        if adt == torch.bfloat16:
+            return torch.bfloat16
+        if adt == torch.float16:
+            raise RuntimeError("fp16 autocast is not supported by the MI355X engine; use bf16-mixed")
+    return torch.float32
+
+
+def to_channels_last(x: torch.Tensor) -> torch.Tensor:
+    """(N,C,D,H,W) -> contiguous (N,D,H,W,C); free when C == 1."""
+    if x.shape[1] == 1:
+        return x.reshape(x.shape[0], *x.shape[2:], 1)
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def to_channels_first(y: torch.Tensor) -> torch.Tensor:
+    """(N,D,H,W,C) -> (N,C,D,H,W); free when C == 1."""
+    if y.shape[-1] == 1:
+        return y.reshape(y.shape[0], 1, *y.shape[1:-1])
+    return y.permute(0, 4, 1, 2, 3).contiguous()
+
+
+class MedNeXt(nn.Module):
+    """MedNeXt v1 trunk (Roy et al., MICCAI 2023) executed by hand-written gfx950 kernels."""
+
+    def __init__(self, in_channels: int, n_channels: int, n_classes: int, exp_r: Union[int, Sequence[int]] = 4,
+                 kernel_size: int = 7, enc_kernel_size: Optional[int] = None,
+                 dec_kernel_size: Optional[int] = None, deep_supervision: bool = False, do_res: bool = False,
+                 do_res_up_down: bool = False, checkpoint_style: Optional[str] = None,
+                 block_counts: Sequence[int] = (2, 2, 2, 2, 2, 2, 2, 2, 2), norm_type: str = "group",
+                 dim: str = "3d", grn: bool = False):
+        super().__init__()
+        if checkpoint_style not in (None, "outside_block"):
+            raise ValueError("checkpoint_style must be None or 'outside_block'")
+        if len(block_counts) != 9:
+            raise ValueError("block_counts must have exactly 9 elements")
+        self.do_ds = deep_supervision
+        self.inside_block_checkpointing = False
+        self.outside_block_checkpointing = checkpoint_style == "outside_block"
+        if kernel_size is not None:
+            enc_kernel_size = dec_kernel_size = kernel_size
+        conv, _ = _conv_nd(dim)
+        if isinstance(exp_r, int):
+            exp_r = [exp_r] * 9
+        exp_r = list(exp_r)
+        n = n_channels
+        self.dim = dim
+        self.stem = conv(in_channels, n, kernel_size=1)
+
+        def blocks(c, r, k, count):
+            return nn.Sequential(*[MedNeXtBlock(c, c, r, k, do_res, norm_type, dim=dim, grn=grn)
+                                   for _ in range(count)])
+
+        for lvl in range(4):
+            setattr(self, f"enc_block_{lvl}", blocks(n << lvl, exp_r[lvl], enc_kernel_size, block_counts[lvl]))
+            setattr(self, f"down_{lvl}", MedNeXtDownBlock(n << lvl, n << (lvl + 1), exp_r[lvl + 1], enc_kernel_size,
+                                                          do_res=do_res_up_down, norm_type=norm_type, dim=dim, grn=grn))
+        self.bottleneck = blocks(n << 4, exp_r[4], dec_kernel_size, block_counts[4])
+        for i, lvl in enumerate((3, 2, 1, 0)):
+            setattr(self, f"up_{lvl}", MedNeXtUpBlock(n << (lvl + 1), n << lvl, exp_r[5 + i], dec_kernel_size,
+                                                      do_res=do_res_up_down, norm_type=norm_type, dim=dim, grn=grn))
+            setattr(self, f"dec_block_{lvl}", blocks(n << lvl, exp_r[5 + i], dec_kernel_size, block_counts[5 + i]))
+        self.out_0 = OutBlock(n, n_classes, dim)
+        self.dummy_tensor = nn.Parameter(torch.tensor([1.0]), requires_grad=True)
+        if deep_supervision:
+            for h in (1, 2, 3, 4):
+                setattr(self, f"out_{h}", OutBlock(n << h, n_classes, dim))
+        self.block_counts = list(block_counts)
+        self.compute_dtype: Optional[torch.dtype] = None   # None -> follow autocast
+        self._hip = HipBlockOps()
+
+    # ---- engine ---------------------------------------------------------------------------------
+    def _check_input(self, x: torch.Tensor):
+        if not x.is_cuda:
+            raise RuntimeError("MedNeXt (pytorch_connectomics_amd) runs only on an MI355X/ROCm device: "
+                               "there is no CPU path. Move the model and input to 'cuda'.")
+        if self.dim != "3d" or x.dim() != 5:
+            raise NotImplementedError("only dim='3d' inputs (B,C,D,H,W) are supported by the HIP engine")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "MedNeXt backward kernels are not built yet (SURVEY.md section 8 row f-1): run the forward under "
+                "torch.no_grad() / model.eval() + torch.inference_mode()")
+
+    def features_cl(self, x_cl: torch.Tensor, collect: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
+        """Channels-last in (N,D,H,W,C_in) fp32/bf16 -> channels-last full-resolution features."""
+        hip = self._hip
+        dt = resolve_compute_dtype(self.compute_dtype)
+        x = hip.pointwise(x_cl, self.stem, out_dtype=dt)
+        skips = []
+        for lvl in range(4):
+            for blk in getattr(self, f"enc_block_{lvl}"):
+                x = hip.block(blk, x)
+            skips.append(x)
+            x = hip.block(getattr(self, f"down_{lvl}"), x)
+        for blk in self.bottleneck:
+            x = hip.block(blk, x)
+        if collect is not None:
+            collect.append(x)
+        for lvl in (3, 2, 1, 0):
+            x = hip.block(getattr(self, f"up_{lvl}"), x, skip=skips[lvl])
+            for blk in getattr(self, f"dec_block_{lvl}"):
+                x = hip.block(blk, x)
+            if collect is not None and lvl != 0:
+                collect.append(x)
+        return x
+
+    def output_cl(self, feat_cl: torch.Tensor, head: int = 0) -> torch.Tensor:
+        """features -> fp32 logits, channels-last."""
+        return self._hip.pointwise(feat_cl, getattr(self, f"out_{head}").conv_out, out_dtype=torch.float32,
+                                   transposed=True)
+
+    def forward_cl(self, x_cl: torch.Tensor):
+        """Channels-last entry used by the sliding-window engine: (N,D,H,W,C_in) -> (N,D,H,W,n_classes) fp32."""
+        return self.output_cl(self.features_cl(x_cl))
+
+    # ---- reference-visible API (mednext_models.py:215-231) ---------------------------------------
+    def forward_features(self, x: torch.Tensor) -> torch.Tensor:
+        self._check_input(x)
+        return to_channels_first(self.features_cl(to_channels_last(x.float())).float())
+
+    def forward_output(self, features: torch.Tensor) -> torch.Tensor:
+        if not features.is_cuda:
+            raise RuntimeError("forward_output needs a CUDA tensor: there is no CPU path")
+        dt = resolve_compute_dtype(self.compute_dtype)
+        return to_channels_first(self.output_cl(to_channels_last(features).to(dt)))
+
+    def forward(self, x: torch.Tensor):
+        self._check_input(x)
+        feats: Optional[List[torch.Tensor]] = [] if self.do_ds else None
+        f = self.features_cl(to_channels_last(x.float()), collect=feats)
+        out = to_channels_first(self.output_cl(f))
+        if not self.do_ds:
+            return out
+        # feats = [bottleneck, dec_3, dec_2, dec_1] -> out_4 .. out_1 ; returned [x, ds_1 .. ds_4]
+        ds = [to_channels_first(self.output_cl(ft, h)) for ft, h in zip(feats, (4, 3, 2, 1))]
+        return [out, ds[3], ds[2], ds[1], ds[0]]
+
+
+def create_mednext_v1(num_input_channels: int, num_classes: int, model_id: str, kernel_size: int = 3,
+                      deep_supervision: bool = False) -> MedNeXt:
+    """Size table of the upstream factory (S/B/M/L); see SURVEY.md section 8(c) for its provenance."""
+    table = {
+        "S": dict(exp_r=2, block_counts=[2] * 9, checkpoint_style=None),
+        "B": dict(exp_r=[2, 3, 4, 4, 4, 4, 4, 3, 2], block_counts=[2] * 9, checkpoint_style=None),
+        "M": dict(exp_r=[2, 3, 4, 4, 4, 4, 4, 3, 2], block_counts=[3, 4, 4, 4, 4, 4, 4, 4, 3],
+                  checkpoint_style="outside_block"),
+        "L": dict(exp_r=[3, 4, 8, 8, 8, 8, 8, 4, 3], block_counts=[3, 4, 8, 8, 8, 8, 8, 4, 3],
+                  checkpoint_style="outside_block"),
+    }
+    if model_id not in table:
+        raise ValueError(f"model_id must be one of S, B, M, L; got {model_id!r}")
+    return MedNeXt(in_channels=num_input_channels, n_channels=32, n_classes=num_classes,
+                   kernel_size=kernel_size, deep_supervision=deep_supervision, do_res=True,
+                   do_res_up_down=True, **table[model_id])
+
+
+__all__ = ["MedNeXt", "MedNeXtBlock", "MedNeXtDownBlock", "MedNeXtUpBlock", "OutBlock", "create_mednext_v1",
+           "HipBlockOps", "to_channels_last", "to_channels_first", "resolve_compute_dtype"]

@@ -1,0 +1,159 @@
+"""GPU parity of the network kernels (depthwise conv + statistics, GroupNorm finalize, pointwise MFMA
+GEMMs with their prologue/epilogue variants) against plain PyTorch fp32 on the CPU."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _cl(x):   # NCDHW -> NDHWC
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _cf(y):
+    return y.permute(0, 4, 1, 2, 3).contiguous()
+
+
+TOL = {torch.float32: dict(rtol=1e-5, atol=1e-5), torch.bfloat16: dict(rtol=2e-2, atol=2e-2)}
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,K,stride,shape", [(32, 3, 1, (9, 10, 11)), (64, 3, 2, (9, 10, 12)), (16, 5, 1, (7, 8, 9)),
+                                              (8, 7, 2, (9, 9, 9)), (12, 3, 1, (5, 6, 7)), (6, 3, 2, (6, 6, 6)),
+                                              (512, 3, 1, (3, 4, 3))])
+def test_dwconv3d_and_stats(dev, dt, C, K, stride, shape):
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(C * 100 + K)
+    N = 2
+    x = torch.randn(N, C, *shape)
+    w = torch.randn(C, 1, K, K, K) * 0.2
+    b = torch.randn(C)
+    xq = x.to(dt).float()
+    ref = F.conv3d(xq, w, b, stride=stride, padding=K // 2, groups=C)
+    taps = w.reshape(C, K ** 3).t().contiguous().to(dev)
+    y, st = ops.dwconv3d(_cl(xq).to(dev).to(dt), taps, b.to(dev), K=K, stride=stride)
+    got = _cf(y.float().cpu())
+    assert got.shape == ref.shape
+    torch.testing.assert_close(got, ref, **TOL[dt])
+    # statistics are those of the stored (rounded) tensor
+    s = st.sum(1).cpu()
+    torch.testing.assert_close(s[:, 0], got.sum((2, 3, 4)), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(s[:, 1], (got * got).sum((2, 3, 4)), rtol=1e-4, atol=1e-2)
+    # finalize == GroupNorm(C, C) affine
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C)
+    count = float(np.prod(got.shape[2:]))
+    ab = ops.groupnorm_finalize(st, count, gamma.to(dev), beta.to(dev), 1e-5).cpu()
+    normed = ab[:, 0][:, :, None, None, None] * got + ab[:, 1][:, :, None, None, None]
+    torch.testing.assert_close(normed, F.group_norm(got, C, gamma, beta, 1e-5), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,K,shape", [(32, 3, (4, 5, 6)), (8, 5, (3, 4, 5)), (64, 7, (3, 3, 4))])
+def test_dwconv_transposed(dev, dt, C, K, shape):
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(C + K)
+    N = 2
+    x = torch.randn(N, C, *shape).to(dt).float()
+    w = torch.randn(C, 1, K, K, K) * 0.2
+    b = torch.randn(C)
+    ref = F.pad(F.conv_transpose3d(x, w, b, stride=2, padding=K // 2, groups=C), (1, 0, 1, 0, 1, 0))
+    taps = w.reshape(C, K ** 3).t().contiguous().to(dev)
+    y, st = ops.dwconv3d(_cl(x).to(dev).to(dt), taps, b.to(dev), K=K, transposed=True)
+    got = _cf(y.float().cpu())
+    assert got.shape == ref.shape
+    torch.testing.assert_close(got, ref, **TOL[dt])
+    inner = got[:, :, 1:, 1:, 1:]
+    torch.testing.assert_close(st.sum(1).cpu()[:, 0], inner.sum((2, 3, 4)), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(st.sum(1).cpu()[:, 1], (inner * inner).sum((2, 3, 4)), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,rows", [(32, 64, 1000), (64, 32, 777), (1, 32, 300), (32, 1, 513), (8, 3, 100),
+                                           (12, 20, 65), (512, 1024, 90), (1024, 512, 70), (128, 256, 260)])
+def test_pw_conv_plain(dev, dt, cin, cout, rows):
+    """Asymmetric random weights: catches any operand / accumulator transposition."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(cin * 7 + cout)
+    N = 2
+    x = torch.randn(N, rows, cin).to(dt).float()
+    w = (torch.randn(cout, cin) / cin ** 0.5)
+    b = torch.randn(cout)
+    wq = w.to(dt).float()
+    ref = x @ wq.t() + b
+    wp = ops.pw_pack_weight(w.to(dev), dt)
+    y = ops.pw_conv(x.to(dev).to(dt), wp, b.to(dev), N=N, rows_per_sample=rows, c_in=cin, c_out=cout, out_dtype=dt)
+    torch.testing.assert_close(y.float().cpu(), ref, **TOL[dt])
+    # transposed source layout (ConvTranspose3d weight) gives the same operator
+    wp2 = ops.pw_pack_weight(w.t().contiguous().to(dev), dt, transposed=True)
+    assert torch.equal(wp, wp2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_pw_conv_norm_gelu_and_residual(dev, dt):
+    from pytorch_connectomics_amd import _native as nat
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(3)
+    N, rows, C, Hd = 2, 500, 32, 64
+    t = torch.randn(N, rows, C).to(dt).float()
+    xres = torch.randn(N, rows, C).to(dt).float()
+    a, b = torch.rand(N, C) + 0.5, torch.randn(N, C)
+    w2, b2 = torch.randn(Hd, C) / C ** 0.5, torch.randn(Hd)
+    w3, b3 = torch.randn(C, Hd) / Hd ** 0.5, torch.randn(C)
+    ab = torch.stack([a, b], 1).contiguous().to(dev)
+    h = ops.pw_conv(t.to(dev).to(dt), ops.pw_pack_weight(w2.to(dev), dt), b2.to(dev), N=N, rows_per_sample=rows,
+                    c_in=C, c_out=Hd, out_dtype=dt, ab=ab, act=nat.ACT_GELU)
+    tn = (t * a[:, None] + b[:, None])
+    if dt == torch.bfloat16:
+        tn = tn.to(dt).float()
+    href = F.gelu(tn @ w2.to(dt).float().t() + b2)
+    torch.testing.assert_close(h.float().cpu(), href, **TOL[dt])
+    y = ops.pw_conv(h, ops.pw_pack_weight(w3.to(dev), dt), b3.to(dev), N=N, rows_per_sample=rows, c_in=Hd, c_out=C,
+                    out_dtype=dt, res=xres.to(dev).to(dt), res_mode=nat.RES_ADD)
+    yref = h.float().cpu() @ w3.to(dt).float().t() + b3 + xres
+    torch.testing.assert_close(y.float().cpu(), yref, **TOL[dt])
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_pw_conv_strided_gather_and_upsample_epilogue(dev, dt):
+    from pytorch_connectomics_amd import _native as nat
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(4)
+    N, C, Co = 2, 16, 32
+    D, H, W = 5, 6, 7
+    x = torch.randn(N, C, D, H, W).to(dt).float()
+    w, b = torch.randn(Co, C, 1, 1, 1) / 4, torch.randn(Co)
+    ref = F.conv3d(x, w.to(dt).float(), b, stride=2)
+    Do, Ho, Wo = ref.shape[2:]
+    y = ops.pw_conv(_cl(x).to(dev).to(dt), ops.pw_pack_weight(w.reshape(Co, C).to(dev), dt), b.to(dev), N=N,
+                    rows_per_sample=Do * Ho * Wo, c_in=C, c_out=Co, out_dtype=dt, gather=2, grid=(D, H, W))
+    torch.testing.assert_close(_cf(y.view(N, Do, Ho, Wo, Co).float().cpu()), ref, **TOL[dt])
+
+    # up-block epilogue: pad(mlp) + pad(convT_1x1_s2(x_low)) + skip
+    Cl, Cu = 32, 16
+    d, h_, w_ = 3, 4, 5
+    xl = torch.randn(N, Cl, d, h_, w_).to(dt).float()
+    hid = torch.randn(N, 24, 2 * d, 2 * h_, 2 * w_).to(dt).float()   # hidden activations on the padded grid
+    skip = torch.randn(N, Cu, 2 * d, 2 * h_, 2 * w_).to(dt).float()
+    w3, b3 = torch.randn(Cu, 24, 1, 1, 1) / 5, torch.randn(Cu)
+    wr, br = torch.randn(Cl, Cu, 1, 1, 1) / 6, torch.randn(Cu)      # ConvTranspose3d layout (C_in, C_out)
+    mlp = F.conv3d(hid[:, :, 1:, 1:, 1:], w3.to(dt).float(), b3)
+    res = F.conv_transpose3d(xl, wr.to(dt).float(), br, stride=2)
+    ref = F.pad(mlp, (1, 0, 1, 0, 1, 0)) + F.pad(res, (1, 0, 1, 0, 1, 0)) + skip
+    res_low = ops.pw_conv(_cl(xl).to(dev).to(dt), ops.pw_pack_weight(wr.reshape(Cl, Cu).to(dev), dt, transposed=True),
+                          br.to(dev), N=N, rows_per_sample=d * h_ * w_, c_in=Cl, c_out=Cu, out_dtype=dt)
+    rows = 8 * d * h_ * w_
+    y = ops.pw_conv(_cl(hid).to(dev).to(dt), ops.pw_pack_weight(w3.reshape(Cu, 24).to(dev), dt), b3.to(dev), N=N,
+                    rows_per_sample=rows, c_in=24, c_out=Cu, out_dtype=dt, res=_cl(skip).to(dev).to(dt),
+                    res_mode=nat.RES_UPSAMPLE, grid=(2 * d, 2 * h_, 2 * w_), res_low=res_low, res_bias=br.to(dev))
+    tol = dict(TOL[dt])
+    if dt == torch.bfloat16:
+        tol = dict(rtol=3e-2, atol=5e-2)   # res_low is itself rounded to bf16
+    torch.testing.assert_close(_cf(y.view(N, 2 * d, 2 * h_, 2 * w_, Cu).float().cpu()), ref, **tol)
