@@ -1,0 +1,171 @@
+"""bench.py -- headline benchmark of the MI355X engine for the PyTorch Connectomics hot path.
+
+Metric (BASELINE.json): voxels/s, MedNeXt-S 112^3 bf16.  A "step" is one sliding-window batch of the
+Lucchi++ inference workload (configs[1]): gather `sw_batch_size`=8 windows of 112^3 from the HBM-resident
+165x1024x768 volume -> MedNeXt-S forward (bf16 storage, fp32 accumulation) -> bump-weighted overlap-add
+into the HBM-resident accumulators.  value = window-voxels/s of the whole job (all ranks).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: the path shards by independent volumes (the reference's volume-per-rank sharding,
+training/lightning/data.py:234-266): every rank owns one volume, no data-path collective -> weak scaling.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+ROI = (112, 112, 112)
+VOLUME = (165, 1024, 768)          # Lucchi++ test volume (tutorials/mito_lucchi++/README.md:114)
+SW_BATCH = 8
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def build_model(device):
+    from types import SimpleNamespace as NS
+    from pytorch_connectomics_amd.models import build_model as bm
+    cfg = NS(model=NS(arch=NS(type="mednext"), in_channels=1, out_channels=1,
+                      mednext=NS(size="S", kernel_size=3), loss=NS(deep_supervision=False), heads=None))
+    torch.manual_seed(0)
+    model = bm(cfg).to(device).eval()
+    model.model.compute_dtype = torch.bfloat16
+    return model
+
+
+def cpu_baseline(model, seconds_cap: float = 40.0):
+    """Oracle (CPU restatement, kind='port') timed on the host cores on ONE 112^3 window (or a 64^3 one
+    on small hosts); same weights, fp32."""
+    from oracle import mednext_oracle as MO
+    st = {k: v.detach().float().cpu() for k, v in model.model.state_dict().items()}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    kw = dict(n_channels=32, exp_r=2, kernel_size=3, block_counts=[2] * 9)
+    with torch.no_grad():
+        x = torch.rand(1, 1, 32, 32, 32)
+        t0 = time.perf_counter(); MO.forward(st, x, **kw); t_small = time.perf_counter() - t0
+        t0 = time.perf_counter(); MO.forward(st, x, **kw); t_small = min(t_small, time.perf_counter() - t0)
+        # predicted time for 112^3 ~ t_small * (112/32)^3
+        side = 112 if t_small * (112 / 32) ** 3 < seconds_cap else 64
+        x = torch.rand(1, 1, side, side, side)
+        t0 = time.perf_counter(); MO.forward(st, x, **kw); dt = time.perf_counter() - t0
+    return {"value": side ** 3 / dt, "unit": "voxels/s", "cores": cores, "kind": "port",
+            "sample": f"oracle MedNeXt-S fp32 forward of one {side}^3 window ({dt:.2f} s), torch CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from pytorch_connectomics_amd import _native as nat
+    from pytorch_connectomics_amd import hip_ops as ops
+    from pytorch_connectomics_amd.inference.window import EagerSlidingWindowEngine
+
+    model = build_model(dev)
+    eng = EagerSlidingWindowEngine(roi_size=ROI, sw_batch_size=SW_BATCH, overlap=0.5, mode="bump",
+                                   padding_mode="constant", cval=0.0)
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
+    vol = torch.rand((1,) + VOLUME, device=dev, generator=g)            # resident in HBM before timing
+    image_size, starts = eng.plan(VOLUME)
+    (wz, wy, wx), combine = eng._axis_vectors(dev)
+    value = torch.zeros((1,) + image_size, device=dev)
+    weight = torch.zeros(image_size, device=dev)
+    batches = [starts[i:i + SW_BATCH] for i in range(0, len(starts) - SW_BATCH + 1, SW_BATCH)]
+
+    def step(i):
+        b = batches[i % len(batches)]
+        x = ops.gather_windows(vol, b, ROI, pad_mode="constant", cval=0.0)
+        y = model.forward_cl(x)
+        ops.blend_accumulate(y, b, value, weight, wz, wy, wx, combine=combine, floor_w=1e-5)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        barrier()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    vox_per_step = SW_BATCH * ROI[0] * ROI[1] * ROI[2]
+    value_vps = world * vox_per_step * args.steps / dt
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        with torch.no_grad(), ops.profiled() as prof:
+            for i in range(min(args.steps, 5)):
+                step(i)
+        summ = prof.summary()
+        name, rec = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        per_launch_bytes = rec["bytes"] / rec["launches"]
+        per_launch_s = rec["ms"] / rec["launches"] / 1e3
+        achieved = per_launch_bytes / per_launch_s / 1e9
+        roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launch_us": round(per_launch_s * 1e6, 1), "algorithmic_bytes": int(per_launch_bytes),
+                    "share_of_step": round(rec["ms"] / sum(r["ms"] for r in summ.values()), 3),
+                    "kernels_ms_per_step": {k: round(v["ms"] / min(args.steps, 5), 3) for k, v in
+                                            sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(model)
+
+    if rank == 0:
+        out = {
+            "metric": "voxels/s (train + sliding-window infer), MedNeXt-S 112^3 bf16",
+            "value": value_vps, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Lucchi++ sliding-window inference (configs[1]): MedNeXt-S k3, "
+                                   "165x1024x768 volume, roi 112^3, overlap 0.5, bump blending, "
+                                   "sw_batch_size 8, random-init weights; value = window-voxels/s",
+                       "volume": list(VOLUME), "roi": list(ROI), "sw_batch_size": SW_BATCH,
+                       "sharding": "one independent volume per rank, no collective"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -102,8 +102,9 @@ int pytc_ensemble_update(float* acc, const float* x, int64_t n, int mode, int co
 /* ---------------------------------------------------------------- depthwise conv ---------- */
 
 /* number of per-sample partial-statistics slots pytc_dwconv3d_fwd / pytc_dwconvT3d_fwd write for
- * this problem (INPUT dims); -1 when the channel count is unsupported */
-int pytc_dwconv3d_stat_slots(int D, int H, int W, int C, int K, int stride, int dtype, int transposed);
+ * this problem (batch N, INPUT dims); -1 when the channel count is unsupported */
+int pytc_dwconv3d_stat_slots(int N, int D, int H, int W, int C, int K, int stride, int dtype,
+                             int transposed);
 
 /* Depthwise Conv3d (groups == C), kernel K^3 (3/5/7), padding K/2, stride 1 or 2, fused with the
  * per-(n,c) sum / sum-of-squares of the OUTPUT that the following GroupNorm(C,C) needs.
@@ -168,6 +169,37 @@ typedef struct {
 } pytc_pw_args;
 
 int pytc_pw_conv_fwd(const pytc_pw_args* a, void* stream);
+
+/* Fused MedNeXt channel mixer (bf16 activations):
+ *     y = W3 * gelu( W2 * (a*t + b) + b2 ) + b3   (+ residual per res_mode, as in pytc_pw_conv_fwd)
+ * One launch for norm-apply, conv2, GELU, conv3 and the residual add of a MedNeXt block / down block /
+ * up block; the expanded tensor stays in registers.  Replaces MedNeXtBlock.{norm (apply), conv2, act,
+ * conv3} + the block residual (external nnunet_mednext; contract at mednext_models.py:104-126).
+ * Weights must be packed with pytc_pw_pack_weight_paired (bf16).  Supported channel triples are
+ * reported by pytc_pw_mlp_supported (multiples of 32 that occur in MedNeXt with 32 base channels);
+ * other shapes go through two pytc_pw_conv_fwd calls. */
+typedef struct {
+  const void* t;          /* [N][rows][C_in] bf16: depthwise-conv output */
+  const float* ab;        /* [N][2][C_in] GroupNorm affine from pytc_groupnorm_finalize */
+  const void* w2_packed;  /* expand  C_in  -> C_hid */
+  const float* b2;        /* [C_hid] */
+  const void* w3_packed;  /* project C_hid -> C_out */
+  const float* b3;        /* [C_out] */
+  const void* res;        /* see PYTC_RES_* */
+  const void* res_low;
+  const float* res_bias;
+  void* y;                /* [N][rows][C_out] bf16 */
+  int N;
+  int64_t rows_per_sample;
+  int C_in, C_hid, C_out;
+  int res_mode;
+  int Di, Hi, Wi;         /* RES_UPSAMPLE: output grid */
+} pytc_mlp_args;
+
+int pytc_pw_mlp_supported(int C_in, int C_hid, int C_out);
+int pytc_pw_pack_weight_paired(const float* w, int C_out, int C_in, int transposed, void* packed_bf16,
+                               void* stream);
+int pytc_pw_mlp_fwd(const pytc_mlp_args* a, void* stream);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,17 @@ class PwArgs(C.Structure):
     ]
 
 
+class MlpArgs(C.Structure):
+    _fields_ = [
+        ("t", C.c_void_p), ("ab", C.c_void_p), ("w2_packed", C.c_void_p), ("b2", C.c_void_p),
+        ("w3_packed", C.c_void_p), ("b3", C.c_void_p), ("res", C.c_void_p), ("res_low", C.c_void_p),
+        ("res_bias", C.c_void_p), ("y", C.c_void_p),
+        ("N", C.c_int), ("rows_per_sample", C.c_int64),
+        ("C_in", C.c_int), ("C_hid", C.c_int), ("C_out", C.c_int), ("res_mode", C.c_int),
+        ("Di", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int),
+    ]
+
+
 _SIGS = {
     "pytc_abi_version": (C.c_int, []),
     "pytc_last_error": (C.c_char_p, []),
@@ -46,7 +57,7 @@ _SIGS = {
                                         C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pytc_blend_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "pytc_ensemble_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
-    "pytc_dwconv3d_stat_slots": (C.c_int, [C.c_int] * 8),
+    "pytc_dwconv3d_stat_slots": (C.c_int, [C.c_int] * 9),
     "pytc_dwconv3d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8
                           + [C.c_void_p]),
     "pytc_dwconvT3d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7
@@ -56,6 +67,9 @@ _SIGS = {
     "pytc_pw_packed_elems": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "pytc_pw_pack_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "pytc_pw_conv_fwd": (C.c_int, [C.POINTER(PwArgs), C.c_void_p]),
+    "pytc_pw_mlp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "pytc_pw_pack_weight_paired": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pytc_pw_mlp_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p]),
 }
 
 _lib = None

@@ -162,6 +162,230 @@ dwconvT3d_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __rest
   if (stats) block_stats_reduce<VEC>(s1, s2, cv, vslot, lane_ok, g, stats, n, slot, lds);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fast path: K = 3, stride 1 -- "z-march".  One workgroup owns an 8 x 8 (y,x) footprint of a 32-channel
+// group and marches along z.  Per step ONE haloed input plane (10 x 10 x 32 ch) is staged in LDS as fp32
+// (converted once, double buffered, loads for plane z+1 in flight while plane z is consumed); each thread
+// owns (position, 4 channels) for 2 positions, keeps its 27 x 4 weights in registers and carries the z
+// extent of the stencil in three rolling fp32 accumulators (outputs z-1, z, z+1), so
+//   * every LDS value (ds_read_b128, lanes contiguous -> conflict free) feeds 3 FMAs per channel,
+//   * the inner loop is FMAs only (no bf16 unpacking), 27 per output channel-voxel,
+//   * HBM sees x once (+ the y/x halo, mostly L2 hits) and y once.
+// Statistics (sum / sum of squares of the stored values) leave as one partial per workgroup.
+constexpr int TILE_Y = 8, TILE_X = 8;
+constexpr int MARCH_CG = 32;
+
+struct DwMarch {
+  int N, D, H, W, C;
+  int ty, tx, zc, nzc;   // footprints per axis, z-chunk length, z-chunks
+  int slots;             // workgroups per (sample, channel group)
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2)
+dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ w,
+                         const float* __restrict__ bias, float* __restrict__ stats, DwMarch g) {
+  constexpr int CG = MARCH_CG, VEC = 4, LPV = CG / VEC, PPP = 256 / LPV, PASSES = (TILE_Y * TILE_X) / PPP;
+  constexpr int EY = TILE_Y + 2, EX = TILE_X + 2;
+  constexpr int EPC = 16 / (int)sizeof(T);          // elements per 16-byte chunk
+  constexpr int CH16 = CG / EPC;                    // chunks per voxel
+  constexpr int NCHUNK = EY * EX * CH16;            // chunks per plane
+  constexpr int CPT = (NCHUNK + 255) / 256;         // chunks per thread
+  __shared__ __attribute__((aligned(16))) float plane[2][EY * EX * CG];
+  __shared__ float red[4][2][CG];
+
+  const int tid = threadIdx.x;
+  const int n = blockIdx.z, cg = blockIdx.y;
+  int b = blockIdx.x;
+  const int fx = b % g.tx; b /= g.tx;
+  const int fy = b % g.ty;
+  const int zchunk = b / g.ty;
+  const int y0 = fy * TILE_Y, x0 = fx * TILE_X;
+  const int zs = zchunk * g.zc;
+  const int ze = min(zs + g.zc, g.D);               // outputs [zs, ze)
+  const int C = g.C;
+  const long plane_elems = (long)g.H * g.W * C;
+  const T* xn = x + (long)n * g.D * plane_elems + cg * CG;
+  T* yn = y + (long)n * g.D * plane_elems + cg * CG;
+
+  // ---- staging descriptors (constant along z)
+  int goff[CPT], loff[CPT];
+  bool cok[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = tid + 256 * i;
+    const int vox = c / CH16, part = c % CH16;
+    const int yy = vox / EX, xx = vox % EX;
+    const int gy = y0 - 1 + yy, gx = x0 - 1 + xx;
+    cok[i] = (c < NCHUNK) && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
+    goff[i] = (gy * g.W + gx) * C + part * EPC;
+    loff[i] = (c < NCHUNK) ? vox * CG + part * EPC : -1;
+  }
+  uint4 stg[CPT];
+  auto issue = [&](int gz) {
+    const bool zok = gz >= 0 && gz < g.D;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      stg[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (zok && cok[i]) stg[i] = *reinterpret_cast<const uint4*>(xn + (long)gz * plane_elems + goff[i]);
+    }
+  };
+  auto commit = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      if (loff[i] < 0) continue;
+      float v[EPC];
+      VecIO<T, EPC>::load(reinterpret_cast<const T*>(&stg[i]), v);
+      float* dst = &plane[slot][loff[i]];
+#pragma unroll
+      for (int q = 0; q < EPC; q += 4)
+        *reinterpret_cast<f32x4_t*>(dst + q) = f32x4_t{v[q], v[q + 1], v[q + 2], v[q + 3]};
+    }
+  };
+
+  // ---- per-thread weights (27 taps x 4 channels), bias, positions
+  const int cv = tid % LPV, pslot = tid / LPV;
+  const int c0 = cg * CG + cv * VEC;
+  float wr[27][VEC];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) VecIO<float, VEC>::load(w + (long)t * C + c0, wr[t]);
+  float bv[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) bv[i] = bias ? bias[c0 + i] : 0.f;
+  int lbase[PASSES];
+  long obase[PASSES];
+  bool pok[PASSES];
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int pos = ps * PPP + pslot;
+    const int py = pos / TILE_X, px = pos % TILE_X;
+    lbase[ps] = (py * EX + px) * CG + cv * VEC;
+    pok[ps] = (y0 + py) < g.H && (x0 + px) < g.W;
+    obase[ps] = ((long)(y0 + py) * g.W + (x0 + px)) * C + cv * VEC;
+  }
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+
+  float accA[PASSES][VEC], accB[PASSES][VEC], accC[PASSES][VEC];
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { accA[ps][i] = bv[i]; accB[ps][i] = bv[i]; accC[ps][i] = bv[i]; }
+
+  // one z step: input plane gz lives in plane[slot]; prev/cur/next = outputs gz-1 / gz / gz+1
+  auto step = [&](int gz, int slot, float (&prev)[PASSES][VEC], float (&cur)[PASSES][VEC],
+                  float (&next)[PASSES][VEC]) {
+    const bool more = gz + 1 <= ze;
+    if (more) issue(gz + 1);
+    if (gz >= 0 && gz < g.D) {
+      const bool vprev = gz - 1 >= zs, vcur = gz >= zs && gz < ze, vnext = gz + 1 < ze;
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(&plane[slot][lbase[ps] + (dy * EX + dx) * CG]);
+            if (vnext) {
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) next[ps][i] = fmaf(v[i], wr[(0 * 3 + dy) * 3 + dx][i], next[ps][i]);
+            }
+            if (vcur) {
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) cur[ps][i] = fmaf(v[i], wr[(1 * 3 + dy) * 3 + dx][i], cur[ps][i]);
+            }
+            if (vprev) {
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) prev[ps][i] = fmaf(v[i], wr[(2 * 3 + dy) * 3 + dx][i], prev[ps][i]);
+            }
+          }
+        }
+      }
+    }
+    if (gz - 1 >= zs) {   // output plane gz-1 is complete
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        if (pok[ps]) {
+          VecIO<T, VEC>::store(yn + (long)(gz - 1) * plane_elems + obase[ps], prev[ps]);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            const float r = to_f32<T>(from_f32<T>(prev[ps][i]));
+            s1[i] += r;
+            s2[i] = fmaf(r, r, s2[i]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) prev[ps][i] = bv[i];
+    if (more) commit(slot ^ 1);
+    __syncthreads();
+  };
+
+  issue(zs - 1);
+  commit(0);
+  __syncthreads();
+  int slot = 0;
+  for (int gz = zs - 1; gz <= ze; gz += 3) {
+    step(gz, slot, accA, accB, accC);
+    slot ^= 1;
+    if (gz + 1 <= ze) { step(gz + 1, slot, accB, accC, accA); slot ^= 1; }
+    if (gz + 2 <= ze) { step(gz + 2, slot, accC, accA, accB); slot ^= 1; }
+  }
+
+  if (stats) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+#pragma unroll
+      for (int off = LPV; off < 64; off <<= 1) {
+        s1[i] += __shfl_xor(s1[i], off, 64);
+        s2[i] += __shfl_xor(s2[i], off, 64);
+      }
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane < LPV) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        red[wave][0][lane * VEC + i] = s1[i];
+        red[wave][1][lane * VEC + i] = s2[i];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * CG) {
+      const int which = tid / CG, ch = tid % CG;
+      float a = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) a += red[wv][which][ch];
+      stats[(((long)n * g.slots + blockIdx.x) * 2 + which) * C + cg * CG + ch] = a;
+    }
+  }
+}
+
+static bool march_ok(int D, int H, int W, int C, int K, int stride, int dtype, int transposed) {
+  if (transposed || K != 3 || stride != 1) return false;
+  if (C % MARCH_CG) return false;
+  return D >= 8 && H >= 16 && W >= 16 && (long)H * W * C < (1L << 30);
+}
+
+static void make_march(DwMarch& t, int N, int D, int H, int W, int C) {
+  t.N = N; t.D = D; t.H = H; t.W = W; t.C = C;
+  t.ty = (H + TILE_Y - 1) / TILE_Y; t.tx = (W + TILE_X - 1) / TILE_X;
+  // z-chunks: enough workgroups to fill 256 CUs x 2 several times over, chunks >= 14 planes (halo <= 14 %)
+  const long fp = (long)t.ty * t.tx * (C / MARCH_CG) * N;
+  int nzc = (int)((8L * 512 + fp - 1) / fp);
+  if (nzc < 1) nzc = 1;
+  int maxc = D / 14;
+  if (maxc < 1) maxc = 1;
+  if (nzc > maxc) nzc = maxc;
+  t.zc = (D + nzc - 1) / nzc;
+  t.nzc = (D + t.zc - 1) / t.zc;
+  t.slots = t.ty * t.tx * t.nzc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // stats [N][slots][2][C] -> ab [N][2][C]   (a = gamma*rstd, b = beta - mean*a)
 constexpr int FIN_CH = 16, FIN_SL = 16;
@@ -269,6 +493,19 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
   PYTC_REQUIRE(N >= 1 && D >= 1 && H >= 1 && W >= 1 && C >= 1, "dwconv3d: bad shape");
   PYTC_REQUIRE(stride == 1 || stride == 2, "dwconv3d: stride must be 1 or 2");
   PYTC_REQUIRE(dtype == PYTC_F32 || dtype == PYTC_BF16, "dwconv3d: bad dtype");
+  if (march_ok(D, H, W, C, K, stride, dtype, transposed)) {
+    DwMarch t;
+    make_march(t, N, D, H, W, C);
+    dim3 grid(t.slots, C / MARCH_CG, N), block(256);
+    if (dtype == PYTC_BF16)
+      hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream,
+                         (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t);
+    else
+      hipLaunchKernelGGL((dwconv3d_k3_march_kernel<float>), grid, block, 0, (hipStream_t)stream,
+                         (const float*)x, (float*)y, w, bias, stats, t);
+    PYTC_LAUNCH_CHECK("dwconv3d_k3_march");
+    return PYTC_OK;
+  }
   DwGeom g;
   int vec;
   if (!make_geom(g, N, D, H, W, C, K, stride, dtype, transposed, vec)) {
@@ -287,10 +524,16 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
 
 using namespace pytc;
 
-extern "C" int pytc_dwconv3d_stat_slots(int D, int H, int W, int C, int K, int stride, int dtype, int transposed) {
+extern "C" int pytc_dwconv3d_stat_slots(int N, int D, int H, int W, int C, int K, int stride, int dtype,
+                                        int transposed) {
+  if (march_ok(D, H, W, C, K, stride, dtype, transposed)) {
+    DwMarch t;
+    make_march(t, N, D, H, W, C);
+    return t.slots;
+  }
   DwGeom g;
   int vec;
-  if (!make_geom(g, 1, D, H, W, C, K, stride, dtype, transposed, vec)) return -1;
+  if (!make_geom(g, N, D, H, W, C, K, stride, dtype, transposed, vec)) return -1;
   return g.slots;
 }
 

@@ -1,0 +1,131 @@
+// Shared pieces of the pointwise (1x1x1) MFMA kernels: operand traits and the residual/store epilogue.
+#pragma once
+#include "pytc_common.h"
+
+namespace pytc {
+
+template <typename TW>
+struct Mma;
+
+template <>
+struct Mma<bf16_t> {
+  static constexpr int EPL = 8;     // fragment elements per lane
+  static constexpr int KSTEP = 32;  // k covered by one fragment set
+  typedef bf16x8_t frag_t;
+  static __device__ __forceinline__ f32x4_t mma(frag_t a, frag_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ frag_t from_floats(const float (&v)[8]) {
+    f32x8_t f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = v[i];
+    return __builtin_convertvector(f, frag_t);
+  }
+};
+
+template <>
+struct Mma<float> {
+  static constexpr int EPL = 4;
+  static constexpr int KSTEP = 16;
+  typedef f32x4_t frag_t;
+  static __device__ __forceinline__ f32x4_t mma(frag_t a, frag_t b, f32x4_t c) {
+    // logical k of (step s, lane group kb) = kb*4 + s : any bijection works as long as A and B agree
+#pragma unroll
+    for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], c, 0, 0, 0);
+    return c;
+  }
+  static __device__ __forceinline__ frag_t from_floats(const float (&v)[4]) {
+    frag_t f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = v[i];
+    return f;
+  }
+};
+
+// Row permutation used by the "paired" packing: two consecutive 16-row tiles (T = 2p, 2p+1) are
+// interleaved so that the MFMA C/D layout (lane group kb owns rows 4kb..4kb+3 of each tile) leaves
+// every lane with 8 CONSECUTIVE logical rows p*32 + kb*8 + 0..7:
+//     logical(T, m) = (T>>1)*32 + (m>>2)*8 + (T&1)*4 + (m&3)
+// -> 16-byte NDHWC stores / residual loads, 8 consecutive biases, and a GEMM1 accumulator that IS the
+//    natural-k-order B operand of GEMM2 (no cross-lane movement between the two GEMMs).
+__host__ __device__ __forceinline__ int paired_row(int T, int m) {
+  return (T >> 1) * 32 + (m >> 2) * 8 + (T & 1) * 4 + (m & 3);
+}
+
+struct EpiParams {
+  const void* res;        // RES_ADD: residual [rows][C_out]; RES_UPSAMPLE: encoder skip [rows][C_out]
+  const void* res_low;    // RES_UPSAMPLE: low-res transposed-1x1 residual (bias included)
+  const float* res_bias;  // RES_UPSAMPLE: bias of that residual conv (value in the stride holes)
+  void* y;
+  long rps_out;           // output rows per sample
+  int C_out;
+  int res_mode;
+  int Go_d, Go_h, Go_w;   // RES_UPSAMPLE: output grid
+  int Gl_d, Gl_h, Gl_w;   // RES_UPSAMPLE: low-res grid
+};
+
+// v[NCH] = conv result (+bias, activation) for channels o0..o0+NCH-1 of output row `orow` of sample n.
+template <typename TO, int NCH>
+__device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParams& e, int n, long orow, int o0) {
+  TO* yn = reinterpret_cast<TO*>(e.y) + (long)n * e.rps_out * e.C_out;
+  const TO* resn = e.res ? reinterpret_cast<const TO*>(e.res) + (long)n * e.rps_out * e.C_out : nullptr;
+  const long off = orow * e.C_out + o0;
+  const bool full = (e.C_out % NCH) == 0 && (o0 + NCH <= e.C_out);
+  if (e.res_mode == PYTC_RES_ADD) {
+    float rv[NCH];
+    if (full) VecIO<TO, NCH>::load(resn + off, rv);
+    else {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) rv[i] = (o0 + i < e.C_out) ? to_f32<TO>(resn[off + i]) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) v[i] += rv[i];
+  } else if (e.res_mode == PYTC_RES_UPSAMPLE) {
+    int px = (int)(orow % e.Go_w);
+    long t = orow / e.Go_w;
+    int py = (int)(t % e.Go_h);
+    int pz = (int)(t / e.Go_h);
+    float sk[NCH];
+    if (full) VecIO<TO, NCH>::load(resn + off, sk);
+    else {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) sk[i] = (o0 + i < e.C_out) ? to_f32<TO>(resn[off + i]) : 0.f;
+    }
+    if (px == 0 || py == 0 || pz == 0) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) v[i] = sk[i];
+    } else {
+      const int oz = pz - 1, oy = py - 1, ox = px - 1;
+      float rl[NCH];
+      if (e.res_low && !((oz | oy | ox) & 1)) {
+        const TO* rp = reinterpret_cast<const TO*>(e.res_low) +
+                       ((((long)n * e.Gl_d + (oz >> 1)) * e.Gl_h + (oy >> 1)) * e.Gl_w + (ox >> 1)) * e.C_out + o0;
+        if (full) VecIO<TO, NCH>::load(rp, rl);
+        else {
+#pragma unroll
+          for (int i = 0; i < NCH; ++i) rl[i] = (o0 + i < e.C_out) ? to_f32<TO>(rp[i]) : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) rl[i] = (e.res_bias && o0 + i < e.C_out) ? e.res_bias[o0 + i] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) v[i] = v[i] + rl[i] + sk[i];
+    }
+  }
+  if (full) VecIO<TO, NCH>::store(yn + off, v);
+  else {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (o0 + i < e.C_out) yn[off + i] = from_f32<TO>(v[i]);
+  }
+}
+
+__device__ __forceinline__ float apply_act(float t, int act) {
+  if (act == PYTC_ACT_GELU) return gelu_erf(t);
+  if (act == PYTC_ACT_SIGMOID) return 1.f / (1.f + __expf(-t));
+  if (act == PYTC_ACT_TANH) return tanhf(t);
+  return t;
+}
+
+}  // namespace pytc

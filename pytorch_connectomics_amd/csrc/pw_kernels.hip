@@ -8,62 +8,21 @@
 //     4 consecutive output channels of one voxel per lane = one 8/16-byte NDHWC store.
 // bf16 uses v_mfma_f32_16x16x32_bf16, fp32 uses 4x v_mfma_f32_16x16x4_f32 per 16-wide k-group
 // (exact fp32, used for the tight parity gate).
-#include "pytc_common.h"
+#include "pw_common.h"
 
 namespace pytc {
-
-template <typename TW>
-struct Mma;
-
-template <>
-struct Mma<bf16_t> {
-  static constexpr int EPL = 8;     // fragment elements per lane
-  static constexpr int KSTEP = 32;  // k covered by one fragment set
-  typedef bf16x8_t frag_t;
-  static __device__ __forceinline__ f32x4_t mma(frag_t a, frag_t b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ frag_t from_floats(const float (&v)[8]) {
-    f32x8_t f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = v[i];
-    return __builtin_convertvector(f, frag_t);
-  }
-};
-
-template <>
-struct Mma<float> {
-  static constexpr int EPL = 4;
-  static constexpr int KSTEP = 16;
-  typedef f32x4_t frag_t;
-  static __device__ __forceinline__ f32x4_t mma(frag_t a, frag_t b, f32x4_t c) {
-    // logical k of (step s, lane group kb) = kb*4 + s : any bijection works as long as A and B agree
-#pragma unroll
-    for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], c, 0, 0, 0);
-    return c;
-  }
-  static __device__ __forceinline__ frag_t from_floats(const float (&v)[4]) {
-    frag_t f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = v[i];
-    return f;
-  }
-};
 
 struct PwParams {
   const void* x;
   const void* wp;
   const float* bias;
   const float* ab;
-  const void* res;
-  const void* res_low;
-  const float* res_bias;
-  void* y;
+  EpiParams e;
   long rps_out, rps_in;  // rows per sample
   int N, C_in, C_out, KG, MTt;
-  int act, res_mode, gather;
-  int Di, Hi, Wi;        // gather==2: input grid ; RES_UPSAMPLE: OUTPUT grid
-  int Do, Ho, Wo;        // gather==2: output grid ; RES_UPSAMPLE: low-res grid
+  int act, gather;
+  int Di, Hi, Wi;        // gather==2: input grid
+  int Do, Ho, Wo;        // gather==2: output grid
 };
 
 template <typename TI, int EPL>
@@ -157,9 +116,6 @@ pw_conv_kernel(PwParams p) {
   }
 
   // ---- epilogue: lane holds channels o0..o0+3 of voxel orow[nt]
-  TO* yn = reinterpret_cast<TO*>(p.y) + (long)n * p.rps_out * p.C_out;
-  const TO* resn = p.res ? reinterpret_cast<const TO*>(p.res) + (long)n * p.rps_out * p.C_out : nullptr;
-  const bool ovec = (p.C_out % 4) == 0;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int o0 = (mt0 + mt) * 16 + kb * 4;
@@ -172,63 +128,8 @@ pw_conv_kernel(PwParams p) {
       if (orow[nt] >= p.rps_out) continue;
       float v[4];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        float t = acc[mt][nt][rr] + bo[rr];
-        if (p.act == PYTC_ACT_GELU) t = gelu_erf(t);
-        else if (p.act == PYTC_ACT_SIGMOID) t = 1.f / (1.f + expf(-t));
-        else if (p.act == PYTC_ACT_TANH) t = tanhf(t);
-        v[rr] = t;
-      }
-      const long off = orow[nt] * p.C_out + o0;
-      const bool full = ovec && (o0 + 4 <= p.C_out);
-      if (p.res_mode == PYTC_RES_ADD) {
-        float rv[4];
-        if (full) VecIO<TO, 4>::load(resn + off, rv);
-        else {
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) rv[rr] = (o0 + rr < p.C_out) ? to_f32<TO>(resn[off + rr]) : 0.f;
-        }
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) v[rr] += rv[rr];
-      } else if (p.res_mode == PYTC_RES_UPSAMPLE) {
-        // output grid (Di,Hi,Wi); low-res grid (Do,Ho,Wo); see MedNeXtUpBlock restatement
-        int px = (int)(orow[nt] % p.Wi);
-        long t = orow[nt] / p.Wi;
-        int py = (int)(t % p.Hi);
-        int pz = (int)(t / p.Hi);
-        float sk[4];
-        if (full) VecIO<TO, 4>::load(resn + off, sk);
-        else {
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) sk[rr] = (o0 + rr < p.C_out) ? to_f32<TO>(resn[off + rr]) : 0.f;
-        }
-        if (px == 0 || py == 0 || pz == 0) {
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) v[rr] = sk[rr];
-        } else {
-          int oz = pz - 1, oy = py - 1, ox = px - 1;
-          float rl[4];
-          if (p.res_low && !((oz | oy | ox) & 1)) {
-            const TO* rp = reinterpret_cast<const TO*>(p.res_low) +
-                           (((long)n * p.Do + (oz >> 1)) * p.Ho + (oy >> 1)) * (long)p.Wo * p.C_out +
-                           (long)(ox >> 1) * p.C_out + o0;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) rl[rr] = (o0 + rr < p.C_out) ? to_f32<TO>(rp[rr]) : 0.f;
-          } else {
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-              rl[rr] = (p.res_bias && o0 + rr < p.C_out) ? p.res_bias[o0 + rr] : 0.f;
-          }
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) v[rr] = v[rr] + rl[rr] + sk[rr];
-        }
-      }
-      if (full) VecIO<TO, 4>::store(yn + off, v);
-      else {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-          if (o0 + rr < p.C_out) yn[off + rr] = from_f32<TO>(v[rr]);
-      }
+      for (int rr = 0; rr < 4; ++rr) v[rr] = apply_act(acc[mt][nt][rr] + bo[rr], p.act);
+      finish_and_store<TO, 4>(v, p.e, n, orow[nt], o0);
     }
   }
 }
@@ -301,12 +202,14 @@ extern "C" int pytc_pw_conv_fwd(const pytc_pw_args* a, void* stream) {
   PYTC_REQUIRE(a->w_dtype == PYTC_F32 || a->w_dtype == PYTC_BF16, "pw_conv: bad w_dtype");
   PYTC_REQUIRE(a->res_mode == PYTC_RES_NONE || a->res, "pw_conv: residual mode without residual pointer");
   PwParams p;
-  p.x = a->x; p.wp = a->w_packed; p.bias = a->bias; p.ab = a->ab; p.res = a->res; p.res_low = a->res_low;
-  p.res_bias = a->res_bias; p.y = a->y;
+  p.x = a->x; p.wp = a->w_packed; p.bias = a->bias; p.ab = a->ab;
+  p.e.res = a->res; p.e.res_low = a->res_low; p.e.res_bias = a->res_bias; p.e.y = a->y;
+  p.e.rps_out = a->rows_per_sample; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode;
+  p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
   p.N = a->N; p.C_in = a->C_in; p.C_out = a->C_out;
   p.KG = (a->C_in + kstep_of(a->w_dtype) - 1) / kstep_of(a->w_dtype);
   p.MTt = (a->C_out + 15) / 16;
-  p.act = a->act; p.res_mode = a->res_mode; p.gather = a->gather;
+  p.act = a->act; p.gather = a->gather;
   p.rps_out = a->rows_per_sample; p.rps_in = a->rows_per_sample;
   p.Di = a->Di; p.Hi = a->Hi; p.Wi = a->Wi; p.Do = p.Ho = p.Wo = 0;
   if (a->gather == 2) {
@@ -321,7 +224,8 @@ extern "C" int pytc_pw_conv_fwd(const pytc_pw_args* a, void* stream) {
     PYTC_REQUIRE(a->gather == 0, "pw_conv: RES_UPSAMPLE cannot be combined with gather");
     PYTC_REQUIRE((long)a->Di * a->Hi * a->Wi == a->rows_per_sample && !(a->Di & 1) && !(a->Hi & 1) && !(a->Wi & 1),
                  "pw_conv: RES_UPSAMPLE needs the (even) output grid");
-    p.Do = a->Di / 2; p.Ho = a->Hi / 2; p.Wo = a->Wi / 2;
+    p.e.Go_d = a->Di; p.e.Go_h = a->Hi; p.e.Go_w = a->Wi;
+    p.e.Gl_d = a->Di / 2; p.e.Gl_h = a->Hi / 2; p.e.Gl_w = a->Wi / 2;
   }
   int MT = p.MTt >= 4 ? 4 : (p.MTt >= 2 ? 2 : 1);
   hipStream_t s = (hipStream_t)stream;

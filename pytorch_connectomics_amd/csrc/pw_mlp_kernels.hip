@@ -1,0 +1,237 @@
+// Fused MedNeXt channel mixer (bf16):   y = W3 * gelu(W2 * (a*t + b) + b2) + b3  (+ residual variants)
+// One launch replaces GroupNorm-apply, 1x1 expand, GELU, 1x1 project and the residual add; the expanded
+// r*C tensor never leaves the registers.
+//
+// Both GEMMs run in the transposed form of pw_kernels.hip (weights = MFMA A operand, voxels = N), so
+//   * the normalised input tile is loaded straight from NDHWC memory into B-operand registers (16 B/lane);
+//   * with the "paired row" weight packing (pw_common.h) the fp32 accumulator of GEMM1, after GELU and a
+//     v_cvt_pk_bf16_f32, IS the B operand of GEMM2 in natural k order -- no LDS, no cross-lane shuffles;
+//   * every lane ends with 8 consecutive output channels of one voxel -> one 16-byte store, and reads its
+//     residual the same way.
+// HBM traffic per voxel = C_in (t) + C_out (residual) + C_out (y) elements: the byte floor of the op.
+#include "pw_common.h"
+
+namespace pytc {
+
+struct MlpParams {
+  const bf16_t* t;
+  const float* ab;
+  const bf16x8_t* w2;
+  const float* b2;
+  const bf16x8_t* w3;
+  const float* b3;
+  EpiParams e;
+  long rps;        // rows per sample (input == output rows)
+  int C_in, C_hid, C_out, HC;   // HC = C_hid / 32
+};
+
+template <int KS_IN, int MO, int NT>
+__global__ void __launch_bounds__(256)
+pw_mlp_kernel(MlpParams p) {
+  static_assert(MO % 2 == 0, "C_out must be a multiple of 32");
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.y;
+  const long row0 = ((long)blockIdx.x * 4 + wave) * (NT * 16);
+  if (row0 >= p.rps) return;
+  const int r = lane & 15, kb = lane >> 4;
+
+  long orow[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) orow[nt] = row0 + nt * 16 + r;
+
+  // ---- B operand of GEMM1: normalised input, 8 consecutive channels per lane per k-step
+  bf16x8_t bact[KS_IN][NT];
+  const bf16_t* tn = p.t + (long)n * p.rps * p.C_in;
+  const float* an = p.ab + (long)n * 2 * p.C_in;
+#pragma unroll
+  for (int ks = 0; ks < KS_IN; ++ks) {
+    const int k0 = ks * 32 + kb * 8;
+    float av[8], bv[8];
+    VecIO<float, 4>::load(an + k0, reinterpret_cast<float(&)[4]>(av[0]));
+    VecIO<float, 4>::load(an + k0 + 4, reinterpret_cast<float(&)[4]>(av[4]));
+    VecIO<float, 4>::load(an + p.C_in + k0, reinterpret_cast<float(&)[4]>(bv[0]));
+    VecIO<float, 4>::load(an + p.C_in + k0 + 4, reinterpret_cast<float(&)[4]>(bv[4]));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const long rr = orow[nt] < p.rps ? orow[nt] : p.rps - 1;
+      float v[8];
+      VecIO<bf16_t, 8>::load(tn + rr * p.C_in + k0, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], av[j], bv[j]);
+      bact[ks][nt] = Mma<bf16_t>::from_floats(v);
+    }
+  }
+
+  // ---- GEMM2 accumulators start from the projection bias (8 consecutive channels per lane per pair)
+  f32x4_t acc2[MO][NT];
+#pragma unroll
+  for (int pr = 0; pr < MO / 2; ++pr) {
+    float b[8];
+    VecIO<float, 4>::load(p.b3 + pr * 32 + kb * 8, reinterpret_cast<float(&)[4]>(b[0]));
+    VecIO<float, 4>::load(p.b3 + pr * 32 + kb * 8 + 4, reinterpret_cast<float(&)[4]>(b[4]));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      acc2[2 * pr][nt] = f32x4_t{b[0], b[1], b[2], b[3]};
+      acc2[2 * pr + 1][nt] = f32x4_t{b[4], b[5], b[6], b[7]};
+    }
+  }
+
+  // ---- loop over hidden chunks of 32 units: GEMM1 -> GELU -> GEMM2, all in registers
+  for (int hc = 0; hc < p.HC; ++hc) {
+    float b2v[8];
+    VecIO<float, 4>::load(p.b2 + hc * 32 + kb * 8, reinterpret_cast<float(&)[4]>(b2v[0]));
+    VecIO<float, 4>::load(p.b2 + hc * 32 + kb * 8 + 4, reinterpret_cast<float(&)[4]>(b2v[4]));
+    f32x4_t acc1[2][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      acc1[0][nt] = f32x4_t{b2v[0], b2v[1], b2v[2], b2v[3]};
+      acc1[1][nt] = f32x4_t{b2v[4], b2v[5], b2v[6], b2v[7]};
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int ks = 0; ks < KS_IN; ++ks) {
+        const bf16x8_t a = p.w2[((long)(hc * 2 + mt) * KS_IN + ks) * 64 + lane];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc1[mt][nt] = Mma<bf16_t>::mma(a, bact[ks][nt], acc1[mt][nt]);
+      }
+    }
+    bf16x8_t bh[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float g[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        g[j] = gelu_erf(acc1[0][nt][j]);
+        g[4 + j] = gelu_erf(acc1[1][nt][j]);
+      }
+      bh[nt] = Mma<bf16_t>::from_floats(g);
+    }
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo) {
+      const bf16x8_t a = p.w3[((long)mo * p.HC + hc) * 64 + lane];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc2[mo][nt] = Mma<bf16_t>::mma(a, bh[nt], acc2[mo][nt]);
+    }
+  }
+
+  // ---- epilogue: 8 consecutive channels per lane per tile pair
+#pragma unroll
+  for (int pr = 0; pr < MO / 2; ++pr) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (orow[nt] >= p.rps) continue;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = acc2[2 * pr][nt][j];
+        v[4 + j] = acc2[2 * pr + 1][nt][j];
+      }
+      finish_and_store<bf16_t, 8>(v, p.e, n, orow[nt], pr * 32 + kb * 8);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+pw_pack_paired_kernel(const float* __restrict__ w, int C_out, int C_in, int transposed,
+                      bf16_t* __restrict__ packed, int KG, long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int j = (int)(i % 8);
+  long t = i / 8;
+  int lane = (int)(t % 64);
+  t /= 64;
+  int kg = (int)(t % KG);
+  int T = (int)(t / KG);
+  int o = paired_row(T, lane & 15);
+  int k = kg * 32 + (lane >> 4) * 8 + j;
+  float v = 0.f;
+  if (o < C_out && k < C_in) v = transposed ? w[(long)k * C_out + o] : w[(long)o * C_in + k];
+  packed[i] = from_f32<bf16_t>(v);
+}
+
+template <int KS_IN, int MO, int NT>
+static void launch_mlp(const MlpParams& p, int N, hipStream_t s) {
+  long rows_per_block = 4L * NT * 16;
+  dim3 grid((unsigned)((p.rps + rows_per_block - 1) / rows_per_block), (unsigned)N), block(256);
+  hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT>), grid, block, 0, s, p);
+}
+
+// (C_in/32, C_out/16) pairs that occur in MedNeXt with 32 base channels: same-res, down (x2), up (/2)
+static bool dispatch_mlp(const MlpParams& p, int N, hipStream_t s) {
+  const int ks = p.C_in / 32, mo = p.C_out / 16;
+#define PYTC_MLP_CASE(KS, MOO, NTT) \
+  if (ks == KS && mo == MOO) { launch_mlp<KS, MOO, NTT>(p, N, s); return true; }
+  PYTC_MLP_CASE(1, 2, 4)
+  PYTC_MLP_CASE(1, 4, 4)
+  PYTC_MLP_CASE(2, 2, 4)
+  PYTC_MLP_CASE(2, 4, 4)
+  PYTC_MLP_CASE(2, 8, 2)
+  PYTC_MLP_CASE(4, 4, 2)
+  PYTC_MLP_CASE(4, 8, 2)
+  PYTC_MLP_CASE(4, 16, 1)
+  PYTC_MLP_CASE(8, 8, 2)
+  PYTC_MLP_CASE(8, 16, 1)
+  PYTC_MLP_CASE(8, 32, 1)
+  PYTC_MLP_CASE(16, 16, 1)
+  PYTC_MLP_CASE(16, 32, 1)
+#undef PYTC_MLP_CASE
+  return false;
+}
+
+static bool mlp_shape_ok(int C_in, int C_hid, int C_out) {
+  if (C_in % 32 || C_hid % 32 || C_out % 32 || C_in < 32 || C_out < 32 || C_hid < 32) return false;
+  const int ks = C_in / 32, mo = C_out / 16;
+  static const int ok[][2] = {{1, 2}, {1, 4}, {2, 2}, {2, 4}, {2, 8}, {4, 4}, {4, 8}, {4, 16}, {8, 8},
+                              {8, 16}, {8, 32}, {16, 16}, {16, 32}};
+  for (auto& c : ok)
+    if (c[0] == ks && c[1] == mo) return true;
+  return false;
+}
+
+}  // namespace pytc
+
+using namespace pytc;
+
+extern "C" int pytc_pw_mlp_supported(int C_in, int C_hid, int C_out) { return mlp_shape_ok(C_in, C_hid, C_out) ? 1 : 0; }
+
+extern "C" int pytc_pw_pack_weight_paired(const float* w, int C_out, int C_in, int transposed, void* packed,
+                                          void* stream) {
+  PYTC_REQUIRE(w && packed && C_out >= 1 && C_in >= 1, "pw_pack_weight_paired: bad arguments");
+  PYTC_REQUIRE(C_out % 32 == 0, "pw_pack_weight_paired: C_out=%d must be a multiple of 32", C_out);
+  long total = pytc_pw_packed_elems(C_out, C_in, PYTC_BF16);
+  int KG = (C_in + 31) / 32;
+  hipLaunchKernelGGL(pw_pack_paired_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w, C_out,
+                     C_in, transposed, (bf16_t*)packed, KG, total);
+  PYTC_LAUNCH_CHECK("pw_pack_weight_paired");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_pw_mlp_fwd(const pytc_mlp_args* a, void* stream) {
+  PYTC_REQUIRE(a && a->t && a->ab && a->w2_packed && a->w3_packed && a->b2 && a->b3 && a->y, "pw_mlp: null pointer");
+  PYTC_REQUIRE(a->N >= 1 && a->rows_per_sample >= 1, "pw_mlp: bad shape");
+  if (!mlp_shape_ok(a->C_in, a->C_hid, a->C_out)) {
+    set_error("pw_mlp: no fused kernel for C_in=%d C_hid=%d C_out=%d", a->C_in, a->C_hid, a->C_out);
+    return PYTC_ERR_UNSUPPORTED;
+  }
+  PYTC_REQUIRE(a->res_mode == PYTC_RES_NONE || a->res, "pw_mlp: residual mode without residual pointer");
+  MlpParams p;
+  p.t = (const bf16_t*)a->t; p.ab = a->ab; p.w2 = (const bf16x8_t*)a->w2_packed; p.b2 = a->b2;
+  p.w3 = (const bf16x8_t*)a->w3_packed; p.b3 = a->b3;
+  p.rps = a->rows_per_sample; p.C_in = a->C_in; p.C_hid = a->C_hid; p.C_out = a->C_out; p.HC = a->C_hid / 32;
+  p.e.res = a->res; p.e.res_low = a->res_low; p.e.res_bias = a->res_bias; p.e.y = a->y;
+  p.e.rps_out = a->rows_per_sample; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode;
+  p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
+  if (a->res_mode == PYTC_RES_UPSAMPLE) {
+    PYTC_REQUIRE((long)a->Di * a->Hi * a->Wi == a->rows_per_sample && !(a->Di & 1) && !(a->Hi & 1) && !(a->Wi & 1),
+                 "pw_mlp: RES_UPSAMPLE needs the (even) output grid");
+    p.e.Go_d = a->Di; p.e.Go_h = a->Hi; p.e.Go_w = a->Wi;
+    p.e.Gl_d = a->Di / 2; p.e.Gl_h = a->Hi / 2; p.e.Gl_w = a->Wi / 2;
+  }
+  if (!dispatch_mlp(p, a->N, (hipStream_t)stream)) {
+    set_error("pw_mlp: dispatch failed");
+    return PYTC_ERR_UNSUPPORTED;
+  }
+  PYTC_LAUNCH_CHECK("pw_mlp");
+  return PYTC_OK;
+}

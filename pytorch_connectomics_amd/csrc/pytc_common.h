@@ -100,9 +100,20 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// exact (erf) GELU, matches torch.nn.functional.gelu(approximate='none')
+// erf GELU (torch.nn.functional.gelu(approximate='none')) with erf from Abramowitz-Stegun 7.1.26
+// (|abs err| <= 1.5e-7), evaluated as 1+erf(z) = p(t)exp(-z^2) for z<0 and 2 - p(t)exp(-z^2) for
+// z>0 so the negative tail has no cancellation.  ~14 VALU + v_rcp_f32 + v_exp_f32, branch free.
 __device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  const float az = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  p *= t;
+  const float pe = p * __builtin_amdgcn_exp2f(-az * az * 1.44269504088896340736f);
+  const float one_plus_erf = x < 0.f ? pe : 2.0f - pe;
+  return 0.5f * x * one_plus_erf;
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -39,6 +39,56 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline leg) -------
+class _Profiler:
+    def __init__(self):
+        self.enabled = False
+        self.records = []   # (name, start_event, end_event, algorithmic_bytes)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, s, e, nbytes in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0})
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["bytes"] += nbytes
+        return out
+
+
+PROFILER = _Profiler()
+
+
+class profiled:
+    """with profiled(): ... -> PROFILER.summary() gives per-kernel launch counts / ms / algorithmic bytes."""
+
+    def __enter__(self):
+        PROFILER.records = []
+        PROFILER.enabled = True
+        return PROFILER
+
+    def __exit__(self, *exc):
+        PROFILER.enabled = False
+        return False
+
+
+def _run(name: str, nbytes: int, fn, *args) -> None:
+    if PROFILER.enabled:
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        st = fn(*args)
+        e.record()
+        PROFILER.records.append((name, s, e, int(nbytes)))
+    else:
+        st = fn(*args)
+    nat.check(st, name)
+
+
+def _nbytes(*ts) -> int:
+    return sum(t.numel() * t.element_size() for t in ts if t is not None)
+
+
 def _starts_array(starts: Sequence[Sequence[int]]):
     flat = [int(v) for s in starts for v in s]
     return (C.c_int32 * len(flat))(*flat)
@@ -61,9 +111,10 @@ def gather_windows(vol: torch.Tensor, starts, roi, *, view: int = 0, pad_mode: s
     for b0 in range(0, B, 64):
         nb = min(64, B - b0)
         sub = (C.c_int32 * (3 * nb)).from_buffer(st, 4 * 3 * b0)
-        nat.check(nat.lib().pytc_gather_windows(_p(vol), Cc, Z, Y, X, sub, nb, rz, ry, rx, int(view),
-                                                nat.PAD_MODES[pad_mode], float(cval), _p(out[b0:b0 + nb]),
-                                                dtype_code(out.dtype), _stream()), "gather_windows")
+        o = out[b0:b0 + nb]
+        _run("gather_windows", 2 * _nbytes(o) if o.dtype == torch.float32 else 3 * _nbytes(o),
+             nat.lib().pytc_gather_windows, _p(vol), Cc, Z, Y, X, sub, nb, rz, ry, rx, int(view),
+             nat.PAD_MODES[pad_mode], float(cval), _p(o), dtype_code(out.dtype), _stream())
     return out
 
 
@@ -77,23 +128,24 @@ def blend_accumulate(pred: torch.Tensor, starts, value: torch.Tensor, weight: Op
         raise ValueError("value accumulator must be float32 (C, Z, Y, X) with C matching pred")
     _, Z, Y, X = value.shape
     st = _starts_array(starts)
-    nat.check(nat.lib().pytc_blend_accumulate(_p(pred), dtype_code(pred.dtype), B, st, rz, ry, rx, Cc, int(view),
-                                              _p(wz), _p(wy), _p(wx), int(combine), float(floor_w), _p(value),
-                                              _p(weight), Z, Y, X, _stream()), "blend_accumulate")
+    win = B * rz * ry * rx
+    _run("blend_accumulate", _nbytes(pred) + win * 4 * (2 * Cc + (2 if weight is not None else 0)),
+         nat.lib().pytc_blend_accumulate, _p(pred), dtype_code(pred.dtype), B, st, rz, ry, rx, Cc, int(view),
+         _p(wz), _p(wy), _p(wx), int(combine), float(floor_w), _p(value), _p(weight), Z, Y, X, _stream())
 
 
 def blend_finalize(value: torch.Tensor, weight: torch.Tensor, *, clamp: float = 1e-4, act: int = nat.ACT_NONE) -> None:
     _dev(value, "value"); _dev(weight, "weight")
     Cc = value.shape[0]
     nvox = weight.numel()
-    nat.check(nat.lib().pytc_blend_finalize(_p(value), _p(weight), Cc, nvox, float(clamp), int(act), _stream()),
-              "blend_finalize")
+    _run("blend_finalize", 2 * _nbytes(value) + _nbytes(weight), nat.lib().pytc_blend_finalize, _p(value),
+         _p(weight), Cc, nvox, float(clamp), int(act), _stream())
 
 
 def ensemble_update(acc: torch.Tensor, x: torch.Tensor, mode: int, count: int) -> None:
     _dev(acc, "acc"); _dev(x, "x")
-    nat.check(nat.lib().pytc_ensemble_update(_p(acc), _p(x), acc.numel(), int(mode), int(count), _stream()),
-              "ensemble_update")
+    _run("ensemble_update", 2 * _nbytes(acc) + _nbytes(x), nat.lib().pytc_ensemble_update, _p(acc), _p(x),
+         acc.numel(), int(mode), int(count), _stream())
 
 
 # ------------------------------------------------------------------ depthwise conv + norm statistics
@@ -112,16 +164,17 @@ def dwconv3d(x: torch.Tensor, w_taps: torch.Tensor, bias: Optional[torch.Tensor]
         y = torch.empty(oshape, dtype=x.dtype, device=x.device)
     st = None
     if stats:
-        slots = nat.lib().pytc_dwconv3d_stat_slots(D, H, W, Cc, K, stride, dt, int(transposed))
+        slots = nat.lib().pytc_dwconv3d_stat_slots(N, D, H, W, Cc, K, stride, dt, int(transposed))
         if slots < 0:
             raise RuntimeError(f"dwconv3d: unsupported channel count {Cc}")
         st = torch.empty((N, slots, 2, Cc), dtype=torch.float32, device=x.device)
+    tag = f"C{Cc}_k{K}" + ("_s2" if stride == 2 and not transposed else "")
     if transposed:
-        nat.check(nat.lib().pytc_dwconvT3d_fwd(_p(x), _p(y), _p(w_taps), _p(bias), _p(st), N, D, H, W, Cc, K, dt,
-                                               _stream()), "dwconvT3d_fwd")
+        _run(f"dwconvT3d_fwd[{tag}]", _nbytes(x, y), nat.lib().pytc_dwconvT3d_fwd, _p(x), _p(y), _p(w_taps), _p(bias),
+             _p(st), N, D, H, W, Cc, K, dt, _stream())
     else:
-        nat.check(nat.lib().pytc_dwconv3d_fwd(_p(x), _p(y), _p(w_taps), _p(bias), _p(st), N, D, H, W, Cc, K, stride,
-                                              dt, _stream()), "dwconv3d_fwd")
+        _run(f"dwconv3d_fwd[{tag}]", _nbytes(x, y), nat.lib().pytc_dwconv3d_fwd, _p(x), _p(y), _p(w_taps), _p(bias),
+             _p(st), N, D, H, W, Cc, K, stride, dt, _stream())
     return y, st
 
 
@@ -129,8 +182,8 @@ def groupnorm_finalize(stats: torch.Tensor, count: float, gamma: Optional[torch.
                        beta: Optional[torch.Tensor], eps: float = 1e-5) -> torch.Tensor:
     N, slots, _, Cc = stats.shape
     ab = torch.empty((N, 2, Cc), dtype=torch.float32, device=stats.device)
-    nat.check(nat.lib().pytc_groupnorm_finalize(_p(stats), slots, float(count), _p(gamma), _p(beta), float(eps),
-                                                _p(ab), N, Cc, _stream()), "groupnorm_finalize")
+    _run("groupnorm_finalize", _nbytes(stats, ab), nat.lib().pytc_groupnorm_finalize, _p(stats), slots, float(count),
+         _p(gamma), _p(beta), float(eps), _p(ab), N, Cc, _stream())
     return ab
 
 
@@ -143,8 +196,8 @@ def pw_pack_weight(w: torch.Tensor, dtype: torch.dtype, *, transposed: bool = Fa
     c_out, c_in = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
     n = nat.lib().pytc_pw_packed_elems(c_out, c_in, dtype_code(dtype))
     packed = torch.empty((n,), dtype=dtype, device=w.device)
-    nat.check(nat.lib().pytc_pw_pack_weight(_p(w), c_out, c_in, int(transposed), _p(packed), dtype_code(dtype),
-                                            _stream()), "pw_pack_weight")
+    _run("pw_pack_weight", _nbytes(w, packed), nat.lib().pytc_pw_pack_weight, _p(w), c_out, c_in, int(transposed),
+         _p(packed), dtype_code(dtype), _stream())
     return packed
 
 
@@ -167,5 +220,49 @@ def pw_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
     a.Di, a.Hi, a.Wi = (int(v) for v in grid)
     a.res_low = res_low.data_ptr() if res_low is not None else None
     a.res_bias = res_bias.data_ptr() if res_bias is not None else None
-    nat.check(nat.lib().pytc_pw_conv_fwd(C.byref(a), _stream()), "pw_conv_fwd")
+    rows_in = N * rows_per_sample * c_in * x.element_size()    # algorithmic: each operand once
+    nb = rows_in + _nbytes(y) + (_nbytes(y) if res is not None else 0)
+    _run(f"pw_conv_fwd[{c_in}->{c_out}]", nb, nat.lib().pytc_pw_conv_fwd, C.byref(a), _stream())
+    return y
+
+
+def pw_mlp_supported(c_in: int, c_hid: int, c_out: int) -> bool:
+    return bool(nat.lib().pytc_pw_mlp_supported(int(c_in), int(c_hid), int(c_out)))
+
+
+def pw_pack_weight_paired(w: torch.Tensor, *, transposed: bool = False) -> torch.Tensor:
+    """bf16 MFMA image with the paired-row permutation expected by pw_mlp (see csrc/pw_common.h)."""
+    _dev(w, "w")
+    if w.dtype != torch.float32 or w.dim() != 2:
+        raise ValueError("pointwise weight must be float32 2-D")
+    c_out, c_in = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+    n = nat.lib().pytc_pw_packed_elems(c_out, c_in, nat.BF16)
+    packed = torch.empty((n,), dtype=torch.bfloat16, device=w.device)
+    _run("pw_pack_weight_paired", _nbytes(w, packed), nat.lib().pytc_pw_pack_weight_paired, _p(w), c_out, c_in,
+         int(transposed), _p(packed), _stream())
+    return packed
+
+
+def pw_mlp(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.Tensor, w3p: torch.Tensor,
+           b3: torch.Tensor, *, N: int, rows_per_sample: int, c_in: int, c_hid: int, c_out: int,
+           res: Optional[torch.Tensor] = None, res_mode: int = nat.RES_NONE, grid: Sequence[int] = (0, 0, 0),
+           res_low: Optional[torch.Tensor] = None, res_bias: Optional[torch.Tensor] = None,
+           y: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused norm-apply -> 1x1 expand -> GELU -> 1x1 project (+residual) on bf16 NDHWC rows."""
+    _dev(t, "t")
+    if t.dtype != torch.bfloat16:
+        raise TypeError("pw_mlp runs on bfloat16 activations")
+    if y is None:
+        y = torch.empty((N, rows_per_sample, c_out), dtype=torch.bfloat16, device=t.device)
+    a = nat.MlpArgs()
+    a.t, a.ab, a.w2_packed, a.b2, a.w3_packed, a.b3 = (t.data_ptr(), ab.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
+                                                       w3p.data_ptr(), b3.data_ptr())
+    a.res = res.data_ptr() if res is not None else None
+    a.res_low = res_low.data_ptr() if res_low is not None else None
+    a.res_bias = res_bias.data_ptr() if res_bias is not None else None
+    a.y = y.data_ptr()
+    a.N, a.rows_per_sample, a.C_in, a.C_hid, a.C_out, a.res_mode = N, rows_per_sample, c_in, c_hid, c_out, res_mode
+    a.Di, a.Hi, a.Wi = (int(v) for v in grid)
+    nb = N * rows_per_sample * 2 * (c_in + c_out + (c_out if res is not None else 0))
+    _run(f"pw_mlp_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_fwd, C.byref(a), _stream())
     return y

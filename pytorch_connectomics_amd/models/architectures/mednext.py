@@ -145,6 +145,7 @@ class HipBlockOps:
 
     def __init__(self):
         self.cache = _WeightCache()
+        self.fused = True      # bf16: use the fused channel-mixer kernel where a template exists
 
     # ---- parameter repacking (load time / after optimizer steps) -----------------------------
     def _taps(self, conv: nn.Module):
@@ -161,6 +162,13 @@ class HipBlockOps:
             w2 = w.detach().float().reshape(w.shape[0], w.shape[1]).contiguous()
             return ops.pw_pack_weight(w2, dt, transposed=transposed)
         return self.cache.get(("pw", id(conv), dt), [w], make)
+
+    def _pw_paired(self, conv: nn.Module, transposed: bool = False):
+        w = conv.weight
+        def make():
+            w2 = w.detach().float().reshape(w.shape[0], w.shape[1]).contiguous()
+            return ops.pw_pack_weight_paired(w2, transposed=transposed)
+        return self.cache.get(("pwp", id(conv)), [w], make)
 
     def _vec(self, owner, name: str, p: Optional[torch.Tensor]):
         if p is None:
@@ -208,6 +216,9 @@ class HipBlockOps:
         rows = Do * Ho * Wo
         c_hid = m.conv2.weight.shape[0]
         c_out = m.conv3.weight.shape[0]
+        if (self.fused and dt == torch.bfloat16 and m.conv2.bias is not None and m.conv3.bias is not None
+                and ops.pw_mlp_supported(C, c_hid, c_out)):
+            return self._block_fused(m, x, t, ab, skip, (N, D, H, W, C), (Do, Ho, Wo), c_hid, c_out)
         h = ops.pw_conv(t, self._pw(m.conv2, dt), self._vec(m.conv2, "bias", m.conv2.bias), N=N,
                         rows_per_sample=rows, c_in=C, c_out=c_hid, out_dtype=dt, ab=ab, act=nat.ACT_GELU)
         w3, b3 = self._pw(m.conv3, dt), self._vec(m.conv3, "bias", m.conv3.bias)
@@ -236,13 +247,47 @@ class HipBlockOps:
         return y.view(N, Do, Ho, Wo, c_out)
 
 
+def _block_fused(self, m, x, t, ab, skip, ishape, oshape, c_hid, c_out):
+    """bf16 fast path: one pw_mlp launch per block (plus the tiny residual-conv GEMMs of down/up blocks)."""
+    N, D, H, W, C = ishape
+    Do, Ho, Wo = oshape
+    rows = Do * Ho * Wo
+    dt = torch.bfloat16
+    w2, b2 = self._pw_paired(m.conv2), self._vec(m.conv2, "bias", m.conv2.bias)
+    w3, b3 = self._pw_paired(m.conv3), self._vec(m.conv3, "bias", m.conv3.bias)
+    kw = dict(N=N, rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out)
+    if m.kind == "block":
+        y = ops.pw_mlp(t, ab, w2, b2, w3, b3, res=x if m.do_res else None,
+                       res_mode=nat.RES_ADD if m.do_res else nat.RES_NONE, **kw)
+    elif m.kind == "down":
+        res = None
+        if m.resample_do_res:
+            res = ops.pw_conv(x, self._pw(m.res_conv, dt), self._vec(m.res_conv, "bias", m.res_conv.bias), N=N,
+                              rows_per_sample=rows, c_in=C, c_out=c_out, out_dtype=dt, gather=2, grid=(D, H, W))
+        y = ops.pw_mlp(t, ab, w2, b2, w3, b3, res=res, res_mode=nat.RES_ADD if res is not None else nat.RES_NONE, **kw)
+    else:
+        if skip is None:
+            skip = torch.zeros((N, Do, Ho, Wo, c_out), dtype=dt, device=x.device)
+        res_low = res_bias = None
+        if m.resample_do_res:
+            res_bias = self._vec(m.res_conv, "bias", m.res_conv.bias)
+            res_low = ops.pw_conv(x, self._pw(m.res_conv, dt, transposed=True), res_bias, N=N,
+                                  rows_per_sample=D * H * W, c_in=C, c_out=c_out, out_dtype=dt)
+        y = ops.pw_mlp(t, ab, w2, b2, w3, b3, res=skip, res_mode=nat.RES_UPSAMPLE, grid=(Do, Ho, Wo),
+                       res_low=res_low, res_bias=res_bias, **kw)
+    return y.view(N, Do, Ho, Wo, c_out)
+
+
+HipBlockOps._block_fused = _block_fused
+
+
 def resolve_compute_dtype(module_pref: Optional[torch.dtype]) -> torch.dtype:
     """bf16 storage when requested on the module or under torch.autocast(bfloat16) (the reference's
     'bf16-mixed' Lightning precision, training/lightning/trainer.py:216-223); fp32 otherwise."""
     if module_pref is not None:
         return module_pref
-    if torch.is_autocast_enabled():
-        adt = torch.get_autocast_gpu_dtype()
+    if torch.is_autocast_enabled("cuda"):
+        adt = torch.get_autocast_dtype("cuda")
         if adt == torch.bfloat16:
             return torch.bfloat16
         if adt == torch.float16:

@@ -28,7 +28,11 @@ TOL = {torch.float32: dict(rtol=1e-5, atol=1e-5), torch.bfloat16: dict(rtol=2e-2
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("C,K,stride,shape", [(32, 3, 1, (9, 10, 11)), (64, 3, 2, (9, 10, 12)), (16, 5, 1, (7, 8, 9)),
                                               (8, 7, 2, (9, 9, 9)), (12, 3, 1, (5, 6, 7)), (6, 3, 2, (6, 6, 6)),
-                                              (512, 3, 1, (3, 4, 3))])
+                                              (512, 3, 1, (3, 4, 3)),
+                                              # shapes that take the z-march fast path (incl. ragged tiles,
+                                              # two channel groups, several z chunks)
+                                              (32, 3, 1, (12, 20, 24)), (64, 3, 1, (9, 17, 19)),
+                                              (32, 3, 1, (45, 16, 16)), (96, 3, 1, (8, 16, 33))])
 def test_dwconv3d_and_stats(dev, dt, C, K, stride, shape):
     from pytorch_connectomics_amd import hip_ops as ops
     torch.manual_seed(C * 100 + K)
@@ -157,3 +161,70 @@ def test_pw_conv_strided_gather_and_upsample_epilogue(dev, dt):
     if dt == torch.bfloat16:
         tol = dict(rtol=3e-2, atol=5e-2)   # res_low is itself rounded to bf16
     torch.testing.assert_close(_cf(y.view(N, 2 * d, 2 * h_, 2 * w_, Cu).float().cpu()), ref, **tol)
+
+
+@pytest.mark.parametrize("cin,chid,cout,mode", [
+    (32, 64, 32, "add"), (32, 64, 64, "add"), (64, 128, 32, "up"), (64, 128, 64, "add"), (64, 192, 128, "none"),
+    (128, 256, 128, "add"), (128, 512, 64, "up"), (256, 512, 256, "add"), (256, 1024, 512, "add"),
+    (512, 1024, 512, "add"), (512, 1024, 256, "up"), (128, 256, 256, "add"), (256, 2048, 128, "up"),
+])
+def test_pw_mlp_fused_matches_reference(dev, cin, chid, cout, mode):
+    """Fused norm-apply/expand/GELU/project/residual kernel vs fp32 math with bf16 rounding at the same
+    three points (normalised input, hidden activation, output)."""
+    from pytorch_connectomics_amd import _native as nat
+    from pytorch_connectomics_amd import hip_ops as ops
+    assert ops.pw_mlp_supported(cin, chid, cout)
+    torch.manual_seed(cin + chid + cout)
+    bf = torch.bfloat16
+    N = 2
+    if mode == "up":
+        d, h_, w_ = 3, 2, 3
+        grid = (2 * d, 2 * h_, 2 * w_)
+        rows = grid[0] * grid[1] * grid[2]
+    else:
+        rows, grid = 333, (0, 0, 0)
+    t = torch.randn(N, rows, cin).to(bf).float()
+    a, b = torch.rand(N, cin) + 0.5, torch.randn(N, cin) * 0.5
+    w2, b2 = torch.randn(chid, cin) / cin ** 0.5, torch.randn(chid) * 0.5
+    w3, b3 = torch.randn(cout, chid) / chid ** 0.5, torch.randn(cout) * 0.5
+    tn = (t * a[:, None] + b[:, None]).to(bf).float()
+    hid = F.gelu(tn @ w2.to(bf).float().t() + b2).to(bf).float()
+    core = hid @ w3.to(bf).float().t() + b3
+    ab = torch.stack([a, b], 1).contiguous().to(dev)
+    args = dict(N=N, rows_per_sample=rows, c_in=cin, c_hid=chid, c_out=cout)
+    w2p, w3p = ops.pw_pack_weight_paired(w2.to(dev)), ops.pw_pack_weight_paired(w3.to(dev))
+    if mode == "add":
+        res = torch.randn(N, rows, cout).to(bf).float()
+        ref = core + res
+        y = ops.pw_mlp(t.to(dev).to(bf), ab, w2p, b2.to(dev), w3p, b3.to(dev), res=res.to(dev).to(bf),
+                       res_mode=nat.RES_ADD, **args)
+    elif mode == "none":
+        ref = core
+        y = ops.pw_mlp(t.to(dev).to(bf), ab, w2p, b2.to(dev), w3p, b3.to(dev), **args)
+    else:
+        skip = torch.randn(N, rows, cout).to(bf).float()
+        res_low = torch.randn(N, d * h_ * w_, cout).to(bf).float()
+        rbias = torch.randn(cout)
+        c5 = core.view(N, *grid, cout)
+        ref = torch.zeros_like(c5)
+        ref[:, 1:, 1:, 1:] = c5[:, 1:, 1:, 1:] + rbias
+        rl = res_low.view(N, d, h_, w_, cout)
+        # transposed 1x1 stride-2 residual lands on padded positions 1,3,5.. (o = p-1 even)
+        ref[:, 1::2, 1::2, 1::2] = c5[:, 1::2, 1::2, 1::2] + rl
+        ref = ref + skip.view(N, *grid, cout)
+        ref = ref.view(N, rows, cout)
+        y = ops.pw_mlp(t.to(dev).to(bf), ab, w2p, b2.to(dev), w3p, b3.to(dev), res=skip.to(dev).to(bf),
+                       res_mode=nat.RES_UPSAMPLE, grid=grid, res_low=res_low.to(dev).to(bf),
+                       res_bias=rbias.to(dev), **args)
+    torch.testing.assert_close(y.float().cpu(), ref, rtol=2e-2, atol=3e-2)
+
+
+def test_gelu_accuracy(dev):
+    """The in-kernel erf GELU (A&S 7.1.26) against torch's exact erf GELU over the useful range."""
+    from pytorch_connectomics_amd import _native as nat
+    from pytorch_connectomics_amd import hip_ops as ops
+    x = torch.linspace(-9, 9, 16 * 4096).view(1, -1, 16)
+    eye = torch.eye(16)
+    y = ops.pw_conv(x.to(dev), ops.pw_pack_weight(eye.to(dev), torch.float32), None, N=1, rows_per_sample=x.shape[1],
+                    c_in=16, c_out=16, out_dtype=torch.float32, act=nat.ACT_GELU).cpu()
+    torch.testing.assert_close(y, F.gelu(x), rtol=2e-6, atol=2e-6)

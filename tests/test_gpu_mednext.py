@@ -102,11 +102,11 @@ def test_build_model_and_multihead(dev):
                              "sdt": {"out_channels": 1, "num_blocks": 0}}, primary_head="aff"))
     torch.manual_seed(0)
     model = build_model(cfg).to(dev).eval()
-    x = torch.randn(1, 1, 16, 16, 16, device=dev)
+    x = torch.randn(1, 1, 32, 32, 32, device=dev)
     with torch.no_grad():
         out = model(x)
     assert set(out["output"]) == {"aff", "sdt"}
-    assert out["output"]["aff"].shape == (1, 3, 16, 16, 16) and out["output"]["sdt"].shape == (1, 1, 16, 16, 16)
+    assert out["output"]["aff"].shape == (1, 3, 32, 32, 32) and out["output"]["sdt"].shape == (1, 1, 32, 32, 32)
     # oracle: trunk features -> head blocks
     st = {k: v.detach().cpu() for k, v in model.model.state_dict().items()}
     f = MO.forward_features(st, x.cpu(), n_channels=8, exp_r=2, kernel_size=3, block_counts=[1] * 9)

@@ -76,8 +76,9 @@ def test_eager_engine_matches_reference_fixtures(dev, golden_dir):
         y = eng(torch.from_numpy(g[f"{name}__x"]).to(dev), NETS[str(net)]).cpu().numpy()
         exp = g[f"{name}__y"]
         assert y.shape == exp.shape, name
-        if str(net) == "identity":
-            # same fp32 op order as the reference -> bit identical
+        if str(net) == "identity" and str(mode) != "bump":
+            # same fp32 op order as the reference -> bit identical (the bump table goes through the host's
+            # libm exp, which may differ in the last ulp between the fixture host and this one)
             np.testing.assert_array_equal(y, exp, err_msg=name)
         else:
             np.testing.assert_allclose(y, exp, rtol=2e-5, atol=2e-5 * max(1.0, np.abs(exp).max()), err_msg=name)

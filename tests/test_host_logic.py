@@ -1,0 +1,183 @@
+"""CPU tests of the host-side mirror of the reference interface: registry / builder API, planner and
+blending maps (bit-identical to the reference fixtures), config resolution, engine argument errors."""
+import warnings
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from pytorch_connectomics_amd.inference import window as W
+from pytorch_connectomics_amd.models import (ConnectomicsModel, build_model, get_architecture_builder,
+                                             get_architecture_info, is_architecture_available,
+                                             list_architectures, register_architecture, unregister_architecture)
+
+
+# ---- registry (reference tests/unit/test_architecture_registry.py, test_registry_basic.py) ----------
+def test_registry_contract():
+    assert {"mednext", "mednext_custom"} <= set(list_architectures())
+
+    @register_architecture("unit_dummy")
+    def build_dummy(cfg):
+        """Dummy doc."""
+        return nn.Identity()
+
+    assert is_architecture_available("unit_dummy")
+    assert get_architecture_builder("unit_dummy") is build_dummy
+    assert get_architecture_info()["unit_dummy"]["doc"] == "Dummy doc."
+    with pytest.warns(UserWarning, match="already registered"):
+        register_architecture("unit_dummy")(build_dummy)
+    cfg = NS(model=NS(arch=NS(type="unit_dummy")))
+    assert isinstance(build_model(cfg), nn.Identity)
+    unregister_architecture("unit_dummy")
+    assert not is_architecture_available("unit_dummy")
+    with pytest.raises(ValueError, match="not registered"):
+        unregister_architecture("unit_dummy")
+    with pytest.raises(ValueError, match="Available architectures"):
+        get_architecture_builder("nope")
+
+
+def test_base_model_contract():
+    class M(ConnectomicsModel):
+        def __init__(self):
+            super().__init__()
+            self.l = nn.Linear(3, 2)
+
+        def forward(self, x):
+            return self.l(x)
+
+    info = M().get_model_info()
+    assert info["parameters"] == 8 and info["deep_supervision"] is False and info["output_scales"] == 1
+    assert "parameters=8" in repr(M())
+    with pytest.raises(TypeError):
+        ConnectomicsModel()
+
+
+def _mednext_cfg(**kw):
+    md = dict(size="S", kernel_size=3)
+    md.update(kw)
+    return NS(model=NS(arch=NS(type="mednext"), in_channels=1, out_channels=1, mednext=NS(**md),
+                       loss=NS(deep_supervision=False), heads=None))
+
+
+@pytest.mark.parametrize("size,k,millions", [("S", 3, 5.6), ("B", 3, 10.5), ("M", 3, 17.6), ("L", 3, 61.8),
+                                             ("B", 5, 11.0), ("L", 5, 63.0)])
+def test_build_mednext_param_counts(size, k, millions):
+    m = build_model(_mednext_cfg(size=size, kernel_size=k))
+    assert abs(m.get_model_info()["parameters"] / 1e6 - millions) < 0.06     # mednext_models.py:309-312
+    assert m.model.outside_block_checkpointing == (size in "ML")
+
+
+def test_build_mednext_errors_and_state_dict_keys():
+    with pytest.raises(ValueError, match="model_size"):
+        build_model(_mednext_cfg(size="XL"))
+    with pytest.raises(ValueError, match="kernel_size"):
+        build_model(_mednext_cfg(kernel_size=4))
+    with pytest.raises(ValueError, match="checkpoint_style"):
+        build_model(_mednext_cfg(checkpoint_style="inside"))
+    m = build_model(_mednext_cfg(checkpoint_style="outside_block"))
+    assert m.model.outside_block_checkpointing
+    keys = set(m.state_dict())
+    for k in ("model.stem.weight", "model.enc_block_0.0.conv1.weight", "model.enc_block_0.1.norm.bias",
+              "model.down_0.res_conv.weight", "model.bottleneck.1.conv3.bias", "model.up_3.conv1.weight",
+              "model.dec_block_0.1.conv2.weight", "model.out_0.conv_out.weight", "model.dummy_tensor"):
+        assert k in keys
+    sd = m.state_dict()
+    assert sd["model.up_3.res_conv.weight"].shape == (512, 256, 1, 1, 1)     # ConvTranspose layout
+    assert sd["model.enc_block_0.0.conv1.weight"].shape == (32, 1, 3, 3, 3)
+    # optimizer grouping relies on norm params living in norm modules (optimization/build.py:73-112)
+    assert isinstance(m.model.enc_block_0[0].norm, nn.GroupNorm)
+    # deep-supervision variant exposes 5 scales and the extra heads
+    cfg = _mednext_cfg()
+    cfg.model.loss.deep_supervision = True
+    ds = build_model(cfg)
+    assert ds.output_scales == 5 and "model.out_4.conv_out.weight" in ds.state_dict()
+
+
+def test_multihead_wrapper_validation():
+    from pytorch_connectomics_amd.models.architectures.mednext import MedNeXt
+    from pytorch_connectomics_amd.models.architectures.mednext_models import MedNeXtMultiHeadWrapper
+    trunk = MedNeXt(1, 8, 4, exp_r=2, kernel_size=3, do_res=True, do_res_up_down=True, block_counts=[1] * 9)
+    w = MedNeXtMultiHeadWrapper(trunk, {"a": {"out_channels": 3, "num_blocks": 1}, "b": 1})
+    assert w.primary_head == "a" and w.head_specs["b"]["out_channels"] == 1
+    assert w.head_block_kwargs == {"exp_r": 2, "kernel_size": 3, "do_res": True, "norm_type": "group",
+                                   "dim": "3d", "grn": False}
+    with pytest.raises(ValueError, match="at least one"):
+        MedNeXtMultiHeadWrapper(trunk, {})
+    with pytest.raises(ValueError, match="primary_head"):
+        MedNeXtMultiHeadWrapper(trunk, {"a": 1}, primary_head="zzz")
+    with pytest.raises(ValueError, match="hidden_channels must not exceed"):
+        MedNeXtMultiHeadWrapper(trunk, {"a": {"out_channels": 1, "hidden_channels": 99}})
+    ds_trunk = MedNeXt(1, 8, 4, exp_r=2, kernel_size=3, deep_supervision=True, block_counts=[1] * 9)
+    with pytest.raises(ValueError, match="deep supervision"):
+        MedNeXtMultiHeadWrapper(ds_trunk, {"a": 1})
+
+
+# ---- planner + maps: bit-identical to the reference ------------------------------------------------
+def test_planner_matches_reference(golden_dir):
+    g = np.load(golden_dir / "window_grids.npz")
+    for i in range(int(g["n"])):
+        iv = W.compute_scan_interval(g[f"img_{i}"], g[f"roi_{i}"], overlap=tuple(g[f"ov_{i}"]))
+        assert tuple(g[f"interval_{i}"]) == iv
+        st = W.dense_patch_slices(g[f"img_{i}"], g[f"roi_{i}"], iv, return_slice=False)
+        assert np.array_equal(np.asarray(st).reshape(-1, 3), g[f"starts_{i}"])
+    sl = W.dense_patch_slices((24, 24, 24), (16, 16, 16), (8, 8, 8))
+    assert sl[0] == (slice(0, 16),) * 3 and len(sl) == 8
+
+
+def test_importance_maps_match_reference(golden_dir):
+    m = np.load(golden_dir / "importance_maps.npz")
+    for mode in ("constant", "bump", "distance_transform"):
+        for roi in ((8, 8, 8), (5, 5, 5), (2, 3, 3), (4, 6, 10)):
+            got = W.build_sliding_importance_map(roi, mode=mode, device="cpu").numpy()
+            assert np.array_equal(got, m[f"{mode}_{'x'.join(map(str, roi))}"]), (mode, roi)
+    assert np.array_equal(W.compute_importance_map((8, 8, 8), mode="bump").numpy(), m["bump_raw_8x8x8"])
+    with pytest.raises(ValueError, match="unsupported mode"):
+        W.compute_importance_map((4, 4, 4), mode="gaussian")
+    with pytest.raises(ValueError, match="positive"):
+        W.build_sliding_importance_map((0, 4, 4), mode="bump", device="cpu")
+    v, w = W.build_sliding_accumulator_weight_maps((4, 4, 4), mode="bump", device="cpu", value_dtype=torch.float32)
+    assert v is w
+    bm = W.apply_border_mask(torch.ones(6, 6, 6), [1, 0, 2])
+    assert bm[0].sum() == 0 and bm[:, :, :2].sum() == 0 and bm[1:5, :, 2:4].min() == 1
+    with pytest.raises(ValueError, match="too large"):
+        W.apply_border_mask(torch.ones(4, 4, 4), [2, 0, 0])
+
+
+def test_config_resolution():
+    cfg = NS(inference=NS(sliding_window=NS(window_size=[112, 112, 112], sw_batch_size=8, overlap=0.5,
+                                            blending="bump", padding_mode="reflect", cval=0.0,
+                                            keep_input_on_cpu=False, sw_device="none", output_device=None,
+                                            border_mask=None),
+                          model=NS(output_dtype="bf16")))
+    eng = W.build_sliding_inferer(cfg)
+    assert eng.roi_size == (112, 112, 112) and eng.sw_batch_size == 8 and eng.mode == "bump"
+    assert eng.sw_device is None and eng.padding_mode == "reflect"
+    assert W.resolve_model_output_dtype(cfg) == torch.bfloat16
+    assert W.resolve_model_output_dtype(NS()) == torch.float32
+    with pytest.raises(ValueError, match="output_dtype"):
+        W.resolve_model_output_dtype(NS(inference=NS(model=NS(output_dtype="int8"))))
+    assert W.resolve_inferer_overlap(NS(), (4, 4, 4)) == 0.5
+    cfg.inference.sliding_window.overlap = [0.25, 1.5, -1]
+    assert W.resolve_inferer_overlap(cfg, (4, 4, 4)) == (0.25, 0.99, 0.0)
+    assert W.build_sliding_inferer(NS()) is None
+    cfg2 = NS(model=NS(output_size=[64, 64]), data=NS(train=NS(do_2d=True)))
+    assert W.resolve_inferer_roi_size(cfg2) == (1, 64, 64)
+    assert W.resolve_border_mask(NS(inference=NS(sliding_window=NS(border_mask=[2]))), 3) == [2, 2, 2]
+    # canonical `inference.window` alias (schema/inference.py:307-331)
+    cfg3 = NS(inference=NS(window=NS(window_size=[8, 8, 8], overlap=0.25)))
+    assert W.resolve_inferer_roi_size(cfg3) == (8, 8, 8) and W.resolve_inferer_overlap(cfg3, (8,) * 3) == 0.25
+
+
+def test_engine_argument_errors():
+    eng = W.EagerSlidingWindowEngine(roi_size=(8, 8, 8), sw_batch_size=1, overlap=0.5, mode="bump",
+                                     padding_mode="constant", cval=0.0)
+    with pytest.raises(ValueError, match="inputs must have shape"):
+        eng(torch.zeros(8, 8, 8), lambda x: x)
+    with pytest.raises(ValueError, match="batch size 1"):
+        eng(torch.zeros(2, 1, 8, 8, 8), lambda x: x)
+    img, starts = eng.plan((4, 20, 9))
+    assert img == (8, 20, 9) and starts[0] == (0, 0, 0) and starts[-1] == (0, 12, 1)
+    assert W._effective_pad_mode((0, 0, 0), (64,) * 3, (32,) * 3, "reflect") == "constant"
+    assert W._effective_pad_mode((-2, 0, 0), (8,) * 3, (32,) * 3, "reflect") == "reflect"
