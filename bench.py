@@ -143,7 +143,13 @@ def main():
                     "launch_us": round(per_launch_s * 1e6, 1), "algorithmic_bytes": int(per_launch_bytes),
                     "share_of_step": round(rec["ms"] / sum(r["ms"] for r in summ.values()), 3),
                     "kernels_ms_per_step": {k: round(v["ms"] / min(args.steps, 5), 3) for k, v in
-                                            sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]}}
+                                            sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]},
+                    "kernel_ms_total_per_step": round(sum(r["ms"] for r in summ.values()) / min(args.steps, 5), 3)}
+        if os.environ.get("PYTC_BENCH_VERBOSE"):
+            for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+                n = min(args.steps, 5)
+                print(f"  {k:34s} launches/step={v['launches'] / n:5.1f} ms/step={v['ms'] / n:7.3f} "
+                      f"GB/s={v['bytes'] / max(v['ms'], 1e-9) / 1e6:8.1f}", file=sys.stderr)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

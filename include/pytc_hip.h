@@ -64,6 +64,8 @@ int pytc_abi_version(void);
 const char* pytc_last_error(void);
 /* fills cu_count / lds_bytes_per_cu / gcn arch name of `device`; returns status */
 int pytc_device_info(int device, int* cu_count, int* lds_bytes_per_cu, char* arch, int arch_len);
+/* integer tuning knobs (kernel-variant selection for A/B measurements; defaults are the tuned ones) */
+int pytc_set_tuning(const char* key, int value);
 
 /* ---------------------------------------------------------------- sliding window --------- */
 

@@ -49,6 +49,7 @@ _SIGS = {
     "pytc_abi_version": (C.c_int, []),
     "pytc_last_error": (C.c_char_p, []),
     "pytc_device_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "pytc_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "pytc_gather_windows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32),
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                       C.c_void_p, C.c_int, C.c_void_p]),

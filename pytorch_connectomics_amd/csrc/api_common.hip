@@ -16,6 +16,27 @@ int hip_fail(hipError_t e, const char* what) {
 }
 }  // namespace pytc
 
+namespace pytc {
+// Small registry of integer tuning knobs (kernel variant selection for A/B measurements).
+static struct { char key[48]; int value; } g_knobs[32];
+static int g_nknobs = 0;
+int tuning_get(const char* key, int dflt) {
+  for (int i = 0; i < g_nknobs; ++i)
+    if (!strcmp(g_knobs[i].key, key)) return g_knobs[i].value;
+  return dflt;
+}
+}  // namespace pytc
+
+extern "C" int pytc_set_tuning(const char* key, int value) {
+  if (!key || strlen(key) >= 48) return PYTC_ERR_INVALID;
+  for (int i = 0; i < pytc::g_nknobs; ++i)
+    if (!strcmp(pytc::g_knobs[i].key, key)) { pytc::g_knobs[i].value = value; return PYTC_OK; }
+  if (pytc::g_nknobs >= 32) return PYTC_ERR_INVALID;
+  strcpy(pytc::g_knobs[pytc::g_nknobs].key, key);
+  pytc::g_knobs[pytc::g_nknobs++].value = value;
+  return PYTC_OK;
+}
+
 extern "C" int pytc_abi_version(void) { return PYTC_ABI_VERSION; }
 extern "C" const char* pytc_last_error(void) { return pytc::g_err; }
 extern "C" int pytc_device_info(int device, int* cu_count, int* lds_bytes_per_cu, char* arch, int arch_len) {

@@ -131,6 +131,35 @@ dwconvT3d_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __rest
     int oz = pz - 1, oy = py - 1, ox = px - 1;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = bv[i];
+    if constexpr (K == 3) {
+      // stride 2, pad 1: even o -> one tap (k=1, i=o/2); odd o -> two taps (k=0, i=(o+1)/2), (k=2, i=(o-1)/2);
+      // o <= 2D-2 keeps every index in range: no bounds checks
+      int iz[2], kz[2], iy[2], ky[2], ix[2], kx[2];
+      const int nz = 1 + (oz & 1), ny = 1 + (oy & 1), nx = 1 + (ox & 1);
+      if (oz & 1) { iz[0] = (oz + 1) >> 1; kz[0] = 0; iz[1] = (oz - 1) >> 1; kz[1] = 2; } else { iz[0] = oz >> 1; kz[0] = 1; iz[1] = 0; kz[1] = 0; }
+      if (oy & 1) { iy[0] = (oy + 1) >> 1; ky[0] = 0; iy[1] = (oy - 1) >> 1; ky[1] = 2; } else { iy[0] = oy >> 1; ky[0] = 1; iy[1] = 0; ky[1] = 0; }
+      if (ox & 1) { ix[0] = (ox + 1) >> 1; kx[0] = 0; ix[1] = (ox - 1) >> 1; kx[1] = 2; } else { ix[0] = ox >> 1; kx[0] = 1; ix[1] = 0; kx[1] = 0; }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        if (a < nz) {
+#pragma unroll
+          for (int b2 = 0; b2 < 2; ++b2) {
+            if (b2 < ny) {
+#pragma unroll
+              for (int c2 = 0; c2 < 2; ++c2) {
+                if (c2 < nx) {
+                  float xv[VEC], wv[VEC];
+                  VecIO<T, VEC>::load(xn + (((long)iz[a] * g.H + iy[b2]) * g.W + ix[c2]) * C + cv * VEC, xv);
+                  VecIO<float, VEC>::load(w + ((kz[a] * 3 + ky[b2]) * 3 + kx[c2]) * C + cv * VEC, wv);
+#pragma unroll
+                  for (int i = 0; i < VEC; ++i) acc[i] = fmaf(xv[i], wv[i], acc[i]);
+                }
+              }
+            }
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int kz = 0; kz < K; ++kz) {
       int tz = oz + pad - kz;
@@ -150,6 +179,7 @@ dwconvT3d_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __rest
           for (int i = 0; i < VEC; ++i) acc[i] = fmaf(xv[i], wv[i], acc[i]);
         }
       }
+    }
     }
     VecIO<T, VEC>::store(yn + v * C + cv * VEC, acc);
 #pragma unroll
@@ -180,24 +210,34 @@ struct DwMarch {
   int N, D, H, W, C;
   int ty, tx, zc, nzc;   // footprints per axis, z-chunk length, z-chunks
   int slots;             // workgroups per (sample, channel group)
+  int swizzle;           // XCD-aware block remap on/off
 };
 
-template <typename T>
+template <typename T, int VEC, int PF>
 __global__ void __launch_bounds__(256, 2)
 dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ w,
                          const float* __restrict__ bias, float* __restrict__ stats, DwMarch g) {
-  constexpr int CG = MARCH_CG, VEC = 4, LPV = CG / VEC, PPP = 256 / LPV, PASSES = (TILE_Y * TILE_X) / PPP;
+  // VEC channels per lane (4: ds_read_b128, 108 weight registers; 2: ds_read_b64, 54 weight registers ->
+  // more resident workgroups).  PF = planes of global loads kept in flight (register staged).
+  constexpr int CG = MARCH_CG, LPV = CG / VEC, PPP = 256 / LPV, PASSES = (TILE_Y * TILE_X) / PPP;
   constexpr int EY = TILE_Y + 2, EX = TILE_X + 2;
   constexpr int EPC = 16 / (int)sizeof(T);          // elements per 16-byte chunk
   constexpr int CH16 = CG / EPC;                    // chunks per voxel
   constexpr int NCHUNK = EY * EX * CH16;            // chunks per plane
   constexpr int CPT = (NCHUNK + 255) / 256;         // chunks per thread
+  typedef float fvec_t __attribute__((ext_vector_type(VEC)));
   __shared__ __attribute__((aligned(16))) float plane[2][EY * EX * CG];
   __shared__ float red[4][2][CG];
 
   const int tid = threadIdx.x;
-  const int n = blockIdx.z, cg = blockIdx.y;
-  int b = blockIdx.x;
+  // 1-D grid, XCD-aware: logical index = ((n * CGs + cg) * slots + slot); x-/y-neighbouring footprints
+  // (which share halo columns) are consecutive logical indices -> same XCD, same L2
+  int b = g.swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int slot_id = b % g.slots; b /= g.slots;
+  const int ncg = g.C / MARCH_CG;
+  const int cg = b % ncg;
+  const int n = b / ncg;
+  b = slot_id;
   const int fx = b % g.tx; b /= g.tx;
   const int fy = b % g.ty;
   const int zchunk = b / g.ty;
@@ -222,8 +262,8 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
     goff[i] = (gy * g.W + gx) * C + part * EPC;
     loff[i] = (c < NCHUNK) ? vox * CG + part * EPC : -1;
   }
-  uint4 stg[CPT];
-  auto issue = [&](int gz) {
+  uint4 stg0[CPT], stg1[CPT];
+  auto issue = [&](int gz, uint4 (&stg)[CPT]) {
     const bool zok = gz >= 0 && gz < g.D;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
@@ -231,7 +271,7 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
       if (zok && cok[i]) stg[i] = *reinterpret_cast<const uint4*>(xn + (long)gz * plane_elems + goff[i]);
     }
   };
-  auto commit = [&](int slot) {
+  auto commit = [&](int slot, uint4 (&stg)[CPT]) {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       if (loff[i] < 0) continue;
@@ -244,7 +284,7 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
     }
   };
 
-  // ---- per-thread weights (27 taps x 4 channels), bias, positions
+  // ---- per-thread weights (27 taps x VEC channels), bias, positions
   const int cv = tid % LPV, pslot = tid / LPV;
   const int c0 = cg * CG + cv * VEC;
   float wr[27][VEC];
@@ -274,32 +314,27 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { accA[ps][i] = bv[i]; accB[ps][i] = bv[i]; accC[ps][i] = bv[i]; }
 
-  // one z step: input plane gz lives in plane[slot]; prev/cur/next = outputs gz-1 / gz / gz+1
+  // one z step: input plane gz lives in plane[slot]; prev/cur/next = outputs gz-1 / gz / gz+1.
+  // `ld` receives the global loads issued this step (plane gz+PF); `cm` holds plane gz+1 (issued PF-1
+  // steps ago) and is committed to the other LDS slot after the compute.
   auto step = [&](int gz, int slot, float (&prev)[PASSES][VEC], float (&cur)[PASSES][VEC],
-                  float (&next)[PASSES][VEC]) {
-    const bool more = gz + 1 <= ze;
-    if (more) issue(gz + 1);
-    if (gz >= 0 && gz < g.D) {
-      const bool vprev = gz - 1 >= zs, vcur = gz >= zs && gz < ze, vnext = gz + 1 < ze;
+                  float (&next)[PASSES][VEC], uint4 (&ld)[CPT], uint4 (&cm)[CPT]) {
+    if (gz + PF <= ze) issue(gz + PF, ld);
+    // Unconditional accumulation: planes outside the volume were staged as zeros, and accumulators that
+    // belong to outputs outside [zs, ze) are simply never stored (2 wasted planes per z-chunk), which keeps
+    // the inner loop free of per-FMA selects.
 #pragma unroll
-      for (int ps = 0; ps < PASSES; ++ps) {
+    for (int ps = 0; ps < PASSES; ++ps) {
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
+      for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(&plane[slot][lbase[ps] + (dy * EX + dx) * CG]);
-            if (vnext) {
+        for (int dx = 0; dx < 3; ++dx) {
+          const fvec_t v = *reinterpret_cast<const fvec_t*>(&plane[slot][lbase[ps] + (dy * EX + dx) * CG]);
 #pragma unroll
-              for (int i = 0; i < VEC; ++i) next[ps][i] = fmaf(v[i], wr[(0 * 3 + dy) * 3 + dx][i], next[ps][i]);
-            }
-            if (vcur) {
-#pragma unroll
-              for (int i = 0; i < VEC; ++i) cur[ps][i] = fmaf(v[i], wr[(1 * 3 + dy) * 3 + dx][i], cur[ps][i]);
-            }
-            if (vprev) {
-#pragma unroll
-              for (int i = 0; i < VEC; ++i) prev[ps][i] = fmaf(v[i], wr[(2 * 3 + dy) * 3 + dx][i], prev[ps][i]);
-            }
+          for (int i = 0; i < VEC; ++i) {
+            next[ps][i] = fmaf(v[i], wr[(0 * 3 + dy) * 3 + dx][i], next[ps][i]);
+            cur[ps][i] = fmaf(v[i], wr[(1 * 3 + dy) * 3 + dx][i], cur[ps][i]);
+            prev[ps][i] = fmaf(v[i], wr[(2 * 3 + dy) * 3 + dx][i], prev[ps][i]);
           }
         }
       }
@@ -322,19 +357,33 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
     for (int ps = 0; ps < PASSES; ++ps)
 #pragma unroll
       for (int i = 0; i < VEC; ++i) prev[ps][i] = bv[i];
-    if (more) commit(slot ^ 1);
+    if (gz + 1 <= ze) commit(slot ^ 1, cm);
     __syncthreads();
   };
 
-  issue(zs - 1);
-  commit(0);
+  // prologue: plane zs-1 -> LDS slot 0; with PF == 2 plane zs is already in flight in stg1
+  issue(zs - 1, stg0);
+  if (PF == 2) issue(zs, stg1);
+  commit(0, stg0);
   __syncthreads();
   int slot = 0;
-  for (int gz = zs - 1; gz <= ze; gz += 3) {
-    step(gz, slot, accA, accB, accC);
-    slot ^= 1;
-    if (gz + 1 <= ze) { step(gz + 1, slot, accB, accC, accA); slot ^= 1; }
-    if (gz + 2 <= ze) { step(gz + 2, slot, accC, accA, accB); slot ^= 1; }
+  if (PF == 1) {
+    for (int gz = zs - 1; gz <= ze; gz += 3) {
+      step(gz, slot, accA, accB, accC, stg0, stg0); slot ^= 1;
+      if (gz + 1 <= ze) { step(gz + 1, slot, accB, accC, accA, stg0, stg0); slot ^= 1; }
+      if (gz + 2 <= ze) { step(gz + 2, slot, accC, accA, accB, stg0, stg0); slot ^= 1; }
+    }
+  } else {
+    // plane p travels in stg[(p - (zs-1)) & 1]: step k (gz = zs-1+k) loads plane gz+2 into set k&1 and
+    // commits plane gz+1 from set (k+1)&1
+    for (int gz = zs - 1; gz <= ze; gz += 6) {
+      step(gz, slot, accA, accB, accC, stg0, stg1); slot ^= 1;
+      if (gz + 1 <= ze) { step(gz + 1, slot, accB, accC, accA, stg1, stg0); slot ^= 1; }
+      if (gz + 2 <= ze) { step(gz + 2, slot, accC, accA, accB, stg0, stg1); slot ^= 1; }
+      if (gz + 3 <= ze) { step(gz + 3, slot, accA, accB, accC, stg1, stg0); slot ^= 1; }
+      if (gz + 4 <= ze) { step(gz + 4, slot, accB, accC, accA, stg0, stg1); slot ^= 1; }
+      if (gz + 5 <= ze) { step(gz + 5, slot, accC, accA, accB, stg1, stg0); slot ^= 1; }
+    }
   }
 
   if (stats) {
@@ -360,7 +409,7 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
       float a = 0.f;
 #pragma unroll
       for (int wv = 0; wv < 4; ++wv) a += red[wv][which][ch];
-      stats[(((long)n * g.slots + blockIdx.x) * 2 + which) * C + cg * CG + ch] = a;
+      stats[(((long)n * g.slots + slot_id) * 2 + which) * C + cg * CG + ch] = a;
     }
   }
 }
@@ -496,13 +545,23 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
   if (march_ok(D, H, W, C, K, stride, dtype, transposed)) {
     DwMarch t;
     make_march(t, N, D, H, W, C);
-    dim3 grid(t.slots, C / MARCH_CG, N), block(256);
-    if (dtype == PYTC_BF16)
-      hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream,
-                         (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t);
-    else
-      hipLaunchKernelGGL((dwconv3d_k3_march_kernel<float>), grid, block, 0, (hipStream_t)stream,
-                         (const float*)x, (float*)y, w, bias, stats, t);
+    dim3 grid((unsigned)((long)t.slots * (C / MARCH_CG) * N)), block(256);
+    t.swizzle = tuning_get("dwconv_xcd_swizzle", 1);
+    const int variant = tuning_get("dwconv_march_variant", 3);   // bit0: VEC=2, bit1: PF=2
+#define PYTC_MARCH(TT, VV, PP) \
+  hipLaunchKernelGGL((dwconv3d_k3_march_kernel<TT, VV, PP>), grid, block, 0, (hipStream_t)stream, (const TT*)x, \
+                     (TT*)y, w, bias, stats, t)
+    if (dtype == PYTC_BF16) {
+      switch (variant & 3) {
+        case 0: PYTC_MARCH(bf16_t, 4, 1); break;
+        case 1: PYTC_MARCH(bf16_t, 2, 1); break;
+        case 2: PYTC_MARCH(bf16_t, 4, 2); break;
+        default: PYTC_MARCH(bf16_t, 2, 2); break;
+      }
+    } else {
+      PYTC_MARCH(float, 2, 1);
+    }
+#undef PYTC_MARCH
     PYTC_LAUNCH_CHECK("dwconv3d_k3_march");
     return PYTC_OK;
   }

@@ -66,14 +66,19 @@ struct EpiParams {
 
 // v[NCH] = conv result (+bias, activation) for channels o0..o0+NCH-1 of output row `orow` of sample n.
 template <typename TO, int NCH>
-__device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParams& e, int n, long orow, int o0) {
+__device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParams& e, int n, long orow, int o0,
+                                                 const float* pre = nullptr) {
+  // pre != nullptr: the caller already loaded res[orow][o0..o0+NCH) (prefetched ahead of the GEMMs)
   TO* yn = reinterpret_cast<TO*>(e.y) + (long)n * e.rps_out * e.C_out;
   const TO* resn = e.res ? reinterpret_cast<const TO*>(e.res) + (long)n * e.rps_out * e.C_out : nullptr;
   const long off = orow * e.C_out + o0;
   const bool full = (e.C_out % NCH) == 0 && (o0 + NCH <= e.C_out);
   if (e.res_mode == PYTC_RES_ADD) {
     float rv[NCH];
-    if (full) VecIO<TO, NCH>::load(resn + off, rv);
+    if (pre) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) rv[i] = pre[i];
+    } else if (full) VecIO<TO, NCH>::load(resn + off, rv);
     else {
 #pragma unroll
       for (int i = 0; i < NCH; ++i) rv[i] = (o0 + i < e.C_out) ? to_f32<TO>(resn[off + i]) : 0.f;
@@ -86,7 +91,10 @@ __device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParam
     int py = (int)(t % e.Go_h);
     int pz = (int)(t / e.Go_h);
     float sk[NCH];
-    if (full) VecIO<TO, NCH>::load(resn + off, sk);
+    if (pre) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) sk[i] = pre[i];
+    } else if (full) VecIO<TO, NCH>::load(resn + off, sk);
     else {
 #pragma unroll
       for (int i = 0; i < NCH; ++i) sk[i] = (o0 + i < e.C_out) ? to_f32<TO>(resn[off + i]) : 0.f;

@@ -25,10 +25,11 @@ struct MlpParams {
   int C_in, C_hid, C_out, HC;   // HC = C_hid / 32
 };
 
-template <int KS_IN, int MO, int NT>
+template <int KS_IN, int MO, int NT, bool FAST_GELU>
 __global__ void __launch_bounds__(256)
 pw_mlp_kernel(MlpParams p) {
   static_assert(MO % 2 == 0, "C_out must be a multiple of 32");
+  constexpr bool PREFETCH_RES = (MO / 2) * NT <= 4;   // residual rows ride along with the input loads
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = blockIdx.y;
   const long row0 = ((long)blockIdx.x * 4 + wave) * (NT * 16);
@@ -60,6 +61,20 @@ pw_mlp_kernel(MlpParams p) {
       for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], av[j], bv[j]);
       bact[ks][nt] = Mma<bf16_t>::from_floats(v);
     }
+  }
+
+  // ---- residual / skip rows: issue their loads now so they are in flight during both GEMMs
+  uint4 rpre[PREFETCH_RES ? MO / 2 : 1][PREFETCH_RES ? NT : 1];
+  const bool use_pre = PREFETCH_RES && p.e.res_mode != PYTC_RES_NONE;
+  if (use_pre) {
+    const bf16_t* resn = reinterpret_cast<const bf16_t*>(p.e.res) + (long)n * p.rps * p.C_out;
+#pragma unroll
+    for (int pr = 0; pr < (PREFETCH_RES ? MO / 2 : 1); ++pr)
+#pragma unroll
+      for (int nt = 0; nt < (PREFETCH_RES ? NT : 1); ++nt) {
+        const long rr = orow[nt] < p.rps ? orow[nt] : p.rps - 1;
+        rpre[pr][nt] = *reinterpret_cast<const uint4*>(resn + rr * p.C_out + pr * 32 + kb * 8);
+      }
   }
 
   // ---- GEMM2 accumulators start from the projection bias (8 consecutive channels per lane per pair)
@@ -102,8 +117,8 @@ pw_mlp_kernel(MlpParams p) {
       float g[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        g[j] = gelu_erf(acc1[0][nt][j]);
-        g[4 + j] = gelu_erf(acc1[1][nt][j]);
+        g[j] = FAST_GELU ? gelu_fast(acc1[0][nt][j]) : gelu_erf(acc1[0][nt][j]);
+        g[4 + j] = FAST_GELU ? gelu_fast(acc1[1][nt][j]) : gelu_erf(acc1[1][nt][j]);
       }
       bh[nt] = Mma<bf16_t>::from_floats(g);
     }
@@ -127,7 +142,13 @@ pw_mlp_kernel(MlpParams p) {
         v[j] = acc2[2 * pr][nt][j];
         v[4 + j] = acc2[2 * pr + 1][nt][j];
       }
-      finish_and_store<bf16_t, 8>(v, p.e, n, orow[nt], pr * 32 + kb * 8);
+      if (use_pre) {
+        float pre[8];
+        VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(&rpre[PREFETCH_RES ? pr : 0][PREFETCH_RES ? nt : 0]), pre);
+        finish_and_store<bf16_t, 8>(v, p.e, n, orow[nt], pr * 32 + kb * 8, pre);
+      } else {
+        finish_and_store<bf16_t, 8>(v, p.e, n, orow[nt], pr * 32 + kb * 8);
+      }
     }
   }
 }
@@ -154,14 +175,22 @@ template <int KS_IN, int MO, int NT>
 static void launch_mlp(const MlpParams& p, int N, hipStream_t s) {
   long rows_per_block = 4L * NT * 16;
   dim3 grid((unsigned)((p.rps + rows_per_block - 1) / rows_per_block), (unsigned)N), block(256);
-  hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT>), grid, block, 0, s, p);
+  if (tuning_get("mlp_exact_gelu", 0))
+    hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT, false>), grid, block, 0, s, p);
+  else
+    hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT, true>), grid, block, 0, s, p);
 }
 
 // (C_in/32, C_out/16) pairs that occur in MedNeXt with 32 base channels: same-res, down (x2), up (/2)
 static bool dispatch_mlp(const MlpParams& p, int N, hipStream_t s) {
   const int ks = p.C_in / 32, mo = p.C_out / 16;
+  const int variant = tuning_get("mlp_variant", 0);
 #define PYTC_MLP_CASE(KS, MOO, NTT) \
   if (ks == KS && mo == MOO) { launch_mlp<KS, MOO, NTT>(p, N, s); return true; }
+  // voxel tiles per wave (NT) chosen per shape from tools/kbench.py measurements on MI355X
+  if (!(variant & 1)) { PYTC_MLP_CASE(2, 4, 2) }
+  if (variant & 2) { PYTC_MLP_CASE(1, 2, 2) PYTC_MLP_CASE(2, 2, 2) }
+  if (variant & 4) { PYTC_MLP_CASE(1, 4, 2) }
   PYTC_MLP_CASE(1, 2, 4)
   PYTC_MLP_CASE(1, 4, 4)
   PYTC_MLP_CASE(2, 2, 4)

@@ -25,6 +25,7 @@ constexpr int WAVE = 64;
 // ---- last-error plumbing (thread local; the ABI returns an int status) -----------------
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
+int tuning_get(const char* key, int dflt);
 
 #define PYTC_REQUIRE(cond, ...)                     \
   do {                                              \
@@ -114,6 +115,27 @@ __device__ __forceinline__ float gelu_erf(float x) {
   const float pe = p * __builtin_amdgcn_exp2f(-az * az * 1.44269504088896340736f);
   const float one_plus_erf = x < 0.f ? pe : 2.0f - pe;
   return 0.5f * x * one_plus_erf;
+}
+
+// Sigmoid-form GELU for the bf16 fast path:  x * sigmoid(x * (a + b x^2 + c x^4)), minimax fit of the erf
+// GELU on [-8, 8] (max abs error 2.5e-5, i.e. far below the bf16 rounding of the activation it feeds);
+// x^2 is clamped at 64 so the odd polynomial keeps its sign outside the fitted range (sigmoid is saturated
+// there).  7 VALU + v_exp_f32 + v_rcp_f32, about half the cost of gelu_erf.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float x2 = fminf(x * x, 64.0f);
+  // coefficients pre-multiplied by -log2(e)
+  float p = fmaf(x2, 1.0142630e-3f, -1.0677572e-1f);
+  p = fmaf(p, x2, -2.3011213f);
+  const float e = __builtin_amdgcn_exp2f(x * p);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// Bijective XCD-aware remap of a 1-D block index: hardware places block b on XCD b % 8, so logical
+// neighbours (which share halos / operand panels) are given to the SAME XCD's L2, in dispatch order.
+__device__ __forceinline__ int xcd_swizzle(int b, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7;
+  const int xcd = b & 7, idx = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -92,9 +92,17 @@ def test_eager_engine_determinism_and_identity_property(dev):
     a = eng(x, lambda t: t)
     b = eng(x, lambda t: t)
     assert torch.equal(a, b)                     # race-free by construction
-    assert torch.allclose(a, x, atol=1e-5)       # identity network + weighted mean reproduces the input
+    # identity network + weighted mean reproduces the input wherever the accumulated weight clears the
+    # 1e-4 normalisation floor (volume faces are deliberately driven towards 0, window.py:275-294)
+    assert torch.allclose(a[..., 4:-4, 4:-4, 4:-4], x[..., 4:-4, 4:-4, 4:-4], atol=1e-5)
     ref = WO.eager_sliding_window(x.cpu(), lambda t: t, roi=(32, 32, 32), overlap=0.5, mode="bump", sw_batch_size=8)
-    assert torch.equal(a.cpu(), ref)             # bit-exact vs the oracle
+    # the bump table goes through the host libm (numpy in the oracle, torch in the product): last-ulp slack
+    torch.testing.assert_close(a.cpu(), ref, rtol=2e-6, atol=1e-7)
+    eng_c = EagerSlidingWindowEngine(roi_size=(32, 32, 32), sw_batch_size=8, overlap=0.5, mode="constant",
+                                     padding_mode="constant", cval=0.0)
+    ref_c = WO.eager_sliding_window(x.cpu(), lambda t: t * 3 - 1, roi=(32, 32, 32), overlap=0.5, mode="constant",
+                                    sw_batch_size=8)
+    assert torch.equal(eng_c(x, lambda t: t * 3 - 1).cpu(), ref_c)   # same fp32 op order -> bit exact
 
 
 def test_normalize_matches_reference(dev, golden_dir):
