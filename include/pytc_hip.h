@@ -85,17 +85,27 @@ int pytc_gather_windows(const float* vol, int C, int Z, int Y, int X, const int3
  *   pred   [B][rz][ry][rx][C] in pred_dtype (network output, NDHWC)
  *   wz/wy/wx fp32 per-axis blending factors (device), combined by `combine`, floored by `floor_w`
  *   value  fp32 [C][Z][Y][X]  +=  pred * w      weight fp32 [Z][Y][X] += w  (if weight != NULL)
- * Voxels falling outside [0,Z)x[0,Y)x[0,X) are skipped. */
+ * Voxels falling outside [0,Z)x[0,Y)x[0,X) are skipped (this is how region / chunk accumulators clip the
+ * global window grid, inference/lazy.py:1069-1099).  `border` zeroes the outer voxels of the window map
+ * (host int32[3]; apply_border_mask, inference/window.py:297-319). */
 int pytc_blend_accumulate(const void* pred, int pred_dtype, int B, const int32_t* starts, int rz,
                           int ry, int rx, int C, int view, const float* wz, const float* wy,
-                          const float* wx, int combine, float floor_w, float* value, float* weight,
-                          int Z, int Y, int X, void* stream);
+                          const float* wx, int combine, float floor_w, const int32_t* border /*[3] or NULL*/,
+                          float* value, float* weight, int Z, int Y, int X, void* stream);
 
 /* value[c][i] = act(value[c][i] / max(weight[i], clamp)), in place.  Replaces
  * normalize_weighted_accumulator (inference/window.py:275-294) + the sigmoid/tanh of
  * apply_preprocessing (inference/tta.py:312-402). */
 int pytc_blend_finalize(float* value, const float* weight, int C, int64_t nvox, float clamp,
                         int act, void* stream);
+
+/* In-place activation of channels [c0, c1) of a fp32 volume laid out [C][nvox] (channels_last = 0) or
+ * [nvox][C] (channels_last = 1, window predictions): v = act(scale * v) with act in
+ * {NONE, SIGMOID, TANH} or PYTC_ACT_SOFTMAX (across the channel group, scale ignored).  Replaces
+ * TTAPredictor.apply_preprocessing (inference/tta.py:312-402: sigmoid / scale_sigmoid:<t> / tanh / softmax). */
+#define PYTC_ACT_SOFTMAX 4
+int pytc_channel_activation(float* value, int C, int64_t nvox, int channels_last, int c0, int c1, int act,
+                            float scale, void* stream);
 
 /* out = running ensemble update over TTA views (inference/tta_ensemble.py:85-101):
  * mode 0 mean: acc += (x - acc) / count ; mode 1 min ; mode 2 max.  n elements fp32. */

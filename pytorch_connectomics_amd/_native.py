@@ -17,7 +17,7 @@ OK = 0
 VIEW_FLIP_Z, VIEW_FLIP_Y, VIEW_FLIP_X, VIEW_SWAP_YX = 1, 2, 4, 8
 PAD_MODES = {"constant": 0, "reflect": 1, "replicate": 2, "circular": 3}
 BLEND_PRODUCT, BLEND_MIN = 0, 1
-ACT_NONE, ACT_SIGMOID, ACT_TANH, ACT_GELU = 0, 1, 2, 3
+ACT_NONE, ACT_SIGMOID, ACT_TANH, ACT_GELU, ACT_SOFTMAX = 0, 1, 2, 3, 4
 RES_NONE, RES_ADD, RES_UPSAMPLE = 0, 1, 2
 
 
@@ -55,8 +55,11 @@ _SIGS = {
                                       C.c_void_p, C.c_int, C.c_void_p]),
     "pytc_blend_accumulate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                        C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                                        C.c_float, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                        C.c_int, C.c_void_p]),
     "pytc_blend_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
+    "pytc_channel_activation": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_float, C.c_void_p]),
     "pytc_ensemble_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "pytc_dwconv3d_stat_slots": (C.c_int, [C.c_int] * 9),
     "pytc_dwconv3d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8

@@ -84,7 +84,7 @@ template <typename TP>
 __global__ void __launch_bounds__(256)
 blend_accumulate_kernel(const TP* __restrict__ pred, int sz, int sy, int sx, int rz, int ry, int rx,
                         int C, int view, const float* __restrict__ wzv, const float* __restrict__ wyv,
-                        const float* __restrict__ wxv, int combine, float floor_w,
+                        const float* __restrict__ wxv, int combine, float floor_w, int bz, int by, int bx,
                         float* __restrict__ value, float* __restrict__ weight, int Z, int Y, int X) {
   const long per_win = (long)rz * ry * rx;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -106,6 +106,9 @@ blend_accumulate_kernel(const TP* __restrict__ pred, int sz, int sy, int sx, int
     w = fmaxf(w, 1.17549435e-38f);
     w = fmaxf(w, floor_w);
   }
+  // border mask: the outer b voxels of the window map are exactly zero (window.py:297-319, applied after
+  // the floors in the lazy path)
+  if (wz < bz || wz >= rz - bz || wy < by || wy >= ry - by || wx < bx || wx >= rx - bx) w = 0.f;
   const long plane = (long)Z * Y * X;
   long dst = ((long)gz * Y + gy) * X + gx;
   const TP* p = pred + i * C;
@@ -147,9 +150,45 @@ ensemble_update_kernel(float* __restrict__ acc, const float* __restrict__ x, lon
   }
 }
 
+// value [C][nvox]; channels [c0, c1): act in place.  softmax runs across the channel group per voxel.
+__global__ void __launch_bounds__(256)
+channel_activation_kernel(float* __restrict__ value, long nvox, long cs, long vs, int c0, int c1, int act,
+                          float scale) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < nvox; i += stride) {
+    if (act == 4) {   // softmax over [c0, c1)
+      float m = -3.402823466e38f;
+      for (int c = c0; c < c1; ++c) m = fmaxf(m, value[c * cs + i * vs]);
+      float s = 0.f;
+      for (int c = c0; c < c1; ++c) s += expf(value[c * cs + i * vs] - m);
+      for (int c = c0; c < c1; ++c) value[c * cs + i * vs] = expf(value[c * cs + i * vs] - m) / s;
+    } else {
+      for (int c = c0; c < c1; ++c) {
+        float v = value[c * cs + i * vs] * scale;
+        if (act == PYTC_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+        else if (act == PYTC_ACT_TANH) v = tanhf(v);
+        value[c * cs + i * vs] = v;
+      }
+    }
+  }
+}
+
 }  // namespace pytc
 
 using namespace pytc;
+
+extern "C" int pytc_channel_activation(float* value, int C, int64_t nvox, int channels_last, int c0, int c1, int act,
+                                       float scale, void* stream) {
+  PYTC_REQUIRE(value && C >= 1 && nvox > 0 && c0 >= 0 && c1 <= C && c0 < c1, "channel_activation: bad arguments");
+  PYTC_REQUIRE(act == PYTC_ACT_NONE || act == PYTC_ACT_SIGMOID || act == PYTC_ACT_TANH || act == 4,
+               "channel_activation: bad activation %d", act);
+  int blocks = (int)((nvox + 255) / 256 < 8192 ? (nvox + 255) / 256 : 8192);
+  hipLaunchKernelGGL(channel_activation_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, value, (long)nvox,
+                     channels_last ? 1L : (long)nvox, channels_last ? (long)C : 1L, c0, c1, act, scale);
+  PYTC_LAUNCH_CHECK("channel_activation");
+  return PYTC_OK;
+}
 
 extern "C" int pytc_gather_windows(const float* vol, int C, int Z, int Y, int X, const int32_t* starts,
                                    int B, int rz, int ry, int rx, int view, int pad_mode, float cval,
@@ -178,8 +217,8 @@ extern "C" int pytc_gather_windows(const float* vol, int C, int Z, int Y, int X,
 
 extern "C" int pytc_blend_accumulate(const void* pred, int pred_dtype, int B, const int32_t* starts, int rz,
                                      int ry, int rx, int C, int view, const float* wz, const float* wy,
-                                     const float* wx, int combine, float floor_w, float* value,
-                                     float* weight, int Z, int Y, int X, void* stream) {
+                                     const float* wx, int combine, float floor_w, const int32_t* border,
+                                     float* value, float* weight, int Z, int Y, int X, void* stream) {
   PYTC_REQUIRE(pred && starts && wz && wy && wx && value, "blend_accumulate: null pointer");
   PYTC_REQUIRE(B >= 1 && C >= 1, "blend_accumulate: bad B/C");
   PYTC_REQUIRE(!(view & PYTC_VIEW_SWAP_YX) || ry == rx, "blend_accumulate: SWAP_YX needs ry == rx");
@@ -187,16 +226,19 @@ extern "C" int pytc_blend_accumulate(const void* pred, int pred_dtype, int B, co
   long per_win = (long)rz * ry * rx;
   dim3 grid(ceil_div(per_win, 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
+  const int bz = border ? border[0] : 0, by = border ? border[1] : 0, bx = border ? border[2] : 0;
+  PYTC_REQUIRE(bz >= 0 && by >= 0 && bx >= 0 && 2 * bz < rz && 2 * by < ry && 2 * bx < rx,
+               "blend_accumulate: border mask too large for the window");
   for (int b = 0; b < B; ++b) {
     int sz = starts[3 * b], sy = starts[3 * b + 1], sx = starts[3 * b + 2];
     if (pred_dtype == PYTC_F32)
       hipLaunchKernelGGL(blend_accumulate_kernel<float>, grid, block, 0, s,
                          (const float*)pred + (long)b * per_win * C, sz, sy, sx, rz, ry, rx, C, view, wz, wy, wx,
-                         combine, floor_w, value, weight, Z, Y, X);
+                         combine, floor_w, bz, by, bx, value, weight, Z, Y, X);
     else if (pred_dtype == PYTC_BF16)
       hipLaunchKernelGGL(blend_accumulate_kernel<bf16_t>, grid, block, 0, s,
                          (const bf16_t*)pred + (long)b * per_win * C, sz, sy, sx, rz, ry, rx, C, view, wz, wy, wx,
-                         combine, floor_w, value, weight, Z, Y, X);
+                         combine, floor_w, bz, by, bx, value, weight, Z, Y, X);
     else
       PYTC_REQUIRE(false, "blend_accumulate: bad pred_dtype %d", pred_dtype);
   }

@@ -120,7 +120,7 @@ def gather_windows(vol: torch.Tensor, starts, roi, *, view: int = 0, pad_mode: s
 
 def blend_accumulate(pred: torch.Tensor, starts, value: torch.Tensor, weight: Optional[torch.Tensor],
                      wz: torch.Tensor, wy: torch.Tensor, wx: torch.Tensor, *, view: int = 0,
-                     combine: int = nat.BLEND_PRODUCT, floor_w: float = 1e-5) -> None:
+                     combine: int = nat.BLEND_PRODUCT, floor_w: float = 1e-5, border=None) -> None:
     """pred (B, rz, ry, rx, C) NDHWC; value (C,Z,Y,X) += pred*w; weight (Z,Y,X) += w."""
     _dev(pred, "pred"); _dev(value, "value")
     B, rz, ry, rx, Cc = pred.shape
@@ -128,10 +128,11 @@ def blend_accumulate(pred: torch.Tensor, starts, value: torch.Tensor, weight: Op
         raise ValueError("value accumulator must be float32 (C, Z, Y, X) with C matching pred")
     _, Z, Y, X = value.shape
     st = _starts_array(starts)
+    bd = (C.c_int32 * 3)(*[int(v) for v in border]) if border else None
     win = B * rz * ry * rx
     _run("blend_accumulate", _nbytes(pred) + win * 4 * (2 * Cc + (2 if weight is not None else 0)),
          nat.lib().pytc_blend_accumulate, _p(pred), dtype_code(pred.dtype), B, st, rz, ry, rx, Cc, int(view),
-         _p(wz), _p(wy), _p(wx), int(combine), float(floor_w), _p(value), _p(weight), Z, Y, X, _stream())
+         _p(wz), _p(wy), _p(wx), int(combine), float(floor_w), bd, _p(value), _p(weight), Z, Y, X, _stream())
 
 
 def blend_finalize(value: torch.Tensor, weight: torch.Tensor, *, clamp: float = 1e-4, act: int = nat.ACT_NONE) -> None:
@@ -140,6 +141,18 @@ def blend_finalize(value: torch.Tensor, weight: torch.Tensor, *, clamp: float = 
     nvox = weight.numel()
     _run("blend_finalize", 2 * _nbytes(value) + _nbytes(weight), nat.lib().pytc_blend_finalize, _p(value),
          _p(weight), Cc, nvox, float(clamp), int(act), _stream())
+
+
+def channel_activation(value: torch.Tensor, c0: int, c1: int, act: int, scale: float = 1.0, *,
+                       channels_last: bool = False) -> None:
+    """value fp32, (C, *spatial) or (*, C) when channels_last: channels [c0, c1) <- act(scale * v) in place."""
+    _dev(value, "value")
+    if value.dtype != torch.float32:
+        raise TypeError("channel_activation works on float32 volumes")
+    Cc = value.shape[-1] if channels_last else value.shape[0]
+    nvox = value.numel() // Cc
+    _run("channel_activation", 2 * nvox * 4 * (c1 - c0), nat.lib().pytc_channel_activation, _p(value), Cc, nvox,
+         int(channels_last), int(c0), int(c1), int(act), float(scale), _stream())
 
 
 def ensemble_update(acc: torch.Tensor, x: torch.Tensor, mode: int, count: int) -> None:

@@ -1,0 +1,271 @@
+"""Region / whole-volume sliding-window inference from the GLOBAL window grid -- counterpart of the engine
+half of the reference's connectomics/inference/lazy.py (_snap_offsets :269-284, _build_window_axis_offsets
+:307-334, _build_intersecting_window_slices :337-365, _resolve_target_context :368-386,
+_lazy_sliding_window :986-1258, lazy_predict_region :1261, lazy_predict_volume :1295).
+
+Semantics kept: boundary windows centred on the volume faces (offsets from -border_pad, border_pad =
+roi - stride), snap_to_edge stride = int(roi*(1-overlap)), per-window outer padding by `padding_mode`,
+activation / channel selection applied to each window BEFORE blending, optional target_context (predict
+roi + 2*ctx, keep the centre) and border_mask, only the intersection with the requested region is
+accumulated -- so a chunk's prediction equals the matching slice of the whole-volume prediction.
+
+MI355X design: the source volume (numpy / memmap / tensor; host or device) is brought to HBM once per region
+(the bounding box of the intersecting windows), windows are gathered / blended by the HIP kernels and the
+fp32 accumulators never leave the device.  Disk readers (h5/zarr/tiff) are out of scope for round 1.
+"""
+from __future__ import annotations
+
+import itertools
+import logging
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from .. import hip_ops as ops
+from ..utils.channel_slices import resolve_channel_indices
+from ..utils.model_outputs import get_inference_channel_activations, get_inference_select_channel, select_output_tensor
+from .window import (_axis_kernels, compute_scan_interval, resolve_border_mask,
+                     resolve_inferer_overlap, resolve_inferer_roi_size, resolve_model_output_dtype)
+
+logger = logging.getLogger(__name__)
+
+
+def _coerce_overlap(overlap, spatial_dims: int) -> tuple[float, ...]:
+    if isinstance(overlap, (list, tuple)):
+        if len(overlap) != spatial_dims:
+            raise ValueError(f"Overlap rank mismatch: expected {spatial_dims} values, got {overlap}.")
+        return tuple(float(v) for v in overlap)
+    return tuple(float(overlap) for _ in range(spatial_dims))
+
+
+def _snap_offsets(image_size: int, roi_size: int, stride: int, *, border_pad: int = 0) -> list[int]:
+    if image_size <= roi_size:
+        return [0]
+    stride = max(1, stride)
+    lo, hi = -int(border_pad), image_size - roi_size + int(border_pad)
+    offs = list(range(lo, hi + 1, stride))
+    if not offs or offs[-1] != hi:
+        offs.append(hi)
+    return offs
+
+
+def _build_window_axis_offsets(image_size, roi_size, overlap, *, snap_to_edge: bool) -> list[list[int]]:
+    if snap_to_edge:
+        strides = tuple(max(1, int(int(roi_size[a]) * (1.0 - float(overlap[a])))) for a in range(3))
+    else:
+        strides = compute_scan_interval(tuple(int(v) for v in image_size), tuple(int(v) for v in roi_size),
+                                        overlap=tuple(float(v) for v in overlap))
+    return [_snap_offsets(int(image_size[a]), int(roi_size[a]), int(strides[a]),
+                          border_pad=max(0, int(roi_size[a]) - int(strides[a]))) for a in range(3)]
+
+
+def _build_window_slices(image_size, roi_size, overlap, *, snap_to_edge: bool):
+    offs = _build_window_axis_offsets(image_size, roi_size, overlap, snap_to_edge=snap_to_edge)
+    return [tuple(slice(int(s[a]), int(s[a]) + int(roi_size[a])) for a in range(3)) for s in itertools.product(*offs)]
+
+
+def _build_intersecting_window_slices(image_size, roi_size, overlap, *, region_start, region_stop, snap_to_edge: bool):
+    offs = _build_window_axis_offsets(image_size, roi_size, overlap, snap_to_edge=snap_to_edge)
+    keep = [[o for o in offs[a] if o < int(region_stop[a]) and o + int(roi_size[a]) > int(region_start[a])]
+            for a in range(3)]
+    return [tuple(slice(int(s[a]), int(s[a]) + int(roi_size[a])) for a in range(3)) for s in itertools.product(*keep)]
+
+
+def _resolve_target_context(sliding_cfg, roi_size) -> tuple[int, int, int]:
+    ctx = list(getattr(sliding_cfg, "target_context", []) or [])
+    if not ctx:
+        return (0, 0, 0)
+    if len(ctx) == 1:
+        ctx = ctx * 3
+    if len(ctx) != 3:
+        raise ValueError(f"inference.sliding_window.target_context must have length 1 or 3, got {ctx}.")
+    ctx = tuple(int(v) for v in ctx)
+    if any(v < 0 for v in ctx):
+        raise ValueError(f"inference.sliding_window.target_context values must be non-negative, got {ctx}.")
+    return ctx
+
+
+def get_lazy_image_reference_shape(volume) -> tuple[int, int, int]:
+    return tuple(int(v) for v in volume.shape[-3:])
+
+
+def _as_channel_first(volume):
+    if volume.ndim == 3:
+        return volume[None]
+    if volume.ndim == 5 and volume.shape[0] == 1:
+        return volume[0]
+    if volume.ndim != 4:
+        raise ValueError(f"volume must be (Z,Y,X), (C,Z,Y,X) or (1,C,Z,Y,X); got shape {tuple(volume.shape)}")
+    return volume
+
+
+def _window_preprocess(cfg, pred_cl: torch.Tensor) -> torch.Tensor:
+    """Activations + channel selection on a channels-last window batch (lazy path: BEFORE blending)."""
+    pred_cl = pred_cl.float() if pred_cl.dtype != torch.float32 else pred_cl
+    C = int(pred_cl.shape[-1])
+    for entry in get_inference_channel_activations(cfg):
+        ch = entry.get("channels", ":") if isinstance(entry, dict) else getattr(entry, "channels", ":")
+        act = entry.get("activation") if isinstance(entry, dict) else getattr(entry, "activation", None)
+        idx = resolve_channel_indices(ch, num_channels=C, context="inference.model.channel_activations channels")
+        if act is None or (isinstance(act, str) and act.lower() == "none"):
+            continue
+        scale = 1.0
+        if act == "sigmoid":
+            code = nat.ACT_SIGMOID
+        elif isinstance(act, str) and act.startswith("scale_sigmoid"):
+            code, scale = nat.ACT_SIGMOID, (float(act.split(":", 1)[1]) if ":" in act else 0.2)
+        elif act == "tanh":
+            code = nat.ACT_TANH
+        elif act == "softmax":
+            if len(idx) <= 1:
+                continue
+            code = nat.ACT_SOFTMAX
+        else:
+            raise ValueError(f"Unknown activation '{act}' for channels {idx}.")
+        contiguous = idx == list(range(idx[0], idx[-1] + 1))
+        groups = [(idx[0], idx[-1] + 1)] if contiguous else [(c, c + 1) for c in idx]
+        if code == nat.ACT_SOFTMAX and not contiguous:
+            raise NotImplementedError("softmax over a non-contiguous channel list is not supported on device")
+        for a, b in groups:
+            ops.channel_activation(pred_cl, a, b, code, scale, channels_last=True)
+    sel = get_inference_select_channel(cfg)
+    if sel is not None:
+        idx = resolve_channel_indices(sel, num_channels=C, context="inference.model.select_channel")
+        if idx != list(range(C)):
+            pred_cl = pred_cl[..., idx].contiguous()
+    return pred_cl
+
+
+@torch.no_grad()
+def _lazy_sliding_window(cfg, forward_fn, volume, *, region_start, region_stop, device, requested_head=None,
+                         window_filter: Optional[Callable[[int, int], bool]] = None,
+                         return_accumulators: bool = False):
+    roi = resolve_inferer_roi_size(cfg)
+    if roi is None:
+        raise ValueError("Lazy sliding-window inference requires inference.sliding_window.window_size "
+                         "or model.output_size to be configured.")
+    if len(roi) != 3:
+        raise ValueError(f"Lazy sliding-window inference currently supports 3D only, got {roi}.")
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("lazy sliding-window inference (pytorch_connectomics_amd) needs a CUDA(HIP) device: "
+                           "there is no CPU path")
+    overlap = _coerce_overlap(resolve_inferer_overlap(cfg, roi), 3)
+    sw = getattr(getattr(cfg, "inference", None), "sliding_window", None)
+    dl = getattr(getattr(cfg, "data", None), "dataloader", None)
+    swb = max(1, int(getattr(sw, "sw_batch_size", None) or getattr(dl, "batch_size", 1)))
+    blend = str(getattr(sw, "blending", "bump")).strip().lower()
+    pad_mode = getattr(sw, "padding_mode", "constant")
+    cval = float(getattr(sw, "cval", 0.0))
+    snap = bool(getattr(sw, "snap_to_edge", False))
+    ctx = _resolve_target_context(sw, roi)
+    border = resolve_border_mask(cfg, 3) or None
+    primary = getattr(getattr(cfg, "model", None), "primary_head", None)
+
+    vol = _as_channel_first(volume)
+    bounds = tuple(int(v) for v in vol.shape[1:])
+    if any(bounds[a] < int(roi[a]) for a in range(3)):
+        raise ValueError("Lazy sliding-window inference requires the transformed test volume to be at least as "
+                         f"large as the ROI in every axis. Got bounds_shape={bounds}, roi_size={tuple(roi)}.")
+    start = (0, 0, 0) if region_start is None else tuple(max(0, int(v)) for v in region_start)
+    stop = bounds if region_stop is None else tuple(min(bounds[a], int(region_stop[a])) for a in range(3))
+    if any(stop[a] <= start[a] for a in range(3)):
+        raise ValueError(f"Empty lazy inference region: start={start}, stop={stop}")
+    out_size = tuple(stop[a] - start[a] for a in range(3))
+
+    wins = [tuple(int(s.start) for s in sl) for sl in _build_intersecting_window_slices(
+        bounds, roi, overlap, region_start=start, region_stop=stop, snap_to_edge=snap)]
+    if window_filter is not None:
+        wins = [w for i, w in enumerate(wins) if window_filter(i, len(wins))]
+    if not wins:
+        raise RuntimeError("No lazy sliding-window patches were generated for this region.")
+
+    # bring the bounding box of everything the windows read (incl. context) into HBM once
+    read = tuple(int(roi[a]) + 2 * ctx[a] for a in range(3))
+    lo = tuple(max(0, min(w[a] for w in wins) - ctx[a]) for a in range(3))
+    hi = tuple(min(bounds[a], max(w[a] for w in wins) + int(roi[a]) + ctx[a]) for a in range(3))
+    sub = vol[:, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+    if isinstance(sub, np.ndarray):
+        sub = torch.from_numpy(np.ascontiguousarray(sub, dtype=np.float32))
+    sub = sub.to(device=dev, dtype=torch.float32).contiguous()
+    box = tuple(int(v) for v in sub.shape[1:])
+
+    ks, combine = _axis_kernels(roi, blend, torch.float32)
+    wz, wy, wx = (k.to(dev).contiguous() for k in ks)
+    value = None
+    weight = torch.zeros(out_size, dtype=torch.float32, device=dev)
+    fwd_cl = getattr(getattr(forward_fn, "__self__", None), "forward_cl", None) if requested_head is None else None
+
+    for b0 in range(0, len(wins), swb):
+        chunk = wins[b0:b0 + swb]
+        # windows overhang the box only where the box touches the volume border; the kernel's periodic
+        # reflect / replicate / circular index math equals the np.pad semantics of the reference reader
+        rel = [tuple(w[a] - ctx[a] - lo[a] for a in range(3)) for w in chunk]
+        x = ops.gather_windows(sub, rel, read, pad_mode=pad_mode, cval=cval)
+        if fwd_cl is not None:
+            pred = fwd_cl(x)
+        else:
+            xin = x.permute(0, 4, 1, 2, 3)
+            out = forward_fn(xin if x.shape[-1] == 1 else xin.contiguous())
+            out, _ = select_output_tensor(out, requested_head=requested_head, primary_head=primary,
+                                          purpose="inference output selection")
+            pred = out.permute(0, 2, 3, 4, 1).contiguous()
+        if tuple(pred.shape[1:4]) != read:
+            scope = "Lazy sliding-window inference"
+            if any(ctx):
+                raise RuntimeError(f"{scope} with target_context={ctx} expected prediction spatial shape {read}, "
+                                   f"got {tuple(pred.shape[1:4])}.")
+            raise RuntimeError(f"{scope} requires model predictions to have the same spatial shape as the "
+                               f"sliding-window ROI. Got prediction.shape={tuple(pred.shape)} and roi_size={tuple(roi)}.")
+        if any(ctx):
+            pred = pred[:, ctx[0]:ctx[0] + roi[0], ctx[1]:ctx[1] + roi[1], ctx[2]:ctx[2] + roi[2]].contiguous()
+        pred = _window_preprocess(cfg, pred.contiguous())
+        if value is None:
+            value = torch.zeros((int(pred.shape[-1]),) + out_size, dtype=torch.float32, device=dev)
+        rel_starts = [tuple(w[a] - start[a] for a in range(3)) for w in chunk]
+        ops.blend_accumulate(pred, rel_starts, value, weight, wz, wy, wx, combine=combine, floor_w=1e-5, border=border)
+    if return_accumulators:
+        return value, weight
+    ops.blend_finalize(value, weight, clamp=1e-4, act=nat.ACT_NONE)
+    out = value.unsqueeze(0)
+    odt = resolve_model_output_dtype(cfg)
+    return out if odt == torch.float32 else out.to(odt)
+
+
+def lazy_predict_region(cfg, forward_fn, volume, *, region_start: Sequence[int], region_stop: Sequence[int],
+                        device="cuda", requested_head: Optional[str] = None) -> torch.Tensor:
+    """Predict one bounded ZYX region of `volume`; windows come from the full-volume grid, so region borders
+    see real neighbouring data wherever they are not true volume borders.  Returns (1, C, *region) on device."""
+    return _lazy_sliding_window(cfg, forward_fn, volume, region_start=region_start, region_stop=region_stop,
+                                device=device, requested_head=requested_head)
+
+
+def lazy_predict_volume(cfg, forward_fn, volume, *, device="cuda", requested_head: Optional[str] = None) -> torch.Tensor:
+    """Whole-volume variant.  With inference.sliding_window.distributed_sharding and an initialised process
+    group, windows are sharded [rank::world] and value / weight accumulators are summed onto rank 0 with one
+    RCCL reduce each (reference lazy.py:1104-1110, lazy_distributed.py:78-107); other ranks get an empty tensor."""
+    sw = getattr(getattr(cfg, "inference", None), "sliding_window", None)
+    dist_on = (bool(getattr(sw, "distributed_sharding", False)) and torch.distributed.is_available()
+               and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1)
+    if not dist_on:
+        return _lazy_sliding_window(cfg, forward_fn, volume, region_start=None, region_stop=None, device=device,
+                                    requested_head=requested_head)
+    rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+    value, weight = _lazy_sliding_window(cfg, forward_fn, volume, region_start=None, region_stop=None, device=device,
+                                         requested_head=requested_head, return_accumulators=True,
+                                         window_filter=lambda i, n: i % world == rank)
+    torch.distributed.reduce(value, dst=0, op=torch.distributed.ReduceOp.SUM)
+    torch.distributed.reduce(weight, dst=0, op=torch.distributed.ReduceOp.SUM)
+    if rank != 0:
+        return torch.empty(0, device=value.device)
+    ops.blend_finalize(value, weight, clamp=1e-4, act=nat.ACT_NONE)
+    out = value.unsqueeze(0)
+    odt = resolve_model_output_dtype(cfg)
+    return out if odt == torch.float32 else out.to(odt)
+
+
+__all__ = ["lazy_predict_region", "lazy_predict_volume", "get_lazy_image_reference_shape",
+           "_build_window_axis_offsets", "_build_window_slices", "_build_intersecting_window_slices",
+           "_snap_offsets", "_resolve_target_context"]

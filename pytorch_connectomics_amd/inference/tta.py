@@ -1,0 +1,292 @@
+"""Test-time augmentation + activation + channel selection on the device -- counterpart of the reference's
+connectomics/inference/tta.py (TTAPredictor :67, apply_preprocessing :312-402, _run_ensemble :691-769,
+_predict_prepared_tensor :806-878, _predict_patch_first_local :880-1314, predict :1619-1666).
+
+MI355X design: a TTA view is index math inside the gather / blend kernels (no flipped copies of the volume
+or of the predictions); each view gets one overlap-add pass over the SAME window grid into an HBM-resident
+accumulator (the reference's patch-first-local semantics), then normalise -> per-channel activation ->
+channel selection -> streaming mean/min/max ensemble, all as device kernels.
+
+Not built yet: affinity-aware channel remapping / validity boxes
+(inference/tta_affinity.py) and rot90 planes that involve z.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Any, Optional
+
+import torch
+
+from .. import _native as nat
+from .. import hip_ops as ops
+from ..utils.channel_slices import resolve_channel_indices
+from ..utils.model_outputs import (get_inference_channel_activations, get_inference_select_channel,
+                                   select_output_tensor)
+from .tta_combinations import (_resolve_ensemble_mode_map, _resolve_spatial_dims, apply_view,
+                               resolve_tta_augmentation_combinations)
+from .window import is_2d_inference_mode, resolve_model_output_dtype
+
+logger = logging.getLogger(__name__)
+
+_MODE_CODE = {"mean": 0, "min": 1, "max": 2}
+
+
+def view_code(flip_axes, rotation_plane, k: int) -> int:
+    """Map a reference view (flips, then rot90^k in `rotation_plane`; spatial axes 0=z,1=y,2=x) onto the
+    kernels' PYTC_VIEW_* encoding  out[z,y,x] = win[T(F(z,y,x))]  by matching its action on a probe."""
+    probe = torch.arange(2 * 3 * 3).reshape(2, 3, 3)
+    want = apply_view(probe, list(flip_axes or []), rotation_plane, int(k), first_spatial_dim=0)
+    if want.shape != probe.shape:
+        raise NotImplementedError(f"TTA rotation in plane {rotation_plane} changes the window shape; only "
+                                  "rotations in the (y, x) plane are supported by the device engine")
+    for code in range(16):
+        mine = probe.transpose(1, 2) if code & nat.VIEW_SWAP_YX else probe
+        dims = [d for d, bit in enumerate((nat.VIEW_FLIP_Z, nat.VIEW_FLIP_Y, nat.VIEW_FLIP_X)) if code & bit]
+        if dims:
+            mine = torch.flip(mine, dims)
+        if torch.equal(mine, want):
+            return code
+    raise NotImplementedError(f"TTA view (flip={flip_axes}, plane={rotation_plane}, k={k}) is not expressible as "
+                              "flips + a (y, x) transpose")
+
+
+class TTAPredictor:
+    """``predict(images)`` -> ensembled, activated, channel-selected prediction (1, C_sel, Z, Y, X)."""
+
+    def __init__(self, cfg, sliding_inferer, forward_fn, model=None):
+        self.cfg = cfg
+        self.sliding_inferer = sliding_inferer
+        self.forward_fn = forward_fn
+        self.model = model
+        self.channel_activation_types = None
+        self._requested_output_head_override: Optional[str] = None
+        self._last_distributed_sharding_active = False
+        self._last_skip_postprocess_on_rank = False
+
+    # ------------------------------------------------------------------ config helpers
+    def _get_tta_cfg(self):
+        return getattr(getattr(self.cfg, "inference", None), "test_time_augmentation", None)
+
+    def is_distributed_sharding_enabled(self) -> bool:
+        tta = self._get_tta_cfg()
+        is_dist = torch.distributed.is_available() and torch.distributed.is_initialized()
+        return bool(tta is not None and getattr(tta, "enabled", False) and getattr(tta, "distributed_sharding", False)
+                    and is_dist and torch.distributed.get_world_size() > 1)
+
+    def should_skip_postprocess_on_rank(self) -> bool:
+        return bool(self._last_skip_postprocess_on_rank)
+
+    def _select_channel_indices(self, num_channels: int):
+        sel = get_inference_select_channel(self.cfg)
+        if sel is None:
+            return None
+        return resolve_channel_indices(sel, num_channels=int(num_channels), context="inference.model.select_channel")
+
+    def _activation_specs(self, num_channels: int):
+        specs = []
+        for entry in get_inference_channel_activations(self.cfg):
+            ch = entry.get("channels", ":") if isinstance(entry, dict) else getattr(entry, "channels", ":")
+            act = entry.get("activation") if isinstance(entry, dict) else getattr(entry, "activation", None)
+            idx = resolve_channel_indices(ch, num_channels=num_channels,
+                                          context="inference.model.channel_activations channels")
+            specs.append((idx, act))
+        return specs
+
+    # ------------------------------------------------------------------ network plumbing
+    def _network_tensor(self, x: torch.Tensor) -> torch.Tensor:
+        outputs = self.forward_fn(x)
+        primary = getattr(getattr(self.cfg, "model", None), "primary_head", None)
+        out, _ = select_output_tensor(outputs, requested_head=self._requested_output_head_override,
+                                      primary_head=primary, purpose="inference output selection")
+        return out
+
+    def _engine_network(self):
+        """Callable handed to the window engine: the channels-last fast path when the wrapped model offers
+        one and no named head has to be selected, the generic NCDHW callable otherwise."""
+        m = self.model
+        if (m is not None and hasattr(m, "forward_cl") and self._requested_output_head_override is None
+                and getattr(self.forward_fn, "__self__", m) is m):
+            return m
+        return self._network_tensor
+
+    # ------------------------------------------------------------------ activation / selection (device)
+    def apply_preprocessing(self, volume: torch.Tensor) -> torch.Tensor:
+        """volume (1, C, Z, Y, X) fp32 on the device: per-channel activations in place, then channel
+        selection and the output dtype cast (reference tta.py:312-402)."""
+        if not hasattr(self.cfg, "inference"):
+            return volume
+        C = int(volume.shape[1])
+        types: list[Optional[str]] = [None] * C
+        v = volume[0]
+        for idx, act in self._activation_specs(C):
+            for c in idx:
+                types[c] = act
+            contiguous = idx == list(range(idx[0], idx[-1] + 1))
+            groups = [(idx[0], idx[-1] + 1)] if contiguous else [(c, c + 1) for c in idx]
+            if act is None or (isinstance(act, str) and act.lower() == "none"):
+                continue
+            if act == "sigmoid":
+                code, scale = nat.ACT_SIGMOID, 1.0
+            elif isinstance(act, str) and (act == "scale_sigmoid" or act.startswith("scale_sigmoid:")):
+                scale = 0.2
+                if ":" in act:
+                    try:
+                        scale = float(act.split(":", 1)[1])
+                    except ValueError as exc:
+                        raise ValueError(f"Invalid scale_sigmoid scale in '{act}'. "
+                                         "Expected 'scale_sigmoid:<float>'.") from exc
+                code = nat.ACT_SIGMOID
+            elif act == "tanh":
+                code, scale = nat.ACT_TANH, 1.0
+            elif act == "softmax":
+                if len(idx) <= 1:
+                    logger.warning(f"Softmax activation for single channel ({idx[0]}) is not meaningful. Skipping.")
+                    continue
+                if not contiguous:
+                    raise NotImplementedError("softmax over a non-contiguous channel list is not supported on device")
+                code, scale = nat.ACT_SOFTMAX, 1.0
+            else:
+                raise ValueError(f"Unknown activation '{act}' for channels {idx}. Supported: 'sigmoid', "
+                                 "'scale_sigmoid' (or 'scale_sigmoid:<float>'), 'softmax', 'tanh', None")
+            for a, b in groups:
+                ops.channel_activation(v, a, b, code, scale)
+        self.channel_activation_types = types if any(t is not None for t in types) else None
+        sel = self._select_channel_indices(C)
+        if sel is not None:
+            if sel != list(range(C)):
+                volume = volume[:, sel].contiguous()
+            if self.channel_activation_types is not None:
+                self.channel_activation_types = [self.channel_activation_types[i] for i in sel]
+        out_dtype = resolve_model_output_dtype(self.cfg)
+        if volume.dtype != out_dtype:
+            volume = volume.to(out_dtype)
+        return volume
+
+    # ------------------------------------------------------------------ masks
+    def _apply_mask_to_result(self, result: torch.Tensor, mask, mask_align_to_image: bool) -> torch.Tensor:
+        tta = self._get_tta_cfg()
+        apply_mask = getattr(tta, "apply_mask", True) if tta is not None else True
+        if not apply_mask or mask is None:
+            return result
+        if not isinstance(mask, torch.Tensor):
+            logger.warning("Skipping mask application because the provided mask payload is not a tensor-like volume")
+            return result
+        mask = mask.to(device=result.device, dtype=result.dtype)
+        while mask.dim() < result.dim():
+            mask = mask.unsqueeze(0)
+        if tuple(mask.shape[2:]) != tuple(result.shape[2:]):
+            if not mask_align_to_image:
+                raise ValueError(f"mask spatial shape {tuple(mask.shape[2:])} does not match prediction "
+                                 f"{tuple(result.shape[2:])}")
+            pads = []
+            sl = [slice(None), slice(None)]
+            for m, r in zip(mask.shape[2:], result.shape[2:]):   # centre crop / zero pad
+                lo = max(0, (m - r) // 2)
+                sl.append(slice(lo, lo + min(m, r)))
+            mask = mask[tuple(sl)]
+            for m, r in reversed(list(zip(mask.shape[2:], result.shape[2:]))):
+                d = r - m
+                pads += [d // 2, d - d // 2]
+            if any(pads):
+                mask = torch.nn.functional.pad(mask, pads)
+        types = self.channel_activation_types
+        if types is not None and len(types) == result.shape[1]:
+            for c, t in enumerate(types):
+                mc = mask[:, c:c + 1] if mask.shape[1] == result.shape[1] else mask[:, 0:1]
+                if t == "tanh":
+                    result[:, c:c + 1] = mc * result[:, c:c + 1] + (1 - mc) * (-1.0)
+                else:
+                    result[:, c:c + 1] = mc * result[:, c:c + 1]
+            return result
+        return result * mask
+
+    # ------------------------------------------------------------------ predict
+    def _normalize_input(self, images: torch.Tensor) -> torch.Tensor:
+        if images.ndim == 3:
+            images = images.unsqueeze(0).unsqueeze(0)
+        elif images.ndim == 4:
+            images = images.unsqueeze(1)
+        elif images.ndim != 5:
+            raise ValueError(f"TTA requires 3D, 4D, or 5D input tensor. Got {images.ndim}D tensor with shape "
+                             f"{images.shape}. Expected shapes: (D, H, W), (B, D, H, W), or (B, C, D, H, W)")
+        if is_2d_inference_mode(self.cfg) and images.size(2) == 1:
+            raise NotImplementedError("2-D (do_2d) inference is not built for the device engine")
+        return images
+
+    def _engine_for(self, images: torch.Tensor):
+        """The configured sliding engine, or a single-window engine covering the whole image."""
+        if self.sliding_inferer is not None:
+            return self.sliding_inferer
+        from .window import EagerSlidingWindowEngine
+        return EagerSlidingWindowEngine(roi_size=tuple(images.shape[2:]), sw_batch_size=1, overlap=0.0,
+                                        mode="constant", padding_mode="constant", cval=0.0)
+
+    @torch.no_grad()
+    def predict(self, images: torch.Tensor, mask=None, mask_align_to_image: bool = False,
+                requested_head: Optional[str] = None) -> torch.Tensor:
+        prev = self._requested_output_head_override
+        self._requested_output_head_override = requested_head
+        try:
+            images = self._normalize_input(images)
+            if not images.is_cuda:
+                raise RuntimeError("TTAPredictor (pytorch_connectomics_amd) needs a CUDA(HIP) tensor: "
+                                   "there is no CPU path")
+            if images.shape[0] != 1:
+                raise ValueError(f"device inference expects batch size 1; got batch {images.shape[0]}.")
+            self._last_distributed_sharding_active = False
+            self._last_skip_postprocess_on_rank = False
+            engine = self._engine_for(images)
+            network = self._engine_network()
+            tta = self._get_tta_cfg()
+            enabled = tta is not None and getattr(tta, "enabled", True)
+            combos = [([], None, 0)]
+            if enabled:
+                combos = resolve_tta_augmentation_combinations(tta, spatial_dims=_resolve_spatial_dims(images.dim()))
+            vol = images[0].to(torch.float32).contiguous()
+            orig = tuple(int(v) for v in vol.shape[1:])
+
+            def one_view(code, weight):
+                value, weight = engine.accumulate(vol, network, view=code, weight=weight, add_weight=weight is None)
+                ops.blend_finalize(value, weight, clamp=1e-4, act=nat.ACT_NONE)
+                out = value
+                if tuple(out.shape[1:]) != orig:
+                    out = out[:, :orig[0], :orig[1], :orig[2]].contiguous()
+                return self.apply_preprocessing(out.unsqueeze(0)), weight
+
+            if len(combos) == 1 and combos[0] == ([], None, 0):
+                result, _ = one_view(0, None)
+                return self._apply_mask_to_result(result, mask, mask_align_to_image)
+
+            for _f, pl, k in combos:   # same restriction (and message) as the reference, tta.py:1316-1340
+                if pl is not None and k % 2:
+                    img = tuple(int(v) for v in images.shape[2:])
+                    if len({img[a] for a in pl}) != 1 or len({engine.roi_size[a] for a in pl}) != 1:
+                        raise ValueError(
+                            "Patch-first local TTA only supports odd 90-degree rotations when the rotated axes "
+                            f"have equal image and ROI sizes. Got rotation_plane={tuple(a + 2 for a in pl)}, "
+                            f"image_size={img}, roi_size={engine.roi_size}. Use flip-only TTA, constrain "
+                            "rotations to equal-sized axes such as square XY inputs, or disable "
+                            "`inference.test_time_augmentation.patch_first_local`.")
+            codes = [view_code(f, pl, k) for f, pl, k in combos]
+            ensemble_mode = getattr(tta, "ensemble_mode", "mean")
+            acc = None
+            weight = None
+            for i, code in enumerate(codes):
+                pred, weight = one_view(code, weight)
+                pred32 = pred if pred.dtype == torch.float32 else pred.float()
+                if acc is None:
+                    modes = _resolve_ensemble_mode_map(ensemble_mode, int(pred32.shape[1]))
+                    bad = sorted(set(modes) - set(_MODE_CODE))
+                    if bad:
+                        raise ValueError(f"Unknown TTA ensemble modes: {bad}.")
+                    acc = pred32.clone()
+                    continue
+                for c, mode in enumerate(modes):   # contiguous per-channel slabs of the (1,C,Z,Y,X) volume
+                    ops.ensemble_update(acc[0, c], pred32[0, c].contiguous(), _MODE_CODE[mode], i + 1)
+            result = acc.to(resolve_model_output_dtype(self.cfg))
+            return self._apply_mask_to_result(result, mask, mask_align_to_image)
+        finally:
+            self._requested_output_head_override = prev
+
+
+__all__ = ["TTAPredictor", "view_code"]

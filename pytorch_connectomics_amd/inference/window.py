@@ -388,8 +388,7 @@ class EagerSlidingWindowEngine:
             y = y.float()
         return y.contiguous()
 
-    @torch.no_grad()
-    def __call__(self, inputs: torch.Tensor, network: Callable[[torch.Tensor], torch.Tensor]) -> torch.Tensor:
+    def _check_inputs(self, inputs: torch.Tensor):
         nd = len(self.roi_size)
         if nd != 3:
             raise NotImplementedError("the MI355X engine handles 3-D ROIs (use roi (1,H,W) for 2-D data)")
@@ -402,32 +401,57 @@ class EagerSlidingWindowEngine:
         if dev.type != "cuda":
             raise RuntimeError("EagerSlidingWindowEngine (pytorch_connectomics_amd) needs a CUDA(HIP) device: "
                                "there is no CPU path")
-        vol = inputs[0].to(device=dev, dtype=torch.float32).contiguous()
+        return dev
+
+    @torch.no_grad()
+    def accumulate(self, vol: torch.Tensor, network, *, view: int = 0, value: Optional[torch.Tensor] = None,
+                   weight: Optional[torch.Tensor] = None, add_weight: bool = True, starts=None):
+        """One overlap-add pass over `vol` (C,Z,Y,X fp32, device) under TTA `view` (PYTC_VIEW_* bits: the
+        window is flipped / yx-swapped on gather and the prediction is mapped back on blend).  Returns the
+        un-normalised (value, weight) accumulators over the grown image size."""
+        dev = vol.device
         orig = tuple(int(v) for v in vol.shape[1:])
-        # grow-to-roi: windows may overhang the stored volume; the gather kernel fills the
-        # overhang with cval (always constant, reference window.py:583-601)
-        image_size, starts = self.plan(orig)
+        image_size, all_starts = self.plan(orig)
+        if starts is None:
+            starts = all_starts
         (wz, wy, wx), combine = self._axis_vectors(dev)
         roi = self.roi_size
+        if (view & nat.VIEW_SWAP_YX) and roi[1] != roi[2]:
+            raise ValueError("a yx-rotated TTA view needs a window that is square in (y, x)")
 
         def run(batch_starts):
-            x = ops.gather_windows(vol, batch_starts, roi, pad_mode="constant", cval=self.cval)
+            x = ops.gather_windows(vol, batch_starts, roi, view=view, pad_mode="constant", cval=self.cval)
             return self._run_network(network, x)
 
         probe = run(starts[:1])
         c_out = int(probe.shape[-1])
-        value = torch.zeros((c_out,) + image_size, dtype=torch.float32, device=dev)
-        weight = torch.zeros(image_size, dtype=torch.float32, device=dev)
-        ops.blend_accumulate(probe, starts[:1], value, weight, wz, wy, wx, combine=combine, floor_w=1e-5)
+        if value is None:
+            value = torch.zeros((c_out,) + image_size, dtype=torch.float32, device=dev)
+        if weight is None:
+            weight = torch.zeros(image_size, dtype=torch.float32, device=dev)
+            add_weight = True
+        wacc = weight if add_weight else None
+        ops.blend_accumulate(probe, starts[:1], value, wacc, wz, wy, wx, view=view, combine=combine, floor_w=1e-5)
         rest = starts[1:]
         for b0 in range(0, len(rest), self.sw_batch_size):
             chunk = rest[b0:b0 + self.sw_batch_size]
-            pred = run(chunk)
-            ops.blend_accumulate(pred, chunk, value, weight, wz, wy, wx, combine=combine, floor_w=1e-5)
-        ops.blend_finalize(value, weight, clamp=1e-4, act=nat.ACT_NONE)
+            ops.blend_accumulate(run(chunk), chunk, value, wacc, wz, wy, wx, view=view, combine=combine,
+                                 floor_w=1e-5)
         self.last_stats = {"windows": len(starts), "roi": roi, "image_size": image_size}
+        return value, weight
+
+    @torch.no_grad()
+    def __call__(self, inputs: torch.Tensor, network: Callable[[torch.Tensor], torch.Tensor], *,
+                 view: int = 0) -> torch.Tensor:
+        dev = self._check_inputs(inputs)
+        vol = inputs[0].to(device=dev, dtype=torch.float32).contiguous()
+        orig = tuple(int(v) for v in vol.shape[1:])
+        # grow-to-roi: windows may overhang the stored volume; the gather kernel fills the overhang with
+        # cval (always constant, reference window.py:583-601)
+        value, weight = self.accumulate(vol, network, view=view)
+        ops.blend_finalize(value, weight, clamp=1e-4, act=nat.ACT_NONE)
         out = value
-        if image_size != orig:
+        if tuple(out.shape[1:]) != orig:
             out = out[:, :orig[0], :orig[1], :orig[2]].contiguous()
         out = out.unsqueeze(0)
         if self.output_device is not None and torch.device(self.output_device) != out.device:

@@ -1,0 +1,117 @@
+"""Channel selector parsing: ints, "a:b" half-open slice strings (no step), or explicit int lists --
+the contract of the reference's connectomics/utils/channel_slices.py (negative indices follow Python
+rules; out-of-range / empty selections raise ValueError naming the selector)."""
+from __future__ import annotations
+
+from typing import Any, Sequence
+
+
+def _parse(text: str, context: str):
+    t = text.strip()
+    if not t:
+        raise ValueError(f"{context} must not be empty.")
+    if ":" not in t:
+        try:
+            return int(t)
+        except ValueError as exc:
+            raise ValueError(f"{context} must be an integer index or a Python-style slice string, "
+                             f"got {text!r}.") from exc
+    if t.count(":") != 1:
+        raise ValueError(f"{context} must use step-free Python slice syntax 'start:end', got {text!r}.")
+    a, b = (p.strip() for p in t.split(":", 1))
+    try:
+        return slice(int(a) if a else None, int(b) if b else None)
+    except ValueError as exc:
+        raise ValueError(f"{context} must use integer slice bounds in 'start:end', got {text!r}.") from exc
+
+
+def normalize_channel_selector(selector: Any, *, context: str = "channel selector"):
+    """None | int | 'a:b' string | list[int]  (strings holding a single int become ints)."""
+    if selector is None:
+        return None
+    if isinstance(selector, bool):
+        raise TypeError(f"{context} must be an int, a slice string, or a list of ints; got bool.")
+    if isinstance(selector, int):
+        return int(selector)
+    if isinstance(selector, str):
+        parsed = _parse(selector, context)
+        if isinstance(parsed, int):
+            return parsed
+        return f"{'' if parsed.start is None else parsed.start}:{'' if parsed.stop is None else parsed.stop}"
+    if isinstance(selector, Sequence) and not isinstance(selector, (str, bytes)):
+        if len(selector) == 0:
+            raise ValueError(f"{context} must not be an empty channel list.")
+        out = []
+        for raw in selector:
+            if isinstance(raw, int) and not isinstance(raw, bool):
+                out.append(int(raw))
+            elif isinstance(raw, str):
+                try:
+                    out.append(int(raw.strip()))
+                except ValueError as exc:
+                    raise ValueError(f"{context} channel lists must contain only integer indices, "
+                                     f"got {raw!r}.") from exc
+            else:
+                raise TypeError(f"{context} channel lists must contain only integers, got {type(raw).__name__}.")
+        return out
+    raise TypeError(f"{context} must be an int, a Python-style slice string, or an explicit list of ints; "
+                    f"got {type(selector).__name__}.")
+
+
+def resolve_channel_index(index_value: int, *, num_channels: int, context: str = "channel selector") -> int:
+    idx = int(index_value)
+    if idx < 0:
+        idx += num_channels
+    if not 0 <= idx < num_channels:
+        raise ValueError(f"Invalid {context} {index_value!r} for tensor with {num_channels} channels: "
+                         f"resolved index {idx} is out of bounds.")
+    return idx
+
+
+def resolve_channel_range(selector, *, num_channels: int, context: str = "channel selector") -> tuple[int, int]:
+    """Contiguous selector -> absolute half-open (start, stop)."""
+    if num_channels <= 0:
+        raise ValueError(f"{context} requires num_channels > 0, got {num_channels}.")
+    norm = normalize_channel_selector(selector, context=context)
+    if norm is None:
+        return 0, num_channels
+    if isinstance(norm, list):
+        raise TypeError(f"{context} must be an int or a Python-style slice string, got list.")
+    if isinstance(norm, int):
+        i = resolve_channel_index(norm, num_channels=num_channels, context=context)
+        return i, i + 1
+    sl = _parse(norm, context)
+    start = 0 if sl.start is None else int(sl.start)
+    stop = num_channels if sl.stop is None else int(sl.stop)
+    if start < 0:
+        start += num_channels
+    if stop < 0:
+        stop += num_channels
+    if not 0 <= start < num_channels:
+        raise ValueError(f"Invalid {context} {norm!r} for tensor with {num_channels} channels: "
+                         f"resolved start index {start} is out of bounds.")
+    if not 0 <= stop <= num_channels:
+        raise ValueError(f"Invalid {context} {norm!r} for tensor with {num_channels} channels: "
+                         f"resolved stop index {stop} is out of bounds.")
+    if stop <= start:
+        raise ValueError(f"Invalid {context} {norm!r} for tensor with {num_channels} channels: "
+                         f"resolved range [{start}, {stop}) is empty or inverted.")
+    return start, stop
+
+
+def resolve_channel_indices(selector, *, num_channels: int, context: str = "channel selector") -> list[int]:
+    if num_channels <= 0:
+        raise ValueError(f"{context} requires num_channels > 0, got {num_channels}.")
+    norm = normalize_channel_selector(selector, context=context)
+    if norm is None:
+        return list(range(num_channels))
+    if isinstance(norm, list):
+        return [resolve_channel_index(i, num_channels=num_channels, context=context) for i in norm]
+    if isinstance(norm, int):
+        return [resolve_channel_index(norm, num_channels=num_channels, context=context)]
+    a, b = resolve_channel_range(norm, num_channels=num_channels, context=context)
+    return list(range(a, b))
+
+
+__all__ = ["normalize_channel_selector", "resolve_channel_index", "resolve_channel_range",
+           "resolve_channel_indices"]

@@ -57,9 +57,9 @@ def install() -> None:
     # omegaconf dummy for manager.py
     if "omegaconf" not in sys.modules:
         oc = types.ModuleType("omegaconf")
-        oc.DictConfig = dict
-        oc.ListConfig = list
-        oc.OmegaConf = type("OmegaConf", (), {})
+        oc.DictConfig = type("DictConfig", (dict,), {})
+        oc.ListConfig = type("ListConfig", (list,), {})
+        oc.OmegaConf = type("OmegaConf", (), {"to_container": staticmethod(lambda v, resolve=True: v)})
         sys.modules["omegaconf"] = oc
     # lazy.py leaf imports
     aug = types.ModuleType("connectomics.data.augmentation.augment_ops")

@@ -124,7 +124,7 @@ def engine():
     out = {}
     names = []
     for name, shp, roi, ov, mode, pmode, net, swb in cases:
-        g = torch.Generator().manual_seed(abs(hash(name)) % (2 ** 31))
+        g = torch.Generator().manual_seed(sum(ord(c) for c in name))
         if name.startswith("arange") or name == "lazy_vol":
             x = torch.arange(int(np.prod(shp)), dtype=torch.float32).reshape(1, 1, *shp)
         else:
@@ -214,5 +214,167 @@ def chunks():
     save("chunk_grid.npz", **out)
 
 
+
+
+# ---------------------------------------------------------------- TTA (flip / rot90 ensembles)
+def _net_asym(x):
+    """Closed-form, NOT flip/rotation equivariant, 3 output channels."""
+    z = torch.linspace(-1, 1, x.shape[2]).view(1, 1, -1, 1, 1)
+    y = torch.linspace(-1, 1, x.shape[3]).view(1, 1, 1, -1, 1)
+    w = torch.linspace(-1, 1, x.shape[4]).view(1, 1, 1, 1, -1)
+    a = x * (1.0 + 0.5 * w) + 0.25 * y
+    b = torch.tanh(2 * x - 1) * z + 0.1 * w * y
+    c = 3 * x * x - 1.5 * w + z * y
+    return torch.cat([a, b, c], 1)
+
+
+def tta():
+    from types import SimpleNamespace as NS
+    mgr = S.ref("connectomics.inference.manager")
+
+    def cfg_for(tta_ns, *, acts, select=None, roi=(8, 12, 12), blending="bump"):
+        return NS(
+            model=NS(primary_head=None, heads=None, out_channels=3),
+            data=NS(train=NS(do_2d=False), val=NS(do_2d=False), dataloader=NS(batch_size=1)),
+            inference=NS(
+                sliding_window=NS(window_size=list(roi), sw_batch_size=3, overlap=0.5, blending=blending,
+                                  padding_mode="constant", cval=0.0, keep_input_on_cpu=False, sw_device=None,
+                                  output_device=None, border_mask=None, distributed_sharding=False),
+                model=NS(head=None, select_channel=select, output_dtype=None, channel_activations=acts,
+                         crop_pad=None),
+                test_time_augmentation=tta_ns,
+            ),
+        )
+
+    x = torch.rand(1, 1, 14, 22, 26, generator=torch.Generator().manual_seed(21))
+    out = {"x": x.numpy()}
+    cases = {
+        "flip8_mean_sigmoid": (NS(enabled=True, flip_axes="all", rotation90_axes=None, rotate90_k=None,
+                                  ensemble_mode="mean", patch_first_local=True, distributed_sharding=False,
+                                  apply_mask=True, empty_cache_interval=0),
+                               [{"channels": ":", "activation": "sigmoid"}], None),
+        "rot16_min_mixed": (NS(enabled=True, flip_axes="all", rotation90_axes=[[1, 2]], rotate90_k=None,
+                               ensemble_mode=[["0:2", "min"], ["2", "max"]], patch_first_local=True,
+                               distributed_sharding=False, apply_mask=True, empty_cache_interval=0),
+                            [{"channels": "0:2", "activation": "scale_sigmoid:0.5"}, {"channels": "2", "activation": "tanh"}],
+                            None),
+        "flipz_select": (NS(enabled=True, flip_axes=[[0], [1, 2]], rotation90_axes=None, rotate90_k=None,
+                            ensemble_mode="mean", patch_first_local=True, distributed_sharding=False,
+                            apply_mask=True, empty_cache_interval=0),
+                         [{"channels": ":", "activation": "softmax"}], [2, 0]),
+        "notta_tanh": (NS(enabled=False), [{"channels": "1", "activation": "tanh"}], "0:2"),
+    }
+    xsq = torch.rand(1, 1, 14, 24, 24, generator=torch.Generator().manual_seed(22))
+    out["x_square"] = xsq.numpy()
+    for name, (tta_ns, acts, select) in cases.items():
+        cfg = cfg_for(tta_ns, acts=acts, select=select)
+        m = mgr.InferenceManager(cfg=cfg, model=torch.nn.Identity(), forward_fn=_net_asym)
+        xin = xsq if name.startswith("rot") else x
+        y = m.predict_with_tta(xin.clone())
+        out[f"{name}__y"] = y.numpy()
+        print(name, tuple(y.shape), float(y.mean()))
+        if name == "flip8_mean_sigmoid":   # the whole-volume TTA path must agree on this symmetric grid
+            cfg2 = cfg_for(NS(**{**vars(tta_ns), "patch_first_local": False}), acts=acts, select=select)
+            y2 = mgr.InferenceManager(cfg=cfg2, model=torch.nn.Identity(), forward_fn=_net_asym).predict_with_tta(x.clone())
+            print("  whole-volume vs patch-first max diff", float((y - y2).abs().max()))
+    save("tta.npz", **out)
+
+
+# ---------------------------------------------------------------- lazy / region sliding window
+def _net_lazy(x):
+    ramp = torch.linspace(0, 1, x.shape[-1]).view(1, 1, 1, 1, -1)
+    return torch.cat([2 * x - 1 + ramp, 0.5 * x + x.mean(dim=(2, 3, 4), keepdim=True)], 1)
+
+
+def _net_ctx(x):   # reference tests/unit/test_lazy_inference.py:32-35: depends on the z-1 neighbour
+    shifted = torch.zeros_like(x)
+    shifted[..., 1:, :, :] = x[..., :-1, :, :]
+    return x + shifted
+
+
+def lazy():
+    from types import SimpleNamespace as NS
+    lz = S.ref("connectomics.inference.lazy")
+
+    class FakeAccessor:
+        def __init__(self, vol):
+            self.vol = vol.astype(np.float32)
+            self.padded_spatial_shape = tuple(vol.shape[1:])
+            self.channel_count = vol.shape[0]
+            self.kind = "image"
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def close(self):
+            pass
+
+        def read_patch(self, location, patch_size, *, outer_pad_mode, outer_pad_value):
+            start = tuple(int(v) for v in location)
+            end = tuple(start[i] + int(patch_size[i]) for i in range(3))
+            shp = self.padded_spatial_shape
+            lo = tuple(max(0, start[i]) for i in range(3))
+            hi = tuple(min(shp[i], end[i]) for i in range(3))
+            inner = self.vol[:, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+            pads = [(max(0, -start[i]), max(0, end[i] - shp[i])) for i in range(3)]
+            return lz._pad_channel_first(inner, pads, mode=outer_pad_mode, constant_value=outer_pad_value)
+
+    def cfg_for(roi, *, blending="bump", overlap=0.5, padding_mode="reflect", snap=False, ctx=(), border=(), acts=None,
+                select=None, swb=3):
+        return NS(
+            model=NS(primary_head=None, heads=None, out_channels=2, output_size=list(roi)),
+            system=NS(num_workers=0),
+            data=NS(train=NS(do_2d=False), val=NS(do_2d=False), dataloader=NS(batch_size=1, use_lazy_zarr=False, use_lazy_h5=False)),
+            inference=NS(
+                sliding_window=NS(window_size=list(roi), sw_batch_size=swb, overlap=overlap, blending=blending,
+                                  padding_mode=padding_mode, cval=0.0, keep_input_on_cpu=False, sw_device=None,
+                                  output_device=None, border_mask=list(border), distributed_sharding=False,
+                                  snap_to_edge=snap, target_context=list(ctx), distributed_reduce_chunk_mb=128),
+                model=NS(head=None, select_channel=select, output_dtype=None, channel_activations=acts, crop_pad=None),
+                test_time_augmentation=NS(enabled=False, distributed_sharding=False),
+            ),
+        )
+
+    out = {}
+    vols = {"arange": np.arange(4 * 5 * 6, dtype=np.float32).reshape(1, 4, 5, 6),
+            "rand": np.random.default_rng(5).random((1, 20, 30, 34), dtype=np.float32)}
+    for k, v in vols.items():
+        out[f"vol_{k}"] = v
+
+    def run(name, vol_key, cfg, net, region=None):
+        lz._build_accessor = lambda cfg_, path, kind, mode: FakeAccessor(vols[vol_key])
+        if region is None:
+            y = lz.lazy_predict_volume(cfg, net, "fake://", device="cpu")
+        else:
+            y = lz.lazy_predict_region(cfg, net, "fake://", region_start=region[0], region_stop=region[1], device="cpu")
+        out[f"{name}__y"] = y.numpy()
+        print(name, tuple(y.shape), float(y.mean()))
+
+    run("arange_identity", "arange", cfg_for((2, 3, 3)), lambda x: x)
+    sig = [{"channels": "0", "activation": "sigmoid"}]
+    run("rand_full", "rand", cfg_for((8, 12, 16), acts=sig), _net_lazy)
+    run("rand_region", "rand", cfg_for((8, 12, 16), acts=sig), _net_lazy, region=((3, 5, 7), (17, 22, 30)))
+    run("rand_snap_ctx", "rand", cfg_for((8, 12, 16), blending="distance_transform", snap=True, ctx=(1, 2, 2),
+                                        border=(1, 1, 1), overlap=(0.25, 0.5, 0.5)), _net_ctx)
+    run("rand_const_select", "rand", cfg_for((8, 8, 8), blending="constant", padding_mode="constant", overlap=0.0,
+                                            select=[1]), _net_lazy)
+    # the window grid itself (incl. face-centred boundary windows)
+    for i, (img, roi, ov, snap) in enumerate([((4, 5, 6), (2, 3, 3), (0.5,) * 3, False), ((20, 30, 34), (8, 12, 16), (0.5,) * 3, False),
+                                              ((20, 30, 34), (8, 12, 16), (0.25, 0.5, 0.5), True), ((165, 1024, 768), (112,) * 3, (0.5,) * 3, False)]):
+        offs = lz._build_window_axis_offsets(img, roi, ov, snap_to_edge=snap)
+        for a in range(3):
+            out[f"grid{i}_axis{a}"] = np.asarray(offs[a], np.int64)
+        out[f"grid{i}_meta"] = np.asarray(list(img) + list(roi) + [int(snap)], np.int64)
+        out[f"grid{i}_ov"] = np.asarray(ov, np.float64)
+    save("lazy.npz", **out)
+
+
 if __name__ == "__main__":
-    grids(); maps(); normalise(); engine(); rsunets(); chunks()
+    parts = {"grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
+             "chunks": chunks, "tta": tta, "lazy": lazy}
+    chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
+    for name in chosen:
+        parts[name]()

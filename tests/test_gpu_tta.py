@@ -1,0 +1,94 @@
+"""GPU parity of device TTA (views as index math, activations, selection, mean/min/max ensembles) against
+fixtures produced by the reference's InferenceManager / TTAPredictor (tests/golden/make_golden.py --tta)."""
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _net_asym(x):
+    dev = x.device
+    z = torch.linspace(-1, 1, x.shape[2], device=dev).view(1, 1, -1, 1, 1)
+    y = torch.linspace(-1, 1, x.shape[3], device=dev).view(1, 1, 1, -1, 1)
+    w = torch.linspace(-1, 1, x.shape[4], device=dev).view(1, 1, 1, 1, -1)
+    a = x * (1.0 + 0.5 * w) + 0.25 * y
+    b = torch.tanh(2 * x - 1) * z + 0.1 * w * y
+    c = 3 * x * x - 1.5 * w + z * y
+    return torch.cat([a, b, c], 1)
+
+
+def _cfg(tta_ns, acts, select):
+    return NS(model=NS(primary_head=None, heads=None, out_channels=3),
+              data=NS(train=NS(do_2d=False), val=NS(do_2d=False), dataloader=NS(batch_size=1)),
+              inference=NS(sliding_window=NS(window_size=[8, 12, 12], sw_batch_size=3, overlap=0.5, blending="bump",
+                                             padding_mode="constant", cval=0.0, keep_input_on_cpu=False,
+                                             sw_device=None, output_device=None, border_mask=None,
+                                             distributed_sharding=False),
+                           model=NS(head=None, select_channel=select, output_dtype=None, channel_activations=acts,
+                                    crop_pad=None),
+                           test_time_augmentation=tta_ns))
+
+
+CASES = {
+    "flip8_mean_sigmoid": (NS(enabled=True, flip_axes="all", rotation90_axes=None, rotate90_k=None,
+                              ensemble_mode="mean", patch_first_local=True, distributed_sharding=False,
+                              apply_mask=True), [{"channels": ":", "activation": "sigmoid"}], None),
+    "rot16_min_mixed": (NS(enabled=True, flip_axes="all", rotation90_axes=[[1, 2]], rotate90_k=None,
+                           ensemble_mode=[["0:2", "min"], ["2", "max"]], patch_first_local=True,
+                           distributed_sharding=False, apply_mask=True),
+                        [{"channels": "0:2", "activation": "scale_sigmoid:0.5"},
+                         {"channels": "2", "activation": "tanh"}], None),
+    "flipz_select": (NS(enabled=True, flip_axes=[[0], [1, 2]], rotation90_axes=None, rotate90_k=None,
+                        ensemble_mode="mean", patch_first_local=True, distributed_sharding=False, apply_mask=True),
+                     [{"channels": ":", "activation": "softmax"}], [2, 0]),
+    "notta_tanh": (NS(enabled=False), [{"channels": "1", "activation": "tanh"}], "0:2"),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_tta_matches_reference(name, golden_dir):
+    from pytorch_connectomics_amd.inference import InferenceManager
+    g = np.load(golden_dir / "tta.npz")
+    tta_ns, acts, select = CASES[name]
+    x = torch.from_numpy(g["x_square"] if name.startswith("rot") else g["x"]).cuda()
+    mgr = InferenceManager(cfg=_cfg(tta_ns, acts, select), model=torch.nn.Identity(), forward_fn=_net_asym)
+    y = mgr.predict_with_tta(x).cpu().numpy()
+    exp = g[f"{name}__y"]
+    assert y.shape == exp.shape
+    np.testing.assert_allclose(y, exp, rtol=2e-5, atol=2e-5)
+
+
+def test_tta_rotation_needs_square_axes():
+    from pytorch_connectomics_amd.inference import InferenceManager
+    tta_ns, acts, select = CASES["rot16_min_mixed"]
+    mgr = InferenceManager(cfg=_cfg(tta_ns, acts, select), model=torch.nn.Identity(), forward_fn=_net_asym)
+    with pytest.raises(ValueError, match="odd 90-degree rotations"):
+        mgr.predict_with_tta(torch.rand(1, 1, 14, 22, 26).cuda())
+
+
+def test_tta_mask_and_mednext_fast_path():
+    """Mask semantics (tanh channels fall to -1, others to 0) and the forward_cl fast path of our models."""
+    from pytorch_connectomics_amd.inference import InferenceManager
+    from pytorch_connectomics_amd.models.architectures.mednext import MedNeXt
+    from pytorch_connectomics_amd.models.architectures.mednext_models import MedNeXtWrapper
+    torch.manual_seed(0)
+    net = MedNeXtWrapper(MedNeXt(1, 8, 2, exp_r=2, kernel_size=3, do_res=True, do_res_up_down=True,
+                                 block_counts=[1] * 9)).cuda().eval()
+    tta_ns = NS(enabled=True, flip_axes=[[2]], rotation90_axes=None, rotate90_k=None, ensemble_mode="mean",
+                patch_first_local=True, distributed_sharding=False, apply_mask=True)
+    acts = [{"channels": "0", "activation": "sigmoid"}, {"channels": "1", "activation": "tanh"}]
+    cfg = _cfg(tta_ns, acts, None)
+    cfg.inference.sliding_window.window_size = [32, 32, 32]
+    x = torch.rand(1, 1, 40, 40, 40).cuda()
+    mgr = InferenceManager(cfg=cfg, model=net, forward_fn=net.forward)
+    fast = mgr.predict_with_tta(x)
+    slow = InferenceManager(cfg=cfg, model=net, forward_fn=lambda t: net(t)).predict_with_tta(x)
+    assert torch.allclose(fast, slow, atol=1e-6)
+    mask = (torch.rand(1, 1, 40, 40, 40) > 0.5).float().cuda()
+    masked = mgr.predict_with_tta(x, mask=mask)
+    assert torch.all(masked[:, 0][mask[:, 0] == 0] == 0)
+    assert torch.all(masked[:, 1][mask[:, 0] == 0] == -1)
+    assert torch.equal(masked[:, 0][mask[:, 0] == 1], fast[:, 0][mask[:, 0] == 1])

@@ -1,0 +1,133 @@
+"""CPU tests: chunk grid / halo / manifest (vs reference fixtures), lazy window grids, and the multi-rank
+chunk-sharding protocol of chunked inference (2 gloo ranks, injected region predictor)."""
+import json
+import os
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from pytorch_connectomics_amd.chunked import (ManifestConfigMismatch, ResumeManifest, build_chunk_grid,
+                                              resolve_halo_region)
+from pytorch_connectomics_amd.inference import lazy as L
+from pytorch_connectomics_amd.inference.chunked import (resolve_chunk_shape, run_chunked_prediction_inference,
+                                                        stitch_chunk_prediction_files)
+
+
+def test_chunk_grid_and_halo_match_reference(golden_dir):
+    g = np.load(golden_dir / "chunk_grid.npz")
+    for i in range(int(g["n"])):
+        vol, ch, halo, crop = g[f"vol_{i}"], g[f"chunk_{i}"], g[f"halo_{i}"], g[f"crop_{i}"]
+        in_shape = tuple(int(v) + 2 * int(c) for v, c in zip(vol, crop))
+        rows, keys = [], []
+        for r in build_chunk_grid(vol, ch):
+            rs, re, sl = resolve_halo_region(r, in_shape, halo=halo, crop_before=crop)
+            rows.append(list(r.index) + list(r.start) + list(r.stop) + list(rs) + list(re)
+                        + [s.start for s in sl] + [s.stop for s in sl])
+            keys.append(r.key)
+        assert np.array_equal(np.asarray(rows, np.int64), g[f"rows_{i}"])
+        assert keys == list(g[f"keys_{i}"])
+    refs = build_chunk_grid((9, 9, 9), (4, 4, 4))
+    # grid covers the volume without overlap (reference test_chunked_inference.py:33)
+    cover = np.zeros((9, 9, 9), int)
+    for r in refs:
+        cover[r.slices] += 1
+        assert r.shape == tuple(b - a for a, b in zip(r.start, r.stop))
+    assert cover.min() == 1 and cover.max() == 1
+    with pytest.raises(ValueError):
+        build_chunk_grid((9, 9), (4, 4, 4))
+
+
+def test_resume_manifest(tmp_path):
+    p = tmp_path / "m.json"
+    m = ResumeManifest.load_or_create(p, {"chunk_shape": [4, 4, 4], "overlap": 0.5})
+    m.mark_completed("z0_y0_x0")
+    m.mark_many(["z0_y0_x1", "z0_y0_x0"])
+    assert json.loads(p.read_text())["completed"] == ["z0_y0_x0", "z0_y0_x1"]
+    again = ResumeManifest.load_or_create(p, {"chunk_shape": [4, 4, 4], "overlap": 0.5})
+    assert again.completed == {"z0_y0_x0", "z0_y0_x1"}
+    with pytest.raises(ManifestConfigMismatch, match="chunk_shape"):
+        ResumeManifest.load_or_create(p, {"chunk_shape": [8, 4, 4]})
+    fresh = ResumeManifest.load_or_create(p, {"chunk_shape": [8, 4, 4]}, overwrite=True)
+    assert fresh.completed == set() and not (tmp_path / "m.json.tmp").exists()
+
+
+def test_lazy_window_grids(golden_dir):
+    g = np.load(golden_dir / "lazy.npz")
+    for i in range(4):
+        m = g[f"grid{i}_meta"]
+        offs = L._build_window_axis_offsets(m[:3], m[3:6], tuple(g[f"grid{i}_ov"]), snap_to_edge=bool(m[6]))
+        for a in range(3):
+            assert np.array_equal(np.asarray(offs[a]), g[f"grid{i}_axis{a}"])
+    # region grid is a subset of the global grid (reference test_lazy_inference.py)
+    full = set(tuple(s.start for s in sl) for sl in L._build_window_slices((20, 30, 34), (8, 12, 16), (0.5,) * 3, snap_to_edge=False))
+    part = [tuple(s.start for s in sl) for sl in L._build_intersecting_window_slices(
+        (20, 30, 34), (8, 12, 16), (0.5,) * 3, region_start=(3, 5, 7), region_stop=(17, 22, 30), snap_to_edge=False)]
+    assert set(part) <= full and 0 < len(part) < len(full)
+    assert L._snap_offsets(4, 8, 2) == [0]
+    assert L._resolve_target_context(NS(target_context=[2]), (8, 8, 8)) == (2, 2, 2)
+    with pytest.raises(ValueError, match="length 1 or 3"):
+        L._resolve_target_context(NS(target_context=[1, 2]), (8, 8, 8))
+
+
+def _cfg(chunk, halo=(0, 0, 0), axes="all", shard=None):
+    return NS(inference=NS(chunking=NS(enabled=True, chunk_size=list(chunk), halo=list(halo), axes=axes,
+                                       shard_id=None if shard is None else shard[0],
+                                       num_shards=None if shard is None else shard[1])))
+
+
+def _fake_predictor(vol):
+    def fn(start, stop):      # position-dependent "prediction": 2 channels derived from the volume itself
+        sl = tuple(slice(a, b) for a, b in zip(start, stop))
+        v = torch.from_numpy(vol[sl])
+        return torch.stack([v, v * 2 + 1], 0).unsqueeze(0)
+    return fn
+
+
+def test_chunked_single_process_and_external_shards(tmp_path):
+    vol = np.random.default_rng(0).random((10, 13, 9)).astype(np.float32)
+    assert resolve_chunk_shape(_cfg((4, 5, 6), axes="z"), vol.shape) == (4, 13, 9)
+    out = run_chunked_prediction_inference(_cfg((4, 5, 6), halo=(1, 2, 1)), None, vol, output_path=tmp_path / "a.npy",
+                                           predict_region_fn=_fake_predictor(vol))
+    np.testing.assert_array_equal(out, np.stack([vol, vol * 2 + 1]))
+    # external shards: same code run N times sequentially, then stitched (reference test_chunked_inference.py:328-380)
+    for sid in range(3):
+        r = run_chunked_prediction_inference(_cfg((4, 5, 6), shard=(sid, 3)), None, vol, output_path=tmp_path / "b.npy",
+                                             predict_region_fn=_fake_predictor(vol))
+        assert r is None
+    chunks = build_chunk_grid(vol.shape, (4, 5, 6))
+    np.testing.assert_array_equal(stitch_chunk_prediction_files(tmp_path / "b.npy", chunks, vol.shape),
+                                  np.stack([vol, vol * 2 + 1]))
+    with pytest.raises(ValueError, match="shard_id"):
+        run_chunked_prediction_inference(_cfg((4, 5, 6), shard=(3, 3)), None, vol, output_path=tmp_path / "c.npy",
+                                         predict_region_fn=_fake_predictor(vol))
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    vol = np.random.default_rng(0).random((10, 13, 9)).astype(np.float32)
+    calls = []
+    base = _fake_predictor(vol)
+
+    def fn(start, stop):
+        calls.append(tuple(start))
+        return base(start, stop)
+
+    out = run_chunked_prediction_inference(_cfg((4, 5, 6)), None, vol, output_path=os.path.join(tmp, "d.npy"),
+                                           predict_region_fn=fn)
+    chunks = build_chunk_grid(vol.shape, (4, 5, 6))
+    mine = [c for i, c in enumerate(chunks) if i % world == rank]
+    assert sorted(calls) == sorted(tuple(c.start) for c in mine)       # idx % world == rank (chunked.py:471)
+    if rank == 0:
+        np.testing.assert_array_equal(out, np.stack([vol, vol * 2 + 1]))
+    else:
+        assert out is None
+    torch.distributed.destroy_process_group()
+
+
+def test_chunked_two_ranks_gloo(tmp_path):
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)

@@ -1,0 +1,78 @@
+"""CPU tests: channel selectors, output selection, TTA view enumeration / encoding (host logic)."""
+from types import SimpleNamespace as NS
+
+import pytest
+import torch
+
+from pytorch_connectomics_amd.inference.tta import view_code
+from pytorch_connectomics_amd.inference.tta_combinations import (_resolve_ensemble_mode_map, apply_view,
+                                                                resolve_tta_augmentation_combinations)
+from pytorch_connectomics_amd.utils import (resolve_channel_indices, resolve_channel_range, select_output_tensor)
+
+
+def test_channel_selectors():
+    assert resolve_channel_indices(None, num_channels=3) == [0, 1, 2]
+    assert resolve_channel_indices("0:3", num_channels=12) == [0, 1, 2]
+    assert resolve_channel_indices(-1, num_channels=4) == [3]
+    assert resolve_channel_indices("-1", num_channels=4) == [3]
+    assert resolve_channel_indices([2, "0", -1], num_channels=4) == [2, 0, 3]
+    assert resolve_channel_indices(":-1", num_channels=4) == [0, 1, 2]
+    assert resolve_channel_range("1:", num_channels=4) == (1, 4)
+    for bad in ("1:1", "3:1", "7", "0:9", "a:b", "0:4:2", ""):
+        with pytest.raises(ValueError):
+            resolve_channel_range(bad, num_channels=4)
+    with pytest.raises(ValueError, match="empty channel list"):
+        resolve_channel_indices([], num_channels=4)
+    with pytest.raises(TypeError):
+        resolve_channel_indices(1.5, num_channels=4)
+
+
+def test_select_output_tensor():
+    t = torch.zeros(1)
+    assert select_output_tensor(t)[0] is t
+    assert select_output_tensor({"output": t, "ds_1": torch.ones(1)})[0] is t
+    heads = {"output": {"aff": t, "sdt": torch.ones(1)}}
+    assert select_output_tensor(heads, requested_head="aff") == (t, "aff")
+    assert select_output_tensor(heads, primary_head="sdt")[1] == "sdt"
+    with pytest.raises(ValueError, match="explicit head"):
+        select_output_tensor(heads)
+    with pytest.raises(ValueError, match="single tensor"):
+        select_output_tensor(t, requested_head="aff")
+    with pytest.raises(ValueError, match="available output heads"):
+        select_output_tensor(heads, requested_head="zzz")
+    with pytest.raises(TypeError):
+        select_output_tensor(3)
+
+
+def test_tta_combinations_and_view_codes():
+    flips = resolve_tta_augmentation_combinations(NS(flip_axes="all", rotation90_axes=None), spatial_dims=3)
+    assert [f for f, _, _ in flips] == [[], [0], [1], [2], [0, 1], [0, 2], [1, 2], [0, 1, 2]]   # tta_combinations.py:67-73
+    assert resolve_tta_augmentation_combinations(NS(flip_axes=None), spatial_dims=3) == [([], None, 0)]
+    assert resolve_tta_augmentation_combinations(NS(flip_axes=[[0], [1, 2]]), spatial_dims=3) == \
+        [([], None, 0), ([0], None, 0), ([1, 2], None, 0)]
+    rot = resolve_tta_augmentation_combinations(NS(flip_axes="all", rotation90_axes=[[1, 2]]), spatial_dims=3)
+    assert len(rot) == 16                                  # SNEMI: 8 flips x 4 rotations de-duplicated to 16
+    assert sorted(view_code(*c) for c in rot) == list(range(16))
+    # every code reproduces the reference view transform on an asymmetric probe
+    probe = torch.arange(2 * 5 * 5).reshape(2, 5, 5)
+    for f, pl, k in rot:
+        code = view_code(f, pl, k)
+        mine = probe.transpose(1, 2) if code & 8 else probe
+        dims = [d for d, b in enumerate((1, 2, 4)) if code & b]
+        mine = torch.flip(mine, dims) if dims else mine
+        assert torch.equal(mine, apply_view(probe, f, pl, k, first_spatial_dim=0))
+    with pytest.raises(NotImplementedError):
+        view_code([], (0, 1), 1)
+    with pytest.raises(ValueError, match="exactly 2 axes"):
+        resolve_tta_augmentation_combinations(NS(flip_axes=None, rotation90_axes=[[1]]), spatial_dims=3)
+    assert len(resolve_tta_augmentation_combinations(NS(flip_axes=None, rotation90_axes="all", rotate90_k=[0, 2]),
+                                                     spatial_dims=3)) == 4
+
+
+def test_ensemble_mode_map():
+    assert _resolve_ensemble_mode_map("min", 3) == ["min"] * 3
+    assert _resolve_ensemble_mode_map([["0:2", "min"], ["2", "max"]], 3) == ["min", "min", "max"]
+    with pytest.raises(ValueError, match="does not cover"):
+        _resolve_ensemble_mode_map([["0:2", "min"]], 3)
+    with pytest.raises(ValueError, match="Unknown ensemble mode"):
+        _resolve_ensemble_mode_map([[":", "median"]], 3)
