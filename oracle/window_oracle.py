@@ -215,3 +215,91 @@ def halo_region(start, stop, halo, volume_shape, crop_before=(0, 0, 0)):
     lo = tuple(s - r for s, r in zip(cs, rs))
     hi = tuple(e - r for e, r in zip(ce, rs))
     return rs, re_, lo, hi
+
+
+# --------------------------------------------------------------------------- lazy / region engine
+def lazy_axis_offsets(image_size, roi, overlap, snap_to_edge=False):
+    """inference/lazy.py:269-334 -- per-axis window offsets incl. the face-centred boundary windows
+    (from -border_pad to img-roi+border_pad, border_pad = roi - stride); snap_to_edge uses int() not round()."""
+    nd = 3
+    ovs = [float(o) for o in overlap] if isinstance(overlap, (list, tuple)) else [float(overlap)] * nd
+    if snap_to_edge:
+        strides = [max(1, int(int(roi[a]) * (1.0 - ovs[a]))) for a in range(nd)]
+    else:
+        strides = list(scan_interval(image_size, roi, ovs))
+    out = []
+    for a in range(nd):
+        img, r, s = int(image_size[a]), int(roi[a]), max(1, int(strides[a]))
+        if img <= r:
+            out.append([0])
+            continue
+        bp = max(0, r - s)
+        lo, hi = -bp, img - r + bp
+        offs = list(range(lo, hi + 1, s))
+        if offs[-1] != hi:
+            offs.append(hi)
+        out.append(offs)
+    return out
+
+
+def lazy_sliding_window(vol: np.ndarray, network, *, roi, overlap=0.5, mode="bump", sw_batch_size=1,
+                        padding_mode="reflect", cval=0.0, snap_to_edge=False, target_context=(0, 0, 0),
+                        border_mask=(0, 0, 0), region=None, window_post=None) -> torch.Tensor:
+    """inference/lazy.py:986-1258 for a numpy (C,Z,Y,X) volume: global-grid windows intersecting `region`
+    ((start, stop) or None), np.pad outer padding, `window_post` (activation / channel select) applied to
+    every window prediction BEFORE blending, only the intersection is accumulated, then normalisation."""
+    C = vol.shape[0]
+    bounds = tuple(int(v) for v in vol.shape[1:])
+    start, stop = ((0, 0, 0), bounds) if region is None else (tuple(region[0]), tuple(min(bounds[a], region[1][a]) for a in range(3)))
+    ctx = tuple(int(v) for v in target_context)
+    offs = lazy_axis_offsets(bounds, roi, overlap, snap_to_edge)
+    keep = [[o for o in offs[a] if o < stop[a] and o + int(roi[a]) > start[a]] for a in range(3)]
+    wins = list(itertools.product(*keep))
+    wmap = importance_map(roi, mode)
+    bm = [int(b) for b in border_mask]
+    if any(bm):
+        wmap = wmap.copy()
+        for a, k in enumerate(bm):
+            if k > 0:
+                idx = [slice(None)] * 3
+                idx[a] = slice(0, k); wmap[tuple(idx)] = 0
+                idx[a] = slice(wmap.shape[a] - k, None); wmap[tuple(idx)] = 0
+    wmap_t = torch.from_numpy(wmap)
+    np_mode = {"replicate": "edge", "circular": "wrap"}.get(padding_mode, padding_mode)
+    out_size = tuple(stop[a] - start[a] for a in range(3))
+    val = None
+    wgt = torch.zeros((1, 1) + out_size)
+
+    def read(w):
+        s = [w[a] - ctx[a] for a in range(3)]
+        e = [w[a] + int(roi[a]) + ctx[a] for a in range(3)]
+        lo = [max(0, s[a]) for a in range(3)]
+        hi = [min(bounds[a], e[a]) for a in range(3)]
+        inner = vol[:, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+        pads = [(0, 0)] + [(max(0, -s[a]), max(0, e[a] - bounds[a])) for a in range(3)]
+        if not any(p != (0, 0) for p in pads):
+            return inner
+        if np_mode == "constant":
+            return np.pad(inner, pads, mode="constant", constant_values=cval)
+        return np.pad(inner, pads, mode=np_mode)
+
+    for b0 in range(0, len(wins), max(1, sw_batch_size)):
+        chunk = wins[b0:b0 + max(1, sw_batch_size)]
+        x = torch.from_numpy(np.stack([read(w) for w in chunk]).astype(np.float32))
+        with torch.no_grad():
+            p = network(x)
+        if any(ctx):
+            p = p[:, :, ctx[0]:ctx[0] + roi[0], ctx[1]:ctx[1] + roi[1], ctx[2]:ctx[2] + roi[2]]
+        if window_post is not None:
+            p = window_post(p)
+        if val is None:
+            val = torch.zeros((1, p.shape[1]) + out_size)
+        for i, w in enumerate(chunk):
+            ilo = [max(w[a], start[a]) for a in range(3)]
+            ihi = [min(w[a] + int(roi[a]), stop[a]) for a in range(3)]
+            ps = tuple(slice(ilo[a] - w[a], ihi[a] - w[a]) for a in range(3))
+            os_ = tuple(slice(ilo[a] - start[a], ihi[a] - start[a]) for a in range(3))
+            val[(slice(None), slice(None)) + os_] += p[(slice(i, i + 1), slice(None)) + ps] * wmap_t[ps]
+            wgt[(slice(None), slice(None)) + os_] += wmap_t[ps]
+    val /= torch.clamp_min(wgt, 1e-4)
+    return val

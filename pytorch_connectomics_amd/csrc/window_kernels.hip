@@ -10,23 +10,28 @@ struct StartList {
   int s[64 * 3];
 };
 
-__device__ __forceinline__ int pad_index(int i, int n, int mode, bool& inside) {
-  // returns source index for coordinate i on an axis of length n under `mode`
+// Source index for global coordinate g on an axis whose in-volume part of THIS window is [lo, hi).
+// The reference pads the window's inner crop (F.pad in window.py:464-527, np.pad in lazy.py:852-904), so
+// reflect / replicate / circular are evaluated relative to that crop (periodic, like np.pad), not to the
+// whole volume -- the two only differ when the overhang reaches the crop's far end.
+__device__ __forceinline__ int pad_index(int g, int lo, int hi, int mode, bool& inside) {
   inside = true;
-  if (i >= 0 && i < n) return i;
+  if (g >= lo && g < hi) return g;
+  const int n = hi - lo, j = g - lo;
+  if (n <= 0) { inside = false; return 0; }
   switch (mode) {
-    case PYTC_PAD_REFLECT: {  // torch 'reflect': no edge repeat; caller guarantees pad < n
-      if (n == 1) return 0;
+    case PYTC_PAD_REFLECT: {
+      if (n == 1) return lo;
       int p = 2 * (n - 1);
-      int m = i % p;
+      int m = j % p;
       if (m < 0) m += p;
-      return m < n ? m : p - m;
+      return lo + (m < n ? m : p - m);
     }
     case PYTC_PAD_REPLICATE:
-      return i < 0 ? 0 : n - 1;
+      return j < 0 ? lo : hi - 1;
     case PYTC_PAD_CIRCULAR: {
-      int m = i % n;
-      return m < 0 ? m + n : m;
+      int m = j % n;
+      return lo + (m < 0 ? m + n : m);
     }
     default:
       inside = false;
@@ -65,11 +70,16 @@ gather_windows_kernel(const float* __restrict__ vol, int C, int Z, int Y, int X,
   int z = (int)(t / ry);
   int wz, wy, wx;
   view_src(view, rz, ry, rx, z, y, x, wz, wy, wx);
-  int gz = st.s[3 * b + 0] + wz, gy = st.s[3 * b + 1] + wy, gx = st.s[3 * b + 2] + wx;
+  const int s0 = st.s[3 * b + 0], s1 = st.s[3 * b + 1], s2 = st.s[3 * b + 2];
+  int gz = s0 + wz, gy = s1 + wy, gx = s2 + wx;
+  const int lz = max(0, s0), hz = min(Z, s0 + rz), ly = max(0, s1), hy = min(Y, s1 + ry);
+  const int lx = max(0, s2), hx = min(X, s2 + rx);
+  // np.pad 'reflect' on a crop with a length-1 axis degrades to 'edge' for the whole pad (lazy.py:248-253)
+  if (pad_mode == PYTC_PAD_REFLECT && (hz - lz <= 1 || hy - ly <= 1 || hx - lx <= 1)) pad_mode = PYTC_PAD_REPLICATE;
   bool iz, iy, ix;
-  int sz = pad_index(gz, Z, pad_mode, iz);
-  int sy = pad_index(gy, Y, pad_mode, iy);
-  int sx = pad_index(gx, X, pad_mode, ix);
+  int sz = pad_index(gz, lz, hz, pad_mode, iz);
+  int sy = pad_index(gy, ly, hy, pad_mode, iy);
+  int sx = pad_index(gx, lx, hx, pad_mode, ix);
   bool inside = iz && iy && ix;
   TO* o = out + ((long)b * per_win + i) * C;
   const long plane = (long)Z * Y * X;

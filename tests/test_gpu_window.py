@@ -128,3 +128,29 @@ def test_ensemble_update(dev):
         ops.ensemble_update(acc, x, 0, i + 1)
         cpu = x.cpu().clone() if cpu is None else cpu + (x.cpu() - cpu) / (i + 1)   # tta_ensemble.py:95-97
     assert torch.equal(acc.cpu(), cpu)
+
+
+@pytest.mark.parametrize("mode,np_mode", [("reflect", "reflect"), ("replicate", "edge"), ("circular", "wrap"),
+                                          ("constant", "constant")])
+def test_gather_outer_padding_follows_numpy_pad_of_the_inner_crop(dev, mode, np_mode):
+    """Windows of the lazy grid overhang the volume by up to roi/2; the reference pads the in-volume crop of
+    each window with np.pad (lazy.py:852-904) -- incl. the periodic bounce when the pad reaches the crop size."""
+    import itertools
+    from pytorch_connectomics_amd import hip_ops as ops
+    rng = np.random.default_rng(1)
+    vol = rng.random((2, 9, 10, 14), dtype=np.float32)
+    roi = (4, 6, 8)
+    offs = WO.lazy_axis_offsets(vol.shape[1:], roi, 0.5)
+    wins = list(itertools.product(*offs))
+    got = ops.gather_windows(torch.from_numpy(vol).to(dev), wins, roi, pad_mode=mode, cval=0.5).cpu().numpy()
+    for i, w in enumerate(wins):
+        lo = [max(0, w[a]) for a in range(3)]
+        hi = [min(vol.shape[1 + a], w[a] + roi[a]) for a in range(3)]
+        inner = vol[:, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+        pads = [(0, 0)] + [(max(0, -w[a]), max(0, w[a] + roi[a] - vol.shape[1 + a])) for a in range(3)]
+        kw = dict(constant_values=0.5) if np_mode == "constant" else {}
+        m = np_mode
+        if m == "reflect" and min(inner.shape[1:]) <= 1:
+            m = "edge"
+        ref = np.pad(inner, pads, mode=m, **kw)
+        np.testing.assert_array_equal(got[i], np.moveaxis(ref, 0, -1), err_msg=f"window {w}")
