@@ -1,0 +1,155 @@
+"""Entry point mirroring the reference's scripts/main.py + runtime/cli.py + runtime/dispatch.py for the hot path:
+
+    python -m pytorch_connectomics_amd.main --config X.yaml [--mode train|test] [--checkpoint C.ckpt]
+                                            [--fast-dev-run] [key.sub=value ...]
+
+test : build_model(cfg) -> load checkpoint -> volume to HBM -> InferenceManager.predict_with_tta (or chunked
+       inference when inference.chunking.enabled) -> optional binary Jaccard -> <save_path>/results/*_prediction.npy
+train: needs the backward kernels -- raises NotImplementedError until they exist.
+Volumes: .npy / .npz (first array) / random://<name>[?shape=Z,Y,X] ; .h5 when h5py is importable.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import logging
+import sys
+import time
+from pathlib import Path
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from .config import load_config
+
+logger = logging.getLogger("pytorch_connectomics_amd")
+
+
+def parse_args(argv: Optional[Sequence[str]] = None) -> argparse.Namespace:
+    p = argparse.ArgumentParser(description="PyTorch Connectomics hot path on MI355X")
+    p.add_argument("--config", required=True, help="YAML config (reference tutorial format)")
+    p.add_argument("--mode", default="train", choices=["train", "test", "tune", "tune-test"])
+    p.add_argument("--checkpoint", default=None, help="Lightning .ckpt / state-dict file")
+    p.add_argument("--fast-dev-run", nargs="?", const=1, default=0, type=int)
+    p.add_argument("--demo", action="store_true", help="use random:// volumes when no data is configured")
+    p.add_argument("overrides", nargs="*", help="key.sub=value config overrides")
+    return p.parse_args(argv)
+
+
+def read_volume(spec: str, *, default_shape=(64, 128, 128), seed: int = 0) -> np.ndarray:
+    if spec.startswith("random://"):
+        shape = default_shape
+        if "?shape=" in spec:
+            shape = tuple(int(v) for v in spec.split("?shape=", 1)[1].split(","))
+        return np.random.default_rng(seed).random(shape, dtype=np.float32)
+    path = Path(spec)
+    if path.suffix == ".npy":
+        return np.load(path, mmap_mode="r")
+    if path.suffix == ".npz":
+        z = np.load(path)
+        return z[z.files[0]]
+    if path.suffix in (".h5", ".hdf5"):
+        try:
+            import h5py
+        except ImportError as exc:
+            raise RuntimeError(f"{spec}: reading HDF5 needs h5py, which is not installed in this image; convert the "
+                               "volume to .npy") from exc
+        with h5py.File(path, "r") as fh:
+            return np.asarray(fh["main" if "main" in fh else list(fh.keys())[0]])
+    raise ValueError(f"unsupported volume format: {spec}")
+
+
+def load_checkpoint(model: torch.nn.Module, path: str) -> None:
+    """Lightning checkpoints store the LightningModule state (`model.<wrapper attr>...`, model.py:244-297);
+    plain state dicts and `_orig_mod.` / `module.` prefixes are accepted too (model_weights.py:45-72)."""
+    blob = torch.load(path, map_location="cpu", weights_only=False)
+    sd = blob.get("state_dict", blob) if isinstance(blob, dict) else blob
+    own = set(model.state_dict().keys())
+    out = {}
+    for k, v in sd.items():
+        for pre in ("_orig_mod.", "module."):
+            if k.startswith(pre):
+                k = k[len(pre):]
+        if k not in own and k.startswith("model.") and k[len("model."):] in own:
+            k = k[len("model."):]
+        if k.startswith("loss_functions."):
+            continue
+        out[k] = v
+    missing, unexpected = model.load_state_dict(out, strict=False)
+    if missing:
+        raise RuntimeError(f"checkpoint {path} is missing keys: {missing[:5]}{'...' if len(missing) > 5 else ''}")
+    if unexpected:
+        logger.warning("checkpoint has %d unexpected keys (ignored)", len(unexpected))
+
+
+def binary_jaccard(pred: torch.Tensor, label: torch.Tensor, threshold: float = 0.5) -> float:
+    """TP / (TP + FP + FN) after thresholding (evaluation/metric_execution.py:166-200)."""
+    p = pred > threshold
+    t = label > 0
+    inter = (p & t).sum().item()
+    union = (p | t).sum().item()
+    return float(inter) / float(union) if union else 1.0
+
+
+def run_test(cfg, args) -> dict:
+    from .inference import InferenceManager
+    from .inference.chunked import is_chunked_inference_enabled, run_chunked_prediction_inference
+    from .models import build_model
+    if not torch.cuda.is_available():
+        raise RuntimeError("test mode needs an MI355X (ROCm) device: this engine has no CPU path")
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(int(cfg.system.seed))
+    model = build_model(cfg).to(dev).eval()
+    if args.checkpoint:
+        load_checkpoint(model, args.checkpoint)
+    precision = str(cfg.optimization.precision)
+    if "bf16" in precision or "16" in precision:
+        inner = getattr(model, "model", model)
+        if hasattr(inner, "compute_dtype"):
+            inner.compute_dtype = torch.bfloat16      # fp16-mixed configs run as bf16 storage on this engine
+    image_spec = cfg.data.test.image or ("random://demo" if args.demo else None)
+    if image_spec is None:
+        raise ValueError("data.test.image is not set (use --demo for a random volume)")
+    vol = read_volume(str(image_spec))
+    out_dir = Path(cfg.save_path) / "results"
+    out_dir.mkdir(parents=True, exist_ok=True)
+    name = Path(str(image_spec).split("?")[0]).stem or "volume"
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        if is_chunked_inference_enabled(cfg):
+            pred = run_chunked_prediction_inference(cfg, model.forward, vol, output_path=out_dir / f"{name}_prediction.npy",
+                                                    device=dev)
+            pred_t = None if pred is None else torch.from_numpy(pred).unsqueeze(0)
+        else:
+            x = torch.from_numpy(np.ascontiguousarray(vol, dtype=np.float32)).to(dev)
+            while x.dim() < 5:
+                x = x.unsqueeze(0)
+            mgr = InferenceManager(cfg=cfg, model=model, forward_fn=model.forward)
+            pred_t = mgr.predict_with_tta(x)
+            torch.cuda.synchronize()
+            np.save(out_dir / f"{name}_prediction.npy", pred_t[0].float().cpu().numpy())
+    dt = time.perf_counter() - t0
+    metrics = {"seconds": dt, "output_voxels_per_s": float(np.prod(vol.shape[-3:])) / dt}
+    label_spec = cfg.data.test.label
+    if label_spec and pred_t is not None:
+        lab = torch.from_numpy(np.ascontiguousarray(read_volume(str(label_spec))))
+        metrics["jaccard"] = binary_jaccard(pred_t[0, 0].float().cpu(), lab)
+    (out_dir / f"{name}_metrics.json").write_text(json.dumps(metrics, indent=2))
+    logger.info("test done: %s", metrics)
+    return metrics
+
+
+def main(argv: Optional[Sequence[str]] = None):
+    args = parse_args(argv)
+    logging.basicConfig(level=logging.INFO, format="%(message)s")
+    cfg = load_config(args.config, mode=args.mode, overrides=args.overrides)
+    if args.mode in ("test", "tune-test"):
+        return run_test(cfg, args)
+    raise NotImplementedError(
+        f"--mode {args.mode}: training on the MI355X engine needs the backward kernels (SURVEY.md section 8 row f-1), "
+        "which are not built yet; the forward / inference path is complete.")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
