@@ -213,6 +213,56 @@ int pytc_pw_pack_weight_paired(const float* w, int C_out, int C_in, int transpos
                                void* stream);
 int pytc_pw_mlp_fwd(const pytc_mlp_args* a, void* stream);
 
+/* ---------------------------------------------------------------- dense conv / norm / pool (RSUNet) ---------- */
+
+#define PYTC_ACT_RELU 5
+#define PYTC_ACT_LEAKY 6  /* LeakyReLU(slope) and single-weight PReLU */
+#define PYTC_ACT_ELU 7
+
+/* Dense Conv3d, stride 1, zero "same" padding, odd kernel per axis, fused pre-activation
+ *     y = W * act_in(a*x + b) (+ bias) (+ res)
+ * Replaces nn.Conv3d + the preceding NormAct of RSUNet (models/architectures/rsunet.py:87-118, 145-198, 249)
+ * and its 1x1 proj / output heads (:249, :388-399).  Weights packed by pytc_conv3d_pack_weight from the
+ * PyTorch layout [C_out][C_in][kd][kh][kw]. */
+typedef struct {
+  const void* x;        /* [N][D][H][W][C_in] */
+  const void* w_packed;
+  const float* bias;    /* [C_out] or NULL */
+  const float* ab;      /* [N][2][C_in] pre-activation affine (norm apply) or NULL */
+  const void* res;      /* PYTC_RES_ADD residual [N][D][H][W][C_out] or NULL */
+  void* y;
+  int N, D, H, W, C_in, C_out;
+  int kd, kh, kw;
+  int act_in;           /* PYTC_ACT_NONE / RELU / LEAKY / ELU */
+  float act_param;      /* negative slope / PReLU weight / ELU alpha */
+  int res_mode;         /* PYTC_RES_NONE or PYTC_RES_ADD */
+  int dtype;            /* activations and packed weights */
+} pytc_conv3d_args;
+
+int64_t pytc_conv3d_packed_elems(int C_out, int C_in, int kd, int kh, int kw, int dtype);
+int pytc_conv3d_pack_weight(const float* w, int C_out, int C_in, int kd, int kh, int kw, void* packed, int dtype,
+                            void* stream);
+int pytc_conv3d_fwd(const pytc_conv3d_args* a, void* stream);
+
+/* Per-(n,c) partial sum / sum of squares of x [N][rows][C] -> stats [N][slots][2][C]
+ * (slots = pytc_channel_stats_slots(rows)); the statistics half of GroupNorm / InstanceNorm3d in NormAct. */
+int pytc_channel_stats_slots(int64_t rows);
+int pytc_channel_stats(const void* x, float* stats, int N, int64_t rows, int C, int dtype, void* stream);
+/* GroupNorm with `groups` channel groups: ab[N][2][C] = (gamma*rstd_g, beta - mean_g*gamma*rstd_g). */
+int pytc_norm_finalize_groups(const float* stats, int slots, float count, const float* gamma, const float* beta,
+                              float eps, int groups, float* ab, int N, int C, void* stream);
+/* y = act(a[n][c]*x + b[n][c]) elementwise on [N][rows][C] (ab may be NULL); NormAct outside a conv prologue. */
+int pytc_affine_act(const void* x, void* y, const float* ab, int N, int64_t rows, int C, int act, float prm,
+                    int dtype, void* stream);
+/* nn.MaxPool3d(kernel = stride = (fz,fy,fx)) (rsunet.py:216). */
+int pytc_maxpool3d_fwd(const void* x, void* y, int N, int D, int H, int W, int C, int fz, int fy, int fx, int dtype,
+                       void* stream);
+/* Depthwise ConvTranspose3d with arbitrary per-axis kernel / stride / padding (host int32[3] each); weights fp32
+ * [kd*kh*kw][C].  Replaces BilinearUp3d (rsunet.py:33-70). */
+int pytc_dwconvT3d_generic_fwd(const void* x, void* y, const float* w, int N, int D, int H, int W, int C,
+                               const int32_t* kernel, const int32_t* stride, const int32_t* pad, int dtype,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

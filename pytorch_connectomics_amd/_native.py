@@ -17,7 +17,7 @@ OK = 0
 VIEW_FLIP_Z, VIEW_FLIP_Y, VIEW_FLIP_X, VIEW_SWAP_YX = 1, 2, 4, 8
 PAD_MODES = {"constant": 0, "reflect": 1, "replicate": 2, "circular": 3}
 BLEND_PRODUCT, BLEND_MIN = 0, 1
-ACT_NONE, ACT_SIGMOID, ACT_TANH, ACT_GELU, ACT_SOFTMAX = 0, 1, 2, 3, 4
+ACT_NONE, ACT_SIGMOID, ACT_TANH, ACT_GELU, ACT_SOFTMAX, ACT_RELU, ACT_LEAKY, ACT_ELU = 0, 1, 2, 3, 4, 5, 6, 7
 RES_NONE, RES_ADD, RES_UPSAMPLE = 0, 1, 2
 
 
@@ -42,6 +42,16 @@ class MlpArgs(C.Structure):
         ("N", C.c_int), ("rows_per_sample", C.c_int64),
         ("C_in", C.c_int), ("C_hid", C.c_int), ("C_out", C.c_int), ("res_mode", C.c_int),
         ("Di", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int),
+    ]
+
+
+class Conv3dArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("ab", C.c_void_p), ("res", C.c_void_p),
+        ("y", C.c_void_p),
+        ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C_in", C.c_int), ("C_out", C.c_int),
+        ("kd", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
+        ("act_in", C.c_int), ("act_param", C.c_float), ("res_mode", C.c_int), ("dtype", C.c_int),
     ]
 
 
@@ -71,6 +81,19 @@ _SIGS = {
     "pytc_pw_packed_elems": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "pytc_pw_pack_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "pytc_pw_conv_fwd": (C.c_int, [C.POINTER(PwArgs), C.c_void_p]),
+    "pytc_conv3d_packed_elems": (C.c_int64, [C.c_int] * 6),
+    "pytc_conv3d_pack_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                          C.c_void_p]),
+    "pytc_conv3d_fwd": (C.c_int, [C.POINTER(Conv3dArgs), C.c_void_p]),
+    "pytc_channel_stats_slots": (C.c_int, [C.c_int64]),
+    "pytc_channel_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_norm_finalize_groups": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
+                                            C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_affine_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_float,
+                                  C.c_int, C.c_void_p]),
+    "pytc_maxpool3d_fwd": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [C.c_void_p]),
+    "pytc_dwconvT3d_generic_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5
+                                   + [C.POINTER(C.c_int32)] * 3 + [C.c_int, C.c_void_p]),
     "pytc_pw_mlp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pytc_pw_pack_weight_paired": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pytc_pw_mlp_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p]),

@@ -129,6 +129,25 @@ __device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParam
   }
 }
 
+template <typename TI, int EPL>
+__device__ __forceinline__ void load_row_frag(const TI* __restrict__ row, int k0, int C_in, bool vec_ok,
+                                              float (&v)[EPL]) {
+  if (vec_ok && k0 + EPL <= C_in) {
+    if constexpr (sizeof(TI) == 4 && EPL == 8) {
+      float t0[4], t1[4];
+      VecIO<float, 4>::load(reinterpret_cast<const float*>(row) + k0, t0);
+      VecIO<float, 4>::load(reinterpret_cast<const float*>(row) + k0 + 4, t1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = t0[i]; v[4 + i] = t1[i]; }
+    } else {
+      VecIO<TI, EPL>::load(row + k0, v);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) v[j] = (k0 + j < C_in) ? to_f32<TI>(row[k0 + j]) : 0.f;
+  }
+}
+
 __device__ __forceinline__ float apply_act(float t, int act) {
   if (act == PYTC_ACT_GELU) return gelu_erf(t);
   if (act == PYTC_ACT_SIGMOID) return 1.f / (1.f + __expf(-t));

@@ -25,25 +25,6 @@ struct PwParams {
   int Do, Ho, Wo;        // gather==2: output grid
 };
 
-template <typename TI, int EPL>
-__device__ __forceinline__ void load_row_frag(const TI* __restrict__ row, int k0, int C_in, bool vec_ok,
-                                              float (&v)[EPL]) {
-  if (vec_ok && k0 + EPL <= C_in) {
-    if constexpr (sizeof(TI) == 4 && EPL == 8) {
-      float t0[4], t1[4];
-      VecIO<float, 4>::load(reinterpret_cast<const float*>(row) + k0, t0);
-      VecIO<float, 4>::load(reinterpret_cast<const float*>(row) + k0 + 4, t1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { v[i] = t0[i]; v[4 + i] = t1[i]; }
-    } else {
-      VecIO<TI, EPL>::load(row + k0, v);
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) v[j] = (k0 + j < C_in) ? to_f32<TI>(row[k0 + j]) : 0.f;
-  }
-}
-
 template <typename TI, typename TW, typename TO, int MT, int NT>
 __global__ void __launch_bounds__(256)
 pw_conv_kernel(PwParams p) {

@@ -279,3 +279,90 @@ def pw_mlp(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.Tenso
     nb = N * rows_per_sample * 2 * (c_in + c_out + (c_out if res is not None else 0))
     _run(f"pw_mlp_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_fwd, C.byref(a), _stream())
     return y
+
+
+# ------------------------------------------------------------------ dense conv / norm / pool (RSUNet)
+def conv3d_pack_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """w fp32 (C_out, C_in, kd, kh, kw) -> packed MFMA image."""
+    _dev(w, "w")
+    co, ci, kd, kh, kw = w.shape
+    n = nat.lib().pytc_conv3d_packed_elems(co, ci, kd, kh, kw, dtype_code(dtype))
+    packed = torch.empty((n,), dtype=dtype, device=w.device)
+    _run("conv3d_pack_weight", _nbytes(w, packed), nat.lib().pytc_conv3d_pack_weight, _p(w), co, ci, kd, kh, kw,
+         _p(packed), dtype_code(dtype), _stream())
+    return packed
+
+
+def conv3d(x: torch.Tensor, w_packed: torch.Tensor, *, c_out: int, kernel, bias: Optional[torch.Tensor] = None,
+           ab: Optional[torch.Tensor] = None, act_in: int = nat.ACT_NONE, act_param: float = 0.0,
+           res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x (N,D,H,W,C_in) -> (N,D,H,W,C_out): y = W * act_in(a*x+b) + bias + res, stride 1, same padding."""
+    _dev(x, "x")
+    N, D, H, W, ci = x.shape
+    y = torch.empty((N, D, H, W, c_out), dtype=x.dtype, device=x.device)
+    a = nat.Conv3dArgs()
+    a.x, a.w_packed, a.y = x.data_ptr(), w_packed.data_ptr(), y.data_ptr()
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.ab = ab.data_ptr() if ab is not None else None
+    a.res = res.data_ptr() if res is not None else None
+    a.N, a.D, a.H, a.W, a.C_in, a.C_out = N, D, H, W, ci, c_out
+    a.kd, a.kh, a.kw = (int(v) for v in kernel)
+    a.act_in, a.act_param = int(act_in), float(act_param)
+    a.res_mode = nat.RES_ADD if res is not None else nat.RES_NONE
+    a.dtype = dtype_code(x.dtype)
+    _run(f"conv3d_fwd[{ci}->{c_out},k{a.kd}{a.kh}{a.kw}]", _nbytes(x, y), nat.lib().pytc_conv3d_fwd, C.byref(a), _stream())
+    return y
+
+
+def channel_stats(x: torch.Tensor) -> torch.Tensor:
+    """x (N, *spatial, C) -> partial statistics (N, slots, 2, C)."""
+    _dev(x, "x")
+    N, Cc = x.shape[0], x.shape[-1]
+    rows = x.numel() // (N * Cc)
+    slots = nat.lib().pytc_channel_stats_slots(rows)
+    st = torch.empty((N, slots, 2, Cc), dtype=torch.float32, device=x.device)
+    _run("channel_stats", _nbytes(x), nat.lib().pytc_channel_stats, _p(x), _p(st), N, rows, Cc, dtype_code(x.dtype),
+         _stream())
+    return st
+
+
+def norm_finalize_groups(stats: torch.Tensor, count: float, gamma, beta, eps: float, groups: int) -> torch.Tensor:
+    N, slots, _, Cc = stats.shape
+    ab = torch.empty((N, 2, Cc), dtype=torch.float32, device=stats.device)
+    _run("norm_finalize_groups", _nbytes(stats, ab), nat.lib().pytc_norm_finalize_groups, _p(stats), slots, float(count),
+         _p(gamma), _p(beta), float(eps), int(groups), _p(ab), N, Cc, _stream())
+    return ab
+
+
+def maxpool3d(x: torch.Tensor, factor) -> torch.Tensor:
+    _dev(x, "x")
+    N, D, H, W, Cc = x.shape
+    fz, fy, fx = (int(v) for v in factor)
+    y = torch.empty((N, D // fz, H // fy, W // fx, Cc), dtype=x.dtype, device=x.device)
+    _run("maxpool3d", _nbytes(x, y), nat.lib().pytc_maxpool3d_fwd, _p(x), _p(y), N, D, H, W, Cc, fz, fy, fx,
+         dtype_code(x.dtype), _stream())
+    return y
+
+
+def dwconvT3d_generic(x: torch.Tensor, w_taps: torch.Tensor, kernel, stride, pad) -> torch.Tensor:
+    """Depthwise transposed conv with per-axis geometry; w_taps fp32 (kd*kh*kw, C)."""
+    _dev(x, "x")
+    N, D, H, W, Cc = x.shape
+    k, s, p = ([int(v) for v in t] for t in (kernel, stride, pad))
+    out = [(d - 1) * s[i] - 2 * p[i] + k[i] for i, d in enumerate((D, H, W))]
+    y = torch.empty((N, *out, Cc), dtype=x.dtype, device=x.device)
+    arr = lambda v: (C.c_int32 * 3)(*v)
+    _run("dwconvT3d_generic", _nbytes(x, y), nat.lib().pytc_dwconvT3d_generic_fwd, _p(x), _p(y), _p(w_taps), N, D, H, W,
+         Cc, arr(k), arr(s), arr(p), dtype_code(x.dtype), _stream())
+    return y
+
+
+def affine_act(x: torch.Tensor, ab: Optional[torch.Tensor], act: int, param: float = 0.0) -> torch.Tensor:
+    """y = act(a*x + b) elementwise on (N, *spatial, C)."""
+    _dev(x, "x")
+    N, Cc = x.shape[0], x.shape[-1]
+    rows = x.numel() // (N * Cc)
+    y = torch.empty_like(x)
+    _run("affine_act", _nbytes(x, y), nat.lib().pytc_affine_act, _p(x), _p(y), _p(ab), N, rows, Cc, int(act),
+         float(param), dtype_code(x.dtype), _stream())
+    return y

@@ -3,6 +3,7 @@ from .base import ConnectomicsModel
 from .registry import (get_architecture_builder, get_architecture_info, is_architecture_available,
                        list_architectures, register_architecture, unregister_architecture)
 from . import mednext_models  # noqa: F401  (registers 'mednext', 'mednext_custom')
+from . import rsunet  # noqa: F401          (registers 'rsunet', 'rsunet_iso')
 from .mednext_models import MedNeXtMultiHeadWrapper, MedNeXtTaskHead, MedNeXtWrapper
 
 
