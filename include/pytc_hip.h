@@ -263,6 +263,38 @@ int pytc_dwconvT3d_generic_fwd(const void* x, void* y, const float* w, int N, in
                                const int32_t* kernel, const int32_t* stride, const int32_t* pad, int dtype,
                                void* stream);
 
+/* ---------------------------------------------------------------- backward (training step) ------------------- */
+/* Replaces the autograd backward of the ops above inside ConnectomicsModule.training_step
+ * (training/lightning/model.py:863-910 -> Lightning backward).  Two-stage reductions in fixed order
+ * (bit-reproducible); gradients of parameters are fp32 in the packed layouts of the forward kernels. */
+
+/* as pytc_groupnorm_finalize, additionally saving mean_rstd [N][2][C] for the backward pass */
+int pytc_groupnorm_finalize_mr(const float* stats, int slots, float count, const float* gamma, const float* beta,
+                               float eps, float* ab, float* mean_rstd, int N, int C, void* stream);
+/* dy == NULL: out = gelu(x);  else out = dy * gelu'(x)   (erf GELU) */
+int pytc_gelu(const void* x, const void* dy, void* out, int64_t n, int dtype, void* stream);
+int pytc_add_inplace(void* y, const void* x, int64_t n, int dtype, void* stream);
+/* dW[o][k] = sum_r dY[r][o] * f(X[r][k]) (f = optional norm affine, as in the forward prologue), db[o] = sum_r dY;
+ * workspace: pytc_pw_wgrad_slots(N*rows) * (C_out*C_in + C_out) floats */
+int pytc_pw_wgrad_slots(int64_t rows_total);
+int pytc_pw_wgrad(const void* x, const float* ab, const void* dy, float* dW, float* db, float* workspace, int N,
+                  int64_t rows_per_sample, int C_in, int C_out, int dtype, void* stream);
+/* dW[tap][c] = sum_{n,o} G[n][o][c] * X[n][o*stride - K/2 + tap][c], db[c] = sum G.  Depthwise conv: G = dL/dy
+ * (output grid gdims), X = layer input (xdims).  Transposed depthwise conv (stride 2): G = layer input, X = dL/dy.
+ * workspace: pytc_dw_wgrad_slots(...) * (K^3*C + C) floats */
+int pytc_dw_wgrad_slots(int N, const int32_t* gdims, const int32_t* xdims, int C, int K, int stride, int dtype);
+int pytc_dw_wgrad(const void* g, const void* x, float* dW, float* db, float* workspace, int N, const int32_t* gdims,
+                  const int32_t* xdims, int C, int K, int stride, int dtype, void* stream);
+/* GroupNorm(C,C) backward: dt = rstd*gamma*(dtn - mean_v(dtn) - xhat*mean_v(dtn*xhat)); s_out [N][2][C] holds
+ * (sum dtn, sum dtn*xhat) whose sums over N are dbeta / dgamma.  stats_ws: pytc_norm_bwd_ws_elems floats */
+int pytc_norm_bwd_ws_elems(int N, int64_t rows, int C);
+int pytc_norm_bwd(const void* dtn, const void* t, const float* mean_rstd, const float* gamma, float* stats_ws,
+                  float* s_out, void* dt, int N, int64_t rows, float count /* voxels in the statistics */, int C,
+                  int dtype, void* stream);
+/* depthwise conv backward-data, any stride: dx[i] = sum_k dy[(i + K/2 - k)/stride] * w[k] (w: forward taps [K^3][C]) */
+int pytc_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, int N, const int32_t* xdims,
+                           const int32_t* ydims, int C, int K, int stride, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

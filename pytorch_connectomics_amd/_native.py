@@ -94,6 +94,23 @@ _SIGS = {
     "pytc_maxpool3d_fwd": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [C.c_void_p]),
     "pytc_dwconvT3d_generic_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5
                                    + [C.POINTER(C.c_int32)] * 3 + [C.c_int, C.c_void_p]),
+    "pytc_groupnorm_finalize_mr": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_float,
+                                             C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_gelu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "pytc_add_inplace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "pytc_pw_wgrad_slots": (C.c_int, [C.c_int64]),
+    "pytc_pw_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_dw_wgrad_slots": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int,
+                                      C.c_int]),
+    "pytc_dw_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_void_p]),
+    "pytc_norm_bwd_ws_elems": (C.c_int, [C.c_int, C.c_int64, C.c_int]),
+    "pytc_norm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_int, C.c_int64, C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_dwconv3d_bwd_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pytc_pw_mlp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pytc_pw_pack_weight_paired": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pytc_pw_mlp_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p]),

@@ -441,7 +441,7 @@ constexpr int FIN_CH = 16, FIN_SL = 16;
 __global__ void __launch_bounds__(256)
 groupnorm_finalize_kernel(const float* __restrict__ stats, int slots, float count,
                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                          float* __restrict__ ab, int C) {
+                          float* __restrict__ ab, float* __restrict__ mr, int C) {
   __shared__ float red[2][FIN_SL][FIN_CH];
   const int n = blockIdx.y;
   const int cl = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
@@ -469,6 +469,10 @@ groupnorm_finalize_kernel(const float* __restrict__ stats, int slots, float coun
     float b = (beta ? beta[c] : 0.f) - mean * a;
     ab[((long)n * 2 + 0) * C + c] = a;
     ab[((long)n * 2 + 1) * C + c] = b;
+    if (mr) {   // saved for the backward pass
+      mr[((long)n * 2 + 0) * C + c] = mean;
+      mr[((long)n * 2 + 1) * C + c] = rstd;
+    }
   }
 }
 
@@ -606,12 +610,18 @@ extern "C" int pytc_dwconvT3d_fwd(const void* x, void* y, const float* w, const 
   return dw_entry(true, x, y, w, bias, stats, N, D, H, W, C, K, 2, dtype, stream);
 }
 
-extern "C" int pytc_groupnorm_finalize(const float* stats, int slots, float count, const float* gamma,
-                                       const float* beta, float eps, float* ab, int N, int C, void* stream) {
+extern "C" int pytc_groupnorm_finalize_mr(const float* stats, int slots, float count, const float* gamma,
+                                          const float* beta, float eps, float* ab, float* mean_rstd, int N, int C,
+                                          void* stream) {
   PYTC_REQUIRE(stats && ab && slots >= 1 && count > 0 && N >= 1 && C >= 1, "groupnorm_finalize: bad arguments");
   dim3 grid(ceil_div(C, FIN_CH), N), block(256);
   hipLaunchKernelGGL(groupnorm_finalize_kernel, grid, block, 0, (hipStream_t)stream, stats, slots, count, gamma, beta,
-                     eps, ab, C);
+                     eps, ab, mean_rstd, C);
   PYTC_LAUNCH_CHECK("groupnorm_finalize");
   return PYTC_OK;
+}
+
+extern "C" int pytc_groupnorm_finalize(const float* stats, int slots, float count, const float* gamma,
+                                       const float* beta, float eps, float* ab, int N, int C, void* stream) {
+  return pytc_groupnorm_finalize_mr(stats, slots, count, gamma, beta, eps, ab, nullptr, N, C, stream);
 }

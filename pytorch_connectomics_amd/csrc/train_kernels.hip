@@ -1,0 +1,449 @@
+// Backward kernels of the MedNeXt training step (correctness-first, two-stage deterministic reductions):
+//   gelu fwd/bwd (elementwise), pointwise-conv weight gradient, depthwise-conv weight gradient (conv and
+//   transposed conv share one form), GroupNorm backward (statistics + apply), strided depthwise backward-data,
+//   elementwise add.  Data gradients of the 1x1 convs reuse pw_conv with transposed weights; the stride-1
+//   depthwise backward-data reuses the forward kernels with flipped taps.
+#include "pytc_common.h"
+
+namespace pytc {
+
+__device__ __forceinline__ float gelu_grad(float x) {
+  // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+  const float phi_big = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return phi_big + x * pdf;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+gelu_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float v = to_f32<T>(x[i]);
+    out[i] = from_f32<T>(dy ? to_f32<T>(dy[i]) * gelu_grad(v) : gelu_erf(v));
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+add_kernel(T* __restrict__ y, const T* __restrict__ x, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] = from_f32<T>(to_f32<T>(y[i]) + to_f32<T>(x[i]));
+}
+
+// ---- pointwise weight gradient: dWp[slot][o][k] = sum_{rows of slot} dY[r][o] * f(X[r][k]),  dbp[slot][o] ----------
+// workgroup = one (row slot, 64x64 (o,k) tile); rows staged in LDS as fp32 32 at a time; thread = 4x4 (o,k) block.
+constexpr int WG_TO = 64, WG_TK = 64, WG_TR = 32;
+template <typename T>
+__global__ void __launch_bounds__(256)
+pw_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ ab, const T* __restrict__ dy,
+                float* __restrict__ dWp, float* __restrict__ dbp, long rows_total, long rows_per_sample, int C_in,
+                int C_out, long rows_per_slot, int slots) {
+  __shared__ float sx[WG_TR][WG_TK + 1];
+  __shared__ float sd[WG_TR][WG_TO + 1];
+  const int slot = blockIdx.x;
+  const int tiles_k = (C_in + WG_TK - 1) / WG_TK;
+  const int to = blockIdx.y / tiles_k, tk = blockIdx.y % tiles_k;
+  const int o_base = to * WG_TO, k_base = tk * WG_TK;
+  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;     // thread owns o = o_base + ty*4.., k = k_base + tx*4..
+  float acc[4][4];
+  float bacc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  const long r_begin = (long)slot * rows_per_slot;
+  const long r_end = r_begin + rows_per_slot < rows_total ? r_begin + rows_per_slot : rows_total;
+  for (long r0 = r_begin; r0 < r_end; r0 += WG_TR) {
+    for (int i = threadIdx.x; i < WG_TR * WG_TK; i += 256) {
+      const int rr = i / WG_TK, kk = i % WG_TK;
+      const long r = r0 + rr;
+      float v = 0.f;
+      if (r < r_end && k_base + kk < C_in) {
+        v = to_f32<T>(x[r * C_in + k_base + kk]);
+        if (ab) {
+          const long n = r / rows_per_sample;
+          v = fmaf(v, ab[(n * 2 + 0) * C_in + k_base + kk], ab[(n * 2 + 1) * C_in + k_base + kk]);
+          v = to_f32<T>(from_f32<T>(v));      // the forward GEMM consumed the value rounded to T
+        }
+      }
+      sx[rr][kk] = v;
+    }
+    for (int i = threadIdx.x; i < WG_TR * WG_TO; i += 256) {
+      const int rr = i / WG_TO, oo = i % WG_TO;
+      const long r = r0 + rr;
+      sd[rr][oo] = (r < r_end && o_base + oo < C_out) ? to_f32<T>(dy[r * C_out + o_base + oo]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int rr = 0; rr < WG_TR; ++rr) {
+      float dv[4], xv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { dv[i] = sd[rr][ty * 4 + i]; xv[i] = sx[rr][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bacc[i] += dv[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(dv[i], xv[j], acc[i][j]);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int o = o_base + ty * 4 + i;
+    if (o >= C_out) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k_base + tx * 4 + j;
+      if (k < C_in) dWp[((long)slot * C_out + o) * C_in + k] = acc[i][j];
+    }
+    if (tk == 0 && tx == 0 && dbp) dbp[(long)slot * C_out + o] = bacc[i];
+  }
+}
+
+// out[i] = sum_s part[s][i]   (fixed order)
+__global__ void __launch_bounds__(256)
+reduce_slots_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int slots) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+  for (int s = 0; s < slots; ++s) a += part[(long)s * n + i];
+  out[i] = a;
+}
+
+// ---- depthwise weight gradient:  dW[k][c] = sum_{n,o} G[n][o][c] * X[n][o*s - p + k][c],  db[c] = sum G ------------
+// (conv: G = dL/dy on the output grid, X = input;  transposed conv: G = the layer INPUT, X = dL/dy, s = 2)
+struct DwWg {
+  int N, Dg, Hg, Wg, Dx, Hx, Wx, C, K, stride, pad;
+  int lpv, vs, iters, slots;
+};
+
+template <typename T, int VEC, int K>
+__global__ void __launch_bounds__(256)
+dw_wgrad_kernel(const T* __restrict__ g, const T* __restrict__ x, float* __restrict__ dWp, float* __restrict__ dbp,
+                DwWg q) {
+  extern __shared__ float lds[];   // [vs][C]
+  const int n = blockIdx.y, slot = blockIdx.x;
+  const int cv = threadIdx.x % q.lpv, vslot = threadIdx.x / q.lpv;
+  const bool lane_ok = vslot < q.vs;
+  const long vg = (long)q.Dg * q.Hg * q.Wg;
+  const int C = q.C;
+  const T* gn = g + (long)n * vg * C;
+  const T* xn = x + (long)n * q.Dx * q.Hx * q.Wx * C;
+  const long out_base = ((long)n * q.slots + slot);
+  for (int kz = 0; kz < K; ++kz) {
+    float acc[K * K][VEC];
+    float bacc[VEC];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[t][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) bacc[i] = 0.f;
+    for (int it = 0; it < q.iters; ++it) {
+      long v = ((long)slot * q.iters + it) * q.vs + vslot;
+      if (!lane_ok || v >= vg) continue;
+      const int ox = (int)(v % q.Wg);
+      long t = v / q.Wg;
+      const int oy = (int)(t % q.Hg);
+      const int oz = (int)(t / q.Hg);
+      float gv[VEC];
+      VecIO<T, VEC>::load(gn + v * C + cv * VEC, gv);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) bacc[i] += gv[i];
+      const int iz = oz * q.stride - q.pad + kz;
+      if (iz < 0 || iz >= q.Dx) continue;
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const int iy = oy * q.stride - q.pad + ky;
+        if (iy < 0 || iy >= q.Hx) continue;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const int ix = ox * q.stride - q.pad + kx;
+          if (ix < 0 || ix >= q.Wx) continue;
+          float xv[VEC];
+          VecIO<T, VEC>::load(xn + (((long)iz * q.Hx + iy) * q.Wx + ix) * C + cv * VEC, xv);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[ky * K + kx][i] = fmaf(gv[i], xv[i], acc[ky * K + kx][i]);
+        }
+      }
+    }
+    // reduce over the voxel slots of the workgroup (fixed order) and write this kz plane of taps
+    for (int t = 0; t <= K * K; ++t) {     // t == K*K: the bias column (only once, with kz == 0)
+      if (t == K * K && kz != 0) break;
+      __syncthreads();
+      if (lane_ok) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) lds[vslot * C + cv * VEC + i] = (t < K * K) ? acc[t < K * K ? t : 0][i] : bacc[i];
+      }
+      __syncthreads();
+      for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float a = 0.f;
+        for (int vv = 0; vv < q.vs; ++vv) a += lds[vv * C + c];
+        if (t < K * K) dWp[(out_base * K * K * K + (long)kz * K * K + t) * C + c] = a;
+        else if (dbp) dbp[out_base * C + c] = a;
+      }
+    }
+  }
+}
+
+// ---- GroupNorm(C groups = per (n,c)) backward ----------------------------------------------------------------------
+// stats: s[n][slot][0][c] = sum dtn, s[..][1][c] = sum dtn * xhat,  xhat = (t - mean) * rstd
+template <typename T>
+__global__ void __launch_bounds__(256)
+norm_bwd_stats_kernel(const T* __restrict__ dtn, const T* __restrict__ t, const float* __restrict__ mr,
+                      float* __restrict__ stats, long rows, int C, int slots, long rows_per_slot) {
+  extern __shared__ float lds[];
+  const int n = blockIdx.y, slot = blockIdx.x;
+  const long r0 = (long)slot * rows_per_slot;
+  const long r1 = r0 + rows_per_slot < rows ? r0 + rows_per_slot : rows;
+  const T* dn = dtn + (long)n * rows * C;
+  const T* tn = t + (long)n * rows * C;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int Cw = (C - c0) < 256 ? (C - c0) : 256;
+    const int RL = 256 / Cw;
+    const int c = threadIdx.x % Cw, rl = threadIdx.x / Cw;
+    float s1 = 0.f, s2 = 0.f;
+    if (rl < RL) {
+      const float mean = mr[((long)n * 2 + 0) * C + c0 + c], rstd = mr[((long)n * 2 + 1) * C + c0 + c];
+      for (long r = r0 + rl; r < r1; r += RL) {
+        const float d = to_f32<T>(dn[r * C + c0 + c]);
+        const float xh = (to_f32<T>(tn[r * C + c0 + c]) - mean) * rstd;
+        s1 += d;
+        s2 = fmaf(d, xh, s2);
+      }
+      lds[(rl * 2 + 0) * Cw + c] = s1;
+      lds[(rl * 2 + 1) * Cw + c] = s2;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * Cw; i += blockDim.x) {
+      const int which = i / Cw, ch = i % Cw;
+      float a = 0.f;
+      for (int qq = 0; qq < RL; ++qq) a += lds[(qq * 2 + which) * Cw + ch];
+      stats[(((long)n * slots + slot) * 2 + which) * C + c0 + ch] = a;
+    }
+    __syncthreads();
+  }
+}
+
+// dt = rstd * gamma * (dtn - s1/V - xhat * s2/V)
+template <typename T>
+__global__ void __launch_bounds__(256)
+norm_bwd_apply_kernel(const T* __restrict__ dtn, const T* __restrict__ t, const float* __restrict__ mr,
+                      const float* __restrict__ gamma, const float* __restrict__ s, float inv_count,
+                      T* __restrict__ dt, long rows, int C, long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int c = (int)(i % C);
+    const long n = i / (rows * C);
+    const float mean = mr[(n * 2 + 0) * C + c], rstd = mr[(n * 2 + 1) * C + c];
+    const float xh = (to_f32<T>(t[i]) - mean) * rstd;
+    const float g = gamma ? gamma[c] : 1.f;
+    const float v = rstd * g * (to_f32<T>(dtn[i]) - s[(n * 2 + 0) * C + c] * inv_count - xh * s[(n * 2 + 1) * C + c] * inv_count);
+    dt[i] = from_f32<T>(v);
+  }
+}
+
+// ---- strided depthwise backward-data (gather form): dx[i] = sum_k dy[(i + p - k)/s] * w[k] -------------------------
+struct DwBd {
+  int D, H, W, Do, Ho, Wo, C, K, stride, pad;
+};
+template <typename T>
+__global__ void __launch_bounds__(256)
+dwconv_bwd_data_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, DwBd g, long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % g.C);
+  long t = i / g.C;
+  const int ix = (int)(t % g.W); t /= g.W;
+  const int iy = (int)(t % g.H); t /= g.H;
+  const int iz = (int)(t % g.D);
+  const long n = t / g.D;
+  const T* dn = dy + n * (long)g.Do * g.Ho * g.Wo * g.C;
+  float acc = 0.f;
+  for (int kz = 0; kz < g.K; ++kz) {
+    const int tz = iz + g.pad - kz;
+    if (tz < 0 || tz % g.stride || tz / g.stride >= g.Do) continue;
+    for (int ky = 0; ky < g.K; ++ky) {
+      const int ty = iy + g.pad - ky;
+      if (ty < 0 || ty % g.stride || ty / g.stride >= g.Ho) continue;
+      for (int kx = 0; kx < g.K; ++kx) {
+        const int tx = ix + g.pad - kx;
+        if (tx < 0 || tx % g.stride || tx / g.stride >= g.Wo) continue;
+        acc = fmaf(to_f32<T>(dn[(((long)(tz / g.stride) * g.Ho + ty / g.stride) * g.Wo + tx / g.stride) * g.C + c]),
+                   w[((long)(kz * g.K + ky) * g.K + kx) * g.C + c], acc);
+      }
+    }
+  }
+  dx[i] = from_f32<T>(acc);
+}
+
+static int grid_for(long n) { long b = (n + 255) / 256; return (int)(b < 16384 ? b : 16384); }
+
+}  // namespace pytc
+
+using namespace pytc;
+
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F32, name)                 \
+  if ((dtype) == PYTC_BF16) { CALL_BF16; }                            \
+  else if ((dtype) == PYTC_F32) { CALL_F32; }                         \
+  else { PYTC_REQUIRE(false, name ": bad dtype"); }
+
+extern "C" int pytc_gelu(const void* x, const void* dy, void* out, int64_t n, int dtype, void* stream) {
+  PYTC_REQUIRE(x && out && n > 0, "gelu: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(gelu_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)out, (long)n),
+             hipLaunchKernelGGL(gelu_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)x, (const float*)dy, (float*)out, (long)n),
+             "gelu")
+  PYTC_LAUNCH_CHECK("gelu");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_add_inplace(void* y, const void* x, int64_t n, int dtype, void* stream) {
+  PYTC_REQUIRE(x && y && n > 0, "add_inplace: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, (bf16_t*)y, (const bf16_t*)x, (long)n),
+             hipLaunchKernelGGL(add_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (float*)y, (const float*)x, (long)n),
+             "add_inplace")
+  PYTC_LAUNCH_CHECK("add_inplace");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_pw_wgrad_slots(int64_t rows_total) {
+  long s = rows_total / 4096;
+  return (int)(s < 1 ? 1 : (s > 256 ? 256 : s));
+}
+
+extern "C" int pytc_pw_wgrad(const void* x, const float* ab, const void* dy, float* dW, float* db, float* workspace,
+                             int N, int64_t rows_per_sample, int C_in, int C_out, int dtype, void* stream) {
+  PYTC_REQUIRE(x && dy && dW && workspace && N >= 1 && rows_per_sample >= 1, "pw_wgrad: bad arguments");
+  const long rows_total = (long)N * rows_per_sample;
+  const int slots = pytc_pw_wgrad_slots(rows_total);
+  const long rps = (rows_total + slots - 1) / slots;
+  float* dWp = workspace;
+  float* dbp = workspace + (long)slots * C_out * C_in;
+  dim3 grid(slots, ((C_out + WG_TO - 1) / WG_TO) * ((C_in + WG_TK - 1) / WG_TK)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, ab, (const bf16_t*)dy, dWp, db ? dbp : nullptr, rows_total, (long)rows_per_sample, C_in, C_out, rps, slots),
+             hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, block, 0, s, (const float*)x, ab, (const float*)dy, dWp, db ? dbp : nullptr, rows_total, (long)rows_per_sample, C_in, C_out, rps, slots),
+             "pw_wgrad")
+  const long nW = (long)C_out * C_in;
+  hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(nW, 256)), dim3(256), 0, s, dWp, dW, nW, slots);
+  if (db) hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(C_out, 256)), dim3(256), 0, s, dbp, db, (long)C_out, slots);
+  PYTC_LAUNCH_CHECK("pw_wgrad");
+  return PYTC_OK;
+}
+
+static bool make_wg(DwWg& q, int N, const int32_t* gd, const int32_t* xd, int C, int K, int stride, int dtype, int& vec) {
+  int maxv = dtype == PYTC_BF16 ? 4 : 2;
+  vec = 0;
+  for (int v = maxv; v >= 1; v >>= 1)
+    if (C % v == 0 && C / v <= 256) { vec = v; break; }
+  if (!vec) return false;
+  q.N = N; q.Dg = gd[0]; q.Hg = gd[1]; q.Wg = gd[2]; q.Dx = xd[0]; q.Hx = xd[1]; q.Wx = xd[2];
+  q.C = C; q.K = K; q.stride = stride; q.pad = K / 2;
+  q.lpv = C / vec; q.vs = 256 / q.lpv;
+  long vg = (long)q.Dg * q.Hg * q.Wg;
+  long it = vg / ((long)q.vs * 64);
+  q.iters = (int)(it < 1 ? 1 : (it > 256 ? 256 : it));
+  q.slots = (int)((vg + (long)q.vs * q.iters - 1) / ((long)q.vs * q.iters));
+  return true;
+}
+
+extern "C" int pytc_dw_wgrad_slots(int N, const int32_t* gdims, const int32_t* xdims, int C, int K, int stride, int dtype) {
+  DwWg q; int vec;
+  if (!make_wg(q, N, gdims, xdims, C, K, stride, dtype, vec)) return -1;
+  return q.slots * N;
+}
+
+template <typename T, int VEC>
+static int launch_dwwg(const void* g, const void* x, float* dWp, float* dbp, const DwWg& q, hipStream_t s) {
+  dim3 grid(q.slots, q.N), block(256);
+  size_t lds = (size_t)q.vs * q.C * sizeof(float);
+  switch (q.K) {
+    case 3: hipLaunchKernelGGL((dw_wgrad_kernel<T, VEC, 3>), grid, block, lds, s, (const T*)g, (const T*)x, dWp, dbp, q); break;
+    case 5: hipLaunchKernelGGL((dw_wgrad_kernel<T, VEC, 5>), grid, block, lds, s, (const T*)g, (const T*)x, dWp, dbp, q); break;
+    case 7: hipLaunchKernelGGL((dw_wgrad_kernel<T, VEC, 7>), grid, block, lds, s, (const T*)g, (const T*)x, dWp, dbp, q); break;
+    default: set_error("dw_wgrad: unsupported kernel size %d", q.K); return PYTC_ERR_UNSUPPORTED;
+  }
+  return PYTC_OK;
+}
+
+extern "C" int pytc_dw_wgrad(const void* g, const void* x, float* dW, float* db, float* workspace, int N,
+                             const int32_t* gdims, const int32_t* xdims, int C, int K, int stride, int dtype,
+                             void* stream) {
+  PYTC_REQUIRE(g && x && dW && workspace && gdims && xdims, "dw_wgrad: null pointer");
+  DwWg q; int vec;
+  if (!make_wg(q, N, gdims, xdims, C, K, stride, dtype, vec)) { set_error("dw_wgrad: unsupported channel count %d", C); return PYTC_ERR_UNSUPPORTED; }
+  PYTC_REQUIRE((size_t)q.vs * C * sizeof(float) <= 64 * 1024, "dw_wgrad: scratch too large");
+  const int total_slots = q.slots * N;
+  const long nW = (long)K * K * K * C;
+  float* dWp = workspace;
+  float* dbp = workspace + (long)total_slots * nW;
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (dtype == PYTC_BF16) rc = vec == 4 ? launch_dwwg<bf16_t, 4>(g, x, dWp, dbp, q, s) : vec == 2 ? launch_dwwg<bf16_t, 2>(g, x, dWp, dbp, q, s) : launch_dwwg<bf16_t, 1>(g, x, dWp, dbp, q, s);
+  else rc = vec == 2 ? launch_dwwg<float, 2>(g, x, dWp, dbp, q, s) : launch_dwwg<float, 1>(g, x, dWp, dbp, q, s);
+  if (rc != PYTC_OK) return rc;
+  hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(nW, 256)), dim3(256), 0, s, dWp, dW, nW, total_slots);
+  if (db) hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, dbp, db, (long)C, total_slots);
+  PYTC_LAUNCH_CHECK("dw_wgrad");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_norm_bwd(const void* dtn, const void* t, const float* mean_rstd, const float* gamma,
+                             float* stats_ws, float* s_out, void* dt, int N, int64_t rows, float count, int C,
+                             int dtype, void* stream) {
+  PYTC_REQUIRE(dtn && t && mean_rstd && stats_ws && s_out && dt, "norm_bwd: null pointer");
+  long sl = rows / 2048;
+  const int slots = (int)(sl < 1 ? 1 : (sl > 1024 ? 1024 : sl));
+  const long rps = (rows + slots - 1) / slots;
+  const int Cw = C < 256 ? C : 256;
+  size_t lds = (size_t)(256 / Cw) * 2 * Cw * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(slots, N), block(256);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(norm_bwd_stats_kernel<bf16_t>, grid, block, lds, s, (const bf16_t*)dtn, (const bf16_t*)t, mean_rstd, stats_ws, (long)rows, C, slots, rps),
+             hipLaunchKernelGGL(norm_bwd_stats_kernel<float>, grid, block, lds, s, (const float*)dtn, (const float*)t, mean_rstd, stats_ws, (long)rows, C, slots, rps),
+             "norm_bwd")
+  // reduce slots per sample: stats_ws [N][slots][2][C] -> s_out [N][2][C]
+  for (int n = 0; n < N; ++n)
+    hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(2L * C, 256)), dim3(256), 0, s, stats_ws + (long)n * slots * 2 * C,
+                       s_out + (long)n * 2 * C, 2L * C, slots);
+  const long total = (long)N * rows * C;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(norm_bwd_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)dtn, (const bf16_t*)t, mean_rstd, gamma, s_out, 1.0f / count, (bf16_t*)dt, (long)rows, C, total),
+             hipLaunchKernelGGL(norm_bwd_apply_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)dtn, (const float*)t, mean_rstd, gamma, s_out, 1.0f / count, (float*)dt, (long)rows, C, total),
+             "norm_bwd")
+  PYTC_LAUNCH_CHECK("norm_bwd");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_norm_bwd_ws_elems(int N, int64_t rows, int C) {
+  long sl = rows / 2048;
+  const int slots = (int)(sl < 1 ? 1 : (sl > 1024 ? 1024 : sl));
+  return (int)((long)N * slots * 2 * C);
+}
+
+extern "C" int pytc_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, int N, const int32_t* xdims,
+                                      const int32_t* ydims, int C, int K, int stride, int dtype, void* stream) {
+  PYTC_REQUIRE(dy && w && dx && xdims && ydims, "dwconv3d_bwd_data: null pointer");
+  DwBd g;
+  g.D = xdims[0]; g.H = xdims[1]; g.W = xdims[2]; g.Do = ydims[0]; g.Ho = ydims[1]; g.Wo = ydims[2];
+  g.C = C; g.K = K; g.stride = stride; g.pad = K / 2;
+  const long total = (long)N * g.D * g.H * g.W * C;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(dwconv_bwd_data_kernel<bf16_t>, dim3(ceil_div(total, 256)), dim3(256), 0, s, (const bf16_t*)dy, w, (bf16_t*)dx, g, total),
+             hipLaunchKernelGGL(dwconv_bwd_data_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, s, (const float*)dy, w, (float*)dx, g, total),
+             "dwconv3d_bwd_data")
+  PYTC_LAUNCH_CHECK("dwconv3d_bwd_data");
+  return PYTC_OK;
+}

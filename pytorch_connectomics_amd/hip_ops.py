@@ -366,3 +366,85 @@ def affine_act(x: torch.Tensor, ab: Optional[torch.Tensor], act: int, param: flo
     _run("affine_act", _nbytes(x, y), nat.lib().pytc_affine_act, _p(x), _p(y), _p(ab), N, rows, Cc, int(act),
          float(param), dtype_code(x.dtype), _stream())
     return y
+
+
+# ------------------------------------------------------------------ backward (training step)
+def _i3(v):
+    return (C.c_int32 * 3)(*[int(a) for a in v])
+
+
+def groupnorm_finalize_mr(stats: torch.Tensor, count: float, gamma, beta, eps: float = 1e-5):
+    """-> (ab (N,2,C), mean_rstd (N,2,C))"""
+    N, slots, _, Cc = stats.shape
+    ab = torch.empty((N, 2, Cc), dtype=torch.float32, device=stats.device)
+    mr = torch.empty((N, 2, Cc), dtype=torch.float32, device=stats.device)
+    _run("groupnorm_finalize", _nbytes(stats, ab), nat.lib().pytc_groupnorm_finalize_mr, _p(stats), slots, float(count),
+         _p(gamma), _p(beta), float(eps), _p(ab), _p(mr), N, Cc, _stream())
+    return ab, mr
+
+
+def gelu(x: torch.Tensor, dy: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dy is None: gelu(x); else dy * gelu'(x)."""
+    _dev(x, "x")
+    out = torch.empty_like(x)
+    _run("gelu_bwd" if dy is not None else "gelu_fwd", _nbytes(x, out, dy), nat.lib().pytc_gelu, _p(x), _p(dy), _p(out),
+         x.numel(), dtype_code(x.dtype), _stream())
+    return out
+
+
+def add_(y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    _dev(y, "y"); _dev(x, "x")
+    _run("add_inplace", 3 * _nbytes(x), nat.lib().pytc_add_inplace, _p(y), _p(x), y.numel(), dtype_code(y.dtype), _stream())
+    return y
+
+
+def pw_wgrad(x: torch.Tensor, dy: torch.Tensor, *, N: int, rows_per_sample: int, c_in: int, c_out: int,
+             ab: Optional[torch.Tensor] = None, want_bias: bool = True):
+    """-> dW (c_out, c_in) fp32, db (c_out) fp32 | None"""
+    _dev(x, "x"); _dev(dy, "dy")
+    slots = nat.lib().pytc_pw_wgrad_slots(N * rows_per_sample)
+    ws = torch.empty((slots * (c_out * c_in + c_out),), dtype=torch.float32, device=x.device)
+    dW = torch.empty((c_out, c_in), dtype=torch.float32, device=x.device)
+    db = torch.empty((c_out,), dtype=torch.float32, device=x.device) if want_bias else None
+    _run(f"pw_wgrad[{c_in}->{c_out}]", _nbytes(x, dy), nat.lib().pytc_pw_wgrad, _p(x), _p(ab), _p(dy), _p(dW), _p(db),
+         _p(ws), N, rows_per_sample, c_in, c_out, dtype_code(x.dtype), _stream())
+    return dW, db
+
+
+def dw_wgrad(g: torch.Tensor, x: torch.Tensor, *, K: int, stride: int = 1, want_bias: bool = True):
+    """g (N,*gdims,C), x (N,*xdims,C) -> dW (K^3, C) fp32, db (C) | None   (see pytc_dw_wgrad)"""
+    _dev(g, "g"); _dev(x, "x")
+    N, Cc = g.shape[0], g.shape[-1]
+    gd, xd = _i3(g.shape[1:4]), _i3(x.shape[1:4])
+    slots = nat.lib().pytc_dw_wgrad_slots(N, gd, xd, Cc, K, stride, dtype_code(g.dtype))
+    if slots < 0:
+        raise RuntimeError(f"dw_wgrad: unsupported channel count {Cc}")
+    ws = torch.empty((slots * (K ** 3 * Cc + Cc),), dtype=torch.float32, device=g.device)
+    dW = torch.empty((K ** 3, Cc), dtype=torch.float32, device=g.device)
+    db = torch.empty((Cc,), dtype=torch.float32, device=g.device) if want_bias else None
+    _run(f"dw_wgrad[C{Cc}_k{K}]", _nbytes(g, x), nat.lib().pytc_dw_wgrad, _p(g), _p(x), _p(dW), _p(db), _p(ws), N, gd, xd,
+         Cc, K, stride, dtype_code(g.dtype), _stream())
+    return dW, db
+
+
+def norm_bwd(dtn: torch.Tensor, t: torch.Tensor, mean_rstd: torch.Tensor, gamma: Optional[torch.Tensor],
+             count: Optional[float] = None):
+    """-> dt (like t), s (N,2,C) with (sum dtn, sum dtn*xhat); count = voxels the forward statistics covered"""
+    _dev(dtn, "dtn"); _dev(t, "t")
+    N, Cc = t.shape[0], t.shape[-1]
+    rows = t.numel() // (N * Cc)
+    ws = torch.empty((nat.lib().pytc_norm_bwd_ws_elems(N, rows, Cc),), dtype=torch.float32, device=t.device)
+    s = torch.empty((N, 2, Cc), dtype=torch.float32, device=t.device)
+    dt = torch.empty_like(t)
+    _run("norm_bwd", 3 * _nbytes(t) + _nbytes(dtn), nat.lib().pytc_norm_bwd, _p(dtn), _p(t), _p(mean_rstd), _p(gamma),
+         _p(ws), _p(s), _p(dt), N, rows, float(count if count is not None else rows), Cc, dtype_code(t.dtype), _stream())
+    return dt, s
+
+
+def dwconv3d_bwd_data(dy: torch.Tensor, w_taps: torch.Tensor, xdims, *, K: int, stride: int) -> torch.Tensor:
+    _dev(dy, "dy")
+    N, Cc = dy.shape[0], dy.shape[-1]
+    dx = torch.empty((N, *[int(v) for v in xdims], Cc), dtype=dy.dtype, device=dy.device)
+    _run(f"dwconv3d_bwd_data[C{Cc}_k{K}_s{stride}]", _nbytes(dy, dx), nat.lib().pytc_dwconv3d_bwd_data, _p(dy), _p(w_taps),
+         _p(dx), N, _i3(xdims), _i3(dy.shape[1:4]), Cc, K, stride, dtype_code(dy.dtype), _stream())
+    return dx

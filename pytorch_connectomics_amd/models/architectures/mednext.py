@@ -365,10 +365,6 @@ class MedNeXt(nn.Module):
                                "there is no CPU path. Move the model and input to 'cuda'.")
         if self.dim != "3d" or x.dim() != 5:
             raise NotImplementedError("only dim='3d' inputs (B,C,D,H,W) are supported by the HIP engine")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "MedNeXt backward kernels are not built yet (SURVEY.md section 8 row f-1): run the forward under "
-                "torch.no_grad() / model.eval() + torch.inference_mode()")
 
     def features_cl(self, x_cl: torch.Tensor, collect: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
         """Channels-last in (N,D,H,W,C_in) fp32/bf16 -> channels-last full-resolution features."""
@@ -413,8 +409,18 @@ class MedNeXt(nn.Module):
         dt = resolve_compute_dtype(self.compute_dtype)
         return to_channels_first(self.output_cl(to_channels_last(features).to(dt)))
 
+    def _autograd_active(self) -> bool:
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
     def forward(self, x: torch.Tensor):
         self._check_input(x)
+        if self._autograd_active():
+            # training step: forward AND backward run hand-written kernels (training/autograd.py)
+            from ...training.autograd import mednext_train_forward
+            out = mednext_train_forward(self, to_channels_last(x.float()), resolve_compute_dtype(self.compute_dtype))
+            if isinstance(out, list):
+                return [to_channels_first(o) for o in out]
+            return to_channels_first(out)
         feats: Optional[List[torch.Tensor]] = [] if self.do_ds else None
         f = self.features_cl(to_channels_last(x.float()), collect=feats)
         out = to_channels_first(self.output_cl(f))

@@ -1,0 +1,151 @@
+"""GPU parity of the backward kernels and of a full MedNeXt training step against torch autograd on the CPU
+oracle (fp32: tight; bf16 storage: loose)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import mednext_oracle as MO
+
+pytestmark = pytest.mark.gpu
+
+
+def _cl(x):
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _cf(y):
+    return y.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def test_pw_wgrad_and_gelu_and_norm_bwd_kernels():
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(0)
+    N, rows, ci, co = 2, 777, 24, 40
+    x = torch.randn(N, rows, ci)
+    dy = torch.randn(N, rows, co)
+    a, b = torch.rand(N, ci) + 0.5, torch.randn(N, ci)
+    dW, db = ops.pw_wgrad(x.cuda(), dy.cuda(), N=N, rows_per_sample=rows, c_in=ci, c_out=co,
+                          ab=torch.stack([a, b], 1).contiguous().cuda())
+    xn = x * a[:, None] + b[:, None]
+    torch.testing.assert_close(dW.cpu(), torch.einsum("nro,nrk->ok", dy, xn), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(db.cpu(), dy.sum((0, 1)), rtol=1e-4, atol=1e-3)
+    v = torch.linspace(-6, 6, 4001, requires_grad=True)
+    g = torch.randn(4001)
+    F.gelu(v).backward(g)
+    torch.testing.assert_close(ops.gelu(v.detach().cuda()).cpu(), F.gelu(v.detach()), rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(ops.gelu(v.detach().cuda(), dy=g.cuda()).cpu(), v.grad, rtol=1e-4, atol=1e-5)
+    # GroupNorm(C,C) backward
+    C = 12
+    t = torch.randn(2, C, 5, 6, 7, requires_grad=True)
+    gamma, beta = (torch.rand(C) + 0.5).requires_grad_(), torch.randn(C, requires_grad=True)
+    gy = torch.randn(2, C, 5, 6, 7)
+    F.group_norm(t, C, gamma, beta, 1e-5).backward(gy)
+    tc = _cl(t.detach()).cuda()
+    st = ops.channel_stats(tc)
+    ab, mr = ops.groupnorm_finalize_mr(st, 5 * 6 * 7, gamma.detach().cuda(), beta.detach().cuda(), 1e-5)
+    dt, s = ops.norm_bwd(_cl(gy).cuda(), tc, mr, gamma.detach().cuda())
+    torch.testing.assert_close(_cf(dt.cpu()), t.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(s[:, 1].sum(0).cpu(), gamma.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(s[:, 0].sum(0).cpu(), beta.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("C,K,stride,shape", [(8, 3, 1, (6, 7, 9)), (16, 3, 2, (8, 8, 10)), (4, 5, 1, (6, 6, 7)), (32, 3, 1, (9, 17, 18))])
+def test_depthwise_backward_kernels(C, K, stride, shape):
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(C + K)
+    x = torch.randn(2, C, *shape, requires_grad=True)
+    w = (torch.randn(C, 1, K, K, K) * 0.2).requires_grad_()
+    b = torch.randn(C, requires_grad=True)
+    y = F.conv3d(x, w, b, stride=stride, padding=K // 2, groups=C)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    taps = w.detach().reshape(C, K ** 3).t().contiguous().cuda()
+    gyc, xc = _cl(gy).cuda(), _cl(x.detach()).cuda()
+    dW, db = ops.dw_wgrad(gyc, xc, K=K, stride=stride)
+    torch.testing.assert_close(dW.t().reshape(w.shape).cpu(), w.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-4, atol=1e-3)
+    dx = ops.dwconv3d_bwd_data(gyc, taps, shape, K=K, stride=stride)
+    torch.testing.assert_close(_cf(dx.cpu()), x.grad, rtol=1e-4, atol=1e-4)
+    if stride == 1:   # the production path: forward kernel with the reversed stencil
+        dx2, _ = ops.dwconv3d(gyc, torch.flip(taps, dims=[0]).contiguous(), None, K=K, stride=1, stats=False)
+        torch.testing.assert_close(_cf(dx2.cpu()), x.grad, rtol=1e-4, atol=1e-4)
+
+
+def _grads_oracle(st, x, kw, weight_fn):
+    params = {k: v.clone().requires_grad_(True) for k, v in st.items() if v.dtype.is_floating_point}
+    out = MO.forward(params, x, **kw)
+    loss = weight_fn(out)
+    loss.backward()
+    return out.detach(), {k: v.grad for k, v in params.items() if v.grad is not None}
+
+
+@pytest.mark.parametrize("n_channels,counts", [(8, [1] * 9), (16, [1, 2, 1, 1, 1, 1, 1, 1, 2])])
+def test_mednext_training_step_matches_oracle_autograd(n_channels, counts):
+    from pytorch_connectomics_amd.models.architectures.mednext import MedNeXt
+    torch.manual_seed(0)
+    m = MedNeXt(1, n_channels, 2, exp_r=2, kernel_size=3, do_res=True, do_res_up_down=True, block_counts=counts)
+    st = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    kw = dict(n_channels=n_channels, exp_r=2, kernel_size=3, block_counts=counts)
+    x = torch.rand(2, 1, 32, 32, 32)
+    wmap = torch.randn(2, 2, 32, 32, 32)
+    ref_out, ref_g = _grads_oracle(st, x, kw, lambda o: (torch.sigmoid(o) * wmap).mean())
+    m = m.cuda().train()
+    out = m(x.cuda())
+    assert out.requires_grad and out.shape == ref_out.shape
+    (torch.sigmoid(out) * wmap.cuda()).mean().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref_out, rtol=1e-3, atol=1e-3)
+    worst = 0.0
+    for k, g in ref_g.items():
+        if k == "dummy_tensor":
+            continue
+        got = dict(m.named_parameters())[k].grad
+        assert got is not None, k
+        # conv1.bias feeds a per-channel GroupNorm, so its true gradient is ~0 (rounding noise): floor the scale
+        scale = max(g.abs().max().item(), 1e-5)
+        err = (got.cpu() - g).abs().max().item() / scale
+        worst = max(worst, err)
+        assert err < 2e-2, (k, err, g.abs().max().item())
+    assert worst < 2e-2
+
+
+def test_mednext_bf16_training_step_and_optimizer():
+    """bf16 storage: gradients correlate with the fp32 oracle; AdamW step decreases a Dice+BCE loss."""
+    from pytorch_connectomics_amd.models.architectures.mednext import MedNeXt
+    torch.manual_seed(0)
+    m = MedNeXt(1, 32, 1, exp_r=2, kernel_size=3, do_res=True, do_res_up_down=True, block_counts=[1] * 9)
+    st = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    kw = dict(n_channels=32, exp_r=2, kernel_size=3, block_counts=[1] * 9)
+    x = torch.rand(1, 1, 32, 32, 32)
+    y = (torch.rand(1, 1, 32, 32, 32) > 0.85).float()
+    _, ref_g = _grads_oracle(st, x, kw, lambda o: F.binary_cross_entropy_with_logits(o, y))
+    m = m.cuda().train()
+    m.compute_dtype = torch.bfloat16
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    losses = []
+    for it in range(4):
+        opt.zero_grad(set_to_none=True)
+        out = m(x.cuda())
+        p = torch.sigmoid(out)
+        yc = y.cuda()
+        dice = 1 - (2 * (p * yc).sum() + 1e-5) / (p.sum() + yc.sum() + 1e-5)
+        loss = F.binary_cross_entropy_with_logits(out, yc) + dice
+        loss.backward()
+        if it == 0:
+            out2 = m(x.cuda())
+            F.binary_cross_entropy_with_logits(out2, yc).backward(inputs=list(m.parameters()))
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0]
+    # cosine similarity of a few large gradients vs the fp32 oracle (first-iteration grads were overwritten by
+    # training; recompute on fresh weights)
+    m2 = MedNeXt(1, 32, 1, exp_r=2, kernel_size=3, do_res=True, do_res_up_down=True, block_counts=[1] * 9)
+    m2.load_state_dict(st)
+    m2 = m2.cuda().train()
+    m2.compute_dtype = torch.bfloat16
+    F.binary_cross_entropy_with_logits(m2(x.cuda()), y.cuda()).backward()
+    for k in ("stem.weight", "enc_block_0.0.conv2.weight", "bottleneck.0.conv3.weight", "up_0.conv1.weight", "out_0.conv_out.weight"):
+        g = dict(m2.named_parameters())[k].grad.flatten().cpu()
+        r = ref_g[k].flatten()
+        cos = float((g * r).sum() / (g.norm() * r.norm() + 1e-20))
+        assert cos > 0.98, (k, cos)
