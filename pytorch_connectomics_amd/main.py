@@ -140,15 +140,68 @@ def run_test(cfg, args) -> dict:
     return metrics
 
 
+def run_train(cfg, args) -> dict:
+    """DDP-ready training loop on synthetic (random://) patches or patches sampled from .npy volumes."""
+    import os
+    from .training import ConnectomicsModule, fit, synthetic_batches
+    if not torch.cuda.is_available():
+        raise RuntimeError("train mode needs an MI355X (ROCm) device: this engine has no CPU path")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1 and not torch.distributed.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    torch.manual_seed(int(cfg.system.seed))                   # identical initial weights on every rank
+    module = ConnectomicsModule(cfg)
+    if args.checkpoint:
+        module.load_checkpoint_dict(torch.load(args.checkpoint, map_location="cpu", weights_only=False))
+    patch = tuple(cfg.data.dataloader.patch_size or cfg.model.input_size or (64, 64, 64))
+    bs = int(cfg.data.dataloader.batch_size)
+    steps = int(args.fast_dev_run) if args.fast_dev_run else int(cfg.optimization.n_steps_per_epoch or 100) * int(cfg.optimization.max_epochs)
+    img_spec = cfg.data.train.image
+    if img_spec is None or str(img_spec).startswith("random://") or args.demo:
+        batches = synthetic_batches(bs, patch, in_channels=cfg.model.in_channels, out_channels=cfg.model.out_channels,
+                                    seed=int(cfg.system.seed) + rank, device=dev)
+    else:
+        vol = torch.from_numpy(np.ascontiguousarray(read_volume(str(img_spec)), dtype=np.float32))
+        lab = torch.from_numpy(np.ascontiguousarray(read_volume(str(cfg.data.train.label))).astype(np.float32))
+        g = torch.Generator().manual_seed(int(cfg.system.seed) + rank)
+
+        def sampler():
+            while True:
+                xs, ys = [], []
+                for _ in range(bs):
+                    o = [int(torch.randint(0, vol.shape[a] - patch[a] + 1, (1,), generator=g)) for a in range(3)]
+                    sl = tuple(slice(o[a], o[a] + patch[a]) for a in range(3))
+                    xs.append(vol[sl][None]); ys.append((lab[sl] > 0).float()[None])
+                yield {"image": torch.stack(xs), "label": torch.stack(ys)}
+        batches = sampler()
+    t0 = time.perf_counter()
+    history, opt = fit(module, batches, max_steps=steps, device=dev, ddp=world > 1, log=logger.info if rank == 0 else None)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"steps": steps, "first_loss": history[0], "last_loss": history[-1],
+           "voxels_per_s": world * steps * bs * float(np.prod(patch)) / dt}
+    if rank == 0:
+        ck_dir = Path(cfg.save_path) / "checkpoints"
+        ck_dir.mkdir(parents=True, exist_ok=True)
+        torch.save(module.checkpoint_dict(opt), ck_dir / "last.ckpt")
+        logger.info("train done: %s", out)
+    return out
+
+
 def main(argv: Optional[Sequence[str]] = None):
     args = parse_args(argv)
     logging.basicConfig(level=logging.INFO, format="%(message)s")
     cfg = load_config(args.config, mode=args.mode, overrides=args.overrides)
     if args.mode in ("test", "tune-test"):
         return run_test(cfg, args)
-    raise NotImplementedError(
-        f"--mode {args.mode}: training on the MI355X engine needs the backward kernels (SURVEY.md section 8 row f-1), "
-        "which are not built yet; the forward / inference path is complete.")
+    if args.mode == "train":
+        return run_train(cfg, args)
+    raise NotImplementedError(f"--mode {args.mode}: hyper-parameter tuning is outside the hot path of this engine")
 
 
 if __name__ == "__main__":

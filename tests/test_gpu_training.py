@@ -149,3 +149,44 @@ def test_mednext_bf16_training_step_and_optimizer():
         r = ref_g[k].flatten()
         cos = float((g * r).sum() / (g.norm() * r.norm() + 1e-20))
         assert cos > 0.98, (k, cos)
+
+
+def test_cli_train_mode_and_resume(tmp_path):
+    """--mode train on synthetic patches (MedNeXt custom, bf16-mixed), checkpoint in Lightning layout, then test mode."""
+    from pytorch_connectomics_amd.main import main
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text(f"""
+experiment_name: e2e_train
+save_path: {tmp_path / 'out'}
+default:
+  model:
+    arch: {{type: mednext_custom}}
+    in_channels: 1
+    out_channels: 1
+    input_size: [32, 32, 32]
+    mednext: {{base_channels: 8, exp_r: 2, kernel_size: 3, block_counts: [1,1,1,1,1,1,1,1,1]}}
+  data:
+    dataloader: {{batch_size: 2, patch_size: [32, 32, 32]}}
+  inference:
+    window: {{window_size: [32, 32, 32], overlap: 0.5, sw_batch_size: 2}}
+    model: {{channel_activations: [{{channels: ":", activation: sigmoid}}]}}
+train:
+  optimization:
+    precision: "bf16-mixed"
+    gradient_clip_val: 1.0
+    max_epochs: 1
+    n_steps_per_epoch: 12
+    optimizer: {{name: AdamW, lr: 2.0e-3, weight_decay: 0.01}}
+test:
+  data:
+    test: {{image: "random://t?shape=40,40,40"}}
+""")
+    out = main(["--config", str(cfg), "--mode", "train"])
+    assert out["steps"] == 12 and out["last_loss"] < out["first_loss"] and out["voxels_per_s"] > 0
+    ck = tmp_path / "out" / "checkpoints" / "last.ckpt"
+    blob = torch.load(ck, weights_only=False)
+    assert "model.model.stem.weight" in blob["state_dict"] and blob["global_step"] == 12
+    m = main(["--config", str(cfg), "--mode", "test", "--checkpoint", str(ck)])
+    assert m["output_voxels_per_s"] > 0
+    out2 = main(["--config", str(cfg), "--mode", "train", "--checkpoint", str(ck), "--fast-dev-run", "2"])
+    assert out2["steps"] == 2

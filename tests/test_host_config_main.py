@@ -70,9 +70,9 @@ def test_cli_contract(tmp_path):
     with pytest.raises(SystemExit):
         parse_args(["--mode", "test"])
     p = _write(tmp_path)
-    with pytest.warns(UserWarning), pytest.raises(NotImplementedError, match="backward kernels"):
-        main(["--config", str(p), "--mode", "train"])
     if not torch.cuda.is_available():
+        with pytest.warns(UserWarning), pytest.raises(RuntimeError, match="no CPU path"):
+            main(["--config", str(p), "--mode", "train"])
         with pytest.warns(UserWarning), pytest.raises(RuntimeError, match="no CPU path"):
             main(["--config", str(p), "--mode", "test"])
 

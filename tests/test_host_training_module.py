@@ -1,0 +1,126 @@
+"""CPU tests of the training harness (reference tests/unit/test_connectomics_module.py style: a stand-in model):
+loss terms, deep supervision, optimizer grouping, scheduler, checkpoint layout, and DDP over gloo (world 2)."""
+import math
+import os
+from types import SimpleNamespace as NS
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+import torch.nn as nn
+import torch.nn.functional as F
+
+from pytorch_connectomics_amd.config import ConfigNode, schema_defaults
+from pytorch_connectomics_amd.training.module import (ConnectomicsModule, WarmupCosineLR, build_optimizer,
+                                                      dice_loss_sigmoid, fit, synthetic_batches,
+                                                      weighted_bce_with_logits)
+
+
+class SimpleModel(nn.Module):
+    def __init__(self, ds=False):
+        super().__init__()
+        self.conv = nn.Conv3d(1, 1, 3, padding=1)
+        self.norm = nn.GroupNorm(1, 1)
+        self.ds = ds
+
+    def forward(self, x):
+        y = self.norm(self.conv(x))
+        if not self.ds:
+            return y
+        return {"output": y, "ds_1": F.avg_pool3d(y, 2), "ds_2": F.avg_pool3d(y, 4)}
+
+
+def _cfg(**opt):
+    c = ConfigNode(schema_defaults())
+    c.optimization.optimizer.lr = 1e-2
+    for k, v in opt.items():
+        c.optimization[k] = v
+    return c
+
+
+def test_loss_terms_and_deep_supervision():
+    torch.manual_seed(0)
+    logits, target = torch.randn(2, 1, 8, 8, 8), (torch.rand(2, 1, 8, 8, 8) > 0.7).float()
+    p = torch.sigmoid(logits)
+    inter, den = (p * target).sum((2, 3, 4)), p.sum((2, 3, 4)) + target.sum((2, 3, 4))
+    assert torch.allclose(dice_loss_sigmoid(logits, target), (1 - (2 * inter + 1e-5) / (den + 1e-5)).mean())
+    assert torch.allclose(weighted_bce_with_logits(logits, target), F.binary_cross_entropy_with_logits(logits, target))
+    mask = (torch.rand_like(logits) > 0.5).float()
+    ref = (F.binary_cross_entropy_with_logits(logits, target, reduction="none") * mask).sum() / mask.sum()
+    assert torch.allclose(weighted_bce_with_logits(logits, target, weight=mask), ref)
+    cfg = _cfg()
+    cfg.model.loss.deep_supervision = True
+    m = ConnectomicsModule(cfg, model=SimpleModel(ds=True))
+    batch = {"image": torch.rand(2, 1, 8, 8, 8), "label": target}
+    loss = m.training_step(batch)
+    out = m(batch["image"])
+    base = lambda o, t: weighted_bce_with_logits(o, t) + dice_loss_sigmoid(o, t)
+    want = base(out["output"], target) + 0.5 * base(out["ds_1"], F.interpolate(target, size=(4, 4, 4))) \
+        + 0.25 * base(out["ds_2"], F.interpolate(target, size=(2, 2, 2)))
+    assert torch.allclose(loss, want, atol=1e-6) and loss.requires_grad
+    val = m.validation_step(batch)
+    assert 0 <= float(val["val_jaccard"]) <= 1
+    cfg.model.loss.losses = [{"function": "Nope"}]
+    with pytest.raises(ValueError, match="Unknown loss"):
+        ConnectomicsModule(cfg, model=SimpleModel())
+    cfg.model.loss.losses = [{"function": "MSELoss", "weight": 2.0, "pred_slice": "0:1", "target_slice": "0:1"}]
+    cfg.model.loss.deep_supervision = False
+    m2 = ConnectomicsModule(cfg, model=SimpleModel())
+    assert torch.allclose(m2.training_step(batch), 2 * F.mse_loss(m2(batch["image"]), target))
+
+
+def test_optimizer_grouping_and_scheduler():
+    cfg = _cfg()
+    cfg.optimization.optimizer.weight_decay = 0.01
+    model = SimpleModel()
+    opt = build_optimizer(cfg, model)
+    wd = {id(g["params"][0]): g["weight_decay"] for g in opt.param_groups}
+    assert wd[id(model.conv.weight)] == 0.01 and wd[id(model.conv.bias)] == 0.01
+    assert wd[id(model.norm.weight)] == 0.0 and wd[id(model.norm.bias)] == 0.0      # no decay on norm params
+    sch = WarmupCosineLR(opt, max_iters=100, warmup_iters=10, warmup_factor=0.001)
+    lrs = []
+    for _ in range(100):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step(); sch.step()
+    assert lrs[0] == pytest.approx(1e-2 * 0.001) and max(lrs) < 1e-2 and lrs[-1] < lrs[20]
+    assert lrs[50] == pytest.approx(1e-2 * 0.5 * (1 + math.cos(math.pi * 50 / 100)))
+    cfg.optimization.optimizer.name = "lion"
+    with pytest.raises(ValueError, match="Unknown optimizer"):
+        build_optimizer(cfg, model)
+
+
+def test_fit_and_checkpoint_roundtrip(tmp_path):
+    torch.manual_seed(0)
+    cfg = _cfg(gradient_clip_val=1.0)
+    m = ConnectomicsModule(cfg, model=SimpleModel())
+    hist, opt = fit(m, synthetic_batches(2, (8, 8, 8)), max_steps=25, device=torch.device("cpu"), log=None)
+    assert hist[-1] < hist[0] and m.global_step == 25
+    ck = m.checkpoint_dict(opt)
+    assert set(ck["state_dict"]) == {"model.conv.weight", "model.conv.bias", "model.norm.weight", "model.norm.bias"}
+    torch.save(ck, tmp_path / "last.ckpt")
+    m2 = ConnectomicsModule(cfg, model=SimpleModel())
+    m2.load_checkpoint_dict(torch.load(tmp_path / "last.ckpt", weights_only=False))
+    x = torch.rand(1, 1, 8, 8, 8)
+    assert torch.equal(m(x), m2(x)) and m2.global_step == 25
+
+
+def _ddp_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)                                  # same init on every rank
+    m = ConnectomicsModule(_cfg(), model=SimpleModel())
+    fit(m, synthetic_batches(2, (8, 8, 8), seed=42 + rank), max_steps=5, device=torch.device("cpu"), ddp=True, log=None)
+    flat = torch.cat([p.detach().flatten() for p in m.model.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    torch.distributed.all_gather(gathered, flat)
+    assert torch.equal(gathered[0], gathered[1])          # gradients were all-reduced: replicas stay identical
+    # and differ from single-process training on rank-0 data only
+    torch.manual_seed(0)
+    solo = ConnectomicsModule(_cfg(), model=SimpleModel())
+    fit(solo, synthetic_batches(2, (8, 8, 8), seed=42), max_steps=5, device=torch.device("cpu"), log=None)
+    assert not torch.equal(torch.cat([p.detach().flatten() for p in solo.model.parameters()]), flat)
+    torch.distributed.destroy_process_group()
+
+
+def test_ddp_gloo_two_ranks():
+    mp.spawn(_ddp_worker, args=(2, 29500 + (os.getpid() + 7) % 2000), nprocs=2, join=True)
