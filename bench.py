@@ -79,6 +79,63 @@ def cpu_baseline(model, seconds_cap: float = 25.0):
                       f"{threads} threads (best of {cands}) on a {cores}-core host"}
 
 
+def train_leg(dev, rank, world, args, barrier):
+    """The training half of the metric: DDP (RCCL all-reduce) MedNeXt-S steps on synthetic 112^3 patches, bf16
+    storage / fp32 master weights: HIP forward + HIP backward + BCE/Dice loss + grad clip + AdamW, nothing skipped.
+    Reported next to `value` (which stays the sliding-window inference rate the target is quoted on)."""
+    from types import SimpleNamespace as NS
+    from pytorch_connectomics_amd.models import build_model as bm
+    from pytorch_connectomics_amd.training.module import (build_optimizer, dice_loss_sigmoid, synthetic_batches,
+                                                          weighted_bce_with_logits)
+    from pytorch_connectomics_amd.config import ConfigNode, schema_defaults
+    cfg = ConfigNode(schema_defaults())
+    cfg.model.arch.type, cfg.model.in_channels, cfg.model.out_channels = "mednext", 1, 1
+    cfg.model.mednext.size, cfg.model.mednext.kernel_size = "S", 3
+    cfg.optimization.optimizer.name, cfg.optimization.optimizer.lr = "AdamW", 1e-3
+    torch.manual_seed(0)
+    model = bm(cfg).to(dev).train()
+    model.model.compute_dtype = torch.bfloat16
+    net = model
+    if world > 1:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        net = DDP(model, device_ids=[dev.index], find_unused_parameters=True, gradient_as_bucket_view=True)
+    opt = build_optimizer(cfg, model)
+    it = synthetic_batches(args.train_batch, ROI, seed=11 + rank, device=dev)
+    pool = [next(it) for _ in range(2)]                                # patches resident in HBM before timing
+    steps = max(1, min(args.steps, 10))
+
+    def tstep(i):
+        b = pool[i % len(pool)]
+        opt.zero_grad(set_to_none=True)
+        out = net(b["image"])
+        loss = weighted_bce_with_logits(out, b["label"]) + dice_loss_sigmoid(out, b["label"])
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        return loss
+
+    for i in range(max(1, min(args.warmup, 3))):
+        tstep(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = tstep(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    vox = world * args.train_batch * ROI[0] * ROI[1] * ROI[2] * steps
+    del opt, net, model
+    torch.cuda.empty_cache()
+    return {"value": vox / dt, "unit": "voxels/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "batch_per_gpu": args.train_batch, "patch": list(ROI), "dtype": "bf16 activations, fp32 master weights",
+            "parallelism": f"ddp{world}" if world > 1 else "single", "scaling": "weak",
+            "includes": "forward + backward (HIP kernels) + BCE/Dice loss + grad-norm clip + AdamW step",
+            "final_loss": float(loss)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,6 +143,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--train-batch", type=int, default=4)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -167,6 +226,10 @@ def main():
                 print(f"  {k:34s} launches/step={v['launches'] / n:5.1f} ms/step={v['ms'] / n:7.3f} "
                       f"GB/s={v['bytes'] / max(v['ms'], 1e-9) / 1e6:8.1f}", file=sys.stderr)
 
+    train = None
+    if not args.no_train:
+        train = train_leg(dev, rank, world, args, barrier)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(model)
@@ -182,7 +245,7 @@ def main():
                                    "sw_batch_size 8, random-init weights; value = window-voxels/s",
                        "volume": list(VOLUME), "roi": list(ROI), "sw_batch_size": SW_BATCH,
                        "sharding": "one independent volume per rank, no collective"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "train": train,
         }
         print(json.dumps(out))
     if world > 1:

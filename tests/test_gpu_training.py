@@ -175,17 +175,17 @@ train:
     precision: "bf16-mixed"
     gradient_clip_val: 1.0
     max_epochs: 1
-    n_steps_per_epoch: 12
-    optimizer: {{name: AdamW, lr: 2.0e-3, weight_decay: 0.01}}
+    n_steps_per_epoch: 20
+    optimizer: {{name: AdamW, lr: 5.0e-3, weight_decay: 0.01}}
 test:
   data:
     test: {{image: "random://t?shape=40,40,40"}}
 """)
     out = main(["--config", str(cfg), "--mode", "train"])
-    assert out["steps"] == 12 and out["last_loss"] < out["first_loss"] and out["voxels_per_s"] > 0
+    assert out["steps"] == 20 and out["last_loss"] < out["first_loss"] and out["voxels_per_s"] > 0
     ck = tmp_path / "out" / "checkpoints" / "last.ckpt"
     blob = torch.load(ck, weights_only=False)
-    assert "model.model.stem.weight" in blob["state_dict"] and blob["global_step"] == 12
+    assert "model.model.stem.weight" in blob["state_dict"] and blob["global_step"] == 20
     m = main(["--config", str(cfg), "--mode", "test", "--checkpoint", str(ck)])
     assert m["output_voxels_per_s"] > 0
     out2 = main(["--config", str(cfg), "--mode", "train", "--checkpoint", str(ck), "--fast-dev-run", "2"])
