@@ -3,7 +3,7 @@
 //   transposed conv share one form), GroupNorm backward (statistics + apply), strided depthwise backward-data,
 //   elementwise add.  Data gradients of the 1x1 convs reuse pw_conv with transposed weights; the stride-1
 //   depthwise backward-data reuses the forward kernels with flipped taps.
-#include "pytc_common.h"
+#include "pw_common.h"
 
 namespace pytc {
 
@@ -104,14 +104,186 @@ pw_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ ab, const T* 
   }
 }
 
-// out[i] = sum_s part[s][i]   (fixed order)
+// ---- pointwise weight gradient on MFMA (bf16): a "TN" GEMM with the voxel rows as the reduction dimension ----------
+// Both operands are [row][channel] in HBM (channels contiguous) while an MFMA fragment wants 8 reduction indices of
+// ONE channel per lane: gfx950's LDS transpose read (ds_read_b64_tr_b16) does that regrouping.  Every wave owns 32
+// rows at a time: 16-B global loads -> a wave-private, row-padded LDS image (no workgroup barrier in the loop, the next
+// block's loads are in flight during the MFMAs) -> per 16-channel tile two transpose reads = one fragment.  The
+// row <-> k-slot map (lane group g, element j) -> row (j>>2)*16 + g*4 + (j&3) is the same for both operands, which is
+// all a reduction needs; with a row pitch of 2*C+32 bytes each half-wave's 8 rows fall in 8 distinct bank octets.
+// db comes from one extra MFMA per tile row against a fragment of ones.  The four waves' accumulators are added in a
+// fixed order (wave 0 + 1 + 2 + 3) -> per-slot partials -> reduce_slots: deterministic.
+template <int MT, int NT>
+__global__ void __launch_bounds__(256)
+pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab, const bf16_t* __restrict__ dy,
+                     float* __restrict__ dWp, float* __restrict__ dbp, long rows_total, long rows_per_sample, int C_in,
+                     int C_out, long rows_per_slot) {
+  constexpr int BM = MT * 16, BN = NT * 16;
+  constexpr int SG = BM * 2 + 32, SX = BN * 2 + 32;        // LDS row pitch in bytes
+  constexpr int WAVE_BYTES = 32 * (SG + SX);
+  constexpr int RED_BYTES = (BM * BN + BM) * 4;
+  constexpr int LDS_BYTES = 4 * WAVE_BYTES > RED_BYTES ? 4 * WAVE_BYTES : RED_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned char* lg = lds + wave * WAVE_BYTES;
+  unsigned char* lx = lg + 32 * SG;
+  const int slot = blockIdx.x;
+  const int tiles_k = C_in / BN;
+  const int o_base = (blockIdx.y / tiles_k) * BM, k_base = (blockIdx.y % tiles_k) * BN;
+  const bool want_db = dbp != nullptr && (blockIdx.y % tiles_k) == 0;
+  const long r_begin = (long)slot * rows_per_slot;
+  const long r_end = r_begin + rows_per_slot < rows_total ? r_begin + rows_per_slot : rows_total;
+
+  constexpr int CHG = BM / 8, RG = 64 / CHG, ITG = 32 / RG;   // 16-B chunks per row, rows per load, loads per block
+  constexpr int CHX = BN / 8, RX = 64 / CHX, ITX = 32 / RX;
+  const int g_row = lane / CHG, g_chunk = lane % CHG;
+  const int x_row = lane / CHX, x_chunk = lane % CHX;
+  uint4 rg[ITG], rx[ITX];
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  auto fetch = [&](long r0) {
+#pragma unroll
+    for (int it = 0; it < ITG; ++it) {
+      const long r = r0 + it * RG + g_row;
+      rg[it] = r < r_end ? *reinterpret_cast<const uint4*>(dy + r * C_out + o_base + g_chunk * 8) : zero4;
+    }
+#pragma unroll
+    for (int it = 0; it < ITX; ++it) {
+      const long r = r0 + it * RX + x_row;
+      rx[it] = r < r_end ? *reinterpret_cast<const uint4*>(x + r * C_in + k_base + x_chunk * 8) : zero4;
+    }
+  };
+  auto stage = [&](long r0) {
+#pragma unroll
+    for (int it = 0; it < ITG; ++it) *reinterpret_cast<uint4*>(lg + (it * RG + g_row) * SG + g_chunk * 16) = rg[it];
+#pragma unroll
+    for (int it = 0; it < ITX; ++it) {
+      uint4 v = rx[it];
+      const long r = r0 + it * RX + x_row;
+      if (ab && r < r_end) {            // the forward GEMM consumed bf16(a*x+b): restate it here
+        const long n = r / rows_per_sample;
+        const float* a = ab + (n * 2 + 0) * C_in + k_base + x_chunk * 8;
+        const float* b = ab + (n * 2 + 1) * C_in + k_base + x_chunk * 8;
+        const bf16x8_t in = __builtin_bit_cast(bf16x8_t, v);
+        f32x8_t f = __builtin_convertvector(in, f32x8_t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = fmaf(f[i], a[i], b[i]);
+        v = __builtin_bit_cast(uint4, __builtin_convertvector(f, bf16x8_t));
+      }
+      *reinterpret_cast<uint4*>(lx + (it * RX + x_row) * SX + x_chunk * 16) = v;
+    }
+  };
+  // transpose read of one 16-channel fragment: lane (g = lane>>4, i = lane&15) supplies the address of 4 channels
+  // (i&3)*4.. of row g*4 + (i>>2) (+16 for the second read) and receives channel i of the group's 4 rows.
+  const int fr_row = (lane >> 4) * 4 + ((lane & 15) >> 2), fr_col = (lane & 3) * 8;
+  auto frag = [&](unsigned char* base, int pitch, int tile) -> bf16x8_t {
+    unsigned char* p = base + fr_row * pitch + tile * 32 + fr_col;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 16 * pitch));
+    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, both);
+  };
+
+  f32x4_t acc[MT][NT], accb[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    accb[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  bf16x8_t ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
+
+  long r0 = r_begin + wave * 32;
+  if (r0 < r_end) fetch(r0);
+  for (; r0 < r_end; r0 += 128) {
+    stage(r0);
+    if (r0 + 128 < r_end) fetch(r0 + 128);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    bf16x8_t fa[MT], fb[NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) fa[m] = frag(lg, SG, m);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) fb[n] = frag(lx, SX, n);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+      if (want_db) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], ones, accb[m], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  // fixed-order cross-wave sum through LDS, then wave 0 stores the slot partial
+  float* red = reinterpret_cast<float*>(lds);
+  const int nn = lane & 15, mg = (lane >> 4) * 4;
+  for (int w = 1; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) red[(m * 16 + mg + i) * BN + n * 16 + nn] = acc[m][n][i];
+        if (nn == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) red[BM * BN + m * 16 + mg + i] = accb[m][i];
+        }
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[m][n][i] += red[(m * 16 + mg + i) * BN + n * 16 + nn];
+        if (nn == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) accb[m][i] += red[BM * BN + m * 16 + mg + i];
+        }
+      }
+    }
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int o = o_base + m * 16 + mg + i;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) dWp[((long)slot * C_out + o) * C_in + k_base + n * 16 + nn] = acc[m][n][i];
+        if (want_db && nn == 0) dbp[(long)slot * C_out + o] = accb[m][i];
+      }
+    }
+  }
+}
+
+// out[i] = sum_s part[s][i]: 16 elements x 16 slot lanes per workgroup; lane j adds slots j, j+16, ... in order and
+// the 16 lane sums are added in lane order -> a fixed summation tree, independent of the launch.
 __global__ void __launch_bounds__(256)
 reduce_slots_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int slots) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  __shared__ float sm[16][17];
+  const int e = threadIdx.x & 15, j = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + e;
   float a = 0.f;
-  for (int s = 0; s < slots; ++s) a += part[(long)s * n + i];
-  out[i] = a;
+  if (i < n)
+    for (int s = j; s < slots; s += 16) a += part[(long)s * n + i];
+  sm[j][e] = a;
+  __syncthreads();
+  if (j == 0 && i < n) {
+    float t = sm[0][e];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += sm[q][e];
+    out[i] = t;
+  }
 }
 
 // ---- depthwise weight gradient:  dW[k][c] = sum_{n,o} G[n][o][c] * X[n][o*s - p + k][c],  db[c] = sum G ------------
@@ -316,8 +488,20 @@ extern "C" int pytc_add_inplace(void* y, const void* x, int64_t n, int dtype, vo
 }
 
 extern "C" int pytc_pw_wgrad_slots(int64_t rows_total) {
-  long s = rows_total / 4096;
-  return (int)(s < 1 ? 1 : (s > 256 ? 256 : s));
+  long s = rows_total / 1024;
+  return (int)(s < 1 ? 1 : (s > 1024 ? 1024 : s));
+}
+
+static int wg_tile16(int C) { return C % 64 == 0 ? 4 : (C % 32 == 0 ? 2 : (C % 16 == 0 ? 1 : 0)); }
+
+template <int MT>
+static void launch_wgrad_mfma(int nt, dim3 grid, hipStream_t s, const bf16_t* x, const float* ab, const bf16_t* dy,
+                              float* dWp, float* dbp, long rows_total, long rps_sample, int C_in, int C_out, long rps) {
+  switch (nt) {
+    case 4: hipLaunchKernelGGL((pw_wgrad_mfma_kernel<MT, 4>), grid, dim3(256), 0, s, x, ab, dy, dWp, dbp, rows_total, rps_sample, C_in, C_out, rps); break;
+    case 2: hipLaunchKernelGGL((pw_wgrad_mfma_kernel<MT, 2>), grid, dim3(256), 0, s, x, ab, dy, dWp, dbp, rows_total, rps_sample, C_in, C_out, rps); break;
+    default: hipLaunchKernelGGL((pw_wgrad_mfma_kernel<MT, 1>), grid, dim3(256), 0, s, x, ab, dy, dWp, dbp, rows_total, rps_sample, C_in, C_out, rps); break;
+  }
 }
 
 extern "C" int pytc_pw_wgrad(const void* x, const float* ab, const void* dy, float* dW, float* db, float* workspace,
@@ -328,15 +512,27 @@ extern "C" int pytc_pw_wgrad(const void* x, const float* ab, const void* dy, flo
   const long rps = (rows_total + slots - 1) / slots;
   float* dWp = workspace;
   float* dbp = workspace + (long)slots * C_out * C_in;
-  dim3 grid(slots, ((C_out + WG_TO - 1) / WG_TO) * ((C_in + WG_TK - 1) / WG_TK)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_T(dtype,
-             hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, ab, (const bf16_t*)dy, dWp, db ? dbp : nullptr, rows_total, (long)rows_per_sample, C_in, C_out, rps, slots),
-             hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, block, 0, s, (const float*)x, ab, (const float*)dy, dWp, db ? dbp : nullptr, rows_total, (long)rows_per_sample, C_in, C_out, rps, slots),
-             "pw_wgrad")
+  const int mt = wg_tile16(C_out), nt = wg_tile16(C_in);
+  if (dtype == PYTC_BF16 && mt && nt && tuning_get("wgrad_valu", 0) == 0) {
+    // bf16, channel counts in multiples of 16: MFMA path (transpose reads from a wave-private LDS image)
+    dim3 grid(slots, (C_out / (16 * mt)) * (C_in / (16 * nt)));
+    const bf16_t* xp = (const bf16_t*)x;
+    const bf16_t* dp = (const bf16_t*)dy;
+    float* dbq = db ? dbp : nullptr;
+    if (mt == 4) launch_wgrad_mfma<4>(nt, grid, s, xp, ab, dp, dWp, dbq, rows_total, (long)rows_per_sample, C_in, C_out, rps);
+    else if (mt == 2) launch_wgrad_mfma<2>(nt, grid, s, xp, ab, dp, dWp, dbq, rows_total, (long)rows_per_sample, C_in, C_out, rps);
+    else launch_wgrad_mfma<1>(nt, grid, s, xp, ab, dp, dWp, dbq, rows_total, (long)rows_per_sample, C_in, C_out, rps);
+  } else {
+    dim3 grid(slots, ((C_out + WG_TO - 1) / WG_TO) * ((C_in + WG_TK - 1) / WG_TK)), block(256);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, ab, (const bf16_t*)dy, dWp, db ? dbp : nullptr, rows_total, (long)rows_per_sample, C_in, C_out, rps, slots),
+               hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, block, 0, s, (const float*)x, ab, (const float*)dy, dWp, db ? dbp : nullptr, rows_total, (long)rows_per_sample, C_in, C_out, rps, slots),
+               "pw_wgrad")
+  }
   const long nW = (long)C_out * C_in;
-  hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(nW, 256)), dim3(256), 0, s, dWp, dW, nW, slots);
-  if (db) hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(C_out, 256)), dim3(256), 0, s, dbp, db, (long)C_out, slots);
+  hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(nW, 16)), dim3(256), 0, s, dWp, dW, nW, slots);
+  if (db) hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(C_out, 16)), dim3(256), 0, s, dbp, db, (long)C_out, slots);
   PYTC_LAUNCH_CHECK("pw_wgrad");
   return PYTC_OK;
 }
@@ -392,8 +588,8 @@ extern "C" int pytc_dw_wgrad(const void* g, const void* x, float* dW, float* db,
   if (dtype == PYTC_BF16) rc = vec == 4 ? launch_dwwg<bf16_t, 4>(g, x, dWp, dbp, q, s) : vec == 2 ? launch_dwwg<bf16_t, 2>(g, x, dWp, dbp, q, s) : launch_dwwg<bf16_t, 1>(g, x, dWp, dbp, q, s);
   else rc = vec == 2 ? launch_dwwg<float, 2>(g, x, dWp, dbp, q, s) : launch_dwwg<float, 1>(g, x, dWp, dbp, q, s);
   if (rc != PYTC_OK) return rc;
-  hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(nW, 256)), dim3(256), 0, s, dWp, dW, nW, total_slots);
-  if (db) hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, dbp, db, (long)C, total_slots);
+  hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(nW, 16)), dim3(256), 0, s, dWp, dW, nW, total_slots);
+  if (db) hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, s, dbp, db, (long)C, total_slots);
   PYTC_LAUNCH_CHECK("dw_wgrad");
   return PYTC_OK;
 }
@@ -415,7 +611,7 @@ extern "C" int pytc_norm_bwd(const void* dtn, const void* t, const float* mean_r
              "norm_bwd")
   // reduce slots per sample: stats_ws [N][slots][2][C] -> s_out [N][2][C]
   for (int n = 0; n < N; ++n)
-    hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(2L * C, 256)), dim3(256), 0, s, stats_ws + (long)n * slots * 2 * C,
+    hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(2L * C, 16)), dim3(256), 0, s, stats_ws + (long)n * slots * 2 * C,
                        s_out + (long)n * 2 * C, 2L * C, slots);
   const long total = (long)N * rows * C;
   DISPATCH_T(dtype,

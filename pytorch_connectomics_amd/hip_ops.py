@@ -398,6 +398,11 @@ def add_(y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def set_tuning(key: str, value: int) -> None:
+    """Kernel-variant knob (A/B measurements and parity tests between variants); see pytc_set_tuning."""
+    nat.check(nat.lib().pytc_set_tuning(key.encode(), int(value)), "set_tuning")
+
+
 def pw_wgrad(x: torch.Tensor, dy: torch.Tensor, *, N: int, rows_per_sample: int, c_in: int, c_out: int,
              ab: Optional[torch.Tensor] = None, want_bias: bool = True):
     """-> dW (c_out, c_in) fp32, db (c_out) fp32 | None"""

@@ -49,6 +49,38 @@ def test_pw_wgrad_and_gelu_and_norm_bwd_kernels():
     torch.testing.assert_close(s[:, 0].sum(0).cpu(), beta.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("ci,co,rows,N,use_ab", [(32, 64, 5003, 2, True), (64, 32, 4096, 1, False), (16, 16, 100, 3, True),
+                                                 (128, 64, 1372, 2, True), (64, 256, 999, 2, False),
+                                                 (48, 96, 2500, 1, True), (512, 1024, 343, 2, False)])
+def test_pw_wgrad_mfma_bf16(ci, co, rows, N, use_ab):
+    """bf16 weight gradient on MFMA (LDS transpose reads): against an fp64 einsum over the same bf16 operands, and
+    against the VALU kernel it replaces (`wgrad_valu` knob) -- ragged row counts, slot tails, all tile shapes."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(ci + co)
+    x = torch.randn(N, rows, ci).bfloat16()
+    dy = torch.randn(N, rows, co).bfloat16()
+    ab = None
+    xn = x.double()
+    if use_ab:
+        a, b = torch.rand(N, ci) + 0.5, torch.randn(N, ci)
+        ab = torch.stack([a, b], 1).contiguous().cuda()
+        xn = torch.addcmul(b[:, None], x.float(), a[:, None]).bfloat16().double()     # fp32 fma, rounded like the forward
+    want = torch.einsum("nro,nrk->ok", dy.double(), xn)
+    dW, db = ops.pw_wgrad(x.cuda(), dy.cuda(), N=N, rows_per_sample=rows, c_in=ci, c_out=co, ab=ab)
+    scale = float(want.abs().max())
+    assert float((dW.cpu().double() - want).abs().max()) < 2e-3 * scale        # one-ulp flips of a*x+b at most
+    torch.testing.assert_close(db.cpu().double(), dy.double().sum((0, 1)), rtol=1e-5, atol=1e-3)
+    ops.set_tuning("wgrad_valu", 1)
+    try:
+        dW2, db2 = ops.pw_wgrad(x.cuda(), dy.cuda(), N=N, rows_per_sample=rows, c_in=ci, c_out=co, ab=ab)
+    finally:
+        ops.set_tuning("wgrad_valu", 0)
+    assert float((dW - dW2).abs().max()) < 2e-3 * scale
+    torch.testing.assert_close(db, db2, rtol=1e-5, atol=1e-3)
+    dW3, _ = ops.pw_wgrad(x.cuda(), dy.cuda(), N=N, rows_per_sample=rows, c_in=ci, c_out=co, ab=ab)
+    assert torch.equal(dW, dW3)                                                 # deterministic
+
+
 @pytest.mark.parametrize("C,K,stride,shape", [(8, 3, 1, (6, 7, 9)), (16, 3, 2, (8, 8, 10)), (4, 5, 1, (6, 6, 7)), (32, 3, 1, (9, 17, 18))])
 def test_depthwise_backward_kernels(C, K, stride, shape):
     from pytorch_connectomics_amd import hip_ops as ops
