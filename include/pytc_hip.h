@@ -59,6 +59,7 @@ extern "C" {
 #define PYTC_RES_NONE 0
 #define PYTC_RES_ADD 1        /* y = f(x) + R[row]                     (MedNeXt block / down block) */
 #define PYTC_RES_UPSAMPLE 2   /* MedNeXt up block: front-pad + transposed 1x1 residual + skip     */
+#define PYTC_RES_GELU_BWD 3   /* y = f(x) * gelu'(R[row]): GELU backward fused into the data-gradient GEMM */
 
 int pytc_abi_version(void);
 const char* pytc_last_error(void);
@@ -178,6 +179,8 @@ typedef struct {
   int Di, Hi, Wi;       /* input grid (gather == 2) or output grid (RES_UPSAMPLE) */
   const void* res_low;  /* RES_UPSAMPLE: low-res residual [N][Di/2..][C_out] */
   const float* res_bias;/* RES_UPSAMPLE: bias of the transposed 1x1 residual conv */
+  int pre_act;          /* PYTC_ACT_NONE or PYTC_ACT_GELU applied to f(x) BEFORE the GEMM (the stored tensor is the
+                         * pre-activation; training keeps only that one copy of the expanded tensor) */
 } pytc_pw_args;
 
 int pytc_pw_conv_fwd(const pytc_pw_args* a, void* stream);
@@ -278,7 +281,8 @@ int pytc_add_inplace(void* y, const void* x, int64_t n, int dtype, void* stream)
  * workspace: pytc_pw_wgrad_slots(N*rows) * (C_out*C_in + C_out) floats */
 int pytc_pw_wgrad_slots(int64_t rows_total);
 int pytc_pw_wgrad(const void* x, const float* ab, const void* dy, float* dW, float* db, float* workspace, int N,
-                  int64_t rows_per_sample, int C_in, int C_out, int dtype, void* stream);
+                  int64_t rows_per_sample, int C_in, int C_out, int dtype, int x_act /* PYTC_ACT_NONE | PYTC_ACT_GELU:
+                  f(X) = gelu(X), the forward's fused pre-activation */, void* stream);
 /* dW[tap][c] = sum_{n,o} G[n][o][c] * X[n][o*stride - K/2 + tap][c], db[c] = sum G.  Depthwise conv: G = dL/dy
  * (output grid gdims), X = layer input (xdims).  Transposed depthwise conv (stride 2): G = layer input, X = dL/dy.
  * workspace: pytc_dw_wgrad_slots(...) * (K^3*C + C) floats */

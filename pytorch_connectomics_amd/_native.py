@@ -18,7 +18,7 @@ VIEW_FLIP_Z, VIEW_FLIP_Y, VIEW_FLIP_X, VIEW_SWAP_YX = 1, 2, 4, 8
 PAD_MODES = {"constant": 0, "reflect": 1, "replicate": 2, "circular": 3}
 BLEND_PRODUCT, BLEND_MIN = 0, 1
 ACT_NONE, ACT_SIGMOID, ACT_TANH, ACT_GELU, ACT_SOFTMAX, ACT_RELU, ACT_LEAKY, ACT_ELU = 0, 1, 2, 3, 4, 5, 6, 7
-RES_NONE, RES_ADD, RES_UPSAMPLE = 0, 1, 2
+RES_NONE, RES_ADD, RES_UPSAMPLE, RES_GELU_BWD = 0, 1, 2, 3
 
 
 class PwArgs(C.Structure):
@@ -30,7 +30,7 @@ class PwArgs(C.Structure):
         ("in_dtype", C.c_int), ("out_dtype", C.c_int), ("w_dtype", C.c_int),
         ("act", C.c_int), ("res_mode", C.c_int), ("gather", C.c_int),
         ("Di", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int),
-        ("res_low", C.c_void_p), ("res_bias", C.c_void_p),
+        ("res_low", C.c_void_p), ("res_bias", C.c_void_p), ("pre_act", C.c_int),
     ]
 
 
@@ -100,7 +100,7 @@ _SIGS = {
     "pytc_add_inplace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "pytc_pw_wgrad_slots": (C.c_int, [C.c_int64]),
     "pytc_pw_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                                C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pytc_dw_wgrad_slots": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int,
                                       C.c_int]),
     "pytc_dw_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

@@ -436,6 +436,222 @@ static void make_march(DwMarch& t, int N, int D, int H, int W, int C) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Depthwise 3x3x3 stride-1 weight gradient, z-march form:  dW[kz][ky][kx][c] = sum_o G[o][c] * X[o + k - 1][c].
+// Same footprint / staging as the forward march (X plane with halo -> fp32 LDS image, one plane per step), but the
+// roles flip: the 27 x 2 ACCUMULATORS are the taps (per lane: one channel pair), and the three rolling register sets
+// hold G at planes gz-1 / gz / gz+1 for the lane's four positions: X plane gz meets G[gz+1] in the kz=0 taps, G[gz] in
+// kz=1, G[gz-1] in kz=2, so each LDS read feeds three packed FMAs.  G comes straight from HBM one plane ahead (4-byte
+// channel-pair loads, 64-B segments per position).  Partials: lanes of equal channel pair are summed by two xor
+// shuffles, the four waves in LDS in wave order -> dWp[slot][27][C], dbp[slot][C]; reduce_slots finishes.
+template <typename T>
+__global__ void __launch_bounds__(256, 2)
+dw_wgrad_march_kernel(const T* __restrict__ gr, const T* __restrict__ x, float* __restrict__ dWp,
+                      float* __restrict__ dbp, DwMarch g) {
+  constexpr int VEC = 2, CG = MARCH_CG, LPV = CG / VEC, PPP = 256 / LPV, PASSES = (TILE_Y * TILE_X) / PPP;
+  constexpr int EY = TILE_Y + 2, EX = TILE_X + 2;
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int CH16 = CG / EPC;
+  constexpr int NCHUNK = EY * EX * CH16;
+  constexpr int CPT = (NCHUNK + 255) / 256;
+  typedef float fvec_t __attribute__((ext_vector_type(VEC)));
+  __shared__ __attribute__((aligned(16))) float plane[2][EY * EX * CG];
+  static_assert(4 * 28 * CG <= 2 * EY * EX * CG, "cross-wave scratch must fit in the plane buffers");
+
+  const int tid = threadIdx.x;
+  int b = g.swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int slot_id = b % g.slots; b /= g.slots;
+  const int ncg = g.C / MARCH_CG;
+  const int cg = b % ncg;
+  const int n = b / ncg;
+  b = slot_id;
+  const int fx = b % g.tx; b /= g.tx;
+  const int fy = b % g.ty;
+  const int zchunk = b / g.ty;
+  const int y0 = fy * TILE_Y, x0 = fx * TILE_X;
+  const int zs = zchunk * g.zc;
+  const int ze = min(zs + g.zc, g.D);               // G planes [zs, ze) belong to this workgroup
+  const int C = g.C;
+  const long plane_elems = (long)g.H * g.W * C;
+  const T* xn = x + (long)n * g.D * plane_elems + cg * CG;
+  const T* gn = gr + (long)n * g.D * plane_elems + cg * CG;
+
+  int goff[CPT], loff[CPT];
+  bool cok[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = tid + 256 * i;
+    const int vox = c / CH16, part = c % CH16;
+    const int yy = vox / EX, xx = vox % EX;
+    const int gy = y0 - 1 + yy, gx = x0 - 1 + xx;
+    cok[i] = (c < NCHUNK) && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
+    goff[i] = (gy * g.W + gx) * C + part * EPC;
+    loff[i] = (c < NCHUNK) ? vox * CG + part * EPC : -1;
+  }
+  uint4 stg[CPT];
+  auto issue = [&](int gz) {
+    const bool zok = gz >= 0 && gz < g.D;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      stg[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (zok && cok[i]) stg[i] = *reinterpret_cast<const uint4*>(xn + (long)gz * plane_elems + goff[i]);
+    }
+  };
+  auto commit = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      if (loff[i] < 0) continue;
+      float v[EPC];
+      VecIO<T, EPC>::load(reinterpret_cast<const T*>(&stg[i]), v);
+      float* dst = &plane[slot][loff[i]];
+#pragma unroll
+      for (int q = 0; q < EPC; q += 4)
+        *reinterpret_cast<f32x4_t*>(dst + q) = f32x4_t{v[q], v[q + 1], v[q + 2], v[q + 3]};
+    }
+  };
+
+  const int cv = tid % LPV, pslot = tid / LPV;
+  int lbase[PASSES];
+  long obase[PASSES];
+  bool pok[PASSES];
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int pos = ps * PPP + pslot;
+    const int py = pos / TILE_X, px = pos % TILE_X;
+    lbase[ps] = (py * EX + px) * CG + cv * VEC;
+    pok[ps] = (y0 + py) < g.H && (x0 + px) < g.W;
+    obase[ps] = ((long)(y0 + py) * g.W + (x0 + px)) * C + cv * VEC;
+  }
+  float acc[27][VEC], accb[VEC];
+#pragma unroll
+  for (int t = 0; t < 27; ++t)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[t][i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) accb[i] = 0.f;
+  float gA[PASSES][VEC], gB[PASSES][VEC], gC[PASSES][VEC], gq[PASSES][VEC];
+  auto gload = [&](int gz, float (&dst)[PASSES][VEC]) {      // G plane gz at the lane's positions (0 outside the chunk)
+    const bool zok = gz >= zs && gz < ze;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) dst[ps][i] = 0.f;
+      if (zok && pok[ps]) VecIO<T, VEC>::load(gn + (long)gz * plane_elems + obase[ps], dst[ps]);
+    }
+  };
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { gA[ps][i] = 0.f; gB[ps][i] = 0.f; }
+  gload(zs, gC);
+
+  // one z step: X plane gz is in plane[slot]; prev/cur/next = G[gz-1] / G[gz] / G[gz+1]
+  auto step = [&](int gz, int slot, float (&prev)[PASSES][VEC], float (&cur)[PASSES][VEC], float (&next)[PASSES][VEC]) {
+    if (gz + 1 <= ze) issue(gz + 1);
+    gload(gz + 2, gq);
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) accb[i] += next[ps][i];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const fvec_t v = *reinterpret_cast<const fvec_t*>(&plane[slot][lbase[ps] + (dy * EX + dx) * CG]);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            acc[(0 * 3 + dy) * 3 + dx][i] = fmaf(v[i], next[ps][i], acc[(0 * 3 + dy) * 3 + dx][i]);
+            acc[(1 * 3 + dy) * 3 + dx][i] = fmaf(v[i], cur[ps][i], acc[(1 * 3 + dy) * 3 + dx][i]);
+            acc[(2 * 3 + dy) * 3 + dx][i] = fmaf(v[i], prev[ps][i], acc[(2 * 3 + dy) * 3 + dx][i]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) prev[ps][i] = gq[ps][i];      // the freed set becomes G[gz+2]
+    if (gz + 1 <= ze) commit(slot ^ 1);
+    __syncthreads();
+  };
+
+  issue(zs - 1);
+  commit(0);
+  __syncthreads();
+  int slot = 0;
+  for (int gz = zs - 1; gz <= ze; gz += 3) {
+    step(gz, slot, gA, gB, gC); slot ^= 1;
+    if (gz + 1 <= ze) { step(gz + 1, slot, gB, gC, gA); slot ^= 1; }
+    if (gz + 2 <= ze) { step(gz + 2, slot, gC, gA, gB); slot ^= 1; }
+  }
+
+  // lanes cv, cv+16, cv+32, cv+48 hold the same channel pair: xor-shuffle sum, then waves through LDS in order
+#pragma unroll
+  for (int off = LPV; off < 64; off <<= 1) {
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[t][i] += __shfl_xor(acc[t][i], off, 64);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) accb[i] += __shfl_xor(accb[i], off, 64);
+  }
+  float* red = &plane[0][0];                       // [4 waves][28][CG]   (the last step ended with a barrier)
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane < LPV) {
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) red[(wave * 28 + t) * CG + lane * VEC + i] = acc[t][i];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) red[(wave * 28 + 27) * CG + lane * VEC + i] = accb[i];
+  }
+  __syncthreads();
+  const long sidx = (long)n * g.slots + slot_id;
+  for (int e = tid; e < 28 * CG; e += 256) {
+    const int t = e / CG, ch = e % CG;
+    float a = red[(0 * 28 + t) * CG + ch];
+#pragma unroll
+    for (int wv = 1; wv < 4; ++wv) a += red[(wv * 28 + t) * CG + ch];
+    if (t < 27) dWp[(sidx * 27 + t) * C + cg * CG + ch] = a;
+    else if (dbp) dbp[sidx * C + cg * CG + ch] = a;
+  }
+}
+
+static void make_wgrad_march(DwMarch& t, int N, int D, int H, int W, int C) {
+  t.N = N; t.D = D; t.H = H; t.W = W; t.C = C;
+  t.ty = (H + TILE_Y - 1) / TILE_Y; t.tx = (W + TILE_X - 1) / TILE_X;
+  // z-chunks: ~2048 workgroups (each ends with a 3.5 KB partial), chunks of at least 14 planes
+  const long fp = (long)t.ty * t.tx * (C / MARCH_CG) * N;
+  int nzc = (int)((2048 + fp - 1) / fp);
+  if (nzc < 1) nzc = 1;
+  int maxc = D / 14;
+  if (maxc < 1) maxc = 1;
+  if (nzc > maxc) nzc = maxc;
+  t.zc = (D + nzc - 1) / nzc;
+  t.nzc = (D + t.zc - 1) / t.zc;
+  t.slots = t.ty * t.tx * t.nzc;
+}
+
+// used by pytc_dw_wgrad (train_kernels.hip): slot count (0 = shape not covered) and launch of the march form
+int dw_wgrad_march_slots(int N, int D, int H, int W, int C, int K, int stride, int dtype) {
+  if (!march_ok(D, H, W, C, K, stride, dtype, 0) || tuning_get("dw_wgrad_march", 1) == 0) return 0;
+  DwMarch t;
+  make_wgrad_march(t, N, D, H, W, C);
+  return t.slots * N;
+}
+
+void dw_wgrad_march_launch(const void* gr, const void* x, float* dWp, float* dbp, int N, int D, int H, int W, int C,
+                           int dtype, hipStream_t s) {
+  DwMarch t;
+  make_wgrad_march(t, N, D, H, W, C);
+  t.swizzle = tuning_get("dwconv_xcd_swizzle", 1);
+  dim3 grid((unsigned)((long)t.slots * (C / MARCH_CG) * N)), block(256);
+  if (dtype == PYTC_BF16)
+    hipLaunchKernelGGL(dw_wgrad_march_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)gr, (const bf16_t*)x, dWp, dbp, t);
+  else
+    hipLaunchKernelGGL(dw_wgrad_march_kernel<float>, grid, block, 0, s, (const float*)gr, (const float*)x, dWp, dbp, t);
+}
+
+// ---------------------------------------------------------------------------------------------
 // stats [N][slots][2][C] -> ab [N][2][C]   (a = gamma*rstd, b = beta - mean*a)
 constexpr int FIN_CH = 16, FIN_SL = 16;
 __global__ void __launch_bounds__(256)

@@ -1,6 +1,7 @@
 // Per-(n,c) statistics of an arbitrary NDHWC tensor, max-pooling and the generic depthwise transposed conv
 // (RSUNet's fixed-weight "bilinear" upsampling) -- HBM-bound elementwise / reduction kernels, lanes along C.
 #include "pytc_common.h"
+#include "colstats.h"
 
 namespace pytc {
 
@@ -177,10 +178,7 @@ extern "C" int pytc_affine_act(const void* x, void* y, const float* ab, int N, i
   return PYTC_OK;
 }
 
-extern "C" int pytc_channel_stats_slots(int64_t rows) {
-  long s = rows / 2048;
-  return (int)(s < 1 ? 1 : (s > 1024 ? 1024 : s));
-}
+extern "C" int pytc_channel_stats_slots(int64_t rows) { return colstats_slots(rows); }
 
 extern "C" int pytc_channel_stats(const void* x, float* stats, int N, int64_t rows, int C, int dtype, void* stream) {
   PYTC_REQUIRE(x && stats && N >= 1 && rows >= 1 && C >= 1, "channel_stats: bad arguments");
@@ -189,7 +187,13 @@ extern "C" int pytc_channel_stats(const void* x, float* stats, int N, int64_t ro
   const int Cw = C < 256 ? C : 256;
   size_t lds = (size_t)(256 / Cw) * 2 * Cw * sizeof(float);
   dim3 grid(slots, N), block(256);
-  if (dtype == PYTC_BF16)
+  if (dtype == PYTC_BF16 && C % 8 == 0)
+    hipLaunchKernelGGL((colstats_kernel<bf16_t, 0>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)nullptr,
+                       (const float*)nullptr, stats, (long)rows, C, slots, rps);
+  else if (dtype == PYTC_F32 && C % 4 == 0)
+    hipLaunchKernelGGL((colstats_kernel<float, 0>), grid, block, 0, (hipStream_t)stream, (const float*)x, (const float*)nullptr,
+                       (const float*)nullptr, stats, (long)rows, C, slots, rps);
+  else if (dtype == PYTC_BF16)
     hipLaunchKernelGGL(channel_stats_kernel<bf16_t>, grid, block, lds, (hipStream_t)stream, (const bf16_t*)x, stats,
                        (long)rows, C, slots, rps);
   else if (dtype == PYTC_F32)

@@ -85,6 +85,15 @@ __device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParam
     }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) v[i] += rv[i];
+  } else if (e.res_mode == PYTC_RES_GELU_BWD) {
+    float rv[NCH];
+    if (full) VecIO<TO, NCH>::load(resn + off, rv);
+    else {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) rv[i] = (o0 + i < e.C_out) ? to_f32<TO>(resn[off + i]) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) v[i] *= gelu_erf_grad(rv[i]);
   } else if (e.res_mode == PYTC_RES_UPSAMPLE) {
     int px = (int)(orow % e.Go_w);
     long t = orow / e.Go_w;

@@ -20,7 +20,7 @@ struct PwParams {
   EpiParams e;
   long rps_out, rps_in;  // rows per sample
   int N, C_in, C_out, KG, MTt;
-  int act, gather;
+  int act, gather, pre_act;
   int Di, Hi, Wi;        // gather==2: input grid
   int Do, Ho, Wo;        // gather==2: output grid
 };
@@ -83,6 +83,10 @@ pw_conv_kernel(PwParams p) {
       if (p.ab) {
 #pragma unroll
         for (int j = 0; j < EPL; ++j) v[j] = fmaf(v[j], av[j], bv[j]);
+      }
+      if (p.pre_act == PYTC_ACT_GELU) {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) v[j] = gelu_erf(v[j]);
       }
       bf[nt] = M::from_floats(v);
     }
@@ -190,7 +194,8 @@ extern "C" int pytc_pw_conv_fwd(const pytc_pw_args* a, void* stream) {
   p.N = a->N; p.C_in = a->C_in; p.C_out = a->C_out;
   p.KG = (a->C_in + kstep_of(a->w_dtype) - 1) / kstep_of(a->w_dtype);
   p.MTt = (a->C_out + 15) / 16;
-  p.act = a->act; p.gather = a->gather;
+  p.act = a->act; p.gather = a->gather; p.pre_act = a->pre_act;
+  PYTC_REQUIRE(a->pre_act == PYTC_ACT_NONE || a->pre_act == PYTC_ACT_GELU, "pw_conv: bad pre_act");
   p.rps_out = a->rows_per_sample; p.rps_in = a->rows_per_sample;
   p.Di = a->Di; p.Hi = a->Hi; p.Wi = a->Wi; p.Do = p.Ho = p.Wo = 0;
   if (a->gather == 2) {

@@ -117,6 +117,21 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * one_plus_erf;
 }
 
+// d/dx gelu(x) = Phi(x) + x*phi(x) with the same A&S erf: exp(-x^2/2) serves both the erf tail and the pdf.
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float az = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(-az * az * 1.44269504088896340736f);     // exp(-x^2/2)
+  const float pe = p * e;
+  const float one_plus_erf = x < 0.f ? pe : 2.0f - pe;
+  return fmaf(x * 0.3989422804014327f, e, 0.5f * one_plus_erf);
+}
+
 // Sigmoid-form GELU for the bf16 fast path:  x * sigmoid(x * (a + b x^2 + c x^4)), minimax fit of the erf
 // GELU on [-8, 8] (max abs error 2.5e-5, i.e. far below the bf16 rounding of the activation it feeds);
 // x^2 is clamped at 64 so the odd polynomial keeps its sign outside the fitted range (sigmoid is saturated

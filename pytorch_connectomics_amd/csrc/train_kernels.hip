@@ -4,6 +4,7 @@
 //   elementwise add.  Data gradients of the 1x1 convs reuse pw_conv with transposed weights; the stride-1
 //   depthwise backward-data reuses the forward kernels with flipped taps.
 #include "pw_common.h"
+#include "colstats.h"
 
 namespace pytc {
 
@@ -40,7 +41,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 pw_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ ab, const T* __restrict__ dy,
                 float* __restrict__ dWp, float* __restrict__ dbp, long rows_total, long rows_per_sample, int C_in,
-                int C_out, long rows_per_slot, int slots) {
+                int C_out, long rows_per_slot, int slots, int x_act) {
   __shared__ float sx[WG_TR][WG_TK + 1];
   __shared__ float sd[WG_TR][WG_TO + 1];
   const int slot = blockIdx.x;
@@ -68,6 +69,7 @@ pw_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ ab, const T* 
           v = fmaf(v, ab[(n * 2 + 0) * C_in + k_base + kk], ab[(n * 2 + 1) * C_in + k_base + kk]);
           v = to_f32<T>(from_f32<T>(v));      // the forward GEMM consumed the value rounded to T
         }
+        if (x_act == PYTC_ACT_GELU) v = to_f32<T>(from_f32<T>(gelu_erf(v)));
       }
       sx[rr][kk] = v;
     }
@@ -117,7 +119,7 @@ template <int MT, int NT>
 __global__ void __launch_bounds__(256)
 pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab, const bf16_t* __restrict__ dy,
                      float* __restrict__ dWp, float* __restrict__ dbp, long rows_total, long rows_per_sample, int C_in,
-                     int C_out, long rows_per_slot) {
+                     int C_out, long rows_per_slot, int x_act) {
   constexpr int BM = MT * 16, BN = NT * 16;
   constexpr int SG = BM * 2 + 32, SX = BN * 2 + 32;        // LDS row pitch in bytes
   constexpr int WAVE_BYTES = 32 * (SG + SX);
@@ -170,6 +172,12 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
         f32x8_t f = __builtin_convertvector(in, f32x8_t);
 #pragma unroll
         for (int i = 0; i < 8; ++i) f[i] = fmaf(f[i], a[i], b[i]);
+        v = __builtin_bit_cast(uint4, __builtin_convertvector(f, bf16x8_t));
+      }
+      if (x_act == PYTC_ACT_GELU) {     // the forward GEMM consumed bf16(gelu(x)) (fused pre-activation)
+        f32x8_t f = __builtin_convertvector(__builtin_bit_cast(bf16x8_t, v), f32x8_t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = gelu_erf(f[i]);
         v = __builtin_bit_cast(uint4, __builtin_convertvector(f, bf16x8_t));
       }
       *reinterpret_cast<uint4*>(lx + (it * RX + x_row) * SX + x_chunk * 16) = v;
@@ -266,11 +274,75 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
   }
 }
 
+// ---- thin pointwise weight gradient (C_in == 1: stem, or C_out == 1: one-channel heads; no prologue) --------------
+// dW[c] = sum_r big[r][c] * thin[r]: the column-sum lane map of colstats.h (16-byte loads of the wide operand).
+// big_is_dy: big = dY [rows][C_out], thin = X [rows][1], db[c] = sum big;  else big = X [rows][C_in], thin = dY, db[0].
+template <typename T>
+__global__ void __launch_bounds__(256)
+pw_wgrad_thin_kernel(const T* __restrict__ big, const T* __restrict__ thin, float* __restrict__ dWp,
+                     float* __restrict__ dbp, long rows_total, int C, long rows_per_slot, int big_is_dy) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  __shared__ float lds[2 * 256 * EPV];
+  const int slot = blockIdx.x;
+  const long r0 = (long)slot * rows_per_slot;
+  const long r1 = r0 + rows_per_slot < rows_total ? r0 + rows_per_slot : rows_total;
+  const int Cw = C / EPV;                       // <= 256 (checked by the host)
+  const int RL = 256 / Cw;
+  const int ck = threadIdx.x % Cw, rl = threadIdx.x / Cw;
+  if (rl < RL) {
+    float s1[EPV], s2[EPV];
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+#pragma unroll 4
+    for (long r = r0 + rl; r < r1; r += RL) {
+      float v[EPV];
+      VecIO<T, EPV>::load(big + r * C + ck * EPV, v);
+      const float tv = to_f32<T>(thin[r]);
+#pragma unroll
+      for (int i = 0; i < EPV; ++i) { s1[i] = fmaf(v[i], tv, s1[i]); s2[i] += big_is_dy ? v[i] : tv; }
+    }
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) {
+      lds[((rl * 2 + 0) * Cw + ck) * EPV + i] = s1[i];
+      lds[((rl * 2 + 1) * Cw + ck) * EPV + i] = s2[i];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i / C, e = i % C;
+    float acc = 0.f;
+    for (int q = 0; q < RL; ++q) acc += lds[(q * 2 + which) * C + e];
+    if (which == 0) dWp[(long)slot * C + e] = acc;
+    else if (dbp && (big_is_dy || e == 0)) dbp[(long)slot * (big_is_dy ? C : 1) + (big_is_dy ? e : 0)] = acc;
+  }
+}
+
 // out[i] = sum_s part[s][i]: 16 elements x 16 slot lanes per workgroup; lane j adds slots j, j+16, ... in order and
 // the 16 lane sums are added in lane order -> a fixed summation tree, independent of the launch.
 __global__ void __launch_bounds__(256)
 reduce_slots_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int slots) {
   __shared__ float sm[16][17];
+  const int e = threadIdx.x & 15, j = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + e;
+  float a = 0.f;
+  if (i < n)
+    for (int s = j; s < slots; s += 16) a += part[(long)s * n + i];
+  sm[j][e] = a;
+  __syncthreads();
+  if (j == 0 && i < n) {
+    float t = sm[0][e];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += sm[q][e];
+    out[i] = t;
+  }
+}
+
+// batched form: blockIdx.y = sample; part [N][slots][n] -> out [N][n]
+__global__ void __launch_bounds__(256)
+reduce_slots_batched_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int slots) {
+  __shared__ float sm[16][17];
+  part += (long)blockIdx.y * slots * n;
+  out += (long)blockIdx.y * n;
   const int e = threadIdx.x & 15, j = threadIdx.x >> 4;
   const long i = (long)blockIdx.x * 16 + e;
   float a = 0.f;
@@ -420,6 +492,45 @@ norm_bwd_apply_kernel(const T* __restrict__ dtn, const T* __restrict__ t, const 
   }
 }
 
+// 16-byte form of the apply pass (C % (16/sizeof(T)) == 0): lane = (channel chunk, row lane), coefficients in registers
+template <typename T>
+__global__ void __launch_bounds__(256)
+norm_bwd_apply_vec_kernel(const T* __restrict__ dtn, const T* __restrict__ t, const float* __restrict__ mr,
+                          const float* __restrict__ gamma, const float* __restrict__ s, float inv_count,
+                          T* __restrict__ dt, long rows, int C, long rows_per_slot) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  const int n = blockIdx.y, slot = blockIdx.x;
+  const long r0 = (long)slot * rows_per_slot;
+  const long r1 = r0 + rows_per_slot < rows ? r0 + rows_per_slot : rows;
+  const long base = (long)n * rows * C;
+  const int chunks = C / EPV;
+  for (int k0 = 0; k0 < chunks; k0 += 256) {
+    const int Cw = (chunks - k0) < 256 ? (chunks - k0) : 256;
+    const int RL = 256 / Cw;
+    const int ck = threadIdx.x % Cw, rl = threadIdx.x / Cw;
+    if (rl >= RL) continue;
+    const int c = (k0 + ck) * EPV;
+    float mean[EPV], rstd[EPV], rg[EPV], m1[EPV], m2[EPV];
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) {
+      mean[i] = mr[((long)n * 2 + 0) * C + c + i];
+      rstd[i] = mr[((long)n * 2 + 1) * C + c + i];
+      rg[i] = rstd[i] * (gamma ? gamma[c + i] : 1.f);
+      m1[i] = s[((long)n * 2 + 0) * C + c + i] * inv_count;
+      m2[i] = s[((long)n * 2 + 1) * C + c + i] * inv_count;
+    }
+#pragma unroll 2
+    for (long r = r0 + rl; r < r1; r += RL) {
+      float d[EPV], u[EPV], o[EPV];
+      VecIO<T, EPV>::load(dtn + base + r * C + c, d);
+      VecIO<T, EPV>::load(t + base + r * C + c, u);
+#pragma unroll
+      for (int i = 0; i < EPV; ++i) o[i] = rg[i] * (d[i] - m1[i] - (u[i] - mean[i]) * rstd[i] * m2[i]);
+      VecIO<T, EPV>::store(dt + base + r * C + c, o);
+    }
+  }
+}
+
 // ---- strided depthwise backward-data (gather form): dx[i] = sum_k dy[(i + p - k)/s] * w[k] -------------------------
 struct DwBd {
   int D, H, W, Do, Ho, Wo, C, K, stride, pad;
@@ -496,17 +607,18 @@ static int wg_tile16(int C) { return C % 64 == 0 ? 4 : (C % 32 == 0 ? 2 : (C % 1
 
 template <int MT>
 static void launch_wgrad_mfma(int nt, dim3 grid, hipStream_t s, const bf16_t* x, const float* ab, const bf16_t* dy,
-                              float* dWp, float* dbp, long rows_total, long rps_sample, int C_in, int C_out, long rps) {
+                              float* dWp, float* dbp, long rows_total, long rps_sample, int C_in, int C_out, long rps, int x_act) {
   switch (nt) {
-    case 4: hipLaunchKernelGGL((pw_wgrad_mfma_kernel<MT, 4>), grid, dim3(256), 0, s, x, ab, dy, dWp, dbp, rows_total, rps_sample, C_in, C_out, rps); break;
-    case 2: hipLaunchKernelGGL((pw_wgrad_mfma_kernel<MT, 2>), grid, dim3(256), 0, s, x, ab, dy, dWp, dbp, rows_total, rps_sample, C_in, C_out, rps); break;
-    default: hipLaunchKernelGGL((pw_wgrad_mfma_kernel<MT, 1>), grid, dim3(256), 0, s, x, ab, dy, dWp, dbp, rows_total, rps_sample, C_in, C_out, rps); break;
+    case 4: hipLaunchKernelGGL((pw_wgrad_mfma_kernel<MT, 4>), grid, dim3(256), 0, s, x, ab, dy, dWp, dbp, rows_total, rps_sample, C_in, C_out, rps, x_act); break;
+    case 2: hipLaunchKernelGGL((pw_wgrad_mfma_kernel<MT, 2>), grid, dim3(256), 0, s, x, ab, dy, dWp, dbp, rows_total, rps_sample, C_in, C_out, rps, x_act); break;
+    default: hipLaunchKernelGGL((pw_wgrad_mfma_kernel<MT, 1>), grid, dim3(256), 0, s, x, ab, dy, dWp, dbp, rows_total, rps_sample, C_in, C_out, rps, x_act); break;
   }
 }
 
 extern "C" int pytc_pw_wgrad(const void* x, const float* ab, const void* dy, float* dW, float* db, float* workspace,
-                             int N, int64_t rows_per_sample, int C_in, int C_out, int dtype, void* stream) {
+                             int N, int64_t rows_per_sample, int C_in, int C_out, int dtype, int x_act, void* stream) {
   PYTC_REQUIRE(x && dy && dW && workspace && N >= 1 && rows_per_sample >= 1, "pw_wgrad: bad arguments");
+  PYTC_REQUIRE(x_act == PYTC_ACT_NONE || x_act == PYTC_ACT_GELU, "pw_wgrad: bad x_act");
   const long rows_total = (long)N * rows_per_sample;
   const int slots = pytc_pw_wgrad_slots(rows_total);
   const long rps = (rows_total + slots - 1) / slots;
@@ -520,14 +632,23 @@ extern "C" int pytc_pw_wgrad(const void* x, const float* ab, const void* dy, flo
     const bf16_t* xp = (const bf16_t*)x;
     const bf16_t* dp = (const bf16_t*)dy;
     float* dbq = db ? dbp : nullptr;
-    if (mt == 4) launch_wgrad_mfma<4>(nt, grid, s, xp, ab, dp, dWp, dbq, rows_total, (long)rows_per_sample, C_in, C_out, rps);
-    else if (mt == 2) launch_wgrad_mfma<2>(nt, grid, s, xp, ab, dp, dWp, dbq, rows_total, (long)rows_per_sample, C_in, C_out, rps);
-    else launch_wgrad_mfma<1>(nt, grid, s, xp, ab, dp, dWp, dbq, rows_total, (long)rows_per_sample, C_in, C_out, rps);
+    if (mt == 4) launch_wgrad_mfma<4>(nt, grid, s, xp, ab, dp, dWp, dbq, rows_total, (long)rows_per_sample, C_in, C_out, rps, x_act);
+    else if (mt == 2) launch_wgrad_mfma<2>(nt, grid, s, xp, ab, dp, dWp, dbq, rows_total, (long)rows_per_sample, C_in, C_out, rps, x_act);
+    else launch_wgrad_mfma<1>(nt, grid, s, xp, ab, dp, dWp, dbq, rows_total, (long)rows_per_sample, C_in, C_out, rps, x_act);
+  } else if (!ab && x_act == PYTC_ACT_NONE && (C_in == 1 || C_out == 1) && (C_in * C_out) % (dtype == PYTC_BF16 ? 8 : 4) == 0 &&
+             C_in * C_out <= (dtype == PYTC_BF16 ? 2048 : 1024)) {
+    const int Cb = C_in * C_out, big_is_dy = C_in == 1;
+    const void* big = big_is_dy ? dy : x;
+    const void* thin = big_is_dy ? x : dy;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(pw_wgrad_thin_kernel<bf16_t>, dim3(slots), dim3(256), 0, s, (const bf16_t*)big, (const bf16_t*)thin, dWp, db ? dbp : nullptr, rows_total, Cb, rps, big_is_dy),
+               hipLaunchKernelGGL(pw_wgrad_thin_kernel<float>, dim3(slots), dim3(256), 0, s, (const float*)big, (const float*)thin, dWp, db ? dbp : nullptr, rows_total, Cb, rps, big_is_dy),
+               "pw_wgrad")
   } else {
     dim3 grid(slots, ((C_out + WG_TO - 1) / WG_TO) * ((C_in + WG_TK - 1) / WG_TK)), block(256);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, ab, (const bf16_t*)dy, dWp, db ? dbp : nullptr, rows_total, (long)rows_per_sample, C_in, C_out, rps, slots),
-               hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, block, 0, s, (const float*)x, ab, (const float*)dy, dWp, db ? dbp : nullptr, rows_total, (long)rows_per_sample, C_in, C_out, rps, slots),
+               hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, ab, (const bf16_t*)dy, dWp, db ? dbp : nullptr, rows_total, (long)rows_per_sample, C_in, C_out, rps, slots, x_act),
+               hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, block, 0, s, (const float*)x, ab, (const float*)dy, dWp, db ? dbp : nullptr, rows_total, (long)rows_per_sample, C_in, C_out, rps, slots, x_act),
                "pw_wgrad")
   }
   const long nW = (long)C_out * C_in;
@@ -535,6 +656,17 @@ extern "C" int pytc_pw_wgrad(const void* x, const float* ab, const void* dy, flo
   if (db) hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(C_out, 16)), dim3(256), 0, s, dbp, db, (long)C_out, slots);
   PYTC_LAUNCH_CHECK("pw_wgrad");
   return PYTC_OK;
+}
+
+// z-march form of the stride-1 3x3x3 case (dwconv_kernels.hip)
+namespace pytc {
+int dw_wgrad_march_slots(int N, int D, int H, int W, int C, int K, int stride, int dtype);
+void dw_wgrad_march_launch(const void* gr, const void* x, float* dWp, float* dbp, int N, int D, int H, int W, int C,
+                           int dtype, hipStream_t s);
+}
+static int march_slots(int N, const int32_t* gd, const int32_t* xd, int C, int K, int stride, int dtype) {
+  if (gd[0] != xd[0] || gd[1] != xd[1] || gd[2] != xd[2]) return 0;
+  return dw_wgrad_march_slots(N, gd[0], gd[1], gd[2], C, K, stride, dtype);
 }
 
 static bool make_wg(DwWg& q, int N, const int32_t* gd, const int32_t* xd, int C, int K, int stride, int dtype, int& vec) {
@@ -555,6 +687,8 @@ static bool make_wg(DwWg& q, int N, const int32_t* gd, const int32_t* xd, int C,
 
 extern "C" int pytc_dw_wgrad_slots(int N, const int32_t* gdims, const int32_t* xdims, int C, int K, int stride, int dtype) {
   DwWg q; int vec;
+  const int ms = march_slots(N, gdims, xdims, C, K, stride, dtype);
+  if (ms > 0) return ms;
   if (!make_wg(q, N, gdims, xdims, C, K, stride, dtype, vec)) return -1;
   return q.slots * N;
 }
@@ -576,6 +710,18 @@ extern "C" int pytc_dw_wgrad(const void* g, const void* x, float* dW, float* db,
                              const int32_t* gdims, const int32_t* xdims, int C, int K, int stride, int dtype,
                              void* stream) {
   PYTC_REQUIRE(g && x && dW && workspace && gdims && xdims, "dw_wgrad: null pointer");
+  const int ms = march_slots(N, gdims, xdims, C, K, stride, dtype);
+  if (ms > 0) {
+    const long nWm = 27L * C;
+    float* dWm = workspace;
+    float* dbm = workspace + (long)ms * nWm;
+    hipStream_t sm = (hipStream_t)stream;
+    dw_wgrad_march_launch(g, x, dWm, db ? dbm : nullptr, N, gdims[0], gdims[1], gdims[2], C, dtype, sm);
+    hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(nWm, 16)), dim3(256), 0, sm, dWm, dW, nWm, ms);
+    if (db) hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, sm, dbm, db, (long)C, ms);
+    PYTC_LAUNCH_CHECK("dw_wgrad");
+    return PYTC_OK;
+  }
   DwWg q; int vec;
   if (!make_wg(q, N, gdims, xdims, C, K, stride, dtype, vec)) { set_error("dw_wgrad: unsupported channel count %d", C); return PYTC_ERR_UNSUPPORTED; }
   PYTC_REQUIRE((size_t)q.vs * C * sizeof(float) <= 64 * 1024, "dw_wgrad: scratch too large");
@@ -598,33 +744,44 @@ extern "C" int pytc_norm_bwd(const void* dtn, const void* t, const float* mean_r
                              float* stats_ws, float* s_out, void* dt, int N, int64_t rows, float count, int C,
                              int dtype, void* stream) {
   PYTC_REQUIRE(dtn && t && mean_rstd && stats_ws && s_out && dt, "norm_bwd: null pointer");
-  long sl = rows / 2048;
-  const int slots = (int)(sl < 1 ? 1 : (sl > 1024 ? 1024 : sl));
+  const int slots = colstats_slots(rows);
   const long rps = (rows + slots - 1) / slots;
   const int Cw = C < 256 ? C : 256;
   size_t lds = (size_t)(256 / Cw) * 2 * Cw * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(slots, N), block(256);
-  DISPATCH_T(dtype,
-             hipLaunchKernelGGL(norm_bwd_stats_kernel<bf16_t>, grid, block, lds, s, (const bf16_t*)dtn, (const bf16_t*)t, mean_rstd, stats_ws, (long)rows, C, slots, rps),
-             hipLaunchKernelGGL(norm_bwd_stats_kernel<float>, grid, block, lds, s, (const float*)dtn, (const float*)t, mean_rstd, stats_ws, (long)rows, C, slots, rps),
-             "norm_bwd")
+  const bool vec = dtype == PYTC_BF16 ? (C % 8 == 0) : (C % 4 == 0);
+  if (vec) {
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((colstats_kernel<bf16_t, 1>), grid, block, 0, s, (const bf16_t*)dtn, (const bf16_t*)t, mean_rstd, stats_ws, (long)rows, C, slots, rps),
+               hipLaunchKernelGGL((colstats_kernel<float, 1>), grid, block, 0, s, (const float*)dtn, (const float*)t, mean_rstd, stats_ws, (long)rows, C, slots, rps),
+               "norm_bwd")
+  } else {
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(norm_bwd_stats_kernel<bf16_t>, grid, block, lds, s, (const bf16_t*)dtn, (const bf16_t*)t, mean_rstd, stats_ws, (long)rows, C, slots, rps),
+               hipLaunchKernelGGL(norm_bwd_stats_kernel<float>, grid, block, lds, s, (const float*)dtn, (const float*)t, mean_rstd, stats_ws, (long)rows, C, slots, rps),
+               "norm_bwd")
+  }
   // reduce slots per sample: stats_ws [N][slots][2][C] -> s_out [N][2][C]
-  for (int n = 0; n < N; ++n)
-    hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(2L * C, 16)), dim3(256), 0, s, stats_ws + (long)n * slots * 2 * C,
-                       s_out + (long)n * 2 * C, 2L * C, slots);
+  hipLaunchKernelGGL(reduce_slots_batched_kernel, dim3(ceil_div(2L * C, 16), N), dim3(256), 0, s, stats_ws, s_out, 2L * C, slots);
   const long total = (long)N * rows * C;
-  DISPATCH_T(dtype,
-             hipLaunchKernelGGL(norm_bwd_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)dtn, (const bf16_t*)t, mean_rstd, gamma, s_out, 1.0f / count, (bf16_t*)dt, (long)rows, C, total),
-             hipLaunchKernelGGL(norm_bwd_apply_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)dtn, (const float*)t, mean_rstd, gamma, s_out, 1.0f / count, (float*)dt, (long)rows, C, total),
-             "norm_bwd")
+  if (vec) {
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(norm_bwd_apply_vec_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)dtn, (const bf16_t*)t, mean_rstd, gamma, s_out, 1.0f / count, (bf16_t*)dt, (long)rows, C, rps),
+               hipLaunchKernelGGL(norm_bwd_apply_vec_kernel<float>, grid, block, 0, s, (const float*)dtn, (const float*)t, mean_rstd, gamma, s_out, 1.0f / count, (float*)dt, (long)rows, C, rps),
+               "norm_bwd")
+  } else {
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(norm_bwd_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)dtn, (const bf16_t*)t, mean_rstd, gamma, s_out, 1.0f / count, (bf16_t*)dt, (long)rows, C, total),
+               hipLaunchKernelGGL(norm_bwd_apply_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)dtn, (const float*)t, mean_rstd, gamma, s_out, 1.0f / count, (float*)dt, (long)rows, C, total),
+               "norm_bwd")
+  }
   PYTC_LAUNCH_CHECK("norm_bwd");
   return PYTC_OK;
 }
 
 extern "C" int pytc_norm_bwd_ws_elems(int N, int64_t rows, int C) {
-  long sl = rows / 2048;
-  const int slots = (int)(sl < 1 ? 1 : (sl > 1024 ? 1024 : sl));
+  const int slots = colstats_slots(rows);
   return (int)((long)N * slots * 2 * C);
 }
 

@@ -218,7 +218,8 @@ def pw_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
             c_in: int, c_out: int, out_dtype: torch.dtype, ab: Optional[torch.Tensor] = None,
             act: int = nat.ACT_NONE, res: Optional[torch.Tensor] = None, res_mode: int = nat.RES_NONE,
             gather: int = 0, grid: Sequence[int] = (0, 0, 0), res_low: Optional[torch.Tensor] = None,
-            res_bias: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None) -> torch.Tensor:
+            res_bias: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None,
+            pre_act: int = nat.ACT_NONE) -> torch.Tensor:
     _dev(x, "x"); _dev(w_packed, "w_packed")
     if y is None:
         y = torch.empty((N, rows_per_sample, c_out), dtype=out_dtype, device=x.device)
@@ -229,7 +230,7 @@ def pw_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
                                                  res.data_ptr() if res is not None else None, y.data_ptr())
     a.N, a.rows_per_sample, a.C_in, a.C_out = N, rows_per_sample, c_in, c_out
     a.in_dtype, a.out_dtype, a.w_dtype = dtype_code(x.dtype), dtype_code(y.dtype), dtype_code(w_packed.dtype)
-    a.act, a.res_mode, a.gather = act, res_mode, gather
+    a.act, a.res_mode, a.gather, a.pre_act = act, res_mode, gather, pre_act
     a.Di, a.Hi, a.Wi = (int(v) for v in grid)
     a.res_low = res_low.data_ptr() if res_low is not None else None
     a.res_bias = res_bias.data_ptr() if res_bias is not None else None
@@ -321,7 +322,7 @@ def channel_stats(x: torch.Tensor) -> torch.Tensor:
     rows = x.numel() // (N * Cc)
     slots = nat.lib().pytc_channel_stats_slots(rows)
     st = torch.empty((N, slots, 2, Cc), dtype=torch.float32, device=x.device)
-    _run("channel_stats", _nbytes(x), nat.lib().pytc_channel_stats, _p(x), _p(st), N, rows, Cc, dtype_code(x.dtype),
+    _run(f"channel_stats[C{Cc}]", _nbytes(x), nat.lib().pytc_channel_stats, _p(x), _p(st), N, rows, Cc, dtype_code(x.dtype),
          _stream())
     return st
 
@@ -387,14 +388,14 @@ def gelu(x: torch.Tensor, dy: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dy is None: gelu(x); else dy * gelu'(x)."""
     _dev(x, "x")
     out = torch.empty_like(x)
-    _run("gelu_bwd" if dy is not None else "gelu_fwd", _nbytes(x, out, dy), nat.lib().pytc_gelu, _p(x), _p(dy), _p(out),
+    _run(("gelu_bwd" if dy is not None else "gelu_fwd") + f"[C{x.shape[-1]}]", _nbytes(x, out, dy), nat.lib().pytc_gelu, _p(x), _p(dy), _p(out),
          x.numel(), dtype_code(x.dtype), _stream())
     return out
 
 
 def add_(y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     _dev(y, "y"); _dev(x, "x")
-    _run("add_inplace", 3 * _nbytes(x), nat.lib().pytc_add_inplace, _p(y), _p(x), y.numel(), dtype_code(y.dtype), _stream())
+    _run(f"add_inplace[C{x.shape[-1]}]", 3 * _nbytes(x), nat.lib().pytc_add_inplace, _p(y), _p(x), y.numel(), dtype_code(y.dtype), _stream())
     return y
 
 
@@ -404,15 +405,15 @@ def set_tuning(key: str, value: int) -> None:
 
 
 def pw_wgrad(x: torch.Tensor, dy: torch.Tensor, *, N: int, rows_per_sample: int, c_in: int, c_out: int,
-             ab: Optional[torch.Tensor] = None, want_bias: bool = True):
-    """-> dW (c_out, c_in) fp32, db (c_out) fp32 | None"""
+             ab: Optional[torch.Tensor] = None, want_bias: bool = True, x_act: int = nat.ACT_NONE):
+    """-> dW (c_out, c_in) fp32, db (c_out) fp32 | None;  x_act=ACT_GELU: the GEMM operand is gelu(x)"""
     _dev(x, "x"); _dev(dy, "dy")
     slots = nat.lib().pytc_pw_wgrad_slots(N * rows_per_sample)
     ws = torch.empty((slots * (c_out * c_in + c_out),), dtype=torch.float32, device=x.device)
     dW = torch.empty((c_out, c_in), dtype=torch.float32, device=x.device)
     db = torch.empty((c_out,), dtype=torch.float32, device=x.device) if want_bias else None
     _run(f"pw_wgrad[{c_in}->{c_out}]", _nbytes(x, dy), nat.lib().pytc_pw_wgrad, _p(x), _p(ab), _p(dy), _p(dW), _p(db),
-         _p(ws), N, rows_per_sample, c_in, c_out, dtype_code(x.dtype), _stream())
+         _p(ws), N, rows_per_sample, c_in, c_out, dtype_code(x.dtype), int(x_act), _stream())
     return dW, db
 
 
@@ -441,7 +442,7 @@ def norm_bwd(dtn: torch.Tensor, t: torch.Tensor, mean_rstd: torch.Tensor, gamma:
     ws = torch.empty((nat.lib().pytc_norm_bwd_ws_elems(N, rows, Cc),), dtype=torch.float32, device=t.device)
     s = torch.empty((N, 2, Cc), dtype=torch.float32, device=t.device)
     dt = torch.empty_like(t)
-    _run("norm_bwd", 3 * _nbytes(t) + _nbytes(dtn), nat.lib().pytc_norm_bwd, _p(dtn), _p(t), _p(mean_rstd), _p(gamma),
+    _run(f"norm_bwd[C{t.shape[-1]}]", 3 * _nbytes(t) + _nbytes(dtn), nat.lib().pytc_norm_bwd, _p(dtn), _p(t), _p(mean_rstd), _p(gamma),
          _p(ws), _p(s), _p(dt), N, rows, float(count if count is not None else rows), Cc, dtype_code(t.dtype), _stream())
     return dt, s
 

@@ -5,7 +5,8 @@ calls autograd through nnunet_mednext's PyTorch ops).
 One Function per MedNeXt block kind (block / down / up) plus one for plain 1x1 convs (stem, heads).  Activations
 are NDHWC tensors in the compute dtype (fp32 or bf16 storage); parameter gradients are fp32 in PyTorch layout.
 Round-1 status: correctness-first, un-fused schedule (the fused inference kernels are not used here):
-forward = dwconv(+stats) -> finalize -> 1x1 expand (pre-activation saved) -> gelu -> 1x1 project (+residual);
+forward = dwconv(+stats) -> finalize -> 1x1 expand (pre-activation saved) -> 1x1 project with GELU in its operand
+prologue (+residual);
 backward = the mirrored sequence with two-stage deterministic reductions for every parameter gradient.
 Index shuffles of the down/up residual paths (strided slicing / zeroing of the padded faces) are torch views and
 copies; every arithmetic op is a HIP kernel.
@@ -104,23 +105,23 @@ class BlockFn(torch.autograd.Function):
         rows = _rows(t)
         c_hid, c_out = w2.shape[0], w3.shape[0]
         hp = _pw(t, _mat(w2), _f(b2), c_out=c_hid, ab=ab, rows=rows)              # pre-activation (saved)
-        h = ops.gelu(hp)
+        h, G = hp, dict(pre_act=nat.ACT_GELU)       # GELU runs in the operand prologue of the projecting GEMM
         res_low = None
         if kind == "block":
             y = _pw(h, _mat(w3), _f(b3), c_out=c_out, rows=rows, res=x if do_res else None,
-                    res_mode=nat.RES_ADD if do_res else nat.RES_NONE)
+                    res_mode=nat.RES_ADD if do_res else nat.RES_NONE, **G)
         elif kind == "down":
             r = None
             if wres is not None:
                 r = _pw(x, _mat(wres), _f(bres), c_out=c_out, rows=rows, gather=2, grid=(D, H, W))
             y = _pw(h, _mat(w3), _f(b3), c_out=c_out, rows=rows, res=r,
-                    res_mode=nat.RES_ADD if r is not None else nat.RES_NONE)
+                    res_mode=nat.RES_ADD if r is not None else nat.RES_NONE, **G)
         else:
             if wres is not None:
                 res_low = _pw(x, _mat(wres), _f(bres), c_out=c_out, transposed=True)
             sk = skip if skip is not None else torch.zeros((N,) + tuple(t.shape[1:4]) + (c_out,), dtype=dt, device=x.device)
             y = _pw(h, _mat(w3), _f(b3), c_out=c_out, rows=rows, res=sk, res_mode=nat.RES_UPSAMPLE,
-                    grid=tuple(t.shape[1:4]), res_low=res_low, res_bias=_f(bres) if wres is not None else None)
+                    grid=tuple(t.shape[1:4]), res_low=res_low, res_bias=_f(bres) if wres is not None else None, **G)
         ctx.save_for_backward(x, t, ab, mr, hp, w1, gamma, w2, w3, wres if wres is not None else x.new_zeros(0))
         ctx.meta = (kind, do_res, K, count, wres is not None, skip is not None, b1 is not None, bres is not None)
         return y.view(N, *t.shape[1:4], c_out)
@@ -142,12 +143,9 @@ class BlockFn(torch.autograd.Function):
             dcore[:, :, 0] = 0
             dcore[:, :, :, 0] = 0
         # ---- project: y = W3 h + b3
-        h = ops.gelu(hp)
-        dW3, db3 = ops.pw_wgrad(h, dcore, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out)
-        dh = _pw(dcore, _mat(w3), None, c_out=c_hid, transposed=True, rows=rows)
-        del h
-        dhp = ops.gelu(hp, dy=dh)
-        del dh
+        dW3, db3 = ops.pw_wgrad(hp, dcore, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, x_act=nat.ACT_GELU)
+        # dhp = (W3^T dy) * gelu'(hp): the GELU derivative is the epilogue of the data-gradient GEMM
+        dhp = _pw(dcore, _mat(w3), None, c_out=c_hid, transposed=True, rows=rows, res=hp, res_mode=nat.RES_GELU_BWD)
         # ---- expand: hp = W2 (a t + b) + b2
         dW2, db2 = ops.pw_wgrad(t, dhp, N=N, rows_per_sample=rows, c_in=C, c_out=c_hid, ab=ab)
         dtn = _pw(dhp, _mat(w2), None, c_out=C, transposed=True, rows=rows)

@@ -81,7 +81,8 @@ def test_pw_wgrad_mfma_bf16(ci, co, rows, N, use_ab):
     assert torch.equal(dW, dW3)                                                 # deterministic
 
 
-@pytest.mark.parametrize("C,K,stride,shape", [(8, 3, 1, (6, 7, 9)), (16, 3, 2, (8, 8, 10)), (4, 5, 1, (6, 6, 7)), (32, 3, 1, (9, 17, 18))])
+@pytest.mark.parametrize("C,K,stride,shape", [(8, 3, 1, (6, 7, 9)), (16, 3, 2, (8, 8, 10)), (4, 5, 1, (6, 6, 7)), (32, 3, 1, (9, 17, 18)),
+                                              (64, 3, 1, (30, 20, 24))])
 def test_depthwise_backward_kernels(C, K, stride, shape):
     from pytorch_connectomics_amd import hip_ops as ops
     torch.manual_seed(C + K)
@@ -101,6 +102,67 @@ def test_depthwise_backward_kernels(C, K, stride, shape):
     if stride == 1:   # the production path: forward kernel with the reversed stencil
         dx2, _ = ops.dwconv3d(gyc, torch.flip(taps, dims=[0]).contiguous(), None, K=K, stride=1, stats=False)
         torch.testing.assert_close(_cf(dx2.cpu()), x.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("ci,co,dt", [(1, 32, torch.bfloat16), (32, 1, torch.bfloat16), (1, 16, torch.float32),
+                                      (64, 1, torch.float32)])
+def test_pw_wgrad_thin(ci, co, dt):
+    """Stem (C_in = 1) and one-channel head (C_out = 1) weight gradients: the column-sum kernel."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(ci * 3 + co)
+    N, rows = 2, 3001
+    x, dy = torch.randn(N, rows, ci).to(dt), torch.randn(N, rows, co).to(dt)
+    dW, db = ops.pw_wgrad(x.cuda(), dy.cuda(), N=N, rows_per_sample=rows, c_in=ci, c_out=co)
+    torch.testing.assert_close(dW.cpu().double(), torch.einsum("nro,nrk->ok", dy.double(), x.double()), rtol=1e-4, atol=2e-3)
+    torch.testing.assert_close(db.cpu().double(), dy.double().sum((0, 1)), rtol=1e-4, atol=2e-3)
+
+
+def test_gelu_fused_into_gemms():
+    """pre_act=GELU operand prologue, RES_GELU_BWD epilogue and the x_act weight gradient against torch."""
+    from pytorch_connectomics_amd import _native as nat, hip_ops as ops
+    torch.manual_seed(3)
+    N, rows, ch, co = 2, 1111, 64, 32
+    hp = torch.randn(N, rows, ch, requires_grad=True)
+    w3 = (torch.randn(co, ch) * 0.2).requires_grad_()
+    y = F.gelu(hp) @ w3.t()
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    wp = ops.pw_pack_weight(w3.detach().cuda(), torch.float32)
+    yk = ops.pw_conv(hp.detach().cuda(), wp, None, N=N, rows_per_sample=rows, c_in=ch, c_out=co, out_dtype=torch.float32,
+                     pre_act=nat.ACT_GELU)
+    torch.testing.assert_close(yk.cpu(), y.detach(), rtol=1e-4, atol=1e-4)
+    wpt = ops.pw_pack_weight(w3.detach().cuda(), torch.float32, transposed=True)
+    dhp = ops.pw_conv(dy.cuda(), wpt, None, N=N, rows_per_sample=rows, c_in=co, c_out=ch, out_dtype=torch.float32,
+                      res=hp.detach().cuda(), res_mode=nat.RES_GELU_BWD)
+    torch.testing.assert_close(dhp.cpu(), hp.grad, rtol=1e-4, atol=1e-5)
+    dW, _ = ops.pw_wgrad(hp.detach().cuda(), dy.cuda(), N=N, rows_per_sample=rows, c_in=ch, c_out=co, x_act=nat.ACT_GELU)
+    torch.testing.assert_close(dW.cpu(), w3.grad, rtol=1e-4, atol=1e-3)
+    dWb, _ = ops.pw_wgrad(hp.detach().bfloat16().cuda(), dy.bfloat16().cuda(), N=N, rows_per_sample=rows, c_in=ch, c_out=co,
+                          x_act=nat.ACT_GELU)
+    assert float((dWb.cpu() - w3.grad).abs().max()) < 2e-2 * float(w3.grad.abs().max())
+
+
+def test_dw_wgrad_march_bf16_matches_generic_kernel():
+    """z-march weight gradient (bf16 storage) against the generic kernel on the same operands and against fp64."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(5)
+    g = torch.randn(2, 29, 21, 19, 32).bfloat16()
+    x = torch.randn(2, 29, 21, 19, 32).bfloat16()
+    dW, db = ops.dw_wgrad(g.cuda(), x.cuda(), K=3, stride=1)
+    ops.set_tuning("dw_wgrad_march", 0)
+    try:
+        dW0, db0 = ops.dw_wgrad(g.cuda(), x.cuda(), K=3, stride=1)
+    finally:
+        ops.set_tuning("dw_wgrad_march", 1)
+    xp = F.pad(x.double().permute(0, 4, 1, 2, 3), (1, 1, 1, 1, 1, 1))
+    gd = g.double().permute(0, 4, 1, 2, 3)
+    want = torch.stack([(gd * xp[:, :, kz:kz + 29, ky:ky + 21, kx:kx + 19]).sum((0, 2, 3, 4))
+                        for kz in range(3) for ky in range(3) for kx in range(3)])
+    torch.testing.assert_close(dW.cpu().double(), want, rtol=1e-4, atol=2e-3)
+    torch.testing.assert_close(dW, dW0, rtol=1e-4, atol=2e-3)
+    torch.testing.assert_close(db, db0, rtol=1e-5, atol=1e-3)
+    dW2, _ = ops.dw_wgrad(g.cuda(), x.cuda(), K=3, stride=1)
+    assert torch.equal(dW, dW2)
 
 
 def _grads_oracle(st, x, kw, weight_fn):
