@@ -434,6 +434,76 @@ dw_wgrad_kernel(const T* __restrict__ g, const T* __restrict__ x, float* __restr
   }
 }
 
+// 16-byte form for K = 3 at any stride (down blocks, transposed up blocks, volumes too small for the march):
+// workgroup = (position slot, sample, kz); lane = (channel chunk of 16 bytes, position lane); 9 x EPV accumulators.
+// Neighbouring taps / outputs share input lines through L1/L2; every parameter sum is reduced over the position lanes
+// in lane order, then over slots by reduce_slots.
+template <typename T>
+__global__ void __launch_bounds__(256)
+dw_wgrad_vec_kernel(const T* __restrict__ g, const T* __restrict__ x, float* __restrict__ dWp, float* __restrict__ dbp,
+                    DwWg q, long rows_per_slot) {
+  constexpr int EPV = 16 / (int)sizeof(T), K = 3;
+  __shared__ float lds[256 * EPV];                 // [position lane][C]
+  const int slot = blockIdx.x, n = blockIdx.y, kz = blockIdx.z;
+  const int C = q.C, Cw = C / EPV, PL = 256 / Cw;
+  const int ck = threadIdx.x % Cw, pl = threadIdx.x / Cw;
+  const long vg = (long)q.Dg * q.Hg * q.Wg;
+  const T* gn = g + (long)n * vg * C + ck * EPV;
+  const T* xn = x + (long)n * q.Dx * q.Hx * q.Wx * C + ck * EPV;
+  float acc[K * K][EPV], bacc[EPV];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t)
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) acc[t][i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < EPV; ++i) bacc[i] = 0.f;
+  const long v0 = (long)slot * rows_per_slot;
+  const long v1 = v0 + rows_per_slot < vg ? v0 + rows_per_slot : vg;
+  if (pl < PL) {
+    for (long v = v0 + pl; v < v1; v += PL) {
+      const int ox = (int)(v % q.Wg);
+      const long t = v / q.Wg;
+      const int oy = (int)(t % q.Hg), oz = (int)(t / q.Hg);
+      float gv[EPV];
+      VecIO<T, EPV>::load(gn + v * C, gv);
+#pragma unroll
+      for (int i = 0; i < EPV; ++i) bacc[i] += gv[i];
+      const int iz = oz * q.stride - q.pad + kz;
+      if (iz < 0 || iz >= q.Dx) continue;
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const int iy = oy * q.stride - q.pad + ky;
+        if (iy < 0 || iy >= q.Hx) continue;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const int ix = ox * q.stride - q.pad + kx;
+          if (ix < 0 || ix >= q.Wx) continue;
+          float xv[EPV];
+          VecIO<T, EPV>::load(xn + (((long)iz * q.Hx + iy) * q.Wx + ix) * C, xv);
+#pragma unroll
+          for (int i = 0; i < EPV; ++i) acc[ky * K + kx][i] = fmaf(gv[i], xv[i], acc[ky * K + kx][i]);
+        }
+      }
+    }
+  }
+  const long out_base = (long)n * q.slots + slot;
+  for (int t = 0; t <= K * K; ++t) {               // t == K*K: the bias column (kz == 0 only)
+    if (t == K * K && (kz != 0 || !dbp)) break;
+    __syncthreads();
+    if (pl < PL) {
+#pragma unroll
+      for (int i = 0; i < EPV; ++i) lds[pl * C + ck * EPV + i] = t < K * K ? acc[t < K * K ? t : 0][i] : bacc[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float a = 0.f;
+      for (int vv = 0; vv < PL; ++vv) a += lds[vv * C + c];
+      if (t < K * K) dWp[(out_base * K * K * K + (long)kz * K * K + t) * C + c] = a;
+      else dbp[out_base * C + c] = a;
+    }
+  }
+}
+
 // ---- GroupNorm(C groups = per (n,c)) backward ----------------------------------------------------------------------
 // stats: s[n][slot][0][c] = sum dtn, s[..][1][c] = sum dtn * xhat,  xhat = (t - mean) * rstd
 template <typename T>
@@ -565,6 +635,46 @@ dwconv_bwd_data_kernel(const T* __restrict__ dy, const float* __restrict__ w, T*
   dx[i] = from_f32<T>(acc);
 }
 
+// 16-byte form: lane = (input voxel, chunk of EPV channels)
+template <typename T>
+__global__ void __launch_bounds__(256)
+dwconv_bwd_data_vec_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, DwBd g, long total) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int Cw = g.C / EPV;
+  const int c = (int)(i % Cw) * EPV;
+  long t = i / Cw;
+  const int ix = (int)(t % g.W); t /= g.W;
+  const int iy = (int)(t % g.H); t /= g.H;
+  const int iz = (int)(t % g.D);
+  const long n = t / g.D;
+  const T* dn = dy + n * (long)g.Do * g.Ho * g.Wo * g.C + c;
+  float acc[EPV];
+#pragma unroll
+  for (int q = 0; q < EPV; ++q) acc[q] = 0.f;
+  for (int kz = 0; kz < g.K; ++kz) {
+    const int tz = iz + g.pad - kz;
+    if (tz < 0 || tz % g.stride || tz / g.stride >= g.Do) continue;
+    for (int ky = 0; ky < g.K; ++ky) {
+      const int ty = iy + g.pad - ky;
+      if (ty < 0 || ty % g.stride || ty / g.stride >= g.Ho) continue;
+      for (int kx = 0; kx < g.K; ++kx) {
+        const int tx = ix + g.pad - kx;
+        if (tx < 0 || tx % g.stride || tx / g.stride >= g.Wo) continue;
+        float dv[EPV], wv[EPV];
+        VecIO<T, EPV>::load(dn + (((long)(tz / g.stride) * g.Ho + ty / g.stride) * g.Wo + tx / g.stride) * g.C, dv);
+        const float* wp = w + ((long)(kz * g.K + ky) * g.K + kx) * g.C + c;
+        VecIO<float, 4>::load(wp, *reinterpret_cast<float(*)[4]>(&wv[0]));
+        if (EPV == 8) VecIO<float, 4>::load(wp + 4, *reinterpret_cast<float(*)[4]>(&wv[EPV == 8 ? 4 : 0]));
+#pragma unroll
+        for (int q = 0; q < EPV; ++q) acc[q] = fmaf(dv[q], wv[q], acc[q]);
+      }
+    }
+  }
+  VecIO<T, EPV>::store(dx + i * EPV, acc);
+}
+
 static int grid_for(long n) { long b = (n + 255) / 256; return (int)(b < 16384 ? b : 16384); }
 
 }  // namespace pytc
@@ -669,6 +779,20 @@ static int march_slots(int N, const int32_t* gd, const int32_t* xd, int C, int K
   return dw_wgrad_march_slots(N, gd[0], gd[1], gd[2], C, K, stride, dtype);
 }
 
+static bool wg_vec_ok(int C, int K, int dtype) {
+  const int epv = dtype == PYTC_BF16 ? 8 : 4;
+  return K == 3 && C % epv == 0 && C / epv <= 256 && tuning_get("dw_wgrad_vec", 1) != 0;
+}
+static void make_wg_vec(DwWg& q, long& rps, int N, const int32_t* gd, const int32_t* xd, int C, int K, int stride, int dtype) {
+  q.N = N; q.Dg = gd[0]; q.Hg = gd[1]; q.Wg = gd[2]; q.Dx = xd[0]; q.Hx = xd[1]; q.Wx = xd[2];
+  q.C = C; q.K = K; q.stride = stride; q.pad = K / 2; q.lpv = q.vs = q.iters = 0;
+  const int PL = 256 / (C / (dtype == PYTC_BF16 ? 8 : 4));
+  const long vg = (long)q.Dg * q.Hg * q.Wg;
+  long sl = (vg + (long)PL * 16 - 1) / ((long)PL * 16);
+  q.slots = (int)(sl < 1 ? 1 : (sl > 1024 ? 1024 : sl));
+  rps = (vg + q.slots - 1) / q.slots;
+}
+
 static bool make_wg(DwWg& q, int N, const int32_t* gd, const int32_t* xd, int C, int K, int stride, int dtype, int& vec) {
   int maxv = dtype == PYTC_BF16 ? 4 : 2;
   vec = 0;
@@ -689,6 +813,7 @@ extern "C" int pytc_dw_wgrad_slots(int N, const int32_t* gdims, const int32_t* x
   DwWg q; int vec;
   const int ms = march_slots(N, gdims, xdims, C, K, stride, dtype);
   if (ms > 0) return ms;
+  if (wg_vec_ok(C, K, dtype)) { long rps; make_wg_vec(q, rps, N, gdims, xdims, C, K, stride, dtype); return q.slots * N; }
   if (!make_wg(q, N, gdims, xdims, C, K, stride, dtype, vec)) return -1;
   return q.slots * N;
 }
@@ -723,6 +848,24 @@ extern "C" int pytc_dw_wgrad(const void* g, const void* x, float* dW, float* db,
     return PYTC_OK;
   }
   DwWg q; int vec;
+  if (wg_vec_ok(C, K, dtype)) {
+    long rps;
+    make_wg_vec(q, rps, N, gdims, xdims, C, K, stride, dtype);
+    const int total = q.slots * N;
+    const long nWv = 27L * C;
+    float* dWv = workspace;
+    float* dbv = workspace + (long)total * nWv;
+    hipStream_t sv = (hipStream_t)stream;
+    dim3 grid(q.slots, N, 3), block(256);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(dw_wgrad_vec_kernel<bf16_t>, grid, block, 0, sv, (const bf16_t*)g, (const bf16_t*)x, dWv, db ? dbv : nullptr, q, rps),
+               hipLaunchKernelGGL(dw_wgrad_vec_kernel<float>, grid, block, 0, sv, (const float*)g, (const float*)x, dWv, db ? dbv : nullptr, q, rps),
+               "dw_wgrad")
+    hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(nWv, 16)), dim3(256), 0, sv, dWv, dW, nWv, total);
+    if (db) hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, sv, dbv, db, (long)C, total);
+    PYTC_LAUNCH_CHECK("dw_wgrad");
+    return PYTC_OK;
+  }
   if (!make_wg(q, N, gdims, xdims, C, K, stride, dtype, vec)) { set_error("dw_wgrad: unsupported channel count %d", C); return PYTC_ERR_UNSUPPORTED; }
   PYTC_REQUIRE((size_t)q.vs * C * sizeof(float) <= 64 * 1024, "dw_wgrad: scratch too large");
   const int total_slots = q.slots * N;
@@ -793,6 +936,16 @@ extern "C" int pytc_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, 
   g.C = C; g.K = K; g.stride = stride; g.pad = K / 2;
   const long total = (long)N * g.D * g.H * g.W * C;
   hipStream_t s = (hipStream_t)stream;
+  const int epv = dtype == PYTC_BF16 ? 8 : 4;
+  if (C % epv == 0) {
+    const long tv = total / epv;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(dwconv_bwd_data_vec_kernel<bf16_t>, dim3(ceil_div(tv, 256)), dim3(256), 0, s, (const bf16_t*)dy, w, (bf16_t*)dx, g, tv),
+               hipLaunchKernelGGL(dwconv_bwd_data_vec_kernel<float>, dim3(ceil_div(tv, 256)), dim3(256), 0, s, (const float*)dy, w, (float*)dx, g, tv),
+               "dwconv3d_bwd_data")
+    PYTC_LAUNCH_CHECK("dwconv3d_bwd_data");
+    return PYTC_OK;
+  }
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(dwconv_bwd_data_kernel<bf16_t>, dim3(ceil_div(total, 256)), dim3(256), 0, s, (const bf16_t*)dy, w, (bf16_t*)dx, g, total),
              hipLaunchKernelGGL(dwconv_bwd_data_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, s, (const float*)dy, w, (float*)dx, g, total),

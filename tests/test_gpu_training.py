@@ -165,6 +165,23 @@ def test_dw_wgrad_march_bf16_matches_generic_kernel():
     assert torch.equal(dW, dW2)
 
 
+@pytest.mark.parametrize("stride,gshape,xshape", [(2, (7, 8, 9), (14, 16, 18)), (1, (7, 7, 7), (7, 7, 7)), (2, (5, 6, 7), (9, 11, 13))])
+def test_dw_wgrad_vec_bf16_matches_generic_kernel(stride, gshape, xshape):
+    """16-byte depthwise weight gradient (down block: stride 2; up block: transposed form) vs the scalar kernel."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(stride + gshape[0])
+    g = torch.randn(2, *gshape, 64).bfloat16().cuda()
+    x = torch.randn(2, *xshape, 64).bfloat16().cuda()
+    dW, db = ops.dw_wgrad(g, x, K=3, stride=stride)
+    ops.set_tuning("dw_wgrad_vec", 0)
+    try:
+        dW0, db0 = ops.dw_wgrad(g, x, K=3, stride=stride)
+    finally:
+        ops.set_tuning("dw_wgrad_vec", 1)
+    torch.testing.assert_close(dW, dW0, rtol=1e-4, atol=2e-3)
+    torch.testing.assert_close(db, db0, rtol=1e-5, atol=1e-3)
+
+
 def _grads_oracle(st, x, kw, weight_fn):
     params = {k: v.clone().requires_grad_(True) for k, v in st.items() if v.dtype.is_floating_point}
     out = MO.forward(params, x, **kw)
