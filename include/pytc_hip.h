@@ -181,9 +181,13 @@ typedef struct {
   const float* res_bias;/* RES_UPSAMPLE: bias of the transposed 1x1 residual conv */
   int pre_act;          /* PYTC_ACT_NONE or PYTC_ACT_GELU applied to f(x) BEFORE the GEMM (the stored tensor is the
                          * pre-activation; training keeps only that one copy of the expanded tensor) */
+  int w_paired;         /* 0: w_packed from pytc_pw_pack_weight; 1: from pytc_pw_pack_weight_paired (bf16) -- selects
+                         * the 16-byte-store kernel; allowed only when pytc_pw_conv_paired_supported(a) != 0 */
 } pytc_pw_args;
 
 int pytc_pw_conv_fwd(const pytc_pw_args* a, void* stream);
+/* 1 when the shape / dtypes / modes in `a` are covered by the paired-row kernel (pointers are not inspected) */
+int pytc_pw_conv_paired_supported(const pytc_pw_args* a);
 
 /* Fused MedNeXt channel mixer (bf16 activations):
  *     y = W3 * gelu( W2 * (a*t + b) + b2 ) + b3   (+ residual per res_mode, as in pytc_pw_conv_fwd)

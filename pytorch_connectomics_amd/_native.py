@@ -30,7 +30,7 @@ class PwArgs(C.Structure):
         ("in_dtype", C.c_int), ("out_dtype", C.c_int), ("w_dtype", C.c_int),
         ("act", C.c_int), ("res_mode", C.c_int), ("gather", C.c_int),
         ("Di", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int),
-        ("res_low", C.c_void_p), ("res_bias", C.c_void_p), ("pre_act", C.c_int),
+        ("res_low", C.c_void_p), ("res_bias", C.c_void_p), ("pre_act", C.c_int), ("w_paired", C.c_int),
     ]
 
 
@@ -81,6 +81,7 @@ _SIGS = {
     "pytc_pw_packed_elems": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "pytc_pw_pack_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "pytc_pw_conv_fwd": (C.c_int, [C.POINTER(PwArgs), C.c_void_p]),
+    "pytc_pw_conv_paired_supported": (C.c_int, [C.POINTER(PwArgs)]),
     "pytc_conv3d_packed_elems": (C.c_int64, [C.c_int] * 6),
     "pytc_conv3d_pack_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                           C.c_void_p]),

@@ -1,0 +1,162 @@
+// Single pointwise GEMM on the paired-row weight image (bf16 in / weights / out, C_in and C_out multiples of 32):
+// the training step's expand / project / data-gradient convs and the un-fused 1x1 convs of the inference path.
+// Same transposed form as pw_kernels.hip (weights = MFMA A, voxels = N), with what made pw_mlp fast:
+//   * all B-operand loads of a wave's voxel tile (16 B per lane per 32-channel step) are issued up front, the
+//     GroupNorm affine and/or GELU pre-activation are applied while they become MFMA operands;
+//   * output channels are produced one tile PAIR at a time: after the paired-row packing a lane ends with 8 consecutive
+//     channels of one voxel -> 16-byte stores, 16-byte residual / pre-activation loads issued before the pair's MFMAs;
+//   * only 2 x NT accumulators live at a time, so the register budget goes to the operand tile (C_in up to 1024).
+// HBM traffic = each operand once: C_in + C_out (+ C_out residual) elements per voxel.
+#include "pw_common.h"
+
+namespace pytc {
+
+struct PwFastParams {
+  const bf16_t* x;
+  const bf16x8_t* w;      // paired image [C_out/16][KS][64 lanes][8]
+  const float* bias;
+  const float* ab;
+  EpiParams e;
+  long rps;
+  int C_in, C_out, pre_act;
+};
+
+template <int KS, int NT>
+__global__ void __launch_bounds__(256)
+pw_fast_kernel(PwFastParams p) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.y;
+  const long row0 = ((long)blockIdx.x * 4 + wave) * (NT * 16);
+  if (row0 >= p.rps) return;
+  const int r = lane & 15, kb = lane >> 4;
+  long orow[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) orow[nt] = row0 + nt * 16 + r;
+
+  bf16x8_t bact[KS][NT];
+  const bf16_t* xn = p.x + (long)n * p.rps * p.C_in;
+  {
+    uint4 raw[KS][NT];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const long rr = orow[nt] < p.rps ? orow[nt] : p.rps - 1;
+        raw[ks][nt] = *reinterpret_cast<const uint4*>(xn + rr * p.C_in + ks * 32 + kb * 8);
+      }
+    if (p.ab || p.pre_act == PYTC_ACT_GELU) {
+      const float* an = p.ab ? p.ab + (long)n * 2 * p.C_in : nullptr;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int k0 = ks * 32 + kb * 8;
+        float av[8], bv[8];
+        if (an) {
+          VecIO<float, 4>::load(an + k0, reinterpret_cast<float(&)[4]>(av[0]));
+          VecIO<float, 4>::load(an + k0 + 4, reinterpret_cast<float(&)[4]>(av[4]));
+          VecIO<float, 4>::load(an + p.C_in + k0, reinterpret_cast<float(&)[4]>(bv[0]));
+          VecIO<float, 4>::load(an + p.C_in + k0 + 4, reinterpret_cast<float(&)[4]>(bv[4]));
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          float v[8];
+          VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(&raw[ks][nt]), v);
+          if (an) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], av[j], bv[j]);
+          }
+          if (p.pre_act == PYTC_ACT_GELU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+          }
+          bact[ks][nt] = Mma<bf16_t>::from_floats(v);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bact[ks][nt] = __builtin_bit_cast(bf16x8_t, raw[ks][nt]);
+    }
+  }
+
+  const bool pre_ok = p.e.res_mode == PYTC_RES_ADD || p.e.res_mode == PYTC_RES_GELU_BWD;
+  const bf16_t* resn = pre_ok ? reinterpret_cast<const bf16_t*>(p.e.res) + (long)n * p.rps * p.C_out : nullptr;
+  const int pairs = p.C_out / 32;
+  for (int pr = 0; pr < pairs; ++pr) {
+    const int o0 = pr * 32 + kb * 8;
+    uint4 rpre[NT];
+    if (pre_ok) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const long rr = orow[nt] < p.rps ? orow[nt] : p.rps - 1;
+        rpre[nt] = *reinterpret_cast<const uint4*>(resn + rr * p.C_out + o0);
+      }
+    }
+    float b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = 0.f;
+    if (p.bias) {
+      VecIO<float, 4>::load(p.bias + o0, reinterpret_cast<float(&)[4]>(b[0]));
+      VecIO<float, 4>::load(p.bias + o0 + 4, reinterpret_cast<float(&)[4]>(b[4]));
+    }
+    f32x4_t acc[2][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      acc[0][nt] = f32x4_t{b[0], b[1], b[2], b[3]};
+      acc[1][nt] = f32x4_t{b[4], b[5], b[6], b[7]};
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t a = p.w[((long)(pr * 2 + mt) * KS + ks) * 64 + lane];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Mma<bf16_t>::mma(a, bact[ks][nt], acc[mt][nt]);
+      }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (orow[nt] >= p.rps) continue;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = acc[0][nt][j]; v[4 + j] = acc[1][nt][j]; }
+      if (pre_ok) {
+        float pre[8];
+        VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(&rpre[nt]), pre);
+        finish_and_store<bf16_t, 8>(v, p.e, n, orow[nt], o0, pre);
+      } else {
+        finish_and_store<bf16_t, 8>(v, p.e, n, orow[nt], o0);
+      }
+    }
+  }
+}
+
+template <int KS, int NT>
+static void launch_fast(const PwFastParams& p, int N, hipStream_t s) {
+  const long rows_per_block = 4L * NT * 16;
+  dim3 grid((unsigned)((p.rps + rows_per_block - 1) / rows_per_block), (unsigned)N), block(256);
+  hipLaunchKernelGGL((pw_fast_kernel<KS, NT>), grid, block, 0, s, p);
+}
+
+bool pw_fast_supported(const pytc_pw_args* a) {
+  if (a->in_dtype != PYTC_BF16 || a->out_dtype != PYTC_BF16 || a->w_dtype != PYTC_BF16) return false;
+  if (a->C_in % 32 || a->C_out % 32 || a->gather != 0 || a->act != PYTC_ACT_NONE) return false;
+  const int ks = a->C_in / 32;
+  return ks == 1 || ks == 2 || ks == 4 || ks == 8 || ks == 16 || ks == 32;
+}
+
+void pw_fast_launch(const pytc_pw_args* a, const EpiParams& e, hipStream_t s) {
+  PwFastParams p;
+  p.x = (const bf16_t*)a->x; p.w = (const bf16x8_t*)a->w_packed; p.bias = a->bias; p.ab = a->ab; p.e = e;
+  p.rps = a->rows_per_sample; p.C_in = a->C_in; p.C_out = a->C_out; p.pre_act = a->pre_act;
+  const int nt_knob = tuning_get("pw_fast_nt", 0);
+  switch (a->C_in / 32) {
+    case 1: if (nt_knob == 2) launch_fast<1, 2>(p, a->N, s); else launch_fast<1, 4>(p, a->N, s); break;
+    case 2: if (nt_knob == 2) launch_fast<2, 2>(p, a->N, s); else launch_fast<2, 4>(p, a->N, s); break;
+    case 4: if (nt_knob == 4) launch_fast<4, 4>(p, a->N, s); else launch_fast<4, 2>(p, a->N, s); break;
+    case 8: launch_fast<8, 2>(p, a->N, s); break;
+    case 16: launch_fast<16, 1>(p, a->N, s); break;
+    default: launch_fast<32, 1>(p, a->N, s); break;
+  }
+}
+
+}  // namespace pytc

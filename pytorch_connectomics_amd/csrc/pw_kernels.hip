@@ -152,9 +152,14 @@ static void launch_pw(const PwParams& p, int MT, hipStream_t s) {
   }
 }
 
+bool pw_fast_supported(const pytc_pw_args* a);
+void pw_fast_launch(const pytc_pw_args* a, const EpiParams& e, hipStream_t s);
+
 }  // namespace pytc
 
 using namespace pytc;
+
+extern "C" int pytc_pw_conv_paired_supported(const pytc_pw_args* a) { return a && pw_fast_supported(a) ? 1 : 0; }
 
 static int kstep_of(int dtype) { return dtype == PYTC_BF16 ? 32 : 16; }
 
@@ -215,6 +220,12 @@ extern "C" int pytc_pw_conv_fwd(const pytc_pw_args* a, void* stream) {
   }
   int MT = p.MTt >= 4 ? 4 : (p.MTt >= 2 ? 2 : 1);
   hipStream_t s = (hipStream_t)stream;
+  if (a->w_paired) {
+    PYTC_REQUIRE(pw_fast_supported(a), "pw_conv: w_paired set for a shape the paired-row kernel does not cover");
+    pw_fast_launch(a, p.e, s);
+    PYTC_LAUNCH_CHECK("pw_conv");
+    return PYTC_OK;
+  }
   const int ti = a->in_dtype, tw = a->w_dtype, to = a->out_dtype;
   if (ti == PYTC_F32 && tw == PYTC_F32 && to == PYTC_F32) launch_pw<float, float, float, 4>(p, MT, s);
   else if (ti == PYTC_BF16 && tw == PYTC_BF16 && to == PYTC_BF16) launch_pw<bf16_t, bf16_t, bf16_t, 4>(p, MT, s);

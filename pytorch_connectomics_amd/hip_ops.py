@@ -219,7 +219,7 @@ def pw_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
             act: int = nat.ACT_NONE, res: Optional[torch.Tensor] = None, res_mode: int = nat.RES_NONE,
             gather: int = 0, grid: Sequence[int] = (0, 0, 0), res_low: Optional[torch.Tensor] = None,
             res_bias: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None,
-            pre_act: int = nat.ACT_NONE) -> torch.Tensor:
+            pre_act: int = nat.ACT_NONE, w_paired: bool = False) -> torch.Tensor:
     _dev(x, "x"); _dev(w_packed, "w_packed")
     if y is None:
         y = torch.empty((N, rows_per_sample, c_out), dtype=out_dtype, device=x.device)
@@ -230,7 +230,7 @@ def pw_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
                                                  res.data_ptr() if res is not None else None, y.data_ptr())
     a.N, a.rows_per_sample, a.C_in, a.C_out = N, rows_per_sample, c_in, c_out
     a.in_dtype, a.out_dtype, a.w_dtype = dtype_code(x.dtype), dtype_code(y.dtype), dtype_code(w_packed.dtype)
-    a.act, a.res_mode, a.gather, a.pre_act = act, res_mode, gather, pre_act
+    a.act, a.res_mode, a.gather, a.pre_act, a.w_paired = act, res_mode, gather, pre_act, int(w_paired)
     a.Di, a.Hi, a.Wi = (int(v) for v in grid)
     a.res_low = res_low.data_ptr() if res_low is not None else None
     a.res_bias = res_bias.data_ptr() if res_bias is not None else None
@@ -238,6 +238,18 @@ def pw_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
     nb = rows_in + _nbytes(y) + (_nbytes(y) if res is not None else 0)
     _run(f"pw_conv_fwd[{c_in}->{c_out}]", nb, nat.lib().pytc_pw_conv_fwd, C.byref(a), _stream())
     return y
+
+
+def pw_conv_paired_supported(*, c_in: int, c_out: int, in_dtype: torch.dtype, out_dtype: torch.dtype,
+                             w_dtype: torch.dtype = torch.bfloat16, act: int = nat.ACT_NONE, gather: int = 0) -> bool:
+    """True when pw_conv may be given a paired-row weight image (pw_pack_weight_paired) -> 16-byte-store kernel."""
+    a = nat.PwArgs()
+    a.C_in, a.C_out, a.act, a.gather = int(c_in), int(c_out), int(act), int(gather)
+    try:
+        a.in_dtype, a.out_dtype, a.w_dtype = dtype_code(in_dtype), dtype_code(out_dtype), dtype_code(w_dtype)
+    except Exception:
+        return False
+    return bool(nat.lib().pytc_pw_conv_paired_supported(C.byref(a)))
 
 
 def pw_mlp_supported(c_in: int, c_hid: int, c_out: int) -> bool:

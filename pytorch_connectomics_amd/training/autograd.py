@@ -43,11 +43,15 @@ def _pw(x, w_mat, bias, *, c_out, out_dtype=None, transposed=False, **kw):
     """y = pw_conv with freshly packed weights (weights change every step during training)."""
     dt = x.dtype if x.dtype == torch.bfloat16 or out_dtype != torch.bfloat16 else torch.bfloat16
     wdt = torch.bfloat16 if (x.dtype == torch.bfloat16 or out_dtype == torch.bfloat16) else torch.float32
-    wp = ops.pw_pack_weight(w_mat, wdt, transposed=transposed)
+    odt = out_dtype or x.dtype
+    paired = wdt == torch.bfloat16 and ops.pw_conv_paired_supported(
+        c_in=x.shape[-1], c_out=c_out, in_dtype=x.dtype, out_dtype=odt, act=kw.get("act", nat.ACT_NONE),
+        gather=kw.get("gather", 0))
+    wp = ops.pw_pack_weight_paired(w_mat, transposed=transposed) if paired else ops.pw_pack_weight(w_mat, wdt, transposed=transposed)
     N = x.shape[0]
     rows = kw.pop("rows", None) or x.numel() // (N * x.shape[-1])
     y = ops.pw_conv(x, wp, bias, N=N, rows_per_sample=rows, c_in=x.shape[-1], c_out=c_out,
-                    out_dtype=out_dtype or x.dtype, **kw)
+                    out_dtype=odt, w_paired=paired, **kw)
     return y
 
 

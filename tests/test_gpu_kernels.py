@@ -228,3 +228,37 @@ def test_gelu_accuracy(dev):
     y = ops.pw_conv(x.to(dev), ops.pw_pack_weight(eye.to(dev), torch.float32), None, N=1, rows_per_sample=x.shape[1],
                     c_in=16, c_out=16, out_dtype=torch.float32, act=nat.ACT_GELU).cpu()
     torch.testing.assert_close(y, F.gelu(x), rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("ci,co,mode", [(32, 64, "ab"), (64, 32, "gelu_add"), (32, 128, "gelu_bwd"), (128, 64, "plain"),
+                                        (256, 128, "ab"), (512, 1024, "plain"), (1024, 512, "gelu_add"), (128, 32, "up")])
+def test_pw_conv_paired_row_kernel_matches_generic(ci, co, mode):
+    """bf16 1x1 conv on the paired-row weight image (16-byte stores) against the generic kernel, all fused modes."""
+    from pytorch_connectomics_amd import _native as nat, hip_ops as ops
+    torch.manual_seed(ci + co)
+    N, grid = 2, (6, 8, 10)
+    rows = grid[0] * grid[1] * grid[2]
+    x = torch.randn(N, rows, ci).bfloat16().cuda()
+    w = (torch.randn(co, ci) / ci ** 0.5).cuda()
+    b = torch.randn(co).cuda()
+    kw = {}
+    if mode == "ab":
+        kw["ab"] = torch.stack([torch.rand(N, ci) + 0.5, torch.randn(N, ci)], 1).contiguous().cuda()
+    if mode == "gelu_add":
+        kw.update(pre_act=nat.ACT_GELU, res=torch.randn(N, rows, co).bfloat16().cuda(), res_mode=nat.RES_ADD)
+    if mode == "gelu_bwd":
+        kw.update(res=torch.randn(N, rows, co).bfloat16().cuda(), res_mode=nat.RES_GELU_BWD)
+    if mode == "up":
+        low = tuple(g // 2 for g in grid)
+        kw.update(res=torch.randn(N, rows, co).bfloat16().cuda(), res_mode=nat.RES_UPSAMPLE, grid=grid,
+                  res_low=torch.randn(N, low[0] * low[1] * low[2], co).bfloat16().cuda(), res_bias=torch.randn(co).cuda())
+    assert ops.pw_conv_paired_supported(c_in=ci, c_out=co, in_dtype=torch.bfloat16, out_dtype=torch.bfloat16)
+    common = dict(N=N, rows_per_sample=rows, c_in=ci, c_out=co, out_dtype=torch.bfloat16, **kw)
+    y0 = ops.pw_conv(x, ops.pw_pack_weight(w, torch.bfloat16), b, **common)
+    y1 = ops.pw_conv(x, ops.pw_pack_weight_paired(w), b, w_paired=True, **common)
+    d = (y0.float() - y1.float()).abs()
+    assert float(d.max()) <= 2 ** -6 * max(1.0, float(y0.float().abs().max()))      # one bf16 ulp at most
+    assert float((d > 0).float().mean()) < 0.02
+    assert not ops.pw_conv_paired_supported(c_in=24, c_out=64, in_dtype=torch.bfloat16, out_dtype=torch.bfloat16)
+    assert not ops.pw_conv_paired_supported(c_in=32, c_out=64, in_dtype=torch.float32, out_dtype=torch.float32,
+                                            w_dtype=torch.float32)
