@@ -213,7 +213,7 @@ struct DwMarch {
   int swizzle;           // XCD-aware block remap on/off
 };
 
-template <typename T, int VEC, int PF>
+template <typename T, int VEC, int PF, bool ASYNC>
 __global__ void __launch_bounds__(256, 2)
 dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ w,
                          const float* __restrict__ bias, float* __restrict__ stats, DwMarch g) {
@@ -259,24 +259,48 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
     const int yy = vox / EX, xx = vox % EX;
     const int gy = y0 - 1 + yy, gx = x0 - 1 + xx;
     cok[i] = (c < NCHUNK) && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
-    goff[i] = (gy * g.W + gx) * C + part * EPC;
+    // every lane always loads (clamped address, zero-filled at commit): no branches around the loads, and with ASYNC
+    // each wave issues exactly CPT loads per plane, which makes the counted s_waitcnt below exact
+    const int gyc = min(max(gy, 0), g.H - 1), gxc = min(max(gx, 0), g.W - 1);
+    goff[i] = (gyc * g.W + gxc) * C + part * EPC;
     loff[i] = (c < NCHUNK) ? vox * CG + part * EPC : -1;
   }
-  uint4 stg0[CPT], stg1[CPT];
-  auto issue = [&](int gz, uint4 (&stg)[CPT]) {
-    const bool zok = gz >= 0 && gz < g.D;
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t stg0[CPT], stg1[CPT], stg2[PF == 3 ? CPT : 1];
+  // ASYNC: the plane loads are inline asm, invisible to the compiler's wait-count pass (which, with stores pending on the
+  // same counter, would drain everything with vmcnt(0) at the first use).  Loads return in order among loads, so waiting
+  // until at most NEWER = CPT*(planes issued later) operations are outstanding guarantees this plane has landed
+  // whatever the stores do -- the younger planes stay in flight across the barrier.
+  auto issue = [&](int gz, u32x4_t (&stg)[CPT]) {
+    const int zc = min(max(gz, 0), g.D - 1);
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-      stg[i] = make_uint4(0u, 0u, 0u, 0u);
-      if (zok && cok[i]) stg[i] = *reinterpret_cast<const uint4*>(xn + (long)gz * plane_elems + goff[i]);
+      const T* ptr = xn + (long)zc * plane_elems + goff[i];
+      if constexpr (ASYNC) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(stg[i]) : "v"(ptr) : "memory");
+      else stg[i] = *reinterpret_cast<const u32x4_t*>(ptr);
     }
   };
-  auto commit = [&](int slot, uint4 (&stg)[CPT]) {
+  auto landed = [&](u32x4_t (&stg)[CPT], bool younger_in_flight) {
+    if constexpr (ASYNC) {
+      static_assert(CPT == 2, "the wait below names two staging registers");
+      // operand-free waits (a "+v" operand here made hipcc copy the still-in-flight registers BEFORE the wait), then one
+      // anchor that orders every later use of the staging registers after them
+      if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(CPT * (PF - 1)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+      asm volatile("" : "+v"(stg[0]), "+v"(stg[1]) : : "memory");
+    }
+  };
+  auto commit = [&](int slot, u32x4_t (&stg)[CPT], int gz) {
+    const bool zok = gz >= 0 && gz < g.D;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       if (loff[i] < 0) continue;
       float v[EPC];
       VecIO<T, EPC>::load(reinterpret_cast<const T*>(&stg[i]), v);
+      if (!(zok && cok[i])) {
+#pragma unroll
+        for (int q = 0; q < EPC; ++q) v[q] = 0.f;
+      }
       float* dst = &plane[slot][loff[i]];
 #pragma unroll
       for (int q = 0; q < EPC; q += 4)
@@ -318,7 +342,7 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
   // `ld` receives the global loads issued this step (plane gz+PF); `cm` holds plane gz+1 (issued PF-1
   // steps ago) and is committed to the other LDS slot after the compute.
   auto step = [&](int gz, int slot, float (&prev)[PASSES][VEC], float (&cur)[PASSES][VEC],
-                  float (&next)[PASSES][VEC], uint4 (&ld)[CPT], uint4 (&cm)[CPT]) {
+                  float (&next)[PASSES][VEC], u32x4_t (&ld)[CPT], u32x4_t (&cm)[CPT]) {
     if (gz + PF <= ze) issue(gz + PF, ld);
     // Unconditional accumulation: planes outside the volume were staged as zeros, and accumulators that
     // belong to outputs outside [zs, ze) are simply never stored (2 wasted planes per z-chunk), which keeps
@@ -329,7 +353,10 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
       for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-          const fvec_t v = *reinterpret_cast<const fvec_t*>(&plane[slot][lbase[ps] + (dy * EX + dx) * CG]);
+          // ASYNC variant: volatile keeps one ds_read_b64 per tap (the merged ds_read2_b64 runs at half the LDS rate)
+          typedef const volatile __attribute__((address_space(3))) fvec_t* lds_vol_ptr;
+          const fvec_t v = ASYNC ? *(lds_vol_ptr)(&plane[slot][lbase[ps] + (dy * EX + dx) * CG])
+                                 : *reinterpret_cast<const fvec_t*>(&plane[slot][lbase[ps] + (dy * EX + dx) * CG]);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) {
             next[ps][i] = fmaf(v[i], wr[(0 * 3 + dy) * 3 + dx][i], next[ps][i]);
@@ -339,6 +366,11 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
         }
       }
     }
+    if (gz + 1 <= ze) {
+      landed(cm, gz + PF <= ze);
+      commit(slot ^ 1, cm, gz + 1);
+    }
+    // stores after the wait: the only operations younger than the awaited plane are then the newest plane's loads
     if (gz - 1 >= zs) {   // output plane gz-1 is complete
 #pragma unroll
       for (int ps = 0; ps < PASSES; ++ps) {
@@ -357,17 +389,25 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
     for (int ps = 0; ps < PASSES; ++ps)
 #pragma unroll
       for (int i = 0; i < VEC; ++i) prev[ps][i] = bv[i];
-    if (gz + 1 <= ze) commit(slot ^ 1, cm);
     __syncthreads();
   };
 
-  // prologue: plane zs-1 -> LDS slot 0; with PF == 2 plane zs is already in flight in stg1
+  // prologue: plane zs-1 -> LDS slot 0; with PF >= 2 planes zs (.. zs+1) are already in flight in stg1 (stg2)
   issue(zs - 1, stg0);
-  if (PF == 2) issue(zs, stg1);
-  commit(0, stg0);
+  if (PF >= 2) issue(zs, stg1);
+  if constexpr (PF == 3) issue(zs + 1, stg2);
+  landed(stg0, true);
+  commit(0, stg0, zs - 1);
   __syncthreads();
   int slot = 0;
-  if (PF == 1) {
+  if constexpr (PF == 3) {
+    // plane p travels in set (p - (zs-1)) % 3: step k loads plane gz+3 into set k%3, commits plane gz+1 from set (k+1)%3
+    for (int gz = zs - 1; gz <= ze; gz += 3) {
+      step(gz, slot, accA, accB, accC, stg0, stg1); slot ^= 1;
+      if (gz + 1 <= ze) { step(gz + 1, slot, accB, accC, accA, stg1, stg2); slot ^= 1; }
+      if (gz + 2 <= ze) { step(gz + 2, slot, accC, accA, accB, stg2, stg0); slot ^= 1; }
+    }
+  } else if (PF == 1) {
     for (int gz = zs - 1; gz <= ze; gz += 3) {
       step(gz, slot, accA, accB, accC, stg0, stg0); slot ^= 1;
       if (gz + 1 <= ze) { step(gz + 1, slot, accB, accC, accA, stg0, stg0); slot ^= 1; }
@@ -425,7 +465,7 @@ static void make_march(DwMarch& t, int N, int D, int H, int W, int C) {
   t.ty = (H + TILE_Y - 1) / TILE_Y; t.tx = (W + TILE_X - 1) / TILE_X;
   // z-chunks: enough workgroups to fill 256 CUs x 2 several times over, chunks >= 14 planes (halo <= 14 %)
   const long fp = (long)t.ty * t.tx * (C / MARCH_CG) * N;
-  int nzc = (int)((8L * 512 + fp - 1) / fp);
+  int nzc = (int)(((long)tuning_get("dwconv_march_wgs", 4096) + fp - 1) / fp);
   if (nzc < 1) nzc = 1;
   int maxc = D / 14;
   if (maxc < 1) maxc = 1;
@@ -767,12 +807,15 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
     make_march(t, N, D, H, W, C);
     dim3 grid((unsigned)((long)t.slots * (C / MARCH_CG) * N)), block(256);
     t.swizzle = tuning_get("dwconv_xcd_swizzle", 1);
-    const int variant = tuning_get("dwconv_march_variant", 3);   // bit0: VEC=2, bit1: PF=2
+    const int variant = tuning_get("dwconv_march_variant", 9);   // bit0: VEC=2, bit1: PF=2; 5: VEC=2, PF=3; 7 / 9: asm loads + counted waits, PF=2 / 3
 #define PYTC_MARCH(TT, VV, PP) \
-  hipLaunchKernelGGL((dwconv3d_k3_march_kernel<TT, VV, PP>), grid, block, 0, (hipStream_t)stream, (const TT*)x, \
+  hipLaunchKernelGGL((dwconv3d_k3_march_kernel<TT, VV, PP, false>), grid, block, 0, (hipStream_t)stream, (const TT*)x, \
                      (TT*)y, w, bias, stats, t)
     if (dtype == PYTC_BF16) {
-      switch (variant & 3) {
+      if (variant == 7) hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, 2, true>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t);
+      else if (variant == 9) hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, 3, true>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t);
+      else if (variant == 5) PYTC_MARCH(bf16_t, 2, 3);
+      else switch (variant & 3) {
         case 0: PYTC_MARCH(bf16_t, 4, 1); break;
         case 1: PYTC_MARCH(bf16_t, 2, 1); break;
         case 2: PYTC_MARCH(bf16_t, 4, 2); break;

@@ -161,14 +161,14 @@ class HipBlockOps:
         def make():
             w2 = w.detach().float().reshape(w.shape[0], w.shape[1]).contiguous()
             return ops.pw_pack_weight(w2, dt, transposed=transposed)
-        return self.cache.get(("pw", id(conv), dt), [w], make)
+        return self.cache.get(("pw", id(conv), dt, transposed), [w], make)
 
     def _pw_paired(self, conv: nn.Module, transposed: bool = False):
         w = conv.weight
         def make():
             w2 = w.detach().float().reshape(w.shape[0], w.shape[1]).contiguous()
             return ops.pw_pack_weight_paired(w2, transposed=transposed)
-        return self.cache.get(("pwp", id(conv)), [w], make)
+        return self.cache.get(("pwp", id(conv), transposed), [w], make)
 
     def _vec(self, owner, name: str, p: Optional[torch.Tensor]):
         if p is None:
@@ -271,8 +271,10 @@ def _block_fused(self, m, x, t, ab, skip, ishape, oshape, c_hid, c_out):
         res_low = res_bias = None
         if m.resample_do_res:
             res_bias = self._vec(m.res_conv, "bias", m.res_conv.bias)
-            res_low = ops.pw_conv(x, self._pw(m.res_conv, dt, transposed=True), res_bias, N=N,
-                                  rows_per_sample=D * H * W, c_in=C, c_out=c_out, out_dtype=dt)
+            paired = ops.pw_conv_paired_supported(c_in=C, c_out=c_out, in_dtype=dt, out_dtype=dt)
+            wres = self._pw_paired(m.res_conv, transposed=True) if paired else self._pw(m.res_conv, dt, transposed=True)
+            res_low = ops.pw_conv(x, wres, res_bias, N=N, rows_per_sample=D * H * W, c_in=C, c_out=c_out,
+                                  out_dtype=dt, w_paired=paired)
         y = ops.pw_mlp(t, ab, w2, b2, w3, b3, res=skip, res_mode=nat.RES_UPSAMPLE, grid=(Do, Ho, Wo),
                        res_low=res_low, res_bias=res_bias, **kw)
     return y.view(N, Do, Ho, Wo, c_out)

@@ -17,7 +17,7 @@ dev = torch.device("cuda:0")
 bf = torch.bfloat16
 
 
-def timeit(fn, reps=10, warm=3):
+def timeit(fn, reps=10, warm=8):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -40,13 +40,20 @@ def bench_dwconv():
         taps = torch.randn(27, C, device=dev)
         b = torch.randn(C, device=dev)
         nbytes = 2 * x.numel() * 2
-        for var in (0, 1, 3):
-            for swz in (0, 1):
+        knob("dwconv_march_variant", 3)
+        ref, rst = ops.dwconv3d(x, taps, b, K=3)
+        for var in (1, 3, 7, 9):
+            knob("dwconv_march_variant", var)
+            y, st = ops.dwconv3d(x, taps, b, K=3)
+            print(f"variant {var}: bit-exact vs variant 3: y={bool(torch.equal(y, ref))} stats={bool(torch.equal(st, rst))}")
+            for wgs in (4096,):
                 knob("dwconv_march_variant", var)
-                knob("dwconv_xcd_swizzle", swz)
+                knob("dwconv_march_wgs", wgs)
                 us = timeit(lambda: ops.dwconv3d(x, taps, b, K=3))
-                print(f"dwconv3d N{N} {D}^3 C{C} variant{var} (VEC={2 if var & 1 else 4}, PF={2 if var & 2 else 1}) "
-                      f"xcd_swizzle={swz}: {us:8.1f} us  {nbytes / us / 1e3:7.1f} GB/s", flush=True)
+                print(f"dwconv3d N{N} {D}^3 C{C} variant{var} target_wgs={wgs}: "
+                      f"{us:8.1f} us  {nbytes / us / 1e3:7.1f} GB/s", flush=True)
+        knob("dwconv_march_variant", 9)
+        knob("dwconv_march_wgs", 4096)
 
 
 def bench_mlp():
