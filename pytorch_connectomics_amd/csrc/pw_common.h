@@ -65,7 +65,8 @@ struct EpiParams {
 };
 
 // v[NCH] = conv result (+bias, activation) for channels o0..o0+NCH-1 of output row `orow` of sample n.
-template <typename TO, int NCH>
+// GELU_BWD = false compiles the PYTC_RES_GELU_BWD branch out (the fused mixer never uses it and pays registers for it).
+template <typename TO, int NCH, bool GELU_BWD = false>
 __device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParams& e, int n, long orow, int o0,
                                                  const float* pre = nullptr) {
   // pre != nullptr: the caller already loaded res[orow][o0..o0+NCH) (prefetched ahead of the GEMMs)
@@ -85,9 +86,12 @@ __device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParam
     }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) v[i] += rv[i];
-  } else if (e.res_mode == PYTC_RES_GELU_BWD) {
+  } else if (GELU_BWD && e.res_mode == PYTC_RES_GELU_BWD) {
     float rv[NCH];
-    if (full) VecIO<TO, NCH>::load(resn + off, rv);
+    if (pre) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) rv[i] = pre[i];
+    } else if (full) VecIO<TO, NCH>::load(resn + off, rv);
     else {
 #pragma unroll
       for (int i = 0; i < NCH; ++i) rv[i] = (o0 + i < e.C_out) ? to_f32<TO>(resn[off + i]) : 0.f;
@@ -155,6 +159,38 @@ __device__ __forceinline__ void load_row_frag(const TI* __restrict__ row, int k0
 #pragma unroll
     for (int j = 0; j < EPL; ++j) v[j] = (k0 + j < C_in) ? to_f32<TI>(row[k0 + j]) : 0.f;
   }
+}
+
+// L2 warm-up for weight streams: inside a network every launch meets its weights cold, and a wave's hidden-chunk loop
+// is a chain of dependent weight loads (one HBM round trip per link).  At kernel entry the workgroups of each XCD
+// (dispatch order: linear workgroup id % 8) together touch every 128-byte line of the image once, so the chain runs
+// against L2 hits instead.  Fire-and-forget loads into a scratch register; no synchronisation is involved.
+// The destination registers stay reserved until warm_l2_done() -- a load into a register the compiler believes dead
+// would overwrite whatever it keeps there when the data arrives.
+template <int PER>                      // PER loads per image per lane; two images (w2, w3) at most
+struct WarmRegs { unsigned int r[2 * PER]; };
+template <int PER>
+__device__ __forceinline__ void warm_l2(const void* base, long bytes, WarmRegs<PER>& w, int first) {
+  const long lines = (bytes + 127) >> 7;
+  const long lin = (long)blockIdx.z * gridDim.y * gridDim.x + (long)blockIdx.y * gridDim.x + blockIdx.x;
+  const long total = (long)gridDim.x * gridDim.y * gridDim.z;
+  const long per_xcd = (total + 7) >> 3;
+  const long stride = per_xcd * blockDim.x;
+  long l = (lin >> 3) * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < PER; ++it, l += stride) {
+    const long lc = l < lines ? l : lines - 1;          // always issue (clamped): the register is written either way
+    const char* ptr = reinterpret_cast<const char*>(base) + (lc << 7);
+    asm volatile("global_load_dword %0, %1, off" : "=v"(w.r[first + it]) : "v"(ptr) : "memory");
+  }
+}
+template <int PER>
+__device__ __forceinline__ void warm_l2_done(WarmRegs<PER>& w) {
+  // explicit drain, then release the registers: the compiler's own wait for the operand loads may be scheduled later
+  // than this point, so it cannot be relied on.  Call this where the operand tile is consumed anyway.
+  asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+#pragma unroll
+  for (int i = 0; i < 2 * PER; ++i) asm volatile("" : : "v"(w.r[i]) : "memory");
 }
 
 __device__ __forceinline__ float apply_act(float t, int act) {

@@ -114,7 +114,7 @@ pw_conv_kernel(PwParams p) {
       float v[4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) v[rr] = apply_act(acc[mt][nt][rr] + bo[rr], p.act);
-      finish_and_store<TO, 4>(v, p.e, n, orow[nt], o0);
+      finish_and_store<TO, 4, true>(v, p.e, n, orow[nt], o0);
     }
   }
 }

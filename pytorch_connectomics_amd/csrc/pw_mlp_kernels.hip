@@ -32,8 +32,20 @@ pw_mlp_kernel(MlpParams p) {
   constexpr bool PREFETCH_RES = (MO / 2) * NT <= 4;   // residual rows ride along with the input loads
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = blockIdx.y;
+  constexpr bool WARM = KS_IN * MO >= 32;    // >= 64 KB of weights: warm this XCD's L2 (see warm_l2)
+  constexpr int WPER = KS_IN * MO >= 512 ? 6 : 2;   // few workgroups at the deepest level: more lines per lane
+  WarmRegs<WPER> warm;
+  if (WARM) {
+    warm_l2(p.w2, (long)p.C_hid * p.C_in * 2, warm, 0);
+    warm_l2(p.w3, (long)p.C_out * p.C_hid * 2, warm, WPER);
+  }
   const long row0 = ((long)blockIdx.x * 4 + wave) * (NT * 16);
-  if (row0 >= p.rps) return;
+  if (row0 >= p.rps) {
+    // a wave must not end with warm-up loads in flight: their data would land in registers of whichever wave is
+    // allocated next
+    if (WARM) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    return;
+  }
   const int r = lane & 15, kb = lane >> 4;
 
   long orow[NT];
@@ -62,6 +74,8 @@ pw_mlp_kernel(MlpParams p) {
       bact[ks][nt] = Mma<bf16_t>::from_floats(v);
     }
   }
+
+  if (WARM) warm_l2_done(warm);              // bact is built: the (older) warm-up loads have landed
 
   // ---- residual / skip rows: issue their loads now so they are in flight during both GEMMs
   uint4 rpre[PREFETCH_RES ? MO / 2 : 1][PREFETCH_RES ? NT : 1];
@@ -244,6 +258,8 @@ extern "C" int pytc_pw_mlp_fwd(const pytc_mlp_args* a, void* stream) {
     return PYTC_ERR_UNSUPPORTED;
   }
   PYTC_REQUIRE(a->res_mode == PYTC_RES_NONE || a->res, "pw_mlp: residual mode without residual pointer");
+  PYTC_REQUIRE(a->res_mode == PYTC_RES_NONE || a->res_mode == PYTC_RES_ADD || a->res_mode == PYTC_RES_UPSAMPLE,
+               "pw_mlp: unsupported res_mode %d", a->res_mode);
   MlpParams p;
   p.t = (const bf16_t*)a->t; p.ab = a->ab; p.w2 = (const bf16x8_t*)a->w2_packed; p.b2 = a->b2;
   p.w3 = (const bf16x8_t*)a->w3_packed; p.b3 = a->b3;

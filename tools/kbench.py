@@ -87,6 +87,32 @@ def bench_mlp():
         knob("mlp_exact_gelu", 0)
 
 
+def bench_mlp_cold():
+    """Deep-level mixers with COLD weights/activations (a 1 GiB copy runs between launches), as inside the network."""
+    big = torch.empty(1 << 28, device=dev, dtype=torch.float32)
+    big2 = torch.empty_like(big)
+    for (N, D, cin, chid, cout) in ((8, 28, 128, 256, 128), (8, 14, 256, 512, 256), (8, 7, 512, 1024, 512)):
+        rows = D ** 3
+        t = torch.randn(N, rows, cin, device=dev).to(bf)
+        ab = torch.rand(N, 2, cin, device=dev)
+        w2 = ops.pw_pack_weight_paired(torch.randn(chid, cin, device=dev) / cin ** 0.5)
+        w3 = ops.pw_pack_weight_paired(torch.randn(cout, chid, device=dev) / chid ** 0.5)
+        b2, b3 = torch.randn(chid, device=dev), torch.randn(cout, device=dev)
+        res = torch.randn(N, rows, cout, device=dev).to(bf)
+        y = torch.empty(N, rows, cout, device=dev, dtype=bf)
+        kw = dict(N=N, rows_per_sample=rows, c_in=cin, c_hid=chid, c_out=cout, y=y)
+        fn = lambda: ops.pw_mlp(t, ab, w2, b2, w3, b3, res=res, res_mode=nat.RES_ADD, **kw)
+        hot = timeit(fn)
+        tot = 0.0
+        for _ in range(5):
+            big2.copy_(big)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); fn(); e.record()
+            torch.cuda.synchronize()
+            tot += s.elapsed_time(e) * 1e3
+        print(f"pw_mlp {cin}->{chid}->{cout} {D}^3: hot {hot:7.1f} us, cold {tot / 5:7.1f} us", flush=True)
+
+
 def bench_convT():
     N, D, C = 8, 56, 64
     x = torch.randn(N, D, D, D, C, device=dev).to(bf)
@@ -112,4 +138,4 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["copy", "dwconv", "mlp", "convT"]
     torch.manual_seed(0)
     for wname in which:
-        {"dwconv": bench_dwconv, "mlp": bench_mlp, "convT": bench_convT, "copy": bench_copy}[wname]()
+        {"dwconv": bench_dwconv, "mlp": bench_mlp, "mlp_cold": bench_mlp_cold, "convT": bench_convT, "copy": bench_copy}[wname]()
