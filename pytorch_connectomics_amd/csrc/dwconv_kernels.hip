@@ -12,6 +12,7 @@ struct DwGeom {
   int vs;         // voxel slots per pass = 256 / lpv
   int iters;      // passes per workgroup
   int slots;      // workgroups per sample
+  int cell;       // transposed K=3: work items are 2x2x2 output cells (one per input voxel)
 };
 
 template <int VEC>
@@ -92,6 +93,76 @@ dwconv3d_direct_kernel(const T* __restrict__ x, T* __restrict__ y, const float* 
       s2[i] = fmaf(r, r, s2[i]);
     }
   }
+  if (stats) block_stats_reduce<VEC>(s1, s2, cv, vslot, lane_ok, g, stats, n, slot, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K = 3 gather form without branches (stride 1 or 2; the down blocks and the volumes too small for the z-march):
+// every tap is loaded from a clamped address (a branch around a load makes hipcc wait for each one separately) and an
+// out-of-range tap gets a zero weight instead; the 27 x C taps are staged once per workgroup in LDS.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+dwconv3d_k3_gather_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ w,
+                          const float* __restrict__ bias, float* __restrict__ stats, DwGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // 27*C taps, later the statistics scratch
+  const int n = blockIdx.y, slot = blockIdx.x;
+  const int cv = threadIdx.x % g.lpv, vslot = threadIdx.x / g.lpv;
+  const bool lane_ok = vslot < g.vs;
+  const long vout = (long)g.Do * g.Ho * g.Wo;
+  const int C = g.C;
+  for (int i = threadIdx.x; i < 27 * C; i += 256) lds[i] = w[i];
+  __syncthreads();
+  float s1[VEC], s2[VEC], bv[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; bv[i] = bias ? bias[cv * VEC + i] : 0.f; }
+  const T* xn = x + (long)n * g.D * g.H * g.W * C + cv * VEC;
+  T* yn = y + (long)n * vout * C + cv * VEC;
+  const float* wl = lds + cv * VEC;
+  for (int it = 0; it < g.iters; ++it) {
+    const long v = ((long)slot * g.iters + it) * g.vs + vslot;
+    if (!lane_ok || v >= vout) continue;
+    const int ox = (int)(v % g.Wo);
+    const long t = v / g.Wo;
+    const int oy = (int)(t % g.Ho), oz = (int)(t / g.Ho);
+    int zi[3], yi[3], xi[3];
+    bool zv[3], yv[3], xv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int iz = oz * g.stride - 1 + k, iy = oy * g.stride - 1 + k, ix = ox * g.stride - 1 + k;
+      zv[k] = iz >= 0 && iz < g.D; yv[k] = iy >= 0 && iy < g.H; xv[k] = ix >= 0 && ix < g.W;
+      zi[k] = min(max(iz, 0), g.D - 1); yi[k] = min(max(iy, 0), g.H - 1); xi[k] = min(max(ix, 0), g.W - 1);
+    }
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = bv[i];
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+      float in[9][VEC];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+          VecIO<T, VEC>::load(xn + (((long)zi[kz] * g.H + yi[ky]) * g.W + xi[kx]) * C, in[ky * 3 + kx]);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const bool ok = zv[kz] & yv[ky] & xv[kx];
+          float wv[VEC];
+          VecIO<float, VEC>::load(wl + ((kz * 3 + ky) * 3 + kx) * C, wv);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(in[ky * 3 + kx][i], ok ? wv[i] : 0.f, acc[i]);
+        }
+    }
+    VecIO<T, VEC>::store(yn + v * C, acc);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float r = to_f32<T>(from_f32<T>(acc[i]));
+      s1[i] += r;
+      s2[i] = fmaf(r, r, s2[i]);
+    }
+  }
+  __syncthreads();
   if (stats) block_stats_reduce<VEC>(s1, s2, cv, vslot, lane_ok, g, stats, n, slot, lds);
 }
 
@@ -192,6 +263,85 @@ dwconvT3d_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __rest
   if (stats) block_stats_reduce<VEC>(s1, s2, cv, vslot, lane_ok, g, stats, n, slot, lds);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Depthwise transposed conv, K = 3, stride 2, pad 1, "cell" form.  The padded output grid (2D,2H,2W) splits into D*H*W
+// cells of 2x2x2 positions p = 2m + {0,1}; with o = p - 1 the even positions read inputs (m-1: tap 2, m: tap 0) and the
+// odd ones input m (tap 1), so a lane loads the 2x2x2 inputs m-1..m once (16 bytes each) and produces all 8 outputs:
+// no parity divergence, 8 loads per 8 stores, the 27 x C taps staged once per workgroup in LDS (the lanes of a
+// channel chunk read the same address: broadcast).  m-1 = -1 only feeds p = 0 positions, which are the zero faces.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+dwconvT3d_k3_cell_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ w,
+                         const float* __restrict__ bias, float* __restrict__ stats, DwGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // 27*C taps, later the statistics scratch
+  const int n = blockIdx.y, slot = blockIdx.x;
+  const int cv = threadIdx.x % g.lpv, vslot = threadIdx.x / g.lpv;
+  const bool lane_ok = vslot < g.vs;
+  const int C = g.C;
+  for (int i = threadIdx.x; i < 27 * C; i += 256) lds[i] = w[i];
+  __syncthreads();
+  float s1[VEC], s2[VEC], bv[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; bv[i] = bias ? bias[cv * VEC + i] : 0.f; }
+  const long vcells = (long)g.D * g.H * g.W;
+  const T* xn = x + (long)n * vcells * C + cv * VEC;
+  T* yn = y + (long)n * g.Do * g.Ho * g.Wo * C + cv * VEC;
+  const float* wl = lds + cv * VEC;
+  for (int it = 0; it < g.iters; ++it) {
+    const long c = ((long)slot * g.iters + it) * g.vs + vslot;
+    if (!lane_ok || c >= vcells) continue;
+    const int mx = (int)(c % g.W);
+    const long t = c / g.W;
+    const int my = (int)(t % g.H), mz = (int)(t / g.H);
+    float xin[2][2][2][VEC];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const int iz = max(mz - 1 + a, 0), iy = max(my - 1 + b, 0), ix = max(mx - 1 + d, 0);
+          VecIO<T, VEC>::load(xn + (((long)iz * g.H + iy) * g.W + ix) * C, xin[a][b][d]);
+        }
+#pragma unroll
+    for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+      for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          const int Pz = 2 * mz + pz, Py = 2 * my + py, Px = 2 * mx + px;
+          float acc[VEC];
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = bv[i];
+          // per axis: even position -> (input 0, tap 2), (input 1, tap 0); odd position -> (input 1, tap 1)
+#pragma unroll
+          for (int a = pz; a < 2; ++a)
+#pragma unroll
+            for (int b = py; b < 2; ++b)
+#pragma unroll
+              for (int d = px; d < 2; ++d) {
+                const int kz = pz ? 1 : (a ? 0 : 2), ky = py ? 1 : (b ? 0 : 2), kx = px ? 1 : (d ? 0 : 2);
+                float wv[VEC];
+                VecIO<float, VEC>::load(wl + ((kz * 3 + ky) * 3 + kx) * C, wv);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] = fmaf(xin[a][b][d][i], wv[i], acc[i]);
+              }
+          const bool face = (Pz == 0) | (Py == 0) | (Px == 0);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = face ? 0.f : acc[i];
+          VecIO<T, VEC>::store(yn + (((long)Pz * g.Ho + Py) * g.Wo + Px) * C, acc);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            const float r = to_f32<T>(from_f32<T>(acc[i]));     // faces contribute exact zeros
+            s1[i] += r;
+            s2[i] = fmaf(r, r, s2[i]);
+          }
+        }
+  }
+  __syncthreads();                                               // the taps are dead: the scratch may reuse their space
+  if (stats) block_stats_reduce<VEC>(s1, s2, cv, vslot, lane_ok, g, stats, n, slot, lds);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Fast path: K = 3, stride 1 -- "z-march".  One workgroup owns an 8 x 8 (y,x) footprint of a 32-channel
@@ -751,8 +901,9 @@ static bool make_geom(DwGeom& g, int N, int D, int H, int W, int C, int K, int s
   }
   g.lpv = C / vec;
   g.vs = 256 / g.lpv;
-  long vout = (long)g.Do * g.Ho * g.Wo;
-  long it = vout / ((long)g.vs * 96);   // aim for >= ~96 workgroups per sample
+  g.cell = (transposed && K == 3 && 27L * C * 4 <= 64 * 1024 && tuning_get("dwconvT_cell", 1) != 0) ? 1 : 0;
+  long vout = g.cell ? (long)D * H * W : (long)g.Do * g.Ho * g.Wo;
+  long it = vout / ((long)g.vs * (g.cell ? 256 : 96));   // aim for >= ~96 (cells: 256) workgroups per sample
   g.iters = (int)(it < 1 ? 1 : (it > 64 ? 64 : it));
   g.slots = (int)((vout + (long)g.vs * g.iters - 1) / ((long)g.vs * g.iters));
   return true;
@@ -763,6 +914,15 @@ static int launch_dw(bool transposed, const void* x, void* y, const float* w, co
                      const DwGeom& g, hipStream_t s) {
   dim3 grid(g.slots, g.N), block(256);
   size_t lds = stats ? (size_t)g.vs * 2 * g.C * sizeof(float) : 0;
+  const size_t taps = (size_t)27 * g.C * sizeof(float);
+  if (transposed && g.cell) {
+    hipLaunchKernelGGL((dwconvT3d_k3_cell_kernel<T, VEC>), grid, block, lds > taps ? lds : taps, s, (const T*)x, (T*)y, w, bias, stats, g);
+    return PYTC_OK;
+  }
+  if (!transposed && g.K == 3 && taps <= 64 * 1024 && tuning_get("dwconv_gather", 1) != 0) {
+    hipLaunchKernelGGL((dwconv3d_k3_gather_kernel<T, VEC>), grid, block, lds > taps ? lds : taps, s, (const T*)x, (T*)y, w, bias, stats, g);
+    return PYTC_OK;
+  }
 #define PYTC_DW_CASE(KK)                                                                                      \
   case KK:                                                                                                    \
     if (transposed)                                                                                           \

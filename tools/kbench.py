@@ -118,13 +118,29 @@ def bench_convT():
     x = torch.randn(N, D, D, D, C, device=dev).to(bf)
     taps = torch.randn(27, C, device=dev)
     b = torch.randn(C, device=dev)
-    us = timeit(lambda: ops.dwconv3d(x, taps, b, K=3, transposed=True))
     nbytes = x.numel() * 2 * 9
-    print(f"dwconvT3d N{N} {D}^3->{2 * D}^3 C{C}: {us:8.1f} us  {nbytes / us / 1e3:7.1f} GB/s", flush=True)
+    knob("dwconvT_cell", 0)
+    y0, s0 = ops.dwconv3d(x, taps, b, K=3, transposed=True)
+    us = timeit(lambda: ops.dwconv3d(x, taps, b, K=3, transposed=True))
+    print(f"dwconvT3d (per-output kernel) N{N} {D}^3->{2 * D}^3 C{C}: {us:8.1f} us  {nbytes / us / 1e3:7.1f} GB/s", flush=True)
+    knob("dwconvT_cell", 1)
+    y1, s1 = ops.dwconv3d(x, taps, b, K=3, transposed=True)
+    us = timeit(lambda: ops.dwconv3d(x, taps, b, K=3, transposed=True))
+    print(f"dwconvT3d (cell kernel)       N{N} {D}^3->{2 * D}^3 C{C}: {us:8.1f} us  {nbytes / us / 1e3:7.1f} GB/s  "
+          f"y bit-exact={bool(torch.equal(y0, y1))} stats close={bool(torch.allclose(s0.sum(1), s1.sum(1), rtol=1e-4))}", flush=True)
     x = torch.randn(N, 2 * D, 2 * D, 2 * D, 32, device=dev).to(bf)
     taps = torch.randn(27, 32, device=dev)
-    us = timeit(lambda: ops.dwconv3d(x, taps, b[:32].contiguous(), K=3, stride=2))
-    print(f"dwconv3d s2 N{N} {2 * D}^3->{D}^3 C32: {us:8.1f} us", flush=True)
+    for gk in (0, 1):
+        knob("dwconv_gather", gk)
+        us = timeit(lambda: ops.dwconv3d(x, taps, b[:32].contiguous(), K=3, stride=2))
+        print(f"dwconv3d s2 N{N} {2 * D}^3->{D}^3 C32 branchless={gk}: {us:8.1f} us", flush=True)
+    x = torch.randn(N, 14, 14, 14, 256, device=dev).to(bf)
+    taps = torch.randn(27, 256, device=dev)
+    b = torch.randn(256, device=dev)
+    for gk in (0, 1):
+        knob("dwconv_gather", gk)
+        us = timeit(lambda: ops.dwconv3d(x, taps, b, K=3))
+        print(f"dwconv3d N{N} 14^3 C256 branchless={gk}: {us:8.1f} us", flush=True)
 
 
 def bench_copy():
