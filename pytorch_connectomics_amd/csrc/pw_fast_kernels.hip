@@ -17,8 +17,9 @@ struct PwFastParams {
   const float* bias;
   const float* ab;
   EpiParams e;
-  long rps;
+  long rps, rps_in;       // output / input rows per sample (differ with gather)
   int C_in, C_out, pre_act;
+  int gather, Hi, Wi, Ho, Wo;   // gather == 2: output row (oz,oy,ox) reads input voxel (2oz,2oy,2ox)
 };
 
 template <int KS, int NT>
@@ -46,14 +47,20 @@ pw_fast_kernel(PwFastParams p) {
   for (int nt = 0; nt < NT; ++nt) orow[nt] = row0 + nt * 16 + r;
 
   bf16x8_t bact[KS][NT];
-  const bf16_t* xn = p.x + (long)n * p.rps * p.C_in;
+  const bf16_t* xn = p.x + (long)n * p.rps_in * p.C_in;
   {
     uint4 raw[KS][NT];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const long rr = orow[nt] < p.rps ? orow[nt] : p.rps - 1;
+        long rr = orow[nt] < p.rps ? orow[nt] : p.rps - 1;
+        if (p.gather == 2) {
+          const int ox = (int)(rr % p.Wo);
+          const long t = rr / p.Wo;
+          const int oy = (int)(t % p.Ho), oz = (int)(t / p.Ho);
+          rr = ((long)(2 * oz) * p.Hi + 2 * oy) * p.Wi + 2 * ox;
+        }
         raw[ks][nt] = *reinterpret_cast<const uint4*>(xn + rr * p.C_in + ks * 32 + kb * 8);
       }
     if (p.ab || p.pre_act == PYTC_ACT_GELU) {
@@ -152,7 +159,8 @@ static void launch_fast(const PwFastParams& p, int N, hipStream_t s) {
 
 bool pw_fast_supported(const pytc_pw_args* a) {
   if (a->in_dtype != PYTC_BF16 || a->out_dtype != PYTC_BF16 || a->w_dtype != PYTC_BF16) return false;
-  if (a->C_in % 32 || a->C_out % 32 || a->gather != 0 || a->act != PYTC_ACT_NONE) return false;
+  if (a->C_in % 32 || a->C_out % 32 || (a->gather != 0 && a->gather != 2) || a->act != PYTC_ACT_NONE) return false;
+  if (a->gather == 2 && a->res_mode == PYTC_RES_UPSAMPLE) return false;
   const int ks = a->C_in / 32;
   return ks == 1 || ks == 2 || ks == 4 || ks == 8 || ks == 16 || ks == 32;
 }
@@ -160,7 +168,12 @@ bool pw_fast_supported(const pytc_pw_args* a) {
 void pw_fast_launch(const pytc_pw_args* a, const EpiParams& e, hipStream_t s) {
   PwFastParams p;
   p.x = (const bf16_t*)a->x; p.w = (const bf16x8_t*)a->w_packed; p.bias = a->bias; p.ab = a->ab; p.e = e;
-  p.rps = a->rows_per_sample; p.C_in = a->C_in; p.C_out = a->C_out; p.pre_act = a->pre_act;
+  p.rps = a->rows_per_sample; p.rps_in = a->rows_per_sample; p.C_in = a->C_in; p.C_out = a->C_out; p.pre_act = a->pre_act;
+  p.gather = a->gather; p.Hi = p.Wi = p.Ho = p.Wo = 0;
+  if (a->gather == 2) {
+    p.Hi = a->Hi; p.Wi = a->Wi; p.Ho = (a->Hi - 1) / 2 + 1; p.Wo = (a->Wi - 1) / 2 + 1;
+    p.rps_in = (long)a->Di * a->Hi * a->Wi;
+  }
   const int nt_knob = tuning_get("pw_fast_nt", 0);
   switch (a->C_in / 32) {
     case 1: if (nt_knob == 2) launch_fast<1, 2>(p, a->N, s); else launch_fast<1, 4>(p, a->N, s); break;

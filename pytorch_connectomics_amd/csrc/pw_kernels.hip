@@ -119,6 +119,60 @@ pw_conv_kernel(PwParams p) {
   }
 }
 
+// ---- thin pointwise convs: C_in == 1 (stem) and C_out == 1 (one-channel heads) -------------------------------------
+// No GEMM here, just a streaming kernel at 16 bytes per lane on the wide side; weights come from the packed MFMA image
+// (element (o,k) = tile o/16, k-group k/KSTEP, lane (o%16) + 16*((k%KSTEP)/EPL), slot k%EPL), so callers pack as usual
+// and the values are the same rounded weights the MFMA path would use.
+template <typename TW>
+__device__ __forceinline__ float packed_weight(const TW* wp, int KG, int o, int k) {
+  typedef Mma<TW> M;
+  const int kg = k / M::KSTEP, kr = k % M::KSTEP;
+  return to_f32<TW>(wp[(((long)(o / 16) * KG + kg) * 64 + (o % 16) + 16 * (kr / M::EPL)) * M::EPL + kr % M::EPL]);
+}
+
+// y[r][o] = act(w[o] * T(x[r]) + b[o]);  lane = (row, chunk of 8 output channels)
+template <typename TI, typename TW, typename TO>
+__global__ void __launch_bounds__(256)
+pw_stem_kernel(const TI* __restrict__ x, const TW* __restrict__ wp, const float* __restrict__ bias, TO* __restrict__ y,
+               long rows_total, int C_out, int act) {
+  const int chunks = C_out / 8;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long r = i / chunks;
+  const int o0 = (int)(i % chunks) * 8;
+  if (r >= rows_total) return;
+  // the MFMA path rounds the activation to the weight type before multiplying
+  const float xv = to_f32<TW>(from_f32<TW>(to_f32<TI>(x[r])));
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = apply_act(fmaf(packed_weight<TW>(wp, 1, o0 + j, 0), xv, bias ? bias[o0 + j] : 0.f), act);
+  if constexpr (sizeof(TO) == 2) VecIO<TO, 8>::store(y + r * C_out + o0, v);
+  else {
+    VecIO<float, 4>::store(reinterpret_cast<float*>(y) + r * C_out + o0, reinterpret_cast<float(&)[4]>(v[0]));
+    VecIO<float, 4>::store(reinterpret_cast<float*>(y) + r * C_out + o0 + 4, reinterpret_cast<float(&)[4]>(v[4]));
+  }
+}
+
+// y[r] = act(sum_k w[k] * x[r][k] + b);  lane = (row, chunk of 8 input channels), xor-shuffle sum over the chunks
+template <typename TW, typename TO>
+__global__ void __launch_bounds__(256)
+pw_head_kernel(const bf16_t* __restrict__ x, const TW* __restrict__ wp, const float* __restrict__ bias,
+               TO* __restrict__ y, long rows_total, int C_in, int act) {
+  const int chunks = C_in / 8;                      // power of two <= 64 (checked by the host)
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long r = i / chunks;
+  const int k0 = (int)(i % chunks) * 8;
+  const int KG = (C_in + Mma<TW>::KSTEP - 1) / Mma<TW>::KSTEP;
+  float s = 0.f;
+  if (r < rows_total) {
+    float v[8];
+    VecIO<bf16_t, 8>::load(x + r * C_in + k0, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s = fmaf(packed_weight<TW>(wp, KG, 0, k0 + j), v[j], s);
+  }
+  for (int off = 1; off < chunks; off <<= 1) s += __shfl_xor(s, off, 64);
+  if (r < rows_total && k0 == 0) y[r] = from_f32<TO>(apply_act(s + (bias ? bias[0] : 0.f), act));
+}
+
 template <typename TW>
 __global__ void __launch_bounds__(256)
 pw_pack_kernel(const float* __restrict__ w, int C_out, int C_in, int transposed, TW* __restrict__ packed,
@@ -220,13 +274,30 @@ extern "C" int pytc_pw_conv_fwd(const pytc_pw_args* a, void* stream) {
   }
   int MT = p.MTt >= 4 ? 4 : (p.MTt >= 2 ? 2 : 1);
   hipStream_t s = (hipStream_t)stream;
+  const int ti = a->in_dtype, tw = a->w_dtype, to = a->out_dtype;
+  const bool plain = !a->ab && a->pre_act == PYTC_ACT_NONE && a->res_mode == PYTC_RES_NONE && a->gather == 0 && !a->w_paired &&
+                     tuning_get("pw_thin", 1) != 0;
+  const long rows_total = (long)a->N * a->rows_per_sample;
+  if (plain && a->C_in == 1 && a->C_out % 8 == 0 && tw == PYTC_BF16 && (ti == PYTC_F32 || ti == PYTC_BF16) && to == PYTC_BF16) {
+    const long work = rows_total * (a->C_out / 8);
+    if (ti == PYTC_F32) hipLaunchKernelGGL((pw_stem_kernel<float, bf16_t, bf16_t>), dim3(ceil_div(work, 256)), dim3(256), 0, s, (const float*)a->x, (const bf16_t*)a->w_packed, a->bias, (bf16_t*)a->y, rows_total, a->C_out, a->act);
+    else hipLaunchKernelGGL((pw_stem_kernel<bf16_t, bf16_t, bf16_t>), dim3(ceil_div(work, 256)), dim3(256), 0, s, (const bf16_t*)a->x, (const bf16_t*)a->w_packed, a->bias, (bf16_t*)a->y, rows_total, a->C_out, a->act);
+    PYTC_LAUNCH_CHECK("pw_conv");
+    return PYTC_OK;
+  }
+  if (plain && a->C_out == 1 && ti == PYTC_BF16 && tw == PYTC_BF16 && a->C_in >= 8 && a->C_in <= 512 && (a->C_in & (a->C_in - 1)) == 0) {
+    const long work = rows_total * (a->C_in / 8);
+    if (to == PYTC_F32) hipLaunchKernelGGL((pw_head_kernel<bf16_t, float>), dim3(ceil_div(work, 256)), dim3(256), 0, s, (const bf16_t*)a->x, (const bf16_t*)a->w_packed, a->bias, (float*)a->y, rows_total, a->C_in, a->act);
+    else hipLaunchKernelGGL((pw_head_kernel<bf16_t, bf16_t>), dim3(ceil_div(work, 256)), dim3(256), 0, s, (const bf16_t*)a->x, (const bf16_t*)a->w_packed, a->bias, (bf16_t*)a->y, rows_total, a->C_in, a->act);
+    PYTC_LAUNCH_CHECK("pw_conv");
+    return PYTC_OK;
+  }
   if (a->w_paired) {
     PYTC_REQUIRE(pw_fast_supported(a), "pw_conv: w_paired set for a shape the paired-row kernel does not cover");
     pw_fast_launch(a, p.e, s);
     PYTC_LAUNCH_CHECK("pw_conv");
     return PYTC_OK;
   }
-  const int ti = a->in_dtype, tw = a->w_dtype, to = a->out_dtype;
   if (ti == PYTC_F32 && tw == PYTC_F32 && to == PYTC_F32) launch_pw<float, float, float, 4>(p, MT, s);
   else if (ti == PYTC_BF16 && tw == PYTC_BF16 && to == PYTC_BF16) launch_pw<bf16_t, bf16_t, bf16_t, 4>(p, MT, s);
   else if (ti == PYTC_BF16 && tw == PYTC_BF16 && to == PYTC_F32) launch_pw<bf16_t, bf16_t, float, 4>(p, MT, s);

@@ -262,8 +262,10 @@ def _block_fused(self, m, x, t, ab, skip, ishape, oshape, c_hid, c_out):
     elif m.kind == "down":
         res = None
         if m.resample_do_res:
-            res = ops.pw_conv(x, self._pw(m.res_conv, dt), self._vec(m.res_conv, "bias", m.res_conv.bias), N=N,
-                              rows_per_sample=rows, c_in=C, c_out=c_out, out_dtype=dt, gather=2, grid=(D, H, W))
+            paired = ops.pw_conv_paired_supported(c_in=C, c_out=c_out, in_dtype=dt, out_dtype=dt, gather=2)
+            wres = self._pw_paired(m.res_conv) if paired else self._pw(m.res_conv, dt)
+            res = ops.pw_conv(x, wres, self._vec(m.res_conv, "bias", m.res_conv.bias), N=N, rows_per_sample=rows,
+                              c_in=C, c_out=c_out, out_dtype=dt, gather=2, grid=(D, H, W), w_paired=paired)
         y = ops.pw_mlp(t, ab, w2, b2, w3, b3, res=res, res_mode=nat.RES_ADD if res is not None else nat.RES_NONE, **kw)
     else:
         if skip is None:

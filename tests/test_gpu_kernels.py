@@ -262,3 +262,47 @@ def test_pw_conv_paired_row_kernel_matches_generic(ci, co, mode):
     assert not ops.pw_conv_paired_supported(c_in=24, c_out=64, in_dtype=torch.bfloat16, out_dtype=torch.bfloat16)
     assert not ops.pw_conv_paired_supported(c_in=32, c_out=64, in_dtype=torch.float32, out_dtype=torch.float32,
                                             w_dtype=torch.float32)
+
+
+def test_pw_conv_paired_row_kernel_strided_gather():
+    """Down-block residual conv (1x1, stride 2): paired-row kernel with the gather against the generic kernel."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(11)
+    N, grid, ci, co = 2, (6, 9, 10), 32, 64
+    og = tuple((g - 1) // 2 + 1 for g in grid)
+    rows = og[0] * og[1] * og[2]
+    x = torch.randn(N, grid[0] * grid[1] * grid[2], ci).bfloat16().cuda()
+    w, b = (torch.randn(co, ci) / ci ** 0.5).cuda(), torch.randn(co).cuda()
+    kw = dict(N=N, rows_per_sample=rows, c_in=ci, c_out=co, out_dtype=torch.bfloat16, gather=2, grid=grid)
+    assert ops.pw_conv_paired_supported(c_in=ci, c_out=co, in_dtype=torch.bfloat16, out_dtype=torch.bfloat16, gather=2)
+    y0 = ops.pw_conv(x, ops.pw_pack_weight(w, torch.bfloat16), b, **kw)
+    y1 = ops.pw_conv(x, ops.pw_pack_weight_paired(w), b, w_paired=True, **kw)
+    ref = x.float().view(N, *grid, ci)[:, ::2, ::2, ::2].reshape(N, rows, ci) @ w.bfloat16().float().t() + b
+    torch.testing.assert_close(y1.float(), ref.bfloat16().float(), rtol=2e-2, atol=2e-2)
+    assert float((y0.float() - y1.float()).abs().max()) <= 2 ** -6 * max(1.0, float(y0.float().abs().max()))
+
+
+@pytest.mark.parametrize("kind,in_dt,out_dt", [("stem", torch.float32, torch.bfloat16), ("stem", torch.bfloat16, torch.bfloat16),
+                                               ("head", torch.bfloat16, torch.float32), ("head", torch.bfloat16, torch.bfloat16)])
+def test_pw_conv_thin_kernels(kind, in_dt, out_dt):
+    """C_in == 1 (stem) / C_out == 1 (head) streaming kernels against the MFMA kernel they bypass (`pw_thin` knob)."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(5)
+    N, rows = 2, 4099
+    ci, co = (1, 32) if kind == "stem" else (32, 1)
+    x = torch.randn(N, rows, ci).to(in_dt).cuda()
+    w, b = torch.randn(co, ci).cuda(), torch.randn(co).cuda()
+    wp = ops.pw_pack_weight(w, torch.bfloat16)
+    kw = dict(N=N, rows_per_sample=rows, c_in=ci, c_out=co, out_dtype=out_dt)
+    y1 = ops.pw_conv(x, wp, b, **kw)
+    ops.set_tuning("pw_thin", 0)
+    try:
+        y0 = ops.pw_conv(x, wp, b, **kw)
+    finally:
+        ops.set_tuning("pw_thin", 1)
+    if kind == "stem":
+        assert torch.equal(y0, y1)
+    else:
+        torch.testing.assert_close(y1.float(), y0.float(), rtol=1e-2 if out_dt == torch.bfloat16 else 1e-5, atol=1e-2 if out_dt == torch.bfloat16 else 1e-5)
+    ref = x.float().bfloat16().float() @ w.bfloat16().float().t() + b
+    torch.testing.assert_close(y1.float(), ref if out_dt == torch.float32 else ref.bfloat16().float(), rtol=2e-2, atol=2e-2)
