@@ -130,25 +130,31 @@ __device__ __forceinline__ float packed_weight(const TW* wp, int KG, int o, int 
   return to_f32<TW>(wp[(((long)(o / 16) * KG + kg) * 64 + (o % 16) + 16 * (kr / M::EPL)) * M::EPL + kr % M::EPL]);
 }
 
-// y[r][o] = act(w[o] * T(x[r]) + b[o]);  lane = (row, chunk of 8 output channels)
+// y[r][o] = act(w[o] * T(x[r]) + b[o]);  lane = (row, chunk of 8 output channels); grid-stride over rows with the lane's
+// 8 weights and biases in registers (256 % chunks == 0 keeps a lane on its chunk)
 template <typename TI, typename TW, typename TO>
 __global__ void __launch_bounds__(256)
 pw_stem_kernel(const TI* __restrict__ x, const TW* __restrict__ wp, const float* __restrict__ bias, TO* __restrict__ y,
                long rows_total, int C_out, int act) {
   const int chunks = C_out / 8;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const long r = i / chunks;
-  const int o0 = (int)(i % chunks) * 8;
-  if (r >= rows_total) return;
-  // the MFMA path rounds the activation to the weight type before multiplying
-  const float xv = to_f32<TW>(from_f32<TW>(to_f32<TI>(x[r])));
-  float v[8];
+  const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+  const int o0 = (int)(tid % chunks) * 8;
+  const long rstride = (long)gridDim.x * 256 / chunks;
+  float wv[8], bv[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = apply_act(fmaf(packed_weight<TW>(wp, 1, o0 + j, 0), xv, bias ? bias[o0 + j] : 0.f), act);
-  if constexpr (sizeof(TO) == 2) VecIO<TO, 8>::store(y + r * C_out + o0, v);
-  else {
-    VecIO<float, 4>::store(reinterpret_cast<float*>(y) + r * C_out + o0, reinterpret_cast<float(&)[4]>(v[0]));
-    VecIO<float, 4>::store(reinterpret_cast<float*>(y) + r * C_out + o0 + 4, reinterpret_cast<float(&)[4]>(v[4]));
+  for (int j = 0; j < 8; ++j) { wv[j] = packed_weight<TW>(wp, 1, o0 + j, 0); bv[j] = bias ? bias[o0 + j] : 0.f; }
+#pragma unroll 4
+  for (long r = tid / chunks; r < rows_total; r += rstride) {
+    // the MFMA path rounds the activation to the weight type before multiplying
+    const float xv = to_f32<TW>(from_f32<TW>(to_f32<TI>(x[r])));
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = apply_act(fmaf(wv[j], xv, bv[j]), act);
+    if constexpr (sizeof(TO) == 2) VecIO<TO, 8>::store(y + r * C_out + o0, v);
+    else {
+      VecIO<float, 4>::store(reinterpret_cast<float*>(y) + r * C_out + o0, reinterpret_cast<float(&)[4]>(v[0]));
+      VecIO<float, 4>::store(reinterpret_cast<float*>(y) + r * C_out + o0 + 4, reinterpret_cast<float(&)[4]>(v[4]));
+    }
   }
 }
 
@@ -278,10 +284,11 @@ extern "C" int pytc_pw_conv_fwd(const pytc_pw_args* a, void* stream) {
   const bool plain = !a->ab && a->pre_act == PYTC_ACT_NONE && a->res_mode == PYTC_RES_NONE && a->gather == 0 && !a->w_paired &&
                      tuning_get("pw_thin", 1) != 0;
   const long rows_total = (long)a->N * a->rows_per_sample;
-  if (plain && a->C_in == 1 && a->C_out % 8 == 0 && tw == PYTC_BF16 && (ti == PYTC_F32 || ti == PYTC_BF16) && to == PYTC_BF16) {
+  if (plain && a->C_in == 1 && a->C_out % 8 == 0 && 256 % (a->C_out / 8) == 0 && tw == PYTC_BF16 && (ti == PYTC_F32 || ti == PYTC_BF16) && to == PYTC_BF16) {
     const long work = rows_total * (a->C_out / 8);
-    if (ti == PYTC_F32) hipLaunchKernelGGL((pw_stem_kernel<float, bf16_t, bf16_t>), dim3(ceil_div(work, 256)), dim3(256), 0, s, (const float*)a->x, (const bf16_t*)a->w_packed, a->bias, (bf16_t*)a->y, rows_total, a->C_out, a->act);
-    else hipLaunchKernelGGL((pw_stem_kernel<bf16_t, bf16_t, bf16_t>), dim3(ceil_div(work, 256)), dim3(256), 0, s, (const bf16_t*)a->x, (const bf16_t*)a->w_packed, a->bias, (bf16_t*)a->y, rows_total, a->C_out, a->act);
+    const int blocks = (int)(ceil_div(work, 256) < 8192 ? ceil_div(work, 256) : 8192);
+    if (ti == PYTC_F32) hipLaunchKernelGGL((pw_stem_kernel<float, bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, s, (const float*)a->x, (const bf16_t*)a->w_packed, a->bias, (bf16_t*)a->y, rows_total, a->C_out, a->act);
+    else hipLaunchKernelGGL((pw_stem_kernel<bf16_t, bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)a->x, (const bf16_t*)a->w_packed, a->bias, (bf16_t*)a->y, rows_total, a->C_out, a->act);
     PYTC_LAUNCH_CHECK("pw_conv");
     return PYTC_OK;
   }

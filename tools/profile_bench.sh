@@ -5,7 +5,7 @@ set -u
 OUT=$PWD/gpurun_out/prof_bench
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline"
+CMD="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-train"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- $CMD > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- $CMD > $OUT/pmc_write.log 2>&1
