@@ -112,6 +112,19 @@ int pytc_channel_activation(float* value, int C, int64_t nvox, int channels_last
  * mode 0 mean: acc += (x - acc) / count ; mode 1 min ; mode 2 max.  n elements fp32. */
 int pytc_ensemble_update(float* acc, const float* x, int64_t n, int mode, int count, void* stream);
 
+/* Prediction / storage dtype transform on device (inference/output.py:150-243: _apply_intensity_transform,
+ * _convert_intensity_dtype): y = cast(clip(x * scale)) with numpy semantics -- integer targets clip to the type's range
+ * first and truncate toward zero in the cast; float targets only round.  scale <= 0 or == 1 leaves values unscaled
+ * (the reference treats a negative scale as "disabled").  x: fp32 [n]; y: n elements of the target type. */
+#define PYTC_ST_U8 0
+#define PYTC_ST_I8 1
+#define PYTC_ST_U16 2
+#define PYTC_ST_I16 3
+#define PYTC_ST_I32 4
+#define PYTC_ST_F16 5
+#define PYTC_ST_F32 6
+int pytc_scale_cast(const float* x, void* y, int64_t n, float scale, int target, void* stream);
+
 /* ---------------------------------------------------------------- depthwise conv ---------- */
 
 /* number of per-sample partial-statistics slots pytc_dwconv3d_fwd / pytc_dwconvT3d_fwd write for

@@ -79,6 +79,8 @@ def schema_defaults() -> dict:
                                        "rotation90_axes": None, "rotate90_k": None, "patch_first_local": True,
                                        "apply_mask": True, "ensemble_mode": "mean", "empty_cache_interval": 4},
             "save": {"enabled": True, "format": "h5"},
+            "prediction_transform": {"enabled": False, "intensity_scale": -1.0, "intensity_dtype": None},
+            "save_dtype": None,
         },
         "evaluation": {"enabled": False, "metrics": []},
     }

@@ -363,8 +363,8 @@ struct DwMarch {
   int swizzle;           // XCD-aware block remap on/off
 };
 
-template <typename T, int VEC, int PF, bool ASYNC>
-__global__ void __launch_bounds__(256, 2)
+template <typename T, int VEC, int PF, bool ASYNC, int WPS = 2>
+__global__ void __launch_bounds__(256, WPS)
 dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ w,
                          const float* __restrict__ bias, float* __restrict__ stats, DwMarch g) {
   // VEC channels per lane (4: ds_read_b128, 108 weight registers; 2: ds_read_b64, 54 weight registers ->
@@ -499,6 +499,9 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
     // the inner loop free of per-FMA selects.
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
+      // WPS >= 3: keep the LDS reads of one position from being hoisted over the previous position's FMAs (the
+      // register budget of 3 waves/SIMD has no room for all 36 reads of a step in flight)
+      if constexpr (WPS >= 3) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
@@ -974,6 +977,8 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
     if (dtype == PYTC_BF16) {
       if (variant == 7) hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, 2, true>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t);
       else if (variant == 9) hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, 3, true>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t);
+      else if (variant == 11) hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, 3, true, 3>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t);
+      else if (variant == 13) hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, 2, true, 3>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t);
       else if (variant == 5) PYTC_MARCH(bf16_t, 2, 3);
       else switch (variant & 3) {
         case 0: PYTC_MARCH(bf16_t, 4, 1); break;

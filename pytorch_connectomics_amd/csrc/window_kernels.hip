@@ -266,6 +266,52 @@ extern "C" int pytc_blend_finalize(float* value, const float* weight, int C, int
   return PYTC_OK;
 }
 
+namespace pytc {
+template <typename TO, bool INTEGER>
+__global__ void __launch_bounds__(256)
+scale_cast_kernel(const float* __restrict__ x, TO* __restrict__ y, long n, float scale, float lo, float hi) {
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (; i < n; i += stride) {
+    float v[4];
+    if (i + 4 <= n) {
+      const f32x4_t t = *reinterpret_cast<const f32x4_t*>(x + i);
+      v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = i + j < n ? x[i + j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float u = __fmul_rn(v[j], scale);
+      if (INTEGER) u = fminf(fmaxf(u, lo), hi);       // np.clip, then astype truncates toward zero
+      if (i + j < n) y[i + j] = (TO)u;
+    }
+  }
+}
+}  // namespace pytc
+
+extern "C" int pytc_scale_cast(const float* x, void* y, int64_t n, float scale, int target, void* stream) {
+  PYTC_REQUIRE(x && y && n > 0, "scale_cast: bad arguments");
+  const float sc = scale > 0.f ? scale : 1.f;
+  const int blocks = (int)((n / 4 + 255) / 256 < 8192 ? (n / 4 + 255) / 256 + 1 : 8192);
+  hipStream_t s = (hipStream_t)stream;
+#define PYTC_SC(TT, INTG, LO, HI) hipLaunchKernelGGL((pytc::scale_cast_kernel<TT, INTG>), dim3(blocks), dim3(256), 0, s, x, (TT*)y, (long)n, sc, LO, HI)
+  switch (target) {
+    case PYTC_ST_U8: PYTC_SC(unsigned char, true, 0.f, 255.f); break;
+    case PYTC_ST_I8: PYTC_SC(signed char, true, -128.f, 127.f); break;
+    case PYTC_ST_U16: PYTC_SC(unsigned short, true, 0.f, 65535.f); break;
+    case PYTC_ST_I16: PYTC_SC(short, true, -32768.f, 32767.f); break;
+    case PYTC_ST_I32: PYTC_SC(int, true, -2147483648.f, 2147483520.f); break;   // largest fp32 below 2^31
+    case PYTC_ST_F16: PYTC_SC(_Float16, false, 0.f, 0.f); break;
+    case PYTC_ST_F32: PYTC_SC(float, false, 0.f, 0.f); break;
+    default: set_error("scale_cast: unknown target %d", target); return PYTC_ERR_INVALID;
+  }
+#undef PYTC_SC
+  PYTC_LAUNCH_CHECK("scale_cast");
+  return PYTC_OK;
+}
+
 extern "C" int pytc_ensemble_update(float* acc, const float* x, int64_t n, int mode, int count, void* stream) {
   PYTC_REQUIRE(acc && x && n > 0 && mode >= 0 && mode <= 2 && count >= 1, "ensemble_update: bad arguments");
   int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);

@@ -411,6 +411,23 @@ def add_(y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+_ST_CODES = {"uint8": (0, torch.uint8), "int8": (1, torch.int8), "uint16": (2, torch.uint16), "int16": (3, torch.int16),
+             "int32": (4, torch.int32), "float16": (5, torch.float16), "float32": (6, torch.float32)}
+
+
+def scale_cast(x: torch.Tensor, *, scale: float = 1.0, target: str = "float32") -> torch.Tensor:
+    """cast(clip(x * scale)) with numpy's clip-then-truncate semantics (see pytc_scale_cast); x fp32, any shape."""
+    _dev(x, "x")
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("scale_cast expects a contiguous float32 tensor")
+    if target not in _ST_CODES:
+        raise ValueError(f"scale_cast: unsupported target dtype {target!r}; supported: {sorted(_ST_CODES)}")
+    code, tdt = _ST_CODES[target]
+    y = torch.empty(x.shape, dtype=tdt, device=x.device)
+    _run("scale_cast", _nbytes(x, y), nat.lib().pytc_scale_cast, _p(x), _p(y), x.numel(), float(scale), code, _stream())
+    return y
+
+
 def set_tuning(key: str, value: int) -> None:
     """Kernel-variant knob (A/B measurements and parity tests between variants); see pytc_set_tuning."""
     nat.check(nat.lib().pytc_set_tuning(key.encode(), int(value)), "set_tuning")

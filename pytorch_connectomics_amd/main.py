@@ -127,8 +127,21 @@ def run_test(cfg, args) -> dict:
                 x = x.unsqueeze(0)
             mgr = InferenceManager(cfg=cfg, model=model, forward_fn=model.forward)
             pred_t = mgr.predict_with_tta(x)
+            # semantic transform -> storage dtype on the device, then one D2H copy of the (smaller) result
+            from .inference.artifact import build_prediction_artifact_metadata, write_prediction_artifact
+            from .inference.output import apply_prediction_transform, apply_storage_dtype_transform
+            pred_t = apply_prediction_transform(cfg, pred_t)
+            stored = apply_storage_dtype_transform(cfg, pred_t)
             torch.cuda.synchronize()
-            np.save(out_dir / f"{name}_prediction.npy", pred_t[0].float().cpu().numpy())
+            arr = stored[0].cpu().numpy() if isinstance(stored, torch.Tensor) else np.asarray(stored)[0]
+            np.save(out_dir / f"{name}_prediction.npy", arr)
+            tc = getattr(cfg.inference, "prediction_transform", None)
+            md = build_prediction_artifact_metadata(
+                cfg, image_path=image_spec, checkpoint_path=args.checkpoint, input_shape=vol.shape[-3:],
+                final_shape=arr.shape[-3:], intensity_scale=getattr(tc, "intensity_scale", None) if tc else None,
+                intensity_dtype=str(arr.dtype))
+            write_prediction_artifact(out_dir / f"{name}_prediction.h5", arr, metadata=md)
+            pred_t = pred_t if isinstance(pred_t, torch.Tensor) else torch.from_numpy(np.asarray(pred_t))
     dt = time.perf_counter() - t0
     metrics = {"seconds": dt, "output_voxels_per_s": float(np.prod(vol.shape[-3:])) / dt}
     label_spec = cfg.data.test.label

@@ -52,3 +52,21 @@ def test_cli_test_mode_end_to_end(tmp_path):
     m = ref_model.cuda().eval()
     direct = InferenceManager(cfg=cfg, model=m, forward_fn=m.forward).predict_with_tta(torch.from_numpy(img).cuda())
     np.testing.assert_allclose(direct[0].cpu().numpy(), pred, atol=1e-6)
+
+
+def test_cli_writes_uint8_artifact_with_metadata(tmp_path):
+    """prediction_transform (x255 -> uint8 on the device) + the CZYX artifact with its attribute vocabulary."""
+    from pytorch_connectomics_amd.inference.artifact import read_prediction_artifact
+    from pytorch_connectomics_amd.main import main
+    rng = np.random.default_rng(1)
+    np.save(tmp_path / "img.npy", rng.random((34, 36, 40), dtype=np.float32))
+    cfg_path = tmp_path / "cfg.yaml"
+    cfg_path.write_text(YAML.format(save=tmp_path / "out", img=tmp_path / "img.npy", lab="").replace(
+        "    test_time_augmentation:", "    prediction_transform: {enabled: true, intensity_scale: 255.0, intensity_dtype: uint8}\n"
+        "    test_time_augmentation:").replace(', label: ""', ""))
+    main(["--config", str(cfg_path), "--mode", "test"])
+    arr, attrs = read_prediction_artifact(tmp_path / "out" / "results" / "img_prediction.h5", return_metadata=True)
+    assert arr.dtype == np.uint8 and arr.shape == (1, 34, 36, 40) and arr.max() > 0
+    assert attrs["layout"] == "CZYX" and attrs["intensity_dtype"] == "uint8" and attrs["intensity_scale"] == 255.0
+    assert json.loads(attrs["final_shape"]) == [34, 36, 40] and attrs["model_architecture"] == "mednext_custom"
+    assert np.array_equal(np.load(tmp_path / "out" / "results" / "img_prediction.npy"), arr)

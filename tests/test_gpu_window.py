@@ -154,3 +154,20 @@ def test_gather_outer_padding_follows_numpy_pad_of_the_inner_crop(dev, mode, np_
             m = "edge"
         ref = np.pad(inner, pads, mode=m, **kw)
         np.testing.assert_array_equal(got[i], np.moveaxis(ref, 0, -1), err_msg=f"window {w}")
+
+
+@pytest.mark.parametrize("target,scale", [("uint8", 255.0), ("int8", 100.0), ("uint16", 65535.0), ("int16", 3e4),
+                                          ("int32", 1e6), ("float16", 1.0), ("float32", 2.5), ("uint8", -1.0)])
+def test_scale_cast_matches_numpy(target, scale):
+    """Device prediction / storage transform = the reference's numpy ops (scale in fp32, clip, truncating cast)."""
+    from types import SimpleNamespace as NS
+    from pytorch_connectomics_amd.inference.output import apply_prediction_transform, apply_storage_dtype_transform
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(1, 2, 9, 10, 11, generator=g) * 1.6 - 0.3)
+    cfg = NS(inference=NS(prediction_transform=NS(enabled=True, intensity_scale=scale, intensity_dtype=target), save_dtype=None))
+    got = apply_prediction_transform(cfg, x.cuda())
+    want = apply_prediction_transform(cfg, x.numpy().copy())
+    assert str(got.dtype).replace("torch.", "") == str(want.dtype)
+    assert np.array_equal(got.cpu().numpy(), want)
+    st = apply_storage_dtype_transform(NS(inference=NS(save_dtype="float16")), x.cuda())
+    assert np.array_equal(st.cpu().numpy(), x.numpy().astype(np.float16))

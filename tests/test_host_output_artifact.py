@@ -1,0 +1,63 @@
+"""Host logic of the prediction transforms and the artifact writer (reference semantics: inference/output.py:150-243,
+inference/artifact.py:15-240); expectations restate the reference's numpy operations."""
+import json
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+
+from pytorch_connectomics_amd.inference.artifact import (PredictionArtifactMetadata, artifact_attrs,
+                                                         build_prediction_artifact_metadata, read_prediction_artifact,
+                                                         write_prediction_artifact)
+from pytorch_connectomics_amd.inference.output import apply_prediction_transform, apply_storage_dtype_transform
+
+
+def _cfg(**inf):
+    return NS(inference=NS(**inf))
+
+
+def test_prediction_transform_numpy_semantics():
+    rng = np.random.default_rng(0)
+    data = rng.uniform(-0.2, 1.3, size=(2, 5, 6, 7)).astype(np.float32)
+    assert apply_prediction_transform(NS(), data) is data
+    assert apply_prediction_transform(_cfg(), data) is data
+    assert apply_prediction_transform(_cfg(prediction_transform=NS(enabled=False)), data) is data
+    out = apply_prediction_transform(_cfg(prediction_transform=NS(enabled=True, intensity_scale=255.0, intensity_dtype="uint8")), data)
+    want = np.clip(data.astype(np.float32) * 255.0, 0, 255).astype(np.uint8)
+    assert out.dtype == np.uint8 and np.array_equal(out, want)
+    # negative scale = disabled scaling, dtype still applied; unknown dtype keeps the data
+    out = apply_prediction_transform(_cfg(prediction_transform=NS(enabled=True, intensity_scale=-1.0, intensity_dtype="int8")), data)
+    assert np.array_equal(out, np.clip(data, -128, 127).astype(np.int8))
+    out = apply_prediction_transform(_cfg(prediction_transform=NS(enabled=True, intensity_scale=2.0, intensity_dtype="float8")), data)
+    assert out.dtype == np.float32 and np.allclose(out, data * 2.0)
+    assert apply_storage_dtype_transform(_cfg(save_dtype=None), data) is data
+    st = apply_storage_dtype_transform(_cfg(save_dtype="float16"), data)
+    assert st.dtype == np.float16 and np.array_equal(st, data.astype(np.float16))
+
+
+def test_artifact_roundtrip_and_attrs(tmp_path):
+    data = (np.arange(2 * 3 * 4 * 5) % 251).astype(np.uint8).reshape(2, 3, 4, 5)
+    cfg = NS(model=NS(arch=NS(type="mednext")), decoding=NS(enabled=False),
+             data=NS(data_transform=NS(val_transpose=[2, 1, 0])))
+    md = build_prediction_artifact_metadata(cfg, image_path="vol.h5", checkpoint_path="last.ckpt", output_head="aff",
+                                            input_shape=(3, 4, 5), final_shape=(3, 4, 5), crop_pad=[(1, 1), (0, 0), (2, 2)],
+                                            chunk_shape=(2, 2, 2), halo=(1, 1, 1), intensity_scale=255.0,
+                                            intensity_dtype="uint8", extra={"note": "x", "views": [0, 1]})
+    attrs = artifact_attrs(md)
+    assert attrs["kind"] == "raw_prediction" and attrs["layout"] == "CZYX" and attrs["model_architecture"] == "mednext"
+    assert attrs["final_shape"] == json.dumps([3, 4, 5]) and attrs["crop_pad"] == json.dumps([[1, 1], [0, 0], [2, 2]])
+    assert attrs["decode_after_inference"] is False and attrs["transpose"] == json.dumps([2, 1, 0])
+    assert attrs["note"] == "x" and attrs["views"] == json.dumps([0, 1]) and "activation" not in attrs
+    p = write_prediction_artifact(tmp_path / "out" / "pred.h5", data, metadata=md)
+    arr, got = read_prediction_artifact(p, return_metadata=True)
+    assert np.array_equal(arr, data) and got == attrs
+    with pytest.raises(ValueError, match="CZYX"):
+        write_prediction_artifact(tmp_path / "bad.h5", data[0])
+    with pytest.raises(ValueError, match="shape and dtype"):
+        write_prediction_artifact(tmp_path / "bad2.h5", None)
+    # streaming mode + default metadata
+    p2 = write_prediction_artifact(tmp_path / "s.h5", None, shape=(1, 2, 3, 4), dtype="float32",
+                                   writer=lambda d: d.__setitem__((slice(None),) * 4, 1.5))
+    arr2, a2 = read_prediction_artifact(p2, return_metadata=True)
+    assert arr2.shape == (1, 2, 3, 4) and float(arr2.mean()) == 1.5 and a2["final_shape"] == json.dumps([2, 3, 4])
+    assert PredictionArtifactMetadata().kind == "raw_prediction"

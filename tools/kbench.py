@@ -87,6 +87,29 @@ def bench_mlp():
         knob("mlp_exact_gelu", 0)
 
 
+def bench_mlp_up():
+    """Up-block mixer shapes: cost of the up-sampling epilogue vs a plain residual add vs no residual."""
+    for (N, D, cin, chid, cout) in ((8, 56, 128, 256, 64), (8, 28, 256, 512, 128), (8, 112, 64, 128, 32)):
+        rows = D ** 3
+        t = torch.randn(N, rows, cin, device=dev).to(bf)
+        ab = torch.rand(N, 2, cin, device=dev)
+        w2 = ops.pw_pack_weight_paired(torch.randn(chid, cin, device=dev) / cin ** 0.5)
+        w3 = ops.pw_pack_weight_paired(torch.randn(cout, chid, device=dev) / chid ** 0.5)
+        b2, b3 = torch.randn(chid, device=dev), torch.randn(cout, device=dev)
+        res = torch.randn(N, rows, cout, device=dev).to(bf)
+        low = torch.randn(N, (D // 2) ** 3, cout, device=dev).to(bf)
+        y = torch.empty(N, rows, cout, device=dev, dtype=bf)
+        kw = dict(N=N, rows_per_sample=rows, c_in=cin, c_hid=chid, c_out=cout, y=y)
+        for wl in (0, 1):
+            knob("mlp_wlds", wl)
+            a = timeit(lambda: ops.pw_mlp(t, ab, w2, b2, w3, b3, **kw))
+            b = timeit(lambda: ops.pw_mlp(t, ab, w2, b2, w3, b3, res=res, res_mode=nat.RES_ADD, **kw))
+            c = timeit(lambda: ops.pw_mlp(t, ab, w2, b2, w3, b3, res=res, res_mode=nat.RES_UPSAMPLE, grid=(D, D, D),
+                                          res_low=low, res_bias=b3, **kw))
+            print(f"pw_mlp {cin}->{chid}->{cout} {D}^3 wlds={wl}: none {a:7.1f} us, add {b:7.1f} us, up {c:7.1f} us", flush=True)
+    knob("mlp_wlds", 1)
+
+
 def bench_mlp_cold():
     """Deep-level mixers with COLD weights/activations (a 1 GiB copy runs between launches), as inside the network."""
     big = torch.empty(1 << 28, device=dev, dtype=torch.float32)
@@ -154,4 +177,4 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["copy", "dwconv", "mlp", "convT"]
     torch.manual_seed(0)
     for wname in which:
-        {"dwconv": bench_dwconv, "mlp": bench_mlp, "mlp_cold": bench_mlp_cold, "convT": bench_convT, "copy": bench_copy}[wname]()
+        {"dwconv": bench_dwconv, "mlp": bench_mlp, "mlp_cold": bench_mlp_cold, "mlp_up": bench_mlp_up, "convT": bench_convT, "copy": bench_copy}[wname]()
