@@ -94,6 +94,31 @@ int pytc_blend_accumulate(const void* pred, int pred_dtype, int B, const int32_t
                           const float* wx, int combine, float floor_w, const int32_t* border /*[3] or NULL*/,
                           float* value, float* weight, int Z, int Y, int X, void* stream);
 
+/* Affinity-aware overlap-add (inference/tta_affinity.py:350-393 `invert_view` + tta.py:1108-1186): like
+ * pytc_blend_accumulate, but output channel d takes prediction channel chan_src[d] displaced by chan_shift[d] (host
+ * int32 [C] / [C][3], window-local canonical coordinates): the value predicted at q lands at p = q + shift and is
+ * weighted by the blending map at p; p outside the window is dropped (the wrapped face).  C <= 32.  `weight` (may be
+ * NULL) receives the un-shifted map as in pytc_blend_accumulate. */
+int pytc_blend_accumulate_mapped(const void* pred, int pred_dtype, int B, const int32_t* starts, int rz, int ry,
+                                 int rx, int C, int view, const float* wz, const float* wy, const float* wx,
+                                 int combine, float floor_w, const int32_t* border, const int32_t* chan_src,
+                                 const int32_t* chan_shift, float* value, float* weight, int Z, int Y, int X,
+                                 void* stream);
+/* weight += blending map restricted to the positions that a window displaced by `shift` (host int32[3]) covers
+ * (valid_slices_for_shift, tta_affinity.py:100-119; the per-shift weight accumulators of tta.py:1121-1140). */
+int pytc_blend_weight_shifted(int B, const int32_t* starts, int rz, int ry, int rx, const float* wz, const float* wy,
+                              const float* wx, int combine, float floor_w, const int32_t* border,
+                              const int32_t* shift, float* weight, int Z, int Y, int X, void* stream);
+/* value[i] = weight[i] > 0 ? value[i] / weight[i] : 0, in place (tta.py:1238-1244: partial channels are normalised by
+ * their own coverage, without the 1e-4 clamp; coverage = weight > 0 is their validity). */
+int pytc_normalize_covered(float* value, const float* weight, int64_t n, void* stream);
+/* Validity-aware running statistics over TTA views (inference/tta_ensemble.py:122-165): where cover[i] > 0 (cover NULL
+ * = everywhere): mode 0 stat += x, mode 1 stat = min(stat, x), mode 2 max; count += 1.  Finalize (:205-210): mode 0
+ * out = stat / count, else out = stat; the caller rejects count == 0. */
+int pytc_ensemble_update_masked(float* stat, float* count, const float* x, const float* cover, int64_t n, int mode,
+                                void* stream);
+int pytc_ensemble_finalize_masked(const float* stat, const float* count, float* out, int64_t n, int mode, void* stream);
+
 /* value[c][i] = act(value[c][i] / max(weight[i], clamp)), in place.  Replaces
  * normalize_weighted_accumulator (inference/window.py:275-294) + the sigmoid/tanh of
  * apply_preprocessing (inference/tta.py:312-402). */

@@ -80,6 +80,16 @@ _SIGS = {
                                           C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pytc_pw_packed_elems": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "pytc_pw_pack_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "pytc_blend_accumulate_mapped": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int,
+                                               C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                                               C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p,
+                                               C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_blend_weight_shifted": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_int, C.c_float, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                            C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_normalize_covered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pytc_ensemble_update_masked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "pytc_ensemble_finalize_masked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "pytc_scale_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "pytc_pw_conv_fwd": (C.c_int, [C.POINTER(PwArgs), C.c_void_p]),
     "pytc_pw_conv_paired_supported": (C.c_int, [C.POINTER(PwArgs)]),

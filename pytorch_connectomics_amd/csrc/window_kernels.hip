@@ -130,6 +130,114 @@ blend_accumulate_kernel(const TP* __restrict__ pred, int sz, int sy, int sx, int
   if (weight) weight[dst] = __fadd_rn(weight[dst], w);
 }
 
+// ---- affinity-aware blending (inference/tta_affinity.py:350-393 fused into the scatter) ------------------------------
+// Output channel d of the canonical window takes prediction channel src[d], displaced by shift[d]: the value predicted
+// at canonical position q lands at p = q + shift[d] and is weighted by the blending map AT p (the reference multiplies
+// the re-anchored patch by the map); positions with p outside the window do not exist (the wrapped face).
+constexpr int MAX_MAP = 32;
+struct ChanMap { int src[MAX_MAP]; int sz[MAX_MAP]; int sy[MAX_MAP]; int sx[MAX_MAP]; };
+
+__device__ __forceinline__ float window_weight(const float* wzv, const float* wyv, const float* wxv, int combine,
+                                               float floor_w, int z, int y, int x, int rz, int ry, int rx, int bz,
+                                               int by, int bx) {
+  float w;
+  if (combine == PYTC_BLEND_MIN) {
+    w = fminf(fminf(wzv[z], wyv[y]), wxv[x]);
+  } else {
+    w = __fmul_rn(__fmul_rn(wzv[z], wyv[y]), wxv[x]);
+    w = fmaxf(w, 1.17549435e-38f);
+    w = fmaxf(w, floor_w);
+  }
+  if (z < bz || z >= rz - bz || y < by || y >= ry - by || x < bx || x >= rx - bx) w = 0.f;
+  return w;
+}
+
+template <typename TP>
+__global__ void __launch_bounds__(256)
+blend_accumulate_mapped_kernel(const TP* __restrict__ pred, int sz, int sy, int sx, int rz, int ry, int rx, int C,
+                               int view, const float* __restrict__ wzv, const float* __restrict__ wyv,
+                               const float* __restrict__ wxv, int combine, float floor_w, int bz, int by, int bx,
+                               ChanMap m, float* __restrict__ value, float* __restrict__ weight, int Z, int Y, int X) {
+  const long per_win = (long)rz * ry * rx;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per_win) return;
+  const int x = (int)(i % rx);
+  const long t = i / rx;
+  const int y = (int)(t % ry), z = (int)(t / ry);
+  int qz, qy, qx;
+  view_src(view, rz, ry, rx, z, y, x, qz, qy, qx);
+  const long plane = (long)Z * Y * X;
+  const TP* p = pred + i * C;
+  for (int d = 0; d < C; ++d) {
+    const int pz = qz + m.sz[d], py = qy + m.sy[d], px = qx + m.sx[d];
+    if (pz < 0 || pz >= rz || py < 0 || py >= ry || px < 0 || px >= rx) continue;
+    const int gz = sz + pz, gy = sy + py, gx = sx + px;
+    if (gz < 0 || gz >= Z || gy < 0 || gy >= Y || gx < 0 || gx >= X) continue;
+    const float w = window_weight(wzv, wyv, wxv, combine, floor_w, pz, py, px, rz, ry, rx, bz, by, bx);
+    const long dst = ((long)gz * Y + gy) * X + gx;
+    value[d * plane + dst] = __fadd_rn(value[d * plane + dst], __fmul_rn(to_f32<TP>(p[m.src[d]]), w));
+  }
+  if (weight) {
+    const int gz = sz + qz, gy = sy + qy, gx = sx + qx;
+    if (gz >= 0 && gz < Z && gy >= 0 && gy < Y && gx >= 0 && gx < X) {
+      const long dst = ((long)gz * Y + gy) * X + gx;
+      weight[dst] = __fadd_rn(weight[dst], window_weight(wzv, wyv, wxv, combine, floor_w, qz, qy, qx, rz, ry, rx, bz, by, bx));
+    }
+  }
+}
+
+// weight[g(p)] += w(p) for the positions p of a window whose source p - shift lies inside the window
+__global__ void __launch_bounds__(256)
+blend_weight_shifted_kernel(int sz, int sy, int sx, int rz, int ry, int rx, const float* __restrict__ wzv,
+                            const float* __restrict__ wyv, const float* __restrict__ wxv, int combine, float floor_w,
+                            int bz, int by, int bx, int hz, int hy, int hx, float* __restrict__ weight, int Z, int Y, int X) {
+  const long per_win = (long)rz * ry * rx;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per_win) return;
+  const int px = (int)(i % rx);
+  const long t = i / rx;
+  const int py = (int)(t % ry), pz = (int)(t / ry);
+  const int qz = pz - hz, qy = py - hy, qx = px - hx;
+  if (qz < 0 || qz >= rz || qy < 0 || qy >= ry || qx < 0 || qx >= rx) return;
+  const int gz = sz + pz, gy = sy + py, gx = sx + px;
+  if (gz < 0 || gz >= Z || gy < 0 || gy >= Y || gx < 0 || gx >= X) return;
+  const long dst = ((long)gz * Y + gy) * X + gx;
+  weight[dst] = __fadd_rn(weight[dst], window_weight(wzv, wyv, wxv, combine, floor_w, pz, py, px, rz, ry, rx, bz, by, bx));
+}
+
+// v = w > 0 ? v / w : 0   (tta.py:1238-1244: partial channels are normalised by their own coverage, unclamped)
+__global__ void __launch_bounds__(256)
+normalize_covered_kernel(float* __restrict__ value, const float* __restrict__ weight, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) value[i] = weight[i] > 0.f ? __fdiv_rn(value[i], weight[i]) : 0.f;
+}
+
+// validity-aware running statistics (tta_ensemble.py:122-165): where cover > 0: mean -> stat += x, min/max, count += 1
+__global__ void __launch_bounds__(256)
+ensemble_update_masked_kernel(float* __restrict__ stat, float* __restrict__ count, const float* __restrict__ x,
+                              const float* __restrict__ cover, long n, int mode) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    if (cover && !(cover[i] > 0.f)) continue;
+    const float v = x[i];
+    float a = stat[i];
+    a = mode == 0 ? __fadd_rn(a, v) : (mode == 1 ? fminf(a, v) : fmaxf(a, v));
+    stat[i] = a;
+    count[i] = count[i] + 1.f;
+  }
+}
+
+// mean: out = stat / count;  min/max: out = stat   (tta_ensemble.py:205-210; count == 0 is checked by the caller)
+__global__ void __launch_bounds__(256)
+ensemble_finalize_masked_kernel(const float* __restrict__ stat, const float* __restrict__ count, float* __restrict__ out,
+                                long n, int mode) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = mode == 0 ? __fdiv_rn(stat[i], count[i]) : stat[i];
+}
+
 __global__ void __launch_bounds__(256)
 blend_finalize_kernel(float* __restrict__ value, const float* __restrict__ weight, int C, long nvox,
                       float clamp, int act) {
@@ -253,6 +361,84 @@ extern "C" int pytc_blend_accumulate(const void* pred, int pred_dtype, int B, co
       PYTC_REQUIRE(false, "blend_accumulate: bad pred_dtype %d", pred_dtype);
   }
   PYTC_LAUNCH_CHECK("blend_accumulate");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_blend_accumulate_mapped(const void* pred, int pred_dtype, int B, const int32_t* starts, int rz, int ry,
+                                            int rx, int C, int view, const float* wz, const float* wy, const float* wx,
+                                            int combine, float floor_w, const int32_t* border, const int32_t* chan_src,
+                                            const int32_t* chan_shift, float* value, float* weight, int Z, int Y, int X,
+                                            void* stream) {
+  PYTC_REQUIRE(pred && starts && wz && wy && wx && value && chan_src && chan_shift, "blend_accumulate_mapped: null pointer");
+  PYTC_REQUIRE(B >= 1 && C >= 1 && C <= MAX_MAP, "blend_accumulate_mapped: C=%d must be in [1,%d]", C, MAX_MAP);
+  PYTC_REQUIRE(!(view & PYTC_VIEW_SWAP_YX) || ry == rx, "blend_accumulate_mapped: SWAP_YX needs ry == rx");
+  PYTC_REQUIRE(combine == PYTC_BLEND_PRODUCT || combine == PYTC_BLEND_MIN, "blend_accumulate_mapped: bad combine");
+  ChanMap m;
+  for (int d = 0; d < C; ++d) {
+    PYTC_REQUIRE(chan_src[d] >= 0 && chan_src[d] < C, "blend_accumulate_mapped: bad source channel %d", chan_src[d]);
+    m.src[d] = chan_src[d]; m.sz[d] = chan_shift[3 * d]; m.sy[d] = chan_shift[3 * d + 1]; m.sx[d] = chan_shift[3 * d + 2];
+  }
+  const long per_win = (long)rz * ry * rx;
+  dim3 grid(ceil_div(per_win, 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const int bz = border ? border[0] : 0, by = border ? border[1] : 0, bx = border ? border[2] : 0;
+  PYTC_REQUIRE(bz >= 0 && by >= 0 && bx >= 0 && 2 * bz < rz && 2 * by < ry && 2 * bx < rx,
+               "blend_accumulate_mapped: border mask too large for the window");
+  for (int b = 0; b < B; ++b) {
+    const int sz = starts[3 * b], sy = starts[3 * b + 1], sx = starts[3 * b + 2];
+    if (pred_dtype == PYTC_F32)
+      hipLaunchKernelGGL(blend_accumulate_mapped_kernel<float>, grid, block, 0, s, (const float*)pred + (long)b * per_win * C,
+                         sz, sy, sx, rz, ry, rx, C, view, wz, wy, wx, combine, floor_w, bz, by, bx, m, value, weight, Z, Y, X);
+    else if (pred_dtype == PYTC_BF16)
+      hipLaunchKernelGGL(blend_accumulate_mapped_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)pred + (long)b * per_win * C,
+                         sz, sy, sx, rz, ry, rx, C, view, wz, wy, wx, combine, floor_w, bz, by, bx, m, value, weight, Z, Y, X);
+    else
+      PYTC_REQUIRE(false, "blend_accumulate_mapped: bad pred_dtype %d", pred_dtype);
+  }
+  PYTC_LAUNCH_CHECK("blend_accumulate_mapped");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_blend_weight_shifted(int B, const int32_t* starts, int rz, int ry, int rx, const float* wz,
+                                         const float* wy, const float* wx, int combine, float floor_w,
+                                         const int32_t* border, const int32_t* shift, float* weight, int Z, int Y, int X,
+                                         void* stream) {
+  PYTC_REQUIRE(starts && wz && wy && wx && shift && weight && B >= 1, "blend_weight_shifted: bad arguments");
+  const long per_win = (long)rz * ry * rx;
+  const int bz = border ? border[0] : 0, by = border ? border[1] : 0, bx = border ? border[2] : 0;
+  for (int b = 0; b < B; ++b)
+    hipLaunchKernelGGL(blend_weight_shifted_kernel, dim3(ceil_div(per_win, 256)), dim3(256), 0, (hipStream_t)stream,
+                       starts[3 * b], starts[3 * b + 1], starts[3 * b + 2], rz, ry, rx, wz, wy, wx, combine, floor_w, bz, by, bx,
+                       shift[0], shift[1], shift[2], weight, Z, Y, X);
+  PYTC_LAUNCH_CHECK("blend_weight_shifted");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_normalize_covered(float* value, const float* weight, int64_t n, void* stream) {
+  PYTC_REQUIRE(value && weight && n > 0, "normalize_covered: bad arguments");
+  const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  hipLaunchKernelGGL(normalize_covered_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, value, weight, (long)n);
+  PYTC_LAUNCH_CHECK("normalize_covered");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_ensemble_update_masked(float* stat, float* count, const float* x, const float* cover, int64_t n,
+                                           int mode, void* stream) {
+  PYTC_REQUIRE(stat && count && x && n > 0 && mode >= 0 && mode <= 2, "ensemble_update_masked: bad arguments");
+  const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  hipLaunchKernelGGL(ensemble_update_masked_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, stat, count, x, cover,
+                     (long)n, mode);
+  PYTC_LAUNCH_CHECK("ensemble_update_masked");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_ensemble_finalize_masked(const float* stat, const float* count, float* out, int64_t n, int mode,
+                                             void* stream) {
+  PYTC_REQUIRE(stat && count && out && n > 0 && mode >= 0 && mode <= 2, "ensemble_finalize_masked: bad arguments");
+  const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  hipLaunchKernelGGL(ensemble_finalize_masked_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, stat, count, out,
+                     (long)n, mode);
+  PYTC_LAUNCH_CHECK("ensemble_finalize_masked");
   return PYTC_OK;
 }
 

@@ -135,6 +135,64 @@ def blend_accumulate(pred: torch.Tensor, starts, value: torch.Tensor, weight: Op
          _p(wz), _p(wy), _p(wx), int(combine), float(floor_w), bd, _p(value), _p(weight), Z, Y, X, _stream())
 
 
+def blend_accumulate_mapped(pred: torch.Tensor, starts, value: torch.Tensor, weight: Optional[torch.Tensor],
+                            wz: torch.Tensor, wy: torch.Tensor, wx: torch.Tensor, chan_src, chan_shift, *, view: int = 0,
+                            combine: int = nat.BLEND_PRODUCT, floor_w: float = 1e-5, border=None) -> None:
+    """blend_accumulate with the affinity channel map: output channel d <- pred channel chan_src[d] displaced by
+    chan_shift[d] (window-local (z,y,x)); see pytc_blend_accumulate_mapped."""
+    _dev(pred, "pred"); _dev(value, "value")
+    B, rz, ry, rx, Cc = pred.shape
+    if value.dtype != torch.float32 or value.shape[0] != Cc:
+        raise ValueError("value accumulator must be float32 (C, Z, Y, X) with C matching pred")
+    if len(chan_src) != Cc or len(chan_shift) != Cc:
+        raise ValueError("channel map must describe every output channel")
+    _, Z, Y, X = value.shape
+    st = _starts_array(starts)
+    bd = (C.c_int32 * 3)(*[int(v) for v in border]) if border else None
+    cs = (C.c_int32 * Cc)(*[int(v) for v in chan_src])
+    sh = (C.c_int32 * (3 * Cc))(*[int(v) for s3 in chan_shift for v in s3])
+    win = B * rz * ry * rx
+    _run("blend_accumulate_mapped", _nbytes(pred) + win * 4 * (2 * Cc + (2 if weight is not None else 0)),
+         nat.lib().pytc_blend_accumulate_mapped, _p(pred), dtype_code(pred.dtype), B, st, rz, ry, rx, Cc, int(view),
+         _p(wz), _p(wy), _p(wx), int(combine), float(floor_w), bd, cs, sh, _p(value), _p(weight), Z, Y, X, _stream())
+
+
+def blend_weight_shifted(starts, roi, weight: torch.Tensor, wz, wy, wx, shift, *, combine: int = nat.BLEND_PRODUCT,
+                         floor_w: float = 1e-5, border=None) -> None:
+    """weight (Z,Y,X) += blending map over the box a window displaced by `shift` covers (per window, in order)."""
+    _dev(weight, "weight")
+    Z, Y, X = weight.shape
+    st = _starts_array(starts)
+    B = len(starts)
+    bd = (C.c_int32 * 3)(*[int(v) for v in border]) if border else None
+    sh = (C.c_int32 * 3)(*[int(v) for v in shift])
+    _run("blend_weight_shifted", B * int(roi[0]) * int(roi[1]) * int(roi[2]) * 8, nat.lib().pytc_blend_weight_shifted, B, st,
+         int(roi[0]), int(roi[1]), int(roi[2]), _p(wz), _p(wy), _p(wx), int(combine), float(floor_w), bd, sh, _p(weight),
+         Z, Y, X, _stream())
+
+
+def normalize_covered(value: torch.Tensor, weight: torch.Tensor) -> None:
+    """value <- value / weight where weight > 0, else 0 (in place; same shapes)."""
+    _dev(value, "value"); _dev(weight, "weight")
+    if value.numel() != weight.numel() or value.dtype != torch.float32 or weight.dtype != torch.float32:
+        raise ValueError("normalize_covered expects float32 tensors of equal size")
+    _run("normalize_covered", 2 * _nbytes(value) + _nbytes(weight), nat.lib().pytc_normalize_covered, _p(value), _p(weight),
+         value.numel(), _stream())
+
+
+def ensemble_update_masked(stat: torch.Tensor, count: torch.Tensor, x: torch.Tensor, cover: Optional[torch.Tensor],
+                           mode: int) -> None:
+    _dev(stat, "stat"); _dev(x, "x")
+    _run("ensemble_update_masked", 3 * _nbytes(stat) + 2 * _nbytes(count), nat.lib().pytc_ensemble_update_masked, _p(stat),
+         _p(count), _p(x), _p(cover), stat.numel(), int(mode), _stream())
+
+
+def ensemble_finalize_masked(stat: torch.Tensor, count: torch.Tensor, out: torch.Tensor, mode: int) -> None:
+    _dev(stat, "stat"); _dev(out, "out")
+    _run("ensemble_finalize_masked", 3 * _nbytes(stat), nat.lib().pytc_ensemble_finalize_masked, _p(stat), _p(count), _p(out),
+         stat.numel(), int(mode), _stream())
+
+
 def blend_finalize(value: torch.Tensor, weight: torch.Tensor, *, clamp: float = 1e-4, act: int = nat.ACT_NONE) -> None:
     _dev(value, "value"); _dev(weight, "weight")
     Cc = value.shape[0]

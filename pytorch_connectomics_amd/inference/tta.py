@@ -269,6 +269,10 @@ class TTAPredictor:
                             "`inference.test_time_augmentation.patch_first_local`.")
             codes = [view_code(f, pl, k) for f, pl, k in combos]
             ensemble_mode = getattr(tta, "ensemble_mode", "mean")
+            from .tta_affinity import resolve_affinity_channel_groups_from_cfg
+            if resolve_affinity_channel_groups_from_cfg(self.cfg):
+                result = self._predict_affinity_views(vol, orig, engine, network, combos, codes, ensemble_mode)
+                return self._apply_mask_to_result(result, mask, mask_align_to_image)
             acc = None
             weight = None
             for i, code in enumerate(codes):
@@ -288,5 +292,84 @@ class TTAPredictor:
         finally:
             self._requested_output_head_override = prev
 
+
+def _predict_affinity_views(self, vol, orig, engine, network, combos, codes, ensemble_mode):
+    """Directional-affinity outputs (reference tta.py:1036-1275 + tta_affinity.py + tta_ensemble.py): every view is
+    blended with its channel map (channels re-anchored inside each window by the blending kernel), fully valid
+    channels are normalised by the shared weight and ensembled as usual, shifted ("partial") channels by the weight of
+    their own shift -- whose support is also their validity in the mean / min / max."""
+    from .tta_affinity import build_affinity_tta_plan
+    dev = vol.device
+    plan = None
+    acc = None
+    w_full = None
+    w_shift = {}
+    stats = counts = None
+    modes = sel = partial_sel = None
+    for i, (code, combo) in enumerate(zip(codes, combos)):
+        if plan is None:
+            # the plan needs the raw channel count: probe one window of the identity view
+            probe = engine._run_network(network, ops.gather_windows(vol, engine.plan(orig)[1][:1], engine.roi_size,
+                                                                    pad_mode="constant", cval=engine.cval))
+            plan = build_affinity_tta_plan(self.cfg, augmentation_combinations=combos, num_raw=int(probe.shape[-1]),
+                                           requested_head=self._requested_output_head_override)
+            for sh in sorted(plan.shifts):
+                w_shift[tuple(sh)] = engine.shifted_weight(orig, sh, dev)
+        vp = plan.views[i]
+        value, w_full = engine.accumulate(vol, network, view=code, weight=w_full, add_weight=w_full is None,
+                                          chan_map=vp.channel_map(plan.num_channels))
+        covers = [None] * plan.num_channels
+        partial = sorted(plan.partial_channels)
+        if partial:
+            # normalise the shared-weight channels in place (1e-4 clamp), then overwrite the partial ones
+            raw_partial = {c: value[c].clone() for c in partial}
+        ops.blend_finalize(value, w_full, clamp=1e-4, act=nat.ACT_NONE)
+        for c in partial:
+            sh = vp.shift_for_channel(c)
+            wk = w_full if sh is None else w_shift[tuple(sh)]
+            v = raw_partial[c]
+            ops.normalize_covered(v, wk)
+            value[c].copy_(v)
+            covers[c] = wk
+        out = value
+        crop = tuple(out.shape[1:]) != orig
+        if crop:
+            out = out[:, :orig[0], :orig[1], :orig[2]].contiguous()
+        nraw = int(out.shape[0])
+        pred = self.apply_preprocessing(out.unsqueeze(0))
+        pred = pred if pred.dtype == torch.float32 else pred.float()
+        if acc is None:
+            sel = self._select_channel_indices(nraw)
+            sel = list(range(nraw)) if sel is None else [int(v) for v in sel]
+            modes = _resolve_ensemble_mode_map(ensemble_mode, int(pred.shape[1]))
+            bad = sorted(set(modes) - set(_MODE_CODE))
+            if bad:
+                raise ValueError(f"Unknown TTA ensemble modes: {bad}.")
+            partial_sel = [j for j, c in enumerate(sel) if c in plan.partial_channels]
+            acc = pred.clone()
+            if partial_sel:
+                shape = (len(partial_sel),) + tuple(pred.shape[2:])
+                stats = torch.empty(shape, dtype=torch.float32, device=dev)
+                for pi, j in enumerate(partial_sel):
+                    stats[pi].fill_(0.0 if modes[j] == "mean" else (float("inf") if modes[j] == "min" else float("-inf")))
+                counts = torch.zeros(shape, dtype=torch.float32, device=dev)
+        else:
+            for j, mode in enumerate(modes):
+                if j not in partial_sel:
+                    ops.ensemble_update(acc[0, j], pred[0, j].contiguous(), _MODE_CODE[mode], i + 1)
+        for pi, j in enumerate(partial_sel):
+            cov = covers[sel[j]]
+            if cov is not None and crop:
+                cov = cov[:orig[0], :orig[1], :orig[2]].contiguous()
+            ops.ensemble_update_masked(stats[pi], counts[pi], pred[0, j].contiguous(), cov, _MODE_CODE[modes[j]])
+    for pi, j in enumerate(partial_sel or []):
+        if bool((counts[pi] == 0).any()):
+            first = tuple(int(v) for v in torch.nonzero(counts[pi] == 0)[0])
+            raise RuntimeError(f"TTA ensemble has zero valid contributions for channel {j} at voxel index {(0,) + first}.")
+        ops.ensemble_finalize_masked(stats[pi], counts[pi], acc[0, j], _MODE_CODE[modes[j]])
+    return acc.to(resolve_model_output_dtype(self.cfg))
+
+
+TTAPredictor._predict_affinity_views = _predict_affinity_views
 
 __all__ = ["TTAPredictor", "view_code"]

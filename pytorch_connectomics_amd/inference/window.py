@@ -405,10 +405,11 @@ class EagerSlidingWindowEngine:
 
     @torch.no_grad()
     def accumulate(self, vol: torch.Tensor, network, *, view: int = 0, value: Optional[torch.Tensor] = None,
-                   weight: Optional[torch.Tensor] = None, add_weight: bool = True, starts=None):
+                   weight: Optional[torch.Tensor] = None, add_weight: bool = True, starts=None, chan_map=None):
         """One overlap-add pass over `vol` (C,Z,Y,X fp32, device) under TTA `view` (PYTC_VIEW_* bits: the
-        window is flipped / yx-swapped on gather and the prediction is mapped back on blend).  Returns the
-        un-normalised (value, weight) accumulators over the grown image size."""
+        window is flipped / yx-swapped on gather and the prediction is mapped back on blend).  `chan_map` =
+        (src[C], shift[C]) re-anchors affinity channels inside every window (tta_affinity.AffinityViewPlan.channel_map).
+        Returns the un-normalised (value, weight) accumulators over the grown image size."""
         dev = vol.device
         orig = tuple(int(v) for v in vol.shape[1:])
         image_size, all_starts = self.plan(orig)
@@ -431,14 +432,31 @@ class EagerSlidingWindowEngine:
             weight = torch.zeros(image_size, dtype=torch.float32, device=dev)
             add_weight = True
         wacc = weight if add_weight else None
-        ops.blend_accumulate(probe, starts[:1], value, wacc, wz, wy, wx, view=view, combine=combine, floor_w=1e-5)
+
+        def blend(pred, batch_starts):
+            if chan_map is None:
+                ops.blend_accumulate(pred, batch_starts, value, wacc, wz, wy, wx, view=view, combine=combine, floor_w=1e-5)
+            else:
+                ops.blend_accumulate_mapped(pred, batch_starts, value, wacc, wz, wy, wx, chan_map[0], chan_map[1],
+                                            view=view, combine=combine, floor_w=1e-5)
+
+        blend(probe, starts[:1])
         rest = starts[1:]
         for b0 in range(0, len(rest), self.sw_batch_size):
             chunk = rest[b0:b0 + self.sw_batch_size]
-            ops.blend_accumulate(run(chunk), chunk, value, wacc, wz, wy, wx, view=view, combine=combine,
-                                 floor_w=1e-5)
+            blend(run(chunk), chunk)
         self.last_stats = {"windows": len(starts), "roi": roi, "image_size": image_size}
         return value, weight
+
+    def shifted_weight(self, orig_size, shift, device) -> torch.Tensor:
+        """Weight accumulator of the window grid restricted, per window, to the box a window displaced by `shift`
+        covers (the per-shift weight accumulators of reference tta.py:1121-1140)."""
+        image_size, starts = self.plan(tuple(int(v) for v in orig_size))
+        (wz, wy, wx), combine = self._axis_vectors(device)
+        w = torch.zeros(image_size, dtype=torch.float32, device=device)
+        for b0 in range(0, len(starts), 64):
+            ops.blend_weight_shifted(starts[b0:b0 + 64], self.roi_size, w, wz, wy, wx, shift, combine=combine, floor_w=1e-5)
+        return w
 
     @torch.no_grad()
     def __call__(self, inputs: torch.Tensor, network: Callable[[torch.Tensor], torch.Tensor], *,

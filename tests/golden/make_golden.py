@@ -280,6 +280,77 @@ def tta():
     save("tta.npz", **out)
 
 
+# ---------------------------------------------------------------- affinity-aware TTA
+def _net_aff(x, n_out):
+    """Closed-form, not equivariant, n_out channels with distinct spatial structure."""
+    z = torch.linspace(-1, 1, x.shape[2]).view(1, 1, -1, 1, 1)
+    y = torch.linspace(-1, 1, x.shape[3]).view(1, 1, 1, -1, 1)
+    w = torch.linspace(-1, 1, x.shape[4]).view(1, 1, 1, 1, -1)
+    chans = [x * (1.0 + 0.5 * w) + 0.25 * y, torch.tanh(2 * x - 1) * z + 0.1 * w * y, 3 * x * x - 1.5 * w + z * y,
+             x * z - 0.3 * y * w, 0.5 * x + w * w - z, torch.sin(3 * x) + 0.2 * y - 0.4 * z * w]
+    return torch.cat(chans[:n_out], 1)
+
+
+def tta_affinity():
+    from types import SimpleNamespace as NS
+    mgr = S.ref("connectomics.inference.manager")
+
+    def cfg_for(tta_ns, *, n_out, offsets, mode, acts, select=None, roi=(8, 12, 12)):
+        return NS(
+            model=NS(primary_head=None, heads=None, out_channels=n_out),
+            data=NS(train=NS(do_2d=False), val=NS(do_2d=False), dataloader=NS(batch_size=1),
+                    label_transform=NS(stack_outputs=True, targets=[{"name": "affinity", "kwargs": {"offsets": offsets, "affinity_mode": mode}}])),
+            inference=NS(
+                sliding_window=NS(window_size=list(roi), sw_batch_size=3, overlap=0.5, blending="bump",
+                                  padding_mode="constant", cval=0.0, keep_input_on_cpu=False, sw_device=None,
+                                  output_device=None, border_mask=None, distributed_sharding=False),
+                model=NS(head=None, select_channel=select, output_dtype=None, channel_activations=acts, crop_pad=None),
+                test_time_augmentation=tta_ns,
+            ),
+        )
+
+    def tta_ns(flip, rot, mode):
+        return NS(enabled=True, flip_axes=flip, rotation90_axes=rot, rotate90_k=None, ensemble_mode=mode,
+                  patch_first_local=True, distributed_sharding=False, apply_mask=True, empty_cache_interval=0)
+
+    x = torch.rand(1, 1, 14, 22, 26, generator=torch.Generator().manual_seed(31))
+    xsq = torch.rand(1, 1, 14, 24, 24, generator=torch.Generator().manual_seed(32))
+    out = {"x": x.numpy(), "x_square": xsq.numpy()}
+    lr = ["1-0-0", "0-1-0", "0-0-1", "3-0-0", "0-3-0", "0-0-3"]
+    cases = {
+        "aff6_flip8_mean_deepem": (tta_ns("all", None, "mean"), 6, lr, "deepem", [{"channels": ":", "activation": "sigmoid"}], None, x),
+        "aff3_rot16_min_banis": (tta_ns("all", [[1, 2]], "min"), 3, ["1-0-0", "0-1-0", "0-0-1"], "banis",
+                                 [{"channels": ":", "activation": "sigmoid"}], None, xsq),
+        "aff6_flipzy_select_max": (tta_ns([[0], [1], [0, 1]], None, "max"), 6, lr, "deepem",
+                                   [{"channels": ":", "activation": "sigmoid"}], [3, 0, 4], x),
+    }
+    for name, (ns, n_out, offsets, mode, acts, select, xin) in cases.items():
+        cfg = cfg_for(ns, n_out=n_out, offsets=offsets, mode=mode, acts=acts, select=select)
+        m = mgr.InferenceManager(cfg=cfg, model=torch.nn.Identity(), forward_fn=lambda t, n=n_out: _net_aff(t, n))
+        y = m.predict_with_tta(xin.clone())
+        out[f"{name}__y"] = y.numpy()
+        print(name, tuple(y.shape), float(y.mean()))
+    save("tta_affinity.npz", **out)
+    # the reference's channel-move plans for a few view sets (host integer logic; compared exactly)
+    import json
+    ta = S.ref("connectomics.inference.tta_affinity")
+    comb = S.ref("connectomics.inference.tta_combinations")
+    plans = {}
+    for pname, (flip, rot, n_out, offsets, mode) in {
+            "lr6_deepem_all": ("all", None, 6, lr, "deepem"),
+            "unit3_banis_rot": ("all", [[1, 2]], 3, ["1-0-0", "0-1-0", "0-0-1"], "banis"),
+            "diag_deepem_flips": ([[0], [2], [0, 2]], None, 4, ["1-0-0", "0-1-0", "0-0-1", "0-9-0"], "deepem")}.items():
+        cfg = cfg_for(tta_ns(flip, rot, "mean"), n_out=n_out, offsets=offsets, mode=mode, acts=None)
+        combos = comb.resolve_tta_augmentation_combinations(cfg.inference.test_time_augmentation, spatial_dims=3)
+        plan = ta.build_affinity_tta_plan(cfg, augmentation_combinations=combos, num_raw=n_out, requested_head=None)
+        plans[pname] = {"flip": flip, "rot": rot, "n_out": n_out, "offsets": offsets, "mode": mode,
+                        "combos": [[list(f), None if pl is None else list(pl), int(k)] for f, pl, k in combos],
+                        "views": [[[m.src, m.dst, None if m.shift is None else list(m.shift)] for m in v.moves] for v in plan.views],
+                        "partial": sorted(plan.partial_channels), "shifts": sorted(list(s) for s in plan.shifts)}
+    (HERE / "tta_affinity_plans.json").write_text(json.dumps(plans, indent=0))
+    print("wrote tta_affinity_plans.json", {k: len(v["views"]) for k, v in plans.items()})
+
+
 # ---------------------------------------------------------------- lazy / region sliding window
 def _net_lazy(x):
     ramp = torch.linspace(0, 1, x.shape[-1]).view(1, 1, 1, 1, -1)
@@ -374,7 +445,7 @@ def lazy():
 
 if __name__ == "__main__":
     parts = {"grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
-             "chunks": chunks, "tta": tta, "lazy": lazy}
+             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:
         parts[name]()

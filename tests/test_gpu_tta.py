@@ -92,3 +92,40 @@ def test_tta_mask_and_mednext_fast_path():
     assert torch.all(masked[:, 0][mask[:, 0] == 0] == 0)
     assert torch.all(masked[:, 1][mask[:, 0] == 0] == -1)
     assert torch.equal(masked[:, 0][mask[:, 0] == 1], fast[:, 0][mask[:, 0] == 1])
+
+
+# ---- affinity-aware TTA (channel moves + re-anchoring + validity) vs the reference (make_golden.py --tta_affinity)
+def _net_aff(x, n_out):
+    dev = x.device
+    z = torch.linspace(-1, 1, x.shape[2], device=dev).view(1, 1, -1, 1, 1)
+    y = torch.linspace(-1, 1, x.shape[3], device=dev).view(1, 1, 1, -1, 1)
+    w = torch.linspace(-1, 1, x.shape[4], device=dev).view(1, 1, 1, 1, -1)
+    chans = [x * (1.0 + 0.5 * w) + 0.25 * y, torch.tanh(2 * x - 1) * z + 0.1 * w * y, 3 * x * x - 1.5 * w + z * y,
+             x * z - 0.3 * y * w, 0.5 * x + w * w - z, torch.sin(3 * x) + 0.2 * y - 0.4 * z * w]
+    return torch.cat(chans[:n_out], 1)
+
+
+_LR = ["1-0-0", "0-1-0", "0-0-1", "3-0-0", "0-3-0", "0-0-3"]
+AFF_CASES = {
+    "aff6_flip8_mean_deepem": ("all", None, "mean", 6, _LR, "deepem", None, "x"),
+    "aff3_rot16_min_banis": ("all", [[1, 2]], "min", 3, ["1-0-0", "0-1-0", "0-0-1"], "banis", None, "x_square"),
+    "aff6_flipzy_select_max": ([[0], [1], [0, 1]], None, "max", 6, _LR, "deepem", [3, 0, 4], "x"),
+}
+
+
+@pytest.mark.parametrize("name", list(AFF_CASES))
+def test_affinity_tta_matches_reference(name, golden_dir):
+    from pytorch_connectomics_amd.inference import InferenceManager
+    flip, rot, mode, n_out, offsets, amode, select, xkey = AFF_CASES[name]
+    g = np.load(golden_dir / "tta_affinity.npz")
+    tta_ns = NS(enabled=True, flip_axes=flip, rotation90_axes=rot, rotate90_k=None, ensemble_mode=mode,
+                patch_first_local=True, distributed_sharding=False, apply_mask=True)
+    cfg = _cfg(tta_ns, [{"channels": ":", "activation": "sigmoid"}], select)
+    cfg.model.out_channels = n_out
+    cfg.data.label_transform = NS(stack_outputs=True, targets=[{"name": "affinity", "kwargs": {"offsets": offsets,
+                                                                                               "affinity_mode": amode}}])
+    mgr = InferenceManager(cfg=cfg, model=torch.nn.Identity(), forward_fn=lambda t: _net_aff(t, n_out))
+    y = mgr.predict_with_tta(torch.from_numpy(g[xkey]).cuda()).cpu().numpy()
+    exp = g[f"{name}__y"]
+    assert y.shape == exp.shape
+    np.testing.assert_allclose(y, exp, rtol=2e-5, atol=2e-5)

@@ -76,3 +76,42 @@ def test_ensemble_mode_map():
         _resolve_ensemble_mode_map([["0:2", "min"]], 3)
     with pytest.raises(ValueError, match="Unknown ensemble mode"):
         _resolve_ensemble_mode_map([[":", "median"]], 3)
+
+
+def test_affinity_tta_plans_match_reference(golden_dir):
+    """Channel-move plans (which channel lands where, with which displacement) against the reference's own
+    build_affinity_tta_plan for three view sets (tests/golden/tta_affinity_plans.json)."""
+    import json
+    from types import SimpleNamespace as NS
+    from pytorch_connectomics_amd.inference.tta_affinity import build_affinity_tta_plan, transform_offset, valid_slices_for_shift
+    from pytorch_connectomics_amd.inference.tta_combinations import resolve_tta_augmentation_combinations
+    plans = json.loads((golden_dir / "tta_affinity_plans.json").read_text())
+    for name, p in plans.items():
+        cfg = NS(model=NS(out_channels=p["n_out"], heads=None),
+                 data=NS(label_transform=NS(stack_outputs=True, targets=[{"name": "affinity", "kwargs": {
+                     "offsets": p["offsets"], "affinity_mode": p["mode"]}}])))
+        tta = NS(enabled=True, flip_axes=p["flip"], rotation90_axes=p["rot"], rotate90_k=None)
+        combos = resolve_tta_augmentation_combinations(tta, spatial_dims=3)
+        assert [[list(f), None if pl is None else list(pl), int(k)] for f, pl, k in combos] == p["combos"], name
+        plan = build_affinity_tta_plan(cfg, augmentation_combinations=combos, num_raw=p["n_out"], requested_head=None)
+        got = [[[m.src, m.dst, None if m.shift is None else list(m.shift)] for m in v.moves] for v in plan.views]
+        assert got == p["views"], name
+        assert sorted(plan.partial_channels) == p["partial"] and sorted(list(s) for s in plan.shifts) == p["shifts"]
+    # closed forms
+    assert transform_offset((1, 2, 3), flip_axes=[0, 2], rotation_plane_spatial=None, k=0) == (-1, 2, -3)
+    assert transform_offset((0, 1, 0), flip_axes=[], rotation_plane_spatial=(1, 2), k=1) == (0, 0, -1)
+    assert valid_slices_for_shift((8, 9, 10), (3, 0, -2)) == (slice(3, 8), slice(0, 9), slice(0, 8))
+    # errors: no unambiguous mapping, unknown mode, non-closed offset set
+    cfg = NS(model=NS(out_channels=4, heads=None), data=NS(label_transform=NS(stack_outputs=True, targets=[
+        {"name": "affinity", "kwargs": {"offsets": ["1-0-0", "0-1-0", "0-0-1"], "affinity_mode": "deepem"}}])))
+    with pytest.raises(ValueError, match="unambiguous raw-output"):
+        build_affinity_tta_plan(cfg, augmentation_combinations=[([], None, 0)], num_raw=4, requested_head=None)
+    cfg.model.out_channels = 3
+    cfg.data.label_transform.targets[0]["kwargs"]["affinity_mode"] = "nope"
+    with pytest.raises(ValueError, match="Unsupported affinity_mode"):
+        build_affinity_tta_plan(cfg, augmentation_combinations=[([], None, 0)], num_raw=3, requested_head=None)
+    cfg.data.label_transform.targets[0]["kwargs"].update(affinity_mode="deepem", offsets=["1-0-0", "0-2-0", "0-0-1"])
+    with pytest.raises(ValueError, match="counterpart"):
+        build_affinity_tta_plan(cfg, augmentation_combinations=[([], (1, 2), 1)], num_raw=3, requested_head=None)
+    assert build_affinity_tta_plan(NS(model=NS(out_channels=1), data=NS()), augmentation_combinations=[([], None, 0)],
+                                   num_raw=1, requested_head=None) is None
