@@ -88,7 +88,8 @@ class PointwiseFn(torch.autograd.Function):
         dW, db = ops.pw_wgrad(xin.contiguous(), dyx, N=N, rows_per_sample=rows, c_in=c_in, c_out=c_out,
                               want_bias=has_bias)
         dW = dW.t().contiguous() if transposed else dW
-        return dx, dW.view_as(weight).to(weight.dtype), (db.to(weight.dtype) if has_bias else None), None, None
+        return (dx, torch.empty_like(weight).copy_(dW.reshape(weight.shape)), (db.to(weight.dtype) if has_bias else None),
+                None, None)
 
 
 class BlockFn(torch.autograd.Function):
@@ -188,7 +189,8 @@ class BlockFn(torch.autograd.Function):
                 dwres = dwres_m.t().contiguous()                    # ConvTranspose layout (C_in, C_out)
                 dbres = db3.clone()                                 # bias reaches every interior voxel exactly once
                 ops.add_(dx, _pw(drl, _mat(wres), None, c_out=C, transposed=False).view_as(dx))
-        g = lambda v, like: None if v is None else v.reshape(like.shape).to(like.dtype)
+        # torch.empty_like + copy_: canonical strides even for size-1 dims (DDP's bucket views expect them)
+        g = lambda v, like: None if v is None else torch.empty_like(like).copy_(v.reshape(like.shape))
         return (dx, dskip, g(dW1.t().contiguous(), w1), (db1.to(w1.dtype) if has_b1 else None), g(dgamma, gamma),
                 g(dbeta, gamma), g(dW2, w2), db2.to(w2.dtype), g(dW3, w3), db3.to(w3.dtype),
                 (g(dwres, wres) if has_res else None), (dbres.to(w3.dtype) if (has_res and has_bres) else None),

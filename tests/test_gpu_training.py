@@ -301,3 +301,51 @@ test:
     assert m["output_voxels_per_s"] > 0
     out2 = main(["--config", str(cfg), "--mode", "train", "--checkpoint", str(ck), "--fast-dev-run", "2"])
     assert out2["steps"] == 2
+
+
+def test_ddp_over_rccl_single_rank_matches_plain_training():
+    """DistributedDataParallel (backend nccl = RCCL) around the HIP-kernel model: same losses and parameters as the
+    un-wrapped model after two AdamW steps (world size 1 on the test box; the multi-rank reduction itself is RCCL's)."""
+    import os
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from pytorch_connectomics_amd.config import ConfigNode, schema_defaults
+    from pytorch_connectomics_amd.models import build_model
+    from pytorch_connectomics_amd.training.module import build_optimizer, dice_loss_sigmoid, weighted_bce_with_logits
+
+    cfg = ConfigNode(schema_defaults())
+    cfg.model.arch.type = "mednext_custom"
+    cfg.model.mednext.base_channels, cfg.model.mednext.exp_r, cfg.model.mednext.block_counts = 8, 2, [1] * 9
+    cfg.optimization.optimizer.lr = 1e-2
+
+    def run(ddp):
+        torch.manual_seed(0)
+        model = build_model(cfg).cuda().train()
+        model.model.compute_dtype = torch.bfloat16
+        net = DDP(model, device_ids=[0], find_unused_parameters=True) if ddp else model
+        opt = build_optimizer(cfg, model)
+        g = torch.Generator(device="cuda").manual_seed(5)
+        losses = []
+        for _ in range(2):
+            x = torch.rand(2, 1, 32, 32, 32, device="cuda", generator=g)
+            t = (torch.rand(2, 1, 32, 32, 32, device="cuda", generator=g) > 0.8).float()
+            opt.zero_grad(set_to_none=True)
+            out = net(x)
+            loss = weighted_bce_with_logits(out, t) + dice_loss_sigmoid(out, t)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        return losses, torch.cat([p.detach().flatten() for p in model.parameters()])
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        l1, p1 = run(True)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    l0, p0 = run(False)
+    assert l1 == l0 and torch.equal(p0, p1)       # deterministic kernels: bit-identical with and without DDP
