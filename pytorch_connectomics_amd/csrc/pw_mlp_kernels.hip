@@ -9,6 +9,7 @@
 //   * every lane ends with 8 consecutive output channels of one voxel -> one 16-byte store, and reads its
 //     residual the same way.
 // HBM traffic per voxel = C_in (t) + C_out (residual) + C_out (y) elements: the byte floor of the op.
+#include <cmath>
 #include "pw_common.h"
 
 namespace pytc {
@@ -25,10 +26,32 @@ struct MlpParams {
   int C_in, C_hid, C_out, HC;   // HC = C_hid / 32
 };
 
-template <int KS_IN, int MO, int NT, bool FAST_GELU>
+// GELU by table: the mixer is VALU bound on its activation (SQ counters of 64->128->32: 70 % VALU busy, v_exp_f32 and
+// v_rcp_f32 are about 60 % of it).  1024 segments of [-8, 8): y = a_i + b_i * x with (a_i, b_i) from the exact erf GELU
+// in double precision -> |error| <= 2.4e-5 (h^2/8 * max f''), the class of `gelu_fast`; outside the range the end
+// segments extend linearly (slopes 0 and 1 to 1e-14).  One fma + clamp + cvt + ds_read_b64 + fma per element.
+constexpr int GELU_LUT_N = 1024;
+__device__ float2 g_gelu_lut[GELU_LUT_N];
+
+__device__ __forceinline__ float gelu_lut(const float2* __restrict__ tab, float x) {
+  const float t = fminf(fmaxf(fmaf(x, 64.0f, 512.0f), 0.0f), (float)(GELU_LUT_N - 1));
+  const float2 ab = tab[(int)t];
+  return fmaf(ab.y, x, ab.x);
+}
+
+// GELU_MODE: 0 = erf (A&S 7.1.26), 1 = sigmoid-form minimax (gelu_fast), 2 = table
+template <int KS_IN, int MO, int NT, int GELU_MODE>
 __global__ void __launch_bounds__(256)
 pw_mlp_kernel(MlpParams p) {
   static_assert(MO % 2 == 0, "C_out must be a multiple of 32");
+  __shared__ __attribute__((aligned(16))) float2 lut[GELU_MODE == 2 ? GELU_LUT_N : 1];
+  if constexpr (GELU_MODE == 2) {
+    const uint4* src = reinterpret_cast<const uint4*>(g_gelu_lut);
+    uint4* dst = reinterpret_cast<uint4*>(lut);
+    dst[threadIdx.x] = src[threadIdx.x];
+    dst[threadIdx.x + 256] = src[threadIdx.x + 256];
+    __syncthreads();
+  }
   constexpr bool PREFETCH_RES = (MO / 2) * NT <= 4;   // residual rows ride along with the input loads
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = blockIdx.y;
@@ -131,8 +154,8 @@ pw_mlp_kernel(MlpParams p) {
       float g[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        g[j] = FAST_GELU ? gelu_fast(acc1[0][nt][j]) : gelu_erf(acc1[0][nt][j]);
-        g[4 + j] = FAST_GELU ? gelu_fast(acc1[1][nt][j]) : gelu_erf(acc1[1][nt][j]);
+        g[j] = GELU_MODE == 2 ? gelu_lut(lut, acc1[0][nt][j]) : (GELU_MODE == 1 ? gelu_fast(acc1[0][nt][j]) : gelu_erf(acc1[0][nt][j]));
+        g[4 + j] = GELU_MODE == 2 ? gelu_lut(lut, acc1[1][nt][j]) : (GELU_MODE == 1 ? gelu_fast(acc1[1][nt][j]) : gelu_erf(acc1[1][nt][j]));
       }
       bh[nt] = Mma<bf16_t>::from_floats(g);
     }
@@ -185,14 +208,33 @@ pw_pack_paired_kernel(const float* __restrict__ w, int C_out, int C_in, int tran
   packed[i] = from_f32<bf16_t>(v);
 }
 
+// one-time upload of the GELU table (host double precision; blocking copy, first mixer launch of the process)
+static bool ensure_gelu_lut() {
+  static int state = 0;     // 0 = not tried, 1 = ready, -1 = failed
+  if (state == 0) {
+    static float2 host[GELU_LUT_N];
+    auto f = [](double x) { return 0.5 * x * (1.0 + erf(x * 0.70710678118654752440)); };
+    for (int i = 0; i < GELU_LUT_N; ++i) {
+      const double x0 = -8.0 + i / 64.0, x1 = x0 + 1.0 / 64.0;
+      const double b = (f(x1) - f(x0)) * 64.0;
+      host[i].x = (float)(f(x0) - b * x0);
+      host[i].y = (float)b;
+    }
+    state = hipMemcpyToSymbol(HIP_SYMBOL(g_gelu_lut), host, sizeof(host)) == hipSuccess ? 1 : -1;
+  }
+  return state == 1;
+}
+
 template <int KS_IN, int MO, int NT>
 static void launch_mlp(const MlpParams& p, int N, hipStream_t s) {
   long rows_per_block = 4L * NT * 16;
   dim3 grid((unsigned)((p.rps + rows_per_block - 1) / rows_per_block), (unsigned)N), block(256);
   if (tuning_get("mlp_exact_gelu", 0))
-    hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT, false>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT, 0>), grid, block, 0, s, p);
+  else if (tuning_get("mlp_gelu_lut", 0) && ensure_gelu_lut())
+    hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT, 2>), grid, block, 0, s, p);
   else
-    hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT, true>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT, 1>), grid, block, 0, s, p);
 }
 
 // (C_in/32, C_out/16) pairs that occur in MedNeXt with 32 base channels: same-res, down (x2), up (/2)

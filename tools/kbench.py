@@ -101,13 +101,13 @@ def bench_mlp_up():
         y = torch.empty(N, rows, cout, device=dev, dtype=bf)
         kw = dict(N=N, rows_per_sample=rows, c_in=cin, c_hid=chid, c_out=cout, y=y)
         for wl in (0, 1):
-            knob("mlp_wlds", wl)
+            knob("mlp_gelu_lut", wl)
             a = timeit(lambda: ops.pw_mlp(t, ab, w2, b2, w3, b3, **kw))
             b = timeit(lambda: ops.pw_mlp(t, ab, w2, b2, w3, b3, res=res, res_mode=nat.RES_ADD, **kw))
             c = timeit(lambda: ops.pw_mlp(t, ab, w2, b2, w3, b3, res=res, res_mode=nat.RES_UPSAMPLE, grid=(D, D, D),
                                           res_low=low, res_bias=b3, **kw))
-            print(f"pw_mlp {cin}->{chid}->{cout} {D}^3 wlds={wl}: none {a:7.1f} us, add {b:7.1f} us, up {c:7.1f} us", flush=True)
-    knob("mlp_wlds", 1)
+            print(f"pw_mlp {cin}->{chid}->{cout} {D}^3 gelu_lut={wl}: none {a:7.1f} us, add {b:7.1f} us, up {c:7.1f} us", flush=True)
+    knob("mlp_gelu_lut", 1)
 
 
 def bench_mlp_cold():
