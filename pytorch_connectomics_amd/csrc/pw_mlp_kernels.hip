@@ -39,9 +39,18 @@ __device__ __forceinline__ float gelu_lut(const float2* __restrict__ tab, float 
   return fmaf(ab.y, x, ab.x);
 }
 
+// Occupancy hint: with a bare __launch_bounds__(256) hipcc budgets for one wave per SIMD and spends registers freely
+// (176 VGPRs for 128->256->64, i.e. 2 waves/SIMD); the waves of this kernel spend > 40 % of their life waiting on
+// loads (SQ_WAIT_ANY), so the kernels are compiled for the occupancy their live state allows (no spills).
+constexpr int mlp_waves_per_simd(int ks, int mo, int nt) {
+  if (ks >= 8 && nt == 1) return 1;                             // deep levels: weights-in-flight need the registers
+  const int regs = ks * nt * 4 + mo * nt * 4 + 2 * nt * 4;     // operand tile + both accumulators
+  return regs <= 64 ? 4 : (regs <= 112 ? 3 : (regs <= 200 ? 2 : 1));
+}
+
 // GELU_MODE: 0 = erf (A&S 7.1.26), 1 = sigmoid-form minimax (gelu_fast), 2 = table
 template <int KS_IN, int MO, int NT, int GELU_MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, mlp_waves_per_simd(KS_IN, MO, NT))
 pw_mlp_kernel(MlpParams p) {
   static_assert(MO % 2 == 0, "C_out must be a multiple of 32");
   __shared__ __attribute__((aligned(16))) float2 lut[GELU_MODE == 2 ? GELU_LUT_N : 1];
