@@ -22,8 +22,13 @@ struct PwFastParams {
   int gather, Hi, Wi, Ho, Wo;   // gather == 2: output row (oz,oy,ox) reads input voxel (2oz,2oy,2ox)
 };
 
+// waves/SIMD the kernel is compiled for (a bare launch_bounds(256) lets hipcc budget for ONE wave per SIMD)
+constexpr int pw_fast_waves(int ks, int nt) {
+  return nt == 4 ? (ks <= 2 ? 3 : 2) : (ks <= 4 ? 4 : (ks <= 16 ? 3 : 1));
+}
+
 template <int KS, int NT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, pw_fast_waves(KS, NT))
 pw_fast_kernel(PwFastParams p) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = blockIdx.y;

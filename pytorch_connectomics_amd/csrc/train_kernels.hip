@@ -116,7 +116,7 @@ pw_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ ab, const T* 
 // db comes from one extra MFMA per tile row against a fragment of ones.  The four waves' accumulators are added in a
 // fixed order (wave 0 + 1 + 2 + 3) -> per-slot partials -> reduce_slots: deterministic.
 template <int MT, int NT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (MT * NT >= 16 ? 2 : (MT * NT >= 8 ? 3 : 4)))
 pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab, const bf16_t* __restrict__ dy,
                      float* __restrict__ dWp, float* __restrict__ dbp, long rows_total, long rows_per_sample, int C_in,
                      int C_out, long rows_per_slot, int x_act) {
