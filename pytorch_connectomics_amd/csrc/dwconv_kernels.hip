@@ -363,7 +363,7 @@ struct DwMarch {
   int swizzle;           // XCD-aware block remap on/off
 };
 
-template <typename T, int VEC, int PF, bool ASYNC, int WPS = 2>
+template <typename T, int VEC, int PF, bool ASYNC, int WPS = 2, bool WLDS = false>
 __global__ void __launch_bounds__(256, WPS)
 dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ w,
                          const float* __restrict__ bias, float* __restrict__ stats, DwMarch g) {
@@ -378,6 +378,9 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
   typedef float fvec_t __attribute__((ext_vector_type(VEC)));
   __shared__ __attribute__((aligned(16))) float plane[2][EY * EX * CG];
   __shared__ float red[4][2][CG];
+  // WLDS: the 27 x CG taps live in LDS instead of 54 registers per lane (lanes of one channel pair read the same
+  // address: broadcast), which brings the kernel under the 3-waves/SIMD register line
+  __shared__ __attribute__((aligned(16))) float wlds[WLDS ? 27 * CG : 1];
 
   const int tid = threadIdx.x;
   // 1-D grid, XCD-aware: logical index = ((n * CGs + cg) * slots + slot); x-/y-neighbouring footprints
@@ -461,9 +464,14 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
   // ---- per-thread weights (27 taps x VEC channels), bias, positions
   const int cv = tid % LPV, pslot = tid / LPV;
   const int c0 = cg * CG + cv * VEC;
-  float wr[27][VEC];
+  float wr[WLDS ? 1 : 27][VEC];
+  if constexpr (WLDS) {
+    for (int i = tid; i < 27 * CG; i += 256) wlds[i] = w[(long)(i / CG) * C + cg * CG + (i % CG)];
+    // visible after the __syncthreads() that follows the prologue's first commit
+  } else {
 #pragma unroll
-  for (int t = 0; t < 27; ++t) VecIO<float, VEC>::load(w + (long)t * C + c0, wr[t]);
+    for (int t = 0; t < 27; ++t) VecIO<float, VEC>::load(w + (long)t * C + c0, wr[t]);
+  }
   float bv[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) bv[i] = bias ? bias[c0 + i] : 0.f;
@@ -482,7 +490,7 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
 
-  float accA[PASSES][VEC], accB[PASSES][VEC], accC[PASSES][VEC];
+  fvec_t accA[PASSES], accB[PASSES], accC[PASSES];
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps)
 #pragma unroll
@@ -491,12 +499,40 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
   // one z step: input plane gz lives in plane[slot]; prev/cur/next = outputs gz-1 / gz / gz+1.
   // `ld` receives the global loads issued this step (plane gz+PF); `cm` holds plane gz+1 (issued PF-1
   // steps ago) and is committed to the other LDS slot after the compute.
-  auto step = [&](int gz, int slot, float (&prev)[PASSES][VEC], float (&cur)[PASSES][VEC],
-                  float (&next)[PASSES][VEC], u32x4_t (&ld)[CPT], u32x4_t (&cm)[CPT]) {
+  auto step = [&](int gz, int slot, fvec_t (&prev)[PASSES], fvec_t (&cur)[PASSES],
+                  fvec_t (&next)[PASSES], u32x4_t (&ld)[CPT], u32x4_t (&cm)[CPT]) {
     if (gz + PF <= ze) issue(gz + PF, ld);
     // Unconditional accumulation: planes outside the volume were staged as zeros, and accumulators that
     // belong to outputs outside [zs, ze) are simply never stored (2 wasted planes per z-chunk), which keeps
     // the inner loop free of per-FMA selects.
+    if constexpr (WLDS) {
+      // Hand-scheduled tap loop (VEC == 2).  Left to itself hipcc issues all 63 LDS reads of a step first (126 live
+      // registers) and then runs each accumulator's nine FMAs back to back, with an s_nop between dependent
+      // v_pk_fma_f32.  Here the order is fixed by volatile reads and asm-volatile FMAs: tap group g+1 (3 weight + 4 data
+      // reads) is requested before the 12 FMAs of group g, which go round-robin over the 12 independent accumulators
+      // (a dependent FMA is 12 issue slots away).
+      static_assert(VEC == 2, "hand-scheduled path is written for channel pairs");
+      typedef const volatile __attribute__((address_space(3))) fvec_t* lds_vol_ptr;
+      fvec_t wq[2][3], vq[2][PASSES];
+      auto fetch = [&](int g, int buf) {
+        const int dy = g / 3, dx = g % 3;
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) wq[buf][kz] = *(lds_vol_ptr)(&wlds[((kz * 3 + dy) * 3 + dx) * CG + cv * VEC]);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) vq[buf][ps] = *(lds_vol_ptr)(&plane[slot][lbase[ps] + (dy * EX + dx) * CG]);
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int g = 0; g < 9; ++g) {
+        if (g + 1 < 9) fetch(g + 1, (g + 1) & 1);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(next[ps]) : "v"(vq[g & 1][ps]), "v"(wq[g & 1][0]));
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(cur[ps]) : "v"(vq[g & 1][ps]), "v"(wq[g & 1][1]));
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(prev[ps]) : "v"(vq[g & 1][ps]), "v"(wq[g & 1][2]));
+        }
+      }
+    } else {
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       // WPS >= 3: keep the LDS reads of one position from being hoisted over the previous position's FMAs (the
@@ -519,6 +555,7 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
         }
       }
     }
+    }
     if (gz + 1 <= ze) {
       landed(cm, gz + PF <= ze);
       commit(slot ^ 1, cm, gz + 1);
@@ -528,7 +565,10 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
 #pragma unroll
       for (int ps = 0; ps < PASSES; ++ps) {
         if (pok[ps]) {
-          VecIO<T, VEC>::store(yn + (long)(gz - 1) * plane_elems + obase[ps], prev[ps]);
+          float pv[VEC];
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) pv[i] = prev[ps][i];
+          VecIO<T, VEC>::store(yn + (long)(gz - 1) * plane_elems + obase[ps], pv);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) {
             const float r = to_f32<T>(from_f32<T>(prev[ps][i]));
@@ -970,24 +1010,22 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
     make_march(t, N, D, H, W, C);
     dim3 grid((unsigned)((long)t.slots * (C / MARCH_CG) * N)), block(256);
     t.swizzle = tuning_get("dwconv_xcd_swizzle", 1);
-    const int variant = tuning_get("dwconv_march_variant", 9);   // bit0: VEC=2, bit1: PF=2; 5: VEC=2, PF=3; 7 / 9: asm loads + counted waits, PF=2 / 3
-#define PYTC_MARCH(TT, VV, PP) \
-  hipLaunchKernelGGL((dwconv3d_k3_march_kernel<TT, VV, PP, false>), grid, block, 0, (hipStream_t)stream, (const TT*)x, \
-                     (TT*)y, w, bias, stats, t)
+    // variants (all: taps in LDS, hand-scheduled tap loop, asm plane loads with counted waits):
+    //   0 (default) PF=3 compiled for 4 waves/SIMD; 1: PF=3, 3 waves; 2: PF=3, 2 waves; 3: PF=2, 3 waves
+    const int variant = tuning_get("dwconv_march_variant", 0);
+#define PYTC_MARCH(PP, WW) \
+  hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, PP, true, WW, true>), grid, block, 0, (hipStream_t)stream, \
+                     (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t)
     if (dtype == PYTC_BF16) {
-      if (variant == 7) hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, 2, true>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t);
-      else if (variant == 9) hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, 3, true>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t);
-      else if (variant == 11) hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, 3, true, 3>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t);
-      else if (variant == 13) hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, 2, true, 3>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t);
-      else if (variant == 5) PYTC_MARCH(bf16_t, 2, 3);
-      else switch (variant & 3) {
-        case 0: PYTC_MARCH(bf16_t, 4, 1); break;
-        case 1: PYTC_MARCH(bf16_t, 2, 1); break;
-        case 2: PYTC_MARCH(bf16_t, 4, 2); break;
-        default: PYTC_MARCH(bf16_t, 2, 2); break;
+      switch (variant) {
+        case 1: PYTC_MARCH(3, 3); break;
+        case 2: PYTC_MARCH(3, 2); break;
+        case 3: PYTC_MARCH(2, 3); break;
+        default: PYTC_MARCH(3, 4); break;
       }
     } else {
-      PYTC_MARCH(float, 2, 1);
+      hipLaunchKernelGGL((dwconv3d_k3_march_kernel<float, 2, 1, false, 2, true>), grid, block, 0, (hipStream_t)stream,
+                         (const float*)x, (float*)y, w, bias, stats, t);
     }
 #undef PYTC_MARCH
     PYTC_LAUNCH_CHECK("dwconv3d_k3_march");
