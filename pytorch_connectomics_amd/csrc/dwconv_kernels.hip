@@ -754,21 +754,27 @@ dw_wgrad_march_kernel(const T* __restrict__ gr, const T* __restrict__ x, float* 
     pok[ps] = (y0 + py) < g.H && (x0 + px) < g.W;
     obase[ps] = ((long)(y0 + py) * g.W + (x0 + px)) * C + cv * VEC;
   }
-  float acc[27][VEC], accb[VEC];
+  fvec_t acc[27];
+  float accb[VEC];
 #pragma unroll
   for (int t = 0; t < 27; ++t)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[t][i] = 0.f;
 #pragma unroll
   for (int i = 0; i < VEC; ++i) accb[i] = 0.f;
-  float gA[PASSES][VEC], gB[PASSES][VEC], gC[PASSES][VEC], gq[PASSES][VEC];
-  auto gload = [&](int gz, float (&dst)[PASSES][VEC]) {      // G plane gz at the lane's positions (0 outside the chunk)
+  fvec_t gA[PASSES], gB[PASSES], gC[PASSES], gq[PASSES];
+  auto gload = [&](int gz, fvec_t (&dst)[PASSES]) {      // G plane gz at the lane's positions (0 outside the chunk)
     const bool zok = gz >= zs && gz < ze;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) dst[ps][i] = 0.f;
-      if (zok && pok[ps]) VecIO<T, VEC>::load(gn + (long)gz * plane_elems + obase[ps], dst[ps]);
+      if (zok && pok[ps]) {
+        float gv[VEC];
+        VecIO<T, VEC>::load(gn + (long)gz * plane_elems + obase[ps], gv);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) dst[ps][i] = gv[i];
+      }
     }
   };
 #pragma unroll
@@ -778,24 +784,33 @@ dw_wgrad_march_kernel(const T* __restrict__ gr, const T* __restrict__ x, float* 
   gload(zs, gC);
 
   // one z step: X plane gz is in plane[slot]; prev/cur/next = G[gz-1] / G[gz] / G[gz+1]
-  auto step = [&](int gz, int slot, float (&prev)[PASSES][VEC], float (&cur)[PASSES][VEC], float (&next)[PASSES][VEC]) {
+  auto step = [&](int gz, int slot, fvec_t (&prev)[PASSES], fvec_t (&cur)[PASSES], fvec_t (&next)[PASSES]) {
     if (gz + 1 <= ze) issue(gz + 1);
     gload(gz + 2, gq);
 #pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
+    for (int ps = 0; ps < PASSES; ++ps)
 #pragma unroll
       for (int i = 0; i < VEC; ++i) accb[i] += next[ps][i];
+    // hand-scheduled like the forward march: the four positions' reads of tap (dy,dx)+1 are requested before the 12
+    // FMAs of tap (dy,dx); per tap the three kz accumulators take the positions in turn (dependent FMAs 3 slots apart)
+    static_assert(VEC == 2, "hand-scheduled path is written for channel pairs");
+    {
+      typedef const volatile __attribute__((address_space(3))) fvec_t* lds_vol_ptr;
+      fvec_t vq[2][PASSES];
+      auto fetch = [&](int t, int buf) {
+        const int dy = t / 3, dx = t % 3;
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
+        for (int ps = 0; ps < PASSES; ++ps) vq[buf][ps] = *(lds_vol_ptr)(&plane[slot][lbase[ps] + (dy * EX + dx) * CG]);
+      };
+      fetch(0, 0);
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const fvec_t v = *reinterpret_cast<const fvec_t*>(&plane[slot][lbase[ps] + (dy * EX + dx) * CG]);
+      for (int t = 0; t < 9; ++t) {
+        if (t + 1 < 9) fetch(t + 1, (t + 1) & 1);
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) {
-            acc[(0 * 3 + dy) * 3 + dx][i] = fmaf(v[i], next[ps][i], acc[(0 * 3 + dy) * 3 + dx][i]);
-            acc[(1 * 3 + dy) * 3 + dx][i] = fmaf(v[i], cur[ps][i], acc[(1 * 3 + dy) * 3 + dx][i]);
-            acc[(2 * 3 + dy) * 3 + dx][i] = fmaf(v[i], prev[ps][i], acc[(2 * 3 + dy) * 3 + dx][i]);
-          }
+        for (int ps = 0; ps < PASSES; ++ps) {
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[0 * 9 + t]) : "v"(vq[t & 1][ps]), "v"(next[ps]));
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[1 * 9 + t]) : "v"(vq[t & 1][ps]), "v"(cur[ps]));
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[2 * 9 + t]) : "v"(vq[t & 1][ps]), "v"(prev[ps]));
         }
       }
     }

@@ -81,18 +81,22 @@ def build_optimizer(cfg, model: nn.Module) -> torch.optim.Optimizer:
     wd_norm = float(getattr(oc, "weight_decay_norm", 0.0))
     wd_bias = float(getattr(oc, "weight_decay_bias", wd))
     bias_lr = float(getattr(oc, "bias_lr_factor", 1.0))
-    groups, seen = [], set()
+    # the reference (optimization/build.py:73-112) emits one group per parameter; parameters with identical
+    # hyper-parameters are merged here (same update rule, but the multi-tensor optimizer then runs a handful of fused
+    # launches per step instead of ~8 per parameter -- 1 800 tiny launches / 40 ms of host time for MedNeXt-S)
+    merged, seen = {}, set()
     for module in model.modules():
         for key, p in module.named_parameters(recurse=False):
             if not p.requires_grad or p in seen:
                 continue
             seen.add(p)
-            g = {"params": [p], "lr": lr, "weight_decay": wd}
+            g_lr, g_wd = lr, wd
             if isinstance(module, _NORM_TYPES):
-                g["weight_decay"] = wd_norm
+                g_wd = wd_norm
             elif key == "bias":
-                g["lr"], g["weight_decay"] = lr * bias_lr, wd_bias
-            groups.append(g)
+                g_lr, g_wd = lr * bias_lr, wd_bias
+            merged.setdefault((g_lr, g_wd), []).append(p)
+    groups = [{"params": ps, "lr": k[0], "weight_decay": k[1]} for k, ps in merged.items()]
     betas = tuple(getattr(oc, "betas", (0.9, 0.999)))
     eps = float(getattr(oc, "eps", 1e-8))
     if name == "adamw":

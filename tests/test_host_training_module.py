@@ -74,7 +74,8 @@ def test_optimizer_grouping_and_scheduler():
     cfg.optimization.optimizer.weight_decay = 0.01
     model = SimpleModel()
     opt = build_optimizer(cfg, model)
-    wd = {id(g["params"][0]): g["weight_decay"] for g in opt.param_groups}
+    wd = {id(p): g["weight_decay"] for g in opt.param_groups for p in g["params"]}
+    assert len(opt.param_groups) == 2                                               # merged by (lr, weight decay)
     assert wd[id(model.conv.weight)] == 0.01 and wd[id(model.conv.bias)] == 0.01
     assert wd[id(model.norm.weight)] == 0.0 and wd[id(model.norm.bias)] == 0.0      # no decay on norm params
     sch = WarmupCosineLR(opt, max_iters=100, warmup_iters=10, warmup_factor=0.001)
