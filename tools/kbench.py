@@ -87,6 +87,18 @@ def bench_mlp():
         knob("mlp_exact_gelu", 0)
 
 
+def bench_dw_wgrad():
+    N = 4
+    for (D, C) in ((112, 32), (56, 64)):
+        g = torch.randn(N, D, D, D, C, device=dev).to(bf)
+        x = torch.randn(N, D, D, D, C, device=dev).to(bf)
+        us = timeit(lambda: ops.dw_wgrad(g, x, K=3, stride=1))
+        print(f"dw_wgrad march N{N} {D}^3 C{C}: {us:8.1f} us  {2 * g.numel() * 2 / us / 1e3:7.1f} GB/s", flush=True)
+        gs = torch.randn(N, D // 2, D // 2, D // 2, C, device=dev).to(bf)
+        us = timeit(lambda: ops.dw_wgrad(gs, x, K=3, stride=2))
+        print(f"dw_wgrad stride2 N{N} {D}^3->{D // 2}^3 C{C}: {us:8.1f} us  {(gs.numel() + x.numel()) * 2 / us / 1e3:7.1f} GB/s", flush=True)
+
+
 def bench_mlp_up():
     """Up-block mixer shapes: cost of the up-sampling epilogue vs a plain residual add vs no residual."""
     for (N, D, cin, chid, cout) in ((8, 56, 128, 256, 64), (8, 28, 256, 512, 128), (8, 112, 64, 128, 32)):
@@ -177,4 +189,4 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["copy", "dwconv", "mlp", "convT"]
     torch.manual_seed(0)
     for wname in which:
-        {"dwconv": bench_dwconv, "mlp": bench_mlp, "mlp_cold": bench_mlp_cold, "mlp_up": bench_mlp_up, "convT": bench_convT, "copy": bench_copy}[wname]()
+        {"dwconv": bench_dwconv, "mlp": bench_mlp, "mlp_cold": bench_mlp_cold, "dw_wgrad": bench_dw_wgrad, "mlp_up": bench_mlp_up, "convT": bench_convT, "copy": bench_copy}[wname]()
