@@ -145,6 +145,10 @@ def lib():
         raise RuntimeError(
             f"pytorch_connectomics_amd: HIP library {LIB_PATH} is missing. Build it with "
             "`python -m pytorch_connectomics_amd.csrc.build` (needs hipcc). There is no CPU fallback.")
+    # torch first: it ships its own libamdhip64 -- loaded before ours, the library's HIP symbols bind to the runtime
+    # PyTorch's tensors and streams live in; loaded after, the process ends up with two HIP runtimes and this library
+    # sees no device
+    import torch  # noqa: F401
     handle = C.CDLL(str(LIB_PATH))
     for name, (res, args) in _SIGS.items():
         try:
