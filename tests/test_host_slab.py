@@ -1,0 +1,95 @@
+"""z-slab ownership + halo exchange: plan properties and the exchange protocol over gloo
+(world 2 and 3) with the CPU oracle as the accumulator, against the single-process sliding-window oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import window_oracle as WO
+from pytorch_connectomics_amd.inference.slab import exchange_schedule, plan_slabs, slab_predict
+
+
+def _net(x):            # closed form, position dependent inside the window, 2 output channels
+    z = torch.linspace(-1, 1, x.shape[2]).view(1, 1, -1, 1, 1)
+    w = torch.linspace(-1, 1, x.shape[4]).view(1, 1, 1, 1, -1)
+    return torch.cat([x * (1 + 0.5 * w) + 0.1 * z, torch.tanh(2 * x - 1) - 0.2 * w * z], 1)
+
+
+@pytest.mark.parametrize("img,roi,world", [((165, 1024, 768), (112, 112, 112), 8), ((448, 448, 448), (112, 112, 112), 8),
+                                            ((20, 30, 34), (8, 12, 12), 3), ((9, 40, 12), (8, 12, 12), 2),
+                                            ((8, 12, 12), (8, 12, 12), 4)])
+def test_slab_plan_partitions_windows_and_planes(img, roi, world):
+    grown = tuple(max(i, r) for i, r in zip(img, roi))
+    starts = WO.window_starts(grown, roi, WO.scan_interval(grown, roi, 0.5))
+    plan = plan_slabs(grown, roi, starts, world)
+    ax = plan.axis
+    assert sorted(sum((plan.windows_of(r) for r in range(world)), [])) == sorted(tuple(s) for s in starts)
+    edges = [plan.own[0][0]] + [b for _a, b in plan.own]
+    assert edges[0] == 0 and edges[-1] == grown[ax] and all(a <= b for a, b in zip(edges, edges[1:]))
+    assert all(plan.own[r][0] == plan.own[r - 1][1] for r in range(1, world))
+    for r in range(world):
+        wins = plan.windows_of(r)
+        if wins:
+            assert plan.extent[r] == (min(w[ax] for w in wins), min(grown[ax], max(w[ax] for w in wins) + roi[ax]))
+        sends, recvs = exchange_schedule(plan, r)
+        for q, z0, z1 in sends:                      # what r sends to q is exactly what q expects from r
+            assert (r, z0, z1) in exchange_schedule(plan, q)[1]
+        for q, z0, z1 in recvs:
+            assert (r, z0, z1) in exchange_schedule(plan, q)[0]
+    # every plane a rank's windows touch outside its own slab is covered by exactly one send
+    for r in range(world):
+        L, H = plan.extent[r]
+        outside = set(range(L, H)) - set(range(*plan.own[r]))
+        sent = [z for _q, z0, z1 in exchange_schedule(plan, r)[0] for z in range(z0, z1)]
+        assert sorted(sent) == sorted(outside)
+
+
+def _oracle_accumulate(vol, roi, plan):
+    wmap = torch.from_numpy(WO.importance_map(roi, "bump"))
+    ax = plan.axis
+
+    def accumulate(windows, ext):
+        L, H = ext
+        dims = list(plan.image_size)
+        dims[ax] = H - L
+        value = torch.zeros([2] + dims)
+        weight = torch.zeros(dims)
+        for s in windows:
+            pred = _net(WO.extract_window(vol, s, roi, "constant", 0.0))[0]
+            sl = [slice(s[a], s[a] + roi[a]) for a in range(3)]
+            sl[ax] = slice(s[ax] - L, s[ax] - L + roi[ax])
+            value[(slice(None), *sl)] += pred * wmap
+            weight[tuple(sl)] += wmap
+        return value, weight
+    return accumulate
+
+
+def _worker(rank, world, port, img, roi, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    vol = torch.rand((1, 1) + img, generator=torch.Generator().manual_seed(5))
+    starts = WO.window_starts(img, roi, WO.scan_interval(img, roi, 0.5))
+    plan = plan_slabs(img, roi, starts, world)
+    slab = slab_predict(plan, rank, _oracle_accumulate(vol, roi, plan),
+                        lambda v, w: v / torch.clamp_min(w, 1e-4))          # normalize_weighted_accumulator, window.py:275-294
+    np.save(os.path.join(tmp, f"slab{rank}.npy"), np.zeros((2, 0, 0, 0), np.float32) if slab is None else slab.numpy())
+    if rank == 0:
+        np.save(os.path.join(tmp, "axis.npy"), np.asarray([plan.axis] + [b for _a, b in plan.own]))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("img,world", [((20, 30, 34), 2), ((14, 22, 50), 3)])
+def test_slab_exchange_over_gloo_matches_single_process(img, world, tmp_path):
+    roi = (8, 12, 12)
+    mp.spawn(_worker, args=(world, 29500 + (os.getpid() * 7 + world) % 2000, img, roi, str(tmp_path)), nprocs=world, join=True)
+    meta = np.load(tmp_path / "axis.npy")
+    ax = int(meta[0])
+    parts = [np.load(tmp_path / f"slab{r}.npy") for r in range(world)]
+    got = np.concatenate([p for p in parts if p.shape[ax + 1] > 0], axis=ax + 1)
+    vol = torch.rand((1, 1) + img, generator=torch.Generator().manual_seed(5))
+    ref = WO.eager_sliding_window(vol, _net, roi=roi, overlap=0.5, mode="bump", sw_batch_size=2)[0].numpy()
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
