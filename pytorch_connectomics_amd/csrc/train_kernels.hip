@@ -157,21 +157,36 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
       rx[it] = r < r_end ? *reinterpret_cast<const uint4*>(x + r * C_in + k_base + x_chunk * 8) : zero4;
     }
   };
+  // norm affine of the lane's 8 channels, cached per sample: a 32-row block never straddles two samples when
+  // rows_per_sample % 32 == 0 (every MedNeXt level at 112^3), so the sample index is tracked per wave with a
+  // compare instead of a 64-bit division per row, and (a, b) are reloaded only when it changes
+  const bool uniform_n = ab != nullptr && (rows_per_sample % 32) == 0;
+  float av[8], bv[8];
+  long n_cached = -1;
+  auto load_ab = [&](long n) {
+    const float* a = ab + (n * 2 + 0) * C_in + k_base + x_chunk * 8;
+    const float* b = ab + (n * 2 + 1) * C_in + k_base + x_chunk * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { av[i] = a[i]; bv[i] = b[i]; }
+    n_cached = n;
+  };
   auto stage = [&](long r0) {
 #pragma unroll
     for (int it = 0; it < ITG; ++it) *reinterpret_cast<uint4*>(lg + (it * RG + g_row) * SG + g_chunk * 16) = rg[it];
+    if (uniform_n) {
+      const long n = r0 / rows_per_sample;            // r0 is wave-uniform: one division per 32-row block
+      if (n != n_cached) load_ab(n);
+    }
 #pragma unroll
     for (int it = 0; it < ITX; ++it) {
       uint4 v = rx[it];
       const long r = r0 + it * RX + x_row;
       if (ab && r < r_end) {            // the forward GEMM consumed bf16(a*x+b): restate it here
-        const long n = r / rows_per_sample;
-        const float* a = ab + (n * 2 + 0) * C_in + k_base + x_chunk * 8;
-        const float* b = ab + (n * 2 + 1) * C_in + k_base + x_chunk * 8;
+        if (!uniform_n) load_ab(r / rows_per_sample);
         const bf16x8_t in = __builtin_bit_cast(bf16x8_t, v);
         f32x8_t f = __builtin_convertvector(in, f32x8_t);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) f[i] = fmaf(f[i], a[i], b[i]);
+        for (int i = 0; i < 8; ++i) f[i] = fmaf(f[i], av[i], bv[i]);
         v = __builtin_bit_cast(uint4, __builtin_convertvector(f, bf16x8_t));
       }
       if (x_act == PYTC_ACT_GELU) {     // the forward GEMM consumed bf16(gelu(x)) (fused pre-activation)
@@ -730,12 +745,22 @@ extern "C" int pytc_pw_wgrad(const void* x, const float* ab, const void* dy, flo
   PYTC_REQUIRE(x && dy && dW && workspace && N >= 1 && rows_per_sample >= 1, "pw_wgrad: bad arguments");
   PYTC_REQUIRE(x_act == PYTC_ACT_NONE || x_act == PYTC_ACT_GELU, "pw_wgrad: bad x_act");
   const long rows_total = (long)N * rows_per_sample;
-  const int slots = pytc_pw_wgrad_slots(rows_total);
+  const int mt = wg_tile16(C_out), nt = wg_tile16(C_in);
+  // pytc_pw_wgrad_slots() is the workspace bound; the launch uses fewer row slots when the channel tiles already supply
+  // workgroups: every workgroup ends with a cross-wave reduction and a C_out x C_in partial, so short slots (8 row
+  // blocks at level 1) spent most of their time there.  >= 2048 rows per slot, ~1024 workgroups at most.
+  int slots = pytc_pw_wgrad_slots(rows_total);
+  if (dtype == PYTC_BF16 && mt && nt) {
+    const long tiles = (long)(C_out / (16 * mt)) * (C_in / (16 * nt));
+    long want = rows_total / 2048;
+    const long cap = 1024 / tiles > 1 ? 1024 / tiles : 1;
+    want = want < 1 ? 1 : (want > cap ? cap : want);
+    if (want < slots) slots = (int)want;
+  }
   const long rps = (rows_total + slots - 1) / slots;
   float* dWp = workspace;
   float* dbp = workspace + (long)slots * C_out * C_in;
   hipStream_t s = (hipStream_t)stream;
-  const int mt = wg_tile16(C_out), nt = wg_tile16(C_in);
   if (dtype == PYTC_BF16 && mt && nt && tuning_get("wgrad_valu", 0) == 0) {
     // bf16, channel counts in multiples of 16: MFMA path (transpose reads from a wave-private LDS image)
     dim3 grid(slots, (C_out / (16 * mt)) * (C_in / (16 * nt)));
