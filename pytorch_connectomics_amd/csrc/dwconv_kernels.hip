@@ -346,12 +346,14 @@ dwconvT3d_k3_cell_kernel(const T* __restrict__ x, T* __restrict__ y, const float
 // ---------------------------------------------------------------------------------------------
 // Fast path: K = 3, stride 1 -- "z-march".  One workgroup owns an 8 x 8 (y,x) footprint of a 32-channel
 // group and marches along z.  Per step ONE haloed input plane (10 x 10 x 32 ch) is staged in LDS as fp32
-// (converted once, double buffered, loads for plane z+1 in flight while plane z is consumed); each thread
-// owns (position, 4 channels) for 2 positions, keeps its 27 x 4 weights in registers and carries the z
-// extent of the stencil in three rolling fp32 accumulators (outputs z-1, z, z+1), so
-//   * every LDS value (ds_read_b128, lanes contiguous -> conflict free) feeds 3 FMAs per channel,
-//   * the inner loop is FMAs only (no bf16 unpacking), 27 per output channel-voxel,
-//   * HBM sees x once (+ the y/x halo, mostly L2 hits) and y once.
+// (converted once, double buffered; the global loads of the next 2-3 planes are in flight in registers, issued as
+// inline asm and awaited with a COUNTED s_waitcnt so that younger planes survive the wait); each thread owns
+// (4 positions, 2 channels), reads the 27 x 32 taps from LDS (broadcast) and carries the z extent of the stencil in
+// three rolling fp32 accumulators (outputs z-1, z, z+1), so
+//   * every LDS data value (one volatile ds_read_b64 per tap and position) feeds 3 packed FMAs,
+//   * the tap loop is hand scheduled: reads one tap group ahead, 12 asm v_pk_fma_f32 round-robin over the 12
+//     independent accumulators -- 120 VGPRs, 4 workgroups per CU,
+//   * HBM sees x once (+ the y/x halo) and y once.
 // Statistics (sum / sum of squares of the stored values) leave as one partial per workgroup.
 constexpr int TILE_Y = 8, TILE_X = 8;
 constexpr int MARCH_CG = 32;
@@ -363,7 +365,7 @@ struct DwMarch {
   int swizzle;           // XCD-aware block remap on/off
 };
 
-template <typename T, int VEC, int PF, bool ASYNC, int WPS = 2, bool WLDS = false>
+template <typename T, int VEC, int PF, bool ASYNC, int WPS = 2>
 __global__ void __launch_bounds__(256, WPS)
 dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ w,
                          const float* __restrict__ bias, float* __restrict__ stats, DwMarch g) {
@@ -378,9 +380,8 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
   typedef float fvec_t __attribute__((ext_vector_type(VEC)));
   __shared__ __attribute__((aligned(16))) float plane[2][EY * EX * CG];
   __shared__ float red[4][2][CG];
-  // WLDS: the 27 x CG taps live in LDS instead of 54 registers per lane (lanes of one channel pair read the same
-  // address: broadcast), which brings the kernel under the 3-waves/SIMD register line
-  __shared__ __attribute__((aligned(16))) float wlds[WLDS ? 27 * CG : 1];
+  // the 27 x CG taps live in LDS, not in 54 registers per lane (lanes of one channel pair read the same address: broadcast)
+  __shared__ __attribute__((aligned(16))) float wlds[27 * CG];
 
   const int tid = threadIdx.x;
   // 1-D grid, XCD-aware: logical index = ((n * CGs + cg) * slots + slot); x-/y-neighbouring footprints
@@ -464,14 +465,8 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
   // ---- per-thread weights (27 taps x VEC channels), bias, positions
   const int cv = tid % LPV, pslot = tid / LPV;
   const int c0 = cg * CG + cv * VEC;
-  float wr[WLDS ? 1 : 27][VEC];
-  if constexpr (WLDS) {
-    for (int i = tid; i < 27 * CG; i += 256) wlds[i] = w[(long)(i / CG) * C + cg * CG + (i % CG)];
-    // visible after the __syncthreads() that follows the prologue's first commit
-  } else {
-#pragma unroll
-    for (int t = 0; t < 27; ++t) VecIO<float, VEC>::load(w + (long)t * C + c0, wr[t]);
-  }
+  for (int i = tid; i < 27 * CG; i += 256) wlds[i] = w[(long)(i / CG) * C + cg * CG + (i % CG)];
+  // (visible after the __syncthreads() that follows the prologue's first commit)
   float bv[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) bv[i] = bias ? bias[c0 + i] : 0.f;
@@ -505,7 +500,7 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
     // Unconditional accumulation: planes outside the volume were staged as zeros, and accumulators that
     // belong to outputs outside [zs, ze) are simply never stored (2 wasted planes per z-chunk), which keeps
     // the inner loop free of per-FMA selects.
-    if constexpr (WLDS) {
+    {
       // Hand-scheduled tap loop (VEC == 2).  Left to itself hipcc issues all 63 LDS reads of a step first (126 live
       // registers) and then runs each accumulator's nine FMAs back to back, with an s_nop between dependent
       // v_pk_fma_f32.  Here the order is fixed by volatile reads and asm-volatile FMAs: tap group g+1 (3 weight + 4 data
@@ -532,29 +527,6 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
           asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(prev[ps]) : "v"(vq[g & 1][ps]), "v"(wq[g & 1][2]));
         }
       }
-    } else {
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-      // WPS >= 3: keep the LDS reads of one position from being hoisted over the previous position's FMAs (the
-      // register budget of 3 waves/SIMD has no room for all 36 reads of a step in flight)
-      if constexpr (WPS >= 3) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          // ASYNC variant: volatile keeps one ds_read_b64 per tap (the merged ds_read2_b64 runs at half the LDS rate)
-          typedef const volatile __attribute__((address_space(3))) fvec_t* lds_vol_ptr;
-          const fvec_t v = ASYNC ? *(lds_vol_ptr)(&plane[slot][lbase[ps] + (dy * EX + dx) * CG])
-                                 : *reinterpret_cast<const fvec_t*>(&plane[slot][lbase[ps] + (dy * EX + dx) * CG]);
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) {
-            next[ps][i] = fmaf(v[i], wr[(0 * 3 + dy) * 3 + dx][i], next[ps][i]);
-            cur[ps][i] = fmaf(v[i], wr[(1 * 3 + dy) * 3 + dx][i], cur[ps][i]);
-            prev[ps][i] = fmaf(v[i], wr[(2 * 3 + dy) * 3 + dx][i], prev[ps][i]);
-          }
-        }
-      }
-    }
     }
     if (gz + 1 <= ze) {
       landed(cm, gz + PF <= ze);
@@ -1029,7 +1001,7 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
     //   0 (default) PF=3 compiled for 4 waves/SIMD; 1: PF=3, 3 waves; 2: PF=3, 2 waves; 3: PF=2, 3 waves
     const int variant = tuning_get("dwconv_march_variant", 0);
 #define PYTC_MARCH(PP, WW) \
-  hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, PP, true, WW, true>), grid, block, 0, (hipStream_t)stream, \
+  hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, PP, true, WW>), grid, block, 0, (hipStream_t)stream, \
                      (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t)
     if (dtype == PYTC_BF16) {
       switch (variant) {
@@ -1039,7 +1011,7 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
         default: PYTC_MARCH(3, 4); break;
       }
     } else {
-      hipLaunchKernelGGL((dwconv3d_k3_march_kernel<float, 2, 1, false, 2, true>), grid, block, 0, (hipStream_t)stream,
+      hipLaunchKernelGGL((dwconv3d_k3_march_kernel<float, 2, 1, false, 2>), grid, block, 0, (hipStream_t)stream,
                          (const float*)x, (float*)y, w, bias, stats, t);
     }
 #undef PYTC_MARCH
