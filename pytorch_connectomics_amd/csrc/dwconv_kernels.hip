@@ -2,6 +2,7 @@
 // coalesced vector of VEC channels), fused with the per-(n,c) sum / sum-of-squares the
 // following GroupNorm(C, C) needs.  Statistics are written as per-workgroup partials and
 // reduced in a fixed order by groupnorm_finalize -> bit-reproducible, no float atomics.
+#include <type_traits>
 #include "pytc_common.h"
 
 namespace pytc {
@@ -689,24 +690,28 @@ dw_wgrad_march_kernel(const T* __restrict__ gr, const T* __restrict__ x, float* 
     const int yy = vox / EX, xx = vox % EX;
     const int gy = y0 - 1 + yy, gx = x0 - 1 + xx;
     cok[i] = (c < NCHUNK) && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
-    goff[i] = (gy * g.W + gx) * C + part * EPC;
+    // every lane always loads from a clamped address (zero-filled at commit): no branch around a load, so hipcc can
+    // count its waits and the loads of two steps stay in flight
+    goff[i] = (min(max(gy, 0), g.H - 1) * g.W + min(max(gx, 0), g.W - 1)) * C + part * EPC;
     loff[i] = (c < NCHUNK) ? vox * CG + part * EPC : -1;
   }
-  uint4 stg[CPT];
-  auto issue = [&](int gz) {
-    const bool zok = gz >= 0 && gz < g.D;
+  uint4 stgA[CPT], stgB[CPT];
+  auto issue = [&](int gz, uint4 (&stg)[CPT]) {
+    const int zc = min(max(gz, 0), g.D - 1);
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      stg[i] = make_uint4(0u, 0u, 0u, 0u);
-      if (zok && cok[i]) stg[i] = *reinterpret_cast<const uint4*>(xn + (long)gz * plane_elems + goff[i]);
-    }
+    for (int i = 0; i < CPT; ++i) stg[i] = *reinterpret_cast<const uint4*>(xn + (long)zc * plane_elems + goff[i]);
   };
-  auto commit = [&](int slot) {
+  auto commit = [&](int slot, uint4 (&stg)[CPT], int gz) {
+    const bool zok = gz >= 0 && gz < g.D;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       if (loff[i] < 0) continue;
       float v[EPC];
       VecIO<T, EPC>::load(reinterpret_cast<const T*>(&stg[i]), v);
+      if (!(zok && cok[i])) {
+#pragma unroll
+        for (int q = 0; q < EPC; ++q) v[q] = 0.f;
+      }
       float* dst = &plane[slot][loff[i]];
 #pragma unroll
       for (int q = 0; q < EPC; q += 4)
@@ -724,7 +729,7 @@ dw_wgrad_march_kernel(const T* __restrict__ gr, const T* __restrict__ x, float* 
     const int py = pos / TILE_X, px = pos % TILE_X;
     lbase[ps] = (py * EX + px) * CG + cv * VEC;
     pok[ps] = (y0 + py) < g.H && (x0 + px) < g.W;
-    obase[ps] = ((long)(y0 + py) * g.W + (x0 + px)) * C + cv * VEC;
+    obase[ps] = ((long)min(y0 + py, g.H - 1) * g.W + min(x0 + px, g.W - 1)) * C + cv * VEC;   // clamped, see pok
   }
   fvec_t acc[27];
   float accb[VEC];
@@ -734,31 +739,47 @@ dw_wgrad_march_kernel(const T* __restrict__ gr, const T* __restrict__ x, float* 
     for (int i = 0; i < VEC; ++i) acc[t][i] = 0.f;
 #pragma unroll
   for (int i = 0; i < VEC; ++i) accb[i] = 0.f;
-  fvec_t gA[PASSES], gB[PASSES], gC[PASSES], gq[PASSES];
-  auto gload = [&](int gz, fvec_t (&dst)[PASSES]) {      // G plane gz at the lane's positions (0 outside the chunk)
+  // G planes: three converted sets roll through prev / cur / next; two RAW sets hold the loads of G[gz+2] (issued one
+  // step ago) and G[gz+3] (issued this step) so that a G load has two steps to land
+  typedef typename std::conditional<sizeof(T) == 2, unsigned int, fvec_t>::type graw_t;
+  fvec_t gA[PASSES], gB[PASSES], gC[PASSES];
+  graw_t grawA[PASSES], grawB[PASSES];
+  auto graw_load = [&](int gz, graw_t (&dst)[PASSES]) {
+    const int zc = min(max(gz, 0), g.D - 1);
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) dst[ps] = *reinterpret_cast<const graw_t*>(gn + (long)zc * plane_elems + obase[ps]);
+  };
+  auto gconv = [&](int gz, const graw_t (&src)[PASSES], fvec_t (&dst)[PASSES]) {   // 0 outside the chunk / the volume
     const bool zok = gz >= zs && gz < ze;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) dst[ps][i] = 0.f;
-      if (zok && pok[ps]) {
-        float gv[VEC];
-        VecIO<T, VEC>::load(gn + (long)gz * plane_elems + obase[ps], gv);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) dst[ps][i] = gv[i];
+      fvec_t v;
+      if constexpr (sizeof(T) == 2) {
+        v[0] = __uint_as_float(src[ps] << 16);
+        v[1] = __uint_as_float(src[ps] & 0xffff0000u);
+      } else {
+        v = src[ps];
       }
+      const bool ok = zok && pok[ps];
+      dst[ps][0] = ok ? v[0] : 0.f;
+      dst[ps][1] = ok ? v[1] : 0.f;
     }
   };
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { gA[ps][i] = 0.f; gB[ps][i] = 0.f; }
-  gload(zs, gC);
+  graw_load(zs, grawA);
+  gconv(zs, grawA, gC);
+  graw_load(zs + 1, grawB);
 
   // one z step: X plane gz is in plane[slot]; prev/cur/next = G[gz-1] / G[gz] / G[gz+1]
-  auto step = [&](int gz, int slot, fvec_t (&prev)[PASSES], fvec_t (&cur)[PASSES], fvec_t (&next)[PASSES]) {
-    if (gz + 1 <= ze) issue(gz + 1);
-    gload(gz + 2, gq);
+  // `ld` / `gl` receive this step's loads (X plane gz+2, G plane gz+3); `cm` / `gc` were loaded one step ago (X plane
+  // gz+1, G plane gz+2) and are consumed at the end of the step
+  auto step = [&](int gz, int slot, fvec_t (&prev)[PASSES], fvec_t (&cur)[PASSES], fvec_t (&next)[PASSES],
+                  uint4 (&ld)[CPT], uint4 (&cm)[CPT], graw_t (&gl)[PASSES], graw_t (&gc)[PASSES]) {
+    issue(gz + 2, ld);
+    graw_load(gz + 3, gl);
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps)
 #pragma unroll
@@ -786,22 +807,24 @@ dw_wgrad_march_kernel(const T* __restrict__ gr, const T* __restrict__ x, float* 
         }
       }
     }
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps)
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) prev[ps][i] = gq[ps][i];      // the freed set becomes G[gz+2]
-    if (gz + 1 <= ze) commit(slot ^ 1);
+    gconv(gz + 2, gc, prev);                                       // the freed set becomes G[gz+2]
+    if (gz + 1 <= ze) commit(slot ^ 1, cm, gz + 1);
     __syncthreads();
   };
 
-  issue(zs - 1);
-  commit(0);
+  issue(zs - 1, stgA);
+  issue(zs, stgB);
+  commit(0, stgA, zs - 1);
   __syncthreads();
   int slot = 0;
-  for (int gz = zs - 1; gz <= ze; gz += 3) {
-    step(gz, slot, gA, gB, gC); slot ^= 1;
-    if (gz + 1 <= ze) { step(gz + 1, slot, gB, gC, gA); slot ^= 1; }
-    if (gz + 2 <= ze) { step(gz + 2, slot, gC, gA, gB); slot ^= 1; }
+  // accumulator sets rotate with period 3, staging sets with period 2: six steps per trip
+  for (int gz = zs - 1; gz <= ze; gz += 6) {
+    step(gz, slot, gA, gB, gC, stgA, stgB, grawA, grawB); slot ^= 1;
+    if (gz + 1 <= ze) { step(gz + 1, slot, gB, gC, gA, stgB, stgA, grawB, grawA); slot ^= 1; }
+    if (gz + 2 <= ze) { step(gz + 2, slot, gC, gA, gB, stgA, stgB, grawA, grawB); slot ^= 1; }
+    if (gz + 3 <= ze) { step(gz + 3, slot, gA, gB, gC, stgB, stgA, grawB, grawA); slot ^= 1; }
+    if (gz + 4 <= ze) { step(gz + 4, slot, gB, gC, gA, stgA, stgB, grawA, grawB); slot ^= 1; }
+    if (gz + 5 <= ze) { step(gz + 5, slot, gC, gA, gB, stgB, stgA, grawB, grawA); slot ^= 1; }
   }
 
   // lanes cv, cv+16, cv+32, cv+48 hold the same channel pair: xor-shuffle sum, then waves through LDS in order
