@@ -88,9 +88,9 @@ pw_fast_kernel(PwFastParams p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], av[j], bv[j]);
           }
-          if (p.pre_act == PYTC_ACT_GELU) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+          if (p.pre_act == PYTC_ACT_GELU) {   // sigmoid-form GELU (|err| <= 2.5e-5, below the bf16 rounding of its result);
+#pragma unroll                           // the weight-gradient kernel recomputes the same function
+            for (int j = 0; j < 8; ++j) v[j] = gelu_fast(v[j]);
           }
           bact[ks][nt] = Mma<bf16_t>::from_floats(v);
         }

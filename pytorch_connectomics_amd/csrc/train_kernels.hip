@@ -192,7 +192,7 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
       if (x_act == PYTC_ACT_GELU) {     // the forward GEMM consumed bf16(gelu(x)) (fused pre-activation)
         f32x8_t f = __builtin_convertvector(__builtin_bit_cast(bf16x8_t, v), f32x8_t);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) f[i] = gelu_erf(f[i]);
+        for (int i = 0; i < 8; ++i) f[i] = gelu_fast(f[i]);      // the function pw_fast's prologue applied in the forward
         v = __builtin_bit_cast(uint4, __builtin_convertvector(f, bf16x8_t));
       }
       *reinterpret_cast<uint4*>(lx + (it * RX + x_row) * SX + x_chunk * 16) = v;

@@ -258,7 +258,9 @@ def test_pw_conv_paired_row_kernel_matches_generic(ci, co, mode):
     y1 = ops.pw_conv(x, ops.pw_pack_weight_paired(w), b, w_paired=True, **common)
     d = (y0.float() - y1.float()).abs()
     assert float(d.max()) <= 2 ** -6 * max(1.0, float(y0.float().abs().max()))      # one bf16 ulp at most
-    assert float((d > 0).float().mean()) < 0.02
+    # the paired-row kernel applies the sigmoid-form GELU (|err| <= 2.5e-5) where the generic one uses erf: a few more
+    # outputs sit on the other side of a bf16 rounding boundary
+    assert float((d > 0).float().mean()) < (0.06 if mode == "gelu_add" else 0.02)
     assert not ops.pw_conv_paired_supported(c_in=24, c_out=64, in_dtype=torch.bfloat16, out_dtype=torch.bfloat16)
     assert not ops.pw_conv_paired_supported(c_in=32, c_out=64, in_dtype=torch.float32, out_dtype=torch.float32,
                                             w_dtype=torch.float32)
