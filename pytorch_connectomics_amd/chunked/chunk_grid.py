@@ -2,46 +2,48 @@
 row-major (z outermost) order, the last chunk per axis clipped to the volume; key = "z{z}_y{y}_x{x}"."""
 from __future__ import annotations
 
+import itertools
 from dataclasses import dataclass
-from typing import Sequence
+from typing import List, Sequence, Tuple
+
+Int3 = Tuple[int, int, int]
 
 
 @dataclass(frozen=True)
 class ChunkRef:
-    index: tuple[int, int, int]
-    start: tuple[int, int, int]
-    stop: tuple[int, int, int]
+    """One cell of the grid: its (z, y, x) grid index and the half-open voxel box [start, stop) it covers."""
+    index: Int3
+    start: Int3
+    stop: Int3
 
     @property
     def key(self) -> str:
-        return "z{}_y{}_x{}".format(*self.index)
+        iz, iy, ix = self.index
+        return f"z{iz}_y{iy}_x{ix}"
 
     @property
-    def shape(self) -> tuple[int, int, int]:
-        return tuple(b - a for a, b in zip(self.start, self.stop))
+    def shape(self) -> Int3:
+        return (self.stop[0] - self.start[0], self.stop[1] - self.start[1], self.stop[2] - self.start[2])
 
     @property
-    def slices(self) -> tuple[slice, slice, slice]:
-        return tuple(slice(a, b) for a, b in zip(self.start, self.stop))
+    def slices(self):
+        return tuple(slice(lo, hi) for lo, hi in zip(self.start, self.stop))
 
 
-def build_chunk_grid(volume_shape: Sequence[int], chunk_shape: Sequence[int]) -> list[ChunkRef]:
-    vol = tuple(int(v) for v in volume_shape)
-    ch = tuple(int(v) for v in chunk_shape)
-    if len(vol) != 3 or len(ch) != 3:
+def build_chunk_grid(volume_shape: Sequence[int], chunk_shape: Sequence[int]) -> List[ChunkRef]:
+    dims = [int(v) for v in volume_shape]
+    cell = [int(v) for v in chunk_shape]
+    if len(dims) != 3 or len(cell) != 3:
         raise ValueError("volume_shape and chunk_shape must both be length-3 tuples.")
-    if any(c <= 0 for c in ch):
-        raise ValueError(f"chunk_shape must be positive, got {ch}")
-    nz, ny, nx = (-(-v // c) for v, c in zip(vol, ch))
-    out = []
-    for iz in range(nz):
-        for iy in range(ny):
-            for ix in range(nx):
-                idx = (iz, iy, ix)
-                start = tuple(i * c for i, c in zip(idx, ch))
-                stop = tuple(min(s + c, v) for s, c, v in zip(start, ch, vol))
-                out.append(ChunkRef(index=idx, start=start, stop=stop))
-    return out
+    if min(cell) <= 0:
+        raise ValueError(f"chunk_shape must be positive, got {tuple(cell)}")
+    counts = [(d + c - 1) // c for d, c in zip(dims, cell)]
+    grid = []
+    for idx in itertools.product(*(range(n) for n in counts)):        # z outermost, x fastest
+        lo = tuple(i * c for i, c in zip(idx, cell))
+        hi = tuple(min(a + c, d) for a, c, d in zip(lo, cell, dims))
+        grid.append(ChunkRef(index=tuple(idx), start=lo, stop=hi))
+    return grid
 
 
 __all__ = ["ChunkRef", "build_chunk_grid"]
