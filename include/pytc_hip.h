@@ -341,6 +341,37 @@ int pytc_norm_bwd(const void* dtn, const void* t, const float* mean_rstd, const 
 int pytc_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, int N, const int32_t* xdims,
                            const int32_t* ydims, int C, int K, int stride, int dtype, void* stream);
 
+/* ---------------------------------------------------------------- dense-conv (RSUNet) training ---------- */
+/* Backward of the RSUNet building blocks (rsunet.py:73-259 through torch autograd in the reference).  The data
+ * gradient of a dense conv is pytc_conv3d_fwd with flipped / transposed weights.
+ * pytc_conv3d_wgrad: dW[tap][o][k] = sum_r dY[r][o] * A[r + shift(tap)][k] (A = the conv's activated input, zero padded,
+ *   odd kernel sizes, stride 1); workspace: pytc_conv3d_wgrad_slots(rows) * taps * C_out * C_in floats.
+ * pytc_act_bwd: dt = da * act'(t), t = a[n][c]*x + b[n][c] (ab may be NULL: t = x); dp (may be NULL) = da * min(t, 0),
+ *   the summand of the PReLU weight gradient.  act in {RELU, LEAKY (prm = slope), ELU (prm = alpha), NONE}.
+ * pytc_norm_finalize_groups_mr: pytc_norm_finalize_groups that also returns (mean, rstd) per (n, c) in mr [N][2][C].
+ * pytc_norm_bwd_stats: s_out [N][2][C] = (sum d, sum d * xhat); workspace pytc_norm_bwd_ws_elems floats.
+ * pytc_norm_bwd_apply_general: dx = rstd * (gamma*d - M1 - xhat*M2) with M [N][2][C] the means of (gamma*d) and
+ *   (gamma*d*xhat) over the statistics group of (n, c), expanded per channel (GroupNorm / InstanceNorm / BatchNorm).
+ * pytc_maxpool3d_bwd: dx = 0 except the first maximum of every window, which receives dy (nn.MaxPool3d backward).
+ * pytc_dwconv3d_generic_fwd: anisotropic depthwise conv (kernel / stride / pad per axis), the backward-data of
+ *   pytc_dwconvT3d_generic_fwd (BilinearUp3d, rsunet.py:33-70). */
+int pytc_conv3d_wgrad_slots(int64_t rows_total);
+int pytc_conv3d_wgrad(const void* a, const void* dy, float* dW, float* workspace, int N, int D, int H, int W, int C_in,
+                      int C_out, const int32_t* kernel, int dtype, void* stream);
+int pytc_act_bwd(const void* da, const void* x, const float* ab, void* dt, void* dp, int N, int64_t rows, int C, int act,
+                 float prm, int dtype, void* stream);
+int pytc_norm_finalize_groups_mr(const float* stats, int slots, float count, const float* gamma, const float* beta,
+                                 float eps, int groups, float* ab, float* mr, int N, int C, void* stream);
+int pytc_norm_bwd_stats(const void* dtn, const void* t, const float* mean_rstd, float* stats_ws, float* s_out, int N,
+                        int64_t rows, int C, int dtype, void* stream);
+int pytc_norm_bwd_apply_general(const void* d, const void* x, const float* mean_rstd, const float* gamma, const float* M,
+                                void* dx, int N, int64_t rows, int C, int dtype, void* stream);
+int pytc_maxpool3d_bwd(const void* x, const void* dy, void* dx, int N, int D, int H, int W, int C, int fz, int fy, int fx,
+                       int dtype, void* stream);
+int pytc_dwconv3d_generic_fwd(const void* x, void* y, const float* w, int N, int D, int H, int W, int C,
+                              const int32_t* kernel, const int32_t* stride, const int32_t* pad, const int32_t* out_dims,
+                              int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,7 +33,9 @@ def bilinear_kernel(channels: int, factor: Sequence[int]) -> torch.Tensor:
 
 def _norm_act(x, st, prefix, norm, activation, num_groups, act_kwargs):
     c = x.shape[1]
-    if norm == "batch":   # eval-mode statistics
+    if norm == "batch" and act_kwargs.get("bn_training", False):   # training-mode statistics (no running update)
+        x = F.batch_norm(x, None, None, st[prefix + ".norm.weight"], st[prefix + ".norm.bias"], True, 0.0, 1e-5)
+    elif norm == "batch":   # eval-mode statistics
         x = F.batch_norm(x, st[prefix + ".norm.running_mean"], st[prefix + ".norm.running_var"],
                          st[prefix + ".norm.weight"], st[prefix + ".norm.bias"], False, 0.0, 1e-5)
     elif norm == "group":

@@ -123,6 +123,22 @@ _SIGS = {
                                 C.c_int, C.c_int64, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "pytc_dwconv3d_bwd_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32),
                                          C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_conv3d_wgrad_slots": (C.c_int, [C.c_int64]),
+    "pytc_conv3d_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
+    "pytc_act_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int,
+                               C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "pytc_norm_finalize_groups_mr": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
+                                               C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_norm_bwd_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int,
+                                      C.c_int, C.c_void_p]),
+    "pytc_norm_bwd_apply_general": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_maxpool3d_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_dwconv3d_generic_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
     "pytc_pw_mlp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pytc_pw_pack_weight_paired": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pytc_pw_mlp_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p]),

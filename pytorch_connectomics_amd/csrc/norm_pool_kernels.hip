@@ -43,7 +43,8 @@ channel_stats_kernel(const T* __restrict__ x, float* __restrict__ stats, long ro
 // ---- norm finalize with channel groups: ab[N][2][C] ------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 norm_finalize_groups_kernel(const float* __restrict__ stats, int slots, float count, const float* __restrict__ gamma,
-                            const float* __restrict__ beta, float eps, int groups, float* __restrict__ ab, int C) {
+                            const float* __restrict__ beta, float eps, int groups, float* __restrict__ ab, int C,
+                            float* __restrict__ mr = nullptr) {
   // one workgroup per (n, group); deterministic two-level reduction
   __shared__ float red[2][256];
   const int n = blockIdx.y, g = blockIdx.x;
@@ -76,6 +77,10 @@ norm_finalize_groups_kernel(const float* __restrict__ stats, int slots, float co
     const float a = (gamma ? gamma[c] : 1.f) * rstd;
     ab[((long)n * 2 + 0) * C + c] = a;
     ab[((long)n * 2 + 1) * C + c] = (beta ? beta[c] : 0.f) - mean * a;
+    if (mr) {
+      mr[((long)n * 2 + 0) * C + c] = mean;
+      mr[((long)n * 2 + 1) * C + c] = rstd;
+    }
   }
 }
 
@@ -212,6 +217,16 @@ extern "C" int pytc_norm_finalize_groups(const float* stats, int slots, float co
   hipLaunchKernelGGL(norm_finalize_groups_kernel, dim3(groups, N), dim3(256), 0, (hipStream_t)stream, stats, slots,
                      count, gamma, beta, eps, groups, ab, C);
   PYTC_LAUNCH_CHECK("norm_finalize_groups");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_norm_finalize_groups_mr(const float* stats, int slots, float count, const float* gamma,
+                                            const float* beta, float eps, int groups, float* ab, float* mr, int N, int C,
+                                            void* stream) {
+  PYTC_REQUIRE(stats && ab && mr && slots >= 1 && count > 0 && groups >= 1 && C % groups == 0, "norm_finalize_groups_mr: bad arguments");
+  hipLaunchKernelGGL(norm_finalize_groups_kernel, dim3(groups, N), dim3(256), 0, (hipStream_t)stream, stats, slots,
+                     count, gamma, beta, eps, groups, ab, C, mr);
+  PYTC_LAUNCH_CHECK("norm_finalize_groups_mr");
   return PYTC_OK;
 }
 

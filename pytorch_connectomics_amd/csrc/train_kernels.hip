@@ -948,6 +948,33 @@ extern "C" int pytc_norm_bwd(const void* dtn, const void* t, const float* mean_r
   return PYTC_OK;
 }
 
+/* statistics pass only: s_out [N][2][C] = (sum d, sum d * xhat) per (sample, channel) */
+extern "C" int pytc_norm_bwd_stats(const void* dtn, const void* t, const float* mean_rstd, float* stats_ws, float* s_out,
+                                   int N, int64_t rows, int C, int dtype, void* stream) {
+  PYTC_REQUIRE(dtn && t && mean_rstd && stats_ws && s_out, "norm_bwd_stats: null pointer");
+  const int slots = colstats_slots(rows);
+  const long rps = (rows + slots - 1) / slots;
+  const int Cw = C < 256 ? C : 256;
+  size_t lds = (size_t)(256 / Cw) * 2 * Cw * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(slots, N), block(256);
+  const bool vec = dtype == PYTC_BF16 ? (C % 8 == 0) : (C % 4 == 0);
+  if (vec) {
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((colstats_kernel<bf16_t, 1>), grid, block, 0, s, (const bf16_t*)dtn, (const bf16_t*)t, mean_rstd, stats_ws, (long)rows, C, slots, rps),
+               hipLaunchKernelGGL((colstats_kernel<float, 1>), grid, block, 0, s, (const float*)dtn, (const float*)t, mean_rstd, stats_ws, (long)rows, C, slots, rps),
+               "norm_bwd_stats")
+  } else {
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(norm_bwd_stats_kernel<bf16_t>, grid, block, lds, s, (const bf16_t*)dtn, (const bf16_t*)t, mean_rstd, stats_ws, (long)rows, C, slots, rps),
+               hipLaunchKernelGGL(norm_bwd_stats_kernel<float>, grid, block, lds, s, (const float*)dtn, (const float*)t, mean_rstd, stats_ws, (long)rows, C, slots, rps),
+               "norm_bwd_stats")
+  }
+  hipLaunchKernelGGL(reduce_slots_batched_kernel, dim3(ceil_div(2L * C, 16), N), dim3(256), 0, s, stats_ws, s_out, 2L * C, slots);
+  PYTC_LAUNCH_CHECK("norm_bwd_stats");
+  return PYTC_OK;
+}
+
 extern "C" int pytc_norm_bwd_ws_elems(int N, int64_t rows, int C) {
   const int slots = colstats_slots(rows);
   return (int)((long)N * slots * 2 * C);

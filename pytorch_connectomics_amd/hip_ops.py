@@ -444,6 +444,88 @@ def _i3(v):
     return (C.c_int32 * 3)(*[int(a) for a in v])
 
 
+# ---- dense-conv (RSUNet) training ops ---------------------------------------------------------------------------------
+def norm_finalize_groups_mr(stats: torch.Tensor, count: float, gamma, beta, eps: float, groups: int):
+    """-> (ab (N,2,C), mean_rstd (N,2,C))"""
+    N, slots, _, Cc = stats.shape
+    ab = torch.empty((N, 2, Cc), dtype=torch.float32, device=stats.device)
+    mr = torch.empty((N, 2, Cc), dtype=torch.float32, device=stats.device)
+    _run("norm_finalize_groups", _nbytes(stats, ab, mr), nat.lib().pytc_norm_finalize_groups_mr, _p(stats), slots,
+         float(count), _p(gamma), _p(beta), float(eps), int(groups), _p(ab), _p(mr), N, Cc, _stream())
+    return ab, mr
+
+
+def conv3d_wgrad(a: torch.Tensor, dy: torch.Tensor, kernel) -> torch.Tensor:
+    """a (N,D,H,W,C_in) = the conv's (activated) input, dy (N,D,H,W,C_out) -> dW fp32 (C_out, C_in, kd, kh, kw)."""
+    _dev(a, "a"); _dev(dy, "dy")
+    N, D, H, W, ci = a.shape
+    co = dy.shape[-1]
+    kd, kh, kw = (int(v) for v in kernel)
+    taps = kd * kh * kw
+    slots = nat.lib().pytc_conv3d_wgrad_slots(N * D * H * W)
+    ws = torch.empty((slots * taps * co * ci,), dtype=torch.float32, device=a.device)
+    dW = torch.empty((taps, co, ci), dtype=torch.float32, device=a.device)
+    _run(f"conv3d_wgrad[{ci}->{co},k{kd}{kh}{kw}]", taps * _nbytes(a, dy), nat.lib().pytc_conv3d_wgrad, _p(a), _p(dy), _p(dW),
+         _p(ws), N, D, H, W, ci, co, _i3((kd, kh, kw)), dtype_code(a.dtype), _stream())
+    return dW.view(kd, kh, kw, co, ci).permute(3, 4, 0, 1, 2).contiguous()
+
+
+def act_bwd(da: torch.Tensor, x: torch.Tensor, ab: Optional[torch.Tensor], act: int, param: float = 0.0, *,
+            want_prelu: bool = False):
+    """dt = da * act'(a*x + b); with want_prelu also dp = da * min(t, 0) (summed by the caller)."""
+    _dev(da, "da"); _dev(x, "x")
+    N, Cc = x.shape[0], x.shape[-1]
+    rows = x.numel() // (N * Cc)
+    dt = torch.empty_like(x)
+    dp = torch.empty_like(x) if want_prelu else None
+    _run("act_bwd", _nbytes(da, x, dt), nat.lib().pytc_act_bwd, _p(da), _p(x), _p(ab), _p(dt), _p(dp), N, rows, Cc, int(act),
+         float(param), dtype_code(x.dtype), _stream())
+    return dt, dp
+
+
+def norm_bwd_stats(d: torch.Tensor, x: torch.Tensor, mean_rstd: torch.Tensor) -> torch.Tensor:
+    """-> (N, 2, C): (sum d, sum d * xhat) per (sample, channel)"""
+    _dev(d, "d"); _dev(x, "x")
+    N, Cc = x.shape[0], x.shape[-1]
+    rows = x.numel() // (N * Cc)
+    ws = torch.empty((nat.lib().pytc_norm_bwd_ws_elems(N, rows, Cc),), dtype=torch.float32, device=x.device)
+    s = torch.empty((N, 2, Cc), dtype=torch.float32, device=x.device)
+    _run(f"norm_bwd_stats[C{Cc}]", _nbytes(d, x), nat.lib().pytc_norm_bwd_stats, _p(d), _p(x), _p(mean_rstd), _p(ws), _p(s), N,
+         rows, Cc, dtype_code(x.dtype), _stream())
+    return s
+
+
+def norm_bwd_apply_general(d: torch.Tensor, x: torch.Tensor, mean_rstd: torch.Tensor, gamma, M: torch.Tensor) -> torch.Tensor:
+    _dev(d, "d"); _dev(x, "x")
+    N, Cc = x.shape[0], x.shape[-1]
+    rows = x.numel() // (N * Cc)
+    dx = torch.empty_like(x)
+    _run(f"norm_bwd_apply[C{Cc}]", _nbytes(d, x, dx), nat.lib().pytc_norm_bwd_apply_general, _p(d), _p(x), _p(mean_rstd),
+         _p(gamma), _p(M), _p(dx), N, rows, Cc, dtype_code(x.dtype), _stream())
+    return dx
+
+
+def maxpool3d_bwd(x: torch.Tensor, dy: torch.Tensor, factor) -> torch.Tensor:
+    _dev(x, "x"); _dev(dy, "dy")
+    N, D, H, W, Cc = x.shape
+    fz, fy, fx = (int(v) for v in factor)
+    dx = torch.empty_like(x)
+    _run("maxpool3d_bwd", _nbytes(x, dy, dx), nat.lib().pytc_maxpool3d_bwd, _p(x), _p(dy), _p(dx), N, D, H, W, Cc, fz, fy, fx,
+         dtype_code(x.dtype), _stream())
+    return dx
+
+
+def dwconv3d_generic(x: torch.Tensor, w_taps: torch.Tensor, kernel, stride, pad, out_dims) -> torch.Tensor:
+    """Depthwise conv with per-axis kernel / stride / pad (gather form); w_taps fp32 (kd*kh*kw, C)."""
+    _dev(x, "x")
+    N, D, H, W, Cc = x.shape
+    od = tuple(int(v) for v in out_dims)
+    y = torch.empty((N,) + od + (Cc,), dtype=x.dtype, device=x.device)
+    _run("dwconv3d_generic", _nbytes(x, y), nat.lib().pytc_dwconv3d_generic_fwd, _p(x), _p(y), _p(w_taps), N, D, H, W, Cc,
+         _i3(kernel), _i3(stride), _i3(pad), _i3(od), dtype_code(x.dtype), _stream())
+    return y
+
+
 def groupnorm_finalize_mr(stats: torch.Tensor, count: float, gamma, beta, eps: float = 1e-5):
     """-> (ab (N,2,C), mean_rstd (N,2,C))"""
     N, slots, _, Cc = stats.shape

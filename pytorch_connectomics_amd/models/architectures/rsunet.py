@@ -13,7 +13,9 @@ torch.nn children are parameter holders.  `forward` runs hand-written gfx950 ker
                       add as epilogue, then ConvBlock
   heads               1x1 conv with bias (final NormAct fused as prologue)
 
-Inference only (BatchNorm in training mode / autograd are not supported); no CPU path.
+The fused kernels above are the inference path; with autograd enabled `forward` runs the un-fused training schedule of
+training/rsunet_autograd.py (every forward and backward op a HIP kernel; BatchNorm uses batch statistics and updates
+its running buffers like nn.BatchNorm3d).  No CPU path.
 """
 from __future__ import annotations
 
@@ -296,7 +298,11 @@ class RSUNet(ConnectomicsModel):
         if x.dim() != 5:
             raise ValueError(f"RSUNet expects (B, C, D, H, W), got {tuple(x.shape)}")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("RSUNet backward kernels are not built yet: run under torch.no_grad()")
+            # training: autograd Functions whose forward and backward are HIP kernels (training/rsunet_autograd.py)
+            from ...training.rsunet_autograd import rsunet_train_forward
+            res = rsunet_train_forward(self, to_channels_last(x.float()), resolve_compute_dtype(self.compute_dtype))
+            out = {k: v.permute(0, 4, 1, 2, 3) for k, v in res.items()}
+            return out if self.supports_deep_supervision else out["output"]
         out = {k: to_channels_first(v) for k, v in self._forward_cl(to_channels_last(x.float())).items()}
         return out if self.supports_deep_supervision else out["output"]
 

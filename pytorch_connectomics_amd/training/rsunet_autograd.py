@@ -1,0 +1,236 @@
+"""RSUNet training on HIP kernels: autograd Functions for the building blocks of
+models/architectures/rsunet.py (reference rsunet.py:73-259, differentiated by torch autograd there).
+
+The training forward is the un-fused schedule (the inference path keeps its fused kernels):
+    NormAct      statistics -> finalize (affine + mean/rstd) -> affine_act            (activated tensor is materialised)
+    Conv3d       implicit-GEMM forward kernel (+ residual epilogue)
+    MaxPool3d / BilinearUp3d / 1x1 projection
+and every backward piece is a HIP kernel: conv data gradient = the forward kernel with flipped / transposed weights,
+`conv3d_wgrad`, `act_bwd`, `norm_bwd_stats` + `norm_bwd_apply_general` (GroupNorm / InstanceNorm / BatchNorm share one
+formula, only the statistics group differs), `maxpool3d_bwd`, `dwconv3d_generic`.  The (N, 2, C)-sized combinations of
+statistics into group means are torch ops on tiny tensors.  Correctness-first kernels (VALU weight gradient).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _native as nat
+from .. import hip_ops as ops
+
+_ACT = {"relu": nat.ACT_RELU, "leakyrelu": nat.ACT_LEAKY, "prelu": nat.ACT_LEAKY, "elu": nat.ACT_ELU}
+
+
+def _f(p):
+    return None if p is None else p.detach().float().reshape(-1).contiguous()
+
+
+def _rows(x):
+    return x.numel() // (x.shape[0] * x.shape[-1])
+
+
+class NormActFn(torch.autograd.Function):
+    """a = act(norm(x)) on channels-last x.  kind in {none, group, instance, batch}."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, prelu_w, kind: str, groups: int, eps: float, act_kind: str, act_prm: float, bn):
+        N, C = x.shape[0], x.shape[-1]
+        rows = _rows(x)
+        act = _ACT[act_kind]
+        prm = float(prelu_w.detach().reshape(-1)[0]) if act_kind == "prelu" else float(act_prm)
+        ab = mr = None
+        mode = kind
+        if kind in ("group", "instance"):
+            st = ops.channel_stats(x)
+            g = groups if kind == "group" else C
+            ab, mr = ops.norm_finalize_groups_mr(st, rows, _f(gamma), _f(beta), eps, g)
+        elif kind == "batch":
+            if bn.training:
+                st = ops.channel_stats(x)
+                st1 = st.reshape(1, st.shape[0] * st.shape[1], 2, C)
+                ab1, mr1 = ops.norm_finalize_groups_mr(st1, N * rows, _f(gamma), _f(beta), eps, C)
+                ab, mr = ab1.expand(N, 2, C).contiguous(), mr1.expand(N, 2, C).contiguous()
+                if bn.track_running_stats:
+                    with torch.no_grad():
+                        n = float(N * rows)
+                        mean = mr1[0, 0]
+                        var = (1.0 / (mr1[0, 1] * mr1[0, 1]) - eps).clamp_min(0.0) * (n / max(n - 1.0, 1.0))
+                        mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                        bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
+                        bn.running_var.mul_(1 - mom).add_(var.to(bn.running_var.dtype), alpha=mom)
+                        bn.num_batches_tracked += 1
+            else:
+                a = gamma.detach().float() / torch.sqrt(bn.running_var.float() + eps)
+                b = beta.detach().float() - bn.running_mean.float() * a
+                ab = torch.stack([a, b], 0).unsqueeze(0).expand(N, 2, C).contiguous()
+                mode = "batch_eval"
+        out = ops.affine_act(x, ab, act, prm)
+        ctx.save_for_backward(x, ab if ab is not None else x.new_zeros(0), mr if mr is not None else x.new_zeros(0),
+                              gamma if gamma is not None else x.new_zeros(0))
+        ctx.meta = (mode, groups, act, prm, act_kind == "prelu", gamma is not None, beta is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, da):
+        x, ab, mr, gamma = ctx.saved_tensors
+        mode, groups, act, prm, is_prelu, has_g, has_b = ctx.meta
+        N, C = x.shape[0], x.shape[-1]
+        rows = _rows(x)
+        ab_ = ab if ab.numel() else None
+        da = da.contiguous()
+        dt, dp = ops.act_bwd(da, x, ab_, act, prm, want_prelu=is_prelu)
+        dprelu = None
+        if is_prelu:
+            dprelu = ops.channel_stats(dp)[:, :, 0].sum().reshape(1)
+        dgamma = dbeta = None
+        if mode == "none":
+            dx = dt
+        elif mode == "batch_eval":
+            # frozen statistics: the norm is a fixed per-channel affine t = a*x + b
+            scale = torch.stack([ab[:, 0], torch.zeros_like(ab[:, 0])], 1).contiguous()
+            dx = ops.affine_act(dt, scale, nat.ACT_NONE, 0.0)
+            if has_g or has_b:
+                st = ops.channel_stats(dt)[:, :, 0].sum((0, 1))                 # sum dt
+                if has_b:
+                    dbeta = st
+                if has_g:
+                    # sum dt * xhat with xhat = (x - running_mean) * running_rstd = (a*x + b - beta) / gamma
+                    raise NotImplementedError("BatchNorm3d in eval mode with a trainable scale is not supported; "
+                                              "call model.train() or freeze the norm parameters")
+        else:
+            s = ops.norm_bwd_stats(dt, x, mr)                          # (N, 2, C): sum d, sum d*xhat
+            g32 = gamma.detach().float() if has_g else torch.ones(C, device=x.device)
+            if has_b:
+                dbeta = s[:, 0].sum(0)
+            if has_g:
+                dgamma = s[:, 1].sum(0)
+            w = s * g32.view(1, 1, C)                                  # gamma-weighted sums
+            if mode == "batch":
+                M = (w.sum(0, keepdim=True) / float(N * rows)).expand(N, 2, C).contiguous()
+            else:
+                g = groups if mode == "group" else C
+                cpg = C // g
+                M = (w.view(N, 2, g, cpg).sum(-1, keepdim=True) / float(rows * cpg)).expand(N, 2, g, cpg).reshape(N, 2, C).contiguous()
+            dx = ops.norm_bwd_apply_general(dt, x, mr, g32 if has_g else None, M)
+        cast = lambda v, like: None if v is None else v.to(like.dtype).reshape(like.shape)
+        return (dx, cast(dgamma, gamma) if has_g else None, cast(dbeta, gamma) if has_b else None, dprelu, None, None, None,
+                None, None, None)
+
+
+class Conv3dFn(torch.autograd.Function):
+    """y = conv3d(a, W) (+ bias) (+ res): stride 1, 'same' padding, channels-last."""
+
+    @staticmethod
+    def forward(ctx, a, weight, bias, res):
+        ks = tuple(int(k) for k in weight.shape[2:])
+        wp = ops.conv3d_pack_weight(weight.detach().float().contiguous(), a.dtype)
+        y = ops.conv3d(a, wp, c_out=weight.shape[0], kernel=ks, bias=_f(bias), res=res)
+        ctx.save_for_backward(a, weight)
+        ctx.meta = (ks, bias is not None, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, weight = ctx.saved_tensors
+        ks, has_bias, has_res = ctx.meta
+        dy = dy.contiguous()
+        if dy.dtype != a.dtype:
+            dy = dy.to(a.dtype)
+        da = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().float().flip(2, 3, 4).transpose(0, 1).contiguous()       # (C_in, C_out, k...) flipped
+            da = ops.conv3d(dy, ops.conv3d_pack_weight(wt, dy.dtype), c_out=weight.shape[1], kernel=ks)
+        dW = ops.conv3d_wgrad(a, dy, ks).to(weight.dtype)
+        db = ops.channel_stats(dy)[:, :, 0].sum((0, 1)).to(weight.dtype) if has_bias else None
+        return da, dW, db, (dy if has_res else None)
+
+
+class MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, factor):
+        ctx.save_for_backward(x)
+        ctx.factor = tuple(int(f) for f in factor)
+        return ops.maxpool3d(x, ctx.factor)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool3d_bwd(x, dy.contiguous(), ctx.factor), None
+
+
+class UpsampleFn(torch.autograd.Function):
+    """Fixed-weight depthwise transposed conv (BilinearUp3d); only the data gradient exists."""
+
+    @staticmethod
+    def forward(ctx, x, taps, kernel, factor, pad):
+        ctx.save_for_backward(taps)
+        ctx.meta = (tuple(kernel), tuple(factor), tuple(pad), tuple(x.shape[1:4]))
+        return ops.dwconvT3d_generic(x, taps, kernel, factor, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (taps,) = ctx.saved_tensors
+        kernel, factor, pad, in_dims = ctx.meta
+        return ops.dwconv3d_generic(dy.contiguous(), taps, kernel, factor, pad, in_dims), None, None, None, None
+
+
+# ---- module-level composition ----------------------------------------------------------------------------------------
+def _norm_act(na, x):
+    m = na.norm
+    kind = na.kind
+    gamma = getattr(m, "weight", None) if kind != "none" else None
+    beta = getattr(m, "bias", None) if kind != "none" else None
+    groups = m.num_groups if kind == "group" else 1
+    eps = float(getattr(m, "eps", 1e-5))
+    if na.act_kind == "leakyrelu":
+        prm = float(na.act.negative_slope)
+    elif na.act_kind == "elu":
+        prm = float(na.act.alpha)
+    else:
+        prm = 0.0
+    prelu_w = na.act.weight if na.act_kind == "prelu" else None
+    return NormActFn.apply(x, gamma, beta, prelu_w, kind, groups, eps, na.act_kind, prm, m if kind == "batch" else None)
+
+
+def _nac(na, conv, x, res=None):
+    return Conv3dFn.apply(_norm_act(na, x), conv.weight, conv.bias, res)
+
+
+def _conv_block(blk, x):
+    x = _nac(blk.pre[0], blk.pre[1], x)
+    r = blk.res
+    a1 = _norm_act(r.norm_act1, x)
+    # reference quirk: with norm='none' the in-place activation also rewrites the residual source (rsunet.py:103-113)
+    res = a1 if (r.norm_act1.kind == "none" and r.norm_act1.act_kind != "prelu") else x
+    h = Conv3dFn.apply(a1, r.conv1.weight, r.conv1.bias, None)
+    x = _nac(r.norm_act2, r.conv2, h, res=res)
+    return _nac(blk.post[0], blk.post[1], x)
+
+
+def rsunet_train_forward(model, x_cl: torch.Tensor, compute_dtype: torch.dtype):
+    """Differentiable RSUNet forward on channels-last input; returns {"output", "ds_i"...} of fp32 channels-last maps."""
+    x = x_cl if x_cl.dtype == compute_dtype else x_cl.to(compute_dtype)
+    x = _conv_block(model.input_conv, x.contiguous())
+    skips = []
+    for down in model.down_blocks:
+        skips.append(x)
+        x = _conv_block(down.conv, MaxPoolFn.apply(x, down.pool.kernel_size))
+    ds_feats = []
+    for i, up in enumerate(model.up_blocks):
+        if model.supports_deep_supervision and (model.depth - i - 1) < len(model.ds_heads):
+            ds_feats.append(x)
+        u = up.up
+        taps = u.weight.detach().float().reshape(u.groups, -1).t().contiguous()
+        x = UpsampleFn.apply(x, taps, tuple(u.kernel_size), tuple(u.factor), tuple(u.padding))
+        x = Conv3dFn.apply(x, up.proj.weight, up.proj.bias, skips.pop())
+        x = _conv_block(up.conv, x)
+    out = {"output": _nac(model.final_norm, model.output_head, x).float()}
+    if model.supports_deep_supervision:
+        for i, (ft, head) in enumerate(zip(ds_feats, model.ds_heads)):
+            out[f"ds_{i + 1}"] = Conv3dFn.apply(ft, head.weight, head.bias, None).float()
+    return out
+
+
+__all__ = ["NormActFn", "Conv3dFn", "MaxPoolFn", "UpsampleFn", "rsunet_train_forward"]

@@ -1,0 +1,150 @@
+"""GPU parity of the RSUNet training path: every backward kernel against torch autograd of the same op, and a full
+forward + backward of three RSUNet configurations against autograd through the CPU oracle (which equals the reference's
+rsunet.py forward exactly, tests/test_oracle_golden.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cl(x):
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _cf(y):
+    return y.permute(0, 4, 1, 2, 3).contiguous()
+
+
+@pytest.mark.parametrize("ci,co,ks,shape", [(5, 7, (3, 3, 3), (4, 6, 7)), (8, 4, (1, 3, 3), (3, 9, 8)), (3, 70, (1, 1, 1), (4, 5, 6))])
+def test_conv3d_backward_kernels(ci, co, ks, shape):
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(ci + co)
+    x = torch.randn(2, ci, *shape, requires_grad=True)
+    w = (torch.randn(co, ci, *ks) * 0.3).requires_grad_()
+    y = F.conv3d(x, w, padding=tuple(k // 2 for k in ks))
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    dW = ops.conv3d_wgrad(_cl(x.detach()).cuda(), _cl(gy).cuda(), ks)
+    torch.testing.assert_close(dW.cpu(), w.grad, rtol=1e-4, atol=1e-3)
+    wt = w.detach().flip(2, 3, 4).transpose(0, 1).contiguous().cuda()
+    dx = ops.conv3d(_cl(gy).cuda(), ops.conv3d_pack_weight(wt, torch.float32), c_out=ci, kernel=ks)
+    torch.testing.assert_close(_cf(dx.cpu()), x.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_maxpool_and_upsample_backward():
+    from pytorch_connectomics_amd import hip_ops as ops
+    from oracle.rsunet_oracle import bilinear_kernel
+    torch.manual_seed(1)
+    x = torch.randn(2, 5, 6, 8, 10, requires_grad=True)
+    for fac in ((1, 2, 2), (2, 2, 2), (3, 2, 1)):
+        x.grad = None
+        y = F.max_pool3d(x, fac)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        dx = ops.maxpool3d_bwd(_cl(x.detach()).cuda(), _cl(gy).cuda(), fac)
+        torch.testing.assert_close(_cf(dx.cpu()), x.grad)
+    for fac in ((1, 2, 2), (2, 2, 2)):
+        x.grad = None
+        wk = bilinear_kernel(5, fac)
+        import math
+        pad = [int(math.ceil((f - 1) / 2.0)) for f in fac]
+        y = F.conv_transpose3d(x, wk, stride=fac, padding=pad, groups=5)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        taps = wk.reshape(5, -1).t().contiguous().cuda()
+        dx = ops.dwconv3d_generic(_cl(gy).cuda(), taps, wk.shape[2:], fac, pad, x.shape[2:])
+        torch.testing.assert_close(_cf(dx.cpu()), x.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("kind,act", [("group", "relu"), ("instance", "elu"), ("batch", "prelu"), ("none", "leakyrelu")])
+def test_norm_act_function_backward(kind, act):
+    from pytorch_connectomics_amd.models.architectures.rsunet import NormAct
+    from pytorch_connectomics_amd.training.rsunet_autograd import _norm_act
+    torch.manual_seed(3)
+    C = 12
+    na = NormAct(C, kind, act, num_groups=4, negative_slope=0.1, init=0.2, alpha=1.0).train()
+    if kind in ("group", "batch"):
+        with torch.no_grad():
+            na.norm.weight.uniform_(0.5, 1.5)
+            na.norm.bias.normal_()
+    x = torch.randn(2, C, 4, 5, 6, requires_grad=True)
+    ref = na.act(na.norm(x)) if act == "prelu" else na.act(na.norm(x).clone())
+    gy = torch.randn_like(ref)
+    ref.backward(gy)
+    want = {n: p.grad.clone() for n, p in na.named_parameters() if p.grad is not None}
+    xg = x.grad.clone()
+    rm = na.norm.running_mean.clone() if kind == "batch" else None
+    na2 = NormAct(C, kind, act, num_groups=4, negative_slope=0.1, init=0.2, alpha=1.0).train()
+    na2.load_state_dict({k: v for k, v in na.state_dict().items() if "running" not in k and "num_batches" not in k}, strict=False)
+    na2 = na2.cuda()
+    xc = _cl(x.detach()).cuda().requires_grad_()
+    out = _norm_act(na2, xc)
+    torch.testing.assert_close(_cf(out.detach().cpu()), ref.detach(), rtol=1e-4, atol=1e-5)
+    out.backward(_cl(gy).cuda())
+    torch.testing.assert_close(_cf(xc.grad.cpu()), xg, rtol=1e-3, atol=2e-5)
+    for n, p in na2.named_parameters():
+        if n in want:
+            torch.testing.assert_close(p.grad.cpu(), want[n], rtol=1e-3, atol=1e-4)
+    if kind == "batch":
+        torch.testing.assert_close(na2.norm.running_mean.cpu(), rm, rtol=1e-4, atol=1e-6)
+
+
+CFGS = {
+    "c1_group": dict(width=[8, 16], down_factors=[(2, 2, 2)], norm="group", num_groups=8, activation="relu"),
+    "aniso_inst_elu_ds": dict(width=[6, 8, 12], norm="instance", activation="elu", deep_supervision=True),
+    "batch_prelu_2d": dict(width=[4, 8, 8], norm="batch", activation="prelu", depth_2d=1, init=0.1),
+    "none_leaky": dict(width=[4, 8], norm="none", activation="leakyrelu", negative_slope=0.05),
+}
+
+
+@pytest.mark.parametrize("name", list(CFGS))
+def test_rsunet_training_step_matches_oracle_autograd(name):
+    from oracle import rsunet_oracle as RO
+    from pytorch_connectomics_amd.models.architectures.rsunet import RSUNet
+    kw = CFGS[name]
+    torch.manual_seed(11)
+    m = RSUNet(1, 2, **kw).train()
+    with torch.no_grad():                       # non-trivial affine parameters
+        for mod in m.modules():
+            if isinstance(mod, (torch.nn.GroupNorm, torch.nn.BatchNorm3d)):
+                mod.weight.uniform_(0.7, 1.3)
+                mod.bias.normal_(0, 0.2)
+    x = torch.randn(2, 1, 8, 16, 16, generator=torch.Generator().manual_seed(12))
+    tgt = torch.randn(2, 2, 8, 16, 16, generator=torch.Generator().manual_seed(13))
+    params = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in m.state_dict().items()}
+    okw = {k: v for k, v in kw.items()}
+    ref = RO.forward(params, x.clone(), bn_training=True, **okw)
+
+    def loss_of(out):
+        if isinstance(out, dict):
+            l = F.mse_loss(out["output"], tgt)
+            for k in sorted(out):
+                if k != "output":
+                    l = l + 0.5 * out[k].pow(2).mean()
+            return l
+        return F.mse_loss(out, tgt)
+
+    ref_loss = loss_of(ref)
+    ref_loss.backward()
+    mg = m.cuda()
+    out = mg(x.cuda())
+    tg = tgt.cuda()
+    if isinstance(out, dict):
+        loss = F.mse_loss(out["output"], tg)
+        for k in sorted(out):
+            if k != "output":
+                loss = loss + 0.5 * out[k].pow(2).mean()
+    else:
+        loss = F.mse_loss(out, tg)
+    assert abs(float(loss) - float(ref_loss)) < 1e-4 * max(1.0, abs(float(ref_loss)))
+    loss.backward()
+    worst = 0.0
+    for n, p in mg.named_parameters():
+        g_ref = params[n].grad
+        assert p.grad is not None and g_ref is not None, n
+        scale = float(g_ref.abs().max().clamp_min(1e-6))
+        err = float((p.grad.cpu() - g_ref).abs().max()) / scale
+        worst = max(worst, err)
+        assert err < 5e-3, f"{n}: rel grad err {err:.2e}"
+    assert worst < 5e-3
