@@ -345,7 +345,8 @@ int pytc_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, int N, cons
 /* Backward of the RSUNet building blocks (rsunet.py:73-259 through torch autograd in the reference).  The data
  * gradient of a dense conv is pytc_conv3d_fwd with flipped / transposed weights.
  * pytc_conv3d_wgrad: dW[tap][o][k] = sum_r dY[r][o] * A[r + shift(tap)][k] (A = the conv's activated input, zero padded,
- *   odd kernel sizes, stride 1); workspace: pytc_conv3d_wgrad_slots(rows) * taps * C_out * C_in floats.
+ *   odd kernel sizes, stride 1); workspace: pytc_conv3d_wgrad_ws_elems(...) floats.  bf16 with kh = kw = 3 and channel
+ *   counts that are multiples of 16 runs on MFMA (LDS transpose reads), everything else on a VALU kernel.
  * pytc_act_bwd: dt = da * act'(t), t = a[n][c]*x + b[n][c] (ab may be NULL: t = x); dp (may be NULL) = da * min(t, 0),
  *   the summand of the PReLU weight gradient.  act in {RELU, LEAKY (prm = slope), ELU (prm = alpha), NONE}.
  * pytc_norm_finalize_groups_mr: pytc_norm_finalize_groups that also returns (mean, rstd) per (n, c) in mr [N][2][C].
@@ -355,7 +356,7 @@ int pytc_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, int N, cons
  * pytc_maxpool3d_bwd: dx = 0 except the first maximum of every window, which receives dy (nn.MaxPool3d backward).
  * pytc_dwconv3d_generic_fwd: anisotropic depthwise conv (kernel / stride / pad per axis), the backward-data of
  *   pytc_dwconvT3d_generic_fwd (BilinearUp3d, rsunet.py:33-70). */
-int pytc_conv3d_wgrad_slots(int64_t rows_total);
+int64_t pytc_conv3d_wgrad_ws_elems(int N, int D, int H, int W, int C_in, int C_out, const int32_t* kernel, int dtype);
 int pytc_conv3d_wgrad(const void* a, const void* dy, float* dW, float* workspace, int N, int D, int H, int W, int C_in,
                       int C_out, const int32_t* kernel, int dtype, void* stream);
 int pytc_act_bwd(const void* da, const void* x, const float* ab, void* dt, void* dp, int N, int64_t rows, int C, int act,

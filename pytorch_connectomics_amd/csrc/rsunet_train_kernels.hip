@@ -92,6 +92,179 @@ conv3d_wgrad_kernel(const T* __restrict__ a, const T* __restrict__ dy, float* __
   }
 }
 
+// ---- conv3d weight gradient on MFMA (bf16, kh = kw = 3, channels % 16 == 0) --------------------------------------------
+// The reduction runs over voxels; a wave's unit of work is one 32-voxel segment of an x line.  It stages the dY rows
+// of the segment and, for the kernel plane dz of its workgroup, the three neighbouring A lines (y-1, y, y+1) with a
+// one-voxel x halo (zero outside the volume) into a wave-private LDS image, then forms, per tap (dy, dx), the
+// 16x16x32 products  dW[tap] += dY^T * A(shifted)  - the x shift of a tap is a row offset into the staged line, so one
+// staged image serves the nine taps.  Fragments come from gfx950's LDS transpose read as in pw_wgrad_mfma_kernel (same
+// row <-> k-slot map for both operands).  No workgroup barrier in the loop; the next unit's global loads are in flight
+// during the MFMAs.  Workgroup = (row slot, (o, k) tile, dz); the blocks of one slot are dispatched back to back onto
+// ONE XCD (linear id -> XCD = id % 8) so the re-reads of the slot's rows by its (tile, dz) blocks hit that XCD's L2.
+// Cross-wave sum in fixed order, per-slot partials, slot-ordered reduction: deterministic.
+template <int MT, int NT>
+__global__ void __launch_bounds__(256, (MT * NT >= 4 ? 2 : 3))
+conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ dy, float* __restrict__ dWp, int N,
+                         CwGeom g, int C_in, int C_out, long units_per_slot, int slots, int tiles) {
+  constexpr int BM = MT * 16, BN = NT * 16;
+  constexpr int SG = BM * 2 + 32, SX = BN * 2 + 32;        // LDS row pitch in bytes
+  constexpr int AR = 34;                                    // staged rows of an A line: 32 + the x halo
+  constexpr int WAVE_BYTES = 32 * SG + 3 * AR * SX;
+  constexpr int RED_BYTES = 9 * BM * BN * 4;
+  constexpr int LDS_BYTES = 4 * WAVE_BYTES > RED_BYTES ? 4 * WAVE_BYTES : RED_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned char* lg = lds + wave * WAVE_BYTES;
+  unsigned char* la = lg + 32 * SG;
+  // linear block id -> (slot, tile, dz): slot % 8 = XCD, the slot's blocks consecutive on that XCD
+  const int T = tiles * g.kd;
+  const long b = blockIdx.x;
+  const int slot = (int)((b / 8 / T) * 8 + (b % 8));
+  if (slot >= slots) return;
+  const int t = (int)((b / 8) % T);
+  const int dzi = t % g.kd, tile = t / g.kd;
+  const int tiles_k = C_in / BN;
+  const int o_base = (tile / tiles_k) * BM, k_base = (tile % tiles_k) * BN;
+  const int dz = dzi - g.kd / 2;
+  const int nseg = (g.W + 31) / 32;
+  const long units = (long)N * g.D * g.H * nseg;
+  const long u_begin = (long)slot * units_per_slot;
+  const long u_end = u_begin + units_per_slot < units ? u_begin + units_per_slot : units;
+
+  constexpr int CHG = BM / 8, RG = 64 / CHG, ITG = 32 / RG;   // dY: 16-B chunks per row, rows per load, loads
+  constexpr int CHX = BN / 8, ITA = (AR * CHX + 63) / 64;     // A line: chunk loads per lane
+  const int g_row = lane / CHG, g_chunk = lane % CHG;
+  uint4 rg[ITG], ra[3][ITA];
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  auto fetch = [&](long u) {
+    const int xs = (int)(u % nseg);
+    const long line = u / nseg;
+    const int y = (int)(line % g.H);
+    const int z = (int)((line / g.H) % g.D);
+    const int x0 = xs * 32;
+    const bf16_t* dyl = dy + line * g.W * (long)C_out + o_base + g_chunk * 8;
+#pragma unroll
+    for (int it = 0; it < ITG; ++it) {
+      const int x = x0 + it * RG + g_row;
+      rg[it] = x < g.W ? *reinterpret_cast<const uint4*>(dyl + (long)x * C_out) : zero4;
+    }
+    const int sz = z + dz;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      const int sy = y + l - 1;
+      const bool ok = sz >= 0 && sz < g.D && sy >= 0 && sy < g.H;         // wave-uniform
+      const bf16_t* al = a + (line + (long)dz * g.H + (l - 1)) * g.W * (long)C_in + k_base;
+#pragma unroll
+      for (int it = 0; it < ITA; ++it) {
+        const int c = it * 64 + lane;
+        const int row = c / CHX, chunk = c % CHX;
+        const int x = x0 - 1 + row;
+        ra[l][it] = (ok && row < AR && x >= 0 && x < g.W) ? *reinterpret_cast<const uint4*>(al + (long)x * C_in + chunk * 8)
+                                                          : zero4;
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int it = 0; it < ITG; ++it) *reinterpret_cast<uint4*>(lg + (it * RG + g_row) * SG + g_chunk * 16) = rg[it];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int it = 0; it < ITA; ++it) {
+        const int c = it * 64 + lane;
+        const int row = c / CHX, chunk = c % CHX;
+        if (row < AR) *reinterpret_cast<uint4*>(la + (l * AR + row) * SX + chunk * 16) = ra[l][it];
+      }
+  };
+  const int fr_row = (lane >> 4) * 4 + ((lane & 15) >> 2), fr_col = (lane & 3) * 8;
+  auto frag = [&](unsigned char* base, int pitch, int row0, int tl) -> bf16x8_t {
+    unsigned char* p = base + (row0 + fr_row) * pitch + tl * 32 + fr_col;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 16 * pitch));
+    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, both);
+  };
+
+  f32x4_t acc[9][MT][NT];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[tp][m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  long u = u_begin + wave;
+  if (u < u_end) fetch(u);
+  for (; u < u_end; u += 4) {
+    stage();
+    if (u + 4 < u_end) fetch(u + 4);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    bf16x8_t fa[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) fa[m] = frag(lg, SG, 0, m);
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        bf16x8_t fb[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) fb[n] = frag(la, SX, l * AR + dx, n);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[l * 3 + dx][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], fb[n], acc[l * 3 + dx][m][n], 0, 0, 0);
+      }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  float* red = reinterpret_cast<float*>(lds);
+  const int nn = lane & 15, mg = (lane >> 4) * 4;
+  for (int w = 1; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[(tp * BM + m * 16 + mg + i) * BN + n * 16 + nn] = acc[tp][m][n][i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[tp][m][n][i] += red[(tp * BM + m * 16 + mg + i) * BN + n * 16 + nn];
+    }
+  }
+  if (wave == 0) {
+    const int taps = g.kd * 9;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int o = o_base + m * 16 + mg + i;
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            dWp[(((long)slot * taps + dzi * 9 + tp) * C_out + o) * C_in + k_base + n * 16 + nn] = acc[tp][m][n][i];
+        }
+  }
+}
+
 __global__ void __launch_bounds__(256)
 reduce_slots2_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int slots) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -205,9 +378,35 @@ using namespace pytc;
   if (dtype == PYTC_BF16) { BF; } else if (dtype == PYTC_F32) { F32; } else { \
     set_error(what ": bad dtype %d", dtype); return PYTC_ERR_INVALID; }
 
-extern "C" int pytc_conv3d_wgrad_slots(int64_t rows_total) {
-  const long s = rows_total / 8192;
-  return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
+// launch plan shared by the workspace query and the launch
+struct CwPlan { bool mfma; int mt, nt, tiles, slots; long per_slot; };
+static CwPlan cw_plan(int N, int D, int H, int W, int C_in, int C_out, const int32_t* k, int dtype) {
+  CwPlan p{};
+  const long rows_total = (long)N * D * H * W;
+  p.mfma = dtype == PYTC_BF16 && k[1] == 3 && k[2] == 3 && C_in % 16 == 0 && C_out % 16 == 0 && (tuning_get("conv_wgrad_mfma", 1) != 0);
+  if (p.mfma) {
+    p.mt = C_out % 32 == 0 ? 2 : 1;
+    p.nt = C_in % 32 == 0 ? 2 : 1;
+    p.tiles = (C_out / (p.mt * 16)) * (C_in / (p.nt * 16));
+    const long units = (long)N * D * H * ((W + 31) / 32);
+    long s = 4096 / ((long)p.tiles * k[0]);            // ~4096 workgroups in flight over the launch
+    if (s > units / 8) s = units / 8;                  // >= 2 units per wave
+    s = (s / 8) * 8;
+    p.slots = (int)(s < 8 ? 8 : (s > 512 ? 512 : s));
+    p.per_slot = (units + p.slots - 1) / p.slots;
+  } else {
+    const long s = rows_total / 8192;
+    p.slots = (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
+    p.per_slot = (rows_total + p.slots - 1) / p.slots;
+  }
+  return p;
+}
+
+extern "C" int64_t pytc_conv3d_wgrad_ws_elems(int N, int D, int H, int W, int C_in, int C_out, const int32_t* kernel,
+                                              int dtype) {
+  if (!kernel || N < 1) return -1;
+  const CwPlan p = cw_plan(N, D, H, W, C_in, C_out, kernel, dtype);
+  return (int64_t)p.slots * kernel[0] * kernel[1] * kernel[2] * C_out * C_in;
 }
 
 extern "C" int pytc_conv3d_wgrad(const void* a, const void* dy, float* dW, float* workspace, int N, int D, int H, int W,
@@ -216,15 +415,28 @@ extern "C" int pytc_conv3d_wgrad(const void* a, const void* dy, float* dW, float
   CwGeom g{D, H, W, kernel[0], kernel[1], kernel[2]};
   PYTC_REQUIRE(g.kd % 2 == 1 && g.kh % 2 == 1 && g.kw % 2 == 1, "conv3d_wgrad: odd kernel sizes only ('same' padding)");
   const long rows_total = (long)N * D * H * W;
-  const int slots = pytc_conv3d_wgrad_slots(rows_total);
-  const long rps = (rows_total + slots - 1) / slots;
+  const CwPlan p = cw_plan(N, D, H, W, C_in, C_out, kernel, dtype);
+  const int slots = p.slots;
   const int taps = g.kd * g.kh * g.kw;
-  dim3 grid(slots, ((C_out + CW_TO - 1) / CW_TO) * ((C_in + CW_TK - 1) / CW_TK), taps), block(256);
   hipStream_t s = (hipStream_t)stream;
-  RS_DISPATCH(dtype,
-              hipLaunchKernelGGL(conv3d_wgrad_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)a, (const bf16_t*)dy, workspace, rows_total, g, C_in, C_out, rps, slots),
-              hipLaunchKernelGGL(conv3d_wgrad_kernel<float>, grid, block, 0, s, (const float*)a, (const float*)dy, workspace, rows_total, g, C_in, C_out, rps, slots),
-              "conv3d_wgrad")
+  if (p.mfma) {
+    const long blocks = (long)((slots + 7) / 8) * 8 * p.tiles * g.kd;
+    const bf16_t* ap = (const bf16_t*)a;
+    const bf16_t* dp = (const bf16_t*)dy;
+#define CW_LAUNCH(MT, NT) hipLaunchKernelGGL((conv3d_wgrad_mfma_kernel<MT, NT>), dim3((unsigned)blocks), dim3(256), 0, s, ap, dp, workspace, N, g, C_in, C_out, p.per_slot, slots, p.tiles)
+    if (p.mt == 2 && p.nt == 2) CW_LAUNCH(2, 2);
+    else if (p.mt == 2) CW_LAUNCH(2, 1);
+    else if (p.nt == 2) CW_LAUNCH(1, 2);
+    else CW_LAUNCH(1, 1);
+#undef CW_LAUNCH
+  } else {
+    const long rps = p.per_slot;
+    dim3 grid(slots, ((C_out + CW_TO - 1) / CW_TO) * ((C_in + CW_TK - 1) / CW_TK), taps), block(256);
+    RS_DISPATCH(dtype,
+                hipLaunchKernelGGL(conv3d_wgrad_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)a, (const bf16_t*)dy, workspace, rows_total, g, C_in, C_out, rps, slots),
+                hipLaunchKernelGGL(conv3d_wgrad_kernel<float>, grid, block, 0, s, (const float*)a, (const float*)dy, workspace, rows_total, g, C_in, C_out, rps, slots),
+                "conv3d_wgrad")
+  }
   const long nW = (long)taps * C_out * C_in;
   hipLaunchKernelGGL(reduce_slots2_kernel, dim3(ceil_div(nW, 256)), dim3(256), 0, s, workspace, dW, nW, slots);
   PYTC_LAUNCH_CHECK("conv3d_wgrad");

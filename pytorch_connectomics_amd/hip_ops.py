@@ -462,11 +462,12 @@ def conv3d_wgrad(a: torch.Tensor, dy: torch.Tensor, kernel) -> torch.Tensor:
     co = dy.shape[-1]
     kd, kh, kw = (int(v) for v in kernel)
     taps = kd * kh * kw
-    slots = nat.lib().pytc_conv3d_wgrad_slots(N * D * H * W)
-    ws = torch.empty((slots * taps * co * ci,), dtype=torch.float32, device=a.device)
+    k3 = _i3((kd, kh, kw))
+    n_ws = nat.lib().pytc_conv3d_wgrad_ws_elems(N, D, H, W, ci, co, k3, dtype_code(a.dtype))
+    ws = torch.empty((n_ws,), dtype=torch.float32, device=a.device)
     dW = torch.empty((taps, co, ci), dtype=torch.float32, device=a.device)
     _run(f"conv3d_wgrad[{ci}->{co},k{kd}{kh}{kw}]", taps * _nbytes(a, dy), nat.lib().pytc_conv3d_wgrad, _p(a), _p(dy), _p(dW),
-         _p(ws), N, D, H, W, ci, co, _i3((kd, kh, kw)), dtype_code(a.dtype), _stream())
+         _p(ws), N, D, H, W, ci, co, k3, dtype_code(a.dtype), _stream())
     return dW.view(kd, kh, kw, co, ci).permute(3, 4, 0, 1, 2).contiguous()
 
 

@@ -142,8 +142,17 @@ class Conv3dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = weight.detach().float().flip(2, 3, 4).transpose(0, 1).contiguous()       # (C_in, C_out, k...) flipped
             da = ops.conv3d(dy, ops.conv3d_pack_weight(wt, dy.dtype), c_out=weight.shape[1], kernel=ks)
-        dW = ops.conv3d_wgrad(a, dy, ks).to(weight.dtype)
-        db = ops.channel_stats(dy)[:, :, 0].sum((0, 1)).to(weight.dtype) if has_bias else None
+        ci, co = a.shape[-1], dy.shape[-1]
+        db = None
+        if ks == (1, 1, 1) and a.dtype == torch.bfloat16 and ci % 16 == 0 and co % 16 == 0:
+            # 1x1x1 projections: the pointwise MFMA weight-gradient kernel (also returns the bias gradient)
+            dW2, db = ops.pw_wgrad(a, dy, N=a.shape[0], rows_per_sample=_rows(a), c_in=ci, c_out=co, want_bias=has_bias)
+            dW = dW2.view(co, ci, 1, 1, 1).to(weight.dtype)
+            db = db.to(weight.dtype) if has_bias else None
+        else:
+            dW = ops.conv3d_wgrad(a, dy, ks).to(weight.dtype)
+            if has_bias:
+                db = ops.channel_stats(dy)[:, :, 0].sum((0, 1)).to(weight.dtype)
         return da, dW, db, (dy if has_res else None)
 
 

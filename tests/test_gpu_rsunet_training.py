@@ -213,3 +213,43 @@ test:
     ck = tmp_path / "out" / "checkpoints" / "last.ckpt"
     m = main(["--config", str(cfg), "--mode", "test", "--checkpoint", str(ck)])
     assert m["output_voxels_per_s"] > 0
+
+
+def test_minimal_rsunet_tutorial_train_then_infer(tmp_path):
+    """BASELINE.json configs[0]: tutorials/minimal_rsunet.yaml — 2 training steps, then sliding-window inference."""
+    import os
+    from pytorch_connectomics_amd.main import main
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tutorials", "minimal_rsunet.yaml")
+    out = main(["--config", cfg, "--mode", "train", f"save_path={tmp_path / 'out'}"])
+    assert out["steps"] == 2 and out["last_loss"] == out["last_loss"]
+    ck = tmp_path / "out" / "checkpoints" / "last.ckpt"
+    assert "model.input_conv.pre.1.weight" in torch.load(ck, weights_only=False)["state_dict"]
+    res = main(["--config", cfg, "--mode", "test", "--checkpoint", str(ck), f"save_path={tmp_path / 'out'}"])
+    assert res["output_voxels_per_s"] > 0
+
+
+@pytest.mark.parametrize("ci,co,ks,shape", [(16, 16, (3, 3, 3), (3, 5, 32)), (32, 32, (3, 3, 3), (4, 6, 40)),
+                                            (16, 32, (1, 3, 3), (2, 7, 20)), (64, 48, (3, 3, 3), (3, 4, 70)),
+                                            (32, 16, (5, 3, 3), (6, 3, 33))])
+def test_conv3d_wgrad_mfma_bf16(ci, co, ks, shape):
+    """bf16 weight gradient on MFMA (LDS transpose reads) vs fp32 autograd on the same bf16-rounded operands, and
+    vs the VALU kernel (tuning knob) on identical inputs."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(ci * 7 + co)
+    x = torch.randn(2, ci, *shape).bfloat16().float().requires_grad_()
+    w = torch.zeros(co, ci, *ks, requires_grad=True)
+    y = F.conv3d(x, w, padding=tuple(k // 2 for k in ks))
+    gy = torch.randn_like(y).bfloat16().float()
+    y.backward(gy)
+    xa, ga = _cl(x.detach()).cuda().bfloat16(), _cl(gy).cuda().bfloat16()
+    dW = ops.conv3d_wgrad(xa, ga, ks)
+    scale = float(w.grad.abs().max())
+    assert float((dW.cpu() - w.grad).abs().max()) < 2e-5 * scale * 10 + 1e-3
+    torch.testing.assert_close(dW.cpu(), w.grad, rtol=1e-4, atol=2e-4 * scale)
+    ops.set_tuning("conv_wgrad_mfma", 0)
+    try:
+        dW2 = ops.conv3d_wgrad(xa, ga, ks)
+    finally:
+        ops.set_tuning("conv_wgrad_mfma", 1)
+    torch.testing.assert_close(dW, dW2, rtol=1e-4, atol=2e-4 * scale)
+    assert torch.equal(dW, ops.conv3d_wgrad(xa, ga, ks))          # deterministic

@@ -1,0 +1,54 @@
+"""RSUNet training step timing (forward + backward + AdamW) on synthetic patches; run under rocprofv3 for the breakdown.
+    PYTHONPATH=. python tools/rsunet_train_probe.py [--dtype bf16] [--patch 18,160,160] [--batch 2] [--steps 5]"""
+import argparse
+import time
+
+import torch
+import torch.nn.functional as F
+
+from pytorch_connectomics_amd.models.architectures.rsunet import RSUNet
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--patch", default="18,160,160")
+ap.add_argument("--batch", type=int, default=2)
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--norm", default="batch")
+ap.add_argument("--width", default="16,32,64,128")
+a = ap.parse_args()
+patch = tuple(int(v) for v in a.patch.split(","))
+m = RSUNet(1, 3, width=[int(v) for v in a.width.split(",")], norm=a.norm, activation="relu").cuda().train()
+m.compute_dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+opt = torch.optim.AdamW(m.parameters(), lr=1e-4, fused=True)
+x = torch.randn(a.batch, 1, *patch, device="cuda")
+y = (torch.rand(a.batch, 3, *patch, device="cuda") > 0.5).float()
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    loss = F.binary_cross_entropy_with_logits(m(x), y)
+    loss.backward()
+    opt.step()
+    return loss
+
+
+for _ in range(2):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.steps):
+    l = step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.steps
+vox = a.batch * patch[0] * patch[1] * patch[2]
+print(f"rsunet train {a.dtype} norm={a.norm} batch {a.batch} patch {patch}: {dt * 1e3:.1f} ms/step, {vox / dt:.3e} voxels/s, loss {float(l.detach()):.4f}")
+with torch.no_grad():
+    m.eval()
+    for _ in range(2):
+        m(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        m(x)
+    torch.cuda.synchronize()
+    print(f"rsunet infer fwd: {(time.perf_counter() - t0) / a.steps * 1e3:.1f} ms")
