@@ -92,29 +92,36 @@ conv3d_wgrad_kernel(const T* __restrict__ a, const T* __restrict__ dy, float* __
   }
 }
 
-// ---- conv3d weight gradient on MFMA (bf16, kh = kw = 3, channels % 16 == 0) --------------------------------------------
+// ---- conv3d weight gradient on MFMA (bf16, kh = kw = KP in {3, 1}) -----------------------------------------------------
 // The reduction runs over voxels; a wave's unit of work is one 32-voxel segment of an x line.  It stages the dY rows
-// of the segment and, for the kernel plane dz of its workgroup, the three neighbouring A lines (y-1, y, y+1) with a
-// one-voxel x halo (zero outside the volume) into a wave-private LDS image, then forms, per tap (dy, dx), the
-// 16x16x32 products  dW[tap] += dY^T * A(shifted)  - the x shift of a tap is a row offset into the staged line, so one
-// staged image serves the nine taps.  Fragments come from gfx950's LDS transpose read as in pw_wgrad_mfma_kernel (same
+// of the segment and, for the kernel plane dz of its workgroup, the KP neighbouring A lines (y-1, y, y+1) with the x
+// halo (zero outside the volume) into a wave-private LDS image, then forms, per in-plane tap (dy, dx), the 16x16x32
+// products  dW[tap] += dY^T * A(shifted)  - the x shift of a tap is a row offset into the staged line, so one staged
+// image serves all KP*KP taps.  Fragments come from gfx950's LDS transpose read as in pw_wgrad_mfma_kernel (same
 // row <-> k-slot map for both operands).  No workgroup barrier in the loop; the next unit's global loads are in flight
 // during the MFMAs.  Workgroup = (row slot, (o, k) tile, dz); the blocks of one slot are dispatched back to back onto
 // ONE XCD (linear id -> XCD = id % 8) so the re-reads of the slot's rows by its (tile, dz) blocks hit that XCD's L2.
-// Cross-wave sum in fixed order, per-slot partials, slot-ordered reduction: deterministic.
-template <int MT, int NT>
-__global__ void __launch_bounds__(256, (MT * NT >= 4 ? 2 : 3))
+// RAG_O / RAG_K: a channel count below 16 on that side (1-channel input conv, 3-channel heads): the rows are not
+// 16-byte aligned, so the operand is gathered element-wise into a zero-padded 16-channel LDS tile (the op is
+// HBM-bound there; the padded MFMA columns are free).  Cross-wave sum in fixed order, per-slot partials, slot-ordered
+// reduction: deterministic.
+template <int MT, int NT, int KP, bool RAG_O, bool RAG_K>
+__global__ void __launch_bounds__(256, (MT * NT * KP * KP >= 36 ? 2 : 3))
 conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ dy, float* __restrict__ dWp, int N,
                          CwGeom g, int C_in, int C_out, long units_per_slot, int slots, int tiles) {
+  static_assert(!RAG_O || MT == 1, "ragged output side uses one 16-channel tile");
+  static_assert(!RAG_K || NT == 1, "ragged input side uses one 16-channel tile");
   constexpr int BM = MT * 16, BN = NT * 16;
   constexpr int SG = BM * 2 + 32, SX = BN * 2 + 32;        // LDS row pitch in bytes
-  constexpr int AR = 34;                                    // staged rows of an A line: 32 + the x halo
-  constexpr int WAVE_BYTES = 32 * SG + 3 * AR * SX;
-  constexpr int RED_BYTES = 9 * BM * BN * 4;
+  constexpr int PAD = KP / 2, AR = 32 + 2 * PAD;            // staged rows of an A line: 32 + the x halo
+  constexpr int TP = KP * KP;
+  constexpr int WAVE_BYTES = 32 * SG + KP * AR * SX;
+  constexpr int RED_BYTES = TP * BM * BN * 4;
   constexpr int LDS_BYTES = 4 * WAVE_BYTES > RED_BYTES ? 4 * WAVE_BYTES : RED_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
   typedef short s16x4 __attribute__((ext_vector_type(4)));
   typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   unsigned char* lg = lds + wave * WAVE_BYTES;
@@ -126,7 +133,7 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
   if (slot >= slots) return;
   const int t = (int)((b / 8) % T);
   const int dzi = t % g.kd, tile = t / g.kd;
-  const int tiles_k = C_in / BN;
+  const int tiles_k = RAG_K ? 1 : C_in / BN;
   const int o_base = (tile / tiles_k) * BM, k_base = (tile % tiles_k) * BN;
   const int dz = dzi - g.kd / 2;
   const int nseg = (g.W + 31) / 32;
@@ -137,47 +144,95 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
   constexpr int CHG = BM / 8, RG = 64 / CHG, ITG = 32 / RG;   // dY: 16-B chunks per row, rows per load, loads
   constexpr int CHX = BN / 8, ITA = (AR * CHX + 63) / 64;     // A line: chunk loads per lane
   const int g_row = lane / CHG, g_chunk = lane % CHG;
-  uint4 rg[ITG], ra[3][ITA];
+  uint4 rg[ITG], ra[KP][ITA];
   const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  if (RAG_O || RAG_K) {                 // zero the padded channels once; the gather only rewrites the real ones
+    for (int i = lane; i < WAVE_BYTES / 16; i += 64) reinterpret_cast<uint4*>(lg)[i] = zero4;
+  }
   auto fetch = [&](long u) {
     const int xs = (int)(u % nseg);
     const long line = u / nseg;
     const int y = (int)(line % g.H);
     const int z = (int)((line / g.H) % g.D);
     const int x0 = xs * 32;
-    const bf16_t* dyl = dy + line * g.W * (long)C_out + o_base + g_chunk * 8;
+    if (RAG_O) {                        // element e = j*64 + lane of the segment's 32 x C_out values
+      const unsigned short* dyl = reinterpret_cast<const unsigned short*>(dy) + line * g.W * (long)C_out;
+      u16x8 v;
 #pragma unroll
-    for (int it = 0; it < ITG; ++it) {
-      const int x = x0 + it * RG + g_row;
-      rg[it] = x < g.W ? *reinterpret_cast<const uint4*>(dyl + (long)x * C_out) : zero4;
+      for (int j = 0; j < 8; ++j) {
+        const int e = j * 64 + lane;
+        const int row = e / C_out, x = x0 + row;
+        v[j] = (row < 32 && x < g.W) ? dyl[(long)x0 * C_out + e] : (unsigned short)0;
+      }
+      rg[0] = __builtin_bit_cast(uint4, v);
+    } else {
+      const bf16_t* dyl = dy + line * g.W * (long)C_out + o_base + g_chunk * 8;
+#pragma unroll
+      for (int it = 0; it < ITG; ++it) {
+        const int x = x0 + it * RG + g_row;
+        rg[it] = x < g.W ? *reinterpret_cast<const uint4*>(dyl + (long)x * C_out) : zero4;
+      }
     }
     const int sz = z + dz;
 #pragma unroll
-    for (int l = 0; l < 3; ++l) {
-      const int sy = y + l - 1;
+    for (int l = 0; l < KP; ++l) {
+      const int sy = y + l - PAD;
       const bool ok = sz >= 0 && sz < g.D && sy >= 0 && sy < g.H;         // wave-uniform
-      const bf16_t* al = a + (line + (long)dz * g.H + (l - 1)) * g.W * (long)C_in + k_base;
+      if (RAG_K) {
+        const unsigned short* al = reinterpret_cast<const unsigned short*>(a) + (line + (long)dz * g.H + (l - PAD)) * g.W * (long)C_in;
+        u16x8 v;
 #pragma unroll
-      for (int it = 0; it < ITA; ++it) {
-        const int c = it * 64 + lane;
-        const int row = c / CHX, chunk = c % CHX;
-        const int x = x0 - 1 + row;
-        ra[l][it] = (ok && row < AR && x >= 0 && x < g.W) ? *reinterpret_cast<const uint4*>(al + (long)x * C_in + chunk * 8)
-                                                          : zero4;
+        for (int j = 0; j < 8; ++j) {
+          const int e = j * 64 + lane;
+          const int row = e / C_in, x = x0 - PAD + row;
+          v[j] = (ok && row < AR && x >= 0 && x < g.W) ? al[((long)x0 - PAD) * C_in + e] : (unsigned short)0;
+        }
+        ra[l][0] = __builtin_bit_cast(uint4, v);
+      } else {
+        const bf16_t* al = a + (line + (long)dz * g.H + (l - PAD)) * g.W * (long)C_in + k_base;
+#pragma unroll
+        for (int it = 0; it < ITA; ++it) {
+          const int c = it * 64 + lane;
+          const int row = c / CHX, chunk = c % CHX;
+          const int x = x0 - PAD + row;
+          ra[l][it] = (ok && row < AR && x >= 0 && x < g.W) ? *reinterpret_cast<const uint4*>(al + (long)x * C_in + chunk * 8)
+                                                            : zero4;
+        }
       }
     }
   };
   auto stage = [&]() {
+    if (RAG_O) {
+      const u16x8 v = __builtin_bit_cast(u16x8, rg[0]);
 #pragma unroll
-    for (int it = 0; it < ITG; ++it) *reinterpret_cast<uint4*>(lg + (it * RG + g_row) * SG + g_chunk * 16) = rg[it];
-#pragma unroll
-    for (int l = 0; l < 3; ++l)
-#pragma unroll
-      for (int it = 0; it < ITA; ++it) {
-        const int c = it * 64 + lane;
-        const int row = c / CHX, chunk = c % CHX;
-        if (row < AR) *reinterpret_cast<uint4*>(la + (l * AR + row) * SX + chunk * 16) = ra[l][it];
+      for (int j = 0; j < 8; ++j) {
+        const int e = j * 64 + lane;
+        const int row = e / C_out, col = e % C_out;
+        if (row < 32) *reinterpret_cast<unsigned short*>(lg + row * SG + col * 2) = v[j];
       }
+    } else {
+#pragma unroll
+      for (int it = 0; it < ITG; ++it) *reinterpret_cast<uint4*>(lg + (it * RG + g_row) * SG + g_chunk * 16) = rg[it];
+    }
+#pragma unroll
+    for (int l = 0; l < KP; ++l) {
+      if (RAG_K) {
+        const u16x8 v = __builtin_bit_cast(u16x8, ra[l][0]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int e = j * 64 + lane;
+          const int row = e / C_in, col = e % C_in;
+          if (row < AR) *reinterpret_cast<unsigned short*>(la + (l * AR + row) * SX + col * 2) = v[j];
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < ITA; ++it) {
+          const int c = it * 64 + lane;
+          const int row = c / CHX, chunk = c % CHX;
+          if (row < AR) *reinterpret_cast<uint4*>(la + (l * AR + row) * SX + chunk * 16) = ra[l][it];
+        }
+      }
+    }
   };
   const int fr_row = (lane >> 4) * 4 + ((lane & 15) >> 2), fr_col = (lane & 3) * 8;
   auto frag = [&](unsigned char* base, int pitch, int row0, int tl) -> bf16x8_t {
@@ -188,9 +243,9 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
     return __builtin_bit_cast(bf16x8_t, both);
   };
 
-  f32x4_t acc[9][MT][NT];
+  f32x4_t acc[TP][MT][NT];
 #pragma unroll
-  for (int tp = 0; tp < 9; ++tp)
+  for (int tp = 0; tp < TP; ++tp)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -207,9 +262,9 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
 #pragma unroll
     for (int m = 0; m < MT; ++m) fa[m] = frag(lg, SG, 0, m);
 #pragma unroll
-    for (int l = 0; l < 3; ++l)
+    for (int l = 0; l < KP; ++l)
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
+      for (int dx = 0; dx < KP; ++dx) {
         bf16x8_t fb[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) fb[n] = frag(la, SX, l * AR + dx, n);
@@ -217,7 +272,7 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int n = 0; n < NT; ++n)
-            acc[l * 3 + dx][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], fb[n], acc[l * 3 + dx][m][n], 0, 0, 0);
+            acc[l * KP + dx][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], fb[n], acc[l * KP + dx][m][n], 0, 0, 0);
       }
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
@@ -229,7 +284,7 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
     __syncthreads();
     if (wave == w) {
 #pragma unroll
-      for (int tp = 0; tp < 9; ++tp)
+      for (int tp = 0; tp < TP; ++tp)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -240,7 +295,7 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
-      for (int tp = 0; tp < 9; ++tp)
+      for (int tp = 0; tp < TP; ++tp)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -250,28 +305,42 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
     }
   }
   if (wave == 0) {
-    const int taps = g.kd * 9;
+    const int taps = g.kd * TP;
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp)
+    for (int tp = 0; tp < TP; ++tp)
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int o = o_base + m * 16 + mg + i;
 #pragma unroll
-          for (int n = 0; n < NT; ++n)
-            dWp[(((long)slot * taps + dzi * 9 + tp) * C_out + o) * C_in + k_base + n * 16 + nn] = acc[tp][m][n][i];
+          for (int n = 0; n < NT; ++n) {
+            const int k = k_base + n * 16 + nn;
+            if ((!RAG_O || o < C_out) && (!RAG_K || k < C_in))
+              dWp[(((long)slot * taps + dzi * TP + tp) * C_out + o) * C_in + k] = acc[tp][m][n][i];
+          }
         }
   }
 }
 
+// out[i] = sum_s part[s][i] in a fixed tree: 16 elements x 16 slot lanes per workgroup (lane j adds slots j, j+16, ...
+// in order, then the 16 lane sums in lane order)
 __global__ void __launch_bounds__(256)
 reduce_slots2_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int slots) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  __shared__ float sm[16][17];
+  const int e = threadIdx.x & 15, j = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + e;
   float a = 0.f;
-  for (int s = 0; s < slots; ++s) a += part[(long)s * n + i];
-  out[i] = a;
+  if (i < n)
+    for (int s = j; s < slots; s += 16) a += part[(long)s * n + i];
+  sm[j][e] = a;
+  __syncthreads();
+  if (j == 0 && i < n) {
+    float t = sm[0][e];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += sm[q][e];
+    out[i] = t;
+  }
 }
 
 // ---- activation derivative through the norm affine: dt = da * act'(a*x + b);  dp = da * min(t, 0) (PReLU weight) ----
@@ -379,15 +448,19 @@ using namespace pytc;
     set_error(what ": bad dtype %d", dtype); return PYTC_ERR_INVALID; }
 
 // launch plan shared by the workspace query and the launch
-struct CwPlan { bool mfma; int mt, nt, tiles, slots; long per_slot; };
+struct CwPlan { bool mfma, rag_o, rag_k; int mt, nt, kp, tiles, slots; long per_slot; };
 static CwPlan cw_plan(int N, int D, int H, int W, int C_in, int C_out, const int32_t* k, int dtype) {
   CwPlan p{};
   const long rows_total = (long)N * D * H * W;
-  p.mfma = dtype == PYTC_BF16 && k[1] == 3 && k[2] == 3 && C_in % 16 == 0 && C_out % 16 == 0 && (tuning_get("conv_wgrad_mfma", 1) != 0);
+  p.rag_o = C_out < 16;
+  p.rag_k = C_in < 16;
+  p.kp = k[1];
+  p.mfma = dtype == PYTC_BF16 && k[1] == k[2] && (k[1] == 3 || k[1] == 1) && (p.rag_o || C_out % 16 == 0) &&
+           (p.rag_k || C_in % 16 == 0) && (tuning_get("conv_wgrad_mfma", 1) != 0);
   if (p.mfma) {
-    p.mt = C_out % 32 == 0 ? 2 : 1;
-    p.nt = C_in % 32 == 0 ? 2 : 1;
-    p.tiles = (C_out / (p.mt * 16)) * (C_in / (p.nt * 16));
+    p.mt = (!p.rag_o && C_out % 32 == 0) ? 2 : 1;
+    p.nt = (!p.rag_k && C_in % 32 == 0) ? 2 : 1;
+    p.tiles = (p.rag_o ? 1 : C_out / (p.mt * 16)) * (p.rag_k ? 1 : C_in / (p.nt * 16));
     const long units = (long)N * D * H * ((W + 31) / 32);
     long s = 4096 / ((long)p.tiles * k[0]);            // ~4096 workgroups in flight over the launch
     if (s > units / 8) s = units / 8;                  // >= 2 units per wave
@@ -423,11 +496,19 @@ extern "C" int pytc_conv3d_wgrad(const void* a, const void* dy, float* dW, float
     const long blocks = (long)((slots + 7) / 8) * 8 * p.tiles * g.kd;
     const bf16_t* ap = (const bf16_t*)a;
     const bf16_t* dp = (const bf16_t*)dy;
-#define CW_LAUNCH(MT, NT) hipLaunchKernelGGL((conv3d_wgrad_mfma_kernel<MT, NT>), dim3((unsigned)blocks), dim3(256), 0, s, ap, dp, workspace, N, g, C_in, C_out, p.per_slot, slots, p.tiles)
-    if (p.mt == 2 && p.nt == 2) CW_LAUNCH(2, 2);
-    else if (p.mt == 2) CW_LAUNCH(2, 1);
-    else if (p.nt == 2) CW_LAUNCH(1, 2);
-    else CW_LAUNCH(1, 1);
+#define CW_LAUNCH(MT, NT, KP, RO, RK) hipLaunchKernelGGL((conv3d_wgrad_mfma_kernel<MT, NT, KP, RO, RK>), dim3((unsigned)blocks), dim3(256), 0, s, ap, dp, workspace, N, g, C_in, C_out, p.per_slot, slots, p.tiles)
+#define CW_SHAPES(KP)                                                         \
+    if (p.rag_o && p.rag_k) CW_LAUNCH(1, 1, KP, true, true);                  \
+    else if (p.rag_o && p.nt == 2) CW_LAUNCH(1, 2, KP, true, false);          \
+    else if (p.rag_o) CW_LAUNCH(1, 1, KP, true, false);                       \
+    else if (p.rag_k && p.mt == 2) CW_LAUNCH(2, 1, KP, false, true);          \
+    else if (p.rag_k) CW_LAUNCH(1, 1, KP, false, true);                       \
+    else if (p.mt == 2 && p.nt == 2) CW_LAUNCH(2, 2, KP, false, false);       \
+    else if (p.mt == 2) CW_LAUNCH(2, 1, KP, false, false);                    \
+    else if (p.nt == 2) CW_LAUNCH(1, 2, KP, false, false);                    \
+    else CW_LAUNCH(1, 1, KP, false, false);
+    if (p.kp == 3) { CW_SHAPES(3) } else { CW_SHAPES(1) }
+#undef CW_SHAPES
 #undef CW_LAUNCH
   } else {
     const long rps = p.per_slot;
@@ -438,7 +519,7 @@ extern "C" int pytc_conv3d_wgrad(const void* a, const void* dy, float* dW, float
                 "conv3d_wgrad")
   }
   const long nW = (long)taps * C_out * C_in;
-  hipLaunchKernelGGL(reduce_slots2_kernel, dim3(ceil_div(nW, 256)), dim3(256), 0, s, workspace, dW, nW, slots);
+  hipLaunchKernelGGL(reduce_slots2_kernel, dim3(ceil_div(nW, 16)), dim3(256), 0, s, workspace, dW, nW, slots);
   PYTC_LAUNCH_CHECK("conv3d_wgrad");
   return PYTC_OK;
 }

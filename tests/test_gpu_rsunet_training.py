@@ -230,7 +230,10 @@ def test_minimal_rsunet_tutorial_train_then_infer(tmp_path):
 
 @pytest.mark.parametrize("ci,co,ks,shape", [(16, 16, (3, 3, 3), (3, 5, 32)), (32, 32, (3, 3, 3), (4, 6, 40)),
                                             (16, 32, (1, 3, 3), (2, 7, 20)), (64, 48, (3, 3, 3), (3, 4, 70)),
-                                            (32, 16, (5, 3, 3), (6, 3, 33))])
+                                            (32, 16, (5, 3, 3), (6, 3, 33)), (1, 16, (3, 3, 3), (3, 5, 37)),
+                                            (16, 3, (1, 1, 1), (3, 5, 37)), (32, 12, (1, 1, 1), (2, 3, 64)),
+                                            (2, 32, (1, 3, 3), (2, 6, 31)), (3, 5, (3, 3, 3), (3, 4, 20)),
+                                            (48, 16, (1, 1, 1), (2, 5, 33))])
 def test_conv3d_wgrad_mfma_bf16(ci, co, ks, shape):
     """bf16 weight gradient on MFMA (LDS transpose reads) vs fp32 autograd on the same bf16-rounded operands, and
     vs the VALU kernel (tuning knob) on identical inputs."""
