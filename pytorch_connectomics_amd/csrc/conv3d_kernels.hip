@@ -134,6 +134,176 @@ conv3d_kernel(ConvParams p) {
   }
 }
 
+// ---- LDS-tiled form (bf16, C_in % 8 == 0) ------------------------------------------------------------------------------
+// A workgroup owns a 4 x 8 x 16 (z, y, x) block of output voxels and MT*16 output channels.  Per chunk of KC input
+// channels it stages the haloed input block ONCE into LDS with the pre-activation f already applied (the direct kernel
+// above re-loads and re-activates every voxel once per tap), zero outside the volume, then runs the GEMM with the
+// reduction index flattened over (tap, channel-in-chunk): group g covers 32 consecutive flattened indices, lane group
+// kb its 8-channel slice of ONE tap, so a B fragment is one ds_read_b128 at  voxel(lane) + koff[g][kb]  and narrow
+// layers (C_in = 8 / 16) fill the K = 32 of an MFMA with 4 / 2 taps instead of zero padding.  wave = z plane of the
+// block, N tile = one 16-voxel x row.  Weights: packed [mtile][group][lane][8] (conv3d_pack_flat_kernel), streamed
+// from L1/L2 one group ahead of the MFMAs.
+constexpr int CT_TZ = 4, CT_TY = 8, CT_TX = 16;
+struct ConvTile { int KC, nchunks, G, tzh, tyh, txh, tiles_z, tiles_y, tiles_x; };
+
+static __host__ __device__ inline int conv_kc(int C_in) { return C_in % 32 == 0 ? 32 : (C_in % 16 == 0 ? 16 : 8); }
+
+template <int MT>
+__global__ void __launch_bounds__(256, 2)
+conv3d_tile_kernel(ConvParams p, ConvTile t) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int NT = CT_TY;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = lane & 15, kb = lane >> 4;
+  const int P = t.KC * 2;                                   // LDS bytes per staged voxel
+  const int tile_vox = t.tzh * t.tyh * t.txh;
+  const int ZOFF = tile_vox * P;                            // 16 zero bytes: the operand of padded K slots
+  int* koff = reinterpret_cast<int*>(lds + ZOFF + 16);      // [G][4]
+  // block -> (n, z tile, y tile, x tile); blockIdx.y = group of MT output-channel tiles
+  long b = blockIdx.x;
+  const int bx = (int)(b % t.tiles_x); b /= t.tiles_x;
+  const int by = (int)(b % t.tiles_y); b /= t.tiles_y;
+  const int bz = (int)(b % t.tiles_z);
+  const int n = (int)(b / t.tiles_z);
+  const int z0 = bz * CT_TZ, y0 = by * CT_TY, x0 = bx * CT_TX;
+  const int mt0 = blockIdx.y * MT;
+  const int pd = p.kd / 2, ph = p.kh / 2, pw = p.kw / 2;
+  const int ntap = p.kd * p.kh * p.kw;
+  const long rps = (long)p.D * p.H * p.W;
+  const bf16_t* xn = reinterpret_cast<const bf16_t*>(p.x) + (long)n * rps * p.C_in;
+
+  if (threadIdx.x < 4) reinterpret_cast<int*>(lds + ZOFF)[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < t.G * 4; i += 256) {
+    const int idx = i * 8;
+    const int tap = idx / t.KC, c = idx % t.KC;
+    int off = -1;
+    if (tap < ntap) {
+      const int dx = tap % p.kw, tt = tap / p.kw;
+      const int dy = tt % p.kh, dz = tt / p.kh;
+      off = ((dz * t.tyh + dy) * t.txh + dx) * P + c * 2;
+    }
+    koff[i] = off;
+  }
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const bf16x8_t* wp = reinterpret_cast<const bf16x8_t*>(p.wp);
+  const int Gtot = t.nchunks * t.G;
+  const int CH = t.KC / 8;                                  // 16-byte pieces per staged voxel
+  const int base0 = (wave * t.tyh * t.txh + r) * P;         // voxel (z = wave, y = 0, x = r) of the block
+  const int nt_step = t.txh * P;
+
+  for (int ck = 0; ck < t.nchunks; ++ck) {
+    if (ck > 0) __syncthreads();                            // everyone is done reading the previous chunk
+    const int c0 = ck * t.KC;
+    for (int i = threadIdx.x; i < tile_vox * CH; i += 256) {
+      const int vox = i / CH, piece = i % CH;
+      const int tx = vox % t.txh, tq = vox / t.txh;
+      const int ty = tq % t.tyh, tz = tq / t.tyh;
+      const int z = z0 + tz - pd, y = y0 + ty - ph, x = x0 + tx - pw;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (z >= 0 && z < p.D && y >= 0 && y < p.H && x >= 0 && x < p.W) {
+        const int c = c0 + piece * 8;
+        v = *reinterpret_cast<const uint4*>(xn + (((long)z * p.H + y) * p.W + x) * p.C_in + c);
+        if (p.ab != nullptr || p.act_in != PYTC_ACT_NONE) {
+          f32x8_t f = __builtin_convertvector(__builtin_bit_cast(bf16x8_t, v), f32x8_t);
+          if (p.ab != nullptr) {
+            const float* av = p.ab + ((long)n * 2 + 0) * p.C_in + c;
+            const float* bv = p.ab + ((long)n * 2 + 1) * p.C_in + c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = fmaf(f[j], av[j], bv[j]);
+          }
+          if (p.act_in != PYTC_ACT_NONE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = pre_act(f[j], p.act_in, p.act_param);
+          }
+          v = __builtin_bit_cast(uint4, __builtin_convertvector(f, bf16x8_t));
+        }
+      }
+      *reinterpret_cast<uint4*>(lds + vox * P + piece * 16) = v;
+    }
+    __syncthreads();
+
+    bf16x8_t af[MT], afn[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      af[mt] = (mt0 + mt < p.MTt) ? wp[((long)(mt0 + mt) * Gtot + ck * t.G) * 64 + lane] : bf16x8_t{};
+    for (int g = 0; g < t.G; ++g) {
+      if (g + 1 < t.G) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          afn[mt] = (mt0 + mt < p.MTt) ? wp[((long)(mt0 + mt) * Gtot + ck * t.G + g + 1) * 64 + lane] : bf16x8_t{};
+      }
+      const int ko = koff[g * 4 + kb];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int addr = ko < 0 ? ZOFF : base0 + nt * nt_step + ko;
+        const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(lds + addr);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf, acc[mt][nt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) af[mt] = afn[mt];
+    }
+  }
+
+  const int z = z0 + wave;
+  const int x = x0 + r;
+  if (z >= p.D || x >= p.W) return;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int o0 = (mt0 + mt) * 16 + kb * 4;
+    if (o0 >= p.C_out) continue;
+    float bo[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) bo[rr] = (p.bias && o0 + rr < p.C_out) ? p.bias[o0 + rr] : 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int y = y0 + nt;
+      if (y >= p.H) continue;
+      float v[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) v[rr] = apply_act(acc[mt][nt][rr] + bo[rr], p.act_out);
+      finish_and_store<bf16_t, 4>(v, p.e, n, ((long)z * p.H + y) * p.W + x, o0);
+    }
+  }
+}
+
+// packed [mtile][chunk][group][lane][8]: lane (r, kb), element j <-> flattened index q = group*32 + kb*8 + j of the chunk's
+// (tap, channel-in-chunk) reduction: tap = q / KC, channel = chunk*KC + q % KC; zero where tap >= ntap
+__global__ void __launch_bounds__(256)
+conv3d_pack_flat_kernel(const float* __restrict__ w, int C_out, int C_in, int ntap, bf16_t* __restrict__ packed, int KC,
+                        int nchunks, int G, long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i % 8);
+  long q = i / 8;
+  const int lane = (int)(q % 64); q /= 64;
+  const int g = (int)(q % G); q /= G;
+  const int ck = (int)(q % nchunks);
+  const int mt = (int)(q / nchunks);
+  const int o = mt * 16 + (lane & 15);
+  const int f = g * 32 + (lane >> 4) * 8 + j;
+  const int tap = f / KC, c = ck * KC + f % KC;
+  float v = 0.f;
+  if (o < C_out && tap < ntap) v = w[((long)o * C_in + c) * ntap + tap];
+  packed[i] = from_f32<bf16_t>(v);
+}
+
+static bool conv_tile_plan(int dtype, int C_in, int kd, int kh, int kw, ConvTile& t, size_t& lds_bytes) {
+  if (dtype != PYTC_BF16 || C_in % 8 != 0) return false;
+  t.KC = conv_kc(C_in);
+  t.nchunks = C_in / t.KC;
+  t.G = (kd * kh * kw * t.KC + 31) / 32;
+  t.tzh = CT_TZ + kd - 1; t.tyh = CT_TY + kh - 1; t.txh = CT_TX + kw - 1;
+  lds_bytes = (size_t)t.tzh * t.tyh * t.txh * t.KC * 2 + 16 + (size_t)t.G * 16;
+  return lds_bytes <= 160 * 1024 / 2;                      // two workgroups per CU
+}
+
 template <typename TW>
 __global__ void __launch_bounds__(256)
 conv3d_pack_kernel(const float* __restrict__ w, int C_out, int C_in, int ntap, TW* __restrict__ packed, int KG,
@@ -153,6 +323,27 @@ conv3d_pack_kernel(const float* __restrict__ w, int C_out, int C_in, int ntap, T
   float v = 0.f;
   if (o < C_out && k < C_in) v = w[((long)o * C_in + k) * ntap + tap];
   packed[i] = from_f32<TW>(v);
+}
+
+template <int MT>
+static void launch_conv_tile_mt(const ConvParams& p, const ConvTile& t, size_t lds_bytes, dim3 grid, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {      // dynamic LDS above 64 KB needs the opt-in, once per kernel
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_tile_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3d_tile_kernel<MT>), grid, dim3(256), lds_bytes, s, p, t);
+}
+
+static void launch_conv_tile(const ConvParams& p, ConvTile t, size_t lds_bytes, hipStream_t s) {
+  t.tiles_z = (p.D + CT_TZ - 1) / CT_TZ; t.tiles_y = (p.H + CT_TY - 1) / CT_TY; t.tiles_x = (p.W + CT_TX - 1) / CT_TX;
+  const int MT = p.MTt >= 4 ? 4 : (p.MTt >= 2 ? 2 : 1);
+  dim3 grid((unsigned)((long)p.N * t.tiles_z * t.tiles_y * t.tiles_x), (unsigned)((p.MTt + MT - 1) / MT));
+  switch (MT) {
+    case 1: launch_conv_tile_mt<1>(p, t, lds_bytes, grid, s); break;
+    case 2: launch_conv_tile_mt<2>(p, t, lds_bytes, grid, s); break;
+    default: launch_conv_tile_mt<4>(p, t, lds_bytes, grid, s); break;
+  }
 }
 
 template <typename TI, typename TW, typename TO>
@@ -188,7 +379,12 @@ extern "C" int pytc_conv3d_pack_weight(const float* w, int C_out, int C_in, int 
   PYTC_REQUIRE(total > 0, "conv3d_pack_weight: bad arguments");
   int KG = (C_in + kstep_of(dtype) - 1) / kstep_of(dtype);
   dim3 grid(ceil_div(total, 256)), block(256);
-  if (dtype == PYTC_BF16)
+  ConvTile t; size_t lds_bytes;
+  if (conv_tile_plan(dtype, C_in, kd, kh, kw, t, lds_bytes)) {      // the LDS-tiled kernel's layout (same rule as the launch)
+    const long tot2 = (long)((C_out + 15) / 16) * t.nchunks * t.G * 64 * 8;
+    hipLaunchKernelGGL(conv3d_pack_flat_kernel, dim3(ceil_div(tot2, 256)), block, 0, (hipStream_t)stream, w, C_out, C_in,
+                       kd * kh * kw, (bf16_t*)packed, t.KC, t.nchunks, t.G, tot2);
+  } else if (dtype == PYTC_BF16)
     hipLaunchKernelGGL(conv3d_pack_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, w, C_out, C_in, kd * kh * kw,
                        (bf16_t*)packed, KG, total);
   else
@@ -215,7 +411,9 @@ extern "C" int pytc_conv3d_fwd(const pytc_conv3d_args* a, void* stream) {
   p.e.rps_out = (long)a->D * a->H * a->W; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode;
   p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
   hipStream_t s = (hipStream_t)stream;
-  if (a->dtype == PYTC_F32) launch_conv<float, float, float>(p, s);
+  ConvTile t; size_t lds_bytes;
+  if (conv_tile_plan(a->dtype, a->C_in, a->kd, a->kh, a->kw, t, lds_bytes)) launch_conv_tile(p, t, lds_bytes, s);
+  else if (a->dtype == PYTC_F32) launch_conv<float, float, float>(p, s);
   else launch_conv<bf16_t, bf16_t, bf16_t>(p, s);
   PYTC_LAUNCH_CHECK("conv3d");
   return PYTC_OK;

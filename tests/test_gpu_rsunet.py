@@ -69,12 +69,14 @@ def test_rsunet_none_norm_inplace_quirk_and_builders():
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cin,cout,k", [(8, 16, (3, 3, 3)), (16, 8, (1, 3, 3)), (1, 8, (3, 3, 3)), (18, 36, (3, 3, 3)),
-                                        (6, 2, (1, 1, 1))])
+                                        (6, 2, (1, 1, 1)), (16, 16, (3, 3, 3)), (32, 64, (3, 3, 3)), (24, 16, (3, 3, 3)),
+                                        (64, 32, (1, 3, 3)), (128, 32, (3, 3, 3)), (48, 80, (3, 3, 3)),
+                                        (32, 16, (5, 5, 5)), (16, 3, (1, 1, 1)), (8, 8, (3, 1, 1))])
 def test_conv3d_with_fused_preactivation(dt, cin, cout, k):
     from pytorch_connectomics_amd import _native as nat
     from pytorch_connectomics_amd import hip_ops as ops
     torch.manual_seed(cin + cout)
-    N, D, H, W = 2, 5, 9, 11
+    N, D, H, W = (2, 5, 9, 11) if cin < 16 or cin == 18 else (2, 6, 17, 35)      # the larger one spans several LDS tiles
     x = torch.randn(N, cin, D, H, W).to(dt).float()
     w = torch.randn(cout, cin, *k) / (cin * k[0] * k[1] * k[2]) ** 0.5
     a, b = torch.rand(N, cin) + 0.5, torch.randn(N, cin) * 0.3
