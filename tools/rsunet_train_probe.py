@@ -12,7 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--patch", default="18,160,160")
 ap.add_argument("--batch", type=int, default=2)
-ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--norm", default="batch")
 ap.add_argument("--width", default="16,32,64,128")
 a = ap.parse_args()
@@ -32,7 +32,7 @@ def step():
     return loss
 
 
-for _ in range(2):
+for _ in range(5):
     step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
