@@ -373,6 +373,37 @@ int pytc_dwconv3d_generic_fwd(const void* x, void* y, const float* w, int N, int
                               const int32_t* kernel, const int32_t* stride, const int32_t* pad, const int32_t* out_dims,
                               int dtype, void* stream);
 
+/* ---- train-step epilogue on the device ------------------------------------------------
+ * Fused loss  L = w_bce * BCEWithLogits(x, t; weight, pos_weight) + w_dice * Dice(sigmoid(x), t)
+ *   (connectomics/models/losses/losses.py:17-44,190-266 WeightedBCEWithLogitsLoss with reduction='mean' - with a weight
+ *   map: the mean of weight*bce over the voxels with weight > 0, the map broadcast to the logits' shape - and MONAI DiceLoss(sigmoid=True, smooth_nr, smooth_dr): per (n, c) dice over the spatial
+ *   dims, mean over n and c; profiles/loss_profiles.yaml:2-9).  Operands are fp32 (N, C, R) with explicit element strides
+ *   {n, c, r} (the network output is channels-last memory viewed as NCDHW); weight may be NULL.
+ * pytc_bce_dice_fwd: sums [N*C][5] = (sum_{w>0} w*bce, #{w>0}, sum p*t, sum p, sum t), out [4] = (loss, bce, dice, bce denominator);
+ *   workspace pytc_bce_dice_ws_elems floats.  pytc_bce_dice_bwd: dlogits = grad_out[0] * dL/dx from the saved sums.
+ * Optimizer (training/optimization/build.py:86-130, trainer.py:321 gradient_clip_val, callbacks.py:869-907 EMA):
+ *   table = n_tensors records of 7 int64 {param, grad, exp_avg, exp_avg_sq, ema (0 = none), numel, group}; chunks =
+ *   int32 pairs (tensor, chunk index) of pytc_opt_chunk_elems() elements; groups = records of 8 floats {lr, beta1, beta2,
+ *   eps, weight_decay, 1-beta1^t, sqrt(1-beta2^t), ema_decay} in HOST memory (at most 8 groups; they travel as kernel
+ *   arguments, so the per-step scalars need no H2D copy); table and chunks in device memory.
+ * pytc_grad_norm_multi: norm_coef[0] = global L2 norm of the gradients, [1] = min(1, max_norm/(norm+1e-6)) (max_norm <= 0:
+ *   1); workspace n_chunks floats.  pytc_adamw_multi: torch.optim.AdamW update of every tensor with the gradient scaled by
+ *   norm_coef[1] (NULL: unscaled), then ema = d*ema + (1-d)*param where a record carries an ema pointer.  No host sync. */
+int64_t pytc_bce_dice_ws_elems(int N, int C, int64_t R);
+int pytc_bce_dice_fwd(const float* logits, const float* target, const float* weight, int N, int C, int64_t R,
+                      const int64_t* x_strides, const int64_t* t_strides, const int64_t* w_strides, float pos_weight,
+                      float w_bce, float w_dice, float smooth_nr, float smooth_dr, float* workspace, float* sums,
+                      float* out, void* stream);
+int pytc_bce_dice_bwd(const float* logits, const float* target, const float* weight, const float* sums, const float* out,
+                      const float* grad_out, float* dlogits, int N, int C, int64_t R, const int64_t* x_strides,
+                      const int64_t* t_strides, const int64_t* w_strides, const int64_t* d_strides, float pos_weight,
+                      float w_bce, float w_dice, float smooth_nr, float smooth_dr, void* stream);
+int pytc_opt_chunk_elems(void);
+int pytc_grad_norm_multi(const void* table, const void* chunks, int n_chunks, float max_norm, float* workspace,
+                         float* norm_coef, void* stream);
+int pytc_adamw_multi(const void* table, const void* chunks, int n_chunks, const float* groups_host, int n_groups,
+                     const float* norm_coef, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

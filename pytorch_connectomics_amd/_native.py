@@ -139,6 +139,17 @@ _SIGS = {
     "pytc_dwconv3d_generic_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                             C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
+    "pytc_bce_dice_ws_elems": (C.c_int64, [C.c_int, C.c_int, C.c_int64]),
+    "pytc_bce_dice_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_float, C.c_float, C.c_float, C.c_float,
+                                    C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pytc_bce_dice_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_float, C.c_float, C.c_float, C.c_float,
+                                    C.c_float, C.c_void_p]),
+    "pytc_opt_chunk_elems": (C.c_int, []),
+    "pytc_grad_norm_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pytc_adamw_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_void_p]),
     "pytc_pw_mlp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pytc_pw_pack_weight_paired": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pytc_pw_mlp_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p]),

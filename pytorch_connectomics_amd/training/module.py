@@ -5,8 +5,9 @@ weights [1, .5, .25, .125, .0625] (schema/model.py:46-51), AdamW with the no-wei
 (training/optimization/build.py:73-112), WarmupCosineLR (lr_scheduler.py:48-82), global-norm gradient clipping,
 DDP over RCCL, and Lightning-layout checkpoints ("state_dict" with the "model." prefix, model.py:244-297).
 
-The network forward/backward run the HIP kernels; loss and optimizer are plain PyTorch device ops for now
-(SURVEY.md section 8 row f-1 keeps them "next": fused loss / multi-tensor AdamW kernels).
+The network forward/backward run the HIP kernels; on a GPU the BCE + Dice loss and the clip + AdamW (+ EMA) update
+are HIP kernels too (training/fused.py); other loss functions and optimizers are PyTorch
+device ops.
 """
 from __future__ import annotations
 
@@ -38,13 +39,15 @@ def dice_loss_sigmoid(logits: torch.Tensor, target: torch.Tensor, smooth_nr: flo
 
 
 def weighted_bce_with_logits(logits, target, weight=None, pos_weight=None):
-    """models/losses/losses.py:190-266 (reduction='mean'; with a mask the mean is over the weight sum)."""
+    """models/losses/losses.py:17-44,190-266 (reduction='mean'; with a weight map: the mean of weight * bce over the
+    voxels whose weight is > 0, the map broadcast to the logits' shape; 0 when no voxel is valid)."""
     pw = None if pos_weight is None else torch.as_tensor([float(pos_weight)], device=logits.device, dtype=torch.float32)
     bce = F.binary_cross_entropy_with_logits(logits.float(), target.float(), pos_weight=pw, reduction="none")
     if weight is None:
         return bce.mean()
-    w = weight.float()
-    return (bce * w).sum() / w.sum().clamp_min(1e-8)
+    w = weight.float().expand_as(bce)
+    valid = w > 0
+    return (bce * w * valid).sum() / valid.sum().clamp_min(1)
 
 
 _LOSSES = {
@@ -100,6 +103,17 @@ def build_optimizer(cfg, model: nn.Module) -> torch.optim.Optimizer:
     betas = tuple(getattr(oc, "betas", (0.9, 0.999)))
     eps = float(getattr(oc, "eps", 1e-8))
     if name == "adamw":
+        fused = bool(getattr(oc, "fused", True)) and all(p.is_cuda for g in groups for p in g["params"])
+        if fused:
+            # one multi-tensor HIP launch for the clip norm and one for the update (training/fused.py); the clip value
+            # of optimization.gradient_clip_val is applied inside, so fit() skips torch's clip_grad_norm_
+            from .fused import FusedAdamW
+            ema = getattr(cfg.optimization, "ema", None)
+            ema_on = bool(getattr(ema, "enabled", False)) if ema is not None else False
+            return FusedAdamW(groups, lr=lr, betas=betas, eps=eps, weight_decay=wd,
+                              max_grad_norm=float(getattr(cfg.optimization, "gradient_clip_val", 0.0) or 0.0),
+                              ema_decay=float(getattr(ema, "decay", 0.999)) if ema_on else None,
+                              ema_warmup_steps=int(getattr(ema, "warmup_steps", 0) or 0) if ema_on else 0)
         return torch.optim.AdamW(groups, lr=lr, betas=betas, eps=eps, weight_decay=wd)
     if name == "adam":
         return torch.optim.Adam(groups, lr=lr, betas=betas, eps=eps)
@@ -127,13 +141,50 @@ class ConnectomicsModule(nn.Module):
                 raise ValueError(f"Unknown loss function {fn!r}; available: {sorted(_LOSSES)}")
             self.loss_terms.append({"fn": fn, "weight": float(get("weight", 1.0)), "pred_slice": get("pred_slice"),
                                     "target_slice": get("target_slice"), "pos_weight": get("pos_weight")})
+        self.fused_loss = bool(getattr(loss_cfg, "fused", True))
         self.global_step = 0
 
     # ---- reference-visible methods ----------------------------------------------------------------
     def forward(self, x: torch.Tensor):
         return self.model(x)
 
+    _FUSABLE = {"WeightedBCEWithLogitsLoss": "bce", "BCEWithLogitsLoss": "bce", "DiceLoss": "dice"}
+
+    def _fused_term_loss(self, pred, target, mask):
+        """All terms are BCE-with-logits / sigmoid-Dice: one fused HIP reduction per (pred_slice, target_slice) pair."""
+        from .fused import bce_dice_loss
+        groups = {}
+        for i, t in enumerate(self.loss_terms):
+            key = (str(t["pred_slice"]), str(t["target_slice"]))
+            g = groups.setdefault(key, {"bce": None, "dice": None, "t": t})
+            kind = self._FUSABLE[t["fn"]]
+            if g[kind] is not None:
+                return None                   # two terms of one kind on the same slices: take the generic path
+            g[kind] = (i, t)
+        total, parts = 0.0, {}
+        for g in groups.values():
+            t = g["t"]
+            p, y = pred, target
+            if t["pred_slice"] is not None:
+                p = pred[:, resolve_channel_indices(t["pred_slice"], num_channels=pred.shape[1], context="pred_slice")]
+            if t["target_slice"] is not None:
+                y = target[:, resolve_channel_indices(t["target_slice"], num_channels=target.shape[1], context="target_slice")]
+            wb = g["bce"][1]["weight"] if g["bce"] else 0.0
+            wd = g["dice"][1]["weight"] if g["dice"] else 0.0
+            pw = g["bce"][1]["pos_weight"] if g["bce"] and g["bce"][1]["fn"] == "WeightedBCEWithLogitsLoss" else None
+            v, out = bce_dice_loss(p, y, mask, w_bce=wb, w_dice=wd, pos_weight=pw)
+            if g["bce"]:
+                parts[f"loss_{g['bce'][0]}_{g['bce'][1]['fn']}"] = out[1]
+            if g["dice"]:
+                parts[f"loss_{g['dice'][0]}_{g['dice'][1]['fn']}"] = out[2]
+            total = total + v
+        return total, parts
+
     def _term_loss(self, pred, target, mask=None):
+        if pred.is_cuda and self.fused_loss and all(t["fn"] in self._FUSABLE for t in self.loss_terms):
+            res = self._fused_term_loss(pred, target, mask)      # finiteness is checked where fit() reads the value
+            if res is not None:
+                return res
         total, parts = 0.0, {}
         for i, t in enumerate(self.loss_terms):
             p, y = pred, target
@@ -200,6 +251,12 @@ class ConnectomicsModule(nn.Module):
               "pytc_metadata": {"format_version": 1, "model_arch": str(getattr(self.cfg.model.arch, "type", ""))}}
         if optimizer is not None:
             ck["optimizer_states"] = [optimizer.state_dict()]
+            if getattr(optimizer, "ema", None):
+                # the reference persists the EMA under its callback's state (callbacks.py:732-790: "ema_state",
+                # "updates", "decay"); same vocabulary here so either side can resume / evaluate with it
+                ck["callbacks"] = {"EMAWeightsCallback": {
+                    "ema_state": {k: v.cpu() for k, v in optimizer.ema_state_dict(self.model).items()},
+                    "updates": int(optimizer.ema_updates), "decay": float(optimizer.ema_decay)}}
         return ck
 
     def load_checkpoint_dict(self, ck: Dict[str, Any]) -> None:
@@ -241,13 +298,15 @@ def fit(module: ConnectomicsModule, batches, *, max_steps: int, device, log_ever
             out = net(batch["image"])
             loss, logs = module._compute_loss(out, batch["label"], batch.get("mask"))
             (loss / accum).backward()
-        if clip > 0:
+        if clip > 0 and not hasattr(opt, "max_grad_norm"):     # FusedAdamW clips inside its update kernel
             torch.nn.utils.clip_grad_norm_(module.model.parameters(), clip)
         opt.step()
         if sched is not None:
             sched.step()
         module.global_step += 1
         history.append(float(loss.detach()))
+        if not math.isfinite(history[-1]):
+            raise FloatingPointError(f"training loss is not finite at step {step}")
         if log and (step % log_every == 0 or step == max_steps - 1):
             log(f"step {step}: loss {history[-1]:.4f} lr {opt.param_groups[0]['lr']:.2e}")
     return history, opt

@@ -38,6 +38,7 @@ def install() -> None:
     for name in (
         "connectomics.models",
         "connectomics.models.architectures",
+        "connectomics.models.losses",          # stub package: only losses.py (torch-only) is imported, not build.py (MONAI)
         "connectomics.inference",
         "connectomics.config",
         "connectomics.data",

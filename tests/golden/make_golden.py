@@ -442,9 +442,44 @@ def lazy():
         out[f"grid{i}_ov"] = np.asarray(ov, np.float64)
     save("lazy.npz", **out)
 
+# ---------------------------------------------------------------- weighted BCE (train-step loss)
+def losses():
+    """connectomics/models/losses/losses.py:17-44,190-266: WeightedBCEWithLogitsLoss values and input gradients for
+    masks that are binary / broadcast over channels / real-valued with zero and negative entries / all invalid."""
+    ls = S.ref("connectomics.models.losses.losses")
+    g = torch.Generator().manual_seed(2024)
+    out = {}
+    cases = {"plain": (2, None, None), "pos_weight": (1, None, 2.5), "mask_bcast": (3, "bcast", None),
+             "mask_full_pw": (2, "full", 0.4), "mask_real": (2, "real", None), "mask_none_valid": (1, "zero", None)}
+    for name, (C, mk, pw) in cases.items():
+        x = (torch.randn(2, C, 5, 6, 7, generator=g) * 2.5).requires_grad_()
+        t = (torch.rand(2, C, 5, 6, 7, generator=g) > 0.7).float()
+        w = None
+        if mk == "bcast":
+            w = (torch.rand(2, 1, 5, 6, 7, generator=g) > 0.3).float()
+        elif mk == "full":
+            w = (torch.rand(2, C, 5, 6, 7, generator=g) > 0.5).float()
+        elif mk == "real":
+            w = torch.randn(2, C, 5, 6, 7, generator=g)          # negative and positive weights
+            w[0, 0, :2] = 0.0
+        elif mk == "zero":
+            w = torch.zeros(2, 1, 5, 6, 7)
+        crit = ls.WeightedBCEWithLogitsLoss(pos_weight=pw)
+        v = crit(x, t, weight=w)
+        gx = torch.autograd.grad(v, x, allow_unused=True)[0] if v.requires_grad else None
+        out[f"{name}__x"] = x.detach().numpy()
+        out[f"{name}__t"] = t.numpy()
+        if w is not None:
+            out[f"{name}__w"] = w.numpy()
+        out[f"{name}__pw"] = np.asarray([-1.0 if pw is None else pw], np.float64)
+        out[f"{name}__loss"] = np.asarray([float(v)], np.float64)
+        out[f"{name}__grad"] = (torch.zeros_like(x) if gx is None else gx).numpy()
+        print(name, float(v))
+    save("losses.npz", **out)
+
 
 if __name__ == "__main__":
-    parts = {"grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
+    parts = {"losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
              "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:

@@ -125,3 +125,21 @@ def _ddp_worker(rank, world, port):
 
 def test_ddp_gloo_two_ranks():
     mp.spawn(_ddp_worker, args=(2, 29500 + (os.getpid() + 7) % 2000), nprocs=2, join=True)
+
+
+def test_weighted_bce_matches_reference_fixture():
+    """tests/golden/losses.npz: the reference's WeightedBCEWithLogitsLoss (losses.py:17-44,190-266) values and gradients."""
+    import numpy as np
+    from pathlib import Path
+    z = np.load(Path(__file__).parent / "golden" / "losses.npz")
+    names = sorted({k.split("__")[0] for k in z.files})
+    assert len(names) == 6
+    for n in names:
+        x = torch.from_numpy(z[f"{n}__x"]).requires_grad_()
+        t = torch.from_numpy(z[f"{n}__t"])
+        w = torch.from_numpy(z[f"{n}__w"]) if f"{n}__w" in z.files else None
+        pw = float(z[f"{n}__pw"][0])
+        v = weighted_bce_with_logits(x, t, w, None if pw < 0 else pw)
+        assert abs(float(v) - float(z[f"{n}__loss"][0])) < 1e-6, n
+        v.backward()
+        assert torch.allclose(x.grad, torch.from_numpy(z[f"{n}__grad"]), atol=1e-8, rtol=1e-5), n
