@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from ..chunked import ChunkRef, ResumeManifest, build_chunk_grid, resolve_halo_region
+from .crop import cropped_shape, resolve_global_prediction_crop
 from .lazy import get_lazy_image_reference_shape, lazy_predict_region
 
 logger = logging.getLogger(__name__)
@@ -120,7 +121,12 @@ def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, de
     output_path = Path(output_path)
     if output_path.suffix != ".npy":
         output_path = output_path.with_suffix(output_path.suffix + ".npy")
-    vol_shape = get_lazy_image_reference_shape(volume)
+    input_shape = get_lazy_image_reference_shape(volume)
+    # the chunk grid lives in the CROPPED output space (user crop_pad + DeepEM affinity border, reference
+    # chunked.py:743-755); a chunk's core in input coordinates is shifted by the leading crop
+    crop_pad = resolve_global_prediction_crop(cfg)
+    crop_before = tuple(int(crop_pad[a][0]) for a in range(3))
+    vol_shape = cropped_shape(input_shape[-3:], crop_pad)
     ch_cfg = getattr(getattr(cfg, "inference", None), "chunking", None)
     halo = tuple(int(v) for v in (getattr(ch_cfg, "halo", None) or (0, 0, 0)))
     chunk_shape = resolve_chunk_shape(cfg, vol_shape)
@@ -135,7 +141,8 @@ def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, de
         mine = [(i, c) for i, c in enumerate(chunks) if i % world == rank]
     manifest = ResumeManifest.load_or_create(cdir / f"manifest_rank{rank if ext is None else ext[0]}.json",
                                              {"chunk_shape": list(chunk_shape), "output_shape": list(vol_shape),
-                                              "halo": list(halo)}, overwrite=overwrite)
+                                              "halo": list(halo), "crop_pad": [list(p) for p in crop_pad]},
+                                             overwrite=overwrite)
     if predict_region_fn is None:
         def predict_region_fn(start, stop):
             return lazy_predict_region(cfg, forward_fn, volume, region_start=start, region_stop=stop, device=device,
@@ -146,7 +153,7 @@ def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, de
         if f.exists() and c.key in manifest.completed:     # idempotent resume (reference chunked.py:510-523)
             logger.info("chunk %s already done, skipping", c.key)
             continue
-        read_lo, read_hi, core = resolve_halo_region(c, vol_shape, halo=halo)
+        read_lo, read_hi, core = resolve_halo_region(c, input_shape[-3:], halo=halo, crop_before=crop_before)
         pred = predict_region_fn(read_lo, read_hi)
         core_pred = pred[(0, slice(None)) + core]
         arr = core_pred.detach().float().cpu().numpy() if isinstance(core_pred, torch.Tensor) else np.asarray(core_pred)

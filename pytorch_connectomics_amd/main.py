@@ -127,6 +127,11 @@ def run_test(cfg, args) -> dict:
                 x = x.unsqueeze(0)
             mgr = InferenceManager(cfg=cfg, model=model, forward_fn=model.forward)
             pred_t = mgr.predict_with_tta(x)
+            # prediction-space crop: user crop_pad + DeepEM affinity border (test_pipeline.py:734, prediction_crops.py:240-256)
+            from .inference.crop import crop_spatial_by_pad, resolve_global_prediction_crop
+            crop_pad = resolve_global_prediction_crop(cfg)
+            if any(lo or hi for lo, hi in crop_pad):
+                pred_t = crop_spatial_by_pad(pred_t, crop_pad, item_name="prediction").contiguous()
             # semantic transform -> storage dtype on the device, then one D2H copy of the (smaller) result
             from .inference.artifact import build_prediction_artifact_metadata, write_prediction_artifact
             from .inference.output import apply_prediction_transform, apply_storage_dtype_transform
@@ -138,7 +143,7 @@ def run_test(cfg, args) -> dict:
             tc = getattr(cfg.inference, "prediction_transform", None)
             md = build_prediction_artifact_metadata(
                 cfg, image_path=image_spec, checkpoint_path=args.checkpoint, input_shape=vol.shape[-3:],
-                final_shape=arr.shape[-3:], intensity_scale=getattr(tc, "intensity_scale", None) if tc else None,
+                final_shape=arr.shape[-3:], crop_pad=crop_pad, intensity_scale=getattr(tc, "intensity_scale", None) if tc else None,
                 intensity_dtype=str(arr.dtype))
             write_prediction_artifact(out_dir / f"{name}_prediction.h5", arr, metadata=md)
             pred_t = pred_t if isinstance(pred_t, torch.Tensor) else torch.from_numpy(np.asarray(pred_t))

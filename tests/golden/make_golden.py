@@ -478,8 +478,45 @@ def losses():
     save("losses.npz", **out)
 
 
+# ---------------------------------------------------------------- prediction crops (crop_pad + DeepEM affinity border)
+def crops():
+    import json
+    from types import SimpleNamespace as NS
+    aff = S.ref("connectomics.data.processing.affinity")
+    cg = S.ref("connectomics.inference.chunk_grid")
+    out = {"crop_pad": [], "global": [], "normalize": []}
+    offset_sets = [["1-0-0", "0-1-0", "0-0-1"], ["1-0-0", "0-1-0", "0-0-1", "3-0-0", "0-9-0", "0-0-9", "0-0-27"],
+                   [[-1, 0, 0], [0, -2, 0], [0, 0, 3], [2, 4, -5]], ["0-0-0"], [[4, 0, 0], [-4, 0, 0], [0, 7, -7]]]
+    for offs in offset_sets:
+        parsed = aff.parse_affinity_offsets(offs)
+        for mode in ("deepem", "banis"):
+            out["crop_pad"].append({"offsets": [list(o) for o in parsed], "mode": mode,
+                                    "pad": [list(p) for p in aff.compute_affinity_crop_pad(parsed, affinity_mode=mode)]})
+    for v in (None, [], [1, 2, 3], [1, 2, 3, 4, 5, 6], (0, 0, 7)):
+        out["normalize"].append({"value": None if v is None else list(v), "pad": [list(p) for p in cg.normalize_crop_pad(v)]})
+
+    def cfg_for(offsets, mode, crop_pad=None, select=None, extra_target=False):
+        targets = [{"name": "affinity", "kwargs": {"offsets": offsets, "affinity_mode": mode}}]
+        if extra_target:
+            targets = [{"name": "binary", "kwargs": {}}] + targets
+        return NS(model=NS(primary_head=None, heads=None, out_channels=len(offsets) + int(extra_target)),
+                  data=NS(label_transform=NS(stack_outputs=True, targets=targets)),
+                  inference=NS(model=NS(crop_pad=crop_pad, select_channel=select, head=None)))
+
+    cases = [(offset_sets[0], "deepem", None, None, False), (offset_sets[1], "deepem", [2, 0, 0], None, False),
+             (offset_sets[1], "banis", [1, 2, 3, 4, 5, 6], None, False), (offset_sets[1], "deepem", None, "0:3", False),
+             (offset_sets[2], "deepem", [1, 1, 1], [0, 3], False), (offset_sets[1], "deepem", None, "1:4", True)]
+    for offs, mode, cp, sel, extra in cases:
+        c = cfg_for(offs, mode, cp, sel, extra)
+        out["global"].append({"offsets": offs, "mode": mode, "crop_pad": cp, "select": sel, "extra_target": extra,
+                              "selected_offsets": [list(o) for o in cg.resolve_selected_affinity_offsets(c)],
+                              "crop": [list(p) for p in cg.resolve_global_prediction_crop(c)]})
+    (HERE / "crops.json").write_text(json.dumps(out, indent=0))
+    print("wrote crops.json", {k: len(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    parts = {"losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
+    parts = {"crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
              "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:

@@ -131,3 +131,21 @@ def _worker(rank, world, port, tmp):
 def test_chunked_two_ranks_gloo(tmp_path):
     port = 29500 + os.getpid() % 2000
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+
+
+def test_chunked_with_user_crop_and_deepem_affinity_border(tmp_path):
+    """The chunk grid covers the CROPPED output space; the stitched result equals the cropped whole-volume prediction
+    (reference chunked.py:743-755, chunk_grid.py:56-77)."""
+    vol = np.random.default_rng(1).random((12, 13, 11)).astype(np.float32)
+    cfg = _cfg((4, 5, 6), halo=(1, 1, 1))
+    cfg.inference.model = NS(crop_pad=[1, 0, 0, 2, 0, 0], select_channel=None, head=None)
+    cfg.model = NS(primary_head=None, heads=None, out_channels=2)
+    cfg.data = NS(label_transform=NS(stack_outputs=True, targets=[
+        {"name": "affinity", "kwargs": {"offsets": ["0-0-1", "0-2-0"], "affinity_mode": "deepem"}}]))
+    out = run_chunked_prediction_inference(cfg, None, vol, output_path=tmp_path / "c.npy", predict_region_fn=_fake_predictor(vol))
+    want = np.stack([vol, vol * 2 + 1])[:, 1:, 2:-2, 1:]         # crop_pad (1,0),(0,2),(0,0) + DeepEM border (0,0),(2,0),(1,0)
+    assert out.shape == want.shape
+    np.testing.assert_array_equal(out, want)
+    cfg.inference.model.crop_pad = [6, 6, 0, 0, 0, 0]
+    with pytest.raises(ValueError, match="too large"):
+        run_chunked_prediction_inference(cfg, None, vol, output_path=tmp_path / "d.npy", predict_region_fn=_fake_predictor(vol))

@@ -115,3 +115,41 @@ def test_affinity_tta_plans_match_reference(golden_dir):
         build_affinity_tta_plan(cfg, augmentation_combinations=[([], (1, 2), 1)], num_raw=3, requested_head=None)
     assert build_affinity_tta_plan(NS(model=NS(out_channels=1), data=NS()), augmentation_combinations=[([], None, 0)],
                                    num_raw=1, requested_head=None) is None
+
+
+def test_prediction_crop_helpers_match_reference_fixture():
+    """tests/golden/crops.json: compute_affinity_crop_pad / normalize_crop_pad / resolve_global_prediction_crop of the
+    reference (affinity.py:291-316, inference/chunk_grid.py:22-77) for DeepEM and banis conventions."""
+    import json
+    from pathlib import Path
+    from types import SimpleNamespace as NS
+    import numpy as np
+    import pytest
+    import torch
+    from pytorch_connectomics_amd.inference import crop as cr
+    fx = json.loads((Path(__file__).parent / "golden" / "crops.json").read_text())
+    assert len(fx["crop_pad"]) == 10 and len(fx["global"]) == 6
+    for c in fx["crop_pad"]:
+        got = cr.compute_affinity_crop_pad([tuple(o) for o in c["offsets"]], affinity_mode=c["mode"])
+        assert [list(p) for p in got] == c["pad"], c
+    for c in fx["normalize"]:
+        assert [list(p) for p in cr.normalize_crop_pad(c["value"])] == c["pad"]
+    with pytest.raises(ValueError):
+        cr.normalize_crop_pad([1, 2])
+    for c in fx["global"]:
+        targets = [{"name": "affinity", "kwargs": {"offsets": c["offsets"], "affinity_mode": c["mode"]}}]
+        if c["extra_target"]:
+            targets = [{"name": "binary", "kwargs": {}}] + targets
+        cfg = NS(model=NS(primary_head=None, heads=None, out_channels=len(c["offsets"]) + int(c["extra_target"])),
+                 data=NS(label_transform=NS(stack_outputs=True, targets=targets)),
+                 inference=NS(model=NS(crop_pad=c["crop_pad"], select_channel=c["select"], head=None)))
+        assert [list(o) for o in cr.resolve_selected_affinity_offsets(cfg)] == c["selected_offsets"], c
+        assert [list(p) for p in cr.resolve_global_prediction_crop(cfg)] == c["crop"], c
+    a = np.arange(2 * 5 * 6 * 7).reshape(2, 5, 6, 7)
+    got = cr.crop_spatial_by_pad(a, ((1, 0), (0, 2), (3, 1)))
+    assert got.shape == (2, 4, 4, 3) and got[0, 0, 0, 0] == a[0, 1, 0, 3]
+    assert torch.equal(cr.crop_spatial_by_pad(torch.from_numpy(a), ((1, 0), (0, 2), (3, 1))), torch.from_numpy(got.copy()))
+    assert cr.crop_spatial_by_offsets(a, [(1, 0, 0), (0, -2, 0)], affinity_mode="deepem").shape == (2, 4, 4, 7)
+    with pytest.raises(ValueError):
+        cr.crop_spatial_by_pad(a, ((3, 2), (0, 0), (0, 0)))
+    assert cr.cropped_shape((10, 20, 30), ((1, 2), (0, 0), (3, 0))) == (7, 20, 27)
