@@ -87,6 +87,7 @@ def train_leg(dev, rank, world, args, barrier):
     from pytorch_connectomics_amd.models import build_model as bm
     from pytorch_connectomics_amd.training.module import build_optimizer, synthetic_batches
     from pytorch_connectomics_amd.training.fused import bce_dice_loss
+    from pytorch_connectomics_amd.utils.hostgc import quiesce_gc
     from pytorch_connectomics_amd.config import ConfigNode, schema_defaults
     cfg = ConfigNode(schema_defaults())
     cfg.model.arch.type, cfg.model.in_channels, cfg.model.out_channels = "mednext", 1, 1
@@ -116,6 +117,7 @@ def train_leg(dev, rank, world, args, barrier):
 
     for i in range(max(1, min(args.warmup, 3))):
         tstep(i)
+    quiesce_gc()          # what training/module.py:fit does after its first steps (utils/hostgc.py)
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
@@ -133,7 +135,7 @@ def train_leg(dev, rank, world, args, barrier):
             "batch_per_gpu": args.train_batch, "patch": list(ROI), "dtype": "bf16 activations, fp32 master weights",
             "parallelism": f"ddp{world}" if world > 1 else "single", "scaling": "weak",
             "includes": "forward + backward + fused BCE/Dice loss + grad-norm clip + AdamW step, all HIP kernels",
-            "final_loss": float(loss)}
+            "final_loss": float(loss.detach())}
 
 
 def pmc_traffic_bytes(label):

@@ -356,6 +356,19 @@ int pytc_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, int N, cons
  * pytc_maxpool3d_bwd: dx = 0 except the first maximum of every window, which receives dy (nn.MaxPool3d backward).
  * pytc_dwconv3d_generic_fwd: anisotropic depthwise conv (kernel / stride / pad per axis), the backward-data of
  *   pytc_dwconvT3d_generic_fwd (BilinearUp3d, rsunet.py:33-70). */
+ /* pytc_conv3d_pack_weight_dgrad: the packed image of the DATA-GRADIENT conv (C_out -> C_in channels, mirrored taps) read
+ *   straight from the forward weight [C_out][C_in][kd][kh][kw]; feed it to pytc_conv3d_fwd with C_in/C_out swapped.
+ * pytc_norm_bwd_means: from s [N][2][C] (pytc_norm_bwd_stats): dbeta / dgamma (may be NULL) and the group means M [N][2][C]
+ *   of gamma*s that pytc_norm_bwd_apply_general consumes; groups > 0: channel groups within a sample (GroupNorm; groups = C:
+ *   InstanceNorm), groups = 0: over the batch (BatchNorm); rows = voxels per sample.
+ * pytc_bn_update_running: nn.BatchNorm3d's running_mean / running_var update from the batch (mean, rstd) [2][C]
+ *   (unbiased variance, momentum blend); count = N * voxels. */
+int pytc_conv3d_pack_weight_dgrad(const float* w, int C_out, int C_in, int kd, int kh, int kw, void* packed, int dtype,
+                                  void* stream);
+int pytc_norm_bwd_means(const float* s, const float* gamma, float* M, float* dgamma, float* dbeta, int N, int C, int groups,
+                        float rows, void* stream);
+int pytc_bn_update_running(const float* mean_rstd, float* running_mean, float* running_var, int C, float count, float eps,
+                           float momentum, void* stream);
 int64_t pytc_conv3d_wgrad_ws_elems(int N, int D, int H, int W, int C_in, int C_out, const int32_t* kernel, int dtype);
 int pytc_conv3d_wgrad(const void* a, const void* dy, float* dW, float* workspace, int N, int D, int H, int W, int C_in,
                       int C_out, const int32_t* kernel, int dtype, void* stream);

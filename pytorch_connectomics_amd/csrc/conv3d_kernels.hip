@@ -134,6 +134,69 @@ conv3d_kernel(ConvParams p) {
   }
 }
 
+// ---- thin-input form (C_in <= 4: the network's first conv) --------------------------------------------------------------
+// HBM bound (reads C_in, writes C_out channels per voxel) with 27*C_in*C_out FMAs per voxel: one lane = one output voxel
+// x 16 output channels on the VALU, weights as fp32 in LDS (broadcast reads), neighbour voxels from L1/L2.  Reads the
+// same packed weight image as the MFMA kernel above.
+template <typename TI, typename TW, typename TO>
+__global__ void __launch_bounds__(256)
+conv3d_thin_in_kernel(ConvParams p) {
+  typedef Mma<TW> M;
+  constexpr int EPL = M::EPL;
+  extern __shared__ __attribute__((aligned(16))) float wl[];            // [tap][ci][16]
+  const int n = blockIdx.z, oc0 = blockIdx.y * 16;
+  const int ntap = p.kd * p.kh * p.kw;
+  const TW* wp = reinterpret_cast<const TW*>(p.wp);
+  for (int i = threadIdx.x; i < ntap * p.C_in * 16; i += 256) {
+    const int o = i % 16, ci = (i / 16) % p.C_in, tap = i / (16 * p.C_in);
+    const long q = ((((long)blockIdx.y * ntap + tap) * p.KG + ci / M::KSTEP) * 64 + ((ci % M::KSTEP) / EPL) * 16 + o) * EPL + ci % EPL;
+    wl[i] = to_f32<TW>(wp[q]);
+  }
+  __syncthreads();
+  const long rps = (long)p.D * p.H * p.W;
+  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rps) return;
+  const int vx = (int)(row % p.W);
+  const long tq = row / p.W;
+  const int vy = (int)(tq % p.H), vz = (int)(tq / p.H);
+  const TI* xn = reinterpret_cast<const TI*>(p.x) + (long)n * rps * p.C_in;
+  const int pd = p.kd / 2, ph = p.kh / 2, pw = p.kw / 2;
+  float acc[16];
+#pragma unroll
+  for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+  int tap = 0;
+  for (int dz = -pd; dz <= pd; ++dz)
+    for (int dy = -ph; dy <= ph; ++dy)
+      for (int dx = -pw; dx <= pw; ++dx, ++tap) {
+        const int z = vz + dz, y = vy + dy, x = vx + dx;
+        if (z < 0 || z >= p.D || y < 0 || y >= p.H || x < 0 || x >= p.W) continue;      // zero padding of f(X)
+        const TI* xv = xn + (((long)z * p.H + y) * p.W + x) * p.C_in;
+        for (int ci = 0; ci < p.C_in; ++ci) {
+          float v = to_f32<TI>(xv[ci]);
+          if (p.ab) v = fmaf(v, p.ab[((long)n * 2 + 0) * p.C_in + ci], p.ab[((long)n * 2 + 1) * p.C_in + ci]);
+          if (p.act_in != PYTC_ACT_NONE) v = pre_act(v, p.act_in, p.act_param);
+          v = to_f32<TW>(from_f32<TW>(v));                 // the MFMA kernels consume the operand rounded to TW
+          const float4* wq = reinterpret_cast<const float4*>(wl + (tap * p.C_in + ci) * 16);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 w4 = wq[q];
+            acc[q * 4 + 0] = fmaf(v, w4.x, acc[q * 4 + 0]); acc[q * 4 + 1] = fmaf(v, w4.y, acc[q * 4 + 1]);
+            acc[q * 4 + 2] = fmaf(v, w4.z, acc[q * 4 + 2]); acc[q * 4 + 3] = fmaf(v, w4.w, acc[q * 4 + 3]);
+          }
+        }
+      }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int o0 = oc0 + q * 4;
+    if (o0 >= p.C_out) continue;
+    float v[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+      v[rr] = apply_act(acc[q * 4 + rr] + ((p.bias && o0 + rr < p.C_out) ? p.bias[o0 + rr] : 0.f), p.act_out);
+    finish_and_store<TO, 4>(v, p.e, n, row, o0);
+  }
+}
+
 // ---- LDS-tiled form (bf16, C_in % 8 == 0) ------------------------------------------------------------------------------
 // A workgroup owns a 4 x 8 x 16 (z, y, x) block of output voxels and MT*16 output channels.  Per chunk of KC input
 // channels it stages the haloed input block ONCE into LDS with the pre-activation f already applied (the direct kernel
@@ -146,7 +209,10 @@ conv3d_kernel(ConvParams p) {
 constexpr int CT_TZ = 4, CT_TY = 8, CT_TX = 16;
 struct ConvTile { int KC, nchunks, G, tzh, tyh, txh, tiles_z, tiles_y, tiles_x; };
 
-static __host__ __device__ inline int conv_kc(int C_in) { return C_in % 32 == 0 ? 32 : (C_in % 16 == 0 ? 16 : 8); }
+// channels per staged chunk: the whole (narrow) layer when it fits one chunk, else the widest divisor among 32 / 16 / 8
+static __host__ __device__ inline int conv_kc(int C_in) {
+  return C_in <= 32 ? C_in : (C_in % 32 == 0 ? 32 : (C_in % 16 == 0 ? 16 : 8));
+}
 
 template <int MT>
 __global__ void __launch_bounds__(256, 2)
@@ -277,7 +343,7 @@ conv3d_tile_kernel(ConvParams p, ConvTile t) {
 // (tap, channel-in-chunk) reduction: tap = q / KC, channel = chunk*KC + q % KC; zero where tap >= ntap
 __global__ void __launch_bounds__(256)
 conv3d_pack_flat_kernel(const float* __restrict__ w, int C_out, int C_in, int ntap, bf16_t* __restrict__ packed, int KC,
-                        int nchunks, int G, long total) {
+                        int nchunks, int G, long total, long s_o, long s_c, int flip) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int j = (int)(i % 8);
@@ -290,7 +356,7 @@ conv3d_pack_flat_kernel(const float* __restrict__ w, int C_out, int C_in, int nt
   const int f = g * 32 + (lane >> 4) * 8 + j;
   const int tap = f / KC, c = ck * KC + f % KC;
   float v = 0.f;
-  if (o < C_out && tap < ntap) v = w[((long)o * C_in + c) * ntap + tap];
+  if (o < C_out && tap < ntap) v = w[o * s_o + c * s_c + (flip ? ntap - 1 - tap : tap)];
   packed[i] = from_f32<bf16_t>(v);
 }
 
@@ -307,7 +373,7 @@ static bool conv_tile_plan(int dtype, int C_in, int kd, int kh, int kw, ConvTile
 template <typename TW>
 __global__ void __launch_bounds__(256)
 conv3d_pack_kernel(const float* __restrict__ w, int C_out, int C_in, int ntap, TW* __restrict__ packed, int KG,
-                   long total) {
+                   long total, long s_o, long s_c, int flip) {
   // source: PyTorch layout [C_out][C_in][kd][kh][kw]  (tap fastest)
   typedef Mma<TW> M;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -321,7 +387,7 @@ conv3d_pack_kernel(const float* __restrict__ w, int C_out, int C_in, int ntap, T
   int o = mt * 16 + (lane & 15);
   int k = kg * M::KSTEP + (lane >> 4) * M::EPL + j;
   float v = 0.f;
-  if (o < C_out && k < C_in) v = w[((long)o * C_in + k) * ntap + tap];
+  if (o < C_out && k < C_in) v = w[o * s_o + k * s_c + (flip ? ntap - 1 - tap : tap)];
   packed[i] = from_f32<TW>(v);
 }
 
@@ -350,6 +416,12 @@ template <typename TI, typename TW, typename TO>
 static void launch_conv(const ConvParams& p, hipStream_t s) {
   constexpr int NT = 4;
   const long rps = (long)p.D * p.H * p.W;
+  const size_t thin_lds = (size_t)p.kd * p.kh * p.kw * p.C_in * 16 * sizeof(float);
+  if (p.C_in <= 4 && thin_lds <= 48 * 1024 && tuning_get("conv_thin_in", 1) != 0) {
+    dim3 grid((unsigned)((rps + 255) / 256), (unsigned)p.MTt, (unsigned)p.N);
+    hipLaunchKernelGGL((conv3d_thin_in_kernel<TI, TW, TO>), grid, dim3(256), thin_lds, s, p);
+    return;
+  }
   const int MT = p.MTt >= 4 ? 4 : (p.MTt >= 2 ? 2 : 1);
   dim3 grid((unsigned)((rps + 4L * NT * 16 - 1) / (4L * NT * 16)), (unsigned)((p.MTt + MT - 1) / MT), (unsigned)p.N);
   dim3 block(256);
@@ -369,11 +441,16 @@ static int kstep_of(int dtype) { return dtype == PYTC_BF16 ? 32 : 16; }
 extern "C" int64_t pytc_conv3d_packed_elems(int C_out, int C_in, int kd, int kh, int kw, int dtype) {
   if (C_out < 1 || C_in < 1 || kd < 1 || kh < 1 || kw < 1 || (dtype != PYTC_F32 && dtype != PYTC_BF16)) return -1;
   int ks = kstep_of(dtype);
-  return (int64_t)((C_out + 15) / 16) * 16 * kd * kh * kw * ((C_in + ks - 1) / ks) * ks;
+  const int64_t direct = (int64_t)((C_out + 15) / 16) * 16 * kd * kh * kw * ((C_in + ks - 1) / ks) * ks;
+  ConvTile t; size_t lds_bytes;
+  if (!conv_tile_plan(dtype, C_in, kd, kh, kw, t, lds_bytes)) return direct;
+  const int64_t flat = (int64_t)((C_out + 15) / 16) * t.nchunks * t.G * 64 * 8;     // every chunk pads its K to 32
+  return flat > direct ? flat : direct;
 }
 
-extern "C" int pytc_conv3d_pack_weight(const float* w, int C_out, int C_in, int kd, int kh, int kw, void* packed,
-                                       int dtype, void* stream) {
+// C_out / C_in describe the conv the packed image is FOR; (s_o, s_c, flip) say where element (o, c, tap) lives in `w`
+static int pack_conv_weight(const float* w, int C_out, int C_in, int kd, int kh, int kw, void* packed, int dtype, long s_o,
+                            long s_c, int flip, void* stream) {
   PYTC_REQUIRE(w && packed, "conv3d_pack_weight: null pointer");
   long total = pytc_conv3d_packed_elems(C_out, C_in, kd, kh, kw, dtype);
   PYTC_REQUIRE(total > 0, "conv3d_pack_weight: bad arguments");
@@ -383,15 +460,29 @@ extern "C" int pytc_conv3d_pack_weight(const float* w, int C_out, int C_in, int 
   if (conv_tile_plan(dtype, C_in, kd, kh, kw, t, lds_bytes)) {      // the LDS-tiled kernel's layout (same rule as the launch)
     const long tot2 = (long)((C_out + 15) / 16) * t.nchunks * t.G * 64 * 8;
     hipLaunchKernelGGL(conv3d_pack_flat_kernel, dim3(ceil_div(tot2, 256)), block, 0, (hipStream_t)stream, w, C_out, C_in,
-                       kd * kh * kw, (bf16_t*)packed, t.KC, t.nchunks, t.G, tot2);
+                       kd * kh * kw, (bf16_t*)packed, t.KC, t.nchunks, t.G, tot2, s_o, s_c, flip);
   } else if (dtype == PYTC_BF16)
     hipLaunchKernelGGL(conv3d_pack_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, w, C_out, C_in, kd * kh * kw,
-                       (bf16_t*)packed, KG, total);
+                       (bf16_t*)packed, KG, total, s_o, s_c, flip);
   else
     hipLaunchKernelGGL(conv3d_pack_kernel<float>, grid, block, 0, (hipStream_t)stream, w, C_out, C_in, kd * kh * kw,
-                       (float*)packed, KG, total);
+                       (float*)packed, KG, total, s_o, s_c, flip);
   PYTC_LAUNCH_CHECK("conv3d_pack_weight");
   return PYTC_OK;
+}
+
+extern "C" int pytc_conv3d_pack_weight(const float* w, int C_out, int C_in, int kd, int kh, int kw, void* packed,
+                                       int dtype, void* stream) {
+  const long ntap = (long)kd * kh * kw;
+  return pack_conv_weight(w, C_out, C_in, kd, kh, kw, packed, dtype, (long)C_in * ntap, ntap, 0, stream);
+}
+
+// weights of the data-gradient conv (C_out -> C_in channels, taps mirrored) straight from the forward weight
+// w [C_out][C_in][kd][kh][kw]: element (o' = c, c' = o, tap') = w[o][c][ntap - 1 - tap']
+extern "C" int pytc_conv3d_pack_weight_dgrad(const float* w, int C_out, int C_in, int kd, int kh, int kw, void* packed,
+                                             int dtype, void* stream) {
+  const long ntap = (long)kd * kh * kw;
+  return pack_conv_weight(w, C_in, C_out, kd, kh, kw, packed, dtype, ntap, (long)C_in * ntap, 1, stream);
 }
 
 extern "C" int pytc_conv3d_fwd(const pytc_conv3d_args* a, void* stream) {

@@ -141,6 +141,44 @@ dwconvT3d_generic_kernel(const T* __restrict__ x, T* __restrict__ y, const float
   y[i] = from_f32<T>(acc);
 }
 
+// vector form: one lane = VEC channels (16 bytes) of one output voxel, looping only over the taps that land on an input
+// voxel (k = (o + p) mod s, + s, ...: ascending like the scalar loop, so the sums are bit-identical to it)
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+dwconvT3d_generic_vec_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ w, DwTGen g, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int CV = g.C / VEC;
+  const int c = (int)(i % CV) * VEC;
+  long t = i / CV;
+  const int ox = (int)(t % g.Wo); t /= g.Wo;
+  const int oy = (int)(t % g.Ho); t /= g.Ho;
+  const int oz = (int)(t % g.Do);
+  const long n = t / g.Do;
+  const T* xn = x + n * (long)g.D * g.H * g.W * g.C;
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  for (int kz = (oz + g.pz) % g.sz; kz < g.kd; kz += g.sz) {
+    const int iz = (oz + g.pz - kz) / g.sz;
+    if (oz + g.pz - kz < 0 || iz >= g.D) continue;
+    for (int ky = (oy + g.py) % g.sy; ky < g.kh; ky += g.sy) {
+      const int iy = (oy + g.py - ky) / g.sy;
+      if (oy + g.py - ky < 0 || iy >= g.H) continue;
+      for (int kx = (ox + g.px) % g.sx; kx < g.kw; kx += g.sx) {
+        const int ix = (ox + g.px - kx) / g.sx;
+        if (ox + g.px - kx < 0 || ix >= g.W) continue;
+        float xv[VEC];
+        VecIO<T, VEC>::load(xn + (((long)iz * g.H + iy) * g.W + ix) * g.C + c, xv);
+        const float* wp = w + ((long)(kz * g.kh + ky) * g.kw + kx) * g.C + c;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = fmaf(xv[j], wp[j], acc[j]);
+      }
+    }
+  }
+  VecIO<T, VEC>::store(y + (((n * g.Do + oz) * g.Ho + oy) * g.Wo + ox) * g.C + c, acc);
+}
+
 // ---- y = act(a[n][c]*x + b[n][c]) elementwise (norm-apply + activation when it cannot ride in a conv prologue) ----
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -263,7 +301,13 @@ extern "C" int pytc_dwconvT3d_generic_fwd(const void* x, void* y, const float* w
   PYTC_REQUIRE(g.Do >= 1 && g.Ho >= 1 && g.Wo >= 1, "dwconvT3d_generic: empty output");
   const long total = (long)N * g.Do * g.Ho * g.Wo * C;
   dim3 grid(ceil_div(total, 256)), block(256);
-  if (dtype == PYTC_BF16)
+  if (dtype == PYTC_BF16 && C % 8 == 0)
+    hipLaunchKernelGGL((dwconvT3d_generic_vec_kernel<bf16_t, 8>), dim3(ceil_div(total / 8, 256)), block, 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (bf16_t*)y, w, g, total / 8);
+  else if (dtype == PYTC_F32 && C % 4 == 0)
+    hipLaunchKernelGGL((dwconvT3d_generic_vec_kernel<float, 4>), dim3(ceil_div(total / 4, 256)), block, 0, (hipStream_t)stream,
+                       (const float*)x, (float*)y, w, g, total / 4);
+  else if (dtype == PYTC_BF16)
     hipLaunchKernelGGL(dwconvT3d_generic_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x,
                        (bf16_t*)y, w, g, total);
   else if (dtype == PYTC_F32)

@@ -439,6 +439,50 @@ dwconv3d_generic_kernel(const T* __restrict__ x, T* __restrict__ y, const float*
 
 static int grid_for(long n) { long b = (n + 255) / 256; return (int)(b < 16384 ? b : 16384); }
 
+// ---- tiny per-layer combiners (one workgroup): replace a dozen small tensor ops per norm layer ------------------------
+// s [N][2][C] = (sum d, sum d*xhat) per (sample, channel) -> dbeta[c] = sum_n s[n][0][c], dgamma[c] = sum_n s[n][1][c],
+// M [N][2][C] = mean of gamma*s over the statistics group of (n, c): groups > 0: the channel's group within the sample
+// (GroupNorm; groups == C: InstanceNorm); groups == 0: all samples of the channel (BatchNorm).
+__global__ void __launch_bounds__(256)
+norm_bwd_means_kernel(const float* __restrict__ s, const float* __restrict__ gamma, float* __restrict__ M,
+                      float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, int groups, float rows) {
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a0 = 0.f, a1 = 0.f;
+    for (int n = 0; n < N; ++n) { a0 += s[(n * 2 + 0) * C + c]; a1 += s[(n * 2 + 1) * C + c]; }
+    if (dbeta) dbeta[c] = a0;
+    if (dgamma) dgamma[c] = a1;
+    if (groups == 0) {
+      const float gm = gamma ? gamma[c] : 1.0f;
+      const float inv = 1.0f / ((float)N * rows);
+      for (int n = 0; n < N; ++n) { M[(n * 2 + 0) * C + c] = a0 * gm * inv; M[(n * 2 + 1) * C + c] = a1 * gm * inv; }
+    }
+  }
+  if (groups > 0) {
+    const int cpg = C / groups;
+    const float inv = 1.0f / (rows * (float)cpg);
+    for (int i = threadIdx.x; i < N * 2 * groups; i += 256) {
+      const int g = i % groups, nk = i / groups;
+      float a = 0.f;
+      for (int j = 0; j < cpg; ++j) { const int c = g * cpg + j; a += s[nk * C + c] * (gamma ? gamma[c] : 1.0f); }
+      a *= inv;
+      for (int j = 0; j < cpg; ++j) M[nk * C + g * cpg + j] = a;
+    }
+  }
+}
+
+// BatchNorm running buffers from the batch statistics (mean, rstd) of one forward: unbiased variance, momentum blend
+__global__ void __launch_bounds__(256)
+bn_update_running_kernel(const float* __restrict__ mr, float* __restrict__ rmean, float* __restrict__ rvar, int C, float n,
+                         float eps, float momentum) {
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float mean = mr[c], rstd = mr[C + c];
+    float var = 1.0f / (rstd * rstd) - eps;
+    var = (var > 0.f ? var : 0.f) * (n / (n > 1.f ? n - 1.f : 1.f));
+    rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
+    rvar[c] = (1.0f - momentum) * rvar[c] + momentum * var;
+  }
+}
+
 }  // namespace pytc
 
 using namespace pytc;
@@ -579,5 +623,23 @@ extern "C" int pytc_dwconv3d_generic_fwd(const void* x, void* y, const float* w,
               hipLaunchKernelGGL(dwconv3d_generic_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, s, (const float*)x, (float*)y, w, g, total),
               "dwconv3d_generic")
   PYTC_LAUNCH_CHECK("dwconv3d_generic");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_norm_bwd_means(const float* s, const float* gamma, float* M, float* dgamma, float* dbeta, int N, int C,
+                                   int groups, float rows, void* stream) {
+  PYTC_REQUIRE(s && M && N >= 1 && C >= 1 && rows >= 1.f, "norm_bwd_means: bad arguments");
+  PYTC_REQUIRE(groups == 0 || (groups >= 1 && C % groups == 0), "norm_bwd_means: C must be divisible by groups");
+  hipLaunchKernelGGL(norm_bwd_means_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, s, gamma, M, dgamma, dbeta, N, C, groups, rows);
+  PYTC_LAUNCH_CHECK("norm_bwd_means");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_bn_update_running(const float* mean_rstd, float* running_mean, float* running_var, int C, float count,
+                                      float eps, float momentum, void* stream) {
+  PYTC_REQUIRE(mean_rstd && running_mean && running_var && C >= 1 && count >= 1.f, "bn_update_running: bad arguments");
+  hipLaunchKernelGGL(bn_update_running_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mean_rstd, running_mean, running_var, C,
+                     count, eps, momentum);
+  PYTC_LAUNCH_CHECK("bn_update_running");
   return PYTC_OK;
 }

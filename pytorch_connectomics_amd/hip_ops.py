@@ -364,6 +364,39 @@ def conv3d_pack_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return packed
 
 
+def conv3d_pack_weight_dgrad(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """forward weight fp32 (C_out, C_in, kd, kh, kw) -> packed image of the data-gradient conv (C_out -> C_in, mirrored taps)."""
+    _dev(w, "w")
+    co, ci, kd, kh, kw = w.shape
+    n = nat.lib().pytc_conv3d_packed_elems(ci, co, kd, kh, kw, dtype_code(dtype))
+    packed = torch.empty((n,), dtype=dtype, device=w.device)
+    _run("conv3d_pack_weight_dgrad", _nbytes(w, packed), nat.lib().pytc_conv3d_pack_weight_dgrad, _p(w), co, ci, kd, kh, kw,
+         _p(packed), dtype_code(dtype), _stream())
+    return packed
+
+
+def norm_bwd_means(s: torch.Tensor, gamma: Optional[torch.Tensor], groups: int, rows: int, *, want_gamma: bool,
+                   want_beta: bool):
+    """s (N,2,C) -> (M (N,2,C), dgamma (C) | None, dbeta (C) | None); groups = 0: batch statistics"""
+    _dev(s, "s")
+    N, _, Cc = s.shape
+    M = torch.empty_like(s)
+    dg = torch.empty((Cc,), dtype=torch.float32, device=s.device) if want_gamma else None
+    db = torch.empty((Cc,), dtype=torch.float32, device=s.device) if want_beta else None
+    _run("norm_bwd_means", 2 * _nbytes(s), nat.lib().pytc_norm_bwd_means, _p(s), _p(gamma), _p(M), _p(dg), _p(db), N, Cc,
+         int(groups), float(rows), _stream())
+    return M, dg, db
+
+
+def bn_update_running(mean_rstd: torch.Tensor, running_mean: torch.Tensor, running_var: torch.Tensor, count: float,
+                      eps: float, momentum: float) -> None:
+    _dev(mean_rstd, "mean_rstd"); _dev(running_mean, "running_mean"); _dev(running_var, "running_var")
+    if running_mean.dtype != torch.float32 or running_var.dtype != torch.float32:
+        raise RuntimeError("bn_update_running: fp32 running buffers expected")
+    _run("bn_update_running", 0, nat.lib().pytc_bn_update_running, _p(mean_rstd), _p(running_mean), _p(running_var),
+         running_mean.numel(), float(count), float(eps), float(momentum), _stream())
+
+
 def conv3d(x: torch.Tensor, w_packed: torch.Tensor, *, c_out: int, kernel, bias: Optional[torch.Tensor] = None,
            ab: Optional[torch.Tensor] = None, act_in: int = nat.ACT_NONE, act_param: float = 0.0,
            res: Optional[torch.Tensor] = None) -> torch.Tensor:

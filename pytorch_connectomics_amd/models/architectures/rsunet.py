@@ -173,9 +173,8 @@ class _RSUNetHip:
             def make():
                 a = m.weight.detach().float() / torch.sqrt(m.running_var.float() + m.eps)
                 b = m.bias.detach().float() - m.running_mean.float() * a
-                return torch.stack([a, b], 0).contiguous()
-            ab1 = self.cache.get(("bn", id(m)), [m.weight, m.bias, m.running_mean, m.running_var], make)
-            return ab1.unsqueeze(0).expand(N, 2, C).contiguous()
+                return torch.stack([a, b], 0).unsqueeze(0).expand(N, 2, C).contiguous()
+            return self.cache.get(("bn", id(m), N), [m.weight, m.bias, m.running_mean, m.running_var], make)
         st = ops.channel_stats(x)
         if na.kind == "group":
             return ops.norm_finalize_groups(st, rows, self._vec(m, "w", m.weight), self._vec(m, "b", m.bias), m.eps,

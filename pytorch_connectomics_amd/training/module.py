@@ -304,6 +304,9 @@ def fit(module: ConnectomicsModule, batches, *, max_steps: int, device, log_ever
         if sched is not None:
             sched.step()
         module.global_step += 1
+        if step == 2:
+            from ..utils.hostgc import quiesce_gc
+            quiesce_gc()       # the cyclic GC's full passes cost milliseconds per step in a launch-bound loop
         history.append(float(loss.detach()))
         if not math.isfinite(history[-1]):
             raise FloatingPointError(f"training loss is not finite at step {step}")

@@ -54,13 +54,9 @@ class NormActFn(torch.autograd.Function):
                 ab, mr = ab1.expand(N, 2, C).contiguous(), mr1.expand(N, 2, C).contiguous()
                 if bn.track_running_stats:
                     with torch.no_grad():
-                        n = float(N * rows)
-                        mean = mr1[0, 0]
-                        var = (1.0 / (mr1[0, 1] * mr1[0, 1]) - eps).clamp_min(0.0) * (n / max(n - 1.0, 1.0))
-                        mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-                        bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
-                        bn.running_var.mul_(1 - mom).add_(var.to(bn.running_var.dtype), alpha=mom)
                         bn.num_batches_tracked += 1
+                        mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                        ops.bn_update_running(mr1, bn.running_mean, bn.running_var, float(N * rows), eps, mom)
             else:
                 a = gamma.detach().float() / torch.sqrt(bn.running_var.float() + eps)
                 b = beta.detach().float() - bn.running_mean.float() * a
@@ -101,19 +97,10 @@ class NormActFn(torch.autograd.Function):
                                               "call model.train() or freeze the norm parameters")
         else:
             s = ops.norm_bwd_stats(dt, x, mr)                          # (N, 2, C): sum d, sum d*xhat
-            g32 = gamma.detach().float() if has_g else torch.ones(C, device=x.device)
-            if has_b:
-                dbeta = s[:, 0].sum(0)
-            if has_g:
-                dgamma = s[:, 1].sum(0)
-            w = s * g32.view(1, 1, C)                                  # gamma-weighted sums
-            if mode == "batch":
-                M = (w.sum(0, keepdim=True) / float(N * rows)).expand(N, 2, C).contiguous()
-            else:
-                g = groups if mode == "group" else C
-                cpg = C // g
-                M = (w.view(N, 2, g, cpg).sum(-1, keepdim=True) / float(rows * cpg)).expand(N, 2, g, cpg).reshape(N, 2, C).contiguous()
-            dx = ops.norm_bwd_apply_general(dt, x, mr, g32 if has_g else None, M)
+            g32 = _f(gamma) if has_g else None
+            grp = 0 if mode == "batch" else (groups if mode == "group" else C)
+            M, dgamma, dbeta = ops.norm_bwd_means(s, g32, grp, rows, want_gamma=has_g, want_beta=has_b)
+            dx = ops.norm_bwd_apply_general(dt, x, mr, g32, M)
         cast = lambda v, like: None if v is None else v.to(like.dtype).reshape(like.shape)
         return (dx, cast(dgamma, gamma) if has_g else None, cast(dbeta, gamma) if has_b else None, dprelu, None, None, None,
                 None, None, None)
@@ -140,8 +127,9 @@ class Conv3dFn(torch.autograd.Function):
             dy = dy.to(a.dtype)
         da = None
         if ctx.needs_input_grad[0]:
-            wt = weight.detach().float().flip(2, 3, 4).transpose(0, 1).contiguous()       # (C_in, C_out, k...) flipped
-            da = ops.conv3d(dy, ops.conv3d_pack_weight(wt, dy.dtype), c_out=weight.shape[1], kernel=ks)
+            # data gradient = the forward kernel on dY with the transposed, tap-mirrored weights (packed in one launch)
+            da = ops.conv3d(dy, ops.conv3d_pack_weight_dgrad(weight.detach().float().contiguous(), dy.dtype),
+                            c_out=weight.shape[1], kernel=ks)
         ci, co = a.shape[-1], dy.shape[-1]
         db = None
         if ks == (1, 1, 1) and a.dtype == torch.bfloat16 and ci % 16 == 0 and co % 16 == 0:

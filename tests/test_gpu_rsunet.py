@@ -71,7 +71,8 @@ def test_rsunet_none_norm_inplace_quirk_and_builders():
 @pytest.mark.parametrize("cin,cout,k", [(8, 16, (3, 3, 3)), (16, 8, (1, 3, 3)), (1, 8, (3, 3, 3)), (18, 36, (3, 3, 3)),
                                         (6, 2, (1, 1, 1)), (16, 16, (3, 3, 3)), (32, 64, (3, 3, 3)), (24, 16, (3, 3, 3)),
                                         (64, 32, (1, 3, 3)), (128, 32, (3, 3, 3)), (48, 80, (3, 3, 3)),
-                                        (32, 16, (5, 5, 5)), (16, 3, (1, 1, 1)), (8, 8, (3, 1, 1))])
+                                        (32, 16, (5, 5, 5)), (16, 3, (1, 1, 1)), (8, 8, (3, 1, 1)), (24, 16, (1, 1, 1)),
+                                        (40, 16, (3, 3, 3)), (24, 24, (1, 3, 3)), (2, 20, (3, 3, 3)), (3, 5, (1, 1, 1))])
 def test_conv3d_with_fused_preactivation(dt, cin, cout, k):
     from pytorch_connectomics_amd import _native as nat
     from pytorch_connectomics_amd import hip_ops as ops

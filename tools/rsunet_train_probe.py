@@ -15,6 +15,8 @@ ap.add_argument("--batch", type=int, default=2)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--norm", default="batch")
 ap.add_argument("--width", default="16,32,64,128")
+ap.add_argument("--mode", default="both", choices=["both", "train", "infer"])
+ap.add_argument("--gc", default="on", choices=["on", "off", "freeze"])
 a = ap.parse_args()
 patch = tuple(int(v) for v in a.patch.split(","))
 m = RSUNet(1, 3, width=[int(v) for v in a.width.split(",")], norm=a.norm, activation="relu").cuda().train()
@@ -32,16 +34,24 @@ def step():
     return loss
 
 
-for _ in range(5):
-    step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(a.steps):
-    l = step()
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / a.steps
 vox = a.batch * patch[0] * patch[1] * patch[2]
-print(f"rsunet train {a.dtype} norm={a.norm} batch {a.batch} patch {patch}: {dt * 1e3:.1f} ms/step, {vox / dt:.3e} voxels/s, loss {float(l.detach()):.4f}")
+if a.mode != "infer":
+    for _ in range(5):
+        step()
+    import gc
+    if a.gc == "off":
+        gc.disable()
+    elif a.gc == "freeze":
+        gc.collect(); gc.freeze()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        l = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    print(f"rsunet train {a.dtype} norm={a.norm} batch {a.batch} patch {patch}: {dt * 1e3:.1f} ms/step, {vox / dt:.3e} voxels/s, loss {float(l.detach()):.4f}")
+if a.mode == "train":
+    raise SystemExit(0)
 with torch.no_grad():
     m.eval()
     for _ in range(2):
