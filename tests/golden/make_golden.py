@@ -187,6 +187,49 @@ def rsunets():
         arrs["n_params"] = np.asarray(sum(p.numel() for p in m.parameters()))
         save(f"rsunet_{name}.npz", **arrs)
 
+# ---------------------------------------------------------------- RSUNet training step (reference module + torch autograd)
+def rsunet_train():
+    """One forward + backward of the REFERENCE RSUNet in train() mode (BatchNorm with batch statistics): loss, every
+    parameter gradient, the BatchNorm running buffers after the step.  Inputs, targets and the initial state_dict are
+    stored so the HIP training path starts from the same point."""
+    import torch.nn.functional as F
+    cfgs = {
+        "c1_group": dict(width=[8, 16], down_factors=[(2, 2, 2)], norm="group", num_groups=8, activation="relu"),
+        "aniso_inst_elu_ds": dict(width=[6, 8, 12], norm="instance", activation="elu", deep_supervision=True),
+        "batch_prelu_2d": dict(width=[4, 8, 8], norm="batch", activation="prelu", depth_2d=1, init=0.1),
+        "none_leaky": dict(width=[4, 8], norm="none", activation="leakyrelu", negative_slope=0.05),
+    }
+    for name, kw in cfgs.items():
+        torch.manual_seed(21)
+        m = rsunet.RSUNet(1, 2, **kw).train()
+        with torch.no_grad():
+            for mod in m.modules():
+                if isinstance(mod, (torch.nn.GroupNorm, torch.nn.BatchNorm3d)):
+                    mod.weight.uniform_(0.7, 1.3)
+                    mod.bias.normal_(0, 0.2)
+        arrs = {}
+        for k, v in m.state_dict().items():
+            arrs["sd__" + k] = v.detach().clone().numpy()
+        x = torch.randn(2, 1, 8, 16, 16, generator=torch.Generator().manual_seed(22))
+        t = torch.randn(2, 2, 8, 16, 16, generator=torch.Generator().manual_seed(23))
+        x_in = x.clone()       # with norm="none" the reference's in-place activation rewrites the caller's tensor
+        out = m(x)
+        if isinstance(out, dict):
+            loss = F.mse_loss(out["output"], t)
+            for k in sorted(out):
+                if k != "output":
+                    loss = loss + 0.5 * out[k].pow(2).mean()
+        else:
+            loss = F.mse_loss(out, t)
+        loss.backward()
+        arrs["x"], arrs["t"], arrs["loss"] = x_in.numpy(), t.numpy(), np.asarray([float(loss)], np.float64)
+        for k, p in m.named_parameters():
+            arrs["grad__" + k] = p.grad.numpy()
+        for k, b in m.named_buffers():
+            arrs["buf__" + k] = b.detach().numpy()
+        print(name, float(loss), len([k for k in arrs if k.startswith("grad__")]), "grads")
+        save(f"rsunet_train_{name}.npz", **arrs)
+
 
 # ---------------------------------------------------------------- chunk grid / halo
 def chunks():
@@ -516,7 +559,7 @@ def crops():
 
 
 if __name__ == "__main__":
-    parts = {"crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
+    parts = {"rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
              "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:

@@ -90,6 +90,26 @@ def test_norm_act_function_backward(kind, act):
         torch.testing.assert_close(na2.norm.running_mean.cpu(), rm, rtol=1e-4, atol=1e-6)
 
 
+def _check_grads(named_grads, ref_of, kinked: bool):
+    """fp32 gradients vs a reference.  Smooth activations (ELU): tight per-tensor bound.  Kinked ones (ReLU / leaky /
+    PReLU): a pre-activation within fp32 rounding of 0 may land on the other side of the kink than in the reference --
+    ONE such voxel moved d(beta) of a layer by 1.2e-2 and everything upstream by 5e-3 in the c1_group fixture (the
+    channel sum it enters cancels to 1e-2 of that term) -- so the per-tensor bound is loose there and the direction of
+    the whole gradient is checked instead."""
+    flat_g, flat_r = [], []
+    for n, g in named_grads:
+        r = ref_of(n)
+        assert g is not None and r is not None, n
+        err = float((g - r).abs().max()) / float(r.abs().max().clamp_min(1e-6))
+        assert err < (3e-2 if kinked else 2e-4), f"{n}: rel grad err {err:.2e}"
+        flat_g.append(g.flatten().double())
+        flat_r.append(r.flatten().double())
+    g, r = torch.cat(flat_g), torch.cat(flat_r)
+    cos = float((g * r).sum() / (g.norm() * r.norm()))
+    rel2 = float((g - r).norm() / r.norm())
+    assert cos > 0.99995 and rel2 < (1e-2 if kinked else 1e-4), (cos, rel2)
+
+
 CFGS = {
     "c1_group": dict(width=[8, 16], down_factors=[(2, 2, 2)], norm="group", num_groups=8, activation="relu"),
     "aniso_inst_elu_ds": dict(width=[6, 8, 12], norm="instance", activation="elu", deep_supervision=True),
@@ -139,15 +159,7 @@ def test_rsunet_training_step_matches_oracle_autograd(name):
         loss = F.mse_loss(out, tg)
     assert abs(float(loss.detach()) - float(ref_loss.detach())) < 1e-4 * max(1.0, abs(float(ref_loss.detach())))
     loss.backward()
-    worst = 0.0
-    for n, p in mg.named_parameters():
-        g_ref = params[n].grad
-        assert p.grad is not None and g_ref is not None, n
-        scale = float(g_ref.abs().max().clamp_min(1e-6))
-        err = float((p.grad.cpu() - g_ref).abs().max()) / scale
-        worst = max(worst, err)
-        assert err < 5e-3, f"{n}: rel grad err {err:.2e}"
-    assert worst < 5e-3
+    _check_grads([(n, p.grad.cpu()) for n, p in mg.named_parameters()], lambda n: params[n].grad, kw["activation"] != "elu")
 
 
 def test_rsunet_bf16_training_direction():
@@ -256,3 +268,36 @@ def test_conv3d_wgrad_mfma_bf16(ci, co, ks, shape):
         ops.set_tuning("conv_wgrad_mfma", 1)
     torch.testing.assert_close(dW, dW2, rtol=1e-4, atol=2e-4 * scale)
     assert torch.equal(dW, ops.conv3d_wgrad(xa, ga, ks))          # deterministic
+
+
+@pytest.mark.parametrize("name", list(CFGS))
+def test_rsunet_training_step_matches_reference_fixture(name):
+    """HIP forward + backward against the REFERENCE RSUNet's own training step (tests/golden/rsunet_train_*.npz,
+    generated by tests/golden/make_golden.py --rsunet_train): loss, every parameter gradient, BatchNorm running buffers."""
+    import numpy as np
+    from pathlib import Path
+    from pytorch_connectomics_amd.models.architectures.rsunet import RSUNet
+    z = np.load(Path(__file__).parent / "golden" / f"rsunet_train_{name}.npz")
+    m = RSUNet(1, 2, **CFGS[name])
+    m.load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd__")}, strict=True)
+    m = m.cuda().train()
+    out = m(torch.from_numpy(z["x"]).cuda())
+    t = torch.from_numpy(z["t"]).cuda()
+    if isinstance(out, dict):
+        loss = F.mse_loss(out["output"], t)
+        for k in sorted(out):
+            if k != "output":
+                loss = loss + 0.5 * out[k].pow(2).mean()
+    else:
+        loss = F.mse_loss(out, t)
+    ref_loss = float(z["loss"][0])
+    assert abs(float(loss.detach()) - ref_loss) < 1e-4 * max(1.0, ref_loss)
+    loss.backward()
+    _check_grads([(n, p.grad.cpu()) for n, p in m.named_parameters()], lambda n: torch.from_numpy(z["grad__" + n]),
+                 CFGS[name]["activation"] != "elu")
+    for n, b in m.named_buffers():
+        ref = torch.from_numpy(z["buf__" + n])
+        if ref.dtype.is_floating_point:
+            torch.testing.assert_close(b.cpu(), ref, rtol=1e-4, atol=1e-6)
+        else:
+            assert torch.equal(b.cpu(), ref), n

@@ -139,3 +139,45 @@ def test_mednext_feature_contract():
     assert torch.allclose(MO.forward_output(st, f), MO.forward(st, x, **kw))
     outs = MO.forward(st, x, deep_supervision=True, **kw)
     assert [tuple(o.shape[2:]) for o in outs] == [(32,) * 3, (16,) * 3, (8,) * 3, (4,) * 3, (2,) * 3]
+
+
+@pytest.mark.parametrize("name", ["c1_group", "aniso_inst_elu_ds", "batch_prelu_2d", "none_leaky"])
+def test_rsunet_oracle_training_step_matches_reference(name):
+    """tests/golden/rsunet_train_*.npz: loss and parameter gradients of the reference RSUNet in train() mode; pins the
+    oracle's training-mode restatement (bn_training=True) that the GPU gradient-parity tests differentiate through."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from pathlib import Path
+    from oracle import rsunet_oracle as RO
+    cfgs = {
+        "c1_group": dict(width=[8, 16], down_factors=[(2, 2, 2)], norm="group", num_groups=8, activation="relu"),
+        "aniso_inst_elu_ds": dict(width=[6, 8, 12], norm="instance", activation="elu", deep_supervision=True),
+        "batch_prelu_2d": dict(width=[4, 8, 8], norm="batch", activation="prelu", depth_2d=1, init=0.1),
+        "none_leaky": dict(width=[4, 8], norm="none", activation="leakyrelu", negative_slope=0.05),
+    }
+    z = np.load(Path(__file__).parent / "golden" / f"rsunet_train_{name}.npz")
+    st = {k[4:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith("sd__")}
+    for k, v in st.items():
+        if v.dtype.is_floating_point and f"grad__{k}" in z.files:
+            v.requires_grad_()
+    out = RO.forward(st, torch.from_numpy(z["x"]).clone(), bn_training=True, **cfgs[name])
+    t = torch.from_numpy(z["t"])
+    if isinstance(out, dict):
+        loss = F.mse_loss(out["output"], t)
+        for k in sorted(out):
+            if k != "output":
+                loss = loss + 0.5 * out[k].pow(2).mean()
+    else:
+        loss = F.mse_loss(out, t)
+    assert abs(float(loss) - float(z["loss"][0])) < 1e-5 * max(1.0, float(z["loss"][0]))
+    loss.backward()
+    n = 0
+    for k in z.files:
+        if k.startswith("grad__"):
+            g = st[k[6:]].grad
+            assert g is not None, k
+            ref = torch.from_numpy(z[k])
+            assert float((g - ref).abs().max()) <= 1e-4 * float(ref.abs().max().clamp_min(1e-6)) + 1e-7, k
+            n += 1
+    assert n >= 15
