@@ -153,10 +153,13 @@ def pmc_traffic_bytes(label):
         key = f"pw_mlp_kernel<{int(m.group(1)) // 32}, {int(m.group(3)) // 16},"
     else:
         return None          # other kernels run at several shapes under one name: no per-shape counter average
-    for row in csv.DictReader(open(f)):
+    tot = n = 0.0
+    for row in csv.DictReader(open(f)):          # the plain and the head-epilogue variant of the shape, launch-weighted
         if key in row["kernel"]:
-            return int((2 * float(row["FETCH_SIZE_KB_mean"]) + float(row["WRITE_SIZE_KB_mean"])) * 1024)
-    return None
+            k = float(row.get("launches") or 1)
+            tot += k * (2 * float(row["FETCH_SIZE_KB_mean"]) + float(row["WRITE_SIZE_KB_mean"])) * 1024
+            n += k
+    return int(tot / n) if n else None
 
 
 def main():

@@ -257,6 +257,14 @@ int pytc_pw_mlp_supported(int C_in, int C_hid, int C_out);
 int pytc_pw_pack_weight_paired(const float* w, int C_out, int C_in, int transposed, void* packed_bf16,
                                void* stream);
 int pytc_pw_mlp_fwd(const pytc_mlp_args* a, void* stream);
+/* The same mixer with the network's 1x1x1 output projection (mednext OutBlock.conv_out, a transposed 1x1x1 conv on the
+ * full-resolution features) in its epilogue: logits[o] = head_b[o] + sum_c head[o][c] * bf16(y[c]), o < n_head <= 16,
+ * head_y [N][rows][n_head] fp32; head_w = the bf16 MFMA A-fragment image of the head [64 lanes][8]: lane (r, kb) holds
+ * head[o = r][c = kb*8 .. kb*8+7] (zero rows for r >= n_head).  C_out must be 32 (pytc_pw_mlp_head_supported), residual
+ * NONE or ADD.  store_y = 0 skips the 64 B / voxel block output (a->y may then be NULL). */
+int pytc_pw_mlp_head_supported(int C_in, int C_hid, int C_out);
+int pytc_pw_mlp_head_fwd(const pytc_mlp_args* a, const void* head_w, const float* head_b, float* head_y, int n_head,
+                         int store_y, void* stream);
 
 /* ---------------------------------------------------------------- dense conv / norm / pool (RSUNet) ---------- */
 

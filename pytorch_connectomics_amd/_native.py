@@ -157,6 +157,8 @@ _SIGS = {
     "pytc_pw_mlp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pytc_pw_pack_weight_paired": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pytc_pw_mlp_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p]),
+    "pytc_pw_mlp_head_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "pytc_pw_mlp_head_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
 }
 
 _lib = None

@@ -24,6 +24,11 @@ struct MlpParams {
   EpiParams e;
   long rps;        // rows per sample (input == output rows)
   int C_in, C_hid, C_out, HC;   // HC = C_hid / 32
+  // fused output head (HEAD kernels): logits[o] = head_b[o] + sum_c head_w[o][c] * bf16(y[c]),  o < n_head <= 16
+  const bf16x8_t* head_w;   // A fragment image [64 lanes][8]: lane (r, kb) holds head[o = r][c = kb*8 .. +7], bf16
+  const float* head_b;
+  float* head_y;   // [N][rps][n_head] fp32
+  int n_head, store_y;
 };
 
 // GELU by table: the mixer is VALU bound on its activation (SQ counters of 64->128->32: 70 % VALU busy, v_exp_f32 and
@@ -49,10 +54,15 @@ constexpr int mlp_waves_per_simd(int ks, int mo, int nt) {
 }
 
 // GELU_MODE: 0 = erf (A&S 7.1.26), 1 = sigmoid-form minimax (gelu_fast), 2 = table
-template <int KS_IN, int MO, int NT, int GELU_MODE>
+// HEAD: the network's 1x1x1 output projection rides in the epilogue of the LAST mixer (C_out = 32): the block output is
+// rounded to bf16 exactly as the un-fused path stores it, is itself the B fragment of one more 16x16x32 MFMA against the head
+// weights (rows beyond n_head are zero), whose result lanes write the fp32 logits; the 64 B / voxel of
+// block output are not written at all when nothing else reads them (store_y = 0).
+template <int KS_IN, int MO, int NT, int GELU_MODE, bool HEAD = false>
 __global__ void __launch_bounds__(256, mlp_waves_per_simd(KS_IN, MO, NT))
 pw_mlp_kernel(MlpParams p) {
   static_assert(MO % 2 == 0, "C_out must be a multiple of 32");
+  static_assert(!HEAD || MO == 2, "the fused head covers C_out = 32");
   __shared__ __attribute__((aligned(16))) float2 lut[GELU_MODE == 2 ? GELU_LUT_N : 1];
   if constexpr (GELU_MODE == 2) {
     const uint4* src = reinterpret_cast<const uint4*>(g_gelu_lut);
@@ -176,6 +186,40 @@ pw_mlp_kernel(MlpParams p) {
     }
   }
 
+  if constexpr (HEAD) {
+    bf16_t* yn = reinterpret_cast<bf16_t*>(p.e.y) + (long)n * p.rps * 32;
+    const bf16_t* resn = p.e.res ? reinterpret_cast<const bf16_t*>(p.e.res) + (long)n * p.rps * 32 : nullptr;
+    float* hy = p.head_y + (long)n * p.rps * p.n_head;
+    const bf16x8_t ah = p.head_w[lane];        // A fragment of the head: row r = output o (zero rows beyond n_head)
+    float hb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hb[i] = (p.head_b && kb * 4 + i < p.n_head) ? p.head_b[kb * 4 + i] : 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = acc2[0][nt][j]; v[4 + j] = acc2[1][nt][j]; }
+      const bool live = orow[nt] < p.rps;
+      if (p.e.res_mode == PYTC_RES_ADD) {
+        float rv[8];
+        if (use_pre) VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(&rpre[0][PREFETCH_RES ? nt : 0]), rv);
+        else VecIO<bf16_t, 8>::load(resn + (live ? orow[nt] : p.rps - 1) * 32 + kb * 8, rv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += rv[j];
+      }
+      // this lane's 8 output channels of voxel r, rounded as the un-fused path stores them = the B fragment of
+      // logits^T[o][voxel] = sum_c head[o][c] * y[c][voxel]: one more MFMA, no cross-lane traffic
+      const bf16x8_t ob = Mma<bf16_t>::from_floats(v);
+      if (p.store_y && live) *reinterpret_cast<bf16x8_t*>(yn + orow[nt] * 32 + kb * 8) = ob;
+      const f32x4_t h = Mma<bf16_t>::mma(ah, ob, f32x4_t{0.f, 0.f, 0.f, 0.f});
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (kb * 4 + i < p.n_head) hy[orow[nt] * p.n_head + kb * 4 + i] = h[i] + hb[i];
+      }
+    }
+    return;
+  }
   // ---- epilogue: 8 consecutive channels per lane per tile pair
 #pragma unroll
   for (int pr = 0; pr < MO / 2; ++pr) {
@@ -289,6 +333,10 @@ using namespace pytc;
 
 extern "C" int pytc_pw_mlp_supported(int C_in, int C_hid, int C_out) { return mlp_shape_ok(C_in, C_hid, C_out) ? 1 : 0; }
 
+extern "C" int pytc_pw_mlp_head_supported(int C_in, int C_hid, int C_out) {
+  return (C_out == 32 && (C_in == 32 || C_in == 64) && C_hid % 32 == 0 && C_hid >= 32) ? 1 : 0;
+}
+
 extern "C" int pytc_pw_pack_weight_paired(const float* w, int C_out, int C_in, int transposed, void* packed,
                                           void* stream) {
   PYTC_REQUIRE(w && packed && C_out >= 1 && C_in >= 1, "pw_pack_weight_paired: bad arguments");
@@ -298,6 +346,38 @@ extern "C" int pytc_pw_pack_weight_paired(const float* w, int C_out, int C_in, i
   hipLaunchKernelGGL(pw_pack_paired_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w, C_out,
                      C_in, transposed, (bf16_t*)packed, KG, total);
   PYTC_LAUNCH_CHECK("pw_pack_weight_paired");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_pw_mlp_head_fwd(const pytc_mlp_args* a, const void* head_w, const float* head_b, float* head_y,
+                                    int n_head, int store_y, void* stream) {
+  PYTC_REQUIRE(a && a->t && a->ab && a->w2_packed && a->w3_packed && a->b2 && a->b3 && head_w && head_y, "pw_mlp_head: null pointer");
+  PYTC_REQUIRE(!store_y || a->y, "pw_mlp_head: store_y without an output buffer");
+  PYTC_REQUIRE(a->N >= 1 && a->rows_per_sample >= 1 && n_head >= 1 && n_head <= 16, "pw_mlp_head: bad shape");
+  if (!pytc_pw_mlp_head_supported(a->C_in, a->C_hid, a->C_out)) {
+    set_error("pw_mlp_head: no fused kernel for C_in=%d C_hid=%d C_out=%d", a->C_in, a->C_hid, a->C_out);
+    return PYTC_ERR_UNSUPPORTED;
+  }
+  PYTC_REQUIRE(a->res_mode == PYTC_RES_NONE || (a->res_mode == PYTC_RES_ADD && a->res), "pw_mlp_head: residual add or none");
+  MlpParams p;
+  p.t = (const bf16_t*)a->t; p.ab = a->ab; p.w2 = (const bf16x8_t*)a->w2_packed; p.b2 = a->b2;
+  p.w3 = (const bf16x8_t*)a->w3_packed; p.b3 = a->b3;
+  p.rps = a->rows_per_sample; p.C_in = a->C_in; p.C_hid = a->C_hid; p.C_out = a->C_out; p.HC = a->C_hid / 32;
+  p.e.res = a->res; p.e.res_low = nullptr; p.e.res_bias = nullptr; p.e.y = a->y;
+  p.e.rps_out = a->rows_per_sample; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode;
+  p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
+  p.head_w = (const bf16x8_t*)head_w; p.head_b = head_b; p.head_y = head_y; p.n_head = n_head; p.store_y = store_y;
+  dim3 grid((unsigned)((p.rps + 4L * 4 * 16 - 1) / (4L * 4 * 16)), (unsigned)a->N), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const bool exact = tuning_get("mlp_exact_gelu", 0) != 0;
+  if (a->C_in == 32) {
+    if (exact) hipLaunchKernelGGL((pw_mlp_kernel<1, 2, 4, 0, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((pw_mlp_kernel<1, 2, 4, 1, true>), grid, block, 0, s, p);
+  } else {
+    if (exact) hipLaunchKernelGGL((pw_mlp_kernel<2, 2, 4, 0, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((pw_mlp_kernel<2, 2, 4, 1, true>), grid, block, 0, s, p);
+  }
+  PYTC_LAUNCH_CHECK("pw_mlp_head");
   return PYTC_OK;
 }
 
@@ -311,7 +391,7 @@ extern "C" int pytc_pw_mlp_fwd(const pytc_mlp_args* a, void* stream) {
   PYTC_REQUIRE(a->res_mode == PYTC_RES_NONE || a->res, "pw_mlp: residual mode without residual pointer");
   PYTC_REQUIRE(a->res_mode == PYTC_RES_NONE || a->res_mode == PYTC_RES_ADD || a->res_mode == PYTC_RES_UPSAMPLE,
                "pw_mlp: unsupported res_mode %d", a->res_mode);
-  MlpParams p;
+  MlpParams p{};
   p.t = (const bf16_t*)a->t; p.ab = a->ab; p.w2 = (const bf16x8_t*)a->w2_packed; p.b2 = a->b2;
   p.w3 = (const bf16x8_t*)a->w3_packed; p.b3 = a->b3;
   p.rps = a->rows_per_sample; p.C_in = a->C_in; p.C_hid = a->C_hid; p.C_out = a->C_out; p.HC = a->C_hid / 32;

@@ -352,6 +352,49 @@ def pw_mlp(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.Tenso
     return y
 
 
+def pw_mlp_head_supported(c_in: int, c_hid: int, c_out: int) -> bool:
+    return bool(nat.lib().pytc_pw_mlp_head_supported(int(c_in), int(c_hid), int(c_out)))
+
+
+def pack_head_fragment(w: torch.Tensor) -> torch.Tensor:
+    """w (n_head <= 16, 32) fp32 -> (n_head, 64, 8) bf16 whose [0] is the 16x32 MFMA A-fragment image (the leading
+    dimension only carries n_head to pw_mlp_head)."""
+    n_head = w.shape[0]
+    if n_head > 16 or w.shape[1] != 32:
+        raise ValueError("head weights must be (n_head <= 16, 32)")
+    w16 = torch.zeros((16, 32), dtype=torch.float32, device=w.device)
+    w16[:n_head] = w
+    frag = w16.view(16, 4, 8).permute(1, 0, 2).reshape(64, 8).to(torch.bfloat16)
+    return frag.unsqueeze(0).expand(n_head, 64, 8).contiguous()
+
+
+def pw_mlp_head(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.Tensor, w3p: torch.Tensor, b3: torch.Tensor,
+                head_w: torch.Tensor, head_b: Optional[torch.Tensor], *, N: int, rows_per_sample: int, c_in: int,
+                c_hid: int, c_out: int, res: Optional[torch.Tensor] = None, store_y: bool = False):
+    """pw_mlp of the last block with the output projection in its epilogue -> (y | None, logits (N, rows, n_head) fp32).
+    head_w: (n_head, 64, 8) bf16 fragment image from pack_head_fragment."""
+    _dev(t, "t"); _dev(head_w, "head_w")
+    if t.dtype != torch.bfloat16 or head_w.dtype != torch.bfloat16 or tuple(head_w.shape[1:]) != (64, 8):
+        raise TypeError("pw_mlp_head runs on bfloat16 activations and a bf16 head fragment image (n_head, 64, 8)")
+    n_head = head_w.shape[0]
+    y = torch.empty((N, rows_per_sample, c_out), dtype=torch.bfloat16, device=t.device) if store_y else None
+    logits = torch.empty((N, rows_per_sample, n_head), dtype=torch.float32, device=t.device)
+    a = nat.MlpArgs()
+    a.t, a.ab, a.w2_packed, a.b2, a.w3_packed, a.b3 = (t.data_ptr(), ab.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
+                                                       w3p.data_ptr(), b3.data_ptr())
+    a.res = res.data_ptr() if res is not None else None
+    a.res_low = a.res_bias = None
+    a.y = y.data_ptr() if y is not None else None
+    a.N, a.rows_per_sample, a.C_in, a.C_hid, a.C_out = N, rows_per_sample, c_in, c_hid, c_out
+    a.res_mode = nat.RES_ADD if res is not None else nat.RES_NONE
+    a.Di = a.Hi = a.Wi = 0
+    nb = N * rows_per_sample * (2 * (c_in + (c_out if res is not None else 0) + (c_out if store_y else 0)) + 4 * n_head)
+    # same kernel template and GEMM shape as pw_mlp (HEAD flag): one label, each launch with its own byte count
+    _run(f"pw_mlp_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_head_fwd, C.byref(a), _p(head_w),
+         _p(head_b), _p(logits), n_head, int(store_y), _stream())
+    return y, logits
+
+
 # ------------------------------------------------------------------ dense conv / norm / pool (RSUNet)
 def conv3d_pack_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """w fp32 (C_out, C_in, kd, kh, kw) -> packed MFMA image."""

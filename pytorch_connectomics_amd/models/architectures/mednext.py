@@ -170,6 +170,13 @@ class HipBlockOps:
             return ops.pw_pack_weight_paired(w2, transposed=transposed)
         return self.cache.get(("pwp", id(conv), transposed), [w], make)
 
+    def _head_w(self, conv: nn.Module):
+        """bf16 MFMA fragment image of the transposed 1x1x1 output conv (weights rounded like the un-fused head's)."""
+        w = conv.weight
+        def make():
+            return ops.pack_head_fragment(w.detach().float().reshape(w.shape[0], w.shape[1]).t().contiguous())
+        return self.cache.get(("headw", id(conv)), [w], make)
+
     def _vec(self, owner, name: str, p: Optional[torch.Tensor]):
         if p is None:
             return None
@@ -192,7 +199,9 @@ class HipBlockOps:
                         c_out=c_out, out_dtype=out_dtype or x.dtype, act=act)
         return y.view(N, *spatial, c_out)
 
-    def block(self, m: MedNeXtBlock, x: torch.Tensor, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def block(self, m: MedNeXtBlock, x: torch.Tensor, skip: Optional[torch.Tensor] = None, head: Optional[nn.Module] = None):
+        """head: the network's output conv; when the fused mixer can carry it in its epilogue the block returns
+        (None, logits fp32 (N, D, H, W, n_classes)) instead of its bf16 output."""
         if m.grn:
             raise NotImplementedError("MedNeXt GRN (grn=True) has no HIP kernel yet")
         if not isinstance(m.norm, nn.GroupNorm):
@@ -218,6 +227,14 @@ class HipBlockOps:
         c_out = m.conv3.weight.shape[0]
         if (self.fused and dt == torch.bfloat16 and m.conv2.bias is not None and m.conv3.bias is not None
                 and ops.pw_mlp_supported(C, c_hid, c_out)):
+            if (head is not None and kind == "block" and head.weight.shape[1] <= 16
+                    and ops.pw_mlp_head_supported(C, c_hid, c_out)):
+                _, logits = ops.pw_mlp_head(t, ab, self._pw_paired(m.conv2), self._vec(m.conv2, "bias", m.conv2.bias),
+                                            self._pw_paired(m.conv3), self._vec(m.conv3, "bias", m.conv3.bias),
+                                            self._head_w(head), self._vec(head, "bias", head.bias), N=N,
+                                            rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out,
+                                            res=x if m.do_res else None, store_y=False)
+                return None, logits.view(N, Do, Ho, Wo, -1)
             return self._block_fused(m, x, t, ab, skip, (N, D, H, W, C), (Do, Ho, Wo), c_hid, c_out)
         h = ops.pw_conv(t, self._pw(m.conv2, dt), self._vec(m.conv2, "bias", m.conv2.bias), N=N,
                         rows_per_sample=rows, c_in=C, c_out=c_hid, out_dtype=dt, ab=ab, act=nat.ACT_GELU)
@@ -361,6 +378,7 @@ class MedNeXt(nn.Module):
         self.block_counts = list(block_counts)
         self.compute_dtype: Optional[torch.dtype] = None   # None -> follow autocast
         self._hip = HipBlockOps()
+        self.fuse_head = True      # inference: output projection inside the last mixer's epilogue where a kernel exists
 
     # ---- engine ---------------------------------------------------------------------------------
     def _check_input(self, x: torch.Tensor):
@@ -369,11 +387,18 @@ class MedNeXt(nn.Module):
                                "there is no CPU path. Move the model and input to 'cuda'.")
         if self.dim != "3d" or x.dim() != 5:
             raise NotImplementedError("only dim='3d' inputs (B,C,D,H,W) are supported by the HIP engine")
+        if any(int(v) % 16 for v in x.shape[2:]):
+            raise ValueError(f"MedNeXt needs spatial sizes divisible by 16, got {tuple(x.shape[2:])}")
 
-    def features_cl(self, x_cl: torch.Tensor, collect: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
-        """Channels-last in (N,D,H,W,C_in) fp32/bf16 -> channels-last full-resolution features."""
+    def features_cl(self, x_cl: torch.Tensor, collect: Optional[List[torch.Tensor]] = None,
+                    head: Optional[nn.Module] = None):
+        """Channels-last in (N,D,H,W,C_in) fp32/bf16 -> channels-last full-resolution features.  With `head` (the output
+        conv) the last block may return (None, logits) instead -- see HipBlockOps.block."""
         hip = self._hip
         dt = resolve_compute_dtype(self.compute_dtype)
+        if any(int(v) % 16 for v in x_cl.shape[1:4]):
+            # four stride-2 stages: the decoder's skip additions need every level to halve exactly
+            raise ValueError(f"MedNeXt needs spatial sizes divisible by 16, got {tuple(x_cl.shape[1:4])}")
         x = hip.pointwise(x_cl, self.stem, out_dtype=dt)
         skips = []
         for lvl in range(4):
@@ -387,8 +412,10 @@ class MedNeXt(nn.Module):
             collect.append(x)
         for lvl in (3, 2, 1, 0):
             x = hip.block(getattr(self, f"up_{lvl}"), x, skip=skips[lvl])
-            for blk in getattr(self, f"dec_block_{lvl}"):
-                x = hip.block(blk, x)
+            blocks = list(getattr(self, f"dec_block_{lvl}"))
+            for bi, blk in enumerate(blocks):
+                last = lvl == 0 and bi == len(blocks) - 1
+                x = hip.block(blk, x, head=head if last else None)
             if collect is not None and lvl != 0:
                 collect.append(x)
         return x
@@ -400,7 +427,10 @@ class MedNeXt(nn.Module):
 
     def forward_cl(self, x_cl: torch.Tensor):
         """Channels-last entry used by the sliding-window engine: (N,D,H,W,C_in) -> (N,D,H,W,n_classes) fp32."""
-        return self.output_cl(self.features_cl(x_cl))
+        out = self.features_cl(x_cl, head=self.out_0.conv_out if self.fuse_head else None)
+        if isinstance(out, tuple):          # the last mixer carried the output projection in its epilogue
+            return out[1]
+        return self.output_cl(out)
 
     # ---- reference-visible API (mednext_models.py:215-231) ---------------------------------------
     def forward_features(self, x: torch.Tensor) -> torch.Tensor:
@@ -425,7 +455,9 @@ class MedNeXt(nn.Module):
             if isinstance(out, list):
                 return [to_channels_first(o) for o in out]
             return to_channels_first(out)
-        feats: Optional[List[torch.Tensor]] = [] if self.do_ds else None
+        if not self.do_ds:
+            return to_channels_first(self.forward_cl(to_channels_last(x.float())))
+        feats: Optional[List[torch.Tensor]] = []
         f = self.features_cl(to_channels_last(x.float()), collect=feats)
         out = to_channels_first(self.output_cl(f))
         if not self.do_ds:
