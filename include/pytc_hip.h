@@ -263,6 +263,19 @@ int pytc_pw_mlp_fwd(const pytc_mlp_args* a, void* stream);
  * head[o = r][c = kb*8 .. kb*8+7] (zero rows for r >= n_head).  C_out must be 32 (pytc_pw_mlp_head_supported), residual
  * NONE or ADD.  store_y = 0 skips the 64 B / voxel block output (a->y may then be NULL). */
 int pytc_pw_mlp_head_supported(int C_in, int C_hid, int C_out);
+/* The first block of the network (stem fused away, see pytc_stem_dwconv3d_fwd): the mixer's residual is the stem output
+ * recomputed from the 1-channel input, res[c] = bf16(stem_w[c] * stem_x[voxel] + stem_b[c]); C_in = C_out = 32. */
+int pytc_pw_mlp_stemres_fwd(const pytc_mlp_args* a, const float* stem_x, const float* stem_w, const float* stem_b,
+                            void* stream);
+/* Stem (1x1x1 conv 1 -> 32 channels: mednext stem) + first depthwise 3x3x3 conv in one kernel, the stem output never
+ * written: y [N][D][H][W][32] bf16 = dwconv3(stem(x)) with zero padding of the stem output; x [N][D][H][W] fp32;
+ * wx [27][32] = w_taps[tap][c]*stem_w[c], wb [27][32] = w_taps[tap][c]*stem_b[c], cst [32] = bias[c] + sum_tap wb[tap][c]
+ * (fp32, formed by the caller); stats [N][pytc_stem_dwconv3d_stat_slots][2][32] = per-slot (sum, sum of squares) of the stored
+ * values (input of pytc_groupnorm_finalize). */
+int pytc_stem_dwconv3d_stat_slots(int D, int H, int W);
+int pytc_stem_dwconv3d_supported(int C_in, int C, int K);
+int pytc_stem_dwconv3d_fwd(const float* x, const float* wx, const float* wb, const float* cst, void* y, float* stats,
+                           int N, int D, int H, int W, int C, void* stream);
 int pytc_pw_mlp_head_fwd(const pytc_mlp_args* a, const void* head_w, const float* head_b, float* head_y, int n_head,
                          int store_y, void* stream);
 

@@ -29,6 +29,11 @@ struct MlpParams {
   const float* head_b;
   float* head_y;   // [N][rps][n_head] fp32
   int n_head, store_y;
+  // STEMRES kernels: the block's residual is the stem output, recomputed from the 1-channel network input
+  //   res[c] = bf16(stem_w[c] * stem_x[voxel] + stem_b[c])    (what the un-fused stem kernel would have stored)
+  const float* stem_x;     // [N][rps] fp32
+  const float* stem_w;
+  const float* stem_b;
 };
 
 // GELU by table: the mixer is VALU bound on its activation (SQ counters of 64->128->32: 70 % VALU busy, v_exp_f32 and
@@ -58,10 +63,11 @@ constexpr int mlp_waves_per_simd(int ks, int mo, int nt) {
 // rounded to bf16 exactly as the un-fused path stores it, is itself the B fragment of one more 16x16x32 MFMA against the head
 // weights (rows beyond n_head are zero), whose result lanes write the fp32 logits; the 64 B / voxel of
 // block output are not written at all when nothing else reads them (store_y = 0).
-template <int KS_IN, int MO, int NT, int GELU_MODE, bool HEAD = false>
+template <int KS_IN, int MO, int NT, int GELU_MODE, bool HEAD = false, bool STEMRES = false>
 __global__ void __launch_bounds__(256, mlp_waves_per_simd(KS_IN, MO, NT))
 pw_mlp_kernel(MlpParams p) {
   static_assert(MO % 2 == 0, "C_out must be a multiple of 32");
+  static_assert(!STEMRES || (MO == 2 && (MO / 2) * NT <= 4), "the stem-recomputing residual covers C_out = 32");
   static_assert(!HEAD || MO == 2, "the fused head covers C_out = 32");
   __shared__ __attribute__((aligned(16))) float2 lut[GELU_MODE == 2 ? GELU_LUT_N : 1];
   if constexpr (GELU_MODE == 2) {
@@ -122,7 +128,22 @@ pw_mlp_kernel(MlpParams p) {
   // ---- residual / skip rows: issue their loads now so they are in flight during both GEMMs
   uint4 rpre[PREFETCH_RES ? MO / 2 : 1][PREFETCH_RES ? NT : 1];
   const bool use_pre = PREFETCH_RES && p.e.res_mode != PYTC_RES_NONE;
-  if (use_pre) {
+  if constexpr (STEMRES) {
+    const float* sx = p.stem_x + (long)n * p.rps;
+    float sw[8], sb[8];
+    VecIO<float, 4>::load(p.stem_w + kb * 8, reinterpret_cast<float(&)[4]>(sw[0]));
+    VecIO<float, 4>::load(p.stem_w + kb * 8 + 4, reinterpret_cast<float(&)[4]>(sw[4]));
+    VecIO<float, 4>::load(p.stem_b + kb * 8, reinterpret_cast<float(&)[4]>(sb[0]));
+    VecIO<float, 4>::load(p.stem_b + kb * 8 + 4, reinterpret_cast<float(&)[4]>(sb[4]));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float xv = sx[orow[nt] < p.rps ? orow[nt] : p.rps - 1];
+      float rv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rv[j] = fmaf(sw[j], xv, sb[j]);
+      rpre[0][nt] = __builtin_bit_cast(uint4, Mma<bf16_t>::from_floats(rv));
+    }
+  } else if (use_pre) {
     const bf16_t* resn = reinterpret_cast<const bf16_t*>(p.e.res) + (long)n * p.rps * p.C_out;
 #pragma unroll
     for (int pr = 0; pr < (PREFETCH_RES ? MO / 2 : 1); ++pr)
@@ -378,6 +399,31 @@ extern "C" int pytc_pw_mlp_head_fwd(const pytc_mlp_args* a, const void* head_w, 
     else hipLaunchKernelGGL((pw_mlp_kernel<2, 2, 4, 1, true>), grid, block, 0, s, p);
   }
   PYTC_LAUNCH_CHECK("pw_mlp_head");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_pw_mlp_stemres_fwd(const pytc_mlp_args* a, const float* stem_x, const float* stem_w, const float* stem_b,
+                                       void* stream) {
+  PYTC_REQUIRE(a && a->t && a->ab && a->w2_packed && a->w3_packed && a->b2 && a->b3 && a->y && stem_x && stem_w && stem_b,
+               "pw_mlp_stemres: null pointer");
+  PYTC_REQUIRE(a->N >= 1 && a->rows_per_sample >= 1, "pw_mlp_stemres: bad shape");
+  if (!(a->C_in == 32 && a->C_out == 32 && a->C_hid % 32 == 0 && a->C_hid >= 32)) {
+    set_error("pw_mlp_stemres: no fused kernel for C_in=%d C_hid=%d C_out=%d", a->C_in, a->C_hid, a->C_out);
+    return PYTC_ERR_UNSUPPORTED;
+  }
+  MlpParams p{};
+  p.t = (const bf16_t*)a->t; p.ab = a->ab; p.w2 = (const bf16x8_t*)a->w2_packed; p.b2 = a->b2;
+  p.w3 = (const bf16x8_t*)a->w3_packed; p.b3 = a->b3;
+  p.rps = a->rows_per_sample; p.C_in = a->C_in; p.C_hid = a->C_hid; p.C_out = a->C_out; p.HC = a->C_hid / 32;
+  p.e.res = a->y;              // never dereferenced (the residual rows are recomputed); non-null for the epilogue's checks
+  p.e.y = a->y;
+  p.e.rps_out = a->rows_per_sample; p.e.C_out = a->C_out; p.e.res_mode = PYTC_RES_ADD;
+  p.stem_x = stem_x; p.stem_w = stem_w; p.stem_b = stem_b;
+  dim3 grid((unsigned)((p.rps + 4L * 4 * 16 - 1) / (4L * 4 * 16)), (unsigned)a->N), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (tuning_get("mlp_exact_gelu", 0) != 0) hipLaunchKernelGGL((pw_mlp_kernel<1, 2, 4, 0, false, true>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((pw_mlp_kernel<1, 2, 4, 1, false, true>), grid, block, 0, s, p);
+  PYTC_LAUNCH_CHECK("pw_mlp_stemres");
   return PYTC_OK;
 }
 

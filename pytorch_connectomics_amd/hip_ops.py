@@ -352,6 +352,55 @@ def pw_mlp(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.Tenso
     return y
 
 
+def stem_dwconv3d_supported(c_in: int, c: int, K: int) -> bool:
+    return bool(nat.lib().pytc_stem_dwconv3d_supported(int(c_in), int(c), int(K)))
+
+
+def stem_dwconv3d_pack(stem_w: torch.Tensor, stem_b: torch.Tensor, w_taps: torch.Tensor, bias: Optional[torch.Tensor]):
+    """-> (wx (27,C), wb (27,C), cst (C)) fp32: the products pytc_stem_dwconv3d_fwd consumes (cache them per weight version)."""
+    wx = (w_taps * stem_w.view(1, -1)).contiguous()
+    wb = (w_taps * stem_b.view(1, -1)).contiguous()
+    cst = wb.sum(0) + (bias if bias is not None else 0.0)
+    return wx, wb, cst.contiguous()
+
+
+def stem_dwconv3d(x: torch.Tensor, packed):
+    """x (N,D,H,W,1) fp32 -> (t (N,D,H,W,32) bf16 = dwconv3(stem(x)), stats (N,slots,2,32)); the stem output is not formed."""
+    wx, wb, cst = packed
+    _dev(x, "x"); _dev(wx, "wx")
+    if x.dtype != torch.float32 or x.shape[-1] != 1:
+        raise TypeError("stem_dwconv3d takes the 1-channel fp32 network input")
+    N, D, H, W, _ = x.shape
+    Cc = wx.shape[1]
+    y = torch.empty((N, D, H, W, Cc), dtype=torch.bfloat16, device=x.device)
+    slots = nat.lib().pytc_stem_dwconv3d_stat_slots(D, H, W)
+    st = torch.empty((N, slots, 2, Cc), dtype=torch.float32, device=x.device)
+    _run(f"stem_dwconv3d_fwd[C{Cc}_k3]", _nbytes(x, y), nat.lib().pytc_stem_dwconv3d_fwd, _p(x), _p(wx), _p(wb), _p(cst),
+         _p(y), _p(st), N, D, H, W, Cc, _stream())
+    return y, st
+
+
+def pw_mlp_stemres(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.Tensor, w3p: torch.Tensor, b3: torch.Tensor,
+                   x0: torch.Tensor, stem_w: torch.Tensor, stem_b: torch.Tensor, *, N: int, rows_per_sample: int, c_in: int,
+                   c_hid: int, c_out: int) -> torch.Tensor:
+    """pw_mlp whose residual is the stem output recomputed from the 1-channel fp32 input x0 (N, rows)."""
+    _dev(t, "t"); _dev(x0, "x0")
+    if t.dtype != torch.bfloat16 or x0.dtype != torch.float32:
+        raise TypeError("pw_mlp_stemres: bf16 activations and the fp32 network input")
+    y = torch.empty((N, rows_per_sample, c_out), dtype=torch.bfloat16, device=t.device)
+    a = nat.MlpArgs()
+    a.t, a.ab, a.w2_packed, a.b2, a.w3_packed, a.b3 = (t.data_ptr(), ab.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
+                                                       w3p.data_ptr(), b3.data_ptr())
+    a.res = a.res_low = a.res_bias = None
+    a.y = y.data_ptr()
+    a.N, a.rows_per_sample, a.C_in, a.C_hid, a.C_out, a.res_mode = N, rows_per_sample, c_in, c_hid, c_out, nat.RES_ADD
+    a.Di = a.Hi = a.Wi = 0
+    nb = N * rows_per_sample * (2 * (c_in + c_out) + 4)
+    _run(f"pw_mlp_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_stemres_fwd, C.byref(a), _p(x0), _p(stem_w),
+         _p(stem_b), _stream())
+    return y
+
+
 def pw_mlp_head_supported(c_in: int, c_hid: int, c_out: int) -> bool:
     return bool(nat.lib().pytc_pw_mlp_head_supported(int(c_in), int(c_hid), int(c_out)))
 

@@ -264,6 +264,39 @@ class HipBlockOps:
         return y.view(N, Do, Ho, Wo, c_out)
 
 
+def _stem_block_fused(self, stem: nn.Module, m, x_cl: torch.Tensor) -> Optional[torch.Tensor]:
+    """Stem + first block without ever forming the stem output (bf16 inference, 1-channel fp32 input): the depthwise conv
+    reads the network input (pytc_stem_dwconv3d_fwd), the mixer recomputes its residual from it (pytc_pw_mlp_stemres_fwd).
+    Returns None when a precondition fails (the caller then runs stem and block separately)."""
+    N, D, H, W, cin = x_cl.shape
+    C = stem.weight.shape[0]
+    K = m.conv1.weight.shape[-1]
+    if (cin != 1 or x_cl.dtype != torch.float32 or stem.bias is None or m.kind != "block" or not m.do_res or m.grn
+            or not isinstance(m.norm, nn.GroupNorm) or m.dim != "3d" or m.conv2.bias is None or m.conv3.bias is None
+            or m.conv1.weight.shape[0] != C or not ops.stem_dwconv3d_supported(cin, C, K)):
+        return None
+    c_hid, c_out = m.conv2.weight.shape[0], m.conv3.weight.shape[0]
+    if c_out != C or not ops.pw_mlp_supported(C, c_hid, c_out):
+        return None
+    # the un-fused stem kernel consumes bf16-rounded weights (bf16 storage path): same rounding here
+    sw = self.cache.get(("stemw", id(stem)), [stem.weight], lambda: stem.weight.detach().float().reshape(-1).bfloat16().float().contiguous())
+    sb = self._vec(stem, "bias", stem.bias)
+    taps, _ = self._taps(m.conv1)
+    packed = self.cache.get(("stemdw", id(stem), id(m.conv1)), [stem.weight, stem.bias, m.conv1.weight, m.conv1.bias],
+                            lambda: ops.stem_dwconv3d_pack(sw, sb, taps, self._vec(m.conv1, "bias", m.conv1.bias)))
+    t, st = ops.stem_dwconv3d(x_cl, packed)
+    rows = D * H * W
+    ab = ops.groupnorm_finalize(st, float(rows), self._vec(m.norm, "weight", m.norm.weight),
+                                self._vec(m.norm, "bias", m.norm.bias), m.norm.eps)
+    y = ops.pw_mlp_stemres(t, ab, self._pw_paired(m.conv2), self._vec(m.conv2, "bias", m.conv2.bias),
+                           self._pw_paired(m.conv3), self._vec(m.conv3, "bias", m.conv3.bias), x_cl.reshape(N, rows), sw, sb,
+                           N=N, rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out)
+    return y.view(N, D, H, W, c_out)
+
+
+HipBlockOps._stem_block_fused = None   # bound below
+
+
 def _block_fused(self, m, x, t, ab, skip, ishape, oshape, c_hid, c_out):
     """bf16 fast path: one pw_mlp launch per block (plus the tiny residual-conv GEMMs of down/up blocks)."""
     N, D, H, W, C = ishape
@@ -300,6 +333,7 @@ def _block_fused(self, m, x, t, ab, skip, ishape, oshape, c_hid, c_out):
 
 
 HipBlockOps._block_fused = _block_fused
+HipBlockOps._stem_block_fused = _stem_block_fused
 
 
 def resolve_compute_dtype(module_pref: Optional[torch.dtype]) -> torch.dtype:
@@ -379,6 +413,9 @@ class MedNeXt(nn.Module):
         self.compute_dtype: Optional[torch.dtype] = None   # None -> follow autocast
         self._hip = HipBlockOps()
         self.fuse_head = True      # inference: output projection inside the last mixer's epilogue where a kernel exists
+        # stem folded into the first depthwise conv + residual recomputed in its mixer: correct and tested, but the fused
+        # kernel (781 us at 8x112^3) is slower than the stem + depthwise kernels it replaces (174 + 400 us) -> opt-in
+        self.fuse_stem = False
 
     # ---- engine ---------------------------------------------------------------------------------
     def _check_input(self, x: torch.Tensor):
@@ -399,10 +436,18 @@ class MedNeXt(nn.Module):
         if any(int(v) % 16 for v in x_cl.shape[1:4]):
             # four stride-2 stages: the decoder's skip additions need every level to halve exactly
             raise ValueError(f"MedNeXt needs spatial sizes divisible by 16, got {tuple(x_cl.shape[1:4])}")
-        x = hip.pointwise(x_cl, self.stem, out_dtype=dt)
+        enc0 = list(self.enc_block_0)
+        x = None
+        if self.fuse_stem and hip.fused and dt == torch.bfloat16 and enc0:
+            x = hip._stem_block_fused(self.stem, enc0[0], x_cl)      # stem output never written (None: not applicable)
+        first_done = x is not None
+        if x is None:
+            x = hip.pointwise(x_cl, self.stem, out_dtype=dt)
         skips = []
         for lvl in range(4):
-            for blk in getattr(self, f"enc_block_{lvl}"):
+            for bi, blk in enumerate(getattr(self, f"enc_block_{lvl}")):
+                if lvl == 0 and bi == 0 and first_done:
+                    continue
                 x = hip.block(blk, x)
             skips.append(x)
             x = hip.block(getattr(self, f"down_{lvl}"), x)

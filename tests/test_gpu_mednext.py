@@ -161,3 +161,40 @@ def test_fused_output_head_equals_unfused(n_classes, size):
         y1 = m(x.permute(0, 4, 1, 2, 3))
         torch.testing.assert_close(y1, got.permute(0, 4, 1, 2, 3))
         assert torch.equal(m.forward_cl(x), got)           # deterministic
+
+
+@pytest.mark.parametrize("shape", [(16, 32, 48), (32, 16, 16)])
+def test_fused_stem_equals_unfused_and_oracle_math(shape):
+    """Stem folded into the first depthwise conv (stem output never written) + residual recomputed in the mixer, against
+    the un-fused kernels (which round the stem output to bf16 first) and the kernel itself against fp64 math."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    from pytorch_connectomics_amd.models.architectures.mednext import create_mednext_v1
+    torch.manual_seed(7)
+    m = create_mednext_v1(1, 2, "S", 3).cuda().eval()
+    m.compute_dtype = torch.bfloat16
+    with torch.no_grad():
+        m.stem.bias.normal_(0, 0.5)
+        x = torch.randn(2, *shape, 1, device="cuda")
+        m.fuse_stem = False
+        ref = m.forward_cl(x)
+        m.fuse_stem = True
+        got = m.forward_cl(x)
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 4e-2 * scale          # bf16 storage path tolerance (DESIGN section 2)
+        assert float((got - ref).abs().mean()) <= 4e-3 * scale
+        assert torch.equal(m.forward_cl(x), got)
+        # the fused depthwise kernel alone vs float64: t = dwconv3(stem(x)), zero padding of the stem output
+        blk = m.enc_block_0[0]
+        sw = m.stem.weight.detach().float().reshape(-1)
+        sb = m.stem.bias.detach().float()
+        taps = blk.conv1.weight.detach().float().reshape(32, 27).t().contiguous()
+        t, st = ops.stem_dwconv3d(x, ops.stem_dwconv3d_pack(sw, sb, taps, blk.conv1.bias.detach().float()))
+        x64 = x.double().cpu().permute(0, 4, 1, 2, 3)
+        s64 = torch.nn.functional.conv3d(x64, m.stem.weight.detach().double().cpu(), m.stem.bias.detach().double().cpu())
+        t64 = torch.nn.functional.conv3d(s64, blk.conv1.weight.detach().double().cpu(), blk.conv1.bias.detach().double().cpu(),
+                                         padding=1, groups=32).permute(0, 2, 3, 4, 1)
+        err = (t.double().cpu() - t64).abs().max() / t64.abs().max()
+        assert float(err) < 6e-3                                         # one bf16 rounding of the stored result
+        tb = t.float()
+        torch.testing.assert_close(st[:, :, 0].sum(1).cpu(), tb.sum((1, 2, 3)).cpu(), rtol=1e-4, atol=1e-2)
+        torch.testing.assert_close(st[:, :, 1].sum(1).cpu(), (tb * tb).sum((1, 2, 3)).cpu(), rtol=1e-4, atol=1e-2)
