@@ -352,6 +352,38 @@ reduce_slots_kernel(const float* __restrict__ part, float* __restrict__ out, lon
   }
 }
 
+// the weight and bias partials of one gradient in ONE launch (same tree per element as reduce_slots_kernel)
+__global__ void __launch_bounds__(256)
+reduce_slots_pair_kernel(const float* __restrict__ partA, float* __restrict__ outA, long nA, const float* __restrict__ partB,
+                         float* __restrict__ outB, long nB, int slots) {
+  __shared__ float sm[16][17];
+  const long blocksA = (nA + 15) / 16;
+  const bool second = (long)blockIdx.x >= blocksA;
+  const float* part = second ? partB : partA;
+  float* out = second ? outB : outA;
+  const long n = second ? nB : nA;
+  const long b = second ? blockIdx.x - blocksA : blockIdx.x;
+  const int e = threadIdx.x & 15, j = threadIdx.x >> 4;
+  const long i = b * 16 + e;
+  float a = 0.f;
+  if (i < n)
+    for (int s = j; s < slots; s += 16) a += part[(long)s * n + i];
+  sm[j][e] = a;
+  __syncthreads();
+  if (j == 0 && i < n) {
+    float t = sm[0][e];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += sm[q][e];
+    out[i] = t;
+  }
+}
+
+static inline void reduce_slots_pair(const float* pA, float* oA, long nA, const float* pB, float* oB, long nB, int slots,
+                                     hipStream_t s) {
+  const long blocks = (nA + 15) / 16 + (oB ? (nB + 15) / 16 : 0);
+  hipLaunchKernelGGL(reduce_slots_pair_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pA, oA, nA, pB, oB, oB ? nB : 0, slots);
+}
+
 // batched form: blockIdx.y = sample; part [N][slots][n] -> out [N][n]
 __global__ void __launch_bounds__(256)
 reduce_slots_batched_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int slots) {
@@ -787,8 +819,7 @@ extern "C" int pytc_pw_wgrad(const void* x, const float* ab, const void* dy, flo
                "pw_wgrad")
   }
   const long nW = (long)C_out * C_in;
-  hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(nW, 16)), dim3(256), 0, s, dWp, dW, nW, slots);
-  if (db) hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(C_out, 16)), dim3(256), 0, s, dbp, db, (long)C_out, slots);
+  reduce_slots_pair(dWp, dW, nW, dbp, db, (long)C_out, slots, s);
   PYTC_LAUNCH_CHECK("pw_wgrad");
   return PYTC_OK;
 }
@@ -867,8 +898,7 @@ extern "C" int pytc_dw_wgrad(const void* g, const void* x, float* dW, float* db,
     float* dbm = workspace + (long)ms * nWm;
     hipStream_t sm = (hipStream_t)stream;
     dw_wgrad_march_launch(g, x, dWm, db ? dbm : nullptr, N, gdims[0], gdims[1], gdims[2], C, dtype, sm);
-    hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(nWm, 16)), dim3(256), 0, sm, dWm, dW, nWm, ms);
-    if (db) hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, sm, dbm, db, (long)C, ms);
+    reduce_slots_pair(dWm, dW, nWm, dbm, db, (long)C, ms, sm);
     PYTC_LAUNCH_CHECK("dw_wgrad");
     return PYTC_OK;
   }
@@ -886,8 +916,7 @@ extern "C" int pytc_dw_wgrad(const void* g, const void* x, float* dW, float* db,
                hipLaunchKernelGGL(dw_wgrad_vec_kernel<bf16_t>, grid, block, 0, sv, (const bf16_t*)g, (const bf16_t*)x, dWv, db ? dbv : nullptr, q, rps),
                hipLaunchKernelGGL(dw_wgrad_vec_kernel<float>, grid, block, 0, sv, (const float*)g, (const float*)x, dWv, db ? dbv : nullptr, q, rps),
                "dw_wgrad")
-    hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(nWv, 16)), dim3(256), 0, sv, dWv, dW, nWv, total);
-    if (db) hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, sv, dbv, db, (long)C, total);
+    reduce_slots_pair(dWv, dW, nWv, dbv, db, (long)C, total, sv);
     PYTC_LAUNCH_CHECK("dw_wgrad");
     return PYTC_OK;
   }
@@ -902,8 +931,7 @@ extern "C" int pytc_dw_wgrad(const void* g, const void* x, float* dW, float* db,
   if (dtype == PYTC_BF16) rc = vec == 4 ? launch_dwwg<bf16_t, 4>(g, x, dWp, dbp, q, s) : vec == 2 ? launch_dwwg<bf16_t, 2>(g, x, dWp, dbp, q, s) : launch_dwwg<bf16_t, 1>(g, x, dWp, dbp, q, s);
   else rc = vec == 2 ? launch_dwwg<float, 2>(g, x, dWp, dbp, q, s) : launch_dwwg<float, 1>(g, x, dWp, dbp, q, s);
   if (rc != PYTC_OK) return rc;
-  hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(nW, 16)), dim3(256), 0, s, dWp, dW, nW, total_slots);
-  if (db) hipLaunchKernelGGL(reduce_slots_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, s, dbp, db, (long)C, total_slots);
+  reduce_slots_pair(dWp, dW, nW, dbp, db, (long)C, total_slots, s);
   PYTC_LAUNCH_CHECK("dw_wgrad");
   return PYTC_OK;
 }

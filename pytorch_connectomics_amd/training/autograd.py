@@ -189,8 +189,14 @@ class BlockFn(torch.autograd.Function):
                 dwres = dwres_m.t().contiguous()                    # ConvTranspose layout (C_in, C_out)
                 dbres = db3.clone()                                 # bias reaches every interior voxel exactly once
                 ops.add_(dx, _pw(drl, _mat(wres), None, c_out=C, transposed=False).view_as(dx))
-        # torch.empty_like + copy_: canonical strides even for size-1 dims (DDP's bucket views expect them)
-        g = lambda v, like: None if v is None else torch.empty_like(like).copy_(v.reshape(like.shape))
+        # gradients in the parameter's own (contiguous) strides, which DDP's bucket views expect: a view when the kernel
+        # output is already laid out that way (1x1x1 weights, norm vectors), a copy only for the transposed ones
+        def g(v, like):
+            if v is None:
+                return None
+            if v.is_contiguous() and like.is_contiguous():
+                return v.view(like.shape)
+            return torch.empty_like(like).copy_(v.reshape(like.shape))
         return (dx, dskip, g(dW1.t().contiguous(), w1), (db1.to(w1.dtype) if has_b1 else None), g(dgamma, gamma),
                 g(dbeta, gamma), g(dW2, w2), db2.to(w2.dtype), g(dW3, w3), db3.to(w3.dtype),
                 (g(dwres, wres) if has_res else None), (dbres.to(w3.dtype) if (has_res and has_bres) else None),
