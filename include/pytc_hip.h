@@ -423,6 +423,10 @@ int pytc_dwconv3d_generic_fwd(const void* x, void* y, const float* w, int N, int
  * pytc_grad_norm_multi: norm_coef[0] = global L2 norm of the gradients, [1] = min(1, max_norm/(norm+1e-6)) (max_norm <= 0:
  *   1); workspace n_chunks floats.  pytc_adamw_multi: torch.optim.AdamW update of every tensor with the gradient scaled by
  *   norm_coef[1] (NULL: unscaled), then ema = d*ema + (1-d)*param where a record carries an ema pointer.  No host sync. */
+/* MedNeXt norm_type='layer' (channels-first LayerNorm, ConvNeXt style): every row [C] of x [rows][C] normalised over its
+ * channels, y = gamma * (x - mean) / sqrt(var + eps) + beta (gamma / beta may be NULL); C = VEC * 2^k, 2^k <= 64. */
+int pytc_layernorm_rows(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int C, float eps,
+                        int dtype, void* stream);
 int64_t pytc_bce_dice_ws_elems(int N, int C, int64_t R);
 int pytc_bce_dice_fwd(const float* logits, const float* target, const float* weight, int N, int C, int64_t R,
                       const int64_t* x_strides, const int64_t* t_strides, const int64_t* w_strides, float pos_weight,

@@ -179,6 +179,38 @@ dwconvT3d_generic_vec_kernel(const T* __restrict__ x, T* __restrict__ y, const f
   VecIO<T, VEC>::store(y + (((n * g.Do + oz) * g.Ho + oy) * g.Wo + ox) * g.C + c, acc);
 }
 
+// ---- channels-first LayerNorm of MedNeXt (norm_type='layer'): every voxel row normalised over its C channels ---------
+// y[r][c] = gamma[c] * (x[r][c] - mean_r) / sqrt(var_r + eps) + beta[c]   (biased variance, two-pass in registers).
+// L = C / VEC lanes share a row (power of two <= 64), their partial sums meet through xor-shuffles.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+layernorm_rows_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
+                      const float* __restrict__ beta, long rows, int C, float eps) {
+  const int L = C / VEC;                                  // lanes per row
+  const int rows_per_block = 256 / L;
+  const int lr = threadIdx.x / L, lc = threadIdx.x % L;
+  for (long r = (long)blockIdx.x * rows_per_block + lr; r < rows; r += (long)gridDim.x * rows_per_block) {
+    float v[VEC];
+    VecIO<T, VEC>::load(x + r * C + lc * VEC, v);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s += v[j];
+    for (int off = 1; off < L; off <<= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { const float d = v[j] - mean; q = fmaf(d, d, q); }
+    for (int off = 1; off < L; off <<= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = lc * VEC + j;
+      v[j] = fmaf((v[j] - mean) * rstd, gamma ? gamma[c] : 1.0f, beta ? beta[c] : 0.f);
+    }
+    VecIO<T, VEC>::store(y + r * C + lc * VEC, v);
+  }
+}
+
 // ---- y = act(a[n][c]*x + b[n][c]) elementwise (norm-apply + activation when it cannot ride in a conv prologue) ----
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -316,5 +348,32 @@ extern "C" int pytc_dwconvT3d_generic_fwd(const void* x, void* y, const float* w
   else
     PYTC_REQUIRE(false, "dwconvT3d_generic: bad dtype");
   PYTC_LAUNCH_CHECK("dwconvT3d_generic");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_layernorm_rows(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int C,
+                                   float eps, int dtype, void* stream) {
+  PYTC_REQUIRE(x && y && rows >= 1 && C >= 1, "layernorm_rows: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  // widest vector such that C / VEC is a power of two <= 64 (shuffle groups stay inside a wave and tile the workgroup)
+  auto pow2 = [](int v) { return v >= 1 && (v & (v - 1)) == 0; };
+  const int maxv = dtype == PYTC_BF16 ? 8 : 4;
+  int vec = 0;
+  for (int v = maxv; v >= 1; v >>= 1)
+    if (C % v == 0 && pow2(C / v) && C / v <= 64) { vec = v; break; }
+  PYTC_REQUIRE(vec > 0, "layernorm_rows: C=%d must be VEC * 2^k with 2^k <= 64", C);
+  const int rpb = 256 / (C / vec);
+  long blocks = (rows + rpb - 1) / rpb;
+  if (blocks > 65536) blocks = 65536;
+#define LN_LAUNCH(TT, V) hipLaunchKernelGGL((layernorm_rows_kernel<TT, V>), dim3((unsigned)blocks), dim3(256), 0, s, (const TT*)x, (TT*)y, gamma, beta, (long)rows, C, eps)
+  if (dtype == PYTC_BF16) {
+    if (vec == 8) LN_LAUNCH(bf16_t, 8); else if (vec == 4) LN_LAUNCH(bf16_t, 4); else if (vec == 2) LN_LAUNCH(bf16_t, 2); else LN_LAUNCH(bf16_t, 1);
+  } else if (dtype == PYTC_F32) {
+    if (vec == 4) LN_LAUNCH(float, 4); else if (vec == 2) LN_LAUNCH(float, 2); else LN_LAUNCH(float, 1);
+  } else {
+    PYTC_REQUIRE(false, "layernorm_rows: bad dtype");
+  }
+#undef LN_LAUNCH
+  PYTC_LAUNCH_CHECK("layernorm_rows");
   return PYTC_OK;
 }

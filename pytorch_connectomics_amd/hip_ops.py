@@ -249,6 +249,16 @@ def dwconv3d(x: torch.Tensor, w_taps: torch.Tensor, bias: Optional[torch.Tensor]
     return y, st
 
 
+def layernorm_rows(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float = 1e-5) -> torch.Tensor:
+    """Channels-first LayerNorm of MedNeXt: x (..., C) normalised over C per voxel row."""
+    _dev(x, "x")
+    Cc = x.shape[-1]
+    y = torch.empty_like(x)
+    _run(f"layernorm_rows[C{Cc}]", 2 * _nbytes(x), nat.lib().pytc_layernorm_rows, _p(x), _p(y), _p(gamma), _p(beta),
+         x.numel() // Cc, Cc, float(eps), dtype_code(x.dtype), _stream())
+    return y
+
+
 def groupnorm_finalize(stats: torch.Tensor, count: float, gamma: Optional[torch.Tensor],
                        beta: Optional[torch.Tensor], eps: float = 1e-5) -> torch.Tensor:
     N, slots, _, Cc = stats.shape

@@ -177,6 +177,22 @@ class HipBlockOps:
             return ops.pack_head_fragment(w.detach().float().reshape(w.shape[0], w.shape[1]).t().contiguous())
         return self.cache.get(("headw", id(conv)), [w], make)
 
+    def _grn(self, m, h: torch.Tensor, N: int, grid, c_hid: int, kind: str) -> torch.Tensor:
+        """Global response normalisation of the expanded tensor (MedNeXtBlock.forward with grn=True):
+        gx = ||h||_2 over space per (n, c), nx = gx / (mean_c gx + 1e-6), h <- gamma * (h * nx) + beta + h
+        = h * (gamma * nx + 1) + beta: the column sums of squares come from the statistics kernel, the update is one
+        per-(n, c) affine.  For the up block the padded front faces are not part of h's support."""
+        Do, Ho, Wo = grid
+        hv = h.view(N, Do, Ho, Wo, c_hid)
+        core = hv[:, 1:, 1:, 1:].contiguous() if kind == "up" else hv
+        sumsq = ops.channel_stats(core)[:, :, 1].sum(1)                       # (N, C)
+        gx = sumsq.clamp_min(0).sqrt()
+        nx = gx / (gx.mean(1, keepdim=True) + 1e-6)
+        g = self._vec(m, "grn_gamma", m.grn_gamma).view(1, c_hid)
+        b = self._vec(m, "grn_beta", m.grn_beta).view(1, c_hid)
+        ab = torch.stack([g * nx + 1.0, b.expand(N, c_hid)], 1).contiguous()
+        return ops.affine_act(hv, ab, nat.ACT_NONE, 0.0).view(N, Do * Ho * Wo, c_hid)
+
     def _vec(self, owner, name: str, p: Optional[torch.Tensor]):
         if p is None:
             return None
@@ -202,31 +218,35 @@ class HipBlockOps:
     def block(self, m: MedNeXtBlock, x: torch.Tensor, skip: Optional[torch.Tensor] = None, head: Optional[nn.Module] = None):
         """head: the network's output conv; when the fused mixer can carry it in its epilogue the block returns
         (None, logits fp32 (N, D, H, W, n_classes)) instead of its bf16 output."""
-        if m.grn:
-            raise NotImplementedError("MedNeXt GRN (grn=True) has no HIP kernel yet")
-        if not isinstance(m.norm, nn.GroupNorm):
-            raise NotImplementedError("MedNeXt norm_type='layer' has no HIP kernel yet")
         if m.dim != "3d":
             raise NotImplementedError("MedNeXt dim='2d' has no HIP kernel yet")
+        is_ln = isinstance(m.norm, _ChannelLayerNorm)
+        if not is_ln and not isinstance(m.norm, nn.GroupNorm):
+            raise NotImplementedError(f"unsupported MedNeXt norm module {type(m.norm).__name__}")
         dt = x.dtype
         N, D, H, W, C = x.shape
         taps, K = self._taps(m.conv1)
         b1 = self._vec(m.conv1, "bias", m.conv1.bias)
         kind = m.kind
         if kind == "up":
-            t, st = ops.dwconv3d(x, taps, b1, K=K, transposed=True)
+            t, st = ops.dwconv3d(x, taps, b1, K=K, transposed=True, stats=not is_ln)
             count = float((2 * D - 1) * (2 * H - 1) * (2 * W - 1))
         else:
-            t, st = ops.dwconv3d(x, taps, b1, K=K, stride=2 if kind == "down" else 1)
+            t, st = ops.dwconv3d(x, taps, b1, K=K, stride=2 if kind == "down" else 1, stats=not is_ln)
             count = float(t.shape[1] * t.shape[2] * t.shape[3])
-        ab = ops.groupnorm_finalize(st, count, self._vec(m.norm, "weight", m.norm.weight),
-                                    self._vec(m.norm, "bias", m.norm.bias), m.norm.eps)
+        gamma, beta = self._vec(m.norm, "weight", m.norm.weight), self._vec(m.norm, "bias", m.norm.bias)
+        if is_ln:
+            # channels-first LayerNorm: per-voxel statistics over C, applied by its own kernel (no (n, c) affine to fuse)
+            t = ops.layernorm_rows(t, gamma, beta, m.norm.eps)
+            ab = None
+        else:
+            ab = ops.groupnorm_finalize(st, count, gamma, beta, m.norm.eps)
         _, Do, Ho, Wo, _ = t.shape
         rows = Do * Ho * Wo
         c_hid = m.conv2.weight.shape[0]
         c_out = m.conv3.weight.shape[0]
-        if (self.fused and dt == torch.bfloat16 and m.conv2.bias is not None and m.conv3.bias is not None
-                and ops.pw_mlp_supported(C, c_hid, c_out)):
+        if (self.fused and dt == torch.bfloat16 and not m.grn and not is_ln and m.conv2.bias is not None
+                and m.conv3.bias is not None and ops.pw_mlp_supported(C, c_hid, c_out)):
             if (head is not None and kind == "block" and head.weight.shape[1] <= 16
                     and ops.pw_mlp_head_supported(C, c_hid, c_out)):
                 _, logits = ops.pw_mlp_head(t, ab, self._pw_paired(m.conv2), self._vec(m.conv2, "bias", m.conv2.bias),
@@ -238,6 +258,8 @@ class HipBlockOps:
             return self._block_fused(m, x, t, ab, skip, (N, D, H, W, C), (Do, Ho, Wo), c_hid, c_out)
         h = ops.pw_conv(t, self._pw(m.conv2, dt), self._vec(m.conv2, "bias", m.conv2.bias), N=N,
                         rows_per_sample=rows, c_in=C, c_out=c_hid, out_dtype=dt, ab=ab, act=nat.ACT_GELU)
+        if m.grn:
+            h = self._grn(m, h, N, (Do, Ho, Wo), c_hid, kind)
         w3, b3 = self._pw(m.conv3, dt), self._vec(m.conv3, "bias", m.conv3.bias)
         if kind == "block":
             y = ops.pw_conv(h, w3, b3, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, out_dtype=dt,

@@ -198,3 +198,35 @@ def test_fused_stem_equals_unfused_and_oracle_math(shape):
         tb = t.float()
         torch.testing.assert_close(st[:, :, 0].sum(1).cpu(), tb.sum((1, 2, 3)).cpu(), rtol=1e-4, atol=1e-2)
         torch.testing.assert_close(st[:, :, 1].sum(1).cpu(), (tb * tb).sum((1, 2, 3)).cpu(), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("norm_type,grn", [("group", True), ("layer", False), ("layer", True)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_mednext_grn_and_layernorm_variants_match_oracle(dev, norm_type, grn, dt):
+    """build_mednext_custom's norm_type='layer' (channels-first LayerNorm) and grn=True (global response norm) --
+    mednext_models.py:449-463 constructor arguments -- inference against the oracle."""
+    from pytorch_connectomics_amd.models.architectures.mednext import MedNeXt
+    torch.manual_seed(5)
+    kw = dict(n_channels=8, exp_r=[2, 3, 2, 2, 2, 2, 2, 3, 2], kernel_size=3, block_counts=[1, 1, 1, 1, 1, 1, 1, 1, 2])
+    m = MedNeXt(1, kw["n_channels"], 2, exp_r=kw["exp_r"], kernel_size=3, do_res=True, do_res_up_down=True,
+                block_counts=kw["block_counts"], norm_type=norm_type, grn=grn)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("norm.weight") or n.endswith("norm.bias"):
+                p.add_(0.2 * torch.randn_like(p))
+            if "grn_" in n:
+                p.normal_(0, 0.3)
+    st = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(2, 1, 32, 16, 32, generator=torch.Generator().manual_seed(6))
+    ref = MO.forward(st, x, norm_type=norm_type, grn=grn, **kw)
+    m = m.to(dev).eval()
+    m.compute_dtype = dt
+    with torch.no_grad():
+        got = m(x.to(dev)).cpu()
+    assert got.shape == ref.shape
+    tol = TOL_F32_PROB if dt == torch.float32 else TOL_BF16_PROB
+    assert (torch.sigmoid(got) - torch.sigmoid(ref)).abs().max() < tol
+    if dt == torch.float32:
+        torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-3)
+    with pytest.raises(NotImplementedError):
+        m.train()(x.to(dev))                       # the training kernels cover GroupNorm blocks only
