@@ -111,6 +111,59 @@ def stitch_chunk_prediction_files(output_path, chunks, volume_shape, *, dtype=No
     return out
 
 
+class _ChunkWriter:
+    """One background thread that turns (tensor | array, path, key) jobs into chunk files.  CUDA tensors are copied into
+    pinned host memory with a non-blocking copy; the thread synchronises on the copy's event, not on the device."""
+
+    def __init__(self, manifest, depth: int = 2):
+        import queue
+        import threading
+        self.manifest = manifest
+        self.q = queue.Queue(maxsize=depth)          # bounds the pinned memory in flight
+        self.err = None
+        self.t = threading.Thread(target=self._run, name="pytc-chunk-writer", daemon=True)
+        self.t.start()
+
+    def submit(self, core_pred, path: Path, key: str) -> None:
+        if self.err is not None:
+            raise self.err
+        if isinstance(core_pred, torch.Tensor) and core_pred.is_cuda:
+            src = core_pred.detach().float()
+            host = torch.empty(src.shape, dtype=torch.float32, pin_memory=True)
+            host.copy_(src, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.q.put((host, ev, path, key))
+        else:
+            arr = core_pred.detach().float().cpu().numpy() if isinstance(core_pred, torch.Tensor) else np.asarray(core_pred)
+            self.q.put((arr, None, path, key))
+
+    def _run(self):
+        while True:
+            job = self.q.get()
+            if job is None:
+                return
+            if self.err is not None:
+                continue
+            data, ev, path, key = job
+            try:
+                if ev is not None:
+                    ev.synchronize()
+                    data = data.numpy()
+                tmp = path.with_suffix(".tmp.npy")
+                np.save(tmp, data)
+                os.replace(tmp, path)
+                self.manifest.mark_completed(key)
+            except BaseException as e:          # surfaced to the producer at the next submit / close
+                self.err = e
+
+    def close(self) -> None:
+        self.q.put(None)
+        self.t.join()
+        if self.err is not None:
+            raise self.err
+
+
 def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, device="cuda",
                                      requested_head: Optional[str] = None,
                                      predict_region_fn: Optional[Callable] = None, stitch: bool = True,
@@ -148,20 +201,23 @@ def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, de
             return lazy_predict_region(cfg, forward_fn, volume, region_start=start, region_stop=stop, device=device,
                                        requested_head=requested_head)
     channels = None
-    for pos, (idx, c) in enumerate(mine, 1):
-        f = _chunk_file(cdir, c)
-        if f.exists() and c.key in manifest.completed:     # idempotent resume (reference chunked.py:510-523)
-            logger.info("chunk %s already done, skipping", c.key)
-            continue
-        read_lo, read_hi, core = resolve_halo_region(c, input_shape[-3:], halo=halo, crop_before=crop_before)
-        pred = predict_region_fn(read_lo, read_hi)
-        core_pred = pred[(0, slice(None)) + core]
-        arr = core_pred.detach().float().cpu().numpy() if isinstance(core_pred, torch.Tensor) else np.asarray(core_pred)
-        channels = arr.shape[0]
-        tmp = f.with_suffix(".tmp.npy")
-        np.save(tmp, arr)
-        os.replace(tmp, f)
-        manifest.mark_completed(c.key)
+    # device -> pinned host copy and the file write of chunk i overlap the prediction of chunk i+1: the copy is issued
+    # non-blocking behind the chunk's kernels, a writer thread waits on its event, saves atomically (tmp + rename) and
+    # only then marks the chunk completed in the manifest
+    writer = _ChunkWriter(manifest)
+    try:
+        for pos, (idx, c) in enumerate(mine, 1):
+            f = _chunk_file(cdir, c)
+            if f.exists() and c.key in manifest.completed:     # idempotent resume (reference chunked.py:510-523)
+                logger.info("chunk %s already done, skipping", c.key)
+                continue
+            read_lo, read_hi, core = resolve_halo_region(c, input_shape[-3:], halo=halo, crop_before=crop_before)
+            pred = predict_region_fn(read_lo, read_hi)
+            core_pred = pred[(0, slice(None)) + core]
+            channels = int(core_pred.shape[0])
+            writer.submit(core_pred, f, c.key)
+    finally:
+        writer.close()
     if ext is not None:
         return None       # external shards are stitched by a later call once every shard has run
     if world > 1:
