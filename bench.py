@@ -17,6 +17,9 @@ from __future__ import annotations
 import argparse
 import json
 import os
+
+# RCCL / cross-process device memory on this driver stack needs dmabuf IPC (already exported on the target image)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import sys
 import time
 from pathlib import Path

@@ -13,10 +13,14 @@ from __future__ import annotations
 import argparse
 import json
 import logging
+import os
 import sys
 import time
 from pathlib import Path
 from typing import Optional, Sequence
+
+# RCCL / cross-process device memory on this driver stack needs dmabuf IPC (already exported on the target image)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
