@@ -141,6 +141,57 @@ def train_leg(dev, rank, world, args, barrier):
             "final_loss": float(loss.detach())}
 
 
+def rsunet_leg(dev, args):
+    """The path's second architecture, reported next to the headline (single GPU): RSUNet [16, 32, 64, 128], BatchNorm,
+    anisotropic 2 x 18 x 160 x 160 patches, bf16 storage: training step (HIP forward + backward, fused loss, fused AdamW)
+    and inference forward."""
+    import torch.nn.functional as F
+    from pytorch_connectomics_amd.models.architectures.rsunet import RSUNet
+    from pytorch_connectomics_amd.training.fused import FusedAdamW, bce_dice_loss
+    from pytorch_connectomics_amd.utils.hostgc import quiesce_gc
+    torch.manual_seed(0)
+    patch, batch = (18, 160, 160), 2
+    m = RSUNet(1, 3, width=[16, 32, 64, 128], norm="batch", activation="relu").to(dev).train()
+    m.compute_dtype = torch.bfloat16
+    opt = FusedAdamW(m.parameters(), lr=1e-4, weight_decay=1e-2, max_grad_norm=1.0)
+    x = torch.rand(batch, 1, *patch, device=dev)
+    y = (torch.rand(batch, 3, *patch, device=dev) > 0.85).float()
+
+    def tstep():
+        opt.zero_grad(set_to_none=True)
+        loss, _ = bce_dice_loss(m(x), y)
+        loss.backward()
+        opt.step()
+        return loss
+
+    steps = max(1, min(args.steps, 10))
+    for _ in range(4):
+        tstep()
+    quiesce_gc()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tstep()
+    torch.cuda.synchronize()
+    dt_train = (time.perf_counter() - t0) / steps
+    m.eval()
+    with torch.no_grad():
+        for _ in range(3):
+            m(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m(x)
+        torch.cuda.synchronize()
+        dt_inf = (time.perf_counter() - t0) / steps
+    vox = batch * patch[0] * patch[1] * patch[2]
+    del opt, m
+    torch.cuda.empty_cache()
+    return {"model": "RSUNet width [16,32,64,128], BatchNorm, relu", "batch": batch, "patch": list(patch), "dtype": "bf16 activations, fp32 master weights",
+            "train_ms_per_step": dt_train * 1e3, "train_voxels_per_s": vox / dt_train, "infer_ms_per_forward": dt_inf * 1e3,
+            "infer_voxels_per_s": vox / dt_inf, "final_loss": float(loss.detach())}
+
+
 def pmc_traffic_bytes(label):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/r01_bench_hbm_counters.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs by
@@ -266,6 +317,10 @@ def main():
     if not args.no_train:
         train = train_leg(dev, rank, world, args, barrier)
 
+    rsu = None
+    if rank == 0 and world == 1 and not args.no_train:
+        rsu = rsunet_leg(dev, args)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(model)
@@ -281,7 +336,7 @@ def main():
                                    "sw_batch_size 8, random-init weights; value = window-voxels/s",
                        "volume": list(VOLUME), "roi": list(ROI), "sw_batch_size": SW_BATCH,
                        "sharding": "one independent volume per rank, no collective"},
-            "roofline": roofline, "cpu_baseline": cpu, "train": train,
+            "roofline": roofline, "cpu_baseline": cpu, "train": train, "rsunet": rsu,
         }
         print(json.dumps(out))
     if world > 1:
