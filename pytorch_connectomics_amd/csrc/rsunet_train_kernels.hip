@@ -149,11 +149,15 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
   if (RAG_O || RAG_K) {                 // zero the padded channels once; the gather only rewrites the real ones
     for (int i = lane; i < WAVE_BYTES / 16; i += 64) reinterpret_cast<uint4*>(lg)[i] = zero4;
   }
-  auto fetch = [&](long u) {
-    const int xs = (int)(u % nseg);
-    const long line = u / nseg;
-    const int y = (int)(line % g.H);
-    const int z = (int)((line / g.H) % g.D);
+  // unit u -> (column, y) with y fastest: a wave walks DOWN a column of x segments, so of the KP A lines of a unit only the
+  // newest is loaded (the others already sit in the LDS ring from the previous unit); full = first unit of a run / column
+  auto fetch = [&](long u, bool full) {
+    const int y = (int)(u % g.H);
+    const long col = u / g.H;
+    const int xs = (int)(col % nseg);
+    const long nz = col / nseg;                     // n * D + z
+    const int z = (int)(nz % g.D);
+    const long line = nz * g.H + y;
     const int x0 = xs * 32;
     if (RAG_O) {                        // element e = j*64 + lane of the segment's 32 x C_out values
       const unsigned short* dyl = reinterpret_cast<const unsigned short*>(dy) + line * g.W * (long)C_out;
@@ -176,6 +180,7 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
     const int sz = z + dz;
 #pragma unroll
     for (int l = 0; l < KP; ++l) {
+      if (!full && l != KP - 1) continue;
       const int sy = y + l - PAD;
       const bool ok = sz >= 0 && sz < g.D && sy >= 0 && sy < g.H;         // wave-uniform
       if (RAG_K) {
@@ -201,7 +206,8 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
       }
     }
   };
-  auto stage = [&]() {
+  auto ring = [&](int y, int l) { return (y + l - PAD + KP) % KP; };       // LDS slot of line y + l - PAD
+  auto stage = [&](int y, bool full) {
     if (RAG_O) {
       const u16x8 v = __builtin_bit_cast(u16x8, rg[0]);
 #pragma unroll
@@ -216,20 +222,22 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
     }
 #pragma unroll
     for (int l = 0; l < KP; ++l) {
+      if (!full && l != KP - 1) continue;
+      const int sl = ring(y, l);
       if (RAG_K) {
         const u16x8 v = __builtin_bit_cast(u16x8, ra[l][0]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int e = j * 64 + lane;
           const int row = e / C_in, col = e % C_in;
-          if (row < AR) *reinterpret_cast<unsigned short*>(la + (l * AR + row) * SX + col * 2) = v[j];
+          if (row < AR) *reinterpret_cast<unsigned short*>(la + (sl * AR + row) * SX + col * 2) = v[j];
         }
       } else {
 #pragma unroll
         for (int it = 0; it < ITA; ++it) {
           const int c = it * 64 + lane;
           const int row = c / CHX, chunk = c % CHX;
-          if (row < AR) *reinterpret_cast<uint4*>(la + (l * AR + row) * SX + chunk * 16) = ra[l][it];
+          if (row < AR) *reinterpret_cast<uint4*>(la + (sl * AR + row) * SX + chunk * 16) = ra[l][it];
         }
       }
     }
@@ -251,11 +259,16 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[tp][m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  long u = u_begin + wave;
-  if (u < u_end) fetch(u);
-  for (; u < u_end; u += 4) {
-    stage();
-    if (u + 4 < u_end) fetch(u + 4);
+  // the slot's units in four contiguous runs, one per wave
+  const long quarter = (u_end - u_begin + 3) / 4;
+  const long w_begin = u_begin + wave * quarter;
+  const long w_end = w_begin + quarter < u_end ? w_begin + quarter : u_end;
+  long u = w_begin;
+  if (u < w_end) fetch(u, true);
+  for (; u < w_end; ++u) {
+    const int y = (int)(u % g.H);
+    stage(y, u == w_begin || y == 0);
+    if (u + 1 < w_end) fetch(u + 1, ((u + 1) % g.H) == 0);
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
     bf16x8_t fa[MT];
@@ -266,8 +279,9 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
 #pragma unroll
       for (int dx = 0; dx < KP; ++dx) {
         bf16x8_t fb[NT];
+        const int sl = ring(y, l);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) fb[n] = frag(la, SX, l * AR + dx, n);
+        for (int n = 0; n < NT; ++n) fb[n] = frag(la, SX, sl * AR + dx, n);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -506,8 +520,8 @@ static CwPlan cw_plan(int N, int D, int H, int W, int C_in, int C_out, const int
     p.nt = (!p.rag_k && C_in % 32 == 0) ? 2 : 1;
     p.tiles = (p.rag_o ? 1 : C_out / (p.mt * 16)) * (p.rag_k ? 1 : C_in / (p.nt * 16));
     const long units = (long)N * D * H * ((W + 31) / 32);
-    long s = 4096 / ((long)p.tiles * k[0]);            // ~4096 workgroups in flight over the launch
-    if (s > units / 8) s = units / 8;                  // >= 2 units per wave
+    long s = 1536 / ((long)p.tiles * k[0]);            // ~1536 workgroups over the launch (6 per CU)
+    if (s > units / 16) s = units / 16;                // >= 4 consecutive units per wave: the line ring needs a run to pay off
     s = (s / 8) * 8;
     p.slots = (int)(s < 8 ? 8 : (s > 512 ? 512 : s));
     p.per_slot = (units + p.slots - 1) / p.slots;
