@@ -262,6 +262,9 @@ int pytc_pw_mlp_fwd(const pytc_mlp_args* a, void* stream);
  * head_y [N][rows][n_head] fp32; head_w = the bf16 MFMA A-fragment image of the head [64 lanes][8]: lane (r, kb) holds
  * head[o = r][c = kb*8 .. kb*8+7] (zero rows for r >= n_head).  C_out must be 32 (pytc_pw_mlp_head_supported), residual
  * NONE or ADD.  store_y = 0 skips the 64 B / voxel block output (a->y may then be NULL). */
+/* Training forward of the mixer: pytc_pw_mlp_fwd that also stores the hidden pre-activation W2*(a*t+b)+b2 as bf16
+ * [N][rows][C_hid] (the GELU input the backward kernels differentiate); GELU is evaluated at that stored value. */
+int pytc_pw_mlp_train_fwd(const pytc_mlp_args* a, void* hidden_pre, void* stream);
 int pytc_pw_mlp_head_supported(int C_in, int C_hid, int C_out);
 /* The first block of the network (stem fused away, see pytc_stem_dwconv3d_fwd): the mixer's residual is the stem output
  * recomputed from the 1-channel input, res[c] = bf16(stem_w[c] * stem_x[voxel] + stem_b[c]); C_in = C_out = 32. */

@@ -34,6 +34,8 @@ struct MlpParams {
   const float* stem_x;     // [N][rps] fp32
   const float* stem_w;
   const float* stem_b;
+  // STOREH kernels (training forward): the pre-activation of the hidden layer is also written, [N][rps][C_hid] bf16
+  bf16_t* hp;
 };
 
 // GELU by table: the mixer is VALU bound on its activation (SQ counters of 64->128->32: 70 % VALU busy, v_exp_f32 and
@@ -63,7 +65,10 @@ constexpr int mlp_waves_per_simd(int ks, int mo, int nt) {
 // rounded to bf16 exactly as the un-fused path stores it, is itself the B fragment of one more 16x16x32 MFMA against the head
 // weights (rows beyond n_head are zero), whose result lanes write the fp32 logits; the 64 B / voxel of
 // block output are not written at all when nothing else reads them (store_y = 0).
-template <int KS_IN, int MO, int NT, int GELU_MODE, bool HEAD = false, bool STEMRES = false>
+// STOREH: training forward -- the same kernel also stores the hidden pre-activation (GEMM1 + bias, bf16) that the backward
+// pass needs (GELU' and the weight gradient of the projection), so the two-GEMM training forward is one launch and the
+// hidden tensor is written once and not read back in the forward.
+template <int KS_IN, int MO, int NT, int GELU_MODE, bool HEAD = false, bool STEMRES = false, bool STOREH = false>
 __global__ void __launch_bounds__(256, mlp_waves_per_simd(KS_IN, MO, NT))
 pw_mlp_kernel(MlpParams p) {
   static_assert(MO % 2 == 0, "C_out must be a multiple of 32");
@@ -192,6 +197,18 @@ pw_mlp_kernel(MlpParams p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       float g[8];
+      if constexpr (STOREH) {
+        // the backward pass evaluates GELU' and GELU at the STORED (bf16) pre-activation: use the same value here
+        float pre[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pre[j] = acc1[0][nt][j]; pre[4 + j] = acc1[1][nt][j]; }
+        const bf16x8_t hb = Mma<bf16_t>::from_floats(pre);
+        if (orow[nt] < p.rps)
+          *reinterpret_cast<bf16x8_t*>(p.hp + ((long)n * p.rps + orow[nt]) * p.C_hid + hc * 32 + kb * 8) = hb;
+        const f32x8_t hr = __builtin_convertvector(hb, f32x8_t);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc1[0][nt][j] = hr[j]; acc1[1][nt][j] = hr[4 + j]; }
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         g[j] = GELU_MODE == 2 ? gelu_lut(lut, acc1[0][nt][j]) : (GELU_MODE == 1 ? gelu_fast(acc1[0][nt][j]) : gelu_erf(acc1[0][nt][j]));
@@ -303,6 +320,10 @@ template <int KS_IN, int MO, int NT>
 static void launch_mlp(const MlpParams& p, int N, hipStream_t s) {
   long rows_per_block = 4L * NT * 16;
   dim3 grid((unsigned)((p.rps + rows_per_block - 1) / rows_per_block), (unsigned)N), block(256);
+  if (p.hp) {       // training forward: fast GELU (what the backward kernels differentiate), hidden pre-activation stored
+    hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT, 1, false, false, true>), grid, block, 0, s, p);
+    return;
+  }
   if (tuning_get("mlp_exact_gelu", 0))
     hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT, 0>), grid, block, 0, s, p);
   else if (tuning_get("mlp_gelu_lut", 0) && ensure_gelu_lut())
@@ -427,7 +448,16 @@ extern "C" int pytc_pw_mlp_stemres_fwd(const pytc_mlp_args* a, const float* stem
   return PYTC_OK;
 }
 
-extern "C" int pytc_pw_mlp_fwd(const pytc_mlp_args* a, void* stream) {
+static int mlp_fwd_impl(const pytc_mlp_args* a, void* hp, void* stream);
+
+extern "C" int pytc_pw_mlp_train_fwd(const pytc_mlp_args* a, void* hidden_pre, void* stream) {
+  PYTC_REQUIRE(hidden_pre, "pw_mlp_train: null hidden buffer");
+  return mlp_fwd_impl(a, hidden_pre, stream);
+}
+
+extern "C" int pytc_pw_mlp_fwd(const pytc_mlp_args* a, void* stream) { return mlp_fwd_impl(a, nullptr, stream); }
+
+static int mlp_fwd_impl(const pytc_mlp_args* a, void* hp, void* stream) {
   PYTC_REQUIRE(a && a->t && a->ab && a->w2_packed && a->w3_packed && a->b2 && a->b3 && a->y, "pw_mlp: null pointer");
   PYTC_REQUIRE(a->N >= 1 && a->rows_per_sample >= 1, "pw_mlp: bad shape");
   if (!mlp_shape_ok(a->C_in, a->C_hid, a->C_out)) {
@@ -444,6 +474,7 @@ extern "C" int pytc_pw_mlp_fwd(const pytc_mlp_args* a, void* stream) {
   p.e.res = a->res; p.e.res_low = a->res_low; p.e.res_bias = a->res_bias; p.e.y = a->y;
   p.e.rps_out = a->rows_per_sample; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode;
   p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
+  p.hp = (bf16_t*)hp;
   if (a->res_mode == PYTC_RES_UPSAMPLE) {
     PYTC_REQUIRE((long)a->Di * a->Hi * a->Wi == a->rows_per_sample && !(a->Di & 1) && !(a->Hi & 1) && !(a->Wi & 1),
                  "pw_mlp: RES_UPSAMPLE needs the (even) output grid");

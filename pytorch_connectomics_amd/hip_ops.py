@@ -341,8 +341,9 @@ def pw_mlp(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.Tenso
            b3: torch.Tensor, *, N: int, rows_per_sample: int, c_in: int, c_hid: int, c_out: int,
            res: Optional[torch.Tensor] = None, res_mode: int = nat.RES_NONE, grid: Sequence[int] = (0, 0, 0),
            res_low: Optional[torch.Tensor] = None, res_bias: Optional[torch.Tensor] = None,
-           y: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Fused norm-apply -> 1x1 expand -> GELU -> 1x1 project (+residual) on bf16 NDHWC rows."""
+           y: Optional[torch.Tensor] = None, hidden_pre: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused norm-apply -> 1x1 expand -> GELU -> 1x1 project (+residual) on bf16 NDHWC rows.  hidden_pre (N, rows, c_hid)
+    bf16: training forward, the hidden pre-activation is stored there as well."""
     _dev(t, "t")
     if t.dtype != torch.bfloat16:
         raise TypeError("pw_mlp runs on bfloat16 activations")
@@ -358,6 +359,11 @@ def pw_mlp(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.Tenso
     a.N, a.rows_per_sample, a.C_in, a.C_hid, a.C_out, a.res_mode = N, rows_per_sample, c_in, c_hid, c_out, res_mode
     a.Di, a.Hi, a.Wi = (int(v) for v in grid)
     nb = N * rows_per_sample * 2 * (c_in + c_out + (c_out if res is not None else 0))
+    if hidden_pre is not None:
+        _dev(hidden_pre, "hidden_pre")
+        _run(f"pw_mlp_train_fwd[{c_in}->{c_hid}->{c_out}]", nb + N * rows_per_sample * 2 * c_hid, nat.lib().pytc_pw_mlp_train_fwd,
+             C.byref(a), _p(hidden_pre), _stream())
+        return y
     _run(f"pw_mlp_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_fwd, C.byref(a), _stream())
     return y
 

@@ -22,6 +22,11 @@ from .. import _native as nat
 from .. import hip_ops as ops
 
 
+# training forward of a block's channel mixer as ONE fused launch that also stores the hidden pre-activation
+# (pytc_pw_mlp_train_fwd); False: two GEMM launches (expand, then project with the GELU in its operand prologue)
+FUSED_TRAIN_MIXER = True
+
+
 def _taps(w: torch.Tensor):
     c, k = w.shape[0], w.shape[-1]
     return w.detach().float().reshape(c, k ** 3).t().contiguous(), k
@@ -109,24 +114,43 @@ class BlockFn(torch.autograd.Function):
         ab, mr = ops.groupnorm_finalize_mr(st, count, _f(gamma), _f(beta), eps)
         rows = _rows(t)
         c_hid, c_out = w2.shape[0], w3.shape[0]
-        hp = _pw(t, _mat(w2), _f(b2), c_out=c_hid, ab=ab, rows=rows)              # pre-activation (saved)
+        fused = (dt == torch.bfloat16 and b2 is not None and b3 is not None and ops.pw_mlp_supported(C, c_hid, c_out)
+                 and FUSED_TRAIN_MIXER)
+        if fused:
+            # one launch: norm affine -> expand -> (store pre-activation hp) -> GELU -> project -> residual epilogue
+            hp = torch.empty((N, rows, c_hid), dtype=dt, device=x.device)
+            w2p, w3p = ops.pw_pack_weight_paired(_mat(w2)), ops.pw_pack_weight_paired(_mat(w3))
+            mk = dict(N=N, rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out, hidden_pre=hp)
+        else:
+            hp = _pw(t, _mat(w2), _f(b2), c_out=c_hid, ab=ab, rows=rows)              # pre-activation (saved)
         h, G = hp, dict(pre_act=nat.ACT_GELU)       # GELU runs in the operand prologue of the projecting GEMM
         res_low = None
         if kind == "block":
-            y = _pw(h, _mat(w3), _f(b3), c_out=c_out, rows=rows, res=x if do_res else None,
-                    res_mode=nat.RES_ADD if do_res else nat.RES_NONE, **G)
+            if fused:
+                y = ops.pw_mlp(t, ab, w2p, _f(b2), w3p, _f(b3), res=x if do_res else None,
+                               res_mode=nat.RES_ADD if do_res else nat.RES_NONE, **mk)
+            else:
+                y = _pw(h, _mat(w3), _f(b3), c_out=c_out, rows=rows, res=x if do_res else None,
+                        res_mode=nat.RES_ADD if do_res else nat.RES_NONE, **G)
         elif kind == "down":
             r = None
             if wres is not None:
                 r = _pw(x, _mat(wres), _f(bres), c_out=c_out, rows=rows, gather=2, grid=(D, H, W))
-            y = _pw(h, _mat(w3), _f(b3), c_out=c_out, rows=rows, res=r,
-                    res_mode=nat.RES_ADD if r is not None else nat.RES_NONE, **G)
+            if fused:
+                y = ops.pw_mlp(t, ab, w2p, _f(b2), w3p, _f(b3), res=r, res_mode=nat.RES_ADD if r is not None else nat.RES_NONE, **mk)
+            else:
+                y = _pw(h, _mat(w3), _f(b3), c_out=c_out, rows=rows, res=r,
+                        res_mode=nat.RES_ADD if r is not None else nat.RES_NONE, **G)
         else:
             if wres is not None:
                 res_low = _pw(x, _mat(wres), _f(bres), c_out=c_out, transposed=True)
             sk = skip if skip is not None else torch.zeros((N,) + tuple(t.shape[1:4]) + (c_out,), dtype=dt, device=x.device)
-            y = _pw(h, _mat(w3), _f(b3), c_out=c_out, rows=rows, res=sk, res_mode=nat.RES_UPSAMPLE,
-                    grid=tuple(t.shape[1:4]), res_low=res_low, res_bias=_f(bres) if wres is not None else None, **G)
+            if fused:
+                y = ops.pw_mlp(t, ab, w2p, _f(b2), w3p, _f(b3), res=sk, res_mode=nat.RES_UPSAMPLE, grid=tuple(t.shape[1:4]),
+                               res_low=res_low, res_bias=_f(bres) if wres is not None else None, **mk)
+            else:
+                y = _pw(h, _mat(w3), _f(b3), c_out=c_out, rows=rows, res=sk, res_mode=nat.RES_UPSAMPLE,
+                        grid=tuple(t.shape[1:4]), res_low=res_low, res_bias=_f(bres) if wres is not None else None, **G)
         ctx.save_for_backward(x, t, ab, mr, hp, w1, gamma, w2, w3, wres if wres is not None else x.new_zeros(0))
         ctx.meta = (kind, do_res, K, count, wres is not None, skip is not None, b1 is not None, bres is not None)
         return y.view(N, *t.shape[1:4], c_out)
