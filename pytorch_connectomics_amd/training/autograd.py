@@ -153,6 +153,7 @@ class BlockFn(torch.autograd.Function):
                         grid=tuple(t.shape[1:4]), res_low=res_low, res_bias=_f(bres) if wres is not None else None, **G)
         ctx.save_for_backward(x, t, ab, mr, hp, w1, gamma, w2, w3, wres if wres is not None else x.new_zeros(0))
         ctx.meta = (kind, do_res, K, count, wres is not None, skip is not None, b1 is not None, bres is not None)
+        ctx.taps = taps                  # derived from w1 (no gradient flows through it): reused by the backward
         return y.view(N, *t.shape[1:4], c_out)
 
     @staticmethod
@@ -163,7 +164,7 @@ class BlockFn(torch.autograd.Function):
         dy = dy.contiguous()
         rows = _rows(t)
         c_hid, c_out = w2.shape[0], w3.shape[0]
-        taps, _ = _taps(w1)
+        taps = ctx.taps
         dskip = dy if (kind == "up" and has_skip) else None
         dcore = dy
         if kind == "up":
@@ -181,7 +182,8 @@ class BlockFn(torch.autograd.Function):
         del dhp
         # ---- GroupNorm(C, C)
         dt_, s = ops.norm_bwd(dtn, t, mr, _f(gamma), count=count)
-        dgamma, dbeta = s[:, 1].sum(0), s[:, 0].sum(0)
+        ssum = s.sum(0)                  # (2, C): one reduction for both vectors
+        dgamma, dbeta = ssum[1], ssum[0]
         del dtn
         # ---- depthwise conv
         dwres = dbres = None
