@@ -195,6 +195,9 @@ class FusedAdamW(torch.optim.Optimizer):
         self.last_grad_norm = self._norm_coef[0]
         nat.check(lib.pytc_adamw_multi(_p(self._tab), _p(self._chunks), self._nc, groups, len(gtab), _p(self._norm_coef),
                                        _stream()), "adamw_multi")
+        # the kernel wrote the parameters through raw pointers: tell autograd / every (data_ptr, _version)-keyed cache
+        # (the models' repacked-weight caches) that their contents changed
+        torch.autograd.graph.increment_version([it[0] for it in items])
         return loss
 
     def state_dict(self):

@@ -57,6 +57,8 @@ class NormActFn(torch.autograd.Function):
                         bn.num_batches_tracked += 1
                         mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
                         ops.bn_update_running(mr1, bn.running_mean, bn.running_var, float(N * rows), eps, mom)
+                        # written through raw pointers: bump the version counters the eval-mode affine cache keys on
+                        torch.autograd.graph.increment_version([bn.running_mean, bn.running_var])
             else:
                 a = gamma.detach().float() / torch.sqrt(bn.running_var.float() + eps)
                 b = beta.detach().float() - bn.running_mean.float() * a

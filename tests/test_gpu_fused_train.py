@@ -72,6 +72,7 @@ def test_fused_adamw_matches_torch_adamw_with_clip_and_ema():
             torch.testing.assert_close(p, q, rtol=2e-5, atol=2e-6)
     for p, e in zip(pa, ema):
         torch.testing.assert_close(fa.ema[p], e, rtol=2e-5, atol=2e-6)
+    assert all(p._version > 0 for p in pa)          # raw-pointer updates still bump the version counters (weight caches)
     # optimizer state interchanges with torch.optim.AdamW
     sd = fa.state_dict()
     assert float(sd["state"][0]["step"]) == 6.0

@@ -301,3 +301,24 @@ def test_rsunet_training_step_matches_reference_fixture(name):
             torch.testing.assert_close(b.cpu(), ref, rtol=1e-4, atol=1e-6)
         else:
             assert torch.equal(b.cpu(), ref), n
+
+
+def test_rsunet_eval_after_training_uses_updated_batchnorm_buffers():
+    """Eval-mode BatchNorm affines are cached per (buffer, version); the training kernels update the running buffers
+    through raw pointers and must invalidate that cache."""
+    from pytorch_connectomics_amd.models.architectures.rsunet import RSUNet
+    torch.manual_seed(9)
+    m = RSUNet(1, 1, width=[8, 16], norm="batch", activation="relu").cuda()
+    x = torch.randn(2, 1, 8, 16, 16, device="cuda") * 3 + 1
+    with torch.no_grad():
+        before = m.eval()(x).clone()
+    m.train()
+    for _ in range(3):
+        m.zero_grad()
+        m(x).mean().backward()
+    with torch.no_grad():
+        after = m.eval()(x)
+        m._hip.cache.clear()
+        fresh = m(x)
+    assert float((after - before).abs().max()) > 1e-4
+    assert torch.equal(after, fresh)

@@ -376,3 +376,29 @@ def test_fused_training_mixer_matches_two_gemm_forward():
     assert abs(res[True][0] - res[False][0]) < 2e-2 * abs(res[False][0])
     g1, g0 = res[True][1], res[False][1]
     assert float((g1 * g0).sum() / (g1.norm() * g0.norm())) > 0.995
+
+
+def test_inference_after_fused_optimizer_steps_sees_new_weights():
+    """The repacked-weight caches of the inference path are keyed by (data_ptr, _version); FusedAdamW writes through raw
+    pointers and must bump the versions, else an eval forward after training would run on stale packed weights."""
+    from pytorch_connectomics_amd.models.architectures.mednext import MedNeXt
+    from pytorch_connectomics_amd.training.fused import FusedAdamW
+    torch.manual_seed(3)
+    m = MedNeXt(1, 32, 1, exp_r=2, kernel_size=3, do_res=True, do_res_up_down=True, block_counts=[1] * 9).cuda()
+    m.compute_dtype = torch.bfloat16
+    x = torch.rand(1, 1, 32, 32, 32, device="cuda")
+    y = (torch.rand(1, 1, 32, 32, 32, device="cuda") > 0.8).float()
+    with torch.no_grad():
+        before = m.eval()(x).clone()                 # fills the inference caches
+    opt = FusedAdamW(m.parameters(), lr=5e-2)
+    m.train()
+    for _ in range(3):
+        opt.zero_grad()
+        F.binary_cross_entropy_with_logits(m(x), y).backward()
+        opt.step()
+    with torch.no_grad():
+        after = m.eval()(x)
+        m._hip.cache.clear()
+        fresh = m(x)
+    assert float((after - before).abs().max()) > 1e-3          # the weights moved
+    assert torch.equal(after, fresh)                            # ... and the cached path saw them
