@@ -265,6 +265,11 @@ int pytc_pw_mlp_fwd(const pytc_mlp_args* a, void* stream);
 /* Training forward of the mixer: pytc_pw_mlp_fwd that also stores the hidden pre-activation W2*(a*t+b)+b2 as bf16
  * [N][rows][C_hid] (the GELU input the backward kernels differentiate); GELU is evaluated at that stored value. */
 int pytc_pw_mlp_train_fwd(const pytc_mlp_args* a, void* hidden_pre, void* stream);
+/* Training backward of the mixer's data path in one launch: dX = W2^T ((W3^T dY) * GELU'(hidden_pre)); a->t = dY,
+ * a->w2_packed = paired image of W3^T (C_out_fwd -> C_hid), a->w3_packed = paired image of W2^T (C_hid -> C_in_fwd),
+ * a->ab = identity affine [N][2][C], a->b2 / a->b3 = zero vectors, a->res_mode = NONE, a->y = dX; d_hidden
+ * [N][rows][C_hid] bf16 receives the intermediate (the operand of the expanding conv's weight gradient). */
+int pytc_pw_mlp_bwd(const pytc_mlp_args* a, const void* hidden_pre, void* d_hidden, void* stream);
 int pytc_pw_mlp_head_supported(int C_in, int C_hid, int C_out);
 /* The first block of the network (stem fused away, see pytc_stem_dwconv3d_fwd): the mixer's residual is the stem output
  * recomputed from the 1-channel input, res[c] = bf16(stem_w[c] * stem_x[voxel] + stem_b[c]); C_in = C_out = 32. */

@@ -36,6 +36,9 @@ struct MlpParams {
   const float* stem_b;
   // STOREH kernels (training forward): the pre-activation of the hidden layer is also written, [N][rps][C_hid] bf16
   bf16_t* hp;
+  // BWD kernels (training backward, data gradients of both GEMMs in one launch): the "activation" between the GEMMs is
+  // the multiplication by GELU'(hp_in), and hp receives the product (d loss / d pre-activation) for the weight gradient
+  const bf16_t* hp_in;
 };
 
 // GELU by table: the mixer is VALU bound on its activation (SQ counters of 64->128->32: 70 % VALU busy, v_exp_f32 and
@@ -68,7 +71,10 @@ constexpr int mlp_waves_per_simd(int ks, int mo, int nt) {
 // STOREH: training forward -- the same kernel also stores the hidden pre-activation (GEMM1 + bias, bf16) that the backward
 // pass needs (GELU' and the weight gradient of the projection), so the two-GEMM training forward is one launch and the
 // hidden tensor is written once and not read back in the forward.
-template <int KS_IN, int MO, int NT, int GELU_MODE, bool HEAD = false, bool STEMRES = false, bool STOREH = false>
+// BWD: dX = W2^T ((W3^T dY) * GELU'(hp)) -- the two data-gradient GEMMs of a block's mixer with the derivative of the
+// activation between them: t := dY, w2 := W3^T, w3 := W2^T, no affine, no biases, no residual; the intermediate
+// (d loss / d hp, bf16) is stored to p.hp for the weight gradient of the expanding conv.
+template <int KS_IN, int MO, int NT, int GELU_MODE, bool HEAD = false, bool STEMRES = false, bool STOREH = false, bool BWD = false>
 __global__ void __launch_bounds__(256, mlp_waves_per_simd(KS_IN, MO, NT))
 pw_mlp_kernel(MlpParams p) {
   static_assert(MO % 2 == 0, "C_out must be a multiple of 32");
@@ -197,6 +203,20 @@ pw_mlp_kernel(MlpParams p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       float g[8];
+      if constexpr (BWD) {
+        const long rr = orow[nt] < p.rps ? orow[nt] : p.rps - 1;
+        float hv[8];
+        VecIO<bf16_t, 8>::load(p.hp_in + ((long)n * p.rps + rr) * p.C_hid + hc * 32 + kb * 8, hv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          g[j] = acc1[0][nt][j] * gelu_erf_grad(hv[j]);
+          g[4 + j] = acc1[1][nt][j] * gelu_erf_grad(hv[4 + j]);
+        }
+        bh[nt] = Mma<bf16_t>::from_floats(g);
+        if (orow[nt] < p.rps)
+          *reinterpret_cast<bf16x8_t*>(p.hp + ((long)n * p.rps + orow[nt]) * p.C_hid + hc * 32 + kb * 8) = bh[nt];
+        continue;
+      }
       if constexpr (STOREH) {
         // the backward pass evaluates GELU' and GELU at the STORED (bf16) pre-activation: use the same value here
         float pre[8];
@@ -320,6 +340,10 @@ template <int KS_IN, int MO, int NT>
 static void launch_mlp(const MlpParams& p, int N, hipStream_t s) {
   long rows_per_block = 4L * NT * 16;
   dim3 grid((unsigned)((p.rps + rows_per_block - 1) / rows_per_block), (unsigned)N), block(256);
+  if (p.hp_in) {    // training backward: both data-gradient GEMMs with GELU' between them
+    hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT, 1, false, false, false, true>), grid, block, 0, s, p);
+    return;
+  }
   if (p.hp) {       // training forward: fast GELU (what the backward kernels differentiate), hidden pre-activation stored
     hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT, 1, false, false, true>), grid, block, 0, s, p);
     return;
@@ -448,7 +472,16 @@ extern "C" int pytc_pw_mlp_stemres_fwd(const pytc_mlp_args* a, const float* stem
   return PYTC_OK;
 }
 
-static int mlp_fwd_impl(const pytc_mlp_args* a, void* hp, void* stream);
+static int mlp_fwd_impl(const pytc_mlp_args* a, void* hp, void* stream, const void* hp_in = nullptr);
+
+// a->t = dY [N][rows][C_in], a->w2_packed = W3^T image (C_in -> C_hid), a->w3_packed = W2^T image (C_hid -> C_out),
+// a->ab = identity affine, a->b2 / a->b3 = zeros, a->y = dX; hidden_pre = the forward's stored pre-activation,
+// d_hidden receives (W3^T dY) * GELU'(hidden_pre)
+extern "C" int pytc_pw_mlp_bwd(const pytc_mlp_args* a, const void* hidden_pre, void* d_hidden, void* stream) {
+  PYTC_REQUIRE(hidden_pre && d_hidden, "pw_mlp_bwd: null hidden buffers");
+  PYTC_REQUIRE(a && a->res_mode == PYTC_RES_NONE, "pw_mlp_bwd: no residual in the backward mixer");
+  return mlp_fwd_impl(a, d_hidden, stream, hidden_pre);
+}
 
 extern "C" int pytc_pw_mlp_train_fwd(const pytc_mlp_args* a, void* hidden_pre, void* stream) {
   PYTC_REQUIRE(hidden_pre, "pw_mlp_train: null hidden buffer");
@@ -457,7 +490,7 @@ extern "C" int pytc_pw_mlp_train_fwd(const pytc_mlp_args* a, void* hidden_pre, v
 
 extern "C" int pytc_pw_mlp_fwd(const pytc_mlp_args* a, void* stream) { return mlp_fwd_impl(a, nullptr, stream); }
 
-static int mlp_fwd_impl(const pytc_mlp_args* a, void* hp, void* stream) {
+static int mlp_fwd_impl(const pytc_mlp_args* a, void* hp, void* stream, const void* hp_in) {
   PYTC_REQUIRE(a && a->t && a->ab && a->w2_packed && a->w3_packed && a->b2 && a->b3 && a->y, "pw_mlp: null pointer");
   PYTC_REQUIRE(a->N >= 1 && a->rows_per_sample >= 1, "pw_mlp: bad shape");
   if (!mlp_shape_ok(a->C_in, a->C_hid, a->C_out)) {
@@ -475,6 +508,7 @@ static int mlp_fwd_impl(const pytc_mlp_args* a, void* hp, void* stream) {
   p.e.rps_out = a->rows_per_sample; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode;
   p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
   p.hp = (bf16_t*)hp;
+  p.hp_in = (const bf16_t*)hp_in;
   if (a->res_mode == PYTC_RES_UPSAMPLE) {
     PYTC_REQUIRE((long)a->Di * a->Hi * a->Wi == a->rows_per_sample && !(a->Di & 1) && !(a->Hi & 1) && !(a->Wi & 1),
                  "pw_mlp: RES_UPSAMPLE needs the (even) output grid");

@@ -417,6 +417,38 @@ def pw_mlp_stemres(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: tor
     return y
 
 
+_MLP_BWD_CONSTS: dict = {}
+
+
+def pw_mlp_bwd(dy: torch.Tensor, hidden_pre: torch.Tensor, w3t_p: torch.Tensor, w2t_p: torch.Tensor, *, N: int,
+               rows_per_sample: int, c_in: int, c_hid: int, c_out: int):
+    """Data gradients of a block's mixer in one launch.  dy (N, rows, c_out) bf16 -> (dx (N, rows, c_in), d_hidden
+    (N, rows, c_hid)); w3t_p / w2t_p = pw_pack_weight_paired(W3 / W2, transposed=True)."""
+    _dev(dy, "dy"); _dev(hidden_pre, "hidden_pre")
+    if dy.dtype != torch.bfloat16:
+        raise TypeError("pw_mlp_bwd runs on bfloat16 activations")
+    dev = dy.device
+    dx = torch.empty((N, rows_per_sample, c_in), dtype=torch.bfloat16, device=dev)
+    dh = torch.empty((N, rows_per_sample, c_hid), dtype=torch.bfloat16, device=dev)
+    key = (dev, N, c_in, c_hid, c_out)
+    consts = _MLP_BWD_CONSTS.get(key)
+    if consts is None:           # identity affine + zero biases: constants, made once per shape
+        consts = (torch.cat([torch.ones((N, 1, c_out), device=dev), torch.zeros((N, 1, c_out), device=dev)], 1).contiguous(),
+                  torch.zeros((c_hid,), device=dev), torch.zeros((c_in,), device=dev))
+        _MLP_BWD_CONSTS[key] = consts
+    ident, zh, zi = consts
+    a = nat.MlpArgs()
+    a.t, a.ab, a.w2_packed, a.b2, a.w3_packed, a.b3 = (dy.data_ptr(), ident.data_ptr(), w3t_p.data_ptr(), zh.data_ptr(),
+                                                       w2t_p.data_ptr(), zi.data_ptr())
+    a.res = a.res_low = a.res_bias = None
+    a.y = dx.data_ptr()
+    a.N, a.rows_per_sample, a.C_in, a.C_hid, a.C_out, a.res_mode = N, rows_per_sample, c_out, c_hid, c_in, nat.RES_NONE
+    a.Di = a.Hi = a.Wi = 0
+    nb = N * rows_per_sample * 2 * (c_out + 2 * c_hid + c_in)
+    _run(f"pw_mlp_bwd[{c_out}->{c_hid}->{c_in}]", nb, nat.lib().pytc_pw_mlp_bwd, C.byref(a), _p(hidden_pre), _p(dh), _stream())
+    return dx, dh
+
+
 def pw_mlp_head_supported(c_in: int, c_hid: int, c_out: int) -> bool:
     return bool(nat.lib().pytc_pw_mlp_head_supported(int(c_in), int(c_hid), int(c_out)))
 

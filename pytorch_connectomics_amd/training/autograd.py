@@ -25,6 +25,10 @@ from .. import hip_ops as ops
 # training forward of a block's channel mixer as ONE fused launch that also stores the hidden pre-activation
 # (pytc_pw_mlp_train_fwd); False: two GEMM launches (expand, then project with the GELU in its operand prologue)
 FUSED_TRAIN_MIXER = True
+# the two data-gradient GEMMs of the mixer as one launch (pytc_pw_mlp_bwd): bit-identical results and 25 % less traffic,
+# but measured slower than the two launches it replaces (503 vs ~440 us at 4x112^3, level 0: the exact GELU' between the
+# GEMMs sits on the MFMA critical path instead of in a store epilogue) -> off
+FUSED_TRAIN_MIXER_BWD = False
 
 
 def _taps(w: torch.Tensor):
@@ -174,11 +178,19 @@ class BlockFn(torch.autograd.Function):
             dcore[:, :, :, 0] = 0
         # ---- project: y = W3 h + b3
         dW3, db3 = ops.pw_wgrad(hp, dcore, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, x_act=nat.ACT_GELU)
-        # dhp = (W3^T dy) * gelu'(hp): the GELU derivative is the epilogue of the data-gradient GEMM
-        dhp = _pw(dcore, _mat(w3), None, c_out=c_hid, transposed=True, rows=rows, res=hp, res_mode=nat.RES_GELU_BWD)
-        # ---- expand: hp = W2 (a t + b) + b2
-        dW2, db2 = ops.pw_wgrad(t, dhp, N=N, rows_per_sample=rows, c_in=C, c_out=c_hid, ab=ab)
-        dtn = _pw(dhp, _mat(w2), None, c_out=C, transposed=True, rows=rows)
+        fused_bwd = (dy.dtype == torch.bfloat16 and FUSED_TRAIN_MIXER_BWD and ops.pw_mlp_supported(c_out, c_hid, C))
+        if fused_bwd:
+            # both data-gradient GEMMs in one launch: dtn = W2^T ((W3^T dy) * gelu'(hp)); dhp comes back for wgrad2
+            dtn, dhp = ops.pw_mlp_bwd(dcore.view(N, rows, c_out), hp, ops.pw_pack_weight_paired(_mat(w3), transposed=True),
+                                      ops.pw_pack_weight_paired(_mat(w2), transposed=True), N=N, rows_per_sample=rows,
+                                      c_in=C, c_hid=c_hid, c_out=c_out)
+            dW2, db2 = ops.pw_wgrad(t, dhp, N=N, rows_per_sample=rows, c_in=C, c_out=c_hid, ab=ab)
+        else:
+            # dhp = (W3^T dy) * gelu'(hp): the GELU derivative is the epilogue of the data-gradient GEMM
+            dhp = _pw(dcore, _mat(w3), None, c_out=c_hid, transposed=True, rows=rows, res=hp, res_mode=nat.RES_GELU_BWD)
+            # ---- expand: hp = W2 (a t + b) + b2
+            dW2, db2 = ops.pw_wgrad(t, dhp, N=N, rows_per_sample=rows, c_in=C, c_out=c_hid, ab=ab)
+            dtn = _pw(dhp, _mat(w2), None, c_out=C, transposed=True, rows=rows)
         del dhp
         # ---- GroupNorm(C, C)
         dt_, s = ops.norm_bwd(dtn, t, mr, _f(gamma), count=count)
