@@ -15,8 +15,6 @@
 namespace pytc {
 
 constexpr int SD_C = 32;          // channels (MedNeXt base width)
-constexpr int SD_IT = 4;          // voxel groups per lane
-constexpr int SD_GPB = 64 * SD_IT;   // voxel groups per workgroup (64 groups x 4 channel-group lanes = 256 lanes)
 
 struct StemDw { int D, H, W, GX; long groups; };   // GX = W / VX groups per x line, groups per sample
 
@@ -26,6 +24,10 @@ struct StemDw { int D, H, W, GX; long groups; };   // GX = W / VX groups per x l
 // 1-channel input comes from L1 as one 16-byte and two 4-byte loads per row.  (Earlier forms: one lane = one voxel x 32
 // channels with the taps in LDS was LDS-bound at 860 us -- 216 tap reads per voxel; with the taps as scalar operands it
 // waited on 54 s_load_dwordx16 per voxel, 781 us.)
+// Without the compiler barrier at the top of the group loop hipcc keeps the lane's 216 taps (8 channels x 27) in VGPRs
+// across the groups (256 VGPRs, 2 waves/SIMD, no LDS reads in the loop): 985 us against 436 us with the taps re-read from
+// LDS per group (122 VGPRs, 4 waves/SIMD).  SD_IT = groups per lane: 2 -> 542 us, 4 -> 436, 8 -> 433, 16 -> 444.
+constexpr int SD_IT = 4;
 template <int SD_VX>      // consecutive x voxels per lane (4: 406 us at 8x112^3; 8 halves the tap reads but drops to 2 waves/SIMD: 561 us)
 __global__ void __launch_bounds__(256)
 stem_dwconv_k3_kernel(const float* __restrict__ x, const float* __restrict__ wx, const float* __restrict__ wb,
@@ -49,7 +51,7 @@ stem_dwconv_k3_kernel(const float* __restrict__ x, const float* __restrict__ wx,
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
 
   for (int it = 0; it < SD_IT; ++it) {
-    asm volatile("" ::: "memory");                  // keep the tap reads of an iteration inside it (no hoisting + spills)
+    asm volatile("" ::: "memory");                  // keep the tap reads of an iteration inside it
     const long G = ((long)blockIdx.x * SD_IT + it) * 64 + (threadIdx.x >> 2);
     const bool live = G < g.groups;
     const long Gc = live ? G : g.groups - 1;
@@ -148,9 +150,12 @@ using namespace pytc;
 
 static int sd_vx(int) { return 4; }
 
+static int sd_it() { return SD_IT; }
+
 extern "C" int pytc_stem_dwconv3d_stat_slots(int D, int H, int W) {
   const long groups = (long)D * H * (W / sd_vx(W));
-  return (int)((groups + SD_GPB - 1) / SD_GPB);
+  const long gpb = 64L * sd_it();       // voxel groups per workgroup (64 groups x 4 channel-group lanes = 256 lanes)
+  return (int)((groups + gpb - 1) / gpb);
 }
 
 extern "C" int pytc_stem_dwconv3d_supported(int C_in, int C, int K) { return (C_in == 1 && C == SD_C && K == 3) ? 1 : 0; }
