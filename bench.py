@@ -145,7 +145,6 @@ def rsunet_leg(dev, args):
     """The path's second architecture, reported next to the headline (single GPU): RSUNet [16, 32, 64, 128], BatchNorm,
     anisotropic 2 x 18 x 160 x 160 patches, bf16 storage: training step (HIP forward + backward, fused loss, fused AdamW)
     and inference forward."""
-    import torch.nn.functional as F
     from pytorch_connectomics_amd.models.architectures.rsunet import RSUNet
     from pytorch_connectomics_amd.training.fused import FusedAdamW, bce_dice_loss
     from pytorch_connectomics_amd.utils.hostgc import quiesce_gc
@@ -247,7 +246,6 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from pytorch_connectomics_amd import _native as nat
     from pytorch_connectomics_amd import hip_ops as ops
     from pytorch_connectomics_amd.inference.window import EagerSlidingWindowEngine
 

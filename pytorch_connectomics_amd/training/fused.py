@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Dict, Iterable, Optional
+from typing import Dict, Optional
 
 import torch
 

@@ -12,7 +12,6 @@ device ops.
 from __future__ import annotations
 
 import math
-import os
 from typing import Any, Dict, Optional
 
 import torch

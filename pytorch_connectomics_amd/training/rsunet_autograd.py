@@ -12,10 +12,7 @@ statistics into group means are torch ops on tiny tensors.  Correctness-first ke
 """
 from __future__ import annotations
 
-from typing import Optional
-
 import torch
-import torch.nn as nn
 
 from .. import _native as nat
 from .. import hip_ops as ops
