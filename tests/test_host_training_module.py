@@ -143,3 +143,26 @@ def test_weighted_bce_matches_reference_fixture():
         assert abs(float(v) - float(z[f"{n}__loss"][0])) < 1e-6, n
         v.backward()
         assert torch.allclose(x.grad, torch.from_numpy(z[f"{n}__grad"]), atol=1e-8, rtol=1e-5), n
+
+
+def test_fused_epilogue_host_logic_and_no_cpu_path():
+    """training/fused.py without a GPU: the stride collapsing that lets the loss kernel read the channels-last network
+    output in place, and the loud failure on CPU tensors (there is no CPU path)."""
+    from pytorch_connectomics_amd.training.fused import FusedAdamW, _ncr_strides, bce_dice_loss
+    cl = torch.zeros(2, 5, 6, 7, 3).permute(0, 4, 1, 2, 3)            # NDHWC memory viewed as NCDHW
+    assert _ncr_strides(cl) == (5 * 6 * 7 * 3, 1, 3)
+    assert _ncr_strides(torch.zeros(2, 3, 5, 6, 7)) == (3 * 210, 210, 1)
+    assert _ncr_strides(cl[:, 1:3]) == (630, 1, 3)                     # a channel slice stays collapsible
+    assert _ncr_strides(torch.zeros(2, 3, 5, 6, 7)[:, :, :, ::2]) is None   # strided spatial dim: needs a copy
+    assert _ncr_strides(torch.zeros(2, 1, 5, 6, 7).expand(2, 3, 5, 6, 7)) == (210, 0, 1)   # broadcast mask
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        bce_dice_loss(torch.zeros(1, 1, 4, 4, 4), torch.zeros(1, 1, 4, 4, 4))
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        FusedAdamW([p]).step()
+    # build_optimizer falls back to torch.optim.AdamW for CPU parameters (the fused kernel needs device pointers)
+    cfg = _cfg()
+    cfg.optimization.optimizer.name = "AdamW"
+    opt = build_optimizer(cfg, SimpleModel())
+    assert type(opt).__name__ == "AdamW" and not isinstance(opt, FusedAdamW)
