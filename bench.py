@@ -317,7 +317,10 @@ def main():
 
     rsu = None
     if rank == 0 and world == 1 and not args.no_train:
-        rsu = rsunet_leg(dev, args)
+        try:                       # a secondary figure must never cost the headline line
+            rsu = rsunet_leg(dev, args)
+        except Exception as e:     # noqa: BLE001 - reported in the JSON
+            rsu = {"error": f"{type(e).__name__}: {e}"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
