@@ -14,6 +14,7 @@ struct DwGeom {
   int iters;      // passes per workgroup
   int slots;      // workgroups per sample
   int cell;       // transposed K=3: work items are 2x2x2 output cells (one per input voxel)
+  int xblock;     // K=5/7 stride 1: work items are groups of 4 consecutive x outputs
 };
 
 template <int VEC>
@@ -101,17 +102,20 @@ dwconv3d_direct_kernel(const T* __restrict__ x, T* __restrict__ y, const float* 
 // K = 3 gather form without branches (stride 1 or 2; the down blocks and the volumes too small for the z-march):
 // every tap is loaded from a clamped address (a branch around a load makes hipcc wait for each one separately) and an
 // out-of-range tap gets a zero weight instead; the 27 x C taps are staged once per workgroup in LDS.
-template <typename T, int VEC>
+template <typename T, int VEC, int K>
 __global__ void __launch_bounds__(256)
 dwconv3d_k3_gather_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ w,
                           const float* __restrict__ bias, float* __restrict__ stats, DwGeom g) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // 27*C taps, later the statistics scratch
+  // K = 3 keeps its 3x3 plane of inputs in registers; K = 5 / 7 go row by row (K vectors live) -- same clamped,
+  // branch-free loads and zero weights for the taps that fall outside
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // K^3*C taps, later the statistics scratch
+  constexpr int P = K / 2;
   const int n = blockIdx.y, slot = blockIdx.x;
   const int cv = threadIdx.x % g.lpv, vslot = threadIdx.x / g.lpv;
   const bool lane_ok = vslot < g.vs;
   const long vout = (long)g.Do * g.Ho * g.Wo;
   const int C = g.C;
-  for (int i = threadIdx.x; i < 27 * C; i += 256) lds[i] = w[i];
+  for (int i = threadIdx.x; i < K * K * K * C; i += 256) lds[i] = w[i];
   __syncthreads();
   float s1[VEC], s2[VEC], bv[VEC];
 #pragma unroll
@@ -125,35 +129,56 @@ dwconv3d_k3_gather_kernel(const T* __restrict__ x, T* __restrict__ y, const floa
     const int ox = (int)(v % g.Wo);
     const long t = v / g.Wo;
     const int oy = (int)(t % g.Ho), oz = (int)(t / g.Ho);
-    int zi[3], yi[3], xi[3];
-    bool zv[3], yv[3], xv[3];
+    int zi[K], yi[K], xi[K];
+    bool zv[K], yv[K], xv[K];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int iz = oz * g.stride - 1 + k, iy = oy * g.stride - 1 + k, ix = ox * g.stride - 1 + k;
+    for (int k = 0; k < K; ++k) {
+      const int iz = oz * g.stride - P + k, iy = oy * g.stride - P + k, ix = ox * g.stride - P + k;
       zv[k] = iz >= 0 && iz < g.D; yv[k] = iy >= 0 && iy < g.H; xv[k] = ix >= 0 && ix < g.W;
       zi[k] = min(max(iz, 0), g.D - 1); yi[k] = min(max(iy, 0), g.H - 1); xi[k] = min(max(ix, 0), g.W - 1);
     }
     float acc[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = bv[i];
+    if constexpr (K == 3) {
 #pragma unroll
-    for (int kz = 0; kz < 3; ++kz) {
-      float in[9][VEC];
+      for (int kz = 0; kz < 3; ++kz) {
+        float in[9][VEC];
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-          VecIO<T, VEC>::load(xn + (((long)zi[kz] * g.H + yi[ky]) * g.W + xi[kx]) * C, in[ky * 3 + kx]);
+          for (int kx = 0; kx < 3; ++kx)
+            VecIO<T, VEC>::load(xn + (((long)zi[kz] * g.H + yi[ky]) * g.W + xi[kx]) * C, in[ky * 3 + kx]);
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const bool ok = zv[kz] & yv[ky] & xv[kx];
-          float wv[VEC];
-          VecIO<float, VEC>::load(wl + ((kz * 3 + ky) * 3 + kx) * C, wv);
+          for (int kx = 0; kx < 3; ++kx) {
+            const bool ok = zv[kz] & yv[ky] & xv[kx];
+            float wv[VEC];
+            VecIO<float, VEC>::load(wl + ((kz * 3 + ky) * 3 + kx) * C, wv);
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(in[ky * 3 + kx][i], ok ? wv[i] : 0.f, acc[i]);
+            for (int i = 0; i < VEC; ++i) acc[i] = fmaf(in[ky * 3 + kx][i], ok ? wv[i] : 0.f, acc[i]);
+          }
+      }
+    } else {
+      for (int kz = 0; kz < K; ++kz) {
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          const T* row = xn + ((long)zi[kz] * g.H + yi[ky]) * g.W * C;
+          float in[K][VEC];
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) VecIO<T, VEC>::load(row + (long)xi[kx] * C, in[kx]);
+          const bool zy = zv[kz] & yv[ky];
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) {
+            const bool ok = zy & xv[kx];
+            float wv[VEC];
+            VecIO<float, VEC>::load(wl + ((kz * K + ky) * K + kx) * C, wv);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = fmaf(in[kx][i], ok ? wv[i] : 0.f, acc[i]);
+          }
         }
+      }
     }
     VecIO<T, VEC>::store(yn + v * C, acc);
 #pragma unroll
@@ -264,6 +289,88 @@ dwconvT3d_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __rest
   if (stats) block_stats_reduce<VEC>(s1, s2, cv, vslot, lane_ok, g, stats, n, slot, lds);
 }
 
+
+// K = 5 / 7, stride 1: one lane = XB consecutive x outputs of its VEC channels.  A (kz, ky) row of the stencil needs
+// XB + K - 1 input vectors for XB outputs (instead of XB * K) and every tap vector is read from LDS once per XB outputs:
+// the plain gather form spends its time issuing loads (125 / 343 per output).
+template <typename T, int VEC, int K, int XB>
+__global__ void __launch_bounds__(256)
+dwconv3d_xblock_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ w,
+                       const float* __restrict__ bias, float* __restrict__ stats, DwGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // K^3*C taps, later the statistics scratch
+  constexpr int P = K / 2, NI = XB + K - 1;
+  const int n = blockIdx.y, slot = blockIdx.x;
+  const int cv = threadIdx.x % g.lpv, vslot = threadIdx.x / g.lpv;
+  const bool lane_ok = vslot < g.vs;
+  const int C = g.C;
+  for (int i = threadIdx.x; i < K * K * K * C; i += 256) lds[i] = w[i];
+  __syncthreads();
+  float s1[VEC], s2[VEC], bv[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; bv[i] = bias ? bias[cv * VEC + i] : 0.f; }
+  const int GX = (g.W + XB - 1) / XB;
+  const long groups = (long)g.D * g.H * GX;
+  const T* xn = x + (long)n * g.D * g.H * g.W * C + cv * VEC;
+  T* yn = y + (long)n * g.D * g.H * g.W * C + cv * VEC;
+  const float* wl = lds + cv * VEC;
+  for (int it = 0; it < g.iters; ++it) {
+    const long G = ((long)slot * g.iters + it) * g.vs + vslot;
+    if (!lane_ok || G >= groups) continue;
+    const int gx = (int)(G % GX);
+    const long t = G / GX;
+    const int oy = (int)(t % g.H), oz = (int)(t / g.H);
+    const int x0 = gx * XB;
+    int xi[NI];
+    bool xv[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) { const int ix = x0 - P + k; xv[k] = ix >= 0 && ix < g.W; xi[k] = min(max(ix, 0), g.W - 1); }
+    float acc[XB][VEC];
+#pragma unroll
+    for (int v = 0; v < XB; ++v)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[v][i] = bv[i];
+    for (int kz = 0; kz < K; ++kz) {
+      const int iz = oz - P + kz;
+      const bool zok = iz >= 0 && iz < g.D;
+      const int zc = min(max(iz, 0), g.D - 1);
+      for (int ky = 0; ky < K; ++ky) {
+        const int iy = oy - P + ky;
+        const bool zy = zok && iy >= 0 && iy < g.H;
+        const T* row = xn + ((long)zc * g.H + min(max(iy, 0), g.H - 1)) * g.W * C;
+        float in[NI][VEC];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+          VecIO<T, VEC>::load(row + (long)xi[k] * C, in[k]);
+          const bool ok = zy & xv[k];                    // zero padding: the VALUE is zeroed (the tap is shared by XB outputs)
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) in[k][i] = ok ? in[k][i] : 0.f;
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          float wv[VEC];
+          VecIO<float, VEC>::load(wl + ((kz * K + ky) * K + kx) * C, wv);
+#pragma unroll
+          for (int v = 0; v < XB; ++v)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[v][i] = fmaf(in[v + kx][i], wv[i], acc[v][i]);
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < XB; ++v) {
+      if (x0 + v >= g.W) continue;
+      VecIO<T, VEC>::store(yn + (((long)oz * g.H + oy) * g.W + x0 + v) * C, acc[v]);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float r = to_f32<T>(from_f32<T>(acc[v][i]));
+        s1[i] += r;
+        s2[i] = fmaf(r, r, s2[i]);
+      }
+    }
+  }
+  __syncthreads();
+  if (stats) block_stats_reduce<VEC>(s1, s2, cv, vslot, lane_ok, g, stats, n, slot, lds);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Depthwise transposed conv, K = 3, stride 2, pad 1, "cell" form.  The padded output grid (2D,2H,2W) splits into D*H*W
@@ -955,7 +1062,10 @@ static bool make_geom(DwGeom& g, int N, int D, int H, int W, int C, int K, int s
   g.lpv = C / vec;
   g.vs = 256 / g.lpv;
   g.cell = (transposed && K == 3 && 27L * C * 4 <= 64 * 1024 && tuning_get("dwconvT_cell", 1) != 0) ? 1 : 0;
-  long vout = g.cell ? (long)D * H * W : (long)g.Do * g.Ho * g.Wo;
+  // K = 5 / 7, stride 1, 16-byte channel vectors, taps fit LDS: 4 consecutive x outputs per lane (dwconv3d_xblock_kernel)
+  g.xblock = (!transposed && stride == 1 && (K == 5 || K == 7) && vec == 8 && (long)K * K * K * C * 4 <= 64 * 1024 &&
+              tuning_get("dwconv_xblock", 1) != 0 && tuning_get("dwconv_gather", 1) != 0) ? 1 : 0;
+  long vout = g.cell ? (long)D * H * W : (g.xblock ? (long)D * H * ((W + 3) / 4) : (long)g.Do * g.Ho * g.Wo);
   long it = vout / ((long)g.vs * (g.cell ? 256 : 96));   // aim for >= ~96 (cells: 256) workgroups per sample
   g.iters = (int)(it < 1 ? 1 : (it > 64 ? 64 : it));
   g.slots = (int)((vout + (long)g.vs * g.iters - 1) / ((long)g.vs * g.iters));
@@ -967,13 +1077,23 @@ static int launch_dw(bool transposed, const void* x, void* y, const float* w, co
                      const DwGeom& g, hipStream_t s) {
   dim3 grid(g.slots, g.N), block(256);
   size_t lds = stats ? (size_t)g.vs * 2 * g.C * sizeof(float) : 0;
-  const size_t taps = (size_t)27 * g.C * sizeof(float);
+  const size_t taps = (size_t)(transposed ? 27 : g.K * g.K * g.K) * g.C * sizeof(float);
   if (transposed && g.cell) {
     hipLaunchKernelGGL((dwconvT3d_k3_cell_kernel<T, VEC>), grid, block, lds > taps ? lds : taps, s, (const T*)x, (T*)y, w, bias, stats, g);
     return PYTC_OK;
   }
-  if (!transposed && g.K == 3 && taps <= 64 * 1024 && tuning_get("dwconv_gather", 1) != 0) {
-    hipLaunchKernelGGL((dwconv3d_k3_gather_kernel<T, VEC>), grid, block, lds > taps ? lds : taps, s, (const T*)x, (T*)y, w, bias, stats, g);
+  if (!transposed && (g.K == 3 || g.K == 5 || g.K == 7) && taps <= 64 * 1024 && tuning_get("dwconv_gather", 1) != 0) {
+    const size_t dyn = lds > taps ? lds : taps;
+    if constexpr (VEC == 8) {
+      if (g.stride == 1 && g.K >= 5 && g.xblock) {
+        if (g.K == 5) hipLaunchKernelGGL((dwconv3d_xblock_kernel<T, 8, 5, 4>), grid, block, dyn, s, (const T*)x, (T*)y, w, bias, stats, g);
+        else hipLaunchKernelGGL((dwconv3d_xblock_kernel<T, 8, 7, 4>), grid, block, dyn, s, (const T*)x, (T*)y, w, bias, stats, g);
+        return PYTC_OK;
+      }
+    }
+    if (g.K == 3) hipLaunchKernelGGL((dwconv3d_k3_gather_kernel<T, VEC, 3>), grid, block, dyn, s, (const T*)x, (T*)y, w, bias, stats, g);
+    else if (g.K == 5) hipLaunchKernelGGL((dwconv3d_k3_gather_kernel<T, VEC, 5>), grid, block, dyn, s, (const T*)x, (T*)y, w, bias, stats, g);
+    else hipLaunchKernelGGL((dwconv3d_k3_gather_kernel<T, VEC, 7>), grid, block, dyn, s, (const T*)x, (T*)y, w, bias, stats, g);
     return PYTC_OK;
   }
 #define PYTC_DW_CASE(KK)                                                                                      \

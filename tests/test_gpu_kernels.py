@@ -32,7 +32,10 @@ TOL = {torch.float32: dict(rtol=1e-5, atol=1e-5), torch.bfloat16: dict(rtol=2e-2
                                               # shapes that take the z-march fast path (incl. ragged tiles,
                                               # two channel groups, several z chunks)
                                               (32, 3, 1, (12, 20, 24)), (64, 3, 1, (9, 17, 19)),
-                                              (32, 3, 1, (45, 16, 16)), (96, 3, 1, (8, 16, 33))])
+                                              (32, 3, 1, (45, 16, 16)), (96, 3, 1, (8, 16, 33)),
+                                              # K = 5 / 7: x-blocked kernel (bf16, C % 8 == 0), ragged W, stride 2 on the gather form
+                                              (32, 5, 1, (7, 9, 18)), (64, 5, 1, (6, 8, 16)), (32, 7, 1, (8, 7, 13)),
+                                              (32, 5, 2, (8, 10, 12))])
 def test_dwconv3d_and_stats(dev, dt, C, K, stride, shape):
     from pytorch_connectomics_amd import hip_ops as ops
     torch.manual_seed(C * 100 + K)
