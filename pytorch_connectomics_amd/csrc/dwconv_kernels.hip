@@ -1063,8 +1063,8 @@ static bool make_geom(DwGeom& g, int N, int D, int H, int W, int C, int K, int s
   g.vs = 256 / g.lpv;
   g.cell = (transposed && K == 3 && 27L * C * 4 <= 64 * 1024 && tuning_get("dwconvT_cell", 1) != 0) ? 1 : 0;
   // K = 5 / 7, stride 1, 16-byte channel vectors, taps fit LDS: 4 consecutive x outputs per lane (dwconv3d_xblock_kernel)
-  g.xblock = (!transposed && stride == 1 && (K == 5 || K == 7) && vec == 8 && (long)K * K * K * C * 4 <= 64 * 1024 &&
-              tuning_get("dwconv_xblock", 1) != 0 && tuning_get("dwconv_gather", 1) != 0) ? 1 : 0;
+  g.xblock = (!transposed && stride == 1 && (K == 5 || K == 7 || (K == 3 && tuning_get("dwconv_xblock_k3", 1) != 0)) && vec == 8 &&
+              (long)K * K * K * C * 4 <= 64 * 1024 && tuning_get("dwconv_xblock", 1) != 0 && tuning_get("dwconv_gather", 1) != 0) ? 1 : 0;
   long vout = g.cell ? (long)D * H * W : (g.xblock ? (long)D * H * ((W + 3) / 4) : (long)g.Do * g.Ho * g.Wo);
   long it = vout / ((long)g.vs * (g.cell ? 256 : 96));   // aim for >= ~96 (cells: 256) workgroups per sample
   g.iters = (int)(it < 1 ? 1 : (it > 64 ? 64 : it));
@@ -1085,8 +1085,9 @@ static int launch_dw(bool transposed, const void* x, void* y, const float* w, co
   if (!transposed && (g.K == 3 || g.K == 5 || g.K == 7) && taps <= 64 * 1024 && tuning_get("dwconv_gather", 1) != 0) {
     const size_t dyn = lds > taps ? lds : taps;
     if constexpr (VEC == 8) {
-      if (g.stride == 1 && g.K >= 5 && g.xblock) {
-        if (g.K == 5) hipLaunchKernelGGL((dwconv3d_xblock_kernel<T, 8, 5, 4>), grid, block, dyn, s, (const T*)x, (T*)y, w, bias, stats, g);
+      if (g.stride == 1 && g.xblock) {
+        if (g.K == 3) hipLaunchKernelGGL((dwconv3d_xblock_kernel<T, 8, 3, 4>), grid, block, dyn, s, (const T*)x, (T*)y, w, bias, stats, g);
+        else if (g.K == 5) hipLaunchKernelGGL((dwconv3d_xblock_kernel<T, 8, 5, 4>), grid, block, dyn, s, (const T*)x, (T*)y, w, bias, stats, g);
         else hipLaunchKernelGGL((dwconv3d_xblock_kernel<T, 8, 7, 4>), grid, block, dyn, s, (const T*)x, (T*)y, w, bias, stats, g);
         return PYTC_OK;
       }
