@@ -149,3 +149,37 @@ def test_chunked_with_user_crop_and_deepem_affinity_border(tmp_path):
     cfg.inference.model.crop_pad = [6, 6, 0, 0, 0, 0]
     with pytest.raises(ValueError, match="too large"):
         run_chunked_prediction_inference(cfg, None, vol, output_path=tmp_path / "d.npy", predict_region_fn=_fake_predictor(vol))
+
+
+def test_chunk_writer_orders_manifest_after_the_file_and_surfaces_errors(tmp_path):
+    """The background writer marks a chunk completed only after its file is in place, and an IO error reaches the caller."""
+    from pytorch_connectomics_amd.inference.chunked import _ChunkWriter
+
+    class Manifest:
+        def __init__(self):
+            self.seen = []
+
+        def mark_completed(self, key):
+            self.seen.append((key, (tmp_path / f"{key}.npy").exists()))
+
+    man = Manifest()
+    w = _ChunkWriter(man)
+    for i in range(5):
+        w.submit(torch.full((2, 3, 4, 5), float(i)), tmp_path / f"c{i}.npy", f"c{i}")
+    w.close()
+    assert man.seen == [(f"c{i}", True) for i in range(5)]
+    assert float(np.load(tmp_path / "c3.npy").mean()) == 3.0
+    bad = _ChunkWriter(Manifest())
+    bad.submit(np.zeros((1, 2, 2, 2), np.float32), tmp_path / "missing_dir" / "x.npy", "x")
+    with pytest.raises(OSError):
+        bad.close()
+
+
+def test_minimal_rsunet_tutorial_config_parses():
+    import os
+    from pytorch_connectomics_amd.config import load_config
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tutorials", "minimal_rsunet.yaml")
+    tr = load_config(path, mode="train")
+    assert tr.model.arch.type == "rsunet" and list(tr.model.rsunet.width) == [8, 16] and tr.optimization.n_steps_per_epoch == 2
+    te = load_config(path, mode="test", overrides=["inference.window.overlap=0.25"]) if "overrides" in load_config.__code__.co_varnames else load_config(path, mode="test")
+    assert str(te.data.test.image).startswith("random://") and list(te.inference.sliding_window.window_size) == [32, 64, 64]
