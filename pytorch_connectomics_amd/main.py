@@ -5,7 +5,8 @@
 
 test : build_model(cfg) -> load checkpoint -> volume to HBM -> InferenceManager.predict_with_tta (or chunked
        inference when inference.chunking.enabled) -> optional binary Jaccard -> <save_path>/results/*_prediction.npy
-train: needs the backward kernels -- raises NotImplementedError until they exist.
+train: training/module.py's Lightning-free harness (HIP forward + backward, fused loss, fused clip + AdamW), one process
+       per GPU under torch.distributed.run (DDP over RCCL); writes checkpoints/last.ckpt in the Lightning layout.
 Volumes: .npy / .npz (first array) / random://<name>[?shape=Z,Y,X] ; .h5 when h5py is importable.
 """
 from __future__ import annotations

@@ -296,8 +296,10 @@ class RSUNet(ConnectomicsModel):
                                "there is no CPU path. Move the model and input to 'cuda'.")
         if x.dim() != 5:
             raise ValueError(f"RSUNet expects (B, C, D, H, W), got {tuple(x.shape)}")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            # training: autograd Functions whose forward and backward are HIP kernels (training/rsunet_autograd.py)
+        bn_batch_stats = self.training and any(isinstance(mod, nn.BatchNorm3d) for mod in self.modules())
+        if (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())) or bn_batch_stats:
+            # training: autograd Functions whose forward and backward are HIP kernels (training/rsunet_autograd.py); also a
+            # train()-mode forward under no_grad with BatchNorm, which uses batch statistics and updates the running buffers
             from ...training.rsunet_autograd import rsunet_train_forward
             res = rsunet_train_forward(self, to_channels_last(x.float()), resolve_compute_dtype(self.compute_dtype))
             out = {k: v.permute(0, 4, 1, 2, 3) for k, v in res.items()}

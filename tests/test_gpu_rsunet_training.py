@@ -322,3 +322,22 @@ def test_rsunet_eval_after_training_uses_updated_batchnorm_buffers():
         fresh = m(x)
     assert float((after - before).abs().max()) > 1e-4
     assert torch.equal(after, fresh)
+
+
+def test_rsunet_train_mode_forward_under_no_grad_uses_batch_statistics():
+    """model.train() + torch.no_grad() with BatchNorm: batch statistics and running-buffer updates like nn.BatchNorm3d
+    (the fused inference path only knows eval-mode affines)."""
+    from oracle import rsunet_oracle as RO
+    from pytorch_connectomics_amd.models.architectures.rsunet import RSUNet
+    torch.manual_seed(4)
+    kw = dict(width=[4, 8], norm="batch", activation="relu")
+    m = RSUNet(1, 2, **kw)
+    st = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(2, 1, 8, 16, 16)
+    ref = RO.forward(st, x.clone(), bn_training=True, **kw)
+    m = m.cuda().train()
+    rm0 = m.input_conv.pre[0].norm.running_mean.clone()
+    with torch.no_grad():
+        got = m(x.cuda())
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-4, atol=1e-4)
+    assert not torch.equal(m.input_conv.pre[0].norm.running_mean, rm0)
