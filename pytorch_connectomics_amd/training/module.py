@@ -138,7 +138,8 @@ class ConnectomicsModule(nn.Module):
             fn = get("function")
             if fn not in _LOSSES:
                 raise ValueError(f"Unknown loss function {fn!r}; available: {sorted(_LOSSES)}")
-            self.loss_terms.append({"fn": fn, "weight": float(get("weight", 1.0)), "pred_slice": get("pred_slice"),
+            self.loss_terms.append({"fn": fn, "weight": float(get("weight", 1.0)), "pred_head": get("pred_head"),
+                                    "pred_slice": get("pred_slice"),
                                     "target_slice": get("target_slice"), "pos_weight": get("pos_weight")})
         self.fused_loss = bool(getattr(loss_cfg, "fused", True))
         self.global_step = 0
@@ -149,11 +150,11 @@ class ConnectomicsModule(nn.Module):
 
     _FUSABLE = {"WeightedBCEWithLogitsLoss": "bce", "BCEWithLogitsLoss": "bce", "DiceLoss": "dice"}
 
-    def _fused_term_loss(self, pred, target, mask):
+    def _fused_term_loss(self, pred, target, mask, terms):
         """All terms are BCE-with-logits / sigmoid-Dice: one fused HIP reduction per (pred_slice, target_slice) pair."""
         from .fused import bce_dice_loss
         groups = {}
-        for i, t in enumerate(self.loss_terms):
+        for i, t in terms:
             key = (str(t["pred_slice"]), str(t["target_slice"]))
             g = groups.setdefault(key, {"bce": None, "dice": None, "t": t})
             kind = self._FUSABLE[t["fn"]]
@@ -179,13 +180,15 @@ class ConnectomicsModule(nn.Module):
             total = total + v
         return total, parts
 
-    def _term_loss(self, pred, target, mask=None):
-        if pred.is_cuda and self.fused_loss and all(t["fn"] in self._FUSABLE for t in self.loss_terms):
-            res = self._fused_term_loss(pred, target, mask)      # finiteness is checked where fit() reads the value
+    def _term_loss(self, pred, target, mask=None, terms=None):
+        """Weighted sum of the loss terms `terms` (list of (index, term); default: all) on one prediction tensor."""
+        terms = list(enumerate(self.loss_terms)) if terms is None else terms
+        if pred.is_cuda and self.fused_loss and all(t["fn"] in self._FUSABLE for _, t in terms):
+            res = self._fused_term_loss(pred, target, mask, terms)      # finiteness is checked where fit() reads the value
             if res is not None:
                 return res
         total, parts = 0.0, {}
-        for i, t in enumerate(self.loss_terms):
+        for i, t in terms:
             p, y = pred, target
             if t["pred_slice"] is not None:
                 p = pred[:, resolve_channel_indices(t["pred_slice"], num_channels=pred.shape[1], context="pred_slice")]
@@ -198,10 +201,47 @@ class ConnectomicsModule(nn.Module):
             total = total + t["weight"] * v
         return total, parts
 
+    def _head_of(self, term_index: int, term, heads) -> str:
+        """Which named head a term reads (training/losses/orchestrator.py:328-378): its pred_head, else
+        model.primary_head, else the only head; anything else is a configuration error."""
+        want = term["pred_head"]
+        if want is None:
+            primary = getattr(self.cfg.model, "primary_head", None)
+            if primary is not None and primary in heads:
+                want = primary
+            elif len(heads) == 1:
+                want = next(iter(heads))
+            else:
+                raise ValueError(f"Loss term 'loss_{term_index}_{term['fn']}' did not specify pred_head and model.primary_head "
+                                 f"is unset, but model output has multiple heads {sorted(heads)}.")
+        if want not in heads:
+            raise ValueError(f"Loss term 'loss_{term_index}_{term['fn']}' requested pred_head='{want}', but available output "
+                             f"heads are {sorted(heads)}.")
+        if not isinstance(heads[want], torch.Tensor):
+            raise TypeError(f"Output head '{want}' must be a tensor, got {type(heads[want]).__name__}.")
+        return want
+
     def _compute_loss(self, outputs, labels, mask=None):
         main = unwrap_main_output(outputs)
         if isinstance(main, dict):
-            raise NotImplementedError("multi-head loss routing is not built yet")
+            # named heads: every term reads its own head; the terms of one head share a (fused) reduction
+            if not main:
+                raise ValueError("Named-head model output mapping is empty.")
+            by_head: Dict[str, list] = {}
+            for i, t in enumerate(self.loss_terms):
+                by_head.setdefault(self._head_of(i, t, main), []).append((i, t))
+            total, parts = 0.0, {}
+            for head, terms in by_head.items():
+                v, pr = self._term_loss(main[head], labels, mask, terms)
+                total = total + v
+                parts.update(pr)
+            total = self.ds_weights[0] * total
+            parts["train_loss_total"] = total.detach()
+            return total, parts
+        for i, t in enumerate(self.loss_terms):
+            if t["pred_head"] is not None:
+                raise ValueError(f"Loss term 'loss_{i}_{t['fn']}' requested pred_head='{t['pred_head']}' but the model "
+                                 "output is a single tensor.")
         total, parts = self._term_loss(main, labels, mask)
         total = self.ds_weights[0] * total
         if self.deep_supervision and isinstance(outputs, dict):

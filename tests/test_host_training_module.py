@@ -166,3 +166,47 @@ def test_fused_epilogue_host_logic_and_no_cpu_path():
     cfg.optimization.optimizer.name = "AdamW"
     opt = build_optimizer(cfg, SimpleModel())
     assert type(opt).__name__ == "AdamW" and not isinstance(opt, FusedAdamW)
+
+
+def test_named_head_loss_routing():
+    """Loss terms read the head they name (pred_head), else model.primary_head, else the only head
+    (reference training/losses/orchestrator.py:328-378); a head name on a single-tensor output is an error."""
+    class TwoHeads(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Conv3d(1, 1, 1)
+            self.b = torch.nn.Conv3d(1, 2, 1)
+
+        def forward(self, x):
+            return {"output": {"sem": self.a(x), "aff": self.b(x)}}
+
+    torch.manual_seed(0)
+    cfg = _cfg()
+    cfg.model.loss.losses = [{"function": "WeightedBCEWithLogitsLoss", "weight": 1.0, "pred_head": "sem", "target_slice": "0:1"},
+                             {"function": "DiceLoss", "weight": 0.5, "pred_head": "aff", "target_slice": "1:3"},
+                             {"function": "MSELoss", "weight": 0.25, "pred_head": "aff", "pred_slice": "0:1", "target_slice": "0:1"}]
+    net = TwoHeads()
+    m = ConnectomicsModule(cfg, model=net)
+    x = torch.rand(2, 1, 4, 4, 4)
+    y = (torch.rand(2, 3, 4, 4, 4) > 0.5).float()
+    loss = m.training_step({"image": x, "label": y})
+    out = net(x)["output"]
+    want = (weighted_bce_with_logits(out["sem"], y[:, 0:1]) + 0.5 * dice_loss_sigmoid(out["aff"], y[:, 1:3])
+            + 0.25 * F.mse_loss(out["aff"][:, 0:1], y[:, 0:1]))
+    assert torch.allclose(loss, want, atol=1e-6) and loss.requires_grad
+    assert {"loss_0_WeightedBCEWithLogitsLoss", "loss_1_DiceLoss", "loss_2_MSELoss", "train_loss_total"} <= set(m.last_log)
+    # unnamed terms fall back to model.primary_head
+    cfg2 = _cfg()
+    cfg2.model.primary_head = "sem"
+    cfg2.model.loss.losses = [{"function": "DiceLoss", "weight": 1.0, "target_slice": "0:1"}]
+    m2 = ConnectomicsModule(cfg2, model=net)
+    assert torch.allclose(m2.training_step({"image": x, "label": y}), dice_loss_sigmoid(out["sem"], y[:, 0:1]), atol=1e-6)
+    cfg2.model.primary_head = None
+    with pytest.raises(ValueError, match="multiple heads"):
+        m2.training_step({"image": x, "label": y})
+    cfg3 = _cfg()
+    cfg3.model.loss.losses = [{"function": "DiceLoss", "weight": 1.0, "pred_head": "nope"}]
+    with pytest.raises(ValueError, match="available output"):
+        ConnectomicsModule(cfg3, model=net).training_step({"image": x, "label": y})
+    with pytest.raises(ValueError, match="single tensor"):
+        ConnectomicsModule(cfg3, model=SimpleModel()).training_step({"image": torch.rand(2, 1, 8, 8, 8), "label": torch.rand(2, 1, 8, 8, 8)})
