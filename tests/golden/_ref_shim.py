@@ -71,6 +71,10 @@ def install() -> None:
     io_mod._get_tiff_volume_shape = lambda *a, **k: None
     io_mod._tiff_series_are_stackable = lambda *a, **k: False
     sys.modules["connectomics.data.io.io"] = io_mod
+    # inference/output.py: only the numpy dtype / intensity transforms are used; its MONAI-based resampler is not
+    npp = types.ModuleType("connectomics.data.processing.nnunet_preprocess")
+    npp.restore_prediction_to_input_space = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("not available in the shim"))
+    sys.modules["connectomics.data.processing.nnunet_preprocess"] = npp
 
 
 def ref(name: str):

@@ -558,8 +558,28 @@ def crops():
     print("wrote crops.json", {k: len(v) for k, v in out.items()})
 
 
+# ---------------------------------------------------------------- prediction / storage dtype transforms
+def outputs():
+    """connectomics/inference/output.py:146-243: apply_prediction_transform / apply_storage_dtype_transform on a float
+    volume with values outside [0, 1] (clipping), for the dtype vocabulary and the scale conventions."""
+    from types import SimpleNamespace as NS
+    out_mod = S.ref("connectomics.inference.output")
+    rng = np.random.default_rng(7)
+    data = rng.uniform(-0.3, 1.4, size=(2, 4, 5, 6)).astype(np.float32)
+    res = {"data": data}
+    cases = {"u8_255": (255.0, "uint8"), "i8_neg_scale": (-1.0, "int8"), "u16_1000": (1000.0, "uint16"), "f16_2": (2.0, "float16"),
+             "unknown_dtype": (3.0, "float8"), "scale1_none": (1.0, None), "i32_big": (1.0e6, "int32")}
+    for name, (scale, dt) in cases.items():
+        cfg = NS(inference=NS(prediction_transform=NS(enabled=True, intensity_scale=scale, intensity_dtype=dt), save_dtype=None))
+        res["pt__" + name] = out_mod.apply_prediction_transform(cfg, data.copy())
+    for dt in ("uint8", "float16", "int16", "float64"):
+        res["sd__" + dt] = out_mod.apply_storage_dtype_transform(NS(inference=NS(save_dtype=dt)), data.copy() * 100.0)
+    res["pt__disabled"] = out_mod.apply_prediction_transform(NS(inference=NS(prediction_transform=NS(enabled=False))), data.copy())
+    save("output_transforms.npz", **res)
+
+
 if __name__ == "__main__":
-    parts = {"rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
+    parts = {"outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
              "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:

@@ -61,3 +61,22 @@ def test_artifact_roundtrip_and_attrs(tmp_path):
     arr2, a2 = read_prediction_artifact(p2, return_metadata=True)
     assert arr2.shape == (1, 2, 3, 4) and float(arr2.mean()) == 1.5 and a2["final_shape"] == json.dumps([2, 3, 4])
     assert PredictionArtifactMetadata().kind == "raw_prediction"
+
+
+def test_transforms_match_reference_fixture():
+    """tests/golden/output_transforms.npz: outputs of the reference's apply_prediction_transform /
+    apply_storage_dtype_transform (inference/output.py:146-243) for the dtype vocabulary and scale conventions."""
+    from pathlib import Path
+    z = np.load(Path(__file__).parent / "golden" / "output_transforms.npz")
+    data = z["data"]
+    cases = {"u8_255": (255.0, "uint8"), "i8_neg_scale": (-1.0, "int8"), "u16_1000": (1000.0, "uint16"), "f16_2": (2.0, "float16"),
+             "unknown_dtype": (3.0, "float8"), "scale1_none": (1.0, None), "i32_big": (1.0e6, "int32")}
+    for name, (scale, dt) in cases.items():
+        cfg = _cfg(prediction_transform=NS(enabled=True, intensity_scale=scale, intensity_dtype=dt), save_dtype=None)
+        got = apply_prediction_transform(cfg, data.copy())
+        want = z["pt__" + name]
+        assert got.dtype == want.dtype and np.array_equal(got, want), name
+    for dt in ("uint8", "float16", "int16", "float64"):
+        got = apply_storage_dtype_transform(_cfg(save_dtype=dt), data.copy() * 100.0)
+        assert got.dtype == z["sd__" + dt].dtype and np.array_equal(got, z["sd__" + dt]), dt
+    assert np.array_equal(apply_prediction_transform(_cfg(prediction_transform=NS(enabled=False)), data.copy()), z["pt__disabled"])
