@@ -29,9 +29,7 @@ def normalize_channel_selector(selector: Any, *, context: str = "channel selecto
     """None | int | 'a:b' string | list[int]  (strings holding a single int become ints)."""
     if selector is None:
         return None
-    if isinstance(selector, bool):
-        raise TypeError(f"{context} must be an int, a slice string, or a list of ints; got bool.")
-    if isinstance(selector, int):
+    if isinstance(selector, int):            # bool is an int here, as in the reference (True selects channel 1)
         return int(selector)
     if isinstance(selector, str):
         parsed = _parse(selector, context)
@@ -43,7 +41,7 @@ def normalize_channel_selector(selector: Any, *, context: str = "channel selecto
             raise ValueError(f"{context} must not be an empty channel list.")
         out = []
         for raw in selector:
-            if isinstance(raw, int) and not isinstance(raw, bool):
+            if isinstance(raw, int):
                 out.append(int(raw))
             elif isinstance(raw, str):
                 try:
@@ -72,11 +70,11 @@ def resolve_channel_range(selector, *, num_channels: int, context: str = "channe
     """Contiguous selector -> absolute half-open (start, stop)."""
     if num_channels <= 0:
         raise ValueError(f"{context} requires num_channels > 0, got {num_channels}.")
+    if selector is not None and not isinstance(selector, (int, str)):       # a range is one int or one slice string
+        raise TypeError(f"{context} must be an int or a Python-style slice string, got {type(selector).__name__}.")
     norm = normalize_channel_selector(selector, context=context)
     if norm is None:
         return 0, num_channels
-    if isinstance(norm, list):
-        raise TypeError(f"{context} must be an int or a Python-style slice string, got list.")
     if isinstance(norm, int):
         i = resolve_channel_index(norm, num_channels=num_channels, context=context)
         return i, i + 1

@@ -578,8 +578,31 @@ def outputs():
     save("output_transforms.npz", **res)
 
 
+# ---------------------------------------------------------------- channel selectors
+def selectors():
+    """connectomics/utils/channel_slices.py: resolve_channel_indices / resolve_channel_range / normalize_channel_selector for
+    valid and invalid selectors (errors recorded by exception type)."""
+    import json
+    cs = S.ref("connectomics.utils.channel_slices")
+    sels = [None, 0, -1, 5, "2", "-2", ":", "0:", ":-1", "1:3", "-3:-1", "3:1", "0:0", "1:2:3", "a", "", " 1 : 4 ", [0, 2], [3, -1, 0],
+            [0, 0], [], [7], (1, 2), True, 2.5, "99", "0:99", "-99:"]
+    rows = []
+    for sel in sels:
+        for nc in (1, 3, 6):
+            row = {"selector": list(sel) if isinstance(sel, tuple) else sel, "tuple": isinstance(sel, tuple), "num_channels": nc}
+            for name in ("resolve_channel_indices", "resolve_channel_range"):
+                try:
+                    v = getattr(cs, name)(sel, num_channels=nc, context="sel")
+                    row[name] = list(v)
+                except Exception as e:               # noqa: BLE001 - the error type is the fixture
+                    row[name] = {"error": type(e).__name__}
+            rows.append(row)
+    (HERE / "channel_selectors.json").write_text(json.dumps(rows))
+    print("wrote channel_selectors.json", len(rows))
+
+
 if __name__ == "__main__":
-    parts = {"outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
+    parts = {"selectors": selectors, "outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
              "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:

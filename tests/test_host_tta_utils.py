@@ -153,3 +153,24 @@ def test_prediction_crop_helpers_match_reference_fixture():
     with pytest.raises(ValueError):
         cr.crop_spatial_by_pad(a, ((3, 2), (0, 0), (0, 0)))
     assert cr.cropped_shape((10, 20, 30), ((1, 2), (0, 0), (3, 0))) == (7, 20, 27)
+
+
+def test_channel_selectors_match_reference_fixture():
+    """tests/golden/channel_selectors.json: the reference's resolve_channel_indices / resolve_channel_range
+    (utils/channel_slices.py:130-225) for 28 selectors x 3 channel counts, incl. the error type of invalid ones."""
+    import json
+    from pathlib import Path
+    rows = json.loads((Path(__file__).parent / "golden" / "channel_selectors.json").read_text())
+    assert len(rows) == 84
+    bad = []
+    for r in rows:
+        sel = tuple(r["selector"]) if r["tuple"] else r["selector"]
+        for name, fn in (("resolve_channel_indices", resolve_channel_indices), ("resolve_channel_range", resolve_channel_range)):
+            want = r[name]
+            try:
+                got = list(fn(sel, num_channels=r["num_channels"], context="sel"))
+            except Exception as e:                   # noqa: BLE001
+                got = {"error": type(e).__name__}
+            if got != want:
+                bad.append((name, sel, r["num_channels"], got, want))
+    assert not bad, bad[:5]
