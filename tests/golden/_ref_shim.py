@@ -46,6 +46,8 @@ def install() -> None:
         "connectomics.data.augmentation",
         "connectomics.data.io",
         "connectomics.utils",
+        "connectomics.training",
+        "connectomics.training.optimization",
     ):
         _stub_pkg(name)
     # connectomics.config.hardware: only resolve_accelerator_type / empty cache are read

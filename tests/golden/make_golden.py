@@ -601,8 +601,29 @@ def selectors():
     print("wrote channel_selectors.json", len(rows))
 
 
+# ---------------------------------------------------------------- learning-rate schedule
+def schedules():
+    """connectomics/training/optimization/lr_scheduler.py:51-106: WarmupCosineLR learning rates per iteration for two
+    parameter groups (linear warm-up, eta_min)."""
+    import json
+    lrs = S.ref("connectomics.training.optimization.lr_scheduler")
+    rows = []
+    for max_iters, wi, wf, eta in ((50, 10, 0.001, 0.0), (30, 0, 0.1, 1e-5), (40, 60, 0.01, 1e-6), (25, 5, 1.0, 0.0)):
+        ps = [torch.nn.Parameter(torch.zeros(1)), torch.nn.Parameter(torch.zeros(1))]
+        opt = torch.optim.SGD([{"params": [ps[0]], "lr": 0.1}, {"params": [ps[1]], "lr": 0.02}], lr=0.1)
+        sch = lrs.WarmupCosineLR(opt, max_iters=max_iters, warmup_factor=wf, warmup_iters=wi, eta_min=eta)
+        seq = []
+        for _ in range(max_iters):
+            seq.append([g["lr"] for g in opt.param_groups])
+            opt.step()
+            sch.step()
+        rows.append({"max_iters": max_iters, "warmup_iters": wi, "warmup_factor": wf, "eta_min": eta, "lrs": seq})
+    (HERE / "lr_schedule.json").write_text(json.dumps(rows))
+    print("wrote lr_schedule.json", len(rows))
+
+
 if __name__ == "__main__":
-    parts = {"selectors": selectors, "outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
+    parts = {"schedules": schedules, "selectors": selectors, "outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
              "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:

@@ -210,3 +210,21 @@ def test_named_head_loss_routing():
         ConnectomicsModule(cfg3, model=net).training_step({"image": x, "label": y})
     with pytest.raises(ValueError, match="single tensor"):
         ConnectomicsModule(cfg3, model=SimpleModel()).training_step({"image": torch.rand(2, 1, 8, 8, 8), "label": torch.rand(2, 1, 8, 8, 8)})
+
+
+def test_warmup_cosine_lr_matches_reference_fixture():
+    """tests/golden/lr_schedule.json: per-iteration learning rates of the reference's WarmupCosineLR
+    (training/optimization/lr_scheduler.py:51-106) for two parameter groups."""
+    import json
+    from pathlib import Path
+    from pytorch_connectomics_amd.training.module import WarmupCosineLR
+    for case in json.loads((Path(__file__).parent / "golden" / "lr_schedule.json").read_text()):
+        ps = [torch.nn.Parameter(torch.zeros(1)), torch.nn.Parameter(torch.zeros(1))]
+        opt = torch.optim.SGD([{"params": [ps[0]], "lr": 0.1}, {"params": [ps[1]], "lr": 0.02}], lr=0.1)
+        sch = WarmupCosineLR(opt, max_iters=case["max_iters"], warmup_factor=case["warmup_factor"],
+                             warmup_iters=case["warmup_iters"], eta_min=case["eta_min"])
+        for want in case["lrs"]:
+            got = [g["lr"] for g in opt.param_groups]
+            assert all(abs(a - b) <= 1e-12 + 1e-9 * abs(b) for a, b in zip(got, want)), (case["max_iters"], got, want)
+            opt.step()
+            sch.step()
