@@ -117,7 +117,8 @@ def build_optimizer(cfg, model: nn.Module) -> torch.optim.Optimizer:
     if name == "adam":
         return torch.optim.Adam(groups, lr=lr, betas=betas, eps=eps)
     if name == "sgd":
-        return torch.optim.SGD(groups, lr=lr, momentum=float(getattr(oc, "momentum", 0.9)))
+        return torch.optim.SGD(groups, lr=lr, momentum=float(getattr(oc, "momentum", 0.9)), weight_decay=wd,
+                               nesterov=bool(getattr(oc, "nesterov", False)))
     raise ValueError(f"Unknown optimizer: {name}")
 
 

@@ -622,8 +622,47 @@ def schedules():
     print("wrote lr_schedule.json", len(rows))
 
 
+# ---------------------------------------------------------------- optimizer parameter groups
+def _opt_model():
+    torch.manual_seed(0)
+    m = torch.nn.Sequential()
+    m.add_module("conv", torch.nn.Conv3d(1, 4, 3))
+    m.add_module("gn", torch.nn.GroupNorm(2, 4))
+    m.add_module("act", torch.nn.PReLU())
+    m.add_module("conv2", torch.nn.Conv3d(4, 4, 1, bias=False))
+    m.add_module("bn", torch.nn.BatchNorm3d(4))
+    m.add_module("head", torch.nn.Conv3d(4, 2, 1))
+    m.add_module("tied", torch.nn.Conv3d(4, 2, 1))
+    m.tied.weight = m.head.weight                 # shared parameter: listed once
+    m.conv2.weight.requires_grad_(False)          # frozen: not listed
+    return m
+
+
+def optimizers():
+    """connectomics/training/optimization/build.py:47-160: per-parameter (lr, weight_decay) and optimizer class / defaults."""
+    import json
+    from types import SimpleNamespace as NS
+    ob = S.ref("connectomics.training.optimization.build")
+    rows = []
+    for oc in (dict(name="AdamW", lr=1e-3, weight_decay=0.01), dict(name="adamw", lr=2e-4, weight_decay=0.05, weight_decay_norm=0.001,
+               weight_decay_bias=0.0, bias_lr_factor=2.0, betas=[0.8, 0.95], eps=1e-6),
+               dict(name="Adam", lr=1e-3, weight_decay=0.0), dict(name="SGD", lr=0.1, weight_decay=1e-4, momentum=0.8)):
+        m = _opt_model()
+        opt = ob.build_optimizer(NS(optimization=NS(optimizer=NS(**oc))), m)
+        names = {id(p): n for n, p in m.named_parameters()}
+        per = {}
+        for g in opt.param_groups:
+            for p in g["params"]:
+                per[names[id(p)]] = [g["lr"], g["weight_decay"]]
+        g0 = opt.param_groups[0]
+        rows.append({"cfg": oc, "class": type(opt).__name__, "per_param": per, "betas": list(g0.get("betas", [])),
+                     "eps": g0.get("eps"), "momentum": g0.get("momentum")})
+    (HERE / "optimizer_groups.json").write_text(json.dumps(rows))
+    print("wrote optimizer_groups.json", [r["class"] for r in rows])
+
+
 if __name__ == "__main__":
-    parts = {"schedules": schedules, "selectors": selectors, "outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
+    parts = {"optimizers": optimizers, "schedules": schedules, "selectors": selectors, "outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
              "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:

@@ -228,3 +228,47 @@ def test_warmup_cosine_lr_matches_reference_fixture():
             assert all(abs(a - b) <= 1e-12 + 1e-9 * abs(b) for a, b in zip(got, want)), (case["max_iters"], got, want)
             opt.step()
             sch.step()
+
+
+def test_optimizer_groups_match_reference_fixture():
+    """tests/golden/optimizer_groups.json: per-parameter (lr, weight_decay), class and defaults of the reference's
+    build_optimizer (training/optimization/build.py:47-160) incl. shared / frozen parameters and the norm / bias rules."""
+    import json
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).parent / "golden"))
+    rows = json.loads((Path(__file__).parent / "golden" / "optimizer_groups.json").read_text())
+
+    def model():
+        torch.manual_seed(0)
+        m = torch.nn.Sequential()
+        m.add_module("conv", torch.nn.Conv3d(1, 4, 3))
+        m.add_module("gn", torch.nn.GroupNorm(2, 4))
+        m.add_module("act", torch.nn.PReLU())
+        m.add_module("conv2", torch.nn.Conv3d(4, 4, 1, bias=False))
+        m.add_module("bn", torch.nn.BatchNorm3d(4))
+        m.add_module("head", torch.nn.Conv3d(4, 2, 1))
+        m.add_module("tied", torch.nn.Conv3d(4, 2, 1))
+        m.tied.weight = m.head.weight
+        m.conv2.weight.requires_grad_(False)
+        return m
+
+    for r in rows:
+        cfg = _cfg()
+        for k, v in r["cfg"].items():
+            setattr(cfg.optimization.optimizer, k, v)
+        m = model()
+        opt = build_optimizer(cfg, m)
+        assert type(opt).__name__ == r["class"], r["cfg"]
+        names = {id(p): n for n, p in m.named_parameters()}
+        per = {}
+        for g in opt.param_groups:
+            for p in g["params"]:
+                assert names[id(p)] not in per
+                per[names[id(p)]] = [g["lr"], g["weight_decay"]]
+        assert per == {k: v for k, v in r["per_param"].items()}, (r["cfg"], per, r["per_param"])
+        g0 = opt.param_groups[0]
+        if r["betas"]:
+            assert list(g0["betas"]) == r["betas"] and g0["eps"] == r["eps"]
+        if r["momentum"] is not None:
+            assert g0["momentum"] == r["momentum"]
