@@ -49,7 +49,36 @@ def weighted_bce_with_logits(logits, target, weight=None, pos_weight=None):
     return (bce * w * valid).sum() / valid.sum().clamp_min(1)
 
 
+def _reduce_weighted(loss: torch.Tensor, weight: Optional[torch.Tensor]) -> torch.Tensor:
+    """losses.py:17-44 with reduction='mean': plain mean, or the mean of weight * loss over the voxels with weight > 0."""
+    if weight is None:
+        return loss.mean()
+    w = weight.float().expand_as(loss)
+    valid = w > 0
+    return (loss * w * valid).sum() / valid.sum().clamp_min(1)
+
+
+def weighted_regression_loss(kind: str, pred, target, weight=None, *, tanh: bool = False, beta: float = 1.0):
+    """WeightedMSELoss / WeightedMAELoss / SmoothL1Loss of the reference (losses.py:140-187, 725-800): optional tanh on
+    the prediction (distance-transform targets in [-1, 1]), elementwise loss, weighted-valid mean."""
+    p = pred.float()
+    if tanh:
+        p = torch.tanh(p)
+    t = target.float()
+    if kind == "mse":
+        loss = (p - t) ** 2
+    elif kind == "mae":
+        loss = (p - t).abs()
+    else:
+        loss = F.smooth_l1_loss(p, t, beta=float(beta), reduction="none")
+    return _reduce_weighted(loss, weight)
+
+
 _LOSSES = {
+    "WeightedMSELoss": lambda p, t, **kw: weighted_regression_loss("mse", p, t, kw.get("weight"), tanh=bool(kw.get("tanh", False))),
+    "WeightedMAELoss": lambda p, t, **kw: weighted_regression_loss("mae", p, t, kw.get("weight"), tanh=bool(kw.get("tanh", False))),
+    "SmoothL1Loss": lambda p, t, **kw: weighted_regression_loss("huber", p, t, kw.get("weight"), tanh=bool(kw.get("tanh", False)),
+                                                                beta=float(kw.get("beta", 1.0))),
     "DiceLoss": lambda p, t, **kw: dice_loss_sigmoid(p, t),
     "WeightedBCEWithLogitsLoss": lambda p, t, **kw: weighted_bce_with_logits(p, t, kw.get("weight"), kw.get("pos_weight")),
     "BCEWithLogitsLoss": lambda p, t, **kw: weighted_bce_with_logits(p, t, kw.get("weight")),
@@ -141,7 +170,8 @@ class ConnectomicsModule(nn.Module):
                 raise ValueError(f"Unknown loss function {fn!r}; available: {sorted(_LOSSES)}")
             self.loss_terms.append({"fn": fn, "weight": float(get("weight", 1.0)), "pred_head": get("pred_head"),
                                     "pred_slice": get("pred_slice"),
-                                    "target_slice": get("target_slice"), "pos_weight": get("pos_weight")})
+                                    "target_slice": get("target_slice"), "pos_weight": get("pos_weight"),
+                                    "kwargs": dict(get("kwargs", None) or {})})
         self.fused_loss = bool(getattr(loss_cfg, "fused", True))
         self.global_step = 0
 
@@ -195,7 +225,7 @@ class ConnectomicsModule(nn.Module):
                 p = pred[:, resolve_channel_indices(t["pred_slice"], num_channels=pred.shape[1], context="pred_slice")]
             if t["target_slice"] is not None:
                 y = target[:, resolve_channel_indices(t["target_slice"], num_channels=target.shape[1], context="target_slice")]
-            v = _LOSSES[t["fn"]](p, y, weight=mask, pos_weight=t["pos_weight"])
+            v = _LOSSES[t["fn"]](p, y, weight=mask, pos_weight=t["pos_weight"], **t["kwargs"])
             if not torch.isfinite(v):
                 raise FloatingPointError(f"loss term {t['fn']} is not finite")
             parts[f"loss_{i}_{t['fn']}"] = v.detach()

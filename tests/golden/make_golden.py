@@ -518,6 +518,29 @@ def losses():
         out[f"{name}__loss"] = np.asarray([float(v)], np.float64)
         out[f"{name}__grad"] = (torch.zeros_like(x) if gx is None else gx).numpy()
         print(name, float(v))
+    # regression losses (distance transforms): WeightedMSELoss / WeightedMAELoss / SmoothL1Loss, tanh option, weight maps
+    for name, (cls, kw, mk) in {"mse_plain": ("WeightedMSELoss", {}, None), "mse_tanh_mask": ("WeightedMSELoss", {"tanh": True}, "bcast"),
+                                "mae_real": ("WeightedMAELoss", {}, "real"), "huber_beta": ("SmoothL1Loss", {"beta": 0.3, "tanh": True}, "full"),
+                                "huber_none_valid": ("SmoothL1Loss", {}, "zero")}.items():
+        x = (torch.randn(2, 2, 4, 5, 6, generator=g) * 1.5).requires_grad_()
+        t = torch.rand(2, 2, 4, 5, 6, generator=g) * 2 - 1
+        w = None
+        if mk == "bcast":
+            w = (torch.rand(2, 1, 4, 5, 6, generator=g) > 0.3).float()
+        elif mk == "full":
+            w = (torch.rand(2, 2, 4, 5, 6, generator=g) > 0.5).float()
+        elif mk == "real":
+            w = torch.randn(2, 2, 4, 5, 6, generator=g)
+        elif mk == "zero":
+            w = torch.zeros(2, 1, 4, 5, 6)
+        v = getattr(ls, cls)(**kw)(x, t, weight=w)
+        gx = torch.autograd.grad(v, x, allow_unused=True)[0] if v.requires_grad else None
+        out[f"reg_{name}__x"], out[f"reg_{name}__t"] = x.detach().numpy(), t.numpy()
+        if w is not None:
+            out[f"reg_{name}__w"] = w.numpy()
+        out[f"reg_{name}__loss"] = np.asarray([float(v)], np.float64)
+        out[f"reg_{name}__grad"] = (torch.zeros_like(x) if gx is None else gx).numpy()
+        print(name, float(v))
     save("losses.npz", **out)
 
 

@@ -133,7 +133,7 @@ def test_fused_bce_matches_reference_fixture():
     from pathlib import Path
     from pytorch_connectomics_amd.training.fused import bce_dice_loss
     z = np.load(Path(__file__).parent / "golden" / "losses.npz")
-    for n in sorted({k.split("__")[0] for k in z.files}):
+    for n in sorted({k.split("__")[0] for k in z.files if not k.startswith("reg_")}):
         x = torch.from_numpy(z[f"{n}__x"]).cuda().requires_grad_()
         t = torch.from_numpy(z[f"{n}__t"]).cuda()
         w = torch.from_numpy(z[f"{n}__w"]).cuda() if f"{n}__w" in z.files else None

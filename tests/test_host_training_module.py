@@ -132,7 +132,7 @@ def test_weighted_bce_matches_reference_fixture():
     import numpy as np
     from pathlib import Path
     z = np.load(Path(__file__).parent / "golden" / "losses.npz")
-    names = sorted({k.split("__")[0] for k in z.files})
+    names = sorted({k.split("__")[0] for k in z.files if not k.startswith("reg_")})
     assert len(names) == 6
     for n in names:
         x = torch.from_numpy(z[f"{n}__x"]).requires_grad_()
@@ -272,3 +272,21 @@ def test_optimizer_groups_match_reference_fixture():
             assert list(g0["betas"]) == r["betas"] and g0["eps"] == r["eps"]
         if r["momentum"] is not None:
             assert g0["momentum"] == r["momentum"]
+
+
+def test_regression_losses_match_reference_fixture():
+    """WeightedMSELoss / WeightedMAELoss / SmoothL1Loss (losses.py:140-187, 725-800) incl. tanh and weight maps."""
+    import numpy as np
+    from pathlib import Path
+    from pytorch_connectomics_amd.training.module import _LOSSES
+    z = np.load(Path(__file__).parent / "golden" / "losses.npz")
+    cases = {"mse_plain": ("WeightedMSELoss", {}), "mse_tanh_mask": ("WeightedMSELoss", {"tanh": True}), "mae_real": ("WeightedMAELoss", {}),
+             "huber_beta": ("SmoothL1Loss", {"beta": 0.3, "tanh": True}), "huber_none_valid": ("SmoothL1Loss", {})}
+    for n, (fn, kw) in cases.items():
+        x = torch.from_numpy(z[f"reg_{n}__x"]).requires_grad_()
+        t = torch.from_numpy(z[f"reg_{n}__t"])
+        w = torch.from_numpy(z[f"reg_{n}__w"]) if f"reg_{n}__w" in z.files else None
+        v = _LOSSES[fn](x, t, weight=w, pos_weight=None, **kw)
+        assert abs(float(v.detach()) - float(z[f"reg_{n}__loss"][0])) < 1e-6, n
+        v.backward()
+        assert torch.allclose(x.grad, torch.from_numpy(z[f"reg_{n}__grad"]), atol=1e-8, rtol=1e-5), n
