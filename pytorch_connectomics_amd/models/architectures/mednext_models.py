@@ -160,6 +160,12 @@ class MedNeXtMultiHeadWrapper(ConnectomicsModel):
 
     def forward(self, x: torch.Tensor) -> Dict[str, Dict[str, torch.Tensor]]:
         self.model._check_input(x)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training: trunk and heads through the autograd Functions of training/autograd.py (HIP forward + backward)
+            from ...training.autograd import mednext_multihead_train_forward
+            from .mednext import resolve_compute_dtype
+            outs = mednext_multihead_train_forward(self, to_channels_last(x.float()), resolve_compute_dtype(self.model.compute_dtype))
+            return {"output": {k: to_channels_first(v) for k, v in outs.items()}}
         feat_cl = self.model.features_cl(to_channels_last(x.float()))
         return {"output": {k: to_channels_first(v) for k, v in self.forward_heads_cl(feat_cl).items()}}
 

@@ -250,9 +250,8 @@ def _block(m, x, skip=None):
                          None if res is None else res.bias, m.kind, bool(m.do_res), float(m.norm.eps))
 
 
-def mednext_train_forward(trunk, x_cl: torch.Tensor, compute_dtype: torch.dtype):
-    """Differentiable forward of the MedNeXt trunk on channels-last input (N,D,H,W,C_in) fp32.
-    Returns fp32 channels-last logits, or the list [out, ds_1..ds_4] with deep supervision."""
+def mednext_train_features(trunk, x_cl: torch.Tensor, compute_dtype: torch.dtype):
+    """Differentiable trunk up to the full-resolution features: -> (features, [bottleneck, dec_3, dec_2, dec_1])."""
     x = PointwiseFn.apply(x_cl, trunk.stem.weight, trunk.stem.bias, False, compute_dtype)
     skips = []
     for lvl in range(4):
@@ -269,6 +268,13 @@ def mednext_train_forward(trunk, x_cl: torch.Tensor, compute_dtype: torch.dtype)
             x = _block(blk, x)
         if lvl:
             feats.append(x)
+    return x, feats
+
+
+def mednext_train_forward(trunk, x_cl: torch.Tensor, compute_dtype: torch.dtype):
+    """Differentiable forward of the MedNeXt trunk on channels-last input (N,D,H,W,C_in) fp32.
+    Returns fp32 channels-last logits, or the list [out, ds_1..ds_4] with deep supervision."""
+    x, feats = mednext_train_features(trunk, x_cl, compute_dtype)
     head = lambda ft, i: PointwiseFn.apply(ft, getattr(trunk, f"out_{i}").conv_out.weight,
                                            getattr(trunk, f"out_{i}").conv_out.bias, True, torch.float32)
     out = head(x, 0)
@@ -276,3 +282,22 @@ def mednext_train_forward(trunk, x_cl: torch.Tensor, compute_dtype: torch.dtype)
         return out
     ds = [head(ft, h) for ft, h in zip(feats, (4, 3, 2, 1))]
     return [out, ds[3], ds[2], ds[1], ds[0]]
+
+
+def mednext_multihead_train_forward(wrapper, x_cl: torch.Tensor, compute_dtype: torch.dtype):
+    """Differentiable forward of MedNeXtMultiHeadWrapper (mednext_models.py:197-273): shared trunk features, then per
+    named head an optional 1x1 in-projection, its MedNeXt blocks and the 1x1 out-projection.  -> {head: fp32 NDHWC logits}."""
+    feat, _ = mednext_train_features(wrapper.model, x_cl, compute_dtype)
+    outs = {}
+    for name, head in wrapper.heads.items():
+        x = feat
+        if not isinstance(head.input_projection, nn.Identity):
+            x = PointwiseFn.apply(x, head.input_projection.weight, head.input_projection.bias, False, compute_dtype)
+        if not isinstance(head.blocks, nn.Identity):
+            for blk in head.blocks:
+                x = _block(blk, x)
+        outs[name] = PointwiseFn.apply(x, head.projection.weight, head.projection.bias, False, torch.float32)
+    return outs
+
+
+__all__ = ["PointwiseFn", "BlockFn", "mednext_train_forward", "mednext_train_features", "mednext_multihead_train_forward"]

@@ -411,3 +411,55 @@ def test_inference_after_fused_optimizer_steps_sees_new_weights():
         fresh = m(x)
     assert float((after - before).abs().max()) > 1e-3          # the weights moved
     assert torch.equal(after, fresh)                            # ... and the cached path saw them
+
+
+def test_multihead_wrapper_training_matches_oracle_autograd():
+    """MedNeXtMultiHeadWrapper with grad enabled: shared trunk + per-head (in-projection, blocks, out-projection) through
+    the HIP autograd Functions; loss and parameter gradients against autograd through the oracle."""
+    from types import SimpleNamespace as NS
+    from oracle import mednext_oracle as MO
+    from pytorch_connectomics_amd.models.architectures.mednext import MedNeXt
+    from pytorch_connectomics_amd.models.architectures.mednext_models import MedNeXtMultiHeadWrapper
+    torch.manual_seed(17)
+    kw = dict(n_channels=16, exp_r=2, kernel_size=3, block_counts=[1] * 9)
+    trunk = MedNeXt(1, 16, 4, exp_r=2, kernel_size=3, do_res=True, do_res_up_down=True, block_counts=[1] * 9)
+    heads = {"sem": NS(out_channels=1, num_blocks=1, hidden_channels=8), "aff": NS(out_channels=3, num_blocks=0, hidden_channels=None)}
+    w = MedNeXtMultiHeadWrapper(trunk, heads, primary_head="sem")
+    sd = {k: v.detach().clone() for k, v in w.state_dict().items()}
+    x = torch.randn(1, 1, 16, 16, 32)
+    tgt = {"sem": torch.randn(1, 1, 16, 16, 32), "aff": torch.randn(1, 3, 16, 16, 32)}
+    # oracle: trunk features, then the heads from the same arithmetic (1x1 convs + block_forward)
+    ref_p = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    st_trunk = {k[len("model."):]: v for k, v in ref_p.items() if k.startswith("model.")}
+    feat = MO.forward_features(st_trunk, x, **kw)
+    def head_ref(name):
+        st = {k[len(f"heads.{name}."):]: v for k, v in ref_p.items() if k.startswith(f"heads.{name}.")}
+        h = feat
+        if "input_projection.weight" in st:
+            h = F.conv3d(h, st["input_projection.weight"], st["input_projection.bias"])
+        i = 0
+        while f"blocks.{i}.conv1.weight" in st:
+            h = MO.block_forward(h, st, f"blocks.{i}", 3, True, "group", False)
+            i += 1
+        return F.conv3d(h, st["projection.weight"], st["projection.bias"])
+    ref_loss = sum(F.mse_loss(head_ref(n), tgt[n]) for n in ("sem", "aff"))
+    ref_loss.backward()
+    wg = w.cuda().train()
+    out = wg(x.cuda())["output"]
+    loss = sum(F.mse_loss(out[n], tgt[n].cuda()) for n in ("sem", "aff"))
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 1e-4 * max(1.0, float(ref_loss.detach()))
+    loss.backward()
+    checked = 0
+    gmax = max(float(v.grad.abs().max()) for v in ref_p.values() if v.grad is not None)
+    for n, p in wg.named_parameters():
+        r = ref_p[n].grad
+        if r is None:            # parameters the multi-head forward does not touch (the trunk's own output heads)
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        assert p.grad is not None, n
+        # conv1.bias feeds a per-channel GroupNorm, so its true gradient is ~0 (rounding noise): floor the scale
+        scale = max(float(r.abs().max()), 1e-4 * gmax)
+        err = float((p.grad.cpu() - r).abs().max()) / scale
+        assert err < 2e-2, f"{n}: {err:.2e}"
+        checked += 1
+    assert checked > 100
