@@ -684,8 +684,24 @@ def optimizers():
     print("wrote optimizer_groups.json", [r["class"] for r in rows])
 
 
+# ---------------------------------------------------------------- resume manifest file written by the reference
+def manifests():
+    """connectomics/chunked/manifest.py: a manifest file as the reference writes it (config + completed keys), so the
+    on-disk format stays interchangeable (a run can be resumed by either implementation)."""
+    import tempfile
+    man = S.ref("connectomics.chunked.manifest")
+    with tempfile.TemporaryDirectory() as d:
+        path = Path(d) / "m.json"
+        m = man.ResumeManifest.load_or_create(path, {"chunk_shape": [4, 5, 6], "output_shape": [10, 13, 9], "halo": [1, 2, 1], "overlap": 0})
+        for k in ("z0_y0_x0", "z1_y2_x1", "z0_y0_x0", "z2_y0_x1"):
+            m.mark_completed(k)
+        m.mark_many(["z2_y2_x1", "z1_y2_x1"])
+        (HERE / "resume_manifest_ref.json").write_text(path.read_text())
+    print("wrote resume_manifest_ref.json")
+
+
 if __name__ == "__main__":
-    parts = {"optimizers": optimizers, "schedules": schedules, "selectors": selectors, "outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
+    parts = {"manifests": manifests, "optimizers": optimizers, "schedules": schedules, "selectors": selectors, "outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
              "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:

@@ -183,3 +183,23 @@ def test_minimal_rsunet_tutorial_config_parses():
     assert tr.model.arch.type == "rsunet" and list(tr.model.rsunet.width) == [8, 16] and tr.optimization.n_steps_per_epoch == 2
     te = load_config(path, mode="test", overrides=["inference.window.overlap=0.25"]) if "overrides" in load_config.__code__.co_varnames else load_config(path, mode="test")
     assert str(te.data.test.image).startswith("random://") and list(te.inference.sliding_window.window_size) == [32, 64, 64]
+
+
+def test_resume_manifest_file_format_interchanges_with_reference(tmp_path, golden_dir):
+    """tests/golden/resume_manifest_ref.json was written by the reference's ResumeManifest: this implementation resumes
+    from it, refuses a mismatched config like the reference, and writes the same JSON document for the same history."""
+    ref_text = (golden_dir / "resume_manifest_ref.json").read_text()
+    cfg = {"chunk_shape": [4, 5, 6], "output_shape": [10, 13, 9], "halo": [1, 2, 1], "overlap": 0}
+    p = tmp_path / "m.json"
+    p.write_text(ref_text)
+    m = ResumeManifest.load_or_create(p, cfg)
+    assert m.completed == {"z0_y0_x0", "z1_y2_x1", "z2_y0_x1", "z2_y2_x1"}
+    with pytest.raises(ManifestConfigMismatch):
+        ResumeManifest.load_or_create(p, dict(cfg, chunk_shape=[4, 5, 7]))
+    q = tmp_path / "own.json"
+    own = ResumeManifest.load_or_create(q, cfg)
+    for k in ("z0_y0_x0", "z1_y2_x1", "z0_y0_x0", "z2_y0_x1"):
+        own.mark_completed(k)
+    own.mark_many(["z2_y2_x1", "z1_y2_x1"])
+    assert json.loads(q.read_text()) == json.loads(ref_text)
+    assert ResumeManifest.load_or_create(q, cfg, overwrite=True).completed == set()
