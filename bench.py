@@ -1,15 +1,21 @@
 """bench.py -- headline benchmark of the MI355X engine for the PyTorch Connectomics hot path.
 
-Metric (BASELINE.json): voxels/s, MedNeXt-S 112^3 bf16.  A "step" is one sliding-window batch of the
-Lucchi++ inference workload (configs[1]): gather `sw_batch_size`=8 windows of 112^3 from the HBM-resident
-165x1024x768 volume -> MedNeXt-S forward (bf16 storage, fp32 accumulation) -> bump-weighted overlap-add
-into the HBM-resident accumulators.  value = window-voxels/s of the whole job (all ranks).
+Metric (BASELINE.json): voxels/s, MedNeXt-S 112^3 bf16.  A "step" is ONE WHOLE-VOLUME pass of the product's sliding-window
+engine -- `EagerSlidingWindowEngine.__call__(volume, model)` exactly as `main.py --mode test` reaches it -- over the
+Lucchi++ test volume (configs[1]): 165 x 1024 x 768, roi 112^3, overlap 0.5, bump blending, sw_batch_size 8 = 468 windows
+(probe window, accumulator allocation, 59 window batches, normalisation and the crop back are all inside the timed region;
+the volume is resident in HBM before it starts).  value = window-voxels/s of the whole job (all ranks).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Multi-GPU: the path shards by independent volumes (the reference's volume-per-rank sharding,
+Reported next to `value` (rank 0): the same job with 8-flip mean TTA through InferenceManager (`tta8`), the cubic 448^3
+volume (`cube448`), the fp32 parity path (`fp32`), the training half of the metric (`train`, with its own roofline), RSUNet
+and the MONAI-style residual U-Net (configs[4]) legs, the CPU oracle on the host cores (`cpu_baseline`), and for N > 1 the
+strong-scaling slab mode (`strong_slab`: ONE volume cut into N slabs with p2p halo bands, inference/slab.py).
+
+Multi-GPU headline: the path shards by independent volumes (the reference's volume-per-rank sharding,
 training/lightning/data.py:234-266): every rank owns one volume, no data-path collective -> weak scaling.
 """
 from __future__ import annotations
@@ -20,9 +26,11 @@ import os
 
 # RCCL / cross-process device memory on this driver stack needs dmabuf IPC (already exported on the target image)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import statistics
 import sys
 import time
 from pathlib import Path
+from types import SimpleNamespace as NS
 
 import torch
 
@@ -31,14 +39,15 @@ sys.path.insert(0, str(ROOT))
 
 ROI = (112, 112, 112)
 VOLUME = (165, 1024, 768)          # Lucchi++ test volume (tutorials/mito_lucchi++/README.md:114)
+CUBE = (448, 448, 448)             # divisible grid, 7^3 = 343 windows
 SW_BATCH = 8
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
+ROI_VOX = ROI[0] * ROI[1] * ROI[2]
 
 
-def build_model(device):
-    from types import SimpleNamespace as NS
+def build_model(device, out_channels=1):
     from pytorch_connectomics_amd.models import build_model as bm
-    cfg = NS(model=NS(arch=NS(type="mednext"), in_channels=1, out_channels=1,
+    cfg = NS(model=NS(arch=NS(type="mednext"), in_channels=1, out_channels=out_channels,
                       mednext=NS(size="S", kernel_size=3), loss=NS(deep_supervision=False), heads=None))
     torch.manual_seed(0)
     model = bm(cfg).to(device).eval()
@@ -46,47 +55,93 @@ def build_model(device):
     return model
 
 
-def cpu_baseline(model, seconds_cap: float = 25.0):
-    """Oracle (CPU restatement, kind='port') timed on the host cores on ONE window of the same workload
-    (112^3 when it fits the time cap, 64^3 otherwise); same weights, fp32.  The thread count is the best of a
-    short sweep on a 32^3 window (PyTorch's CPU depthwise conv does not scale to hundreds of threads)."""
+def make_engine():
+    from pytorch_connectomics_amd.inference.window import EagerSlidingWindowEngine
+    return EagerSlidingWindowEngine(roi_size=ROI, sw_batch_size=SW_BATCH, overlap=0.5, mode="bump",
+                                    padding_mode="constant", cval=0.0)
+
+
+def infer_cfg(tta: bool):
+    """The Lucchi++ inference section (tutorials/mito_lucchi++/mito_lucchi++.yaml:31-40) as the config tree
+    InferenceManager reads; sigmoid activation, fp32 output."""
+    tta_ns = NS(enabled=tta, flip_axes="all", rotation90_axes=None, rotate90_k=None, ensemble_mode="mean",
+                patch_first_local=True, distributed_sharding=False, apply_mask=True)
+    return NS(model=NS(primary_head=None, heads=None, out_channels=1),
+              data=NS(train=NS(do_2d=False), val=NS(do_2d=False), dataloader=NS(batch_size=1)),
+              inference=NS(sliding_window=NS(window_size=list(ROI), sw_batch_size=SW_BATCH, overlap=0.5, blending="bump",
+                                             padding_mode="constant", cval=0.0, keep_input_on_cpu=False, sw_device=None,
+                                             output_device=None, border_mask=None, distributed_sharding=False),
+                           model=NS(head=None, select_channel=None, output_dtype=None,
+                                    channel_activations=[{"channels": ":", "activation": "sigmoid"}], crop_pad=None),
+                           test_time_augmentation=tta_ns))
+
+
+def timed(fn, sync=True):
+    if sync:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = fn()
+    if sync:
+        torch.cuda.synchronize()
+    return time.perf_counter() - t0, out
+
+
+def job_record(n_windows, views, vol_shape, seconds, **extra):
+    out_vox = vol_shape[0] * vol_shape[1] * vol_shape[2]
+    rec = {"seconds": seconds, "windows": n_windows, "views": views,
+           "window_voxels_per_s": n_windows * views * ROI_VOX / seconds,
+           "output_voxels_per_s": out_vox / seconds, "volume": list(vol_shape)}
+    rec.update(extra)
+    return rec
+
+
+def cpu_baseline(model, threads_cap: int = 32):
+    """Oracle (CPU restatement, kind='port') timed on the host cores on ONE 112^3 window of the same workload, same
+    weights, fp32: 1 warm-up + 3 timed forwards, median (BASELINE.md section 3 prescribes 2 + 5; bounded here to ~20 s of CPU
+    work).  One fixed thread count (PyTorch's CPU depthwise conv stops scaling near 32 threads: round-1 sweep)."""
     from oracle import mednext_oracle as MO
     st = {k: v.detach().float().cpu() for k, v in model.model.state_dict().items()}
     cores = os.cpu_count() or 1
+    threads = max(1, min(threads_cap, cores))
+    torch.set_num_threads(threads)
     kw = dict(n_channels=32, exp_r=2, kernel_size=3, block_counts=[2] * 9)
-
-    def run(side, reps=1):
-        x = torch.rand(1, 1, side, side, side)
-        best = float("inf")
+    x = torch.rand(1, 1, *ROI)
+    times = []
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        MO.forward(st, x, **kw)
+        warm = time.perf_counter() - t0
+        reps = 3 if warm < 8 else 1
         for _ in range(reps):
             t0 = time.perf_counter()
             MO.forward(st, x, **kw)
-            best = min(best, time.perf_counter() - t0)
-        return best
+            times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
+    return {"value": ROI_VOX / dt, "unit": "voxels/s", "cores": threads, "kind": "port",
+            "sample": f"oracle MedNeXt-S fp32 forward of one 112^3 window, 1 warm-up + {len(times)} timed, median "
+                      f"{dt:.2f} s, torch CPU, {threads} threads on a {cores}-core host"}
 
-    with torch.no_grad():
-        cands = sorted({t for t in (8, 16, 32, 64, cores) if t <= cores})
-        timing = {}
-        for t in cands:
-            torch.set_num_threads(t)
-            run(32)
-            timing[t] = run(32, reps=2)
-        threads = min(timing, key=timing.get)
-        torch.set_num_threads(threads)
-        t64 = run(64)
-        side, dt = 64, t64
-        if t64 * (112 / 64) ** 3 < seconds_cap:
-            side, dt = 112, run(112)
-    return {"value": side ** 3 / dt, "unit": "voxels/s", "cores": threads, "kind": "port",
-            "sample": f"oracle MedNeXt-S fp32 forward of one {side}^3 window ({dt:.2f} s), torch CPU, "
-                      f"{threads} threads (best of {cands}) on a {cores}-core host"}
+
+def dominant(summ, n_steps, peak=HBM_PEAK_GBS, traffic_fn=None):
+    name, rec = max(summ.items(), key=lambda kv: kv[1]["ms"])
+    per_launch_bytes = rec["bytes"] / rec["launches"]
+    per_launch_s = rec["ms"] / rec["launches"] / 1e3
+    achieved = per_launch_bytes / per_launch_s / 1e9
+    total_ms = sum(r["ms"] for r in summ.values())
+    return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic_fn(name) if traffic_fn else None,
+            "launch_us": round(per_launch_s * 1e6, 1), "algorithmic_bytes": int(per_launch_bytes),
+            "share_of_step": round(rec["ms"] / total_ms, 3),
+            "kernels_ms_per_step": {k: round(v["ms"] / n_steps, 3) for k, v in
+                                    sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]},
+            "kernel_ms_total_per_step": round(total_ms / n_steps, 3)}
 
 
 def train_leg(dev, rank, world, args, barrier):
     """The training half of the metric: DDP (RCCL all-reduce) MedNeXt-S steps on synthetic 112^3 patches, bf16
     storage / fp32 master weights: HIP forward + HIP backward + BCE/Dice loss + grad clip + AdamW, nothing skipped.
     Reported next to `value` (which stays the sliding-window inference rate the target is quoted on)."""
-    from types import SimpleNamespace as NS
+    from pytorch_connectomics_amd import hip_ops as ops
     from pytorch_connectomics_amd.models import build_model as bm
     from pytorch_connectomics_amd.training.module import build_optimizer, synthetic_batches
     from pytorch_connectomics_amd.training.fused import bce_dice_loss
@@ -107,7 +162,7 @@ def train_leg(dev, rank, world, args, barrier):
     opt = build_optimizer(cfg, model)
     it = synthetic_batches(args.train_batch, ROI, seed=11 + rank, device=dev)
     pool = [next(it) for _ in range(2)]                                # patches resident in HBM before timing
-    steps = max(1, min(args.steps, 10))
+    steps = max(1, args.train_steps)
 
     def tstep(i):
         b = pool[i % len(pool)]
@@ -118,7 +173,7 @@ def train_leg(dev, rank, world, args, barrier):
         opt.step()
         return loss
 
-    for i in range(max(1, min(args.warmup, 3))):
+    for i in range(3):
         tstep(i)
     quiesce_gc()          # what training/module.py:fit does after its first steps (utils/hostgc.py)
     barrier()
@@ -131,30 +186,35 @@ def train_leg(dev, rank, world, args, barrier):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    vox = world * args.train_batch * ROI[0] * ROI[1] * ROI[2] * steps
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        with ops.profiled() as prof:
+            for i in range(2):
+                tstep(i)
+        roof = dominant(prof.summary(), 2)
+    vox = world * args.train_batch * ROI_VOX * steps
     del opt, net, model
     torch.cuda.empty_cache()
     return {"value": vox / dt, "unit": "voxels/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "batch_per_gpu": args.train_batch, "patch": list(ROI), "dtype": "bf16 activations, fp32 master weights",
             "parallelism": f"ddp{world}" if world > 1 else "single", "scaling": "weak",
             "includes": "forward + backward + fused BCE/Dice loss + grad-norm clip + AdamW step, all HIP kernels",
-            "final_loss": float(loss.detach())}
+            "final_loss": float(loss.detach()), "roofline": roof}
 
 
-def rsunet_leg(dev, args):
-    """The path's second architecture, reported next to the headline (single GPU): RSUNet [16, 32, 64, 128], BatchNorm,
-    anisotropic 2 x 18 x 160 x 160 patches, bf16 storage: training step (HIP forward + backward, fused loss, fused AdamW)
-    and inference forward."""
-    from pytorch_connectomics_amd.models.architectures.rsunet import RSUNet
+def _unet_leg(dev, args, make, label, patch, batch, out_ch):
+    from pytorch_connectomics_amd import hip_ops as ops
     from pytorch_connectomics_amd.training.fused import FusedAdamW, bce_dice_loss
     from pytorch_connectomics_amd.utils.hostgc import quiesce_gc
     torch.manual_seed(0)
-    patch, batch = (18, 160, 160), 2
-    m = RSUNet(1, 3, width=[16, 32, 64, 128], norm="batch", activation="relu").to(dev).train()
-    m.compute_dtype = torch.bfloat16
+    m = make().to(dev).train()
+    inner = getattr(m, "model", m)
+    for mod in (m, inner):
+        if hasattr(mod, "compute_dtype"):
+            mod.compute_dtype = torch.bfloat16
     opt = FusedAdamW(m.parameters(), lr=1e-4, weight_decay=1e-2, max_grad_norm=1.0)
     x = torch.rand(batch, 1, *patch, device=dev)
-    y = (torch.rand(batch, 3, *patch, device=dev) > 0.85).float()
+    y = (torch.rand(batch, out_ch, *patch, device=dev) > 0.85).float()
 
     def tstep():
         opt.zero_grad(set_to_none=True)
@@ -163,51 +223,67 @@ def rsunet_leg(dev, args):
         opt.step()
         return loss
 
-    steps = max(1, min(args.steps, 10))
+    steps = max(1, args.train_steps)
     for _ in range(4):
         tstep()
     quiesce_gc()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = tstep()
-    torch.cuda.synchronize()
-    dt_train = (time.perf_counter() - t0) / steps
+    dt_train, loss = timed(lambda: [tstep() for _ in range(steps)][-1])
+    dt_train /= steps
+    roof = None
+    if not args.no_roofline:
+        with ops.profiled() as prof:
+            for _ in range(2):
+                tstep()
+        roof = dominant(prof.summary(), 2)
     m.eval()
     with torch.no_grad():
         for _ in range(3):
             m(x)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            m(x)
-        torch.cuda.synchronize()
-        dt_inf = (time.perf_counter() - t0) / steps
+        dt_inf, _ = timed(lambda: [m(x) for _ in range(steps)])
+        dt_inf /= steps
     vox = batch * patch[0] * patch[1] * patch[2]
     del opt, m
     torch.cuda.empty_cache()
-    return {"model": "RSUNet width [16,32,64,128], BatchNorm, relu", "batch": batch, "patch": list(patch), "dtype": "bf16 activations, fp32 master weights",
+    return {"model": label, "batch": batch, "patch": list(patch), "dtype": "bf16 activations, fp32 master weights",
             "train_ms_per_step": dt_train * 1e3, "train_voxels_per_s": vox / dt_train, "infer_ms_per_forward": dt_inf * 1e3,
-            "infer_voxels_per_s": vox / dt_inf, "final_loss": float(loss.detach())}
+            "infer_voxels_per_s": vox / dt_inf, "final_loss": float(loss.detach()), "train_roofline": roof}
+
+
+def rsunet_leg(dev, args):
+    """The path's second architecture (single GPU): RSUNet [16, 32, 64, 128], BatchNorm, anisotropic 2 x 18 x 160 x 160
+    patches, bf16 storage: training step (HIP forward + backward, fused loss, fused AdamW) and inference forward."""
+    from pytorch_connectomics_amd.models.architectures.rsunet import RSUNet
+    return _unet_leg(dev, args, lambda: RSUNet(1, 3, width=[16, 32, 64, 128], norm="batch", activation="relu"),
+                     "RSUNet width [16,32,64,128], BatchNorm, relu", (18, 160, 160), 2, 3)
+
+
+def monai_unet_leg(dev, args):
+    """BASELINE configs[4] (CREMI synapse): MONAI-style residual U-Net, filters [32,64,128,256], anisotropic 20 x 256 x 256
+    patches, bf16 storage: training step and inference forward."""
+    from pytorch_connectomics_amd.models import build_model as bm
+    cfg = NS(model=NS(arch=NS(type="monai_unet"), in_channels=1, out_channels=1, input_size=[20, 256, 256],
+                      monai=NS(filters=[32, 64, 128, 256], num_res_units=2, kernel_size=3, norm="batch", dropout=0.0,
+                               upsample_mode="deconv")))
+    return _unet_leg(dev, args, lambda: bm(cfg), "MONAI-style residual U-Net filters [32,64,128,256], BatchNorm, PReLU",
+                     (20, 256, 256), 2, 1)
 
 
 def pmc_traffic_bytes(label):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_bench_hbm_counters.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs by
-    tools/profile_bench.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if the file or
-    the kernel is missing -- counters cannot be collected from inside the timed process."""
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command (newest
+    profiles/rNN_bench_hbm_counters.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs by
+    tools/profile_bench.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if the file or the
+    kernel is missing -- counters cannot be collected from inside the timed process."""
     import csv
     import re
-    f = ROOT / "profiles" / "r01_bench_hbm_counters.csv"
-    if not f.exists():
+    files = sorted((ROOT / "profiles").glob("r*_bench_hbm_counters.csv"))
+    if not files:
         return None
     m = re.match(r"pw_mlp_fwd\[(\d+)->(\d+)->(\d+)\]", label)
-    if m:
-        key = f"pw_mlp_kernel<{int(m.group(1)) // 32}, {int(m.group(3)) // 16},"
-    else:
+    if not m:
         return None          # other kernels run at several shapes under one name: no per-shape counter average
+    key = f"pw_mlp_kernel<{int(m.group(1)) // 32}, {int(m.group(3)) // 16},"
     tot = n = 0.0
-    for row in csv.DictReader(open(f)):          # the plain and the head-epilogue variant of the shape, launch-weighted
+    for row in csv.DictReader(open(files[-1])):   # the plain and the epilogue variants of the shape, launch-weighted
         if key in row["kernel"]:
             k = float(row.get("launches") or 1)
             tot += k * (2 * float(row["FETCH_SIZE_KB_mean"]) + float(row["WRITE_SIZE_KB_mean"])) * 1024
@@ -218,12 +294,14 @@ def pmc_traffic_bytes(label):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the tta8 / cube448 / fp32 / U-Net legs")
     ap.add_argument("--train-batch", type=int, default=4)
+    ap.add_argument("--train-steps", type=int, default=10)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -247,80 +325,134 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from pytorch_connectomics_amd import hip_ops as ops
-    from pytorch_connectomics_amd.inference.window import EagerSlidingWindowEngine
 
+    volume = tuple(int(v) for v in os.environ.get("PYTC_BENCH_VOLUME", "").split("x")) if os.environ.get("PYTC_BENCH_VOLUME") else VOLUME
     model = build_model(dev)
-    eng = EagerSlidingWindowEngine(roi_size=ROI, sw_batch_size=SW_BATCH, overlap=0.5, mode="bump",
-                                   padding_mode="constant", cval=0.0)
+    eng = make_engine()
     g = torch.Generator(device=dev).manual_seed(7 + rank)
-    vol = torch.rand((1,) + VOLUME, device=dev, generator=g)            # resident in HBM before timing
-    image_size, starts = eng.plan(VOLUME)
-    (wz, wy, wx), combine = eng._axis_vectors(dev)
-    value = torch.zeros((1,) + image_size, device=dev)
-    weight = torch.zeros(image_size, device=dev)
-    batches = [starts[i:i + SW_BATCH] for i in range(0, len(starts) - SW_BATCH + 1, SW_BATCH)]
-
-    def step(i):
-        b = batches[i % len(batches)]
-        x = ops.gather_windows(vol, b, ROI, pad_mode="constant", cval=0.0)
-        y = model.forward_cl(x)
-        ops.blend_accumulate(y, b, value, weight, wz, wy, wx, combine=combine, floor_w=1e-5)
+    vol = torch.rand((1, 1) + volume, device=dev, generator=g)          # resident in HBM before timing
+    _, starts = eng.plan(volume)
+    n_win = len(starts)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def step():
+        return eng(vol, model)       # the product call: probe, accumulators, all window batches, finalize, crop
+
     with torch.no_grad():
-        for i in range(args.warmup):
-            step(i)
+        for _ in range(args.warmup):
+            step()
         barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
+        for _ in range(args.steps):
+            out = step()
         barrier()
         dt = time.perf_counter() - t0
+    out_shape = tuple(out.shape)
+    del out
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-
-    vox_per_step = SW_BATCH * ROI[0] * ROI[1] * ROI[2]
-    value_vps = world * vox_per_step * args.steps / dt
+    per_call = dt / args.steps
+    value_vps = world * n_win * ROI_VOX * args.steps / dt
 
     roofline = None
     if rank == 0 and not args.no_roofline:
-        with torch.no_grad(), ops.profiled() as prof:
-            for i in range(min(args.steps, 5)):
-                step(i)
+        (wz, wy, wx), combine = eng._axis_vectors(dev)
+        value = torch.zeros((1,) + tuple(max(volume[a], ROI[a]) for a in range(3)), device=dev)
+        weight = torch.zeros(value.shape[1:], device=dev)
+        nprof = 5
+        with torch.no_grad(), ops.profiled() as prof:      # per-kernel HIP events over 5 window batches of the same job
+            for i in range(nprof):
+                b = starts[1 + i * SW_BATCH: 1 + (i + 1) * SW_BATCH]
+                x = ops.gather_windows(vol[0], b, ROI, pad_mode="constant", cval=0.0)
+                y = model.forward_cl(x)
+                ops.blend_accumulate(y, b, value, weight, wz, wy, wx, combine=combine, floor_w=1e-5)
         summ = prof.summary()
-        name, rec = max(summ.items(), key=lambda kv: kv[1]["ms"])
-        per_launch_bytes = rec["bytes"] / rec["launches"]
-        per_launch_s = rec["ms"] / rec["launches"] / 1e3
-        achieved = per_launch_bytes / per_launch_s / 1e9
-        roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_bytes(name),
-                    "launch_us": round(per_launch_s * 1e6, 1), "algorithmic_bytes": int(per_launch_bytes),
-                    "share_of_step": round(rec["ms"] / sum(r["ms"] for r in summ.values()), 3),
-                    "kernels_ms_per_step": {k: round(v["ms"] / min(args.steps, 5), 3) for k, v in
-                                            sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]},
-                    "kernel_ms_total_per_step": round(sum(r["ms"] for r in summ.values()) / min(args.steps, 5), 3)}
+        roofline = dominant(summ, nprof, traffic_fn=pmc_traffic_bytes)
+        del value, weight
         if os.environ.get("PYTC_BENCH_VERBOSE"):
             for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
-                n = min(args.steps, 5)
-                print(f"  {k:34s} launches/step={v['launches'] / n:5.1f} ms/step={v['ms'] / n:7.3f} "
+                print(f"  {k:34s} launches/step={v['launches'] / nprof:5.1f} ms/step={v['ms'] / nprof:7.3f} "
                       f"GB/s={v['bytes'] / max(v['ms'], 1e-9) / 1e6:8.1f}", file=sys.stderr)
 
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras:
+        from pytorch_connectomics_amd.inference import InferenceManager
+        with torch.no_grad():
+            try:   # secondary figures must never cost the headline line
+                mgr0 = InferenceManager(infer_cfg(False), model, model.forward)
+                s0, o = timed(lambda: mgr0.predict_with_tta(vol))
+                extras["tta_off_manager"] = job_record(n_win, 1, volume, s0, path="InferenceManager.predict_with_tta, "
+                                                       "TTA off, sigmoid, fp32 out")
+                del o
+                mgr8 = InferenceManager(infer_cfg(True), model, model.forward)
+                s8, o = timed(lambda: mgr8.predict_with_tta(vol))
+                extras["tta8"] = job_record(n_win, 8, volume, s8, path="InferenceManager.predict_with_tta, 8-flip mean "
+                                            "TTA (tta_combinations order), sigmoid per view, fp32 out")
+                del o
+            except Exception as e:     # noqa: BLE001 - reported in the JSON
+                extras["tta8"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                cube = torch.rand((1, 1) + CUBE, device=dev, generator=g)
+                _, cstarts = eng.plan(CUBE)
+                eng(cube[:, :, :112, :224, :224].contiguous(), model)
+                sc, o = timed(lambda: eng(cube, model))
+                extras["cube448"] = job_record(len(cstarts), 1, CUBE, sc)
+                del o, cube
+            except Exception as e:     # noqa: BLE001
+                extras["cube448"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                model.model.compute_dtype = torch.float32
+                eng(vol[:, :, :112, :224, :224].contiguous(), model)
+                s32, o = timed(lambda: eng(vol, model))
+                extras["fp32"] = job_record(n_win, 1, volume, s32, dtype="f32 (the parity path: 1e-3 gate against the oracle)")
+                del o
+            except Exception as e:     # noqa: BLE001
+                extras["fp32"] = {"error": f"{type(e).__name__}: {e}"}
+            finally:
+                model.model.compute_dtype = torch.bfloat16
+        torch.cuda.empty_cache()
+
+    strong = None
+    if world > 1:
+        from pytorch_connectomics_amd.inference.slab import slab_predict_volume
+        g0 = torch.Generator(device=dev).manual_seed(7)
+        shared = torch.rand((1,) + volume, device=dev, generator=g0)   # every rank holds the planes its windows touch
+        with torch.no_grad():
+            slab_predict_volume(shared, eng, model)
+            barrier()
+            t0 = time.perf_counter()
+            slab_predict_volume(shared, eng, model)
+            barrier()
+            ds = time.perf_counter() - t0
+        t = torch.tensor([ds], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        strong = job_record(n_win, 1, volume, float(t.item()), scaling="strong",
+                            path=f"slab_predict_volume: one volume, {world} slabs, p2p halo bands (RCCL send/recv), result sharded")
+        del shared
+
+    del vol
+    torch.cuda.empty_cache()
     train = None
     if not args.no_train:
         train = train_leg(dev, rank, world, args, barrier)
 
-    rsu = None
-    if rank == 0 and world == 1 and not args.no_train:
-        try:                       # a secondary figure must never cost the headline line
-            rsu = rsunet_leg(dev, args)
-        except Exception as e:     # noqa: BLE001 - reported in the JSON
-            rsu = {"error": f"{type(e).__name__}: {e}"}
+    rsu = unet = None
+    if rank == 0 and world == 1 and not args.no_train and not args.no_extras:
+        for name, leg in (("rsunet", rsunet_leg), ("monai_unet", monai_unet_leg)):
+            try:
+                res = leg(dev, args)
+            except Exception as e:     # noqa: BLE001 - reported in the JSON
+                res = {"error": f"{type(e).__name__}: {e}"}
+            if name == "rsunet":
+                rsu = res
+            else:
+                unet = res
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -330,15 +462,21 @@ def main():
         out = {
             "metric": "voxels/s (train + sliding-window infer), MedNeXt-S 112^3 bf16",
             "value": value_vps, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": per_call * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "Lucchi++ sliding-window inference (configs[1]): MedNeXt-S k3, "
-                                   "165x1024x768 volume, roi 112^3, overlap 0.5, bump blending, "
-                                   "sw_batch_size 8, random-init weights; value = window-voxels/s",
-                       "volume": list(VOLUME), "roi": list(ROI), "sw_batch_size": SW_BATCH,
+                                   f"{'x'.join(map(str, volume))} volume, roi 112^3, overlap 0.5, bump blending, "
+                                   "sw_batch_size 8, random-init weights; step = one whole-volume "
+                                   "EagerSlidingWindowEngine call (TTA off); value = window-voxels/s",
+                       "volume": list(volume), "roi": list(ROI), "sw_batch_size": SW_BATCH, "windows_per_step": n_win,
                        "sharding": "one independent volume per rank, no collective"},
-            "roofline": roofline, "cpu_baseline": cpu, "train": train, "rsunet": rsu,
+            "window_voxels_per_s": value_vps,
+            "output_voxels_per_s": world * volume[0] * volume[1] * volume[2] * args.steps / dt,
+            "ms_per_8_windows": per_call * 1e3 * SW_BATCH / n_win, "timed_region_s": dt, "output_shape": list(out_shape),
+            "roofline": roofline, "cpu_baseline": cpu, "train": train, "strong_slab": strong,
+            "rsunet": rsu, "monai_unet": unet,
         }
+        out.update(extras)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

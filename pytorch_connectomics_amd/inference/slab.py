@@ -189,9 +189,35 @@ def slab_predict_volume(vol: torch.Tensor, engine, network, *, group=None, gathe
         slab = slab[:, :keep[0], :keep[1], :keep[2]].contiguous()
     if not gather:
         return slab
-    parts = [None] * world
-    dist.all_gather_object(parts, None if slab is None else slab.cpu(), group=group)
-    return torch.cat([p for p in parts if p is not None and p.shape[ax + 1] > 0], dim=ax + 1).to(vol.device)
+    return gather_slabs(slab, plan, orig, vol.device, group=group)
 
 
-__all__ = ["SlabPlan", "plan_slabs", "exchange_schedule", "slab_predict", "slab_predict_volume"]
+def gather_slabs(slab: Optional[torch.Tensor], plan: SlabPlan, orig: Sequence[int], device, *, c_out: Optional[int] = None,
+                 group=None) -> torch.Tensor:
+    """All ranks -> the full (C_out, *orig) volume, on the device: every rank contributes its slab padded to the widest
+    ownership range (the plan is known everywhere, so sizes need no exchange) through ONE tensor all-gather (RCCL
+    all_gather over xGMI on the GPU box; no pickling, no host staging), then the pads are dropped."""
+    world = len(plan.own)
+    ax = plan.axis
+    widths = [max(0, min(b1, int(orig[ax])) - b0) for b0, b1 in plan.own]
+    wmax = max(widths)
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if c_out is None:
+        # a rank that owns nothing still has to join the collective with the right channel count
+        c = torch.tensor([0 if slab is None else int(slab.shape[0])], device=device, dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(c, op=dist.ReduceOp.MAX, group=group)
+        c_out = int(c.item())
+    shp = [c_out] + [int(v) for v in orig]
+    shp[ax + 1] = wmax
+    mine = torch.zeros(shp, dtype=torch.float32, device=device)
+    if slab is not None and widths[rank] > 0:
+        mine.narrow(ax + 1, 0, widths[rank]).copy_(slab)
+    if world == 1:
+        return mine.narrow(ax + 1, 0, widths[0]).contiguous()
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    return torch.cat([p.narrow(ax + 1, 0, w) for p, w in zip(parts, widths) if w > 0], dim=ax + 1)
+
+
+__all__ = ["SlabPlan", "plan_slabs", "exchange_schedule", "slab_predict", "slab_predict_volume", "gather_slabs"]

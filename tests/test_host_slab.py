@@ -8,7 +8,7 @@ import torch
 import torch.multiprocessing as mp
 
 from oracle import window_oracle as WO
-from pytorch_connectomics_amd.inference.slab import exchange_schedule, plan_slabs, slab_predict
+from pytorch_connectomics_amd.inference.slab import exchange_schedule, gather_slabs, plan_slabs, slab_predict
 
 
 def _net(x):            # closed form, position dependent inside the window, 2 output channels
@@ -75,6 +75,9 @@ def _worker(rank, world, port, img, roi, tmp):
     slab = slab_predict(plan, rank, _oracle_accumulate(vol, roi, plan),
                         lambda v, w: v / torch.clamp_min(w, 1e-4))          # normalize_weighted_accumulator, window.py:275-294
     np.save(os.path.join(tmp, f"slab{rank}.npy"), np.zeros((2, 0, 0, 0), np.float32) if slab is None else slab.numpy())
+    # device-side gather (one tensor all_gather of padded slabs; channel count agreed by all_reduce)
+    full = gather_slabs(slab, plan, img, torch.device("cpu"))
+    np.save(os.path.join(tmp, f"gathered{rank}.npy"), full.numpy())
     if rank == 0:
         np.save(os.path.join(tmp, "axis.npy"), np.asarray([plan.axis] + [b for _a, b in plan.own]))
     torch.distributed.barrier()
@@ -93,3 +96,5 @@ def test_slab_exchange_over_gloo_matches_single_process(img, world, tmp_path):
     ref = WO.eager_sliding_window(vol, _net, roi=roi, overlap=0.5, mode="bump", sw_batch_size=2)[0].numpy()
     assert got.shape == ref.shape
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
+    for r in range(world):            # every rank holds the full volume after gather_slabs
+        np.testing.assert_array_equal(np.load(tmp_path / f"gathered{r}.npy"), got)
