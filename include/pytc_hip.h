@@ -415,6 +415,31 @@ int pytc_dwconv3d_generic_fwd(const void* x, void* y, const float* w, int N, int
                               const int32_t* kernel, const int32_t* stride, const int32_t* pad, const int32_t* out_dims,
                               int dtype, void* stream);
 
+/* ---------------------------------------------------------------- strided / transposed dense conv (MONAI-style U-Net) - */
+/* Replaces the resampling convolutions of the reference's `monai_unet` architecture
+ * (connectomics/models/architectures/monai_models.py:197-250 -> monai ResidualUnit / Convolution: nn.Conv3d with stride 2,
+ * nn.ConvTranspose3d(k 3, stride 2, padding 1, output_padding 1)) and their torch-autograd backward.
+ * pytc_conv3d_strided_fwd: `a` as for pytc_conv3d_fwd but a->D/H/W are the OUTPUT grid and x lives on `in_dims`;
+ *   transposed = 0: y[o] = sum_t W[t] * f(x)[o*stride + t - pad];  transposed = 1 (gather form of ConvTranspose3d):
+ *   y[o] = sum_t W[t] * f(x)[(o + pad - t) / stride] over the taps where the division is exact.  Weights come from
+ *   pytc_conv3d_pack_weight_direct, which reads element (o, c, tap) of the conv the image is FOR at
+ *   w[o*s_o + c*s_c + (flip ? ntap-1-tap : tap)] -- nn.Conv3d weight: s_o = C_in*ntap, s_c = ntap; nn.ConvTranspose3d weight
+ *   [C_in][C_out][k] used as the forward of the transposed conv or as the data gradient of a strided conv: s_o = ntap,
+ *   s_c = C_out*ntap.  The data gradient of a strided conv is the transposed gather, that of a transposed conv the strided
+ *   conv, both through this entry.
+ * pytc_conv3d_wgrad_strided: dW[o][k][tap] = sum_{r in small grid} small[r][o] * big[r*stride + tap - pad][k]
+ *   (strided conv: small = dY, big = conv input; transposed conv: small = conv input, big = dY -> ConvTranspose3d layout);
+ *   dW is written [tap][o][k]; workspace pytc_conv3d_wgrad_strided_ws_elems floats; deterministic two-stage sum. */
+int64_t pytc_conv3d_direct_packed_elems(int C_out, int C_in, int kd, int kh, int kw, int dtype);
+int pytc_conv3d_pack_weight_direct(const float* w, int C_out, int C_in, int kd, int kh, int kw, int64_t s_o, int64_t s_c,
+                                   int flip, void* packed, int dtype, void* stream);
+int pytc_conv3d_strided_fwd(const pytc_conv3d_args* a, const int32_t* in_dims, const int32_t* stride, const int32_t* pad,
+                            int transposed, void* stream);
+int64_t pytc_conv3d_wgrad_strided_ws_elems(int N, const int32_t* small_dims, int C_k, int C_o, const int32_t* kernel);
+int pytc_conv3d_wgrad_strided(const void* big, const void* small, float* dW, float* workspace, int N,
+                              const int32_t* big_dims, const int32_t* small_dims, int C_k, int C_o, const int32_t* kernel,
+                              const int32_t* stride, const int32_t* pad, int dtype, void* stream);
+
 /* ---- train-step epilogue on the device ------------------------------------------------
  * Fused loss  L = w_bce * BCEWithLogits(x, t; weight, pos_weight) + w_dice * Dice(sigmoid(x), t)
  *   (connectomics/models/losses/losses.py:17-44,190-266 WeightedBCEWithLogitsLoss with reduction='mean' - with a weight

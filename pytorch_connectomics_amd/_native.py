@@ -139,6 +139,15 @@ _SIGS = {
     "pytc_dwconv3d_generic_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                             C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
+    "pytc_conv3d_direct_packed_elems": (C.c_int64, [C.c_int] * 6),
+    "pytc_conv3d_pack_weight_direct": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                                 C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "pytc_conv3d_strided_fwd": (C.c_int, [C.POINTER(Conv3dArgs), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                          C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
+    "pytc_conv3d_wgrad_strided_ws_elems": (C.c_int64, [C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(C.c_int32)]),
+    "pytc_conv3d_wgrad_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
     "pytc_conv3d_pack_weight_dgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "pytc_norm_bwd_means": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_float, C.c_void_p]),

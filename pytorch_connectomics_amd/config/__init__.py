@@ -37,7 +37,7 @@ def _window_defaults() -> dict:
 
 def schema_defaults() -> dict:
     """Defaults of the reference dataclasses for the sections the engine reads
-    (schema/model.py:23-120, schema/model_mednext.py:7-21, schema/model_rsunet.py:7-19,
+    (schema/model.py:23-120, schema/model_mednext.py:7-21, schema/model_rsunet.py:7-19, schema/model_monai.py:7-22,
     schema/inference.py:21-174, schema/optimization.py, schema/system.py)."""
     return {
         "experiment_name": "experiment", "description": "", "save_path": "outputs/experiment",
@@ -51,6 +51,9 @@ def schema_defaults() -> dict:
             "rsunet": {"width": [16, 32, 64, 128], "norm": "batch", "activation": "relu", "num_groups": 8,
                        "down_factors": None, "depth_2d": 0, "kernel_2d": [1, 3, 3], "act_negative_slope": 0.01,
                        "act_init": 0.25},
+            "monai": {"filters": [32, 64, 128, 256, 512], "dropout": 0.0, "norm": "batch", "num_groups": 8,
+                      "activation": "relu", "spatial_dims": 3, "num_res_units": 2, "kernel_size": 3, "strides": None,
+                      "upsample_mode": "deconv", "upsample_interp_mode": "linear", "upsample_align_corners": True},
             "loss": {"deep_supervision": False, "deep_supervision_weights": [1.0, 0.5, 0.25, 0.125, 0.0625],
                      "losses": None},
         },

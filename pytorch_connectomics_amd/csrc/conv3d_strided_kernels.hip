@@ -1,0 +1,388 @@
+// Dense Conv3d with a stride and dense ConvTranspose3d (gather form) on MFMA, plus their weight gradient -- the
+// resampling convolutions of the MONAI-style residual U-Net (reference models/architectures/monai_models.py:197-250:
+// ResidualUnit down layers with stride 2, `Convolution(is_transposed=True)` up layers, kernel 3, padding 1,
+// output_padding stride-1).  Same transposed implicit GEMM as conv3d_kernels.hip
+//     Y^T[o][v] = sum_{tap,c} W[o][tap][c] * f(X)^T[c][src(v, tap)]
+// only the source voxel of (output voxel v, tap) differs:
+//     strided conv      src = v * s + tap - pad                      (zero outside the input)
+//     transposed conv   src = (v + pad - tap) / s  when divisible    (else the tap contributes nothing)
+// so one kernel serves: strided forward, transposed forward, the data gradient of a strided conv (= transposed gather
+// with the forward weights read [C_out][C_in] -> [in][out]) and the data gradient of a transposed conv (= strided conv).
+// The fused pre-activation f(x) = act(a[n][c] * x + b[n][c]) is available exactly as in the stride-1 kernel.
+#include "pw_common.h"
+
+namespace pytc {
+
+struct SConvParams {
+  const void* x;
+  const void* wp;       // [mtile][tap][kgroup][lane][EPL]  (conv3d_pack_kernel layout)
+  const float* bias;
+  const float* ab;      // [N][2][C_in] or NULL
+  EpiParams e;
+  int N, C_in, C_out, KG, MTt;
+  int Do, Ho, Wo;       // output grid
+  int Di, Hi, Wi;       // input grid
+  int kd, kh, kw;
+  int sd, sh, sw;       // stride per axis
+  int pd, ph, pw;       // padding per axis
+  int transposed;
+  int act_in;
+  float act_param;
+};
+
+__device__ __forceinline__ float s_pre_act(float v, int act, float prm) {
+  switch (act) {
+    case PYTC_ACT_RELU: return fmaxf(v, 0.f);
+    case PYTC_ACT_LEAKY: return v > 0.f ? v : v * prm;
+    case PYTC_ACT_ELU: return v > 0.f ? v : prm * (__expf(v) - 1.0f);
+    default: return v;
+  }
+}
+
+// source coordinate along one axis; returns false when the tap does not touch the input
+__device__ __forceinline__ bool src_coord(int o, int t, int s, int pad, int n_in, int transposed, int& i) {
+  if (!transposed) {
+    i = o * s + t - pad;
+    return i >= 0 && i < n_in;
+  }
+  const int num = o + pad - t;
+  if (num < 0) return false;
+  i = num / s;
+  return (num - i * s) == 0 && i < n_in;
+}
+
+template <typename TI, typename TW, typename TO, int MT, int NT>
+__global__ void __launch_bounds__(256)
+conv3d_strided_kernel(SConvParams p) {
+  typedef Mma<TW> M;
+  constexpr int EPL = M::EPL;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.z;
+  const int mt0 = blockIdx.y * MT;
+  const long rps = (long)p.Do * p.Ho * p.Wo;
+  const long rps_in = (long)p.Di * p.Hi * p.Wi;
+  const long row0 = ((long)blockIdx.x * 4 + wave) * (NT * 16);
+  if (row0 >= rps) return;
+  const int r = lane & 15, kb = lane >> 4;
+
+  long orow[NT];
+  int vz[NT], vy[NT], vx[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    long o = row0 + nt * 16 + r;
+    orow[nt] = o;
+    long oc = o < rps ? o : rps - 1;
+    vx[nt] = (int)(oc % p.Wo);
+    long t = oc / p.Wo;
+    vy[nt] = (int)(t % p.Ho);
+    vz[nt] = (int)(t / p.Ho);
+  }
+  const TI* xn = reinterpret_cast<const TI*>(p.x) + (long)n * rps_in * p.C_in;
+  const bool vec_ok = (p.C_in % EPL) == 0;
+  const bool affine = p.ab != nullptr;
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const typename M::frag_t* wp = reinterpret_cast<const typename M::frag_t*>(p.wp);
+  const int ntap = p.kd * p.kh * p.kw;
+  for (int kg = 0; kg < p.KG; ++kg) {
+    const int k0 = kg * M::KSTEP + kb * EPL;
+    float av[EPL], bv[EPL];
+    if (affine) {
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        bool ok = k0 + j < p.C_in;
+        av[j] = ok ? p.ab[((long)n * 2 + 0) * p.C_in + k0 + j] : 0.f;
+        bv[j] = ok ? p.ab[((long)n * 2 + 1) * p.C_in + k0 + j] : 0.f;
+      }
+    }
+    for (int tap = 0; tap < ntap; ++tap) {
+      const int tx = tap % p.kw;
+      const int tt = tap / p.kw;
+      const int ty = tt % p.kh;
+      const int tz = tt / p.kh;
+      typename M::frag_t bf[NT];
+      bool any = false;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        int z, y, x;
+        const bool ok = src_coord(vz[nt], tz, p.sd, p.pd, p.Di, p.transposed, z) &
+                        src_coord(vy[nt], ty, p.sh, p.ph, p.Hi, p.transposed, y) &
+                        src_coord(vx[nt], tx, p.sw, p.pw, p.Wi, p.transposed, x);
+        float v[EPL];
+        if (ok) {
+          load_row_frag<TI, EPL>(xn + (((long)z * p.Hi + y) * p.Wi + x) * p.C_in, k0, p.C_in, vec_ok, v);
+          if (affine) {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) v[j] = fmaf(v[j], av[j], bv[j]);
+          }
+          if (p.act_in != PYTC_ACT_NONE) {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) v[j] = (k0 + j < p.C_in) ? s_pre_act(v[j], p.act_in, p.act_param) : 0.f;
+          }
+          any = true;
+        } else {
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) v[j] = 0.f;
+        }
+        bf[nt] = M::from_floats(v);
+      }
+      // a transposed conv touches 1/(sd*sh*sw) of the taps per voxel: skip the MFMAs of a tap no lane of the wave uses
+      if (!__any(any)) continue;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if (mt0 + mt < p.MTt) {
+          typename M::frag_t af = wp[(((long)(mt0 + mt) * ntap + tap) * p.KG + kg) * 64 + lane];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = M::mma(af, bf[nt], acc[mt][nt]);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int o0 = (mt0 + mt) * 16 + kb * 4;
+    if (o0 >= p.C_out) continue;
+    float bo[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) bo[rr] = (p.bias && o0 + rr < p.C_out) ? p.bias[o0 + rr] : 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (orow[nt] >= rps) continue;
+      float v[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) v[rr] = acc[mt][nt][rr] + bo[rr];
+      finish_and_store<TO, 4>(v, p.e, n, orow[nt], o0);
+    }
+  }
+}
+
+template <typename TW>
+__global__ void __launch_bounds__(256)
+conv3d_pack_direct_kernel(const float* __restrict__ w, int C_out, int C_in, int ntap, TW* __restrict__ packed, int KG,
+                          long total, long s_o, long s_c, int flip) {
+  typedef Mma<TW> M;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int j = (int)(i % M::EPL);
+  long t = i / M::EPL;
+  int lane = (int)(t % 64); t /= 64;
+  int kg = (int)(t % KG); t /= KG;
+  int tap = (int)(t % ntap);
+  int mt = (int)(t / ntap);
+  int o = mt * 16 + (lane & 15);
+  int k = kg * M::KSTEP + (lane >> 4) * M::EPL + j;
+  float v = 0.f;
+  if (o < C_out && k < C_in) v = w[o * s_o + k * s_c + (flip ? ntap - 1 - tap : tap)];
+  packed[i] = from_f32<TW>(v);
+}
+
+// ---- weight gradient of the strided / transposed conv (VALU, fp32 accumulation, per-slot partials, fixed-order sum) -----
+//   dW[o][k][tap] = sum_{rows r of the SMALL grid}  G[r][o] * A[src(r, tap)][k]
+// strided conv:    G = dY on the output grid (C_out channels), A = the conv input on the input grid;  src = r*s + tap - pad
+// transposed conv: G = the conv INPUT x (low-res grid, C_in_T channels), A = dY (high-res grid, C_out_T channels): the result
+//                  [C_in_T][C_out_T][tap] is ConvTranspose3d's weight layout.
+struct SwGeom { int Ds, Hs, Ws, Db, Hb, Wb, kd, kh, kw, sd, sh, sw, pd, ph, pw; };
+constexpr int SW_TO = 64, SW_TK = 64, SW_TR = 32;
+template <typename T>
+__global__ void __launch_bounds__(256)
+conv3d_wgrad_strided_kernel(const T* __restrict__ a, const T* __restrict__ gsm, float* __restrict__ dWp, long rows_total,
+                            SwGeom g, int C_k, int C_o, long rows_per_slot, int slots) {
+  __shared__ float sa[SW_TR][SW_TK + 1];
+  __shared__ float sd[SW_TR][SW_TO + 1];
+  const int slot = blockIdx.x, tap = blockIdx.z;
+  const int tiles_k = (C_k + SW_TK - 1) / SW_TK;
+  const int o_base = (blockIdx.y / tiles_k) * SW_TO, k_base = (blockIdx.y % tiles_k) * SW_TK;
+  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+  const int tz_ = tap / (g.kh * g.kw), ty_ = (tap / g.kw) % g.kh, tx_ = tap % g.kw;
+  const long vol_s = (long)g.Ds * g.Hs * g.Ws;
+  const long vol_b = (long)g.Db * g.Hb * g.Wb;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  const long r_begin = (long)slot * rows_per_slot;
+  const long r_end = r_begin + rows_per_slot < rows_total ? r_begin + rows_per_slot : rows_total;
+  for (long r0 = r_begin; r0 < r_end; r0 += SW_TR) {
+    for (int i = threadIdx.x; i < SW_TR * SW_TK; i += 256) {
+      const int rr = i / SW_TK, kk = i % SW_TK;
+      const long r = r0 + rr;
+      float v = 0.f;
+      if (r < r_end && k_base + kk < C_k) {
+        const long n = r / vol_s, rem = r % vol_s;
+        const int x = (int)(rem % g.Ws), y = (int)((rem / g.Ws) % g.Hs), z = (int)(rem / ((long)g.Ws * g.Hs));
+        const int bz = z * g.sd + tz_ - g.pd, by = y * g.sh + ty_ - g.ph, bx = x * g.sw + tx_ - g.pw;
+        if (bz >= 0 && bz < g.Db && by >= 0 && by < g.Hb && bx >= 0 && bx < g.Wb)
+          v = to_f32<T>(a[(n * vol_b + ((long)bz * g.Hb + by) * g.Wb + bx) * C_k + k_base + kk]);
+      }
+      sa[rr][kk] = v;
+    }
+    for (int i = threadIdx.x; i < SW_TR * SW_TO; i += 256) {
+      const int rr = i / SW_TO, oo = i % SW_TO;
+      const long r = r0 + rr;
+      sd[rr][oo] = (r < r_end && o_base + oo < C_o) ? to_f32<T>(gsm[r * C_o + o_base + oo]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int rr = 0; rr < SW_TR; ++rr) {
+      float dv[4], xv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { dv[i] = sd[rr][ty * 4 + i]; xv[i] = sa[rr][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(dv[i], xv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  const int taps = g.kd * g.kh * g.kw;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int o = o_base + ty * 4 + i;
+    if (o >= C_o) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k_base + tx * 4 + j;
+      if (k < C_k) dWp[(((long)slot * taps + tap) * C_o + o) * C_k + k] = acc[i][j];
+    }
+  }
+}
+
+// out[i] = sum_s part[s][i], slots in order within 16 interleaved lanes, then the lanes in order (fixed tree)
+__global__ void __launch_bounds__(256)
+sw_reduce_slots_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int slots) {
+  __shared__ float sm[16][17];
+  const int e = threadIdx.x & 15, j = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + e;
+  float a = 0.f;
+  if (i < n)
+    for (int s = j; s < slots; s += 16) a += part[(long)s * n + i];
+  sm[j][e] = a;
+  __syncthreads();
+  if (j == 0 && i < n) {
+    float t = sm[0][e];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += sm[q][e];
+    out[i] = t;
+  }
+}
+
+template <typename TI, typename TW, typename TO>
+static void launch_sconv(const SConvParams& p, hipStream_t s) {
+  constexpr int NT = 4;
+  const long rps = (long)p.Do * p.Ho * p.Wo;
+  const int MT = p.MTt >= 4 ? 4 : (p.MTt >= 2 ? 2 : 1);
+  dim3 grid((unsigned)((rps + 4L * NT * 16 - 1) / (4L * NT * 16)), (unsigned)((p.MTt + MT - 1) / MT), (unsigned)p.N);
+  dim3 block(256);
+  switch (MT) {
+    case 1: hipLaunchKernelGGL((conv3d_strided_kernel<TI, TW, TO, 1, NT>), grid, block, 0, s, p); break;
+    case 2: hipLaunchKernelGGL((conv3d_strided_kernel<TI, TW, TO, 2, NT>), grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL((conv3d_strided_kernel<TI, TW, TO, 4, NT>), grid, block, 0, s, p); break;
+  }
+}
+
+static int sw_slots(long rows_total) {
+  const long s = rows_total / 4096;
+  return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
+}
+
+}  // namespace pytc
+
+using namespace pytc;
+
+static int s_kstep(int dtype) { return dtype == PYTC_BF16 ? 32 : 16; }
+
+extern "C" int64_t pytc_conv3d_direct_packed_elems(int C_out, int C_in, int kd, int kh, int kw, int dtype) {
+  if (C_out < 1 || C_in < 1 || kd < 1 || kh < 1 || kw < 1 || (dtype != PYTC_F32 && dtype != PYTC_BF16)) return -1;
+  const int ks = s_kstep(dtype);
+  return (int64_t)((C_out + 15) / 16) * 16 * kd * kh * kw * ((C_in + ks - 1) / ks) * ks;
+}
+
+extern "C" int pytc_conv3d_pack_weight_direct(const float* w, int C_out, int C_in, int kd, int kh, int kw, int64_t s_o,
+                                              int64_t s_c, int flip, void* packed, int dtype, void* stream) {
+  PYTC_REQUIRE(w && packed, "conv3d_pack_weight_direct: null pointer");
+  const long total = pytc_conv3d_direct_packed_elems(C_out, C_in, kd, kh, kw, dtype);
+  PYTC_REQUIRE(total > 0, "conv3d_pack_weight_direct: bad arguments");
+  const int KG = (C_in + s_kstep(dtype) - 1) / s_kstep(dtype);
+  dim3 grid(ceil_div(total, 256)), block(256);
+  if (dtype == PYTC_BF16)
+    hipLaunchKernelGGL(conv3d_pack_direct_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, w, C_out, C_in, kd * kh * kw,
+                       (bf16_t*)packed, KG, total, (long)s_o, (long)s_c, flip);
+  else
+    hipLaunchKernelGGL(conv3d_pack_direct_kernel<float>, grid, block, 0, (hipStream_t)stream, w, C_out, C_in, kd * kh * kw,
+                       (float*)packed, KG, total, (long)s_o, (long)s_c, flip);
+  PYTC_LAUNCH_CHECK("conv3d_pack_weight_direct");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_conv3d_strided_fwd(const pytc_conv3d_args* a, const int32_t* in_dims, const int32_t* stride,
+                                       const int32_t* pad, int transposed, void* stream) {
+  PYTC_REQUIRE(a && a->x && a->w_packed && a->y && in_dims && stride && pad, "conv3d_strided: null pointer");
+  PYTC_REQUIRE(a->N >= 1 && a->D >= 1 && a->H >= 1 && a->W >= 1 && a->C_in >= 1 && a->C_out >= 1, "conv3d_strided: bad shape");
+  PYTC_REQUIRE(in_dims[0] >= 1 && in_dims[1] >= 1 && in_dims[2] >= 1 && stride[0] >= 1 && stride[1] >= 1 && stride[2] >= 1 &&
+               pad[0] >= 0 && pad[1] >= 0 && pad[2] >= 0, "conv3d_strided: bad geometry");
+  PYTC_REQUIRE(a->dtype == PYTC_F32 || a->dtype == PYTC_BF16, "conv3d_strided: bad dtype");
+  PYTC_REQUIRE(a->res_mode == PYTC_RES_NONE || (a->res_mode == PYTC_RES_ADD && a->res), "conv3d_strided: bad residual");
+  SConvParams p;
+  p.x = a->x; p.wp = a->w_packed; p.bias = a->bias; p.ab = a->ab;
+  p.N = a->N; p.Do = a->D; p.Ho = a->H; p.Wo = a->W; p.C_in = a->C_in; p.C_out = a->C_out;
+  p.Di = in_dims[0]; p.Hi = in_dims[1]; p.Wi = in_dims[2];
+  p.KG = (a->C_in + s_kstep(a->dtype) - 1) / s_kstep(a->dtype);
+  p.MTt = (a->C_out + 15) / 16;
+  p.kd = a->kd; p.kh = a->kh; p.kw = a->kw;
+  p.sd = stride[0]; p.sh = stride[1]; p.sw = stride[2];
+  p.pd = pad[0]; p.ph = pad[1]; p.pw = pad[2];
+  p.transposed = transposed ? 1 : 0;
+  p.act_in = a->act_in; p.act_param = a->act_param;
+  p.e.res = a->res; p.e.res_low = nullptr; p.e.res_bias = nullptr; p.e.y = a->y;
+  p.e.rps_out = (long)a->D * a->H * a->W; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode;
+  p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->dtype == PYTC_F32) launch_sconv<float, float, float>(p, s);
+  else launch_sconv<bf16_t, bf16_t, bf16_t>(p, s);
+  PYTC_LAUNCH_CHECK("conv3d_strided");
+  return PYTC_OK;
+}
+
+extern "C" int64_t pytc_conv3d_wgrad_strided_ws_elems(int N, const int32_t* small_dims, int C_k, int C_o,
+                                                      const int32_t* kernel) {
+  if (!small_dims || !kernel || N < 1) return -1;
+  const long rows_total = (long)N * small_dims[0] * small_dims[1] * small_dims[2];
+  return (int64_t)sw_slots(rows_total) * kernel[0] * kernel[1] * kernel[2] * C_o * C_k;
+}
+
+extern "C" int pytc_conv3d_wgrad_strided(const void* big, const void* small, float* dW, float* workspace, int N,
+                                         const int32_t* big_dims, const int32_t* small_dims, int C_k, int C_o,
+                                         const int32_t* kernel, const int32_t* stride, const int32_t* pad, int dtype,
+                                         void* stream) {
+  PYTC_REQUIRE(big && small && dW && workspace && big_dims && small_dims && kernel && stride && pad && N >= 1,
+               "conv3d_wgrad_strided: bad arguments");
+  SwGeom g{small_dims[0], small_dims[1], small_dims[2], big_dims[0], big_dims[1], big_dims[2], kernel[0], kernel[1], kernel[2],
+           stride[0], stride[1], stride[2], pad[0], pad[1], pad[2]};
+  const long rows_total = (long)N * g.Ds * g.Hs * g.Ws;
+  const int slots = sw_slots(rows_total);
+  const long rps = (rows_total + slots - 1) / slots;
+  const int taps = g.kd * g.kh * g.kw;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(slots, ((C_o + SW_TO - 1) / SW_TO) * ((C_k + SW_TK - 1) / SW_TK), taps), block(256);
+  if (dtype == PYTC_BF16)
+    hipLaunchKernelGGL(conv3d_wgrad_strided_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)big, (const bf16_t*)small,
+                       workspace, rows_total, g, C_k, C_o, rps, slots);
+  else if (dtype == PYTC_F32)
+    hipLaunchKernelGGL(conv3d_wgrad_strided_kernel<float>, grid, block, 0, s, (const float*)big, (const float*)small,
+                       workspace, rows_total, g, C_k, C_o, rps, slots);
+  else {
+    set_error("conv3d_wgrad_strided: bad dtype %d", dtype);
+    return PYTC_ERR_INVALID;
+  }
+  const long nW = (long)taps * C_o * C_k;
+  hipLaunchKernelGGL(sw_reduce_slots_kernel, dim3(ceil_div(nW, 16)), dim3(256), 0, s, workspace, dW, nW, slots);
+  PYTC_LAUNCH_CHECK("conv3d_wgrad_strided");
+  return PYTC_OK;
+}

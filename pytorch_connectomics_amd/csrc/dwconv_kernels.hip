@@ -736,9 +736,12 @@ static bool march_ok(int D, int H, int W, int C, int K, int stride, int dtype, i
 static void make_march(DwMarch& t, int N, int D, int H, int W, int C) {
   t.N = N; t.D = D; t.H = H; t.W = W; t.C = C;
   t.ty = (H + TILE_Y - 1) / TILE_Y; t.tx = (W + TILE_X - 1) / TILE_X;
-  // z-chunks: enough workgroups to fill 256 CUs x 2 several times over, chunks >= 14 planes (halo <= 14 %)
-  const long fp = (long)t.ty * t.tx * (C / MARCH_CG) * N;
-  int nzc = (int)(((long)tuning_get("dwconv_march_wgs", 4096) + fp - 1) / fp);
+  // z-chunks: enough workgroups PER SAMPLE to fill the chip (>= 1024: 4 per CU at batch 1), chunks >= 14 planes (halo <= 14 %).
+  // The split must not depend on N: the statistics partials (one per workgroup) are summed in slot order, so a sample's
+  // mean / rstd -- and with them its bf16 prediction -- would otherwise change with the batch it happens to travel in
+  // (chunked == whole-volume and rank-sharded == single-process exactness rely on batch-invariant windows).
+  const long fp = (long)t.ty * t.tx * (C / MARCH_CG);
+  int nzc = (int)(((long)tuning_get("dwconv_march_wgs", 1024) + fp - 1) / fp);
   if (nzc < 1) nzc = 1;
   int maxc = D / 14;
   if (maxc < 1) maxc = 1;

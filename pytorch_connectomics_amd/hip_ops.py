@@ -797,3 +797,70 @@ def dwconv3d_bwd_data(dy: torch.Tensor, w_taps: torch.Tensor, xdims, *, K: int, 
     _run(f"dwconv3d_bwd_data[C{Cc}_k{K}_s{stride}]", _nbytes(dy, dx), nat.lib().pytc_dwconv3d_bwd_data, _p(dy), _p(w_taps),
          _p(dx), N, _i3(xdims), _i3(dy.shape[1:4]), Cc, K, stride, dtype_code(dy.dtype), _stream())
     return dx
+
+
+# ---- strided / transposed dense conv (MONAI-style residual U-Net) ------------------------------------------------------
+def conv3d_pack_weight_direct(w: torch.Tensor, dtype: torch.dtype, *, layout: str) -> torch.Tensor:
+    """fp32 5-D weight -> packed image for conv3d_strided.  layout:
+      'conv'      w is nn.Conv3d [C_out][C_in][k]: forward of a (strided) conv
+      'convT'     w is nn.ConvTranspose3d [C_in][C_out][k]: forward of the transposed conv (gather form)
+      'conv_dgrad'  w is nn.Conv3d [C_out][C_in][k]: data gradient of that conv (transposed gather, C_out -> C_in)
+      'convT_dgrad' w is nn.ConvTranspose3d [C_in][C_out][k]: data gradient of that transposed conv (strided conv, C_out -> C_in)"""
+    _dev(w, "w")
+    a, b, kd, kh, kw = w.shape
+    ntap = kd * kh * kw
+    if layout == "conv":
+        co, ci, s_o, s_c = a, b, b * ntap, ntap
+    elif layout == "convT":
+        co, ci, s_o, s_c = b, a, ntap, b * ntap
+    elif layout == "conv_dgrad":          # out channels of the gradient conv = C_in (b), its in channels = C_out (a)
+        co, ci, s_o, s_c = b, a, ntap, b * ntap
+    elif layout == "convT_dgrad":         # out channels = C_in_T (a), in channels = C_out_T (b)
+        co, ci, s_o, s_c = a, b, b * ntap, ntap
+    else:
+        raise ValueError(f"unknown weight layout {layout!r}")
+    n = nat.lib().pytc_conv3d_direct_packed_elems(co, ci, kd, kh, kw, dtype_code(dtype))
+    packed = torch.empty((n,), dtype=dtype, device=w.device)
+    _run("conv3d_pack_weight_direct", _nbytes(w, packed), nat.lib().pytc_conv3d_pack_weight_direct, _p(w), co, ci, kd, kh, kw,
+         s_o, s_c, 0, _p(packed), dtype_code(dtype), _stream())
+    return packed
+
+
+def conv3d_strided(x: torch.Tensor, w_packed: torch.Tensor, *, c_out: int, kernel, stride, pad, out_dims, transposed: bool,
+                   bias: Optional[torch.Tensor] = None, ab: Optional[torch.Tensor] = None, act_in: int = nat.ACT_NONE,
+                   act_param: float = 0.0, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x (N,Di,Hi,Wi,C_in) -> (N,*out_dims,C_out): strided conv (transposed=False) or ConvTranspose3d in gather form."""
+    _dev(x, "x")
+    N, Di, Hi, Wi, ci = x.shape
+    Do, Ho, Wo = (int(v) for v in out_dims)
+    y = torch.empty((N, Do, Ho, Wo, c_out), dtype=x.dtype, device=x.device)
+    a = nat.Conv3dArgs()
+    a.x, a.w_packed, a.y = x.data_ptr(), w_packed.data_ptr(), y.data_ptr()
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.ab = ab.data_ptr() if ab is not None else None
+    a.res = res.data_ptr() if res is not None else None
+    a.N, a.D, a.H, a.W, a.C_in, a.C_out = N, Do, Ho, Wo, ci, c_out
+    a.kd, a.kh, a.kw = (int(v) for v in kernel)
+    a.act_in, a.act_param = int(act_in), float(act_param)
+    a.res_mode = nat.RES_ADD if res is not None else nat.RES_NONE
+    a.dtype = dtype_code(x.dtype)
+    tag = "convT3d" if transposed else "conv3d_s"
+    _run(f"{tag}_fwd[{ci}->{c_out},k{a.kd}{a.kh}{a.kw}]", _nbytes(x, y), nat.lib().pytc_conv3d_strided_fwd, C.byref(a),
+         _i3((Di, Hi, Wi)), _i3(stride), _i3(pad), 1 if transposed else 0, _stream())
+    return y
+
+
+def conv3d_wgrad_strided(big: torch.Tensor, small: torch.Tensor, kernel, stride, pad) -> torch.Tensor:
+    """dW fp32 (C_small, C_big, kd, kh, kw) = sum_r small[r][o] * big[r*stride + tap - pad][k] (see pytc_hip.h)."""
+    _dev(big, "big"); _dev(small, "small")
+    N = big.shape[0]
+    ck, co = big.shape[-1], small.shape[-1]
+    kd, kh, kw = (int(v) for v in kernel)
+    taps = kd * kh * kw
+    n_ws = nat.lib().pytc_conv3d_wgrad_strided_ws_elems(N, _i3(small.shape[1:4]), ck, co, _i3((kd, kh, kw)))
+    ws = torch.empty((n_ws,), dtype=torch.float32, device=big.device)
+    dW = torch.empty((taps, co, ck), dtype=torch.float32, device=big.device)
+    _run(f"conv3d_wgrad_strided[{ck}x{co},k{kd}{kh}{kw}]", taps * _nbytes(big, small), nat.lib().pytc_conv3d_wgrad_strided,
+         _p(big), _p(small), _p(dW), _p(ws), N, _i3(big.shape[1:4]), _i3(small.shape[1:4]), ck, co, _i3((kd, kh, kw)),
+         _i3(stride), _i3(pad), dtype_code(big.dtype), _stream())
+    return dW.view(kd, kh, kw, co, ck).permute(3, 4, 0, 1, 2).contiguous()

@@ -28,6 +28,29 @@ def _rows(x):
     return x.numel() // (x.shape[0] * x.shape[-1])
 
 
+# The kernels take the PReLU slope by value.  Reading a device scalar costs a stream synchronisation, so the values are
+# cached per parameter version and a model can refresh all of its (stale) slopes with ONE transfer per forward.
+_PRELU_VALUES: dict = {}
+
+
+def prelu_value(w: torch.Tensor) -> float:
+    key, ver = id(w), w._version
+    hit = _PRELU_VALUES.get(key)
+    if hit is None or hit[0] != ver:
+        hit = (ver, float(w.detach().reshape(-1)[0]))
+        _PRELU_VALUES[key] = hit
+    return hit[1]
+
+
+def prefetch_prelu(weights) -> None:
+    stale = [w for w in weights if _PRELU_VALUES.get(id(w), (None,))[0] != w._version]
+    if not stale:
+        return
+    vals = torch.stack([w.detach().reshape(-1)[0].float() for w in stale]).tolist()      # one device -> host copy
+    for w, v in zip(stale, vals):
+        _PRELU_VALUES[id(w)] = (w._version, float(v))
+
+
 class NormActFn(torch.autograd.Function):
     """a = act(norm(x)) on channels-last x.  kind in {none, group, instance, batch}."""
 
@@ -36,7 +59,7 @@ class NormActFn(torch.autograd.Function):
         N, C = x.shape[0], x.shape[-1]
         rows = _rows(x)
         act = _ACT[act_kind]
-        prm = float(prelu_w.detach().reshape(-1)[0]) if act_kind == "prelu" else float(act_prm)
+        prm = prelu_value(prelu_w) if act_kind == "prelu" else float(act_prm)
         ab = mr = None
         mode = kind
         if kind in ("group", "instance"):
@@ -172,6 +195,75 @@ class UpsampleFn(torch.autograd.Function):
         return ops.dwconv3d_generic(dy.contiguous(), taps, kernel, factor, pad, in_dims), None, None, None, None
 
 
+class ResampleConv3dFn(torch.autograd.Function):
+    """Dense conv with a stride, or dense ConvTranspose3d (k, stride s, padding p, output_padding s - 1), channels-last -- the
+    resampling convolutions of the MONAI-style U-Net (models/architectures/monai_models.py).  stride 1 takes the stride-1
+    kernels of Conv3dFn.  Backward: data gradient of a strided conv = the transposed gather with the same weights, that of a
+    transposed conv = the strided conv; weight gradient = `conv3d_wgrad_strided` with the roles of the two grids swapped
+    for the transposed case (csrc/conv3d_strided_kernels.hip)."""
+
+    @staticmethod
+    def forward(ctx, a, weight, bias, stride: int, pad: int, transposed: bool):
+        ks = tuple(int(k) for k in weight.shape[2:])
+        s3, p3 = (int(stride),) * 3, (int(pad),) * 3
+        plain = (not transposed) and stride == 1 and all(pad == k // 2 for k in ks)
+        w32 = weight.detach().float().contiguous()
+        if plain:
+            y = ops.conv3d(a, ops.conv3d_pack_weight(w32, a.dtype), c_out=weight.shape[0], kernel=ks, bias=_f(bias))
+        elif transposed:
+            out_dims = tuple((int(d) - 1) * stride - 2 * pad + k + (stride - 1) for d, k in zip(a.shape[1:4], ks))
+            y = ops.conv3d_strided(a, ops.conv3d_pack_weight_direct(w32, a.dtype, layout="convT"), c_out=weight.shape[1],
+                                   kernel=ks, stride=s3, pad=p3, out_dims=out_dims, transposed=True, bias=_f(bias))
+        else:
+            out_dims = tuple((int(d) + 2 * pad - k) // stride + 1 for d, k in zip(a.shape[1:4], ks))
+            y = ops.conv3d_strided(a, ops.conv3d_pack_weight_direct(w32, a.dtype, layout="conv"), c_out=weight.shape[0],
+                                   kernel=ks, stride=s3, pad=p3, out_dims=out_dims, transposed=False, bias=_f(bias))
+        ctx.save_for_backward(a, weight)
+        ctx.meta = (ks, s3, p3, bool(transposed), plain, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, weight = ctx.saved_tensors
+        ks, s3, p3, transposed, plain, has_bias = ctx.meta
+        dy = dy.contiguous()
+        if dy.dtype != a.dtype:
+            dy = dy.to(a.dtype)
+        w32 = weight.detach().float().contiguous()
+        in_dims = tuple(int(v) for v in a.shape[1:4])
+        da = None
+        if plain:
+            if ctx.needs_input_grad[0]:
+                da = ops.conv3d(dy, ops.conv3d_pack_weight_dgrad(w32, dy.dtype), c_out=weight.shape[1], kernel=ks)
+            dW = ops.conv3d_wgrad(a, dy, ks)
+        elif transposed:
+            if ctx.needs_input_grad[0]:
+                da = ops.conv3d_strided(dy, ops.conv3d_pack_weight_direct(w32, dy.dtype, layout="convT_dgrad"),
+                                        c_out=weight.shape[0], kernel=ks, stride=s3, pad=p3, out_dims=in_dims, transposed=False)
+            dW = ops.conv3d_wgrad_strided(dy, a, ks, s3, p3)          # (C_in_T, C_out_T, k): ConvTranspose3d layout
+        else:
+            if ctx.needs_input_grad[0]:
+                da = ops.conv3d_strided(dy, ops.conv3d_pack_weight_direct(w32, dy.dtype, layout="conv_dgrad"),
+                                        c_out=weight.shape[1], kernel=ks, stride=s3, pad=p3, out_dims=in_dims, transposed=True)
+            dW = ops.conv3d_wgrad_strided(a, dy, ks, s3, p3)          # (C_out, C_in, k)
+        db = ops.channel_stats(dy)[:, :, 0].sum((0, 1)).to(weight.dtype) if has_bias else None
+        return da, dW.to(weight.dtype), db, None, None, None
+
+
+class AddFn(torch.autograd.Function):
+    """y = a + b (the residual sum of a MONAI ResidualUnit) with the HIP add kernel; both gradients are dy."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        y = a.clone()
+        ops.add_(y, b.contiguous() if b.dtype == a.dtype else b.to(a.dtype).contiguous())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
 # ---- module-level composition ----------------------------------------------------------------------------------------
 def _norm_act(na, x):
     m = na.norm
@@ -229,4 +321,4 @@ def rsunet_train_forward(model, x_cl: torch.Tensor, compute_dtype: torch.dtype):
     return out
 
 
-__all__ = ["NormActFn", "Conv3dFn", "MaxPoolFn", "UpsampleFn", "rsunet_train_forward"]
+__all__ = ["NormActFn", "Conv3dFn", "ResampleConv3dFn", "AddFn", "MaxPoolFn", "UpsampleFn", "rsunet_train_forward"]

@@ -1,0 +1,179 @@
+"""GPU parity of the MONAI-style residual U-Net (BASELINE configs[4], reference monai_models.py:197-250) and of its
+resampling-convolution kernels (csrc/conv3d_strided_kernels.hip) against PyTorch-CPU fp32 / the CPU oracle
+(oracle/monai_unet_oracle.py: parity unpinned w.r.t. the un-vendored `monai` package)."""
+from types import SimpleNamespace as NS
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import monai_unet_oracle as UO
+
+pytestmark = pytest.mark.gpu
+
+
+def _cl(x):
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _cf(x):
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+@pytest.mark.parametrize("ci,co,dims", [(1, 32, (8, 12, 16)), (32, 64, (6, 10, 12)), (20, 24, (5, 9, 7))])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+def test_strided_and_transposed_conv_forward(ci, co, dims, dt, tol):
+    from pytorch_connectomics_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(ci * 100 + co)
+    x = torch.randn(2, ci, *dims, generator=g)
+    w = torch.randn(co, ci, 3, 3, 3, generator=g) * 0.1
+    b = torch.randn(co, generator=g)
+    ref = F.conv3d(x, w, b, stride=2, padding=1)
+    xd = _cl(x).cuda().to(dt)
+    y = ops.conv3d_strided(xd, ops.conv3d_pack_weight_direct(w.cuda(), dt, layout="conv"), c_out=co, kernel=(3, 3, 3),
+                           stride=(2, 2, 2), pad=(1, 1, 1), out_dims=ref.shape[2:], transposed=False, bias=b.cuda())
+    err = (_cf(y.float().cpu()) - ref).abs().max() / ref.abs().max()
+    assert float(err) < tol
+    # ConvTranspose3d(k3, s2, p1, output_padding 1): exact doubling
+    wt = torch.randn(ci, co, 3, 3, 3, generator=g) * 0.1
+    reft = F.conv_transpose3d(x, wt, b, stride=2, padding=1, output_padding=1)
+    assert tuple(reft.shape[2:]) == tuple(2 * d for d in dims)
+    yt = ops.conv3d_strided(xd, ops.conv3d_pack_weight_direct(wt.cuda(), dt, layout="convT"), c_out=co, kernel=(3, 3, 3),
+                            stride=(2, 2, 2), pad=(1, 1, 1), out_dims=reft.shape[2:], transposed=True, bias=b.cuda())
+    err = (_cf(yt.float().cpu()) - reft).abs().max() / reft.abs().max()
+    assert float(err) < tol
+
+
+@pytest.mark.parametrize("transposed", [False, True])
+@pytest.mark.parametrize("ci,co", [(1, 16), (24, 40), (64, 8)])
+def test_resample_conv_autograd_matches_torch(transposed, ci, co):
+    """ResampleConv3dFn forward + data / weight / bias gradients vs torch autograd of the same op (fp32)."""
+    from pytorch_connectomics_amd.training.rsunet_autograd import ResampleConv3dFn
+    g = torch.Generator().manual_seed(7 + ci + co)
+    x = torch.randn(2, ci, 6, 8, 10, generator=g, requires_grad=True)
+    w = (torch.randn(*((ci, co) if transposed else (co, ci)), 3, 3, 3, generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(co, generator=g, requires_grad=True)
+    if transposed:
+        ref = F.conv_transpose3d(x, w, b, stride=2, padding=1, output_padding=1)
+    else:
+        ref = F.conv3d(x, w, b, stride=2, padding=1)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    xd = _cl(x.detach()).cuda().requires_grad_(True)
+    wd = w.detach().cuda().requires_grad_(True)
+    bd = b.detach().cuda().requires_grad_(True)
+    y = ResampleConv3dFn.apply(xd, wd, bd, 2, 1, transposed)
+    assert tuple(y.shape) == (2,) + tuple(ref.shape[2:]) + (co,)
+    y.backward(_cl(gy).cuda())
+    rel = lambda a, r: float((a - r).abs().max() / r.abs().max().clamp_min(1e-8))
+    assert rel(_cf(y.detach().cpu()), ref.detach()) < 2e-5
+    assert rel(_cf(xd.grad.cpu()), x.grad) < 2e-5
+    assert rel(wd.grad.cpu(), w.grad) < 5e-5
+    assert rel(bd.grad.cpu(), b.grad) < 2e-5
+
+
+def _cfg(filters, norm="batch", size=(16, 32, 32), in_ch=1, out_ch=2, res_units=2):
+    return NS(model=NS(arch=NS(type="monai_unet"), in_channels=in_ch, out_channels=out_ch, input_size=list(size),
+                       monai=NS(filters=list(filters), num_res_units=res_units, kernel_size=3, norm=norm, num_groups=2,
+                                dropout=0.0, upsample_mode="deconv")))
+
+
+def _build(cfg, seed=0):
+    from pytorch_connectomics_amd.models import build_model
+    torch.manual_seed(seed)
+    m = build_model(cfg)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():       # a "trained" state: non-trivial norm affine, running statistics and PReLU slopes
+        for n, p in m.named_parameters():
+            if n.endswith("adn.N.weight") or n.endswith("adn.N.bias"):
+                p.add_(0.2 * torch.randn(p.shape, generator=g))
+            if n.endswith("adn.A.weight"):
+                p.copy_(0.1 + 0.3 * torch.rand(p.shape, generator=g))
+        for n, b in m.named_buffers():
+            if n.endswith("running_mean"):
+                b.copy_(0.3 * torch.randn(b.shape, generator=g))
+            if n.endswith("running_var"):
+                b.copy_(0.5 + torch.rand(b.shape, generator=g))
+    return m
+
+
+@pytest.mark.parametrize("filters,norm,size", [((8, 16, 32), "batch", (16, 32, 32)), ((8, 16), "instance", (8, 16, 24)),
+                                               ((16, 24, 32), "group", (16, 16, 32)),
+                                               ((32, 64, 128, 256), "batch", (24, 64, 64))])
+def test_monai_unet_forward_matches_oracle(filters, norm, size):
+    cfg = _cfg(filters, norm, size)
+    m = _build(cfg)
+    st = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.rand(2, 1, *size, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        ref = UO.forward(st, x, n_levels=len(filters), norm=norm, num_groups=2)
+        m = m.cuda().eval()
+        got = m(x.cuda()).cpu()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            got16 = m(x.cuda()).float().cpu()
+    assert got.shape == ref.shape == (2, 2) + tuple(size) and got.dtype == torch.float32
+    assert (torch.sigmoid(got) - torch.sigmoid(ref)).abs().max() < 1e-3
+    torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-3 * float(ref.abs().max()))
+    assert (torch.sigmoid(got16) - torch.sigmoid(ref)).abs().max() < 6e-2
+    # state-dict vocabulary of monai.networks.nets.UNet behind the reference wrapper
+    keys = set(st)
+    assert "model.model.0.conv.unit0.conv.weight" in keys and "model.model.0.residual.weight" in keys
+    assert "model.model.2.0.conv.weight" in keys and "model.model.2.1.conv.unit0.conv.weight" in keys
+    assert not any(k.startswith("model.model.2.1.conv.unit0.adn") for k in keys)       # top level: last_conv_only
+
+
+def test_monai_unet_training_step_matches_oracle_autograd():
+    """train() mode (BatchNorm batch statistics): loss, input gradient and every parameter gradient vs torch autograd through
+    the oracle; running buffers updated like nn.BatchNorm3d."""
+    cfg = _cfg((8, 16, 32), "batch", (16, 16, 32), out_ch=1)
+    m = _build(cfg, seed=4)
+    st = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.rand(2, 1, 16, 16, 32, generator=torch.Generator().manual_seed(5))
+    tgt = (torch.rand(2, 1, 16, 16, 32, generator=torch.Generator().manual_seed(6)) > 0.7).float()
+    params = {k: v.clone().requires_grad_(True) for k, v in st.items() if v.dtype.is_floating_point and "running" not in k}
+    full = dict(st)
+    full.update(params)
+    ref_loss = F.binary_cross_entropy_with_logits(UO.forward(full, x, n_levels=3, norm="batch", training=True), tgt)
+    ref_loss.backward()
+    m = m.cuda().train()
+    out = m(x.cuda())
+    loss = F.binary_cross_entropy_with_logits(out, tgt.cuda())
+    loss.backward()
+    assert abs(float(loss) - float(ref_loss)) < 1e-4
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for k, p in params.items():
+        gh = named[k].grad
+        assert gh is not None, k
+        scale = float(p.grad.abs().max().clamp_min(1e-6))
+        worst = max(worst, float((gh.cpu() - p.grad).abs().max()) / scale)
+    assert worst < 5e-3, worst
+    # running statistics moved away from the stored ones by the momentum blend
+    rm = m.state_dict()["model.model.0.conv.unit0.adn.N.running_mean"].cpu()
+    assert not torch.allclose(rm, st["model.model.0.conv.unit0.adn.N.running_mean"])
+    assert int(m.state_dict()["model.model.0.conv.unit0.adn.N.num_batches_tracked"]) == 1
+
+
+def test_monai_unet_rejects_sizes_the_reference_cannot_run():
+    m = _build(_cfg((8, 16, 32, 64), "batch")).cuda().eval()
+    with pytest.raises(ValueError, match="divisible"):
+        with torch.no_grad():
+            m(torch.rand(1, 1, 20, 32, 32).cuda())         # 20 -> 10 -> 5 -> 3 -> up 6 != 5: torch.cat would fail in MONAI
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.rand(1, 1, 16, 32, 32))
+
+
+def test_monai_unet_in_sliding_window_engine():
+    from oracle import window_oracle as WO
+    from pytorch_connectomics_amd.inference.window import EagerSlidingWindowEngine
+    cfg = _cfg((8, 16), "batch", (16, 32, 32), out_ch=1)
+    m = _build(cfg, seed=9)
+    st = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.cuda().eval()
+    vol = torch.rand(1, 1, 24, 40, 48, generator=torch.Generator().manual_seed(2))
+    eng = EagerSlidingWindowEngine(roi_size=(16, 32, 32), sw_batch_size=3, overlap=0.5, mode="bump", padding_mode="constant",
+                                   cval=0.0)
+    got = eng(vol.cuda(), m).cpu()
+    ref = WO.eager_sliding_window(vol, lambda t: UO.forward(st, t, n_levels=2, norm="batch"), roi=(16, 32, 32), overlap=0.5,
+                                  mode="bump", sw_batch_size=3)
+    assert (torch.sigmoid(got) - torch.sigmoid(ref)).abs().max() < 1e-3
