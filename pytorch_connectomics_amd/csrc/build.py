@@ -42,6 +42,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     stamp = LIB_DIR / "build.sha256"
     dig = _digest()
     if not force and LIB.exists() and stamp.exists() and stamp.read_text().strip() == dig:
+        build_h5(verbose=verbose)
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
@@ -60,7 +61,33 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     stamp.write_text(dig)
+    build_h5(verbose=verbose)
     return LIB
+
+
+H5_LIB = LIB_DIR / "libpytc_h5.so"
+H5_SRC = CSRC / "host" / "h5io.c"
+
+
+def build_h5(verbose: bool = True):
+    """libpytc_h5.so: the C shim over the image's HDF5 C library (csrc/host/h5io.c).  Optional: when no hdf5.h / libhdf5 is
+    found the engine keeps its .npy artifact layout (utils/h5lite.available() is False)."""
+    for root in (os.environ.get("HDF5_ROOT"), "/opt/conda", "/usr"):
+        if root and (Path(root) / "include" / "hdf5.h").exists() and list((Path(root) / "lib").glob("libhdf5.so*")):
+            break
+    else:
+        if verbose:
+            print("[build] HDF5 headers not found: libpytc_h5.so skipped")
+        return None
+    if H5_LIB.exists() and H5_LIB.stat().st_mtime >= H5_SRC.stat().st_mtime:
+        return H5_LIB
+    LIB_DIR.mkdir(exist_ok=True)
+    cmd = ["gcc", "-O2", "-fPIC", "-shared", f"-I{root}/include", str(H5_SRC), f"-L{root}/lib", "-lhdf5",
+           f"-Wl,-rpath,{root}/lib", "-o", str(H5_LIB)]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return H5_LIB
 
 
 if __name__ == "__main__":

@@ -1,0 +1,263 @@
+/* libpytc_h5.so -- a small C shim over the HDF5 C library (libhdf5 1.10, shipped under /opt/conda in this image; h5py is
+ * not).  It is the native IO layer under pytorch_connectomics_amd/utils/h5lite.py, which offers the slice of the h5py API
+ * the reference's inference writers / readers use (connectomics/inference/artifact.py:141-240 `main` CZYX dataset + JSON
+ * attrs; inference/chunked.py:317-434 per-chunk `chunk_{key}.h5` files streamed into the stitched artifact by z slabs;
+ * inference/lazy.py:456-917 hyperslab reads of the source volume), so the files this engine writes are real HDF5,
+ * readable by h5py / the reference's decoders, and the reference's HDF5 volumes are readable here.
+ * Plain C ABI: int64 handles, int status (0 ok), last error text per thread. */
+#include <hdf5.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+
+static __thread char g_err[512];
+static void set_err(const char* what) { snprintf(g_err, sizeof(g_err), "%s", what); }
+const char* pytc_h5_last_error(void) { return g_err; }
+
+/* dtype codes shared with h5lite.py */
+enum { DT_U8 = 0, DT_I8, DT_U16, DT_I16, DT_U32, DT_I32, DT_U64, DT_I64, DT_F16, DT_F32, DT_F64, DT_BOOL };
+
+static hid_t make_f16(void) {
+  hid_t t = H5Tcopy(H5T_IEEE_F32LE);
+  H5Tset_fields(t, 15, 10, 5, 0, 10);
+  H5Tset_size(t, 2);
+  H5Tset_ebias(t, 15);
+  return t;
+}
+static hid_t make_bool(void) {          /* h5py's mapping of numpy bool: enum {FALSE = 0, TRUE = 1} over int8 */
+  hid_t t = H5Tenum_create(H5T_NATIVE_INT8);
+  int8_t v = 0; H5Tenum_insert(t, "FALSE", &v);
+  v = 1; H5Tenum_insert(t, "TRUE", &v);
+  return t;
+}
+/* returns a NEW type id the caller closes */
+static hid_t type_of(int code) {
+  switch (code) {
+    case DT_U8: return H5Tcopy(H5T_NATIVE_UINT8);
+    case DT_I8: return H5Tcopy(H5T_NATIVE_INT8);
+    case DT_U16: return H5Tcopy(H5T_NATIVE_UINT16);
+    case DT_I16: return H5Tcopy(H5T_NATIVE_INT16);
+    case DT_U32: return H5Tcopy(H5T_NATIVE_UINT32);
+    case DT_I32: return H5Tcopy(H5T_NATIVE_INT32);
+    case DT_U64: return H5Tcopy(H5T_NATIVE_UINT64);
+    case DT_I64: return H5Tcopy(H5T_NATIVE_INT64);
+    case DT_F16: return make_f16();
+    case DT_F32: return H5Tcopy(H5T_NATIVE_FLOAT);
+    case DT_F64: return H5Tcopy(H5T_NATIVE_DOUBLE);
+    case DT_BOOL: return make_bool();
+    default: return -1;
+  }
+}
+static int code_of(hid_t t) {
+  H5T_class_t c = H5Tget_class(t);
+  size_t sz = H5Tget_size(t);
+  if (c == H5T_INTEGER) {
+    int sgn = H5Tget_sign(t) != H5T_SGN_NONE;
+    switch (sz) {
+      case 1: return sgn ? DT_I8 : DT_U8;
+      case 2: return sgn ? DT_I16 : DT_U16;
+      case 4: return sgn ? DT_I32 : DT_U32;
+      case 8: return sgn ? DT_I64 : DT_U64;
+    }
+  } else if (c == H5T_FLOAT) {
+    if (sz == 2) return DT_F16;
+    if (sz == 4) return DT_F32;
+    if (sz == 8) return DT_F64;
+  } else if (c == H5T_ENUM && sz == 1) {
+    return DT_BOOL;
+  }
+  return -1;
+}
+
+int pytc_h5_init(void) {
+  if (H5open() < 0) { set_err("H5open failed"); return 1; }
+  H5Eset_auto2(H5E_DEFAULT, NULL, NULL);   /* errors come back as status codes, not on stderr */
+  return 0;
+}
+
+/* mode: 0 read-only, 1 read/write existing, 2 create/truncate */
+int64_t pytc_h5_file_open(const char* path, int mode) {
+  hid_t f = -1;
+  if (mode == 2) f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+  else f = H5Fopen(path, mode == 1 ? H5F_ACC_RDWR : H5F_ACC_RDONLY, H5P_DEFAULT);
+  if (f < 0) { snprintf(g_err, sizeof(g_err), "cannot open HDF5 file '%s' (mode %d)", path, mode); return -1; }
+  return (int64_t)f;
+}
+int pytc_h5_file_close(int64_t f) {
+  H5Fflush((hid_t)f, H5F_SCOPE_GLOBAL);
+  return H5Fclose((hid_t)f) < 0 ? 1 : 0;
+}
+
+/* names of the links in the root group, '\n' separated; returns the number of links or -1 */
+int pytc_h5_list(int64_t f, char* buf, int len) {
+  H5G_info_t info;
+  if (H5Gget_info((hid_t)f, &info) < 0) { set_err("H5Gget_info failed"); return -1; }
+  int pos = 0;
+  if (len > 0) buf[0] = 0;
+  for (hsize_t i = 0; i < info.nlinks; ++i) {
+    char name[256];
+    ssize_t n = H5Lget_name_by_idx((hid_t)f, ".", H5_INDEX_NAME, H5_ITER_INC, i, name, sizeof(name), H5P_DEFAULT);
+    if (n < 0) continue;
+    int w = snprintf(buf + pos, pos < len ? (size_t)(len - pos) : 0, "%s\n", name);
+    pos += w;
+  }
+  return (int)info.nlinks;
+}
+int pytc_h5_exists(int64_t f, const char* name) { return H5Lexists((hid_t)f, name, H5P_DEFAULT) > 0 ? 1 : 0; }
+
+int64_t pytc_h5_dset_create(int64_t f, const char* name, int dtype, int ndim, const int64_t* dims, const int64_t* chunks,
+                            int gzip_level) {
+  hsize_t d[8], c[8];
+  if (ndim < 1 || ndim > 8) { set_err("dset_create: bad rank"); return -1; }
+  for (int i = 0; i < ndim; ++i) { d[i] = (hsize_t)dims[i]; c[i] = chunks ? (hsize_t)chunks[i] : 0; }
+  hid_t t = type_of(dtype);
+  if (t < 0) { set_err("dset_create: bad dtype"); return -1; }
+  hid_t sp = H5Screate_simple(ndim, d, NULL);
+  hid_t pl = H5Pcreate(H5P_DATASET_CREATE);
+  if (chunks) {
+    H5Pset_chunk(pl, ndim, c);
+    if (gzip_level >= 0) H5Pset_deflate(pl, (unsigned)gzip_level);
+  }
+  hid_t ds = H5Dcreate2((hid_t)f, name, t, sp, H5P_DEFAULT, pl, H5P_DEFAULT);
+  H5Pclose(pl); H5Sclose(sp); H5Tclose(t);
+  if (ds < 0) { snprintf(g_err, sizeof(g_err), "cannot create dataset '%s'", name); return -1; }
+  return (int64_t)ds;
+}
+int64_t pytc_h5_dset_open(int64_t f, const char* name) {
+  hid_t ds = H5Dopen2((hid_t)f, name, H5P_DEFAULT);
+  if (ds < 0) { snprintf(g_err, sizeof(g_err), "no dataset '%s'", name); return -1; }
+  return (int64_t)ds;
+}
+int pytc_h5_dset_close(int64_t ds) { return H5Dclose((hid_t)ds) < 0 ? 1 : 0; }
+
+int pytc_h5_dset_info(int64_t ds, int* ndim, int64_t* dims, int* dtype, int64_t* chunks, int* has_chunks) {
+  hid_t sp = H5Dget_space((hid_t)ds);
+  hsize_t d[8];
+  int n = H5Sget_simple_extent_ndims(sp);
+  if (n < 0 || n > 8) { H5Sclose(sp); set_err("dset_info: bad rank"); return 1; }
+  H5Sget_simple_extent_dims(sp, d, NULL);
+  H5Sclose(sp);
+  *ndim = n;
+  for (int i = 0; i < n; ++i) dims[i] = (int64_t)d[i];
+  hid_t t = H5Dget_type((hid_t)ds);
+  *dtype = code_of(t);
+  H5Tclose(t);
+  hid_t pl = H5Dget_create_plist((hid_t)ds);
+  *has_chunks = 0;
+  if (H5Pget_layout(pl) == H5D_CHUNKED) {
+    hsize_t c[8];
+    H5Pget_chunk(pl, n, c);
+    for (int i = 0; i < n; ++i) chunks[i] = (int64_t)c[i];
+    *has_chunks = 1;
+  }
+  H5Pclose(pl);
+  return 0;
+}
+
+/* hyperslab IO: start/count per axis, memory buffer contiguous in the dataset's own dtype (mem_dtype converts on the fly) */
+static int slab_io(int64_t ds, int ndim, const int64_t* start, const int64_t* count, void* buf, int mem_dtype, int write) {
+  hsize_t s[8], c[8];
+  for (int i = 0; i < ndim; ++i) { s[i] = (hsize_t)start[i]; c[i] = (hsize_t)count[i]; }
+  hid_t fsp = H5Dget_space((hid_t)ds);
+  if (H5Sselect_hyperslab(fsp, H5S_SELECT_SET, s, NULL, c, NULL) < 0) { H5Sclose(fsp); set_err("bad hyperslab"); return 1; }
+  hid_t msp = H5Screate_simple(ndim, c, NULL);
+  hid_t t = type_of(mem_dtype);
+  herr_t e = write ? H5Dwrite((hid_t)ds, t, msp, fsp, H5P_DEFAULT, buf) : H5Dread((hid_t)ds, t, msp, fsp, H5P_DEFAULT, buf);
+  H5Tclose(t); H5Sclose(msp); H5Sclose(fsp);
+  if (e < 0) { set_err(write ? "H5Dwrite failed" : "H5Dread failed"); return 1; }
+  return 0;
+}
+int pytc_h5_dset_write(int64_t ds, int ndim, const int64_t* start, const int64_t* count, const void* buf, int mem_dtype) {
+  return slab_io(ds, ndim, start, count, (void*)buf, mem_dtype, 1);
+}
+int pytc_h5_dset_read(int64_t ds, int ndim, const int64_t* start, const int64_t* count, void* buf, int mem_dtype) {
+  return slab_io(ds, ndim, start, count, buf, mem_dtype, 0);
+}
+
+/* ---- attributes on a dataset (or file) object.  kind: 0 = utf-8 string (variable length, as h5py writes str),
+ *      1 = int64, 2 = float64, 3 = bool (h5py enum) */
+int pytc_h5_attr_write(int64_t obj, const char* key, int kind, const char* sval, int64_t ival, double dval) {
+  if (H5Aexists((hid_t)obj, key) > 0) H5Adelete((hid_t)obj, key);
+  hid_t sp = H5Screate(H5S_SCALAR), t = -1, a = -1;
+  herr_t e = -1;
+  if (kind == 0) {
+    t = H5Tcopy(H5T_C_S1);
+    H5Tset_size(t, H5T_VARIABLE);
+    H5Tset_cset(t, H5T_CSET_UTF8);
+    a = H5Acreate2((hid_t)obj, key, t, sp, H5P_DEFAULT, H5P_DEFAULT);
+    if (a >= 0) e = H5Awrite(a, t, &sval);
+  } else if (kind == 1) {
+    t = H5Tcopy(H5T_NATIVE_INT64);
+    a = H5Acreate2((hid_t)obj, key, t, sp, H5P_DEFAULT, H5P_DEFAULT);
+    if (a >= 0) e = H5Awrite(a, t, &ival);
+  } else if (kind == 2) {
+    t = H5Tcopy(H5T_NATIVE_DOUBLE);
+    a = H5Acreate2((hid_t)obj, key, t, sp, H5P_DEFAULT, H5P_DEFAULT);
+    if (a >= 0) e = H5Awrite(a, t, &dval);
+  } else if (kind == 3) {
+    t = make_bool();
+    int8_t v = ival ? 1 : 0;
+    a = H5Acreate2((hid_t)obj, key, t, sp, H5P_DEFAULT, H5P_DEFAULT);
+    if (a >= 0) e = H5Awrite(a, t, &v);
+  }
+  if (a >= 0) H5Aclose(a);
+  if (t >= 0) H5Tclose(t);
+  H5Sclose(sp);
+  if (e < 0) { snprintf(g_err, sizeof(g_err), "cannot write attribute '%s'", key); return 1; }
+  return 0;
+}
+int pytc_h5_attr_count(int64_t obj) {
+  H5O_info_t info;
+  if (H5Oget_info((hid_t)obj, &info) < 0) return -1;
+  return (int)info.num_attrs;
+}
+int pytc_h5_attr_name(int64_t obj, int idx, char* buf, int len) {
+  ssize_t n = H5Aget_name_by_idx((hid_t)obj, ".", H5_INDEX_NAME, H5_ITER_INC, (hsize_t)idx, buf, (size_t)len, H5P_DEFAULT);
+  return n < 0 ? 1 : 0;
+}
+/* reads a scalar attribute: kind as above (strings, fixed or variable length, are copied into sbuf) */
+int pytc_h5_attr_read(int64_t obj, const char* key, int* kind, char* sbuf, int slen, int64_t* ival, double* dval) {
+  hid_t a = H5Aopen((hid_t)obj, key, H5P_DEFAULT);
+  if (a < 0) { snprintf(g_err, sizeof(g_err), "no attribute '%s'", key); return 1; }
+  hid_t t = H5Aget_type(a);
+  H5T_class_t c = H5Tget_class(t);
+  int rc = 0;
+  if (c == H5T_STRING) {
+    *kind = 0;
+    if (H5Tis_variable_str(t) > 0) {
+      char* p = NULL;
+      hid_t mt = H5Tcopy(H5T_C_S1);
+      H5Tset_size(mt, H5T_VARIABLE);
+      H5Tset_cset(mt, H5Tget_cset(t));
+      if (H5Aread(a, mt, &p) < 0 || !p) rc = 1;
+      else { snprintf(sbuf, (size_t)slen, "%s", p); free(p); }
+      H5Tclose(mt);
+    } else {
+      size_t sz = H5Tget_size(t);
+      char* tmp = (char*)calloc(sz + 1, 1);
+      if (H5Aread(a, t, tmp) < 0) rc = 1;
+      else snprintf(sbuf, (size_t)slen, "%s", tmp);
+      free(tmp);
+    }
+  } else if (c == H5T_INTEGER) {
+    *kind = 1;
+    if (H5Aread(a, H5T_NATIVE_INT64, ival) < 0) rc = 1;
+  } else if (c == H5T_FLOAT) {
+    *kind = 2;
+    if (H5Aread(a, H5T_NATIVE_DOUBLE, dval) < 0) rc = 1;
+  } else if (c == H5T_ENUM) {
+    *kind = 3;
+    int8_t v = 0;
+    hid_t bt = make_bool();
+    if (H5Aread(a, bt, &v) < 0) rc = 1;
+    H5Tclose(bt);
+    *ival = v;
+  } else {
+    rc = 2;
+  }
+  H5Tclose(t);
+  H5Aclose(a);
+  if (rc) snprintf(g_err, sizeof(g_err), "cannot read attribute '%s' (rc %d)", key, rc);
+  return rc;
+}

@@ -139,15 +139,23 @@ def test_monai_unet_training_step_matches_oracle_autograd():
     out = m(x.cuda())
     loss = F.binary_cross_entropy_with_logits(out, tgt.cuda())
     loss.backward()
-    assert abs(float(loss) - float(ref_loss)) < 1e-4
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 1e-4
     named = dict(m.named_parameters())
-    worst = 0.0
+    # PReLU is kinked: a pre-activation within fp32 rounding of 0 may fall on the other side of the kink than in the oracle and
+    # move a cancelling channel sum by ~1e-2 (analysed for RSUNet in tests/test_gpu_rsunet_training.py:_check_grads) -> loose
+    # per-tensor bound, tight bound on the direction / L2 distance of the whole gradient
+    flat_g, flat_r = [], []
     for k, p in params.items():
         gh = named[k].grad
         assert gh is not None, k
-        scale = float(p.grad.abs().max().clamp_min(1e-6))
-        worst = max(worst, float((gh.cpu() - p.grad).abs().max()) / scale)
-    assert worst < 5e-3, worst
+        err = float((gh.cpu() - p.grad).abs().max()) / float(p.grad.abs().max().clamp_min(1e-6))
+        assert err < 3e-2, f"{k}: rel grad err {err:.2e}"
+        flat_g.append(gh.cpu().flatten().double())
+        flat_r.append(p.grad.flatten().double())
+    g, r = torch.cat(flat_g), torch.cat(flat_r)
+    cos = float((g * r).sum() / (g.norm() * r.norm()))
+    rel2 = float((g - r).norm() / r.norm())
+    assert cos > 0.99995 and rel2 < 1e-2, (cos, rel2)
     # running statistics moved away from the stored ones by the momentum blend
     rm = m.state_dict()["model.model.0.conv.unit0.adn.N.running_mean"].cpu()
     assert not torch.allclose(rm, st["model.model.0.conv.unit0.adn.N.running_mean"])
