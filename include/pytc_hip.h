@@ -270,6 +270,17 @@ int pytc_pw_mlp_train_fwd(const pytc_mlp_args* a, void* hidden_pre, void* stream
  * a->ab = identity affine [N][2][C], a->b2 / a->b3 = zero vectors, a->res_mode = NONE, a->y = dX; d_hidden
  * [N][rows][C_hid] bf16 receives the intermediate (the operand of the expanding conv's weight gradient). */
 int pytc_pw_mlp_bwd(const pytc_mlp_args* a, const void* hidden_pre, void* d_hidden, void* stream);
+/* Fused MedNeXt UP block: the depthwise transposed 3x3x3 conv (stride 2, padding 1, written at the +1 offset of
+ * MedNeXtUpBlock's F.pad((1,0,1,0,1,0))) is computed in the mixer's prologue from the LOW-resolution block input, so the
+ * 2C-channel high-resolution tensor t never touches HBM: a->t = x_low [N][Di][Hi][Wi][C_in] bf16, a->Di/Hi/Wi = the
+ * low-res grid, a->res = encoder skip [N][2Di][2Hi][2Wi][C_out], a->res_low / a->res_bias / a->y as for
+ * PYTC_RES_UPSAMPLE, a->ab = GroupNorm affine of t (statistics: pytc_dwconvT3d_fwd with y = NULL, the statistics-only
+ * mode of the same cell kernel); taps [27][C_in] fp32 tap-major; dw_bias [C_in] and a->res_bias [C_out] must be given
+ * (zero vectors when the conv has no bias / the block has no residual conv).  Results are bit-identical to
+ * pytc_dwconvT3d_fwd + pytc_pw_mlp_fwd(PYTC_RES_UPSAMPLE).  Replaces MedNeXtUpBlock.forward (external nnunet_mednext;
+ * contract at mednext_models.py:104-126). */
+int pytc_pw_mlp_up_supported(int C_in, int C_hid, int C_out);
+int pytc_pw_mlp_up_fwd(const pytc_mlp_args* a, const float* taps, const float* dw_bias, void* stream);
 int pytc_pw_mlp_head_supported(int C_in, int C_hid, int C_out);
 /* The first block of the network (stem fused away, see pytc_stem_dwconv3d_fwd): the mixer's residual is the stem output
  * recomputed from the 1-channel input, res[c] = bf16(stem_w[c] * stem_x[voxel] + stem_b[c]); C_in = C_out = 32. */

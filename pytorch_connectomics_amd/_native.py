@@ -174,6 +174,8 @@ _SIGS = {
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pytc_pw_mlp_train_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p, C.c_void_p]),
     "pytc_pw_mlp_bwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pytc_pw_mlp_up_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "pytc_pw_mlp_up_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
     "pytc_pw_mlp_head_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pytc_pw_mlp_head_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
 }

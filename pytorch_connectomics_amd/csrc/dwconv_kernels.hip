@@ -438,7 +438,8 @@ dwconvT3d_k3_cell_kernel(const T* __restrict__ x, T* __restrict__ y, const float
           const bool face = (Pz == 0) | (Py == 0) | (Px == 0);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) acc[i] = face ? 0.f : acc[i];
-          VecIO<T, VEC>::store(yn + (((long)Pz * g.Ho + Py) * g.Wo + Px) * C, acc);
+          // y == nullptr: statistics only (the fused up-block mixer recomputes t in its prologue, pw_mlp_up_kernels.hip)
+          if (y) VecIO<T, VEC>::store(yn + (((long)Pz * g.Ho + Py) * g.Wo + Px) * C, acc);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) {
             const float r = to_f32<T>(from_f32<T>(acc[i]));     // faces contribute exact zeros
@@ -1135,7 +1136,13 @@ static int dispatch_vec(int vec, bool transposed, const void* x, void* y, const 
 
 static int dw_entry(bool transposed, const void* x, void* y, const float* w, const float* bias, float* stats,
                     int N, int D, int H, int W, int C, int K, int stride, int dtype, void* stream) {
-  PYTC_REQUIRE(x && y && w, "dwconv3d: null pointer");
+  PYTC_REQUIRE(x && w, "dwconv3d: null pointer");
+  if (!y) {   // statistics-only pass: the K = 3 transposed cell kernel (what the fused up-block path launches)
+    DwGeom g0;
+    int vec0;
+    PYTC_REQUIRE(transposed && K == 3 && stats && make_geom(g0, N, D, H, W, C, K, stride, dtype, transposed, vec0) && g0.cell,
+                 "dwconv3d: a null output (statistics only) is supported by the K = 3 transposed cell kernel only");
+  }
   PYTC_REQUIRE(N >= 1 && D >= 1 && H >= 1 && W >= 1 && C >= 1, "dwconv3d: bad shape");
   PYTC_REQUIRE(stride == 1 || stride == 2, "dwconv3d: stride must be 1 or 2");
   PYTC_REQUIRE(dtype == PYTC_F32 || dtype == PYTC_BF16, "dwconv3d: bad dtype");

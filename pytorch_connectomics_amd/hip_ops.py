@@ -221,8 +221,9 @@ def ensemble_update(acc: torch.Tensor, x: torch.Tensor, mode: int, count: int) -
 
 # ------------------------------------------------------------------ depthwise conv + norm statistics
 def dwconv3d(x: torch.Tensor, w_taps: torch.Tensor, bias: Optional[torch.Tensor], *, K: int, stride: int = 1,
-             stats: bool = True, transposed: bool = False, y: Optional[torch.Tensor] = None):
-    """x (N,D,H,W,C) -> y, stats(N,slots,2,C)|None.  w_taps fp32 (K^3, C)."""
+             stats: bool = True, transposed: bool = False, y: Optional[torch.Tensor] = None, store: bool = True):
+    """x (N,D,H,W,C) -> y, stats(N,slots,2,C)|None.  w_taps fp32 (K^3, C).  store=False (transposed K = 3 only): statistics
+    only, y is returned as None (the fused up-block mixer recomputes it)."""
     _dev(x, "x"); _dev(w_taps, "w_taps")
     N, D, H, W, Cc = x.shape
     dt = dtype_code(x.dtype)
@@ -231,7 +232,11 @@ def dwconv3d(x: torch.Tensor, w_taps: torch.Tensor, bias: Optional[torch.Tensor]
     else:
         p = K // 2
         oshape = (N, (D + 2 * p - K) // stride + 1, (H + 2 * p - K) // stride + 1, (W + 2 * p - K) // stride + 1, Cc)
-    if y is None:
+    if not store:
+        if not (transposed and K == 3 and stats):
+            raise ValueError("dwconv3d(store=False) is the statistics-only mode of the K = 3 transposed conv")
+        y = None
+    elif y is None:
         y = torch.empty(oshape, dtype=x.dtype, device=x.device)
     st = None
     if stats:
@@ -241,7 +246,7 @@ def dwconv3d(x: torch.Tensor, w_taps: torch.Tensor, bias: Optional[torch.Tensor]
         st = torch.empty((N, slots, 2, Cc), dtype=torch.float32, device=x.device)
     tag = f"C{Cc}_k{K}" + ("_s2" if stride == 2 and not transposed else "")
     if transposed:
-        _run(f"dwconvT3d_fwd[{tag}]", _nbytes(x, y), nat.lib().pytc_dwconvT3d_fwd, _p(x), _p(y), _p(w_taps), _p(bias),
+        _run(f"dwconvT3d_fwd[{tag}]" if store else f"dwconvT3d_stats[{tag}]", _nbytes(x, y), nat.lib().pytc_dwconvT3d_fwd, _p(x), _p(y), _p(w_taps), _p(bias),
              _p(st), N, D, H, W, Cc, K, dt, _stream())
     else:
         _run(f"dwconv3d_fwd[{tag}]", _nbytes(x, y), nat.lib().pytc_dwconv3d_fwd, _p(x), _p(y), _p(w_taps), _p(bias),
@@ -365,6 +370,41 @@ def pw_mlp(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.Tenso
              C.byref(a), _p(hidden_pre), _stream())
         return y
     _run(f"pw_mlp_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_fwd, C.byref(a), _stream())
+    return y
+
+
+def pw_mlp_up_supported(c_in: int, c_hid: int, c_out: int) -> bool:
+    return bool(nat.lib().pytc_pw_mlp_up_supported(int(c_in), int(c_hid), int(c_out)))
+
+
+def pw_mlp_up(x_low: torch.Tensor, taps: torch.Tensor, dw_bias: Optional[torch.Tensor], ab: torch.Tensor, w2p: torch.Tensor,
+              b2: torch.Tensor, w3p: torch.Tensor, b3: torch.Tensor, skip: torch.Tensor, *, c_hid: int, c_out: int,
+              res_low: Optional[torch.Tensor] = None, res_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused MedNeXt up block on bf16 NDHWC tensors: x_low (N,D,H,W,C_in) -> y (N,2D,2H,2W,C_out); the depthwise transposed
+    conv output is formed in the mixer's prologue and never stored (csrc/pw_mlp_up_kernels.hip)."""
+    _dev(x_low, "x_low"); _dev(skip, "skip"); _dev(taps, "taps")
+    if x_low.dtype != torch.bfloat16 or skip.dtype != torch.bfloat16:
+        raise TypeError("pw_mlp_up runs on bfloat16 activations")
+    N, D, H, W, c_in = x_low.shape
+    if tuple(skip.shape) != (N, 2 * D, 2 * H, 2 * W, c_out):
+        raise ValueError(f"pw_mlp_up: skip shape {tuple(skip.shape)} does not match the up-sampled grid")
+    y = torch.empty((N, 2 * D, 2 * H, 2 * W, c_out), dtype=torch.bfloat16, device=x_low.device)
+    a = nat.MlpArgs()
+    a.t, a.ab, a.w2_packed, a.b2, a.w3_packed, a.b3 = (x_low.data_ptr(), ab.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
+                                                       w3p.data_ptr(), b3.data_ptr())
+    a.res = skip.data_ptr()
+    if dw_bias is None:
+        dw_bias = torch.zeros((c_in,), dtype=torch.float32, device=x_low.device)
+    if res_bias is None:
+        res_bias = torch.zeros((c_out,), dtype=torch.float32, device=x_low.device)
+    a.res_low = res_low.data_ptr() if res_low is not None else None
+    a.res_bias = res_bias.data_ptr()
+    a.y = y.data_ptr()
+    a.N, a.rows_per_sample, a.C_in, a.C_hid, a.C_out, a.res_mode = N, 8 * D * H * W, c_in, c_hid, c_out, nat.RES_UPSAMPLE
+    a.Di, a.Hi, a.Wi = D, H, W
+    nb = _nbytes(x_low, skip, y) + (_nbytes(res_low) if res_low is not None else 0)
+    _run(f"pw_mlp_up_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_up_fwd, C.byref(a), _p(taps), _p(dw_bias),
+         _stream())
     return y
 
 

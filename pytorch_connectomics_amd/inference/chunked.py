@@ -1,28 +1,42 @@
 """Chunk-grid inference with exact seams -- counterpart of the reference's connectomics/inference/chunked.py
-(run_chunked_prediction_inference :725-944, _run_chunked_prediction_per_rank :437-722,
-_stitch_chunk_prediction_files :317-434, _write_chunk_index :279-314) and inference/chunk_grid.py:90-111.
+(run_chunked_prediction_inference :725-944, _run_chunked_prediction_per_rank :437-722, _stitch_chunk_prediction_files
+:317-434, _write_chunk_index :279-314, _filter_chunks_to_roi :246-272, _resolve_inference_roi :217-243,
+_resolve_external_chunk_shard :196-214, _to_abiss_affinity_convention :133-165) and inference/chunk_grid.py:78-111.
 
-Every chunk is predicted as `lazy_predict_region(core +- halo)` from the GLOBAL window grid and cropped to
-its core, so the stitched result equals the whole-volume prediction bit for bit (the reference asserts the
-same, tests/unit/test_chunked_inference.py:177).  Chunks are dealt to ranks `idx % world == rank`
-(chunked.py:471), each rank writes its own disjoint files, one barrier, rank 0 writes the index and
-stitches -- no data-path collective.  Files are .npy (C,Z,Y,X) because h5py is not part of this image; the
-naming (chunk_{zI_yJ_xK}) and index.json layout follow the reference.
+Every chunk is predicted as `lazy_predict_region(core +- halo)` from the GLOBAL window grid and cropped to its core, so
+the stitched result equals the whole-volume prediction bit for bit (the reference asserts the same,
+tests/unit/test_chunked_inference.py:177; the kernels are batch-invariant so this holds for real networks too).
+Chunks are dealt to ranks `idx % world == rank` (chunked.py:471), each rank writes its own disjoint files, one
+barrier, rank 0 writes the index and stitches -- no data-path collective.
+
+On-disk layout = the reference's: `<output>.chunks/chunk_{zI_yJ_xK}.h5` (dataset `main` CZYX, gzip, HDF5 chunks
+(C, <=64, <=64, <=64), the reference's attribute vocabulary incl. chunk_key / chunk_*_zyx), `<output>.index.json`
+(input_shape, final_shape, chunk_shape, halo, crop_pad, checkpoint_path, world_size, chunks[{key, index_zyx, start_zyx,
+stop_zyx, path}]) and the stitched CZYX artifact streamed by z slabs.  HDF5 comes from h5py or utils/h5lite.py (libhdf5
+of the image); an output path ending in `.npy` (or a box without any HDF5 library) selects the .npy container with the
+same naming and index.  The semantic / storage dtype transforms run on the device before the D2H copy; the copy (pinned,
+non-blocking) and the file write of chunk i overlap the prediction of chunk i+1 on a writer thread, and the resume
+manifest entry follows the atomic rename.
 """
 from __future__ import annotations
 
 import json
 import logging
 import os
+from dataclasses import replace
 from pathlib import Path
-from typing import Callable, Optional, Sequence
+from typing import Any, Callable, Optional, Sequence
 
 import numpy as np
 import torch
 
 from ..chunked import ChunkRef, ResumeManifest, build_chunk_grid, resolve_halo_region
+from ..utils.h5lite import get_h5_backend
+from .artifact import build_prediction_artifact_metadata, read_prediction_artifact, write_prediction_artifact
+from .chunk_grid import resolve_chunk_shape, resolve_h5_spatial_chunks, validate_chunked_output_format
 from .crop import cropped_shape, resolve_global_prediction_crop
 from .lazy import get_lazy_image_reference_shape, lazy_predict_region
+from .output import apply_prediction_transform, apply_storage_dtype_transform
 
 logger = logging.getLogger(__name__)
 
@@ -32,23 +46,6 @@ def is_chunked_inference_enabled(cfg) -> bool:
     ch = getattr(inf, "chunking", None)
     strategy = getattr(inf, "strategy", None) or getattr(getattr(inf, "execution", None), "strategy", None)
     return bool(getattr(ch, "enabled", False) or strategy == "chunked")
-
-
-def resolve_chunk_shape(cfg, volume_shape: Sequence[int]) -> tuple[int, int, int]:
-    """chunking.chunk_size, with axes == 'z' keeping full YX (reference inference/chunk_grid.py:90-101)."""
-    ch = getattr(getattr(cfg, "inference", None), "chunking", None)
-    size = getattr(ch, "chunk_size", None)
-    if not size:
-        raise ValueError("inference.chunking.chunk_size must be set for chunked inference")
-    size = [int(v) for v in size]
-    if len(size) != 3 or any(v <= 0 for v in size):
-        raise ValueError(f"inference.chunking.chunk_size must be 3 positive ints, got {size}")
-    axes = str(getattr(ch, "axes", "all")).lower()
-    if axes == "z":
-        size = [size[0], int(volume_shape[1]), int(volume_shape[2])]
-    elif axes != "all":
-        raise ValueError(f"inference.chunking.axes must be 'all' or 'z', got {axes!r}")
-    return tuple(min(s, int(v)) for s, v in zip(size, volume_shape))
 
 
 def _rank_world() -> tuple[int, int]:
@@ -62,24 +59,100 @@ def _resolve_external_chunk_shard(cfg) -> Optional[tuple[int, int]]:
     sid, n = getattr(ch, "shard_id", None), getattr(ch, "num_shards", None)
     if sid is None and n is None:
         return None
-    if sid is None or n is None or int(n) <= 0 or not 0 <= int(sid) < int(n):
-        raise ValueError(f"inference.chunking.shard_id/num_shards invalid: shard_id={sid}, num_shards={n}")
-    return int(sid), int(n)
+    if sid is None or n is None:
+        raise ValueError("Both inference.chunking.shard_id and num_shards must be set together.")
+    sid, n = int(sid), int(n)
+    if n <= 0:
+        raise ValueError(f"inference.chunking.num_shards must be positive, got {n}.")
+    if sid < 0 or sid >= n:
+        raise ValueError(f"inference.chunking.shard_id={sid} out of range for num_shards={n}.")
+    return sid, n
+
+
+def is_external_chunk_sharding_enabled(cfg) -> bool:
+    return _resolve_external_chunk_shard(cfg) is not None
+
+
+def _resolve_inference_roi(cfg):
+    """`inference.chunking.roi` in INPUT voxel coordinates (ZYX): 3 ints = size from the origin, 6 ints = start / stop.
+    Chunks outside it are pure padding of an over-sized volume and are skipped."""
+    ch = getattr(getattr(cfg, "inference", None), "chunking", None)
+    roi = getattr(ch, "roi", None) if ch is not None else None
+    if roi is None:
+        return None
+    vals = [int(v) for v in roi]
+    if len(vals) == 3:
+        start, stop = (0, 0, 0), tuple(vals)
+    elif len(vals) == 6:
+        start, stop = tuple(vals[:3]), tuple(vals[3:])
+    else:
+        raise ValueError(f"inference.chunking.roi must have 3 (size) or 6 (start/stop) ints ZYX, got {roi!r}.")
+    if any(stop[a] <= start[a] for a in range(3)):
+        raise ValueError(f"inference.chunking.roi stop must exceed start on every axis, got {roi!r}.")
+    return start, stop
+
+
+def _filter_chunks_to_roi(chunks: Sequence[ChunkRef], roi, crop_before) -> list[ChunkRef]:
+    """Drop the chunks that miss the ROI, crop the ones that straddle its boundary; index / key stay those of the full grid
+    so file names still follow the global naming."""
+    r0, r1 = roi
+    kept = []
+    for ch in chunks:
+        cs = tuple(ch.start[a] + crop_before[a] for a in range(3))
+        ce = tuple(ch.stop[a] + crop_before[a] for a in range(3))
+        if not all(cs[a] < r1[a] and ce[a] > r0[a] for a in range(3)):
+            continue
+        start = tuple(max(cs[a], r0[a]) - crop_before[a] for a in range(3))
+        stop = tuple(min(ce[a], r1[a]) - crop_before[a] for a in range(3))
+        kept.append(ch if (start, stop) == (ch.start, ch.stop) else replace(ch, start=start, stop=stop))
+    return kept
+
+
+def _to_abiss_affinity_convention(pred: np.ndarray) -> np.ndarray:
+    """Source-stored 3-channel affinity (C, Z, Y, X) -> the convention ABISS reads: edge shift dst[c, v] = src[c, v-1] along
+    spatial axis c (zero at index 0), then channel reversal [z, y, x] -> [x, y, z].  Apply on the HALOED array."""
+    if pred.shape[0] != 3:
+        raise ValueError("chunking.precomputed_affinity_convention='abiss' expects 3-channel affinity in (C, Z, Y, X) order, "
+                         f"got shape {tuple(pred.shape)}.")
+    shifted = np.zeros_like(pred)
+    for c in range(3):
+        dst, src = [slice(None)] * 4, [slice(None)] * 4
+        dst[0] = src[0] = c
+        dst[c + 1], src[c + 1] = slice(1, None), slice(0, -1)
+        shifted[tuple(dst)] = pred[tuple(src)]
+    return shifted[::-1]
+
+
+# --------------------------------------------------------------------------------------------- file layout
+def _use_h5(output_path: Path) -> bool:
+    return output_path.suffix != ".npy" and get_h5_backend() is not None
+
+
+def _normalise_output_path(output_path) -> Path:
+    p = Path(output_path)
+    if p.suffix == ".npy":
+        return p
+    if get_h5_backend() is None:
+        logger.warning("no HDF5 backend (h5py / libpytc_h5.so): chunked prediction falls back to the .npy container")
+        return p.with_suffix(p.suffix + ".npy")
+    return p if p.suffix in (".h5", ".hdf5") else p.with_suffix(p.suffix + ".h5")
 
 
 def _chunks_dir(output_path: Path) -> Path:
     return output_path.with_suffix(output_path.suffix + ".chunks")
 
 
-def _chunk_file(chunks_dir: Path, chunk: ChunkRef) -> Path:
-    return chunks_dir / f"chunk_{chunk.key}.npy"
+def _chunk_file(chunks_dir: Path, chunk: ChunkRef, h5: bool = False) -> Path:
+    return chunks_dir / f"chunk_{chunk.key}.{'h5' if h5 else 'npy'}"
 
 
-def _write_chunk_index(output_path: Path, chunks, chunks_dir: Path, volume_shape, chunk_shape, halo, channels: int):
-    index = {"volume_shape": [int(v) for v in volume_shape], "chunk_shape": list(chunk_shape), "halo": list(halo),
-             "channels": int(channels),
-             "chunks": [{"key": c.key, "index": list(c.index), "start": list(c.start), "stop": list(c.stop),
-                         "path": str(_chunk_file(chunks_dir, c).relative_to(output_path.parent))} for c in chunks]}
+def _write_chunk_index(output_path: Path, chunks, chunks_dir: Path, *, input_shape, final_shape, crop_pad, chunk_shape, halo,
+                       checkpoint_path, world_size: int, h5: bool) -> Path:
+    index = {"input_shape": [int(v) for v in input_shape], "final_shape": [int(v) for v in final_shape],
+             "chunk_shape": list(chunk_shape), "halo": list(halo), "crop_pad": [list(p) for p in crop_pad],
+             "checkpoint_path": str(checkpoint_path) if checkpoint_path is not None else None, "world_size": int(world_size),
+             "chunks": [{"key": c.key, "index_zyx": list(c.index), "start_zyx": list(c.start), "stop_zyx": list(c.stop),
+                         "path": str(_chunk_file(chunks_dir, c, h5).relative_to(output_path.parent))} for c in chunks]}
     p = output_path.with_suffix(output_path.suffix + ".index.json")
     tmp = p.with_suffix(p.suffix + ".tmp")
     tmp.write_text(json.dumps(index, indent=2))
@@ -87,55 +160,105 @@ def _write_chunk_index(output_path: Path, chunks, chunks_dir: Path, volume_shape
     return p
 
 
-def stitch_chunk_prediction_files(output_path, chunks, volume_shape, *, dtype=None) -> np.ndarray:
-    """Assemble per-chunk files into one (C,Z,Y,X) array (z-slab streaming is unnecessary here: the result is
-    returned in host memory and also saved as <output_path>)."""
+def _read_chunk(path: Path) -> np.ndarray:
+    return np.load(path) if path.suffix == ".npy" else read_prediction_artifact(path)
+
+
+def stitch_chunk_prediction_files(output_path, chunks, volume_shape, *, dtype=None, cfg=None, metadata=None,
+                                  return_array: bool = True) -> Optional[np.ndarray]:
+    """Assemble the per-chunk files into the canonical (C, Z, Y, X) artifact at `output_path`.  HDF5: streamed by z slabs of
+    the HDF5 chunk depth into a gzip dataset chunked (C, <=64, <=64, <=64), never holding more than a slab
+    (chunked.py:317-434); .npy: one array.  Returns the stitched array when `return_array`."""
     output_path = Path(output_path)
+    h5 = _use_h5(output_path)
     cdir = _chunks_dir(output_path)
-    first = _chunk_file(cdir, chunks[0])
+    if not chunks:
+        raise ValueError("Cannot stitch chunked predictions: no chunks were generated.")
+    first = _chunk_file(cdir, chunks[0], h5)
     if not first.exists():
         raise FileNotFoundError(f"Missing first chunk prediction file: {first}")
-    head = np.load(first, mmap_mode="r")
-    out = np.zeros((head.shape[0],) + tuple(int(v) for v in volume_shape), dtype=dtype or head.dtype)
-    for i, c in enumerate(chunks, 1):
-        f = _chunk_file(cdir, c)
-        if not f.exists():
-            raise FileNotFoundError(f"Missing chunk prediction file {i}/{len(chunks)}: {f}")
-        arr = np.load(f)
-        if arr.shape[0] != out.shape[0]:
-            raise ValueError(f"Chunk {c.key} channel mismatch: {arr.shape[0]} vs {out.shape[0]}")
-        if tuple(arr.shape[1:]) != c.shape:
-            raise ValueError(f"Chunk {c.key} spatial shape mismatch: {tuple(arr.shape[1:])} vs {c.shape}")
-        out[(slice(None),) + c.slices] = arr
-    np.save(output_path, out)
-    return out
+    if not h5:
+        head = np.load(first, mmap_mode="r")
+        out = np.zeros((head.shape[0],) + tuple(int(v) for v in volume_shape), dtype=dtype or head.dtype)
+        for i, c in enumerate(chunks, 1):
+            f = _chunk_file(cdir, c)
+            if not f.exists():
+                raise FileNotFoundError(f"Missing chunk prediction file {i}/{len(chunks)}: {f}")
+            arr = np.load(f)
+            if arr.shape[0] != out.shape[0]:
+                raise ValueError(f"Chunk {c.key} channel mismatch: {arr.shape[0]} vs {out.shape[0]}")
+            if tuple(arr.shape[1:]) != c.shape:
+                raise ValueError(f"Chunk {c.key} spatial shape mismatch: {tuple(arr.shape[1:])} vs {c.shape}")
+            out[(slice(None),) + c.slices] = arr
+        np.save(output_path, out)
+        return out if return_array else None
+    be = get_h5_backend()
+    with be.File(first, "r") as fh:
+        channels, out_dtype = int(fh["main"].shape[0]), fh["main"].dtype
+    spatial_chunks = resolve_h5_spatial_chunks(volume_shape)
+    if metadata is not None and metadata.intensity_dtype is None:
+        metadata = replace(metadata, intensity_dtype=str(np.dtype(dtype or out_dtype)))
+
+    def write_chunks(dataset) -> None:
+        for i, c in enumerate(chunks, 1):
+            f = _chunk_file(cdir, c, True)
+            if not f.exists():
+                raise FileNotFoundError(f"Missing chunk prediction file {i}/{len(chunks)}: {f}")
+            with be.File(f, "r") as fh:
+                src = fh["main"]
+                if int(src.shape[0]) != channels:
+                    raise ValueError(f"Chunk {c.key} channel mismatch: {src.shape[0]} vs {channels}")
+                if tuple(int(v) for v in src.shape[-3:]) != c.shape:
+                    raise ValueError(f"Chunk {c.key} spatial shape mismatch: {tuple(src.shape[-3:])} vs {c.shape}")
+                depth = max(1, int(spatial_chunks[0]))
+                for z0 in range(0, c.shape[0], depth):          # z slabs: stitching never materialises a multi-GB chunk
+                    z1 = min(z0 + depth, c.shape[0])
+                    dataset[:, c.start[0] + z0:c.start[0] + z1, c.start[1]:c.stop[1], c.start[2]:c.stop[2]] = src[:, z0:z1]
+
+    write_prediction_artifact(output_path, metadata=metadata, compression="gzip", shape=(channels, *[int(v) for v in volume_shape]),
+                              dtype=dtype or out_dtype, chunks=(channels, *spatial_chunks), writer=write_chunks)
+    return read_prediction_artifact(output_path) if return_array else None
 
 
 class _ChunkWriter:
     """One background thread that turns (tensor | array, path, key) jobs into chunk files.  CUDA tensors are copied into
-    pinned host memory with a non-blocking copy; the thread synchronises on the copy's event, not on the device."""
+    pinned host memory with a non-blocking copy (in their storage dtype: a uint8 chunk crosses PCIe at a quarter of the fp32
+    bytes); the thread synchronises on the copy's event, not on the device."""
 
-    def __init__(self, manifest, depth: int = 2):
+    def __init__(self, manifest, depth: int = 2, save: Optional[Callable[[Path, np.ndarray, str], None]] = None):
         import queue
         import threading
         self.manifest = manifest
         self.q = queue.Queue(maxsize=depth)          # bounds the pinned memory in flight
         self.err = None
+        self.save = save or self._save_npy
         self.t = threading.Thread(target=self._run, name="pytc-chunk-writer", daemon=True)
         self.t.start()
+
+    @staticmethod
+    def _save_npy(path: Path, data: np.ndarray, key: str) -> None:
+        tmp = path.with_suffix(".tmp.npy")
+        np.save(tmp, data)
+        os.replace(tmp, path)
 
     def submit(self, core_pred, path: Path, key: str) -> None:
         if self.err is not None:
             raise self.err
         if isinstance(core_pred, torch.Tensor) and core_pred.is_cuda:
-            src = core_pred.detach().float()
-            host = torch.empty(src.shape, dtype=torch.float32, pin_memory=True)
+            src = core_pred.detach()
+            if src.dtype == torch.bfloat16:
+                src = src.float()
+            host = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
             host.copy_(src, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             self.q.put((host, ev, path, key))
         else:
-            arr = core_pred.detach().float().cpu().numpy() if isinstance(core_pred, torch.Tensor) else np.asarray(core_pred)
+            if isinstance(core_pred, torch.Tensor):
+                t = core_pred.detach().cpu()
+                arr = (t.float() if t.dtype == torch.bfloat16 else t).numpy()
+            else:
+                arr = np.asarray(core_pred)
             self.q.put((arr, None, path, key))
 
     def _run(self):
@@ -150,9 +273,7 @@ class _ChunkWriter:
                 if ev is not None:
                     ev.synchronize()
                     data = data.numpy()
-                tmp = path.with_suffix(".tmp.npy")
-                np.save(tmp, data)
-                os.replace(tmp, path)
+                self.save(path, data, key)
                 self.manifest.mark_completed(key)
             except BaseException as e:          # surfaced to the producer at the next submit / close
                 self.err = e
@@ -167,23 +288,34 @@ class _ChunkWriter:
 def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, device="cuda",
                                      requested_head: Optional[str] = None,
                                      predict_region_fn: Optional[Callable] = None, stitch: bool = True,
-                                     overwrite: bool = False):
-    """Predict `volume` chunk by chunk.  Returns the stitched (C,Z,Y,X) numpy array on rank 0 (None elsewhere,
-    or when stitch=False / external sharding is active).  `predict_region_fn(start, stop) -> (1,C,*region)`
-    replaces the device predictor in host-logic tests."""
-    output_path = Path(output_path)
-    if output_path.suffix != ".npy":
-        output_path = output_path.with_suffix(output_path.suffix + ".npy")
+                                     overwrite: bool = False, image_path: Optional[str] = None,
+                                     checkpoint_path: Optional[str] = None, return_array: bool = True):
+    """Predict `volume` chunk by chunk.  Returns the stitched (C,Z,Y,X) numpy array on rank 0 (None elsewhere, when
+    stitch=False / external sharding is active, or with return_array=False).  `predict_region_fn(start, stop) ->
+    (1,C,*region)` replaces the device predictor in host-logic tests."""
+    ch_cfg = getattr(getattr(cfg, "inference", None), "chunking", None)
+    if bool(getattr(ch_cfg, "precomputed", False)):
+        raise NotImplementedError("inference.chunking.precomputed (CloudVolume layer output) is outside this engine: it is the "
+                                  "reference's cloud storage client, not the hot path; write HDF5 chunks and upload them")
+    validate_chunked_output_format(cfg)
+    output_path = _normalise_output_path(output_path)
+    h5 = _use_h5(output_path)
     input_shape = get_lazy_image_reference_shape(volume)
     # the chunk grid lives in the CROPPED output space (user crop_pad + DeepEM affinity border, reference
     # chunked.py:743-755); a chunk's core in input coordinates is shifted by the leading crop
     crop_pad = resolve_global_prediction_crop(cfg)
     crop_before = tuple(int(crop_pad[a][0]) for a in range(3))
     vol_shape = cropped_shape(input_shape[-3:], crop_pad)
-    ch_cfg = getattr(getattr(cfg, "inference", None), "chunking", None)
     halo = tuple(int(v) for v in (getattr(ch_cfg, "halo", None) or (0, 0, 0)))
     chunk_shape = resolve_chunk_shape(cfg, vol_shape)
     chunks = build_chunk_grid(vol_shape, chunk_shape)
+    roi = _resolve_inference_roi(cfg)
+    if roi is not None:
+        n_before = len(chunks)
+        chunks = _filter_chunks_to_roi(chunks, roi, crop_before)
+        logger.info("inference.chunking.roi %s: %d of %d chunks kept", roi, len(chunks), n_before)
+        if not chunks:
+            raise ValueError(f"inference.chunking.roi {roi} does not intersect the volume")
     cdir = _chunks_dir(output_path)
     cdir.mkdir(parents=True, exist_ok=True)
     rank, world = _rank_world()
@@ -194,27 +326,48 @@ def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, de
         mine = [(i, c) for i, c in enumerate(chunks) if i % world == rank]
     manifest = ResumeManifest.load_or_create(cdir / f"manifest_rank{rank if ext is None else ext[0]}.json",
                                              {"chunk_shape": list(chunk_shape), "output_shape": list(vol_shape),
-                                              "halo": list(halo), "crop_pad": [list(p) for p in crop_pad]},
+                                              "halo": list(halo), "crop_pad": [list(p) for p in crop_pad],
+                                              "roi": None if roi is None else [list(roi[0]), list(roi[1])],
+                                              "container": "h5" if h5 else "npy"},
                                              overwrite=overwrite)
     if predict_region_fn is None:
         def predict_region_fn(start, stop):
             return lazy_predict_region(cfg, forward_fn, volume, region_start=start, region_stop=stop, device=device,
                                        requested_head=requested_head)
+    tc = getattr(getattr(cfg, "inference", None), "prediction_transform", None)
+    tc_on = tc is not None and bool(getattr(tc, "enabled", False))
+    img_name = image_path if image_path is not None else getattr(volume, "filename", None) or "<array>"
+    meta_of: dict = {}
+
+    def save_h5(path: Path, data: np.ndarray, key: str) -> None:
+        c, read_lo, read_hi = meta_of.pop(key)
+        md = build_prediction_artifact_metadata(
+            cfg, image_path=str(img_name), checkpoint_path=checkpoint_path, output_head=requested_head,
+            input_shape=tuple(read_hi[a] - read_lo[a] for a in range(3)), final_shape=c.shape, chunk_shape=c.shape, halo=halo,
+            intensity_scale=float(getattr(tc, "intensity_scale", -1.0)) if tc_on else None,
+            intensity_dtype=str(getattr(tc, "intensity_dtype", data.dtype)) if tc_on else str(data.dtype),
+            extra={"compression": "gzip", "chunk_key": c.key, "chunk_index_zyx": list(c.index), "chunk_start_zyx": list(c.start),
+                   "chunk_stop_zyx": list(c.stop), "chunk_read_start_zyx": list(read_lo), "chunk_read_stop_zyx": list(read_hi),
+                   "chunk_read_shape_zyx": [read_hi[a] - read_lo[a] for a in range(3)]})
+        tmp = path.with_suffix(".tmp.h5")
+        sp = tuple(max(1, min(int(s), int(e))) for s, e in zip(resolve_h5_spatial_chunks(c.shape), c.shape))
+        write_prediction_artifact(tmp, data, metadata=md, compression="gzip", chunks=(int(data.shape[0]), *sp))
+        os.replace(tmp, path)
+
     channels = None
-    # device -> pinned host copy and the file write of chunk i overlap the prediction of chunk i+1: the copy is issued
-    # non-blocking behind the chunk's kernels, a writer thread waits on its event, saves atomically (tmp + rename) and
-    # only then marks the chunk completed in the manifest
-    writer = _ChunkWriter(manifest)
+    writer = _ChunkWriter(manifest, save=save_h5 if h5 else None)
     try:
         for pos, (idx, c) in enumerate(mine, 1):
-            f = _chunk_file(cdir, c)
+            f = _chunk_file(cdir, c, h5)
             if f.exists() and c.key in manifest.completed:     # idempotent resume (reference chunked.py:510-523)
                 logger.info("chunk %s already done, skipping", c.key)
                 continue
             read_lo, read_hi, core = resolve_halo_region(c, input_shape[-3:], halo=halo, crop_before=crop_before)
             pred = predict_region_fn(read_lo, read_hi)
             core_pred = pred[(0, slice(None)) + core]
+            core_pred = apply_storage_dtype_transform(cfg, apply_prediction_transform(cfg, core_pred))
             channels = int(core_pred.shape[0])
+            meta_of[c.key] = (c, tuple(read_lo), tuple(read_hi))
             writer.submit(core_pred, f, c.key)
     finally:
         writer.close()
@@ -224,11 +377,20 @@ def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, de
         torch.distributed.barrier()
     if rank != 0:
         return None
-    if channels is None:
-        channels = int(np.load(_chunk_file(cdir, chunks[0]), mmap_mode="r").shape[0])
-    _write_chunk_index(output_path, chunks, cdir, vol_shape, chunk_shape, halo, channels)
-    return stitch_chunk_prediction_files(output_path, chunks, vol_shape) if stitch else None
+    _write_chunk_index(output_path, chunks, cdir, input_shape=input_shape[-3:], final_shape=vol_shape, crop_pad=crop_pad,
+                       chunk_shape=chunk_shape, halo=halo, checkpoint_path=checkpoint_path, world_size=world, h5=h5)
+    if not stitch:
+        return None
+    if roi is not None and return_array:
+        logger.info("ROI-restricted chunking: voxels outside the ROI stay zero in the stitched artifact")
+    md = build_prediction_artifact_metadata(
+        cfg, image_path=str(img_name), checkpoint_path=checkpoint_path, output_head=requested_head, input_shape=input_shape[-3:],
+        final_shape=vol_shape, crop_pad=crop_pad, chunk_shape=chunk_shape, halo=halo,
+        intensity_scale=float(getattr(tc, "intensity_scale", -1.0)) if tc_on else None,
+        intensity_dtype=str(getattr(tc, "intensity_dtype", None)) if tc_on else None,
+        extra={"compression": "gzip", "chunk_stitch_source": str(cdir)})
+    return stitch_chunk_prediction_files(output_path, chunks, vol_shape, cfg=cfg, metadata=md, return_array=return_array)
 
 
 __all__ = ["run_chunked_prediction_inference", "stitch_chunk_prediction_files", "is_chunked_inference_enabled",
-           "resolve_chunk_shape"]
+           "is_external_chunk_sharding_enabled", "resolve_chunk_shape"]

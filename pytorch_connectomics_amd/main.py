@@ -7,7 +7,7 @@ test : build_model(cfg) -> load checkpoint -> volume to HBM -> InferenceManager.
        inference when inference.chunking.enabled) -> optional binary Jaccard -> <save_path>/results/*_prediction.npy
 train: training/module.py's Lightning-free harness (HIP forward + backward, fused loss, fused clip + AdamW), one process
        per GPU under torch.distributed.run (DDP over RCCL); writes checkpoints/last.ckpt in the Lightning layout.
-Volumes: .npy / .npz (first array) / random://<name>[?shape=Z,Y,X] ; .h5 when h5py is importable.
+Volumes: .npy / .npz (first array) / random://<name>[?shape=Z,Y,X] / .h5 (dataset `main`; h5py or the in-repo libhdf5 shim).
 """
 from __future__ import annotations
 
@@ -55,13 +55,13 @@ def read_volume(spec: str, *, default_shape=(64, 128, 128), seed: int = 0) -> np
         z = np.load(path)
         return z[z.files[0]]
     if path.suffix in (".h5", ".hdf5"):
-        try:
-            import h5py
-        except ImportError as exc:
-            raise RuntimeError(f"{spec}: reading HDF5 needs h5py, which is not installed in this image; convert the "
-                               "volume to .npy") from exc
-        with h5py.File(path, "r") as fh:
-            return np.asarray(fh["main" if "main" in fh else list(fh.keys())[0]])
+        from .utils.h5lite import get_h5_backend
+        be = get_h5_backend()
+        if be is None:
+            raise RuntimeError(f"{spec}: reading HDF5 needs h5py or the in-repo libpytc_h5.so (built from csrc/host/h5io.c "
+                               "against libhdf5); neither is available -- convert the volume to .npy")
+        with be.File(path, "r") as fh:
+            return np.asarray(fh["main" if "main" in fh else list(fh.keys())[0]][...])
     raise ValueError(f"unsupported volume format: {spec}")
 
 
@@ -123,8 +123,8 @@ def run_test(cfg, args) -> dict:
     t0 = time.perf_counter()
     with torch.no_grad():
         if is_chunked_inference_enabled(cfg):
-            pred = run_chunked_prediction_inference(cfg, model.forward, vol, output_path=out_dir / f"{name}_prediction.npy",
-                                                    device=dev)
+            pred = run_chunked_prediction_inference(cfg, model.forward, vol, output_path=out_dir / f"{name}_prediction.h5",
+                                                    device=dev, image_path=str(image_spec), checkpoint_path=args.checkpoint)
             pred_t = None if pred is None else torch.from_numpy(pred).unsqueeze(0)
         else:
             x = torch.from_numpy(np.ascontiguousarray(vol, dtype=np.float32)).to(dev)

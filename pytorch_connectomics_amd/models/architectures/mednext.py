@@ -146,6 +146,10 @@ class HipBlockOps:
     def __init__(self):
         self.cache = _WeightCache()
         self.fused = True      # bf16: use the fused channel-mixer kernel where a template exists
+        # bf16 up blocks: depthwise transposed conv recomputed in the mixer's prologue, its 2C-channel high-resolution
+        # output never written (pw_mlp_up_kernels.hip); statistics from a store-less launch of the same depthwise kernel
+        self.fuse_up = True
+        self.fuse_up_cin = (64, 128)       # input widths the fused up kernel is used for (A/B switch for measurements)
 
     # ---- parameter repacking (load time / after optimizer steps) -----------------------------
     def _taps(self, conv: nn.Module):
@@ -228,6 +232,12 @@ class HipBlockOps:
         taps, K = self._taps(m.conv1)
         b1 = self._vec(m.conv1, "bias", m.conv1.bias)
         kind = m.kind
+        c_hid = m.conv2.weight.shape[0]
+        c_out = m.conv3.weight.shape[0]
+        if (kind == "up" and self.fused and self.fuse_up and C in self.fuse_up_cin and dt == torch.bfloat16 and K == 3 and not m.grn and not is_ln
+                and skip is not None and m.conv2.bias is not None and m.conv3.bias is not None
+                and ops.pw_mlp_up_supported(C, c_hid, c_out)):
+            return self._up_block_fused(m, x, skip, taps, b1, c_hid, c_out)
         if kind == "up":
             t, st = ops.dwconv3d(x, taps, b1, K=K, transposed=True, stats=not is_ln)
             count = float((2 * D - 1) * (2 * H - 1) * (2 * W - 1))
@@ -243,8 +253,6 @@ class HipBlockOps:
             ab = ops.groupnorm_finalize(st, count, gamma, beta, m.norm.eps)
         _, Do, Ho, Wo, _ = t.shape
         rows = Do * Ho * Wo
-        c_hid = m.conv2.weight.shape[0]
-        c_out = m.conv3.weight.shape[0]
         if (self.fused and dt == torch.bfloat16 and not m.grn and not is_ln and m.conv2.bias is not None
                 and m.conv3.bias is not None and ops.pw_mlp_supported(C, c_hid, c_out)):
             if (head is not None and kind == "block" and head.weight.shape[1] <= 16
@@ -354,6 +362,27 @@ def _block_fused(self, m, x, t, ab, skip, ishape, oshape, c_hid, c_out):
     return y.view(N, Do, Ho, Wo, c_out)
 
 
+def _up_block_fused(self, m, x, skip, taps, b1, c_hid, c_out):
+    """Up block without the depthwise output in HBM: statistics-only pass of the transposed depthwise kernel (bit-identical
+    partial sums), then ONE mixer launch that forms its operand from the low-resolution input."""
+    N, D, H, W, C = x.shape
+    dt = torch.bfloat16
+    _, st = ops.dwconv3d(x, taps, b1, K=3, transposed=True, stats=True, store=False)
+    ab = ops.groupnorm_finalize(st, float((2 * D - 1) * (2 * H - 1) * (2 * W - 1)), self._vec(m.norm, "weight", m.norm.weight),
+                                self._vec(m.norm, "bias", m.norm.bias), m.norm.eps)
+    res_low = res_bias = None
+    if m.resample_do_res:
+        res_bias = self._vec(m.res_conv, "bias", m.res_conv.bias)
+        paired = ops.pw_conv_paired_supported(c_in=C, c_out=c_out, in_dtype=dt, out_dtype=dt)
+        wres = self._pw_paired(m.res_conv, transposed=True) if paired else self._pw(m.res_conv, dt, transposed=True)
+        res_low = ops.pw_conv(x, wres, res_bias, N=N, rows_per_sample=D * H * W, c_in=C, c_out=c_out, out_dtype=dt,
+                              w_paired=paired)
+    return ops.pw_mlp_up(x, taps, b1, ab, self._pw_paired(m.conv2), self._vec(m.conv2, "bias", m.conv2.bias),
+                         self._pw_paired(m.conv3), self._vec(m.conv3, "bias", m.conv3.bias), skip.contiguous(),
+                         c_hid=c_hid, c_out=c_out, res_low=res_low, res_bias=res_bias)
+
+
+HipBlockOps._up_block_fused = _up_block_fused
 HipBlockOps._block_fused = _block_fused
 HipBlockOps._stem_block_fused = _stem_block_fused
 

@@ -230,3 +230,26 @@ def test_mednext_grn_and_layernorm_variants_match_oracle(dev, norm_type, grn, dt
         torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-3)
     with pytest.raises(NotImplementedError):
         m.train()(x.to(dev))                       # the training kernels cover GroupNorm blocks only
+
+
+@pytest.mark.parametrize("size,shape", [("S", (32, 32, 48)), ("S", (16, 48, 80)), ("L", (32, 32, 32)), ("B", (16, 32, 64))])
+def test_fused_up_block_is_bit_identical_to_unfused(size, shape):
+    """pw_mlp_up (depthwise transposed conv recomputed in the mixer prologue, statistics from the store-less launch of the same
+    depthwise kernel) against dwconvT3d + pw_mlp(RES_UPSAMPLE): same fp32 operation order, same bf16 roundings, same partial-sum
+    tree -> bit-identical logits.  Shapes include low-resolution rows that are not multiples of the 16-cell tile."""
+    from pytorch_connectomics_amd.models.architectures.mednext import create_mednext_v1
+    torch.manual_seed(3)
+    m = create_mednext_v1(1, 2, size, 3).cuda().eval()
+    m.compute_dtype = torch.bfloat16
+    with torch.no_grad():
+        for n, p_ in m.named_parameters():
+            if n.endswith("norm.weight") or n.endswith("norm.bias") or n.endswith("conv1.bias") or n.endswith("res_conv.bias"):
+                p_.add_(0.2 * torch.randn_like(p_))
+        x = torch.randn(2, *shape, 1, device="cuda")
+        m._hip.fuse_up = False
+        ref = m.forward_cl(x)
+        m._hip.fuse_up = True
+        got = m.forward_cl(x)
+        assert torch.equal(got, ref)
+        m._hip.fuse_up_cin = (64,)            # level 0 only
+        assert torch.equal(m.forward_cl(x), ref)

@@ -203,3 +203,106 @@ def test_resume_manifest_file_format_interchanges_with_reference(tmp_path, golde
     own.mark_many(["z2_y2_x1", "z1_y2_x1"])
     assert json.loads(q.read_text()) == json.loads(ref_text)
     assert ResumeManifest.load_or_create(q, cfg, overwrite=True).completed == set()
+
+
+# ------------------------------------------------------------------------------------------------ HDF5 container / ROI
+h5 = pytest.importorskip("pytorch_connectomics_amd.utils.h5lite")
+needs_h5 = pytest.mark.skipif(h5.get_h5_backend() is None, reason="no HDF5 backend (h5py / libhdf5) on this box")
+
+
+@needs_h5
+def test_chunked_hdf5_layout_matches_reference_vocabulary(tmp_path):
+    """chunk_{key}.h5 files (dataset `main` CZYX, gzip, (C, <=64^3) HDF5 chunks, the reference's attribute vocabulary),
+    <output>.index.json in the reference's field names, stitched artifact streamed by z slabs (reference chunked.py:279-434)."""
+    be = h5.get_h5_backend()
+    vol = np.random.default_rng(3).random((10, 13, 9)).astype(np.float32)
+    cfg = _cfg((4, 5, 6), halo=(1, 2, 1))
+    cfg.model = NS(arch=NS(type="mednext"))
+    cfg.inference.prediction_transform = NS(enabled=True, intensity_scale=255.0, intensity_dtype="uint8")
+    out = run_chunked_prediction_inference(cfg, None, vol, output_path=tmp_path / "pred.h5", predict_region_fn=_fake_predictor(vol),
+                                           image_path="vol.h5", checkpoint_path="last.ckpt")
+    want = np.clip(np.stack([vol, vol * 2 + 1]) * np.float32(255.0), 0, 255).astype(np.uint8)
+    assert out.dtype == np.uint8 and np.array_equal(out, want)
+    files = sorted(p.name for p in (tmp_path / "pred.h5.chunks").glob("chunk_*.h5"))
+    assert len(files) == 3 * 3 * 2 and files[0] == "chunk_z0_y0_x0.h5"
+    with be.File(tmp_path / "pred.h5.chunks" / "chunk_z1_y2_x1.h5", "r") as fh:
+        d = fh["main"]
+        assert d.shape == (2, 4, 3, 3) and d.dtype == np.uint8 and d.chunks == (2, 4, 3, 3)
+        a = dict(d.attrs.items())
+        assert a["kind"] == "raw_prediction" and a["layout"] == "CZYX" and a["chunk_key"] == "z1_y2_x1"
+        assert json.loads(a["chunk_start_zyx"]) == [4, 10, 6] and json.loads(a["chunk_stop_zyx"]) == [8, 13, 9]
+        assert json.loads(a["chunk_read_start_zyx"]) == [3, 8, 5] and json.loads(a["chunk_read_stop_zyx"]) == [9, 13, 9]
+        assert json.loads(a["halo"]) == [1, 2, 1] and a["intensity_dtype"] == "uint8" and a["intensity_scale"] == 255.0
+        assert a["image_path"] == "vol.h5" and a["checkpoint_path"] == "last.ckpt" and a["model_architecture"] == "mednext"
+        assert np.array_equal(d[...], want[:, 4:8, 10:13, 6:9])
+    idx = json.loads((tmp_path / "pred.h5.index.json").read_text())
+    assert set(idx) == {"input_shape", "final_shape", "chunk_shape", "halo", "crop_pad", "checkpoint_path", "world_size", "chunks"}
+    assert idx["final_shape"] == [10, 13, 9] and idx["world_size"] == 1 and len(idx["chunks"]) == 18
+    assert idx["chunks"][0] == {"key": "z0_y0_x0", "index_zyx": [0, 0, 0], "start_zyx": [0, 0, 0], "stop_zyx": [4, 5, 6],
+                               "path": "pred.h5.chunks/chunk_z0_y0_x0.h5"}
+    with be.File(tmp_path / "pred.h5", "r") as fh:
+        d = fh["main"]
+        assert d.shape == (2, 10, 13, 9) and d.chunks == (2, 10, 13, 9)
+        a = dict(d.attrs.items())
+        assert json.loads(a["final_shape"]) == [10, 13, 9] and "chunk_stitch_source" in a and a["compression"] == "gzip"
+    # resume: every chunk is on disk and in the manifest -> nothing is predicted again
+    def boom(*_a):
+        raise AssertionError("chunk recomputed on resume")
+    again = run_chunked_prediction_inference(cfg, None, vol, output_path=tmp_path / "pred.h5", predict_region_fn=boom)
+    assert np.array_equal(again, want)
+    cfg.inference.save_backend = "zarr"
+    with pytest.raises(ValueError, match="single streamed HDF5"):
+        run_chunked_prediction_inference(cfg, None, vol, output_path=tmp_path / "x.h5", predict_region_fn=boom)
+    cfg.inference.save_backend = "h5"
+    cfg.inference.chunking.precomputed = True
+    with pytest.raises(NotImplementedError, match="precomputed"):
+        run_chunked_prediction_inference(cfg, None, vol, output_path=tmp_path / "y.h5", predict_region_fn=boom)
+
+
+def test_roi_restricted_chunking_and_helpers(tmp_path):
+    """inference.chunking.roi (chunked.py:217-272): chunks outside the ROI are dropped, straddling ones cropped, keys keep
+    the global grid naming; plus the chunk_grid.py:78-111 resolvers."""
+    from pytorch_connectomics_amd.inference.chunk_grid import (resolve_chunk_output_mode, resolve_h5_spatial_chunks,
+                                                               validate_chunked_output_format)
+    from pytorch_connectomics_amd.inference.chunked import (_filter_chunks_to_roi, _resolve_inference_roi,
+                                                            _to_abiss_affinity_convention)
+    cfg = _cfg((4, 5, 6))
+    assert _resolve_inference_roi(cfg) is None
+    cfg.inference.chunking.roi = [6, 7, 9]
+    assert _resolve_inference_roi(cfg) == ((0, 0, 0), (6, 7, 9))
+    cfg.inference.chunking.roi = [1, 2, 0, 6, 7, 8]
+    roi = _resolve_inference_roi(cfg)
+    assert roi == ((1, 2, 0), (6, 7, 8))
+    for bad in ([1, 2], [3, 3, 3, 3, 9, 9]):
+        cfg.inference.chunking.roi = bad
+        with pytest.raises(ValueError, match="roi"):
+            _resolve_inference_roi(cfg)
+    chunks = build_chunk_grid((10, 13, 9), (4, 5, 6))
+    kept = _filter_chunks_to_roi(chunks, roi, (0, 0, 0))
+    assert [c.key for c in kept] == ["z0_y0_x0", "z0_y0_x1", "z0_y1_x0", "z0_y1_x1", "z1_y0_x0", "z1_y0_x1", "z1_y1_x0", "z1_y1_x1"]
+    assert kept[0].start == (1, 2, 0) and kept[0].stop == (4, 5, 6) and kept[-1].start == (4, 5, 6) and kept[-1].stop == (6, 7, 8)
+    # with a leading crop the ROI (input coordinates) is shifted into the cropped output space
+    k2 = _filter_chunks_to_roi(build_chunk_grid((8, 13, 9), (4, 5, 6)), ((2, 0, 0), (6, 13, 9)), (2, 0, 0))
+    assert {c.key for c in k2} == {f"z0_y{y}_x{x}" for y in range(3) for x in range(2)} and all(c.stop[0] == 4 for c in k2)
+    vol = np.random.default_rng(4).random((10, 13, 9)).astype(np.float32)
+    cfg.inference.chunking.roi = [1, 2, 0, 6, 7, 8]
+    out = run_chunked_prediction_inference(cfg, None, vol, output_path=tmp_path / "r.npy", predict_region_fn=_fake_predictor(vol))
+    want = np.zeros((2, 10, 13, 9), np.float32)
+    want[:, 1:6, 2:7, 0:8] = np.stack([vol, vol * 2 + 1])[:, 1:6, 2:7, 0:8]
+    np.testing.assert_array_equal(out, want)
+    assert len(list((tmp_path / "r.npy.chunks").glob("chunk_*.npy"))) == 8
+    # resolvers
+    assert resolve_h5_spatial_chunks((10, 200, 64)) == (10, 64, 64)
+    cfg.inference.chunking.output_mode = "raw_prediction"
+    assert resolve_chunk_output_mode(cfg) == "raw_prediction"
+    cfg.inference.chunking.output_mode = "labels"
+    with pytest.raises(ValueError, match="output_mode"):
+        resolve_chunk_output_mode(cfg)
+    validate_chunked_output_format(cfg)
+    # ABISS convention: dst[c, v] = src[c, v-1] along spatial axis c, then channels reversed
+    a = np.arange(3 * 2 * 3 * 4, dtype=np.float32).reshape(3, 2, 3, 4)
+    b = _to_abiss_affinity_convention(a)
+    assert np.array_equal(b[2][1:], a[0][:-1]) and np.all(b[2][0] == 0)          # z-affinity: shifted in z, now channel 2
+    assert np.array_equal(b[0][:, :, 1:], a[2][:, :, :-1]) and np.all(b[0][:, :, 0] == 0)
+    with pytest.raises(ValueError, match="3-channel"):
+        _to_abiss_affinity_convention(a[:2])

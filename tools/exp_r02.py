@@ -80,7 +80,22 @@ def lut():
     knob("dwconv_march_wgs", 1024)
 
 
+def upfuse():
+    m = model_s()
+    x = torch.rand(8, 112, 112, 112, 1, device=dev)
+    hip = m.model._hip
+    for name, on, cin in (("unfused", False, (64, 128)), ("fused L0", True, (64,)), ("fused L0+L1", True, (64, 128))):
+        hip.fuse_up, hip.fuse_up_cin = on, cin
+        print(f"up blocks {name}: {time_forward(m, x):8.3f} ms / 8 windows", flush=True)
+    hip.fuse_up, hip.fuse_up_cin = True, (64, 128)
+    with torch.no_grad(), ops.profiled() as prof:
+        for _ in range(3):
+            m.forward_cl(x)
+    for k, v in sorted(prof.summary().items(), key=lambda kv: -kv[1]["ms"])[:14]:
+        print(f"   {k:36s} launches={v['launches'] / 3:5.1f} ms/fwd={v['ms'] / 3:7.3f} GB/s={v['bytes'] / max(v['ms'], 1e-9) / 1e6:8.1f}")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["nsweep", "lut"]
+    which = sys.argv[1:] or ["nsweep", "lut", "upfuse"]
     for w in which:
         globals()[w]()
