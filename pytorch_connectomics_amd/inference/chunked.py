@@ -35,7 +35,9 @@ from ..utils.h5lite import get_h5_backend
 from .artifact import build_prediction_artifact_metadata, read_prediction_artifact, write_prediction_artifact
 from .chunk_grid import resolve_chunk_shape, resolve_h5_spatial_chunks, validate_chunked_output_format
 from .crop import cropped_shape, resolve_global_prediction_crop
-from .lazy import get_lazy_image_reference_shape, lazy_predict_region
+from .lazy import (LazyVolumeAccessor, get_lazy_image_reference_shape, lazy_predict_region, lazy_region_read_box,
+                   open_lazy_source)
+from .lazy_accessor import RegionPrefetcher
 from .output import apply_prediction_transform, apply_storage_dtype_transform
 
 logger = logging.getLogger(__name__)
@@ -300,7 +302,12 @@ def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, de
     validate_chunked_output_format(cfg)
     output_path = _normalise_output_path(output_path)
     h5 = _use_h5(output_path)
-    input_shape = get_lazy_image_reference_shape(volume)
+    owned_source = None
+    if isinstance(volume, (str, bytes)) or hasattr(volume, "__fspath__"):      # a disk-backed volume: open it once
+        if image_path is None:
+            image_path = str(volume)
+        volume = owned_source = open_lazy_source(cfg, volume)
+    input_shape = get_lazy_image_reference_shape(volume, cfg)
     # the chunk grid lives in the CROPPED output space (user crop_pad + DeepEM affinity border, reference
     # chunked.py:743-755); a chunk's core in input coordinates is shifted by the leading crop
     crop_pad = resolve_global_prediction_crop(cfg)
@@ -330,10 +337,21 @@ def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, de
                                               "roi": None if roi is None else [list(roi[0]), list(roi[1])],
                                               "container": "h5" if h5 else "npy"},
                                              overwrite=overwrite)
+    prefetch = None
     if predict_region_fn is None:
+        todo = [c for _i, c in mine if not (_chunk_file(cdir, c, h5).exists() and c.key in manifest.completed)]
+        if isinstance(volume, LazyVolumeAccessor) and not volume.needs_per_patch_host_path and todo:
+            # disk read + decompression of chunk i+1 into pinned memory on an IO thread while chunk i is predicted
+            boxes = []
+            for c in todo:
+                rl, rh, _core = resolve_halo_region(c, input_shape[-3:], halo=halo, crop_before=crop_before)
+                boxes.append(lazy_region_read_box(cfg, input_shape[-3:], rl, rh))
+            prefetch = RegionPrefetcher(volume, boxes)
+
         def predict_region_fn(start, stop):
+            pre = prefetch.get() if prefetch is not None else None
             return lazy_predict_region(cfg, forward_fn, volume, region_start=start, region_stop=stop, device=device,
-                                       requested_head=requested_head)
+                                       requested_head=requested_head, preloaded=pre)
     tc = getattr(getattr(cfg, "inference", None), "prediction_transform", None)
     tc_on = tc is not None and bool(getattr(tc, "enabled", False))
     img_name = image_path if image_path is not None else getattr(volume, "filename", None) or "<array>"
@@ -371,6 +389,8 @@ def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, de
             writer.submit(core_pred, f, c.key)
     finally:
         writer.close()
+        if owned_source is not None:
+            owned_source.close()
     if ext is not None:
         return None       # external shards are stitched by a later call once every shard has run
     if world > 1:

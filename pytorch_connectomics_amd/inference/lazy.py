@@ -11,7 +11,10 @@ accumulated -- so a chunk's prediction equals the matching slice of the whole-vo
 
 MI355X design: the source volume (numpy / memmap / tensor; host or device) is brought to HBM once per region
 (the bounding box of the intersecting windows), windows are gathered / blended by the HIP kernels and the
-fp32 accumulators never leave the device.  Disk readers (h5/zarr/tiff) are out of scope for round 1.
+fp32 accumulators never leave the device.  Disk-backed sources go through inference/lazy_accessor.py (`LazyVolumeAccessor`
+over HDF5 / .npy / zarr v2 with the reference's lazy transforms): a path or an accessor may be passed as `volume`; the region
+box is read once (`read_region`, optionally prefetched into pinned memory by the chunked runner) unless the image pipeline
+needs per-window statistics, in which case windows are read one by one with `read_patch` exactly like the reference.
 """
 from __future__ import annotations
 
@@ -26,6 +29,7 @@ from .. import _native as nat
 from .. import hip_ops as ops
 from ..utils.channel_slices import resolve_channel_indices
 from ..utils.model_outputs import get_inference_channel_activations, get_inference_select_channel, select_output_tensor
+from .lazy_accessor import LazyVolumeAccessor, build_accessor
 from .window import (_axis_kernels, compute_scan_interval, resolve_border_mask,
                      resolve_inferer_overlap, resolve_inferer_roi_size, resolve_model_output_dtype)
 
@@ -87,8 +91,36 @@ def _resolve_target_context(sliding_cfg, roi_size) -> tuple[int, int, int]:
     return ctx
 
 
-def get_lazy_image_reference_shape(volume) -> tuple[int, int, int]:
+def get_lazy_image_reference_shape(volume, cfg=None) -> tuple[int, int, int]:
+    """ZYX extent of the (transformed, context-padded) test volume: arrays / tensors / accessors by shape, paths through an
+    accessor built from `cfg` (reference lazy.py:962-983)."""
+    if isinstance(volume, (str, bytes)) or hasattr(volume, "__fspath__"):
+        with open_lazy_source(cfg, volume) as acc:
+            return tuple(int(v) for v in acc.padded_spatial_shape)
     return tuple(int(v) for v in volume.shape[-3:])
+
+
+class _DefaultDataCfg:
+    """cfg.data view with the reference's defaults for configs that carry no data section (tests, array sources)."""
+
+    def __init__(self, cfg):
+        from types import SimpleNamespace as NS
+        d = getattr(cfg, "data", None)
+        self.system = getattr(cfg, "system", None) or NS(num_workers=1)
+        self.data = NS(dataloader=getattr(d, "dataloader", None) or NS(patch_size=None),
+                       data_transform=getattr(d, "data_transform", None) or NS(val_transpose=None, pad_size=[0, 0, 0],
+                                                                               pad_mode="reflect", resize=None),
+                       image_transform=getattr(d, "image_transform", None) or NS(normalize="none", clip_percentile_low=0.0,
+                                                                                 clip_percentile_high=1.0, resize=None),
+                       mask_transform=getattr(d, "mask_transform", None))
+
+
+def open_lazy_source(cfg, volume):
+    """path -> LazyVolumeAccessor under the config's test-time transforms; accessors pass through."""
+    if isinstance(volume, LazyVolumeAccessor):
+        return volume
+    return build_accessor(_DefaultDataCfg(cfg), str(volume if not isinstance(volume, bytes) else volume.decode()), kind="image",
+                          mode="test")
 
 
 def _as_channel_first(volume):
@@ -141,7 +173,7 @@ def _window_preprocess(cfg, pred_cl: torch.Tensor) -> torch.Tensor:
 @torch.no_grad()
 def _lazy_sliding_window(cfg, forward_fn, volume, *, region_start, region_stop, device, requested_head=None,
                          window_filter: Optional[Callable[[int, int], bool]] = None,
-                         return_accumulators: bool = False):
+                         return_accumulators: bool = False, preloaded=None):
     roi = resolve_inferer_roi_size(cfg)
     if roi is None:
         raise ValueError("Lazy sliding-window inference requires inference.sliding_window.window_size "
@@ -164,8 +196,12 @@ def _lazy_sliding_window(cfg, forward_fn, volume, *, region_start, region_stop, 
     border = resolve_border_mask(cfg, 3) or None
     primary = getattr(getattr(cfg, "model", None), "primary_head", None)
 
-    vol = _as_channel_first(volume)
-    bounds = tuple(int(v) for v in vol.shape[1:])
+    owned = None
+    if isinstance(volume, (str, bytes)) or hasattr(volume, "__fspath__"):
+        volume = owned = open_lazy_source(cfg, volume)
+    accessor = volume if isinstance(volume, LazyVolumeAccessor) else None
+    vol = None if accessor is not None else _as_channel_first(volume)
+    bounds = tuple(int(v) for v in (accessor.padded_spatial_shape if accessor is not None else vol.shape[1:]))
     if any(bounds[a] < int(roi[a]) for a in range(3)):
         raise ValueError("Lazy sliding-window inference requires the transformed test volume to be at least as "
                          f"large as the ROI in every axis. Got bounds_shape={bounds}, roi_size={tuple(roi)}.")
@@ -186,11 +222,18 @@ def _lazy_sliding_window(cfg, forward_fn, volume, *, region_start, region_stop, 
     read = tuple(int(roi[a]) + 2 * ctx[a] for a in range(3))
     lo = tuple(max(0, min(w[a] for w in wins) - ctx[a]) for a in range(3))
     hi = tuple(min(bounds[a], max(w[a] for w in wins) + int(roi[a]) + ctx[a]) for a in range(3))
-    sub = vol[:, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
-    if isinstance(sub, np.ndarray):
-        sub = torch.from_numpy(np.ascontiguousarray(sub, dtype=np.float32))
-    sub = sub.to(device=dev, dtype=torch.float32).contiguous()
-    box = tuple(int(v) for v in sub.shape[1:])
+    per_patch = accessor is not None and accessor.needs_per_patch_host_path
+    sub = None
+    if preloaded is not None and tuple(preloaded[0]) == (lo, hi):
+        sub = preloaded[1]                                   # read ahead by the chunked runner (pinned host memory)
+    elif accessor is not None and not per_patch:
+        sub = torch.from_numpy(np.ascontiguousarray(accessor.read_region(lo, hi)))
+    elif accessor is None:
+        sub = vol[:, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+        if isinstance(sub, np.ndarray):
+            sub = torch.from_numpy(np.ascontiguousarray(sub, dtype=np.float32))
+    if sub is not None:
+        sub = sub.to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
 
     ks, combine = _axis_kernels(roi, blend, torch.float32)
     wz, wy, wx = (k.to(dev).contiguous() for k in ks)
@@ -202,8 +245,14 @@ def _lazy_sliding_window(cfg, forward_fn, volume, *, region_start, region_stop, 
         chunk = wins[b0:b0 + swb]
         # windows overhang the box only where the box touches the volume border; the kernel's periodic
         # reflect / replicate / circular index math equals the np.pad semantics of the reference reader
-        rel = [tuple(w[a] - ctx[a] - lo[a] for a in range(3)) for w in chunk]
-        x = ops.gather_windows(sub, rel, read, pad_mode=pad_mode, cval=cval)
+        if per_patch:
+            # per-window statistics (z-score / min-max / percentile clip of THAT window): host reads like the reference
+            host = np.stack([accessor.read_patch(tuple(w[a] - ctx[a] for a in range(3)), read, outer_pad_mode=pad_mode,
+                                                 outer_pad_value=cval) for w in chunk])
+            x = torch.from_numpy(host).to(dev).permute(0, 2, 3, 4, 1).contiguous()
+        else:
+            rel = [tuple(w[a] - ctx[a] - lo[a] for a in range(3)) for w in chunk]
+            x = ops.gather_windows(sub, rel, read, pad_mode=pad_mode, cval=cval)
         if fwd_cl is not None:
             pred = fwd_cl(x)
         else:
@@ -226,6 +275,8 @@ def _lazy_sliding_window(cfg, forward_fn, volume, *, region_start, region_stop, 
             value = torch.zeros((int(pred.shape[-1]),) + out_size, dtype=torch.float32, device=dev)
         rel_starts = [tuple(w[a] - start[a] for a in range(3)) for w in chunk]
         ops.blend_accumulate(pred, rel_starts, value, weight, wz, wy, wx, combine=combine, floor_w=1e-5, border=border)
+    if owned is not None:
+        owned.close()
     if return_accumulators:
         return value, weight
     ops.blend_finalize(value, weight, clamp=1e-4, act=nat.ACT_NONE)
@@ -234,12 +285,28 @@ def _lazy_sliding_window(cfg, forward_fn, volume, *, region_start, region_stop, 
     return out if odt == torch.float32 else out.to(odt)
 
 
+def lazy_region_read_box(cfg, bounds, region_start, region_stop):
+    """(lo, hi) of the box `_lazy_sliding_window` reads for a region: the bounding box of the global-grid windows that
+    intersect it (plus target_context), clipped to the volume.  The chunked runner prefetches exactly this box."""
+    roi = resolve_inferer_roi_size(cfg)
+    overlap = _coerce_overlap(resolve_inferer_overlap(cfg, roi), 3)
+    sw = getattr(getattr(cfg, "inference", None), "sliding_window", None)
+    ctx = _resolve_target_context(sw, roi)
+    start = tuple(max(0, int(v)) for v in region_start)
+    stop = tuple(min(int(bounds[a]), int(region_stop[a])) for a in range(3))
+    wins = [tuple(int(s.start) for s in sl) for sl in _build_intersecting_window_slices(
+        bounds, roi, overlap, region_start=start, region_stop=stop, snap_to_edge=bool(getattr(sw, "snap_to_edge", False)))]
+    lo = tuple(max(0, min(w[a] for w in wins) - ctx[a]) for a in range(3))
+    hi = tuple(min(int(bounds[a]), max(w[a] for w in wins) + int(roi[a]) + ctx[a]) for a in range(3))
+    return lo, hi
+
+
 def lazy_predict_region(cfg, forward_fn, volume, *, region_start: Sequence[int], region_stop: Sequence[int],
-                        device="cuda", requested_head: Optional[str] = None) -> torch.Tensor:
+                        device="cuda", requested_head: Optional[str] = None, preloaded=None) -> torch.Tensor:
     """Predict one bounded ZYX region of `volume`; windows come from the full-volume grid, so region borders
     see real neighbouring data wherever they are not true volume borders.  Returns (1, C, *region) on device."""
     return _lazy_sliding_window(cfg, forward_fn, volume, region_start=region_start, region_stop=region_stop,
-                                device=device, requested_head=requested_head)
+                                device=device, requested_head=requested_head, preloaded=preloaded)
 
 
 def lazy_predict_volume(cfg, forward_fn, volume, *, device="cuda", requested_head: Optional[str] = None) -> torch.Tensor:
@@ -266,6 +333,6 @@ def lazy_predict_volume(cfg, forward_fn, volume, *, device="cuda", requested_hea
     return out if odt == torch.float32 else out.to(odt)
 
 
-__all__ = ["lazy_predict_region", "lazy_predict_volume", "get_lazy_image_reference_shape",
+__all__ = ["lazy_predict_region", "lazy_predict_volume", "get_lazy_image_reference_shape", "open_lazy_source", "lazy_region_read_box",
            "_build_window_axis_offsets", "_build_window_slices", "_build_intersecting_window_slices",
            "_snap_offsets", "_resolve_target_context"]

@@ -116,14 +116,19 @@ def run_test(cfg, args) -> dict:
     image_spec = cfg.data.test.image or ("random://demo" if args.demo else None)
     if image_spec is None:
         raise ValueError("data.test.image is not set (use --demo for a random volume)")
-    vol = read_volume(str(image_spec))
+    lazy_dl = bool(getattr(cfg.data.dataloader, "use_lazy_h5", False) or getattr(cfg.data.dataloader, "use_lazy_zarr", False))
+    if is_chunked_inference_enabled(cfg) and lazy_dl and not str(image_spec).startswith("random://"):
+        vol = None           # disk-backed: the chunked runner reads region by region through LazyVolumeAccessor
+    else:
+        vol = read_volume(str(image_spec))
     out_dir = Path(cfg.save_path) / "results"
     out_dir.mkdir(parents=True, exist_ok=True)
     name = Path(str(image_spec).split("?")[0]).stem or "volume"
     t0 = time.perf_counter()
     with torch.no_grad():
         if is_chunked_inference_enabled(cfg):
-            pred = run_chunked_prediction_inference(cfg, model.forward, vol, output_path=out_dir / f"{name}_prediction.h5",
+            pred = run_chunked_prediction_inference(cfg, model.forward, vol if vol is not None else str(image_spec),
+                                                    output_path=out_dir / f"{name}_prediction.h5",
                                                     device=dev, image_path=str(image_spec), checkpoint_path=args.checkpoint)
             pred_t = None if pred is None else torch.from_numpy(pred).unsqueeze(0)
         else:
@@ -153,7 +158,8 @@ def run_test(cfg, args) -> dict:
             write_prediction_artifact(out_dir / f"{name}_prediction.h5", arr, metadata=md)
             pred_t = pred_t if isinstance(pred_t, torch.Tensor) else torch.from_numpy(np.asarray(pred_t))
     dt = time.perf_counter() - t0
-    metrics = {"seconds": dt, "output_voxels_per_s": float(np.prod(vol.shape[-3:])) / dt}
+    out_vox = float(np.prod(vol.shape[-3:])) if vol is not None else (float(np.prod(pred_t.shape[-3:])) if pred_t is not None else 0.0)
+    metrics = {"seconds": dt, "output_voxels_per_s": out_vox / dt}
     label_spec = cfg.data.test.label
     if label_spec and pred_t is not None:
         lab = torch.from_numpy(np.ascontiguousarray(read_volume(str(label_spec))))

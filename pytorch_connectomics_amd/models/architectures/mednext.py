@@ -147,8 +147,11 @@ class HipBlockOps:
         self.cache = _WeightCache()
         self.fused = True      # bf16: use the fused channel-mixer kernel where a template exists
         # bf16 up blocks: depthwise transposed conv recomputed in the mixer's prologue, its 2C-channel high-resolution
-        # output never written (pw_mlp_up_kernels.hip); statistics from a store-less launch of the same depthwise kernel
-        self.fuse_up = True
+        # output never written (pw_mlp_up_kernels.hip); statistics from a store-less launch of the same depthwise kernel.
+        # Bit-identical to the un-fused schedule and 1.9x less HBM traffic, but MEASURED SLOWER on MI355X (level 0, 8 x 112^3:
+        # 1.33 + 0.27 ms against 1.03 + 0.49 ms; profiles/r02_upfuse.txt): the mixer is bound by its VALU work (GELU), not by
+        # HBM, and the prologue adds 20 % more of it -- off by default, kept as the switch for when the activation gets cheaper.
+        self.fuse_up = False
         self.fuse_up_cin = (64, 128)       # input widths the fused up kernel is used for (A/B switch for measurements)
 
     # ---- parameter repacking (load time / after optimizer steps) -----------------------------

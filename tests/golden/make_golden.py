@@ -700,9 +700,65 @@ def manifests():
     print("wrote resume_manifest_ref.json")
 
 
+# ---------------------------------------------------------------- LazyVolumeAccessor (disk-backed reader) on an HDF5 file
+def accessor():
+    """connectomics/inference/lazy.py:456-917: the reference's own LazyVolumeAccessor reading HDF5 files, with the in-repo
+    h5lite module standing in for the absent `h5py` (both are thin layers over libhdf5; the files are ordinary HDF5) and the
+    REAL `smart_normalize` / `_detect_format` of the reference (imageio / cv2, which those modules import but these functions
+    do not use, are empty stubs).  Stores the input volumes and the patches / regions / shapes the reference returns."""
+    import tempfile
+    import types
+    REPO = HERE.parent.parent
+    sys.path.insert(0, str(REPO))
+    from pytorch_connectomics_amd.utils import h5lite
+    assert h5lite.available(), "libpytc_h5.so is needed to generate the accessor fixtures"
+    S.install()
+    sys.modules["h5py"] = h5lite
+    for name in ("imageio", "cv2"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    for name in ("connectomics.data.augmentation.augment_ops", "connectomics.data.io.io", "connectomics.inference.lazy"):
+        sys.modules.pop(name, None)          # drop the stubs / an earlier stub-based import: the real modules are wanted here
+    lz = S.ref("connectomics.inference.lazy")
+    rng = np.random.default_rng(21)
+    vols = {"zyx": (rng.random((12, 14, 18)) * 200).astype(np.uint8),                 # no channel axis
+            "czyx": rng.random((2, 10, 12, 16)).astype(np.float32),                   # channel first
+            "zyxc": (rng.random((10, 12, 16, 3)) * 1000).astype(np.uint16)}           # channel last
+    out = {}
+    cases = {
+        "plain": ("zyx", dict(kind="image"), [((0, 0, 0), (6, 7, 8)), ((-2, 3, 12), (6, 8, 10)), ((8, 10, 14), (8, 8, 8))], "reflect", 0.0),
+        "transpose_pad_reflect_div": ("zyx", dict(kind="image", transpose_axes=(2, 0, 1), context_pad=((2, 1), (0, 3), (2, 2)),
+                                                  context_pad_mode="reflect", normalize_mode="divide-255"),
+                                      [((0, 0, 0), (8, 8, 8)), ((-3, -1, 5), (10, 9, 12)), ((15, 6, 10), (8, 8, 8))], "constant", 0.25),
+        "resize_bilinear_znorm": ("czyx", dict(kind="image", scale_factors=(1.5, 0.75, 1.25), context_pad=((1, 1), (1, 1), (1, 1)),
+                                               context_pad_mode="constant", normalize_mode="normal", clip_percentile_low=0.05,
+                                               clip_percentile_high=0.95),
+                                  [((0, 0, 0), (8, 6, 10)), ((5, 2, 8), (8, 8, 8)), ((-1, -2, 14), (6, 6, 10))], "replicate", 0.0),
+        "channel_last_edge_01": ("zyxc", dict(kind="image", context_pad=((0, 2), (2, 0), (1, 1)), context_pad_mode="edge",
+                                              normalize_mode="0-1"),
+                                 [((0, 0, 0), (6, 6, 6)), ((6, 8, 10), (6, 8, 8))], "reflect", 0.0),
+        "mask_nearest_binarize": ("zyx", dict(kind="mask", scale_factors=(0.5, 2.0, 1.0), binarize=True, threshold=100.0),
+                                  [((0, 0, 0), (4, 10, 8)), ((2, 20, 10), (4, 8, 8))], "constant", 0.0),
+    }
+    with tempfile.TemporaryDirectory() as d:
+        paths = {}
+        for k, v in vols.items():
+            paths[k] = str(Path(d) / f"{k}.h5")
+            with h5lite.File(paths[k], "w") as fh:
+                fh.create_dataset("main", data=v, compression="gzip")
+            out[f"vol_{k}"] = v
+        for name, (vk, kw, reads, outer_mode, outer_val) in cases.items():
+            with lz.LazyVolumeAccessor(paths[vk], **kw) as acc:
+                out[f"{name}__shapes"] = np.asarray([acc.channel_count, *acc.raw_spatial_shape, *acc.logical_spatial_shape,
+                                                     *acc.transformed_spatial_shape, *acc.padded_spatial_shape], np.int64)
+                for i, (loc, size) in enumerate(reads):
+                    out[f"{name}__patch{i}"] = acc.read_patch(loc, size, outer_pad_mode=outer_mode, outer_pad_value=outer_val)
+                out[f"{name}__full"] = acc.load_full()
+    save("lazy_accessor.npz", **out)
+
+
 if __name__ == "__main__":
     parts = {"manifests": manifests, "optimizers": optimizers, "schedules": schedules, "selectors": selectors, "outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
-             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy}
+             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "accessor": accessor}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:
         parts[name]()
