@@ -301,6 +301,11 @@ pw_mlp_kernel(MlpParams p) {
   }
 }
 
+// Measured and removed (round 2, profiles/r02_mixer_two_tiles_per_wave.txt): a variant in which a wave owns TWO voxel tiles and
+// requests the rows of both before computing the first (to overlap one tile's loads with the other's GEMMs inside a wave) was
+// bit-identical and SLOWER at every shape (forward 9.39 -> 10.1 ms; 128->256->128: 0.26 -> 0.61 ms): the registers of the second
+// tile cost a wave per SIMD, and this kernel lives on occupancy -- its per-wave critical path (MFMA -> GELU -> MFMA dependency
+// chains) is hidden by other waves, not by memory-level parallelism inside one.
 __global__ void __launch_bounds__(256)
 pw_pack_paired_kernel(const float* __restrict__ w, int C_out, int C_in, int transposed,
                       bf16_t* __restrict__ packed, int KG, long total) {

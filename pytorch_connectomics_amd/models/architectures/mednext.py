@@ -435,6 +435,9 @@ class MedNeXt(nn.Module):
         self.do_ds = deep_supervision
         self.inside_block_checkpointing = False
         self.outside_block_checkpointing = checkpoint_style == "outside_block"
+        # how the training path honours `outside_block` (training/autograd.py:use_block_recompute): 'auto' recomputes the
+        # per-block activations only when keeping them would take more than half of the free HBM; 'always' / 'never' force it
+        self.checkpoint_policy = "auto"
         if kernel_size is not None:
             enc_kernel_size = dec_kernel_size = kernel_size
         conv, _ = _conv_nd(dim)

@@ -102,20 +102,39 @@ class PointwiseFn(torch.autograd.Function):
 
 
 class BlockFn(torch.autograd.Function):
-    """MedNeXt block / down block / up block.  `kind` in {"block", "down", "up"}."""
+    """MedNeXt block / down block / up block.  `kind` in {"block", "down", "up"}.  `recompute` = the reference's
+    `outside_block` activation checkpointing (mednext_models.py:386-393: torch.utils.checkpoint around every block): only the
+    block input and the (N, 2, C) norm vectors are kept; the depthwise output and the hidden pre-activation are rebuilt by
+    the same kernels at the start of the backward (bit-identical values, one extra block forward)."""
 
     @staticmethod
-    def forward(ctx, x, skip, w1, b1, gamma, beta, w2, b2, w3, b3, wres, bres, kind: str, do_res: bool, eps: float):
+    def forward(ctx, x, skip, w1, b1, gamma, beta, w2, b2, w3, b3, wres, bres, kind: str, do_res: bool, eps: float,
+                recompute: bool = False):
+        y, t, ab, mr, hp, taps, K, count = BlockFn._core(x, skip, w1, b1, gamma, beta, w2, b2, w3, b3, wres, bres, kind,
+                                                         do_res, eps, None)
+        keep = x.new_zeros(0)
+        ctx.save_for_backward(x, keep if recompute else t, ab, mr, keep if recompute else hp, w1, gamma, w2, w3,
+                              wres if wres is not None else keep, skip if (recompute and skip is not None) else keep,
+                              b1 if (recompute and b1 is not None) else keep, b2 if recompute else keep, b3 if recompute else keep,
+                              bres if (recompute and bres is not None) else keep)
+        ctx.meta = (kind, do_res, K, count, wres is not None, skip is not None, b1 is not None, bres is not None, recompute, eps)
+        ctx.taps = taps                  # derived from w1 (no gradient flows through it): reused by the backward
+        return y
+
+    @staticmethod
+    def _core(x, skip, w1, b1, gamma, beta, w2, b2, w3, b3, wres, bres, kind, do_res, eps, ab_mr):
+        """The block's forward kernels.  ab_mr = (ab, mr) of an earlier identical call: the statistics pass is skipped
+        (recomputation inside the backward)."""
         N, D, H, W, C = x.shape
         dt = x.dtype
         taps, K = _taps(w1)
         if kind == "up":
-            t, st = ops.dwconv3d(x, taps, _f(b1), K=K, transposed=True)
+            t, st = ops.dwconv3d(x, taps, _f(b1), K=K, transposed=True, stats=ab_mr is None)
             count = float((2 * D - 1) * (2 * H - 1) * (2 * W - 1))
         else:
-            t, st = ops.dwconv3d(x, taps, _f(b1), K=K, stride=2 if kind == "down" else 1)
+            t, st = ops.dwconv3d(x, taps, _f(b1), K=K, stride=2 if kind == "down" else 1, stats=ab_mr is None)
             count = float(_rows(t))
-        ab, mr = ops.groupnorm_finalize_mr(st, count, _f(gamma), _f(beta), eps)
+        ab, mr = ops.groupnorm_finalize_mr(st, count, _f(gamma), _f(beta), eps) if ab_mr is None else ab_mr
         rows = _rows(t)
         c_hid, c_out = w2.shape[0], w3.shape[0]
         fused = (dt == torch.bfloat16 and b2 is not None and b3 is not None and ops.pw_mlp_supported(C, c_hid, c_out)
@@ -155,15 +174,19 @@ class BlockFn(torch.autograd.Function):
             else:
                 y = _pw(h, _mat(w3), _f(b3), c_out=c_out, rows=rows, res=sk, res_mode=nat.RES_UPSAMPLE,
                         grid=tuple(t.shape[1:4]), res_low=res_low, res_bias=_f(bres) if wres is not None else None, **G)
-        ctx.save_for_backward(x, t, ab, mr, hp, w1, gamma, w2, w3, wres if wres is not None else x.new_zeros(0))
-        ctx.meta = (kind, do_res, K, count, wres is not None, skip is not None, b1 is not None, bres is not None)
-        ctx.taps = taps                  # derived from w1 (no gradient flows through it): reused by the backward
-        return y.view(N, *t.shape[1:4], c_out)
+        return y.view(N, *t.shape[1:4], c_out), t, ab, mr, hp, taps, K, count
 
     @staticmethod
     def backward(ctx, dy):
-        x, t, ab, mr, hp, w1, gamma, w2, w3, wres = ctx.saved_tensors
-        kind, do_res, K, count, has_res, has_skip, has_b1, has_bres = ctx.meta
+        x, t, ab, mr, hp, w1, gamma, w2, w3, wres, skip_s, b1_s, b2_s, b3_s, bres_s = ctx.saved_tensors
+        kind, do_res, K, count, has_res, has_skip, has_b1, has_bres, recompute, eps = ctx.meta
+        if recompute:
+            # outside-block checkpointing: rebuild t and the hidden pre-activation with the forward's own kernels
+            with torch.no_grad():
+                _y, t, _ab, _mr, hp, _taps_, _K, _c = BlockFn._core(
+                    x, skip_s if (has_skip and skip_s.numel()) else None, w1, b1_s if has_b1 else None, gamma, None, w2, b2_s, w3,
+                    b3_s, wres if has_res else None, bres_s if has_bres else None, kind, do_res, eps, (ab, mr))
+            del _y
         N, D, H, W, C = x.shape
         dy = dy.contiguous()
         rows = _rows(t)
@@ -238,34 +261,72 @@ class BlockFn(torch.autograd.Function):
         return (dx, dskip, g(dW1.t().contiguous(), w1), (db1.to(w1.dtype) if has_b1 else None), g(dgamma, gamma),
                 g(dbeta, gamma), g(dW2, w2), db2.to(w2.dtype), g(dW3, w3), db3.to(w3.dtype),
                 (g(dwres, wres) if has_res else None), (dbres.to(w3.dtype) if (has_res and has_bres) else None),
-                None, None, None)
+                None, None, None, None)
 
 
-def _block(m, x, skip=None):
+def _block(m, x, skip=None, recompute: bool = False):
     if m.grn or not isinstance(m.norm, nn.GroupNorm) or m.dim != "3d":
         raise NotImplementedError("training kernels cover GroupNorm / 3-D MedNeXt blocks only")
     res = getattr(m, "res_conv", None) if getattr(m, "resample_do_res", False) else None
     return BlockFn.apply(x, skip, m.conv1.weight, m.conv1.bias, m.norm.weight, m.norm.bias, m.conv2.weight,
                          m.conv2.bias, m.conv3.weight, m.conv3.bias, None if res is None else res.weight,
-                         None if res is None else res.bias, m.kind, bool(m.do_res), float(m.norm.eps))
+                         None if res is None else res.bias, m.kind, bool(m.do_res), float(m.norm.eps), bool(recompute))
+
+
+def saved_activation_bytes(trunk, in_shape, compute_dtype: torch.dtype) -> int:
+    """Bytes BlockFn keeps per training forward without checkpointing (block input + depthwise output + hidden
+    pre-activation of every block), from the trunk's widths and the (N, D, H, W, C) input shape."""
+    N, D, H, W = (int(v) for v in in_shape[:4])
+    esz = 2 if compute_dtype == torch.bfloat16 else 4
+    total = 0
+    for name, mod in trunk.named_modules():
+        if hasattr(mod, "conv2") and hasattr(mod, "kind"):
+            lvl_vox = None
+            c_in, c_hid = mod.conv2.weight.shape[1], mod.conv2.weight.shape[0]
+            # the level of a block follows from its width: width = n_channels * 2^level
+            lvl = max(0, (c_in // trunk.stem.weight.shape[0]).bit_length() - 1)
+            if mod.kind == "up":
+                lvl -= 1
+            elif mod.kind == "down":
+                lvl += 1
+            lvl_vox = N * (D >> lvl) * (H >> lvl) * (W >> lvl)
+            total += lvl_vox * (2 * c_in + c_hid) * esz
+    return int(total)
+
+
+def use_block_recompute(trunk, x_cl: torch.Tensor, compute_dtype: torch.dtype) -> bool:
+    """`outside_block` checkpointing policy: 'always' / 'never', or 'auto' (default) = recompute only when the activations
+    this forward would keep exceed half of the free HBM.  MedNeXt-S at 4 x 112^3 keeps ~25 GB of 288 GB: with 'auto' the flag
+    that the reference's Lucchi++ config sets (mito_lucchi++.yaml:22) costs nothing here, and MedNeXt-L at large patches
+    still trains."""
+    if not getattr(trunk, "outside_block_checkpointing", False):
+        return False
+    policy = str(getattr(trunk, "checkpoint_policy", "auto")).lower()
+    if policy in ("always", "never"):
+        return policy == "always"
+    if policy != "auto":
+        raise ValueError(f"MedNeXt.checkpoint_policy must be 'auto', 'always' or 'never', got {policy!r}")
+    free, _total = torch.cuda.mem_get_info(x_cl.device)
+    return saved_activation_bytes(trunk, x_cl.shape, compute_dtype) > 0.5 * free
 
 
 def mednext_train_features(trunk, x_cl: torch.Tensor, compute_dtype: torch.dtype):
     """Differentiable trunk up to the full-resolution features: -> (features, [bottleneck, dec_3, dec_2, dec_1])."""
+    rc = use_block_recompute(trunk, x_cl, compute_dtype)
     x = PointwiseFn.apply(x_cl, trunk.stem.weight, trunk.stem.bias, False, compute_dtype)
     skips = []
     for lvl in range(4):
         for blk in getattr(trunk, f"enc_block_{lvl}"):
-            x = _block(blk, x)
+            x = _block(blk, x, recompute=rc)
         skips.append(x)
-        x = _block(getattr(trunk, f"down_{lvl}"), x)
+        x = _block(getattr(trunk, f"down_{lvl}"), x, recompute=rc)
     for blk in trunk.bottleneck:
-        x = _block(blk, x)
+        x = _block(blk, x, recompute=rc)
     feats = [x]
     for lvl in (3, 2, 1, 0):
-        x = _block(getattr(trunk, f"up_{lvl}"), x, skip=skips[lvl])
+        x = _block(getattr(trunk, f"up_{lvl}"), x, skip=skips[lvl], recompute=rc)
         for blk in getattr(trunk, f"dec_block_{lvl}"):
-            x = _block(blk, x)
+            x = _block(blk, x, recompute=rc)
         if lvl:
             feats.append(x)
     return x, feats

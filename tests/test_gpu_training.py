@@ -463,3 +463,40 @@ def test_multihead_wrapper_training_matches_oracle_autograd():
         assert err < 2e-2, f"{n}: {err:.2e}"
         checked += 1
     assert checked > 100
+
+
+def test_outside_block_checkpointing_recomputes_bit_identically():
+    """`checkpoint_style: outside_block` (mednext_models.py:386-393; set by the reference's Lucchi++ config): with the policy
+    forced to 'always' every block keeps only its input and rebuilds the depthwise output / hidden pre-activation inside the
+    backward with the forward's own kernels -> loss and every gradient are bit-identical to the un-checkpointed step; 'auto'
+    (the default) keeps the activations while they fit (a few MB here)."""
+    from pytorch_connectomics_amd.models.architectures.mednext import MedNeXt
+    from pytorch_connectomics_amd.training.autograd import saved_activation_bytes, use_block_recompute
+    torch.manual_seed(1)
+    m = MedNeXt(1, 32, 2, exp_r=2, kernel_size=3, do_res=True, do_res_up_down=True, block_counts=[1] * 9,
+                checkpoint_style="outside_block").cuda().train()
+    m.compute_dtype = torch.bfloat16
+    assert m.outside_block_checkpointing and m.checkpoint_policy == "auto"
+    x = torch.rand(2, 1, 32, 32, 32, device="cuda")
+    y = (torch.rand(2, 2, 32, 32, 32, device="cuda") > 0.8).float()
+    xcl = x.permute(0, 2, 3, 4, 1).contiguous()
+    assert not use_block_recompute(m, xcl, torch.bfloat16)                       # fits: nothing is recomputed
+    est = saved_activation_bytes(m, xcl.shape, torch.bfloat16)
+    assert 5e6 < est < 1e8, est
+    res = {}
+    for policy in ("never", "always"):
+        m.checkpoint_policy = policy
+        m.zero_grad(set_to_none=True)
+        torch.cuda.reset_peak_memory_stats()
+        loss = F.binary_cross_entropy_with_logits(m(x), y)
+        peak_fwd = torch.cuda.max_memory_allocated()
+        loss.backward()
+        res[policy] = (float(loss.detach()), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}, peak_fwd)
+    assert res["never"][0] == res["always"][0]
+    assert res["never"][1].keys() == res["always"][1].keys()
+    for n, g in res["never"][1].items():
+        assert torch.equal(g, res["always"][1][n]), n
+    assert res["always"][2] < res["never"][2]                                    # the forward holds less
+    m.checkpoint_policy = "sometimes"
+    with pytest.raises(ValueError, match="checkpoint_policy"):
+        m(x)
