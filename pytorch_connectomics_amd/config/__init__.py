@@ -55,7 +55,7 @@ def schema_defaults() -> dict:
                       "activation": "relu", "spatial_dims": 3, "num_res_units": 2, "kernel_size": 3, "strides": None,
                       "upsample_mode": "deconv", "upsample_interp_mode": "linear", "upsample_align_corners": True},
             "loss": {"deep_supervision": False, "deep_supervision_weights": [1.0, 0.5, 0.25, 0.125, 0.0625],
-                     "losses": None},
+                     "deep_supervision_clamp_min": -20.0, "deep_supervision_clamp_max": 20.0, "losses": None},
         },
         "data": {"train": {"image": None, "label": None, "do_2d": False},
                  "val": {"image": None, "label": None, "do_2d": False},
@@ -63,11 +63,17 @@ def schema_defaults() -> dict:
                  "dataloader": {"batch_size": 1, "patch_size": None, "use_lazy_zarr": False, "use_lazy_h5": False},
                  "data_transform": {"patch_size": None},
                  "image_transform": {"normalize": "none"}},
-        "optimization": {"precision": "32", "gradient_clip_val": 0.0, "accumulate_grad_batches": 1,
-                         "max_epochs": 1, "n_steps_per_epoch": None,
-                         "optimizer": {"name": "AdamW", "lr": 1e-3, "weight_decay": 0.01, "betas": [0.9, 0.999],
-                                       "eps": 1e-8},
-                         "scheduler": {"name": None}, "ema": {"enabled": False, "decay": 0.999}},
+        # schema/optimization.py:8-113 (OptimizerConfig, SchedulerConfig, EMAConfig, OptimizationConfig)
+        "optimization": {"precision": "16-mixed", "gradient_clip_val": 1.0, "accumulate_grad_batches": 1,
+                         "max_epochs": 200, "max_steps": None, "n_steps_per_epoch": -1,
+                         "optimizer": {"name": "AdamW", "lr": 1e-3, "weight_decay": 0.01, "momentum": 0.9,
+                                       "betas": [0.9, 0.999], "eps": 1e-8},
+                         "scheduler": {"profile": None, "name": "CosineAnnealingLR", "params": {}, "monitor": None,
+                                       "mode": "min", "factor": 0.1, "patience": 10, "threshold": 1e-4, "cooldown": 0,
+                                       "eps": 1e-8, "warmup_epochs": 10, "warmup_start_lr": 1e-4, "min_lr": 1e-5,
+                                       "interval": "epoch", "frequency": 1},
+                         "ema": {"enabled": False, "decay": 0.999, "warmup_steps": 0, "validate_with_ema": True,
+                                 "device": None, "copy_buffers": True}},
         "monitor": {},
         "inference": {
             "model": {"head": None, "select_channel": None, "output_dtype": None, "channel_activations": None,

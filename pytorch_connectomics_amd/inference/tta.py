@@ -257,6 +257,10 @@ class TTAPredictor:
                 result, _ = one_view(0, None)
                 return self._apply_mask_to_result(result, mask, mask_align_to_image)
 
+            if not bool(getattr(tta, "patch_first_local", False)) and self.sliding_inferer is not None:
+                # reference predict() :1652-1660: without patch-first-local every view is a whole-volume pass
+                result = self._predict_whole_volume_views(vol, engine, network, combos, getattr(tta, "ensemble_mode", "mean"))
+                return self._apply_mask_to_result(result, mask, mask_align_to_image)
             for _f, pl, k in combos:   # same restriction (and message) as the reference, tta.py:1316-1340
                 if pl is not None and k % 2:
                     img = tuple(int(v) for v in images.shape[2:])
@@ -291,6 +295,49 @@ class TTAPredictor:
             return self._apply_mask_to_result(result, mask, mask_align_to_image)
         finally:
             self._requested_output_head_override = prev
+
+
+def _predict_whole_volume_views(self, vol, engine, network, combos, ensemble_mode):
+    """`patch_first_local: false` (reference _predict_prepared_tensor :806-878 + _run_ensemble :691-769): each view flips /
+    rotates the WHOLE volume, runs its own sliding-window pass over the augmented geometry (its own window grid and weight
+    map, so non-square rotations are fine), and the blended prediction is rotated / flipped back before activation and
+    the ensemble.  The augmented volume is one device copy per view; the windows still gather from HBM as usual."""
+    from .tta_affinity import resolve_affinity_channel_groups_from_cfg
+    if resolve_affinity_channel_groups_from_cfg(self.cfg):
+        raise NotImplementedError("whole-volume TTA (patch_first_local: false) of directional-affinity outputs is not built; "
+                                  "use patch_first_local: true (the reference default)")
+    acc = modes = None
+    weights = {}
+    for i, (flips, pl, k) in enumerate(combos):
+        x = vol
+        if flips:
+            x = torch.flip(x, dims=[int(a) + 1 for a in flips])
+        if pl is not None and k > 0:
+            x = torch.rot90(x, k=int(k), dims=(int(pl[0]) + 1, int(pl[1]) + 1))
+        x = x.contiguous()
+        shape = tuple(int(v) for v in x.shape[1:])
+        w = weights.get(shape)
+        value, w = engine.accumulate(x, network, view=0, weight=w, add_weight=w is None)
+        weights[shape] = w
+        ops.blend_finalize(value, w, clamp=1e-4, act=nat.ACT_NONE)
+        if tuple(value.shape[1:]) != shape:
+            value = value[:, :shape[0], :shape[1], :shape[2]]
+        if pl is not None and k > 0:
+            value = torch.rot90(value, k=-int(k), dims=(int(pl[0]) + 1, int(pl[1]) + 1))
+        if flips:
+            value = torch.flip(value, dims=[int(a) + 1 for a in flips])
+        pred = self.apply_preprocessing(value.contiguous().unsqueeze(0))
+        pred32 = pred if pred.dtype == torch.float32 else pred.float()
+        if acc is None:
+            modes = _resolve_ensemble_mode_map(ensemble_mode, int(pred32.shape[1]))
+            bad = sorted(set(modes) - set(_MODE_CODE))
+            if bad:
+                raise ValueError(f"Unknown TTA ensemble modes: {bad}.")
+            acc = pred32.clone()
+            continue
+        for c, mode in enumerate(modes):
+            ops.ensemble_update(acc[0, c], pred32[0, c].contiguous(), _MODE_CODE[mode], i + 1)
+    return acc.to(resolve_model_output_dtype(self.cfg))
 
 
 def _predict_affinity_views(self, vol, orig, engine, network, combos, codes, ensemble_mode):

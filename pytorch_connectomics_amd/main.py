@@ -65,10 +65,21 @@ def read_volume(spec: str, *, default_shape=(64, 128, 128), seed: int = 0) -> np
     raise ValueError(f"unsupported volume format: {spec}")
 
 
+def _load_checkpoint_file(path: str):
+    """torch.load with weights_only=True first (tensors, containers, numbers: what this engine and plain state dicts hold);
+    only a Lightning checkpoint that pickles other objects (hyper-parameter namespaces) falls back to the full unpickler,
+    with a warning -- such a file executes code on load and must come from a trusted source."""
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as exc:      # noqa: BLE001 - pickle.UnpicklingError and friends
+        logger.warning("checkpoint %s needs the full (unsafe) unpickler (%s): load only trusted files", path, type(exc).__name__)
+        return torch.load(path, map_location="cpu", weights_only=False)
+
+
 def load_checkpoint(model: torch.nn.Module, path: str) -> None:
     """Lightning checkpoints store the LightningModule state (`model.<wrapper attr>...`, model.py:244-297);
     plain state dicts and `_orig_mod.` / `module.` prefixes are accepted too (model_weights.py:45-72)."""
-    blob = torch.load(path, map_location="cpu", weights_only=False)
+    blob = _load_checkpoint_file(path)
     sd = blob.get("state_dict", blob) if isinstance(blob, dict) else blob
     own = set(model.state_dict().keys())
     out = {}
@@ -110,9 +121,9 @@ def run_test(cfg, args) -> dict:
         load_checkpoint(model, args.checkpoint)
     precision = str(cfg.optimization.precision)
     if "bf16" in precision or "16" in precision:
-        inner = getattr(model, "model", model)
-        if hasattr(inner, "compute_dtype"):
-            inner.compute_dtype = torch.bfloat16      # fp16-mixed configs run as bf16 storage on this engine
+        for mod in (model, getattr(model, "model", model)):
+            if hasattr(mod, "compute_dtype"):
+                mod.compute_dtype = torch.bfloat16    # fp16-mixed configs run as bf16 storage on this engine
     image_spec = cfg.data.test.image or ("random://demo" if args.demo else None)
     if image_spec is None:
         raise ValueError("data.test.image is not set (use --demo for a random volume)")
@@ -186,10 +197,11 @@ def run_train(cfg, args) -> dict:
     torch.manual_seed(int(cfg.system.seed))                   # identical initial weights on every rank
     module = ConnectomicsModule(cfg)
     if args.checkpoint:
-        module.load_checkpoint_dict(torch.load(args.checkpoint, map_location="cpu", weights_only=False))
+        module.load_checkpoint_dict(_load_checkpoint_file(args.checkpoint))
     patch = tuple(cfg.data.dataloader.patch_size or cfg.model.input_size or (64, 64, 64))
     bs = int(cfg.data.dataloader.batch_size)
-    steps = int(args.fast_dev_run) if args.fast_dev_run else int(cfg.optimization.n_steps_per_epoch or 100) * int(cfg.optimization.max_epochs)
+    from .training.module import resolve_training_steps
+    steps, per_epoch = resolve_training_steps(cfg, fast_dev_run=int(args.fast_dev_run or 0))
     img_spec = cfg.data.train.image
     if img_spec is None or str(img_spec).startswith("random://") or args.demo:
         batches = synthetic_batches(bs, patch, in_channels=cfg.model.in_channels, out_channels=cfg.model.out_channels,
@@ -209,7 +221,10 @@ def run_train(cfg, args) -> dict:
                 yield {"image": torch.stack(xs), "label": torch.stack(ys)}
         batches = sampler()
     t0 = time.perf_counter()
-    history, opt = fit(module, batches, max_steps=steps, device=dev, ddp=world > 1, log=logger.info if rank == 0 else None)
+    history, opt = fit(module, batches, max_steps=steps, device=dev, ddp=world > 1, log=logger.info if rank == 0 else None,
+                       steps_per_epoch=per_epoch)
+    if not history:
+        raise RuntimeError(f"nothing to train: the checkpoint is already at step {module.global_step} of {steps}")
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out = {"steps": steps, "first_loss": history[0], "last_loss": history[-1],

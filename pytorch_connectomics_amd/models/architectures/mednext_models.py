@@ -6,7 +6,8 @@ connectomics/models/architectures/mednext_models.py (MedNeXtWrapper :38-89, MedN
 """
 from __future__ import annotations
 
-from typing import Any, Dict, Mapping, Union
+from dataclasses import dataclass
+from typing import Any, Dict, Mapping, Optional, Union
 
 import torch
 import torch.nn as nn
@@ -42,28 +43,41 @@ class MedNeXtWrapper(ConnectomicsModel):
 
 
 def _cfg_value(cfg: Any, key: str, default: Any = None) -> Any:
-    if isinstance(cfg, Mapping):
-        return cfg.get(key, default)
-    return getattr(cfg, key, default)
+    return cfg.get(key, default) if isinstance(cfg, Mapping) else getattr(cfg, key, default)
+
+
+_NORM_NAME = {nn.GroupNorm: "group"}
 
 
 def _infer_mednext_head_block_kwargs(model: nn.Module) -> dict:
-    if not hasattr(model, "dec_block_0") or len(model.dec_block_0) == 0:
+    """Constructor arguments of a task-head block, read off the trunk's last decoder block (mednext_models.py:99-126)."""
+    blocks = getattr(model, "dec_block_0", None)
+    if blocks is None or len(blocks) == 0:
         raise ValueError("MedNeXt trunk must expose a non-empty dec_block_0 to build task heads.")
-    ref_block = model.dec_block_0[0]
-    if not isinstance(ref_block, MedNeXtBlock):
+    ref = blocks[0]
+    if not isinstance(ref, MedNeXtBlock):
         raise TypeError("Expected MedNeXt dec_block_0 to contain MedNeXtBlock instances for multi-head reuse.")
-    kernel_size = ref_block.conv1.kernel_size
-    if isinstance(kernel_size, tuple):
-        kernel_size = kernel_size[0]
-    return {
-        "exp_r": ref_block.conv2.out_channels // ref_block.conv2.in_channels,
-        "kernel_size": int(kernel_size),
-        "do_res": ref_block.do_res,
-        "norm_type": "group" if isinstance(ref_block.norm, nn.GroupNorm) else "layer",
-        "dim": ref_block.dim,
-        "grn": ref_block.grn,
-    }
+    k = ref.conv1.kernel_size
+    return dict(exp_r=ref.conv2.out_channels // ref.conv2.in_channels, kernel_size=int(k[0] if isinstance(k, tuple) else k),
+                do_res=ref.do_res, norm_type=_NORM_NAME.get(type(ref.norm), "layer"), dim=ref.dim, grn=ref.grn)
+
+
+@dataclass(frozen=True)
+class _HeadSpec:
+    """One entry of `model.heads`: a mapping / namespace with out_channels [, num_blocks, hidden_channels], or a bare int."""
+    out_channels: int
+    num_blocks: int = 0
+    hidden_channels: Optional[int] = None
+
+    @classmethod
+    def parse(cls, entry: Any) -> "_HeadSpec":
+        hidden = _cfg_value(entry, "hidden_channels", None)
+        return cls(int(_cfg_value(entry, "out_channels", entry)), int(_cfg_value(entry, "num_blocks", 0)),
+                   None if hidden is None else int(hidden))
+
+    def as_dict(self, feature_channels: int) -> dict:
+        return {"out_channels": self.out_channels, "num_blocks": self.num_blocks,
+                "hidden_channels": self.hidden_channels or feature_channels}
 
 
 class MedNeXtTaskHead(nn.Module):
@@ -72,30 +86,24 @@ class MedNeXtTaskHead(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, num_blocks: int, hidden_channels: int | None = None,
                  *, exp_r: int, kernel_size: int, do_res: bool, norm_type: str, dim: str, grn: bool):
         super().__init__()
-        if num_blocks < 0:
-            raise ValueError(f"MedNeXt task head num_blocks must be >= 0, got {num_blocks}")
-        if out_channels <= 0:
-            raise ValueError(f"MedNeXt task head out_channels must be positive, got {out_channels}")
-        if hidden_channels is None:
-            hidden_channels = in_channels
-        if hidden_channels <= 0:
-            raise ValueError(f"MedNeXt task head hidden_channels must be positive, got {hidden_channels}")
-        if hidden_channels > in_channels:
-            raise ValueError("MedNeXt task head hidden_channels must not exceed the shared feature width "
-                             f"({hidden_channels} > {in_channels})")
-        if dim == "2d":
-            conv = nn.Conv2d
-        elif dim == "3d":
-            conv = nn.Conv3d
-        else:
-            raise ValueError(f"MedNeXt task head dim must be '2d' or '3d', got {dim}")
-        self.input_projection = (conv(in_channels, hidden_channels, kernel_size=1)
-                                 if hidden_channels != in_channels else nn.Identity())
-        blocks = [MedNeXtBlock(hidden_channels, hidden_channels, exp_r=exp_r, kernel_size=kernel_size,
-                               do_res=do_res, norm_type=norm_type, dim=dim, grn=grn) for _ in range(num_blocks)]
-        self.blocks = nn.Sequential(*blocks) if blocks else nn.Identity()
-        self.projection = conv(hidden_channels, out_channels, kernel_size=1)
-        self.hidden_channels = hidden_channels
+        width = in_channels if hidden_channels is None else hidden_channels
+        # (condition that must hold, message) in the order the reference raises them
+        for ok, msg in (
+                (num_blocks >= 0, f"MedNeXt task head num_blocks must be >= 0, got {num_blocks}"),
+                (out_channels > 0, f"MedNeXt task head out_channels must be positive, got {out_channels}"),
+                (width > 0, f"MedNeXt task head hidden_channels must be positive, got {width}"),
+                (width <= in_channels, "MedNeXt task head hidden_channels must not exceed the shared feature width "
+                                       f"({width} > {in_channels})"),
+                (dim in ("2d", "3d"), f"MedNeXt task head dim must be '2d' or '3d', got {dim}")):
+            if not ok:
+                raise ValueError(msg)
+        conv = nn.Conv3d if dim == "3d" else nn.Conv2d
+        block_kw = dict(exp_r=exp_r, kernel_size=kernel_size, do_res=do_res, norm_type=norm_type, dim=dim, grn=grn)
+        self.input_projection = nn.Identity() if width == in_channels else conv(in_channels, width, kernel_size=1)
+        self.blocks = (nn.Sequential(*(MedNeXtBlock(width, width, **block_kw) for _ in range(num_blocks)))
+                       if num_blocks else nn.Identity())
+        self.projection = conv(width, out_channels, kernel_size=1)
+        self.hidden_channels = width
 
     def forward_cl(self, hip, feat_cl: torch.Tensor) -> torch.Tensor:
         x = feat_cl
@@ -125,25 +133,17 @@ class MedNeXtMultiHeadWrapper(ConnectomicsModel):
         self.model = model
         self.supports_deep_supervision = False
         self.output_scales = 1
-        self.feature_channels = int(self.model.stem.out_channels)
+        self.feature_channels = int(model.stem.out_channels)
         self.head_block_kwargs = _infer_mednext_head_block_kwargs(model)
-        task_heads, head_specs = {}, {}
-        for head_name, head_cfg in heads.items():
-            out_channels = int(_cfg_value(head_cfg, "out_channels", head_cfg))
-            num_blocks = int(_cfg_value(head_cfg, "num_blocks", 0))
-            hidden_channels = _cfg_value(head_cfg, "hidden_channels", None)
-            hidden_channels = int(hidden_channels) if hidden_channels is not None else None
-            task_heads[head_name] = MedNeXtTaskHead(self.feature_channels, out_channels, num_blocks,
-                                                    hidden_channels, **self.head_block_kwargs)
-            head_specs[head_name] = {"out_channels": out_channels, "num_blocks": num_blocks,
-                                     "hidden_channels": hidden_channels or self.feature_channels}
-        self.heads = nn.ModuleDict(task_heads)
-        self.head_specs = head_specs
-        resolved = primary_head or next(iter(self.heads.keys()))
-        if resolved not in self.heads:
-            raise ValueError(f"primary_head '{resolved}' is not one of the configured heads: "
+        specs = {name: _HeadSpec.parse(entry) for name, entry in heads.items()}
+        self.heads = nn.ModuleDict({name: MedNeXtTaskHead(self.feature_channels, sp.out_channels, sp.num_blocks,
+                                                          sp.hidden_channels, **self.head_block_kwargs)
+                                    for name, sp in specs.items()})
+        self.head_specs = {name: sp.as_dict(self.feature_channels) for name, sp in specs.items()}
+        self.primary_head = primary_head if primary_head else next(iter(specs))
+        if self.primary_head not in self.heads:
+            raise ValueError(f"primary_head '{self.primary_head}' is not one of the configured heads: "
                              f"{sorted(self.heads.keys())}")
-        self.primary_head = resolved
 
     def forward_features(self, x: torch.Tensor) -> torch.Tensor:
         return self.model.forward_features(x)
@@ -176,97 +176,90 @@ class MedNeXtMultiHeadWrapper(ConnectomicsModel):
 
 
 def _get_mednext_heads_cfg(cfg):
-    raw_heads = getattr(cfg.model, "heads", None)
-    if not raw_heads:
-        return {}, None
-    return dict(raw_heads), getattr(cfg.model, "primary_head", None)
+    heads = getattr(cfg.model, "heads", None)
+    return (dict(heads), getattr(cfg.model, "primary_head", None)) if heads else ({}, None)
 
 
 def _resolve_mednext_num_classes(cfg, head_cfg: Mapping[str, Any]) -> int:
+    """Width of the trunk's own output projection: the heads' channels together (at least 1), else model.out_channels."""
+    if not head_cfg:
+        return int(cfg.model.out_channels)
+    return max(1, sum(int(_cfg_value(spec, "out_channels", 0)) for spec in head_cfg.values()))
+
+
+def _finish(model: nn.Module, head_cfg, primary_head, deep_supervision: bool) -> ConnectomicsModel:
     if head_cfg:
-        total = sum(int(_cfg_value(spec, "out_channels", 0)) for spec in head_cfg.values())
-        return max(1, total)
-    return int(cfg.model.out_channels)
+        return MedNeXtMultiHeadWrapper(model, head_cfg, primary_head=primary_head)
+    return MedNeXtWrapper(model, deep_supervision=deep_supervision)
+
+
+_SIZE_HELP = ("Model sizes:\n  - S (Small): 5.6M params\n  - B (Base): 10.5M params\n"
+              "  - M (Medium): 17.6M params\n  - L (Large): 61.8M params")
 
 
 @register_architecture("mednext")
 def build_mednext(cfg) -> ConnectomicsModel:
     """MedNeXt with a predefined size: model.mednext.size in S/B/M/L (5.6/10.5/17.6/61.8 M params at k=3),
-    model.mednext.kernel_size in 3/5/7, model.loss.deep_supervision, optional model.heads."""
-    in_channels = cfg.model.in_channels
-    model_size = getattr(cfg.model.mednext, "size", "S")
-    kernel_size = getattr(cfg.model.mednext, "kernel_size", 3)
-    loss_cfg = getattr(cfg.model, "loss", None)
-    deep_supervision = getattr(loss_cfg, "deep_supervision", False)
+    model.mednext.kernel_size in 3/5/7, model.loss.deep_supervision, optional model.heads; model.mednext.checkpoint_style
+    'outside_block' turns on per-block activation checkpointing (policy: MedNeXt.checkpoint_policy)."""
+    mn = cfg.model.mednext
+    size, ksize = getattr(mn, "size", "S"), getattr(mn, "kernel_size", 3)
+    ds = getattr(getattr(cfg.model, "loss", None), "deep_supervision", False)
     head_cfg, primary_head = _get_mednext_heads_cfg(cfg)
-    out_channels = _resolve_mednext_num_classes(cfg, head_cfg)
-    if model_size not in ["S", "B", "M", "L"]:
-        raise ValueError(f"MedNeXt model_size must be 'S', 'B', 'M', or 'L'. Got: {model_size}\n"
-                         "Model sizes:\n  - S (Small): 5.6M params\n  - B (Base): 10.5M params\n"
-                         "  - M (Medium): 17.6M params\n  - L (Large): 61.8M params")
-    if kernel_size not in [3, 5, 7]:
-        raise ValueError(f"MedNeXt kernel_size must be 3, 5, or 7. Got: {kernel_size}\n"
-                         "Recommended: Start with kernel_size=3")
-    model = create_mednext_v1(num_input_channels=in_channels, num_classes=out_channels, model_id=model_size,
-                              kernel_size=kernel_size, deep_supervision=deep_supervision)
-    checkpoint_style = getattr(cfg.model.mednext, "checkpoint_style", None)
-    if checkpoint_style is not None:
-        if checkpoint_style != "outside_block":
-            raise ValueError("model.mednext.checkpoint_style must be None or 'outside_block', "
-                             f"got: {checkpoint_style!r}")
+    if size not in ("S", "B", "M", "L"):
+        raise ValueError(f"MedNeXt model_size must be 'S', 'B', 'M', or 'L'. Got: {size}\n{_SIZE_HELP}")
+    if ksize not in (3, 5, 7):
+        raise ValueError(f"MedNeXt kernel_size must be 3, 5, or 7. Got: {ksize}\nRecommended: Start with kernel_size=3")
+    model = create_mednext_v1(num_input_channels=cfg.model.in_channels, num_classes=_resolve_mednext_num_classes(cfg, head_cfg),
+                              model_id=size, kernel_size=ksize, deep_supervision=ds)
+    style = getattr(mn, "checkpoint_style", None)
+    if style is not None:
+        if style != "outside_block":
+            raise ValueError(f"model.mednext.checkpoint_style must be None or 'outside_block', got: {style!r}")
         model.outside_block_checkpointing = True
-    if head_cfg:
-        return MedNeXtMultiHeadWrapper(model, head_cfg, primary_head=primary_head)
-    return MedNeXtWrapper(model, deep_supervision=deep_supervision)
+    return _finish(model, head_cfg, primary_head, ds)
+
+
+# constructor argument -> (config key under model.mednext, default), mednext_models.py:449-463
+_CUSTOM_ARGS = (("n_channels", "base_channels", 32), ("exp_r", "exp_r", 4), ("kernel_size", "kernel_size", 7),
+                ("do_res", "do_res", True), ("do_res_up_down", "do_res_up_down", True), ("block_counts", "block_counts", [2] * 9),
+                ("checkpoint_style", "checkpoint_style", None), ("norm_type", "norm", "group"), ("dim", "dim", "3d"),
+                ("grn", "grn", False))
 
 
 @register_architecture("mednext_custom")
 def build_mednext_custom(cfg) -> ConnectomicsModel:
     """MedNeXt with explicit base_channels / exp_r / kernel_size / block_counts / norm / dim / grn."""
     head_cfg, primary_head = _get_mednext_heads_cfg(cfg)
-    params = {
-        "in_channels": cfg.model.in_channels,
-        "n_channels": getattr(cfg.model.mednext, "base_channels", 32),
-        "n_classes": _resolve_mednext_num_classes(cfg, head_cfg),
-        "exp_r": getattr(cfg.model.mednext, "exp_r", 4),
-        "kernel_size": getattr(cfg.model.mednext, "kernel_size", 7),
-        "deep_supervision": getattr(cfg.model.loss, "deep_supervision", False),
-        "do_res": getattr(cfg.model.mednext, "do_res", True),
-        "do_res_up_down": getattr(cfg.model.mednext, "do_res_up_down", True),
-        "block_counts": getattr(cfg.model.mednext, "block_counts", [2] * 9),
-        "checkpoint_style": getattr(cfg.model.mednext, "checkpoint_style", None),
-        "norm_type": getattr(cfg.model.mednext, "norm", "group"),
-        "dim": getattr(cfg.model.mednext, "dim", "3d"),
-        "grn": getattr(cfg.model.mednext, "grn", False),
-    }
-    if params["dim"] not in ["2d", "3d"]:
-        raise ValueError(f"mednext_dim must be '2d' or '3d', got: {params['dim']}")
-    if params["norm_type"] not in ["group", "layer"]:
-        raise ValueError(f"mednext_norm must be 'group' or 'layer', got: {params['norm_type']}")
-    if len(params["block_counts"]) != 9:
-        raise ValueError("mednext_block_counts must have exactly 9 elements (one per level), "
-                         f"got {len(params['block_counts'])}")
+    params = {arg: getattr(cfg.model.mednext, key, default) for arg, key, default in _CUSTOM_ARGS}
+    params.update(in_channels=cfg.model.in_channels, n_classes=_resolve_mednext_num_classes(cfg, head_cfg),
+                  deep_supervision=getattr(cfg.model.loss, "deep_supervision", False))
+    for ok, msg in ((params["dim"] in ("2d", "3d"), f"mednext_dim must be '2d' or '3d', got: {params['dim']}"),
+                    (params["norm_type"] in ("group", "layer"), f"mednext_norm must be 'group' or 'layer', got: {params['norm_type']}"),
+                    (len(params["block_counts"]) == 9, "mednext_block_counts must have exactly 9 elements (one per level), "
+                                                       f"got {len(params['block_counts'])}")):
+        if not ok:
+            raise ValueError(msg)
     params["block_counts"] = list(params["block_counts"])
     if not isinstance(params["exp_r"], int):
         params["exp_r"] = list(params["exp_r"])
-    model = MedNeXtBase(**params)
-    if head_cfg:
-        return MedNeXtMultiHeadWrapper(model, head_cfg, primary_head=primary_head)
-    return MedNeXtWrapper(model, deep_supervision=params["deep_supervision"])
+    return _finish(MedNeXtBase(**params), head_cfg, primary_head, params["deep_supervision"])
 
 
 def upkern_load_weights(target_model: MedNeXtWrapper, source_model: MedNeXtWrapper) -> MedNeXtWrapper:
-    """UpKern: initialise a large-kernel model from a trained small-kernel one -- every tensor is
-    copied, depthwise kernels of differing size are trilinearly resized (one-off, load time)."""
+    """UpKern (mednext_models.py:487-537 -> nnunet_mednext.run.load_weights): initialise a large-kernel model from a trained
+    small-kernel one.  Tensors of equal shape are copied; depthwise kernels (same channels, different spatial size) are
+    resized with trilinear interpolation (align_corners=False, as F.interpolate defaults); anything else is an error."""
     tgt, src = target_model.model.state_dict(), source_model.model.state_dict()
+    missing = [k for k in tgt if k not in src]
+    if missing:
+        raise KeyError(f"UpKern: key {missing[0]} missing in the source model")
     new = {}
     for k, v in tgt.items():
-        if k not in src:
-            raise KeyError(f"UpKern: key {k} missing in the source model")
         s = src[k]
         if s.shape == v.shape:
             new[k] = s.clone()
-        elif s.dim() == 5 and s.shape[:2] == v.shape[:2]:
+        elif s.dim() == v.dim() == 5 and s.shape[:2] == v.shape[:2]:
             new[k] = F.interpolate(s.float(), size=tuple(v.shape[2:]), mode="trilinear").to(v.dtype)
         else:
             raise ValueError(f"UpKern: incompatible shapes for {k}: {tuple(s.shape)} -> {tuple(v.shape)}")

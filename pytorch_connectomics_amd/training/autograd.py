@@ -117,7 +117,8 @@ class BlockFn(torch.autograd.Function):
                               wres if wres is not None else keep, skip if (recompute and skip is not None) else keep,
                               b1 if (recompute and b1 is not None) else keep, b2 if recompute else keep, b3 if recompute else keep,
                               bres if (recompute and bres is not None) else keep)
-        ctx.meta = (kind, do_res, K, count, wres is not None, skip is not None, b1 is not None, bres is not None, recompute, eps)
+        ctx.meta = (kind, do_res, K, count, wres is not None, skip is not None, b1 is not None, bres is not None, recompute, eps,
+                    b2 is not None, b3 is not None)
         ctx.taps = taps                  # derived from w1 (no gradient flows through it): reused by the backward
         return y
 
@@ -179,7 +180,7 @@ class BlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, t, ab, mr, hp, w1, gamma, w2, w3, wres, skip_s, b1_s, b2_s, b3_s, bres_s = ctx.saved_tensors
-        kind, do_res, K, count, has_res, has_skip, has_b1, has_bres, recompute, eps = ctx.meta
+        kind, do_res, K, count, has_res, has_skip, has_b1, has_bres, recompute, eps, has_b2, has_b3 = ctx.meta
         if recompute:
             # outside-block checkpointing: rebuild t and the hidden pre-activation with the forward's own kernels
             with torch.no_grad():
@@ -259,7 +260,8 @@ class BlockFn(torch.autograd.Function):
                 return v.view(like.shape)
             return torch.empty_like(like).copy_(v.reshape(like.shape))
         return (dx, dskip, g(dW1.t().contiguous(), w1), (db1.to(w1.dtype) if has_b1 else None), g(dgamma, gamma),
-                g(dbeta, gamma), g(dW2, w2), db2.to(w2.dtype), g(dW3, w3), db3.to(w3.dtype),
+                g(dbeta, gamma), g(dW2, w2), (db2.to(w2.dtype) if has_b2 else None), g(dW3, w3),
+                (db3.to(w3.dtype) if has_b3 else None),
                 (g(dwres, wres) if has_res else None), (dbres.to(w3.dtype) if (has_res and has_bres) else None),
                 None, None, None, None)
 

@@ -151,13 +151,11 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        items, gtab = [], []
+        items, gtab, vrow = [], [], {}
         self.ema_updates += 1
         d = 0.0 if self.ema_decay is None else (0.0 if self.ema_updates <= self.ema_warmup_steps else float(self.ema_decay))
         for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
-            t = group.get("_t", 0) + 1
-            any_grad = False
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -178,16 +176,23 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 if self.ema_decay is not None and p not in self.ema:
                     self.ema[p] = p.detach().clone()
-                items.append((p, g, gi))
-                any_grad = True
-            if any_grad:
-                group["_t"] = t
-            gtab.append([group["lr"], b1, b2, group["eps"], group["weight_decay"], 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), d])
+                # steps are counted PER PARAMETER like torch.optim.AdamW (a parameter that starts receiving gradients later --
+                # an unused head under DDP -- gets its own bias correction): parameters of a group that share a step count
+                # share one row of the scalar table, a different count opens another row
+                t = int(st.get("_t", 0)) + 1
+                st["_t"] = t
+                key = (gi, t)
+                if key not in vrow:
+                    vrow[key] = len(gtab)
+                    gtab.append([group["lr"], b1, b2, group["eps"], group["weight_decay"], 1.0 - b1 ** t,
+                                 math.sqrt(1.0 - b2 ** t), d])
+                items.append((p, g, vrow[key]))
         if not items:
             return loss
         self._tables(items)
         if len(gtab) > 8:
-            raise RuntimeError("FusedAdamW: at most 8 parameter groups (merge groups with equal hyper-parameters)")
+            raise RuntimeError("FusedAdamW: at most 8 (parameter group, step count) rows per update (merge groups with equal "
+                               "hyper-parameters)")
         groups = (C.c_float * (8 * len(gtab)))(*[float(v) for row in gtab for v in row])
         lib = nat.lib()
         nat.check(lib.pytc_grad_norm_multi(_p(self._tab), _p(self._chunks), self._nc, self.max_grad_norm, _p(self._work),
@@ -201,26 +206,37 @@ class FusedAdamW(torch.optim.Optimizer):
         return loss
 
     def state_dict(self):
-        for group in self.param_groups:
-            t = float(group.get("_t", 0))
-            for p in group["params"]:
-                if p in self.state and "step" in self.state[p]:
-                    self.state[p]["step"] = torch.tensor(t)
-        return super().state_dict()
+        for st in self.state.values():
+            if "_t" in st:
+                st["step"] = torch.tensor(float(st["_t"]))
+        sd = super().state_dict()
+        for st in sd["state"].values():          # `_t` is this optimizer's host-side counter, `step` the interchange field
+            st.pop("_t", None)
+        return sd
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._key = None
         for group in self.param_groups:
-            steps = [float(self.state[p]["step"]) for p in group["params"] if p in self.state and "step" in self.state[p]]
-            if steps:
-                group["_t"] = int(max(steps))
             for p in group["params"]:
                 st = self.state.get(p)
                 if st:
+                    if "step" in st:
+                        st["_t"] = int(float(st["step"]))
                     for k in ("exp_avg", "exp_avg_sq"):
                         if k in st:
                             st[k] = st[k].to(device=p.device, dtype=torch.float32).contiguous()
+
+    def load_ema_state_dict(self, model: torch.nn.Module, ema_state: Dict[str, torch.Tensor], updates: int = 0) -> None:
+        """Resume the EMA shadow weights (the reference callback's `ema_state` / `updates`, callbacks.py:732-790)."""
+        if self.ema_decay is None:
+            return
+        owned = {id(p) for g in self.param_groups for p in g["params"]}
+        for n, p in model.named_parameters():
+            if id(p) in owned and n in ema_state:
+                self.ema[p] = ema_state[n].detach().to(device=p.device, dtype=torch.float32).contiguous().clone()
+        self.ema_updates = int(updates)
+        self._key = None
 
 
 __all__ = ["bce_dice_loss", "BceDiceLossFn", "FusedAdamW"]

@@ -12,7 +12,7 @@ device ops.
 from __future__ import annotations
 
 import math
-from typing import Any, Dict, Optional
+from typing import Any, Dict, Mapping, Optional
 
 import torch
 import torch.nn as nn
@@ -86,6 +86,31 @@ _LOSSES = {
 }
 
 
+def match_target_to_output(target: torch.Tensor, output: torch.Tensor) -> torch.Tensor:
+    """Deep-supervision target at an output's resolution (training/losses/orchestrator.py:892-952): integer labels by nearest
+    neighbour (kept integer), dense float targets by trilinear interpolation (align_corners=False) and clamped back to
+    [-1, 1] / [0, 1] when the original lies in that range (interpolation overshoot of tanh-SDT / sigmoid targets)."""
+    if target.shape == output.shape:
+        return target
+    if target.dtype in (torch.long, torch.int, torch.int32, torch.int64, torch.uint8):
+        return F.interpolate(target.float(), size=output.shape[2:], mode="nearest").long()
+    out = F.interpolate(target, size=output.shape[2:], mode="trilinear", align_corners=False)
+    lo, hi = float(target.min()), float(target.max())
+    if lo >= -1.5 and hi <= 1.5:
+        out = torch.clamp(out, -1.0, 1.0)
+    elif lo >= 0.0 and hi <= 1.5:
+        out = torch.clamp(out, 0.0, 1.0)
+    return out
+
+
+def resize_class_index_to_output(t: torch.Tensor, output: torch.Tensor) -> torch.Tensor:
+    """Nearest-neighbour resize regardless of dtype (orchestrator.py:277-291): batch masks and class-index targets."""
+    if t.shape[2:] == output.shape[2:]:
+        return t
+    r = F.interpolate(t.float(), size=output.shape[2:], mode="nearest")
+    return r.to(t.dtype) if t.dtype.is_floating_point else r.long()
+
+
 class WarmupCosineLR(torch.optim.lr_scheduler.LRScheduler):
     """lr = eta_min + (base * warmup(t) - eta_min) * 0.5 (1 + cos(pi t / max_iters))."""
 
@@ -115,12 +140,13 @@ def build_optimizer(cfg, model: nn.Module) -> torch.optim.Optimizer:
     # the reference (optimization/build.py:73-112) emits one group per parameter; parameters with identical
     # hyper-parameters are merged here (same update rule, but the multi-tensor optimizer then runs a handful of fused
     # launches per step instead of ~8 per parameter -- 1 800 tiny launches / 40 ms of host time for MedNeXt-S)
-    merged, seen = {}, set()
+    merged, seen, seen_order = {}, set(), []
     for module in model.modules():
         for key, p in module.named_parameters(recurse=False):
             if not p.requires_grad or p in seen:
                 continue
             seen.add(p)
+            seen_order.append(p)
             g_lr, g_wd = lr, wd
             if isinstance(module, _NORM_TYPES):
                 g_wd = wd_norm
@@ -128,6 +154,7 @@ def build_optimizer(cfg, model: nn.Module) -> torch.optim.Optimizer:
                 g_lr, g_wd = lr * bias_lr, wd_bias
             merged.setdefault((g_lr, g_wd), []).append(p)
     groups = [{"params": ps, "lr": k[0], "weight_decay": k[1]} for k, ps in merged.items()]
+    model_order = {id(p): i for i, p in enumerate(p for p in seen_order)}
     betas = tuple(getattr(oc, "betas", (0.9, 0.999)))
     eps = float(getattr(oc, "eps", 1e-8))
     if name == "adamw":
@@ -138,17 +165,75 @@ def build_optimizer(cfg, model: nn.Module) -> torch.optim.Optimizer:
             from .fused import FusedAdamW
             ema = getattr(cfg.optimization, "ema", None)
             ema_on = bool(getattr(ema, "enabled", False)) if ema is not None else False
-            return FusedAdamW(groups, lr=lr, betas=betas, eps=eps, weight_decay=wd,
-                              max_grad_norm=float(getattr(cfg.optimization, "gradient_clip_val", 0.0) or 0.0),
-                              ema_decay=float(getattr(ema, "decay", 0.999)) if ema_on else None,
-                              ema_warmup_steps=int(getattr(ema, "warmup_steps", 0) or 0) if ema_on else 0)
-        return torch.optim.AdamW(groups, lr=lr, betas=betas, eps=eps, weight_decay=wd)
-    if name == "adam":
-        return torch.optim.Adam(groups, lr=lr, betas=betas, eps=eps)
-    if name == "sgd":
-        return torch.optim.SGD(groups, lr=lr, momentum=float(getattr(oc, "momentum", 0.9)), weight_decay=wd,
-                               nesterov=bool(getattr(oc, "nesterov", False)))
-    raise ValueError(f"Unknown optimizer: {name}")
+            opt = FusedAdamW(groups, lr=lr, betas=betas, eps=eps, weight_decay=wd,
+                             max_grad_norm=float(getattr(cfg.optimization, "gradient_clip_val", 0.0) or 0.0),
+                             ema_decay=float(getattr(ema, "decay", 0.999)) if ema_on else None,
+                             ema_warmup_steps=int(getattr(ema, "warmup_steps", 0) or 0) if ema_on else 0)
+        else:
+            opt = torch.optim.AdamW(groups, lr=lr, betas=betas, eps=eps, weight_decay=wd)
+    elif name == "adam":
+        opt = torch.optim.Adam(groups, lr=lr, betas=betas, eps=eps)
+    elif name == "sgd":
+        opt = torch.optim.SGD(groups, lr=lr, momentum=float(getattr(oc, "momentum", 0.9)), weight_decay=wd,
+                              nesterov=bool(getattr(oc, "nesterov", False)))
+    else:
+        raise ValueError(f"Unknown optimizer: '{name}'. Supported optimizers: adamw, adam, sgd")
+    opt._pytc_model_order = model_order          # position of every parameter in registration order (checkpoint remapping)
+    return opt
+
+
+def _sched_param(sc, key, default, *, specific=False):
+    """optimization/build.py:30-44: `scheduler.params[key]` first; then (unless scheduler-specific) the direct field."""
+    params = getattr(sc, "params", None)
+    if isinstance(params, Mapping) and key in params and params[key] is not None:
+        return params[key]
+    if specific:
+        return default
+    v = getattr(sc, key, default)
+    return default if v is None else v
+
+
+def build_lr_scheduler(cfg, optimizer):
+    """The reference's scheduler table (optimization/build.py:155-324): cosineannealinglr (default, also for unknown names),
+    cosineannealingwarmrestarts, steplr, multisteplr, reducelronplateau, warmupcosine[lr], constant[lr]; parameters from
+    `scheduler.params` then the typed fields; `name: null` = no scheduler.  WarmupCosineLR also accepts the round-1 spellings
+    (max_iters / warmup_iters / warmup_factor)."""
+    from torch.optim import lr_scheduler as LS
+    sc = getattr(cfg.optimization, "scheduler", None)
+    if sc is None or getattr(sc, "name", "cosineannealinglr") is None:
+        return None
+    name = str(_sched_param(sc, "name", "cosineannealinglr")).lower()
+    max_epochs = int(getattr(cfg.optimization, "max_epochs", 100) or 100)
+    if name in ("cosineannealingwarmrestarts", "cosinewarmrestarts"):
+        return LS.CosineAnnealingWarmRestarts(optimizer, T_0=int(_sched_param(sc, "T_0", 200, specific=True)),
+                                              T_mult=int(_sched_param(sc, "T_mult", 1, specific=True)),
+                                              eta_min=float(_sched_param(sc, "min_lr", 1e-5)))
+    if name == "steplr":
+        return LS.StepLR(optimizer, step_size=int(_sched_param(sc, "step_size", 30, specific=True)),
+                         gamma=float(_sched_param(sc, "gamma", 0.1, specific=True)))
+    if name == "multisteplr":
+        return LS.MultiStepLR(optimizer, milestones=list(_sched_param(sc, "milestones", [30, 60, 90], specific=True)),
+                              gamma=float(_sched_param(sc, "gamma", 0.1, specific=True)))
+    if name == "reducelronplateau":
+        return LS.ReduceLROnPlateau(optimizer, mode=_sched_param(sc, "mode", "min"), factor=float(_sched_param(sc, "factor", 0.1)),
+                                    patience=int(_sched_param(sc, "patience", 10)), threshold=float(_sched_param(sc, "threshold", 1e-4)),
+                                    cooldown=int(_sched_param(sc, "cooldown", 0)), eps=float(_sched_param(sc, "eps", 1e-8)),
+                                    min_lr=float(_sched_param(sc, "min_lr", 1e-6)))
+    if name in ("warmupcosine", "warmupcosinelr", "warmup_cosine", "warmup_cosine_lr"):
+        max_iter = _sched_param(sc, "max_iter", None, specific=True) or getattr(sc, "max_iters", None) or max_epochs
+        warm = getattr(sc, "warmup_iters", None)
+        factor = getattr(sc, "warmup_factor", None)
+        return WarmupCosineLR(optimizer, int(max_iter),
+                              warmup_factor=float(factor if factor is not None else _sched_param(sc, "warmup_start_lr", 0.001)),
+                              warmup_iters=int(warm if warm is not None else _sched_param(sc, "warmup_epochs", 5)),
+                              eta_min=float(_sched_param(sc, "min_lr", 0.0)))
+    if name in ("constant", "constantlr"):
+        return LS.LambdaLR(optimizer, lr_lambda=lambda epoch: 1.0)
+    if name != "cosineannealinglr":
+        import logging
+        logging.getLogger(__name__).warning("unknown scheduler %r: using CosineAnnealingLR like the reference builder", name)
+    return LS.CosineAnnealingLR(optimizer, T_max=int(_sched_param(sc, "t_max", max_epochs, specific=True)),
+                                eta_min=float(_sched_param(sc, "min_lr", 1e-6)))
 
 
 class ConnectomicsModule(nn.Module):
@@ -173,7 +258,11 @@ class ConnectomicsModule(nn.Module):
                                     "target_slice": get("target_slice"), "pos_weight": get("pos_weight"),
                                     "kwargs": dict(get("kwargs", None) or {})})
         self.fused_loss = bool(getattr(loss_cfg, "fused", True))
+        # every prediction is clamped before its loss, at every scale (orchestrator.py:95-96,574; schema/model.py:50-51)
+        self.clamp_min = float(getattr(loss_cfg, "deep_supervision_clamp_min", -20.0))
+        self.clamp_max = float(getattr(loss_cfg, "deep_supervision_clamp_max", 20.0))
         self.global_step = 0
+        self.current_epoch = 0
 
     # ---- reference-visible methods ----------------------------------------------------------------
     def forward(self, x: torch.Tensor):
@@ -214,6 +303,7 @@ class ConnectomicsModule(nn.Module):
     def _term_loss(self, pred, target, mask=None, terms=None):
         """Weighted sum of the loss terms `terms` (list of (index, term); default: all) on one prediction tensor."""
         terms = list(enumerate(self.loss_terms)) if terms is None else terms
+        pred = torch.clamp(pred, min=self.clamp_min, max=self.clamp_max)
         if pred.is_cuda and self.fused_loss and all(t["fn"] in self._FUSABLE for _, t in terms):
             res = self._fused_term_loss(pred, target, mask, terms)      # finiteness is checked where fit() reads the value
             if res is not None:
@@ -280,8 +370,8 @@ class ConnectomicsModule(nn.Module):
                 ds = outputs.get(f"ds_{i}")
                 if ds is None:
                     continue
-                tgt = F.interpolate(labels.float(), size=ds.shape[2:], mode="nearest")
-                m = None if mask is None else F.interpolate(mask.float(), size=ds.shape[2:], mode="nearest")
+                tgt = match_target_to_output(labels, ds)
+                m = None if mask is None else resize_class_index_to_output(mask, ds)
                 li, _ = self._term_loss(ds, tgt, m)
                 total = total + self.ds_weights[i] * li
         parts["train_loss_total"] = total.detach()
@@ -304,21 +394,17 @@ class ConnectomicsModule(nn.Module):
 
     def configure_optimizers(self):
         opt = build_optimizer(self.cfg, self.model)
-        sc = getattr(self.cfg.optimization, "scheduler", None)
-        name = str(getattr(sc, "name", None) or "").lower()
-        sched = None
-        if name in ("warmupcosinelr", "warmup_cosine", "warmup_cosine_lr"):
-            sched = WarmupCosineLR(opt, max_iters=int(getattr(sc, "max_iters", 1000)),
-                                   warmup_iters=int(getattr(sc, "warmup_iters", 100)),
-                                   warmup_factor=float(getattr(sc, "warmup_factor", 0.001)),
-                                   eta_min=float(getattr(sc, "min_lr", 0.0)))
-        return opt, sched
+        return opt, build_lr_scheduler(self.cfg, opt)
 
     # ---- checkpoints in the Lightning layout ------------------------------------------------------
     def checkpoint_dict(self, optimizer=None) -> Dict[str, Any]:
         ck = {"state_dict": {"model." + k: v.detach().cpu() for k, v in self.model.state_dict().items()},
               "global_step": self.global_step,
               "pytc_metadata": {"format_version": 1, "model_arch": str(getattr(self.cfg.model.arch, "type", ""))}}
+        ck["epoch"] = int(getattr(self, "current_epoch", 0))
+        sched = getattr(self, "_scheduler", None)
+        if sched is not None:
+            ck["lr_schedulers"] = [sched.state_dict()]
         if optimizer is not None:
             ck["optimizer_states"] = [optimizer.state_dict()]
             if getattr(optimizer, "ema", None):
@@ -330,10 +416,71 @@ class ConnectomicsModule(nn.Module):
         return ck
 
     def load_checkpoint_dict(self, ck: Dict[str, Any]) -> None:
+        """Model weights + counters now; optimizer / scheduler / EMA state is kept and applied by `restore_training_state`
+        once `fit` has built them (a true resume: Adam moments, the LR schedule position and the EMA shadow continue)."""
         sd = {k[len("model."):]: v for k, v in ck["state_dict"].items()
               if k.startswith("model.") and not k.startswith("model.loss_functions.")}
-        self.model.load_state_dict(sd, strict=True)
+        missing, unexpected = self.model.load_state_dict(sd, strict=False)
+        # a reference checkpoint may carry deep-supervision heads of a trunk built with them (`out_1..out_4`); anything else
+        # missing / unexpected is an architecture mismatch
+        bad_unexpected = [k for k in unexpected if not any(f".out_{i}." in "." + k for i in (1, 2, 3, 4))]
+        if missing or bad_unexpected:
+            raise RuntimeError(f"checkpoint does not match the model: missing {missing[:5]}, unexpected {bad_unexpected[:5]}")
         self.global_step = int(ck.get("global_step", 0))
+        self.current_epoch = int(ck.get("epoch", 0))
+        self._resume = {k: ck[k] for k in ("optimizer_states", "lr_schedulers", "callbacks") if k in ck}
+
+    def restore_training_state(self, optimizer, scheduler=None) -> bool:
+        """Apply the optimizer / scheduler / EMA state of a loaded checkpoint.  Optimizer states written with the reference's
+        one-group-per-parameter layout (or torch's) are remapped by parameter order onto this optimizer's merged groups."""
+        res = getattr(self, "_resume", None)
+        if not res:
+            return False
+        if res.get("optimizer_states"):
+            _load_optimizer_state(optimizer, res["optimizer_states"][0])
+        if scheduler is not None and res.get("lr_schedulers"):
+            scheduler.load_state_dict(res["lr_schedulers"][0])
+        ema = (res.get("callbacks") or {}).get("EMAWeightsCallback")
+        if ema and getattr(optimizer, "ema_decay", None) is not None and hasattr(optimizer, "load_ema_state_dict"):
+            optimizer.load_ema_state_dict(self.model, ema["ema_state"], int(ema.get("updates", 0)))
+        self._resume = None
+        return True
+
+
+def _load_optimizer_state(optimizer, state: Dict[str, Any]) -> None:
+    """optimizer.load_state_dict that tolerates a different GROUPING of the same parameters in the same order: torch maps
+    saved state to parameters by position, so the per-parameter state (exp_avg, exp_avg_sq, step) is re-keyed onto this
+    optimizer's parameter order and the groups keep their own hyper-parameters (the checkpoint's lr is adopted per
+    parameter when the group counts match, as torch would)."""
+    saved_groups = state["param_groups"]
+    own_groups = optimizer.state_dict()["param_groups"]
+    n_saved = sum(len(g["params"]) for g in saved_groups)
+    n_own = sum(len(g["params"]) for g in own_groups)
+    if n_saved != n_own:
+        raise ValueError(f"optimizer state holds {n_saved} parameters, the optimizer {n_own}: different models")
+    if [len(g["params"]) for g in saved_groups] == [len(g["params"]) for g in own_groups]:
+        optimizer.load_state_dict(state)
+        return
+    # position of every parameter in the model-order enumeration both layouts were built from
+    order_own = [pid for g in own_groups for pid in g["params"]]
+    if len(saved_groups) == n_saved:                 # reference layout: one group per parameter, in model order
+        order_saved = [g["params"][0] for g in saved_groups]
+        model_pos_of_own = _model_order_positions(optimizer)
+        remap = {order_saved[model_pos_of_own[i]]: order_own[i] for i in range(n_own)}
+    else:
+        raise ValueError("optimizer state has a parameter grouping this loader cannot remap "
+                         f"({len(saved_groups)} groups for {n_saved} parameters)")
+    new_state = {remap[k]: v for k, v in state["state"].items() if k in remap}
+    optimizer.load_state_dict({"state": new_state, "param_groups": own_groups})
+
+
+def _model_order_positions(optimizer):
+    """For the i-th parameter in the optimizer's flattened group order: its index in model (registration) order."""
+    order = getattr(optimizer, "_pytc_model_order", None)
+    if order is None:
+        raise ValueError("the optimizer does not know the model order of its parameters (built outside build_optimizer)")
+    flat = [p for g in optimizer.param_groups for p in g["params"]]
+    return [order[id(p)] for p in flat]
 
 
 def precision_to_dtype(precision) -> torch.dtype:
@@ -341,15 +488,41 @@ def precision_to_dtype(precision) -> torch.dtype:
     return torch.bfloat16 if any(s in str(precision) for s in ("16", "bf16")) else torch.float32
 
 
+def resolve_training_steps(cfg, *, fast_dev_run: int = 0, dataset_steps_per_epoch: Optional[int] = None) -> tuple[int, int]:
+    """(total optimizer steps, steps per epoch) from optimization.{max_steps, max_epochs, n_steps_per_epoch}.  The reference's
+    default n_steps_per_epoch = -1 means "from the dataset size" (schema/optimization.py:96): with an iterable synthetic /
+    sampled source there is no such size, so `dataset_steps_per_epoch` (when the caller knows one) or an explicit error."""
+    oc = cfg.optimization
+    if fast_dev_run:
+        return int(fast_dev_run), int(fast_dev_run)
+    per_epoch = getattr(oc, "n_steps_per_epoch", None)
+    per_epoch = int(per_epoch) if per_epoch is not None else -1
+    if per_epoch <= 0:
+        if dataset_steps_per_epoch is None or dataset_steps_per_epoch <= 0:
+            raise ValueError("optimization.n_steps_per_epoch is -1 / unset (auto from the dataset size) but the training source "
+                             "is an endless sampler: set optimization.n_steps_per_epoch (or optimization.max_steps)")
+        per_epoch = int(dataset_steps_per_epoch)
+    total = per_epoch * max(1, int(getattr(oc, "max_epochs", 1) or 1))
+    max_steps = getattr(oc, "max_steps", None)
+    if max_steps is not None and int(max_steps) > 0:
+        total = min(total, int(max_steps)) if getattr(oc, "max_epochs", None) else int(max_steps)
+    return total, per_epoch
+
+
 def fit(module: ConnectomicsModule, batches, *, max_steps: int, device, log_every: int = 10, ddp: bool = False,
-        log=print):
+        log=print, steps_per_epoch: Optional[int] = None):
     """Minimal training loop: forward (HIP) -> loss -> backward (HIP) -> clip -> optimizer (+ scheduler).
-    `batches` yields {"image","label"[,"mask"]} dicts of (B,C,D,H,W) tensors."""
+    `batches` yields {"image","label"[,"mask"]} dicts of (B,C,D,H,W) tensors.  `max_steps` is the TOTAL step count of the run:
+    after `load_checkpoint_dict` the loop continues from `module.global_step` with the optimizer moments, the scheduler
+    position and the EMA shadow of the checkpoint.  The scheduler steps per `optimization.scheduler.interval` ('epoch', the
+    reference default, every `steps_per_epoch` optimizer steps; or 'step') and `frequency` (lightning/model.py:1174-1200)."""
     cfg = module.cfg
     module.to(device).train()
     inner = getattr(module.model, "model", module.model)
-    if hasattr(inner, "compute_dtype"):
-        inner.compute_dtype = precision_to_dtype(getattr(cfg.optimization, "precision", "32"))
+    dt = precision_to_dtype(getattr(cfg.optimization, "precision", "32"))
+    for mod in (module.model, inner):
+        if hasattr(mod, "compute_dtype"):
+            mod.compute_dtype = dt
     net = module
     if ddp:
         from torch.nn.parallel import DistributedDataParallel as DDP
@@ -357,11 +530,22 @@ def fit(module: ConnectomicsModule, batches, *, max_steps: int, device, log_ever
         # the MedNeXt trunk carries an unused `dummy_tensor` parameter (trainer.py:241-253 uses the same flag)
         net = DDP(module, device_ids=dev_ids, find_unused_parameters=True)
     opt, sched = module.configure_optimizers()
+    module._scheduler = sched
+    resumed = module.restore_training_state(opt, sched)
+    sc = getattr(cfg.optimization, "scheduler", None)
+    interval = str(getattr(sc, "interval", "epoch") or "epoch").lower()
+    frequency = max(1, int(getattr(sc, "frequency", 1) or 1))
+    if interval not in ("epoch", "step"):
+        raise ValueError(f"optimization.scheduler.interval must be 'epoch' or 'step', got {interval!r}")
+    per_epoch = int(steps_per_epoch) if steps_per_epoch else max_steps
+    plateau = isinstance(sched, torch.optim.lr_scheduler.ReduceLROnPlateau)
     clip = float(getattr(cfg.optimization, "gradient_clip_val", 0.0) or 0.0)
     accum = max(1, int(getattr(cfg.optimization, "accumulate_grad_batches", 1) or 1))
     history = []
     it = iter(batches)
-    for step in range(max_steps):
+    first = module.global_step if resumed else 0
+    epoch_loss, epoch_n = 0.0, 0
+    for step in range(first, max_steps):
         opt.zero_grad(set_to_none=True)
         for _ in range(accum):
             batch = {k: v.to(device, non_blocking=True) for k, v in next(it).items()}
@@ -371,13 +555,23 @@ def fit(module: ConnectomicsModule, batches, *, max_steps: int, device, log_ever
         if clip > 0 and not hasattr(opt, "max_grad_norm"):     # FusedAdamW clips inside its update kernel
             torch.nn.utils.clip_grad_norm_(module.model.parameters(), clip)
         opt.step()
+        module.global_step = step + 1
+        history.append(float(loss.detach()))
+        epoch_loss, epoch_n = epoch_loss + history[-1], epoch_n + 1
+        end_of_epoch = (step + 1) % per_epoch == 0
+        if end_of_epoch:
+            module.current_epoch += 1
         if sched is not None:
-            sched.step()
-        module.global_step += 1
-        if step == 2:
+            if interval == "step":
+                if (step + 1) % frequency == 0:
+                    sched.step(history[-1]) if plateau else sched.step()
+            elif end_of_epoch and module.current_epoch % frequency == 0:
+                sched.step(epoch_loss / max(1, epoch_n)) if plateau else sched.step()
+        if end_of_epoch:
+            epoch_loss, epoch_n = 0.0, 0
+        if step - first == 2:
             from ..utils.hostgc import quiesce_gc
             quiesce_gc()       # the cyclic GC's full passes cost milliseconds per step in a launch-bound loop
-        history.append(float(loss.detach()))
         if not math.isfinite(history[-1]):
             raise FloatingPointError(f"training loss is not finite at step {step}")
         if log and (step % log_every == 0 or step == max_steps - 1):
@@ -395,5 +589,6 @@ def synthetic_batches(batch_size: int, patch, *, in_channels=1, out_channels=1, 
         yield {"image": img, "label": lab}
 
 
-__all__ = ["ConnectomicsModule", "build_optimizer", "WarmupCosineLR", "fit", "synthetic_batches",
+__all__ = ["ConnectomicsModule", "build_optimizer", "build_lr_scheduler", "WarmupCosineLR", "fit", "resolve_training_steps",
+           "match_target_to_output", "synthetic_batches",
            "dice_loss_sigmoid", "weighted_bce_with_logits", "precision_to_dtype"]

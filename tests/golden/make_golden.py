@@ -320,6 +320,19 @@ def tta():
             cfg2 = cfg_for(NS(**{**vars(tta_ns), "patch_first_local": False}), acts=acts, select=select)
             y2 = mgr.InferenceManager(cfg=cfg2, model=torch.nn.Identity(), forward_fn=_net_asym).predict_with_tta(x.clone())
             print("  whole-volume vs patch-first max diff", float((y - y2).abs().max()))
+    # patch_first_local: false -- every view is its own whole-volume sliding pass (tta.py:691-769, 806-878); the window grid of
+    # a flipped / rotated 14x22x26 volume differs from the identity view's, and odd rotations of a non-square plane are allowed
+    whole = {
+        "whole_flip8_mean_sigmoid": (NS(**{**vars(cases["flip8_mean_sigmoid"][0]), "patch_first_local": False}),
+                                     [{"channels": ":", "activation": "sigmoid"}], None),
+        "whole_rot16_nonsquare_minmax": (NS(**{**vars(cases["rot16_min_mixed"][0]), "patch_first_local": False}),
+                                         cases["rot16_min_mixed"][1], None),
+    }
+    for name, (tta_ns, acts, select) in whole.items():
+        cfg = cfg_for(tta_ns, acts=acts, select=select, roi=(8, 12, 16))
+        y = mgr.InferenceManager(cfg=cfg, model=torch.nn.Identity(), forward_fn=_net_asym).predict_with_tta(x.clone())
+        out[f"{name}__y"] = y.numpy()
+        print(name, tuple(y.shape), float(y.mean()))
     save("tta.npz", **out)
 
 
@@ -756,9 +769,65 @@ def accessor():
     save("lazy_accessor.npz", **out)
 
 
+# ---------------------------------------------------------------- deep-supervision loss through the reference orchestrator
+def ds_loss():
+    """connectomics/training/losses/orchestrator.py: LossOrchestrator.compute_deep_supervision_loss / compute_standard_loss with
+    the reference's WeightedBCEWithLogitsLoss (models/losses/losses.py) on 5 output scales: logits beyond the +-20 clamp, dense
+    float targets (trilinear resize + range clamp, orchestrator.py:892-952), a batch mask (nearest resize).  Stores inputs,
+    totals, per-scale values and the gradients w.r.t. every output."""
+    from types import SimpleNamespace as NS
+    S._stub_pkg("connectomics.training.losses")
+    S._stub_pkg("connectomics.config.pipeline")
+    meta = S.ref("connectomics.models.losses.metadata")
+    ml = sys.modules["connectomics.models.losses"]
+    for n in dir(meta):
+        if not n.startswith("_"):
+            setattr(ml, n, getattr(meta, n))
+    losses_mod = S.ref("connectomics.models.losses.losses")
+    orch = S.ref("connectomics.training.losses.orchestrator")
+    cfg = NS(model=NS(loss=NS(deep_supervision=True, deep_supervision_weights=[1.0, 0.5, 0.25, 0.125, 0.0625],
+                              deep_supervision_clamp_min=-20.0, deep_supervision_clamp_max=20.0,
+                              losses=[{"function": "WeightedBCEWithLogitsLoss", "weight": 1.0}], loss_balancing=None),
+                      primary_head=None, heads=None, out_channels=2), data=NS(label_transform=None))
+    o = orch.LossOrchestrator(cfg, torch.nn.ModuleList([losses_mod.WeightedBCEWithLogitsLoss()]), [1.0], enable_nan_detection=False,
+                              debug_on_nan=False, resolve_affinity_mode_fn=lambda c: None)
+    g = torch.Generator().manual_seed(0)
+    out = {}
+    outs = {"output": (torch.randn(2, 2, 16, 16, 16, generator=g) * 12).requires_grad_(True)}
+    for i, sz in enumerate((8, 4, 2, 1), 1):
+        outs[f"ds_{i}"] = (torch.randn(2, 2, sz, sz, sz, generator=g) * 30).requires_grad_(True)
+    lab = (torch.rand(2, 2, 16, 16, 16, generator=g) > 0.7).float()
+    lab[:, 1] = torch.rand(2, 16, 16, 16, generator=g)                    # a real-valued channel in [0, 1]
+    mask = (torch.rand(2, 1, 16, 16, 16, generator=g) > 0.3).float()
+    for name, m in (("nomask", None), ("mask", mask)):
+        for t in outs.values():
+            t.grad = None
+        tot, logs = o.compute_deep_supervision_loss(outs, lab, stage="train", mask=m)
+        tot.backward()
+        out[f"{name}__total"] = np.float32(tot.item())
+        out[f"{name}__scales"] = np.asarray([logs[f"train_loss_scale_{i}"] for i in range(5)], np.float32)
+        for k, t in outs.items():
+            out[f"{name}__grad_{k}"] = t.grad.numpy().copy()
+    # single-scale (standard) path: the clamp applies there too
+    outs["output"].grad = None
+    tot, _ = o.compute_standard_loss(outs["output"], lab, stage="train", mask=mask)
+    tot.backward()
+    out["standard__total"] = np.float32(tot.item())
+    out["standard__grad_output"] = outs["output"].grad.numpy().copy()
+    for k, t in outs.items():
+        out[f"in_{k}"] = t.detach().numpy()
+    out["label"], out["mask"] = lab.numpy(), mask.numpy()
+    # the resize helper on its own: [-1, 1] targets keep their range, integer labels stay integer
+    sdt = torch.rand(1, 1, 9, 10, 11, generator=g) * 2 - 1
+    out["sdt"], out["sdt_resized"] = sdt.numpy(), orch.match_target_to_output(sdt, torch.zeros(1, 1, 4, 5, 5)).numpy()
+    ilab = torch.randint(0, 5, (1, 1, 9, 10, 11), generator=g)
+    out["ilab"], out["ilab_resized"] = ilab.numpy(), orch.match_target_to_output(ilab, torch.zeros(1, 1, 4, 5, 5)).numpy()
+    save("ds_loss.npz", **out)
+
+
 if __name__ == "__main__":
     parts = {"manifests": manifests, "optimizers": optimizers, "schedules": schedules, "selectors": selectors, "outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
-             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "accessor": accessor}
+             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "accessor": accessor, "ds_loss": ds_loss}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:
         parts[name]()

@@ -46,7 +46,7 @@ def test_load_config_stage_merge_and_aliases(tmp_path):
     assert cfg.inference.sliding_window.padding_mode == "reflect"                      # schema default
     assert cfg.inference.test_time_augmentation.flip_axes == "all"
     assert cfg.inference.model.select_channel == [0] and cfg.inference.select_channel == [0]
-    assert cfg.optimization.precision == "32"                                          # train section not merged in test
+    assert cfg.optimization.precision == "16-mixed"                                    # schema default (train section not merged in test)
     assert cfg.data.test.image.startswith("random://")
     with pytest.warns(UserWarning):
         tr = load_config(p, mode="train")

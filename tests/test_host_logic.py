@@ -181,3 +181,58 @@ def test_engine_argument_errors():
     assert img == (8, 20, 9) and starts[0] == (0, 0, 0) and starts[-1] == (0, 12, 1)
     assert W._effective_pad_mode((0, 0, 0), (64,) * 3, (32,) * 3, "reflect") == "constant"
     assert W._effective_pad_mode((-2, 0, 0), (8,) * 3, (32,) * 3, "reflect") == "reflect"
+
+
+def test_upkern_load_weights_and_head_spec_parsing():
+    """upkern_load_weights (reference mednext_models.py:487-537): k3 -> k5: every non-depthwise tensor copied, depthwise kernels
+    resized trilinearly (the centre tap maps onto itself), mismatched architectures rejected; head specs accept mappings,
+    namespaces and bare ints (mednext_models.py:245-262)."""
+    from types import SimpleNamespace as NS
+    from pytorch_connectomics_amd.models import build_model
+    from pytorch_connectomics_amd.models.architectures.mednext_models import (MedNeXtMultiHeadWrapper, _HeadSpec,
+                                                                              upkern_load_weights)
+    import torch.nn.functional as F
+
+    def cfg(k, base=8, counts=(1,) * 9):
+        return NS(model=NS(arch=NS(type="mednext_custom"), in_channels=1, out_channels=2, heads=None,
+                           mednext=NS(base_channels=base, exp_r=2, kernel_size=k, block_counts=list(counts)),
+                           loss=NS(deep_supervision=False)))
+    torch.manual_seed(0)
+    src, tgt = build_model(cfg(3)), build_model(cfg(5))
+    before = {k: v.clone() for k, v in tgt.model.state_dict().items()}
+    out = upkern_load_weights(tgt, src)
+    assert out is tgt
+    s, t = src.model.state_dict(), tgt.model.state_dict()
+    resized = 0
+    for k, v in t.items():
+        if s[k].shape == v.shape:
+            assert torch.equal(v, s[k]), k
+        else:
+            resized += 1
+            assert k.endswith("conv1.weight") and v.shape[-3:] == (5, 5, 5) and s[k].shape[-3:] == (3, 3, 3)
+            torch.testing.assert_close(v[..., 2, 2, 2], s[k][..., 1, 1, 1])                  # centre tap preserved
+            torch.testing.assert_close(v, F.interpolate(s[k], size=(5, 5, 5), mode="trilinear"))
+            assert not torch.equal(v, before[k])
+    assert resized == 9 + 4 + 4                                        # 9 block groups x 1 block + 4 down + 4 up depthwise convs
+    with pytest.raises(ValueError, match="incompatible shapes"):
+        upkern_load_weights(build_model(cfg(5, base=16)), src)
+    # head specs
+    assert _HeadSpec.parse({"out_channels": 3, "num_blocks": 2, "hidden_channels": 4}) == _HeadSpec(3, 2, 4)
+    assert _HeadSpec.parse(NS(out_channels=1)) == _HeadSpec(1, 0, None) and _HeadSpec.parse(5) == _HeadSpec(5, 0, None)
+    w = MedNeXtMultiHeadWrapper(build_model(cfg(3)).model, {"a": {"out_channels": 3, "num_blocks": 1, "hidden_channels": 4}, "b": 2})
+    assert w.head_specs == {"a": {"out_channels": 3, "num_blocks": 1, "hidden_channels": 4},
+                            "b": {"out_channels": 2, "num_blocks": 0, "hidden_channels": 8}} and w.primary_head == "a"
+    assert w.head_block_kwargs == dict(exp_r=2, kernel_size=3, do_res=True, norm_type="group", dim="3d", grn=False)
+    for bad, msg in ((dict(out_channels=0), "out_channels must be positive"), (dict(out_channels=1, num_blocks=-1), "num_blocks must be >= 0"),
+                     (dict(out_channels=1, hidden_channels=16), "must not exceed the shared feature width"),
+                     (dict(out_channels=1, hidden_channels=0), "hidden_channels must be positive")):
+        with pytest.raises(ValueError, match=msg):
+            MedNeXtMultiHeadWrapper(build_model(cfg(3)).model, {"h": bad})
+    with pytest.raises(ValueError, match="primary_head 'zz'"):
+        MedNeXtMultiHeadWrapper(build_model(cfg(3)).model, {"h": 1}, primary_head="zz")
+    c = cfg(3)
+    c.model.mednext.checkpoint_style = "inside_block"
+    c.model.arch.type = "mednext"
+    c.model.mednext.size = "S"
+    with pytest.raises(ValueError, match="checkpoint_style must be None or 'outside_block'"):
+        build_model(c)

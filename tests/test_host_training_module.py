@@ -2,8 +2,10 @@
 loss terms, deep supervision, optimizer grouping, scheduler, checkpoint layout, and DDP over gloo (world 2)."""
 import math
 import os
+from pathlib import Path
 from types import SimpleNamespace as NS
 
+import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp
@@ -11,6 +13,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from pytorch_connectomics_amd.config import ConfigNode, schema_defaults
+
+GOLD = Path(__file__).parent / "golden"
 from pytorch_connectomics_amd.training.module import (ConnectomicsModule, WarmupCosineLR, build_optimizer,
                                                       dice_loss_sigmoid, fit, synthetic_batches,
                                                       weighted_bce_with_logits)
@@ -55,8 +59,8 @@ def test_loss_terms_and_deep_supervision():
     loss = m.training_step(batch)
     out = m(batch["image"])
     base = lambda o, t: weighted_bce_with_logits(o, t) + dice_loss_sigmoid(o, t)
-    want = base(out["output"], target) + 0.5 * base(out["ds_1"], F.interpolate(target, size=(4, 4, 4))) \
-        + 0.25 * base(out["ds_2"], F.interpolate(target, size=(2, 2, 2)))
+    rs = lambda t, n: F.interpolate(t, size=(n, n, n), mode="trilinear", align_corners=False).clamp(-1, 1)   # float targets
+    want = base(out["output"], target) + 0.5 * base(out["ds_1"], rs(target, 4)) + 0.25 * base(out["ds_2"], rs(target, 2))
     assert torch.allclose(loss, want, atol=1e-6) and loss.requires_grad
     val = m.validation_step(batch)
     assert 0 <= float(val["val_jaccard"]) <= 1
@@ -290,3 +294,145 @@ def test_regression_losses_match_reference_fixture():
         assert abs(float(v.detach()) - float(z[f"reg_{n}__loss"][0])) < 1e-6, n
         v.backward()
         assert torch.allclose(x.grad, torch.from_numpy(z[f"reg_{n}__grad"]), atol=1e-8, rtol=1e-5), n
+
+
+def test_deep_supervision_loss_matches_reference_orchestrator_fixture():
+    """tests/golden/ds_loss.npz (make_golden.py --ds_loss): LossOrchestrator.compute_deep_supervision_loss /
+    compute_standard_loss on 5 scales with logits beyond the +-20 clamp, a real-valued target channel (trilinear resize +
+    range clamp) and a batch mask (nearest resize): totals, per-scale values and every gradient."""
+    from pytorch_connectomics_amd.training.module import match_target_to_output
+    g = np.load(GOLD / "ds_loss.npz")
+    cfg = _cfg()
+    cfg.model.loss.deep_supervision = True
+    cfg.model.loss.losses = [{"function": "WeightedBCEWithLogitsLoss", "weight": 1.0}]
+    m = ConnectomicsModule(cfg, model=SimpleModel())
+    names = ["output", "ds_1", "ds_2", "ds_3", "ds_4"]
+    lab, mask = torch.from_numpy(g["label"]), torch.from_numpy(g["mask"])
+    for case, mk in (("nomask", None), ("mask", mask)):
+        outs = {k: torch.from_numpy(g[f"in_{k}"]).clone().requires_grad_(True) for k in names}
+        tot, _ = m._compute_loss(outs, lab, mk)
+        tot.backward()
+        assert float(tot) == pytest.approx(float(g[f"{case}__total"]), rel=2e-6)
+        for k in names:
+            assert torch.allclose(outs[k].grad, torch.from_numpy(g[f"{case}__grad_{k}"]), rtol=1e-5, atol=1e-9), (case, k)
+        # per-scale values (unweighted), the reference logs them as train_loss_scale_i
+        for i, k in enumerate(names):
+            tgt = match_target_to_output(lab, outs[k])
+            mm = None if mk is None else F.interpolate(mk, size=outs[k].shape[2:], mode="nearest")
+            v, _ = m._term_loss(outs[k].detach(), tgt, mm)
+            assert float(v) == pytest.approx(float(g[f"{case}__scales"][i]), rel=2e-6), (case, i)
+    cfg.model.loss.deep_supervision = False
+    m1 = ConnectomicsModule(cfg, model=SimpleModel())
+    o = torch.from_numpy(g["in_output"]).clone().requires_grad_(True)
+    tot, _ = m1._compute_loss(o, lab, mask)
+    tot.backward()
+    assert float(tot) == pytest.approx(float(g["standard__total"]), rel=2e-6)                  # the clamp applies here too
+    assert torch.allclose(o.grad, torch.from_numpy(g["standard__grad_output"]), rtol=1e-5, atol=1e-9)
+    assert (o.grad[torch.from_numpy(g["in_output"]).abs() > 20] == 0).all()                    # clamped logits get no gradient
+    sdt = match_target_to_output(torch.from_numpy(g["sdt"]), torch.zeros(1, 1, 4, 5, 5))
+    assert torch.allclose(sdt, torch.from_numpy(g["sdt_resized"]), atol=1e-7)
+    il = match_target_to_output(torch.from_numpy(g["ilab"]), torch.zeros(1, 1, 4, 5, 5))
+    assert il.dtype == torch.int64 and torch.equal(il, torch.from_numpy(g["ilab_resized"]))
+
+
+def test_scheduler_table_defaults_and_interval():
+    """optimization/build.py:155-324 + schema/optimization.py defaults: CosineAnnealingLR(T_max=max_epochs, eta_min=min_lr)
+    stepping once per EPOCH; `name: null` = none; 'step' interval; unknown interval is an error."""
+    from torch.optim import lr_scheduler as LS
+    from pytorch_connectomics_amd.training.module import build_lr_scheduler, resolve_training_steps
+    d = schema_defaults()["optimization"]
+    assert d["gradient_clip_val"] == 1.0 and d["precision"] == "16-mixed" and d["n_steps_per_epoch"] == -1
+    assert d["scheduler"]["name"] == "CosineAnnealingLR" and d["scheduler"]["min_lr"] == 1e-5 and d["scheduler"]["interval"] == "epoch"
+    cfg = _cfg(max_epochs=4)
+    model = SimpleModel()
+    opt = build_optimizer(cfg, model)
+    sch = build_lr_scheduler(cfg, opt)
+    assert isinstance(sch, LS.CosineAnnealingLR) and sch.T_max == 4 and sch.eta_min == 1e-5
+    for name, kind in (("StepLR", LS.StepLR), ("MultiStepLR", LS.MultiStepLR), ("ReduceLROnPlateau", LS.ReduceLROnPlateau),
+                       ("CosineAnnealingWarmRestarts", LS.CosineAnnealingWarmRestarts), ("WarmupCosineLR", WarmupCosineLR),
+                       ("constant", LS.LambdaLR), ("somethingelse", LS.CosineAnnealingLR)):
+        cfg.optimization.scheduler.name = name
+        assert isinstance(build_lr_scheduler(cfg, build_optimizer(cfg, model)), kind), name
+    cfg.optimization.scheduler.name = None
+    assert build_lr_scheduler(cfg, opt) is None
+    # epoch interval: 12 steps, 3 per epoch -> 4 scheduler steps; lr constant within an epoch
+    cfg.optimization.scheduler.name = "CosineAnnealingLR"
+    cfg.optimization.n_steps_per_epoch = 3
+    total, per = resolve_training_steps(cfg)
+    assert (total, per) == (12, 3)
+    lrs = []
+    m = ConnectomicsModule(cfg, model=SimpleModel())
+    fit(m, synthetic_batches(1, (8, 8, 8)), max_steps=total, steps_per_epoch=per, device=torch.device("cpu"),
+        log=lambda msg: lrs.append(float(msg.rsplit("lr ", 1)[1])), log_every=1)
+    assert m.current_epoch == 4 and m._scheduler.last_epoch == 4
+    # the line is logged after the step's scheduler update: the third step of an epoch already shows the next epoch's lr
+    assert lrs[0] == lrs[1] == pytest.approx(1e-2) and lrs[2] < lrs[1] and lrs[2] == lrs[3] == lrs[4] and lrs[-1] < lrs[6]
+    cfg.optimization.scheduler.interval = "step"
+    m = ConnectomicsModule(cfg, model=SimpleModel())
+    fit(m, synthetic_batches(1, (8, 8, 8)), max_steps=6, steps_per_epoch=3, device=torch.device("cpu"), log=None)
+    assert m._scheduler.last_epoch == 6
+    cfg.optimization.scheduler.interval = "hourly"
+    with pytest.raises(ValueError, match="interval"):
+        fit(ConnectomicsModule(cfg, model=SimpleModel()), synthetic_batches(1, (8, 8, 8)), max_steps=2, device=torch.device("cpu"), log=None)
+    # n_steps_per_epoch = -1 (schema default) with an endless sampler: explicit error, fast_dev_run / max_steps still work
+    cfg.optimization.n_steps_per_epoch = -1
+    with pytest.raises(ValueError, match="n_steps_per_epoch"):
+        resolve_training_steps(cfg)
+    assert resolve_training_steps(cfg, fast_dev_run=3) == (3, 3)
+    assert resolve_training_steps(cfg, dataset_steps_per_epoch=7) == (28, 7)
+
+
+def test_resume_continues_optimizer_scheduler_and_counters(tmp_path):
+    """Save at step 6 of 12, reload into a fresh module, continue: identical weights and LR trajectory to the uninterrupted
+    run (Adam moments, scheduler position, epoch / step counters all restored; lightning/model.py + trainer resume)."""
+    def make():
+        torch.manual_seed(0)
+        cfg = _cfg(max_epochs=4, n_steps_per_epoch=3)
+        return ConnectomicsModule(cfg, model=SimpleModel())
+    dev = torch.device("cpu")
+    full = make()
+    fit(full, synthetic_batches(2, (8, 8, 8), seed=5), max_steps=12, steps_per_epoch=3, device=dev, log=None)
+    half = make()
+    _, opt = fit(half, synthetic_batches(2, (8, 8, 8), seed=5), max_steps=6, steps_per_epoch=3, device=dev, log=None)
+    ck = half.checkpoint_dict(opt)
+    assert ck["epoch"] == 2 and ck["global_step"] == 6 and ck["lr_schedulers"][0]["last_epoch"] == 2
+    torch.save(ck, tmp_path / "mid.ckpt")
+    res = make()
+    res.load_checkpoint_dict(torch.load(tmp_path / "mid.ckpt", weights_only=True))       # plain tensors / numbers only
+    import itertools
+    rest = itertools.islice(synthetic_batches(2, (8, 8, 8), seed=5), 6, None)                  # the batches the full run saw next
+    hist, opt2 = fit(res, rest, max_steps=12, steps_per_epoch=3, device=dev, log=None)
+    assert len(hist) == 6 and res.global_step == 12 and res.current_epoch == 4
+    for a, b in zip(full.model.parameters(), res.model.parameters()):
+        assert torch.allclose(a, b, rtol=0, atol=1e-7)
+    assert opt2.param_groups[0]["lr"] == pytest.approx(full._scheduler.get_last_lr()[0])
+    # a resumed run without the optimizer state is a different trajectory (the moments matter)
+    cold = make()
+    ck2 = {k: v for k, v in ck.items() if k not in ("optimizer_states", "lr_schedulers")}
+    cold.load_checkpoint_dict(ck2)
+    fit(cold, itertools.islice(synthetic_batches(2, (8, 8, 8), seed=5), 6, None), max_steps=12, steps_per_epoch=3, device=dev, log=None)
+    assert not all(torch.allclose(a, b, atol=1e-7) for a, b in zip(full.model.parameters(), cold.model.parameters()))
+
+
+def test_resume_accepts_reference_optimizer_layout_and_extra_heads():
+    """The reference builds ONE param group per parameter (build.py:73-112); its optimizer_states map onto this engine's merged
+    groups by model order.  Reference MedNeXt checkpoints also carry out_1..out_4 heads with deep_supervision off."""
+    torch.manual_seed(0)
+    cfg = _cfg()
+    m = ConnectomicsModule(cfg, model=SimpleModel())
+    params = [p for p in m.model.parameters() if p.requires_grad]
+    ref_opt = torch.optim.AdamW([{"params": [p], "lr": 1e-2, "weight_decay": 0.0 if p.ndim == 1 else 0.01} for p in params])
+    for p in params:
+        p.grad = torch.randn_like(p)
+    ref_opt.step()
+    ck = {"state_dict": {"model." + k: v.clone() for k, v in m.model.state_dict().items()}, "global_step": 1, "epoch": 0,
+          "optimizer_states": [ref_opt.state_dict()]}
+    ck["state_dict"]["model.out_1.conv_out.weight"] = torch.zeros(1, 1, 1, 1, 1)              # ignored extra head
+    m2 = ConnectomicsModule(cfg, model=SimpleModel())
+    m2.load_checkpoint_dict(ck)
+    opt, sched = m2.configure_optimizers()
+    assert m2.restore_training_state(opt, sched)
+    for p_ref, p_new in zip(params, [p for p in m2.model.parameters() if p.requires_grad]):
+        assert torch.equal(ref_opt.state[p_ref]["exp_avg"], opt.state[p_new]["exp_avg"])
+        assert torch.equal(ref_opt.state[p_ref]["exp_avg_sq"], opt.state[p_new]["exp_avg_sq"])
+        assert float(opt.state[p_new]["step"]) == 1.0
