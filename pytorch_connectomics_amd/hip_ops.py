@@ -23,6 +23,12 @@ def dtype_code(dt: torch.dtype) -> int:
         raise TypeError(f"pytorch_connectomics_amd kernels support float32/bfloat16, got {dt}") from None
 
 
+def require_device(device, what: str = "this inference path") -> None:
+    """The engines call this before touching data: anything but a HIP device is an error (there is no CPU path)."""
+    if torch.device(device).type != "cuda":
+        raise RuntimeError(f"{what} (pytorch_connectomics_amd) needs a CUDA(HIP) device: there is no CPU path")
+
+
 def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError(f"{name} must be a CUDA(HIP) tensor: pytorch_connectomics_amd has no CPU path")

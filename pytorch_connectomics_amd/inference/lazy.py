@@ -30,6 +30,8 @@ from .. import hip_ops as ops
 from ..utils.channel_slices import resolve_channel_indices
 from ..utils.model_outputs import get_inference_channel_activations, get_inference_select_channel, select_output_tensor
 from .lazy_accessor import LazyVolumeAccessor, build_accessor
+from .lazy_distributed import (distributed_context, is_distributed_window_sharding_enabled, make_accumulator_reduce_hook,
+                               validate_distributed_patch_shard)
 from .window import (_axis_kernels, compute_scan_interval, resolve_border_mask,
                      resolve_inferer_overlap, resolve_inferer_roi_size, resolve_model_output_dtype)
 
@@ -181,9 +183,7 @@ def _lazy_sliding_window(cfg, forward_fn, volume, *, region_start, region_stop, 
     if len(roi) != 3:
         raise ValueError(f"Lazy sliding-window inference currently supports 3D only, got {roi}.")
     dev = torch.device(device)
-    if dev.type != "cuda":
-        raise RuntimeError("lazy sliding-window inference (pytorch_connectomics_amd) needs a CUDA(HIP) device: "
-                           "there is no CPU path")
+    ops.require_device(dev, "lazy sliding-window inference")
     overlap = _coerce_overlap(resolve_inferer_overlap(cfg, roi), 3)
     sw = getattr(getattr(cfg, "inference", None), "sliding_window", None)
     dl = getattr(getattr(cfg, "data", None), "dataloader", None)
@@ -213,10 +213,13 @@ def _lazy_sliding_window(cfg, forward_fn, volume, *, region_start, region_stop, 
 
     wins = [tuple(int(s.start) for s in sl) for sl in _build_intersecting_window_slices(
         bounds, roi, overlap, region_start=start, region_stop=stop, snap_to_edge=snap)]
-    if window_filter is not None:
-        wins = [w for i, w in enumerate(wins) if window_filter(i, len(wins))]
     if not wins:
         raise RuntimeError("No lazy sliding-window patches were generated for this region.")
+    if window_filter is not None:
+        total = len(wins)
+        wins = [w for i, w in enumerate(wins) if window_filter(i, total)]
+        # an empty shard on ANY rank fails on EVERY rank before anything is read or reduced (lazy_distributed.py:110-129)
+        validate_distributed_patch_shard(local_count=len(wins), total_count=total, device=dev)
 
     # bring the bounding box of everything the windows read (incl. context) into HBM once
     read = tuple(int(roi[a]) + 2 * ctx[a] for a in range(3))
@@ -310,23 +313,29 @@ def lazy_predict_region(cfg, forward_fn, volume, *, region_start: Sequence[int],
 
 
 def lazy_predict_volume(cfg, forward_fn, volume, *, device="cuda", requested_head: Optional[str] = None) -> torch.Tensor:
-    """Whole-volume variant.  With inference.sliding_window.distributed_sharding and an initialised process
-    group, windows are sharded [rank::world] and value / weight accumulators are summed onto rank 0 with one
-    RCCL reduce each (reference lazy.py:1104-1110, lazy_distributed.py:78-107); other ranks get an empty tensor."""
-    sw = getattr(getattr(cfg, "inference", None), "sliding_window", None)
-    dist_on = (bool(getattr(sw, "distributed_sharding", False)) and torch.distributed.is_available()
-               and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1)
-    if not dist_on:
+    """Whole-volume variant.  With inference.sliding_window.distributed_sharding, a lazy data path and an initialised
+    process group (lazy_distributed.is_distributed_window_sharding_enabled), the windows are sharded [rank::world]
+    (reference lazy.py:1104-1110), every rank's shard is validated non-empty, and the HBM-resident value / weight
+    accumulators are summed onto rank 0 in place, `distributed_reduce_chunk_mb` per collective
+    (lazy_distributed.py:78-169); rank 0 normalises, the other ranks get an empty tensor.  TTA-view sharding cannot be
+    combined with it (lazy.py:1039-1043)."""
+    if not is_distributed_window_sharding_enabled(cfg):
         return _lazy_sliding_window(cfg, forward_fn, volume, region_start=None, region_stop=None, device=device,
                                     requested_head=requested_head)
-    rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+    tta = getattr(getattr(cfg, "inference", None), "test_time_augmentation", None)
+    if tta is not None and getattr(tta, "enabled", False) and getattr(tta, "distributed_sharding", False):
+        raise RuntimeError("Lazy sliding-window inference does not support "
+                           "`inference.test_time_augmentation.distributed_sharding`. Disable it first.")
+    sw = cfg.inference.sliding_window
+    _is_dist, rank, world = distributed_context()
     value, weight = _lazy_sliding_window(cfg, forward_fn, volume, region_start=None, region_stop=None, device=device,
                                          requested_head=requested_head, return_accumulators=True,
                                          window_filter=lambda i, n: i % world == rank)
-    torch.distributed.reduce(value, dst=0, op=torch.distributed.ReduceOp.SUM)
-    torch.distributed.reduce(weight, dst=0, op=torch.distributed.ReduceOp.SUM)
-    if rank != 0:
+    hook = make_accumulator_reduce_hook(chunk_mb=int(getattr(sw, "distributed_reduce_chunk_mb", 128) or 128))
+    reduced = hook(value, weight)
+    if reduced is None:
         return torch.empty(0, device=value.device)
+    value, weight = reduced
     ops.blend_finalize(value, weight, clamp=1e-4, act=nat.ACT_NONE)
     out = value.unsqueeze(0)
     odt = resolve_model_output_dtype(cfg)

@@ -22,6 +22,7 @@ from .. import hip_ops as ops
 from ..utils.channel_slices import resolve_channel_indices
 from ..utils.model_outputs import (get_inference_channel_activations, get_inference_select_channel,
                                    select_output_tensor)
+from .lazy_distributed import reduce_view_ensemble, validate_view_shards
 from .tta_combinations import (_resolve_ensemble_mode_map, _resolve_spatial_dims, apply_view,
                                resolve_tta_augmentation_combinations)
 from .window import is_2d_inference_mode, resolve_model_output_dtype
@@ -200,6 +201,25 @@ class TTAPredictor:
             return result
         return result * mask
 
+    # ------------------------------------------------------------------ view sharding
+    def _reduce_views(self, acc, n_local, total, modes, *, skip=(), stats=None, counts=None, partial_modes=()):
+        """Per-rank ensembles -> rank 0 (tta.py:1341-1519), in place in HBM; None on the other ranks."""
+        tta = self._get_tta_cfg()
+        return_value = reduce_view_ensemble(acc.contiguous(), n_local, total, modes,
+                                            chunk_mb=int(getattr(tta, "distributed_reduce_chunk_mb", 128) or 128),
+                                            skip_channels=skip, stats=stats, counts=counts, partial_modes=partial_modes)
+        if return_value is None:
+            return None
+        return return_value[0] if stats is None else return_value
+
+    def _finish(self, result, mask, mask_align_to_image):
+        """Mask + return on the rank that holds the ensemble; the contributing ranks of a sharded run return an empty
+        tensor and skip post-processing (tta.py:868-873)."""
+        if result is None:
+            self._last_skip_postprocess_on_rank = True
+            return torch.empty(0, device=self._last_device)
+        return self._apply_mask_to_result(result, mask, mask_align_to_image)
+
     # ------------------------------------------------------------------ predict
     def _normalize_input(self, images: torch.Tensor) -> torch.Tensor:
         if images.ndim == 3:
@@ -228,9 +248,7 @@ class TTAPredictor:
         self._requested_output_head_override = requested_head
         try:
             images = self._normalize_input(images)
-            if not images.is_cuda:
-                raise RuntimeError("TTAPredictor (pytorch_connectomics_amd) needs a CUDA(HIP) tensor: "
-                                   "there is no CPU path")
+            ops.require_device(images.device, "TTAPredictor")
             if images.shape[0] != 1:
                 raise ValueError(f"device inference expects batch size 1; got batch {images.shape[0]}.")
             self._last_distributed_sharding_active = False
@@ -244,6 +262,7 @@ class TTAPredictor:
                 combos = resolve_tta_augmentation_combinations(tta, spatial_dims=_resolve_spatial_dims(images.dim()))
             vol = images[0].to(torch.float32).contiguous()
             orig = tuple(int(v) for v in vol.shape[1:])
+            self._last_device = vol.device
 
             def one_view(code, weight):
                 value, weight = engine.accumulate(vol, network, view=code, weight=weight, add_weight=weight is None)
@@ -257,10 +276,15 @@ class TTAPredictor:
                 result, _ = one_view(0, None)
                 return self._apply_mask_to_result(result, mask, mask_align_to_image)
 
+            # view sharding (tta.py:771-792): this rank runs views [rank::world]; the per-rank ensembles meet on rank 0
+            sharded = self.is_distributed_sharding_enabled()
+            self._last_distributed_sharding_active = sharded
+            local = validate_view_shards(len(combos))[2] if sharded else list(range(len(combos)))
             if not bool(getattr(tta, "patch_first_local", False)) and self.sliding_inferer is not None:
                 # reference predict() :1652-1660: without patch-first-local every view is a whole-volume pass
-                result = self._predict_whole_volume_views(vol, engine, network, combos, getattr(tta, "ensemble_mode", "mean"))
-                return self._apply_mask_to_result(result, mask, mask_align_to_image)
+                result = self._predict_whole_volume_views(vol, engine, network, combos, getattr(tta, "ensemble_mode", "mean"),
+                                                          local, sharded)
+                return self._finish(result, mask, mask_align_to_image)
             for _f, pl, k in combos:   # same restriction (and message) as the reference, tta.py:1316-1340
                 if pl is not None and k % 2:
                     img = tuple(int(v) for v in images.shape[2:])
@@ -275,12 +299,12 @@ class TTAPredictor:
             ensemble_mode = getattr(tta, "ensemble_mode", "mean")
             from .tta_affinity import resolve_affinity_channel_groups_from_cfg
             if resolve_affinity_channel_groups_from_cfg(self.cfg):
-                result = self._predict_affinity_views(vol, orig, engine, network, combos, codes, ensemble_mode)
-                return self._apply_mask_to_result(result, mask, mask_align_to_image)
+                result = self._predict_affinity_views(vol, orig, engine, network, combos, codes, ensemble_mode, local, sharded)
+                return self._finish(result, mask, mask_align_to_image)
             acc = None
             weight = None
-            for i, code in enumerate(codes):
-                pred, weight = one_view(code, weight)
+            for n, i in enumerate(local):
+                pred, weight = one_view(codes[i], weight)
                 pred32 = pred if pred.dtype == torch.float32 else pred.float()
                 if acc is None:
                     modes = _resolve_ensemble_mode_map(ensemble_mode, int(pred32.shape[1]))
@@ -290,14 +314,16 @@ class TTAPredictor:
                     acc = pred32.clone()
                     continue
                 for c, mode in enumerate(modes):   # contiguous per-channel slabs of the (1,C,Z,Y,X) volume
-                    ops.ensemble_update(acc[0, c], pred32[0, c].contiguous(), _MODE_CODE[mode], i + 1)
-            result = acc.to(resolve_model_output_dtype(self.cfg))
-            return self._apply_mask_to_result(result, mask, mask_align_to_image)
+                    ops.ensemble_update(acc[0, c], pred32[0, c].contiguous(), _MODE_CODE[mode], n + 1)
+            if sharded:
+                acc = self._reduce_views(acc, len(local), len(combos), modes)
+            result = None if acc is None else acc.to(resolve_model_output_dtype(self.cfg))
+            return self._finish(result, mask, mask_align_to_image)
         finally:
             self._requested_output_head_override = prev
 
 
-def _predict_whole_volume_views(self, vol, engine, network, combos, ensemble_mode):
+def _predict_whole_volume_views(self, vol, engine, network, combos, ensemble_mode, local=None, sharded=False):
     """`patch_first_local: false` (reference _predict_prepared_tensor :806-878 + _run_ensemble :691-769): each view flips /
     rotates the WHOLE volume, runs its own sliding-window pass over the augmented geometry (its own window grid and weight
     map, so non-square rotations are fine), and the blended prediction is rotated / flipped back before activation and
@@ -308,7 +334,8 @@ def _predict_whole_volume_views(self, vol, engine, network, combos, ensemble_mod
                                   "use patch_first_local: true (the reference default)")
     acc = modes = None
     weights = {}
-    for i, (flips, pl, k) in enumerate(combos):
+    local = list(range(len(combos))) if local is None else local
+    for n, (flips, pl, k) in enumerate(combos[i] for i in local):
         x = vol
         if flips:
             x = torch.flip(x, dims=[int(a) + 1 for a in flips])
@@ -336,11 +363,13 @@ def _predict_whole_volume_views(self, vol, engine, network, combos, ensemble_mod
             acc = pred32.clone()
             continue
         for c, mode in enumerate(modes):
-            ops.ensemble_update(acc[0, c], pred32[0, c].contiguous(), _MODE_CODE[mode], i + 1)
-    return acc.to(resolve_model_output_dtype(self.cfg))
+            ops.ensemble_update(acc[0, c], pred32[0, c].contiguous(), _MODE_CODE[mode], n + 1)
+    if sharded:
+        acc = self._reduce_views(acc, len(local), len(combos), modes)
+    return None if acc is None else acc.to(resolve_model_output_dtype(self.cfg))
 
 
-def _predict_affinity_views(self, vol, orig, engine, network, combos, codes, ensemble_mode):
+def _predict_affinity_views(self, vol, orig, engine, network, combos, codes, ensemble_mode, local=None, sharded=False):
     """Directional-affinity outputs (reference tta.py:1036-1275 + tta_affinity.py + tta_ensemble.py): every view is
     blended with its channel map (channels re-anchored inside each window by the blending kernel), fully valid
     channels are normalised by the shared weight and ensembled as usual, shifted ("partial") channels by the weight of
@@ -353,7 +382,9 @@ def _predict_affinity_views(self, vol, orig, engine, network, combos, codes, ens
     w_shift = {}
     stats = counts = None
     modes = sel = partial_sel = None
-    for i, (code, combo) in enumerate(zip(codes, combos)):
+    local = list(range(len(combos))) if local is None else local
+    for n, i in enumerate(local):
+        code = codes[i]
         if plan is None:
             # the plan needs the raw channel count: probe one window of the identity view
             probe = engine._run_network(network, ops.gather_windows(vol, engine.plan(orig)[1][:1], engine.roi_size,
@@ -403,12 +434,22 @@ def _predict_affinity_views(self, vol, orig, engine, network, combos, codes, ens
         else:
             for j, mode in enumerate(modes):
                 if j not in partial_sel:
-                    ops.ensemble_update(acc[0, j], pred[0, j].contiguous(), _MODE_CODE[mode], i + 1)
+                    ops.ensemble_update(acc[0, j], pred[0, j].contiguous(), _MODE_CODE[mode], n + 1)
         for pi, j in enumerate(partial_sel):
             cov = covers[sel[j]]
             if cov is not None and crop:
                 cov = cov[:orig[0], :orig[1], :orig[2]].contiguous()
             ops.ensemble_update_masked(stats[pi], counts[pi], pred[0, j].contiguous(), cov, _MODE_CODE[modes[j]])
+    if sharded:
+        red = self._reduce_views(acc, len(local), len(combos), modes, skip=partial_sel, stats=stats, counts=counts,
+                                 partial_modes=[modes[j] for j in partial_sel]) if partial_sel else \
+            self._reduce_views(acc, len(local), len(combos), modes)
+        if red is None:
+            return None
+        if partial_sel:
+            acc, stats, counts = red
+        else:
+            acc = red
     for pi, j in enumerate(partial_sel or []):
         if bool((counts[pi] == 0).any()):
             first = tuple(int(v) for v in torch.nonzero(counts[pi] == 0)[0])
