@@ -155,6 +155,25 @@ int pytc_h5_dset_info(int64_t ds, int* ndim, int64_t* dims, int* dtype, int64_t*
   return 0;
 }
 
+/* first compression filter of the dataset's pipeline: H5Z id (0 = none, 1 = deflate, 4 = szip, 32000 = lzf) and, for
+ * deflate, its level in *level (-1 otherwise) -- what h5py reports as Dataset.compression / compression_opts */
+int pytc_h5_dset_filter(int64_t ds, int* level) {
+  hid_t pl = H5Dget_create_plist((hid_t)ds);
+  int n = H5Pget_nfilters(pl), found = 0;
+  *level = -1;
+  for (int i = 0; i < n && !found; ++i) {
+    unsigned flags = 0, cd[8] = {0}, cfg = 0;
+    size_t ncd = 8;
+    char nm[32];
+    H5Z_filter_t id = H5Pget_filter2(pl, (unsigned)i, &flags, &ncd, cd, sizeof(nm), nm, &cfg);
+    if (id == H5Z_FILTER_DEFLATE) { found = 1; *level = ncd > 0 ? (int)cd[0] : -1; }
+    else if (id == H5Z_FILTER_SZIP) found = 4;
+    else if (id == 32000) found = 32000;
+  }
+  H5Pclose(pl);
+  return found;
+}
+
 /* hyperslab IO: start/count per axis, memory buffer contiguous in the dataset's own dtype (mem_dtype converts on the fly) */
 static int slab_io(int64_t ds, int ndim, const int64_t* start, const int64_t* count, void* buf, int mem_dtype, int write) {
   hsize_t s[8], c[8];

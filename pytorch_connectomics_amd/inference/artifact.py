@@ -16,6 +16,7 @@ from typing import Any, Callable, Mapping, Optional, Sequence, Tuple
 import numpy as np
 
 from ..utils.h5lite import get_h5_backend
+from ..utils.model_outputs import get_inference_select_channel
 
 h5py = get_h5_backend()                # h5py, or the in-repo h5lite over libhdf5, or None
 
@@ -62,7 +63,22 @@ def _tuple_or_none(value: Optional[Sequence[Any]]):
 def build_prediction_artifact_metadata(cfg: Any, *, image_path=None, checkpoint_path=None, output_head=None,
                                        input_shape=None, final_shape=None, crop_pad=None, chunk_shape=None, halo=None,
                                        intensity_scale=None, intensity_dtype=None, extra=None) -> PredictionArtifactMetadata:
-    """artifact.py:78-121."""
+    """artifact.py:78-121: intensity scale / dtype default to the enabled prediction transform's; the output identity
+    string is `head=<h>` (or `primary_head=<p>`) + `select_channel=<sel>` joined by ';' (artifact.py:55-71)."""
+    tc = _cfg_get(cfg, "inference.prediction_transform")
+    if bool(getattr(tc, "enabled", False)):
+        if intensity_scale is None:
+            intensity_scale = float(getattr(tc, "intensity_scale", -1.0))
+        if intensity_dtype is None:
+            intensity_dtype = getattr(tc, "intensity_dtype", None)
+    ident = []
+    if output_head:
+        ident.append(f"head={output_head}")
+    elif _cfg_get(cfg, "model.primary_head"):
+        ident.append(f"primary_head={_cfg_get(cfg, 'model.primary_head')}")
+    sel = get_inference_select_channel(cfg)
+    if sel is not None:
+        ident.append(f"select_channel={sel}")
     return PredictionArtifactMetadata(
         image_path=None if image_path is None else str(image_path),
         checkpoint_path=None if checkpoint_path is None else str(checkpoint_path),
@@ -70,7 +86,7 @@ def build_prediction_artifact_metadata(cfg: Any, *, image_path=None, checkpoint_
         crop_pad=tuple((int(p[0]), int(p[1])) for p in crop_pad) if crop_pad is not None else None,
         transpose=_tuple_or_none(_cfg_get(cfg, "data.data_transform.val_transpose")),
         model_architecture=_cfg_get(cfg, "model.arch.type"),
-        model_output_identity=output_head,
+        model_output_identity=";".join(ident) if ident else None,
         decode_after_inference=bool(_cfg_get(cfg, "decoding.enabled", True)),
         chunk_shape=_tuple_or_none(chunk_shape), halo=_tuple_or_none(halo),
         intensity_scale=intensity_scale, intensity_dtype=intensity_dtype, extra=extra or {})

@@ -4,7 +4,7 @@
                                             [--fast-dev-run] [key.sub=value ...]
 
 test : build_model(cfg) -> load checkpoint -> volume to HBM -> InferenceManager.predict_with_tta (or chunked
-       inference when inference.chunking.enabled) -> optional binary Jaccard -> <save_path>/results/*_prediction.npy
+       inference when inference.chunking.enabled) -> optional binary Jaccard -> <save_path>/results/*_prediction.h5 (the CZYX raw-prediction artifact)
 train: training/module.py's Lightning-free harness (HIP forward + backward, fused loss, fused clip + AdamW), one process
        per GPU under torch.distributed.run (DDP over RCCL); writes checkpoints/last.ckpt in the Lightning layout.
 Volumes: .npy / .npz (first array) / random://<name>[?shape=Z,Y,X] / .h5 (dataset `main`; h5py or the in-repo libhdf5 shim).
@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import argparse
 import json
+from types import SimpleNamespace as NS
 import logging
 import os
 import sys
@@ -147,27 +148,21 @@ def run_test(cfg, args) -> dict:
             while x.dim() < 5:
                 x = x.unsqueeze(0)
             mgr = InferenceManager(cfg=cfg, model=model, forward_fn=model.forward)
-            pred_t = mgr.predict_with_tta(x)
             # prediction-space crop: user crop_pad + DeepEM affinity border (test_pipeline.py:734, prediction_crops.py:240-256)
             from .inference.crop import crop_spatial_by_pad, resolve_global_prediction_crop
+            from .inference.stage import run_prediction_inference
             crop_pad = resolve_global_prediction_crop(cfg)
-            if any(lo or hi for lo, hi in crop_pad):
+            cropping = any(lo or hi for lo, hi in crop_pad)
+            art = out_dir / f"{name}_prediction.h5"
+            # predict; with no crop the stage writes the artifact itself (transform + storage dtype on the device, one D2H
+            # copy of the stored representation); with a crop the stage is re-entered on the cropped prediction
+            pred_t = run_prediction_inference(mgr, x, output_path=None if cropping else art, image_path=str(image_spec),
+                                              checkpoint_path=args.checkpoint, input_shape=vol.shape[-3:], crop_pad=crop_pad)
+            if cropping:
                 pred_t = crop_spatial_by_pad(pred_t, crop_pad, item_name="prediction").contiguous()
-            # semantic transform -> storage dtype on the device, then one D2H copy of the (smaller) result
-            from .inference.artifact import build_prediction_artifact_metadata, write_prediction_artifact
-            from .inference.output import apply_prediction_transform, apply_storage_dtype_transform
-            pred_t = apply_prediction_transform(cfg, pred_t)
-            stored = apply_storage_dtype_transform(cfg, pred_t)
-            torch.cuda.synchronize()
-            arr = stored[0].cpu().numpy() if isinstance(stored, torch.Tensor) else np.asarray(stored)[0]
-            np.save(out_dir / f"{name}_prediction.npy", arr)
-            tc = getattr(cfg.inference, "prediction_transform", None)
-            md = build_prediction_artifact_metadata(
-                cfg, image_path=image_spec, checkpoint_path=args.checkpoint, input_shape=vol.shape[-3:],
-                final_shape=arr.shape[-3:], crop_pad=crop_pad, intensity_scale=getattr(tc, "intensity_scale", None) if tc else None,
-                intensity_dtype=str(arr.dtype))
-            write_prediction_artifact(out_dir / f"{name}_prediction.h5", arr, metadata=md)
-            pred_t = pred_t if isinstance(pred_t, torch.Tensor) else torch.from_numpy(np.asarray(pred_t))
+                held = NS(cfg=cfg, predict_with_tta=lambda *_a, **_k: pred_t)
+                run_prediction_inference(held, x, output_path=art, image_path=str(image_spec), checkpoint_path=args.checkpoint,
+                                         input_shape=vol.shape[-3:], crop_pad=crop_pad)
     dt = time.perf_counter() - t0
     out_vox = float(np.prod(vol.shape[-3:])) if vol is not None else (float(np.prod(pred_t.shape[-3:])) if pred_t is not None else 0.0)
     metrics = {"seconds": dt, "output_voxels_per_s": out_vox / dt}
@@ -202,6 +197,8 @@ def run_train(cfg, args) -> dict:
     bs = int(cfg.data.dataloader.batch_size)
     from .training.module import resolve_training_steps
     steps, per_epoch = resolve_training_steps(cfg, fast_dev_run=int(args.fast_dev_run or 0))
+    if args.fast_dev_run and args.checkpoint:
+        steps += int(module.global_step)          # --fast-dev-run N on a resumed run = N MORE steps (Lightning runs N batches)
     img_spec = cfg.data.train.image
     if img_spec is None or str(img_spec).startswith("random://") or args.demo:
         batches = synthetic_batches(bs, patch, in_channels=cfg.model.in_channels, out_channels=cfg.model.out_channels,
@@ -227,8 +224,8 @@ def run_train(cfg, args) -> dict:
         raise RuntimeError(f"nothing to train: the checkpoint is already at step {module.global_step} of {steps}")
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    out = {"steps": steps, "first_loss": history[0], "last_loss": history[-1],
-           "voxels_per_s": world * steps * bs * float(np.prod(patch)) / dt}
+    out = {"steps": len(history), "global_step": int(module.global_step), "first_loss": history[0], "last_loss": history[-1],
+           "voxels_per_s": world * len(history) * bs * float(np.prod(patch)) / dt}
     if rank == 0:
         ck_dir = Path(cfg.save_path) / "checkpoints"
         ck_dir.mkdir(parents=True, exist_ok=True)

@@ -210,8 +210,9 @@ class FusedAdamW(torch.optim.Optimizer):
             if "_t" in st:
                 st["step"] = torch.tensor(float(st["_t"]))
         sd = super().state_dict()
-        for st in sd["state"].values():          # `_t` is this optimizer's host-side counter, `step` the interchange field
-            st.pop("_t", None)
+        # `_t` is this optimizer's host-side counter, `step` the interchange field.  Optimizer.state_dict() hands out the LIVE
+        # per-parameter dicts, so the counter is dropped from copies, never from the optimizer's own state
+        sd["state"] = {k: {kk: vv for kk, vv in st.items() if kk != "_t"} for k, st in sd["state"].items()}
         return sd
 
     def load_state_dict(self, state_dict):

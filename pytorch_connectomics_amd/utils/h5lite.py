@@ -67,6 +67,7 @@ def _load():
         "pytc_h5_dset_open": (i64, [i64, C.c_char_p]),
         "pytc_h5_dset_close": (C.c_int, [i64]),
         "pytc_h5_dset_info": (C.c_int, [i64, C.POINTER(C.c_int), p64, C.POINTER(C.c_int), p64, C.POINTER(C.c_int)]),
+        "pytc_h5_dset_filter": (C.c_int, [i64, C.POINTER(C.c_int)]),
         "pytc_h5_dset_write": (C.c_int, [i64, C.c_int, p64, p64, C.c_void_p, C.c_int]),
         "pytc_h5_dset_read": (C.c_int, [i64, C.c_int, p64, p64, C.c_void_p, C.c_int]),
         "pytc_h5_attr_write": (C.c_int, [i64, C.c_char_p, C.c_int, C.c_char_p, i64, C.c_double]),
@@ -203,6 +204,10 @@ class Dataset:
         self.shape = tuple(int(dims[i]) for i in range(nd.value))
         self.dtype = _DTYPE_OF[dt.value]
         self.chunks = tuple(int(chunks[i]) for i in range(nd.value)) if hc.value else None
+        lvl = C.c_int(-1)
+        fid = lib.pytc_h5_dset_filter(ds_id, C.byref(lvl))
+        self.compression = {0: None, 1: "gzip", 4: "szip", 32000: "lzf"}.get(int(fid))       # h5py's names
+        self.compression_opts = int(lvl.value) if fid == 1 else None
         self.attrs = AttributeManager(self)
 
     ndim = property(lambda self: len(self.shape))

@@ -300,7 +300,11 @@ test:
     m = main(["--config", str(cfg), "--mode", "test", "--checkpoint", str(ck)])
     assert m["output_voxels_per_s"] > 0
     out2 = main(["--config", str(cfg), "--mode", "train", "--checkpoint", str(ck), "--fast-dev-run", "2"])
-    assert out2["steps"] == 2
+    assert out2["steps"] == 2 and out2["global_step"] == 22          # a true resume: two MORE steps from step 20
+    blob2 = torch.load(ck, weights_only=True)                          # the engine's checkpoints are plain tensors / numbers
+    assert blob2["global_step"] == 22 and blob2["epoch"] == 1 and "lr_schedulers" in blob2
+    st = blob2["optimizer_states"][0]["state"]
+    assert all(float(v["step"]) == 22.0 for v in st.values() if "step" in v)   # Adam moments continued, not restarted
 
 
 def test_ddp_over_rccl_single_rank_matches_plain_training():

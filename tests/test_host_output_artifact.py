@@ -5,6 +5,7 @@ from types import SimpleNamespace as NS
 
 import numpy as np
 import pytest
+import torch
 
 from pytorch_connectomics_amd.inference.artifact import (PredictionArtifactMetadata, artifact_attrs,
                                                          build_prediction_artifact_metadata, read_prediction_artifact,
@@ -80,3 +81,76 @@ def test_transforms_match_reference_fixture():
         got = apply_storage_dtype_transform(_cfg(save_dtype=dt), data.copy() * 100.0)
         assert got.dtype == z["sd__" + dt].dtype and np.array_equal(got, z["sd__" + dt]), dt
     assert np.array_equal(apply_prediction_transform(_cfg(prediction_transform=NS(enabled=False)), data.copy()), z["pt__disabled"])
+
+
+class _HeldManager:
+    """reference tests/unit/test_inference_stage.py:13-33: a manager that returns a fixed prediction and records the call."""
+
+    def __init__(self, cfg, prediction):
+        self.cfg, self.prediction, self.observed = cfg, prediction, {}
+
+    def predict_with_tta(self, images, *, mask=None, mask_align_to_image=False, requested_head=None):
+        self.observed = {"images_shape": tuple(images.shape), "mask": mask, "mask_align_to_image": mask_align_to_image,
+                         "requested_head": requested_head}
+        return self.prediction
+
+
+def test_run_prediction_inference_writes_raw_artifact_metadata(tmp_path):
+    """reference tests/unit/test_inference_stage.py:36-71, same inputs and expectations (HDF5 read back through the same
+    backend the reference's decoders would use)."""
+    import json
+    from pytorch_connectomics_amd.config import ConfigNode, schema_defaults
+    from pytorch_connectomics_amd.inference import run_prediction_inference
+    from pytorch_connectomics_amd.utils.h5lite import get_h5_backend
+    h5 = get_h5_backend()
+    if h5 is None:
+        pytest.skip("no HDF5 backend")
+    cfg = ConfigNode(schema_defaults())
+    cfg.model.arch.type = "mednext"
+    cfg.data.data_transform.val_transpose = [2, 1, 0]
+    cfg.inference.save_dtype = "float16"
+    cfg.inference.model.select_channel = [0, 1]
+    prediction = torch.arange(1 * 2 * 3 * 4 * 5, dtype=torch.float32).reshape(1, 2, 3, 4, 5)
+    manager = _HeldManager(cfg, prediction)
+    out = tmp_path / "raw_prediction.h5"
+    returned = run_prediction_inference(manager, torch.zeros(1, 1, 3, 4, 5), requested_head="affinity", output_path=out,
+                                        image_path="input.h5", checkpoint_path="checkpoint.ckpt", input_shape=(3, 4, 5))
+    assert returned is prediction and manager.observed["requested_head"] == "affinity"
+    with h5.File(out, "r") as handle:
+        d = handle["main"]
+        assert tuple(d.shape) == (2, 3, 4, 5) and np.dtype(d.dtype) == np.dtype("float16")
+        assert d.attrs["image_path"] == "input.h5" and d.attrs["checkpoint_path"] == "checkpoint.ckpt"
+        assert d.attrs["output_head"] == "affinity" and d.attrs["model_architecture"] == "mednext"
+        assert d.attrs["model_output_identity"] == "head=affinity;select_channel=[0, 1]"
+        assert bool(d.attrs["decode_after_inference"]) is True
+        assert json.loads(d.attrs["transpose"]) == [2, 1, 0] and json.loads(d.attrs["final_shape"]) == [3, 4, 5]
+        assert np.array_equal(d[...], prediction[0].numpy().astype(np.float16))
+    # no output path: prediction only; batch > 1 cannot become one artifact; a contributing rank of a sharded run writes nothing
+    assert run_prediction_inference(manager, torch.zeros(1, 1, 3, 4, 5)) is prediction
+    with pytest.raises(ValueError, match="one artifact per call"):
+        run_prediction_inference(_HeldManager(cfg, torch.zeros(2, 1, 3, 4, 5)), torch.zeros(2, 1, 3, 4, 5), output_path=tmp_path / "b.h5")
+    skipper = _HeldManager(cfg, torch.empty(0))
+    skipper.should_skip_postprocess_on_rank = lambda: True
+    assert run_prediction_inference(skipper, torch.zeros(1, 1, 3, 4, 5), output_path=tmp_path / "none.h5").numel() == 0
+    assert not (tmp_path / "none.h5").exists()
+
+
+def test_run_prediction_inference_honors_save_compression(tmp_path):
+    """reference test_inference_stage.py:74-99: inference.save_compression reaches the HDF5 writer."""
+    from pytorch_connectomics_amd.config import ConfigNode, schema_defaults
+    from pytorch_connectomics_amd.inference import run_prediction_inference
+    from pytorch_connectomics_amd.utils.h5lite import get_h5_backend
+    h5 = get_h5_backend()
+    if h5 is None:
+        pytest.skip("no HDF5 backend")
+    cfg = ConfigNode(schema_defaults())
+    cfg.model.arch.type = "mednext"
+    prediction = torch.arange(60, dtype=torch.float32).reshape(1, 1, 3, 4, 5)
+    for comp, want in (("gzip", "gzip"), ("none", None)):
+        cfg.inference.save_compression = comp
+        out = tmp_path / f"raw_{comp}.h5"
+        run_prediction_inference(_HeldManager(cfg, prediction), torch.zeros(1, 1, 3, 4, 5), output_path=out, image_path="input.h5",
+                                 checkpoint_path="checkpoint.ckpt", input_shape=(3, 4, 5))
+        with h5.File(out, "r") as handle:
+            assert handle["main"].compression == want
+            assert np.array_equal(handle["main"][...], prediction[0].numpy())
