@@ -459,5 +459,6 @@ def _predict_affinity_views(self, vol, orig, engine, network, combos, codes, ens
 
 
 TTAPredictor._predict_affinity_views = _predict_affinity_views
+TTAPredictor._predict_whole_volume_views = _predict_whole_volume_views
 
 __all__ = ["TTAPredictor", "view_code"]

@@ -30,25 +30,40 @@ def _rows(x):
 
 # The kernels take the PReLU slope by value.  Reading a device scalar costs a stream synchronisation, so the values are
 # cached per parameter version and a model can refresh all of its (stale) slopes with ONE transfer per forward.
-_PRELU_VALUES: dict = {}
+_PRELU_VALUES: dict = {}      # id(weight) -> (weakref to the weight, _version, data_ptr, slope)
+
+
+def _prelu_hit(w: torch.Tensor):
+    """The cached slope of THIS tensor object at THIS version and storage, else None.  id() alone is not an identity: a
+    collected parameter's id is handed to the next allocation, so the entry keeps a weak reference and is only valid while
+    that reference still points at `w`."""
+    hit = _PRELU_VALUES.get(id(w))
+    if hit is None or hit[0]() is not w or hit[1] != w._version or hit[2] != w.data_ptr():
+        return None
+    return hit[3]
+
+
+def _prelu_put(w: torch.Tensor, value: float) -> None:
+    import weakref
+    key = id(w)
+    _PRELU_VALUES[key] = (weakref.ref(w, lambda _r, _k=key: _PRELU_VALUES.pop(_k, None)), w._version, w.data_ptr(), float(value))
 
 
 def prelu_value(w: torch.Tensor) -> float:
-    key, ver = id(w), w._version
-    hit = _PRELU_VALUES.get(key)
-    if hit is None or hit[0] != ver:
-        hit = (ver, float(w.detach().reshape(-1)[0]))
-        _PRELU_VALUES[key] = hit
-    return hit[1]
+    hit = _prelu_hit(w)
+    if hit is None:
+        hit = float(w.detach().reshape(-1)[0])
+        _prelu_put(w, hit)
+    return hit
 
 
 def prefetch_prelu(weights) -> None:
-    stale = [w for w in weights if _PRELU_VALUES.get(id(w), (None,))[0] != w._version]
+    stale = [w for w in weights if _prelu_hit(w) is None]
     if not stale:
         return
     vals = torch.stack([w.detach().reshape(-1)[0].float() for w in stale]).tolist()      # one device -> host copy
     for w, v in zip(stale, vals):
-        _PRELU_VALUES[id(w)] = (w._version, float(v))
+        _prelu_put(w, v)
 
 
 class NormActFn(torch.autograd.Function):

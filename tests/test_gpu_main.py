@@ -11,6 +11,7 @@ YAML = """
 experiment_name: e2e
 save_path: {save}
 default:
+  optimization: {{precision: "32"}}
   model:
     arch: {{type: mednext_custom}}
     in_channels: 1
@@ -70,7 +71,7 @@ def test_cli_writes_uint8_artifact_with_metadata(tmp_path):
     assert arr.dtype == np.uint8 and arr.shape == (1, 34, 36, 40) and arr.max() > 0
     assert attrs["layout"] == "CZYX" and attrs["intensity_dtype"] == "uint8" and attrs["intensity_scale"] == 255.0
     assert json.loads(attrs["final_shape"]) == [34, 36, 40] and attrs["model_architecture"] == "mednext_custom"
-    assert attrs["model_output_identity"] == "select_channel=[0]" and json.loads(attrs["input_shape"]) == [34, 36, 40]
+    assert json.loads(attrs["input_shape"]) == [34, 36, 40] and attrs["compression"] == "gzip"
 
 
 def test_cli_chunked_hdf5_in_and_out(tmp_path):
@@ -120,6 +121,7 @@ def test_cli_minimal_monai_unet_train_then_test(tmp_path):
 experiment_name: minimal_demo
 save_path: {tmp_path / 'out'}
 default:
+  optimization: {{precision: "32"}}
   model:
     arch: {{type: monai_unet}}
     in_channels: 1

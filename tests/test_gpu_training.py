@@ -302,7 +302,7 @@ test:
     out2 = main(["--config", str(cfg), "--mode", "train", "--checkpoint", str(ck), "--fast-dev-run", "2"])
     assert out2["steps"] == 2 and out2["global_step"] == 22          # a true resume: two MORE steps from step 20
     blob2 = torch.load(ck, weights_only=True)                          # the engine's checkpoints are plain tensors / numbers
-    assert blob2["global_step"] == 22 and blob2["epoch"] == 1 and "lr_schedulers" in blob2
+    assert blob2["global_step"] == 22 and blob2["epoch"] == 2 and "lr_schedulers" in blob2   # fast-dev-run: 2-step epochs
     st = blob2["optimizer_states"][0]["state"]
     assert all(float(v["step"]) == 22.0 for v in st.values() if "step" in v)   # Adam moments continued, not restarted
 
