@@ -251,11 +251,19 @@ typedef struct {
   int C_in, C_hid, C_out;
   int res_mode;
   int Di, Hi, Wi;         /* RES_UPSAMPLE: output grid */
+  int w3_format;          /* PYTC_W3_BF16 (0): w3_packed from pytc_pw_pack_weight_paired; PYTC_W3_F16: from
+                           * pytc_pw_pack_weight_paired_f16 -- the hidden activation then runs the packed-fp16 GELU and the
+                           * projection the f16 MFMA (pytc_pw_mlp_fwd / pytc_pw_mlp_train_fwd only) */
 } pytc_mlp_args;
+#define PYTC_W3_BF16 0
+#define PYTC_W3_F16 1
 
 int pytc_pw_mlp_supported(int C_in, int C_hid, int C_out);
 int pytc_pw_pack_weight_paired(const float* w, int C_out, int C_in, int transposed, void* packed_bf16,
                                void* stream);
+/* the same image in IEEE fp16 (round to nearest even) for pytc_mlp_args.w3_format = PYTC_W3_F16 */
+int pytc_pw_pack_weight_paired_f16(const float* w, int C_out, int C_in, int transposed, void* packed_f16,
+                                   void* stream);
 int pytc_pw_mlp_fwd(const pytc_mlp_args* a, void* stream);
 /* The same mixer with the network's 1x1x1 output projection (mednext OutBlock.conv_out, a transposed 1x1x1 conv on the
  * full-resolution features) in its epilogue: logits[o] = head_b[o] + sum_c head[o][c] * bf16(y[c]), o < n_head <= 16,

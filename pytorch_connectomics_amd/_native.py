@@ -41,8 +41,11 @@ class MlpArgs(C.Structure):
         ("res_bias", C.c_void_p), ("y", C.c_void_p),
         ("N", C.c_int), ("rows_per_sample", C.c_int64),
         ("C_in", C.c_int), ("C_hid", C.c_int), ("C_out", C.c_int), ("res_mode", C.c_int),
-        ("Di", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int),
+        ("Di", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("w3_format", C.c_int),
     ]
+
+
+W3_BF16, W3_F16 = 0, 1
 
 
 class Conv3dArgs(C.Structure):
@@ -166,6 +169,7 @@ _SIGS = {
     "pytc_adamw_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_void_p]),
     "pytc_pw_mlp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pytc_pw_pack_weight_paired": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pytc_pw_pack_weight_paired_f16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pytc_pw_mlp_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p]),
     "pytc_pw_mlp_stemres_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pytc_stem_dwconv3d_stat_slots": (C.c_int, [C.c_int, C.c_int, C.c_int]),

@@ -24,6 +24,7 @@ struct MlpParams {
   EpiParams e;
   long rps;        // rows per sample (input == output rows)
   int C_in, C_hid, C_out, HC;   // HC = C_hid / 32
+  int w3_f16;      // w3 is the fp16 paired image: packed-fp16 GELU + f16 MFMA for the projection (GELU_MODE 3)
   // fused output head (HEAD kernels): logits[o] = head_b[o] + sum_c head_w[o][c] * bf16(y[c]),  o < n_head <= 16
   const bf16x8_t* head_w;   // A fragment image [64 lanes][8]: lane (r, kb) holds head[o = r][c = kb*8 .. +7], bf16
   const float* head_b;
@@ -63,7 +64,8 @@ constexpr int mlp_waves_per_simd(int ks, int mo, int nt) {
   return regs <= 64 ? 4 : (regs <= 112 ? 3 : (regs <= 200 ? 2 : 1));
 }
 
-// GELU_MODE: 0 = erf (A&S 7.1.26), 1 = sigmoid-form minimax (gelu_fast), 2 = table
+// GELU_MODE: 0 = erf (A&S 7.1.26), 1 = sigmoid-form minimax (gelu_fast), 2 = table, 3 = packed fp16 polynomial (gelu_h2;
+// the projection then runs on v_mfma_f32_16x16x32_f16 with the fp16 image of W3)
 // HEAD: the network's 1x1x1 output projection rides in the epilogue of the LAST mixer (C_out = 32): the block output is
 // rounded to bf16 exactly as the un-fused path stores it, is itself the B fragment of one more 16x16x32 MFMA against the head
 // weights (rows beyond n_head are zero), whose result lanes write the fp32 logits; the 64 B / voxel of
@@ -200,6 +202,7 @@ pw_mlp_kernel(MlpParams p) {
       }
     }
     bf16x8_t bh[NT];
+    h8_t bhh[GELU_MODE == 3 ? NT : 1];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       float g[8];
@@ -229,6 +232,12 @@ pw_mlp_kernel(MlpParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { acc1[0][nt][j] = hr[j]; acc1[1][nt][j] = hr[4 + j]; }
       }
+      if constexpr (GELU_MODE == 3) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { g[j] = acc1[0][nt][j]; g[4 + j] = acc1[1][nt][j]; }
+        bhh[nt] = gelu_h8_from_f32(g);
+        continue;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         g[j] = GELU_MODE == 2 ? gelu_lut(lut, acc1[0][nt][j]) : (GELU_MODE == 1 ? gelu_fast(acc1[0][nt][j]) : gelu_erf(acc1[0][nt][j]));
@@ -238,9 +247,15 @@ pw_mlp_kernel(MlpParams p) {
     }
 #pragma unroll
     for (int mo = 0; mo < MO; ++mo) {
-      const bf16x8_t a = p.w3[((long)mo * p.HC + hc) * 64 + lane];
+      if constexpr (GELU_MODE == 3) {
+        const h8_t a = reinterpret_cast<const h8_t*>(p.w3)[((long)mo * p.HC + hc) * 64 + lane];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc2[mo][nt] = Mma<bf16_t>::mma(a, bh[nt], acc2[mo][nt]);
+        for (int nt = 0; nt < NT; ++nt) acc2[mo][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bhh[nt], acc2[mo][nt], 0, 0, 0);
+      } else {
+        const bf16x8_t a = p.w3[((long)mo * p.HC + hc) * 64 + lane];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc2[mo][nt] = Mma<bf16_t>::mma(a, bh[nt], acc2[mo][nt]);
+      }
     }
   }
 
@@ -306,9 +321,10 @@ pw_mlp_kernel(MlpParams p) {
 // bit-identical and SLOWER at every shape (forward 9.39 -> 10.1 ms; 128->256->128: 0.26 -> 0.61 ms): the registers of the second
 // tile cost a wave per SIMD, and this kernel lives on occupancy -- its per-wave critical path (MFMA -> GELU -> MFMA dependency
 // chains) is hidden by other waves, not by memory-level parallelism inside one.
+template <typename OUT>
 __global__ void __launch_bounds__(256)
 pw_pack_paired_kernel(const float* __restrict__ w, int C_out, int C_in, int transposed,
-                      bf16_t* __restrict__ packed, int KG, long total) {
+                      OUT* __restrict__ packed, int KG, long total) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   int j = (int)(i % 8);
@@ -321,7 +337,8 @@ pw_pack_paired_kernel(const float* __restrict__ w, int C_out, int C_in, int tran
   int k = kg * 32 + (lane >> 4) * 8 + j;
   float v = 0.f;
   if (o < C_out && k < C_in) v = transposed ? w[(long)k * C_out + o] : w[(long)o * C_in + k];
-  packed[i] = from_f32<bf16_t>(v);
+  if constexpr (sizeof(OUT) == 2 && !__is_same(OUT, bf16_t)) packed[i] = (OUT)v;      // fp16 image (round to nearest even)
+  else packed[i] = from_f32<bf16_t>(v);
 }
 
 // one-time upload of the GELU table (host double precision; blocking copy, first mixer launch of the process)
@@ -350,7 +367,12 @@ static void launch_mlp(const MlpParams& p, int N, hipStream_t s) {
     return;
   }
   if (p.hp) {       // training forward: fast GELU (what the backward kernels differentiate), hidden pre-activation stored
-    hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT, 1, false, false, true>), grid, block, 0, s, p);
+    if (p.w3_f16) hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT, 3, false, false, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT, 1, false, false, true>), grid, block, 0, s, p);
+    return;
+  }
+  if (p.w3_f16) {
+    hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT, 3>), grid, block, 0, s, p);
     return;
   }
   if (tuning_get("mlp_exact_gelu", 0))
@@ -414,9 +436,21 @@ extern "C" int pytc_pw_pack_weight_paired(const float* w, int C_out, int C_in, i
   PYTC_REQUIRE(C_out % 32 == 0, "pw_pack_weight_paired: C_out=%d must be a multiple of 32", C_out);
   long total = pytc_pw_packed_elems(C_out, C_in, PYTC_BF16);
   int KG = (C_in + 31) / 32;
-  hipLaunchKernelGGL(pw_pack_paired_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w, C_out,
+  hipLaunchKernelGGL(pw_pack_paired_kernel<bf16_t>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w, C_out,
                      C_in, transposed, (bf16_t*)packed, KG, total);
   PYTC_LAUNCH_CHECK("pw_pack_weight_paired");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_pw_pack_weight_paired_f16(const float* w, int C_out, int C_in, int transposed, void* packed,
+                                              void* stream) {
+  PYTC_REQUIRE(w && packed && C_out >= 1 && C_in >= 1, "pw_pack_weight_paired_f16: bad arguments");
+  PYTC_REQUIRE(C_out % 32 == 0, "pw_pack_weight_paired_f16: C_out=%d must be a multiple of 32", C_out);
+  long total = pytc_pw_packed_elems(C_out, C_in, PYTC_BF16);       // same element count, 2 bytes each
+  int KG = (C_in + 31) / 32;
+  hipLaunchKernelGGL(pw_pack_paired_kernel<_Float16>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     C_out, C_in, transposed, (_Float16*)packed, KG, total);
+  PYTC_LAUNCH_CHECK("pw_pack_weight_paired_f16");
   return PYTC_OK;
 }
 
@@ -438,10 +472,14 @@ extern "C" int pytc_pw_mlp_head_fwd(const pytc_mlp_args* a, const void* head_w, 
   p.e.rps_out = a->rows_per_sample; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode;
   p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
   p.head_w = (const bf16x8_t*)head_w; p.head_b = head_b; p.head_y = head_y; p.n_head = n_head; p.store_y = store_y;
+  p.w3_f16 = a->w3_format == PYTC_W3_F16 ? 1 : 0;
   dim3 grid((unsigned)((p.rps + 4L * 4 * 16 - 1) / (4L * 4 * 16)), (unsigned)a->N), block(256);
   hipStream_t s = (hipStream_t)stream;
   const bool exact = tuning_get("mlp_exact_gelu", 0) != 0;
-  if (a->C_in == 32) {
+  if (p.w3_f16) {
+    if (a->C_in == 32) hipLaunchKernelGGL((pw_mlp_kernel<1, 2, 4, 3, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((pw_mlp_kernel<2, 2, 4, 3, true>), grid, block, 0, s, p);
+  } else if (a->C_in == 32) {
     if (exact) hipLaunchKernelGGL((pw_mlp_kernel<1, 2, 4, 0, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((pw_mlp_kernel<1, 2, 4, 1, true>), grid, block, 0, s, p);
   } else {
@@ -469,9 +507,11 @@ extern "C" int pytc_pw_mlp_stemres_fwd(const pytc_mlp_args* a, const float* stem
   p.e.y = a->y;
   p.e.rps_out = a->rows_per_sample; p.e.C_out = a->C_out; p.e.res_mode = PYTC_RES_ADD;
   p.stem_x = stem_x; p.stem_w = stem_w; p.stem_b = stem_b;
+  p.w3_f16 = a->w3_format == PYTC_W3_F16 ? 1 : 0;
   dim3 grid((unsigned)((p.rps + 4L * 4 * 16 - 1) / (4L * 4 * 16)), (unsigned)a->N), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (tuning_get("mlp_exact_gelu", 0) != 0) hipLaunchKernelGGL((pw_mlp_kernel<1, 2, 4, 0, false, true>), grid, block, 0, s, p);
+  if (p.w3_f16) hipLaunchKernelGGL((pw_mlp_kernel<1, 2, 4, 3, false, true>), grid, block, 0, s, p);
+  else if (tuning_get("mlp_exact_gelu", 0) != 0) hipLaunchKernelGGL((pw_mlp_kernel<1, 2, 4, 0, false, true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((pw_mlp_kernel<1, 2, 4, 1, false, true>), grid, block, 0, s, p);
   PYTC_LAUNCH_CHECK("pw_mlp_stemres");
   return PYTC_OK;
@@ -514,6 +554,8 @@ static int mlp_fwd_impl(const pytc_mlp_args* a, void* hp, void* stream, const vo
   p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
   p.hp = (bf16_t*)hp;
   p.hp_in = (const bf16_t*)hp_in;
+  p.w3_f16 = a->w3_format == PYTC_W3_F16 ? 1 : 0;
+  PYTC_REQUIRE(!(p.w3_f16 && hp_in), "pw_mlp_bwd: the backward mixer takes bf16 weight images");
   if (a->res_mode == PYTC_RES_UPSAMPLE) {
     PYTC_REQUIRE((long)a->Di * a->Hi * a->Wi == a->rows_per_sample && !(a->Di & 1) && !(a->Hi & 1) && !(a->Wi & 1),
                  "pw_mlp: RES_UPSAMPLE needs the (even) output grid");

@@ -145,6 +145,48 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// Packed-fp16 GELU for the fused mixers (round 2).  SQ counters put the bf16 mixers at ~70 % VALU busy with v_exp_f32 +
+// v_rcp_f32 (quarter rate) as 60 % of it; packed fp32 FMAs bring nothing on gfx950 (profiles/r02_gelu_valu_probe.txt), but
+// v_pk_*_f16 really does process two values per lane and instruction.  Transcendental-free form
+//     gelu(x) = max(x, 0) - r(min(|x|, U)),   r(u) = u * Phi(-u)   (a bump: 0 at 0, 0.17 at 0.75, 3.3e-4 at U = 3.75)
+// with r as a degree-7 polynomial in t = 2u/U - 1 (Chebyshev fit, |fit error| <= 1.0e-4): and, min, fma, 7 fma, max, sub =
+// 12 packed instructions per TWO elements (6 per element vs 7 VALU + 2 quarter-rate transcendentals = ~15 for gelu_fast).
+// Emulated over every fp16 input in [-8, 8]: max |error| 1.1e-3 at |x| ~ 3 (= half an fp16 ulp of the RESULT, whose
+// spacing there is 2^-9; bf16, which the result used to be rounded to, has 2^-6), mean 1.5e-4.  The result IS the f16 B
+// operand of the projecting MFMA (v_mfma_f32_16x16x32_f16), so the hidden activation carries 11 mantissa bits instead of
+// bf16's 8.  Inputs are converted with round-toward-zero saturation (v_cvt_pkrtz_f16_f32: finite in, finite out).
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ h2_t gelu_h2(h2_t x) {
+  const h2_t U = {(_Float16)3.75f, (_Float16)3.75f};
+  const h2_t u = __builtin_elementwise_min(__builtin_elementwise_abs(x), U);
+  const h2_t t = u * (h2_t){(_Float16)(2.0f / 3.75f), (_Float16)(2.0f / 3.75f)} + (h2_t){(_Float16)-1.0f, (_Float16)-1.0f};
+#define PYTC_H2C(v) ((h2_t){(_Float16)(v), (_Float16)(v)})
+  h2_t p = PYTC_H2C(-6.166994737e-02f);
+  p = p * t + PYTC_H2C(6.367329291e-02f);
+  p = p * t + PYTC_H2C(1.683184914e-01f);
+  p = p * t + PYTC_H2C(-3.056981228e-01f);
+  p = p * t + PYTC_H2C(7.903670132e-02f);
+  p = p * t + PYTC_H2C(1.852329106e-01f);
+  p = p * t + PYTC_H2C(-1.855973189e-01f);
+  p = p * t + PYTC_H2C(5.694380662e-02f);
+#undef PYTC_H2C
+  return __builtin_elementwise_max(x, (h2_t){(_Float16)0.0f, (_Float16)0.0f}) - p;
+}
+
+// eight fp32 pre-activations -> gelu -> the f16 B fragment of the next MFMA
+__device__ __forceinline__ h8_t gelu_h8_from_f32(const float (&v)[8]) {
+  h8_t out;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const h2_t g = gelu_h2(__builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(v[2 * q], v[2 * q + 1])));
+    out[2 * q] = g[0];
+    out[2 * q + 1] = g[1];
+  }
+  return out;
+}
+
 // Bijective XCD-aware remap of a 1-D block index: hardware places block b on XCD b % 8, so logical
 // neighbours (which share halos / operand panels) are given to the SAME XCD's L2, in dispatch order.
 __device__ __forceinline__ int xcd_swizzle(int b, int nblocks) {

@@ -335,17 +335,28 @@ def pw_mlp_supported(c_in: int, c_hid: int, c_out: int) -> bool:
     return bool(nat.lib().pytc_pw_mlp_supported(int(c_in), int(c_hid), int(c_out)))
 
 
-def pw_pack_weight_paired(w: torch.Tensor, *, transposed: bool = False) -> torch.Tensor:
-    """bf16 MFMA image with the paired-row permutation expected by pw_mlp (see csrc/pw_common.h)."""
+# The projecting GEMM of the fused mixers (w3) takes its weights as an fp16 image: the hidden activation is then produced by
+# the packed-fp16 polynomial GELU (two values per VALU instruction, no transcendentals) and consumed by the f16 MFMA
+# (csrc/pytc_common.h: gelu_h2).  False restores the bf16 image + sigmoid-form GELU (exp + rcp in fp32).
+MLP_F16_PROJECT = True
+
+
+def pw_pack_weight_paired(w: torch.Tensor, *, transposed: bool = False, f16: bool = False) -> torch.Tensor:
+    """MFMA image with the paired-row permutation expected by pw_mlp (see csrc/pw_common.h): bf16, or fp16 (`f16=True`, the
+    projection weights of a mixer that runs the packed-fp16 GELU; the tensor's dtype tells the launch wrappers which)."""
     _dev(w, "w")
     if w.dtype != torch.float32 or w.dim() != 2:
         raise ValueError("pointwise weight must be float32 2-D")
     c_out, c_in = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
     n = nat.lib().pytc_pw_packed_elems(c_out, c_in, nat.BF16)
-    packed = torch.empty((n,), dtype=torch.bfloat16, device=w.device)
-    _run("pw_pack_weight_paired", _nbytes(w, packed), nat.lib().pytc_pw_pack_weight_paired, _p(w), c_out, c_in,
-         int(transposed), _p(packed), _stream())
+    packed = torch.empty((n,), dtype=torch.float16 if f16 else torch.bfloat16, device=w.device)
+    fn = nat.lib().pytc_pw_pack_weight_paired_f16 if f16 else nat.lib().pytc_pw_pack_weight_paired
+    _run("pw_pack_weight_paired", _nbytes(w, packed), fn, _p(w), c_out, c_in, int(transposed), _p(packed), _stream())
     return packed
+
+
+def _w3_format(w3p: torch.Tensor) -> int:
+    return nat.W3_F16 if w3p.dtype == torch.float16 else nat.W3_BF16
 
 
 def pw_mlp(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.Tensor, w3p: torch.Tensor,
@@ -363,6 +374,7 @@ def pw_mlp(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.Tenso
     a = nat.MlpArgs()
     a.t, a.ab, a.w2_packed, a.b2, a.w3_packed, a.b3 = (t.data_ptr(), ab.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
                                                        w3p.data_ptr(), b3.data_ptr())
+    a.w3_format = _w3_format(w3p)
     a.res = res.data_ptr() if res is not None else None
     a.res_low = res_low.data_ptr() if res_low is not None else None
     a.res_bias = res_bias.data_ptr() if res_bias is not None else None
@@ -398,6 +410,8 @@ def pw_mlp_up(x_low: torch.Tensor, taps: torch.Tensor, dw_bias: Optional[torch.T
     a = nat.MlpArgs()
     a.t, a.ab, a.w2_packed, a.b2, a.w3_packed, a.b3 = (x_low.data_ptr(), ab.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
                                                        w3p.data_ptr(), b3.data_ptr())
+    if w3p.dtype != torch.bfloat16:
+        raise TypeError("pw_mlp_up takes the bf16 image of the projection weights")
     a.res = skip.data_ptr()
     if dw_bias is None:
         dw_bias = torch.zeros((c_in,), dtype=torch.float32, device=x_low.device)
@@ -453,6 +467,7 @@ def pw_mlp_stemres(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: tor
     a = nat.MlpArgs()
     a.t, a.ab, a.w2_packed, a.b2, a.w3_packed, a.b3 = (t.data_ptr(), ab.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
                                                        w3p.data_ptr(), b3.data_ptr())
+    a.w3_format = _w3_format(w3p)
     a.res = a.res_low = a.res_bias = None
     a.y = y.data_ptr()
     a.N, a.rows_per_sample, a.C_in, a.C_hid, a.C_out, a.res_mode = N, rows_per_sample, c_in, c_hid, c_out, nat.RES_ADD
@@ -486,6 +501,7 @@ def pw_mlp_bwd(dy: torch.Tensor, hidden_pre: torch.Tensor, w3t_p: torch.Tensor, 
     a = nat.MlpArgs()
     a.t, a.ab, a.w2_packed, a.b2, a.w3_packed, a.b3 = (dy.data_ptr(), ident.data_ptr(), w3t_p.data_ptr(), zh.data_ptr(),
                                                        w2t_p.data_ptr(), zi.data_ptr())
+    a.w3_format = nat.W3_BF16
     a.res = a.res_low = a.res_bias = None
     a.y = dx.data_ptr()
     a.N, a.rows_per_sample, a.C_in, a.C_hid, a.C_out, a.res_mode = N, rows_per_sample, c_out, c_hid, c_in, nat.RES_NONE
@@ -525,6 +541,7 @@ def pw_mlp_head(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.
     a = nat.MlpArgs()
     a.t, a.ab, a.w2_packed, a.b2, a.w3_packed, a.b3 = (t.data_ptr(), ab.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
                                                        w3p.data_ptr(), b3.data_ptr())
+    a.w3_format = _w3_format(w3p)
     a.res = res.data_ptr() if res is not None else None
     a.res_low = a.res_bias = None
     a.y = y.data_ptr() if y is not None else None

@@ -170,12 +170,15 @@ class HipBlockOps:
             return ops.pw_pack_weight(w2, dt, transposed=transposed)
         return self.cache.get(("pw", id(conv), dt, transposed), [w], make)
 
-    def _pw_paired(self, conv: nn.Module, transposed: bool = False):
+    def _pw_paired(self, conv: nn.Module, transposed: bool = False, project: bool = False):
+        """`project`: the mixer's second (projecting) conv -- its image is fp16 when ops.MLP_F16_PROJECT (packed-fp16 GELU +
+        f16 MFMA in the fused mixer), bf16 otherwise."""
         w = conv.weight
+        f16 = bool(project and ops.MLP_F16_PROJECT)
         def make():
             w2 = w.detach().float().reshape(w.shape[0], w.shape[1]).contiguous()
-            return ops.pw_pack_weight_paired(w2, transposed=transposed)
-        return self.cache.get(("pwp", id(conv), transposed), [w], make)
+            return ops.pw_pack_weight_paired(w2, transposed=transposed, f16=f16)
+        return self.cache.get(("pwp", id(conv), transposed, f16), [w], make)
 
     def _head_w(self, conv: nn.Module):
         """bf16 MFMA fragment image of the transposed 1x1x1 output conv (weights rounded like the un-fused head's)."""
@@ -261,7 +264,7 @@ class HipBlockOps:
             if (head is not None and kind == "block" and head.weight.shape[1] <= 16
                     and ops.pw_mlp_head_supported(C, c_hid, c_out)):
                 _, logits = ops.pw_mlp_head(t, ab, self._pw_paired(m.conv2), self._vec(m.conv2, "bias", m.conv2.bias),
-                                            self._pw_paired(m.conv3), self._vec(m.conv3, "bias", m.conv3.bias),
+                                            self._pw_paired(m.conv3, project=True), self._vec(m.conv3, "bias", m.conv3.bias),
                                             self._head_w(head), self._vec(head, "bias", head.bias), N=N,
                                             rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out,
                                             res=x if m.do_res else None, store_y=False)
@@ -322,7 +325,7 @@ def _stem_block_fused(self, stem: nn.Module, m, x_cl: torch.Tensor) -> Optional[
     ab = ops.groupnorm_finalize(st, float(rows), self._vec(m.norm, "weight", m.norm.weight),
                                 self._vec(m.norm, "bias", m.norm.bias), m.norm.eps)
     y = ops.pw_mlp_stemres(t, ab, self._pw_paired(m.conv2), self._vec(m.conv2, "bias", m.conv2.bias),
-                           self._pw_paired(m.conv3), self._vec(m.conv3, "bias", m.conv3.bias), x_cl.reshape(N, rows), sw, sb,
+                           self._pw_paired(m.conv3, project=True), self._vec(m.conv3, "bias", m.conv3.bias), x_cl.reshape(N, rows), sw, sb,
                            N=N, rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out)
     return y.view(N, D, H, W, c_out)
 
@@ -337,7 +340,7 @@ def _block_fused(self, m, x, t, ab, skip, ishape, oshape, c_hid, c_out):
     rows = Do * Ho * Wo
     dt = torch.bfloat16
     w2, b2 = self._pw_paired(m.conv2), self._vec(m.conv2, "bias", m.conv2.bias)
-    w3, b3 = self._pw_paired(m.conv3), self._vec(m.conv3, "bias", m.conv3.bias)
+    w3, b3 = self._pw_paired(m.conv3, project=True), self._vec(m.conv3, "bias", m.conv3.bias)
     kw = dict(N=N, rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out)
     if m.kind == "block":
         y = ops.pw_mlp(t, ab, w2, b2, w3, b3, res=x if m.do_res else None,

@@ -143,7 +143,7 @@ class BlockFn(torch.autograd.Function):
         if fused:
             # one launch: norm affine -> expand -> (store pre-activation hp) -> GELU -> project -> residual epilogue
             hp = torch.empty((N, rows, c_hid), dtype=dt, device=x.device)
-            w2p, w3p = ops.pw_pack_weight_paired(_mat(w2)), ops.pw_pack_weight_paired(_mat(w3))
+            w2p, w3p = ops.pw_pack_weight_paired(_mat(w2)), ops.pw_pack_weight_paired(_mat(w3), f16=ops.MLP_F16_PROJECT)
             mk = dict(N=N, rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out, hidden_pre=hp)
         else:
             hp = _pw(t, _mat(w2), _f(b2), c_out=c_hid, ab=ab, rows=rows)              # pre-activation (saved)

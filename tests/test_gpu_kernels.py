@@ -171,9 +171,11 @@ def test_pw_conv_strided_gather_and_upsample_epilogue(dev, dt):
     (128, 256, 128, "add"), (128, 512, 64, "up"), (256, 512, 256, "add"), (256, 1024, 512, "add"),
     (512, 1024, 512, "add"), (512, 1024, 256, "up"), (128, 256, 256, "add"), (256, 2048, 128, "up"),
 ])
-def test_pw_mlp_fused_matches_reference(dev, cin, chid, cout, mode):
-    """Fused norm-apply/expand/GELU/project/residual kernel vs fp32 math with bf16 rounding at the same
-    three points (normalised input, hidden activation, output)."""
+@pytest.mark.parametrize("hidden", ["bf16", "f16"])
+def test_pw_mlp_fused_matches_reference(dev, cin, chid, cout, mode, hidden):
+    """Fused norm-apply/expand/GELU/project/residual kernel vs fp32 math with rounding at the same three points (normalised
+    input -> bf16, hidden activation -> bf16 or fp16, output -> bf16).  hidden = "f16": the projection weights are the fp16
+    image, the hidden activation comes from the packed-fp16 polynomial GELU and feeds the f16 MFMA (the default of the models)."""
     from pytorch_connectomics_amd import _native as nat
     from pytorch_connectomics_amd import hip_ops as ops
     assert ops.pw_mlp_supported(cin, chid, cout)
@@ -191,11 +193,13 @@ def test_pw_mlp_fused_matches_reference(dev, cin, chid, cout, mode):
     w2, b2 = torch.randn(chid, cin) / cin ** 0.5, torch.randn(chid) * 0.5
     w3, b3 = torch.randn(cout, chid) / chid ** 0.5, torch.randn(cout) * 0.5
     tn = (t * a[:, None] + b[:, None]).to(bf).float()
-    hid = F.gelu(tn @ w2.to(bf).float().t() + b2).to(bf).float()
-    core = hid @ w3.to(bf).float().t() + b3
+    hdt = torch.float16 if hidden == "f16" else bf
+    hid = F.gelu(tn @ w2.to(bf).float().t() + b2).to(hdt).float()
+    core = hid @ w3.to(hdt).float().t() + b3
     ab = torch.stack([a, b], 1).contiguous().to(dev)
     args = dict(N=N, rows_per_sample=rows, c_in=cin, c_hid=chid, c_out=cout)
-    w2p, w3p = ops.pw_pack_weight_paired(w2.to(dev)), ops.pw_pack_weight_paired(w3.to(dev))
+    w2p, w3p = ops.pw_pack_weight_paired(w2.to(dev)), ops.pw_pack_weight_paired(w3.to(dev), f16=hidden == "f16")
+    assert w3p.dtype == hdt
     if mode == "add":
         res = torch.randn(N, rows, cout).to(bf).float()
         ref = core + res
@@ -220,6 +224,27 @@ def test_pw_mlp_fused_matches_reference(dev, cin, chid, cout, mode):
                        res_mode=nat.RES_UPSAMPLE, grid=grid, res_low=res_low.to(dev).to(bf),
                        res_bias=rbias.to(dev), **args)
     torch.testing.assert_close(y.float().cpu(), ref, rtol=2e-2, atol=3e-2)
+
+
+def test_packed_fp16_gelu_accuracy(dev):
+    """gelu_h2 (csrc/pytc_common.h) through the fused mixer: identity-like first GEMM, one-hot projection, so the output is
+    bf16(gelu_h2(x)) for a dense sweep of x.  Error budget: polynomial fit 1e-4 + fp16 evaluation, then the bf16 output
+    rounding -> |y - gelu(x)| <= 1.2e-3 + 2^-8 |gelu(x)|; the result is more accurate than the bf16 hidden activation it
+    replaces wherever |gelu| > 0.1."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    C = 32
+    xs = torch.linspace(-8, 8, 64 * 512).view(1, -1, 1)
+    t = (xs * torch.ones(1, 1, C)).to(torch.bfloat16)                 # every channel carries x
+    eye = torch.eye(C)
+    ab = torch.stack([torch.ones(1, C), torch.zeros(1, C)], 1).contiguous().to(dev)
+    z = torch.zeros(C, device=dev)
+    y = ops.pw_mlp(t.to(dev), ab, ops.pw_pack_weight_paired(eye.to(dev)), z, ops.pw_pack_weight_paired(eye.to(dev), f16=True), z,
+                   N=1, rows_per_sample=t.shape[1], c_in=C, c_hid=C, c_out=C).float().cpu()
+    want = F.gelu(t.float())
+    err = (y - want).abs()
+    assert float((err - (1.2e-3 + 2.0 ** -8 * want.abs())).max()) <= 0, float(err.max())
+    assert float(err.mean()) < 1e-3
+    assert torch.equal(y[..., 0], y[..., C - 1])                        # all channels evaluate the same function
 
 
 def test_gelu_accuracy(dev):

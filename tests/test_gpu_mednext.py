@@ -233,11 +233,14 @@ def test_mednext_grn_and_layernorm_variants_match_oracle(dev, norm_type, grn, dt
 
 
 @pytest.mark.parametrize("size,shape", [("S", (32, 32, 48)), ("S", (16, 48, 80)), ("L", (32, 32, 32)), ("B", (16, 32, 64))])
-def test_fused_up_block_is_bit_identical_to_unfused(size, shape):
+def test_fused_up_block_is_bit_identical_to_unfused(size, shape, monkeypatch):
     """pw_mlp_up (depthwise transposed conv recomputed in the mixer prologue, statistics from the store-less launch of the same
     depthwise kernel) against dwconvT3d + pw_mlp(RES_UPSAMPLE): same fp32 operation order, same bf16 roundings, same partial-sum
-    tree -> bit-identical logits.  Shapes include low-resolution rows that are not multiples of the 16-cell tile."""
+    tree -> bit-identical logits.  Shapes include low-resolution rows that are not multiples of the 16-cell tile.  The fused up
+    kernel (off by default: measured slower) keeps the bf16 hidden activation, so the comparison runs the mixers in that mode."""
+    from pytorch_connectomics_amd import hip_ops
     from pytorch_connectomics_amd.models.architectures.mednext import create_mednext_v1
+    monkeypatch.setattr(hip_ops, "MLP_F16_PROJECT", False)
     torch.manual_seed(3)
     m = create_mednext_v1(1, 2, size, 3).cuda().eval()
     m.compute_dtype = torch.bfloat16

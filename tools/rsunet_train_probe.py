@@ -17,6 +17,7 @@ ap.add_argument("--norm", default="batch")
 ap.add_argument("--width", default="16,32,64,128")
 ap.add_argument("--mode", default="both", choices=["both", "train", "infer"])
 ap.add_argument("--gc", default="on", choices=["on", "off", "freeze"])
+ap.add_argument("--ops", action="store_true")
 a = ap.parse_args()
 patch = tuple(int(v) for v in a.patch.split(","))
 m = RSUNet(1, 3, width=[int(v) for v in a.width.split(",")], norm=a.norm, activation="relu").cuda().train()
@@ -50,6 +51,18 @@ if a.mode != "infer":
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     print(f"rsunet train {a.dtype} norm={a.norm} batch {a.batch} patch {patch}: {dt * 1e3:.1f} ms/step, {vox / dt:.3e} voxels/s, loss {float(l.detach()):.4f}")
+if a.ops:
+    from pytorch_connectomics_amd import hip_ops as ops
+    m.train()
+    with ops.profiled() as prof:
+        for _ in range(2):
+            step()
+    summ = prof.summary()
+    tot = sum(v["ms"] for v in summ.values())
+    print(f"total kernel ms per step: {tot / 2:.2f}")
+    for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:45]:
+        print(f"  {k:34s} launches={v['launches'] // 2:4d} ms={v['ms'] / 2:8.3f}/step avg_us={v['ms'] / v['launches'] * 1e3:8.1f} "
+              f"GB/s={v['bytes'] / max(v['ms'], 1e-9) / 1e6:8.1f}")
 if a.mode == "train":
     raise SystemExit(0)
 with torch.no_grad():
