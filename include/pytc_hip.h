@@ -169,6 +169,15 @@ int pytc_dwconv3d_fwd(const void* x, void* y, const float* w, const float* bias,
                       int N, int D, int H, int W, int C, int K, int stride, int dtype,
                       void* stream);
 
+/* y = pytc_dwconv3d_fwd(x) + res (res laid out like y, no statistics): the data gradient of a residual MedNeXt block,
+ * dx = conv_reversed_taps(dt) + dy, without the separate add pass.  bf16, z-march shapes only (K = 3, stride 1, C % 32 == 0,
+ * D >= 8, H, W >= 16): pytc_dwconv3d_res_supported; other shapes: convolve, then pytc_add_inplace.  The sum is formed on the
+ * fp32 accumulator and rounded once (the two-step form rounds the convolution first).  Replaces the autograd accumulation of the residual
+ * branch (MedNeXtBlock.forward: x + conv path; mednext attribute contract at mednext_models.py:104-117). */
+int pytc_dwconv3d_res_supported(int D, int H, int W, int C, int K, int stride, int dtype);
+int pytc_dwconv3d_fwd_res(const void* x, const void* res, void* y, const float* w, const float* bias, int N, int D, int H,
+                          int W, int C, int K, int stride, int dtype, void* stream);
+
 /* Depthwise ConvTranspose3d (groups == C), kernel K^3, stride 2, padding K/2 -> Do = 2D-1.
  * Replaces MedNeXtUpBlock.conv1.  Output is written into a buffer of spatial size
  * (2D)x(2H)x(2W) at offset +1 on every axis (the block's later F.pad((1,0,1,0,1,0)) is thereby
@@ -261,6 +270,13 @@ typedef struct {
 int pytc_pw_mlp_supported(int C_in, int C_hid, int C_out);
 int pytc_pw_pack_weight_paired(const float* w, int C_out, int C_in, int transposed, void* packed_bf16,
                                void* stream);
+/* All per-step weight re-layouts of a model in one launch (training).  table_dev: device array [n_items][8] int64
+ *   {src (fp32), dst, kind, C_out, C_in, aux, first_element, element_count}, rows sorted by first_element, contiguous:
+ *   kind 0 / 1: pytc_pw_pack_weight_paired of a [C_out][C_in] / transposed source (aux = ceil(C_in/32));
+ *   kind 2 / 3: the same as pytc_pw_pack_weight_paired_f16;
+ *   kind 4 / 5: depthwise stencil [C][K^3] -> tap-major [K^3][C] fp32, as stored / reversed (aux = K^3, C_out = C).
+ * Results are bit-identical to the individual pack calls. */
+int pytc_pack_multi(const int64_t* table_dev, int n_items, int64_t total_elems, void* stream);
 /* the same image in IEEE fp16 (round to nearest even) for pytc_mlp_args.w3_format = PYTC_W3_F16 */
 int pytc_pw_pack_weight_paired_f16(const float* w, int C_out, int C_in, int transposed, void* packed_f16,
                                    void* stream);
@@ -379,6 +395,24 @@ int pytc_pw_wgrad(const void* x, const float* ab, const void* dy, float* dW, flo
 int pytc_dw_wgrad_slots(int N, const int32_t* gdims, const int32_t* xdims, int C, int K, int stride, int dtype);
 int pytc_dw_wgrad(const void* g, const void* x, float* dW, float* db, float* workspace, int N, const int32_t* gdims,
                   const int32_t* xdims, int C, int K, int stride, int dtype, void* stream);
+
+/* Deferred-reduction forms (training backward of one block): everything pytc_pw_wgrad / pytc_dw_wgrad do EXCEPT the final
+ * slot reduction.  *slots_out = number of partial slots written: dW partials at workspace[0 .. slots*nW), bias partials
+ * (want_db != 0) at workspace[slots*nW .. slots*(nW+nB)), nW = C_out*C_in (pw) or K^3*C (dw), nB = C_out or C.  The caller
+ * collects the (partials, output, n, slots) items of several gradients and reduces them in ONE launch with
+ * pytc_reduce_slots_multi (<= 12 items; per element the same summation tree as the immediate forms, so results are
+ * bit-identical).  Replaces the per-gradient reduction launches of the reference's autograd accumulation for a block. */
+int pytc_pw_wgrad_partial(const void* x, const float* ab, const void* dy, float* workspace, int want_db, int N,
+                          int64_t rows_per_sample, int C_in, int C_out, int dtype, int x_act, int* slots_out, void* stream);
+int pytc_dw_wgrad_partial(const void* g, const void* x, float* workspace, int want_db, int N, const int32_t* gdims,
+                          const int32_t* xdims, int C, int K, int stride, int dtype, int* slots_out, void* stream);
+typedef struct {
+  const float* part;   /* [slots][n] fp32 partials */
+  float* out;          /* [n] */
+  int64_t n;
+  int32_t slots;
+} pytc_reduce_item;
+int pytc_reduce_slots_multi(const pytc_reduce_item* items, int n_items, void* stream);
 /* GroupNorm(C,C) backward: dt = rstd*gamma*(dtn - mean_v(dtn) - xhat*mean_v(dtn*xhat)); s_out [N][2][C] holds
  * (sum dtn, sum dtn*xhat) whose sums over N are dbeta / dgamma.  stats_ws: pytc_norm_bwd_ws_elems floats */
 int pytc_norm_bwd_ws_elems(int N, int64_t rows, int C);

@@ -48,6 +48,10 @@ class MlpArgs(C.Structure):
 W3_BF16, W3_F16 = 0, 1
 
 
+class ReduceItem(C.Structure):
+    _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("n", C.c_int64), ("slots", C.c_int32)]
+
+
 class Conv3dArgs(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("ab", C.c_void_p), ("res", C.c_void_p),
@@ -77,6 +81,9 @@ _SIGS = {
     "pytc_dwconv3d_stat_slots": (C.c_int, [C.c_int] * 9),
     "pytc_dwconv3d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8
                           + [C.c_void_p]),
+    "pytc_dwconv3d_res_supported": (C.c_int, [C.c_int] * 7),
+    "pytc_dwconv3d_fwd_res": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8
+                              + [C.c_void_p]),
     "pytc_dwconvT3d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7
                            + [C.c_void_p]),
     "pytc_groupnorm_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_float,
@@ -116,6 +123,11 @@ _SIGS = {
     "pytc_pw_wgrad_slots": (C.c_int, [C.c_int64]),
     "pytc_pw_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_pw_wgrad_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
+    "pytc_dw_wgrad_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
+    "pytc_reduce_slots_multi": (C.c_int, [C.POINTER(ReduceItem), C.c_int, C.c_void_p]),
     "pytc_dw_wgrad_slots": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int,
                                       C.c_int]),
     "pytc_dw_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -169,6 +181,7 @@ _SIGS = {
     "pytc_adamw_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_void_p]),
     "pytc_pw_mlp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pytc_pw_pack_weight_paired": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pytc_pack_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "pytc_pw_pack_weight_paired_f16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pytc_pw_mlp_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p]),
     "pytc_pw_mlp_stemres_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -22,6 +22,25 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 
 
+NO_SPILL_KERNELS = {"dwconv_kernels.hip": ("dwconv3d_k3_march_kernel", "dw_wgrad_march_kernel")}
+
+
+def _check_no_spills(fname: str, remarks: str, patterns) -> None:
+    """Parse hipcc's kernel-resource-usage remarks: every kernel whose mangled name contains one of `patterns` must report
+    `VGPRs Spill: 0` and `ScratchSize [bytes/lane]: 0`."""
+    import re
+    name = None
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            continue
+        m = re.search(r"(VGPRs Spill|ScratchSize \[bytes/lane\]): (\d+)", line)
+        if m and name and any(p in name for p in patterns) and int(m.group(2)) != 0:
+            raise RuntimeError(f"{fname}: kernel {name} reports {m.group(1)} = {m.group(2)}; the asm-load / counted-wait kernels "
+                               "must be spill-free (lower the occupancy hint of that instantiation)")
+
+
 def _sources():
     return sorted(CSRC.glob("*.hip"))
 
@@ -51,7 +70,14 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+        if src.name in NO_SPILL_KERNELS:
+            # kernels that issue their global loads from inline asm and wait on counted s_waitcnt: a register the compiler
+            # spills while such a load is still writing it is corrupted (seen: garbage output of a 31-spill variant), so a
+            # spill in one of them is a BUILD error, not a performance note
+            out = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], check=True, capture_output=True, text=True).stderr
+            _check_no_spills(src.name, out, NO_SPILL_KERNELS[src.name])
+        else:
+            subprocess.run(cmd, check=True)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:

@@ -474,10 +474,16 @@ struct DwMarch {
   int swizzle;           // XCD-aware block remap on/off
 };
 
-template <typename T, int VEC, int PF, bool ASYNC, int WPS = 2>
+// RES: y = conv(x) + res (res laid out like y).  The training backward uses it for the data gradient of a residual block,
+// dx = conv_reversed(dt) + dy: the separate read-modify-write pass over dx (add_inplace: 3 tensor passes, 1.8 ms of a
+// 36 ms MedNeXt-S step) becomes one extra read inside the kernel that already writes dx.  The residual values of output
+// plane p travel in registers (one channel pair per position: 4-byte loads, 64-B segments), requested at step p -- BEFORE
+// that step's input-plane request -- and consumed by the stores of step p+1; the counted wait below includes them.
+template <typename T, int VEC, int PF, bool ASYNC, int WPS = 2, bool RES = false>
 __global__ void __launch_bounds__(256, WPS)
 dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ w,
-                         const float* __restrict__ bias, float* __restrict__ stats, DwMarch g) {
+                         const float* __restrict__ bias, float* __restrict__ stats, DwMarch g,
+                         const T* __restrict__ res = nullptr) {
   // VEC channels per lane (4: ds_read_b128, 108 weight registers; 2: ds_read_b64, 54 weight registers ->
   // more resident workgroups).  PF = planes of global loads kept in flight (register staged).
   constexpr int CG = MARCH_CG, LPV = CG / VEC, PPP = 256 / LPV, PASSES = (TILE_Y * TILE_X) / PPP;
@@ -511,6 +517,7 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
   const long plane_elems = (long)g.H * g.W * C;
   const T* xn = x + (long)n * g.D * plane_elems + cg * CG;
   T* yn = y + (long)n * g.D * plane_elems + cg * CG;
+  const T* rn = RES ? res + (long)n * g.D * plane_elems + cg * CG : nullptr;
 
   // ---- staging descriptors (constant along z)
   int goff[CPT], loff[CPT];
@@ -543,13 +550,17 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
       else stg[i] = *reinterpret_cast<const u32x4_t*>(ptr);
     }
   };
-  auto landed = [&](u32x4_t (&stg)[CPT], bool younger_in_flight) {
+  // with_res: this step also issued its PASSES residual loads (before its plane request), and the previous step's residual
+  // values are about to be used: everything younger than THOSE may stay in flight -- the previous step's plane request, this
+  // step's residual loads, this step's plane request (PF = 3; with PF = 2 the awaited plane is itself that younger request)
+  auto landed = [&](u32x4_t (&stg)[CPT], bool younger_in_flight, bool with_res) {
     if constexpr (ASYNC) {
       static_assert(CPT == 2, "the wait below names two staging registers");
       // operand-free waits (a "+v" operand here made hipcc copy the still-in-flight registers BEFORE the wait), then one
       // anchor that orders every later use of the staging registers after them
-      if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(CPT * (PF - 1)) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+      if (!younger_in_flight) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+      else if (RES && with_res) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(CPT * (PF - 1) + PASSES) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(CPT * (PF - 1)) : "memory");
       asm volatile("" : "+v"(stg[0]), "+v"(stg[1]) : : "memory");
     }
   };
@@ -590,6 +601,27 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
     pok[ps] = (y0 + py) < g.H && (x0 + px) < g.W;
     obase[ps] = ((long)(y0 + py) * g.W + (x0 + px)) * C + cv * VEC;
   }
+  // residual staging: one 4-byte (bf16 pair) / 8-byte (fp32 pair) value per position; three rotating sets, two live
+  typedef typename std::conditional<sizeof(T) == 2, unsigned int, unsigned long long>::type rq_t;
+  rq_t rq0[RES ? PASSES : 1], rq1[RES ? PASSES : 1], rq2[RES ? PASSES : 1];
+  auto issue_res = [&](int gz, rq_t (&rq)[RES ? PASSES : 1]) {
+    if constexpr (RES) {
+      static_assert(VEC == 2, "residual staging carries channel pairs");
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        // every lane always loads (clamped position): exactly PASSES loads per wave and step keep the counted wait exact
+        const int pos = ps * PPP + pslot;
+        const int yy = min(y0 + pos / TILE_X, g.H - 1), xx = min(x0 + pos % TILE_X, g.W - 1);
+        const T* ptr = rn + (long)gz * plane_elems + ((long)yy * g.W + xx) * C + cv * VEC;
+        if constexpr (ASYNC) {
+          if constexpr (sizeof(T) == 2) asm volatile("global_load_dword %0, %1, off" : "=&v"(rq[ps]) : "v"(ptr) : "memory");
+          else asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(rq[ps]) : "v"(ptr) : "memory");
+        } else {
+          rq[ps] = *reinterpret_cast<const rq_t*>(ptr);
+        }
+      }
+    }
+  };
   float s1[VEC], s2[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
@@ -604,7 +636,10 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
   // `ld` receives the global loads issued this step (plane gz+PF); `cm` holds plane gz+1 (issued PF-1
   // steps ago) and is committed to the other LDS slot after the compute.
   auto step = [&](int gz, int slot, fvec_t (&prev)[PASSES], fvec_t (&cur)[PASSES],
-                  fvec_t (&next)[PASSES], u32x4_t (&ld)[CPT], u32x4_t (&cm)[CPT]) {
+                  fvec_t (&next)[PASSES], u32x4_t (&ld)[CPT], u32x4_t (&cm)[CPT],
+                  rq_t (&rnew)[RES ? PASSES : 1], rq_t (&rold)[RES ? PASSES : 1]) {
+    const bool res_now = RES && gz >= zs && gz < ze;      // residual of output plane gz (stored by the NEXT step)
+    if (res_now) issue_res(gz, rnew);
     if (gz + PF <= ze) issue(gz + PF, ld);
     // Unconditional accumulation: planes outside the volume were staged as zeros, and accumulators that
     // belong to outputs outside [zs, ze) are simply never stored (2 wasted planes per z-chunk), which keeps
@@ -638,8 +673,14 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
       }
     }
     if (gz + 1 <= ze) {
-      landed(cm, gz + PF <= ze);
+      landed(cm, gz + PF <= ze, res_now);
       commit(slot ^ 1, cm, gz + 1);
+    } else if constexpr (RES && ASYNC) {
+      asm volatile("s_waitcnt vmcnt(0)" : : : "memory");      // last step: the residual of plane ze-1 has to be there
+    }
+    if constexpr (RES && ASYNC) {
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) asm volatile("" : "+v"(rold[ps]) : : "memory");    // uses stay after the wait
     }
     // stores after the wait: the only operations younger than the awaited plane are then the newest plane's loads
     if (gz - 1 >= zs) {   // output plane gz-1 is complete
@@ -649,6 +690,15 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
           float pv[VEC];
 #pragma unroll
           for (int i = 0; i < VEC; ++i) pv[i] = prev[ps][i];
+          if constexpr (RES) {
+            if constexpr (sizeof(T) == 2) {
+              pv[0] += __uint_as_float((unsigned int)rold[ps] << 16);
+              pv[1] += __uint_as_float((unsigned int)rold[ps] & 0xffff0000u);
+            } else {
+              pv[0] += __uint_as_float((unsigned int)rold[ps]);
+              pv[1] += __uint_as_float((unsigned int)((unsigned long long)rold[ps] >> 32));
+            }
+          }
           VecIO<T, VEC>::store(yn + (long)(gz - 1) * plane_elems + obase[ps], pv);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) {
@@ -670,33 +720,34 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
   issue(zs - 1, stg0);
   if (PF >= 2) issue(zs, stg1);
   if constexpr (PF == 3) issue(zs + 1, stg2);
-  landed(stg0, true);
+  landed(stg0, true, false);
   commit(0, stg0, zs - 1);
   __syncthreads();
   int slot = 0;
+  // residual sets rotate with period 3 like the accumulators: step k requests into set k % 3 and consumes set (k - 1) % 3
   if constexpr (PF == 3) {
     // plane p travels in set (p - (zs-1)) % 3: step k loads plane gz+3 into set k%3, commits plane gz+1 from set (k+1)%3
     for (int gz = zs - 1; gz <= ze; gz += 3) {
-      step(gz, slot, accA, accB, accC, stg0, stg1); slot ^= 1;
-      if (gz + 1 <= ze) { step(gz + 1, slot, accB, accC, accA, stg1, stg2); slot ^= 1; }
-      if (gz + 2 <= ze) { step(gz + 2, slot, accC, accA, accB, stg2, stg0); slot ^= 1; }
+      step(gz, slot, accA, accB, accC, stg0, stg1, rq0, rq2); slot ^= 1;
+      if (gz + 1 <= ze) { step(gz + 1, slot, accB, accC, accA, stg1, stg2, rq1, rq0); slot ^= 1; }
+      if (gz + 2 <= ze) { step(gz + 2, slot, accC, accA, accB, stg2, stg0, rq2, rq1); slot ^= 1; }
     }
   } else if (PF == 1) {
     for (int gz = zs - 1; gz <= ze; gz += 3) {
-      step(gz, slot, accA, accB, accC, stg0, stg0); slot ^= 1;
-      if (gz + 1 <= ze) { step(gz + 1, slot, accB, accC, accA, stg0, stg0); slot ^= 1; }
-      if (gz + 2 <= ze) { step(gz + 2, slot, accC, accA, accB, stg0, stg0); slot ^= 1; }
+      step(gz, slot, accA, accB, accC, stg0, stg0, rq0, rq2); slot ^= 1;
+      if (gz + 1 <= ze) { step(gz + 1, slot, accB, accC, accA, stg0, stg0, rq1, rq0); slot ^= 1; }
+      if (gz + 2 <= ze) { step(gz + 2, slot, accC, accA, accB, stg0, stg0, rq2, rq1); slot ^= 1; }
     }
   } else {
     // plane p travels in stg[(p - (zs-1)) & 1]: step k (gz = zs-1+k) loads plane gz+2 into set k&1 and
     // commits plane gz+1 from set (k+1)&1
     for (int gz = zs - 1; gz <= ze; gz += 6) {
-      step(gz, slot, accA, accB, accC, stg0, stg1); slot ^= 1;
-      if (gz + 1 <= ze) { step(gz + 1, slot, accB, accC, accA, stg1, stg0); slot ^= 1; }
-      if (gz + 2 <= ze) { step(gz + 2, slot, accC, accA, accB, stg0, stg1); slot ^= 1; }
-      if (gz + 3 <= ze) { step(gz + 3, slot, accA, accB, accC, stg1, stg0); slot ^= 1; }
-      if (gz + 4 <= ze) { step(gz + 4, slot, accB, accC, accA, stg0, stg1); slot ^= 1; }
-      if (gz + 5 <= ze) { step(gz + 5, slot, accC, accA, accB, stg1, stg0); slot ^= 1; }
+      step(gz, slot, accA, accB, accC, stg0, stg1, rq0, rq2); slot ^= 1;
+      if (gz + 1 <= ze) { step(gz + 1, slot, accB, accC, accA, stg1, stg0, rq1, rq0); slot ^= 1; }
+      if (gz + 2 <= ze) { step(gz + 2, slot, accC, accA, accB, stg0, stg1, rq2, rq1); slot ^= 1; }
+      if (gz + 3 <= ze) { step(gz + 3, slot, accA, accB, accC, stg1, stg0, rq0, rq2); slot ^= 1; }
+      if (gz + 4 <= ze) { step(gz + 4, slot, accB, accC, accA, stg0, stg1, rq1, rq0); slot ^= 1; }
+      if (gz + 5 <= ze) { step(gz + 5, slot, accC, accA, accB, stg1, stg0, rq2, rq1); slot ^= 1; }
     }
   }
 
@@ -1135,8 +1186,16 @@ static int dispatch_vec(int vec, bool transposed, const void* x, void* y, const 
 }
 
 static int dw_entry(bool transposed, const void* x, void* y, const float* w, const float* bias, float* stats,
-                    int N, int D, int H, int W, int C, int K, int stride, int dtype, void* stream) {
+                    int N, int D, int H, int W, int C, int K, int stride, int dtype, void* stream,
+                    const void* res = nullptr) {
   PYTC_REQUIRE(x && w, "dwconv3d: null pointer");
+  if (res) {      // y = conv(x) + res: the z-march kernel only (stride 1, K = 3, C % 32 == 0, planes >= 16 x 16, depth >= 8)
+    PYTC_REQUIRE(y && !stats, "dwconv3d_res: needs an output and takes no statistics");
+    if (dtype != PYTC_BF16 || !march_ok(D, H, W, C, K, stride, dtype, transposed)) {
+      set_error("dwconv3d_res: bf16 only, shape outside the z-march kernel (N=%d D=%d H=%d W=%d C=%d K=%d stride=%d)", N, D, H, W, C, K, stride);
+      return PYTC_ERR_UNSUPPORTED;
+    }
+  }
   if (!y) {   // statistics-only pass: the K = 3 transposed cell kernel (what the fused up-block path launches)
     DwGeom g0;
     int vec0;
@@ -1157,7 +1216,13 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
 #define PYTC_MARCH(PP, WW) \
   hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, PP, true, WW>), grid, block, 0, (hipStream_t)stream, \
                      (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t)
-    if (dtype == PYTC_BF16) {
+    if (res) {
+      // 8 more live registers than the plain kernel (two residual sets in flight): compiled for 3 waves / SIMD.  At the
+      // 4-waves budget (128 VGPRs) hipcc spills 31 registers, and a spill of a register an asm-issued load is still
+      // writing corrupts the value -- the counted-wait scheme REQUIRES a spill-free kernel (measured: garbage output)
+      hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, 3, true, 3, true>), grid, block, 0, (hipStream_t)stream,
+                         (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t, (const bf16_t*)res);
+    } else if (dtype == PYTC_BF16) {
       switch (variant) {
         case 1: PYTC_MARCH(3, 3); break;
         case 2: PYTC_MARCH(3, 2); break;
@@ -1206,6 +1271,16 @@ extern "C" int pytc_dwconv3d_stat_slots(int N, int D, int H, int W, int C, int K
 extern "C" int pytc_dwconv3d_fwd(const void* x, void* y, const float* w, const float* bias, float* stats, int N,
                                  int D, int H, int W, int C, int K, int stride, int dtype, void* stream) {
   return dw_entry(false, x, y, w, bias, stats, N, D, H, W, C, K, stride, dtype, stream);
+}
+
+extern "C" int pytc_dwconv3d_res_supported(int D, int H, int W, int C, int K, int stride, int dtype) {
+  return (dtype == PYTC_BF16 && march_ok(D, H, W, C, K, stride, dtype, 0)) ? 1 : 0;
+}
+
+extern "C" int pytc_dwconv3d_fwd_res(const void* x, const void* res, void* y, const float* w, const float* bias, int N,
+                                     int D, int H, int W, int C, int K, int stride, int dtype, void* stream) {
+  PYTC_REQUIRE(res, "dwconv3d_res: null residual");
+  return dw_entry(false, x, y, w, bias, nullptr, N, D, H, W, C, K, stride, dtype, stream, res);
 }
 
 extern "C" int pytc_dwconvT3d_fwd(const void* x, void* y, const float* w, const float* bias, float* stats, int N,

@@ -341,6 +341,46 @@ pw_pack_paired_kernel(const float* __restrict__ w, int C_out, int C_in, int tran
   else packed[i] = from_f32<bf16_t>(v);
 }
 
+// Every per-step weight re-layout of a model in ONE launch (training: the weights change at every optimizer step, so the
+// MFMA images of all 1x1x1 convs -- forward and transposed for the data gradients -- and the tap-major depthwise stencils
+// have to be rebuilt once per step; as ~120 separate launches of 5 us kernels they cost 0.8 ms of a 36 ms MedNeXt-S step).
+// table [n_items][8] int64: {src fp32, dst, kind, C_out, C_in, aux, first element, element count}
+//   kind 0 / 1: paired bf16 image of [C_out][C_in] / of a transposed source;  2 / 3: the same as fp16
+//   kind 4: depthwise taps [C][K3] -> [K3][C] fp32 (aux = K3, C_out = C);      5: the same with the stencil reversed
+__global__ void __launch_bounds__(256)
+pack_multi_kernel(const long* __restrict__ table, int n_items, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {                                   // last item whose first element is <= i
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid * 8 + 6] <= i) lo = mid; else hi = mid - 1;
+  }
+  const long* it = table + lo * 8;
+  const float* w = reinterpret_cast<const float*>(it[0]);
+  const int kind = (int)it[2], C_out = (int)it[3], C_in = (int)it[4], aux = (int)it[5];
+  const long e = i - it[6];
+  if (kind >= 4) {
+    const int K3 = aux, C = C_out;
+    const int k = (int)(e / C), c = (int)(e % C);
+    reinterpret_cast<float*>(it[1])[e] = w[(long)c * K3 + (kind == 5 ? K3 - 1 - k : k)];
+    return;
+  }
+  const int KG = aux, transposed = kind & 1;
+  const int j = (int)(e % 8);
+  long t = e / 8;
+  const int lane = (int)(t % 64);
+  t /= 64;
+  const int kg = (int)(t % KG);
+  const int T = (int)(t / KG);
+  const int o = paired_row(T, lane & 15);
+  const int k = kg * 32 + (lane >> 4) * 8 + j;
+  float v = 0.f;
+  if (o < C_out && k < C_in) v = transposed ? w[(long)k * C_out + o] : w[(long)o * C_in + k];
+  if (kind >= 2) reinterpret_cast<_Float16*>(it[1])[e] = (_Float16)v;
+  else reinterpret_cast<bf16_t*>(it[1])[e] = from_f32<bf16_t>(v);
+}
+
 // one-time upload of the GELU table (host double precision; blocking copy, first mixer launch of the process)
 static bool ensure_gelu_lut() {
   static int state = 0;     // 0 = not tried, 1 = ready, -1 = failed
@@ -451,6 +491,14 @@ extern "C" int pytc_pw_pack_weight_paired_f16(const float* w, int C_out, int C_i
   hipLaunchKernelGGL(pw_pack_paired_kernel<_Float16>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
                      C_out, C_in, transposed, (_Float16*)packed, KG, total);
   PYTC_LAUNCH_CHECK("pw_pack_weight_paired_f16");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_pack_multi(const int64_t* table_dev, int n_items, int64_t total_elems, void* stream) {
+  PYTC_REQUIRE(table_dev && n_items >= 1 && total_elems >= 1, "pack_multi: bad arguments");
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(ceil_div(total_elems, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long*>(table_dev), n_items, (long)total_elems);
+  PYTC_LAUNCH_CHECK("pack_multi");
   return PYTC_OK;
 }
 

@@ -334,6 +334,22 @@ pw_wgrad_thin_kernel(const T* __restrict__ big, const T* __restrict__ thin, floa
 
 // out[i] = sum_s part[s][i]: 16 elements x 16 slot lanes per workgroup; lane j adds slots j, j+16, ... in order and
 // the 16 lane sums are added in lane order -> a fixed summation tree, independent of the launch.
+// one slot-lane's share of a [slots][n] -> [n] reduction: slots j, j+16, j+32, ...  Four independent accumulators keep four
+// loads in flight per thread (a 1024-slot reduction was a 64-deep chain of dependent loads); every reduce kernel of the
+// training path uses this function, so immediate, paired, batched and deferred reductions share one summation tree.
+__device__ __forceinline__ float slot_lane_sum(const float* __restrict__ part, long n, long i, int j, int slots) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int s = j;
+  for (; s + 48 < slots; s += 64) {
+    a0 += part[(long)s * n + i];
+    a1 += part[(long)(s + 16) * n + i];
+    a2 += part[(long)(s + 32) * n + i];
+    a3 += part[(long)(s + 48) * n + i];
+  }
+  for (; s < slots; s += 16) a0 += part[(long)s * n + i];
+  return (a0 + a1) + (a2 + a3);
+}
+
 __global__ void __launch_bounds__(256)
 reduce_slots_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int slots) {
   __shared__ float sm[16][17];
@@ -341,7 +357,7 @@ reduce_slots_kernel(const float* __restrict__ part, float* __restrict__ out, lon
   const long i = (long)blockIdx.x * 16 + e;
   float a = 0.f;
   if (i < n)
-    for (int s = j; s < slots; s += 16) a += part[(long)s * n + i];
+    a = slot_lane_sum(part, n, i, j, slots);
   sm[j][e] = a;
   __syncthreads();
   if (j == 0 && i < n) {
@@ -367,7 +383,7 @@ reduce_slots_pair_kernel(const float* __restrict__ partA, float* __restrict__ ou
   const long i = b * 16 + e;
   float a = 0.f;
   if (i < n)
-    for (int s = j; s < slots; s += 16) a += part[(long)s * n + i];
+    a = slot_lane_sum(part, n, i, j, slots);
   sm[j][e] = a;
   __syncthreads();
   if (j == 0 && i < n) {
@@ -384,6 +400,41 @@ static inline void reduce_slots_pair(const float* pA, float* oA, long nA, const 
   hipLaunchKernelGGL(reduce_slots_pair_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pA, oA, nA, pB, oB, oB ? nB : 0, slots);
 }
 
+// several independent slot reductions in ONE launch (the gradients of one block's backward: dW3/db3, dW2/db2, dW1/db1,
+// the norm sums, the residual conv): same per-element tree as reduce_slots_kernel, so deferring changes no bit
+constexpr int REDUCE_MULTI_MAX = 12;
+struct ReduceMulti {
+  const float* part[REDUCE_MULTI_MAX];
+  float* out[REDUCE_MULTI_MAX];
+  long n[REDUCE_MULTI_MAX];
+  int slots[REDUCE_MULTI_MAX];
+  int blk_end[REDUCE_MULTI_MAX];     // exclusive prefix end of each item's block range
+  int count;
+};
+__global__ void __launch_bounds__(256)
+reduce_slots_multi_kernel(ReduceMulti m) {
+  __shared__ float sm[16][17];
+  int k = 0;
+  while (k + 1 < m.count && (int)blockIdx.x >= m.blk_end[k]) ++k;
+  const long b = (long)blockIdx.x - (k ? m.blk_end[k - 1] : 0);
+  const float* __restrict__ part = m.part[k];
+  const long n = m.n[k];
+  const int slots = m.slots[k];
+  const int e = threadIdx.x & 15, j = threadIdx.x >> 4;
+  const long i = b * 16 + e;
+  float a = 0.f;
+  if (i < n)
+    a = slot_lane_sum(part, n, i, j, slots);
+  sm[j][e] = a;
+  __syncthreads();
+  if (j == 0 && i < n) {
+    float t = sm[0][e];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += sm[q][e];
+    m.out[k][i] = t;
+  }
+}
+
 // batched form: blockIdx.y = sample; part [N][slots][n] -> out [N][n]
 __global__ void __launch_bounds__(256)
 reduce_slots_batched_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int slots) {
@@ -394,7 +445,7 @@ reduce_slots_batched_kernel(const float* __restrict__ part, float* __restrict__ 
   const long i = (long)blockIdx.x * 16 + e;
   float a = 0.f;
   if (i < n)
-    for (int s = j; s < slots; s += 16) a += part[(long)s * n + i];
+    a = slot_lane_sum(part, n, i, j, slots);
   sm[j][e] = a;
   __syncthreads();
   if (j == 0 && i < n) {
@@ -772,9 +823,12 @@ static void launch_wgrad_mfma(int nt, dim3 grid, hipStream_t s, const bf16_t* x,
   }
 }
 
-extern "C" int pytc_pw_wgrad(const void* x, const float* ab, const void* dy, float* dW, float* db, float* workspace,
-                             int N, int64_t rows_per_sample, int C_in, int C_out, int dtype, int x_act, void* stream) {
-  PYTC_REQUIRE(x && dy && dW && workspace && N >= 1 && rows_per_sample >= 1, "pw_wgrad: bad arguments");
+// reduce = false: everything but the final slot reduction (`db` then only says whether bias partials are wanted);
+// *slots_out = partial slots written (dW partials at workspace[0 .. slots*C_out*C_in), db partials right after)
+static int pw_wgrad_impl(const void* x, const float* ab, const void* dy, float* dW, float* db, float* workspace,
+                         int N, int64_t rows_per_sample, int C_in, int C_out, int dtype, int x_act, void* stream,
+                         bool reduce, int* slots_out) {
+  PYTC_REQUIRE(x && dy && (dW || !reduce) && workspace && N >= 1 && rows_per_sample >= 1, "pw_wgrad: bad arguments");
   PYTC_REQUIRE(x_act == PYTC_ACT_NONE || x_act == PYTC_ACT_GELU, "pw_wgrad: bad x_act");
   const long rows_total = (long)N * rows_per_sample;
   const int mt = wg_tile16(C_out), nt = wg_tile16(C_in);
@@ -819,8 +873,39 @@ extern "C" int pytc_pw_wgrad(const void* x, const float* ab, const void* dy, flo
                "pw_wgrad")
   }
   const long nW = (long)C_out * C_in;
-  reduce_slots_pair(dWp, dW, nW, dbp, db, (long)C_out, slots, s);
+  if (slots_out) *slots_out = slots;
+  if (reduce) reduce_slots_pair(dWp, dW, nW, dbp, db, (long)C_out, slots, s);
   PYTC_LAUNCH_CHECK("pw_wgrad");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_pw_wgrad(const void* x, const float* ab, const void* dy, float* dW, float* db, float* workspace,
+                             int N, int64_t rows_per_sample, int C_in, int C_out, int dtype, int x_act, void* stream) {
+  return pw_wgrad_impl(x, ab, dy, dW, db, workspace, N, rows_per_sample, C_in, C_out, dtype, x_act, stream, true, nullptr);
+}
+
+extern "C" int pytc_pw_wgrad_partial(const void* x, const float* ab, const void* dy, float* workspace, int want_db, int N,
+                                     int64_t rows_per_sample, int C_in, int C_out, int dtype, int x_act, int* slots_out,
+                                     void* stream) {
+  PYTC_REQUIRE(slots_out, "pw_wgrad_partial: null slots_out");
+  float* db_flag = want_db ? workspace : nullptr;      // non-null = "write bias partials" (never dereferenced as output)
+  return pw_wgrad_impl(x, ab, dy, nullptr, db_flag, workspace, N, rows_per_sample, C_in, C_out, dtype, x_act, stream, false,
+                       slots_out);
+}
+
+extern "C" int pytc_reduce_slots_multi(const pytc_reduce_item* items, int n_items, void* stream) {
+  PYTC_REQUIRE(items && n_items >= 1 && n_items <= REDUCE_MULTI_MAX, "reduce_slots_multi: 1..%d items", REDUCE_MULTI_MAX);
+  ReduceMulti m;
+  int blocks = 0;
+  for (int k = 0; k < n_items; ++k) {
+    PYTC_REQUIRE(items[k].part && items[k].out && items[k].n >= 1 && items[k].slots >= 1, "reduce_slots_multi: bad item %d", k);
+    m.part[k] = items[k].part; m.out[k] = items[k].out; m.n[k] = (long)items[k].n; m.slots[k] = items[k].slots;
+    blocks += (int)((items[k].n + 15) / 16);
+    m.blk_end[k] = blocks;
+  }
+  m.count = n_items;
+  hipLaunchKernelGGL(reduce_slots_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, m);
+  PYTC_LAUNCH_CHECK("reduce_slots_multi");
   return PYTC_OK;
 }
 
@@ -887,10 +972,10 @@ static int launch_dwwg(const void* g, const void* x, float* dWp, float* dbp, con
   return PYTC_OK;
 }
 
-extern "C" int pytc_dw_wgrad(const void* g, const void* x, float* dW, float* db, float* workspace, int N,
-                             const int32_t* gdims, const int32_t* xdims, int C, int K, int stride, int dtype,
-                             void* stream) {
-  PYTC_REQUIRE(g && x && dW && workspace && gdims && xdims, "dw_wgrad: null pointer");
+static int dw_wgrad_impl(const void* g, const void* x, float* dW, float* db, float* workspace, int N,
+                         const int32_t* gdims, const int32_t* xdims, int C, int K, int stride, int dtype,
+                         void* stream, bool reduce, int* slots_out) {
+  PYTC_REQUIRE(g && x && (dW || !reduce) && workspace && gdims && xdims, "dw_wgrad: null pointer");
   const int ms = march_slots(N, gdims, xdims, C, K, stride, dtype);
   if (ms > 0) {
     const long nWm = 27L * C;
@@ -898,7 +983,8 @@ extern "C" int pytc_dw_wgrad(const void* g, const void* x, float* dW, float* db,
     float* dbm = workspace + (long)ms * nWm;
     hipStream_t sm = (hipStream_t)stream;
     dw_wgrad_march_launch(g, x, dWm, db ? dbm : nullptr, N, gdims[0], gdims[1], gdims[2], C, dtype, sm);
-    reduce_slots_pair(dWm, dW, nWm, dbm, db, (long)C, ms, sm);
+    if (slots_out) *slots_out = ms;
+    if (reduce) reduce_slots_pair(dWm, dW, nWm, dbm, db, (long)C, ms, sm);
     PYTC_LAUNCH_CHECK("dw_wgrad");
     return PYTC_OK;
   }
@@ -916,7 +1002,8 @@ extern "C" int pytc_dw_wgrad(const void* g, const void* x, float* dW, float* db,
                hipLaunchKernelGGL(dw_wgrad_vec_kernel<bf16_t>, grid, block, 0, sv, (const bf16_t*)g, (const bf16_t*)x, dWv, db ? dbv : nullptr, q, rps),
                hipLaunchKernelGGL(dw_wgrad_vec_kernel<float>, grid, block, 0, sv, (const float*)g, (const float*)x, dWv, db ? dbv : nullptr, q, rps),
                "dw_wgrad")
-    reduce_slots_pair(dWv, dW, nWv, dbv, db, (long)C, total, sv);
+    if (slots_out) *slots_out = total;
+    if (reduce) reduce_slots_pair(dWv, dW, nWv, dbv, db, (long)C, total, sv);
     PYTC_LAUNCH_CHECK("dw_wgrad");
     return PYTC_OK;
   }
@@ -931,9 +1018,23 @@ extern "C" int pytc_dw_wgrad(const void* g, const void* x, float* dW, float* db,
   if (dtype == PYTC_BF16) rc = vec == 4 ? launch_dwwg<bf16_t, 4>(g, x, dWp, dbp, q, s) : vec == 2 ? launch_dwwg<bf16_t, 2>(g, x, dWp, dbp, q, s) : launch_dwwg<bf16_t, 1>(g, x, dWp, dbp, q, s);
   else rc = vec == 2 ? launch_dwwg<float, 2>(g, x, dWp, dbp, q, s) : launch_dwwg<float, 1>(g, x, dWp, dbp, q, s);
   if (rc != PYTC_OK) return rc;
-  reduce_slots_pair(dWp, dW, nW, dbp, db, (long)C, total_slots, s);
+  if (slots_out) *slots_out = total_slots;
+  if (reduce) reduce_slots_pair(dWp, dW, nW, dbp, db, (long)C, total_slots, s);
   PYTC_LAUNCH_CHECK("dw_wgrad");
   return PYTC_OK;
+}
+
+extern "C" int pytc_dw_wgrad(const void* g, const void* x, float* dW, float* db, float* workspace, int N,
+                             const int32_t* gdims, const int32_t* xdims, int C, int K, int stride, int dtype,
+                             void* stream) {
+  return dw_wgrad_impl(g, x, dW, db, workspace, N, gdims, xdims, C, K, stride, dtype, stream, true, nullptr);
+}
+
+extern "C" int pytc_dw_wgrad_partial(const void* g, const void* x, float* workspace, int want_db, int N, const int32_t* gdims,
+                                     const int32_t* xdims, int C, int K, int stride, int dtype, int* slots_out, void* stream) {
+  PYTC_REQUIRE(slots_out, "dw_wgrad_partial: null slots_out");
+  return dw_wgrad_impl(g, x, nullptr, want_db ? workspace : nullptr, workspace, N, gdims, xdims, C, K, stride, dtype, stream,
+                       false, slots_out);
 }
 
 extern "C" int pytc_norm_bwd(const void* dtn, const void* t, const float* mean_rstd, const float* gamma,

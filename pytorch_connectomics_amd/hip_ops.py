@@ -260,6 +260,24 @@ def dwconv3d(x: torch.Tensor, w_taps: torch.Tensor, bias: Optional[torch.Tensor]
     return y, st
 
 
+def dwconv3d_res_supported(x: torch.Tensor, K: int, stride: int = 1) -> bool:
+    N, D, H, W, Cc = x.shape
+    return bool(nat.lib().pytc_dwconv3d_res_supported(D, H, W, Cc, K, stride, dtype_code(x.dtype)))
+
+
+def dwconv3d_res(x: torch.Tensor, w_taps: torch.Tensor, res: torch.Tensor, *, K: int = 3) -> torch.Tensor:
+    """y = dwconv3d(x, taps) + res in one kernel (bf16, z-march shapes: dwconv3d_res_supported); the data gradient of a residual
+    block.  The residual is added to the fp32 accumulator: one rounding, where dwconv3d followed by add_ has two."""
+    _dev(x, "x"); _dev(res, "res"); _dev(w_taps, "w_taps")
+    if res.shape != x.shape or res.dtype != x.dtype:
+        raise ValueError("dwconv3d_res: the residual must match the (stride-1) output shape and dtype")
+    N, D, H, W, Cc = x.shape
+    y = torch.empty_like(x)
+    _run(f"dwconv3d_res[C{Cc}_k{K}]", _nbytes(x, y, res), nat.lib().pytc_dwconv3d_fwd_res, _p(x), _p(res), _p(y), _p(w_taps), None,
+         N, D, H, W, Cc, K, 1, dtype_code(x.dtype), _stream())
+    return y
+
+
 def layernorm_rows(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float = 1e-5) -> torch.Tensor:
     """Channels-first LayerNorm of MedNeXt: x (..., C) normalised over C per voxel row."""
     _dev(x, "x")
@@ -353,6 +371,87 @@ def pw_pack_weight_paired(w: torch.Tensor, *, transposed: bool = False, f16: boo
     fn = nat.lib().pytc_pw_pack_weight_paired_f16 if f16 else nat.lib().pytc_pw_pack_weight_paired
     _run("pw_pack_weight_paired", _nbytes(w, packed), fn, _p(w), c_out, c_in, int(transposed), _p(packed), _stream())
     return packed
+
+
+PACK_PAIRED, PACK_PAIRED_T, PACK_PAIRED_F16, PACK_PAIRED_F16_T, PACK_TAPS, PACK_TAPS_FLIPPED = range(6)
+
+
+class StepPacks:
+    """The per-step weight re-layouts of ONE model (MFMA images of its 1x1x1 convs, tap-major depthwise stencils), rebuilt by
+    a single launch per optimizer step (pytc_pack_multi) instead of one launch each.  Training code asks `lookup(w, kind)`;
+    a miss is served by the individual pack function and `register`ed, so the set fills itself during the first step and
+    `refresh()` -- called at the start of every training forward -- repacks everything whose parameter version moved.
+    Entries hold a reference to their source weight, so a data pointer identifies a parameter for the life of the set."""
+
+    def __init__(self):
+        self.rows = []          # [src weight, out, kind, C_out, C_in, aux, n_elems, version]
+        self.index = {}
+        self.table = None
+        self.total = 0
+
+    def lookup(self, w: torch.Tensor, kind: int):
+        i = self.index.get((w.data_ptr(), kind))
+        if i is None:
+            return None
+        row = self.rows[i]
+        return row[1] if row[7] == w._version else None
+
+    def register(self, w: torch.Tensor, kind: int, out: torch.Tensor, c_out: int, c_in: int, aux: int) -> None:
+        key = (w.data_ptr(), kind)
+        i = self.index.get(key)
+        row = [w, out, int(kind), int(c_out), int(c_in), int(aux), int(out.numel()), w._version]
+        if i is None:
+            self.index[key] = len(self.rows)
+            self.rows.append(row)
+        else:
+            self.rows[i] = row
+        self.table = None       # rebuilt (one small upload) at the next refresh
+
+    def refresh(self) -> None:
+        if not self.rows or all(r[7] == r[0]._version for r in self.rows):
+            return
+        dev = self.rows[0][1].device
+        if self.table is None:
+            flat, pos = [], 0
+            for src, out, kind, c_out, c_in, aux, n, _ver in self.rows:
+                flat += [src.data_ptr(), out.data_ptr(), kind, c_out, c_in, aux, pos, n]
+                pos += n
+            self.table = torch.tensor(flat, dtype=torch.int64).to(dev)
+            self.total = pos
+        _run("pack_multi", self.total * 6, nat.lib().pytc_pack_multi, _p(self.table), len(self.rows), self.total, _stream())
+        for r in self.rows:
+            r[7] = r[0]._version
+
+
+def packed_paired(w_mat: torch.Tensor, *, transposed: bool = False, f16: bool = False, packs: Optional[StepPacks] = None):
+    """pw_pack_weight_paired through a StepPacks set (w_mat: the fp32 (C_a, C_b) matrix view of the parameter)."""
+    if packs is None:
+        return pw_pack_weight_paired(w_mat, transposed=transposed, f16=f16)
+    kind = (PACK_PAIRED_F16 if f16 else PACK_PAIRED) + (1 if transposed else 0)
+    hit = packs.lookup(w_mat, kind)
+    if hit is not None:
+        return hit
+    out = pw_pack_weight_paired(w_mat, transposed=transposed, f16=f16)
+    c_out, c_in = (w_mat.shape[1], w_mat.shape[0]) if transposed else (w_mat.shape[0], w_mat.shape[1])
+    packs.register(w_mat, kind, out, c_out, c_in, (c_in + 31) // 32)
+    return out
+
+
+def packed_taps(w: torch.Tensor, *, flipped: bool = False, packs: Optional[StepPacks] = None) -> torch.Tensor:
+    """Depthwise conv weight (C, 1, k, k, k) fp32 -> tap-major (k^3, C) fp32 (reversed stencil when `flipped`)."""
+    c, k3 = w.shape[0], w.shape[-1] ** 3
+    src = w.detach()
+    kind = PACK_TAPS_FLIPPED if flipped else PACK_TAPS
+    if packs is not None and src.dtype == torch.float32 and src.is_contiguous():
+        hit = packs.lookup(src, kind)
+        if hit is not None:
+            return hit
+    out = src.float().reshape(c, k3).t().contiguous()
+    if flipped:
+        out = torch.flip(out, dims=[0]).contiguous()
+    if packs is not None and src.dtype == torch.float32 and src.is_contiguous():
+        packs.register(src, kind, out, c, 1, k3)
+    return out
 
 
 def _w3_format(w3p: torch.Tensor) -> int:
@@ -810,30 +909,80 @@ def set_tuning(key: str, value: int) -> None:
     nat.check(nat.lib().pytc_set_tuning(key.encode(), int(value)), "set_tuning")
 
 
+class DeferredReduce:
+    """Collects the slot partials of several weight gradients (and any other [slots][n] -> [n] sums) of one backward
+    function and reduces them in ONE launch (pytc_reduce_slots_multi) instead of one launch per gradient.  The outputs are
+    valid after flush(); results are bit-identical to the immediate reductions."""
+
+    MAX_ITEMS = 12
+
+    def __init__(self):
+        self.items = []       # (partials view, out, n, slots)
+        self.keep = []        # workspaces the partial views live in
+
+    def add(self, part: torch.Tensor, out: torch.Tensor, n: int, slots: int, keep=None) -> None:
+        self.items.append((part, out, int(n), int(slots)))
+        if keep is not None:
+            self.keep.append(keep)
+
+    def flush(self) -> None:
+        for b0 in range(0, len(self.items), self.MAX_ITEMS):
+            chunk = self.items[b0:b0 + self.MAX_ITEMS]
+            arr = (nat.ReduceItem * len(chunk))()
+            for i, (part, out, n, slots) in enumerate(chunk):
+                arr[i].part, arr[i].out, arr[i].n, arr[i].slots = part.data_ptr(), out.data_ptr(), n, slots
+            _run("reduce_slots_multi", sum(4 * n * (s + 1) for _p0, _o, n, s in chunk), nat.lib().pytc_reduce_slots_multi, arr,
+                 len(chunk), _stream())
+        self.items, self.keep = [], []
+
+
 def pw_wgrad(x: torch.Tensor, dy: torch.Tensor, *, N: int, rows_per_sample: int, c_in: int, c_out: int,
-             ab: Optional[torch.Tensor] = None, want_bias: bool = True, x_act: int = nat.ACT_NONE):
-    """-> dW (c_out, c_in) fp32, db (c_out) fp32 | None;  x_act=ACT_GELU: the GEMM operand is gelu(x)"""
+             ab: Optional[torch.Tensor] = None, want_bias: bool = True, x_act: int = nat.ACT_NONE,
+             defer: Optional[DeferredReduce] = None):
+    """-> dW (c_out, c_in) fp32, db (c_out) fp32 | None;  x_act=ACT_GELU: the GEMM operand is gelu(x).  With `defer` the
+    slot reduction joins that object's single launch: dW / db hold their values only after defer.flush()."""
     _dev(x, "x"); _dev(dy, "dy")
     slots = nat.lib().pytc_pw_wgrad_slots(N * rows_per_sample)
-    ws = torch.empty((slots * (c_out * c_in + c_out),), dtype=torch.float32, device=x.device)
+    nW = c_out * c_in
+    ws = torch.empty((slots * (nW + c_out),), dtype=torch.float32, device=x.device)
     dW = torch.empty((c_out, c_in), dtype=torch.float32, device=x.device)
     db = torch.empty((c_out,), dtype=torch.float32, device=x.device) if want_bias else None
+    if defer is not None:
+        used = C.c_int(0)
+        _run(f"pw_wgrad[{c_in}->{c_out}]", _nbytes(x, dy), nat.lib().pytc_pw_wgrad_partial, _p(x), _p(ab), _p(dy), _p(ws),
+             int(want_bias), N, rows_per_sample, c_in, c_out, dtype_code(x.dtype), int(x_act), C.byref(used), _stream())
+        u = int(used.value)
+        defer.add(ws[:u * nW], dW, nW, u, keep=ws)
+        if want_bias:
+            defer.add(ws[u * nW:u * (nW + c_out)], db, c_out, u)
+        return dW, db
     _run(f"pw_wgrad[{c_in}->{c_out}]", _nbytes(x, dy), nat.lib().pytc_pw_wgrad, _p(x), _p(ab), _p(dy), _p(dW), _p(db),
          _p(ws), N, rows_per_sample, c_in, c_out, dtype_code(x.dtype), int(x_act), _stream())
     return dW, db
 
 
-def dw_wgrad(g: torch.Tensor, x: torch.Tensor, *, K: int, stride: int = 1, want_bias: bool = True):
-    """g (N,*gdims,C), x (N,*xdims,C) -> dW (K^3, C) fp32, db (C) | None   (see pytc_dw_wgrad)"""
+def dw_wgrad(g: torch.Tensor, x: torch.Tensor, *, K: int, stride: int = 1, want_bias: bool = True,
+             defer: Optional[DeferredReduce] = None):
+    """g (N,*gdims,C), x (N,*xdims,C) -> dW (K^3, C) fp32, db (C) | None   (see pytc_dw_wgrad); `defer` as in pw_wgrad"""
     _dev(g, "g"); _dev(x, "x")
     N, Cc = g.shape[0], g.shape[-1]
     gd, xd = _i3(g.shape[1:4]), _i3(x.shape[1:4])
     slots = nat.lib().pytc_dw_wgrad_slots(N, gd, xd, Cc, K, stride, dtype_code(g.dtype))
     if slots < 0:
         raise RuntimeError(f"dw_wgrad: unsupported channel count {Cc}")
-    ws = torch.empty((slots * (K ** 3 * Cc + Cc),), dtype=torch.float32, device=g.device)
+    nW = K ** 3 * Cc
+    ws = torch.empty((slots * (nW + Cc),), dtype=torch.float32, device=g.device)
     dW = torch.empty((K ** 3, Cc), dtype=torch.float32, device=g.device)
     db = torch.empty((Cc,), dtype=torch.float32, device=g.device) if want_bias else None
+    if defer is not None:
+        used = C.c_int(0)
+        _run(f"dw_wgrad[C{Cc}_k{K}]", _nbytes(g, x), nat.lib().pytc_dw_wgrad_partial, _p(g), _p(x), _p(ws), int(want_bias), N,
+             gd, xd, Cc, K, stride, dtype_code(g.dtype), C.byref(used), _stream())
+        u = int(used.value)
+        defer.add(ws[:u * nW], dW, nW, u, keep=ws)
+        if want_bias:
+            defer.add(ws[u * nW:u * (nW + Cc)], db, Cc, u)
+        return dW, db
     _run(f"dw_wgrad[C{Cc}_k{K}]", _nbytes(g, x), nat.lib().pytc_dw_wgrad, _p(g), _p(x), _p(dW), _p(db), _p(ws), N, gd, xd,
          Cc, K, stride, dtype_code(g.dtype), _stream())
     return dW, db

@@ -29,11 +29,28 @@ FUSED_TRAIN_MIXER = True
 # but measured slower than the two launches it replaces (503 vs ~440 us at 4x112^3, level 0: the exact GELU' between the
 # GEMMs sits on the MFMA critical path instead of in a store epilogue) -> off
 FUSED_TRAIN_MIXER_BWD = False
+# data gradient of a residual block, dx = conv_reversed(dt) + dy, with the "+ dy" inside the depthwise kernel (bf16, z-march
+# shapes) instead of a separate read-modify-write pass over dx
+FUSED_RESIDUAL_DGRAD = True
 
 
-def _taps(w: torch.Tensor):
-    c, k = w.shape[0], w.shape[-1]
-    return w.detach().float().reshape(c, k ** 3).t().contiguous(), k
+# every per-step weight re-layout (MFMA images, tap-major stencils) of a model is rebuilt by ONE launch: the StepPacks set of
+# the trunk whose training forward runs (ops.StepPacks; False: one pack launch per use, ~120 per MedNeXt-S step)
+BATCHED_WEIGHT_PACKS = True
+
+
+def _packs_of(owner):
+    if not BATCHED_WEIGHT_PACKS:
+        return None
+    ps = getattr(owner, "_step_packs", None)
+    if ps is None:
+        ps = ops.StepPacks()
+        object.__setattr__(owner, "_step_packs", ps)      # not a parameter / buffer / sub-module
+    return ps
+
+
+def _taps(w: torch.Tensor, packs=None, flipped: bool = False):
+    return ops.packed_taps(w, flipped=flipped, packs=packs), w.shape[-1]
 
 
 def _mat(w: torch.Tensor) -> torch.Tensor:
@@ -48,15 +65,15 @@ def _rows(t: torch.Tensor) -> int:
     return t.shape[1] * t.shape[2] * t.shape[3]
 
 
-def _pw(x, w_mat, bias, *, c_out, out_dtype=None, transposed=False, **kw):
-    """y = pw_conv with freshly packed weights (weights change every step during training)."""
+def _pw(x, w_mat, bias, *, c_out, out_dtype=None, transposed=False, packs=None, **kw):
+    """y = pw_conv with this step's packed weights (they change at every optimizer step; `packs`: the model's StepPacks)."""
     dt = x.dtype if x.dtype == torch.bfloat16 or out_dtype != torch.bfloat16 else torch.bfloat16
     wdt = torch.bfloat16 if (x.dtype == torch.bfloat16 or out_dtype == torch.bfloat16) else torch.float32
     odt = out_dtype or x.dtype
     paired = wdt == torch.bfloat16 and ops.pw_conv_paired_supported(
         c_in=x.shape[-1], c_out=c_out, in_dtype=x.dtype, out_dtype=odt, act=kw.get("act", nat.ACT_NONE),
         gather=kw.get("gather", 0))
-    wp = ops.pw_pack_weight_paired(w_mat, transposed=transposed) if paired else ops.pw_pack_weight(w_mat, wdt, transposed=transposed)
+    wp = ops.packed_paired(w_mat, transposed=transposed, packs=packs) if paired else ops.pw_pack_weight(w_mat, wdt, transposed=transposed)
     N = x.shape[0]
     rows = kw.pop("rows", None) or x.numel() // (N * x.shape[-1])
     y = ops.pw_conv(x, wp, bias, N=N, rows_per_sample=rows, c_in=x.shape[-1], c_out=c_out,
@@ -68,11 +85,12 @@ class PointwiseFn(torch.autograd.Function):
     """y = W x + b on channels-last rows (stem, output heads, task-head projections)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, transposed: bool, out_dtype):
+    def forward(ctx, x, weight, bias, transposed: bool, out_dtype, packs=None):
         w = _mat(weight)                              # (a, b) as stored
         c_out = w.shape[1] if transposed else w.shape[0]
-        y = _pw(x, w, _f(bias), c_out=c_out, out_dtype=out_dtype, transposed=transposed)
+        y = _pw(x, w, _f(bias), c_out=c_out, out_dtype=out_dtype, transposed=transposed, packs=packs)
         ctx.save_for_backward(x, weight)
+        ctx.packs = packs
         ctx.meta = (transposed, bias is not None, c_out)
         return y.view(*x.shape[:-1], c_out)
 
@@ -92,7 +110,55 @@ class PointwiseFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             # dX = dY . W : operator c_out -> c_in with matrix W^T
-            dx = _pw(dyx, w, None, c_out=c_in, transposed=not transposed).view_as(x)
+            dx = _pw(dyx, w, None, c_out=c_in, transposed=not transposed, packs=ctx.packs).view_as(x)
+        xin = x if x.dtype == dyx.dtype else x.to(dyx.dtype)
+        dW, db = ops.pw_wgrad(xin.contiguous(), dyx, N=N, rows_per_sample=rows, c_in=c_in, c_out=c_out,
+                              want_bias=has_bias)
+        dW = dW.t().contiguous() if transposed else dW
+        return (dx, torch.empty_like(weight).copy_(dW.reshape(weight.shape)), (db.to(weight.dtype) if has_bias else None),
+                None, None, None)
+
+
+class BlockFn(torch.autograd.Function):
+    """MedNeXt block / down block / up block.  `kind` in {"block", "down", "up"}.  `recompute` = the reference's
+    `outside_block` activation checkpointing (mednext_models.py:386-393: torch.utils.checkpoint around every block): only the
+    block input and the (N, 2, C) norm vectors are kept; the depthwise output and the hidden pre-activation are rebuilt by
+    the same kernels at the start of the backward (bit-identical values, one extra block forward)."""
+
+    @staticmethod
+    def forward(ctx, x, skip, w1, b1, gamma, beta, w2, b2, w3, b3, wres, bres, kind: str, do_res: bool, eps: float,
+                recompute: bool = False, packs=None):
+        ctx.packs = packs
+        y, t, ab, mr, hp, taps, K, count = BlockFn._core(x, skip, w1, b1, gamma, beta, w2, b2, w3, b3, wres, bres, kind,
+                                                         do_res, eps, None, packs)
+        keep = x.new_zeros(0)
+        ctx.save_for_backward(x, keep if recompute else t, ab, mr, keep if recompute else hp, w1, gamma, w2, w3,
+                              wres if wres is not None else keep, skip if (recompute and skip is not None) else keep,
+                              b1 if (recompute and b1 is not None) else keep, b2 if recompute else keep, b3 if recompute else keep,
+                              bres if (recompute and bres is not None) else keep)
+        ctx.meta = (kind, do_res, K, count, wres is not None, skip is not None, b1 is not None, bres is not None, recompute, eps,
+                    b2 is not None, b3 is not None)
+        ctx.taps = taps                  # derived from w1 (no gradient flows through it): reused by the backward
+        return y
+
+    @staticmethod
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        transposed, has_bias, c_out = ctx.meta
+        w = _mat(weight)
+        c_in = x.shape[-1]
+        N = x.shape[0]
+        rows = x.numel() // (N * c_in)
+        dyc = dy.contiguous()
+        if dyc.dtype != x.dtype and x.dtype in (torch.float32, torch.bfloat16):
+            dyx = dyc.to(x.dtype)
+        else:
+            dyx = dyc
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # dX = dY . W : operator c_out -> c_in with matrix W^T
+            dx = _pw(dyx, w, None, c_out=c_in, transposed=not transposed, packs=ctx.packs).view_as(x)
         xin = x if x.dtype == dyx.dtype else x.to(dyx.dtype)
         dW, db = ops.pw_wgrad(xin.contiguous(), dyx, N=N, rows_per_sample=rows, c_in=c_in, c_out=c_out,
                               want_bias=has_bias)
@@ -109,9 +175,10 @@ class BlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, skip, w1, b1, gamma, beta, w2, b2, w3, b3, wres, bres, kind: str, do_res: bool, eps: float,
-                recompute: bool = False):
+                recompute: bool = False, packs=None):
+        ctx.packs = packs
         y, t, ab, mr, hp, taps, K, count = BlockFn._core(x, skip, w1, b1, gamma, beta, w2, b2, w3, b3, wres, bres, kind,
-                                                         do_res, eps, None)
+                                                         do_res, eps, None, packs)
         keep = x.new_zeros(0)
         ctx.save_for_backward(x, keep if recompute else t, ab, mr, keep if recompute else hp, w1, gamma, w2, w3,
                               wres if wres is not None else keep, skip if (recompute and skip is not None) else keep,
@@ -123,12 +190,12 @@ class BlockFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    def _core(x, skip, w1, b1, gamma, beta, w2, b2, w3, b3, wres, bres, kind, do_res, eps, ab_mr):
+    def _core(x, skip, w1, b1, gamma, beta, w2, b2, w3, b3, wres, bres, kind, do_res, eps, ab_mr, packs=None):
         """The block's forward kernels.  ab_mr = (ab, mr) of an earlier identical call: the statistics pass is skipped
         (recomputation inside the backward)."""
         N, D, H, W, C = x.shape
         dt = x.dtype
-        taps, K = _taps(w1)
+        taps, K = _taps(w1, packs)
         if kind == "up":
             t, st = ops.dwconv3d(x, taps, _f(b1), K=K, transposed=True, stats=ab_mr is None)
             count = float((2 * D - 1) * (2 * H - 1) * (2 * W - 1))
@@ -143,10 +210,14 @@ class BlockFn(torch.autograd.Function):
         if fused:
             # one launch: norm affine -> expand -> (store pre-activation hp) -> GELU -> project -> residual epilogue
             hp = torch.empty((N, rows, c_hid), dtype=dt, device=x.device)
-            w2p, w3p = ops.pw_pack_weight_paired(_mat(w2)), ops.pw_pack_weight_paired(_mat(w3), f16=ops.MLP_F16_PROJECT)
+            w2p = ops.packed_paired(_mat(w2), packs=packs)
+            # bf16 image: the hidden-storing training forward measured FASTER with the bf16 sigmoid-form GELU than with the
+            # packed-fp16 one (357 vs 395 us at 32->64->32: the stored pre-activation is rounded to bf16 and read back first,
+            # and the extra conversions cost the kernel its 4th wave per SIMD), unlike the inference mixers
+            w3p = ops.packed_paired(_mat(w3), packs=packs)
             mk = dict(N=N, rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out, hidden_pre=hp)
         else:
-            hp = _pw(t, _mat(w2), _f(b2), c_out=c_hid, ab=ab, rows=rows)              # pre-activation (saved)
+            hp = _pw(t, _mat(w2), _f(b2), c_out=c_hid, ab=ab, rows=rows, packs=packs)              # pre-activation (saved)
         h, G = hp, dict(pre_act=nat.ACT_GELU)       # GELU runs in the operand prologue of the projecting GEMM
         res_low = None
         if kind == "block":
@@ -155,38 +226,39 @@ class BlockFn(torch.autograd.Function):
                                res_mode=nat.RES_ADD if do_res else nat.RES_NONE, **mk)
             else:
                 y = _pw(h, _mat(w3), _f(b3), c_out=c_out, rows=rows, res=x if do_res else None,
-                        res_mode=nat.RES_ADD if do_res else nat.RES_NONE, **G)
+                        res_mode=nat.RES_ADD if do_res else nat.RES_NONE, packs=packs, **G)
         elif kind == "down":
             r = None
             if wres is not None:
-                r = _pw(x, _mat(wres), _f(bres), c_out=c_out, rows=rows, gather=2, grid=(D, H, W))
+                r = _pw(x, _mat(wres), _f(bres), c_out=c_out, rows=rows, gather=2, grid=(D, H, W), packs=packs)
             if fused:
                 y = ops.pw_mlp(t, ab, w2p, _f(b2), w3p, _f(b3), res=r, res_mode=nat.RES_ADD if r is not None else nat.RES_NONE, **mk)
             else:
                 y = _pw(h, _mat(w3), _f(b3), c_out=c_out, rows=rows, res=r,
-                        res_mode=nat.RES_ADD if r is not None else nat.RES_NONE, **G)
+                        res_mode=nat.RES_ADD if r is not None else nat.RES_NONE, packs=packs, **G)
         else:
             if wres is not None:
-                res_low = _pw(x, _mat(wres), _f(bres), c_out=c_out, transposed=True)
+                res_low = _pw(x, _mat(wres), _f(bres), c_out=c_out, transposed=True, packs=packs)
             sk = skip if skip is not None else torch.zeros((N,) + tuple(t.shape[1:4]) + (c_out,), dtype=dt, device=x.device)
             if fused:
                 y = ops.pw_mlp(t, ab, w2p, _f(b2), w3p, _f(b3), res=sk, res_mode=nat.RES_UPSAMPLE, grid=tuple(t.shape[1:4]),
                                res_low=res_low, res_bias=_f(bres) if wres is not None else None, **mk)
             else:
                 y = _pw(h, _mat(w3), _f(b3), c_out=c_out, rows=rows, res=sk, res_mode=nat.RES_UPSAMPLE,
-                        grid=tuple(t.shape[1:4]), res_low=res_low, res_bias=_f(bres) if wres is not None else None, **G)
+                        grid=tuple(t.shape[1:4]), res_low=res_low, res_bias=_f(bres) if wres is not None else None, packs=packs, **G)
         return y.view(N, *t.shape[1:4], c_out), t, ab, mr, hp, taps, K, count
 
     @staticmethod
     def backward(ctx, dy):
         x, t, ab, mr, hp, w1, gamma, w2, w3, wres, skip_s, b1_s, b2_s, b3_s, bres_s = ctx.saved_tensors
         kind, do_res, K, count, has_res, has_skip, has_b1, has_bres, recompute, eps, has_b2, has_b3 = ctx.meta
+        packs = ctx.packs
         if recompute:
             # outside-block checkpointing: rebuild t and the hidden pre-activation with the forward's own kernels
             with torch.no_grad():
                 _y, t, _ab, _mr, hp, _taps_, _K, _c = BlockFn._core(
                     x, skip_s if (has_skip and skip_s.numel()) else None, w1, b1_s if has_b1 else None, gamma, None, w2, b2_s, w3,
-                    b3_s, wres if has_res else None, bres_s if has_bres else None, kind, do_res, eps, (ab, mr))
+                    b3_s, wres if has_res else None, bres_s if has_bres else None, kind, do_res, eps, (ab, mr), packs)
             del _y
         N, D, H, W, C = x.shape
         dy = dy.contiguous()
@@ -200,57 +272,65 @@ class BlockFn(torch.autograd.Function):
             dcore[:, 0] = 0
             dcore[:, :, 0] = 0
             dcore[:, :, :, 0] = 0
+        # every slot reduction of this block's gradients (dW3/db3, dW2/db2, the norm sums, dW1/db1, the residual conv) joins
+        # ONE launch at the end (ops.DeferredReduce): ~5 tiny launches per block become 1, bit-identical results
+        dr = ops.DeferredReduce()
         # ---- project: y = W3 h + b3
-        dW3, db3 = ops.pw_wgrad(hp, dcore, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, x_act=nat.ACT_GELU)
+        dW3, db3 = ops.pw_wgrad(hp, dcore, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, x_act=nat.ACT_GELU, defer=dr)
         fused_bwd = (dy.dtype == torch.bfloat16 and FUSED_TRAIN_MIXER_BWD and ops.pw_mlp_supported(c_out, c_hid, C))
         if fused_bwd:
             # both data-gradient GEMMs in one launch: dtn = W2^T ((W3^T dy) * gelu'(hp)); dhp comes back for wgrad2
-            dtn, dhp = ops.pw_mlp_bwd(dcore.view(N, rows, c_out), hp, ops.pw_pack_weight_paired(_mat(w3), transposed=True),
-                                      ops.pw_pack_weight_paired(_mat(w2), transposed=True), N=N, rows_per_sample=rows,
+            dtn, dhp = ops.pw_mlp_bwd(dcore.view(N, rows, c_out), hp, ops.packed_paired(_mat(w3), transposed=True, packs=packs),
+                                      ops.packed_paired(_mat(w2), transposed=True, packs=packs), N=N, rows_per_sample=rows,
                                       c_in=C, c_hid=c_hid, c_out=c_out)
-            dW2, db2 = ops.pw_wgrad(t, dhp, N=N, rows_per_sample=rows, c_in=C, c_out=c_hid, ab=ab)
+            dW2, db2 = ops.pw_wgrad(t, dhp, N=N, rows_per_sample=rows, c_in=C, c_out=c_hid, ab=ab, defer=dr)
         else:
             # dhp = (W3^T dy) * gelu'(hp): the GELU derivative is the epilogue of the data-gradient GEMM
-            dhp = _pw(dcore, _mat(w3), None, c_out=c_hid, transposed=True, rows=rows, res=hp, res_mode=nat.RES_GELU_BWD)
+            dhp = _pw(dcore, _mat(w3), None, c_out=c_hid, transposed=True, rows=rows, res=hp, res_mode=nat.RES_GELU_BWD, packs=packs)
             # ---- expand: hp = W2 (a t + b) + b2
-            dW2, db2 = ops.pw_wgrad(t, dhp, N=N, rows_per_sample=rows, c_in=C, c_out=c_hid, ab=ab)
-            dtn = _pw(dhp, _mat(w2), None, c_out=C, transposed=True, rows=rows)
+            dW2, db2 = ops.pw_wgrad(t, dhp, N=N, rows_per_sample=rows, c_in=C, c_out=c_hid, ab=ab, defer=dr)
+            dtn = _pw(dhp, _mat(w2), None, c_out=C, transposed=True, rows=rows, packs=packs)
         del dhp
         # ---- GroupNorm(C, C)
         dt_, s = ops.norm_bwd(dtn, t, mr, _f(gamma), count=count)
-        ssum = s.sum(0)                  # (2, C): one reduction for both vectors
+        ssum = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        dr.add(s, ssum, 2 * C, N)        # (N, 2, C) -> (2, C): the samples are the "slots"
         dgamma, dbeta = ssum[1], ssum[0]
         del dtn
         # ---- depthwise conv
         dwres = dbres = None
         if kind == "block":
-            dW1, db1 = ops.dw_wgrad(dt_.view_as(t), x, K=K, stride=1)
-            flipped = torch.flip(taps, dims=[0]).contiguous()      # correlation with the reversed stencil
-            dx, _ = ops.dwconv3d(dt_.view_as(t), flipped, None, K=K, stride=1, stats=False)
-            if do_res:
-                ops.add_(dx, dy)
+            dW1, db1 = ops.dw_wgrad(dt_.view_as(t), x, K=K, stride=1, defer=dr)
+            flipped, _ = _taps(w1, packs, flipped=True)             # correlation with the reversed stencil
+            gt = dt_.view_as(t)
+            if do_res and FUSED_RESIDUAL_DGRAD and ops.dwconv3d_res_supported(gt, K, 1):
+                dx = ops.dwconv3d_res(gt, flipped, dy, K=K)        # dx = conv_reversed(dt) + dy in the conv kernel's epilogue
+            else:
+                dx, _ = ops.dwconv3d(gt, flipped, None, K=K, stride=1, stats=False)
+                if do_res:
+                    ops.add_(dx, dy)
         elif kind == "down":
-            dW1, db1 = ops.dw_wgrad(dt_.view_as(t), x, K=K, stride=2)
+            dW1, db1 = ops.dw_wgrad(dt_.view_as(t), x, K=K, stride=2, defer=dr)
             dx = ops.dwconv3d_bwd_data(dt_.view_as(t), taps, (D, H, W), K=K, stride=2)
             if has_res:
                 xg = x[:, ::2, ::2, ::2, :].contiguous()
-                dwres, dbres = ops.pw_wgrad(xg, dy, N=N, rows_per_sample=rows, c_in=C, c_out=c_out)
-                dxg = _pw(dy, _mat(wres), None, c_out=C, transposed=True, rows=rows).view_as(xg)
-                full = torch.zeros_like(dx)
-                full[:, ::2, ::2, ::2, :] = dxg
-                ops.add_(dx, full)
+                dwres, dbres = ops.pw_wgrad(xg, dy, N=N, rows_per_sample=rows, c_in=C, c_out=c_out, defer=dr)
+                dxg = _pw(dy, _mat(wres), None, c_out=C, transposed=True, rows=rows, packs=packs).view_as(xg)
+                dx[:, ::2, ::2, ::2, :] += dxg         # strided in-place add: only the 1/8 of dx the 1x1x1 stride-2 conv read
         else:
             dtp = dt_.view_as(t)
             dtc = dtp[:, 1:, 1:, 1:, :].contiguous()                # compact (2D-1)^3 grid of the transposed conv
-            dW1, _ = ops.dw_wgrad(x, dtc, K=K, stride=2, want_bias=False)
+            dW1, _ = ops.dw_wgrad(x, dtc, K=K, stride=2, want_bias=False, defer=dr)
             db1 = ops.channel_stats(dtc).sum(1)[:, 0].sum(0)
             dx, _ = ops.dwconv3d(dtc, taps, None, K=K, stride=2, stats=False)
             if has_res:
                 drl = dy[:, 1::2, 1::2, 1::2, :].contiguous()       # positions fed by the transposed 1x1 conv
-                dwres_m, _ = ops.pw_wgrad(x, drl, N=N, rows_per_sample=D * H * W, c_in=C, c_out=c_out, want_bias=False)
-                dwres = dwres_m.t().contiguous()                    # ConvTranspose layout (C_in, C_out)
-                dbres = db3.clone()                                 # bias reaches every interior voxel exactly once
-                ops.add_(dx, _pw(drl, _mat(wres), None, c_out=C, transposed=False).view_as(dx))
+                dwres_m, _ = ops.pw_wgrad(x, drl, N=N, rows_per_sample=D * H * W, c_in=C, c_out=c_out, want_bias=False, defer=dr)
+                ops.add_(dx, _pw(drl, _mat(wres), None, c_out=C, transposed=False, packs=packs).view_as(dx))
+        dr.flush()                       # all weight / bias / norm gradients of the block are final from here on
+        if kind == "up" and has_res:
+            dwres = dwres_m.t().contiguous()                        # ConvTranspose layout (C_in, C_out)
+            dbres = db3.clone()                                     # bias reaches every interior voxel exactly once
         # gradients in the parameter's own (contiguous) strides, which DDP's bucket views expect: a view when the kernel
         # output is already laid out that way (1x1x1 weights, norm vectors), a copy only for the transposed ones
         def g(v, like):
@@ -263,16 +343,16 @@ class BlockFn(torch.autograd.Function):
                 g(dbeta, gamma), g(dW2, w2), (db2.to(w2.dtype) if has_b2 else None), g(dW3, w3),
                 (db3.to(w3.dtype) if has_b3 else None),
                 (g(dwres, wres) if has_res else None), (dbres.to(w3.dtype) if (has_res and has_bres) else None),
-                None, None, None, None)
+                None, None, None, None, None)
 
 
-def _block(m, x, skip=None, recompute: bool = False):
+def _block(m, x, skip=None, recompute: bool = False, packs=None):
     if m.grn or not isinstance(m.norm, nn.GroupNorm) or m.dim != "3d":
         raise NotImplementedError("training kernels cover GroupNorm / 3-D MedNeXt blocks only")
     res = getattr(m, "res_conv", None) if getattr(m, "resample_do_res", False) else None
     return BlockFn.apply(x, skip, m.conv1.weight, m.conv1.bias, m.norm.weight, m.norm.bias, m.conv2.weight,
                          m.conv2.bias, m.conv3.weight, m.conv3.bias, None if res is None else res.weight,
-                         None if res is None else res.bias, m.kind, bool(m.do_res), float(m.norm.eps), bool(recompute))
+                         None if res is None else res.bias, m.kind, bool(m.do_res), float(m.norm.eps), bool(recompute), packs)
 
 
 def saved_activation_bytes(trunk, in_shape, compute_dtype: torch.dtype) -> int:
@@ -315,20 +395,23 @@ def use_block_recompute(trunk, x_cl: torch.Tensor, compute_dtype: torch.dtype) -
 def mednext_train_features(trunk, x_cl: torch.Tensor, compute_dtype: torch.dtype):
     """Differentiable trunk up to the full-resolution features: -> (features, [bottleneck, dec_3, dec_2, dec_1])."""
     rc = use_block_recompute(trunk, x_cl, compute_dtype)
-    x = PointwiseFn.apply(x_cl, trunk.stem.weight, trunk.stem.bias, False, compute_dtype)
+    packs = _packs_of(trunk)
+    if packs is not None:
+        packs.refresh()          # ONE launch rebuilds every weight image / stencil whose parameter changed since the last step
+    x = PointwiseFn.apply(x_cl, trunk.stem.weight, trunk.stem.bias, False, compute_dtype, packs)
     skips = []
     for lvl in range(4):
         for blk in getattr(trunk, f"enc_block_{lvl}"):
-            x = _block(blk, x, recompute=rc)
+            x = _block(blk, x, recompute=rc, packs=packs)
         skips.append(x)
-        x = _block(getattr(trunk, f"down_{lvl}"), x, recompute=rc)
+        x = _block(getattr(trunk, f"down_{lvl}"), x, recompute=rc, packs=packs)
     for blk in trunk.bottleneck:
-        x = _block(blk, x, recompute=rc)
+        x = _block(blk, x, recompute=rc, packs=packs)
     feats = [x]
     for lvl in (3, 2, 1, 0):
-        x = _block(getattr(trunk, f"up_{lvl}"), x, skip=skips[lvl], recompute=rc)
+        x = _block(getattr(trunk, f"up_{lvl}"), x, skip=skips[lvl], recompute=rc, packs=packs)
         for blk in getattr(trunk, f"dec_block_{lvl}"):
-            x = _block(blk, x, recompute=rc)
+            x = _block(blk, x, recompute=rc, packs=packs)
         if lvl:
             feats.append(x)
     return x, feats
@@ -338,8 +421,9 @@ def mednext_train_forward(trunk, x_cl: torch.Tensor, compute_dtype: torch.dtype)
     """Differentiable forward of the MedNeXt trunk on channels-last input (N,D,H,W,C_in) fp32.
     Returns fp32 channels-last logits, or the list [out, ds_1..ds_4] with deep supervision."""
     x, feats = mednext_train_features(trunk, x_cl, compute_dtype)
+    packs = _packs_of(trunk)
     head = lambda ft, i: PointwiseFn.apply(ft, getattr(trunk, f"out_{i}").conv_out.weight,
-                                           getattr(trunk, f"out_{i}").conv_out.bias, True, torch.float32)
+                                           getattr(trunk, f"out_{i}").conv_out.bias, True, torch.float32, packs)
     out = head(x, 0)
     if not trunk.do_ds:
         return out
@@ -355,11 +439,13 @@ def mednext_multihead_train_forward(wrapper, x_cl: torch.Tensor, compute_dtype: 
     for name, head in wrapper.heads.items():
         x = feat
         if not isinstance(head.input_projection, nn.Identity):
-            x = PointwiseFn.apply(x, head.input_projection.weight, head.input_projection.bias, False, compute_dtype)
+            x = PointwiseFn.apply(x, head.input_projection.weight, head.input_projection.bias, False, compute_dtype,
+                                  _packs_of(wrapper.model))
         if not isinstance(head.blocks, nn.Identity):
             for blk in head.blocks:
-                x = _block(blk, x)
-        outs[name] = PointwiseFn.apply(x, head.projection.weight, head.projection.bias, False, torch.float32)
+                x = _block(blk, x, packs=_packs_of(wrapper.model))
+        outs[name] = PointwiseFn.apply(x, head.projection.weight, head.projection.bias, False, torch.float32,
+                                       _packs_of(wrapper.model))
     return outs
 
 

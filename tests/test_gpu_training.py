@@ -504,3 +504,78 @@ def test_outside_block_checkpointing_recomputes_bit_identically():
     m.checkpoint_policy = "sometimes"
     with pytest.raises(ValueError, match="checkpoint_policy"):
         m(x)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_batched_packs_and_deferred_reductions_are_bit_identical(dtype, monkeypatch):
+    """Round-2 launch batching: ONE pack_multi launch per step for every weight image / stencil (ops.StepPacks) and ONE
+    reduce_slots_multi launch per block backward (ops.DeferredReduce) against the one-launch-per-tensor forms: identical
+    losses, gradients and weights over three AdamW steps (same kernels per element, same summation trees)."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    from pytorch_connectomics_amd.models.architectures.mednext import MedNeXt
+    from pytorch_connectomics_amd.training import autograd as AG
+
+    class _Immediate(ops.DeferredReduce):        # reduce every item at once, one launch each (the round-1 behaviour)
+        def add(self, part, out, n, slots, keep=None):
+            super().add(part, out, n, slots, keep)
+            self.flush()
+
+    def run(batched: bool):
+        monkeypatch.setattr(AG, "BATCHED_WEIGHT_PACKS", batched)
+        monkeypatch.setattr(ops, "DeferredReduce", ops.DeferredReduce if batched else _Immediate)
+        torch.manual_seed(0)
+        m = MedNeXt(1, 32, 2, exp_r=2, kernel_size=3, do_res=True, do_res_up_down=True, block_counts=[1] * 9).cuda().train()
+        m.compute_dtype = dtype
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+        g = torch.Generator().manual_seed(1)
+        x = torch.rand(2, 1, 32, 32, 32, generator=g).cuda()
+        y = (torch.rand(2, 2, 32, 32, 32, generator=g) > 0.7).float().cuda()
+        losses, launches = [], []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            with ops.profiled() as prof:
+                loss = F.binary_cross_entropy_with_logits(m(x), y)
+                loss.backward()
+            summ = prof.summary()
+            launches.append({k: v["launches"] for k, v in summ.items() if k in ("pack_multi", "pw_pack_weight_paired", "reduce_slots_multi")})
+            opt.step()
+            losses.append(float(loss))
+        grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+        return losses, grads, {k: p.detach().clone() for k, p in m.named_parameters()}, launches
+
+    l1, g1, w1, n1 = run(True)
+    l0, g0, w0, n0 = run(False)
+    assert l1 == l0
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), k
+    for k in w0:
+        assert torch.equal(w1[k], w0[k]), k
+    # batched: the set fills itself in step 1 (individual packs), steps 2 and 3 run ONE pack launch and no individual one
+    assert n1[1].get("pack_multi") == 1 and n1[2].get("pack_multi") == 1
+    if dtype == torch.bfloat16:
+        assert n1[0].get("pw_pack_weight_paired", 0) > 30 and n1[1].get("pw_pack_weight_paired", 0) == 0
+        assert n0[1].get("pw_pack_weight_paired", 0) == n0[0].get("pw_pack_weight_paired", 0) > 30
+    assert n1[2]["reduce_slots_multi"] < n0[2]["reduce_slots_multi"] / 3
+
+
+@pytest.mark.parametrize("shape,C", [((2, 16, 24, 40), 32), ((1, 20, 17, 33), 64), ((1, 9, 16, 16), 32)])
+def test_dwconv_with_fused_residual_is_bit_identical_to_conv_then_add(shape, C):
+    """pytc_dwconv3d_fwd_res (y = conv(x) + res in the z-march kernel, the residual travelling in registers with a counted
+    wait) against conv-in-fp32 + add + one rounding; ragged planes, a depth that is not a multiple of the z-chunk."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    N, D, H, W = shape
+    g = torch.Generator().manual_seed(C + D)
+    x = torch.randn(N, D, H, W, C, generator=g).cuda().to(torch.bfloat16)
+    res = torch.randn(N, D, H, W, C, generator=g).cuda().to(torch.bfloat16)
+    taps = torch.randn(27, C, generator=g).cuda()
+    assert ops.dwconv3d_res_supported(x, 3, 1)
+    want, _ = ops.dwconv3d(x, taps, None, K=3, stride=1, stats=False)
+    want32 = want.float()           # conv rounded to bf16, then added: NOT what the fused kernel does (one rounding) ...
+    # ... so the reference is built from the fp32 accumulator: conv in fp32 storage, add, round once
+    x32, _ = ops.dwconv3d(x.float(), taps, None, K=3, stride=1, stats=False)
+    ref = (x32 + res.float()).to(torch.bfloat16)
+    got = ops.dwconv3d_res(x, taps, res, K=3)
+    assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
+    # the two-step form (round the conv, add, round again) differs from it by at most one bf16 ulp of the result
+    assert float((ref.float() - (want32 + res.float())).abs().max()) <= 2.0 ** -6 * float(ref.float().abs().max())
+    assert not ops.dwconv3d_res_supported(x.float(), 3, 1) and not ops.dwconv3d_res_supported(x[:, :4], 3, 1)
