@@ -258,14 +258,16 @@ def rsunet_leg(dev, args):
 
 
 def monai_unet_leg(dev, args):
-    """BASELINE configs[4] (CREMI synapse): MONAI-style residual U-Net, filters [32,64,128,256], anisotropic 20 x 256 x 256
-    patches, bf16 storage: training step and inference forward."""
+    """BASELINE configs[4] (CREMI synapse): MONAI-style residual U-Net, filters [32,64,128,256], anisotropic patches, bf16
+    storage: training step and inference forward.  The reference's builder strides every level by 2 on every axis
+    (monai_models.py:228-229), so a 20 x 256 x 256 patch cannot pass its own skip concatenations (20 -> 10 -> 5 -> 3, up 6 != 5:
+    torch.cat fails in MONAI too); the leg runs the nearest size the architecture accepts, 24 x 256 x 256."""
     from pytorch_connectomics_amd.models import build_model as bm
-    cfg = NS(model=NS(arch=NS(type="monai_unet"), in_channels=1, out_channels=1, input_size=[20, 256, 256],
+    cfg = NS(model=NS(arch=NS(type="monai_unet"), in_channels=1, out_channels=1, input_size=[24, 256, 256],
                       monai=NS(filters=[32, 64, 128, 256], num_res_units=2, kernel_size=3, norm="batch", dropout=0.0,
                                upsample_mode="deconv")))
     return _unet_leg(dev, args, lambda: bm(cfg), "MONAI-style residual U-Net filters [32,64,128,256], BatchNorm, PReLU",
-                     (20, 256, 256), 2, 1)
+                     (24, 256, 256), 2, 1)
 
 
 def pmc_traffic_bytes(label):
