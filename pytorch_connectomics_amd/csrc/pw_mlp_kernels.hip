@@ -316,6 +316,11 @@ pw_mlp_kernel(MlpParams p) {
   }
 }
 
+// Also measured and removed (round 2, profiles/r02_mixer_split_and_lds_weights.txt): (a) the four waves of a workgroup sharing
+// one voxel tile and splitting the hidden chunks between them (fixed-order LDS reduction): wins only at 7^3, loses at 14^3;
+// (b) each hidden chunk's weight fragments fetched once per workgroup into double-buffered LDS instead of streamed from L2 by
+// every wave: bit-identical and slower at every shape -- the per-chunk barrier exposes the next chunk's load latency that
+// independent waves otherwise hide.  The mixers are not limited by L2 weight bandwidth.
 // Measured and removed (round 2, profiles/r02_mixer_two_tiles_per_wave.txt): a variant in which a wave owns TWO voxel tiles and
 // requests the rows of both before computing the first (to overlap one tile's loads with the other's GEMMs inside a wave) was
 // bit-identical and SLOWER at every shape (forward 9.39 -> 10.1 ms; 128->256->128: 0.26 -> 0.61 ms): the registers of the second
