@@ -187,11 +187,18 @@ def train_leg(dev, rank, world, args, barrier):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     roof = None
-    if rank == 0 and not args.no_roofline:
-        with ops.profiled() as prof:
+    if not args.no_roofline:
+        # two more steps with per-kernel HIP events on rank 0; under DDP EVERY rank has to run them (the gradient
+        # all-reduce is a collective: a rank that skipped them would leave rank 0 waiting on a closed connection)
+        if rank == 0:
+            with ops.profiled() as prof:
+                for i in range(2):
+                    tstep(i)
+            roof = dominant(prof.summary(), 2)
+        else:
             for i in range(2):
                 tstep(i)
-        roof = dominant(prof.summary(), 2)
+        barrier()
     vox = world * args.train_batch * ROI_VOX * steps
     del opt, net, model
     torch.cuda.empty_cache()
