@@ -449,6 +449,15 @@ int pytc_conv3d_pack_weight_dgrad(const float* w, int C_out, int C_in, int kd, i
                                   void* stream);
 int pytc_norm_bwd_means(const float* s, const float* gamma, float* M, float* dgamma, float* dbeta, int N, int C, int groups,
                         float rows, void* stream);
+/* nn.BatchNorm3d in train() mode after the statistics pass, one launch: stats [slots_total][2][C] = the (sum, sum of squares)
+ * partials of ALL samples (pytc_channel_stats output viewed flat), count = N * voxels; writes the batch affine ab [N][2][C] and
+ * (mean, rstd) [N][2][C] (identical for every n), blends running_mean / running_var (unbiased variance, `momentum`; NULL pair =
+ * track_running_stats off) and increments num_batches_tracked (int64, NULL to skip).  Same arithmetic as
+ * pytc_norm_finalize_groups_mr(groups = C) + pytc_bn_update_running.  Replaces the BatchNorm half of RSUNet's NormAct
+ * (rsunet.py:87-118) and of MONAI's ADN in training. */
+int pytc_bn_train_finalize(const float* stats, int slots_total, float count, const float* gamma, const float* beta, float eps,
+                           float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* ab,
+                           float* mean_rstd, int N, int C, void* stream);
 int pytc_bn_update_running(const float* mean_rstd, float* running_mean, float* running_var, int C, float count, float eps,
                            float momentum, void* stream);
 int64_t pytc_conv3d_wgrad_ws_elems(int N, int D, int H, int W, int C_in, int C_out, const int32_t* kernel, int dtype);

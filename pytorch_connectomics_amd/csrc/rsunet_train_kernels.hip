@@ -497,6 +497,51 @@ bn_update_running_kernel(const float* __restrict__ mr, float* __restrict__ rmean
   }
 }
 
+// BatchNorm3d in train() mode, everything after the statistics pass in ONE launch: per channel the fixed-order reduction of
+// the slot partials of ALL samples (same tree as norm_finalize_groups_kernel with groups = C on the flattened slots), the affine
+// (a, b) and (mean, rstd) written for every sample of the batch, the running_mean / running_var blend (same expressions as
+// bn_update_running_kernel) and num_batches_tracked += 1.  Replaces 5 launches per NormAct forward (finalize, two expand copies,
+// the counter increment, the running update): RSUNet and the MONAI U-Net are launch bound at their patch sizes.
+__global__ void __launch_bounds__(256)
+bn_train_finalize_kernel(const float* __restrict__ stats, int slots, float count, const float* __restrict__ gamma,
+                         const float* __restrict__ beta, float eps, float momentum, float* __restrict__ rmean,
+                         float* __restrict__ rvar, long long* __restrict__ nbt, float* __restrict__ ab, float* __restrict__ mr,
+                         int N, int C) {
+  __shared__ float red[2][256];
+  const int c = blockIdx.x;
+  float a1 = 0.f, a2 = 0.f;
+  for (long s = threadIdx.x; s < slots; s += blockDim.x) {
+    a1 += stats[(s * 2 + 0) * C + c];
+    a2 += stats[(s * 2 + 1) * C + c];
+  }
+  red[0][threadIdx.x] = a1;
+  red[1][threadIdx.x] = a2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int i = 0; i < 256; ++i) { t1 += red[0][i]; t2 += red[1][i]; }
+    const float mean = t1 / count;
+    const float var = fmaxf(t2 / count - mean * mean, 0.f);
+    float rstd = rsqrtf(var + eps);
+    rstd = rstd * (1.5f - 0.5f * (var + eps) * rstd * rstd);
+    const float a = (gamma ? gamma[c] : 1.f) * rstd;
+    const float b = (beta ? beta[c] : 0.f) - mean * a;
+    for (int n = 0; n < N; ++n) {
+      ab[((long)n * 2 + 0) * C + c] = a;
+      ab[((long)n * 2 + 1) * C + c] = b;
+      mr[((long)n * 2 + 0) * C + c] = mean;
+      mr[((long)n * 2 + 1) * C + c] = rstd;
+    }
+    if (rmean) {
+      float v = 1.0f / (rstd * rstd) - eps;
+      v = (v > 0.f ? v : 0.f) * (count / (count > 1.f ? count - 1.f : 1.f));
+      rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
+      rvar[c] = (1.0f - momentum) * rvar[c] + momentum * v;
+    }
+    if (nbt && c == 0) *nbt += 1;
+  }
+}
+
 }  // namespace pytc
 
 using namespace pytc;
@@ -646,6 +691,18 @@ extern "C" int pytc_norm_bwd_means(const float* s, const float* gamma, float* M,
   PYTC_REQUIRE(groups == 0 || (groups >= 1 && C % groups == 0), "norm_bwd_means: C must be divisible by groups");
   hipLaunchKernelGGL(norm_bwd_means_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, s, gamma, M, dgamma, dbeta, N, C, groups, rows);
   PYTC_LAUNCH_CHECK("norm_bwd_means");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_bn_train_finalize(const float* stats, int slots_total, float count, const float* gamma, const float* beta,
+                                      float eps, float momentum, float* running_mean, float* running_var,
+                                      int64_t* num_batches_tracked, float* ab, float* mean_rstd, int N, int C, void* stream) {
+  PYTC_REQUIRE(stats && ab && mean_rstd && slots_total >= 1 && count >= 1.f && N >= 1 && C >= 1, "bn_train_finalize: bad arguments");
+  PYTC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_finalize: running buffers come as a pair");
+  hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, slots_total, count, gamma, beta,
+                     eps, momentum, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), ab, mean_rstd, N,
+                     C);
+  PYTC_LAUNCH_CHECK("bn_train_finalize");
   return PYTC_OK;
 }
 

@@ -690,6 +690,26 @@ def norm_bwd_means(s: torch.Tensor, gamma: Optional[torch.Tensor], groups: int, 
     return M, dg, db
 
 
+def bn_train_finalize(stats: torch.Tensor, count: float, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float,
+                      momentum: float, running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor],
+                      num_batches_tracked: Optional[torch.Tensor], N: int):
+    """BatchNorm (training) after the statistics pass in one launch: stats (N, slots, 2, C) of the whole batch -> ab (N,2,C),
+    mean_rstd (N,2,C); blends the running buffers and increments num_batches_tracked in place (pass None to skip either)."""
+    _dev(stats, "stats")
+    Cc = stats.shape[-1]
+    slots_total = stats.numel() // (2 * Cc)
+    ab = torch.empty((N, 2, Cc), dtype=torch.float32, device=stats.device)
+    mr = torch.empty((N, 2, Cc), dtype=torch.float32, device=stats.device)
+    if running_mean is not None and (running_mean.dtype != torch.float32 or running_var.dtype != torch.float32):
+        raise RuntimeError("bn_train_finalize: fp32 running buffers expected")
+    if num_batches_tracked is not None and num_batches_tracked.dtype != torch.int64:
+        raise RuntimeError("bn_train_finalize: int64 num_batches_tracked expected")
+    _run("bn_train_finalize", _nbytes(stats, ab, mr), nat.lib().pytc_bn_train_finalize, _p(stats), slots_total, float(count), _p(gamma),
+         _p(beta), float(eps), float(momentum), _p(running_mean), _p(running_var), _p(num_batches_tracked), _p(ab), _p(mr), N, Cc,
+         _stream())
+    return ab, mr
+
+
 def bn_update_running(mean_rstd: torch.Tensor, running_mean: torch.Tensor, running_var: torch.Tensor, count: float,
                       eps: float, momentum: float) -> None:
     _dev(mean_rstd, "mean_rstd"); _dev(running_mean, "running_mean"); _dev(running_var, "running_var")

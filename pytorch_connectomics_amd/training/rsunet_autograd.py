@@ -82,7 +82,16 @@ class NormActFn(torch.autograd.Function):
             g = groups if kind == "group" else C
             ab, mr = ops.norm_finalize_groups_mr(st, rows, _f(gamma), _f(beta), eps, g)
         elif kind == "batch":
-            if bn.training:
+            if bn.training and (not bn.track_running_stats or bn.momentum is not None):
+                # statistics pass, then ONE launch: batch affine for every sample, running-buffer blend, counter increment
+                st = ops.channel_stats(x)
+                track = bn.track_running_stats
+                ab, mr = ops.bn_train_finalize(st, float(N * rows), _f(gamma), _f(beta), eps, float(bn.momentum or 0.0),
+                                               bn.running_mean if track else None, bn.running_var if track else None,
+                                               bn.num_batches_tracked if track else None, N)
+                if track:   # written through raw pointers: bump the version counters the eval-mode affine cache keys on
+                    torch.autograd.graph.increment_version([bn.running_mean, bn.running_var, bn.num_batches_tracked])
+            elif bn.training:          # momentum=None: cumulative moving average needs the counter's value on the host
                 st = ops.channel_stats(x)
                 st1 = st.reshape(1, st.shape[0] * st.shape[1], 2, C)
                 ab1, mr1 = ops.norm_finalize_groups_mr(st1, N * rows, _f(gamma), _f(beta), eps, C)
