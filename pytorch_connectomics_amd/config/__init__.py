@@ -1,8 +1,11 @@
 """Config surface of the hot path -- a small PyYAML loader for the keys SURVEY.md section 5.6 lists
-(the reference uses OmegaConf dataclasses, config/pipeline/config_io.py:264-297; neither OmegaConf nor the
-reference's profile YAMLs are available to this engine, so profiles are not expanded).
+(the reference uses OmegaConf dataclasses, config/pipeline/config_io.py:264-297; OmegaConf is not in the image).
 
-Supported: `_base_` inheritance (relative paths, missing bases are skipped with a warning), the
+Supported: `_base_` inheritance (relative paths, missing bases are skipped with a warning), the reference's YAML
+PROFILE ENGINE (config/pipeline/profile_engine.py: selectors such as `model.arch.profile: rsunet` expand the
+registries -- `arch_profiles`, `loss_profiles`, `optimizer_profiles`, `activation_profiles`, ... -- that a config pulls in
+through `_base_: ../connectomics/config/all_profiles.yaml`; the registries themselves are the reference's data files and
+are read from wherever the user's `_base_` points, they are not shipped here), the
 `default` + `train|test|tune` stage sections merged into the runtime tree (stage_resolver.py:336),
 `key.sub=value` CLI overrides (config_io.py:351), schema defaults for the sections the engine reads, and the
 canonical `inference.window` -> runtime `inference.sliding_window` alias sync (schema/inference.py:278-331).
@@ -159,6 +162,162 @@ def _load_with_bases(path: Path, seen: tuple = ()) -> dict:
     return merged
 
 
+# ---------------------------------------------------------------------------------------------- profile engine
+# (profiles_key, stages, selector path relative to the stage, target path relative to the stage, list key) -- the table of
+# config/pipeline/profile_engine.py:484-551; "" = the stage section itself.  Order matters: pipeline / system, arch, the rest.
+_STAGES = ("default", "train", "test", "tune")
+_VALUE_PROFILE_FAMILIES = [
+    ("pipeline_profiles", ("default",), "pipeline_profile", "", None),
+    ("system_profiles", _STAGES, "system.profile", "system", None),
+    ("arch_profiles", _STAGES, "model.arch.profile", "model", None),
+    ("augmentation_profiles", ("default", "train"), "data.augmentation.profile", "data.augmentation", None),
+    ("dataloader_profiles", _STAGES, "data.dataloader.profile", "data.dataloader", None),
+    ("optimizer_profiles", ("default", "train"), "optimization.profile", "optimization", None),
+    ("loss_profiles", ("default", "train"), "model.loss.profile", "model.loss", "losses"),
+    ("label_profiles", ("default", "train"), "data.label_transform.profile", "data.label_transform", None),
+    ("activation_profiles", ("default", "test", "tune"), "inference.model.activation_profile", "inference.model",
+     "channel_activations"),
+    ("tune_profiles", ("tune",), "profile", "", None),
+]
+# `${profiles_key.name}` string references, resolved at these stage-relative paths (profile_engine.py:578-587)
+_REFERENCE_PROFILE_FAMILIES = [("loss_profiles", ("default", "train"), "model.loss"),
+                               ("label_profiles", ("default", "train"), "data.label_transform"),
+                               ("activation_profiles", ("default", "test", "tune"), "inference.model"),
+                               ("augmentation_profiles", ("default", "train"), "data.augmentation")]
+
+
+def _join(stage: str, rel: str) -> str:
+    return f"{stage}.{rel}" if (stage and rel) else (stage or rel)
+
+
+def _select(tree: Mapping, path: str):
+    node: Any = tree
+    for part in [p for p in path.split(".") if p]:
+        if not isinstance(node, Mapping) or part not in node:
+            return None
+        node = node[part]
+    return node
+
+
+def _assign(tree: dict, path: str, value) -> None:
+    parts = [p for p in path.split(".") if p]
+    if not parts:                                    # the stage root itself: merge the mapping in place
+        tree.clear()
+        tree.update(value)
+        return
+    node = tree
+    for part in parts[:-1]:
+        if not isinstance(node.get(part), dict):
+            node[part] = {}
+        node = node[part]
+    node[parts[-1]] = value
+
+
+def _allowed_selector_paths() -> set:
+    return {_join(stage, sel) for _k, stages, sel, _t, _l in _VALUE_PROFILE_FAMILIES for stage in stages}
+
+
+def _reject_noncanonical_selectors(raw: Mapping) -> None:
+    """A `profile` / `*_profile` key with a value anywhere but at a selector path of the table is an error
+    (profile_engine.py:150-164): a typo there would otherwise silently train the default architecture."""
+    allowed = _allowed_selector_paths()
+    parents = {sel.rsplit(".", 1)[0] if "." in sel else "" for _k, _s, sel, _t, _l in _VALUE_PROFILE_FAMILIES if sel.endswith("profile")}
+    found = set()
+
+    def walk(node, path, in_registry):
+        if isinstance(node, list):
+            for item in node:
+                walk(item, path, in_registry)
+            return
+        if not isinstance(node, Mapping):
+            return
+        for key, child in node.items():
+            key = str(key)
+            child_path = f"{path}.{key}" if path else key
+            reg = in_registry or (path == "" and (key.endswith("_profiles") or key.endswith("_templates")))
+            if not reg and child not in (None, ""):
+                if key.endswith("_profile"):
+                    found.add(child_path)
+                elif key == "profile":
+                    parent = path
+                    head, _, tail = parent.partition(".")
+                    rel = tail if head in _STAGES else parent
+                    if head in _STAGES and not tail:
+                        rel = ""
+                    if rel in parents:
+                        found.add(child_path)
+            walk(child, child_path, reg)
+
+    walk(raw, "", False)
+    bad = sorted(p for p in found if p not in allowed)
+    if bad:
+        raise ValueError("Non-canonical profile selector path(s) detected: " + ", ".join(bad) +
+                         ". Allowed selector paths: [" + ", ".join(sorted(allowed)) + "]")
+
+
+def apply_profiles(raw: dict) -> dict:
+    """Expand profile selectors in place (profile_engine.py ValueProfileApplier / ReferenceProfileApplier /
+    YamlProfileEngine): for every family and stage, `stage.<selector>: name` merges `<profiles_key>[name]` into
+    `stage.<target>` with the values already written there WINNING over the profile payload (lists replace, mappings merge);
+    an `overrides: {index: patch}` mapping next to the selector patches entries of the expanded list; `${key.name}` strings at
+    the reference paths are replaced by the payload; the registries are removed afterwards."""
+    if "shared" in raw:
+        raise ValueError("Top-level 'shared' config section has been removed. Use top-level 'default' instead.")
+    _reject_noncanonical_selectors(raw)
+    for key, stages, sel_rel, tgt_rel, list_key in _VALUE_PROFILE_FAMILIES:
+        for stage in stages:
+            sel_path, tgt_path = _join(stage, sel_rel), _join(stage, tgt_rel)
+            selected = _select(raw, sel_path)
+            if selected is None:
+                continue
+            profiles = raw.get(key)
+            if profiles is None:
+                raise ValueError(f"Selector '{selected}' at '{sel_path}' requires '{key}' to be defined in YAML.")
+            if selected not in profiles:
+                raise ValueError(f"Unknown selector '{selected}' at '{sel_path}'. Available profiles: ["
+                                 + ", ".join(sorted(str(k) for k in profiles)) + "]")
+            payload = copy.deepcopy(profiles[selected])
+            existing = _select(raw, tgt_path)
+            if isinstance(existing, Mapping) and isinstance(payload, Mapping):
+                merged = _deep_merge(payload, copy.deepcopy(dict(existing)))      # explicit values win
+            else:
+                merged = payload if existing is None else existing
+            _assign(raw, tgt_path, merged)
+            # positional overrides of a list-valued profile (profile_engine.py:207-247)
+            parent = sel_path.rsplit(".", 1)[0] if "." in sel_path else ""
+            ov = _select(raw, _join(parent, "overrides"))
+            if isinstance(ov, Mapping):
+                lst = _select(raw, _join(tgt_path, list_key) if list_key else tgt_path)
+                if isinstance(lst, list):
+                    for idx_key, patch in ov.items():
+                        idx = int(idx_key)
+                        if idx < 0 or idx >= len(lst):
+                            raise ValueError(f"Override index {idx} at '{_join(parent, 'overrides')}' is out of range for profile "
+                                             f"list at '{tgt_path}' (length {len(lst)}).")
+                        if isinstance(patch, Mapping) and isinstance(lst[idx], Mapping):
+                            lst[idx] = _deep_merge(copy.deepcopy(dict(lst[idx])), dict(patch))
+                    holder = _select(raw, parent) if parent else raw
+                    if isinstance(holder, dict):
+                        holder.pop("overrides", None)
+    import re
+    for key, stages, tgt_rel in _REFERENCE_PROFILE_FAMILIES:
+        profiles = raw.get(key)
+        if profiles is None:
+            continue
+        pat = re.compile(r"\$\{" + re.escape(key) + r"\.([A-Za-z0-9_\-]+)\}")
+        for stage in stages:
+            value = _select(raw, _join(stage, tgt_rel))
+            m = pat.fullmatch(value) if isinstance(value, str) else None
+            if m:
+                if m.group(1) not in profiles:
+                    raise ValueError(f"Unknown profile '{m.group(1)}' in {key}. Available profiles: ["
+                                     + ", ".join(sorted(str(k) for k in profiles)) + "]")
+                _assign(raw, _join(stage, tgt_rel), copy.deepcopy(profiles[m.group(1)]))
+    for k in [k for k in raw if k.endswith("_profiles") or k.endswith("_templates")]:
+        raw.pop(k)
+    return raw
+
+
 def sync_inference_runtime_aliases(cfg: ConfigNode, user_window: Mapping | None = None) -> None:
     """Copy the canonical `inference.window` values the user set into `inference.sliding_window`."""
     inf = cfg.get("inference")
@@ -193,9 +352,7 @@ def resolve_default_profiles(raw: Mapping, mode: str = "train") -> dict:
 
 def load_config(path: str | Path, mode: str = "train", overrides: Iterable[str] = ()) -> ConfigNode:
     raw = _load_with_bases(Path(path))
-    # profile libraries pulled in through _base_ (e.g. all_profiles.yaml) are tolerated but not expanded
-    for k in [k for k in raw if k.endswith("_profiles") or k.endswith("_templates")]:
-        raw.pop(k)
+    apply_profiles(raw)          # selectors -> payloads of the registries pulled in through _base_; registries removed
     unknown = sorted(set(raw) - _TOP_LEVEL)
     if unknown:
         raise ValueError(f"Unknown top-level config keys {unknown} in {path}. Allowed: {sorted(_TOP_LEVEL)}")
@@ -241,5 +398,5 @@ def validate_config(cfg: ConfigNode) -> None:
         raise ValueError(f"inference.window.window_size must be 2 or 3 positive ints, got {ws}")
 
 
-__all__ = ["Config", "ConfigNode", "load_config", "resolve_default_profiles", "sync_inference_runtime_aliases",
+__all__ = ["Config", "ConfigNode", "load_config", "apply_profiles", "resolve_default_profiles", "sync_inference_runtime_aliases",
            "update_from_cli", "validate_config", "schema_defaults"]

@@ -37,10 +37,119 @@ def dice_loss_sigmoid(logits: torch.Tensor, target: torch.Tensor, smooth_nr: flo
     return (1.0 - (2.0 * inter + smooth_nr) / (den + smooth_dr)).mean()
 
 
+def _mask_for_unweighted_loss(pred, target, mask, clamp_min: float):
+    """Losses without a spatial-weight argument (the MONAI ones) see a mask through their INPUTS
+    (training/losses/orchestrator.py:648-655): invalid voxels get the clamp floor as logit and 0 as target."""
+    if mask is None:
+        return pred, target
+    valid = (mask > 0).expand_as(pred)
+    return pred.masked_fill(~valid, float(clamp_min)), target * (mask > 0).to(target.dtype)
+
+
+def _drop_background(p, t, include_background: bool):
+    if include_background or p.shape[1] == 1:          # MONAI: "single channel prediction, include_background=False ignored"
+        return p, t
+    return p[:, 1:], t[:, 1:]
+
+
+def monai_dice_loss(logits, target, *, sigmoid: bool = False, include_background: bool = True, smooth_nr=1e-5, smooth_dr=1e-5,
+                    squared_pred: bool = False, **_unused):
+    """monai.losses.DiceLoss as the reference instantiates it (models/losses/build.py:58-61; reduction 'mean', batch=False):
+    1 - (2 sum(p t) + smooth_nr) / (sum(p) + sum(t) + smooth_dr) per (B, C) over the spatial dims, mean over B and C.
+    `sigmoid` defaults to False as in MONAI (a config that omits it trains Dice on the raw logits).  Parity unpinned: MONAI
+    is not in the image; restated from its documented formula."""
+    p = torch.sigmoid(logits.float()) if sigmoid else logits.float()
+    t = target.float()
+    p, t = _drop_background(p, t, bool(include_background))
+    dims = tuple(range(2, p.dim()))
+    inter = (p * t).sum(dims)
+    den = ((p * p).sum(dims) + (t * t).sum(dims)) if squared_pred else (p.sum(dims) + t.sum(dims))
+    return (1.0 - (2.0 * inter + float(smooth_nr)) / (den + float(smooth_dr))).mean()
+
+
+def monai_tversky_loss(logits, target, *, sigmoid: bool = False, include_background: bool = True, alpha: float = 0.5,
+                       beta: float = 0.5, smooth_nr=1e-5, smooth_dr=1e-5, **_unused):
+    """monai.losses.TverskyLoss: tp = sum(p t), fp = alpha sum(p (1 - t)), fn = beta sum((1 - p) t) per (B, C);
+    1 - (tp + smooth_nr) / (tp + fp + fn + smooth_dr), mean.  Parity unpinned (see monai_dice_loss)."""
+    p = torch.sigmoid(logits.float()) if sigmoid else logits.float()
+    t = target.float()
+    p, t = _drop_background(p, t, bool(include_background))
+    dims = tuple(range(2, p.dim()))
+    tp = (p * t).sum(dims)
+    fp = float(alpha) * (p * (1.0 - t)).sum(dims)
+    fn = float(beta) * ((1.0 - p) * t).sum(dims)
+    return (1.0 - (tp + float(smooth_nr)) / (tp + fp + fn + float(smooth_dr))).mean()
+
+
+def monai_focal_loss(logits, target, *, gamma: float = 2.0, alpha=None, include_background: bool = True, **_unused):
+    """monai.losses.FocalLoss (sigmoid form, use_softmax=False, reduction 'mean'): BCE-with-logits * (1 - p_t)^gamma, with
+    alpha: * (alpha t + (1 - alpha)(1 - t)); mean over every element.  Parity unpinned (see monai_dice_loss)."""
+    x, t = logits.float(), target.float()
+    x, t = _drop_background(x, t, bool(include_background))
+    bce = F.binary_cross_entropy_with_logits(x, t, reduction="none")
+    # (1 - p_t)^gamma = exp(gamma * logsigmoid(-x (2t - 1))): stable for large |x|
+    mod = torch.exp(float(gamma) * F.logsigmoid(-x * (2.0 * t - 1.0)))
+    loss = mod * bce
+    if alpha is not None:
+        loss = loss * (float(alpha) * t + (1.0 - float(alpha)) * (1.0 - t))
+    return loss.mean()
+
+
+def auto_pos_weight_scalar(target, mask=None, cap: float = 10.0) -> torch.Tensor:
+    """`pos_weight: auto` of a weighted-BCE term (orchestrator.py:180-197): min(neg / pos, 10) over the valid voxels, 1 when
+    either class is absent -- computed on the device, no host synchronisation."""
+    valid = torch.ones_like(target, dtype=torch.bool) if mask is None else (mask > 0).expand_as(target)
+    pos = ((target > 0) & valid).sum().float()
+    neg = ((target <= 0) & valid).sum().float()
+    ratio = torch.clamp(neg / pos.clamp_min(1.0), max=float(cap))
+    return torch.where((pos > 0) & (neg > 0), ratio, torch.ones_like(ratio)).reshape(1)
+
+
+def per_channel_bce_with_logits(logits, target, weight=None, *, auto_pos_weight: bool = True, max_pos_weight: float = 10.0,
+                                reduction: str = "mean"):
+    """models/losses/losses.py:269-351: BCE per channel with its own class-balancing weight min(n_neg / n_pos, max_pos_weight)
+    (1 for a channel without positives) from the valid voxels of the current batch, reduced per channel (weighted-valid mean or
+    sum), summed over the channels."""
+    x, t = logits.float(), target.float()
+    C = x.shape[1]
+    pw = None
+    if auto_pos_weight:
+        valid = (weight > 0).expand_as(t) if weight is not None else torch.ones_like(t, dtype=torch.bool)
+        dims = (0,) + tuple(range(2, t.dim()))
+        pos = ((t > 0) & valid).sum(dims).float()
+        neg = ((t <= 0) & valid).sum(dims).float()
+        ratio = torch.clamp(neg / pos.clamp_min(1.0), max=float(max_pos_weight))
+        pw = torch.where(pos > 0, ratio, torch.ones_like(ratio)).reshape(1, C, *([1] * (t.dim() - 2)))
+    bce = F.binary_cross_entropy_with_logits(x, t, pos_weight=pw, reduction="none")
+    total = x.new_zeros(())
+    w = None if weight is None else weight.float().expand_as(bce)
+    for c in range(C):
+        b = bce[:, c:c + 1]
+        if w is None:
+            total = total + (b.mean() if reduction == "mean" else b.sum())
+        else:
+            wc = w[:, c:c + 1]
+            bw = b * wc
+            valid_c = wc > 0
+            total = total + ((bw * valid_c).sum() / valid_c.sum().clamp_min(1) if reduction == "mean" else bw.sum())
+    return total
+
+
 def weighted_bce_with_logits(logits, target, weight=None, pos_weight=None):
     """models/losses/losses.py:17-44,190-266 (reduction='mean'; with a weight map: the mean of weight * bce over the
     voxels whose weight is > 0, the map broadcast to the logits' shape; 0 when no voxel is valid)."""
-    pw = None if pos_weight is None else torch.as_tensor([float(pos_weight)], device=logits.device, dtype=torch.float32)
+    if pos_weight is None:
+        pw = None
+    elif isinstance(pos_weight, str):
+        if pos_weight != "auto":
+            raise ValueError(f"Unsupported pos_weight mode: {pos_weight!r}. Expected a positive number or 'auto'.")
+        pw = auto_pos_weight_scalar(target, weight).to(logits.device)
+    elif isinstance(pos_weight, torch.Tensor):
+        pw = pos_weight.to(device=logits.device, dtype=torch.float32)
+    else:
+        if float(pos_weight) <= 0:
+            raise ValueError(f"pos_weight must be > 0, got {float(pos_weight)}")
+        pw = torch.as_tensor([float(pos_weight)], device=logits.device, dtype=torch.float32)
     bce = F.binary_cross_entropy_with_logits(logits.float(), target.float(), pos_weight=pw, reduction="none")
     if weight is None:
         return bce.mean()
@@ -79,7 +188,15 @@ _LOSSES = {
     "WeightedMAELoss": lambda p, t, **kw: weighted_regression_loss("mae", p, t, kw.get("weight"), tanh=bool(kw.get("tanh", False))),
     "SmoothL1Loss": lambda p, t, **kw: weighted_regression_loss("huber", p, t, kw.get("weight"), tanh=bool(kw.get("tanh", False)),
                                                                 beta=float(kw.get("beta", 1.0))),
-    "DiceLoss": lambda p, t, **kw: dice_loss_sigmoid(p, t),
+    "DiceLoss": lambda p, t, **kw: monai_dice_loss(*_mask_for_unweighted_loss(p, t, kw.get("weight"), kw.get("clamp_min", -20.0)),
+                                                   **{k: v for k, v in kw.items() if k not in ("weight", "pos_weight", "clamp_min")}),
+    "TverskyLoss": lambda p, t, **kw: monai_tversky_loss(*_mask_for_unweighted_loss(p, t, kw.get("weight"), kw.get("clamp_min", -20.0)),
+                                                         **{k: v for k, v in kw.items() if k not in ("weight", "pos_weight", "clamp_min")}),
+    "FocalLoss": lambda p, t, **kw: monai_focal_loss(*_mask_for_unweighted_loss(p, t, kw.get("weight"), kw.get("clamp_min", -20.0)),
+                                                     **{k: v for k, v in kw.items() if k not in ("weight", "pos_weight", "clamp_min")}),
+    "PerChannelBCEWithLogitsLoss": lambda p, t, **kw: per_channel_bce_with_logits(
+        p, t, kw.get("weight"), auto_pos_weight=bool(kw.get("auto_pos_weight", True)),
+        max_pos_weight=float(kw.get("max_pos_weight", 10.0)), reduction=str(kw.get("reduction", "mean"))),
     "WeightedBCEWithLogitsLoss": lambda p, t, **kw: weighted_bce_with_logits(p, t, kw.get("weight"), kw.get("pos_weight")),
     "BCEWithLogitsLoss": lambda p, t, **kw: weighted_bce_with_logits(p, t, kw.get("weight")),
     "MSELoss": lambda p, t, **kw: F.mse_loss(p.float(), t.float()),
@@ -246,7 +363,8 @@ class ConnectomicsModule(nn.Module):
         self.ds_weights = list(getattr(loss_cfg, "deep_supervision_weights", None) or DS_WEIGHTS)
         terms = getattr(loss_cfg, "losses", None)
         if not terms:
-            terms = [{"function": "WeightedBCEWithLogitsLoss", "weight": 1.0}, {"function": "DiceLoss", "weight": 1.0}]
+            terms = [{"function": "WeightedBCEWithLogitsLoss", "weight": 1.0},
+                     {"function": "DiceLoss", "weight": 1.0, "kwargs": {"sigmoid": True}}]
         self.loss_terms = []
         for t in terms:
             get = (lambda k, d=None, _t=t: _t.get(k, d)) if isinstance(t, dict) else (lambda k, d=None, _t=t: getattr(_t, k, d))
@@ -269,6 +387,20 @@ class ConnectomicsModule(nn.Module):
         return self.model(x)
 
     _FUSABLE = {"WeightedBCEWithLogitsLoss": "bce", "BCEWithLogitsLoss": "bce", "DiceLoss": "dice"}
+
+    def _term_is_fusable(self, t, pred) -> bool:
+        """The fused kernel computes mean-reduced BCE-with-logits (numeric pos_weight) and sigmoid Dice with MONAI's default
+        smoothing over all channels; any other variant of those terms takes the generic path."""
+        if t["fn"] not in self._FUSABLE:
+            return False
+        kw = t["kwargs"]
+        if self._FUSABLE[t["fn"]] == "bce":
+            return not isinstance(t["pos_weight"], str) and str(kw.get("reduction", "mean")) == "mean" and \
+                not (set(kw) - {"reduction"})
+        smooth_ok = abs(float(kw.get("smooth_nr", 1e-5)) - 1e-5) < 1e-12 and abs(float(kw.get("smooth_dr", 1e-5)) - 1e-5) < 1e-12
+        bg_ok = bool(kw.get("include_background", True)) or pred.shape[1] == 1
+        return bool(kw.get("sigmoid", False)) and smooth_ok and bg_ok and not kw.get("squared_pred", False) and \
+            not (set(kw) - {"sigmoid", "smooth_nr", "smooth_dr", "include_background", "squared_pred"})
 
     def _fused_term_loss(self, pred, target, mask, terms):
         """All terms are BCE-with-logits / sigmoid-Dice: one fused HIP reduction per (pred_slice, target_slice) pair."""
@@ -304,7 +436,7 @@ class ConnectomicsModule(nn.Module):
         """Weighted sum of the loss terms `terms` (list of (index, term); default: all) on one prediction tensor."""
         terms = list(enumerate(self.loss_terms)) if terms is None else terms
         pred = torch.clamp(pred, min=self.clamp_min, max=self.clamp_max)
-        if pred.is_cuda and self.fused_loss and all(t["fn"] in self._FUSABLE for _, t in terms):
+        if pred.is_cuda and self.fused_loss and all(self._term_is_fusable(t, pred) for _, t in terms):
             res = self._fused_term_loss(pred, target, mask, terms)      # finiteness is checked where fit() reads the value
             if res is not None:
                 return res
@@ -315,7 +447,7 @@ class ConnectomicsModule(nn.Module):
                 p = pred[:, resolve_channel_indices(t["pred_slice"], num_channels=pred.shape[1], context="pred_slice")]
             if t["target_slice"] is not None:
                 y = target[:, resolve_channel_indices(t["target_slice"], num_channels=target.shape[1], context="target_slice")]
-            v = _LOSSES[t["fn"]](p, y, weight=mask, pos_weight=t["pos_weight"], **t["kwargs"])
+            v = _LOSSES[t["fn"]](p, y, weight=mask, pos_weight=t["pos_weight"], clamp_min=self.clamp_min, **t["kwargs"])
             if not torch.isfinite(v):
                 raise FloatingPointError(f"loss term {t['fn']} is not finite")
             parts[f"loss_{i}_{t['fn']}"] = v.detach()

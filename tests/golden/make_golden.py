@@ -825,9 +825,56 @@ def ds_loss():
     save("ds_loss.npz", **out)
 
 
+def losses_extra():
+    """models/losses/losses.py:269-351 PerChannelBCEWithLogitsLoss (per-channel class balancing, capped ratio, a channel without
+    positives, valid-mask weights) values + gradients, and the orchestrator's scalar `pos_weight: auto`
+    (training/losses/orchestrator.py:180-197: min(neg / pos, 10) over the valid voxels, 1 when a class is absent)."""
+    from types import SimpleNamespace as NS
+    ls = S.ref("connectomics.models.losses.losses")
+    g = torch.Generator().manual_seed(77)
+    out = {}
+    for name, (C, mk, kw) in {"pc_plain": (3, None, {}), "pc_cap": (2, None, {"max_pos_weight": 1.5}), "pc_mask": (3, "full", {"max_pos_weight": 50.0}),
+                              "pc_noauto": (2, "full", {"auto_pos_weight": False}), "pc_sum": (2, None, {"reduction": "sum"})}.items():
+        x = (torch.randn(2, C, 4, 6, 5, generator=g) * 2).requires_grad_()
+        t = (torch.rand(2, C, 4, 6, 5, generator=g) > 0.8).float()
+        t[:, 0] = 0.0                                              # a channel without positives: weight stays 1
+        w = (torch.rand(2, C, 4, 6, 5, generator=g) > 0.4).float() if mk else None
+        v = ls.PerChannelBCEWithLogitsLoss(**kw)(x, t, weight=w)
+        out[f"{name}__x"], out[f"{name}__t"] = x.detach().numpy(), t.numpy()
+        if w is not None:
+            out[f"{name}__w"] = w.numpy()
+        out[f"{name}__loss"] = np.asarray([float(v)], np.float64)
+        out[f"{name}__grad"] = torch.autograd.grad(v, x)[0].numpy()
+        out[f"{name}__kw"] = np.asarray([float(kw.get("max_pos_weight", 10.0)), float(kw.get("auto_pos_weight", True)),
+                                         1.0 if kw.get("reduction") == "sum" else 0.0])
+        print(name, float(v))
+    S._stub_pkg("connectomics.training.losses")
+    S._stub_pkg("connectomics.config.pipeline")
+    meta = S.ref("connectomics.models.losses.metadata")
+    ml = sys.modules["connectomics.models.losses"]
+    for n in dir(meta):
+        if not n.startswith("_"):
+            setattr(ml, n, getattr(meta, n))
+    orch = S.ref("connectomics.training.losses.orchestrator")
+    cfg = NS(model=NS(loss=NS(deep_supervision=False, deep_supervision_weights=[1.0], deep_supervision_clamp_min=-20.0,
+                              deep_supervision_clamp_max=20.0, losses=[{"function": "WeightedBCEWithLogitsLoss", "weight": 1.0}],
+                              loss_balancing=None), primary_head=None, heads=None, out_channels=1), data=NS(label_transform=None))
+    o = orch.LossOrchestrator(cfg, torch.nn.ModuleList([ls.WeightedBCEWithLogitsLoss()]), [1.0], enable_nan_detection=False,
+                              debug_on_nan=False, resolve_affinity_mode_fn=lambda c: None)
+    for name, (frac, masked) in {"auto_sparse": (0.97, False), "auto_mask": (0.6, True), "auto_nopos": (2.0, False)}.items():
+        t = (torch.rand(2, 1, 5, 6, 7, generator=g) > frac).float()
+        m = (torch.rand(2, 1, 5, 6, 7, generator=g) > 0.5).float() if masked else None
+        out[f"{name}__t"] = t.numpy()
+        if m is not None:
+            out[f"{name}__m"] = m.numpy()
+        out[f"{name}__pw"] = np.asarray([o._compute_auto_pos_weight_scalar(t, valid_mask=m)], np.float64)
+        print(name, out[f"{name}__pw"])
+    save("losses_extra.npz", **out)
+
+
 if __name__ == "__main__":
     parts = {"manifests": manifests, "optimizers": optimizers, "schedules": schedules, "selectors": selectors, "outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
-             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "accessor": accessor, "ds_loss": ds_loss}
+             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "accessor": accessor, "ds_loss": ds_loss, "losses_extra": losses_extra}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:
         parts[name]()

@@ -106,7 +106,7 @@ def test_module_fused_loss_equals_generic_path_with_deep_supervision():
     cfg.model.deep_supervision = True
     cfg.model.loss.deep_supervision = True
     cfg.model.loss.losses = [{"function": "WeightedBCEWithLogitsLoss", "weight": 1.0, "pos_weight": 2.0},
-                             {"function": "DiceLoss", "weight": 0.5}]
+                             {"function": "DiceLoss", "weight": 0.5, "kwargs": {"sigmoid": True}}]
     torch.manual_seed(3)
     mod = ConnectomicsModule(cfg).cuda().train()
     x = torch.rand(2, 1, 32, 32, 32, device="cuda")

@@ -150,7 +150,8 @@ test:
     test: {{image: "random://minimal/test_image?shape=40,96,80"}}
 """)
     out = main(["--config", str(cfg), "--mode", "train"])
-    assert out["steps"] == 1 and np.isfinite(out["first_loss"]) and 0.0 < out["first_loss"] <= 1.0     # a Dice value
+    # the reference's minimal.yaml gives DiceLoss no kwargs: MONAI's default sigmoid=False, i.e. Dice on the raw logits
+    assert out["steps"] == 1 and np.isfinite(out["first_loss"])
     ck = tmp_path / "out" / "checkpoints" / "last.ckpt"
     blob = torch.load(ck, weights_only=True)
     assert blob["global_step"] == 1 and any(k.startswith("model.model.") for k in blob["state_dict"])
