@@ -1,5 +1,6 @@
 """CPU tests: YAML config surface (stage merge, _base_, overrides, alias sync) and the CLI contract."""
 import textwrap
+from pathlib import Path
 
 import pytest
 import torch
@@ -89,3 +90,87 @@ def test_volume_reader_and_jaccard(tmp_path):
     lab = torch.tensor([1, 0, 1, 0])
     assert binary_jaccard(pred, lab) == pytest.approx(1 / 3)
     assert binary_jaccard(torch.zeros(4), torch.zeros(4)) == 1.0
+
+
+def test_profile_engine_expands_selectors_like_the_reference(tmp_path):
+    """config/pipeline/profile_engine.py semantics: a selector merges its registry payload under the target with the values already
+    written there winning; positional `overrides` patch the expanded list; stage sections carry their own selectors; registries
+    disappear from the result; unknown names, missing registries and selectors at non-canonical paths are errors."""
+    from pytorch_connectomics_amd.config import apply_profiles, load_config
+    (tmp_path / "lib.yaml").write_text("""
+arch_profiles:
+  rsunet_small: {arch: {type: rsunet}, rsunet: {width: [8, 16], norm: group, num_groups: 4}}
+  mednext_s: {arch: {type: mednext}, mednext: {size: S, kernel_size: 3}}
+loss_profiles:
+  bce_dice:
+    losses:
+      - {function: WeightedBCEWithLogitsLoss, weight: 1.0}
+      - {function: DiceLoss, weight: 1.0, kwargs: {sigmoid: true}}
+optimizer_profiles:
+  adamw_cos: {optimizer: {name: AdamW, lr: 3.0e-4}, scheduler: {name: WarmupCosineLR, warmup_epochs: 3}}
+activation_profiles:
+  sig: {channel_activations: [{channels: ":", activation: sigmoid}]}
+""")
+    (tmp_path / "cfg.yaml").write_text("""
+_base_: [lib.yaml]
+default:
+  model:
+    arch: {profile: rsunet_small}
+    rsunet: {norm: batch}                 # written explicitly: wins over the profile's `group`
+    loss:
+      profile: bce_dice
+      overrides: {0: {pos_weight: auto}, 1: {weight: 0.5}}
+  inference:
+    model: {activation_profile: sig}
+train:
+  optimization: {profile: adamw_cos, optimizer: {lr: 1.0e-3}}
+""")
+    cfg = load_config(tmp_path / "cfg.yaml", mode="train")
+    assert cfg.model.arch.type == "rsunet" and cfg.model.rsunet.width == [8, 16] and cfg.model.rsunet.num_groups == 4
+    assert cfg.model.rsunet.norm == "batch"
+    terms = [dict(t) for t in cfg.model.loss.losses]
+    assert terms[0]["pos_weight"] == "auto" and terms[1]["weight"] == 0.5 and terms[1]["kwargs"]["sigmoid"] is True
+    assert not hasattr(cfg.model.loss, "overrides")
+    assert cfg.optimization.optimizer.lr == 1.0e-3 and cfg.optimization.scheduler.name == "WarmupCosineLR"       # explicit lr wins
+    assert cfg.optimization.scheduler.warmup_epochs == 3
+    test_cfg = load_config(tmp_path / "cfg.yaml", mode="test")
+    assert [dict(a) for a in test_cfg.inference.model.channel_activations] == [{"channels": ":", "activation": "sigmoid"}]
+    assert test_cfg.optimization.optimizer.lr != 3.0e-4                        # the train-stage selector is not applied in test mode
+    raw = {"arch_profiles": {"a": {"arch": {"type": "rsunet"}}}, "default": {"model": {"arch": {"profile": "b"}}}}
+    with pytest.raises(ValueError, match=r"Unknown selector 'b' at 'default.model.arch.profile'. Available profiles: \[a\]"):
+        apply_profiles(raw)
+    with pytest.raises(ValueError, match="requires 'arch_profiles' to be defined"):
+        apply_profiles({"default": {"model": {"arch": {"profile": "a"}}}})
+    with pytest.raises(ValueError, match="Non-canonical profile selector path"):
+        apply_profiles({"arch_profiles": {"a": {}}, "default": {"model": {"backbone_profile": "a"}}})
+    with pytest.raises(ValueError, match="Override index 3"):
+        apply_profiles({"loss_profiles": {"p": {"losses": [{"function": "DiceLoss"}]}},
+                        "default": {"model": {"loss": {"profile": "p", "overrides": {3: {"weight": 2.0}}}}}})
+    with pytest.raises(ValueError, match="'shared' config section has been removed"):
+        apply_profiles({"shared": {}})
+
+
+@pytest.mark.skipif(not Path("/root/reference/tutorials").exists(), reason="reference checkout not present")
+def test_reference_tutorial_configs_resolve_through_their_own_profile_library():
+    """Drop-in check against the reference's data files where they lie (never copied): every training tutorial loads in train and
+    test mode, its architecture profile picks the right builder, and the loss / activation profiles expand to terms this engine knows."""
+    import warnings
+    from pytorch_connectomics_amd.config import load_config
+    from pytorch_connectomics_amd.models import build_model
+    from pytorch_connectomics_amd.training.module import _LOSSES
+    tut = Path("/root/reference/tutorials")
+    expect = {"syn_cremi.yaml": "rsunet", "nuc_nucmm-z.yaml": "monai_unet", "minimal.yaml": "monai_unet", "fiber_linghu26.yaml": "mednext",
+              "neuron_liconn_mit.yaml": "mednext", "banis.yaml": "mednext"}
+    for name, arch in expect.items():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            cfg = load_config(tut / name, mode="train")
+            test_cfg = load_config(tut / name, mode="test")
+            model = build_model(cfg)
+        assert cfg.model.arch.type == arch, name
+        assert sum(p.numel() for p in model.parameters()) > 1e5
+        for term in cfg.model.loss.losses or []:
+            assert dict(term)["function"] in _LOSSES, (name, dict(term)["function"])
+        assert test_cfg.inference.sliding_window.window_size is None or len(test_cfg.inference.sliding_window.window_size) in (2, 3)
+    cremi = load_config(tut / "syn_cremi.yaml", mode="train")
+    assert list(cremi.model.rsunet.width) == [18, 36, 48, 64, 80] and cremi.model.rsunet.norm == "batch"      # explicit `batch` over the profile's `group`
