@@ -21,7 +21,7 @@ struct LossGeom {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
-// sums[slot][n*C + c][5] = (sum_{w>0} w*bce, #{w>0}, sum p*t, sum p, sum t) over the slot's rows
+// sums[slot][n*C + c][5] = (sum_{w>0} w*bce, #{w>0}, sum_{w>0} p*t, sum_{w>0} p, sum_{w>0} t) over the slot's rows
 __global__ void __launch_bounds__(256)
 bce_dice_sums_kernel(const float* __restrict__ x, const float* __restrict__ t, const float* __restrict__ w,
                      float* __restrict__ part, LossGeom g, long rows_per_slot) {
@@ -41,8 +41,12 @@ bce_dice_sums_kernel(const float* __restrict__ x, const float* __restrict__ t, c
     const float lw = 1.0f + (g.pos_weight - 1.0f) * tv;
     const float bce = (1.0f - tv) * xv + lw * (log1pf(__expf(-fabsf(xv))) + fmaxf(-xv, 0.f));
     const float p = sigmoidf_(xv);
-    if (wv > 0.f) { s[0] += wv * bce; s[1] += 1.0f; }      // mean over the valid (weight > 0) voxels, losses.py:17-44
-    s[2] += p * tv; s[3] += p; s[4] += tv;
+    if (wv > 0.f) {
+      s[0] += wv * bce; s[1] += 1.0f;      // mean over the valid (weight > 0) voxels, losses.py:17-44
+      // Dice has no weight argument: the reference feeds it masked INPUTS (orchestrator.py:648-655: invalid voxels get the
+      // clamp floor -20 as logit and 0 as target), i.e. they drop out of all three sums up to sigmoid(-20) = 2e-9 each
+      s[2] += p * tv; s[3] += p; s[4] += tv;
+    }
   }
 #pragma unroll
   for (int k = 0; k < 5; ++k) sm[k][threadIdx.x] = s[k];
@@ -109,7 +113,7 @@ bce_dice_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, co
     const float wv = wp ? wp[r * g.ws_r] : 1.0f;
     const float p = sigmoidf_(xv);
     const float gb = wv > 0.f ? kb * wv * (p * (1.0f + (g.pos_weight - 1.0f) * tv) - g.pos_weight * tv) : 0.f;
-    const float gd = kd * (I2 - 2.0f * tv * Dn) * p * (1.0f - p);
+    const float gd = wv > 0.f ? kd * (I2 - 2.0f * tv * Dn) * p * (1.0f - p) : 0.f;      // masked_fill blocks the gradient
     dp[r * g.ds_r] = gb + gd;
   }
 }

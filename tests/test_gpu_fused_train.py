@@ -8,8 +8,11 @@ pytestmark = pytest.mark.gpu
 
 
 def _ref_loss(x, t, w, w_bce, w_dice, pw):
-    from pytorch_connectomics_amd.training.module import dice_loss_sigmoid, weighted_bce_with_logits
-    return w_bce * weighted_bce_with_logits(x, t, w, pw) + w_dice * dice_loss_sigmoid(x, t)
+    """BCE takes the mask as its weight argument; Dice has none and sees it through its inputs (orchestrator.py:648-655):
+    invalid voxels carry the clamp floor as logit (sigmoid(-20) = 2e-9: the kernel uses exactly 0) and 0 as target."""
+    from pytorch_connectomics_amd.training.module import _mask_for_unweighted_loss, dice_loss_sigmoid, weighted_bce_with_logits
+    xd, td = _mask_for_unweighted_loss(x, t, w, -20.0)
+    return w_bce * weighted_bce_with_logits(x, t, w, pw) + w_dice * dice_loss_sigmoid(xd, td)
 
 
 @pytest.mark.parametrize("C,layout,mask,pw,wb,wd", [(1, "ncdhw", False, None, 1.0, 1.0), (3, "cl", False, None, 1.0, 0.5),
