@@ -375,7 +375,10 @@ class ConnectomicsModule(nn.Module):
                                     "pred_slice": get("pred_slice"),
                                     "target_slice": get("target_slice"), "pos_weight": get("pos_weight"),
                                     "kwargs": dict(get("kwargs", None) or {})})
-        self.fused_loss = bool(getattr(loss_cfg, "fused", True))
+        # adaptive loss balancing (training/losses/balancing.py): a trainable sub-module, every loss entry is one task
+        from .balancing import build_loss_weighter
+        self.loss_weighter = build_loss_weighter(cfg, len(self.loss_terms), self.model)
+        self.fused_loss = bool(getattr(loss_cfg, "fused", True)) and self.loss_weighter is None
         # every prediction is clamped before its loss, at every scale (orchestrator.py:95-96,574; schema/model.py:50-51)
         self.clamp_min = float(getattr(loss_cfg, "deep_supervision_clamp_min", -20.0))
         self.clamp_max = float(getattr(loss_cfg, "deep_supervision_clamp_max", 20.0))
@@ -441,6 +444,7 @@ class ConnectomicsModule(nn.Module):
             if res is not None:
                 return res
         total, parts = 0.0, {}
+        tasks, names = [], []
         for i, t in terms:
             p, y = pred, target
             if t["pred_slice"] is not None:
@@ -451,7 +455,17 @@ class ConnectomicsModule(nn.Module):
             if not torch.isfinite(v):
                 raise FloatingPointError(f"loss term {t['fn']} is not finite")
             parts[f"loss_{i}_{t['fn']}"] = v.detach()
-            total = total + t["weight"] * v
+            if self.loss_weighter is not None:
+                tasks.append(t["weight"] * v)
+                names.append(f"loss_{i}_{t['fn']}")
+            else:
+                total = total + t["weight"] * v
+        if self.loss_weighter is not None and tasks:
+            # task losses = raw value x static weight; the weighter returns the scalar to back-propagate (orchestrator.py:110-127)
+            total, wts, logs = self.loss_weighter.combine(tasks, names, "train" if self.training else "val")
+            for n, w in zip(names, wts):
+                parts[f"{n}_balance_weight"] = w
+            parts.update(logs)
         return total, parts
 
     def _head_of(self, term_index: int, term, heads) -> str:
@@ -525,12 +539,17 @@ class ConnectomicsModule(nn.Module):
         return {"val_loss_total": loss, "val_jaccard": (p & t).sum().float() / union}
 
     def configure_optimizers(self):
-        opt = build_optimizer(self.cfg, self.model)
+        # with an adaptive loss weighter the optimizer takes the whole module (its task weights train with the network), as the
+        # reference does (lightning/model.py:1160-1162)
+        opt = build_optimizer(self.cfg, self if self.loss_weighter is not None else self.model)
         return opt, build_lr_scheduler(self.cfg, opt)
 
     # ---- checkpoints in the Lightning layout ------------------------------------------------------
     def checkpoint_dict(self, optimizer=None) -> Dict[str, Any]:
-        ck = {"state_dict": {"model." + k: v.detach().cpu() for k, v in self.model.state_dict().items()},
+        sd = {"model." + k: v.detach().cpu() for k, v in self.model.state_dict().items()}
+        if self.loss_weighter is not None:      # a sub-module of the LightningModule in the reference: same key prefix
+            sd.update({"loss_weighter." + k: v.detach().cpu() for k, v in self.loss_weighter.state_dict().items() if v is not None})
+        ck = {"state_dict": sd,
               "global_step": self.global_step,
               "pytc_metadata": {"format_version": 1, "model_arch": str(getattr(self.cfg.model.arch, "type", ""))}}
         ck["epoch"] = int(getattr(self, "current_epoch", 0))
@@ -558,6 +577,12 @@ class ConnectomicsModule(nn.Module):
         bad_unexpected = [k for k in unexpected if not any(f".out_{i}." in "." + k for i in (1, 2, 3, 4))]
         if missing or bad_unexpected:
             raise RuntimeError(f"checkpoint does not match the model: missing {missing[:5]}, unexpected {bad_unexpected[:5]}")
+        if self.loss_weighter is not None:
+            wsd = {k[len("loss_weighter."):]: v for k, v in ck["state_dict"].items() if k.startswith("loss_weighter.")}
+            if wsd:
+                if "initial_losses" in wsd and getattr(self.loss_weighter, "initial_losses", 0) is None:
+                    self.loss_weighter.initial_losses = wsd["initial_losses"].clone()     # a None buffer cannot be load_state_dict'ed
+                self.loss_weighter.load_state_dict({k: v for k, v in wsd.items() if k != "initial_losses"}, strict=False)
         self.global_step = int(ck.get("global_step", 0))
         self.current_epoch = int(ck.get("epoch", 0))
         self._resume = {k: ck[k] for k in ("optimizer_states", "lr_schedulers", "callbacks") if k in ck}
