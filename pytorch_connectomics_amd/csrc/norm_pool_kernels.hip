@@ -232,6 +232,37 @@ affine_act_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __res
   }
 }
 
+// 16-byte form (C % VEC == 0): one thread = VEC consecutive channels of one voxel, one index decomposition per chunk instead of
+// a 64-bit modulo and divide per element; same arithmetic per element as affine_act_kernel.
+template <typename T>
+__global__ void __launch_bounds__(256)
+affine_act_vec_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ ab, long rows, int C, int act,
+                      float prm, long chunks) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int cq = C / VEC;
+  const long per_sample = rows * cq;
+  long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; q < chunks; q += stride) {
+    const int c0 = (int)(q % cq) * VEC;
+    const long n = q / per_sample;
+    float v[VEC];
+    VecIO<T, VEC>::load(x + q * VEC, v);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float t = v[j];
+      if (ab) t = fmaf(t, ab[(n * 2 + 0) * C + c0 + j], ab[(n * 2 + 1) * C + c0 + j]);
+      if (act == PYTC_ACT_RELU) t = fmaxf(t, 0.f);
+      else if (act == PYTC_ACT_LEAKY) t = t > 0.f ? t : t * prm;
+      else if (act == PYTC_ACT_ELU) t = t > 0.f ? t : prm * (__expf(t) - 1.0f);
+      else if (act == PYTC_ACT_SIGMOID) t = 1.f / (1.f + __expf(-t));
+      else if (act == PYTC_ACT_TANH) t = tanhf(t);
+      v[j] = t;
+    }
+    VecIO<T, VEC>::store(y + q * VEC, v);
+  }
+}
+
 }  // namespace pytc
 
 using namespace pytc;
@@ -240,6 +271,19 @@ extern "C" int pytc_affine_act(const void* x, void* y, const float* ab, int N, i
                                int dtype, void* stream) {
   PYTC_REQUIRE(x && y && N >= 1 && rows >= 1 && C >= 1, "affine_act: bad arguments");
   const long total = (long)N * rows * C;
+  const int vec = dtype == PYTC_BF16 ? 8 : 4;
+  if ((dtype == PYTC_BF16 || dtype == PYTC_F32) && C % vec == 0 && tuning_get("elementwise_vec", 1)) {
+    const long chunks = total / vec;
+    const int vb = (int)((chunks + 255) / 256 < 16384 ? (chunks + 255) / 256 : 16384);
+    if (dtype == PYTC_BF16)
+      hipLaunchKernelGGL(affine_act_vec_kernel<bf16_t>, dim3(vb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, ab,
+                         (long)rows, C, act, prm, chunks);
+    else
+      hipLaunchKernelGGL(affine_act_vec_kernel<float>, dim3(vb), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, ab,
+                         (long)rows, C, act, prm, chunks);
+    PYTC_LAUNCH_CHECK("affine_act");
+    return PYTC_OK;
+  }
   int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   if (dtype == PYTC_BF16)
     hipLaunchKernelGGL(affine_act_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,

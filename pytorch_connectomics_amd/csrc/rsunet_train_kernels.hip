@@ -375,6 +375,63 @@ act_bwd_kernel(const T* __restrict__ da, const T* __restrict__ x, const float* _
   }
 }
 
+// 16-byte forms of act_bwd / norm_bwd_apply_general (C % VEC == 0): one thread = VEC consecutive channels of one voxel; the
+// element-wise arithmetic is the scalar kernels', so results are bit-identical (A/B: pytc_set_tuning("elementwise_vec", 0)).
+template <typename T>
+__global__ void __launch_bounds__(256)
+act_bwd_vec_kernel(const T* __restrict__ da, const T* __restrict__ x, const float* __restrict__ ab, T* __restrict__ dt,
+                   T* __restrict__ dp, long rows, int C, long chunks, int act, float prm) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int cq = C / VEC;
+  const long per_sample = rows * cq;
+  long q = (long)blockIdx.x * 256 + threadIdx.x;
+  const long stride = (long)gridDim.x * 256;
+  for (; q < chunks; q += stride) {
+    const int c0 = (int)(q % cq) * VEC;
+    const long n = q / per_sample;
+    float xv[VEC], dv[VEC], o[VEC], pv[VEC];
+    VecIO<T, VEC>::load(x + q * VEC, xv);
+    VecIO<T, VEC>::load(da + q * VEC, dv);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float t = xv[j];
+      if (ab) t = to_f32<T>(from_f32<T>(fmaf(t, ab[(n * 2 + 0) * C + c0 + j], ab[(n * 2 + 1) * C + c0 + j])));
+      o[j] = dv[j] * act_der(t, act, prm);
+      pv[j] = t < 0.f ? dv[j] * t : 0.f;
+    }
+    VecIO<T, VEC>::store(dt + q * VEC, o);
+    if (dp) VecIO<T, VEC>::store(dp + q * VEC, pv);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+norm_bwd_apply_general_vec_kernel(const T* __restrict__ d, const T* __restrict__ x, const float* __restrict__ mr,
+                                  const float* __restrict__ gamma, const float* __restrict__ M, T* __restrict__ dx,
+                                  long rows, int C, long chunks) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int cq = C / VEC;
+  const long per_sample = rows * cq;
+  long q = (long)blockIdx.x * 256 + threadIdx.x;
+  const long stride = (long)gridDim.x * 256;
+  for (; q < chunks; q += stride) {
+    const int c0 = (int)(q % cq) * VEC;
+    const long n = q / per_sample;
+    float xv[VEC], dv[VEC], o[VEC];
+    VecIO<T, VEC>::load(x + q * VEC, xv);
+    VecIO<T, VEC>::load(d + q * VEC, dv);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = c0 + j;
+      const float mean = mr[(n * 2 + 0) * C + c], rstd = mr[(n * 2 + 1) * C + c];
+      const float xh = (xv[j] - mean) * rstd;
+      const float gd = (gamma ? gamma[c] : 1.f) * dv[j];
+      o[j] = rstd * (gd - M[(n * 2 + 0) * C + c] - xh * M[(n * 2 + 1) * C + c]);
+    }
+    VecIO<T, VEC>::store(dx + q * VEC, o);
+  }
+}
+
 // ---- general norm backward apply: dx = rstd * (gamma * d - M1 - xhat * M2), M per (n, c) (group-expanded means) -----
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -632,6 +689,18 @@ extern "C" int pytc_act_bwd(const void* da, const void* x, const float* ab, void
   PYTC_REQUIRE(da && x && dt && N >= 1 && rows >= 1 && C >= 1, "act_bwd: bad arguments");
   const long total = (long)N * rows * C;
   hipStream_t s = (hipStream_t)stream;
+  {
+    const int vec = dtype == PYTC_BF16 ? 8 : 4;
+    if ((dtype == PYTC_BF16 || dtype == PYTC_F32) && C % vec == 0 && tuning_get("elementwise_vec", 1)) {
+      const long chunks = total / vec;
+      if (dtype == PYTC_BF16)
+        hipLaunchKernelGGL(act_bwd_vec_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(256), 0, s, (const bf16_t*)da, (const bf16_t*)x, ab, (bf16_t*)dt, (bf16_t*)dp, (long)rows, C, chunks, act, prm);
+      else
+        hipLaunchKernelGGL(act_bwd_vec_kernel<float>, dim3(grid_for(chunks)), dim3(256), 0, s, (const float*)da, (const float*)x, ab, (float*)dt, (float*)dp, (long)rows, C, chunks, act, prm);
+      PYTC_LAUNCH_CHECK("act_bwd");
+      return PYTC_OK;
+    }
+  }
   RS_DISPATCH(dtype,
               hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)da, (const bf16_t*)x, ab, (bf16_t*)dt, (bf16_t*)dp, (long)rows, C, total, act, prm),
               hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)da, (const float*)x, ab, (float*)dt, (float*)dp, (long)rows, C, total, act, prm),
@@ -645,6 +714,18 @@ extern "C" int pytc_norm_bwd_apply_general(const void* d, const void* x, const f
   PYTC_REQUIRE(d && x && mean_rstd && M && dx, "norm_bwd_apply_general: null pointer");
   const long total = (long)N * rows * C;
   hipStream_t s = (hipStream_t)stream;
+  {
+    const int vec = dtype == PYTC_BF16 ? 8 : 4;
+    if ((dtype == PYTC_BF16 || dtype == PYTC_F32) && C % vec == 0 && tuning_get("elementwise_vec", 1)) {
+      const long chunks = total / vec;
+      if (dtype == PYTC_BF16)
+        hipLaunchKernelGGL(norm_bwd_apply_general_vec_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(256), 0, s, (const bf16_t*)d, (const bf16_t*)x, mean_rstd, gamma, M, (bf16_t*)dx, (long)rows, C, chunks);
+      else
+        hipLaunchKernelGGL(norm_bwd_apply_general_vec_kernel<float>, dim3(grid_for(chunks)), dim3(256), 0, s, (const float*)d, (const float*)x, mean_rstd, gamma, M, (float*)dx, (long)rows, C, chunks);
+      PYTC_LAUNCH_CHECK("norm_bwd_apply_general");
+      return PYTC_OK;
+    }
+  }
   RS_DISPATCH(dtype,
               hipLaunchKernelGGL(norm_bwd_apply_general_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)d, (const bf16_t*)x, mean_rstd, gamma, M, (bf16_t*)dx, (long)rows, C, total),
               hipLaunchKernelGGL(norm_bwd_apply_general_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)d, (const float*)x, mean_rstd, gamma, M, (float*)dx, (long)rows, C, total),

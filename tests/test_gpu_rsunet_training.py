@@ -341,3 +341,39 @@ def test_rsunet_train_mode_forward_under_no_grad_uses_batch_statistics():
         got = m(x.cuda())
     torch.testing.assert_close(got.cpu(), ref, rtol=1e-4, atol=1e-4)
     assert not torch.equal(m.input_conv.pre[0].norm.running_mean, rm0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_vectorised_elementwise_kernels_are_bit_identical_to_the_scalar_ones(dtype):
+    """affine_act / act_bwd / norm_bwd_apply_general in their 16-byte forms (C % 8 == 0 for bf16, % 4 for fp32) against the scalar
+    kernels they replace (pytc_set_tuning("elementwise_vec", 0)): same arithmetic per element, so torch.equal."""
+    from pytorch_connectomics_amd import _native as nat
+    from pytorch_connectomics_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(9)
+    N, D, H, W, C = 2, 5, 7, 9, 16
+    x = torch.randn(N, D, H, W, C, generator=g).cuda().to(dtype)
+    d = torch.randn(N, D, H, W, C, generator=g).cuda().to(dtype)
+    ab = torch.randn(N, 2, C, generator=g).cuda()
+    mr = torch.stack([torch.randn(N, C, generator=g), torch.rand(N, C, generator=g) + 0.5], 1).cuda().contiguous()
+    M = torch.randn(N, 2, C, generator=g).cuda()
+    gamma = torch.randn(C, generator=g).cuda()
+
+    def run():
+        outs = []
+        for act, prm in ((nat.ACT_RELU, 0.0), (nat.ACT_LEAKY, 0.2), (nat.ACT_ELU, 1.0), (nat.ACT_NONE, 0.0)):
+            outs.append(ops.affine_act(x, ab, act, prm))
+            dt, dp = ops.act_bwd(d, x, ab, act, prm, want_prelu=act == nat.ACT_LEAKY)
+            outs.append(dt)
+            if dp is not None:
+                outs.append(dp)
+        outs.append(ops.affine_act(x, None, nat.ACT_SIGMOID, 0.0))
+        outs.append(ops.norm_bwd_apply_general(d, x, mr, gamma, M))
+        outs.append(ops.norm_bwd_apply_general(d, x, mr, None, M))
+        return outs
+    fast = run()
+    ops.set_tuning("elementwise_vec", 0)
+    try:
+        slow = run()
+    finally:
+        ops.set_tuning("elementwise_vec", 1)
+    assert len(fast) == len(slow) and all(torch.equal(a, b) for a, b in zip(fast, slow))
