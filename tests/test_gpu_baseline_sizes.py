@@ -224,3 +224,73 @@ def test_c4_chunked_mednext_l_96_crop_vs_oracle(tmp_path):
             bf16_mean_dP=d16.mean(), bf16_label_flip_frac=float(((np.asarray(got16) > 0.5) != (ref > 0.5)).mean()))
     assert d32.max() < TOL_F32_PROB
     assert d16.max() < 8e-2
+
+
+def test_c5_monai_unet_24x256x256_vs_oracle():
+    """BASELINE configs[4] (CREMI synapse): the MONAI-style residual U-Net [32, 64, 128, 256] (BatchNorm, PReLU) on an anisotropic
+    patch at the bench leg's size -- 24 x 256 x 256, the nearest size to the config's 20 x 256 x 256 that the architecture's
+    all-axes stride-2 levels accept (20 fails MONAI's own skip concatenation) -- fp32 gate 1e-3, bf16 reported."""
+    from oracle import monai_unet_oracle as UO
+    from pytorch_connectomics_amd.models import build_model
+    cfg = NS(model=NS(arch=NS(type="monai_unet"), in_channels=1, out_channels=1, input_size=[24, 256, 256],
+                      monai=NS(filters=[32, 64, 128, 256], num_res_units=2, kernel_size=3, norm="batch", dropout=0.0,
+                               upsample_mode="deconv")))
+    torch.manual_seed(0)
+    m = build_model(cfg)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():       # a "trained" state: non-trivial norm affine, running statistics, PReLU slopes
+        for n, p in m.named_parameters():
+            if n.endswith("adn.N.weight") or n.endswith("adn.N.bias"):
+                p.add_(0.2 * torch.randn(p.shape, generator=g))
+            if n.endswith("adn.A.weight"):
+                p.copy_(0.1 + 0.3 * torch.rand(p.shape, generator=g))
+        for n, b in m.named_buffers():
+            if n.endswith("running_mean"):
+                b.copy_(0.3 * torch.randn(b.shape, generator=g))
+            if n.endswith("running_var"):
+                b.copy_(0.5 + torch.rand(b.shape, generator=g))
+    st = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.rand(1, 1, 24, 256, 256, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        ref = UO.forward(st, x, n_levels=4, norm="batch")
+        m = m.cuda().eval()
+        got32 = m(x.cuda()).float().cpu()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            got16 = m(x.cuda()).float().cpu()
+    mx32, mean32, flip32 = _stats(got32, ref)
+    mx16, mean16, flip16 = _stats(got16, ref)
+    _report("C5_monai_unet_24x256x256", fp32_max_dP=mx32, fp32_mean_dP=mean32, fp32_label_flip_frac=flip32, bf16_max_dP=mx16,
+            bf16_mean_dP=mean16, bf16_label_flip_frac=flip16)
+    assert mx32 < TOL_F32_PROB
+    margin = (torch.sigmoid(ref) - 0.5).abs() > TOL_F32_PROB
+    assert torch.equal((torch.sigmoid(got32) > 0.5)[margin], (torch.sigmoid(ref) > 0.5)[margin])
+    assert mx16 < 6e-2          # bf16 through 4 levels of strided / transposed dense convs and BatchNorm affines
+
+
+def test_c1_minimal_rsunet_64_vs_oracle():
+    """BASELINE configs[0] at its own size: RSUNet 2-level, 1 x 8ch, 64^3 (tutorials/minimal_rsunet.yaml's model), fp32 and bf16."""
+    from oracle import rsunet_oracle as RO
+    from pytorch_connectomics_amd.models.architectures.rsunet import RSUNet
+    torch.manual_seed(0)
+    m = RSUNet(1, 1, width=[8, 16], norm="batch", activation="relu")
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n, b in m.named_buffers():
+            if n.endswith("running_mean"):
+                b.copy_(0.2 * torch.randn(b.shape, generator=g))
+            if n.endswith("running_var"):
+                b.copy_(0.5 + torch.rand(b.shape, generator=g))
+    st = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.rand(1, 1, 64, 64, 64, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        ref = RO.forward(st, x, width=[8, 16], norm="batch", activation="relu")
+        m = m.cuda().eval()
+        got32 = m(x.cuda()).float().cpu()
+        m.compute_dtype = torch.bfloat16
+        got16 = m(x.cuda()).float().cpu()
+    mx32, mean32, flip32 = _stats(got32, ref)
+    mx16, mean16, flip16 = _stats(got16, ref)
+    _report("C1_rsunet_2level_64", fp32_max_dP=mx32, fp32_mean_dP=mean32, bf16_max_dP=mx16, bf16_mean_dP=mean16,
+            bf16_label_flip_frac=flip16)
+    # bf16: measured max 4.2e-2 at one voxel (mean 2.1e-3) with random running statistics on 8-channel layers
+    assert mx32 < TOL_F32_PROB and mx16 < 6e-2 and mean16 < 5e-3
