@@ -63,6 +63,9 @@ def read_volume(spec: str, *, default_shape=(64, 128, 128), seed: int = 0) -> np
                                "against libhdf5); neither is available -- convert the volume to .npy")
         with be.File(path, "r") as fh:
             return np.asarray(fh["main" if "main" in fh else list(fh.keys())[0]][...])
+    if path.suffix.lower() in (".tif", ".tiff"):
+        from .utils.tiffstack import read_tiff_volume
+        return read_tiff_volume(str(path))
     raise ValueError(f"unsupported volume format: {spec}")
 
 

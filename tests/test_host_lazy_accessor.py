@@ -146,3 +146,46 @@ def test_zarr_reader_rejects_what_it_cannot_decode(tmp_path):
                                            "compressor": None, "fill_value": 7, "order": "C", "filters": None}))
     a = ZarrV2Array(str(z))
     assert float(a[1:3, :, 0:2].mean()) == 7.0            # missing chunks read as fill_value
+
+
+@pytest.mark.parametrize("dtype,compression", [(np.uint8, None), (np.uint16, "tiff_lzw"), (np.float32, "tiff_adobe_deflate")])
+def test_tiff_stack_reader_and_accessor(tmp_path, dtype, compression):
+    """Multi-page TIFF stacks (what Lucchi++ / SNEMI3D ship): whole-volume read, page-range region reads, and the lazy
+    accessor over them give exactly what the same data gives from .npy (reference io.py:199-237, lazy.py:639-676)."""
+    from PIL import Image
+    from pytorch_connectomics_amd.main import read_volume
+    from pytorch_connectomics_amd.utils.tiffstack import TiffStack, read_tiff_volume, tiff_volume_shape
+    rng = np.random.default_rng(3)
+    vol = (rng.random((7, 12, 10)) * (255 if dtype == np.uint8 else 4000)).astype(dtype)
+    path = tmp_path / "stack.tif"
+    pages = [Image.fromarray(p) for p in vol]
+    pages[0].save(path, save_all=True, append_images=pages[1:], **({"compression": compression} if compression else {}))
+    assert tiff_volume_shape(str(path)) == vol.shape
+    got = read_tiff_volume(str(path))
+    assert got.dtype == vol.dtype
+    np.testing.assert_array_equal(got, vol)
+    np.testing.assert_array_equal(read_volume(str(path)), vol)
+    with TiffStack(str(path)) as st:
+        assert st.shape == vol.shape and st.ndim == 3 and len(st) == 7
+        np.testing.assert_array_equal(st[2:5, 3:9, 1:7], vol[2:5, 3:9, 1:7])
+        np.testing.assert_array_equal(st[-1], vol[-1])
+        np.testing.assert_array_equal(st[..., 4], vol[..., 4])
+        assert st[3:3].shape == (0, 12, 10)
+        with pytest.raises(IndexError):
+            st[7]
+    np.save(tmp_path / "stack.npy", vol)
+    kw = dict(kind="image", transpose_axes=(1, 0, 2), context_pad=((1, 1), (2, 0), (0, 2)), context_pad_mode="reflect",
+              normalize_mode="divide-255")
+    with LazyVolumeAccessor(str(path), **kw) as a, LazyVolumeAccessor(str(tmp_path / "stack.npy"), **kw) as b:
+        assert a.fmt == "tiff" and a.padded_spatial_shape == b.padded_spatial_shape
+        np.testing.assert_array_equal(a.read_region((0, 0, 0), a.padded_spatial_shape), b.read_region((0, 0, 0), b.padded_spatial_shape))
+        pa = a.read_patch((3, 2, 1), (6, 4, 8), outer_pad_mode="constant", outer_pad_value=0.0)
+        np.testing.assert_array_equal(pa, b.read_patch((3, 2, 1), (6, 4, 8), outer_pad_mode="constant", outer_pad_value=0.0))
+    one = tmp_path / "one.tif"
+    Image.fromarray(vol[0]).save(one)
+    assert tiff_volume_shape(str(one)) == vol.shape[1:]
+    with pytest.raises(ValueError, match="single-page"):
+        LazyVolumeAccessor(str(one), kind="image")
+    (tmp_path / "fake.tif").write_bytes(b"not a tiff")
+    with pytest.raises(Exception):
+        TiffStack(str(tmp_path / "fake.tif"))
