@@ -57,10 +57,13 @@ def topology(n_channels: int, exp_r, block_counts: Sequence[int]):
 
 def init_state(in_channels=1, n_channels=32, n_classes=1, exp_r=2, kernel_size=3,
                block_counts=(2,) * 9, deep_supervision=False, do_res_up_down=True,
-               grn=False, norm_type="group", seed=0) -> Dict[str, torch.Tensor]:
-    """Random parameters with the upstream key names and PyTorch-layout shapes."""
+               grn=False, norm_type="group", seed=0, dim="3d") -> Dict[str, torch.Tensor]:
+    """Random parameters with the upstream key names and PyTorch-layout shapes.  dim='2d': the Conv2d /
+    ConvTranspose2d twin the constructor builds for `dim='2d'` (mednext_models.py:449-467); every function
+    below picks the 2-D or 3-D functional op from the rank of the weight it is given."""
     g = torch.Generator().manual_seed(seed)
     k = int(kernel_size)
+    nd = {"2d": 2, "3d": 3}[dim]
     st: Dict[str, torch.Tensor] = {}
 
     def rnd(*shape, scale=1.0):
@@ -68,7 +71,7 @@ def init_state(in_channels=1, n_channels=32, n_classes=1, exp_r=2, kernel_size=3
 
     def conv(name, cout, cin_per_group, ks, fan_in):
         b = 1.0 / (fan_in ** 0.5)
-        st[name + ".weight"] = rnd(cout, cin_per_group, ks, ks, ks, scale=b)
+        st[name + ".weight"] = rnd(cout, cin_per_group, *([ks] * nd), scale=b)
         st[name + ".bias"] = rnd(cout, scale=b)
 
     def block(prefix, cin, cout, r, transposed_res=None):
@@ -78,8 +81,8 @@ def init_state(in_channels=1, n_channels=32, n_classes=1, exp_r=2, kernel_size=3
         conv(prefix + ".conv2", r * cin, cin, 1, cin)
         conv(prefix + ".conv3", cout, r * cin, 1, r * cin)
         if grn:
-            st[prefix + ".grn_beta"] = 0.1 * rnd(1, r * cin, 1, 1, 1)
-            st[prefix + ".grn_gamma"] = 0.1 * rnd(1, r * cin, 1, 1, 1)
+            st[prefix + ".grn_beta"] = 0.1 * rnd(1, r * cin, *([1] * nd))
+            st[prefix + ".grn_gamma"] = 0.1 * rnd(1, r * cin, *([1] * nd))
 
     conv("stem", n_channels, in_channels, 1, in_channels)
     for kind, name, cin, cout, r, nb in topology(n_channels, exp_r, list(block_counts)):
@@ -93,16 +96,28 @@ def init_state(in_channels=1, n_channels=32, n_classes=1, exp_r=2, kernel_size=3
                     conv(name + ".res_conv", cout, cin, 1, cin)
                 else:  # ConvTranspose3d weight layout is (C_in, C_out, 1,1,1)
                     b = 1.0 / (cout ** 0.5)
-                    st[name + ".res_conv.weight"] = rnd(cin, cout, 1, 1, 1, scale=b)
+                    st[name + ".res_conv.weight"] = rnd(cin, cout, *([1] * nd), scale=b)
                     st[name + ".res_conv.bias"] = rnd(cout, scale=b)
     heads = [0] + ([1, 2, 3, 4] if deep_supervision else [])
     for h in heads:
         c = n_channels << h
         b = 1.0 / (n_classes ** 0.5)
-        st[f"out_{h}.conv_out.weight"] = rnd(c, n_classes, 1, 1, 1, scale=b)  # ConvTranspose layout
+        st[f"out_{h}.conv_out.weight"] = rnd(c, n_classes, *([1] * nd), scale=b)  # ConvTranspose layout
         st[f"out_{h}.conv_out.bias"] = rnd(n_classes, scale=b)
     st["dummy_tensor"] = torch.ones(1)
     return st
+
+
+def _conv(x, w, b, **kw):
+    return (F.conv2d if w.dim() == 4 else F.conv3d)(x, w, b, **kw)
+
+
+def _convT(x, w, b, **kw):
+    return (F.conv_transpose2d if w.dim() == 4 else F.conv_transpose3d)(x, w, b, **kw)
+
+
+def _front_pad(y):
+    return F.pad(y, (1, 0) * (y.dim() - 2))
 
 
 def _norm(t, st, prefix, norm_type):
@@ -113,43 +128,43 @@ def _norm(t, st, prefix, norm_type):
     u = t.mean(1, keepdim=True)
     s = (t - u).pow(2).mean(1, keepdim=True)
     tn = (t - u) / torch.sqrt(s + 1e-5)
-    return st[prefix + ".norm.weight"][None, :, None, None, None] * tn + \
-        st[prefix + ".norm.bias"][None, :, None, None, None]
+    bc = (1, -1) + (1,) * (t.dim() - 2)
+    return st[prefix + ".norm.weight"].view(bc) * tn + st[prefix + ".norm.bias"].view(bc)
 
 
 def _mlp(t, st, prefix, norm_type, grn):
-    h = F.gelu(F.conv3d(_norm(t, st, prefix, norm_type), st[prefix + ".conv2.weight"],
-                        st[prefix + ".conv2.bias"]))
+    h = F.gelu(_conv(_norm(t, st, prefix, norm_type), st[prefix + ".conv2.weight"],
+                     st[prefix + ".conv2.bias"]))
     if grn:
-        gx = torch.norm(h, p=2, dim=(-3, -2, -1), keepdim=True)
+        gx = torch.norm(h, p=2, dim=tuple(range(2, h.dim())), keepdim=True)
         nx = gx / (gx.mean(dim=1, keepdim=True) + 1e-6)
         h = st[prefix + ".grn_gamma"] * (h * nx) + st[prefix + ".grn_beta"] + h
-    return F.conv3d(h, st[prefix + ".conv3.weight"], st[prefix + ".conv3.bias"])
+    return _conv(h, st[prefix + ".conv3.weight"], st[prefix + ".conv3.bias"])
 
 
 def block_forward(x, st, prefix, k, do_res=True, norm_type="group", grn=False):
-    t = F.conv3d(x, st[prefix + ".conv1.weight"], st[prefix + ".conv1.bias"], padding=k // 2,
-                 groups=x.shape[1])
+    t = _conv(x, st[prefix + ".conv1.weight"], st[prefix + ".conv1.bias"], padding=k // 2,
+              groups=x.shape[1])
     y = _mlp(t, st, prefix, norm_type, grn)
     return x + y if do_res else y
 
 
 def down_forward(x, st, prefix, k, norm_type="group", grn=False):
-    t = F.conv3d(x, st[prefix + ".conv1.weight"], st[prefix + ".conv1.bias"], stride=2,
-                 padding=k // 2, groups=x.shape[1])
+    t = _conv(x, st[prefix + ".conv1.weight"], st[prefix + ".conv1.bias"], stride=2,
+              padding=k // 2, groups=x.shape[1])
     y = _mlp(t, st, prefix, norm_type, grn)
     if prefix + ".res_conv.weight" in st:
-        y = y + F.conv3d(x, st[prefix + ".res_conv.weight"], st[prefix + ".res_conv.bias"], stride=2)
+        y = y + _conv(x, st[prefix + ".res_conv.weight"], st[prefix + ".res_conv.bias"], stride=2)
     return y
 
 
 def up_forward(x, st, prefix, k, norm_type="group", grn=False):
-    t = F.conv_transpose3d(x, st[prefix + ".conv1.weight"], st[prefix + ".conv1.bias"], stride=2,
-                           padding=k // 2, groups=x.shape[1])
-    y = F.pad(_mlp(t, st, prefix, norm_type, grn), (1, 0, 1, 0, 1, 0))
+    t = _convT(x, st[prefix + ".conv1.weight"], st[prefix + ".conv1.bias"], stride=2,
+               padding=k // 2, groups=x.shape[1])
+    y = _front_pad(_mlp(t, st, prefix, norm_type, grn))
     if prefix + ".res_conv.weight" in st:
-        r = F.conv_transpose3d(x, st[prefix + ".res_conv.weight"], st[prefix + ".res_conv.bias"], stride=2)
-        y = y + F.pad(r, (1, 0, 1, 0, 1, 0))
+        r = _convT(x, st[prefix + ".res_conv.weight"], st[prefix + ".res_conv.bias"], stride=2)
+        y = y + _front_pad(r)
     return y
 
 
@@ -159,7 +174,7 @@ def forward_features(st, x, *, n_channels=32, exp_r=2, kernel_size=3, block_coun
     If `collect` is a list, decoder-level features (deepest first: bottleneck, dec_3, dec_2,
     dec_1) are appended for the deep-supervision heads."""
     k = int(kernel_size)
-    x = F.conv3d(x, st["stem.weight"], st["stem.bias"])
+    x = _conv(x, st["stem.weight"], st["stem.bias"])
     skips = {}
     for kind, name, cin, cout, r, nb in topology(n_channels, exp_r, list(block_counts)):
         if kind == "blocks":
@@ -177,7 +192,7 @@ def forward_features(st, x, *, n_channels=32, exp_r=2, kernel_size=3, block_coun
 
 
 def forward_output(st, feat, head=0):
-    return F.conv_transpose3d(feat, st[f"out_{head}.conv_out.weight"], st[f"out_{head}.conv_out.bias"])
+    return _convT(feat, st[f"out_{head}.conv_out.weight"], st[f"out_{head}.conv_out.bias"])
 
 
 def forward(st, x, *, deep_supervision=False, **kw):

@@ -229,9 +229,13 @@ class TTAPredictor:
         elif images.ndim != 5:
             raise ValueError(f"TTA requires 3D, 4D, or 5D input tensor. Got {images.ndim}D tensor with shape "
                              f"{images.shape}. Expected shapes: (D, H, W), (B, D, H, W), or (B, C, D, H, W)")
-        if is_2d_inference_mode(self.cfg) and images.size(2) == 1:
-            raise NotImplementedError("2-D (do_2d) inference is not built for the device engine")
+        # 2-D mode (data.*.do_2d with a depth-1 batch): the reference squeezes the depth axis here (tta.py:598-599) and runs
+        # everything in 2-D; the device engine keeps the depth-1 volume (its kernels index three axes) and predict() drops
+        # the axis from the result instead
         return images
+
+    def _is_flat_2d(self, images: torch.Tensor) -> bool:
+        return bool(is_2d_inference_mode(self.cfg) and images.dim() == 5 and images.size(2) == 1)
 
     def _engine_for(self, images: torch.Tensor):
         """The configured sliding engine, or a single-window engine covering the whole image."""
@@ -244,10 +248,18 @@ class TTAPredictor:
     @torch.no_grad()
     def predict(self, images: torch.Tensor, mask=None, mask_align_to_image: bool = False,
                 requested_head: Optional[str] = None) -> torch.Tensor:
+        images = self._normalize_input(images)
+        flat2d = self._is_flat_2d(images)
+        if flat2d and isinstance(mask, torch.Tensor) and mask.dim() == 4:
+            mask = mask.unsqueeze(2)                        # (B, C, H, W) -> the depth-1 volume the result is masked as
+        out = self._predict_volume(images, mask, mask_align_to_image, requested_head, flat2d)
+        return out.squeeze(2) if (flat2d and out.dim() == 5) else out      # (B, C, H, W) like the reference's 2-D mode
+
+    def _predict_volume(self, images: torch.Tensor, mask, mask_align_to_image: bool, requested_head: Optional[str],
+                        flat2d: bool) -> torch.Tensor:
         prev = self._requested_output_head_override
         self._requested_output_head_override = requested_head
         try:
-            images = self._normalize_input(images)
             ops.require_device(images.device, "TTAPredictor")
             if images.shape[0] != 1:
                 raise ValueError(f"device inference expects batch size 1; got batch {images.shape[0]}.")
@@ -259,7 +271,13 @@ class TTAPredictor:
             enabled = tta is not None and getattr(tta, "enabled", True)
             combos = [([], None, 0)]
             if enabled:
-                combos = resolve_tta_augmentation_combinations(tta, spatial_dims=_resolve_spatial_dims(images.dim()))
+                if flat2d:
+                    # the configuration speaks of the 2 image axes (0 = y, 1 = x; tta_combinations.py:29-34): resolve them
+                    # there, then name the same axes in the depth-1 volume (1 = y, 2 = x)
+                    combos = [([int(a) + 1 for a in f], None if pl is None else tuple(int(a) + 1 for a in pl), k)
+                              for f, pl, k in resolve_tta_augmentation_combinations(tta, spatial_dims=2)]
+                else:
+                    combos = resolve_tta_augmentation_combinations(tta, spatial_dims=_resolve_spatial_dims(images.dim()))
             vol = images[0].to(torch.float32).contiguous()
             orig = tuple(int(v) for v in vol.shape[1:])
             self._last_device = vol.device

@@ -160,7 +160,8 @@ class HipBlockOps:
         def make():
             c = w.shape[0]
             k = w.shape[-1]
-            return w.detach().float().reshape(c, k ** 3).t().contiguous(), k
+            w3 = embed_stencil_2d(w.detach().float()) if w.dim() == 4 else w.detach().float()
+            return w3.reshape(c, k ** 3).t().contiguous(), k
         return self.cache.get(("taps", id(conv)), [w], make)
 
     def _pw(self, conv: nn.Module, dt: torch.dtype, transposed: bool = False):
@@ -227,9 +228,25 @@ class HipBlockOps:
 
     def block(self, m: MedNeXtBlock, x: torch.Tensor, skip: Optional[torch.Tensor] = None, head: Optional[nn.Module] = None):
         """head: the network's output conv; when the fused mixer can carry it in its epilogue the block returns
-        (None, logits fp32 (N, D, H, W, n_classes)) instead of its bf16 output."""
-        if m.dim != "3d":
-            raise NotImplementedError("MedNeXt dim='2d' has no HIP kernel yet")
+        (None, logits fp32 (N, D, H, W, n_classes)) instead of its bf16 output.
+
+        dim='2d' blocks run the same kernels on a depth-1 volume (N, 1, H, W, C): a k x k stencil is the centre z-plane of
+        a k^3 one whose other planes only ever meet the zero padding, the stride-2 and 1x1 convs reduce to their 2-D forms
+        at depth 1, and the statistics / GRN sums run over the same H x W support.  Only the up block needs care: the 3-D
+        transposed conv + front padding doubles the depth as well, so its result is computed on a depth-2 grid whose
+        plane 0 is the padded face and whose plane 1 is the 2-D answer."""
+        if m.dim == "2d":
+            if x.shape[1] != 1:
+                raise ValueError(f"dim='2d' MedNeXt blocks take depth-1 volumes (N, 1, H, W, C), got {tuple(x.shape)}")
+            if m.kind == "up":
+                sk3 = None
+                if skip is not None:
+                    sk3 = skip.new_zeros((skip.shape[0], 2) + tuple(skip.shape[2:]))
+                    sk3[:, 1] = skip[:, 0]
+                return self._block(m, x, sk3, None)[:, 1:2].contiguous()
+        return self._block(m, x, skip, head)
+
+    def _block(self, m: MedNeXtBlock, x: torch.Tensor, skip: Optional[torch.Tensor] = None, head: Optional[nn.Module] = None):
         is_ln = isinstance(m.norm, _ChannelLayerNorm)
         if not is_ln and not isinstance(m.norm, nn.GroupNorm):
             raise NotImplementedError(f"unsupported MedNeXt norm module {type(m.norm).__name__}")
@@ -241,6 +258,7 @@ class HipBlockOps:
         c_hid = m.conv2.weight.shape[0]
         c_out = m.conv3.weight.shape[0]
         if (kind == "up" and self.fused and self.fuse_up and C in self.fuse_up_cin and dt == torch.bfloat16 and K == 3 and not m.grn and not is_ln
+                and m.dim == "3d"
                 and skip is not None and m.conv2.bias is not None and m.conv3.bias is not None
                 and ops.pw_mlp_up_supported(C, c_hid, c_out)):
             return self._up_block_fused(m, x, skip, taps, b1, c_hid, c_out)
@@ -407,6 +425,14 @@ def resolve_compute_dtype(module_pref: Optional[torch.dtype]) -> torch.dtype:
     return torch.float32
 
 
+def embed_stencil_2d(w: torch.Tensor) -> torch.Tensor:
+    """Depthwise (C, 1, k, k) stencil -> (C, 1, k, k, k) with the 2-D taps in the centre z-plane and zeros elsewhere."""
+    k = w.shape[-1]
+    out = w.new_zeros((w.shape[0], w.shape[1], k, k, k))
+    out[:, :, k // 2] = w
+    return out
+
+
 def to_channels_last(x: torch.Tensor) -> torch.Tensor:
     """(N,C,D,H,W) -> contiguous (N,D,H,W,C); free when C == 1."""
     if x.shape[1] == 1:
@@ -482,10 +508,28 @@ class MedNeXt(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("MedNeXt (pytorch_connectomics_amd) runs only on an MI355X/ROCm device: "
                                "there is no CPU path. Move the model and input to 'cuda'.")
-        if self.dim != "3d" or x.dim() != 5:
-            raise NotImplementedError("only dim='3d' inputs (B,C,D,H,W) are supported by the HIP engine")
-        if any(int(v) % 16 for v in x.shape[2:]):
-            raise ValueError(f"MedNeXt needs spatial sizes divisible by 16, got {tuple(x.shape[2:])}")
+        if self.dim == "2d":
+            if x.dim() not in (4, 5) or (x.dim() == 5 and x.shape[2] != 1):
+                raise ValueError(f"MedNeXt dim='2d' takes (B,C,H,W) (or (B,C,1,H,W)) inputs, got {tuple(x.shape)}")
+        elif x.dim() != 5:
+            raise ValueError(f"MedNeXt dim='3d' takes (B,C,D,H,W) inputs, got {tuple(x.shape)}")
+        spatial = x.shape[-2:] if self.dim == "2d" else x.shape[2:]
+        if any(int(v) % 16 for v in spatial):
+            raise ValueError(f"MedNeXt needs spatial sizes divisible by 16, got {tuple(spatial)}")
+
+    def _lift(self, x: torch.Tensor):
+        """dim='2d': (B,C,H,W) -> the depth-1 volume (B,C,1,H,W) the kernels run on; -> (tensor, was_4d)."""
+        if self.dim == "2d" and x.dim() == 4:
+            return x.unsqueeze(2), True
+        return x, False
+
+    @staticmethod
+    def _drop(y, was_4d: bool):
+        if not was_4d:
+            return y
+        if isinstance(y, list):
+            return [v.squeeze(2) for v in y]
+        return y.squeeze(2)
 
     def features_cl(self, x_cl: torch.Tensor, collect: Optional[List[torch.Tensor]] = None,
                     head: Optional[nn.Module] = None):
@@ -493,9 +537,11 @@ class MedNeXt(nn.Module):
         conv) the last block may return (None, logits) instead -- see HipBlockOps.block."""
         hip = self._hip
         dt = resolve_compute_dtype(self.compute_dtype)
-        if any(int(v) % 16 for v in x_cl.shape[1:4]):
+        spatial = x_cl.shape[2:4] if self.dim == "2d" else x_cl.shape[1:4]
+        if any(int(v) % 16 for v in spatial) or (self.dim == "2d" and x_cl.shape[1] != 1):
             # four stride-2 stages: the decoder's skip additions need every level to halve exactly
-            raise ValueError(f"MedNeXt needs spatial sizes divisible by 16, got {tuple(x_cl.shape[1:4])}")
+            raise ValueError(f"MedNeXt needs spatial sizes divisible by 16, got {tuple(x_cl.shape[1:4])}"
+                             + (" (dim='2d': depth must be 1)" if self.dim == "2d" else ""))
         enc0 = list(self.enc_block_0)
         x = None
         if self.fuse_stem and hip.fused and dt == torch.bfloat16 and enc0:
@@ -540,19 +586,25 @@ class MedNeXt(nn.Module):
     # ---- reference-visible API (mednext_models.py:215-231) ---------------------------------------
     def forward_features(self, x: torch.Tensor) -> torch.Tensor:
         self._check_input(x)
-        return to_channels_first(self.features_cl(to_channels_last(x.float())).float())
+        x, flat = self._lift(x)
+        return self._drop(to_channels_first(self.features_cl(to_channels_last(x.float())).float()), flat)
 
     def forward_output(self, features: torch.Tensor) -> torch.Tensor:
         if not features.is_cuda:
             raise RuntimeError("forward_output needs a CUDA tensor: there is no CPU path")
         dt = resolve_compute_dtype(self.compute_dtype)
-        return to_channels_first(self.output_cl(to_channels_last(features).to(dt)))
+        features, flat = self._lift(features)
+        return self._drop(to_channels_first(self.output_cl(to_channels_last(features).to(dt))), flat)
 
     def _autograd_active(self) -> bool:
         return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
     def forward(self, x: torch.Tensor):
         self._check_input(x)
+        x, flat = self._lift(x)
+        return self._drop(self._forward5(x), flat)
+
+    def _forward5(self, x: torch.Tensor):
         if self._autograd_active():
             # training step: forward AND backward run hand-written kernels (training/autograd.py)
             from ...training.autograd import mednext_train_forward
@@ -565,8 +617,6 @@ class MedNeXt(nn.Module):
         feats: Optional[List[torch.Tensor]] = []
         f = self.features_cl(to_channels_last(x.float()), collect=feats)
         out = to_channels_first(self.output_cl(f))
-        if not self.do_ds:
-            return out
         # feats = [bottleneck, dec_3, dec_2, dec_1] -> out_4 .. out_1 ; returned [x, ds_1 .. ds_4]
         ds = [to_channels_first(self.output_cl(ft, h)) for ft, h in zip(feats, (4, 3, 2, 1))]
         return [out, ds[3], ds[2], ds[1], ds[0]]

@@ -155,19 +155,22 @@ class MedNeXtMultiHeadWrapper(ConnectomicsModel):
     def forward_heads(self, features: torch.Tensor) -> Dict[str, torch.Tensor]:
         from .mednext import resolve_compute_dtype
         dt = resolve_compute_dtype(self.model.compute_dtype)
+        features, flat = self.model._lift(features)
         outs = self.forward_heads_cl(to_channels_last(features).to(dt))
-        return {k: to_channels_first(v) for k, v in outs.items()}
+        return {k: self.model._drop(to_channels_first(v), flat) for k, v in outs.items()}
 
     def forward(self, x: torch.Tensor) -> Dict[str, Dict[str, torch.Tensor]]:
         self.model._check_input(x)
+        x, flat = self.model._lift(x)
+        drop = self.model._drop
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # training: trunk and heads through the autograd Functions of training/autograd.py (HIP forward + backward)
             from ...training.autograd import mednext_multihead_train_forward
             from .mednext import resolve_compute_dtype
             outs = mednext_multihead_train_forward(self, to_channels_last(x.float()), resolve_compute_dtype(self.model.compute_dtype))
-            return {"output": {k: to_channels_first(v) for k, v in outs.items()}}
+            return {"output": {k: drop(to_channels_first(v), flat) for k, v in outs.items()}}
         feat_cl = self.model.features_cl(to_channels_last(x.float()))
-        return {"output": {k: to_channels_first(v) for k, v in self.forward_heads_cl(feat_cl).items()}}
+        return {"output": {k: drop(to_channels_first(v), flat) for k, v in self.forward_heads_cl(feat_cl).items()}}
 
     def forward_cl(self, x_cl: torch.Tensor) -> torch.Tensor:
         """Channels-last fast path: all heads concatenated along C in declaration order."""

@@ -50,6 +50,11 @@ def _packs_of(owner):
 
 
 def _taps(w: torch.Tensor, packs=None, flipped: bool = False):
+    if w.dim() == 4:
+        # dim='2d' block: the k x k stencil is the centre z-plane of a k^3 one (models/architectures/mednext.py
+        # embed_stencil_2d); a temporary, so it does not join the per-step pack set
+        from ..models.architectures.mednext import embed_stencil_2d
+        return ops.packed_taps(embed_stencil_2d(w.detach().float()), flipped=flipped, packs=None), w.shape[-1]
     return ops.packed_taps(w, flipped=flipped, packs=packs), w.shape[-1]
 
 
@@ -339,7 +344,10 @@ class BlockFn(torch.autograd.Function):
             if v.is_contiguous() and like.is_contiguous():
                 return v.view(like.shape)
             return torch.empty_like(like).copy_(v.reshape(like.shape))
-        return (dx, dskip, g(dW1.t().contiguous(), w1), (db1.to(w1.dtype) if has_b1 else None), g(dgamma, gamma),
+        dW1 = dW1.t().contiguous()
+        if w1.dim() == 4:                # dim='2d': only the centre z-plane of the embedded stencil is a parameter
+            dW1 = dW1.view(C, 1, K, K, K)[:, :, K // 2].contiguous()
+        return (dx, dskip, g(dW1, w1), (db1.to(w1.dtype) if has_b1 else None), g(dgamma, gamma),
                 g(dbeta, gamma), g(dW2, w2), (db2.to(w2.dtype) if has_b2 else None), g(dW3, w3),
                 (db3.to(w3.dtype) if has_b3 else None),
                 (g(dwres, wres) if has_res else None), (dbres.to(w3.dtype) if (has_res and has_bres) else None),
@@ -347,12 +355,20 @@ class BlockFn(torch.autograd.Function):
 
 
 def _block(m, x, skip=None, recompute: bool = False, packs=None):
-    if m.grn or not isinstance(m.norm, nn.GroupNorm) or m.dim != "3d":
-        raise NotImplementedError("training kernels cover GroupNorm / 3-D MedNeXt blocks only")
+    if m.grn or not isinstance(m.norm, nn.GroupNorm):
+        raise NotImplementedError("training kernels cover GroupNorm MedNeXt blocks only (no LayerNorm / GRN backward)")
     res = getattr(m, "res_conv", None) if getattr(m, "resample_do_res", False) else None
-    return BlockFn.apply(x, skip, m.conv1.weight, m.conv1.bias, m.norm.weight, m.norm.bias, m.conv2.weight,
-                         m.conv2.bias, m.conv3.weight, m.conv3.bias, None if res is None else res.weight,
-                         None if res is None else res.bias, m.kind, bool(m.do_res), float(m.norm.eps), bool(recompute), packs)
+    flat_up = m.dim == "2d" and m.kind == "up"
+    if m.dim == "2d":
+        if x.shape[1] != 1:
+            raise ValueError(f"dim='2d' MedNeXt blocks take depth-1 volumes (N, 1, H, W, C), got {tuple(x.shape)}")
+        if flat_up and skip is not None:
+            # the 3-D up block doubles the depth too: plane 0 of its depth-2 grid is the padded face, plane 1 the 2-D answer
+            skip = torch.cat([torch.zeros_like(skip), skip], dim=1)
+    y = BlockFn.apply(x, skip, m.conv1.weight, m.conv1.bias, m.norm.weight, m.norm.bias, m.conv2.weight,
+                      m.conv2.bias, m.conv3.weight, m.conv3.bias, None if res is None else res.weight,
+                      None if res is None else res.bias, m.kind, bool(m.do_res), float(m.norm.eps), bool(recompute), packs)
+    return y[:, 1:2].contiguous() if flat_up else y
 
 
 def saved_activation_bytes(trunk, in_shape, compute_dtype: torch.dtype) -> int:
@@ -371,7 +387,7 @@ def saved_activation_bytes(trunk, in_shape, compute_dtype: torch.dtype) -> int:
                 lvl -= 1
             elif mod.kind == "down":
                 lvl += 1
-            lvl_vox = N * (D >> lvl) * (H >> lvl) * (W >> lvl)
+            lvl_vox = N * max(1, D >> lvl) * (H >> lvl) * (W >> lvl)     # (dim='2d': D stays 1)
             total += lvl_vox * (2 * c_in + c_hid) * esz
     return int(total)
 

@@ -211,7 +211,9 @@ def match_target_to_output(target: torch.Tensor, output: torch.Tensor) -> torch.
         return target
     if target.dtype in (torch.long, torch.int, torch.int32, torch.int64, torch.uint8):
         return F.interpolate(target.float(), size=output.shape[2:], mode="nearest").long()
-    out = F.interpolate(target, size=output.shape[2:], mode="trilinear", align_corners=False)
+    # (B, C, H, W) targets of a dim='2d' model: the bilinear twin (the reference names "trilinear" unconditionally, which
+    # torch rejects for 4-D tensors, so its 2-D + deep-supervision configs cannot reach this line)
+    out = F.interpolate(target, size=output.shape[2:], mode="trilinear" if target.dim() == 5 else "bilinear", align_corners=False)
     lo, hi = float(target.min()), float(target.max())
     if lo >= -1.5 and hi <= 1.5:
         out = torch.clamp(out, -1.0, 1.0)
