@@ -522,6 +522,20 @@ int pytc_conv3d_wgrad_strided(const void* big, const void* small, float* dW, flo
  * channels, y = gamma * (x - mean) / sqrt(var + eps) + beta (gamma / beta may be NULL); C = VEC * 2^k, 2^k <= 64. */
 int pytc_layernorm_rows(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int C, float eps,
                         int dtype, void* stream);
+/* Backward of the two MedNeXt block variants (reference constructor mednext_models.py:449-463, norm_type='layer' / grn=True;
+ * torch autograd through upstream's LayerNorm(channels_first) and GRN branch in the reference's training_step,
+ * training/lightning/model.py:863-910).
+ * pytc_layernorm_rows_bwd: dx [rows][C] = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)), g = dy * gamma, statistics
+ *   recomputed from x; partial [slots][2][C] fp32 (slots = pytc_layernorm_rows_bwd_slots) = per-workgroup sums of dy ([0] ->
+ *   dbeta) and dy * xhat ([1] -> dgamma), to be reduced over slots with pytc_reduce_slots / pytc_reduce_slots_multi.
+ * pytc_grn_bwd_apply: out = (dh2 * A[n][c] + gelu(hp) * B[n][c]) * gelu'(hp) on [N][rows][C]: the derivative of
+ *   h2 = h * (gamma * nx + 1) + beta, h = gelu(hp), with the per-(sample, channel) coefficients A = gamma * nx + 1 and
+ *   B = (dL/dgx) / gx built by the caller from the (N, 2, C) sums of pytc_norm_bwd_stats(dh2, h). */
+int pytc_layernorm_rows_bwd_slots(int64_t rows, int C, int dtype);
+int pytc_layernorm_rows_bwd(const void* dy, const void* x, const float* gamma, void* dx, float* partial, int64_t rows, int C,
+                            float eps, int dtype, void* stream);
+int pytc_grn_bwd_apply(const void* dh2, const void* hp, const float* A, const float* B, void* out, int N, int64_t rows, int C,
+                       int dtype, void* stream);
 int64_t pytc_bce_dice_ws_elems(int N, int C, int64_t R);
 int pytc_bce_dice_fwd(const float* logits, const float* target, const float* weight, int N, int C, int64_t R,
                       const int64_t* x_strides, const int64_t* t_strides, const int64_t* w_strides, float pos_weight,

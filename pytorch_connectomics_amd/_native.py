@@ -170,6 +170,11 @@ _SIGS = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pytc_bn_update_running": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "pytc_layernorm_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "pytc_layernorm_rows_bwd_slots": (C.c_int, [C.c_int64, C.c_int, C.c_int]),
+    "pytc_layernorm_rows_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float,
+                                          C.c_int, C.c_void_p]),
+    "pytc_grn_bwd_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                     C.c_void_p]),
     "pytc_bce_dice_ws_elems": (C.c_int64, [C.c_int, C.c_int, C.c_int64]),
     "pytc_bce_dice_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64),
                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_float, C.c_float, C.c_float, C.c_float,

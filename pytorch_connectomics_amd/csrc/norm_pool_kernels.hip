@@ -401,9 +401,8 @@ extern "C" int pytc_layernorm_rows(const void* x, void* y, const float* gamma, c
   hipStream_t s = (hipStream_t)stream;
   // widest vector such that C / VEC is a power of two <= 64 (shuffle groups stay inside a wave and tile the workgroup)
   auto pow2 = [](int v) { return v >= 1 && (v & (v - 1)) == 0; };
-  const int maxv = dtype == PYTC_BF16 ? 8 : 4;
-  int vec = 0;
-  for (int v = maxv; v >= 1; v >>= 1)
+  int vec = 0;          // fp32 rows use 8-wide chunks too (two 16-byte loads): C = 512 still fits the 64 lanes of a wave
+  for (int v = 8; v >= 1; v >>= 1)
     if (C % v == 0 && pow2(C / v) && C / v <= 64) { vec = v; break; }
   PYTC_REQUIRE(vec > 0, "layernorm_rows: C=%d must be VEC * 2^k with 2^k <= 64", C);
   const int rpb = 256 / (C / vec);
@@ -413,7 +412,7 @@ extern "C" int pytc_layernorm_rows(const void* x, void* y, const float* gamma, c
   if (dtype == PYTC_BF16) {
     if (vec == 8) LN_LAUNCH(bf16_t, 8); else if (vec == 4) LN_LAUNCH(bf16_t, 4); else if (vec == 2) LN_LAUNCH(bf16_t, 2); else LN_LAUNCH(bf16_t, 1);
   } else if (dtype == PYTC_F32) {
-    if (vec == 4) LN_LAUNCH(float, 4); else if (vec == 2) LN_LAUNCH(float, 2); else LN_LAUNCH(float, 1);
+    if (vec == 8) LN_LAUNCH(float, 8); else if (vec == 4) LN_LAUNCH(float, 4); else if (vec == 2) LN_LAUNCH(float, 2); else LN_LAUNCH(float, 1);
   } else {
     PYTC_REQUIRE(false, "layernorm_rows: bad dtype");
   }

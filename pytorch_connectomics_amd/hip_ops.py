@@ -288,6 +288,33 @@ def layernorm_rows(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optiona
     return y
 
 
+def layernorm_rows_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: Optional[torch.Tensor], eps: float = 1e-5):
+    """Backward of layernorm_rows: -> dx (like x), partial (slots, 2, C) fp32 whose sums over slots are dbeta ([:, 0]) and
+    dgamma ([:, 1])."""
+    _dev(dy, "dy"); _dev(x, "x")
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    slots = nat.lib().pytc_layernorm_rows_bwd_slots(rows, Cc, dtype_code(x.dtype))
+    if slots <= 0:
+        raise ValueError(f"layernorm_rows_bwd: unsupported channel count {Cc}")
+    dx = torch.empty_like(x)
+    partial = torch.empty((slots, 2, Cc), dtype=torch.float32, device=x.device)
+    _run(f"layernorm_rows_bwd[C{Cc}]", _nbytes(dy, x, dx), nat.lib().pytc_layernorm_rows_bwd, _p(dy), _p(x), _p(gamma), _p(dx),
+         _p(partial), rows, Cc, float(eps), dtype_code(x.dtype), _stream())
+    return dx, partial
+
+
+def grn_bwd_apply(dh2: torch.Tensor, hp: torch.Tensor, A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """(dh2 * A[n, c] + gelu(hp) * B[n, c]) * gelu'(hp) on (N, rows, C) tensors; A, B (N, C) fp32."""
+    _dev(dh2, "dh2"); _dev(hp, "hp")
+    N, Cc = hp.shape[0], hp.shape[-1]
+    rows = hp.numel() // (N * Cc)
+    out = torch.empty_like(hp)
+    _run(f"grn_bwd_apply[C{Cc}]", _nbytes(dh2, hp, out), nat.lib().pytc_grn_bwd_apply, _p(dh2), _p(hp), _p(A), _p(B), _p(out), N,
+         rows, Cc, dtype_code(hp.dtype), _stream())
+    return out
+
+
 def groupnorm_finalize(stats: torch.Tensor, count: float, gamma: Optional[torch.Tensor],
                        beta: Optional[torch.Tensor], eps: float = 1e-5) -> torch.Tensor:
     N, slots, _, Cc = stats.shape

@@ -124,6 +124,45 @@ class PointwiseFn(torch.autograd.Function):
                 None, None, None)
 
 
+def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res, dr):
+    """Depthwise-conv half of a block backward, shared by BlockFn and NormVariantBlockFn: from dt (gradient of the depthwise
+    output) to dx, dW1 (tap-major), db1 and the gradients of the resampling residual conv.  Slot reductions join `dr`."""
+    N, D, H, W, C = x.shape
+    rows = _rows(t)
+    c_out = dy.shape[-1]
+    dwres_m = None
+    dwres = dbres = None
+    if kind == "block":
+        dW1, db1 = ops.dw_wgrad(dt_.view_as(t), x, K=K, stride=1, defer=dr)
+        flipped, _ = _taps(w1, packs, flipped=True)             # correlation with the reversed stencil
+        gt = dt_.view_as(t)
+        if do_res and FUSED_RESIDUAL_DGRAD and ops.dwconv3d_res_supported(gt, K, 1):
+            dx = ops.dwconv3d_res(gt, flipped, dy, K=K)        # dx = conv_reversed(dt) + dy in the conv kernel's epilogue
+        else:
+            dx, _ = ops.dwconv3d(gt, flipped, None, K=K, stride=1, stats=False)
+            if do_res:
+                ops.add_(dx, dy)
+    elif kind == "down":
+        dW1, db1 = ops.dw_wgrad(dt_.view_as(t), x, K=K, stride=2, defer=dr)
+        dx = ops.dwconv3d_bwd_data(dt_.view_as(t), taps, (D, H, W), K=K, stride=2)
+        if has_res:
+            xg = x[:, ::2, ::2, ::2, :].contiguous()
+            dwres, dbres = ops.pw_wgrad(xg, dy, N=N, rows_per_sample=rows, c_in=C, c_out=c_out, defer=dr)
+            dxg = _pw(dy, _mat(wres), None, c_out=C, transposed=True, rows=rows, packs=packs).view_as(xg)
+            dx[:, ::2, ::2, ::2, :] += dxg         # strided in-place add: only the 1/8 of dx the 1x1x1 stride-2 conv read
+    else:
+        dtp = dt_.view_as(t)
+        dtc = dtp[:, 1:, 1:, 1:, :].contiguous()                # compact (2D-1)^3 grid of the transposed conv
+        dW1, _ = ops.dw_wgrad(x, dtc, K=K, stride=2, want_bias=False, defer=dr)
+        db1 = ops.channel_stats(dtc).sum(1)[:, 0].sum(0)
+        dx, _ = ops.dwconv3d(dtc, taps, None, K=K, stride=2, stats=False)
+        if has_res:
+            drl = dy[:, 1::2, 1::2, 1::2, :].contiguous()       # positions fed by the transposed 1x1 conv
+            dwres_m, _ = ops.pw_wgrad(x, drl, N=N, rows_per_sample=D * H * W, c_in=C, c_out=c_out, want_bias=False, defer=dr)
+            ops.add_(dx, _pw(drl, _mat(wres), None, c_out=C, transposed=False, packs=packs).view_as(dx))
+    return dx, dW1, db1, dwres, dbres, dwres_m
+
+
 class BlockFn(torch.autograd.Function):
     """MedNeXt block / down block / up block.  `kind` in {"block", "down", "up"}.  `recompute` = the reference's
     `outside_block` activation checkpointing (mednext_models.py:386-393: torch.utils.checkpoint around every block): only the
@@ -303,35 +342,7 @@ class BlockFn(torch.autograd.Function):
         dgamma, dbeta = ssum[1], ssum[0]
         del dtn
         # ---- depthwise conv
-        dwres = dbres = None
-        if kind == "block":
-            dW1, db1 = ops.dw_wgrad(dt_.view_as(t), x, K=K, stride=1, defer=dr)
-            flipped, _ = _taps(w1, packs, flipped=True)             # correlation with the reversed stencil
-            gt = dt_.view_as(t)
-            if do_res and FUSED_RESIDUAL_DGRAD and ops.dwconv3d_res_supported(gt, K, 1):
-                dx = ops.dwconv3d_res(gt, flipped, dy, K=K)        # dx = conv_reversed(dt) + dy in the conv kernel's epilogue
-            else:
-                dx, _ = ops.dwconv3d(gt, flipped, None, K=K, stride=1, stats=False)
-                if do_res:
-                    ops.add_(dx, dy)
-        elif kind == "down":
-            dW1, db1 = ops.dw_wgrad(dt_.view_as(t), x, K=K, stride=2, defer=dr)
-            dx = ops.dwconv3d_bwd_data(dt_.view_as(t), taps, (D, H, W), K=K, stride=2)
-            if has_res:
-                xg = x[:, ::2, ::2, ::2, :].contiguous()
-                dwres, dbres = ops.pw_wgrad(xg, dy, N=N, rows_per_sample=rows, c_in=C, c_out=c_out, defer=dr)
-                dxg = _pw(dy, _mat(wres), None, c_out=C, transposed=True, rows=rows, packs=packs).view_as(xg)
-                dx[:, ::2, ::2, ::2, :] += dxg         # strided in-place add: only the 1/8 of dx the 1x1x1 stride-2 conv read
-        else:
-            dtp = dt_.view_as(t)
-            dtc = dtp[:, 1:, 1:, 1:, :].contiguous()                # compact (2D-1)^3 grid of the transposed conv
-            dW1, _ = ops.dw_wgrad(x, dtc, K=K, stride=2, want_bias=False, defer=dr)
-            db1 = ops.channel_stats(dtc).sum(1)[:, 0].sum(0)
-            dx, _ = ops.dwconv3d(dtc, taps, None, K=K, stride=2, stats=False)
-            if has_res:
-                drl = dy[:, 1::2, 1::2, 1::2, :].contiguous()       # positions fed by the transposed 1x1 conv
-                dwres_m, _ = ops.pw_wgrad(x, drl, N=N, rows_per_sample=D * H * W, c_in=C, c_out=c_out, want_bias=False, defer=dr)
-                ops.add_(dx, _pw(drl, _mat(wres), None, c_out=C, transposed=False, packs=packs).view_as(dx))
+        dx, dW1, db1, dwres, dbres, dwres_m = _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res, dr)
         dr.flush()                       # all weight / bias / norm gradients of the block are final from here on
         if kind == "up" and has_res:
             dwres = dwres_m.t().contiguous()                        # ConvTranspose layout (C_in, C_out)
@@ -354,9 +365,189 @@ class BlockFn(torch.autograd.Function):
                 None, None, None, None, None)
 
 
+def _grad_like(v, like):
+    """A gradient in the parameter's own (contiguous) strides: a view when the kernel output is already laid out that way."""
+    if v is None:
+        return None
+    if v.is_contiguous() and like.is_contiguous():
+        return v.view(like.shape)
+    return torch.empty_like(like).copy_(v.reshape(like.shape))
+
+
+def _grn_coeffs(h, grid, kind: str, gamma_vec: torch.Tensor):
+    """GRN statistics of the activated hidden tensor h (N, rows, C): gx = ||h||_2 over the block's spatial support per
+    (n, c), nx = gx / (mean_c gx + 1e-6), A = gamma * nx + 1 (upstream MedNeXtBlock.forward, grn branch).  For the up block
+    the padded front faces are not part of the support.  -> gx, nx, A (each (N, C) fp32)."""
+    N, c_hid = h.shape[0], h.shape[-1]
+    hv = h.view(N, *grid, c_hid)
+    core = hv[:, 1:, 1:, 1:].contiguous() if kind == "up" else hv
+    gx = ops.channel_stats(core)[:, :, 1].sum(1).clamp_min(0).sqrt()
+    nx = gx / (gx.mean(1, keepdim=True) + 1e-6)
+    return gx, nx, (gamma_vec.view(1, c_hid) * nx + 1.0).contiguous()
+
+
+class NormVariantBlockFn(torch.autograd.Function):
+    """MedNeXt block / down block / up block with norm_type='layer' (per-voxel LayerNorm over C) and / or grn=True (global
+    response normalisation of the expanded tensor) -- the two constructor variants of mednext_models.py:449-463 that
+    BlockFn's fused GroupNorm schedule does not cover.  Un-fused schedule:
+
+      forward   dwconv(+stats for GroupNorm) -> [layernorm_rows] -> 1x1 expand (pre-activation hp saved)
+                -> grn: h = gelu(hp), h2 = h * (gamma * nx + 1) + beta (two elementwise passes + one statistics pass)
+                -> 1x1 project (GELU in its operand prologue when there is no GRN) + the block's residual epilogue
+      backward  the mirrored sequence; LayerNorm: pytc_layernorm_rows_bwd; GRN: (sum dh2, sum dh2 * h) per (n, c) from
+                pytc_norm_bwd_stats, the tiny (N, C) coefficient algebra on the host side, then pytc_grn_bwd_apply, which
+                also carries the GELU derivative.
+
+    Saved: x, t (depthwise output), hp, the norm vectors and gx (N, C)."""
+
+    @staticmethod
+    def forward(ctx, x, skip, w1, b1, gamma, beta, w2, b2, w3, b3, wres, bres, grn_g, grn_b, kind: str, do_res: bool,
+                eps: float, is_ln: bool, packs=None):
+        N, D, H, W, C = x.shape
+        dt = x.dtype
+        has_grn = grn_g is not None
+        taps, K = _taps(w1, packs)
+        if kind == "up":
+            t, st = ops.dwconv3d(x, taps, _f(b1), K=K, transposed=True, stats=not is_ln)
+            count = float((2 * D - 1) * (2 * H - 1) * (2 * W - 1))
+        else:
+            t, st = ops.dwconv3d(x, taps, _f(b1), K=K, stride=2 if kind == "down" else 1, stats=not is_ln)
+            count = float(_rows(t))
+        rows = _rows(t)
+        grid = tuple(t.shape[1:4])
+        c_hid, c_out = w2.shape[0], w3.shape[0]
+        keep = x.new_zeros(0)
+        if is_ln:
+            tn, ab, mr = ops.layernorm_rows(t, _f(gamma), _f(beta), eps), None, None
+        else:
+            ab, mr = ops.groupnorm_finalize_mr(st, count, _f(gamma), _f(beta), eps)
+            tn = t
+        hp = _pw(tn, _mat(w2), _f(b2), c_out=c_hid, ab=ab, rows=rows, packs=packs)                  # pre-activation (saved)
+        del tn
+        gx = None
+        if has_grn:
+            h = ops.gelu(hp)
+            gx, _nx, A = _grn_coeffs(h, grid, kind, _f(grn_g).reshape(-1))
+            ab2 = torch.stack([A, _f(grn_b).reshape(1, c_hid).expand(N, c_hid)], 1).contiguous()
+            hin = ops.affine_act(h.view(N, *grid, c_hid), ab2, nat.ACT_NONE, 0.0).view(N, rows, c_hid)
+            del h
+            G = {}
+        else:
+            hin, G = hp, dict(pre_act=nat.ACT_GELU)
+        if kind == "block":
+            y = _pw(hin, _mat(w3), _f(b3), c_out=c_out, rows=rows, res=x if do_res else None,
+                    res_mode=nat.RES_ADD if do_res else nat.RES_NONE, packs=packs, **G)
+        elif kind == "down":
+            r = None
+            if wres is not None:
+                r = _pw(x, _mat(wres), _f(bres), c_out=c_out, rows=rows, gather=2, grid=(D, H, W), packs=packs)
+            y = _pw(hin, _mat(w3), _f(b3), c_out=c_out, rows=rows, res=r,
+                    res_mode=nat.RES_ADD if r is not None else nat.RES_NONE, packs=packs, **G)
+        else:
+            res_low = None
+            if wres is not None:
+                res_low = _pw(x, _mat(wres), _f(bres), c_out=c_out, transposed=True, packs=packs)
+            sk = skip if skip is not None else torch.zeros((N,) + grid + (c_out,), dtype=dt, device=x.device)
+            y = _pw(hin, _mat(w3), _f(b3), c_out=c_out, rows=rows, res=sk, res_mode=nat.RES_UPSAMPLE, grid=grid,
+                    res_low=res_low, res_bias=_f(bres) if wres is not None else None, packs=packs, **G)
+        ctx.save_for_backward(x, t, hp, ab if ab is not None else keep, mr if mr is not None else keep,
+                              gx if gx is not None else keep, w1, gamma, beta if beta is not None else keep, w2, w3,
+                              wres if wres is not None else keep, grn_g if has_grn else keep, grn_b if has_grn else keep)
+        ctx.meta = (kind, do_res, K, count, wres is not None, skip is not None, b1 is not None, bres is not None, eps,
+                    b2 is not None, b3 is not None, is_ln, has_grn)
+        ctx.taps, ctx.packs = taps, packs
+        return y.view(N, *grid, c_out)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, t, hp, ab, mr, gx, w1, gamma, beta, w2, w3, wres, grn_g, grn_b = ctx.saved_tensors
+        kind, do_res, K, count, has_res, has_skip, has_b1, has_bres, eps, has_b2, has_b3, is_ln, has_grn = ctx.meta
+        packs, taps = ctx.packs, ctx.taps
+        N, D, H, W, C = x.shape
+        dy = dy.contiguous()
+        rows = _rows(t)
+        grid = tuple(t.shape[1:4])
+        c_hid, c_out = w2.shape[0], w3.shape[0]
+        dskip = dy if (kind == "up" and has_skip) else None
+        dcore = dy
+        if kind == "up":
+            dcore = dy.clone()      # the padded front faces are not outputs of the mixer
+            dcore[:, 0] = 0
+            dcore[:, :, 0] = 0
+            dcore[:, :, :, 0] = 0
+        dr = ops.DeferredReduce()
+        dgrn_g = dgrn_b = None
+        if has_grn:
+            # h2 = h * A + beta_grn with h = gelu(hp): rebuilt by the forward's own kernels
+            gvec = _f(grn_g).reshape(-1)
+            h = ops.gelu(hp)
+            gx_, nx, A = _grn_coeffs(h, grid, kind, gvec)
+            ab2 = torch.stack([A, _f(grn_b).reshape(1, c_hid).expand(N, c_hid)], 1).contiguous()
+            h2 = ops.affine_act(h.view(N, *grid, c_hid), ab2, nat.ACT_NONE, 0.0).view(N, rows, c_hid)
+            dW3, db3 = ops.pw_wgrad(h2, dcore, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, defer=dr)
+            del h2
+            dh2 = _pw(dcore, _mat(w3), None, c_out=c_hid, transposed=True, rows=rows, packs=packs)
+            # per (n, c): Q = sum dh2, P = sum dh2 * h (xhat = h with mean 0, rstd 1); dh2 is zero on an up block's padded faces
+            unit = torch.stack([torch.zeros_like(gx_), torch.ones_like(gx_)], 1).contiguous()
+            s = ops.norm_bwd_stats(dh2, h, unit)
+            del h
+            Q, P = s[:, 0], s[:, 1]
+            dgrn_b = Q.sum(0)
+            dgrn_g = (nx * P).sum(0)
+            dnx = gvec.view(1, c_hid) * P
+            den = gx_.mean(1, keepdim=True) + 1e-6
+            dgx = dnx / den - (dnx * gx_).sum(1, keepdim=True) / (c_hid * den * den)
+            Bc = torch.where(gx_ > 0, dgx / gx_.clamp_min(1e-30), torch.zeros_like(dgx)).contiguous()   # d||h|| / dh = h / ||h||
+            dhp = ops.grn_bwd_apply(dh2, hp, A, Bc)
+            del dh2
+            if kind == "up":         # h on the padded faces is not part of the GRN support: no gradient reaches it
+                dv = dhp.view(N, *grid, c_hid)
+                dv[:, 0] = 0
+                dv[:, :, 0] = 0
+                dv[:, :, :, 0] = 0
+        else:
+            dW3, db3 = ops.pw_wgrad(hp, dcore, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, x_act=nat.ACT_GELU, defer=dr)
+            dhp = _pw(dcore, _mat(w3), None, c_out=c_hid, transposed=True, rows=rows, res=hp, res_mode=nat.RES_GELU_BWD, packs=packs)
+        # ---- expand: hp = W2 norm(t) + b2
+        if is_ln:
+            tn = ops.layernorm_rows(t, _f(gamma), _f(beta) if beta.numel() else None, eps)
+            dW2, db2 = ops.pw_wgrad(tn, dhp, N=N, rows_per_sample=rows, c_in=C, c_out=c_hid, defer=dr)
+            del tn
+        else:
+            dW2, db2 = ops.pw_wgrad(t, dhp, N=N, rows_per_sample=rows, c_in=C, c_out=c_hid, ab=ab, defer=dr)
+        dtn = _pw(dhp, _mat(w2), None, c_out=C, transposed=True, rows=rows, packs=packs)
+        del dhp
+        # ---- norm
+        ssum = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        if is_ln:
+            dt_, part = ops.layernorm_rows_bwd(dtn, t, _f(gamma), eps)
+            dr.add(part, ssum, 2 * C, part.shape[0], keep=part)
+        else:
+            dt_, s = ops.norm_bwd(dtn, t, mr, _f(gamma), count=count)
+            dr.add(s, ssum, 2 * C, N, keep=s)
+        dgamma, dbeta = ssum[1], ssum[0]
+        del dtn
+        dx, dW1, db1, dwres, dbres, dwres_m = _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res, dr)
+        dr.flush()
+        if kind == "up" and has_res:
+            dwres = dwres_m.t().contiguous()                        # ConvTranspose layout (C_in, C_out)
+            dbres = db3.clone()                                     # bias reaches every interior voxel exactly once
+        dW1 = dW1.t().contiguous()
+        if w1.dim() == 4:                # dim='2d': only the centre z-plane of the embedded stencil is a parameter
+            dW1 = dW1.view(C, 1, K, K, K)[:, :, K // 2].contiguous()
+        g = _grad_like
+        return (dx, dskip, g(dW1, w1), (db1.to(w1.dtype) if has_b1 else None), g(dgamma, gamma),
+                (g(dbeta, gamma) if beta.numel() else None), g(dW2, w2), (db2.to(w2.dtype) if has_b2 else None), g(dW3, w3),
+                (db3.to(w3.dtype) if has_b3 else None),
+                (g(dwres, wres) if has_res else None), (dbres.to(w3.dtype) if (has_res and has_bres) else None),
+                (g(dgrn_g, grn_g) if has_grn else None), (g(dgrn_b, grn_b) if has_grn else None),
+                None, None, None, None, None)
+
+
 def _block(m, x, skip=None, recompute: bool = False, packs=None):
-    if m.grn or not isinstance(m.norm, nn.GroupNorm):
-        raise NotImplementedError("training kernels cover GroupNorm MedNeXt blocks only (no LayerNorm / GRN backward)")
+    is_ln = not isinstance(m.norm, nn.GroupNorm)
+    if is_ln and type(m.norm).__name__ != "_ChannelLayerNorm":
+        raise NotImplementedError(f"no training kernels for MedNeXt norm module {type(m.norm).__name__}")
     res = getattr(m, "res_conv", None) if getattr(m, "resample_do_res", False) else None
     flat_up = m.dim == "2d" and m.kind == "up"
     if m.dim == "2d":
@@ -365,9 +556,17 @@ def _block(m, x, skip=None, recompute: bool = False, packs=None):
         if flat_up and skip is not None:
             # the 3-D up block doubles the depth too: plane 0 of its depth-2 grid is the padded face, plane 1 the 2-D answer
             skip = torch.cat([torch.zeros_like(skip), skip], dim=1)
-    y = BlockFn.apply(x, skip, m.conv1.weight, m.conv1.bias, m.norm.weight, m.norm.bias, m.conv2.weight,
-                      m.conv2.bias, m.conv3.weight, m.conv3.bias, None if res is None else res.weight,
-                      None if res is None else res.bias, m.kind, bool(m.do_res), float(m.norm.eps), bool(recompute), packs)
+    if m.grn or is_ln:
+        # norm_type='layer' / grn=True: the un-fused variant schedule (no block-level recomputation: `outside_block`
+        # checkpointing keeps its activations here)
+        y = NormVariantBlockFn.apply(x, skip, m.conv1.weight, m.conv1.bias, m.norm.weight, m.norm.bias, m.conv2.weight,
+                                     m.conv2.bias, m.conv3.weight, m.conv3.bias, None if res is None else res.weight,
+                                     None if res is None else res.bias, m.grn_gamma if m.grn else None,
+                                     m.grn_beta if m.grn else None, m.kind, bool(m.do_res), float(m.norm.eps), is_ln, packs)
+    else:
+        y = BlockFn.apply(x, skip, m.conv1.weight, m.conv1.bias, m.norm.weight, m.norm.bias, m.conv2.weight,
+                          m.conv2.bias, m.conv3.weight, m.conv3.bias, None if res is None else res.weight,
+                          None if res is None else res.bias, m.kind, bool(m.do_res), float(m.norm.eps), bool(recompute), packs)
     return y[:, 1:2].contiguous() if flat_up else y
 
 

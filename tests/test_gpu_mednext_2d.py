@@ -74,10 +74,11 @@ def test_mednext_s_2d_bf16_fused_mixers():
     assert (torch.sigmoid(got16) - torch.sigmoid(ref)).abs().mean() < 5e-3
 
 
-@pytest.mark.parametrize("n_channels,k,ds", [(8, 3, True), (16, 5, False)])
-def test_mednext_2d_training_step_matches_oracle_autograd(n_channels, k, ds):
-    m, st = _build(n_channels=n_channels, k=k, ds=ds)
-    kw = dict(n_channels=n_channels, exp_r=2, kernel_size=k, block_counts=[1] * 9)
+@pytest.mark.parametrize("n_channels,k,ds,norm_type,grn", [(8, 3, True, "group", False), (16, 5, False, "group", False),
+                                                          (8, 3, False, "layer", True)])
+def test_mednext_2d_training_step_matches_oracle_autograd(n_channels, k, ds, norm_type, grn):
+    m, st = _build(n_channels=n_channels, k=k, ds=ds, norm_type=norm_type, grn=grn)
+    kw = dict(n_channels=n_channels, exp_r=2, kernel_size=k, block_counts=[1] * 9, norm_type=norm_type, grn=grn)
     x = torch.rand(2, 1, 32, 48)
     wmaps = [torch.randn(2, 2, 32 >> i, 48 >> i, generator=torch.Generator().manual_seed(10 + i)) for i in range(5)]
 
@@ -101,15 +102,9 @@ def test_mednext_2d_training_step_matches_oracle_autograd(n_channels, k, ds):
         got = named[name].grad
         assert got is not None and got.shape == p.grad.shape, name
         # conv1.bias feeds a per-channel GroupNorm: its true gradient is 0 and both sides hold rounding noise -> floor the scale
-        scale = max(p.grad.abs().max().item(), 1e-4 if name.endswith("conv1.bias") else 1e-5)
+        scale = max(p.grad.abs().max().item(), 1e-3 if (name.endswith("conv1.bias") and norm_type == "group") else 1e-5)
         err = (got.cpu() - p.grad).abs().max().item() / scale
         assert err < 2e-2, (name, err, scale)
-
-
-def test_mednext_2d_norm_variants_still_refuse_training():
-    m, _ = _build(n_channels=8, norm_type="layer")
-    with pytest.raises(NotImplementedError, match="LayerNorm / GRN"):
-        m.cuda().train()(torch.rand(1, 1, 32, 32, device="cuda"))
 
 
 def test_build_model_2d_multihead_and_module_training_step():

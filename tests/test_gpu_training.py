@@ -607,3 +607,96 @@ def test_gradnorm_balancing_trains_through_the_hip_autograd_functions():
     assert m.loss_weighter.initial_losses is not None and m.loss_weighter.initial_losses.numel() == 3
     ck = m.checkpoint_dict(opt)
     assert "loss_weighter.task_weights" in ck["state_dict"]
+
+
+@pytest.mark.parametrize("C,rows,dt", [(32, 1000, torch.float32), (64, 777, torch.float32), (512, 343, torch.float32),
+                                       (4, 50, torch.float32), (128, 5003, torch.bfloat16), (256, 64, torch.bfloat16)])
+def test_layernorm_rows_backward_kernel(C, rows, dt):
+    """pytc_layernorm_rows_bwd against autograd through the channel LayerNorm of the oracle (mednext_oracle._norm)."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(C + rows)
+    x = (torch.randn(rows, C) * 1.5 + 0.3).to(dt)
+    dy = torch.randn(rows, C).to(dt)
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C)
+    xr = x.float().requires_grad_()
+    gr = gamma.clone().requires_grad_()
+    br = beta.clone().requires_grad_()
+    u = xr.mean(1, keepdim=True)
+    v = (xr - u).pow(2).mean(1, keepdim=True)
+    y = gr * (xr - u) / torch.sqrt(v + 1e-5) + br
+    y.backward(dy.float())
+    got_y = ops.layernorm_rows(x.cuda(), gamma.cuda(), beta.cuda(), 1e-5)
+    dx, part = ops.layernorm_rows_bwd(dy.cuda(), x.cuda(), gamma.cuda(), 1e-5)
+    tol = dict(rtol=1e-4, atol=1e-5) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(got_y.float().cpu(), y.detach(), **tol)
+    torch.testing.assert_close(dx.float().cpu(), xr.grad, **tol)
+    assert part.shape[1:] == (2, C)
+    sums = part.sum(0).cpu()
+    torch.testing.assert_close(sums[0], br.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(sums[1], gr.grad, rtol=1e-3 if dt == torch.float32 else 2e-2, atol=1e-3 if dt == torch.float32 else 0.3)
+
+
+def test_grn_backward_apply_kernel():
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(5)
+    N, rows, C = 2, 301, 24
+    hp = torch.randn(N, rows, C) * 2
+    dh2 = torch.randn(N, rows, C)
+    A, B = torch.rand(N, C) + 0.5, torch.randn(N, C) * 0.1
+    hr = hp.clone().requires_grad_()
+    h = F.gelu(hr)
+    # a function whose derivative w.r.t. h is dh2 * A + h * B
+    ((h * A[:, None]) * dh2).sum().add(0.5 * (h * h * B[:, None]).sum()).backward()
+    got = ops.grn_bwd_apply(dh2.cuda(), hp.cuda(), A.cuda(), B.cuda())
+    torch.testing.assert_close(got.cpu(), hr.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("norm_type,grn,n_channels", [("layer", False, 8), ("group", True, 8), ("layer", True, 16)])
+def test_mednext_norm_variants_training_step_matches_oracle_autograd(norm_type, grn, n_channels):
+    """norm_type='layer' / grn=True (constructor variants, mednext_models.py:449-463): forward and every parameter gradient
+    -- LayerNorm affine and GRN gamma / beta included -- against autograd through the oracle, deep supervision on."""
+    from pytorch_connectomics_amd.models.architectures.mednext import MedNeXt
+    torch.manual_seed(0)
+    counts = [1] * 9
+    m = MedNeXt(1, n_channels, 2, exp_r=2, kernel_size=3, do_res=True, do_res_up_down=True, block_counts=counts,
+                norm_type=norm_type, grn=grn, deep_supervision=True)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith(("norm.weight", "norm.bias", "grn_gamma", "grn_beta")):
+                p.add_(0.3 * torch.randn_like(p))
+    st = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    kw = dict(n_channels=n_channels, exp_r=2, kernel_size=3, block_counts=counts, norm_type=norm_type, grn=grn)
+    x = torch.rand(2, 1, 32, 32, 32)
+    wmaps = [torch.randn(2, 2, 32 >> i, 32 >> i, 32 >> i, generator=torch.Generator().manual_seed(20 + i)) for i in range(5)]
+    params = {k: v.clone().requires_grad_(True) for k, v in st.items() if v.dtype.is_floating_point}
+    ref = MO.forward(params, x, deep_supervision=True, **kw)
+    sum((torch.sigmoid(o) * w).mean() for o, w in zip(ref, wmaps)).backward()
+    m = m.cuda().train()
+    out = m(x.cuda())
+    sum((torch.sigmoid(o) * w.cuda()).mean() for o, w in zip(out, wmaps)).backward()
+    for g, r in zip(out, ref):
+        torch.testing.assert_close(g.detach().cpu(), r.detach(), rtol=1e-3, atol=1e-3)
+    named = dict(m.named_parameters())
+    seen_variant = 0
+    for name, p in params.items():
+        if p.grad is None or name == "dummy_tensor":
+            continue
+        got = named[name].grad
+        assert got is not None and got.shape == p.grad.shape, name
+        # conv1.bias feeds a per-channel GroupNorm: its true gradient is 0 and both sides hold rounding noise -> absolute bound
+        floor = 1e-3 if (name.endswith("conv1.bias") and norm_type == "group") else 1e-5
+        scale = max(p.grad.abs().max().item(), floor)
+        err = (got.cpu() - p.grad).abs().max().item() / scale
+        assert err < 2e-2, (name, err, scale)
+        seen_variant += name.endswith(("grn_gamma", "grn_beta"))
+    assert seen_variant == (2 * 17 if grn else 0)
+    # bf16 storage runs the same schedule: finite, and close to the fp32 result
+    m.compute_dtype = torch.bfloat16
+    m.zero_grad()
+    out16 = m(x.cuda())
+    sum((torch.sigmoid(o) * w.cuda()).mean() for o, w in zip(out16, wmaps)).backward()
+    assert (torch.sigmoid(out16[0].float().cpu()) - torch.sigmoid(ref[0].detach())).abs().max() < 6e-2
+    gW = named["enc_block_0.0.conv2.weight"].grad.flatten().cpu()
+    rW = params["enc_block_0.0.conv2.weight"].grad.flatten()
+    assert all(torch.isfinite(q.grad).all() for q in m.parameters() if q.grad is not None)
+    assert float((gW * rW).sum() / (gW.norm() * rW.norm() + 1e-20)) > 0.97
