@@ -228,8 +228,10 @@ def test_mednext_grn_and_layernorm_variants_match_oracle(dev, norm_type, grn, dt
     assert (torch.sigmoid(got) - torch.sigmoid(ref)).abs().max() < tol
     if dt == torch.float32:
         torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-3)
-    with pytest.raises(NotImplementedError):
-        m.train()(x.to(dev))                       # the training kernels cover GroupNorm blocks only
+    tr = m.train()(x.to(dev))                      # the variants train too (NormVariantBlockFn; gradients: test_gpu_training.py)
+    assert tr.requires_grad
+    tol_train = 1e-3 if dt == torch.float32 else TOL_BF16_PROB
+    assert (torch.sigmoid(tr.detach().float().cpu()) - torch.sigmoid(ref)).abs().max() < tol_train
 
 
 @pytest.mark.parametrize("size,shape", [("S", (32, 32, 48)), ("S", (16, 48, 80)), ("L", (32, 32, 32)), ("B", (16, 32, 64))])
