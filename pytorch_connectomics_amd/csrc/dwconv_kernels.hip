@@ -1058,29 +1058,39 @@ void dw_wgrad_march_launch(const void* gr, const void* x, float* dWp, float* dbp
 
 // ---------------------------------------------------------------------------------------------
 // stats [N][slots][2][C] -> ab [N][2][C]   (a = gamma*rstd, b = beta - mean*a)
-constexpr int FIN_CH = 16, FIN_SL = 16;
-__global__ void __launch_bounds__(256)
+// workgroup = 16 channels x 64 slot lanes (1024 threads): the slot loop is a chain of dependent-latency reads (26 launches per
+// MedNeXt-S forward sit between a depthwise conv and its mixer), so it is spread over 4x the lanes and unrolled; the 4 slot
+// lanes of a wave meet through shuffles, the 16 waves through LDS.
+constexpr int FIN_CH = 16, FIN_SL = 64, FIN_WAVES = FIN_CH * FIN_SL / 64;
+__global__ void __launch_bounds__(FIN_CH * FIN_SL)
 groupnorm_finalize_kernel(const float* __restrict__ stats, int slots, float count,
                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                           float* __restrict__ ab, float* __restrict__ mr, int C) {
-  __shared__ float red[2][FIN_SL][FIN_CH];
+  __shared__ float red[2][FIN_WAVES][FIN_CH];
   const int n = blockIdx.y;
   const int cl = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
   const int c = blockIdx.x * FIN_CH + cl;
   float a1 = 0.f, a2 = 0.f;
   if (c < C) {
     const float* base = stats + (long)n * slots * 2 * C;
+#pragma unroll 4
     for (int s = sl; s < slots; s += FIN_SL) {
       a1 += base[((long)s * 2 + 0) * C + c];
       a2 += base[((long)s * 2 + 1) * C + c];
     }
   }
-  red[0][sl][cl] = a1;
-  red[1][sl][cl] = a2;
+  a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64);
+  a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+  const int wave = threadIdx.x / 64;
+  if ((threadIdx.x % 64) < FIN_CH) {
+    red[0][wave][cl] = a1;
+    red[1][wave][cl] = a2;
+  }
   __syncthreads();
-  if (sl == 0 && c < C) {
+  if (threadIdx.x < FIN_CH && c < C) {
     float t1 = 0.f, t2 = 0.f;
-    for (int s = 0; s < FIN_SL; ++s) { t1 += red[0][s][cl]; t2 += red[1][s][cl]; }
+#pragma unroll
+    for (int s = 0; s < FIN_WAVES; ++s) { t1 += red[0][s][cl]; t2 += red[1][s][cl]; }
     float mean = t1 / count;
     float var = fmaxf(t2 / count - mean * mean, 0.f);
     float rstd = rsqrtf(var + eps);
@@ -1292,7 +1302,7 @@ extern "C" int pytc_groupnorm_finalize_mr(const float* stats, int slots, float c
                                           const float* beta, float eps, float* ab, float* mean_rstd, int N, int C,
                                           void* stream) {
   PYTC_REQUIRE(stats && ab && slots >= 1 && count > 0 && N >= 1 && C >= 1, "groupnorm_finalize: bad arguments");
-  dim3 grid(ceil_div(C, FIN_CH), N), block(256);
+  dim3 grid(ceil_div(C, FIN_CH), N), block(FIN_CH * FIN_SL);
   hipLaunchKernelGGL(groupnorm_finalize_kernel, grid, block, 0, (hipStream_t)stream, stats, slots, count, gamma, beta,
                      eps, ab, mean_rstd, C);
   PYTC_LAUNCH_CHECK("groupnorm_finalize");
