@@ -85,7 +85,7 @@ def test_volume_reader_and_jaccard(tmp_path):
     np.save(tmp_path / "v.npy", v)
     assert np.array_equal(read_volume(str(tmp_path / "v.npy")), v)
     with pytest.raises(ValueError, match="unsupported"):
-        read_volume("x.tiff")
+        read_volume("x.nii.gz")
     pred = torch.tensor([0.9, 0.8, 0.2, 0.1])
     lab = torch.tensor([1, 0, 1, 0])
     assert binary_jaccard(pred, lab) == pytest.approx(1 / 3)
