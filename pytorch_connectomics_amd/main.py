@@ -151,6 +151,21 @@ def run_test(cfg, args) -> dict:
             while x.dim() < 5:
                 x = x.unsqueeze(0)
             mgr = InferenceManager(cfg=cfg, model=model, forward_fn=model.forward)
+            from .inference.window import is_2d_inference_mode
+            if is_2d_inference_mode(cfg) and x.shape[2] > 1:
+                # data.*.do_2d ("extract 2D slices from 3D volumes", config/schema/data.py:221): every z-slice is one 2-D image
+                # through the 2-D mode of the predictor (no sliding window, views over y / x); results restacked along z
+                slice_mgr = mgr
+
+                def _per_slice(images, mask=None, **k):
+                    outs = []
+                    for z in range(images.shape[2]):
+                        mz = mask
+                        if isinstance(mask, torch.Tensor) and mask.dim() >= 3 and mask.shape[-3] == images.shape[2]:
+                            mz = mask[..., z:z + 1, :, :]
+                        outs.append(slice_mgr.predict_with_tta(images[:, :, z:z + 1], mask=mz, **k))
+                    return torch.stack(outs, dim=2)
+                mgr = NS(cfg=cfg, predict_with_tta=_per_slice)
             # prediction-space crop: user crop_pad + DeepEM affinity border (test_pipeline.py:734, prediction_crops.py:240-256)
             from .inference.crop import crop_spatial_by_pad, resolve_global_prediction_crop
             from .inference.stage import run_prediction_inference
@@ -215,9 +230,12 @@ def run_train(cfg, args) -> dict:
             while True:
                 xs, ys = [], []
                 for _ in range(bs):
-                    o = [int(torch.randint(0, vol.shape[a] - patch[a] + 1, (1,), generator=g)) for a in range(3)]
-                    sl = tuple(slice(o[a], o[a] + patch[a]) for a in range(3))
-                    xs.append(vol[sl][None]); ys.append((lab[sl] > 0).float()[None])
+                    # a 2-D patch_size on a 3-D volume = one z-slice per sample (data.*.do_2d semantics)
+                    full = ((1,) * (vol.dim() - len(patch))) + tuple(patch)
+                    o = [int(torch.randint(0, vol.shape[a] - full[a] + 1, (1,), generator=g)) for a in range(vol.dim())]
+                    sl = tuple(slice(o[a], o[a] + full[a]) for a in range(vol.dim()))
+                    xv, yv = vol[sl].reshape(patch), lab[sl].reshape(patch)
+                    xs.append(xv[None]); ys.append((yv > 0).float()[None])
                 yield {"image": torch.stack(xs), "label": torch.stack(ys)}
         batches = sampler()
     t0 = time.perf_counter()

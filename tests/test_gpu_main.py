@@ -170,3 +170,80 @@ test:
     x = torch.from_numpy(np.ascontiguousarray(read_volume("random://minimal/test_image?shape=40,96,80"), dtype=np.float32)).cuda()
     direct = InferenceManager(cfg=c, model=net, forward_fn=net.forward).predict_with_tta(x)
     np.testing.assert_allclose(direct[0].cpu().numpy(), pred, atol=1e-6)
+
+
+def test_cli_mednext_2d_train_then_slicewise_test(tmp_path):
+    """A `mednext.dim: 2d` configuration shaped like the reference's tutorials/mito_mitolab.yaml (deep supervision, Dice + two BCE
+    terms + tanh-MSE on channel slices, 2-D patches): --mode train on random 2-D patches, then --mode test with data.*.do_2d,
+    where every z-slice of the test volume is one 2-D image (no sliding window) and the results are restacked."""
+    from pytorch_connectomics_amd.inference.artifact import read_prediction_artifact
+    from pytorch_connectomics_amd.main import main
+    cfg = tmp_path / "m2d.yaml"
+    cfg.write_text(f"""
+experiment_name: mednext2d
+save_path: {tmp_path / 'out'}
+default:
+  optimization: {{precision: "32"}}
+  model:
+    arch: {{type: mednext_custom}}
+    in_channels: 1
+    out_channels: 3
+    mednext: {{base_channels: 8, exp_r: 2, kernel_size: 3, block_counts: [1,1,1,1,1,1,1,1,1], dim: 2d}}
+    loss:
+      deep_supervision: true
+      losses:
+        - {{function: DiceLoss, weight: 1.0, kwargs: {{include_background: false, sigmoid: true, smooth_nr: 1.0e-5, smooth_dr: 1.0e-5}}, pred_slice: "0:1", target_slice: "0:1"}}
+        - {{function: BCEWithLogitsLoss, weight: 0.5, pred_slice: "0:1", target_slice: "0:1"}}
+        - {{function: BCEWithLogitsLoss, weight: 0.5, pred_slice: "1:2", target_slice: "1:2"}}
+        - {{function: WeightedMSELoss, weight: 1.0, kwargs: {{tanh: true}}, pred_slice: "2:3", target_slice: "2:3"}}
+  data:
+    train: {{image: "random://m2d/train_image", label: "random://m2d/train_label", do_2d: true}}
+    dataloader: {{batch_size: 2, patch_size: [64, 48]}}
+  inference:
+    model:
+      channel_activations:
+        - {{channels: "0:2", activation: sigmoid}}
+        - {{channels: "2:3", activation: tanh}}
+    test_time_augmentation: {{enabled: true, flip_axes: [[0], [1]]}}
+train:
+  optimization:
+    max_epochs: 1
+    n_steps_per_epoch: 2
+    optimizer: {{name: AdamW, lr: 1.0e-3}}
+  system: {{seed: 7}}
+test:
+  data:
+    test: {{image: "random://m2d/test_image?shape=3,64,48"}}
+""")
+    out = main(["--config", str(cfg), "--mode", "train"])
+    assert out["steps"] == 2 and np.isfinite(out["first_loss"]) and np.isfinite(out["last_loss"])
+    ck = tmp_path / "out" / "checkpoints" / "last.ckpt"
+    blob = torch.load(ck, weights_only=True)
+    assert blob["state_dict"]["model.model.enc_block_0.0.conv1.weight"].dim() == 4              # Conv2d parameters
+    m = main(["--config", str(cfg), "--mode", "test", "--checkpoint", str(ck)])
+    assert m["output_voxels_per_s"] > 0
+    pred = read_prediction_artifact(next((tmp_path / "out" / "results").glob("*_prediction.h5")))
+    assert pred.shape == (3, 3, 64, 48)
+    assert 0.0 <= pred[:2].min() and pred[:2].max() <= 1.0 and -1.0 <= pred[2].min() and pred[2].max() <= 1.0
+    # slice z of the artifact = the 3-view ensemble of the 2-D model on that slice
+    from pytorch_connectomics_amd.config import load_config
+    from pytorch_connectomics_amd.main import load_checkpoint, read_volume
+    from pytorch_connectomics_amd.models import build_model
+    c = load_config(cfg, mode="test")
+    net = build_model(c).cuda().eval()
+    load_checkpoint(net, str(ck))
+    vol = torch.from_numpy(np.ascontiguousarray(read_volume("random://m2d/test_image?shape=3,64,48"), dtype=np.float32)).cuda()
+
+    def act(o):
+        return torch.cat([torch.sigmoid(o[:, :2]), torch.tanh(o[:, 2:3])], 1)
+    with torch.no_grad():
+        for z in range(3):
+            x = vol[z][None, None]
+            out0 = net(x)
+            out0 = out0["output"] if isinstance(out0, dict) else (out0[0] if isinstance(out0, list) else out0)
+            views = [act(out0)]
+            for ax in (2, 3):
+                o = net(torch.flip(x, [ax]).contiguous())
+                o = o["output"] if isinstance(o, dict) else (o[0] if isinstance(o, list) else o)
+                views.append(torch.flip(act(o), [ax]))
+            np.testing.assert_allclose(torch.stack(views).mean(0)[0].cpu().numpy(), pred[:, z], atol=2e-5)
