@@ -314,11 +314,16 @@ int pytc_pw_mlp_stemres_fwd(const pytc_mlp_args* a, const float* stem_x, const f
  * written: y [N][D][H][W][32] bf16 = dwconv3(stem(x)) with zero padding of the stem output; x [N][D][H][W] fp32;
  * wx [27][32] = w_taps[tap][c]*stem_w[c], wb [27][32] = w_taps[tap][c]*stem_b[c], cst [32] = bias[c] + sum_tap wb[tap][c]
  * (fp32, formed by the caller); stats [N][pytc_stem_dwconv3d_stat_slots][2][32] = per-slot (sum, sum of squares) of the stored
- * values (input of pytc_groupnorm_finalize). */
+ * values (input of pytc_groupnorm_finalize).
+ * W % 16 == 0 runs the matrix-core form (one v_mfma_f32_16x16x32_f16 per 16 voxels x 16 channels over f16 copies of the input
+ * and of the fused taps): it reads its A fragments and constants from `mfma_image` (pytc_stem_dwconv3d_mfma_image_bytes bytes,
+ * written by pytc_stem_dwconv3d_pack_mfma from the same wx / wb / cst); other widths run the fp32 VALU form (image may be NULL). */
 int pytc_stem_dwconv3d_stat_slots(int D, int H, int W);
 int pytc_stem_dwconv3d_supported(int C_in, int C, int K);
-int pytc_stem_dwconv3d_fwd(const float* x, const float* wx, const float* wb, const float* cst, void* y, float* stats,
-                           int N, int D, int H, int W, int C, void* stream);
+int pytc_stem_dwconv3d_mfma_image_bytes(void);
+int pytc_stem_dwconv3d_pack_mfma(const float* wx, const float* wb, const float* cst, void* image, void* stream);
+int pytc_stem_dwconv3d_fwd(const float* x, const float* wx, const float* wb, const float* cst, const void* mfma_image, void* y,
+                           float* stats, int N, int D, int H, int W, int C, void* stream);
 int pytc_pw_mlp_head_fwd(const pytc_mlp_args* a, const void* head_w, const float* head_b, float* head_y, int n_head,
                          int store_y, void* stream);
 

@@ -194,7 +194,9 @@ _SIGS = {
     "pytc_pw_mlp_stemres_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pytc_stem_dwconv3d_stat_slots": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pytc_stem_dwconv3d_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
-    "pytc_stem_dwconv3d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+    "pytc_stem_dwconv3d_mfma_image_bytes": (C.c_int, []),
+    "pytc_stem_dwconv3d_pack_mfma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pytc_stem_dwconv3d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pytc_pw_mlp_train_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p, C.c_void_p]),
     "pytc_pw_mlp_bwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p, C.c_void_p, C.c_void_p]),

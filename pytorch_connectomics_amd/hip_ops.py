@@ -559,16 +559,19 @@ def stem_dwconv3d_supported(c_in: int, c: int, K: int) -> bool:
 
 
 def stem_dwconv3d_pack(stem_w: torch.Tensor, stem_b: torch.Tensor, w_taps: torch.Tensor, bias: Optional[torch.Tensor]):
-    """-> (wx (27,C), wb (27,C), cst (C)) fp32: the products pytc_stem_dwconv3d_fwd consumes (cache them per weight version)."""
+    """-> (wx (27,C), wb (27,C), cst (C), image): the fp32 products pytc_stem_dwconv3d_fwd consumes and the f16 fragment image of
+    its matrix-core form (pytc_stem_dwconv3d_pack_mfma).  Cache them per weight version."""
     wx = (w_taps * stem_w.view(1, -1)).contiguous()
     wb = (w_taps * stem_b.view(1, -1)).contiguous()
-    cst = wb.sum(0) + (bias if bias is not None else 0.0)
-    return wx, wb, cst.contiguous()
+    cst = (wb.sum(0) + (bias if bias is not None else 0.0)).contiguous()
+    image = torch.empty((nat.lib().pytc_stem_dwconv3d_mfma_image_bytes(),), dtype=torch.uint8, device=wx.device)
+    _run("stem_dwconv3d_pack_mfma", 0, nat.lib().pytc_stem_dwconv3d_pack_mfma, _p(wx), _p(wb), _p(cst), _p(image), _stream())
+    return wx, wb, cst, image
 
 
 def stem_dwconv3d(x: torch.Tensor, packed):
     """x (N,D,H,W,1) fp32 -> (t (N,D,H,W,32) bf16 = dwconv3(stem(x)), stats (N,slots,2,32)); the stem output is not formed."""
-    wx, wb, cst = packed
+    wx, wb, cst, image = packed
     _dev(x, "x"); _dev(wx, "wx")
     if x.dtype != torch.float32 or x.shape[-1] != 1:
         raise TypeError("stem_dwconv3d takes the 1-channel fp32 network input")
@@ -578,7 +581,7 @@ def stem_dwconv3d(x: torch.Tensor, packed):
     slots = nat.lib().pytc_stem_dwconv3d_stat_slots(D, H, W)
     st = torch.empty((N, slots, 2, Cc), dtype=torch.float32, device=x.device)
     _run(f"stem_dwconv3d_fwd[C{Cc}_k3]", _nbytes(x, y), nat.lib().pytc_stem_dwconv3d_fwd, _p(x), _p(wx), _p(wb), _p(cst),
-         _p(y), _p(st), N, D, H, W, Cc, _stream())
+         _p(image), _p(y), _p(st), N, D, H, W, Cc, _stream())
     return y, st
 
 
