@@ -479,7 +479,13 @@ struct DwMarch {
 // 36 ms MedNeXt-S step) becomes one extra read inside the kernel that already writes dx.  The residual values of output
 // plane p travel in registers (one channel pair per position: 4-byte loads, 64-B segments), requested at step p -- BEFORE
 // that step's input-plane request -- and consumed by the stores of step p+1; the counted wait below includes them.
-template <typename T, int VEC, int PF, bool ASYNC, int WPS = 2, bool RES = false>
+// H16 (bf16 storage only): the nine in-plane taps of a z step are accumulated in PACKED f16 (v_pk_fma_f16: two channels per
+// lane-instruction at full rate, where v_pk_fma_f32 takes two passes) and each 9-tap partial sum is then added to its fp32
+// accumulator.  The kernel is bound by VALU issue -- 27 FMAs x 360 M outputs per level-0 launch = 250 us at the fp32 FMA peak,
+// 340 us as scheduled -- so this removes ~40 % of its issue cycles; the input plane and the taps live in LDS as f16 (half the
+// bytes per read).  Error budget: the bf16 inputs are exact in f16 (8 -> 11 mantissa bits), a 9-term f16 partial sum carries
+// ~sqrt(9) * 2^-12 = 7e-4 relative error, below the 2^-9 rounding of the bf16 result; the z direction stays in fp32.
+template <typename T, int VEC, int PF, bool ASYNC, int WPS = 2, bool RES = false, bool H16 = false>
 __global__ void __launch_bounds__(256, WPS)
 dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ w,
                          const float* __restrict__ bias, float* __restrict__ stats, DwMarch g,
@@ -493,10 +499,12 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
   constexpr int NCHUNK = EY * EX * CH16;            // chunks per plane
   constexpr int CPT = (NCHUNK + 255) / 256;         // chunks per thread
   typedef float fvec_t __attribute__((ext_vector_type(VEC)));
-  __shared__ __attribute__((aligned(16))) float plane[2][EY * EX * CG];
+  static_assert(!H16 || (sizeof(T) == 2 && VEC == 2), "the packed-f16 tap loop is for bf16 storage, channel pairs");
+  typedef typename std::conditional<H16, _Float16, float>::type lds_t;
+  __shared__ __attribute__((aligned(16))) lds_t plane[2][EY * EX * CG];
   __shared__ float red[4][2][CG];
   // the 27 x CG taps live in LDS, not in 54 registers per lane (lanes of one channel pair read the same address: broadcast)
-  __shared__ __attribute__((aligned(16))) float wlds[27 * CG];
+  __shared__ __attribute__((aligned(16))) lds_t wlds[27 * CG];
 
   const int tid = threadIdx.x;
   // 1-D grid, XCD-aware: logical index = ((n * CGs + cg) * slots + slot); x-/y-neighbouring footprints
@@ -575,17 +583,25 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
 #pragma unroll
         for (int q = 0; q < EPC; ++q) v[q] = 0.f;
       }
-      float* dst = &plane[slot][loff[i]];
+      lds_t* dst = &plane[slot][loff[i]];
+      if constexpr (H16) {
+        // f16 image: clamp to the f16 range first (a bf16 activation beyond 6e4 would become inf and poison the sums)
+        h8_t hv;
 #pragma unroll
-      for (int q = 0; q < EPC; q += 4)
-        *reinterpret_cast<f32x4_t*>(dst + q) = f32x4_t{v[q], v[q + 1], v[q + 2], v[q + 3]};
+        for (int q = 0; q < EPC; ++q) hv[q] = (_Float16)fminf(fmaxf(v[q], -60000.f), 60000.f);
+        *reinterpret_cast<h8_t*>(dst) = hv;
+      } else {
+#pragma unroll
+        for (int q = 0; q < EPC; q += 4)
+          *reinterpret_cast<f32x4_t*>(dst + q) = f32x4_t{v[q], v[q + 1], v[q + 2], v[q + 3]};
+      }
     }
   };
 
   // ---- per-thread weights (27 taps x VEC channels), bias, positions
   const int cv = tid % LPV, pslot = tid / LPV;
   const int c0 = cg * CG + cv * VEC;
-  for (int i = tid; i < 27 * CG; i += 256) wlds[i] = w[(long)(i / CG) * C + cg * CG + (i % CG)];
+  for (int i = tid; i < 27 * CG; i += 256) wlds[i] = (lds_t)w[(long)(i / CG) * C + cg * CG + (i % CG)];
   // (visible after the __syncthreads() that follows the prologue's first commit)
   float bv[VEC];
 #pragma unroll
@@ -644,7 +660,48 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
     // Unconditional accumulation: planes outside the volume were staged as zeros, and accumulators that
     // belong to outputs outside [zs, ze) are simply never stored (2 wasted planes per z-chunk), which keeps
     // the inner loop free of per-FMA selects.
-    {
+    if constexpr (H16) {
+      // packed-f16 form of the hand-scheduled loop below: tap group g+1 (3 weight + 4 data reads, 4 bytes each) is requested
+      // before the 12 v_pk_fma_f16 of group g; the three 9-tap partial sums per position then join the fp32 accumulators
+      typedef const volatile __attribute__((address_space(3))) h2_t* lds_vol_h2;
+      h2_t wq[2][3], vq[2][PASSES];
+      h2_t pn[PASSES], pc[PASSES], pp[PASSES];
+      auto fetch = [&](int g, int buf) {
+        const int dy = g / 3, dx = g % 3;
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) wq[buf][kz] = *(lds_vol_h2)(&wlds[((kz * 3 + dy) * 3 + dx) * CG + cv * VEC]);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) vq[buf][ps] = *(lds_vol_h2)(&plane[slot][lbase[ps] + (dy * EX + dx) * CG]);
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int g = 0; g < 9; ++g) {
+        if (g + 1 < 9) fetch(g + 1, (g + 1) & 1);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+          if (g == 0) {
+            asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(pn[ps]) : "v"(vq[0][ps]), "v"(wq[0][0]));
+            asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(pc[ps]) : "v"(vq[0][ps]), "v"(wq[0][1]));
+            asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(pp[ps]) : "v"(vq[0][ps]), "v"(wq[0][2]));
+          } else {
+            asm volatile("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(pn[ps]) : "v"(vq[g & 1][ps]), "v"(wq[g & 1][0]));
+            asm volatile("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(pc[ps]) : "v"(vq[g & 1][ps]), "v"(wq[g & 1][1]));
+            asm volatile("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(pp[ps]) : "v"(vq[g & 1][ps]), "v"(wq[g & 1][2]));
+          }
+        }
+      }
+      // acc (fp32) += partial (f16 half): one v_fma_mix_f32 each (f16 source selected by op_sel, times 1.0, plus the fp32 acc)
+#define PYTC_MIX_ADD(ACC, P)                                                                                                  \
+  asm volatile("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(ACC[0]) : "v"(P));                     \
+  asm volatile("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(ACC[1]) : "v"(P));
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        float an[2] = {next[ps][0], next[ps][1]}, ac[2] = {cur[ps][0], cur[ps][1]}, ap[2] = {prev[ps][0], prev[ps][1]};
+        PYTC_MIX_ADD(an, pn[ps]) PYTC_MIX_ADD(ac, pc[ps]) PYTC_MIX_ADD(ap, pp[ps])
+        next[ps][0] = an[0]; next[ps][1] = an[1]; cur[ps][0] = ac[0]; cur[ps][1] = ac[1]; prev[ps][0] = ap[0]; prev[ps][1] = ap[1];
+      }
+#undef PYTC_MIX_ADD
+    } else {
       // Hand-scheduled tap loop (VEC == 2).  Left to itself hipcc issues all 63 LDS reads of a step first (126 live
       // registers) and then runs each accumulator's nine FMAs back to back, with an s_nop between dependent
       // v_pk_fma_f32.  Here the order is fixed by volatile reads and asm-volatile FMAs: tap group g+1 (3 weight + 4 data
@@ -1226,12 +1283,20 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
 #define PYTC_MARCH(PP, WW) \
   hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, PP, true, WW>), grid, block, 0, (hipStream_t)stream, \
                      (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t)
+    const int h16 = tuning_get("dwconv_march_h16", 1);      // packed-f16 in-plane partial sums (see the kernel header); 0: fp32 taps
     if (res) {
       // 8 more live registers than the plain kernel (two residual sets in flight): compiled for 3 waves / SIMD.  At the
       // 4-waves budget (128 VGPRs) hipcc spills 31 registers, and a spill of a register an asm-issued load is still
       // writing corrupts the value -- the counted-wait scheme REQUIRES a spill-free kernel (measured: garbage output)
-      hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, 3, true, 3, true>), grid, block, 0, (hipStream_t)stream,
-                         (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t, (const bf16_t*)res);
+      if (h16)
+        hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, 3, true, 3, true, true>), grid, block, 0, (hipStream_t)stream,
+                           (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t, (const bf16_t*)res);
+      else
+        hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, 3, true, 3, true>), grid, block, 0, (hipStream_t)stream,
+                           (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t, (const bf16_t*)res);
+    } else if (dtype == PYTC_BF16 && h16) {
+      hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, 3, true, 4, false, true>), grid, block, 0, (hipStream_t)stream,
+                         (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t);
     } else if (dtype == PYTC_BF16) {
       switch (variant) {
         case 1: PYTC_MARCH(3, 3); break;

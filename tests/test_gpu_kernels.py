@@ -336,3 +336,45 @@ def test_pw_conv_thin_kernels(kind, in_dt, out_dt):
         torch.testing.assert_close(y1.float(), y0.float(), rtol=1e-2 if out_dt == torch.bfloat16 else 1e-5, atol=1e-2 if out_dt == torch.bfloat16 else 1e-5)
     ref = x.float().bfloat16().float() @ w.bfloat16().float().t() + b
     torch.testing.assert_close(y1.float(), ref if out_dt == torch.float32 else ref.bfloat16().float(), rtol=2e-2, atol=2e-2)
+
+
+def test_dwconv_march_packed_f16_error_budget(dev):
+    """The z-march depthwise conv accumulates the nine in-plane taps of a z step in packed f16 and the z direction in fp32
+    (`dwconv_march_h16`, default on for bf16 storage).  Budget, against an fp64 convolution of the same bf16 operands: the mean
+    error stays within 15 % of what rounding the EXACT result to bf16 costs on its own, the worst element within 1.5x the worst
+    element of the fp32-tap form (knob off), which is reproduced within that noise.  Large activations are clamped into the f16
+    range at staging instead of becoming inf."""
+    from pytorch_connectomics_amd import _native as nat
+    from pytorch_connectomics_amd import hip_ops as ops
+
+    def knob(v):
+        nat.check(nat.lib().pytc_set_tuning(b"dwconv_march_h16", int(v)), "set_tuning")
+
+    torch.manual_seed(11)
+    N, D, C = 1, 24, 64
+    x = (torch.randn(N, D, D, D, C, device=dev) * 2).to(torch.bfloat16)
+    taps = torch.randn(27, C, device=dev) * 0.3
+    b = torch.randn(C, device=dev) * 0.1
+    w64 = taps.t().reshape(C, 1, 3, 3, 3).double().cpu()
+    ref = F.conv3d(x.double().cpu().permute(0, 4, 1, 2, 3), w64, b.double().cpu(), padding=1, groups=C).permute(0, 2, 3, 4, 1)
+    floor = (ref.float().to(torch.bfloat16).double() - ref).abs().mean()
+    out = {}
+    try:
+        for h in (0, 1):
+            knob(h)
+            y, st = ops.dwconv3d(x, taps, b, K=3)
+            out[h] = y.double().cpu()
+            err = (out[h] - ref).abs()
+            assert float(err.mean()) < (1.02 if h == 0 else 1.15) * float(floor), (h, float(err.mean()), float(floor))
+            out[("max", h)] = float(err.max())
+            s = st.sum(1).cpu().double()                                  # statistics of the stored tensor, either way
+            torch.testing.assert_close(s[:, 0], out[h].sum((1, 2, 3)), rtol=1e-4, atol=1e-2)
+        assert float((out[1] - out[0]).abs().mean()) < 0.6 * float(floor)
+        assert out[("max", 1)] <= 1.5 * out[("max", 0)]
+        knob(1)
+        big = x.clone()
+        big[0, 5, 5, 5, :] = 3.0e5                                       # beyond f16: clamped to 6e4, finite everywhere
+        yb, _ = ops.dwconv3d(big, taps, b, K=3)
+        assert bool(torch.isfinite(yb.float()).all())
+    finally:
+        knob(1)

@@ -561,14 +561,29 @@ def test_batched_packs_and_deferred_reductions_are_bit_identical(dtype, monkeypa
 @pytest.mark.parametrize("shape,C", [((2, 16, 24, 40), 32), ((1, 20, 17, 33), 64), ((1, 9, 16, 16), 32)])
 def test_dwconv_with_fused_residual_is_bit_identical_to_conv_then_add(shape, C):
     """pytc_dwconv3d_fwd_res (y = conv(x) + res in the z-march kernel, the residual travelling in registers with a counted
-    wait) against conv-in-fp32 + add + one rounding; ragged planes, a depth that is not a multiple of the z-chunk."""
+    wait) against conv-in-fp32 + add + one rounding; ragged planes, a depth that is not a multiple of the z-chunk.  Bit-identity
+    is a statement about the fp32-tap form (`dwconv_march_h16` = 0); the default packed-f16 in-plane sums reproduce it within
+    the noise of the bf16 result."""
+    from pytorch_connectomics_amd import _native as nat
     from pytorch_connectomics_amd import hip_ops as ops
+
+    def knob(v):
+        nat.check(nat.lib().pytc_set_tuning(b"dwconv_march_h16", int(v)), "set_tuning")
     N, D, H, W = shape
     g = torch.Generator().manual_seed(C + D)
     x = torch.randn(N, D, H, W, C, generator=g).cuda().to(torch.bfloat16)
     res = torch.randn(N, D, H, W, C, generator=g).cuda().to(torch.bfloat16)
     taps = torch.randn(27, C, generator=g).cuda()
     assert ops.dwconv3d_res_supported(x, 3, 1)
+    got16 = ops.dwconv3d_res(x, taps, res, K=3)            # default form
+    knob(0)
+    try:
+        _fused_residual_bit_identity(ops, x, res, taps, got16)
+    finally:
+        knob(1)
+
+
+def _fused_residual_bit_identity(ops, x, res, taps, got16):
     want, _ = ops.dwconv3d(x, taps, None, K=3, stride=1, stats=False)
     want32 = want.float()           # conv rounded to bf16, then added: NOT what the fused kernel does (one rounding) ...
     # ... so the reference is built from the fp32 accumulator: conv in fp32 storage, add, round once
@@ -579,6 +594,8 @@ def test_dwconv_with_fused_residual_is_bit_identical_to_conv_then_add(shape, C):
     # the two-step form (round the conv, add, round again) differs from it by at most one bf16 ulp of the result
     assert float((ref.float() - (want32 + res.float())).abs().max()) <= 2.0 ** -6 * float(ref.float().abs().max())
     assert not ops.dwconv3d_res_supported(x.float(), 3, 1) and not ops.dwconv3d_res_supported(x[:, :4], 3, 1)
+    d16 = (got16.float() - ref.float()).abs()
+    assert float(d16.max()) <= 2.0 ** -6 * float(ref.float().abs().max()) and float(d16.mean()) < 1e-3 * float(ref.float().abs().mean())
 
 
 def test_gradnorm_balancing_trains_through_the_hip_autograd_functions():

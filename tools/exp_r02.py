@@ -80,6 +80,13 @@ def lut():
     knob("dwconv_march_wgs", 1024)
 
 
+def fwd():
+    """MedNeXt-S forward, 8 windows, with whatever knobs are set."""
+    m = model_s()
+    x = torch.rand(8, 112, 112, 112, 1, device=dev)
+    print(f"forward: {time_forward(m, x, reps=10):8.3f} ms / 8 windows", flush=True)
+
+
 def upfuse():
     m = model_s()
     x = torch.rand(8, 112, 112, 112, 1, device=dev)
@@ -98,4 +105,9 @@ def upfuse():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["nsweep", "lut", "upfuse"]
     for w in which:
+        if w.startswith("knob:"):                     # knob:<name>=<int> sets a tuning knob for the experiments that follow
+            k, v = w[5:].split("=")
+            knob(k, int(v))
+            print(f"[knob] {k} = {v}", flush=True)
+            continue
         globals()[w]()
