@@ -277,20 +277,24 @@ def monai_unet_leg(dev, args):
                      (24, 256, 256), 2, 1)
 
 
+def _kernel_key(label):
+    """rocprof kernel-name prefix of a bench label: the fused mixer of one shape (plain and epilogue variants).  Other kernels run
+    at several shapes under one name: no per-shape counter average."""
+    import re
+    m = re.match(r"pw_mlp_fwd\[(\d+)->(\d+)->(\d+)\]", label)
+    return f"pw_mlp_kernel<{int(m.group(1)) // 32}, {int(m.group(3)) // 16}," if m else None
+
+
 def pmc_traffic_bytes(label):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command (newest
     profiles/rNN_bench_hbm_counters.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs by
     tools/profile_bench.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if the file or the
-    kernel is missing -- counters cannot be collected from inside the timed process."""
+    kernel is missing."""
     import csv
-    import re
     files = sorted((ROOT / "profiles").glob("r*_bench_hbm_counters.csv"))
-    if not files:
+    key = _kernel_key(label)
+    if not files or key is None:
         return None
-    m = re.match(r"pw_mlp_fwd\[(\d+)->(\d+)->(\d+)\]", label)
-    if not m:
-        return None          # other kernels run at several shapes under one name: no per-shape counter average
-    key = f"pw_mlp_kernel<{int(m.group(1)) // 32}, {int(m.group(3)) // 16},"
     tot = n = 0.0
     for row in csv.DictReader(open(files[-1])):   # the plain and the epilogue variants of the shape, launch-weighted
         if key in row["kernel"]:
@@ -300,6 +304,49 @@ def pmc_traffic_bytes(label):
     return int(tot / n) if n else None
 
 
+def live_pmc_traffic_bytes(label, timeout_s=150):
+    """The same counters collected NOW, on this box: two child runs of this script (one whole-volume step, inference only) under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, no trace domains, as MI355X_MICROARCH.md prescribes --
+    outside the timed region.  FETCH_SIZE / WRITE_SIZE are reported in KB; FETCH_SIZE is doubled for gfx950.  None when rocprofv3 is
+    missing, a pass fails or times out, or the kernel does not show up (the caller then falls back to the committed passes)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    key = _kernel_key(label)
+    exe = shutil.which("rocprofv3")
+    if key is None or exe is None:
+        return None
+    means = {}
+    tmp = tempfile.mkdtemp(prefix="pytc_pmc_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "bench", "--", sys.executable,
+                   str(ROOT / "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline", "--no-train",
+                   "--no-extras"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter and key in row.get("Kernel_Name", ""):
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None
+            means[counter] = sum(vals) / len(vals)
+        return int((2 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024)
+    except Exception:      # noqa: BLE001 - a profiler hiccup must not take the bench line down
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -307,6 +354,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed PMC passes only (no rocprofv3 child runs)")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the tta8 / cube448 / fp32 / U-Net legs")
     ap.add_argument("--train-batch", type=int, default=4)
@@ -384,6 +432,14 @@ def main():
         summ = prof.summary()
         roofline = dominant(summ, nprof, traffic_fn=pmc_traffic_bytes)
         del value, weight
+        if roofline is not None:
+            roofline["traffic_source"] = "committed rocprofv3 --pmc passes of this command (profiles/rNN_bench_hbm_counters.csv)"
+            if world == 1 and not args.no_live_pmc:
+                live = live_pmc_traffic_bytes(roofline["kernel"])
+                if live:
+                    roofline["traffic"] = live
+                    roofline["traffic_source"] = ("live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child runs of this command "
+                                                  "on this box (separate passes, FETCH_SIZE x 2)")
         if os.environ.get("PYTC_BENCH_VERBOSE"):
             for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
                 print(f"  {k:34s} launches/step={v['launches'] / nprof:5.1f} ms/step={v['ms'] / nprof:7.3f} "
