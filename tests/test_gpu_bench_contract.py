@@ -40,6 +40,11 @@ def test_single_gpu_line_has_every_contract_field():
     roof = d["roofline"]
     assert roof["bound"] in ("hbm", "mfma") and roof["unit"] == "GB/s" and 0 < roof["frac"] <= 1.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    # HBM bytes per launch of the dominant kernel: PMC counters collected live by child runs under rocprofv3 (or, without the
+    # profiler, the committed passes); a fused mixer moves its algorithmic bytes, not more
+    assert roof["traffic_source"].startswith(("live", "committed"))
+    if roof["traffic_source"].startswith("live"):
+        assert 0.7 * roof["algorithmic_bytes"] < roof["traffic"] < 1.3 * roof["algorithmic_bytes"]
     assert d["train"]["ms_per_step"] > 0 and d["train"]["roofline"]["frac"] > 0
 
 
