@@ -86,7 +86,8 @@ def schema_defaults() -> dict:
             "sliding_window": _window_defaults(),
             "chunking": {"enabled": False, "output_mode": "decoded", "chunk_size": None, "halo": [0, 0, 0],
                          "axes": "all", "roi": None, "shard_id": None, "num_shards": None, "temp_dir": "",
-                         "save_intermediate": False},
+                         "save_intermediate": False, "precomputed": False, "precomputed_resolution": None,
+                         "precomputed_chunk_size": [128, 128, 64], "precomputed_affinity_convention": "none"},
             "test_time_augmentation": {"enabled": False, "distributed_sharding": True, "flip_axes": "all",
                                        "rotation90_axes": None, "rotate90_k": None, "patch_first_local": True,
                                        "apply_mask": True, "ensemble_mode": "mean", "empty_cache_interval": 4},

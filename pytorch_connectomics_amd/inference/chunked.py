@@ -296,9 +296,18 @@ def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, de
     stitch=False / external sharding is active, or with return_array=False).  `predict_region_fn(start, stop) ->
     (1,C,*region)` replaces the device predictor in host-logic tests."""
     ch_cfg = getattr(getattr(cfg, "inference", None), "chunking", None)
-    if bool(getattr(ch_cfg, "precomputed", False)):
-        raise NotImplementedError("inference.chunking.precomputed (CloudVolume layer output) is outside this engine: it is the "
-                                  "reference's cloud storage client, not the hot path; write HDF5 chunks and upload them")
+    # optional: stream chunks straight into a neuroglancer precomputed layer instead of per-chunk HDF5 + stitching
+    # (reference chunked.py:485-507); the layer directory is the output path without its suffix
+    pc_out = bool(getattr(ch_cfg, "precomputed", False))
+    pc_convention = str(getattr(ch_cfg, "precomputed_affinity_convention", "none") or "none").lower()
+    pc_resolution = pc_chunk_xyz = None
+    if pc_out:
+        if pc_convention not in ("none", "abiss"):
+            raise ValueError(f"inference.chunking.precomputed_affinity_convention must be 'none' or 'abiss', got {pc_convention!r}.")
+        pc_resolution = getattr(ch_cfg, "precomputed_resolution", None)
+        if not pc_resolution:
+            raise ValueError("inference.chunking.precomputed requires inference.chunking.precomputed_resolution (XYZ nm).")
+        pc_chunk_xyz = [int(v) for v in (getattr(ch_cfg, "precomputed_chunk_size", None) or [128, 128, 64])]
     validate_chunked_output_format(cfg)
     output_path = _normalise_output_path(output_path)
     h5 = _use_h5(output_path)
@@ -315,6 +324,9 @@ def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, de
     vol_shape = cropped_shape(input_shape[-3:], crop_pad)
     halo = tuple(int(v) for v in (getattr(ch_cfg, "halo", None) or (0, 0, 0)))
     chunk_shape = resolve_chunk_shape(cfg, vol_shape)
+    if pc_out:
+        from .precomputed import open_precomputed_layer, validate_precomputed_alignment
+        validate_precomputed_alignment(chunk_shape, pc_chunk_xyz)
     chunks = build_chunk_grid(vol_shape, chunk_shape)
     roi = _resolve_inference_roi(cfg)
     if roi is not None:
@@ -337,9 +349,13 @@ def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, de
                                               "roi": None if roi is None else [list(roi[0]), list(roi[1])],
                                               "container": "h5" if h5 else "npy"},
                                              overwrite=overwrite)
+    def _done_file(c) -> Path:
+        # a precomputed layer has no per-chunk file to stat: completion is a marker file (reference chunked.py:59-66)
+        return cdir / f"chunk_{c.key}.done" if pc_out else _chunk_file(cdir, c, h5)
+
     prefetch = None
     if predict_region_fn is None:
-        todo = [c for _i, c in mine if not (_chunk_file(cdir, c, h5).exists() and c.key in manifest.completed)]
+        todo = [c for _i, c in mine if not (_done_file(c).exists() and c.key in manifest.completed)]
         if isinstance(volume, LazyVolumeAccessor) and not volume.needs_per_patch_host_path and todo:
             # disk read + decompression of chunk i+1 into pinned memory on an IO thread while chunk i is predicted
             boxes = []
@@ -372,16 +388,35 @@ def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, de
         write_prediction_artifact(tmp, data, metadata=md, compression="gzip", chunks=(int(data.shape[0]), *sp))
         os.replace(tmp, path)
 
+    pc_layer_dir = output_path.with_suffix("")
+    pc_layer = [None]
+
+    def save_precomputed(path: Path, data: np.ndarray, key: str) -> None:
+        c, _read_lo, _read_hi = meta_of.pop(key)
+        if pc_layer[0] is None:
+            pc_layer[0] = open_precomputed_layer(pc_layer_dir, volume_size_xyz=tuple(reversed(vol_shape)),
+                                                 num_channels=int(data.shape[0]), data_type=str(data.dtype),
+                                                 resolution_xyz=pc_resolution, chunk_size_xyz=pc_chunk_xyz)
+        pc_layer[0].write_czyx(c.start, data)
+        z0, y0, x0 = (int(v) for v in c.start)
+        path.write_text(json.dumps({"chunk_key": c.key, "chunk_start_zyx": list(c.start), "chunk_stop_zyx": list(c.stop),
+                                    "written_xyz": [[x0, y0, z0], [x0 + data.shape[3], y0 + data.shape[2], z0 + data.shape[1]]]}))
+
     channels = None
-    writer = _ChunkWriter(manifest, save=save_h5 if h5 else None)
+    writer = _ChunkWriter(manifest, save=save_precomputed if pc_out else (save_h5 if h5 else None))
     try:
         for pos, (idx, c) in enumerate(mine, 1):
-            f = _chunk_file(cdir, c, h5)
+            f = _done_file(c)
             if f.exists() and c.key in manifest.completed:     # idempotent resume (reference chunked.py:510-523)
                 logger.info("chunk %s already done, skipping", c.key)
                 continue
             read_lo, read_hi, core = resolve_halo_region(c, input_shape[-3:], halo=halo, crop_before=crop_before)
             pred = predict_region_fn(read_lo, read_hi)
+            if pc_out and pc_convention == "abiss":
+                # on the HALOED array: the edge shift reads voxel v-1, so the halo (not a zero fill) supplies each core face
+                # except at a true volume boundary (reference chunked.py:566-569)
+                pred_np = pred.detach().cpu().numpy() if isinstance(pred, torch.Tensor) else np.asarray(pred)
+                pred = _to_abiss_affinity_convention(pred_np[0])[None]
             core_pred = pred[(0, slice(None)) + core]
             core_pred = apply_storage_dtype_transform(cfg, apply_prediction_transform(cfg, core_pred))
             channels = int(core_pred.shape[0])
@@ -395,6 +430,11 @@ def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, de
         return None       # external shards are stitched by a later call once every shard has run
     if world > 1:
         torch.distributed.barrier()
+    if pc_out:
+        # the layer IS the output: every chunk wrote its own disjoint, storage-chunk-aligned region; nothing to stitch
+        if rank == 0:
+            logger.info("chunked raw prediction wrote %d chunks into precomputed layer %s", len(chunks), pc_layer_dir)
+        return None
     if rank != 0:
         return None
     _write_chunk_index(output_path, chunks, cdir, input_shape=input_shape[-3:], final_shape=vol_shape, crop_pad=crop_pad,

@@ -254,9 +254,74 @@ def test_chunked_hdf5_layout_matches_reference_vocabulary(tmp_path):
     with pytest.raises(ValueError, match="single streamed HDF5"):
         run_chunked_prediction_inference(cfg, None, vol, output_path=tmp_path / "x.h5", predict_region_fn=boom)
     cfg.inference.save_backend = "h5"
-    cfg.inference.chunking.precomputed = True
-    with pytest.raises(NotImplementedError, match="precomputed"):
-        run_chunked_prediction_inference(cfg, None, vol, output_path=tmp_path / "y.h5", predict_region_fn=boom)
+
+
+def test_chunked_precomputed_layer_output(tmp_path):
+    """inference.chunking.precomputed: chunk predictions go straight into a raw-encoded neuroglancer precomputed layer (reference
+    chunked.py:485-507, :590-612: info fields of CloudVolume.create_new_info, storage-chunk-aligned writes, `.done` markers for
+    resume, no stitching).  The layer is read back with an independent decoder of the format specification."""
+    import gzip
+    from pytorch_connectomics_amd.inference.precomputed import PrecomputedLayer, validate_precomputed_alignment
+    vol = np.random.default_rng(5).random((8, 12, 10)).astype(np.float32)
+    cfg = _cfg((4, 6, 10), halo=(1, 2, 0))
+    cfg.inference.prediction_transform = NS(enabled=True, intensity_scale=255.0, intensity_dtype="uint8")
+    ch = cfg.inference.chunking
+    ch.precomputed, ch.precomputed_resolution, ch.precomputed_chunk_size = True, [8, 8, 30], [5, 3, 2]
+    ch.precomputed_affinity_convention = "none"
+    out = run_chunked_prediction_inference(cfg, None, vol, output_path=tmp_path / "pred.h5", predict_region_fn=_fake_predictor(vol))
+    assert out is None                                                # the layer is the output: nothing is stitched
+    layer = tmp_path / "pred"
+    info = json.loads((layer / "info").read_text())
+    assert info["type"] == "image" and info["data_type"] == "uint8" and info["num_channels"] == 2
+    assert info["scales"] == [{"key": "8_8_30", "size": [10, 12, 8], "resolution": [8, 8, 30], "voxel_offset": [0, 0, 0],
+                               "chunk_sizes": [[5, 3, 2]], "encoding": "raw"}]
+    want = np.clip(np.stack([vol, vol * 2 + 1]) * np.float32(255.0), 0, 255).astype(np.uint8)
+    # independent decode of one storage chunk: x 5..10, y 3..6, z 2..4 -> gzip'd bytes, Fortran order over (x, y, z, channel)
+    raw = gzip.decompress((layer / "8_8_30" / "5-10_3-6_2-4.gz").read_bytes())
+    cell = np.frombuffer(raw, dtype=np.uint8).reshape((5, 3, 2, 2), order="F")
+    assert np.array_equal(cell.transpose(3, 2, 1, 0), want[:, 2:4, 3:6, 5:10])
+    assert len(list((layer / "8_8_30").glob("*.gz"))) == 2 * 4 * 4
+    got = PrecomputedLayer(layer).read_czyx((0, 0, 0), (8, 12, 10), fill_missing=False)
+    assert got.dtype == np.uint8 and np.array_equal(got, want)
+    assert np.array_equal(PrecomputedLayer(layer).read_czyx((1, 2, 3), (7, 11, 9)), want[:, 1:7, 2:11, 3:9])
+    markers = sorted(p.name for p in (tmp_path / "pred.h5.chunks").glob("chunk_*.done"))
+    assert markers == ["chunk_z0_y0_x0.done", "chunk_z0_y1_x0.done", "chunk_z1_y0_x0.done", "chunk_z1_y1_x0.done"]
+    m = json.loads((tmp_path / "pred.h5.chunks" / "chunk_z1_y1_x0.done").read_text())
+    assert m == {"chunk_key": "z1_y1_x0", "chunk_start_zyx": [4, 6, 0], "chunk_stop_zyx": [8, 12, 10],
+                 "written_xyz": [[0, 6, 4], [10, 12, 8]]}
+
+    def boom(*_a):
+        raise AssertionError("chunk recomputed on resume")
+    assert run_chunked_prediction_inference(cfg, None, vol, output_path=tmp_path / "pred.h5", predict_region_fn=boom) is None
+    # ABISS convention: edge shift along each channel's own axis (read from the halo) + channel reversal, on 3-channel affinities
+    aff = np.random.default_rng(6).random((3, 8, 12, 10)).astype(np.float32)
+    cfg3 = _cfg((4, 6, 10), halo=(1, 1, 1))
+    c3 = cfg3.inference.chunking
+    c3.precomputed, c3.precomputed_resolution, c3.precomputed_chunk_size = True, [8, 8, 30], [10, 6, 4]
+    c3.precomputed_affinity_convention = "abiss"
+
+    def predict_aff(start, stop):
+        return aff[(slice(None),) + tuple(slice(a, b) for a, b in zip(start, stop))][None]
+    run_chunked_prediction_inference(cfg3, None, vol, output_path=tmp_path / "aff.h5", predict_region_fn=predict_aff)
+    shifted = np.zeros_like(aff)
+    shifted[0, 1:] = aff[0, :-1]
+    shifted[1, :, 1:] = aff[1, :, :-1]
+    shifted[2, :, :, 1:] = aff[2, :, :, :-1]
+    got3 = PrecomputedLayer(tmp_path / "aff").read_czyx((0, 0, 0), (8, 12, 10), fill_missing=False)
+    assert got3.dtype == np.float32 and np.array_equal(got3, shifted[::-1])
+    # configuration errors, with the reference's messages
+    c3.precomputed_affinity_convention = "seung"
+    with pytest.raises(ValueError, match="must be 'none' or 'abiss'"):
+        run_chunked_prediction_inference(cfg3, None, vol, output_path=tmp_path / "e.h5", predict_region_fn=boom)
+    c3.precomputed_affinity_convention, c3.precomputed_resolution = "none", None
+    with pytest.raises(ValueError, match="requires inference.chunking.precomputed_resolution"):
+        run_chunked_prediction_inference(cfg3, None, vol, output_path=tmp_path / "e.h5", predict_region_fn=boom)
+    c3.precomputed_resolution, c3.precomputed_chunk_size = [8, 8, 30], [4, 6, 4]
+    with pytest.raises(ValueError, match="x: inference chunk 10 is not a multiple of storage chunk 4"):
+        run_chunked_prediction_inference(cfg3, None, vol, output_path=tmp_path / "e.h5", predict_region_fn=boom)
+    validate_precomputed_alignment((4, 6, 10), (5, 3, 2))
+    with pytest.raises(ValueError, match="does not cover storage chunk"):
+        PrecomputedLayer(layer).write_czyx((0, 0, 0), want[:, :3, :3, :5])
 
 
 def test_roi_restricted_chunking_and_helpers(tmp_path):
