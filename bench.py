@@ -304,7 +304,7 @@ def pmc_traffic_bytes(label):
     return int(tot / n) if n else None
 
 
-def live_pmc_traffic_bytes(label, timeout_s=150):
+def live_pmc_traffic_bytes(label, timeout_s=90):
     """The same counters collected NOW, on this box: two child runs of this script (one whole-volume step, inference only) under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, no trace domains, as MI355X_MICROARCH.md prescribes --
     outside the timed region.  FETCH_SIZE / WRITE_SIZE are reported in KB; FETCH_SIZE is doubled for gfx950.  None when rocprofv3 is
