@@ -195,6 +195,7 @@ conv3d_wgrad_strided_kernel(const T* __restrict__ a, const T* __restrict__ gsm, 
                             SwGeom g, int C_k, int C_o, long rows_per_slot, int slots) {
   __shared__ float sa[SW_TR][SW_TK + 1];
   __shared__ float sd[SW_TR][SW_TO + 1];
+  __shared__ long rsrc[SW_TR];                 // element offset of the row's source voxel in `a` (-1: outside / past the slot)
   const int slot = blockIdx.x, tap = blockIdx.z;
   const int tiles_k = (C_k + SW_TK - 1) / SW_TK;
   const int o_base = (blockIdx.y / tiles_k) * SW_TO, k_base = (blockIdx.y % tiles_k) * SW_TK;
@@ -210,18 +211,25 @@ conv3d_wgrad_strided_kernel(const T* __restrict__ a, const T* __restrict__ gsm, 
   const long r_begin = (long)slot * rows_per_slot;
   const long r_end = r_begin + rows_per_slot < rows_total ? r_begin + rows_per_slot : rows_total;
   for (long r0 = r_begin; r0 < r_end; r0 += SW_TR) {
-    for (int i = threadIdx.x; i < SW_TR * SW_TK; i += 256) {
-      const int rr = i / SW_TK, kk = i % SW_TK;
-      const long r = r0 + rr;
-      float v = 0.f;
-      if (r < r_end && k_base + kk < C_k) {
+    // the source voxel of a row is the same for all its channels: decode it ONCE per row (the 64-bit divisions used to run
+    // per staged element -- 64x per row -- and dominated the kernel)
+    if (threadIdx.x < SW_TR) {
+      const long r = r0 + threadIdx.x;
+      long off = -1;
+      if (r < r_end) {
         const long n = r / vol_s, rem = r % vol_s;
         const int x = (int)(rem % g.Ws), y = (int)((rem / g.Ws) % g.Hs), z = (int)(rem / ((long)g.Ws * g.Hs));
         const int bz = z * g.sd + tz_ - g.pd, by = y * g.sh + ty_ - g.ph, bx = x * g.sw + tx_ - g.pw;
         if (bz >= 0 && bz < g.Db && by >= 0 && by < g.Hb && bx >= 0 && bx < g.Wb)
-          v = to_f32<T>(a[(n * vol_b + ((long)bz * g.Hb + by) * g.Wb + bx) * C_k + k_base + kk]);
+          off = (n * vol_b + ((long)bz * g.Hb + by) * g.Wb + bx) * C_k;
       }
-      sa[rr][kk] = v;
+      rsrc[threadIdx.x] = off;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SW_TR * SW_TK; i += 256) {
+      const int rr = i / SW_TK, kk = i % SW_TK;
+      const long off = rsrc[rr];
+      sa[rr][kk] = (off >= 0 && k_base + kk < C_k) ? to_f32<T>(a[off + k_base + kk]) : 0.f;
     }
     for (int i = threadIdx.x; i < SW_TR * SW_TO; i += 256) {
       const int rr = i / SW_TO, oo = i % SW_TO;
@@ -251,6 +259,111 @@ conv3d_wgrad_strided_kernel(const T* __restrict__ a, const T* __restrict__ gsm, 
       const int k = k_base + tx * 4 + j;
       if (k < C_k) dWp[(((long)slot * taps + tap) * C_o + o) * C_k + k] = acc[i][j];
     }
+  }
+}
+
+
+// C_k <= 4 (the first conv of a U-Net, 1 -> C; the last transposed conv, C -> 1): the 64 x 64 tile above would spend 63 / 64 of
+// its staging and FMAs on padding (3.4 ms per launch for 1 -> 32 at 2 x 24 x 256 x 256).  Here a thread owns one output channel
+// o and every 4th row of its slot: G[r][o] is a coalesced 64-lane load, the row's C_k source values are wave-uniform (broadcast
+// loads), the row coordinates advance incrementally (no divisions in the loop); the 4 row lanes meet in LDS in a fixed order.
+constexpr int SWT_TO = 64, SWT_RL = 4, SWT_KMAX = 4;
+template <typename T>
+__global__ void __launch_bounds__(256)
+conv3d_wgrad_strided_thin_kernel(const T* __restrict__ a, const T* __restrict__ gsm, float* __restrict__ dWp, long rows_total,
+                                 SwGeom g, int C_k, int C_o, long rows_per_slot, int slots) {
+  __shared__ float red[SWT_RL][SWT_TO][SWT_KMAX];
+  const int slot = blockIdx.x, tap = blockIdx.z;
+  const int o = blockIdx.y * SWT_TO + (threadIdx.x % SWT_TO), rl = threadIdx.x / SWT_TO;
+  const int tz_ = tap / (g.kh * g.kw), ty_ = (tap / g.kw) % g.kh, tx_ = tap % g.kw;
+  const long vol_s = (long)g.Ds * g.Hs * g.Ws;
+  const long vol_b = (long)g.Db * g.Hb * g.Wb;
+  const long r_begin = (long)slot * rows_per_slot;
+  const long r_end = r_begin + rows_per_slot < rows_total ? r_begin + rows_per_slot : rows_total;
+  float acc[SWT_KMAX] = {0.f, 0.f, 0.f, 0.f};
+  long r = r_begin + rl;
+  if (r < r_end) {
+    long n = r / vol_s;
+    const long rem = r % vol_s;
+    int x = (int)(rem % g.Ws), y = (int)((rem / g.Ws) % g.Hs), z = (int)(rem / ((long)g.Ws * g.Hs));
+    const bool o_ok = o < C_o;
+    for (; r < r_end; r += SWT_RL) {
+      const int bz = z * g.sd + tz_ - g.pd, by = y * g.sh + ty_ - g.ph, bx = x * g.sw + tx_ - g.pw;
+      if (bz >= 0 && bz < g.Db && by >= 0 && by < g.Hb && bx >= 0 && bx < g.Wb && o_ok) {     // wave-uniform except o_ok
+        const float gv = to_f32<T>(gsm[r * C_o + o]);
+        const T* src = a + (n * vol_b + ((long)bz * g.Hb + by) * g.Wb + bx) * C_k;
+#pragma unroll
+        for (int k = 0; k < SWT_KMAX; ++k)
+          if (k < C_k) acc[k] = fmaf(gv, to_f32<T>(src[k]), acc[k]);
+      }
+      x += SWT_RL;
+      while (x >= g.Ws) { x -= g.Ws; if (++y == g.Hs) { y = 0; if (++z == g.Ds) { z = 0; ++n; } } }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < SWT_KMAX; ++k) red[rl][threadIdx.x % SWT_TO][k] = acc[k];
+  __syncthreads();
+  if (rl == 0 && o < C_o) {
+    const int taps = g.kd * g.kh * g.kw;
+    for (int k = 0; k < C_k; ++k) {
+      const int oo = threadIdx.x % SWT_TO;
+      dWp[(((long)slot * taps + tap) * C_o + o) * C_k + k] = ((red[0][oo][k] + red[1][oo][k]) + red[2][oo][k]) + red[3][oo][k];
+    }
+  }
+}
+
+// C_k == 1 and 3 x 3 x 3 taps (the two layers above in a 1-channel network): all 27 taps in one pass -- G[r][o] is read ONCE
+// instead of once per tap (27 launches-worth of re-reads), the 27 source values of a row are wave-uniform broadcast loads.
+template <typename T>
+__global__ void __launch_bounds__(256)
+conv3d_wgrad_strided_thin1_kernel(const T* __restrict__ a, const T* __restrict__ gsm, float* __restrict__ dWp, long rows_total,
+                                  SwGeom g, int C_o, long rows_per_slot, int slots) {
+  __shared__ float red[SWT_RL][SWT_TO][27 + 1];
+  const int slot = blockIdx.x;
+  const int oo = threadIdx.x % SWT_TO, o = blockIdx.y * SWT_TO + oo, rl = threadIdx.x / SWT_TO;
+  const long vol_s = (long)g.Ds * g.Hs * g.Ws;
+  const long vol_b = (long)g.Db * g.Hb * g.Wb;
+  const long r_begin = (long)slot * rows_per_slot;
+  const long r_end = r_begin + rows_per_slot < rows_total ? r_begin + rows_per_slot : rows_total;
+  float acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+  long r = r_begin + rl;
+  if (r < r_end) {
+    long n = r / vol_s;
+    const long rem = r % vol_s;
+    int x = (int)(rem % g.Ws), y = (int)((rem / g.Ws) % g.Hs), z = (int)(rem / ((long)g.Ws * g.Hs));
+    const bool o_ok = o < C_o;
+    for (; r < r_end; r += SWT_RL) {
+      const float gv = o_ok ? to_f32<T>(gsm[r * C_o + o]) : 0.f;
+      const T* base = a + n * vol_b;
+      const int bz0 = z * g.sd - g.pd, by0 = y * g.sh - g.ph, bx0 = x * g.sw - g.pw;
+#pragma unroll
+      for (int tz = 0; tz < 3; ++tz) {
+        const int bz = bz0 + tz;
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+          const int by = by0 + ty;
+          const bool row_ok = bz >= 0 && bz < g.Db && by >= 0 && by < g.Hb;
+          const T* rowp = base + ((long)min(max(bz, 0), g.Db - 1) * g.Hb + min(max(by, 0), g.Hb - 1)) * g.Wb;
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx) {
+            const int bx = bx0 + tx;
+            const float av = (row_ok && bx >= 0 && bx < g.Wb) ? to_f32<T>(rowp[bx]) : 0.f;      // wave-uniform address
+            acc[(tz * 3 + ty) * 3 + tx] = fmaf(gv, av, acc[(tz * 3 + ty) * 3 + tx]);
+          }
+        }
+      }
+      x += SWT_RL;
+      while (x >= g.Ws) { x -= g.Ws; if (++y == g.Hs) { y = 0; if (++z == g.Ds) { z = 0; ++n; } } }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 27; ++t) red[rl][oo][t] = acc[t];
+  __syncthreads();
+  if (rl == 0 && o < C_o) {
+    for (int t = 0; t < 27; ++t)
+      dWp[((long)slot * 27 + t) * C_o + o] = ((red[0][oo][t] + red[1][oo][t]) + red[2][oo][t]) + red[3][oo][t];
   }
 }
 
@@ -287,7 +400,11 @@ static void launch_sconv(const SConvParams& p, hipStream_t s) {
   }
 }
 
-static int sw_slots(long rows_total) {
+static int sw_slots(long rows_total, int C_k) {
+  if (C_k <= SWT_KMAX) {               // thin kernels: one workgroup per (slot, 64 channels [, tap]) -- many small slots fill the chip
+    const long s = rows_total / 512;
+    return (int)(s < 1 ? 1 : (s > 1024 ? 1024 : s));
+  }
   const long s = rows_total / 4096;
   return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
 }
@@ -354,7 +471,7 @@ extern "C" int64_t pytc_conv3d_wgrad_strided_ws_elems(int N, const int32_t* smal
                                                       const int32_t* kernel) {
   if (!small_dims || !kernel || N < 1) return -1;
   const long rows_total = (long)N * small_dims[0] * small_dims[1] * small_dims[2];
-  return (int64_t)sw_slots(rows_total) * kernel[0] * kernel[1] * kernel[2] * C_o * C_k;
+  return (int64_t)sw_slots(rows_total, C_k) * kernel[0] * kernel[1] * kernel[2] * C_o * C_k;
 }
 
 extern "C" int pytc_conv3d_wgrad_strided(const void* big, const void* small, float* dW, float* workspace, int N,
@@ -366,12 +483,29 @@ extern "C" int pytc_conv3d_wgrad_strided(const void* big, const void* small, flo
   SwGeom g{small_dims[0], small_dims[1], small_dims[2], big_dims[0], big_dims[1], big_dims[2], kernel[0], kernel[1], kernel[2],
            stride[0], stride[1], stride[2], pad[0], pad[1], pad[2]};
   const long rows_total = (long)N * g.Ds * g.Hs * g.Ws;
-  const int slots = sw_slots(rows_total);
+  const int slots = sw_slots(rows_total, C_k);
   const long rps = (rows_total + slots - 1) / slots;
   const int taps = g.kd * g.kh * g.kw;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(slots, ((C_o + SW_TO - 1) / SW_TO) * ((C_k + SW_TK - 1) / SW_TK), taps), block(256);
-  if (dtype == PYTC_BF16)
+  if (C_k == 1 && g.kd == 3 && g.kh == 3 && g.kw == 3 && (dtype == PYTC_BF16 || dtype == PYTC_F32) &&
+      tuning_get("conv3d_wgrad_thin", 1) != 0) {
+    dim3 tgrid(slots, (C_o + SWT_TO - 1) / SWT_TO);
+    if (dtype == PYTC_BF16)
+      hipLaunchKernelGGL(conv3d_wgrad_strided_thin1_kernel<bf16_t>, tgrid, block, 0, s, (const bf16_t*)big, (const bf16_t*)small,
+                         workspace, rows_total, g, C_o, rps, slots);
+    else
+      hipLaunchKernelGGL(conv3d_wgrad_strided_thin1_kernel<float>, tgrid, block, 0, s, (const float*)big, (const float*)small,
+                         workspace, rows_total, g, C_o, rps, slots);
+  } else if (C_k <= SWT_KMAX && (dtype == PYTC_BF16 || dtype == PYTC_F32) && tuning_get("conv3d_wgrad_thin", 1) != 0) {
+    dim3 tgrid(slots, (C_o + SWT_TO - 1) / SWT_TO, taps);
+    if (dtype == PYTC_BF16)
+      hipLaunchKernelGGL(conv3d_wgrad_strided_thin_kernel<bf16_t>, tgrid, block, 0, s, (const bf16_t*)big, (const bf16_t*)small,
+                         workspace, rows_total, g, C_k, C_o, rps, slots);
+    else
+      hipLaunchKernelGGL(conv3d_wgrad_strided_thin_kernel<float>, tgrid, block, 0, s, (const float*)big, (const float*)small,
+                         workspace, rows_total, g, C_k, C_o, rps, slots);
+  } else if (dtype == PYTC_BF16)
     hipLaunchKernelGGL(conv3d_wgrad_strided_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)big, (const bf16_t*)small,
                        workspace, rows_total, g, C_k, C_o, rps, slots);
   else if (dtype == PYTC_F32)
