@@ -315,7 +315,7 @@ def live_pmc_traffic_bytes(label, timeout_s=90):
     import subprocess
     import tempfile
     key = _kernel_key(label)
-    exe = shutil.which("rocprofv3")
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if key is None or exe is None:
         return None
     means = {}
