@@ -1,11 +1,14 @@
 """RSUNet training step timing (forward + backward + AdamW) on synthetic patches; run under rocprofv3 for the breakdown.
-    PYTHONPATH=. python tools/rsunet_train_probe.py [--dtype bf16] [--patch 18,160,160] [--batch 2] [--steps 5]"""
+    python tools/rsunet_train_probe.py [--dtype bf16] [--patch 18,160,160] [--batch 2] [--steps 5]"""
 import argparse
+import sys
 import time
+from pathlib import Path
 
 import torch
 import torch.nn.functional as F
 
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from pytorch_connectomics_amd.models.architectures.rsunet import RSUNet
 
 ap = argparse.ArgumentParser()
