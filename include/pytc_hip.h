@@ -506,6 +506,12 @@ int64_t pytc_conv3d_wgrad_strided_ws_elems(int N, const int32_t* small_dims, int
 int pytc_conv3d_wgrad_strided(const void* big, const void* small, float* dW, float* workspace, int N,
                               const int32_t* big_dims, const int32_t* small_dims, int C_k, int C_o, const int32_t* kernel,
                               const int32_t* stride, const int32_t* pad, int dtype, void* stream);
+/* ConvTranspose3d(kernel 3, stride 2, padding 1, output_padding 1) forward for C_out <= 4 (the last up-sampling layer of the
+ * MONAI-style U-Net, monai_models.py:228-250 with out_channels 1): one thread per output voxel, only the 1..8 taps that reach it;
+ * x [N][Di][Hi][Wi][C_in], w fp32 in ConvTranspose3d layout [C_in][C_out][27], y [N][2Di][2Hi][2Wi][C_out] in x's dtype. */
+int pytc_convT3d_thin_supported(int C_in, int C_out);
+int pytc_convT3d_thin_fwd(const void* x, const float* w, const float* bias, void* y, int N, const int32_t* in_dims, int C_in,
+                          int C_out, int dtype, void* stream);
 
 /* ---- train-step epilogue on the device ------------------------------------------------
  * Fused loss  L = w_bce * BCEWithLogits(x, t; weight, pos_weight) + w_dice * Dice(sigmoid(x), t)

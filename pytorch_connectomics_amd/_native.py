@@ -194,6 +194,9 @@ _SIGS = {
     "pytc_pw_mlp_stemres_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pytc_stem_dwconv3d_stat_slots": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pytc_stem_dwconv3d_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "pytc_convT3d_thin_supported": (C.c_int, [C.c_int, C.c_int]),
+    "pytc_convT3d_thin_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int,
+                                        C.c_int, C.c_void_p]),
     "pytc_stem_dwconv3d_mfma_image_bytes": (C.c_int, []),
     "pytc_stem_dwconv3d_pack_mfma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pytc_stem_dwconv3d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

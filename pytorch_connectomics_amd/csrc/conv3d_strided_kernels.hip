@@ -400,6 +400,75 @@ static void launch_sconv(const SConvParams& p, hipStream_t s) {
   }
 }
 
+// ---- ConvTranspose3d(k 3, stride 2, padding 1, output_padding 1) with C_out <= 4: the last up-sampling layer of a U-Net whose
+// output has one (or a few) channels.  On the MFMA kernel above its single output channel is a 16-row tile and every one of
+// the 27 taps is decoded per voxel (1.9 ms for 64 -> 1 at 2 x 24 x 256 x 256).  Here a thread owns one output voxel: along each
+// axis an even coordinate has ONE contributing tap (t = 1, source o / 2) and an odd one two (t = 0 / 2, sources (o + 1) / 2 and
+// (o - 1) / 2), so 1 .. 8 of the 27 taps are visited; the source row is read in 16-byte channel chunks, the taps come from LDS
+// ([tap][o][c] fp32).  w: ConvTranspose3d layout [C_in][C_out][27] fp32.
+constexpr int CT_OMAX = 4;
+template <typename T>
+__global__ void __launch_bounds__(256)
+convT3d_thin_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y,
+                    int N, int Di, int Hi, int Wi, int C_in, int C_out) {
+  extern __shared__ float wl[];                            // [27][C_out][C_in]
+  for (int i = threadIdx.x; i < 27 * C_out * C_in; i += 256) {
+    const int c = i % C_in, o = (i / C_in) % C_out, t = i / (C_in * C_out);
+    wl[i] = w[((long)c * C_out + o) * 27 + t];
+  }
+  __syncthreads();
+  const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
+  const long total = (long)N * Do * Ho * Wo;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long)gridDim.x * 256) {
+    const int ox = (int)(v % Wo);
+    long t = v / Wo;
+    const int oy = (int)(t % Ho); t /= Ho;
+    const int oz = (int)(t % Do);
+    const long n = t / Do;
+    float acc[CT_OMAX];
+#pragma unroll
+    for (int o = 0; o < CT_OMAX; ++o) acc[o] = (bias && o < C_out) ? bias[o] : 0.f;
+    // candidate taps per axis: (tap, source) pairs; -1 marks "none"
+    int tz[2], sz[2], ty[2], sy[2], tx[2], sx[2];
+    auto axis = [](int o, int n_in, int (&tp)[2], int (&sp)[2]) {
+      if ((o & 1) == 0) { tp[0] = 1; sp[0] = o >> 1; tp[1] = -1; sp[1] = 0; }
+      else {
+        tp[0] = 0; sp[0] = (o + 1) >> 1; tp[1] = 2; sp[1] = (o - 1) >> 1;
+        if (sp[0] >= n_in) tp[0] = -1;
+      }
+    };
+    axis(oz, Di, tz, sz); axis(oy, Hi, ty, sy); axis(ox, Wi, tx, sx);
+    for (int a = 0; a < 2; ++a) {
+      if (tz[a] < 0) continue;
+      for (int b = 0; b < 2; ++b) {
+        if (ty[b] < 0) continue;
+        for (int c2 = 0; c2 < 2; ++c2) {
+          if (tx[c2] < 0) continue;
+          const int tap = (tz[a] * 3 + ty[b]) * 3 + tx[c2];
+          const T* row = x + (((n * Di + sz[a]) * Hi + sy[b]) * Wi + sx[c2]) * C_in;
+          const float* wt = wl + (long)tap * C_out * C_in;
+          for (int c = 0; c < C_in; c += 8) {
+            float xv[8];
+            VecIO<T, 8>::load(row + c, xv);
+#pragma unroll
+            for (int o = 0; o < CT_OMAX; ++o) {
+              if (o < C_out) {
+                const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(wt + o * C_in + c);
+                const f32x4_t w1 = *reinterpret_cast<const f32x4_t*>(wt + o * C_in + c + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[o] = fmaf(xv[j], w0[j], acc[o]); acc[o] = fmaf(xv[4 + j], w1[j], acc[o]); }
+              }
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < CT_OMAX; ++o)
+      if (o < C_out) y[v * C_out + o] = from_f32<T>(acc[o]);
+  }
+}
+
 static int sw_slots(long rows_total, int C_k) {
   if (C_k <= SWT_KMAX) {               // thin kernels: one workgroup per (slot, 64 channels [, tap]) -- many small slots fill the chip
     const long s = rows_total / 512;
@@ -518,5 +587,30 @@ extern "C" int pytc_conv3d_wgrad_strided(const void* big, const void* small, flo
   const long nW = (long)taps * C_o * C_k;
   hipLaunchKernelGGL(sw_reduce_slots_kernel, dim3(ceil_div(nW, 16)), dim3(256), 0, s, workspace, dW, nW, slots);
   PYTC_LAUNCH_CHECK("conv3d_wgrad_strided");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_convT3d_thin_supported(int C_in, int C_out) {
+  return (C_out >= 1 && C_out <= CT_OMAX && C_in >= 8 && C_in % 8 == 0 && (size_t)27 * C_out * C_in * 4 <= 64 * 1024) ? 1 : 0;
+}
+
+extern "C" int pytc_convT3d_thin_fwd(const void* x, const float* w, const float* bias, void* y, int N, const int32_t* in_dims,
+                                     int C_in, int C_out, int dtype, void* stream) {
+  PYTC_REQUIRE(x && w && y && in_dims && N >= 1, "convT3d_thin: bad arguments");
+  PYTC_REQUIRE(pytc_convT3d_thin_supported(C_in, C_out), "convT3d_thin: needs C_out <= 4 and C_in %% 8 == 0 (got %d -> %d)", C_in, C_out);
+  const long total = (long)N * 8 * in_dims[0] * in_dims[1] * in_dims[2];
+  long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  const size_t lds = (size_t)27 * C_out * C_in * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == PYTC_BF16)
+    hipLaunchKernelGGL(convT3d_thin_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), lds, s, (const bf16_t*)x, w, bias, (bf16_t*)y, N,
+                       in_dims[0], in_dims[1], in_dims[2], C_in, C_out);
+  else if (dtype == PYTC_F32)
+    hipLaunchKernelGGL(convT3d_thin_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, s, (const float*)x, w, bias, (float*)y, N,
+                       in_dims[0], in_dims[1], in_dims[2], C_in, C_out);
+  else
+    PYTC_REQUIRE(false, "convT3d_thin: bad dtype %d", dtype);
+  PYTC_LAUNCH_CHECK("convT3d_thin");
   return PYTC_OK;
 }

@@ -1112,6 +1112,23 @@ def conv3d_strided(x: torch.Tensor, w_packed: torch.Tensor, *, c_out: int, kerne
     return y
 
 
+def convT3d_thin_supported(c_in: int, c_out: int) -> bool:
+    return bool(nat.lib().pytc_convT3d_thin_supported(int(c_in), int(c_out)))
+
+
+def convT3d_thin(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """ConvTranspose3d(k 3, s 2, p 1, op 1) for C_out <= 4: x (N,D,H,W,C_in) -> (N,2D,2H,2W,C_out); w fp32 (C_in, C_out, 3,3,3)."""
+    _dev(x, "x"); _dev(w, "w")
+    N, D, H, W, ci = x.shape
+    co = w.shape[1]
+    if tuple(w.shape) != (ci, co, 3, 3, 3) or w.dtype != torch.float32 or not w.is_contiguous():
+        raise ValueError(f"convT3d_thin: weight must be contiguous fp32 (C_in={ci}, C_out, 3, 3, 3), got {tuple(w.shape)} {w.dtype}")
+    y = torch.empty((N, 2 * D, 2 * H, 2 * W, co), dtype=x.dtype, device=x.device)
+    _run(f"convT3d_fwd[{ci}->{co},k333]", _nbytes(x, y), nat.lib().pytc_convT3d_thin_fwd, _p(x), _p(w), _p(bias), _p(y), N,
+         _i3((D, H, W)), ci, co, dtype_code(x.dtype), _stream())
+    return y
+
+
 def conv3d_wgrad_strided(big: torch.Tensor, small: torch.Tensor, kernel, stride, pad) -> torch.Tensor:
     """dW fp32 (C_small, C_big, kd, kh, kw) = sum_r small[r][o] * big[r*stride + tap - pad][k] (see pytc_hip.h)."""
     _dev(big, "big"); _dev(small, "small")

@@ -234,6 +234,11 @@ class ResampleConv3dFn(torch.autograd.Function):
         w32 = weight.detach().float().contiguous()
         if plain:
             y = ops.conv3d(a, ops.conv3d_pack_weight(w32, a.dtype), c_out=weight.shape[0], kernel=ks, bias=_f(bias))
+        elif (transposed and ks == (3, 3, 3) and stride == 2 and pad == 1 and a.dtype in (torch.bfloat16, torch.float32)
+              and ops.convT3d_thin_supported(weight.shape[0], weight.shape[1])):
+            # few output channels (the network's last up-sampling layer): one thread per output voxel instead of an MFMA tile
+            # padded to 16 channels (csrc/conv3d_strided_kernels.hip convT3d_thin_kernel); the backward is unchanged
+            y = ops.convT3d_thin(a.contiguous(), w32, _f(bias))
         elif transposed:
             out_dims = tuple((int(d) - 1) * stride - 2 * pad + k + (stride - 1) for d, k in zip(a.shape[1:4], ks))
             y = ops.conv3d_strided(a, ops.conv3d_pack_weight_direct(w32, a.dtype, layout="convT"), c_out=weight.shape[1],
