@@ -378,3 +378,26 @@ def test_dwconv_march_packed_f16_error_budget(dev):
         assert bool(torch.isfinite(yb.float()).all())
     finally:
         knob(1)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,shape", [(64, 1, (3, 5, 4)), (8, 3, (2, 2, 3)), (32, 4, (4, 3, 2)), (16, 2, (1, 1, 1))])
+def test_conv_transpose_thin_matches_torch(dev, dt, cin, cout, shape):
+    """ConvTranspose3d(k 3, s 2, p 1, output_padding 1) with few output channels (one thread per output voxel, 1..8 taps each)
+    against torch, and against the MFMA gather kernel it replaces for such layers."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(cin * 10 + cout)
+    N = 2
+    x = torch.randn(N, cin, *shape)
+    w = torch.randn(cin, cout, 3, 3, 3) * 0.2
+    b = torch.randn(cout)
+    xq = x.to(dt).float()
+    ref = F.conv_transpose3d(xq, w, b, stride=2, padding=1, output_padding=1)
+    assert ops.convT3d_thin_supported(cin, cout) and not ops.convT3d_thin_supported(cin, 5) and not ops.convT3d_thin_supported(12, cout)
+    got = ops.convT3d_thin(_cl(xq).to(dev).to(dt), w.to(dev), b.to(dev))
+    assert tuple(got.shape) == (N, 2 * shape[0], 2 * shape[1], 2 * shape[2], cout) and got.dtype == dt
+    torch.testing.assert_close(_cf(got.float().cpu()), ref, **(dict(rtol=1e-4, atol=1e-4) if dt == torch.float32 else dict(rtol=2e-2, atol=3e-2)))
+    mf = ops.conv3d_strided(_cl(xq).to(dev).to(dt), ops.conv3d_pack_weight_direct(w.to(dev), dt, layout="convT"), c_out=cout,
+                            kernel=(3, 3, 3), stride=(2, 2, 2), pad=(1, 1, 1), out_dims=tuple(2 * s for s in shape), transposed=True,
+                            bias=b.to(dev))
+    torch.testing.assert_close(got.float(), mf.float(), **(dict(rtol=1e-4, atol=1e-4) if dt == torch.float32 else dict(rtol=2e-2, atol=3e-2)))
