@@ -66,6 +66,9 @@ def read_volume(spec: str, *, default_shape=(64, 128, 128), seed: int = 0) -> np
     if path.suffix.lower() in (".tif", ".tiff"):
         from .utils.tiffstack import read_tiff_volume
         return read_tiff_volume(str(path))
+    if path.name.lower().endswith((".nii", ".nii.gz")):
+        from .utils.niftilite import read_nifti
+        return read_nifti(str(path))
     raise ValueError(f"unsupported volume format: {spec}")
 
 

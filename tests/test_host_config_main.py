@@ -85,7 +85,7 @@ def test_volume_reader_and_jaccard(tmp_path):
     np.save(tmp_path / "v.npy", v)
     assert np.array_equal(read_volume(str(tmp_path / "v.npy")), v)
     with pytest.raises(ValueError, match="unsupported"):
-        read_volume("x.nii.gz")
+        read_volume("x.mrc")
     pred = torch.tensor([0.9, 0.8, 0.2, 0.1])
     lab = torch.tensor([1, 0, 1, 0])
     assert binary_jaccard(pred, lab) == pytest.approx(1 / 3)
@@ -174,3 +174,49 @@ def test_reference_tutorial_configs_resolve_through_their_own_profile_library():
         assert test_cfg.inference.sliding_window.window_size is None or len(test_cfg.inference.sliding_window.window_size) in (2, 3)
     cremi = load_config(tut / "syn_cremi.yaml", mode="train")
     assert list(cremi.model.rsunet.width) == [18, 36, 48, 64, 80] and cremi.model.rsunet.norm == "batch"      # explicit `batch` over the profile's `group`
+
+
+@pytest.mark.parametrize("dtype,suffix", [("uint8", ".nii"), ("int16", ".nii.gz"), ("float32", ".nii.gz")])
+def test_nifti_volumes_without_nibabel(tmp_path, dtype, suffix):
+    """Single-file NIfTI-1 (.nii / .nii.gz): voxels in Fortran order, returned in the reference's axis convention ((X, Y, Z) ->
+    (D, H, W), (X, Y, Z, C) -> (C, D, H, W); io.py:267-306), header scaling applied only when asked for, big-endian files."""
+    import gzip
+    import struct
+    import numpy as np
+    from pytorch_connectomics_amd.utils.niftilite import nifti_shape, read_nifti, write_nifti
+    rng = np.random.default_rng(1)
+    vol = (rng.random((5, 6, 7)) * 100).astype(dtype)                     # (D, H, W)
+    p = tmp_path / f"v{suffix}"
+    write_nifti(str(p), vol)
+    raw = (gzip.open(p, "rb") if suffix.endswith(".gz") else open(p, "rb")).read()
+    assert struct.unpack("<i", raw[:4])[0] == 348 and raw[344:348] == b"n+1\x00" and struct.unpack("<8h", raw[40:56])[:4] == (3, 7, 6, 5)
+    # the stored bytes are the (X, Y, Z) array in Fortran order: x fastest
+    stored = np.frombuffer(raw, dtype=np.dtype(dtype).newbyteorder("<"), offset=352).reshape((7, 6, 5), order="F")
+    assert np.array_equal(stored.transpose(2, 1, 0), vol)
+    got = read_nifti(str(p))
+    assert got.dtype == np.dtype(dtype) and got.flags.c_contiguous and np.array_equal(got, vol)
+    assert nifti_shape(str(p)) == (5, 6, 7) and np.array_equal(read_volume(str(p)), vol)
+    vol4 = (rng.random((2, 3, 4, 5)) * 50).astype(dtype)                  # (C, D, H, W)
+    q = tmp_path / f"c{suffix}"
+    write_nifti(str(q), vol4)
+    assert nifti_shape(str(q)) == (2, 3, 4, 5) and np.array_equal(read_nifti(str(q)), vol4)
+    # scl_slope / scl_inter: applied like nibabel's dataobj (float64 result); a big-endian copy reads the same
+    hdr = bytearray(raw[:352])
+    struct.pack_into("<2f", hdr, 112, 0.5, 3.0)
+    s = tmp_path / "scaled.nii"
+    s.write_bytes(bytes(hdr) + raw[352:])
+    sc = read_nifti(str(s))
+    assert sc.dtype == np.float64 and np.allclose(sc, vol.astype(np.float64) * 0.5 + 3.0)
+    be = bytearray(348)
+    struct.pack_into(">i", be, 0, 348)
+    struct.pack_into(">8h", be, 40, 3, 7, 6, 5, 1, 1, 1, 1)
+    struct.pack_into(">h", be, 70, struct.unpack("<h", raw[70:72])[0])
+    struct.pack_into(">f", be, 108, 352.0)
+    struct.pack_into(">2f", be, 112, 1.0, 0.0)
+    be[344:348] = b"n+1\x00"
+    b = tmp_path / "big.nii"
+    b.write_bytes(bytes(be) + b"\x00" * 4 + vol.transpose(2, 1, 0).astype(np.dtype(dtype).newbyteorder(">")).tobytes(order="F"))
+    assert np.array_equal(read_nifti(str(b)), vol)
+    (tmp_path / "bad.nii").write_bytes(b"\x00" * 400)
+    with pytest.raises(ValueError, match="not a NIfTI-1"):
+        read_nifti(str(tmp_path / "bad.nii"))
