@@ -66,6 +66,16 @@ def read_volume(spec: str, *, default_shape=(64, 128, 128), seed: int = 0) -> np
     if path.suffix.lower() in (".tif", ".tiff"):
         from .utils.tiffstack import read_tiff_volume
         return read_tiff_volume(str(path))
+    if path.suffix.lower() == ".png":
+        # a glob pattern of PNG slices (reference io.py:161-177 read_images + :346-350): sorted, stacked along z; colour slices
+        # (D, H, W, C) become (C, D, H, W)
+        import glob
+        from PIL import Image
+        files = sorted(glob.glob(spec))
+        if not files:
+            raise ValueError(f"No files found matching: {spec}")
+        data = np.stack([np.asarray(Image.open(f)) for f in files], axis=0)
+        return data.transpose(3, 0, 1, 2) if data.ndim == 4 else data
     if path.name.lower().endswith((".nii", ".nii.gz")):
         from .utils.niftilite import read_nifti
         return read_nifti(str(path))

@@ -220,3 +220,19 @@ def test_nifti_volumes_without_nibabel(tmp_path, dtype, suffix):
     (tmp_path / "bad.nii").write_bytes(b"\x00" * 400)
     with pytest.raises(ValueError, match="not a NIfTI-1"):
         read_nifti(str(tmp_path / "bad.nii"))
+
+
+def test_png_slice_stack(tmp_path):
+    import numpy as np
+    from PIL import Image
+    vol = (np.random.default_rng(2).random((4, 9, 11)) * 255).astype(np.uint8)
+    for z in range(4):
+        Image.fromarray(vol[z]).save(tmp_path / f"s_{z:03d}.png")
+    got = read_volume(str(tmp_path / "s_*.png"))
+    assert got.dtype == np.uint8 and np.array_equal(got, vol)
+    rgb = (np.random.default_rng(3).random((2, 5, 6, 3)) * 255).astype(np.uint8)
+    for z in range(2):
+        Image.fromarray(rgb[z]).save(tmp_path / f"c_{z}.png")
+    assert np.array_equal(read_volume(str(tmp_path / "c_*.png")), rgb.transpose(3, 0, 1, 2))
+    with pytest.raises(ValueError, match="No files found"):
+        read_volume(str(tmp_path / "none_*.png"))
