@@ -236,3 +236,22 @@ def test_png_slice_stack(tmp_path):
     assert np.array_equal(read_volume(str(tmp_path / "c_*.png")), rgb.transpose(3, 0, 1, 2))
     with pytest.raises(ValueError, match="No files found"):
         read_volume(str(tmp_path / "none_*.png"))
+
+
+def test_zarr_v2_volume(tmp_path):
+    import json
+    import zlib
+    import numpy as np
+    vol = (np.random.default_rng(4).random((5, 6, 7)) * 1000).astype(np.uint16)
+    root = tmp_path / "v.zarr" / "img"
+    root.mkdir(parents=True)
+    (root / ".zarray").write_text(json.dumps({"zarr_format": 2, "shape": [5, 6, 7], "chunks": [3, 4, 7], "dtype": "<u2", "order": "C",
+                                              "compressor": {"id": "zlib", "level": 1}, "fill_value": 0, "filters": None}))
+    for iz in range(2):
+        for iy in range(2):
+            block = np.zeros((3, 4, 7), np.uint16)
+            sub = vol[iz * 3:(iz + 1) * 3, iy * 4:(iy + 1) * 4]
+            block[:sub.shape[0], :sub.shape[1]] = sub
+            (root / f"{iz}.{iy}.0").write_bytes(zlib.compress(block.tobytes()))
+    assert np.array_equal(read_volume(str(tmp_path / "v.zarr" / "img")), vol)
+    assert np.array_equal(read_volume(str(tmp_path / "v.zarr")), vol)            # first array of the group
