@@ -22,6 +22,13 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 
 
+# per-file extra flags (packed-fp32 VALU results were observed corrupted when kernels of two HIP
+# streams share a SIMD, so the compiler's SLP vectoriser -- the only source of v_pk_*_f32 in compiler-generated code -- is off)
+_NO_SLP = os.environ.get("PYTC_NO_SLP_FILES", "dwconv_kernels.hip,train_kernels.hip,rsunet_train_kernels.hip,"
+                         "conv3d_strided_kernels.hip,loss_optim_kernels.hip")
+EXTRA_FLAGS = {p.name: ["-fno-slp-vectorize"] for p in Path(__file__).resolve().parent.glob("*.hip")
+               if _NO_SLP == "all" or p.name in _NO_SLP.split(",")}
+
 NO_SPILL_KERNELS = {"dwconv_kernels.hip": ("dwconv3d_k3_march_kernel", "dw_wgrad_march_kernel")}
 
 
@@ -41,6 +48,32 @@ def _check_no_spills(fname: str, remarks: str, patterns) -> None:
                                "must be spill-free (lower the occupancy hint of that instantiation)")
 
 
+def _check_packed_fp32_selects(obj: Path) -> None:
+    """Disassemble the gfx950 code object inside `obj` and fail on a packed-fp32 VALU instruction whose LOW lane selects a
+    high source dword (`v_pk_{fma,mul,add}_f32 ... op_sel:[..1..]`).  hipcc's SLP vectoriser emits that form when it packs two
+    outputs that share a scalar operand; the one kernel of this library that contained it (dwconv3d_xblock_kernel) returned
+    wrong values in single quarter-waves whenever an MFMA kernel of another HIP stream shared the GPU, and is exact without
+    it (tools/exp_r03_aggressor.py, profiles/r03_stream_pipeline.txt).  Files that trip this check go on the no-SLP list."""
+    import re
+    objdump = Path(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")).resolve().parent.parent / "lib" / "llvm" / "bin" / "llvm-objdump"
+    if not objdump.exists():
+        objdump = Path("/opt/rocm/lib/llvm/bin/llvm-objdump")
+    if not objdump.exists():
+        return
+    subprocess.run([str(objdump), "--offloading", obj.name], cwd=obj.parent, check=True, capture_output=True)
+    pat = re.compile(r"v_pk_(fma|mul|add)_f32 .*op_sel:\[")
+    try:
+        for co in obj.parent.glob(obj.name + ".*gfx950*"):
+            dis = subprocess.run([str(objdump), "-d", str(co)], check=True, capture_output=True, text=True).stdout
+            hits = [ln.strip() for ln in dis.splitlines() if pat.search(ln)]
+            if hits:
+                raise RuntimeError(f"{obj.name}: {len(hits)} packed-fp32 instructions with a low-lane high-dword select, e.g. "
+                                   f"`{hits[0]}`; add the source to PYTC_NO_SLP_FILES / EXTRA_FLAGS in csrc/build.py")
+    finally:
+        for extra in obj.parent.glob(obj.name + ".*"):
+            extra.unlink()
+
+
 def _sources():
     return sorted(CSRC.glob("*.hip"))
 
@@ -51,6 +84,7 @@ def _digest() -> str:
         h.update(p.name.encode())
         h.update(p.read_bytes())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -67,7 +101,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
     def compile_one(src: Path) -> Path:
         obj = obj_dir / (src.stem + ".o")
-        cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         if src.name in NO_SPILL_KERNELS:
@@ -78,6 +112,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
             _check_no_spills(src.name, out, NO_SPILL_KERNELS[src.name])
         else:
             subprocess.run(cmd, check=True)
+        _check_packed_fp32_selects(obj)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:

@@ -335,6 +335,16 @@ def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, de
         logger.info("inference.chunking.roi %s: %d of %d chunks kept", roi, len(chunks), n_before)
         if not chunks:
             raise ValueError(f"inference.chunking.roi {roi} does not intersect the volume")
+    if pc_out:
+        # every chunk is written as whole storage chunks: an ROI that clips a chunk off that grid would only fail in
+        # write_czyx AFTER the chunk's prediction has been computed -- refuse it here
+        cz = tuple(reversed(pc_chunk_xyz))
+        for c in chunks:
+            for a in range(3):
+                if c.start[a] % cz[a] or (c.stop[a] % cz[a] and c.stop[a] != vol_shape[a]):
+                    raise ValueError(f"inference.chunking.precomputed: chunk {c.key} [{tuple(c.start)}, {tuple(c.stop)}) is not aligned "
+                                     f"to the storage chunks {tuple(cz)} (zyx)" + (" -- align inference.chunking.roi to them"
+                                                                                 if roi is not None else ""))
     cdir = _chunks_dir(output_path)
     cdir.mkdir(parents=True, exist_ok=True)
     rank, world = _rank_world()

@@ -128,25 +128,35 @@ def open_precomputed_layer(layer_dir, *, volume_size_xyz, num_channels: int, dat
     info_path = layer_dir / "info"
     if str(data_type) not in _DTYPES:
         raise ValueError(f"precomputed layers store one of {sorted(_DTYPES)}, got {data_type!r}")
+    res = [int(v) for v in resolution_xyz]
+    info = {"@type": "neuroglancer_multiscale_volume", "type": "image", "data_type": str(data_type),
+            "num_channels": int(num_channels),
+            "scales": [{"key": "_".join(str(v) for v in res), "size": [int(v) for v in volume_size_xyz],
+                        "resolution": res, "voxel_offset": [0, 0, 0],
+                        "chunk_sizes": [[int(v) for v in chunk_size_xyz]], "encoding": "raw"}]}
     if not info_path.exists():
         lock = layer_dir / ".info.lock"
+        try:
+            # a lock older than the wait below belongs to a run that died between taking it and committing `info`
+            if time.time() - lock.stat().st_mtime > 120.0:
+                lock.unlink()
+        except OSError:
+            pass
         try:
             fd = os.open(str(lock), os.O_CREAT | os.O_EXCL | os.O_WRONLY)
         except FileExistsError:
             fd = None
         if fd is not None:
             try:
-                res = [int(v) for v in resolution_xyz]
-                info = {"@type": "neuroglancer_multiscale_volume", "type": "image", "data_type": str(data_type),
-                        "num_channels": int(num_channels),
-                        "scales": [{"key": "_".join(str(v) for v in res), "size": [int(v) for v in volume_size_xyz],
-                                    "resolution": res, "voxel_offset": [0, 0, 0],
-                                    "chunk_sizes": [[int(v) for v in chunk_size_xyz]], "encoding": "raw"}]}
                 tmp = layer_dir / f".info.tmp{os.getpid()}"
                 tmp.write_text(json.dumps(info))
                 os.replace(tmp, info_path)
             finally:
                 os.close(fd)
+                try:
+                    lock.unlink()           # the lock only guards the creation of `info`
+                except OSError:
+                    pass
         else:
             for _ in range(600):            # ~60 s; the writer only has one small file to commit
                 if info_path.exists():
@@ -154,4 +164,15 @@ def open_precomputed_layer(layer_dir, *, volume_size_xyz, num_channels: int, dat
                 time.sleep(0.1)
             if not info_path.exists():
                 raise RuntimeError(f"Timed out waiting for precomputed info at {info_path}")
+    # an existing layer must describe THIS run: chunks of another volume size / dtype / channel count / chunking would be
+    # written mis-shaped or mis-typed into it
+    have = json.loads(info_path.read_text())
+    hs, ws = (have.get("scales") or [{}])[0], info["scales"][0]
+    diffs = [f"{k}: layer has {a!r}, this run needs {b!r}" for k, a, b in
+             [("data_type", have.get("data_type"), info["data_type"]), ("num_channels", have.get("num_channels"), info["num_channels"]),
+              ("size", hs.get("size"), ws["size"]), ("chunk_sizes", hs.get("chunk_sizes"), ws["chunk_sizes"]),
+              ("encoding", hs.get("encoding"), ws["encoding"])] if a != b]
+    if diffs:
+        raise ValueError(f"precomputed layer {layer_dir} was created with different parameters ({'; '.join(diffs)}); "
+                         "write to a fresh directory or remove the old layer")
     return PrecomputedLayer(layer_dir)

@@ -12,6 +12,7 @@ Planner helpers (integers / tiny tables) are plain host code.
 from __future__ import annotations
 
 import logging
+import os
 from collections.abc import Mapping
 from typing import Callable, Optional, Sequence, Tuple, Union
 
@@ -352,6 +353,9 @@ class EagerSlidingWindowEngine:
         self.output_device = output_device
         self.progress = bool(progress)
         self._axis_cache = {}
+        self._stream_cache = {}
+        # HIP streams the window batches are spread over (1 = the caller's stream only); results do not depend on it
+        self.pipeline_streams = int(os.environ.get("PYTC_SW_STREAMS", "2"))
         self.last_stats = {}
 
     def _axis_vectors(self, device):
@@ -442,11 +446,46 @@ class EagerSlidingWindowEngine:
 
         blend(probe, starts[:1])
         rest = starts[1:]
-        for b0 in range(0, len(rest), self.sw_batch_size):
-            chunk = rest[b0:b0 + self.sw_batch_size]
-            blend(run(chunk), chunk)
-        self.last_stats = {"windows": len(starts), "roi": roi, "image_size": image_size}
+        chunks = [rest[b0:b0 + self.sw_batch_size] for b0 in range(0, len(rest), self.sw_batch_size)]
+        lanes = self._lanes(dev, len(chunks))
+        if not lanes:
+            for chunk in chunks:
+                blend(run(chunk), chunk)
+        else:
+            # Window batches k, k+1, ... travel on `pipeline_streams` HIP streams: the deep levels of one batch (10-40
+            # workgroups per launch, latency bound) run under the HBM-bound level-0 launches of its neighbours.  The
+            # accumulators see the batches in window order all the same -- blend k waits for the event recorded after
+            # blend k-1 -- so the result is bit-identical to the single-stream pass (reference window.py:648-675).
+            main = torch.cuda.current_stream(dev)
+            for s in lanes:
+                s.wait_stream(main)
+            order_ev = None
+            for i, chunk in enumerate(chunks):
+                s = lanes[i % len(lanes)]
+                with torch.cuda.stream(s):
+                    pred = run(chunk)
+                    if order_ev is not None:
+                        s.wait_event(order_ev)
+                    blend(pred, chunk)
+                    order_ev = torch.cuda.Event()
+                    order_ev.record(s)
+                del pred
+            for s in lanes:
+                main.wait_stream(s)
+        self.last_stats = {"windows": len(starts), "roi": roi, "image_size": image_size, "streams": max(1, len(lanes))}
         return value, weight
+
+    def _lanes(self, dev, n_chunks: int):
+        """Side streams of the window pipeline ([] = everything on the caller's stream)."""
+        n = min(int(self.pipeline_streams), n_chunks)
+        if n < 2 or ops.PROFILER.enabled or torch.cuda.is_current_stream_capturing():
+            return []
+        key = (str(dev), n)
+        hit = self._stream_cache.get(key)
+        if hit is None:
+            hit = [torch.cuda.Stream(device=dev) for _ in range(n)]
+            self._stream_cache[key] = hit
+        return hit
 
     def shifted_weight(self, orig_size, shift, device) -> torch.Tensor:
         """Weight accumulator of the window grid restricted, per window, to the box a window displaced by `shift`

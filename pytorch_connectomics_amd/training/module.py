@@ -377,10 +377,15 @@ class ConnectomicsModule(nn.Module):
                                     "pred_slice": get("pred_slice"),
                                     "target_slice": get("target_slice"), "pos_weight": get("pos_weight"),
                                     "kwargs": dict(get("kwargs", None) or {})})
-        # adaptive loss balancing (training/losses/balancing.py): a trainable sub-module, every loss entry is one task
-        from .balancing import build_loss_weighter
-        self.loss_weighter = build_loss_weighter(cfg, len(self.loss_terms), self.model)
-        self.fused_loss = bool(getattr(loss_cfg, "fused", True)) and self.loss_weighter is None
+        # adaptive loss balancing (uncertainty / GradNorm, reference training/losses/balancing.py) is outside the hot path this
+        # package replaces: static term weights only, anything else is refused up front
+        lb = getattr(loss_cfg, "loss_balancing", None)
+        strategy = (lb.get("strategy") if isinstance(lb, dict) else getattr(lb, "strategy", None)) if lb is not None else \
+            getattr(loss_cfg, "strategy", None)
+        if strategy not in (None, "", "none", "static", "fixed"):
+            raise NotImplementedError(f"model.loss.loss_balancing.strategy={strategy!r}: adaptive loss balancing is not part of "
+                                      "pytorch_connectomics_amd (static loss weights only)")
+        self.fused_loss = bool(getattr(loss_cfg, "fused", True))
         # every prediction is clamped before its loss, at every scale (orchestrator.py:95-96,574; schema/model.py:50-51)
         self.clamp_min = float(getattr(loss_cfg, "deep_supervision_clamp_min", -20.0))
         self.clamp_max = float(getattr(loss_cfg, "deep_supervision_clamp_max", 20.0))
@@ -446,7 +451,6 @@ class ConnectomicsModule(nn.Module):
             if res is not None:
                 return res
         total, parts = 0.0, {}
-        tasks, names = [], []
         for i, t in terms:
             p, y = pred, target
             if t["pred_slice"] is not None:
@@ -457,17 +461,7 @@ class ConnectomicsModule(nn.Module):
             if not torch.isfinite(v):
                 raise FloatingPointError(f"loss term {t['fn']} is not finite")
             parts[f"loss_{i}_{t['fn']}"] = v.detach()
-            if self.loss_weighter is not None:
-                tasks.append(t["weight"] * v)
-                names.append(f"loss_{i}_{t['fn']}")
-            else:
-                total = total + t["weight"] * v
-        if self.loss_weighter is not None and tasks:
-            # task losses = raw value x static weight; the weighter returns the scalar to back-propagate (orchestrator.py:110-127)
-            total, wts, logs = self.loss_weighter.combine(tasks, names, "train" if self.training else "val")
-            for n, w in zip(names, wts):
-                parts[f"{n}_balance_weight"] = w
-            parts.update(logs)
+            total = total + t["weight"] * v
         return total, parts
 
     def _head_of(self, term_index: int, term, heads) -> str:
@@ -541,16 +535,12 @@ class ConnectomicsModule(nn.Module):
         return {"val_loss_total": loss, "val_jaccard": (p & t).sum().float() / union}
 
     def configure_optimizers(self):
-        # with an adaptive loss weighter the optimizer takes the whole module (its task weights train with the network), as the
-        # reference does (lightning/model.py:1160-1162)
-        opt = build_optimizer(self.cfg, self if self.loss_weighter is not None else self.model)
+        opt = build_optimizer(self.cfg, self.model)
         return opt, build_lr_scheduler(self.cfg, opt)
 
     # ---- checkpoints in the Lightning layout ------------------------------------------------------
     def checkpoint_dict(self, optimizer=None) -> Dict[str, Any]:
         sd = {"model." + k: v.detach().cpu() for k, v in self.model.state_dict().items()}
-        if self.loss_weighter is not None:      # a sub-module of the LightningModule in the reference: same key prefix
-            sd.update({"loss_weighter." + k: v.detach().cpu() for k, v in self.loss_weighter.state_dict().items() if v is not None})
         ck = {"state_dict": sd,
               "global_step": self.global_step,
               "pytc_metadata": {"format_version": 1, "model_arch": str(getattr(self.cfg.model.arch, "type", ""))}}
@@ -579,12 +569,6 @@ class ConnectomicsModule(nn.Module):
         bad_unexpected = [k for k in unexpected if not any(f".out_{i}." in "." + k for i in (1, 2, 3, 4))]
         if missing or bad_unexpected:
             raise RuntimeError(f"checkpoint does not match the model: missing {missing[:5]}, unexpected {bad_unexpected[:5]}")
-        if self.loss_weighter is not None:
-            wsd = {k[len("loss_weighter."):]: v for k, v in ck["state_dict"].items() if k.startswith("loss_weighter.")}
-            if wsd:
-                if "initial_losses" in wsd and getattr(self.loss_weighter, "initial_losses", 0) is None:
-                    self.loss_weighter.initial_losses = wsd["initial_losses"].clone()     # a None buffer cannot be load_state_dict'ed
-                self.loss_weighter.load_state_dict({k: v for k, v in wsd.items() if k != "initial_losses"}, strict=False)
         self.global_step = int(ck.get("global_step", 0))
         self.current_epoch = int(ck.get("epoch", 0))
         self._resume = {k: ck[k] for k in ("optimizer_states", "lr_schedulers", "callbacks") if k in ck}
@@ -656,13 +640,17 @@ def resolve_training_steps(cfg, *, fast_dev_run: int = 0, dataset_steps_per_epoc
         return int(fast_dev_run), int(fast_dev_run)
     per_epoch = getattr(oc, "n_steps_per_epoch", None)
     per_epoch = int(per_epoch) if per_epoch is not None else -1
+    max_steps = getattr(oc, "max_steps", None)
+    if per_epoch <= 0 and (dataset_steps_per_epoch is None or dataset_steps_per_epoch <= 0) \
+            and max_steps is not None and int(max_steps) > 0:
+        # no epoch length from either side, but a total: the run is one "epoch" of max_steps optimizer steps
+        return int(max_steps), int(max_steps)
     if per_epoch <= 0:
         if dataset_steps_per_epoch is None or dataset_steps_per_epoch <= 0:
             raise ValueError("optimization.n_steps_per_epoch is -1 / unset (auto from the dataset size) but the training source "
                              "is an endless sampler: set optimization.n_steps_per_epoch (or optimization.max_steps)")
         per_epoch = int(dataset_steps_per_epoch)
     total = per_epoch * max(1, int(getattr(oc, "max_epochs", 1) or 1))
-    max_steps = getattr(oc, "max_steps", None)
     if max_steps is not None and int(max_steps) > 0:
         total = min(total, int(max_steps)) if getattr(oc, "max_epochs", None) else int(max_steps)
     return total, per_epoch

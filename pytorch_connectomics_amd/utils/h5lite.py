@@ -75,6 +75,9 @@ def _load():
         "pytc_h5_attr_name": (C.c_int, [i64, C.c_int, C.c_char_p, C.c_int]),
         "pytc_h5_attr_read": (C.c_int, [i64, C.c_char_p, C.POINTER(C.c_int), C.c_char_p, C.c_int, p64,
                                         C.POINTER(C.c_double)]),
+        "pytc_h5_attr_write_array": (C.c_int, [i64, C.c_char_p, C.POINTER(C.c_double), C.c_int, C.c_int]),
+        "pytc_h5_attr_read_array": (C.c_int, [i64, C.c_char_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int),
+                                              C.POINTER(C.c_int)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -143,8 +146,13 @@ class AttributeManager:
         elif isinstance(value, (str, bytes)):
             sval = value if isinstance(value, bytes) else value.encode("utf-8")
             rc = lib.pytc_h5_attr_write(self._o._id, k, 0, sval, 0, 0.0)
+        elif isinstance(value, (list, tuple, np.ndarray)) and np.asarray(value).dtype.kind in "iuf" and np.asarray(value).ndim == 1:
+            arr = np.asarray(value)
+            buf = (C.c_double * max(arr.size, 1))(*[float(v) for v in arr])
+            rc = lib.pytc_h5_attr_write_array(self._o._id, k, buf, int(arr.size), int(arr.dtype.kind in "iu"))
         else:
-            raise TypeError(f"h5lite attributes hold str / int / float / bool scalars, got {type(value).__name__} for {key!r}")
+            raise TypeError(f"h5lite attributes hold str / int / float / bool scalars or 1-D numeric arrays, got "
+                            f"{type(value).__name__} for {key!r}")
         if rc != 0:
             raise OSError(_err(lib))
 
@@ -164,7 +172,15 @@ class AttributeManager:
         lib = _need()
         kind, ival, dval = C.c_int(0), C.c_int64(0), C.c_double(0.0)
         sbuf = C.create_string_buffer(1 << 16)
-        if lib.pytc_h5_attr_read(self._o._id, key.encode(), C.byref(kind), sbuf, len(sbuf), C.byref(ival), C.byref(dval)) != 0:
+        rc = lib.pytc_h5_attr_read(self._o._id, key.encode(), C.byref(kind), sbuf, len(sbuf), C.byref(ival), C.byref(dval))
+        if rc == 3:     # array-valued attribute (e.g. `resolution`): numeric arrays come back as numpy arrays
+            cap = 4096
+            buf, n, is_int = (C.c_double * cap)(), C.c_int(0), C.c_int(0)
+            if lib.pytc_h5_attr_read_array(self._o._id, key.encode(), buf, cap, C.byref(n), C.byref(is_int)) != 0 or n.value > cap:
+                raise KeyError(f"{key} (array-valued attribute of an unsupported type or size)")
+            arr = np.array(buf[:max(n.value, 0)], dtype=np.float64)
+            return arr.astype(np.int64) if is_int.value else arr
+        if rc != 0:
             raise KeyError(key)
         return {0: lambda: sbuf.value.decode("utf-8", errors="replace"), 1: lambda: int(ival.value),
                 2: lambda: float(dval.value), 3: lambda: bool(ival.value)}[kind.value]()

@@ -154,3 +154,24 @@ def test_run_prediction_inference_honors_save_compression(tmp_path):
         with h5.File(out, "r") as handle:
             assert handle["main"].compression == want
             assert np.array_equal(handle["main"][...], prediction[0].numpy())
+
+
+def test_array_valued_hdf5_attributes_do_not_overrun_the_scalar_reader(tmp_path):
+    """third-party EM files carry array attributes (e.g. `resolution`); the scalar reader used to H5Aread them into
+    one int64 / double.  They now come back as numpy arrays, and `dict(attrs)` over a mix of scalar and array attributes works."""
+    from pytorch_connectomics_amd.utils import h5lite
+    if not h5lite.available():
+        pytest.skip("no libhdf5 in this image")
+    path = tmp_path / "a.h5"
+    with h5lite.File(str(path), "w") as f:
+        ds = f.create_dataset("main", data=np.zeros((2, 3), np.float32))
+        ds.attrs["resolution"] = [30, 8, 8]
+        ds.attrs["scale"] = np.array([1.5, 2.5, -3.25])
+        ds.attrs["n"] = 3
+        ds.attrs["name"] = "vol"
+        ds.attrs["flag"] = True
+    with h5lite.File(str(path), "r") as f:
+        a = dict(f["main"].attrs.items())
+    assert a["n"] == 3 and a["name"] == "vol" and a["flag"] is True
+    assert a["resolution"].dtype == np.int64 and a["resolution"].tolist() == [30, 8, 8]
+    assert a["scale"].dtype == np.float64 and a["scale"].tolist() == [1.5, 2.5, -3.25]

@@ -174,3 +174,25 @@ def test_channel_selectors_match_reference_fixture():
             if got != want:
                 bad.append((name, sel, r["num_channels"], got, want))
     assert not bad, bad[:5]
+
+
+def test_view_map_is_the_tensor_op():
+    """ViewMap (signed axis permutation) of every (flip, plane, k) triple reproduces flip -> rot90 on an asymmetric probe, and two
+    triples have equal maps exactly when they move the voxels the same way (the reference de-duplicates by a probe tensor)."""
+    from itertools import combinations
+    from pytorch_connectomics_amd.inference.tta_combinations import ViewMap
+    probe = torch.arange(2 * 3 * 5).reshape(2, 3, 5)
+    flips = [list(c) for r in range(4) for c in combinations(range(3), r)]
+    seen = {}
+    for f in flips:
+        for plane in ((0, 1), (0, 2), (1, 2), (2, 1)):
+            for k in range(4):
+                vm = ViewMap.of(3, f, plane, k)
+                want = apply_view(probe, f, plane, k, first_spatial_dim=0)
+                got = probe.permute(*vm.src)
+                rev = [a for a in range(3) if vm.rev[a]]
+                got = torch.flip(got, rev) if rev else got
+                assert torch.equal(got, want), (f, plane, k)
+                sig = (tuple(want.shape), tuple(want.reshape(-1).tolist()))
+                assert seen.setdefault(vm, sig) == sig
+    assert len(seen) == len({v for v in seen.values()}) == 32          # 48 signed permutations minus the 16 that need a 3-cycle
