@@ -95,46 +95,122 @@ def job_record(n_windows, views, vol_shape, seconds, **extra):
     return rec
 
 
-def cpu_baseline(model, threads_cap: int = 32):
-    """Oracle (CPU restatement, kind='port') timed on the host cores on ONE 112^3 window of the same workload, same
-    weights, fp32: 1 warm-up + 3 timed forwards, median (BASELINE.md section 3 prescribes 2 + 5; bounded here to ~20 s of CPU
-    work).  One fixed thread count (PyTorch's CPU depthwise conv stops scaling near 32 threads: round-1 sweep)."""
+def _median_timed(fn, warmup, timed_runs, budget_s):
+    """`warmup` untimed + up to `timed_runs` timed calls of fn (at least one), stopping early once `budget_s` of CPU work is spent."""
+    spent, times = 0.0, []
+    for i in range(warmup + timed_runs):
+        t0 = time.perf_counter()
+        fn()
+        dt = time.perf_counter() - t0
+        spent += dt
+        if i >= warmup:
+            times.append(dt)
+        if spent > budget_s and times:
+            break
+    if not times:
+        times = [dt]
+    return statistics.median(times), len(times)
+
+
+def cpu_baseline(model, budget_s: float = 60.0):
+    """Oracle (CPU restatement, kind='port') timed on the host cores, same weights, fp32, following BASELINE.md section 3 as far as
+    a bounded sample allows: a thread sweep that includes os.cpu_count() (one 112^3 window forward each), then 2 warm-up + 5 timed
+    forwards at the best thread count, median; and -- the metric is "train + infer" -- `train`: forward + backward (torch
+    autograd through the oracle) + BCE/Dice + torch.optim.AdamW on one 112^3 patch.  Each part stops early once its share of
+    `budget_s` is spent (at least one timed run); `sample` says what was actually run."""
     from oracle import mednext_oracle as MO
+    from pytorch_connectomics_amd.training.module import dice_loss_sigmoid, weighted_bce_with_logits
     st = {k: v.detach().float().cpu() for k, v in model.model.state_dict().items()}
     cores = os.cpu_count() or 1
-    threads = max(1, min(threads_cap, cores))
-    torch.set_num_threads(threads)
     kw = dict(n_channels=32, exp_r=2, kernel_size=3, block_counts=[2] * 9)
     x = torch.rand(1, 1, *ROI)
-    times = []
+    y = (torch.rand(1, 1, *ROI) > 0.85).float()
+    sweep = {}
     with torch.no_grad():
-        t0 = time.perf_counter()
-        MO.forward(st, x, **kw)
-        warm = time.perf_counter() - t0
-        reps = 3 if warm < 8 else 1
-        for _ in range(reps):
+        for threads in sorted({min(32, cores), min(64, cores), cores}):
+            torch.set_num_threads(threads)
             t0 = time.perf_counter()
             MO.forward(st, x, **kw)
-            times.append(time.perf_counter() - t0)
-    dt = statistics.median(times)
-    return {"value": ROI_VOX / dt, "unit": "voxels/s", "cores": threads, "kind": "port",
-            "sample": f"oracle MedNeXt-S fp32 forward of one 112^3 window, 1 warm-up + {len(times)} timed, median "
-                      f"{dt:.2f} s, torch CPU, {threads} threads on a {cores}-core host"}
+            sweep[threads] = ROI_VOX / (time.perf_counter() - t0)
+        best = max(sweep, key=sweep.get)
+        torch.set_num_threads(best)
+        dt, n_inf = _median_timed(lambda: MO.forward(st, x, **kw), 1, 5, 0.5 * budget_s)     # the sweep run at `best` was warm-up #1
+    params = {k: v.clone().requires_grad_(True) for k, v in st.items() if v.dtype.is_floating_point and k != "dummy_tensor"}
+    opt = torch.optim.AdamW(list(params.values()), lr=1e-3)
+
+    def train_step():
+        opt.zero_grad(set_to_none=True)
+        out = MO.forward(dict(params, dummy_tensor=st["dummy_tensor"]), x, **kw)
+        (weighted_bce_with_logits(out, y, None, None) + dice_loss_sigmoid(out, y)).backward()
+        opt.step()
+    dtt, n_tr = _median_timed(train_step, 1, 2, 0.5 * budget_s)
+    return {"value": ROI_VOX / dt, "unit": "voxels/s", "cores": best, "kind": "port", "host_cores": cores,
+            "thread_sweep_voxels_per_s": {str(k): round(v, 1) for k, v in sweep.items()},
+            "sample": f"oracle MedNeXt-S fp32 forward of one 112^3 window: thread sweep {sorted(sweep)} (one forward each), then "
+                      f"2 warm-up (incl. the sweep run) + {n_inf} timed at {best} threads, median {dt:.2f} s, torch CPU",
+            "train": {"value": ROI_VOX / dtt, "unit": "voxels/s", "cores": best, "kind": "port",
+                      "sample": f"oracle forward + autograd backward + BCE/Dice + torch.optim.AdamW on one 112^3 patch, 1 warm-up + "
+                                f"{n_tr} timed, median {dtt:.2f} s, {best} threads"}}
+
+
+MFMA_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 2:1-sparsity figure is not used)
+
+
+def _is_dense_conv(label):
+    return label.startswith(("conv3d_", "convT3d_", "conv3d_s_"))
+
+
+def roofline_entry(name, rec, traffic=None):
+    """One kernel (label or symbol) against the roofline that bounds it: dense k^3 convolutions are MFMA work (TFLOP/s against the
+    2.5 PFLOP/s dense bf16 peak), everything else on this path is HBM-bound (algorithmic GB/s against 8 TB/s)."""
+    per_launch_s = rec["ms"] / rec["launches"] / 1e3
+    if rec.get("flops") and _is_dense_conv(name):
+        ach = rec["flops"] / rec["launches"] / per_launch_s / 1e12
+        return {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "launch_us": round(per_launch_s * 1e6, 1),
+                "algorithmic_flops": int(rec["flops"] / rec["launches"]), "launches": rec["launches"]}
+    per_launch_bytes = rec["bytes"] / rec["launches"]
+    ach = per_launch_bytes / per_launch_s / 1e9
+    return {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "launch_us": round(per_launch_s * 1e6, 1),
+            "algorithmic_bytes": int(per_launch_bytes), "launches": rec["launches"]}
 
 
 def dominant(summ, n_steps, peak=HBM_PEAK_GBS, traffic_fn=None):
     name, rec = max(summ.items(), key=lambda kv: kv[1]["ms"])
-    per_launch_bytes = rec["bytes"] / rec["launches"]
-    per_launch_s = rec["ms"] / rec["launches"] / 1e3
-    achieved = per_launch_bytes / per_launch_s / 1e9
     total_ms = sum(r["ms"] for r in summ.values())
-    return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic_fn(name) if traffic_fn else None,
-            "launch_us": round(per_launch_s * 1e6, 1), "algorithmic_bytes": int(per_launch_bytes),
-            "share_of_step": round(rec["ms"] / total_ms, 3),
-            "kernels_ms_per_step": {k: round(v["ms"] / n_steps, 3) for k, v in
-                                    sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]},
-            "kernel_ms_total_per_step": round(total_ms / n_steps, 3)}
+    out = roofline_entry(name, rec, traffic_fn(name) if traffic_fn else None)
+    out.update({"share_of_step": round(rec["ms"] / total_ms, 3),
+                "kernels_ms_per_step": {k: round(v["ms"] / n_steps, 3) for k, v in
+                                        sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]},
+                "kernel_ms_total_per_step": round(total_ms / n_steps, 3)})
+    return out
+
+
+def by_symbol(summ):
+    """Per-label profiler records regrouped by device kernel family (hip_ops.PROFILER.by_symbol on an existing summary)."""
+    out = {}
+    for name, rec in summ.items():
+        d = out.setdefault(rec.get("symbol") or name.split("[")[0], {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0})
+        for k in ("launches", "ms", "bytes", "flops"):
+            d[k] += rec.get(k, 0)
+    return out
+
+
+def largest_symbols(summ, n_steps, top=3, traffic_of=None):
+    """The `top` kernel families by time, each with its own roofline entry (launch-weighted over every shape it runs at): the
+    z-march depthwise conv runs under one label per shape and would otherwise never be the 'dominant' line although it is the
+    largest rocprof symbol of the step."""
+    total_ms = sum(r["ms"] for r in summ.values())
+    rows = []
+    for sym, rec in sorted(by_symbol(summ).items(), key=lambda kv: -kv[1]["ms"])[:top]:
+        e = roofline_entry(sym, rec, traffic_of(sym) if traffic_of else None)
+        e.update({"share_of_step": round(rec["ms"] / total_ms, 3), "launches_per_step": round(rec["launches"] / n_steps, 1),
+                  "ms_per_step": round(rec["ms"] / n_steps, 3)})
+        if e.get("traffic") and e["bound"] == "hbm":
+            e["traffic_over_algorithmic"] = round(e["traffic"] / max(e["algorithmic_bytes"], 1), 3)
+        rows.append(e)
+    return rows
 
 
 def train_leg(dev, rank, world, args, barrier):
@@ -278,47 +354,61 @@ def monai_unet_leg(dev, args):
 
 
 def _kernel_key(label):
-    """rocprof kernel-name prefix of a bench label: the fused mixer of one shape (plain and epilogue variants).  Other kernels run
-    at several shapes under one name: no per-shape counter average."""
+    """rocprof kernel-name substring of a bench label or kernel family: the fused mixer of one shape (plain and epilogue variants),
+    or a whole kernel family (`dwconv3d_k3_march_kernel`, ...: launch-weighted over the shapes it runs at).  Per-shape labels of
+    kernels that run at several shapes have no counter average of their own."""
     import re
     m = re.match(r"pw_mlp_fwd\[(\d+)->(\d+)->(\d+)\]", label)
-    return f"pw_mlp_kernel<{int(m.group(1)) // 32}, {int(m.group(3)) // 16}," if m else None
+    if m:
+        return f"pw_mlp_kernel<{int(m.group(1)) // 32}, {int(m.group(3)) // 16},"
+    if "[" not in label and label.endswith("_kernel"):
+        return label
+    return None
 
 
-def pmc_traffic_bytes(label):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command (newest
-    profiles/rNN_bench_hbm_counters.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs by
-    tools/profile_bench.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if the file or the
-    kernel is missing."""
-    import csv
-    files = sorted((ROOT / "profiles").glob("r*_bench_hbm_counters.csv"))
-    key = _kernel_key(label)
-    if not files or key is None:
+def _traffic_from_table(table, key):
+    """launch-weighted (2 x FETCH_SIZE + WRITE_SIZE) bytes per launch over the rows of `table` whose kernel name contains key."""
+    if not table or key is None:
         return None
     tot = n = 0.0
-    for row in csv.DictReader(open(files[-1])):   # the plain and the epilogue variants of the shape, launch-weighted
-        if key in row["kernel"]:
-            k = float(row.get("launches") or 1)
-            tot += k * (2 * float(row["FETCH_SIZE_KB_mean"]) + float(row["WRITE_SIZE_KB_mean"])) * 1024
-            n += k
+    for kernel, (launches, fetch_kb, write_kb) in table.items():
+        if key in kernel:
+            tot += launches * (2 * fetch_kb + write_kb) * 1024
+            n += launches
     return int(tot / n) if n else None
 
 
-def live_pmc_traffic_bytes(label, timeout_s=90):
+def committed_pmc_table():
+    """kernel -> (launches, FETCH_SIZE KB mean, WRITE_SIZE KB mean) from the newest profiles/rNN_bench_hbm_counters.csv (separate
+    --pmc passes of this same command, tools/profile_bench.sh + tools/make_hbm_counters_csv.py)."""
+    import csv
+    files = sorted((ROOT / "profiles").glob("r*_bench_hbm_counters.csv"))
+    if not files:
+        return None
+    return {row["kernel"]: (float(row.get("launches") or 1), float(row["FETCH_SIZE_KB_mean"]), float(row["WRITE_SIZE_KB_mean"]))
+            for row in csv.DictReader(open(files[-1]))}
+
+
+def pmc_traffic_bytes(label):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950).  None if the file or the kernel is missing."""
+    return _traffic_from_table(committed_pmc_table(), _kernel_key(label))
+
+
+def live_pmc_table(timeout_s=90):
     """The same counters collected NOW, on this box: two child runs of this script (one whole-volume step, inference only) under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, no trace domains, as MI355X_MICROARCH.md prescribes --
-    outside the timed region.  FETCH_SIZE / WRITE_SIZE are reported in KB; FETCH_SIZE is doubled for gfx950.  None when rocprofv3 is
-    missing, a pass fails or times out, or the kernel does not show up (the caller then falls back to the committed passes)."""
+    outside the timed region.  -> kernel -> (launches, FETCH KB mean, WRITE KB mean), or None when rocprofv3 is missing or a pass
+    fails / times out (the caller then falls back to the committed passes)."""
     import csv
     import glob
     import shutil
     import subprocess
     import tempfile
-    key = _kernel_key(label)
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
-    if key is None or exe is None:
+    if exe is None:
         return None
-    means = {}
+    sums = {}
     tmp = tempfile.mkdtemp(prefix="pytc_pmc_")
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -326,25 +416,35 @@ def live_pmc_traffic_bytes(label, timeout_s=90):
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "bench", "--", sys.executable,
                    str(ROOT / "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline", "--no-train",
                    "--no-extras"]
-            env = dict(os.environ, TMPDIR="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp", PYTC_SW_STREAMS="1")      # counters per kernel: one stream, no co-running kernels
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
                 env.pop(k, None)
             r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
             if r.returncode != 0:
                 return None
-            vals = []
+            seen = False
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if row.get("Counter_Name") == counter and key in row.get("Kernel_Name", ""):
-                        vals.append(float(row["Counter_Value"]))
-            if not vals:
+                    if row.get("Counter_Name") == counter:
+                        d = sums.setdefault(row.get("Kernel_Name", ""), {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
+                        d[counter][0] += float(row["Counter_Value"])
+                        d[counter][1] += 1
+                        seen = True
+            if not seen:
                 return None
-            means[counter] = sum(vals) / len(vals)
-        return int((2 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024)
+        return {k: (max(d["FETCH_SIZE"][1], d["WRITE_SIZE"][1]), d["FETCH_SIZE"][0] / max(d["FETCH_SIZE"][1], 1),
+                    d["WRITE_SIZE"][0] / max(d["WRITE_SIZE"][1], 1)) for k, d in sums.items()}
     except Exception:      # noqa: BLE001 - a profiler hiccup must not take the bench line down
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def live_pmc_traffic_bytes(label, timeout_s=90):
+    key = _kernel_key(label)
+    if key is None:
+        return None          # nothing to collect: no child run
+    return _traffic_from_table(live_pmc_table(timeout_s), key)
 
 
 def main():
@@ -376,10 +476,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        # a rank that dies inside a collective must turn into an error on its peers, not into a hang of the whole job
+        tmo = datetime.timedelta(seconds=int(os.environ.get("PYTC_BENCH_COLLECTIVE_TIMEOUT_S", "600")))
         if share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
 
     from pytorch_connectomics_amd import hip_ops as ops
 
@@ -396,20 +499,58 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    errors = {}          # leg -> {rank: message}; a failing rank reports instead of leaving its peers inside a collective
+
+    def agree(leg, exc):
+        """Collective: every rank says whether `leg` worked for it; -> True when it worked everywhere.  Failures (with the rank
+        they happened on) go into the JSON line."""
+        msg = None if exc is None else f"{type(exc).__name__}: {exc}"
+        if world == 1:
+            if msg:
+                errors[leg] = {"0": msg}
+            return msg is None
+        msgs = [None] * world
+        torch.distributed.all_gather_object(msgs, msg)
+        bad = {str(r): m for r, m in enumerate(msgs) if m}
+        if bad:
+            errors[leg] = bad
+        return not bad
+
     def step():
         return eng(vol, model)       # the product call: probe, accumulators, all window batches, finalize, crop
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
+    exc, dt, out_shape = None, float("nan"), ()
+    try:
+        with torch.no_grad():
+            for _ in range(args.warmup):
+                step()
+    except Exception as e:     # noqa: BLE001 - reported by agree()
+        exc = e
+    headline_ok = agree("warmup", exc)
+    if headline_ok:
+        exc = None
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
-        barrier()
+        try:
+            with torch.no_grad():
+                for _ in range(args.steps):
+                    out = step()
+            torch.cuda.synchronize()
+            out_shape = tuple(out.shape)
+            del out
+        except Exception as e:     # noqa: BLE001
+            exc = e
+        headline_ok = agree("headline", exc)       # doubles as the closing barrier: every rank has finished (or failed) its steps
+        torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    out_shape = tuple(out.shape)
-    del out
+    if not headline_ok:
+        if rank == 0:
+            print(json.dumps({"metric": "voxels/s (train + sliding-window infer), MedNeXt-S 112^3 bf16", "value": None,
+                              "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "higher_is_better": True, "scaling": "weak", "errors": errors}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        raise SystemExit(1)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -430,16 +571,19 @@ def main():
                 y = model.forward_cl(x)
                 ops.blend_accumulate(y, b, value, weight, wz, wy, wx, combine=combine, floor_w=1e-5)
         summ = prof.summary()
-        roofline = dominant(summ, nprof, traffic_fn=pmc_traffic_bytes)
         del value, weight
+        table, source = committed_pmc_table(), "committed rocprofv3 --pmc passes of this command (profiles/rNN_bench_hbm_counters.csv)"
+        if world == 1 and not args.no_live_pmc:
+            live = live_pmc_table()
+            if live:
+                table, source = live, ("live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child runs of this command on this box "
+                                       "(separate passes, FETCH_SIZE x 2)")
+        traffic_of = lambda name: _traffic_from_table(table, _kernel_key(name))      # noqa: E731
+        roofline = dominant(summ, nprof, traffic_fn=traffic_of)
         if roofline is not None:
-            roofline["traffic_source"] = "committed rocprofv3 --pmc passes of this command (profiles/rNN_bench_hbm_counters.csv)"
-            if world == 1 and not args.no_live_pmc:
-                live = live_pmc_traffic_bytes(roofline["kernel"])
-                if live:
-                    roofline["traffic"] = live
-                    roofline["traffic_source"] = ("live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child runs of this command "
-                                                  "on this box (separate passes, FETCH_SIZE x 2)")
+            roofline["traffic_source"] = source
+            # the kernel families of the step by time, each with its own fraction (the largest rocprof symbol first)
+            roofline["by_symbol"] = largest_symbols(summ, nprof, top=3, traffic_of=traffic_of)
         if os.environ.get("PYTC_BENCH_VERBOSE"):
             for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
                 print(f"  {k:34s} launches/step={v['launches'] / nprof:5.1f} ms/step={v['ms'] / nprof:7.3f} "
@@ -483,29 +627,48 @@ def main():
                 model.model.compute_dtype = torch.bfloat16
         torch.cuda.empty_cache()
 
-    strong = None
-    if world > 1:
-        from pytorch_connectomics_amd.inference.slab import slab_predict_volume
-        g0 = torch.Generator(device=dev).manual_seed(7)
-        shared = torch.rand((1,) + volume, device=dev, generator=g0)   # every rank holds the planes its windows touch
-        with torch.no_grad():
-            slab_predict_volume(shared, eng, model)
-            barrier()
-            t0 = time.perf_counter()
-            slab_predict_volume(shared, eng, model)
-            barrier()
-            ds = time.perf_counter() - t0
-        t = torch.tensor([ds], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        strong = job_record(n_win, 1, volume, float(t.item()), scaling="strong",
-                            path=f"slab_predict_volume: one volume, {world} slabs, p2p halo bands (RCCL send/recv), result sharded")
-        del shared
-
     del vol
     torch.cuda.empty_cache()
+    strong = None
+    if world > 1:
+        from pytorch_connectomics_amd.inference.slab import slab_extent, slab_predict_volume
+        exc, ds = None, float("nan")
+        try:
+            # ONE volume for the whole job; a rank materialises only the planes its own windows read (its slab + halo):
+            # rows of a seeded host stream, so the overlapping planes agree between neighbours
+            ax, (lo, hi) = slab_extent(volume, eng, world, rank)
+            shp = list(volume)
+            shp[ax] = hi - lo
+            rows = torch.rand((volume[ax], 1 + 1), generator=torch.Generator().manual_seed(7))[lo:hi, 0]
+            mine = torch.rand((1,) + tuple(shp), device=dev, generator=torch.Generator(device=dev).manual_seed(1000 + lo))
+            mine = (0.5 * mine + 0.5 * rows.to(dev).view([-1 if a == ax + 1 else 1 for a in range(4)])).contiguous()
+            with torch.no_grad():
+                slab_predict_volume(mine, eng, model, full_size=volume)
+                barrier()
+                t0 = time.perf_counter()
+                slab_predict_volume(mine, eng, model, full_size=volume)
+                torch.cuda.synchronize()
+                ds = time.perf_counter() - t0
+            del mine
+        except Exception as e:     # noqa: BLE001
+            exc = e
+        if agree("strong_slab", exc):
+            t = torch.tensor([ds], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            strong = job_record(n_win, 1, volume, float(t.item()), scaling="strong",
+                                path=f"slab_predict_volume: one volume, {world} slabs (each rank holds only its slab + halo planes), "
+                                     "p2p halo bands (RCCL send/recv), result sharded")
+        torch.cuda.empty_cache()
+
     train = None
     if not args.no_train:
-        train = train_leg(dev, rank, world, args, barrier)
+        exc = None
+        try:
+            train = train_leg(dev, rank, world, args, barrier)
+        except Exception as e:     # noqa: BLE001
+            exc = e
+        if not agree("train", exc):
+            train = None
 
     rsu = unet = None
     if rank == 0 and world == 1 and not args.no_train and not args.no_extras:
@@ -529,12 +692,14 @@ def main():
             "value": value_vps, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": per_call * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "rccl_ranks": world if (world > 1 and not share) else 0, "errors": errors or None,
             "config": {"workload": "Lucchi++ sliding-window inference (configs[1]): MedNeXt-S k3, "
                                    f"{'x'.join(map(str, volume))} volume, roi 112^3, overlap 0.5, bump blending, "
                                    "sw_batch_size 8, random-init weights; step = one whole-volume "
                                    "EagerSlidingWindowEngine call (TTA off); value = window-voxels/s",
                        "volume": list(volume), "roi": list(ROI), "sw_batch_size": SW_BATCH, "windows_per_step": n_win,
-                       "sharding": "one independent volume per rank, no collective"},
+                       "sharding": "one independent volume per rank, no collective",
+                       "window_pipeline_streams": eng.last_stats.get("streams", 1)},
             "window_voxels_per_s": value_vps,
             "output_voxels_per_s": world * volume[0] * volume[1] * volume[2] * args.steps / dt,
             "ms_per_8_windows": per_call * 1e3 * SW_BATCH / n_win, "timed_region_s": dt, "output_shape": list(out_shape),

@@ -157,6 +157,11 @@ int pytc_scale_cast(const float* x, void* y, int64_t n, float scale, int target,
 int pytc_dwconv3d_stat_slots(int N, int D, int H, int W, int C, int K, int stride, int dtype,
                              int transposed);
 
+/* which kernel family pytc_dwconv3d_fwd / pytc_dwconvT3d_fwd runs for this problem (measurement bookkeeping only:
+ * bench.py groups its per-launch timings by device kernel): 0 direct, 1 K=3/5/7 gather, 2 x-block, 3 z-march,
+ * 4 transposed 2x2x2-cell, 5 transposed direct; -1 unsupported channel count */
+int pytc_dwconv3d_kernel_variant(int N, int D, int H, int W, int C, int K, int stride, int dtype, int transposed);
+
 /* Depthwise Conv3d (groups == C), kernel K^3 (3/5/7), padding K/2, stride 1 or 2, fused with the
  * per-(n,c) sum / sum-of-squares of the OUTPUT that the following GroupNorm(C,C) needs.
  * Replaces MedNeXtBlock.conv1 (+ first half of .norm) -- external nnunet_mednext, attribute
@@ -169,10 +174,17 @@ int pytc_dwconv3d_fwd(const void* x, void* y, const float* w, const float* bias,
                       int N, int D, int H, int W, int C, int K, int stride, int dtype,
                       void* stream);
 
+/* pytc_dwconv3d_fwd for operands of arbitrary magnitude -- the training backward convolves GRADIENT tensors (|v| ~ 1e-7 under a
+ * mean-reduced loss), which the packed-f16 in-plane sums of the bf16 z-march kernel cannot represent: this entry keeps fp32 taps
+ * and fp32 partial sums on every path.  Same arguments and semantics otherwise. */
+int pytc_dwconv3d_fwd_wide(const void* x, void* y, const float* w, const float* bias, float* stats, int N, int D, int H,
+                           int W, int C, int K, int stride, int dtype, void* stream);
+
 /* y = pytc_dwconv3d_fwd(x) + res (res laid out like y, no statistics): the data gradient of a residual MedNeXt block,
  * dx = conv_reversed_taps(dt) + dy, without the separate add pass.  bf16, z-march shapes only (K = 3, stride 1, C % 32 == 0,
  * D >= 8, H, W >= 16): pytc_dwconv3d_res_supported; other shapes: convolve, then pytc_add_inplace.  The sum is formed on the
- * fp32 accumulator and rounded once (the two-step form rounds the convolution first).  Replaces the autograd accumulation of the residual
+ * fp32 accumulator and rounded once (the two-step form rounds the convolution first); fp32 taps / partial sums always
+ * (gradient operands, see pytc_dwconv3d_fwd_wide).  Replaces the autograd accumulation of the residual
  * branch (MedNeXtBlock.forward: x + conv path; mednext attribute contract at mednext_models.py:104-117). */
 int pytc_dwconv3d_res_supported(int D, int H, int W, int C, int K, int stride, int dtype);
 int pytc_dwconv3d_fwd_res(const void* x, const void* res, void* y, const float* w, const float* bias, int N, int D, int H,

@@ -79,8 +79,11 @@ _SIGS = {
                                           C.c_float, C.c_void_p]),
     "pytc_ensemble_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "pytc_dwconv3d_stat_slots": (C.c_int, [C.c_int] * 9),
+    "pytc_dwconv3d_kernel_variant": (C.c_int, [C.c_int] * 9),
     "pytc_dwconv3d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8
                           + [C.c_void_p]),
+    "pytc_dwconv3d_fwd_wide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8
+                               + [C.c_void_p]),
     "pytc_dwconv3d_res_supported": (C.c_int, [C.c_int] * 7),
     "pytc_dwconv3d_fwd_res": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8
                               + [C.c_void_p]),

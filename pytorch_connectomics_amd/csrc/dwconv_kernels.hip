@@ -1254,7 +1254,7 @@ static int dispatch_vec(int vec, bool transposed, const void* x, void* y, const 
 
 static int dw_entry(bool transposed, const void* x, void* y, const float* w, const float* bias, float* stats,
                     int N, int D, int H, int W, int C, int K, int stride, int dtype, void* stream,
-                    const void* res = nullptr) {
+                    const void* res = nullptr, bool wide_range = false) {
   PYTC_REQUIRE(x && w, "dwconv3d: null pointer");
   if (res) {      // y = conv(x) + res: the z-march kernel only (stride 1, K = 3, C % 32 == 0, planes >= 16 x 16, depth >= 8)
     PYTC_REQUIRE(y && !stats, "dwconv3d_res: needs an output and takes no statistics");
@@ -1283,7 +1283,11 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
 #define PYTC_MARCH(PP, WW) \
   hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, PP, true, WW>), grid, block, 0, (hipStream_t)stream, \
                      (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t)
-    const int h16 = tuning_get("dwconv_march_h16", 1);      // packed-f16 in-plane partial sums (see the kernel header); 0: fp32 taps
+    // packed-f16 in-plane partial sums (see the kernel header); 0: fp32 taps.  f16 resolves 6e-8 at best: it is for ACTIVATIONS.
+    // Gradient operands (a mean-reduced loss over 1.4 M voxels gives |dL/dx| ~ 1e-7) sit in its subnormal range -- measured:
+    // every parameter gradient behind the last block off by 35-85 % at 112^3 (tests/test_gpu_baseline_sizes.py training gate,
+    // profiles/r03_training_gradient_gate.txt) -- so the residual / wide-range entries always take the fp32-tap kernel
+    const int h16 = (res || wide_range) ? 0 : tuning_get("dwconv_march_h16", 1);
     if (res) {
       // 8 more live registers than the plain kernel (two residual sets in flight): compiled for 3 waves / SIMD.  At the
       // 4-waves budget (128 VGPRs) hipcc spills 31 registers, and a spill of a register an asm-issued load is still
@@ -1343,9 +1347,27 @@ extern "C" int pytc_dwconv3d_stat_slots(int N, int D, int H, int W, int C, int K
   return g.slots;
 }
 
+extern "C" int pytc_dwconv3d_kernel_variant(int N, int D, int H, int W, int C, int K, int stride, int dtype, int transposed) {
+  // mirrors dw_entry / launch_dw: which kernel family a call with these arguments dispatches to
+  if (march_ok(D, H, W, C, K, stride, dtype, transposed)) return 3;
+  DwGeom g;
+  int vec;
+  if (!make_geom(g, N, D, H, W, C, K, stride, dtype, transposed, vec)) return -1;
+  if (transposed) return g.cell ? 4 : 5;
+  const size_t taps = (size_t)K * K * K * C * sizeof(float);
+  if ((K == 3 || K == 5 || K == 7) && taps <= 64 * 1024 && tuning_get("dwconv_gather", 1) != 0)
+    return (vec == 8 && stride == 1 && g.xblock) ? 2 : 1;
+  return 0;
+}
+
 extern "C" int pytc_dwconv3d_fwd(const void* x, void* y, const float* w, const float* bias, float* stats, int N,
                                  int D, int H, int W, int C, int K, int stride, int dtype, void* stream) {
   return dw_entry(false, x, y, w, bias, stats, N, D, H, W, C, K, stride, dtype, stream);
+}
+
+extern "C" int pytc_dwconv3d_fwd_wide(const void* x, void* y, const float* w, const float* bias, float* stats, int N,
+                                      int D, int H, int W, int C, int K, int stride, int dtype, void* stream) {
+  return dw_entry(false, x, y, w, bias, stats, N, D, H, W, C, K, stride, dtype, stream, nullptr, true);
 }
 
 extern "C" int pytc_dwconv3d_res_supported(int D, int H, int W, int C, int K, int stride, int dtype) {

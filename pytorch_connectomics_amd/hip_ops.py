@@ -49,16 +49,29 @@ def _stream():
 class _Profiler:
     def __init__(self):
         self.enabled = False
-        self.records = []   # (name, start_event, end_event, algorithmic_bytes)
+        self.records = []   # (name, start_event, end_event, algorithmic_bytes, flops, kernel symbol)
 
     def summary(self):
+        """label -> launches / ms / algorithmic bytes / flops / the device kernel family the label dispatches to."""
         torch.cuda.synchronize()
         out = {}
-        for name, s, e, nbytes in self.records:
-            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0})
+        for name, s, e, nbytes, flops, symbol in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0, "symbol": symbol})
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
             d["bytes"] += nbytes
+            d["flops"] += flops
+        return out
+
+    def by_symbol(self):
+        """The same records grouped by device kernel family (one rocprof symbol, or one template): a kernel that runs under
+        several per-shape labels shows up with its whole share of the step."""
+        out = {}
+        for name, rec in self.summary().items():
+            d = out.setdefault(rec["symbol"], {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0, "labels": []})
+            for k in ("launches", "ms", "bytes", "flops"):
+                d[k] += rec[k]
+            d["labels"].append(name)
         return out
 
 
@@ -78,14 +91,14 @@ class profiled:
         return False
 
 
-def _run(name: str, nbytes: int, fn, *args) -> None:
+def _run(name: str, nbytes: int, fn, *args, flops: int = 0, symbol: Optional[str] = None) -> None:
     if PROFILER.enabled:
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
         st = fn(*args)
         e.record()
-        PROFILER.records.append((name, s, e, int(nbytes)))
+        PROFILER.records.append((name, s, e, int(nbytes), int(flops), symbol or name.split("[")[0]))
     else:
         st = fn(*args)
     nat.check(st, name)
@@ -227,9 +240,11 @@ def ensemble_update(acc: torch.Tensor, x: torch.Tensor, mode: int, count: int) -
 
 # ------------------------------------------------------------------ depthwise conv + norm statistics
 def dwconv3d(x: torch.Tensor, w_taps: torch.Tensor, bias: Optional[torch.Tensor], *, K: int, stride: int = 1,
-             stats: bool = True, transposed: bool = False, y: Optional[torch.Tensor] = None, store: bool = True):
+             stats: bool = True, transposed: bool = False, y: Optional[torch.Tensor] = None, store: bool = True,
+             wide_range: bool = False):
     """x (N,D,H,W,C) -> y, stats(N,slots,2,C)|None.  w_taps fp32 (K^3, C).  store=False (transposed K = 3 only): statistics
-    only, y is returned as None (the fused up-block mixer recomputes it)."""
+    only, y is returned as None (the fused up-block mixer recomputes it).  wide_range: x is a GRADIENT (values far below the
+    f16 range): the bf16 z-march kernel keeps fp32 partial sums (pytc_dwconv3d_fwd_wide)."""
     _dev(x, "x"); _dev(w_taps, "w_taps")
     N, D, H, W, Cc = x.shape
     dt = dtype_code(x.dtype)
@@ -255,9 +270,17 @@ def dwconv3d(x: torch.Tensor, w_taps: torch.Tensor, bias: Optional[torch.Tensor]
         _run(f"dwconvT3d_fwd[{tag}]" if store else f"dwconvT3d_stats[{tag}]", _nbytes(x, y), nat.lib().pytc_dwconvT3d_fwd, _p(x), _p(y), _p(w_taps), _p(bias),
              _p(st), N, D, H, W, Cc, K, dt, _stream())
     else:
-        _run(f"dwconv3d_fwd[{tag}]", _nbytes(x, y), nat.lib().pytc_dwconv3d_fwd, _p(x), _p(y), _p(w_taps), _p(bias),
-             _p(st), N, D, H, W, Cc, K, stride, dt, _stream())
+        sym = None
+        if PROFILER.enabled:
+            sym = _DW_VARIANTS.get(nat.lib().pytc_dwconv3d_kernel_variant(N, D, H, W, Cc, K, stride, dt, 0))
+        fn = nat.lib().pytc_dwconv3d_fwd_wide if wide_range else nat.lib().pytc_dwconv3d_fwd
+        _run(f"dwconv3d_fwd[{tag}]", _nbytes(x, y), fn, _p(x), _p(y), _p(w_taps), _p(bias),
+             _p(st), N, D, H, W, Cc, K, stride, dt, _stream(), symbol=sym)
     return y, st
+
+
+_DW_VARIANTS = {0: "dwconv3d_direct_kernel", 1: "dwconv3d_k3_gather_kernel", 2: "dwconv3d_xblock_kernel",
+                3: "dwconv3d_k3_march_kernel", 4: "dwconvT3d_k3_cell_kernel", 5: "dwconvT3d_kernel"}
 
 
 def dwconv3d_res_supported(x: torch.Tensor, K: int, stride: int = 1) -> bool:
@@ -274,7 +297,7 @@ def dwconv3d_res(x: torch.Tensor, w_taps: torch.Tensor, res: torch.Tensor, *, K:
     N, D, H, W, Cc = x.shape
     y = torch.empty_like(x)
     _run(f"dwconv3d_res[C{Cc}_k{K}]", _nbytes(x, y, res), nat.lib().pytc_dwconv3d_fwd_res, _p(x), _p(res), _p(y), _p(w_taps), None,
-         N, D, H, W, Cc, K, 1, dtype_code(x.dtype), _stream())
+         N, D, H, W, Cc, K, 1, dtype_code(x.dtype), _stream(), symbol="dwconv3d_k3_march_kernel")
     return y
 
 
@@ -766,7 +789,8 @@ def conv3d(x: torch.Tensor, w_packed: torch.Tensor, *, c_out: int, kernel, bias:
     a.act_in, a.act_param = int(act_in), float(act_param)
     a.res_mode = nat.RES_ADD if res is not None else nat.RES_NONE
     a.dtype = dtype_code(x.dtype)
-    _run(f"conv3d_fwd[{ci}->{c_out},k{a.kd}{a.kh}{a.kw}]", _nbytes(x, y), nat.lib().pytc_conv3d_fwd, C.byref(a), _stream())
+    _run(f"conv3d_fwd[{ci}->{c_out},k{a.kd}{a.kh}{a.kw}]", _nbytes(x, y), nat.lib().pytc_conv3d_fwd, C.byref(a), _stream(),
+         flops=2 * N * D * H * W * ci * c_out * a.kd * a.kh * a.kw)
     return y
 
 
@@ -852,7 +876,7 @@ def conv3d_wgrad(a: torch.Tensor, dy: torch.Tensor, kernel) -> torch.Tensor:
     ws = torch.empty((n_ws,), dtype=torch.float32, device=a.device)
     dW = torch.empty((taps, co, ci), dtype=torch.float32, device=a.device)
     _run(f"conv3d_wgrad[{ci}->{co},k{kd}{kh}{kw}]", taps * _nbytes(a, dy), nat.lib().pytc_conv3d_wgrad, _p(a), _p(dy), _p(dW),
-         _p(ws), N, D, H, W, ci, co, k3, dtype_code(a.dtype), _stream())
+         _p(ws), N, D, H, W, ci, co, k3, dtype_code(a.dtype), _stream(), flops=2 * N * D * H * W * ci * co * taps)
     return dW.view(kd, kh, kw, co, ci).permute(3, 4, 0, 1, 2).contiguous()
 
 
@@ -1108,7 +1132,9 @@ def conv3d_strided(x: torch.Tensor, w_packed: torch.Tensor, *, c_out: int, kerne
     a.dtype = dtype_code(x.dtype)
     tag = "convT3d" if transposed else "conv3d_s"
     _run(f"{tag}_fwd[{ci}->{c_out},k{a.kd}{a.kh}{a.kw}]", _nbytes(x, y), nat.lib().pytc_conv3d_strided_fwd, C.byref(a),
-         _i3((Di, Hi, Wi)), _i3(stride), _i3(pad), 1 if transposed else 0, _stream())
+         _i3((Di, Hi, Wi)), _i3(stride), _i3(pad), 1 if transposed else 0, _stream(),
+         # useful MACs: a transposed stride-2 conv reaches an output through (3/2)^3 taps on average, a strided one through all
+         flops=int(2 * N * Do * Ho * Wo * ci * c_out * a.kd * a.kh * a.kw * (0.125 if transposed else 1.0)))
     return y
 
 
@@ -1141,5 +1167,6 @@ def conv3d_wgrad_strided(big: torch.Tensor, small: torch.Tensor, kernel, stride,
     dW = torch.empty((taps, co, ck), dtype=torch.float32, device=big.device)
     _run(f"conv3d_wgrad_strided[{ck}x{co},k{kd}{kh}{kw}]", taps * _nbytes(big, small), nat.lib().pytc_conv3d_wgrad_strided,
          _p(big), _p(small), _p(dW), _p(ws), N, _i3(big.shape[1:4]), _i3(small.shape[1:4]), ck, co, _i3((kd, kh, kw)),
-         _i3(stride), _i3(pad), dtype_code(big.dtype), _stream())
+         _i3(stride), _i3(pad), dtype_code(big.dtype), _stream(),
+         flops=2 * N * int(small.shape[1]) * int(small.shape[2]) * int(small.shape[3]) * ck * co * taps)
     return dW.view(kd, kh, kw, co, ck).permute(3, 4, 0, 1, 2).contiguous()

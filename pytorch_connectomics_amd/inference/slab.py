@@ -146,24 +146,44 @@ def slab_predict(plan: SlabPlan, rank: int, accumulate: Callable[[List[Tuple[int
     return finalize(cut(value, B0 - L, B1 - L, 1).contiguous(), cut(weight, B0 - L, B1 - L, 0).contiguous())
 
 
+def slab_extent(full_size: Sequence[int], engine, world: int, rank: int) -> Tuple[int, Tuple[int, int]]:
+    """(axis, (L, H)): the planes of a `full_size` volume that rank's windows read -- what a rank has to hold in HBM when the
+    volume is handed to slab_predict_volume as per-rank extents (`full_size=`); H is clipped to the stored size."""
+    orig = tuple(int(v) for v in full_size)
+    image_size, starts = engine.plan(orig)
+    plan = plan_slabs(image_size, engine.roi_size, starts, world)
+    L, H = plan.extent[rank]
+    return plan.axis, (L, min(H, orig[plan.axis]))
+
+
 @torch.no_grad()
-def slab_predict_volume(vol: torch.Tensor, engine, network, *, group=None, gather: bool = False) -> Optional[torch.Tensor]:
-    """Device path: `vol` (C, Z, Y, X) fp32 on this rank's GPU (every rank holds, or can read, the planes its windows
-    touch), `engine` an EagerSlidingWindowEngine.  Returns this rank's slab (C_out, B1-B0, Y, X) cropped to the original
-    size, or with gather=True the full volume on every rank (all_gather of the slabs)."""
+def slab_predict_volume(vol: torch.Tensor, engine, network, *, group=None, gather: bool = False,
+                        full_size: Optional[Sequence[int]] = None) -> Optional[torch.Tensor]:
+    """Device path: `vol` (C, Z, Y, X) fp32 on this rank's GPU, `engine` an EagerSlidingWindowEngine.  Either every rank
+    passes the whole volume, or -- with `full_size` = the (Z, Y, X) size of the whole volume -- only the planes its own
+    windows touch (`slab_extent`): nothing outside a rank's extent is ever read.  Returns this rank's slab (C_out, B1-B0, Y, X)
+    cropped to the original size, or with gather=True the full volume on every rank (all_gather of the slabs)."""
     from .. import _native as nat
     from .. import hip_ops as ops
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    orig = tuple(int(v) for v in vol.shape[1:])
+    orig = tuple(int(v) for v in (full_size if full_size is not None else vol.shape[1:]))
     image_size, starts = engine.plan(orig)
     plan = plan_slabs(image_size, engine.roi_size, starts, world)
 
     ax = plan.axis
+    held_from = 0
+    if full_size is not None:
+        held_from, held_to = plan.extent[rank][0], min(plan.extent[rank][1], orig[ax])
+        want = list(orig)
+        want[ax] = max(0, held_to - held_from)
+        if [int(v) for v in vol.shape[1:]] != want:
+            raise ValueError(f"slab_predict_volume(full_size={orig}): rank {rank} must pass planes [{held_from}, {held_to}) along "
+                             f"axis {ax}, i.e. spatial shape {tuple(want)}; got {tuple(vol.shape[1:])}")
 
     def accumulate(windows, ext):
         L, H = ext
-        sub = vol.narrow(ax + 1, L, min(H, orig[ax]) - L).contiguous()
+        sub = vol.narrow(ax + 1, L - held_from, min(H, orig[ax]) - L).contiguous()
         shifted = [tuple(c - L if a == ax else c for a, c in enumerate(w)) for w in windows]
         value, weight = engine.accumulate(sub, network, starts=shifted)
         # the engine grows its accumulators to at least one window; keep exactly the planes of the extent
@@ -220,4 +240,4 @@ def gather_slabs(slab: Optional[torch.Tensor], plan: SlabPlan, orig: Sequence[in
     return torch.cat([p.narrow(ax + 1, 0, w) for p, w in zip(parts, widths) if w > 0], dim=ax + 1)
 
 
-__all__ = ["SlabPlan", "plan_slabs", "exchange_schedule", "slab_predict", "slab_predict_volume", "gather_slabs"]
+__all__ = ["SlabPlan", "plan_slabs", "exchange_schedule", "slab_predict", "slab_predict_volume", "slab_extent", "gather_slabs"]

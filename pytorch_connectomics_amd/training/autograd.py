@@ -139,7 +139,7 @@ def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res,
         if do_res and FUSED_RESIDUAL_DGRAD and ops.dwconv3d_res_supported(gt, K, 1):
             dx = ops.dwconv3d_res(gt, flipped, dy, K=K)        # dx = conv_reversed(dt) + dy in the conv kernel's epilogue
         else:
-            dx, _ = ops.dwconv3d(gt, flipped, None, K=K, stride=1, stats=False)
+            dx, _ = ops.dwconv3d(gt, flipped, None, K=K, stride=1, stats=False, wide_range=True)
             if do_res:
                 ops.add_(dx, dy)
     elif kind == "down":
@@ -155,7 +155,7 @@ def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res,
         dtc = dtp[:, 1:, 1:, 1:, :].contiguous()                # compact (2D-1)^3 grid of the transposed conv
         dW1, _ = ops.dw_wgrad(x, dtc, K=K, stride=2, want_bias=False, defer=dr)
         db1 = ops.channel_stats(dtc).sum(1)[:, 0].sum(0)
-        dx, _ = ops.dwconv3d(dtc, taps, None, K=K, stride=2, stats=False)
+        dx, _ = ops.dwconv3d(dtc, taps, None, K=K, stride=2, stats=False, wide_range=True)
         if has_res:
             drl = dy[:, 1::2, 1::2, 1::2, :].contiguous()       # positions fed by the transposed 1x1 conv
             dwres_m, _ = ops.pw_wgrad(x, drl, N=N, rows_per_sample=D * H * W, c_in=C, c_out=c_out, want_bias=False, defer=dr)

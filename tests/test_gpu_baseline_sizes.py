@@ -68,6 +68,25 @@ def _build_s(out_channels, heads=None, primary=None, size="S"):
     return model
 
 
+def _autocast(fn):
+    """The oracle under torch.autocast('cpu', bfloat16): what the reference's `precision: bf16-mixed` computes
+    (/root/reference/connectomics/training/lightning/trainer.py:216-223,320 hands Lightning that precision; inference reuses the
+    trainer).  Its distance from the fp32 oracle is the reference's OWN bf16 noise: the yard-stick the HIP bf16 path is held to."""
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        return fn().float()
+
+
+def _bf16_gate(key, m16, mac, *, slack=1.5):
+    """HIP-bf16 vs fp32 oracle (m16) against autocast-oracle vs fp32 oracle (mac): max and mean |dP| within `slack` x the
+    reference's own bf16 error, label flips no more frequent than the reference's."""
+    _report(key + "_autocast_oracle", autocast_max_dP=mac[0], autocast_mean_dP=mac[1], autocast_label_flip_frac=mac[2],
+            hip_over_autocast_max=m16[0] / mac[0], hip_over_autocast_mean=m16[1] / mac[1],
+            hip_over_autocast_flips=m16[2] / max(mac[2], 1e-12))
+    assert m16[0] <= slack * mac[0], f"{key}: HIP bf16 max |dP| {m16[0]:.3e} > {slack} x autocast oracle {mac[0]:.3e}"
+    assert m16[1] <= slack * mac[1], f"{key}: HIP bf16 mean |dP| {m16[1]:.3e} > {slack} x autocast oracle {mac[1]:.3e}"
+    assert m16[2] <= mac[2] * 1.0 + 1e-6, f"{key}: HIP bf16 label flips {m16[2]:.3e} > autocast oracle {mac[2]:.3e}"
+
+
 def _oracle_kw(size):
     s = MO.SIZES[size]
     return dict(n_channels=32, exp_r=s["exp_r"], kernel_size=3, block_counts=s["block_counts"])
@@ -89,6 +108,8 @@ def test_c2_bench_path_mednext_s_112_engine_vs_oracle():
     with torch.no_grad():
         ref = WO.eager_sliding_window(vol, lambda x: MO.forward(st, x, **_oracle_kw("S")), roi=(112, 112, 112),
                                       overlap=0.5, mode="bump", sw_batch_size=8)
+        ref_ac = WO.eager_sliding_window(vol, lambda x: _autocast(lambda: MO.forward(st, x, **_oracle_kw("S"))),
+                                         roi=(112, 112, 112), overlap=0.5, mode="bump", sw_batch_size=8)
         model.model.compute_dtype = torch.float32
         got32 = eng(vol.cuda(), model).cpu()
         model.model.compute_dtype = torch.bfloat16
@@ -107,6 +128,7 @@ def test_c2_bench_path_mednext_s_112_engine_vs_oracle():
     margin16 = (torch.sigmoid(ref) - 0.5).abs() > m16[0]
     assert torch.equal((got16 > 0)[margin16], (ref > 0)[margin16])
     assert torch.equal(got16, got16_again)            # the benched path is deterministic
+    _bf16_gate("C2_mednextS_112_engine_sw8", m16, _stats(ref_ac, ref))
 
 
 def test_c3_affinity_3ch_mednext_s_112_vs_oracle():
@@ -118,6 +140,7 @@ def test_c3_affinity_3ch_mednext_s_112_vs_oracle():
     x = torch.rand(2, 1, 112, 112, 112, generator=torch.Generator().manual_seed(11))
     with torch.no_grad():
         ref = MO.forward(st, x, **_oracle_kw("S"))
+        ref_ac = _autocast(lambda: MO.forward(st, x, **_oracle_kw("S")))
         xcl = x.cuda().permute(0, 2, 3, 4, 1).contiguous()
         model.model.compute_dtype = torch.float32
         got32 = model.forward_cl(xcl).permute(0, 4, 1, 2, 3).cpu()
@@ -129,6 +152,7 @@ def test_c3_affinity_3ch_mednext_s_112_vs_oracle():
             bf16_max_dP=m16[0], bf16_mean_dP=m16[1], bf16_label_flip_frac=m16[2])
     assert m32[0] < TOL_F32_PROB
     assert m16[0] < TOL_BF16_PROB and m16[1] < 4e-3
+    _bf16_gate("C3_mednextS_112_aff3", m16, _stats(ref_ac, ref))
 
 
 MITO_HEADS = {"aff_r1": {"out_channels": 3, "num_blocks": 1, "hidden_channels": 8},
@@ -158,6 +182,7 @@ def test_c4_mednext_l_three_heads_160_window_vs_oracle():
     x = torch.rand(1, 1, 160, 160, 160, generator=torch.Generator().manual_seed(13))
     with torch.no_grad():
         ref = _oracle_multihead(model, x)
+        ref_ac = _autocast(lambda: _oracle_multihead(model, x))
         model = model.cuda().eval()
         xcl = x.cuda().permute(0, 2, 3, 4, 1).contiguous()
         model.model.compute_dtype = torch.float32
@@ -170,6 +195,7 @@ def test_c4_mednext_l_three_heads_160_window_vs_oracle():
             bf16_max_dP=m16[0], bf16_mean_dP=m16[1], bf16_label_flip_frac=m16[2])
     assert m32[0] < TOL_F32_PROB
     assert m16[0] < 8e-2 and m16[1] < 8e-3          # 2.5x the depth of S: budget doubled, measured value reported
+    _bf16_gate("C4_mednextL_160_3heads", m16, _stats(ref_ac, ref))
 
 
 def _chunk_cfg(roi, chunk, halo, swb):
@@ -294,3 +320,157 @@ def test_c1_minimal_rsunet_64_vs_oracle():
             bf16_label_flip_frac=flip16)
     # bf16: measured max 4.2e-2 at one voxel (mean 2.1e-3) with random running statistics on 8-channel layers
     assert mx32 < TOL_F32_PROB and mx16 < 6e-2 and mean16 < 5e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Training half of the metric at BASELINE width: MedNeXt-S = 32 base channels, blocks [2]*9, the model
+# bench.py's `train` leg steps, against torch autograd through the CPU oracle.
+def _train_model_and_state():
+    from pytorch_connectomics_amd.models.architectures.mednext import create_mednext_v1
+    torch.manual_seed(0)
+    m = create_mednext_v1(1, 1, "S", kernel_size=3)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(5)
+        for n, p in m.named_parameters():
+            if n.endswith("norm.weight") or n.endswith("norm.bias"):
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    st = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    return m, st
+
+
+def _train_loss(out, y):
+    from pytorch_connectomics_amd.training.module import dice_loss_sigmoid, weighted_bce_with_logits
+    return weighted_bce_with_logits(out, y, None, None) + dice_loss_sigmoid(out, y)
+
+
+class _Bf16Storage:
+    """The oracle with bf16 STORAGE at the points where `precision: bf16-mixed` (torch.autocast) holds bf16 tensors: conv inputs,
+    weights and outputs, GELU outputs; GroupNorm and the loss stay fp32, master weights stay fp32.  `t.bfloat16().float()` is
+    differentiable (its backward rounds the incoming gradient to bf16 as well), so autograd through this oracle carries the
+    reference's own bf16 gradient noise while every kernel still runs in fp32.  It stands in for torch.autocast in the TRAINING
+    gate because torch 2.10's CPU autocast backward of this network at 112^3 dies with a segmentation fault
+    (gpurun_out/r03/tr.log: _engine_run_backward under autocast), while its forward -- used by the inference gates above -- works."""
+
+    def __enter__(self):
+        import types
+        r = lambda t: None if t is None else t.bfloat16().float()      # noqa: E731
+        self.saved = (MO._conv, MO._convT, MO.F)
+        conv, convT, F0 = self.saved
+        MO._conv = lambda x, w, b, **kw: r(conv(r(x), r(w), r(b), **kw))
+        MO._convT = lambda x, w, b, **kw: r(convT(r(x), r(w), r(b), **kw))
+        shim = types.SimpleNamespace(**{k: getattr(F0, k) for k in dir(F0) if not k.startswith("__")})
+        shim.gelu = lambda t: r(F0.gelu(t))
+        MO.F = shim
+        return self
+
+    def __exit__(self, *exc):
+        MO._conv, MO._convT, MO.F = self.saved
+        return False
+
+
+def _oracle_grads(st, x, y, bf16_storage=False):
+    params = {k: v.clone().requires_grad_(True) for k, v in st.items() if v.dtype.is_floating_point}
+    if bf16_storage:
+        with _Bf16Storage():
+            loss = _train_loss(MO.forward(params, x, **_oracle_kw("S")), y)
+    else:
+        loss = _train_loss(MO.forward(params, x, **_oracle_kw("S")), y)
+    loss.backward()
+    return float(loss.detach()), {k: v.grad for k, v in params.items() if v.grad is not None and k != "dummy_tensor"}
+
+
+def _grad_table(model, ref_g):
+    """`model`: an nn.Module holding .grad, or a dict name -> gradient.  per parameter: (max |d| / max |g_ref|, cosine, relative L2).  conv1.bias feeds a per-channel GroupNorm, so its exact
+    gradient is 0 and both sides hold rounding noise only: those rows are compared on an absolute floor."""
+    named = model if isinstance(model, dict) else {k: p.grad for k, p in model.named_parameters()}
+    scale_all = max(float(g.abs().max()) for g in ref_g.values())
+    rows = {}
+    for k, g in ref_g.items():
+        got = named[k]
+        assert got is not None, k
+        got = got.detach().float().cpu()
+        if k.endswith("conv1.bias"):
+            rows[k] = (float((got - g).abs().max()) / scale_all, 1.0, 0.0)
+            continue
+        rel_max = float((got - g).abs().max()) / max(float(g.abs().max()), 1e-12)
+        cos = float((got.flatten() * g.flatten()).sum() / (got.norm() * g.norm() + 1e-30))
+        rows[k] = (rel_max, cos, float((got - g).norm() / (g.norm() + 1e-30)))
+    return rows
+
+
+def test_c2_training_gradients_mednext_s_fp32_64_vs_oracle_autograd():
+    """fp32 storage, one 64^3 patch: the loss and EVERY parameter gradient of MedNeXt-S against autograd through the oracle."""
+    m, st = _train_model_and_state()
+    x = torch.rand(1, 1, 64, 64, 64, generator=torch.Generator().manual_seed(21))
+    y = (torch.rand(1, 1, 64, 64, 64, generator=torch.Generator().manual_seed(22)) > 0.85).float()
+    ref_loss, ref_g = _oracle_grads(st, x, y)
+    m = m.cuda().train()
+    m.compute_dtype = torch.float32
+    loss = _train_loss(m(x.cuda()), y.cuda())
+    loss.backward()
+    rows = _grad_table(m, ref_g)
+    worst = max(rows.items(), key=lambda kv: kv[1][0])
+    _report("C2_train_fp32_64", loss=float(loss.detach()), oracle_loss=ref_loss, worst_rel_max=worst[1][0],
+            min_cosine=min(r[1] for r in rows.values()), max_rel_l2=max(r[2] for r in rows.values()), tensors=len(rows))
+    assert abs(float(loss.detach()) - ref_loss) < 1e-4 * abs(ref_loss)
+    assert len(rows) == len([k for k in st if k != "dummy_tensor"])
+    for k, (rel_max, cos, rl2) in rows.items():
+        assert rel_max <= 2e-3, (k, rel_max)
+
+
+def test_c2_training_step_mednext_s_bf16_112_vs_oracle_autograd():
+    """bf16 storage (the benched training path), one 112^3 patch: every parameter gradient by direction and size, then three
+    product training steps (fused BCE + Dice, clip, fused AdamW) against oracle autograd + torch.optim.AdamW from the same init."""
+    from pytorch_connectomics_amd.training.fused import FusedAdamW, bce_dice_loss
+    m, st = _train_model_and_state()
+    x = torch.rand(1, 1, 112, 112, 112, generator=torch.Generator().manual_seed(23))
+    y = (torch.rand(1, 1, 112, 112, 112, generator=torch.Generator().manual_seed(24)) > 0.85).float()
+    ref_loss, ref_g = _oracle_grads(st, x, y)
+    m = m.cuda().train()
+    m.compute_dtype = torch.bfloat16
+    xc, yc = x.cuda(), y.cuda()
+    loss, _ = bce_dice_loss(m(xc), yc)
+    loss.backward()
+    rows = _grad_table(m, ref_g)
+    _, ac_g = _oracle_grads(st, x, y, bf16_storage=True)
+    ac_rows = _grad_table(ac_g, ref_g)
+    try:
+        (ROOT / "gpurun_out" / "r03").mkdir(parents=True, exist_ok=True)
+        (ROOT / "gpurun_out" / "r03" / "train_grad_table_bf16_112.json").write_text(json.dumps(
+            {k: {"hip": rows[k], "bf16_storage_oracle": ac_rows[k], "ref_norm": float(ref_g[k].norm())} for k in rows}, indent=0))
+    except OSError:
+        pass
+    _report("C2_train_bf16_112", loss=float(loss.detach()), oracle_loss=ref_loss, min_cosine=min(r[1] for r in rows.values()),
+            max_rel_l2=max(r[2] for r in rows.values()), worst_noise_row=max(r[0] for k, r in rows.items() if k.endswith("conv1.bias")),
+            bf16_oracle_min_cosine=min(r[1] for r in ac_rows.values()), bf16_oracle_max_rel_l2=max(r[2] for r in ac_rows.values()),
+            tensors=len(rows))
+    assert abs(float(loss.detach()) - ref_loss) < 2e-3 * abs(ref_loss)
+    bad = {k: (r, ac_rows[k]) for k, r in rows.items() if not k.endswith("conv1.bias") and (r[1] < 0.99 or r[2] > 5e-2)}
+    assert not bad, bad
+    # three optimizer steps on both sides
+    lr, wd, clip = 1e-3, 1e-2, 1.0
+    ref_p = {k: v.clone().requires_grad_(True) for k, v in st.items() if v.dtype.is_floating_point and k != "dummy_tensor"}
+    ref_opt = torch.optim.AdamW(list(ref_p.values()), lr=lr, weight_decay=wd)
+    opt = FusedAdamW([p for n, p in m.named_parameters() if n != "dummy_tensor"], lr=lr, weight_decay=wd, max_grad_norm=clip)
+    ref_losses, losses = [], []
+    for _ in range(3):
+        ref_opt.zero_grad(set_to_none=True)
+        full = dict(ref_p, dummy_tensor=st["dummy_tensor"])
+        rl = _train_loss(MO.forward(full, x, **_oracle_kw("S")), y)
+        rl.backward()
+        torch.nn.utils.clip_grad_norm_(list(ref_p.values()), clip)
+        ref_opt.step()
+        ref_losses.append(float(rl.detach()))
+        opt.zero_grad(set_to_none=True)
+        l, _ = bce_dice_loss(m(xc), yc)
+        l.backward()
+        opt.step()
+        losses.append(float(l.detach()))
+    with torch.no_grad():
+        ref_final = float(_train_loss(MO.forward(dict(ref_p, dummy_tensor=st["dummy_tensor"]), x, **_oracle_kw("S")), y))
+        m.eval()
+        final = float(_train_loss(m(xc).float(), yc))
+    _report("C2_train_bf16_112_3steps", final_loss=final, oracle_final_loss=ref_final, **{f"loss_{i}": v for i, v in enumerate(losses)},
+            **{f"oracle_loss_{i}": v for i, v in enumerate(ref_losses)})
+    assert ref_losses[-1] < ref_losses[0] and losses[-1] < losses[0]
+    assert abs(final - ref_final) < 1e-3, (final, ref_final)

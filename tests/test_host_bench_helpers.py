@@ -31,3 +31,28 @@ def test_dominant_kernel_record():
     assert r["kernel"] == "a" and r["unit"] == "GB/s" and r["bound"] == "hbm"
     assert abs(r["achieved"] - 4000.0) < 1e-6 and abs(r["frac"] - 0.5) < 1e-6 and r["launch_us"] == 500.0
     assert r["algorithmic_bytes"] == 2_000_000_000 and abs(r["share_of_step"] - 0.667) < 1e-3 and r["traffic"] is None
+
+
+def test_kernel_families_and_mfma_bound_entries():
+    """Round 3: the step's kernel FAMILIES get their own roofline entries (the z-march depthwise conv runs under one label per shape
+    and is the largest rocprof symbol), dense convolutions are priced against the MFMA peak, not against HBM."""
+    b = _bench()
+    summ = {"dwconv3d_fwd[C32_k3]": {"ms": 3.0, "bytes": 9e9, "launches": 6, "flops": 0, "symbol": "dwconv3d_k3_march_kernel"},
+            "dwconv3d_fwd[C64_k3]": {"ms": 1.0, "bytes": 1e9, "launches": 8, "flops": 0, "symbol": "dwconv3d_k3_march_kernel"},
+            "dwconv3d_fwd[C256_k3]": {"ms": 0.5, "bytes": 1e8, "launches": 8, "flops": 0, "symbol": "dwconv3d_xblock_kernel"},
+            "pw_mlp_fwd[32->64->32]": {"ms": 3.5, "bytes": 14e9, "launches": 8, "flops": 0, "symbol": "pw_mlp_kernel"}}
+    assert b.dominant(summ, 2)["kernel"] == "pw_mlp_fwd[32->64->32]"
+    rows = b.largest_symbols(summ, 2, top=2, traffic_of=lambda sym: 1_000_000_000 if "march" in sym else None)
+    assert [r["kernel"] for r in rows] == ["dwconv3d_k3_march_kernel", "pw_mlp_kernel"]
+    m = rows[0]
+    assert m["launches_per_step"] == 7.0 and m["ms_per_step"] == 2.0 and m["bound"] == "hbm"
+    assert abs(m["achieved"] - 10e9 / 4e-3 / 1e9) < 1e-6 and m["algorithmic_bytes"] == int(10e9 / 14)
+    assert m["traffic"] == 1_000_000_000 and abs(m["traffic_over_algorithmic"] - 1.4) < 1e-3
+    assert b._kernel_key("dwconv3d_k3_march_kernel") == "dwconv3d_k3_march_kernel" and b._kernel_key("pw_conv_fwd[32->64]") is None
+    conv = {"conv3d_fwd[64->64,k333]": {"ms": 1.0, "bytes": 1e9, "launches": 10, "flops": 2e12, "symbol": "conv3d_fwd"}}
+    r = b.dominant(conv, 1)
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["achieved"] - 2000.0) < 1e-6 and abs(r["frac"] - 0.8) < 1e-6
+    # the committed counter passes, per kernel family
+    t = b._traffic_from_table({"void pytc::dwconv3d_k3_march_kernel<x>": (10, 100.0, 50.0), "other": (5, 1.0, 1.0)}, "dwconv3d_k3_march_kernel")
+    assert t == int((2 * 100.0 + 50.0) * 1024)
