@@ -1000,6 +1000,12 @@ class DeferredReduce:
             self.keep.append(keep)
 
     def flush(self) -> None:
+        # partials / outputs may have been allocated on another stream (training/autograd.py _WgradLane): this launch, and
+        # whoever reads the outputs afterwards, use them on the current stream
+        cur = torch.cuda.current_stream()
+        for part, out, _n, _s in self.items:
+            part.record_stream(cur)
+            out.record_stream(cur)
         for b0 in range(0, len(self.items), self.MAX_ITEMS):
             chunk = self.items[b0:b0 + self.MAX_ITEMS]
             arr = (nat.ReduceItem * len(chunk))()

@@ -39,6 +39,44 @@ FUSED_RESIDUAL_DGRAD = True
 BATCHED_WEIGHT_PACKS = True
 
 
+# weight-gradient kernels of a block backward on a second HIP stream: they are off the critical path (only the optimizer reads
+# them), the data-gradient chain is what the next block waits for.  At levels >= 2 both are latency bound (10-60 workgroups per
+# launch on 256 CUs), so running them side by side is nearly free; at level 0 both are HBM bound and merely share the bandwidth.
+SIDE_STREAM_WGRAD = True
+_SIDE_STREAMS = {}
+
+
+class _WgradLane:
+    """`run(fn, *deps)`: fn's launches go to the side stream once everything enqueued on the caller's stream so far is done
+    (deps = tensors of the caller's stream fn reads: kept from being recycled under it); `join()`: the caller's stream waits for
+    the side stream.  Off (everything on the caller's stream) while per-kernel timing is on."""
+
+    def __init__(self, device):
+        self.on = bool(SIDE_STREAM_WGRAD and device.type == "cuda" and not ops.PROFILER.enabled
+                       and not torch.cuda.is_current_stream_capturing())
+        if self.on:
+            self.main = torch.cuda.current_stream(device)
+            key = (device.index, self.main.cuda_stream)
+            side = _SIDE_STREAMS.get(key)
+            if side is None:
+                side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+            self.side = side
+
+    def run(self, fn, *deps):
+        if not self.on:
+            return fn()
+        self.side.wait_stream(self.main)
+        for t in deps:
+            if t is not None:
+                t.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            return fn()
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.side)
+
+
 def _packs_of(owner):
     if not BATCHED_WEIGHT_PACKS:
         return None
@@ -124,7 +162,7 @@ class PointwiseFn(torch.autograd.Function):
                 None, None, None)
 
 
-def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res, dr):
+def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res, dr, lane=None):
     """Depthwise-conv half of a block backward, shared by BlockFn and NormVariantBlockFn: from dt (gradient of the depthwise
     output) to dx, dW1 (tap-major), db1 and the gradients of the resampling residual conv.  Slot reductions join `dr`."""
     N, D, H, W, C = x.shape
@@ -132,8 +170,9 @@ def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res,
     c_out = dy.shape[-1]
     dwres_m = None
     dwres = dbres = None
+    lane = lane or _WgradLane(torch.device("cpu"))
     if kind == "block":
-        dW1, db1 = ops.dw_wgrad(dt_.view_as(t), x, K=K, stride=1, defer=dr)
+        dW1, db1 = lane.run(lambda: ops.dw_wgrad(dt_.view_as(t), x, K=K, stride=1, defer=dr), dt_, x)
         flipped, _ = _taps(w1, packs, flipped=True)             # correlation with the reversed stencil
         gt = dt_.view_as(t)
         if do_res and FUSED_RESIDUAL_DGRAD and ops.dwconv3d_res_supported(gt, K, 1):
@@ -143,72 +182,25 @@ def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res,
             if do_res:
                 ops.add_(dx, dy)
     elif kind == "down":
-        dW1, db1 = ops.dw_wgrad(dt_.view_as(t), x, K=K, stride=2, defer=dr)
+        dW1, db1 = lane.run(lambda: ops.dw_wgrad(dt_.view_as(t), x, K=K, stride=2, defer=dr), dt_, x)
         dx = ops.dwconv3d_bwd_data(dt_.view_as(t), taps, (D, H, W), K=K, stride=2)
         if has_res:
             xg = x[:, ::2, ::2, ::2, :].contiguous()
-            dwres, dbres = ops.pw_wgrad(xg, dy, N=N, rows_per_sample=rows, c_in=C, c_out=c_out, defer=dr)
+            dwres, dbres = lane.run(lambda: ops.pw_wgrad(xg, dy, N=N, rows_per_sample=rows, c_in=C, c_out=c_out, defer=dr), xg, dy)
             dxg = _pw(dy, _mat(wres), None, c_out=C, transposed=True, rows=rows, packs=packs).view_as(xg)
             dx[:, ::2, ::2, ::2, :] += dxg         # strided in-place add: only the 1/8 of dx the 1x1x1 stride-2 conv read
     else:
         dtp = dt_.view_as(t)
         dtc = dtp[:, 1:, 1:, 1:, :].contiguous()                # compact (2D-1)^3 grid of the transposed conv
-        dW1, _ = ops.dw_wgrad(x, dtc, K=K, stride=2, want_bias=False, defer=dr)
+        dW1, _ = lane.run(lambda: ops.dw_wgrad(x, dtc, K=K, stride=2, want_bias=False, defer=dr), x, dtc)
         db1 = ops.channel_stats(dtc).sum(1)[:, 0].sum(0)
         dx, _ = ops.dwconv3d(dtc, taps, None, K=K, stride=2, stats=False, wide_range=True)
         if has_res:
             drl = dy[:, 1::2, 1::2, 1::2, :].contiguous()       # positions fed by the transposed 1x1 conv
-            dwres_m, _ = ops.pw_wgrad(x, drl, N=N, rows_per_sample=D * H * W, c_in=C, c_out=c_out, want_bias=False, defer=dr)
+            dwres_m, _ = lane.run(lambda: ops.pw_wgrad(x, drl, N=N, rows_per_sample=D * H * W, c_in=C, c_out=c_out, want_bias=False,
+                                                       defer=dr), x, drl)
             ops.add_(dx, _pw(drl, _mat(wres), None, c_out=C, transposed=False, packs=packs).view_as(dx))
     return dx, dW1, db1, dwres, dbres, dwres_m
-
-
-class BlockFn(torch.autograd.Function):
-    """MedNeXt block / down block / up block.  `kind` in {"block", "down", "up"}.  `recompute` = the reference's
-    `outside_block` activation checkpointing (mednext_models.py:386-393: torch.utils.checkpoint around every block): only the
-    block input and the (N, 2, C) norm vectors are kept; the depthwise output and the hidden pre-activation are rebuilt by
-    the same kernels at the start of the backward (bit-identical values, one extra block forward)."""
-
-    @staticmethod
-    def forward(ctx, x, skip, w1, b1, gamma, beta, w2, b2, w3, b3, wres, bres, kind: str, do_res: bool, eps: float,
-                recompute: bool = False, packs=None):
-        ctx.packs = packs
-        y, t, ab, mr, hp, taps, K, count = BlockFn._core(x, skip, w1, b1, gamma, beta, w2, b2, w3, b3, wres, bres, kind,
-                                                         do_res, eps, None, packs)
-        keep = x.new_zeros(0)
-        ctx.save_for_backward(x, keep if recompute else t, ab, mr, keep if recompute else hp, w1, gamma, w2, w3,
-                              wres if wres is not None else keep, skip if (recompute and skip is not None) else keep,
-                              b1 if (recompute and b1 is not None) else keep, b2 if recompute else keep, b3 if recompute else keep,
-                              bres if (recompute and bres is not None) else keep)
-        ctx.meta = (kind, do_res, K, count, wres is not None, skip is not None, b1 is not None, bres is not None, recompute, eps,
-                    b2 is not None, b3 is not None)
-        ctx.taps = taps                  # derived from w1 (no gradient flows through it): reused by the backward
-        return y
-
-    @staticmethod
-    @staticmethod
-    def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
-        transposed, has_bias, c_out = ctx.meta
-        w = _mat(weight)
-        c_in = x.shape[-1]
-        N = x.shape[0]
-        rows = x.numel() // (N * c_in)
-        dyc = dy.contiguous()
-        if dyc.dtype != x.dtype and x.dtype in (torch.float32, torch.bfloat16):
-            dyx = dyc.to(x.dtype)
-        else:
-            dyx = dyc
-        dx = None
-        if ctx.needs_input_grad[0]:
-            # dX = dY . W : operator c_out -> c_in with matrix W^T
-            dx = _pw(dyx, w, None, c_out=c_in, transposed=not transposed, packs=ctx.packs).view_as(x)
-        xin = x if x.dtype == dyx.dtype else x.to(dyx.dtype)
-        dW, db = ops.pw_wgrad(xin.contiguous(), dyx, N=N, rows_per_sample=rows, c_in=c_in, c_out=c_out,
-                              want_bias=has_bias)
-        dW = dW.t().contiguous() if transposed else dW
-        return (dx, torch.empty_like(weight).copy_(dW.reshape(weight.shape)), (db.to(weight.dtype) if has_bias else None),
-                None, None)
 
 
 class BlockFn(torch.autograd.Function):
@@ -319,20 +311,22 @@ class BlockFn(torch.autograd.Function):
         # every slot reduction of this block's gradients (dW3/db3, dW2/db2, the norm sums, dW1/db1, the residual conv) joins
         # ONE launch at the end (ops.DeferredReduce): ~5 tiny launches per block become 1, bit-identical results
         dr = ops.DeferredReduce()
+        lane = _WgradLane(x.device)
         # ---- project: y = W3 h + b3
-        dW3, db3 = ops.pw_wgrad(hp, dcore, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, x_act=nat.ACT_GELU, defer=dr)
+        dW3, db3 = lane.run(lambda: ops.pw_wgrad(hp, dcore, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, x_act=nat.ACT_GELU,
+                                                 defer=dr), hp, dcore)
         fused_bwd = (dy.dtype == torch.bfloat16 and FUSED_TRAIN_MIXER_BWD and ops.pw_mlp_supported(c_out, c_hid, C))
         if fused_bwd:
             # both data-gradient GEMMs in one launch: dtn = W2^T ((W3^T dy) * gelu'(hp)); dhp comes back for wgrad2
             dtn, dhp = ops.pw_mlp_bwd(dcore.view(N, rows, c_out), hp, ops.packed_paired(_mat(w3), transposed=True, packs=packs),
                                       ops.packed_paired(_mat(w2), transposed=True, packs=packs), N=N, rows_per_sample=rows,
                                       c_in=C, c_hid=c_hid, c_out=c_out)
-            dW2, db2 = ops.pw_wgrad(t, dhp, N=N, rows_per_sample=rows, c_in=C, c_out=c_hid, ab=ab, defer=dr)
+            dW2, db2 = lane.run(lambda: ops.pw_wgrad(t, dhp, N=N, rows_per_sample=rows, c_in=C, c_out=c_hid, ab=ab, defer=dr), t, dhp, ab)
         else:
             # dhp = (W3^T dy) * gelu'(hp): the GELU derivative is the epilogue of the data-gradient GEMM
             dhp = _pw(dcore, _mat(w3), None, c_out=c_hid, transposed=True, rows=rows, res=hp, res_mode=nat.RES_GELU_BWD, packs=packs)
             # ---- expand: hp = W2 (a t + b) + b2
-            dW2, db2 = ops.pw_wgrad(t, dhp, N=N, rows_per_sample=rows, c_in=C, c_out=c_hid, ab=ab, defer=dr)
+            dW2, db2 = lane.run(lambda: ops.pw_wgrad(t, dhp, N=N, rows_per_sample=rows, c_in=C, c_out=c_hid, ab=ab, defer=dr), t, dhp, ab)
             dtn = _pw(dhp, _mat(w2), None, c_out=C, transposed=True, rows=rows, packs=packs)
         del dhp
         # ---- GroupNorm(C, C)
@@ -342,7 +336,8 @@ class BlockFn(torch.autograd.Function):
         dgamma, dbeta = ssum[1], ssum[0]
         del dtn
         # ---- depthwise conv
-        dx, dW1, db1, dwres, dbres, dwres_m = _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res, dr)
+        dx, dW1, db1, dwres, dbres, dwres_m = _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res, dr, lane)
+        lane.join()
         dr.flush()                       # all weight / bias / norm gradients of the block are final from here on
         if kind == "up" and has_res:
             dwres = dwres_m.t().contiguous()                        # ConvTranspose layout (C_in, C_out)
