@@ -18,7 +18,7 @@ from typing import Optional, Sequence
 
 import torch
 
-__all__ = ["distributed_context", "is_distributed_window_sharding_enabled", "distributed_reduction_device",
+__all__ = ["reduce_cpu_tensor_to_rank_zero", "distributed_context", "is_distributed_window_sharding_enabled", "distributed_reduction_device",
            "validate_distributed_tensor_shape", "reduce_tensor_to_rank_zero", "validate_distributed_patch_shard",
            "make_accumulator_reduce_hook", "shard_indices", "validate_view_shards", "reduce_view_ensemble"]
 
@@ -93,6 +93,33 @@ def reduce_tensor_to_rank_zero(tensor: torch.Tensor, *, op, chunk_mb: int, name:
     for s in range(0, flat.numel(), per):
         torch.distributed.reduce(flat[s:s + per], dst=0, op=op)
     return tensor if rank == 0 else None
+
+
+def reduce_cpu_tensor_to_rank_zero(tensor: torch.Tensor, *, op, reduction_device=None, chunk_mb: int = 128,
+                                   name: str = "tensor") -> Optional[torch.Tensor]:
+    """The reference's entry point by its own name and signature (lazy_distributed.py:78-107): reduce an accumulator onto rank 0 in
+    `chunk_mb` pieces; rank 0 gets the reduced tensor, every other rank None.  A device tensor is reduced in place where it lives
+    (`reduce_tensor_to_rank_zero`; `reduction_device` is then irrelevant); a HOST tensor -- the reference's case -- is staged
+    through `reduction_device` piece by piece exactly as the reference does, for callers that keep their accumulators on the CPU."""
+    is_dist, rank, _world = distributed_context()
+    if not is_dist:
+        return tensor
+    if tensor.is_cuda:
+        return reduce_tensor_to_rank_zero(tensor, op=op, chunk_mb=chunk_mb, name=name)
+    validate_distributed_tensor_shape(tensor, name=name)
+    if reduction_device is not None:
+        dev = torch.device(reduction_device)
+    else:       # the reference passes the inference device; without one: this rank's GPU, or the host under a CPU backend (gloo)
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    flat = tensor.contiguous().view(-1)
+    per = max(1, (max(1, int(chunk_mb or 128)) * 1024 * 1024) // max(1, flat.element_size()))
+    out = torch.empty_like(flat) if rank == 0 else None
+    for s in range(0, flat.numel(), per):
+        piece = flat[s:s + per].to(device=dev)
+        torch.distributed.reduce(piece, dst=0, op=op)
+        if rank == 0:
+            out[s:s + per].copy_(piece.cpu())
+    return out.view_as(tensor) if rank == 0 else None
 
 
 def validate_distributed_patch_shard(*, local_count: int, total_count: int, device) -> None:

@@ -159,6 +159,13 @@ class AffinityViewPlan:
 
 
 @dataclass(frozen=True)
+class ViewValidity:
+    """Per output channel of one inverted view: None = valid everywhere, a tuple of slices = the box that received real
+    (non-wrapped) values, or a boolean mask (reference tta_affinity.py ViewValidity / ValidityEntry)."""
+    channels: tuple
+
+
+@dataclass(frozen=True)
 class AffinityTTAPlan:
     views: Tuple[AffinityViewPlan, ...]
     partial_channels: frozenset
@@ -193,6 +200,46 @@ def valid_slices_for_shift(spatial_shape: Sequence[int], shift: Sequence[int]) -
         n, s = int(n), int(s)
         out.append(slice(min(s, n), n) if s > 0 else (slice(0, max(0, n + s)) if s < 0 else slice(0, n)))
     return tuple(out)
+
+
+def invert_view(prediction, *, flip_axes: Sequence[int], rotation_plane_spatial, k: int, view_plan: Optional["AffinityViewPlan"],
+                tta_plan: Optional["AffinityTTAPlan"]):
+    """A whole prediction (N, C, *spatial) of one TTA view mapped back to the canonical frame: inverse quarter turns, inverse flips,
+    then the affinity channel moves of `view_plan` -- a shifted channel is displaced by its full offset, the positions that would
+    wrap are zeroed and reported as missing validity (reference tta_affinity.py:350-393).  -> (tensor, ViewValidity).
+
+    Public adapter for callers of the reference API.  The engine itself never materialises an un-inverted prediction: the same
+    index map runs per window inside `pytc_blend_accumulate_mapped` (AffinityViewPlan.channel_map).  Pure data movement (torch
+    indexing on whatever device the prediction lives on)."""
+    import torch
+    out = prediction
+    if rotation_plane_spatial is not None and int(k) % 4:
+        out = torch.rot90(out, k=-int(k), dims=tuple(int(a) + 2 for a in rotation_plane_spatial))
+    if flip_axes:
+        out = torch.flip(out, dims=[int(a) + 2 for a in flip_axes])
+    if tta_plan is not None:
+        if int(out.shape[1]) != int(tta_plan.num_channels):
+            raise ValueError(f"Affinity TTA plan was built for {tta_plan.num_channels} raw output channels, "
+                             f"but the model produced {int(out.shape[1])}.")
+        if tta_plan.spatial_rank and tta_plan.spatial_rank != out.dim() - 2:
+            raise ValueError(f"Affinity offset rank {tta_plan.spatial_rank} does not match raw output spatial rank {out.dim() - 2}.")
+    validity: list = [None] * int(out.shape[1])
+    if view_plan is None or not view_plan.moves:
+        return out, ViewValidity(tuple(validity))
+    fixed = out.clone()
+    spatial = tuple(int(v) for v in out.shape[2:])
+    for m in view_plan.moves:
+        if m.shift is None:
+            fixed[:, m.dst] = out[:, m.src]
+            continue
+        if len(m.shift) != len(spatial):
+            raise ValueError(f"Affinity roll shift rank {len(m.shift)} does not match raw output spatial rank {len(spatial)}.")
+        dst_box = valid_slices_for_shift(spatial, m.shift)
+        src_box = tuple(slice(b.start - int(s), b.stop - int(s)) for b, s in zip(dst_box, m.shift))
+        fixed[:, m.dst].zero_()
+        fixed[(slice(None), m.dst) + dst_box] = out[(slice(None), m.src) + src_box]
+        validity[m.dst] = dst_box
+    return fixed, ViewValidity(tuple(validity))
 
 
 def _raw_groups(cfg: Any, *, num_raw: int, requested_head: Optional[str]) -> List[Group]:
@@ -306,7 +353,7 @@ def build_affinity_tta_plan(cfg: Any, *, augmentation_combinations, num_raw: int
                            num_channels=int(num_raw), spatial_rank=rank)
 
 
-__all__ = ["AffinityTTAPlan", "AffinityViewPlan", "ChannelMove", "build_affinity_tta_plan", "transform_offset",
+__all__ = ["AffinityTTAPlan", "AffinityViewPlan", "ChannelMove", "ViewValidity", "invert_view", "build_affinity_tta_plan", "transform_offset",
            "valid_slices_for_shift", "parse_affinity_offsets", "resolve_affinity_offsets_from_kwargs",
            "resolve_affinity_mode_from_cfg", "resolve_affinity_channel_groups_from_cfg",
            "resolve_stacked_label_channel_count"]

@@ -34,6 +34,65 @@ def get_model_head_names(cfg: Any) -> list[str]:
     return list(heads.keys()) if isinstance(heads, Mapping) else []
 
 
+def _named_heads(cfg: Any) -> Mapping:
+    heads = _cfg_value(_cfg_value(cfg, "model", None), "heads", None)
+    return heads if isinstance(heads, Mapping) else {}
+
+
+def _checked_head(name: Any, heads: Mapping, what: str, purpose: str) -> str:
+    if not isinstance(name, str) or not name.strip():
+        raise ValueError(f"{what} for {purpose} must be a non-empty string.")
+    name = name.strip()
+    if name not in heads:
+        lead = f"Requested output head '{name}'" if what.startswith("Requested") else f"{what}='{name}'"
+        raise ValueError(f"{lead} for {purpose} is not present in model.heads ({sorted(heads.keys())}).")
+    return name
+
+
+def resolve_output_head(cfg: Any, *, requested_head: Optional[str] = None, purpose: str = "output selection",
+                        allow_none: bool = True) -> Optional[str]:
+    """Which named head a caller means (reference utils/model_outputs.py:61-131): the explicit request, else
+    `inference.model.head` (a comma-separated list there is a merged-inference spec, not a single head), else
+    `model.primary_head`, else the only head; None for models without named heads."""
+    heads = _named_heads(cfg)
+    if not heads:
+        return None
+    if requested_head is not None:
+        return _checked_head(requested_head, heads, "Requested output head", purpose)
+    configured = get_inference_model_value(cfg, "head", None)
+    if configured is not None and not (isinstance(configured, str) and "," in configured):
+        return _checked_head(configured, heads, "Requested output head", purpose)
+    primary = _cfg_value(_cfg_value(cfg, "model", None), "primary_head", None)
+    if primary is not None:
+        return _checked_head(primary, heads, "model.primary_head", purpose)
+    if len(heads) == 1:
+        return next(iter(heads))
+    if allow_none:
+        return None
+    raise ValueError(f"{purpose} requires inference.model.head or model.primary_head when model.heads has "
+                     f"multiple entries ({sorted(heads.keys())}).")
+
+
+def resolve_output_heads(cfg: Any, *, purpose: str = "output selection") -> list[str]:
+    """One or more heads for merged inference: `inference.model.head: "a,b,c"` in the order written, else the single
+    resolved head (reference utils/model_outputs.py:146-172)."""
+    heads = _named_heads(cfg)
+    if not heads:
+        return []
+    configured = get_inference_model_value(cfg, "head", None)
+    if isinstance(configured, str) and "," in configured:
+        names = [h.strip() for h in configured.split(",") if h.strip()]
+        if not names:
+            raise ValueError(f"inference.model.head for {purpose} is an empty list.")
+        unknown = [n for n in names if n not in heads]
+        if unknown:
+            raise ValueError(f"inference.model.head for {purpose} references unknown heads {unknown}; "
+                             f"available: {sorted(heads.keys())}.")
+        return names
+    one = resolve_output_head(cfg, purpose=purpose, allow_none=True)
+    return [one] if one else []
+
+
 def unwrap_main_output(outputs: Any) -> Any:
     if isinstance(outputs, Mapping) and "output" in outputs:
         return outputs["output"]
@@ -68,5 +127,5 @@ def select_output_tensor(outputs: Any, *, requested_head: Optional[str] = None, 
     return sel, head
 
 
-__all__ = ["select_output_tensor", "unwrap_main_output", "get_inference_select_channel",
+__all__ = ["select_output_tensor", "resolve_output_head", "resolve_output_heads", "unwrap_main_output", "get_inference_select_channel",
            "get_inference_channel_activations", "get_inference_model_value", "get_model_head_names"]

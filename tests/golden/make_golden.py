@@ -407,6 +407,72 @@ def tta_affinity():
     print("wrote tta_affinity_plans.json", {k: len(v["views"]) for k, v in plans.items()})
 
 
+def public_adapters():
+    """Fixtures for the public names a drop-in importer reaches for: the reference's own `invert_view`,
+    `TTAEnsembleAccumulator` and `resolve_output_head(s)` on small seeded inputs."""
+    import json
+    from types import SimpleNamespace as NS
+    ta = S.ref("connectomics.inference.tta_affinity")
+    te = S.ref("connectomics.inference.tta_ensemble")
+    comb = S.ref("connectomics.inference.tta_combinations")
+    mo = S.ref("connectomics.utils.model_outputs")
+    lr = ["1-0-0", "0-1-0", "0-0-1", "3-0-0", "0-2-0", "0-0-2"]
+    cfg = NS(model=NS(primary_head=None, heads=None, out_channels=6),
+             data=NS(train=NS(do_2d=False), val=NS(do_2d=False), dataloader=NS(batch_size=1),
+                     label_transform=NS(stack_outputs=True, targets=[{"name": "affinity", "kwargs": {"offsets": lr, "affinity_mode": "deepem"}}])),
+             inference=NS(model=NS(head=None, select_channel=None, output_dtype=None, channel_activations=None, crop_pad=None),
+                          test_time_augmentation=NS(enabled=True, flip_axes="all", rotation90_axes=[[1, 2]], rotate90_k=None,
+                                                    ensemble_mode="mean")))
+    combos = comb.resolve_tta_augmentation_combinations(cfg.inference.test_time_augmentation, spatial_dims=3)
+    plan = ta.build_affinity_tta_plan(cfg, augmentation_combinations=combos, num_raw=6, requested_head=None)
+    g = torch.Generator().manual_seed(41)
+    out = {"combos": np.asarray([[sum(1 << a for a in f), -1 if pl is None else pl[0] * 3 + pl[1], k] for f, pl, k in combos], np.int64)}
+    modes = ["mean", "min", "max", "mean", "max", "min"]
+    acc = te.TTAEnsembleAccumulator((1, 6, 5, 8, 8), dtype=torch.float32, device=torch.device("cpu"), mode_map=modes,
+                                    partial_channels=sorted(plan.partial_channels), distributed_sharding=False, max_views=len(combos))
+    for i, (f, pl, k) in enumerate(combos):
+        pred = torch.rand(1, 6, 5, 8, 8, generator=g)
+        # the view as the network would have seen it: forward transform of a canonical tensor
+        view = comb_apply(pred, f, pl, k)
+        inv, val = ta.invert_view(view, flip_axes=f, rotation_plane_spatial=pl, k=k, view_plan=plan.views[i], tta_plan=plan)
+        out[f"view{i}"] = view.numpy()
+        out[f"inv{i}"] = inv.numpy()
+        out[f"valid{i}"] = np.asarray([[-1] * 6 if v is None else [s.start for s in v] + [s.stop for s in v] for v in val.channels], np.int64)
+        acc.add(inv, val)
+    out["ensemble"] = acc.finalize().numpy()
+    out["partial"] = np.asarray(sorted(plan.partial_channels), np.int64)
+    save("public_adapters.npz", **out)
+    heads = {"aff": {"out_channels": 3}, "sdt": {"out_channels": 1}}
+    cases = []
+    for model_kw, inf_head, req, allow_none in [
+            (dict(heads=None, primary_head=None), None, None, True), (dict(heads=heads, primary_head=None), None, None, True),
+            (dict(heads=heads, primary_head=None), None, None, False), (dict(heads=heads, primary_head="sdt"), None, None, True),
+            (dict(heads=heads, primary_head="zzz"), None, None, True), (dict(heads=heads, primary_head=None), "aff", None, True),
+            (dict(heads=heads, primary_head="sdt"), "aff,sdt", None, True), (dict(heads=heads, primary_head=None), "aff, sdt", None, True),
+            (dict(heads=heads, primary_head=None), "aff,nope", None, True), (dict(heads=heads, primary_head=None), None, "sdt", True),
+            (dict(heads=heads, primary_head=None), None, "bad", True), (dict(heads=heads, primary_head=None), None, "  ", True),
+            (dict(heads={"only": {"out_channels": 2}}, primary_head=None), None, None, False)]:
+        c = NS(model=NS(**model_kw), inference=NS(model=NS(head=inf_head)))
+        rec = {"model": {k: v for k, v in model_kw.items()}, "inference_head": inf_head, "requested": req, "allow_none": allow_none}
+        for fn_name, call in (("one", lambda: mo.resolve_output_head(c, requested_head=req, purpose="t", allow_none=allow_none)),
+                              ("many", lambda: mo.resolve_output_heads(c, purpose="t"))):
+            try:
+                rec[fn_name] = {"value": call()}
+            except Exception as e:      # noqa: BLE001
+                rec[fn_name] = {"error": type(e).__name__, "message": str(e)}
+        cases.append(rec)
+    (HERE / "output_heads.json").write_text(json.dumps(cases, indent=0))
+    print("public adapters:", len(combos), "views,", len(cases), "head cases")
+
+
+def comb_apply(x, flip_axes, plane, k):
+    if flip_axes:
+        x = torch.flip(x, dims=[a + 2 for a in flip_axes])
+    if plane is not None and k % 4:
+        x = torch.rot90(x, k=k, dims=[plane[0] + 2, plane[1] + 2])
+    return x
+
+
 # ---------------------------------------------------------------- lazy / region sliding window
 def _net_lazy(x):
     ramp = torch.linspace(0, 1, x.shape[-1]).view(1, 1, 1, 1, -1)
@@ -874,7 +940,7 @@ def losses_extra():
 
 if __name__ == "__main__":
     parts = {"manifests": manifests, "optimizers": optimizers, "schedules": schedules, "selectors": selectors, "outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
-             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "accessor": accessor, "ds_loss": ds_loss, "losses_extra": losses_extra}
+             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "accessor": accessor, "ds_loss": ds_loss, "losses_extra": losses_extra, "public_adapters": public_adapters}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:
         parts[name]()

@@ -153,3 +153,27 @@ def test_affinity_tta_matches_reference(name, golden_dir):
     exp = g[f"{name}__y"]
     assert y.shape == exp.shape
     np.testing.assert_allclose(y, exp, rtol=2e-5, atol=2e-5)
+
+
+def test_tta_ensemble_accumulator_matches_the_reference(golden_dir):
+    """The public `TTAEnsembleAccumulator` (device statistics, ensemble kernels) fed with the canonical predictions and validity
+    boxes of 16 views: equal to the reference accumulator's result (tests/golden/public_adapters.npz)."""
+    from types import SimpleNamespace as NS
+    from pytorch_connectomics_amd.inference import TTAEnsembleAccumulator
+    from pytorch_connectomics_amd.inference.tta_affinity import ViewValidity
+    z = np.load(golden_dir / "public_adapters.npz")
+    n_views = z["combos"].shape[0]
+    modes = ["mean", "min", "max", "mean", "max", "min"]
+    acc = TTAEnsembleAccumulator((1, 6, 5, 8, 8), dtype=torch.float32, device="cuda", mode_map=modes,
+                                 partial_channels=z["partial"].tolist(), distributed_sharding=False, max_views=n_views)
+    assert acc.has_partial_channels and acc.full_channels == tuple(c for c in range(6) if c not in z["partial"].tolist())
+    for i in range(n_views):
+        val = ViewValidity(tuple(None if row[0] < 0 else tuple(slice(int(a), int(b)) for a, b in zip(row[:3], row[3:]))
+                                 for row in z[f"valid{i}"]))
+        acc.add(torch.from_numpy(z[f"inv{i}"]).cuda(), val)
+    torch.testing.assert_close(acc.finalize().cpu(), torch.from_numpy(z["ensemble"]), rtol=1e-6, atol=1e-6)
+    with pytest.raises(ValueError, match="does not match accumulator shape"):
+        acc.add(torch.zeros(1, 6, 4, 8, 8, device="cuda"), NS(channels=(None,) * 6))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        TTAEnsembleAccumulator((1, 2, 4, 4, 4), dtype=torch.float32, device="cpu", mode_map=["mean", "mean"], partial_channels=[],
+                               distributed_sharding=False, max_views=2)

@@ -178,6 +178,13 @@ def _window_worker(rank, world, port):
             assert got is buf and torch.equal(got, want)                                   # in place, no staging copy
         else:
             assert got is None
+    # the reference's own entry point (host accumulators staged through `reduction_device` in chunk_mb pieces)
+    host = torch.arange(300_000, dtype=torch.float32) + rank
+    got = LD.reduce_cpu_tensor_to_rank_zero(host, op=torch.distributed.ReduceOp.SUM, reduction_device=torch.device("cpu"), chunk_mb=1,
+                                            name="host accumulator")
+    assert (got is None) == (rank != 0)
+    if rank == 0:
+        assert torch.equal(got, 2 * torch.arange(300_000, dtype=torch.float32) + 1) and got.shape == host.shape
     with pytest.raises(ValueError, match="contiguous"):
         LD.reduce_tensor_to_rank_zero(torch.zeros(4, 4).t(), op=torch.distributed.ReduceOp.SUM, chunk_mb=1, name="v", validate=False)
     hook = LD.make_accumulator_reduce_hook(chunk_mb=1)

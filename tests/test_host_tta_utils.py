@@ -196,3 +196,59 @@ def test_view_map_is_the_tensor_op():
                 sig = (tuple(want.shape), tuple(want.reshape(-1).tolist()))
                 assert seen.setdefault(vm, sig) == sig
     assert len(seen) == len({v for v in seen.values()}) == 32          # 48 signed permutations minus the 16 that need a 3-cycle
+
+
+def _combo_from_code(row):
+    flip = [a for a in range(3) if int(row[0]) >> a & 1]
+    plane = None if int(row[1]) < 0 else (int(row[1]) // 3, int(row[1]) % 3)
+    return flip, plane, int(row[2])
+
+
+def _adapter_plan():
+    from pytorch_connectomics_amd.inference.tta_affinity import build_affinity_tta_plan
+    lr = ["1-0-0", "0-1-0", "0-0-1", "3-0-0", "0-2-0", "0-0-2"]
+    cfg = NS(model=NS(primary_head=None, heads=None, out_channels=6),
+             data=NS(train=NS(do_2d=False), val=NS(do_2d=False), dataloader=NS(batch_size=1),
+                     label_transform=NS(stack_outputs=True, targets=[{"name": "affinity", "kwargs": {"offsets": lr, "affinity_mode": "deepem"}}])),
+             inference=NS(model=NS(head=None, select_channel=None, output_dtype=None, channel_activations=None, crop_pad=None),
+                          test_time_augmentation=NS(enabled=True, flip_axes="all", rotation90_axes=[[1, 2]], rotate90_k=None,
+                                                    ensemble_mode="mean")))
+    combos = resolve_tta_augmentation_combinations(cfg.inference.test_time_augmentation, spatial_dims=3)
+    return combos, build_affinity_tta_plan(cfg, augmentation_combinations=combos, num_raw=6, requested_head=None)
+
+
+def test_invert_view_matches_the_reference(golden_dir):
+    """tests/golden/public_adapters.npz (make_golden.py --public_adapters): the reference's `invert_view` on 16 flip x rot90 views of a
+    6-channel long-range affinity prediction -- canonical tensor and per-channel validity boxes."""
+    import numpy as np
+    from pytorch_connectomics_amd.inference import invert_view
+    z = np.load(golden_dir / "public_adapters.npz")
+    combos, plan = _adapter_plan()
+    assert [list(_combo_from_code(r)) for r in z["combos"]] == [[list(f), None if pl is None else tuple(pl), k] for f, pl, k in combos]
+    assert sorted(plan.partial_channels) == z["partial"].tolist()
+    for i, (f, pl, k) in enumerate(combos):
+        inv, val = invert_view(torch.from_numpy(z[f"view{i}"]), flip_axes=f, rotation_plane_spatial=pl, k=k, view_plan=plan.views[i],
+                               tta_plan=plan)
+        assert torch.equal(inv, torch.from_numpy(z[f"inv{i}"])), i
+        want = [None if row[0] < 0 else tuple(slice(int(a), int(b)) for a, b in zip(row[:3], row[3:])) for row in z[f"valid{i}"]]
+        assert list(val.channels) == want, i
+    with pytest.raises(ValueError, match="was built for 6 raw output channels"):
+        invert_view(torch.zeros(1, 5, 5, 8, 8), flip_axes=[], rotation_plane_spatial=None, k=0, view_plan=None, tta_plan=plan)
+
+
+def test_resolve_output_heads_match_the_reference(golden_dir):
+    import json
+    from pytorch_connectomics_amd.utils import resolve_output_head, resolve_output_heads
+    cases = json.loads((golden_dir / "output_heads.json").read_text())
+    assert len(cases) == 13
+    for c in cases:
+        cfg = NS(model=NS(**c["model"]), inference=NS(model=NS(head=c["inference_head"])))
+        for key, call in (("one", lambda: resolve_output_head(cfg, requested_head=c["requested"], purpose="t", allow_none=c["allow_none"])),
+                          ("many", lambda: resolve_output_heads(cfg, purpose="t"))):
+            want = c[key]
+            if "error" in want:
+                with pytest.raises(ValueError) as e:
+                    call()
+                assert str(e.value) == want["message"], (c, key)
+            else:
+                assert call() == want["value"], (c, key)
