@@ -150,6 +150,41 @@ int pytc_ensemble_update(float* acc, const float* x, int64_t n, int mode, int co
 #define PYTC_ST_F32 6
 int pytc_scale_cast(const float* x, void* y, int64_t n, float scale, int target, void* stream);
 
+/* ---------------------------------------------------------------- disk-backed test volumes -- */
+
+/* The transform half of the reference's LazyVolumeAccessor (inference/lazy.py:456-917: `_read_raw_crop` :691-717,
+ * `_read_transformed_bbox` :719-780, `_read_padded_inner_region` :782-850) as ONE gather over the raw storage box:
+ *   out[c][z][y][x] = blend over {i0, i1} per axis of raw[c*s_c + iz*s_z + iy*s_y + ix*s_x]
+ * raw: the storage bytes of the box (device), element type `raw_dtype`; strides_czyx (host, elements): where the CHANNEL and
+ * the three LOGICAL axes (after `val_transpose`) live in the box, so channel layouts and the transpose cost nothing;
+ * tab_i0 / tab_i1 / tab_f (device, nz + ny + nx entries each, z | y | x back to back): per output index the two box-local raw
+ * indices it reads and the weight of the second (0: nearest / no resize; i0 < 0: outside a constant context pad -> 0) --
+ * resize (nearest for labels and masks, trilinear align_corners=True for images) and context padding (constant / reflect /
+ * edge) are folded into the tables by the host (inference/lazy_accessor.py).  out: fp32 (C, nz, ny, nx). */
+#define PYTC_RAW_U8 0
+#define PYTC_RAW_I8 1
+#define PYTC_RAW_U16 2
+#define PYTC_RAW_I16 3
+#define PYTC_RAW_U32 4
+#define PYTC_RAW_I32 5
+#define PYTC_RAW_F32 6
+#define PYTC_RAW_F64 7
+int pytc_resample_region(const void* raw, int raw_dtype, const int64_t* strides_czyx, int C, const int32_t* tab_i0,
+                         const int32_t* tab_i1, const float* tab_f, const int32_t* dims_zyx, float* out, void* stream);
+
+/* The per-window finishing of `read_patch` (lazy.py:896-904) + `smart_normalize` (data/augmentation/augment_ops.py:552-611) on a
+ * batch of gathered windows x fp32 (B, n), in place: optional binarisation (v > threshold), optional clipping to per-window bounds
+ * clip (B, 2) (the percentile bounds), then mode: NONE | ZSCORE ((v - mean) / std when std > 1e-8) | MINMAX ((v - min) / (max - min)
+ * when max > min) | DIVIDE (v / divide).  Statistics are those of THAT window after binarise / clip, two-stage fixed-order reduction
+ * in fp64.  workspace: pytc_window_normalize_ws_elems(B, n) doubles (statistics modes only). */
+#define PYTC_NORM_NONE 0
+#define PYTC_NORM_ZSCORE 1
+#define PYTC_NORM_MINMAX 2
+#define PYTC_NORM_DIVIDE 3
+int64_t pytc_window_normalize_ws_elems(int B, int64_t n);
+int pytc_window_normalize(float* x, int B, int64_t n, int mode, int binarize, float threshold, float divide, const float* clip,
+                          double* workspace, void* stream);
+
 /* ---------------------------------------------------------------- depthwise conv ---------- */
 
 /* number of per-sample partial-statistics slots pytc_dwconv3d_fwd / pytc_dwconvT3d_fwd write for

@@ -46,6 +46,8 @@ class MlpArgs(C.Structure):
 
 
 W3_BF16, W3_F16 = 0, 1
+NORM_NONE, NORM_ZSCORE, NORM_MINMAX, NORM_DIVIDE = 0, 1, 2, 3
+RAW_DTYPES = {"uint8": 0, "int8": 1, "uint16": 2, "int16": 3, "uint32": 4, "int32": 5, "float32": 6, "float64": 7}
 
 
 class ReduceItem(C.Structure):
@@ -104,6 +106,11 @@ _SIGS = {
     "pytc_ensemble_update_masked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "pytc_ensemble_finalize_masked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "pytc_scale_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
+    "pytc_resample_region": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
+    "pytc_window_normalize_ws_elems": (C.c_int64, [C.c_int, C.c_int64]),
+    "pytc_window_normalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
     "pytc_pw_conv_fwd": (C.c_int, [C.POINTER(PwArgs), C.c_void_p]),
     "pytc_pw_conv_paired_supported": (C.c_int, [C.POINTER(PwArgs)]),
     "pytc_conv3d_packed_elems": (C.c_int64, [C.c_int] * 6),

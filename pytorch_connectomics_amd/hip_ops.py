@@ -238,6 +238,46 @@ def ensemble_update(acc: torch.Tensor, x: torch.Tensor, mode: int, count: int) -
          acc.numel(), int(mode), int(count), _stream())
 
 
+# ------------------------------------------------------------------ disk-backed volumes (csrc/volume_kernels.hip)
+def resample_region(raw_bytes: torch.Tensor, raw_dtype: str, strides_czyx, channels: int, tab_i0: torch.Tensor,
+                    tab_i1: torch.Tensor, tab_f: torch.Tensor, dims_zyx) -> torch.Tensor:
+    """raw_bytes: the storage bytes of a raw box on the device (uint8 view of any stored dtype `raw_dtype`); tables: int32 / fp32
+    device vectors of nz + ny + nx entries (see pytc_resample_region) -> fp32 (C, nz, ny, nx)."""
+    _dev(raw_bytes, "raw_bytes"); _dev(tab_i0, "tab_i0"); _dev(tab_i1, "tab_i1"); _dev(tab_f, "tab_f")
+    if raw_dtype not in nat.RAW_DTYPES:
+        raise TypeError(f"resample_region: stored dtype {raw_dtype} is not supported (one of {sorted(nat.RAW_DTYPES)})")
+    nz, ny, nx = (int(v) for v in dims_zyx)
+    n = nz + ny + nx
+    if tab_i0.numel() != n or tab_i1.numel() != n or tab_f.numel() != n or tab_i0.dtype != torch.int32 or tab_f.dtype != torch.float32:
+        raise ValueError("resample_region: tables must be int32 / int32 / float32 vectors of nz + ny + nx entries")
+    out = torch.empty((int(channels), nz, ny, nx), dtype=torch.float32, device=raw_bytes.device)
+    st = (C.c_int64 * 4)(*[int(v) for v in strides_czyx])
+    _run("resample_region", raw_bytes.numel() + _nbytes(out), nat.lib().pytc_resample_region, _p(raw_bytes), nat.RAW_DTYPES[raw_dtype],
+         st, int(channels), _p(tab_i0), _p(tab_i1), _p(tab_f), _i3((nz, ny, nx)), _p(out), _stream())
+    return out
+
+
+def window_normalize(x: torch.Tensor, *, mode: int = nat.NORM_NONE, binarize: bool = False, threshold: float = 0.0,
+                     divide: float = 1.0, clip: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x fp32 (B, ...) contiguous, IN PLACE: per window (= leading index) binarise, clip to clip[b] = (lo, hi), then
+    NORM_ZSCORE / NORM_MINMAX with that window's own statistics, or NORM_DIVIDE (pytc_window_normalize)."""
+    _dev(x, "x")
+    if x.dtype != torch.float32:
+        raise TypeError("window_normalize works on float32 windows")
+    B = int(x.shape[0])
+    n = x.numel() // max(B, 1)
+    if clip is not None:
+        _dev(clip, "clip")
+        if tuple(clip.shape) != (B, 2) or clip.dtype != torch.float32:
+            raise ValueError("window_normalize: clip must be float32 (B, 2)")
+    ws = None
+    if mode in (nat.NORM_ZSCORE, nat.NORM_MINMAX):
+        ws = torch.empty((int(nat.lib().pytc_window_normalize_ws_elems(B, n)),), dtype=torch.float64, device=x.device)
+    _run("window_normalize", 2 * _nbytes(x) * (2 if ws is not None else 1), nat.lib().pytc_window_normalize, _p(x), B, n, int(mode),
+         int(bool(binarize)), float(threshold), float(divide), _p(clip), _p(ws), _stream())
+    return x
+
+
 # ------------------------------------------------------------------ depthwise conv + norm statistics
 def dwconv3d(x: torch.Tensor, w_taps: torch.Tensor, bias: Optional[torch.Tensor], *, K: int, stride: int = 1,
              stats: bool = True, transposed: bool = False, y: Optional[torch.Tensor] = None, store: bool = True,

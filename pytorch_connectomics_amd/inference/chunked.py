@@ -366,8 +366,8 @@ def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, de
     prefetch = None
     if predict_region_fn is None:
         todo = [c for _i, c in mine if not (_done_file(c).exists() and c.key in manifest.completed)]
-        if isinstance(volume, LazyVolumeAccessor) and not volume.needs_per_patch_host_path and todo:
-            # disk read + decompression of chunk i+1 into pinned memory on an IO thread while chunk i is predicted
+        if isinstance(volume, LazyVolumeAccessor) and todo:
+            # disk read + decompression of chunk i+1's raw box into pinned memory on an IO thread while chunk i is predicted
             boxes = []
             for c in todo:
                 rl, rh, _core = resolve_halo_region(c, input_shape[-3:], halo=halo, crop_before=crop_before)

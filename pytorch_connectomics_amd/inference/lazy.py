@@ -13,8 +13,10 @@ MI355X design: the source volume (numpy / memmap / tensor; host or device) is br
 (the bounding box of the intersecting windows), windows are gathered / blended by the HIP kernels and the
 fp32 accumulators never leave the device.  Disk-backed sources go through inference/lazy_accessor.py (`LazyVolumeAccessor`
 over HDF5 / .npy / zarr v2 with the reference's lazy transforms): a path or an accessor may be passed as `volume`; the region
-box is read once (`read_region`, optionally prefetched into pinned memory by the chunked runner) unless the image pipeline
-needs per-window statistics, in which case windows are read one by one with `read_patch` exactly like the reference.
+box's RAW storage bytes are staged once (`stage_region`, optionally read ahead into pinned memory by the chunked runner), turned
+into the transformed, context-padded fp32 region by one kernel, the windows are gathered from it on the device, and the per-window
+tail of the reader's pipeline (binarise, percentile clip, z-score / min-max / divide-K with each window's own statistics) runs on
+the gathered batch (`LazyVolumeAccessor.finish_windows`).  Nothing is resampled or normalised on the host.
 """
 from __future__ import annotations
 
@@ -225,17 +227,17 @@ def _lazy_sliding_window(cfg, forward_fn, volume, *, region_start, region_stop, 
     read = tuple(int(roi[a]) + 2 * ctx[a] for a in range(3))
     lo = tuple(max(0, min(w[a] for w in wins) - ctx[a]) for a in range(3))
     hi = tuple(min(bounds[a], max(w[a] for w in wins) + int(roi[a]) + ctx[a]) for a in range(3))
-    per_patch = accessor is not None and accessor.needs_per_patch_host_path
-    sub = None
     if preloaded is not None and tuple(preloaded[0]) == (lo, hi):
-        sub = preloaded[1]                                   # read ahead by the chunked runner (pinned host memory)
-    elif accessor is not None and not per_patch:
-        sub = torch.from_numpy(np.ascontiguousarray(accessor.read_region(lo, hi)))
-    elif accessor is None:
+        sub = preloaded[1]                                   # staged ahead by the chunked runner (raw bytes in pinned host memory)
+    elif accessor is not None:
+        sub = accessor.stage_region(lo, hi)
+    else:
         sub = vol[:, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
         if isinstance(sub, np.ndarray):
             sub = torch.from_numpy(np.ascontiguousarray(sub, dtype=np.float32))
-    if sub is not None:
+    if hasattr(sub, "to_device"):                            # StagedRegion: one H2D copy of the stored bytes + one resample kernel
+        sub = sub.to_device(dev)
+    else:
         sub = sub.to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
 
     ks, combine = _axis_kernels(roi, blend, torch.float32)
@@ -248,14 +250,12 @@ def _lazy_sliding_window(cfg, forward_fn, volume, *, region_start, region_stop, 
         chunk = wins[b0:b0 + swb]
         # windows overhang the box only where the box touches the volume border; the kernel's periodic
         # reflect / replicate / circular index math equals the np.pad semantics of the reference reader
-        if per_patch:
-            # per-window statistics (z-score / min-max / percentile clip of THAT window): host reads like the reference
-            host = np.stack([accessor.read_patch(tuple(w[a] - ctx[a] for a in range(3)), read, outer_pad_mode=pad_mode,
-                                                 outer_pad_value=cval) for w in chunk])
-            x = torch.from_numpy(host).to(dev).permute(0, 2, 3, 4, 1).contiguous()
-        else:
-            rel = [tuple(w[a] - ctx[a] - lo[a] for a in range(3)) for w in chunk]
-            x = ops.gather_windows(sub, rel, read, pad_mode=pad_mode, cval=cval)
+        rel = [tuple(w[a] - ctx[a] - lo[a] for a in range(3)) for w in chunk]
+        x = ops.gather_windows(sub, rel, read, pad_mode=pad_mode, cval=cval)
+        if accessor is not None:
+            # the reader's per-window tail (reference read_patch: binarise, percentile clip, normalisation of THAT window,
+            # outer padding included) on the gathered batch
+            x = accessor.finish_windows(x)
         if fwd_cl is not None:
             pred = fwd_cl(x)
         else:

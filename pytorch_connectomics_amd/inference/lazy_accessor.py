@@ -1,316 +1,187 @@
-"""LazyVolumeAccessor -- random-access reader of a disk-backed test volume that reproduces the test-time transforms lazily;
-counterpart of the reader half of the reference's connectomics/inference/lazy.py (`LazyVolumeAccessor` :456-917:
-`read_patch` :852-904, `_read_padded_inner_region` :782-850, `_read_transformed_bbox` :719-780, `_read_raw_crop` :691-717,
-layout inference :567-596, `_build_accessor` :920-959, `_resolve_scale_factors` :420-453, helpers :161-268) and of
-`smart_normalize` (data/augmentation/augment_ops.py:552-611).
+"""Disk-backed test volumes for the lazy / chunked sliding-window path: the reader the reference calls `LazyVolumeAccessor`
+(connectomics/inference/lazy.py:456-917) re-designed around the device.
 
-Semantics kept (pinned by tests/golden/lazy_accessor.npz, generated by running the reference's own accessor over an HDF5
-file): channel layout inferred from the raw shape, `val_transpose` applied lazily by permuting the slice request,
-`resize` through output->input coordinate maps (nearest for labels / masks, trilinear align_corners=True for images),
-`pad_size` context padding (constant / reflect / edge) by index mapping, the window's outer padding by np.pad, optional
-mask binarisation and PER-PATCH `smart_normalize` (percentile clip, z-score / min-max / divide).
+What a window of the reference's reader goes through -- `val_transpose`, `resize` (nearest for labels / masks, trilinear
+align_corners=True for images), `pad_size` context padding (constant / reflect / edge), the window's own outer padding, mask
+binarisation and `smart_normalize` (data/augmentation/augment_ops.py:552-611) -- is split here into
 
-MI355X side: sources are HDF5 (h5py or the in-repo libhdf5 shim), `.npy` (memory-mapped) and zarr v2 directories (a small
-in-repo reader: uncompressed / zlib / gzip / bz2 / lzma chunks); `read_region` returns the transformed, context-padded box
-a whole chunk needs so the sliding-window kernels gather windows from HBM (one host read + one H2D copy per region instead
-of one per window), and `RegionPrefetcher` reads the NEXT region into pinned memory on an IO thread while the current one
-is predicted.  Per-patch statistics modes ('normal', '0-1', percentile clipping) keep the per-window host path: they are
-functions of the individual window, not of the region.
+  host   one `VolumeSource.read_box`: the RAW stored values of the storage box a region needs (storage dtype, storage axis order),
+         optionally into pinned memory on an IO thread (`RegionPrefetcher`), plus three small per-axis index tables (`AxisMap.table`)
+         that say which raw indices every output index reads;
+  device `pytc_resample_region` (transpose + resize + context pad in one gather over the raw box -> fp32 (C, z, y, x) region in HBM),
+         the sliding-window gather kernel (outer padding, as for in-memory volumes), and `pytc_window_normalize` (binarise, percentile
+         clip, z-score / min-max / divide-K with the statistics of each WINDOW) -- `LazyVolumeAccessor.finish_windows`.
+
+Nothing is resampled or normalised in numpy; `read_patch` / `read_region` / `load_full` (the reference's host-array API, kept for its
+callers and for the reference fixtures of tests/golden/lazy_accessor.npz) run the same kernels and copy the result back.
 """
 from __future__ import annotations
 
-import json
 import math
 import threading
-from pathlib import Path
-from typing import Any, Optional, Sequence
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
-from ..utils.h5lite import get_h5_backend
+from .. import _native as nat
+from .. import hip_ops as ops
+from .volume_source import VolumeSource, ZarrV2Array, box_strides, detect_format
 
-
-# ------------------------------------------------------------------------------------------------ helpers (lazy.py:161-268)
-def _detect_format(filename: str) -> str:
-    """data/io/io.py:33-58 plus `.npy` (memory-mapped arrays, the container this engine also writes)."""
-    if filename.endswith(".nii.gz"):
-        return "nifti"
-    suffix = Path(filename).suffix.lower().lstrip(".")
-    fmt = {"h5": "h5", "hdf5": "h5", "tif": "tiff", "tiff": "tiff", "png": "png", "nii": "nifti", "npy": "npy"}.get(suffix)
-    if fmt is not None:
-        return fmt
-    if ".zarr" in filename:
-        return "zarr"
-    raise ValueError(f"Unrecognizable file format for {filename}. Expected: h5, hdf5, tif, tiff, png, nii, nii.gz, zarr")
+_NORM_CODES = {"none": nat.NORM_NONE, "normal": nat.NORM_ZSCORE, "0-1": nat.NORM_MINMAX, "divide": nat.NORM_DIVIDE}
 
 
-def _normalize_transpose_axes(transpose_axes) -> tuple:
-    if transpose_axes is None:
-        return ()
-    axes = tuple(int(a) for a in transpose_axes)
-    if not axes:
-        return ()
-    if len(axes) != 3 or sorted(axes) != [0, 1, 2]:
-        raise ValueError(f"transpose_axes must be a permutation of [0,1,2], got {transpose_axes}")
-    return axes
+# ------------------------------------------------------------------------------------------------ geometry
+@dataclass(frozen=True)
+class AxisMap:
+    """One axis of the presented volume: `stored` raw samples -> `resized` samples (nearest or linear, align_corners) -> context
+    pad of (before, after) samples in `pad_mode`.  `table(lo, hi)` composes the three steps BACKWARDS for output indices
+    [lo, hi): -> (i0, i1, f) with out = (1 - f) * raw[i0] + f * raw[i1]; i0 = -1 marks a sample outside a constant pad."""
+    stored: int
+    resized: int
+    pad: Tuple[int, int]
+    pad_mode: str
+    linear: bool
+    resizes: bool
+
+    @property
+    def length(self) -> int:
+        return self.resized + self.pad[0] + self.pad[1]
+
+    def _unpad(self, idx: np.ndarray):
+        t = self.resized
+        if self.pad_mode == "constant":
+            return (idx >= 0) & (idx < t), np.clip(idx, 0, max(t - 1, 0))
+        ok = np.ones(idx.shape, dtype=bool)
+        if self.pad_mode == "edge" or t <= 1:
+            return ok, np.clip(idx, 0, max(t - 1, 0))
+        if self.pad_mode == "reflect":
+            period = 2 * t - 2
+            m = np.abs(idx) % period
+            return ok, np.where(m < t, m, period - m)
+        raise ValueError(f"Unsupported context pad mode '{self.pad_mode}'.")
+
+    def table(self, lo: int, hi: int):
+        valid, m = self._unpad(np.arange(int(lo), int(hi), dtype=np.int64) - int(self.pad[0]))
+        f = np.zeros(m.shape, dtype=np.float32)
+        if not self.resizes:
+            i0 = i1 = m
+        elif self.stored <= 1 or self.resized <= 1:
+            i0 = i1 = np.zeros_like(m)
+        elif not self.linear:
+            # floor(i * in / out) in float32, the arithmetic of the reference's nearest map
+            c = np.floor(m.astype(np.float32) * np.float32(self.stored) / np.float32(self.resized))
+            i0 = i1 = np.clip(c, 0, self.stored - 1).astype(np.int64)
+        else:
+            c = m.astype(np.float32) * np.float32(self.stored - 1) / np.float32(self.resized - 1)      # align_corners=True
+            i0 = np.clip(np.floor(c), 0, self.stored - 1).astype(np.int64)
+            i1 = np.minimum(i0 + 1, self.stored - 1)
+            f = (c - i0.astype(np.float32)).astype(np.float32)
+            f[i1 == i0] = 0.0
+        i0 = np.where(valid, i0, -1)
+        return i0.astype(np.int64), np.where(valid, i1, -1).astype(np.int64), np.where(valid, f, 0).astype(np.float32)
 
 
-def _invert_transpose_axes(transpose_axes) -> tuple:
-    if not transpose_axes:
-        return ()
-    inv = [0, 0, 0]
-    for out_axis, in_axis in enumerate(transpose_axes):
-        inv[in_axis] = out_axis
-    return tuple(inv)
-
-
-def _scaled_length(length: int, factor: float) -> int:
+def _resized_length(length: int, factor: float) -> int:
     if factor <= 0:
         raise ValueError(f"scale factor must be positive, got {factor}.")
     return max(1, int(math.floor(float(length) * float(factor) + 1e-6)))
 
 
-def _normalize_pad_mode(mode: str) -> str:
+def _pad_mode_name(mode: str) -> str:
     m = str(mode).lower()
     return "edge" if m == "replicate" else m
 
 
-def _output_indices_to_input_coords(start: int, end: int, *, input_size: int, output_size: int, mode: str,
-                                    align_corners: Optional[bool]) -> np.ndarray:
-    idx = np.arange(int(start), int(end), dtype=np.float32)
-    if idx.size == 0:
-        return idx
-    if input_size <= 1 or output_size <= 1:
-        return np.zeros_like(idx, dtype=np.float32)
-    if mode == "nearest":
-        c = np.floor(idx * float(input_size) / float(output_size))
-        return np.clip(c, 0, input_size - 1).astype(np.float32, copy=False)
-    if align_corners:
-        c = idx * float(input_size - 1) / float(output_size - 1)
-    else:
-        c = np.clip(((idx + 0.5) * float(input_size) / float(output_size)) - 0.5, 0.0, float(input_size - 1))
-    return c.astype(np.float32, copy=False)
+class StagedRegion:
+    """Raw storage bytes of one box + the index tables that turn them into the presented region: everything the device needs.
+    `raw` is a host uint8 tensor (pinned when staged by the prefetcher); `to_device` does the H2D copy and ONE kernel."""
 
+    def __init__(self, box: Tuple[Tuple[int, int, int], Tuple[int, int, int]], raw: Optional[torch.Tensor], raw_dtype: str,
+                 strides, channels: int, tables, dims):
+        self.box = box
+        self.raw, self.raw_dtype, self.strides, self.channels = raw, raw_dtype, strides, int(channels)
+        self.tables, self.dims = tables, tuple(int(v) for v in dims)
 
-def _normalize_grid_axis(coords: np.ndarray, axis_length: int) -> np.ndarray:
-    if coords.size == 0:
-        return coords.astype(np.float32, copy=False)
-    if axis_length <= 1:
-        return np.zeros_like(coords, dtype=np.float32)
-    return ((2.0 * coords) / float(axis_length - 1) - 1.0).astype(np.float32, copy=False)
+    @property
+    def shape(self):
+        return (self.channels,) + self.dims
 
+    def pin(self) -> "StagedRegion":
+        if self.raw is not None and torch.cuda.is_available() and not self.raw.is_pinned():
+            self.raw = self.raw.pin_memory()
+        return self
 
-def _reflect_indices(indices: np.ndarray, length: int) -> np.ndarray:
-    if length <= 1:
-        return np.zeros_like(indices, dtype=np.int64)
-    period = 2 * length - 2
-    mod = np.abs(indices).astype(np.int64) % period
-    return np.where(mod < length, mod, period - mod)
-
-
-def _pad_channel_first(array: np.ndarray, pads, *, mode: str, constant_value: float = 0.0) -> np.ndarray:
-    if not any(b > 0 or a > 0 for b, a in pads):
-        return array
-    np_mode = _normalize_pad_mode(mode)
-    width = [(0, 0)] + [(int(b), int(a)) for b, a in pads]
-    if np_mode == "constant":
-        return np.pad(array, width, mode=np_mode, constant_values=constant_value)
-    if np_mode == "reflect" and any(s <= 1 for s in array.shape[1:]):
-        np_mode = "edge"
-    if np_mode == "circular":
-        np_mode = "wrap"
-    return np.pad(array, width, mode=np_mode)
-
-
-def get_padsize(pad_size, ndim: int = 3):
-    """data/processing/misc.py:20-41."""
-    if isinstance(pad_size, int):
-        return tuple((pad_size, pad_size) for _ in range(ndim))
-    pad_size = list(pad_size)
-    if len(pad_size) not in (1, ndim, 2 * ndim):
-        raise ValueError(f"pad_size length must be 1, {ndim}, or {2 * ndim}, got {len(pad_size)}")
-    if len(pad_size) == 1:
-        return tuple((pad_size[0], pad_size[0]) for _ in range(ndim))
-    if len(pad_size) == ndim:
-        return tuple((x, x) for x in pad_size)
-    return tuple((pad_size[2 * i], pad_size[2 * i + 1]) for i in range(len(pad_size) // 2))
-
-
-def smart_normalize(volume: np.ndarray, mode: str, divide_value: Optional[float] = None, clip_percentile_low: float = 0.0,
-                    clip_percentile_high: float = 1.0) -> np.ndarray:
-    """augment_ops.py:552-611: optional percentile clipping, then 'none' | 'normal' (z-score) | '0-1' | 'divide' | 'divide-K'."""
-    if mode.startswith("divide-"):
-        try:
-            divide_value = float(mode.split("-", 1)[1])
-        except ValueError as exc:
-            raise ValueError(f"Invalid divide mode '{mode}'. Format should be 'divide-K' where K is a number "
-                             "(e.g., 'divide-255').") from exc
-        mode = "divide"
-    volume = volume.copy()
-    if clip_percentile_low > 0.0 or clip_percentile_high < 1.0:
-        lo = np.percentile(volume, clip_percentile_low * 100)
-        hi = np.percentile(volume, clip_percentile_high * 100)
-        volume = np.clip(volume, lo, hi)
-    if mode == "none":
-        pass
-    elif mode == "normal":
-        mean, std = volume.mean(), volume.std()
-        if std > 1e-8:
-            volume = (volume - mean) / std
-    elif mode == "0-1":
-        lo, hi = volume.min(), volume.max()
-        if hi > lo:
-            volume = (volume - lo) / (hi - lo)
-    elif mode == "divide":
-        if divide_value is None or float(divide_value) == 0.0:
-            raise ValueError("smart_normalize mode='divide' requires a non-zero divide_value (or use 'divide-K' form to embed "
-                             "the divisor in the mode string).")
-        volume = volume / float(divide_value)
-    else:
-        raise ValueError(f"Unknown smart_normalize mode '{mode}'. Expected 'none', 'normal', '0-1', 'divide', or 'divide-K'.")
-    return volume
-
-
-# ------------------------------------------------------------------------------------------------ zarr v2 (read only)
-class ZarrV2Array:
-    """Minimal zarr v2 array reader (directory store, C order, '.'/'/' chunk keys; compressor None / zlib / gzip / bz2 /
-    lzma).  zarr / numcodecs are not part of the image; blosc- or zstd-compressed stores need them and raise."""
-
-    def __init__(self, path: str):
-        p = str(path)
-        i = p.index(".zarr") + len(".zarr")
-        root, sub = Path(p[:i]), p[i:].strip("/")
-        self.root = root / sub if sub else root
-        meta_file = self.root / ".zarray"
-        if not meta_file.exists():
-            keys = sorted(q.name for q in self.root.iterdir() if (q / ".zarray").exists()) if self.root.is_dir() else []
-            if not keys:
-                raise FileNotFoundError(f"{self.root}: no .zarray (zarr v2 array) found")
-            self.root = self.root / keys[0]
-            meta_file = self.root / ".zarray"
-        meta = json.loads(meta_file.read_text())
-        if meta.get("zarr_format") != 2:
-            raise ValueError(f"{self.root}: only zarr v2 is supported, got format {meta.get('zarr_format')}")
-        if meta.get("order", "C") != "C" or meta.get("filters"):
-            raise NotImplementedError(f"{self.root}: zarr arrays with order='F' or filters are not supported")
-        self.shape = tuple(int(v) for v in meta["shape"])
-        self.chunks = tuple(int(v) for v in meta["chunks"])
-        self.dtype = np.dtype(meta["dtype"])
-        self.fill = meta.get("fill_value") or 0
-        self.sep = meta.get("dimension_separator", ".")
-        comp = meta.get("compressor")
-        self.codec = None if comp is None else str(comp.get("id"))
-        if self.codec not in (None, "zlib", "gzip", "bz2", "lzma"):
-            raise NotImplementedError(f"{self.root}: zarr compressor {self.codec!r} needs numcodecs (not in this image); "
-                                      "re-encode with zlib / gzip or use HDF5")
-
-    def _decode(self, raw: bytes) -> bytes:
-        if self.codec is None:
-            return raw
-        if self.codec == "zlib":
-            import zlib
-            return zlib.decompress(raw)
-        if self.codec == "gzip":
-            import gzip
-            return gzip.decompress(raw)
-        if self.codec == "bz2":
-            import bz2
-            return bz2.decompress(raw)
-        import lzma
-        return lzma.decompress(raw)
-
-    def _chunk(self, idx) -> np.ndarray:
-        f = self.root / self.sep.join(str(i) for i in idx)
-        if not f.exists():
-            return np.full(self.chunks, self.fill, dtype=self.dtype)
-        return np.frombuffer(self._decode(f.read_bytes()), dtype=self.dtype).reshape(self.chunks)
-
-    def __getitem__(self, key) -> np.ndarray:
-        if not isinstance(key, tuple):
-            key = (key,)
-        key = key + (slice(None),) * (len(self.shape) - len(key))
-        lo, hi = [], []
-        for k, n in zip(key, self.shape):
-            s, e, st = k.indices(n)
-            if st != 1:
-                raise NotImplementedError("unit-step slices only")
-            lo.append(s); hi.append(max(s, e))
-        out = np.empty([h - l for l, h in zip(lo, hi)], dtype=self.dtype)
-        if out.size == 0:
-            return out
-        ranges = [range(l // c, (h - 1) // c + 1) for l, h, c in zip(lo, hi, self.chunks)]
-        import itertools
-        for cidx in itertools.product(*ranges):
-            chunk = self._chunk(cidx)
-            src, dst = [], []
-            for a, ci in enumerate(cidx):
-                c0 = ci * self.chunks[a]
-                s, e = max(lo[a], c0), min(hi[a], c0 + self.chunks[a], self.shape[a])
-                src.append(slice(s - c0, e - c0)); dst.append(slice(s - lo[a], e - lo[a]))
-            out[tuple(dst)] = chunk[tuple(src)]
-        return out
+    def to_device(self, device, non_blocking: bool = True) -> torch.Tensor:
+        dev = torch.device(device)
+        ops.require_device(dev, "LazyVolumeAccessor")
+        if self.raw is None:                                   # the whole box lies in a constant context pad
+            return torch.zeros(self.shape, dtype=torch.float32, device=dev)
+        i0, i1, f = (t.to(dev, non_blocking=non_blocking) for t in self.tables)
+        return ops.resample_region(self.raw.to(dev, non_blocking=non_blocking), self.raw_dtype, self.strides, self.channels,
+                                   i0, i1, f, self.dims)
 
 
 # ------------------------------------------------------------------------------------------------ the accessor
 class LazyVolumeAccessor:
-    """Random-access reader that reproduces the relevant test-time transforms lazily (reference lazy.py:456-917)."""
+    """Random access to the test volume as the model sees it (channel-first, transposed, resized, context-padded), computed on
+    the device from raw storage boxes.  Attribute names follow the reference class so configuration code reads alike."""
+
+    ndim = 4
 
     def __init__(self, path: str, *, kind: str, transpose_axes: Sequence[int] = (), scale_factors=None, context_pad=None,
                  context_pad_mode: str = "constant", normalize_mode: str = "none", clip_percentile_low: float = 0.0,
-                 clip_percentile_high: float = 1.0, binarize: bool = False, threshold: float = 0.0, tile_read_workers: int = 1):
-        self.path = str(path)
-        self.kind = kind
+                 clip_percentile_high: float = 1.0, binarize: bool = False, threshold: float = 0.0, tile_read_workers: int = 1,
+                 device=None):
+        self.path, self.kind = str(path), kind
         self.tile_read_workers = max(1, int(tile_read_workers))
-        self.fmt = _detect_format(self.path)
-        self.transpose_axes = _normalize_transpose_axes(transpose_axes)
-        self.inverse_transpose_axes = _invert_transpose_axes(self.transpose_axes)
+        axes = tuple(int(a) for a in (transpose_axes or ()))
+        if axes and (len(axes) != 3 or sorted(axes) != [0, 1, 2]):
+            raise ValueError(f"transpose_axes must be a permutation of [0,1,2], got {transpose_axes}")
+        self.transpose_axes = axes
         self.scale_factors = tuple(float(v) for v in scale_factors) if scale_factors is not None else None
-        self.context_pad = tuple(tuple(int(v) for v in p) for p in (context_pad or ((0, 0), (0, 0), (0, 0))))
+        self.context_pad = tuple(tuple(int(v) for v in p) for p in (context_pad or ((0, 0),) * 3))
         self.context_pad_mode = context_pad_mode
         self.normalize_mode = normalize_mode
-        self.clip_percentile_low = float(clip_percentile_low)
-        self.clip_percentile_high = float(clip_percentile_high)
-        self.binarize = bool(binarize)
-        self.threshold = float(threshold)
-        self._handle = None
-        self._dataset = None
-        self._open_handle()
-        self.raw_shape = tuple(int(v) for v in self._dataset.shape)
-        self.layout = self._infer_layout(self.raw_shape)
-        self.channel_count, self.raw_spatial_shape = self._resolve_channel_and_spatial_shape(self.raw_shape, self.layout)
-        self.logical_spatial_shape = self._transpose_shape(self.raw_spatial_shape)
-        self.transformed_spatial_shape = tuple(
-            _scaled_length(s, f) for s, f in zip(self.logical_spatial_shape, self.scale_factors or (1.0,) * 3))
-        self.padded_spatial_shape = tuple(self.transformed_spatial_shape[a] + self.context_pad[a][0] + self.context_pad[a][1]
-                                          for a in range(3))
+        self.clip_percentile_low, self.clip_percentile_high = float(clip_percentile_low), float(clip_percentile_high)
+        self.binarize, self.threshold = bool(binarize), float(threshold)
+        self.device = device
+        self._norm_code, self._divisor = self._parse_normalize(normalize_mode) if kind == "image" else (nat.NORM_NONE, 1.0)
+        self.source = VolumeSource(self.path)
+        self.fmt = self.source.fmt
+        self.channel_count = self.source.channels
+        self.raw_spatial_shape = self.source.spatial_shape
+        self._stored_axis = axes or (0, 1, 2)                  # logical axis a is stored along spatial axis _stored_axis[a]
+        self.logical_spatial_shape = tuple(self.raw_spatial_shape[s] for s in self._stored_axis)
+        linear = kind not in {"label", "mask"}
+        mode = _pad_mode_name(context_pad_mode)
+        self.axes = tuple(AxisMap(stored=self.logical_spatial_shape[a],
+                                  resized=_resized_length(self.logical_spatial_shape[a], (self.scale_factors or (1.0,) * 3)[a]),
+                                  pad=self.context_pad[a], pad_mode=mode, linear=linear, resizes=self.scale_factors is not None)
+                          for a in range(3))
+        self.transformed_spatial_shape = tuple(ax.resized for ax in self.axes)
+        self.padded_spatial_shape = tuple(ax.length for ax in self.axes)
 
-    # ---- handles
-    def _open_handle(self) -> None:
-        if self.fmt == "h5":
-            be = get_h5_backend()
-            if be is None:
-                raise RuntimeError(f"{self.path}: HDF5 needs h5py or the in-repo libpytc_h5.so (csrc/host/h5io.c); neither loads")
-            self._handle = be.File(self.path, "r")
-            self._dataset = self._handle[list(self._handle.keys())[0]]
-        elif self.fmt == "zarr":
-            self._dataset = ZarrV2Array(self.path)
-        elif self.fmt == "npy":
-            self._dataset = np.load(self.path, mmap_mode="r")
-        elif self.fmt == "tiff":
-            from ..utils.tiffstack import TiffStack
-            self._handle = self._dataset = TiffStack(self.path)          # page-range reads (reference lazy.py:639-676)
-            if self._dataset.ndim == 2:
-                raise ValueError(f"{self.path}: a single-page TIFF is not a volume")
-        else:
-            raise ValueError(f"Lazy sliding-window inference does not support format '{self.fmt}' for {self.path}.")
+    @staticmethod
+    def _parse_normalize(mode: str):
+        if mode.startswith("divide-"):
+            try:
+                return nat.NORM_DIVIDE, float(mode.split("-", 1)[1])
+            except ValueError as exc:
+                raise ValueError(f"Invalid divide mode '{mode}'. Format should be 'divide-K' where K is a number "
+                                 "(e.g., 'divide-255').") from exc
+        if mode == "divide":
+            raise ValueError("smart_normalize mode='divide' requires a non-zero divide_value (or use 'divide-K' form to embed "
+                             "the divisor in the mode string).")
+        if mode not in _NORM_CODES:
+            raise ValueError(f"Unknown smart_normalize mode '{mode}'. Expected 'none', 'normal', '0-1', 'divide', or 'divide-K'.")
+        return _NORM_CODES[mode], 1.0
 
+    # ---- life cycle
     def close(self) -> None:
-        if self._handle is not None and hasattr(self._handle, "close"):
-            self._handle.close()
-        self._handle = None
-        self._dataset = None
+        if self.source is not None:
+            self.source.close()
 
     def __enter__(self):
         return self
@@ -318,212 +189,186 @@ class LazyVolumeAccessor:
     def __exit__(self, *exc):
         self.close()
 
-    # ---- geometry
-    @staticmethod
-    def _infer_layout(shape) -> str:
-        if len(shape) == 3:
-            return "no_channel"
-        if len(shape) != 4:
-            raise ValueError(f"Unsupported lazy volume rank {len(shape)} for shape {shape}.")
-        m = int(np.argmin(shape))
-        return {0: "channel_first", 3: "channel_last", 1: "channel_second"}.get(m, "channel_first")
-
-    @staticmethod
-    def _resolve_channel_and_spatial_shape(shape, layout: str):
-        if layout == "no_channel":
-            return 1, tuple(int(v) for v in shape)
-        if layout == "channel_first":
-            return int(shape[0]), tuple(int(v) for v in shape[1:])
-        if layout == "channel_last":
-            return int(shape[-1]), tuple(int(v) for v in shape[:3])
-        if layout == "channel_second":
-            return int(shape[1]), (int(shape[0]), int(shape[2]), int(shape[3]))
-        raise ValueError(f"Unknown layout: {layout}")
-
-    def _transpose_shape(self, shape):
-        return tuple(int(v) for v in shape) if not self.transpose_axes else tuple(int(shape[i]) for i in self.transpose_axes)
-
-    def _logical_to_raw_slices(self, lo, hi):
-        if not self.transpose_axes:
-            return tuple(slice(int(lo[i]), int(hi[i])) for i in range(3))
-        return tuple(slice(int(lo[self.inverse_transpose_axes[r]]), int(hi[self.inverse_transpose_axes[r]])) for r in range(3))
-
-    # ---- raw reads
-    def _read_raw_crop(self, lo, hi) -> np.ndarray:
-        z, y, x = self._logical_to_raw_slices(lo, hi)
-        ds, t = self._dataset, self.transpose_axes
-        if self.layout == "no_channel":
-            data = np.asarray(ds[(z, y, x)])
-            return (np.transpose(data, t) if t else data)[np.newaxis]
-        if self.layout == "channel_first":
-            data = np.asarray(ds[(slice(None), z, y, x)])
-            return np.transpose(data, [0, *[a + 1 for a in t]]) if t else data
-        if self.layout == "channel_last":
-            data = np.asarray(ds[(z, y, x, slice(None))])
-            if t:
-                data = np.transpose(data, [*t, 3])
-            return np.moveaxis(data, -1, 0)
-        data = np.asarray(ds[(z, slice(None), y, x)])                      # channel_second
-        return np.transpose(data, [1, 0, *[a + 2 for a in t]]) if t else np.transpose(data, (1, 0, 2, 3))
-
-    def _read_transformed_bbox(self, start, end, *, mode: str, align_corners) -> np.ndarray:
-        shape = tuple(int(end[i]) - int(start[i]) for i in range(3))
-        if any(s <= 0 for s in shape):
-            return np.zeros((self.channel_count, *shape), dtype=np.float32)
-        if not self.scale_factors:
-            return self._read_raw_crop(start, end).astype(np.float32, copy=False)
-        coords = [_output_indices_to_input_coords(int(start[i]), int(end[i]), input_size=int(self.logical_spatial_shape[i]),
-                                                  output_size=int(self.transformed_spatial_shape[i]), mode=mode,
-                                                  align_corners=align_corners) for i in range(3)]
-        raw_lo = tuple(int(math.floor(float(c.min()))) for c in coords)
-        raw_hi = tuple(min(int(self.logical_spatial_shape[i]), int(math.ceil(float(coords[i].max()))) + 1) for i in range(3))
-        raw = self._read_raw_crop(raw_lo, raw_hi).astype(np.float32, copy=False)
-        local = [coords[i] - float(raw_lo[i]) for i in range(3)]
-        if mode == "nearest":
-            li = [c.astype(np.int64, copy=False) for c in local]
-            g = np.take(np.take(np.take(raw, li[0], axis=1), li[1], axis=2), li[2], axis=3)
-            return g.astype(np.float32, copy=False)
-        ga = [_normalize_grid_axis(local[i], int(raw.shape[i + 1])) for i in range(3)]
-        zz, yy, xx = np.meshgrid(ga[0], ga[1], ga[2], indexing="ij")
-        grid = torch.from_numpy(np.stack([xx, yy, zz], axis=-1)).unsqueeze(0)
-        out = F.grid_sample(torch.from_numpy(np.ascontiguousarray(raw)).unsqueeze(0), grid, mode="bilinear", padding_mode="zeros",
-                            align_corners=True)
-        return out.squeeze(0).numpy().astype(np.float32, copy=False)
-
-    def _read_padded_inner_region(self, inner_start, inner_end, *, mode: str, align_corners) -> np.ndarray:
-        mapped, valid, b0, b1 = [], [], [], []
-        pm = _normalize_pad_mode(self.context_pad_mode)
-        for a in range(3):
-            un = np.arange(int(inner_start[a]), int(inner_end[a]), dtype=np.int64) - int(self.context_pad[a][0])
-            size = int(self.transformed_spatial_shape[a])
-            if pm == "constant":
-                v, m = (un >= 0) & (un < size), np.clip(un, 0, max(size - 1, 0))
-            elif pm == "reflect":
-                v, m = np.ones_like(un, dtype=bool), _reflect_indices(un, size)
-            elif pm == "edge":
-                v, m = np.ones_like(un, dtype=bool), np.clip(un, 0, max(size - 1, 0))
-            else:
-                raise ValueError(f"Unsupported context pad mode '{self.context_pad_mode}'.")
-            mapped.append(m); valid.append(v)
-            b0.append(int(m.min()) if m.size else 0); b1.append(int(m.max()) + 1 if m.size else 0)
-        region = self._read_transformed_bbox(b0, b1, mode=mode, align_corners=align_corners)
-        li = [mapped[a] - b0[a] for a in range(3)]
-        g = np.take(np.take(np.take(region, li[0], axis=1), li[1], axis=2), li[2], axis=3)
-        if pm == "constant":
-            mask = valid[0][:, None, None] & valid[1][None, :, None] & valid[2][None, None, :]
-            g = g * mask[None].astype(g.dtype, copy=False)
-        return g
-
-    def _interp(self):
-        mode = "nearest" if self.kind in {"label", "mask"} else "bilinear"
-        return mode, (None if mode == "nearest" else True)
-
-    # ---- public reads
-    @property
-    def needs_per_patch_host_path(self) -> bool:
-        """True when a window's values depend on statistics of THAT window (z-score / min-max / percentile clipping): such
-        windows are read one by one on the host like the reference does; pointwise modes commute with the device gather."""
-        if self.kind != "image":
-            return False
-        if self.clip_percentile_low > 0.0 or self.clip_percentile_high < 1.0:
-            return True
-        return self.normalize_mode in ("normal", "0-1")
-
-    def read_patch(self, location, patch_size, *, outer_pad_mode: str, outer_pad_value: float) -> np.ndarray:
-        """(C, *patch_size) fp32 window at `location` of the padded, transformed volume (lazy.py:852-904)."""
-        start = tuple(int(v) for v in location)
-        size = tuple(int(v) for v in patch_size)
-        end = tuple(start[i] + size[i] for i in range(3))
-        istart = tuple(max(0, start[i]) for i in range(3))
-        iend = tuple(min(int(self.padded_spatial_shape[i]), end[i]) for i in range(3))
-        if any(iend[i] <= istart[i] for i in range(3)):
-            inner = np.zeros((self.channel_count, 0, 0, 0), dtype=np.float32)
-        else:
-            mode, ac = self._interp()
-            inner = self._read_padded_inner_region(istart, iend, mode=mode, align_corners=ac)
-        pads = [(max(0, -start[a]), max(0, end[a] - int(self.padded_spatial_shape[a]))) for a in range(3)]
-        patch = _pad_channel_first(inner, pads, mode=outer_pad_mode, constant_value=outer_pad_value)
-        return self._finish(patch)
-
-    def _finish(self, patch: np.ndarray) -> np.ndarray:
-        if self.binarize:
-            patch = (patch > self.threshold).astype(np.float32, copy=False)
-        if self.kind == "image" and self.normalize_mode != "none":
-            patch = smart_normalize(patch, self.normalize_mode, divide_value=None, clip_percentile_low=self.clip_percentile_low,
-                                    clip_percentile_high=self.clip_percentile_high).astype(np.float32, copy=False)
-        return patch.astype(np.float32, copy=False)
-
-    def read_region(self, start, stop) -> np.ndarray:
-        """(C, *(stop-start)) fp32 box of the padded, transformed volume, clipped to it, with the POINTWISE part of the
-        pipeline applied (binarise, 'divide-K'); the box a chunk's windows are gathered from on the device."""
-        if self.needs_per_patch_host_path:
-            raise RuntimeError("read_region: per-patch normalisation statistics need read_patch")
-        lo = tuple(max(0, int(v)) for v in start)
-        hi = tuple(min(int(self.padded_spatial_shape[a]), int(stop[a])) for a in range(3))
-        mode, ac = self._interp()
-        return self._finish(self._read_padded_inner_region(lo, hi, mode=mode, align_corners=ac))
-
-    def load_full(self) -> np.ndarray:
-        mode, ac = self._interp()
-        full = self._read_transformed_bbox((0, 0, 0), self.transformed_spatial_shape, mode=mode, align_corners=ac)
-        if self.binarize:
-            full = (full > self.threshold).astype(np.float32, copy=False)
-        return full.astype(np.float32, copy=False)
-
-    # the window engine reads volumes through `.shape` / slicing: present the padded, transformed volume that way
     @property
     def shape(self):
         return (self.channel_count, *self.padded_spatial_shape)
 
-    ndim = 4
+    # ---- host half: raw bytes + tables
+    def stage_region(self, start: Sequence[int], stop: Sequence[int], *, context: bool = True) -> StagedRegion:
+        """Everything the device needs for box [start, stop) of the padded volume (`context=False`: of the resized volume without
+        its context pad -- `load_full`).  Reads the raw storage box; no arithmetic on the values."""
+        lo, hi = tuple(int(v) for v in start), tuple(int(v) for v in stop)
+        axes = self.axes if context else tuple(AxisMap(ax.stored, ax.resized, (0, 0), "constant", ax.linear, ax.resizes)
+                                               for ax in self.axes)
+        tabs = [axes[a].table(lo[a], hi[a]) for a in range(3)]
+        dims = tuple(hi[a] - lo[a] for a in range(3))
+        used = [t[0] >= 0 for t in tabs]
+        if not all(u.any() for u in used):
+            return StagedRegion((lo, hi), None, str(self.source.dtype), (0, 0, 0, 0), self.channel_count, None, dims)
+        raw_lo = [int(tabs[a][0][used[a]].min()) for a in range(3)]
+        raw_hi = [int(tabs[a][1][used[a]].max()) + 1 for a in range(3)]
+        # storage box: logical axis a lives on stored spatial axis _stored_axis[a]
+        s_lo, s_hi = [0, 0, 0], [0, 0, 0]
+        for a in range(3):
+            s_lo[self._stored_axis[a]], s_hi[self._stored_axis[a]] = raw_lo[a], raw_hi[a]
+        box = self.source.read_box(s_lo, s_hi)
+        strides = box_strides(self.source, box, self._stored_axis)
+        shift = lambda t, a: np.where(t >= 0, t - raw_lo[a], -1).astype(np.int32)      # noqa: E731  box-local indices
+        i0 = torch.from_numpy(np.concatenate([shift(tabs[a][0], a) for a in range(3)]))
+        i1 = torch.from_numpy(np.concatenate([shift(tabs[a][1], a) for a in range(3)]))
+        f = torch.from_numpy(np.concatenate([tabs[a][2] for a in range(3)]))
+        raw = torch.from_numpy(box.reshape(-1).view(np.uint8))
+        return StagedRegion((lo, hi), raw, str(box.dtype), strides, self.channel_count, (i0, i1, f), dims)
+
+    # ---- device half
+    def _device(self, device=None):
+        dev = torch.device(device if device is not None else (self.device if self.device is not None else "cuda"))
+        ops.require_device(dev, "LazyVolumeAccessor")
+        if not torch.cuda.is_available():
+            raise RuntimeError("LazyVolumeAccessor (pytorch_connectomics_amd) needs a CUDA(HIP) device: there is no CPU path")
+        return dev
+
+    @property
+    def needs_window_statistics(self) -> bool:
+        """A window's values depend on statistics of THAT window (z-score, min-max, percentile clipping)."""
+        if self.kind != "image":
+            return False
+        return self._clips or self._norm_code in (nat.NORM_ZSCORE, nat.NORM_MINMAX)
+
+    needs_per_patch_host_path = needs_window_statistics          # the reference-era name; nothing runs on the host any more
+
+    @property
+    def _clips(self) -> bool:
+        return self.kind == "image" and self.normalize_mode != "none" and (self.clip_percentile_low > 0.0 or self.clip_percentile_high < 1.0)
+
+    def finish_windows(self, x: torch.Tensor) -> torch.Tensor:
+        """The per-window tail of the pipeline on a batch of gathered windows x fp32 (B, ...) on the device, in place:
+        binarise (masks), then for images percentile clip + normalisation with each window's own statistics."""
+        norm = self._norm_code if self.kind == "image" else nat.NORM_NONE
+        if not self.binarize and norm == nat.NORM_NONE:
+            return x
+        clip = None
+        if self._clips:
+            if self.binarize:
+                ops.window_normalize(x, binarize=True, threshold=self.threshold)
+            clip = _percentile_bounds(x.reshape(x.shape[0], -1), self.clip_percentile_low, self.clip_percentile_high)
+            return ops.window_normalize(x, mode=norm, divide=self._divisor, clip=clip)
+        return ops.window_normalize(x, mode=norm, binarize=self.binarize, threshold=self.threshold, divide=self._divisor)
+
+    def region_to_device(self, start, stop, device=None) -> torch.Tensor:
+        """fp32 (C, *box) of the padded volume, clipped to it, un-normalised, resident on the device."""
+        lo = tuple(max(0, int(v)) for v in start)
+        hi = tuple(min(int(self.padded_spatial_shape[a]), int(stop[a])) for a in range(3))
+        return self.stage_region(lo, hi).to_device(self._device(device), non_blocking=False)
+
+    # ---- the reference's host-array API (device compute, one copy back)
+    def read_patch(self, location, patch_size, *, outer_pad_mode: str, outer_pad_value: float) -> np.ndarray:
+        """(C, *patch_size) fp32 window at `location` of the padded volume, outer-padded where it overhangs (lazy.py:852-904)."""
+        start = tuple(int(v) for v in location)
+        size = tuple(int(v) for v in patch_size)
+        lo = tuple(max(0, start[a]) for a in range(3))
+        hi = tuple(min(int(self.padded_spatial_shape[a]), start[a] + size[a]) for a in range(3))
+        dev = self._device()
+        if any(hi[a] <= lo[a] for a in range(3)):
+            x = torch.full((1,) + size + (self.channel_count,), float(outer_pad_value), dtype=torch.float32, device=dev)
+        else:
+            inner = self.stage_region(lo, hi).to_device(dev, non_blocking=False)
+            rel = tuple(start[a] - lo[a] for a in range(3))
+            x = ops.gather_windows(inner, [rel], size, pad_mode=_gather_mode(outer_pad_mode), cval=float(outer_pad_value))
+        x = self.finish_windows(x)
+        return x[0].permute(3, 0, 1, 2).contiguous().cpu().numpy()
+
+    def read_region(self, start, stop) -> np.ndarray:
+        """(C, *box) fp32 of the padded volume clipped to it, with the POINTWISE finishing (binarise, divide-K) applied; modes
+        that need window statistics have no region form."""
+        if self.needs_window_statistics:
+            raise RuntimeError("read_region: per-patch normalisation statistics need read_patch")
+        reg = self.region_to_device(start, stop)
+        return self.finish_windows(reg.unsqueeze(0))[0].cpu().numpy()
+
+    def load_full(self) -> np.ndarray:
+        """The whole resized volume without context pad or normalisation (masks binarised), as the reference's `load_full`."""
+        full = self.stage_region((0, 0, 0), self.transformed_spatial_shape, context=False).to_device(self._device(), non_blocking=False)
+        if self.binarize:
+            ops.window_normalize(full.unsqueeze(0), binarize=True, threshold=self.threshold)
+        return full.cpu().numpy()
+
+
+def _gather_mode(mode: str) -> str:
+    m = str(mode).lower()
+    return {"edge": "replicate", "wrap": "circular"}.get(m, m)
+
+
+def _percentile_bounds(flat: torch.Tensor, q_lo: float, q_hi: float) -> torch.Tensor:
+    """np.percentile (linear interpolation) of every window, on the device: (B, n) -> float32 (B, 2).  Order statistics come from a
+    device sort (torch.sort); this is the one step of the pipeline that is not a kernel of this package -- percentile clipping is a
+    rarely used option and needs a selection algorithm, not arithmetic."""
+    n = flat.shape[1]
+    srt = torch.sort(flat, dim=1).values
+    out = []
+    for q in (q_lo, q_hi):
+        pos = float(q) * (n - 1)
+        k = int(math.floor(pos))
+        frac = pos - k
+        a, b = srt[:, k], srt[:, min(k + 1, n - 1)]
+        out.append(a + (b - a) * frac if frac < 0.5 else b - (b - a) * (1.0 - frac))      # numpy's lerp form
+    return torch.stack(out, 1).to(torch.float32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ configuration
+def get_padsize(pad_size, ndim: int = 3):
+    """`pad_size` in any of the config's spellings -> ((before, after),) * ndim: an int, one value, one per axis, or
+    before / after per axis (reference data/processing/misc.py:20-41)."""
+    if isinstance(pad_size, int):
+        return ((pad_size, pad_size),) * ndim
+    values = list(pad_size)
+    if len(values) == 1:
+        return ((values[0], values[0]),) * ndim
+    if len(values) == ndim:
+        return tuple((v, v) for v in values)
+    if len(values) == 2 * ndim:
+        return tuple((values[2 * i], values[2 * i + 1]) for i in range(ndim))
+    raise ValueError(f"pad_size length must be 1, {ndim}, or {2 * ndim}, got {len(values)}")
 
 
 def _resolve_scale_factors(cfg, *, kind: str, mode: str):
-    """lazy.py:420-453."""
-    data_cfg = cfg.data
-    dt = getattr(data_cfg, "data_transform", None)
-    resize_cfg = getattr(dt, "resize", None)
-    patch_size_cfg = getattr(getattr(data_cfg, "dataloader", None), "patch_size", None)
-    if mode in {"test", "tune"} and resize_cfg:
-        if patch_size_cfg and len(patch_size_cfg) == len(resize_cfg) and all(float(v) > 0 for v in patch_size_cfg):
-            return tuple(float(o) / float(i) for o, i in zip(resize_cfg, patch_size_cfg))
+    """Per-axis resize factors of the test volume (reference lazy.py:420-453): `data_transform.resize` relative to the patch size
+    in test / tune mode, else the per-kind `resize` factors."""
+    data = cfg.data
+    shared = getattr(data, "data_transform", None)
+    target = getattr(shared, "resize", None)
+    if mode in {"test", "tune"} and target:
+        patch = getattr(getattr(data, "dataloader", None), "patch_size", None)
+        if patch and len(patch) == len(target) and all(float(v) > 0 for v in patch):
+            return tuple(float(o) / float(i) for o, i in zip(target, patch))
         raise ValueError("Lazy sliding-window inference requires data.dataloader.patch_size when "
                          "data_transform.resize is configured.")
-    if kind in {"image", "label"}:
-        f = getattr(getattr(data_cfg, "image_transform", None), "resize", None)
-        if f:
-            return tuple(float(v) for v in f)
-    if kind == "mask":
-        mask_cfg = getattr(data_cfg, "mask_transform", None) or dt
-        f = getattr(mask_cfg, "resize", None)
-        if f:
-            return tuple(float(v) for v in f)
-    return None
+    holder = {"image": getattr(data, "image_transform", None), "label": getattr(data, "image_transform", None),
+              "mask": getattr(data, "mask_transform", None) or shared}.get(kind)
+    factors = getattr(holder, "resize", None)
+    return tuple(float(v) for v in factors) if factors else None
 
 
-def build_accessor(cfg, path: str, *, kind: str, mode: str = "test") -> LazyVolumeAccessor:
-    """lazy.py:920-959 (`_build_accessor`): the accessor for `path` under the config's test-time transforms."""
-    data_cfg = cfg.data
-    dt = getattr(data_cfg, "data_transform", None)
-    it = getattr(data_cfg, "image_transform", None)
-    pad = get_padsize(getattr(dt, "pad_size", [0, 0, 0]) or [0, 0, 0], ndim=3)
-    norm, lo, hi = "none", 0.0, 1.0
+def build_accessor(cfg, path: str, *, kind: str, mode: str = "test", device=None) -> LazyVolumeAccessor:
+    """The accessor for `path` under the config's test-time transforms (reference lazy.py:920-959)."""
+    data = cfg.data
+    shared = getattr(data, "data_transform", None)
+    image = getattr(data, "image_transform", None)
+    pad = get_padsize(getattr(shared, "pad_size", [0, 0, 0]) or [0, 0, 0], ndim=3)
+    options = dict(normalize_mode="none", clip_percentile_low=0.0, clip_percentile_high=1.0, binarize=False, threshold=0.0)
     if kind == "image":
-        norm = getattr(it, "normalize", "none") or "none"
-        lo = float(getattr(it, "clip_percentile_low", 0.0))
-        hi = float(getattr(it, "clip_percentile_high", 1.0))
-    binarize, threshold = False, 0.0
-    if kind == "mask":
-        mask_cfg = getattr(data_cfg, "mask_transform", None) or dt
-        binarize = bool(getattr(mask_cfg, "binarize", False))
-        threshold = float(getattr(mask_cfg, "threshold", 0.0))
+        options.update(normalize_mode=getattr(image, "normalize", "none") or "none",
+                       clip_percentile_low=float(getattr(image, "clip_percentile_low", 0.0)),
+                       clip_percentile_high=float(getattr(image, "clip_percentile_high", 1.0)))
+    elif kind == "mask":
+        mask = getattr(data, "mask_transform", None) or shared
+        options.update(binarize=bool(getattr(mask, "binarize", False)), threshold=float(getattr(mask, "threshold", 0.0)))
     return LazyVolumeAccessor(
-        path, kind=kind, transpose_axes=getattr(dt, "val_transpose", None) or (),
+        path, kind=kind, transpose_axes=getattr(shared, "val_transpose", None) or (),
         scale_factors=_resolve_scale_factors(cfg, kind=kind, mode=mode),
-        context_pad=pad if kind in {"image", "mask"} else ((0, 0), (0, 0), (0, 0)),
-        context_pad_mode=(getattr(dt, "pad_mode", "reflect") if kind == "image" else "constant"),
-        normalize_mode=norm, clip_percentile_low=lo, clip_percentile_high=hi, binarize=binarize, threshold=threshold,
-        tile_read_workers=max(1, int(getattr(getattr(cfg, "system", None), "num_workers", 1) or 1)))
+        context_pad=pad if kind in {"image", "mask"} else ((0, 0),) * 3,
+        context_pad_mode=getattr(shared, "pad_mode", "reflect") if kind == "image" else "constant",
+        tile_read_workers=max(1, int(getattr(getattr(cfg, "system", None), "num_workers", 1) or 1)), device=device, **options)
 
 
 def load_lazy_volume(cfg, path: str, *, kind: str, mode: str = "test") -> np.ndarray:
@@ -531,49 +376,47 @@ def load_lazy_volume(cfg, path: str, *, kind: str, mode: str = "test") -> np.nda
         return acc.load_full()
 
 
+# ------------------------------------------------------------------------------------------------ read-ahead
 class RegionPrefetcher:
-    """Reads regions of an accessor on an IO thread into pinned host memory, one region ahead of the consumer: while the
-    GPU predicts chunk i the disk read + decompression of chunk i+1 is in flight."""
+    """Stages the regions of an accessor one ahead of the consumer on an IO thread: while the GPU predicts chunk i, the disk read
+    and decompression of chunk i+1's RAW box land in pinned memory (SURVEY section 8 f-4).  `get()` hands over a `StagedRegion`;
+    its `to_device` is one H2D copy of the stored bytes and one kernel."""
 
     def __init__(self, accessor: LazyVolumeAccessor, regions, *, pin: bool = True):
-        self.acc = accessor
-        self.regions = list(regions)
-        self.pin = pin and torch.cuda.is_available()
+        self.acc, self.regions, self.pin = accessor, list(regions), bool(pin)
         self._next = 0
         self._slot = None
-        self._thread: Optional[threading.Thread] = None
         self._err: Optional[BaseException] = None
+        self._thread: Optional[threading.Thread] = None
         self._kick()
 
-    def _read(self, region):
+    def _stage(self, region) -> None:
         try:
-            arr = self.acc.read_region(*region)
-            t = torch.from_numpy(np.ascontiguousarray(arr))
-            self._slot = (region, t.pin_memory() if self.pin else t)
+            lo = tuple(max(0, int(v)) for v in region[0])
+            hi = tuple(min(int(self.acc.padded_spatial_shape[a]), int(region[1][a])) for a in range(3))
+            staged = self.acc.stage_region(lo, hi)
+            self._slot = (region, staged.pin() if self.pin else staged)
         except BaseException as e:      # surfaced by get()
             self._err = e
 
-    def _kick(self):
+    def _kick(self) -> None:
+        self._thread = None
         if self._next < len(self.regions):
-            self._thread = threading.Thread(target=self._read, args=(self.regions[self._next],), name="pytc-region-prefetch",
-                                            daemon=True)
+            self._thread = threading.Thread(target=self._stage, args=(self.regions[self._next],), name="pytc-region-prefetch", daemon=True)
             self._thread.start()
-        else:
-            self._thread = None
 
     def get(self):
-        """-> (region, tensor (C, *box) in pinned memory) of the next region; starts reading the one after it."""
+        """-> (region, StagedRegion) of the next region; starts staging the one after it."""
         if self._thread is None:
             raise StopIteration
         self._thread.join()
         if self._err is not None:
             raise self._err
-        out = self._slot
-        self._slot = None
+        out, self._slot = self._slot, None
         self._next += 1
         self._kick()
         return out
 
 
-__all__ = ["LazyVolumeAccessor", "ZarrV2Array", "build_accessor", "load_lazy_volume", "smart_normalize", "get_padsize",
-           "RegionPrefetcher"]
+__all__ = ["LazyVolumeAccessor", "AxisMap", "StagedRegion", "ZarrV2Array", "build_accessor", "load_lazy_volume", "get_padsize",
+           "RegionPrefetcher", "detect_format"]

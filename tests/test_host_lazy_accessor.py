@@ -1,6 +1,10 @@
-"""CPU parity of the disk-backed volume reader (inference/lazy_accessor.py) against tests/golden/lazy_accessor.npz -- outputs of
-the REFERENCE's LazyVolumeAccessor (connectomics/inference/lazy.py:456-917) reading HDF5 files through the same libhdf5
-(make_golden.py --accessor) -- plus the other sources (.npy memmap, zarr v2 directory) and the region prefetcher."""
+"""CPU half of the disk-backed volume reader (inference/lazy_accessor.py, inference/volume_source.py): the storage back ends
+(HDF5 / .npy / zarr v2 / TIFF raw box reads), the geometry (per-axis index tables) and the staging / read-ahead protocol.
+
+The device half (resample / normalise kernels) cannot run here; the numpy restatement of it, oracle/accessor_oracle.py, executes the
+SAME staged regions and is pinned against tests/golden/lazy_accessor.npz -- outputs of the REFERENCE's LazyVolumeAccessor
+(connectomics/inference/lazy.py:456-917, make_golden.py --accessor).  That pins the host geometry on the CPU; the HIP kernels meet the
+same fixtures in tests/test_gpu_lazy_accessor.py."""
 import itertools
 import json
 import zlib
@@ -9,97 +13,91 @@ from types import SimpleNamespace as NS
 import numpy as np
 import pytest
 
-from pytorch_connectomics_amd.inference.lazy_accessor import (LazyVolumeAccessor, RegionPrefetcher, ZarrV2Array, build_accessor,
-                                                              get_padsize, smart_normalize)
+from oracle import accessor_oracle as AO
+from pytorch_connectomics_amd.inference.lazy_accessor import (AxisMap, LazyVolumeAccessor, RegionPrefetcher, ZarrV2Array,
+                                                              build_accessor, get_padsize)
 from pytorch_connectomics_amd.utils import h5lite
 
-CASES = {
-    "plain": ("zyx", dict(kind="image"), [((0, 0, 0), (6, 7, 8)), ((-2, 3, 12), (6, 8, 10)), ((8, 10, 14), (8, 8, 8))], "reflect", 0.0),
-    "transpose_pad_reflect_div": ("zyx", dict(kind="image", transpose_axes=(2, 0, 1), context_pad=((2, 1), (0, 3), (2, 2)),
-                                              context_pad_mode="reflect", normalize_mode="divide-255"),
-                                  [((0, 0, 0), (8, 8, 8)), ((-3, -1, 5), (10, 9, 12)), ((15, 6, 10), (8, 8, 8))], "constant", 0.25),
-    "resize_bilinear_znorm": ("czyx", dict(kind="image", scale_factors=(1.5, 0.75, 1.25), context_pad=((1, 1), (1, 1), (1, 1)),
-                                           context_pad_mode="constant", normalize_mode="normal", clip_percentile_low=0.05,
-                                           clip_percentile_high=0.95),
-                              [((0, 0, 0), (8, 6, 10)), ((5, 2, 8), (8, 8, 8)), ((-1, -2, 14), (6, 6, 10))], "replicate", 0.0),
-    "channel_last_edge_01": ("zyxc", dict(kind="image", context_pad=((0, 2), (2, 0), (1, 1)), context_pad_mode="edge",
-                                          normalize_mode="0-1"),
-                             [((0, 0, 0), (6, 6, 6)), ((6, 8, 10), (6, 8, 8))], "reflect", 0.0),
-    "mask_nearest_binarize": ("zyx", dict(kind="mask", scale_factors=(0.5, 2.0, 1.0), binarize=True, threshold=100.0),
-                              [((0, 0, 0), (4, 10, 8)), ((2, 20, 10), (4, 8, 8))], "constant", 0.0),
-}
-
-
-def _write_sources(g, tmp_path, key):
-    """the same volume as .h5, .npy and a zlib-compressed zarr v2 directory with ragged edge chunks"""
-    vol = g[f"vol_{key}"]
-    paths = {"npy": str(tmp_path / f"{key}.npy")}
-    np.save(paths["npy"], vol)
-    be = h5lite.get_h5_backend()
-    if be is not None:
-        paths["h5"] = str(tmp_path / f"{key}.h5")
-        with be.File(paths["h5"], "w") as fh:
-            fh.create_dataset("main", data=vol, compression="gzip")
-    zdir = tmp_path / f"{key}.zarr"
-    zdir.mkdir()
-    chunks = tuple(max(1, (s + 2) // 3) for s in vol.shape)
-    (zdir / ".zarray").write_text(json.dumps({"zarr_format": 2, "shape": list(vol.shape), "chunks": list(chunks),
-                                               "dtype": vol.dtype.str, "compressor": {"id": "zlib", "level": 1},
-                                               "fill_value": 0, "order": "C", "filters": None}))
-    for idx in itertools.product(*[range((s + c - 1) // c) for s, c in zip(vol.shape, chunks)]):
-        block = np.zeros(chunks, vol.dtype)
-        sl = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(idx, chunks, vol.shape))
-        block[tuple(slice(0, s.stop - s.start) for s in sl)] = vol[sl]
-        (zdir / ".".join(map(str, idx))).write_bytes(zlib.compress(block.tobytes(), 1))
-    paths["zarr"] = str(zdir)
-    return paths
+from accessor_cases import CASES, _write_sources  # noqa: E402
 
 
 @pytest.mark.parametrize("name", list(CASES))
-def test_accessor_matches_reference_fixture(name, golden_dir, tmp_path):
+def test_staged_regions_reproduce_the_reference_fixture(name, golden_dir, tmp_path):
+    """Every case x every storage back end: shapes, three windows (inner box staged by the accessor, executed by the oracle, outer
+    padding + per-window finishing as in read_patch) and the full volume against the reference accessor's arrays.  Trilinear cases
+    carry fp32 weight rounding (the reference goes through a normalised grid and F.grid_sample): 2e-6 of the value range."""
     g = np.load(golden_dir / "lazy_accessor.npz")
     vk, kw, reads, outer_mode, outer_val = CASES[name]
+    tol = dict(rtol=1e-6, atol=1e-6) if kw.get("kind") == "mask" or "scale_factors" not in kw else dict(rtol=2e-5, atol=6e-4)
     for fmt, path in _write_sources(g, tmp_path, vk).items():
         with LazyVolumeAccessor(path, **kw) as acc:
             shapes = [acc.channel_count, *acc.raw_spatial_shape, *acc.logical_spatial_shape, *acc.transformed_spatial_shape,
                       *acc.padded_spatial_shape]
             assert shapes == list(g[f"{name}__shapes"]), fmt
             for i, (loc, size) in enumerate(reads):
-                got = acc.read_patch(loc, size, outer_pad_mode=outer_mode, outer_pad_value=outer_val)
+                got = AO.read_patch(acc, loc, size, outer_pad_mode=outer_mode, outer_pad_value=outer_val)
                 want = g[f"{name}__patch{i}"]
                 assert got.shape == want.shape and got.dtype == np.float32
-                np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6, err_msg=f"{name} {fmt} patch {i}")
-            np.testing.assert_allclose(acc.load_full(), g[f"{name}__full"], rtol=1e-6, atol=1e-6)
+                np.testing.assert_allclose(got, want, err_msg=f"{name} {fmt} patch {i}", **tol)
+            np.testing.assert_allclose(AO.load_full(acc), g[f"{name}__full"], **tol)
             assert acc.shape == (acc.channel_count, *acc.padded_spatial_shape)
 
 
-def test_read_region_is_the_union_of_its_patches_and_prefetcher(golden_dir, tmp_path):
-    """Pointwise pipelines: a region read once equals what per-window read_patch calls return inside it (the device engine
-    gathers windows from the region); per-patch statistics modes refuse the region path."""
+def test_axis_tables():
+    """AxisMap.table: transpose-free per-axis composition of context pad, resize and storage index."""
+    ax = AxisMap(stored=10, resized=10, pad=(2, 3), pad_mode="reflect", linear=True, resizes=False)
+    i0, i1, f = ax.table(0, ax.length)
+    assert ax.length == 15 and i0.tolist() == [2, 1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 8, 7, 6] and (i1 == i0).all() and not f.any()
+    i0, _i1, _f = AxisMap(10, 10, (2, 1), "constant", True, False).table(0, 13)
+    assert i0.tolist() == [-1, -1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, -1]
+    i0, _i1, _f = AxisMap(4, 4, (3, 3), "edge", True, False).table(0, 10)
+    assert i0.tolist() == [0, 0, 0, 0, 1, 2, 3, 3, 3, 3]
+    # nearest resize 6 -> 9: floor(i * 6 / 9); linear 5 -> 9 (align_corners): c = i * 4 / 8
+    i0, i1, f = AxisMap(6, 9, (0, 0), "constant", False, True).table(0, 9)
+    assert i0.tolist() == [0, 0, 1, 2, 2, 3, 4, 4, 5] and (i1 == i0).all() and not f.any()
+    i0, i1, f = AxisMap(5, 9, (0, 0), "constant", True, True).table(0, 9)
+    assert i0.tolist() == [0, 0, 1, 1, 2, 2, 3, 3, 4] and i1.tolist() == [1, 1, 2, 2, 3, 3, 4, 4, 4]
+    np.testing.assert_allclose(f, [0, .5, 0, .5, 0, .5, 0, .5, 0], atol=1e-7)
+    assert AxisMap(1, 3, (0, 0), "constant", True, True).table(0, 3)[0].tolist() == [0, 0, 0]            # degenerate axis
+    with pytest.raises(ValueError, match="Unsupported context pad mode"):
+        AxisMap(4, 4, (1, 1), "wrap", True, False).table(0, 6)
+
+
+def test_staging_moves_raw_bytes_only_and_prefetcher(golden_dir, tmp_path):
+    """A staged region holds the STORED dtype (uint8 here: a quarter of the fp32 bytes), the transpose is a stride permutation, a
+    region equals the union of its windows, and the prefetcher hands regions over in order."""
     g = np.load(golden_dir / "lazy_accessor.npz")
-    path = _write_sources(g, tmp_path, "zyx")["npy"]
+    vol = (g["vol_zyx"] % 251).astype(np.uint8)
+    np.save(tmp_path / "u8.npy", vol)
     kw = dict(kind="image", transpose_axes=(2, 0, 1), context_pad=((2, 1), (0, 3), (2, 2)), context_pad_mode="reflect",
               normalize_mode="divide-255")
-    with LazyVolumeAccessor(path, **kw) as acc:
-        assert not acc.needs_per_patch_host_path
-        reg = acc.read_region((3, 2, 4), (15, 12, 16))
-        assert reg.shape == (1, 12, 10, 12)
-        p = acc.read_patch((5, 4, 6), (6, 6, 8), outer_pad_mode="constant", outer_pad_value=0.0)
-        np.testing.assert_array_equal(reg[:, 2:8, 2:8, 2:10], p)
-        clipped = acc.read_region((-4, 0, 0), (4, 100, 5))                 # clipped to the padded volume
-        assert clipped.shape == (1, 4, acc.padded_spatial_shape[1], 5)
+    with LazyVolumeAccessor(str(tmp_path / "u8.npy"), **kw) as acc:
+        assert not acc.needs_window_statistics
+        st = acc.stage_region((3, 2, 4), (15, 12, 16))
+        assert st.raw.dtype.is_floating_point is False and st.raw_dtype == "uint8" and st.shape == (1, 12, 10, 12)
+        assert st.raw.numel() <= vol.size                             # raw box bytes, not fp32
+        reg = AO.execute_staged(st)
+        ref = np.pad(vol.transpose(2, 0, 1).astype(np.float32), ((2, 1), (0, 3), (2, 2)), mode="reflect")
+        np.testing.assert_array_equal(reg[0], ref[3:15, 2:12, 4:16])
+        p = AO.read_patch(acc, (5, 4, 6), (6, 6, 8), outer_pad_mode="constant", outer_pad_value=0.0)
+        np.testing.assert_array_equal(p[0], ref[5:11, 4:10, 6:14] / np.float32(255))
+        empty = acc.stage_region((0, 0, 0), (2, 4, 4))                # fully inside the reflect pad: still real data
+        assert empty.raw is not None
         regions = [((0, 0, 0), (8, 8, 8)), ((8, 0, 0), (16, 8, 8)), ((4, 4, 4), (12, 12, 12))]
         pf = RegionPrefetcher(acc, regions, pin=False)
         for r in regions:
-            rr, t = pf.get()
+            rr, staged = pf.get()
             assert rr == r
-            np.testing.assert_array_equal(t.numpy(), acc.read_region(*r))
+            np.testing.assert_array_equal(AO.execute_staged(staged)[0], ref[tuple(slice(a, b) for a, b in zip(*r))])
         with pytest.raises(StopIteration):
             pf.get()
-    with LazyVolumeAccessor(path, kind="image", normalize_mode="normal") as acc:
-        assert acc.needs_per_patch_host_path
-        with pytest.raises(RuntimeError, match="read_patch"):
-            acc.read_region((0, 0, 0), (4, 4, 4))
+    with LazyVolumeAccessor(str(tmp_path / "u8.npy"), kind="image", context_pad=((4, 4),) * 3, context_pad_mode="constant") as acc:
+        assert acc.stage_region((0, 0, 0), (3, 8, 8)).raw is None                   # entirely inside the constant pad: nothing is read
+    with LazyVolumeAccessor(str(tmp_path / "u8.npy"), kind="image", normalize_mode="normal") as acc:
+        assert acc.needs_window_statistics
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        with LazyVolumeAccessor(str(tmp_path / "u8.npy"), kind="image") as acc:
+            acc.read_patch((0, 0, 0), (4, 4, 4), outer_pad_mode="constant", outer_pad_value=0.0)      # device compute only
 
 
 def test_build_accessor_from_config_and_helpers(tmp_path):
@@ -113,7 +111,7 @@ def test_build_accessor_from_config_and_helpers(tmp_path):
     with build_accessor(cfg, str(tmp_path / "v.npy"), kind="image") as acc:
         assert acc.transpose_axes == (0, 2, 1) and acc.context_pad == ((2, 2), (0, 0), (1, 1))
         assert acc.padded_spatial_shape == (13, 11, 12) and acc.normalize_mode == "divide-255"
-        p = acc.read_patch((2, 0, 1), (4, 4, 4), outer_pad_mode="constant", outer_pad_value=0.0)
+        p = AO.read_patch(acc, (2, 0, 1), (4, 4, 4), outer_pad_mode="constant", outer_pad_value=0.0)
         np.testing.assert_allclose(p[0], vol.transpose(0, 2, 1)[0:4, 0:4, 0:4].astype(np.float32) / 255.0, rtol=1e-6)
     with build_accessor(cfg, str(tmp_path / "v.npy"), kind="label") as acc:           # labels: no context pad, no normalisation
         assert acc.context_pad == ((0, 0), (0, 0), (0, 0)) and acc.normalize_mode == "none"
@@ -126,11 +124,10 @@ def test_build_accessor_from_config_and_helpers(tmp_path):
     assert get_padsize(3) == ((3, 3),) * 3 and get_padsize([1, 2, 3, 4, 5, 6]) == ((1, 2), (3, 4), (5, 6))
     with pytest.raises(ValueError):
         get_padsize([1, 2])
-    x = np.linspace(-1, 3, 50, dtype=np.float32)
-    np.testing.assert_allclose(smart_normalize(x, "divide-4"), x / 4)
-    assert abs(float(smart_normalize(x, "normal").std()) - 1.0) < 1e-5 and float(smart_normalize(x, "0-1").max()) == 1.0
     with pytest.raises(ValueError, match="Unknown smart_normalize"):
-        smart_normalize(x, "zscore")
+        LazyVolumeAccessor(str(tmp_path / "v.npy"), kind="image", normalize_mode="zscore")
+    with pytest.raises(ValueError, match="Invalid divide mode"):
+        LazyVolumeAccessor(str(tmp_path / "v.npy"), kind="image", normalize_mode="divide-x")
     with pytest.raises(ValueError, match="Unrecognizable file format"):
         LazyVolumeAccessor(str(tmp_path / "v.raw"), kind="image")
 
@@ -178,9 +175,10 @@ def test_tiff_stack_reader_and_accessor(tmp_path, dtype, compression):
               normalize_mode="divide-255")
     with LazyVolumeAccessor(str(path), **kw) as a, LazyVolumeAccessor(str(tmp_path / "stack.npy"), **kw) as b:
         assert a.fmt == "tiff" and a.padded_spatial_shape == b.padded_spatial_shape
-        np.testing.assert_array_equal(a.read_region((0, 0, 0), a.padded_spatial_shape), b.read_region((0, 0, 0), b.padded_spatial_shape))
-        pa = a.read_patch((3, 2, 1), (6, 4, 8), outer_pad_mode="constant", outer_pad_value=0.0)
-        np.testing.assert_array_equal(pa, b.read_patch((3, 2, 1), (6, 4, 8), outer_pad_mode="constant", outer_pad_value=0.0))
+        full = ((0, 0, 0), a.padded_spatial_shape)
+        np.testing.assert_array_equal(AO.execute_staged(a.stage_region(*full)), AO.execute_staged(b.stage_region(*full)))
+        pa = AO.read_patch(a, (3, 2, 1), (6, 4, 8), outer_pad_mode="constant", outer_pad_value=0.0)
+        np.testing.assert_array_equal(pa, AO.read_patch(b, (3, 2, 1), (6, 4, 8), outer_pad_mode="constant", outer_pad_value=0.0))
     one = tmp_path / "one.tif"
     Image.fromarray(vol[0]).save(one)
     assert tiff_volume_shape(str(one)) == vol.shape[1:]
