@@ -470,6 +470,7 @@ constexpr int MARCH_CG = 32;
 struct DwMarch {
   int N, D, H, W, C;
   int ty, tx, zc, nzc;   // footprints per axis, z-chunk length, z-chunks
+  int tilex;             // x extent of a footprint (8, or 16 for the 512-thread forward variant)
   int slots;             // workgroups per (sample, channel group)
   int swizzle;           // XCD-aware block remap on/off
 };
@@ -485,24 +486,29 @@ struct DwMarch {
 // 340 us as scheduled -- so this removes ~40 % of its issue cycles; the input plane and the taps live in LDS as f16 (half the
 // bytes per read).  Error budget: the bf16 inputs are exact in f16 (8 -> 11 mantissa bits), a 9-term f16 partial sum carries
 // ~sqrt(9) * 2^-12 = 7e-4 relative error, below the 2^-9 rounding of the bf16 result; the z direction stays in fp32.
-template <typename T, int VEC, int PF, bool ASYNC, int WPS = 2, bool RES = false, bool H16 = false>
-__global__ void __launch_bounds__(256, WPS)
+// TX / NT: x extent of the footprint and threads per workgroup.  8 / 256 is the original shape; 16 / 512 (two 8 x 8 sub-tiles staged
+// as ONE 10 x 18 haloed plane, same work and registers per thread) shares the halo columns between the sub-tiles inside the
+// workgroup instead of hoping for an L2 hit: x-halo traffic 10/8 -> 18/16, and a row segment of 18 voxels touches 10 cache
+// lines for 8 useful ones where two 10-voxel segments touch 12.
+template <typename T, int VEC, int PF, bool ASYNC, int WPS = 2, bool RES = false, bool H16 = false, int TX = 8, int NT = 256>
+__global__ void __launch_bounds__(NT, WPS)
 dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ w,
                          const float* __restrict__ bias, float* __restrict__ stats, DwMarch g,
                          const T* __restrict__ res = nullptr) {
   // VEC channels per lane (4: ds_read_b128, 108 weight registers; 2: ds_read_b64, 54 weight registers ->
   // more resident workgroups).  PF = planes of global loads kept in flight (register staged).
-  constexpr int CG = MARCH_CG, LPV = CG / VEC, PPP = 256 / LPV, PASSES = (TILE_Y * TILE_X) / PPP;
+  constexpr int TILE_X = TX;
+  constexpr int CG = MARCH_CG, LPV = CG / VEC, PPP = NT / LPV, PASSES = (TILE_Y * TILE_X) / PPP;
   constexpr int EY = TILE_Y + 2, EX = TILE_X + 2;
   constexpr int EPC = 16 / (int)sizeof(T);          // elements per 16-byte chunk
   constexpr int CH16 = CG / EPC;                    // chunks per voxel
   constexpr int NCHUNK = EY * EX * CH16;            // chunks per plane
-  constexpr int CPT = (NCHUNK + 255) / 256;         // chunks per thread
+  constexpr int CPT = (NCHUNK + NT - 1) / NT;       // chunks per thread
   typedef float fvec_t __attribute__((ext_vector_type(VEC)));
   static_assert(!H16 || (sizeof(T) == 2 && VEC == 2), "the packed-f16 tap loop is for bf16 storage, channel pairs");
   typedef typename std::conditional<H16, _Float16, float>::type lds_t;
   __shared__ __attribute__((aligned(16))) lds_t plane[2][EY * EX * CG];
-  __shared__ float red[4][2][CG];
+  __shared__ float red[NT / 64][2][CG];
   // the 27 x CG taps live in LDS, not in 54 registers per lane (lanes of one channel pair read the same address: broadcast)
   __shared__ __attribute__((aligned(16))) lds_t wlds[27 * CG];
 
@@ -532,7 +538,7 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
   bool cok[CPT];
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = tid + 256 * i;
+    const int c = tid + NT * i;
     const int vox = c / CH16, part = c % CH16;
     const int yy = vox / EX, xx = vox % EX;
     const int gy = y0 - 1 + yy, gx = x0 - 1 + xx;
@@ -601,7 +607,7 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
   // ---- per-thread weights (27 taps x VEC channels), bias, positions
   const int cv = tid % LPV, pslot = tid / LPV;
   const int c0 = cg * CG + cv * VEC;
-  for (int i = tid; i < 27 * CG; i += 256) wlds[i] = (lds_t)w[(long)(i / CG) * C + cg * CG + (i % CG)];
+  for (int i = tid; i < 27 * CG; i += NT) wlds[i] = (lds_t)w[(long)(i / CG) * C + cg * CG + (i % CG)];
   // (visible after the __syncthreads() that follows the prologue's first commit)
   float bv[VEC];
 #pragma unroll
@@ -830,7 +836,7 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
       const int which = tid / CG, ch = tid % CG;
       float a = 0.f;
 #pragma unroll
-      for (int wv = 0; wv < 4; ++wv) a += red[wv][which][ch];
+      for (int wv = 0; wv < NT / 64; ++wv) a += red[wv][which][ch];
       stats[(((long)n * g.slots + slot_id) * 2 + which) * C + cg * CG + ch] = a;
     }
   }
@@ -842,9 +848,15 @@ static bool march_ok(int D, int H, int W, int C, int K, int stride, int dtype, i
   return D >= 8 && H >= 16 && W >= 16 && (long)H * W * C < (1L << 30);
 }
 
-static void make_march(DwMarch& t, int N, int D, int H, int W, int C) {
+// the forward kernel's footprint: 8 x 16 where the rows divide into whole 16-voxel tiles (level 0: W = 112), 8 x 8 otherwise
+static int march_tile_x(int W, int dtype) {
+  return (dtype == PYTC_BF16 && W % 16 == 0 && tuning_get("dwconv_march_tx16", 0) != 0) ? 16 : TILE_X;
+}
+
+static void make_march(DwMarch& t, int N, int D, int H, int W, int C, int tilex = TILE_X) {
   t.N = N; t.D = D; t.H = H; t.W = W; t.C = C;
-  t.ty = (H + TILE_Y - 1) / TILE_Y; t.tx = (W + TILE_X - 1) / TILE_X;
+  t.tilex = tilex;
+  t.ty = (H + TILE_Y - 1) / TILE_Y; t.tx = (W + tilex - 1) / tilex;
   // z-chunks: enough workgroups PER SAMPLE to fill the chip (>= 1024: 4 per CU at batch 1), chunks >= 14 planes (halo <= 14 %).
   // The split must not depend on N: the statistics partials (one per workgroup) are summed in slot order, so a sample's
   // mean / rstd -- and with them its bf16 prediction -- would otherwise change with the batch it happens to travel in
@@ -1272,10 +1284,14 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
   PYTC_REQUIRE(N >= 1 && D >= 1 && H >= 1 && W >= 1 && C >= 1, "dwconv3d: bad shape");
   PYTC_REQUIRE(stride == 1 || stride == 2, "dwconv3d: stride must be 1 or 2");
   PYTC_REQUIRE(dtype == PYTC_F32 || dtype == PYTC_BF16, "dwconv3d: bad dtype");
+  PYTC_REQUIRE(!(wide_range && stats), "dwconv3d_fwd_wide: the gradient entry computes no statistics");
   if (march_ok(D, H, W, C, K, stride, dtype, transposed)) {
     DwMarch t;
-    make_march(t, N, D, H, W, C);
-    dim3 grid((unsigned)((long)t.slots * (C / MARCH_CG) * N)), block(256);
+    // the 8 x 16 / 512-thread footprint serves the plain packed-f16 forward (the launches that carry statistics, so the slot
+    // count of pytc_dwconv3d_stat_slots follows the same rule); gradient entries keep the 8 x 8 kernels
+    const bool wide_tile = !res && !wide_range && tuning_get("dwconv_march_h16", 1) != 0 && march_tile_x(W, dtype) == 16;
+    make_march(t, N, D, H, W, C, wide_tile ? 16 : TILE_X);
+    dim3 grid((unsigned)((long)t.slots * (C / MARCH_CG) * N)), block(wide_tile ? 512 : 256);
     t.swizzle = tuning_get("dwconv_xcd_swizzle", 1);
     // variants (all: taps in LDS, hand-scheduled tap loop, asm plane loads with counted waits):
     //   0 (default) PF=3 compiled for 4 waves/SIMD; 1: PF=3, 3 waves; 2: PF=3, 2 waves; 3: PF=2, 3 waves
@@ -1298,6 +1314,9 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
       else
         hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, 3, true, 3, true>), grid, block, 0, (hipStream_t)stream,
                            (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t, (const bf16_t*)res);
+    } else if (dtype == PYTC_BF16 && h16 && wide_tile) {
+      hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, 3, true, 2, false, true, 16, 512>), grid, block, 0, (hipStream_t)stream,
+                         (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t);
     } else if (dtype == PYTC_BF16 && h16) {
       hipLaunchKernelGGL((dwconv3d_k3_march_kernel<bf16_t, 2, 3, true, 4, false, true>), grid, block, 0, (hipStream_t)stream,
                          (const bf16_t*)x, (bf16_t*)y, w, bias, stats, t);
@@ -1338,7 +1357,7 @@ extern "C" int pytc_dwconv3d_stat_slots(int N, int D, int H, int W, int C, int K
                                         int transposed) {
   if (march_ok(D, H, W, C, K, stride, dtype, transposed)) {
     DwMarch t;
-    make_march(t, N, D, H, W, C);
+    make_march(t, N, D, H, W, C, tuning_get("dwconv_march_h16", 1) != 0 ? march_tile_x(W, dtype) : TILE_X);
     return t.slots;
   }
   DwGeom g;
