@@ -469,6 +469,198 @@ convT3d_thin_kernel(const T* __restrict__ x, const float* __restrict__ w, const 
   }
 }
 
+
+// ---- stride-2 weight gradient on the matrix cores (bf16, k = 3^3, stride 2, pad 1 on every axis) ------------------------------
+// dW[tap][o][k] = sum_r small[r][o] * big[2r + tap - 1][k]  (strided conv: small = dY, big = the conv's input; transposed conv:
+// small = the conv's input, big = dY).  Same scheme as conv3d_wgrad_mfma_kernel (csrc/rsunet_train_kernels.hip): the reduction
+// runs over voxels, both operands are [row][channel] in HBM while an MFMA fragment wants 8 reduction indices of one channel per
+// lane -> 16-byte global loads into a wave-private, row-padded LDS image, gfx950's ds_read_b64_tr_b16 transpose read, then
+// v_mfma_f32_16x16x32_bf16.  A wave's unit is one 32-voxel x segment of a line of the SMALL grid, for ONE (dz, dy) of the stencil:
+// the big line (z, y) = (2 zs + dz - 1, 2 ys + dy - 1) is staged DE-INTERLEAVED -- odd image O[j] = big[2 (x0 + j) - 1] (33 rows),
+// even image E[i] = big[2 (x0 + i)] (32 rows) -- so the three x taps read 32 CONSECUTIVE LDS rows each: dx = 0 -> O[0..31],
+// dx = 1 -> E[0..31], dx = 2 -> O[1..32].  One staged line, three taps, 3 x MT x NT MFMAs per unit; the next unit's loads are
+// in flight during them; no workgroup barrier in the loop.  Workgroup = (row slot, 32 x 32 (o, k) tile, (dz, dy)); the blocks of
+// a slot go to one XCD back to back so the 9 x tiles re-reads of the slot's rows hit that XCD's L2.  Per-slot partials, fixed-order
+// cross-wave and cross-slot sums: deterministic.  Replaces the VALU kernel above for the wide layers (64 x 128: 2.3 ms).
+template <int MT, int NT>
+__global__ void __launch_bounds__(256, 3)
+conv3d_wgrad_s2_mfma_kernel(const bf16_t* __restrict__ big, const bf16_t* __restrict__ small, float* __restrict__ dWp, int N,
+                            SwGeom g, int C_k, int C_o, long units_per_slot, int slots, int tiles) {
+  constexpr int BM = MT * 16, BN = NT * 16;
+  constexpr int SG = BM * 2 + 32, SX = BN * 2 + 32;        // LDS row pitch in bytes
+  constexpr int AR = 65, ODD = 0, EVEN = 33;                // staged big rows: O[0..32] then E[0..31]
+  constexpr int WAVE_BYTES = 32 * SG + AR * SX;
+  constexpr int RED_BYTES = 3 * BM * BN * 4;
+  constexpr int LDS_BYTES = 4 * WAVE_BYTES > RED_BYTES ? 4 * WAVE_BYTES : RED_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned char* lg = lds + wave * WAVE_BYTES;
+  unsigned char* la = lg + 32 * SG;
+  const int T = tiles * 9;
+  const long b = blockIdx.x;
+  const int slot = (int)((b / 8 / T) * 8 + (b % 8));
+  if (slot >= slots) return;
+  const int t = (int)((b / 8) % T);
+  const int zy = t % 9, tile = t / 9;
+  const int dzi = zy / 3, dyi = zy % 3;
+  const int tiles_k = C_k / BN;
+  const int o_base = (tile / tiles_k) * BM, k_base = (tile % tiles_k) * BN;
+  const int nseg = (g.Ws + 31) / 32;
+  const long units = (long)N * g.Ds * g.Hs * nseg;
+  const long u_begin = (long)slot * units_per_slot;
+  const long u_end = u_begin + units_per_slot < units ? u_begin + units_per_slot : units;
+
+  constexpr int CHG = BM / 8, RG = 64 / CHG, ITG = 32 / RG;   // small rows: 16-B chunks per row, rows per load, loads
+  constexpr int CHX = BN / 8, ITA = (AR * CHX + 63) / 64;     // big line: chunk loads per lane
+  const int g_row = lane / CHG, g_chunk = lane % CHG;
+  uint4 rg[ITG], ra[ITA];
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+
+  auto fetch = [&](long u) {
+    const int xs = (int)(u % nseg);
+    const long line = u / nseg;                     // (n * Ds + zs) * Hs + ys
+    const int ys = (int)(line % g.Hs);
+    const long nz = line / g.Hs;
+    const int zs = (int)(nz % g.Ds), n = (int)(nz / g.Ds);
+    const int x0 = xs * 32;
+    const bf16_t* sl = small + line * g.Ws * (long)C_o + o_base + g_chunk * 8;
+#pragma unroll
+    for (int it = 0; it < ITG; ++it) {
+      const int x = x0 + it * RG + g_row;
+      rg[it] = x < g.Ws ? *reinterpret_cast<const uint4*>(sl + (long)x * C_o) : zero4;
+    }
+    const int zb = 2 * zs + dzi - 1, yb = 2 * ys + dyi - 1;
+    const bool ok = zb >= 0 && zb < g.Db && yb >= 0 && yb < g.Hb;           // wave-uniform
+    const bf16_t* bl = big + (((long)n * g.Db + (ok ? zb : 0)) * g.Hb + (ok ? yb : 0)) * g.Wb * (long)C_k + k_base;
+#pragma unroll
+    for (int it = 0; it < ITA; ++it) {
+      const int c = it * 64 + lane;
+      const int row = c / CHX, chunk = c % CHX;
+      const int xb = row < EVEN ? 2 * (x0 + row) - 1 : 2 * (x0 + row - EVEN);
+      ra[it] = (ok && row < AR && xb >= 0 && xb < g.Wb) ? *reinterpret_cast<const uint4*>(bl + (long)xb * C_k + chunk * 8) : zero4;
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int it = 0; it < ITG; ++it) *reinterpret_cast<uint4*>(lg + (it * RG + g_row) * SG + g_chunk * 16) = rg[it];
+#pragma unroll
+    for (int it = 0; it < ITA; ++it) {
+      const int c = it * 64 + lane;
+      const int row = c / CHX, chunk = c % CHX;
+      if (row < AR) *reinterpret_cast<uint4*>(la + row * SX + chunk * 16) = ra[it];
+    }
+  };
+  const int fr_row = (lane >> 4) * 4 + ((lane & 15) >> 2), fr_col = (lane & 3) * 8;
+  auto frag = [&](unsigned char* base, int pitch, int row0, int tl) -> bf16x8_t {
+    unsigned char* p = base + (row0 + fr_row) * pitch + tl * 32 + fr_col;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 16 * pitch));
+    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, both);
+  };
+
+  f32x4_t acc[3][MT][NT];
+#pragma unroll
+  for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[tp][m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const long quarter = (u_end - u_begin + 3) / 4;
+  const long w_begin = u_begin + wave * quarter;
+  const long w_end = w_begin + quarter < u_end ? w_begin + quarter : u_end;
+  long u = w_begin;
+  if (u < w_end) fetch(u);
+  for (; u < w_end; ++u) {
+    stage();
+    if (u + 1 < w_end) fetch(u + 1);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    bf16x8_t fa[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) fa[m] = frag(lg, SG, 0, m);
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int row0 = dx == 0 ? ODD : (dx == 1 ? EVEN : ODD + 1);
+      bf16x8_t fb[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) fb[n] = frag(la, SX, row0, n);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[dx][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], fb[n], acc[dx][m][n], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  float* red = reinterpret_cast<float*>(lds);
+  const int nn = lane & 15, mg = (lane >> 4) * 4;
+  for (int w = 1; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[(tp * BM + m * 16 + mg + i) * BN + n * 16 + nn] = acc[tp][m][n][i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[tp][m][n][i] += red[(tp * BM + m * 16 + mg + i) * BN + n * 16 + nn];
+    }
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int o = o_base + m * 16 + mg + i;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const int k = k_base + n * 16 + nn;
+            dWp[(((long)slot * 27 + zy * 3 + tp) * C_o + o) * C_k + k] = acc[tp][m][n][i];
+          }
+        }
+  }
+}
+
+struct SwMfmaPlan { bool ok; int mt, nt, tiles, slots; long per_slot; };
+static SwMfmaPlan sw_mfma_plan(int N, const int32_t* small_dims, int C_k, int C_o, const int32_t* kernel, const int32_t* stride,
+                               const int32_t* pad, int dtype) {
+  SwMfmaPlan p{};
+  p.ok = dtype == PYTC_BF16 && C_k % 16 == 0 && C_o % 16 == 0 && tuning_get("conv_wgrad_s2_mfma", 1) != 0;
+  for (int a = 0; a < 3 && p.ok; ++a) p.ok = kernel[a] == 3 && (!stride || stride[a] == 2) && (!pad || pad[a] == 1);
+  if (!p.ok) return p;
+  p.mt = C_o % 32 == 0 ? 2 : 1;
+  p.nt = C_k % 32 == 0 ? 2 : 1;
+  p.tiles = (C_o / (p.mt * 16)) * (C_k / (p.nt * 16));
+  const long units = (long)N * small_dims[0] * small_dims[1] * ((small_dims[2] + 31) / 32);
+  long s = 4096 / ((long)p.tiles * 9);                 // ~4096 workgroups over the launch
+  if (s > units / 8) s = units / 8;
+  s = (s / 8) * 8;
+  p.slots = (int)(s < 8 ? 8 : (s > 256 ? 256 : s));
+  p.per_slot = (units + p.slots - 1) / p.slots;
+  return p;
+}
+
 static int sw_slots(long rows_total, int C_k) {
   if (C_k <= SWT_KMAX) {               // thin kernels: one workgroup per (slot, 64 channels [, tap]) -- many small slots fill the chip
     const long s = rows_total / 512;
@@ -540,7 +732,11 @@ extern "C" int64_t pytc_conv3d_wgrad_strided_ws_elems(int N, const int32_t* smal
                                                       const int32_t* kernel) {
   if (!small_dims || !kernel || N < 1) return -1;
   const long rows_total = (long)N * small_dims[0] * small_dims[1] * small_dims[2];
-  return (int64_t)sw_slots(rows_total, C_k) * kernel[0] * kernel[1] * kernel[2] * C_o * C_k;
+  int slots = sw_slots(rows_total, C_k);
+  // the matrix-core path (bf16, k 3, stride 2, pad 1) has its own slot count; the query does not know dtype / stride: size for both
+  const SwMfmaPlan m = sw_mfma_plan(N, small_dims, C_k, C_o, kernel, nullptr, nullptr, PYTC_BF16);
+  if (m.ok && m.slots > slots) slots = m.slots;
+  return (int64_t)slots * kernel[0] * kernel[1] * kernel[2] * C_o * C_k;
 }
 
 extern "C" int pytc_conv3d_wgrad_strided(const void* big, const void* small, float* dW, float* workspace, int N,
@@ -552,12 +748,23 @@ extern "C" int pytc_conv3d_wgrad_strided(const void* big, const void* small, flo
   SwGeom g{small_dims[0], small_dims[1], small_dims[2], big_dims[0], big_dims[1], big_dims[2], kernel[0], kernel[1], kernel[2],
            stride[0], stride[1], stride[2], pad[0], pad[1], pad[2]};
   const long rows_total = (long)N * g.Ds * g.Hs * g.Ws;
-  const int slots = sw_slots(rows_total, C_k);
+  int slots = sw_slots(rows_total, C_k);
   const long rps = (rows_total + slots - 1) / slots;
   const int taps = g.kd * g.kh * g.kw;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(slots, ((C_o + SW_TO - 1) / SW_TO) * ((C_k + SW_TK - 1) / SW_TK), taps), block(256);
-  if (C_k == 1 && g.kd == 3 && g.kh == 3 && g.kw == 3 && (dtype == PYTC_BF16 || dtype == PYTC_F32) &&
+  const SwMfmaPlan mp = sw_mfma_plan(N, small_dims, C_k, C_o, kernel, stride, pad, dtype);
+  if (mp.ok && C_k > SWT_KMAX && big_dims[0] >= 1) {
+    slots = mp.slots;
+    const long blocks = (long)((slots + 7) / 8) * 8 * mp.tiles * 9;
+#define SW_MFMA(MT, NT) hipLaunchKernelGGL((conv3d_wgrad_s2_mfma_kernel<MT, NT>), dim3((unsigned)blocks), dim3(256), 0, s, \
+                                           (const bf16_t*)big, (const bf16_t*)small, workspace, N, g, C_k, C_o, mp.per_slot, slots, mp.tiles)
+    if (mp.mt == 2 && mp.nt == 2) SW_MFMA(2, 2);
+    else if (mp.mt == 2) SW_MFMA(2, 1);
+    else if (mp.nt == 2) SW_MFMA(1, 2);
+    else SW_MFMA(1, 1);
+#undef SW_MFMA
+  } else if (C_k == 1 && g.kd == 3 && g.kh == 3 && g.kw == 3 && (dtype == PYTC_BF16 || dtype == PYTC_F32) &&
       tuning_get("conv3d_wgrad_thin", 1) != 0) {
     dim3 tgrid(slots, (C_o + SWT_TO - 1) / SWT_TO);
     if (dtype == PYTC_BF16)
