@@ -496,6 +496,7 @@ conv3d_wgrad_s2_mfma_kernel(const bf16_t* __restrict__ big, const bf16_t* __rest
   typedef short s16x4 __attribute__((ext_vector_type(4)));
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+  typedef unsigned int q4_t __attribute__((ext_vector_type(4)));      // (arrays of the uint4 STRUCT end up in scratch memory)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   unsigned char* lg = lds + wave * WAVE_BYTES;
   unsigned char* la = lg + 32 * SG;
@@ -516,8 +517,8 @@ conv3d_wgrad_s2_mfma_kernel(const bf16_t* __restrict__ big, const bf16_t* __rest
   constexpr int CHG = BM / 8, RG = 64 / CHG, ITG = 32 / RG;   // small rows: 16-B chunks per row, rows per load, loads
   constexpr int CHX = BN / 8, ITA = (AR * CHX + 63) / 64;     // big line: chunk loads per lane
   const int g_row = lane / CHG, g_chunk = lane % CHG;
-  uint4 rg[ITG], ra[ITA];
-  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  q4_t rg[ITG], ra[ITA];
+  const q4_t zero4 = {0u, 0u, 0u, 0u};
 
   auto fetch = [&](long u) {
     const int xs = (int)(u % nseg);
@@ -530,7 +531,7 @@ conv3d_wgrad_s2_mfma_kernel(const bf16_t* __restrict__ big, const bf16_t* __rest
 #pragma unroll
     for (int it = 0; it < ITG; ++it) {
       const int x = x0 + it * RG + g_row;
-      rg[it] = x < g.Ws ? *reinterpret_cast<const uint4*>(sl + (long)x * C_o) : zero4;
+      rg[it] = x < g.Ws ? *reinterpret_cast<const q4_t*>(sl + (long)x * C_o) : zero4;
     }
     const int zb = 2 * zs + dzi - 1, yb = 2 * ys + dyi - 1;
     const bool ok = zb >= 0 && zb < g.Db && yb >= 0 && yb < g.Hb;           // wave-uniform
@@ -540,17 +541,17 @@ conv3d_wgrad_s2_mfma_kernel(const bf16_t* __restrict__ big, const bf16_t* __rest
       const int c = it * 64 + lane;
       const int row = c / CHX, chunk = c % CHX;
       const int xb = row < EVEN ? 2 * (x0 + row) - 1 : 2 * (x0 + row - EVEN);
-      ra[it] = (ok && row < AR && xb >= 0 && xb < g.Wb) ? *reinterpret_cast<const uint4*>(bl + (long)xb * C_k + chunk * 8) : zero4;
+      ra[it] = (ok && row < AR && xb >= 0 && xb < g.Wb) ? *reinterpret_cast<const q4_t*>(bl + (long)xb * C_k + chunk * 8) : zero4;
     }
   };
   auto stage = [&]() {
 #pragma unroll
-    for (int it = 0; it < ITG; ++it) *reinterpret_cast<uint4*>(lg + (it * RG + g_row) * SG + g_chunk * 16) = rg[it];
+    for (int it = 0; it < ITG; ++it) *reinterpret_cast<q4_t*>(lg + (it * RG + g_row) * SG + g_chunk * 16) = rg[it];
 #pragma unroll
     for (int it = 0; it < ITA; ++it) {
       const int c = it * 64 + lane;
       const int row = c / CHX, chunk = c % CHX;
-      if (row < AR) *reinterpret_cast<uint4*>(la + row * SX + chunk * 16) = ra[it];
+      if (row < AR) *reinterpret_cast<q4_t*>(la + row * SX + chunk * 16) = ra[it];
     }
   };
   const int fr_row = (lane >> 4) * 4 + ((lane & 15) >> 2), fr_col = (lane & 3) * 8;

@@ -123,6 +123,7 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+  typedef unsigned int q4_t __attribute__((ext_vector_type(4)));      // (arrays of the uint4 STRUCT end up in scratch memory)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   unsigned char* lg = lds + wave * WAVE_BYTES;
   unsigned char* la = lg + 32 * SG;
@@ -144,10 +145,10 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
   constexpr int CHG = BM / 8, RG = 64 / CHG, ITG = 32 / RG;   // dY: 16-B chunks per row, rows per load, loads
   constexpr int CHX = BN / 8, ITA = (AR * CHX + 63) / 64;     // A line: chunk loads per lane
   const int g_row = lane / CHG, g_chunk = lane % CHG;
-  uint4 rg[ITG], ra[KP][ITA];
-  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  q4_t rg[ITG], ra[KP][ITA];
+  const q4_t zero4 = {0u, 0u, 0u, 0u};
   if (RAG_O || RAG_K) {                 // zero the padded channels once; the gather only rewrites the real ones
-    for (int i = lane; i < WAVE_BYTES / 16; i += 64) reinterpret_cast<uint4*>(lg)[i] = zero4;
+    for (int i = lane; i < WAVE_BYTES / 16; i += 64) reinterpret_cast<q4_t*>(lg)[i] = zero4;
   }
   // unit u -> (column, y) with y fastest: a wave walks DOWN a column of x segments, so of the KP A lines of a unit only the
   // newest is loaded (the others already sit in the LDS ring from the previous unit); full = first unit of a run / column
@@ -168,13 +169,13 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
         const int row = e / C_out, x = x0 + row;
         v[j] = (row < 32 && x < g.W) ? dyl[(long)x0 * C_out + e] : (unsigned short)0;
       }
-      rg[0] = __builtin_bit_cast(uint4, v);
+      rg[0] = __builtin_bit_cast(q4_t, v);
     } else {
       const bf16_t* dyl = dy + line * g.W * (long)C_out + o_base + g_chunk * 8;
 #pragma unroll
       for (int it = 0; it < ITG; ++it) {
         const int x = x0 + it * RG + g_row;
-        rg[it] = x < g.W ? *reinterpret_cast<const uint4*>(dyl + (long)x * C_out) : zero4;
+        rg[it] = x < g.W ? *reinterpret_cast<const q4_t*>(dyl + (long)x * C_out) : zero4;
       }
     }
     const int sz = z + dz;
@@ -192,7 +193,7 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
           const int row = e / C_in, x = x0 - PAD + row;
           v[j] = (ok && row < AR && x >= 0 && x < g.W) ? al[((long)x0 - PAD) * C_in + e] : (unsigned short)0;
         }
-        ra[l][0] = __builtin_bit_cast(uint4, v);
+        ra[l][0] = __builtin_bit_cast(q4_t, v);
       } else {
         const bf16_t* al = a + (line + (long)dz * g.H + (l - PAD)) * g.W * (long)C_in + k_base;
 #pragma unroll
@@ -200,7 +201,7 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
           const int c = it * 64 + lane;
           const int row = c / CHX, chunk = c % CHX;
           const int x = x0 - PAD + row;
-          ra[l][it] = (ok && row < AR && x >= 0 && x < g.W) ? *reinterpret_cast<const uint4*>(al + (long)x * C_in + chunk * 8)
+          ra[l][it] = (ok && row < AR && x >= 0 && x < g.W) ? *reinterpret_cast<const q4_t*>(al + (long)x * C_in + chunk * 8)
                                                             : zero4;
         }
       }
@@ -218,7 +219,7 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
       }
     } else {
 #pragma unroll
-      for (int it = 0; it < ITG; ++it) *reinterpret_cast<uint4*>(lg + (it * RG + g_row) * SG + g_chunk * 16) = rg[it];
+      for (int it = 0; it < ITG; ++it) *reinterpret_cast<q4_t*>(lg + (it * RG + g_row) * SG + g_chunk * 16) = rg[it];
     }
 #pragma unroll
     for (int l = 0; l < KP; ++l) {
@@ -237,7 +238,7 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
         for (int it = 0; it < ITA; ++it) {
           const int c = it * 64 + lane;
           const int row = c / CHX, chunk = c % CHX;
-          if (row < AR) *reinterpret_cast<uint4*>(la + (sl * AR + row) * SX + chunk * 16) = ra[l][it];
+          if (row < AR) *reinterpret_cast<q4_t*>(la + (sl * AR + row) * SX + chunk * 16) = ra[l][it];
         }
       }
     }

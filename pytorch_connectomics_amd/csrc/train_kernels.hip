@@ -116,7 +116,7 @@ pw_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ ab, const T* 
 // db comes from one extra MFMA per tile row against a fragment of ones.  The four waves' accumulators are added in a
 // fixed order (wave 0 + 1 + 2 + 3) -> per-slot partials -> reduce_slots: deterministic.
 template <int MT, int NT>
-__global__ void __launch_bounds__(256, (MT * NT >= 16 ? 2 : (MT * NT >= 8 ? 3 : 4)))
+__global__ void __launch_bounds__(256, (MT * NT >= 8 ? 2 : (MT * NT >= 4 ? 3 : 4)))
 pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab, const bf16_t* __restrict__ dy,
                      float* __restrict__ dWp, float* __restrict__ dbp, long rows_total, long rows_per_sample, int C_in,
                      int C_out, long rows_per_slot, int x_act) {
@@ -143,18 +143,21 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
   constexpr int CHX = BN / 8, RX = 64 / CHX, ITX = 32 / RX;
   const int g_row = lane / CHG, g_chunk = lane % CHG;
   const int x_row = lane / CHX, x_chunk = lane % CHX;
-  uint4 rg[ITG], rx[ITX];
-  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-  auto fetch = [&](long r0) {
+  // two register sets: the loads of TWO row blocks are in flight while one is multiplied (one block ahead left each wave waiting
+  // on HBM for most of an iteration: 12 MFMAs cover ~200 cycles of a ~2 us round trip; measured 2.3 TB/s at level 0)
+  typedef unsigned int q4_t __attribute__((ext_vector_type(4)));      // (a uint4 STRUCT array ends up in scratch memory here)
+  q4_t rgA[ITG], rxA[ITX], rgB[ITG], rxB[ITX];
+  const q4_t zero4 = {0u, 0u, 0u, 0u};
+  auto fetch = [&](long r0, q4_t (&rg)[ITG], q4_t (&rx)[ITX]) {
 #pragma unroll
     for (int it = 0; it < ITG; ++it) {
       const long r = r0 + it * RG + g_row;
-      rg[it] = r < r_end ? *reinterpret_cast<const uint4*>(dy + r * C_out + o_base + g_chunk * 8) : zero4;
+      rg[it] = r < r_end ? *reinterpret_cast<const q4_t*>(dy + r * C_out + o_base + g_chunk * 8) : zero4;
     }
 #pragma unroll
     for (int it = 0; it < ITX; ++it) {
       const long r = r0 + it * RX + x_row;
-      rx[it] = r < r_end ? *reinterpret_cast<const uint4*>(x + r * C_in + k_base + x_chunk * 8) : zero4;
+      rx[it] = r < r_end ? *reinterpret_cast<const q4_t*>(x + r * C_in + k_base + x_chunk * 8) : zero4;
     }
   };
   // norm affine of the lane's 8 channels, cached per sample: a 32-row block never straddles two samples when
@@ -170,16 +173,16 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
     for (int i = 0; i < 8; ++i) { av[i] = a[i]; bv[i] = b[i]; }
     n_cached = n;
   };
-  auto stage = [&](long r0) {
+  auto stage = [&](long r0, q4_t (&rg)[ITG], q4_t (&rx)[ITX]) {
 #pragma unroll
-    for (int it = 0; it < ITG; ++it) *reinterpret_cast<uint4*>(lg + (it * RG + g_row) * SG + g_chunk * 16) = rg[it];
+    for (int it = 0; it < ITG; ++it) *reinterpret_cast<q4_t*>(lg + (it * RG + g_row) * SG + g_chunk * 16) = rg[it];
     if (uniform_n) {
       const long n = r0 / rows_per_sample;            // r0 is wave-uniform: one division per 32-row block
       if (n != n_cached) load_ab(n);
     }
 #pragma unroll
     for (int it = 0; it < ITX; ++it) {
-      uint4 v = rx[it];
+      q4_t v = rx[it];
       const long r = r0 + it * RX + x_row;
       if (ab && r < r_end) {            // the forward GEMM consumed bf16(a*x+b): restate it here
         if (!uniform_n) load_ab(r / rows_per_sample);
@@ -187,15 +190,15 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
         f32x8_t f = __builtin_convertvector(in, f32x8_t);
 #pragma unroll
         for (int i = 0; i < 8; ++i) f[i] = fmaf(f[i], av[i], bv[i]);
-        v = __builtin_bit_cast(uint4, __builtin_convertvector(f, bf16x8_t));
+        v = __builtin_bit_cast(q4_t, __builtin_convertvector(f, bf16x8_t));
       }
       if (x_act == PYTC_ACT_GELU) {     // the forward GEMM consumed bf16(gelu(x)) (fused pre-activation)
         f32x8_t f = __builtin_convertvector(__builtin_bit_cast(bf16x8_t, v), f32x8_t);
 #pragma unroll
         for (int i = 0; i < 8; ++i) f[i] = gelu_fast(f[i]);      // the function pw_fast's prologue applied in the forward
-        v = __builtin_bit_cast(uint4, __builtin_convertvector(f, bf16x8_t));
+        v = __builtin_bit_cast(q4_t, __builtin_convertvector(f, bf16x8_t));
       }
-      *reinterpret_cast<uint4*>(lx + (it * RX + x_row) * SX + x_chunk * 16) = v;
+      *reinterpret_cast<q4_t*>(lx + (it * RX + x_row) * SX + x_chunk * 16) = v;
     }
   };
   // transpose read of one 16-channel fragment: lane (g = lane>>4, i = lane&15) supplies the address of 4 channels
@@ -220,11 +223,7 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
 
-  long r0 = r_begin + wave * 32;
-  if (r0 < r_end) fetch(r0);
-  for (; r0 < r_end; r0 += 128) {
-    stage(r0);
-    if (r0 + 128 < r_end) fetch(r0 + 128);
+  auto multiply = [&]() {
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
     bf16x8_t fa[MT], fb[NT];
@@ -240,6 +239,19 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
+  };
+  long r0 = r_begin + wave * 32;
+  if (r0 < r_end) fetch(r0, rgA, rxA);
+  if (r0 + 128 < r_end) fetch(r0 + 128, rgB, rxB);
+  for (; r0 < r_end; r0 += 256) {                    // same block order per wave as before: the sums are bit-identical
+    stage(r0, rgA, rxA);
+    if (r0 + 256 < r_end) fetch(r0 + 256, rgA, rxA);
+    multiply();
+    if (r0 + 128 < r_end) {
+      stage(r0 + 128, rgB, rxB);
+      if (r0 + 384 < r_end) fetch(r0 + 384, rgB, rxB);
+      multiply();
+    }
   }
 
   // fixed-order cross-wave sum through LDS, then wave 0 stores the slot partial
@@ -841,6 +853,11 @@ static int pw_wgrad_impl(const void* x, const float* ab, const void* dy, float* 
     long want = rows_total / 2048;
     const long cap = 1024 / tiles > 1 ? 1024 / tiles : 1;
     want = want < 1 ? 1 : (want > cap ? cap : want);
+    // a launch that needs the cap would run 1024 workgroups over 256 CUs x (2 | 3 | 4) resident ones: 1.33 rounds, the last a
+    // third full.  Cut it to whole rounds of resident workgroups (the slot count only groups rows: sums stay in slot order)
+    const int per_cu = mt * nt >= 8 ? 2 : (mt * nt >= 4 ? 3 : 4);
+    const long resident = 256L * per_cu / tiles;
+    if (tuning_get("wgrad_whole_rounds", 1) && resident >= 8 && want > resident) want = (want / resident) * resident;
     if (want < slots) slots = (int)want;
   }
   const long rps = (rows_total + slots - 1) / slots;
