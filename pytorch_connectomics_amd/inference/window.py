@@ -334,6 +334,9 @@ def _extract_padded_patch_batch(tensor: torch.Tensor, patch_slices, *, roi_size,
     return cl.permute(0, 4, 1, 2, 3).contiguous().to(tensor.dtype), locs
 
 
+_PIPELINE_STREAMS: dict = {}
+
+
 class EagerSlidingWindowEngine:
     """``engine(inputs=(1,C,*spatial), network=fn) -> (1,C_out,*spatial)`` with everything in HBM.
 
@@ -353,7 +356,6 @@ class EagerSlidingWindowEngine:
         self.output_device = output_device
         self.progress = bool(progress)
         self._axis_cache = {}
-        self._stream_cache = {}
         # HIP streams the window batches are spread over (1 = the caller's stream only); results do not depend on it
         self.pipeline_streams = int(os.environ.get("PYTC_SW_STREAMS", "2"))
         self.last_stats = {}
@@ -480,11 +482,13 @@ class EagerSlidingWindowEngine:
         n = min(int(self.pipeline_streams), n_chunks)
         if n < 2 or ops.PROFILER.enabled or torch.cuda.is_current_stream_capturing():
             return []
+        # one set of side streams per device for the whole process: the caching allocator keeps a memory pool per stream, and an
+        # engine object that made its own streams would fault in ~10 GB of fresh activations on its first pass
         key = (str(dev), n)
-        hit = self._stream_cache.get(key)
+        hit = _PIPELINE_STREAMS.get(key)
         if hit is None:
             hit = [torch.cuda.Stream(device=dev) for _ in range(n)]
-            self._stream_cache[key] = hit
+            _PIPELINE_STREAMS[key] = hit
         return hit
 
     def shifted_weight(self, orig_size, shift, device) -> torch.Tensor:
