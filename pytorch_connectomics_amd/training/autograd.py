@@ -40,9 +40,11 @@ BATCHED_WEIGHT_PACKS = True
 
 
 # weight-gradient kernels of a block backward on a second HIP stream: they are off the critical path (only the optimizer reads
-# them), the data-gradient chain is what the next block waits for.  At levels >= 2 both are latency bound (10-60 workgroups per
-# launch on 256 CUs), so running them side by side is nearly free; at level 0 both are HBM bound and merely share the bandwidth.
-SIDE_STREAM_WGRAD = True
+# them), the data-gradient chain is what the next block waits for.  Bit-identical gradients (tools/exp_r03_train_lane.py), but
+# MEASURED: 34.3 -> 33.9 ms per step before the weight-gradient kernels were fixed and 31.1 -> 31.1 ms after (round 3; the same
+# lane around the dense-conv backward of RSUNet / the MONAI-style U-Net: 10.5 -> 10.8 / 11.4 -> 11.4 ms): the step is bound by the
+# sum of its HBM-bound level-0 / level-1 kernels, not by the latency-bound deep ones.  Off by default; kept as the switch.
+SIDE_STREAM_WGRAD = False
 _SIDE_STREAMS = {}
 
 
@@ -72,9 +74,14 @@ class _WgradLane:
         with torch.cuda.stream(self.side):
             return fn()
 
-    def join(self):
+    def join(self, *produced):
+        """The caller's stream waits for the side stream; `produced`: tensors allocated on the side stream that the caller's
+        stream uses from here on."""
         if self.on:
             self.main.wait_stream(self.side)
+            for t in produced:
+                if t is not None:
+                    t.record_stream(self.main)
 
 
 def _packs_of(owner):
