@@ -270,7 +270,12 @@ def train_leg(dev, rank, world, args, barrier):
             with ops.profiled() as prof:
                 for i in range(2):
                     tstep(i)
-            roof = dominant(prof.summary(), 2)
+            table = committed_pmc_table("train")
+            roof = dominant(prof.summary(), 2, traffic_fn=lambda name: _traffic_from_table(table, _train_kernel_key(name)))
+            roof["traffic_source"] = ("committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this training step "
+                                      "(profiles/rNN_train_hbm_counters.csv; FETCH_SIZE x 2)")
+            if roof.get("traffic"):
+                roof["traffic_over_algorithmic"] = round(roof["traffic"] / max(roof["algorithmic_bytes"], 1), 3)
         else:
             for i in range(2):
                 tstep(i)
@@ -378,11 +383,22 @@ def _traffic_from_table(table, key):
     return int(tot / n) if n else None
 
 
-def committed_pmc_table():
-    """kernel -> (launches, FETCH_SIZE KB mean, WRITE_SIZE KB mean) from the newest profiles/rNN_bench_hbm_counters.csv (separate
-    --pmc passes of this same command, tools/profile_bench.sh + tools/make_hbm_counters_csv.py)."""
+def _train_kernel_key(label):
+    """rocprof symbol substring of a training-step label: the MFMA pointwise weight gradient of one channel pair (tile counts as
+    csrc/train_kernels.hip wg_tile16 picks them: <C_out tiles, C_in tiles>), or a kernel family name."""
+    import re
+    m = re.match(r"pw_wgrad\[(\d+)->(\d+)\]", label)
+    if m:
+        t = lambda c: 4 if c % 64 == 0 else (2 if c % 32 == 0 else 1)      # noqa: E731
+        return f"pw_wgrad_mfma_kernelILi{t(int(m.group(2)))}ELi{t(int(m.group(1)))}E"
+    return _kernel_key(label)
+
+
+def committed_pmc_table(leg="bench"):
+    """kernel -> (launches, FETCH_SIZE KB mean, WRITE_SIZE KB mean) from the newest profiles/rNN_<leg>_hbm_counters.csv (separate
+    --pmc passes of this same command or of the training step, tools/profile_r03.sh + tools/make_hbm_counters_csv.py)."""
     import csv
-    files = sorted((ROOT / "profiles").glob("r*_bench_hbm_counters.csv"))
+    files = sorted((ROOT / "profiles").glob(f"r*_{leg}_hbm_counters.csv"))
     if not files:
         return None
     return {row["kernel"]: (float(row.get("launches") or 1), float(row["FETCH_SIZE_KB_mean"]), float(row["WRITE_SIZE_KB_mean"]))
