@@ -471,6 +471,32 @@ int pytc_norm_bwd_ws_elems(int N, int64_t rows, int C);
 int pytc_norm_bwd(const void* dtn, const void* t, const float* mean_rstd, const float* gamma, float* stats_ws,
                   float* s_out, void* dt, int N, int64_t rows, float count /* voxels in the statistics */, int C,
                   int dtype, void* stream);
+/* GroupNorm-fed expand conv (MedNeXt block: hp = W2 (gamma * xhat + beta) + b2): the weight-gradient sums AND the statistics of
+ * the GroupNorm backward from ONE pass over (t, dhp).  With M[n][h][c] = sum_r dhp[r][h] xhat[r][c] and q[n][h] = sum_r dhp[r][h]
+ * (the MFMA weight-gradient kernel against xhat, `sps` row slots per sample),
+ *   dW2 [C_hid][C] = sum_n term[n],  term[n] = gamma*M[n] + beta*q[n];   db2 [C_hid] = sum_n q[n]
+ *   (sum_r dtn, sum_r dtn*xhat)[n][c] = (sum_h W2[h][c] q[n][h], sum_h W2[h][c] M[n][h][c])      with dtn = W2^T dhp
+ * -- the statistics pass of pytc_norm_bwd over (dtn, t) is not needed.  mean_rstd / ab: [N][2][C] of pytc_norm_finalize_groups_mr,
+ * W2: fp32 [C_hid][C].  bf16, C and C_hid multiples of 16 (pytc_pw_wgrad_groupnorm_supported).
+ * workspace (pytc_pw_wgrad_groupnorm_ws_elems floats), sps = pytc_pw_wgrad_groupnorm_sps(...):
+ *   [N*sps][C_hid*C] dW partials | [N*sps][C_hid] bias partials | term [N][C_hid*C] | q [N][C_hid]
+ * the caller reduces term and q over their N slots (pytc_reduce_slots_multi).  s_part [parts][N][2][C], parts =
+ * pytc_pw_wgrad_groupnorm_parts(C_hid): the statistics in hidden-channel chunks; pytc_norm_bwd_apply adds them, and their sum
+ * over parts*N is (dbeta, dgamma).  Replaces autograd's separate Conv3d-weight and GroupNorm backward reductions (reference:
+ * torch.nn.GroupNorm + Conv3d under connectomics/training/lightning/model.py:863-910).
+ * pytc_norm_bwd_apply: the apply pass of pytc_norm_bwd with s given as [s_parts][N][2][C]; crop_grid (nullable int32[3], the
+ * (D,H,W) grid of the rows): rows on the front faces are dropped and dt is the compact (D-1,H-1,W-1) grid (the zero-padded
+ * faces of an up block, MedNeXtUpBlock's F.pad). */
+int pytc_pw_wgrad_groupnorm_supported(int C, int C_hid, int dtype);
+int pytc_pw_wgrad_groupnorm_sps(int N, int64_t rows_per_sample, int C, int C_hid);
+int pytc_pw_wgrad_groupnorm_parts(int C_hid);
+int64_t pytc_pw_wgrad_groupnorm_ws_elems(int N, int64_t rows_per_sample, int C, int C_hid);
+int pytc_pw_wgrad_groupnorm(const void* t, const float* mean_rstd, const float* ab, const void* dhp, const float* W2,
+                            const float* gamma, float* s_part, float* workspace, int N, int64_t rows_per_sample, int C,
+                            int C_hid, int dtype, void* stream);
+int pytc_norm_bwd_apply(const void* dtn, const void* t, const float* mean_rstd, const float* gamma, const float* s_in,
+                        int s_parts, void* dt, int N, int64_t rows, int C, float count, int dtype, const int32_t* crop_grid,
+                        void* stream);
 /* depthwise conv backward-data, any stride: dx[i] = sum_k dy[(i + K/2 - k)/stride] * w[k] (w: forward taps [K^3][C]) */
 int pytc_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, int N, const int32_t* xdims,
                            const int32_t* ydims, int C, int K, int stride, int dtype, void* stream);

@@ -143,6 +143,13 @@ _SIGS = {
     "pytc_dw_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p]),
+    "pytc_pw_wgrad_groupnorm_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "pytc_pw_wgrad_groupnorm_sps": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int]),
+    "pytc_pw_wgrad_groupnorm_parts": (C.c_int, [C.c_int]),
+    "pytc_pw_wgrad_groupnorm_ws_elems": (C.c_int64, [C.c_int, C.c_int64, C.c_int, C.c_int]),
+    "pytc_pw_wgrad_groupnorm": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_norm_bwd_apply": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_int,
+                                      C.c_void_p, C.c_void_p]),
     "pytc_norm_bwd_ws_elems": (C.c_int, [C.c_int, C.c_int64, C.c_int]),
     "pytc_norm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_int, C.c_int64, C.c_float, C.c_int, C.c_int, C.c_void_p]),

@@ -106,8 +106,9 @@ pw_fast_kernel(PwFastParams p) {
   if (WARM) warm_l2_done(warm);
   const bool pre_ok = p.e.res_mode == PYTC_RES_ADD || p.e.res_mode == PYTC_RES_GELU_BWD;
   const bf16_t* resn = pre_ok ? reinterpret_cast<const bf16_t*>(p.e.res) + (long)n * p.rps * p.C_out : nullptr;
-  const int pairs = p.C_out / 32;
-  for (int pr = 0; pr < pairs; ++pr) {
+  // blockIdx.z owns a contiguous share of the output-channel pairs (launch_fast: > 1 only when the rows alone leave CUs idle)
+  const int pairs_z = p.C_out / 32 / (int)gridDim.z;
+  for (int pr = blockIdx.z * pairs_z; pr < (int)(blockIdx.z + 1) * pairs_z; ++pr) {
     const int o0 = pr * 32 + kb * 8;
     uint4 rpre[NT];
     if (pre_ok) {
@@ -158,7 +159,13 @@ pw_fast_kernel(PwFastParams p) {
 template <int KS, int NT>
 static void launch_fast(const PwFastParams& p, int N, hipStream_t s) {
   const long rows_per_block = 4L * NT * 16;
-  dim3 grid((unsigned)((p.rps + rows_per_block - 1) / rows_per_block), (unsigned)N), block(256);
+  const long row_blocks = (p.rps + rows_per_block - 1) / rows_per_block * N;
+  // deep levels (level 3: 172 row blocks, bottleneck: 22 for 256 CUs): the output-channel pairs are shared out over blockIdx.z
+  // until ~2 workgroups per CU exist; every share re-reads the operand rows (L2 hits: the whole tensor is a few MB there)
+  int zsplit = 1;
+  if (tuning_get("pw_fast_zsplit", 1))
+    while (row_blocks * zsplit < 512 && (p.C_out / 32) % (zsplit * 2) == 0) zsplit *= 2;
+  dim3 grid((unsigned)((p.rps + rows_per_block - 1) / rows_per_block), (unsigned)N, (unsigned)zsplit), block(256);
   hipLaunchKernelGGL((pw_fast_kernel<KS, NT>), grid, block, 0, s, p);
 }
 

@@ -119,7 +119,10 @@ template <int MT, int NT>
 __global__ void __launch_bounds__(256, (MT * NT >= 8 ? 2 : (MT * NT >= 4 ? 3 : 4)))
 pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab, const bf16_t* __restrict__ dy,
                      float* __restrict__ dWp, float* __restrict__ dbp, long rows_total, long rows_per_sample, int C_in,
-                     int C_out, long rows_per_slot, int x_act) {
+                     int C_out, long rows_per_slot, int x_act, int sps, int ab_mode) {
+  // sps > 0: `sps` slots PER SAMPLE (slot = n * sps + j covers rows of sample n only): the partials then are per-sample sums,
+  // which pytc_pw_wgrad_groupnorm turns into the GroupNorm backward statistics.  ab_mode 1: `ab` holds (mean, rstd) and the
+  // operand is the normalised xhat = (x - mean) * rstd instead of a * x + b.
   constexpr int BM = MT * 16, BN = NT * 16;
   constexpr int SG = BM * 2 + 32, SX = BN * 2 + 32;        // LDS row pitch in bytes
   constexpr int WAVE_BYTES = 32 * (SG + SX);
@@ -136,8 +139,13 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
   const int tiles_k = C_in / BN;
   const int o_base = (blockIdx.y / tiles_k) * BM, k_base = (blockIdx.y % tiles_k) * BN;
   const bool want_db = dbp != nullptr && (blockIdx.y % tiles_k) == 0;
-  const long r_begin = (long)slot * rows_per_slot;
-  const long r_end = r_begin + rows_per_slot < rows_total ? r_begin + rows_per_slot : rows_total;
+  long r_begin = (long)slot * rows_per_slot;
+  long r_end = r_begin + rows_per_slot < rows_total ? r_begin + rows_per_slot : rows_total;
+  if (sps > 0) {
+    const long sample_begin = (long)(slot / sps) * rows_per_sample;
+    r_begin = sample_begin + (long)(slot % sps) * rows_per_slot;
+    r_end = r_begin + rows_per_slot < sample_begin + rows_per_sample ? r_begin + rows_per_slot : sample_begin + rows_per_sample;
+  }
 
   constexpr int CHG = BM / 8, RG = 64 / CHG, ITG = 32 / RG;   // 16-B chunks per row, rows per load, loads per block
   constexpr int CHX = BN / 8, RX = 64 / CHX, ITX = 32 / RX;
@@ -163,14 +171,17 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
   // norm affine of the lane's 8 channels, cached per sample: a 32-row block never straddles two samples when
   // rows_per_sample % 32 == 0 (every MedNeXt level at 112^3), so the sample index is tracked per wave with a
   // compare instead of a 64-bit division per row, and (a, b) are reloaded only when it changes
-  const bool uniform_n = ab != nullptr && (rows_per_sample % 32) == 0;
+  const bool uniform_n = ab != nullptr && (sps > 0 || (rows_per_sample % 32) == 0);
   float av[8], bv[8];
   long n_cached = -1;
   auto load_ab = [&](long n) {
     const float* a = ab + (n * 2 + 0) * C_in + k_base + x_chunk * 8;
     const float* b = ab + (n * 2 + 1) * C_in + k_base + x_chunk * 8;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { av[i] = a[i]; bv[i] = b[i]; }
+    for (int i = 0; i < 8; ++i) {
+      if (ab_mode) { av[i] = b[i]; bv[i] = -a[i] * b[i]; }       // (mean, rstd) -> xhat = rstd * x - mean * rstd
+      else { av[i] = a[i]; bv[i] = b[i]; }
+    }
     n_cached = n;
   };
   auto stage = [&](long r0, q4_t (&rg)[ITG], q4_t (&rx)[ITX]) {
@@ -553,7 +564,7 @@ __global__ void __launch_bounds__(256)
 dw_wgrad_vec_kernel(const T* __restrict__ g, const T* __restrict__ x, float* __restrict__ dWp, float* __restrict__ dbp,
                     DwWg q, long rows_per_slot) {
   constexpr int EPV = 16 / (int)sizeof(T), K = 3;
-  __shared__ float lds[256 * EPV];                 // [position lane][C]
+  __shared__ float lds[5 * 256 * EPV];             // [value][position lane][C], five parameter rows per round
   const int slot = blockIdx.x, n = blockIdx.y, kz = blockIdx.z;
   const int C = q.C, Cw = C / EPV, PL = 256 / Cw;
   const int ck = threadIdx.x % Cw, pl = threadIdx.x / Cw;
@@ -597,17 +608,25 @@ dw_wgrad_vec_kernel(const T* __restrict__ g, const T* __restrict__ x, float* __r
     }
   }
   const long out_base = (long)n * q.slots + slot;
-  for (int t = 0; t <= K * K; ++t) {               // t == K*K: the bias column (kz == 0 only)
-    if (t == K * K && (kz != 0 || !dbp)) break;
+  // the 9 tap sums + the bias column cross the position lanes through LDS five at a time (two rounds instead of ten: the tail
+  // was a third of a 14^3 launch); per parameter the position lanes are added in lane order, as before
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
     __syncthreads();
     if (pl < PL) {
 #pragma unroll
-      for (int i = 0; i < EPV; ++i) lds[pl * C + ck * EPV + i] = t < K * K ? acc[t < K * K ? t : 0][i] : bacc[i];
+      for (int j = 0; j < 5; ++j) {
+        const int t = half * 5 + j;
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) lds[(j * PL + pl) * C + ck * EPV + i] = t < K * K ? acc[t < K * K ? t : 0][i] : bacc[i];
+      }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int idx = threadIdx.x; idx < 5 * C; idx += 256) {
+      const int j = idx / C, c = idx % C, t = half * 5 + j;
+      if (t == K * K && (kz != 0 || !dbp)) continue;          // the bias column: kz == 0 only
       float a = 0.f;
-      for (int vv = 0; vv < PL; ++vv) a += lds[vv * C + c];
+      for (int vv = 0; vv < PL; ++vv) a += lds[(j * PL + vv) * C + c];
       if (t < K * K) dWp[(out_base * K * K * K + (long)kz * K * K + t) * C + c] = a;
       else dbp[out_base * C + c] = a;
     }
@@ -673,16 +692,32 @@ norm_bwd_apply_kernel(const T* __restrict__ dtn, const T* __restrict__ t, const 
 }
 
 // 16-byte form of the apply pass (C % (16/sizeof(T)) == 0): lane = (channel chunk, row lane), coefficients in registers
+constexpr int NORM_APPLY_MAX_PART_C = 2048;      // channels when the statistics arrive in parts (LDS: 2 * C floats)
 template <typename T>
 __global__ void __launch_bounds__(256)
 norm_bwd_apply_vec_kernel(const T* __restrict__ dtn, const T* __restrict__ t, const float* __restrict__ mr,
                           const float* __restrict__ gamma, const float* __restrict__ s, float inv_count,
-                          T* __restrict__ dt, long rows, int C, long rows_per_slot) {
+                          T* __restrict__ dt, long rows, int C, long rows_per_slot, int crop_h = 0, int crop_w = 0,
+                          int s_parts = 1) {
+  // s: [s_parts][N][2][C], summed over the parts in order (1: the reduced sums of the statistics pass; > 1: the hidden-channel
+  // chunks of norm_bwd_from_wgrad_kernel)
+  // crop_h / crop_w > 0: the rows are a (D, crop_h, crop_w) grid whose FRONT faces (z, y or x == 0: the zero padding of an up
+  // block's transposed conv) are dropped -- dt is the compact (D-1, crop_h-1, crop_w-1) grid the transposed conv's backward reads
   constexpr int EPV = 16 / (int)sizeof(T);
   const int n = blockIdx.y, slot = blockIdx.x;
+  __shared__ float sm_s[2 * NORM_APPLY_MAX_PART_C];
+  if (s_parts > 1) {      // the workgroup adds the parts once, together (a lane-private loop was 2 * EPV * parts scattered loads)
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+      float a = 0.f;
+      for (int pp = 0; pp < s_parts; ++pp) a += s[((long)pp * gridDim.y + n) * 2 * C + i];
+      sm_s[i] = a;
+    }
+    __syncthreads();
+  }
   const long r0 = (long)slot * rows_per_slot;
   const long r1 = r0 + rows_per_slot < rows ? r0 + rows_per_slot : rows;
   const long base = (long)n * rows * C;
+  const long obase = crop_w > 0 ? (long)n * (rows / ((long)crop_h * crop_w) - 1) * (crop_h - 1) * (crop_w - 1) * C : base;
   const int chunks = C / EPV;
   for (int k0 = 0; k0 < chunks; k0 += 256) {
     const int Cw = (chunks - k0) < 256 ? (chunks - k0) : 256;
@@ -696,8 +731,8 @@ norm_bwd_apply_vec_kernel(const T* __restrict__ dtn, const T* __restrict__ t, co
       mean[i] = mr[((long)n * 2 + 0) * C + c + i];
       rstd[i] = mr[((long)n * 2 + 1) * C + c + i];
       rg[i] = rstd[i] * (gamma ? gamma[c + i] : 1.f);
-      m1[i] = s[((long)n * 2 + 0) * C + c + i] * inv_count;
-      m2[i] = s[((long)n * 2 + 1) * C + c + i] * inv_count;
+      m1[i] = (s_parts > 1 ? sm_s[c + i] : s[((long)n * 2 + 0) * C + c + i]) * inv_count;
+      m2[i] = (s_parts > 1 ? sm_s[C + c + i] : s[((long)n * 2 + 1) * C + c + i]) * inv_count;
     }
 #pragma unroll 2
     for (long r = r0 + rl; r < r1; r += RL) {
@@ -706,8 +741,78 @@ norm_bwd_apply_vec_kernel(const T* __restrict__ dtn, const T* __restrict__ t, co
       VecIO<T, EPV>::load(t + base + r * C + c, u);
 #pragma unroll
       for (int i = 0; i < EPV; ++i) o[i] = rg[i] * (d[i] - m1[i] - (u[i] - mean[i]) * rstd[i] * m2[i]);
-      VecIO<T, EPV>::store(dt + base + r * C + c, o);
+      long ro = r;
+      if (crop_w > 0) {
+        const int x = (int)(r % crop_w);
+        const long q = r / crop_w;
+        const int y = (int)(q % crop_h);
+        const long z = q / crop_h;
+        if (x == 0 || y == 0 || z == 0) continue;
+        ro = ((z - 1) * (crop_h - 1) + (y - 1)) * (crop_w - 1) + (x - 1);
+      }
+      VecIO<T, EPV>::store(dt + obase + ro * C + c, o);
     }
+  }
+}
+
+// ---- GroupNorm backward statistics from the per-sample weight-gradient partials -------------------------------------------
+// With hp = W2 (gamma * xhat + beta) + b2 and dtn = W2^T dhp, the two sums the GroupNorm backward needs per (sample, channel),
+//     S1[n][c] = sum_r dtn[r][c]            = sum_h W2[h][c] * q[n][h],      q[n][h]    = sum_r dhp[r][h]
+//     S2[n][c] = sum_r dtn[r][c] xhat[r][c] = sum_h W2[h][c] * M[n][h][c],   M[n][h][c] = sum_r dhp[r][h] xhat[r][c]
+// are contractions of the PER-SAMPLE weight-gradient sums M, q (the MFMA weight-gradient kernel run against xhat with per-sample
+// slots) with the weights: no pass over the activations.  The parameter gradients follow from the same sums:
+//     dW2[h][c] = sum_n gamma[c] * M[n][h][c] + beta[n][c] * q[n][h],   db2[h] = sum_n q[n][h]      (beta = b + mean * a of `ab`)
+// workgroup = (16 channels, 64 hidden channels, sample); thread = (channel, h lane): h = lane, lane + 16, ...  It writes its
+// share s_part[h chunk][n][2][C] of the sums (added in chunk order by the apply pass), the sample's term of dW2 IN PLACE of
+// M[n], and q[n] (from the bias partials dbp [N][sps][H]) -- both then reduced over n like any other slot partial.
+__global__ void __launch_bounds__(256)
+norm_bwd_from_wgrad_kernel(float* __restrict__ M, const float* __restrict__ dbp, float* __restrict__ q,
+                           const float* __restrict__ W2, const float* __restrict__ gamma, const float* __restrict__ ab,
+                           const float* __restrict__ mr, float* __restrict__ s_part, int N, int C, int H, int sps) {
+  __shared__ float sm_q[4][64];
+  __shared__ float sm[2][16][17];
+  const int n = blockIdx.z, hc = blockIdx.y;
+  const int h0 = hc * 64;
+  {   // q[n][h0 .. h0+63] = sum over the sample's slots, four interleaved partial sums added in a fixed order
+    const int hh = threadIdx.x & 63, part = threadIdx.x >> 6;
+    float a = 0.f;
+    if (h0 + hh < H)
+      for (int j = part; j < sps; j += 4) a += dbp[((long)n * sps + j) * H + h0 + hh];
+    sm_q[part][hh] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const float a = (sm_q[0][threadIdx.x] + sm_q[1][threadIdx.x]) + (sm_q[2][threadIdx.x] + sm_q[3][threadIdx.x]);
+    sm_q[0][threadIdx.x] = a;
+    if (blockIdx.x == 0 && h0 + (int)threadIdx.x < H) q[(long)n * H + h0 + threadIdx.x] = a;
+  }
+  __syncthreads();
+  const int cl = threadIdx.x & 15, hl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const bool ok = c < C;
+  float s1 = 0.f, s2 = 0.f;
+  if (ok) {
+    const float g = gamma ? gamma[c] : 1.f;
+    const float beta = fmaf(mr[((long)n * 2 + 0) * C + c], ab[((long)n * 2 + 0) * C + c], ab[((long)n * 2 + 1) * C + c]);
+    float* Mn = M + (long)n * H * C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int hh = hl + 16 * k, h = h0 + hh;
+      if (h >= H) break;
+      const float w = W2[(long)h * C + c], m = Mn[(long)h * C + c], qq = sm_q[0][hh];
+      s1 = fmaf(w, qq, s1);
+      s2 = fmaf(w, m, s2);
+      Mn[(long)h * C + c] = fmaf(g, m, beta * qq);
+    }
+  }
+  sm[0][hl][cl] = s1;
+  sm[1][hl][cl] = s2;
+  __syncthreads();
+  if (hl < 2 && ok) {
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a += sm[hl][j][cl];
+    s_part[(((long)hc * N + n) * 2 + hl) * C + c] = a;
   }
 }
 
@@ -819,19 +924,45 @@ extern "C" int pytc_add_inplace(void* y, const void* x, int64_t n, int dtype, vo
 }
 
 extern "C" int pytc_pw_wgrad_slots(int64_t rows_total) {
-  long s = rows_total / 1024;
+  // the workspace bound: >= every slot count a launch may pick (wgrad_mfma_slots: down to 256 rows per slot on small problems)
+  long s = rows_total / 256;
   return (int)(s < 1 ? 1 : (s > 1024 ? 1024 : s));
 }
 
 static int wg_tile16(int C) { return C % 64 == 0 ? 4 : (C % 32 == 0 ? 2 : (C % 16 == 0 ? 1 : 0)); }
 
+// row slots of the MFMA weight-gradient launch: pytc_pw_wgrad_slots() is the workspace bound; the launch uses fewer row slots when
+// the channel tiles already supply workgroups
+static int wgrad_mfma_slots(long rows_total, int C_in, int C_out, int slots) {
+  const int mt = wg_tile16(C_out), nt = wg_tile16(C_in);
+  const long tiles = (long)(C_out / (16 * mt)) * (C_in / (16 * nt));
+  long want = rows_total / 2048;
+  const long cap = 1024 / tiles > 1 ? 1024 / tiles : 1;
+  want = want < 1 ? 1 : (want > cap ? cap : want);
+  // a launch that needs the cap would run 1024 workgroups over 256 CUs x (2 | 3 | 4) resident ones: 1.33 rounds, the last a
+  // third full.  Cut it to whole rounds of resident workgroups (the slot count only groups rows: sums stay in slot order)
+  const int per_cu = mt * nt >= 8 ? 2 : (mt * nt >= 4 ? 3 : 4);
+  const long resident = 256L * per_cu / tiles;
+  if (tuning_get("wgrad_whole_rounds", 1) && resident >= 8 && want > resident) want = (want / resident) * resident;
+  // deep levels (14^3 / 7^3 voxels per sample): 2048-row slots leave 160 / 128 workgroups, each a chain of 11-17 dependent
+  // row blocks per wave (42-48 us for 17 / 4 MB of operands).  Up to ~2 workgroups per CU, slots shrink to >= 256 rows
+  // (2 row blocks per wave: what the two-deep prefetch needs); the extra partials are a few MB
+  if (tuning_get("wgrad_small_split", 1) && want * tiles < 512) {
+    long more = 512 / tiles, most = rows_total / 256;
+    more = more < most ? more : most;
+    if (more > want) want = more;
+  }
+  return want < slots ? (int)want : slots;
+}
+
 template <int MT>
 static void launch_wgrad_mfma(int nt, dim3 grid, hipStream_t s, const bf16_t* x, const float* ab, const bf16_t* dy,
-                              float* dWp, float* dbp, long rows_total, long rps_sample, int C_in, int C_out, long rps, int x_act) {
+                              float* dWp, float* dbp, long rows_total, long rps_sample, int C_in, int C_out, long rps, int x_act,
+                              int sps = 0, int ab_mode = 0) {
   switch (nt) {
-    case 4: hipLaunchKernelGGL((pw_wgrad_mfma_kernel<MT, 4>), grid, dim3(256), 0, s, x, ab, dy, dWp, dbp, rows_total, rps_sample, C_in, C_out, rps, x_act); break;
-    case 2: hipLaunchKernelGGL((pw_wgrad_mfma_kernel<MT, 2>), grid, dim3(256), 0, s, x, ab, dy, dWp, dbp, rows_total, rps_sample, C_in, C_out, rps, x_act); break;
-    default: hipLaunchKernelGGL((pw_wgrad_mfma_kernel<MT, 1>), grid, dim3(256), 0, s, x, ab, dy, dWp, dbp, rows_total, rps_sample, C_in, C_out, rps, x_act); break;
+    case 4: hipLaunchKernelGGL((pw_wgrad_mfma_kernel<MT, 4>), grid, dim3(256), 0, s, x, ab, dy, dWp, dbp, rows_total, rps_sample, C_in, C_out, rps, x_act, sps, ab_mode); break;
+    case 2: hipLaunchKernelGGL((pw_wgrad_mfma_kernel<MT, 2>), grid, dim3(256), 0, s, x, ab, dy, dWp, dbp, rows_total, rps_sample, C_in, C_out, rps, x_act, sps, ab_mode); break;
+    default: hipLaunchKernelGGL((pw_wgrad_mfma_kernel<MT, 1>), grid, dim3(256), 0, s, x, ab, dy, dWp, dbp, rows_total, rps_sample, C_in, C_out, rps, x_act, sps, ab_mode); break;
   }
 }
 
@@ -844,22 +975,10 @@ static int pw_wgrad_impl(const void* x, const float* ab, const void* dy, float* 
   PYTC_REQUIRE(x_act == PYTC_ACT_NONE || x_act == PYTC_ACT_GELU, "pw_wgrad: bad x_act");
   const long rows_total = (long)N * rows_per_sample;
   const int mt = wg_tile16(C_out), nt = wg_tile16(C_in);
-  // pytc_pw_wgrad_slots() is the workspace bound; the launch uses fewer row slots when the channel tiles already supply
-  // workgroups: every workgroup ends with a cross-wave reduction and a C_out x C_in partial, so short slots (8 row
-  // blocks at level 1) spent most of their time there.  >= 2048 rows per slot, ~1024 workgroups at most.
+  // every workgroup ends with a cross-wave reduction and a C_out x C_in partial, so short slots (8 row blocks at level 1) spent
+  // most of their time there: >= 2048 rows per slot, ~1024 workgroups at most (wgrad_mfma_slots)
   int slots = pytc_pw_wgrad_slots(rows_total);
-  if (dtype == PYTC_BF16 && mt && nt) {
-    const long tiles = (long)(C_out / (16 * mt)) * (C_in / (16 * nt));
-    long want = rows_total / 2048;
-    const long cap = 1024 / tiles > 1 ? 1024 / tiles : 1;
-    want = want < 1 ? 1 : (want > cap ? cap : want);
-    // a launch that needs the cap would run 1024 workgroups over 256 CUs x (2 | 3 | 4) resident ones: 1.33 rounds, the last a
-    // third full.  Cut it to whole rounds of resident workgroups (the slot count only groups rows: sums stay in slot order)
-    const int per_cu = mt * nt >= 8 ? 2 : (mt * nt >= 4 ? 3 : 4);
-    const long resident = 256L * per_cu / tiles;
-    if (tuning_get("wgrad_whole_rounds", 1) && resident >= 8 && want > resident) want = (want / resident) * resident;
-    if (want < slots) slots = (int)want;
-  }
+  if (dtype == PYTC_BF16 && mt && nt) slots = wgrad_mfma_slots(rows_total, C_in, C_out, slots);
   const long rps = (rows_total + slots - 1) / slots;
   float* dWp = workspace;
   float* dbp = workspace + (long)slots * C_out * C_in;
@@ -923,6 +1042,87 @@ extern "C" int pytc_reduce_slots_multi(const pytc_reduce_item* items, int n_item
   m.count = n_items;
   hipLaunchKernelGGL(reduce_slots_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, m);
   PYTC_LAUNCH_CHECK("reduce_slots_multi");
+  return PYTC_OK;
+}
+
+/* GroupNorm-fed expand conv: weight-gradient sums AND the norm-backward statistics from one pass over (t, dhp) (see
+   norm_bwd_from_wgrad_kernel).  bf16, C and C_hid multiples of 16.  workspace (pytc_pw_wgrad_groupnorm_ws_elems floats):
+     [N*sps][C_hid*C] dW partials | [N*sps][C_hid] bias partials | term [N][C_hid*C] | q [N][C_hid]
+   with sps = pytc_pw_wgrad_groupnorm_sps.  On return  dW2 = sum_n term[n],  db2 = sum_n q[n]  (left to the caller's slot
+   reduction, N slots each) and s_part [parts][N][2][C] (parts = pytc_pw_wgrad_groupnorm_parts) holds the statistics in
+   hidden-channel chunks: pytc_norm_bwd_apply adds them; dbeta / dgamma = their sums over parts * N. */
+extern "C" int pytc_pw_wgrad_groupnorm_sps(int N, int64_t rows_per_sample, int C, int C_hid) {
+  const long rows_total = (long)N * rows_per_sample;
+  const int slots = wgrad_mfma_slots(rows_total, C, C_hid, pytc_pw_wgrad_slots(rows_total));
+  const int sps = slots / N;
+  return sps < 1 ? 1 : sps;
+}
+
+extern "C" int pytc_pw_wgrad_groupnorm_parts(int C_hid) { return (C_hid + 63) / 64; }
+
+extern "C" int pytc_pw_wgrad_groupnorm_supported(int C, int C_hid, int dtype) {
+  return dtype == PYTC_BF16 && wg_tile16(C) != 0 && wg_tile16(C_hid) != 0;
+}
+
+extern "C" int64_t pytc_pw_wgrad_groupnorm_ws_elems(int N, int64_t rows_per_sample, int C, int C_hid) {
+  const long per = (long)C_hid * C + C_hid;
+  return (int64_t)N * pytc_pw_wgrad_groupnorm_sps(N, rows_per_sample, C, C_hid) * per + (int64_t)N * per;
+}
+
+extern "C" int pytc_pw_wgrad_groupnorm(const void* t, const float* mean_rstd, const float* ab, const void* dhp, const float* W2,
+                                       const float* gamma, float* s_part, float* workspace, int N, int64_t rows_per_sample,
+                                       int C, int C_hid, int dtype, void* stream) {
+  PYTC_REQUIRE(t && mean_rstd && ab && dhp && W2 && s_part && workspace && N >= 1 && N <= 65535 && rows_per_sample >= 1,
+               "pw_wgrad_groupnorm: bad arguments");
+  PYTC_REQUIRE(pytc_pw_wgrad_groupnorm_supported(C, C_hid, dtype), "pw_wgrad_groupnorm: bf16 with C, C_hid multiples of 16 (got %d, %d)", C, C_hid);
+  const int sps = pytc_pw_wgrad_groupnorm_sps(N, rows_per_sample, C, C_hid);
+  const long rps = (rows_per_sample + sps - 1) / sps;
+  const long nW = (long)C_hid * C;
+  float* dWp = workspace;                                  // [N][sps][C_hid][C]
+  float* dbp = dWp + (long)N * sps * nW;                   // [N][sps][C_hid]
+  float* term = dbp + (long)N * sps * C_hid;               // M [N][C_hid][C] -> the samples' terms of dW2
+  float* qv = term + (long)N * nW;                         // q [N][C_hid]
+  hipStream_t s = (hipStream_t)stream;
+  const int mt = wg_tile16(C_hid), nt = wg_tile16(C);
+  dim3 grid(N * sps, (C_hid / (16 * mt)) * (C / (16 * nt)));
+  const bf16_t* xp = (const bf16_t*)t;
+  const bf16_t* dp = (const bf16_t*)dhp;
+  const long rows_total = (long)N * rows_per_sample;
+  if (mt == 4) launch_wgrad_mfma<4>(nt, grid, s, xp, mean_rstd, dp, dWp, dbp, rows_total, (long)rows_per_sample, C, C_hid, rps, PYTC_ACT_NONE, sps, 1);
+  else if (mt == 2) launch_wgrad_mfma<2>(nt, grid, s, xp, mean_rstd, dp, dWp, dbp, rows_total, (long)rows_per_sample, C, C_hid, rps, PYTC_ACT_NONE, sps, 1);
+  else launch_wgrad_mfma<1>(nt, grid, s, xp, mean_rstd, dp, dWp, dbp, rows_total, (long)rows_per_sample, C, C_hid, rps, PYTC_ACT_NONE, sps, 1);
+  hipLaunchKernelGGL(reduce_slots_batched_kernel, dim3(ceil_div(nW, 16), N), dim3(256), 0, s, dWp, term, nW, sps);
+  hipLaunchKernelGGL(norm_bwd_from_wgrad_kernel, dim3((C + 15) / 16, pytc_pw_wgrad_groupnorm_parts(C_hid), N), dim3(256), 0, s, term, dbp,
+                     qv, W2, gamma, ab, mean_rstd, s_part, N, C, C_hid, sps);
+  PYTC_LAUNCH_CHECK("pw_wgrad_groupnorm");
+  return PYTC_OK;
+}
+
+/* the apply pass of pytc_norm_bwd with the statistics given: s_in [s_parts][N][2][C], added over the parts (1 for the output
+   of pytc_norm_bwd_stats).  crop_grid (nullable, int32[3] = the (D, H, W) grid of the rows): drop the front faces, dt is the
+   compact (D-1, H-1, W-1) grid. */
+extern "C" int pytc_norm_bwd_apply(const void* dtn, const void* t, const float* mean_rstd, const float* gamma, const float* s_in,
+                                   int s_parts, void* dt, int N, int64_t rows, int C, float count, int dtype,
+                                   const int32_t* crop_grid, void* stream) {
+  PYTC_REQUIRE(dtn && t && mean_rstd && s_in && s_parts >= 1 && dt && count > 0.f, "norm_bwd_apply: bad arguments");
+  const bool vec = dtype == PYTC_BF16 ? (C % 8 == 0) : (C % 4 == 0);
+  PYTC_REQUIRE(vec, "norm_bwd_apply: C must be a multiple of %d", dtype == PYTC_BF16 ? 8 : 4);
+  PYTC_REQUIRE(s_parts == 1 || C <= NORM_APPLY_MAX_PART_C, "norm_bwd_apply: statistics in parts need C <= %d", NORM_APPLY_MAX_PART_C);
+  int ch = 0, cw = 0;
+  if (crop_grid) {
+    PYTC_REQUIRE((long)crop_grid[0] * crop_grid[1] * crop_grid[2] == rows && crop_grid[0] > 1 && crop_grid[1] > 1 && crop_grid[2] > 1,
+                 "norm_bwd_apply: crop grid does not match the rows");
+    ch = crop_grid[1]; cw = crop_grid[2];
+  }
+  const int slots = colstats_slots(rows);
+  const long rps = (rows + slots - 1) / slots;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(slots, N), block(256);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(norm_bwd_apply_vec_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)dtn, (const bf16_t*)t, mean_rstd, gamma, s_in, 1.0f / count, (bf16_t*)dt, (long)rows, C, rps, ch, cw, s_parts),
+             hipLaunchKernelGGL(norm_bwd_apply_vec_kernel<float>, grid, block, 0, s, (const float*)dtn, (const float*)t, mean_rstd, gamma, s_in, 1.0f / count, (float*)dt, (long)rows, C, rps, ch, cw, s_parts),
+             "norm_bwd_apply")
+  PYTC_LAUNCH_CHECK("norm_bwd_apply");
   return PYTC_OK;
 }
 

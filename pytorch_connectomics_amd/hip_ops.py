@@ -945,6 +945,55 @@ def norm_bwd_stats(d: torch.Tensor, x: torch.Tensor, mean_rstd: torch.Tensor) ->
     return s
 
 
+def pw_wgrad_groupnorm_supported(c: int, c_hid: int, dtype: torch.dtype) -> bool:
+    return dtype == torch.bfloat16 and bool(nat.lib().pytc_pw_wgrad_groupnorm_supported(int(c), int(c_hid), dtype_code(dtype)))
+
+
+def pw_wgrad_groupnorm(t: torch.Tensor, mean_rstd: torch.Tensor, ab: torch.Tensor, dhp: torch.Tensor, w2: torch.Tensor,
+                       gamma: Optional[torch.Tensor], *, N: int, rows_per_sample: int, c: int, c_hid: int,
+                       defer: Optional["DeferredReduce"] = None):
+    """Weight gradient of a GroupNorm-fed expand conv AND the GroupNorm backward statistics from one pass over (t, dhp)
+    (pytc_pw_wgrad_groupnorm).  w2: fp32 (c_hid, c).  -> dW2 (c_hid, c), db2 (c_hid), s_part (parts, N, 2, c): the sums
+    (sum dtn, sum dtn * xhat) in hidden-channel chunks, which norm_bwd_apply adds.  dW2 / db2 are sums over N sample terms: with
+    `defer` they join that object's single reduction launch and hold their values only after defer.flush()."""
+    _dev(t, "t"); _dev(dhp, "dhp")
+    dev = t.device
+    lib = nat.lib()
+    sps, parts = lib.pytc_pw_wgrad_groupnorm_sps(N, rows_per_sample, c, c_hid), lib.pytc_pw_wgrad_groupnorm_parts(c_hid)
+    nW = c_hid * c
+    ws = torch.empty((int(lib.pytc_pw_wgrad_groupnorm_ws_elems(N, rows_per_sample, c, c_hid)),), dtype=torch.float32, device=dev)
+    s = torch.empty((parts, N, 2, c), dtype=torch.float32, device=dev)
+    _run(f"pw_wgrad_gn[{c}->{c_hid}]", _nbytes(t, dhp), lib.pytc_pw_wgrad_groupnorm, _p(t), _p(mean_rstd), _p(ab), _p(dhp), _p(w2),
+         _p(gamma), _p(s), _p(ws), N, rows_per_sample, c, c_hid, dtype_code(t.dtype), _stream(), symbol="pw_wgrad_mfma_kernel")
+    term0 = N * sps * (nW + c_hid)
+    dW = torch.empty((c_hid, c), dtype=torch.float32, device=dev)
+    db = torch.empty((c_hid,), dtype=torch.float32, device=dev)
+    own = defer if defer is not None else DeferredReduce()
+    own.add(ws[term0:term0 + N * nW], dW, nW, N, keep=ws)
+    own.add(ws[term0 + N * nW:term0 + N * (nW + c_hid)], db, c_hid, N)
+    if defer is None:
+        own.flush()
+    return dW, db, s
+
+
+def norm_bwd_apply(dtn: torch.Tensor, t: torch.Tensor, mean_rstd: torch.Tensor, gamma: Optional[torch.Tensor], s: torch.Tensor, *,
+                   count: float, crop_grid=None) -> torch.Tensor:
+    """The apply pass of norm_bwd with the statistics given: s (N, 2, C), or (parts, N, 2, C) to be added over the parts.
+    crop_grid = (D, H, W) of the rows: the front faces are dropped, -> (N, D-1, H-1, W-1, C); otherwise -> shaped like dtn."""
+    _dev(dtn, "dtn"); _dev(t, "t")
+    N, Cc = t.shape[0], t.shape[-1]
+    rows = t.numel() // (N * Cc)
+    parts = s.shape[0] if s.dim() == 4 else 1
+    if crop_grid is not None:
+        d, h, w = (int(v) for v in crop_grid)
+        dt = torch.empty((N, d - 1, h - 1, w - 1, Cc), dtype=t.dtype, device=t.device)
+    else:
+        dt = torch.empty_like(dtn)
+    _run(f"norm_bwd_apply[C{Cc}]", _nbytes(dtn, t, dt), nat.lib().pytc_norm_bwd_apply, _p(dtn), _p(t), _p(mean_rstd), _p(gamma), _p(s),
+         parts, _p(dt), N, rows, Cc, float(count), dtype_code(t.dtype), _i3(crop_grid) if crop_grid is not None else None, _stream())
+    return dt
+
+
 def norm_bwd_apply_general(d: torch.Tensor, x: torch.Tensor, mean_rstd: torch.Tensor, gamma, M: torch.Tensor) -> torch.Tensor:
     _dev(d, "d"); _dev(x, "x")
     N, Cc = x.shape[0], x.shape[-1]

@@ -13,6 +13,7 @@ copies; every arithmetic op is a HIP kernel.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -25,6 +26,10 @@ from .. import hip_ops as ops
 # training forward of a block's channel mixer as ONE fused launch that also stores the hidden pre-activation
 # (pytc_pw_mlp_train_fwd); False: two GEMM launches (expand, then project with the GELU in its operand prologue)
 FUSED_TRAIN_MIXER = True
+# ... but only where the voxel rows alone fill the chip: the fused mixer parallelises over rows (64 per workgroup), so the 7^3 / 14^3
+# levels of a 112^3 patch run it on 86 / 686 workgroups that each stream BOTH weight images; below this many rows (N * voxels) the
+# two single GEMMs, which also share out their output channels (pw_fast_kernels.hip: blockIdx.z), are faster
+FUSED_TRAIN_MIXER_MIN_ROWS = int(os.environ.get("PYTC_FUSED_MIXER_MIN_ROWS", "16384"))
 # the two data-gradient GEMMs of the mixer as one launch (pytc_pw_mlp_bwd): bit-identical results and 25 % less traffic,
 # but measured slower than the two launches it replaces (503 vs ~440 us at 4x112^3, level 0: the exact GELU' between the
 # GEMMs sits on the MFMA critical path instead of in a store epilogue) -> off
@@ -32,6 +37,10 @@ FUSED_TRAIN_MIXER_BWD = False
 # data gradient of a residual block, dx = conv_reversed(dt) + dy, with the "+ dy" inside the depthwise kernel (bf16, z-march
 # shapes) instead of a separate read-modify-write pass over dx
 FUSED_RESIDUAL_DGRAD = True
+# GroupNorm backward statistics (sum dtn, sum dtn * xhat per sample and channel) as contractions of the expand conv's PER-SAMPLE
+# weight-gradient sums with its weights (pytc_pw_wgrad_groupnorm) instead of a pass over (dtn, t); the up block's apply pass then
+# also writes the compact grid the transposed conv's backward reads (no crop copy).  False: pytc_norm_bwd (statistics + apply)
+NORM_STATS_FROM_WGRAD = os.environ.get("PYTC_NORM_STATS_FROM_WGRAD", "1") != "0"
 
 
 # every per-step weight re-layout (MFMA images, tap-major stencils) of a model is rebuilt by ONE launch: the StepPacks set of
@@ -153,15 +162,19 @@ class PointwiseFn(torch.autograd.Function):
         N = x.shape[0]
         rows = x.numel() // (N * c_in)
         dyc = dy.contiguous()
+        dyx, xin = dyc, x
         if dyc.dtype != x.dtype and x.dtype in (torch.float32, torch.bfloat16):
-            dyx = dyc.to(x.dtype)
-        else:
-            dyx = dyc
+            # one dtype for both GEMM operands: convert the SMALLER tensor.  The stem meets its fp32 one-channel input with a bf16
+            # 32-channel gradient: rounding the input (what autocast does to a conv input) moves 34 MB, converting the gradient
+            # moved 1.1 GB and doubled the bytes the weight-gradient kernel read
+            if x.numel() < dyc.numel() and not ctx.needs_input_grad[0]:
+                xin = x.to(dyc.dtype)
+            else:
+                dyx = dyc.to(x.dtype)
         dx = None
         if ctx.needs_input_grad[0]:
             # dX = dY . W : operator c_out -> c_in with matrix W^T
             dx = _pw(dyx, w, None, c_out=c_in, transposed=not transposed, packs=ctx.packs).view_as(x)
-        xin = x if x.dtype == dyx.dtype else x.to(dyx.dtype)
         dW, db = ops.pw_wgrad(xin.contiguous(), dyx, N=N, rows_per_sample=rows, c_in=c_in, c_out=c_out,
                               want_bias=has_bias)
         dW = dW.t().contiguous() if transposed else dW
@@ -169,7 +182,7 @@ class PointwiseFn(torch.autograd.Function):
                 None, None, None)
 
 
-def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res, dr, lane=None):
+def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res, dr, lane=None, dtc=None):
     """Depthwise-conv half of a block backward, shared by BlockFn and NormVariantBlockFn: from dt (gradient of the depthwise
     output) to dx, dW1 (tap-major), db1 and the gradients of the resampling residual conv.  Slot reductions join `dr`."""
     N, D, H, W, C = x.shape
@@ -197,8 +210,8 @@ def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res,
             dxg = _pw(dy, _mat(wres), None, c_out=C, transposed=True, rows=rows, packs=packs).view_as(xg)
             dx[:, ::2, ::2, ::2, :] += dxg         # strided in-place add: only the 1/8 of dx the 1x1x1 stride-2 conv read
     else:
-        dtp = dt_.view_as(t)
-        dtc = dtp[:, 1:, 1:, 1:, :].contiguous()                # compact (2D-1)^3 grid of the transposed conv
+        if dtc is None:                                             # (given: the norm backward already wrote the compact grid)
+            dtc = dt_.view_as(t)[:, 1:, 1:, 1:, :].contiguous()     # compact (2D-1)^3 grid of the transposed conv
         dW1, _ = lane.run(lambda: ops.dw_wgrad(x, dtc, K=K, stride=2, want_bias=False, defer=dr), x, dtc)
         db1 = ops.channel_stats(dtc).sum(1)[:, 0].sum(0)
         dx, _ = ops.dwconv3d(dtc, taps, None, K=K, stride=2, stats=False, wide_range=True)
@@ -249,7 +262,7 @@ class BlockFn(torch.autograd.Function):
         rows = _rows(t)
         c_hid, c_out = w2.shape[0], w3.shape[0]
         fused = (dt == torch.bfloat16 and b2 is not None and b3 is not None and ops.pw_mlp_supported(C, c_hid, c_out)
-                 and FUSED_TRAIN_MIXER)
+                 and FUSED_TRAIN_MIXER and N * rows >= FUSED_TRAIN_MIXER_MIN_ROWS)
         if fused:
             # one launch: norm affine -> expand -> (store pre-activation hp) -> GELU -> project -> residual epilogue
             hp = torch.empty((N, rows, c_hid), dtype=dt, device=x.device)
@@ -323,27 +336,43 @@ class BlockFn(torch.autograd.Function):
         dW3, db3 = lane.run(lambda: ops.pw_wgrad(hp, dcore, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, x_act=nat.ACT_GELU,
                                                  defer=dr), hp, dcore)
         fused_bwd = (dy.dtype == torch.bfloat16 and FUSED_TRAIN_MIXER_BWD and ops.pw_mlp_supported(c_out, c_hid, C))
+        # expand conv hp = W2 (a t + b) + b2: its weight gradient, and with it the GroupNorm backward sums (one pass over (t, dhp))
+        stats_from_wgrad = NORM_STATS_FROM_WGRAD and ops.pw_wgrad_groupnorm_supported(C, c_hid, dy.dtype)
+
+        def wgrad2(dhp):
+            if stats_from_wgrad:
+                return ops.pw_wgrad_groupnorm(t, mr, ab, dhp, _mat(w2), _f(gamma), N=N, rows_per_sample=rows, c=C, c_hid=c_hid, defer=dr)
+            return lane.run(lambda: ops.pw_wgrad(t, dhp, N=N, rows_per_sample=rows, c_in=C, c_out=c_hid, ab=ab, defer=dr), t, dhp, ab) + (None,)
+
         if fused_bwd:
             # both data-gradient GEMMs in one launch: dtn = W2^T ((W3^T dy) * gelu'(hp)); dhp comes back for wgrad2
             dtn, dhp = ops.pw_mlp_bwd(dcore.view(N, rows, c_out), hp, ops.packed_paired(_mat(w3), transposed=True, packs=packs),
                                       ops.packed_paired(_mat(w2), transposed=True, packs=packs), N=N, rows_per_sample=rows,
                                       c_in=C, c_hid=c_hid, c_out=c_out)
-            dW2, db2 = lane.run(lambda: ops.pw_wgrad(t, dhp, N=N, rows_per_sample=rows, c_in=C, c_out=c_hid, ab=ab, defer=dr), t, dhp, ab)
+            dW2, db2, s = wgrad2(dhp)
         else:
             # dhp = (W3^T dy) * gelu'(hp): the GELU derivative is the epilogue of the data-gradient GEMM
             dhp = _pw(dcore, _mat(w3), None, c_out=c_hid, transposed=True, rows=rows, res=hp, res_mode=nat.RES_GELU_BWD, packs=packs)
-            # ---- expand: hp = W2 (a t + b) + b2
-            dW2, db2 = lane.run(lambda: ops.pw_wgrad(t, dhp, N=N, rows_per_sample=rows, c_in=C, c_out=c_hid, ab=ab, defer=dr), t, dhp, ab)
+            dW2, db2, s = wgrad2(dhp)
             dtn = _pw(dhp, _mat(w2), None, c_out=C, transposed=True, rows=rows, packs=packs)
         del dhp
         # ---- GroupNorm(C, C)
-        dt_, s = ops.norm_bwd(dtn, t, mr, _f(gamma), count=count)
+        dtc = None
+        if stats_from_wgrad:
+            if kind == "up":
+                dtc = ops.norm_bwd_apply(dtn, t, mr, _f(gamma), s, count=count, crop_grid=tuple(t.shape[1:4]))
+                dt_ = None
+            else:
+                dt_ = ops.norm_bwd_apply(dtn, t, mr, _f(gamma), s, count=count)
+        else:
+            dt_, s = ops.norm_bwd(dtn, t, mr, _f(gamma), count=count)
         ssum = torch.empty((2, C), dtype=torch.float32, device=x.device)
-        dr.add(s, ssum, 2 * C, N)        # (N, 2, C) -> (2, C): the samples are the "slots"
+        dr.add(s, ssum, 2 * C, s.numel() // (2 * C))        # ([parts,] N, 2, C) -> (2, C): samples (x chunks) are the "slots"
         dgamma, dbeta = ssum[1], ssum[0]
         del dtn
         # ---- depthwise conv
-        dx, dW1, db1, dwres, dbres, dwres_m = _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res, dr, lane)
+        dx, dW1, db1, dwres, dbres, dwres_m = _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res, dr, lane,
+                                                           dtc=dtc)
         lane.join()
         dr.flush()                       # all weight / bias / norm gradients of the block are final from here on
         if kind == "up" and has_res:

@@ -689,3 +689,100 @@ def test_mednext_norm_variants_training_step_matches_oracle_autograd(norm_type, 
     rW = params["enc_block_0.0.conv2.weight"].grad.flatten()
     assert all(torch.isfinite(q.grad).all() for q in m.parameters() if q.grad is not None)
     assert float((gW * rW).sum() / (gW.norm() * rW.norm() + 1e-20)) > 0.97
+
+
+@pytest.mark.parametrize("C,H,rows,N", [(32, 64, 5003, 2), (64, 128, 4096, 3), (16, 16, 100, 1), (256, 512, 343, 2), (48, 96, 2500, 4)])
+def test_groupnorm_backward_statistics_from_weight_gradient_sums(C, H, rows, N):
+    """pytc_pw_wgrad_groupnorm: the GroupNorm backward sums (sum dtn, sum dtn * xhat per sample and channel; dtn = W2^T dhp) as
+    contractions of the per-sample weight-gradient sums with the weights, against fp64 math on the same bf16 operands -- and the
+    weight / bias gradients it returns against the plain weight-gradient kernel (operand a*t+b)."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(C + H + rows)
+    t = (torch.randn(N, rows, C) * 1.7 + 0.4).bfloat16()
+    dhp = (torch.randn(N, rows, H) * 1e-3).bfloat16()             # gradient-sized values
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.3
+    W2 = torch.randn(H, C) / C ** 0.5
+    tc = t.cuda().view(N, rows, 1, 1, C)
+    ab, mr = ops.groupnorm_finalize_mr(ops.channel_stats(tc), float(rows), gamma.cuda(), beta.cuda(), 1e-5)
+    dW, db, s = ops.pw_wgrad_groupnorm(t.cuda(), mr, ab, dhp.cuda(), W2.cuda(), gamma.cuda(), N=N, rows_per_sample=rows, c=C, c_hid=H)
+    assert s.shape == (-(-H // 64), N, 2, C)
+    s = s.sum(0)                                                  # hidden-channel chunks, added by norm_bwd_apply
+    mean, rstd = mr[:, 0].double().cpu(), mr[:, 1].double().cpu()
+    xhat = (t.double() - mean[:, None]) * rstd[:, None]
+    xhat_b = xhat.float().bfloat16().double()                     # the MFMA operand
+    d = dhp.double()
+    M = torch.einsum("nrh,nrc->nhc", d, xhat_b)
+    q = d.sum(1)
+    s_ref = torch.stack([torch.einsum("hc,nh->nc", W2.double(), q), torch.einsum("hc,nhc->nc", W2.double(), M)], 1)
+    scale = s_ref.abs().max().item()
+    assert (s.double().cpu() - s_ref).abs().max().item() <= 2e-4 * scale + 1e-9
+    # the same sums the direct pass would produce from the UNROUNDED dtn (what the kernel replaces rounds dtn to bf16 first)
+    dtn = torch.einsum("nrh,hc->nrc", d, W2.double())
+    direct = torch.stack([dtn.sum(1), (dtn * xhat).sum(1)], 1)
+    assert (s.double().cpu() - direct).abs().max().item() <= 6e-3 * direct.abs().max().item()
+    dW_ref = gamma.double() * M.sum(0) + beta.double() * q.sum(0)[:, None]
+    assert (dW.double().cpu() - dW_ref).abs().max().item() <= 1e-3 * dW_ref.abs().max().item() + 1e-9
+    torch.testing.assert_close(db.double().cpu(), q.sum(0), rtol=1e-4, atol=1e-7)
+    dW_plain, db_plain = ops.pw_wgrad(t.cuda(), dhp.cuda(), N=N, rows_per_sample=rows, c_in=C, c_out=H, ab=ab)
+    assert (dW.cpu() - dW_plain.cpu()).abs().max().item() <= 1.5e-2 * dW_plain.abs().max().item()
+    torch.testing.assert_close(db.cpu(), db_plain.cpu(), rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_norm_backward_apply_with_given_statistics_and_front_face_crop(dt):
+    """pytc_norm_bwd_apply == the apply half of pytc_norm_bwd (bit-identical with the same sums); with crop_grid it writes the
+    compact grid without the front faces (what the up block's transposed-conv backward reads)."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(3)
+    N, D, H, W, C = 2, 6, 8, 10, 32
+    t = torch.randn(N, D, H, W, C).to(dt).cuda()
+    dtn = torch.randn(N, D, H, W, C).to(dt).cuda()
+    gamma = (torch.rand(C) + 0.5).cuda()
+    ab, mr = ops.groupnorm_finalize_mr(ops.channel_stats(t), float(D * H * W), gamma, torch.zeros(C).cuda(), 1e-5)
+    full, s = ops.norm_bwd(dtn, t, mr, gamma, count=float(D * H * W))
+    again = ops.norm_bwd_apply(dtn, t, mr, gamma, s, count=float(D * H * W))
+    assert torch.equal(full, again)
+    chunks = torch.stack([s, torch.zeros_like(s), torch.zeros_like(s)], 0).contiguous()       # (parts, N, 2, C): an exact split
+    assert torch.equal(full, ops.norm_bwd_apply(dtn, t, mr, gamma, chunks, count=float(D * H * W)))
+    crop = ops.norm_bwd_apply(dtn, t, mr, gamma, chunks, count=float(D * H * W), crop_grid=(D, H, W))
+    assert crop.shape == (N, D - 1, H - 1, W - 1, C)
+    assert torch.equal(crop, full[:, 1:, 1:, 1:].contiguous())
+
+
+def test_mednext_gradients_with_algebraic_norm_statistics_are_as_close_to_fp32_as_the_two_pass_form(monkeypatch):
+    """BlockFn with NORM_STATS_FROM_WGRAD on / off (bf16 storage, all three block kinds) against the fp32 path of the same model:
+    the algebraic statistics must not add error (they use unrounded dtn where the two-pass form reads bf16(dtn))."""
+    from pytorch_connectomics_amd.models.architectures.mednext import MedNeXt
+    from pytorch_connectomics_amd.training import autograd as ag
+    from pytorch_connectomics_amd.training.fused import bce_dice_loss
+    torch.manual_seed(0)
+    m = MedNeXt(1, 16, 2, exp_r=2, kernel_size=3, do_res=True, do_res_up_down=True, block_counts=[1] * 9).cuda().train()
+    x = torch.rand(2, 1, 32, 32, 32).cuda()
+    y = (torch.rand(2, 2, 32, 32, 32) > 0.8).float().cuda()
+
+    def grads(dtype, flag):
+        monkeypatch.setattr(ag, "NORM_STATS_FROM_WGRAD", flag)
+        m.compute_dtype = dtype
+        m.zero_grad(set_to_none=True)
+        loss, _ = bce_dice_loss(m(x), y)
+        loss.backward()
+        return {n: p.grad.detach().double().flatten().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    ref = grads(torch.float32, False)
+    new, old = grads(torch.bfloat16, True), grads(torch.bfloat16, False)
+    assert ref.keys() == new.keys() == old.keys() and len(ref) > 50
+    # a bias in front of a GroupNorm has a zero gradient (what the kernels return for it is rounding noise): not compared
+    for g in (ref, new, old):
+        for n in [n for n in g if n.endswith("conv1.bias")]:
+            del g[n]
+    rel = lambda g: {n: ((g[n] - ref[n]).norm() / ref[n].norm().clamp_min(1e-30)).item() for n in ref}      # noqa: E731
+    e_new, e_old = rel(new), rel(old)
+    worst_new, worst_old = max(e_new.values()), max(e_old.values())
+    mean_new, mean_old = sum(e_new.values()) / len(e_new), sum(e_old.values()) / len(e_old)
+    print(f"[algebraic norm statistics] relative L2 error against fp32: worst {worst_new:.3e} (two-pass {worst_old:.3e}), "
+          f"mean {mean_new:.3e} (two-pass {mean_old:.3e})")
+    assert worst_new <= 1.25 * worst_old + 1e-3 and mean_new <= 1.1 * mean_old + 1e-4
+    # the norm parameters are what the statistics feed directly
+    for n in ref:
+        if ".norm." in n:
+            assert e_new[n] <= 1.5 * e_old[n] + 5e-3, (n, e_new[n], e_old[n])
