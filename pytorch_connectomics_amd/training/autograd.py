@@ -182,7 +182,7 @@ class PointwiseFn(torch.autograd.Function):
                 None, None, None)
 
 
-def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res, dr, lane=None, dtc=None):
+def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res, dr, lane=None, dtc=None, norm_is_per_channel=False):
     """Depthwise-conv half of a block backward, shared by BlockFn and NormVariantBlockFn: from dt (gradient of the depthwise
     output) to dx, dW1 (tap-major), db1 and the gradients of the resampling residual conv.  Slot reductions join `dr`."""
     N, D, H, W, C = x.shape
@@ -213,7 +213,13 @@ def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res,
         if dtc is None:                                             # (given: the norm backward already wrote the compact grid)
             dtc = dt_.view_as(t)[:, 1:, 1:, 1:, :].contiguous()     # compact (2D-1)^3 grid of the transposed conv
         dW1, _ = lane.run(lambda: ops.dw_wgrad(x, dtc, K=K, stride=2, want_bias=False, defer=dr), x, dtc)
-        db1 = ops.channel_stats(dtc).sum(1)[:, 0].sum(0)
+        if norm_is_per_channel:
+            # GroupNorm(C, C) subtracts the per-(sample, channel) mean over exactly the voxels the bias reaches: its gradient
+            # sum_r dt[r][c] = rstd*gamma * (S1 - count*S1/count - S2/count * sum_r xhat) is zero identically; what a pass over dt
+            # returned for it was rounding noise (as autograd's value is in the reference)
+            db1 = torch.zeros((C,), dtype=torch.float32, device=x.device)
+        else:
+            db1 = ops.channel_stats(dtc).sum(1)[:, 0].sum(0)
         dx, _ = ops.dwconv3d(dtc, taps, None, K=K, stride=2, stats=False, wide_range=True)
         if has_res:
             drl = dy[:, 1::2, 1::2, 1::2, :].contiguous()       # positions fed by the transposed 1x1 conv
@@ -372,7 +378,7 @@ class BlockFn(torch.autograd.Function):
         del dtn
         # ---- depthwise conv
         dx, dW1, db1, dwres, dbres, dwres_m = _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res, dr, lane,
-                                                           dtc=dtc)
+                                                           dtc=dtc, norm_is_per_channel=True)
         lane.join()
         dr.flush()                       # all weight / bias / norm gradients of the block are final from here on
         if kind == "up" and has_res:
