@@ -549,6 +549,17 @@ int pytc_norm_bwd_stats(const void* dtn, const void* t, const float* mean_rstd, 
                         int64_t rows, int C, int dtype, void* stream);
 int pytc_norm_bwd_apply_general(const void* d, const void* x, const float* mean_rstd, const float* gamma, const float* M,
                                 void* dx, int N, int64_t rows, int C, int dtype, void* stream);
+/* act_bwd + the norm backward WITHOUT the intermediate dt tensor (RSUNet / MONAI-style conv -> norm -> activation units;
+ * reference: torch autograd through nn.BatchNorm3d / GroupNorm + ReLU / PReLU / ELU, rsunet.py + monai BasicUNet blocks): dt = da *
+ * act'(a*x + b) is recomputed in registers by the statistics pass and by the apply pass, rounded to the storage type where the
+ * three-pass form stored it (same dt values; sums differ by fp32 summation order only).  pytc_act_norm_bwd_stats: s_out [N][2][C] = (sum dt, sum dt * xhat);
+ * p_out (nullable, with p_ws) [N][C] = sum da * min(a*x + b, 0), the PReLU weight gradient's summand.  stats_ws:
+ * pytc_norm_bwd_ws_elems floats, p_ws half of that.  pytc_act_norm_bwd_apply: dx = rstd * (gamma * dt - M1 - xhat * M2), M from
+ * pytc_norm_bwd_means.  C a multiple of 8 (bf16) / 4 (fp32). */
+int pytc_act_norm_bwd_stats(const void* da, const void* x, const float* ab, const float* mean_rstd, float* stats_ws, float* s_out,
+                            float* p_ws, float* p_out, int N, int64_t rows, int C, int act, float prm, int dtype, void* stream);
+int pytc_act_norm_bwd_apply(const void* da, const void* x, const float* ab, const float* mean_rstd, const float* gamma,
+                            const float* M, void* dx, int N, int64_t rows, int C, int act, float prm, int dtype, void* stream);
 int pytc_maxpool3d_bwd(const void* x, const void* dy, void* dx, int N, int D, int H, int W, int C, int fz, int fy, int fx,
                        int dtype, void* stream);
 int pytc_dwconv3d_generic_fwd(const void* x, void* y, const float* w, int N, int D, int H, int W, int C,

@@ -403,8 +403,13 @@ static void launch_conv_tile_mt(const ConvParams& p, const ConvTile& t, size_t l
 
 static void launch_conv_tile(const ConvParams& p, ConvTile t, size_t lds_bytes, hipStream_t s) {
   t.tiles_z = (p.D + CT_TZ - 1) / CT_TZ; t.tiles_y = (p.H + CT_TY - 1) / CT_TY; t.tiles_x = (p.W + CT_TX - 1) / CT_TX;
-  const int MT = p.MTt >= 4 ? 4 : (p.MTt >= 2 ? 2 : 1);
-  dim3 grid((unsigned)((long)p.N * t.tiles_z * t.tiles_y * t.tiles_x), (unsigned)((p.MTt + MT - 1) / MT));
+  int MT = p.MTt >= 4 ? 4 : (p.MTt >= 2 ? 2 : 1);
+  // deep levels (2 x 18 x 20 x 20 voxels = 60 spatial tiles): 64 output channels per workgroup leave 120 workgroups for 256 CUs;
+  // fewer output tiles per workgroup (every workgroup stages the same input tile: L2 hits) until one per CU exists (more costs level 1 its 64-channel reuse: 40 -> 55 us)
+  const long spatial = (long)p.N * t.tiles_z * t.tiles_y * t.tiles_x;
+  if (tuning_get("conv_tile_small_mt", 1))
+    while (MT > 1 && spatial * ((p.MTt + MT - 1) / MT) < 256) MT >>= 1;
+  dim3 grid((unsigned)spatial, (unsigned)((p.MTt + MT - 1) / MT));
   switch (MT) {
     case 1: launch_conv_tile_mt<1>(p, t, lds_bytes, grid, s); break;
     case 2: launch_conv_tile_mt<2>(p, t, lds_bytes, grid, s); break;

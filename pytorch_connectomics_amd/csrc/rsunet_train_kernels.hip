@@ -6,6 +6,7 @@
 //   bilinear transposed-conv upsampling).
 // Data gradients of the dense convs reuse the forward implicit-GEMM kernel with flipped / transposed weights.
 #include "pytc_common.h"
+#include "colstats.h"
 
 namespace pytc {
 
@@ -338,6 +339,27 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
   }
 }
 
+// batched form of reduce_slots2_kernel: blockIdx.y = sample; part [N][slots][n] -> out [N][n], same summation tree
+__global__ void __launch_bounds__(256)
+reduce_slots_batched_rs_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int slots) {
+  __shared__ float sm[16][17];
+  part += (long)blockIdx.y * slots * n;
+  out += (long)blockIdx.y * n;
+  const int e = threadIdx.x & 15, j = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + e;
+  float a = 0.f;
+  if (i < n)
+    for (int s = j; s < slots; s += 16) a += part[(long)s * n + i];
+  sm[j][e] = a;
+  __syncthreads();
+  if (j == 0 && i < n) {
+    float t = sm[0][e];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += sm[q][e];
+    out[i] = t;
+  }
+}
+
 // out[i] = sum_s part[s][i] in a fixed tree: 16 elements x 16 slot lanes per workgroup (lane j adds slots j, j+16, ...
 // in order, then the 16 lane sums in lane order)
 __global__ void __launch_bounds__(256)
@@ -431,6 +453,141 @@ norm_bwd_apply_general_vec_kernel(const T* __restrict__ d, const T* __restrict__
     }
     VecIO<T, VEC>::store(dx + q * VEC, o);
   }
+}
+
+// ---- activation derivative + norm backward WITHOUT the intermediate dt tensor -----------------------------------------------
+// The three passes  act_bwd (dt = da * act'(t)) -> norm_bwd_stats(dt, x) -> norm_bwd_apply_general(dt, x)  move 8 tensor-sized
+// units (2 reads + 1 write, 2 reads, 2 reads + 1 write); dt is a function of (da, x) alone, so the statistics pass and the apply
+// pass each recompute it in registers from the same two tensors: 5 units, one launch less.  dt is rounded to the storage type
+// exactly where the three-pass form stored it: the same dt values enter the sums and dx (only the fp32 summation order of the
+// slot reduction differs).  PRELU: third column sum da*min(t,0).
+template <typename T>
+__device__ __forceinline__ void act_dt_vec(const float (&xv)[16 / sizeof(T)], const float (&dv)[16 / sizeof(T)], const float* a,
+                                           const float* b, int act, float prm, float (&dt)[16 / sizeof(T)],
+                                           float (&dp)[16 / sizeof(T)]) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    float t = xv[j];
+    if (a) t = to_f32<T>(from_f32<T>(fmaf(t, a[j], b[j])));
+    dt[j] = to_f32<T>(from_f32<T>(dv[j] * act_der(t, act, prm)));
+    dp[j] = to_f32<T>(from_f32<T>(t < 0.f ? dv[j] * t : 0.f));
+  }
+}
+
+template <typename T, bool PRELU>
+__global__ void __launch_bounds__(256)
+act_norm_bwd_stats_kernel(const T* __restrict__ da, const T* __restrict__ x, const float* __restrict__ ab,
+                          const float* __restrict__ mr, float* __restrict__ stats, float* __restrict__ pstats, long rows, int C,
+                          int slots, long rows_per_slot, int act, float prm) {
+  constexpr int EPV = 16 / (int)sizeof(T), W = PRELU ? 3 : 2;
+  __shared__ float lds[W * 256 * EPV];                 // [row lane][W][Cw * EPV]
+  const int n = blockIdx.y, slot = blockIdx.x;
+  const long r0 = (long)slot * rows_per_slot;
+  const long r1 = r0 + rows_per_slot < rows ? r0 + rows_per_slot : rows;
+  const T* dn = da + (long)n * rows * C;
+  const T* xn = x + (long)n * rows * C;
+  const int chunks = C / EPV;
+  for (int k0 = 0; k0 < chunks; k0 += 256) {
+    const int Cw = (chunks - k0) < 256 ? (chunks - k0) : 256;
+    const int RL = 256 / Cw;
+    const int ck = threadIdx.x % Cw, rl = threadIdx.x / Cw;
+    const int c = (k0 + ck) * EPV;
+    if (rl < RL) {
+      float s1[EPV], s2[EPV], s3[EPV], mean[EPV], rstd[EPV], av[EPV], bv[EPV];
+#pragma unroll
+      for (int i = 0; i < EPV; ++i) {
+        s1[i] = 0.f; s2[i] = 0.f; s3[i] = 0.f;
+        mean[i] = mr[((long)n * 2 + 0) * C + c + i];
+        rstd[i] = mr[((long)n * 2 + 1) * C + c + i];
+        av[i] = ab ? ab[((long)n * 2 + 0) * C + c + i] : 1.f;
+        bv[i] = ab ? ab[((long)n * 2 + 1) * C + c + i] : 0.f;
+      }
+#pragma unroll 2
+      for (long r = r0 + rl; r < r1; r += RL) {
+        float dv[EPV], xv[EPV], dt[EPV], dp[EPV];
+        VecIO<T, EPV>::load(dn + r * C + c, dv);
+        VecIO<T, EPV>::load(xn + r * C + c, xv);
+        act_dt_vec<T>(xv, dv, ab ? av : nullptr, bv, act, prm, dt, dp);
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) {
+          s1[i] += dt[i];
+          s2[i] = fmaf(dt[i], (xv[i] - mean[i]) * rstd[i], s2[i]);
+          if (PRELU) s3[i] += dp[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < EPV; ++i) {
+        lds[((rl * W + 0) * Cw + ck) * EPV + i] = s1[i];
+        lds[((rl * W + 1) * Cw + ck) * EPV + i] = s2[i];
+        if (PRELU) lds[((rl * W + 2) * Cw + ck) * EPV + i] = s3[i];
+      }
+    }
+    __syncthreads();
+    const int width = Cw * EPV;
+    for (int i = threadIdx.x; i < W * width; i += 256) {
+      const int which = i / width, e = i % width;
+      float acc = 0.f;
+      for (int q = 0; q < RL; ++q) acc += lds[(q * W + which) * width + e];
+      if (which < 2) stats[(((long)n * slots + slot) * 2 + which) * C + k0 * EPV + e] = acc;
+      else pstats[((long)n * slots + slot) * C + k0 * EPV + e] = acc;
+    }
+    __syncthreads();
+  }
+}
+
+// apply pass: workgroup = (row slot, sample), lane = (16-byte channel chunk, row lane); the seven per-channel coefficients live
+// in registers for the whole slot (a grid-stride form re-loaded them per element: 56 scalar loads around two 16-byte ones)
+template <typename T>
+__global__ void __launch_bounds__(256)
+act_norm_bwd_apply_kernel(const T* __restrict__ da, const T* __restrict__ x, const float* __restrict__ ab,
+                          const float* __restrict__ mr, const float* __restrict__ gamma, const float* __restrict__ M,
+                          T* __restrict__ dx, long rows, int C, long rows_per_slot, int act, float prm) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  const int n = blockIdx.y, slot = blockIdx.x;
+  const long r0 = (long)slot * rows_per_slot;
+  const long r1 = r0 + rows_per_slot < rows ? r0 + rows_per_slot : rows;
+  const long base = (long)n * rows * C;
+  const int chunks = C / EPV;
+  for (int k0 = 0; k0 < chunks; k0 += 256) {
+    const int Cw = (chunks - k0) < 256 ? (chunks - k0) : 256;
+    const int RL = 256 / Cw;
+    const int ck = threadIdx.x % Cw, rl = threadIdx.x / Cw;
+    if (rl >= RL) continue;
+    const int c = (k0 + ck) * EPV;
+    float mean[EPV], rstd[EPV], g[EPV], m1[EPV], m2[EPV], av[EPV], bv[EPV];
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) {
+      mean[i] = mr[((long)n * 2 + 0) * C + c + i];
+      rstd[i] = mr[((long)n * 2 + 1) * C + c + i];
+      g[i] = gamma ? gamma[c + i] : 1.f;
+      m1[i] = M[((long)n * 2 + 0) * C + c + i];
+      m2[i] = M[((long)n * 2 + 1) * C + c + i];
+      av[i] = ab ? ab[((long)n * 2 + 0) * C + c + i] : 1.f;
+      bv[i] = ab ? ab[((long)n * 2 + 1) * C + c + i] : 0.f;
+    }
+#pragma unroll 2
+    for (long r = r0 + rl; r < r1; r += RL) {
+      float dv[EPV], xv[EPV], dt[EPV], dp[EPV], o[EPV];
+      VecIO<T, EPV>::load(da + base + r * C + c, dv);
+      VecIO<T, EPV>::load(x + base + r * C + c, xv);
+      act_dt_vec<T>(xv, dv, ab ? av : nullptr, bv, act, prm, dt, dp);
+#pragma unroll
+      for (int i = 0; i < EPV; ++i) {
+        const float xh = (xv[i] - mean[i]) * rstd[i];
+        o[i] = rstd[i] * (g[i] * dt[i] - m1[i] - xh * m2[i]);
+      }
+      VecIO<T, EPV>::store(dx + base + r * C + c, o);
+    }
+  }
+}
+
+// row slots of the two kernels above: >= 16 rows per lane (a 16-channel tensor has 128 row lanes per workgroup; with the 64-row
+// slots of colstats_slots a lane met 3 rows and the launch was all prologue and LDS reduction)
+static inline int act_norm_slots(long rows, int C, int epv) {
+  const int chunks = C / epv, Cw = chunks < 256 ? chunks : 256, RL = 256 / Cw;
+  const long s = rows / ((long)RL * 16), cap = colstats_slots(rows);      // the workspace is sized for colstats_slots
+  return (int)(s < 1 ? 1 : (s > cap ? cap : s));
 }
 
 // ---- general norm backward apply: dx = rstd * (gamma * d - M1 - xhat * M2), M per (n, c) (group-expanded means) -----
@@ -732,6 +889,50 @@ extern "C" int pytc_norm_bwd_apply_general(const void* d, const void* x, const f
               hipLaunchKernelGGL(norm_bwd_apply_general_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)d, (const float*)x, mean_rstd, gamma, M, (float*)dx, (long)rows, C, total),
               "norm_bwd_apply_general")
   PYTC_LAUNCH_CHECK("norm_bwd_apply_general");
+  return PYTC_OK;
+}
+
+/* act_bwd + norm_bwd_stats without the intermediate dt: s_out [N][2][C] = (sum dt, sum dt * xhat), dt = da * act'(a*x + b) rounded
+   to the storage type; p_out (nullable, PReLU) [N][C] = sum da * min(a*x + b, 0).  stats_ws: pytc_norm_bwd_ws_elems floats, p_ws:
+   half of that.  C a multiple of 8 (bf16) / 4 (fp32). */
+extern "C" int pytc_act_norm_bwd_stats(const void* da, const void* x, const float* ab, const float* mean_rstd, float* stats_ws,
+                                       float* s_out, float* p_ws, float* p_out, int N, int64_t rows, int C, int act, float prm,
+                                       int dtype, void* stream) {
+  PYTC_REQUIRE(da && x && mean_rstd && stats_ws && s_out && N >= 1 && rows >= 1, "act_norm_bwd_stats: bad arguments");
+  PYTC_REQUIRE((p_ws == nullptr) == (p_out == nullptr), "act_norm_bwd_stats: p_ws and p_out come as a pair");
+  PYTC_REQUIRE((dtype == PYTC_BF16 && C % 8 == 0) || (dtype == PYTC_F32 && C % 4 == 0), "act_norm_bwd_stats: C %% (16 bytes) != 0");
+  const int slots = act_norm_slots(rows, C, dtype == PYTC_BF16 ? 8 : 4);      // <= colstats_slots(rows): the workspace bound
+  const long rps = (rows + slots - 1) / slots;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(slots, N), block(256);
+  if (dtype == PYTC_BF16) {
+    if (p_ws) hipLaunchKernelGGL((act_norm_bwd_stats_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)da, (const bf16_t*)x, ab, mean_rstd, stats_ws, p_ws, (long)rows, C, slots, rps, act, prm);
+    else hipLaunchKernelGGL((act_norm_bwd_stats_kernel<bf16_t, false>), grid, block, 0, s, (const bf16_t*)da, (const bf16_t*)x, ab, mean_rstd, stats_ws, p_ws, (long)rows, C, slots, rps, act, prm);
+  } else {
+    if (p_ws) hipLaunchKernelGGL((act_norm_bwd_stats_kernel<float, true>), grid, block, 0, s, (const float*)da, (const float*)x, ab, mean_rstd, stats_ws, p_ws, (long)rows, C, slots, rps, act, prm);
+    else hipLaunchKernelGGL((act_norm_bwd_stats_kernel<float, false>), grid, block, 0, s, (const float*)da, (const float*)x, ab, mean_rstd, stats_ws, p_ws, (long)rows, C, slots, rps, act, prm);
+  }
+  hipLaunchKernelGGL(reduce_slots_batched_rs_kernel, dim3(ceil_div(2L * C, 16), N), dim3(256), 0, s, stats_ws, s_out, 2L * C, slots);
+  if (p_ws) hipLaunchKernelGGL(reduce_slots_batched_rs_kernel, dim3(ceil_div((long)C, 16), N), dim3(256), 0, s, p_ws, p_out, (long)C, slots);
+  PYTC_LAUNCH_CHECK("act_norm_bwd_stats");
+  return PYTC_OK;
+}
+
+/* act_bwd + norm_bwd_apply_general without the intermediate dt: dx = rstd * (gamma * dt - M1 - xhat * M2) */
+extern "C" int pytc_act_norm_bwd_apply(const void* da, const void* x, const float* ab, const float* mean_rstd, const float* gamma,
+                                       const float* M, void* dx, int N, int64_t rows, int C, int act, float prm, int dtype,
+                                       void* stream) {
+  PYTC_REQUIRE(da && x && mean_rstd && M && dx, "act_norm_bwd_apply: null pointer");
+  PYTC_REQUIRE((dtype == PYTC_BF16 && C % 8 == 0) || (dtype == PYTC_F32 && C % 4 == 0), "act_norm_bwd_apply: C %% (16 bytes) != 0");
+  const int slots = act_norm_slots(rows, C, dtype == PYTC_BF16 ? 8 : 4);
+  const long rps = (rows + slots - 1) / slots;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(slots, N), block(256);
+  if (dtype == PYTC_BF16)
+    hipLaunchKernelGGL(act_norm_bwd_apply_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)da, (const bf16_t*)x, ab, mean_rstd, gamma, M, (bf16_t*)dx, (long)rows, C, rps, act, prm);
+  else
+    hipLaunchKernelGGL(act_norm_bwd_apply_kernel<float>, grid, block, 0, s, (const float*)da, (const float*)x, ab, mean_rstd, gamma, M, (float*)dx, (long)rows, C, rps, act, prm);
+  PYTC_LAUNCH_CHECK("act_norm_bwd_apply");
   return PYTC_OK;
 }
 

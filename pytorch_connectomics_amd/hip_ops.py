@@ -994,6 +994,36 @@ def norm_bwd_apply(dtn: torch.Tensor, t: torch.Tensor, mean_rstd: torch.Tensor, 
     return dt
 
 
+def act_norm_bwd_supported(x: torch.Tensor) -> bool:
+    return x.shape[-1] % (8 if x.dtype == torch.bfloat16 else 4) == 0 and x.dtype in (torch.bfloat16, torch.float32)
+
+
+def act_norm_bwd_stats(da: torch.Tensor, x: torch.Tensor, ab: Optional[torch.Tensor], mean_rstd: torch.Tensor, act: int, prm: float,
+                       want_prelu: bool = False):
+    """-> s (N, 2, C) = (sum dt, sum dt * xhat) with dt = da * act'(a*x + b) never stored, p (N, C) | None = sum da * min(t, 0)"""
+    _dev(da, "da"); _dev(x, "x")
+    N, Cc = x.shape[0], x.shape[-1]
+    rows = x.numel() // (N * Cc)
+    n_ws = nat.lib().pytc_norm_bwd_ws_elems(N, rows, Cc)
+    ws = torch.empty((n_ws + (n_ws // 2 if want_prelu else 0),), dtype=torch.float32, device=x.device)
+    s = torch.empty((N, 2, Cc), dtype=torch.float32, device=x.device)
+    p = torch.empty((N, Cc), dtype=torch.float32, device=x.device) if want_prelu else None
+    _run(f"act_norm_bwd_stats[C{Cc}]", _nbytes(da, x), nat.lib().pytc_act_norm_bwd_stats, _p(da), _p(x), _p(ab), _p(mean_rstd), _p(ws),
+         _p(s), _p(ws[n_ws:]) if want_prelu else None, _p(p), N, rows, Cc, int(act), float(prm), dtype_code(x.dtype), _stream())
+    return s, p
+
+
+def act_norm_bwd_apply(da: torch.Tensor, x: torch.Tensor, ab: Optional[torch.Tensor], mean_rstd: torch.Tensor, gamma, M: torch.Tensor,
+                       act: int, prm: float) -> torch.Tensor:
+    _dev(da, "da"); _dev(x, "x")
+    N, Cc = x.shape[0], x.shape[-1]
+    rows = x.numel() // (N * Cc)
+    dx = torch.empty_like(x)
+    _run(f"act_norm_bwd_apply[C{Cc}]", _nbytes(da, x, dx), nat.lib().pytc_act_norm_bwd_apply, _p(da), _p(x), _p(ab), _p(mean_rstd),
+         _p(gamma), _p(M), _p(dx), N, rows, Cc, int(act), float(prm), dtype_code(x.dtype), _stream())
+    return dx
+
+
 def norm_bwd_apply_general(d: torch.Tensor, x: torch.Tensor, mean_rstd: torch.Tensor, gamma, M: torch.Tensor) -> torch.Tensor:
     _dev(d, "d"); _dev(x, "x")
     N, Cc = x.shape[0], x.shape[-1]

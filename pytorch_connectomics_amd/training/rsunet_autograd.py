@@ -66,6 +66,12 @@ def prefetch_prelu(weights) -> None:
         _prelu_put(w, v)
 
 
+# activation derivative + norm backward without the intermediate dt tensor (pytc_act_norm_bwd_stats / _apply): the same dt values as
+# the three passes act_bwd -> norm_bwd_stats -> norm_bwd_apply_general (rounded where they were stored), 5 instead of 8 tensor-sized
+# memory passes
+FUSED_ACT_NORM_BWD = True
+
+
 class NormActFn(torch.autograd.Function):
     """a = act(norm(x)) on channels-last x.  kind in {none, group, instance, batch}."""
 
@@ -122,6 +128,17 @@ class NormActFn(torch.autograd.Function):
         rows = _rows(x)
         ab_ = ab if ab.numel() else None
         da = da.contiguous()
+        if FUSED_ACT_NORM_BWD and mode in ("group", "instance", "batch") and da.dtype == x.dtype and ops.act_norm_bwd_supported(x):
+            # dt = da * act'(t) is recomputed from (da, x) inside the statistics pass and the apply pass: never stored
+            s, p = ops.act_norm_bwd_stats(da, x, ab_, mr, act, prm, want_prelu=is_prelu)
+            dprelu = p.sum().reshape(1) if is_prelu else None
+            g32 = _f(gamma) if has_g else None
+            grp = 0 if mode == "batch" else (groups if mode == "group" else C)
+            M, dgamma, dbeta = ops.norm_bwd_means(s, g32, grp, rows, want_gamma=has_g, want_beta=has_b)
+            dx = ops.act_norm_bwd_apply(da, x, ab_, mr, g32, M, act, prm)
+            cast = lambda v, like: None if v is None else v.to(like.dtype).reshape(like.shape)      # noqa: E731
+            return (dx, cast(dgamma, gamma) if has_g else None, cast(dbeta, gamma) if has_b else None, dprelu, None, None, None,
+                    None, None, None)
         dt, dp = ops.act_bwd(da, x, ab_, act, prm, want_prelu=is_prelu)
         dprelu = None
         if is_prelu:
