@@ -525,6 +525,14 @@ int pytc_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, int N, cons
  *   (unbiased variance, momentum blend); count = N * voxels. */
 int pytc_conv3d_pack_weight_dgrad(const float* w, int C_out, int C_in, int kd, int kh, int kw, void* packed, int dtype,
                                   void* stream);
+/* Every conv-weight image of a model in ONE launch (the per-step repack of a training run).  pytc_conv3d_pack_plan: the layout
+ * pytc_conv3d_pack_weight (direct = 0) / pytc_conv3d_pack_weight_direct (direct = 1) writes for these channel counts: out[0] = kind
+ * (0 tap-major, 1 flat chunked), out[1] = KG | KC, out[2] = nchunks, out[3] = G, out[4] = elements written.  pytc_conv3d_pack_multi:
+ * table_dev = n_items x 16 int64 on the device { w, packed, s_o, s_c, first block, elements, C_out, C_in, ntap, kind, fp32 image,
+ * flip, out[1], out[2], out[3], 0 } with element (o, c, tap) of the conv read from w[o*s_o + c*s_c + (flip ? ntap-1-tap : tap)];
+ * total_blocks = sum of ceil(elements / 256).  Images are bit-identical to the single-weight packs. */
+int pytc_conv3d_pack_plan(int C_out, int C_in, int kd, int kh, int kw, int dtype, int direct, int64_t* out);
+int pytc_conv3d_pack_multi(const int64_t* table_dev, int n_items, int64_t total_blocks, void* stream);
 int pytc_norm_bwd_means(const float* s, const float* gamma, float* M, float* dgamma, float* dbeta, int N, int C, int groups,
                         float rows, void* stream);
 /* nn.BatchNorm3d in train() mode after the statistics pass, one launch: stats [slots_total][2][C] = the (sum, sum of squares)

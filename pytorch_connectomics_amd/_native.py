@@ -182,6 +182,8 @@ _SIGS = {
     "pytc_conv3d_wgrad_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32),
                                             C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                             C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
+    "pytc_conv3d_pack_plan": (C.c_int, [C.c_int] * 7 + [C.c_void_p]),
+    "pytc_conv3d_pack_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "pytc_conv3d_pack_weight_dgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "pytc_norm_bwd_means": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_float, C.c_void_p]),

@@ -391,6 +391,53 @@ conv3d_pack_kernel(const float* __restrict__ w, int C_out, int C_in, int ntap, T
   packed[i] = from_f32<TW>(v);
 }
 
+// Every conv-weight image of a model in ONE launch (the per-step repack of a training run: 64 launches of ~7 us each per RSUNet
+// step otherwise).  table: n_items rows of 16 int64 = { w, packed, s_o, s_c, first block, elements, C_out, C_in, ntap,
+// kind (0: [mtile][tap][kgroup][lane][EPL] of conv3d_pack_kernel / conv3d_pack_direct_kernel, 1: the flat chunked layout of
+// conv3d_pack_flat_kernel), fp32 image (else bf16), flip, KG | KC, nchunks, G, 0 }; a 256-thread block belongs to one row.
+__global__ void __launch_bounds__(256)
+conv3d_pack_multi_kernel(const long* __restrict__ table, int n_items) {
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {                                  // last row whose first block <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[(long)mid * 16 + 4] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long* r = table + (long)lo * 16;
+  const long i = ((long)blockIdx.x - r[4]) * 256 + threadIdx.x;
+  if (i >= r[5]) return;
+  const float* w = reinterpret_cast<const float*>(r[0]);
+  const long s_o = r[2], s_c = r[3];
+  const int C_out = (int)r[6], C_in = (int)r[7], ntap = (int)r[8], kind = (int)r[9], f32 = (int)r[10], flip = (int)r[11];
+  int o, k, tap;
+  if (kind == 1) {
+    const int KC = (int)r[12], nchunks = (int)r[13], G = (int)r[14];
+    const int j = (int)(i % 8);
+    long q = i / 8;
+    const int lane = (int)(q % 64); q /= 64;
+    const int g = (int)(q % G); q /= G;
+    const int ck = (int)(q % nchunks);
+    const int mt = (int)(q / nchunks);
+    o = mt * 16 + (lane & 15);
+    const int f = g * 32 + (lane >> 4) * 8 + j;
+    tap = f / KC;
+    k = ck * KC + f % KC;
+  } else {
+    const int KG = (int)r[12], EPL = f32 ? 4 : 8, KSTEP = f32 ? 16 : 32;
+    const int j = (int)(i % EPL);
+    long t = i / EPL;
+    const int lane = (int)(t % 64); t /= 64;
+    const int kg = (int)(t % KG); t /= KG;
+    tap = (int)(t % ntap);
+    const int mt = (int)(t / ntap);
+    o = mt * 16 + (lane & 15);
+    k = kg * KSTEP + (lane >> 4) * EPL + j;
+  }
+  float v = 0.f;
+  if (o < C_out && k < C_in && tap < ntap) v = w[o * s_o + k * s_c + (flip ? ntap - 1 - tap : tap)];
+  if (f32) reinterpret_cast<float*>(r[1])[i] = v;
+  else reinterpret_cast<bf16_t*>(r[1])[i] = from_f32<bf16_t>(v);
+}
+
 template <int MT>
 static void launch_conv_tile_mt(const ConvParams& p, const ConvTile& t, size_t lds_bytes, dim3 grid, hipStream_t s) {
   static bool attr_set = false;
@@ -488,6 +535,33 @@ extern "C" int pytc_conv3d_pack_weight_dgrad(const float* w, int C_out, int C_in
                                              int dtype, void* stream) {
   const long ntap = (long)kd * kh * kw;
   return pack_conv_weight(w, C_in, C_out, kd, kh, kw, packed, dtype, ntap, (long)C_in * ntap, 1, stream);
+}
+
+/* the layout pytc_conv3d_pack_weight (direct = 0) / pytc_conv3d_pack_weight_direct (direct = 1) would write for a conv with these
+   channel counts: out[0] = kind (0 tap-major, 1 flat chunked), out[1] = KG | KC, out[2] = nchunks, out[3] = G, out[4] = elements the
+   pack writes (<= the *_packed_elems allocation).  For building the table of pytc_conv3d_pack_multi. */
+extern "C" int pytc_conv3d_pack_plan(int C_out, int C_in, int kd, int kh, int kw, int dtype, int direct, int64_t* out) {
+  PYTC_REQUIRE(out && C_out >= 1 && C_in >= 1 && kd >= 1 && kh >= 1 && kw >= 1 && (dtype == PYTC_F32 || dtype == PYTC_BF16),
+               "conv3d_pack_plan: bad arguments");
+  const int ks = kstep_of(dtype);
+  ConvTile t; size_t lds_bytes;
+  if (!direct && conv_tile_plan(dtype, C_in, kd, kh, kw, t, lds_bytes)) {
+    out[0] = 1; out[1] = t.KC; out[2] = t.nchunks; out[3] = t.G;
+    out[4] = (int64_t)((C_out + 15) / 16) * t.nchunks * t.G * 64 * 8;
+  } else {
+    out[0] = 0; out[1] = (C_in + ks - 1) / ks; out[2] = 0; out[3] = 0;
+    out[4] = (int64_t)((C_out + 15) / 16) * 16 * kd * kh * kw * ((C_in + ks - 1) / ks) * ks;
+  }
+  return PYTC_OK;
+}
+
+/* table_dev: n_items x 16 int64 on the device (layout: conv3d_pack_multi_kernel), total_blocks = sum of ceil(elements / 256) */
+extern "C" int pytc_conv3d_pack_multi(const int64_t* table_dev, int n_items, int64_t total_blocks, void* stream) {
+  PYTC_REQUIRE(table_dev && n_items >= 1 && total_blocks >= 1 && total_blocks < (1LL << 31), "conv3d_pack_multi: bad arguments");
+  hipLaunchKernelGGL(conv3d_pack_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long*>(table_dev), n_items);
+  PYTC_LAUNCH_CHECK("conv3d_pack_multi");
+  return PYTC_OK;
 }
 
 extern "C" int pytc_conv3d_fwd(const pytc_conv3d_args* a, void* stream) {

@@ -770,6 +770,91 @@ def conv3d_pack_weight_dgrad(w: torch.Tensor, dtype: torch.dtype) -> torch.Tenso
     return packed
 
 
+# layouts of a conv weight image: (pack function, channel / stride rule).  "fwd" / "dgrad": the stride-1 'same' conv and its data
+# gradient (conv3d_pack_weight / _dgrad: LDS-tiled flat layout when the channel count allows); the other four: conv3d_strided
+_CONV_LAYOUTS = ("fwd", "dgrad", "conv", "convT", "conv_dgrad", "convT_dgrad")
+
+
+def _conv_layout_rule(shape, layout: str):
+    """-> (C_out, C_in of the conv the image is for, s_o, s_c, flip, direct) for a 5-D weight of this shape"""
+    a, b, kd, kh, kw = (int(v) for v in shape)
+    ntap = kd * kh * kw
+    if layout == "fwd":
+        return a, b, b * ntap, ntap, 0, 0
+    if layout == "dgrad":
+        return b, a, ntap, b * ntap, 1, 0
+    if layout in ("conv", "convT_dgrad"):
+        return a, b, b * ntap, ntap, 0, 1
+    if layout in ("convT", "conv_dgrad"):
+        return b, a, ntap, b * ntap, 0, 1
+    raise ValueError(f"unknown weight layout {layout!r}")
+
+
+class ConvPackSet:
+    """The per-step conv-weight images of the dense-conv models (RSUNet, MONAI-style U-Net) in training: every image asked for
+    through `get` is remembered, and `refresh()` -- called at the start of a training forward -- rebuilds ALL images whose
+    weight changed since in ONE launch (pytc_conv3d_pack_multi) instead of one launch per conv and direction (64 per RSUNet
+    step).  Images are bit-identical to the single packs.  Rows hold their weight weakly: a dropped model drops its rows."""
+
+    def __init__(self):
+        self.rows = {}          # (data_ptr, layout, dtype) -> [weakref(weight), out, version, plan tuple]
+        self.table = None
+        self.blocks = 0
+
+    def get(self, weight: torch.Tensor, layout: str, dtype: torch.dtype) -> torch.Tensor:
+        key = (weight.data_ptr(), layout, dtype)
+        row = self.rows.get(key)
+        if row is not None and row[0]() is weight and row[2] == weight._version:
+            return row[1]
+        w32 = weight.detach()
+        if w32.dtype != torch.float32 or not w32.is_contiguous():       # not a plain fp32 parameter: single pack, not tracked
+            return _conv_pack_single(w32.float().contiguous(), layout, dtype)
+        out = _conv_pack_single(w32, layout, dtype)
+        import weakref
+        self.rows[key] = [weakref.ref(weight), out, weight._version, None]
+        self.table = None
+        return out
+
+    def refresh(self) -> None:
+        dead = [k for k, r in self.rows.items() if r[0]() is None]
+        for k in dead:
+            del self.rows[k]
+        if dead:
+            self.table = None
+        live = [(k, r, r[0]()) for k, r in self.rows.items()]
+        if not live or all(r[2] == w._version for _k, r, w in live):
+            return
+        dev = live[0][1][1].device
+        if self.table is None:
+            flat, blk = [], 0
+            plan = (C.c_int64 * 5)()
+            for (_ptr, layout, dtype), r, w in live:
+                co, ci, s_o, s_c, flip, direct = _conv_layout_rule(w.shape, layout)
+                kd, kh, kw = (int(v) for v in w.shape[2:])
+                nat.check(nat.lib().pytc_conv3d_pack_plan(co, ci, kd, kh, kw, dtype_code(dtype), direct, plan), "conv3d_pack_plan")
+                kind, p1, p2, p3, n = (int(v) for v in plan)
+                flat += [w.data_ptr(), r[1].data_ptr(), s_o, s_c, blk, n, co, ci, kd * kh * kw, kind, int(dtype == torch.float32), flip,
+                         p1, p2, p3, 0]
+                blk += (n + 255) // 256
+            self.table = torch.tensor(flat, dtype=torch.int64).to(dev)
+            self.blocks = blk
+        _run("conv3d_pack_multi", sum(2 * r[1].numel() * r[1].element_size() for _k, r, _w in live), nat.lib().pytc_conv3d_pack_multi,
+             _p(self.table), len(live), self.blocks, _stream())
+        for _k, r, w in live:
+            r[2] = w._version
+
+
+def _conv_pack_single(w32: torch.Tensor, layout: str, dtype: torch.dtype) -> torch.Tensor:
+    if layout == "fwd":
+        return conv3d_pack_weight(w32, dtype)
+    if layout == "dgrad":
+        return conv3d_pack_weight_dgrad(w32, dtype)
+    return conv3d_pack_weight_direct(w32, dtype, layout=layout)
+
+
+CONV_PACKS = ConvPackSet()
+
+
 def norm_bwd_means(s: torch.Tensor, gamma: Optional[torch.Tensor], groups: int, rows: int, *, want_gamma: bool,
                    want_beta: bool):
     """s (N,2,C) -> (M (N,2,C), dgamma (C) | None, dbeta (C) | None); groups = 0: batch statistics"""

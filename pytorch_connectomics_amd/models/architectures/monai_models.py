@@ -247,8 +247,9 @@ class MONAIModelWrapper(ConnectomicsModel):
         if not x_cl.is_cuda:
             raise RuntimeError("monai_unet (pytorch_connectomics_amd) runs only on an MI355X/ROCm device: "
                                "there is no CPU path. Move the model and input to 'cuda'.")
-        from ...training.rsunet_autograd import prefetch_prelu
+        from ...training.rsunet_autograd import prefetch_prelu, refresh_conv_packs
         prefetch_prelu([m.weight for m in self.model.modules() if isinstance(m, nn.PReLU)])   # one host read, not one per layer
+        refresh_conv_packs()          # every conv-weight image whose weight changed since the last forward, in one launch
         dt = resolve_compute_dtype(self.compute_dtype)
         x = x_cl if x_cl.dtype == dt else x_cl.to(dt)
         return _run(self.model.model, x.contiguous()).float()

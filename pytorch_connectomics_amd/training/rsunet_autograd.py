@@ -66,6 +66,23 @@ def prefetch_prelu(weights) -> None:
         _prelu_put(w, v)
 
 
+# conv-weight images (forward, data gradient, strided / transposed forms) through ops.CONV_PACKS: after the first step every image
+# of the model is rebuilt by ONE launch at the start of the training forward (refresh_conv_packs) instead of one launch per conv and
+# direction; False: one pack launch per use
+BATCHED_CONV_PACKS = True
+
+
+def _packed(weight, layout: str, dtype):
+    if BATCHED_CONV_PACKS:
+        return ops.CONV_PACKS.get(weight, layout, dtype)
+    return ops._conv_pack_single(weight.detach().float().contiguous(), layout, dtype)
+
+
+def refresh_conv_packs() -> None:
+    if BATCHED_CONV_PACKS:
+        ops.CONV_PACKS.refresh()
+
+
 # activation derivative + norm backward without the intermediate dt tensor (pytc_act_norm_bwd_stats / _apply): the same dt values as
 # the three passes act_bwd -> norm_bwd_stats -> norm_bwd_apply_general (rounded where they were stored), 5 instead of 8 tensor-sized
 # memory passes
@@ -175,7 +192,7 @@ class Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, weight, bias, res):
         ks = tuple(int(k) for k in weight.shape[2:])
-        wp = ops.conv3d_pack_weight(weight.detach().float().contiguous(), a.dtype)
+        wp = _packed(weight, "fwd", a.dtype)
         y = ops.conv3d(a, wp, c_out=weight.shape[0], kernel=ks, bias=_f(bias), res=res)
         ctx.save_for_backward(a, weight)
         ctx.meta = (ks, bias is not None, res is not None)
@@ -191,7 +208,7 @@ class Conv3dFn(torch.autograd.Function):
         da = None
         if ctx.needs_input_grad[0]:
             # data gradient = the forward kernel on dY with the transposed, tap-mirrored weights (packed in one launch)
-            da = ops.conv3d(dy, ops.conv3d_pack_weight_dgrad(weight.detach().float().contiguous(), dy.dtype),
+            da = ops.conv3d(dy, _packed(weight, "dgrad", dy.dtype),
                             c_out=weight.shape[1], kernel=ks)
         ci, co = a.shape[-1], dy.shape[-1]
         db = None
@@ -250,7 +267,7 @@ class ResampleConv3dFn(torch.autograd.Function):
         plain = (not transposed) and stride == 1 and all(pad == k // 2 for k in ks)
         w32 = weight.detach().float().contiguous()
         if plain:
-            y = ops.conv3d(a, ops.conv3d_pack_weight(w32, a.dtype), c_out=weight.shape[0], kernel=ks, bias=_f(bias))
+            y = ops.conv3d(a, _packed(weight, "fwd", a.dtype), c_out=weight.shape[0], kernel=ks, bias=_f(bias))
         elif (transposed and ks == (3, 3, 3) and stride == 2 and pad == 1 and a.dtype in (torch.bfloat16, torch.float32)
               and ops.convT3d_thin_supported(weight.shape[0], weight.shape[1])):
             # few output channels (the network's last up-sampling layer): one thread per output voxel instead of an MFMA tile
@@ -258,11 +275,11 @@ class ResampleConv3dFn(torch.autograd.Function):
             y = ops.convT3d_thin(a.contiguous(), w32, _f(bias))
         elif transposed:
             out_dims = tuple((int(d) - 1) * stride - 2 * pad + k + (stride - 1) for d, k in zip(a.shape[1:4], ks))
-            y = ops.conv3d_strided(a, ops.conv3d_pack_weight_direct(w32, a.dtype, layout="convT"), c_out=weight.shape[1],
+            y = ops.conv3d_strided(a, _packed(weight, "convT", a.dtype), c_out=weight.shape[1],
                                    kernel=ks, stride=s3, pad=p3, out_dims=out_dims, transposed=True, bias=_f(bias))
         else:
             out_dims = tuple((int(d) + 2 * pad - k) // stride + 1 for d, k in zip(a.shape[1:4], ks))
-            y = ops.conv3d_strided(a, ops.conv3d_pack_weight_direct(w32, a.dtype, layout="conv"), c_out=weight.shape[0],
+            y = ops.conv3d_strided(a, _packed(weight, "conv", a.dtype), c_out=weight.shape[0],
                                    kernel=ks, stride=s3, pad=p3, out_dims=out_dims, transposed=False, bias=_f(bias))
         ctx.save_for_backward(a, weight)
         ctx.meta = (ks, s3, p3, bool(transposed), plain, bias is not None)
@@ -275,21 +292,20 @@ class ResampleConv3dFn(torch.autograd.Function):
         dy = dy.contiguous()
         if dy.dtype != a.dtype:
             dy = dy.to(a.dtype)
-        w32 = weight.detach().float().contiguous()
         in_dims = tuple(int(v) for v in a.shape[1:4])
         da = None
         if plain:
             if ctx.needs_input_grad[0]:
-                da = ops.conv3d(dy, ops.conv3d_pack_weight_dgrad(w32, dy.dtype), c_out=weight.shape[1], kernel=ks)
+                da = ops.conv3d(dy, _packed(weight, "dgrad", dy.dtype), c_out=weight.shape[1], kernel=ks)
             dW = ops.conv3d_wgrad(a, dy, ks)
         elif transposed:
             if ctx.needs_input_grad[0]:
-                da = ops.conv3d_strided(dy, ops.conv3d_pack_weight_direct(w32, dy.dtype, layout="convT_dgrad"),
+                da = ops.conv3d_strided(dy, _packed(weight, "convT_dgrad", dy.dtype),
                                         c_out=weight.shape[0], kernel=ks, stride=s3, pad=p3, out_dims=in_dims, transposed=False)
             dW = ops.conv3d_wgrad_strided(dy, a, ks, s3, p3)          # (C_in_T, C_out_T, k): ConvTranspose3d layout
         else:
             if ctx.needs_input_grad[0]:
-                da = ops.conv3d_strided(dy, ops.conv3d_pack_weight_direct(w32, dy.dtype, layout="conv_dgrad"),
+                da = ops.conv3d_strided(dy, _packed(weight, "conv_dgrad", dy.dtype),
                                         c_out=weight.shape[1], kernel=ks, stride=s3, pad=p3, out_dims=in_dims, transposed=True)
             dW = ops.conv3d_wgrad_strided(a, dy, ks, s3, p3)          # (C_out, C_in, k)
         db = ops.channel_stats(dy)[:, :, 0].sum((0, 1)).to(weight.dtype) if has_bias else None
@@ -345,6 +361,7 @@ def _conv_block(blk, x):
 
 def rsunet_train_forward(model, x_cl: torch.Tensor, compute_dtype: torch.dtype):
     """Differentiable RSUNet forward on channels-last input; returns {"output", "ds_i"...} of fp32 channels-last maps."""
+    refresh_conv_packs()
     x = x_cl if x_cl.dtype == compute_dtype else x_cl.to(compute_dtype)
     x = _conv_block(model.input_conv, x.contiguous())
     skips = []

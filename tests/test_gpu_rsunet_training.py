@@ -411,3 +411,44 @@ def test_norm_act_backward_without_the_stored_activation_gradient_matches_the_th
     assert res[True][1].keys() == res[False][1].keys()
     for n, g in res[True][1].items():
         torch.testing.assert_close(g, res[False][1][n], rtol=1e-4, atol=1e-4)
+
+
+def test_batched_conv_weight_packs_are_bit_identical_to_the_single_packs():
+    """pytc_conv3d_pack_multi (every conv-weight image of a model in one launch per step) against the per-weight pack functions,
+    all six layouts, flat and tap-major plans, bf16 and fp32 images; and a stale image is rebuilt by refresh()."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(0)
+    packs = ops.ConvPackSet()
+    cases = []
+    for shape in [(16, 16, 3, 3, 3), (32, 16, 3, 3, 3), (64, 64, 3, 3, 3), (128, 128, 3, 3, 3), (8, 3, 1, 3, 3), (24, 20, 3, 3, 3),
+                  (32, 64, 2, 2, 2), (1, 32, 1, 1, 1)]:
+        w = torch.nn.Parameter(torch.randn(*shape, device="cuda"))
+        for layout in ("fwd", "dgrad", "conv", "convT", "conv_dgrad", "convT_dgrad"):
+            if layout in ("fwd", "dgrad") and any(k % 2 == 0 for k in shape[2:]):
+                continue
+            for dt in (torch.bfloat16, torch.float32):
+                cases.append((w, layout, dt, packs.get(w, layout, dt)))
+    assert len(packs.rows) == len(cases)
+    with torch.no_grad():
+        for w in {id(c[0]): c[0] for c in cases}.values():
+            w.mul_(1.5).add_(0.25)                       # version moves: every image is stale
+    for w, layout, dt, img in cases:
+        assert not torch.equal(img, ops._conv_pack_single(w.detach(), layout, dt)) or w.numel() < 64
+    packs.refresh()
+    import ctypes
+    from pytorch_connectomics_amd import _native as nat
+    plan = (ctypes.c_int64 * 5)()
+    for w, layout, dt, img in cases:
+        want = ops._conv_pack_single(w.detach(), layout, dt)
+        co, ci, _so, _sc, _flip, direct = ops._conv_layout_rule(w.shape, layout)
+        nat.check(nat.lib().pytc_conv3d_pack_plan(co, ci, *w.shape[2:], ops.dtype_code(dt), direct, plan), "plan")
+        n = int(plan[4])                                  # elements the pack writes (the allocation may be larger)
+        bits = torch.int16 if dt == torch.bfloat16 else torch.int32
+        assert img.shape == want.shape and 0 < n <= img.numel()
+        assert torch.equal(img[:n].view(bits), want[:n].view(bits)), (w.shape, layout, dt)
+        assert packs.get(w, layout, dt) is img           # a hit, no launch
+    del cases, w, img, want
+    import gc
+    gc.collect()
+    packs.refresh()
+    assert not packs.rows                                # rows of dropped weights go away
