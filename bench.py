@@ -387,10 +387,13 @@ def _train_kernel_key(label):
     """rocprof symbol substring of a training-step label: the MFMA pointwise weight gradient of one channel pair (tile counts as
     csrc/train_kernels.hip wg_tile16 picks them: <C_out tiles, C_in tiles>), or a kernel family name."""
     import re
-    m = re.match(r"pw_wgrad\[(\d+)->(\d+)\]", label)
+    m = re.match(r"pw_wgrad(?:_gn)?\[(\d+)->(\d+)\]", label)
     if m:
         t = lambda c: 4 if c % 64 == 0 else (2 if c % 32 == 0 else 1)      # noqa: E731
         return f"pw_wgrad_mfma_kernelILi{t(int(m.group(2)))}ELi{t(int(m.group(1)))}E"
+    m = re.match(r"pw_conv_fwd\[(\d+)->(\d+)\]", label)
+    if m and int(m.group(1)) % 32 == 0 and int(m.group(2)) % 32 == 0:
+        return f"pw_fast_kernel<{int(m.group(1)) // 32},"       # every launch with this C_in (the symbol does not carry C_out)
     return _kernel_key(label)
 
 

@@ -19,6 +19,7 @@ There is no CPU path: calling ``forward`` with a CPU tensor raises.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Union
 
 import torch
@@ -26,6 +27,13 @@ import torch.nn as nn
 
 from ... import _native as nat
 from ... import hip_ops as ops
+
+# a block whose mixer sees fewer voxel rows than this (N * voxels: the 7^3 / 14^3 levels of 8 windows of 112^3) runs expand and
+# project as two single GEMMs instead of the fused mixer (see _block).  MEASURED on the whole-volume bench (round 3,
+# tools/r03_ab_infer.sh): 16384 rows 7.70 -> 7.81 ms per 8 windows with two window streams, 8.79 -> 8.75 with one; 32768 rows 7.96 /
+# 8.91 -- the training step gains from this schedule (training/autograd.py FUSED_TRAIN_MIXER_MIN_ROWS), the inference engine does
+# not (no hidden tensor to store, and the second window stream already fills the idle CUs).  0 = off (default).
+SMALL_ROWS_TWO_GEMMS = int(os.environ.get("PYTC_MIXER_TWO_GEMM_ROWS", "0"))
 
 
 def _conv_nd(dim: str):
@@ -277,7 +285,12 @@ class HipBlockOps:
             ab = ops.groupnorm_finalize(st, count, gamma, beta, m.norm.eps)
         _, Do, Ho, Wo, _ = t.shape
         rows = Do * Ho * Wo
-        if (self.fused and dt == torch.bfloat16 and not m.grn and not is_ln and m.conv2.bias is not None
+        # optional two-GEMM schedule for the deep levels (SMALL_ROWS_TWO_GEMMS, off by default: measured slower here): expand, then
+        # project with the GELU in the operand prologue -- pw_fast shares out its output channels over blockIdx.z on small problems
+        small = (self.fused and dt == torch.bfloat16 and not m.grn and not is_ln and N * rows < SMALL_ROWS_TWO_GEMMS
+                 and ops.pw_conv_paired_supported(c_in=C, c_out=c_hid, in_dtype=dt, out_dtype=dt)
+                 and ops.pw_conv_paired_supported(c_in=c_hid, c_out=c_out, in_dtype=dt, out_dtype=dt))
+        if (not small and self.fused and dt == torch.bfloat16 and not m.grn and not is_ln and m.conv2.bias is not None
                 and m.conv3.bias is not None and ops.pw_mlp_supported(C, c_hid, c_out)):
             if (head is not None and kind == "block" and head.weight.shape[1] <= 16
                     and ops.pw_mlp_head_supported(C, c_hid, c_out)):
@@ -288,14 +301,21 @@ class HipBlockOps:
                                             res=x if m.do_res else None, store_y=False)
                 return None, logits.view(N, Do, Ho, Wo, -1)
             return self._block_fused(m, x, t, ab, skip, (N, D, H, W, C), (Do, Ho, Wo), c_hid, c_out)
-        h = ops.pw_conv(t, self._pw(m.conv2, dt), self._vec(m.conv2, "bias", m.conv2.bias), N=N,
-                        rows_per_sample=rows, c_in=C, c_out=c_hid, out_dtype=dt, ab=ab, act=nat.ACT_GELU)
-        if m.grn:
-            h = self._grn(m, h, N, (Do, Ho, Wo), c_hid, kind)
-        w3, b3 = self._pw(m.conv3, dt), self._vec(m.conv3, "bias", m.conv3.bias)
+        G = {}
+        if small:
+            h = ops.pw_conv(t, self._pw_paired(m.conv2), self._vec(m.conv2, "bias", m.conv2.bias), N=N, rows_per_sample=rows,
+                            c_in=C, c_out=c_hid, out_dtype=dt, ab=ab, w_paired=True)                   # pre-activation
+            w3, b3 = self._pw_paired(m.conv3), self._vec(m.conv3, "bias", m.conv3.bias)
+            G = dict(pre_act=nat.ACT_GELU, w_paired=True)
+        else:
+            h = ops.pw_conv(t, self._pw(m.conv2, dt), self._vec(m.conv2, "bias", m.conv2.bias), N=N,
+                            rows_per_sample=rows, c_in=C, c_out=c_hid, out_dtype=dt, ab=ab, act=nat.ACT_GELU)
+            if m.grn:
+                h = self._grn(m, h, N, (Do, Ho, Wo), c_hid, kind)
+            w3, b3 = self._pw(m.conv3, dt), self._vec(m.conv3, "bias", m.conv3.bias)
         if kind == "block":
             y = ops.pw_conv(h, w3, b3, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, out_dtype=dt,
-                            res=x if m.do_res else None, res_mode=nat.RES_ADD if m.do_res else nat.RES_NONE)
+                            res=x if m.do_res else None, res_mode=nat.RES_ADD if m.do_res else nat.RES_NONE, **G)
         elif kind == "down":
             res = None
             if m.resample_do_res:
@@ -303,7 +323,7 @@ class HipBlockOps:
                                   N=N, rows_per_sample=rows, c_in=C, c_out=c_out, out_dtype=dt, gather=2,
                                   grid=(D, H, W))
             y = ops.pw_conv(h, w3, b3, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, out_dtype=dt,
-                            res=res, res_mode=nat.RES_ADD if res is not None else nat.RES_NONE)
+                            res=res, res_mode=nat.RES_ADD if res is not None else nat.RES_NONE, **G)
         else:  # up: result + padded transposed-1x1 residual + encoder skip, one epilogue
             if skip is None:
                 skip = torch.zeros((N, Do, Ho, Wo, c_out), dtype=dt, device=x.device)
@@ -314,7 +334,7 @@ class HipBlockOps:
                                       rows_per_sample=D * H * W, c_in=C, c_out=c_out, out_dtype=dt)
             y = ops.pw_conv(h, w3, b3, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, out_dtype=dt,
                             res=skip, res_mode=nat.RES_UPSAMPLE, grid=(Do, Ho, Wo), res_low=res_low,
-                            res_bias=res_bias)
+                            res_bias=res_bias, **G)
         return y.view(N, Do, Ho, Wo, c_out)
 
 
