@@ -60,6 +60,8 @@ extern "C" {
 #define PYTC_RES_ADD 1        /* y = f(x) + R[row]                     (MedNeXt block / down block) */
 #define PYTC_RES_UPSAMPLE 2   /* MedNeXt up block: front-pad + transposed 1x1 residual + skip     */
 #define PYTC_RES_GELU_BWD 3   /* y = f(x) * gelu'(R[row]): GELU backward fused into the data-gradient GEMM */
+#define PYTC_RES_NORM_BWD 4   /* y = A[n][o]*f(x) + B[n][o]*R[row][o] + C[n][o], (A, B, C) = res_bias [N][3][C_out]: the GroupNorm backward
+                               * apply pass fused into the data-gradient GEMM that produces its operand (w_paired kernel only) */
 
 int pytc_abi_version(void);
 const char* pytc_last_error(void);
@@ -471,29 +473,29 @@ int pytc_norm_bwd_ws_elems(int N, int64_t rows, int C);
 int pytc_norm_bwd(const void* dtn, const void* t, const float* mean_rstd, const float* gamma, float* stats_ws,
                   float* s_out, void* dt, int N, int64_t rows, float count /* voxels in the statistics */, int C,
                   int dtype, void* stream);
-/* GroupNorm-fed expand conv (MedNeXt block: hp = W2 (gamma * xhat + beta) + b2): the weight-gradient sums AND the statistics of
- * the GroupNorm backward from ONE pass over (t, dhp).  With M[n][h][c] = sum_r dhp[r][h] xhat[r][c] and q[n][h] = sum_r dhp[r][h]
- * (the MFMA weight-gradient kernel against xhat, `sps` row slots per sample),
+/* GroupNorm-fed expand conv (MedNeXt block: hp = W2 (gamma * xhat + beta) + b2): the weight-gradient sums AND the GroupNorm
+ * backward from ONE pass over (t, dhp) plus an epilogue.  With M[n][h][c] = sum_r dhp[r][h] xhat[r][c] and q[n][h] = sum_r dhp[r][h]
+ * (the MFMA weight-gradient kernel against xhat in bf16 high + low parts, `sps` row slots per sample),
  *   dW2 [C_hid][C] = sum_n term[n],  term[n] = gamma*M[n] + beta*q[n];   db2 [C_hid] = sum_n q[n]
- *   (sum_r dtn, sum_r dtn*xhat)[n][c] = (sum_h W2[h][c] q[n][h], sum_h W2[h][c] M[n][h][c])      with dtn = W2^T dhp
- * -- the statistics pass of pytc_norm_bwd over (dtn, t) is not needed.  mean_rstd / ab: [N][2][C] of pytc_norm_finalize_groups_mr,
- * W2: fp32 [C_hid][C].  bf16, C and C_hid multiples of 16 (pytc_pw_wgrad_groupnorm_supported).
- * workspace (pytc_pw_wgrad_groupnorm_ws_elems floats), sps = pytc_pw_wgrad_groupnorm_sps(...):
+ *   s_out [N][2][C] = (sum_r dtn, sum_r dtn*xhat) = (sum_h w2[h][c] q[n][h], sum_h w2[h][c] M[n][h][c]),  dtn = w2^T dhp,
+ *   w2 = bf16(W2), the data-gradient GEMM's weights;  coef [N][3][C] = (A, B, C) with  dt = A*dtn + B*t + C  the GroupNorm backward
+ * -- feed coef to pytc_pw_conv_fwd(res_mode = PYTC_RES_NORM_BWD, res = t, res_bias = coef) of the GEMM that computes dtn: neither
+ * the statistics pass nor the apply pass of pytc_norm_bwd runs, and dtn is never stored.  (The statistics alone must NOT be
+ * combined with an apply pass over the stored bf16(dtn): they describe the unrounded values.)  mean_rstd / ab: [N][2][C] of
+ * pytc_norm_finalize_groups_mr, W2: fp32 [C_hid][C], count = voxels in the statistics.  bf16, C and C_hid multiples of 16
+ * (pytc_pw_wgrad_groupnorm_supported).  workspace (pytc_pw_wgrad_groupnorm_ws_elems floats), sps = pytc_pw_wgrad_groupnorm_sps(...):
  *   [N*sps][C_hid*C] dW partials | [N*sps][C_hid] bias partials | term [N][C_hid*C] | q [N][C_hid]
- * the caller reduces term and q over their N slots (pytc_reduce_slots_multi).  s_part [parts][N][2][C], parts =
- * pytc_pw_wgrad_groupnorm_parts(C_hid): the statistics in hidden-channel chunks; pytc_norm_bwd_apply adds them, and their sum
- * over parts*N is (dbeta, dgamma).  Replaces autograd's separate Conv3d-weight and GroupNorm backward reductions (reference:
- * torch.nn.GroupNorm + Conv3d under connectomics/training/lightning/model.py:863-910).
- * pytc_norm_bwd_apply: the apply pass of pytc_norm_bwd with s given as [s_parts][N][2][C]; crop_grid (nullable int32[3], the
- * (D,H,W) grid of the rows): rows on the front faces are dropped and dt is the compact (D-1,H-1,W-1) grid (the zero-padded
- * faces of an up block, MedNeXtUpBlock's F.pad). */
+ * the caller reduces term and q over their N slots (pytc_reduce_slots_multi).  Replaces autograd's separate Conv3d-weight and
+ * GroupNorm backward passes (reference: torch.nn.GroupNorm + Conv3d under connectomics/training/lightning/model.py:863-910).
+ * pytc_norm_bwd_apply: the apply pass of pytc_norm_bwd with s given as [s_parts][N][2][C] (summed over the parts); crop_grid
+ * (nullable int32[3], the (D,H,W) grid of the rows): rows on the front faces are dropped and dt is the compact (D-1,H-1,W-1)
+ * grid (the zero-padded faces of an up block, MedNeXtUpBlock's F.pad). */
 int pytc_pw_wgrad_groupnorm_supported(int C, int C_hid, int dtype);
 int pytc_pw_wgrad_groupnorm_sps(int N, int64_t rows_per_sample, int C, int C_hid);
-int pytc_pw_wgrad_groupnorm_parts(int C_hid);
 int64_t pytc_pw_wgrad_groupnorm_ws_elems(int N, int64_t rows_per_sample, int C, int C_hid);
 int pytc_pw_wgrad_groupnorm(const void* t, const float* mean_rstd, const float* ab, const void* dhp, const float* W2,
-                            const float* gamma, float* s_part, float* workspace, int N, int64_t rows_per_sample, int C,
-                            int C_hid, int dtype, void* stream);
+                            const float* gamma, float count, float* s_out, float* coef, float* workspace, int N,
+                            int64_t rows_per_sample, int C, int C_hid, int dtype, void* stream);
 int pytc_norm_bwd_apply(const void* dtn, const void* t, const float* mean_rstd, const float* gamma, const float* s_in,
                         int s_parts, void* dt, int N, int64_t rows, int C, float count, int dtype, const int32_t* crop_grid,
                         void* stream);

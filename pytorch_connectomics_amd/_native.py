@@ -18,7 +18,7 @@ VIEW_FLIP_Z, VIEW_FLIP_Y, VIEW_FLIP_X, VIEW_SWAP_YX = 1, 2, 4, 8
 PAD_MODES = {"constant": 0, "reflect": 1, "replicate": 2, "circular": 3}
 BLEND_PRODUCT, BLEND_MIN = 0, 1
 ACT_NONE, ACT_SIGMOID, ACT_TANH, ACT_GELU, ACT_SOFTMAX, ACT_RELU, ACT_LEAKY, ACT_ELU = 0, 1, 2, 3, 4, 5, 6, 7
-RES_NONE, RES_ADD, RES_UPSAMPLE, RES_GELU_BWD = 0, 1, 2, 3
+RES_NONE, RES_ADD, RES_UPSAMPLE, RES_GELU_BWD, RES_NORM_BWD = 0, 1, 2, 3, 4
 
 
 class PwArgs(C.Structure):
@@ -145,9 +145,9 @@ _SIGS = {
                                 C.c_void_p]),
     "pytc_pw_wgrad_groupnorm_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pytc_pw_wgrad_groupnorm_sps": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int]),
-    "pytc_pw_wgrad_groupnorm_parts": (C.c_int, [C.c_int]),
     "pytc_pw_wgrad_groupnorm_ws_elems": (C.c_int64, [C.c_int, C.c_int64, C.c_int, C.c_int]),
-    "pytc_pw_wgrad_groupnorm": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_pw_wgrad_groupnorm": (C.c_int, [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 3 + [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p]),
     "pytc_norm_bwd_apply": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_int,
                                       C.c_void_p, C.c_void_p]),
     "pytc_norm_bwd_ws_elems": (C.c_int, [C.c_int, C.c_int64, C.c_int]),

@@ -98,6 +98,21 @@ __device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParam
     }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) v[i] *= gelu_erf_grad(rv[i]);
+  } else if (GELU_BWD && e.res_mode == PYTC_RES_NORM_BWD) {
+    // GroupNorm backward of the GEMM's own (unrounded) result: dt = A*v + B*t + C per (sample, channel), R = t
+    float rv[NCH];
+    if (pre) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) rv[i] = pre[i];
+    } else if (full) VecIO<TO, NCH>::load(resn + off, rv);
+    else {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) rv[i] = (o0 + i < e.C_out) ? to_f32<TO>(resn[off + i]) : 0.f;
+    }
+    const float* cf = e.res_bias + (long)n * 3 * e.C_out + o0;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (o0 + i < e.C_out) v[i] = fmaf(cf[i], v[i], fmaf(cf[e.C_out + i], rv[i], cf[2 * e.C_out + i]));
   } else if (e.res_mode == PYTC_RES_UPSAMPLE) {
     int px = (int)(orow % e.Go_w);
     long t = orow / e.Go_w;

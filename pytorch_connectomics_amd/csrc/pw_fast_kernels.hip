@@ -104,7 +104,7 @@ pw_fast_kernel(PwFastParams p) {
   }
 
   if (WARM) warm_l2_done(warm);
-  const bool pre_ok = p.e.res_mode == PYTC_RES_ADD || p.e.res_mode == PYTC_RES_GELU_BWD;
+  const bool pre_ok = p.e.res_mode == PYTC_RES_ADD || p.e.res_mode == PYTC_RES_GELU_BWD || p.e.res_mode == PYTC_RES_NORM_BWD;
   const bf16_t* resn = pre_ok ? reinterpret_cast<const bf16_t*>(p.e.res) + (long)n * p.rps * p.C_out : nullptr;
   // blockIdx.z owns a contiguous share of the output-channel pairs (launch_fast: > 1 only when the rows alone leave CUs idle)
   const int pairs_z = p.C_out / 32 / (int)gridDim.z;

@@ -251,6 +251,8 @@ extern "C" int pytc_pw_conv_fwd(const pytc_pw_args* a, void* stream) {
   PYTC_REQUIRE(a->N >= 1 && a->rows_per_sample >= 1 && a->C_in >= 1 && a->C_out >= 1, "pw_conv: bad shape");
   PYTC_REQUIRE(a->w_dtype == PYTC_F32 || a->w_dtype == PYTC_BF16, "pw_conv: bad w_dtype");
   PYTC_REQUIRE(a->res_mode == PYTC_RES_NONE || a->res, "pw_conv: residual mode without residual pointer");
+  PYTC_REQUIRE(a->res_mode != PYTC_RES_NORM_BWD || (a->w_paired && a->res_bias),
+               "pw_conv: RES_NORM_BWD runs on the paired-row kernel and needs its coefficients in res_bias");
   PwParams p;
   p.x = a->x; p.wp = a->w_packed; p.bias = a->bias; p.ab = a->ab;
   p.e.res = a->res; p.e.res_low = a->res_low; p.e.res_bias = a->res_bias; p.e.y = a->y;

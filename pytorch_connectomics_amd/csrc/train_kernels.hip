@@ -125,7 +125,7 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
   // operand is the normalised xhat = (x - mean) * rstd instead of a * x + b.
   constexpr int BM = MT * 16, BN = NT * 16;
   constexpr int SG = BM * 2 + 32, SX = BN * 2 + 32;        // LDS row pitch in bytes
-  constexpr int WAVE_BYTES = 32 * (SG + SX);
+  constexpr int WAVE_BYTES = 32 * (SG + 2 * SX);             // dY rows, operand rows, and the operand's low part (ab_mode 1)
   constexpr int RED_BYTES = (BM * BN + BM) * 4;
   constexpr int LDS_BYTES = 4 * WAVE_BYTES > RED_BYTES ? 4 * WAVE_BYTES : RED_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
@@ -135,6 +135,10 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   unsigned char* lg = lds + wave * WAVE_BYTES;
   unsigned char* lx = lg + 32 * SG;
+  unsigned char* lx2 = lx + 32 * SX;
+  // ab_mode 1 (xhat operand): the operand is split into bf16 high and low parts, two MFMAs per tile -- xhat to 2^-17 instead of
+  // 2^-9, because the sums of this mode become the statistics of a norm backward whose apply pass sees the exact xhat
+  const bool split = ab_mode != 0;
   const int slot = blockIdx.x;
   const int tiles_k = C_in / BN;
   const int o_base = (blockIdx.y / tiles_k) * BM, k_base = (blockIdx.y % tiles_k) * BN;
@@ -201,7 +205,15 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
         f32x8_t f = __builtin_convertvector(in, f32x8_t);
 #pragma unroll
         for (int i = 0; i < 8; ++i) f[i] = fmaf(f[i], av[i], bv[i]);
-        v = __builtin_bit_cast(q4_t, __builtin_convertvector(f, bf16x8_t));
+        const bf16x8_t hi = __builtin_convertvector(f, bf16x8_t);
+        v = __builtin_bit_cast(q4_t, hi);
+        if (split) {
+          const f32x8_t back = __builtin_convertvector(hi, f32x8_t);
+          *reinterpret_cast<q4_t*>(lx2 + (it * RX + x_row) * SX + x_chunk * 16) =
+              __builtin_bit_cast(q4_t, __builtin_convertvector(f - back, bf16x8_t));
+        }
+      } else if (split) {
+        *reinterpret_cast<q4_t*>(lx2 + (it * RX + x_row) * SX + x_chunk * 16) = zero4;
       }
       if (x_act == PYTC_ACT_GELU) {     // the forward GEMM consumed bf16(gelu(x)) (fused pre-activation)
         f32x8_t f = __builtin_convertvector(__builtin_bit_cast(bf16x8_t, v), f32x8_t);
@@ -247,6 +259,14 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
       if (want_db) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], ones, accb[m], 0, 0, 0);
+    }
+    if (split) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) fb[n] = frag(lx2, SX, n);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
@@ -759,60 +779,77 @@ norm_bwd_apply_vec_kernel(const T* __restrict__ dtn, const T* __restrict__ t, co
 // With hp = W2 (gamma * xhat + beta) + b2 and dtn = W2^T dhp, the two sums the GroupNorm backward needs per (sample, channel),
 //     S1[n][c] = sum_r dtn[r][c]            = sum_h W2[h][c] * q[n][h],      q[n][h]    = sum_r dhp[r][h]
 //     S2[n][c] = sum_r dtn[r][c] xhat[r][c] = sum_h W2[h][c] * M[n][h][c],   M[n][h][c] = sum_r dhp[r][h] xhat[r][c]
-// are contractions of the PER-SAMPLE weight-gradient sums M, q (the MFMA weight-gradient kernel run against xhat with per-sample
-// slots) with the weights: no pass over the activations.  The parameter gradients follow from the same sums:
+// are contractions of the PER-SAMPLE weight-gradient sums M, q (the MFMA weight-gradient kernel run against xhat, split into bf16
+// high and low parts, with per-sample slots) with the weights: no pass over the activations.  W2 is rounded to bf16 here, as the
+// data-gradient GEMM's weight image is, so S1 / S2 are the sums of exactly the (unrounded) dtn that GEMM accumulates -- its
+// epilogue (PYTC_RES_NORM_BWD) applies  dt = rstd*gamma * (dtn - S1/V - xhat * S2/V) = A*dtn + B*t + C  to those values, which
+// makes dt orthogonal to (1, xhat) per channel as the two-pass form is.  (Statistics of the unrounded dtn combined with an apply
+// pass over bf16(dtn) leave a component along xhat that the depthwise weight gradient amplifies: DESIGN.md section 4.4.)
+// The parameter gradients follow from the same sums:
 //     dW2[h][c] = sum_n gamma[c] * M[n][h][c] + beta[n][c] * q[n][h],   db2[h] = sum_n q[n][h]      (beta = b + mean * a of `ab`)
-// workgroup = (16 channels, 64 hidden channels, sample); thread = (channel, h lane): h = lane, lane + 16, ...  It writes its
-// share s_part[h chunk][n][2][C] of the sums (added in chunk order by the apply pass), the sample's term of dW2 IN PLACE of
-// M[n], and q[n] (from the bias partials dbp [N][sps][H]) -- both then reduced over n like any other slot partial.
+// workgroup = (16 channels, sample); thread = (channel, h lane): h = lane, lane + 16, ... over all hidden channels in chunks of
+// 64 (q of a chunk is summed over the sample's slots first, four interleaved partial sums added in a fixed order).  It writes
+// s_out [N][2][C], coef [N][3][C] = (A, B, C), the sample's term of dW2 IN PLACE of M[n], and q[n] -- term and q are then
+// reduced over n like any other slot partial.
 __global__ void __launch_bounds__(256)
 norm_bwd_from_wgrad_kernel(float* __restrict__ M, const float* __restrict__ dbp, float* __restrict__ q,
                            const float* __restrict__ W2, const float* __restrict__ gamma, const float* __restrict__ ab,
-                           const float* __restrict__ mr, float* __restrict__ s_part, int N, int C, int H, int sps) {
+                           const float* __restrict__ mr, float* __restrict__ s_out, float* __restrict__ coef, int N, int C,
+                           int H, int sps, float inv_count) {
   __shared__ float sm_q[4][64];
   __shared__ float sm[2][16][17];
-  const int n = blockIdx.z, hc = blockIdx.y;
-  const int h0 = hc * 64;
-  {   // q[n][h0 .. h0+63] = sum over the sample's slots, four interleaved partial sums added in a fixed order
-    const int hh = threadIdx.x & 63, part = threadIdx.x >> 6;
-    float a = 0.f;
-    if (h0 + hh < H)
-      for (int j = part; j < sps; j += 4) a += dbp[((long)n * sps + j) * H + h0 + hh];
-    sm_q[part][hh] = a;
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const float a = (sm_q[0][threadIdx.x] + sm_q[1][threadIdx.x]) + (sm_q[2][threadIdx.x] + sm_q[3][threadIdx.x]);
-    sm_q[0][threadIdx.x] = a;
-    if (blockIdx.x == 0 && h0 + (int)threadIdx.x < H) q[(long)n * H + h0 + threadIdx.x] = a;
-  }
-  __syncthreads();
+  const int n = blockIdx.y;
   const int cl = threadIdx.x & 15, hl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   const bool ok = c < C;
+  const float g = ok ? (gamma ? gamma[c] : 1.f) : 0.f;
+  const float mean = ok ? mr[((long)n * 2 + 0) * C + c] : 0.f, rstd = ok ? mr[((long)n * 2 + 1) * C + c] : 0.f;
+  const float beta = ok ? fmaf(mean, ab[((long)n * 2 + 0) * C + c], ab[((long)n * 2 + 1) * C + c]) : 0.f;
+  float* Mn = M + (long)n * H * C;
   float s1 = 0.f, s2 = 0.f;
-  if (ok) {
-    const float g = gamma ? gamma[c] : 1.f;
-    const float beta = fmaf(mr[((long)n * 2 + 0) * C + c], ab[((long)n * 2 + 0) * C + c], ab[((long)n * 2 + 1) * C + c]);
-    float* Mn = M + (long)n * H * C;
+  for (int h0 = 0; h0 < H; h0 += 64) {
+    __syncthreads();                                  // the previous chunk's q is no longer read
+    {
+      const int hh = threadIdx.x & 63, part = threadIdx.x >> 6;
+      float a = 0.f;
+      if (h0 + hh < H)
+        for (int j = part; j < sps; j += 4) a += dbp[((long)n * sps + j) * H + h0 + hh];
+      sm_q[part][hh] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const float a = (sm_q[0][threadIdx.x] + sm_q[1][threadIdx.x]) + (sm_q[2][threadIdx.x] + sm_q[3][threadIdx.x]);
+      sm_q[0][threadIdx.x] = a;
+      if (blockIdx.x == 0 && h0 + (int)threadIdx.x < H) q[(long)n * H + h0 + threadIdx.x] = a;
+    }
+    __syncthreads();
+    if (ok) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int hh = hl + 16 * k, h = h0 + hh;
-      if (h >= H) break;
-      const float w = W2[(long)h * C + c], m = Mn[(long)h * C + c], qq = sm_q[0][hh];
-      s1 = fmaf(w, qq, s1);
-      s2 = fmaf(w, m, s2);
-      Mn[(long)h * C + c] = fmaf(g, m, beta * qq);
+      for (int k = 0; k < 4; ++k) {
+        const int hh = hl + 16 * k, h = h0 + hh;
+        if (h >= H) break;
+        const float w = to_f32<bf16_t>(from_f32<bf16_t>(W2[(long)h * C + c]));      // the data-gradient GEMM's weight
+        const float m = Mn[(long)h * C + c], qq = sm_q[0][hh];
+        s1 = fmaf(w, qq, s1);
+        s2 = fmaf(w, m, s2);
+        Mn[(long)h * C + c] = fmaf(g, m, beta * qq);
+      }
     }
   }
   sm[0][hl][cl] = s1;
   sm[1][hl][cl] = s2;
   __syncthreads();
-  if (hl < 2 && ok) {
-    float a = 0.f;
+  if (hl == 0 && ok) {
+    float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) a += sm[hl][j][cl];
-    s_part[(((long)hc * N + n) * 2 + hl) * C + c] = a;
+    for (int j = 0; j < 16; ++j) { a1 += sm[0][j][cl]; a2 += sm[1][j][cl]; }
+    s_out[((long)n * 2 + 0) * C + c] = a1;
+    s_out[((long)n * 2 + 1) * C + c] = a2;
+    const float rg = rstd * g, m1 = a1 * inv_count, m2 = a2 * inv_count;
+    const float B = -rg * rstd * m2;
+    coef[((long)n * 3 + 0) * C + c] = rg;
+    coef[((long)n * 3 + 1) * C + c] = B;
+    coef[((long)n * 3 + 2) * C + c] = -rg * m1 - B * mean;
   }
 }
 
@@ -1076,16 +1113,14 @@ extern "C" int pytc_reduce_slots_multi(const pytc_reduce_item* items, int n_item
    norm_bwd_from_wgrad_kernel).  bf16, C and C_hid multiples of 16.  workspace (pytc_pw_wgrad_groupnorm_ws_elems floats):
      [N*sps][C_hid*C] dW partials | [N*sps][C_hid] bias partials | term [N][C_hid*C] | q [N][C_hid]
    with sps = pytc_pw_wgrad_groupnorm_sps.  On return  dW2 = sum_n term[n],  db2 = sum_n q[n]  (left to the caller's slot
-   reduction, N slots each) and s_part [parts][N][2][C] (parts = pytc_pw_wgrad_groupnorm_parts) holds the statistics in
-   hidden-channel chunks: pytc_norm_bwd_apply adds them; dbeta / dgamma = their sums over parts * N. */
+   reduction, N slots each), s_out [N][2][C] = (sum dtn, sum dtn * xhat) and coef [N][3][C] = (A, B, C) for the data-gradient
+   GEMM's PYTC_RES_NORM_BWD epilogue (count = voxels in the statistics). */
 extern "C" int pytc_pw_wgrad_groupnorm_sps(int N, int64_t rows_per_sample, int C, int C_hid) {
   const long rows_total = (long)N * rows_per_sample;
   const int slots = wgrad_mfma_slots(rows_total, C, C_hid, pytc_pw_wgrad_slots(rows_total));
   const int sps = slots / N;
   return sps < 1 ? 1 : sps;
 }
-
-extern "C" int pytc_pw_wgrad_groupnorm_parts(int C_hid) { return (C_hid + 63) / 64; }
 
 extern "C" int pytc_pw_wgrad_groupnorm_supported(int C, int C_hid, int dtype) {
   return dtype == PYTC_BF16 && wg_tile16(C) != 0 && wg_tile16(C_hid) != 0;
@@ -1097,10 +1132,10 @@ extern "C" int64_t pytc_pw_wgrad_groupnorm_ws_elems(int N, int64_t rows_per_samp
 }
 
 extern "C" int pytc_pw_wgrad_groupnorm(const void* t, const float* mean_rstd, const float* ab, const void* dhp, const float* W2,
-                                       const float* gamma, float* s_part, float* workspace, int N, int64_t rows_per_sample,
-                                       int C, int C_hid, int dtype, void* stream) {
-  PYTC_REQUIRE(t && mean_rstd && ab && dhp && W2 && s_part && workspace && N >= 1 && N <= 65535 && rows_per_sample >= 1,
-               "pw_wgrad_groupnorm: bad arguments");
+                                       const float* gamma, float count, float* s_out, float* coef, float* workspace, int N,
+                                       int64_t rows_per_sample, int C, int C_hid, int dtype, void* stream) {
+  PYTC_REQUIRE(t && mean_rstd && ab && dhp && W2 && s_out && coef && workspace && N >= 1 && N <= 65535 && rows_per_sample >= 1 &&
+               count > 0.f, "pw_wgrad_groupnorm: bad arguments");
   PYTC_REQUIRE(pytc_pw_wgrad_groupnorm_supported(C, C_hid, dtype), "pw_wgrad_groupnorm: bf16 with C, C_hid multiples of 16 (got %d, %d)", C, C_hid);
   const int sps = pytc_pw_wgrad_groupnorm_sps(N, rows_per_sample, C, C_hid);
   const long rps = (rows_per_sample + sps - 1) / sps;
@@ -1119,8 +1154,8 @@ extern "C" int pytc_pw_wgrad_groupnorm(const void* t, const float* mean_rstd, co
   else if (mt == 2) launch_wgrad_mfma<2>(nt, grid, s, xp, mean_rstd, dp, dWp, dbp, rows_total, (long)rows_per_sample, C, C_hid, rps, PYTC_ACT_NONE, sps, 1);
   else launch_wgrad_mfma<1>(nt, grid, s, xp, mean_rstd, dp, dWp, dbp, rows_total, (long)rows_per_sample, C, C_hid, rps, PYTC_ACT_NONE, sps, 1);
   hipLaunchKernelGGL(reduce_slots_batched_kernel, dim3(ceil_div(nW, 16), N), dim3(256), 0, s, dWp, term, nW, sps);
-  hipLaunchKernelGGL(norm_bwd_from_wgrad_kernel, dim3((C + 15) / 16, pytc_pw_wgrad_groupnorm_parts(C_hid), N), dim3(256), 0, s, term, dbp,
-                     qv, W2, gamma, ab, mean_rstd, s_part, N, C, C_hid, sps);
+  hipLaunchKernelGGL(norm_bwd_from_wgrad_kernel, dim3((C + 15) / 16, N), dim3(256), 0, s, term, dbp, qv, W2, gamma, ab, mean_rstd,
+                     s_out, coef, N, C, C_hid, sps, 1.0f / count);
   PYTC_LAUNCH_CHECK("pw_wgrad_groupnorm");
   return PYTC_OK;
 }

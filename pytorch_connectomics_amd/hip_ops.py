@@ -1035,21 +1035,23 @@ def pw_wgrad_groupnorm_supported(c: int, c_hid: int, dtype: torch.dtype) -> bool
 
 
 def pw_wgrad_groupnorm(t: torch.Tensor, mean_rstd: torch.Tensor, ab: torch.Tensor, dhp: torch.Tensor, w2: torch.Tensor,
-                       gamma: Optional[torch.Tensor], *, N: int, rows_per_sample: int, c: int, c_hid: int,
+                       gamma: Optional[torch.Tensor], *, N: int, rows_per_sample: int, c: int, c_hid: int, count: float,
                        defer: Optional["DeferredReduce"] = None):
-    """Weight gradient of a GroupNorm-fed expand conv AND the GroupNorm backward statistics from one pass over (t, dhp)
-    (pytc_pw_wgrad_groupnorm).  w2: fp32 (c_hid, c).  -> dW2 (c_hid, c), db2 (c_hid), s_part (parts, N, 2, c): the sums
-    (sum dtn, sum dtn * xhat) in hidden-channel chunks, which norm_bwd_apply adds.  dW2 / db2 are sums over N sample terms: with
-    `defer` they join that object's single reduction launch and hold their values only after defer.flush()."""
+    """Weight gradient of a GroupNorm-fed expand conv AND the GroupNorm backward from one pass over (t, dhp)
+    (pytc_pw_wgrad_groupnorm).  w2: fp32 (c_hid, c).  -> dW2 (c_hid, c), db2 (c_hid), s (N, 2, c) = (sum dtn, sum dtn * xhat),
+    coef (N, 3, c) for pw_conv(res_mode=RES_NORM_BWD, res=t, res_bias=coef) of the data-gradient GEMM.  dW2 / db2 are sums over N
+    sample terms: with `defer` they join that object's single reduction launch and hold their values only after defer.flush()."""
     _dev(t, "t"); _dev(dhp, "dhp")
     dev = t.device
     lib = nat.lib()
-    sps, parts = lib.pytc_pw_wgrad_groupnorm_sps(N, rows_per_sample, c, c_hid), lib.pytc_pw_wgrad_groupnorm_parts(c_hid)
+    sps = lib.pytc_pw_wgrad_groupnorm_sps(N, rows_per_sample, c, c_hid)
     nW = c_hid * c
     ws = torch.empty((int(lib.pytc_pw_wgrad_groupnorm_ws_elems(N, rows_per_sample, c, c_hid)),), dtype=torch.float32, device=dev)
-    s = torch.empty((parts, N, 2, c), dtype=torch.float32, device=dev)
+    s = torch.empty((N, 2, c), dtype=torch.float32, device=dev)
+    coef = torch.empty((N, 3, c), dtype=torch.float32, device=dev)
     _run(f"pw_wgrad_gn[{c}->{c_hid}]", _nbytes(t, dhp), lib.pytc_pw_wgrad_groupnorm, _p(t), _p(mean_rstd), _p(ab), _p(dhp), _p(w2),
-         _p(gamma), _p(s), _p(ws), N, rows_per_sample, c, c_hid, dtype_code(t.dtype), _stream(), symbol="pw_wgrad_mfma_kernel")
+         _p(gamma), float(count), _p(s), _p(coef), _p(ws), N, rows_per_sample, c, c_hid, dtype_code(t.dtype), _stream(),
+         symbol="pw_wgrad_mfma_kernel")
     term0 = N * sps * (nW + c_hid)
     dW = torch.empty((c_hid, c), dtype=torch.float32, device=dev)
     db = torch.empty((c_hid,), dtype=torch.float32, device=dev)
@@ -1058,7 +1060,11 @@ def pw_wgrad_groupnorm(t: torch.Tensor, mean_rstd: torch.Tensor, ab: torch.Tenso
     own.add(ws[term0 + N * nW:term0 + N * (nW + c_hid)], db, c_hid, N)
     if defer is None:
         own.flush()
-    return dW, db, s
+    return dW, db, s, coef
+
+
+def norm_bwd_apply_supported(x: torch.Tensor) -> bool:
+    return x.dtype in (torch.bfloat16, torch.float32) and x.shape[-1] % (8 if x.dtype == torch.bfloat16 else 4) == 0
 
 
 def norm_bwd_apply(dtn: torch.Tensor, t: torch.Tensor, mean_rstd: torch.Tensor, gamma: Optional[torch.Tensor], s: torch.Tensor, *,

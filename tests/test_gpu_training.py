@@ -692,11 +692,13 @@ def test_mednext_norm_variants_training_step_matches_oracle_autograd(norm_type, 
 
 
 @pytest.mark.parametrize("C,H,rows,N", [(32, 64, 5003, 2), (64, 128, 4096, 3), (16, 16, 100, 1), (256, 512, 343, 2), (48, 96, 2500, 4)])
-def test_groupnorm_backward_statistics_from_weight_gradient_sums(C, H, rows, N):
-    """pytc_pw_wgrad_groupnorm: the GroupNorm backward sums (sum dtn, sum dtn * xhat per sample and channel; dtn = W2^T dhp) as
-    contractions of the per-sample weight-gradient sums with the weights, against fp64 math on the same bf16 operands -- and the
-    weight / bias gradients it returns against the plain weight-gradient kernel (operand a*t+b)."""
+def test_groupnorm_backward_from_weight_gradient_sums_and_gemm_epilogue(C, H, rows, N):
+    """pytc_pw_wgrad_groupnorm + the RES_NORM_BWD epilogue of the data-gradient GEMM: the GroupNorm backward sums (sum dtn,
+    sum dtn * xhat per sample and channel; dtn = bf16(W2)^T dhp) as contractions of the per-sample weight-gradient sums with the
+    weights, against fp64 math on the same bf16 operands; the weight / bias gradients against the plain weight-gradient kernel;
+    and dt from the epilogue against the fp64 norm backward of the unrounded dtn -- including its orthogonality to (1, xhat)."""
     from pytorch_connectomics_amd import hip_ops as ops
+    from pytorch_connectomics_amd import _native as nat
     torch.manual_seed(C + H + rows)
     t = (torch.randn(N, rows, C) * 1.7 + 0.4).bfloat16()
     dhp = (torch.randn(N, rows, H) * 1e-3).bfloat16()             # gradient-sized values
@@ -704,28 +706,37 @@ def test_groupnorm_backward_statistics_from_weight_gradient_sums(C, H, rows, N):
     W2 = torch.randn(H, C) / C ** 0.5
     tc = t.cuda().view(N, rows, 1, 1, C)
     ab, mr = ops.groupnorm_finalize_mr(ops.channel_stats(tc), float(rows), gamma.cuda(), beta.cuda(), 1e-5)
-    dW, db, s = ops.pw_wgrad_groupnorm(t.cuda(), mr, ab, dhp.cuda(), W2.cuda(), gamma.cuda(), N=N, rows_per_sample=rows, c=C, c_hid=H)
-    assert s.shape == (-(-H // 64), N, 2, C)
-    s = s.sum(0)                                                  # hidden-channel chunks, added by norm_bwd_apply
+    dW, db, s, coef = ops.pw_wgrad_groupnorm(t.cuda(), mr, ab, dhp.cuda(), W2.cuda(), gamma.cuda(), N=N, rows_per_sample=rows, c=C,
+                                             c_hid=H, count=float(rows))
     mean, rstd = mr[:, 0].double().cpu(), mr[:, 1].double().cpu()
     xhat = (t.double() - mean[:, None]) * rstd[:, None]
-    xhat_b = xhat.float().bfloat16().double()                     # the MFMA operand
     d = dhp.double()
-    M = torch.einsum("nrh,nrc->nhc", d, xhat_b)
-    q = d.sum(1)
-    s_ref = torch.stack([torch.einsum("hc,nh->nc", W2.double(), q), torch.einsum("hc,nhc->nc", W2.double(), M)], 1)
+    w2 = W2.bfloat16().double()                                   # the data-gradient GEMM's weights
+    dtn = torch.einsum("nrh,hc->nrc", d, w2)
+    s_ref = torch.stack([dtn.sum(1), (dtn * xhat).sum(1)], 1)
     scale = s_ref.abs().max().item()
-    assert (s.double().cpu() - s_ref).abs().max().item() <= 2e-4 * scale + 1e-9
-    # the same sums the direct pass would produce from the UNROUNDED dtn (what the kernel replaces rounds dtn to bf16 first)
-    dtn = torch.einsum("nrh,hc->nrc", d, W2.double())
-    direct = torch.stack([dtn.sum(1), (dtn * xhat).sum(1)], 1)
-    assert (s.double().cpu() - direct).abs().max().item() <= 6e-3 * direct.abs().max().item()
+    assert (s.double().cpu() - s_ref).abs().max().item() <= 2e-4 * scale + 1e-12
+    M = torch.einsum("nrh,nrc->nhc", d, xhat)
+    q = d.sum(1)
     dW_ref = gamma.double() * M.sum(0) + beta.double() * q.sum(0)[:, None]
-    assert (dW.double().cpu() - dW_ref).abs().max().item() <= 1e-3 * dW_ref.abs().max().item() + 1e-9
+    assert (dW.double().cpu() - dW_ref).abs().max().item() <= 1e-3 * dW_ref.abs().max().item() + 1e-12
     torch.testing.assert_close(db.double().cpu(), q.sum(0), rtol=1e-4, atol=1e-7)
     dW_plain, db_plain = ops.pw_wgrad(t.cuda(), dhp.cuda(), N=N, rows_per_sample=rows, c_in=C, c_out=H, ab=ab)
     assert (dW.cpu() - dW_plain.cpu()).abs().max().item() <= 1.5e-2 * dW_plain.abs().max().item()
     torch.testing.assert_close(db.cpu(), db_plain.cpu(), rtol=1e-4, atol=1e-7)
+    if not ops.pw_conv_paired_supported(c_in=H, c_out=C, in_dtype=torch.bfloat16, out_dtype=torch.bfloat16):
+        return
+    # the epilogue: dt = rstd*gamma*(dtn - S1/V - xhat*S2/V) on the GEMM's own fp32 result
+    wp = ops.pw_pack_weight_paired(W2.cuda(), transposed=True)
+    dt = ops.pw_conv(dhp.cuda(), wp, None, N=N, rows_per_sample=rows, c_in=H, c_out=C, out_dtype=torch.bfloat16, res=t.cuda(),
+                     res_mode=nat.RES_NORM_BWD, res_bias=coef, w_paired=True).double().cpu()
+    rg = rstd * gamma.double()
+    dt_ref = rg[:, None] * (dtn - s_ref[:, 0][:, None] / rows - xhat * s_ref[:, 1][:, None] / rows)
+    err = (dt - dt_ref).abs().max().item()
+    assert err <= 2.0 ** -7 * dt_ref.abs().max().item(), err           # one bf16 rounding of the result
+    # orthogonality per (sample, channel): what is left is the rounding of dt itself, not a systematic component
+    noise = 2.0 ** -9 * dt_ref.abs().mean().item() * rows ** 0.5
+    assert dt.sum(1).abs().max().item() <= 8 * noise and (dt * xhat).sum(1).abs().max().item() <= 8 * noise * 2.0
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
@@ -749,7 +760,7 @@ def test_norm_backward_apply_with_given_statistics_and_front_face_crop(dt):
     assert torch.equal(crop, full[:, 1:, 1:, 1:].contiguous())
 
 
-def test_mednext_gradients_with_algebraic_norm_statistics_are_as_close_to_fp32_as_the_two_pass_form(monkeypatch):
+def test_mednext_gradients_with_the_norm_backward_in_the_gemm_epilogue_are_as_close_to_fp32_as_the_two_pass_form(monkeypatch):
     """BlockFn with NORM_STATS_FROM_WGRAD on / off (bf16 storage, all three block kinds) against the fp32 path of the same model:
     the algebraic statistics must not add error (they use unrounded dtn where the two-pass form reads bf16(dtn))."""
     from pytorch_connectomics_amd.models.architectures.mednext import MedNeXt
