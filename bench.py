@@ -187,6 +187,22 @@ def dominant(summ, n_steps, peak=HBM_PEAK_GBS, traffic_fn=None):
     return out
 
 
+def merge_by_kernel(summ, key_fn):
+    """Profiler labels that run the SAME device kernel template (key_fn(label) -> rocprof name substring, None = no mapping) merged
+    into one record named by that substring -- so that event time, algorithmic bytes and the rocprofv3 counter average of the kernel
+    all describe one set of launches.  -> (records, {kernel substring: [labels]})"""
+    out, members = {}, {}
+    for name, rec in summ.items():
+        key = key_fn(name)
+        tgt = key if key is not None else name
+        d = out.setdefault(tgt, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0})
+        for k in ("launches", "ms", "bytes", "flops"):
+            d[k] += rec.get(k, 0)
+        if key is not None:
+            members.setdefault(key, []).append(name)
+    return out, members
+
+
 def by_symbol(summ):
     """Per-label profiler records regrouped by device kernel family (hip_ops.PROFILER.by_symbol on an existing summary)."""
     out = {}
@@ -271,9 +287,13 @@ def train_leg(dev, rank, world, args, barrier):
                 for i in range(2):
                     tstep(i)
             table = committed_pmc_table("train")
-            roof = dominant(prof.summary(), 2, traffic_fn=lambda name: _traffic_from_table(table, _train_kernel_key(name)))
+            merged, members = merge_by_kernel(prof.summary(), _train_kernel_key)
+            roof = dominant(merged, 2, traffic_fn=lambda name: _traffic_from_table(table, name if name in members else None))
+            if roof["kernel"] in members:
+                roof["labels"] = members[roof["kernel"]]
             roof["traffic_source"] = ("committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this training step "
-                                      "(profiles/rNN_train_hbm_counters.csv; FETCH_SIZE x 2)")
+                                      "(profiles/rNN_train_hbm_counters.csv; FETCH_SIZE x 2); the entry covers every launch of the "
+                                      "device kernel named in `kernel` (`labels`), which is what the counter average covers")
             if roof.get("traffic"):
                 roof["traffic_over_algorithmic"] = round(roof["traffic"] / max(roof["algorithmic_bytes"], 1), 3)
         else:

@@ -380,15 +380,21 @@ def test_fused_training_mixer_matches_two_gemm_forward():
     assert abs(res[True][0] - res[False][0]) < 2e-2 * abs(res[False][0])
     g1, g0 = res[True][1], res[False][1]
     assert float((g1 * g0).sum() / (g1.norm() * g0.norm())) > 0.995
-    # the one-launch backward mixer (off by default: measured slower) computes the same bits as the two launches
-    AG.FUSED_TRAIN_MIXER_BWD = True
+    # the one-launch backward mixer (off by default: measured slower) computes the same bits as the two launches -- both with the
+    # two-pass norm backward (the epilogue form of NORM_STATS_FROM_WGRAD belongs to the two-launch schedule only)
+    stats_flag = AG.NORM_STATS_FROM_WGRAD
+    AG.NORM_STATS_FROM_WGRAD = False
     try:
-        m.zero_grad()
-        F.binary_cross_entropy_with_logits(m(x), y).backward()
+        grads = []
+        for fused_bwd in (False, True):
+            AG.FUSED_TRAIN_MIXER_BWD = fused_bwd
+            m.zero_grad()
+            F.binary_cross_entropy_with_logits(m(x), y).backward()
+            grads.append(torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None]))
     finally:
         AG.FUSED_TRAIN_MIXER_BWD = False
-    g2 = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
-    assert torch.equal(g2, g1)
+        AG.NORM_STATS_FROM_WGRAD = stats_flag
+    assert torch.equal(grads[0], grads[1])
 
 
 def test_inference_after_fused_optimizer_steps_sees_new_weights():

@@ -56,3 +56,21 @@ def test_kernel_families_and_mfma_bound_entries():
     # the committed counter passes, per kernel family
     t = b._traffic_from_table({"void pytc::dwconv3d_k3_march_kernel<x>": (10, 100.0, 50.0), "other": (5, 1.0, 1.0)}, "dwconv3d_k3_march_kernel")
     assert t == int((2 * 100.0 + 50.0) * 1024)
+
+
+def test_training_labels_merge_by_device_kernel_before_counters_are_attached():
+    """`train.roofline`: labels that run one device kernel template are merged, so the event time, the algorithmic bytes and the
+    rocprofv3 counter average of that kernel describe the same launches."""
+    b = _bench()
+    summ = {"pw_conv_fwd[32->64]": {"ms": 3.0, "bytes": 9e9, "launches": 12, "flops": 0},
+            "pw_conv_fwd[32->128]": {"ms": 1.5, "bytes": 5e9, "launches": 2, "flops": 0},
+            "pw_wgrad_gn[32->64]": {"ms": 2.0, "bytes": 4e9, "launches": 10, "flops": 0},
+            "norm_bwd[C32]": {"ms": 1.0, "bytes": 2e9, "launches": 10, "flops": 0}}
+    merged, members = b.merge_by_kernel(summ, b._train_kernel_key)
+    assert members == {"pw_fast_kernel<1,": ["pw_conv_fwd[32->64]", "pw_conv_fwd[32->128]"],
+                       "pw_wgrad_mfma_kernelILi4ELi2E": ["pw_wgrad_gn[32->64]"]}
+    assert merged["pw_fast_kernel<1,"] == {"launches": 14, "ms": 4.5, "bytes": 14e9, "flops": 0} and "norm_bwd[C32]" in merged
+    table = {"void pytc::pw_fast_kernel<1, 4>(pytc::PwFastParams)": (7, 500000.0, 100000.0)}
+    r = b.dominant(merged, 2, traffic_fn=lambda name: b._traffic_from_table(table, name if name in members else None))
+    assert r["kernel"] == "pw_fast_kernel<1," and r["traffic"] == int((2 * 500000.0 + 100000.0) * 1024)
+    assert r["algorithmic_bytes"] == int(14e9 / 14)
