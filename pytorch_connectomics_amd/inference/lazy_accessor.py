@@ -148,7 +148,7 @@ class LazyVolumeAccessor:
         self.binarize, self.threshold = bool(binarize), float(threshold)
         self.device = device
         self._norm_code, self._divisor = self._parse_normalize(normalize_mode) if kind == "image" else (nat.NORM_NONE, 1.0)
-        self.source = VolumeSource(self.path)
+        self.source = VolumeSource(self.path, kind=kind, read_workers=self.tile_read_workers)
         self.fmt = self.source.fmt
         self.channel_count = self.source.channels
         self.raw_spatial_shape = self.source.spatial_shape

@@ -1,4 +1,5 @@
-"""Storage back ends of disk-backed test volumes: HDF5, `.npy` (memory-mapped), zarr v2 directories, multi-page TIFF.
+"""Storage back ends of disk-backed test volumes: HDF5, `.npy` (memory-mapped), zarr v2 / v3 directories, multi-page TIFF, and
+section directories of image tiles described by a tile-metadata JSON (or inferred from the directory).
 
 A `VolumeSource` knows the stored array (shape, dtype, which axis -- if any -- is the channel axis) and does exactly one thing:
 `read_box(lo, hi)` returns the RAW stored values of a spatial box, in storage axis order and storage dtype, as one contiguous
@@ -23,7 +24,17 @@ from ..utils.h5lite import get_h5_backend
 _SUFFIX_FORMAT = {"h5": "h5", "hdf5": "h5", "tif": "tiff", "tiff": "tiff", "png": "png", "nii": "nifti", "npy": "npy"}
 
 
+def is_tile_source(path: str) -> bool:
+    """A metadata `.json` or a directory that is not (inside) a zarr store -- the reference's rule (inference/lazy.py:153-157)."""
+    if ".zarr" in str(path):
+        return False
+    q = Path(path)
+    return q.suffix.lower() == ".json" or q.is_dir()
+
+
 def detect_format(filename: str) -> str:
+    if is_tile_source(filename):
+        return "tile"
     if filename.endswith(".nii.gz"):
         return "nifti"
     fmt = _SUFFIX_FORMAT.get(Path(filename).suffix.lower().lstrip("."))
@@ -105,12 +116,211 @@ class ZarrV2Array:
         return out
 
 
+# ------------------------------------------------------------------------------------------------ zarr v3 (read only)
+class ZarrV3Array:
+    """Minimal zarr v3 array reader (directory store, regular chunk grid, `default` or `v2` chunk keys; codec chain
+    [transpose] -> bytes -> [gzip] [crc32c]).  Written from the zarr v3 core specification -- the zarr package is not part of the
+    image, so there is no reference-produced fixture behind it (parity unpinned); zstd / blosc / sharded stores need libraries
+    the image lacks and are refused by name."""
+
+    def __init__(self, root: Path):
+        self.root = Path(root)
+        meta = json.loads((self.root / "zarr.json").read_text())
+        if meta.get("node_type") == "group":
+            arrays = sorted(q.name for q in self.root.iterdir() if (q / "zarr.json").exists())
+            arrays = [a for a in arrays if json.loads((self.root / a / "zarr.json").read_text()).get("node_type") == "array"]
+            if not arrays:
+                raise FileNotFoundError(f"{self.root}: zarr v3 group without an array")
+            self.root = self.root / arrays[0]
+            meta = json.loads((self.root / "zarr.json").read_text())
+        if meta.get("zarr_format") != 3 or meta.get("node_type") != "array":
+            raise ValueError(f"{self.root}: not a zarr v3 array")
+        grid = meta["chunk_grid"]
+        if grid.get("name") != "regular":
+            raise NotImplementedError(f"{self.root}: chunk grid {grid.get('name')!r} is not supported")
+        self.shape = tuple(int(v) for v in meta["shape"])
+        self.chunks = tuple(int(v) for v in grid["configuration"]["chunk_shape"])
+        self.dtype = np.dtype(meta["data_type"])
+        self.fill = meta.get("fill_value") or 0
+        enc = meta.get("chunk_key_encoding", {"name": "default"})
+        self.key_style = enc.get("name", "default")
+        self.sep = (enc.get("configuration") or {}).get("separator", "/" if self.key_style == "default" else ".")
+        self.order = None                      # transpose codec: stored axis i = array axis order[i]
+        self.endian = "<"
+        self.tail = []                         # bytes -> bytes codecs, in encoding order
+        for codec in meta.get("codecs", []):
+            name, conf = codec.get("name"), codec.get("configuration") or {}
+            if name == "transpose":
+                self.order = tuple(int(v) for v in conf["order"])
+            elif name == "bytes":
+                self.endian = ">" if conf.get("endian", "little") == "big" else "<"
+            elif name in ("gzip", "crc32c"):
+                self.tail.append(name)
+            else:
+                raise NotImplementedError(f"{self.root}: zarr v3 codec {name!r} needs a library that is not in this image; "
+                                          "re-encode with gzip or use HDF5")
+
+    def _chunk(self, index) -> np.ndarray:
+        parts = [str(i) for i in index]
+        key = self.sep.join((["c"] if self.key_style == "default" else []) + parts) if parts else "c"
+        f = self.root / key
+        if not f.exists():
+            return np.full(self.chunks, self.fill, dtype=self.dtype)
+        raw = f.read_bytes()
+        for name in reversed(self.tail):
+            if name == "crc32c":
+                raw = raw[:-4]
+            else:
+                import gzip
+                raw = gzip.decompress(raw)
+        stored = self.chunks if self.order is None else tuple(self.chunks[a] for a in self.order)
+        chunk = np.frombuffer(raw, dtype=self.dtype.newbyteorder(self.endian)).reshape(stored).astype(self.dtype, copy=False)
+        return chunk if self.order is None else chunk.transpose(np.argsort(self.order))
+
+    __getitem__ = ZarrV2Array.__getitem__
+
+
+# ------------------------------------------------------------------------------------------------ image-tile sections
+def _coerce_tile_size(value) -> Tuple[int, int]:
+    if isinstance(value, int):
+        return int(value), int(value)
+    if isinstance(value, (list, tuple)) and len(value) == 2:
+        return int(value[0]), int(value[1])
+    raise ValueError(f"Tile metadata requires tile_size as int or [height, width], got {value!r}.")
+
+
+def _read_tile_image(path: str) -> Optional[np.ndarray]:
+    """One tile as (H, W, C); None when the file does not exist (the reference leaves the background value there)."""
+    if not Path(path).exists():
+        return None
+    from PIL import Image
+    with Image.open(path) as im:
+        a = np.asarray(im)
+    return a[:, :, None] if a.ndim == 2 else a
+
+
+class TileGridArray:
+    """A (depth, height, width) volume stored as one image tile grid per section (reference: inference/lazy.py:61-150 metadata,
+    data/io/tiles.py:19-156 assembly).  Metadata comes from a JSON object -- `image` / `images` (one path pattern per section,
+    `{row}_{column}` placeholders, relative to the JSON), `height`, `width`, `tile_size`, optional `depth`, `dtype` (uint8),
+    `tile_st` ([0, 0]: tile index of the grid origin), `tile_ratio` (1.0: tiles are rescaled by it before placement) -- or is
+    inferred from a directory of numeric section directories holding `<row>_<column>.png` tiles.  `array[z0:z1, y0:y1, x0:x1]`
+    assembles the box from the tiles it touches; voxels no tile covers keep the background value 128.  `kind == "label"` tiles
+    are VAST RGB ids (R * 65536 + G * 256 + B); every other kind reads channel 0."""
+
+    BACKGROUND = 128
+
+    def __init__(self, source: str, *, kind: str = "image", read_workers: int = 1):
+        path = Path(source)
+        if path.is_dir():
+            meta = self._infer(path)
+        elif path.suffix.lower() == ".json" and path.exists():
+            meta = self._load_json(path)
+        elif path.suffix.lower() == ".json" and path.with_suffix("").is_dir():
+            meta = self._infer(path.with_suffix(""))
+        else:
+            raise ValueError(f"Tile source {source} is neither an existing metadata JSON nor a tiled directory.")
+        self.patterns = list(meta["image"])
+        self.shape = (int(meta["depth"]), int(meta["height"]), int(meta["width"]))
+        self.dtype = np.dtype(meta.get("dtype", "uint8"))
+        self.tile_h, self.tile_w = _coerce_tile_size(meta["tile_size"])
+        start = meta.get("tile_st") or [0, 0]
+        self.row0, self.col0 = int(start[0]), int(start[1])
+        self.ratio = float(meta.get("tile_ratio", 1.0))
+        self.is_image = kind != "label"
+        self.read_workers = max(1, int(read_workers))
+        self.ndim = 3
+
+    @staticmethod
+    def _load_json(path: Path) -> dict:
+        meta = json.loads(path.read_text(encoding="utf-8"))
+        if not isinstance(meta, dict):
+            raise ValueError(f"Tile metadata must be a JSON object, got {type(meta).__name__}.")
+        patterns = meta.get("image", meta.get("images"))
+        if not patterns:
+            raise ValueError(f"Tile metadata {path} must contain an 'image' or 'images' list.")
+        if not isinstance(patterns, list):
+            raise ValueError(f"Tile metadata {path} image patterns must be a list.")
+        meta = dict(meta)
+        meta["image"] = [str(q if q.is_absolute() else path.parent / q) for q in (Path(str(v)) for v in patterns)]
+        meta.setdefault("depth", len(meta["image"]))
+        for key in ("height", "width", "tile_size"):
+            if key not in meta:
+                raise ValueError(f"Tile metadata {path} is missing required key '{key}'.")
+        return meta
+
+    @staticmethod
+    def _infer(path: Path) -> dict:
+        sections = sorted((q for q in path.iterdir() if q.is_dir() and q.name.isdigit()), key=lambda q: int(q.name))
+        if not sections:
+            raise ValueError(f"Cannot infer tile metadata from {path}: expected numeric section directories.")
+        tiles = sorted(sections[0].glob("*_*.png"))
+        if not tiles:
+            raise ValueError(f"Cannot infer tile metadata from {path}: no '<row>_<column>.png' tiles found in {sections[0]}.")
+        cells = []
+        for t in tiles:
+            r, _, c = t.stem.partition("_")
+            if r.lstrip("-").isdigit() and c.lstrip("-").isdigit():
+                cells.append((int(r), int(c)))
+        if not cells:
+            raise ValueError(f"Cannot infer tile grid from {sections[0]}.")
+        sample = _read_tile_image(str(tiles[0]))
+        th, tw = int(sample.shape[0]), int(sample.shape[1])
+        rows, cols = [r for r, _ in cells], [c for _, c in cells]
+        return {"image": [str(sec / "{row}_{column}.png") for sec in sections], "depth": len(sections),
+                "height": (max(rows) - min(rows) + 1) * th, "width": (max(cols) - min(cols) + 1) * tw, "tile_size": [th, tw],
+                "dtype": str(sample.dtype), "tile_st": [min(rows), min(cols)], "tile_ratio": 1.0}
+
+    def _fill_section(self, out: np.ndarray, z: int, y0: int, y1: int, x0: int, x1: int) -> None:
+        pattern = self.patterns[z]
+        for row in range(y0 // self.tile_h, (y1 + self.tile_h - 1) // self.tile_h):
+            for col in range(x0 // self.tile_w, (x1 + self.tile_w - 1) // self.tile_w):
+                name = pattern.format(row=row + self.row0, column=col + self.col0) if "{row}_{column}" in pattern else pattern
+                tile = _read_tile_image(name)
+                if tile is None:
+                    continue
+                if self.ratio != 1:
+                    from scipy.ndimage import zoom
+                    tile = zoom(tile, [self.ratio, self.ratio, 1], order=int(self.is_image))
+                ty, tx = row * self.tile_h, col * self.tile_w
+                ya, ye = max(y0, ty), min(y1, ty + tile.shape[0])
+                xa, xe = max(x0, tx), min(x1, tx + tile.shape[1])
+                if ye <= ya or xe <= xa:
+                    continue
+                part = tile[ya - ty:ye - ty, xa - tx:xe - tx]
+                if self.is_image:
+                    part = part[:, :, 0]
+                elif part.shape[-1] == 1:
+                    part = part[:, :, 0]
+                else:
+                    part = (part[:, :, 0].astype(np.uint32) * 65536 + part[:, :, 1].astype(np.uint32) * 256
+                            + part[:, :, 2].astype(np.uint32))
+                out[ya - y0:ye - y0, xa - x0:xe - x0] = part
+
+    def __getitem__(self, key) -> np.ndarray:
+        key = key if isinstance(key, tuple) else (key,)
+        key = key + (slice(None),) * (3 - len(key))
+        (z0, z1), (y0, y1), (x0, x1) = ((k.indices(n)[0], max(k.indices(n)[0], k.indices(n)[1])) for k, n in zip(key, self.shape))
+        out = np.full((z1 - z0, y1 - y0, x1 - x0), self.BACKGROUND, dtype=self.dtype)
+        if out.size == 0:
+            return out
+        jobs = [(out[z - z0], z, y0, y1, x0, x1) for z in range(z0, z1)]
+        if self.read_workers > 1 and len(jobs) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(self.read_workers, len(jobs))) as pool:   # sections are disjoint planes
+                list(pool.map(lambda j: self._fill_section(*j), jobs))
+        else:
+            for j in jobs:
+                self._fill_section(*j)
+        return out
+
+
 # ------------------------------------------------------------------------------------------------ the source
 class VolumeSource:
     """An opened stored array + its channel axis.  `spatial_axes` are the storage axes of the three spatial dimensions in
     storage order; `read_box` slices them and keeps every channel."""
 
-    def __init__(self, path: str):
+    def __init__(self, path: str, *, kind: str = "image", read_workers: int = 1):
         self.path = str(path)
         self.fmt = detect_format(self.path)
         self._owner = None
@@ -121,7 +331,9 @@ class VolumeSource:
             self._owner = backend.File(self.path, "r")
             self.array = self._owner[list(self._owner.keys())[0]]
         elif self.fmt == "zarr":
-            self.array = ZarrV2Array(self.path)
+            self.array = open_zarr(self.path)
+        elif self.fmt == "tile":
+            self.array = TileGridArray(self.path, kind=kind, read_workers=read_workers)
         elif self.fmt == "npy":
             self.array = np.load(self.path, mmap_mode="r")
         elif self.fmt == "tiff":
@@ -168,4 +380,16 @@ def box_strides(source: VolumeSource, box: np.ndarray, logical_to_stored: Tuple[
     return (channel,) + tuple(es[source.spatial_axes[logical_to_stored[a]]] // item for a in range(3))
 
 
-__all__ = ["VolumeSource", "ZarrV2Array", "detect_format", "box_strides"]
+def open_zarr(path: str):
+    """zarr v2 (`.zarray`) or v3 (`zarr.json`) array under `<store>.zarr[/key]`."""
+    p = str(path)
+    cut = p.index(".zarr") + len(".zarr")
+    store, key = Path(p[:cut]), p[cut:].strip("/")
+    root = store / key if key else store
+    if (root / "zarr.json").exists():
+        return ZarrV3Array(root)
+    return ZarrV2Array(p)
+
+
+__all__ = ["VolumeSource", "ZarrV2Array", "ZarrV3Array", "TileGridArray", "open_zarr", "detect_format", "is_tile_source",
+           "box_strides"]

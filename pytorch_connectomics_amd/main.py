@@ -67,9 +67,9 @@ def read_volume(spec: str, *, default_shape=(64, 128, 128), seed: int = 0) -> np
         from .utils.tiffstack import read_tiff_volume
         return read_tiff_volume(str(path))
     if ".zarr" in spec:
-        # zarr v2 directory store (optionally <store>.zarr/<array key>), read whole (inference/lazy_accessor.py ZarrV2Array)
-        from .inference.lazy_accessor import ZarrV2Array
-        arr = ZarrV2Array(spec)
+        # zarr v2 / v3 directory store (optionally <store>.zarr/<array key>), read whole (inference/volume_source.py)
+        from .inference.volume_source import open_zarr
+        arr = open_zarr(spec)
         return np.asarray(arr[(slice(None),) * len(arr.shape)])
     if path.suffix.lower() == ".png":
         # a glob pattern of PNG slices (reference io.py:161-177 read_images + :346-350): sorted, stacked along z; colour slices

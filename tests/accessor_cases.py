@@ -3,6 +3,7 @@ tests/golden/lazy_accessor.npz (make_golden.py --accessor) and the writer of the
 import itertools
 import json
 import zlib
+from pathlib import Path
 
 import numpy as np
 
@@ -48,3 +49,50 @@ def _write_sources(g, tmp_path, key):
         (zdir / ".".join(map(str, idx))).write_bytes(zlib.compress(block.tobytes(), 1))
     paths["zarr"] = str(zdir)
     return paths
+
+
+# ---- tile-grid sources (tests/golden/lazy_accessor_tiles.npz, make_golden.py --accessor_tiles)
+TILE_CASES = {
+    # name: (layout, accessor kwargs, [(location, size) ...], outer pad mode, outer pad value)
+    "tiles_json_plain": ("json", dict(kind="image"), [((0, 0, 0), (4, 12, 14)), ((1, 5, 7), (3, 16, 12)), ((-1, 14, 12), (4, 12, 10))], "reflect", 0.0),
+    "tiles_json_transpose_pad_div": ("json", dict(kind="image", transpose_axes=(1, 2, 0), context_pad=((1, 2), (2, 0), (1, 1)),
+                                                  context_pad_mode="reflect", normalize_mode="divide-255"),
+                                     [((0, 0, 0), (10, 10, 4)), ((12, 9, 2), (12, 12, 4))], "constant", 0.5),
+    "tiles_dir_inferred": ("dir", dict(kind="image", scale_factors=(1.0, 0.5, 1.5)), [((0, 0, 0), (4, 8, 16)), ((2, 4, 12), (2, 8, 18))], "replicate", 0.0),
+    "tiles_json_ratio2_mask": ("json_ratio2", dict(kind="mask", binarize=True, threshold=120.0), [((0, 10, 10), (4, 30, 24)), ((2, 20, 0), (2, 28, 40))], "constant", 0.0),
+    "tiles_json_rgb_label": ("json_rgb", dict(kind="label"), [((0, 0, 0), (3, 16, 20)), ((1, 7, 9), (3, 12, 10))], "constant", 0.0),
+}
+
+
+def write_tile_layout(root, layout, tiles, rgb_tiles):
+    """tiles (Z, R, C, h, w) uint8 / rgb_tiles (Z, R, C, h, w, 3) uint8 -> a tile source under `root`; returns its path.
+    json: sections sec<z>/, tile index origin (1, 2), tile (z=2, r=2, c=1) missing (stays background); dir: numeric section
+    directories the metadata is inferred from; json_ratio2: tiles zoomed x2 at read time; json_rgb: VAST RGB label tiles."""
+    from PIL import Image
+    root = Path(root)
+    Z, R, Cc, h, w = tiles.shape
+    if layout == "dir":
+        for z in range(Z):
+            (root / "stack" / str(z)).mkdir(parents=True, exist_ok=True)
+            for r in range(R):
+                for c in range(Cc):
+                    Image.fromarray(tiles[z, r, c]).save(root / "stack" / str(z) / f"{r + 3}_{c + 1}.png")
+        return str(root / "stack")
+    rgb = layout == "json_rgb"
+    scale = 2 if layout == "json_ratio2" else 1
+    name = f"tiles_{layout}"
+    for z in range(Z):
+        (root / name / f"sec{z}").mkdir(parents=True, exist_ok=True)
+        for r in range(R):
+            for c in range(Cc):
+                if layout == "json" and (z, r, c) == (2, 2, 1):
+                    continue
+                Image.fromarray(rgb_tiles[z, r, c] if rgb else tiles[z, r, c]).save(root / name / f"sec{z}" / f"{r + 1}_{c + 2}.png")
+    meta = {"image": [f"{name}/sec{z}/{{row}}_{{column}}.png" for z in range(Z)], "height": R * h * scale, "width": Cc * w * scale,
+            "tile_size": [h * scale, w * scale], "tile_st": [1, 2]}
+    if scale != 1:
+        meta["tile_ratio"] = float(scale)
+    if rgb:
+        meta["dtype"] = "uint32"
+    (root / f"{name}.json").write_text(json.dumps(meta))
+    return str(root / f"{name}.json")

@@ -835,6 +835,53 @@ def accessor():
     save("lazy_accessor.npz", **out)
 
 
+
+# ---------------------------------------------------------------- tile-grid sources through the reference accessor
+def accessor_tiles():
+    """connectomics/inference/lazy.py:61-157, :675-708 + data/io/tiles.py:19-156: the reference's LazyVolumeAccessor on tile-grid
+    sources (metadata JSON with relative `{row}_{column}` patterns, a missing tile, `tile_st`, `tile_ratio`, RGB label tiles, and
+    a directory whose metadata is inferred).  `imageio` is absent from the image: its `imread` is provided by Pillow here (PNG is
+    lossless, both decode to the same pixel values); scipy's zoom is the real one."""
+    import tempfile
+    import types
+    from PIL import Image
+    sys.path.insert(0, str(HERE.parent.parent))
+    sys.path.insert(0, str(HERE.parent))
+    from accessor_cases import TILE_CASES, write_tile_layout          # shared with the tests that read the fixture
+    S.install()
+    imageio = types.ModuleType("imageio")
+    imageio.imread = lambda f: np.asarray(Image.open(f))
+    imageio.v2 = types.ModuleType("imageio.v2")
+    imageio.v2.imread = imageio.imread
+    sys.modules["imageio"], sys.modules["imageio.v2"] = imageio, imageio.v2
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    REPO = HERE.parent.parent
+    sys.path.insert(0, str(REPO))
+    from pytorch_connectomics_amd.utils import h5lite
+    sys.modules.setdefault("h5py", h5lite)
+    for name in ("connectomics.data.augmentation.augment_ops", "connectomics.data.io.io", "connectomics.data.io.tiles",
+                 "connectomics.data.io.utils", "connectomics.inference.lazy"):
+        sys.modules.pop(name, None)
+    lz = S.ref("connectomics.inference.lazy")
+    rng = np.random.default_rng(33)
+    tiles = (rng.random((4, 3, 2, 8, 10)) * 255).astype(np.uint8)
+    rgb_tiles = (rng.random((4, 3, 2, 8, 10, 3)) * 255).astype(np.uint8)
+    rgb_tiles[..., 0] //= 64                                    # ids below 2^24 / 64: exact in the fp32 the accessor returns
+    out = {"tiles": tiles, "rgb_tiles": rgb_tiles}
+    with tempfile.TemporaryDirectory() as d:
+        for name, (layout, kw, reads, outer_mode, outer_val) in TILE_CASES.items():
+            src = write_tile_layout(d, layout, tiles, rgb_tiles)
+            with lz.LazyVolumeAccessor(src, **kw) as acc:
+                assert acc.fmt == "tile"
+                out[f"{name}__shapes"] = np.asarray([acc.channel_count, *acc.raw_spatial_shape, *acc.logical_spatial_shape,
+                                                     *acc.transformed_spatial_shape, *acc.padded_spatial_shape], np.int64)
+                for i, (loc, size) in enumerate(reads):
+                    out[f"{name}__patch{i}"] = acc.read_patch(loc, size, outer_pad_mode=outer_mode, outer_pad_value=outer_val)
+                out[f"{name}__full"] = acc.load_full()
+                print(name, out[f"{name}__shapes"], out[f"{name}__full"].dtype, float(out[f"{name}__full"].max()))
+    save("lazy_accessor_tiles.npz", **out)
+
+
 # ---------------------------------------------------------------- deep-supervision loss through the reference orchestrator
 def ds_loss():
     """connectomics/training/losses/orchestrator.py: LossOrchestrator.compute_deep_supervision_loss / compute_standard_loss with
@@ -940,7 +987,7 @@ def losses_extra():
 
 if __name__ == "__main__":
     parts = {"manifests": manifests, "optimizers": optimizers, "schedules": schedules, "selectors": selectors, "outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
-             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "accessor": accessor, "ds_loss": ds_loss, "losses_extra": losses_extra, "public_adapters": public_adapters}
+             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "accessor": accessor, "accessor_tiles": accessor_tiles, "ds_loss": ds_loss, "losses_extra": losses_extra, "public_adapters": public_adapters}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:
         parts[name]()
