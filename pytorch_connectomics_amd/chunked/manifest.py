@@ -8,6 +8,7 @@ import os
 from pathlib import Path
 from typing import Any, Iterable, Mapping
 
+# the geometry a resumed run must agree on with the run that wrote the manifest
 _CHECKED = ("chunk_shape", "overlap", "output_dtype", "output_shape")
 
 
@@ -15,52 +16,55 @@ class ManifestConfigMismatch(ValueError):
     pass
 
 
+def _atomic_json(path: Path, payload) -> None:
+    """Readers see the old file or the new one, never a torn write: temp file in the same directory, fsync, rename."""
+    scratch = path.with_name(path.name + ".tmp")
+    with open(scratch, "w") as fh:
+        fh.write(json.dumps(payload, indent=2))
+        fh.flush()
+        os.fsync(fh.fileno())
+    os.replace(scratch, path)
+
+
 class ResumeManifest:
     def __init__(self, path, config: Mapping[str, Any]):
-        self.path = Path(path)
-        self.config = dict(config)
+        self.path, self.config = Path(path), dict(config)
         self._completed: set[str] = set()
 
     @classmethod
     def load_or_create(cls, path, config: Mapping[str, Any], *, overwrite: bool = False) -> "ResumeManifest":
-        path = Path(path)
-        if overwrite and path.exists():
-            path.unlink()
-        m = cls(path, config)
-        if not path.exists():
-            m._write()
-            return m
-        payload = json.loads(path.read_text())
-        m._completed = set(payload.get("completed", []))
-        old = payload.get("config", {})
-        diffs = [f"{k}: existing={old[k]} requested={m.config[k]}" for k in _CHECKED
-                 if k in m.config and k in old and old[k] != m.config[k]]
-        if diffs:
-            raise ManifestConfigMismatch(f"Resume manifest at {path} disagrees with requested config: "
-                                         + "; ".join(diffs)
-                                         + ". Re-run with overwrite=True or change the requested config.")
-        return m
+        manifest = cls(path, config)
+        if overwrite:
+            manifest.path.unlink(missing_ok=True)
+        try:
+            stored = json.loads(manifest.path.read_text())
+        except FileNotFoundError:
+            manifest._write()
+            return manifest
+        manifest._completed.update(stored.get("completed", ()))
+        before = stored.get("config", {})
+        clashes = "; ".join(f"{key}: existing={before[key]} requested={manifest.config[key]}" for key in _CHECKED
+                            if key in before and key in manifest.config and before[key] != manifest.config[key])
+        if clashes:
+            raise ManifestConfigMismatch(f"Resume manifest at {manifest.path} disagrees with requested config: {clashes}"
+                                         ". Re-run with overwrite=True or change the requested config.")
+        return manifest
 
     @property
     def completed(self) -> set[str]:
         return set(self._completed)
 
     def mark_completed(self, chunk_key: str) -> None:
-        self.mark_many([chunk_key])
+        self.mark_many((chunk_key,))
 
     def mark_many(self, chunk_keys: Iterable[str]) -> None:
-        new = {k for k in chunk_keys if k not in self._completed}
-        if new:
-            self._completed |= new
+        before = len(self._completed)
+        self._completed.update(chunk_keys)
+        if len(self._completed) != before:
             self._write()
 
     def _write(self) -> None:
-        tmp = self.path.with_suffix(self.path.suffix + ".tmp")
-        with tmp.open("w") as fh:
-            json.dump({"config": self.config, "completed": sorted(self._completed)}, fh, indent=2)
-            fh.flush()
-            os.fsync(fh.fileno())
-        os.replace(tmp, self.path)
+        _atomic_json(self.path, {"config": self.config, "completed": sorted(self._completed)})
 
 
 __all__ = ["ResumeManifest", "ManifestConfigMismatch"]

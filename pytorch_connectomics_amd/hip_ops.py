@@ -544,6 +544,15 @@ def packed_taps(w: torch.Tensor, *, flipped: bool = False, packs: Optional[StepP
     return out
 
 
+def _check_out(y: torch.Tensor, numel: int, dtype: torch.dtype, what: str) -> None:
+    """A caller-provided output buffer (e.g. a sample slice of a larger batch tensor) must be a dense device tensor of the size
+    and dtype the kernel writes."""
+    _dev(y, "y")
+    if y.dtype != dtype or y.numel() != numel or not y.is_contiguous():
+        raise ValueError(f"{what}: output buffer must be a contiguous {dtype} tensor of {numel} elements, got "
+                         f"{tuple(y.shape)} {y.dtype} contiguous={y.is_contiguous()}")
+
+
 def _w3_format(w3p: torch.Tensor) -> int:
     return nat.W3_F16 if w3p.dtype == torch.float16 else nat.W3_BF16
 
@@ -560,6 +569,8 @@ def pw_mlp(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.Tenso
         raise TypeError("pw_mlp runs on bfloat16 activations")
     if y is None:
         y = torch.empty((N, rows_per_sample, c_out), dtype=torch.bfloat16, device=t.device)
+    else:
+        _check_out(y, N * rows_per_sample * c_out, torch.bfloat16, "pw_mlp")
     a = nat.MlpArgs()
     a.t, a.ab, a.w2_packed, a.b2, a.w3_packed, a.b3 = (t.data_ptr(), ab.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
                                                        w3p.data_ptr(), b3.data_ptr())
@@ -650,12 +661,15 @@ def stem_dwconv3d(x: torch.Tensor, packed):
 
 def pw_mlp_stemres(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.Tensor, w3p: torch.Tensor, b3: torch.Tensor,
                    x0: torch.Tensor, stem_w: torch.Tensor, stem_b: torch.Tensor, *, N: int, rows_per_sample: int, c_in: int,
-                   c_hid: int, c_out: int) -> torch.Tensor:
+                   c_hid: int, c_out: int, y: Optional[torch.Tensor] = None) -> torch.Tensor:
     """pw_mlp whose residual is the stem output recomputed from the 1-channel fp32 input x0 (N, rows)."""
     _dev(t, "t"); _dev(x0, "x0")
     if t.dtype != torch.bfloat16 or x0.dtype != torch.float32:
         raise TypeError("pw_mlp_stemres: bf16 activations and the fp32 network input")
-    y = torch.empty((N, rows_per_sample, c_out), dtype=torch.bfloat16, device=t.device)
+    if y is None:
+        y = torch.empty((N, rows_per_sample, c_out), dtype=torch.bfloat16, device=t.device)
+    else:
+        _check_out(y, N * rows_per_sample * c_out, torch.bfloat16, "pw_mlp_stemres")
     a = nat.MlpArgs()
     a.t, a.ab, a.w2_packed, a.b2, a.w3_packed, a.b3 = (t.data_ptr(), ab.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
                                                        w3p.data_ptr(), b3.data_ptr())

@@ -9,42 +9,52 @@ from typing import Any, Sequence
 from .crop import normalize_crop_pad, resolve_global_prediction_crop, resolve_selected_affinity_offsets
 
 
+_HDF5_BACKENDS = ("h5", "hdf5")
+_OUTPUT_MODES = ("decoded", "raw_prediction")
+_H5_CHUNK_EDGE = 64
+
+
+def _chunking(cfg: Any):
+    return getattr(getattr(cfg, "inference", None), "chunking", None)
+
+
 def validate_chunked_output_format(cfg: Any) -> None:
     """chunk_grid.py:78-86: chunked inference streams ONE HDF5 output; any other save backend is a configuration error."""
-    backend = str(getattr(getattr(cfg, "inference", None), "save_backend", "h5")).lower()
-    if backend not in {"h5", "hdf5"}:
-        raise ValueError("Chunked inference writes a single streamed HDF5 output only; "
-                         f"unsupported inference.save_backend={backend!r}.")
+    chosen = str(getattr(getattr(cfg, "inference", None), "save_backend", _HDF5_BACKENDS[0])).lower()
+    if chosen in _HDF5_BACKENDS:
+        return
+    raise ValueError(f"Chunked inference writes a single streamed HDF5 output only; unsupported inference.save_backend={chosen!r}.")
 
 
 def resolve_chunk_shape(cfg: Any, final_shape: Sequence[int]) -> tuple[int, int, int]:
     """chunk_grid.py:89-97: `chunking.chunk_size`, `axes: z` keeps full YX, every axis clipped to the (cropped) volume."""
-    ch = getattr(getattr(cfg, "inference", None), "chunking", None)
-    size = getattr(ch, "chunk_size", None)
-    if not size:
+    section = _chunking(cfg)
+    wanted = [int(v) for v in (getattr(section, "chunk_size", None) or ())]
+    if not wanted:
         raise ValueError("inference.chunking.chunk_size must be set for chunked inference")
-    size = [int(v) for v in size]
-    if len(size) != 3 or any(v <= 0 for v in size):
-        raise ValueError(f"inference.chunking.chunk_size must be 3 positive ints, got {size}")
-    axes = str(getattr(ch, "axes", "all")).lower()
-    if axes == "z":
-        return (size[0], int(final_shape[1]), int(final_shape[2]))
-    if axes != "all":
-        raise ValueError("inference.chunking.axes must be 'all' or 'z'")
-    return tuple(min(size[a], int(final_shape[a])) for a in range(3))
+    if len(wanted) != 3 or min(wanted) <= 0:
+        raise ValueError(f"inference.chunking.chunk_size must be 3 positive ints, got {wanted}")
+    extent = [int(v) for v in final_shape[:3]]
+    split = str(getattr(section, "axes", "all")).lower()
+    if split == "all":
+        return tuple(min(w, e) for w, e in zip(wanted, extent))
+    if split == "z":
+        return (wanted[0], extent[1], extent[2])
+    raise ValueError("inference.chunking.axes must be 'all' or 'z'")
 
 
 def resolve_h5_spatial_chunks(spatial_shape: Sequence[int]) -> tuple[int, int, int]:
     """chunk_grid.py:100-102: HDF5 chunk = min(64, extent) per spatial axis (the channel axis is chunked whole)."""
-    return tuple(min(int(spatial_shape[a]), 64) for a in range(3))
+    z, y, x = (min(_H5_CHUNK_EDGE, int(v)) for v in spatial_shape[:3])
+    return (z, y, x)
 
 
 def resolve_chunk_output_mode(cfg: Any) -> str:
     """chunk_grid.py:105-110."""
-    mode = str(getattr(cfg.inference.chunking, "output_mode", "decoded")).lower()
-    if mode not in {"decoded", "raw_prediction"}:
-        raise ValueError("inference.chunking.output_mode must be 'decoded' or 'raw_prediction'.")
-    return mode
+    mode = str(getattr(cfg.inference.chunking, "output_mode", _OUTPUT_MODES[0])).lower()
+    if mode in _OUTPUT_MODES:
+        return mode
+    raise ValueError("inference.chunking.output_mode must be 'decoded' or 'raw_prediction'.")
 
 
 __all__ = ["normalize_crop_pad", "resolve_selected_affinity_offsets", "resolve_global_prediction_crop",

@@ -22,19 +22,26 @@ __all__ = ["run_prediction_inference"]
 
 def _prediction_tensor_to_czyx(predictions: torch.Tensor) -> torch.Tensor:
     """(1, C, Z, Y, X) or (C, Z, Y, X) -> CZYX, still on the device (stage.py:16-28, same messages)."""
-    t = predictions.detach()
-    if t.ndim == 5:
-        if t.shape[0] != 1:
-            raise ValueError("run_prediction_inference can write one artifact per call; "
-                             f"got batch size {t.shape[0]}.")
-        t = t[0]
-    if t.ndim != 4:
-        raise ValueError(f"Prediction artifact expects CZYX data, got shape {tuple(t.shape)}.")
-    return t
+    shape = tuple(predictions.shape)
+    if len(shape) == 5 and shape[0] != 1:
+        raise ValueError(f"run_prediction_inference can write one artifact per call; got batch size {shape[0]}.")
+    if len(shape) not in (4, 5):
+        raise ValueError(f"Prediction artifact expects CZYX data, got shape {shape}.")
+    return predictions.detach().reshape(shape[-4:])
 
 
 def _normalize_compression(value: Any) -> Optional[str]:
-    return None if value in (None, "", "none") else str(value)
+    return str(value) if value not in (None, "", "none") else None
+
+
+def _stored_representation(cfg, czyx: torch.Tensor) -> np.ndarray:
+    """Semantic transform (intensity scale / dtype) and storage dtype ON THE DEVICE, then the one device -> host copy."""
+    stored = apply_storage_dtype_transform(cfg, apply_prediction_transform(cfg, czyx))
+    if isinstance(stored, torch.Tensor):
+        if stored.is_cuda:
+            torch.cuda.current_stream(stored.device).synchronize()
+        stored = stored.cpu().numpy()
+    return np.asarray(stored)
 
 
 def run_prediction_inference(manager, images: torch.Tensor, *, mask: Optional[torch.Tensor] = None,
@@ -47,23 +54,15 @@ def run_prediction_inference(manager, images: torch.Tensor, *, mask: Optional[to
     run (`manager.should_skip_postprocess_on_rank()`) nothing is written and the empty tensor is returned."""
     predictions = manager.predict_with_tta(images, mask=mask, mask_align_to_image=mask_align_to_image,
                                            requested_head=requested_head)
-    skip = getattr(manager, "should_skip_postprocess_on_rank", None)
-    if output_path is None or (skip is not None and skip()):
+    contributes_only = getattr(manager, "should_skip_postprocess_on_rank", lambda: False)
+    if output_path is None or contributes_only():
         return predictions
     cfg = manager.cfg
-    data = _prediction_tensor_to_czyx(predictions)
-    stored = apply_storage_dtype_transform(cfg, apply_prediction_transform(cfg, data))
-    if isinstance(stored, torch.Tensor):
-        if stored.is_cuda:
-            torch.cuda.current_stream(stored.device).synchronize()
-        stored = stored.cpu().numpy()                   # the only D2H copy: the stored representation
-    stored = np.asarray(stored)
+    stored = _stored_representation(cfg, _prediction_tensor_to_czyx(predictions))
     compression = _normalize_compression(getattr(cfg.inference, "save_compression", "gzip"))
-    write_prediction_artifact(
-        output_path, stored,
-        metadata=build_prediction_artifact_metadata(
-            cfg, image_path=image_path, checkpoint_path=str(checkpoint_path) if checkpoint_path is not None else None,
-            output_head=requested_head, input_shape=input_shape, final_shape=stored.shape[-3:], crop_pad=crop_pad,
-            intensity_dtype=str(stored.dtype), extra={"compression": str(compression)}),
-        compression=compression)
+    described = build_prediction_artifact_metadata(
+        cfg, image_path=image_path, checkpoint_path=None if checkpoint_path is None else str(checkpoint_path),
+        output_head=requested_head, input_shape=input_shape, final_shape=stored.shape[-3:], crop_pad=crop_pad,
+        intensity_dtype=str(stored.dtype), extra={"compression": str(compression)})
+    write_prediction_artifact(output_path, stored, metadata=described, compression=compression)
     return predictions

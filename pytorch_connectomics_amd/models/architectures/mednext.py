@@ -35,6 +35,18 @@ from ... import hip_ops as ops
 # not (no hidden tensor to store, and the second window stream already fills the idle CUs).  0 = off (default).
 SMALL_ROWS_TWO_GEMMS = int(os.environ.get("PYTC_MIXER_TWO_GEMM_ROWS", "0"))
 
+# bf16 inference: samples per depth-first chain at the FULL-RESOLUTION level (MedNeXt.features_cl).  The level-0 tensors of an
+# 8-window batch (0.72 GB each at 112^3 x 32 channels) are far larger than the 256 MiB Infinity Cache, so every kernel streams its
+# operands from HBM; run sample slice by sample slice (stem + encoder blocks + down block, later up block + decoder blocks + head), a
+# slice's depthwise output / block output (90 MB per window) could be re-read by the next kernel of the chain while still
+# cache-resident.  MEASURED on the whole-volume bench (round 3, profiles/r03_l0_subbatch.txt): no such gain -- 7.57 ms per 8 windows
+# for the whole batch against 7.60 / 7.79 / 7.98 for slices of 4 / 2 / 1 windows with two window streams (8.58 against 8.67 / 9.12 /
+# 10.0 with one): smaller launches fill the chip worse and nothing comes back from the cache to pay for it.  Results are bit-identical
+# for every value (no kernel lets a sample's arithmetic depend on the batch it travels in; tests/test_gpu_mednext.py::
+# test_level0_subbatch_is_bit_identical), so the switch stays as a memory knob (a slice's level-0 temporaries instead of the
+# batch's).  0 = off (default).
+L0_SUBBATCH = int(os.environ.get("PYTC_L0_SUBBATCH", "0"))
+
 
 def _conv_nd(dim: str):
     if dim == "3d":
@@ -234,9 +246,12 @@ class HipBlockOps:
                         c_out=c_out, out_dtype=out_dtype or x.dtype, act=act)
         return y.view(N, *spatial, c_out)
 
-    def block(self, m: MedNeXtBlock, x: torch.Tensor, skip: Optional[torch.Tensor] = None, head: Optional[nn.Module] = None):
+    def block(self, m: MedNeXtBlock, x: torch.Tensor, skip: Optional[torch.Tensor] = None, head: Optional[nn.Module] = None,
+              out: Optional[torch.Tensor] = None):
         """head: the network's output conv; when the fused mixer can carry it in its epilogue the block returns
         (None, logits fp32 (N, D, H, W, n_classes)) instead of its bf16 output.
+        out: a dense buffer of the block's output shape (a sample slice of a batch tensor): the fused bf16 mixer writes its
+        result there directly, every other schedule copies into it; the return value is `out` then (not with `head`).
 
         dim='2d' blocks run the same kernels on a depth-1 volume (N, 1, H, W, C): a k x k stencil is the centre z-plane of
         a k^3 one whose other planes only ever meet the zero padding, the stride-2 and 1x1 convs reduce to their 2-D forms
@@ -251,10 +266,21 @@ class HipBlockOps:
                 if skip is not None:
                     sk3 = skip.new_zeros((skip.shape[0], 2) + tuple(skip.shape[2:]))
                     sk3[:, 1] = skip[:, 0]
-                return self._block(m, x, sk3, None)[:, 1:2].contiguous()
-        return self._block(m, x, skip, head)
+                y = self._block(m, x, sk3, None)[:, 1:2].contiguous()
+                return y if out is None else out.copy_(y)
+        return self._block(m, x, skip, head, out)
 
-    def _block(self, m: MedNeXtBlock, x: torch.Tensor, skip: Optional[torch.Tensor] = None, head: Optional[nn.Module] = None):
+    def _block(self, m: MedNeXtBlock, x: torch.Tensor, skip: Optional[torch.Tensor] = None, head: Optional[nn.Module] = None,
+               out: Optional[torch.Tensor] = None):
+        y = self._block_any(m, x, skip, head, out)
+        if out is None or isinstance(y, tuple) or y is out:
+            return y
+        if y.data_ptr() == out.data_ptr():          # written in place by the fused mixer (a view of `out`)
+            return out
+        return out.copy_(y.view(out.shape))
+
+    def _block_any(self, m: MedNeXtBlock, x: torch.Tensor, skip: Optional[torch.Tensor] = None, head: Optional[nn.Module] = None,
+                   out: Optional[torch.Tensor] = None):
         is_ln = isinstance(m.norm, _ChannelLayerNorm)
         if not is_ln and not isinstance(m.norm, nn.GroupNorm):
             raise NotImplementedError(f"unsupported MedNeXt norm module {type(m.norm).__name__}")
@@ -300,7 +326,7 @@ class HipBlockOps:
                                             rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out,
                                             res=x if m.do_res else None, store_y=False)
                 return None, logits.view(N, Do, Ho, Wo, -1)
-            return self._block_fused(m, x, t, ab, skip, (N, D, H, W, C), (Do, Ho, Wo), c_hid, c_out)
+            return self._block_fused(m, x, t, ab, skip, (N, D, H, W, C), (Do, Ho, Wo), c_hid, c_out, out)
         G = {}
         if small:
             h = ops.pw_conv(t, self._pw_paired(m.conv2), self._vec(m.conv2, "bias", m.conv2.bias), N=N, rows_per_sample=rows,
@@ -338,7 +364,7 @@ class HipBlockOps:
         return y.view(N, Do, Ho, Wo, c_out)
 
 
-def _stem_block_fused(self, stem: nn.Module, m, x_cl: torch.Tensor) -> Optional[torch.Tensor]:
+def _stem_block_fused(self, stem: nn.Module, m, x_cl: torch.Tensor, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """Stem + first block without ever forming the stem output (bf16 inference, 1-channel fp32 input): the depthwise conv
     reads the network input (pytc_stem_dwconv3d_fwd), the mixer recomputes its residual from it (pytc_pw_mlp_stemres_fwd).
     Returns None when a precondition fails (the caller then runs stem and block separately)."""
@@ -364,14 +390,15 @@ def _stem_block_fused(self, stem: nn.Module, m, x_cl: torch.Tensor) -> Optional[
                                 self._vec(m.norm, "bias", m.norm.bias), m.norm.eps)
     y = ops.pw_mlp_stemres(t, ab, self._pw_paired(m.conv2), self._vec(m.conv2, "bias", m.conv2.bias),
                            self._pw_paired(m.conv3, project=True), self._vec(m.conv3, "bias", m.conv3.bias), x_cl.reshape(N, rows), sw, sb,
-                           N=N, rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out)
+                           N=N, rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out,
+                           y=None if out is None else out.view(N, rows, c_out))
     return y.view(N, D, H, W, c_out)
 
 
 HipBlockOps._stem_block_fused = None   # bound below
 
 
-def _block_fused(self, m, x, t, ab, skip, ishape, oshape, c_hid, c_out):
+def _block_fused(self, m, x, t, ab, skip, ishape, oshape, c_hid, c_out, out=None):
     """bf16 fast path: one pw_mlp launch per block (plus the tiny residual-conv GEMMs of down/up blocks)."""
     N, D, H, W, C = ishape
     Do, Ho, Wo = oshape
@@ -380,6 +407,10 @@ def _block_fused(self, m, x, t, ab, skip, ishape, oshape, c_hid, c_out):
     w2, b2 = self._pw_paired(m.conv2), self._vec(m.conv2, "bias", m.conv2.bias)
     w3, b3 = self._pw_paired(m.conv3, project=True), self._vec(m.conv3, "bias", m.conv3.bias)
     kw = dict(N=N, rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out)
+    if out is not None:
+        if tuple(out.shape) != (N, Do, Ho, Wo, c_out):
+            raise ValueError(f"block output buffer {tuple(out.shape)} != {(N, Do, Ho, Wo, c_out)}")
+        kw["y"] = out.view(N, rows, c_out)
     if m.kind == "block":
         y = ops.pw_mlp(t, ab, w2, b2, w3, b3, res=x if m.do_res else None,
                        res_mode=nat.RES_ADD if m.do_res else nat.RES_NONE, **kw)
@@ -522,6 +553,7 @@ class MedNeXt(nn.Module):
         # inference: stem folded into the first depthwise conv (406 us against 174 + 400 us for the two kernels it replaces,
         # the stem output never written) + the residual recomputed from the 1-channel input in that block's mixer
         self.fuse_stem = True
+        self.l0_subbatch = L0_SUBBATCH   # bf16 inference: samples per depth-first chain at the full-resolution level (0 = off)
 
     # ---- engine ---------------------------------------------------------------------------------
     def _check_input(self, x: torch.Tensor):
@@ -563,17 +595,53 @@ class MedNeXt(nn.Module):
             raise ValueError(f"MedNeXt needs spatial sizes divisible by 16, got {tuple(x_cl.shape[1:4])}"
                              + (" (dim='2d': depth must be 1)" if self.dim == "2d" else ""))
         enc0 = list(self.enc_block_0)
-        x = None
-        if self.fuse_stem and hip.fused and dt == torch.bfloat16 and enc0:
-            x = hip._stem_block_fused(self.stem, enc0[0], x_cl)      # stem output never written (None: not applicable)
-        first_done = x is not None
-        if x is None:
-            x = hip.pointwise(x_cl, self.stem, out_dtype=dt)
+        N = int(x_cl.shape[0])
+        sb = int(self.l0_subbatch)
+        chained = 0 < sb < N and dt == torch.bfloat16 and hip.fused and self.dim == "3d"
+        fuse_stem = self.fuse_stem and hip.fused and dt == torch.bfloat16 and bool(enc0)
+
+        def level0_encoder(xs: torch.Tensor, skip_out: Optional[torch.Tensor], down_out: Optional[torch.Tensor]):
+            """stem -> enc_block_0 -> down_0 on the samples of xs; the level's skip tensor and the down block's result go to the
+            given buffers (sample slices of the batch tensors) when there are any."""
+            blocks = list(enc0)
+            h = None
+            if fuse_stem:
+                h = hip._stem_block_fused(self.stem, blocks[0], xs, skip_out if len(blocks) == 1 else None)
+                if h is not None:
+                    blocks = blocks[1:]          # stem output never written (None: not applicable)
+            if h is None:
+                h = hip.pointwise(xs, self.stem, out_dtype=dt)
+                if not blocks and skip_out is not None:
+                    h = skip_out.copy_(h)
+            for bi, blk in enumerate(blocks):
+                h = hip.block(blk, h, out=skip_out if bi == len(blocks) - 1 else None)
+            return h, hip.block(self.down_0, h, out=down_out)
+
+        def level0_decoder(xl: torch.Tensor, sk: torch.Tensor, y_out: Optional[torch.Tensor] = None):
+            """up_0 -> dec_block_0 (the last block may carry the output head: -> (None, logits))."""
+            h = hip.block(self.up_0, xl, skip=sk)
+            blocks = list(self.dec_block_0)
+            for bi, blk in enumerate(blocks):
+                last = bi == len(blocks) - 1
+                h = hip.block(blk, h, head=head if last else None, out=y_out if last else None)
+            if not blocks and y_out is not None:
+                h = y_out.copy_(h)
+            return h
+
         skips = []
-        for lvl in range(4):
-            for bi, blk in enumerate(getattr(self, f"enc_block_{lvl}")):
-                if lvl == 0 and bi == 0 and first_done:
-                    continue
+        if chained:
+            _, D0, H0, W0, _ = x_cl.shape
+            c0, c1 = self.stem.weight.shape[0], self.down_0.conv3.weight.shape[0]
+            skip0 = torch.empty((N, D0, H0, W0, c0), dtype=dt, device=x_cl.device)
+            x = torch.empty((N, D0 // 2, H0 // 2, W0 // 2, c1), dtype=dt, device=x_cl.device)
+            for s0 in range(0, N, sb):
+                level0_encoder(x_cl[s0:s0 + sb], skip0[s0:s0 + sb], x[s0:s0 + sb])
+            skips.append(skip0)
+        else:
+            h, x = level0_encoder(x_cl, None, None)
+            skips.append(h)
+        for lvl in range(1, 4):
+            for blk in getattr(self, f"enc_block_{lvl}"):
                 x = hip.block(blk, x)
             skips.append(x)
             x = hip.block(getattr(self, f"down_{lvl}"), x)
@@ -581,15 +649,23 @@ class MedNeXt(nn.Module):
             x = hip.block(blk, x)
         if collect is not None:
             collect.append(x)
-        for lvl in (3, 2, 1, 0):
+        for lvl in (3, 2, 1):
             x = hip.block(getattr(self, f"up_{lvl}"), x, skip=skips[lvl])
-            blocks = list(getattr(self, f"dec_block_{lvl}"))
-            for bi, blk in enumerate(blocks):
-                last = lvl == 0 and bi == len(blocks) - 1
-                x = hip.block(blk, x, head=head if last else None)
-            if collect is not None and lvl != 0:
+            for blk in getattr(self, f"dec_block_{lvl}"):
+                x = hip.block(blk, x)
+            if collect is not None:
                 collect.append(x)
-        return x
+        if not chained:
+            return level0_decoder(x, skips[0])
+        first = level0_decoder(x[0:sb], skips[0][0:sb])
+        if isinstance(first, tuple):                    # (None, logits): 4 B per voxel and class, the concatenation is noise
+            parts = [first[1]] + [level0_decoder(x[s0:s0 + sb], skips[0][s0:s0 + sb])[1] for s0 in range(sb, N, sb)]
+            return None, torch.cat(parts, 0)
+        y0 = torch.empty((N,) + tuple(first.shape[1:]), dtype=first.dtype, device=first.device)
+        y0[0:sb].copy_(first)
+        for s0 in range(sb, N, sb):
+            level0_decoder(x[s0:s0 + sb], skips[0][s0:s0 + sb], y0[s0:s0 + sb])
+        return y0
 
     def output_cl(self, feat_cl: torch.Tensor, head: int = 0) -> torch.Tensor:
         """features -> fp32 logits, channels-last."""

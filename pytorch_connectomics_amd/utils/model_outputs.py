@@ -8,35 +8,44 @@ from typing import Any, Optional
 import torch
 
 
+_ABSENT = object()
+
+
+def _dig(node: Any, *path: str, default: Any = None) -> Any:
+    """node[path[0]][path[1]]... through mappings and attribute namespaces alike; `default` as soon as a step is missing."""
+    for key in path:
+        if node is None:
+            return default
+        node = node.get(key, _ABSENT) if isinstance(node, Mapping) else getattr(node, key, _ABSENT)
+        if node is _ABSENT:
+            return default
+    return node
+
+
 def _cfg_value(obj: Any, key: str, default: Any = None) -> Any:
-    if obj is None:
-        return default
-    if isinstance(obj, Mapping):
-        return obj.get(key, default)
-    return getattr(obj, key, default)
+    return _dig(obj, key, default=default)
 
 
 def get_inference_model_value(cfg: Any, key: str, default: Any = None) -> Any:
-    return _cfg_value(_cfg_value(_cfg_value(cfg, "inference", None), "model", None), key, default)
+    return _dig(cfg, "inference", "model", key, default=default)
 
 
 def get_inference_select_channel(cfg: Any) -> Any:
-    return get_inference_model_value(cfg, "select_channel", None)
+    return get_inference_model_value(cfg, "select_channel")
 
 
 def get_inference_channel_activations(cfg: Any) -> list:
-    value = get_inference_model_value(cfg, "channel_activations", None)
-    return list(value) if isinstance(value, (list, tuple)) else []
-
-
-def get_model_head_names(cfg: Any) -> list[str]:
-    heads = _cfg_value(_cfg_value(cfg, "model", None), "heads", None) or {}
-    return list(heads.keys()) if isinstance(heads, Mapping) else []
+    specs = get_inference_model_value(cfg, "channel_activations")
+    return list(specs) if isinstance(specs, (list, tuple)) else []
 
 
 def _named_heads(cfg: Any) -> Mapping:
-    heads = _cfg_value(_cfg_value(cfg, "model", None), "heads", None)
+    heads = _dig(cfg, "model", "heads")
     return heads if isinstance(heads, Mapping) else {}
+
+
+def get_model_head_names(cfg: Any) -> list[str]:
+    return list(_named_heads(cfg))
 
 
 def _checked_head(name: Any, heads: Mapping, what: str, purpose: str) -> str:
@@ -62,7 +71,7 @@ def resolve_output_head(cfg: Any, *, requested_head: Optional[str] = None, purpo
     configured = get_inference_model_value(cfg, "head", None)
     if configured is not None and not (isinstance(configured, str) and "," in configured):
         return _checked_head(configured, heads, "Requested output head", purpose)
-    primary = _cfg_value(_cfg_value(cfg, "model", None), "primary_head", None)
+    primary = _dig(cfg, "model", "primary_head")
     if primary is not None:
         return _checked_head(primary, heads, "model.primary_head", purpose)
     if len(heads) == 1:
@@ -94,37 +103,33 @@ def resolve_output_heads(cfg: Any, *, purpose: str = "output selection") -> list
 
 
 def unwrap_main_output(outputs: Any) -> Any:
-    if isinstance(outputs, Mapping) and "output" in outputs:
-        return outputs["output"]
-    return outputs
+    return outputs["output"] if isinstance(outputs, Mapping) and "output" in outputs else outputs
 
 
 def select_output_tensor(outputs: Any, *, requested_head: Optional[str] = None, primary_head: Optional[str] = None,
                          purpose: str = "output selection") -> tuple[torch.Tensor, Optional[str]]:
-    out = unwrap_main_output(outputs)
-    if isinstance(out, torch.Tensor):
-        if requested_head is not None:
-            raise ValueError(f"{purpose} requested head '{requested_head}', but the model output is a single tensor.")
-        return out, None
-    if not isinstance(out, Mapping):
-        raise TypeError(f"{purpose} expected a tensor or mapping, got {type(out).__name__}.")
-    if not out:
+    """-> (tensor, head name | None).  A plain tensor has no head to ask for; in a {head: tensor} mapping the head is the
+    request, else `primary_head` when present, else the only entry (messages: reference utils/model_outputs.py:244-300)."""
+    main = unwrap_main_output(outputs)
+    if torch.is_tensor(main):
+        if requested_head is None:
+            return main, None
+        raise ValueError(f"{purpose} requested head '{requested_head}', but the model output is a single tensor.")
+    if not isinstance(main, Mapping):
+        raise TypeError(f"{purpose} expected a tensor or mapping, got {type(main).__name__}.")
+    names = sorted(main)
+    if not names:
         raise ValueError(f"{purpose} received an empty output mapping.")
     head = requested_head
     if head is None:
-        if primary_head is not None and primary_head in out:
-            head = primary_head
-        elif len(out) == 1:
-            head = next(iter(out.keys()))
-        else:
-            raise ValueError(f"{purpose} requires an explicit head because available output heads are "
-                             f"{sorted(out.keys())}.")
-    if head not in out:
-        raise ValueError(f"{purpose} requested head '{head}', but available output heads are {sorted(out.keys())}.")
-    sel = out[head]
-    if not isinstance(sel, torch.Tensor):
-        raise TypeError(f"{purpose} requires head '{head}' to be a tensor, got {type(sel).__name__}.")
-    return sel, head
+        head = primary_head if primary_head in main and primary_head is not None else (names[0] if len(names) == 1 else None)
+        if head is None:
+            raise ValueError(f"{purpose} requires an explicit head because available output heads are {names}.")
+    elif head not in main:
+        raise ValueError(f"{purpose} requested head '{head}', but available output heads are {names}.")
+    if not torch.is_tensor(main[head]):
+        raise TypeError(f"{purpose} requires head '{head}' to be a tensor, got {type(main[head]).__name__}.")
+    return main[head], head
 
 
 __all__ = ["select_output_tensor", "resolve_output_head", "resolve_output_heads", "unwrap_main_output", "get_inference_select_channel",

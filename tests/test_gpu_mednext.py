@@ -258,3 +258,37 @@ def test_fused_up_block_is_bit_identical_to_unfused(size, shape, monkeypatch):
         assert torch.equal(got, ref)
         m._hip.fuse_up_cin = (64,)            # level 0 only
         assert torch.equal(m.forward_cl(x), ref)
+
+
+@pytest.mark.parametrize("counts,ds", [([2] * 9, False), ([1, 2, 1, 1, 1, 1, 1, 2, 1], True), ([1] * 9, False)])
+def test_level0_subbatch_is_bit_identical(dev, counts, ds):
+    """MedNeXt.l0_subbatch (PYTC_L0_SUBBATCH): the full-resolution level run depth-first over sample slices -- stem + encoder
+    blocks + down block, later up block + decoder blocks (+ head) per slice, results written straight into the batch tensors --
+    must not change a single bit of the output, for slices that divide the batch and for a ragged last slice, with the output
+    head in the last mixer's epilogue, without it, and with deep supervision."""
+    m, _ = _build(dev, n_channels=32, exp_r=2, kernel_size=3, block_counts=counts, ds=ds)
+    m.compute_dtype = torch.bfloat16
+    x = torch.randn(5, 1, 32, 32, 48, generator=torch.Generator().manual_seed(3)).to(dev)
+
+    def run():
+        with torch.no_grad():
+            out = m(x)
+            feats = m.forward_features(x)
+        outs = out if isinstance(out, list) else [out]
+        return [o.clone() for o in outs] + [feats.clone()]
+
+    m.l0_subbatch = 0
+    ref = run()
+    for sb in (1, 2, 4, 5, 8):
+        m.l0_subbatch = sb
+        got = run()
+        assert len(got) == len(ref)
+        for a, b in zip(ref, got):
+            assert a.shape == b.shape and a.dtype == b.dtype
+            assert torch.equal(a, b), f"l0_subbatch={sb}: max |d| {(a.float() - b.float()).abs().max().item():.3e}"
+    m.fuse_head = False                # output projection as its own launch: the chains end in the block's bf16 output
+    m.l0_subbatch = 0
+    ref = run()
+    m.l0_subbatch = 2
+    for a, b in zip(ref, run()):
+        assert torch.equal(a, b)
