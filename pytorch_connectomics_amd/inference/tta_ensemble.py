@@ -18,58 +18,63 @@ from .. import hip_ops as ops
 from .tta_affinity import ViewValidity
 
 _MODE = {"mean": 0, "min": 1, "max": 2}
+_IDENTITY = {"mean": 0.0, "min": float("inf"), "max": float("-inf")}       # the statistic before any view has contributed
+
+
+def _channel_plan(shape, mode_map, partial_channels):
+    """Validated (modes, partial channel tuple, full channel tuple) of an (N, C, *spatial) ensemble."""
+    modes = tuple(str(m) for m in mode_map)
+    channels = shape[1] if len(shape) >= 3 else -1
+    if channels != len(modes):
+        raise ValueError(f"Invalid TTA accumulator shape/modes: shape={shape}, modes={len(modes)}.")
+    strangers = sorted(set(modes).difference(_MODE))
+    if strangers:
+        raise ValueError(f"Unknown TTA ensemble modes: {strangers}.")
+    partial = tuple(sorted(set(map(int, partial_channels))))
+    if partial and not (0 <= partial[0] and partial[-1] < channels):
+        raise ValueError(f"Partial TTA channels {partial} are invalid for {channels} output channels.")
+    return modes, partial, tuple(c for c in range(channels) if c not in partial)
 
 
 class TTAEnsembleAccumulator:
     def __init__(self, shape: Sequence[int], *, dtype: torch.dtype, device, mode_map: Sequence[str],
                  partial_channels: Sequence[int], distributed_sharding: bool, max_views: int) -> None:
-        self.shape = tuple(int(v) for v in shape)
-        self.dtype = dtype
         self.device = torch.device(device)
         ops.require_device(self.device, "TTAEnsembleAccumulator")
-        self.mode_map = tuple(str(m) for m in mode_map)
-        if len(self.shape) < 3 or len(self.mode_map) != self.shape[1]:
-            raise ValueError(f"Invalid TTA accumulator shape/modes: shape={self.shape}, modes={len(self.mode_map)}.")
-        unknown = sorted(set(self.mode_map) - set(_MODE))
-        if unknown:
-            raise ValueError(f"Unknown TTA ensemble modes: {unknown}.")
-        self.partial_channels = tuple(sorted({int(c) for c in partial_channels}))
-        if any(c < 0 or c >= self.shape[1] for c in self.partial_channels):
-            raise ValueError(f"Partial TTA channels {self.partial_channels} are invalid for {self.shape[1]} output channels.")
-        self.full_channels = tuple(c for c in range(self.shape[1]) if c not in set(self.partial_channels))
-        self.distributed_sharding = bool(distributed_sharding)
-        self.max_views = int(max_views)
+        self.shape, self.dtype = tuple(map(int, shape)), dtype
+        self.mode_map, self.partial_channels, self.full_channels = _channel_plan(self.shape, mode_map, partial_channels)
+        self.distributed_sharding, self.max_views = bool(distributed_sharding), int(max_views)
         self.num_predictions = 0
-        self.legacy_result = torch.zeros(self.shape, device=self.device, dtype=torch.float32)
-        pshape = (self.shape[0], len(self.partial_channels)) + self.shape[2:]
-        self.partial_statistics = torch.empty(pshape, device=self.device, dtype=torch.float32)
-        for pi, c in enumerate(self.partial_channels):
-            mode = self.mode_map[c]
-            self.partial_statistics[:, pi].fill_(0.0 if mode == "mean" else float("inf") if mode == "min" else float("-inf"))
-        self.partial_counts = torch.zeros(pshape, device=self.device, dtype=torch.float32)
+        on_device = dict(device=self.device, dtype=torch.float32)
+        self.legacy_result = torch.zeros(self.shape, **on_device)
+        slabs = (self.shape[0], len(self.partial_channels), *self.shape[2:])
+        self.partial_counts = torch.zeros(slabs, **on_device)
+        self.partial_statistics = torch.empty(slabs, **on_device)
+        for slot, channel in enumerate(self.partial_channels):
+            self.partial_statistics[:, slot] = _IDENTITY[self.mode_map[channel]]
 
     @property
     def has_partial_channels(self) -> bool:
-        return bool(self.partial_channels)
+        return len(self.partial_channels) > 0
 
     def _cover(self, validity, like: torch.Tensor) -> Optional[torch.Tensor]:
         """None (valid everywhere) | tuple of slices (valid box) | bool tensor  ->  fp32 cover mask shaped like `like` or None."""
         if validity is None:
             return None
-        if isinstance(validity, tuple):
+        if isinstance(validity, tuple):                               # a box: ones inside, zeros outside, built on the device
             cover = torch.zeros_like(like)
-            cover[(slice(None),) + tuple(validity)] = 1.0
+            cover[(slice(None), *validity)] = 1.0
             return cover
         mask = validity.to(device=like.device)
-        if mask.dim() == like.dim() - 1:
-            mask = mask.unsqueeze(0)
+        if mask.dim() + 1 == like.dim():                              # no batch axis: one mask for every sample
+            mask = mask[None]
         if mask.dim() != like.dim():
             raise ValueError(f"TTA validity tensor rank {mask.dim()} does not match channel value rank {like.dim()}.")
-        if mask.shape[0] == 1 and like.shape[0] != 1:
+        if mask.shape[0] == 1 and like.shape[0] > 1:
             mask = mask.expand(like.shape[0], *mask.shape[1:])
-        if tuple(mask.shape) != tuple(like.shape):
+        if mask.shape != like.shape:
             raise ValueError(f"TTA validity shape {tuple(mask.shape)} does not match channel value shape {tuple(like.shape)}.")
-        return mask.to(torch.float32).contiguous()
+        return mask.float().contiguous()
 
     def add(self, prediction: torch.Tensor, validity: ViewValidity) -> None:
         """Stream one canonical prediction (N, C, *spatial) into the accumulator."""
