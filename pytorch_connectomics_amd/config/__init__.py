@@ -128,7 +128,12 @@ class ConfigNode(dict):
         return {k: (v.to_dict() if isinstance(v, ConfigNode) else copy.deepcopy(v)) for k, v in self.items()}
 
 
-Config = ConfigNode
+class Config(ConfigNode):
+    """`Config()` = the schema defaults of the sections the engine reads, like the reference's dataclass constructor
+    (`cfg = Config(); cfg.inference.sliding_window.window_size = [...]`); `Config(mapping)` wraps the mapping as it is."""
+
+    def __init__(self, data: Mapping | None = None):
+        super().__init__(schema_defaults() if data is None else data)
 
 
 def _deep_merge(dst: dict, src: Mapping) -> dict:

@@ -138,14 +138,17 @@ def validate_distributed_patch_shard(*, local_count: int, total_count: int, devi
                            "smaller inference.sliding_window.window_size.")
 
 
-def make_accumulator_reduce_hook(*, chunk_mb: int):
-    """hook(value, weight) -> (value, weight) on rank 0, None on every other rank (lazy_distributed.py:132-169)."""
+def make_accumulator_reduce_hook(*, chunk_mb: int, reduction_device=None):
+    """hook(value, weight) -> (value, weight) on rank 0, None on every other rank -- never (None, None)
+    (lazy_distributed.py:132-169, same keywords).  The accumulators go through `reduce_cpu_tensor_to_rank_zero`, looked up when
+    the hook runs: HBM-resident ones are reduced in place where they live (`reduction_device` does not matter then), host
+    tensors are staged through `reduction_device` like the reference's."""
     def _hook(value: torch.Tensor, weight: torch.Tensor):
-        rv = reduce_tensor_to_rank_zero(value, op=torch.distributed.ReduceOp.SUM, chunk_mb=chunk_mb, name="value accumulator")
-        rw = reduce_tensor_to_rank_zero(weight, op=torch.distributed.ReduceOp.SUM, chunk_mb=chunk_mb, name="weight accumulator")
-        if rv is None or rw is None:
-            return None
-        return rv, rw
+        pair = []
+        for tensor, what in ((value, "value accumulator"), (weight, "weight accumulator")):
+            pair.append(reduce_cpu_tensor_to_rank_zero(tensor, op=torch.distributed.ReduceOp.SUM, reduction_device=reduction_device,
+                                                       chunk_mb=chunk_mb, name=what))
+        return None if any(t is None for t in pair) else tuple(pair)
     return _hook
 
 
