@@ -74,3 +74,29 @@ def test_training_labels_merge_by_device_kernel_before_counters_are_attached():
     r = b.dominant(merged, 2, traffic_fn=lambda name: b._traffic_from_table(table, name if name in members else None))
     assert r["kernel"] == "pw_fast_kernel<1," and r["traffic"] == int((2 * 500000.0 + 100000.0) * 1024)
     assert r["algorithmic_bytes"] == int(14e9 / 14)
+
+
+def test_headline_watchdog_prints_the_line_and_leaves(tmp_path):
+    """bench.HeadlineWatchdog: a process whose secondary legs never return (here: a sleep standing in for a peer that died inside a
+    collective) still ends with ONE JSON line and exit code 0 once the budget is over; a disarmed watchdog does nothing."""
+    import json
+    import subprocess
+    import sys
+    import time
+    script = tmp_path / "hang.py"
+    script.write_text(
+        "import importlib.util, json, sys, time\n"
+        f"spec = importlib.util.spec_from_file_location('bench_module', {str(ROOT / 'bench.py')!r})\n"
+        "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+        "quiet = b.HeadlineWatchdog(0.2, lambda: json.dumps({'value': -1})).arm(); quiet.disarm()\n"
+        "off = b.HeadlineWatchdog(0.0, lambda: json.dumps({'value': -2})).arm()\n"
+        "time.sleep(0.6)\n"
+        "b.HeadlineWatchdog(0.5, lambda: json.dumps({'value': 42.0, 'errors': {'watchdog': {'0': 'late'}}})).arm()\n"
+        "time.sleep(60)\n"
+        "print('never')\n")
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=50)
+    assert time.perf_counter() - t0 < 40 and p.returncode == 0, p.stderr[-400:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"value": 42.0, "errors": {"watchdog": {"0": "late"}}}
+    assert "never" not in p.stdout
