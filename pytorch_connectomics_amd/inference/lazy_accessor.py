@@ -212,6 +212,10 @@ class LazyVolumeAccessor:
         for a in range(3):
             s_lo[self._stored_axis[a]], s_hi[self._stored_axis[a]] = raw_lo[a], raw_hi[a]
         box = self.source.read_box(s_lo, s_hi)
+        if str(box.dtype) not in nat.RAW_DTYPES:
+            # a storage dtype the gather kernel has no reader for (64-bit ids, float16, bool): the one case with a host conversion
+            # -- to float32, which is what the presented region holds anyway (and what the reference's reader converts to)
+            box = np.ascontiguousarray(box, dtype=np.float32)
         strides = box_strides(self.source, box, self._stored_axis)
         shift = lambda t, a: np.where(t >= 0, t - raw_lo[a], -1).astype(np.int32)      # noqa: E731  box-local indices
         i0 = torch.from_numpy(np.concatenate([shift(tabs[a][0], a) for a in range(3)]))

@@ -293,3 +293,16 @@ def test_zarr_v3_arrays(tmp_path):
         "codecs": [{"name": "bytes"}, {"name": "zstd", "configuration": {"level": 3}}]}))
     with pytest.raises(NotImplementedError, match="zstd"):
         open_zarr(str(tmp_path / "z.zarr"))
+
+
+@pytest.mark.parametrize("dtype", ["int64", "uint64", "float16", "bool"])
+def test_storage_dtypes_without_a_device_reader_are_staged_as_float32(dtype, tmp_path):
+    """64-bit label ids, half floats and boolean masks have no reader in the gather kernel: their raw box is converted to float32
+    on the host (the one host conversion; the presented region is float32 anyway) instead of failing on the device."""
+    rng = np.random.default_rng(9)
+    vol = (rng.random((6, 7, 8)) * 50).astype(dtype) if dtype != "bool" else rng.random((6, 7, 8)) > 0.5
+    np.save(tmp_path / "v.npy", vol)
+    with LazyVolumeAccessor(str(tmp_path / "v.npy"), kind="label", transpose_axes=(1, 0, 2)) as acc:
+        st = acc.stage_region((1, 0, 2), (6, 5, 8))
+        assert st.raw_dtype == "float32"
+        np.testing.assert_array_equal(AO.execute_staged(st)[0], vol.transpose(1, 0, 2).astype(np.float32)[1:6, 0:5, 2:8])
