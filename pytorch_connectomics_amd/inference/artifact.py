@@ -107,6 +107,12 @@ def artifact_attrs(metadata: PredictionArtifactMetadata) -> dict:
     return {k: _json_attr(v) for k, v in {**attrs, **dict(extra)}.items() if v is not None}
 
 
+def write_prediction_artifact_attrs(dataset: Any, metadata: PredictionArtifactMetadata) -> None:
+    """The metadata attributes on an open HDF5 dataset (h5py or the in-repo shim: anything with `.attrs[key] = value`)."""
+    for key, value in artifact_attrs(metadata).items():
+        dataset.attrs[key] = value
+
+
 def write_prediction_artifact(path, data: Optional[np.ndarray] = None, *, metadata: Optional[PredictionArtifactMetadata] = None,
                               dataset: str = "main", compression: Optional[str] = "gzip", shape=None, dtype=None,
                               chunks=None, writer: Optional[Callable[[Any], None]] = None) -> Path:
@@ -163,5 +169,5 @@ def read_prediction_artifact(path, *, dataset: str = "main", return_metadata: bo
     return (arr, attrs) if return_metadata else arr
 
 
-__all__ = ["PredictionArtifactMetadata", "build_prediction_artifact_metadata", "artifact_attrs",
+__all__ = ["PredictionArtifactMetadata", "build_prediction_artifact_metadata", "artifact_attrs", "write_prediction_artifact_attrs",
            "write_prediction_artifact", "read_prediction_artifact"]

@@ -31,7 +31,7 @@ from .. import _native as nat
 from .. import hip_ops as ops
 from ..utils.channel_slices import resolve_channel_indices
 from ..utils.model_outputs import get_inference_channel_activations, get_inference_select_channel, select_output_tensor
-from .lazy_accessor import LazyVolumeAccessor, build_accessor
+from .lazy_accessor import LazyVolumeAccessor, build_accessor, load_lazy_volume
 from .lazy_distributed import (distributed_context, is_distributed_window_sharding_enabled, make_accumulator_reduce_hook,
                                validate_distributed_patch_shard)
 from .window import (_axis_kernels, compute_scan_interval, resolve_border_mask,
@@ -342,6 +342,6 @@ def lazy_predict_volume(cfg, forward_fn, volume, *, device="cuda", requested_hea
     return out if odt == torch.float32 else out.to(odt)
 
 
-__all__ = ["lazy_predict_region", "lazy_predict_volume", "get_lazy_image_reference_shape", "open_lazy_source", "lazy_region_read_box",
+__all__ = ["lazy_predict_region", "lazy_predict_volume", "load_lazy_volume", "LazyVolumeAccessor", "get_lazy_image_reference_shape", "open_lazy_source", "lazy_region_read_box",
            "_build_window_axis_offsets", "_build_window_slices", "_build_intersecting_window_slices",
            "_snap_offsets", "_resolve_target_context"]

@@ -174,6 +174,18 @@ class AffinityTTAPlan:
     spatial_rank: int
 
 
+def validate_affinity_output(plan: Optional["AffinityTTAPlan"], prediction) -> None:
+    """A prediction (N, C, *spatial) must have the channel count and spatial rank the plan was derived for
+    (reference tta_affinity.py:332-347); no plan, nothing to check."""
+    if plan is None:
+        return
+    channels, rank = int(prediction.shape[1]), int(prediction.dim()) - 2
+    if channels != int(plan.num_channels):
+        raise ValueError(f"Affinity TTA plan expects {plan.num_channels} raw output channels, but the model produced {channels}.")
+    if plan.spatial_rank and int(plan.spatial_rank) != rank:
+        raise ValueError(f"Affinity offset rank {plan.spatial_rank} does not match raw output spatial rank {rank}.")
+
+
 def transform_offset(offset: Sequence[int], *, flip_axes: Sequence[int], rotation_plane_spatial, k: int) -> Offset:
     """Linear part of (inverse rotation, then inverse flips) applied to an offset vector."""
     v = [int(c) for c in offset]
@@ -217,12 +229,7 @@ def invert_view(prediction, *, flip_axes: Sequence[int], rotation_plane_spatial,
         out = torch.rot90(out, k=-int(k), dims=tuple(int(a) + 2 for a in rotation_plane_spatial))
     if flip_axes:
         out = torch.flip(out, dims=[int(a) + 2 for a in flip_axes])
-    if tta_plan is not None:
-        if int(out.shape[1]) != int(tta_plan.num_channels):
-            raise ValueError(f"Affinity TTA plan was built for {tta_plan.num_channels} raw output channels, "
-                             f"but the model produced {int(out.shape[1])}.")
-        if tta_plan.spatial_rank and tta_plan.spatial_rank != out.dim() - 2:
-            raise ValueError(f"Affinity offset rank {tta_plan.spatial_rank} does not match raw output spatial rank {out.dim() - 2}.")
+    validate_affinity_output(tta_plan, out)
     validity: list = [None] * int(out.shape[1])
     if view_plan is None or not view_plan.moves:
         return out, ViewValidity(tuple(validity))
@@ -353,7 +360,7 @@ def build_affinity_tta_plan(cfg: Any, *, augmentation_combinations, num_raw: int
                            num_channels=int(num_raw), spatial_rank=rank)
 
 
-__all__ = ["AffinityTTAPlan", "AffinityViewPlan", "ChannelMove", "ViewValidity", "invert_view", "build_affinity_tta_plan", "transform_offset",
+__all__ = ["AffinityTTAPlan", "AffinityViewPlan", "ChannelMove", "ViewValidity", "invert_view", "validate_affinity_output", "build_affinity_tta_plan", "transform_offset",
            "valid_slices_for_shift", "parse_affinity_offsets", "resolve_affinity_offsets_from_kwargs",
            "resolve_affinity_mode_from_cfg", "resolve_affinity_channel_groups_from_cfg",
            "resolve_stacked_label_channel_count"]

@@ -3,7 +3,10 @@ the contract of the reference's connectomics/utils/channel_slices.py (negative i
 rules; out-of-range / empty selections raise ValueError naming the selector)."""
 from __future__ import annotations
 
-from typing import Any, Sequence
+from typing import Any, Optional, Sequence, Union
+
+ChannelRangeSelector = Union[int, str]                    # one channel or one 'a:b' slice string
+ChannelSelector = Union[int, str, Sequence[int]]          # ... or an explicit channel list
 
 
 def _parse(text: str, context: str):
@@ -111,5 +114,34 @@ def resolve_channel_indices(selector, *, num_channels: int, context: str = "chan
     return list(range(a, b))
 
 
-__all__ = ["normalize_channel_selector", "resolve_channel_index", "resolve_channel_range",
-           "resolve_channel_indices"]
+def normalize_channel_range_selector(selector: Any, *, context: str = "channel selector") -> Optional[ChannelRangeSelector]:
+    """A CONTIGUOUS selector in canonical form: None (all channels), an int, or an 'a:b' string; channel lists are refused."""
+    if selector is None or isinstance(selector, (int, str)):
+        return normalize_channel_selector(selector, context=context)
+    raise TypeError(f"{context} must be an int or a Python-style slice string, got {type(selector).__name__}.")
+
+
+def infer_min_required_channels(selector: Any, *, context: str = "channel selector") -> Optional[int]:
+    """The smallest channel count for which `selector` is valid (None selects everything: no requirement).  An index i needs
+    i + 1 channels (-i needs i); a list needs what its most demanding entry needs; a slice is tried against growing channel
+    counts up to |bound| + 2, the first count it resolves against without an empty selection wins."""
+    norm = normalize_channel_selector(selector, context=context)
+    if norm is None:
+        return None
+    if isinstance(norm, list):
+        return max(infer_min_required_channels(entry, context=context) or 1 for entry in norm)
+    if isinstance(norm, int):
+        return norm + 1 if norm >= 0 else -norm
+    piece = _parse(norm, context)
+    reach = max([1] + [abs(bound) + 2 for bound in (piece.start, piece.stop) if bound is not None])
+    for count in range(1, reach + 1):
+        try:
+            resolve_channel_range(norm, num_channels=count, context=context)
+        except ValueError:
+            continue
+        return count
+    raise ValueError(f"Could not infer a valid channel count for {context} {norm!r}.")
+
+
+__all__ = ["ChannelRangeSelector", "ChannelSelector", "normalize_channel_selector", "normalize_channel_range_selector",
+           "resolve_channel_index", "resolve_channel_range", "resolve_channel_indices", "infer_min_required_channels"]

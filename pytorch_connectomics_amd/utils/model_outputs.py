@@ -26,6 +26,11 @@ def _cfg_value(obj: Any, key: str, default: Any = None) -> Any:
     return _dig(obj, key, default=default)
 
 
+def get_inference_model_config(cfg: Any) -> Any:
+    """The `inference.model` node (head / channel selection / activations at inference time), None when absent."""
+    return _dig(cfg, "inference", "model")
+
+
 def get_inference_model_value(cfg: Any, key: str, default: Any = None) -> Any:
     return _dig(cfg, "inference", "model", key, default=default)
 
@@ -102,6 +107,54 @@ def resolve_output_heads(cfg: Any, *, purpose: str = "output selection") -> list
     return [one] if one else []
 
 
+def resolve_configured_output_head(cfg: Any, *, purpose: str = "output selection", allow_none: bool = True) -> Optional[str]:
+    """`resolve_output_head` for what the CONFIG asks for (no explicit request)."""
+    return resolve_output_head(cfg, requested_head=None, purpose=purpose, allow_none=allow_none)
+
+
+def _head_width(heads: Mapping, name: str) -> int:
+    return int(_dig(heads[name], "out_channels", default=0))
+
+
+def get_total_model_head_channels(cfg: Any) -> int:
+    """Sum of the `out_channels` of every named head (0 without named heads)."""
+    heads = _named_heads(cfg)
+    return sum(_head_width(heads, name) for name in heads)
+
+
+def resolve_output_channels(cfg: Any, *, requested_head: Optional[str] = None, purpose: str = "output selection",
+                            allow_ambiguous: bool = True) -> Optional[int]:
+    """How many channels the selected output carries (reference utils/model_outputs.py:175-221): the width of the requested /
+    configured head, the SUM over a comma-separated head list (merged inference), `model.out_channels` for a model without named
+    heads; None when several heads exist, none is selected and `allow_ambiguous`."""
+    heads = _named_heads(cfg)
+    if not heads:
+        width = _dig(cfg, "model", "out_channels")
+        return None if width is None else int(width)
+    if isinstance(requested_head, str) and "," in requested_head:
+        wanted = [part.strip() for part in requested_head.split(",") if part.strip()]
+        unknown = [name for name in wanted if name not in heads]
+        if unknown:
+            raise ValueError(f"Requested output heads {unknown} for {purpose} not in model.heads ({sorted(heads.keys())}).")
+        return sum(_head_width(heads, name) for name in wanted)
+    if requested_head is None:
+        merged = resolve_output_heads(cfg, purpose=purpose)
+        if len(merged) > 1:
+            return sum(_head_width(heads, name) for name in merged)
+    chosen = resolve_output_head(cfg, requested_head=requested_head, purpose=purpose, allow_none=allow_ambiguous)
+    return None if chosen is None else _head_width(heads, chosen)
+
+
+def resolve_configured_output_channels(cfg: Any, *, purpose: str = "output selection", allow_ambiguous: bool = True) -> Optional[int]:
+    return resolve_output_channels(cfg, requested_head=None, purpose=purpose, allow_ambiguous=allow_ambiguous)
+
+
+def resolve_head_target_slice(cfg: Any, head_name: str):
+    """The label `target_slice` configured for a named head; None for an unknown head or a head without one."""
+    heads = _named_heads(cfg)
+    return _dig(heads[head_name], "target_slice") if head_name in heads else None
+
+
 def unwrap_main_output(outputs: Any) -> Any:
     return outputs["output"] if isinstance(outputs, Mapping) and "output" in outputs else outputs
 
@@ -133,4 +186,6 @@ def select_output_tensor(outputs: Any, *, requested_head: Optional[str] = None, 
 
 
 __all__ = ["select_output_tensor", "resolve_output_head", "resolve_output_heads", "unwrap_main_output", "get_inference_select_channel",
-           "get_inference_channel_activations", "get_inference_model_value", "get_model_head_names"]
+           "get_inference_channel_activations", "get_inference_model_value", "get_inference_model_config", "get_model_head_names",
+           "get_total_model_head_channels", "resolve_configured_output_head", "resolve_output_channels",
+           "resolve_configured_output_channels", "resolve_head_target_slice"]

@@ -465,6 +465,67 @@ def public_adapters():
     print("public adapters:", len(combos), "views,", len(cases), "head cases")
 
 
+def public_helpers():
+    """Round 3, second pass over the public names of the in-scope modules: the reference's `resolve_output_channels` family,
+    `get_total_model_head_channels`, `resolve_head_target_slice`, `normalize_channel_range_selector`,
+    `infer_min_required_channels` and `validate_affinity_output` on small inputs -> tests/golden/public_helpers.json."""
+    import json
+    from types import SimpleNamespace as NS
+    mo = S.ref("connectomics.utils.model_outputs")
+    cs = S.ref("connectomics.utils.channel_slices")
+    ta = S.ref("connectomics.inference.tta_affinity")
+
+    def attempt(call):
+        try:
+            return {"value": call()}
+        except Exception as e:      # noqa: BLE001
+            return {"error": type(e).__name__, "message": str(e)}
+
+    heads = {"aff": {"out_channels": 3, "target_slice": "0:3"}, "sdt": {"out_channels": 1}, "lsd": {"out_channels": 10, "target_slice": [4, 5]}}
+    channel_cases = []
+    for model_kw, inf_head, req, allow in [
+            (dict(heads=None, primary_head=None, out_channels=7), None, None, True),
+            (dict(heads=None, primary_head=None, out_channels=None), None, None, True),
+            (dict(heads=heads, primary_head=None, out_channels=2), None, None, True),
+            (dict(heads=heads, primary_head=None, out_channels=2), None, None, False),
+            (dict(heads=heads, primary_head="lsd", out_channels=2), None, None, True),
+            (dict(heads=heads, primary_head=None, out_channels=2), "aff,sdt", None, True),
+            (dict(heads=heads, primary_head=None, out_channels=2), "aff", None, True),
+            (dict(heads=heads, primary_head=None, out_channels=2), None, "sdt, lsd", True),
+            (dict(heads=heads, primary_head=None, out_channels=2), None, "sdt,zzz", True),
+            (dict(heads=heads, primary_head=None, out_channels=2), None, "lsd", True),
+            (dict(heads=heads, primary_head=None, out_channels=2), None, "nope", True),
+            (dict(heads={"only": {"out_channels": 4}}, primary_head=None, out_channels=1), None, None, False)]:
+        c = NS(model=NS(**model_kw), inference=NS(model=NS(head=inf_head)))
+        channel_cases.append({
+            "model": dict(model_kw), "inference_head": inf_head, "requested": req, "allow": allow,
+            "channels": attempt(lambda: mo.resolve_output_channels(c, requested_head=req, purpose="t", allow_ambiguous=allow)),
+            "configured_channels": attempt(lambda: mo.resolve_configured_output_channels(c, purpose="t", allow_ambiguous=allow)),
+            "configured_head": attempt(lambda: mo.resolve_configured_output_head(c, purpose="t", allow_none=allow)),
+            "total": attempt(lambda: mo.get_total_model_head_channels(c)),
+            "slices": {h: attempt(lambda h=h: mo.resolve_head_target_slice(c, h)) for h in ("aff", "sdt", "lsd", "ghost")},
+            "has_inference_model": mo.get_inference_model_config(c) is not None})
+    empty = NS(model=NS(heads=None))
+    channel_cases.append({"model": {"heads": None}, "no_inference": True, "has_inference_model": mo.get_inference_model_config(empty) is not None,
+                          "total": attempt(lambda: mo.get_total_model_head_channels(empty))})
+    selectors = [None, 0, 3, -1, -4, True, "2", " -2 ", ":", "1:", ":3", "1:3", "-3:-1", ":-2", "5:2", "0:0", "1:2:3", "a:b", "", "x", [0, 2], [3, -5, "1"], [], [0.5], 1.5, (1, 4)]
+    sel_cases = []
+    for sel in selectors:
+        shown = list(sel) if isinstance(sel, tuple) else sel
+        sel_cases.append({"selector": shown, "tuple": isinstance(sel, tuple),
+                          "range_form": attempt(lambda: cs.normalize_channel_range_selector(sel, context="sel")),
+                          "min_channels": attempt(lambda: cs.infer_min_required_channels(sel, context="sel"))})
+    plan = NS(num_channels=6, spatial_rank=3)
+    aff = []
+    for shape in [(1, 6, 4, 5, 5), (2, 5, 4, 5, 5), (1, 6, 5, 5), (1, 6, 2, 4, 5, 5)]:
+        aff.append({"shape": list(shape), "result": attempt(lambda: ta.validate_affinity_output(plan, torch.zeros(shape)))})
+    aff.append({"shape": [1, 3, 4, 4], "plan": None, "result": attempt(lambda: ta.validate_affinity_output(None, torch.zeros(1, 3, 4, 4)))})
+    aff.append({"shape": [1, 6, 4, 4], "rank0": True, "result": attempt(lambda: ta.validate_affinity_output(NS(num_channels=6, spatial_rank=0), torch.zeros(1, 6, 4, 4)))})
+    (HERE / "public_helpers.json").write_text(json.dumps({"channels": channel_cases, "selectors": sel_cases, "affinity": aff}, indent=0))
+    print("public helpers:", len(channel_cases), "channel cases,", len(sel_cases), "selectors,", len(aff), "affinity checks")
+
+
+
 def comb_apply(x, flip_axes, plane, k):
     if flip_axes:
         x = torch.flip(x, dims=[a + 2 for a in flip_axes])
@@ -987,7 +1048,7 @@ def losses_extra():
 
 if __name__ == "__main__":
     parts = {"manifests": manifests, "optimizers": optimizers, "schedules": schedules, "selectors": selectors, "outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
-             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "accessor": accessor, "accessor_tiles": accessor_tiles, "ds_loss": ds_loss, "losses_extra": losses_extra, "public_adapters": public_adapters}
+             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "accessor": accessor, "accessor_tiles": accessor_tiles, "ds_loss": ds_loss, "losses_extra": losses_extra, "public_adapters": public_adapters, "public_helpers": public_helpers}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:
         parts[name]()

@@ -232,7 +232,7 @@ def test_invert_view_matches_the_reference(golden_dir):
         assert torch.equal(inv, torch.from_numpy(z[f"inv{i}"])), i
         want = [None if row[0] < 0 else tuple(slice(int(a), int(b)) for a, b in zip(row[:3], row[3:])) for row in z[f"valid{i}"]]
         assert list(val.channels) == want, i
-    with pytest.raises(ValueError, match="was built for 6 raw output channels"):
+    with pytest.raises(ValueError, match="expects 6 raw output channels"):
         invert_view(torch.zeros(1, 5, 5, 8, 8), flip_axes=[], rotation_plane_spatial=None, k=0, view_plan=None, tta_plan=plan)
 
 
@@ -252,3 +252,50 @@ def test_resolve_output_heads_match_the_reference(golden_dir):
                 assert str(e.value) == want["message"], (c, key)
             else:
                 assert call() == want["value"], (c, key)
+
+
+def test_public_helpers_match_the_reference(golden_dir):
+    """The remaining public names of the in-scope host modules (utils/model_outputs.py, utils/channel_slices.py,
+    inference/tta_affinity.py:validate_affinity_output), value by value and error by error against the reference's own functions
+    (tests/golden/public_helpers.json, make_golden.py --public_helpers)."""
+    import json
+    from types import SimpleNamespace as NS
+
+    import torch
+
+    from pytorch_connectomics_amd.inference.tta_affinity import validate_affinity_output
+    from pytorch_connectomics_amd.utils import channel_slices as cs
+    from pytorch_connectomics_amd.utils import model_outputs as mo
+    ref = json.loads((golden_dir / "public_helpers.json").read_text())
+
+    def same(call, want, what):
+        if "error" in want:
+            with pytest.raises(Exception) as info:
+                call()
+            assert type(info.value).__name__ == want["error"] and str(info.value) == want["message"], (what, str(info.value))
+        else:
+            got = call()
+            assert got == want["value"] and type(got) is type(want["value"]), (what, got, want["value"])
+
+    for case in ref["channels"]:
+        if case.get("no_inference"):
+            cfg = NS(model=NS(heads=None))
+            assert (mo.get_inference_model_config(cfg) is not None) == case["has_inference_model"]
+            same(lambda: mo.get_total_model_head_channels(cfg), case["total"], "total without inference")
+            continue
+        cfg = NS(model=NS(**case["model"]), inference=NS(model=NS(head=case["inference_head"])))
+        req, allow = case["requested"], case["allow"]
+        same(lambda: mo.resolve_output_channels(cfg, requested_head=req, purpose="t", allow_ambiguous=allow), case["channels"], case)
+        same(lambda: mo.resolve_configured_output_channels(cfg, purpose="t", allow_ambiguous=allow), case["configured_channels"], case)
+        same(lambda: mo.resolve_configured_output_head(cfg, purpose="t", allow_none=allow), case["configured_head"], case)
+        same(lambda: mo.get_total_model_head_channels(cfg), case["total"], case)
+        for head, want in case["slices"].items():
+            same(lambda: mo.resolve_head_target_slice(cfg, head), want, (case, head))
+        assert (mo.get_inference_model_config(cfg) is not None) == case["has_inference_model"]
+    for case in ref["selectors"]:
+        sel = tuple(case["selector"]) if case["tuple"] else case["selector"]
+        same(lambda: cs.normalize_channel_range_selector(sel, context="sel"), case["range_form"], ("range", sel))
+        same(lambda: cs.infer_min_required_channels(sel, context="sel"), case["min_channels"], ("min", sel))
+    for case in ref["affinity"]:
+        plan = None if "plan" in case else NS(num_channels=6, spatial_rank=0 if case.get("rank0") else 3)
+        same(lambda: validate_affinity_output(plan, torch.zeros(case["shape"])), case["result"], case)
