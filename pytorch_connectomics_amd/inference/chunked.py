@@ -287,14 +287,25 @@ class _ChunkWriter:
             raise self.err
 
 
-def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, device="cuda",
+def run_chunked_prediction_inference(cfg, forward_fn, volume=None, *, output_path, device="cuda",
                                      requested_head: Optional[str] = None,
                                      predict_region_fn: Optional[Callable] = None, stitch: bool = True,
                                      overwrite: bool = False, image_path: Optional[str] = None,
-                                     checkpoint_path: Optional[str] = None, return_array: bool = True):
+                                     checkpoint_path: Optional[str] = None, return_array: bool = True,
+                                     mask_path=None, mask_align_to_image: bool = False, qc_streaming_callback=None):
     """Predict `volume` chunk by chunk.  Returns the stitched (C,Z,Y,X) numpy array on rank 0 (None elsewhere, when
     stitch=False / external sharding is active, or with return_array=False).  `predict_region_fn(start, stop) ->
-    (1,C,*region)` replaces the device predictor in host-logic tests."""
+    (1,C,*region)` replaces the device predictor in host-logic tests.
+
+    Reference keywords (chunked.py:725-737): the test volume may be named `image_path=` (then it is also the path recorded in the
+    artifact metadata); `mask_path` / `mask_align_to_image` reach every chunk's `lazy_predict_region`;
+    `qc_streaming_callback.update(array, z_offset=0, z_axis=1)` receives the stitched (C,Z,Y,X) prediction on rank 0."""
+    if volume is None:
+        if image_path is None:
+            raise TypeError("run_chunked_prediction_inference needs the test volume (third argument, or `image_path=`)")
+        volume = image_path
+    if image_path is not None and not (isinstance(image_path, (str, bytes)) or hasattr(image_path, "__fspath__")):
+        image_path = None          # an array / accessor handed over under the reference's keyword: no path to record
     ch_cfg = getattr(getattr(cfg, "inference", None), "chunking", None)
     # optional: stream chunks straight into a neuroglancer precomputed layer instead of per-chunk HDF5 + stitching
     # (reference chunked.py:485-507); the layer directory is the output path without its suffix
@@ -377,7 +388,8 @@ def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, de
         def predict_region_fn(start, stop):
             pre = prefetch.get() if prefetch is not None else None
             return lazy_predict_region(cfg, forward_fn, volume, region_start=start, region_stop=stop, device=device,
-                                       requested_head=requested_head, preloaded=pre)
+                                       requested_head=requested_head, preloaded=pre, mask_path=mask_path,
+                                       mask_align_to_image=mask_align_to_image)
     tc = getattr(getattr(cfg, "inference", None), "prediction_transform", None)
     tc_on = tc is not None and bool(getattr(tc, "enabled", False))
     img_name = image_path if image_path is not None else getattr(volume, "filename", None) or "<array>"
@@ -459,7 +471,11 @@ def run_chunked_prediction_inference(cfg, forward_fn, volume, *, output_path, de
         intensity_scale=float(getattr(tc, "intensity_scale", -1.0)) if tc_on else None,
         intensity_dtype=str(getattr(tc, "intensity_dtype", None)) if tc_on else None,
         extra={"compression": "gzip", "chunk_stitch_source": str(cdir)})
-    return stitch_chunk_prediction_files(output_path, chunks, vol_shape, cfg=cfg, metadata=md, return_array=return_array)
+    stitched = stitch_chunk_prediction_files(output_path, chunks, vol_shape, cfg=cfg, metadata=md,
+                                             return_array=return_array or qc_streaming_callback is not None)
+    if qc_streaming_callback is not None and stitched is not None:
+        qc_streaming_callback.update(stitched, z_offset=0, z_axis=1)
+    return stitched if return_array else None
 
 
 __all__ = ["run_chunked_prediction_inference", "stitch_chunk_prediction_files", "is_chunked_inference_enabled",

@@ -95,13 +95,26 @@ def _resolve_target_context(sliding_cfg, roi_size) -> tuple[int, int, int]:
     return ctx
 
 
-def get_lazy_image_reference_shape(volume, cfg=None) -> tuple[int, int, int]:
-    """ZYX extent of the (transformed, context-padded) test volume: arrays / tensors / accessors by shape, paths through an
-    accessor built from `cfg` (reference lazy.py:962-983)."""
-    if isinstance(volume, (str, bytes)) or hasattr(volume, "__fspath__"):
-        with open_lazy_source(cfg, volume) as acc:
-            return tuple(int(v) for v in acc.padded_spatial_shape)
-    return tuple(int(v) for v in volume.shape[-3:])
+def get_lazy_image_reference_shape(cfg, image_path=None, *, mode: str = "test") -> tuple:
+    """The reference's `get_lazy_image_reference_shape(cfg, image_path)` (lazy.py:962-978): (1, C, *padded spatial shape) of the
+    test volume under the config's test-time transforms, refusing a transformed volume smaller than `data.dataloader.patch_size`.
+    This package's earlier form -- `(volume, cfg=None)` with an array / accessor / path first -> the ZYX extent -- is recognised by
+    its argument types and kept."""
+    def is_source(v):
+        return isinstance(v, (str, bytes, LazyVolumeAccessor)) or hasattr(v, "__fspath__") or hasattr(v, "shape")
+    if is_source(cfg) and not is_source(image_path):
+        volume, cfg = cfg, image_path
+        if isinstance(volume, (str, bytes)) or hasattr(volume, "__fspath__"):
+            with open_lazy_source(cfg, volume) as acc:
+                return tuple(int(v) for v in acc.padded_spatial_shape)
+        return tuple(int(v) for v in (volume.padded_spatial_shape if isinstance(volume, LazyVolumeAccessor) else volume.shape[-3:]))
+    with build_accessor(_DefaultDataCfg(cfg), str(image_path), kind="image", mode=mode) as acc:
+        patch = getattr(getattr(getattr(cfg, "data", None), "dataloader", None), "patch_size", None)
+        if patch and any(acc.transformed_spatial_shape[a] < int(patch[a]) for a in range(3)):
+            raise ValueError("Lazy sliding-window inference currently requires the transformed test volume to be at least as large "
+                             f"as data.dataloader.patch_size in every axis. Got transformed_shape={acc.transformed_spatial_shape}, "
+                             f"patch_size={tuple(int(v) for v in patch)}.")
+        return (1, int(acc.channel_count), *(int(v) for v in acc.padded_spatial_shape))
 
 
 class _DefaultDataCfg:
@@ -175,9 +188,31 @@ def _window_preprocess(cfg, pred_cl: torch.Tensor) -> torch.Tensor:
 
 
 @torch.no_grad()
+def _lazy_tta_views(cfg) -> int:
+    """How many test-time-augmentation views the configuration asks for per window (1 = none)."""
+    tta = getattr(getattr(cfg, "inference", None), "test_time_augmentation", None)
+    if tta is None or not getattr(tta, "enabled", True):
+        return 1
+    from .tta_combinations import resolve_tta_augmentation_combinations
+    return len(resolve_tta_augmentation_combinations(tta, spatial_dims=3))
+
+
+def _open_mask(cfg, mask):
+    """mask volume of a lazy run: a path (-> accessor under the config's mask transforms), an accessor, or an array-like
+    (Z,Y,X) / (C,Z,Y,X) volume.  -> (accessor | None, array | None, owned accessor | None)"""
+    if mask is None:
+        return None, None, None
+    if isinstance(mask, LazyVolumeAccessor):
+        return mask, None, None
+    if isinstance(mask, (str, bytes)) or hasattr(mask, "__fspath__"):
+        acc = build_accessor(_DefaultDataCfg(cfg), str(mask if not isinstance(mask, bytes) else mask.decode()), kind="mask", mode="test")
+        return acc, None, acc
+    return None, _as_channel_first(mask), None
+
+
 def _lazy_sliding_window(cfg, forward_fn, volume, *, region_start, region_stop, device, requested_head=None,
                          window_filter: Optional[Callable[[int, int], bool]] = None,
-                         return_accumulators: bool = False, preloaded=None):
+                         return_accumulators: bool = False, preloaded=None, mask=None, mask_align_to_image: bool = False):
     roi = resolve_inferer_roi_size(cfg)
     if roi is None:
         raise ValueError("Lazy sliding-window inference requires inference.sliding_window.window_size "
@@ -240,6 +275,26 @@ def _lazy_sliding_window(cfg, forward_fn, volume, *, region_start, region_stop, 
     else:
         sub = sub.to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
 
+    # per-window test-time augmentation and / or a mask volume: every window batch goes through the predictor the way the
+    # reference's loop does (lazy.py:1193-1198); without either, the channels-last fast path below
+    mask_acc, mask_vol, mask_owned = _open_mask(cfg, mask)
+    predictor = None
+    if _lazy_tta_views(cfg) > 1 or mask_acc is not None or mask_vol is not None:
+        from .tta import TTAPredictor
+        predictor = TTAPredictor(cfg=cfg, sliding_inferer=None, forward_fn=forward_fn)
+    mask_sub = None
+    if mask_acc is not None:
+        if tuple(mask_acc.padded_spatial_shape) != bounds:
+            raise ValueError(f"mask volume shape {tuple(mask_acc.padded_spatial_shape)} does not match the image volume {bounds}")
+        mask_sub = mask_acc.stage_region(lo, hi).to_device(dev)
+    elif mask_vol is not None:
+        if tuple(int(v) for v in mask_vol.shape[1:]) != bounds:
+            raise ValueError(f"mask volume shape {tuple(mask_vol.shape[1:])} does not match the image volume {bounds}")
+        mask_sub = mask_vol[:, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+        if isinstance(mask_sub, np.ndarray):
+            mask_sub = torch.from_numpy(np.ascontiguousarray(mask_sub, dtype=np.float32))
+        mask_sub = mask_sub.to(device=dev, dtype=torch.float32).contiguous()
+
     ks, combine = _axis_kernels(roi, blend, torch.float32)
     wz, wy, wx = (k.to(dev).contiguous() for k in ks)
     value = None
@@ -256,7 +311,17 @@ def _lazy_sliding_window(cfg, forward_fn, volume, *, region_start, region_stop, 
             # the reader's per-window tail (reference read_patch: binarise, percentile clip, normalisation of THAT window,
             # outer padding included) on the gathered batch
             x = accessor.finish_windows(x)
-        if fwd_cl is not None:
+        if predictor is not None:
+            m = None
+            if mask_sub is not None:                         # the mask window of the same box, zero outside the volume
+                m = ops.gather_windows(mask_sub, rel, read, pad_mode="constant", cval=0.0)
+                if mask_acc is not None:
+                    m = mask_acc.finish_windows(m)
+                m = m.permute(0, 4, 1, 2, 3).contiguous()
+            out = predictor.predict_windows(x.permute(0, 4, 1, 2, 3).contiguous(), mask=m, mask_align_to_image=mask_align_to_image,
+                                            requested_head=requested_head)
+            pred = out.permute(0, 2, 3, 4, 1).contiguous()
+        elif fwd_cl is not None:
             pred = fwd_cl(x)
         else:
             xin = x.permute(0, 4, 1, 2, 3)
@@ -273,13 +338,17 @@ def _lazy_sliding_window(cfg, forward_fn, volume, *, region_start, region_stop, 
                                f"sliding-window ROI. Got prediction.shape={tuple(pred.shape)} and roi_size={tuple(roi)}.")
         if any(ctx):
             pred = pred[:, ctx[0]:ctx[0] + roi[0], ctx[1]:ctx[1] + roi[1], ctx[2]:ctx[2] + roi[2]].contiguous()
-        pred = _window_preprocess(cfg, pred.contiguous())
+        # activations / channel selection: the predictor applied them per view (before the ensemble, as the reference does)
+        pred = (pred.float() if pred.dtype != torch.float32 else pred).contiguous() if predictor is not None else \
+            _window_preprocess(cfg, pred.contiguous())
         if value is None:
             value = torch.zeros((int(pred.shape[-1]),) + out_size, dtype=torch.float32, device=dev)
         rel_starts = [tuple(w[a] - start[a] for a in range(3)) for w in chunk]
         ops.blend_accumulate(pred, rel_starts, value, weight, wz, wy, wx, combine=combine, floor_w=1e-5, border=border)
     if owned is not None:
         owned.close()
+    if mask_owned is not None:
+        mask_owned.close()
     if return_accumulators:
         return value, weight
     ops.blend_finalize(value, weight, clamp=1e-4, act=nat.ACT_NONE)
@@ -304,24 +373,39 @@ def lazy_region_read_box(cfg, bounds, region_start, region_stop):
     return lo, hi
 
 
-def lazy_predict_region(cfg, forward_fn, volume, *, region_start: Sequence[int], region_stop: Sequence[int],
-                        device="cuda", requested_head: Optional[str] = None, preloaded=None) -> torch.Tensor:
-    """Predict one bounded ZYX region of `volume`; windows come from the full-volume grid, so region borders
-    see real neighbouring data wherever they are not true volume borders.  Returns (1, C, *region) on device."""
-    return _lazy_sliding_window(cfg, forward_fn, volume, region_start=region_start, region_stop=region_stop,
-                                device=device, requested_head=requested_head, preloaded=preloaded)
+def _source_argument(image_path, volume):
+    """The reference names the third argument `image_path`; this engine also takes an accessor or an array there.  `volume=`
+    (this package's earlier keyword) keeps working."""
+    if (image_path is None) == (volume is None):
+        raise TypeError("pass the test volume once: as `image_path` (path, accessor or array), or as `volume`")
+    return image_path if image_path is not None else volume
 
 
-def lazy_predict_volume(cfg, forward_fn, volume, *, device="cuda", requested_head: Optional[str] = None) -> torch.Tensor:
+def lazy_predict_region(cfg, forward_fn, image_path=None, *, region_start: Sequence[int], region_stop: Sequence[int],
+                        mask_path=None, mask_align_to_image: bool = False, device="cuda", requested_head: Optional[str] = None,
+                        preloaded=None, volume=None) -> torch.Tensor:
+    """Predict one bounded ZYX region (transformed / padded coordinates) of the test volume; windows come from the full-volume
+    grid, so region borders see real neighbouring data wherever they are not true volume borders.  `mask_path`: a mask volume
+    of the same (transformed) shape whose windows multiply the per-window prediction after test-time augmentation, as in the
+    reference (lazy.py:1261-1292).  Returns (1, C, *region) on the device."""
+    return _lazy_sliding_window(cfg, forward_fn, _source_argument(image_path, volume), region_start=region_start,
+                                region_stop=region_stop, device=device, requested_head=requested_head, preloaded=preloaded,
+                                mask=mask_path, mask_align_to_image=mask_align_to_image)
+
+
+def lazy_predict_volume(cfg, forward_fn, image_path=None, *, mask_path=None, mask_align_to_image: bool = False, device="cuda",
+                        requested_head: Optional[str] = None, volume=None) -> torch.Tensor:
     """Whole-volume variant.  With inference.sliding_window.distributed_sharding, a lazy data path and an initialised
     process group (lazy_distributed.is_distributed_window_sharding_enabled), the windows are sharded [rank::world]
     (reference lazy.py:1104-1110), every rank's shard is validated non-empty, and the HBM-resident value / weight
     accumulators are summed onto rank 0 in place, `distributed_reduce_chunk_mb` per collective
     (lazy_distributed.py:78-169); rank 0 normalises, the other ranks get an empty tensor.  TTA-view sharding cannot be
     combined with it (lazy.py:1039-1043)."""
+    volume = _source_argument(image_path, volume)
+    masked = dict(mask=mask_path, mask_align_to_image=mask_align_to_image)
     if not is_distributed_window_sharding_enabled(cfg):
         return _lazy_sliding_window(cfg, forward_fn, volume, region_start=None, region_stop=None, device=device,
-                                    requested_head=requested_head)
+                                    requested_head=requested_head, **masked)
     tta = getattr(getattr(cfg, "inference", None), "test_time_augmentation", None)
     if tta is not None and getattr(tta, "enabled", False) and getattr(tta, "distributed_sharding", False):
         raise RuntimeError("Lazy sliding-window inference does not support "
@@ -330,7 +414,7 @@ def lazy_predict_volume(cfg, forward_fn, volume, *, device="cuda", requested_hea
     _is_dist, rank, world = distributed_context()
     value, weight = _lazy_sliding_window(cfg, forward_fn, volume, region_start=None, region_stop=None, device=device,
                                          requested_head=requested_head, return_accumulators=True,
-                                         window_filter=lambda i, n: i % world == rank)
+                                         window_filter=lambda i, n: i % world == rank, **masked)
     hook = make_accumulator_reduce_hook(chunk_mb=int(getattr(sw, "distributed_reduce_chunk_mb", 128) or 128))
     reduced = hook(value, weight)
     if reduced is None:

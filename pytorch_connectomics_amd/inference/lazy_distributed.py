@@ -54,8 +54,10 @@ def shard_indices(count: int, rank: int, world: int) -> list[int]:
     return list(range(int(count)))[int(rank)::int(world)]
 
 
-def validate_distributed_tensor_shape(tensor: torch.Tensor, *, name: str) -> None:
-    """Every rank must reduce the same shape: all_gather of a (1 + 8) int64 shape vector (lazy_distributed.py:42-75)."""
+def validate_distributed_tensor_shape(tensor: torch.Tensor, *, name: str, reduction_device=None) -> None:
+    """Every rank must reduce the same shape: all_gather of a (1 + 8) int64 shape vector (lazy_distributed.py:42-75).  The shape
+    vector travels on the tensor's own device; `reduction_device` (the reference's keyword) names where a HOST tensor's vector
+    goes instead."""
     is_dist, _rank, world = distributed_context()
     if not is_dist:
         return
@@ -65,7 +67,7 @@ def validate_distributed_tensor_shape(tensor: torch.Tensor, *, name: str) -> Non
     info[0] = tensor.ndim
     for i, d in enumerate(tensor.shape):
         info[i + 1] = int(d)
-    info = info.to(tensor.device)
+    info = info.to(tensor.device if (tensor.is_cuda or reduction_device is None) else torch.device(reduction_device))
     gathered = [torch.empty_like(info) for _ in range(world)]
     torch.distributed.all_gather(gathered, info)
     host = torch.stack(gathered).cpu().tolist()           # one device -> host copy for all ranks' vectors
@@ -122,13 +124,13 @@ def reduce_cpu_tensor_to_rank_zero(tensor: torch.Tensor, *, op, reduction_device
     return out.view_as(tensor) if rank == 0 else None
 
 
-def validate_distributed_patch_shard(*, local_count: int, total_count: int, device) -> None:
+def validate_distributed_patch_shard(*, local_count: int, total_count: int, device=None, reduction_device=None) -> None:
     """all_gather of the per-rank window counts; ANY empty shard fails on EVERY rank with the same message
     (lazy_distributed.py:110-129), so no rank is left waiting in the reduction."""
     is_dist, _rank, world = distributed_context()
     if not is_dist:
         return
-    count = torch.tensor([int(local_count)], dtype=torch.int64, device=device)
+    count = torch.tensor([int(local_count)], dtype=torch.int64, device=device if device is not None else reduction_device)
     gathered = [torch.empty_like(count) for _ in range(world)]
     torch.distributed.all_gather(gathered, count)
     counts = [int(v) for v in torch.cat(gathered).cpu().tolist()]

@@ -111,14 +111,14 @@ class TTAPredictor:
         return self._network_tensor
 
     # ------------------------------------------------------------------ activation / selection (device)
-    def apply_preprocessing(self, volume: torch.Tensor) -> torch.Tensor:
-        """volume (1, C, Z, Y, X) fp32 on the device: per-channel activations in place, then channel
-        selection and the output dtype cast (reference tta.py:312-402)."""
+    def apply_preprocessing(self, tensor: torch.Tensor) -> torch.Tensor:
+        """volume (N, C, Z, Y, X) fp32 on the device (N = 1 for a whole volume, a window batch in the lazy path): per-channel
+        activations in place, then channel selection and the output dtype cast (reference tta.py:312-402)."""
+        volume = tensor
         if not hasattr(self.cfg, "inference"):
             return volume
         C = int(volume.shape[1])
         types: list[Optional[str]] = [None] * C
-        v = volume[0]
         for idx, act in self._activation_specs(C):
             for c in idx:
                 types[c] = act
@@ -149,8 +149,9 @@ class TTAPredictor:
             else:
                 raise ValueError(f"Unknown activation '{act}' for channels {idx}. Supported: 'sigmoid', "
                                  "'scale_sigmoid' (or 'scale_sigmoid:<float>'), 'softmax', 'tanh', None")
-            for a, b in groups:
-                ops.channel_activation(v, a, b, code, scale)
+            for sample in volume:                       # (C, Z, Y, X) slabs of the batch
+                for a, b in groups:
+                    ops.channel_activation(sample, a, b, code, scale)
         self.channel_activation_types = types if any(t is not None for t in types) else None
         sel = self._select_channel_indices(C)
         if sel is not None:
@@ -254,6 +255,53 @@ class TTAPredictor:
             mask = mask.unsqueeze(2)                        # (B, C, H, W) -> the depth-1 volume the result is masked as
         out = self._predict_volume(images, mask, mask_align_to_image, requested_head, flat2d)
         return out.squeeze(2) if (flat2d and out.dim() == 5) else out      # (B, C, H, W) like the reference's 2-D mode
+
+    def predict_windows(self, windows: torch.Tensor, mask=None, mask_align_to_image: bool = False,
+                        requested_head: Optional[str] = None) -> torch.Tensor:
+        """A BATCH of windows (B, C, *roi) through the network without a sliding engine -- what the reference's lazy loop asks
+        its predictor for (lazy.py:1193-1198 -> tta.py:806-878 with `use_sliding=False`): every configured view of the batch is
+        predicted, mapped back (`invert_view`: inverse quarter turns / flips, affinity channels re-anchored), activated and
+        channel-selected, and streamed into a `TTAEnsembleAccumulator` (mean / min / max per channel, validity-aware); the
+        ensemble is masked last.  -> (B, C_sel, *roi) in the configured output dtype, on the device."""
+        from .tta_affinity import ViewValidity, build_affinity_tta_plan, invert_view, resolve_affinity_channel_groups_from_cfg, \
+            validate_affinity_output
+        from .tta_ensemble import TTAEnsembleAccumulator
+        prev, self._requested_output_head_override = self._requested_output_head_override, requested_head
+        try:
+            ops.require_device(windows.device, "TTAPredictor")
+            x = windows if windows.dtype == torch.float32 else windows.float()
+            tta = self._get_tta_cfg()
+            combos = [([], None, 0)]
+            if tta is not None and getattr(tta, "enabled", True):
+                combos = resolve_tta_augmentation_combinations(tta, spatial_dims=_resolve_spatial_dims(x.dim()))
+            has_affinity = bool(resolve_affinity_channel_groups_from_cfg(self.cfg))
+            plan = None
+            acc = None
+            for i, (flips, plane, k) in enumerate(combos):
+                pred = self._network_tensor(apply_view(x, flips, plane, k, first_spatial_dim=2).contiguous())
+                pred = pred if pred.dtype == torch.float32 else pred.float()
+                if has_affinity and plan is None:
+                    plan = build_affinity_tta_plan(self.cfg, augmentation_combinations=combos, num_raw=int(pred.shape[1]),
+                                                   requested_head=requested_head)
+                if len(combos) == 1:                      # no augmentation: nothing to invert or to ensemble
+                    validate_affinity_output(plan, pred)
+                    return self._apply_mask_to_result(self.apply_preprocessing(pred.contiguous()), mask, mask_align_to_image)
+                pred, validity = invert_view(pred, flip_axes=flips, rotation_plane_spatial=plane, k=k,
+                                             view_plan=None if plan is None else plan.views[i], tta_plan=plan)
+                raw_channels = int(pred.shape[1])
+                sel = self._select_channel_indices(raw_channels)
+                done = self.apply_preprocessing(pred.contiguous())
+                kept = list(range(raw_channels)) if sel is None else list(sel)
+                if acc is None:
+                    partial = [] if plan is None else [j for j, c in enumerate(kept) if c in plan.partial_channels]
+                    acc = TTAEnsembleAccumulator(tuple(done.shape), dtype=resolve_model_output_dtype(self.cfg), device=done.device,
+                                                 mode_map=_resolve_ensemble_mode_map(getattr(tta, "ensemble_mode", "mean"),
+                                                                                     int(done.shape[1])),
+                                                 partial_channels=partial, distributed_sharding=False, max_views=len(combos))
+                acc.add(done, ViewValidity(tuple(validity.channels[c] for c in kept)))
+            return self._apply_mask_to_result(acc.finalize(), mask, mask_align_to_image)
+        finally:
+            self._requested_output_head_override = prev
 
     def _predict_volume(self, images: torch.Tensor, mask, mask_align_to_image: bool, requested_head: Optional[str],
                         flat2d: bool) -> torch.Tensor:

@@ -897,6 +897,62 @@ def accessor():
 
 
 
+def _lazy_tta_cases():
+    sys.path.insert(0, str(HERE.parent))
+    import lazy_tta_cases as L
+    return L.LAZY_TTA_CASES, L.lazy_tta_cfg
+
+
+def lazy_tta():
+    """connectomics/inference/lazy.py:986-1258 with test-time augmentation and a mask volume: the reference's lazy loop runs its
+    TTAPredictor on every window batch (views -> forward -> inverse view -> activations / channel selection -> streaming
+    ensemble -> mask), then blends.  Numpy-backed accessors as in lazy(); -> tests/golden/lazy_tta.npz."""
+    LAZY_TTA_CASES, lazy_tta_cfg = _lazy_tta_cases()
+    lz = S.ref("connectomics.inference.lazy")
+
+    class FakeAccessor:
+        def __init__(self, vol, kind):
+            self.vol = vol.astype(np.float32)
+            self.padded_spatial_shape = tuple(vol.shape[1:])
+            self.channel_count = vol.shape[0]
+            self.kind = kind
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def close(self):
+            pass
+
+        def read_patch(self, location, patch_size, *, outer_pad_mode, outer_pad_value):
+            start = tuple(int(v) for v in location)
+            end = tuple(start[i] + int(patch_size[i]) for i in range(3))
+            shp = self.padded_spatial_shape
+            lo = tuple(max(0, start[i]) for i in range(3))
+            hi = tuple(min(shp[i], end[i]) for i in range(3))
+            inner = self.vol[:, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+            pads = [(max(0, -start[i]), max(0, end[i] - shp[i])) for i in range(3)]
+            return lz._pad_channel_first(inner, pads, mode=outer_pad_mode, constant_value=outer_pad_value)
+
+    rng = np.random.default_rng(17)
+    vol = rng.random((1, 20, 30, 34), dtype=np.float32)
+    mask = (rng.random((1, 20, 30, 34)) > 0.35).astype(np.float32)
+    out = {"vol": vol, "mask": mask}
+    for name, case in LAZY_TTA_CASES.items():
+        cfg = lazy_tta_cfg(**case["cfg"])
+        lz._build_accessor = lambda cfg_, path, kind, mode: FakeAccessor(mask if kind == "mask" else vol, kind)
+        kw = dict(mask_path="fake://mask" if case.get("mask") else None, mask_align_to_image=False, device="cpu")
+        if case.get("region") is None:
+            y = lz.lazy_predict_volume(cfg, _net_lazy, "fake://", **kw)
+        else:
+            y = lz.lazy_predict_region(cfg, _net_lazy, "fake://", region_start=case["region"][0], region_stop=case["region"][1], **kw)
+        out[f"{name}__y"] = y.numpy()
+        print(name, tuple(y.shape), float(y.mean()))
+    save("lazy_tta.npz", **out)
+
+
 # ---------------------------------------------------------------- tile-grid sources through the reference accessor
 def accessor_tiles():
     """connectomics/inference/lazy.py:61-157, :675-708 + data/io/tiles.py:19-156: the reference's LazyVolumeAccessor on tile-grid
@@ -1048,7 +1104,7 @@ def losses_extra():
 
 if __name__ == "__main__":
     parts = {"manifests": manifests, "optimizers": optimizers, "schedules": schedules, "selectors": selectors, "outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
-             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "accessor": accessor, "accessor_tiles": accessor_tiles, "ds_loss": ds_loss, "losses_extra": losses_extra, "public_adapters": public_adapters, "public_helpers": public_helpers}
+             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "lazy_tta": lazy_tta, "accessor": accessor, "accessor_tiles": accessor_tiles, "ds_loss": ds_loss, "losses_extra": losses_extra, "public_adapters": public_adapters, "public_helpers": public_helpers}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:
         parts[name]()

@@ -1,0 +1,131 @@
+"""Lazy sliding-window inference with per-window test-time augmentation and a mask volume (reference inference/lazy.py:986-1258:
+its loop hands every window batch to a TTAPredictor) -- the host orchestration on the CPU.
+
+The product has no CPU path, so the kernel module (`hip_ops`) is replaced by the small torch stand-ins below (test infrastructure,
+same idea as tests/test_host_distributed_inference.py): window gather with the reader's outer padding, blending, activations, the
+ensemble update.  Everything above the kernels -- which views run, inverse views, activation-before-ensemble order, per-channel
+ensemble modes, mask application, channel selection, blending of the ensembled windows -- is the product code, checked against
+tests/golden/lazy_tta.npz, the output of the REFERENCE's own lazy loop on the same volume / mask / network.  The same fixtures
+meet the real kernels in tests/test_gpu_lazy_chunked.py."""
+import numpy as np
+import pytest
+import torch
+
+from lazy_tta_cases import LAZY_TTA_CASES, lazy_tta_cfg
+from test_host_distributed_inference import _CpuOps
+
+
+class _Ops(_CpuOps):
+    @staticmethod
+    def gather_windows(vol, starts, roi, pad_mode="constant", cval=0.0, **_kw):
+        """(C,Z,Y,X) -> (B, *roi, C); a window overhanging the box is padded like np.pad (constant / reflect / replicate)."""
+        mode = {"constant": "constant", "reflect": "reflect", "replicate": "edge", "edge": "edge"}[str(pad_mode)]
+        ext = vol.shape[1:]
+        out = []
+        for s in starts:
+            lo = [max(0, s[a]) for a in range(3)]
+            hi = [min(ext[a], s[a] + roi[a]) for a in range(3)]
+            inner = vol[:, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]].numpy()
+            pads = [(0, 0)] + [(lo[a] - s[a], s[a] + roi[a] - hi[a]) for a in range(3)]
+            kw = dict(constant_values=float(cval)) if mode == "constant" else {}
+            out.append(torch.from_numpy(np.pad(inner, pads, mode=mode, **kw)).permute(1, 2, 3, 0))
+        return torch.stack(out).contiguous()
+
+    @staticmethod
+    def channel_activation(value, c0, c1, act, scale=1.0, *, channels_last=False):
+        from pytorch_connectomics_amd import _native as nat
+        v = value[..., c0:c1] if channels_last else value[c0:c1]
+        if act == nat.ACT_SIGMOID:
+            v.copy_(torch.sigmoid(scale * v))
+        elif act == nat.ACT_TANH:
+            v.copy_(torch.tanh(scale * v))
+        elif act == nat.ACT_SOFTMAX:
+            v.copy_(torch.softmax(v, dim=-1 if channels_last else 0))
+        else:
+            raise AssertionError(act)
+
+
+def _net_lazy(x):
+    ramp = torch.linspace(0, 1, x.shape[-1]).view(1, 1, 1, 1, -1)
+    return torch.cat([2 * x - 1 + ramp, 0.5 * x + x.mean(dim=(2, 3, 4), keepdim=True)], 1)
+
+
+@pytest.fixture()
+def cpu_kernels(monkeypatch):
+    import pytorch_connectomics_amd.inference.lazy as lazy
+    import pytorch_connectomics_amd.inference.tta as tta
+    import pytorch_connectomics_amd.inference.tta_ensemble as ens
+    for mod in (lazy, tta, ens):
+        monkeypatch.setattr(mod, "ops", _Ops)
+    return lazy
+
+
+@pytest.mark.parametrize("name", list(LAZY_TTA_CASES))
+def test_lazy_tta_and_mask_match_the_reference_loop(name, golden_dir, cpu_kernels):
+    g = np.load(golden_dir / "lazy_tta.npz")
+    case = LAZY_TTA_CASES[name]
+    cfg = lazy_tta_cfg(**case["cfg"])
+    kw = dict(mask_path=g["mask"] if case.get("mask") else None, device="cpu")
+    if case.get("region") is None:
+        y = cpu_kernels.lazy_predict_volume(cfg, _net_lazy, g["vol"], **kw)
+    else:
+        y = cpu_kernels.lazy_predict_region(cfg, _net_lazy, image_path=g["vol"], region_start=case["region"][0],
+                                            region_stop=case["region"][1], **kw)
+    want = g[f"{name}__y"]
+    assert tuple(y.shape) == want.shape
+    np.testing.assert_allclose(y.numpy(), want, rtol=2e-5, atol=2e-5)
+
+
+def test_lazy_entry_points_take_the_reference_keywords(golden_dir, cpu_kernels):
+    g = np.load(golden_dir / "lazy_tta.npz")
+    cfg = lazy_tta_cfg(roi=(8, 12, 16), tta=False)
+    a = cpu_kernels.lazy_predict_volume(cfg, _net_lazy, g["vol"], device="cpu")
+    b = cpu_kernels.lazy_predict_volume(cfg, _net_lazy, image_path=g["vol"], mask_path=None, mask_align_to_image=False, device="cpu")
+    c = cpu_kernels.lazy_predict_volume(cfg, _net_lazy, volume=g["vol"], device="cpu")          # this package's earlier keyword
+    assert torch.equal(a, b) and torch.equal(a, c)
+    with pytest.raises(TypeError, match="pass the test volume once"):
+        cpu_kernels.lazy_predict_volume(cfg, _net_lazy, device="cpu")
+    with pytest.raises(ValueError, match="mask volume shape"):
+        cpu_kernels.lazy_predict_volume(cfg, _net_lazy, g["vol"], mask_path=g["mask"][:, :10], device="cpu")
+    # both argument orders of get_lazy_image_reference_shape
+    assert cpu_kernels.get_lazy_image_reference_shape(g["vol"], cfg) == (20, 30, 34)
+    assert cpu_kernels.get_lazy_image_reference_shape(torch.zeros(1, 2, 4, 5, 6)) == (4, 5, 6)
+
+
+def test_reference_shape_of_a_stored_volume(tmp_path):
+    """`get_lazy_image_reference_shape(cfg, image_path)` in the reference's argument order: (1, C, *padded shape); a transformed
+    volume smaller than data.dataloader.patch_size is refused with the reference's message."""
+    from types import SimpleNamespace as NS
+    from pytorch_connectomics_amd.inference.lazy import get_lazy_image_reference_shape
+    np.save(tmp_path / "v.npy", np.zeros((2, 9, 10, 11), np.uint8))
+    cfg = NS(data=NS(dataloader=NS(patch_size=[8, 8, 8]), data_transform=NS(pad_size=[1, 2, 3], pad_mode="reflect", val_transpose=None,
+                                                                         resize=None),
+                     image_transform=NS(normalize="none", clip_percentile_low=0.0, clip_percentile_high=1.0, resize=None),
+                     mask_transform=None),
+             system=NS(num_workers=1))
+    assert get_lazy_image_reference_shape(cfg, str(tmp_path / "v.npy")) == (1, 2, 11, 14, 17)
+    assert get_lazy_image_reference_shape(str(tmp_path / "v.npy"), cfg) == (11, 14, 17)          # earlier form of this package
+    cfg.data.dataloader.patch_size = [16, 8, 8]
+    with pytest.raises(ValueError, match=r"at least as large as data.dataloader.patch_size in every axis. Got transformed_shape=\(9, 10, 11\)"):
+        get_lazy_image_reference_shape(cfg, str(tmp_path / "v.npy"), mode="test")
+
+
+def test_chunked_runner_passes_mask_and_views_to_every_chunk(tmp_path, golden_dir, cpu_kernels):
+    """run_chunked_prediction_inference under the reference's keywords (`image_path=`, `mask_path=`, `qc_streaming_callback=`):
+    the stitched chunks equal the whole-volume lazy prediction with the same per-window TTA and mask."""
+    from types import SimpleNamespace as NS
+    from pytorch_connectomics_amd.inference.chunked import run_chunked_prediction_inference
+    g = np.load(golden_dir / "lazy_tta.npz")
+    cfg = lazy_tta_cfg(roi=(8, 12, 16), flips=[[1]], acts=[{"channels": "0", "activation": "sigmoid"}], padding_mode="constant")
+    cfg.inference.chunking = NS(enabled=True, chunk_size=[9, 16, 20], halo=[2, 3, 4], axes="all", shard_id=None, num_shards=None)
+    full = cpu_kernels.lazy_predict_volume(cfg, _net_lazy, g["vol"], mask_path=g["mask"], device="cpu")
+    seen = []
+    probe = NS(update=lambda a, z_offset, z_axis: seen.append((a.shape, z_offset, z_axis)))
+    out = run_chunked_prediction_inference(cfg, _net_lazy, image_path=g["vol"], mask_path=g["mask"], output_path=tmp_path / "p.npy",
+                                           device="cpu", qc_streaming_callback=probe)
+    np.testing.assert_allclose(out, full[0].numpy(), rtol=0, atol=0)
+    assert seen == [(out.shape, 0, 1)]
+    unmasked = cpu_kernels.lazy_predict_volume(cfg, _net_lazy, g["vol"], device="cpu")
+    assert not torch.equal(unmasked, full)                                   # the mask did reach the windows
+    with pytest.raises(TypeError, match="needs the test volume"):
+        run_chunked_prediction_inference(cfg, _net_lazy, output_path=tmp_path / "q.npy", device="cpu")
