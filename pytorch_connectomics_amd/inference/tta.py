@@ -26,6 +26,7 @@ from .lazy_distributed import reduce_view_ensemble, validate_view_shards
 from .tta_combinations import (_resolve_ensemble_mode_map, _resolve_spatial_dims, apply_view,
                                resolve_tta_augmentation_combinations)
 from .window import is_2d_inference_mode, resolve_model_output_dtype
+from ..utils.model_outputs import resolve_output_channels, resolve_output_heads
 
 logger = logging.getLogger(__name__)
 
@@ -63,6 +64,26 @@ class TTAPredictor:
         self._requested_output_head_override: Optional[str] = None
         self._last_distributed_sharding_active = False
         self._last_skip_postprocess_on_rank = False
+        self._parse_channel_activations()
+
+    def _parse_channel_activations(self) -> None:
+        """Activation name per output channel from the configuration alone (the channel count the config declares for the
+        selected output, else model.out_channels) -- so a bad `channel_activations` entry is refused when the predictor is built,
+        not in the middle of a volume (reference tta.py:202-230).  `apply_preprocessing` refreshes it from the real tensor."""
+        if not hasattr(self.cfg, "inference") or not get_inference_channel_activations(self.cfg):
+            return
+        hint = resolve_output_channels(self.cfg, requested_head=self._requested_output_head_override,
+                                       purpose="TTA channel activation parsing", allow_ambiguous=True)
+        if hint is None:
+            hint = int(getattr(getattr(self.cfg, "model", None), "out_channels", 0) or 0)
+        if hint <= 0:
+            self.channel_activation_types = None
+            return
+        names: list = [None] * hint
+        for idx, act in self._resolve_channel_activation_specs(hint):
+            for c in idx:
+                names[c] = act
+        self.channel_activation_types = names if any(n is not None for n in names) else None
 
     # ------------------------------------------------------------------ config helpers
     def _get_tta_cfg(self):
@@ -83,15 +104,57 @@ class TTAPredictor:
             return None
         return resolve_channel_indices(sel, num_channels=int(num_channels), context="inference.model.select_channel")
 
-    def _activation_specs(self, num_channels: int):
-        specs = []
-        for entry in get_inference_channel_activations(self.cfg):
-            ch = entry.get("channels", ":") if isinstance(entry, dict) else getattr(entry, "channels", ":")
-            act = entry.get("activation") if isinstance(entry, dict) else getattr(entry, "activation", None)
-            idx = resolve_channel_indices(ch, num_channels=num_channels,
-                                          context="inference.model.channel_activations channels")
-            specs.append((idx, act))
+    def _merged_head_window(self):
+        """(offset, width, merged width) of the head being predicted inside the MERGED output, or None.  With
+        `inference.model.head: "aff,sdt"` every head is predicted on its own and the results are concatenated, but
+        `channel_activations` is written against the concatenation ("0:6" aff, "6:7" sdt): the entries have to be resolved there
+        and shifted into the head's own channel numbering (reference tta.py:94-139).  None for single-tensor models, for a
+        request that is itself a list, and for a head that is not part of the configured merged output."""
+        head = self._requested_output_head_override
+        if not isinstance(head, str) or "," in head:
+            return None
+        merged = resolve_output_heads(self.cfg, purpose="channel activation scoping")
+        if head not in merged:
+            return None
+        def width(names):
+            return resolve_output_channels(self.cfg, requested_head=",".join(names), purpose="channel activation scoping",
+                                           allow_ambiguous=False)
+        total, own = width(merged), width([head])
+        if total is None or own is None:
+            return None
+        before = merged[:merged.index(head)]
+        return (int(width(before) or 0) if before else 0), int(own), int(total)
+
+    def _resolve_channel_activation_specs(self, num_channels: int):
+        """`inference.model.channel_activations` -> [(channel indices of THIS tensor, activation)]: every entry a mapping with
+        `channels` and `activation`, no channel claimed twice; under merged-head inference the selectors are resolved in the merged
+        numbering, entries of other heads dropped and the rest shifted to local indices (reference tta.py:141-200)."""
+        window = self._merged_head_window()
+        specs, taken = [], set()
+        for pos, entry in enumerate(get_inference_channel_activations(self.cfg)):
+            if not isinstance(entry, dict):
+                raise ValueError("inference.model.channel_activations entries must be mappings with keys "
+                                 f"'channels' and 'activation', got {type(entry).__name__}.")
+            if "channels" not in entry or "activation" not in entry:
+                raise ValueError(f"inference.model.channel_activations[{pos}] must define both 'channels' and 'activation'.")
+            where = f"inference.model.channel_activations[{pos}].channels"
+            if window is None:
+                idx = resolve_channel_indices(entry["channels"], num_channels=num_channels, context=where)
+            else:
+                first, own, total = window
+                idx = [c - first for c in resolve_channel_indices(entry["channels"], num_channels=total, context=where)
+                       if first <= c < first + own]
+                if not idx:
+                    continue                              # an entry of another head of the merged output
+            twice = sorted(taken.intersection(idx))
+            if twice:
+                raise ValueError(f"inference.model.channel_activations[{pos}] overlaps already assigned channels: "
+                                 f"{', '.join(map(str, twice))}.")
+            taken.update(idx)
+            specs.append((idx, entry["activation"]))
         return specs
+
+    _activation_specs = _resolve_channel_activation_specs
 
     # ------------------------------------------------------------------ network plumbing
     def _network_tensor(self, x: torch.Tensor) -> torch.Tensor:

@@ -521,7 +521,44 @@ def public_helpers():
         aff.append({"shape": list(shape), "result": attempt(lambda: ta.validate_affinity_output(plan, torch.zeros(shape)))})
     aff.append({"shape": [1, 3, 4, 4], "plan": None, "result": attempt(lambda: ta.validate_affinity_output(None, torch.zeros(1, 3, 4, 4)))})
     aff.append({"shape": [1, 6, 4, 4], "rank0": True, "result": attempt(lambda: ta.validate_affinity_output(NS(num_channels=6, spatial_rank=0), torch.zeros(1, 6, 4, 4)))})
-    (HERE / "public_helpers.json").write_text(json.dumps({"channels": channel_cases, "selectors": sel_cases, "affinity": aff}, indent=0))
+    # channel-activation scoping of the predictor (tta.py:94-200), incl. merged-head inference ("aff,sdt": specs written against the
+    # concatenated tensor, every head activated on its own slice)
+    tta = S.ref("connectomics.inference.tta")
+    two = {"aff": {"out_channels": 6}, "sdt": {"out_channels": 1}}
+    act_cases = []
+    for label, model_kw, inf_head, acts, override, width in [
+            ("merged_aff", dict(heads=two, primary_head="aff", out_channels=7), "aff,sdt", [{"channels": "0:6", "activation": "scale_sigmoid"}, {"channels": "6:7", "activation": "tanh"}], "aff", 6),
+            ("merged_sdt", dict(heads=two, primary_head="aff", out_channels=7), "aff,sdt", [{"channels": "0:6", "activation": "scale_sigmoid"}, {"channels": "6:7", "activation": "tanh"}], "sdt", 1),
+            ("merged_straddle", dict(heads=two, primary_head="aff", out_channels=7), "aff, sdt", [{"channels": "4:", "activation": "sigmoid"}, {"channels": [0, 2], "activation": "tanh"}], "sdt", 1),
+            ("merged_straddle_aff", dict(heads=two, primary_head="aff", out_channels=7), "aff, sdt", [{"channels": "4:", "activation": "sigmoid"}, {"channels": [0, 2], "activation": "tanh"}], "aff", 6),
+            ("merged_request_is_list", dict(heads=two, primary_head="aff", out_channels=7), "aff,sdt", [{"channels": "0:6", "activation": "sigmoid"}], "aff,sdt", 7),
+            ("head_outside_merged", dict(heads={**two, "lsd": {"out_channels": 3}}, primary_head="aff", out_channels=7), "aff,sdt", [{"channels": "0:2", "activation": "sigmoid"}], "lsd", 3),
+            ("single_head_config", dict(heads=two, primary_head="sdt", out_channels=7), None, [{"channels": ":", "activation": "tanh"}], "sdt", 1),
+            ("no_heads", dict(heads=None, primary_head=None, out_channels=3), None, [{"channels": "0:2", "activation": "sigmoid"}, {"channels": "2:3", "activation": "tanh"}], None, 3),
+            ("overlap", dict(heads=None, primary_head=None, out_channels=3), None, [{"channels": "0:2", "activation": "sigmoid"}, {"channels": "1:3", "activation": "tanh"}], None, 3),
+            ("not_a_mapping", dict(heads=None, primary_head=None, out_channels=3), None, [["0:2", "sigmoid"]], None, 3),
+            ("missing_key", dict(heads=None, primary_head=None, out_channels=3), None, [{"channels": "0:2"}], None, 3),
+            ("out_of_range", dict(heads=None, primary_head=None, out_channels=3), None, [{"channels": "5", "activation": "tanh"}], None, 3),
+            ("none_configured", dict(heads=None, primary_head=None, out_channels=3), None, None, None, 3)]:
+        c = NS(model=NS(**model_kw), inference=NS(model=NS(head=inf_head, channel_activations=acts, select_channel=None, output_dtype=None),
+                                                  test_time_augmentation=NS(enabled=False)))
+        built = attempt(lambda: tta.TTAPredictor(cfg=c, sliding_inferer=None, forward_fn=lambda x: x))
+        rec = {"label": label, "model": dict(model_kw), "inference_head": inf_head, "activations": acts, "override": override, "width": width}
+        if "error" in built:                       # the constructor parses the activations (tta.py:202-230) and refuses bad entries
+            rec["construct"] = built
+        else:
+            pr = built["value"]
+            rec["construct"] = {"value": pr.channel_activation_types}
+            pr._requested_output_head_override = override
+            window = attempt(lambda: pr._merged_head_window())
+            if "value" in window and window["value"] is not None:
+                window["value"] = list(window["value"])
+            rec["window"] = window
+            rec["specs"] = attempt(lambda: [[list(i), a] for i, a in pr._resolve_channel_activation_specs(width)])
+        act_cases.append(rec)
+    (HERE / "public_helpers.json").write_text(json.dumps({"channels": channel_cases, "selectors": sel_cases, "affinity": aff,
+                                                         "activation_specs": act_cases}, indent=0))
+    print("activation scoping:", len(act_cases), "cases")
     print("public helpers:", len(channel_cases), "channel cases,", len(sel_cases), "selectors,", len(aff), "affinity checks")
 
 

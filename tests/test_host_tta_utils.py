@@ -299,3 +299,29 @@ def test_public_helpers_match_the_reference(golden_dir):
     for case in ref["affinity"]:
         plan = None if "plan" in case else NS(num_channels=6, spatial_rank=0 if case.get("rank0") else 3)
         same(lambda: validate_affinity_output(plan, torch.zeros(case["shape"])), case["result"], case)
+
+
+def test_channel_activation_scoping_matches_the_reference_predictor(golden_dir):
+    """TTAPredictor._merged_head_window / _resolve_channel_activation_specs / the constructor's activation parsing (reference
+    tta.py:94-230): merged-head inference ("aff,sdt") resolves `channel_activations` in the concatenated numbering and shifts each
+    head's entries to its own channels; malformed, overlapping or out-of-range entries are refused when the predictor is built."""
+    import json
+    from types import SimpleNamespace as NS
+
+    from pytorch_connectomics_amd.inference.tta import TTAPredictor
+    for case in json.loads((golden_dir / "public_helpers.json").read_text())["activation_specs"]:
+        cfg = NS(model=NS(**case["model"]),
+                 inference=NS(model=NS(head=case["inference_head"], channel_activations=case["activations"], select_channel=None,
+                                       output_dtype=None), test_time_augmentation=NS(enabled=False)))
+        build = lambda: TTAPredictor(cfg=cfg, sliding_inferer=None, forward_fn=lambda x: x)      # noqa: E731
+        if "error" in case["construct"]:
+            with pytest.raises(ValueError) as info:
+                build()
+            assert str(info.value) == case["construct"]["message"], case["label"]
+            continue
+        pr = build()
+        assert pr.channel_activation_types == case["construct"]["value"], case["label"]
+        pr._requested_output_head_override = case["override"]
+        window = pr._merged_head_window()
+        assert (None if window is None else list(window)) == case["window"]["value"], case["label"]
+        assert [[list(i), a] for i, a in pr._resolve_channel_activation_specs(case["width"])] == case["specs"]["value"], case["label"]
