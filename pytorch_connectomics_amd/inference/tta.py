@@ -228,42 +228,88 @@ class TTAPredictor:
         return volume
 
     # ------------------------------------------------------------------ masks
+    @classmethod
+    def _coerce_mask_to_tensor(cls, mask) -> torch.Tensor:
+        """What a dataloader's collation can hand over as "the mask" -> one tensor: singleton lists / tuples are unwrapped, arrays
+        wrapped, longer lists stacked (reference tta.py:550-574)."""
+        while isinstance(mask, (list, tuple)) and len(mask) == 1:
+            mask = mask[0]
+        if torch.is_tensor(mask):
+            return mask
+        try:
+            import numpy as np
+            if isinstance(mask, np.ndarray):
+                return torch.from_numpy(mask)
+        except ImportError:      # pragma: no cover
+            pass
+        if not isinstance(mask, (list, tuple)):
+            raise TypeError(f"Unsupported mask type: {type(mask).__name__}")
+        parts = [cls._coerce_mask_to_tensor(item) for item in mask]
+        if not parts:
+            raise ValueError("Mask list is empty after collation.")
+        if len({tuple(t.shape) for t in parts}) > 1:
+            raise ValueError(f"Mask list contains tensors with incompatible shapes for stacking: {[tuple(t.shape) for t in parts]}")
+        return torch.stack(parts)
+
+    def _validate_and_prepare_mask(self, mask, prediction: torch.Tensor, align_to_image: bool = False) -> torch.Tensor:
+        """-> the BINARY mask (mask > 0) in the prediction's dtype, rank, batch and spatial shape (reference tta.py:465-548): a
+        missing channel axis (or batch and channel axes) is added, a depth-1 mask meets a 2-D prediction, a single mask serves the
+        whole batch, one mask channel serves all prediction channels; spatial shapes must agree unless `align_to_image` allows the
+        centre crop / zero pad."""
+        if mask is None:
+            raise ValueError("Mask is None while mask application is enabled.")
+        mask = self._coerce_mask_to_tensor(mask).to(device=prediction.device)
+        missing = prediction.dim() - mask.dim()
+        if missing == 1:
+            mask = mask[:, None]
+        elif missing == 2:
+            mask = mask[None, None]
+        elif missing == -1 and prediction.dim() == 4 and mask.shape[2] == 1:
+            mask = mask[:, :, 0]
+        if mask.dim() != prediction.dim():
+            raise ValueError(f"Mask rank {mask.dim()} does not match prediction rank {prediction.dim()}. "
+                             f"mask.shape={tuple(mask.shape)}, prediction.shape={tuple(prediction.shape)}")
+        if mask.shape[0] != prediction.shape[0]:
+            if mask.shape[0] != 1:
+                raise ValueError(f"Mask batch {mask.shape[0]} does not match prediction batch {prediction.shape[0]}.")
+            mask = mask.expand(prediction.shape[0], *mask.shape[1:])
+        if mask.shape[1] not in (1, prediction.shape[1]):
+            raise ValueError(f"Mask channels {mask.shape[1]} incompatible with prediction channels {prediction.shape[1]}. "
+                             f"Expected C=1 or C={prediction.shape[1]}.")
+        if mask.shape[2:] != prediction.shape[2:]:
+            if not align_to_image:
+                raise ValueError("Mask spatial shape must exactly match prediction spatial shape. "
+                                 f"Got mask.shape={tuple(mask.shape)} and prediction.shape={tuple(prediction.shape)}. "
+                                 "Fix test/tune mask preprocessing so they produce identical spatial dimensions.")
+            for dim in range(2, prediction.dim()):
+                extra = int(mask.shape[dim]) - int(prediction.shape[dim])
+                if extra > 0:                                   # centre crop
+                    mask = mask.narrow(dim, extra // 2, int(prediction.shape[dim]))
+                elif extra < 0:                                 # centre zero pad
+                    before = (-extra) // 2
+                    widths = [0, 0] * (prediction.dim() - 1 - dim) + [before, -extra - before]
+                    mask = torch.nn.functional.pad(mask, widths, mode="constant", value=0)
+        return (mask > 0).to(prediction.dtype)
+
     def _apply_mask_to_result(self, result: torch.Tensor, mask, mask_align_to_image: bool) -> torch.Tensor:
+        """result * mask, channel by channel; a `tanh` channel is filled with -1 (its background value) outside the mask instead
+        of 0 (reference tta.py:1568-1617)."""
         tta = self._get_tta_cfg()
-        apply_mask = getattr(tta, "apply_mask", True) if tta is not None else True
-        if not apply_mask or mask is None:
+        if mask is None or not (getattr(tta, "apply_mask", True) if tta is not None else True):
             return result
-        if not isinstance(mask, torch.Tensor):
-            logger.warning("Skipping mask application because the provided mask payload is not a tensor-like volume")
+        try:
+            mask = self._validate_and_prepare_mask(mask, result, align_to_image=mask_align_to_image)
+        except TypeError as exc:
+            logger.warning("Skipping mask application because the provided mask payload is not a tensor-like volume: %s", exc)
             return result
-        mask = mask.to(device=result.device, dtype=result.dtype)
-        while mask.dim() < result.dim():
-            mask = mask.unsqueeze(0)
-        if tuple(mask.shape[2:]) != tuple(result.shape[2:]):
-            if not mask_align_to_image:
-                raise ValueError(f"mask spatial shape {tuple(mask.shape[2:])} does not match prediction "
-                                 f"{tuple(result.shape[2:])}")
-            pads = []
-            sl = [slice(None), slice(None)]
-            for m, r in zip(mask.shape[2:], result.shape[2:]):   # centre crop / zero pad
-                lo = max(0, (m - r) // 2)
-                sl.append(slice(lo, lo + min(m, r)))
-            mask = mask[tuple(sl)]
-            for m, r in reversed(list(zip(mask.shape[2:], result.shape[2:]))):
-                d = r - m
-                pads += [d // 2, d - d // 2]
-            if any(pads):
-                mask = torch.nn.functional.pad(mask, pads)
         types = self.channel_activation_types
-        if types is not None and len(types) == result.shape[1]:
-            for c, t in enumerate(types):
-                mc = mask[:, c:c + 1] if mask.shape[1] == result.shape[1] else mask[:, 0:1]
-                if t == "tanh":
-                    result[:, c:c + 1] = mc * result[:, c:c + 1] + (1 - mc) * (-1.0)
-                else:
-                    result[:, c:c + 1] = mc * result[:, c:c + 1]
-            return result
-        return result * mask
+        if types is None or len(types) != result.shape[1]:
+            return result * mask
+        for c, name in enumerate(types):
+            m = mask[:, c:c + 1] if mask.shape[1] == result.shape[1] else mask[:, :1]
+            kept = m * result[:, c:c + 1]
+            result[:, c:c + 1] = kept + (m - 1) if name == "tanh" else kept
+        return result
 
     # ------------------------------------------------------------------ view sharding
     def _reduce_views(self, acc, n_local, total, modes, *, skip=(), stats=None, counts=None, partial_modes=()):

@@ -934,6 +934,38 @@ def accessor():
 
 
 
+def masks():
+    """connectomics/inference/tta.py:465-574, :1568-1617: the reference predictor's mask application (binarised mask, rank / batch /
+    channel normalisation, optional centre alignment, tanh channels filled with -1) -> tests/golden/mask_application.npz + .json."""
+    import json
+    from types import SimpleNamespace as NS
+    tta = S.ref("connectomics.inference.tta")
+    sys.path.insert(0, str(HERE.parent))
+    from lazy_tta_cases import mask_cases
+    out, index = {}, []
+    g = torch.Generator().manual_seed(29)
+    for label, shape, make, align, types, apply_mask in mask_cases():
+        cfg = NS(model=NS(heads=None, primary_head=None, out_channels=shape[1]),
+                 inference=NS(model=NS(head=None, channel_activations=None, select_channel=None, output_dtype=None),
+                              test_time_augmentation=NS(enabled=False, apply_mask=apply_mask)))
+        pr = tta.TTAPredictor(cfg=cfg, sliding_inferer=None, forward_fn=lambda x: x)
+        pr.channel_activation_types = types
+        pred = torch.rand(*shape, generator=g) * 2 - 1
+        mask = make()
+        rec = {"label": label}
+        try:
+            res = pr._apply_mask_to_result(pred.clone(), mask, align)
+            out[f"{label}__result"] = res.numpy()
+        except Exception as e:      # noqa: BLE001
+            rec.update(error=type(e).__name__, message=str(e))
+        out[f"{label}__pred"] = pred.numpy()
+        index.append(rec)
+    save("mask_application.npz", **out)
+    (HERE / "mask_application.json").write_text(json.dumps(index, indent=0))
+    print("mask cases:", len(index), "errors:", sum("error" in r for r in index))
+
+
+
 def _lazy_tta_cases():
     sys.path.insert(0, str(HERE.parent))
     import lazy_tta_cases as L
@@ -1141,7 +1173,7 @@ def losses_extra():
 
 if __name__ == "__main__":
     parts = {"manifests": manifests, "optimizers": optimizers, "schedules": schedules, "selectors": selectors, "outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
-             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "lazy_tta": lazy_tta, "accessor": accessor, "accessor_tiles": accessor_tiles, "ds_loss": ds_loss, "losses_extra": losses_extra, "public_adapters": public_adapters, "public_helpers": public_helpers}
+             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "lazy_tta": lazy_tta, "masks": masks, "accessor": accessor, "accessor_tiles": accessor_tiles, "ds_loss": ds_loss, "losses_extra": losses_extra, "public_adapters": public_adapters, "public_helpers": public_helpers}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:
         parts[name]()

@@ -2,6 +2,8 @@
 tests/golden/lazy_tta.npz: lazy sliding-window inference with per-window test-time augmentation and / or a mask volume."""
 from types import SimpleNamespace as NS
 
+import torch
+
 SIG_TANH = [{"channels": "0", "activation": "sigmoid"}, {"channels": "1", "activation": "tanh"}]
 
 
@@ -32,3 +34,33 @@ LAZY_TTA_CASES = {
                               region=((3, 5, 7), (17, 22, 30))),
     "select_channel_tta": dict(cfg=dict(roi=(8, 8, 8), flips=[[0, 2]], select=[1], acts=SIG_TANH, blending="constant", overlap=0.25)),
 }
+
+
+# ---- mask application (tests/golden/mask_application.npz, make_golden.py --masks)
+def mask_cases():
+    """Inputs of the mask-application fixture (shared with tests/test_host_tta_utils.py): (label, prediction shape, mask builder,
+    align, activation types, apply_mask)."""
+    g = torch.Generator().manual_seed(23)
+    def rnd(*shape):
+        return torch.rand(*shape, generator=g)
+    return [
+        ("binary_same_shape", (1, 2, 4, 5, 6), lambda: (rnd(1, 1, 4, 5, 6) > 0.4).float(), False, None, True),
+        ("uint8_255", (1, 2, 4, 5, 6), lambda: ((rnd(1, 1, 4, 5, 6) > 0.4) * 255).to(torch.uint8), False, None, True),
+        ("real_valued_and_negative", (1, 2, 4, 5, 6), lambda: rnd(1, 1, 4, 5, 6) - 0.5, False, None, True),
+        ("per_channel", (2, 3, 4, 5, 6), lambda: (rnd(2, 3, 4, 5, 6) > 0.5).float(), False, None, True),
+        ("no_channel_axis", (2, 3, 4, 5, 6), lambda: (rnd(2, 4, 5, 6) > 0.5).float(), False, None, True),
+        ("spatial_only_broadcast_batch", (2, 3, 4, 5, 6), lambda: (rnd(4, 5, 6) > 0.5).float(), False, None, True),
+        ("numpy_nested_singletons", (1, 2, 4, 5, 6), lambda: [[(rnd(1, 4, 5, 6) > 0.5).float().numpy()]], False, None, True),
+        ("list_of_two_stacks", (2, 1, 4, 5, 6), lambda: [(rnd(1, 4, 5, 6) > 0.5).float(), (rnd(1, 4, 5, 6) > 0.5).float()], False, None, True),
+        ("tanh_channel_fills_minus_one", (1, 3, 4, 5, 6), lambda: (rnd(1, 1, 4, 5, 6) > 0.5).float(), False, ["sigmoid", "tanh", None], True),
+        ("types_of_other_width_ignored", (1, 3, 4, 5, 6), lambda: (rnd(1, 1, 4, 5, 6) > 0.5).float(), False, ["tanh", "tanh"], True),
+        ("align_crop_and_pad", (1, 2, 4, 6, 5), lambda: (rnd(1, 1, 7, 3, 5) > 0.3).float(), True, None, True),
+        ("depth1_mask_for_2d_prediction", (2, 2, 5, 6), lambda: (rnd(2, 1, 1, 5, 6) > 0.5).float(), False, None, True),
+        ("apply_mask_off", (1, 2, 4, 5, 6), lambda: torch.zeros(1, 1, 4, 5, 6), False, None, False),
+        ("error_shape", (1, 2, 4, 5, 6), lambda: torch.ones(1, 1, 4, 5, 7), False, None, True),
+        ("error_channels", (1, 3, 4, 5, 6), lambda: torch.ones(1, 2, 4, 5, 6), False, None, True),
+        ("error_batch", (3, 2, 4, 5, 6), lambda: torch.ones(2, 1, 4, 5, 6), False, None, True),
+        ("error_rank", (1, 2, 4, 5, 6), lambda: torch.ones(5, 6), False, None, True),
+        ("error_ragged_list", (2, 1, 4, 5, 6), lambda: [torch.ones(1, 4, 5, 6), torch.ones(1, 4, 5, 5)], False, None, True),
+        ("unsupported_payload_is_skipped", (1, 2, 4, 5, 6), lambda: "not a mask", False, None, True),
+    ]

@@ -325,3 +325,34 @@ def test_channel_activation_scoping_matches_the_reference_predictor(golden_dir):
         window = pr._merged_head_window()
         assert (None if window is None else list(window)) == case["window"]["value"], case["label"]
         assert [[list(i), a] for i, a in pr._resolve_channel_activation_specs(case["width"])] == case["specs"]["value"], case["label"]
+
+
+def test_mask_application_matches_the_reference_predictor(golden_dir):
+    """TTAPredictor._apply_mask_to_result (pure tensor code, runs anywhere): the mask is BINARISED (mask > 0 -- a 0 / 255 uint8 mask
+    or a real-valued one must not scale the prediction), gets its missing axes, broadcasts over batch and channels, may be centre
+    aligned, tanh channels are filled with -1 outside it; nested lists / arrays from a dataloader are accepted; wrong shapes raise
+    the reference's messages; an unusable payload is skipped with a warning (reference tta.py:465-574, :1568-1617)."""
+    import json
+    from types import SimpleNamespace as NS
+
+    import numpy as np
+    import torch
+
+    from lazy_tta_cases import mask_cases
+    from pytorch_connectomics_amd.inference.tta import TTAPredictor
+    g = np.load(golden_dir / "mask_application.npz")
+    index = {r["label"]: r for r in json.loads((golden_dir / "mask_application.json").read_text())}
+    for label, shape, make, align, types, apply_mask in mask_cases():
+        cfg = NS(model=NS(heads=None, primary_head=None, out_channels=shape[1]),
+                 inference=NS(model=NS(head=None, channel_activations=None, select_channel=None, output_dtype=None),
+                              test_time_augmentation=NS(enabled=False, apply_mask=apply_mask)))
+        pr = TTAPredictor(cfg=cfg, sliding_inferer=None, forward_fn=lambda x: x)
+        pr.channel_activation_types = types
+        pred, mask = torch.from_numpy(g[f"{label}__pred"]), make()
+        if "error" in index[label]:
+            with pytest.raises(Exception) as info:
+                pr._apply_mask_to_result(pred.clone(), mask, align)
+            assert type(info.value).__name__ == index[label]["error"] and str(info.value) == index[label]["message"], label
+        else:
+            got = pr._apply_mask_to_result(pred.clone(), mask, align)
+            np.testing.assert_array_equal(got.numpy(), g[f"{label}__result"], err_msg=label)
