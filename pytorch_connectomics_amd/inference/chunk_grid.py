@@ -32,15 +32,17 @@ def resolve_chunk_shape(cfg: Any, final_shape: Sequence[int]) -> tuple[int, int,
     wanted = [int(v) for v in (getattr(section, "chunk_size", None) or ())]
     if not wanted:
         raise ValueError("inference.chunking.chunk_size must be set for chunked inference")
-    if len(wanted) != 3 or min(wanted) <= 0:
-        raise ValueError(f"inference.chunking.chunk_size must be 3 positive ints, got {wanted}")
     extent = [int(v) for v in final_shape[:3]]
     split = str(getattr(section, "axes", "all")).lower()
-    if split == "all":
-        return tuple(min(w, e) for w, e in zip(wanted, extent))
+    if split not in ("all", "z"):
+        raise ValueError("inference.chunking.axes must be 'all' or 'z'")
+    used = wanted[:1] if split == "z" else wanted[:3]          # like the reference: z slabs read the first entry only
+    if len(used) < (1 if split == "z" else 3) or min(used) <= 0:
+        # (the reference lets a zero / negative / short chunk_size through and fails later with an empty grid or an IndexError)
+        raise ValueError(f"inference.chunking.chunk_size must be 3 positive ints, got {wanted}")
     if split == "z":
-        return (wanted[0], extent[1], extent[2])
-    raise ValueError("inference.chunking.axes must be 'all' or 'z'")
+        return (used[0], extent[1], extent[2])
+    return tuple(min(w, e) for w, e in zip(used, extent))
 
 
 def resolve_h5_spatial_chunks(spatial_shape: Sequence[int]) -> tuple[int, int, int]:
