@@ -162,9 +162,126 @@ def main():
     for fn in ("resolve_channel_indices", "resolve_channel_range"):
         t.run(f"channel_slices.{fn}", [(s, n) for s in sels for n in (0, 1, 3, 7)],
               lambda s, n, fn=fn: getattr(rs, fn)(s, num_channels=n, context="c"), lambda s, n, fn=fn: getattr(os_, fn)(s, num_channels=n, context="c"))
+    affinity_views(t, rnd)
+    prediction_crops(t, rnd)
+    blending_maps(t, rnd)
+    output_transforms(t, rnd)
     total, bad = sum(r[1] for r in t.rows), sum(r[2] for r in t.rows)
     print(f"TOTAL {total} cases, {bad} mismatches over {len(t.rows)} function pairs")
     return bad
+
+
+def affinity_views(t, rnd):
+    """Affinity-aware TTA end to end: plan construction (or its refusal) and, per view, the inverted prediction + the validity of
+    every channel -- reference `build_affinity_tta_plan` + `invert_view` against this package's."""
+    import torch
+    ra, oa = S.ref("connectomics.inference.tta_affinity"), __import__("pytorch_connectomics_amd.inference.tta_affinity", fromlist=["x"])
+    rc, oc = S.ref("connectomics.inference.tta_combinations"), __import__("pytorch_connectomics_amd.inference.tta_combinations", fromlist=["x"])
+    unit = ["1-0-0", "0-1-0", "0-0-1"]
+    offset_sets = [unit, unit + ["3-0-0", "0-3-0", "0-0-3"], unit + ["2-0-0", "0-4-0", "0-0-4"], ["0-1-0", "0-0-1"], ["1-0-0"],
+                   unit + ["1-1-0"], ["0-1-1", "0-1--1"], unit + ["0-9-0", "0-0-9"], ["1-0-0", "0-1-0", "0-0-1", "1-0-0"]]
+    tta_sets = [dict(flip_axes="all", rotation90_axes=None), dict(flip_axes=[[0]], rotation90_axes=[[1, 2]]),
+                dict(flip_axes="all", rotation90_axes=[[1, 2]]), dict(flip_axes=[[1], [2]], rotation90_axes=None),
+                dict(flip_axes=None, rotation90_axes=[[1, 2]], rotate90_k=[1, 3]), dict(flip_axes=[[0, 1, 2]], rotation90_axes=[[0, 1]])]
+    cases = []
+    for offs in offset_sets:
+        for mode in ("deepem", "banis"):
+            for tk in tta_sets:
+                for extra_before, extra_after in ((0, 0), (1, 0), (0, 2)):
+                    targets = [{"name": "binary"}] * extra_before + [{"name": "affinity", "kwargs": {"offsets": offs, "affinity_mode": mode}}] \
+                        + [{"name": "binary"}] * extra_after
+                    width = extra_before + len(offs) + extra_after
+                    heads, req = None, None
+                    if rnd.random() < 0.3:
+                        heads, req = {"aff": {"out_channels": len(offs), "target_slice": f"{extra_before}:{extra_before + len(offs)}"},
+                                      "aux": {"out_channels": 1}}, "aff"
+                    cases.append((targets, width if heads is None else len(offs), heads, req, tk))
+
+    def run(mod_a, mod_c, targets, num_raw, heads, req, tk):
+        cfg = NS(model=NS(primary_head=None, heads=heads, out_channels=num_raw),
+                 data=NS(label_transform=NS(stack_outputs=True, targets=targets)),
+                 inference=NS(model=NS(head=None, select_channel=None, output_dtype=None, channel_activations=None),
+                              test_time_augmentation=NS(enabled=True, rotate90_k=tk.get("rotate90_k"), ensemble_mode="mean", **{k: v for k, v in tk.items() if k != "rotate90_k"})))
+        combos = mod_c.resolve_tta_augmentation_combinations(cfg.inference.test_time_augmentation, spatial_dims=3)
+        plan = mod_a.build_affinity_tta_plan(cfg, augmentation_combinations=combos, num_raw=num_raw, requested_head=req)
+        g = torch.Generator().manual_seed(num_raw * 7 + len(combos))
+        out = []
+        for i, (f, pl, k) in enumerate(combos):
+            pred = torch.rand(1, num_raw, 5, 6, 6, generator=g)
+            plane = pl if pl is None else tuple(int(a) - (2 if min(pl) >= 2 else 0) for a in pl)
+            inv, val = mod_a.invert_view(pred, flip_axes=f, rotation_plane_spatial=plane, k=k, view_plan=None if plan is None else plan.views[i],
+                                         tta_plan=plan)
+            out.append((round(float(inv.double().sum()), 5), round(float((inv.double() ** 2).sum()), 5),
+                        [None if v is None else [(s.start, s.stop) for s in v] for v in val.channels]))
+        return (None if plan is None else sorted(plan.partial_channels)), out
+    t.run("affinity TTA: plan + invert_view per view", cases, lambda *c: run(ra, rc, *c), lambda *c: run(oa, oc, *c))
+
+
+def _tensor_digest(x, digits=6):
+    import torch
+    x = x.detach().double()
+    return (tuple(x.shape), str(x.dtype), round(float(x.sum()), digits), round(float((x * x).sum()), digits), round(float(x.min()), digits),
+            round(float(x.max()), digits))
+
+
+def blending_maps(t, rnd):
+    """The blending maps as numbers (sum / sum of squares / extrema to 1e-6): importance maps, the floored sliding maps incl. the
+    distance transform, border masks."""
+    import torch
+    rw, ow = S.ref("connectomics.inference.window"), __import__("pytorch_connectomics_amd.inference.window", fromlist=["x"])
+    rois = [(1, 1, 1), (2, 3, 3), (8, 12, 16), (112, 112, 112), (1, 32, 48), (5, 7, 9), (160, 160, 160), (3, 1, 4)] + \
+        [tuple(rnd.randint(1, 40) for _ in range(3)) for _ in range(40)]
+    modes = ["constant", "bump", "gaussian", "distance_transform", "dt", "BUMP", "const", "nope"]
+    t.run("compute_importance_map", [(r, m) for r in rois for m in modes],
+          lambda r, m: _tensor_digest(rw.compute_importance_map(r, mode=m, device="cpu", dtype=torch.float32)),
+          lambda r, m: _tensor_digest(ow.compute_importance_map(r, mode=m, device="cpu", dtype=torch.float32)))
+    t.run("build_sliding_importance_map", [(r, m) for r in rois for m in modes],
+          lambda r, m: _tensor_digest(rw.build_sliding_importance_map(r, mode=m, device="cpu", dtype=torch.float32)),
+          lambda r, m: _tensor_digest(ow.build_sliding_importance_map(r, mode=m, device="cpu", dtype=torch.float32)))
+    borders = [[], [0, 0, 0], [1, 1, 1], [2, 0, 1], [50, 1, 1], [1, 1], [-1, 0, 0], None]
+    t.run("apply_border_mask", [(r, b) for r in rois[:20] for b in borders],
+          lambda r, b: _tensor_digest(rw.apply_border_mask(torch.ones(r) + torch.arange(r[2]), b)),
+          lambda r, b: _tensor_digest(ow.apply_border_mask(torch.ones(r) + torch.arange(r[2]), b)))
+
+
+def output_transforms(t, rnd):
+    import numpy as np
+    ro, oo = S.ref("connectomics.inference.output"), __import__("pytorch_connectomics_amd.inference.output", fromlist=["x"])
+    rng = np.random.default_rng(3)
+    data = [(rng.random((2, 3, 4, 5)).astype(np.float32) * s + o) for s, o in ((1.0, 0.0), (300.0, -20.0), (1e-3, 0.0), (70000.0, 0.0))]
+    cases = []
+    for d in data:
+        for enabled in (True, False):
+            for scale in (-1.0, 255.0, 1.0, 0.5, 65535.0, None):
+                for idt in (None, "uint8", "uint16", "float16", "int8", "float32", "int16", "bogus"):
+                    for sdt in (None, "float16", "uint8", "bogus"):
+                        cases.append((NS(inference=NS(prediction_transform=NS(enabled=enabled, intensity_scale=scale, intensity_dtype=idt),
+                                                      save_dtype=sdt, save_prediction=NS(storage_dtype=sdt))), d))
+
+    def digest(a):
+        a = np.asarray(a)
+        return (a.shape, str(a.dtype), round(float(a.astype(np.float64).sum()), 4), float(a.min()), float(a.max()))
+    t.run("apply_prediction_transform", cases, lambda c, d: digest(ro.apply_prediction_transform(c, d.copy())),
+          lambda c, d: digest(oo.apply_prediction_transform(c, d.copy())))
+    t.run("apply_storage_dtype_transform", cases, lambda c, d: digest(ro.apply_storage_dtype_transform(c, d.copy())),
+          lambda c, d: digest(oo.apply_storage_dtype_transform(c, d.copy())))
+
+
+def prediction_crops(t, rnd):
+    rk, ok_ = S.ref("connectomics.inference.chunk_grid"), __import__("pytorch_connectomics_amd.inference.chunk_grid", fromlist=["x"])
+    unit = ["1-0-0", "0-1-0", "0-0-1"]
+    cases = []
+    for offs in (unit, unit + ["3-0-0", "0-9-0", "0-0-27"], ["0-0-1"], ["-2-0-0", "0-3-0"], [], None):
+        for mode in ("deepem", "banis", None):
+            for crop in (None, [1, 1, 1], [[0, 2], [1, 1], [3, 0]], 2):
+                for sel in (None, "0:3", [0], "3:"):
+                    targets = [] if offs is None else [{"name": "affinity", "kwargs": {"offsets": offs, **({"affinity_mode": mode} if mode else {})}}]
+                    cases.append((NS(model=NS(heads=None, primary_head=None, out_channels=len(offs or [1])),
+                                     data=NS(label_transform=NS(stack_outputs=True, targets=targets)),
+                                     inference=NS(model=NS(head=None, select_channel=sel, crop_pad=crop, channel_activations=None, output_dtype=None),
+                                                  chunking=NS(enabled=True))),))
+    t.run("resolve_global_prediction_crop", cases, rk.resolve_global_prediction_crop, ok_.resolve_global_prediction_crop)
+    t.run("resolve_selected_affinity_offsets", cases, rk.resolve_selected_affinity_offsets, ok_.resolve_selected_affinity_offsets)
 
 
 if __name__ == "__main__":
