@@ -166,6 +166,7 @@ def main():
     prediction_crops(t, rnd)
     blending_maps(t, rnd)
     output_transforms(t, rnd)
+    training_host_side(t, rnd)
     total, bad = sum(r[1] for r in t.rows), sum(r[2] for r in t.rows)
     print(f"TOTAL {total} cases, {bad} mismatches over {len(t.rows)} function pairs")
     return bad
@@ -265,6 +266,89 @@ def output_transforms(t, rnd):
           lambda c, d: digest(oo.apply_prediction_transform(c, d.copy())))
     t.run("apply_storage_dtype_transform", cases, lambda c, d: digest(ro.apply_storage_dtype_transform(c, d.copy())),
           lambda c, d: digest(oo.apply_storage_dtype_transform(c, d.copy())))
+
+
+def training_host_side(t, rnd):
+    """Learning-rate schedule, optimizer parameter groups and the torch restatements of the reference's weighted losses (value and
+    gradient digests) on generated configurations / tensors."""
+    import torch
+    import pytorch_connectomics_amd.training.module as om
+    rl = S.ref("connectomics.training.optimization.lr_scheduler")
+    rb = S.ref("connectomics.training.optimization.build")
+    ls = S.ref("connectomics.models.losses.losses")
+
+    def lr_curve(cls, max_iters, wi, wf, eta):
+        ps = [torch.nn.Parameter(torch.zeros(1)), torch.nn.Parameter(torch.zeros(1))]
+        opt = torch.optim.SGD([{"params": [ps[0]], "lr": 0.1}, {"params": [ps[1]], "lr": 0.02}], lr=0.1)
+        sch = cls(opt, max_iters=max_iters, warmup_factor=wf, warmup_iters=wi, eta_min=eta)
+        seq = []
+        for _ in range(max_iters):
+            seq.append([round(g["lr"], 12) for g in opt.param_groups])
+            opt.step()
+            sch.step()
+        return seq
+    cases = [(rnd.randint(2, 80), rnd.choice([0, 1, 5, 20, 100]), rnd.choice([1e-3, 0.1, 1.0, 0.0]), rnd.choice([0.0, 1e-6, 1e-3])) for _ in range(60)]
+    t.run("WarmupCosineLR per-iteration rates", cases, lambda *c: lr_curve(rl.WarmupCosineLR, *c), lambda *c: lr_curve(om.WarmupCosineLR, *c))
+
+    def model():
+        torch.manual_seed(0)
+        m = torch.nn.Sequential()
+        m.add_module("conv", torch.nn.Conv3d(1, 4, 3))
+        m.add_module("gn", torch.nn.GroupNorm(2, 4))
+        m.add_module("act", torch.nn.PReLU())
+        m.add_module("conv2", torch.nn.Conv3d(4, 4, 1, bias=False))
+        m.add_module("bn", torch.nn.BatchNorm3d(4))
+        m.add_module("ln", torch.nn.LayerNorm(4))
+        m.add_module("head", torch.nn.Conv3d(4, 2, 1))
+        m.add_module("tied", torch.nn.Conv3d(4, 2, 1))
+        m.tied.weight = m.head.weight
+        m.conv2.weight.requires_grad_(False)
+        return m
+
+    def groups(build, oc):
+        m = model()
+        opt = build(NS(optimization=NS(optimizer=NS(**oc))), m)
+        names = {id(p): n for n, p in m.named_parameters()}
+        per = {names[id(p)]: (g["lr"], g["weight_decay"]) for g in opt.param_groups for p in g["params"]}
+        g0 = opt.param_groups[0]
+        return type(opt).__name__, sorted(per.items()), g0.get("betas"), g0.get("eps"), g0.get("momentum")
+    ocs = []
+    for name in ("AdamW", "adamw", "Adam", "SGD", "sgd", "RMSprop", "nonsense"):
+        for _ in range(6):
+            oc = dict(name=name, lr=rnd.choice([1e-3, 2e-4, 0.1]), weight_decay=rnd.choice([0.0, 0.01, 0.05]))
+            if rnd.random() < 0.5:
+                oc.update(weight_decay_norm=rnd.choice([0.0, 0.001]), weight_decay_bias=rnd.choice([0.0, 0.02]), bias_lr_factor=rnd.choice([1.0, 2.0]))
+            if rnd.random() < 0.4:
+                oc.update(betas=[0.8, 0.95], eps=1e-6, momentum=0.8)
+            ocs.append((oc,))
+    t.run("build_optimizer per-parameter (lr, weight_decay)", ocs, lambda oc: groups(rb.build_optimizer, oc), lambda oc: groups(om.build_optimizer, oc))
+
+    g = torch.Generator().manual_seed(77)
+    def loss_digest(fn, shape, weight_kind, pos):
+        x = (torch.randn(*shape, generator=g) * 3).requires_grad_(True)
+        y = (torch.rand(*shape, generator=g) > 0.6).float()
+        w = {None: None, "full": torch.rand(*shape, generator=g), "broadcast": torch.rand(shape[0], 1, *shape[2:], generator=g),
+             "zeros": torch.zeros(*shape)}[weight_kind]
+        v = fn(x, y, w, pos)
+        if v.requires_grad:                 # an all-invalid weight map gives the reference a constant 0 (no graph): gradient 0 either way
+            v.backward()
+        return round(float(v), 6), round(float(x.grad.double().abs().sum()), 6) if x.grad is not None else 0.0
+    shapes = [(2, 1, 4, 5, 6), (1, 3, 3, 4, 4), (2, 2, 6, 6)]
+    lcases = [(sh, wk, pw) for sh in shapes for wk in (None, "full", "broadcast", "zeros") for pw in (None, 2.5)]
+    def ref_bce(x, y, w, pos):
+        return ls.WeightedBCEWithLogitsLoss(pos_weight=None if pos is None else torch.tensor(pos))(x, y, w)
+    def our_bce(x, y, w, pos):
+        return om.weighted_bce_with_logits(x, y, w, None if pos is None else torch.tensor(pos))
+    state = {}
+    def seeded(fn):
+        def run(*c):
+            g.manual_seed(hash(str(c)) % (2 ** 31))
+            return loss_digest(fn, *c)
+        return run
+    t.run("WeightedBCEWithLogitsLoss value + gradient", lcases, seeded(ref_bce), seeded(our_bce))
+    for kind, cls in (("mse", ls.WeightedMSELoss), ("mae", ls.WeightedMAELoss)):
+        t.run(f"Weighted{kind.upper()}Loss value + gradient", [(sh, wk, None) for sh in shapes for wk in (None, "full", "broadcast")],
+              seeded(lambda x, y, w, pos, cls=cls: cls()(x, y, w)), seeded(lambda x, y, w, pos, kind=kind: om.weighted_regression_loss(kind, x, y, w)))
 
 
 def prediction_crops(t, rnd):
