@@ -168,6 +168,7 @@ def main():
     output_transforms(t, rnd)
     training_host_side(t, rnd)
     predictor_orchestration(t, rnd)
+    model_builders(t, rnd)
     total, bad = sum(r[1] for r in t.rows), sum(r[2] for r in t.rows)
     print(f"TOTAL {total} cases, {bad} mismatches over {len(t.rows)} function pairs")
     return bad
@@ -428,6 +429,37 @@ def predictor_orchestration(t, rnd):
         ra, rb = eval(a[1]), eval(b[1])
         return ra[0] == rb[0] and ra[1] == rb[1] == "torch.float16" and all(abs(u - v) <= 2e-3 * max(1.0, abs(u)) for u, v in zip(ra[2:], rb[2:]))
     t.run("TTAPredictor.predict (views, activations, selection, modes, mask)", cases, ref_run, our_run, same=half_precision_close)
+
+
+def model_builders(t, rnd):
+    """`build_rsunet` / `build_rsunet_iso` over generated model configurations: state-dict keys, shapes and dtypes, buffers, the
+    model-info dictionary and constructor errors of the reference RSUNet against this package's (a checkpoint of one loads into the
+    other with strict=True iff these agree).  MedNeXt / MONAI builders need packages the image lacks on the reference side."""
+    rr = S.ref("connectomics.models.architectures.rsunet")
+    import pytorch_connectomics_amd.models.architectures.rsunet as orr
+
+    def describe(mod, builder, cfg):
+        m = getattr(mod, builder)(cfg)
+        sd = m.state_dict()
+        info = m.get_model_info() if hasattr(m, "get_model_info") else {}
+        return (sorted((k, tuple(v.shape), str(v.dtype)) for k, v in sd.items()),
+                {k: info.get(k) for k in ("parameters", "trainable_parameters", "deep_supervision", "output_scales")})
+    widths = [[8, 16], [16, 32, 64, 128], [6, 8, 12], [4], [4, 4, 4, 4, 4], [16, 16]]
+    cases = []
+    for w in widths:
+        for norm in ("batch", "group", "instance", "none", "layer", "weird"):
+            for act in ("relu", "elu", "leaky_relu", "prelu", "gelu", "bogus"):
+                if rnd.random() > 0.35:
+                    continue
+                depth = len(w) - 1
+                down = rnd.choice([None, [[1, 2, 2]] * depth, [[2, 2, 2]] * depth, [[1, 2, 2]] * max(0, depth - 1)])
+                rs = NS(width=w, norm=norm, activation=act, num_groups=rnd.choice([2, 4, 8, 3]), down_factors=down,
+                        depth_2d=rnd.choice([0, 1, 2]), kernel_2d=rnd.choice([None, [1, 3, 3], [1, 5, 5]]),
+                        act_negative_slope=0.05, act_init=0.1)
+                cfg = NS(model=NS(in_channels=rnd.choice([1, 2]), out_channels=rnd.choice([1, 3]), rsunet=rs,
+                                  loss=NS(deep_supervision=rnd.random() < 0.4)))
+                cases.append((rnd.choice(["build_rsunet", "build_rsunet_iso"]), cfg))
+    t.run("build_rsunet / build_rsunet_iso: state dict + model info", cases, lambda b, c: describe(rr, b, c), lambda b, c: describe(orr, b, c))
 
 
 def prediction_crops(t, rnd):
