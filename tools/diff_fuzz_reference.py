@@ -169,6 +169,7 @@ def main():
     training_host_side(t, rnd)
     predictor_orchestration(t, rnd)
     model_builders(t, rnd)
+    lazy_accessor_geometry(t, rnd)
     total, bad = sum(r[1] for r in t.rows), sum(r[2] for r in t.rows)
     print(f"TOTAL {total} cases, {bad} mismatches over {len(t.rows)} function pairs")
     return bad
@@ -460,6 +461,77 @@ def model_builders(t, rnd):
                                   loss=NS(deep_supervision=rnd.random() < 0.4)))
                 cases.append((rnd.choice(["build_rsunet", "build_rsunet_iso"]), cfg))
     t.run("build_rsunet / build_rsunet_iso: state dict + model info", cases, lambda b, c: describe(rr, b, c), lambda b, c: describe(orr, b, c))
+
+
+def lazy_accessor_geometry(t, rnd):
+    """The disk-backed volume reader on generated geometries: the REFERENCE's LazyVolumeAccessor (HDF5 through the in-repo libhdf5
+    shim standing in for h5py, its real smart_normalize / grid_sample path) against this package's accessor (raw storage box + index
+    tables, executed by the numpy restatement of the device kernels, oracle/accessor_oracle.py): shapes, a window that overhangs
+    the volume, the full volume.  Values to 1e-3 of the range (trilinear weights travel through a normalised grid in the reference)."""
+    import tempfile
+    import types
+    import numpy as np
+    from oracle import accessor_oracle as AO
+    from pytorch_connectomics_amd.inference.lazy_accessor import LazyVolumeAccessor
+    from pytorch_connectomics_amd.utils import h5lite
+    if not h5lite.available():
+        print("lazy accessor geometry: skipped (libpytc_h5.so not built)")
+        return
+    sys.modules["h5py"] = h5lite
+    for name in ("imageio", "cv2"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    for name in ("connectomics.data.augmentation.augment_ops", "connectomics.data.io.io", "connectomics.inference.lazy"):
+        sys.modules.pop(name, None)
+    lz = S.ref("connectomics.inference.lazy")
+    rng = np.random.default_rng(11)
+    cases = []
+    with tempfile.TemporaryDirectory() as d:
+        vols = {"u8": (rng.random((9, 11, 13)) * 255).astype(np.uint8), "f32c": rng.random((2, 8, 10, 12)).astype(np.float32),
+                "u16last": (rng.random((8, 9, 10, 3)) * 900).astype(np.uint16)}
+        paths = {}
+        for k, v in vols.items():
+            paths[k] = str(Path(d) / f"{k}.h5")
+            with h5lite.File(paths[k], "w") as fh:
+                fh.create_dataset("main", data=v, compression="gzip")
+        for i in range(70):
+            key = rnd.choice(list(vols))
+            kind = rnd.choice(["image", "image", "mask"])
+            kw = dict(kind=kind)
+            if rnd.random() < 0.5:
+                kw["transpose_axes"] = tuple(rnd.sample([0, 1, 2], 3))
+            if rnd.random() < 0.5:
+                kw["scale_factors"] = tuple(rnd.choice([0.5, 0.75, 1.0, 1.25, 1.5, 2.0]) for _ in range(3))
+            if rnd.random() < 0.6:
+                kw["context_pad"] = tuple((rnd.randint(0, 3), rnd.randint(0, 3)) for _ in range(3))
+                kw["context_pad_mode"] = rnd.choice(["constant", "reflect", "edge", "replicate"]) if kind == "image" else "constant"
+            if kind == "image":
+                kw["normalize_mode"] = rnd.choice(["none", "0-1", "normal", "divide-255", "divide-2.5"])
+                if kw["normalize_mode"] != "none" and rnd.random() < 0.4:
+                    kw["clip_percentile_low"], kw["clip_percentile_high"] = 0.05, 0.95
+            else:
+                kw["binarize"], kw["threshold"] = True, rnd.choice([0.3, 100.0])
+            # windows that overhang the volume but always intersect it (a window entirely outside has no defined result in the
+            # reference: it returns a zero-extent array)
+            loc = tuple(rnd.randint(-2, 2) for _ in range(3))
+            size = tuple(rnd.randint(4, 8) for _ in range(3))
+            outer = rnd.choice(["constant", "reflect", "replicate"])
+            cases.append((paths[key], kw, loc, size, outer))
+
+        def digest(a):
+            a = np.asarray(a, dtype=np.float64)
+            span = max(1.0, float(np.abs(a).max()))
+            return (a.shape, round(float(a.sum()) / span / max(1, a.size) * 1e3), round(float(np.abs(a).sum()) / span / max(1, a.size) * 1e3))
+
+        def ref_run(path, kw, loc, size, outer):
+            with lz.LazyVolumeAccessor(path, **kw) as acc:
+                shapes = [acc.channel_count, *acc.raw_spatial_shape, *acc.logical_spatial_shape, *acc.transformed_spatial_shape, *acc.padded_spatial_shape]
+                return shapes, digest(acc.read_patch(loc, size, outer_pad_mode=outer, outer_pad_value=0.25)), digest(acc.load_full())
+
+        def our_run(path, kw, loc, size, outer):
+            with LazyVolumeAccessor(path, **kw) as acc:
+                shapes = [acc.channel_count, *acc.raw_spatial_shape, *acc.logical_spatial_shape, *acc.transformed_spatial_shape, *acc.padded_spatial_shape]
+                return shapes, digest(AO.read_patch(acc, loc, size, outer_pad_mode=outer, outer_pad_value=0.25)), digest(AO.load_full(acc))
+        t.run("LazyVolumeAccessor geometry (transpose / resize / pad / normalise / window)", cases, ref_run, our_run)
 
 
 def prediction_crops(t, rnd):
