@@ -170,6 +170,7 @@ def main():
     predictor_orchestration(t, rnd)
     model_builders(t, rnd)
     lazy_accessor_geometry(t, rnd)
+    lazy_engine(t, rnd)
     total, bad = sum(r[1] for r in t.rows), sum(r[2] for r in t.rows)
     print(f"TOTAL {total} cases, {bad} mismatches over {len(t.rows)} function pairs")
     return bad
@@ -532,6 +533,96 @@ def lazy_accessor_geometry(t, rnd):
                 shapes = [acc.channel_count, *acc.raw_spatial_shape, *acc.logical_spatial_shape, *acc.transformed_spatial_shape, *acc.padded_spatial_shape]
                 return shapes, digest(AO.read_patch(acc, loc, size, outer_pad_mode=outer, outer_pad_value=0.25)), digest(AO.load_full(acc))
         t.run("LazyVolumeAccessor geometry (transpose / resize / pad / normalise / window)", cases, ref_run, our_run)
+
+
+def lazy_engine(t, rnd):
+    """The lazy region / volume engine end to end on generated configurations (blending mode, per-axis overlap, snapped grids, target
+    context, regions, per-window TTA, mask volumes, activations, channel selection): the REFERENCE's lazy loop on numpy-backed
+    accessors against this package's loop with the device kernels replaced by torch stand-ins (tests/test_host_lazy_tta.py)."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, str(ROOT / "tests"))
+    import test_host_lazy_tta as L
+    import pytorch_connectomics_amd.inference.lazy as ol
+    import pytorch_connectomics_amd.inference.tta as otta
+    import pytorch_connectomics_amd.inference.tta_ensemble as oens
+    ol.ops = otta.ops = oens.ops = L._Ops
+    for name in ("connectomics.inference.lazy",):
+        sys.modules.pop(name, None)
+    lz = S.ref("connectomics.inference.lazy")
+    rng = np.random.default_rng(19)
+    vol = rng.random((1, 14, 22, 26), dtype=np.float32)
+    mask = (rng.random((1, 14, 22, 26)) > 0.4).astype(np.float32)
+
+    class Fake:
+        def __init__(self, v, kind):
+            self.vol, self.kind = v, kind
+            self.padded_spatial_shape, self.channel_count = tuple(v.shape[1:]), v.shape[0]
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def close(self):
+            pass
+
+        def read_patch(self, location, patch_size, *, outer_pad_mode, outer_pad_value):
+            start = tuple(int(v) for v in location)
+            end = tuple(start[i] + int(patch_size[i]) for i in range(3))
+            shp = self.padded_spatial_shape
+            lo = tuple(max(0, start[i]) for i in range(3))
+            hi = tuple(min(shp[i], end[i]) for i in range(3))
+            pads = [(max(0, -start[i]), max(0, end[i] - shp[i])) for i in range(3)]
+            return lz._pad_channel_first(self.vol[:, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]], pads, mode=outer_pad_mode, constant_value=outer_pad_value)
+    lz._build_accessor = lambda cfg_, path, kind, mode: Fake(mask if kind == "mask" else vol, kind)
+
+    def net(x):
+        ramp = torch.linspace(0, 1, x.shape[-1]).view(1, 1, 1, 1, -1)
+        shifted = torch.zeros_like(x)
+        shifted[..., 1:, :, :] = x[..., :-1, :, :]
+        return torch.cat([2 * x - 1 + ramp, 0.5 * x + shifted], 1)
+    cases = []
+    for _ in range(70):
+        roi = rnd.choice([(6, 8, 8), (4, 6, 10), (8, 8, 8), (5, 7, 9)])
+        ctx = rnd.choice([[], [], [1, 1, 1], [0, 2, 1]])
+        tta = rnd.random() < 0.5
+        kw = dict(roi=roi, blending=rnd.choice(["bump", "constant", "gaussian", "distance_transform"]),
+                  overlap=rnd.choice([0.5, 0.25, 0.0, [0.25, 0.5, 0.5]]), snap=rnd.random() < 0.4, ctx=ctx,
+                  padding_mode=rnd.choice(["constant", "reflect", "replicate"]), swb=rnd.choice([1, 3, 4]),
+                  acts=rnd.choice([None, [{"channels": "0", "activation": "sigmoid"}], [{"channels": ":", "activation": "tanh"}]]),
+                  select=rnd.choice([None, [1], "0:1"]), tta=tta, flips=rnd.choice(["all", [[0]], [[1, 2]]]) if tta else None,
+                  mode=rnd.choice(["mean", "min", "max"]))
+        region = None
+        if rnd.random() < 0.4:
+            lo = tuple(rnd.randint(0, d - 3) for d in vol.shape[1:])
+            region = (lo, tuple(rnd.randint(l + 2, d) for l, d in zip(lo, vol.shape[1:])))
+        cases.append((kw, region, rnd.random() < 0.4))
+
+    def cfg_of(kw):
+        return NS(model=NS(primary_head=None, heads=None, out_channels=2, output_size=list(kw["roi"])), system=NS(num_workers=0),
+                  data=NS(train=NS(do_2d=False), val=NS(do_2d=False), dataloader=NS(batch_size=1, use_lazy_zarr=False, use_lazy_h5=False), label_transform=None),
+                  inference=NS(sliding_window=NS(window_size=list(kw["roi"]), sw_batch_size=kw["swb"], overlap=kw["overlap"], blending=kw["blending"],
+                                                 padding_mode=kw["padding_mode"], cval=0.0, keep_input_on_cpu=False, sw_device=None, output_device=None,
+                                                 border_mask=[], distributed_sharding=False, snap_to_edge=kw["snap"], target_context=list(kw["ctx"]),
+                                                 distributed_reduce_chunk_mb=128),
+                               model=NS(head=None, select_channel=kw["select"], output_dtype=None, channel_activations=kw["acts"], crop_pad=None),
+                               test_time_augmentation=NS(enabled=kw["tta"], distributed_sharding=False, flip_axes=kw["flips"], rotation90_axes=None,
+                                                         rotate90_k=None, ensemble_mode=kw["mode"], patch_first_local=True, apply_mask=True,
+                                                         empty_cache_interval=0)))
+
+    def run(mod, source, mask_arg, kw, region, use_mask):
+        cfg = cfg_of(kw)
+        extra = dict(mask_path=mask_arg if use_mask else None, device="cpu")
+        if region is None:
+            y = mod.lazy_predict_volume(cfg, net, source, **extra)
+        else:
+            y = mod.lazy_predict_region(cfg, net, source, region_start=region[0], region_stop=region[1], **extra)
+        return _tensor_digest(y, 3)
+    t.run("lazy engine end to end (grid, blending, context, regions, TTA, masks)", cases,
+          lambda kw, region, use_mask: run(lz, "fake://", "fake://mask", kw, region, use_mask),
+          lambda kw, region, use_mask: run(ol, vol, mask, kw, region, use_mask))
 
 
 def prediction_crops(t, rnd):
