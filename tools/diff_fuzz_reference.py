@@ -171,6 +171,7 @@ def main():
     model_builders(t, rnd)
     lazy_accessor_geometry(t, rnd)
     lazy_engine(t, rnd)
+    chunked_runner(t, rnd)
     total, bad = sum(r[1] for r in t.rows), sum(r[2] for r in t.rows)
     print(f"TOTAL {total} cases, {bad} mismatches over {len(t.rows)} function pairs")
     return bad
@@ -623,6 +624,108 @@ def lazy_engine(t, rnd):
     t.run("lazy engine end to end (grid, blending, context, regions, TTA, masks)", cases,
           lambda kw, region, use_mask: run(lz, "fake://", "fake://mask", kw, region, use_mask),
           lambda kw, region, use_mask: run(ol, vol, mask, kw, region, use_mask))
+
+
+def chunked_runner(t, rnd):
+    """`run_chunked_prediction_inference` end to end on generated chunk geometries (chunk size, halo, z slabs, global crop, per-window
+    TTA, mask volume, prediction transform / storage dtype): the reference runner (streams into one HDF5 through the libhdf5 shim)
+    against this package's (chunk files + stitch; device kernels replaced by the torch stand-ins) -- the stitched `main` array."""
+    import tempfile
+    import types
+    import numpy as np
+    import torch
+    from pytorch_connectomics_amd.utils import h5lite
+    if not h5lite.available():
+        print("chunked runner: skipped (libpytc_h5.so not built)")
+        return
+    sys.path.insert(0, str(ROOT / "tests"))
+    import test_host_lazy_tta as L
+    import pytorch_connectomics_amd.inference.chunked as oc
+    import pytorch_connectomics_amd.inference.lazy as ol
+    import pytorch_connectomics_amd.inference.tta as otta
+    import pytorch_connectomics_amd.inference.tta_ensemble as oens
+    ol.ops = otta.ops = oens.ops = L._Ops
+    sys.modules["h5py"] = h5lite
+    for name in ("imageio", "cv2"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    for name in ("connectomics.data.io.io", "connectomics.data.augmentation.augment_ops", "connectomics.inference.lazy", "connectomics.inference.chunked"):
+        sys.modules.pop(name, None)
+    rc, lz = S.ref("connectomics.inference.chunked"), S.ref("connectomics.inference.lazy")
+    rng = np.random.default_rng(23)
+    vol = rng.random((1, 14, 22, 26), dtype=np.float32)
+    mask = (rng.random((1, 14, 22, 26)) > 0.4).astype(np.float32)
+
+    class Fake:
+        def __init__(self, v, kind):
+            self.vol, self.kind = v, kind
+            self.padded_spatial_shape = self.transformed_spatial_shape = tuple(v.shape[1:])
+            self.channel_count = v.shape[0]
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def close(self):
+            pass
+
+        def read_patch(self, location, patch_size, *, outer_pad_mode, outer_pad_value):
+            start = tuple(int(v) for v in location)
+            end = tuple(start[i] + int(patch_size[i]) for i in range(3))
+            shp = self.padded_spatial_shape
+            lo = tuple(max(0, start[i]) for i in range(3))
+            hi = tuple(min(shp[i], end[i]) for i in range(3))
+            pads = [(max(0, -start[i]), max(0, end[i] - shp[i])) for i in range(3)]
+            return lz._pad_channel_first(self.vol[:, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]], pads, mode=outer_pad_mode, constant_value=outer_pad_value)
+    lz._build_accessor = lambda cfg_, path, kind, mode: Fake(mask if kind == "mask" else vol, kind)
+
+    def net(x):
+        ramp = torch.linspace(0, 1, x.shape[-1]).view(1, 1, 1, 1, -1)
+        return torch.cat([2 * x - 1 + ramp, 0.5 * x + x.mean(dim=(2, 3, 4), keepdim=True)], 1)
+
+    def cfg_of(kw):
+        roi = kw["roi"]
+        return NS(model=NS(primary_head=None, heads=None, out_channels=2, output_size=list(roi)), system=NS(num_workers=0),
+                  data=NS(train=NS(do_2d=False), val=NS(do_2d=False), dataloader=NS(batch_size=1, use_lazy_zarr=False, use_lazy_h5=False, patch_size=None),
+                          label_transform=None),
+                  inference=NS(save_backend="h5", save_compression="gzip",
+                               sliding_window=NS(window_size=list(roi), sw_batch_size=3, overlap=0.5, blending=kw["blending"], padding_mode="reflect", cval=0.0,
+                                                 keep_input_on_cpu=False, sw_device=None, output_device=None, border_mask=[], distributed_sharding=False,
+                                                 snap_to_edge=False, target_context=[], distributed_reduce_chunk_mb=128),
+                               model=NS(head=None, select_channel=kw["select"], output_dtype=None, channel_activations=[{"channels": "0", "activation": "sigmoid"}],
+                                        crop_pad=kw["crop"]),
+                               prediction_transform=NS(enabled=kw["scale"] is not None, intensity_scale=kw["scale"] or -1.0, intensity_dtype=kw["idt"]),
+                               save_dtype=kw["sdt"],
+                               chunking=NS(enabled=True, chunk_size=list(kw["chunk"]), halo=list(kw["halo"]), axes=kw["axes"], output_mode="raw_prediction",
+                                           shard_id=None, num_shards=None, roi=None, temp_dir="", save_intermediate=False, precomputed=False),
+                               test_time_augmentation=NS(enabled=kw["flips"] is not None, distributed_sharding=False, flip_axes=kw["flips"], rotation90_axes=None,
+                                                         rotate90_k=None, ensemble_mode="mean", patch_first_local=True, apply_mask=True, empty_cache_interval=0)))
+    cases = []
+    for _ in range(40):
+        cases.append((dict(roi=rnd.choice([(6, 8, 8), (4, 6, 10)]), blending=rnd.choice(["bump", "constant"]), select=rnd.choice([None, [1]]),
+                           crop=rnd.choice([None, None, [[1, 0], [2, 1], [0, 3]]]), scale=rnd.choice([None, 255.0]), idt=rnd.choice([None, "uint8"]),
+                           sdt=rnd.choice([None, "float16"]), chunk=(rnd.randint(3, 16), rnd.randint(4, 24), rnd.randint(4, 28)),
+                           halo=(rnd.randint(0, 3), rnd.randint(0, 4), rnd.randint(0, 4)), axes=rnd.choice(["all", "all", "z"]),
+                           flips=rnd.choice([None, None, [[0]], [[1, 2]]])), rnd.random() < 0.35))
+
+    def digest(a):
+        a = np.asarray(a)
+        return (a.shape, str(a.dtype), round(float(a.astype(np.float64).sum()), 2), float(a.min()), float(a.max()))
+
+    def ref_run(kw, use_mask):
+        with tempfile.TemporaryDirectory() as d:
+            out = rc.run_chunked_prediction_inference(cfg_of(kw), net, "fake://", output_path=Path(d) / "pred.h5", device="cpu",
+                                                      mask_path="fake://mask" if use_mask else None)
+            with h5lite.File(str(out), "r") as fh:
+                return digest(fh["main"][...])
+
+    def our_run(kw, use_mask):
+        with tempfile.TemporaryDirectory() as d:
+            out = oc.run_chunked_prediction_inference(cfg_of(kw), net, image_path=vol, output_path=Path(d) / "pred.h5", device="cpu",
+                                                      mask_path=mask if use_mask else None)
+            return digest(out)
+    t.run("run_chunked_prediction_inference (chunk geometry, crop, TTA, mask, dtypes)", cases, ref_run, our_run)
 
 
 def prediction_crops(t, rnd):
