@@ -704,7 +704,7 @@ def chunked_runner(t, rnd):
     cases = []
     for _ in range(40):
         cases.append((dict(roi=rnd.choice([(6, 8, 8), (4, 6, 10)]), blending=rnd.choice(["bump", "constant"]), select=rnd.choice([None, [1]]),
-                           crop=rnd.choice([None, None, [[1, 0], [2, 1], [0, 3]]]), scale=rnd.choice([None, 255.0]), idt=rnd.choice([None, "uint8"]),
+                           crop=rnd.choice([None, None, [1, 0, 2, 1, 0, 3], [1, 1, 2]]), scale=rnd.choice([None, 255.0]), idt=rnd.choice([None, "uint8"]),
                            sdt=rnd.choice([None, "float16"]), chunk=(rnd.randint(3, 16), rnd.randint(4, 24), rnd.randint(4, 28)),
                            halo=(rnd.randint(0, 3), rnd.randint(0, 4), rnd.randint(0, 4)), axes=rnd.choice(["all", "all", "z"]),
                            flips=rnd.choice([None, None, [[0]], [[1, 2]]])), rnd.random() < 0.35))
