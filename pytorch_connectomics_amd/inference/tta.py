@@ -359,6 +359,23 @@ class TTAPredictor:
     def predict(self, images: torch.Tensor, mask=None, mask_align_to_image: bool = False,
                 requested_head: Optional[str] = None) -> torch.Tensor:
         images = self._normalize_input(images)
+        if images.shape[0] > 1:
+            # a batch of volumes: one after the other through the single-volume engine (the reference's patch-first loop also walks
+            # the batch sample by sample, tta.py:942-944); a mask with a matching batch axis is split along with it
+            whole = None
+            if mask is not None:
+                try:
+                    whole = self._coerce_mask_to_tensor(mask)
+                except TypeError:
+                    whole = None
+            def mask_of(b):
+                if whole is None:
+                    return mask
+                batched = whole.dim() >= images.dim() - 1 and whole.shape[0] == images.shape[0]
+                return whole[b:b + 1] if batched else whole
+            parts = [self.predict(images[b:b + 1], mask=mask_of(b), mask_align_to_image=mask_align_to_image,
+                                  requested_head=requested_head) for b in range(images.shape[0])]
+            return torch.cat(parts, 0) if all(p.numel() for p in parts) else parts[0]
         flat2d = self._is_flat_2d(images)
         if flat2d and isinstance(mask, torch.Tensor) and mask.dim() == 4:
             mask = mask.unsqueeze(2)                        # (B, C, H, W) -> the depth-1 volume the result is masked as

@@ -432,6 +432,19 @@ def predictor_orchestration(t, rnd):
         ra, rb = eval(a[1]), eval(b[1])
         return ra[0] == rb[0] and ra[1] == rb[1] == "torch.float16" and all(abs(u - v) <= 2e-3 * max(1.0, abs(u)) for u, v in zip(ra[2:], rb[2:]))
     t.run("TTAPredictor.predict (views, activations, selection, modes, mask)", cases, ref_run, our_run, same=half_precision_close)
+    # a batch of two volumes (sample-wise masks), a subset of the configurations
+    xb = torch.rand(2, 1, 6, 10, 10, generator=g)
+    mb = (torch.rand(2, 1, 6, 10, 10, generator=g) > 0.4).float()
+
+    def ref_batch(a, sel, m, f, r, use_mask, odt):
+        p = rtta.TTAPredictor(cfg=cfg_of(a, sel, m, f, r, odt), sliding_inferer=None, forward_fn=net)
+        return _tensor_digest(p.predict(xb.clone(), mask=mb if use_mask else None), 4)
+
+    def our_batch(a, sel, m, f, r, use_mask, odt):
+        p = otta.TTAPredictor(cfg=cfg_of(a, sel, m, f, r, odt), sliding_inferer=Engine(tuple(xb.shape[2:])), forward_fn=net)
+        p._engine_network = lambda: net
+        return _tensor_digest(p.predict(xb.clone(), mask=mb if use_mask else None), 4)
+    t.run("TTAPredictor.predict on a batch of two volumes", cases[::6], ref_batch, our_batch, same=half_precision_close)
 
 
 def model_builders(t, rnd):
