@@ -105,6 +105,37 @@ def auto_pos_weight_scalar(target, mask=None, cap: float = 10.0) -> torch.Tensor
     return torch.where((pos > 0) & (neg > 0), ratio, torch.ones_like(ratio)).reshape(1)
 
 
+def class_balance_weight(target: torch.Tensor, pos_weight=None, valid_mask=None, cap: float = 10.0) -> torch.Tensor:
+    """The spatial weight map the reference's orchestrator hands to every `weight`-taking loss except the weighted BCE when a term
+    carries no mask of its own (orchestrator.py:129-178, :606-612).  `pos_weight` None / "auto": foreground (target > 0) and
+    background weights in the ratio neg : pos, scaled so that the valid voxels average 1, each capped at `cap`; ones when a class
+    is absent.  A number: that weight on the foreground, 1 elsewhere.  Counts stay on the device (no host synchronisation)."""
+    t = target
+    ones = torch.ones_like(t)
+    if pos_weight is not None and not isinstance(pos_weight, str):
+        fg = float(pos_weight)
+        if fg <= 0:
+            raise ValueError(f"pos_weight must be > 0, got {fg}")
+        return torch.where(t > 0, ones * fg, ones)
+    if isinstance(pos_weight, str) and pos_weight != "auto":
+        raise ValueError(f"Unsupported pos_weight mode: {pos_weight!r}. Expected a positive number or 'auto'.")
+    valid = torch.ones_like(t, dtype=torch.bool) if valid_mask is None else (valid_mask > 0).expand_as(t)
+    pos = ((t > 0) & valid).sum().to(t.dtype if t.is_floating_point() else torch.float32)
+    neg = ((t <= 0) & valid).sum().to(pos.dtype)
+    both = (pos > 0) & (neg > 0)
+    count = pos + neg
+    fg = torch.clamp(count / (2.0 * pos.clamp_min(1.0)), max=float(cap))
+    bg = torch.clamp(count / (2.0 * neg.clamp_min(1.0)), max=float(cap))
+    balanced = torch.where(t > 0, ones * fg, ones * bg)
+    return torch.where(both, balanced, ones)
+
+
+# losses whose spatial argument is a WEIGHT map (reference models/losses/metadata.py:38-48); every other loss sees a mask as
+# "logits at the clamp minimum, target 0" outside it
+_WEIGHT_TAKING = {"SmoothL1Loss", "WeightedBCEWithLogitsLoss", "PerChannelBCEWithLogitsLoss", "WeightedMSELoss", "WeightedMAELoss"}
+_OWN_CLASS_BALANCE = {"WeightedBCEWithLogitsLoss", "PerChannelBCEWithLogitsLoss"}      # pos_weight defaults to 1 there (plan.py:105-112)
+
+
 def per_channel_bce_with_logits(logits, target, weight=None, *, auto_pos_weight: bool = True, max_pos_weight: float = 10.0,
                                 reduction: str = "mean"):
     """models/losses/losses.py:269-351: BCE per channel with its own class-balancing weight min(n_neg / n_pos, max_pos_weight)
@@ -198,8 +229,10 @@ _LOSSES = {
         p, t, kw.get("weight"), auto_pos_weight=bool(kw.get("auto_pos_weight", True)),
         max_pos_weight=float(kw.get("max_pos_weight", 10.0)), reduction=str(kw.get("reduction", "mean"))),
     "WeightedBCEWithLogitsLoss": lambda p, t, **kw: weighted_bce_with_logits(p, t, kw.get("weight"), kw.get("pos_weight")),
-    "BCEWithLogitsLoss": lambda p, t, **kw: weighted_bce_with_logits(p, t, kw.get("weight")),
-    "MSELoss": lambda p, t, **kw: F.mse_loss(p.float(), t.float()),
+    # torch's own losses take no spatial argument: a mask reaches them as "logit at the clamp minimum, target 0" outside it
+    "BCEWithLogitsLoss": lambda p, t, **kw: F.binary_cross_entropy_with_logits(
+        *(v.float() for v in _mask_for_unweighted_loss(p, t, kw.get("weight"), kw.get("clamp_min", -20.0)))),
+    "MSELoss": lambda p, t, **kw: F.mse_loss(*(v.float() for v in _mask_for_unweighted_loss(p, t, kw.get("weight"), kw.get("clamp_min", -20.0)))),
 }
 
 
@@ -373,9 +406,22 @@ class ConnectomicsModule(nn.Module):
             fn = get("function")
             if fn not in _LOSSES:
                 raise ValueError(f"Unknown loss function {fn!r}; available: {sorted(_LOSSES)}")
-            self.loss_terms.append({"fn": fn, "weight": float(get("weight", 1.0)), "pred_head": get("pred_head"),
-                                    "pred_slice": get("pred_slice"),
-                                    "target_slice": get("target_slice"), "pos_weight": get("pos_weight"),
+            pos_weight = get("pos_weight")
+            if isinstance(pos_weight, str):
+                if pos_weight.strip().lower() != "auto":
+                    raise ValueError(f"losses[{len(self.loss_terms)}] pos_weight must be a positive number or 'auto', got {pos_weight!r}")
+                pos_weight = "auto"
+            elif pos_weight is not None and float(pos_weight) <= 0:
+                raise ValueError(f"losses[{len(self.loss_terms)}] pos_weight must be > 0, got {float(pos_weight)}")
+            if pos_weight is not None and fn not in _WEIGHT_TAKING:
+                raise ValueError(f"losses[{len(self.loss_terms)}] pos_weight is only supported for losses with "
+                                 f"spatial_weight_arg='weight' (got {fn})")
+            # the reference's spellings (training/losses/plan.py:126-147): coefficient = weight, pred / target / mask = *_slice
+            self.loss_terms.append({"fn": fn, "weight": float(get("coefficient", get("weight", 1.0))), "pred_head": get("pred_head"),
+                                    "pred_slice": get("pred_slice", get("pred")),
+                                    "target_slice": get("target_slice", get("target")), "pos_weight": pos_weight,
+                                    "mask_slice": get("mask_slice", get("mask")),
+                                    "apply_deep_supervision": bool(get("apply_deep_supervision", True)),
                                     "kwargs": dict(get("kwargs", None) or {})})
         # adaptive loss balancing (uncertainty / GradNorm, reference training/losses/balancing.py) is outside the hot path this
         # package replaces: static term weights only, anything else is refused up front
@@ -401,7 +447,7 @@ class ConnectomicsModule(nn.Module):
     def _term_is_fusable(self, t, pred) -> bool:
         """The fused kernel computes mean-reduced BCE-with-logits (numeric pos_weight) and sigmoid Dice with MONAI's default
         smoothing over all channels; any other variant of those terms takes the generic path."""
-        if t["fn"] not in self._FUSABLE:
+        if t["fn"] not in self._FUSABLE or t.get("mask_slice") is not None:
             return False
         kw = t["kwargs"]
         if self._FUSABLE[t["fn"]] == "bce":
@@ -446,7 +492,10 @@ class ConnectomicsModule(nn.Module):
         """Weighted sum of the loss terms `terms` (list of (index, term); default: all) on one prediction tensor."""
         terms = list(enumerate(self.loss_terms)) if terms is None else terms
         pred = torch.clamp(pred, min=self.clamp_min, max=self.clamp_max)
-        if pred.is_cuda and self.fused_loss and all(self._term_is_fusable(t, pred) for _, t in terms):
+        # (torch's BCEWithLogitsLoss under a mask averages over ALL voxels -- masked ones as logit -20 / target 0 --, which the fused
+        # kernel's valid-voxel mean is not)
+        plain_bce_masked = mask is not None and any(t["fn"] == "BCEWithLogitsLoss" for _, t in terms)
+        if pred.is_cuda and self.fused_loss and not plain_bce_masked and all(self._term_is_fusable(t, pred) for _, t in terms):
             res = self._fused_term_loss(pred, target, mask, terms)      # finiteness is checked where fit() reads the value
             if res is not None:
                 return res
@@ -457,7 +506,29 @@ class ConnectomicsModule(nn.Module):
                 p = pred[:, resolve_channel_indices(t["pred_slice"], num_channels=pred.shape[1], context="pred_slice")]
             if t["target_slice"] is not None:
                 y = target[:, resolve_channel_indices(t["target_slice"], num_channels=target.shape[1], context="target_slice")]
-            v = _LOSSES[t["fn"]](p, y, weight=mask, pos_weight=t["pos_weight"], clamp_min=self.clamp_min, **t["kwargs"])
+            # what the loss sees as its spatial argument (reference orchestrator.py:566-646): a term's own mask channels
+            # (`mask_slice` of the labels) x the batch mask; a `weight`-taking loss without a mask of its own gets the
+            # class-balancing map instead (not the weighted BCE, whose pos_weight is a scalar of its own)
+            own = None
+            if t.get("mask_slice") is not None:
+                own = target[:, resolve_channel_indices(t["mask_slice"], num_channels=target.shape[1], context="mask_slice")]
+            valid = own if mask is None else (mask if own is None else own * mask)
+            fn = t["fn"]
+            if fn in _WEIGHT_TAKING:
+                spatial = own
+                if spatial is None and fn != "WeightedBCEWithLogitsLoss":
+                    spatial = class_balance_weight(y, 1.0 if (t["pos_weight"] is None and fn in _OWN_CLASS_BALANCE) else t["pos_weight"],
+                                                   valid_mask=valid)
+                if mask is not None:
+                    spatial = mask if spatial is None else spatial * mask
+                pw = t["pos_weight"] if fn == "WeightedBCEWithLogitsLoss" else None
+                if isinstance(pw, str):
+                    pw = auto_pos_weight_scalar(y, valid)
+                elif pw is not None and float(pw) == 1.0:
+                    pw = None
+                v = _LOSSES[fn](p, y, weight=spatial, pos_weight=pw, clamp_min=self.clamp_min, **t["kwargs"])
+            else:
+                v = _LOSSES[fn](p, y, weight=valid, pos_weight=None, clamp_min=self.clamp_min, **t["kwargs"])
             if not torch.isfinite(v):
                 raise FloatingPointError(f"loss term {t['fn']} is not finite")
             parts[f"loss_{i}_{t['fn']}"] = v.detach()
@@ -514,7 +585,10 @@ class ConnectomicsModule(nn.Module):
                     continue
                 tgt = match_target_to_output(labels, ds)
                 m = None if mask is None else resize_class_index_to_output(mask, ds)
-                li, _ = self._term_loss(ds, tgt, m)
+                on_scales = [(j, t) for j, t in enumerate(self.loss_terms) if t.get("apply_deep_supervision", True)]
+                if not on_scales:
+                    continue
+                li, _ = self._term_loss(ds, tgt, m, on_scales)
                 total = total + self.ds_weights[i] * li
         parts["train_loss_total"] = total.detach()
         return total, parts

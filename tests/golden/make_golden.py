@@ -1124,6 +1124,47 @@ def ds_loss():
     save("ds_loss.npz", **out)
 
 
+def loss_orchestration():
+    """connectomics/training/losses/orchestrator.py:500-890 + plan.py: the training loss as the reference's LossOrchestrator assembles
+    it for the term lists of tests/loss_cases.py -- class-balancing weight maps for `weight`-taking losses, term masks, pos_weight
+    spellings, batch masks, deep supervision, terms skipped on the deep-supervision scales -> tests/golden/loss_orchestration.npz
+    (total loss and the gradient of every output scale)."""
+    import warnings
+    warnings.filterwarnings("ignore")
+    sys.path.insert(0, str(HERE.parent))
+    from loss_cases import CASES, loss_cfg, loss_tensors
+    S._stub_pkg("connectomics.training.losses")
+    S._stub_pkg("connectomics.config.pipeline")
+    meta = S.ref("connectomics.models.losses.metadata")
+    ml = sys.modules["connectomics.models.losses"]
+    for n in dir(meta):
+        if not n.startswith("_"):
+            setattr(ml, n, getattr(meta, n))
+    ls = S.ref("connectomics.models.losses.losses")
+    orch = S.ref("connectomics.training.losses.orchestrator")
+    make = {"WeightedBCEWithLogitsLoss": ls.WeightedBCEWithLogitsLoss, "WeightedMSELoss": ls.WeightedMSELoss, "WeightedMAELoss": ls.WeightedMAELoss,
+            "SmoothL1Loss": ls.SmoothL1Loss, "PerChannelBCEWithLogitsLoss": ls.PerChannelBCEWithLogitsLoss,
+            "BCEWithLogitsLoss": torch.nn.BCEWithLogitsLoss, "MSELoss": torch.nn.MSELoss}
+    out = {}
+    for index, (label, terms, ds, use_mask) in enumerate(CASES):
+        mods = torch.nn.ModuleList([make[t["function"]](**dict(t.get("kwargs", {}))) for t in terms])
+        o = orch.LossOrchestrator(loss_cfg(terms, ds), mods, [float(t.get("coefficient", t.get("weight", 1.0))) for t in terms],
+                                  enable_nan_detection=False, debug_on_nan=False, resolve_affinity_mode_fn=lambda c: None)
+        outs, lab, mask = loss_tensors(index)
+        outs = {k: v.requires_grad_(True) for k, v in outs.items()}
+        if ds:
+            total, _ = o.compute_deep_supervision_loss(outs, lab, stage="train", mask=mask if use_mask else None)
+        else:
+            total, _ = o.compute_standard_loss(outs["output"], lab, stage="train", mask=mask if use_mask else None)
+        total.backward()
+        out[f"{label}__total"] = np.float64(total.item())
+        for k, v in outs.items():
+            if v.grad is not None:
+                out[f"{label}__grad_{k}"] = v.grad.numpy().copy()
+        print(label, float(total))
+    save("loss_orchestration.npz", **out)
+
+
 def losses_extra():
     """models/losses/losses.py:269-351 PerChannelBCEWithLogitsLoss (per-channel class balancing, capped ratio, a channel without
     positives, valid-mask weights) values + gradients, and the orchestrator's scalar `pos_weight: auto`
@@ -1173,7 +1214,7 @@ def losses_extra():
 
 if __name__ == "__main__":
     parts = {"manifests": manifests, "optimizers": optimizers, "schedules": schedules, "selectors": selectors, "outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
-             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "lazy_tta": lazy_tta, "masks": masks, "accessor": accessor, "accessor_tiles": accessor_tiles, "ds_loss": ds_loss, "losses_extra": losses_extra, "public_adapters": public_adapters, "public_helpers": public_helpers}
+             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "lazy_tta": lazy_tta, "masks": masks, "accessor": accessor, "accessor_tiles": accessor_tiles, "ds_loss": ds_loss, "loss_orchestration": loss_orchestration, "losses_extra": losses_extra, "public_adapters": public_adapters, "public_helpers": public_helpers}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:
         parts[name]()

@@ -8,6 +8,9 @@ from types import SimpleNamespace as NS
 import numpy as np
 import pytest
 import torch
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent))
 import torch.multiprocessing as mp
 import torch.nn as nn
 import torch.nn.functional as F
@@ -511,3 +514,31 @@ def test_adaptive_loss_balancing_is_refused():
             ConnectomicsModule(cfg, model=SimpleModel())
     cfg.model.loss.loss_balancing = {"strategy": "none"}
     assert ConnectomicsModule(cfg, model=SimpleModel()).fused_loss
+
+
+def test_loss_orchestration_matches_reference_orchestrator_fixture():
+    """tests/golden/loss_orchestration.npz (make_golden.py --loss_orchestration): the reference's LossOrchestrator on the term lists
+    of tests/loss_cases.py.  What it pins beyond the per-loss fixtures: a `weight`-taking regression loss (WeightedMSE / MAE /
+    SmoothL1) gets a CLASS-BALANCING weight map by default (foreground : background = neg : pos, mean 1, capped at 10; a numeric
+    pos_weight = that weight on the foreground), a term's own `mask_slice` replaces it, the weighted BCE keeps a scalar pos_weight,
+    torch's own BCE / MSE see masks through their inputs, `apply_deep_supervision: false` keeps a term off the coarser scales,
+    `coefficient` / `pred` / `target` / `mask` are accepted spellings."""
+    from loss_cases import CASES, loss_cfg, loss_tensors
+    g = np.load(GOLD / "loss_orchestration.npz")
+    for index, (label, terms, ds, use_mask) in enumerate(CASES):
+        m = ConnectomicsModule(loss_cfg(terms, ds), model=SimpleModel())
+        outs, lab, mask = loss_tensors(index)
+        outs = {k: v.requires_grad_(True) for k, v in outs.items()}
+        total, _ = m._compute_loss(outs if ds else outs["output"], lab, mask if use_mask else None)
+        total.backward()
+        assert float(total) == pytest.approx(float(g[f"{label}__total"]), rel=3e-6), label
+        for k, v in outs.items():
+            key = f"{label}__grad_{k}"
+            if key in g.files:
+                assert torch.allclose(v.grad, torch.from_numpy(g[key]), rtol=2e-5, atol=1e-8), (label, k)
+            else:
+                assert v.grad is None or float(v.grad.abs().sum()) == 0.0, (label, k)
+    with pytest.raises(ValueError, match="pos_weight is only supported for losses with spatial_weight_arg='weight'"):
+        ConnectomicsModule(loss_cfg([{"function": "DiceLoss", "weight": 1.0, "pos_weight": 2.0}], False), model=SimpleModel())
+    with pytest.raises(ValueError, match="pos_weight must be a positive number or 'auto'"):
+        ConnectomicsModule(loss_cfg([{"function": "WeightedMSELoss", "weight": 1.0, "pos_weight": "balanced"}], False), model=SimpleModel())

@@ -172,6 +172,7 @@ def main():
     lazy_accessor_geometry(t, rnd)
     lazy_engine(t, rnd)
     chunked_runner(t, rnd)
+    loss_orchestration(t, rnd)
     total, bad = sum(r[1] for r in t.rows), sum(r[2] for r in t.rows)
     print(f"TOTAL {total} cases, {bad} mismatches over {len(t.rows)} function pairs")
     return bad
@@ -739,6 +740,101 @@ def chunked_runner(t, rnd):
                                                       mask_path=mask if use_mask else None)
             return digest(out)
     t.run("run_chunked_prediction_inference (chunk geometry, crop, TTA, mask, dtypes)", cases, ref_run, our_run)
+
+
+def loss_orchestration(t, rnd):
+    """The training loss as the reference's LossOrchestrator assembles it (training/losses/orchestrator.py:500-890, plan.py) against
+    ConnectomicsModule._compute_loss (unfused path, CPU tensors): term lists over the torch-only losses with coefficients, pred /
+    target / mask slices, pos_weight (default, 'auto', numeric), batch masks, deep supervision and `apply_deep_supervision` --
+    total loss and the gradient of every output scale."""
+    import warnings
+    import torch
+    warnings.filterwarnings("ignore")
+    S._stub_pkg("connectomics.training.losses")
+    S._stub_pkg("connectomics.config.pipeline")
+    meta = S.ref("connectomics.models.losses.metadata")
+    ml = sys.modules["connectomics.models.losses"]
+    for n in dir(meta):
+        if not n.startswith("_"):
+            setattr(ml, n, getattr(meta, n))
+    ls = S.ref("connectomics.models.losses.losses")
+    orch = S.ref("connectomics.training.losses.orchestrator")
+    from pytorch_connectomics_amd.training.module import ConnectomicsModule
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, x):
+            return x
+    make = {"WeightedBCEWithLogitsLoss": lambda kw: ls.WeightedBCEWithLogitsLoss(**kw), "WeightedMSELoss": lambda kw: ls.WeightedMSELoss(**kw),
+            "WeightedMAELoss": lambda kw: ls.WeightedMAELoss(**kw), "SmoothL1Loss": lambda kw: ls.SmoothL1Loss(**kw),
+            "PerChannelBCEWithLogitsLoss": lambda kw: ls.PerChannelBCEWithLogitsLoss(**kw),
+            "BCEWithLogitsLoss": lambda kw: torch.nn.BCEWithLogitsLoss(**kw), "MSELoss": lambda kw: torch.nn.MSELoss(**kw)}
+    weight_taking = {"WeightedBCEWithLogitsLoss", "WeightedMSELoss", "WeightedMAELoss", "SmoothL1Loss", "PerChannelBCEWithLogitsLoss"}
+    cases = []
+    for _ in range(160):
+        terms = []
+        for _k in range(rnd.randint(1, 3)):
+            fn = rnd.choice(list(make))
+            term = {"function": fn, "weight": rnd.choice([1.0, 0.5, 2.0])}
+            term["target_slice"] = "0:3"                 # labels carry a 4th channel (a term-mask candidate); the network has 3
+            if rnd.random() < 0.4:
+                term["pred_slice"], term["target_slice"] = rnd.choice([("0:1", "0:1"), ("1:3", "1:3"), ("0:2", "1:3")])
+            if fn in weight_taking and rnd.random() < 0.4:
+                term["pos_weight"] = rnd.choice(["auto", 2.5, 1.0])
+            if rnd.random() < 0.25 and fn != "PerChannelBCEWithLogitsLoss":      # (the reference's per-channel BCE cannot take a 1-channel mask)
+                term["mask_slice"] = "3:4"
+            if rnd.random() < 0.2:
+                term["apply_deep_supervision"] = False
+            if fn == "SmoothL1Loss" and rnd.random() < 0.5:
+                term["kwargs"] = {"beta": 0.5}
+            terms.append(term)
+        cases.append((terms, rnd.random() < 0.5, rnd.random() < 0.5, rnd.randint(0, 10 ** 6)))
+
+    def cfg_of(terms, ds):
+        return NS(model=NS(loss=NS(deep_supervision=ds, deep_supervision_weights=[1.0, 0.5, 0.25, 0.125, 0.0625], deep_supervision_clamp_min=-20.0,
+                                   deep_supervision_clamp_max=20.0, losses=terms, loss_balancing=None, fused=False),
+                           primary_head=None, heads=None, out_channels=3), data=NS(label_transform=None))
+
+    def tensors(seed):
+        g = torch.Generator().manual_seed(seed)
+        outs = {"output": torch.randn(2, 3, 8, 8, 8, generator=g) * 6, "ds_1": torch.randn(2, 3, 4, 4, 4, generator=g) * 6}
+        lab = (torch.rand(2, 4, 8, 8, 8, generator=g) > 0.7).float()
+        lab[:, 2] = torch.rand(2, 8, 8, 8, generator=g)
+        lab[:, 3] = (torch.rand(2, 8, 8, 8, generator=g) > 0.3).float()
+        return outs, lab, (torch.rand(2, 1, 8, 8, 8, generator=g) > 0.3).float()
+
+    def digest(total, outs):
+        total.backward()
+        return (round(float(total.detach()), 5),) + tuple(round(float(v.grad.double().abs().sum()), 4) if v.grad is not None else None for v in outs.values())
+
+    def ref_run(terms, ds, use_mask, seed):
+        cfg = cfg_of(terms, ds)
+        mods = torch.nn.ModuleList([make[t["function"]](dict(t.get("kwargs", {}))) for t in terms])
+        o = orch.LossOrchestrator(cfg, mods, [t["weight"] for t in terms], enable_nan_detection=False, debug_on_nan=False, resolve_affinity_mode_fn=lambda c: None)
+        outs, lab, mask = tensors(seed)
+        outs = {k: v.requires_grad_(True) for k, v in outs.items()}
+        if ds:
+            total, _ = o.compute_deep_supervision_loss(outs, lab, stage="train", mask=mask if use_mask else None)
+        else:
+            total, _ = o.compute_standard_loss(outs["output"], lab, stage="train", mask=mask if use_mask else None)
+        return digest(total, outs)
+
+    def our_run(terms, ds, use_mask, seed):
+        m = ConnectomicsModule(cfg_of(terms, ds), model=Tiny())
+        outs, lab, mask = tensors(seed)
+        outs = {k: v.requires_grad_(True) for k, v in outs.items()}
+        total, _ = m._compute_loss(outs if ds else outs["output"], lab, mask if use_mask else None)
+        return digest(total, outs)
+    def close(case, a, b):
+        if a[0] != "ok" or b[0] != "ok":
+            return False
+        ra, rb = eval(a[1]), eval(b[1])
+        return len(ra) == len(rb) and all((u is None and v is None) or (u is not None and v is not None and abs(u - v) <= 2e-5 * max(1.0, abs(u)))
+                                          for u, v in zip(ra, rb))
+    t.run("loss orchestration (terms, slices, pos_weight, masks, deep supervision)", cases, ref_run, our_run, same=close)
 
 
 def prediction_crops(t, rnd):
