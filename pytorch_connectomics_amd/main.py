@@ -165,7 +165,10 @@ def run_test(cfg, args) -> dict:
                                                     device=dev, image_path=str(image_spec), checkpoint_path=args.checkpoint)
             pred_t = None if pred is None else torch.from_numpy(pred).unsqueeze(0)
         else:
-            x = torch.from_numpy(np.ascontiguousarray(vol, dtype=np.float32)).to(dev)
+            host = np.ascontiguousarray(vol, dtype=np.float32)
+            if not host.flags.writeable:          # a read-only memory map (.npy opened with mmap): torch wants a writable buffer
+                host = host.copy()
+            x = torch.from_numpy(host).to(dev)
             while x.dim() < 5:
                 x = x.unsqueeze(0)
             mgr = InferenceManager(cfg=cfg, model=model, forward_fn=model.forward)
