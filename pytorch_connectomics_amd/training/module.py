@@ -20,7 +20,7 @@ import torch.nn.functional as F
 
 from ..models import build_model
 from ..utils.channel_slices import resolve_channel_indices
-from ..utils.model_outputs import unwrap_main_output
+from ..utils.model_outputs import resolve_head_target_slice, unwrap_main_output
 
 _NORM_TYPES = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.SyncBatchNorm, nn.GroupNorm, nn.InstanceNorm1d,
                nn.InstanceNorm2d, nn.InstanceNorm3d, nn.LayerNorm, nn.LocalResponseNorm)
@@ -416,10 +416,28 @@ class ConnectomicsModule(nn.Module):
             if pos_weight is not None and fn not in _WEIGHT_TAKING:
                 raise ValueError(f"losses[{len(self.loss_terms)}] pos_weight is only supported for losses with "
                                  f"spatial_weight_arg='weight' (got {fn})")
+            # which head a term reads is settled when the module is built (training/losses/plan.py:183-229): pred_head, else
+            # model.primary_head, else the only head; a term that names no target channels takes that head's `target_slice`
+            heads = getattr(cfg.model, "heads", None)
+            heads = heads if isinstance(heads, Mapping) else {}
+            where, pred_head, primary = f"losses[{len(self.loss_terms)}]", get("pred_head"), getattr(cfg.model, "primary_head", None)
+            if heads:
+                if pred_head is not None and pred_head not in heads:
+                    raise ValueError(f"{where} pred_head={pred_head!r} is not one of the configured model.heads {sorted(heads)}")
+                if pred_head is None and primary is None and len(heads) > 1:
+                    raise ValueError(f"{where} must define pred_head or model.primary_head when model.heads has multiple entries "
+                                     f"{sorted(heads)}")
+            elif pred_head is not None:
+                raise ValueError(f"{where} uses pred_head/pred2_head but model.heads is not configured.")
+            target_slice = get("target_slice", get("target"))
+            if target_slice is None:
+                head = pred_head or primary or (next(iter(heads)) if len(heads) == 1 else None)
+                if head is not None:
+                    target_slice = resolve_head_target_slice(cfg, head)
             # the reference's spellings (training/losses/plan.py:126-147): coefficient = weight, pred / target / mask = *_slice
             self.loss_terms.append({"fn": fn, "weight": float(get("coefficient", get("weight", 1.0))), "pred_head": get("pred_head"),
                                     "pred_slice": get("pred_slice", get("pred")),
-                                    "target_slice": get("target_slice", get("target")), "pos_weight": pos_weight,
+                                    "target_slice": target_slice, "pos_weight": pos_weight,
                                     "mask_slice": get("mask_slice", get("mask")),
                                     "apply_deep_supervision": bool(get("apply_deep_supervision", True)),
                                     "kwargs": dict(get("kwargs", None) or {})})

@@ -188,7 +188,9 @@ def test_named_head_loss_routing():
             return {"output": {"sem": self.a(x), "aff": self.b(x)}}
 
     torch.manual_seed(0)
+    HEADS = {"sem": {"out_channels": 1}, "aff": {"out_channels": 2}}
     cfg = _cfg()
+    cfg.model.heads = HEADS
     cfg.model.loss.losses = [{"function": "WeightedBCEWithLogitsLoss", "weight": 1.0, "pred_head": "sem", "target_slice": "0:1"},
                              {"function": "DiceLoss", "weight": 0.5, "pred_head": "aff", "target_slice": "1:3", "kwargs": {"sigmoid": True}},
                              {"function": "MSELoss", "weight": 0.25, "pred_head": "aff", "pred_slice": "0:1", "target_slice": "0:1"}]
@@ -204,19 +206,33 @@ def test_named_head_loss_routing():
     assert {"loss_0_WeightedBCEWithLogitsLoss", "loss_1_DiceLoss", "loss_2_MSELoss", "train_loss_total"} <= set(m.last_log)
     # unnamed terms fall back to model.primary_head
     cfg2 = _cfg()
-    cfg2.model.primary_head = "sem"
+    cfg2.model.heads, cfg2.model.primary_head = HEADS, "sem"
     cfg2.model.loss.losses = [{"function": "DiceLoss", "weight": 1.0, "target_slice": "0:1", "kwargs": {"sigmoid": True}}]
     m2 = ConnectomicsModule(cfg2, model=net)
     assert torch.allclose(m2.training_step({"image": x, "label": y}), dice_loss_sigmoid(out["sem"], y[:, 0:1]), atol=1e-6)
-    cfg2.model.primary_head = None
+    cfg2.model.primary_head = None                      # changed behind the module's back: caught when the loss runs ...
     with pytest.raises(ValueError, match="multiple heads"):
         m2.training_step({"image": x, "label": y})
+    with pytest.raises(ValueError, match=r"losses\[0\] must define pred_head or model.primary_head when model.heads has multiple entries"):
+        ConnectomicsModule(cfg2, model=net)             # ... and refused up front when the module is built (plan.py:213-218)
+    # the head's own target_slice is the default target of its terms (plan.py:189-193)
+    cfg4 = _cfg()
+    cfg4.model.heads = {"sem": {"out_channels": 1, "target_slice": "2:3"}, "aff": {"out_channels": 2, "target_slice": "0:2"}}
+    cfg4.model.loss.losses = [{"function": "DiceLoss", "weight": 1.0, "pred_head": "sem", "kwargs": {"sigmoid": True}}]
+    assert torch.allclose(ConnectomicsModule(cfg4, model=net).training_step({"image": x, "label": y}),
+                          dice_loss_sigmoid(out["sem"], y[:, 2:3]), atol=1e-6)
     cfg3 = _cfg()
+    cfg3.model.heads = HEADS
     cfg3.model.loss.losses = [{"function": "DiceLoss", "weight": 1.0, "pred_head": "nope"}]
-    with pytest.raises(ValueError, match="available output"):
-        ConnectomicsModule(cfg3, model=net).training_step({"image": x, "label": y})
+    with pytest.raises(ValueError, match=r"pred_head='nope' is not one of the configured model.heads \['aff', 'sem'\]"):
+        ConnectomicsModule(cfg3, model=net)
+    cfg3.model.heads = None
+    with pytest.raises(ValueError, match="uses pred_head/pred2_head but model.heads is not configured"):
+        ConnectomicsModule(cfg3, model=net)
+    cfg5 = _cfg()                                       # heads configured, single-tensor network: caught when the loss runs
+    cfg5.model.heads, cfg5.model.loss.losses = HEADS, [{"function": "DiceLoss", "weight": 1.0, "pred_head": "sem"}]
     with pytest.raises(ValueError, match="single tensor"):
-        ConnectomicsModule(cfg3, model=SimpleModel()).training_step({"image": torch.rand(2, 1, 8, 8, 8), "label": torch.rand(2, 1, 8, 8, 8)})
+        ConnectomicsModule(cfg5, model=SimpleModel()).training_step({"image": torch.rand(2, 1, 8, 8, 8), "label": torch.rand(2, 1, 8, 8, 8)})
 
 
 def test_warmup_cosine_lr_matches_reference_fixture():

@@ -836,6 +836,53 @@ def loss_orchestration(t, rnd):
                                           for u, v in zip(ra, rb))
     t.run("loss orchestration (terms, slices, pos_weight, masks, deep supervision)", cases, ref_run, our_run, same=close)
 
+    # named heads: every term reads its head (pred_head / primary head), its target channels default to the head's target_slice
+    heads = {"aff": {"out_channels": 2, "target_slice": "0:2"}, "sdt": {"out_channels": 1, "target_slice": "2:3"}}
+    hcases = []
+    for _ in range(80):
+        terms = []
+        for _k in range(rnd.randint(1, 3)):
+            head = rnd.choice(["aff", "sdt", None])
+            fn = rnd.choice(["WeightedBCEWithLogitsLoss", "WeightedMSELoss", "SmoothL1Loss"])
+            term = {"function": fn, "weight": rnd.choice([1.0, 0.5])}
+            if head is not None:
+                term["pred_head"] = head
+            if rnd.random() < 0.3:
+                term["target_slice"] = "2:3" if head == "sdt" else "0:2"
+            if fn != "WeightedBCEWithLogitsLoss" and rnd.random() < 0.3:
+                term["pos_weight"] = rnd.choice(["auto", 3.0])
+            terms.append(term)
+        hcases.append((terms, rnd.choice(["aff", "sdt", None]), rnd.random() < 0.5, rnd.randint(0, 10 ** 6)))
+
+    def hcfg(terms, primary):
+        c = cfg_of(terms, False)
+        c.model.heads, c.model.primary_head, c.model.out_channels = heads, primary, 3
+        return c
+
+    def htensors(seed):
+        g = torch.Generator().manual_seed(seed)
+        outs = {"aff": torch.randn(2, 2, 6, 6, 6, generator=g) * 4, "sdt": torch.randn(2, 1, 6, 6, 6, generator=g) * 4}
+        lab = (torch.rand(2, 3, 6, 6, 6, generator=g) > 0.6).float()
+        lab[:, 2] = torch.rand(2, 6, 6, 6, generator=g) * 2 - 1
+        return outs, lab, (torch.rand(2, 1, 6, 6, 6, generator=g) > 0.3).float()
+
+    def href(terms, primary, use_mask, seed):
+        cfg = hcfg(terms, primary)
+        mods = torch.nn.ModuleList([make[t["function"]](dict(t.get("kwargs", {}))) for t in terms])
+        o = orch.LossOrchestrator(cfg, mods, [t["weight"] for t in terms], enable_nan_detection=False, debug_on_nan=False, resolve_affinity_mode_fn=lambda c: None)
+        outs, lab, mask = htensors(seed)
+        outs = {k: v.requires_grad_(True) for k, v in outs.items()}
+        total, _ = o.compute_standard_loss({"output": outs}, lab, stage="train", mask=mask if use_mask else None)
+        return digest(total, outs)
+
+    def hours(terms, primary, use_mask, seed):
+        m = ConnectomicsModule(hcfg(terms, primary), model=Tiny())
+        outs, lab, mask = htensors(seed)
+        outs = {k: v.requires_grad_(True) for k, v in outs.items()}
+        total, _ = m._compute_loss({"output": outs}, lab, mask if use_mask else None)
+        return digest(total, outs)
+    t.run("loss orchestration on named heads (pred_head, primary head, head target slices)", hcases, href, hours, same=close)
+
 
 def prediction_crops(t, rnd):
     rk, ok_ = S.ref("connectomics.inference.chunk_grid"), __import__("pytorch_connectomics_amd.inference.chunk_grid", fromlist=["x"])
