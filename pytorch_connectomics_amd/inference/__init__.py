@@ -5,7 +5,7 @@ from .artifact import (PredictionArtifactMetadata, build_prediction_artifact_met
 from .chunked import is_chunked_inference_enabled, is_external_chunk_sharding_enabled, run_chunked_prediction_inference
 from .lazy import lazy_predict_region, lazy_predict_volume
 from .manager import InferenceManager
-from .output import apply_prediction_transform, apply_storage_dtype_transform
+from .output import apply_prediction_transform, apply_storage_dtype_transform, resolve_output_filenames, write_outputs
 from .stage import run_prediction_inference
 from .tta import TTAPredictor
 from .tta_affinity import invert_view
@@ -19,5 +19,5 @@ __all__ = ["InferenceManager", "TTAPredictor", "TTAEnsembleAccumulator", "invert
            "lazy_predict_region", "lazy_predict_volume", "run_chunked_prediction_inference", "is_chunked_inference_enabled",
            "PredictionArtifactMetadata", "build_prediction_artifact_metadata", "read_prediction_artifact",
            "write_prediction_artifact", "write_prediction_artifact_attrs", "apply_prediction_transform",
-           "apply_storage_dtype_transform", "is_2d_inference_mode", "is_external_chunk_sharding_enabled", "resolve_inferer_overlap",
+           "apply_storage_dtype_transform", "resolve_output_filenames", "write_outputs", "is_2d_inference_mode", "is_external_chunk_sharding_enabled", "resolve_inferer_overlap",
            "resolve_inferer_roi_size"]

@@ -175,3 +175,36 @@ def test_array_valued_hdf5_attributes_do_not_overrun_the_scalar_reader(tmp_path)
     assert a["n"] == 3 and a["name"] == "vol" and a["flag"] is True
     assert a["resolution"].dtype == np.int64 and a["resolution"].tolist() == [30, 8, 8]
     assert a["scale"].dtype == np.float64 and a["scale"].tolist() == [1.5, 2.5, -3.25]
+
+
+def test_output_file_names_and_hdf5_writer(tmp_path):
+    """`resolve_output_filenames` / `write_outputs` (reference inference/output.py:19-83, :252-356; stem rule of
+    runtime/output_naming.py:54-94; fuzzed against the reference in tools/diff_fuzz_reference.py): uninformative stems climb to the
+    first informative directory, container directories are skipped, items without a name get `volume_<step>_<index>`; predictions
+    land in `<save_path>/<stem>/<suffix stem>.h5` as dataset `main` in the storage dtype; other backends are refused by name."""
+    from types import SimpleNamespace as NS
+    from pytorch_connectomics_amd.inference import resolve_output_filenames, write_outputs
+    from pytorch_connectomics_amd.inference.output import volume_stem_from_path
+    from pytorch_connectomics_amd.utils import h5lite
+    stems = {"/data/seed101/data.zarr/img": "seed101", "/data/seed101/img.h5": "seed101", "/data/sample.h5": "sample",
+             "/data/seed101/raw_aff.h5": "raw_aff", "img.tif": "volume", "/a/b.n5/data/raw": "a", "/data/vol.ome.zarr/0": "0"}
+    for path, want in stems.items():
+        assert volume_stem_from_path(path) == want, path
+    batch = {"image": np.zeros((3, 1, 2, 2, 2)), "image_meta_dict": [{"filename_or_obj": "/d/s1/img.h5"}, {"filename_or_obj": "/d/s2/em.h5"}]}
+    assert resolve_output_filenames(None, batch, global_step=4) == ["s1", "s2", "volume_4_2"]
+    assert resolve_output_filenames(None, {"image": "/d/s3/vol.h5"}) == ["vol"]
+    assert resolve_output_filenames(None, {"image": np.zeros((2, 1, 2, 2, 2)), "image_meta_dict": {"filename_or_obj": ["/x/a.h5", None]}}, 1) == ["a", "volume_1_1"]
+    if not h5lite.available():
+        pytest.skip("libpytc_h5.so not built")
+    cfg = NS(inference=NS(save_path=str(tmp_path / "out"), save_backend="h5", save_dtype="float16"), data=NS(nnunet_preprocessing=None))
+    preds = np.random.default_rng(0).random((2, 2, 3, 4, 5)).astype(np.float32)
+    write_outputs(cfg, preds, ["s1", "s2"], suffix="prediction.h5")
+    for i, stem in enumerate(("s1", "s2")):
+        with h5lite.File(str(tmp_path / "out" / stem / "prediction.h5"), "r") as fh:
+            got = np.asarray(fh["main"][...])
+        assert got.dtype == np.float16 and got.shape == (2, 3, 4, 5)
+        np.testing.assert_array_equal(got, preds[i].astype(np.float16))
+    cfg.inference.save_backend = "tiff"
+    with pytest.raises(NotImplementedError, match="save_backend='tiff'"):
+        write_outputs(cfg, preds, ["s1", "s2"])
+    write_outputs(NS(inference=NS(save_path=None)), preds, ["s1", "s2"])          # no output directory: nothing to do

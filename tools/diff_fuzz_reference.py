@@ -173,6 +173,7 @@ def main():
     lazy_engine(t, rnd)
     chunked_runner(t, rnd)
     loss_orchestration(t, rnd)
+    output_files(t, rnd)
     total, bad = sum(r[1] for r in t.rows), sum(r[2] for r in t.rows)
     print(f"TOTAL {total} cases, {bad} mismatches over {len(t.rows)} function pairs")
     return bad
@@ -882,6 +883,71 @@ def loss_orchestration(t, rnd):
         total, _ = m._compute_loss({"output": outs}, lab, mask if use_mask else None)
         return digest(total, outs)
     t.run("loss orchestration on named heads (pred_head, primary head, head target slices)", hcases, href, hours, same=close)
+
+
+def output_files(t, rnd):
+    """Per-volume output naming and the HDF5 writer: `resolve_output_filenames` over generated batch metadata (the stem rule of
+    runtime/output_naming.py) and `write_outputs` (directory layout, dataset name, storage dtype) -- the reference's functions with
+    the libhdf5 shim standing in for h5py."""
+    import tempfile
+    import types
+    import numpy as np
+    from pytorch_connectomics_amd.utils import h5lite
+    sys.modules["h5py"] = h5lite
+    for name in ("imageio", "cv2"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    S.install()
+    S._stub_pkg("connectomics.runtime")
+    for name in ("connectomics.data.io.io", "connectomics.inference.output"):
+        sys.modules.pop(name, None)
+    ro = S.ref("connectomics.inference.output")
+    io_real = S.ref("connectomics.data.io.io")                     # the reference's own HDF5 writer, on the libhdf5 shim
+    for name in ("write_hdf5", "save_volume"):
+        setattr(sys.modules["connectomics.data.io"], name, getattr(io_real, name))
+    import pytorch_connectomics_amd.inference.output as oo
+    paths = ["/data/seed101/data.zarr/img", "/data/seed101/img.h5", "/data/sample.h5", "/data/seed101/raw_aff.h5", "img.tif", "/em/raw/main.h5",
+             "/a/b.n5/data/raw", "relative/vol_07.nii.gz", "/x/y/Image.PNG", "", "/", "/data/.zarr/img", "C:/weird path/em.h5", "/data/vol.ome.zarr/0"]
+    cases = []
+    for _ in range(300):
+        n = rnd.randint(1, 3)
+        picks = [rnd.choice(paths) for _ in range(n)]
+        style = rnd.choice(["meta_list", "meta_dict_list", "meta_dict_one", "image_paths", "image_one", "none", "partial"])
+        batch = {"image": np.zeros((n, 1, 2, 2, 2), np.float32)}
+        if style == "meta_list":
+            batch["image_meta_dict"] = [{"filename_or_obj": p} for p in picks]
+        elif style == "meta_dict_list":
+            batch["image_meta_dict"] = {"filename_or_obj": picks}
+        elif style == "meta_dict_one":
+            batch["image_meta_dict"] = {"filename_or_obj": picks[0]}
+        elif style == "image_paths":
+            batch["image"] = picks
+        elif style == "image_one":
+            batch["image"] = picks[0]
+        elif style == "partial":
+            batch["image_meta_dict"] = [{"filename_or_obj": picks[0]}, {"other": 1}, None][:n]
+        cases.append((batch, rnd.randint(0, 9)))
+    t.run("resolve_output_filenames", cases, lambda b, g: ro.resolve_output_filenames(None, b, g), lambda b, g: oo.resolve_output_filenames(None, b, g))
+
+    rng = np.random.default_rng(4)
+    wcases = []
+    for _ in range(40):
+        n = rnd.randint(1, 3)
+        shape = rnd.choice([(n, 2, 3, 4, 5), (n, 1, 3, 4, 5), (n, 3, 4, 5), (3, 4, 5), (4, 5)])
+        wcases.append((rng.random(shape).astype(np.float32), [f"vol{i}" for i in range(rnd.choice([n, n, max(1, n - 1)]))],
+                       rnd.choice(["prediction.h5", "prediction", "decoded.seg.h5", "x.nii.gz"]), rnd.choice([None, "float16", "uint8"])))
+
+    def written(mod, preds, names, suffix, sdt):
+        with tempfile.TemporaryDirectory() as d:
+            cfg = NS(inference=NS(save_path=d, save_backend="h5", save_dtype=sdt), data=NS(nnunet_preprocessing=None))
+            mod.write_outputs(cfg, preds.copy(), list(names), suffix=suffix, mode="test")
+            out = []
+            for f in sorted(Path(d).rglob("*")):
+                if f.is_file():
+                    with h5lite.File(str(f), "r") as fh:
+                        a = np.asarray(fh["main"][...])
+                    out.append((str(f.relative_to(d)), a.shape, str(a.dtype), round(float(a.astype(np.float64).sum()), 3)))
+            return out
+    t.run("write_outputs (layout, dataset, storage dtype)", wcases, lambda *c: written(ro, *c), lambda *c: written(oo, *c))
 
 
 def prediction_crops(t, rnd):
