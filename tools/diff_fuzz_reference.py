@@ -174,6 +174,7 @@ def main():
     chunked_runner(t, rnd)
     loss_orchestration(t, rnd)
     output_files(t, rnd)
+    eager_engine(t, rnd)
     total, bad = sum(r[1] for r in t.rows), sum(r[2] for r in t.rows)
     print(f"TOTAL {total} cases, {bad} mismatches over {len(t.rows)} function pairs")
     return bad
@@ -948,6 +949,44 @@ def output_files(t, rnd):
                     out.append((str(f.relative_to(d)), a.shape, str(a.dtype), round(float(a.astype(np.float64).sum()), 3)))
             return out
     t.run("write_outputs (layout, dataset, storage dtype)", wcases, lambda *c: written(ro, *c), lambda *c: written(oo, *c))
+
+
+def eager_engine(t, rnd):
+    """EagerSlidingWindowEngine.__call__ on generated volumes (smaller and larger than the window, every padding / blending mode,
+    per-axis overlaps, batch sizes): the reference engine on CPU tensors against this package's engine with the gather / blend /
+    finalize kernels replaced by torch stand-ins -- plan, probe window, blending order, normalisation, crop back."""
+    import torch
+    sys.path.insert(0, str(ROOT / "tests"))
+    import test_host_lazy_tta as L
+    import pytorch_connectomics_amd.inference.window as ow
+    rw = S.ref("connectomics.inference.window")
+
+    class Ops(L._Ops):
+        @staticmethod
+        def gather_windows(vol, starts, roi, *, view=0, pad_mode="constant", cval=0.0, **_kw):
+            assert view == 0
+            return L._Ops.gather_windows(vol, starts, roi, pad_mode=pad_mode, cval=cval)
+    ow.ops = Ops
+
+    def net(x):
+        ramp = torch.linspace(0, 1, x.shape[-1]).view(1, 1, 1, 1, -1)
+        return torch.cat([2 * x - 1 + ramp, 0.5 * x * x + x.mean(dim=(2, 3, 4), keepdim=True)], 1)
+    cases = []
+    for _ in range(120):
+        roi = rnd.choice([(4, 6, 6), (6, 8, 8), (8, 8, 8), (2, 12, 10)])
+        shape = tuple(rnd.choice([max(1, r - rnd.randint(0, 3)), r, r + rnd.randint(1, 9), 2 * r + rnd.randint(0, 5)]) for r in roi)
+        cases.append((shape, roi, rnd.choice([0.0, 0.25, 0.5, 0.75, (0.25, 0.5, 0.5)]), rnd.choice(["constant", "bump", "gaussian", "distance_transform", "nope"]),
+                      rnd.choice(["constant", "reflect", "replicate", "circular"]), rnd.choice([0.0, 0.3]), rnd.choice([1, 3, 8]), rnd.randint(0, 10 ** 6)))
+
+    def run(mod, patch, shape, roi, overlap, mode, padding, cval, swb, seed):
+        x = torch.rand((1, 1) + shape, generator=torch.Generator().manual_seed(seed))
+        eng = mod.EagerSlidingWindowEngine(roi_size=roi, sw_batch_size=swb, overlap=overlap, mode=mode, padding_mode=padding, cval=cval,
+                                           sw_device=None, output_device=None)
+        if patch:
+            eng._check_inputs = lambda inputs: torch.device("cpu")
+            eng.pipeline_streams = 1
+        return _tensor_digest(eng(x, net), 4)
+    t.run("EagerSlidingWindowEngine (plan, probe, blending, normalisation, crop)", cases, lambda *c: run(rw, False, *c), lambda *c: run(ow, True, *c))
 
 
 def prediction_crops(t, rnd):
