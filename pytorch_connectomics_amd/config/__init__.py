@@ -65,7 +65,11 @@ def schema_defaults() -> dict:
                  "test": {"image": None, "label": None},
                  "dataloader": {"batch_size": 1, "patch_size": None, "use_lazy_zarr": False, "use_lazy_h5": False},
                  "data_transform": {"patch_size": None},
-                 "image_transform": {"normalize": "none"}},
+                 "image_transform": {"normalize": "none"},
+                 "mask_transform": None,
+                 # schema/data.py:66-86 (the keys the inference path reads: stacked label targets -> affinity channel groups)
+                 "label_transform": {"keys": ["label"], "stack_outputs": True, "retain_original": False, "output_dtype": "float32",
+                                     "targets": []}},
         # schema/optimization.py:8-113 (OptimizerConfig, SchedulerConfig, EMAConfig, OptimizationConfig)
         "optimization": {"precision": "16-mixed", "gradient_clip_val": 1.0, "accumulate_grad_batches": 1,
                          "max_epochs": 200, "max_steps": None, "n_steps_per_epoch": -1,

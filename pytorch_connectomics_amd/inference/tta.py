@@ -25,10 +25,11 @@ from ..utils.model_outputs import (get_inference_channel_activations, get_infere
 from .lazy_distributed import reduce_view_ensemble, validate_view_shards
 from .tta_combinations import (_resolve_ensemble_mode_map, _resolve_spatial_dims, apply_view,
                                resolve_tta_augmentation_combinations)
-from .window import is_2d_inference_mode, resolve_model_output_dtype
+from .window import is_2d_inference_mode, resolve_inferer_roi_size, resolve_model_output_dtype
 from ..utils.model_outputs import resolve_output_channels, resolve_output_heads
 
 logger = logging.getLogger(__name__)
+tqdm = None          # the device engine reports no per-batch progress; the name exists because callers of the reference module patch it
 
 _MODE_CODE = {"mean": 0, "min": 1, "max": 2}
 
@@ -86,6 +87,17 @@ class TTAPredictor:
         self.channel_activation_types = names if any(n is not None for n in names) else None
 
     # ------------------------------------------------------------------ config helpers
+    @staticmethod
+    def _distributed_context():
+        """(initialised?, rank, world size) -- lazy_distributed.distributed_context under the reference predictor's name."""
+        from .lazy_distributed import distributed_context
+        return distributed_context()
+
+    def _build_augmentation_combinations(self, tta_cfg, ndim: int):
+        """The (flip axes, rotation plane, k) views of a configuration for tensors of rank `ndim` (reference tta.py: rotation planes
+        in TENSOR dims there, spatial axes here -- callers of this package use resolve_tta_augmentation_combinations directly)."""
+        return resolve_tta_augmentation_combinations(tta_cfg, spatial_dims=_resolve_spatial_dims(ndim))
+
     def _get_tta_cfg(self):
         return getattr(getattr(self.cfg, "inference", None), "test_time_augmentation", None)
 
@@ -480,11 +492,12 @@ class TTAPredictor:
             for _f, pl, k in combos:   # same restriction (and message) as the reference, tta.py:1316-1340
                 if pl is not None and k % 2:
                     img = tuple(int(v) for v in images.shape[2:])
-                    if len({img[a] for a in pl}) != 1 or len({engine.roi_size[a] for a in pl}) != 1:
+                    roi = tuple(getattr(engine, "roi_size", None) or resolve_inferer_roi_size(self.cfg) or img)
+                    if len({img[a] for a in pl}) != 1 or len({roi[a] for a in pl}) != 1:
                         raise ValueError(
                             "Patch-first local TTA only supports odd 90-degree rotations when the rotated axes "
                             f"have equal image and ROI sizes. Got rotation_plane={tuple(a + 2 for a in pl)}, "
-                            f"image_size={img}, roi_size={engine.roi_size}. Use flip-only TTA, constrain "
+                            f"image_size={img}, roi_size={roi}. Use flip-only TTA, constrain "
                             "rotations to equal-sized axes such as square XY inputs, or disable "
                             "`inference.test_time_augmentation.patch_first_local`.")
             codes = [view_code(f, pl, k) for f, pl, k in combos]
@@ -520,10 +533,13 @@ def _predict_whole_volume_views(self, vol, engine, network, combos, ensemble_mod
     rotates the WHOLE volume, runs its own sliding-window pass over the augmented geometry (its own window grid and weight
     map, so non-square rotations are fine), and the blended prediction is rotated / flipped back before activation and
     the ensemble.  The augmented volume is one device copy per view; the windows still gather from HBM as usual."""
-    from .tta_affinity import resolve_affinity_channel_groups_from_cfg
-    if resolve_affinity_channel_groups_from_cfg(self.cfg):
-        raise NotImplementedError("whole-volume TTA (patch_first_local: false) of directional-affinity outputs is not built; "
-                                  "use patch_first_local: true (the reference default)")
+    from .tta_affinity import ViewValidity, build_affinity_tta_plan, invert_view, resolve_affinity_channel_groups_from_cfg
+    from .tta_ensemble import TTAEnsembleAccumulator
+    has_affinity = bool(resolve_affinity_channel_groups_from_cfg(self.cfg))
+    if has_affinity and sharded:
+        raise NotImplementedError("whole-volume TTA (patch_first_local: false) of directional-affinity outputs cannot be sharded over "
+                                  "ranks here; use patch_first_local: true (the reference default) with distributed_sharding")
+    plan = ens = None
     acc = modes = None
     weights = {}
     local = list(range(len(combos))) if local is None else local
@@ -541,6 +557,28 @@ def _predict_whole_volume_views(self, vol, engine, network, combos, ensemble_mod
         ops.blend_finalize(value, w, clamp=1e-4, act=nat.ACT_NONE)
         if tuple(value.shape[1:]) != shape:
             value = value[:, :shape[0], :shape[1], :shape[2]]
+        if has_affinity:
+            # directional-affinity outputs: the inverse view also re-anchors the affinity channels and says where each channel
+            # received real values; the streaming accumulator counts only those (reference tta.py:691-769, tta_affinity.py:350-393)
+            raw = value.contiguous().unsqueeze(0)
+            if plan is None:
+                plan = build_affinity_tta_plan(self.cfg, augmentation_combinations=combos, num_raw=int(raw.shape[1]),
+                                               requested_head=self._requested_output_head_override)
+            view_index = local[n]
+            inv, validity = invert_view(raw, flip_axes=flips, rotation_plane_spatial=pl, k=k,
+                                        view_plan=None if plan is None else plan.views[view_index], tta_plan=plan)
+            channels = int(inv.shape[1])
+            sel = self._select_channel_indices(channels)
+            kept = list(range(channels)) if sel is None else list(sel)
+            done = self.apply_preprocessing(inv.contiguous())
+            done = done if done.dtype == torch.float32 else done.float()
+            if ens is None:
+                partial = [] if plan is None else [j for j, c in enumerate(kept) if c in plan.partial_channels]
+                ens = TTAEnsembleAccumulator(tuple(done.shape), dtype=resolve_model_output_dtype(self.cfg), device=done.device,
+                                             mode_map=_resolve_ensemble_mode_map(ensemble_mode, int(done.shape[1])),
+                                             partial_channels=partial, distributed_sharding=False, max_views=len(combos))
+            ens.add(done, ViewValidity(tuple(validity.channels[c] for c in kept)))
+            continue
         if pl is not None and k > 0:
             value = torch.rot90(value, k=-int(k), dims=(int(pl[0]) + 1, int(pl[1]) + 1))
         if flips:
@@ -556,6 +594,8 @@ def _predict_whole_volume_views(self, vol, engine, network, combos, ensemble_mod
             continue
         for c, mode in enumerate(modes):
             ops.ensemble_update(acc[0, c], pred32[0, c].contiguous(), _MODE_CODE[mode], n + 1)
+    if ens is not None:
+        return ens.finalize()
     if sharded:
         acc = self._reduce_views(acc, len(local), len(combos), modes)
     return None if acc is None else acc.to(resolve_model_output_dtype(self.cfg))

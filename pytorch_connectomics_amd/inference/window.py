@@ -273,6 +273,22 @@ def resolve_inferer_overlap(cfg, roi_size) -> Union[float, Tuple[float, ...]]:
     return float(max(0.0, min(ov, 0.99)))
 
 
+def resolve_accelerator_type(requested: str = "auto") -> str:
+    """'cuda' (= HIP on this build) when a device is visible, else 'cpu'; an explicit 'cuda' without a device is an error.  The name
+    the reference's window module looks the accelerator up under (config/hardware/gpu_utils.py:31-53) -- kept as a module attribute
+    so that code patching it there keeps working.  There is no MPS on an MI355X host."""
+    want = str(requested or "auto").strip().lower()
+    if want not in ("auto", "cpu", "cuda", "mps"):
+        raise ValueError(f"system.accelerator must be one of: auto, cpu, cuda, mps (got {requested!r})")
+    if want == "auto":
+        return "cuda" if torch.cuda.is_available() else "cpu"
+    if want == "cuda" and not torch.cuda.is_available():
+        raise RuntimeError("system.accelerator='cuda' was requested but CUDA is not available")
+    if want == "mps":
+        raise RuntimeError("system.accelerator='mps' was requested but MPS is not available")
+    return want
+
+
 def _resolve_sliding_window_runtime(cfg, roi_size) -> dict:
     sw = _sliding_cfg(cfg)
     dl = getattr(getattr(cfg, "data", None), "dataloader", None)
@@ -286,10 +302,14 @@ def _resolve_sliding_window_runtime(cfg, roi_size) -> dict:
     output_device = none_if_blank(getattr(sw, "output_device", None) if sw else None)
     keep_cpu = bool(getattr(sw, "keep_input_on_cpu", False)) if sw else False
     if keep_cpu:
-        if sw_device is None and torch.cuda.is_available():
-            sw_device = "cuda"
+        if sw_device is None:
+            found = resolve_accelerator_type("auto")
+            sw_device = None if found == "cpu" else found
         if output_device is None:
             output_device = "cpu"
+        if sw_device is None:
+            logger.warning("inference.sliding_window.keep_input_on_cpu=True but no sw_device was set and no accelerator is "
+                           "available. Sliding-window inference will run on CPU.")
     return {
         "overlap": resolve_inferer_overlap(cfg, roi_size),
         "sw_batch_size": max(1, int(cfg_bs if cfg_bs is not None else data_bs)),

@@ -45,6 +45,26 @@ class _Ops(_CpuOps):
             raise AssertionError(act)
 
 
+    @staticmethod
+    def ensemble_update_masked(stat, count, x, cover, mode):
+        """validity-aware streaming ensemble (csrc/window_kernels.hip pytc_ensemble_update_masked): only covered voxels contribute;
+        mean keeps a running sum, min / max the extreme; `count` the number of contributions."""
+        from pytorch_connectomics_amd.inference.tta import _MODE_CODE
+        inside = torch.ones_like(x, dtype=torch.bool) if cover is None else cover > 0
+        if mode == _MODE_CODE["mean"]:
+            stat += torch.where(inside, x, torch.zeros_like(x))
+        elif mode == _MODE_CODE["min"]:
+            stat.copy_(torch.where(inside, torch.minimum(stat, x), stat))
+        else:
+            stat.copy_(torch.where(inside, torch.maximum(stat, x), stat))
+        count += inside.to(count.dtype)
+
+    @staticmethod
+    def ensemble_finalize_masked(stat, count, out, mode):
+        from pytorch_connectomics_amd.inference.tta import _MODE_CODE
+        out.copy_(stat / count if mode == _MODE_CODE["mean"] else stat)
+
+
 def _net_lazy(x):
     ramp = torch.linspace(0, 1, x.shape[-1]).view(1, 1, 1, 1, -1)
     return torch.cat([2 * x - 1 + ramp, 0.5 * x + x.mean(dim=(2, 3, 4), keepdim=True)], 1)

@@ -449,6 +449,45 @@ def predictor_orchestration(t, rnd):
         return _tensor_digest(p.predict(xb.clone(), mask=mb if use_mask else None), 4)
     t.run("TTAPredictor.predict on a batch of two volumes", cases[::6], ref_batch, our_batch, same=half_precision_close)
 
+    # directional-affinity outputs, whole-volume views (`patch_first_local: false`): inverse views re-anchor the affinity channels,
+    # the ensemble counts only the voxels a view really covers
+    unit = ["1-0-0", "0-1-0", "0-0-1"]
+    acases = []
+    for offs in (unit, unit + ["3-0-0", "0-3-0", "0-0-3"], unit + ["2-0-0", "0-4-0", "0-0-4"]):
+        for amode in ("deepem", "banis"):
+            for f, r in (("all", None), ([[0]], [[1, 2]]), ([[1], [2]], None), (None, [[1, 2]]), ("all", [[1, 2]])):
+                for m in ("mean", "min", "max"):
+                    for sel in (None, "0:3", [2, 0]):
+                        if rnd.random() < 0.5:
+                            acases.append((offs, amode, f, r, m, sel, rnd.random() < 0.4))
+
+    def acfg(offs, amode, f, r, m, sel):
+        c = cfg_of([{"channels": ":", "activation": "sigmoid"}], sel, m, f, r, None)
+        c.model.out_channels = len(offs)
+        c.data.label_transform = NS(stack_outputs=True, targets=[{"name": "affinity", "kwargs": {"offsets": offs, "affinity_mode": amode}}])
+        c.inference.test_time_augmentation.patch_first_local = False
+        return c
+    xa = torch.rand(1, 1, 6, 8, 8, generator=g)
+    ma = (torch.rand(1, 1, 6, 8, 8, generator=g) > 0.4).float()
+
+    def anet(n):
+        def fn(x):
+            w = torch.linspace(-1, 1, x.shape[4]).view(1, 1, 1, 1, -1)
+            z = torch.linspace(-1, 1, x.shape[2]).view(1, 1, -1, 1, 1)
+            return torch.cat([x * (1.0 + 0.3 * i) + 0.2 * w * (i % 2) + 0.1 * z * i for i in range(n)], 1)
+        return fn
+
+    def aref(offs, amode, f, r, m, sel, use_mask):
+        p = rtta.TTAPredictor(cfg=acfg(offs, amode, f, r, m, sel), sliding_inferer=None, forward_fn=anet(len(offs)))
+        return _tensor_digest(p.predict(xa.clone(), mask=ma if use_mask else None), 4)
+
+    def aours(offs, amode, f, r, m, sel, use_mask):
+        fn = anet(len(offs))
+        p = otta.TTAPredictor(cfg=acfg(offs, amode, f, r, m, sel), sliding_inferer=Engine(tuple(xa.shape[2:])), forward_fn=fn)
+        p._engine_network = lambda: fn
+        return _tensor_digest(p.predict(xa.clone(), mask=ma if use_mask else None), 4)
+    t.run("TTAPredictor.predict, affinity outputs, whole-volume views", acases, aref, aours)
+
 
 def model_builders(t, rnd):
     """`build_rsunet` / `build_rsunet_iso` over generated model configurations: state-dict keys, shapes and dtypes, buffers, the

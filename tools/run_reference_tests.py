@@ -8,6 +8,7 @@ MI355X: on a CPU-only host those tests are reported as such by their RuntimeErro
 
     python tools/run_reference_tests.py                     # the default list below
     python tools/run_reference_tests.py tests/unit/test_x.py
+    PYTC_STANDIN_KERNELS=1 python tools/run_reference_tests.py ...   # device kernels replaced by the torch stand-ins of tests/
 
 Prints one line per test file and a summary; `--junit DIR` keeps pytest's XML reports."""
 from __future__ import annotations
@@ -27,27 +28,87 @@ DEFAULT = ["tests/unit/test_architecture_registry.py", "tests/unit/test_predicti
            "tests/unit/test_mednext_multi_head_wrapper.py", "tests/unit/test_mednext_features.py", "tests/test_rsunet.py"]
 
 ALIAS_CONFTEST = '''
-import importlib, importlib.abc, importlib.util, sys
+import importlib, importlib.abc, importlib.util, os, sys, types
 sys.path.insert(0, {root!r})
+# packages the image lacks, provided by what IS here: h5py by the in-repo libhdf5 shim, imageio's reader by Pillow
+try:
+    from pytorch_connectomics_amd.utils import h5lite as _h5
+    if _h5.available():
+        sys.modules.setdefault("h5py", _h5)
+except Exception:
+    pass
+if "imageio" not in sys.modules:
+    try:
+        import numpy as _np
+        from PIL import Image as _Image
+        _io = types.ModuleType("imageio"); _io.v2 = types.ModuleType("imageio.v2")
+        _io.imread = _io.v2.imread = lambda f: _np.asarray(_Image.open(f))
+        _io.imwrite = _io.v2.imwrite = lambda f, a: _Image.fromarray(_np.asarray(a)).save(f)
+        _io.volread = _io.v2.volread = lambda f: _np.stack([_np.asarray(p) for p in __import__("PIL.ImageSequence", fromlist=["x"]).Iterator(_Image.open(f))])
+        sys.modules["imageio"], sys.modules["imageio.v2"] = _io, _io.v2
+    except Exception:
+        pass
+
+REF_PKG = "/root/reference/connectomics"
+
 
 class _Alias(importlib.abc.MetaPathFinder, importlib.abc.Loader):
-    """`connectomics[.x.y]` -> `pytorch_connectomics_amd[.x.y]` (the same module object under both names)."""
+    """`connectomics[.x.y]` -> `pytorch_connectomics_amd[.x.y]` (the same module object under both names).  A name this package
+    has no counterpart for (data pipeline, config schema, runtime helpers: out of the hot path) falls back to the REFERENCE's own
+    file under that name -- the integration picture: the reference with this package swapped in at the seams.  Reference
+    packages load as empty namespaces (their __init__ files pull in Lightning / MONAI / Hydra), leaf modules as they are."""
     def find_spec(self, name, path=None, target=None):
-        if name == "connectomics" or name.startswith("connectomics."):
-            real = "pytorch_connectomics_amd" + name[len("connectomics"):]
-            try:
-                if importlib.util.find_spec(real) is None:
-                    return None
-            except (ImportError, ValueError):
-                return None
-            return importlib.util.spec_from_loader(name, self, origin=real)
+        if not (name == "connectomics" or name.startswith("connectomics.")):
+            return None
+        rest = name[len("connectomics"):]
+        real = "pytorch_connectomics_amd" + rest
+        try:
+            if importlib.util.find_spec(real) is not None:
+                return importlib.util.spec_from_loader(name, self, origin=real)
+        except (ImportError, ValueError, AttributeError):
+            pass
+        rel = rest.lstrip(".").replace(".", "/")
+        if os.path.isdir(os.path.join(REF_PKG, rel)):
+            spec = importlib.util.spec_from_loader(name, self, origin="ref-package:" + rel, is_package=True)
+            spec.submodule_search_locations = [os.path.join(REF_PKG, rel)]
+            return spec
+        leaf = os.path.join(REF_PKG, rel + ".py")
+        if os.path.isfile(leaf):
+            return importlib.util.spec_from_file_location(name, leaf)
         return None
     def create_module(self, spec):
+        if spec.origin.startswith("ref-package:"):
+            return None
         return importlib.import_module(spec.origin)
     def exec_module(self, module):
         pass
 
 sys.meta_path.insert(0, _Alias())
+
+if os.environ.get("PYTC_STANDIN_KERNELS") == "1":
+    # the product has no CPU path; with this switch the reference's device-free tests run OUR orchestration over the torch stand-ins
+    # of the kernels that this repository's own host tests use (tests/test_host_lazy_tta.py) -- test infrastructure, not product
+    sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import torch
+    import test_host_lazy_tta as _L
+    import pytorch_connectomics_amd.inference.window as _w
+    import pytorch_connectomics_amd.inference.lazy as _lz
+    import pytorch_connectomics_amd.inference.tta as _t
+    import pytorch_connectomics_amd.inference.tta_ensemble as _e
+
+    class _Ops(_L._Ops):
+        @staticmethod
+        def gather_windows(vol, starts, roi, *, view=0, pad_mode="constant", cval=0.0, **_kw):
+            assert view == 0
+            return _L._Ops.gather_windows(vol, starts, roi, pad_mode=pad_mode, cval=cval)
+    for _m in (_w, _lz, _t, _e):
+        _m.ops = _Ops
+    _w.EagerSlidingWindowEngine._check_inputs = lambda self, inputs: torch.device("cpu")
+    _init = _w.EagerSlidingWindowEngine.__init__
+    def _one_stream(self, *a, **k):
+        _init(self, *a, **k)
+        self.pipeline_streams = 1
+    _w.EagerSlidingWindowEngine.__init__ = _one_stream
 '''
 
 
