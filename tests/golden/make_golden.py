@@ -387,6 +387,22 @@ def tta_affinity():
         out[f"{name}__y"] = y.numpy()
         print(name, tuple(y.shape), float(y.mean()))
     save("tta_affinity.npz", **out)
+    # the same predictor with `patch_first_local: false`: every view is a whole-volume sliding pass, inverted (affinity channels
+    # re-anchored) and ensembled with per-voxel validity (tta.py:691-769) -> tests/golden/tta_affinity_whole.npz
+    whole = {"x": x.numpy(), "x_square": xsq.numpy()}
+    for name, (ns, n_out, offsets, mode, acts, select, xin) in {
+            "whole_aff6_flip8_mean_deepem": (tta_ns("all", None, "mean"), 6, lr, "deepem", [{"channels": ":", "activation": "sigmoid"}], None, x),
+            "whole_aff3_rot_min_banis": (tta_ns([[0]], [[1, 2]], "min"), 3, ["1-0-0", "0-1-0", "0-0-1"], "banis",
+                                         [{"channels": ":", "activation": "sigmoid"}], None, xsq),
+            "whole_aff6_select_max": (tta_ns([[1], [2], [1, 2]], None, "max"), 6, lr, "deepem",
+                                      [{"channels": ":", "activation": "sigmoid"}], [3, 0, 4], x)}.items():
+        ns.patch_first_local = False
+        cfg = cfg_for(ns, n_out=n_out, offsets=offsets, mode=mode, acts=acts, select=select)
+        m = mgr.InferenceManager(cfg=cfg, model=torch.nn.Identity(), forward_fn=lambda t, n=n_out: _net_aff(t, n))
+        y = m.predict_with_tta(xin.clone())
+        whole[f"{name}__y"] = y.numpy()
+        print(name, tuple(y.shape), float(y.mean()))
+    save("tta_affinity_whole.npz", **whole)
     # the reference's channel-move plans for a few view sets (host integer logic; compared exactly)
     import json
     ta = S.ref("connectomics.inference.tta_affinity")

@@ -46,3 +46,33 @@ def test_chunked_runner_passes_the_mask_and_views_on(tmp_path, golden_dir):
                                            device="cuda", qc_streaming_callback=NS(update=lambda a, z_offset, z_axis: seen.append((a.shape, z_offset, z_axis))))
     np.testing.assert_array_equal(out, full[0].cpu().numpy())
     assert seen == [(out.shape, 0, 1)]
+
+
+_LR = ["1-0-0", "0-1-0", "0-0-1", "3-0-0", "0-3-0", "0-0-3"]
+WHOLE_AFF_CASES = {
+    "whole_aff6_flip8_mean_deepem": ("all", None, "mean", 6, _LR, "deepem", None, "x"),
+    "whole_aff3_rot_min_banis": ([[0]], [[1, 2]], "min", 3, ["1-0-0", "0-1-0", "0-0-1"], "banis", None, "x_square"),
+    "whole_aff6_select_max": ([[1], [2], [1, 2]], None, "max", 6, _LR, "deepem", [3, 0, 4], "x"),
+}
+
+
+@pytest.mark.parametrize("name", list(WHOLE_AFF_CASES))
+def test_whole_volume_affinity_tta_matches_reference(name, golden_dir):
+    """`patch_first_local: false` with directional-affinity outputs (refused before this round's second session): every view is a
+    whole-volume sliding pass, the inverse view re-anchors the affinity channels, the ensemble counts per-voxel validity --
+    against the reference's InferenceManager.predict_with_tta (tests/golden/tta_affinity_whole.npz)."""
+    from types import SimpleNamespace as NS
+    from pytorch_connectomics_amd.inference import InferenceManager
+    from test_gpu_tta import _cfg, _net_aff
+    flip, rot, mode, n_out, offsets, amode, select, xkey = WHOLE_AFF_CASES[name]
+    g = np.load(golden_dir / "tta_affinity_whole.npz")
+    tta_ns = NS(enabled=True, flip_axes=flip, rotation90_axes=rot, rotate90_k=None, ensemble_mode=mode, patch_first_local=False,
+                distributed_sharding=False, apply_mask=True)
+    cfg = _cfg(tta_ns, [{"channels": ":", "activation": "sigmoid"}], select)
+    cfg.model.out_channels = n_out
+    cfg.data.label_transform = NS(stack_outputs=True, targets=[{"name": "affinity", "kwargs": {"offsets": offsets, "affinity_mode": amode}}])
+    mgr = InferenceManager(cfg=cfg, model=torch.nn.Identity(), forward_fn=lambda t: _net_aff(t, n_out))
+    y = mgr.predict_with_tta(torch.from_numpy(g[xkey]).cuda()).cpu().numpy()
+    want = g[f"{name}__y"]
+    assert y.shape == want.shape
+    np.testing.assert_allclose(y, want, rtol=2e-5, atol=2e-5)
