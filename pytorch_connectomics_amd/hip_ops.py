@@ -108,7 +108,11 @@ def _nbytes(*ts) -> int:
     return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
 
-def _starts_array(starts: Sequence[Sequence[int]]):
+def _starts_array(starts: Sequence[Sequence[int]], windows: Optional[int] = None):
+    """Window positions as a flat int32 array; with `windows`, refuses a batch whose size is not the number of positions (a network
+    that dropped or added samples would otherwise blend the wrong windows, or read past the array)."""
+    if windows is not None and len(starts) != int(windows):
+        raise ValueError(f"{int(windows)} window predictions for {len(starts)} window positions: the network must keep the batch size")
     flat = [int(v) for s in starts for v in s]
     return (C.c_int32 * len(flat))(*flat)
 
@@ -146,7 +150,7 @@ def blend_accumulate(pred: torch.Tensor, starts, value: torch.Tensor, weight: Op
     if value.dtype != torch.float32 or value.shape[0] != Cc:
         raise ValueError("value accumulator must be float32 (C, Z, Y, X) with C matching pred")
     _, Z, Y, X = value.shape
-    st = _starts_array(starts)
+    st = _starts_array(starts, B)
     bd = (C.c_int32 * 3)(*[int(v) for v in border]) if border else None
     win = B * rz * ry * rx
     _run("blend_accumulate", _nbytes(pred) + win * 4 * (2 * Cc + (2 if weight is not None else 0)),
@@ -166,7 +170,7 @@ def blend_accumulate_mapped(pred: torch.Tensor, starts, value: torch.Tensor, wei
     if len(chan_src) != Cc or len(chan_shift) != Cc:
         raise ValueError("channel map must describe every output channel")
     _, Z, Y, X = value.shape
-    st = _starts_array(starts)
+    st = _starts_array(starts, B)
     bd = (C.c_int32 * 3)(*[int(v) for v in border]) if border else None
     cs = (C.c_int32 * Cc)(*[int(v) for v in chan_src])
     sh = (C.c_int32 * (3 * Cc))(*[int(v) for s3 in chan_shift for v in s3])

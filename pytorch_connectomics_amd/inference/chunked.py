@@ -47,7 +47,7 @@ def is_chunked_inference_enabled(cfg) -> bool:
     inf = getattr(cfg, "inference", None)
     ch = getattr(inf, "chunking", None)
     strategy = getattr(inf, "strategy", None) or getattr(getattr(inf, "execution", None), "strategy", None)
-    return bool(getattr(ch, "enabled", False) or strategy == "chunked")
+    return bool(getattr(ch, "enabled", False) or str(strategy).lower() == "chunked")
 
 
 def _rank_world() -> tuple[int, int]:
@@ -160,6 +160,24 @@ def _write_chunk_index(output_path: Path, chunks, chunks_dir: Path, *, input_sha
     tmp.write_text(json.dumps(index, indent=2))
     os.replace(tmp, p)
     return p
+
+
+def _precomputed_marker_path(chunks_dir: Path, chunk: ChunkRef) -> Path:
+    """Completion marker of a chunk written into a precomputed layer, which has no per-chunk file to stat (chunked.py:59-66)."""
+    return chunks_dir / f"chunk_{chunk.key}.done"
+
+
+def _validate_precomputed_alignment(chunk_shape_zyx: Sequence[int], chunk_size_xyz: Sequence[int]) -> None:
+    """The reference keeps this guard here (chunked.py:168-188); the implementation lives with the layer writer."""
+    from .precomputed import validate_precomputed_alignment
+    validate_precomputed_alignment(chunk_shape_zyx, chunk_size_xyz)
+
+
+def _open_precomputed_layer(layer_dir, *, volume_size_xyz, num_channels: int, data_type: str, resolution_xyz, chunk_size_xyz):
+    """chunked.py:68-130 under its name there; returns this package's `PrecomputedLayer` (no CloudVolume in the image)."""
+    from .precomputed import open_precomputed_layer
+    return open_precomputed_layer(Path(layer_dir), volume_size_xyz=volume_size_xyz, num_channels=num_channels, data_type=data_type,
+                                  resolution_xyz=resolution_xyz, chunk_size_xyz=chunk_size_xyz)
 
 
 def _read_chunk(path: Path) -> np.ndarray:
@@ -372,7 +390,7 @@ def run_chunked_prediction_inference(cfg, forward_fn, volume=None, *, output_pat
                                              overwrite=overwrite)
     def _done_file(c) -> Path:
         # a precomputed layer has no per-chunk file to stat: completion is a marker file (reference chunked.py:59-66)
-        return cdir / f"chunk_{c.key}.done" if pc_out else _chunk_file(cdir, c, h5)
+        return _precomputed_marker_path(cdir, c) if pc_out else _chunk_file(cdir, c, h5)
 
     prefetch = None
     if predict_region_fn is None:

@@ -188,6 +188,21 @@ def _window_preprocess(cfg, pred_cl: torch.Tensor) -> torch.Tensor:
 
 
 @torch.no_grad()
+def _require_window_shape(prediction: torch.Tensor, read, roi, ctx, *, channels_last: bool = False) -> None:
+    """The window contract of the lazy loop (reference lazy.py:389-419): the network keeps the spatial shape of what it was given --
+    the ROI, or ROI + 2 * target_context, of which the loop then keeps the centre.  Messages in the caller's (N, C, Z, Y, X) order."""
+    shape = tuple(int(v) for v in prediction.shape)
+    if channels_last and len(shape) == 5:
+        shape = (shape[0], shape[4]) + shape[1:4]
+    if shape[2:] == tuple(read):
+        return
+    scope = "Lazy sliding-window inference"
+    if any(ctx):
+        raise RuntimeError(f"{scope} with target_context={tuple(ctx)} expected prediction spatial shape {tuple(read)}, got {shape[2:]}.")
+    raise RuntimeError(f"{scope} requires model predictions to have the same spatial shape as the sliding-window ROI. "
+                       f"Got prediction.shape={shape} and roi_size={tuple(roi)}.")
+
+
 def _lazy_tta_views(cfg) -> int:
     """How many test-time-augmentation views the configuration asks for per window (1 = none)."""
     tta = getattr(getattr(cfg, "inference", None), "test_time_augmentation", None)
@@ -320,22 +335,18 @@ def _lazy_sliding_window(cfg, forward_fn, volume, *, region_start, region_stop, 
                 m = m.permute(0, 4, 1, 2, 3).contiguous()
             out = predictor.predict_windows(x.permute(0, 4, 1, 2, 3).contiguous(), mask=m, mask_align_to_image=mask_align_to_image,
                                             requested_head=requested_head)
+            _require_window_shape(out, read, roi, ctx)
             pred = out.permute(0, 2, 3, 4, 1).contiguous()
         elif fwd_cl is not None:
             pred = fwd_cl(x)
+            _require_window_shape(pred, read, roi, ctx, channels_last=True)
         else:
             xin = x.permute(0, 4, 1, 2, 3)
             out = forward_fn(xin if x.shape[-1] == 1 else xin.contiguous())
             out, _ = select_output_tensor(out, requested_head=requested_head, primary_head=primary,
                                           purpose="inference output selection")
+            _require_window_shape(out, read, roi, ctx)
             pred = out.permute(0, 2, 3, 4, 1).contiguous()
-        if tuple(pred.shape[1:4]) != read:
-            scope = "Lazy sliding-window inference"
-            if any(ctx):
-                raise RuntimeError(f"{scope} with target_context={ctx} expected prediction spatial shape {read}, "
-                                   f"got {tuple(pred.shape[1:4])}.")
-            raise RuntimeError(f"{scope} requires model predictions to have the same spatial shape as the "
-                               f"sliding-window ROI. Got prediction.shape={tuple(pred.shape)} and roi_size={tuple(roi)}.")
         if any(ctx):
             pred = pred[:, ctx[0]:ctx[0] + roi[0], ctx[1]:ctx[1] + roi[1], ctx[2]:ctx[2] + roi[2]].contiguous()
         # activations / channel selection: the predictor applied them per view (before the ensemble, as the reference does)

@@ -29,8 +29,8 @@ _MISS_REMOVE = "Architecture '{name}' not registered."
 def register_architecture(name: str):
     """Decorator: ``@register_architecture("my_model") def build(cfg) -> nn.Module``."""
     def decorator(builder_fn: Callable) -> Callable:
-        replaced = _ARCHITECTURE_REGISTRY.pop(name, None) is not None
-        _ARCHITECTURE_REGISTRY[name] = builder_fn
+        replaced = name in _ARCHITECTURE_REGISTRY
+        _ARCHITECTURE_REGISTRY[name] = builder_fn                     # an overwritten name keeps its place in the table
         if replaced:
             warnings.warn(f"Architecture '{name}' already registered. Overwriting previous registration.", UserWarning)
         return builder_fn

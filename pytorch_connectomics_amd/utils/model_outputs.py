@@ -41,7 +41,7 @@ def get_inference_select_channel(cfg: Any) -> Any:
 
 def get_inference_channel_activations(cfg: Any) -> list:
     specs = get_inference_model_value(cfg, "channel_activations")
-    return list(specs) if isinstance(specs, (list, tuple)) else []
+    return specs if isinstance(specs, list) else []                # like the reference: anything but a list (a tuple too) means "none"
 
 
 def _named_heads(cfg: Any) -> Mapping:

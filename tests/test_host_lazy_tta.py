@@ -149,3 +149,21 @@ def test_chunked_runner_passes_mask_and_views_to_every_chunk(tmp_path, golden_di
     assert not torch.equal(unmasked, full)                                   # the mask did reach the windows
     with pytest.raises(TypeError, match="needs the test volume"):
         run_chunked_prediction_inference(cfg, _net_lazy, output_path=tmp_path / "q.npy", device="cpu")
+
+
+def test_window_contract_messages_and_batch_guard():
+    """A network that changes the spatial shape of its window is refused with the reference's messages in the caller's (N, C, Z, Y, X)
+    order (reference lazy.py:389-419); a batch whose size is not the number of window positions is refused before any kernel runs."""
+    from pytorch_connectomics_amd import hip_ops
+    from pytorch_connectomics_amd.inference.lazy import _require_window_shape
+    _require_window_shape(torch.zeros(2, 3, 6, 8, 8), (6, 8, 8), (6, 8, 8), (0, 0, 0))
+    _require_window_shape(torch.zeros(2, 6, 8, 8, 3), (6, 8, 8), (6, 8, 8), (0, 0, 0), channels_last=True)
+    with pytest.raises(RuntimeError, match=r"Got prediction.shape=\(2, 3, 5, 8, 8\) and roi_size=\(6, 8, 8\)\."):
+        _require_window_shape(torch.zeros(2, 5, 8, 8, 3), (6, 8, 8), (6, 8, 8), (0, 0, 0), channels_last=True)
+    with pytest.raises(RuntimeError, match=r"Got prediction.shape=\(2, 6, 8, 8\) and roi_size"):
+        _require_window_shape(torch.zeros(2, 6, 8, 8), (6, 8, 8), (6, 8, 8), (0, 0, 0))
+    with pytest.raises(RuntimeError, match=r"with target_context=\(1, 1, 1\) expected prediction spatial shape \(8, 10, 10\), got \(6, 8, 8\)\."):
+        _require_window_shape(torch.zeros(2, 3, 6, 8, 8), (8, 10, 10), (6, 8, 8), (1, 1, 1))
+    assert len(hip_ops._starts_array([(0, 0, 0), (1, 2, 3)], 2)) == 6
+    with pytest.raises(ValueError, match="1 window predictions for 2 window positions"):
+        hip_ops._starts_array([(0, 0, 0), (1, 2, 3)], 1)

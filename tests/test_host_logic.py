@@ -236,3 +236,33 @@ def test_upkern_load_weights_and_head_spec_parsing():
     c.model.mednext.size = "S"
     with pytest.raises(ValueError, match="checkpoint_style must be None or 'outside_block'"):
         build_model(c)
+
+
+def test_small_resolver_behaviours_found_by_the_differential_fuzzer():
+    """Three behaviours of the reference that tools/diff_fuzz_reference.py (section `small_resolvers`) pinned: an overwritten
+    architecture keeps its place in the registry table (registry.py:34-41: plain dict assignment), `inference.strategy` is compared
+    case-insensitively (inference/chunked.py:34-40), and channel activations that are not a LIST mean "none"
+    (utils/model_outputs.py:42-45)."""
+    from pytorch_connectomics_amd.inference.chunked import is_chunked_inference_enabled
+    from pytorch_connectomics_amd.models.architectures import registry as R
+    from pytorch_connectomics_amd.utils.model_outputs import get_inference_channel_activations
+    saved = dict(R._ARCHITECTURE_REGISTRY)
+    try:
+        R._ARCHITECTURE_REGISTRY.clear()
+        for name in ("first", "second"):
+            R.register_architecture(name)(lambda cfg: None)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            R.register_architecture("first")(lambda cfg: None)
+        assert [str(w.message) for w in caught] == ["Architecture 'first' already registered. Overwriting previous registration."]
+        assert list(R.get_architecture_info()) == ["first", "second"]
+    finally:
+        R._ARCHITECTURE_REGISTRY.clear()
+        R._ARCHITECTURE_REGISTRY.update(saved)
+    assert is_chunked_inference_enabled(NS(inference=NS(strategy="Chunked")))
+    assert not is_chunked_inference_enabled(NS(inference=NS(strategy="whole_volume", chunking=NS(enabled=False))))
+    assert is_chunked_inference_enabled(NS(inference=NS(chunking=NS(enabled=True))))
+    spec = {"channels": "0", "activation": "tanh"}
+    assert get_inference_channel_activations(NS(inference=NS(model=NS(channel_activations=[spec])))) == [spec]
+    assert get_inference_channel_activations(NS(inference=NS(model=NS(channel_activations=(spec,))))) == []
+    assert get_inference_channel_activations(NS(inference=NS(model=NS(channel_activations="sigmoid")))) == []

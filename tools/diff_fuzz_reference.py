@@ -175,6 +175,7 @@ def main():
     loss_orchestration(t, rnd)
     output_files(t, rnd)
     eager_engine(t, rnd)
+    small_resolvers(t, rnd)
     total, bad = sum(r[1] for r in t.rows), sum(r[2] for r in t.rows)
     print(f"TOTAL {total} cases, {bad} mismatches over {len(t.rows)} function pairs")
     return bad
@@ -680,6 +681,29 @@ def lazy_engine(t, rnd):
           lambda kw, region, use_mask: run(lz, "fake://", "fake://mask", kw, region, use_mask),
           lambda kw, region, use_mask: run(ol, vol, mask, kw, region, use_mask))
 
+    # networks that break the window contract (lazy.py:389-419 `_crop_prediction_to_roi`, the tensor / mapping checks around it)
+    bad_nets = {
+        "smaller": lambda x: net(x)[..., 1:, :, :],
+        "larger": lambda x: torch.nn.functional.pad(net(x), (1, 1, 0, 0, 0, 0)),
+        "mapping": lambda x: {"output": net(x)},
+        "deep_supervision": lambda x: {"output": net(x), "ds_1": net(x)[..., ::2, ::2, ::2]},
+        "named_heads": lambda x: {"output": {"a": net(x), "b": net(x)}},
+        "not_a_tensor": lambda x: [net(x)],
+        "rank4": lambda x: net(x)[0],
+        "no_batch_match": lambda x: net(x)[:1],
+    }
+
+    def run_bad(mod, source, which, ctx, tta):
+        kw = dict(roi=(6, 8, 8), blending="bump", overlap=0.5, snap=False, ctx=ctx, padding_mode="reflect", swb=2, acts=None, select=None, tta=tta,
+                  flips=[[0]] if tta else None, mode="mean")
+        y = mod.lazy_predict_volume(cfg_of(kw), bad_nets[which], source, mask_path=None, device="cpu")
+        return _tensor_digest(y, 3)
+    t.run("lazy engine: networks that break the window contract", [(w, c, tt) for w in bad_nets for c in ([], [1, 1, 1]) for tt in (False, True)],
+          lambda w, c, tt: run_bad(lz, "fake://", w, c, tt), lambda w, c, tt: run_bad(ol, vol, w, c, tt), show=12,
+          # a network that drops samples fails in both, by accident in the reference (a broadcast error of its accumulation) and in the
+          # stand-in kernels here; the product refuses it by name in hip_ops.blend_accumulate
+          same=lambda case, a, b: case[0] == "no_batch_match" and a[0] == b[0] == "err")
+
 
 def chunked_runner(t, rnd):
     """`run_chunked_prediction_inference` end to end on generated chunk geometries (chunk size, halo, z slabs, global crop, per-window
@@ -1027,6 +1051,39 @@ def eager_engine(t, rnd):
         return _tensor_digest(eng(x, net), 4)
     t.run("EagerSlidingWindowEngine (plan, probe, blending, normalisation, crop)", cases, lambda *c: run(rw, False, *c), lambda *c: run(ow, True, *c))
 
+    bad_nets = {"mapping": lambda x: {"output": net(x)}, "list": lambda x: [net(x)], "none": lambda x: None, "rank4": lambda x: net(x)[0],
+                "half": lambda x: net(x).half(), "double": lambda x: net(x).double(), "bf16": lambda x: net(x).bfloat16()}
+    inputs = {"rank4": (1, 9, 9, 9), "batch2": (2, 1, 9, 9, 9), "fine": (1, 1, 9, 10, 11), "smaller_than_roi": (1, 1, 3, 5, 7), "two_channels": (1, 2, 5, 7, 9)}
+
+    def run_bad(mod, patch, which_net, which_in):
+        x = torch.rand(inputs[which_in], generator=torch.Generator().manual_seed(3))
+        eng = mod.EagerSlidingWindowEngine(roi_size=(4, 6, 6), sw_batch_size=2, overlap=0.5, mode="bump", padding_mode="constant", cval=0.0,
+                                           sw_device=None, output_device=None)
+        if patch:
+            def on_cpu(inp, _eng=eng):                       # every check of the engine but "needs a HIP device"
+                try:
+                    return type(_eng)._check_inputs(_eng, inp)
+                except RuntimeError as e:
+                    if "no CPU path" not in str(e):
+                        raise
+                    return torch.device("cpu")
+            eng._check_inputs = on_cpu
+            eng.pipeline_streams = 1
+        one = lambda v: net(v[:, :1])                        # noqa: E731
+        y = eng(x, bad_nets.get(which_net, one))
+        return (str(y.dtype), _tensor_digest(y.float(), 3))
+
+    def documented(case, a, b):
+        """(1) accumulators are fp32 whatever the network returns and the result stays fp32 (DESIGN.md section 3 iii; the reference
+        accumulates in the network's dtype): same values to the narrow type's rounding.  (2) a rank-4 network output, which the
+        reference broadcasts into a (1, 2C, ...) result by accident, is refused by name."""
+        if case[0] in ("half", "double", "bf16") and a[0] == b[0] == "ok":
+            ra, rb = eval(a[1])[1], eval(b[1])[1]
+            return ra[0] == rb[0] and all(abs(p - q) <= 2e-3 * max(1.0, abs(p)) + 0.011 for p, q in zip(ra[2:], rb[2:]))
+        return case[0] == "rank4" and b[:2] == ("err", "ValueError") and "must preserve the ROI shape" in b[2]
+    t.run("EagerSlidingWindowEngine: bad networks and inputs", [(n, "fine") for n in bad_nets] + [("ok", i) for i in inputs],
+          lambda n, i: run_bad(rw, False, n, i), lambda n, i: run_bad(ow, True, n, i), show=12, same=documented)
+
 
 def prediction_crops(t, rnd):
     rk, ok_ = S.ref("connectomics.inference.chunk_grid"), __import__("pytorch_connectomics_amd.inference.chunk_grid", fromlist=["x"])
@@ -1043,6 +1100,260 @@ def prediction_crops(t, rnd):
                                                   chunking=NS(enabled=True))),))
     t.run("resolve_global_prediction_crop", cases, rk.resolve_global_prediction_crop, ok_.resolve_global_prediction_crop)
     t.run("resolve_selected_affinity_offsets", cases, rk.resolve_selected_affinity_offsets, ok_.resolve_selected_affinity_offsets)
+
+
+
+def small_resolvers(t, rnd):
+    """The small configuration resolvers and helpers around the engines."""
+    import json
+    import tempfile
+    import numpy as np
+    import torch
+    pkg = lambda name: __import__(f"pytorch_connectomics_amd.{name}", fromlist=["x"])          # noqa: E731
+    rw, ow = S.ref("connectomics.inference.window"), pkg("inference.window")
+
+    def maybe(pool):
+        return rnd.choice(pool)
+
+    def window_cfg():
+        sw = NS()
+        for key, pool in (("window_size", [None, [8, 8, 8], (4, 6, 8), [], [16, 16]]), ("overlap", [None, 0.5, 0.0, 1.5, -0.2, [0.25, 0.5, 0.995], (0.1, 0.2)]),
+                          ("sw_batch_size", [None, 1, 4, 0, -3, "2"]), ("blending", ["bump", "constant", "gaussian", "distance", "distance_transform", "Bump", " EDT "]),
+                          ("padding_mode", ["constant", "reflect", "replicate"]), ("cval", [0.0, 1, "0.5"]), ("keep_input_on_cpu", [False, True, 0, 1]),
+                          ("sw_device", [None, "", "none", "cuda", "cpu", "NULL"]), ("output_device", [None, "", "None", "cpu", "cuda:0"]),
+                          ("border_mask", [None, [], [2], [1, 2, 3], [1, 2], 0, ["3"]])):
+            if rnd.random() < 0.7:
+                setattr(sw, key, maybe(pool))
+        cfg = NS()
+        if rnd.random() < 0.85:
+            cfg.inference = NS(sliding_window=sw) if rnd.random() < 0.9 else NS()
+            if rnd.random() < 0.5:
+                cfg.inference.model = NS(output_dtype=maybe([None, "float32", "fp16", "torch.bfloat16", " Half ", "float64", "int8", 16, "bf16"]))
+        if rnd.random() < 0.6:
+            cfg.model = NS(output_size=maybe([None, [8, 8, 8], [16, 16], (4, 4, 4), []]))
+        if rnd.random() < 0.7:
+            cfg.data = NS()
+            if rnd.random() < 0.6:
+                cfg.data.data_transform = NS(patch_size=maybe([None, [6, 6, 6], [12, 12], []]))
+            if rnd.random() < 0.6:
+                cfg.data.dataloader = NS(batch_size=maybe([1, 3, 0]))
+            if rnd.random() < 0.5:
+                cfg.data.train = NS(do_2d=maybe([True, False]))
+            if rnd.random() < 0.3:
+                cfg.data.val = NS(do_2d=maybe([True, False]))
+        return cfg
+    cfgs = [(window_cfg(),) for _ in range(600)]
+    for fn in ("resolve_model_output_dtype", "is_2d_inference_mode", "resolve_inferer_roi_size"):
+        t.run(f"window.{fn}", cfgs, getattr(rw, fn), getattr(ow, fn))
+    t.run("window.resolve_border_mask", [(c[0], d) for c in cfgs for d in (2, 3)], rw.resolve_border_mask, ow.resolve_border_mask)
+    t.run("window.resolve_inferer_overlap", cfgs, lambda c: rw.resolve_inferer_overlap(c, (8, 8, 8)), lambda c: ow.resolve_inferer_overlap(c, (8, 8, 8)))
+    t.run("window._resolve_sliding_window_runtime", cfgs, lambda c: rw._resolve_sliding_window_runtime(c, (8, 8, 8)),
+          lambda c: ow._resolve_sliding_window_runtime(c, (8, 8, 8)))
+    t.run("window.is_distance_transform_blending", [(m,) for m in ("bump", "distance", "distance_transform", "EDT", " edt ", "constant", "dt", "Distance", "", "gaussian")],
+          rw.is_distance_transform_blending, ow.is_distance_transform_blending)
+
+    def maps(mod):
+        def f(roi, mode, dt):
+            v, w = mod.build_sliding_accumulator_weight_maps(roi, mode=mode, device="cpu", value_dtype=dt)
+            return (_tensor_digest(v), str(v.dtype), v is w or bool(torch.equal(v, w)), tuple(w.shape))
+        return f
+    t.run("build_sliding_accumulator_weight_maps",
+          [(tuple(rnd.randint(1, 12) for _ in range(rnd.choice((2, 3)))), m, dt) for m in ("bump", "constant", "distance", "gaussian")
+           for dt in (torch.float32, torch.float16, torch.bfloat16) for _ in range(6)], maps(rw), maps(ow))
+
+    rl, ol = S.ref("connectomics.inference.lazy"), pkg("inference.lazy")
+    t.run("lazy._snap_offsets", [(rnd.randint(1, 80), rnd.randint(1, 30), rnd.randint(-2, 20), rnd.choice((0, 0, 3, 11))) for _ in range(500)],
+          lambda i, r, s_, b: rl._snap_offsets(i, r, s_, border_pad=b), lambda i, r, s_, b: ol._snap_offsets(i, r, s_, border_pad=b))
+
+    rd, od = S.ref("connectomics.inference.lazy_distributed"), pkg("inference.lazy_distributed")
+
+    def dist_cfg():
+        cfg = NS()
+        if rnd.random() < 0.9:
+            cfg.inference = NS()
+            if rnd.random() < 0.9:
+                cfg.inference.sliding_window = NS(distributed_sharding=maybe([True, False, 1, None]))
+        if rnd.random() < 0.8:
+            cfg.data = NS(dataloader=NS(use_lazy_zarr=maybe([True, False]), use_lazy_h5=maybe([True, False])))
+        return cfg
+    t.run("lazy_distributed (single process): context, sharding switch, devices, validators, reduce", [(dist_cfg(), rnd.randint(1, 5)) for _ in range(120)],
+          lambda c, n: (rd.distributed_context(), rd.is_distributed_window_sharding_enabled(c), str(rd.distributed_reduction_device(torch.device("cpu"))),
+                        rd.validate_distributed_tensor_shape(torch.zeros(n), name="acc", reduction_device=torch.device("cpu")),
+                        rd.validate_distributed_patch_shard(local_count=0, total_count=n, reduction_device=torch.device("cpu")),
+                        rd.reduce_cpu_tensor_to_rank_zero(torch.arange(n), op=None, reduction_device=torch.device("cpu"), chunk_mb=1, name="acc").tolist()),
+          lambda c, n: (od.distributed_context(), od.is_distributed_window_sharding_enabled(c), str(od.distributed_reduction_device(torch.device("cpu"))),
+                        od.validate_distributed_tensor_shape(torch.zeros(n), name="acc", reduction_device=torch.device("cpu")),
+                        od.validate_distributed_patch_shard(local_count=0, total_count=n, reduction_device=torch.device("cpu")),
+                        od.reduce_cpu_tensor_to_rank_zero(torch.arange(n), op=None, reduction_device=torch.device("cpu"), chunk_mb=1, name="acc").tolist()))
+
+    rc, oc = S.ref("connectomics.inference.chunked"), pkg("inference.chunked")
+    rg, og = S.ref("connectomics.chunked.chunk_grid"), pkg("chunked.chunk_grid")
+
+    def chunk_cfg():
+        cfg = NS()
+        if rnd.random() < 0.9:
+            cfg.inference = NS()
+            if rnd.random() < 0.6:
+                cfg.inference.strategy = maybe(["whole_volume", "chunked", "Chunked", None, "lazy"])
+            if rnd.random() < 0.8:
+                ck = NS()
+                for key, pool in (("enabled", [True, False, 0, 1, None]), ("shard_id", [None, 0, 1, 3, -1, "2"]), ("num_shards", [None, 1, 2, 4, 0, -2, "3"]),
+                                  ("roi", [None, [4, 4, 4], [1, 2, 3, 7, 8, 9], [1, 2], [3, 3, 3, 3, 9, 9], [0, 0, 0], (5, 6, 7), ["4", "4", "4"]])):
+                    if rnd.random() < 0.7:
+                        setattr(ck, key, maybe(pool))
+                cfg.inference.chunking = ck
+        return cfg
+    ccfgs = [(chunk_cfg(),) for _ in range(500)]
+    for fn in ("is_chunked_inference_enabled", "_resolve_external_chunk_shard", "is_external_chunk_sharding_enabled", "_resolve_inference_roi"):
+        t.run(f"chunked.{fn}", ccfgs, getattr(rc, fn), getattr(oc, fn))
+
+    def roi_cases():
+        for _ in range(300):
+            vol = tuple(rnd.randint(4, 60) for _ in range(3))
+            chunk = tuple(rnd.randint(2, 25) for _ in range(3))
+            crop = tuple(rnd.randint(0, 4) for _ in range(3))
+            lo = tuple(rnd.randint(0, v) for v in vol)
+            hi = tuple(l + rnd.randint(1, 40) for l in lo)
+            yield vol, chunk, crop, lo, hi
+    t.run("chunked._filter_chunks_to_roi", list(roi_cases()),
+          lambda v, c, cr, lo, hi: rc._filter_chunks_to_roi(rg.build_chunk_grid(v, c), (lo, hi), cr),
+          lambda v, c, cr, lo, hi: oc._filter_chunks_to_roi(og.build_chunk_grid(v, c), (lo, hi), cr))
+
+    def abiss(mod):
+        def f(shape, seed):
+            a = np.random.default_rng(seed).random(shape, dtype=np.float32)
+            out = mod._to_abiss_affinity_convention(a)
+            return (out.shape, str(out.dtype), float(np.abs(out).sum()), out.reshape(-1)[:: max(1, out.size // 17)].tolist())
+        return f
+    t.run("chunked._to_abiss_affinity_convention", [((c, rnd.randint(1, 6), rnd.randint(1, 6), rnd.randint(1, 6)), i) for i, c in enumerate([3] * 40 + [1, 2, 4, 6])],
+          abiss(rc), abiss(oc))
+
+    rm, om = S.ref("connectomics.chunked.manifest"), pkg("chunked.manifest")
+
+    def manifest_script(mod):
+        def f(cfg_a, cfg_b, keys, overwrite):
+            with tempfile.TemporaryDirectory() as d:
+                path = Path(d) / "resume.json"
+                m = mod.ResumeManifest.load_or_create(path, cfg_a)
+                m.mark_completed(keys[0]); m.mark_completed(keys[0]); m.mark_many(keys)
+                first = json.loads(path.read_text())
+                m2 = mod.ResumeManifest.load_or_create(path, cfg_b, overwrite=overwrite)
+                m2.mark_many(keys[:1])
+                return (first, sorted(m2.completed), json.loads(path.read_text()), sorted(p.name for p in Path(d).iterdir()))
+        return f
+
+    def manifest_cases():
+        base = {"chunk_shape": [8, 8, 8], "overlap": 0.5, "output_dtype": "float32", "output_shape": [16, 16, 16], "note": "a"}
+        for _ in range(120):
+            other = dict(base)
+            for k in list(other):
+                r = rnd.random()
+                if r < 0.15:
+                    other.pop(k)
+                elif r < 0.35:
+                    other[k] = {"chunk_shape": [4, 8, 8], "overlap": 0.25, "output_dtype": "uint8", "output_shape": [16, 16, 8], "note": "b"}[k]
+            keys = [f"z{rnd.randint(0, 3)}_y{rnd.randint(0, 3)}_x0" for _ in range(rnd.randint(1, 5))]
+            yield base, other, keys, rnd.random() < 0.3
+    t.run("ResumeManifest (create, mark, reload, mismatch, overwrite)", list(manifest_cases()), manifest_script(rm), manifest_script(om),
+          same=lambda case, a, b: a[0] == b[0] == "err" and a[1] == b[1] and a[2].split("resume.json")[-1] == b[2].split("resume.json")[-1])
+
+    ru, ou = S.ref("connectomics.utils.model_outputs"), pkg("utils.model_outputs")
+
+    def head_cfg():
+        cfg = NS()
+        heads = maybe([None, {}, {"aff": NS(out_channels=3, target_slice="0:3")}, {"aff": NS(out_channels=3), "sdt": NS(out_channels=1, target_slice=[3])},
+                       {"a": {"out_channels": 2, "target_slice": "0:2"}, "b": {"out_channels": 1}, "c": {"out_channels": 4}}])
+        cfg.model = NS(out_channels=maybe([1, 3, None]))
+        if heads is not None:
+            cfg.model.heads = heads
+        if rnd.random() < 0.5:
+            cfg.model.primary_head = maybe([None, "aff", "sdt", "a", "zz", "", 3])
+        if rnd.random() < 0.8:
+            cfg.inference = NS(model=NS())
+            if rnd.random() < 0.6:
+                cfg.inference.model.head = maybe([None, "aff", "sdt", "a,b", "a, c ,b", "b,zz", ",", "", " aff ", "c", 5])
+            if rnd.random() < 0.5:
+                cfg.inference.model.select_channel = maybe([None, [0, 1], "0:2", -1])
+            if rnd.random() < 0.5:
+                cfg.inference.model.channel_activations = maybe([None, [], [["0:3", "sigmoid"]], ({"channels": "0", "activation": "tanh"},), "sigmoid"])
+        return cfg
+    hcfgs = [head_cfg() for _ in range(500)]
+    reqs = [None, "aff", "sdt", "a", "a,b", "zz", "", "  ", 3, "b, c", "a,zz"]
+    for fn in ("get_inference_model_config", "get_inference_select_channel", "get_inference_channel_activations", "get_model_head_names", "get_total_model_head_channels",
+               "resolve_output_heads", "resolve_configured_output_head", "resolve_configured_output_channels"):
+        t.run(f"model_outputs.{fn}", [(c,) for c in hcfgs], lambda c, fn=fn: _plain_ns(getattr(ru, fn)(c)), lambda c, fn=fn: _plain_ns(getattr(ou, fn)(c)))
+    t.run("model_outputs.resolve_output_head", [(c, rnd.choice(reqs), rnd.random() < 0.5) for c in hcfgs],
+          lambda c, r, an: ru.resolve_output_head(c, requested_head=r, purpose="fuzz", allow_none=an),
+          lambda c, r, an: ou.resolve_output_head(c, requested_head=r, purpose="fuzz", allow_none=an))
+    t.run("model_outputs.resolve_output_channels", [(c, rnd.choice(reqs), rnd.random() < 0.5) for c in hcfgs],
+          lambda c, r, aa: ru.resolve_output_channels(c, requested_head=r, purpose="fuzz", allow_ambiguous=aa),
+          lambda c, r, aa: ou.resolve_output_channels(c, requested_head=r, purpose="fuzz", allow_ambiguous=aa))
+    t.run("model_outputs.resolve_head_target_slice", [(c, rnd.choice(["aff", "sdt", "a", "b", "zz"])) for c in hcfgs], ru.resolve_head_target_slice, ou.resolve_head_target_slice)
+
+    def outputs():
+        x, y = torch.zeros(1, 2, 2), torch.ones(1, 3, 3)
+        return maybe([x, {"output": x}, {"output": x, "ds_1": y}, {"output": {"a": x, "b": y}}, {"a": x}, {"output": {}}, {"output": {"a": x}}, {"output": {"a": 5}},
+                      [x], None, {"output": None}, {"b": y, "a": x}])
+
+    def select(mod):
+        def f(out, req, primary):
+            tns, head = mod.select_output_tensor(out, requested_head=req, primary_head=primary, purpose="fuzz")
+            return (tuple(tns.shape), head)
+        return f
+    t.run("model_outputs.select_output_tensor", [(outputs(), rnd.choice([None, "a", "b", "zz"]), rnd.choice([None, "a", "b", "zz"])) for _ in range(400)],
+          select(ru), select(ou))
+
+    rr, orr = S.ref("connectomics.models.architectures.registry"), pkg("models.architectures.registry")
+
+    def registry_script(mod):
+        def f(ops):
+            import warnings
+            saved = dict(mod._ARCHITECTURE_REGISTRY)
+            mod._ARCHITECTURE_REGISTRY.clear()
+            log = []
+            try:
+                for op, name in ops:
+                    with warnings.catch_warnings(record=True) as caught:
+                        warnings.simplefilter("always")
+                        try:
+                            if op == "register":
+                                def builder(cfg, _n=name):
+                                    """doc of the builder."""
+                                    return _n
+                                mod.register_architecture(name)(builder)
+                                log.append(("registered", name))
+                            elif op == "get":
+                                log.append(("built", mod.get_architecture_builder(name)(None)))
+                            elif op == "has":
+                                log.append(("has", mod.is_architecture_available(name)))
+                            elif op == "drop":
+                                log.append(("dropped", mod.unregister_architecture(name)))
+                            elif op == "list":
+                                log.append(("list", mod.list_architectures()))
+                            else:
+                                log.append(("info", {k: sorted(v) for k, v in mod.get_architecture_info().items()}))
+                        except Exception as e:      # noqa: BLE001
+                            log.append(("err", type(e).__name__, str(e)))
+                        log.append(("warnings", [str(w.message) for w in caught]))
+                return log
+            finally:
+                mod._ARCHITECTURE_REGISTRY.clear()
+                mod._ARCHITECTURE_REGISTRY.update(saved)
+        return f
+    names = ["unet", "mednext", "rsunet", "x"]
+    t.run("architecture registry (register / overwrite / get / has / drop / list / info)",
+          [([(rnd.choice(["register", "register", "get", "has", "drop", "list", "info"]), rnd.choice(names)) for _ in range(rnd.randint(3, 12))],) for _ in range(200)],
+          registry_script(rr), registry_script(orr))
+
+
+def _plain_ns(v):
+    if isinstance(v, NS):
+        return {k: _plain_ns(x) for k, x in sorted(vars(v).items())}
+    if isinstance(v, dict):
+        return {k: _plain_ns(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_plain_ns(x) for x in v]
+    return v
 
 
 if __name__ == "__main__":

@@ -25,7 +25,8 @@ REF = Path("/root/reference")
 DEFAULT = ["tests/unit/test_architecture_registry.py", "tests/unit/test_prediction_transform.py", "tests/unit/test_registry_basic.py",
            "tests/unit/test_window_engine.py", "tests/unit/test_inference_stage.py", "tests/unit/test_lazy_inference.py",
            "tests/unit/test_chunked_inference.py", "tests/unit/test_inference_tta_affinity.py", "tests/unit/test_inference_tta_masking.py",
-           "tests/unit/test_mednext_multi_head_wrapper.py", "tests/unit/test_mednext_features.py", "tests/test_rsunet.py"]
+           "tests/unit/test_mednext_multi_head_wrapper.py", "tests/unit/test_mednext_features.py", "tests/test_rsunet.py",
+           "tests/unit/test_precomputed_affinity_output.py"]
 
 ALIAS_CONFTEST = '''
 import importlib, importlib.abc, importlib.util, os, sys, types
