@@ -675,11 +675,30 @@ class ConnectomicsModule(nn.Module):
             _load_optimizer_state(optimizer, res["optimizer_states"][0])
         if scheduler is not None and res.get("lr_schedulers"):
             scheduler.load_state_dict(res["lr_schedulers"][0])
-        ema = (res.get("callbacks") or {}).get("EMAWeightsCallback")
+        ema = _ema_callback_entry(res)
         if ema and getattr(optimizer, "ema_decay", None) is not None and hasattr(optimizer, "load_ema_state_dict"):
-            optimizer.load_ema_state_dict(self.model, ema["ema_state"], int(ema.get("updates", 0)))
+            optimizer.load_ema_state_dict(self.model, ema[EMA_STATE_KEY], int(ema.get("updates", 0)))
         self._resume = None
         return True
+
+
+EMA_STATE_KEY = "ema_state"                    # the reference callback's vocabulary (callbacks.py:752 `EMAWeightsCallback.EMA_STATE_KEY`)
+
+
+def _ema_callback_entry(checkpoint: Dict[str, Any]) -> Optional[Dict[str, Any]]:
+    """The EMA callback's state inside a Lightning-layout checkpoint: Lightning keys callback states by `state_key`, the class name
+    optionally followed by its arguments, hence the prefix match (reference callbacks.py:54-59)."""
+    for key, state in (checkpoint.get("callbacks") or {}).items():
+        if isinstance(state, dict) and str(key).startswith("EMAWeightsCallback") and state.get(EMA_STATE_KEY):
+            return state
+    return None
+
+
+def load_ema_state_dict(checkpoint: Dict[str, Any]) -> Optional[Dict[str, torch.Tensor]]:
+    """The EMA weights stored in `checkpoint`, keyed like `model.state_dict()`; None when the run had EMA off or the checkpoint
+    carries none (reference training/lightning/callbacks.py:46-60 -- same contract, so `--ema` evaluation reads either side's files)."""
+    entry = _ema_callback_entry(checkpoint)
+    return dict(entry[EMA_STATE_KEY]) if entry else None
 
 
 def _load_optimizer_state(optimizer, state: Dict[str, Any]) -> None:
