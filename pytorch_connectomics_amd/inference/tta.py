@@ -94,9 +94,17 @@ class TTAPredictor:
         return distributed_context()
 
     def _build_augmentation_combinations(self, tta_cfg, ndim: int):
-        """The (flip axes, rotation plane, k) views of a configuration for tensors of rank `ndim` (reference tta.py: rotation planes
-        in TENSOR dims there, spatial axes here -- callers of this package use resolve_tta_augmentation_combinations directly)."""
-        return resolve_tta_augmentation_combinations(tta_cfg, spatial_dims=_resolve_spatial_dims(ndim))
+        """The (flip axes, rotation plane, k) views of a configuration for tensors of rank `ndim`, in the reference predictor's
+        convention (tta.py:603-624): flip axes as configured (0 = z, 1 = y, 2 = x), rotation planes in TENSOR dims (+2 for batch and
+        channel).  The one place the predictor enumerates views, so it is also the seam for a caller that wants its own list."""
+        return [(flips, None if plane is None else tuple(int(a) + 2 for a in plane), k)
+                for flips, plane, k in resolve_tta_augmentation_combinations(tta_cfg, spatial_dims=_resolve_spatial_dims(ndim))]
+
+    @staticmethod
+    def _spatial_augmentation_combinations(augmentation_combinations):
+        """The same views with rotation planes as SPATIAL axes -- what the engine and the affinity plans index (tta.py:626-636)."""
+        return [(flips, None if plane is None else (int(plane[0]) - 2, int(plane[1]) - 2), k)
+                for flips, plane, k in augmentation_combinations]
 
     def _get_tta_cfg(self):
         return getattr(getattr(self.cfg, "inference", None), "test_time_augmentation", None)
@@ -411,7 +419,7 @@ class TTAPredictor:
             tta = self._get_tta_cfg()
             combos = [([], None, 0)]
             if tta is not None and getattr(tta, "enabled", True):
-                combos = resolve_tta_augmentation_combinations(tta, spatial_dims=_resolve_spatial_dims(x.dim()))
+                combos = self._spatial_augmentation_combinations(self._build_augmentation_combinations(tta, x.dim()))
             has_affinity = bool(resolve_affinity_channel_groups_from_cfg(self.cfg))
             plan = None
             acc = None
@@ -451,6 +459,11 @@ class TTAPredictor:
                 raise ValueError(f"device inference expects batch size 1; got batch {images.shape[0]}.")
             self._last_distributed_sharding_active = False
             self._last_skip_postprocess_on_rank = False
+            if self.sliding_inferer is None and not flat2d and not self.is_distributed_sharding_enabled():
+                # no sliding engine: the network sees every whole view directly, as in the reference (`_run_network` without an
+                # inferer, tta.py:415-433) -- so it may change the spatial shape (a view that transposes unequal axes, a network
+                # that pads its output; the mask check then speaks), which a window engine could not allow
+                return self.predict_windows(images, mask=mask, mask_align_to_image=mask_align_to_image, requested_head=requested_head)
             engine = self._engine_for(images)
             network = self._engine_network()
             tta = self._get_tta_cfg()
@@ -463,7 +476,7 @@ class TTAPredictor:
                     combos = [([int(a) + 1 for a in f], None if pl is None else tuple(int(a) + 1 for a in pl), k)
                               for f, pl, k in resolve_tta_augmentation_combinations(tta, spatial_dims=2)]
                 else:
-                    combos = resolve_tta_augmentation_combinations(tta, spatial_dims=_resolve_spatial_dims(images.dim()))
+                    combos = self._spatial_augmentation_combinations(self._build_augmentation_combinations(tta, images.dim()))
             vol = images[0].to(torch.float32).contiguous()
             orig = tuple(int(v) for v in vol.shape[1:])
             self._last_device = vol.device

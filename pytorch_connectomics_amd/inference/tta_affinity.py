@@ -164,6 +164,15 @@ class ViewValidity:
     (non-wrapped) values, or a boolean mask (reference tta_affinity.py ViewValidity / ValidityEntry)."""
     channels: tuple
 
+    @classmethod
+    def all_valid(cls, num_channels: int) -> "ViewValidity":
+        """Every channel valid everywhere (a view that moved no affinity channel)."""
+        return cls((None,) * int(num_channels))
+
+    def select(self, indices: Optional[Sequence[int]]) -> "ViewValidity":
+        """The validity of a channel selection, in the selection's order (None = all channels)."""
+        return self if indices is None else ViewValidity(tuple(self.channels[int(i)] for i in indices))
+
 
 @dataclass(frozen=True)
 class AffinityTTAPlan:

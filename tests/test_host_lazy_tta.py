@@ -17,7 +17,7 @@ from test_host_distributed_inference import _CpuOps
 
 class _Ops(_CpuOps):
     @staticmethod
-    def gather_windows(vol, starts, roi, pad_mode="constant", cval=0.0, **_kw):
+    def _gather_plain(vol, starts, roi, pad_mode="constant", cval=0.0, **_kw):
         """(C,Z,Y,X) -> (B, *roi, C); a window overhanging the box is padded like np.pad (constant / reflect / replicate)."""
         mode = {"constant": "constant", "reflect": "reflect", "replicate": "edge", "edge": "edge"}[str(pad_mode)]
         ext = vol.shape[1:]
@@ -30,6 +30,100 @@ class _Ops(_CpuOps):
             kw = dict(constant_values=float(cval)) if mode == "constant" else {}
             out.append(torch.from_numpy(np.pad(inner, pads, mode=mode, **kw)).permute(1, 2, 3, 0))
         return torch.stack(out).contiguous()
+
+    # ---- TTA view codes, affinity channel maps (csrc/window_kernels.hip: view_src, blend_accumulate[_mapped], blend_weight_shifted) ----
+    @staticmethod
+    def _to_view(win, view):
+        """canonical window (..., z, y, x, C) -> the view the network sees: out[z, y, x] = win[T(F(z, y, x))]."""
+        from pytorch_connectomics_amd import _native as nat
+        if view & nat.VIEW_SWAP_YX:
+            win = win.transpose(-3, -2)
+        dims = [d for d, bit in ((-4, nat.VIEW_FLIP_Z), (-3, nat.VIEW_FLIP_Y), (-2, nat.VIEW_FLIP_X)) if view & bit]
+        return torch.flip(win, dims) if dims else win
+
+    @staticmethod
+    def _from_view(pred, view):
+        """prediction of a view (..., z, y, x, C) -> canonical window frame (the inverse of `_to_view`)."""
+        from pytorch_connectomics_amd import _native as nat
+        dims = [d for d, bit in ((-4, nat.VIEW_FLIP_Z), (-3, nat.VIEW_FLIP_Y), (-2, nat.VIEW_FLIP_X)) if view & bit]
+        pred = torch.flip(pred, dims) if dims else pred
+        return pred.transpose(-3, -2) if view & nat.VIEW_SWAP_YX else pred
+
+    @staticmethod
+    def _window_map(wz, wy, wx, combine, floor_w, border):
+        from pytorch_connectomics_amd.inference.window import _combine_axes
+        w = _combine_axes([wz, wy, wx], combine, floor_w, "cpu", torch.float32).clone()
+        if border is not None and any(int(b) for b in border):
+            keep = torch.zeros_like(w)
+            bz, by, bx = (int(b) for b in border)
+            keep[bz:w.shape[0] - bz, by:w.shape[1] - by, bx:w.shape[2] - bx] = 1.0
+            w = w * keep
+        return w
+
+    @staticmethod
+    def _land(dst, src, start, lo=(0, 0, 0)):
+        """dst[start + lo ...] += src, clipped to dst (voxels of a window outside the accumulator are skipped)."""
+        ext, size = dst.shape[-3:], src.shape[-3:]
+        a = [start[i] + lo[i] for i in range(3)]
+        l = [max(0, a[i]) for i in range(3)]
+        h = [min(ext[i], a[i] + size[i]) for i in range(3)]
+        if any(h[i] <= l[i] for i in range(3)):
+            return
+        d = tuple(slice(l[i], h[i]) for i in range(3))
+        s_ = tuple(slice(l[i] - a[i], h[i] - a[i]) for i in range(3))
+        dst[(Ellipsis,) + d] += src[(Ellipsis,) + s_]
+
+    @classmethod
+    def gather_windows(cls, vol, starts, roi, *, view=0, pad_mode="constant", cval=0.0, **_kw):  # noqa: F811  (view-aware form)
+        return cls._to_view(cls._gather_plain(vol, starts, roi, pad_mode=pad_mode, cval=cval), view).contiguous()
+
+    @classmethod
+    def blend_accumulate(cls, pred, starts, value, weight, wz, wy, wx, *, view=0, combine=0, floor_w=1e-5, border=None):
+        assert len(starts) == pred.shape[0]
+        w = cls._window_map(wz, wy, wx, combine, floor_w, border)
+        canon = cls._from_view(pred.float(), view)
+        for i, s in enumerate(starts):
+            cls._land(value, canon[i].permute(3, 0, 1, 2) * w, s)
+            if weight is not None:
+                cls._land(weight, w, s)
+
+    @classmethod
+    def blend_accumulate_mapped(cls, pred, starts, value, weight, wz, wy, wx, chan_src, chan_shift, *, view=0, combine=0, floor_w=1e-5,
+                                border=None):
+        """output channel d <- canonical prediction channel chan_src[d] displaced by chan_shift[d]: the value predicted at q lands
+        at p = q + shift, weighted by the window map at p; p outside the window is dropped."""
+        assert len(starts) == pred.shape[0]
+        w = cls._window_map(wz, wy, wx, combine, floor_w, border)
+        canon = cls._from_view(pred.float(), view)
+        roi = canon.shape[1:4]
+        for i, s in enumerate(starts):
+            for d, (src, sh) in enumerate(zip(chan_src, chan_shift)):
+                q_lo = [max(0, -int(sh[a])) for a in range(3)]
+                q_hi = [min(roi[a], roi[a] - int(sh[a])) for a in range(3)]
+                if any(q_hi[a] <= q_lo[a] for a in range(3)):
+                    continue
+                q = tuple(slice(q_lo[a], q_hi[a]) for a in range(3))
+                p_lo = [q_lo[a] + int(sh[a]) for a in range(3)]
+                pbox = tuple(slice(p_lo[a], p_lo[a] + q_hi[a] - q_lo[a]) for a in range(3))
+                cls._land(value[d], canon[i][q + (int(src),)] * w[pbox], s, p_lo)
+            if weight is not None:
+                cls._land(weight, w, s)
+
+    @classmethod
+    def blend_weight_shifted(cls, starts, roi, weight, wz, wy, wx, shift, *, combine=0, floor_w=1e-5, border=None):
+        """weight += the window map over the positions p of each window whose source p - shift lies inside the window."""
+        w = cls._window_map(wz, wy, wx, combine, floor_w, border)
+        p_lo = [max(0, int(shift[a])) for a in range(3)]
+        p_hi = [min(int(roi[a]), int(roi[a]) + int(shift[a])) for a in range(3)]
+        if any(p_hi[a] <= p_lo[a] for a in range(3)):
+            return
+        box = tuple(slice(p_lo[a], p_hi[a]) for a in range(3))
+        for s in starts:
+            cls._land(weight, w[box], s, p_lo)
+
+    @staticmethod
+    def normalize_covered(value, weight):
+        value.copy_(torch.where(weight > 0, value / torch.where(weight > 0, weight, torch.ones_like(weight)), torch.zeros_like(value)))
 
     @staticmethod
     def channel_activation(value, c0, c1, act, scale=1.0, *, channels_last=False):

@@ -176,6 +176,7 @@ def main():
     output_files(t, rnd)
     eager_engine(t, rnd)
     small_resolvers(t, rnd)
+    patch_first_local(t, rnd)
     total, bad = sum(r[1] for r in t.rows), sum(r[2] for r in t.rows)
     print(f"TOTAL {total} cases, {bad} mismatches over {len(t.rows)} function pairs")
     return bad
@@ -1024,12 +1025,7 @@ def eager_engine(t, rnd):
     import pytorch_connectomics_amd.inference.window as ow
     rw = S.ref("connectomics.inference.window")
 
-    class Ops(L._Ops):
-        @staticmethod
-        def gather_windows(vol, starts, roi, *, view=0, pad_mode="constant", cval=0.0, **_kw):
-            assert view == 0
-            return L._Ops.gather_windows(vol, starts, roi, pad_mode=pad_mode, cval=cval)
-    ow.ops = Ops
+    ow.ops = L._Ops
 
     def net(x):
         ramp = torch.linspace(0, 1, x.shape[-1]).view(1, 1, 1, 1, -1)
@@ -1354,6 +1350,88 @@ def _plain_ns(v):
     if isinstance(v, (list, tuple)):
         return [_plain_ns(x) for x in v]
     return v
+
+
+def patch_first_local(t, rnd):
+    """Patch-first-local TTA (the reference default; tta.py:880-1314) through REAL sliding engines on both sides: the reference predictor +
+    its engine on CPU tensors against this package's predictor + engine with the device kernels replaced by the torch stand-ins
+    (view-coded gather / blend, affinity channel maps, per-shift weights: tests/test_host_lazy_tta.py `_Ops`).  Plain and
+    directional-affinity outputs; flips and quarter turns; blending modes, overlaps, ensemble modes, channel selection, masks."""
+    import torch
+    sys.path.insert(0, str(ROOT / "tests"))
+    import test_host_lazy_tta as L
+    import pytorch_connectomics_amd.inference.tta as otta
+    import pytorch_connectomics_amd.inference.tta_ensemble as oens
+    import pytorch_connectomics_amd.inference.window as ow
+    rtta, rw = S.ref("connectomics.inference.tta"), S.ref("connectomics.inference.window")
+    otta.ops = oens.ops = ow.ops = L._Ops
+
+    def net3(x):
+        z = torch.linspace(-1, 1, x.shape[2]).view(1, 1, -1, 1, 1)
+        y = torch.linspace(-1, 1, x.shape[3]).view(1, 1, 1, -1, 1)
+        w = torch.linspace(-1, 1, x.shape[4]).view(1, 1, 1, 1, -1)
+        return torch.cat([x * (1.0 + 0.5 * w) + 0.25 * y, torch.tanh(2 * x - 1) * z + 0.1 * w * y, 3 * x * x - 1.5 * w + z * y], 1)
+
+    def anet(n):
+        def f(x):
+            parts = net3(x)
+            return torch.cat([parts, 0.5 * parts + 0.1], 1)[:, :n]
+        return f
+
+    def cfg_of(kw):
+        offs = kw.get("offsets")
+        return NS(model=NS(primary_head=None, heads=None, out_channels=len(offs) if offs else 3),
+                  data=NS(train=NS(do_2d=False), val=NS(do_2d=False), dataloader=NS(batch_size=1),
+                          label_transform=None if not offs else NS(stack_outputs=True, targets=[
+                              {"name": "affinity", "kwargs": {"offsets": offs, "affinity_mode": kw["amode"]}}])),
+                  inference=NS(sliding_window=NS(window_size=list(kw["roi"]), sw_batch_size=kw["swb"], overlap=kw["overlap"], blending=kw["blending"],
+                                                 padding_mode="constant", cval=0.0, keep_input_on_cpu=False, sw_device=None, output_device=None,
+                                                 border_mask=[], distributed_sharding=False),
+                               model=NS(head=None, select_channel=kw["select"], output_dtype=None, channel_activations=kw["acts"], crop_pad=None),
+                               test_time_augmentation=NS(enabled=True, flip_axes=kw["flips"], rotation90_axes=kw["rot"], rotate90_k=kw["ks"],
+                                                         ensemble_mode=kw["mode"], patch_first_local=kw["patch_first"], distributed_sharding=False,
+                                                         apply_mask=True, empty_cache_interval=0)))
+    unit = ["1-0-0", "0-1-0", "0-0-1"]
+    cases = []
+    for _ in range(140):
+        square = rnd.random() < 0.6
+        roi = rnd.choice([(4, 6, 6), (5, 8, 8), (6, 6, 6)]) if square else rnd.choice([(4, 6, 8), (5, 7, 6)])
+        shape = tuple(r + rnd.choice([0, 2, 5, r]) for r in roi)
+        if square:
+            shape = (shape[0], shape[1], shape[1])
+        rot = rnd.choice([None, [[1, 2]]]) if square else None
+        affinity = rnd.random() < 0.5
+        offs = rnd.choice([unit, unit + ["2-0-0", "0-3-0", "0-0-3"], unit + ["3-0-0", "0-2-0", "0-0-2"]]) if affinity else None
+        cases.append(dict(roi=roi, shape=shape, swb=rnd.choice([1, 2, 4]), overlap=rnd.choice([0.0, 0.25, 0.5, (0.25, 0.5, 0.5)]),
+                          blending=rnd.choice(["constant", "bump", "bump", "distance_transform"]), flips=rnd.choice(["all", [[0]], [[1, 2]], [[2], [0, 1]], None]), rot=rot,
+                          ks=rnd.choice([None, [1], [1, 3], [0, 2]]) if rot else None, mode=rnd.choice(["mean", "min", "max", [["0", "max"], ["1:", "mean"]]]),
+                          select=rnd.choice([None, [2, 0], "0:2", [1]]),
+                          acts=rnd.choice([None, [{"channels": ":", "activation": "sigmoid"}], [{"channels": "0", "activation": "tanh"}]]),
+                          offsets=offs, amode=rnd.choice(["deepem", "banis"]), patch_first=rnd.random() < 0.8, use_mask=rnd.random() < 0.3,
+                          seed=rnd.randint(0, 10 ** 6)))
+
+    def run(tta_mod, win_mod, patch, kw):
+        cfg = cfg_of(kw)
+        g = torch.Generator().manual_seed(kw["seed"])
+        x = torch.rand((1, 1) + kw["shape"], generator=g)
+        mask = (torch.rand((1, 1) + kw["shape"], generator=g) > 0.4).float() if kw["use_mask"] else None
+        eng = win_mod.build_sliding_inferer(cfg)
+        if patch:
+            eng._check_inputs = lambda inp: torch.device("cpu")
+            eng.pipeline_streams = 1
+        network = anet(len(kw["offsets"])) if kw["offsets"] else net3
+        p = tta_mod.TTAPredictor(cfg=cfg, sliding_inferer=eng, forward_fn=network)
+        return _tensor_digest(p.predict(x, mask=mask), 3)
+
+    def close(case, a, b):
+        """fp32 summation order inside a window batch differs by construction (one scatter per window in order here, the reference adds
+        whole patches): equal to rounding."""
+        if a[0] != "ok" or b[0] != "ok":
+            return False
+        ra, rb = eval(a[1]), eval(b[1])
+        return ra[:2] == rb[:2] and all(abs(u - v) <= 2e-3 * max(1.0, abs(u)) for u, v in zip(ra[2:], rb[2:]))
+    t.run("TTAPredictor.predict through sliding engines (patch-first-local and whole-volume views, plain and affinity outputs)",
+          [(kw,) for kw in cases], lambda kw: run(rtta, rw, False, kw), lambda kw: run(otta, ow, True, kw), same=close, show=6)
 
 
 if __name__ == "__main__":

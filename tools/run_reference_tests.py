@@ -97,13 +97,8 @@ if os.environ.get("PYTC_STANDIN_KERNELS") == "1":
     import pytorch_connectomics_amd.inference.tta as _t
     import pytorch_connectomics_amd.inference.tta_ensemble as _e
 
-    class _Ops(_L._Ops):
-        @staticmethod
-        def gather_windows(vol, starts, roi, *, view=0, pad_mode="constant", cval=0.0, **_kw):
-            assert view == 0
-            return _L._Ops.gather_windows(vol, starts, roi, pad_mode=pad_mode, cval=cval)
     for _m in (_w, _lz, _t, _e):
-        _m.ops = _Ops
+        _m.ops = _L._Ops
     _w.EagerSlidingWindowEngine._check_inputs = lambda self, inputs: torch.device("cpu")
     _init = _w.EagerSlidingWindowEngine.__init__
     def _one_stream(self, *a, **k):
@@ -145,8 +140,8 @@ def main(argv):
         rec = run(rel, junit)
         print(f"{rel}: rc={rec['rc']}  {rec['summary']}")
         if verbose or rec["rc"] not in (0,):
-            for line in rec["lines"][-12:-1]:
-                print("    " + line[:220])
+            for line in (rec["lines"][:-1] if verbose else rec["lines"][-12:-1]):
+                print("    " + line[:260])
 
 
 if __name__ == "__main__":
