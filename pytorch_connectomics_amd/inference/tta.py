@@ -367,11 +367,20 @@ class TTAPredictor:
     def _is_flat_2d(self, images: torch.Tensor) -> bool:
         return bool(is_2d_inference_mode(self.cfg) and images.dim() == 5 and images.size(2) == 1)
 
+    def _foreign_inferer(self) -> bool:
+        """A sliding inferer that is not this package's engine: a plain callable without the `accumulate` entry point."""
+        return self.sliding_inferer is not None and not hasattr(self.sliding_inferer, "accumulate")
+
     def _engine_for(self, images: torch.Tensor):
-        """The configured sliding engine, or a single-window engine covering the whole image."""
-        if self.sliding_inferer is not None:
+        """The configured sliding engine (for a caller's own inferer: the engine the configuration describes), or a single-window
+        engine covering the whole image."""
+        if self.sliding_inferer is not None and not self._foreign_inferer():
             return self.sliding_inferer
-        from .window import EagerSlidingWindowEngine
+        from .window import EagerSlidingWindowEngine, build_sliding_inferer
+        if self._foreign_inferer():
+            own = build_sliding_inferer(self.cfg)
+            if own is not None:
+                return own
         return EagerSlidingWindowEngine(roi_size=tuple(images.shape[2:]), sw_batch_size=1, overlap=0.0,
                                         mode="constant", padding_mode="constant", cval=0.0)
 
@@ -403,12 +412,13 @@ class TTAPredictor:
         return out.squeeze(2) if (flat2d and out.dim() == 5) else out      # (B, C, H, W) like the reference's 2-D mode
 
     def predict_windows(self, windows: torch.Tensor, mask=None, mask_align_to_image: bool = False,
-                        requested_head: Optional[str] = None) -> torch.Tensor:
+                        requested_head: Optional[str] = None, run=None) -> torch.Tensor:
         """A BATCH of windows (B, C, *roi) through the network without a sliding engine -- what the reference's lazy loop asks
         its predictor for (lazy.py:1193-1198 -> tta.py:806-878 with `use_sliding=False`): every configured view of the batch is
         predicted, mapped back (`invert_view`: inverse quarter turns / flips, affinity channels re-anchored), activated and
         channel-selected, and streamed into a `TTAEnsembleAccumulator` (mean / min / max per channel, validity-aware); the
-        ensemble is masked last.  -> (B, C_sel, *roi) in the configured output dtype, on the device."""
+        ensemble is masked last.  -> (B, C_sel, *roi) in the configured output dtype, on the device.  `run` replaces the direct network
+        call per view (a caller-supplied sliding inferer: `predict`)."""
         from .tta_affinity import ViewValidity, build_affinity_tta_plan, invert_view, resolve_affinity_channel_groups_from_cfg, \
             validate_affinity_output
         from .tta_ensemble import TTAEnsembleAccumulator
@@ -424,7 +434,7 @@ class TTAPredictor:
             plan = None
             acc = None
             for i, (flips, plane, k) in enumerate(combos):
-                pred = self._network_tensor(apply_view(x, flips, plane, k, first_spatial_dim=2).contiguous())
+                pred = (run or self._network_tensor)(apply_view(x, flips, plane, k, first_spatial_dim=2).contiguous())
                 pred = pred if pred.dtype == torch.float32 else pred.float()
                 if has_affinity and plan is None:
                     plan = build_affinity_tta_plan(self.cfg, augmentation_combinations=combos, num_raw=int(pred.shape[1]),
@@ -464,10 +474,20 @@ class TTAPredictor:
                 # inferer, tta.py:415-433) -- so it may change the spatial shape (a view that transposes unequal axes, a network
                 # that pads its output; the mask check then speaks), which a window engine could not allow
                 return self.predict_windows(images, mask=mask, mask_align_to_image=mask_align_to_image, requested_head=requested_head)
-            engine = self._engine_for(images)
-            network = self._engine_network()
             tta = self._get_tta_cfg()
             enabled = tta is not None and getattr(tta, "enabled", True)
+            if self._foreign_inferer() and not (enabled and bool(getattr(tta, "patch_first_local", False))):
+                # a caller's own sliding inferer -- any `inferer(inputs=(1, C, *spatial), network=callable)` (MONAI's
+                # SlidingWindowInferer, a wrapper around this package's engine): every whole view goes through it, as in the reference
+                # (`_run_network`, tta.py:415-433).  Patch-first-local TTA never calls it (reference tta.py:880-1000 builds its own
+                # window loop from the configuration); `_engine_for` does the same below.
+                if flat2d or self.is_distributed_sharding_enabled():
+                    raise TypeError("a sliding inferer without `accumulate` (not this package's EagerSlidingWindowEngine) supports neither "
+                                    "2-D mode nor view sharding here")
+                return self.predict_windows(images, mask=mask, mask_align_to_image=mask_align_to_image, requested_head=requested_head,
+                                            run=lambda view: self.sliding_inferer(inputs=view, network=self._network_tensor))
+            engine = self._engine_for(images)
+            network = self._engine_network()
             combos = [([], None, 0)]
             if enabled:
                 if flat2d:

@@ -85,3 +85,33 @@ def test_predictor_without_a_sliding_engine_calls_the_network_on_whole_views(sta
     with pytest.raises(ValueError, match="Mask spatial shape must exactly match"):
         wider.predict(x, mask=torch.zeros(1, 1, 4, 5, 7))
     assert torch.all(wider.predict(x, mask=torch.zeros(1, 1, 4, 5, 7), mask_align_to_image=True) == 0)
+
+
+def test_a_callers_own_sliding_inferer_is_called_per_whole_view(standin_engine, golden_dir):
+    """Drop-in boundary (b)-2: the predictor takes ANY `inferer(inputs=, network=)` callable.  Without patch-first-local TTA every view
+    goes through it (reference `_run_network`, tta.py:415-433); patch-first-local TTA never calls it and runs the window loop the
+    configuration describes (reference tests/unit/test_inference_tta_masking.py:372-410) -- both give the engine's own answer."""
+    from pytorch_connectomics_amd.inference.tta import TTAPredictor
+    from pytorch_connectomics_amd.inference.window import build_sliding_inferer
+
+    class Tracking:
+        def __init__(self, inferer):
+            self.inferer, self.calls = inferer, 0
+
+        def __call__(self, *args, **kwargs):
+            self.calls += 1
+            return self.inferer(*args, **kwargs)
+    g = np.load(golden_dir / "tta.npz")
+    x = torch.from_numpy(g["x"])
+    tta_ns, acts, select = G.CASES["flipz_select"]
+    results = {}
+    for patch_first in (False, True):
+        cfg = G._cfg(NS(**{**vars(tta_ns), "patch_first_local": patch_first}), acts, select)
+        own = TTAPredictor(cfg=cfg, sliding_inferer=build_sliding_inferer(cfg), forward_fn=G._net_asym).predict(x)
+        wrapped = Tracking(build_sliding_inferer(cfg))
+        got = TTAPredictor(cfg=cfg, sliding_inferer=wrapped, forward_fn=G._net_asym).predict(x)
+        assert wrapped.calls == (0 if patch_first else 3)                     # identity, [0], [1, 2]
+        torch.testing.assert_close(got, own, rtol=1e-6, atol=1e-6)
+        results[patch_first] = got
+    # (the two modes differ for this position-dependent network; the reference fixture is the patch-first one)
+    np.testing.assert_allclose(results[True].numpy(), g["flipz_select__y"], rtol=2e-5, atol=2e-5)
