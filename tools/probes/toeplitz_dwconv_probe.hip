@@ -38,6 +38,10 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
 
+// PIPE = false: load a plane, unpack it, then compute (every 16-byte load is waited for on the spot: 4.5 serial HBM round trips per plane
+// with one wave per SIMD -- 470 us per 2 windows, profiles/r03_toeplitz_probe_v2.txt).  PIPE = true: the loads of plane z + 2 are issued
+// into registers before the MFMA phase of plane z and unpacked into the ring after it (software pipeline, +20 VGPRs).
+template <bool PIPE>
 __global__ void __launch_bounds__(256, 1)
 toeplitz_dwconv_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, const float* __restrict__ w,
                        const float* __restrict__ bias, float* __restrict__ stats, Geom g) {
@@ -55,6 +59,12 @@ toeplitz_dwconv_kernel(const unsigned short* __restrict__ x, unsigned short* __r
   const unsigned short* xn = x + (long)n * g.D * plane_elems;
   unsigned short* yn = y + (long)n * g.D * plane_elems;
 
+  // ---- the 27 x 32 taps go through LDS once (coalesced), so that the 320 fragment elements per lane are unconditional LDS reads: the
+  //      first version read them with 320 conditional global loads per lane, each behind its own branch and `s_waitcnt vmcnt(0)` --
+  //      ~130 us of serialised round trips per workgroup, which was the whole 545 us of profiles/r03_toeplitz_probe.txt
+  __shared__ float wl[27 * C];
+  for (int i = tid; i < 27 * C; i += 256) wl[i] = w[i];
+  __syncthreads();
   // ---- A fragments of this wave's 8 channels: afr[ch][s] = rows m (= lane & 15) of the banded Toeplitz block of tap pair s
   const int m = lane & 15, kg = lane >> 4;
   bf16x8_t afr[CPW][5];
@@ -68,9 +78,9 @@ toeplitz_dwconv_kernel(const unsigned short* __restrict__ x, unsigned short* __r
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int j = (kg & 1) * 8 + i, dx = j - m;
-        float v = 0.f;
-        if (q <= 8 && m < TX && dx >= 0 && dx <= 2) v = w[(long)(q * 3 + dx) * C + c];      // taps [kz][ky][kx][c], q = kz * 3 + ky
-        f[i] = (__bf16)v;
+        const bool on = q <= 8 && m < TX && dx >= 0 && dx <= 2;                            // taps [kz][ky][kx][c], q = kz * 3 + ky
+        const float v = wl[on ? (q * 3 + dx) * C + c : c];
+        f[i] = (__bf16)(on ? v : 0.f);
       }
       afr[ch][s] = f;
     }
@@ -98,11 +108,57 @@ toeplitz_dwconv_kernel(const unsigned short* __restrict__ x, unsigned short* __r
     }
   };
 
-  stage(zs - 1, (zs - 1 + 3) % 3);
-  stage(zs, zs % 3);
+  // ---- the same staging split in two: `issue` puts the 16-byte loads of a plane in flight (registers), `commit` unpacks them into a slot
+  constexpr int NPRE = (ROWS * WIN * (C / 8) + 255) / 256;                                      // 5 loads per thread and plane
+  u32x4_t pre[NPRE];
+  auto issue = [&](int gz) {
+    const bool zok = gz >= 0 && gz < g.D;
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int chunk = tid + k * 256;
+      const int part = chunk & 3, vox = chunk >> 2;
+      const int row = vox / WIN, col = vox % WIN;
+      const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      if (chunk < ROWS * WIN * (C / 8) && zok && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W)
+        v = *reinterpret_cast<const u32x4_t*>(xn + (long)gz * plane_elems + ((long)gy * g.W + gx) * C + part * 8);
+      pre[k] = v;
+    }
+  };
+  auto commit = [&](int slot) {
+    unsigned short* dst = ring[slot];
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int chunk = tid + k * 256;
+      if (chunk < ROWS * WIN * (C / 8)) {
+        const int part = chunk & 3, vox = chunk >> 2;
+        const int row = vox / WIN, col = vox % WIN;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const unsigned int d = pre[k][i >> 1];
+          dst[(part * 8 + i) * CH_PITCH + row * WIN + col] = (unsigned short)((i & 1) ? (d >> 16) : (d & 0xFFFFu));
+        }
+      }
+    }
+  };
+
+  if (PIPE) {
+    issue(zs - 1); commit((zs - 1 + 3) % 3);
+    issue(zs); commit(zs % 3);
+    issue(zs + 1);                                     // in flight until the top of the first iteration
+  } else {
+    stage(zs - 1, (zs - 1 + 3) % 3);
+    stage(zs, zs % 3);
+  }
   for (int z = zs; z < ze; ++z) {
-    stage(z + 1, (z + 1) % 3);
-    __syncthreads();                                   // planes z-1, z, z+1 are in LDS
+    if (PIPE) {
+      commit((z + 1) % 3);                             // plane z + 1 (loaded during the previous iteration): slot (z - 2) % 3 is free
+      __syncthreads();                                 // planes z-1, z, z+1 are in LDS
+      if (z + 1 < ze) issue(z + 2);                    // lands while the matrix cores work on plane z
+    } else {
+      stage(z + 1, (z + 1) % 3);
+      __syncthreads();                                 // planes z-1, z, z+1 are in LDS
+    }
     // ---- (b) this wave's channels
 #pragma unroll
     for (int ch = 0; ch < CPW; ++ch) {
@@ -172,7 +228,8 @@ static Geom make_geom(int N, int D, int H, int W) {
 
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(_e), __LINE__); exit(1); } } while (0)
 
-static double run_case(int N, int D, int H, int W, bool check, int reps) {
+static double run_case(int N, int D, int H, int W, bool check, int reps, bool pipe) {
+  auto kernel = pipe ? toeplitz_dwconv_kernel<true> : toeplitz_dwconv_kernel<false>;
   const long vox = (long)N * D * H * W, elems = vox * C;
   std::vector<unsigned short> hx(elems), hy(elems);
   std::vector<float> hw(27 * C), hb(C);
@@ -189,13 +246,13 @@ static double run_case(int N, int D, int H, int W, bool check, int reps) {
   CK(hipMemcpy(dx, hx.data(), elems * 2, hipMemcpyHostToDevice));
   CK(hipMemcpy(dw, hw.data(), 27 * C * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(db, hb.data(), C * 4, hipMemcpyHostToDevice));
   CK(hipMemset(dy, 0, elems * 2));
-  hipLaunchKernelGGL(toeplitz_dwconv_kernel, dim3((unsigned)wgs), dim3(256), 0, 0, dx, dy, dw, db, dst, g);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)wgs), dim3(256), 0, 0, dx, dy, dw, db, dst, g);
   CK(hipDeviceSynchronize());
   double ms = 0.0;
   if (reps > 0) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0));
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(toeplitz_dwconv_kernel, dim3((unsigned)wgs), dim3(256), 0, 0, dx, dy, dw, db, dst, g);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kernel, dim3((unsigned)wgs), dim3(256), 0, 0, dx, dy, dw, db, dst, g);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float t; CK(hipEventElapsedTime(&t, e0, e1)); ms = t / reps;
   }
@@ -218,7 +275,7 @@ static double run_case(int N, int D, int H, int W, bool check, int reps) {
       sum_ref += ref;
     }
     for (long i = 0; i < wgs; ++i) for (int c = 0; c < C; ++c) sum_got += hst[(i * 2) * C + c];
-    printf("check %dx%dx%dx%d: max |d| %.3e, outside one bf16 ulp: %ld of %ld; statistics sum %.4f vs reference %.4f\n", N, D, H, W, worst, bad,
+    printf("%s check %dx%dx%dx%d: max |d| %.3e, outside one bf16 ulp: %ld of %ld; statistics sum %.4f vs reference %.4f\n", pipe ? "pipelined" : "plain    ", N, D, H, W, worst, bad,
            elems, sum_got, sum_ref);
   }
   CK(hipFree(dx)); CK(hipFree(dy)); CK(hipFree(dw)); CK(hipFree(db)); CK(hipFree(dst));
@@ -226,13 +283,17 @@ static double run_case(int N, int D, int H, int W, bool check, int reps) {
 }
 
 int main(int argc, char** argv) {
-  run_case(1, 9, 20, 31, true, 0);
-  run_case(2, 16, 32, 28, true, 0);
+  for (int pipe = 0; pipe < 2; ++pipe) {
+    run_case(1, 9, 20, 31, true, 0, pipe != 0);
+    run_case(2, 16, 32, 28, true, 0, pipe != 0);
+  }
   if (argc > 1 && std::string(argv[1]) == "check") return 0;
   const int batch = argc > 2 ? atoi(argv[2]) : 8;                       // `time 2`: a 2-window batch (0.36 GB of traffic: partly cache-resident)
-  const double ms = run_case(batch, 112, 112, 112, false, 10);
   const double gb = 2.0 * batch * 112.0 * 112 * 112 * C * 2 / 1e9;
-  printf("%d x 112^3 x 32 bf16: %.1f us per launch, %.2f TB/s algorithmic (x + y once); the z-march VALU kernel: ~420 us per 8 windows in the network\n",
-         batch, ms * 1e3, gb / ms);
+  for (int pipe = 0; pipe < 2; ++pipe) {
+    const double ms = run_case(batch, 112, 112, 112, false, 10, pipe != 0);
+    printf("%s %d x 112^3 x 32 bf16: %.1f us per launch, %.2f TB/s algorithmic (x + y once); the z-march VALU kernel: ~0.53 ms per 8 windows at level 0\n",
+           pipe ? "pipelined" : "plain    ", batch, ms * 1e3, gb / ms);
+  }
   return 0;
 }
