@@ -44,7 +44,7 @@ def schema_defaults() -> dict:
     schema/inference.py:21-174, schema/optimization.py, schema/system.py)."""
     return {
         "experiment_name": "experiment", "description": "", "save_path": "outputs/experiment",
-        "system": {"num_gpus": 1, "num_workers": 0, "seed": 42, "accelerator": "auto"},
+        "system": {"profile": None, "num_gpus": 1, "num_workers": 8, "seed": 42, "accelerator": "auto"},      # schema/system.py (8 readers)
         "model": {
             "arch": {"type": "mednext"}, "in_channels": 1, "out_channels": 1, "input_size": None,
             "output_size": None, "heads": None, "primary_head": None,
@@ -63,9 +63,13 @@ def schema_defaults() -> dict:
         "data": {"train": {"image": None, "label": None, "do_2d": False},
                  "val": {"image": None, "label": None, "do_2d": False},
                  "test": {"image": None, "label": None},
-                 "dataloader": {"batch_size": 1, "patch_size": None, "use_lazy_zarr": False, "use_lazy_h5": False},
+                 # schema/data.py: batch_size 4 (also the sliding-window batch when sw_batch_size is unset, window.py:413-423) and image
+                 # normalisation "0-1" are the reference's defaults -- tutorials such as mito_lucchi++ rely on them unnamed.  NOT taken
+                 # over: dataloader.patch_size / model.input_size / model.output_size = [128, 128, 128] (here None: a configuration
+                 # names its patch and window sizes) and model.arch.type = monai_basic_unet3d (outside the hot path; here mednext)
+                 "dataloader": {"batch_size": 4, "patch_size": None, "use_lazy_zarr": False, "use_lazy_h5": False},
                  "data_transform": {"patch_size": None},
-                 "image_transform": {"normalize": "none"},
+                 "image_transform": {"transform_profile": None, "normalize": "0-1", "clip_percentile_low": 0.0, "clip_percentile_high": 1.0},
                  "mask_transform": None,
                  # schema/data.py:66-86 (the keys the inference path reads: stacked label targets -> affinity channel groups)
                  "label_transform": {"keys": ["label"], "stack_outputs": True, "retain_original": False, "output_dtype": "float32",

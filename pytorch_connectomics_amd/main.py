@@ -165,7 +165,10 @@ def run_test(cfg, args) -> dict:
                                                     device=dev, image_path=str(image_spec), checkpoint_path=args.checkpoint)
             pred_t = None if pred is None else torch.from_numpy(pred).unsqueeze(0)
         else:
-            host = np.ascontiguousarray(vol, dtype=np.float32)
+            # the reference's test pipeline normalises every loaded image under data.image_transform (schema default "0-1"); the
+            # chunked branch above does it per window through the accessor, like the reference's lazy reader
+            from .utils.volume_normalize import normalize_image_for_config
+            host = np.ascontiguousarray(normalize_image_for_config(vol, cfg), dtype=np.float32)
             if not host.flags.writeable:          # a read-only memory map (.npy opened with mmap): torch wants a writable buffer
                 host = host.copy()
             x = torch.from_numpy(host).to(dev)
@@ -243,7 +246,8 @@ def run_train(cfg, args) -> dict:
         batches = synthetic_batches(bs, patch, in_channels=cfg.model.in_channels, out_channels=cfg.model.out_channels,
                                     seed=int(cfg.system.seed) + rank, device=dev)
     else:
-        vol = torch.from_numpy(np.ascontiguousarray(read_volume(str(img_spec)), dtype=np.float32))
+        from .utils.volume_normalize import normalize_image_for_config
+        vol = torch.from_numpy(np.ascontiguousarray(normalize_image_for_config(read_volume(str(img_spec)), cfg), dtype=np.float32))
         lab = torch.from_numpy(np.ascontiguousarray(read_volume(str(cfg.data.train.label))).astype(np.float32))
         g = torch.Generator().manual_seed(int(cfg.system.seed) + rank)
 

@@ -1,0 +1,66 @@
+"""Whole-volume intensity normalisation of an image loaded for the eager test / training path of `main.py`.
+
+The reference's data pipeline applies `smart_normalize` (connectomics/data/augmentation/augment_ops.py:552-611) to every loaded image under
+`data.image_transform` -- and its schema default is mode "0-1" (config/schema/data.py:129), which tutorials such as mito_lucchi++ rely on
+without naming it.  The lazy / chunked path does this per window on the device (`LazyVolumeAccessor.finish_windows`); this is the same
+arithmetic for a whole host volume, in numpy, before the one upload: percentile clip first, then `none` | `normal` (z-score, skipped for
+a flat volume) | `0-1` (min-max, skipped for a flat volume) | `divide` / `divide-K`.  Pinned by tests/golden/smart_normalize.npz."""
+from __future__ import annotations
+
+from typing import Any, Optional
+
+import numpy as np
+
+_MODES = "'none', 'normal', '0-1', 'divide', or 'divide-K'"
+
+
+def _divisor(mode: str, divide_value: Optional[float]) -> tuple[str, Optional[float]]:
+    """('divide-255', _) -> ('divide', 255.0); every other mode unchanged."""
+    head, dash, tail = mode.partition("-")
+    if head != "divide" or not dash:
+        return mode, divide_value
+    try:
+        return "divide", float(tail)
+    except ValueError as exc:
+        raise ValueError(f"Invalid divide mode '{mode}'. Format should be 'divide-K' where K is a number (e.g., 'divide-255').") from exc
+
+
+def normalize_volume(volume: np.ndarray, mode: str = "0-1", *, divide_value: Optional[float] = None, clip_percentile_low: float = 0.0,
+                     clip_percentile_high: float = 1.0) -> np.ndarray:
+    """A normalised COPY of `volume` (numpy's own type promotion, like the reference: integer volumes come back as float64)."""
+    mode, divide_value = _divisor(str(mode), divide_value)
+    out = np.array(volume, copy=True)
+    if clip_percentile_low > 0.0 or clip_percentile_high < 1.0:
+        lo, hi = (np.percentile(out, 100.0 * q) for q in (clip_percentile_low, clip_percentile_high))
+        out = np.clip(out, lo, hi)
+    if mode == "none":
+        return out
+    if mode == "normal":
+        centre, spread = out.mean(), out.std()
+        return (out - centre) / spread if spread > 1e-8 else out
+    if mode == "0-1":
+        lo, hi = out.min(), out.max()
+        return (out - lo) / (hi - lo) if hi > lo else out
+    if mode == "divide":
+        if divide_value is None or float(divide_value) == 0.0:
+            raise ValueError("smart_normalize mode='divide' requires a non-zero divide_value (or use 'divide-K' form to embed the divisor "
+                             "in the mode string).")
+        return out / float(divide_value)
+    raise ValueError(f"Unknown smart_normalize mode '{mode}'. Expected {_MODES}.")
+
+
+def normalize_image_for_config(volume: np.ndarray, cfg: Any) -> np.ndarray:
+    """`normalize_volume` under `cfg.data.image_transform` (normalize / clip_percentile_low / clip_percentile_high); a configuration
+    without that section means mode "none" (array-driven callers and tests that hand over prepared data)."""
+    section = getattr(getattr(cfg, "data", None), "image_transform", None)
+    mode = getattr(section, "normalize", None) if section is not None else None
+    if mode is None:
+        return volume
+    low = float(getattr(section, "clip_percentile_low", 0.0) or 0.0)
+    high = float(getattr(section, "clip_percentile_high", 1.0) or 1.0)
+    if str(mode) == "none" and low <= 0.0 and high >= 1.0:
+        return volume
+    return normalize_volume(volume, str(mode), clip_percentile_low=low, clip_percentile_high=high)
+
+
+__all__ = ["normalize_volume", "normalize_image_for_config"]

@@ -1228,9 +1228,61 @@ def losses_extra():
     save("losses_extra.npz", **out)
 
 
+def volume_normalisation():
+    """connectomics/data/augmentation/augment_ops.py:552-611 `smart_normalize` on whole volumes -- what the reference's test pipeline
+    applies to a loaded image under `data.image_transform` (default mode "0-1"); `cv2`, which the module imports and this function
+    does not use, is an empty stub.  Inputs and outputs for every mode, with and without percentile clipping, on uint8 / uint16 /
+    float volumes, a constant volume, and the error messages."""
+    import json
+    import types
+    S.install()
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    sys.modules.pop("connectomics.data.augmentation.augment_ops", None)
+    ops_ = S.ref("connectomics.data.augmentation.augment_ops")
+    rng = np.random.default_rng(77)
+    vols = {"u8": (rng.random((6, 9, 11)) * 255).astype(np.uint8), "u16": (rng.random((5, 8, 8)) * 4000).astype(np.uint16),
+            "f32": rng.normal(3.0, 2.0, (4, 7, 9)).astype(np.float32), "const": np.full((3, 4, 5), 7, np.uint8)}
+    out, cases, errors = {}, [], {}
+    for vn, vol in vols.items():
+        out[f"in_{vn}"] = vol
+        for mode in ("none", "normal", "0-1", "divide-255", "divide-2.5", "divide"):
+            for lo, hi in ((0.0, 1.0), (0.02, 0.98), (0.0, 0.9)):
+                key = f"{vn}__{mode}__{lo}__{hi}"
+                kw = dict(divide_value=4.0) if mode == "divide" else {}
+                out[key] = ops_.smart_normalize(vol, mode, clip_percentile_low=lo, clip_percentile_high=hi, **kw)
+                cases.append([vn, mode, lo, hi, kw.get("divide_value")])
+    for mode, kw in (("divide", {}), ("divide", dict(divide_value=0.0)), ("divide-x", {}), ("zscore", {})):
+        try:
+            ops_.smart_normalize(vols["u8"], mode, **kw)
+        except Exception as e:          # noqa: BLE001
+            errors[f"{mode}|{kw.get('divide_value')}"] = [type(e).__name__, str(e)]
+    save("smart_normalize", **out)
+    (HERE / "smart_normalize.json").write_text(json.dumps({"cases": cases, "errors": errors}, indent=1))
+
+
+def config_defaults():
+    """The reference's schema defaults (connectomics/config/schema/root.py `Config()`, plain dataclasses) as a JSON tree: what a YAML that
+    does not name a key gets.  tests/test_host_config_main.py compares this package's `Config()` with it key by key."""
+    import dataclasses
+    import json
+    S.install()
+    root = S.ref("connectomics.config.schema.root")
+
+    def plain(v):
+        if dataclasses.is_dataclass(v):
+            return {f.name: plain(getattr(v, f.name)) for f in dataclasses.fields(v)}
+        if isinstance(v, dict):
+            return {str(k): plain(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [plain(x) for x in v]
+        return v if isinstance(v, (str, int, float, bool, type(None))) else repr(v)
+    (HERE / "config_defaults.json").write_text(json.dumps(plain(root.Config()), indent=1, sort_keys=True))
+    print("wrote config_defaults.json")
+
+
 if __name__ == "__main__":
     parts = {"manifests": manifests, "optimizers": optimizers, "schedules": schedules, "selectors": selectors, "outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
-             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "lazy_tta": lazy_tta, "masks": masks, "accessor": accessor, "accessor_tiles": accessor_tiles, "ds_loss": ds_loss, "loss_orchestration": loss_orchestration, "losses_extra": losses_extra, "public_adapters": public_adapters, "public_helpers": public_helpers}
+             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "lazy_tta": lazy_tta, "masks": masks, "accessor": accessor, "accessor_tiles": accessor_tiles, "ds_loss": ds_loss, "loss_orchestration": loss_orchestration, "losses_extra": losses_extra, "public_adapters": public_adapters, "public_helpers": public_helpers, "volume_normalisation": volume_normalisation, "config_defaults": config_defaults}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:
         parts[name]()

@@ -21,6 +21,8 @@ default:
     window: {{window_size: [32, 32, 32], overlap: 0.5, blending: bump, sw_batch_size: 4}}
     model: {{channel_activations: [{{channels: ":", activation: sigmoid}}]}}
     test_time_augmentation: {{enabled: true, flip_axes: [[2]]}}
+  data:
+    image_transform: {{normalize: none}}
 test:
   data:
     test: {{image: "{img}", label: "{lab}"}}
@@ -135,6 +137,7 @@ default:
   data:
     train: {{image: "random://minimal/train_image", label: "random://minimal/train_label"}}
     dataloader: {{batch_size: 1, patch_size: [32, 64, 64]}}
+    image_transform: {{normalize: none}}
   inference:
     window: {{window_size: [32, 64, 64], overlap: 0.5, sw_batch_size: 2}}
     model: {{channel_activations: [{{channels: ":", activation: sigmoid}}]}}
@@ -199,6 +202,7 @@ default:
   data:
     train: {{image: "random://m2d/train_image", label: "random://m2d/train_label", do_2d: true}}
     dataloader: {{batch_size: 2, patch_size: [64, 48]}}
+    image_transform: {{normalize: none}}
   inference:
     model:
       channel_activations:

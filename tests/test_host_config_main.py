@@ -1,7 +1,9 @@
 """CPU tests: YAML config surface (stage merge, _base_, overrides, alias sync) and the CLI contract."""
 import textwrap
 from pathlib import Path
+from types import SimpleNamespace as NS
 
+import numpy as np
 import pytest
 import torch
 
@@ -255,3 +257,65 @@ def test_zarr_v2_volume(tmp_path):
             (root / f"{iz}.{iy}.0").write_bytes(zlib.compress(block.tobytes()))
     assert np.array_equal(read_volume(str(tmp_path / "v.zarr" / "img")), vol)
     assert np.array_equal(read_volume(str(tmp_path / "v.zarr")), vol)            # first array of the group
+
+
+def test_schema_defaults_against_the_reference_schema(golden_dir):
+    """Every key this package's `Config()` carries has the reference schema's default (tests/golden/config_defaults.json, generated
+    from connectomics/config/schema by make_golden.py --config_defaults) -- a YAML that does not name a key must behave the same on
+    both sides -- except the deviations listed here, each on purpose."""
+    import json
+    from pytorch_connectomics_amd.config import Config
+    reference = json.loads((golden_dir / "config_defaults.json").read_text())
+    on_purpose = {
+        "experiment_name", "save_path",                       # naming of this package's own output directory
+        "model.arch.type",                                    # reference default monai_basic_unet3d is outside the hot path
+        "model.input_size", "model.output_size", "data.dataloader.patch_size",   # [128]*3 there; here a configuration names its sizes
+        "model.heads", "inference.model.channel_activations", "evaluation.metrics",   # None / {} / []: the same meaning
+        "model.loss.deep_supervision_weights",                # None there = the same [1, .5, .25, .125, .0625] spelled out
+    }
+    only_here = {"data.data_transform.patch_size", "inference.window.edge_offset", "inference.window.min_contact",
+                 "inference.sliding_window.edge_offset", "inference.sliding_window.min_contact", "inference.save"}
+    differing, unknown = [], []
+
+    def plain(v):
+        if hasattr(v, "items"):
+            return {k: plain(x) for k, x in v.items()}
+        return [plain(x) for x in v] if isinstance(v, (list, tuple)) else v
+
+    def walk(ours, theirs, path):
+        for key, value in ours.items():
+            here = f"{path}.{key}" if path else key
+            if not isinstance(theirs, dict) or key not in theirs:
+                unknown.append(here)
+            elif isinstance(value, dict) and isinstance(theirs[key], dict):
+                walk(value, theirs[key], here)
+            elif value != theirs[key]:
+                differing.append(here)
+    walk(plain(Config()), reference, "")
+    assert set(differing) == on_purpose, sorted(set(differing) ^ on_purpose)
+    assert set(unknown) == only_here, sorted(set(unknown) ^ only_here)
+    cfg = Config()
+    assert cfg.data.image_transform.normalize == "0-1" and cfg.data.dataloader.batch_size == 4 and cfg.system.num_workers == 8
+
+
+def test_whole_volume_normalisation_matches_the_reference(golden_dir):
+    """`normalize_volume` == the reference's `smart_normalize` (augment_ops.py:552-611) bit for bit, dtype included, on 72 mode / clip /
+    dtype combinations; same error messages; `normalize_image_for_config` reads data.image_transform and leaves arrays alone when a
+    configuration has no such section."""
+    import json
+    from pytorch_connectomics_amd.utils.volume_normalize import normalize_image_for_config, normalize_volume
+    g, meta = np.load(golden_dir / "smart_normalize.npz"), json.loads((golden_dir / "smart_normalize.json").read_text())
+    for vol, mode, low, high, divisor in meta["cases"]:
+        want = g[f"{vol}__{mode}__{low}__{high}"]
+        got = normalize_volume(g[f"in_{vol}"], mode, divide_value=divisor, clip_percentile_low=low, clip_percentile_high=high)
+        assert got.dtype == want.dtype and np.array_equal(got, want), (vol, mode, low, high)
+    for key, (kind, message) in meta["errors"].items():
+        mode, divisor = key.split("|")
+        with pytest.raises(ValueError) as err:
+            normalize_volume(g["in_u8"], mode, divide_value=None if divisor == "None" else float(divisor))
+        assert type(err.value).__name__ == kind and str(err.value) == message
+    raw = g["in_u8"]
+    assert normalize_image_for_config(raw, NS()) is raw
+    assert normalize_image_for_config(raw, NS(data=NS(image_transform=NS(normalize="none")))) is raw
+    scaled = normalize_image_for_config(raw, NS(data=NS(image_transform=NS(normalize="0-1", clip_percentile_low=0.0, clip_percentile_high=1.0))))
+    assert np.array_equal(scaled, g["u8__0-1__0.0__1.0"]) and raw.dtype == np.uint8       # the input is not modified
