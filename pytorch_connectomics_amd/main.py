@@ -165,10 +165,11 @@ def run_test(cfg, args) -> dict:
                                                     device=dev, image_path=str(image_spec), checkpoint_path=args.checkpoint)
             pred_t = None if pred is None else torch.from_numpy(pred).unsqueeze(0)
         else:
-            # the reference's test pipeline normalises every loaded image under data.image_transform (schema default "0-1"); the
-            # chunked branch above does it per window through the accessor, like the reference's lazy reader
-            from .utils.volume_normalize import normalize_image_for_config
-            host = np.ascontiguousarray(normalize_image_for_config(vol, cfg), dtype=np.float32)
+            # the reference's test transforms, in their order (data/augmentation/build.py:416-655); the chunked branch above does the
+            # same per region / window through the accessor, like the reference's lazy reader
+            from .utils.volume_normalize import prepare_test_image
+            vol = prepare_test_image(vol, cfg)              # val_transpose, context border (pad_size / pad_mode), normalisation
+            host = np.ascontiguousarray(vol, dtype=np.float32)
             if not host.flags.writeable:          # a read-only memory map (.npy opened with mmap): torch wants a writable buffer
                 host = host.copy()
             x = torch.from_numpy(host).to(dev)

@@ -63,4 +63,46 @@ def normalize_image_for_config(volume: np.ndarray, cfg: Any) -> np.ndarray:
     return normalize_volume(volume, str(mode), clip_percentile_low=low, clip_percentile_high=high)
 
 
-__all__ = ["normalize_volume", "normalize_image_for_config"]
+def _spatial_pad_widths(pad_size, ndim: int):
+    """`data.data_transform.pad_size` (1, 3 or 6 ints, ZYX) -> np.pad widths for a (Z, Y, X) or (C, Z, Y, X) volume."""
+    values = [int(v) for v in (pad_size or [])]
+    if not values or not any(values):
+        return None
+    if len(values) == 1:
+        values = values * 3
+    if len(values) == 3:
+        pairs = [(v, v) for v in values]
+    elif len(values) == 6:
+        pairs = [(values[2 * i], values[2 * i + 1]) for i in range(3)]
+    else:
+        raise ValueError(f"pad_size length must be 1, 3, or 6, got {len(values)}")
+    return [(0, 0)] * (ndim - 3) + pairs
+
+
+def prepare_test_image(volume: np.ndarray, cfg: Any) -> np.ndarray:
+    """What the reference's TEST transforms do to a loaded image before sliding-window inference, in their order
+    (data/augmentation/build.py:416-655): `data_transform.val_transpose` on the spatial axes, the explicit context border
+    `data_transform.pad_size` in `pad_mode` (reflect by default -- the border that `inference.crop_pad` removes again from the
+    prediction, e.g. tutorials/neuron_snemi), then the intensity normalisation over the padded volume.  `data_transform.resize` is
+    refused by name: resampling lives in the lazy reader of this package (`data.dataloader.use_lazy_*`)."""
+    shared = getattr(getattr(cfg, "data", None), "data_transform", None)
+    out = volume
+    if shared is not None:
+        if getattr(shared, "resize", None):
+            raise NotImplementedError("data.data_transform.resize is honoured by the lazy reader only (set data.dataloader.use_lazy_h5 / "
+                                      "use_lazy_zarr with inference.chunking), not by the eager test path of main.py")
+        axes = [int(a) for a in (getattr(shared, "val_transpose", None) or [])]
+        if axes:
+            if sorted(axes) != [0, 1, 2]:
+                raise ValueError(f"data.data_transform.val_transpose must be a permutation of (0, 1, 2), got {axes}")
+            lead = out.ndim - 3
+            out = np.transpose(out, list(range(lead)) + [lead + a for a in axes])
+        widths = _spatial_pad_widths(getattr(shared, "pad_size", None), out.ndim)
+        if widths is not None:
+            mode = str(getattr(shared, "pad_mode", "reflect") or "reflect")
+            mode = {"replicate": "edge", "circular": "wrap"}.get(mode, mode)
+            out = np.pad(out, widths, mode="constant", constant_values=0) if mode == "constant" else np.pad(out, widths, mode=mode)
+    return normalize_image_for_config(out, cfg)
+
+
+__all__ = ["normalize_volume", "normalize_image_for_config", "prepare_test_image"]

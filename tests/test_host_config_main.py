@@ -319,3 +319,33 @@ def test_whole_volume_normalisation_matches_the_reference(golden_dir):
     assert normalize_image_for_config(raw, NS(data=NS(image_transform=NS(normalize="none")))) is raw
     scaled = normalize_image_for_config(raw, NS(data=NS(image_transform=NS(normalize="0-1", clip_percentile_low=0.0, clip_percentile_high=1.0))))
     assert np.array_equal(scaled, g["u8__0-1__0.0__1.0"]) and raw.dtype == np.uint8       # the input is not modified
+
+
+def test_prepare_test_image_follows_the_reference_test_transforms():
+    """val_transpose -> context border (pad_size, pad_mode) -> normalisation over the padded volume (reference
+    data/augmentation/build.py:416-655); the SNEMI tutorial's pad_size [16, 80, 80] + crop_pad [15, 16, 79, 80, 79, 80] + the deepem
+    affinity crop bring the prediction back to the label's field of view."""
+    from pytorch_connectomics_amd.inference.crop import cropped_shape, resolve_global_prediction_crop
+    from pytorch_connectomics_amd.utils.volume_normalize import normalize_volume, prepare_test_image
+    rng = np.random.default_rng(3)
+    vol = (rng.random((5, 6, 7)) * 200).astype(np.uint8)
+    cfg = NS(data=NS(data_transform=NS(val_transpose=[2, 0, 1], pad_size=[1, 2, 3], pad_mode="reflect", resize=None),
+                     image_transform=NS(normalize="normal", clip_percentile_low=0.0, clip_percentile_high=1.0)))
+    want = normalize_volume(np.pad(np.transpose(vol, (2, 0, 1)), [(1, 1), (2, 2), (3, 3)], mode="reflect"), "normal")
+    got = prepare_test_image(vol, cfg)
+    assert got.shape == (9, 9, 12) and np.array_equal(got, want)
+    four = np.stack([vol, vol[::-1]])                                   # (C, Z, Y, X): the channel axis is left alone
+    cfg.data.data_transform = NS(val_transpose=[], pad_size=[1, 0, 2, 0, 0, 3], pad_mode="constant", resize=None)
+    cfg.data.image_transform = NS(normalize="none")
+    padded = prepare_test_image(four, cfg)
+    assert padded.shape == (2, 6, 8, 10) and np.array_equal(padded[:, 1:, 2:, :7], four) and padded[:, 0].max() == 0
+    cfg.data.data_transform = NS(val_transpose=None, pad_size=[0, 0, 0], pad_mode="reflect", resize=None)
+    assert prepare_test_image(vol, cfg) is vol
+    cfg.data.data_transform.resize = [8, 8, 8]
+    with pytest.raises(NotImplementedError, match="lazy reader"):
+        prepare_test_image(vol, cfg)
+    snemi = NS(data=NS(label_transform=NS(stack_outputs=True, targets=[{"name": "affinity", "kwargs": {
+                   "offsets": ["1-0-0", "0-1-0", "0-0-1"], "affinity_mode": "deepem"}}])),
+               inference=NS(crop_pad=None, model=NS(select_channel=[0, 1, 2], crop_pad=[15, 16, 79, 80, 79, 80])))
+    crop = resolve_global_prediction_crop(snemi)
+    assert cropped_shape((100 + 32, 1024 + 160, 1024 + 160), crop) == (100, 1024, 1024)
