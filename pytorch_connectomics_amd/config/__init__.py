@@ -62,7 +62,7 @@ def schema_defaults() -> dict:
         },
         "data": {"train": {"image": None, "label": None, "do_2d": False},
                  "val": {"image": None, "label": None, "do_2d": False},
-                 "test": {"image": None, "label": None},
+                 "test": {"image": None, "label": None, "mask": None},
                  # schema/data.py: batch_size 4 (also the sliding-window batch when sw_batch_size is unset, window.py:413-423) and image
                  # normalisation "0-1" are the reference's defaults -- tutorials such as mito_lucchi++ rely on them unnamed.  NOT taken
                  # over: dataloader.patch_size / model.input_size / model.output_size = [128, 128, 128] (here None: a configuration

@@ -157,12 +157,18 @@ def run_test(cfg, args) -> dict:
     out_dir = Path(cfg.save_path) / "results"
     out_dir.mkdir(parents=True, exist_ok=True)
     name = Path(str(image_spec).split("?")[0]).stem or "volume"
+    # data.test.mask: multiplied into the prediction after the ensemble (TTAPredictor._apply_mask_to_result; the lazy / chunked path
+    # reads it region by region), with the reference's alignment switch (test_pipeline.py:282-288)
+    from .utils.volume_normalize import mask_align_to_image, prepare_test_mask
+    mask_spec = getattr(cfg.data.test, "mask", None)
+    align_mask = mask_align_to_image(cfg)
     t0 = time.perf_counter()
     with torch.no_grad():
         if is_chunked_inference_enabled(cfg):
             pred = run_chunked_prediction_inference(cfg, model.forward, vol if vol is not None else str(image_spec),
                                                     output_path=out_dir / f"{name}_prediction.h5",
-                                                    device=dev, image_path=str(image_spec), checkpoint_path=args.checkpoint)
+                                                    device=dev, image_path=str(image_spec), checkpoint_path=args.checkpoint,
+                                                    mask_path=str(mask_spec) if mask_spec else None, mask_align_to_image=align_mask)
             pred_t = None if pred is None else torch.from_numpy(pred).unsqueeze(0)
         else:
             # the reference's test transforms, in their order (data/augmentation/build.py:416-655); the chunked branch above does the
@@ -199,8 +205,14 @@ def run_test(cfg, args) -> dict:
             art = out_dir / f"{name}_prediction.h5"
             # predict; with no crop the stage writes the artifact itself (transform + storage dtype on the device, one D2H
             # copy of the stored representation); with a crop the stage is re-entered on the cropped prediction
-            pred_t = run_prediction_inference(mgr, x, output_path=None if cropping else art, image_path=str(image_spec),
-                                              checkpoint_path=args.checkpoint, input_shape=vol.shape[-3:], crop_pad=crop_pad)
+            mask_t = None
+            if mask_spec:
+                mask_t = torch.from_numpy(np.ascontiguousarray(prepare_test_mask(read_volume(str(mask_spec)), cfg), dtype=np.float32)).to(dev)
+                while mask_t.dim() < 5:
+                    mask_t = mask_t.unsqueeze(0)
+            pred_t = run_prediction_inference(mgr, x, mask=mask_t, mask_align_to_image=align_mask, output_path=None if cropping else art,
+                                              image_path=str(image_spec), checkpoint_path=args.checkpoint, input_shape=vol.shape[-3:],
+                                              crop_pad=crop_pad)
             if cropping:
                 pred_t = crop_spatial_by_pad(pred_t, crop_pad, item_name="prediction").contiguous()
                 held = NS(cfg=cfg, predict_with_tta=lambda *_a, **_k: pred_t)

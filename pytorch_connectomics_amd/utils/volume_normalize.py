@@ -105,4 +105,32 @@ def prepare_test_image(volume: np.ndarray, cfg: Any) -> np.ndarray:
     return normalize_image_for_config(out, cfg)
 
 
-__all__ = ["normalize_volume", "normalize_image_for_config", "prepare_test_image"]
+def _mask_section(cfg: Any):
+    data = getattr(cfg, "data", None)
+    return getattr(data, "mask_transform", None) or getattr(data, "data_transform", None)
+
+
+def mask_align_to_image(cfg: Any) -> bool:
+    """`align_to_image` of `data.mask_transform` (else `data.data_transform`): allow the small centre pad / crop of a mask onto the
+    prediction (reference training/lightning/test_pipeline.py:282-288)."""
+    return bool(getattr(_mask_section(cfg), "align_to_image", False))
+
+
+def prepare_test_mask(mask: np.ndarray, cfg: Any) -> np.ndarray:
+    """The test transforms of a MASK volume (reference data/augmentation/build.py:566-615): the image's val_transpose, strict
+    binarisation `mask > threshold` when `mask_transform.binarize` (dtype kept), and the context border filled with zeros -- outside the
+    source field of view nothing is kept."""
+    shared = getattr(getattr(cfg, "data", None), "data_transform", None)
+    section = _mask_section(cfg)
+    out = mask
+    axes = [int(a) for a in (getattr(shared, "val_transpose", None) or [])]
+    if axes:
+        lead = out.ndim - 3
+        out = np.transpose(out, list(range(lead)) + [lead + a for a in axes])
+    if bool(getattr(section, "binarize", False)):
+        out = (out > float(getattr(section, "threshold", 0.0))).astype(out.dtype, copy=False)
+    widths = _spatial_pad_widths(getattr(shared, "pad_size", None), out.ndim)
+    return out if widths is None else np.pad(out, widths, mode="constant", constant_values=0)
+
+
+__all__ = ["normalize_volume", "normalize_image_for_config", "prepare_test_image", "prepare_test_mask", "mask_align_to_image"]

@@ -349,3 +349,22 @@ def test_prepare_test_image_follows_the_reference_test_transforms():
                inference=NS(crop_pad=None, model=NS(select_channel=[0, 1, 2], crop_pad=[15, 16, 79, 80, 79, 80])))
     crop = resolve_global_prediction_crop(snemi)
     assert cropped_shape((100 + 32, 1024 + 160, 1024 + 160), crop) == (100, 1024, 1024)
+
+
+def test_prepare_test_mask_and_alignment_switch():
+    """A mask volume gets the image's transpose, strict `mask > threshold` binarisation under mask_transform.binarize (dtype kept) and a
+    ZERO context border (reference data/augmentation/build.py:566-615); `align_to_image` comes from mask_transform, else data_transform
+    (test_pipeline.py:282-288)."""
+    from pytorch_connectomics_amd.utils.volume_normalize import mask_align_to_image, prepare_test_mask
+    mask = np.array([[[0, 3], [255, 1]], [[2, 0], [0, 9]]], dtype=np.uint8)
+    cfg = NS(data=NS(data_transform=NS(val_transpose=[0, 2, 1], pad_size=[1, 0, 1], pad_mode="reflect", align_to_image=True),
+                     mask_transform=NS(binarize=True, threshold=2.0)))
+    out = prepare_test_mask(mask, cfg)
+    assert out.dtype == np.uint8 and out.shape == (4, 2, 4)
+    assert np.array_equal(out[1:3, :, 1:3], (np.transpose(mask, (0, 2, 1)) > 2).astype(np.uint8))
+    assert out[0].max() == 0 and out[-1].max() == 0 and out[:, :, 0].max() == 0 and out[:, :, -1].max() == 0
+    assert mask_align_to_image(cfg) is False                       # mask_transform wins and has no align_to_image
+    cfg.data.mask_transform = None
+    assert mask_align_to_image(cfg) is True
+    assert np.array_equal(prepare_test_mask(mask, NS(data=NS(data_transform=None, mask_transform=None))), mask)
+    assert mask_align_to_image(NS()) is False
