@@ -70,9 +70,136 @@ static int code_of(hid_t t) {
   return -1;
 }
 
+/* ---- LZF as an HDF5 filter (id 32000, the id h5py registers for `compression="lzf"`), so that volumes written by h5py with its
+ * default fast filter can be read and `inference.save_compression: lzf` can be written.  The byte format is Marc Lehmann's LZF
+ * (liblzf): a control byte < 32 starts a run of (ctrl + 1) literals; otherwise (ctrl >> 5) is a match length -- 7 means "add the
+ * next byte" -- the low 5 bits and the following byte are the distance - 1 (<= 8191), and length + 2 bytes are copied from there.
+ * Compressor: greedy, one hash table over 3-byte sequences.  Filter client data as h5py writes it: {filter revision 4, LZF version
+ * 0x0105, bytes of one uncompressed chunk}. */
+#define PYTC_H5Z_LZF 32000
+#define LZF_MAX_OFF 8192
+#define LZF_MAX_LEN 264
+#define LZF_HASH_BITS 14
+
+static size_t lzf_pack(const unsigned char* in, size_t n, unsigned char* out, size_t cap) {
+  if (n == 0 || cap < 2) return 0;
+  static __thread const unsigned char* table[1 << LZF_HASH_BITS];
+  memset(table, 0, sizeof(table));
+  size_t ip = 0, op = 1, run = 0;                  /* out[op - run - 1] is the control byte of the open literal run */
+  while (ip < n) {
+    size_t len = 0, dist = 0;
+    if (ip + 2 < n) {
+      unsigned h = ((unsigned)in[ip] << 16) | ((unsigned)in[ip + 1] << 8) | in[ip + 2];
+      h = ((h * 2654435761u) >> (32 - LZF_HASH_BITS)) & ((1u << LZF_HASH_BITS) - 1);
+      const unsigned char* ref = table[h];
+      table[h] = in + ip;
+      if (ref && (size_t)(in + ip - ref) <= LZF_MAX_OFF && ref[0] == in[ip] && ref[1] == in[ip + 1] && ref[2] == in[ip + 2]) {
+        size_t most = n - ip < LZF_MAX_LEN ? n - ip : LZF_MAX_LEN;
+        len = 3;
+        while (len < most && ref[len] == in[ip + len]) ++len;
+        dist = (size_t)(in + ip - ref) - 1;
+      }
+    }
+    if (len >= 3) {
+      if (run) { out[op - run - 1] = (unsigned char)(run - 1); run = 0; } else --op;      /* close the run, or take its unused control byte back */
+      if (op + 4 > cap) return 0;
+      size_t l = len - 2;
+      if (l < 7) out[op++] = (unsigned char)((l << 5) | (dist >> 8));
+      else { out[op++] = (unsigned char)((7u << 5) | (dist >> 8)); out[op++] = (unsigned char)(l - 7); }
+      out[op++] = (unsigned char)(dist & 0xff);
+      ip += len;
+      ++op;                                        /* control byte of the next literal run */
+      if (op > cap) return 0;
+    } else {
+      if (op >= cap) return 0;
+      out[op++] = in[ip++];
+      if (++run == 32) { out[op - run - 1] = 31; run = 0; if (op >= cap) return 0; ++op; }
+    }
+  }
+  if (run) out[op - run - 1] = (unsigned char)(run - 1); else --op;
+  return op;
+}
+
+/* returns the number of bytes written, 0 on a malformed stream, (size_t)-1 when `cap` is too small */
+static size_t lzf_unpack(const unsigned char* in, size_t n, unsigned char* out, size_t cap) {
+  size_t ip = 0, op = 0;
+  while (ip < n) {
+    unsigned ctrl = in[ip++];
+    if (ctrl < 32) {
+      size_t run = ctrl + 1;
+      if (ip + run > n) return 0;
+      if (op + run > cap) return (size_t)-1;
+      memcpy(out + op, in + ip, run);
+      ip += run; op += run;
+    } else {
+      size_t len = ctrl >> 5;
+      if (len == 7) { if (ip >= n) return 0; len += in[ip++]; }
+      if (ip >= n) return 0;
+      size_t dist = (((size_t)ctrl & 0x1f) << 8) + in[ip++] + 1;
+      len += 2;
+      if (dist > op) return 0;
+      if (op + len > cap) return (size_t)-1;
+      for (size_t k = 0; k < len; ++k, ++op) out[op] = out[op - dist];       /* byte-wise: the match may overlap its own output */
+    }
+  }
+  return op;
+}
+
+static herr_t lzf_set_local(hid_t dcpl, hid_t type, hid_t space) {
+  (void)space;
+  unsigned flags = 0, values[8] = {0};
+  size_t nel = 8;
+  if (H5Pget_filter_by_id2(dcpl, PYTC_H5Z_LZF, &flags, &nel, values, 0, NULL, NULL) < 0) return -1;
+  if (nel < 3) nel = 3;
+  if (values[0] == 0) values[0] = 4;
+  if (values[1] == 0) values[1] = 0x0105;
+  hsize_t dims[32];
+  int rank = H5Pget_chunk(dcpl, 32, dims);
+  if (rank < 0) return -1;
+  size_t bytes = H5Tget_size(type);
+  for (int i = 0; i < rank; ++i) bytes *= (size_t)dims[i];
+  values[2] = (unsigned)bytes;
+  return H5Pmodify_filter(dcpl, PYTC_H5Z_LZF, flags, nel, values) < 0 ? -1 : 1;
+}
+
+static size_t lzf_filter(unsigned flags, size_t cd_nelmts, const unsigned cd_values[], size_t nbytes, size_t* buf_size, void** buf) {
+  unsigned char* out = NULL;
+  size_t got = 0;
+  if (!(flags & H5Z_FLAG_REVERSE)) {                 /* compress: give up (optional filter: the chunk is stored raw) unless it shrinks */
+    out = (unsigned char*)malloc(nbytes ? nbytes : 1);
+    if (!out) return 0;
+    got = nbytes > 4 ? lzf_pack((const unsigned char*)*buf, nbytes, out, nbytes - 1) : 0;
+    if (!got) { free(out); return 0; }
+    free(*buf); *buf = out; *buf_size = nbytes;
+    return got;
+  }
+  size_t cap = (cd_nelmts >= 3 && cd_values[2]) ? (size_t)cd_values[2] : (*buf_size > nbytes ? *buf_size : nbytes * 4 + 64);
+  for (;;) {
+    out = (unsigned char*)malloc(cap);
+    if (!out) return 0;
+    got = lzf_unpack((const unsigned char*)*buf, nbytes, out, cap);
+    if (got != (size_t)-1) break;
+    free(out);
+    cap *= 2;
+  }
+  if (!got) { free(out); return 0; }
+  free(*buf); *buf = out; *buf_size = cap;
+  return got;
+}
+
+static const H5Z_class2_t LZF_CLASS = {H5Z_CLASS_T_VERS, (H5Z_filter_t)PYTC_H5Z_LZF, 1, 1, "lzf", NULL, lzf_set_local, lzf_filter};
+
+/* self-test hooks for the Python layer (tests): pack / unpack a buffer through the codec above */
+int64_t pytc_h5_lzf_pack(const void* in, int64_t n, void* out, int64_t cap) { return (int64_t)lzf_pack(in, (size_t)n, out, (size_t)cap); }
+int64_t pytc_h5_lzf_unpack(const void* in, int64_t n, void* out, int64_t cap) {
+  size_t got = lzf_unpack(in, (size_t)n, out, (size_t)cap);
+  return got == (size_t)-1 ? -1 : (int64_t)got;
+}
+
 int pytc_h5_init(void) {
   if (H5open() < 0) { set_err("H5open failed"); return 1; }
   H5Eset_auto2(H5E_DEFAULT, NULL, NULL);   /* errors come back as status codes, not on stderr */
+  if (H5Zfilter_avail(PYTC_H5Z_LZF) <= 0 && H5Zregister(&LZF_CLASS) < 0) { set_err("cannot register the LZF filter"); return 1; }
   return 0;
 }
 
@@ -118,6 +245,7 @@ int64_t pytc_h5_dset_create(int64_t f, const char* name, int dtype, int ndim, co
   if (chunks) {
     H5Pset_chunk(pl, ndim, c);
     if (gzip_level >= 0) H5Pset_deflate(pl, (unsigned)gzip_level);
+    else if (gzip_level == -2) H5Pset_filter(pl, PYTC_H5Z_LZF, H5Z_FLAG_OPTIONAL, 0, NULL);      /* -2: LZF */
   }
   hid_t ds = H5Dcreate2((hid_t)f, name, t, sp, H5P_DEFAULT, pl, H5P_DEFAULT);
   H5Pclose(pl); H5Sclose(sp); H5Tclose(t);

@@ -59,6 +59,8 @@ def _load():
     sig = {
         "pytc_h5_last_error": (C.c_char_p, []),
         "pytc_h5_init": (C.c_int, []),
+        "pytc_h5_lzf_pack": (i64, [C.c_void_p, i64, C.c_void_p, i64]),
+        "pytc_h5_lzf_unpack": (i64, [C.c_void_p, i64, C.c_void_p, i64]),
         "pytc_h5_file_open": (i64, [C.c_char_p, C.c_int]),
         "pytc_h5_file_close": (C.c_int, [i64]),
         "pytc_h5_list": (C.c_int, [i64, C.c_char_p, C.c_int]),
@@ -374,9 +376,12 @@ class File:
         shape = tuple(int(v) for v in shape)
         gz = -1
         if compression is not None:
-            if compression not in ("gzip", "GZIP") and not isinstance(compression, int):
-                raise NotImplementedError(f"h5lite writes gzip (deflate) compression only, got {compression!r}")
-            gz = int(compression) if isinstance(compression, int) else int(4 if compression_opts is None else compression_opts)
+            if isinstance(compression, str) and compression.lower() == "lzf":
+                gz = -2                                  # h5py's fast filter (id 32000), registered by the shim (csrc/host/h5io.c)
+            elif compression not in ("gzip", "GZIP") and not isinstance(compression, int):
+                raise NotImplementedError(f"h5lite writes gzip (deflate) or lzf compression, got {compression!r}")
+            else:
+                gz = int(compression) if isinstance(compression, int) else int(4 if compression_opts is None else compression_opts)
             if chunks is None or chunks is True:
                 chunks = guess_chunk(shape, dt.itemsize)
         if chunks is True:

@@ -208,3 +208,47 @@ def test_output_file_names_and_hdf5_writer(tmp_path):
     with pytest.raises(NotImplementedError, match="save_backend='tiff'"):
         write_outputs(cfg, preds, ["s1", "s2"])
     write_outputs(NS(inference=NS(save_path=None)), preds, ["s1", "s2"])          # no output directory: nothing to do
+
+
+def test_lzf_filter_codec_and_hdf5_round_trip(tmp_path):
+    """`compression="lzf"` (h5py's filter id 32000, which the shim registers on libhdf5): the codec against hand-built vectors of the LZF
+    byte format (literal run; overlapping short match; long match with its extra length byte; malformed distance; short output),
+    round trips of compressible / incompressible buffers, and datasets written and read through HDF5 -- an incompressible chunk is
+    stored raw (optional filter) and still reads back (reference tests/unit/test_inference_stage.py:79-97 saves with lzf)."""
+    import ctypes as C
+    from pytorch_connectomics_amd.utils import h5lite
+    if not h5lite.available():
+        pytest.skip("libpytc_h5.so not built")
+    lib = h5lite._need()
+
+    def unpack(stream: bytes, cap: int):
+        out = (C.c_ubyte * max(cap, 1))()
+        n = lib.pytc_h5_lzf_unpack(stream, len(stream), out, cap)
+        return n, bytes(out[:max(n, 0)])
+
+    def pack(raw: bytes) -> bytes:
+        out = (C.c_ubyte * (len(raw) + 64))()
+        return bytes(out[:lib.pytc_h5_lzf_pack(raw, len(raw), out, len(raw) + 64)])
+    assert unpack(bytes([4]) + b"hello", 16) == (5, b"hello")
+    assert unpack(bytes([0]) + b"a" + bytes([(1 << 5) | 0, 0]), 16) == (4, b"aaaa")
+    assert unpack(bytes([2]) + b"abc" + bytes([(7 << 5) | 0, 3, 2]), 64) == (15, b"abc" * 5)
+    assert unpack(bytes([0]) + b"a" + bytes([(1 << 5) | 0, 5]), 16)[0] == 0
+    assert unpack(bytes([4]) + b"hello", 3)[0] == -1
+    rng = np.random.default_rng(0)
+    for raw in (b"abc", b"aaaa", bytes(1000), bytes(range(256)) * 40, rng.integers(0, 4, 70000, dtype=np.uint8).tobytes(),
+                (b"x" * 33 + b"y") * 500, np.repeat(rng.integers(0, 256, 300, dtype=np.uint8), 300).tobytes()):
+        packed = pack(raw)
+        assert packed and unpack(packed, len(raw)) == (len(raw), raw)
+    assert len(pack(bytes(100000))) < 1500 and pack(rng.integers(0, 256, 5000, dtype=np.uint8).tobytes()) == b""     # noise: "does not shrink"
+    vol = np.repeat(rng.integers(0, 255, (8, 16, 4), dtype=np.uint8), 8, axis=2)
+    noise = rng.random((4, 8, 8)).astype(np.float32)
+    with h5lite.File(tmp_path / "z.h5", "w") as f:
+        f.create_dataset("main", data=vol, chunks=(4, 8, 16), compression="lzf")
+        f.create_dataset("noise", data=noise, chunks=(2, 8, 8), compression="lzf")
+    with h5lite.File(tmp_path / "z.h5", "r") as f:
+        assert f["main"].compression == "lzf" and f["noise"].compression == "lzf"
+        assert np.array_equal(f["main"][...], vol) and np.array_equal(f["noise"][...], noise)
+        assert np.array_equal(f["main"][2:7, 3:11, 5:30], vol[2:7, 3:11, 5:30])
+    with pytest.raises(NotImplementedError, match="gzip \\(deflate\\) or lzf"):
+        with h5lite.File(tmp_path / "bad.h5", "w") as f:
+            f.create_dataset("main", data=vol, compression="szip")
