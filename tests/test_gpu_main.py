@@ -251,3 +251,55 @@ test:
                 o = o["output"] if isinstance(o, dict) else (o[0] if isinstance(o, list) else o)
                 views.append(torch.flip(act(o), [ax]))
             np.testing.assert_allclose(torch.stack(views).mean(0)[0].cpu().numpy(), pred[:, z], atol=2e-5)
+
+
+@pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent: first hardware run pending (expected to pass)")
+def test_cli_context_border_crop_and_mask(tmp_path):
+    """The SNEMI-style test flow through the CLI: `data_transform.pad_size` adds a reflected context border to the loaded image,
+    `inference.model.crop_pad` removes it from the prediction again (back to the label's field of view), `data.test.mask` (binarised,
+    zero border) is multiplied into the ensemble -- equal to the same steps done by hand around the InferenceManager."""
+    from pytorch_connectomics_amd.config import load_config
+    from pytorch_connectomics_amd.inference import InferenceManager
+    from pytorch_connectomics_amd.inference.artifact import read_prediction_artifact
+    from pytorch_connectomics_amd.main import main
+    from pytorch_connectomics_amd.models import build_model
+    rng = np.random.default_rng(11)
+    img = (rng.random((20, 24, 28)) * 255).astype(np.uint8)
+    mask = (rng.random((20, 24, 28)) > 0.3).astype(np.uint8) * 200
+    np.save(tmp_path / "img.npy", img)
+    np.save(tmp_path / "mask.npy", mask)
+    cfg_path = tmp_path / "cfg.yaml"
+    cfg_path.write_text(f"""
+experiment_name: border
+save_path: {tmp_path / 'out'}
+default:
+  optimization: {{precision: "32"}}
+  model:
+    arch: {{type: mednext_custom}}
+    in_channels: 1
+    out_channels: 1
+    mednext: {{base_channels: 8, exp_r: 2, kernel_size: 3, block_counts: [1,1,1,1,1,1,1,1,1]}}
+  data:
+    data_transform: {{pad_size: [4, 8, 8], pad_mode: reflect}}
+    image_transform: {{normalize: divide-255}}
+    mask_transform: {{binarize: true, threshold: 0.0}}
+  inference:
+    window: {{window_size: [16, 16, 16], overlap: 0.5, blending: bump, sw_batch_size: 4}}
+    model: {{channel_activations: [{{channels: ":", activation: sigmoid}}], crop_pad: [4, 4, 8, 8, 8, 8]}}
+    test_time_augmentation: {{enabled: true, flip_axes: [[1]]}}
+test:
+  data:
+    test: {{image: "{tmp_path / 'img.npy'}", mask: "{tmp_path / 'mask.npy'}"}}
+""")
+    main(["--config", str(cfg_path), "--mode", "test"])
+    pred = read_prediction_artifact(tmp_path / "out" / "results" / "img_prediction.h5")
+    assert pred.shape == (1, 20, 24, 28)
+    assert np.all(pred[0][mask == 0] == 0.0) and pred[0][mask > 0].min() > 0.0
+    cfg = load_config(cfg_path, mode="test")
+    torch.manual_seed(int(cfg.system.seed))
+    net = build_model(cfg).cuda().eval()
+    padded = np.pad(img, [(4, 4), (8, 8), (8, 8)], mode="reflect") / 255.0
+    padded_mask = np.pad((mask > 0).astype(np.float32), [(4, 4), (8, 8), (8, 8)], mode="constant")
+    direct = InferenceManager(cfg=cfg, model=net, forward_fn=net.forward).predict_with_tta(
+        torch.from_numpy(padded.astype(np.float32)).cuda()[None, None], mask=torch.from_numpy(padded_mask).cuda()[None, None])
+    np.testing.assert_allclose(direct[0, :, 4:-4, 8:-8, 8:-8].cpu().numpy(), pred, atol=1e-6)
