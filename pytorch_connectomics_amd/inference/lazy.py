@@ -203,6 +203,23 @@ def _require_window_shape(prediction: torch.Tensor, read, roi, ctx, *, channels_
                        f"Got prediction.shape={shape} and roi_size={tuple(roi)}.")
 
 
+def _crop_prediction_to_roi(prediction: torch.Tensor, *, roi_size, target_context, scope: str = "Lazy sliding-window inference") -> torch.Tensor:
+    """The centre ROI of a window prediction (N, C, Z, Y, X) made with `target_context` voxels of extra context per side -- the
+    reference's helper under its name (lazy.py:389-419); the lazy loop itself does the same on channels-last batches."""
+    roi = tuple(int(v) for v in roi_size)
+    ctx = tuple(int(v) for v in target_context)
+    read = tuple(r + 2 * c for r, c in zip(roi, ctx)) if any(ctx) else roi
+    shape = tuple(int(v) for v in prediction.shape)
+    if shape[2:] != read:
+        if any(ctx):
+            raise RuntimeError(f"{scope} with target_context={ctx} expected prediction spatial shape {read}, got {shape[2:]}.")
+        raise RuntimeError(f"{scope} requires model predictions to have the same spatial shape as the sliding-window ROI. "
+                           f"Got prediction.shape={shape} and roi_size={roi}.")
+    if not any(ctx):
+        return prediction
+    return prediction[(slice(None), slice(None)) + tuple(slice(c, c + r) for c, r in zip(ctx, roi))]
+
+
 def _lazy_tta_views(cfg) -> int:
     """How many test-time-augmentation views the configuration asks for per window (1 = none)."""
     tta = getattr(getattr(cfg, "inference", None), "test_time_augmentation", None)

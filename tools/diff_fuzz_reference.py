@@ -1161,6 +1161,15 @@ def small_resolvers(t, rnd):
     t.run("lazy._snap_offsets", [(rnd.randint(1, 80), rnd.randint(1, 30), rnd.randint(-2, 20), rnd.choice((0, 0, 3, 11))) for _ in range(500)],
           lambda i, r, s_, b: rl._snap_offsets(i, r, s_, border_pad=b), lambda i, r, s_, b: ol._snap_offsets(i, r, s_, border_pad=b))
 
+    def crop_case():
+        roi = tuple(rnd.randint(1, 6) for _ in range(3))
+        ctx = rnd.choice([(0, 0, 0), (0, 0, 0), tuple(rnd.randint(0, 2) for _ in range(3))])
+        got = tuple(r + 2 * c + rnd.choice([0, 0, 0, 1, -1]) for r, c in zip(roi, ctx))
+        return (torch.arange(2 * 3 * max(1, got[0]) * max(1, got[1]) * max(1, got[2]), dtype=torch.float32).reshape(2, 3, *[max(1, g) for g in got]), roi, ctx)
+    t.run("lazy._crop_prediction_to_roi", [crop_case() for _ in range(300)],
+          lambda p_, r, c: _tensor_digest(rl._crop_prediction_to_roi(p_, roi_size=r, target_context=c, scope="fuzz")),
+          lambda p_, r, c: _tensor_digest(ol._crop_prediction_to_roi(p_, roi_size=r, target_context=c, scope="fuzz")))
+
     rd, od = S.ref("connectomics.inference.lazy_distributed"), pkg("inference.lazy_distributed")
 
     def dist_cfg():
