@@ -187,7 +187,6 @@ def _window_preprocess(cfg, pred_cl: torch.Tensor) -> torch.Tensor:
     return pred_cl
 
 
-@torch.no_grad()
 def _require_window_shape(prediction: torch.Tensor, read, roi, ctx, *, channels_last: bool = False) -> None:
     """The window contract of the lazy loop (reference lazy.py:389-419): the network keeps the spatial shape of what it was given --
     the ROI, or ROI + 2 * target_context, of which the loop then keeps the centre.  Messages in the caller's (N, C, Z, Y, X) order."""
@@ -242,6 +241,7 @@ def _open_mask(cfg, mask):
     return None, _as_channel_first(mask), None
 
 
+@torch.no_grad()
 def _lazy_sliding_window(cfg, forward_fn, volume, *, region_start, region_stop, device, requested_head=None,
                          window_filter: Optional[Callable[[int, int], bool]] = None,
                          return_accumulators: bool = False, preloaded=None, mask=None, mask_align_to_image: bool = False):

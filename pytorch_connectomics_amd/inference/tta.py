@@ -411,6 +411,7 @@ class TTAPredictor:
         out = self._predict_volume(images, mask, mask_align_to_image, requested_head, flat2d)
         return out.squeeze(2) if (flat2d and out.dim() == 5) else out      # (B, C, H, W) like the reference's 2-D mode
 
+    @torch.no_grad()
     def predict_windows(self, windows: torch.Tensor, mask=None, mask_align_to_image: bool = False,
                         requested_head: Optional[str] = None, run=None) -> torch.Tensor:
         """A BATCH of windows (B, C, *roi) through the network without a sliding engine -- what the reference's lazy loop asks
