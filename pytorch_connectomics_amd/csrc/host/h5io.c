@@ -363,23 +363,26 @@ int pytc_h5_attr_name(int64_t obj, int idx, char* buf, int len) {
   ssize_t n = H5Aget_name_by_idx((hid_t)obj, ".", H5_INDEX_NAME, H5_ITER_INC, (hsize_t)idx, buf, (size_t)len, H5P_DEFAULT);
   return n < 0 ? 1 : 0;
 }
-/* 1-D numeric attribute (int64 when is_int, float64 otherwise) from n doubles */
-int pytc_h5_attr_write_array(int64_t obj, const char* key, const double* vals, int n, int is_int) {
+/* 1-D numeric attribute from n 8-byte elements: is_int 0 = float64 values, 1 = int64 values, 2 = uint64 values (the buffer is
+   reinterpreted, never converted through doubles: ids / offsets above 2^53 survive) */
+int pytc_h5_attr_write_array(int64_t obj, const char* key, const void* vals, int n, int is_int) {
   if (H5Aexists((hid_t)obj, key) > 0) H5Adelete((hid_t)obj, key);
   hsize_t dim = (hsize_t)n;
   hid_t sp = H5Screate_simple(1, &dim, NULL);
-  hid_t t = H5Tcopy(is_int ? H5T_NATIVE_INT64 : H5T_NATIVE_DOUBLE);
+  hid_t mem = is_int == 2 ? H5T_NATIVE_UINT64 : is_int ? H5T_NATIVE_INT64 : H5T_NATIVE_DOUBLE;
+  hid_t t = H5Tcopy(mem);
   hid_t a = H5Acreate2((hid_t)obj, key, t, sp, H5P_DEFAULT, H5P_DEFAULT);
   herr_t e = -1;
-  if (a >= 0) { e = n > 0 ? H5Awrite(a, H5T_NATIVE_DOUBLE, vals) : 0; H5Aclose(a); }
+  if (a >= 0) { e = n > 0 ? H5Awrite(a, mem, vals) : 0; H5Aclose(a); }
   H5Tclose(t);
   H5Sclose(sp);
   if (e < 0) { snprintf(g_err, sizeof(g_err), "cannot write array attribute '%s'", key); return 1; }
   return 0;
 }
-/* numeric (integer / float) attribute of any shape as doubles: *n = element count (at most cap are written), *is_int = 1 for an
-   integer type.  rc 2: not a numeric attribute. */
-int pytc_h5_attr_read_array(int64_t obj, const char* key, double* out, int cap, int* n, int* is_int) {
+/* numeric (integer / float) attribute of any shape into 8-byte elements: *n = element count (nothing is read when it exceeds
+   cap: call once with cap 0 for the size), *is_int = 0 float64 values, 1 int64 values, 2 uint64 values (an unsigned 8-byte
+   type).  rc 2: not a numeric attribute. */
+int pytc_h5_attr_read_array(int64_t obj, const char* key, void* out, int cap, int* n, int* is_int) {
   hid_t a = H5Aopen((hid_t)obj, key, H5P_DEFAULT);
   if (a < 0) { snprintf(g_err, sizeof(g_err), "no attribute '%s'", key); return 1; }
   hid_t t = H5Aget_type(a);
@@ -389,13 +392,11 @@ int pytc_h5_attr_read_array(int64_t obj, const char* key, double* out, int cap, 
   if (sp >= 0) H5Sclose(sp);
   int rc = 0;
   *n = (int)npoints;
-  *is_int = c == H5T_INTEGER;
+  *is_int = c != H5T_INTEGER ? 0 : (H5Tget_sign(t) == H5T_SGN_NONE && H5Tget_size(t) == 8) ? 2 : 1;
   if ((c != H5T_INTEGER && c != H5T_FLOAT) || npoints < 0) rc = 2;
-  else if (npoints > 0) {
-    double* tmp = (double*)calloc((size_t)npoints, sizeof(double));
-    if (!tmp || H5Aread(a, H5T_NATIVE_DOUBLE, tmp) < 0) rc = 1;
-    else for (hssize_t i = 0; i < npoints && i < cap; ++i) out[i] = tmp[i];
-    free(tmp);
+  else if (npoints > 0 && npoints <= cap) {
+    hid_t mem = *is_int == 2 ? H5T_NATIVE_UINT64 : *is_int ? H5T_NATIVE_INT64 : H5T_NATIVE_DOUBLE;
+    if (H5Aread(a, mem, out) < 0) rc = 1;
   }
   H5Tclose(t);
   H5Aclose(a);

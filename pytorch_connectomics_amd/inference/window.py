@@ -377,8 +377,19 @@ class EagerSlidingWindowEngine:
         self.progress = bool(progress)
         self._axis_cache = {}
         # HIP streams the window batches are spread over (1 = the caller's stream only); results do not depend on it
-        self.pipeline_streams = int(os.environ.get("PYTC_SW_STREAMS", "2"))
+        self._pipeline_streams = int(os.environ.get("PYTC_SW_STREAMS", "2"))
+        self._streams_requested = "PYTC_SW_STREAMS" in os.environ
+        self._probe_bytes = 0                   # peak activation bytes of the one-window probe pass (0 = unknown)
         self.last_stats = {}
+
+    @property
+    def pipeline_streams(self) -> int:
+        return self._pipeline_streams
+
+    @pipeline_streams.setter
+    def pipeline_streams(self, n: int) -> None:
+        self._pipeline_streams = int(n)
+        self._streams_requested = True            # an explicit choice also covers callables that are not this package's models
 
     def _axis_vectors(self, device):
         key = (self.roi_size, self.mode, str(device))
@@ -450,7 +461,12 @@ class EagerSlidingWindowEngine:
             x = ops.gather_windows(vol, batch_starts, roi, view=view, pad_mode="constant", cval=self.cval)
             return self._run_network(network, x)
 
+        before = torch.cuda.memory_allocated(dev)
+        peak_before = torch.cuda.max_memory_allocated(dev)
         probe = run(starts[:1])
+        peak = torch.cuda.max_memory_allocated(dev)
+        # a rising peak gives the probe's activation footprint; a stale higher peak from earlier work tells nothing (0)
+        self._probe_bytes = max(0, peak - before) if peak > peak_before else 0
         c_out = int(probe.shape[-1])
         if value is None:
             value = torch.zeros((c_out,) + image_size, dtype=torch.float32, device=dev)
@@ -469,7 +485,7 @@ class EagerSlidingWindowEngine:
         blend(probe, starts[:1])
         rest = starts[1:]
         chunks = [rest[b0:b0 + self.sw_batch_size] for b0 in range(0, len(rest), self.sw_batch_size)]
-        lanes = self._lanes(dev, len(chunks))
+        lanes = self._lanes(dev, len(chunks), network)
         if not lanes:
             for chunk in chunks:
                 blend(run(chunk), chunk)
@@ -482,26 +498,43 @@ class EagerSlidingWindowEngine:
             for s in lanes:
                 s.wait_stream(main)
             order_ev = None
-            for i, chunk in enumerate(chunks):
-                s = lanes[i % len(lanes)]
-                with torch.cuda.stream(s):
-                    pred = run(chunk)
-                    if order_ev is not None:
-                        s.wait_event(order_ev)
-                    blend(pred, chunk)
-                    order_ev = torch.cuda.Event()
-                    order_ev.record(s)
-                del pred
-            for s in lanes:
-                main.wait_stream(s)
+            try:
+                for i, chunk in enumerate(chunks):
+                    s = lanes[i % len(lanes)]
+                    with torch.cuda.stream(s):
+                        pred = run(chunk)
+                        if order_ev is not None:
+                            s.wait_event(order_ev)
+                        blend(pred, chunk)
+                        order_ev = torch.cuda.Event()
+                        order_ev.record(s)
+                    del pred
+            finally:
+                # always join: if `run` / `blend` raised, the side streams may still be writing the accumulators the caller
+                # is about to read or free
+                for s in lanes:
+                    main.wait_stream(s)
         self.last_stats = {"windows": len(starts), "roi": roi, "image_size": image_size, "streams": max(1, len(lanes))}
         return value, weight
 
-    def _lanes(self, dev, n_chunks: int):
-        """Side streams of the window pipeline ([] = everything on the caller's stream)."""
+    def _lanes(self, dev, n_chunks: int, network=None):
+        """Side streams of the window pipeline ([] = everything on the caller's stream).
+
+        Two batches are in flight with two streams: twice the activation memory of one, and `network` is entered from two
+        streams at once.  This package's models (`forward_cl`) are stream-safe by construction (no lazily built shared buffers,
+        weight packs keyed per parameter version and allocated before the first side-stream call by the probe window); an
+        arbitrary callable is only pipelined when the caller asks for it (`PYTC_SW_STREAMS` set, or `pipeline_streams`
+        assigned after construction), and never when less than a second arena's worth of HBM is free."""
         n = min(int(self.pipeline_streams), n_chunks)
         if n < 2 or ops.PROFILER.enabled or torch.cuda.is_current_stream_capturing():
             return []
+        if network is not None and getattr(network, "forward_cl", None) is None and not self._streams_requested:
+            return []
+        if self._probe_bytes:
+            free, _ = torch.cuda.mem_get_info(dev)
+            cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+            if free + cached < (n - 1) * self._probe_bytes * self.sw_batch_size:
+                return []
         # one set of side streams per device for the whole process: the caching allocator keeps a memory pool per stream, and an
         # engine object that made its own streams would fault in ~10 GB of fresh activations on its first pass
         key = (str(dev), n)

@@ -655,6 +655,14 @@ class ConnectomicsModule(nn.Module):
         once `fit` has built them (a true resume: Adam moments, the LR schedule position and the EMA shadow continue)."""
         sd = {k[len("model."):]: v for k, v in ck["state_dict"].items()
               if k.startswith("model.") and not k.startswith("model.loss_functions.")}
+        weighter = sorted(k for k in ck["state_dict"] if k.startswith("loss_weighter.") or ".loss_weighter." in "." + k)
+        if weighter:
+            # the reference saves the adaptive balancer's learned task weights beside the model (orchestrator `loss_weighter`);
+            # this package trains with static term weights only, so a resume would silently fall back to them -- say so
+            import warnings
+            warnings.warn(f"checkpoint carries adaptive loss-balancing state ({len(weighter)} tensors, e.g. {weighter[0]!r}); "
+                          "pytorch_connectomics_amd uses static loss weights: the learned task weights are NOT restored",
+                          RuntimeWarning, stacklevel=2)
         missing, unexpected = self.model.load_state_dict(sd, strict=False)
         # a reference checkpoint may carry deep-supervision heads of a trunk built with them (`out_1..out_4`); anything else
         # missing / unexpected is an architecture mismatch

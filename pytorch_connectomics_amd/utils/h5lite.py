@@ -77,8 +77,8 @@ def _load():
         "pytc_h5_attr_name": (C.c_int, [i64, C.c_int, C.c_char_p, C.c_int]),
         "pytc_h5_attr_read": (C.c_int, [i64, C.c_char_p, C.POINTER(C.c_int), C.c_char_p, C.c_int, p64,
                                         C.POINTER(C.c_double)]),
-        "pytc_h5_attr_write_array": (C.c_int, [i64, C.c_char_p, C.POINTER(C.c_double), C.c_int, C.c_int]),
-        "pytc_h5_attr_read_array": (C.c_int, [i64, C.c_char_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int),
+        "pytc_h5_attr_write_array": (C.c_int, [i64, C.c_char_p, C.c_void_p, C.c_int, C.c_int]),
+        "pytc_h5_attr_read_array": (C.c_int, [i64, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int),
                                               C.POINTER(C.c_int)]),
     }
     for name, (res, args) in sig.items():
@@ -150,8 +150,10 @@ class AttributeManager:
             rc = lib.pytc_h5_attr_write(self._o._id, k, 0, sval, 0, 0.0)
         elif isinstance(value, (list, tuple, np.ndarray)) and np.asarray(value).dtype.kind in "iuf" and np.asarray(value).ndim == 1:
             arr = np.asarray(value)
-            buf = (C.c_double * max(arr.size, 1))(*[float(v) for v in arr])
-            rc = lib.pytc_h5_attr_write_array(self._o._id, k, buf, int(arr.size), int(arr.dtype.kind in "iu"))
+            # integers travel as 8-byte integers (never through doubles: uint64 ids / offsets above 2^53 stay exact)
+            is_int = 2 if (arr.dtype.kind == "u" and arr.dtype.itemsize == 8) else int(arr.dtype.kind in "iu")
+            data = np.ascontiguousarray(arr, dtype=(np.float64, np.int64, np.uint64)[is_int])
+            rc = lib.pytc_h5_attr_write_array(self._o._id, k, data.ctypes.data_as(C.c_void_p), int(arr.size), is_int)
         else:
             raise TypeError(f"h5lite attributes hold str / int / float / bool scalars or 1-D numeric arrays, got "
                             f"{type(value).__name__} for {key!r}")
@@ -176,12 +178,18 @@ class AttributeManager:
         sbuf = C.create_string_buffer(1 << 16)
         rc = lib.pytc_h5_attr_read(self._o._id, key.encode(), C.byref(kind), sbuf, len(sbuf), C.byref(ival), C.byref(dval))
         if rc == 3:     # array-valued attribute (e.g. `resolution`): numeric arrays come back as numpy arrays
-            cap = 4096
-            buf, n, is_int = (C.c_double * cap)(), C.c_int(0), C.c_int(0)
-            if lib.pytc_h5_attr_read_array(self._o._id, key.encode(), buf, cap, C.byref(n), C.byref(is_int)) != 0 or n.value > cap:
-                raise KeyError(f"{key} (array-valued attribute of an unsupported type or size)")
-            arr = np.array(buf[:max(n.value, 0)], dtype=np.float64)
-            return arr.astype(np.int64) if is_int.value else arr
+            n, is_int = C.c_int(0), C.c_int(0)
+            rc = lib.pytc_h5_attr_read_array(self._o._id, key.encode(), None, 0, C.byref(n), C.byref(is_int))      # size + type
+            if rc == 2:
+                raise TypeError(f"attribute {key!r} is an array of a type h5lite does not map (numeric arrays only: "
+                                "string / compound / reference arrays are not supported)")
+            if rc != 0:
+                raise OSError(_err(lib))
+            out = np.zeros(max(n.value, 0), dtype=(np.float64, np.int64, np.uint64)[is_int.value])
+            if out.size and lib.pytc_h5_attr_read_array(self._o._id, key.encode(), out.ctypes.data_as(C.c_void_p), int(out.size),
+                                                        C.byref(n), C.byref(is_int)) != 0:
+                raise OSError(_err(lib))
+            return out
         if rc != 0:
             raise KeyError(key)
         return {0: lambda: sbuf.value.decode("utf-8", errors="replace"), 1: lambda: int(ival.value),

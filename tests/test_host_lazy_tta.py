@@ -261,3 +261,22 @@ def test_window_contract_messages_and_batch_guard():
     assert len(hip_ops._starts_array([(0, 0, 0), (1, 2, 3)], 2)) == 6
     with pytest.raises(ValueError, match="1 window predictions for 2 window positions"):
         hip_ops._starts_array([(0, 0, 0), (1, 2, 3)], 1)
+
+
+def test_lazy_loop_and_window_predictor_run_the_network_without_autograd(golden_dir, cpu_kernels):
+    """`@torch.no_grad()` had slid onto a helper, so the lazy loop ran the network with autograd enabled (the HIP
+    models then take their training forward: saved activations, other kernels).  The reference decorates the loop itself
+    (lazy.py:986) -- a caller without an outer no_grad must still meet a grad-free forward."""
+    g = np.load(golden_dir / "lazy_tta.npz")
+    seen = []
+
+    def net(x):
+        seen.append(torch.is_grad_enabled())
+        return _net_lazy(x)
+
+    assert torch.is_grad_enabled()
+    for tta in (False, True):
+        cfg = lazy_tta_cfg(roi=(8, 12, 16), tta=tta)
+        cpu_kernels.lazy_predict_volume(cfg, net, g["vol"], device="cpu")
+    assert seen and not any(seen)
+    assert hasattr(cpu_kernels._lazy_sliding_window, "__wrapped__")

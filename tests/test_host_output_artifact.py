@@ -177,6 +177,25 @@ def test_array_valued_hdf5_attributes_do_not_overrun_the_scalar_reader(tmp_path)
     assert a["scale"].dtype == np.float64 and a["scale"].tolist() == [1.5, 2.5, -3.25]
 
 
+def test_integer_array_attributes_are_exact_beyond_2_pow_53_and_long(tmp_path):
+    """integer array attributes went through float64 (ids / offsets above 2^53 corrupted) and arrays longer than 4096
+    elements raised KeyError; they travel as 8-byte integers now and have no length cap."""
+    from pytorch_connectomics_amd.utils import h5lite
+    if not h5lite.available():
+        pytest.skip("no libhdf5 in this image")
+    big = np.array([2 ** 53 + 1, 2 ** 63 - 1, -(2 ** 62) - 3], np.int64)
+    ubig = np.array([2 ** 64 - 1, 2 ** 53 + 1], np.uint64)
+    long = np.arange(6000, dtype=np.int32)            # 48 kB: under HDF5's own 64 kB object-header limit
+    with h5lite.File(str(tmp_path / "b.h5"), "w") as f:
+        ds = f.create_dataset("main", data=np.zeros((2,), np.uint8))
+        ds.attrs["ids"], ds.attrs["uids"], ds.attrs["long"] = big, ubig, long
+    with h5lite.File(str(tmp_path / "b.h5"), "r") as f:
+        a = f["main"].attrs
+        assert a["ids"].dtype == np.int64 and np.array_equal(a["ids"], big)
+        assert a["uids"].dtype == np.uint64 and np.array_equal(a["uids"], ubig)
+        assert np.array_equal(a["long"], long)
+
+
 def test_output_file_names_and_hdf5_writer(tmp_path):
     """`resolve_output_filenames` / `write_outputs` (reference inference/output.py:19-83, :252-356; stem rule of
     runtime/output_naming.py:54-94; fuzzed against the reference in tools/diff_fuzz_reference.py): uninformative stems climb to the

@@ -457,6 +457,19 @@ def test_resume_accepts_reference_optimizer_layout_and_extra_heads():
         assert float(opt.state[p_new]["step"]) == 1.0
 
 
+def test_checkpoint_with_adaptive_loss_weights_warns_instead_of_dropping_them_silently():
+    """a reference run trained with `loss_balancing.strategy: uncertainty` stores `loss_weighter.*` tensors; this
+    package has static weights only, so loading such a checkpoint must say that the learned task weights are not restored."""
+    cfg = _cfg()
+    m = ConnectomicsModule(cfg, model=SimpleModel())
+    ck = {"state_dict": {"model." + k: v.clone() for k, v in m.model.state_dict().items()}, "global_step": 3, "epoch": 1}
+    ck["state_dict"]["loss_weighter.log_vars"] = torch.zeros(2)
+    m2 = ConnectomicsModule(cfg, model=SimpleModel())
+    with pytest.warns(RuntimeWarning, match="adaptive loss-balancing state"):
+        m2.load_checkpoint_dict(ck)
+    assert m2.global_step == 3
+
+
 def test_per_channel_bce_and_auto_pos_weight_match_reference_fixture():
     """tests/golden/losses_extra.npz (make_golden.py --losses_extra): the reference's PerChannelBCEWithLogitsLoss values and
     gradients (per-channel balancing, caps, a channel without positives, valid masks, sum reduction) and the orchestrator's
