@@ -223,7 +223,7 @@ def run_test(cfg, args) -> dict:
     metrics = {"seconds": dt, "output_voxels_per_s": out_vox / dt}
     label_spec = cfg.data.test.label
     if label_spec and pred_t is not None:
-        lab = torch.from_numpy(np.ascontiguousarray(read_volume(str(label_spec))))
+        lab = torch.from_numpy(np.array(read_volume(str(label_spec)), copy=True))       # an own, writable array (memmaps are read-only)
         metrics["jaccard"] = binary_jaccard(pred_t[0, 0].float().cpu(), lab)
     (out_dir / f"{name}_metrics.json").write_text(json.dumps(metrics, indent=2))
     logger.info("test done: %s", metrics)

@@ -253,7 +253,6 @@ test:
             np.testing.assert_allclose(torch.stack(views).mean(0)[0].cpu().numpy(), pred[:, z], atol=2e-5)
 
 
-@pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent: first hardware run pending (expected to pass)")
 def test_cli_context_border_crop_and_mask(tmp_path):
     """The SNEMI-style test flow through the CLI: `data_transform.pad_size` adds a reflected context border to the loaded image,
     `inference.model.crop_pad` removes it from the prediction again (back to the label's field of view), `data.test.mask` (binarised,
