@@ -186,6 +186,22 @@ def cpu_baseline(model, budget_s: float = 60.0):
 
 
 MFMA_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 2:1-sparsity figure is not used)
+# minimum HBM bytes per window-voxel of a MedNeXt-S k3 forward at 112^3 with one output channel (every block:
+# read x twice + write y once, the expanded tensor never in HBM) -- the figure of merit of the step as a whole; training ~ 3 x
+ALG_BYTES_PER_VOXEL_FWD = 1557.0
+ALG_FLOP_PER_VOXEL_FWD = 1.235e5
+
+
+def whole_step_roofline(voxels_per_s_per_gpu, passes=1.0):
+    """The whole network step against the HBM roofline on SURVEY 8(d)'s byte floor (`passes` = 3 for a training step: forward +
+    data gradients + weight gradients), with the MFMA fraction of the same step beside it."""
+    gbs = voxels_per_s_per_gpu * ALG_BYTES_PER_VOXEL_FWD * passes / 1e9
+    tfl = voxels_per_s_per_gpu * ALG_FLOP_PER_VOXEL_FWD * passes / 1e12
+    return {"bound": "hbm", "algorithmic_bytes_per_voxel": ALG_BYTES_PER_VOXEL_FWD * passes, "achieved_GBs": round(gbs, 1),
+            "peak_GBs": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "algorithmic_flop_per_voxel": ALG_FLOP_PER_VOXEL_FWD * passes, "achieved_TFLOPs": round(tfl, 1),
+            "mfma_frac": round(tfl / MFMA_PEAK_TFLOPS, 4),
+            "source": "SURVEY.md section 8(d): MedNeXt-S k3 112^3 byte / FLOP floor per window-voxel x this leg's voxels/s per GPU"}
 
 
 def _is_dense_conv(label):
@@ -328,11 +344,15 @@ def train_leg(dev, rank, world, args, barrier):
                                       "device kernel named in `kernel` (`labels`), which is what the counter average covers")
             if roof.get("traffic"):
                 roof["traffic_over_algorithmic"] = round(roof["traffic"] / max(roof["algorithmic_bytes"], 1), 3)
+            roof["by_symbol"] = largest_symbols(prof.summary(), 2, top=4,
+                                                traffic_of=lambda sym: _traffic_from_table(table, _kernel_key(sym)))
         else:
             for i in range(2):
                 tstep(i)
         barrier()
     vox = world * args.train_batch * ROI_VOX * steps
+    if roof is not None:
+        roof["whole_step"] = whole_step_roofline(vox / dt / world, passes=3.0)
     del opt, net, model
     torch.cuda.empty_cache()
     return {"value": vox / dt, "unit": "voxels/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
@@ -681,11 +701,16 @@ def main():
                 table, source = live, ("live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child runs of this command on this box "
                                        "(separate passes, FETCH_SIZE x 2)")
         traffic_of = lambda name: _traffic_from_table(table, _kernel_key(name))      # noqa: E731
-        roofline = dominant(summ, nprof, traffic_fn=traffic_of)
-        if roofline is not None:
-            roofline["traffic_source"] = source
-            # the kernel families of the step by time, each with its own fraction (the largest rocprof symbol first)
-            roofline["by_symbol"] = largest_symbols(summ, nprof, top=3, traffic_of=traffic_of)
+        # `roofline` IS the largest rocprof SYMBOL of the step (launch-weighted over the shapes it runs at: what a rocprofv3 --stats
+        # row of the same command averages over); the largest per-shape LABEL -- one mixer shape -- sits beside it as `by_label`, the
+        # three largest families as `by_symbol`, and the step as a whole on SURVEY 8(d)'s byte floor as `whole_step`
+        families = largest_symbols(summ, nprof, top=3, traffic_of=traffic_of)
+        by_label = dominant(summ, nprof, traffic_fn=traffic_of)
+        roofline = dict(families[0])
+        roofline.update({"traffic_source": source, "by_label": by_label, "by_symbol": families,
+                         "kernels_ms_per_step": by_label.pop("kernels_ms_per_step"),
+                         "kernel_ms_total_per_step": by_label.pop("kernel_ms_total_per_step"),
+                         "whole_step": whole_step_roofline(value_vps / world)})
         if os.environ.get("PYTC_BENCH_VERBOSE"):
             for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
                 print(f"  {k:34s} launches/step={v['launches'] / nprof:5.1f} ms/step={v['ms'] / nprof:7.3f} "

@@ -43,9 +43,17 @@ def test_single_gpu_line_has_every_contract_field():
     # HBM bytes per launch of the dominant kernel: PMC counters collected live by child runs under rocprofv3 (or, without the
     # profiler, the committed passes); a fused mixer moves its algorithmic bytes, not more
     assert roof["traffic_source"].startswith(("live", "committed"))
-    if roof["traffic_source"].startswith("live"):
-        assert 0.7 * roof["algorithmic_bytes"] < roof["traffic"] < 1.3 * roof["algorithmic_bytes"]
-    assert d["train"]["ms_per_step"] > 0 and d["train"]["roofline"]["frac"] > 0
+    # `roofline` is the largest rocprof SYMBOL of the step, the largest per-shape label rides as `by_label`
+    assert roof["kernel"].endswith("_kernel") and roof["kernel"] == roof["by_symbol"][0]["kernel"]
+    lab = roof["by_label"]
+    if roof["traffic_source"].startswith("live") and lab.get("traffic"):
+        assert 0.7 * lab["algorithmic_bytes"] < lab["traffic"] < 1.3 * lab["algorithmic_bytes"]      # a fused mixer re-reads nothing
+    ws = roof["whole_step"]
+    assert ws["algorithmic_bytes_per_voxel"] == 1557.0
+    assert abs(ws["frac"] - d["value"] * 1557.0 / 8e12) < 5e-4
+    tr = d["train"]
+    assert tr["ms_per_step"] > 0 and tr["roofline"]["frac"] > 0 and tr["roofline"]["by_symbol"]
+    assert abs(tr["roofline"]["whole_step"]["frac"] - tr["value"] * 3 * 1557.0 / 8e12) < 5e-4
 
 
 def test_two_ranks_sharing_the_gpu_run_weak_strong_and_ddp_legs():
