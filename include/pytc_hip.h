@@ -312,6 +312,9 @@ typedef struct {
   int w3_format;          /* PYTC_W3_BF16 (0): w3_packed from pytc_pw_pack_weight_paired; PYTC_W3_F16: from
                            * pytc_pw_pack_weight_paired_f16 -- the hidden activation then runs the packed-fp16 GELU and the
                            * projection the f16 MFMA (pytc_pw_mlp_fwd / pytc_pw_mlp_train_fwd only) */
+  int per_sample;         /* 1: ab = NULL and the GroupNorm affine is already inside the expanding conv (pytc_groupnorm_fold_mlp):
+                           * w2_packed = N images back to back, b2 = [N][C_hid]; the mixer reads t raw.  Inference entries only
+                           * (pytc_pw_mlp_fwd, _head_fwd, _stemres_fwd) */
 } pytc_mlp_args;
 #define PYTC_W3_BF16 0
 #define PYTC_W3_F16 1
@@ -330,6 +333,16 @@ int pytc_pack_multi(const int64_t* table_dev, int n_items, int64_t total_elems, 
 int pytc_pw_pack_weight_paired_f16(const float* w, int C_out, int C_in, int transposed, void* packed_f16,
                                    void* stream);
 int pytc_pw_mlp_fwd(const pytc_mlp_args* a, void* stream);
+/* GroupNorm finalize + fold into the mixer's expanding conv, one launch (replaces pytc_groupnorm_finalize in front of an
+ * inference mixer: MedNeXtBlock.norm followed by conv2, external nnunet_mednext block; contract at mednext_models.py:99-126):
+ *   a_n = gamma * rstd_n, b_n = beta - mean_n * a_n   from stats [N][slots][2][C] (fixed summation order per sample),
+ *   w2n[n] = paired bf16 image of W2 * diag(a_n)   (pytc_pw_pack_weight_paired layout, N images back to back),
+ *   b2n[n][o] = b2[o] + sum_k W2[o][k] * b_n[k]     (fp32),
+ * so that W2n * t + b2n == W2 * (a*t + b) + b2 and the mixer's operand is the raw depthwise output.  w2 fp32 [C_hid][C]
+ * row-major (the conv weight as PyTorch stores it), C in {32, 64, 128}, C_hid % 32 == 0, C_hid <= 512; ab_out [N][2][C] or NULL. */
+int pytc_groupnorm_fold_mlp(const float* stats, int slots, float count, const float* gamma, const float* beta, float eps,
+                            const float* w2, const float* b2, void* w2n, float* b2n, float* ab_out, int N, int C, int C_hid,
+                            void* stream);
 /* The same mixer with the network's 1x1x1 output projection (mednext OutBlock.conv_out, a transposed 1x1x1 conv on the
  * full-resolution features) in its epilogue: logits[o] = head_b[o] + sum_c head[o][c] * bf16(y[c]), o < n_head <= 16,
  * head_y [N][rows][n_head] fp32; head_w = the bf16 MFMA A-fragment image of the head [64 lanes][8]: lane (r, kb) holds

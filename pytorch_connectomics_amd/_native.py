@@ -41,7 +41,7 @@ class MlpArgs(C.Structure):
         ("res_bias", C.c_void_p), ("y", C.c_void_p),
         ("N", C.c_int), ("rows_per_sample", C.c_int64),
         ("C_in", C.c_int), ("C_hid", C.c_int), ("C_out", C.c_int), ("res_mode", C.c_int),
-        ("Di", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("w3_format", C.c_int),
+        ("Di", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("w3_format", C.c_int), ("per_sample", C.c_int),
     ]
 
 
@@ -93,6 +93,8 @@ _SIGS = {
                            + [C.c_void_p]),
     "pytc_groupnorm_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_float,
                                           C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_groupnorm_fold_mlp": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pytc_pw_packed_elems": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "pytc_pw_pack_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "pytc_blend_accumulate_mapped": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int,

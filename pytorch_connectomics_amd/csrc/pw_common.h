@@ -66,9 +66,11 @@ struct EpiParams {
 
 // v[NCH] = conv result (+bias, activation) for channels o0..o0+NCH-1 of output row `orow` of sample n.
 // GELU_BWD = false compiles the PYTC_RES_GELU_BWD branch out (the fused mixer never uses it and pays registers for it).
+// pos != nullptr (RES_UPSAMPLE only): {pz, py, px} of `orow` in the output grid, already known to the caller (the fused mixer
+// derives them once per wave and steps them per tile: the generic form below costs two integer divisions per stored 16 bytes).
 template <typename TO, int NCH, bool GELU_BWD = false>
 __device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParams& e, int n, long orow, int o0,
-                                                 const float* pre = nullptr) {
+                                                 const float* pre = nullptr, const int* pos = nullptr) {
   // pre != nullptr: the caller already loaded res[orow][o0..o0+NCH) (prefetched ahead of the GEMMs)
   TO* yn = reinterpret_cast<TO*>(e.y) + (long)n * e.rps_out * e.C_out;
   const TO* resn = e.res ? reinterpret_cast<const TO*>(e.res) + (long)n * e.rps_out * e.C_out : nullptr;
@@ -114,10 +116,16 @@ __device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParam
     for (int i = 0; i < NCH; ++i)
       if (o0 + i < e.C_out) v[i] = fmaf(cf[i], v[i], fmaf(cf[e.C_out + i], rv[i], cf[2 * e.C_out + i]));
   } else if (e.res_mode == PYTC_RES_UPSAMPLE) {
-    int px = (int)(orow % e.Go_w);
-    long t = orow / e.Go_w;
-    int py = (int)(t % e.Go_h);
-    int pz = (int)(t / e.Go_h);
+    int px, py, pz;
+    if (pos) { pz = pos[0]; py = pos[1]; px = pos[2]; }
+    else {
+      // rows per sample fit 32 bits (checked at the API): 32-bit divisions -- the 64-bit forms compile to a call-sized sequence
+      const unsigned ur = (unsigned)orow, gw = (unsigned)e.Go_w, gh = (unsigned)e.Go_h;
+      const unsigned t = ur / gw;
+      px = (int)(ur - t * gw);
+      pz = (int)(t / gh);
+      py = (int)(t - (unsigned)pz * gh);
+    }
     float sk[NCH];
     if (pre) {
 #pragma unroll

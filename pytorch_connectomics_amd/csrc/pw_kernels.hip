@@ -277,6 +277,7 @@ extern "C" int pytc_pw_conv_fwd(const pytc_pw_args* a, void* stream) {
     PYTC_REQUIRE(a->gather == 0, "pw_conv: RES_UPSAMPLE cannot be combined with gather");
     PYTC_REQUIRE((long)a->Di * a->Hi * a->Wi == a->rows_per_sample && !(a->Di & 1) && !(a->Hi & 1) && !(a->Wi & 1),
                  "pw_conv: RES_UPSAMPLE needs the (even) output grid");
+    PYTC_REQUIRE(a->rows_per_sample < (1L << 31), "pw_conv: RES_UPSAMPLE positions are 32-bit (rows per sample < 2^31)");
     p.e.Go_d = a->Di; p.e.Go_h = a->Hi; p.e.Go_w = a->Wi;
     p.e.Gl_d = a->Di / 2; p.e.Gl_h = a->Hi / 2; p.e.Gl_w = a->Wi / 2;
   }

@@ -25,6 +25,11 @@ struct MlpParams {
   long rps;        // rows per sample (input == output rows)
   int C_in, C_hid, C_out, HC;   // HC = C_hid / 32
   int w3_f16;      // w3 is the fp16 paired image: packed-fp16 GELU + f16 MFMA for the projection (GELU_MODE 3)
+  // per-sample expand operands (ab == nullptr): the GroupNorm affine is folded into the expanding conv by
+  // groupnorm_fold_mlp_kernel -- W2_n = W2 * diag(a_n), b2_n = b2 + W2 * b_n -- so the B operand of GEMM1 is the RAW bf16 tile
+  // (no unpack / fma / repack per element: the mixers are bound by VALU issue); w2 / b2 then hold N
+  // images / vectors back to back
+  long w2_stride;  // bf16x8 elements per sample image
   // fused output head (HEAD kernels): logits[o] = head_b[o] + sum_c head_w[o][c] * bf16(y[c]),  o < n_head <= 16
   const bf16x8_t* head_w;   // A fragment image [64 lanes][8]: lane (r, kb) holds head[o = r][c = kb*8 .. +7], bf16
   const float* head_b;
@@ -96,8 +101,11 @@ pw_mlp_kernel(MlpParams p) {
   constexpr bool WARM = KS_IN * MO >= 32;    // >= 64 KB of weights: warm this XCD's L2 (see warm_l2)
   constexpr int WPER = KS_IN * MO >= 512 ? 6 : 2;   // few workgroups at the deepest level: more lines per lane
   WarmRegs<WPER> warm;
+  const bool folded = p.ab == nullptr;        // wave-uniform: per-sample expand operands (see MlpParams)
+  const bf16x8_t* w2 = p.w2 + (folded ? (long)n * p.w2_stride : 0L);
+  const float* b2 = p.b2 + (folded ? (long)n * p.C_hid : 0L);
   if (WARM) {
-    warm_l2(p.w2, (long)p.C_hid * p.C_in * 2, warm, 0);
+    warm_l2(w2, (long)p.C_hid * p.C_in * 2, warm, 0);
     warm_l2(p.w3, (long)p.C_out * p.C_hid * 2, warm, WPER);
   }
   const long row0 = ((long)blockIdx.x * 4 + wave) * (NT * 16);
@@ -116,9 +124,19 @@ pw_mlp_kernel(MlpParams p) {
   // ---- B operand of GEMM1: normalised input, 8 consecutive channels per lane per k-step
   bf16x8_t bact[KS_IN][NT];
   const bf16_t* tn = p.t + (long)n * p.rps * p.C_in;
+  if (folded) {
+#pragma unroll
+    for (int ks = 0; ks < KS_IN; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const long rr = orow[nt] < p.rps ? orow[nt] : p.rps - 1;
+        bact[ks][nt] = *reinterpret_cast<const bf16x8_t*>(tn + rr * p.C_in + ks * 32 + kb * 8);
+      }
+  }
   const float* an = p.ab + (long)n * 2 * p.C_in;
 #pragma unroll
   for (int ks = 0; ks < KS_IN; ++ks) {
+    if (folded) break;
     const int k0 = ks * 32 + kb * 8;
     float av[8], bv[8];
     VecIO<float, 4>::load(an + k0, reinterpret_cast<float(&)[4]>(av[0]));
@@ -184,8 +202,8 @@ pw_mlp_kernel(MlpParams p) {
   // ---- loop over hidden chunks of 32 units: GEMM1 -> GELU -> GEMM2, all in registers
   for (int hc = 0; hc < p.HC; ++hc) {
     float b2v[8];
-    VecIO<float, 4>::load(p.b2 + hc * 32 + kb * 8, reinterpret_cast<float(&)[4]>(b2v[0]));
-    VecIO<float, 4>::load(p.b2 + hc * 32 + kb * 8 + 4, reinterpret_cast<float(&)[4]>(b2v[4]));
+    VecIO<float, 4>::load(b2 + hc * 32 + kb * 8, reinterpret_cast<float(&)[4]>(b2v[0]));
+    VecIO<float, 4>::load(b2 + hc * 32 + kb * 8 + 4, reinterpret_cast<float(&)[4]>(b2v[4]));
     f32x4_t acc1[2][NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -196,7 +214,7 @@ pw_mlp_kernel(MlpParams p) {
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
       for (int ks = 0; ks < KS_IN; ++ks) {
-        const bf16x8_t a = p.w2[((long)(hc * 2 + mt) * KS_IN + ks) * 64 + lane];
+        const bf16x8_t a = w2[((long)(hc * 2 + mt) * KS_IN + ks) * 64 + lane];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc1[mt][nt] = Mma<bf16_t>::mma(a, bact[ks][nt], acc1[mt][nt]);
       }
@@ -294,6 +312,24 @@ pw_mlp_kernel(MlpParams p) {
     return;
   }
   // ---- epilogue: 8 consecutive channels per lane per tile pair
+  // RES_UPSAMPLE needs each row's position in the output grid: one division pair per WAVE (its first row, wave-uniform), then
+  // per lane an add and a carry per tile -- not two divisions per stored 16 bytes
+  int upos[NT][3];
+  const bool ups = p.e.res_mode == PYTC_RES_UPSAMPLE;
+  if (ups) {
+    const unsigned ur = (unsigned)row0, gw = (unsigned)p.e.Go_w, gh = (unsigned)p.e.Go_h;
+    const unsigned t0 = ur / gw;
+    const int bx = (int)(ur - t0 * gw);
+    const int bz = (int)(t0 / gh);
+    const int by = (int)(t0 - (unsigned)bz * gh);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      int px = bx + nt * 16 + r, py = by, pz = bz;
+      while (px >= p.e.Go_w) { px -= p.e.Go_w; ++py; }
+      while (py >= p.e.Go_h) { py -= p.e.Go_h; ++pz; }
+      upos[nt][0] = pz; upos[nt][1] = py; upos[nt][2] = px;
+    }
+  }
 #pragma unroll
   for (int pr = 0; pr < MO / 2; ++pr) {
 #pragma unroll
@@ -308,14 +344,17 @@ pw_mlp_kernel(MlpParams p) {
       if (use_pre) {
         float pre[8];
         VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(&rpre[PREFETCH_RES ? pr : 0][PREFETCH_RES ? nt : 0]), pre);
-        finish_and_store<bf16_t, 8>(v, p.e, n, orow[nt], pr * 32 + kb * 8, pre);
+        finish_and_store<bf16_t, 8>(v, p.e, n, orow[nt], pr * 32 + kb * 8, pre, ups ? upos[nt] : nullptr);
       } else {
-        finish_and_store<bf16_t, 8>(v, p.e, n, orow[nt], pr * 32 + kb * 8);
+        finish_and_store<bf16_t, 8>(v, p.e, n, orow[nt], pr * 32 + kb * 8, nullptr, ups ? upos[nt] : nullptr);
       }
     }
   }
 }
 
+// Measured and removed (round 4, profiles/r04_mixer_occupancy_and_issue_rates.txt): the level-0 / level-1 shapes compiled for 4 / 5 /
+// 6 waves per SIMD (launch-bounds override, NT = 2 and 4): no shape gets faster, the spilling ones get slower (64->128->32: 910 ->
+// 1106 us at 4 waves with 36 spilled registers) -- occupancy is not what these kernels lack.
 // Also measured and removed (round 2, profiles/r02_mixer_split_and_lds_weights.txt): (a) the four waves of a workgroup sharing
 // one voxel tile and splitting the hidden chunks between them (fixed-order LDS reduction): wins only at 7^3, loses at 14^3;
 // (b) each hidden chunk's weight fragments fetched once per workgroup into double-buffered LDS instead of streamed from L2 by
@@ -384,6 +423,67 @@ pack_multi_kernel(const long* __restrict__ table, int n_items, long total) {
   if (o < C_out && k < C_in) v = transposed ? w[(long)k * C_out + o] : w[(long)o * C_in + k];
   if (kind >= 2) reinterpret_cast<_Float16*>(it[1])[e] = (_Float16)v;
   else reinterpret_cast<bf16_t*>(it[1])[e] = from_f32<bf16_t>(v);
+}
+
+// GroupNorm finalize + fold into the expanding conv of the mixer that follows (see MlpParams::w2_stride): one workgroup of
+// 1024 threads per sample -- C channel lanes x 1024/C slot lanes reduce the (sum, sum of squares) slots in a fixed order, the
+// affine goes to LDS, and every thread then writes its share of the sample's paired bf16 image of W2 * diag(a) and of the
+// folded bias.  Takes the place of groupnorm_finalize_kernel (same latency class: the slot loop dominates).
+__global__ void __launch_bounds__(1024)
+groupnorm_fold_mlp_kernel(const float* __restrict__ stats, int slots, float count, const float* __restrict__ gamma,
+                          const float* __restrict__ beta, float eps, const float* __restrict__ w2, const float* __restrict__ b2,
+                          bf16_t* __restrict__ w2n, float* __restrict__ b2n, float* __restrict__ ab_out, int C, int C_hid) {
+  __shared__ float red[2][1024];
+  __shared__ float sa[128], sb[128];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int cl = tid % C, sl = tid / C, SL = 1024 / C;
+  const float* base = stats + (long)n * slots * 2 * C;
+  float a1 = 0.f, a2 = 0.f;
+#pragma unroll 4
+  for (int s = sl; s < slots; s += SL) {
+    a1 += base[((long)s * 2 + 0) * C + cl];
+    a2 += base[((long)s * 2 + 1) * C + cl];
+  }
+  red[0][tid] = a1;
+  red[1][tid] = a2;
+  __syncthreads();
+  if (tid < C) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int s = 0; s < SL; ++s) { t1 += red[0][s * C + tid]; t2 += red[1][s * C + tid]; }
+    const float mean = t1 / count;
+    const float var = fmaxf(t2 / count - mean * mean, 0.f);
+    float rstd = rsqrtf(var + eps);
+    rstd = rstd * (1.5f - 0.5f * (var + eps) * rstd * rstd);      // one Newton step: rsqrtf is approximate
+    const float a = (gamma ? gamma[tid] : 1.f) * rstd;
+    const float b = (beta ? beta[tid] : 0.f) - mean * a;
+    sa[tid] = a;
+    sb[tid] = b;
+    if (ab_out) {
+      ab_out[((long)n * 2 + 0) * C + tid] = a;
+      ab_out[((long)n * 2 + 1) * C + tid] = b;
+    }
+  }
+  __syncthreads();
+  const int KG = C / 32;
+  const long total = (long)C_hid * C;
+  bf16_t* img = w2n + (long)n * total;
+  for (long e = tid; e < total; e += 1024) {
+    const int j = (int)(e % 8);
+    long t = e / 8;
+    const int lane = (int)(t % 64);
+    t /= 64;
+    const int kg = (int)(t % KG);
+    const int T = (int)(t / KG);
+    const int o = paired_row(T, lane & 15);
+    const int k = kg * 32 + (lane >> 4) * 8 + j;
+    img[e] = from_f32<bf16_t>(w2[(long)o * C + k] * sa[k]);
+  }
+  for (int o = tid; o < C_hid; o += 1024) {
+    float acc = b2 ? b2[o] : 0.f;
+    const float* wr = w2 + (long)o * C;
+    for (int k = 0; k < C; ++k) acc = fmaf(wr[k], sb[k], acc);
+    b2n[(long)n * C_hid + o] = acc;
+  }
 }
 
 // one-time upload of the GELU table (host double precision; blocking copy, first mixer launch of the process)
@@ -471,6 +571,18 @@ using namespace pytc;
 
 extern "C" int pytc_pw_mlp_supported(int C_in, int C_hid, int C_out) { return mlp_shape_ok(C_in, C_hid, C_out) ? 1 : 0; }
 
+extern "C" int pytc_groupnorm_fold_mlp(const float* stats, int slots, float count, const float* gamma, const float* beta,
+                                       float eps, const float* w2, const float* b2, void* w2n, float* b2n, float* ab_out, int N,
+                                       int C, int C_hid, void* stream) {
+  PYTC_REQUIRE(stats && w2 && w2n && b2n && slots >= 1 && count > 0 && N >= 1, "groupnorm_fold_mlp: bad arguments");
+  PYTC_REQUIRE(C == 32 || C == 64 || C == 128, "groupnorm_fold_mlp: C=%d (32, 64 or 128)", C);
+  PYTC_REQUIRE(C_hid % 32 == 0 && C_hid >= 32 && C_hid <= 512, "groupnorm_fold_mlp: C_hid=%d", C_hid);
+  hipLaunchKernelGGL(groupnorm_fold_mlp_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, stats, slots, count, gamma, beta,
+                     eps, w2, b2, (bf16_t*)w2n, b2n, ab_out, C, C_hid);
+  PYTC_LAUNCH_CHECK("groupnorm_fold_mlp");
+  return PYTC_OK;
+}
+
 extern "C" int pytc_pw_mlp_head_supported(int C_in, int C_hid, int C_out) {
   return (C_out == 32 && (C_in == 32 || C_in == 64) && C_hid % 32 == 0 && C_hid >= 32) ? 1 : 0;
 }
@@ -509,7 +621,8 @@ extern "C" int pytc_pack_multi(const int64_t* table_dev, int n_items, int64_t to
 
 extern "C" int pytc_pw_mlp_head_fwd(const pytc_mlp_args* a, const void* head_w, const float* head_b, float* head_y,
                                     int n_head, int store_y, void* stream) {
-  PYTC_REQUIRE(a && a->t && a->ab && a->w2_packed && a->w3_packed && a->b2 && a->b3 && head_w && head_y, "pw_mlp_head: null pointer");
+  PYTC_REQUIRE(a && a->t && (a->ab || a->per_sample) && a->w2_packed && a->w3_packed && a->b2 && a->b3 && head_w && head_y, "pw_mlp_head: null pointer");
+  PYTC_REQUIRE(!(a->ab && a->per_sample), "pw_mlp_head: per-sample (norm-folded) expand operands come without an affine");
   PYTC_REQUIRE(!store_y || a->y, "pw_mlp_head: store_y without an output buffer");
   PYTC_REQUIRE(a->N >= 1 && a->rows_per_sample >= 1 && n_head >= 1 && n_head <= 16, "pw_mlp_head: bad shape");
   if (!pytc_pw_mlp_head_supported(a->C_in, a->C_hid, a->C_out)) {
@@ -521,6 +634,7 @@ extern "C" int pytc_pw_mlp_head_fwd(const pytc_mlp_args* a, const void* head_w, 
   p.t = (const bf16_t*)a->t; p.ab = a->ab; p.w2 = (const bf16x8_t*)a->w2_packed; p.b2 = a->b2;
   p.w3 = (const bf16x8_t*)a->w3_packed; p.b3 = a->b3;
   p.rps = a->rows_per_sample; p.C_in = a->C_in; p.C_hid = a->C_hid; p.C_out = a->C_out; p.HC = a->C_hid / 32;
+  p.w2_stride = (long)(a->C_hid / 16) * (a->C_in / 32) * 64;
   p.e.res = a->res; p.e.res_low = nullptr; p.e.res_bias = nullptr; p.e.y = a->y;
   p.e.rps_out = a->rows_per_sample; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode;
   p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
@@ -545,8 +659,9 @@ extern "C" int pytc_pw_mlp_head_fwd(const pytc_mlp_args* a, const void* head_w, 
 
 extern "C" int pytc_pw_mlp_stemres_fwd(const pytc_mlp_args* a, const float* stem_x, const float* stem_w, const float* stem_b,
                                        void* stream) {
-  PYTC_REQUIRE(a && a->t && a->ab && a->w2_packed && a->w3_packed && a->b2 && a->b3 && a->y && stem_x && stem_w && stem_b,
+  PYTC_REQUIRE(a && a->t && (a->ab || a->per_sample) && a->w2_packed && a->w3_packed && a->b2 && a->b3 && a->y && stem_x && stem_w && stem_b,
                "pw_mlp_stemres: null pointer");
+  PYTC_REQUIRE(!(a->ab && a->per_sample), "pw_mlp_stemres: per-sample (norm-folded) expand operands come without an affine");
   PYTC_REQUIRE(a->N >= 1 && a->rows_per_sample >= 1, "pw_mlp_stemres: bad shape");
   if (!(a->C_in == 32 && a->C_out == 32 && a->C_hid % 32 == 0 && a->C_hid >= 32)) {
     set_error("pw_mlp_stemres: no fused kernel for C_in=%d C_hid=%d C_out=%d", a->C_in, a->C_hid, a->C_out);
@@ -556,6 +671,7 @@ extern "C" int pytc_pw_mlp_stemres_fwd(const pytc_mlp_args* a, const float* stem
   p.t = (const bf16_t*)a->t; p.ab = a->ab; p.w2 = (const bf16x8_t*)a->w2_packed; p.b2 = a->b2;
   p.w3 = (const bf16x8_t*)a->w3_packed; p.b3 = a->b3;
   p.rps = a->rows_per_sample; p.C_in = a->C_in; p.C_hid = a->C_hid; p.C_out = a->C_out; p.HC = a->C_hid / 32;
+  p.w2_stride = (long)(a->C_hid / 16) * (a->C_in / 32) * 64;
   p.e.res = a->y;              // never dereferenced (the residual rows are recomputed); non-null for the epilogue's checks
   p.e.y = a->y;
   p.e.rps_out = a->rows_per_sample; p.e.C_out = a->C_out; p.e.res_mode = PYTC_RES_ADD;
@@ -589,7 +705,9 @@ extern "C" int pytc_pw_mlp_train_fwd(const pytc_mlp_args* a, void* hidden_pre, v
 extern "C" int pytc_pw_mlp_fwd(const pytc_mlp_args* a, void* stream) { return mlp_fwd_impl(a, nullptr, stream); }
 
 static int mlp_fwd_impl(const pytc_mlp_args* a, void* hp, void* stream, const void* hp_in) {
-  PYTC_REQUIRE(a && a->t && a->ab && a->w2_packed && a->w3_packed && a->b2 && a->b3 && a->y, "pw_mlp: null pointer");
+  PYTC_REQUIRE(a && a->t && (a->ab || a->per_sample) && a->w2_packed && a->w3_packed && a->b2 && a->b3 && a->y, "pw_mlp: null pointer");
+  PYTC_REQUIRE(!(a->ab && a->per_sample), "pw_mlp: per-sample (norm-folded) expand operands come without an affine");
+  PYTC_REQUIRE(!(a->per_sample && (hp || hp_in)), "pw_mlp: the training kernels take the shared expand image and the affine");
   PYTC_REQUIRE(a->N >= 1 && a->rows_per_sample >= 1, "pw_mlp: bad shape");
   if (!mlp_shape_ok(a->C_in, a->C_hid, a->C_out)) {
     set_error("pw_mlp: no fused kernel for C_in=%d C_hid=%d C_out=%d", a->C_in, a->C_hid, a->C_out);
@@ -602,6 +720,7 @@ static int mlp_fwd_impl(const pytc_mlp_args* a, void* hp, void* stream, const vo
   p.t = (const bf16_t*)a->t; p.ab = a->ab; p.w2 = (const bf16x8_t*)a->w2_packed; p.b2 = a->b2;
   p.w3 = (const bf16x8_t*)a->w3_packed; p.b3 = a->b3;
   p.rps = a->rows_per_sample; p.C_in = a->C_in; p.C_hid = a->C_hid; p.C_out = a->C_out; p.HC = a->C_hid / 32;
+  p.w2_stride = (long)(a->C_hid / 16) * (a->C_in / 32) * 64;
   p.e.res = a->res; p.e.res_low = a->res_low; p.e.res_bias = a->res_bias; p.e.y = a->y;
   p.e.rps_out = a->rows_per_sample; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode;
   p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
@@ -612,6 +731,7 @@ static int mlp_fwd_impl(const pytc_mlp_args* a, void* hp, void* stream, const vo
   if (a->res_mode == PYTC_RES_UPSAMPLE) {
     PYTC_REQUIRE((long)a->Di * a->Hi * a->Wi == a->rows_per_sample && !(a->Di & 1) && !(a->Hi & 1) && !(a->Wi & 1),
                  "pw_mlp: RES_UPSAMPLE needs the (even) output grid");
+    PYTC_REQUIRE(a->rows_per_sample < (1L << 31), "pw_mlp: RES_UPSAMPLE positions are 32-bit (rows per sample < 2^31)");
     p.e.Go_d = a->Di; p.e.Go_h = a->Hi; p.e.Go_w = a->Wi;
     p.e.Gl_d = a->Di / 2; p.e.Gl_h = a->Hi / 2; p.e.Gl_w = a->Wi / 2;
   }

@@ -391,6 +391,27 @@ def groupnorm_finalize(stats: torch.Tensor, count: float, gamma: Optional[torch.
     return ab
 
 
+def groupnorm_fold_mlp_supported(c: int, c_hid: int) -> bool:
+    return c in (32, 64, 128) and c_hid % 32 == 0 and 32 <= c_hid <= 512
+
+
+def groupnorm_fold_mlp(stats: torch.Tensor, count: float, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float,
+                       w2: torch.Tensor, b2: Optional[torch.Tensor], *, want_ab: bool = False):
+    """GroupNorm finalize folded into the mixer's expanding conv (pytc_groupnorm_fold_mlp): stats (N, slots, 2, C), w2 fp32
+    (C_hid, C) -> (w2n (N, C_hid * C) bf16 paired images, b2n (N, C_hid) fp32[, ab (N, 2, C)]); pw_mlp(t, None, w2n, b2n, ...) then
+    equals pw_mlp(t, ab, pack(w2), b2, ...) up to the rounding point (the weight instead of the normalised activation)."""
+    N, slots, _, Cc = stats.shape
+    c_hid = int(w2.shape[0])
+    if w2.dtype != torch.float32 or tuple(w2.shape) != (c_hid, Cc) or not w2.is_contiguous():
+        raise ValueError(f"groupnorm_fold_mlp: w2 must be contiguous fp32 (C_hid, {Cc}), got {tuple(w2.shape)} {w2.dtype}")
+    w2n = torch.empty((N, c_hid * Cc), dtype=torch.bfloat16, device=stats.device)
+    b2n = torch.empty((N, c_hid), dtype=torch.float32, device=stats.device)
+    ab = torch.empty((N, 2, Cc), dtype=torch.float32, device=stats.device) if want_ab else None
+    _run("groupnorm_finalize", _nbytes(stats, w2n, b2n), nat.lib().pytc_groupnorm_fold_mlp, _p(stats), slots, float(count),
+         _p(gamma), _p(beta), float(eps), _p(w2), _p(b2), _p(w2n), _p(b2n), _p(ab), N, Cc, c_hid, _stream())
+    return (w2n, b2n, ab) if want_ab else (w2n, b2n)
+
+
 # ------------------------------------------------------------------ pointwise convs (MFMA GEMMs)
 def pw_pack_weight(w: torch.Tensor, dtype: torch.dtype, *, transposed: bool = False) -> torch.Tensor:
     """w fp32 (C_out, C_in) [or (C_in, C_out) when transposed] -> packed MFMA operand image."""
@@ -561,7 +582,17 @@ def _w3_format(w3p: torch.Tensor) -> int:
     return nat.W3_F16 if w3p.dtype == torch.float16 else nat.W3_BF16
 
 
-def pw_mlp(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.Tensor, w3p: torch.Tensor,
+def _folded_operands(ab, w2p: torch.Tensor, b2: torch.Tensor, N: int, c_in: int, c_hid: int) -> int:
+    """ab is None <=> the caller passes groupnorm_fold_mlp's per-sample operands: shapes checked here, flag for pytc_mlp_args."""
+    if ab is not None:
+        return 0
+    if tuple(w2p.shape) != (N, c_hid * c_in) or tuple(b2.shape) != (N, c_hid) or w2p.dtype != torch.bfloat16:
+        raise ValueError(f"norm-folded mixer operands must be w2n (N, C_hid*C_in) bf16 and b2n (N, C_hid); got {tuple(w2p.shape)} "
+                         f"{w2p.dtype} / {tuple(b2.shape)}")
+    return 1
+
+
+def pw_mlp(t: torch.Tensor, ab: Optional[torch.Tensor], w2p: torch.Tensor, b2: torch.Tensor, w3p: torch.Tensor,
            b3: torch.Tensor, *, N: int, rows_per_sample: int, c_in: int, c_hid: int, c_out: int,
            res: Optional[torch.Tensor] = None, res_mode: int = nat.RES_NONE, grid: Sequence[int] = (0, 0, 0),
            res_low: Optional[torch.Tensor] = None, res_bias: Optional[torch.Tensor] = None,
@@ -576,8 +607,9 @@ def pw_mlp(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.Tenso
     else:
         _check_out(y, N * rows_per_sample * c_out, torch.bfloat16, "pw_mlp")
     a = nat.MlpArgs()
-    a.t, a.ab, a.w2_packed, a.b2, a.w3_packed, a.b3 = (t.data_ptr(), ab.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
-                                                       w3p.data_ptr(), b3.data_ptr())
+    a.t, a.ab, a.w2_packed, a.b2, a.w3_packed, a.b3 = (t.data_ptr(), None if ab is None else ab.data_ptr(), w2p.data_ptr(),
+                                                       b2.data_ptr(), w3p.data_ptr(), b3.data_ptr())
+    a.per_sample = _folded_operands(ab, w2p, b2, N, c_in, c_hid)
     a.w3_format = _w3_format(w3p)
     a.res = res.data_ptr() if res is not None else None
     a.res_low = res_low.data_ptr() if res_low is not None else None
@@ -675,8 +707,9 @@ def pw_mlp_stemres(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: tor
     else:
         _check_out(y, N * rows_per_sample * c_out, torch.bfloat16, "pw_mlp_stemres")
     a = nat.MlpArgs()
-    a.t, a.ab, a.w2_packed, a.b2, a.w3_packed, a.b3 = (t.data_ptr(), ab.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
-                                                       w3p.data_ptr(), b3.data_ptr())
+    a.t, a.ab, a.w2_packed, a.b2, a.w3_packed, a.b3 = (t.data_ptr(), None if ab is None else ab.data_ptr(), w2p.data_ptr(),
+                                                       b2.data_ptr(), w3p.data_ptr(), b3.data_ptr())
+    a.per_sample = _folded_operands(ab, w2p, b2, N, c_in, c_hid)
     a.w3_format = _w3_format(w3p)
     a.res = a.res_low = a.res_bias = None
     a.y = y.data_ptr()
@@ -749,8 +782,9 @@ def pw_mlp_head(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.
     y = torch.empty((N, rows_per_sample, c_out), dtype=torch.bfloat16, device=t.device) if store_y else None
     logits = torch.empty((N, rows_per_sample, n_head), dtype=torch.float32, device=t.device)
     a = nat.MlpArgs()
-    a.t, a.ab, a.w2_packed, a.b2, a.w3_packed, a.b3 = (t.data_ptr(), ab.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
-                                                       w3p.data_ptr(), b3.data_ptr())
+    a.t, a.ab, a.w2_packed, a.b2, a.w3_packed, a.b3 = (t.data_ptr(), None if ab is None else ab.data_ptr(), w2p.data_ptr(),
+                                                       b2.data_ptr(), w3p.data_ptr(), b3.data_ptr())
+    a.per_sample = _folded_operands(ab, w2p, b2, N, c_in, c_hid)
     a.w3_format = _w3_format(w3p)
     a.res = res.data_ptr() if res is not None else None
     a.res_low = a.res_bias = None

@@ -173,6 +173,10 @@ class HipBlockOps:
         # HBM, and the prologue adds 20 % more of it -- off by default, kept as the switch for when the activation gets cheaper.
         self.fuse_up = False
         self.fuse_up_cin = (64, 128)       # input widths the fused up kernel is used for (A/B switch for measurements)
+        # bf16 fused mixers at C_in <= 128: GroupNorm's affine folded into the expanding conv per sample (ops.groupnorm_fold_mlp in
+        # the place of groupnorm_finalize), the mixer loads its operand raw.  Round 4: the mixers are bound by VALU issue and the
+        # affine (unpack + fma + repack per element) was ~13 % of their instructions.  PYTC_FOLD_NORM=0 restores the affine prologue.
+        self.fold_norm = os.environ.get("PYTC_FOLD_NORM", "1") != "0"
 
     # ---- parameter repacking (load time / after optimizer steps) -----------------------------
     def _taps(self, conv: nn.Module):
@@ -200,6 +204,21 @@ class HipBlockOps:
             w2 = w.detach().float().reshape(w.shape[0], w.shape[1]).contiguous()
             return ops.pw_pack_weight_paired(w2, transposed=transposed, f16=f16)
         return self.cache.get(("pwp", id(conv), transposed, f16), [w], make)
+
+    def _w2_matrix(self, conv: nn.Module):
+        """(C_hid, C_in) fp32 contiguous view of the expanding 1x1x1 conv's weight (operand of ops.groupnorm_fold_mlp)."""
+        w = conv.weight
+        return self.cache.get(("w2mat", id(conv)), [w], lambda: w.detach().float().reshape(w.shape[0], w.shape[1]).contiguous())
+
+    def _fold(self, m, st, count, C: int, c_hid: int):
+        """-> (None, w2n, b2n) when the block's norm can be folded into its expanding conv, else (ab, shared image, b2)."""
+        gamma, beta = self._vec(m.norm, "weight", m.norm.weight), self._vec(m.norm, "bias", m.norm.bias)
+        if self.fold_norm and ops.groupnorm_fold_mlp_supported(C, c_hid):
+            w2n, b2n = ops.groupnorm_fold_mlp(st, count, gamma, beta, m.norm.eps, self._w2_matrix(m.conv2),
+                                              self._vec(m.conv2, "bias", m.conv2.bias))
+            return None, w2n, b2n
+        return (ops.groupnorm_finalize(st, count, gamma, beta, m.norm.eps), self._pw_paired(m.conv2),
+                self._vec(m.conv2, "bias", m.conv2.bias))
 
     def _head_w(self, conv: nn.Module):
         """bf16 MFMA fragment image of the transposed 1x1x1 output conv (weights rounded like the un-fused head's)."""
@@ -308,7 +327,7 @@ class HipBlockOps:
             t = ops.layernorm_rows(t, gamma, beta, m.norm.eps)
             ab = None
         else:
-            ab = ops.groupnorm_finalize(st, count, gamma, beta, m.norm.eps)
+            ab = None                                   # finalized below: folded into conv2 on the fused bf16 path
         _, Do, Ho, Wo, _ = t.shape
         rows = Do * Ho * Wo
         # optional two-GEMM schedule for the deep levels (SMALL_ROWS_TWO_GEMMS, off by default: measured slower here): expand, then
@@ -318,15 +337,18 @@ class HipBlockOps:
                  and ops.pw_conv_paired_supported(c_in=c_hid, c_out=c_out, in_dtype=dt, out_dtype=dt))
         if (not small and self.fused and dt == torch.bfloat16 and not m.grn and not is_ln and m.conv2.bias is not None
                 and m.conv3.bias is not None and ops.pw_mlp_supported(C, c_hid, c_out)):
+            ab, w2x, b2x = self._fold(m, st, count, C, c_hid)
             if (head is not None and kind == "block" and head.weight.shape[1] <= 16
                     and ops.pw_mlp_head_supported(C, c_hid, c_out)):
-                _, logits = ops.pw_mlp_head(t, ab, self._pw_paired(m.conv2), self._vec(m.conv2, "bias", m.conv2.bias),
+                _, logits = ops.pw_mlp_head(t, ab, w2x, b2x,
                                             self._pw_paired(m.conv3, project=True), self._vec(m.conv3, "bias", m.conv3.bias),
                                             self._head_w(head), self._vec(head, "bias", head.bias), N=N,
                                             rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out,
                                             res=x if m.do_res else None, store_y=False)
                 return None, logits.view(N, Do, Ho, Wo, -1)
-            return self._block_fused(m, x, t, ab, skip, (N, D, H, W, C), (Do, Ho, Wo), c_hid, c_out, out)
+            return self._block_fused(m, x, t, ab, skip, (N, D, H, W, C), (Do, Ho, Wo), c_hid, c_out, out, w2x, b2x)
+        if not is_ln:
+            ab = ops.groupnorm_finalize(st, count, gamma, beta, m.norm.eps)
         G = {}
         if small:
             h = ops.pw_conv(t, self._pw_paired(m.conv2), self._vec(m.conv2, "bias", m.conv2.bias), N=N, rows_per_sample=rows,
@@ -386,9 +408,8 @@ def _stem_block_fused(self, stem: nn.Module, m, x_cl: torch.Tensor, out: Optiona
                             lambda: ops.stem_dwconv3d_pack(sw, sb, taps, self._vec(m.conv1, "bias", m.conv1.bias)))
     t, st = ops.stem_dwconv3d(x_cl, packed)
     rows = D * H * W
-    ab = ops.groupnorm_finalize(st, float(rows), self._vec(m.norm, "weight", m.norm.weight),
-                                self._vec(m.norm, "bias", m.norm.bias), m.norm.eps)
-    y = ops.pw_mlp_stemres(t, ab, self._pw_paired(m.conv2), self._vec(m.conv2, "bias", m.conv2.bias),
+    ab, w2x, b2x = self._fold(m, st, float(rows), C, c_hid)
+    y = ops.pw_mlp_stemres(t, ab, w2x, b2x,
                            self._pw_paired(m.conv3, project=True), self._vec(m.conv3, "bias", m.conv3.bias), x_cl.reshape(N, rows), sw, sb,
                            N=N, rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out,
                            y=None if out is None else out.view(N, rows, c_out))
@@ -398,13 +419,15 @@ def _stem_block_fused(self, stem: nn.Module, m, x_cl: torch.Tensor, out: Optiona
 HipBlockOps._stem_block_fused = None   # bound below
 
 
-def _block_fused(self, m, x, t, ab, skip, ishape, oshape, c_hid, c_out, out=None):
-    """bf16 fast path: one pw_mlp launch per block (plus the tiny residual-conv GEMMs of down/up blocks)."""
+def _block_fused(self, m, x, t, ab, skip, ishape, oshape, c_hid, c_out, out=None, w2=None, b2=None):
+    """bf16 fast path: one pw_mlp launch per block (plus the tiny residual-conv GEMMs of down/up blocks).  (ab, w2, b2) from
+    HipBlockOps._fold: ab None = the norm lives inside the per-sample expand operands."""
     N, D, H, W, C = ishape
     Do, Ho, Wo = oshape
     rows = Do * Ho * Wo
     dt = torch.bfloat16
-    w2, b2 = self._pw_paired(m.conv2), self._vec(m.conv2, "bias", m.conv2.bias)
+    if w2 is None:
+        w2, b2 = self._pw_paired(m.conv2), self._vec(m.conv2, "bias", m.conv2.bias)
     w3, b3 = self._pw_paired(m.conv3, project=True), self._vec(m.conv3, "bias", m.conv3.bias)
     kw = dict(N=N, rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out)
     if out is not None:

@@ -226,6 +226,74 @@ def test_pw_mlp_fused_matches_reference(dev, cin, chid, cout, mode, hidden):
     torch.testing.assert_close(y.float().cpu(), ref, rtol=2e-2, atol=3e-2)
 
 
+@pytest.mark.parametrize("C,chid,cout,mode", [(32, 64, 32, "add"), (64, 128, 32, "up"), (64, 128, 64, "add"), (128, 256, 128, "none"),
+                                               (128, 512, 64, "add")])
+def test_groupnorm_fold_into_the_expanding_conv(dev, C, chid, cout, mode):
+    """pytc_groupnorm_fold_mlp (round 4): the statistics slots become per-sample expand operands W2 * diag(a_n), b2 + W2 b_n --
+    (i) the affine it derives equals groupnorm_finalize's, (ii) the image is the paired bf16 image of the scaled weight, bit for
+    bit, (iii) the folded bias matches fp64, and (iv) the mixer fed the RAW tensor and these operands equals the fp32 math
+    W3 gelu(W2 (a t + b) + b2) + b3 (+ residual) within the fused kernel's own tolerance."""
+    from pytorch_connectomics_amd import _native as nat
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(C + chid)
+    bf = torch.bfloat16
+    N, slots = 3, 37
+    if mode == "up":
+        grid = (4, 6, 4)
+        rows = 96
+    else:
+        rows, grid = 333, (0, 0, 0)
+    t = (torch.randn(N, rows, C) * 1.7 + torch.randn(1, 1, C)).to(bf)
+    # statistics slots whose sums are the true column sums (split unevenly over the slots)
+    tf = t.float()
+    s1, s2 = tf.sum(1), (tf * tf).sum(1)                                   # (N, C)
+    wts = torch.rand(N, slots, 1)
+    wts = wts / wts.sum(1, keepdim=True)
+    stats = torch.stack([wts * s1[:, None], wts * s2[:, None]], 2).contiguous().to(dev)      # (N, slots, 2, C)
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.3
+    w2, b2 = torch.randn(chid, C) / C ** 0.5, torch.randn(chid) * 0.5
+    w3, b3 = torch.randn(cout, chid) / chid ** 0.5, torch.randn(cout) * 0.5
+    ab_ref = ops.groupnorm_finalize(stats, float(rows), gamma.to(dev), beta.to(dev), 1e-5)
+    w2n, b2n, ab = ops.groupnorm_fold_mlp(stats, float(rows), gamma.to(dev), beta.to(dev), 1e-5, w2.to(dev), b2.to(dev), want_ab=True)
+    torch.testing.assert_close(ab, ab_ref, rtol=2e-6, atol=2e-6)
+    a, b = ab[:, 0].cpu(), ab[:, 1].cpu()
+    for n in range(N):
+        img = ops.pw_pack_weight_paired((w2 * a[n][None, :]).to(dev))
+        assert torch.equal(img.view(torch.int16), w2n[n].view(torch.int16)), n
+    want_b = (b2.double()[None] + b.double() @ w2.double().t()).float()
+    torch.testing.assert_close(b2n.cpu(), want_b, rtol=1e-5, atol=1e-5)
+    # the mixer on raw t
+    hid = F.gelu((tf * a[:, None] + b[:, None]) @ w2.t() + b2)
+    core = hid @ w3.t() + b3
+    w3p = ops.pw_pack_weight_paired(w3.to(dev), f16=True)
+    args = dict(N=N, rows_per_sample=rows, c_in=C, c_hid=chid, c_out=cout)
+    if mode == "add":
+        res = torch.randn(N, rows, cout).to(bf)
+        ref = core + res.float()
+        y = ops.pw_mlp(t.to(dev), None, w2n, b2n, w3p, b3.to(dev), res=res.to(dev), res_mode=nat.RES_ADD, **args)
+        y_aff = ops.pw_mlp(t.to(dev), ab, ops.pw_pack_weight_paired(w2.to(dev)), b2.to(dev), w3p, b3.to(dev), res=res.to(dev),
+                           res_mode=nat.RES_ADD, **args)
+    elif mode == "none":
+        ref = core
+        y = ops.pw_mlp(t.to(dev), None, w2n, b2n, w3p, b3.to(dev), **args)
+        y_aff = ops.pw_mlp(t.to(dev), ab, ops.pw_pack_weight_paired(w2.to(dev)), b2.to(dev), w3p, b3.to(dev), **args)
+    else:
+        skip = torch.randn(N, rows, cout).to(bf)
+        c5 = core.view(N, *grid, cout)
+        ref = torch.zeros_like(c5)
+        ref[:, 1:, 1:, 1:] = c5[:, 1:, 1:, 1:]
+        ref = (ref + skip.float().view(N, *grid, cout)).view(N, rows, cout)
+        kw = dict(res=skip.to(dev), res_mode=nat.RES_UPSAMPLE, grid=grid, **args)
+        y = ops.pw_mlp(t.to(dev), None, w2n, b2n, w3p, b3.to(dev), **kw)
+        y_aff = ops.pw_mlp(t.to(dev), ab, ops.pw_pack_weight_paired(w2.to(dev)), b2.to(dev), w3p, b3.to(dev), **kw)
+    torch.testing.assert_close(y.float().cpu(), ref, rtol=2e-2, atol=3e-2)
+    # and no further from the fp32 math than the affine-prologue form is (mean absolute error within 25 %)
+    e_fold, e_aff = (y.float().cpu() - ref).abs().mean(), (y_aff.float().cpu() - ref).abs().mean()
+    assert float(e_fold) <= 1.25 * float(e_aff) + 1e-4, (float(e_fold), float(e_aff))
+    with pytest.raises(ValueError, match="norm-folded mixer operands"):
+        ops.pw_mlp(t.to(dev), None, w2n[:1], b2n, w3p, b3.to(dev), **args)
+
+
 def test_packed_fp16_gelu_accuracy(dev):
     """gelu_h2 (csrc/pytc_common.h) through the fused mixer: identity-like first GEMM, one-hot projection, so the output is
     bf16(gelu_h2(x)) for a dense sweep of x.  Error budget: polynomial fit 1e-4 + fp16 evaluation, then the bf16 output
