@@ -409,12 +409,48 @@ def _unet_leg(dev, args, make, label, patch, batch, out_ch):
             "infer_voxels_per_s": vox / dt_inf, "final_loss": float(loss.detach()), "train_roofline": roof}
 
 
+RSUNET_STOCK = dict(width=[18, 36, 48, 64, 80], norm="group", num_groups=4, activation="elu", down_factors=[(1, 2, 2)] * 4, depth_2d=1,
+                    kernel_2d=(1, 3, 3))
+
+
 def rsunet_leg(dev, args):
-    """The path's second architecture (single GPU): RSUNet [16, 32, 64, 128], BatchNorm, anisotropic 2 x 18 x 160 x 160
-    patches, bf16 storage: training step (HIP forward + backward, fused loss, fused AdamW) and inference forward."""
+    """The path's second architecture (single GPU), AS THE REFERENCE SHIPS IT (config/profiles/arch_profiles.yaml:34-44, what
+    tutorials/syn_cremi.yaml trains): width [18, 36, 48, 64, 80], GroupNorm(4) (GroupNorm(3, 18) on the first level), ELU, down
+    (1,2,2) x 4, (1,3,3) kernels on level 0; anisotropic 2 x 18 x 256 x 256 patches, bf16 storage: training step (HIP forward +
+    backward, fused loss, fused AdamW) and inference forward.  The two widths that are no multiple of 8 travel as 24 / 40 channels
+    (ops.pad_channels).  `pow2` = the hand-picked widths [16, 32, 64, 128] / BatchNorm / ReLU the earlier rounds benched, at the same
+    patch, with the per-FLOP ratio of the two training steps (conv FLOPs of the reference's own channel counts)."""
     from pytorch_connectomics_amd.models.architectures.rsunet import RSUNet
-    return _unet_leg(dev, args, lambda: RSUNet(1, 3, width=[16, 32, 64, 128], norm="batch", activation="relu"),
-                     "RSUNet width [16,32,64,128], BatchNorm, relu", (18, 160, 160), 2, 3)
+    patch = (18, 256, 256)
+    res = _unet_leg(dev, args, lambda: RSUNet(1, 1, **RSUNET_STOCK),
+                    "RSUNet stock profile: width [18,36,48,64,80], GroupNorm(4), ELU, down (1,2,2)x4, depth_2d 1", patch, 2, 1)
+    try:
+        pow2 = _unet_leg(dev, args, lambda: RSUNet(1, 1, width=[16, 32, 64, 128], norm="batch", activation="relu"),
+                         "RSUNet width [16,32,64,128], BatchNorm, relu", patch, 2, 1)
+        gf = lambda w, k0: _rsunet_conv_gflop(w, patch, 2, k0)      # noqa: E731
+        res["pow2"] = {k: pow2[k] for k in ("model", "train_ms_per_step", "infer_ms_per_forward")}
+        res["train_us_per_gflop"] = round(res["train_ms_per_step"] * 1e3 / gf([18, 36, 48, 64, 80], 9), 3)
+        res["pow2"]["train_us_per_gflop"] = round(pow2["train_ms_per_step"] * 1e3 / gf([16, 32, 64, 128], 27), 3)
+        res["per_flop_ratio_vs_pow2"] = round(res["train_us_per_gflop"] / res["pow2"]["train_us_per_gflop"], 3)
+    except Exception as e:     # noqa: BLE001 - the comparison must not cost the leg
+        res["pow2"] = {"error": f"{type(e).__name__}: {e}"}
+    return res
+
+
+def _rsunet_conv_gflop(width, patch, batch, taps_level0):
+    """Forward + backward conv GFLOP of one RSUNet training step at the REFERENCE's channel counts (3 x forward; the 1-channel stem
+    and head convs left out): per level 4 convs width -> width (3 of them ResBlock / post convs) + the in-projection from the level
+    above, encoder and decoder sides, (1,2,2) pooling, `taps_level0` taps on level 0 and 27 below."""
+    vox = batch * patch[0] * patch[1] * patch[2]
+    total = 0.0
+    for lvl, w in enumerate(width):
+        taps = taps_level0 if lvl == 0 else 27
+        sides = 1 if lvl == len(width) - 1 else 2                       # the deepest level has no decoder twin
+        total += sides * 4 * 2.0 * vox * w * w * taps
+        if lvl + 1 < len(width):
+            total += 2.0 * vox * w * width[lvl + 1]                     # 1x1x1 up-projection into this level
+        vox /= 4
+    return 3 * total / 1e9
 
 
 def monai_unet_leg(dev, args):

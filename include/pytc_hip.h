@@ -550,6 +550,20 @@ int pytc_conv3d_pack_plan(int C_out, int C_in, int kd, int kh, int kw, int dtype
 int pytc_conv3d_pack_multi(const int64_t* table_dev, int n_items, int64_t total_blocks, void* stream);
 int pytc_norm_bwd_means(const float* s, const float* gamma, float* M, float* dgamma, float* dbeta, int N, int C, int groups,
                         float rows, void* stream);
+/* The two group-statistics kernels with an explicit group width (round 4): `groups` groups of `cpg` channels, and the channels from
+ * groups * cpg up to C are ALIGNMENT PADDING -- all-zero tails the model adds so that rows are 16-byte aligned when the reference's
+ * channel counts are not (RSUNet's stock widths [18, 36, ...], config/profiles/arch_profiles.yaml:34-44, run as 24 / 40 channels):
+ * GroupNorm(g, C_real) of rsunet.py:88-94 on the real channels, affine (0, 0) / mean = rstd = 0 / M = 0 on the padding; gamma and
+ * beta hold groups * cpg entries.  cpg = 0 is the plain C / groups form; mr may be NULL in the finalize. */
+/* pytc_bn_train_finalize with C_real <= C: the channels from C_real on are alignment padding (affine / mean / rstd 0; gamma, beta and
+ * the running buffers hold C_real entries) */
+int pytc_bn_train_finalize_cpad(const float* stats, int slots_total, float count, const float* gamma, const float* beta, float eps,
+                                float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* ab,
+                                float* mean_rstd, int N, int C, int C_real, void* stream);
+int pytc_norm_finalize_groups_cpg(const float* stats, int slots, float count, const float* gamma, const float* beta, float eps,
+                                  int groups, int cpg, float* ab, float* mr, int N, int C, void* stream);
+int pytc_norm_bwd_means_cpg(const float* s, const float* gamma, float* M, float* dgamma, float* dbeta, int N, int C, int groups,
+                            int cpg, float rows, void* stream);
 /* nn.BatchNorm3d in train() mode after the statistics pass, one launch: stats [slots_total][2][C] = the (sum, sum of squares)
  * partials of ALL samples (pytc_channel_stats output viewed flat), count = N * voxels; writes the batch affine ab [N][2][C] and
  * (mean, rstd) [N][2][C] (identical for every n), blends running_mean / running_var (unbiased variance, `momentum`; NULL pair =

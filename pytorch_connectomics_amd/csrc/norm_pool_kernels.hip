@@ -44,11 +44,22 @@ channel_stats_kernel(const T* __restrict__ x, float* __restrict__ stats, long ro
 __global__ void __launch_bounds__(256)
 norm_finalize_groups_kernel(const float* __restrict__ stats, int slots, float count, const float* __restrict__ gamma,
                             const float* __restrict__ beta, float eps, int groups, float* __restrict__ ab, int C,
-                            float* __restrict__ mr = nullptr) {
+                            float* __restrict__ mr = nullptr, int cpg_arg = 0) {
   // one workgroup per (n, group); deterministic two-level reduction
+  // cpg_arg > 0: `groups` groups of cpg_arg channels each; the channels from groups * cpg_arg on are alignment padding of an
+  // all-zero tensor tail (the extra workgroup blockIdx.x == groups): affine (0, 0), mean / rstd 0 -- they stay zero through
+  // any activation with act(0) = 0 and contribute nothing to the backward pass
   __shared__ float red[2][256];
   const int n = blockIdx.y, g = blockIdx.x;
-  const int cpg = C / groups;
+  const int cpg = cpg_arg > 0 ? cpg_arg : C / groups;
+  if (g == groups) {
+    for (int c = groups * cpg + threadIdx.x; c < C; c += blockDim.x) {
+      ab[((long)n * 2 + 0) * C + c] = 0.f;
+      ab[((long)n * 2 + 1) * C + c] = 0.f;
+      if (mr) { mr[((long)n * 2 + 0) * C + c] = 0.f; mr[((long)n * 2 + 1) * C + c] = 0.f; }
+    }
+    return;
+  }
   float a1 = 0.f, a2 = 0.f;
   const float* base = stats + (long)n * slots * 2 * C;
   for (long i = threadIdx.x; i < (long)slots * cpg; i += blockDim.x) {
@@ -334,14 +345,23 @@ extern "C" int pytc_norm_finalize_groups(const float* stats, int slots, float co
   return PYTC_OK;
 }
 
+extern "C" int pytc_norm_finalize_groups_cpg(const float* stats, int slots, float count, const float* gamma, const float* beta,
+                                             float eps, int groups, int cpg, float* ab, float* mr, int N, int C, void* stream) {
+  PYTC_REQUIRE(stats && ab && slots >= 1 && count > 0 && groups >= 1, "norm_finalize_groups: bad arguments");
+  PYTC_REQUIRE(cpg > 0 ? groups * cpg <= C : C % groups == 0,
+               "norm_finalize_groups: C=%d, groups=%d, channels per group %d", C, groups, cpg);
+  const int pad = (cpg > 0 && groups * cpg < C) ? 1 : 0;
+  hipLaunchKernelGGL(norm_finalize_groups_kernel, dim3(groups + pad, N), dim3(256), 0, (hipStream_t)stream, stats, slots,
+                     count, gamma, beta, eps, groups, ab, C, mr, cpg);
+  PYTC_LAUNCH_CHECK("norm_finalize_groups");
+  return PYTC_OK;
+}
+
 extern "C" int pytc_norm_finalize_groups_mr(const float* stats, int slots, float count, const float* gamma,
                                             const float* beta, float eps, int groups, float* ab, float* mr, int N, int C,
                                             void* stream) {
-  PYTC_REQUIRE(stats && ab && mr && slots >= 1 && count > 0 && groups >= 1 && C % groups == 0, "norm_finalize_groups_mr: bad arguments");
-  hipLaunchKernelGGL(norm_finalize_groups_kernel, dim3(groups, N), dim3(256), 0, (hipStream_t)stream, stats, slots,
-                     count, gamma, beta, eps, groups, ab, C, mr);
-  PYTC_LAUNCH_CHECK("norm_finalize_groups_mr");
-  return PYTC_OK;
+  PYTC_REQUIRE(mr, "norm_finalize_groups_mr: null mean/rstd output");
+  return pytc_norm_finalize_groups_cpg(stats, slots, count, gamma, beta, eps, groups, 0, ab, mr, N, C, stream);
 }
 
 extern "C" int pytc_maxpool3d_fwd(const void* x, void* y, int N, int D, int H, int W, int C, int fz, int fy, int fx,

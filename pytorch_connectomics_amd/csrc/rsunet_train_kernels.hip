@@ -135,7 +135,7 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
   if (slot >= slots) return;
   const int t = (int)((b / 8) % T);
   const int dzi = t % g.kd, tile = t / g.kd;
-  const int tiles_k = RAG_K ? 1 : C_in / BN;
+  const int tiles_k = RAG_K ? 1 : (C_in + BN - 1) / BN;      // the last tile may be partly filled (C % 8 == 0 is all that is asked)
   const int o_base = (tile / tiles_k) * BM, k_base = (tile % tiles_k) * BN;
   const int dz = dzi - g.kd / 2;
   const int nseg = (g.W + 31) / 32;
@@ -173,10 +173,11 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
       rg[0] = __builtin_bit_cast(q4_t, v);
     } else {
       const bf16_t* dyl = dy + line * g.W * (long)C_out + o_base + g_chunk * 8;
+      const bool och = o_base + g_chunk * 8 < C_out;        // 8-channel pieces beyond C_out (partly filled last tile): zeros
 #pragma unroll
       for (int it = 0; it < ITG; ++it) {
         const int x = x0 + it * RG + g_row;
-        rg[it] = x < g.W ? *reinterpret_cast<const q4_t*>(dyl + (long)x * C_out) : zero4;
+        rg[it] = (x < g.W && och) ? *reinterpret_cast<const q4_t*>(dyl + (long)x * C_out) : zero4;
       }
     }
     const int sz = z + dz;
@@ -202,8 +203,8 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
           const int c = it * 64 + lane;
           const int row = c / CHX, chunk = c % CHX;
           const int x = x0 - PAD + row;
-          ra[l][it] = (ok && row < AR && x >= 0 && x < g.W) ? *reinterpret_cast<const q4_t*>(al + (long)x * C_in + chunk * 8)
-                                                            : zero4;
+          ra[l][it] = (ok && row < AR && x >= 0 && x < g.W && k_base + chunk * 8 < C_in)
+                          ? *reinterpret_cast<const q4_t*>(al + (long)x * C_in + chunk * 8) : zero4;
         }
       }
     }
@@ -332,7 +333,7 @@ conv3d_wgrad_mfma_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict_
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
             const int k = k_base + n * 16 + nn;
-            if ((!RAG_O || o < C_out) && (!RAG_K || k < C_in))
+            if (o < C_out && k < C_in)
               dWp[(((long)slot * taps + dzi * TP + tp) * C_out + o) * C_in + k] = acc[tp][m][n][i];
           }
         }
@@ -674,12 +675,18 @@ static int grid_for(long n) { long b = (n + 255) / 256; return (int)(b < 16384 ?
 // (GroupNorm; groups == C: InstanceNorm); groups == 0: all samples of the channel (BatchNorm).
 __global__ void __launch_bounds__(256)
 norm_bwd_means_kernel(const float* __restrict__ s, const float* __restrict__ gamma, float* __restrict__ M,
-                      float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, int groups, float rows) {
+                      float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, int groups, float rows, int cpg_arg) {
+  // cpg_arg > 0: `groups` groups of cpg_arg channels; channels from groups * cpg_arg on are alignment padding (all zero tensors):
+  // M = 0 there and gamma (groups * cpg_arg entries) is not read
+  const int cpg_ = groups > 0 ? (cpg_arg > 0 ? cpg_arg : C / groups) : 0;
+  const int C_real = groups > 0 ? groups * cpg_ : C;
   for (int c = threadIdx.x; c < C; c += 256) {
     float a0 = 0.f, a1 = 0.f;
     for (int n = 0; n < N; ++n) { a0 += s[(n * 2 + 0) * C + c]; a1 += s[(n * 2 + 1) * C + c]; }
     if (dbeta) dbeta[c] = a0;
     if (dgamma) dgamma[c] = a1;
+    if (c >= C_real)
+      for (int n = 0; n < N; ++n) { M[(n * 2 + 0) * C + c] = 0.f; M[(n * 2 + 1) * C + c] = 0.f; }
     if (groups == 0) {
       const float gm = gamma ? gamma[c] : 1.0f;
       const float inv = 1.0f / ((float)N * rows);
@@ -687,7 +694,7 @@ norm_bwd_means_kernel(const float* __restrict__ s, const float* __restrict__ gam
     }
   }
   if (groups > 0) {
-    const int cpg = C / groups;
+    const int cpg = cpg_;
     const float inv = 1.0f / (rows * (float)cpg);
     for (int i = threadIdx.x; i < N * 2 * groups; i += 256) {
       const int g = i % groups, nk = i / groups;
@@ -721,9 +728,17 @@ __global__ void __launch_bounds__(256)
 bn_train_finalize_kernel(const float* __restrict__ stats, int slots, float count, const float* __restrict__ gamma,
                          const float* __restrict__ beta, float eps, float momentum, float* __restrict__ rmean,
                          float* __restrict__ rvar, long long* __restrict__ nbt, float* __restrict__ ab, float* __restrict__ mr,
-                         int N, int C) {
+                         int N, int C, int C_real) {
   __shared__ float red[2][256];
   const int c = blockIdx.x;
+  if (c >= C_real) {        // alignment padding (all-zero channels): affine (0, 0), no parameters or running buffers behind them
+    if (threadIdx.x == 0)
+      for (int n = 0; n < N; ++n) {
+        ab[((long)n * 2 + 0) * C + c] = 0.f; ab[((long)n * 2 + 1) * C + c] = 0.f;
+        mr[((long)n * 2 + 0) * C + c] = 0.f; mr[((long)n * 2 + 1) * C + c] = 0.f;
+      }
+    return;
+  }
   float a1 = 0.f, a2 = 0.f;
   for (long s = threadIdx.x; s < slots; s += blockDim.x) {
     a1 += stats[(s * 2 + 0) * C + c];
@@ -773,12 +788,14 @@ static CwPlan cw_plan(int N, int D, int H, int W, int C_in, int C_out, const int
   p.rag_o = C_out < 16;
   p.rag_k = C_in < 16;
   p.kp = k[1];
-  p.mfma = dtype == PYTC_BF16 && k[1] == k[2] && (k[1] == 3 || k[1] == 1) && (p.rag_o || C_out % 16 == 0) &&
-           (p.rag_k || C_in % 16 == 0) && (tuning_get("conv_wgrad_mfma", 1) != 0);
+  // rows must be 16-byte aligned (C % 8 == 0); a channel count that is not a multiple of the tile width leaves the last tile
+  // partly filled (24 = 16 + 8, 40 = 16 + 16 + 8: RSUNet's stock widths [18, 36, ...] padded to 8 by the model)
+  p.mfma = dtype == PYTC_BF16 && k[1] == k[2] && (k[1] == 3 || k[1] == 1) && (p.rag_o || C_out % 8 == 0) &&
+           (p.rag_k || C_in % 8 == 0) && (tuning_get("conv_wgrad_mfma", 1) != 0);
   if (p.mfma) {
     p.mt = (!p.rag_o && C_out % 32 == 0) ? 2 : 1;
     p.nt = (!p.rag_k && C_in % 32 == 0) ? 2 : 1;
-    p.tiles = (p.rag_o ? 1 : C_out / (p.mt * 16)) * (p.rag_k ? 1 : C_in / (p.nt * 16));
+    p.tiles = (p.rag_o ? 1 : (C_out + p.mt * 16 - 1) / (p.mt * 16)) * (p.rag_k ? 1 : (C_in + p.nt * 16 - 1) / (p.nt * 16));
     const long units = (long)N * D * H * ((W + 31) / 32);
     long s = 1536 / ((long)p.tiles * k[0]);            // ~1536 workgroups over the launch (6 per CU)
     if (s > units / 16) s = units / 16;                // >= 4 consecutive units per wave: the line ring needs a run to pay off
@@ -968,25 +985,41 @@ extern "C" int pytc_dwconv3d_generic_fwd(const void* x, void* y, const float* w,
   return PYTC_OK;
 }
 
+extern "C" int pytc_norm_bwd_means_cpg(const float* s, const float* gamma, float* M, float* dgamma, float* dbeta, int N, int C,
+                                       int groups, int cpg, float rows, void* stream) {
+  PYTC_REQUIRE(s && M && N >= 1 && C >= 1 && rows >= 1.f, "norm_bwd_means: bad arguments");
+  PYTC_REQUIRE(groups == 0 || (groups >= 1 && (cpg > 0 ? groups * cpg <= C : C % groups == 0)),
+               "norm_bwd_means: C must be divisible by groups (or groups * cpg <= C with explicit channels per group)");
+  hipLaunchKernelGGL(norm_bwd_means_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, s, gamma, M, dgamma, dbeta, N, C, groups, rows,
+                     cpg);
+  PYTC_LAUNCH_CHECK("norm_bwd_means");
+  return PYTC_OK;
+}
+
 extern "C" int pytc_norm_bwd_means(const float* s, const float* gamma, float* M, float* dgamma, float* dbeta, int N, int C,
                                    int groups, float rows, void* stream) {
-  PYTC_REQUIRE(s && M && N >= 1 && C >= 1 && rows >= 1.f, "norm_bwd_means: bad arguments");
-  PYTC_REQUIRE(groups == 0 || (groups >= 1 && C % groups == 0), "norm_bwd_means: C must be divisible by groups");
-  hipLaunchKernelGGL(norm_bwd_means_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, s, gamma, M, dgamma, dbeta, N, C, groups, rows);
-  PYTC_LAUNCH_CHECK("norm_bwd_means");
+  return pytc_norm_bwd_means_cpg(s, gamma, M, dgamma, dbeta, N, C, groups, 0, rows, stream);
+}
+
+extern "C" int pytc_bn_train_finalize_cpad(const float* stats, int slots_total, float count, const float* gamma, const float* beta,
+                                           float eps, float momentum, float* running_mean, float* running_var,
+                                           int64_t* num_batches_tracked, float* ab, float* mean_rstd, int N, int C, int C_real,
+                                           void* stream) {
+  PYTC_REQUIRE(stats && ab && mean_rstd && slots_total >= 1 && count >= 1.f && N >= 1 && C >= 1 && C_real >= 1 && C_real <= C,
+               "bn_train_finalize: bad arguments");
+  PYTC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_finalize: running buffers come as a pair");
+  hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, slots_total, count, gamma, beta,
+                     eps, momentum, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), ab, mean_rstd, N,
+                     C, C_real);
+  PYTC_LAUNCH_CHECK("bn_train_finalize");
   return PYTC_OK;
 }
 
 extern "C" int pytc_bn_train_finalize(const float* stats, int slots_total, float count, const float* gamma, const float* beta,
                                       float eps, float momentum, float* running_mean, float* running_var,
                                       int64_t* num_batches_tracked, float* ab, float* mean_rstd, int N, int C, void* stream) {
-  PYTC_REQUIRE(stats && ab && mean_rstd && slots_total >= 1 && count >= 1.f && N >= 1 && C >= 1, "bn_train_finalize: bad arguments");
-  PYTC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_finalize: running buffers come as a pair");
-  hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, slots_total, count, gamma, beta,
-                     eps, momentum, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), ab, mean_rstd, N,
-                     C);
-  PYTC_LAUNCH_CHECK("bn_train_finalize");
-  return PYTC_OK;
+  return pytc_bn_train_finalize_cpad(stats, slots_total, count, gamma, beta, eps, momentum, running_mean, running_var,
+                                     num_batches_tracked, ab, mean_rstd, N, C, C, stream);
 }
 
 extern "C" int pytc_bn_update_running(const float* mean_rstd, float* running_mean, float* running_var, int C, float count,

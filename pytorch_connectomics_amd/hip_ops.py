@@ -842,6 +842,38 @@ def _conv_layout_rule(shape, layout: str):
     raise ValueError(f"unknown weight layout {layout!r}")
 
 
+def _conv_pack_row(w: torch.Tensor, out_ptr: int, layout: str, dtype: torch.dtype, pad_to, first_block: int):
+    """One row of pytc_conv3d_pack_multi's table for weight `w` (fp32, contiguous): the image is laid out for (co_p, ci_p) = pad_to
+    channels (default: the conv's own), the SOURCE bounds stay the weight's -- the kernel writes zeros beyond them.  -> (row, n)"""
+    co, ci, s_o, s_c, flip, direct = _conv_layout_rule(w.shape, layout)
+    co_p, ci_p = (co, ci) if pad_to is None else pad_to
+    if co_p < co or ci_p < ci:
+        raise ValueError(f"padded conv image ({co_p}, {ci_p}) smaller than the weight's ({co}, {ci})")
+    kd, kh, kw = (int(v) for v in w.shape[2:])
+    plan = (C.c_int64 * 5)()
+    nat.check(nat.lib().pytc_conv3d_pack_plan(co_p, ci_p, kd, kh, kw, dtype_code(dtype), direct, plan), "conv3d_pack_plan")
+    kind, p1, p2, p3, n = (int(v) for v in plan)
+    return [w.data_ptr(), out_ptr, s_o, s_c, first_block, n, co, ci, kd * kh * kw, kind, int(dtype == torch.float32), flip,
+            p1, p2, p3, 0], n
+
+
+def conv3d_pack_weight_padded(w: torch.Tensor, layout: str, dtype: torch.dtype, pad_to) -> torch.Tensor:
+    """The image of `w` for a conv that runs with pad_to = (C_out, C_in) channels (pad_channels): one-row pytc_conv3d_pack_multi."""
+    _dev(w, "w")
+    co, ci, *_ = _conv_layout_rule(w.shape, layout)
+    kd, kh, kw = (int(v) for v in w.shape[2:])
+    direct = _conv_layout_rule(w.shape, layout)[5]
+    n_alloc = (nat.lib().pytc_conv3d_packed_elems(pad_to[0], pad_to[1], kd, kh, kw, dtype_code(dtype)) if not direct
+               else None)
+    if n_alloc is None:
+        raise NotImplementedError("padded images exist for the stride-1 conv layouts ('fwd', 'dgrad')")
+    out = torch.zeros((n_alloc,), dtype=dtype, device=w.device)
+    row, n = _conv_pack_row(w, out.data_ptr(), layout, dtype, pad_to, 0)
+    table = torch.tensor(row, dtype=torch.int64).to(w.device)
+    _run("conv3d_pack_multi", _nbytes(w, out), nat.lib().pytc_conv3d_pack_multi, _p(table), 1, (n + 255) // 256, _stream())
+    return out
+
+
 class ConvPackSet:
     """The per-step conv-weight images of the dense-conv models (RSUNet, MONAI-style U-Net) in training: every image asked for
     through `get` is remembered, and `refresh()` -- called at the start of a training forward -- rebuilds ALL images whose
@@ -853,15 +885,20 @@ class ConvPackSet:
         self.table = None
         self.blocks = 0
 
-    def get(self, weight: torch.Tensor, layout: str, dtype: torch.dtype) -> torch.Tensor:
-        key = (weight.data_ptr(), layout, dtype)
+    def get(self, weight: torch.Tensor, layout: str, dtype: torch.dtype, pad_to=None) -> torch.Tensor:
+        """pad_to = (C_out, C_in) the conv RUNS with (pad_channels; in the orientation of the image, i.e. already swapped for
+        'dgrad'), None = the weight's own."""
+        if pad_to is not None:
+            own = _conv_layout_rule(weight.shape, layout)[:2]
+            pad_to = None if tuple(pad_to) == tuple(own) else (int(pad_to[0]), int(pad_to[1]))
+        key = (weight.data_ptr(), layout, dtype, pad_to)
         row = self.rows.get(key)
         if row is not None and row[0]() is weight and row[2] == weight._version:
             return row[1]
         w32 = weight.detach()
         if w32.dtype != torch.float32 or not w32.is_contiguous():       # not a plain fp32 parameter: single pack, not tracked
-            return _conv_pack_single(w32.float().contiguous(), layout, dtype)
-        out = _conv_pack_single(w32, layout, dtype)
+            return _conv_pack_single(w32.float().contiguous(), layout, dtype, pad_to)
+        out = _conv_pack_single(w32, layout, dtype, pad_to)
         import weakref
         self.rows[key] = [weakref.ref(weight), out, weight._version, None]
         self.table = None
@@ -879,14 +916,9 @@ class ConvPackSet:
         dev = live[0][1][1].device
         if self.table is None:
             flat, blk = [], 0
-            plan = (C.c_int64 * 5)()
-            for (_ptr, layout, dtype), r, w in live:
-                co, ci, s_o, s_c, flip, direct = _conv_layout_rule(w.shape, layout)
-                kd, kh, kw = (int(v) for v in w.shape[2:])
-                nat.check(nat.lib().pytc_conv3d_pack_plan(co, ci, kd, kh, kw, dtype_code(dtype), direct, plan), "conv3d_pack_plan")
-                kind, p1, p2, p3, n = (int(v) for v in plan)
-                flat += [w.data_ptr(), r[1].data_ptr(), s_o, s_c, blk, n, co, ci, kd * kh * kw, kind, int(dtype == torch.float32), flip,
-                         p1, p2, p3, 0]
+            for (_ptr, layout, dtype, pad_to), r, w in live:
+                row, n = _conv_pack_row(w, r[1].data_ptr(), layout, dtype, pad_to, blk)
+                flat += row
                 blk += (n + 255) // 256
             self.table = torch.tensor(flat, dtype=torch.int64).to(dev)
             self.blocks = blk
@@ -896,7 +928,9 @@ class ConvPackSet:
             r[2] = w._version
 
 
-def _conv_pack_single(w32: torch.Tensor, layout: str, dtype: torch.dtype) -> torch.Tensor:
+def _conv_pack_single(w32: torch.Tensor, layout: str, dtype: torch.dtype, pad_to=None) -> torch.Tensor:
+    if pad_to is not None:
+        return conv3d_pack_weight_padded(w32, layout, dtype, pad_to)
     if layout == "fwd":
         return conv3d_pack_weight(w32, dtype)
     if layout == "dgrad":
@@ -908,15 +942,16 @@ CONV_PACKS = ConvPackSet()
 
 
 def norm_bwd_means(s: torch.Tensor, gamma: Optional[torch.Tensor], groups: int, rows: int, *, want_gamma: bool,
-                   want_beta: bool):
-    """s (N,2,C) -> (M (N,2,C), dgamma (C) | None, dbeta (C) | None); groups = 0: batch statistics"""
+                   want_beta: bool, cpg: int = 0):
+    """s (N,2,C) -> (M (N,2,C), dgamma (C) | None, dbeta (C) | None); groups = 0: batch statistics; cpg > 0: `groups` groups of
+    `cpg` real channels, the rest of C is alignment padding (M = 0 there; gamma holds groups * cpg entries)"""
     _dev(s, "s")
     N, _, Cc = s.shape
     M = torch.empty_like(s)
     dg = torch.empty((Cc,), dtype=torch.float32, device=s.device) if want_gamma else None
     db = torch.empty((Cc,), dtype=torch.float32, device=s.device) if want_beta else None
-    _run("norm_bwd_means", 2 * _nbytes(s), nat.lib().pytc_norm_bwd_means, _p(s), _p(gamma), _p(M), _p(dg), _p(db), N, Cc,
-         int(groups), float(rows), _stream())
+    _run("norm_bwd_means", 2 * _nbytes(s), nat.lib().pytc_norm_bwd_means_cpg, _p(s), _p(gamma), _p(M), _p(dg), _p(db), N, Cc,
+         int(groups), int(cpg), float(rows), _stream())
     return M, dg, db
 
 
@@ -934,9 +969,11 @@ def bn_train_finalize(stats: torch.Tensor, count: float, gamma: Optional[torch.T
         raise RuntimeError("bn_train_finalize: fp32 running buffers expected")
     if num_batches_tracked is not None and num_batches_tracked.dtype != torch.int64:
         raise RuntimeError("bn_train_finalize: int64 num_batches_tracked expected")
-    _run("bn_train_finalize", _nbytes(stats, ab, mr), nat.lib().pytc_bn_train_finalize, _p(stats), slots_total, float(count), _p(gamma),
-         _p(beta), float(eps), float(momentum), _p(running_mean), _p(running_var), _p(num_batches_tracked), _p(ab), _p(mr), N, Cc,
-         _stream())
+    # channels beyond the norm's own count (gamma / running buffers) are alignment padding of the activation (pad_channels)
+    c_real = int(gamma.numel()) if gamma is not None else (int(running_mean.numel()) if running_mean is not None else Cc)
+    _run("bn_train_finalize", _nbytes(stats, ab, mr), nat.lib().pytc_bn_train_finalize_cpad, _p(stats), slots_total, float(count),
+         _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean), _p(running_var), _p(num_batches_tracked), _p(ab), _p(mr),
+         N, Cc, c_real, _stream())
     return ab, mr
 
 
@@ -983,11 +1020,21 @@ def channel_stats(x: torch.Tensor) -> torch.Tensor:
     return st
 
 
-def norm_finalize_groups(stats: torch.Tensor, count: float, gamma, beta, eps: float, groups: int) -> torch.Tensor:
+def pad_channels(c: int, dtype: torch.dtype) -> int:
+    """Channel count a dense-conv model's activations are carried with: rows 16-byte aligned (8 bf16 / 4 fp32 channels) so that every
+    kernel of the path runs its vector form.  The reference's stock RSUNet widths [18, 36, 48, 64, 80] (arch_profiles.yaml:34-44)
+    travel as 24 / 40 / 48 / 64 / 80 channels in bf16, the extra ones all-zero (zero weight rows / columns, affine (0, 0), act(0) = 0).
+    Counts up to 4 (network inputs, heads) are served by the thin kernels and stay as they are."""
+    q = 8 if dtype == torch.bfloat16 else 4
+    return c if (c <= 4 or c % q == 0) else (c + q - 1) // q * q
+
+
+def norm_finalize_groups(stats: torch.Tensor, count: float, gamma, beta, eps: float, groups: int, cpg: int = 0) -> torch.Tensor:
+    """cpg > 0: `groups` groups of `cpg` real channels; the channels of `stats` beyond groups * cpg are alignment padding (affine 0)."""
     N, slots, _, Cc = stats.shape
     ab = torch.empty((N, 2, Cc), dtype=torch.float32, device=stats.device)
-    _run("norm_finalize_groups", _nbytes(stats, ab), nat.lib().pytc_norm_finalize_groups, _p(stats), slots, float(count),
-         _p(gamma), _p(beta), float(eps), int(groups), _p(ab), N, Cc, _stream())
+    _run("norm_finalize_groups", _nbytes(stats, ab), nat.lib().pytc_norm_finalize_groups_cpg, _p(stats), slots, float(count),
+         _p(gamma), _p(beta), float(eps), int(groups), int(cpg), _p(ab), None, N, Cc, _stream())
     return ab
 
 
@@ -1031,13 +1078,13 @@ def _i3(v):
 
 
 # ---- dense-conv (RSUNet) training ops ---------------------------------------------------------------------------------
-def norm_finalize_groups_mr(stats: torch.Tensor, count: float, gamma, beta, eps: float, groups: int):
-    """-> (ab (N,2,C), mean_rstd (N,2,C))"""
+def norm_finalize_groups_mr(stats: torch.Tensor, count: float, gamma, beta, eps: float, groups: int, cpg: int = 0):
+    """-> (ab (N,2,C), mean_rstd (N,2,C)); cpg as in norm_finalize_groups"""
     N, slots, _, Cc = stats.shape
     ab = torch.empty((N, 2, Cc), dtype=torch.float32, device=stats.device)
     mr = torch.empty((N, 2, Cc), dtype=torch.float32, device=stats.device)
-    _run("norm_finalize_groups", _nbytes(stats, ab, mr), nat.lib().pytc_norm_finalize_groups_mr, _p(stats), slots,
-         float(count), _p(gamma), _p(beta), float(eps), int(groups), _p(ab), _p(mr), N, Cc, _stream())
+    _run("norm_finalize_groups", _nbytes(stats, ab, mr), nat.lib().pytc_norm_finalize_groups_cpg, _p(stats), slots,
+         float(count), _p(gamma), _p(beta), float(eps), int(groups), int(cpg), _p(ab), _p(mr), N, Cc, _stream())
     return ab, mr
 
 

@@ -138,15 +138,25 @@ class _RSUNetHip:
     def __init__(self):
         self.cache = _WeightCache()
 
-    def _conv_w(self, conv: nn.Conv3d, dt):
+    def _conv_w(self, conv: nn.Conv3d, dt, pad_to=None):
+        """pad_to = (C_out, C_in) the conv runs with when its feature maps carry alignment padding (ops.pad_channels)."""
         w = conv.weight
-        return self.cache.get(("c3", id(conv), dt), [w],
-                              lambda: ops.conv3d_pack_weight(w.detach().float().contiguous(), dt))
+        if pad_to is not None and tuple(pad_to) == (conv.out_channels, conv.in_channels):
+            pad_to = None
+        if pad_to is None:
+            return self.cache.get(("c3", id(conv), dt), [w],
+                                  lambda: ops.conv3d_pack_weight(w.detach().float().contiguous(), dt))
+        return self.cache.get(("c3", id(conv), dt, tuple(pad_to)), [w],
+                              lambda: ops.conv3d_pack_weight_padded(w.detach().float().contiguous(), "fwd", dt, tuple(pad_to)))
 
-    def _vec(self, owner, name, p):
+    def _vec(self, owner, name, p, n: Optional[int] = None):
+        """fp32 copy of a per-channel parameter, zero-extended to n entries next to channel-padded activations."""
         if p is None:
             return None
-        return self.cache.get(("v", id(owner), name), [p], lambda: p.detach().float().reshape(-1).contiguous())
+        if n is None or n == p.numel():
+            return self.cache.get(("v", id(owner), name), [p], lambda: p.detach().float().reshape(-1).contiguous())
+        return self.cache.get(("v", id(owner), name, n), [p],
+                              lambda: torch.nn.functional.pad(p.detach().float().reshape(-1), (0, n - p.numel())).contiguous())
 
     def _act(self, na: NormAct):
         k = na.act_kind
@@ -173,18 +183,24 @@ class _RSUNetHip:
             def make():
                 a = m.weight.detach().float() / torch.sqrt(m.running_var.float() + m.eps)
                 b = m.bias.detach().float() - m.running_mean.float() * a
-                return torch.stack([a, b], 0).unsqueeze(0).expand(N, 2, C).contiguous()
-            return self.cache.get(("bn", id(m), N), [m.weight, m.bias, m.running_mean, m.running_var], make)
+                pad = (0, C - a.numel())          # channel-padded features: affine (0, 0) on the zero tail
+                return torch.stack([torch.nn.functional.pad(a, pad), torch.nn.functional.pad(b, pad)],
+                                   0).unsqueeze(0).expand(N, 2, C).contiguous()
+            return self.cache.get(("bn", id(m), N, C), [m.weight, m.bias, m.running_mean, m.running_var], make)
         st = ops.channel_stats(x)
         if na.kind == "group":
+            c_real = int(m.num_channels)
             return ops.norm_finalize_groups(st, rows, self._vec(m, "w", m.weight), self._vec(m, "b", m.bias), m.eps,
-                                            m.num_groups)
-        return ops.norm_finalize_groups(st, rows, None, None, m.eps, C)     # instance norm, no affine
+                                            m.num_groups, c_real // m.num_groups if c_real != C else 0)
+        return ops.norm_finalize_groups(st, rows, None, None, m.eps, C)     # instance norm, no affine (a zero tail stays zero)
 
-    def norm_act_conv(self, na: NormAct, conv: nn.Conv3d, x: torch.Tensor, res=None) -> torch.Tensor:
+    def norm_act_conv(self, na: NormAct, conv: nn.Conv3d, x: torch.Tensor, res=None, pad_out: bool = True) -> torch.Tensor:
+        """pad_out: the result is an internal feature map and travels with ops.pad_channels(C_out) channels (16-byte rows for every
+        kernel; the reference's stock widths 18 / 36 become 24 / 40, the extra channels exactly zero); heads pass False."""
         act, prm = self._act(na)
-        return ops.conv3d(x, self._conv_w(conv, x.dtype), c_out=conv.out_channels, kernel=conv.kernel_size,
-                          bias=self._vec(conv, "bias", conv.bias), ab=self.norm_affine(na, x), act_in=act,
+        co = ops.pad_channels(conv.out_channels, x.dtype) if pad_out else conv.out_channels
+        return ops.conv3d(x, self._conv_w(conv, x.dtype, (co, int(x.shape[-1]))), c_out=co, kernel=conv.kernel_size,
+                          bias=self._vec(conv, "bias", conv.bias, co), ab=self.norm_affine(na, x), act_in=act,
                           act_param=prm, res=res)
 
     def conv_block(self, blk: ConvBlock, x: torch.Tensor) -> torch.Tensor:
@@ -202,10 +218,14 @@ class _RSUNetHip:
 
     def up_block(self, blk: UpBlock, x: torch.Tensor, skip: torch.Tensor) -> torch.Tensor:
         up = blk.up
-        taps = self.cache.get(("up", id(up)), [up.weight],
-                              lambda: up.weight.detach().float().reshape(up.groups, -1).t().contiguous())
+        cp = int(x.shape[-1])
+        taps = self.cache.get(("up", id(up), cp), [up.weight],
+                              lambda: torch.nn.functional.pad(up.weight.detach().float().reshape(up.groups, -1).t(),
+                                                              (0, cp - up.groups)).contiguous())
         x = ops.dwconvT3d_generic(x, taps, up.kernel_size, up.factor, up.padding)
-        x = ops.conv3d(x, self._conv_w(blk.proj, x.dtype), c_out=blk.proj.out_channels, kernel=(1, 1, 1), res=skip)
+        co = ops.pad_channels(blk.proj.out_channels, x.dtype)
+        x = ops.conv3d(x, self._conv_w(blk.proj, x.dtype, (co, cp)), c_out=co, kernel=(1, 1, 1),
+                       bias=self._vec(blk.proj, "bias", blk.proj.bias, co), res=skip)
         return self.conv_block(blk.conv, x)
 
 
@@ -279,11 +299,12 @@ class RSUNet(ConnectomicsModel):
             if self.supports_deep_supervision and (self.depth - i - 1) < len(self.ds_heads):
                 ds_feats.append(x)
             x = hip.up_block(up, x, skips.pop())
-        out = {"output": hip.norm_act_conv(self.final_norm, self.output_head, x).float()}
+        out = {"output": hip.norm_act_conv(self.final_norm, self.output_head, x, pad_out=False).float()}
         if self.supports_deep_supervision:
             for i, (ft, head) in enumerate(zip(ds_feats, self.ds_heads)):
-                out[f"ds_{i + 1}"] = ops.conv3d(ft, hip._conv_w(head, ft.dtype), c_out=head.out_channels,
-                                                kernel=(1, 1, 1), bias=hip._vec(head, "bias", head.bias)).float()
+                out[f"ds_{i + 1}"] = ops.conv3d(ft, hip._conv_w(head, ft.dtype, (head.out_channels, int(ft.shape[-1]))),
+                                                c_out=head.out_channels, kernel=(1, 1, 1),
+                                                bias=hip._vec(head, "bias", head.bias)).float()
         return out
 
     def forward_cl(self, x_cl: torch.Tensor) -> torch.Tensor:

@@ -72,10 +72,20 @@ def prefetch_prelu(weights) -> None:
 BATCHED_CONV_PACKS = True
 
 
-def _packed(weight, layout: str, dtype):
+def _packed(weight, layout: str, dtype, pad_to=None):
+    """pad_to = (C_out, C_in) of the conv the image is FOR when that conv runs on channel-padded activations (ops.pad_channels)."""
     if BATCHED_CONV_PACKS:
-        return ops.CONV_PACKS.get(weight, layout, dtype)
-    return ops._conv_pack_single(weight.detach().float().contiguous(), layout, dtype)
+        return ops.CONV_PACKS.get(weight, layout, dtype, pad_to)
+    own = ops._conv_layout_rule(weight.shape, layout)[:2]
+    return ops._conv_pack_single(weight.detach().float().contiguous(), layout, dtype,
+                                 None if (pad_to is None or tuple(pad_to) == tuple(own)) else tuple(pad_to))
+
+
+def _padded_vec(v, n: int):
+    """fp32 vector `v` (or None) zero-extended to n entries: per-channel parameters next to channel-padded activations."""
+    if v is None or v.numel() == n:
+        return v
+    return torch.nn.functional.pad(v, (0, n - v.numel()))
 
 
 def refresh_conv_packs() -> None:
@@ -100,10 +110,13 @@ class NormActFn(torch.autograd.Function):
         prm = prelu_value(prelu_w) if act_kind == "prelu" else float(act_prm)
         ab = mr = None
         mode = kind
+        # x may carry alignment padding (ops.pad_channels): the norm's own channel count is its parameters'; the all-zero tail gets
+        # the affine (0, 0) and stays zero through the activation
+        c_real = int(gamma.numel()) if gamma is not None else (int(bn.num_features) if bn is not None else C)
         if kind in ("group", "instance"):
             st = ops.channel_stats(x)
-            g = groups if kind == "group" else C
-            ab, mr = ops.norm_finalize_groups_mr(st, rows, _f(gamma), _f(beta), eps, g)
+            g = groups if kind == "group" else c_real
+            ab, mr = ops.norm_finalize_groups_mr(st, rows, _f(gamma), _f(beta), eps, g, c_real // g if c_real != C else 0)
         elif kind == "batch":
             if bn.training and (not bn.track_running_stats or bn.momentum is not None):
                 # statistics pass, then ONE launch: batch affine for every sample, running-buffer blend, counter increment
@@ -117,19 +130,20 @@ class NormActFn(torch.autograd.Function):
             elif bn.training:          # momentum=None: cumulative moving average needs the counter's value on the host
                 st = ops.channel_stats(x)
                 st1 = st.reshape(1, st.shape[0] * st.shape[1], 2, C)
-                ab1, mr1 = ops.norm_finalize_groups_mr(st1, N * rows, _f(gamma), _f(beta), eps, C)
+                ab1, mr1 = ops.norm_finalize_groups_mr(st1, N * rows, _f(gamma), _f(beta), eps, c_real, 1 if c_real != C else 0)
                 ab, mr = ab1.expand(N, 2, C).contiguous(), mr1.expand(N, 2, C).contiguous()
                 if bn.track_running_stats:
                     with torch.no_grad():
                         bn.num_batches_tracked += 1
                         mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                        ops.bn_update_running(mr1, bn.running_mean, bn.running_var, float(N * rows), eps, mom)
+                        ops.bn_update_running(mr1 if c_real == C else mr1[:, :, :c_real].contiguous(), bn.running_mean,
+                                              bn.running_var, float(N * rows), eps, mom)
                         # written through raw pointers: bump the version counters the eval-mode affine cache keys on
                         torch.autograd.graph.increment_version([bn.running_mean, bn.running_var])
             else:
                 a = gamma.detach().float() / torch.sqrt(bn.running_var.float() + eps)
                 b = beta.detach().float() - bn.running_mean.float() * a
-                ab = torch.stack([a, b], 0).unsqueeze(0).expand(N, 2, C).contiguous()
+                ab = torch.stack([_padded_vec(a, C), _padded_vec(b, C)], 0).unsqueeze(0).expand(N, 2, C).contiguous()
                 mode = "batch_eval"
         out = ops.affine_act(x, ab, act, prm)
         ctx.save_for_backward(x, ab if ab is not None else x.new_zeros(0), mr if mr is not None else x.new_zeros(0),
@@ -145,15 +159,21 @@ class NormActFn(torch.autograd.Function):
         rows = _rows(x)
         ab_ = ab if ab.numel() else None
         da = da.contiguous()
+        # channel-padded activations: the group algebra sees the norm's own channels (cpg), kernels that index gamma per channel
+        # of x get it zero-extended, the parameter gradients are the leading c_real entries
+        c_real = int(gamma.numel()) if has_g else C
+        cpg = (c_real // groups) if (mode == "group" and c_real != C) else 0
+        g32 = _padded_vec(_f(gamma), C) if has_g else None
+        grp = 0 if mode == "batch" else (groups if mode == "group" else c_real)
+        if mode == "instance" and c_real != C:
+            cpg = 1
+        cast = lambda v, like: None if v is None else v[:like.numel()].to(like.dtype).reshape(like.shape)      # noqa: E731
         if FUSED_ACT_NORM_BWD and mode in ("group", "instance", "batch") and da.dtype == x.dtype and ops.act_norm_bwd_supported(x):
             # dt = da * act'(t) is recomputed from (da, x) inside the statistics pass and the apply pass: never stored
             s, p = ops.act_norm_bwd_stats(da, x, ab_, mr, act, prm, want_prelu=is_prelu)
             dprelu = p.sum().reshape(1) if is_prelu else None
-            g32 = _f(gamma) if has_g else None
-            grp = 0 if mode == "batch" else (groups if mode == "group" else C)
-            M, dgamma, dbeta = ops.norm_bwd_means(s, g32, grp, rows, want_gamma=has_g, want_beta=has_b)
+            M, dgamma, dbeta = ops.norm_bwd_means(s, g32, grp, rows, want_gamma=has_g, want_beta=has_b, cpg=cpg)
             dx = ops.act_norm_bwd_apply(da, x, ab_, mr, g32, M, act, prm)
-            cast = lambda v, like: None if v is None else v.to(like.dtype).reshape(like.shape)      # noqa: E731
             return (dx, cast(dgamma, gamma) if has_g else None, cast(dbeta, gamma) if has_b else None, dprelu, None, None, None,
                     None, None, None)
         dt, dp = ops.act_bwd(da, x, ab_, act, prm, want_prelu=is_prelu)
@@ -177,11 +197,8 @@ class NormActFn(torch.autograd.Function):
                                               "call model.train() or freeze the norm parameters")
         else:
             s = ops.norm_bwd_stats(dt, x, mr)                          # (N, 2, C): sum d, sum d*xhat
-            g32 = _f(gamma) if has_g else None
-            grp = 0 if mode == "batch" else (groups if mode == "group" else C)
-            M, dgamma, dbeta = ops.norm_bwd_means(s, g32, grp, rows, want_gamma=has_g, want_beta=has_b)
+            M, dgamma, dbeta = ops.norm_bwd_means(s, g32, grp, rows, want_gamma=has_g, want_beta=has_b, cpg=cpg)
             dx = ops.norm_bwd_apply_general(dt, x, mr, g32, M)
-        cast = lambda v, like: None if v is None else v.to(like.dtype).reshape(like.shape)
         return (dx, cast(dgamma, gamma) if has_g else None, cast(dbeta, gamma) if has_b else None, dprelu, None, None, None,
                 None, None, None)
 
@@ -190,10 +207,19 @@ class Conv3dFn(torch.autograd.Function):
     """y = conv3d(a, W) (+ bias) (+ res): stride 1, 'same' padding, channels-last."""
 
     @staticmethod
-    def forward(ctx, a, weight, bias, res):
+    def forward(ctx, a, weight, bias, res, pad_out=False):
+        """pad_out: the output is an internal feature map and is carried with ops.pad_channels(C_out) channels (all-zero tail: zero
+        weight rows, zero bias); the INPUT padding follows `a` (zero weight columns).  Both directions pack their images for the
+        padded channel counts; the gradients returned are the weight's own shape."""
         ks = tuple(int(k) for k in weight.shape[2:])
-        wp = _packed(weight, "fwd", a.dtype)
-        y = ops.conv3d(a, wp, c_out=weight.shape[0], kernel=ks, bias=_f(bias), res=res)
+        co, ci = int(weight.shape[0]), int(weight.shape[1])
+        ci_p = int(a.shape[-1])
+        co_p = ops.pad_channels(co, a.dtype) if pad_out else co
+        if ci_p < ci or (res is not None and int(res.shape[-1]) != co_p):
+            raise ValueError(f"Conv3dFn: input / residual channels ({ci_p}, {None if res is None else res.shape[-1]}) do not fit a "
+                             f"{ci} -> {co} conv (padded output {co_p})")
+        wp = _packed(weight, "fwd", a.dtype, (co_p, ci_p))
+        y = ops.conv3d(a, wp, c_out=co_p, kernel=ks, bias=_padded_vec(_f(bias), co_p), res=res)
         ctx.save_for_backward(a, weight)
         ctx.meta = (ks, bias is not None, res is not None)
         return y
@@ -205,23 +231,25 @@ class Conv3dFn(torch.autograd.Function):
         dy = dy.contiguous()
         if dy.dtype != a.dtype:
             dy = dy.to(a.dtype)
+        co_r, ci_r = int(weight.shape[0]), int(weight.shape[1])
+        ci, co = a.shape[-1], dy.shape[-1]                 # channel counts the conv ran with (>= the weight's)
         da = None
         if ctx.needs_input_grad[0]:
             # data gradient = the forward kernel on dY with the transposed, tap-mirrored weights (packed in one launch)
-            da = ops.conv3d(dy, _packed(weight, "dgrad", dy.dtype),
-                            c_out=weight.shape[1], kernel=ks)
-        ci, co = a.shape[-1], dy.shape[-1]
+            da = ops.conv3d(dy, _packed(weight, "dgrad", dy.dtype, (ci, co)), c_out=ci, kernel=ks)
         db = None
         if ks == (1, 1, 1) and a.dtype == torch.bfloat16 and ci % 16 == 0 and co % 16 == 0:
             # 1x1x1 projections: the pointwise MFMA weight-gradient kernel (also returns the bias gradient)
             dW2, db = ops.pw_wgrad(a, dy, N=a.shape[0], rows_per_sample=_rows(a), c_in=ci, c_out=co, want_bias=has_bias)
-            dW = dW2.view(co, ci, 1, 1, 1).to(weight.dtype)
-            db = db.to(weight.dtype) if has_bias else None
+            dW = dW2.view(co, ci, 1, 1, 1)
+            db = db[:co_r].to(weight.dtype) if has_bias else None
         else:
-            dW = ops.conv3d_wgrad(a, dy, ks).to(weight.dtype)
+            dW = ops.conv3d_wgrad(a, dy, ks)
             if has_bias:
-                db = ops.channel_stats(dy)[:, :, 0].sum((0, 1)).to(weight.dtype)
-        return da, dW, db, (dy if has_res else None)
+                db = ops.channel_stats(dy)[:, :, 0].sum((0, 1))[:co_r].to(weight.dtype)
+        if co != co_r or ci != ci_r:
+            dW = dW[:co_r, :ci_r]
+        return da, dW.to(weight.dtype).contiguous(), db, (dy if has_res else None), None
 
 
 class MaxPoolFn(torch.autograd.Function):
@@ -344,17 +372,19 @@ def _norm_act(na, x):
     return NormActFn.apply(x, gamma, beta, prelu_w, kind, groups, eps, na.act_kind, prm, m if kind == "batch" else None)
 
 
-def _nac(na, conv, x, res=None):
-    return Conv3dFn.apply(_norm_act(na, x), conv.weight, conv.bias, res)
+def _nac(na, conv, x, res=None, pad_out=True):
+    return Conv3dFn.apply(_norm_act(na, x), conv.weight, conv.bias, res, pad_out)
 
 
 def _conv_block(blk, x):
+    """Feature maps between the convs of RSUNet travel with ops.pad_channels(width) channels (16-byte rows for every kernel: the
+    reference's stock widths 18 / 36 are not multiples of 8); only the heads produce their own channel count."""
     x = _nac(blk.pre[0], blk.pre[1], x)
     r = blk.res
     a1 = _norm_act(r.norm_act1, x)
     # reference quirk: with norm='none' the in-place activation also rewrites the residual source (rsunet.py:103-113)
     res = a1 if (r.norm_act1.kind == "none" and r.norm_act1.act_kind != "prelu") else x
-    h = Conv3dFn.apply(a1, r.conv1.weight, r.conv1.bias, None)
+    h = Conv3dFn.apply(a1, r.conv1.weight, r.conv1.bias, None, True)
     x = _nac(r.norm_act2, r.conv2, h, res=res)
     return _nac(blk.post[0], blk.post[1], x)
 
@@ -374,13 +404,15 @@ def rsunet_train_forward(model, x_cl: torch.Tensor, compute_dtype: torch.dtype):
             ds_feats.append(x)
         u = up.up
         taps = u.weight.detach().float().reshape(u.groups, -1).t().contiguous()
+        if taps.shape[1] != x.shape[-1]:                      # fixed bilinear stencil per channel: any value serves the zero tail
+            taps = torch.nn.functional.pad(taps, (0, x.shape[-1] - taps.shape[1]))
         x = UpsampleFn.apply(x, taps, tuple(u.kernel_size), tuple(u.factor), tuple(u.padding))
-        x = Conv3dFn.apply(x, up.proj.weight, up.proj.bias, skips.pop())
+        x = Conv3dFn.apply(x, up.proj.weight, up.proj.bias, skips.pop(), True)
         x = _conv_block(up.conv, x)
-    out = {"output": _nac(model.final_norm, model.output_head, x).float()}
+    out = {"output": _nac(model.final_norm, model.output_head, x, pad_out=False).float()}
     if model.supports_deep_supervision:
         for i, (ft, head) in enumerate(zip(ds_feats, model.ds_heads)):
-            out[f"ds_{i + 1}"] = Conv3dFn.apply(ft, head.weight, head.bias, None).float()
+            out[f"ds_{i + 1}"] = Conv3dFn.apply(ft, head.weight, head.bias, None, False).float()
     return out
 
 

@@ -8,6 +8,7 @@ next to this script.  The fixtures are data; no reference source travels with th
 """
 from __future__ import annotations
 
+import os
 import sys
 from pathlib import Path
 
@@ -198,8 +199,18 @@ def rsunet_train():
         "aniso_inst_elu_ds": dict(width=[6, 8, 12], norm="instance", activation="elu", deep_supervision=True),
         "batch_prelu_2d": dict(width=[4, 8, 8], norm="batch", activation="prelu", depth_2d=1, init=0.1),
         "none_leaky": dict(width=[4, 8], norm="none", activation="leakyrelu", negative_slope=0.05),
+        # the reference's stock profile (config/profiles/arch_profiles.yaml:34-44): widths that are no multiple of 8 -> GroupNorm(3, 18),
+        # GroupNorm(4, 36), ...; and the same widths with BatchNorm (tutorials/syn_cremi.yaml overrides `norm: batch`)
+        # (two levels keep the fixture small; the full five-level profile is checked against the oracle at test time)
+        "stock_group_elu": dict(width=[18, 36], norm="group", num_groups=4, activation="elu",
+                                down_factors=[(1, 2, 2)], depth_2d=1, kernel_2d=(1, 3, 3)),
+        "stock_batch_elu": dict(width=[18, 36], norm="batch", num_groups=8, activation="elu",
+                                down_factors=[(1, 2, 2)], depth_2d=1, kernel_2d=(1, 3, 3)),
     }
+    only = os.environ.get("PYTC_GOLDEN_RSUNET_TRAIN")           # comma-separated config names: regenerate these only
     for name, kw in cfgs.items():
+        if only and name not in only.split(","):
+            continue
         torch.manual_seed(21)
         m = rsunet.RSUNet(1, 2, **kw).train()
         with torch.no_grad():

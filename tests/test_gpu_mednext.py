@@ -251,6 +251,7 @@ def test_fused_up_block_is_bit_identical_to_unfused(size, shape, monkeypatch):
             if n.endswith("norm.weight") or n.endswith("norm.bias") or n.endswith("conv1.bias") or n.endswith("res_conv.bias"):
                 p_.add_(0.2 * torch.randn_like(p_))
         x = torch.randn(2, *shape, 1, device="cuda")
+        m._hip.fold_norm = False          # the fused up kernel applies the affine itself: compare like with like
         m._hip.fuse_up = False
         ref = m.forward_cl(x)
         m._hip.fuse_up = True
@@ -258,6 +259,23 @@ def test_fused_up_block_is_bit_identical_to_unfused(size, shape, monkeypatch):
         assert torch.equal(got, ref)
         m._hip.fuse_up_cin = (64,)            # level 0 only
         assert torch.equal(m.forward_cl(x), ref)
+
+
+def test_norm_folded_mixers_stay_within_the_affine_form_of_the_oracle_error(dev):
+    """HipBlockOps.fold_norm (round 4, default): GroupNorm's affine inside per-sample expand weights instead of the mixer prologue.
+    Same arithmetic, one rounding moved (weight instead of normalised activation): against the fp32 path of the same weights the
+    folded bf16 forward is no further away than the affine-prologue form (10 % slack), at every level a MedNeXt-S forward has."""
+    m, _ = _build(dev, n_channels=32, exp_r=2, kernel_size=3, block_counts=[2] * 9, ds=False)
+    x = torch.rand(2, 32, 48, 48, 1, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    with torch.no_grad():
+        m.compute_dtype = torch.float32
+        ref = m.forward_cl(x).float()
+        m.compute_dtype = torch.bfloat16
+        errs = {}
+        for fold in (False, True):
+            m._hip.fold_norm = fold
+            errs[fold] = float((m.forward_cl(x).float() - ref).abs().mean())
+    assert errs[True] <= 1.10 * errs[False] + 1e-6, errs
 
 
 @pytest.mark.parametrize("counts,ds", [([2] * 9, False), ([1, 2, 1, 1, 1, 1, 1, 2, 1], True), ([1] * 9, False)])

@@ -115,6 +115,12 @@ CFGS = {
     "aniso_inst_elu_ds": dict(width=[6, 8, 12], norm="instance", activation="elu", deep_supervision=True),
     "batch_prelu_2d": dict(width=[4, 8, 8], norm="batch", activation="prelu", depth_2d=1, init=0.1),
     "none_leaky": dict(width=[4, 8], norm="none", activation="leakyrelu", negative_slope=0.05),
+    # the reference's stock widths (arch_profiles.yaml:34-44) are no multiples of 8: the HIP path carries them as 24 / 40 channels
+    # (fp32: 20 / 36) with an all-zero tail -- GroupNorm(3, 18) / (4, 36) on the real channels, BatchNorm as tutorials/syn_cremi.yaml
+    "stock_group_elu": dict(width=[18, 36], norm="group", num_groups=4, activation="elu", down_factors=[(1, 2, 2)], depth_2d=1,
+                            kernel_2d=(1, 3, 3)),
+    "stock_batch_elu": dict(width=[18, 36], norm="batch", num_groups=8, activation="elu", down_factors=[(1, 2, 2)], depth_2d=1,
+                            kernel_2d=(1, 3, 3)),
 }
 
 
@@ -245,7 +251,13 @@ def test_minimal_rsunet_tutorial_train_then_infer(tmp_path):
                                             (32, 16, (5, 3, 3), (6, 3, 33)), (1, 16, (3, 3, 3), (3, 5, 37)),
                                             (16, 3, (1, 1, 1), (3, 5, 37)), (32, 12, (1, 1, 1), (2, 3, 64)),
                                             (2, 32, (1, 3, 3), (2, 6, 31)), (3, 5, (3, 3, 3), (3, 4, 20)),
-                                            (48, 16, (1, 1, 1), (2, 5, 33))])
+                                            (48, 16, (1, 1, 1), (2, 5, 33)),
+                                            # channel counts that are multiples of 8 but not of the 16-wide tile (round 4: the
+                                            # stock RSUNet widths padded to 24 / 40): partly filled last tiles on either side
+                                            (24, 24, (1, 3, 3), (2, 6, 40)), (40, 40, (3, 3, 3), (3, 4, 33)),
+                                            (24, 40, (3, 3, 3), (3, 5, 20)), (40, 24, (1, 1, 1), (2, 5, 33)),
+                                            (48, 40, (1, 1, 1), (2, 3, 64)), (1, 24, (1, 3, 3), (2, 6, 31)),
+                                            (24, 1, (1, 1, 1), (2, 6, 31)), (72, 8, (3, 3, 3), (2, 3, 32))])
 def test_conv3d_wgrad_mfma_bf16(ci, co, ks, shape):
     """bf16 weight gradient on MFMA (LDS transpose reads) vs fp32 autograd on the same bf16-rounded operands, and
     vs the VALU kernel (tuning knob) on identical inputs."""
@@ -452,3 +464,58 @@ def test_batched_conv_weight_packs_are_bit_identical_to_the_single_packs():
     gc.collect()
     packs.refresh()
     assert not packs.rows                                # rows of dropped weights go away
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stock_rsunet_profile_forward_and_training_step_against_the_oracle(dtype):
+    """RSUNet exactly as config/profiles/arch_profiles.yaml:34-44 ships it (width [18, 36, 48, 64, 80],
+    GroupNorm(4) -> GroupNorm(3, 18) on the first level, ELU, down (1,2,2) x 4, depth_2d 1) at 18 x 64 x 64: inference forward and
+    one training step (loss, every parameter gradient) against autograd through the oracle (rsunet_oracle == the reference,
+    tests/test_oracle_golden.py).  The HIP path runs the two widths that are no multiple of 8 with zero-padded channels (24 / 40 in
+    bf16, 20 / 36 in fp32) so that every kernel takes its 16-byte form -- state_dict shapes, outputs and gradients are the
+    reference's.  fp32: tight; bf16: the direction of the whole gradient and the output error against the fp32 oracle."""
+    from oracle import rsunet_oracle as RO
+    from pytorch_connectomics_amd.models.architectures.rsunet import RSUNet
+    kw = dict(width=[18, 36, 48, 64, 80], norm="group", num_groups=4, activation="elu", down_factors=[(1, 2, 2)] * 4, depth_2d=1,
+              kernel_2d=(1, 3, 3))
+    torch.manual_seed(5)
+    m = RSUNet(1, 1, **kw).train()
+    gn = [mod for mod in m.modules() if isinstance(mod, torch.nn.GroupNorm)]
+    assert {(g.num_groups, g.num_channels) for g in gn} >= {(3, 18), (4, 36), (4, 48), (4, 64), (4, 80)}
+    with torch.no_grad():
+        for mod in gn:
+            mod.weight.uniform_(0.7, 1.3)
+            mod.bias.normal_(0, 0.2)
+    x = torch.rand(2, 1, 18, 64, 64, generator=torch.Generator().manual_seed(6))
+    tgt = (torch.rand(2, 1, 18, 64, 64, generator=torch.Generator().manual_seed(7)) > 0.8).float()
+    params = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in m.state_dict().items()}
+    ref = RO.forward(params, x.clone(), bn_training=True, **kw)
+    ref_loss = F.binary_cross_entropy_with_logits(ref, tgt)
+    ref_loss.backward()
+    mg = m.cuda()
+    mg.compute_dtype = dtype
+    out = mg(x.cuda())
+    assert tuple(out.shape) == (2, 1, 18, 64, 64)
+    loss = F.binary_cross_entropy_with_logits(out.float(), tgt.cuda())
+    loss.backward()
+    for n, p in mg.named_parameters():
+        assert p.grad is not None and tuple(p.grad.shape) == tuple(params[n].shape), n
+    g = torch.cat([p.grad.flatten().double().cpu() for _n, p in mg.named_parameters()])
+    r = torch.cat([params[n].grad.flatten().double() for n, _p in mg.named_parameters()])
+    cos = float((g * r).sum() / (g.norm() * r.norm()))
+    err_out = float((out.detach().float().cpu() - ref.detach()).abs().max())
+    if dtype == torch.float32:
+        assert abs(float(loss) - float(ref_loss)) < 1e-4 and err_out < 2e-3, (float(loss), float(ref_loss), err_out)
+        _check_grads([(n, p.grad.cpu()) for n, p in mg.named_parameters()], lambda n: params[n].grad, False)
+    else:
+        assert abs(float(loss) - float(ref_loss)) < 2e-2 and cos > 0.97, (float(loss), float(ref_loss), cos)
+    mg.eval()
+    with torch.no_grad():
+        y = mg(x.cuda())
+        want = RO.forward({k: v.detach() for k, v in params.items()}, x.clone(), **kw)
+    d = (y.float().cpu() - want).abs()
+    if dtype == torch.float32:
+        assert float(d.max()) < 2e-3
+    else:       # bf16 storage through ~45 conv layers: judged against the spread of the logits, mean and worst voxel
+        assert float(d.mean()) < 2e-2 * float(want.std()) and float(d.max()) < 0.12 * float(want.abs().max()), \
+            (float(d.mean()), float(d.max()), float(want.std()), float(want.abs().max()))
