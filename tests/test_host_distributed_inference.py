@@ -199,6 +199,40 @@ def test_window_sharding_world2():
     mp.spawn(_window_worker, args=(2, _free_port()), nprocs=2, join=True)
 
 
+def _window_worker_world8(rank, world, port):
+    """The reference's window sharding ([rank::world] + reduce to rank 0, lazy.py:1104, lazy_distributed.py:78-107) at the rank count
+    of the target node, on the Lucchi++ window grid scaled to roi 8^3: 2 x 18 x 13 = 468 windows, 58 or 59 per rank."""
+    _init(rank, world, port)
+    lazy, _ = _patch_ops()
+    vol = np.random.default_rng(8).random((1, 12, 76, 56), dtype=np.float32)
+    roi = (8, 8, 8)
+    seen = []
+
+    def net(x):
+        seen.append(int(x.shape[0]))
+        return _net(x)
+
+    out = lazy.lazy_predict_volume(_lazy_cfg(roi), net, vol, device="cpu")
+    mine = torch.tensor([sum(seen)])
+    counts = [torch.zeros(1, dtype=torch.long) for _ in range(world)]
+    torch.distributed.all_gather(counts, mine)
+    total = int(sum(int(c) for c in counts))
+    # the lazy grid (reference lazy.py:104-214: its own stride / edge rule) has more windows than the eager 468; whatever their number,
+    # the shards are the interleaved partition [rank::world] of it: every window predicted exactly once
+    assert [int(c) for c in counts] == [len(range(total)[r::world]) for r in range(world)] and total >= 468
+    if rank == 0:
+        want = WO.lazy_sliding_window(vol, _net, roi=roi, overlap=0.5, mode="bump", sw_batch_size=2, padding_mode="constant")
+        assert tuple(out.shape) == (1, 3, 12, 76, 56)
+        assert torch.allclose(out, want, rtol=1e-5, atol=1e-5), float((out - want).abs().max())
+    else:
+        assert out.numel() == 0
+    torch.distributed.destroy_process_group()
+
+
+def test_window_sharding_world8_on_the_lucchi_window_grid():
+    mp.spawn(_window_worker_world8, args=(8, _free_port()), nprocs=8, join=True)
+
+
 # --------------------------------------------------------------------------------------------------- view sharding
 def _tta_cfg(mode, *, sharded, flips="all"):
     return NS(model=NS(primary_head=None, heads=None, out_channels=3),

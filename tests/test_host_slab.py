@@ -84,9 +84,16 @@ def _worker(rank, world, port, img, roi, tmp):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("img,world", [((20, 30, 34), 2), ((14, 22, 50), 3)])
-def test_slab_exchange_over_gloo_matches_single_process(img, world, tmp_path):
-    roi = (8, 12, 12)
+# (12, 76, 56) at roi 8^3 / overlap 0.5 has the window grid of the Lucchi++ volume at roi 112^3: 2 x 18 x 13 = 468 windows -- at world 8 the
+# 18 window rows along y fall into uneven slabs (2 / 3 rows), the split the 8-GPU strong-scaling leg of bench.py runs
+@pytest.mark.parametrize("img,world,roi", [((20, 30, 34), 2, (8, 12, 12)), ((14, 22, 50), 3, (8, 12, 12)), ((12, 76, 56), 8, (8, 8, 8))])
+def test_slab_exchange_over_gloo_matches_single_process(img, world, roi, tmp_path):
+    if world == 8:
+        starts = WO.window_starts(img, roi, WO.scan_interval(img, roi, 0.5))
+        assert len(starts) == 468 and len({s[1] for s in starts}) == 18 and len({s[2] for s in starts}) == 13
+        plan = plan_slabs(img, roi, starts, world)
+        per_rank = [len(plan.windows_of(r)) for r in range(world)]
+        assert plan.axis == 1 and sum(per_rank) == 468 and sorted(set(per_rank)) == [52, 78]      # 2 and 3 window rows of 26
     mp.spawn(_worker, args=(world, 29500 + (os.getpid() * 7 + world) % 2000, img, roi, str(tmp_path)), nprocs=world, join=True)
     meta = np.load(tmp_path / "axis.npy")
     ax = int(meta[0])
