@@ -362,6 +362,84 @@ def train_leg(dev, rank, world, args, barrier):
             "final_loss": float(loss.detach()), "roofline": roof}
 
 
+def c3_affinity_tta16_leg(dev, model3):
+    """BASELINE configs[2]'s inference (tutorials/neuron_snemi/neuron_snemi.yaml:72-90): MedNeXt-S with a 3-channel nearest-neighbour
+    affinity output (affinity_mode deepem), 16 test-time views (8 flips x yx quarter turn), affinity-aware -- every view's channels are
+    moved and re-anchored to the canonical frame -- ensemble_mode `min`, patch-first-local through InferenceManager, bf16, over a
+    165 x 448 x 448 volume at roi 112^3 / overlap 0.5 / sw 8 (the SNEMI volume is 100 x 1024 x 1024; its own window 32 x 160 x 160 is a
+    different config of the same engine)."""
+    from pytorch_connectomics_amd.inference import InferenceManager
+    vol_shape = (165, 448, 448)
+    cfg = infer_cfg(True)
+    cfg.model.out_channels = 3
+    tta = cfg.inference.test_time_augmentation
+    tta.rotation90_axes, tta.ensemble_mode = [[1, 2]], "min"
+    cfg.data.label_transform = NS(stack_outputs=True, targets=[{"name": "affinity", "kwargs": {
+        "offsets": ["1-0-0", "0-1-0", "0-0-1"], "affinity_mode": "deepem"}}])
+    vol = torch.rand((1, 1) + vol_shape, device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+    mgr = InferenceManager(cfg, model3, model3.forward)
+    with torch.no_grad():
+        mgr.predict_with_tta(vol[:, :, :112, :224, :224].contiguous())          # warm-up: weight images, allocator pools
+        s, out = timed(lambda: mgr.predict_with_tta(vol))
+    _, starts = make_engine().plan(vol_shape)
+    rec = job_record(len(starts), 16, vol_shape, s, path="InferenceManager.predict_with_tta: 8 flips x yx rot90 = 16 views, affinity-aware "
+                     "(deepem offsets 1-0-0 / 0-1-0 / 0-0-1), ensemble min, sigmoid per view, fp32 out", out_channels=int(out.shape[1]))
+    del out, vol
+    torch.cuda.empty_cache()
+    return rec
+
+
+def c4_chunked_leg(dev):
+    """BASELINE configs[3] (MitoEM-R): MedNeXt-L k3 with the three MitoEM heads (7 channels), roi 160^3, overlap 0.5, reflect padding,
+    chunked sliding-window inference with chunk 320^3 and halo 80 -- the per-rank work of the 8-GPU job (640^3 = 8 chunks, one per rank,
+    chunked.py:471: idx % world == rank) measured on ONE GPU over a 320 x 320 x 640 volume = 2 chunks: region read (host array ->
+    pinned -> HBM), every window of the haloed region through the lazy engine in bf16, stitched crop written as chunk_{key} files."""
+    import tempfile
+    from pytorch_connectomics_amd.inference.chunked import run_chunked_prediction_inference
+    from pytorch_connectomics_amd.models import build_model as bm
+    heads = {"aff_r1": {"out_channels": 3, "num_blocks": 1, "hidden_channels": 8},
+             "aff_r5": {"out_channels": 3, "num_blocks": 1, "hidden_channels": 8},
+             "sdt": {"out_channels": 1, "num_blocks": 1, "hidden_channels": 8}}
+    mcfg = NS(model=NS(arch=NS(type="mednext"), in_channels=1, out_channels=7, mednext=NS(size="L", kernel_size=3),
+                       loss=NS(deep_supervision=False), heads=heads, primary_head="aff_r1"))
+    torch.manual_seed(0)
+    model = bm(mcfg).to(dev).eval()
+    model.model.compute_dtype = torch.bfloat16
+    roi, chunk, halo = (160, 160, 160), (320, 320, 320), (80, 80, 80)
+    cfg = NS(model=NS(primary_head=None, heads=None, out_channels=7, output_size=list(roi)), system=NS(num_workers=0),
+             data=NS(train=NS(do_2d=False), val=NS(do_2d=False), dataloader=NS(batch_size=1)),
+             inference=NS(sliding_window=NS(window_size=list(roi), sw_batch_size=2, overlap=0.5, blending="bump", padding_mode="reflect",
+                                            cval=0.0, border_mask=[], distributed_sharding=False, snap_to_edge=False, target_context=[]),
+                          model=NS(head=None, select_channel=None, output_dtype=None,
+                                   channel_activations=[{"channels": ":", "activation": "sigmoid"}]),
+                          chunking=NS(enabled=True, chunk_size=list(chunk), halo=list(halo), axes="all", shard_id=None, num_shards=None),
+                          test_time_augmentation=NS(enabled=False)))
+    vol_shape = (320, 320, 640)
+    vol = torch.rand((1,) + vol_shape, generator=torch.Generator().manual_seed(17)).numpy()
+    windows = []
+    fwd_cl = model.forward_cl
+
+    def counting_forward_cl(x_cl):          # the lazy engine takes the bound model's channels-last path (merged heads: 7 channels)
+        windows.append(int(x_cl.shape[0]))
+        return fwd_cl(x_cl)
+    model.forward_cl = counting_forward_cl
+
+    with tempfile.TemporaryDirectory(prefix="pytc_c4_") as tmp, torch.no_grad():
+        fwd_cl(torch.rand(1, *roi, 1, device=dev))                              # warm-up: weight images, allocator pools
+        s, out = timed(lambda: run_chunked_prediction_inference(cfg, model.forward, vol, output_path=os.path.join(tmp, "pred"),
+                                                                device="cuda"))
+        shape = tuple(out.shape)
+    n_win = sum(windows)
+    rec = {"seconds": s, "chunks": 2, "seconds_per_chunk": s / 2, "windows": n_win, "roi": list(roi), "volume": list(vol_shape),
+           "window_voxels_per_s": n_win * roi[0] * roi[1] * roi[2] / s,
+           "output_voxels_per_s": vol_shape[0] * vol_shape[1] * vol_shape[2] / s, "output_shape": list(shape),
+           "path": "run_chunked_prediction_inference: MedNeXt-L k3 + 3 MitoEM heads (7 ch), bf16, chunk 320^3 / halo 80, reflect padding, "
+                   "sw 2, chunk files written (host volume -> pinned -> HBM reads included)"}
+    del model, out
+    torch.cuda.empty_cache()
+    return rec
+
+
 def _unet_leg(dev, args, make, label, patch, batch, out_ch):
     from pytorch_connectomics_amd import hip_ops as ops
     from pytorch_connectomics_amd.training.fused import FusedAdamW, bce_dice_loss
@@ -474,6 +552,12 @@ def _kernel_key(label):
     m = re.match(r"pw_mlp_fwd\[(\d+)->(\d+)->(\d+)\]", label)
     if m:
         return f"pw_mlp_kernel<{int(m.group(1)) // 32}, {int(m.group(3)) // 16},"
+    # one template INSTANCE of the fused mixer = one rocprof symbol (hip_ops gives every launch its instance: plain, +head, +stemres):
+    # <KS_IN, MO, NT, GELU_MODE, HEAD, STEMRES, STOREH, BWD>
+    m = re.match(r"pw_mlp_kernel<(\d+), (\d+)>(\+head|\+stemres)?$", label)
+    if m:
+        flags = {None: "false, false", "+head": "true, false", "+stemres": "false, true"}[m.group(3)]
+        return re.compile(rf"pw_mlp_kernel<{m.group(1)}, {m.group(2)}, \d+, \d+, {flags}, false, false>")
     if "[" not in label and label.endswith("_kernel"):
         return label
     return None
@@ -484,8 +568,9 @@ def _traffic_from_table(table, key):
     if not table or key is None:
         return None
     tot = n = 0.0
+    hit = (lambda k: key.search(k) is not None) if hasattr(key, "search") else (lambda k: key in k)
     for kernel, (launches, fetch_kb, write_kb) in table.items():
-        if key in kernel:
+        if hit(kernel):
             tot += launches * (2 * fetch_kb + write_kb) * 1024
             n += launches
     return int(tot / n) if n else None
@@ -789,6 +874,13 @@ def main():
             finally:
                 model.model.compute_dtype = torch.bfloat16
         torch.cuda.empty_cache()
+        for name, leg in (("c3_affinity_tta16_min", lambda: c3_affinity_tta16_leg(dev, build_model(dev, out_channels=3))),
+                          ("c4_mednext_l_160_chunked", lambda: c4_chunked_leg(dev))):
+            try:       # BASELINE configs[2] / configs[3] inference at their real windows
+                extras[name] = leg()
+            except Exception as e:     # noqa: BLE001
+                extras[name] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
 
     del vol
     torch.cuda.empty_cache()

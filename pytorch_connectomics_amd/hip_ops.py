@@ -623,7 +623,8 @@ def pw_mlp(t: torch.Tensor, ab: Optional[torch.Tensor], w2p: torch.Tensor, b2: t
         _run(f"pw_mlp_train_fwd[{c_in}->{c_hid}->{c_out}]", nb + N * rows_per_sample * 2 * c_hid, nat.lib().pytc_pw_mlp_train_fwd,
              C.byref(a), _p(hidden_pre), _stream())
         return y
-    _run(f"pw_mlp_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_fwd, C.byref(a), _stream())
+    _run(f"pw_mlp_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_fwd, C.byref(a), _stream(),
+         symbol=f"pw_mlp_kernel<{c_in // 32}, {c_out // 16}>")
     return y
 
 
@@ -717,7 +718,7 @@ def pw_mlp_stemres(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: tor
     a.Di = a.Hi = a.Wi = 0
     nb = N * rows_per_sample * (2 * (c_in + c_out) + 4)
     _run(f"pw_mlp_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_stemres_fwd, C.byref(a), _p(x0), _p(stem_w),
-         _p(stem_b), _stream())
+         _p(stem_b), _stream(), symbol=f"pw_mlp_kernel<{c_in // 32}, {c_out // 16}>+stemres")
     return y
 
 
@@ -795,7 +796,7 @@ def pw_mlp_head(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.
     nb = N * rows_per_sample * (2 * (c_in + (c_out if res is not None else 0) + (c_out if store_y else 0)) + 4 * n_head)
     # same kernel template and GEMM shape as pw_mlp (HEAD flag): one label, each launch with its own byte count
     _run(f"pw_mlp_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_head_fwd, C.byref(a), _p(head_w),
-         _p(head_b), _p(logits), n_head, int(store_y), _stream())
+         _p(head_b), _p(logits), n_head, int(store_y), _stream(), symbol=f"pw_mlp_kernel<{c_in // 32}, {c_out // 16}>+head")
     return y, logits
 
 

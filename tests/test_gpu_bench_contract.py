@@ -44,7 +44,7 @@ def test_single_gpu_line_has_every_contract_field():
     # profiler, the committed passes); a fused mixer moves its algorithmic bytes, not more
     assert roof["traffic_source"].startswith(("live", "committed"))
     # `roofline` is the largest rocprof SYMBOL of the step, the largest per-shape label rides as `by_label`
-    assert roof["kernel"].endswith("_kernel") and roof["kernel"] == roof["by_symbol"][0]["kernel"]
+    assert "_kernel" in roof["kernel"] and roof["kernel"] == roof["by_symbol"][0]["kernel"]
     lab = roof["by_label"]
     if roof["traffic_source"].startswith("live") and lab.get("traffic"):
         assert 0.7 * lab["algorithmic_bytes"] < lab["traffic"] < 1.3 * lab["algorithmic_bytes"]      # a fused mixer re-reads nothing
