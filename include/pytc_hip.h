@@ -319,6 +319,18 @@ typedef struct {
 #define PYTC_W3_BF16 0
 #define PYTC_W3_F16 1
 
+/* Deep levels (round 4): the two 1x1x1 convs of a MedNeXt block as two LDS-tiled MFMA GEMM launches instead of the fused mixer, for
+ * batches of fewer than ~30 k voxel rows (levels 3-4 of an 8-window batch), where the fused kernel's per-wave hidden loop leaves most
+ * SIMDs idle.  y[r][o] = epi(sum_k f(x[r][k]) * w[o][k] + bias[o]): x [N * rows][C_in] bf16 (in_f16 = 0, optional GroupNorm affine
+ * ab [N][2][C_in]) or fp16 (in_f16 = 1), w [C_out][C_in] ROW-MAJOR in the same 16-bit type (the conv weight as PyTorch stores it,
+ * cast; no packed image), gelu_out = 1: y fp16 = packed-fp16 GELU of the accumulator (the hidden tensor), gelu_out = 0: y bf16 with
+ * res / res_low / res_bias / res_mode / (Di, Hi, Wi) as pytc_pw_mlp_fwd.  A block computed as gemm(gelu_out = 1) -> gemm(in_f16 = 1)
+ * is bit-identical to pytc_pw_mlp_fwd with w3_format = PYTC_W3_F16.  C_in % 64 == 0, C_out % 128 == 0.  Replaces conv2 / act / conv3 of
+ * the external nnunet_mednext block (contract at mednext_models.py:99-126). */
+int pytc_pw_gemm_supported(int C_in, int C_out);
+int pytc_pw_gemm_fwd(const void* x, const void* w, const float* bias, const float* ab, void* y, int N, int64_t rows_per_sample,
+                     int C_in, int C_out, int in_f16, int gelu_out, const void* res, const void* res_low, const float* res_bias,
+                     int res_mode, int Di, int Hi, int Wi, void* stream);
 int pytc_pw_mlp_supported(int C_in, int C_hid, int C_out);
 int pytc_pw_pack_weight_paired(const float* w, int C_out, int C_in, int transposed, void* packed_bf16,
                                void* stream);

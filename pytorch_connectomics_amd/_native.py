@@ -95,6 +95,10 @@ _SIGS = {
                                           C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pytc_groupnorm_fold_mlp": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_pw_gemm_supported": (C.c_int, [C.c_int, C.c_int]),
+    "pytc_pw_gemm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p]),
     "pytc_pw_packed_elems": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "pytc_pw_pack_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "pytc_blend_accumulate_mapped": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int,

@@ -628,6 +628,33 @@ def pw_mlp(t: torch.Tensor, ab: Optional[torch.Tensor], w2p: torch.Tensor, b2: t
     return y
 
 
+def pw_gemm_supported(c_in: int, c_out: int) -> bool:
+    return bool(nat.lib().pytc_pw_gemm_supported(int(c_in), int(c_out)))
+
+
+def pw_gemm(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, *, N: int, rows_per_sample: int, ab: Optional[torch.Tensor] = None,
+            gelu: bool = False, res: Optional[torch.Tensor] = None, res_mode: int = nat.RES_NONE, grid: Sequence[int] = (0, 0, 0),
+            res_low: Optional[torch.Tensor] = None, res_bias: Optional[torch.Tensor] = None,
+            y: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One 1x1x1 conv of a deep-level block as an LDS-tiled MFMA GEMM (pytc_pw_gemm_fwd): x (N, rows, C_in) bf16 [+ GroupNorm affine
+    ab] or fp16, w (C_out, C_in) row-major in x's dtype -> (N, rows, C_out): fp16 = GELU(acc) when `gelu`, else bf16 with the residual
+    epilogue of pw_mlp."""
+    _dev(x, "x"); _dev(w, "w")
+    c_out, c_in = int(w.shape[0]), int(w.shape[1])
+    if x.dtype not in (torch.bfloat16, torch.float16) or w.dtype != x.dtype or not w.is_contiguous() or int(x.shape[-1]) != c_in:
+        raise TypeError(f"pw_gemm: x {tuple(x.shape)} {x.dtype} / w {tuple(w.shape)} {w.dtype}: same 16-bit type, w (C_out, C_in) contiguous")
+    out_dt = torch.float16 if gelu else torch.bfloat16
+    if y is None:
+        y = torch.empty((N, rows_per_sample, c_out), dtype=out_dt, device=x.device)
+    else:
+        _check_out(y, N * rows_per_sample * c_out, out_dt, "pw_gemm")
+    nb = N * rows_per_sample * 2 * (c_in + c_out + (c_out if res is not None else 0)) + 2 * c_in * c_out
+    _run(f"pw_gemm[{c_in}->{c_out}]", nb, nat.lib().pytc_pw_gemm_fwd, _p(x), _p(w), _p(bias), _p(ab), _p(y), N, rows_per_sample, c_in,
+         c_out, int(x.dtype == torch.float16), int(gelu), _p(res), _p(res_low), _p(res_bias), int(res_mode), *(int(v) for v in grid),
+         _stream(), flops=2 * N * rows_per_sample * c_in * c_out, symbol="pw_gemm_lds_kernel")
+    return y
+
+
 def pw_mlp_up_supported(c_in: int, c_hid: int, c_out: int) -> bool:
     return bool(nat.lib().pytc_pw_mlp_up_supported(int(c_in), int(c_hid), int(c_out)))
 

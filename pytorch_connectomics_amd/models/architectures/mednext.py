@@ -177,6 +177,10 @@ class HipBlockOps:
         # the place of groupnorm_finalize), the mixer loads its operand raw.  Round 4: the mixers are bound by VALU issue and the
         # affine (unpack + fma + repack per element) was ~13 % of their instructions.  PYTC_FOLD_NORM=0 restores the affine prologue.
         self.fold_norm = os.environ.get("PYTC_FOLD_NORM", "1") != "0"
+        # bf16 blocks of batches with at most this many voxel rows (levels 3-4 of an 8-window batch: 21 952 / 2 744 rows) run their
+        # two 1x1x1 convs as two LDS-tiled GEMM launches (ops.pw_gemm) instead of the fused mixer: bit-identical, and the deep levels
+        # stop leaving most SIMDs idle.  0 switches the path off.
+        self.deep_gemm_rows = int(os.environ.get("PYTC_DEEP_GEMM_ROWS", "32768"))
 
     # ---- parameter repacking (load time / after optimizer steps) -----------------------------
     def _taps(self, conv: nn.Module):
@@ -336,6 +340,11 @@ class HipBlockOps:
                  and ops.pw_conv_paired_supported(c_in=C, c_out=c_hid, in_dtype=dt, out_dtype=dt)
                  and ops.pw_conv_paired_supported(c_in=c_hid, c_out=c_out, in_dtype=dt, out_dtype=dt))
         if (not small and self.fused and dt == torch.bfloat16 and not m.grn and not is_ln and m.conv2.bias is not None
+                and m.conv3.bias is not None and head is None and ops.MLP_F16_PROJECT and N * rows <= self.deep_gemm_rows
+                and ops.pw_gemm_supported(C, c_hid) and ops.pw_gemm_supported(c_hid, c_out)):
+            ab = ops.groupnorm_finalize(st, count, gamma, beta, m.norm.eps)
+            return self._block_deep_gemm(m, x, t, ab, skip, (N, D, H, W, C), (Do, Ho, Wo), c_hid, c_out, out)
+        if (not small and self.fused and dt == torch.bfloat16 and not m.grn and not is_ln and m.conv2.bias is not None
                 and m.conv3.bias is not None and ops.pw_mlp_supported(C, c_hid, c_out)):
             ab, w2x, b2x = self._fold(m, st, count, C, c_hid)
             if (head is not None and kind == "block" and head.weight.shape[1] <= 16
@@ -460,6 +469,44 @@ def _block_fused(self, m, x, t, ab, skip, ishape, oshape, c_hid, c_out, out=None
     return y.view(N, Do, Ho, Wo, c_out)
 
 
+def _block_deep_gemm(self, m, x, t, ab, skip, ishape, oshape, c_hid, c_out, out=None):
+    """Deep-level schedule: expand (+ GroupNorm affine, GELU, fp16 hidden) and project (+ residual epilogue) as two GEMM launches."""
+    N, D, H, W, C = ishape
+    Do, Ho, Wo = oshape
+    rows = Do * Ho * Wo
+    dt = torch.bfloat16
+    w2 = self.cache.get(("gw2", id(m.conv2)), [m.conv2.weight],
+                        lambda: m.conv2.weight.detach().float().reshape(c_hid, C).to(torch.bfloat16).contiguous())
+    w3 = self.cache.get(("gw3", id(m.conv3)), [m.conv3.weight],
+                        lambda: m.conv3.weight.detach().float().reshape(c_out, c_hid).to(torch.float16).contiguous())
+    b2, b3 = self._vec(m.conv2, "bias", m.conv2.bias), self._vec(m.conv3, "bias", m.conv3.bias)
+    h = ops.pw_gemm(t.view(N, rows, C), w2, b2, N=N, rows_per_sample=rows, ab=ab, gelu=True)
+    kw = dict(N=N, rows_per_sample=rows)
+    if out is not None:
+        kw["y"] = out.view(N, rows, c_out)
+    if m.kind == "block":
+        y = ops.pw_gemm(h, w3, b3, res=x if m.do_res else None, res_mode=nat.RES_ADD if m.do_res else nat.RES_NONE, **kw)
+    elif m.kind == "down":
+        res = None
+        if m.resample_do_res:
+            paired = ops.pw_conv_paired_supported(c_in=C, c_out=c_out, in_dtype=dt, out_dtype=dt, gather=2)
+            wres = self._pw_paired(m.res_conv) if paired else self._pw(m.res_conv, dt)
+            res = ops.pw_conv(x, wres, self._vec(m.res_conv, "bias", m.res_conv.bias), N=N, rows_per_sample=rows,
+                              c_in=C, c_out=c_out, out_dtype=dt, gather=2, grid=(D, H, W), w_paired=paired)
+        y = ops.pw_gemm(h, w3, b3, res=res, res_mode=nat.RES_ADD if res is not None else nat.RES_NONE, **kw)
+    else:
+        if skip is None:
+            skip = torch.zeros((N, Do, Ho, Wo, c_out), dtype=dt, device=x.device)
+        res_low = res_bias = None
+        if m.resample_do_res:
+            res_bias = self._vec(m.res_conv, "bias", m.res_conv.bias)
+            paired = ops.pw_conv_paired_supported(c_in=C, c_out=c_out, in_dtype=dt, out_dtype=dt)
+            wres = self._pw_paired(m.res_conv, transposed=True) if paired else self._pw(m.res_conv, dt, transposed=True)
+            res_low = ops.pw_conv(x, wres, res_bias, N=N, rows_per_sample=D * H * W, c_in=C, c_out=c_out, out_dtype=dt, w_paired=paired)
+        y = ops.pw_gemm(h, w3, b3, res=skip, res_mode=nat.RES_UPSAMPLE, grid=(Do, Ho, Wo), res_low=res_low, res_bias=res_bias, **kw)
+    return y.view(N, Do, Ho, Wo, c_out)
+
+
 def _up_block_fused(self, m, x, skip, taps, b1, c_hid, c_out):
     """Up block without the depthwise output in HBM: statistics-only pass of the transposed depthwise kernel (bit-identical
     partial sums), then ONE mixer launch that forms its operand from the low-resolution input."""
@@ -481,6 +528,7 @@ def _up_block_fused(self, m, x, skip, taps, b1, c_hid, c_out):
 
 
 HipBlockOps._up_block_fused = _up_block_fused
+HipBlockOps._block_deep_gemm = _block_deep_gemm
 HipBlockOps._block_fused = _block_fused
 HipBlockOps._stem_block_fused = _stem_block_fused
 

@@ -294,6 +294,44 @@ def test_groupnorm_fold_into_the_expanding_conv(dev, C, chid, cout, mode):
         ops.pw_mlp(t.to(dev), None, w2n[:1], b2n, w3p, b3.to(dev), **args)
 
 
+@pytest.mark.parametrize("cin,chid,cout,mode,N,rows", [(256, 512, 256, "add", 3, 1000), (512, 1024, 512, "add", 8, 343),
+                                                         (512, 1024, 256, "up", 2, 96), (128, 256, 128, "none", 2, 2197),
+                                                         (256, 512, 512, "add", 1, 17), (128, 512, 128, "add", 5, 4096)])
+@pytest.mark.parametrize("rows_knob", [0, 64, 128])
+def test_deep_level_gemm_pair_is_bit_identical_to_the_fused_mixer(dev, cin, chid, cout, mode, N, rows, rows_knob):
+    """ops.pw_gemm x 2 (round 4: the deep levels' convs as LDS-tiled GEMM launches) against ops.pw_mlp with the fp16 projection: the
+    same operations in the same order -- bias-initialised accumulators, k ascending in steps of 32, GroupNorm affine in fp32 rounded
+    to bf16, packed-fp16 GELU, fp16 hidden, f16 MFMA projection, the shared residual epilogue -- hence equal BITS, for both workgroup
+    heights, rows that are no multiple of the tile and tiles that straddle samples."""
+    from pytorch_connectomics_amd import _native as nat
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(cin + rows)
+    bf = torch.bfloat16
+    grid = (4, 6, 4) if mode == "up" else (0, 0, 0)
+    t = torch.randn(N, rows, cin, device=dev).to(bf)
+    ab = torch.stack([torch.rand(N, cin, device=dev) + 0.5, torch.randn(N, cin, device=dev) * 0.5], 1).contiguous()
+    w2, b2 = torch.randn(chid, cin, device=dev) / cin ** 0.5, torch.randn(chid, device=dev) * 0.5
+    w3, b3 = torch.randn(cout, chid, device=dev) / chid ** 0.5, torch.randn(cout, device=dev) * 0.5
+    res = torch.randn(N, rows, cout, device=dev).to(bf)
+    kw = dict(N=N, rows_per_sample=rows)
+    ekw = {}
+    if mode == "add":
+        ekw = dict(res=res, res_mode=nat.RES_ADD)
+    elif mode == "up":
+        low = torch.randn(N, rows // 8, cout, device=dev).to(bf)
+        ekw = dict(res=res, res_mode=nat.RES_UPSAMPLE, grid=grid, res_low=low, res_bias=b3)
+    want = ops.pw_mlp(t, ab, ops.pw_pack_weight_paired(w2), b2, ops.pw_pack_weight_paired(w3, f16=True), b3, c_in=cin, c_hid=chid,
+                      c_out=cout, **kw, **ekw)
+    ops.set_tuning("pw_gemm_rows", rows_knob)
+    try:
+        h = ops.pw_gemm(t, w2.to(bf).contiguous(), b2, ab=ab, gelu=True, **kw)
+        got = ops.pw_gemm(h, w3.to(torch.float16).contiguous(), b3, **kw, **ekw)
+    finally:
+        ops.set_tuning("pw_gemm_rows", 0)
+    assert h.dtype == torch.float16 and got.dtype == bf and got.shape == want.shape
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+
+
 def test_packed_fp16_gelu_accuracy(dev):
     """gelu_h2 (csrc/pytc_common.h) through the fused mixer: identity-like first GEMM, one-hot projection, so the output is
     bf16(gelu_h2(x)) for a dense sweep of x.  Error budget: polynomial fit 1e-4 + fp16 evaluation, then the bf16 output

@@ -94,7 +94,54 @@ def convT(N, D, C):
     print(f"dwconvT3d k3 {D}^3 -> {2 * D}^3 x{N} C{C}: {us:8.1f} us  {9 * x.numel() * 2 / us / 1e3:7.1f} GB/s", flush=True)
 
 
-TARGETS = {"copy0": lambda: copy(8, 112, 32), "copy64": lambda: copy(8, 112, 64), "mix0": lambda: mixer(8, 112, 32, 64, 32, "add"), "up0": lambda: mixer(8, 112, 64, 128, 32, "up"),
+def deep(N, D, cin, chid, cout):
+    """fused mixer against the two-GEMM schedule of the deep levels at one shape (both bit-identical)"""
+    rows = D ** 3
+    t = torch.randn(N, rows, cin, device=dev).to(bf)
+    ab = torch.rand(N, 2, cin, device=dev)
+    w2f, w3f = torch.randn(chid, cin, device=dev) / cin ** 0.5, torch.randn(cout, chid, device=dev) / chid ** 0.5
+    b2, b3 = torch.randn(chid, device=dev), torch.randn(cout, device=dev)
+    res = torch.randn(N, rows, cout, device=dev).to(bf)
+    w2p, w3p = ops.pw_pack_weight_paired(w2f), ops.pw_pack_weight_paired(w3f, f16=True)
+    w2, w3 = w2f.to(bf).contiguous(), w3f.to(torch.float16).contiguous()
+    kw = dict(N=N, rows_per_sample=rows)
+    fused = lambda: ops.pw_mlp(t, ab, w2p, b2, w3p, b3, res=res, res_mode=nat.RES_ADD, c_in=cin, c_hid=chid, c_out=cout, **kw)      # noqa: E731
+    flops = 2 * N * rows * (cin * chid + chid * cout)
+    uf = timeit(fused)
+    line = f"deep {cin}->{chid}->{cout} {D}^3 x{N} ({N * rows} rows): fused {uf:7.1f} us ({flops / uf / 1e6:6.1f} TFLOP/s)"
+    for knob_rows in (64, 128):
+        knob("pw_gemm_rows", knob_rows)
+        g1 = lambda: ops.pw_gemm(t, w2, b2, ab=ab, gelu=True, **kw)      # noqa: E731
+        h = g1()
+        g2 = lambda: ops.pw_gemm(h, w3, b3, res=res, res_mode=nat.RES_ADD, **kw)      # noqa: E731
+        u1, u2 = timeit(g1), timeit(g2)
+        line += f" | BR{knob_rows}: {u1:6.1f} + {u2:6.1f} = {u1 + u2:6.1f} us ({flops / (u1 + u2) / 1e6:6.1f} TFLOP/s)"
+    knob("pw_gemm_rows", 0)
+    print(line, flush=True)
+
+
+def gemm_sweep():
+    """one GEMM launch at the L3-up expand shape (21 952 rows -> 1024 channels) against K, with / without affine, GELU epilogue"""
+    N, rows, cout = 8, 14 ** 3, 1024
+    for cin in (64, 128, 256, 512, 1024):
+        x = torch.randn(N, rows, cin, device=dev).to(bf)
+        w = (torch.randn(cout, cin, device=dev) / cin ** 0.5).to(bf).contiguous()
+        b = torch.randn(cout, device=dev)
+        ab = torch.rand(N, 2, cin, device=dev)
+        kw = dict(N=N, rows_per_sample=rows)
+        line = f"gemm {rows * N} x {cin} -> {cout}:"
+        for label, fn in (("gelu+affine", lambda: ops.pw_gemm(x, w, b, ab=ab, gelu=True, **kw)),
+                          ("gelu", lambda: ops.pw_gemm(x, w, b, gelu=True, **kw)),
+                          ("plain bf16 out", lambda: ops.pw_gemm(x, w, b, **kw))):
+            us = timeit(fn)
+            line += f"  {label} {us:6.1f} us ({2 * N * rows * cin * cout / us / 1e6:6.1f} TF)"
+        print(line, flush=True)
+
+
+TARGETS = {"gemm_sweep": gemm_sweep, "deep4": lambda: deep(8, 7, 512, 1024, 512), "deep3": lambda: deep(8, 14, 256, 512, 256),
+           "deep3up": lambda: deep(8, 14, 512, 1024, 256), "deep2": lambda: deep(8, 28, 128, 256, 128),
+           "deep2up": lambda: deep(8, 28, 256, 512, 128), "deep4dn": lambda: deep(8, 7, 256, 512, 512),
+           "copy0": lambda: copy(8, 112, 32), "copy64": lambda: copy(8, 112, 64), "mix0": lambda: mixer(8, 112, 32, 64, 32, "add"), "up0": lambda: mixer(8, 112, 64, 128, 32, "up"),
            "dw0": lambda: dw(8, 112, 32), "convT0": lambda: convT(8, 56, 64),
            "mix1": lambda: mixer(8, 56, 64, 128, 64, "add"), "up1": lambda: mixer(8, 56, 128, 256, 64, "up"),
            "dw1": lambda: dw(8, 56, 64)}
