@@ -433,50 +433,67 @@ __global__ void __launch_bounds__(1024)
 groupnorm_fold_mlp_kernel(const float* __restrict__ stats, int slots, float count, const float* __restrict__ gamma,
                           const float* __restrict__ beta, float eps, const float* __restrict__ w2, const float* __restrict__ b2,
                           bf16_t* __restrict__ w2n, float* __restrict__ b2n, float* __restrict__ ab_out, int C, int C_hid) {
-  __shared__ float red[2][1024];
+  // slot reduction: a thread owns 4 consecutive channels of one of (sum | sum of squares) and every (1024 / (C/2))-th slot -- 16-byte
+  // loads, 64 (C = 32) ... 16 (C = 128) slot lanes, so the dependent-load chain of the level-0 launch is 1176 / 64 = 19 steps (the
+  // first cut: 4-byte loads, 32 lanes, 37 steps of two loads each = 12.7 us against groupnorm_finalize's 4.9); the lane partials meet
+  // in LDS in two fixed-order stages
+  __shared__ __attribute__((aligned(16))) float red[1024 * 4];
+  __shared__ float part[8][2 * 128];
   __shared__ float sa[128], sb[128];
   const int n = blockIdx.x, tid = threadIdx.x;
-  const int cl = tid % C, sl = tid / C, SL = 1024 / C;
-  const float* base = stats + (long)n * slots * 2 * C;
-  float a1 = 0.f, a2 = 0.f;
+  const int Q = C / 2;                        // float4 columns of one slot row: [sum C | sum of squares C]
+  const int col = tid % Q, sl = tid / Q, SL = 1024 / Q;
+  const float* base = stats + (long)n * slots * 2 * C + col * 4;
+  f32x4_t a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-  for (int s = sl; s < slots; s += SL) {
-    a1 += base[((long)s * 2 + 0) * C + cl];
-    a2 += base[((long)s * 2 + 1) * C + cl];
-  }
-  red[0][tid] = a1;
-  red[1][tid] = a2;
+  for (int s = sl; s < slots; s += SL) a += *reinterpret_cast<const f32x4_t*>(base + (long)s * 2 * C);
+  *reinterpret_cast<f32x4_t*>(&red[tid * 4]) = a;             // red[sl][2C] as float4 columns
   __syncthreads();
-  if (tid < C) {
-    float t1 = 0.f, t2 = 0.f;
-    for (int s = 0; s < SL; ++s) { t1 += red[0][s * C + tid]; t2 += red[1][s * C + tid]; }
-    const float mean = t1 / count;
-    const float var = fmaxf(t2 / count - mean * mean, 0.f);
-    float rstd = rsqrtf(var + eps);
-    rstd = rstd * (1.5f - 0.5f * (var + eps) * rstd * rstd);      // one Newton step: rsqrtf is approximate
-    const float a = (gamma ? gamma[tid] : 1.f) * rstd;
-    const float b = (beta ? beta[tid] : 0.f) - mean * a;
-    sa[tid] = a;
-    sb[tid] = b;
-    if (ab_out) {
-      ab_out[((long)n * 2 + 0) * C + tid] = a;
-      ab_out[((long)n * 2 + 1) * C + tid] = b;
+  {
+    // stage 1: 8 partial sums per (which, channel) over SL / 8 lanes each; stage 2 below adds the 8 in order
+    const int e = tid % (2 * C), pg = tid / (2 * C);           // 2C <= 256 elements, up to 1024 / (2C) >= 4 part groups
+    const int groups = 1024 / (2 * C) < 8 ? 1024 / (2 * C) : 8;
+    if (pg < groups) {
+      float t = 0.f;
+      for (int s = pg; s < SL; s += groups) t += red[s * 2 * C + e];
+      part[pg][e] = t;
+    }
+    __syncthreads();
+    if (tid < C) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int g = 0; g < groups; ++g) { t1 += part[g][tid]; t2 += part[g][C + tid]; }
+      const float mean = t1 / count;
+      const float var = fmaxf(t2 / count - mean * mean, 0.f);
+      float rstd = rsqrtf(var + eps);
+      rstd = rstd * (1.5f - 0.5f * (var + eps) * rstd * rstd);      // one Newton step: rsqrtf is approximate
+      const float av = (gamma ? gamma[tid] : 1.f) * rstd;
+      const float bv = (beta ? beta[tid] : 0.f) - mean * av;
+      sa[tid] = av;
+      sb[tid] = bv;
+      if (ab_out) {
+        ab_out[((long)n * 2 + 0) * C + tid] = av;
+        ab_out[((long)n * 2 + 1) * C + tid] = bv;
+      }
     }
   }
   __syncthreads();
   const int KG = C / 32;
   const long total = (long)C_hid * C;
   bf16_t* img = w2n + (long)n * total;
-  for (long e = tid; e < total; e += 1024) {
-    const int j = (int)(e % 8);
-    long t = e / 8;
+  for (long e8 = tid; e8 < total / 8; e8 += 1024) {           // one 16-byte fragment piece (8 consecutive k of one output row) per step
+    long t = e8;
     const int lane = (int)(t % 64);
     t /= 64;
     const int kg = (int)(t % KG);
     const int T = (int)(t / KG);
     const int o = paired_row(T, lane & 15);
-    const int k = kg * 32 + (lane >> 4) * 8 + j;
-    img[e] = from_f32<bf16_t>(w2[(long)o * C + k] * sa[k]);
+    const int k = kg * 32 + (lane >> 4) * 8;
+    float v[8];
+    VecIO<float, 4>::load(w2 + (long)o * C + k, reinterpret_cast<float(&)[4]>(v[0]));
+    VecIO<float, 4>::load(w2 + (long)o * C + k + 4, reinterpret_cast<float(&)[4]>(v[4]));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= sa[k + j];
+    *reinterpret_cast<bf16x8_t*>(img + e8 * 8) = Mma<bf16_t>::from_floats(v);
   }
   for (int o = tid; o < C_hid; o += 1024) {
     float acc = b2 ? b2[o] : 0.f;

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-3 evidence (run on the GPU box from the repo root): rocprofv3 kernel trace + stats of the bench command with ONE window
+# Round-4 evidence (run on the GPU box from the repo root): rocprofv3 kernel trace + stats of the bench command with ONE window
 # stream (per-kernel averages that agree with bench.py's event timings) and with the default TWO streams (overlap timeline), the
 # HBM byte counters of the bench in separate --pmc passes, and the same three things for the MedNeXt-S training step.
-# Output: gpurun_out/prof_r03/ ; condensed files are copied to profiles/ by hand after review.
+# Output: gpurun_out/prof_r04/ ; condensed files are copied to profiles/ by hand after review.
 set -u
-OUT=$PWD/gpurun_out/prof_r03
+OUT=$PWD/gpurun_out/prof_r04
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-train --no-extras"
