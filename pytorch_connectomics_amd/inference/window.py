@@ -461,10 +461,11 @@ class EagerSlidingWindowEngine:
             x = ops.gather_windows(vol, batch_starts, roi, view=view, pad_mode="constant", cval=self.cval)
             return self._run_network(network, x)
 
-        before = torch.cuda.memory_allocated(dev)
-        peak_before = torch.cuda.max_memory_allocated(dev)
+        on_gpu = dev.type == "cuda"
+        before = torch.cuda.memory_allocated(dev) if on_gpu else 0
+        peak_before = torch.cuda.max_memory_allocated(dev) if on_gpu else 0
         probe = run(starts[:1])
-        peak = torch.cuda.max_memory_allocated(dev)
+        peak = torch.cuda.max_memory_allocated(dev) if on_gpu else 0
         # a rising peak gives the probe's activation footprint; a stale higher peak from earlier work tells nothing (0)
         self._probe_bytes = max(0, peak - before) if peak > peak_before else 0
         c_out = int(probe.shape[-1])

@@ -24,7 +24,7 @@ def standin_engine(monkeypatch):
     for mod in (tta, ens, window):
         monkeypatch.setattr(mod, "ops", _Ops)
     monkeypatch.setattr(window.EagerSlidingWindowEngine, "_check_inputs", lambda self, inputs: torch.device("cpu"))
-    monkeypatch.setattr(window.EagerSlidingWindowEngine, "_lanes", lambda self, dev, n: [])
+    monkeypatch.setattr(window.EagerSlidingWindowEngine, "_lanes", lambda self, dev, n, network=None: [])
     from pytorch_connectomics_amd.inference import InferenceManager
     return InferenceManager
 
