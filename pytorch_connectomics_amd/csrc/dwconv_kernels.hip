@@ -591,11 +591,17 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
       }
       lds_t* dst = &plane[slot][loff[i]];
       if constexpr (H16) {
-        // f16 image: clamp to the f16 range first (a bf16 activation beyond 6e4 would become inf and poison the sums)
-        h8_t hv;
+        // f16 image: clamp into the f16 range first (a bf16 activation beyond it would become inf and poison the sums --
+        // v_cvt_pkrtz_f16_f32 does NOT saturate on gfx950, measured in round 4), as ONE v_med3_f32 per element: fminf(fmaxf())
+        // compiled to v_max + v_med3 (32 of the step's ~226 VALU instructions for 16 elements).  Every bf16 value inside the normal
+        // f16 range converts exactly whatever the rounding mode, so the packed round-toward-zero conversion is as good as RNE here.
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 packed;
 #pragma unroll
-        for (int q = 0; q < EPC; ++q) hv[q] = (_Float16)fminf(fmaxf(v[q], -60000.f), 60000.f);
-        *reinterpret_cast<h8_t*>(dst) = hv;
+        for (int q = 0; q < EPC; q += 2)
+          packed[q / 2] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_fmed3f(v[q], -60000.f, 60000.f),
+                                                                                      __builtin_amdgcn_fmed3f(v[q + 1], -60000.f, 60000.f)));
+        *reinterpret_cast<u32x4*>(dst) = packed;
       } else {
 #pragma unroll
         for (int q = 0; q < EPC; q += 4)

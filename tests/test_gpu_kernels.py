@@ -479,9 +479,15 @@ def test_dwconv_march_packed_f16_error_budget(dev):
         assert out[("max", 1)] <= 1.5 * out[("max", 0)]
         knob(1)
         big = x.clone()
-        big[0, 5, 5, 5, :] = 3.0e5                                       # beyond f16: clamped to 6e4, finite everywhere
+        big[0, 5, 5, 5, :] = 3.0e5                                       # beyond f16: saturates at the largest f16, finite everywhere
+        big[0, 9, 9, 9, :] = -3.0e5
         yb, _ = ops.dwconv3d(big, taps, b, K=3)
         assert bool(torch.isfinite(yb.float()).all())
+        # the result is the convolution of the input clamped to +-6e4 at staging (one v_med3_f32 per element since round 4)
+        sat = big.double().cpu().clamp(-60000.0, 60000.0)
+        refb = F.conv3d(sat.permute(0, 4, 1, 2, 3), w64, b.double().cpu(), padding=1, groups=C).permute(0, 2, 3, 4, 1)
+        errb = (yb.double().cpu() - refb).abs()
+        assert float((errb / (refb.abs() + 1.0)).max()) < 2e-2, float((errb / (refb.abs() + 1.0)).max())
     finally:
         knob(1)
 
