@@ -1,9 +1,9 @@
 """`TTAEnsembleAccumulator` -- the reference's streaming, validity-aware ensemble of TTA views
 (connectomics/inference/tta_ensemble.py:13-211) as a public, device-resident object.
 
-`TTAPredictor` does not go through this class (its ensemble is fused with per-view normalisation, and the affinity channel moves
-are index math inside the blending kernel); the class exists for callers of the reference API that hold whole canonical
-predictions.  Same constructor / `add` / `finalize` contract; the statistics live in HBM and every update is one of the
+`TTAPredictor.predict` (whole volumes) does not go through this class (its ensemble is fused with per-view normalisation, and the
+affinity channel moves are index math inside the blending kernel); `TTAPredictor.predict_windows` -- the lazy / chunked path, one
+accumulator per window batch -- and callers of the reference API that hold whole canonical predictions do.  Same constructor / `add` / `finalize` contract; the statistics live in HBM and every update is one of the
 ensemble kernels of csrc/window_kernels.hip (`pytc_ensemble_update`, `pytc_ensemble_update_masked`,
 `pytc_ensemble_finalize_masked`).  Differences from the reference, both inside its contract: partial-channel counts are fp32
 (exact to 2^24 views) instead of uint8 / int16, and a box validity is expanded to a cover mask on the device.
@@ -37,6 +37,11 @@ def _channel_plan(shape, mode_map, partial_channels):
 
 
 class TTAEnsembleAccumulator:
+    """Statistics are stored CHANNEL-MAJOR, (C, N, *spatial): a channel -- and a run of consecutive channels that share an ensemble
+    mode -- is one contiguous block, so a view is streamed in with one kernel launch per run directly on the stored statistics
+    (round 3 kept (N, C, ...) and paid three strided-to-contiguous copies per channel and view: ADVICE r03).  `legacy_result`,
+    `partial_statistics`, `partial_counts` are the reference's attribute names and shapes, as views."""
+
     def __init__(self, shape: Sequence[int], *, dtype: torch.dtype, device, mode_map: Sequence[str],
                  partial_channels: Sequence[int], distributed_sharding: bool, max_views: int) -> None:
         self.device = torch.device(device)
@@ -46,12 +51,24 @@ class TTAEnsembleAccumulator:
         self.distributed_sharding, self.max_views = bool(distributed_sharding), int(max_views)
         self.num_predictions = 0
         on_device = dict(device=self.device, dtype=torch.float32)
-        self.legacy_result = torch.zeros(self.shape, **on_device)
-        slabs = (self.shape[0], len(self.partial_channels), *self.shape[2:])
-        self.partial_counts = torch.zeros(slabs, **on_device)
-        self.partial_statistics = torch.empty(slabs, **on_device)
+        n, c = self.shape[0], self.shape[1]
+        self._stat = torch.zeros((c, n, *self.shape[2:]), **on_device)
+        slabs = (len(self.partial_channels), n, *self.shape[2:])
+        self._pcount = torch.zeros(slabs, **on_device)
+        self._pstat = torch.empty(slabs, **on_device)
         for slot, channel in enumerate(self.partial_channels):
-            self.partial_statistics[:, slot] = _IDENTITY[self.mode_map[channel]]
+            self._pstat[slot] = _IDENTITY[self.mode_map[channel]]
+        # runs of consecutive fully valid channels with one ensemble mode: (first, stop, mode)
+        self._runs = []
+        for ch in self.full_channels:
+            if self._runs and self._runs[-1][1] == ch and self._runs[-1][2] == self.mode_map[ch]:
+                self._runs[-1][1] = ch + 1
+            else:
+                self._runs.append([ch, ch + 1, self.mode_map[ch]])
+
+    legacy_result = property(lambda self: self._stat.transpose(0, 1))
+    partial_statistics = property(lambda self: self._pstat.transpose(0, 1))
+    partial_counts = property(lambda self: self._pcount.transpose(0, 1))
 
     @property
     def has_partial_channels(self) -> bool:
@@ -82,41 +99,38 @@ class TTAEnsembleAccumulator:
             raise ValueError(f"TTA prediction shape {tuple(prediction.shape)} does not match accumulator shape {self.shape}.")
         if len(validity.channels) != self.shape[1]:
             raise ValueError(f"TTA validity describes {len(validity.channels)} channels, expected {self.shape[1]}.")
-        pred = prediction.to(device=self.device, dtype=torch.float32)
-        for c in self.full_channels:
-            incoming = pred[:, c].contiguous()
+        pcn = prediction.to(device=self.device, dtype=torch.float32).transpose(0, 1)         # (C, N, *spatial) view
+        for c0, c1, mode in self._runs:
+            acc = self._stat[c0:c1]                                  # contiguous block: updated in place
             if self.num_predictions == 0:
-                self.legacy_result[:, c].copy_(incoming)
-            elif self.mode_map[c] == "mean" and self.distributed_sharding:
-                self.legacy_result[:, c] += incoming               # shards sum, the reduce divides (reference :95-97)
+                acc.copy_(pcn[c0:c1])
+            elif mode == "mean" and self.distributed_sharding:
+                acc += pcn[c0:c1]                                    # shards sum, the reduce divides (reference :95-97)
             else:
-                acc = self.legacy_result[:, c].contiguous()
-                ops.ensemble_update(acc, incoming, _MODE[self.mode_map[c]], self.num_predictions + 1)
-                self.legacy_result[:, c].copy_(acc)
+                ops.ensemble_update(acc, pcn[c0:c1].contiguous(), _MODE[mode], self.num_predictions + 1)
         for pi, c in enumerate(self.partial_channels):
-            values = pred[:, c].contiguous()
-            stat, count = self.partial_statistics[:, pi].contiguous(), self.partial_counts[:, pi].contiguous()
-            ops.ensemble_update_masked(stat, count, values, self._cover(validity.channels[c], values), _MODE[self.mode_map[c]])
-            self.partial_statistics[:, pi].copy_(stat)
-            self.partial_counts[:, pi].copy_(count)
+            values = pcn[c].contiguous()
+            ops.ensemble_update_masked(self._pstat[pi], self._pcount[pi], values, self._cover(validity.channels[c], values),
+                                       _MODE[self.mode_map[c]])
         self.num_predictions += 1
 
     def finalize(self, *, legacy_result: Optional[torch.Tensor] = None, partial_statistics: Optional[torch.Tensor] = None,
                  partial_counts: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """The aggregate in `dtype`; a partial channel without any valid contribution somewhere is an error."""
-        result = (self.legacy_result if legacy_result is None else legacy_result).to(torch.float32).clone()
-        stats = self.partial_statistics if partial_statistics is None else partial_statistics
-        counts = self.partial_counts if partial_counts is None else partial_counts
-        for pi, c in enumerate(self.partial_channels):
-            cnt = counts[:, pi].to(torch.float32).contiguous()
-            empty = cnt == 0
-            if bool(empty.any()):
-                first = tuple(int(v) for v in torch.nonzero(empty)[0])
-                raise RuntimeError(f"TTA ensemble has zero valid contributions for channel {c} at voxel index {first}.")
-            out = torch.empty_like(cnt)
-            ops.ensemble_finalize_masked(stats[:, pi].to(torch.float32).contiguous(), cnt, out, _MODE[self.mode_map[c]])
-            result[:, c].copy_(out)
-        return result.to(self.dtype)
+        """The aggregate in `dtype`; a partial channel without any valid contribution somewhere is an error.  The optional arguments
+        are (N, C, ...)-shaped replacements of the stored statistics (a distributed reduce hands back the reduced tensors)."""
+        cn = lambda t: t.to(device=self.device, dtype=torch.float32).transpose(0, 1)      # noqa: E731
+        result = (self._stat if legacy_result is None else cn(legacy_result)).clone(memory_format=torch.contiguous_format)
+        stats = self._pstat if partial_statistics is None else cn(partial_statistics).contiguous()
+        counts = self._pcount if partial_counts is None else cn(partial_counts).contiguous()
+        if self.partial_channels:
+            empty = counts == 0
+            if bool(empty.any()):                                    # ONE device -> host check for all partial channels
+                pi, *where = (int(v) for v in torch.nonzero(empty)[0])
+                raise RuntimeError(f"TTA ensemble has zero valid contributions for channel {self.partial_channels[pi]} at voxel index "
+                                   f"{tuple(where)}.")
+            for pi, c in enumerate(self.partial_channels):
+                ops.ensemble_finalize_masked(stats[pi], counts[pi], result[c], _MODE[self.mode_map[c]])
+        return result.transpose(0, 1).contiguous().to(self.dtype)
 
 
 __all__ = ["TTAEnsembleAccumulator"]
