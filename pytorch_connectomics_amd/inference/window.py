@@ -377,7 +377,9 @@ class EagerSlidingWindowEngine:
         self.progress = bool(progress)
         self._axis_cache = {}
         # HIP streams the window batches are spread over (1 = the caller's stream only); results do not depend on it
-        self._pipeline_streams = int(os.environ.get("PYTC_SW_STREAMS", "2"))
+        # 3 since round 4 (7.59 -> 7.48 ms per 8 windows; round 3 measured 3 slower than 2: the deep levels were the fused mixer
+        # then, now they are short GEMM launches that a third batch's level-0 kernels cover); 4 is slower again (7.83)
+        self._pipeline_streams = int(os.environ.get("PYTC_SW_STREAMS", "3"))
         self._streams_requested = "PYTC_SW_STREAMS" in os.environ
         self._probe_bytes = 0                   # peak activation bytes of the one-window probe pass (0 = unknown)
         self.last_stats = {}

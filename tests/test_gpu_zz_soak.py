@@ -4,7 +4,7 @@ Round 3 found one kernel (the K = 3 x-block depthwise conv: compiler-generated p
 results changed when an MFMA kernel of another HIP stream shared the GPU; the fix is a build rule (csrc/build.py: no SLP
 vectorisation in the files that contained such forms + an ISA grep) whose mechanism was never pinned down, and two streams are the
 DEFAULT and the benched path.  The short guard in test_gpu_window.py runs 4 passes on a reduced volume with MedNeXt-S only; this file is the
-long form: every architecture of the path, at its real window, whole volumes, 30 passes per stream count, every pass compared bit
+long form: every architecture of the path, at its real window, whole volumes, 15 passes on one stream and 15 each on two and three, every pass compared bit
 for bit with the first one-stream pass -- and the training step with its weight-gradient side stream off / on.
 Runs last (file name) and takes about a minute of GPU time."""
 from types import SimpleNamespace as NS
@@ -67,7 +67,7 @@ def test_two_window_streams_are_bit_identical_over_many_whole_volume_passes(name
         ref = eng(vol, model).clone()
         torch.cuda.synchronize()
         assert eng.last_stats["streams"] == 1
-        for streams in (2, 1, 2):
+        for streams in (2, 1, 3):                       # 3 = the engine's default since round 4
             eng.pipeline_streams = streams
             for i in range(PASSES // 2 if streams == 1 else PASSES // 2 + (PASSES % 2)):
                 y = eng(vol, model)

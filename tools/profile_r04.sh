@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 evidence (run on the GPU box from the repo root): rocprofv3 kernel trace + stats of the bench command with ONE window
-# stream (per-kernel averages that agree with bench.py's event timings) and with the default TWO streams (overlap timeline), the
+# stream (per-kernel averages that agree with bench.py's event timings) and with the default window streams (three since round 4) (overlap timeline), the
 # HBM byte counters of the bench in separate --pmc passes, and the same three things for the MedNeXt-S training step.
 # Output: gpurun_out/prof_r04/ ; condensed files are copied to profiles/ by hand after review.
 set -u
@@ -15,21 +15,21 @@ PYTC_SW_STREAMS=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/bench_1
 PYTC_SW_STREAMS=1 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/bench_1stream/pmc_write -o bench -- $BENCH1 > /dev/null 2>&1
 python tools/prof_bench_summary.py $OUT/bench_1stream > $OUT/bench_1stream_summary.txt 2>&1
 python tools/make_hbm_counters_csv.py $OUT/bench_1stream $OUT/bench_hbm_counters.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_2streams/trace -o bench -- $BENCH > $OUT/bench_2streams.log 2>&1
-F=$(find $OUT/bench_2streams -name "*kernel_trace.csv" | head -1)
-python tools/trace_overlap.py $F 70 > $OUT/overlap_2streams.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_streams/trace -o bench -- $BENCH > $OUT/bench_streams.log 2>&1
+F=$(find $OUT/bench_streams -name "*kernel_trace.csv" | head -1)
+python tools/trace_overlap.py $F 70 > $OUT/overlap_streams.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train/trace -o train -- $TRAIN > $OUT/train.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/train/pmc_fetch -o train -- $TRAIN > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/train/pmc_write -o train -- $TRAIN > /dev/null 2>&1
 python tools/prof_bench_summary.py $OUT/train > $OUT/train_summary.txt 2>&1
 python tools/make_hbm_counters_csv.py $OUT/train $OUT/train_hbm_counters.csv
-for d in bench_1stream bench_2streams train; do
+for d in bench_1stream bench_streams train; do
   S=$(find $OUT/$d/trace -name "*kernel_stats.csv" | head -1); cp $S $OUT/${d}_kernel_stats.csv
 done
 # keep the merge-back small: the raw traces stay on the box
-rm -rf $OUT/bench_1stream $OUT/bench_2streams $OUT/train
+rm -rf $OUT/bench_1stream $OUT/bench_streams $OUT/train
 grep "^{" $OUT/bench_1stream.log | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('1 stream ms/8win', d['ms_per_8_windows'])"
-grep "^{" $OUT/bench_2streams.log | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('2 streams ms/8win', d['ms_per_8_windows'])"
-head -16 $OUT/overlap_2streams.txt
+grep "^{" $OUT/bench_streams.log | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('default streams ms/8win', d['ms_per_8_windows'])"
+head -16 $OUT/overlap_streams.txt
 head -14 $OUT/train_summary.txt
 ls -la $OUT
