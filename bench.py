@@ -261,13 +261,15 @@ def by_symbol(summ):
     return out
 
 
-def largest_symbols(summ, n_steps, top=3, traffic_of=None):
+def largest_symbols(summ, n_steps, top=3, traffic_of=None, symbols=None):
     """The `top` kernel families by time, each with its own roofline entry (launch-weighted over every shape it runs at): the
     z-march depthwise conv runs under one label per shape and would otherwise never be the 'dominant' line although it is the
     largest rocprof symbol of the step."""
     total_ms = sum(r["ms"] for r in summ.values())
     rows = []
-    for sym, rec in sorted(by_symbol(summ).items(), key=lambda kv: -kv[1]["ms"])[:top]:
+    # `symbols` = PROFILER.by_symbol() of the same run (per-record grouping: the launches of one label can be different template
+    # instances -- the mixer's plain / +head / +stemres forms); without it the summary's per-label symbol stands in
+    for sym, rec in sorted((symbols if symbols is not None else by_symbol(summ)).items(), key=lambda kv: -kv[1]["ms"])[:top]:
         e = roofline_entry(sym, rec, traffic_of(sym) if traffic_of else None)
         e.update({"share_of_step": round(rec["ms"] / total_ms, 3), "launches_per_step": round(rec["launches"] / n_steps, 1),
                   "ms_per_step": round(rec["ms"] / n_steps, 3)})
@@ -344,7 +346,7 @@ def train_leg(dev, rank, world, args, barrier):
                                       "device kernel named in `kernel` (`labels`), which is what the counter average covers")
             if roof.get("traffic"):
                 roof["traffic_over_algorithmic"] = round(roof["traffic"] / max(roof["algorithmic_bytes"], 1), 3)
-            roof["by_symbol"] = largest_symbols(prof.summary(), 2, top=4,
+            roof["by_symbol"] = largest_symbols(prof.summary(), 2, top=4, symbols=prof.by_symbol(),
                                                 traffic_of=lambda sym: _traffic_from_table(table, _kernel_key(sym)))
         else:
             for i in range(2):
@@ -834,7 +836,7 @@ def main():
         # `roofline` IS the largest rocprof SYMBOL of the step (launch-weighted over the shapes it runs at: what a rocprofv3 --stats
         # row of the same command averages over); the largest per-shape LABEL -- one mixer shape -- sits beside it as `by_label`, the
         # three largest families as `by_symbol`, and the step as a whole on SURVEY 8(d)'s byte floor as `whole_step`
-        families = largest_symbols(summ, nprof, top=3, traffic_of=traffic_of)
+        families = largest_symbols(summ, nprof, top=3, traffic_of=traffic_of, symbols=prof.by_symbol())
         by_label = dominant(summ, nprof, traffic_fn=traffic_of)
         roofline = dict(families[0])
         roofline.update({"traffic_source": source, "by_label": by_label, "by_symbol": families,

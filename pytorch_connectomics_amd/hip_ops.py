@@ -66,12 +66,16 @@ class _Profiler:
     def by_symbol(self):
         """The same records grouped by device kernel family (one rocprof symbol, or one template): a kernel that runs under
         several per-shape labels shows up with its whole share of the step."""
+        torch.cuda.synchronize()
         out = {}
-        for name, rec in self.summary().items():
-            d = out.setdefault(rec["symbol"], {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0, "labels": []})
-            for k in ("launches", "ms", "bytes", "flops"):
-                d[k] += rec[k]
-            d["labels"].append(name)
+        for name, s, e, nbytes, flops, symbol in self.records:        # per RECORD: launches of one label may be different template
+            d = out.setdefault(symbol, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0, "labels": []})      # instances (mixer +head ...)
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["bytes"] += nbytes
+            d["flops"] += flops
+            if name not in d["labels"]:
+                d["labels"].append(name)
         return out
 
 
