@@ -345,6 +345,13 @@ int pytc_pack_multi(const int64_t* table_dev, int n_items, int64_t total_elems, 
 int pytc_pw_pack_weight_paired_f16(const float* w, int C_out, int C_in, int transposed, void* packed_f16,
                                    void* stream);
 int pytc_pw_mlp_fwd(const pytc_mlp_args* a, void* stream);
+
+/* pytc_pw_mlp_fwd (w3_format = PYTC_W3_F16, forward only) for the mid-level shapes 64->128->64, 128->256->64 and 128->256->128, as a
+ * PERSISTENT kernel with both weight images resident in LDS (csrc/pw_mlp_lds_kernels.hip): a workgroup stages the images once and
+ * walks a contiguous share of the (sample, row tile) sequence; results are bit-identical to pytc_pw_mlp_fwd.  Same reference
+ * boundary as pytc_pw_mlp_fwd (MedNeXtBlock.forward: norm -> conv2 -> act -> conv3 -> + x). */
+int pytc_pw_mlp_lds_supported(int C_in, int C_hid, int C_out);
+int pytc_pw_mlp_lds_fwd(const pytc_mlp_args* a, void* stream);
 /* GroupNorm finalize + fold into the mixer's expanding conv, one launch (replaces pytc_groupnorm_finalize in front of an
  * inference mixer: MedNeXtBlock.norm followed by conv2, external nnunet_mednext block; contract at mednext_models.py:99-126):
  *   a_n = gamma * rstd_n, b_n = beta - mean_n * a_n   from stats [N][slots][2][C] (fixed summation order per sample),

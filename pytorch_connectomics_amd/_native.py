@@ -224,6 +224,8 @@ _SIGS = {
     "pytc_pack_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "pytc_pw_pack_weight_paired_f16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pytc_pw_mlp_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p]),
+    "pytc_pw_mlp_lds_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "pytc_pw_mlp_lds_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p]),
     "pytc_pw_mlp_stemres_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pytc_stem_dwconv3d_stat_slots": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pytc_stem_dwconv3d_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),

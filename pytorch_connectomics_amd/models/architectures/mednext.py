@@ -181,6 +181,11 @@ class HipBlockOps:
         # two 1x1x1 convs as two LDS-tiled GEMM launches (ops.pw_gemm) instead of the fused mixer: bit-identical, and the deep levels
         # stop leaving most SIMDs idle.  0 switches the path off.
         self.deep_gemm_rows = int(os.environ.get("PYTC_DEEP_GEMM_ROWS", "32768"))
+        # bf16 blocks of the mid-level shapes (ops.pw_mlp_lds_supported: 64->128->64, 128->256->64, 128->256->128, 64->128->32) with at
+        # least this many voxel rows in the batch run the PERSISTENT mixer whose weight images stay in LDS (pw_mlp_lds_kernels.hip):
+        # bit-identical, 15 ... 35 % faster at 8 windows; below the threshold staging the images costs more than it saves (5 x 14^3:
+        # 27 against 19 us).  0 switches the path off.
+        self.lds_mixer_rows = int(os.environ.get("PYTC_LDS_MIXER_ROWS", "131072"))
 
     # ---- parameter repacking (load time / after optimizer steps) -----------------------------
     def _taps(self, conv: nn.Module):
@@ -439,6 +444,9 @@ def _block_fused(self, m, x, t, ab, skip, ishape, oshape, c_hid, c_out, out=None
         w2, b2 = self._pw_paired(m.conv2), self._vec(m.conv2, "bias", m.conv2.bias)
     w3, b3 = self._pw_paired(m.conv3, project=True), self._vec(m.conv3, "bias", m.conv3.bias)
     kw = dict(N=N, rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out)
+    if (self.lds_mixer_rows and N * rows >= self.lds_mixer_rows and w3.dtype == torch.float16
+            and ops.pw_mlp_lds_supported(C, c_hid, c_out)):
+        kw["lds"] = True
     if out is not None:
         if tuple(out.shape) != (N, Do, Ho, Wo, c_out):
             raise ValueError(f"block output buffer {tuple(out.shape)} != {(N, Do, Ho, Wo, c_out)}")

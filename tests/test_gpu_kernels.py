@@ -332,6 +332,68 @@ def test_deep_level_gemm_pair_is_bit_identical_to_the_fused_mixer(dev, cin, chid
     assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
 
 
+@pytest.mark.parametrize("cin,chid,cout,mode,N,grid", [(64, 128, 64, "add", 3, (19, 19, 19)), (128, 256, 64, "up", 5, (14, 14, 14)),
+                                                       (128, 256, 128, "add", 2, (13, 11, 9)), (64, 128, 32, "up", 3, (18, 16, 22)),
+                                                       (64, 128, 64, "none", 1, (40, 40, 40)), (128, 256, 64, "up", 1, (2, 2, 2)),
+                                                       (128, 256, 128, "add", 8, (28, 28, 28))])
+@pytest.mark.parametrize("folded", [True, False])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+def test_lds_resident_mixer_is_bit_identical(dev, cin, chid, cout, mode, N, grid, folded, variant):
+    """ops.pw_mlp(lds=True) -- the persistent mixer with both weight images in LDS (round 4, pw_mlp_lds_kernels.hip) -- against the
+    streaming kernel: same MFMA order, GELU and epilogue, hence equal BITS; ragged last tiles, shares of the (sample, tile) sequence
+    that cross samples (per-sample images re-staged), fewer tiles than workgroups, every launch variant."""
+    from pytorch_connectomics_amd import _native as nat
+    from pytorch_connectomics_amd import hip_ops as ops
+    assert ops.pw_mlp_lds_supported(cin, chid, cout) and not ops.pw_mlp_lds_supported(32, 64, 32)
+    torch.manual_seed(cin + grid[0])
+    bf = torch.bfloat16
+    rows = grid[0] * grid[1] * grid[2]
+    t = torch.randn(N, rows, cin, device=dev).to(bf)
+    w2f = torch.randn(chid, cin, device=dev) / cin ** 0.5
+    w3 = ops.pw_pack_weight_paired(torch.randn(cout, chid, device=dev) / chid ** 0.5, f16=True)
+    b3 = torch.randn(cout, device=dev) * 0.5
+    if folded:
+        ab = None
+        w2 = torch.stack([ops.pw_pack_weight_paired(w2f * (1 + 0.25 * n)) for n in range(N)])
+        b2 = torch.randn(N, chid, device=dev) * 0.5
+    else:
+        ab = torch.stack([torch.rand(N, cin, device=dev) + 0.5, torch.randn(N, cin, device=dev) * 0.5], 1).contiguous()
+        w2, b2 = ops.pw_pack_weight_paired(w2f), torch.randn(chid, device=dev) * 0.5
+    kw = dict(N=N, rows_per_sample=rows, c_in=cin, c_hid=chid, c_out=cout)
+    res = torch.randn(N, rows, cout, device=dev).to(bf)
+    if mode == "add":
+        kw.update(res=res, res_mode=nat.RES_ADD)
+    elif mode == "up":
+        low = torch.randn(N, rows // 8, cout, device=dev).to(bf)
+        kw.update(res=res, res_mode=nat.RES_UPSAMPLE, grid=grid, res_low=low, res_bias=b3)
+    want = ops.pw_mlp(t, ab, w2, b2, w3, b3, **kw)
+    got = torch.full_like(want, float("nan"))
+    ops.set_tuning("mlp_lds_variant", variant)
+    try:
+        ops.pw_mlp(t, ab, w2, b2, w3, b3, y=got, lds=True, **kw)
+    finally:
+        ops.set_tuning("mlp_lds_variant", 0)
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+
+
+def test_lds_resident_mixer_refuses_what_it_does_not_cover(dev):
+    from pytorch_connectomics_amd import _native as nat
+    from pytorch_connectomics_amd import hip_ops as ops
+    t = torch.zeros(1, 64, 32, device=dev, dtype=torch.bfloat16)
+    ab = torch.zeros(1, 2, 32, device=dev)
+    z = torch.zeros(64, device=dev)
+    w = torch.zeros(64, 32, device=dev)
+    with pytest.raises(RuntimeError, match="no LDS-resident kernel"):
+        ops.pw_mlp(t, ab, ops.pw_pack_weight_paired(w), z, ops.pw_pack_weight_paired(w.t().contiguous(), f16=True), z[:32], N=1,
+                   rows_per_sample=64, c_in=32, c_hid=64, c_out=32, lds=True)
+    t = torch.zeros(1, 64, 64, device=dev, dtype=torch.bfloat16)
+    ab = torch.zeros(1, 2, 64, device=dev)
+    w2 = torch.zeros(128, 64, device=dev)
+    with pytest.raises(RuntimeError, match="must be fp16"):
+        ops.pw_mlp(t, ab, ops.pw_pack_weight_paired(w2), torch.zeros(128, device=dev), ops.pw_pack_weight_paired(w2.t().contiguous()),
+                   z, N=1, rows_per_sample=64, c_in=64, c_hid=128, c_out=64, lds=True)
+
+
 def test_packed_fp16_gelu_accuracy(dev):
     """gelu_h2 (csrc/pytc_common.h) through the fused mixer: identity-like first GEMM, one-hot projection, so the output is
     bf16(gelu_h2(x)) for a dense sweep of x.  Error budget: polynomial fit 1e-4 + fp16 evaluation, then the bf16 output
