@@ -7,6 +7,7 @@ is raised.  The library is built in-tree by ``python -m pytorch_connectomics_amd
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libpytc_hip.so"
@@ -276,6 +277,11 @@ def lib():
     if handle.pytc_abi_version() != 1:
         raise RuntimeError("libpytc_hip.so ABI version mismatch; rebuild the library")
     _lib = handle
+    # PYTC_TUNING="knob=value,knob=value": kernel-variant knobs (pytc_set_tuning) for A/B runs of unmodified commands
+    for item in filter(None, (t.strip() for t in os.environ.get("PYTC_TUNING", "").split(","))):
+        key, _, val = item.partition("=")
+        if handle.pytc_set_tuning(key.strip().encode(), int(val)) != OK:
+            raise RuntimeError(f"PYTC_TUNING: cannot set {item!r}")
     return _lib
 
 

@@ -24,12 +24,13 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-re
 
 # per-file extra flags (packed-fp32 VALU results were observed corrupted when kernels of two HIP
 # streams share a SIMD, so the compiler's SLP vectoriser -- the only source of v_pk_*_f32 in compiler-generated code -- is off)
-_NO_SLP = os.environ.get("PYTC_NO_SLP_FILES", "dwconv_kernels.hip,train_kernels.hip,rsunet_train_kernels.hip,"
+_NO_SLP = os.environ.get("PYTC_NO_SLP_FILES", "dwconv_kernels.hip,dwconv_mfma_kernels.hip,train_kernels.hip,rsunet_train_kernels.hip,"
                          "conv3d_strided_kernels.hip,loss_optim_kernels.hip,volume_kernels.hip")
 EXTRA_FLAGS = {p.name: ["-fno-slp-vectorize"] for p in Path(__file__).resolve().parent.glob("*.hip")
                if _NO_SLP == "all" or p.name in _NO_SLP.split(",")}
 
-NO_SPILL_KERNELS = {"dwconv_kernels.hip": ("dwconv3d_k3_march_kernel", "dw_wgrad_march_kernel")}
+NO_SPILL_KERNELS = {"dwconv_kernels.hip": ("dwconv3d_k3_march_kernel", "dw_wgrad_march_kernel"),
+                    "dwconv_mfma_kernels.hip": ("dwconv3d_k3_mfma_kernel",)}
 
 
 def _check_no_spills(fname: str, remarks: str, patterns) -> None:

@@ -4,6 +4,7 @@
 // reduced in a fixed order by groupnorm_finalize -> bit-reproducible, no float atomics.
 #include <type_traits>
 #include "pytc_common.h"
+#include "dwconv_march.h"
 
 namespace pytc {
 
@@ -467,13 +468,7 @@ dwconvT3d_k3_cell_kernel(const T* __restrict__ x, T* __restrict__ y, const float
 constexpr int TILE_Y = 8, TILE_X = 8;
 constexpr int MARCH_CG = 32;
 
-struct DwMarch {
-  int N, D, H, W, C;
-  int ty, tx, zc, nzc;   // footprints per axis, z-chunk length, z-chunks
-  int tilex;             // x extent of a footprint (8, or 16 for the 512-thread forward variant)
-  int slots;             // workgroups per (sample, channel group)
-  int swizzle;           // XCD-aware block remap on/off
-};
+// struct DwMarch: dwconv_march.h (shared with dwconv_mfma_kernels.hip)
 
 // RES: y = conv(x) + res (res laid out like y).  The training backward uses it for the data gradient of a residual block,
 // dx = conv_reversed(dt) + dy: the separate read-modify-write pass over dx (add_inplace: 3 tensor passes, 1.8 ms of a
@@ -516,10 +511,13 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
   // 1-D grid, XCD-aware: logical index = ((n * CGs + cg) * slots + slot); x-/y-neighbouring footprints
   // (which share halo columns) are consecutive logical indices -> same XCD, same L2
   int b = g.swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
-  const int slot_id = b % g.slots; b /= g.slots;
+  // channel groups innermost: the workgroups that split a voxel's channels (64 bytes each of its 128-byte lines) are dispatched back
+  // to back on one XCD, so the second one finds the lines in L2 (slot-major order fetched every line of a C >= 64 level twice:
+  // 56^3 x 64 at 2.4 TB/s against 3.4 at C = 32, profiles/r04_dwconv_mfma.txt)
   const int ncg = g.C / MARCH_CG;
-  const int cg = b % ncg;
-  const int n = b / ncg;
+  const int cg = g.cg_inner ? b % ncg : (b / g.slots) % ncg;
+  const int slot_id = g.cg_inner ? (b / ncg) % g.slots : b % g.slots;
+  const int n = b / (ncg * g.slots);
   b = slot_id;
   const int fx = b % g.tx; b /= g.tx;
   const int fy = b % g.ty;
@@ -856,7 +854,7 @@ static bool march_ok(int D, int H, int W, int C, int K, int stride, int dtype, i
 
 // the forward kernel's footprint: 8 x 16 where the rows divide into whole 16-voxel tiles (level 0: W = 112), 8 x 8 otherwise
 static int march_tile_x(int W, int dtype) {
-  return (dtype == PYTC_BF16 && W % 16 == 0 && tuning_get("dwconv_march_tx16", 0) != 0) ? 16 : TILE_X;
+  return (dtype == PYTC_BF16 && W % 16 == 0 && tuning_get("dwconv_march_tx16", 0) != 0 && tuning_get("dwconv_mfma", 1) == 0) ? 16 : TILE_X;
 }
 
 static void make_march(DwMarch& t, int N, int D, int H, int W, int C, int tilex = TILE_X) {
@@ -902,10 +900,13 @@ dw_wgrad_march_kernel(const T* __restrict__ gr, const T* __restrict__ x, float* 
 
   const int tid = threadIdx.x;
   int b = g.swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
-  const int slot_id = b % g.slots; b /= g.slots;
+  // channel groups innermost: the workgroups that split a voxel's channels (64 bytes each of its 128-byte lines) are dispatched back
+  // to back on one XCD, so the second one finds the lines in L2 (slot-major order fetched every line of a C >= 64 level twice:
+  // 56^3 x 64 at 2.4 TB/s against 3.4 at C = 32, profiles/r04_dwconv_mfma.txt)
   const int ncg = g.C / MARCH_CG;
-  const int cg = b % ncg;
-  const int n = b / ncg;
+  const int cg = g.cg_inner ? b % ncg : (b / g.slots) % ncg;
+  const int slot_id = g.cg_inner ? (b / ncg) % g.slots : b % g.slots;
+  const int n = b / (ncg * g.slots);
   b = slot_id;
   const int fx = b % g.tx; b /= g.tx;
   const int fy = b % g.ty;
@@ -1124,6 +1125,7 @@ void dw_wgrad_march_launch(const void* gr, const void* x, float* dWp, float* dbp
   DwMarch t;
   make_wgrad_march(t, N, D, H, W, C);
   t.swizzle = tuning_get("dwconv_xcd_swizzle", 1);
+  t.cg_inner = tuning_get("dwconv_cg_inner", 1);
   dim3 grid((unsigned)((long)t.slots * (C / MARCH_CG) * N)), block(256);
   if (dtype == PYTC_BF16)
     hipLaunchKernelGGL(dw_wgrad_march_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)gr, (const bf16_t*)x, dWp, dbp, t);
@@ -1299,6 +1301,14 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
     make_march(t, N, D, H, W, C, wide_tile ? 16 : TILE_X);
     dim3 grid((unsigned)((long)t.slots * (C / MARCH_CG) * N)), block(wide_tile ? 512 : 256);
     t.swizzle = tuning_get("dwconv_xcd_swizzle", 1);
+  t.cg_inner = tuning_get("dwconv_cg_inner", 1);
+    // bf16 forward launches (activations: statistics, no residual): the matrix-core form (dwconv_mfma_kernels.hip) -- one channel per
+    // block of v_mfma_f32_4x4x4_16b_bf16, fp32 accumulation.  The gradient entries (res / wide range) keep the fp32-tap VALU kernels.
+    if (dtype == PYTC_BF16 && !res && !wide_range && y && tuning_get("dwconv_mfma", 1) != 0) {
+      dwconv_mfma_launch(x, y, w, bias, stats, t, tuning_get("dwconv_mfma_variant", 0), (hipStream_t)stream);
+      PYTC_LAUNCH_CHECK("dwconv3d_k3_mfma");
+      return PYTC_OK;
+    }
     // variants (all: taps in LDS, hand-scheduled tap loop, asm plane loads with counted waits):
     //   0 (default) PF=3 compiled for 4 waves/SIMD; 1: PF=3, 3 waves; 2: PF=3, 2 waves; 3: PF=2, 3 waves
     const int variant = tuning_get("dwconv_march_variant", 0);
@@ -1374,7 +1384,7 @@ extern "C" int pytc_dwconv3d_stat_slots(int N, int D, int H, int W, int C, int K
 
 extern "C" int pytc_dwconv3d_kernel_variant(int N, int D, int H, int W, int C, int K, int stride, int dtype, int transposed) {
   // mirrors dw_entry / launch_dw: which kernel family a call with these arguments dispatches to
-  if (march_ok(D, H, W, C, K, stride, dtype, transposed)) return 3;
+  if (march_ok(D, H, W, C, K, stride, dtype, transposed)) return (dtype == PYTC_BF16 && tuning_get("dwconv_mfma", 1) != 0) ? 6 : 3;
   DwGeom g;
   int vec;
   if (!make_geom(g, N, D, H, W, C, K, stride, dtype, transposed, vec)) return -1;

@@ -1,0 +1,21 @@
+// Geometry of the z-march depthwise kernels (dwconv_kernels.hip: VALU forms; dwconv_mfma_kernels.hip: matrix-core form).
+#pragma once
+#include "pytc_common.h"
+
+namespace pytc {
+
+struct DwMarch {
+  int N, D, H, W, C;
+  int ty, tx, zc, nzc;   // footprints per axis, z-chunk length, z-chunks
+  int tilex;             // x extent of a footprint (8, or 16 for the 512-thread forward variant)
+  int slots;             // workgroups per (sample, channel group)
+  int swizzle;           // XCD-aware block remap on/off
+  int cg_inner;          // block order: channel group fastest (else slot fastest)
+};
+
+// dwconv_mfma_kernels.hip: bf16, K = 3, stride 1, C % 32 == 0, 8 x 8 footprints (g.tilex == 8); grid = slots * (C / 32) * N blocks.
+// variant (knob dwconv_mfma_variant): bit 0 = hi + lo weights, bit 1 = two planes in flight; 91 / 93 = timing probes.
+void dwconv_mfma_launch(const void* x, void* y, const float* w, const float* bias, float* stats, const DwMarch& g, int variant,
+                        hipStream_t s);
+
+}  // namespace pytc

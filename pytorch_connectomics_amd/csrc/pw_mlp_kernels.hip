@@ -444,9 +444,40 @@ groupnorm_fold_mlp_kernel(const float* __restrict__ stats, int slots, float coun
   const int Q = C / 2;                        // float4 columns of one slot row: [sum C | sum of squares C]
   const int col = tid % Q, sl = tid / Q, SL = 1024 / Q;
   const float* base = stats + (long)n * slots * 2 * C + col * 4;
+  // the weight pieces this thread will scale do not depend on the statistics: request them first (their L2 latency rides under the
+  // slot loads), then ALL slot rows of a pass before the first addition -- one memory round trip per 20 * SL slots instead of a
+  // dependent chain (additions in slot order as before: same bits)
+  const int KG = C / 32;
+  const long total = (long)C_hid * C;
+  constexpr int PRE = 2;
+  f32x4_t wpre[PRE][2];
+#pragma unroll
+  for (int i = 0; i < PRE; ++i) {
+    const long e8 = tid + (long)i * 1024;
+    if (e8 < total / 8) {
+      long t = e8;
+      const int lane = (int)(t % 64);
+      t /= 64;
+      const int kg = (int)(t % KG);
+      const int o = paired_row((int)(t / KG), lane & 15);
+      const float* src = w2 + (long)o * C + kg * 32 + (lane >> 4) * 8;
+      wpre[i][0] = *reinterpret_cast<const f32x4_t*>(src);
+      wpre[i][1] = *reinterpret_cast<const f32x4_t*>(src + 4);
+    }
+  }
   f32x4_t a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int s = sl; s < slots; s += SL) a += *reinterpret_cast<const f32x4_t*>(base + (long)s * 2 * C);
+  constexpr int INFL = 20;
+  for (int s0 = sl; s0 < slots; s0 += SL * INFL) {
+    f32x4_t v[INFL];
+#pragma unroll
+    for (int i = 0; i < INFL; ++i) {
+      const int s = s0 + i * SL;
+      v[i] = s < slots ? *reinterpret_cast<const f32x4_t*>(base + (long)s * 2 * C) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < INFL; ++i)
+      if (s0 + i * SL < slots) a += v[i];
+  }
   *reinterpret_cast<f32x4_t*>(&red[tid * 4]) = a;             // red[sl][2C] as float4 columns
   __syncthreads();
   {
@@ -477,10 +508,8 @@ groupnorm_fold_mlp_kernel(const float* __restrict__ stats, int slots, float coun
     }
   }
   __syncthreads();
-  const int KG = C / 32;
-  const long total = (long)C_hid * C;
   bf16_t* img = w2n + (long)n * total;
-  for (long e8 = tid; e8 < total / 8; e8 += 1024) {           // one 16-byte fragment piece (8 consecutive k of one output row) per step
+  for (long e8 = tid, i = 0; e8 < total / 8; e8 += 1024, ++i) {   // one 16-byte fragment piece (8 consecutive k of one output row) per step
     long t = e8;
     const int lane = (int)(t % 64);
     t /= 64;
@@ -489,8 +518,17 @@ groupnorm_fold_mlp_kernel(const float* __restrict__ stats, int slots, float coun
     const int o = paired_row(T, lane & 15);
     const int k = kg * 32 + (lane >> 4) * 8;
     float v[8];
-    VecIO<float, 4>::load(w2 + (long)o * C + k, reinterpret_cast<float(&)[4]>(v[0]));
-    VecIO<float, 4>::load(w2 + (long)o * C + k + 4, reinterpret_cast<float(&)[4]>(v[4]));
+    if (i < PRE) {
+#pragma unroll
+      for (int q = 0; q < PRE; ++q)
+        if (q == i) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[j] = wpre[q][0][j]; v[4 + j] = wpre[q][1][j]; }
+        }
+    } else {
+      VecIO<float, 4>::load(w2 + (long)o * C + k, reinterpret_cast<float(&)[4]>(v[0]));
+      VecIO<float, 4>::load(w2 + (long)o * C + k + 4, reinterpret_cast<float(&)[4]>(v[4]));
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] *= sa[k + j];
     *reinterpret_cast<bf16x8_t*>(img + e8 * 8) = Mma<bf16_t>::from_floats(v);
@@ -498,7 +536,11 @@ groupnorm_fold_mlp_kernel(const float* __restrict__ stats, int slots, float coun
   for (int o = tid; o < C_hid; o += 1024) {
     float acc = b2 ? b2[o] : 0.f;
     const float* wr = w2 + (long)o * C;
-    for (int k = 0; k < C; ++k) acc = fmaf(wr[k], sb[k], acc);
+    for (int k = 0; k < C; k += 4) {                  // 16-byte loads (a lane walks its own row: 64 lines per load instruction), k ascending
+      const f32x4_t w4 = *reinterpret_cast<const f32x4_t*>(wr + k);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = fmaf(w4[j], sb[k + j], acc);
+    }
     b2n[(long)n * C_hid + o] = acc;
   }
 }

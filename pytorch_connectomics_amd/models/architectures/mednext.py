@@ -181,6 +181,8 @@ class HipBlockOps:
         # two 1x1x1 convs as two LDS-tiled GEMM launches (ops.pw_gemm) instead of the fused mixer: bit-identical, and the deep levels
         # stop leaving most SIMDs idle.  0 switches the path off.
         self.deep_gemm_rows = int(os.environ.get("PYTC_DEEP_GEMM_ROWS", "32768"))
+        # ... and so do blocks at least this wide whatever their row count (the 256 -> 512 -> 128 up block at 28^3); 0 = rows rule only
+        self.deep_gemm_cin = int(os.environ.get("PYTC_DEEP_GEMM_CIN", "0"))
         # bf16 blocks of the mid-level shapes (ops.pw_mlp_lds_supported: 64->128->64, 128->256->64, 128->256->128, 64->128->32) with at
         # least this many voxel rows in the batch run the PERSISTENT mixer whose weight images stay in LDS (pw_mlp_lds_kernels.hip):
         # bit-identical, 15 ... 35 % faster at 8 windows; below the threshold staging the images costs more than it saves (5 x 14^3:
@@ -345,7 +347,8 @@ class HipBlockOps:
                  and ops.pw_conv_paired_supported(c_in=C, c_out=c_hid, in_dtype=dt, out_dtype=dt)
                  and ops.pw_conv_paired_supported(c_in=c_hid, c_out=c_out, in_dtype=dt, out_dtype=dt))
         if (not small and self.fused and dt == torch.bfloat16 and not m.grn and not is_ln and m.conv2.bias is not None
-                and m.conv3.bias is not None and head is None and ops.MLP_F16_PROJECT and N * rows <= self.deep_gemm_rows
+                and m.conv3.bias is not None and head is None and ops.MLP_F16_PROJECT
+                and (N * rows <= self.deep_gemm_rows or (self.deep_gemm_cin and C >= self.deep_gemm_cin))
                 and ops.pw_gemm_supported(C, c_hid) and ops.pw_gemm_supported(c_hid, c_out)):
             ab = ops.groupnorm_finalize(st, count, gamma, beta, m.norm.eps)
             return self._block_deep_gemm(m, x, t, ab, skip, (N, D, H, W, C), (Do, Ho, Wo), c_hid, c_out, out)

@@ -518,6 +518,7 @@ def test_dwconv_march_packed_f16_error_budget(dev):
     def knob(v):
         nat.check(nat.lib().pytc_set_tuning(b"dwconv_march_h16", int(v)), "set_tuning")
 
+    ops.set_tuning("dwconv_mfma", 0)                   # the VALU forms (gradient entries; forward when the matrix-core form is off)
     torch.manual_seed(11)
     N, D, C = 1, 24, 64
     x = (torch.randn(N, D, D, D, C, device=dev) * 2).to(torch.bfloat16)
@@ -552,6 +553,65 @@ def test_dwconv_march_packed_f16_error_budget(dev):
         assert float((errb / (refb.abs() + 1.0)).max()) < 2e-2, float((errb / (refb.abs() + 1.0)).max())
     finally:
         knob(1)
+        ops.set_tuning("dwconv_mfma", 1)
+
+
+@pytest.mark.parametrize("N,shape,C", [(1, (9, 20, 31), 32), (2, (16, 32, 28), 64), (1, (30, 17, 16), 96), (1, (24, 24, 24), 128),
+                                       (3, (8, 16, 16), 32)])
+def test_dwconv_matrix_core_form(dev, N, shape, C):
+    """dwconv3d, bf16, K = 3, stride 1 on v_mfma_f32_4x4x4_16b_bf16 (one channel per block of the instruction; round 4,
+    csrc/dwconv_mfma_kernels.hip) against an fp64 convolution of the same bf16 operands.  hi + lo weight instructions (variant bit 0):
+    fp32-weight accuracy -- the mean error is the bf16 rounding of the exact result; hi only (default): bf16 weights, what
+    torch.autocast gives the reference's Conv3d -- within 1.8x of that floor (27 taps of 2^-9 relative weight error each).  Activations are used as stored: no range clamp (3e5 is
+    exact), fp32 accumulation.  Planes in flight (bit 1) do not change a bit; statistics are those of the stored tensor; ragged
+    footprints, several channel groups, several z chunks, batch-invariant results."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(C + shape[0])
+    x = (torch.randn(N, *shape, C, device=dev) * 2).to(torch.bfloat16)
+    taps = torch.randn(27, C, device=dev) * 0.3
+    b = torch.randn(C, device=dev) * 0.1
+    w64 = taps.t().reshape(C, 1, 3, 3, 3).double().cpu()
+
+    def conv64(t, w, bias):
+        return F.conv3d(t.double().cpu().permute(0, 4, 1, 2, 3), w, bias, padding=1, groups=C).permute(0, 2, 3, 4, 1)
+
+    ref, mag = conv64(x, w64, b.double().cpu()), conv64(x.abs(), w64.abs(), b.double().cpu().abs())
+    floor = float((ref.float().to(torch.bfloat16).double() - ref).abs().mean())
+    spiky = x.clone()
+    spiky[0, 3, 5, 5, :] = 3.0e5                                          # beyond f16, exact in bf16
+    spiky[0, 4, 9, 9, :] = -3.0e5
+    ref_s, mag_s = conv64(spiky, w64, b.double().cpu()), conv64(spiky.abs(), w64.abs(), b.double().cpu().abs())
+    out = {}
+    try:
+        from pytorch_connectomics_amd import _native as nat
+        assert nat.lib().pytc_dwconv3d_kernel_variant(N, *shape, C, 3, 1, nat.BF16, 0) == 6
+        for v in (0, 1, 2, 3):
+            ops.set_tuning("dwconv_mfma_variant", v)
+            y, st = ops.dwconv3d(x, taps, b, K=3)
+            out[v] = y.double().cpu()
+            err = (out[v] - ref).abs()
+            assert float(err.mean()) < (1.02 if v & 1 else 1.8) * floor, (v, float(err.mean()), floor)
+            assert float((err / (mag + 1.0)).max()) < (2.0 ** -8 if v & 1 else 2.0 ** -7), (v, float((err / (mag + 1.0)).max()))
+            s = st.sum(1).cpu().double()
+            torch.testing.assert_close(s[:, 0], out[v].sum((1, 2, 3)), rtol=1e-4, atol=1e-2)
+            torch.testing.assert_close(s[:, 1], (out[v] * out[v]).sum((1, 2, 3)), rtol=1e-4, atol=1e-2)
+            ys, _ = ops.dwconv3d(spiky, taps, b, K=3)                     # no clamp, no overflow: error relative to sum |w| |x|
+            assert bool(torch.isfinite(ys.float()).all())
+            errs = (ys.double().cpu() - ref_s).abs()
+            assert float((errs / (mag_s + 1.0)).max()) < (2.0 ** -8 if v & 1 else 2.0 ** -7), (v, float((errs / (mag_s + 1.0)).max()))
+        assert torch.equal(out[0], out[2]) and torch.equal(out[1], out[3])
+        ops.set_tuning("dwconv_mfma_variant", 0)
+        if N > 1:                                                         # a sample's result and statistics do not depend on its batch
+            y1, st1 = ops.dwconv3d(x[1:2].contiguous(), taps, b, K=3)
+            yN, stN = ops.dwconv3d(x, taps, b, K=3)
+            assert torch.equal(y1[0], yN[1]) and torch.equal(st1[0], stN[1])
+        ops.set_tuning("dwconv_mfma", 0)                                  # and the VALU z-march agrees to the rounding of either
+        yv, _ = ops.dwconv3d(x, taps, b, K=3)
+        dv = (yv.double().cpu() - out[1]).abs()
+        assert float(dv.mean()) < 0.6 * floor
+    finally:
+        ops.set_tuning("dwconv_mfma_variant", 0)
+        ops.set_tuning("dwconv_mfma", 1)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
