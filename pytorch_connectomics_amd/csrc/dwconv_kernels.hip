@@ -1283,16 +1283,26 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
       return PYTC_ERR_UNSUPPORTED;
     }
   }
-  if (!y) {   // statistics-only pass: the K = 3 transposed cell kernel (what the fused up-block path launches)
+  const bool tt_form = transposed && K == 3 && dtype == PYTC_BF16 && (C == 64 || C == 128) && tuning_get("dwconvT_tile", 1) != 0;
+  if (!y && !tt_form) {   // statistics-only pass: the K = 3 transposed kernels (what the fused up-block path launches)
     DwGeom g0;
     int vec0;
     PYTC_REQUIRE(transposed && K == 3 && stats && make_geom(g0, N, D, H, W, C, K, stride, dtype, transposed, vec0) && g0.cell,
-                 "dwconv3d: a null output (statistics only) is supported by the K = 3 transposed cell kernel only");
+                 "dwconv3d: a null output (statistics only) is supported by the K = 3 transposed kernels only");
   }
   PYTC_REQUIRE(N >= 1 && D >= 1 && H >= 1 && W >= 1 && C >= 1, "dwconv3d: bad shape");
   PYTC_REQUIRE(stride == 1 || stride == 2, "dwconv3d: stride must be 1 or 2");
   PYTC_REQUIRE(dtype == PYTC_F32 || dtype == PYTC_BF16, "dwconv3d: bad dtype");
   PYTC_REQUIRE(!(wide_range && stats), "dwconv3d_fwd_wide: the gradient entry computes no statistics");
+  if (tt_form) {          // the up blocks' resampling conv at C = 64 / 128: one tile of input cells per workgroup (dwconvT_tile_kernels.hip)
+    PYTC_REQUIRE(y || stats, "dwconvT3d: neither output nor statistics requested");
+    DwTTile tt;
+    if (dwconvT_tile_plan(tt, N, D, H, W, C)) {
+      dwconvT_tile_launch(x, y, w, bias, stats, tt, (hipStream_t)stream);
+      PYTC_LAUNCH_CHECK("dwconvT3d_k3_tile");
+      return PYTC_OK;
+    }
+  }
   if (march_ok(D, H, W, C, K, stride, dtype, transposed)) {
     DwMarch t;
     // the 8 x 16 / 512-thread footprint serves the plain packed-f16 forward (the launches that carry statistics, so the slot
@@ -1376,6 +1386,10 @@ extern "C" int pytc_dwconv3d_stat_slots(int N, int D, int H, int W, int C, int K
     make_march(t, N, D, H, W, C, tuning_get("dwconv_march_h16", 1) != 0 ? march_tile_x(W, dtype) : TILE_X);
     return t.slots;
   }
+  if (transposed && K == 3 && dtype == PYTC_BF16 && (C == 64 || C == 128) && tuning_get("dwconvT_tile", 1) != 0) {
+    DwTTile tt;
+    if (dwconvT_tile_plan(tt, N, D, H, W, C)) return tt.slots;
+  }
   DwGeom g;
   int vec;
   if (!make_geom(g, N, D, H, W, C, K, stride, dtype, transposed, vec)) return -1;
@@ -1388,6 +1402,7 @@ extern "C" int pytc_dwconv3d_kernel_variant(int N, int D, int H, int W, int C, i
   DwGeom g;
   int vec;
   if (!make_geom(g, N, D, H, W, C, K, stride, dtype, transposed, vec)) return -1;
+  if (transposed && K == 3 && dtype == PYTC_BF16 && (C == 64 || C == 128) && tuning_get("dwconvT_tile", 1) != 0) return 7;
   if (transposed) return g.cell ? 4 : 5;
   const size_t taps = (size_t)K * K * K * C * sizeof(float);
   if ((K == 3 || K == 5 || K == 7) && taps <= 64 * 1024 && tuning_get("dwconv_gather", 1) != 0)

@@ -18,4 +18,9 @@ struct DwMarch {
 void dwconv_mfma_launch(const void* x, void* y, const float* w, const float* bias, float* stats, const DwMarch& g, int variant,
                         hipStream_t s);
 
+// dwconvT_tile_kernels.hip: transposed K = 3 / stride 2 conv, bf16, C = 64 / 128, one tile of input cells per workgroup
+struct DwTTile { int N, D, H, W, C, tz, ty, tx, slots; };
+bool dwconvT_tile_plan(DwTTile& g, int N, int D, int H, int W, int C);
+void dwconvT_tile_launch(const void* x, void* y, const float* w, const float* bias, float* stats, const DwTTile& g, hipStream_t s);
+
 }  // namespace pytc

@@ -556,6 +556,35 @@ def test_dwconv_march_packed_f16_error_budget(dev):
         ops.set_tuning("dwconv_mfma", 1)
 
 
+@pytest.mark.parametrize("N,shape,C", [(2, (5, 9, 11), 64), (1, (8, 8, 16), 128), (3, (3, 4, 7), 128), (1, (14, 14, 14), 64)])
+def test_dwconv_transposed_tile_form_is_bit_identical_to_the_cell_kernel(dev, N, shape, C):
+    """The up blocks' transposed depthwise conv at C = 64 / 128 (round 4, csrc/dwconvT_tile_kernels.hip: one tile of input cells per
+    workgroup, taps in registers, no load after the first store) against the cell kernel (knob dwconvT_tile = 0): the same fp32 FMAs in
+    the same order, hence equal BITS; statistics equal to summation order; ragged tiles, several samples, the statistics-only mode."""
+    from pytorch_connectomics_amd import _native as nat
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(C + shape[2])
+    x = torch.randn(N, *shape, C, device=dev).to(torch.bfloat16)
+    taps = torch.randn(27, C, device=dev) * 0.3
+    b = torch.randn(C, device=dev) * 0.2
+    assert nat.lib().pytc_dwconv3d_kernel_variant(N, *shape, C, 3, 2, nat.BF16, 1) == 7
+    try:
+        y1, st1 = ops.dwconv3d(x, taps, b, K=3, transposed=True)
+        y_none, st_only = ops.dwconv3d(x, taps, b, K=3, transposed=True, store=False)
+        ops.set_tuning("dwconvT_tile", 0)
+        assert nat.lib().pytc_dwconv3d_kernel_variant(N, *shape, C, 3, 2, nat.BF16, 1) == 4
+        y0, st0 = ops.dwconv3d(x, taps, b, K=3, transposed=True)
+    finally:
+        ops.set_tuning("dwconvT_tile", 1)
+    assert y1.shape == (N, 2 * shape[0], 2 * shape[1], 2 * shape[2], C) and y_none is None
+    assert torch.equal(y1, y0), float((y1.float() - y0.float()).abs().max())
+    torch.testing.assert_close(st1.sum(1), st0.sum(1), rtol=1e-5, atol=1e-3)
+    assert torch.equal(st_only, st1)
+    yf = y1.float()
+    torch.testing.assert_close(st1.sum(1)[:, 0], yf.sum((1, 2, 3)), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(st1.sum(1)[:, 1], (yf * yf).sum((1, 2, 3)), rtol=1e-4, atol=1e-2)
+
+
 @pytest.mark.parametrize("N,shape,C", [(1, (9, 20, 31), 32), (2, (16, 32, 28), 64), (1, (30, 17, 16), 96), (1, (24, 24, 24), 128),
                                        (3, (8, 16, 16), 32)])
 def test_dwconv_matrix_core_form(dev, N, shape, C):
