@@ -561,8 +561,11 @@ def _kernel_key(label):
     kernels that run at several shapes have no counter average of their own."""
     import re
     m = re.match(r"pw_mlp_fwd\[(\d+)->(\d+)->(\d+)\]", label)
+    if m:      # streaming or LDS-resident form (pw_mlp_lds_kernel<KS_IN, MO, NT, NWAVES, WPS>): whichever the shape runs on
+        return re.compile(rf"pw_mlp(_lds)?_kernel<{int(m.group(1)) // 32}, {int(m.group(3)) // 16},")
+    m = re.match(r"pw_mlp_lds_kernel<(\d+), (\d+)>$", label)
     if m:
-        return f"pw_mlp_kernel<{int(m.group(1)) // 32}, {int(m.group(3)) // 16},"
+        return re.compile(rf"pw_mlp_lds_kernel<{m.group(1)}, {m.group(2)},")
     # one template INSTANCE of the fused mixer = one rocprof symbol (hip_ops gives every launch its instance: plain, +head, +stemres):
     # <KS_IN, MO, NT, GELU_MODE, HEAD, STEMRES, STOREH, BWD>
     m = re.match(r"pw_mlp_kernel<(\d+), (\d+)>(\+head|\+stemres)?$", label)

@@ -14,8 +14,11 @@ def _bench():
 
 def test_counter_traffic_of_the_dominant_kernel():
     b = _bench()
-    assert b._kernel_key("pw_mlp_fwd[32->64->32]") == "pw_mlp_kernel<1, 2,"
-    assert b._kernel_key("pw_mlp_fwd[64->128->32]") == "pw_mlp_kernel<2, 2,"
+    k = b._kernel_key("pw_mlp_fwd[32->64->32]")          # streaming or LDS-resident form of the shape
+    assert k.search("void pytc::pw_mlp_kernel<1, 2, 4, 3, false, false, false, false>") and not k.search("pw_mlp_kernel<1, 4, 4,")
+    k = b._kernel_key("pw_mlp_fwd[64->128->32]")
+    assert k.search("pytc::pw_mlp_lds_kernel<2, 2, 2, 16, 4>") and k.search("pw_mlp_kernel<2, 2, 4, 3,") and not k.search("pw_mlp_lds_kernel<2, 4,")
+    assert b._kernel_key("pw_mlp_lds_kernel<2, 4>").search("void pytc::pw_mlp_lds_kernel<2, 4, 2, 12, 3>(pytc::MlpLdsParams)")
     assert b._kernel_key("dwconv3d_fwd[C32_k3]") is None          # runs at several shapes under one name: no per-shape average
     t = b.pmc_traffic_bytes("pw_mlp_fwd[32->64->32]")              # committed rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE)
     alg = 3 * 32 * 2 * 8 * 112 ** 3                                # t + residual + y of a plain launch
