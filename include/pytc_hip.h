@@ -197,7 +197,7 @@ int pytc_dwconv3d_stat_slots(int N, int D, int H, int W, int C, int K, int strid
 /* which kernel family pytc_dwconv3d_fwd / pytc_dwconvT3d_fwd runs for this problem (measurement bookkeeping only:
  * bench.py groups its per-launch timings by device kernel): 0 direct, 1 K=3/5/7 gather, 2 x-block, 3 z-march,
  * 4 transposed 2x2x2-cell, 5 transposed direct, 6 z-march on the matrix cores (bf16 forward),
- * 7 transposed tile form (bf16, C = 64 / 128); -1 unsupported channel count */
+ * 7 transposed tile form (bf16, C = 64 / 128), 8 stride-2 z-march (bf16, C = 32 / 64); -1 unsupported channel count */
 int pytc_dwconv3d_kernel_variant(int N, int D, int H, int W, int C, int K, int stride, int dtype, int transposed);
 
 /* Depthwise Conv3d (groups == C), kernel K^3 (3/5/7), padding K/2, stride 1 or 2, fused with the

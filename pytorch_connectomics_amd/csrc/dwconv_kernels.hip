@@ -1303,6 +1303,14 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
       return PYTC_OK;
     }
   }
+  if (!transposed && K == 3 && stride == 2 && dtype == PYTC_BF16 && y && tuning_get("dwconv_s2_march", 1) != 0) {
+    DwS2 t2;          // the down blocks' resampling conv at C = 32 / 64: z-march over an LDS ring (dwconv_s2_kernels.hip)
+    if (dwconv_s2_plan(t2, N, D, H, W, C)) {
+      dwconv_s2_launch(x, y, w, bias, stats, t2, (hipStream_t)stream);
+      PYTC_LAUNCH_CHECK("dwconv3d_k3_s2_march");
+      return PYTC_OK;
+    }
+  }
   if (march_ok(D, H, W, C, K, stride, dtype, transposed)) {
     DwMarch t;
     // the 8 x 16 / 512-thread footprint serves the plain packed-f16 forward (the launches that carry statistics, so the slot
@@ -1390,6 +1398,10 @@ extern "C" int pytc_dwconv3d_stat_slots(int N, int D, int H, int W, int C, int K
     DwTTile tt;
     if (dwconvT_tile_plan(tt, N, D, H, W, C)) return tt.slots;
   }
+  if (!transposed && K == 3 && stride == 2 && dtype == PYTC_BF16 && tuning_get("dwconv_s2_march", 1) != 0) {
+    DwS2 t2;
+    if (dwconv_s2_plan(t2, N, D, H, W, C)) return t2.slots;
+  }
   DwGeom g;
   int vec;
   if (!make_geom(g, N, D, H, W, C, K, stride, dtype, transposed, vec)) return -1;
@@ -1403,6 +1415,7 @@ extern "C" int pytc_dwconv3d_kernel_variant(int N, int D, int H, int W, int C, i
   int vec;
   if (!make_geom(g, N, D, H, W, C, K, stride, dtype, transposed, vec)) return -1;
   if (transposed && K == 3 && dtype == PYTC_BF16 && (C == 64 || C == 128) && tuning_get("dwconvT_tile", 1) != 0) return 7;
+  if (!transposed && K == 3 && stride == 2 && dtype == PYTC_BF16 && (C == 32 || C == 64) && tuning_get("dwconv_s2_march", 1) != 0) return 8;
   if (transposed) return g.cell ? 4 : 5;
   const size_t taps = (size_t)K * K * K * C * sizeof(float);
   if ((K == 3 || K == 5 || K == 7) && taps <= 64 * 1024 && tuning_get("dwconv_gather", 1) != 0)

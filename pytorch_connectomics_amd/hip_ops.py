@@ -329,7 +329,7 @@ def dwconv3d(x: torch.Tensor, w_taps: torch.Tensor, bias: Optional[torch.Tensor]
 
 _DW_VARIANTS = {0: "dwconv3d_direct_kernel", 1: "dwconv3d_k3_gather_kernel", 2: "dwconv3d_xblock_kernel",
                 3: "dwconv3d_k3_march_kernel", 4: "dwconvT3d_k3_cell_kernel", 5: "dwconvT3d_kernel",
-                6: "dwconv3d_k3_mfma_kernel", 7: "dwconvT3d_k3_tile_kernel"}
+                6: "dwconv3d_k3_mfma_kernel", 7: "dwconvT3d_k3_tile_kernel", 8: "dwconv3d_k3_s2_march_kernel"}
 
 
 def dwconv3d_res_supported(x: torch.Tensor, K: int, stride: int = 1) -> bool:

@@ -171,7 +171,7 @@ class HipBlockOps:
         # Bit-identical to the un-fused schedule and 1.9x less HBM traffic, but MEASURED SLOWER on MI355X (level 0, 8 x 112^3:
         # 1.33 + 0.27 ms against 1.03 + 0.49 ms; profiles/r02_upfuse.txt): the mixer is bound by its VALU work (GELU), not by
         # HBM, and the prologue adds 20 % more of it -- off by default, kept as the switch for when the activation gets cheaper.
-        self.fuse_up = False
+        self.fuse_up = os.environ.get("PYTC_FUSE_UP", "0") == "1"
         self.fuse_up_cin = (64, 128)       # input widths the fused up kernel is used for (A/B switch for measurements)
         # bf16 fused mixers at C_in <= 128: GroupNorm's affine folded into the expanding conv per sample (ops.groupnorm_fold_mlp in
         # the place of groupnorm_finalize), the mixer loads its operand raw.  Round 4: the mixers are bound by VALU issue and the

@@ -556,6 +556,36 @@ def test_dwconv_march_packed_f16_error_budget(dev):
         ops.set_tuning("dwconv_mfma", 1)
 
 
+@pytest.mark.parametrize("N,shape,C", [(2, (9, 20, 31), 32), (1, (16, 16, 32), 64), (3, (7, 5, 6), 32), (1, (30, 18, 17), 64), (1, (44, 32, 32), 32)])
+def test_dwconv_stride2_march_is_bit_identical_to_the_gather_kernel(dev, N, shape, C):
+    """The down blocks' stride-2 depthwise conv at C = 32 / 64 (round 4, csrc/dwconv_s2_kernels.hip: z-march over an LDS ring of input
+    planes, taps in registers) against the gather kernel (knob dwconv_s2_march = 0): fp32 FMAs in the same (kz, ky, kx) order, hence equal
+    BITS; statistics equal to summation order; odd and even extents, ragged tiles, several z chunks, batch-invariant results."""
+    from pytorch_connectomics_amd import _native as nat
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(C + shape[1])
+    x = torch.randn(N, *shape, C, device=dev).to(torch.bfloat16)
+    taps = torch.randn(27, C, device=dev) * 0.3
+    b = torch.randn(C, device=dev) * 0.2
+    assert nat.lib().pytc_dwconv3d_kernel_variant(N, *shape, C, 3, 2, nat.BF16, 0) == 8
+    try:
+        y1, st1 = ops.dwconv3d(x, taps, b, K=3, stride=2)
+        ops.set_tuning("dwconv_s2_march", 0)
+        assert nat.lib().pytc_dwconv3d_kernel_variant(N, *shape, C, 3, 2, nat.BF16, 0) == 1
+        y0, st0 = ops.dwconv3d(x, taps, b, K=3, stride=2)
+    finally:
+        ops.set_tuning("dwconv_s2_march", 1)
+    assert y1.shape == y0.shape == (N, (shape[0] - 1) // 2 + 1, (shape[1] - 1) // 2 + 1, (shape[2] - 1) // 2 + 1, C)
+    assert torch.equal(y1, y0), float((y1.float() - y0.float()).abs().max())
+    torch.testing.assert_close(st1.sum(1), st0.sum(1), rtol=1e-5, atol=1e-3)
+    yf = y1.float()
+    torch.testing.assert_close(st1.sum(1)[:, 0], yf.sum((1, 2, 3)), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(st1.sum(1)[:, 1], (yf * yf).sum((1, 2, 3)), rtol=1e-4, atol=1e-2)
+    if N > 1:
+        y_one, st_one = ops.dwconv3d(x[1:2].contiguous(), taps, b, K=3, stride=2)
+        assert torch.equal(y_one[0], y1[1]) and torch.equal(st_one[0], st1[1])
+
+
 @pytest.mark.parametrize("N,shape,C", [(2, (5, 9, 11), 64), (1, (8, 8, 16), 128), (3, (3, 4, 7), 128), (1, (14, 14, 14), 64)])
 def test_dwconv_transposed_tile_form_is_bit_identical_to_the_cell_kernel(dev, N, shape, C):
     """The up blocks' transposed depthwise conv at C = 64 / 128 (round 4, csrc/dwconvT_tile_kernels.hip: one tile of input cells per
