@@ -68,14 +68,17 @@ struct EpiParams {
 // GELU_BWD = false compiles the PYTC_RES_GELU_BWD branch out (the fused mixer never uses it and pays registers for it).
 // pos != nullptr (RES_UPSAMPLE only): {pz, py, px} of `orow` in the output grid, already known to the caller (the fused mixer
 // derives them once per wave and steps them per tile: the generic form below costs two integer divisions per stored 16 bytes).
-template <typename TO, int NCH, bool GELU_BWD = false>
+// COUT > 0: the caller knows C_out at compile time (the fused mixers: MO * 16) -- row offsets become shifts instead of 64-bit multiplies
+// (v_mad_u64_u32 / v_mul_lo_u32 are quarter rate, and instruction time adds to memory time on this machine: DESIGN.md 4.17).
+template <typename TO, int NCH, bool GELU_BWD = false, int COUT = 0>
 __device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParams& e, int n, long orow, int o0,
                                                  const float* pre = nullptr, const int* pos = nullptr) {
+  const int C_out = COUT > 0 ? COUT : e.C_out;
   // pre != nullptr: the caller already loaded res[orow][o0..o0+NCH) (prefetched ahead of the GEMMs)
-  TO* yn = reinterpret_cast<TO*>(e.y) + (long)n * e.rps_out * e.C_out;
-  const TO* resn = e.res ? reinterpret_cast<const TO*>(e.res) + (long)n * e.rps_out * e.C_out : nullptr;
-  const long off = orow * e.C_out + o0;
-  const bool full = (e.C_out % NCH) == 0 && (o0 + NCH <= e.C_out);
+  TO* yn = reinterpret_cast<TO*>(e.y) + (long)n * e.rps_out * C_out;
+  const TO* resn = e.res ? reinterpret_cast<const TO*>(e.res) + (long)n * e.rps_out * C_out : nullptr;
+  const long off = orow * C_out + o0;
+  const bool full = (C_out % NCH) == 0 && (o0 + NCH <= C_out);
   if (e.res_mode == PYTC_RES_ADD) {
     float rv[NCH];
     if (pre) {
@@ -84,7 +87,7 @@ __device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParam
     } else if (full) VecIO<TO, NCH>::load(resn + off, rv);
     else {
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) rv[i] = (o0 + i < e.C_out) ? to_f32<TO>(resn[off + i]) : 0.f;
+      for (int i = 0; i < NCH; ++i) rv[i] = (o0 + i < C_out) ? to_f32<TO>(resn[off + i]) : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) v[i] += rv[i];
@@ -96,7 +99,7 @@ __device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParam
     } else if (full) VecIO<TO, NCH>::load(resn + off, rv);
     else {
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) rv[i] = (o0 + i < e.C_out) ? to_f32<TO>(resn[off + i]) : 0.f;
+      for (int i = 0; i < NCH; ++i) rv[i] = (o0 + i < C_out) ? to_f32<TO>(resn[off + i]) : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) v[i] *= gelu_erf_grad(rv[i]);
@@ -109,12 +112,12 @@ __device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParam
     } else if (full) VecIO<TO, NCH>::load(resn + off, rv);
     else {
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) rv[i] = (o0 + i < e.C_out) ? to_f32<TO>(resn[off + i]) : 0.f;
+      for (int i = 0; i < NCH; ++i) rv[i] = (o0 + i < C_out) ? to_f32<TO>(resn[off + i]) : 0.f;
     }
-    const float* cf = e.res_bias + (long)n * 3 * e.C_out + o0;
+    const float* cf = e.res_bias + (long)n * 3 * C_out + o0;
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
-      if (o0 + i < e.C_out) v[i] = fmaf(cf[i], v[i], fmaf(cf[e.C_out + i], rv[i], cf[2 * e.C_out + i]));
+      if (o0 + i < C_out) v[i] = fmaf(cf[i], v[i], fmaf(cf[C_out + i], rv[i], cf[2 * C_out + i]));
   } else if (e.res_mode == PYTC_RES_UPSAMPLE) {
     int px, py, pz;
     if (pos) { pz = pos[0]; py = pos[1]; px = pos[2]; }
@@ -133,7 +136,7 @@ __device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParam
     } else if (full) VecIO<TO, NCH>::load(resn + off, sk);
     else {
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) sk[i] = (o0 + i < e.C_out) ? to_f32<TO>(resn[off + i]) : 0.f;
+      for (int i = 0; i < NCH; ++i) sk[i] = (o0 + i < C_out) ? to_f32<TO>(resn[off + i]) : 0.f;
     }
     if (px == 0 || py == 0 || pz == 0) {
 #pragma unroll
@@ -143,15 +146,15 @@ __device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParam
       float rl[NCH];
       if (e.res_low && !((oz | oy | ox) & 1)) {
         const TO* rp = reinterpret_cast<const TO*>(e.res_low) +
-                       ((((long)n * e.Gl_d + (oz >> 1)) * e.Gl_h + (oy >> 1)) * e.Gl_w + (ox >> 1)) * e.C_out + o0;
+                       ((((long)n * e.Gl_d + (oz >> 1)) * e.Gl_h + (oy >> 1)) * e.Gl_w + (ox >> 1)) * C_out + o0;
         if (full) VecIO<TO, NCH>::load(rp, rl);
         else {
 #pragma unroll
-          for (int i = 0; i < NCH; ++i) rl[i] = (o0 + i < e.C_out) ? to_f32<TO>(rp[i]) : 0.f;
+          for (int i = 0; i < NCH; ++i) rl[i] = (o0 + i < C_out) ? to_f32<TO>(rp[i]) : 0.f;
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) rl[i] = (e.res_bias && o0 + i < e.C_out) ? e.res_bias[o0 + i] : 0.f;
+        for (int i = 0; i < NCH; ++i) rl[i] = (e.res_bias && o0 + i < C_out) ? e.res_bias[o0 + i] : 0.f;
       }
 #pragma unroll
       for (int i = 0; i < NCH; ++i) v[i] = v[i] + rl[i] + sk[i];
@@ -161,7 +164,7 @@ __device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParam
   else {
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
-      if (o0 + i < e.C_out) yn[off + i] = from_f32<TO>(v[i]);
+      if (o0 + i < C_out) yn[off + i] = from_f32<TO>(v[i]);
   }
 }
 

@@ -84,6 +84,8 @@ constexpr int mlp_waves_per_simd(int ks, int mo, int nt) {
 template <int KS_IN, int MO, int NT, int GELU_MODE, bool HEAD = false, bool STEMRES = false, bool STOREH = false, bool BWD = false>
 __global__ void __launch_bounds__(256, mlp_waves_per_simd(KS_IN, MO, NT))
 pw_mlp_kernel(MlpParams p) {
+  // channel counts are the template's: row offsets compile to shifts (64-bit multiplies by a runtime C are quarter-rate instructions)
+  constexpr int CIN = KS_IN * 32, COUT = MO * 16;
   static_assert(MO % 2 == 0, "C_out must be a multiple of 32");
   static_assert(!STEMRES || (MO == 2 && (MO / 2) * NT <= 4), "the stem-recomputing residual covers C_out = 32");
   static_assert(!HEAD || MO == 2, "the fused head covers C_out = 32");
@@ -105,8 +107,8 @@ pw_mlp_kernel(MlpParams p) {
   const bf16x8_t* w2 = p.w2 + (folded ? (long)n * p.w2_stride : 0L);
   const float* b2 = p.b2 + (folded ? (long)n * p.C_hid : 0L);
   if (WARM) {
-    warm_l2(w2, (long)p.C_hid * p.C_in * 2, warm, 0);
-    warm_l2(p.w3, (long)p.C_out * p.C_hid * 2, warm, WPER);
+    warm_l2(w2, (long)p.C_hid * CIN * 2, warm, 0);
+    warm_l2(p.w3, (long)COUT * p.C_hid * 2, warm, WPER);
   }
   const long row0 = ((long)blockIdx.x * 4 + wave) * (NT * 16);
   if (row0 >= p.rps) {
@@ -123,17 +125,17 @@ pw_mlp_kernel(MlpParams p) {
 
   // ---- B operand of GEMM1: normalised input, 8 consecutive channels per lane per k-step
   bf16x8_t bact[KS_IN][NT];
-  const bf16_t* tn = p.t + (long)n * p.rps * p.C_in;
+  const bf16_t* tn = p.t + (long)n * p.rps * CIN;
   if (folded) {
 #pragma unroll
     for (int ks = 0; ks < KS_IN; ++ks)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const long rr = orow[nt] < p.rps ? orow[nt] : p.rps - 1;
-        bact[ks][nt] = *reinterpret_cast<const bf16x8_t*>(tn + rr * p.C_in + ks * 32 + kb * 8);
+        bact[ks][nt] = *reinterpret_cast<const bf16x8_t*>(tn + rr * CIN + ks * 32 + kb * 8);
       }
   }
-  const float* an = p.ab + (long)n * 2 * p.C_in;
+  const float* an = p.ab + (long)n * 2 * CIN;
 #pragma unroll
   for (int ks = 0; ks < KS_IN; ++ks) {
     if (folded) break;
@@ -141,13 +143,13 @@ pw_mlp_kernel(MlpParams p) {
     float av[8], bv[8];
     VecIO<float, 4>::load(an + k0, reinterpret_cast<float(&)[4]>(av[0]));
     VecIO<float, 4>::load(an + k0 + 4, reinterpret_cast<float(&)[4]>(av[4]));
-    VecIO<float, 4>::load(an + p.C_in + k0, reinterpret_cast<float(&)[4]>(bv[0]));
-    VecIO<float, 4>::load(an + p.C_in + k0 + 4, reinterpret_cast<float(&)[4]>(bv[4]));
+    VecIO<float, 4>::load(an + CIN + k0, reinterpret_cast<float(&)[4]>(bv[0]));
+    VecIO<float, 4>::load(an + CIN + k0 + 4, reinterpret_cast<float(&)[4]>(bv[4]));
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const long rr = orow[nt] < p.rps ? orow[nt] : p.rps - 1;
       float v[8];
-      VecIO<bf16_t, 8>::load(tn + rr * p.C_in + k0, v);
+      VecIO<bf16_t, 8>::load(tn + rr * CIN + k0, v);
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], av[j], bv[j]);
       bact[ks][nt] = Mma<bf16_t>::from_floats(v);
@@ -175,13 +177,13 @@ pw_mlp_kernel(MlpParams p) {
       rpre[0][nt] = __builtin_bit_cast(uint4, Mma<bf16_t>::from_floats(rv));
     }
   } else if (use_pre) {
-    const bf16_t* resn = reinterpret_cast<const bf16_t*>(p.e.res) + (long)n * p.rps * p.C_out;
+    const bf16_t* resn = reinterpret_cast<const bf16_t*>(p.e.res) + (long)n * p.rps * COUT;
 #pragma unroll
     for (int pr = 0; pr < (PREFETCH_RES ? MO / 2 : 1); ++pr)
 #pragma unroll
       for (int nt = 0; nt < (PREFETCH_RES ? NT : 1); ++nt) {
         const long rr = orow[nt] < p.rps ? orow[nt] : p.rps - 1;
-        rpre[pr][nt] = *reinterpret_cast<const uint4*>(resn + rr * p.C_out + pr * 32 + kb * 8);
+        rpre[pr][nt] = *reinterpret_cast<const uint4*>(resn + rr * COUT + pr * 32 + kb * 8);
       }
   }
 
@@ -344,9 +346,9 @@ pw_mlp_kernel(MlpParams p) {
       if (use_pre) {
         float pre[8];
         VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(&rpre[PREFETCH_RES ? pr : 0][PREFETCH_RES ? nt : 0]), pre);
-        finish_and_store<bf16_t, 8>(v, p.e, n, orow[nt], pr * 32 + kb * 8, pre, ups ? upos[nt] : nullptr);
+        finish_and_store<bf16_t, 8, false, COUT>(v, p.e, n, orow[nt], pr * 32 + kb * 8, pre, ups ? upos[nt] : nullptr);
       } else {
-        finish_and_store<bf16_t, 8>(v, p.e, n, orow[nt], pr * 32 + kb * 8, nullptr, ups ? upos[nt] : nullptr);
+        finish_and_store<bf16_t, 8, false, COUT>(v, p.e, n, orow[nt], pr * 32 + kb * 8, nullptr, ups ? upos[nt] : nullptr);
       }
     }
   }

@@ -36,22 +36,22 @@ struct LdsTile {
 template <int KS_IN, int MO, int NT>
 __device__ __forceinline__ void lds_tile_load(LdsTile<KS_IN, MO, NT>& T, const MlpLdsParams& p, int n, long row0, int r, int kb,
                                               bool with_res) {
-  const bf16_t* tn = p.t + (long)n * p.rps * p.C_in;
+  const bf16_t* tn = p.t + (long)n * p.rps * (KS_IN * 32);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const long o = row0 + nt * 16 + r;
     const long rr = o < p.rps ? o : p.rps - 1;
 #pragma unroll
-    for (int ks = 0; ks < KS_IN; ++ks) T.raw[ks][nt] = *reinterpret_cast<const uint4*>(tn + rr * p.C_in + ks * 32 + kb * 8);
+    for (int ks = 0; ks < KS_IN; ++ks) T.raw[ks][nt] = *reinterpret_cast<const uint4*>(tn + rr * (KS_IN * 32) + ks * 32 + kb * 8);
   }
   if (with_res) {
-    const bf16_t* resn = reinterpret_cast<const bf16_t*>(p.e.res) + (long)n * p.rps * p.C_out;
+    const bf16_t* resn = reinterpret_cast<const bf16_t*>(p.e.res) + (long)n * p.rps * (MO * 16);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const long o = row0 + nt * 16 + r;
       const long rr = o < p.rps ? o : p.rps - 1;
 #pragma unroll
-      for (int pr = 0; pr < MO / 2; ++pr) T.res[pr][nt] = *reinterpret_cast<const uint4*>(resn + rr * p.C_out + pr * 32 + kb * 8);
+      for (int pr = 0; pr < MO / 2; ++pr) T.res[pr][nt] = *reinterpret_cast<const uint4*>(resn + rr * (MO * 16) + pr * 32 + kb * 8);
     }
   }
 }
@@ -63,14 +63,15 @@ __device__ __forceinline__ void lds_tile_load(LdsTile<KS_IN, MO, NT>& T, const M
 template <int KS_IN, int MO, int NT, int NWAVES, int WPS>
 __global__ void __launch_bounds__(NWAVES * 64, WPS)
 pw_mlp_lds_kernel(MlpLdsParams p) {
+  constexpr int CIN = KS_IN * 32, COUT = MO * 16;       // compile-time row pitches: shifts, not 64-bit multiplies
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   bf16x8_t* lw2 = reinterpret_cast<bf16x8_t*>(lds_raw);                                   // [HC*2][KS_IN][64]
-  h8_t* lw3 = reinterpret_cast<h8_t*>(lds_raw + (size_t)p.C_hid * p.C_in * 2);             // [MO][HC][64]
-  float* lb2 = reinterpret_cast<float*>(lds_raw + (size_t)p.C_hid * (p.C_in + p.C_out) * 2);  // [C_hid]
+  h8_t* lw3 = reinterpret_cast<h8_t*>(lds_raw + (size_t)p.C_hid * CIN * 2);             // [MO][HC][64]
+  float* lb2 = reinterpret_cast<float*>(lds_raw + (size_t)p.C_hid * (CIN + COUT) * 2);  // [C_hid]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, kb = lane >> 4;
   const bool folded = p.ab == nullptr;
-  const int n_w2 = p.C_hid * p.C_in / 8, n_w3 = p.C_out * p.C_hid / 8;                     // 16-byte pieces
+  const int n_w2 = p.C_hid * CIN / 8, n_w3 = COUT * p.C_hid / 8;                     // 16-byte pieces
   for (int i = tid; i < n_w3; i += NWAVES * 64) lw3[i] = p.w3[i];
   const long Ts = (p.rps + NT * 16 - 1) / (NT * 16);       // row tiles per sample
   const long G = Ts * p.N;
@@ -93,7 +94,7 @@ pw_mlp_lds_kernel(MlpLdsParams p) {
       staged = n;
       __syncthreads();
     }
-    const float* an = folded ? nullptr : p.ab + (long)n * 2 * p.C_in;
+    const float* an = folded ? nullptr : p.ab + (long)n * 2 * CIN;
     const long t_base = (long)n * Ts;
 
     for (long gt = g + wave; gt < seg_end; gt += NWAVES) {
@@ -116,8 +117,8 @@ pw_mlp_lds_kernel(MlpLdsParams p) {
           float av[8], bv[8];
           VecIO<float, 4>::load(an + k0, reinterpret_cast<float(&)[4]>(av[0]));
           VecIO<float, 4>::load(an + k0 + 4, reinterpret_cast<float(&)[4]>(av[4]));
-          VecIO<float, 4>::load(an + p.C_in + k0, reinterpret_cast<float(&)[4]>(bv[0]));
-          VecIO<float, 4>::load(an + p.C_in + k0 + 4, reinterpret_cast<float(&)[4]>(bv[4]));
+          VecIO<float, 4>::load(an + CIN + k0, reinterpret_cast<float(&)[4]>(bv[0]));
+          VecIO<float, 4>::load(an + CIN + k0 + 4, reinterpret_cast<float(&)[4]>(bv[4]));
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             float v[8];
@@ -198,9 +199,9 @@ pw_mlp_lds_kernel(MlpLdsParams p) {
           if (with_res) {
             float pre[8];
             VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(&cur.res[pr][nt]), pre);
-            finish_and_store<bf16_t, 8>(v, p.e, n, orow[nt], pr * 32 + kb * 8, pre, ups ? upos[nt] : nullptr);
+            finish_and_store<bf16_t, 8, false, COUT>(v, p.e, n, orow[nt], pr * 32 + kb * 8, pre, ups ? upos[nt] : nullptr);
           } else {
-            finish_and_store<bf16_t, 8>(v, p.e, n, orow[nt], pr * 32 + kb * 8, nullptr, nullptr);
+            finish_and_store<bf16_t, 8, false, COUT>(v, p.e, n, orow[nt], pr * 32 + kb * 8, nullptr, nullptr);
           }
         }
       }
