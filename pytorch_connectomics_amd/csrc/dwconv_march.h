@@ -24,7 +24,7 @@ bool dwconvT_tile_plan(DwTTile& g, int N, int D, int H, int W, int C);
 void dwconvT_tile_launch(const void* x, void* y, const float* w, const float* bias, float* stats, const DwTTile& g, hipStream_t s);
 
 // dwconv_s2_kernels.hip: K = 3 / stride 2 conv of the down blocks, bf16, C = 32 / 64, z-march over an LDS ring of input planes
-struct DwS2 { int N, D, H, W, C, Do, Ho, Wo, ty, tx, zc, nzc, slots; };
+struct DwS2 { int N, D, H, W, C, Do, Ho, Wo, ty, tx, zc, nzc, slots, tyo; };
 bool dwconv_s2_plan(DwS2& g, int N, int D, int H, int W, int C);
 void dwconv_s2_launch(const void* x, void* y, const float* w, const float* bias, float* stats, const DwS2& g, hipStream_t s);
 

@@ -1,7 +1,8 @@
 // Depthwise 3x3x3 conv, STRIDE 2, pad 1 (bf16 NDHWC, C = 32 / 64): the down blocks' resampling conv, as a z-march over LDS.
 // The gather kernel (dwconv_kernels.hip) fetched 27 taps x 16 bytes per output through L1 with 64-bit address arithmetic and read its
 // weights from LDS per tap (54 ds_read_b128 per output and 8 channels): 8 x 112^3 x 32 -> 56^3 took 295-330 us for 0.81 GB (a copy of the
-// input alone: 265).  Here a workgroup owns an 8 (x) x TYO (y) footprint of OUTPUT voxels and marches along z: the haloed input planes
+// input alone: 265).  Here a workgroup owns an 8 (x) x TYO (y) footprint of OUTPUT voxels (TYO = 4: 31 KB of LDS at C = 32, four
+// workgroups per CU; 8 x 8 footprints measured 5 % slower) and marches along z: the haloed input planes
 // (17 x (2 TYO + 1) voxels, all channels) live in a ring of three LDS slots -- two new planes per output plane, requested into registers
 // BEFORE the arithmetic of the current plane and written to LDS after it -- so HBM sees the input once (+ 13 % in-plane halo); a thread
 // keeps the 27 taps of ITS channel pair in registers (no weight reads at all), reads 27 x 4 bytes of LDS per output, and the plane's
@@ -23,7 +24,8 @@ dwconv3d_k3_s2_march_kernel(const unsigned short* __restrict__ x, unsigned short
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
   typedef float f2_t __attribute__((ext_vector_type(2)));
   typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
-  static_assert(OUTV % VS == 0 && OUTV * C / 8 == 256, "one 16-byte output piece per thread and plane");
+  constexpr int OPIECES = OUTV * C / 8;                // 16-byte pieces of the output tile (at most one per thread)
+  static_assert(OUTV % VS == 0 && OPIECES <= 256, "at most one 16-byte output piece per thread and plane");
   extern __shared__ __attribute__((aligned(16))) unsigned short ring[];      // [3][IY][IX][C], then the output tile [OUTV][C]
   unsigned short* const otile = ring + 3 * PLANE;
   __shared__ float red[4][2][2 * 64];
@@ -79,7 +81,7 @@ dwconv3d_k3_s2_march_kernel(const unsigned short* __restrict__ x, unsigned short
   // output piece of this thread: voxel tid / (C/8) of the tile (row-major), channels (tid % (C/8)) * 8 ..
   const int ovx = tid / (C / 8), opart = tid % (C / 8);
   const int oyy = yo0 + ovx / TXO, oxx = xo0 + ovx % TXO;
-  const bool ook = oyy < g.Ho && oxx < g.Wo;
+  const bool ook = tid < OPIECES && oyy < g.Ho && oxx < g.Wo;
   const long obase = ((long)oyy * g.Wo + oxx) * C + opart * 8;
 
   u32x4_t sa[LPT], sb[LPT];
@@ -124,7 +126,7 @@ dwconv3d_k3_s2_march_kernel(const unsigned short* __restrict__ x, unsigned short
       s2 = __builtin_elementwise_fma(r, r, s2);
     }
     __syncthreads();                                     // the tile is complete; nobody reads the two oldest ring slots any more
-    const u32x4_t o = *reinterpret_cast<const u32x4_t*>(otile + tid * 8);
+    const u32x4_t o = *reinterpret_cast<const u32x4_t*>(otile + (tid < OPIECES ? tid : 0) * 8);
     if (ook) *reinterpret_cast<u32x4_t*>(yn + (long)zo * g.Ho * g.Wo * C + obase) = o;
     if (more) { deposit(2 * zo + 2, sa); deposit(2 * zo + 3, sb); }
     __syncthreads();
@@ -155,7 +157,8 @@ dwconv3d_k3_s2_march_kernel(const unsigned short* __restrict__ x, unsigned short
 
 bool dwconv_s2_plan(DwS2& g, int N, int D, int H, int W, int C) {
   if (C != 32 && C != 64) return false;
-  const int tyo = C == 32 ? 8 : 4;
+  const int tyo = (C == 32 && tuning_get("dwconv_s2_tyo4", 1) == 0) ? 8 : 4;   // 4 x 8 outputs: 31 KB of LDS, four workgroups per CU (8 x 8: 60 KB, two; 5 % slower)
+  g.tyo = tyo;
   g.N = N; g.D = D; g.H = H; g.W = W; g.C = C;
   g.Do = (D - 1) / 2 + 1; g.Ho = (H - 1) / 2 + 1; g.Wo = (W - 1) / 2 + 1;
   g.ty = (g.Ho + tyo - 1) / tyo; g.tx = (g.Wo + 7) / 8;
@@ -185,7 +188,9 @@ void dwconv_s2_launch(const void* x, void* y, const float* w, const float* bias,
     }                                                                                                                         \
     hipLaunchKernelGGL((dwconv3d_k3_s2_march_kernel<CC, TYY>), grid, block, lds, s, xp, yp, w, bias, stats, g);               \
   } while (0)
-  if (g.C == 32) PYTC_S2(32, 8); else PYTC_S2(64, 4);
+  if (g.C == 32 && g.tyo == 8) PYTC_S2(32, 8);
+  else if (g.C == 32) PYTC_S2(32, 4);
+  else PYTC_S2(64, 4);
 #undef PYTC_S2
 }
 
