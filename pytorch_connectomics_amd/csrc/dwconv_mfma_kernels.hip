@@ -2,7 +2,7 @@
 // 4x4x4 products per instruction, and a depthwise conv shares nothing between channels -- so one block of the instruction is one
 // CHANNEL (round 4; the 16x16x32 Toeplitz form of round 3/4, one channel per instruction with 29/32 zeros, lost 2.3x to the VALU
 // z-march: profiles/r04_toeplitz_probe.txt).  Per block (= channel c) and per in-plane column offset dx:
-//     D[i][j] += sum_k A[i][k] * B[k][j]      i = z tap (output plane gz+1-i... see below), k = input row, j = output column
+//     D[i][j] += sum_k A[i][k] * B[k][j]      i = output plane gz - 1 + i (z tap dz = 2 - i), k = input row, j = output column
 //     A[i][k] = w_c[dz = 2 - i][dy = k - r][dx]   (r = 0 / 1: the two output rows that share the four input rows; row i = 3 is zero)
 //     B[k][j] = in_c[gz][y0 + k][x0 + j + dx]     (four consecutive rows of the haloed plane, read as 8 bytes from an LDS image that
 //                                                  keeps y innermost)
@@ -10,13 +10,14 @@
 // of (16 channels x 4 columns x 2 rows x 1 input plane) is 6 instructions (12 with the hi/lo weight split) against 108 v_pk_fma_f16 +
 // 63 LDS reads for the same work in the z-march.  The z extent rides in the accumulator's four VGPRs (outputs gz-1, gz, gz+1, unused):
 // after the instructions of input plane gz VGPR 0 is a finished output and the tuple rotates.
-// Operands: activations are bf16 as stored (no conversion, no range clamp); the fp32 weights go in as hi + lo bf16 pairs (two
-// instructions, 16 mantissa bits) -- the matrix pipe is otherwise idle.  Accumulation is fp32 throughout (the packed-f16 z-march
-// sums nine taps in f16).
+// Operands: activations are bf16 as stored (no conversion, no range clamp); the fp32 weights go in as bf16 -- hi halves only by default
+// (= the weights torch.autocast hands the reference's Conv3d), hi + lo pairs on request (two instructions per operand, 16 mantissa
+// bits: fp32-weight accuracy) -- and accumulation is fp32 throughout (the packed-f16 z-march sums nine taps in f16).
 // Data movement is the z-march's: 8 x 8 footprint of a 32-channel group, z-chunks, one haloed plane per step through LDS (double
 // buffered), plane loads as inline asm with counted waits (PF planes in flight in registers), HBM sees x once (+ halo) and y once,
 // statistics leave as one partial per workgroup.  Both transpositions (NDHWC <-> channel-major rows) happen in LDS: 2-byte writes at
-// commit, and a 1 KB tile per wave that turns the accumulator layout (lane = channel x column) back into 16-byte NDHWC stores.
+// commit, and a 4 KB tile per workgroup that turns the accumulator layout (lane = channel x column) back into 16-byte NDHWC stores
+// (full 64-byte voxel rows, one step later).
 // Measured and removed (profiles/r04_dwconv_mfma.txt; level 0, 8 windows, hi + lo: 435 us): (a) a FIFTH wave that only stores, so that
 // the other waves' vmcnt (loads and stores share it on gfx9) counts loads only: 555 us (3 workgroups per CU instead of 4); (b) waves
 // SPECIALISED into 4 compute + 4 loader waves (512 threads, 6-8 planes in flight): 436 us, and its 3-planes build faulted (an asm-issued
