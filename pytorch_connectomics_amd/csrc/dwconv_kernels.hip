@@ -866,6 +866,9 @@ static void make_march(DwMarch& t, int N, int D, int H, int W, int C, int tilex 
   // mean / rstd -- and with them its bf16 prediction -- would otherwise change with the batch it happens to travel in
   // (chunked == whole-volume and rank-sharded == single-process exactness rely on batch-invariant windows).
   const long fp = (long)t.ty * t.tx * (C / MARCH_CG);
+  // Measured and removed (round 4): choosing the split that minimises ceil(workgroups / 1024 resident) x (zc + 2) for an 8-window batch
+  // (56^3 x 64: 5 chunks instead of 4; 112^3 x 32: 7 instead of 6) changed no launch time (396 / 116 / 41 us either way): the
+  // workgroups of these kernels do not advance in rounds, the launch is throughput bound.
   int nzc = (int)(((long)tuning_get("dwconv_march_wgs", 1024) + fp - 1) / fp);
   if (nzc < 1) nzc = 1;
   int maxc = D / 14;
