@@ -852,6 +852,14 @@ static bool march_ok(int D, int H, int W, int C, int K, int stride, int dtype, i
   return D >= 8 && H >= 16 && W >= 16 && (long)H * W * C < (1L << 30);
 }
 
+// planes too small for the VALU z-march (8 <= H, W < 16; 14^3 at level 3 of a 112^3 window) still fit the matrix-core form, whose
+// footprints handle ragged tiles the same way: bf16 forward launches only (the gather / x-block kernels keep everything else)
+static bool mfma_small_ok(int D, int H, int W, int C, int K, int stride, int dtype, int transposed) {
+  if (transposed || K != 3 || stride != 1 || dtype != PYTC_BF16 || (C % MARCH_CG) != 0) return false;
+  if (tuning_get("dwconv_mfma", 1) == 0 || tuning_get("dwconv_mfma_small", 1) == 0) return false;
+  return D >= 8 && H >= 8 && W >= 8 && (H < 16 || W < 16);
+}
+
 // the forward kernel's footprint: 8 x 16 where the rows divide into whole 16-voxel tiles (level 0: W = 112), 8 x 8 otherwise
 static int march_tile_x(int W, int dtype) {
   return (dtype == PYTC_BF16 && W % 16 == 0 && tuning_get("dwconv_march_tx16", 0) != 0 && tuning_get("dwconv_mfma", 1) == 0) ? 16 : TILE_X;
@@ -1314,6 +1322,17 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
       return PYTC_OK;
     }
   }
+  if (!res && !wide_range && y && mfma_small_ok(D, H, W, C, K, stride, dtype, transposed)) {
+    DwMarch t;
+    make_march(t, N, D, H, W, C, TILE_X);
+    t.swizzle = tuning_get("dwconv_xcd_swizzle", 1);
+    t.cg_inner = tuning_get("dwconv_cg_inner", 1);
+    // hi + lo weights here: these launches are latency bound (22 us either way), and with bf16 weights at the 14^3 level the
+    // training gate's worst tensor (bottleneck.1.norm.weight) moved from 0.050 to 0.066 relative L2 against a 0.05 class
+    dwconv_mfma_launch(x, y, w, bias, stats, t, tuning_get("dwconv_mfma_variant", 0) | 1, (hipStream_t)stream);
+    PYTC_LAUNCH_CHECK("dwconv3d_k3_mfma");
+    return PYTC_OK;
+  }
   if (march_ok(D, H, W, C, K, stride, dtype, transposed)) {
     DwMarch t;
     // the 8 x 16 / 512-thread footprint serves the plain packed-f16 forward (the launches that carry statistics, so the slot
@@ -1397,6 +1416,11 @@ extern "C" int pytc_dwconv3d_stat_slots(int N, int D, int H, int W, int C, int K
     make_march(t, N, D, H, W, C, tuning_get("dwconv_march_h16", 1) != 0 ? march_tile_x(W, dtype) : TILE_X);
     return t.slots;
   }
+  if (mfma_small_ok(D, H, W, C, K, stride, dtype, transposed)) {
+    DwMarch t;
+    make_march(t, N, D, H, W, C, TILE_X);
+    return t.slots;
+  }
   if (transposed && K == 3 && dtype == PYTC_BF16 && (C == 64 || C == 128) && tuning_get("dwconvT_tile", 1) != 0) {
     DwTTile tt;
     if (dwconvT_tile_plan(tt, N, D, H, W, C)) return tt.slots;
@@ -1414,6 +1438,7 @@ extern "C" int pytc_dwconv3d_stat_slots(int N, int D, int H, int W, int C, int K
 extern "C" int pytc_dwconv3d_kernel_variant(int N, int D, int H, int W, int C, int K, int stride, int dtype, int transposed) {
   // mirrors dw_entry / launch_dw: which kernel family a call with these arguments dispatches to
   if (march_ok(D, H, W, C, K, stride, dtype, transposed)) return (dtype == PYTC_BF16 && tuning_get("dwconv_mfma", 1) != 0) ? 6 : 3;
+  if (mfma_small_ok(D, H, W, C, K, stride, dtype, transposed)) return 6;
   DwGeom g;
   int vec;
   if (!make_geom(g, N, D, H, W, C, K, stride, dtype, transposed, vec)) return -1;

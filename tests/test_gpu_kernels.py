@@ -616,7 +616,7 @@ def test_dwconv_transposed_tile_form_is_bit_identical_to_the_cell_kernel(dev, N,
 
 
 @pytest.mark.parametrize("N,shape,C", [(1, (9, 20, 31), 32), (2, (16, 32, 28), 64), (1, (30, 17, 16), 96), (1, (24, 24, 24), 128),
-                                       (3, (8, 16, 16), 32)])
+                                       (3, (8, 16, 16), 32), (2, (14, 14, 14), 256), (1, (9, 10, 13), 64)])
 def test_dwconv_matrix_core_form(dev, N, shape, C):
     """dwconv3d, bf16, K = 3, stride 1 on v_mfma_f32_4x4x4_16b_bf16 (one channel per block of the instruction; round 4,
     csrc/dwconv_mfma_kernels.hip) against an fp64 convolution of the same bf16 operands.  hi + lo weight instructions (variant bit 0):
