@@ -279,9 +279,13 @@ def lib():
     _lib = handle
     # PYTC_TUNING="knob=value,knob=value": kernel-variant knobs (pytc_set_tuning) for A/B runs of unmodified commands
     for item in filter(None, (t.strip() for t in os.environ.get("PYTC_TUNING", "").split(","))):
-        key, _, val = item.partition("=")
-        if handle.pytc_set_tuning(key.strip().encode(), int(val)) != OK:
-            raise RuntimeError(f"PYTC_TUNING: cannot set {item!r}")
+        key, sep, val = item.partition("=")
+        try:
+            ok = bool(sep) and bool(key.strip()) and handle.pytc_set_tuning(key.strip().encode(), int(val)) == OK
+        except ValueError:
+            ok = False
+        if not ok:
+            raise RuntimeError(f"PYTC_TUNING: cannot set {item!r} (expected knob=integer[,knob=integer...])")
     return _lib
 
 

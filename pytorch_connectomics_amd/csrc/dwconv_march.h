@@ -14,7 +14,7 @@ struct DwMarch {
 };
 
 // dwconv_mfma_kernels.hip: bf16, K = 3, stride 1, C % 32 == 0, 8 x 8 footprints (g.tilex == 8); grid = slots * (C / 32) * N blocks.
-// variant (knob dwconv_mfma_variant): bit 0 = hi + lo weights, bit 1 = two planes in flight; 91 / 93 = timing probes.
+// variant (knob dwconv_mfma_variant): bit 0 = hi + lo weights, bit 1 = two planes in flight.
 void dwconv_mfma_launch(const void* x, void* y, const float* w, const float* bias, float* stats, const DwMarch& g, int variant,
                         hipStream_t s);
 

@@ -294,9 +294,11 @@ void dwconv_mfma_launch(const void* x, void* y, const float* w, const float* bia
   unsigned short* yp = (unsigned short*)y;
 #define PYTC_MF(PFV, LOV, NM) hipLaunchKernelGGL((dwconv3d_k3_mfma_kernel<PFV, LOV, NM>), grid, block, 0, s, xp, yp, w, bias, stats, g)
   // variant: bit 0 = hi + lo weight instructions (16-bit weight mantissa; default: hi only = bf16 weights, what torch.autocast gives the
-  // reference's Conv3d), bit 1 = two planes in flight instead of three; 91 / 93: timing probes
-  if (variant == 91) PYTC_MF(3, false, 1);
-  else if (variant == 93) PYTC_MF(3, false, 3);
+  // reference's Conv3d), bit 1 = two planes in flight instead of three.  Knob dwconv_mfma_probe (1 / 3; measurements only, WRONG results):
+  // the kernel without its matrix instructions / without them and without the output path.
+  const int probe = tuning_get("dwconv_mfma_probe", 0);
+  if (probe == 1) PYTC_MF(3, false, 1);
+  else if (probe == 3) PYTC_MF(3, false, 3);
   else if (variant & 1) { if (variant & 2) PYTC_MF(2, true, 0); else PYTC_MF(3, true, 0); }
   else { if (variant & 2) PYTC_MF(2, false, 0); else PYTC_MF(3, false, 0); }
 #undef PYTC_MF

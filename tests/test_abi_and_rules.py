@@ -1,6 +1,7 @@
 """CPU checks: the C-ABI library loads and exports every symbol include/pytc_hip.h declares; the
 product package never touches the oracle; the product refuses to run without a GPU."""
 import ctypes
+import os
 import re
 from pathlib import Path
 
@@ -68,3 +69,19 @@ def test_no_cpu_fallback():
         eng(torch.zeros(1, 1, 16, 16, 16), lambda x: x)
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.blend_finalize(torch.zeros(1, 4, 4, 4), torch.zeros(4, 4, 4))
+
+
+def test_tuning_knobs_from_the_environment():
+    """PYTC_TUNING="knob=value,..." reaches pytc_set_tuning when the library is loaded (A/B runs of unmodified commands); a
+    malformed entry fails loudly instead of being ignored."""
+    import subprocess
+    import sys
+    root = str(Path(__file__).resolve().parent.parent)
+    code = "from pytorch_connectomics_amd import _native as nat; nat.lib(); print('loaded')"
+    good = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True,
+                          env={**os.environ, "PYTC_TUNING": "dwconv_mfma=0, mlp_lds_variant=3"})
+    assert good.returncode == 0 and "loaded" in good.stdout, good.stderr[-500:]
+    for bad_value in ("dwconv_mfma", "dwconv_mfma=fast", "=3"):
+        bad = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True,
+                             env={**os.environ, "PYTC_TUNING": bad_value})
+        assert bad.returncode != 0 and "PYTC_TUNING" in bad.stderr, (bad_value, bad.stderr[-300:])

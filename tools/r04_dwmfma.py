@@ -75,10 +75,12 @@ def bench(N, D, C):
     line += f"  z-march {us:7.1f} us ({nb / us / 1e3:5.0f} GB/s) |"
     ops.set_tuning("dwconv_mfma", 1)
     for v in (0, 1, 2, 3, 91, 93):
-        ops.set_tuning("dwconv_mfma_variant", v)
+        ops.set_tuning("dwconv_mfma_variant", v if v < 90 else 0)
+        ops.set_tuning("dwconv_mfma_probe", v - 90 if v >= 90 else 0)      # 91 / 93: the timing probes (wrong results)
         us = timeit(lambda: ops.dwconv3d(x, taps, bias, K=3, y=y))
         line += f"  v{v} {us:6.1f}"
     ops.set_tuning("dwconv_mfma_variant", 0)
+    ops.set_tuning("dwconv_mfma_probe", 0)
     print(line, flush=True)
 
 
