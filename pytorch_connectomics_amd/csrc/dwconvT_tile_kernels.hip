@@ -12,6 +12,8 @@
 // (statistics-only mode) 180-195 us, stores alone 210 us -- the two ADD here as in every other kernel of this library on this machine,
 // so what is left is instruction count: four-byte instead of sixteen-byte stores, four instead of three workgroups per CU, and
 // staggered workgroup starts all changed nothing.
+#include <mutex>
+
 #include "dwconv_march.h"
 
 namespace pytc {
@@ -203,12 +205,11 @@ void dwconvT_tile_launch(const void* x, void* y, const float* w, const float* bi
   unsigned short* yp = (unsigned short*)y;
 #define PYTC_TT(CC, TYY, ST)                                                                                                  \
   do {                                                                                                                        \
-    static bool once = false;                                                                                                 \
-    if (!once) {                                                                                                              \
+    static std::once_flag once;                                                                                \
+    std::call_once(once, [] {                                                                      \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconvT3d_k3_tile_kernel<CC, TYY, ST>),                        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);                                      \
-      once = true;                                                                                                            \
-    }                                                                                                                         \
+    });                                                                                                    \
     hipLaunchKernelGGL((dwconvT3d_k3_tile_kernel<CC, TYY, ST>), grid, block,                                                  \
                        (size_t)(TT_TZ + 1) * (TYY + 1) * (TT_TX + 1) * CC * 2 + 4 * 2048, s, xp, yp, w, bias, stats, g);                  \
   } while (0)

@@ -8,6 +8,8 @@
 // keeps the 27 taps of ITS channel pair in registers (no weight reads at all), reads 27 x 4 bytes of LDS per output, and the plane's
 // results leave through a 4 KB LDS tile as 16-byte stores.  fp32 FMAs in (kz, ky, kx) order with zero contributions for taps outside
 // the volume = the gather kernel's arithmetic: outputs are BIT-IDENTICAL; statistics leave as one partial per workgroup.
+#include <mutex>
+
 #include "dwconv_march.h"
 
 namespace pytc {
@@ -180,12 +182,11 @@ void dwconv_s2_launch(const void* x, void* y, const float* w, const float* bias,
 #define PYTC_S2(CC, TYY)                                                                                                      \
   do {                                                                                                                        \
     const size_t lds = (size_t)(3 * (2 * TYY + 1) * 17 * CC + TYY * 8 * CC) * 2;                                               \
-    static bool once = false;                                                                                                 \
-    if (!once) {                                                                                                              \
+    static std::once_flag once;                                                                                \
+    std::call_once(once, [] {                                                                      \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3d_k3_s2_march_kernel<CC, TYY>),                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);                                      \
-      once = true;                                                                                                            \
-    }                                                                                                                         \
+    });                                                                                                    \
     hipLaunchKernelGGL((dwconv3d_k3_s2_march_kernel<CC, TYY>), grid, block, lds, s, xp, yp, w, bias, stats, g);               \
   } while (0)
   if (g.C == 32 && g.tyo == 8) PYTC_S2(32, 8);

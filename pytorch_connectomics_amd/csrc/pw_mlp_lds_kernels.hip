@@ -9,6 +9,8 @@
 // The arithmetic is pw_mlp_kernel<..., GELU_MODE = 3>'s, instruction for instruction (same MFMA order, same packed-fp16 GELU, same
 // epilogue): results are bit-identical (tests/test_gpu_kernels.py::test_lds_resident_mixer_is_bit_identical).  Per-sample folded
 // expand operands (pytc_groupnorm_fold_mlp) are supported: the W2 image is re-staged when the sample changes.
+#include <mutex>
+
 #include "pw_common.h"
 
 namespace pytc {
@@ -213,11 +215,10 @@ pw_mlp_lds_kernel(MlpLdsParams p) {
 template <int KS_IN, int MO, int NT, int NWAVES, int WPS>
 static void launch_mlp_lds_v(const MlpLdsParams& p, size_t lds, hipStream_t s) {
   auto kern = &pw_mlp_lds_kernel<KS_IN, MO, NT, NWAVES, WPS>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;           // per template instance; hip_ops may launch from several host threads
+  std::call_once(attr_once, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  });
   const long tiles = ((p.rps + NT * 16 - 1) / (NT * 16)) * p.N;
   const int by_lds = (int)((160 * 1024) / lds), by_waves = WPS * 4 / NWAVES;
   const int per_cu = by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves;

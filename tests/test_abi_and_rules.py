@@ -85,3 +85,28 @@ def test_tuning_knobs_from_the_environment():
         bad = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True,
                              env={**os.environ, "PYTC_TUNING": bad_value})
         assert bad.returncode != 0 and "PYTC_TUNING" in bad.stderr, (bad_value, bad.stderr[-300:])
+
+
+def test_depthwise_dispatch_table_and_batch_invariant_statistics_slots():
+    """Which device kernel a depthwise launch of the MedNeXt-S 112^3 window takes at every level (pytc_dwconv3d_kernel_variant mirrors
+    the dispatch), and that the number of statistics slots per sample never depends on the batch size: a window's GroupNorm partial
+    sums -- and with them its bf16 prediction -- must not change with the batch it travels in (chunked == whole-volume exactness)."""
+    from pytorch_connectomics_amd import _native as nat
+    lib = nat.lib()
+    kv, slots = lib.pytc_dwconv3d_kernel_variant, lib.pytc_dwconv3d_stat_slots
+    B, F = nat.BF16, nat.F32
+    # stride 1, K = 3: matrix-core z-march from 112^3 down to 14^3, x-block kernel at the 7^3 bottleneck; fp32: VALU z-march / gather
+    for side, C in ((112, 32), (56, 64), (28, 128), (14, 256)):
+        assert kv(8, side, side, side, C, 3, 1, B, 0) == 6, (side, C)
+    assert kv(8, 7, 7, 7, 512, 3, 1, B, 0) == 2
+    assert kv(8, 112, 112, 112, 32, 3, 1, F, 0) == 3 and kv(8, 14, 14, 14, 256, 3, 1, F, 0) in (1, 2)
+    # down blocks: LDS z-march at C = 32 / 64, gather kernel deeper; up blocks: tile kernel at C = 64 / 128, cell kernel deeper
+    assert kv(8, 112, 112, 112, 32, 3, 2, B, 0) == 8 and kv(8, 56, 56, 56, 64, 3, 2, B, 0) == 8 and kv(8, 28, 28, 28, 128, 3, 2, B, 0) == 1
+    assert kv(8, 56, 56, 56, 64, 3, 2, B, 1) == 7 and kv(8, 28, 28, 28, 128, 3, 2, B, 1) == 7 and kv(8, 14, 14, 14, 256, 3, 2, B, 1) == 4
+    # K = 5 / 7 and odd channel counts stay on the generic kernels
+    assert kv(2, 32, 32, 32, 32, 5, 1, B, 0) in (1, 2) and kv(2, 32, 32, 32, 12, 3, 1, B, 0) in (0, 1)
+    for args in ((112, 112, 112, 32, 3, 1, B, 0), (56, 56, 56, 64, 3, 1, B, 0), (14, 14, 14, 256, 3, 1, B, 0), (112, 112, 112, 32, 3, 2, B, 0),
+                 (56, 56, 56, 64, 3, 2, B, 0), (56, 56, 56, 64, 3, 2, B, 1), (28, 28, 28, 128, 3, 2, B, 1), (33, 47, 20, 64, 3, 1, B, 0),
+                 (9, 20, 31, 32, 3, 2, B, 0), (160, 160, 160, 32, 3, 1, B, 0)):
+        counts = {slots(n, *args) for n in (1, 2, 8, 13)}
+        assert len(counts) == 1 and counts.pop() > 0, args
