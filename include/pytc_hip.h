@@ -207,7 +207,12 @@ int pytc_dwconv3d_kernel_variant(int N, int D, int H, int W, int C, int K, int s
  *   x [N][D][H][W][C]   y [N][Do][Ho][Wo][C]   (dtype)      Do = (D + 2*(K/2) - K)/stride + 1
  *   w fp32 [K*K*K][C] (tap-major: w[(kz*K+ky)*K+kx][c] = torch_weight[c][0][kz][ky][kx])
  *   bias fp32 [C] or NULL
- *   stats fp32 [N][slots][2][C] (sum, sumsq per slot) or NULL */
+ *   stats fp32 [N][slots][2][C] (sum, sumsq per slot) or NULL
+ * Arithmetic: fp32 accumulation of fp32 taps, except the bf16 / K = 3 / stride 1 / C % 32 == 0 launches on planes of >= 8 x 8 voxels, which
+ * run on the matrix cores (csrc/dwconv_mfma_kernels.hip): the taps enter as bf16 (round to nearest even -- what torch.autocast hands the
+ * reference's Conv3d), products are exact, accumulation is fp32; knob dwconv_mfma_variant bit 0 adds the low halves of the taps (16-bit
+ * mantissa; always on for planes below 16 voxels), knob dwconv_mfma = 0 restores the VALU kernels (fp32 taps, nine-tap f16 partial sums).
+ * The statistics are those of the STORED (rounded) tensor and their slot count does not depend on N. */
 int pytc_dwconv3d_fwd(const void* x, void* y, const float* w, const float* bias, float* stats,
                       int N, int D, int H, int W, int C, int K, int stride, int dtype,
                       void* stream);
