@@ -58,7 +58,10 @@ def schema_defaults() -> dict:
                       "activation": "relu", "spatial_dims": 3, "num_res_units": 2, "kernel_size": 3, "strides": None,
                       "upsample_mode": "deconv", "upsample_interp_mode": "linear", "upsample_align_corners": True},
             "loss": {"deep_supervision": False, "deep_supervision_weights": [1.0, 0.5, 0.25, 0.125, 0.0625],
-                     "deep_supervision_clamp_min": -20.0, "deep_supervision_clamp_max": 20.0, "losses": None},
+                     "deep_supervision_clamp_min": -20.0, "deep_supervision_clamp_max": 20.0, "losses": None,
+                     # schema/model.py:13-19 (LossBalancingConfig): None | "uncertainty" | "gradnorm" (training/balancing.py)
+                     "loss_balancing": {"strategy": None, "gradnorm_alpha": 0.5, "gradnorm_lambda": 1.0,
+                                        "gradnorm_parameter_strategy": "last"}},
         },
         "data": {"train": {"image": None, "label": None, "do_2d": False},
                  "val": {"image": None, "label": None, "do_2d": False},

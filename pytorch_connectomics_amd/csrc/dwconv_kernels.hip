@@ -1294,25 +1294,33 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
       return PYTC_ERR_UNSUPPORTED;
     }
   }
-  const bool tt_form = transposed && K == 3 && dtype == PYTC_BF16 && (C == 64 || C == 128) && tuning_get("dwconvT_tile", 1) != 0;
-  if (!y && !tt_form) {   // statistics-only pass: the K = 3 transposed kernels (what the fused up-block path launches)
-    DwGeom g0;
-    int vec0;
-    PYTC_REQUIRE(transposed && K == 3 && stats && make_geom(g0, N, D, H, W, C, K, stride, dtype, transposed, vec0) && g0.cell,
-                 "dwconv3d: a null output (statistics only) is supported by the K = 3 transposed kernels only");
-  }
   PYTC_REQUIRE(N >= 1 && D >= 1 && H >= 1 && W >= 1 && C >= 1, "dwconv3d: bad shape");
   PYTC_REQUIRE(stride == 1 || stride == 2, "dwconv3d: stride must be 1 or 2");
   PYTC_REQUIRE(dtype == PYTC_F32 || dtype == PYTC_BF16, "dwconv3d: bad dtype");
   PYTC_REQUIRE(!(wide_range && stats), "dwconv3d_fwd_wide: the gradient entry computes no statistics");
-  if (tt_form) {          // the up blocks' resampling conv at C = 64 / 128: one tile of input cells per workgroup (dwconvT_tile_kernels.hip)
-    PYTC_REQUIRE(y || stats, "dwconvT3d: neither output nor statistics requested");
-    DwTTile tt;
-    if (dwconvT_tile_plan(tt, N, D, H, W, C)) {
-      dwconvT_tile_launch(x, y, w, bias, stats, tt, (hipStream_t)stream);
-      PYTC_LAUNCH_CHECK("dwconvT3d_k3_tile");
-      return PYTC_OK;
+  // the up blocks' resampling conv at C = 64 / 128: one tile of input cells per workgroup (dwconvT_tile_kernels.hip).  The plan is made
+  // FIRST: a shape it rejects falls through to the generic kernels, which take a null output only in their cell form (checked below)
+  DwTTile tt;
+  const bool tt_form = transposed && K == 3 && dtype == PYTC_BF16 && (C == 64 || C == 128) && tuning_get("dwconvT_tile", 1) != 0 &&
+                       dwconvT_tile_plan(tt, N, D, H, W, C);
+  // statistics-only passes (null output): the matrix-core stride-1 kernel (the fused block's first pass, pw_dwmix_kernels.hip) and
+  // the K = 3 transposed kernels (tile form / cell form: the fused up-block path)
+  const bool mfma_form = !transposed && !res && !wide_range && dtype == PYTC_BF16 && tuning_get("dwconv_mfma", 1) != 0 &&
+                         (march_ok(D, H, W, C, K, stride, dtype, transposed) || mfma_small_ok(D, H, W, C, K, stride, dtype, transposed));
+  if (!y) {
+    PYTC_REQUIRE(stats, "dwconv3d: neither output nor statistics requested");
+    if (!tt_form && !mfma_form) {
+      DwGeom g0;
+      int vec0;
+      PYTC_REQUIRE(transposed && K == 3 && make_geom(g0, N, D, H, W, C, K, stride, dtype, transposed, vec0) && g0.cell,
+                   "dwconv3d: a null output (statistics only) is supported by the bf16 matrix-core stride-1 kernel and the K = 3 "
+                   "transposed kernels only");
     }
+  }
+  if (tt_form) {
+    dwconvT_tile_launch(x, y, w, bias, stats, tt, (hipStream_t)stream);
+    PYTC_LAUNCH_CHECK("dwconvT3d_k3_tile");
+    return PYTC_OK;
   }
   if (!transposed && K == 3 && stride == 2 && dtype == PYTC_BF16 && y && tuning_get("dwconv_s2_march", 1) != 0) {
     DwS2 t2;          // the down blocks' resampling conv at C = 32 / 64: z-march over an LDS ring (dwconv_s2_kernels.hip)
@@ -1322,7 +1330,7 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
       return PYTC_OK;
     }
   }
-  if (!res && !wide_range && y && mfma_small_ok(D, H, W, C, K, stride, dtype, transposed)) {
+  if (!res && !wide_range && mfma_small_ok(D, H, W, C, K, stride, dtype, transposed)) {
     DwMarch t;
     make_march(t, N, D, H, W, C, TILE_X);
     t.swizzle = tuning_get("dwconv_xcd_swizzle", 1);
@@ -1344,7 +1352,7 @@ static int dw_entry(bool transposed, const void* x, void* y, const float* w, con
   t.cg_inner = tuning_get("dwconv_cg_inner", 1);
     // bf16 forward launches (activations: statistics, no residual): the matrix-core form (dwconv_mfma_kernels.hip) -- one channel per
     // block of v_mfma_f32_4x4x4_16b_bf16, fp32 accumulation.  The gradient entries (res / wide range) keep the fp32-tap VALU kernels.
-    if (dtype == PYTC_BF16 && !res && !wide_range && y && tuning_get("dwconv_mfma", 1) != 0) {
+    if (dtype == PYTC_BF16 && !res && !wide_range && tuning_get("dwconv_mfma", 1) != 0) {
       dwconv_mfma_launch(x, y, w, bias, stats, t, tuning_get("dwconv_mfma_variant", 0), (hipStream_t)stream);
       PYTC_LAUNCH_CHECK("dwconv3d_k3_mfma");
       return PYTC_OK;

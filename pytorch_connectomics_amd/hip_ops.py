@@ -290,8 +290,8 @@ def window_normalize(x: torch.Tensor, *, mode: int = nat.NORM_NONE, binarize: bo
 def dwconv3d(x: torch.Tensor, w_taps: torch.Tensor, bias: Optional[torch.Tensor], *, K: int, stride: int = 1,
              stats: bool = True, transposed: bool = False, y: Optional[torch.Tensor] = None, store: bool = True,
              wide_range: bool = False):
-    """x (N,D,H,W,C) -> y, stats(N,slots,2,C)|None.  w_taps fp32 (K^3, C).  store=False (transposed K = 3 only): statistics
-    only, y is returned as None (the fused up-block mixer recomputes it).  wide_range: x is a GRADIENT (values far below the
+    """x (N,D,H,W,C) -> y, stats(N,slots,2,C)|None.  w_taps fp32 (K^3, C).  store=False (K = 3: transposed, or bf16 stride 1 on
+    the matrix-core kernel): statistics only, y is returned as None (the fused block / up-block kernels recompute it).  wide_range: x is a GRADIENT (values far below the
     f16 range): the bf16 z-march kernel keeps fp32 partial sums (pytc_dwconv3d_fwd_wide)."""
     _dev(x, "x"); _dev(w_taps, "w_taps")
     N, D, H, W, Cc = x.shape
@@ -302,8 +302,9 @@ def dwconv3d(x: torch.Tensor, w_taps: torch.Tensor, bias: Optional[torch.Tensor]
         p = K // 2
         oshape = (N, (D + 2 * p - K) // stride + 1, (H + 2 * p - K) // stride + 1, (W + 2 * p - K) // stride + 1, Cc)
     if not store:
-        if not (transposed and K == 3 and stats):
-            raise ValueError("dwconv3d(store=False) is the statistics-only mode of the K = 3 transposed conv")
+        # statistics only: the K = 3 transposed kernels and the bf16 matrix-core stride-1 kernel (the C ABI rejects other shapes)
+        if not (K == 3 and stats and (transposed or (stride == 1 and x.dtype == torch.bfloat16))):
+            raise ValueError("dwconv3d(store=False) is the statistics-only mode of the K = 3 transposed / bf16 stride-1 convs")
         y = None
     elif y is None:
         y = torch.empty(oshape, dtype=x.dtype, device=x.device)
@@ -322,7 +323,7 @@ def dwconv3d(x: torch.Tensor, w_taps: torch.Tensor, bias: Optional[torch.Tensor]
         if PROFILER.enabled:
             sym = _DW_VARIANTS.get(nat.lib().pytc_dwconv3d_kernel_variant(N, D, H, W, Cc, K, stride, dt, 0))
         fn = nat.lib().pytc_dwconv3d_fwd_wide if wide_range else nat.lib().pytc_dwconv3d_fwd
-        _run(f"dwconv3d_fwd[{tag}]", _nbytes(x, y), fn, _p(x), _p(y), _p(w_taps), _p(bias),
+        _run(f"dwconv3d_fwd[{tag}]" if store else f"dwconv3d_stats[{tag}]", _nbytes(x, y), fn, _p(x), _p(y), _p(w_taps), _p(bias),
              _p(st), N, D, H, W, Cc, K, stride, dt, _stream(), symbol=sym)
     return y, st
 

@@ -441,14 +441,11 @@ class ConnectomicsModule(nn.Module):
                                     "mask_slice": get("mask_slice", get("mask")),
                                     "apply_deep_supervision": bool(get("apply_deep_supervision", True)),
                                     "kwargs": dict(get("kwargs", None) or {})})
-        # adaptive loss balancing (uncertainty / GradNorm, reference training/losses/balancing.py) is outside the hot path this
-        # package replaces: static term weights only, anything else is refused up front
-        lb = getattr(loss_cfg, "loss_balancing", None)
-        strategy = (lb.get("strategy") if isinstance(lb, dict) else getattr(lb, "strategy", None)) if lb is not None else \
-            getattr(loss_cfg, "strategy", None)
-        if strategy not in (None, "", "none", "static", "fixed"):
-            raise NotImplementedError(f"model.loss.loss_balancing.strategy={strategy!r}: adaptive loss balancing is not part of "
-                                      "pytorch_connectomics_amd (static loss weights only)")
+        # adaptive loss balancing (reference training/losses/balancing.py:64-222; tutorials/mitoEM/common.yaml:54-55): a trainable
+        # sub-module, every loss entry is one task.  `uncertainty` rides on the fused loss kernel (the learned task coefficients
+        # enter it as host scalars, _balanced_scale_loss); `gradnorm` needs every task's own graph and takes the generic path
+        from .balancing import build_loss_weighter
+        self.loss_weighter = build_loss_weighter(cfg, len(self.loss_terms), self.model)
         self.fused_loss = bool(getattr(loss_cfg, "fused", True))
         # every prediction is clamped before its loss, at every scale (orchestrator.py:95-96,574; schema/model.py:50-51)
         self.clamp_min = float(getattr(loss_cfg, "deep_supervision_clamp_min", -20.0))
@@ -506,14 +503,19 @@ class ConnectomicsModule(nn.Module):
             total = total + v
         return total, parts
 
-    def _term_loss(self, pred, target, mask=None, terms=None):
-        """Weighted sum of the loss terms `terms` (list of (index, term); default: all) on one prediction tensor."""
-        terms = list(enumerate(self.loss_terms)) if terms is None else terms
-        pred = torch.clamp(pred, min=self.clamp_min, max=self.clamp_max)
+    def _fusable(self, pred, mask, terms) -> bool:
         # (torch's BCEWithLogitsLoss under a mask averages over ALL voxels -- masked ones as logit -20 / target 0 --, which the fused
         # kernel's valid-voxel mean is not)
         plain_bce_masked = mask is not None and any(t["fn"] == "BCEWithLogitsLoss" for _, t in terms)
-        if pred.is_cuda and self.fused_loss and not plain_bce_masked and all(self._term_is_fusable(t, pred) for _, t in terms):
+        return bool(pred.is_cuda and self.fused_loss and not plain_bce_masked and all(self._term_is_fusable(t, pred) for _, t in terms))
+
+    def _term_loss(self, pred, target, mask=None, terms=None, tasks=None):
+        """Weighted sum of the loss terms `terms` (list of (index, term); default: all) on one prediction tensor.
+        tasks: a dict that receives {term index: static weight x raw value, WITH its graph} (adaptive balancing: the caller
+        combines the tasks); the fused kernel steps aside then -- it returns one scalar for all its terms."""
+        terms = list(enumerate(self.loss_terms)) if terms is None else terms
+        pred = torch.clamp(pred, min=self.clamp_min, max=self.clamp_max)
+        if tasks is None and self._fusable(pred, mask, terms):
             res = self._fused_term_loss(pred, target, mask, terms)      # finiteness is checked where fit() reads the value
             if res is not None:
                 return res
@@ -550,7 +552,60 @@ class ConnectomicsModule(nn.Module):
             if not torch.isfinite(v):
                 raise FloatingPointError(f"loss term {t['fn']} is not finite")
             parts[f"loss_{i}_{t['fn']}"] = v.detach()
+            if tasks is not None:
+                tasks[i] = t["weight"] * v
             total = total + t["weight"] * v
+        return total, parts
+
+    def _balanced_scale_loss(self, items, stage: str):
+        """One output scale under adaptive loss balancing (orchestrator.py:110-127, 779-790): `items` = [(pred, target, mask, terms)]
+        (one entry per head); every term is a task whose loss is its static weight x raw value, the weighter combines ALL tasks of
+        the scale in one call.  Uncertainty weighting on fusable terms keeps the fused HIP loss: the per-task coefficients
+        0.5 * exp(-s_i) multiply the static weights as host scalars (one device -> host read of T floats per scale), the kernel's
+        scalar is sum_i coef_i * task_i exactly, and the gradient of the log-variances -- which the kernel knows nothing of -- comes
+        from a zero-valued term built on the detached task values."""
+        from .balancing import UncertaintyLossWeighter
+        w = self.loss_weighter
+        idx = sorted(i for _, _, _, terms in items for i, _ in terms)
+        if idx != list(range(len(self.loss_terms))):
+            raise ValueError(f"adaptive loss balancing combines all {len(self.loss_terms)} loss terms at every scale it sees; this scale "
+                             f"carries terms {idx} (apply_deep_supervision: false on a term is not compatible with loss_balancing)")
+        names = [f"loss_{i}_{self.loss_terms[i]['fn']}" for i in idx]
+        parts: Dict[str, Any] = {}
+        if isinstance(w, UncertaintyLossWeighter) and all(self._fusable(torch.clamp(p, self.clamp_min, self.clamp_max), m, terms)
+                                                           for p, _, m, terms in items):
+            coef = 0.5 * torch.exp(-w.log_vars)
+            host = [float(c) for c in coef.detach().cpu().tolist()]
+            fused_total, ok = 0.0, True
+            raw: Dict[int, torch.Tensor] = {}
+            for pred, target, mask, terms in items:
+                scaled = [(i, {**t, "weight": t["weight"] * host[i]}) for i, t in terms]
+                res = self._fused_term_loss(torch.clamp(pred, min=self.clamp_min, max=self.clamp_max), target, mask, scaled)
+                if res is None:
+                    ok = False
+                    break
+                fused_total = fused_total + res[0]
+                for i, t in terms:
+                    raw[i] = res[1][f"loss_{i}_{t['fn']}"]
+                parts.update(res[1])
+            if ok:
+                tasks = torch.stack([self.loss_terms[i]["weight"] * raw[i].detach().float().reshape(()) for i in idx])
+                total = fused_total + ((coef - coef.detach()) * tasks).sum() + 0.5 * w.log_vars.sum()
+                wts = torch.exp(-w.log_vars).detach()
+                for n, wt in zip(names, wts):
+                    parts[f"{n}_balance_weight"] = wt
+                    parts[f"{stage}_loss_uncertainty/{n}_weight"] = wt
+                parts[f"{stage}_loss_uncertainty/reg"] = (0.5 * w.log_vars.sum()).detach()
+                return total, parts
+            parts = {}
+        tasks: Dict[int, torch.Tensor] = {}
+        for pred, target, mask, terms in items:
+            _, pr = self._term_loss(pred, target, mask, terms, tasks=tasks)
+            parts.update(pr)
+        total, wts, logs = w.combine([tasks[i] for i in idx], names, stage)
+        for n, wt in zip(names, wts):
+            parts[f"{n}_balance_weight"] = wt
+        parts.update(logs)
         return total, parts
 
     def _head_of(self, term_index: int, term, heads) -> str:
@@ -574,6 +629,7 @@ class ConnectomicsModule(nn.Module):
         return want
 
     def _compute_loss(self, outputs, labels, mask=None):
+        stage = "train" if self.training else "val"
         main = unwrap_main_output(outputs)
         if isinstance(main, dict):
             # named heads: every term reads its own head; the terms of one head share a (fused) reduction
@@ -583,10 +639,13 @@ class ConnectomicsModule(nn.Module):
             for i, t in enumerate(self.loss_terms):
                 by_head.setdefault(self._head_of(i, t, main), []).append((i, t))
             total, parts = 0.0, {}
-            for head, terms in by_head.items():
-                v, pr = self._term_loss(main[head], labels, mask, terms)
-                total = total + v
-                parts.update(pr)
+            if self.loss_weighter is not None:
+                total, parts = self._balanced_scale_loss([(main[head], labels, mask, terms) for head, terms in by_head.items()], stage)
+            else:
+                for head, terms in by_head.items():
+                    v, pr = self._term_loss(main[head], labels, mask, terms)
+                    total = total + v
+                    parts.update(pr)
             total = self.ds_weights[0] * total
             parts["train_loss_total"] = total.detach()
             return total, parts
@@ -594,7 +653,11 @@ class ConnectomicsModule(nn.Module):
             if t["pred_head"] is not None:
                 raise ValueError(f"Loss term 'loss_{i}_{t['fn']}' requested pred_head='{t['pred_head']}' but the model "
                                  "output is a single tensor.")
-        total, parts = self._term_loss(main, labels, mask)
+        all_terms = list(enumerate(self.loss_terms))
+        if self.loss_weighter is not None:
+            total, parts = self._balanced_scale_loss([(main, labels, mask, all_terms)], stage)
+        else:
+            total, parts = self._term_loss(main, labels, mask)
         total = self.ds_weights[0] * total
         if self.deep_supervision and isinstance(outputs, dict):
             for i in range(1, 5):
@@ -606,7 +669,10 @@ class ConnectomicsModule(nn.Module):
                 on_scales = [(j, t) for j, t in enumerate(self.loss_terms) if t.get("apply_deep_supervision", True)]
                 if not on_scales:
                     continue
-                li, _ = self._term_loss(ds, tgt, m, on_scales)
+                if self.loss_weighter is not None:
+                    li, _ = self._balanced_scale_loss([(ds, tgt, m, on_scales)], stage)
+                else:
+                    li, _ = self._term_loss(ds, tgt, m, on_scales)
                 total = total + self.ds_weights[i] * li
         parts["train_loss_total"] = total.detach()
         return total, parts
@@ -627,12 +693,18 @@ class ConnectomicsModule(nn.Module):
         return {"val_loss_total": loss, "val_jaccard": (p & t).sum().float() / union}
 
     def configure_optimizers(self):
-        opt = build_optimizer(self.cfg, self.model)
+        # with an adaptive loss weighter the optimizer takes the whole module (its task weights train with the network), as the
+        # reference does (lightning/model.py:1160-1162)
+        opt = build_optimizer(self.cfg, self if self.loss_weighter is not None else self.model)
         return opt, build_lr_scheduler(self.cfg, opt)
 
     # ---- checkpoints in the Lightning layout ------------------------------------------------------
     def checkpoint_dict(self, optimizer=None) -> Dict[str, Any]:
         sd = {"model." + k: v.detach().cpu() for k, v in self.model.state_dict().items()}
+        if self.loss_weighter is not None:      # a sub-module of the LightningModule in the reference: same key prefix
+            sd.update({"loss_weighter." + k: v.detach().cpu() for k, v in self.loss_weighter.state_dict().items() if v is not None})
+            if getattr(self.loss_weighter, "initial_losses", None) is not None:
+                sd["loss_weighter.initial_losses"] = self.loss_weighter.initial_losses.detach().cpu()
         ck = {"state_dict": sd,
               "global_step": self.global_step,
               "pytc_metadata": {"format_version": 1, "model_arch": str(getattr(self.cfg.model.arch, "type", ""))}}
@@ -655,14 +727,17 @@ class ConnectomicsModule(nn.Module):
         once `fit` has built them (a true resume: Adam moments, the LR schedule position and the EMA shadow continue)."""
         sd = {k[len("model."):]: v for k, v in ck["state_dict"].items()
               if k.startswith("model.") and not k.startswith("model.loss_functions.")}
-        weighter = sorted(k for k in ck["state_dict"] if k.startswith("loss_weighter.") or ".loss_weighter." in "." + k)
-        if weighter:
-            # the reference saves the adaptive balancer's learned task weights beside the model (orchestrator `loss_weighter`);
-            # this package trains with static term weights only, so a resume would silently fall back to them -- say so
+        wsd = {k[len("loss_weighter."):]: v for k, v in ck["state_dict"].items() if k.startswith("loss_weighter.")}
+        if wsd and self.loss_weighter is None:
             import warnings
-            warnings.warn(f"checkpoint carries adaptive loss-balancing state ({len(weighter)} tensors, e.g. {weighter[0]!r}); "
-                          "pytorch_connectomics_amd uses static loss weights: the learned task weights are NOT restored",
-                          RuntimeWarning, stacklevel=2)
+            warnings.warn(f"checkpoint carries adaptive loss-balancing state ({len(wsd)} tensors, e.g. 'loss_weighter.{sorted(wsd)[0]}') but "
+                          "model.loss.loss_balancing is not configured: the learned task weights are NOT restored", RuntimeWarning, stacklevel=2)
+        elif wsd:
+            if "initial_losses" in wsd and getattr(self.loss_weighter, "initial_losses", 0) is None:
+                self.loss_weighter.initial_losses = wsd["initial_losses"].clone()        # a None buffer cannot be load_state_dict'ed
+            bad = self.loss_weighter.load_state_dict({k: v for k, v in wsd.items() if k != "initial_losses"}, strict=False)
+            if bad.unexpected_keys:
+                raise RuntimeError(f"checkpoint loss_weighter state does not match the configured strategy: unexpected {bad.unexpected_keys}")
         missing, unexpected = self.model.load_state_dict(sd, strict=False)
         # a reference checkpoint may carry deep-supervision heads of a trunk built with them (`out_1..out_4`); anything else
         # missing / unexpected is an architecture mismatch

@@ -1291,9 +1291,64 @@ def config_defaults():
     print("wrote config_defaults.json")
 
 
+
+def balancing():
+    """connectomics/training/losses/balancing.py: UncertaintyLossWeighter and GradNormLossWeighter `combine` on a two-layer toy model
+    with three task losses: totals, the task weights, the gradients w.r.t. the weighter's own parameters and the model, a second
+    step (initial losses frozen at the first), eval mode."""
+    S._stub_pkg("connectomics.training.losses")
+    bal = S.ref("connectomics.training.losses.balancing")
+    out = {}
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    out["w0"], out["b0"], out["w2"], out["b2"] = (p.detach().numpy().copy() for p in net.parameters())
+    x = torch.randn(7, 6)
+    tgt = torch.randn(7, 3)
+    out["x"], out["tgt"] = x.numpy(), tgt.numpy()
+
+    def tasks():
+        y = net(x)
+        return [((y[:, 0] - tgt[:, 0]) ** 2).mean() * 1.0, (y[:, 1] - tgt[:, 1]).abs().mean() * 0.5, torch.nn.functional.softplus(y[:, 2] * tgt[:, 2]).mean() * 2.0]
+    names = ["a", "b", "c"]
+    uw = bal.UncertaintyLossWeighter(3)
+    with torch.no_grad():
+        uw.log_vars.copy_(torch.tensor([0.3, -0.2, 0.0]))
+    tot, wts, _ = uw.combine(tasks(), names, "train")
+    tot.backward()
+    out["unc_total"], out["unc_weights"] = np.float64(tot.item()), wts.numpy()
+    out["unc_grad_logvars"], out["unc_grad_w2"] = uw.log_vars.grad.numpy().copy(), net[2].weight.grad.numpy().copy()
+    for strat in ("last", "first", "all"):
+        net.zero_grad()
+        cfg_params = bal._select_shared_parameters(net, strat)
+        gw = bal.GradNormLossWeighter(3, alpha=0.5, gradnorm_lambda=1.0, shared_parameters=cfg_params)
+        with torch.no_grad():
+            gw.task_weights.copy_(torch.tensor([1.5, 0.7, 1.0]))
+        gw.train()
+        tot, wts, _ = gw.combine(tasks(), names, "train")
+        tot.backward()
+        out[f"gn_{strat}_total"], out[f"gn_{strat}_weights"] = np.float64(tot.item()), wts.numpy()
+        out[f"gn_{strat}_grad_tw"], out[f"gn_{strat}_grad_w2"] = gw.task_weights.grad.numpy().copy(), net[2].weight.grad.numpy().copy()
+        if strat == "last":      # a second step after an SGD move: ratios against the FIRST step's losses
+            with torch.no_grad():
+                for p in net.parameters():
+                    p -= 0.05 * p.grad
+                gw.task_weights -= 0.1 * gw.task_weights.grad
+            net.zero_grad(); gw.task_weights.grad = None
+            tot2, wts2, _ = gw.combine(tasks(), names, "train")
+            tot2.backward()
+            out["gn_step2_total"], out["gn_step2_weights"], out["gn_step2_grad_tw"] = np.float64(tot2.item()), wts2.numpy(), gw.task_weights.grad.numpy().copy()
+            gw.eval()
+            tot3, _, _ = gw.combine(tasks(), names, "val")
+            out["gn_eval_total"] = np.float64(tot3.item())
+            with torch.no_grad():      # restore the initial weights for the other strategies
+                for p, k in zip(net.parameters(), ("w0", "b0", "w2", "b2")):
+                    p.copy_(torch.from_numpy(out[k]))
+    save("balancing.npz", **out)
+
+
 if __name__ == "__main__":
     parts = {"manifests": manifests, "optimizers": optimizers, "schedules": schedules, "selectors": selectors, "outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
-             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "lazy_tta": lazy_tta, "masks": masks, "accessor": accessor, "accessor_tiles": accessor_tiles, "ds_loss": ds_loss, "loss_orchestration": loss_orchestration, "losses_extra": losses_extra, "public_adapters": public_adapters, "public_helpers": public_helpers, "volume_normalisation": volume_normalisation, "config_defaults": config_defaults}
+             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "lazy_tta": lazy_tta, "masks": masks, "accessor": accessor, "accessor_tiles": accessor_tiles, "ds_loss": ds_loss, "loss_orchestration": loss_orchestration, "losses_extra": losses_extra, "balancing": balancing, "public_adapters": public_adapters, "public_helpers": public_helpers, "volume_normalisation": volume_normalisation, "config_defaults": config_defaults}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:
         parts[name]()

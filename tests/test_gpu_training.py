@@ -803,3 +803,77 @@ def test_mednext_gradients_with_the_norm_backward_in_the_gemm_epilogue_are_as_cl
     for n in ref:
         if ".norm." in n:
             assert e_new[n] <= 1.5 * e_old[n] + 5e-3, (n, e_new[n], e_old[n])
+
+
+def _balancing_cfg(strategy):
+    from pytorch_connectomics_amd.config import ConfigNode, schema_defaults
+    cfg = ConfigNode(schema_defaults())
+    cfg.model.arch.type, cfg.model.in_channels, cfg.model.out_channels = "mednext_custom", 1, 2
+    cfg.model.mednext.base_channels, cfg.model.mednext.exp_r, cfg.model.mednext.kernel_size = 8, 2, 3
+    cfg.model.mednext.block_counts = [1] * 9
+    cfg.optimization.precision = "bf16-mixed"
+    cfg.optimization.optimizer.lr = 1e-2
+    cfg.model.loss.loss_balancing = {"strategy": strategy}
+    return cfg
+
+
+def test_uncertainty_balancing_rides_on_the_fused_loss_kernel():
+    """`model.loss.loss_balancing.strategy: uncertainty` (tutorials/mitoEM/common.yaml:54-55; reference balancing.py:64-88): with
+    fusable terms the fused BCE / Dice kernel takes the learned coefficients 0.5 exp(-s_i) as host scalars.  Value, gradient of the
+    log-variances and gradient of the logits equal the generic path's (torch ops + UncertaintyLossWeighter.combine) on the same
+    tensors; the module trains, the log-variances move, and they travel in the checkpoint under the reference's key prefix."""
+    from pytorch_connectomics_amd.training.module import ConnectomicsModule, fit, synthetic_batches
+    dev = torch.device("cuda")
+    cfg = _balancing_cfg("uncertainty")
+    cfg.model.loss.losses = [{"function": "WeightedBCEWithLogitsLoss", "weight": 1.0, "pos_weight": 2.0, "pred_slice": "0:1", "target_slice": "0:1"},
+                             {"function": "DiceLoss", "weight": 0.5, "kwargs": {"sigmoid": True}, "pred_slice": "0:1", "target_slice": "0:1"},
+                             {"function": "DiceLoss", "weight": 2.0, "kwargs": {"sigmoid": True}, "pred_slice": "1:2", "target_slice": "1:2"}]
+    torch.manual_seed(0)
+    m = ConnectomicsModule(cfg).to(dev)
+    with torch.no_grad():
+        m.loss_weighter.log_vars.copy_(torch.tensor([0.3, -0.4, 0.1]))
+    pred0 = torch.randn(2, 2, 16, 16, 16, device=dev)
+    tgt = (torch.rand(2, 2, 16, 16, 16, device=dev) > 0.7).float()
+    res = {}
+    for fused in (True, False):
+        m.fused_loss = fused
+        pred = pred0.clone().requires_grad_(True)
+        m.loss_weighter.log_vars.grad = None
+        tot, parts = m._balanced_scale_loss([(pred, tgt, None, list(enumerate(m.loss_terms)))], "train")
+        tot.backward()
+        res[fused] = (float(tot), m.loss_weighter.log_vars.grad.clone(), pred.grad.clone(), parts)
+    assert res[True][0] == pytest.approx(res[False][0], rel=2e-6)
+    assert torch.allclose(res[True][1], res[False][1], rtol=1e-5, atol=1e-7)
+    assert torch.allclose(res[True][2], res[False][2], rtol=1e-4, atol=1e-9)
+    assert set(res[False][3]) <= set(res[True][3]) and "loss_2_DiceLoss_balance_weight" in res[True][3]
+    m.fused_loss = True
+    s0 = m.loss_weighter.log_vars.detach().clone()
+    hist, opt = fit(m, synthetic_batches(2, (32, 32, 32), out_channels=2, device=dev), max_steps=6, device=dev, log=None)
+    assert all(torch.isfinite(torch.tensor(hist)))
+    assert not torch.equal(m.loss_weighter.log_vars.detach(), s0)            # the task weights trained with the network
+    ck = m.checkpoint_dict(opt)
+    assert "loss_weighter.log_vars" in ck["state_dict"]
+    m2 = ConnectomicsModule(cfg).to(dev)
+    m2.load_checkpoint_dict(ck)
+    assert torch.equal(m2.loss_weighter.log_vars.detach().cpu(), m.loss_weighter.log_vars.detach().cpu())
+
+
+def test_gradnorm_balancing_trains_through_the_hip_autograd_functions():
+    """`model.loss.loss_balancing.strategy: gradnorm` (mito_betaseg tutorials): per-task gradient norms are taken on the last
+    trainable parameter with retain_graph through the HIP autograd Functions, the task weights get gradients and move with the
+    optimizer that now owns the whole module."""
+    from pytorch_connectomics_amd.training.module import ConnectomicsModule, fit, synthetic_batches
+    cfg = _balancing_cfg("gradnorm")
+    cfg.model.loss.losses = [{"function": "WeightedBCEWithLogitsLoss", "weight": 1.0, "pos_weight": "auto", "pred_slice": "0:1", "target_slice": "0:1"},
+                             {"function": "DiceLoss", "weight": 1.0, "kwargs": {"sigmoid": True}, "pred_slice": "0:1", "target_slice": "0:1"},
+                             {"function": "WeightedMSELoss", "weight": 2.0, "kwargs": {"tanh": True}, "pred_slice": "1:2", "target_slice": "1:2"}]
+    torch.manual_seed(0)
+    m = ConnectomicsModule(cfg)
+    w0 = m.loss_weighter.task_weights.detach().clone()
+    hist, opt = fit(m, synthetic_batches(2, (32, 32, 32), out_channels=2, device=torch.device("cuda")), max_steps=6,
+                    device=torch.device("cuda"), log=None)
+    assert all(torch.isfinite(torch.tensor(hist))) and hist[-1] < hist[0] * 1.5
+    assert not torch.equal(m.loss_weighter.task_weights.detach().cpu(), w0)            # the task weights trained
+    assert m.loss_weighter.initial_losses is not None and m.loss_weighter.initial_losses.numel() == 3
+    ck = m.checkpoint_dict(opt)
+    assert "loss_weighter.task_weights" in ck["state_dict"]

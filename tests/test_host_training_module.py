@@ -457,17 +457,24 @@ def test_resume_accepts_reference_optimizer_layout_and_extra_heads():
         assert float(opt.state[p_new]["step"]) == 1.0
 
 
-def test_checkpoint_with_adaptive_loss_weights_warns_instead_of_dropping_them_silently():
-    """a reference run trained with `loss_balancing.strategy: uncertainty` stores `loss_weighter.*` tensors; this
-    package has static weights only, so loading such a checkpoint must say that the learned task weights are not restored."""
+def test_checkpoint_with_adaptive_loss_weights_warns_when_no_balancer_is_configured():
+    """a reference run trained with `loss_balancing.strategy: uncertainty` stores `loss_weighter.*` tensors; a module built
+    WITHOUT loss balancing cannot use them and says so; one built with it restores them (test_loss_balancing_matches_reference_fixture)."""
     cfg = _cfg()
     m = ConnectomicsModule(cfg, model=SimpleModel())
     ck = {"state_dict": {"model." + k: v.clone() for k, v in m.model.state_dict().items()}, "global_step": 3, "epoch": 1}
-    ck["state_dict"]["loss_weighter.log_vars"] = torch.zeros(2)
+    ck["state_dict"]["loss_weighter.log_vars"] = torch.tensor([0.25, -0.5])
     m2 = ConnectomicsModule(cfg, model=SimpleModel())
     with pytest.warns(RuntimeWarning, match="adaptive loss-balancing state"):
         m2.load_checkpoint_dict(ck)
     assert m2.global_step == 3
+    cfg.model.loss.loss_balancing = {"strategy": "uncertainty"}
+    m3 = ConnectomicsModule(cfg, model=SimpleModel())
+    m3.load_checkpoint_dict(ck)
+    assert torch.equal(m3.loss_weighter.log_vars.detach(), torch.tensor([0.25, -0.5]))
+    cfg.model.loss.loss_balancing = {"strategy": "gradnorm"}
+    with pytest.raises(RuntimeError, match="does not match the configured strategy"):
+        ConnectomicsModule(cfg, model=SimpleModel()).load_checkpoint_dict(ck)
 
 
 def test_per_channel_bce_and_auto_pos_weight_match_reference_fixture():
@@ -533,16 +540,14 @@ def test_monai_style_losses_follow_their_published_formulas():
     assert torch.allclose(tot, want, rtol=1e-6) and len(parts) == 4
 
 
-def test_adaptive_loss_balancing_is_refused():
-    """Uncertainty / GradNorm balancing (reference training/losses/balancing.py) is outside the hot path:
-    a config that asks for it fails at construction instead of silently training with static weights."""
+def test_static_loss_weights_are_the_default():
+    """No `loss_balancing` (or strategy none): no weighter, the fused loss path stays on (the adaptive strategies:
+    test_loss_balancing_matches_reference_fixture)."""
     cfg = _cfg()
-    for strategy in ("gradnorm", "uncertainty"):
-        cfg.model.loss.loss_balancing = {"strategy": strategy}
-        with pytest.raises(NotImplementedError, match="adaptive loss balancing"):
-            ConnectomicsModule(cfg, model=SimpleModel())
-    cfg.model.loss.loss_balancing = {"strategy": "none"}
-    assert ConnectomicsModule(cfg, model=SimpleModel()).fused_loss
+    m = ConnectomicsModule(cfg, model=SimpleModel())
+    assert m.loss_weighter is None and m.fused_loss
+    cfg.model.loss.loss_balancing = {"strategy": None}
+    assert ConnectomicsModule(cfg, model=SimpleModel()).loss_weighter is None
 
 
 def test_loss_orchestration_matches_reference_orchestrator_fixture():
@@ -585,3 +590,100 @@ def test_load_ema_state_dict_finds_the_callback_entry():
     assert load_ema_state_dict({"callbacks": {"EMAWeightsCallback": {"ema_state": {}, "updates": 0}}}) is None
     assert load_ema_state_dict({"callbacks": {"ModelCheckpoint": {}}}) is None
     assert load_ema_state_dict({"callbacks": None}) is None and load_ema_state_dict({}) is None
+
+
+def test_loss_balancing_matches_reference_fixture():
+    """tests/golden/balancing.npz (make_golden.py --balancing): the reference's UncertaintyLossWeighter and GradNormLossWeighter on a
+    toy model with three task losses -- totals, task weights, gradients of the weighter's parameters and of the model, the second
+    step's ratios against the first step's losses, eval mode."""
+    from pytorch_connectomics_amd.training.balancing import (GradNormLossWeighter, UncertaintyLossWeighter, build_loss_weighter,
+                                                             select_shared_parameters)
+    z = np.load(GOLD / "balancing.npz")
+    net = nn.Sequential(nn.Linear(6, 5), nn.Tanh(), nn.Linear(5, 3))
+
+    def reset():
+        with torch.no_grad():
+            for p, k in zip(net.parameters(), ("w0", "b0", "w2", "b2")):
+                p.copy_(torch.from_numpy(z[k]))
+        net.zero_grad()
+    x, tgt = torch.from_numpy(z["x"]), torch.from_numpy(z["tgt"])
+
+    def tasks():
+        y = net(x)
+        return [((y[:, 0] - tgt[:, 0]) ** 2).mean() * 1.0, (y[:, 1] - tgt[:, 1]).abs().mean() * 0.5, F.softplus(y[:, 2] * tgt[:, 2]).mean() * 2.0]
+    names = ["a", "b", "c"]
+    reset()
+    uw = UncertaintyLossWeighter(3)
+    with torch.no_grad():
+        uw.log_vars.copy_(torch.tensor([0.3, -0.2, 0.0]))
+    tot, wts, _ = uw.combine(tasks(), names, "train")
+    tot.backward()
+    assert float(tot) == pytest.approx(float(z["unc_total"]), rel=1e-6) and np.allclose(wts.numpy(), z["unc_weights"], rtol=1e-6)
+    assert np.allclose(uw.log_vars.grad.numpy(), z["unc_grad_logvars"], rtol=1e-5) and np.allclose(net[2].weight.grad.numpy(), z["unc_grad_w2"], rtol=1e-5, atol=1e-8)
+    for strat in ("last", "first", "all"):
+        reset()
+        gw = GradNormLossWeighter(3, alpha=0.5, gradnorm_lambda=1.0, shared_parameters=select_shared_parameters(net, strat))
+        with torch.no_grad():
+            gw.task_weights.copy_(torch.tensor([1.5, 0.7, 1.0]))
+        gw.train()
+        tot, wts, _ = gw.combine(tasks(), names, "train")
+        tot.backward()
+        assert float(tot) == pytest.approx(float(z[f"gn_{strat}_total"]), rel=1e-6), strat
+        assert np.allclose(wts.numpy(), z[f"gn_{strat}_weights"], rtol=1e-6)
+        assert np.allclose(gw.task_weights.grad.numpy(), z[f"gn_{strat}_grad_tw"], rtol=2e-5, atol=1e-7), strat
+        assert np.allclose(net[2].weight.grad.numpy(), z[f"gn_{strat}_grad_w2"], rtol=1e-5, atol=1e-8)
+        if strat == "last":
+            with torch.no_grad():
+                for p in net.parameters():
+                    p -= 0.05 * p.grad
+                gw.task_weights -= 0.1 * gw.task_weights.grad
+            net.zero_grad(); gw.task_weights.grad = None
+            tot2, wts2, _ = gw.combine(tasks(), names, "train")
+            tot2.backward()
+            assert float(tot2) == pytest.approx(float(z["gn_step2_total"]), rel=1e-6) and np.allclose(wts2.numpy(), z["gn_step2_weights"], rtol=1e-6)
+            assert np.allclose(gw.task_weights.grad.numpy(), z["gn_step2_grad_tw"], rtol=2e-5, atol=1e-7)
+            gw.eval()
+            assert float(gw.combine(tasks(), names, "val")[0]) == pytest.approx(float(z["gn_eval_total"]), rel=1e-6)
+    # through the module: the weighter is a trainable sub-module, the optimizer gets its parameters, the fused loss path steps aside
+    cfg = _cfg()
+    cfg.model.loss.losses = [{"function": "WeightedBCEWithLogitsLoss", "weight": 1.0}, {"function": "DiceLoss", "weight": 0.5, "kwargs": {"sigmoid": True}}]
+    cfg.model.loss.loss_balancing = {"strategy": "gradnorm", "gradnorm_alpha": 0.5}
+    m = ConnectomicsModule(cfg, model=SimpleModel())
+    assert isinstance(m.loss_weighter, GradNormLossWeighter) and m.loss_weighter.shared_parameters[0] is list(m.model.parameters())[-1]
+    opt, _ = m.configure_optimizers()
+    assert any(p is m.loss_weighter.task_weights for g in opt.param_groups for p in g["params"])
+    batch = {"image": torch.rand(2, 1, 8, 8, 8), "label": (torch.rand(2, 1, 8, 8, 8) > 0.7).float()}
+    loss = m.training_step(batch)
+    loss.backward()
+    assert m.loss_weighter.task_weights.grad is not None and "loss_1_DiceLoss_balance_weight" in m.last_log
+    # checkpoint round trip: task weights and the first step's losses travel under the reference's `loss_weighter.` prefix
+    ck = m.checkpoint_dict()
+    assert {"loss_weighter.task_weights", "loss_weighter.initial_losses"} <= set(ck["state_dict"])
+    m2 = ConnectomicsModule(cfg, model=SimpleModel())
+    with torch.no_grad():
+        m.loss_weighter.task_weights.add_(0.25)
+    m2.load_checkpoint_dict(m.checkpoint_dict())
+    assert torch.equal(m2.loss_weighter.task_weights, m.loss_weighter.task_weights) and torch.equal(m2.loss_weighter.initial_losses, m.loss_weighter.initial_losses)
+    # uncertainty (tutorials/mitoEM/common.yaml:54-55) through the module: total = sum 0.5 exp(-s_i) w_i L_i + 0.5 sum s_i
+    cfg.model.loss.loss_balancing = {"strategy": "uncertainty"}
+    mu = ConnectomicsModule(cfg, model=SimpleModel())
+    assert isinstance(mu.loss_weighter, UncertaintyLossWeighter)
+    with torch.no_grad():
+        mu.loss_weighter.log_vars.copy_(torch.tensor([0.4, -0.3]))
+    loss = mu.training_step(batch)
+    raw = [float(mu.last_log["loss_0_WeightedBCEWithLogitsLoss"]), float(mu.last_log["loss_1_DiceLoss"])]
+    want = 0.5 * np.exp(-0.4) * 1.0 * raw[0] + 0.5 * np.exp(0.3) * 0.5 * raw[1] + 0.5 * (0.4 - 0.3)
+    assert float(loss) == pytest.approx(want, rel=1e-5)
+    loss.backward()
+    g = mu.loss_weighter.log_vars.grad
+    assert g[0].item() == pytest.approx(-0.5 * np.exp(-0.4) * raw[0] + 0.5, rel=1e-5) and g[1].item() == pytest.approx(-0.5 * np.exp(0.3) * 0.5 * raw[1] + 0.5, rel=1e-5)
+    # a term that skips the deep-supervision scales cannot be balanced there (the weighter's vector has one entry per term)
+    cfg.model.loss.losses[1]["apply_deep_supervision"] = False
+    md = ConnectomicsModule(cfg, model=SimpleModel())
+    with pytest.raises(ValueError, match="apply_deep_supervision"):
+        md._balanced_scale_loss([(torch.zeros(1, 1, 4, 4, 4), torch.zeros(1, 1, 4, 4, 4), None, [(0, md.loss_terms[0])])], "train")
+    del cfg.model.loss.losses[1]["apply_deep_supervision"]
+    cfg.model.loss.loss_balancing = {"strategy": "pcgrad"}
+    with pytest.raises(ValueError, match="Unknown loss balancing strategy"):
+        ConnectomicsModule(cfg, model=SimpleModel())
+    assert build_loss_weighter(_cfg(), 2, None) is None
