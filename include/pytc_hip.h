@@ -212,7 +212,9 @@ int pytc_dwconv3d_kernel_variant(int N, int D, int H, int W, int C, int K, int s
  * run on the matrix cores (csrc/dwconv_mfma_kernels.hip): the taps enter as bf16 (round to nearest even -- what torch.autocast hands the
  * reference's Conv3d), products are exact, accumulation is fp32; knob dwconv_mfma_variant bit 0 adds the low halves of the taps (16-bit
  * mantissa; always on for planes below 16 voxels), knob dwconv_mfma = 0 restores the VALU kernels (fp32 taps, nine-tap f16 partial sums).
- * The statistics are those of the STORED (rounded) tensor and their slot count does not depend on N. */
+ * The statistics are those of the STORED (rounded) tensor and their slot count does not depend on N.
+ * y = NULL (statistics must be given): the statistics-only pass of the matrix-core launches -- the same products, roundings and partial
+ * sums, bit-identical statistics, nothing stored (first pass of pytc_dwmix_fwd); other kernel families refuse a NULL output. */
 int pytc_dwconv3d_fwd(const void* x, void* y, const float* w, const float* bias, float* stats,
                       int N, int D, int H, int W, int C, int K, int stride, int dtype,
                       void* stream);
@@ -230,6 +232,23 @@ int pytc_dwconv3d_fwd_wide(const void* x, void* y, const float* w, const float* 
  * (gradient operands, see pytc_dwconv3d_fwd_wide).  Replaces the autograd accumulation of the residual
  * branch (MedNeXtBlock.forward: x + conv path; mednext attribute contract at mednext_models.py:104-117). */
 int pytc_dwconv3d_res_supported(int D, int H, int W, int C, int K, int stride, int dtype);
+
+/* Fused MedNeXt residual block (round 5; kind "block": conv1 -> norm -> conv2 -> act -> conv3 -> + x of the external nnunet_mednext
+ * MedNeXtBlock.forward, contract at mednext_models.py:99-126) whose depthwise output never reaches HBM -- SURVEY.md 8(d)'s byte floor
+ * "read x twice, write y once":
+ *   1. pytc_dwconv3d_fwd(x, y = NULL, taps, dw_bias, stats, ...)      statistics of the depthwise output (nothing stored)
+ *   2. pytc_groupnorm_fold_mlp(stats, ...) -> w2n, b2n                GroupNorm folded into per-sample expand operands
+ *   3. pytc_dwmix_fwd(...)                                            the depthwise conv re-formed plane by plane in LDS by the same
+ *      matrix-core kernel, each plane's 64 positions x 32 channels handed through LDS to the channel mixer (expand -> packed-fp16 GELU
+ *      -> fp16 projection -> + x when residual = 1), y [N][D][H][W][32] bf16.
+ * x [N][D][H][W][32] bf16; taps [27][32], dw_bias [32] fp32; w2n = N paired bf16 images of [C_hid][32], b2n [N][C_hid]; w3_f16 =
+ * pytc_pw_pack_weight_paired_f16 image of [32][C_hid], b3 [32].  head_w != NULL: pytc_pw_mlp_head_fwd's epilogue (head_y
+ * [N][D*H*W][n_head] fp32; y may then be NULL).  Results are BIT-IDENTICAL to pytc_dwconv3d_fwd + pytc_pw_mlp_fwd (per_sample = 1,
+ * w3_format = PYTC_W3_F16) / pytc_pw_mlp_head_fwd on the same operands.  C = C_out = 32, C_hid in {64, 96, 128}. */
+int pytc_dwmix_supported(int D, int H, int W, int C, int C_hid, int C_out, int dtype);
+int pytc_dwmix_fwd(const void* x, const float* taps, const float* dw_bias, const void* w2n, const float* b2n, const void* w3_f16,
+                   const float* b3, int residual, void* y, const void* head_w, const float* head_b, float* head_y, int n_head, int N,
+                   int D, int H, int W, int C, int C_hid, int C_out, int dtype, void* stream);
 int pytc_dwconv3d_fwd_res(const void* x, const void* res, void* y, const float* w, const float* bias, int N, int D, int H,
                           int W, int C, int K, int stride, int dtype, void* stream);
 

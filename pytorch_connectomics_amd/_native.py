@@ -88,6 +88,8 @@ _SIGS = {
     "pytc_dwconv3d_fwd_wide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8
                                + [C.c_void_p]),
     "pytc_dwconv3d_res_supported": (C.c_int, [C.c_int] * 7),
+    "pytc_dwmix_supported": (C.c_int, [C.c_int] * 7),
+    "pytc_dwmix_fwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 9 + [C.c_void_p]),
     "pytc_dwconv3d_fwd_res": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8
                               + [C.c_void_p]),
     "pytc_dwconvT3d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7

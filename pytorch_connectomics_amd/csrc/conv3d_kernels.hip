@@ -578,7 +578,7 @@ extern "C" int pytc_conv3d_fwd(const pytc_conv3d_args* a, void* stream) {
   p.kd = a->kd; p.kh = a->kh; p.kw = a->kw;
   p.act_in = a->act_in; p.act_param = a->act_param; p.act_out = PYTC_ACT_NONE;
   p.e.res = a->res; p.e.res_low = nullptr; p.e.res_bias = nullptr; p.e.y = a->y;
-  p.e.rps_out = (long)a->D * a->H * a->W; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode;
+  p.e.rps_out = (long)a->D * a->H * a->W; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode; p.e.nt = 0;
   p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
   hipStream_t s = (hipStream_t)stream;
   ConvTile t; size_t lds_bytes;

@@ -1479,6 +1479,41 @@ extern "C" int pytc_dwconv3d_fwd_res(const void* x, const void* res, void* y, co
   return dw_entry(false, x, y, w, bias, nullptr, N, D, H, W, C, K, stride, dtype, stream, res);
 }
 
+extern "C" int pytc_dwmix_supported(int D, int H, int W, int C, int C_hid, int C_out, int dtype) {
+  return (dtype == PYTC_BF16 && C == 32 && C_out == 32 && (C_hid == 64 || C_hid == 96 || C_hid == 128) && tuning_get("dwconv_mfma", 1) != 0 &&
+          (march_ok(D, H, W, C, 3, 1, dtype, 0) || mfma_small_ok(D, H, W, C, 3, 1, dtype, 0))) ? 1 : 0;
+}
+
+extern "C" int pytc_dwmix_fwd(const void* x, const float* taps, const float* dw_bias, const void* w2n, const float* b2n,
+                              const void* w3_f16, const float* b3, int residual, void* y, const void* head_w, const float* head_b,
+                              float* head_y, int n_head, int N, int D, int H, int W, int C, int C_hid, int C_out, int dtype,
+                              void* stream) {
+  PYTC_REQUIRE(x && taps && w2n && b2n && w3_f16 && b3, "dwmix: null pointer");
+  PYTC_REQUIRE(N >= 1 && pytc_dwmix_supported(D, H, W, C, C_hid, C_out, dtype),
+               "dwmix: bf16, C = C_out = 32, C_hid in {64, 96, 128}, a shape of the matrix-core depthwise kernel (D >= 8, H, W >= 8)");
+  PYTC_REQUIRE(y || (head_w && head_y), "dwmix: neither the block output nor the head output requested");
+  PYTC_REQUIRE(!head_w || (head_y && n_head >= 1 && n_head <= 16), "dwmix: the fused head writes 1..16 channels to head_y");
+  DwMarch t;
+  make_march(t, N, D, H, W, C, TILE_X);
+  t.swizzle = tuning_get("dwconv_xcd_swizzle", 1);
+  t.cg_inner = tuning_get("dwconv_cg_inner", 1);
+  DwMix mx{};
+  mx.w2n = (const bf16x8_t*)w2n; mx.b2n = b2n; mx.w3 = (const h8_t*)w3_f16; mx.b3 = b3;
+  mx.w2_stride = (long)C_hid * C / 8;
+  mx.residual = residual ? 1 : 0;
+  mx.head_w = (const bf16x8_t*)head_w; mx.head_b = head_b; mx.head_y = head_y; mx.n_head = n_head; mx.store_y = y ? 1 : 0;
+  // measurement only (knob dwconv_mfma_probe = 4): the address of a [N][slots][4][9] fp32 buffer in the knobs dwmix_prof_lo / _hi
+  if (tuning_get("dwconv_mfma_probe", 0) == 4)
+    mx.prof = (float*)(((unsigned long long)(unsigned)tuning_get("dwmix_prof_hi", 0) << 32) | (unsigned)tuning_get("dwmix_prof_lo", 0));
+  // the statistics this block was normalised with are those of pytc_dwconv3d_fwd(y = NULL) under the same knobs: same variant here
+  // (small planes -- the 8 <= H, W < 16 launches -- always carry hi + lo weights there)
+  int variant = tuning_get("dwconv_mfma_variant", 0);
+  if (!march_ok(D, H, W, C, 3, 1, dtype, 0)) variant |= 1;
+  PYTC_REQUIRE(dwmix_launch(x, y, taps, dw_bias, t, mx, C_hid, variant, (hipStream_t)stream) == 0, "dwmix: unsupported hidden width");
+  PYTC_LAUNCH_CHECK("dwmix");
+  return PYTC_OK;
+}
+
 extern "C" int pytc_dwconvT3d_fwd(const void* x, void* y, const float* w, const float* bias, float* stats, int N,
                                   int D, int H, int W, int C, int K, int dtype, void* stream) {
   return dw_entry(true, x, y, w, bias, stats, N, D, H, W, C, K, 2, dtype, stream);

@@ -18,6 +18,24 @@ struct DwMarch {
 void dwconv_mfma_launch(const void* x, void* y, const float* w, const float* bias, float* stats, const DwMarch& g, int variant,
                         hipStream_t s);
 
+// Fused block on the same kernel (see the comment at DwMix's use in dwconv_mfma_kernels.hip)
+struct DwMix {
+  const bf16x8_t* w2n;     // per-sample paired bf16 images of W2 * diag(a_n): [N][MIXHC * 2 * 64] fragments (pytc_groupnorm_fold_mlp)
+  const float* b2n;        // [N][32 * MIXHC] folded expand bias
+  const h8_t* w3;          // paired fp16 image of the projecting conv [2][MIXHC][64]
+  const float* b3;         // [32]
+  long w2_stride;          // fragments per sample image
+  int residual;            // 1: y = mixer + x
+  // output head in the epilogue (pw_mlp_kernel HEAD): logits[o] = head_b[o] + sum_c head_w[o][c] * bf16(y[c]), o < n_head <= 16
+  const bf16x8_t* head_w;
+  const float* head_b;
+  float* head_y;           // [N][D*H*W][n_head] fp32
+  int n_head, store_y;
+  float* prof;             // PROBE 4 only (knob dwconv_mfma_probe = 4): [N][slots][4 waves][8] section cycle sums
+};
+int dwmix_launch(const void* x, void* y, const float* w, const float* bias, const DwMarch& g, const DwMix& mx, int c_hid, int variant,
+                 hipStream_t s);
+
 // dwconvT_tile_kernels.hip: transposed K = 3 / stride 2 conv, bf16, C = 64 / 128, one tile of input cells per workgroup
 struct DwTTile { int N, D, H, W, C, tz, ty, tx, slots; };
 bool dwconvT_tile_plan(DwTTile& g, int N, int D, int H, int W, int C);

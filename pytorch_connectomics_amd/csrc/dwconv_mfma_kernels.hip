@@ -36,6 +36,7 @@
 #include <type_traits>
 
 #include "dwconv_march.h"
+#include "pw_common.h"
 
 namespace pytc {
 
@@ -72,11 +73,35 @@ __device__ __forceinline__ void mf_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)
 // plane, 3 LDS commit, 4 output rounding + tile writes, 5 barrier, 6 steps, 7 whole kernel (profiles/r05_additivity.txt).
 // STORE = false: the statistics-only pass of the fused block (pw_dwmix_kernels.hip): same products, same rounding, same partial sums
 // in the same order as the storing kernel (bit-identical statistics) -- the output tile, its LDS traffic and the HBM stores are gone.
-template <int PF, bool LO, int PROBE = 0, bool STORE = true>
-__global__ void __launch_bounds__(256, 4)
+// MIXHC > 0: the FUSED BLOCK (round 5; C = 32, C_out = 32, hidden width 32 * MIXHC): the depthwise output of a plane goes no
+// further than the workgroup's LDS tile -- a step later every wave reads 16 of its 64 positions back as the B operand of the
+// expanding 1x1x1 conv and runs the channel mixer of pw_mlp_kernels.hip on them (GroupNorm folded into per-sample expand weights by
+// groupnorm_fold_mlp_kernel from the statistics of a STORE = false pass; packed-fp16 GELU; f16 projection; + x; one 16-byte store
+// per lane).  Same products, same accumulation order, same roundings as dwconv3d_k3_mfma_kernel followed by pw_mlp_kernel<1, 2, NT, 3>
+// with per-sample operands: the block output is BIT-IDENTICAL to the two-launch path, and the 2 * C bytes per voxel of the depthwise
+// tensor never reach HBM (read x twice, write y once).  The residual rows ride in the asm-load pipeline: R(z) = the
+// 64 x 64 bytes of x at the footprint of plane z, requested at step z (before the plane loads of that step), consumed at step z + 2.
+
+template <int N>
+__device__ __forceinline__ void mf_wait_vm_upto(int n) {     // s_waitcnt vmcnt(n) for a wave-uniform runtime n in 0..N
+  if constexpr (N > 0) {
+    if (n >= N) { mf_wait_vm<N>(); return; }
+    mf_wait_vm_upto<N - 1>(n);
+  } else {
+    mf_wait_vm<0>();
+  }
+}
+
+template <int PF, bool LO, int PROBE = 0, bool STORE = true, int MIXHC = 0>
+__global__ void __launch_bounds__(256, MIXHC ? 3 : 4)
 dwconv3d_k3_mfma_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, const float* __restrict__ w,
-                        const float* __restrict__ bias, float* __restrict__ stats, DwMarch g) {
+                        const float* __restrict__ bias, float* __restrict__ stats, DwMarch g, DwMix mx) {
   static_assert(PF == 2 || PF == 3, "two or three planes in flight");
+  static_assert(MIXHC == 0 || (STORE && PF == 3), "the fused block keeps the output tile and three planes in flight");
+  constexpr bool MIX = MIXHC > 0;
+  __shared__ __attribute__((aligned(16))) bf16x8_t w2s[MIX ? MIXHC * 2 * 64 : 1];
+  __shared__ __attribute__((aligned(16))) h8_t w3s[MIX ? 2 * MIXHC * 64 : 1];
+  __shared__ __attribute__((aligned(16))) float mbias[MIX ? 32 * MIXHC + 32 : 4];     // folded expand bias of this sample | projection bias
   __shared__ __attribute__((aligned(16))) unsigned short image[2][MF_IMG];
   __shared__ __attribute__((aligned(16))) unsigned short otile[STORE ? 2 : 1][STORE ? MF_TY * MF_RS : 8];   // per step parity: 8 rows x (8 positions x 32 channels + pad)
   __shared__ float wl[27 * MF_CG];
@@ -107,6 +132,12 @@ dwconv3d_k3_mfma_kernel(const unsigned short* __restrict__ x, unsigned short* __
 
   // ---- weights: 27 x 32 taps through LDS
   for (int i = tid; i < 27 * MF_CG; i += 256) wl[i] = w[(long)(i / MF_CG) * C + cg * MF_CG + (i % MF_CG)];
+  if constexpr (MIX) {     // both mixer images of this sample: 4 KB + 4 KB at MIXHC = 2
+    const bf16x8_t* w2g = mx.w2n + (long)n * mx.w2_stride;
+    for (int i = tid; i < MIXHC * 2 * 64; i += 256) { w2s[i] = w2g[i]; w3s[i] = mx.w3[i]; }
+    if (tid < 32 * MIXHC) mbias[tid] = mx.b2n[(long)n * (32 * MIXHC) + tid];
+    else if (tid < 32 * MIXHC + 32) mbias[tid] = mx.b3[tid - 32 * MIXHC];
+  }
   __syncthreads();
 
   // ---- staging descriptors (constant along z): chunk = 8 channels of one haloed voxel, consecutive lanes walk channels, then x, then y
@@ -135,10 +166,9 @@ dwconv3d_k3_mfma_kernel(const unsigned short* __restrict__ x, unsigned short* __
   };
   // loads return in order among loads: once at most MF_CPT * (planes requested after the awaited one) operations are outstanding it
   // has landed, whatever the stores (same counter) do
+  // `younger`: LOADS requested after the awaited plane (plane loads of later planes, and the fused block's residual loads)
   auto landed = [&](u32x4_t (&st)[MF_CPT], int younger) {
-    if (younger <= 0) mf_wait_vm<0>();
-    else if (younger == 1) mf_wait_vm<MF_CPT>();
-    else mf_wait_vm<2 * MF_CPT>();
+    mf_wait_vm_upto<2 * MF_CPT + 2>(younger);
     asm volatile("" : "+v"(st[0]), "+v"(st[1]) : : "memory");
   };
   auto commit = [&](int slot, u32x4_t (&st)[MF_CPT], int gz) {
@@ -217,6 +247,65 @@ dwconv3d_k3_mfma_kernel(const unsigned short* __restrict__ x, unsigned short* __
     if (ook) *reinterpret_cast<u32x4_t*>(yn + (long)zo * plane_elems + obase) = o;
   };
 
+  // ---- fused block: this wave's 16 positions of the footprint (two rows), lane (r, kb) = position 16 wave + r, channels kb*8 .. +7
+  const int mr = lane & 15, mkb = lane >> 4;
+  const int mp = wave * 16 + mr, my = mp >> 3, mxx = mp & 7;
+  const bool mok = (y0 + my) < g.H && (x0 + mxx) < g.W;
+  const long mbase = ((long)min(y0 + my, g.H - 1) * g.W + min(x0 + mxx, g.W - 1)) * C + mkb * 8;    // C = 32 (one channel group)
+  const int mtile = my * MF_RS + mxx * MF_TS + mkb * 8;
+  u32x4_t rres[MIX ? 3 : 1];                        // residual rows in flight: plane z travels in set (z - (zs - 1)) % 3
+  auto issue_res = [&](int z, u32x4_t& rr) {          // R(z): this lane's 16 bytes of x at output plane z
+    const unsigned short* ptr = xn + (long)z * plane_elems + mbase;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rr) : "v"(ptr) : "memory");
+  };
+  // channel mixer of output plane zo: tile of parity zo & 1 (written a step ago, a barrier in between) -> y.  `younger`: loads
+  // requested after R(zo)
+  auto mix = [&](int zo, u32x4_t& rr, int younger) {
+    if constexpr (MIX) {
+      const bf16x8_t bact = *reinterpret_cast<const bf16x8_t*>(&otile[zo & 1][mtile]);
+      // biases from LDS (8 consecutive channels per lane): registers are what limits this kernel's occupancy
+      f32x4_t acc2[2] = {*reinterpret_cast<const f32x4_t*>(&mbias[32 * MIXHC + mkb * 8]), *reinterpret_cast<const f32x4_t*>(&mbias[32 * MIXHC + mkb * 8 + 4])};
+#pragma unroll
+      for (int hc = 0; hc < MIXHC; ++hc) {
+        f32x4_t acc1[2] = {*reinterpret_cast<const f32x4_t*>(&mbias[hc * 32 + mkb * 8]), *reinterpret_cast<const f32x4_t*>(&mbias[hc * 32 + mkb * 8 + 4])};
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc1[mt] = Mma<bf16_t>::mma(w2s[(hc * 2 + mt) * 64 + lane], bact, acc1[mt]);
+        float gg[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { gg[q] = acc1[0][q]; gg[4 + q] = acc1[1][q]; }
+        const h8_t bhh = gelu_h8_from_f32(gg);
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo) acc2[mo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3s[(mo * MIXHC + hc) * 64 + lane], bhh, acc2[mo], 0, 0, 0);
+      }
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { v[q] = acc2[0][q]; v[4 + q] = acc2[1][q]; }
+      if (mx.residual) {
+        mf_wait_vm_upto<5>(younger);
+        asm volatile("" : "+v"(rr) : : "memory");
+        float rv[8];
+        VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(&rr), rv);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += rv[q];
+      }
+      const long vo = (long)zo * plane_elems + mbase;
+      if (mx.head_w) {
+        // the block output rounded as the un-fused path stores it = the B fragment of logits^T[o][voxel] = sum_c head[o][c] y[c][voxel]
+        const bf16x8_t ob = Mma<bf16_t>::from_floats(v);
+        if (mx.store_y && mok) *reinterpret_cast<bf16x8_t*>(yn + vo) = ob;
+        const f32x4_t hh = Mma<bf16_t>::mma(mx.head_w[lane], ob, f32x4_t{0.f, 0.f, 0.f, 0.f});
+        if (mok) {
+          float* hy = mx.head_y + ((long)n * g.D * g.H * g.W + (vo - mkb * 8) / C) * mx.n_head;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (mkb * 4 + i < mx.n_head) hy[mkb * 4 + i] = hh[i] + (mx.head_b ? mx.head_b[mkb * 4 + i] : 0.f);
+        }
+      } else if (mok) {
+        VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(yn + vo), v);
+      }
+    }
+  };
+
   f32x4_t acc[4][2];
 #pragma unroll
   for (int u = 0; u < 4; ++u)
@@ -225,7 +314,7 @@ dwconv3d_k3_mfma_kernel(const unsigned short* __restrict__ x, unsigned short* __
   float s1 = 0.f, s2 = 0.f;
   // PROBE 4: per-section cycle sums of this wave (wave-uniform values; s_memtime waits on lgkmcnt, i.e. also drains the wave's own
   // LDS operations at each stamp: the sections are slightly serialised against the untimed kernel, +5 % launch time measured)
-  unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, tstart = 0;
+  unsigned long long tk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, tstart = 0;
   auto stamp = [&](int k) {
     if constexpr (PROBE == 4) {
       const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -236,8 +325,18 @@ dwconv3d_k3_mfma_kernel(const unsigned short* __restrict__ x, unsigned short* __
   if constexpr (PROBE == 4) { tstart = __builtin_amdgcn_s_memtime(); tlast = tstart; }
 
   // one z step: input plane gz is image[slot]; `ld` receives plane gz+PF, `cm` holds plane gz+1 and is committed after the compute
-  auto step = [&](int gz, int slot, u32x4_t (&ld)[MF_CPT], u32x4_t (&cm)[MF_CPT]) {
-    if (STORE && gz - 2 >= zs && PROBE != 3) flush(gz - 2);
+  // (fused block: `rn` receives the residual rows of plane gz, `ro` holds those of plane gz - 2)
+  auto exists_p = [&](int z) { return z <= ze; };                       // plane load P(z) was / will be requested (z >= zs - 1 + PF)
+  auto exists_r = [&](int z) { return MIX && mx.residual && z >= zs && z < ze; };
+  auto step = [&](int gz, int slot, u32x4_t (&ld)[MF_CPT], u32x4_t (&cm)[MF_CPT], u32x4_t& rn, u32x4_t& ro) {
+    if constexpr (MIX) {
+      // requested after R(gz - 2): P(gz + 1), then R(gz - 1), P(gz + 2) (request order within a step: residual, then plane)
+      if (gz - 2 >= zs) mix(gz - 2, ro, (exists_p(gz + 1) ? MF_CPT : 0) + (exists_r(gz - 1) ? 1 : 0) + (exists_p(gz + 2) ? MF_CPT : 0));
+      stamp(8);
+      if (exists_r(gz)) issue_res(gz, rn);
+    } else {
+      if (STORE && gz - 2 >= zs && PROBE != 3) flush(gz - 2);
+    }
     if (gz + PF <= ze) issue(gz + PF, ld);
     stamp(0);
     // ---- the stencil of this plane: 3 row offsets x (2 output columns x hi/lo) instructions per unit
@@ -261,7 +360,9 @@ dwconv3d_k3_mfma_kernel(const unsigned short* __restrict__ x, unsigned short* __
     stamp(1);
     // ---- plane gz+1 into the other image slot
     if (gz + 1 <= ze) {
-      landed(cm, min(PF - 1, ze - gz - 1));           // planes requested after plane gz+1 (gz+2 .. gz+PF, as far as the chunk goes)
+      // loads requested after plane gz+1: planes gz+2 .. gz+PF as far as the chunk goes, and (fused block) the residual rows of the
+      // steps in between: R(gz - 1) and R(gz) at PF = 3
+      landed(cm, MF_CPT * min(PF - 1, ze - gz - 1) + (exists_r(gz - 1) ? 1 : 0) + (exists_r(gz) ? 1 : 0));
       stamp(2);
       commit(slot ^ 1, cm, gz + 1);
       stamp(3);
@@ -279,10 +380,12 @@ dwconv3d_k3_mfma_kernel(const unsigned short* __restrict__ x, unsigned short* __
           ot[ooff[u]] = (unsigned short)(bits & 0xffffu);
           ot[ooff[u] + MF_TS] = (unsigned short)(bits >> 16);
         }
-        float r0 = __uint_as_float(bits << 16), r1 = __uint_as_float(bits & 0xffff0000u);
-        if (!inner) { r0 = pok[u][0] ? r0 : 0.f; r1 = pok[u][1] ? r1 : 0.f; }
-        s1 += r0; s2 = fmaf(r0, r0, s2);
-        s1 += r1; s2 = fmaf(r1, r1, s2);
+        if constexpr (!MIX) {       // (the fused block takes no statistics: they come from the STORE = false pass)
+          float r0 = __uint_as_float(bits << 16), r1 = __uint_as_float(bits & 0xffff0000u);
+          if (!inner) { r0 = pok[u][0] ? r0 : 0.f; r1 = pok[u][1] ? r1 : 0.f; }
+          s1 += r0; s2 = fmaf(r0, r0, s2);
+          s1 += r1; s2 = fmaf(r1, r1, s2);
+        }
       }
     }
 #pragma unroll
@@ -299,20 +402,36 @@ dwconv3d_k3_mfma_kernel(const unsigned short* __restrict__ x, unsigned short* __
   // (gz = zs-1+k) requests plane gz+PF into set k % PF and commits plane gz+1 from set (k+1) % PF
 #pragma unroll
   for (int q = 0; q < PF; ++q) issue(zs - 1 + q, stg[q]);
-  landed(stg[0], PF - 1);
+  landed(stg[0], MF_CPT * (PF - 1));
   commit(0, stg[0], zs - 1);
   __syncthreads();
   int slot = 0;
   for (int gz = zs - 1; gz <= ze; gz += PF) {
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
-      if (gz + k <= ze) { step(gz + k, slot, stg[k], stg[(k + 1) % PF]); slot ^= 1; }
+      if (gz + k <= ze) { step(gz + k, slot, stg[k], stg[(k + 1) % PF], rres[MIX ? k : 0], rres[MIX ? (k + 1) % 3 : 0]); slot ^= 1; }
     }
   }
-  if (STORE && PROBE != 3) flush(ze - 1);
+  if constexpr (MIX) {
+    // the last plane: its residual rows were requested at step ze - 1, nothing was requested after them.  Their register set is the
+    // one of plane (ze - 1): (ze - 1 - (zs - 1)) % 3 -- a wave-uniform runtime index, resolved by a three-way branch
+    const int rs = (ze - zs) % 3;
+    if (rs == 0) mix(ze - 1, rres[0], 0);
+    else if (rs == 1) mix(ze - 1, rres[MIX ? 1 : 0], 0);
+    else mix(ze - 1, rres[MIX ? 2 : 0], 0);
+  } else {
+    if (STORE && PROBE != 3) flush(ze - 1);
+  }
 
   if constexpr (PROBE == 4) {
-    if (stats && lane == 0) {
+    if constexpr (MIX) {
+      if (mx.prof && lane == 0) {      // [N][slots][4 waves][9]: sections 0..7 as below, 8 = channel mixer (incl. its wait for the residual rows)
+        tk[7] = __builtin_amdgcn_s_memtime() - tstart;
+        float* o = mx.prof + (((long)n * g.slots + slot_id) * 4 + wave) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[k] = (float)tk[k];
+      }
+    } else if (stats && lane == 0) {
       tk[7] = __builtin_amdgcn_s_memtime() - tstart;
       float* o = stats + (((long)n * g.slots + slot_id) * 2) * C + cg * MF_CG + wave * 8;
 #pragma unroll
@@ -320,7 +439,7 @@ dwconv3d_k3_mfma_kernel(const unsigned short* __restrict__ x, unsigned short* __
     }
     return;
   }
-  if (stats) {
+  if (!MIX && stats) {
     s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
     s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
     if (j == 0) { red[wave][0][cl] = s1; red[wave][1][cl] = s2; }
@@ -338,8 +457,9 @@ void dwconv_mfma_launch(const void* x, void* y, const float* w, const float* bia
   dim3 grid((unsigned)((long)g.slots * (g.C / MF_CG) * g.N)), block(256);
   const unsigned short* xp = (const unsigned short*)x;
   unsigned short* yp = (unsigned short*)y;
-#define PYTC_MF(PFV, LOV, NM) hipLaunchKernelGGL((dwconv3d_k3_mfma_kernel<PFV, LOV, NM>), grid, block, 0, s, xp, yp, w, bias, stats, g)
-#define PYTC_MF_STATS(PFV, LOV) hipLaunchKernelGGL((dwconv3d_k3_mfma_kernel<PFV, LOV, 0, false>), grid, block, 0, s, xp, yp, w, bias, stats, g)
+  const DwMix none{};
+#define PYTC_MF(PFV, LOV, NM) hipLaunchKernelGGL((dwconv3d_k3_mfma_kernel<PFV, LOV, NM>), grid, block, 0, s, xp, yp, w, bias, stats, g, none)
+#define PYTC_MF_STATS(PFV, LOV) hipLaunchKernelGGL((dwconv3d_k3_mfma_kernel<PFV, LOV, 0, false>), grid, block, 0, s, xp, yp, w, bias, stats, g, none)
   // variant: bit 0 = hi + lo weight instructions (16-bit weight mantissa; default: hi only = bf16 weights, what torch.autocast gives the
   // reference's Conv3d), bit 1 = two planes in flight instead of three.  Knob dwconv_mfma_probe (1 / 3; measurements only, WRONG results):
   // the kernel without its matrix instructions / without them and without the output path.
@@ -355,6 +475,30 @@ void dwconv_mfma_launch(const void* x, void* y, const float* w, const float* bia
   else { if (variant & 2) PYTC_MF(2, false, 0); else PYTC_MF(3, false, 0); }
 #undef PYTC_MF
 #undef PYTC_MF_STATS
+}
+
+// Fused block launch (see DwMix): C = 32, hidden width 64 / 96 / 128, bf16; variant bit 0 = hi + lo depthwise weights (must equal the
+// variant of the statistics pass: the statistics are those of the tensor this kernel re-forms)
+int dwmix_launch(const void* x, void* y, const float* w, const float* bias, const DwMarch& g, const DwMix& mx, int c_hid, int variant,
+                 hipStream_t s) {
+  dim3 grid((unsigned)((long)g.slots * g.N)), block(256);
+  const unsigned short* xp = (const unsigned short*)x;
+  unsigned short* yp = (unsigned short*)y;
+#define PYTC_DM(LOV, HCV, PRB) hipLaunchKernelGGL((dwconv3d_k3_mfma_kernel<3, LOV, PRB, true, HCV>), grid, block, 0, s, xp, yp, w, bias, (float*)nullptr, g, mx)
+  const bool lo = variant & 1;
+  if (mx.prof) {                        // measurement only: section cycle counters (tools/r05_additivity.py phases_mix)
+    if (c_hid != 64 || lo) return -1;
+    PYTC_DM(false, 2, 4);
+    return 0;
+  }
+  switch (c_hid) {
+    case 64: if (lo) PYTC_DM(true, 2, 0); else PYTC_DM(false, 2, 0); break;
+    case 96: if (lo) PYTC_DM(true, 3, 0); else PYTC_DM(false, 3, 0); break;
+    case 128: if (lo) PYTC_DM(true, 4, 0); else PYTC_DM(false, 4, 0); break;
+    default: return -1;
+  }
+#undef PYTC_DM
+  return 0;
 }
 
 }  // namespace pytc

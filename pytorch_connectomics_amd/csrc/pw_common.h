@@ -62,7 +62,28 @@ struct EpiParams {
   int res_mode;
   int Go_d, Go_h, Go_w;   // RES_UPSAMPLE: output grid
   int Gl_d, Gl_h, Gl_w;   // RES_UPSAMPLE: low-res grid
+  // 1: the big streams (operand rows, residual / skip rows, output rows) as nontemporal loads / stores (knob stream_nt; measured
+  // neutral for the mixers, see stream_nt_policy)
+  int nt;
 };
+
+// 16-byte row piece, plain or nontemporal (wave-uniform flag)
+typedef unsigned int pytc_u32x4_t __attribute__((ext_vector_type(4)));
+template <typename V>
+__device__ __forceinline__ V ld_stream(const V* ptr, int nt) {
+  static_assert(sizeof(V) == 16, "16-byte row pieces");
+  if (nt) return __builtin_bit_cast(V, __builtin_nontemporal_load(reinterpret_cast<const pytc_u32x4_t*>(ptr)));
+  return *ptr;
+}
+
+// policy of the launch wrappers: knob stream_nt = 1 puts the mixers' big streams on nontemporal loads / stores, 0 (default) keeps plain
+// ones.  Measured (profiles/r05_stream_policy.txt): a bare three-stream kernel gains 9 % from nt (5.9 -> 6.45 TB/s), the mixers gain
+// nothing (32->64->32: 543 vs 536 us isolated, whole step 6.47 vs 6.48 ms per 8 windows) -- they saturate the memory system at ~5 TB/s
+// with ~4 us of queueing latency whatever the cache policy -- so the default stays plain.
+static inline int stream_nt_policy(long bytes_largest_tensor) {
+  (void)bytes_largest_tensor;
+  return tuning_get("stream_nt", 0) > 0 ? 1 : 0;
+}
 
 // v[NCH] = conv result (+bias, activation) for channels o0..o0+NCH-1 of output row `orow` of sample n.
 // GELU_BWD = false compiles the PYTC_RES_GELU_BWD branch out (the fused mixer never uses it and pays registers for it).
@@ -160,8 +181,18 @@ __device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParam
       for (int i = 0; i < NCH; ++i) v[i] = v[i] + rl[i] + sk[i];
     }
   }
-  if (full) VecIO<TO, NCH>::store(yn + off, v);
-  else {
+  if (full) {
+    if constexpr (sizeof(TO) == 2 && NCH == 8) {
+      if (e.nt) {          // same conversion as VecIO::store, nontemporal 16-byte store
+        f32x8_t f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = v[i];
+        __builtin_nontemporal_store(__builtin_convertvector(f, bf16x8_t), reinterpret_cast<bf16x8_t*>(yn + off));
+        return;
+      }
+    }
+    VecIO<TO, NCH>::store(yn + off, v);
+  } else {
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
       if (o0 + i < C_out) yn[off + i] = from_f32<TO>(v[i]);

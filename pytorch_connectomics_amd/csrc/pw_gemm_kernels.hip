@@ -216,7 +216,7 @@ extern "C" int pytc_pw_gemm_fwd(const void* x, const void* w, const float* bias,
   p.yh = (unsigned short*)y;
   p.rps = rows_per_sample; p.rows_total = (long)N * rows_per_sample; p.C_in = C_in; p.C_out = C_out; p.gelu = gelu_out;
   p.e.res = res; p.e.res_low = res_low; p.e.res_bias = res_bias; p.e.y = y; p.e.rps_out = rows_per_sample; p.e.C_out = C_out;
-  p.e.res_mode = res_mode;
+  p.e.res_mode = res_mode; p.e.nt = 0;
   p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
   if (res_mode == PYTC_RES_UPSAMPLE) {
     PYTC_REQUIRE((long)Di * Hi * Wi == rows_per_sample && !(Di & 1) && !(Hi & 1) && !(Wi & 1) && rows_per_sample < (1L << 31),

@@ -256,7 +256,7 @@ extern "C" int pytc_pw_conv_fwd(const pytc_pw_args* a, void* stream) {
   PwParams p;
   p.x = a->x; p.wp = a->w_packed; p.bias = a->bias; p.ab = a->ab;
   p.e.res = a->res; p.e.res_low = a->res_low; p.e.res_bias = a->res_bias; p.e.y = a->y;
-  p.e.rps_out = a->rows_per_sample; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode;
+  p.e.rps_out = a->rows_per_sample; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode; p.e.nt = 0;
   p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
   p.N = a->N; p.C_in = a->C_in; p.C_out = a->C_out;
   p.KG = (a->C_in + kstep_of(a->w_dtype) - 1) / kstep_of(a->w_dtype);

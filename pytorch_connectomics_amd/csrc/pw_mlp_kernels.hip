@@ -132,7 +132,7 @@ pw_mlp_kernel(MlpParams p) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const long rr = orow[nt] < p.rps ? orow[nt] : p.rps - 1;
-        bact[ks][nt] = *reinterpret_cast<const bf16x8_t*>(tn + rr * CIN + ks * 32 + kb * 8);
+        bact[ks][nt] = ld_stream(reinterpret_cast<const bf16x8_t*>(tn + rr * CIN + ks * 32 + kb * 8), p.e.nt);
       }
   }
   const float* an = p.ab + (long)n * 2 * CIN;
@@ -183,7 +183,7 @@ pw_mlp_kernel(MlpParams p) {
 #pragma unroll
       for (int nt = 0; nt < (PREFETCH_RES ? NT : 1); ++nt) {
         const long rr = orow[nt] < p.rps ? orow[nt] : p.rps - 1;
-        rpre[pr][nt] = *reinterpret_cast<const uint4*>(resn + rr * COUT + pr * 32 + kb * 8);
+        rpre[pr][nt] = ld_stream(reinterpret_cast<const uint4*>(resn + rr * COUT + pr * 32 + kb * 8), p.e.nt);
       }
   }
 
@@ -698,6 +698,7 @@ extern "C" int pytc_pw_mlp_head_fwd(const pytc_mlp_args* a, const void* head_w, 
   p.w2_stride = (long)(a->C_hid / 16) * (a->C_in / 32) * 64;
   p.e.res = a->res; p.e.res_low = nullptr; p.e.res_bias = nullptr; p.e.y = a->y;
   p.e.rps_out = a->rows_per_sample; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode;
+  p.e.nt = stream_nt_policy((long)a->N * a->rows_per_sample * (a->C_in > a->C_out ? a->C_in : a->C_out) * 2);
   p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
   p.head_w = (const bf16x8_t*)head_w; p.head_b = head_b; p.head_y = head_y; p.n_head = n_head; p.store_y = store_y;
   p.w3_f16 = a->w3_format == PYTC_W3_F16 ? 1 : 0;
@@ -736,6 +737,7 @@ extern "C" int pytc_pw_mlp_stemres_fwd(const pytc_mlp_args* a, const float* stem
   p.e.res = a->y;              // never dereferenced (the residual rows are recomputed); non-null for the epilogue's checks
   p.e.y = a->y;
   p.e.rps_out = a->rows_per_sample; p.e.C_out = a->C_out; p.e.res_mode = PYTC_RES_ADD;
+  p.e.nt = stream_nt_policy((long)a->N * a->rows_per_sample * (a->C_in > a->C_out ? a->C_in : a->C_out) * 2);
   p.stem_x = stem_x; p.stem_w = stem_w; p.stem_b = stem_b;
   p.w3_f16 = a->w3_format == PYTC_W3_F16 ? 1 : 0;
   dim3 grid((unsigned)((p.rps + 4L * 4 * 16 - 1) / (4L * 4 * 16)), (unsigned)a->N), block(256);
@@ -784,6 +786,7 @@ static int mlp_fwd_impl(const pytc_mlp_args* a, void* hp, void* stream, const vo
   p.w2_stride = (long)(a->C_hid / 16) * (a->C_in / 32) * 64;
   p.e.res = a->res; p.e.res_low = a->res_low; p.e.res_bias = a->res_bias; p.e.y = a->y;
   p.e.rps_out = a->rows_per_sample; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode;
+  p.e.nt = stream_nt_policy((long)a->N * a->rows_per_sample * (a->C_in > a->C_out ? a->C_in : a->C_out) * 2);
   p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
   p.hp = (bf16_t*)hp;
   p.hp_in = (const bf16_t*)hp_in;

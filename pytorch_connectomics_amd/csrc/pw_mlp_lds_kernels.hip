@@ -44,7 +44,7 @@ __device__ __forceinline__ void lds_tile_load(LdsTile<KS_IN, MO, NT>& T, const M
     const long o = row0 + nt * 16 + r;
     const long rr = o < p.rps ? o : p.rps - 1;
 #pragma unroll
-    for (int ks = 0; ks < KS_IN; ++ks) T.raw[ks][nt] = *reinterpret_cast<const uint4*>(tn + rr * (KS_IN * 32) + ks * 32 + kb * 8);
+    for (int ks = 0; ks < KS_IN; ++ks) T.raw[ks][nt] = ld_stream(reinterpret_cast<const uint4*>(tn + rr * (KS_IN * 32) + ks * 32 + kb * 8), p.e.nt);
   }
   if (with_res) {
     const bf16_t* resn = reinterpret_cast<const bf16_t*>(p.e.res) + (long)n * p.rps * (MO * 16);
@@ -53,7 +53,7 @@ __device__ __forceinline__ void lds_tile_load(LdsTile<KS_IN, MO, NT>& T, const M
       const long o = row0 + nt * 16 + r;
       const long rr = o < p.rps ? o : p.rps - 1;
 #pragma unroll
-      for (int pr = 0; pr < MO / 2; ++pr) T.res[pr][nt] = *reinterpret_cast<const uint4*>(resn + rr * (MO * 16) + pr * 32 + kb * 8);
+      for (int pr = 0; pr < MO / 2; ++pr) T.res[pr][nt] = ld_stream(reinterpret_cast<const uint4*>(resn + rr * (MO * 16) + pr * 32 + kb * 8), p.e.nt);
     }
   }
 }
@@ -275,6 +275,7 @@ extern "C" int pytc_pw_mlp_lds_fwd(const pytc_mlp_args* a, void* stream) {
   p.w2_stride = (long)(a->C_hid / 16) * (a->C_in / 32) * 64;
   p.e.res = a->res; p.e.res_low = a->res_low; p.e.res_bias = a->res_bias; p.e.y = a->y;
   p.e.rps_out = a->rows_per_sample; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode;
+  p.e.nt = stream_nt_policy((long)a->N * a->rows_per_sample * (a->C_in > a->C_out ? a->C_in : a->C_out) * 2);
   p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
   if (a->res_mode == PYTC_RES_UPSAMPLE) {
     PYTC_REQUIRE((long)a->Di * a->Hi * a->Wi == a->rows_per_sample && !(a->Di & 1) && !(a->Hi & 1) && !(a->Wi & 1) &&

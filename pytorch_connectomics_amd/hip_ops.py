@@ -842,6 +842,47 @@ def pw_mlp_head(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.
     return y, logits
 
 
+def dwmix_supported(x: torch.Tensor, c_hid: int, c_out: int) -> bool:
+    """pytc_dwmix_fwd covers this block input: bf16 (N, D, H, W, 32), hidden width 64 / 96 / 128, 32 output channels, a shape of the
+    matrix-core depthwise kernel."""
+    if x.dim() != 5 or x.dtype != torch.bfloat16:
+        return False
+    _, D, H, W, Cc = x.shape
+    return bool(nat.lib().pytc_dwmix_supported(D, H, W, Cc, int(c_hid), int(c_out), dtype_code(x.dtype)))
+
+
+def dwmix(x: torch.Tensor, w_taps: torch.Tensor, dw_bias: Optional[torch.Tensor], w2n: torch.Tensor, b2n: torch.Tensor,
+          w3p: torch.Tensor, b3: torch.Tensor, *, c_hid: int, c_out: int = 32, residual: bool = True, y: Optional[torch.Tensor] = None,
+          head_w: Optional[torch.Tensor] = None, head_b: Optional[torch.Tensor] = None, store_y: bool = True):
+    """Fused MedNeXt residual block (pytc_dwmix_fwd): depthwise 3x3x3 conv re-formed in LDS -> folded norm -> expand -> GELU -> project
+    -> + x, the depthwise tensor never stored.  (w2n, b2n) = groupnorm_fold_mlp(statistics of dwconv3d(x, ..., store=False)).
+    -> y (N, D, H, W, 32) bf16, or with head_w (pack_head_fragment): (y | None, logits (N, D, H, W, n_head) fp32)."""
+    _dev(x, "x"); _dev(w_taps, "w_taps"); _dev(w2n, "w2n"); _dev(w3p, "w3p")
+    N, D, H, W, Cc = x.shape
+    if x.dtype != torch.bfloat16 or w2n.dtype != torch.bfloat16 or w3p.dtype != torch.float16:
+        raise TypeError("dwmix runs on bfloat16 activations, per-sample bf16 expand images and the fp16 projection image")
+    if tuple(w2n.shape) != (N, c_hid * Cc) or tuple(b2n.shape) != (N, c_hid) or tuple(w_taps.shape) != (27, Cc):
+        raise ValueError(f"dwmix: operands do not match N={N}, C={Cc}, C_hid={c_hid}: w2n {tuple(w2n.shape)}, b2n {tuple(b2n.shape)}, taps {tuple(w_taps.shape)}")
+    logits = None
+    n_head = 0
+    if head_w is not None:
+        if head_w.dtype != torch.bfloat16 or tuple(head_w.shape[1:]) != (64, 8):
+            raise TypeError("dwmix: the head fragment image is (n_head, 64, 8) bf16 (pack_head_fragment)")
+        n_head = int(head_w.shape[0])
+        logits = torch.empty((N, D, H, W, n_head), dtype=torch.float32, device=x.device)
+        if not store_y:
+            y = None
+    if y is None and (head_w is None or store_y):
+        y = torch.empty((N, D, H, W, c_out), dtype=torch.bfloat16, device=x.device)
+    if y is not None and (tuple(y.shape) != (N, D, H, W, c_out) or y.dtype != torch.bfloat16 or not y.is_contiguous()):
+        raise ValueError(f"dwmix: output buffer must be contiguous bf16 {(N, D, H, W, c_out)}")
+    nb = _nbytes(x) * (2 if residual else 1) + _nbytes(y, logits)          # x read for the conv and (from L2) as the residual
+    _run(f"dwmix_fwd[{Cc}->{c_hid}->{c_out}]", nb, nat.lib().pytc_dwmix_fwd, _p(x), _p(w_taps), _p(dw_bias), _p(w2n), _p(b2n), _p(w3p),
+         _p(b3), int(bool(residual)), _p(y), _p(head_w), _p(head_b), _p(logits), n_head, N, D, H, W, Cc, int(c_hid), int(c_out),
+         dtype_code(x.dtype), _stream(), symbol="dwconv3d_k3_mfma_kernel+mix" + ("+head" if head_w is not None else ""))
+    return y if head_w is None else (y, logits)
+
+
 # ------------------------------------------------------------------ dense conv / norm / pool (RSUNet)
 def conv3d_pack_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """w fp32 (C_out, C_in, kd, kh, kw) -> packed MFMA image."""

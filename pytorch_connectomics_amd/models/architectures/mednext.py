@@ -188,6 +188,12 @@ class HipBlockOps:
         # bit-identical, 15 ... 35 % faster at 8 windows; below the threshold staging the images costs more than it saves (5 x 14^3:
         # 27 against 19 us).  0 switches the path off.
         self.lds_mixer_rows = int(os.environ.get("PYTC_LDS_MIXER_ROWS", "131072"))
+        # bf16 residual blocks with 32 channels (level 0: the widest tensors of the network) can run as statistics pass + ONE fused kernel
+        # (ops.dwmix): the depthwise output is re-formed in LDS and never stored -- 3 instead of 5 tensor passes per block, bit-identical
+        # to the two-launch schedule.  Measured on MI355X (profiles/r05_fused_block.txt): the fused kernel is bound by instruction issue,
+        # not by memory (44 % of its wave cycles are the mixer's GELU): 236 + 517 us against 318 + 14 + 412 us for 8 x 112^3 -- parity
+        # (0.98x), 1.03x at MedNeXt-L's 2 x 160^3 x (32 -> 96 -> 32), whole step 6.70 against 6.54 ms per 8 windows.  Off by default.
+        self.fuse_block = int(os.environ.get("PYTC_FUSE_BLOCK", "0"))
 
     # ---- parameter repacking (load time / after optimizer steps) -----------------------------
     def _taps(self, conv: nn.Module):
@@ -326,6 +332,11 @@ class HipBlockOps:
                 and skip is not None and m.conv2.bias is not None and m.conv3.bias is not None
                 and ops.pw_mlp_up_supported(C, c_hid, c_out)):
             return self._up_block_fused(m, x, skip, taps, b1, c_hid, c_out)
+        if (kind == "block" and self.fused and self.fuse_block and self.fold_norm and dt == torch.bfloat16 and K == 3 and not m.grn and not is_ln
+                and m.dim == "3d" and m.conv2.bias is not None and m.conv3.bias is not None and ops.MLP_F16_PROJECT
+                and ops.dwmix_supported(x, c_hid, c_out) and ops.groupnorm_fold_mlp_supported(C, c_hid)
+                and (head is None or (head.weight.shape[1] <= 16 and ops.pw_mlp_head_supported(C, c_hid, c_out)))):
+            return self._block_dwmix(m, x, taps, b1, c_hid, c_out, head, out)
         if kind == "up":
             t, st = ops.dwconv3d(x, taps, b1, K=K, transposed=True, stats=not is_ln)
             count = float((2 * D - 1) * (2 * H - 1) * (2 * W - 1))
@@ -401,6 +412,26 @@ class HipBlockOps:
                             res=skip, res_mode=nat.RES_UPSAMPLE, grid=(Do, Ho, Wo), res_low=res_low,
                             res_bias=res_bias, **G)
         return y.view(N, Do, Ho, Wo, c_out)
+
+
+def _block_dwmix(self, m, x, taps, b1, c_hid, c_out, head=None, out=None):
+    """Residual block as statistics pass + fused kernel (HipBlockOps.fuse_block): same arithmetic as dwconv3d -> _fold -> pw_mlp /
+    pw_mlp_head, the depthwise tensor never stored."""
+    N, D, H, W, C = x.shape
+    _, st = ops.dwconv3d(x, taps, b1, K=3, store=False)
+    w2n, b2n = ops.groupnorm_fold_mlp(st, float(D * H * W), self._vec(m.norm, "weight", m.norm.weight), self._vec(m.norm, "bias", m.norm.bias),
+                                      m.norm.eps, self._w2_matrix(m.conv2), self._vec(m.conv2, "bias", m.conv2.bias))
+    w3, b3 = self._pw_paired(m.conv3, project=True), self._vec(m.conv3, "bias", m.conv3.bias)
+    if head is not None:
+        _, logits = ops.dwmix(x, taps, b1, w2n, b2n, w3, b3, c_hid=c_hid, c_out=c_out, residual=bool(m.do_res),
+                              head_w=self._head_w(head), head_b=self._vec(head, "bias", head.bias), store_y=False)
+        return None, logits
+    if out is not None and tuple(out.shape) != (N, D, H, W, c_out):
+        raise ValueError(f"block output buffer {tuple(out.shape)} != {(N, D, H, W, c_out)}")
+    return ops.dwmix(x, taps, b1, w2n, b2n, w3, b3, c_hid=c_hid, c_out=c_out, residual=bool(m.do_res), y=out)
+
+
+HipBlockOps._block_dwmix = None   # bound below
 
 
 def _stem_block_fused(self, stem: nn.Module, m, x_cl: torch.Tensor, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
@@ -542,6 +573,7 @@ HipBlockOps._up_block_fused = _up_block_fused
 HipBlockOps._block_deep_gemm = _block_deep_gemm
 HipBlockOps._block_fused = _block_fused
 HipBlockOps._stem_block_fused = _stem_block_fused
+HipBlockOps._block_dwmix = _block_dwmix
 
 
 def resolve_compute_dtype(module_pref: Optional[torch.dtype]) -> torch.dtype:

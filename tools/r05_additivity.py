@@ -306,11 +306,51 @@ def phases():
               ", ".join(f"w{w} wait {float(per[..., w, 2].mean()):.0f} barrier {float(per[..., w, 5].mean()):.0f}" for w in range(4)))
 
 
+def phases_mix():
+    """section cycles of the fused block kernel (dwconv3d_k3_mfma_kernel<3, false, 4, true, 2>) at level 0"""
+    N, D, c_hid = 8, 112, 64
+    x = torch.randn(N, D, D, D, 32, device=dev).to(bf)
+    taps, b1 = torch.randn(27, 32, device=dev) * 0.2, torch.randn(32, device=dev)
+    gamma, beta = torch.rand(32, device=dev) + 0.5, torch.randn(32, device=dev) * 0.1
+    w2, b2 = (torch.randn(c_hid, 32, device=dev) / 32 ** 0.5).contiguous(), torch.randn(c_hid, device=dev) * 0.1
+    w3 = ops.pw_pack_weight_paired((torch.randn(32, c_hid, device=dev) / c_hid ** 0.5).contiguous(), f16=True)
+    b3 = torch.randn(32, device=dev) * 0.1
+    _, st = ops.dwconv3d(x, taps, b1, K=3, store=False)
+    w2n, b2n = ops.groupnorm_fold_mlp(st, float(D ** 3), gamma, beta, 1e-5, w2, b2)
+    y = torch.empty_like(x)
+    slots = st.shape[1]
+    for residual in (True, False):
+        knob("dwconv_mfma_probe", 0)
+        us0, _, _ = run_for(lambda: ops.dwmix(x, taps, b1, w2n, b2n, w3, b3, c_hid=c_hid, residual=residual, y=y), 0.5)
+        prof = torch.zeros(N, slots, 4, 9, device=dev)
+        ptr = prof.data_ptr()
+        lo, hi = ptr & 0xffffffff, ptr >> 32
+        knob("dwmix_prof_lo", lo - (1 << 32) if lo >= (1 << 31) else lo)
+        knob("dwmix_prof_hi", hi)
+        knob("dwconv_mfma_probe", 4)
+        us4, _, _ = run_for(lambda: ops.dwmix(x, taps, b1, w2n, b2n, w3, b3, c_hid=c_hid, residual=residual, y=y), 0.5)
+        torch.cuda.synchronize()
+        knob("dwconv_mfma_probe", 0)
+        v = prof.double()
+        steps = v[..., 6]
+        names = ["load issue", "matrix instr", "wait plane", "LDS commit", "round+tile", "barrier", None, None, "channel mixer"]
+        print(f"fused block {N}x{D}^3x32 -> {c_hid} -> 32, residual {residual}: launch {us0:.1f} us (probe 4: {us4:.1f} us); cycles per plane step, mean over waves:")
+        tot = v[..., 7]
+        for i, nm in enumerate(names):
+            if nm is None:
+                continue
+            m = v[..., i] / steps
+            print(f"   {nm:14s} {float(m.mean()):8.0f}   {100 * float(v[..., i].sum() / tot.sum()):5.1f} % of wave life")
+        print(f"   step total     {float(((v[..., :6].sum(-1) + v[..., 8]) / steps).mean()):8.0f}   wave life {float(tot.mean()):.0f} cycles")
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["telemetry", "clocks", "phases"]
     print(torch.cuda.get_device_name(0))
     if "phases" in what:
         phases()
+    if "phases_mix" in what:
+        phases_mix()
     if "telemetry" in what:
         telemetry()
     if "clocks" in what:
