@@ -23,7 +23,9 @@
 extern "C" {
 #endif
 
-#define PYTC_ABI_VERSION 1
+/* 2 (round 5): pytc_mlp_args.per_sample (added in round 4 without a bump: ADVICE r04), pytc_dwconv3d_fwd with y = NULL, pytc_dwmix_*.
+ * Bumped whenever a struct layout or the meaning of an argument changes; _native.py refuses a library of another version. */
+#define PYTC_ABI_VERSION 2
 
 #define PYTC_OK 0
 #define PYTC_ERR_INVALID 1     /* bad argument (shape, dtype, alignment) */

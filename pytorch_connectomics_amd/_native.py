@@ -11,6 +11,7 @@ import os
 from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libpytc_hip.so"
+ABI_VERSION = 2          # include/pytc_hip.h PYTC_ABI_VERSION
 
 F32, BF16 = 0, 1
 OK = 0
@@ -276,8 +277,8 @@ def lib():
             raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
         fn.restype = res
         fn.argtypes = args
-    if handle.pytc_abi_version() != 1:
-        raise RuntimeError("libpytc_hip.so ABI version mismatch; rebuild the library")
+    if handle.pytc_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libpytc_hip.so ABI version {handle.pytc_abi_version()} != {ABI_VERSION} (include/pytc_hip.h PYTC_ABI_VERSION); rebuild the library")
     _lib = handle
     # PYTC_TUNING="knob=value,knob=value": kernel-variant knobs (pytc_set_tuning) for A/B runs of unmodified commands
     for item in filter(None, (t.strip() for t in os.environ.get("PYTC_TUNING", "").split(","))):

@@ -1,5 +1,9 @@
 #include <stdarg.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "pytc_common.h"
 
 namespace pytc {
@@ -13,6 +17,42 @@ void set_error(const char* fmt, ...) {
 int hip_fail(hipError_t e, const char* what) {
   set_error("%s: HIP error %d (%s)", what, (int)e, hipGetErrorString(e));
   return PYTC_ERR_HIP;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: a process that launches on a second GPU has to
+// opt that device in as well (the per-process once-flags left every device but the first at the 64 KB default, and the
+// return code was dropped).  Remembered per (kernel, device); the device's LDS size is checked; failures surface through the launch
+// wrapper's error string.
+static thread_local bool g_launch_failed = false;
+bool take_launch_failure() {
+  const bool f = g_launch_failed;
+  g_launch_failed = false;
+  return f;
+}
+static bool ensure_dynamic_lds_impl(const void* kernel, size_t bytes, const char* what);
+bool ensure_dynamic_lds(const void* kernel, size_t bytes, const char* what) {
+  const bool ok = ensure_dynamic_lds_impl(kernel, bytes, what);
+  if (!ok) g_launch_failed = true;
+  return ok;
+}
+static bool ensure_dynamic_lds_impl(const void* kernel, size_t bytes, const char* what) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) { hip_fail(e, what); return false; }
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({kernel, dev})) return true;
+  int lds = 0;
+  e = hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+  if (e == hipSuccess && lds > 0 && bytes > (size_t)160 * 1024) {
+    set_error("%s: %zu bytes of dynamic LDS requested, a CDNA4 workgroup has 160 KB", what, bytes);
+    return false;
+  }
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) { hip_fail(e, what); return false; }
+  done.insert({kernel, dev});
+  return true;
 }
 }  // namespace pytc
 

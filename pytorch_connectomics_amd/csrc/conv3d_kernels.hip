@@ -440,11 +440,8 @@ conv3d_pack_multi_kernel(const long* __restrict__ table, int n_items) {
 
 template <int MT>
 static void launch_conv_tile_mt(const ConvParams& p, const ConvTile& t, size_t lds_bytes, dim3 grid, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {      // dynamic LDS above 64 KB needs the opt-in, once per kernel
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_tile_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    attr_set = true;
-  }
+  // dynamic LDS above 64 KB needs the opt-in, once per kernel and device
+  if (!ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3d_tile_kernel<MT>), 80 * 1024, "conv3d_tile")) return;
   hipLaunchKernelGGL((conv3d_tile_kernel<MT>), grid, dim3(256), lds_bytes, s, p, t);
 }
 

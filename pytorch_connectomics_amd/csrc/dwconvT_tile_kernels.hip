@@ -205,11 +205,7 @@ void dwconvT_tile_launch(const void* x, void* y, const float* w, const float* bi
   unsigned short* yp = (unsigned short*)y;
 #define PYTC_TT(CC, TYY, ST)                                                                                                  \
   do {                                                                                                                        \
-    static std::once_flag once;                                                                                \
-    std::call_once(once, [] {                                                                      \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconvT3d_k3_tile_kernel<CC, TYY, ST>),                        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);                                      \
-    });                                                                                                    \
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(&dwconvT3d_k3_tile_kernel<CC, TYY, ST>), 64 * 1024, "dwconvT3d_k3_tile")) return; \
     hipLaunchKernelGGL((dwconvT3d_k3_tile_kernel<CC, TYY, ST>), grid, block,                                                  \
                        (size_t)(TT_TZ + 1) * (TYY + 1) * (TT_TX + 1) * CC * 2 + 4 * 2048, s, xp, yp, w, bias, stats, g);                  \
   } while (0)

@@ -182,11 +182,7 @@ void dwconv_s2_launch(const void* x, void* y, const float* w, const float* bias,
 #define PYTC_S2(CC, TYY)                                                                                                      \
   do {                                                                                                                        \
     const size_t lds = (size_t)(3 * (2 * TYY + 1) * 17 * CC + TYY * 8 * CC) * 2;                                               \
-    static std::once_flag once;                                                                                \
-    std::call_once(once, [] {                                                                      \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3d_k3_s2_march_kernel<CC, TYY>),                         \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);                                      \
-    });                                                                                                    \
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(&dwconv3d_k3_s2_march_kernel<CC, TYY>), 72 * 1024, "dwconv3d_k3_s2_march")) return; \
     hipLaunchKernelGGL((dwconv3d_k3_s2_march_kernel<CC, TYY>), grid, block, lds, s, xp, yp, w, bias, stats, g);               \
   } while (0)
   if (g.C == 32 && g.tyo == 8) PYTC_S2(32, 8);

@@ -215,10 +215,7 @@ pw_mlp_lds_kernel(MlpLdsParams p) {
 template <int KS_IN, int MO, int NT, int NWAVES, int WPS>
 static void launch_mlp_lds_v(const MlpLdsParams& p, size_t lds, hipStream_t s) {
   auto kern = &pw_mlp_lds_kernel<KS_IN, MO, NT, NWAVES, WPS>;
-  static std::once_flag attr_once;           // per template instance; hip_ops may launch from several host threads
-  std::call_once(attr_once, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  });
+  if (!ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, "pw_mlp_lds")) return;     // per (kernel, device); thread safe
   const long tiles = ((p.rps + NT * 16 - 1) / (NT * 16)) * p.N;
   const int by_lds = (int)((160 * 1024) / lds), by_waves = WPS * 4 / NWAVES;
   const int per_cu = by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves;

@@ -26,6 +26,8 @@ constexpr int WAVE = 64;
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
 int tuning_get(const char* key, int dflt);
+bool ensure_dynamic_lds(const void* kernel, size_t bytes, const char* what);   // per (kernel, device) opt-in above 64 KB of dynamic LDS
+bool take_launch_failure();   // a launch helper gave up before launching (error string set): PYTC_LAUNCH_CHECK turns it into a status
 
 #define PYTC_REQUIRE(cond, ...)                     \
   do {                                              \
@@ -37,6 +39,7 @@ int tuning_get(const char* key, int dflt);
 
 #define PYTC_LAUNCH_CHECK(name)                                  \
   do {                                                           \
+    if (pytc::take_launch_failure()) return PYTC_ERR_HIP;        \
     hipError_t e_ = hipGetLastError();                           \
     if (e_ != hipSuccess) return pytc::hip_fail(e_, name);       \
   } while (0)

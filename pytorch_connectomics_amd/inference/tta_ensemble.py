@@ -66,9 +66,26 @@ class TTAEnsembleAccumulator:
             else:
                 self._runs.append([ch, ch + 1, self.mode_map[ch]])
 
-    legacy_result = property(lambda self: self._stat.transpose(0, 1))
-    partial_statistics = property(lambda self: self._pstat.transpose(0, 1))
-    partial_counts = property(lambda self: self._pcount.transpose(0, 1))
+    # The reference keeps these three as plain (N, C, ...) tensor attributes that its distributed TTA reduction reads, reduces and
+    # assigns back.  Here they are VIEWS of the channel-major stores (non-contiguous: an in-place collective needs `.contiguous()`
+    # first, or the stores themselves -- inference/tta.py reduces `_stat` / `_pstat` / `_pcount` directly); assignment copies the
+    # given (N, C, ...) tensor into the store, so `acc.legacy_result = reduced` works as it does on the reference's class.
+    def _store_property(name):            # noqa: N805
+        def get(self):
+            return getattr(self, name).transpose(0, 1)
+
+        def set_(self, value):
+            store = getattr(self, name)
+            value = torch.as_tensor(value, device=store.device)
+            if tuple(value.shape) != tuple(store.transpose(0, 1).shape):
+                raise ValueError(f"expected shape {tuple(store.transpose(0, 1).shape)}, got {tuple(value.shape)}")
+            store.copy_(value.transpose(0, 1))
+        return property(get, set_)
+
+    legacy_result = _store_property("_stat")
+    partial_statistics = _store_property("_pstat")
+    partial_counts = _store_property("_pcount")
+    del _store_property
 
     @property
     def has_partial_channels(self) -> bool:

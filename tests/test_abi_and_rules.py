@@ -26,7 +26,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in pytc_hip.h but not exported"
     assert set(_native.exported_symbols()) <= set(declared)
-    assert lib.pytc_abi_version() == 1
+    header = (ROOT / "include" / "pytc_hip.h").read_text()
+    assert lib.pytc_abi_version() == _native.ABI_VERSION == int(re.search(r"#define PYTC_ABI_VERSION (\d+)", header).group(1))
 
 
 def test_abi_pure_host_queries():

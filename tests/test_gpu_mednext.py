@@ -310,3 +310,23 @@ def test_level0_subbatch_is_bit_identical(dev, counts, ds):
     m.l0_subbatch = 2
     for a, b in zip(ref, run()):
         assert torch.equal(a, b)
+
+
+def test_a_window_gives_the_same_bits_alone_and_inside_a_batch_at_112():
+    """the block schedule (fused folded mixer / LDS-resident mixer / two-GEMM pair of the deep levels) is chosen from
+    batch-independent quantities, so a 112^3 window -- whose levels straddle every row threshold at N = 1 .. 8 -- gives the same bf16
+    bits as the engine's probe window (N = 1), in a ragged last batch (N = 3) and in a full batch of 8."""
+    from types import SimpleNamespace as NS
+    from pytorch_connectomics_amd.models import build_model
+    cfg = NS(model=NS(arch=NS(type="mednext"), in_channels=1, out_channels=1, mednext=NS(size="S", kernel_size=3),
+                      loss=NS(deep_supervision=False), heads=None))
+    torch.manual_seed(0)
+    model = build_model(cfg).cuda().eval()
+    model.model.compute_dtype = torch.bfloat16
+    x = torch.rand(8, 112, 112, 112, 1, device="cuda")
+    with torch.no_grad():
+        full = model.forward_cl(x).clone()
+        one = model.forward_cl(x[5:6].contiguous()).clone()
+        three = model.forward_cl(x[2:5].contiguous()).clone()
+    assert torch.equal(one[0], full[5])
+    assert torch.equal(three, full[2:5])

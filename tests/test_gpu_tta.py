@@ -177,3 +177,23 @@ def test_tta_ensemble_accumulator_matches_the_reference(golden_dir):
     with pytest.raises(RuntimeError, match="no CPU path"):
         TTAEnsembleAccumulator((1, 2, 4, 4, 4), dtype=torch.float32, device="cpu", mode_map=["mean", "mean"], partial_channels=[],
                                distributed_sharding=False, max_views=2)
+
+
+def test_ensemble_accumulator_attributes_are_assignable_like_the_reference_class():
+    """`legacy_result` / `partial_statistics` / `partial_counts` are the reference's (N, C, ...) tensor attributes, which
+    its distributed reduction reads, reduces and assigns back.  Here they are views of channel-major stores: reading gives the
+    reference's shape, `.contiguous()` gives a collective-ready tensor, assignment writes through to the store."""
+    from pytorch_connectomics_amd.inference.tta_ensemble import TTAEnsembleAccumulator
+    dev = torch.device("cuda")
+    acc = TTAEnsembleAccumulator((2, 3, 4, 5, 6), dtype=torch.float32, device=dev, mode_map=["mean", "min", "max"],
+                                 partial_channels=[1], distributed_sharding=True, max_views=4)
+    assert tuple(acc.legacy_result.shape) == (2, 3, 4, 5, 6) and tuple(acc.partial_statistics.shape) == (2, 1, 4, 5, 6)
+    new = torch.rand(2, 3, 4, 5, 6, device=dev)
+    acc.legacy_result = new
+    assert torch.equal(acc.legacy_result, new) and torch.equal(acc._stat, new.transpose(0, 1))
+    cnt = torch.full((2, 1, 4, 5, 6), 3.0, device=dev)
+    acc.partial_counts = cnt
+    acc.partial_statistics = cnt * 2
+    assert torch.equal(acc.partial_counts.contiguous(), cnt) and float(acc._pstat.max()) == 6.0
+    with pytest.raises(ValueError, match="expected shape"):
+        acc.legacy_result = torch.zeros(3, 2, 4, 5, 6, device=dev)
