@@ -355,13 +355,33 @@ def train_leg(dev, rank, world, args, barrier):
     vox = world * args.train_batch * ROI_VOX * steps
     if roof is not None:
         roof["whole_step"] = whole_step_roofline(vox / dt / world, passes=3.0)
+    # what the collective moved, so that the first multi-GPU run explains itself: per-rank placement, backend, DDP's bucket layout and
+    # the gradient bytes all-reduced per step (ring all-reduce over xGMI: each rank sends and receives 2 (N-1)/N of them)
+    ddp_info = None
+    if world > 1:
+        try:
+            log = net._get_ddp_logging_data()
+            nbytes = sum(p_.numel() * 4 for p_ in model.parameters() if p_.requires_grad)
+            mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", rank)), "device": torch.cuda.get_device_name(dev),
+                    "device_index": dev.index, "ms_per_step_local": dt / steps * 1e3}
+            ranks = [None] * world
+            torch.distributed.all_gather_object(ranks, mine)
+            sizes = [int(v) for v in str(log.get("bucket_sizes", "")).replace(",", " ").split() if v.strip().isdigit()]
+            ddp_info = {"backend": str(log.get("backend_name", torch.distributed.get_backend())), "world_size": world,
+                        "rccl_ranks": world, "buckets": len(sizes) or None, "bucket_bytes": sizes or None,
+                        "bucket_cap_bytes": int(log.get("bucket_cap_bytes", 0)) or None,
+                        "gradient_bytes_allreduced_per_step": nbytes,
+                        "ring_bytes_sent_per_rank_per_step": int(2 * (world - 1) / world * nbytes),
+                        "find_unused_parameters": True, "gradient_as_bucket_view": True, "ranks": ranks}
+        except Exception as exc:  # noqa: BLE001
+            ddp_info = {"error": f"{type(exc).__name__}: {exc}"}
     del opt, net, model
     torch.cuda.empty_cache()
     return {"value": vox / dt, "unit": "voxels/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "batch_per_gpu": args.train_batch, "patch": list(ROI), "dtype": "bf16 activations, fp32 master weights",
             "parallelism": f"ddp{world}" if world > 1 else "single", "scaling": "weak",
             "includes": "forward + backward + fused BCE/Dice loss + grad-norm clip + AdamW step, all HIP kernels",
-            "final_loss": float(loss.detach()), "roofline": roof}
+            "final_loss": float(loss.detach()), "roofline": roof, "ddp": ddp_info}
 
 
 def c3_affinity_tta16_leg(dev, model3):
@@ -435,17 +455,56 @@ def c4_chunked_leg(dev):
         y = lazy_predict_region(cfg, model.forward, vol, region_start=lo, region_stop=hi, device="cuda")
         return y[(Ellipsis,) + tuple(core)].contiguous()
 
+    kept = {}
+
+    def run_chunks():
+        shapes = []
+        for c in chunks:
+            y = one_chunk(c)
+            shapes.append(tuple(y.shape))
+            kept["last"] = y                                                    # (1, 7, 320, 320, 320) fp32 = 0.92 GB
+        return shapes
+
     with torch.no_grad():
         fwd_cl(torch.rand(1, *roi, 1, device=dev))                              # warm-up: weight images, allocator pools
-        s, outs = timed(lambda: [tuple(one_chunk(c).shape) for c in chunks])
+        s, outs = timed(run_chunks)
     n_win = sum(windows)
+    # the chunk FILE of the last chunk, as the chunked runner writes it (chunked.py: write_prediction_artifact, gzip, HDF5 chunks
+    # (C, 64, 64, 64)): device -> host copy, then the parallel deflate writer (csrc/host/h5io.c; round 4: one zlib thread, 63 s)
+    write = None
+    try:
+        import tempfile
+        import time as _time
+        from pytorch_connectomics_amd.inference.artifact import write_prediction_artifact
+        from pytorch_connectomics_amd.utils import h5lite
+        if h5lite.available():
+            t0 = _time.perf_counter()
+            host = kept["last"][0].cpu().numpy()
+            t1 = _time.perf_counter()
+            with tempfile.TemporaryDirectory() as td:
+                write_prediction_artifact(Path(td) / "chunk_z0_y0_x0.h5", host, compression="gzip", chunks=(int(host.shape[0]), 64, 64, 64))
+                t2 = _time.perf_counter()
+                fsz = (Path(td) / "chunk_z0_y0_x0.h5").stat().st_size
+            write = {"d2h_seconds": t1 - t0, "write_seconds": t2 - t1, "threads": h5lite.write_threads(), "bytes": int(host.nbytes),
+                     "file_bytes": int(fsz), "MB_per_s": host.nbytes / 1e6 / max(t2 - t1, 1e-9),
+                     "note": "gzip level 4 on uniform-random-like sigmoid outputs (near-incompressible: the worst case for zlib)"}
+    except Exception as exc:  # noqa: BLE001
+        write = {"error": f"{type(exc).__name__}: {exc}"}
+    kept.clear()
     rec = {"seconds": s, "chunks": len(chunks), "seconds_per_chunk": s / len(chunks), "windows": n_win, "roi": list(roi),
            "volume": list(vol_shape), "chunk": list(chunk), "halo": list(halo),
            "window_voxels_per_s": n_win * roi[0] * roi[1] * roi[2] / s,
            "output_voxels_per_s": vol_shape[0] * vol_shape[1] * vol_shape[2] / s, "chunk_output_shape": list(outs[0]),
+           "chunk_file_write": write,
+           "roofline": {"bound": "mfma+hbm", "algorithmic_bytes_per_voxel": 2322.0, "algorithmic_flop_per_voxel": 4.781e5,
+                        "achieved_GBs": n_win * roi[0] * roi[1] * roi[2] / s * 2322.0 / 1e9, "hbm_frac": n_win * roi[0] * roi[1] * roi[2] / s * 2322.0 / 8e12,
+                        "achieved_TFLOPs": n_win * roi[0] * roi[1] * roi[2] / s * 4.781e5 / 1e12,
+                        "mfma_frac": n_win * roi[0] * roi[1] * roi[2] / s * 4.781e5 / 2.5e15,
+                        "source": "SURVEY.md section 8(d): MedNeXt-L k3 160^3 byte / FLOP floor per window-voxel x this leg's window-voxels/s "
+                                  "(the leg's time includes host -> HBM reads of the lazy volume, blending and the crop)"},
            "path": "per chunk: lazy_predict_region over the haloed region on the global window grid (what run_chunked_prediction_inference "
                    "calls) + crop: MedNeXt-L k3 + 3 MitoEM heads (7 ch), bf16, chunk 320^3 / halo 80, reflect padding, sw 2; host volume -> "
-                   "pinned -> HBM reads included, gzip chunk files (zlib-bound, writer thread) not timed"}
+                   "pinned -> HBM reads included; the gzip chunk file of one chunk is timed separately (chunk_file_write)"}
     del model
     torch.cuda.empty_cache()
     return rec

@@ -29,6 +29,7 @@ _NO_SLP = os.environ.get("PYTC_NO_SLP_FILES", "dwconv_kernels.hip,dwconv_mfma_ke
 EXTRA_FLAGS = {p.name: ["-fno-slp-vectorize"] for p in Path(__file__).resolve().parent.glob("*.hip")
                if _NO_SLP == "all" or p.name in _NO_SLP.split(",")}
 
+# (also the kernels of csrc/asm_check.py's build-time walk: asm-issued loads, counted waits)
 NO_SPILL_KERNELS = {"dwconv_kernels.hip": ("dwconv3d_k3_march_kernel", "dw_wgrad_march_kernel"),
                     "dwconv_mfma_kernels.hip": ("dwconv3d_k3_mfma_kernel",)}
 
@@ -47,6 +48,29 @@ def _check_no_spills(fname: str, remarks: str, patterns) -> None:
         if m and name and any(p in name for p in patterns) and int(m.group(2)) != 0:
             raise RuntimeError(f"{fname}: kernel {name} reports {m.group(1)} = {m.group(2)}; the asm-load / counted-wait kernels "
                                "must be spill-free (lower the occupancy hint of that instantiation)")
+
+
+def asm_listing(src: Path, hipcc: str = "/opt/rocm/bin/hipcc") -> str:
+    """gfx950 assembly listing of one source with the flags the object is built with (a second device-only compile, ~2 s)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = Path(td) / (src.stem + ".s")
+        subprocess.run([hipcc, *FLAGS, *EXTRA_FLAGS.get(src.name, []), "-S", "--cuda-device-only", str(src), "-o", str(out)],
+                       check=True, capture_output=True)
+        return out.read_text()
+
+
+def _check_asm_load_discipline(src: Path, hipcc: str) -> None:
+    """csrc/asm_check.py on the listing of an asm-load / counted-wait source: no compiler instruction may touch a staged register between
+    an asm-issued load and the next hand-written s_waitcnt vmcnt, on any control-flow path.  A violation is a BUILD error."""
+    from . import asm_check
+    text = asm_listing(src, hipcc)
+    pats = NO_SPILL_KERNELS[src.name]
+    if asm_check.asm_loads_in(text, pats) == 0:
+        raise RuntimeError(f"{src.name}: no asm-issued register loads found in kernels {pats}: the ISA check would be checking nothing")
+    bad = asm_check.check_listing(text, pats)
+    if bad:
+        raise RuntimeError(f"{src.name}: {len(bad)} violations of the asm-load discipline (csrc/asm_check.py), e.g.\n  " + "\n  ".join(bad[:5]))
 
 
 def _check_packed_fp32_selects(obj: Path) -> None:
@@ -111,6 +135,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
             # spill in one of them is a BUILD error, not a performance note
             out = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], check=True, capture_output=True, text=True).stderr
             _check_no_spills(src.name, out, NO_SPILL_KERNELS[src.name])
+            _check_asm_load_discipline(src, hipcc)
         else:
             subprocess.run(cmd, check=True)
         _check_packed_fp32_selects(obj)
@@ -144,7 +169,7 @@ def build_h5(verbose: bool = True):
     if H5_LIB.exists() and H5_LIB.stat().st_mtime >= H5_SRC.stat().st_mtime:
         return H5_LIB
     LIB_DIR.mkdir(exist_ok=True)
-    cmd = ["gcc", "-O2", "-fPIC", "-shared", f"-I{root}/include", str(H5_SRC), f"-L{root}/lib", "-lhdf5",
+    cmd = ["gcc", "-O2", "-fPIC", "-shared", f"-I{root}/include", str(H5_SRC), f"-L{root}/lib", "-lhdf5", "-lz", "-lpthread",
            f"-Wl,-rpath,{root}/lib", "-o", str(H5_LIB)]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)

@@ -367,6 +367,68 @@ conv3d_wgrad_strided_thin1_kernel(const T* __restrict__ a, const T* __restrict__
   }
 }
 
+// C_k == 1, 3 x 3 x 3 taps, stride 2, padding 1 as a REDUCTION over staged lines (round 5).  The kernel above walks its rows with 27
+// dependent broadcast loads each (499 us for 2 x 12 x 128 x 128 x 32 gradients: 30 MB of operands, 0.0005 of anything).  Here a
+// workgroup takes whole x-lines of the small grid: the 9 source lines (3 z x 3 y of the 1-channel input, zero padded, as fp32) and the
+// gradient line ([Ws][C_o] as fp32) are staged in LDS with coalesced loads, then thread (tap slot t / 32, channel t % 32) runs along
+// the line: one LDS read of its gradient value(s), one broadcast LDS read and one FMA per tap it owns (taps slot, slot + 8, slot + 16,
+// slot + 24).  One partial [27][C_o] per workgroup (slot order fixed: deterministic), sw_reduce_slots_kernel finishes.
+template <typename T, int COG>
+__global__ void __launch_bounds__(256)
+conv3d_wgrad_s2_c1_line_kernel(const T* __restrict__ a, const T* __restrict__ gsm, float* __restrict__ dWp, int N, SwGeom g, int C_o,
+                               int lines_per_slot) {
+  extern __shared__ float lds_f[];
+  const int WP = g.Wb + 2;                                   // column bx lives at index bx + 1 (bx = -1 .. Wb)
+  float* bl = lds_f;                                         // [9][WP]
+  float* gl = lds_f + 9 * WP;                                // [Ws][C_o]
+  const int tid = threadIdx.x, o = tid & 31, ts = tid >> 5;  // channel (+ 32 c), tap slot 0..7
+  const long lines_total = (long)N * g.Ds * g.Hs;
+  const long l_begin = (long)blockIdx.x * lines_per_slot;
+  const long l_end = l_begin + lines_per_slot < lines_total ? l_begin + lines_per_slot : lines_total;
+  float acc[4][COG];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int c = 0; c < COG; ++c) acc[k][c] = 0.f;
+  int lrow[4], lcol[4];                                      // this thread's taps: source line (tz * 3 + ty) and column offset tx
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int tap = ts + 8 * k; lrow[k] = tap < 27 ? tap / 3 : 0; lcol[k] = tap % 3; }
+  for (long line = l_begin; line < l_end; ++line) {
+    const int y = (int)(line % g.Hs);
+    const int z = (int)((line / g.Hs) % g.Ds);
+    const long n = line / ((long)g.Hs * g.Ds);
+    __syncthreads();                                          // the previous line's reads are done
+    for (int i = tid; i < 9 * WP; i += 256) {
+      const int l = i / WP, bx = i % WP - 1;
+      const int bz = 2 * z - 1 + l / 3, by = 2 * y - 1 + l % 3;
+      const bool ok = bz >= 0 && bz < g.Db && by >= 0 && by < g.Hb && bx >= 0 && bx < g.Wb;
+      bl[i] = ok ? to_f32<T>(a[((n * g.Db + bz) * g.Hb + by) * g.Wb + bx]) : 0.f;
+    }
+    const T* gline = gsm + line * g.Ws * C_o;
+    for (int i = tid; i < g.Ws * C_o; i += 256) gl[i] = to_f32<T>(gline[i]);
+    __syncthreads();
+    for (int x = 0; x < g.Ws; ++x) {
+      float gv[COG];
+#pragma unroll
+      for (int c = 0; c < COG; ++c) gv[c] = gl[x * C_o + o + 32 * c];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float av = bl[lrow[k] * WP + 2 * x + lcol[k]];           // source column 2x + tx - 1, stored at + 1
+#pragma unroll
+        for (int c = 0; c < COG; ++c) acc[k][c] = fmaf(gv[c], av, acc[k][c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int tap = ts + 8 * k;
+    if (tap < 27) {
+#pragma unroll
+      for (int c = 0; c < COG; ++c) dWp[((long)blockIdx.x * 27 + tap) * C_o + o + 32 * c] = acc[k][c];
+    }
+  }
+}
+
 // out[i] = sum_s part[s][i], slots in order within 16 interleaved lanes, then the lanes in order (fixed tree)
 __global__ void __launch_bounds__(256)
 sw_reduce_slots_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int slots) {
@@ -675,6 +737,13 @@ static int sw_slots(long rows_total, int C_k) {
 
 using namespace pytc;
 
+// the line-reduction kernel: one input channel, 32 or 64 gradient channels, k 3 / stride 2 / pad 1 on every axis, lines that fit 64 KB of LDS
+static bool sw_c1_line_ok(const SwGeom& g, int C_k, int C_o, int dtype) {
+  if (C_k != 1 || (C_o != 32 && C_o != 64) || (dtype != PYTC_BF16 && dtype != PYTC_F32) || tuning_get("conv3d_wgrad_c1_line", 1) == 0) return false;
+  if (g.kd != 3 || g.kh != 3 || g.kw != 3 || g.sd != 2 || g.sh != 2 || g.sw != 2 || g.pd != 1 || g.ph != 1 || g.pw != 1) return false;
+  return (size_t)(9 * (g.Wb + 2) + g.Ws * C_o) * sizeof(float) <= 64 * 1024 && 2 * (g.Ws - 1) + 2 - 1 < g.Wb + 1;
+}
+
 static int s_kstep(int dtype) { return dtype == PYTC_BF16 ? 32 : 16; }
 
 extern "C" int64_t pytc_conv3d_direct_packed_elems(int C_out, int C_in, int kd, int kh, int kw, int dtype) {
@@ -765,6 +834,19 @@ extern "C" int pytc_conv3d_wgrad_strided(const void* big, const void* small, flo
     else if (mp.nt == 2) SW_MFMA(1, 2);
     else SW_MFMA(1, 1);
 #undef SW_MFMA
+  } else if (sw_c1_line_ok(g, C_k, C_o, dtype)) {
+    // slot = a run of whole x-lines; the workspace query (pytc_conv3d_wgrad_strided_ws_elems) sizes for sw_slots(): never more here
+    const long lines_total = (long)N * g.Ds * g.Hs;
+    int lslots = (int)(lines_total < slots ? lines_total : slots);
+    const int lps = (int)((lines_total + lslots - 1) / lslots);
+    lslots = (int)((lines_total + lps - 1) / lps);
+    slots = lslots;
+    const size_t lds = (size_t)(9 * (g.Wb + 2) + g.Ws * C_o) * sizeof(float);
+#define SW_C1(TT, COGV) hipLaunchKernelGGL((conv3d_wgrad_s2_c1_line_kernel<TT, COGV>), dim3((unsigned)lslots), block, lds, s, (const TT*)big, \
+                                           (const TT*)small, workspace, N, g, C_o, lps)
+    if (dtype == PYTC_BF16) { if (C_o == 32) SW_C1(bf16_t, 1); else SW_C1(bf16_t, 2); }
+    else { if (C_o == 32) SW_C1(float, 1); else SW_C1(float, 2); }
+#undef SW_C1
   } else if (C_k == 1 && g.kd == 3 && g.kh == 3 && g.kw == 3 && (dtype == PYTC_BF16 || dtype == PYTC_F32) &&
       tuning_get("conv3d_wgrad_thin", 1) != 0) {
     dim3 tgrid(slots, (C_o + SWT_TO - 1) / SWT_TO);

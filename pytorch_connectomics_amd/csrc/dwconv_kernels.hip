@@ -742,8 +742,10 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
     if (gz + 1 <= ze) {
       landed(cm, gz + PF <= ze, res_now);
       commit(slot ^ 1, cm, gz + 1);
-    } else if constexpr (RES && ASYNC) {
-      asm volatile("s_waitcnt vmcnt(0)" : : : "memory");      // last step: the residual of plane ze-1 has to be there
+    } else if constexpr (ASYNC) {
+      // last step: the residual of plane ze-1 has to be there (RES).  Without a residual nothing is in flight here; the statement stays
+      // so that EVERY path through a step executes a hand-written wait after the step's requests (csrc/asm_check.py, build-time)
+      asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
     }
     if constexpr (RES && ASYNC) {
 #pragma unroll
@@ -817,6 +819,7 @@ dwconv3d_k3_march_kernel(const T* __restrict__ x, T* __restrict__ y, const float
       if (gz + 5 <= ze) { step(gz + 5, slot, accC, accA, accB, stg1, stg0, rq2, rq1); slot ^= 1; }
     }
   }
+  if constexpr (ASYNC) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // (asm_check.py: the epilogue is reached through a wait)
 
   if (stats) {
 #pragma unroll

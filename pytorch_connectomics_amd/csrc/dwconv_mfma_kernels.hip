@@ -366,6 +366,11 @@ dwconv3d_k3_mfma_kernel(const unsigned short* __restrict__ x, unsigned short* __
       stamp(2);
       commit(slot ^ 1, cm, gz + 1);
       stamp(3);
+    } else {
+      // last step of the chunk: nothing is in flight any more.  The statement is here for csrc/asm_check.py: EVERY path through a step
+      // executes a hand-written vmcnt wait after the step's load requests, so "no compiler instruction touches a staged register
+      // before a hand-written wait" is a property of the listing that a static walk can establish (build-time check)
+      mf_wait_vm<0>();
     }
     // ---- output plane gz-1 is complete: accumulator VGPR 0, lane = (channel, column) -> the workgroup's NDHWC tile of parity
     //      (gz-1) & 1; it leaves at the start of the next step, after this step's barrier
@@ -412,6 +417,7 @@ dwconv3d_k3_mfma_kernel(const unsigned short* __restrict__ x, unsigned short* __
       if (gz + k <= ze) { step(gz + k, slot, stg[k], stg[(k + 1) % PF], rres[MIX ? k : 0], rres[MIX ? (k + 1) % 3 : 0]); slot ^= 1; }
     }
   }
+  mf_wait_vm<0>();       // (asm_check.py: the epilogue below is reached through a hand-written wait on every static path)
   if constexpr (MIX) {
     // the last plane: its residual rows were requested at step ze - 1, nothing was requested after them.  Their register set is the
     // one of plane (ze - 1): (ze - 1 - (zs - 1)) % 3 -- a wave-uniform runtime index, resolved by a three-way branch

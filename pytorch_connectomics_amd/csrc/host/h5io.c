@@ -6,10 +6,12 @@
  * readable by h5py / the reference's decoders, and the reference's HDF5 volumes are readable here.
  * Plain C ABI: int64 handles, int status (0 ok), last error text per thread. */
 #include <hdf5.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <zlib.h>
 
 static __thread char g_err[512];
 static void set_err(const char* what) { snprintf(g_err, sizeof(g_err), "%s", what); }
@@ -320,6 +322,145 @@ int pytc_h5_dset_write(int64_t ds, int ndim, const int64_t* start, const int64_t
 }
 int pytc_h5_dset_read(int64_t ds, int ndim, const int64_t* start, const int64_t* count, void* buf, int mem_dtype) {
   return slab_io(ds, ndim, start, count, buf, mem_dtype, 0);
+}
+
+/* ---- parallel deflate + direct chunk write (round 5).  H5Dwrite pushes every chunk of a gzip dataset through zlib on ONE thread:
+ * 63 s for the 0.9 GB of a 7-channel fp32 320^3 prediction chunk, 40x the 1.45 s the GPU needs to predict it (bench.py C4 leg, r04).
+ * Here `nthreads` workers each take whole HDF5 chunks of the region: gather the chunk from the caller's contiguous buffer (edge chunks
+ * are zero-padded to the full chunk shape, as the library stores them), compress2() it, and hand the compressed bytes to
+ * H5Dwrite_chunk (filter mask 0 = "deflate applied") under a mutex -- the library itself is not thread safe, zlib is.  The file is an
+ * ordinary gzip-chunked HDF5 dataset: h5py, the reference's readers (inference/artifact.py:141-203, chunked.py:279-314) and this shim's
+ * own H5Dread decode it like any other.
+ * Requirements (checked; the caller falls back to pytc_h5_dset_write otherwise): chunked layout, no filter or deflate as the ONLY
+ * filter, buffer dtype == dataset dtype, region starting on chunk boundaries and ending on a chunk boundary or at the dataset's end. */
+typedef struct {
+  hid_t ds;
+  int ndim, level, deflate;
+  size_t esize;
+  hsize_t dims[8], chunk[8], start[8], count[8], nch[8];   /* dataset dims, chunk shape, region start / extent, chunks of the region per axis */
+  const unsigned char* src;
+  size_t src_stride[8];                                     /* elements per step along each axis of the source buffer */
+  long total;
+  long next;                                                /* next chunk index (under mu) */
+  int failed;
+  pthread_mutex_t mu;
+} pw_job;
+
+static void* pw_worker(void* arg) {
+  pw_job* j = (pw_job*)arg;
+  size_t celems = 1;
+  for (int a = 0; a < j->ndim; ++a) celems *= (size_t)j->chunk[a];
+  const size_t cbytes = celems * j->esize;
+  unsigned char* raw = (unsigned char*)malloc(cbytes);
+  uLongf cap = j->deflate ? compressBound((uLong)cbytes) : 0;
+  unsigned char* zbuf = j->deflate ? (unsigned char*)malloc(cap) : NULL;
+  if (!raw || (j->deflate && !zbuf)) { pthread_mutex_lock(&j->mu); j->failed = 1; pthread_mutex_unlock(&j->mu); free(raw); free(zbuf); return NULL; }
+  const int last = j->ndim - 1;
+  for (;;) {
+    pthread_mutex_lock(&j->mu);
+    const long idx = j->failed ? j->total : j->next++;
+    pthread_mutex_unlock(&j->mu);
+    if (idx >= j->total) break;
+    /* chunk coordinates within the region (row-major over nch) */
+    hsize_t cc[8], off[8], ext[8];
+    long r = idx;
+    for (int a = last; a >= 0; --a) { cc[a] = (hsize_t)(r % (long)j->nch[a]); r /= (long)j->nch[a]; }
+    int full = 1;
+    for (int a = 0; a < j->ndim; ++a) {
+      off[a] = j->start[a] + cc[a] * j->chunk[a];                       /* dataset coordinates of the chunk's origin */
+      const hsize_t end = j->start[a] + j->count[a];
+      ext[a] = off[a] + j->chunk[a] <= end ? j->chunk[a] : end - off[a];    /* valid extent (edge chunks) */
+      if (ext[a] != j->chunk[a]) full = 0;
+    }
+    if (!full) memset(raw, 0, cbytes);
+    /* gather: rows along the last axis are contiguous in both layouts */
+    hsize_t it[8] = {0};
+    const size_t row = (size_t)ext[last] * j->esize;
+    for (;;) {
+      size_t so = 0, dofs = 0, mul = 1;
+      for (int a = last; a >= 0; --a) {
+        const hsize_t pos = a == last ? 0 : it[a];
+        so += ((size_t)(cc[a] * j->chunk[a] + pos)) * j->src_stride[a];
+        dofs += (size_t)pos * mul;
+        mul *= (size_t)j->chunk[a];
+      }
+      memcpy(raw + dofs * j->esize, j->src + so * j->esize, row);
+      int a = last - 1;
+      for (; a >= 0; --a) { if (++it[a] < ext[a]) break; it[a] = 0; }
+      if (a < 0) break;
+    }
+    const unsigned char* out = raw;
+    size_t nout = cbytes;
+    if (j->deflate) {
+      uLongf zn = cap;
+      if (compress2(zbuf, &zn, raw, (uLong)cbytes, j->level) != Z_OK) { pthread_mutex_lock(&j->mu); j->failed = 1; pthread_mutex_unlock(&j->mu); break; }
+      out = zbuf; nout = (size_t)zn;
+    }
+    pthread_mutex_lock(&j->mu);
+    if (!j->failed && H5Dwrite_chunk(j->ds, H5P_DEFAULT, 0, off, nout, out) < 0) j->failed = 1;
+    pthread_mutex_unlock(&j->mu);
+  }
+  free(raw); free(zbuf);
+  return NULL;
+}
+
+/* returns 0 = written, 1 = error (pytc_h5_last_error), 2 = the region / dataset does not meet the requirements (nothing written) */
+int pytc_h5_dset_write_parallel(int64_t ds, int ndim, const int64_t* start, const int64_t* count, const void* buf, int mem_dtype,
+                                int nthreads) {
+  pw_job j;
+  memset(&j, 0, sizeof(j));
+  j.ds = (hid_t)ds; j.ndim = ndim; j.src = (const unsigned char*)buf;
+  if (ndim < 1 || ndim > 8) return 2;
+  hid_t sp = H5Dget_space(j.ds);
+  if (H5Sget_simple_extent_ndims(sp) != ndim) { H5Sclose(sp); return 2; }
+  H5Sget_simple_extent_dims(sp, j.dims, NULL);
+  H5Sclose(sp);
+  hid_t t = H5Dget_type(j.ds);
+  const int file_code = code_of(t);
+  j.esize = H5Tget_size(t);
+  H5Tclose(t);
+  if (file_code != mem_dtype || j.esize == 0) return 2;
+  hid_t pl = H5Dget_create_plist(j.ds);
+  int ok = H5Pget_layout(pl) == H5D_CHUNKED;
+  if (ok) H5Pget_chunk(pl, ndim, j.chunk);
+  const int nf = ok ? H5Pget_nfilters(pl) : 0;
+  if (nf > 1) ok = 0;
+  if (ok && nf == 1) {
+    unsigned flags = 0, cd[8] = {0}, cfg = 0;
+    size_t ncd = 8;
+    char nm[32];
+    if (H5Pget_filter2(pl, 0, &flags, &ncd, cd, sizeof(nm), nm, &cfg) != H5Z_FILTER_DEFLATE) ok = 0;
+    else { j.deflate = 1; j.level = ncd > 0 ? (int)cd[0] : 4; }
+  }
+  H5Pclose(pl);
+  if (!ok) return 2;
+  j.total = 1;
+  for (int a = 0; a < ndim; ++a) {
+    if (start[a] < 0 || count[a] <= 0 || (hsize_t)(start[a] + count[a]) > j.dims[a]) { set_err("write_parallel: region outside the dataset"); return 1; }
+    j.start[a] = (hsize_t)start[a]; j.count[a] = (hsize_t)count[a];
+    if (j.start[a] % j.chunk[a]) return 2;
+    const hsize_t end = j.start[a] + j.count[a];
+    if (end % j.chunk[a] && end != j.dims[a]) return 2;
+    j.nch[a] = (j.count[a] + j.chunk[a] - 1) / j.chunk[a];
+    j.total *= (long)j.nch[a];
+  }
+  size_t st = 1;
+  for (int a = ndim - 1; a >= 0; --a) { j.src_stride[a] = st; st *= (size_t)j.count[a]; }
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 256) nthreads = 256;
+  if ((long)nthreads > j.total) nthreads = (int)j.total;
+  pthread_mutex_init(&j.mu, NULL);
+  pthread_t th[256];
+  int started = 0;
+  for (int i = 0; i < nthreads; ++i) {
+    if (pthread_create(&th[i], NULL, pw_worker, &j) != 0) break;
+    ++started;
+  }
+  if (started == 0) pw_worker(&j);
+  for (int i = 0; i < started; ++i) pthread_join(th[i], NULL);
+  pthread_mutex_destroy(&j.mu);
+  if (j.failed) { set_err("write_parallel: compress2 / H5Dwrite_chunk failed"); return 1; }
+  return 0;
 }
 
 /* ---- attributes on a dataset (or file) object.  kind: 0 = utf-8 string (variable length, as h5py writes str),

@@ -6,6 +6,8 @@ connectomics/models/architectures/mednext_models.py (MedNeXtWrapper :38-89, MedN
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Any, Dict, Mapping, Optional, Union
 
@@ -60,6 +62,10 @@ def _infer_mednext_head_block_kwargs(model: nn.Module) -> dict:
     k = ref.conv1.kernel_size
     return dict(exp_r=ref.conv2.out_channels // ref.conv2.in_channels, kernel_size=int(k[0] if isinstance(k, tuple) else k),
                 do_res=ref.do_res, norm_type=_NORM_NAME.get(type(ref.norm), "layer"), dim=ref.dim, grn=ref.grn)
+
+
+# narrow task heads run as one block-diagonal 32-channel head at inference (MedNeXtMultiHeadWrapper._merged_heads); 0 = one pass per head
+MERGE_NARROW_HEADS = os.environ.get("PYTC_MERGE_HEADS", "1") != "0"
 
 
 @dataclass(frozen=True)
@@ -150,7 +156,81 @@ class MedNeXtMultiHeadWrapper(ConnectomicsModel):
 
     def forward_heads_cl(self, feat_cl: torch.Tensor) -> Dict[str, torch.Tensor]:
         hip = self.model._hip
+        y = self._merged_heads_cl(feat_cl)
+        if y is not None:
+            outs, c0 = {}, 0
+            for name, head in self.heads.items():
+                c1 = c0 + head.projection.out_channels
+                outs[name] = y[..., c0:c1]
+                c0 = c1
+            return outs
         return {name: head.forward_cl(hip, feat_cl) for name, head in self.heads.items()}
+
+    def _merged_heads_cl(self, feat_cl: torch.Tensor) -> Optional[torch.Tensor]:
+        """All heads' outputs concatenated along C in declaration order through the merged head, or None (see _merged_heads)."""
+        merged = self._merged_heads(feat_cl) if (MERGE_NARROW_HEADS and not torch.is_grad_enabled()) else None
+        if merged is None:
+            return None
+        hip = self.model._hip
+        x = hip.pointwise(feat_cl, merged.input_projection)
+        for blk in merged.blocks:
+            x = hip.block(blk, x)
+        return hip.pointwise(x, merged.projection, out_dtype=torch.float32)
+
+    def _merged_heads(self, feat_cl: torch.Tensor):
+        """Narrow task heads (MitoEM: three heads of 8 hidden channels, one block each -- tutorials/mitoEM/common.yaml:10-39) as ONE
+        32-channel head with block-diagonal weights: head i owns channels [i*w, (i+1)*w) of the merged in-projection / depthwise conv /
+        GroupNorm(C, C) (per-channel statistics: grouping heads changes nothing) and the matching diagonal blocks of conv2 / conv3 / the
+        out-projection; padded channels and hidden units carry zero weights and biases (GELU(0) = 0).  Same function, but on the kernels of
+        a level-0 trunk block (matrix-core depthwise conv, MFMA mixer 32 -> 32 exp_r -> 32) instead of three passes of 8-channel
+        kernels over the full-resolution tensor: MedNeXt-L 2 x 160^3: 4.4 -> 1.1 ms of a 19 ms forward (profiles/r05_mednext_l_*).
+        bf16 inference only; returns None when the heads are not of that shape (then each head runs on its own)."""
+        heads = list(self.heads.values())
+        if feat_cl.dtype != torch.bfloat16 or feat_cl.dim() != 5 or len(heads) < 2:
+            return None
+        kw = self.head_block_kwargs
+        w, nb = heads[0].hidden_channels, (len(heads[0].blocks) if not isinstance(heads[0].blocks, nn.Identity) else 0)
+        feat, Wp = self.feature_channels, 32
+        if (feat != 32 or kw["dim"] != "3d" or kw["grn"] or kw["norm_type"] != "group" or kw["kernel_size"] != 3 or nb < 1
+                or len(heads) * w > Wp or (kw["exp_r"] * Wp) not in (64, 96, 128)
+                or any(isinstance(h.input_projection, nn.Identity) or h.hidden_channels != w
+                       or (0 if isinstance(h.blocks, nn.Identity) else len(h.blocks)) != nb for h in heads)):
+            return None
+        params = [p_ for h in heads for p_ in h.parameters()]
+        key = tuple((p_.data_ptr(), p_._version) for p_ in params) + (str(feat_cl.device),)
+        cached = self.__dict__.get("_merged_cache")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        e, dev = kw["exp_r"] * w, feat_cl.device
+        with torch.no_grad():
+            m = nn.Module()
+            m.input_projection = nn.Conv3d(feat, Wp, kernel_size=1).to(dev)
+            m.projection = nn.Conv3d(Wp, sum(h.projection.out_channels for h in heads), kernel_size=1).to(dev)
+            m.blocks = nn.ModuleList(MedNeXtBlock(Wp, Wp, **kw).to(dev) for _ in range(nb))
+            for t in m.parameters():
+                t.zero_()
+            c0 = 0
+            for i, h in enumerate(heads):
+                ch, hid = slice(i * w, (i + 1) * w), slice(i * e, (i + 1) * e)
+                m.input_projection.weight[ch] = h.input_projection.weight
+                m.input_projection.bias[ch] = h.input_projection.bias
+                for mb, hb in zip(m.blocks, h.blocks):
+                    mb.conv1.weight[ch] = hb.conv1.weight
+                    mb.conv1.bias[ch] = hb.conv1.bias
+                    mb.norm.weight[ch], mb.norm.bias[ch] = hb.norm.weight, hb.norm.bias
+                    mb.conv2.weight[hid, ch] = hb.conv2.weight
+                    mb.conv2.bias[hid] = hb.conv2.bias
+                    mb.conv3.weight[ch, hid] = hb.conv3.weight
+                    mb.conv3.bias[ch] = hb.conv3.bias
+                c1 = c0 + h.projection.out_channels
+                m.projection.weight[c0:c1, ch] = h.projection.weight
+                m.projection.bias[c0:c1] = h.projection.bias
+                c0 = c1
+            m.eval()
+            for t in m.parameters():
+                t.requires_grad_(False)
+        self.__dict__["_merged_cache"] = (key, m)          # not a sub-module: no entry in state_dict(), rebuilt when a head parameter changes
+        return m
 
     def forward_heads(self, features: torch.Tensor) -> Dict[str, torch.Tensor]:
         from .mednext import resolve_compute_dtype
@@ -174,7 +254,11 @@ class MedNeXtMultiHeadWrapper(ConnectomicsModel):
 
     def forward_cl(self, x_cl: torch.Tensor) -> torch.Tensor:
         """Channels-last fast path: all heads concatenated along C in declaration order."""
-        outs = self.forward_heads_cl(self.model.features_cl(x_cl))
+        feat_cl = self.model.features_cl(x_cl)
+        y = self._merged_heads_cl(feat_cl)
+        if y is not None:
+            return y
+        outs = self.forward_heads_cl(feat_cl)
         return torch.cat(list(outs.values()), dim=-1) if len(outs) > 1 else next(iter(outs.values()))
 
 

@@ -330,3 +330,43 @@ def test_a_window_gives_the_same_bits_alone_and_inside_a_batch_at_112():
         three = model.forward_cl(x[2:5].contiguous()).clone()
     assert torch.equal(one[0], full[5])
     assert torch.equal(three, full[2:5])
+
+
+def test_narrow_task_heads_merged_into_one_block_diagonal_head_match_the_per_head_passes(monkeypatch):
+    """MedNeXtMultiHeadWrapper._merged_heads: three 8-channel MitoEM heads (tutorials/mitoEM/common.yaml:10-39) as one 32-channel head
+    with block-diagonal weights.  Same function as the per-head passes -- per-channel GroupNorm, zero off-diagonal blocks -- on other
+    kernels (matrix-core depthwise conv, MFMA mixer): equal to the rounding of the bf16 path, far inside the C4 oracle gate."""
+    from types import SimpleNamespace as NS
+    from pytorch_connectomics_amd.models import build_model
+    from pytorch_connectomics_amd.models.architectures import mednext_models as MM
+    heads = {"aff_r1": {"out_channels": 3, "num_blocks": 1, "hidden_channels": 8},
+             "aff_r5": {"out_channels": 3, "num_blocks": 1, "hidden_channels": 8},
+             "sdt": {"out_channels": 1, "num_blocks": 1, "hidden_channels": 8}}
+    cfg = NS(model=NS(arch=NS(type="mednext"), in_channels=1, out_channels=7, mednext=NS(size="L", kernel_size=3),
+                      loss=NS(deep_supervision=False), heads=heads, primary_head="aff_r1"))
+    torch.manual_seed(0)
+    model = build_model(cfg).cuda().eval()
+    with torch.no_grad():                                  # heads are zero-initialised biases by default: give every parameter a value
+        for p in model.heads.parameters():
+            p.copy_(torch.randn_like(p) * 0.3)
+    model.model.compute_dtype = torch.bfloat16
+    x = torch.rand(2, 32, 32, 48, 1, device="cuda")
+    with torch.no_grad():
+        feat = model.model.features_cl(x)
+        monkeypatch.setattr(MM, "MERGE_NARROW_HEADS", False)
+        want = model.forward_heads_cl(feat)
+        monkeypatch.setattr(MM, "MERGE_NARROW_HEADS", True)
+        assert model._merged_heads(feat) is not None
+        got = model.forward_heads_cl(feat)
+        cat = model._merged_heads_cl(feat)
+    assert list(got) == list(want) == ["aff_r1", "aff_r5", "sdt"] and cat.shape[-1] == 7
+    for k in want:
+        scale = float(want[k].abs().max())
+        err = (got[k] - want[k]).abs()
+        assert got[k].shape == want[k].shape and float(err.max()) < 0.03 * scale and float(err.mean()) < 3e-3 * scale, (k, float(err.max()), scale)
+    # a head parameter changes -> the merged weights are rebuilt
+    with torch.no_grad():
+        model.heads["sdt"].projection.bias.add_(1.0)
+        again = model.forward_heads_cl(feat)
+    assert float((again["sdt"] - got["sdt"] - 1.0).abs().max()) < 1e-5 and torch.equal(again["aff_r1"], got["aff_r1"])
+    assert "_merged_cache" not in dict(model.named_modules()) and not any("merged" in k for k in model.state_dict())

@@ -134,6 +134,49 @@ def test_ddp_gloo_two_ranks():
     mp.spawn(_ddp_worker, args=(2, 29500 + (os.getpid() + 7) % 2000), nprocs=2, join=True)
 
 
+def _ddp_worker8(rank, world, port):
+    """The 8-rank job of BASELINE configs[2] in miniature (gloo here, RCCL on the node): every rank its own data stream, UNEVEN local
+    batches (1 or 2 samples, what a DistributedSampler without drop_last leaves the last ranks with), one gradient all-reduce per step."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    bs = lambda r: 1 + (r % 2)                            # noqa: E731
+    cfg = _cfg()
+    cfg.optimization.optimizer.name, cfg.optimization.optimizer.lr, cfg.optimization.optimizer.weight_decay = "SGD", 0.1, 0.0
+    torch.manual_seed(0)
+    m = ConnectomicsModule(cfg, model=SimpleModel())
+    w0 = [p.detach().clone() for p in m.model.parameters()]
+    fit(m, synthetic_batches(bs(rank), (8, 8, 8), seed=42 + rank), max_steps=1, device=torch.device("cpu"), ddp=True, log=None)
+    flat = torch.cat([p.detach().flatten() for p in m.model.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    torch.distributed.all_gather(gathered, flat)
+    assert all(torch.equal(gathered[0], g) for g in gathered[1:])          # replicas identical on all 8 ranks
+    if rank == 0:
+        # the step every rank took is SGD on the MEAN over ranks of the local (per-rank mean) gradients -- DDP's contract, whatever
+        # the local batch sizes: recomputed here from the eight data streams on one process
+        grads = None
+        for r in range(world):
+            torch.manual_seed(0)
+            solo = ConnectomicsModule(cfg, model=SimpleModel())
+            batch = next(iter(synthetic_batches(bs(r), (8, 8, 8), seed=42 + r)))
+            loss, _ = solo._compute_loss(solo(batch["image"]), batch["label"])
+            loss.backward()
+            g = [p.grad.clone() for p in solo.model.parameters()]
+            grads = g if grads is None else [a + b for a, b in zip(grads, g)]
+        want = torch.cat([(w - 0.1 * g / world).flatten() for w, g in zip(w0, grads)])
+        assert torch.allclose(flat, want, rtol=1e-5, atol=1e-7), float((flat - want).abs().max())
+    # three more steps keep the replicas in lock step
+    fit(m, synthetic_batches(bs(rank), (8, 8, 8), seed=142 + rank), max_steps=4, device=torch.device("cpu"), ddp=True, log=None)
+    flat = torch.cat([p.detach().flatten() for p in m.model.parameters()])
+    torch.distributed.all_gather(gathered, flat)
+    assert all(torch.equal(gathered[0], g) for g in gathered[1:])
+    torch.distributed.destroy_process_group()
+
+
+def test_ddp_gloo_eight_ranks_with_uneven_local_batches():
+    mp.spawn(_ddp_worker8, args=(8, 31500 + (os.getpid() + 11) % 2000), nprocs=8, join=True)
+
+
 def test_weighted_bce_matches_reference_fixture():
     """tests/golden/losses.npz: the reference's WeightedBCEWithLogitsLoss (losses.py:17-44,190-266) values and gradients."""
     import numpy as np
