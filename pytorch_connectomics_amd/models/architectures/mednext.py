@@ -180,13 +180,13 @@ class HipBlockOps:
         # bf16 blocks of batches with at most this many voxel rows (levels 3-4 of an 8-window batch: 21 952 / 2 744 rows) run their
         # two 1x1x1 convs as two LDS-tiled GEMM launches (ops.pw_gemm) instead of the fused mixer: bit-identical, and the deep levels
         # stop leaving most SIMDs idle.  0 switches the path off.
-        self.deep_gemm_rows = int(os.environ.get("PYTC_DEEP_GEMM_ROWS", "32768"))
-        # The choice must not depend on the batch a window travels in: the GEMM pair applies the GroupNorm affine to the ACTIVATION, the
-        # fused mixer folds it into the expand WEIGHTS -- two rounding points, so the same window would otherwise give different bf16 bits
-        # alone (the engine's probe window, a ragged last batch) and inside a full batch, breaking "chunked == whole volume" /
-        # "rank-sharded == single process".  The rule is therefore applied to the rows of ONE sample times this nominal batch (the
-        # sliding-window batch the thresholds were measured at), whatever N is.
-        self.schedule_batch = int(os.environ.get("PYTC_SCHEDULE_BATCH", "8"))
+        self.deep_gemm_rows = int(os.environ.get("PYTC_DEEP_GEMM_ROWS", "8192"))
+        # The threshold is on the rows of ONE sample (round 5; it was N * rows <= 32768): the GEMM pair applies the GroupNorm affine to the
+        # ACTIVATION, the fused mixer folds it into the expand WEIGHTS -- two rounding points -- so a rule that looked at the batch gave the
+        # same window different bf16 bits alone (the engine's probe window, a ragged last batch) and inside a full batch,
+        # breaking "chunked == whole volume" / "rank-sharded == single process".  8192 rows per sample reproduces the schedules the old rule
+        # chose at the batch sizes it was measured at: MedNeXt-S 112^3 x 8 (level 3: 2 744 rows, level 4: 343) and MedNeXt-L 160^3 x 2
+        # (level 3: 8 000, level 4: 1 000) take the GEMM pair, the 21 952 / 64 000 rows of their level 2 the fused mixer.
         # ... and so do blocks at least this wide whatever their row count (the 256 -> 512 -> 128 up block at 28^3); 0 = rows rule only
         self.deep_gemm_cin = int(os.environ.get("PYTC_DEEP_GEMM_CIN", "0"))
         # bf16 blocks of the mid-level shapes (ops.pw_mlp_lds_supported: 64->128->64, 128->256->64, 128->256->128, 64->128->32) with at
@@ -365,7 +365,7 @@ class HipBlockOps:
                  and ops.pw_conv_paired_supported(c_in=c_hid, c_out=c_out, in_dtype=dt, out_dtype=dt))
         if (not small and self.fused and dt == torch.bfloat16 and not m.grn and not is_ln and m.conv2.bias is not None
                 and m.conv3.bias is not None and head is None and ops.MLP_F16_PROJECT
-                and (self.schedule_batch * rows <= self.deep_gemm_rows or (self.deep_gemm_cin and C >= self.deep_gemm_cin))
+                and (rows <= self.deep_gemm_rows or (self.deep_gemm_cin and C >= self.deep_gemm_cin))
                 and ops.pw_gemm_supported(C, c_hid) and ops.pw_gemm_supported(c_hid, c_out)):
             ab = ops.groupnorm_finalize(st, count, gamma, beta, m.norm.eps)
             return self._block_deep_gemm(m, x, t, ab, skip, (N, D, H, W, C), (Do, Ho, Wo), c_hid, c_out, out)
