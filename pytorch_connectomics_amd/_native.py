@@ -145,6 +145,9 @@ _SIGS = {
                                 C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pytc_pw_wgrad_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
+    "pytc_pw_wgrad_dgrad_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "pytc_pw_wgrad_dgrad_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64,
+                                              C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     "pytc_dw_wgrad_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     "pytc_reduce_slots_multi": (C.c_int, [C.POINTER(ReduceItem), C.c_int, C.c_void_p]),

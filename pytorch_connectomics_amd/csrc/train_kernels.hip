@@ -115,11 +115,21 @@ pw_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ ab, const T* 
 // all a reduction needs; with a row pitch of 2*C+32 bytes each half-wave's 8 rows fall in 8 distinct bank octets.
 // db comes from one extra MFMA per tile row against a fragment of ones.  The four waves' accumulators are added in a
 // fixed order (wave 0 + 1 + 2 + 3) -> per-slot partials -> reduce_slots: deterministic.
-template <int MT, int NT>
+// DG (round 5): the same pass ALSO forms the data gradient of the projecting conv behind the activation,
+//     dxo[r][k] = bf16( (sum_o W[o][k] dy[r][o]) * gelu'(x[r][k]) ),      x = the hidden pre-activation, W = the conv's [C_out][C_in] weight,
+// from the rows it has staged anyway: the gradient rows are the B operand of one more MFMA per 16 x 16 tile (A = the paired image of
+// W^T, read once per wave), the pre-activation comes back from a second copy of the staged rows (the first is turned into gelu(x) for the
+// weight gradient), and the product leaves as 16-byte stores.  One pass over (x, dy) instead of two -- pytc_pw_wgrad reads them, then
+// pytc_pw_conv_fwd(RES_GELU_BWD) reads them again: 3 x 64 B per voxel saved per level-0 block -- with the same bits as that GEMM on the
+// paired weight image (same MFMA on the same operands, same GELU', same rounding; the training step's default two-launch GEMM takes the
+// plain image: another summation order inside the instruction, differences at the bf16 rounding of dx).  Needs the whole channel extent in one workgroup: C_out = 16 MT,
+// C_in = 16 NT, gridDim.y = 1.
+template <int MT, int NT, bool DG = false>
 __global__ void __launch_bounds__(256, (MT * NT >= 8 ? 2 : (MT * NT >= 4 ? 3 : 4)))
 pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab, const bf16_t* __restrict__ dy,
                      float* __restrict__ dWp, float* __restrict__ dbp, long rows_total, long rows_per_sample, int C_in,
-                     int C_out, long rows_per_slot, int x_act, int sps, int ab_mode) {
+                     int C_out, long rows_per_slot, int x_act, int sps, int ab_mode, const bf16x8_t* __restrict__ w_dg = nullptr,
+                     bf16_t* __restrict__ dxo = nullptr) {
   // sps > 0: `sps` slots PER SAMPLE (slot = n * sps + j covers rows of sample n only): the partials then are per-sample sums,
   // which pytc_pw_wgrad_groupnorm turns into the GroupNorm backward statistics.  ab_mode 1: `ab` holds (mean, rstd) and the
   // operand is the normalised xhat = (x - mean) * rstd instead of a * x + b.
@@ -215,6 +225,7 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
       } else if (split) {
         *reinterpret_cast<q4_t*>(lx2 + (it * RX + x_row) * SX + x_chunk * 16) = zero4;
       }
+      if constexpr (DG) *reinterpret_cast<q4_t*>(lx2 + (it * RX + x_row) * SX + x_chunk * 16) = v;     // the raw pre-activation rows (split is off)
       if (x_act == PYTC_ACT_GELU) {     // the forward GEMM consumed bf16(gelu(x)) (fused pre-activation)
         f32x8_t f = __builtin_convertvector(__builtin_bit_cast(bf16x8_t, v), f32x8_t);
 #pragma unroll
@@ -246,9 +257,34 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
 
-  auto multiply = [&]() {
+  // DG: A fragments of W^T (paired image [C_in][C_out]: NT M-tiles x one 32-wide k-step per MT = 2), constant for the wave
+  bf16x8_t wdg[DG ? NT : 1];
+  if constexpr (DG) {
+    static_assert(!DG || MT == 2, "the fused data gradient is written for C_out = 32 (one k-step)");
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wdg[t] = w_dg[t * 64 + lane];
+  }
+  auto multiply = [&](long r0) {
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
+    if constexpr (DG) {
+      const int rr = lane & 15, kb = lane >> 4;
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {                  // the two 16-row tiles of the 32-row block
+        const bf16x8_t bdy = *reinterpret_cast<const bf16x8_t*>(lg + (t2 * 16 + rr) * SG + kb * 16);
+        const long row = r0 + t2 * 16 + rr;
+#pragma unroll
+        for (int pr = 0; pr < NT / 2; ++pr) {
+          const f32x4_t lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdg[2 * pr], bdy, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          const f32x4_t hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdg[2 * pr + 1], bdy, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          float hv[8], v[8];
+          VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(lx2 + (t2 * 16 + rr) * SX + (pr * 32 + kb * 8) * 2), hv);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { v[i] = lo[i] * gelu_erf_grad(hv[i]); v[4 + i] = hi[i] * gelu_erf_grad(hv[4 + i]); }
+          if (row < r_end) VecIO<bf16_t, 8>::store(dxo + row * C_in + pr * 32 + kb * 8, v);
+        }
+      }
+    }
     bf16x8_t fa[MT], fb[NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) fa[m] = frag(lg, SG, m);
@@ -277,11 +313,11 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
   for (; r0 < r_end; r0 += 256) {                    // same block order per wave as before: the sums are bit-identical
     stage(r0, rgA, rxA);
     if (r0 + 256 < r_end) fetch(r0 + 256, rgA, rxA);
-    multiply();
+    multiply(r0);
     if (r0 + 128 < r_end) {
       stage(r0 + 128, rgB, rxB);
       if (r0 + 384 < r_end) fetch(r0 + 384, rgB, rxB);
-      multiply();
+      multiply(r0 + 128);
     }
   }
 
@@ -1091,6 +1127,36 @@ extern "C" int pytc_pw_wgrad_partial(const void* x, const float* ab, const void*
   float* db_flag = want_db ? workspace : nullptr;      // non-null = "write bias partials" (never dereferenced as output)
   return pw_wgrad_impl(x, ab, dy, nullptr, db_flag, workspace, N, rows_per_sample, C_in, C_out, dtype, x_act, stream, false,
                        slots_out);
+}
+
+extern "C" int pytc_pw_wgrad_dgrad_supported(int C_in, int C_out, int dtype) {
+  return (dtype == PYTC_BF16 && C_out == 32 && (C_in == 64 || C_in == 32) && tuning_get("wgrad_dgrad_fused", 1) != 0) ? 1 : 0;
+}
+
+extern "C" int pytc_pw_wgrad_dgrad_partial(const void* x, const void* dy, const void* w_t_paired, void* dx, float* workspace,
+                                           int want_db, int N, int64_t rows_per_sample, int C_in, int C_out, int dtype,
+                                           int* slots_out, void* stream) {
+  PYTC_REQUIRE(x && dy && w_t_paired && dx && workspace && slots_out && N >= 1 && rows_per_sample >= 1, "pw_wgrad_dgrad: bad arguments");
+  PYTC_REQUIRE(pytc_pw_wgrad_dgrad_supported(C_in, C_out, dtype), "pw_wgrad_dgrad: bf16, C_out = 32, C_in in {32, 64} (C_in=%d C_out=%d)", C_in, C_out);
+  const long rows_total = (long)N * rows_per_sample;
+  int slots = wgrad_mfma_slots(rows_total, C_in, C_out, pytc_pw_wgrad_slots(rows_total));
+  // one workgroup per row slot holds ALL channels here (the plain launch splits 32 x 64 into channel tiles only above 64 x 64: same grid)
+  const long rps = (rows_total + slots - 1) / slots;
+  float* dWp = workspace;
+  float* dbp = workspace + (long)slots * C_out * C_in;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(slots, 1);
+  const bf16_t* xp = (const bf16_t*)x;
+  const bf16_t* dp = (const bf16_t*)dy;
+  if (C_in == 64)
+    hipLaunchKernelGGL((pw_wgrad_mfma_kernel<2, 4, true>), grid, dim3(256), 0, s, xp, (const float*)nullptr, dp, dWp, want_db ? dbp : nullptr, rows_total,
+                       (long)rows_per_sample, C_in, C_out, rps, PYTC_ACT_GELU, 0, 0, (const bf16x8_t*)w_t_paired, (bf16_t*)dx);
+  else
+    hipLaunchKernelGGL((pw_wgrad_mfma_kernel<2, 2, true>), grid, dim3(256), 0, s, xp, (const float*)nullptr, dp, dWp, want_db ? dbp : nullptr, rows_total,
+                       (long)rows_per_sample, C_in, C_out, rps, PYTC_ACT_GELU, 0, 0, (const bf16x8_t*)w_t_paired, (bf16_t*)dx);
+  *slots_out = slots;
+  PYTC_LAUNCH_CHECK("pw_wgrad_dgrad");
+  return PYTC_OK;
 }
 
 extern "C" int pytc_reduce_slots_multi(const pytc_reduce_item* items, int n_items, void* stream) {

@@ -1434,6 +1434,43 @@ def pw_wgrad(x: torch.Tensor, dy: torch.Tensor, *, N: int, rows_per_sample: int,
     return dW, db
 
 
+def pw_wgrad_dgrad_supported(c_in: int, c_out: int, dtype: torch.dtype) -> bool:
+    try:
+        return bool(nat.lib().pytc_pw_wgrad_dgrad_supported(int(c_in), int(c_out), dtype_code(dtype)))
+    except Exception:
+        return False
+
+
+def pw_wgrad_dgrad(hp: torch.Tensor, dy: torch.Tensor, w_t_paired: torch.Tensor, *, N: int, rows_per_sample: int, c_in: int, c_out: int,
+                   want_bias: bool = True, defer: Optional[DeferredReduce] = None):
+    """One pass over the hidden pre-activation hp (N, rows, c_in) and the output gradient dy (N, rows, c_out) of a mixer's projecting
+    conv: -> (dW (c_out, c_in), db (c_out) | None, dhp (N, rows, c_in) bf16) with dW = sum_r dy^T gelu(hp) and
+    dhp = (W^T dy) * gelu'(hp); w_t_paired = packed_paired(W, transposed=True).  Bit-identical to pw_wgrad(x_act=GELU) + the
+    RES_GELU_BWD data-gradient GEMM on that paired image (pytc_pw_wgrad_dgrad_partial); `defer` as in pw_wgrad."""
+    _dev(hp, "hp"); _dev(dy, "dy"); _dev(w_t_paired, "w_t_paired")
+    if hp.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16 or w_t_paired.dtype != torch.bfloat16:
+        raise TypeError("pw_wgrad_dgrad runs on bfloat16 operands and the bf16 paired image of W^T")
+    slots = nat.lib().pytc_pw_wgrad_slots(N * rows_per_sample)
+    nW = c_out * c_in
+    ws = torch.empty((slots * (nW + c_out),), dtype=torch.float32, device=hp.device)
+    dW = torch.empty((c_out, c_in), dtype=torch.float32, device=hp.device)
+    db = torch.empty((c_out,), dtype=torch.float32, device=hp.device) if want_bias else None
+    dhp = torch.empty((N, rows_per_sample, c_in), dtype=torch.bfloat16, device=hp.device)
+    own = defer is None
+    if own:
+        defer = DeferredReduce()
+    used = C.c_int(0)
+    _run(f"pw_wgrad_dgrad[{c_in}->{c_out}]", _nbytes(hp, dy, dhp), nat.lib().pytc_pw_wgrad_dgrad_partial, _p(hp), _p(dy), _p(w_t_paired),
+         _p(dhp), _p(ws), int(want_bias), N, rows_per_sample, c_in, c_out, dtype_code(hp.dtype), C.byref(used), _stream())
+    u = int(used.value)
+    defer.add(ws[:u * nW], dW, nW, u, keep=ws)
+    if want_bias:
+        defer.add(ws[u * nW:u * (nW + c_out)], db, c_out, u)
+    if own:
+        defer.flush()
+    return dW, db, dhp
+
+
 def dw_wgrad(g: torch.Tensor, x: torch.Tensor, *, K: int, stride: int = 1, want_bias: bool = True,
              defer: Optional[DeferredReduce] = None):
     """g (N,*gdims,C), x (N,*xdims,C) -> dW (K^3, C) fp32, db (C) | None   (see pytc_dw_wgrad); `defer` as in pw_wgrad"""

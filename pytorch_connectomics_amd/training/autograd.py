@@ -34,6 +34,9 @@ FUSED_TRAIN_MIXER_MIN_ROWS = int(os.environ.get("PYTC_FUSED_MIXER_MIN_ROWS", "16
 # but measured slower than the two launches it replaces (503 vs ~440 us at 4x112^3, level 0: the exact GELU' between the
 # GEMMs sits on the MFMA critical path instead of in a store epilogue) -> off
 FUSED_TRAIN_MIXER_BWD = False
+# the projecting conv's weight gradient fused with the data gradient behind the activation: one pass over (hp, dy) instead of two at the
+# level-0 shapes (csrc/train_kernels.hip pw_wgrad_mfma_kernel<.., DG>; same arithmetic, 27.4 -> 26.4 ms per 4 x 112^3 step)
+FUSED_WGRAD_DGRAD = os.environ.get("PYTC_FUSED_WGRAD_DGRAD", "1") != "0"
 # data gradient of a residual block, dx = conv_reversed(dt) + dy, with the "+ dy" inside the depthwise kernel (bf16, z-march
 # shapes) instead of a separate read-modify-write pass over dx
 FUSED_RESIDUAL_DGRAD = True
@@ -343,9 +346,18 @@ class BlockFn(torch.autograd.Function):
         dr = ops.DeferredReduce()
         lane = _WgradLane(x.device)
         # ---- project: y = W3 h + b3
-        dW3, db3 = lane.run(lambda: ops.pw_wgrad(hp, dcore, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, x_act=nat.ACT_GELU,
-                                                 defer=dr), hp, dcore)
         fused_bwd = (dy.dtype == torch.bfloat16 and FUSED_TRAIN_MIXER_BWD and ops.pw_mlp_supported(c_out, c_hid, C))
+        # round 5: the projecting conv's weight gradient and the data gradient behind the activation in ONE pass over (hp, dy)
+        # (pytc_pw_wgrad_dgrad_partial: level-0 shapes)
+        wg_dg = (FUSED_WGRAD_DGRAD and not fused_bwd and hp.dim() == 3 and ops.pw_wgrad_dgrad_supported(c_hid, c_out, dy.dtype)
+                 and hp.dtype == torch.bfloat16)
+        dhp = None
+        if wg_dg:
+            dW3, db3, dhp = ops.pw_wgrad_dgrad(hp, dcore.view(N, rows, c_out), ops.packed_paired(_mat(w3), transposed=True, packs=packs),
+                                               N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, defer=dr)
+        else:
+            dW3, db3 = lane.run(lambda: ops.pw_wgrad(hp, dcore, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, x_act=nat.ACT_GELU,
+                                                     defer=dr), hp, dcore)
         # expand conv hp = W2 (a t + b) + b2.  NORM_STATS_FROM_WGRAD: its weight-gradient pass (against xhat, per-sample slots) also
         # yields the GroupNorm backward sums, and the data-gradient GEMM applies the norm backward to its own unrounded result in its
         # epilogue (RES_NORM_BWD): no statistics pass, no apply pass, dtn never stored.  Up blocks (cropped output) take the two-pass form.
@@ -357,7 +369,7 @@ class BlockFn(torch.autograd.Function):
             dtn, dhp = ops.pw_mlp_bwd(dcore.view(N, rows, c_out), hp, ops.packed_paired(_mat(w3), transposed=True, packs=packs),
                                       ops.packed_paired(_mat(w2), transposed=True, packs=packs), N=N, rows_per_sample=rows,
                                       c_in=C, c_hid=c_hid, c_out=c_out)
-        else:
+        elif dhp is None:
             # dhp = (W3^T dy) * gelu'(hp): the GELU derivative is the epilogue of the data-gradient GEMM
             dhp = _pw(dcore, _mat(w3), None, c_out=c_hid, transposed=True, rows=rows, res=hp, res_mode=nat.RES_GELU_BWD, packs=packs)
         if stats_from_wgrad:

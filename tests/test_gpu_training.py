@@ -382,8 +382,11 @@ def test_fused_training_mixer_matches_two_gemm_forward():
     assert float((g1 * g0).sum() / (g1.norm() * g0.norm())) > 0.995
     # the one-launch backward mixer (off by default: measured slower) computes the same bits as the two launches -- both with the
     # two-pass norm backward (the epilogue form of NORM_STATS_FROM_WGRAD belongs to the two-launch schedule only)
-    stats_flag = AG.NORM_STATS_FROM_WGRAD
+    # (round 5: with the weight-gradient + data-gradient pass of the level-0 blocks off as well -- that pass multiplies against the
+    # PAIRED image of W3^T, the two-launch GEMM here against the plain one: same products, another summation order inside the MFMA)
+    stats_flag, wgdg_flag = AG.NORM_STATS_FROM_WGRAD, AG.FUSED_WGRAD_DGRAD
     AG.NORM_STATS_FROM_WGRAD = False
+    AG.FUSED_WGRAD_DGRAD = False
     try:
         grads = []
         for fused_bwd in (False, True):
@@ -394,7 +397,21 @@ def test_fused_training_mixer_matches_two_gemm_forward():
     finally:
         AG.FUSED_TRAIN_MIXER_BWD = False
         AG.NORM_STATS_FROM_WGRAD = stats_flag
+        AG.FUSED_WGRAD_DGRAD = wgdg_flag
     assert torch.equal(grads[0], grads[1])
+    # the fused weight-gradient + data-gradient pass (default on) against the two launches: the same gradients to bf16 rounding
+    both = []
+    for flag in (False, True):
+        AG.FUSED_WGRAD_DGRAD = flag
+        try:
+            m.zero_grad()
+            F.binary_cross_entropy_with_logits(m(x), y).backward()
+        finally:
+            AG.FUSED_WGRAD_DGRAD = wgdg_flag
+        both.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    for k in both[0]:
+        a, b = both[0][k].flatten().double(), both[1][k].flatten().double()
+        assert float((a - b).norm()) <= 2e-3 * float(a.norm()) + 1e-12, k
 
 
 def test_inference_after_fused_optimizer_steps_sees_new_weights():
@@ -877,3 +894,31 @@ def test_gradnorm_balancing_trains_through_the_hip_autograd_functions():
     assert m.loss_weighter.initial_losses is not None and m.loss_weighter.initial_losses.numel() == 3
     ck = m.checkpoint_dict(opt)
     assert "loss_weighter.task_weights" in ck["state_dict"]
+
+
+@pytest.mark.parametrize("N,rows,c_hid", [(2, 4096 + 37, 64), (1, 777, 64), (3, 2048, 32), (4, 50176, 64)])
+def test_fused_weight_gradient_and_data_gradient_of_the_projecting_conv(N, rows, c_hid):
+    """pytc_pw_wgrad_dgrad_partial: one pass over (hp, dy) gives dW3 / db3 AND dhp = (W3^T dy) * gelu'(hp) -- the same bits as
+    pw_wgrad(x_act = GELU) followed by the RES_GELU_BWD data-gradient GEMM on the PAIRED image of W3^T (ragged row counts, slots that
+    end inside a 32-row block)."""
+    from pytorch_connectomics_amd import _native as nat
+    from pytorch_connectomics_amd import hip_ops as ops
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(rows)
+    c_out = 32
+    assert ops.pw_wgrad_dgrad_supported(c_hid, c_out, torch.bfloat16)
+    hp = (torch.randn(N, rows, c_hid, device=dev, generator=g) * 1.5).bfloat16()
+    dy = (torch.randn(N, rows, c_out, device=dev, generator=g) * 1e-3).bfloat16()
+    w3 = (torch.randn(c_out, c_hid, device=dev, generator=g) / c_hid ** 0.5).contiguous()
+    wt = ops.pw_pack_weight_paired(w3, transposed=True)
+    dW0, db0 = ops.pw_wgrad(hp, dy, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, x_act=nat.ACT_GELU)
+    dhp0 = ops.pw_conv(dy, wt, None, N=N, rows_per_sample=rows, c_in=c_out, c_out=c_hid, out_dtype=torch.bfloat16, res=hp,
+                       res_mode=nat.RES_GELU_BWD, w_paired=True)
+    dW1, db1, dhp1 = ops.pw_wgrad_dgrad(hp, dy, wt, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out)
+    torch.cuda.synchronize()
+    assert torch.equal(dW1, dW0) and torch.equal(db1, db0)
+    assert torch.equal(dhp1, dhp0.view(N, rows, c_hid))
+    # and against fp32 torch
+    h = hp.float()
+    ref = (dy.float() @ w3.bfloat16().float()) * (0.5 * (1 + torch.erf(h / 2 ** 0.5)) + h * torch.exp(-h * h / 2) / (2 * 3.141592653589793) ** 0.5)
+    assert float((dhp1.float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
