@@ -56,7 +56,7 @@ BATCHED_WEIGHT_PACKS = True
 
 
 # weight-gradient kernels of a block backward on a second HIP stream: they are off the critical path (only the optimizer reads
-# them), the data-gradient chain is what the next block waits for.  Bit-identical gradients (tools/exp_r03_train_lane.py), but
+# them), the data-gradient chain is what the next block waits for.  Bit-identical gradients (tools/history/exp_r03_train_lane.py), but
 # MEASURED: 34.3 -> 33.9 ms per step before the weight-gradient kernels were fixed and 31.1 -> 31.1 ms after (round 3; the same
 # lane around the dense-conv backward of RSUNet / the MONAI-style U-Net: 10.5 -> 10.8 / 11.4 -> 11.4 ms): the step is bound by the
 # sum of its HBM-bound level-0 / level-1 kernels, not by the latency-bound deep ones.  Off by default; kept as the switch.

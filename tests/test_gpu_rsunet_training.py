@@ -171,7 +171,7 @@ def test_rsunet_training_step_matches_oracle_autograd(name):
 def test_rsunet_bf16_training_direction():
     """bf16 storage: gradients keep the direction of the fp32 ones and SGD steps lower the loss.  On this random-target
     problem torch.autocast(bf16) through the oracle reaches cosines of 0.84-0.87 on the first layers and 0.998 on the last
-    (ReLU masks flip on bf16-rounded pre-activations); the HIP path measures the same (tools/rs_bf16_fidelity.py)."""
+    (ReLU masks flip on bf16-rounded pre-activations); the HIP path measures the same (tools/history/rs_bf16_fidelity.py)."""
     from pytorch_connectomics_amd.models.architectures.rsunet import RSUNet
     torch.manual_seed(5)
     m = RSUNet(1, 1, width=[8, 16, 24], norm="group", num_groups=8, activation="relu").cuda().train()

@@ -10,7 +10,7 @@ from types import SimpleNamespace as NS
 
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from pytorch_connectomics_amd import _native as nat  # noqa: E402
 from pytorch_connectomics_amd import hip_ops as ops  # noqa: E402
 from pytorch_connectomics_amd.models import build_model  # noqa: E402

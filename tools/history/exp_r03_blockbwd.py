@@ -3,7 +3,7 @@ the oracle block in fp32, under the training path's switches."""
 import sys
 from pathlib import Path
 import torch
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 from oracle import mednext_oracle as MO  # noqa: E402
 from pytorch_connectomics_amd.models.architectures.mednext import MedNeXtBlock  # noqa: E402

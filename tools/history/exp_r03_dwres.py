@@ -3,7 +3,7 @@ against the un-fused kernels / fp32 math."""
 import sys
 from pathlib import Path
 import torch
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 from pytorch_connectomics_amd import hip_ops as ops  # noqa: E402
 

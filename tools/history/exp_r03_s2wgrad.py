@@ -3,7 +3,7 @@ replaces (knob conv_wgrad_s2_mfma) and against an fp64 einsum on a small case; t
 import sys
 from pathlib import Path
 import torch
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 from pytorch_connectomics_amd import _native as nat  # noqa: E402
 from pytorch_connectomics_amd import hip_ops as ops  # noqa: E402

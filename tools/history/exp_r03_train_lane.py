@@ -4,7 +4,7 @@ import sys
 import time
 from pathlib import Path
 import torch
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 from pytorch_connectomics_amd.models.architectures.mednext import create_mednext_v1  # noqa: E402
 from pytorch_connectomics_amd.training import autograd as AG  # noqa: E402

@@ -1,4 +1,4 @@
-"""Summarise rocprofv3 (rocpd sqlite) outputs written by tools/prof_kernels.sh: per-kernel average
+"""Summarise rocprofv3 (rocpd sqlite) outputs written by tools/history/prof_kernels.sh: per-kernel average
 duration from the kernel trace and per-kernel mean counter values from the PMC passes."""
 import glob
 import re

@@ -4,7 +4,7 @@ set -u
 OUT=$PWD/gpurun_out/prof_rsunet
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp PYTHONPATH=$PWD
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o rsunet -- python tools/rsunet_train_probe.py --steps 5 --gc freeze > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o rsunet -- python tools/history/rsunet_train_probe.py --steps 5 --gc freeze > $OUT/trace.log 2>&1
 tail -2 $OUT/trace.log
 python - <<PY
 import csv, glob

@@ -4,7 +4,7 @@ set -u
 OUT=$PWD/gpurun_out/prof_rsunet_pmc
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp PYTHONPATH=$PWD
-CMD="python tools/rsunet_train_probe.py --steps 3 --gc freeze"
+CMD="python tools/history/rsunet_train_probe.py --steps 3 --gc freeze"
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVES --output-format csv -d $OUT/p1 -o r -- $CMD > $OUT/p1.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS --output-format csv -d $OUT/p2 -o r -- $CMD > $OUT/p2.log 2>&1
 python - <<PY

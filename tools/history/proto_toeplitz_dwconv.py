@@ -15,7 +15,7 @@ so that D[m][n] = out[z][y0 + n][x0 + m][c].  The input plane has to sit in LDS 
 lane (n, kg) then reads its 8 consecutive columns with one 16-byte LDS read; the NDHWC plane is transposed while it is staged, and the
 result (a lane holds 4 consecutive x of ONE channel) is transposed back through LDS before it is stored.
 
-    python tools/proto_toeplitz_dwconv.py        # self-check on a few shapes, prints the largest deviation from the direct convolution
+    python tools/history/proto_toeplitz_dwconv.py        # self-check on a few shapes, prints the largest deviation from the direct convolution
 """
 from __future__ import annotations
 

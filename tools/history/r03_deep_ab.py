@@ -1,8 +1,8 @@
 """Round 3: deep-level (7^3 / 14^3) GEMMs of the MedNeXt-S training step -- output-channel split of pw_fast (blockIdx.z) and the
-un-fused mixer below a row threshold, measured on bench.py's training leg.  python tools/r03_deep_ab.py"""
+un-fused mixer below a row threshold, measured on bench.py's training leg.  python tools/history/r03_deep_ab.py"""
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import torch
 import bench
 from pytorch_connectomics_amd import hip_ops as ops

@@ -3,7 +3,7 @@ import sys
 from pathlib import Path
 from types import SimpleNamespace as NS
 import torch
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 import bench  # noqa: E402
 from pytorch_connectomics_amd import hip_ops as ops  # noqa: E402

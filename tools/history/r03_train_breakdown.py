@@ -3,7 +3,7 @@ of every launch (single stream), grouped by kernel family and by resolution leve
 import re, sys
 from pathlib import Path
 import torch
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 from pytorch_connectomics_amd import hip_ops as ops  # noqa: E402
 from pytorch_connectomics_amd.models.architectures.mednext import create_mednext_v1  # noqa: E402

@@ -4,7 +4,7 @@ from pathlib import Path
 
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from pytorch_connectomics_amd import hip_ops as ops  # noqa: E402
 
 dev = torch.device("cuda:0")

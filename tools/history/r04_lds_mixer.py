@@ -1,14 +1,14 @@
 """Round 4: the LDS-resident persistent mixer (pytc_pw_mlp_lds_fwd) against the streaming one (pytc_pw_mlp_fwd) at the three mid-level
 shapes, every launch variant (knob mlp_lds_variant), folded and affine operands; bit-identity is asserted before anything is timed.
 
-    python tools/r04_lds_mixer.py
+    python tools/history/r04_lds_mixer.py
 """
 import sys
 from pathlib import Path
 
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from pytorch_connectomics_amd import _native as nat  # noqa: E402
 from pytorch_connectomics_amd import hip_ops as ops  # noqa: E402
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel statistics of tools/r04_kb.py targets (true kernel durations: the event loop of r04_kb.py is host-bound below ~15 us)
-#   tools/r04_prof_kb.sh <name> <targets...>   -> gpurun_out/prof_<name>/stats.txt
+#   tools/history/r04_prof_kb.sh <name> <targets...>   -> gpurun_out/prof_<name>/stats.txt
 NAME=$1; shift
 OUT=$PWD/gpurun_out/prof_$NAME
 rm -rf $OUT; mkdir -p $OUT

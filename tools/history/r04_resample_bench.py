@@ -1,14 +1,14 @@
 """Round 4: the resampling depthwise convs of the down / up blocks (stride-2 gather kernel, transposed cell kernel) against plain
 fills / copies of the same byte counts -- how far from the memory roof they are.
 
-    python tools/r04_resample_bench.py
+    python tools/history/r04_resample_bench.py
 """
 import sys
 from pathlib import Path
 
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from pytorch_connectomics_amd import hip_ops as ops  # noqa: E402
 
 dev = torch.device("cuda:0")

@@ -1,12 +1,12 @@
 """RSUNet as the reference ships it (config/profiles/arch_profiles.yaml:34-44: width [18, 36, 48, 64, 80], GroupNorm(4), ELU, down
 (1,2,2) x 4, depth_2d 1) against the hand-picked bench widths: training step + inference forward timings with the per-op table.
-    python tools/r04_rsunet_stock.py [stock] [padded] [bench]"""
+    python tools/history/r04_rsunet_stock.py [stock] [padded] [bench]"""
 import sys
 from pathlib import Path
 
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from pytorch_connectomics_amd import hip_ops as ops  # noqa: E402
 from pytorch_connectomics_amd.models.architectures.rsunet import RSUNet  # noqa: E402
 from pytorch_connectomics_amd.training.fused import FusedAdamW, bce_dice_loss  # noqa: E402

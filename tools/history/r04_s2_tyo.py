@@ -2,7 +2,7 @@
 import sys
 from pathlib import Path
 import torch
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from pytorch_connectomics_amd import hip_ops as ops
 dev = torch.device("cuda:0")
 x = torch.randn(8, 112, 112, 112, 32, device=dev).to(torch.bfloat16)

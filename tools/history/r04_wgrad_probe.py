@@ -5,7 +5,7 @@ from pathlib import Path
 
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from pytorch_connectomics_amd import _native as nat  # noqa: E402
 from pytorch_connectomics_amd import hip_ops as ops  # noqa: E402
 

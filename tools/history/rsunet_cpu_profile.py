@@ -1,7 +1,7 @@
 """Host-side cost of one RSUNet training step (cProfile)."""
 import cProfile, pstats, sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import torch
 import torch.nn.functional as F
 from pytorch_connectomics_amd.models.architectures.rsunet import RSUNet

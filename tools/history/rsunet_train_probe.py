@@ -1,5 +1,5 @@
 """RSUNet training step timing (forward + backward + AdamW) on synthetic patches; run under rocprofv3 for the breakdown.
-    python tools/rsunet_train_probe.py [--dtype bf16] [--patch 18,160,160] [--batch 2] [--steps 5]"""
+    python tools/history/rsunet_train_probe.py [--dtype bf16] [--patch 18,160,160] [--batch 2] [--steps 5]"""
 import argparse
 import sys
 import time
@@ -8,7 +8,7 @@ from pathlib import Path
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from pytorch_connectomics_amd.models.architectures.rsunet import RSUNet
 
 ap = argparse.ArgumentParser()

@@ -1,7 +1,7 @@
 """Host-side cost of one training step (cProfile): where the Python time goes when the GPU is not the limiter."""
 import cProfile, pstats, sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import torch
 import bench
 

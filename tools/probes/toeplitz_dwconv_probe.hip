@@ -1,5 +1,5 @@
 // Probe (standalone, not part of libpytc_hip.so): depthwise 3x3x3 convolution on the matrix cores in TOEPLITZ form -- the round-4
-// candidate of DESIGN.md section 7, first correct-by-construction version (index algebra: tools/proto_toeplitz_dwconv.py).
+// candidate of DESIGN.md section 7, first correct-by-construction version (index algebra: tools/history/proto_toeplitz_dwconv.py).
 //
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/probes/toeplitz_dwconv_probe.hip -o tools/probes/bin/toeplitz_dwconv_probe
 //   tools/probes/bin/toeplitz_dwconv_probe            # checks a small volume against a CPU convolution, then times 8 x 112^3 x 32

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 evidence for the bench command (run on the GPU box): kernel trace + stats, and -- in SEPARATE
-# passes -- the HBM byte counters.  Writes gpurun_out/prof_bench/ ; tools/prof_summary.py condenses it.
+# passes -- the HBM byte counters.  Writes gpurun_out/prof_bench/ ; tools/history/prof_summary.py condenses it.
 set -u
 OUT=$PWD/gpurun_out/prof_bench
 rm -rf $OUT; mkdir -p $OUT
