@@ -409,9 +409,14 @@ def test_fused_training_mixer_matches_two_gemm_forward():
         finally:
             AG.FUSED_WGRAD_DGRAD = wgdg_flag
         both.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    # (per tensor, with an absolute floor: the bias of a conv that feeds a GroupNorm has a gradient that is zero in exact arithmetic --
+    # what is computed there is rounding noise of either schedule, 1e-5 per entry against 1e-1 for the weights)
+    floor = 1e-3 * max(float(v.double().pow(2).mean().sqrt()) for v in both[0].values())
     for k in both[0]:
         a, b = both[0][k].flatten().double(), both[1][k].flatten().double()
-        assert float((a - b).norm()) <= 2e-3 * float(a.norm()) + 1e-12, k
+        assert float((a - b).norm()) <= 2e-3 * float(a.norm()) + floor * a.numel() ** 0.5, k
+    ga, gb = (torch.cat([v.flatten().double() for v in d.values()]) for d in both)
+    assert float((ga * gb).sum() / (ga.norm() * gb.norm())) > 0.999999
 
 
 def test_inference_after_fused_optimizer_steps_sees_new_weights():
