@@ -1445,8 +1445,8 @@ def pw_wgrad_dgrad(hp: torch.Tensor, dy: torch.Tensor, w_t_paired: torch.Tensor,
                    want_bias: bool = True, defer: Optional[DeferredReduce] = None):
     """One pass over the hidden pre-activation hp (N, rows, c_in) and the output gradient dy (N, rows, c_out) of a mixer's projecting
     conv: -> (dW (c_out, c_in), db (c_out) | None, dhp (N, rows, c_in) bf16) with dW = sum_r dy^T gelu(hp) and
-    dhp = (W^T dy) * gelu'(hp); w_t_paired = packed_paired(W, transposed=True).  Bit-identical to pw_wgrad(x_act=GELU) + the
-    RES_GELU_BWD data-gradient GEMM on that paired image (pytc_pw_wgrad_dgrad_partial); `defer` as in pw_wgrad."""
+    dhp = (W^T dy) * gelu'(hp); w_t_paired = packed_paired(W, transposed=True).  dW / db bit-identical to pw_wgrad(x_act=GELU); dhp equal to the
+    RES_GELU_BWD data-gradient GEMM on that paired image up to one bf16 ulp in a few outputs per million; `defer` as in pw_wgrad."""
     _dev(hp, "hp"); _dev(dy, "dy"); _dev(w_t_paired, "w_t_paired")
     if hp.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16 or w_t_paired.dtype != torch.bfloat16:
         raise TypeError("pw_wgrad_dgrad runs on bfloat16 operands and the bf16 paired image of W^T")

@@ -903,9 +903,9 @@ def test_gradnorm_balancing_trains_through_the_hip_autograd_functions():
 
 @pytest.mark.parametrize("N,rows,c_hid", [(2, 4096 + 37, 64), (1, 777, 64), (3, 2048, 32), (4, 50176, 64)])
 def test_fused_weight_gradient_and_data_gradient_of_the_projecting_conv(N, rows, c_hid):
-    """pytc_pw_wgrad_dgrad_partial: one pass over (hp, dy) gives dW3 / db3 AND dhp = (W3^T dy) * gelu'(hp) -- the same bits as
-    pw_wgrad(x_act = GELU) followed by the RES_GELU_BWD data-gradient GEMM on the PAIRED image of W3^T (ragged row counts, slots that
-    end inside a 32-row block)."""
+    """pytc_pw_wgrad_dgrad_partial: one pass over (hp, dy) gives dW3 / db3 AND dhp = (W3^T dy) * gelu'(hp): dW3 / db3 with the same
+    bits as pw_wgrad(x_act = GELU), dhp equal to the RES_GELU_BWD data-gradient GEMM on the PAIRED image of W3^T up to one bf16 ulp in
+    a few outputs per million (ragged row counts, slots that end inside a 32-row block)."""
     from pytorch_connectomics_amd import _native as nat
     from pytorch_connectomics_amd import hip_ops as ops
     dev = torch.device("cuda")
@@ -922,7 +922,13 @@ def test_fused_weight_gradient_and_data_gradient_of_the_projecting_conv(N, rows,
     dW1, db1, dhp1 = ops.pw_wgrad_dgrad(hp, dy, wt, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out)
     torch.cuda.synchronize()
     assert torch.equal(dW1, dW0) and torch.equal(db1, db0)
-    assert torch.equal(dhp1, dhp0.view(N, rows, c_hid))
+    # the data gradient: same MFMA on the same operands; the GELU' expression is compiled into two different kernels (fp contraction
+    # differs with the surrounding code), so a few outputs per million land on the other side of a bf16 rounding boundary: at most
+    # one bf16 ulp, at most 1e-5 of the elements (measured: 2 of 529 024, 13 of 12.8 M)
+    a, b = dhp1.float(), dhp0.view(N, rows, c_hid).float()
+    neq = a != b
+    assert float(neq.float().mean()) <= 1e-5
+    assert float(((a - b).abs() / b.abs().clamp_min(1e-30))[neq].max() if bool(neq.any()) else 0.0) <= 2.0 ** -7
     # and against fp32 torch
     h = hp.float()
     ref = (dy.float() @ w3.bfloat16().float()) * (0.5 * (1 + torch.erf(h / 2 ** 0.5)) + h * torch.exp(-h * h / 2) / (2 * 3.141592653589793) ** 0.5)
