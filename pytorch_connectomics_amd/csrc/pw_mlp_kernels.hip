@@ -367,6 +367,212 @@ pw_mlp_kernel(MlpParams p) {
 // bit-identical and SLOWER at every shape (forward 9.39 -> 10.1 ms; 128->256->128: 0.26 -> 0.61 ms): the registers of the second
 // tile cost a wave per SIMD, and this kernel lives on occupancy -- its per-wave critical path (MFMA -> GELU -> MFMA dependency
 // chains) is hidden by other waves, not by memory-level parallelism inside one.
+
+// ---- level-0 mixer with its operand rows landing in LDS by DMA, one tile ahead (round 5) ------------------------------------------------------
+// pw_mlp_kernel<1, 2, 4, 3> is memory bound at ~5.0 TB/s where a bare read-read-write kernel reaches 5.9 (profiles/r05_stream_policy.txt): its waves
+// hold 8 KB of loads in flight only until they start computing (60 % of their cycles waiting), ~77 KB per CU on average against the ~100 KB the
+// loaded memory system's 4 us want.  Prefetching the next tile into REGISTERS costs a wave per SIMD and lost twice (rounds 2 and 4).  Here the next
+// tile's rows travel by `global_load_lds_dwordx4` into a wave-private LDS landing area (8 KB per wave: each lane's 16 bytes land at its own
+// lane slot, so reading them back is a conflict-free identity map) while the wave computes the current tile from registers: no register cost, the
+// same occupancy, and every wave has a tile in flight all the time.  A wave walks tiles gw, gw + W, gw + 2W ... of its sample (W = waves of the
+// launch: neighbouring waves stay on neighbouring rows).  Order inside an iteration: wait (all DMA of this tile, and the stores of the tile before
+// last, have had a whole compute phase) -> landing area to registers -> stores of the PREVIOUS tile's results -> DMA of the next tile -> compute.
+// (Loads and stores share vmcnt and return out of order with respect to each other: the stores must not sit between a DMA and its wait.)
+// Same MFMA order, GELU and epilogue arithmetic as pw_mlp_kernel<1, 2, 4, 3> with per-sample operands: bit-identical output.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {      // lane l's dword lands at lds_dst + 4 l
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// KIND 0: plain / residual-add epilogue; 1: the first block's residual rows recomputed from the raw input (pw_mlp_kernel's STEMRES: the row's
+// fp32 input voxel rides the DMA as a dword); 2: the last block with the output heads fused (pw_mlp_kernel's HEAD)
+template <int HCT, int KIND>
+__global__ void __launch_bounds__(256, 3)
+pw_mlp_dma_kernel(MlpParams p, int waves_per_sample) {
+  constexpr int NT = 4, CIN = 32, COUT = 32;
+  constexpr bool STEM = KIND == 1, HEAD = KIND == 2;
+  // 32 KB of landing area + the sample's operands (the compiler's own loads of them inside the loop would share vmcnt with the DMA and, returning
+  // in order behind it, wait for the prefetch they are meant to overlap): 40.4 KB at HCT = 2, 49.4 KB at 4 -> 3 workgroups per CU
+  __shared__ __attribute__((aligned(16))) uint4 land[4][2][NT * 64];        // [wave][t | residual (STEM: input voxels)][tile][lane]
+  __shared__ __attribute__((aligned(16))) uint4 w2s[HCT * 2 * 64], w3s[2 * HCT * 64];
+  __shared__ __attribute__((aligned(16))) float b2s[HCT * 32], b3s[32];
+  __shared__ __attribute__((aligned(16))) float auxa[STEM ? 32 : (HEAD ? 256 : 4)], auxb[STEM ? 32 : (HEAD ? 16 : 4)];   // stem w, b / head image, bias
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.y;
+  const int r = lane & 15, kb = lane >> 4;
+  const long tiles = (p.rps + NT * 16 - 1) / (NT * 16);
+  const bool with_res = STEM || p.e.res_mode == PYTC_RES_ADD;
+  const bf16_t* tn = p.t + (long)n * p.rps * CIN;
+  const bf16_t* resn = (!STEM && with_res) ? reinterpret_cast<const bf16_t*>(p.e.res) + (long)n * p.rps * COUT : nullptr;
+  const float* sx = STEM ? p.stem_x + (long)n * p.rps : nullptr;
+  bf16_t* yn = reinterpret_cast<bf16_t*>(p.e.y) + (long)n * p.rps * COUT;
+  float* hy = HEAD ? p.head_y + (long)n * p.rps * p.n_head : nullptr;
+  {
+    const uint4* w2 = reinterpret_cast<const uint4*>(p.w2 + (long)n * p.w2_stride);
+    const uint4* w3 = reinterpret_cast<const uint4*>(p.w3);
+    for (int i = threadIdx.x; i < HCT * 2 * 64; i += 256) { w2s[i] = w2[i]; w3s[i] = w3[i]; }
+    if (threadIdx.x < HCT * 32) b2s[threadIdx.x] = p.b2[(long)n * p.C_hid + threadIdx.x];
+    if (threadIdx.x < 32) b3s[threadIdx.x] = p.b3[threadIdx.x];
+    if constexpr (STEM) {
+      if (threadIdx.x < 32) { auxa[threadIdx.x] = p.stem_w[threadIdx.x]; auxb[threadIdx.x] = p.stem_b[threadIdx.x]; }
+    }
+    if constexpr (HEAD) {
+      reinterpret_cast<float*>(auxa)[threadIdx.x] = reinterpret_cast<const float*>(p.head_w)[threadIdx.x];     // 64 lanes x 16 bytes
+      if (threadIdx.x < 16) auxb[threadIdx.x] = (p.head_b && (int)threadIdx.x < p.n_head) ? p.head_b[threadIdx.x] : 0.f;
+    }
+  }
+  __syncthreads();
+  // the compiler's own loads above are awaited before the first DMA is issued (its waits do not know about asm-issued loads)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const unsigned lbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)&land[wave][0][0]);
+  auto request = [&](long tile) {                  // 4 (+ 4) DMA loads: lane (r, kb) of tile nt fetches row tile*64 + nt*16 + r, piece kb
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      long row = tile * (NT * 16) + nt * 16 + r;
+      row = row < p.rps ? row : p.rps - 1;
+      glds16(tn + row * CIN + kb * 8, lbase + (unsigned)(nt * 64) * 16);
+      if constexpr (STEM) glds4(sx + row, lbase + (unsigned)(NT * 64) * 16 + (unsigned)(nt * 64) * 4);
+      else if (with_res) glds16(resn + row * COUT + kb * 8, lbase + (unsigned)((NT + nt) * 64) * 16);
+    }
+  };
+  bf16x8_t out[NT];                                // results of the previous tile (stored at the start of the next iteration)
+  f32x4_t hout[HEAD ? NT : 1];
+  auto store = [&](long tile) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const long row = tile * (NT * 16) + nt * 16 + r;
+      if (row >= p.rps) continue;
+      if (!HEAD || p.store_y) *reinterpret_cast<bf16x8_t*>(yn + row * COUT + kb * 8) = out[nt];
+      if constexpr (HEAD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (kb * 4 + i < p.n_head) hy[row * p.n_head + kb * 4 + i] = hout[nt][i];
+      }
+    }
+  };
+  const long gw = (long)blockIdx.x * 4 + wave;
+  long tile = gw;
+  if (tile >= tiles) return;
+  request(tile);
+  long out_tile = -1;
+  for (; tile < tiles; tile += waves_per_sample) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (out_tile >= 0) store(out_tile);
+    bf16x8_t bact[NT];
+    uint4 rpre[STEM ? 1 : NT];
+    float xin[STEM ? NT : 1];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      bact[nt] = __builtin_bit_cast(bf16x8_t, land[wave][0][nt * 64 + lane]);
+      if constexpr (STEM) xin[nt] = reinterpret_cast<const float*>(&land[wave][1][0])[nt * 64 + lane];
+      else if (with_res) rpre[nt] = land[wave][1][nt * 64 + lane];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the landing area is free again before the next DMA may write it
+    __builtin_amdgcn_wave_barrier();
+    if (tile + waves_per_sample < tiles) request(tile + waves_per_sample);
+    // ---- the mixer of pw_mlp_kernel<1, 2, 4, 3> on this tile
+    f32x4_t acc2[2][NT];
+    {
+      const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(&b3s[kb * 8]), hi = *reinterpret_cast<const f32x4_t*>(&b3s[kb * 8 + 4]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) { acc2[0][nt] = lo; acc2[1][nt] = hi; }
+    }
+#pragma unroll
+    for (int hc = 0; hc < HCT; ++hc) {
+      f32x4_t acc1[2][NT];
+      {
+        const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(&b2s[hc * 32 + kb * 8]), hi = *reinterpret_cast<const f32x4_t*>(&b2s[hc * 32 + kb * 8 + 4]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { acc1[0][nt] = lo; acc1[1][nt] = hi; }
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const bf16x8_t a2 = __builtin_bit_cast(bf16x8_t, w2s[(hc * 2 + mt) * 64 + lane]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc1[mt][nt] = Mma<bf16_t>::mma(a2, bact[nt], acc1[mt][nt]);
+      }
+      h8_t bhh[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float g[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { g[j] = acc1[0][nt][j]; g[4 + j] = acc1[1][nt][j]; }
+        bhh[nt] = gelu_h8_from_f32(g);
+      }
+#pragma unroll
+      for (int mo = 0; mo < 2; ++mo) {
+        const h8_t a3 = __builtin_bit_cast(h8_t, w3s[(mo * HCT + hc) * 64 + lane]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc2[mo][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3, bhh[nt], acc2[mo][nt], 0, 0, 0);
+      }
+    }
+    float sw[STEM ? 8 : 1], sb[STEM ? 8 : 1];
+    if constexpr (STEM) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sw[j] = auxa[kb * 8 + j]; sb[j] = auxb[kb * 8 + j]; }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = acc2[0][nt][j]; v[4 + j] = acc2[1][nt][j]; }
+      if constexpr (STEM) {
+        float rv[8], pre[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rv[j] = fmaf(sw[j], xin[nt], sb[j]);
+        const bf16x8_t rb = Mma<bf16_t>::from_floats(rv);          // the residual row as the stem would have stored it
+        VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(&rb), pre);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += pre[j];
+      } else if (with_res) {
+        float pre[8];
+        VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(&rpre[nt]), pre);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += pre[j];
+      }
+      out[nt] = Mma<bf16_t>::from_floats(v);
+      if constexpr (HEAD) {
+        const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, reinterpret_cast<const uint4*>(auxa)[lane]);
+        const f32x4_t hb = *reinterpret_cast<const f32x4_t*>(&auxb[kb * 4]);
+        const f32x4_t h = Mma<bf16_t>::mma(ah, out[nt], f32x4_t{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hout[nt][i] = h[i] + hb[i];
+      }
+    }
+    out_tile = tile;
+  }
+  store(out_tile);
+}
+
+// which launches take the DMA form: level-0 width, per-sample operands, fp16 projection image, a launch of at least `mlp_dma_rows` rows
+static bool mlp_dma_applies(const pytc_mlp_args* a, const MlpParams& p) {
+  return a->per_sample && p.w3_f16 && a->C_in == 32 && a->C_out == 32 && (p.HC == 2 || p.HC == 3 || p.HC == 4) &&
+         (a->res_mode == PYTC_RES_NONE || a->res_mode == PYTC_RES_ADD) && tuning_get("mlp_dma", 1) != 0 &&
+         (long)a->N * a->rows_per_sample >= (long)tuning_get("mlp_dma_rows", 1 << 20);
+}
+template <int KIND>
+static void mlp_dma_launch(const pytc_mlp_args* a, const MlpParams& p, hipStream_t s) {
+  const long tiles = (a->rows_per_sample + 63) / 64;
+  // workgroups of the launch per sample: several waves' worth per CU slot (3 workgroups per CU by LDS); every wave gets >= 2 tiles
+  long wgs = ((long)tuning_get("mlp_dma_grid", 3072) + a->N - 1) / a->N;
+  const long most = (tiles / 2 + 3) / 4;
+  if (wgs > most) wgs = most < 1 ? 1 : most;
+  if (const int forced = tuning_get("mlp_dma_wgs", 0); forced > 0) wgs = forced;
+  dim3 grid((unsigned)wgs, (unsigned)a->N), block(256);
+  const int wps = (int)(wgs * 4);
+  if (p.HC == 2) hipLaunchKernelGGL((pw_mlp_dma_kernel<2, KIND>), grid, block, 0, s, p, wps);
+  else if (p.HC == 3) hipLaunchKernelGGL((pw_mlp_dma_kernel<3, KIND>), grid, block, 0, s, p, wps);
+  else hipLaunchKernelGGL((pw_mlp_dma_kernel<4, KIND>), grid, block, 0, s, p, wps);
+}
+
 template <typename OUT>
 __global__ void __launch_bounds__(256)
 pw_pack_paired_kernel(const float* __restrict__ w, int C_out, int C_in, int transposed,
@@ -705,6 +911,11 @@ extern "C" int pytc_pw_mlp_head_fwd(const pytc_mlp_args* a, const void* head_w, 
   dim3 grid((unsigned)((p.rps + 4L * 4 * 16 - 1) / (4L * 4 * 16)), (unsigned)a->N), block(256);
   hipStream_t s = (hipStream_t)stream;
   const bool exact = tuning_get("mlp_exact_gelu", 0) != 0;
+  if (mlp_dma_applies(a, p)) {
+    mlp_dma_launch<2>(a, p, s);
+    PYTC_LAUNCH_CHECK("pw_mlp_head_dma");
+    return PYTC_OK;
+  }
   if (p.w3_f16) {
     if (a->C_in == 32) hipLaunchKernelGGL((pw_mlp_kernel<1, 2, 4, 3, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((pw_mlp_kernel<2, 2, 4, 3, true>), grid, block, 0, s, p);
@@ -742,6 +953,13 @@ extern "C" int pytc_pw_mlp_stemres_fwd(const pytc_mlp_args* a, const float* stem
   p.w3_f16 = a->w3_format == PYTC_W3_F16 ? 1 : 0;
   dim3 grid((unsigned)((p.rps + 4L * 4 * 16 - 1) / (4L * 4 * 16)), (unsigned)a->N), block(256);
   hipStream_t s = (hipStream_t)stream;
+  pytc_mlp_args shape = *a;
+  shape.res_mode = PYTC_RES_NONE;          // this entry ignores a->res_mode (the residual is the recomputed stem row)
+  if (mlp_dma_applies(&shape, p)) {
+    mlp_dma_launch<1>(a, p, s);
+    PYTC_LAUNCH_CHECK("pw_mlp_stemres_dma");
+    return PYTC_OK;
+  }
   if (p.w3_f16) hipLaunchKernelGGL((pw_mlp_kernel<1, 2, 4, 3, false, true>), grid, block, 0, s, p);
   else if (tuning_get("mlp_exact_gelu", 0) != 0) hipLaunchKernelGGL((pw_mlp_kernel<1, 2, 4, 0, false, true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((pw_mlp_kernel<1, 2, 4, 1, false, true>), grid, block, 0, s, p);
@@ -798,6 +1016,12 @@ static int mlp_fwd_impl(const pytc_mlp_args* a, void* hp, void* stream, const vo
     PYTC_REQUIRE(a->rows_per_sample < (1L << 31), "pw_mlp: RES_UPSAMPLE positions are 32-bit (rows per sample < 2^31)");
     p.e.Go_d = a->Di; p.e.Go_h = a->Hi; p.e.Go_w = a->Wi;
     p.e.Gl_d = a->Di / 2; p.e.Gl_h = a->Hi / 2; p.e.Gl_w = a->Wi / 2;
+  }
+  // level-0 shapes of the inference mixers with per-sample operands: the DMA-prefetching form (pw_mlp_dma_kernel)
+  if (!hp && !hp_in && mlp_dma_applies(a, p)) {
+    mlp_dma_launch<0>(a, p, (hipStream_t)stream);
+    PYTC_LAUNCH_CHECK("pw_mlp_dma");
+    return PYTC_OK;
   }
   if (!dispatch_mlp(p, a->N, (hipStream_t)stream)) {
     set_error("pw_mlp: dispatch failed");

@@ -376,6 +376,56 @@ def test_lds_resident_mixer_is_bit_identical(dev, cin, chid, cout, mode, N, grid
     assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
 
 
+@pytest.mark.parametrize("N,rows,chid,n_head", [(1, 1, 64, 1), (2, 63, 64, 3), (3, 1000, 96, 16), (2, 4097, 128, 5), (5, 777, 64, 2)])
+@pytest.mark.parametrize("wgs", [0, 1, 3])
+def test_dma_prefetch_mixer_is_bit_identical(dev, N, rows, chid, n_head, wgs):
+    """pw_mlp_dma_kernel (round 5): the level-0 mixer whose operand rows land in LDS by `global_load_lds` one tile ahead of the tile a
+    wave computes, results stored one tile late -- plain, residual-add, recomputed-stem-residual and fused-head forms -- against the
+    one-tile-per-wave kernel it replaces above `mlp_dma_rows` rows: same MFMA order, GELU and epilogue, hence equal BITS; single-row and
+    ragged samples, fewer tiles than waves (wgs 0 = the launch's own grid), waves that walk many tiles (1 workgroup per sample)."""
+    from pytorch_connectomics_amd import _native as nat
+    from pytorch_connectomics_amd import hip_ops as ops
+    bf = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(rows)
+    t = torch.randn(N, rows, 32, generator=g).to(bf).to(dev)
+    res = torch.randn(N, rows, 32, generator=g).to(bf).to(dev)
+    w2n = torch.stack([ops.pw_pack_weight_paired((torch.randn(chid, 32, generator=g) / 32 ** 0.5).to(dev)) for _ in range(N)])
+    b2n = torch.randn(N, chid, generator=g).to(dev)
+    w3 = ops.pw_pack_weight_paired((torch.randn(32, chid, generator=g) / chid ** 0.5).to(dev), f16=True)
+    b3 = torch.randn(32, generator=g).to(dev)
+    x0 = torch.randn(N, rows, generator=g).to(dev)
+    sw, sb = torch.randn(32, generator=g).to(dev), torch.randn(32, generator=g).to(dev)
+    hw = ops.pack_head_fragment((torch.randn(n_head, 32, generator=g) / 32 ** 0.5).to(dev))
+    hb = torch.randn(n_head, generator=g).to(dev)
+    kw = dict(N=N, rows_per_sample=rows, c_in=32, c_hid=chid, c_out=32)
+
+    def everything():
+        out = [ops.pw_mlp(t, None, w2n, b2n, w3, b3, **kw), ops.pw_mlp(t, None, w2n, b2n, w3, b3, res=res, res_mode=nat.RES_ADD, **kw),
+               ops.pw_mlp_stemres(t, None, w2n, b2n, w3, b3, x0, sw, sb, **kw)]
+        for add in (False, True):
+            for store_y in (False, True):
+                out += list(ops.pw_mlp_head(t, None, w2n, b2n, w3, b3, hw, hb if add else None, res=res if add else None, store_y=store_y, **kw))
+        torch.cuda.synchronize()
+        return out
+
+    ops.set_tuning("mlp_dma_rows", 0)
+    try:
+        ops.set_tuning("mlp_dma", 0)
+        want = everything()
+        ops.set_tuning("mlp_dma", 1)
+        ops.set_tuning("mlp_dma_wgs", wgs)
+        got = everything()
+    finally:
+        ops.set_tuning("mlp_dma", 1)
+        ops.set_tuning("mlp_dma_wgs", 0)
+        ops.set_tuning("mlp_dma_rows", 1 << 20)
+    assert len(want) == len(got) == 11
+    for i, (a, b) in enumerate(zip(want, got)):
+        assert (a is None) == (b is None), i
+        if a is not None:
+            assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
+
+
 def test_lds_resident_mixer_refuses_what_it_does_not_cover(dev):
     from pytorch_connectomics_amd import _native as nat
     from pytorch_connectomics_amd import hip_ops as ops

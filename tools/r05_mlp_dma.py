@@ -1,0 +1,158 @@
+"""Level-0 mixer with LDS-DMA prefetch (pw_mlp_dma_kernel) against the one-tile-per-wave kernel: bit identity on ragged shapes, then time
+per launch at the network's level-0 shape, alternating, with a sweep of workgroups per sample.  python tools/r05_mlp_dma.py [check] [time]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pytorch_connectomics_amd import _native as nat  # noqa: E402
+from pytorch_connectomics_amd import hip_ops as ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+bf = torch.bfloat16
+
+
+def knob(k, v):
+    nat.check(nat.lib().pytc_set_tuning(k.encode(), int(v)), "set_tuning")
+
+
+def operands(N, rows, chid, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    t = torch.randn(N, rows, 32, generator=g).to(bf).to(dev)
+    res = torch.randn(N, rows, 32, generator=g).to(bf).to(dev)
+    w2n = torch.stack([ops.pw_pack_weight_paired((torch.randn(chid, 32, generator=g) / 32 ** 0.5).to(dev)) for _ in range(N)])
+    b2n = torch.randn(N, chid, generator=g).to(dev)
+    w3 = ops.pw_pack_weight_paired((torch.randn(32, chid, generator=g) / chid ** 0.5).to(dev), f16=True)
+    b3 = torch.randn(32, generator=g).to(dev)
+    return t, res, w2n, b2n, w3, b3
+
+
+def run(t, res, w2n, b2n, w3, b3, add, y=None):
+    N, rows, chid = t.shape[0], t.shape[1], b2n.shape[1]
+    kw = dict(N=N, rows_per_sample=rows, c_in=32, c_hid=chid, c_out=32, y=y)
+    if add:
+        return ops.pw_mlp(t, None, w2n, b2n, w3, b3, res=res, res_mode=nat.RES_ADD, **kw)
+    return ops.pw_mlp(t, None, w2n, b2n, w3, b3, **kw)
+
+
+def run_stem(t, res, w2n, b2n, w3, b3, x0, sw, sb, y=None):
+    N, rows, chid = t.shape[0], t.shape[1], b2n.shape[1]
+    return ops.pw_mlp_stemres(t, None, w2n, b2n, w3, b3, x0, sw, sb, N=N, rows_per_sample=rows, c_in=32, c_hid=chid, c_out=32, y=y)
+
+
+def run_head(t, res, w2n, b2n, w3, b3, hw, hb, add, store_y):
+    N, rows, chid = t.shape[0], t.shape[1], b2n.shape[1]
+    return ops.pw_mlp_head(t, None, w2n, b2n, w3, b3, hw, hb, N=N, rows_per_sample=rows, c_in=32, c_hid=chid, c_out=32,
+                           res=res if add else None, store_y=store_y)
+
+
+def extras(N, rows, n_head, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed + 7)
+    x0 = torch.randn(N, rows, generator=g).to(dev)
+    sw, sb = torch.randn(32, generator=g).to(dev), torch.randn(32, generator=g).to(dev)
+    hw = ops.pack_head_fragment((torch.randn(n_head, 32, generator=g) / 32 ** 0.5).to(dev))
+    hb = torch.randn(n_head, generator=g).to(dev)
+    return x0, sw, sb, hw, hb
+
+
+def same(a, b):
+    if a is None or b is None:
+        return a is None and b is None
+    return torch.equal(a.view(torch.int16 if a.dtype == bf else torch.int32), b.view(torch.int16 if b.dtype == bf else torch.int32))
+
+
+def check_kinds():
+    knob("mlp_dma_rows", 0)
+    for N, rows, chid, n_head in [(1, 1, 64, 1), (2, 63, 64, 3), (3, 1000, 96, 16), (2, 4097, 128, 5), (8, 28 ** 3, 64, 3), (1, 112 ** 3, 64, 2)]:
+        o = operands(N, rows, chid, seed=rows)
+        x0, sw, sb, hw, hb = extras(N, rows, n_head, rows)
+        got = {}
+        for dma in (0, 1):
+            knob("mlp_dma", dma)
+            got[dma] = [run_stem(*o, x0, sw, sb)]
+            for add in (False, True):
+                for store_y in (False, True):
+                    y, logits = run_head(*o, hw, hb if add else None, add, store_y)
+                    got[dma] += [y, logits]
+        torch.cuda.synchronize()
+        ok = all(same(a, b) for a, b in zip(got[0], got[1]))
+        print(f"stem-residual / head kinds: N {N} rows {rows} hid {chid} heads {n_head}: {'bit-identical' if ok else 'MISMATCH'}", flush=True)
+        assert ok
+
+
+def check():
+    knob("mlp_dma_rows", 0)
+    for N, rows, chid in [(1, 64, 64), (1, 1, 64), (2, 63, 64), (3, 1000, 96), (2, 4097, 128), (8, 28 ** 3, 64), (1, 112 ** 3, 64), (5, 777, 64)]:
+        for add in (False, True):
+            for wgs in (0, 1, 3):
+                o = operands(N, rows, chid, seed=rows)
+                knob("mlp_dma", 0)
+                want = run(*o, add)
+                knob("mlp_dma", 1)
+                if wgs:
+                    knob("mlp_dma_wgs", wgs)
+                got = run(*o, add)
+                torch.cuda.synchronize()
+                ok = torch.equal(want.view(torch.int16), got.view(torch.int16))
+                print(f"N {N} rows {rows} hid {chid} add {int(add)} wgs {wgs or 'auto'}: {'bit-identical' if ok else 'MISMATCH'}", flush=True)
+                assert ok
+                if wgs:
+                    knob("mlp_dma_wgs", 0)
+
+
+def timeit(fn, reps=20, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e3
+
+
+def time_kinds():
+    knob("mlp_dma_rows", 0)
+    for N, D, chid, n_head in [(8, 112, 64, 3), (2, 160, 96, 3)]:
+        rows = D ** 3
+        o = operands(N, rows, chid)
+        x0, sw, sb, hw, hb = extras(N, rows, n_head, 1)
+        y = torch.empty(N, rows, 32, device=dev, dtype=bf)
+        for label, fn, nbytes in [("stem residual", lambda: run_stem(*o, x0, sw, sb, y=y), N * rows * (128 + 4)),
+                                  ("head (add, no y)", lambda: run_head(*o, hw, hb, True, False), N * rows * (128 + 4 * n_head))]:
+            for rnd in range(2):
+                for dma in (0, 1):
+                    knob("mlp_dma", dma)
+                    us = timeit(fn)
+                    print(f"x{N} {D}^3 hid {chid} {label:18s} | {'dma' if dma else 'one tile per wave':18s} {us:8.1f} us  {nbytes / us / 1e3:7.1f} GB/s", flush=True)
+
+
+def time():
+    knob("mlp_dma_rows", 0)
+    for N, D, chid in [(8, 112, 64), (2, 160, 128)]:
+        rows = D ** 3
+        o = operands(N, rows, chid)
+        y = torch.empty(N, rows, 32, device=dev, dtype=bf)
+        for add in (False, True):
+            nbytes = N * rows * 2 * 32 * (3 if add else 2)
+            for rnd in range(2):
+                for label, kn in [("one tile per wave", {"mlp_dma": 0}), ("dma auto", {"mlp_dma": 1, "mlp_dma_wgs": 0})] + \
+                        [(f"dma wgs {w}", {"mlp_dma": 1, "mlp_dma_wgs": w}) for w in ((96, 384, 768) if rnd == 0 else ())]:
+                    for k, v in kn.items():
+                        knob(k, v)
+                    us = timeit(lambda: run(*o, add, y=y))
+                    print(f"x{N} {D}^3 hid {chid} {'add' if add else 'none'} | {label:18s} {us:8.1f} us  {nbytes / us / 1e3:7.1f} GB/s", flush=True)
+    knob("mlp_dma_wgs", 0)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["check", "time"]
+    if "check" in what:
+        check_kinds()
+        check()
+    if "time" in what:
+        time_kinds()
+        time()
