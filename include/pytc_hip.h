@@ -379,6 +379,12 @@ int pytc_pw_mlp_fwd(const pytc_mlp_args* a, void* stream);
  * boundary as pytc_pw_mlp_fwd (MedNeXtBlock.forward: norm -> conv2 -> act -> conv3 -> + x). */
 int pytc_pw_mlp_lds_supported(int C_in, int C_hid, int C_out);
 int pytc_pw_mlp_lds_fwd(const pytc_mlp_args* a, void* stream);
+/* pytc_pw_mlp_fwd (w3_format = PYTC_W3_F16, forward only) for wide hidden layers whose weight images exceed LDS (C_in / C_out of
+ * 64->128, 128->64, 128->128, 256->128; any C_hid that is a multiple of 32 up to 8192: MedNeXt-L's 128->1024->128, 256->2048->128,
+ * 128->512->64, 64->512->128) -- csrc/pw_mlp_chunk_kernels.hip: the waves of a workgroup share each 32-wide hidden chunk's weight
+ * fragments, streamed L2 -> LDS by DMA two chunks ahead; results are bit-identical to pytc_pw_mlp_fwd.  Same reference boundary. */
+int pytc_pw_mlp_chunk_supported(int C_in, int C_hid, int C_out);
+int pytc_pw_mlp_chunk_fwd(const pytc_mlp_args* a, void* stream);
 /* GroupNorm finalize + fold into the mixer's expanding conv, one launch (replaces pytc_groupnorm_finalize in front of an
  * inference mixer: MedNeXtBlock.norm followed by conv2, external nnunet_mednext block; contract at mednext_models.py:99-126):
  *   a_n = gamma * rstd_n, b_n = beta - mean_n * a_n   from stats [N][slots][2][C] (fixed summation order per sample),

@@ -233,6 +233,8 @@ _SIGS = {
     "pytc_pw_mlp_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p]),
     "pytc_pw_mlp_lds_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pytc_pw_mlp_lds_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p]),
+    "pytc_pw_mlp_chunk_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "pytc_pw_mlp_chunk_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p]),
     "pytc_pw_mlp_stemres_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pytc_stem_dwconv3d_stat_slots": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pytc_stem_dwconv3d_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),

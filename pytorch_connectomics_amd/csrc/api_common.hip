@@ -58,7 +58,7 @@ static bool ensure_dynamic_lds_impl(const void* kernel, size_t bytes, const char
 
 namespace pytc {
 // Small registry of integer tuning knobs (kernel variant selection for A/B measurements).
-static struct { char key[48]; int value; } g_knobs[32];
+static struct { char key[48]; int value; } g_knobs[64];
 static int g_nknobs = 0;
 int tuning_get(const char* key, int dflt) {
   for (int i = 0; i < g_nknobs; ++i)
@@ -71,7 +71,7 @@ extern "C" int pytc_set_tuning(const char* key, int value) {
   if (!key || strlen(key) >= 48) return PYTC_ERR_INVALID;
   for (int i = 0; i < pytc::g_nknobs; ++i)
     if (!strcmp(pytc::g_knobs[i].key, key)) { pytc::g_knobs[i].value = value; return PYTC_OK; }
-  if (pytc::g_nknobs >= 32) return PYTC_ERR_INVALID;
+  if (pytc::g_nknobs >= 64) return PYTC_ERR_INVALID;
   strcpy(pytc::g_knobs[pytc::g_nknobs].key, key);
   pytc::g_knobs[pytc::g_nknobs++].value = value;
   return PYTC_OK;

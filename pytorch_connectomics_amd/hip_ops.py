@@ -602,10 +602,12 @@ def pw_mlp(t: torch.Tensor, ab: Optional[torch.Tensor], w2p: torch.Tensor, b2: t
            b3: torch.Tensor, *, N: int, rows_per_sample: int, c_in: int, c_hid: int, c_out: int,
            res: Optional[torch.Tensor] = None, res_mode: int = nat.RES_NONE, grid: Sequence[int] = (0, 0, 0),
            res_low: Optional[torch.Tensor] = None, res_bias: Optional[torch.Tensor] = None,
-           y: Optional[torch.Tensor] = None, hidden_pre: Optional[torch.Tensor] = None, lds: bool = False) -> torch.Tensor:
+           y: Optional[torch.Tensor] = None, hidden_pre: Optional[torch.Tensor] = None, lds: bool = False,
+           chunked: bool = False) -> torch.Tensor:
     """Fused norm-apply -> 1x1 expand -> GELU -> 1x1 project (+residual) on bf16 NDHWC rows.  hidden_pre (N, rows, c_hid)
     bf16: training forward, the hidden pre-activation is stored there as well.  lds: the persistent kernel with the weight images
-    resident in LDS (pw_mlp_lds_supported shapes, fp16 projection image; bit-identical)."""
+    resident in LDS (pw_mlp_lds_supported shapes, fp16 projection image; bit-identical).  chunked: the kernel whose workgroups stream
+    the weight images through LDS one hidden chunk at a time (pw_mlp_chunk_supported shapes: wide hidden layers; bit-identical)."""
     _dev(t, "t")
     if t.dtype != torch.bfloat16:
         raise TypeError("pw_mlp runs on bfloat16 activations")
@@ -634,6 +636,10 @@ def pw_mlp(t: torch.Tensor, ab: Optional[torch.Tensor], w2p: torch.Tensor, b2: t
         _run(f"pw_mlp_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_lds_fwd, C.byref(a), _stream(),
              symbol=f"pw_mlp_lds_kernel<{c_in // 32}, {c_out // 16}>")
         return y
+    if chunked:
+        _run(f"pw_mlp_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_chunk_fwd, C.byref(a), _stream(),
+             symbol=f"pw_mlp_chunk_kernel<{c_in // 32}, {c_out // 16}>")
+        return y
     _run(f"pw_mlp_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_fwd, C.byref(a), _stream(),
          symbol=f"pw_mlp_kernel<{c_in // 32}, {c_out // 16}>")
     return y
@@ -641,6 +647,10 @@ def pw_mlp(t: torch.Tensor, ab: Optional[torch.Tensor], w2p: torch.Tensor, b2: t
 
 def pw_mlp_lds_supported(c_in: int, c_hid: int, c_out: int) -> bool:
     return bool(nat.lib().pytc_pw_mlp_lds_supported(int(c_in), int(c_hid), int(c_out)))
+
+
+def pw_mlp_chunk_supported(c_in: int, c_hid: int, c_out: int) -> bool:
+    return bool(nat.lib().pytc_pw_mlp_chunk_supported(int(c_in), int(c_hid), int(c_out)))
 
 
 def pw_gemm_supported(c_in: int, c_out: int) -> bool:

@@ -194,6 +194,11 @@ class HipBlockOps:
         # bit-identical, 15 ... 35 % faster at 8 windows; below the threshold staging the images costs more than it saves (5 x 14^3:
         # 27 against 19 us).  0 switches the path off.
         self.lds_mixer_rows = int(os.environ.get("PYTC_LDS_MIXER_ROWS", "131072"))
+        # ... and blocks whose images exceed LDS (ops.pw_mlp_chunk_supported with c_hid >= PYTC_CHUNK_MIXER_HID: MedNeXt-L's 128->1024->128,
+        # 256->2048->128, 128->512->64, 64->512->128) the kernel that streams the images through LDS one hidden chunk per workgroup step
+        # (pw_mlp_chunk_kernels.hip; bit-identical) from this many rows in the batch.  0 switches the path off.
+        self.chunk_mixer_rows = int(os.environ.get("PYTC_CHUNK_MIXER_ROWS", "16384"))
+        self.chunk_mixer_hid = int(os.environ.get("PYTC_CHUNK_MIXER_HID", "512"))
         # bf16 residual blocks with 32 channels (level 0: the widest tensors of the network) can run as statistics pass + ONE fused kernel
         # (ops.dwmix): the depthwise output is re-formed in LDS and never stored -- 3 instead of 5 tensor passes per block, bit-identical
         # to the two-launch schedule.  Measured on MI355X (profiles/r05_fused_block.txt): the fused kernel is bound by instruction issue,
@@ -487,6 +492,11 @@ def _block_fused(self, m, x, t, ab, skip, ishape, oshape, c_hid, c_out, out=None
     if (self.lds_mixer_rows and N * rows >= self.lds_mixer_rows and w3.dtype == torch.float16
             and ops.pw_mlp_lds_supported(C, c_hid, c_out)):
         kw["lds"] = True
+    chunk_ok = (self.chunk_mixer_rows and N * rows >= self.chunk_mixer_rows and w3.dtype == torch.float16
+                and ops.pw_mlp_chunk_supported(C, c_hid, c_out))
+    if chunk_ok and (c_hid >= self.chunk_mixer_hid or (C, c_out) == (128, 64)):
+        kw.pop("lds", None)                  # 128 -> 256 -> 64 (up block): 241 against 261 us for the LDS-resident form at 8 x 56^3
+        kw["chunked"] = True
     if out is not None:
         if tuple(out.shape) != (N, Do, Ho, Wo, c_out):
             raise ValueError(f"block output buffer {tuple(out.shape)} != {(N, Do, Ho, Wo, c_out)}")

@@ -426,6 +426,68 @@ def test_dma_prefetch_mixer_is_bit_identical(dev, N, rows, chid, n_head, wgs):
             assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
 
 
+@pytest.mark.parametrize("cin,chid,cout,mode,N,grid", [(128, 1024, 128, "add", 2, (7, 7, 7)), (128, 1024, 128, "none", 1, (3, 3, 3)),
+                                                       (256, 2048, 128, "up", 2, (6, 6, 6)), (128, 512, 64, "up", 3, (4, 4, 4)),
+                                                       (64, 512, 128, "none", 2, (9, 9, 9)), (128, 96, 128, "add", 2, (5, 5, 5)),
+                                                       (128, 64, 64, "add", 1, (4, 4, 4)), (64, 128, 32, "up", 2, (6, 6, 6)),
+                                                       (64, 256, 64, "add", 2, (7, 7, 7)), (128, 256, 64, "up", 2, (14, 14, 14))])
+@pytest.mark.parametrize("folded", [True, False])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+def test_chunk_streamed_mixer_is_bit_identical(dev, cin, chid, cout, mode, N, grid, folded, variant):
+    """ops.pw_mlp(chunked=True) -- the mixer whose workgroups stream both weight images through an LDS ring one 32-wide hidden chunk at a
+    time by LDS-DMA (round 5, pw_mlp_chunk_kernels.hip: MedNeXt-L's wide hidden layers) -- against the streaming kernel: same MFMA order,
+    GELU and epilogue, hence equal BITS; one / two / three chunks (ring start-up and drain), ragged last workgroups, waves without rows,
+    every launch variant (8 / 12 / 16 waves: 3, 2, 1 or no DMA pieces per wave and chunk)."""
+    from pytorch_connectomics_amd import _native as nat
+    from pytorch_connectomics_amd import hip_ops as ops
+    assert ops.pw_mlp_chunk_supported(cin, chid, cout) and not ops.pw_mlp_chunk_supported(32, 64, 32)
+    bf = torch.bfloat16
+    rows = grid[0] * grid[1] * grid[2]
+    g = torch.Generator(device="cpu").manual_seed(cin + rows)
+    t = torch.randn(N, rows, cin, generator=g).to(bf).to(dev)
+    w3 = ops.pw_pack_weight_paired((torch.randn(cout, chid, generator=g) / chid ** 0.5).to(dev), f16=True)
+    b3 = (torch.randn(cout, generator=g) * 0.5).to(dev)
+    if folded:
+        ab = None
+        w2 = torch.stack([ops.pw_pack_weight_paired((torch.randn(chid, cin, generator=g) / cin ** 0.5).to(dev)) for _ in range(N)])
+        b2 = (torch.randn(N, chid, generator=g) * 0.5).to(dev)
+    else:
+        ab = torch.stack([torch.rand(N, cin, generator=g) + 0.5, torch.randn(N, cin, generator=g) * 0.5], 1).contiguous().to(dev)
+        w2, b2 = ops.pw_pack_weight_paired((torch.randn(chid, cin, generator=g) / cin ** 0.5).to(dev)), (torch.randn(chid, generator=g) * 0.5).to(dev)
+    kw = dict(N=N, rows_per_sample=rows, c_in=cin, c_hid=chid, c_out=cout)
+    res = torch.randn(N, rows, cout, generator=g).to(bf).to(dev)
+    if mode == "add":
+        kw.update(res=res, res_mode=nat.RES_ADD)
+    elif mode == "up":
+        low = torch.randn(N, rows // 8, cout, generator=g).to(bf).to(dev)
+        kw.update(res=res, res_mode=nat.RES_UPSAMPLE, grid=grid, res_low=low, res_bias=b3)
+    want = ops.pw_mlp(t, ab, w2, b2, w3, b3, **kw)
+    got = torch.full_like(want, float("nan"))
+    ops.set_tuning("mlp_chunk_variant", variant)
+    try:
+        ops.pw_mlp(t, ab, w2, b2, w3, b3, y=got, chunked=True, **kw)
+    finally:
+        ops.set_tuning("mlp_chunk_variant", 0)
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+
+
+def test_chunk_streamed_mixer_refuses_what_it_does_not_cover(dev):
+    from pytorch_connectomics_amd import hip_ops as ops
+    t = torch.zeros(1, 64, 32, device=dev, dtype=torch.bfloat16)
+    ab = torch.zeros(1, 2, 32, device=dev)
+    z = torch.zeros(64, device=dev)
+    w = torch.zeros(64, 32, device=dev)
+    with pytest.raises(RuntimeError, match="no chunk-streamed kernel"):
+        ops.pw_mlp(t, ab, ops.pw_pack_weight_paired(w), z, ops.pw_pack_weight_paired(w.t().contiguous(), f16=True), z[:32], N=1,
+                   rows_per_sample=64, c_in=32, c_hid=64, c_out=32, chunked=True)
+    t = torch.zeros(1, 64, 128, device=dev, dtype=torch.bfloat16)
+    ab = torch.zeros(1, 2, 128, device=dev)
+    w2 = torch.zeros(256, 128, device=dev)
+    with pytest.raises(RuntimeError, match="fp16"):                       # bf16 projection image
+        ops.pw_mlp(t, ab, ops.pw_pack_weight_paired(w2), torch.zeros(256, device=dev), ops.pw_pack_weight_paired(w2.t().contiguous()),
+                   torch.zeros(128, device=dev), N=1, rows_per_sample=64, c_in=128, c_hid=256, c_out=128, chunked=True)
+
+
 def test_lds_resident_mixer_refuses_what_it_does_not_cover(dev):
     from pytorch_connectomics_amd import _native as nat
     from pytorch_connectomics_amd import hip_ops as ops
