@@ -30,12 +30,16 @@ struct GemmParams {
 };
 
 constexpr int GEMM_BN = 128;            // output channels per workgroup
-constexpr int GEMM_KS = 64;             // k per staged step = two 16x16x32 MFMA sub-steps (one barrier per 64 k)
-constexpr int GEMM_PITCH = GEMM_KS + 8; // LDS row pitch in elements (144 bytes: the 16 rows of a fragment read hit 16 distinct 16-byte columns)
+constexpr int GEMM_KS = 64;             // k per staged step = two 16x16x32 MFMA sub-steps (one barrier per 64 k); the template's default
 
-template <bool F16, int BR>             // F16: fp16 operands (the projecting conv); BR rows per workgroup (64 or 128)
-__global__ void __launch_bounds__(256, 2)
+// KS = 32 (round 5): half the LDS per workgroup (41 KB at BR = 128, 31 KB at BR = 64) -> 3 / 4 workgroups per CU instead of 2.  These launches
+// are latency bound, not MFMA bound (256 -> 2048 on 16 000 rows: a workgroup lives 12 us for 0.85 us of MFMAs -- every k step exposes a global
+// load round trip that one step of compute cannot cover), so resident workgroups are what hides it.  Same k order: bit-identical.
+template <bool F16, int BR, int KS = GEMM_KS>     // F16: fp16 operands (the projecting conv); BR rows per workgroup (64 or 128)
+__global__ void __launch_bounds__(256, KS == 32 ? (BR == 64 ? 4 : 3) : 2)
 pw_gemm_lds_kernel(GemmParams p) {
+  constexpr int GEMM_KS = KS;
+  constexpr int GEMM_PITCH = GEMM_KS + 8; // LDS row pitch in elements (144 / 80 bytes: the 16 rows of a fragment read hit 16 distinct 16-byte columns)
   constexpr int NT = BR / 2 / 16;       // 16-row tiles per wave (2 row halves per workgroup)
   constexpr int MT = 4;                 // 16-channel tiles per wave (2 channel halves of 64)
   constexpr int CPR = GEMM_KS / 8;      // 16-byte pieces per staged row
@@ -227,14 +231,28 @@ extern "C" int pytc_pw_gemm_fwd(const void* x, const void* w, const float* bias,
   // 128-row workgroups once they alone fill the chip twice over, 64-row ones below (the bottleneck level: 2 744 rows)
   const long tiles128 = (p.rows_total + 127) / 128 * (C_out / GEMM_BN);
   const bool big = tiles128 >= 512 && tuning_get("pw_gemm_rows", 0) != 64;
+  // 32-wide k steps for the short-K (expanding) GEMMs, 64-wide for the long-K (projecting) ones: MI355X, profiles/r05_gemm_k_step.txt --
+  // 256 -> 2048 on 16 000 rows 51 -> 46 us, 512 -> 1024 on 21 952 rows 61 -> 57; 2048 -> 256 34 -> 40 (a barrier per 32 k over 64 steps)
+  const int ks_knob = tuning_get("pw_gemm_ks", 0);
+  const bool ks32 = ks_knob ? ks_knob == 32 : C_in <= 512;
   if (big || tuning_get("pw_gemm_rows", 0) == 128) {
     dim3 grid((unsigned)((p.rows_total + 127) / 128 * (C_out / GEMM_BN)));
-    if (in_f16) hipLaunchKernelGGL((pw_gemm_lds_kernel<true, 128>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((pw_gemm_lds_kernel<false, 128>), grid, dim3(256), 0, s, p);
+    if (ks32) {
+      if (in_f16) hipLaunchKernelGGL((pw_gemm_lds_kernel<true, 128, 32>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((pw_gemm_lds_kernel<false, 128, 32>), grid, dim3(256), 0, s, p);
+    } else {
+      if (in_f16) hipLaunchKernelGGL((pw_gemm_lds_kernel<true, 128>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((pw_gemm_lds_kernel<false, 128>), grid, dim3(256), 0, s, p);
+    }
   } else {
     dim3 grid((unsigned)((p.rows_total + 63) / 64 * (C_out / GEMM_BN)));
-    if (in_f16) hipLaunchKernelGGL((pw_gemm_lds_kernel<true, 64>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((pw_gemm_lds_kernel<false, 64>), grid, dim3(256), 0, s, p);
+    if (ks32) {
+      if (in_f16) hipLaunchKernelGGL((pw_gemm_lds_kernel<true, 64, 32>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((pw_gemm_lds_kernel<false, 64, 32>), grid, dim3(256), 0, s, p);
+    } else {
+      if (in_f16) hipLaunchKernelGGL((pw_gemm_lds_kernel<true, 64>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((pw_gemm_lds_kernel<false, 64>), grid, dim3(256), 0, s, p);
+    }
   }
   PYTC_LAUNCH_CHECK("pw_gemm");
   return PYTC_OK;

@@ -178,15 +178,39 @@ __device__ __forceinline__ h2_t gelu_h2(h2_t x) {
   return __builtin_elementwise_max(x, (h2_t){(_Float16)0.0f, (_Float16)0.0f}) - p;
 }
 
-// eight fp32 pre-activations -> gelu -> the f16 B fragment of the next MFMA
+// eight fp32 pre-activations -> gelu -> the f16 B fragment of the next MFMA: gelu_h2 on four pairs, written step by step ACROSS the pairs.
+// The polynomial is a chain of dependent v_pk_fma_f16, and hipcc pads every dependent pair of them with an `s_nop 0` when it emits one
+// chain after the other (64 of the 201 instructions of a mixer's hidden-chunk loop were those nops); with each step's four independent
+// packed instructions side by side the next step's operands are four instructions old and the nops are gone.  Same operations per
+// element in the same order: same bits as four gelu_h2 calls.
 __device__ __forceinline__ h8_t gelu_h8_from_f32(const float (&v)[8]) {
+#define PYTC_H2C(c) ((h2_t){(_Float16)(c), (_Float16)(c)})
+  h2_t x[4], t[4], p[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) x[q] = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(v[2 * q], v[2 * q + 1]));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) t[q] = __builtin_elementwise_min(__builtin_elementwise_abs(x[q]), PYTC_H2C(3.75f));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) t[q] = t[q] * PYTC_H2C(2.0f / 3.75f) + PYTC_H2C(-1.0f);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) p[q] = PYTC_H2C(-6.166994737e-02f) * t[q] + PYTC_H2C(6.367329291e-02f);
+#define PYTC_STEP(c)                                                    \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) p[q] = p[q] * t[q] + PYTC_H2C(c);
+  PYTC_STEP(1.683184914e-01f)
+  PYTC_STEP(-3.056981228e-01f)
+  PYTC_STEP(7.903670132e-02f)
+  PYTC_STEP(1.852329106e-01f)
+  PYTC_STEP(-1.855973189e-01f)
+  PYTC_STEP(5.694380662e-02f)
+#undef PYTC_STEP
   h8_t out;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const h2_t g = gelu_h2(__builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(v[2 * q], v[2 * q + 1])));
+    const h2_t g = __builtin_elementwise_max(x[q], PYTC_H2C(0.0f)) - p[q];
     out[2 * q] = g[0];
     out[2 * q + 1] = g[1];
   }
+#undef PYTC_H2C
   return out;
 }
 

@@ -140,7 +140,7 @@ def gemm_sweep():
 
 TARGETS = {"gemm_sweep": gemm_sweep, "deep4": lambda: deep(8, 7, 512, 1024, 512), "deep3": lambda: deep(8, 14, 256, 512, 256),
            "deep3up": lambda: deep(8, 14, 512, 1024, 256), "deep2": lambda: deep(8, 28, 128, 256, 128),
-           "deep2up": lambda: deep(8, 28, 256, 512, 128), "deep4dn": lambda: deep(8, 7, 256, 512, 512),
+           "deep2up": lambda: deep(8, 28, 256, 512, 128), "deep4dn": lambda: deep(8, 7, 256, 512, 512), "deepL3": lambda: deep(2, 20, 256, 2048, 256), "deepL4": lambda: deep(2, 10, 512, 4096, 512),
            "copy0": lambda: copy(8, 112, 32), "copy64": lambda: copy(8, 112, 64), "mix0": lambda: mixer(8, 112, 32, 64, 32, "add"), "up0": lambda: mixer(8, 112, 64, 128, 32, "up"),
            "dw0": lambda: dw(8, 112, 32), "convT0": lambda: convT(8, 56, 64),
            "mix1": lambda: mixer(8, 56, 64, 128, 64, "add"), "up1": lambda: mixer(8, 56, 128, 256, 64, "up"),
