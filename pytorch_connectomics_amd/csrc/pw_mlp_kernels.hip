@@ -647,7 +647,7 @@ groupnorm_fold_mlp_kernel(const float* __restrict__ stats, int slots, float coun
   // in LDS in two fixed-order stages
   __shared__ __attribute__((aligned(16))) float red[1024 * 4];
   __shared__ float part[8][2 * 128];
-  __shared__ float sa[128], sb[128];
+  __shared__ float sa[128], sb[128], smean[128], sbeta[128];
   const int n = blockIdx.x, tid = threadIdx.x;
   const int Q = C / 2;                        // float4 columns of one slot row: [sum C | sum of squares C]
   const int col = tid % Q, sl = tid / Q, SL = 1024 / Q;
@@ -709,6 +709,8 @@ groupnorm_fold_mlp_kernel(const float* __restrict__ stats, int slots, float coun
       const float bv = (beta ? beta[tid] : 0.f) - mean * av;
       sa[tid] = av;
       sb[tid] = bv;
+      smean[tid] = mean;
+      sbeta[tid] = beta ? beta[tid] : 0.f;
       if (ab_out) {
         ab_out[((long)n * 2 + 0) * C + tid] = av;
         ab_out[((long)n * 2 + 1) * C + tid] = bv;
@@ -741,13 +743,26 @@ groupnorm_fold_mlp_kernel(const float* __restrict__ stats, int slots, float coun
     for (int j = 0; j < 8; ++j) v[j] *= sa[k + j];
     *reinterpret_cast<bf16x8_t*>(img + e8 * 8) = Mma<bf16_t>::from_floats(v);
   }
+  // Folded bias, centred with the weights the mixer will actually multiply by:  W2 (a (t - mean) + beta) + b2 = sum_k bf16(W2 a)_k (t_k - mean_k)
+  // + sum_k W2_k beta_k + b2 up to the rounding of (W2 a)_k TIMES (t_k - mean_k) -- the spread of the channel, not its offset.  (The first
+  // cut used b2 + W2 (beta - mean a) with the UNROUNDED product: the rounding error of every folded weight then met the channel's MEAN, an
+  // error that grows like |mean| / std relative to the affine-prologue form -- ADVICE r04.)  k ascending, fixed order.
   for (int o = tid; o < C_hid; o += 1024) {
     float acc = b2 ? b2[o] : 0.f;
     const float* wr = w2 + (long)o * C;
-    for (int k = 0; k < C; k += 4) {                  // 16-byte loads (a lane walks its own row: 64 lines per load instruction), k ascending
-      const f32x4_t w4 = *reinterpret_cast<const f32x4_t*>(wr + k);
+    for (int k = 0; k < C; k += 8) {                  // 16-byte loads (a lane walks its own row: 64 lines per load instruction), k ascending
+      const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(wr + k), w1 = *reinterpret_cast<const f32x4_t*>(wr + k + 4);
+      float v[8], wn[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = fmaf(w4[j], sb[k + j], acc);
+      for (int j = 0; j < 4; ++j) { v[j] = w0[j] * sa[k + j]; v[4 + j] = w1[j] * sa[k + 4 + j]; }
+      const bf16x8_t rounded = Mma<bf16_t>::from_floats(v);           // the very conversion that produced the image above
+      VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(&rounded), wn);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float wj = j < 4 ? w0[j] : w1[j - 4];
+        acc = fmaf(wj, sbeta[k + j], acc);
+        acc = fmaf(-wn[j], smean[k + j], acc);
+      }
     }
     b2n[(long)n * C_hid + o] = acc;
   }

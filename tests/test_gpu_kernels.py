@@ -260,8 +260,11 @@ def test_groupnorm_fold_into_the_expanding_conv(dev, C, chid, cout, mode):
     for n in range(N):
         img = ops.pw_pack_weight_paired((w2 * a[n][None, :]).to(dev))
         assert torch.equal(img.view(torch.int16), w2n[n].view(torch.int16)), n
-    want_b = (b2.double()[None] + b.double() @ w2.double().t()).float()
-    torch.testing.assert_close(b2n.cpu(), want_b, rtol=1e-5, atol=1e-5)
+    # (iii) the bias is centred with the ROUNDED folded weights: b2 + W2 beta - bf16(W2 a) mean, in fp64
+    mean = (s1 / rows).double()                                            # (N, C)
+    w2r = torch.stack([(w2 * a[n][None, :]).to(bf).double() for n in range(N)])      # (N, chid, C)
+    want_b = (b2.double()[None] + (w2.double() @ beta.double())[None] - torch.einsum("nok,nk->no", w2r, mean)).float()
+    torch.testing.assert_close(b2n.cpu(), want_b, rtol=2e-5, atol=2e-5)
     # the mixer on raw t
     hid = F.gelu((tf * a[:, None] + b[:, None]) @ w2.t() + b2)
     core = hid @ w3.t() + b3
@@ -292,6 +295,39 @@ def test_groupnorm_fold_into_the_expanding_conv(dev, C, chid, cout, mode):
     assert float(e_fold) <= 1.25 * float(e_aff) + 1e-4, (float(e_fold), float(e_aff))
     with pytest.raises(ValueError, match="norm-folded mixer operands"):
         ops.pw_mlp(t.to(dev), None, w2n[:1], b2n, w3p, b3.to(dev), **args)
+
+
+@pytest.mark.parametrize("offset", [0.0, 8.0, 64.0])
+def test_norm_fold_with_large_channel_offsets(dev, offset):
+    """channels with |mean| >> std (a large depthwise bias).  The folded form multiplies ROUNDED weights bf16(W2 a) by the raw
+    activation; with the bias folded at the unrounded product every weight's rounding error met the channel MEAN (error ~ |mean| / std
+    times the affine form's).  Centred with the rounded weights (groupnorm_fold_mlp_kernel) the error meets only the spread: the folded
+    mixer stays within 1.25x of the affine-prologue form's distance from the fp64 math at any offset."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(int(offset) + 3)
+    bf = torch.bfloat16
+    N, rows, C, chid, cout, slots = 2, 2000, 32, 64, 32, 11
+    t = (torch.randn(N, rows, C) + offset * (torch.rand(1, 1, C) + 0.5) * torch.sign(torch.randn(1, 1, C))).to(bf)
+    tf = t.double()
+    s1, s2 = tf.sum(1), (tf * tf).sum(1)
+    wts = torch.full((N, slots, 1), 1.0 / slots, dtype=torch.float64)
+    stats = torch.stack([wts * s1[:, None], wts * s2[:, None]], 2).float().contiguous().to(dev)
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.3
+    w2, b2 = torch.randn(chid, C) / C ** 0.5, torch.randn(chid) * 0.5
+    w3, b3 = torch.randn(cout, chid) / chid ** 0.5, torch.randn(cout) * 0.5
+    w2n, b2n, ab = ops.groupnorm_fold_mlp(stats, float(rows), gamma.to(dev), beta.to(dev), 1e-5, w2.to(dev), b2.to(dev), want_ab=True)
+    mean = s1 / rows
+    var = s2 / rows - mean * mean
+    a = gamma.double()[None] / torch.sqrt(var + 1e-5)
+    b = beta.double()[None] - mean * a
+    hid = F.gelu((tf * a[:, None] + b[:, None]) @ w2.double().t() + b2.double())
+    ref = (hid @ w3.double().t() + b3.double()).float()
+    w3p = ops.pw_pack_weight_paired(w3.to(dev), f16=True)
+    args = dict(N=N, rows_per_sample=rows, c_in=C, c_hid=chid, c_out=cout)
+    y = ops.pw_mlp(t.to(dev), None, w2n, b2n, w3p, b3.to(dev), **args).float().cpu()
+    y_aff = ops.pw_mlp(t.to(dev), ab, ops.pw_pack_weight_paired(w2.to(dev)), b2.to(dev), w3p, b3.to(dev), **args).float().cpu()
+    e_fold, e_aff = float((y - ref).abs().mean()), float((y_aff - ref).abs().mean())
+    assert e_fold <= 1.25 * e_aff + 1e-4, (offset, e_fold, e_aff)
 
 
 @pytest.mark.parametrize("cin,chid,cout,mode,N,rows", [(256, 512, 256, "add", 3, 1000), (512, 1024, 512, "add", 8, 343),
