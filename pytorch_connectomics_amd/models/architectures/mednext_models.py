@@ -66,6 +66,7 @@ def _infer_mednext_head_block_kwargs(model: nn.Module) -> dict:
 
 # narrow task heads run as one block-diagonal 32-channel head at inference (MedNeXtMultiHeadWrapper._merged_heads); 0 = one pass per head
 MERGE_NARROW_HEADS = os.environ.get("PYTC_MERGE_HEADS", "1") != "0"
+FUSE_MERGED_HEAD_PROJECTION = os.environ.get("PYTC_FUSE_MERGED_HEAD", "1") != "0"
 
 
 @dataclass(frozen=True)
@@ -173,8 +174,12 @@ class MedNeXtMultiHeadWrapper(ConnectomicsModel):
             return None
         hip = self.model._hip
         x = hip.pointwise(feat_cl, merged.input_projection)
-        for blk in merged.blocks:
-            x = hip.block(blk, x)
+        for i, blk in enumerate(merged.blocks):
+            # the out-projection rides in the last mixer's epilogue where the fused kernel can carry it (the trunk's own output conv does the
+            # same): (None, logits fp32) comes back and the block's 64 B / voxel are never written
+            x = hip.block(blk, x, head=merged.projection_t if (i + 1 == len(merged.blocks) and FUSE_MERGED_HEAD_PROJECTION) else None)
+        if isinstance(x, tuple):
+            return x[1]
         return hip.pointwise(x, merged.projection, out_dtype=torch.float32)
 
     def _merged_heads(self, feat_cl: torch.Tensor):
@@ -226,6 +231,10 @@ class MedNeXtMultiHeadWrapper(ConnectomicsModel):
                 m.projection.weight[c0:c1, ch] = h.projection.weight
                 m.projection.bias[c0:c1] = h.projection.bias
                 c0 = c1
+            # the same projection in the layout of the trunk's output conv (ConvTranspose3d: weight (in, out, 1, 1, 1)), which the fused head takes
+            m.projection_t = nn.ConvTranspose3d(Wp, m.projection.out_channels, kernel_size=1).to(dev)
+            m.projection_t.weight.copy_(m.projection.weight.reshape(m.projection.out_channels, Wp).t().reshape(Wp, -1, 1, 1, 1))
+            m.projection_t.bias.copy_(m.projection.bias)
             m.eval()
             for t in m.parameters():
                 t.requires_grad_(False)

@@ -364,6 +364,13 @@ def test_narrow_task_heads_merged_into_one_block_diagonal_head_match_the_per_hea
         scale = float(want[k].abs().max())
         err = (got[k] - want[k]).abs()
         assert got[k].shape == want[k].shape and float(err.max()) < 0.03 * scale and float(err.mean()) < 3e-3 * scale, (k, float(err.max()), scale)
+    # the merged out-projection in the last mixer's epilogue (default) against its own launch: same bf16 block output, same weights
+    with torch.no_grad():
+        monkeypatch.setattr(MM, "FUSE_MERGED_HEAD_PROJECTION", False)
+        unfused = model._merged_heads_cl(feat)
+        monkeypatch.setattr(MM, "FUSE_MERGED_HEAD_PROJECTION", True)
+    assert unfused.dtype == cat.dtype == torch.float32 and unfused.shape == cat.shape
+    torch.testing.assert_close(cat, unfused, rtol=1e-5, atol=1e-5 * float(unfused.abs().max()))
     # a head parameter changes -> the merged weights are rebuilt
     with torch.no_grad():
         model.heads["sdt"].projection.bias.add_(1.0)
