@@ -383,6 +383,12 @@ int pytc_pw_mlp_lds_fwd(const pytc_mlp_args* a, void* stream);
  * 64->128, 128->64, 128->128, 256->128; any C_hid that is a multiple of 32 up to 8192: MedNeXt-L's 128->1024->128, 256->2048->128,
  * 128->512->64, 64->512->128) -- csrc/pw_mlp_chunk_kernels.hip: the waves of a workgroup share each 32-wide hidden chunk's weight
  * fragments, streamed L2 -> LDS by DMA two chunks ahead; results are bit-identical to pytc_pw_mlp_fwd.  Same reference boundary. */
+/* The mixer of a 32-channel residual block with a 32 -> 32 1x1x1 conv of its bf16-rounded output in the epilogue, z = bf16(W y + b) -- the input
+ * projection of task heads behind the trunk's last block (reference: MedNeXtTaskHead.input_projection after dec_block_0, mednext_models.py:99-126;
+ * here the block-diagonal merged projection).  proj_w: paired bf16 image of W (pytc_pw_pack_weight_paired, 32 x 32); y is written only when
+ * store_y.  Per-sample (norm-folded) expand operands, fp16 projection image, C_hid in {64, 96, 128}. */
+int pytc_pw_mlp_proj_supported(int C_in, int C_hid, int C_out, int C_proj);
+int pytc_pw_mlp_proj_fwd(const pytc_mlp_args* a, const void* proj_w, const float* proj_b, void* z, int store_y, void* stream);
 int pytc_pw_mlp_chunk_supported(int C_in, int C_hid, int C_out);
 int pytc_pw_mlp_chunk_fwd(const pytc_mlp_args* a, void* stream);
 /* GroupNorm finalize + fold into the mixer's expanding conv, one launch (replaces pytc_groupnorm_finalize in front of an

@@ -35,6 +35,9 @@ struct MlpParams {
   const float* head_b;
   float* head_y;   // [N][rps][n_head] fp32
   int n_head, store_y;
+  // PROJ form of pw_mlp_dma_kernel: a 32 -> 32 conv of the block output in the epilogue (head_w = its paired bf16 image, 2 tiles x 64 lanes x 8;
+  // head_b = its bias [32]); z = bf16(W bf16(y) + b) goes to proj_y [N][rps][32], y itself only when store_y
+  bf16_t* proj_y;
   // STEMRES kernels: the block's residual is the stem output, recomputed from the 1-channel network input
   //   res[c] = bf16(stem_w[c] * stem_x[voxel] + stem_b[c])    (what the un-fused stem kernel would have stored)
   const float* stem_x;     // [N][rps] fp32
@@ -391,18 +394,19 @@ __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {     
 }
 
 // KIND 0: plain / residual-add epilogue; 1: the first block's residual rows recomputed from the raw input (pw_mlp_kernel's STEMRES: the row's
-// fp32 input voxel rides the DMA as a dword); 2: the last block with the output heads fused (pw_mlp_kernel's HEAD)
+// fp32 input voxel rides the DMA as a dword); 2: the last block with the output heads fused (pw_mlp_kernel's HEAD); 3: the last block with a
+// 32 -> 32 conv of its output fused (the input projection of merged task heads): the rounded block output is the B operand of two more MFMAs
 template <int HCT, int KIND>
 __global__ void __launch_bounds__(256, 3)
 pw_mlp_dma_kernel(MlpParams p, int waves_per_sample) {
   constexpr int NT = 4, CIN = 32, COUT = 32;
-  constexpr bool STEM = KIND == 1, HEAD = KIND == 2;
+  constexpr bool STEM = KIND == 1, HEAD = KIND == 2, PROJ = KIND == 3;
   // 32 KB of landing area + the sample's operands (the compiler's own loads of them inside the loop would share vmcnt with the DMA and, returning
   // in order behind it, wait for the prefetch they are meant to overlap): 40.4 KB at HCT = 2, 49.4 KB at 4 -> 3 workgroups per CU
   __shared__ __attribute__((aligned(16))) uint4 land[4][2][NT * 64];        // [wave][t | residual (STEM: input voxels)][tile][lane]
   __shared__ __attribute__((aligned(16))) uint4 w2s[HCT * 2 * 64], w3s[2 * HCT * 64];
   __shared__ __attribute__((aligned(16))) float b2s[HCT * 32], b3s[32];
-  __shared__ __attribute__((aligned(16))) float auxa[STEM ? 32 : (HEAD ? 256 : 4)], auxb[STEM ? 32 : (HEAD ? 16 : 4)];   // stem w, b / head image, bias
+  __shared__ __attribute__((aligned(16))) float auxa[STEM ? 32 : (HEAD ? 256 : (PROJ ? 512 : 4))], auxb[(STEM || PROJ) ? 32 : (HEAD ? 16 : 4)];   // stem w, b / head (projection) image, bias
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = blockIdx.y;
   const int r = lane & 15, kb = lane >> 4;
@@ -413,6 +417,7 @@ pw_mlp_dma_kernel(MlpParams p, int waves_per_sample) {
   const float* sx = STEM ? p.stem_x + (long)n * p.rps : nullptr;
   bf16_t* yn = reinterpret_cast<bf16_t*>(p.e.y) + (long)n * p.rps * COUT;
   float* hy = HEAD ? p.head_y + (long)n * p.rps * p.n_head : nullptr;
+  bf16_t* zn = PROJ ? p.proj_y + (long)n * p.rps * 32 : nullptr;
   {
     const uint4* w2 = reinterpret_cast<const uint4*>(p.w2 + (long)n * p.w2_stride);
     const uint4* w3 = reinterpret_cast<const uint4*>(p.w3);
@@ -425,6 +430,11 @@ pw_mlp_dma_kernel(MlpParams p, int waves_per_sample) {
     if constexpr (HEAD) {
       reinterpret_cast<float*>(auxa)[threadIdx.x] = reinterpret_cast<const float*>(p.head_w)[threadIdx.x];     // 64 lanes x 16 bytes
       if (threadIdx.x < 16) auxb[threadIdx.x] = (p.head_b && (int)threadIdx.x < p.n_head) ? p.head_b[threadIdx.x] : 0.f;
+    }
+    if constexpr (PROJ) {
+      auxa[threadIdx.x] = reinterpret_cast<const float*>(p.head_w)[threadIdx.x];                                 // 2 tiles x 64 lanes x 16 bytes
+      auxa[threadIdx.x + 256] = reinterpret_cast<const float*>(p.head_w)[threadIdx.x + 256];
+      if (threadIdx.x < 32) auxb[threadIdx.x] = p.head_b ? p.head_b[threadIdx.x] : 0.f;
     }
   }
   __syncthreads();
@@ -444,12 +454,14 @@ pw_mlp_dma_kernel(MlpParams p, int waves_per_sample) {
   };
   bf16x8_t out[NT];                                // results of the previous tile (stored at the start of the next iteration)
   f32x4_t hout[HEAD ? NT : 1];
+  bf16x8_t zout[PROJ ? NT : 1];
   auto store = [&](long tile) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const long row = tile * (NT * 16) + nt * 16 + r;
       if (row >= p.rps) continue;
-      if (!HEAD || p.store_y) *reinterpret_cast<bf16x8_t*>(yn + row * COUT + kb * 8) = out[nt];
+      if (!(HEAD || PROJ) || p.store_y) *reinterpret_cast<bf16x8_t*>(yn + row * COUT + kb * 8) = out[nt];
+      if constexpr (PROJ) *reinterpret_cast<bf16x8_t*>(zn + row * 32 + kb * 8) = zout[nt];
       if constexpr (HEAD) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -545,6 +557,16 @@ pw_mlp_dma_kernel(MlpParams p, int waves_per_sample) {
         const f32x4_t h = Mma<bf16_t>::mma(ah, out[nt], f32x4_t{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
         for (int i = 0; i < 4; ++i) hout[nt][i] = h[i] + hb[i];
+      }
+      if constexpr (PROJ) {
+        // z = W bf16(y) + b: accumulators start from the bias, one K = 32 MFMA per 16-channel tile, 8 consecutive channels per lane (paired rows)
+        f32x4_t z0 = *reinterpret_cast<const f32x4_t*>(&auxb[kb * 8]), z1 = *reinterpret_cast<const f32x4_t*>(&auxb[kb * 8 + 4]);
+        z0 = Mma<bf16_t>::mma(__builtin_bit_cast(bf16x8_t, reinterpret_cast<const uint4*>(auxa)[lane]), out[nt], z0);
+        z1 = Mma<bf16_t>::mma(__builtin_bit_cast(bf16x8_t, reinterpret_cast<const uint4*>(auxa)[64 + lane]), out[nt], z1);
+        float zv[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { zv[j] = z0[j]; zv[4 + j] = z1[j]; }
+        zout[nt] = Mma<bf16_t>::from_floats(zv);
       }
     }
     out_tile = tile;
@@ -979,6 +1001,36 @@ extern "C" int pytc_pw_mlp_stemres_fwd(const pytc_mlp_args* a, const float* stem
   else if (tuning_get("mlp_exact_gelu", 0) != 0) hipLaunchKernelGGL((pw_mlp_kernel<1, 2, 4, 0, false, true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((pw_mlp_kernel<1, 2, 4, 1, false, true>), grid, block, 0, s, p);
   PYTC_LAUNCH_CHECK("pw_mlp_stemres");
+  return PYTC_OK;
+}
+
+// The mixer of a 32-channel block with a 32 -> 32 1x1x1 conv of its (bf16-rounded) output in the epilogue: z = bf16(W y + b).  proj_w: the conv's
+// paired bf16 image (pytc_pw_pack_weight_paired, C_out = C_in = 32); y itself is written only when store_y.  Folded operands, fp16 projection
+// image of the mixer, hidden width 64 / 96 / 128 (the shapes of pw_mlp_dma_kernel; any row count).
+extern "C" int pytc_pw_mlp_proj_supported(int C_in, int C_hid, int C_out, int C_proj) {
+  return (C_in == 32 && C_out == 32 && C_proj == 32 && (C_hid == 64 || C_hid == 96 || C_hid == 128)) ? 1 : 0;
+}
+extern "C" int pytc_pw_mlp_proj_fwd(const pytc_mlp_args* a, const void* proj_w, const float* proj_b, void* z, int store_y, void* stream) {
+  PYTC_REQUIRE(a && a->t && a->w2_packed && a->w3_packed && a->b2 && a->b3 && proj_w && z, "pw_mlp_proj: null pointer");
+  PYTC_REQUIRE(a->per_sample && !a->ab, "pw_mlp_proj: takes the per-sample (norm-folded) expand operands");
+  PYTC_REQUIRE(a->w3_format == PYTC_W3_F16, "pw_mlp_proj: the mixer's projection image must be fp16 (pytc_pw_pack_weight_paired_f16)");
+  PYTC_REQUIRE(!store_y || a->y, "pw_mlp_proj: store_y without an output buffer");
+  PYTC_REQUIRE(a->N >= 1 && a->rows_per_sample >= 1, "pw_mlp_proj: bad shape");
+  if (!pytc_pw_mlp_proj_supported(a->C_in, a->C_hid, a->C_out, 32)) {
+    set_error("pw_mlp_proj: no fused kernel for C_in=%d C_hid=%d C_out=%d", a->C_in, a->C_hid, a->C_out);
+    return PYTC_ERR_UNSUPPORTED;
+  }
+  PYTC_REQUIRE(a->res_mode == PYTC_RES_NONE || (a->res_mode == PYTC_RES_ADD && a->res), "pw_mlp_proj: residual add or none");
+  MlpParams p{};
+  p.t = (const bf16_t*)a->t; p.ab = nullptr; p.w2 = (const bf16x8_t*)a->w2_packed; p.b2 = a->b2;
+  p.w3 = (const bf16x8_t*)a->w3_packed; p.b3 = a->b3;
+  p.rps = a->rows_per_sample; p.C_in = a->C_in; p.C_hid = a->C_hid; p.C_out = a->C_out; p.HC = a->C_hid / 32;
+  p.w2_stride = (long)(a->C_hid / 16) * (a->C_in / 32) * 64;
+  p.e.res = a->res; p.e.y = a->y; p.e.rps_out = a->rows_per_sample; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode;
+  p.head_w = (const bf16x8_t*)proj_w; p.head_b = proj_b; p.proj_y = (bf16_t*)z; p.store_y = store_y;
+  p.w3_f16 = 1;
+  mlp_dma_launch<3>(a, p, (hipStream_t)stream);
+  PYTC_LAUNCH_CHECK("pw_mlp_proj");
   return PYTC_OK;
 }
 

@@ -807,6 +807,36 @@ def pw_mlp_bwd(dy: torch.Tensor, hidden_pre: torch.Tensor, w3t_p: torch.Tensor, 
     return dx, dh
 
 
+def pw_mlp_proj_supported(c_in: int, c_hid: int, c_out: int, c_proj: int) -> bool:
+    return bool(nat.lib().pytc_pw_mlp_proj_supported(int(c_in), int(c_hid), int(c_out), int(c_proj)))
+
+
+def pw_mlp_proj(t: torch.Tensor, w2n: torch.Tensor, b2n: torch.Tensor, w3p: torch.Tensor, b3: torch.Tensor, proj_w: torch.Tensor,
+                proj_b: Optional[torch.Tensor], *, N: int, rows_per_sample: int, c_in: int, c_hid: int, c_out: int,
+                res: Optional[torch.Tensor] = None, store_y: bool = False):
+    """pw_mlp of a 32-channel block (norm-folded operands) with a 32 -> 32 conv of its output in the epilogue -> (y | None, z (N, rows, 32)
+    bf16 = bf16(W bf16(y) + b)).  proj_w: pw_pack_weight_paired of the conv's (32, 32) weight."""
+    _dev(t, "t"); _dev(proj_w, "proj_w")
+    if t.dtype != torch.bfloat16 or proj_w.dtype != torch.bfloat16 or proj_w.numel() != 32 * 32:
+        raise TypeError("pw_mlp_proj runs on bfloat16 activations and the paired bf16 image of a 32 x 32 projection")
+    y = torch.empty((N, rows_per_sample, c_out), dtype=torch.bfloat16, device=t.device) if store_y else None
+    z = torch.empty((N, rows_per_sample, 32), dtype=torch.bfloat16, device=t.device)
+    a = nat.MlpArgs()
+    a.t, a.ab, a.w2_packed, a.b2, a.w3_packed, a.b3 = t.data_ptr(), None, w2n.data_ptr(), b2n.data_ptr(), w3p.data_ptr(), b3.data_ptr()
+    a.per_sample = _folded_operands(None, w2n, b2n, N, c_in, c_hid)
+    a.w3_format = _w3_format(w3p)
+    a.res = res.data_ptr() if res is not None else None
+    a.res_low = a.res_bias = None
+    a.y = y.data_ptr() if y is not None else None
+    a.N, a.rows_per_sample, a.C_in, a.C_hid, a.C_out = N, rows_per_sample, c_in, c_hid, c_out
+    a.res_mode = nat.RES_ADD if res is not None else nat.RES_NONE
+    a.Di = a.Hi = a.Wi = 0
+    nb = N * rows_per_sample * 2 * (c_in + (c_out if res is not None else 0) + (c_out if store_y else 0) + 32)
+    _run(f"pw_mlp_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_proj_fwd, C.byref(a), _p(proj_w), _p(proj_b), _p(z),
+         int(store_y), _stream(), symbol=f"pw_mlp_dma_kernel<{c_hid // 32}, 3>+proj")
+    return y, z
+
+
 def pw_mlp_head_supported(c_in: int, c_hid: int, c_out: int) -> bool:
     return bool(nat.lib().pytc_pw_mlp_head_supported(int(c_in), int(c_hid), int(c_out)))
 

@@ -294,9 +294,12 @@ class HipBlockOps:
         return y.view(N, *spatial, c_out)
 
     def block(self, m: MedNeXtBlock, x: torch.Tensor, skip: Optional[torch.Tensor] = None, head: Optional[nn.Module] = None,
-              out: Optional[torch.Tensor] = None):
+              out: Optional[torch.Tensor] = None, proj: Optional[nn.Module] = None):
         """head: the network's output conv; when the fused mixer can carry it in its epilogue the block returns
         (None, logits fp32 (N, D, H, W, n_classes)) instead of its bf16 output.
+        proj: a 32 -> 32 1x1x1 Conv3d applied to the block's output (the merged input projection of task heads): when the fused mixer
+        can carry it the block returns (None, z bf16 (N, D, H, W, 32)) and its own output is never written; otherwise the block's output
+        comes back as usual and the caller applies the conv.
         out: a dense buffer of the block's output shape (a sample slice of a batch tensor): the fused bf16 mixer writes its
         result there directly, every other schedule copies into it; the return value is `out` then (not with `head`).
 
@@ -315,11 +318,11 @@ class HipBlockOps:
                     sk3[:, 1] = skip[:, 0]
                 y = self._block(m, x, sk3, None)[:, 1:2].contiguous()
                 return y if out is None else out.copy_(y)
-        return self._block(m, x, skip, head, out)
+        return self._block(m, x, skip, head, out, proj)
 
     def _block(self, m: MedNeXtBlock, x: torch.Tensor, skip: Optional[torch.Tensor] = None, head: Optional[nn.Module] = None,
-               out: Optional[torch.Tensor] = None):
-        y = self._block_any(m, x, skip, head, out)
+               out: Optional[torch.Tensor] = None, proj: Optional[nn.Module] = None):
+        y = self._block_any(m, x, skip, head, out, proj)
         if out is None or isinstance(y, tuple) or y is out:
             return y
         if y.data_ptr() == out.data_ptr():          # written in place by the fused mixer (a view of `out`)
@@ -327,7 +330,7 @@ class HipBlockOps:
         return out.copy_(y.view(out.shape))
 
     def _block_any(self, m: MedNeXtBlock, x: torch.Tensor, skip: Optional[torch.Tensor] = None, head: Optional[nn.Module] = None,
-                   out: Optional[torch.Tensor] = None):
+                   out: Optional[torch.Tensor] = None, proj: Optional[nn.Module] = None):
         is_ln = isinstance(m.norm, _ChannelLayerNorm)
         if not is_ln and not isinstance(m.norm, nn.GroupNorm):
             raise NotImplementedError(f"unsupported MedNeXt norm module {type(m.norm).__name__}")
@@ -346,6 +349,7 @@ class HipBlockOps:
         if (kind == "block" and self.fused and self.fuse_block and self.fold_norm and dt == torch.bfloat16 and K == 3 and not m.grn and not is_ln
                 and m.dim == "3d" and m.conv2.bias is not None and m.conv3.bias is not None and ops.MLP_F16_PROJECT
                 and ops.dwmix_supported(x, c_hid, c_out) and ops.groupnorm_fold_mlp_supported(C, c_hid)
+                and proj is None
                 and (head is None or (head.weight.shape[1] <= 16 and ops.pw_mlp_head_supported(C, c_hid, c_out)))):
             return self._block_dwmix(m, x, taps, b1, c_hid, c_out, head, out)
         if kind == "up":
@@ -385,6 +389,12 @@ class HipBlockOps:
                                             rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out,
                                             res=x if m.do_res else None, store_y=False)
                 return None, logits.view(N, Do, Ho, Wo, -1)
+            if (proj is not None and head is None and out is None and kind == "block" and ab is None and ops.MLP_F16_PROJECT
+                    and tuple(proj.weight.shape[:2]) == (32, c_out) and ops.pw_mlp_proj_supported(C, c_hid, c_out, 32)):
+                _, z = ops.pw_mlp_proj(t, w2x, b2x, self._pw_paired(m.conv3, project=True), self._vec(m.conv3, "bias", m.conv3.bias),
+                                       self._pw_paired(proj), self._vec(proj, "bias", proj.bias), N=N, rows_per_sample=rows, c_in=C,
+                                       c_hid=c_hid, c_out=c_out, res=x if m.do_res else None, store_y=False)
+                return None, z.view(N, Do, Ho, Wo, 32)
             return self._block_fused(m, x, t, ab, skip, (N, D, H, W, C), (Do, Ho, Wo), c_hid, c_out, out, w2x, b2x)
         if not is_ln:
             ab = ops.groupnorm_finalize(st, count, gamma, beta, m.norm.eps)
@@ -714,9 +724,10 @@ class MedNeXt(nn.Module):
         return y.squeeze(2)
 
     def features_cl(self, x_cl: torch.Tensor, collect: Optional[List[torch.Tensor]] = None,
-                    head: Optional[nn.Module] = None):
+                    head: Optional[nn.Module] = None, proj: Optional[nn.Module] = None):
         """Channels-last in (N,D,H,W,C_in) fp32/bf16 -> channels-last full-resolution features.  With `head` (the output
-        conv) the last block may return (None, logits) instead -- see HipBlockOps.block."""
+        conv) the last block may return (None, logits) instead, with `proj` (a 32 -> 32 conv of the features) (None, proj(features)) --
+        see HipBlockOps.block."""
         hip = self._hip
         dt = resolve_compute_dtype(self.compute_dtype)
         spatial = x_cl.shape[2:4] if self.dim == "2d" else x_cl.shape[1:4]
@@ -753,7 +764,7 @@ class MedNeXt(nn.Module):
             blocks = list(self.dec_block_0)
             for bi, blk in enumerate(blocks):
                 last = bi == len(blocks) - 1
-                h = hip.block(blk, h, head=head if last else None, out=y_out if last else None)
+                h = hip.block(blk, h, head=head if last else None, out=y_out if last else None, proj=proj if last else None)
             if not blocks and y_out is not None:
                 h = y_out.copy_(h)
             return h

@@ -172,8 +172,12 @@ class MedNeXtMultiHeadWrapper(ConnectomicsModel):
         merged = self._merged_heads(feat_cl) if (MERGE_NARROW_HEADS and not torch.is_grad_enabled()) else None
         if merged is None:
             return None
+        return self._run_merged(merged, hip_in=None, feat_cl=feat_cl)
+
+    def _run_merged(self, merged, hip_in: Optional[torch.Tensor], feat_cl: Optional[torch.Tensor]) -> torch.Tensor:
+        """the merged head on the trunk's features, or (hip_in) on features the trunk's last mixer has already projected"""
         hip = self.model._hip
-        x = hip.pointwise(feat_cl, merged.input_projection)
+        x = hip_in if hip_in is not None else hip.pointwise(feat_cl, merged.input_projection)
         for i, blk in enumerate(merged.blocks):
             # the out-projection rides in the last mixer's epilogue where the fused kernel can carry it (the trunk's own output conv does the
             # same): (None, logits fp32) comes back and the block's 64 B / voxel are never written
@@ -263,6 +267,18 @@ class MedNeXtMultiHeadWrapper(ConnectomicsModel):
 
     def forward_cl(self, x_cl: torch.Tensor) -> torch.Tensor:
         """Channels-last fast path: all heads concatenated along C in declaration order."""
+        from .mednext import resolve_compute_dtype
+        merged = None
+        if MERGE_NARROW_HEADS and FUSE_MERGED_HEAD_PROJECTION and not torch.is_grad_enabled():
+            # the merged input projection rides in the epilogue of the trunk's last mixer where the fused kernel can carry it: the features
+            # themselves (64 B / voxel written, read back) never exist
+            probe = torch.empty((0, 1, 1, 1, self.feature_channels), dtype=resolve_compute_dtype(self.model.compute_dtype), device=x_cl.device)
+            merged = self._merged_heads(probe)
+        if merged is not None:
+            feat_cl = self.model.features_cl(x_cl, proj=merged.input_projection)
+            if isinstance(feat_cl, tuple):
+                return self._run_merged(merged, hip_in=feat_cl[1], feat_cl=None)
+            return self._run_merged(merged, hip_in=None, feat_cl=feat_cl)
         feat_cl = self.model.features_cl(x_cl)
         y = self._merged_heads_cl(feat_cl)
         if y is not None:

@@ -524,6 +524,40 @@ def test_chunk_streamed_mixer_refuses_what_it_does_not_cover(dev):
                    torch.zeros(128, device=dev), N=1, rows_per_sample=64, c_in=128, c_hid=256, c_out=128, chunked=True)
 
 
+@pytest.mark.parametrize("N,rows,chid,add", [(1, 1, 64, True), (2, 63, 96, False), (3, 1000, 128, True), (2, 4097, 96, True)])
+def test_mixer_with_a_projection_in_its_epilogue(dev, N, rows, chid, add):
+    """pytc_pw_mlp_proj_fwd (round 5): the 32-channel mixer with a 32 -> 32 conv of its output in the epilogue (merged task heads' input
+    projection): y (store_y) carries the bits of the plain mixer; z = bf16(W bf16(y) + b) equals the conv launched on y up to where the
+    bias enters the fp32 sum (accumulators start from it here): at most one bf16 ulp, on a small fraction of the outputs."""
+    from pytorch_connectomics_amd import _native as nat
+    from pytorch_connectomics_amd import hip_ops as ops
+    bf = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(rows + chid)
+    t = torch.randn(N, rows, 32, generator=g).to(bf).to(dev)
+    res = torch.randn(N, rows, 32, generator=g).to(bf).to(dev) if add else None
+    w2n = torch.stack([ops.pw_pack_weight_paired((torch.randn(chid, 32, generator=g) / 32 ** 0.5).to(dev)) for _ in range(N)])
+    b2n = torch.randn(N, chid, generator=g).to(dev)
+    w3 = ops.pw_pack_weight_paired((torch.randn(32, chid, generator=g) / chid ** 0.5).to(dev), f16=True)
+    b3 = torch.randn(32, generator=g).to(dev)
+    wp = (torch.randn(32, 32, generator=g) / 32 ** 0.5).to(dev)
+    bp = torch.randn(32, generator=g).to(dev)
+    wpp = ops.pw_pack_weight_paired(wp)
+    kw = dict(N=N, rows_per_sample=rows, c_in=32, c_hid=chid, c_out=32)
+    assert ops.pw_mlp_proj_supported(32, chid, 32, 32) and not ops.pw_mlp_proj_supported(64, 128, 64, 32)
+    y_ref = ops.pw_mlp(t, None, w2n, b2n, w3, b3, res=res, res_mode=nat.RES_ADD if add else nat.RES_NONE, **kw)
+    z_ref = ops.pw_conv(y_ref, wpp, bp, N=N, rows_per_sample=rows, c_in=32, c_out=32, out_dtype=bf, w_paired=True)
+    y, z = ops.pw_mlp_proj(t, w2n, b2n, w3, b3, wpp, bp, res=res, store_y=True, **kw)
+    none, z2 = ops.pw_mlp_proj(t, w2n, b2n, w3, b3, wpp, bp, res=res, store_y=False, **kw)
+    assert none is None and torch.equal(y, y_ref) and torch.equal(z, z2)
+    zf, rf = z.float(), z_ref.float()
+    diff = (zf - rf).abs()
+    assert float((diff > 0).float().mean()) < 0.02, float((diff > 0).float().mean())
+    assert bool((diff <= rf.abs() * 2.0 ** -7 + 1e-30).all()), float((diff / rf.abs().clamp_min(1e-6)).max())
+    # and against fp64 math on the rounded y
+    want = (y_ref.double() @ wp.to(bf).double().t() + bp.double()).float()
+    torch.testing.assert_close(zf, want, rtol=2.0 ** -7, atol=1e-3)
+
+
 def test_lds_resident_mixer_refuses_what_it_does_not_cover(dev):
     from pytorch_connectomics_amd import _native as nat
     from pytorch_connectomics_amd import hip_ops as ops

@@ -371,6 +371,22 @@ def test_narrow_task_heads_merged_into_one_block_diagonal_head_match_the_per_hea
         monkeypatch.setattr(MM, "FUSE_MERGED_HEAD_PROJECTION", True)
     assert unfused.dtype == cat.dtype == torch.float32 and unfused.shape == cat.shape
     torch.testing.assert_close(cat, unfused, rtol=1e-5, atol=1e-5 * float(unfused.abs().max()))
+    # the whole channels-last forward: the merged INPUT projection in the epilogue of the trunk's last mixer (pytc_pw_mlp_proj_fwd: the
+    # features are never written) against features -> projection launch; one bf16 rounding of z may fall differently (bias-first accumulate)
+    with torch.no_grad():
+        whole = model.forward_cl(x)
+        monkeypatch.setattr(MM, "FUSE_MERGED_HEAD_PROJECTION", False)
+        whole_unfused = model.forward_cl(x)
+        monkeypatch.setattr(MM, "FUSE_MERGED_HEAD_PROJECTION", True)
+    assert whole.shape == whole_unfused.shape == cat.shape and whole.dtype == torch.float32
+    scale = float(whole_unfused.abs().max())
+    err = (whole - whole_unfused).abs()
+    assert float(err.max()) < 0.01 * scale and float(err.mean()) < 5e-4 * scale, (float(err.max()), float(err.mean()), scale)
+    from pytorch_connectomics_amd import hip_ops as ops
+    with ops.profiled() as prof, torch.no_grad():                # ... and it is that kernel which ran
+        model.forward_cl(x)
+    torch.cuda.synchronize()
+    assert any(str(r[5]).endswith("+proj") for r in prof.records), sorted({str(r[5]) for r in prof.records})
     # a head parameter changes -> the merged weights are rebuilt
     with torch.no_grad():
         model.heads["sdt"].projection.bias.add_(1.0)
