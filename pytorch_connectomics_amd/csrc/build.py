@@ -169,7 +169,7 @@ def build_h5(verbose: bool = True):
     if H5_LIB.exists() and H5_LIB.stat().st_mtime >= H5_SRC.stat().st_mtime:
         return H5_LIB
     LIB_DIR.mkdir(exist_ok=True)
-    cmd = ["gcc", "-O2", "-fPIC", "-shared", f"-I{root}/include", str(H5_SRC), f"-L{root}/lib", "-lhdf5", "-lz", "-lpthread",
+    cmd = ["gcc", "-O2", "-fPIC", "-shared", f"-I{root}/include", str(H5_SRC), f"-L{root}/lib", "-lhdf5", "-lz", "-lpthread", "-ldl",
            f"-Wl,-rpath,{root}/lib", "-o", str(H5_LIB)]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)

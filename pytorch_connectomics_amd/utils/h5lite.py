@@ -74,6 +74,8 @@ def _load():
         "pytc_h5_dset_write": (C.c_int, [i64, C.c_int, p64, p64, C.c_void_p, C.c_int]),
         "pytc_h5_dset_read": (C.c_int, [i64, C.c_int, p64, p64, C.c_void_p, C.c_int]),
         "pytc_h5_dset_write_parallel": (C.c_int, [i64, C.c_int, p64, p64, C.c_void_p, C.c_int, C.c_int]),
+        "pytc_h5_write_parallel_stats": (None, [C.POINTER(C.c_double)]),
+        "pytc_h5_deflate_backend": (C.c_int, []),
         "pytc_h5_attr_write": (C.c_int, [i64, C.c_char_p, C.c_int, C.c_char_p, i64, C.c_double]),
         "pytc_h5_attr_count": (C.c_int, [i64]),
         "pytc_h5_attr_name": (C.c_int, [i64, C.c_int, C.c_char_p, C.c_int]),
@@ -111,7 +113,41 @@ def write_threads() -> int:
         n = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         n = os.cpu_count() or 1
+    q = _cgroup_cpu_quota()
+    if q is not None:
+        n = min(n, max(1, int(2 * q + 0.5)))          # two workers per granted core: the serialized H5Dwrite_chunk calls overlap with deflate
     return max(1, min(128, n))
+
+
+def _cgroup_cpu_quota() -> Optional[float]:
+    """CPUs the container may use at once (cgroup v2 cpu.max, v1 cfs quota / period), or None when unlimited / unknown.  The MI355X boxes
+    show 256 cores in the affinity mask under a quota of 16: 128 deflate threads there run no faster than 16 and pay for the oversubscription
+    (1.9 against 1.56 s per 0.92 GB chunk, tools/r05_h5_threads.py)."""
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt and txt[0] != "max":
+            return float(txt[0]) / float(txt[1])
+        return None
+    except (OSError, ValueError, IndexError):
+        pass
+    try:
+        quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return quota / period if quota > 0 and period > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
+def last_parallel_write_stats() -> Optional[dict]:
+    """Where the last parallel chunk write of this process spent its time (csrc/host/h5io.c): thread-seconds of gather and deflate summed over the
+    workers, seconds inside the serialized H5Dwrite_chunk calls, wall seconds, workers; None without the library."""
+    lib = _load()
+    if lib is None:
+        return None
+    out = (C.c_double * 5)()
+    lib.pytc_h5_write_parallel_stats(out)
+    return {"gather_thread_s": out[0], "deflate_thread_s": out[1], "h5_write_serial_s": out[2], "wall_s": out[3], "threads": int(out[4]),
+            "deflate": "libdeflate" if lib.pytc_h5_deflate_backend() else "zlib"}
 
 
 def _need():

@@ -1,6 +1,8 @@
 """Host logic of the prediction transforms and the artifact writer (reference semantics: inference/output.py:150-243,
 inference/artifact.py:15-240); expectations restate the reference's numpy operations."""
 import json
+import os
+from pathlib import Path
 from types import SimpleNamespace as NS
 
 import numpy as np
@@ -315,3 +317,46 @@ def test_parallel_deflate_writer_round_trips_and_matches_the_serial_writer(tmp_p
         d[...] = src2
     with h5lite.File(tmp_path / "raw.h5", "r") as f:
         assert np.array_equal(f["main"][...], src2)
+
+
+def test_parallel_writer_deflate_backends_and_thread_policy(tmp_path, monkeypatch):
+    """The deflate workers use libdeflate when the image has it (bound at run time, no header) and zlib otherwise or under PYTC_H5_DEFLATE=zlib:
+    both produce zlib streams that HDF5's own gzip filter inflates back to the source.  The backend is chosen once per process, so the
+    zlib arm runs in a child process.  write_threads() honours a cgroup CPU quota (two workers per granted core)."""
+    import subprocess
+    import sys
+    import numpy as np
+    from pytorch_connectomics_amd.utils import h5lite
+    if not h5lite.available():
+        pytest.skip("libpytc_h5.so not built")
+    rng = np.random.default_rng(1)
+    data = (1.0 / (1.0 + np.exp(-rng.standard_normal((2, 70, 64, 130)).astype(np.float32)))).astype(np.float32)
+    np.save(tmp_path / "src.npy", data)
+    monkeypatch.setattr(h5lite, "PARALLEL_WRITE_MIN_BYTES", 1)
+    monkeypatch.setenv("PYTC_H5_THREADS", "3")
+    with h5lite.File(tmp_path / "here.h5", "w") as f:
+        f.create_dataset("main", data=data, chunks=(2, 64, 64, 64), compression="gzip")
+    st = h5lite.last_parallel_write_stats()
+    assert st["deflate"] in ("libdeflate", "zlib") and st["threads"] == 3 and st["deflate_thread_s"] > 0 and st["wall_s"] > 0
+    child = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {str(Path(__file__).resolve().parents[1])!r})\n"
+        "from pytorch_connectomics_amd.utils import h5lite\n"
+        "h5lite.PARALLEL_WRITE_MIN_BYTES = 1\n"
+        f"data = np.load({str(tmp_path / 'src.npy')!r})\n"
+        f"with h5lite.File({str(tmp_path / 'zlib.h5')!r}, 'w') as f:\n"
+        "    f.create_dataset('main', data=data, chunks=(2, 64, 64, 64), compression='gzip')\n"
+        "print(h5lite.last_parallel_write_stats()['deflate'])\n")
+    env = dict(os.environ, PYTC_H5_DEFLATE="zlib", PYTC_H5_THREADS="3")
+    out = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "zlib"
+    for name in ("here.h5", "zlib.h5"):
+        with h5lite.File(tmp_path / name, "r") as f:
+            assert f["main"].compression == "gzip" and np.array_equal(f["main"][...], data), name
+    # thread policy: PYTC_H5_THREADS wins; otherwise a quota of q CPUs gives 2 q workers (at most 128, at most the affinity mask)
+    monkeypatch.delenv("PYTC_H5_THREADS")
+    monkeypatch.setattr(h5lite, "_cgroup_cpu_quota", lambda: 1.0)
+    assert h5lite.write_threads() == min(2, len(os.sched_getaffinity(0)))
+    monkeypatch.setattr(h5lite, "_cgroup_cpu_quota", lambda: None)
+    assert h5lite.write_threads() == min(128, len(os.sched_getaffinity(0)))
