@@ -487,7 +487,9 @@ def c4_chunked_leg(dev):
                 fsz = (Path(td) / "chunk_z0_y0_x0.h5").stat().st_size
             write = {"d2h_seconds": t1 - t0, "write_seconds": t2 - t1, "threads": h5lite.write_threads(), "bytes": int(host.nbytes),
                      "file_bytes": int(fsz), "MB_per_s": host.nbytes / 1e6 / max(t2 - t1, 1e-9),
-                     "note": "gzip level 4 on uniform-random-like sigmoid outputs (near-incompressible: the worst case for zlib)"}
+                     "writer": h5lite.last_parallel_write_stats(),
+                     "note": "gzip level 4 on uniform-random-like sigmoid outputs (near-incompressible: the worst case for deflate); "
+                             "writer = thread-seconds of gather / deflate, seconds inside the serialized H5Dwrite_chunk calls, backend"}
     except Exception as exc:  # noqa: BLE001
         write = {"error": f"{type(exc).__name__}: {exc}"}
     kept.clear()
