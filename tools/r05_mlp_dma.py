@@ -1,5 +1,7 @@
 """Level-0 mixer with LDS-DMA prefetch (pw_mlp_dma_kernel) against the one-tile-per-wave kernel: bit identity on ragged shapes, then time
-per launch at the network's level-0 shape, alternating, with a sweep of workgroups per sample.  python tools/r05_mlp_dma.py [check] [time]"""
+per launch at the network's level-0 shape, alternating, with a sweep of workgroups per sample; `chunk`: the chunk-streamed mixer of the wide hidden
+layers against the streaming / LDS-resident kernels.  python tools/r05_mlp_dma.py [check] [time] [chunk]
+(The `lds` mode that produced the last section of profiles/r05_mlp_dma_prefetch.txt -- the same prefetch inside pw_mlp_lds_kernel -- went with that code.)"""
 import os
 import sys
 
@@ -148,48 +150,6 @@ def time():
     knob("mlp_dma_wgs", 0)
 
 
-def lds_mixers():
-    """the LDS-resident persistent mixer (mid levels, level-0 up block) with and without the DMA prefetch: bits, then time per variant"""
-    for cin, chid, cout, mode, N, D in [(64, 128, 32, "up", 8, 112), (64, 128, 64, "add", 8, 56), (64, 128, 64, "add", 3, 9), (64, 128, 32, "up", 2, 6),
-                                        (64, 128, 64, "none", 2, 20)]:
-        rows = D ** 3
-        g = torch.Generator(device="cpu").manual_seed(rows)
-        t = torch.randn(N, rows, cin, generator=g).to(bf).to(dev)
-        res = torch.randn(N, rows, cout, generator=g).to(bf).to(dev)
-        w2n = torch.stack([ops.pw_pack_weight_paired((torch.randn(chid, cin, generator=g) / cin ** 0.5).to(dev)) for _ in range(N)])
-        b2n = torch.randn(N, chid, generator=g).to(dev)
-        w3 = ops.pw_pack_weight_paired((torch.randn(cout, chid, generator=g) / chid ** 0.5).to(dev), f16=True)
-        b3 = torch.randn(cout, generator=g).to(dev)
-        kw = dict(N=N, rows_per_sample=rows, c_in=cin, c_hid=chid, c_out=cout)
-        nbytes = N * rows * 2 * (cin + cout + (cout if mode != "none" else 0))
-        if mode == "add":
-            kw.update(res=res, res_mode=nat.RES_ADD)
-        elif mode == "up":
-            low = torch.randn(N, rows // 8, cout, generator=g).to(bf).to(dev)
-            kw.update(res=res, res_mode=nat.RES_UPSAMPLE, grid=(D, D, D), res_low=low, res_bias=b3)
-            nbytes += low.numel() * 2
-        want = ops.pw_mlp(t, None, w2n, b2n, w3, b3, **kw)
-        y = torch.empty_like(want)
-        combos = [(v, d, 0) for v in (1, 2, 3, 4) for d in (0, 1)] + [(v, d, c) for v in (2, 4) for d in (0, 1) for c in (48, 192, 768, 3072)]
-        for rnd in range(2 if rows > 100000 else 1):
-            for variant, dma, chunk in combos:
-                if True:
-                    knob("mlp_lds_variant", variant)
-                    knob("mlp_lds_dma", dma)
-                    knob("mlp_lds_chunk", chunk)
-                    y.fill_(float("nan"))
-                    ops.pw_mlp(t, None, w2n, b2n, w3, b3, y=y, lds=True, **kw)
-                    torch.cuda.synchronize()
-                    ok = torch.equal(y.view(torch.int16), want.view(torch.int16))
-                    us = timeit(lambda: ops.pw_mlp(t, None, w2n, b2n, w3, b3, y=y, lds=True, **kw)) if rows > 100000 else 0.0
-                    print(f"lds mixer {cin}->{chid}->{cout} {mode} x{N} {D}^3 variant {variant} dma {dma} chunk {chunk}: {'bit-identical' if ok else 'MISMATCH'}"
-                          f"  {us:8.1f} us  {nbytes / max(us, 1e-9) / 1e3:7.1f} GB/s", flush=True)
-                    assert ok
-    knob("mlp_lds_variant", 0)
-    knob("mlp_lds_chunk", 0)
-    knob("mlp_lds_dma", 1)
-
-
 def chunk_mixers():
     """the chunk-streamed mixer (wide hidden layers) against the streaming kernel: bits on ragged shapes, then time per variant at MedNeXt-L's"""
     shapes = [(128, 1024, 128, "add", 2, 7), (128, 1024, 128, "none", 1, 3), (256, 2048, 128, "up", 2, 6), (128, 512, 64, "up", 3, 4),
@@ -253,7 +213,5 @@ if __name__ == "__main__":
     if "time" in what:
         time_kinds()
         time()
-    if "lds" in what:
-        lds_mixers()
     if "chunk" in what:
         chunk_mixers()
