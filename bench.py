@@ -637,8 +637,13 @@ def _kernel_key(label):
     kernels that run at several shapes have no counter average of their own."""
     import re
     m = re.match(r"pw_mlp_fwd\[(\d+)->(\d+)->(\d+)\]", label)
-    if m:      # streaming or LDS-resident form (pw_mlp_lds_kernel<KS_IN, MO, NT, NWAVES, WPS>): whichever the shape runs on
-        return re.compile(rf"pw_mlp(_lds)?_kernel<{int(m.group(1)) // 32}, {int(m.group(3)) // 16},")
+    if m:      # streaming, LDS-resident (pw_mlp_lds_kernel<KS_IN, MO, NT, NWAVES, WPS>) or chunk-streamed form (pw_mlp_chunk_kernel<KS_IN, MO, NW, WPS>)
+        # -- whichever the shape runs on -- and, for the 32-channel level-0 shapes, the DMA-prefetching form pw_mlp_dma_kernel<C_hid / 32, KIND>
+        ks, mo, hc = int(m.group(1)) // 32, int(m.group(3)) // 16, int(m.group(2)) // 32
+        pat = rf"pw_mlp(_lds|_chunk)?_kernel<{ks}, {mo},"
+        if ks == 1 and mo == 2:
+            pat += rf"|pw_mlp_dma_kernel<{hc}, \d>"
+        return re.compile(pat)
     m = re.match(r"pw_mlp_lds_kernel<(\d+), (\d+)>$", label)
     if m:
         return re.compile(rf"pw_mlp_lds_kernel<{m.group(1)}, {m.group(2)},")
@@ -648,6 +653,12 @@ def _kernel_key(label):
     if m:
         flags = {None: "false, false", "+head": "true, false", "+stemres": "false, true"}[m.group(3)]
         return re.compile(rf"pw_mlp_kernel<{m.group(1)}, {m.group(2)}, \d+, \d+, {flags}, false, false>")
+    m = re.match(r"(pw_mlp_dma_kernel)<(\d+), (\d+)>$", label)             # one instance = one rocprof symbol
+    if m:
+        return re.compile(rf"pw_mlp_dma_kernel<{m.group(2)}, {m.group(3)}>")
+    m = re.match(r"(pw_mlp_chunk_kernel)<(\d+), (\d+)>$", label)           # <KS_IN, MO>: every workgroup shape of it
+    if m:
+        return re.compile(rf"pw_mlp_chunk_kernel<{m.group(2)}, {m.group(3)},")
     if "[" not in label and label.endswith("_kernel"):
         return label
     return None

@@ -387,6 +387,9 @@ int pytc_pw_mlp_lds_fwd(const pytc_mlp_args* a, void* stream);
  * projection of task heads behind the trunk's last block (reference: MedNeXtTaskHead.input_projection after dec_block_0, mednext_models.py:99-126;
  * here the block-diagonal merged projection).  proj_w: paired bf16 image of W (pytc_pw_pack_weight_paired, 32 x 32); y is written only when
  * store_y.  Per-sample (norm-folded) expand operands, fp16 projection image, C_hid in {64, 96, 128}. */
+/* 1 when pytc_pw_mlp_fwd / pytc_pw_mlp_head_fwd / pytc_pw_mlp_stemres_fwd (ignore_res_mode = 1) will run these arguments on the DMA-prefetching
+ * level-0 kernel (pw_mlp_dma_kernel), 0 for the one-tile-per-wave kernel: same results either way; for tools that name launches by device symbol. */
+int pytc_pw_mlp_dma_applies(const pytc_mlp_args* a, int ignore_res_mode);
 int pytc_pw_mlp_proj_supported(int C_in, int C_hid, int C_out, int C_proj);
 int pytc_pw_mlp_proj_fwd(const pytc_mlp_args* a, const void* proj_w, const float* proj_b, void* z, int store_y, void* stream);
 int pytc_pw_mlp_chunk_supported(int C_in, int C_hid, int C_out);

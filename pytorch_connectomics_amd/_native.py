@@ -233,6 +233,7 @@ _SIGS = {
     "pytc_pw_mlp_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p]),
     "pytc_pw_mlp_lds_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pytc_pw_mlp_lds_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p]),
+    "pytc_pw_mlp_dma_applies": (C.c_int, [C.POINTER(MlpArgs), C.c_int]),
     "pytc_pw_mlp_proj_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "pytc_pw_mlp_proj_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pytc_pw_mlp_chunk_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),

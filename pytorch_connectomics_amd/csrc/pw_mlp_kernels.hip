@@ -1004,6 +1004,18 @@ extern "C" int pytc_pw_mlp_stemres_fwd(const pytc_mlp_args* a, const float* stem
   return PYTC_OK;
 }
 
+// Which kernel pytc_pw_mlp_fwd / _head_fwd / _stemres_fwd will launch for these arguments: 1 = the DMA-prefetching form (pw_mlp_dma_kernel), 0 = the
+// one-tile-per-wave kernel.  For profilers and bench tables that name launches by device symbol; `ignore_res_mode` = the stem-residual entry.
+extern "C" int pytc_pw_mlp_dma_applies(const pytc_mlp_args* a, int ignore_res_mode) {
+  if (!a) return 0;
+  MlpParams p{};
+  p.HC = a->C_hid / 32;
+  p.w3_f16 = a->w3_format == PYTC_W3_F16 ? 1 : 0;
+  pytc_mlp_args shape = *a;
+  if (ignore_res_mode) shape.res_mode = PYTC_RES_NONE;
+  return mlp_dma_applies(&shape, p) ? 1 : 0;
+}
+
 // The mixer of a 32-channel block with a 32 -> 32 1x1x1 conv of its (bf16-rounded) output in the epilogue: z = bf16(W y + b).  proj_w: the conv's
 // paired bf16 image (pytc_pw_pack_weight_paired, C_out = C_in = 32); y itself is written only when store_y.  Folded operands, fp16 projection
 // image of the mixer, hidden width 64 / 96 / 128 (the shapes of pw_mlp_dma_kernel; any row count).

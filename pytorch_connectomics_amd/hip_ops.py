@@ -470,6 +470,16 @@ def pw_conv_paired_supported(*, c_in: int, c_out: int, in_dtype: torch.dtype, ou
     return bool(nat.lib().pytc_pw_conv_paired_supported(C.byref(a)))
 
 
+def _mlp_symbol(a, plain: str, kind: int) -> str:
+    """Device symbol of a fused-mixer launch for the profiler tables: `plain` (the one-tile-per-wave kernel's instance), or the DMA-prefetching
+    kernel's instance when the library will pick it for these arguments (kind 0 plain / residual, 1 stem residual, 2 fused head)."""
+    if not PROFILER.enabled:
+        return plain
+    if nat.lib().pytc_pw_mlp_dma_applies(C.byref(a), 1 if kind == 1 else 0):
+        return f"pw_mlp_dma_kernel<{int(a.C_hid) // 32}, {kind}>"
+    return plain
+
+
 def pw_mlp_supported(c_in: int, c_hid: int, c_out: int) -> bool:
     return bool(nat.lib().pytc_pw_mlp_supported(int(c_in), int(c_hid), int(c_out)))
 
@@ -641,7 +651,7 @@ def pw_mlp(t: torch.Tensor, ab: Optional[torch.Tensor], w2p: torch.Tensor, b2: t
              symbol=f"pw_mlp_chunk_kernel<{c_in // 32}, {c_out // 16}>")
         return y
     _run(f"pw_mlp_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_fwd, C.byref(a), _stream(),
-         symbol=f"pw_mlp_kernel<{c_in // 32}, {c_out // 16}>")
+         symbol=_mlp_symbol(a, f"pw_mlp_kernel<{c_in // 32}, {c_out // 16}>", 0))
     return y
 
 
@@ -770,7 +780,7 @@ def pw_mlp_stemres(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: tor
     a.Di = a.Hi = a.Wi = 0
     nb = N * rows_per_sample * (2 * (c_in + c_out) + 4)
     _run(f"pw_mlp_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_stemres_fwd, C.byref(a), _p(x0), _p(stem_w),
-         _p(stem_b), _stream(), symbol=f"pw_mlp_kernel<{c_in // 32}, {c_out // 16}>+stemres")
+         _p(stem_b), _stream(), symbol=_mlp_symbol(a, f"pw_mlp_kernel<{c_in // 32}, {c_out // 16}>+stemres", 1))
     return y
 
 
@@ -833,7 +843,7 @@ def pw_mlp_proj(t: torch.Tensor, w2n: torch.Tensor, b2n: torch.Tensor, w3p: torc
     a.Di = a.Hi = a.Wi = 0
     nb = N * rows_per_sample * 2 * (c_in + (c_out if res is not None else 0) + (c_out if store_y else 0) + 32)
     _run(f"pw_mlp_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_proj_fwd, C.byref(a), _p(proj_w), _p(proj_b), _p(z),
-         int(store_y), _stream(), symbol=f"pw_mlp_dma_kernel<{c_hid // 32}, 3>+proj")
+         int(store_y), _stream(), symbol=f"pw_mlp_dma_kernel<{c_hid // 32}, 3>")
     return y, z
 
 
@@ -878,7 +888,8 @@ def pw_mlp_head(t: torch.Tensor, ab: torch.Tensor, w2p: torch.Tensor, b2: torch.
     nb = N * rows_per_sample * (2 * (c_in + (c_out if res is not None else 0) + (c_out if store_y else 0)) + 4 * n_head)
     # same kernel template and GEMM shape as pw_mlp (HEAD flag): one label, each launch with its own byte count
     _run(f"pw_mlp_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_head_fwd, C.byref(a), _p(head_w),
-         _p(head_b), _p(logits), n_head, int(store_y), _stream(), symbol=f"pw_mlp_kernel<{c_in // 32}, {c_out // 16}>+head")
+         _p(head_b), _p(logits), n_head, int(store_y), _stream(),
+         symbol=_mlp_symbol(a, f"pw_mlp_kernel<{c_in // 32}, {c_out // 16}>+head", 2))
     return y, logits
 
 

@@ -386,7 +386,7 @@ def test_narrow_task_heads_merged_into_one_block_diagonal_head_match_the_per_hea
     with ops.profiled() as prof, torch.no_grad():                # ... and it is that kernel which ran
         model.forward_cl(x)
     torch.cuda.synchronize()
-    assert any(str(r[5]).endswith("+proj") for r in prof.records), sorted({str(r[5]) for r in prof.records})
+    assert any(str(r[5]) == "pw_mlp_dma_kernel<3, 3>" for r in prof.records), sorted({str(r[5]) for r in prof.records})
     # a head parameter changes -> the merged weights are rebuilt
     with torch.no_grad():
         model.heads["sdt"].projection.bias.add_(1.0)

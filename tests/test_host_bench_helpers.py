@@ -14,8 +14,12 @@ def _bench():
 
 def test_counter_traffic_of_the_dominant_kernel():
     b = _bench()
-    k = b._kernel_key("pw_mlp_fwd[32->64->32]")          # streaming or LDS-resident form of the shape
+    k = b._kernel_key("pw_mlp_fwd[32->64->32]")          # streaming, DMA-prefetching, LDS-resident or chunk-streamed form of the shape
     assert k.search("void pytc::pw_mlp_kernel<1, 2, 4, 3, false, false, false, false>") and not k.search("pw_mlp_kernel<1, 4, 4,")
+    assert k.search("void pytc::pw_mlp_dma_kernel<2, 0>(pytc::MlpParams, int)") and k.search("pw_mlp_dma_kernel<2, 2>") and not k.search("pw_mlp_dma_kernel<3, 0>")
+    assert b._kernel_key("pw_mlp_fwd[128->256->64]").search("void pytc::pw_mlp_chunk_kernel<4, 4, 8, 4>(pytc::MlpChunkParams)")
+    assert b._kernel_key("pw_mlp_dma_kernel<2, 1>").search("pw_mlp_dma_kernel<2, 1>(") and not b._kernel_key("pw_mlp_dma_kernel<2, 1>").search("pw_mlp_dma_kernel<2, 0>(")
+    assert b._kernel_key("pw_mlp_chunk_kernel<8, 8>").search("pw_mlp_chunk_kernel<8, 8, 8, 2>")
     k = b._kernel_key("pw_mlp_fwd[64->128->32]")
     assert k.search("pytc::pw_mlp_lds_kernel<2, 2, 2, 16, 4>") and k.search("pw_mlp_kernel<2, 2, 4, 3,") and not k.search("pw_mlp_lds_kernel<2, 4,")
     assert b._kernel_key("pw_mlp_lds_kernel<2, 4>").search("void pytc::pw_mlp_lds_kernel<2, 4, 2, 12, 3>(pytc::MlpLdsParams)")
