@@ -882,7 +882,12 @@ static void make_march(DwMarch& t, int N, int D, int H, int W, int C, int tilex 
   // workgroups of these kernels do not advance in rounds, the launch is throughput bound.
   int nzc = (int)(((long)tuning_get("dwconv_march_wgs", 1024) + fp - 1) / fp);
   if (nzc < 1) nzc = 1;
-  int maxc = D / 14;
+  // ... unless 14-plane chunks leave a sample with fewer than `dwconv_march_small_wgs` workgroups (the 20^3 x 256 level of MedNeXt-L: 72): such a
+  // launch is a chain of D + 2 dependent plane steps on a fraction of the chip, its bytes are irrelevant -- chunks of >= 5 planes then
+  // (24.5 -> 16.5 us there; applied to the larger levels the extra halo costs more than it saves: profiles/r05_short_z_chunks.txt).
+  // A per-sample rule: the split still does not depend on N.
+  const int min_planes = fp * (D / 14 > 0 ? D / 14 : 1) < (long)tuning_get("dwconv_march_small_wgs", 128) ? 5 : 14;
+  int maxc = D / tuning_get("dwconv_march_min_planes", min_planes);
   if (maxc < 1) maxc = 1;
   if (nzc > maxc) nzc = maxc;
   t.zc = (D + nzc - 1) / nzc;
