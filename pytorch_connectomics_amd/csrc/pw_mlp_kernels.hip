@@ -376,11 +376,12 @@ pw_mlp_kernel(MlpParams p) {
 // hold 8 KB of loads in flight only until they start computing (60 % of their cycles waiting), ~77 KB per CU on average against the ~100 KB the
 // loaded memory system's 4 us want.  Prefetching the next tile into REGISTERS costs a wave per SIMD and lost twice (rounds 2 and 4).  Here the next
 // tile's rows travel by `global_load_lds_dwordx4` into a wave-private LDS landing area (8 KB per wave: each lane's 16 bytes land at its own
-// lane slot, so reading them back is a conflict-free identity map) while the wave computes the current tile from registers: no register cost, the
-// same occupancy, and every wave has a tile in flight all the time.  A wave walks tiles gw, gw + W, gw + 2W ... of its sample (W = waves of the
-// launch: neighbouring waves stay on neighbouring rows).  Order inside an iteration: wait (all DMA of this tile, and the stores of the tile before
-// last, have had a whole compute phase) -> landing area to registers -> stores of the PREVIOUS tile's results -> DMA of the next tile -> compute.
-// (Loads and stores share vmcnt and return out of order with respect to each other: the stores must not sit between a DMA and its wait.)
+// lane slot, so reading them back is a conflict-free identity map) while the wave computes the current tile from registers: no register cost, 12
+// waves per CU instead of 16 (LDS: 41 - 51 KB per workgroup with the operands below), and every wave has a tile in flight all the time.  A wave
+// walks tiles gw, gw + W, gw + 2W ... of its sample (W = waves of the launch: neighbouring waves stay on neighbouring rows).  Order inside an
+// iteration: wait (the DMA of this tile, and the stores of the tile before last, have had a whole compute phase) -> stores of the PREVIOUS tile's
+// results -> landing area to registers -> DMA of the next tile -> compute.  (Loads and stores share vmcnt and return out of order with respect
+// to each other: the stores must not sit between a DMA and its wait.)
 // Same MFMA order, GELU and epilogue arithmetic as pw_mlp_kernel<1, 2, 4, 3> with per-sample operands: bit-identical output.
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
