@@ -215,7 +215,9 @@ template <int KS_IN, int MO, int NW, int WPS>
 static void launch_mlp_chunk_v(const MlpChunkParams& p, hipStream_t s) {
   auto kern = &pw_mlp_chunk_kernel<KS_IN, MO, NW, WPS>;
   const size_t lds = (size_t)3 * (2 * KS_IN + MO) * 1024 + (size_t)(p.C_hid + MO * 16) * 4;
-  if (!ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "pw_mlp_chunk")) return;     // per (kernel, device); thread safe
+  // the opt-in is remembered per (kernel, device): ask for the device's whole LDS once, not for this launch's size (a later launch of the same
+  // instance with a wider hidden layer -- 256 -> 512 -> 128, then 256 -> 2048 -> 128 -- needs more for its bias vector)
+  if (!ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, "pw_mlp_chunk")) return;     // thread safe
   const long wg_rows = (long)NW * 32;
   dim3 grid((unsigned)((p.rps + wg_rows - 1) / wg_rows), (unsigned)p.N), block(NW * 64);
   hipLaunchKernelGGL(kern, grid, block, lds, s, p);

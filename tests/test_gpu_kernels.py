@@ -462,7 +462,8 @@ def test_dma_prefetch_mixer_is_bit_identical(dev, N, rows, chid, n_head, wgs):
             assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
 
 
-@pytest.mark.parametrize("cin,chid,cout,mode,N,grid", [(128, 1024, 128, "add", 2, (7, 7, 7)), (128, 1024, 128, "none", 1, (3, 3, 3)),
+@pytest.mark.parametrize("cin,chid,cout,mode,N,grid", [(256, 64, 128, "none", 1, (5, 5, 5)),       # first: the narrow instance of <8, 8> opts into > 64 KB of LDS
+                                                       (128, 1024, 128, "add", 2, (7, 7, 7)), (128, 1024, 128, "none", 1, (3, 3, 3)),
                                                        (256, 2048, 128, "up", 2, (6, 6, 6)), (128, 512, 64, "up", 3, (4, 4, 4)),
                                                        (64, 512, 128, "none", 2, (9, 9, 9)), (128, 96, 128, "add", 2, (5, 5, 5)),
                                                        (128, 64, 64, "add", 1, (4, 4, 4)), (64, 128, 32, "up", 2, (6, 6, 6)),
