@@ -360,3 +360,32 @@ def test_parallel_writer_deflate_backends_and_thread_policy(tmp_path, monkeypatc
     assert h5lite.write_threads() == min(2, len(os.sched_getaffinity(0)))
     monkeypatch.setattr(h5lite, "_cgroup_cpu_quota", lambda: None)
     assert h5lite.write_threads() == min(128, len(os.sched_getaffinity(0)))
+
+
+def test_cgroup_cpu_quota_parsing(monkeypatch):
+    """h5lite._cgroup_cpu_quota: cgroup v2 `cpu.max` ("<quota> <period>" or "max <period>"), cgroup v1 cfs quota / period (-1 = unlimited),
+    neither file -> None.  The MI355X boxes grant 16 CPUs ("1600000 100000") under a 256-core affinity mask."""
+    import builtins
+    import io
+    from pytorch_connectomics_amd.utils import h5lite
+    real_open = builtins.open
+
+    def fake(files):
+        def _open(path, *a, **k):
+            p = str(path)
+            if p.startswith("/sys/fs/cgroup/"):
+                if p in files:
+                    return io.StringIO(files[p])
+                raise FileNotFoundError(p)
+            return real_open(path, *a, **k)
+        return _open
+
+    v2, q1, p1 = "/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us"
+    cases = [({v2: "1600000 100000\n"}, 16.0), ({v2: "max 100000\n"}, None), ({v2: "150000 100000"}, 1.5),
+             ({q1: "400000\n", p1: "100000\n"}, 4.0), ({q1: "-1\n", p1: "100000\n"}, None), ({}, None), ({v2: "garbage"}, None)]
+    for files, want in cases:
+        monkeypatch.setattr(builtins, "open", fake(files))
+        assert h5lite._cgroup_cpu_quota() == want, (files, want)
+    monkeypatch.setattr(builtins, "open", fake({v2: "1600000 100000"}))
+    monkeypatch.delenv("PYTC_H5_THREADS", raising=False)
+    assert h5lite.write_threads() == min(32, len(os.sched_getaffinity(0)))
