@@ -1012,8 +1012,9 @@ def main():
             t = torch.tensor([ds], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             strong = job_record(n_win, 1, volume, float(t.item()), scaling="strong",
-                                path=f"slab_predict_volume: one volume, {world} slabs (each rank holds only its slab + halo planes), "
-                                     "p2p halo bands (RCCL send/recv), result sharded")
+                                path=f"slab_predict_volume: one volume, windows dealt to {world} ranks in contiguous runs (counts within one: "
+                                     "58 / 59 of 468 at 8 ranks; each rank holds only the planes its windows read), "
+                                     "p2p boxes of partial sums to the ranks whose cells touch (RCCL send/recv), result sharded")
         torch.cuda.empty_cache()
 
     train = None
