@@ -124,8 +124,23 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
+    headers = sorted(CSRC.glob("*.h")) + [PKG.parent / "include" / "pytc_hip.h", Path(__file__), CSRC / "asm_check.py"]
+
+    def object_digest(src: Path) -> str:
+        """One object's inputs: its source, every header of the directory, its flags and the build-time checks themselves."""
+        h = hashlib.sha256()
+        for q in [src] + headers:
+            h.update(q.name.encode())
+            h.update(q.read_bytes())
+        h.update(" ".join(FLAGS + EXTRA_FLAGS.get(src.name, [])).encode())
+        return h.hexdigest()
+
     def compile_one(src: Path) -> Path:
         obj = obj_dir / (src.stem + ".o")
+        ostamp = obj_dir / (src.stem + ".sha256")
+        odig = object_digest(src)
+        if not force and obj.exists() and ostamp.exists() and ostamp.read_text().strip() == odig:
+            return obj                  # unchanged since it last passed the checks below (the stamp is written after them)
         cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
@@ -139,6 +154,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         else:
             subprocess.run(cmd, check=True)
         _check_packed_fp32_selects(obj)
+        ostamp.write_text(odig)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:

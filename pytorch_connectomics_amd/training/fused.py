@@ -21,7 +21,8 @@ from .. import _native as nat
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    from ..hip_ops import _stream as raw_stream          # the raw-handle getter (no Stream object per launch)
+    return raw_stream()
 
 
 def _p(t):
