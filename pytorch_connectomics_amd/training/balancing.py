@@ -98,11 +98,13 @@ def build_loss_weighter(cfg, num_tasks: int, model: Optional[nn.Module] = None) 
     if strategy is None:
         return None
     strategy = str(strategy).lower()
+    if strategy in ("", "none", "static", "fixed"):           # static weights, as configs of rounds 1-4 of this package spelled it
+        return None
     if strategy == "uncertainty":
         return UncertaintyLossWeighter(num_tasks)
     if strategy == "gradnorm":
         shared = select_shared_parameters(model, getattr(lb, "gradnorm_parameter_strategy", "last")) if model is not None else []
-        return GradNormLossWeighter(num_tasks, alpha=getattr(lb, "gradnorm_alpha", 0.5) or 0.5,
+        return GradNormLossWeighter(num_tasks, alpha=getattr(lb, "gradnorm_alpha", 0.5) if getattr(lb, "gradnorm_alpha", None) is not None else 0.5,
                                     gradnorm_lambda=getattr(lb, "gradnorm_lambda", 1.0) if getattr(lb, "gradnorm_lambda", None) is not None else 1.0,
                                     shared_parameters=shared)
     raise ValueError(f"Unknown loss balancing strategy: {strategy}")

@@ -733,11 +733,14 @@ class ConnectomicsModule(nn.Module):
             warnings.warn(f"checkpoint carries adaptive loss-balancing state ({len(wsd)} tensors, e.g. 'loss_weighter.{sorted(wsd)[0]}') but "
                           "model.loss.loss_balancing is not configured: the learned task weights are NOT restored", RuntimeWarning, stacklevel=2)
         elif wsd:
-            if "initial_losses" in wsd and getattr(self.loss_weighter, "initial_losses", 0) is None:
-                self.loss_weighter.initial_losses = wsd["initial_losses"].clone()        # a None buffer cannot be load_state_dict'ed
+            if "initial_losses" in wsd and hasattr(self.loss_weighter, "initial_losses"):
+                # (a None buffer cannot be load_state_dict'ed; a checkpointed reference point always replaces the live one)
+                self.loss_weighter.initial_losses = wsd["initial_losses"].clone()
             bad = self.loss_weighter.load_state_dict({k: v for k, v in wsd.items() if k != "initial_losses"}, strict=False)
-            if bad.unexpected_keys:
-                raise RuntimeError(f"checkpoint loss_weighter state does not match the configured strategy: unexpected {bad.unexpected_keys}")
+            missing_w = [k for k in bad.missing_keys if k != "initial_losses"]
+            if bad.unexpected_keys or missing_w:
+                raise RuntimeError(f"checkpoint loss_weighter state does not match the configured strategy: unexpected "
+                                   f"{bad.unexpected_keys}, missing {missing_w}")
         missing, unexpected = self.model.load_state_dict(sd, strict=False)
         # a reference checkpoint may carry deep-supervision heads of a trunk built with them (`out_1..out_4`); anything else
         # missing / unexpected is an architecture mismatch
@@ -865,11 +868,19 @@ def fit(module: ConnectomicsModule, batches, *, max_steps: int, device, log_ever
         if hasattr(mod, "compute_dtype"):
             mod.compute_dtype = dt
     net = module
+    weighter_params = []
     if ddp:
         from torch.nn.parallel import DistributedDataParallel as DDP
         dev_ids = [device.index] if device.type == "cuda" else None
-        # the MedNeXt trunk carries an unused `dummy_tensor` parameter (trainer.py:241-253 uses the same flag)
-        net = DDP(module, device_ids=dev_ids, find_unused_parameters=True)
+        # the MedNeXt trunk carries an unused `dummy_tensor` parameter (trainer.py:241-253 uses the same flag).
+        # DDP wraps the NETWORK, not the whole module: the loss -- and with adaptive loss balancing the weighter's own parameters
+        # (log-variances / task weights) -- is computed after the wrapped forward returns, where DDP's reducer would first mark those
+        # parameters unused and then see their gradient hooks fire ("Expected to mark a variable ready only once").  The
+        # reference computes its loss inside the wrapped training_step (lightning/model.py:863-910); here the weighter's few gradients
+        # are averaged over the ranks by hand below, which gives every rank the same update DDP would.
+        net = DDP(module.model, device_ids=dev_ids, find_unused_parameters=True)
+        if module.loss_weighter is not None:
+            weighter_params = [p for p in module.loss_weighter.parameters() if p.requires_grad]
     opt, sched = module.configure_optimizers()
     module._scheduler = sched
     resumed = module.restore_training_state(opt, sched)
@@ -893,8 +904,17 @@ def fit(module: ConnectomicsModule, batches, *, max_steps: int, device, log_ever
             out = net(batch["image"])
             loss, logs = module._compute_loss(out, batch["label"], batch.get("mask"))
             (loss / accum).backward()
+        if weighter_params:
+            world = torch.distributed.get_world_size()
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in weighter_params])
+            torch.distributed.all_reduce(flat)
+            at = 0
+            for p in weighter_params:
+                p.grad = (flat[at:at + p.numel()] / world).view_as(p).clone()
+                at += p.numel()
         if clip > 0 and not hasattr(opt, "max_grad_norm"):     # FusedAdamW clips inside its update kernel
-            torch.nn.utils.clip_grad_norm_(module.model.parameters(), clip)
+            # every parameter the optimizer owns (with a loss weighter: its parameters too), as Lightning clips (and as FusedAdamW does)
+            torch.nn.utils.clip_grad_norm_([p for g in opt.param_groups for p in g["params"]], clip)
         opt.step()
         module.global_step = step + 1
         history.append(float(loss.detach()))

@@ -102,6 +102,11 @@ def available() -> bool:
 PARALLEL_WRITE_MIN_BYTES = 4 << 20
 
 
+_UNSET = object()
+_quota_cache = _UNSET
+_last_write_was_parallel = False
+
+
 def write_threads() -> int:
     """Host threads of the parallel deflate writer: PYTC_H5_THREADS, else the cores this process may run on, at most 128 (zlib level 4
     compresses ~15 MB/s per core on near-incompressible fp32 predictions; measured on the 256-core MI355X host: 64 threads 1.77 s for
@@ -113,7 +118,10 @@ def write_threads() -> int:
         n = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         n = os.cpu_count() or 1
-    q = _cgroup_cpu_quota()
+    global _quota_cache
+    if _quota_cache is _UNSET:
+        _quota_cache = _cgroup_cpu_quota()         # a property of the container: read once per process
+    q = _quota_cache
     if q is not None:
         n = min(n, max(1, int(2 * q + 0.5)))          # two workers per granted core: the serialized H5Dwrite_chunk calls overlap with deflate
     return max(1, min(128, n))
@@ -140,9 +148,10 @@ def _cgroup_cpu_quota() -> Optional[float]:
 
 def last_parallel_write_stats() -> Optional[dict]:
     """Where the last parallel chunk write of this process spent its time (csrc/host/h5io.c): thread-seconds of gather and deflate summed over the
-    workers, seconds inside the serialized H5Dwrite_chunk calls, wall seconds, workers; None without the library."""
+    workers, seconds inside the serialized H5Dwrite_chunk calls, wall seconds, workers; None without the library or when the LAST dataset write
+    did not take the parallel path (small, contiguous-layout or declined by the library)."""
     lib = _load()
-    if lib is None:
+    if lib is None or not _last_write_was_parallel:          # the last write took the plain hyperslab path: the library's record is stale
         return None
     out = (C.c_double * 5)()
     lib.pytc_h5_write_parallel_stats(out)
@@ -343,11 +352,15 @@ class Dataset:
             # chunk-aligned writes into a chunked (gzip or unfiltered) dataset: N host threads deflate whole HDF5 chunks and the
             # compressed bytes go in through H5Dwrite_chunk (csrc/host/h5io.c) -- H5Dwrite would run zlib on ONE thread (63 s for a
             # 0.9 GB prediction chunk, 40x the GPU time that produced it).  rc 2 = not applicable here: the plain hyperslab write.
-            nthreads = write_threads()
-            if nthreads > 1 and self.chunks is not None and arr.nbytes >= PARALLEL_WRITE_MIN_BYTES:
+            global _last_write_was_parallel
+            _last_write_was_parallel = False
+            # (size and layout first: write_threads() reads the environment and, once per process, the cgroup files)
+            nthreads = write_threads() if (self.chunks is not None and arr.nbytes >= PARALLEL_WRITE_MIN_BYTES) else 1
+            if nthreads > 1:
                 rc = lib.pytc_h5_dset_write_parallel(self._id, len(start), _i64(start), _i64(count), arr.ctypes.data_as(C.c_void_p),
                                                      _CODE_OF[self.dtype], nthreads)
                 if rc == 0:
+                    _last_write_was_parallel = True
                     return
                 if rc == 1:
                     raise OSError(_err(lib))

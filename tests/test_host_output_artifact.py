@@ -355,9 +355,21 @@ def test_parallel_writer_deflate_backends_and_thread_policy(tmp_path, monkeypatc
         with h5lite.File(tmp_path / name, "r") as f:
             assert f["main"].compression == "gzip" and np.array_equal(f["main"][...], data), name
     # thread policy: PYTC_H5_THREADS wins; otherwise a quota of q CPUs gives 2 q workers (at most 128, at most the affinity mask)
+    #  a write that does not take the parallel path leaves no stale record behind
+    with h5lite.File(tmp_path / "here.h5", "r+") as f:
+        f["main"][0, 0, 0, :4] = np.zeros(4, np.float32)                   # a few bytes below the threshold
+    monkeypatch.setattr(h5lite, "PARALLEL_WRITE_MIN_BYTES", 4 << 20)
+    with h5lite.File(tmp_path / "small.h5", "w") as f:
+        f.create_dataset("main", data=data[:, :4], chunks=(2, 4, 64, 64), compression="gzip")
+    assert h5lite.last_parallel_write_stats() is None
     monkeypatch.delenv("PYTC_H5_THREADS")
+    monkeypatch.setattr(h5lite, "_quota_cache", h5lite._UNSET)
     monkeypatch.setattr(h5lite, "_cgroup_cpu_quota", lambda: 1.0)
     assert h5lite.write_threads() == min(2, len(os.sched_getaffinity(0)))
+    calls = []
+    monkeypatch.setattr(h5lite, "_cgroup_cpu_quota", lambda: calls.append(1))
+    assert h5lite.write_threads() == min(2, len(os.sched_getaffinity(0))) and not calls       # the quota is read once per process
+    monkeypatch.setattr(h5lite, "_quota_cache", h5lite._UNSET)
     monkeypatch.setattr(h5lite, "_cgroup_cpu_quota", lambda: None)
     assert h5lite.write_threads() == min(128, len(os.sched_getaffinity(0)))
 

@@ -177,6 +177,37 @@ def test_ddp_gloo_eight_ranks_with_uneven_local_batches():
     mp.spawn(_ddp_worker8, args=(8, 31500 + (os.getpid() + 11) % 2000), nprocs=8, join=True)
 
 
+def _ddp_balancing_worker(rank, world, port, strategy):
+    """fit(ddp=True) with an adaptive loss weighter (tutorials/mitoEM/common.yaml trains with `uncertainty`) raised
+    'Expected to mark a variable ready only once' at the first backward -- the weighter's parameters were DDP parameters used outside
+    the wrapped forward.  Now DDP wraps the network and the weighter's gradients are averaged by hand."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    cfg = _cfg(gradient_clip_val=1.0)
+    cfg.model.loss.losses = [{"function": "WeightedBCEWithLogitsLoss", "weight": 1.0},
+                             {"function": "DiceLoss", "weight": 0.5, "kwargs": {"sigmoid": True}}]
+    cfg.model.loss.loss_balancing = {"strategy": strategy, "gradnorm_alpha": 0.0}
+    torch.manual_seed(0)
+    m = ConnectomicsModule(cfg, model=SimpleModel())
+    if strategy == "gradnorm":
+        assert m.loss_weighter.alpha == 0.0                    # an explicit 0.0 (equal gradient norms) is not the default 0.5
+    w0 = torch.cat([p.detach().flatten().clone() for p in m.loss_weighter.parameters()])
+    fit(m, synthetic_batches(2, (8, 8, 8), seed=42 + rank), max_steps=4, device=torch.device("cpu"), ddp=True, log=None)
+    flat = torch.cat([p.detach().flatten() for p in list(m.model.parameters()) + list(m.loss_weighter.parameters())])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    torch.distributed.all_gather(gathered, flat)
+    assert all(torch.equal(gathered[0], g) for g in gathered[1:])       # network AND weighter parameters identical on all ranks
+    w1 = torch.cat([p.detach().flatten() for p in m.loss_weighter.parameters()])
+    assert not torch.equal(w0, w1)                                       # ... and the weighter did train
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("strategy", ["uncertainty", "gradnorm"])
+def test_ddp_with_adaptive_loss_balancing_keeps_weighter_replicas_identical(strategy):
+    mp.spawn(_ddp_balancing_worker, args=(2, 33500 + (os.getpid() + 13) % 2000, strategy), nprocs=2, join=True)
+
+
 def test_weighted_bce_matches_reference_fixture():
     """tests/golden/losses.npz: the reference's WeightedBCEWithLogitsLoss (losses.py:17-44,190-266) values and gradients."""
     import numpy as np
