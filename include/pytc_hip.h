@@ -25,7 +25,7 @@ extern "C" {
 
 /* 2 (round 5): pytc_mlp_args.per_sample (added in round 4 without a bump: ADVICE r04), pytc_dwconv3d_fwd with y = NULL, pytc_dwmix_*.
  * Bumped whenever a struct layout or the meaning of an argument changes; _native.py refuses a library of another version. */
-#define PYTC_ABI_VERSION 2
+#define PYTC_ABI_VERSION 3
 
 #define PYTC_OK 0
 #define PYTC_ERR_INVALID 1     /* bad argument (shape, dtype, alignment) */
@@ -40,6 +40,10 @@ extern "C" {
 #define PYTC_VIEW_FLIP_Y 2
 #define PYTC_VIEW_FLIP_X 4
 #define PYTC_VIEW_SWAP_YX 8
+/* round 6: quarter turns in the planes that contain z (inference/tta_combinations.py:90-119 accepts any plane): the window axes of the
+ * plane are exchanged after the flips; at most ONE swap bit per view, and the two exchanged axes of the window must have equal length */
+#define PYTC_VIEW_SWAP_ZY 16
+#define PYTC_VIEW_SWAP_ZX 32
 
 /* padding modes of inference/window.py:464-527 */
 #define PYTC_PAD_CONSTANT 0

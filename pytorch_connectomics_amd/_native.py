@@ -11,12 +11,13 @@ import os
 from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libpytc_hip.so"
-ABI_VERSION = 2          # include/pytc_hip.h PYTC_ABI_VERSION
+ABI_VERSION = 3          # include/pytc_hip.h PYTC_ABI_VERSION
 
 F32, BF16 = 0, 1
 OK = 0
 
-VIEW_FLIP_Z, VIEW_FLIP_Y, VIEW_FLIP_X, VIEW_SWAP_YX = 1, 2, 4, 8
+VIEW_FLIP_Z, VIEW_FLIP_Y, VIEW_FLIP_X, VIEW_SWAP_YX, VIEW_SWAP_ZY, VIEW_SWAP_ZX = 1, 2, 4, 8, 16, 32
+VIEW_SWAPS = {VIEW_SWAP_YX: (1, 2), VIEW_SWAP_ZY: (0, 1), VIEW_SWAP_ZX: (0, 2)}      # swap bit -> the two window axes it exchanges
 PAD_MODES = {"constant": 0, "reflect": 1, "replicate": 2, "circular": 3}
 BLEND_PRODUCT, BLEND_MIN = 0, 1
 ACT_NONE, ACT_SIGMOID, ACT_TANH, ACT_GELU, ACT_SOFTMAX, ACT_RELU, ACT_LEAKY, ACT_ELU = 0, 1, 2, 3, 4, 5, 6, 7

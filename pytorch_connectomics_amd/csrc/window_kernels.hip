@@ -39,7 +39,7 @@ __device__ __forceinline__ int pad_index(int g, int lo, int hi, int mode, bool& 
   }
 }
 
-// view: out[z,y,x] = win[T(F(z,y,x))], F = per-axis flips, T = optional (y,x) swap
+// view: out[z,y,x] = win[T(F(z,y,x))], F = per-axis flips, T = optional exchange of two axes ((y,x), (z,y) or (z,x): at most one)
 __device__ __forceinline__ void view_src(int view, int rz, int ry, int rx, int z, int y, int x,
                                          int& wz, int& wy, int& wx) {
   int fz = (view & PYTC_VIEW_FLIP_Z) ? rz - 1 - z : z;
@@ -47,9 +47,23 @@ __device__ __forceinline__ void view_src(int view, int rz, int ry, int rx, int z
   int fx = (view & PYTC_VIEW_FLIP_X) ? rx - 1 - x : x;
   if (view & PYTC_VIEW_SWAP_YX) {
     wz = fz; wy = fx; wx = fy;
+  } else if (view & PYTC_VIEW_SWAP_ZY) {
+    wz = fy; wy = fz; wx = fx;
+  } else if (view & PYTC_VIEW_SWAP_ZX) {
+    wz = fx; wy = fy; wx = fz;
   } else {
     wz = fz; wy = fy; wx = fx;
   }
+}
+
+static inline bool view_ok(int view, int rz, int ry, int rx) {
+  const int swaps = view & (PYTC_VIEW_SWAP_YX | PYTC_VIEW_SWAP_ZY | PYTC_VIEW_SWAP_ZX);
+  if (view & ~63) return false;
+  if (swaps == 0) return true;
+  if (swaps == PYTC_VIEW_SWAP_YX) return ry == rx;
+  if (swaps == PYTC_VIEW_SWAP_ZY) return rz == ry;
+  if (swaps == PYTC_VIEW_SWAP_ZX) return rz == rx;
+  return false;
 }
 
 template <typename TO>
@@ -314,7 +328,7 @@ extern "C" int pytc_gather_windows(const float* vol, int C, int Z, int Y, int X,
   PYTC_REQUIRE(vol && out && starts, "gather_windows: null pointer");
   PYTC_REQUIRE(B >= 1 && B <= 64, "gather_windows: B=%d must be in [1,64]", B);
   PYTC_REQUIRE(C >= 1 && rz > 0 && ry > 0 && rx > 0 && Z > 0 && Y > 0 && X > 0, "gather_windows: bad shape");
-  PYTC_REQUIRE(!(view & PYTC_VIEW_SWAP_YX) || ry == rx, "gather_windows: SWAP_YX needs ry == rx");
+  PYTC_REQUIRE(view_ok(view, rz, ry, rx), "gather_windows: at most one SWAP bit, and the exchanged window axes must have equal length");
   PYTC_REQUIRE(pad_mode >= 0 && pad_mode <= 3, "gather_windows: bad pad_mode %d", pad_mode);
   StartList st;
   memcpy(st.s, starts, sizeof(int) * 3 * B);
@@ -339,7 +353,7 @@ extern "C" int pytc_blend_accumulate(const void* pred, int pred_dtype, int B, co
                                      float* value, float* weight, int Z, int Y, int X, void* stream) {
   PYTC_REQUIRE(pred && starts && wz && wy && wx && value, "blend_accumulate: null pointer");
   PYTC_REQUIRE(B >= 1 && C >= 1, "blend_accumulate: bad B/C");
-  PYTC_REQUIRE(!(view & PYTC_VIEW_SWAP_YX) || ry == rx, "blend_accumulate: SWAP_YX needs ry == rx");
+  PYTC_REQUIRE(view_ok(view, rz, ry, rx), "blend_accumulate: at most one SWAP bit, and the exchanged window axes must have equal length");
   PYTC_REQUIRE(combine == PYTC_BLEND_PRODUCT || combine == PYTC_BLEND_MIN, "blend_accumulate: bad combine");
   long per_win = (long)rz * ry * rx;
   dim3 grid(ceil_div(per_win, 256)), block(256);
@@ -371,7 +385,7 @@ extern "C" int pytc_blend_accumulate_mapped(const void* pred, int pred_dtype, in
                                             void* stream) {
   PYTC_REQUIRE(pred && starts && wz && wy && wx && value && chan_src && chan_shift, "blend_accumulate_mapped: null pointer");
   PYTC_REQUIRE(B >= 1 && C >= 1 && C <= MAX_MAP, "blend_accumulate_mapped: C=%d must be in [1,%d]", C, MAX_MAP);
-  PYTC_REQUIRE(!(view & PYTC_VIEW_SWAP_YX) || ry == rx, "blend_accumulate_mapped: SWAP_YX needs ry == rx");
+  PYTC_REQUIRE(view_ok(view, rz, ry, rx), "blend_accumulate_mapped: at most one SWAP bit, and the exchanged window axes must have equal length");
   PYTC_REQUIRE(combine == PYTC_BLEND_PRODUCT || combine == PYTC_BLEND_MIN, "blend_accumulate_mapped: bad combine");
   ChanMap m;
   for (int d = 0; d < C; ++d) {

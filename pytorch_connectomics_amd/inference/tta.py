@@ -7,8 +7,9 @@ or of the predictions); each view gets one overlap-add pass over the SAME window
 accumulator (the reference's patch-first-local semantics), then normalise -> per-channel activation ->
 channel selection -> streaming mean/min/max ensemble, all as device kernels.
 
-Not built yet: affinity-aware channel remapping / validity boxes
-(inference/tta_affinity.py) and rot90 planes that involve z.
+Quarter turns in every plane (round 6: the planes that contain z exchange z with y / x inside the gather and blend kernels,
+PYTC_VIEW_SWAP_ZY / _ZX); an odd turn needs a window -- and, patch-first, an image -- of equal size along the plane's axes, as in the
+reference (tta.py:1316-1340).
 """
 from __future__ import annotations
 
@@ -36,21 +37,22 @@ _MODE_CODE = {"mean": 0, "min": 1, "max": 2}
 
 def view_code(flip_axes, rotation_plane, k: int) -> int:
     """Map a reference view (flips, then rot90^k in `rotation_plane`; spatial axes 0=z,1=y,2=x) onto the
-    kernels' PYTC_VIEW_* encoding  out[z,y,x] = win[T(F(z,y,x))]  by matching its action on a probe."""
-    probe = torch.arange(2 * 3 * 3).reshape(2, 3, 3)
+    kernels' PYTC_VIEW_* encoding  out[z,y,x] = win[T(F(z,y,x))]  (F: per-axis flips, T: exchange of the two axes of the plane)
+    by matching its action on a cubic probe.  Any plane (tta_combinations.py:90-119): an odd turn exchanges the plane's two window
+    axes, which must then have equal length -- checked where the window size is known (EagerSlidingWindowEngine.accumulate, the
+    kernels)."""
+    probe = torch.arange(3 * 3 * 3).reshape(3, 3, 3)
     want = apply_view(probe, list(flip_axes or []), rotation_plane, int(k), first_spatial_dim=0)
-    if want.shape != probe.shape:
-        raise NotImplementedError(f"TTA rotation in plane {rotation_plane} changes the window shape; only "
-                                  "rotations in the (y, x) plane are supported by the device engine")
-    for code in range(16):
-        mine = probe.transpose(1, 2) if code & nat.VIEW_SWAP_YX else probe
-        dims = [d for d, bit in enumerate((nat.VIEW_FLIP_Z, nat.VIEW_FLIP_Y, nat.VIEW_FLIP_X)) if code & bit]
-        if dims:
-            mine = torch.flip(mine, dims)
-        if torch.equal(mine, want):
-            return code
+    swaps = [0] + sorted(nat.VIEW_SWAPS)
+    for swap in swaps:
+        t = probe.transpose(*nat.VIEW_SWAPS[swap]) if swap else probe
+        for flips in range(8):
+            dims = [d for d, bit in enumerate((nat.VIEW_FLIP_Z, nat.VIEW_FLIP_Y, nat.VIEW_FLIP_X)) if flips & bit]
+            mine = torch.flip(t, dims) if dims else t
+            if torch.equal(mine, want):
+                return swap | flips
     raise NotImplementedError(f"TTA view (flip={flip_axes}, plane={rotation_plane}, k={k}) is not expressible as "
-                              "flips + a (y, x) transpose")
+                              "flips + one exchange of two axes")
 
 
 class TTAPredictor:

@@ -456,8 +456,10 @@ class EagerSlidingWindowEngine:
             starts = all_starts
         (wz, wy, wx), combine = self._axis_vectors(dev)
         roi = self.roi_size
-        if (view & nat.VIEW_SWAP_YX) and roi[1] != roi[2]:
-            raise ValueError("a yx-rotated TTA view needs a window that is square in (y, x)")
+        for bit, (a0, a1) in nat.VIEW_SWAPS.items():
+            if (view & bit) and roi[a0] != roi[a1]:
+                raise ValueError(f"a TTA view rotated in the plane of spatial axes ({a0}, {a1}) needs a window of equal size along them, "
+                                 f"got roi {tuple(roi)}" + (" (a yx-rotated TTA view needs a window that is square in (y, x))" if bit == nat.VIEW_SWAP_YX else ""))
 
         def run(batch_starts):
             x = ops.gather_windows(vol, batch_starts, roi, view=view, pad_mode="constant", cval=self.cval)

@@ -434,6 +434,75 @@ def tta_affinity():
     print("wrote tta_affinity_plans.json", {k: len(v["views"]) for k, v in plans.items()})
 
 
+def tta_zplanes():
+    """Round 6: quarter turns in the planes that contain z (tta_combinations.py:90-119 accepts any plane whose axes have equal image and
+    window size): the reference's InferenceManager.predict_with_tta on small volumes -> tests/golden/tta_zplanes.npz."""
+    from types import SimpleNamespace as NS
+    mgr = S.ref("connectomics.inference.manager")
+
+    def cfg_for(tta_ns, *, n_out, acts, roi, select=None, offsets=None, amode=None):
+        cfg = NS(model=NS(primary_head=None, heads=None, out_channels=n_out),
+                 data=NS(train=NS(do_2d=False), val=NS(do_2d=False), dataloader=NS(batch_size=1)),
+                 inference=NS(sliding_window=NS(window_size=list(roi), sw_batch_size=3, overlap=0.5, blending="bump",
+                                                padding_mode="constant", cval=0.0, keep_input_on_cpu=False, sw_device=None,
+                                                output_device=None, border_mask=None, distributed_sharding=False),
+                              model=NS(head=None, select_channel=select, output_dtype=None, channel_activations=acts, crop_pad=None),
+                              test_time_augmentation=tta_ns))
+        if offsets is not None:
+            cfg.data.label_transform = NS(stack_outputs=True, targets=[{"name": "affinity", "kwargs": {"offsets": offsets, "affinity_mode": amode}}])
+        return cfg
+
+    def ns(flip, rot, mode, ks=None):
+        return NS(enabled=True, flip_axes=flip, rotation90_axes=rot, rotate90_k=ks, ensemble_mode=mode, patch_first_local=True,
+                  distributed_sharding=False, apply_mask=True, empty_cache_interval=0)
+
+    g = torch.Generator().manual_seed(61)
+    xc = torch.rand(1, 1, 16, 16, 16, generator=g)          # cube: every plane
+    xzy = torch.rand(1, 1, 20, 20, 14, generator=g)         # z == y
+    xzx = torch.rand(1, 1, 16, 22, 16, generator=g)         # z == x
+    out = {"x_cube": xc.numpy(), "x_zy": xzy.numpy(), "x_zx": xzx.numpy()}
+    sig = [{"channels": ":", "activation": "sigmoid"}]
+    cases = {
+        "cube_all32_mean": (ns("all", "all", "mean"), 3, sig, (8, 8, 8), None, None, None, xc, _net_asym),
+        "zy_flipx_minmax": (ns([[2]], [[0, 1]], [["0:2", "min"], ["2", "max"]]), 3,
+                            [{"channels": "0:2", "activation": "scale_sigmoid:0.5"}, {"channels": "2", "activation": "tanh"}],
+                            (8, 8, 12), None, None, None, xzy, _net_asym),
+        "zx_k13_select": (ns(None, [[0, 2]], "mean", ks=[1, 3]), 3, [{"channels": ":", "activation": "softmax"}], (8, 12, 8), [2, 0],
+                          None, None, xzx, _net_asym),
+        "aff3_zx_mean_deepem": (ns([[1]], [[0, 2]], "mean"), 3, sig, (8, 12, 8), None, ["1-0-0", "0-1-0", "0-0-1"], "deepem", xzx,
+                                lambda t: _net_aff(t, 3)),
+        "aff6_cube_zy_min_banis": (ns("all", [[0, 1]], "min"), 6, sig, (8, 8, 8), None,
+                                   ["1-0-0", "0-1-0", "0-0-1", "3-0-0", "0-3-0", "0-0-3"], "banis", xc, lambda t: _net_aff(t, 6)),
+    }
+    for name, (tta_ns, n_out, acts, roi, select, offsets, amode, xin, net) in cases.items():
+        cfg = cfg_for(tta_ns, n_out=n_out, acts=acts, roi=roi, select=select, offsets=offsets, amode=amode)
+        y = mgr.InferenceManager(cfg=cfg, model=torch.nn.Identity(), forward_fn=net).predict_with_tta(xin.clone())
+        out[f"{name}__y"] = y.numpy()
+        print(name, tuple(y.shape), float(y.mean()))
+    save("tta_zplanes.npz", **out)
+    # the reference's channel-move plans for view sets with z planes, appended to tests/golden/tta_affinity_plans.json (the host
+    # test walks every entry of that file)
+    import json
+    ta = S.ref("connectomics.inference.tta_affinity")
+    comb = S.ref("connectomics.inference.tta_combinations")
+    path = HERE / "tta_affinity_plans.json"
+    plans = json.loads(path.read_text())
+    lr = ["1-0-0", "0-1-0", "0-0-1", "3-0-0", "0-3-0", "0-0-3"]
+    for pname, (flip, rot, n_out, offsets, mode) in {
+            "z_unit3_deepem_all_planes": ("all", "all", 3, ["1-0-0", "0-1-0", "0-0-1"], "deepem"),
+            "z_lr6_banis_zy": ("all", [[0, 1]], 6, lr, "banis"),
+            "z_lr6_deepem_zx_flipy": ([[1]], [[0, 2]], 6, lr, "deepem")}.items():
+        cfg = cfg_for(ns(flip, rot, "mean"), n_out=n_out, acts=None, roi=(8, 8, 8), offsets=offsets, amode=mode)
+        combos = comb.resolve_tta_augmentation_combinations(cfg.inference.test_time_augmentation, spatial_dims=3)
+        plan = ta.build_affinity_tta_plan(cfg, augmentation_combinations=combos, num_raw=n_out, requested_head=None)
+        plans[pname] = {"flip": flip, "rot": rot, "n_out": n_out, "offsets": offsets, "mode": mode,
+                        "combos": [[list(f), None if pl is None else list(pl), int(k)] for f, pl, k in combos],
+                        "views": [[[m.src, m.dst, None if m.shift is None else list(m.shift)] for m in v.moves] for v in plan.views],
+                        "partial": sorted(plan.partial_channels), "shifts": sorted(list(s) for s in plan.shifts)}
+    path.write_text(json.dumps(plans, indent=0))
+    print("tta_affinity_plans.json now holds", sorted(plans))
+
+
 def public_adapters():
     """Fixtures for the public names a drop-in importer reaches for: the reference's own `invert_view`,
     `TTAEnsembleAccumulator` and `resolve_output_head(s)` on small seeded inputs."""
@@ -1348,7 +1417,7 @@ def balancing():
 
 if __name__ == "__main__":
     parts = {"manifests": manifests, "optimizers": optimizers, "schedules": schedules, "selectors": selectors, "outputs": outputs, "rsunet_train": rsunet_train, "crops": crops, "losses": losses, "grids": grids, "maps": maps, "normalise": normalise, "engine": engine, "rsunets": rsunets,
-             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "lazy": lazy, "lazy_tta": lazy_tta, "masks": masks, "accessor": accessor, "accessor_tiles": accessor_tiles, "ds_loss": ds_loss, "loss_orchestration": loss_orchestration, "losses_extra": losses_extra, "balancing": balancing, "public_adapters": public_adapters, "public_helpers": public_helpers, "volume_normalisation": volume_normalisation, "config_defaults": config_defaults}
+             "chunks": chunks, "tta": tta, "tta_affinity": tta_affinity, "tta_zplanes": tta_zplanes, "lazy": lazy, "lazy_tta": lazy_tta, "masks": masks, "accessor": accessor, "accessor_tiles": accessor_tiles, "ds_loss": ds_loss, "loss_orchestration": loss_orchestration, "losses_extra": losses_extra, "balancing": balancing, "public_adapters": public_adapters, "public_helpers": public_helpers, "volume_normalisation": volume_normalisation, "config_defaults": config_defaults}
     chosen = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or list(parts)
     for name in chosen:
         parts[name]()

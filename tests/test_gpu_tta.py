@@ -155,6 +155,64 @@ def test_affinity_tta_matches_reference(name, golden_dir):
     np.testing.assert_allclose(y, exp, rtol=2e-5, atol=2e-5)
 
 
+# ---- round 6: quarter turns in the planes that contain z (PYTC_VIEW_SWAP_ZY / _ZX) vs the reference (make_golden.py --tta_zplanes)
+def _zns(flip, rot, mode, ks=None):
+    return NS(enabled=True, flip_axes=flip, rotation90_axes=rot, rotate90_k=ks, ensemble_mode=mode, patch_first_local=True,
+              distributed_sharding=False, apply_mask=True)
+
+
+_SIG = [{"channels": ":", "activation": "sigmoid"}]
+ZPLANE_CASES = {
+    "cube_all32_mean": (_zns("all", "all", "mean"), 3, _SIG, (8, 8, 8), None, None, None, "x_cube"),
+    "zy_flipx_minmax": (_zns([[2]], [[0, 1]], [["0:2", "min"], ["2", "max"]]), 3,
+                        [{"channels": "0:2", "activation": "scale_sigmoid:0.5"}, {"channels": "2", "activation": "tanh"}],
+                        (8, 8, 12), None, None, None, "x_zy"),
+    "zx_k13_select": (_zns(None, [[0, 2]], "mean", ks=[1, 3]), 3, [{"channels": ":", "activation": "softmax"}], (8, 12, 8), [2, 0],
+                      None, None, "x_zx"),
+    "aff3_zx_mean_deepem": (_zns([[1]], [[0, 2]], "mean"), 3, _SIG, (8, 12, 8), None, ["1-0-0", "0-1-0", "0-0-1"], "deepem", "x_zx"),
+    "aff6_cube_zy_min_banis": (_zns("all", [[0, 1]], "min"), 6, _SIG, (8, 8, 8), None, _LR, "banis", "x_cube"),
+}
+
+
+@pytest.mark.parametrize("name", list(ZPLANE_CASES))
+def test_tta_rotations_in_planes_with_z_match_reference(name, golden_dir):
+    """tta_combinations.py:90-119 accepts any rotation plane whose axes have equal image and window size; the device engine exchanges
+    z with y / x inside the gather and blend kernels.  Plain and affinity-aware (channel moves + re-anchoring) predictors."""
+    from pytorch_connectomics_amd.inference import InferenceManager
+    tta_ns, n_out, acts, roi, select, offsets, amode, xkey = ZPLANE_CASES[name]
+    g = np.load(golden_dir / "tta_zplanes.npz")
+    cfg = _cfg(tta_ns, acts, select)
+    cfg.model.out_channels = n_out
+    cfg.inference.sliding_window.window_size = list(roi)
+    net = _net_asym
+    if offsets is not None:
+        cfg.data.label_transform = NS(stack_outputs=True, targets=[{"name": "affinity", "kwargs": {"offsets": offsets, "affinity_mode": amode}}])
+        net = lambda t: _net_aff(t, n_out)        # noqa: E731
+    y = InferenceManager(cfg=cfg, model=torch.nn.Identity(), forward_fn=net).predict_with_tta(torch.from_numpy(g[xkey]).cuda()).cpu().numpy()
+    exp = g[f"{name}__y"]
+    assert y.shape == exp.shape
+    np.testing.assert_allclose(y, exp, rtol=2e-5, atol=2e-5)
+
+
+def test_tta_rotation_with_z_needs_equal_axes():
+    from pytorch_connectomics_amd.inference import InferenceManager
+    from pytorch_connectomics_amd import hip_ops as ops
+    from pytorch_connectomics_amd import _native as nat
+    cfg = _cfg(_zns(None, [[0, 1]], "mean"), _SIG, None)           # window 8 x 12 x 12: z != y
+    with pytest.raises(ValueError, match="odd 90-degree rotations"):
+        InferenceManager(cfg=cfg, model=torch.nn.Identity(), forward_fn=_net_asym).predict_with_tta(torch.rand(1, 1, 16, 16, 16).cuda())
+    vol = torch.rand(1, 8, 12, 12).cuda()
+    with pytest.raises(RuntimeError, match="exchanged window axes"):
+        ops.gather_windows(vol, [(0, 0, 0)], (8, 12, 12), view=nat.VIEW_SWAP_ZY)
+    with pytest.raises(RuntimeError, match="at most one SWAP bit"):
+        ops.gather_windows(vol, [(0, 0, 0)], (8, 8, 8), view=nat.VIEW_SWAP_ZY | nat.VIEW_SWAP_YX)
+    # the gather of a z-x exchanged, x-flipped window is the torch transform of the plain window
+    cube = torch.rand(1, 8, 8, 8).cuda()
+    plain = ops.gather_windows(cube, [(0, 0, 0)], (8, 8, 8))
+    got = ops.gather_windows(cube, [(0, 0, 0)], (8, 8, 8), view=nat.VIEW_SWAP_ZX | nat.VIEW_FLIP_X)
+    assert torch.equal(got, torch.flip(plain.transpose(1, 3), dims=[3]))
+
+
 def test_tta_ensemble_accumulator_matches_the_reference(golden_dir):
     """The public `TTAEnsembleAccumulator` (device statistics, ensemble kernels) fed with the canonical predictions and validity
     boxes of 16 views: equal to the reference accumulator's result (tests/golden/public_adapters.npz)."""

@@ -61,8 +61,21 @@ def test_tta_combinations_and_view_codes():
         dims = [d for d, b in enumerate((1, 2, 4)) if code & b]
         mine = torch.flip(mine, dims) if dims else mine
         assert torch.equal(mine, apply_view(probe, f, pl, k, first_spatial_dim=0))
-    with pytest.raises(NotImplementedError):
-        view_code([], (0, 1), 1)
+    # round 6: quarter turns in EVERY plane (tta_combinations.py:90-119): the planes with z exchange z with y / x (swap bits 16 / 32)
+    every = resolve_tta_augmentation_combinations(NS(flip_axes="all", rotation90_axes="all"), spatial_dims=3)
+    cube = torch.arange(4 * 4 * 4).reshape(4, 4, 4)
+    seen = set()
+    for f, pl, k in every:
+        code = view_code(f, pl, k)
+        swaps = [b for b in (8, 16, 32) if code & b]
+        assert len(swaps) <= 1 and code < 64
+        mine = cube.transpose(*{8: (1, 2), 16: (0, 1), 32: (0, 2)}[swaps[0]]) if swaps else cube
+        dims = [d for d, b in enumerate((1, 2, 4)) if code & b]
+        mine = torch.flip(mine, dims) if dims else mine
+        assert torch.equal(mine, apply_view(cube, f, pl, k, first_spatial_dim=0)), (f, pl, k, code)
+        seen.add(code)
+    assert len(seen) == len(every) == 32                   # 8 flip sets x {identity, three axis exchanges}: de-duplicated views
+    assert view_code([], (0, 1), 1) & 16 and view_code([], (0, 2), 3) & 32 and view_code([], (0, 1), 2) == 3
     with pytest.raises(ValueError, match="exactly 2 axes"):
         resolve_tta_augmentation_combinations(NS(flip_axes=None, rotation90_axes=[[1]]), spatial_dims=3)
     assert len(resolve_tta_augmentation_combinations(NS(flip_axes=None, rotation90_axes="all", rotate90_k=[0, 2]),
