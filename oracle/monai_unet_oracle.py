@@ -11,6 +11,7 @@ the published `monai.networks.nets.UNet` / `blocks.ResidualUnit` / `blocks.Convo
                     res = conv(k, s, p) if strided else conv(1) if widths differ else identity;  out = cx + res
     up            = ConvTranspose(k, s, p, output_padding = s-1) -> norm -> PReLU, then ResidualUnit(subunits 1,
                     last_conv_only at the top level: no norm / activation on the output)
+    num_res_units = 0: down = one conv -> norm -> PReLU, up = the transposed conv (-> norm -> PReLU below the top level) alone
 
 anchored on the reference's own shape tests (tests/unit/test_registry_basic.py:64-138: output shape == input spatial
 shape, out_channels channels) and on the state-dict key vocabulary.  It walks a state dict by those keys, so it does not
@@ -67,15 +68,25 @@ def _residual_unit(st, prefix, x, *, stride, kind, training, groups):
     return cx + res
 
 
+def _down(st, prefix, x, *, stride, kind, training, groups):
+    """UNet._get_down_layer: a ResidualUnit (keys `<prefix>.conv.unitN...`), or with num_res_units = 0 one Convolution
+    (keys `<prefix>.conv.weight`)."""
+    if prefix + ".conv.weight" in st:
+        return _convolution(st, prefix, x, stride=stride, transposed=False, kind=kind, training=training, groups=groups)
+    return _residual_unit(st, prefix, x, stride=stride, kind=kind, training=training, groups=groups)
+
+
 def _block(st, prefix, x, levels_left: int, *, kind, training, groups):
     """prefix addresses a Sequential(down, SkipConnection(sub), up)."""
-    d = _residual_unit(st, prefix + ".0", x, stride=2, kind=kind, training=training, groups=groups)
+    d = _down(st, prefix + ".0", x, stride=2, kind=kind, training=training, groups=groups)
     sub_prefix = prefix + ".1.submodule"
     if levels_left > 1:
         s = _block(st, sub_prefix, d, levels_left - 1, kind=kind, training=training, groups=groups)
-    else:                                                   # bottom layer: a stride-1 ResidualUnit
-        s = _residual_unit(st, sub_prefix, d, stride=1, kind=kind, training=training, groups=groups)
+    else:                                                   # bottom layer: a stride-1 down layer
+        s = _down(st, sub_prefix, d, stride=1, kind=kind, training=training, groups=groups)
     c = torch.cat([d, s], 1)
+    if prefix + ".2.conv.weight" in st:                     # num_res_units = 0: the up layer is the transposed Convolution alone
+        return _convolution(st, prefix + ".2", c, stride=2, transposed=True, kind=kind, training=training, groups=groups)
     u = _convolution(st, prefix + ".2.0", c, stride=2, transposed=True, kind=kind, training=training, groups=groups)
     return _residual_unit(st, prefix + ".2.1", u, stride=1, kind=kind, training=training, groups=groups)
 

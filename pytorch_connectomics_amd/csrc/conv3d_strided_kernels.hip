@@ -26,6 +26,7 @@ struct SConvParams {
   int sd, sh, sw;       // stride per axis
   int pd, ph, pw;       // padding per axis
   int transposed;
+  int phase_major;      // transposed, stride 2 on every axis, output grid = 2 x input grid: rows are enumerated phase by phase (below)
   int act_in;
   float act_param;
 };
@@ -65,17 +66,34 @@ conv3d_strided_kernel(SConvParams p) {
   if (row0 >= rps) return;
   const int r = lane & 15, kb = lane >> 4;
 
+  // Round 6: a stride-2 transposed gather enumerates its output rows PHASE BY PHASE -- row = phase * (Di Hi Wi) + input-grid position,
+  // output voxel (2 iz + a, 2 iy + b, 2 ix + c) for phase (a, b, c).  The taps an output voxel sees depend only on its phase (per
+  // axis: one tap for an even coordinate, two for an odd one -- 27 taps spread over 8 phases), so all 16 rows of a fragment, and all
+  // NT fragments of a wave, use the SAME taps: the wave-uniform skip below drops the others (27 / 8 = 3.4 tap iterations per row on
+  // average).  In raster order every wave held both x parities: 6.75 iterations of which half the lanes contributed zeros.
+  // Same taps in the same ascending order per output voxel -> same bits.
   long orow[NT];
   int vz[NT], vy[NT], vx[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     long o = row0 + nt * 16 + r;
-    orow[nt] = o;
     long oc = o < rps ? o : rps - 1;
-    vx[nt] = (int)(oc % p.Wo);
-    long t = oc / p.Wo;
-    vy[nt] = (int)(t % p.Ho);
-    vz[nt] = (int)(t / p.Ho);
+    if (p.phase_major) {
+      const int phase = (int)(oc / rps_in);
+      long q = oc - (long)phase * rps_in;
+      const int ix = (int)(q % p.Wi);
+      q /= p.Wi;
+      vx[nt] = 2 * ix + (phase & 1);
+      vy[nt] = 2 * (int)(q % p.Hi) + ((phase >> 1) & 1);
+      vz[nt] = 2 * (int)(q / p.Hi) + (phase >> 2);
+      orow[nt] = o < rps ? ((long)vz[nt] * p.Ho + vy[nt]) * p.Wo + vx[nt] : rps;
+    } else {
+      orow[nt] = o;
+      vx[nt] = (int)(oc % p.Wo);
+      long t = oc / p.Wo;
+      vy[nt] = (int)(t % p.Ho);
+      vz[nt] = (int)(t / p.Ho);
+    }
   }
   const TI* xn = reinterpret_cast<const TI*>(p.x) + (long)n * rps_in * p.C_in;
   const bool vec_ok = (p.C_in % EPL) == 0;
@@ -787,6 +805,8 @@ extern "C" int pytc_conv3d_strided_fwd(const pytc_conv3d_args* a, const int32_t*
   p.sd = stride[0]; p.sh = stride[1]; p.sw = stride[2];
   p.pd = pad[0]; p.ph = pad[1]; p.pw = pad[2];
   p.transposed = transposed ? 1 : 0;
+  p.phase_major = (p.transposed && p.sd == 2 && p.sh == 2 && p.sw == 2 && p.Do == 2 * p.Di && p.Ho == 2 * p.Hi && p.Wo == 2 * p.Wi &&
+                   tuning_get("convT_phase_major", 1) != 0) ? 1 : 0;
   p.act_in = a->act_in; p.act_param = a->act_param;
   p.e.res = a->res; p.e.res_low = nullptr; p.e.res_bias = nullptr; p.e.y = a->y;
   p.e.rps_out = (long)a->D * a->H * a->W; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode; p.e.nt = 0;

@@ -126,8 +126,6 @@ class UNet(nn.Module):
         delta = len(strides) - (len(channels) - 1)
         if delta < 0:
             raise ValueError("the length of `strides` should equal to `len(channels) - 1`.")
-        if num_res_units <= 0:
-            raise NotImplementedError("monai_unet with num_res_units=0 (plain Convolution blocks) is not built")
         self.dimensions = spatial_dims
         self.in_channels, self.out_channels = in_channels, out_channels
         self.channels, self.strides = tuple(channels), tuple(strides)
@@ -147,12 +145,20 @@ class UNet(nn.Module):
         self.model = create(in_channels, out_channels, self.channels, self.strides, True)
 
     def _down(self, inc: int, outc: int, strides: int) -> nn.Module:
-        return ResidualUnit(inc, outc, strides=strides, kernel_size=self.kernel_size, subunits=self.num_res_units,
-                            norm=self.norm, dropout=self.dropout, bias=self.bias)
+        """monai UNet._get_down_layer: a ResidualUnit, or with num_res_units = 0 one plain Convolution (conv -> norm -> PReLU)."""
+        if self.num_res_units > 0:
+            return ResidualUnit(inc, outc, strides=strides, kernel_size=self.kernel_size, subunits=self.num_res_units,
+                                norm=self.norm, dropout=self.dropout, bias=self.bias)
+        return Convolution(inc, outc, strides=strides, kernel_size=self.kernel_size, norm=self.norm, dropout=self.dropout,
+                           bias=self.bias)
 
     def _up(self, inc: int, outc: int, strides: int, is_top: bool) -> nn.Module:
+        """monai UNet._get_up_layer: transposed Convolution (+ a one-subunit ResidualUnit when num_res_units > 0); the top layer ends
+        without norm / activation -- on the ResidualUnit's last conv, or with num_res_units = 0 on the transposed conv itself."""
         conv = Convolution(inc, outc, strides=strides, kernel_size=self.up_kernel_size, norm=self.norm,
-                           dropout=self.dropout, bias=self.bias, conv_only=False, is_transposed=True)
+                           dropout=self.dropout, bias=self.bias, conv_only=is_top and self.num_res_units == 0, is_transposed=True)
+        if self.num_res_units <= 0:
+            return conv
         ru = ResidualUnit(outc, outc, strides=1, kernel_size=self.kernel_size, subunits=1, norm=self.norm,
                           dropout=self.dropout, bias=self.bias, last_conv_only=is_top)
         return nn.Sequential(conv, ru)

@@ -162,6 +162,39 @@ def test_monai_unet_training_step_matches_oracle_autograd():
     assert int(m.state_dict()["model.model.0.conv.unit0.adn.N.num_batches_tracked"]) == 1
 
 
+@pytest.mark.parametrize("filters,norm,size", [((8, 16, 32), "batch", (16, 32, 32)), ((16, 24), "group", (8, 16, 24))])
+def test_monai_unet_without_residual_units_matches_oracle(filters, norm, size):
+    """model.monai.num_res_units = 0 (monai UNet._get_down_layer / _get_up_layer without residual units): every down layer one
+    conv -> norm -> PReLU, every up layer the transposed conv alone (no norm / activation at the top); forward in eval mode and one
+    training step (loss + all gradients) against the oracle."""
+    cfg = _cfg(filters, norm, size, out_ch=1, res_units=0)
+    m = _build(cfg, seed=7)
+    st = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    keys = set(st)
+    assert "model.model.0.conv.weight" in keys and "model.model.0.adn.N.weight" in keys and "model.model.2.conv.weight" in keys
+    assert not any(k.startswith("model.model.2.adn") or ".residual." in k or ".unit0." in k for k in keys)
+    x = torch.rand(2, 1, *size, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        ref = UO.forward(st, x, n_levels=len(filters), norm=norm, num_groups=2)
+        got = m.cuda().eval()(x.cuda()).cpu()
+    assert got.shape == ref.shape == (2, 1) + tuple(size)
+    torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-3 * float(ref.abs().max()))
+    tgt = (torch.rand(ref.shape, generator=torch.Generator().manual_seed(6)) > 0.7).float()
+    params = {k: v.clone().requires_grad_(True) for k, v in st.items() if v.dtype.is_floating_point and "running" not in k}
+    full = dict(st)
+    full.update(params)
+    ref_loss = F.binary_cross_entropy_with_logits(UO.forward(full, x, n_levels=len(filters), norm=norm, training=True, num_groups=2), tgt)
+    ref_loss.backward()
+    m = m.train()
+    loss = F.binary_cross_entropy_with_logits(m(x.cuda()), tgt.cuda())
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 1e-4
+    named = dict(m.named_parameters())
+    g = torch.cat([named[k].grad.cpu().flatten().double() for k in params])
+    r = torch.cat([p.grad.flatten().double() for p in params.values()])
+    assert float((g * r).sum() / (g.norm() * r.norm())) > 0.99995 and float((g - r).norm() / r.norm()) < 1e-2
+
+
 def test_monai_unet_rejects_sizes_the_reference_cannot_run():
     m = _build(_cfg((8, 16, 32, 64), "batch")).cuda().eval()
     with pytest.raises(ValueError, match="divisible"):
