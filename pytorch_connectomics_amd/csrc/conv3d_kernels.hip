@@ -19,6 +19,11 @@ struct ConvParams {
   int act_in;           // PYTC_ACT_* of the fused pre-activation (NONE = affine only)
   float act_param;      // leaky slope / prelu weight / elu alpha
   int act_out;
+  // LDS-tiled form only (round 6): low-side zero padding per axis (a 'same' conv: k / 2) and the output map -- om = 1: the voxel
+  // (z, y, x) of the D x H x W grid the kernel walks is stored at (2z + oz, 2y + oy, 2x + ox) of a Do x Ho x Wo tensor (one PHASE of a
+  // stride-2 transposed conv: csrc/conv3d_kernels.hip convT phase form)
+  int pd, ph, pw;
+  int om, oz, oy, ox, Ho, Wo;
 };
 
 __device__ __forceinline__ float pre_act(float v, int act, float prm) {
@@ -233,7 +238,7 @@ conv3d_tile_kernel(ConvParams p, ConvTile t) {
   const int n = (int)(b / t.tiles_z);
   const int z0 = bz * CT_TZ, y0 = by * CT_TY, x0 = bx * CT_TX;
   const int mt0 = blockIdx.y * MT;
-  const int pd = p.kd / 2, ph = p.kh / 2, pw = p.kw / 2;
+  const int pd = p.pd, ph = p.ph, pw = p.pw;
   const int ntap = p.kd * p.kh * p.kw;
   const long rps = (long)p.D * p.H * p.W;
   const bf16_t* xn = reinterpret_cast<const bf16_t*>(p.x) + (long)n * rps * p.C_in;
@@ -334,7 +339,8 @@ conv3d_tile_kernel(ConvParams p, ConvTile t) {
       float v[4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) v[rr] = apply_act(acc[mt][nt][rr] + bo[rr], p.act_out);
-      finish_and_store<bf16_t, 4>(v, p.e, n, ((long)z * p.H + y) * p.W + x, o0);
+      const long row = p.om ? ((long)(2 * z + p.oz) * p.Ho + (2 * y + p.oy)) * p.Wo + (2 * x + p.ox) : ((long)z * p.H + y) * p.W + x;
+      finish_and_store<bf16_t, 4>(v, p.e, n, row, o0);
     }
   }
 }
@@ -409,6 +415,32 @@ conv3d_pack_multi_kernel(const long* __restrict__ table, int n_items) {
   const long s_o = r[2], s_c = r[3];
   const int C_out = (int)r[6], C_in = (int)r[7], ntap = (int)r[8], kind = (int)r[9], f32 = (int)r[10], flip = (int)r[11];
   int o, k, tap;
+  if (kind == 2) {
+    // one phase (bits a b c = z y x parity of the output voxel) of a k 3 / stride 2 / pad 1 transposed gather as a stride-1 conv with
+    // (1 + a) x (1 + b) x (1 + c) taps on the input grid: out[2i] = w[1] x[i];  out[2i + 1] = w[2] x[i] + w[0] x[i + 1] per axis --
+    // flat chunked layout of kind 1 with the phase's tap count, the source tap read off the sub-tap (d = 0 -> x[i], d = 1 -> x[i + 1])
+    const int KC = (int)r[12], nchunks = (int)r[13], G = (int)r[14], phase = flip;
+    const int j = (int)(i % 8);
+    long q = i / 8;
+    const int lane = (int)(q % 64); q /= 64;
+    const int g = (int)(q % G); q /= G;
+    const int ck = (int)(q % nchunks);
+    const int mt = (int)(q / nchunks);
+    o = mt * 16 + (lane & 15);
+    const int f = g * 32 + (lane >> 4) * 8 + j;
+    const int st = f / KC;                       // sub-tap of the phase, (dz, dy, dx) with extents (1 + a, 1 + b, 1 + c)
+    k = ck * KC + f % KC;
+    const int a = (phase >> 2) & 1, b = (phase >> 1) & 1, c = phase & 1;
+    float v = 0.f;
+    if (o < C_out && k < C_in && st < ntap) {
+      const int dx = st % (1 + c), t2 = st / (1 + c);
+      const int dy = t2 % (1 + b), dz = t2 / (1 + b);
+      const int tz = a ? (dz ? 0 : 2) : 1, ty = b ? (dy ? 0 : 2) : 1, tx = c ? (dx ? 0 : 2) : 1;
+      v = w[o * s_o + k * s_c + (tz * 3 + ty) * 3 + tx];
+    }
+    reinterpret_cast<bf16_t*>(r[1])[i] = from_f32<bf16_t>(v);
+    return;
+  }
   if (kind == 1) {
     const int KC = (int)r[12], nchunks = (int)r[13], G = (int)r[14];
     const int j = (int)(i % 8);
@@ -574,6 +606,8 @@ extern "C" int pytc_conv3d_fwd(const pytc_conv3d_args* a, void* stream) {
   p.MTt = (a->C_out + 15) / 16;
   p.kd = a->kd; p.kh = a->kh; p.kw = a->kw;
   p.act_in = a->act_in; p.act_param = a->act_param; p.act_out = PYTC_ACT_NONE;
+  p.pd = a->kd / 2; p.ph = a->kh / 2; p.pw = a->kw / 2;
+  p.om = p.oz = p.oy = p.ox = p.Ho = p.Wo = 0;
   p.e.res = a->res; p.e.res_low = nullptr; p.e.res_bias = nullptr; p.e.y = a->y;
   p.e.rps_out = (long)a->D * a->H * a->W; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode; p.e.nt = 0;
   p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
@@ -585,3 +619,67 @@ extern "C" int pytc_conv3d_fwd(const pytc_conv3d_args* a, void* stream) {
   PYTC_LAUNCH_CHECK("conv3d");
   return PYTC_OK;
 }
+
+// ---- stride-2 transposed gather (k 3, pad 1, output = 2 x input grid) as EIGHT stride-1 convs on the LDS-tiled kernel (round 6) ---------
+// The gather form (conv3d_strided_kernels.hip) loads every operand fragment from global memory per tap with nothing in flight:
+// convT3d_fwd[384 -> 64] ran at 11 TFLOP/s, and halving its tap iterations (phase-major rows) bought 4 %.  A phase
+// (a, b, c) = parity of the output voxel is a stride-1 correlation with (1 + a)(1 + b)(1 + c) taps on the INPUT grid (forward halo of one
+// voxel on the odd axes) that writes every second voxel per axis: conv3d_tile_kernel with explicit padding and the 2x output map, one
+// launch per phase (27 taps over 8 phases: no zero work), the haloed input block staged once per chunk of input channels.
+// Serves ConvTranspose3d(k 3, s 2, p 1, output_padding 1) and the data gradient of Conv3d(k 3, s 2, p 1) on even grids.
+static bool convT_phase_plan(int dtype, int C_in, ConvTile (&t)[8], size_t (&lds)[8]) {
+  for (int ph = 0; ph < 8; ++ph)
+    if (!conv_tile_plan(dtype, C_in, 1 + ((ph >> 2) & 1), 1 + ((ph >> 1) & 1), 1 + (ph & 1), t[ph], lds[ph])) return false;
+  return true;
+}
+
+/* out[0..7] = element offset of the phase images in one buffer, out[8] = total elements, out[9] = KC, out[10] = nchunks, out[11..18] = G */
+extern "C" int pytc_convT3d_phase_plan(int C_out, int C_in, int dtype, int64_t* out) {
+  PYTC_REQUIRE(out && C_out >= 1 && C_in >= 1, "convT3d_phase_plan: bad arguments");
+  ConvTile t[8]; size_t lds[8];
+  if (!convT_phase_plan(dtype, C_in, t, lds)) return PYTC_ERR_UNSUPPORTED;
+  int64_t off = 0;
+  for (int ph = 0; ph < 8; ++ph) {
+    out[ph] = off;
+    out[11 + ph] = t[ph].G;
+    off += (int64_t)((C_out + 15) / 16) * t[ph].nchunks * t[ph].G * 64 * 8;
+  }
+  out[8] = off; out[9] = t[0].KC; out[10] = t[0].nchunks;
+  return PYTC_OK;
+}
+
+extern "C" int pytc_convT3d_phase_supported(int C_out, int C_in, int dtype) {
+  ConvTile t[8]; size_t lds[8];
+  return (C_out >= 1 && C_in >= 1 && convT_phase_plan(dtype, C_in, t, lds) && tuning_get("convT_phase_tile", 1) != 0) ? 1 : 0;
+}
+
+/* a->D/H/W: the OUTPUT grid (= 2 x in_dims), a->w_packed: the eight phase images (pytc_convT3d_phase_plan offsets), a->kd = kh = kw = 3 */
+extern "C" int pytc_convT3d_phase_fwd(const pytc_conv3d_args* a, const int32_t* in_dims, void* stream) {
+  PYTC_REQUIRE(a && a->x && a->w_packed && a->y && in_dims, "convT3d_phase: null pointer");
+  PYTC_REQUIRE(a->N >= 1 && a->C_in >= 1 && a->C_out >= 1 && a->dtype == PYTC_BF16, "convT3d_phase: bf16 only");
+  PYTC_REQUIRE(a->kd == 3 && a->kh == 3 && a->kw == 3 && a->D == 2 * in_dims[0] && a->H == 2 * in_dims[1] && a->W == 2 * in_dims[2],
+               "convT3d_phase: kernel 3, stride 2, padding 1, output grid = 2 x input grid");
+  PYTC_REQUIRE(a->res_mode == PYTC_RES_NONE || (a->res_mode == PYTC_RES_ADD && a->res), "convT3d_phase: bad residual");
+  ConvTile t[8]; size_t lds[8];
+  PYTC_REQUIRE(convT_phase_plan(a->dtype, a->C_in, t, lds), "convT3d_phase: C_in % 8 != 0 or the tile does not fit LDS");
+  hipStream_t s = (hipStream_t)stream;
+  long off = 0;
+  for (int ph = 0; ph < 8; ++ph) {
+    ConvParams p;
+    p.x = a->x; p.wp = reinterpret_cast<const bf16_t*>(a->w_packed) + off; p.bias = a->bias; p.ab = a->ab;
+    p.N = a->N; p.D = in_dims[0]; p.H = in_dims[1]; p.W = in_dims[2]; p.C_in = a->C_in; p.C_out = a->C_out;
+    p.KG = 0; p.MTt = (a->C_out + 15) / 16;
+    p.kd = 1 + ((ph >> 2) & 1); p.kh = 1 + ((ph >> 1) & 1); p.kw = 1 + (ph & 1);
+    p.act_in = a->act_in; p.act_param = a->act_param; p.act_out = PYTC_ACT_NONE;
+    p.pd = p.ph = p.pw = 0;
+    p.om = 1; p.oz = (ph >> 2) & 1; p.oy = (ph >> 1) & 1; p.ox = ph & 1; p.Ho = a->H; p.Wo = a->W;
+    p.e.res = a->res; p.e.res_low = nullptr; p.e.res_bias = nullptr; p.e.y = a->y;
+    p.e.rps_out = (long)a->D * a->H * a->W; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode; p.e.nt = 0;
+    p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
+    launch_conv_tile(p, t[ph], lds[ph], s);
+    off += (long)p.MTt * t[ph].nchunks * t[ph].G * 64 * 8;
+  }
+  PYTC_LAUNCH_CHECK("convT3d_phase");
+  return PYTC_OK;
+}
+
