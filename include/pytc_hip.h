@@ -697,6 +697,19 @@ int pytc_dwconv3d_generic_fwd(const void* x, void* y, const float* w, int N, int
 int64_t pytc_conv3d_direct_packed_elems(int C_out, int C_in, int kd, int kh, int kw, int dtype);
 int pytc_conv3d_pack_weight_direct(const float* w, int C_out, int C_in, int kd, int kh, int kw, int64_t s_o, int64_t s_c,
                                    int flip, void* packed, int dtype, void* stream);
+/* Round 6 -- the stride-2 transposed gather (ConvTranspose3d k 3 / s 2 / p 1 / output_padding 1, and the data gradient of Conv3d k 3 / s 2 /
+ * p 1 on even grids) as EIGHT stride-1 convs on the LDS-tiled kernel of pytc_conv3d_fwd, one per parity (a, b, c) of the output voxel:
+ *   y[2i + a, 2j + b, 2k + c] = sum over the (1 + a)(1 + b)(1 + c) sub-taps of W_phase * f(x)[i + dz, j + dy, k + dx]
+ * (per axis: even -> tap 1 at offset 0; odd -> tap 2 at offset 0 and tap 0 at offset 1).  bf16, C_in % 8 == 0.
+ * pytc_convT3d_phase_plan: out[0..7] element offsets of the eight phase images in ONE buffer, out[8] total elements, out[9] = KC,
+ *   out[10] = chunks, out[11..18] = groups per phase; PYTC_ERR_UNSUPPORTED when the shape has no tile plan.
+ * The images are written by pytc_conv3d_pack_multi rows of kind 2: { w, image + offset, s_o, s_c, first block, elements, C_out, C_in,
+ *   sub-taps of the phase, 2, 0, PHASE (4a + 2b + c), KC, chunks, groups, 0 } with element (o, c, tap) of the 27-tap conv at
+ *   w[o*s_o + c*s_c + tap].
+ * pytc_convT3d_phase_fwd: `a` as for pytc_conv3d_strided_fwd (a->D/H/W the OUTPUT grid = 2 x in_dims, kernel 3), a->w_packed the images. */
+int pytc_convT3d_phase_plan(int C_out, int C_in, int dtype, int64_t* out);
+int pytc_convT3d_phase_supported(int C_out, int C_in, int dtype);
+int pytc_convT3d_phase_fwd(const pytc_conv3d_args* a, const int32_t* in_dims, void* stream);
 int pytc_conv3d_strided_fwd(const pytc_conv3d_args* a, const int32_t* in_dims, const int32_t* stride, const int32_t* pad,
                             int transposed, void* stream);
 int64_t pytc_conv3d_wgrad_strided_ws_elems(int N, const int32_t* small_dims, int C_k, int C_o, const int32_t* kernel);

@@ -213,6 +213,9 @@ conv3d_thin_in_kernel(ConvParams p) {
 // from L1/L2 one group ahead of the MFMAs.
 constexpr int CT_TZ = 4, CT_TY = 8, CT_TX = 16;
 struct ConvTile { int KC, nchunks, G, tzh, tyh, txh, tiles_z, tiles_y, tiles_x; };
+// the eight phases of a stride-2 transposed gather in ONE launch (blockIdx.z = phase = 4a + 2b + c): per phase the tap extents are
+// (1 + a, 1 + b, 1 + c), the groups per chunk G and the element offset of its weight image differ; n = 0: an ordinary conv
+struct ConvPhases { int n; int G[8]; long woff[8]; };
 
 // channels per staged chunk: the whole (narrow) layer when it fits one chunk, else the widest divisor among 32 / 16 / 8
 static __host__ __device__ inline int conv_kc(int C_in) {
@@ -221,9 +224,17 @@ static __host__ __device__ inline int conv_kc(int C_in) {
 
 template <int MT>
 __global__ void __launch_bounds__(256, 2)
-conv3d_tile_kernel(ConvParams p, ConvTile t) {
+conv3d_tile_kernel(ConvParams p, ConvTile t, ConvPhases ps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int NT = CT_TY;
+  if (ps.n) {
+    const int phz = blockIdx.z, a = (phz >> 2) & 1, b = (phz >> 1) & 1, c = phz & 1;
+    p.kd = 1 + a; p.kh = 1 + b; p.kw = 1 + c;
+    p.oz = a; p.oy = b; p.ox = c;
+    p.wp = reinterpret_cast<const bf16_t*>(p.wp) + ps.woff[phz];
+    t.G = ps.G[phz];
+    t.tzh = CT_TZ + a; t.tyh = CT_TY + b; t.txh = CT_TX + c;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = lane & 15, kb = lane >> 4;
   const int P = t.KC * 2;                                   // LDS bytes per staged voxel
@@ -474,7 +485,13 @@ template <int MT>
 static void launch_conv_tile_mt(const ConvParams& p, const ConvTile& t, size_t lds_bytes, dim3 grid, hipStream_t s) {
   // dynamic LDS above 64 KB needs the opt-in, once per kernel and device
   if (!ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3d_tile_kernel<MT>), 80 * 1024, "conv3d_tile")) return;
-  hipLaunchKernelGGL((conv3d_tile_kernel<MT>), grid, dim3(256), lds_bytes, s, p, t);
+  hipLaunchKernelGGL((conv3d_tile_kernel<MT>), grid, dim3(256), lds_bytes, s, p, t, ConvPhases{});
+}
+
+template <int MT>
+static void launch_conv_phases_mt(const ConvParams& p, const ConvTile& t, const ConvPhases& ps, size_t lds_bytes, dim3 grid, hipStream_t s) {
+  if (!ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3d_tile_kernel<MT>), 80 * 1024, "conv3d_tile")) return;
+  hipLaunchKernelGGL((conv3d_tile_kernel<MT>), grid, dim3(256), lds_bytes, s, p, t, ps);
 }
 
 static void launch_conv_tile(const ConvParams& p, ConvTile t, size_t lds_bytes, hipStream_t s) {
@@ -663,21 +680,36 @@ extern "C" int pytc_convT3d_phase_fwd(const pytc_conv3d_args* a, const int32_t* 
   ConvTile t[8]; size_t lds[8];
   PYTC_REQUIRE(convT_phase_plan(a->dtype, a->C_in, t, lds), "convT3d_phase: C_in % 8 != 0 or the tile does not fit LDS");
   hipStream_t s = (hipStream_t)stream;
+  ConvParams p;
+  p.x = a->x; p.wp = a->w_packed; p.bias = a->bias; p.ab = a->ab;
+  p.N = a->N; p.D = in_dims[0]; p.H = in_dims[1]; p.W = in_dims[2]; p.C_in = a->C_in; p.C_out = a->C_out;
+  p.KG = 0; p.MTt = (a->C_out + 15) / 16;
+  p.kd = p.kh = p.kw = 1;                                  // (set per phase in the kernel)
+  p.act_in = a->act_in; p.act_param = a->act_param; p.act_out = PYTC_ACT_NONE;
+  p.pd = p.ph = p.pw = 0;
+  p.om = 1; p.oz = p.oy = p.ox = 0; p.Ho = a->H; p.Wo = a->W;
+  p.e.res = a->res; p.e.res_low = nullptr; p.e.res_bias = nullptr; p.e.y = a->y;
+  p.e.rps_out = (long)a->D * a->H * a->W; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode; p.e.nt = 0;
+  p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
+  ConvPhases ps;
+  ps.n = 8;
   long off = 0;
+  size_t lds_max = 0;
   for (int ph = 0; ph < 8; ++ph) {
-    ConvParams p;
-    p.x = a->x; p.wp = reinterpret_cast<const bf16_t*>(a->w_packed) + off; p.bias = a->bias; p.ab = a->ab;
-    p.N = a->N; p.D = in_dims[0]; p.H = in_dims[1]; p.W = in_dims[2]; p.C_in = a->C_in; p.C_out = a->C_out;
-    p.KG = 0; p.MTt = (a->C_out + 15) / 16;
-    p.kd = 1 + ((ph >> 2) & 1); p.kh = 1 + ((ph >> 1) & 1); p.kw = 1 + (ph & 1);
-    p.act_in = a->act_in; p.act_param = a->act_param; p.act_out = PYTC_ACT_NONE;
-    p.pd = p.ph = p.pw = 0;
-    p.om = 1; p.oz = (ph >> 2) & 1; p.oy = (ph >> 1) & 1; p.ox = ph & 1; p.Ho = a->H; p.Wo = a->W;
-    p.e.res = a->res; p.e.res_low = nullptr; p.e.res_bias = nullptr; p.e.y = a->y;
-    p.e.rps_out = (long)a->D * a->H * a->W; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode; p.e.nt = 0;
-    p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
-    launch_conv_tile(p, t[ph], lds[ph], s);
+    ps.G[ph] = t[ph].G; ps.woff[ph] = off;
     off += (long)p.MTt * t[ph].nchunks * t[ph].G * 64 * 8;
+    if (lds[ph] > lds_max) lds_max = lds[ph];
+  }
+  ConvTile tt = t[7];
+  tt.tiles_z = (p.D + CT_TZ - 1) / CT_TZ; tt.tiles_y = (p.H + CT_TY - 1) / CT_TY; tt.tiles_x = (p.W + CT_TX - 1) / CT_TX;
+  int MT = p.MTt >= 4 ? 4 : (p.MTt >= 2 ? 2 : 1);
+  const long spatial = (long)p.N * tt.tiles_z * tt.tiles_y * tt.tiles_x;
+  while (MT > 1 && spatial * 8 * ((p.MTt + MT - 1) / MT) < 512) MT >>= 1;       // (as launch_conv_tile: enough workgroups for the chip)
+  dim3 grid((unsigned)spatial, (unsigned)((p.MTt + MT - 1) / MT), 8);
+  switch (MT) {
+    case 1: launch_conv_phases_mt<1>(p, tt, ps, lds_max, grid, s); break;
+    case 2: launch_conv_phases_mt<2>(p, tt, ps, lds_max, grid, s); break;
+    default: launch_conv_phases_mt<4>(p, tt, ps, lds_max, grid, s); break;
   }
   PYTC_LAUNCH_CHECK("convT3d_phase");
   return PYTC_OK;

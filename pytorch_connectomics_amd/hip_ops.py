@@ -980,9 +980,22 @@ def _conv_layout_rule(shape, layout: str):
         return b, a, ntap, b * ntap, 1, 0
     if layout in ("conv", "convT_dgrad"):
         return a, b, b * ntap, ntap, 0, 1
-    if layout in ("convT", "conv_dgrad"):
+    if layout in ("convT", "conv_dgrad", "convT_phase", "conv_dgrad_phase"):
         return b, a, ntap, b * ntap, 0, 1
     raise ValueError(f"unknown weight layout {layout!r}")
+
+
+_PHASE_LAYOUTS = ("convT_phase", "conv_dgrad_phase")
+
+
+def convT3d_phase_plan(c_out: int, c_in: int):
+    """(offsets[8], total elements, KC, chunks, groups[8]) of the eight phase images of a stride-2 transposed gather, or None when the
+    shape has no LDS-tile plan (pytc_convT3d_phase_plan)."""
+    out = (C.c_int64 * 19)()
+    if nat.lib().pytc_convT3d_phase_plan(int(c_out), int(c_in), nat.BF16, out) != nat.OK:
+        return None
+    v = [int(x) for x in out]
+    return v[0:8], v[8], v[9], v[10], v[11:19]
 
 
 def _conv_pack_row(w: torch.Tensor, out_ptr: int, layout: str, dtype: torch.dtype, pad_to, first_block: int):
@@ -993,11 +1006,29 @@ def _conv_pack_row(w: torch.Tensor, out_ptr: int, layout: str, dtype: torch.dtyp
     if co_p < co or ci_p < ci:
         raise ValueError(f"padded conv image ({co_p}, {ci_p}) smaller than the weight's ({co}, {ci})")
     kd, kh, kw = (int(v) for v in w.shape[2:])
+    if layout in _PHASE_LAYOUTS:
+        # eight rows of kind 2 (one per output parity) into ONE buffer: the images of pytc_convT3d_phase_fwd
+        plan = convT3d_phase_plan(co_p, ci_p)
+        if plan is None or (kd, kh, kw) != (3, 3, 3) or dtype != torch.bfloat16 or pad_to is not None:
+            raise ValueError(f"no phase images for a {tuple(w.shape)} weight in {dtype}")
+        offs, total, kc, nchunks, groups = plan
+        rows, blk = [], first_block
+        for ph in range(8):
+            n_ph = (offs[ph + 1] if ph < 7 else total) - offs[ph]
+            ntap_ph = (1 + ((ph >> 2) & 1)) * (1 + ((ph >> 1) & 1)) * (1 + (ph & 1))
+            rows += [w.data_ptr(), out_ptr + 2 * offs[ph], s_o, s_c, blk, n_ph, co, ci, ntap_ph, 2, 0, ph, kc, nchunks, groups[ph], 0]
+            blk += (n_ph + 255) // 256
+        return rows, total
     plan = (C.c_int64 * 5)()
     nat.check(nat.lib().pytc_conv3d_pack_plan(co_p, ci_p, kd, kh, kw, dtype_code(dtype), direct, plan), "conv3d_pack_plan")
     kind, p1, p2, p3, n = (int(v) for v in plan)
     return [w.data_ptr(), out_ptr, s_o, s_c, first_block, n, co, ci, kd * kh * kw, kind, int(dtype == torch.float32), flip,
             p1, p2, p3, 0], n
+
+
+def _row_blocks(row) -> int:
+    """256-thread blocks of a (possibly multi-row) table entry: sum over its rows of ceil(elements / 256)"""
+    return sum((row[i + 5] + 255) // 256 for i in range(0, len(row), 16))
 
 
 def conv3d_pack_weight_padded(w: torch.Tensor, layout: str, dtype: torch.dtype, pad_to) -> torch.Tensor:
@@ -1027,6 +1058,7 @@ class ConvPackSet:
         self.rows = {}          # (data_ptr, layout, dtype) -> [weakref(weight), out, version, plan tuple]
         self.table = None
         self.blocks = 0
+        self.n_rows = 0
 
     def get(self, weight: torch.Tensor, layout: str, dtype: torch.dtype, pad_to=None) -> torch.Tensor:
         """pad_to = (C_out, C_in) the conv RUNS with (pad_channels; in the orientation of the image, i.e. already swapped for
@@ -1060,13 +1092,14 @@ class ConvPackSet:
         if self.table is None:
             flat, blk = [], 0
             for (_ptr, layout, dtype, pad_to), r, w in live:
-                row, n = _conv_pack_row(w, r[1].data_ptr(), layout, dtype, pad_to, blk)
+                row, _n = _conv_pack_row(w, r[1].data_ptr(), layout, dtype, pad_to, blk)
                 flat += row
-                blk += (n + 255) // 256
+                blk += _row_blocks(row)
             self.table = torch.tensor(flat, dtype=torch.int64).to(dev)
             self.blocks = blk
+            self.n_rows = len(flat) // 16
         _run("conv3d_pack_multi", sum(2 * r[1].numel() * r[1].element_size() for _k, r, _w in live), nat.lib().pytc_conv3d_pack_multi,
-             _p(self.table), len(live), self.blocks, _stream())
+             _p(self.table), self.n_rows, self.blocks, _stream())
         for _k, r, w in live:
             r[2] = w._version
 
@@ -1078,6 +1111,17 @@ def _conv_pack_single(w32: torch.Tensor, layout: str, dtype: torch.dtype, pad_to
         return conv3d_pack_weight(w32, dtype)
     if layout == "dgrad":
         return conv3d_pack_weight_dgrad(w32, dtype)
+    if layout in _PHASE_LAYOUTS:
+        _dev(w32, "w")
+        co, ci, *_ = _conv_layout_rule(w32.shape, layout)
+        plan = convT3d_phase_plan(co, ci)
+        if plan is None:
+            raise ValueError(f"no phase images for a {tuple(w32.shape)} weight")
+        out = torch.empty((plan[1],), dtype=dtype, device=w32.device)
+        rows, _n = _conv_pack_row(w32, out.data_ptr(), layout, dtype, None, 0)
+        table = torch.tensor(rows, dtype=torch.int64).to(w32.device)
+        _run("conv3d_pack_multi", _nbytes(w32, out), nat.lib().pytc_conv3d_pack_multi, _p(table), 8, _row_blocks(rows), _stream())
+        return out
     return conv3d_pack_weight_direct(w32, dtype, layout=layout)
 
 
@@ -1630,6 +1674,34 @@ def conv3d_strided(x: torch.Tensor, w_packed: torch.Tensor, *, c_out: int, kerne
          _i3((Di, Hi, Wi)), _i3(stride), _i3(pad), 1 if transposed else 0, _stream(),
          # useful MACs: a transposed stride-2 conv reaches an output through (3/2)^3 taps on average, a strided one through all
          flops=int(2 * N * Do * Ho * Wo * ci * c_out * a.kd * a.kh * a.kw * (0.125 if transposed else 1.0)))
+    return y
+
+
+def convT3d_phase_supported(c_out: int, c_in: int, dtype: torch.dtype) -> bool:
+    """the LDS-tiled phase form covers this stride-2 transposed gather (bf16, C_in % 8 == 0, knob convT_phase_tile)"""
+    return dtype == torch.bfloat16 and bool(nat.lib().pytc_convT3d_phase_supported(int(c_out), int(c_in), nat.BF16))
+
+
+def convT3d_phase(x: torch.Tensor, w_images: torch.Tensor, *, c_out: int, bias: Optional[torch.Tensor] = None,
+                  ab: Optional[torch.Tensor] = None, act_in: int = nat.ACT_NONE, act_param: float = 0.0,
+                  res: Optional[torch.Tensor] = None, tag: str = "convT3d") -> torch.Tensor:
+    """x (N,D,H,W,C_in) bf16 -> (N,2D,2H,2W,C_out): the k 3 / stride 2 / pad 1 transposed gather as eight stride-1 convs on the LDS-tiled
+    kernel (pytc_convT3d_phase_fwd); w_images from the 'convT_phase' / 'conv_dgrad_phase' layouts."""
+    _dev(x, "x"); _dev(w_images, "w_images")
+    N, Di, Hi, Wi, ci = x.shape
+    y = torch.empty((N, 2 * Di, 2 * Hi, 2 * Wi, c_out), dtype=x.dtype, device=x.device)
+    a = nat.Conv3dArgs()
+    a.x, a.w_packed, a.y = x.data_ptr(), w_images.data_ptr(), y.data_ptr()
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.ab = ab.data_ptr() if ab is not None else None
+    a.res = res.data_ptr() if res is not None else None
+    a.N, a.D, a.H, a.W, a.C_in, a.C_out = N, 2 * Di, 2 * Hi, 2 * Wi, ci, c_out
+    a.kd, a.kh, a.kw = 3, 3, 3
+    a.act_in, a.act_param = int(act_in), float(act_param)
+    a.res_mode = nat.RES_ADD if res is not None else nat.RES_NONE
+    a.dtype = dtype_code(x.dtype)
+    _run(f"{tag}_fwd[{ci}->{c_out},k333]", _nbytes(x, y), nat.lib().pytc_convT3d_phase_fwd, C.byref(a), _i3((Di, Hi, Wi)), _stream(),
+         flops=int(2 * N * 8 * Di * Hi * Wi * ci * c_out * 27 * 0.125))
     return y
 
 

@@ -301,6 +301,10 @@ class ResampleConv3dFn(torch.autograd.Function):
             # few output channels (the network's last up-sampling layer): one thread per output voxel instead of an MFMA tile
             # padded to 16 channels (csrc/conv3d_strided_kernels.hip convT3d_thin_kernel); the backward is unchanged
             y = ops.convT3d_thin(a.contiguous(), w32, _f(bias))
+        elif (transposed and ks == (3, 3, 3) and stride == 2 and pad == 1
+              and ops.convT3d_phase_supported(weight.shape[1], weight.shape[0], a.dtype)):
+            # eight stride-1 convs (one per output parity) on the LDS-tiled kernel instead of the gather form (round 6)
+            y = ops.convT3d_phase(a.contiguous(), _packed(weight, "convT_phase", a.dtype), c_out=weight.shape[1], bias=_f(bias))
         elif transposed:
             out_dims = tuple((int(d) - 1) * stride - 2 * pad + k + (stride - 1) for d, k in zip(a.shape[1:4], ks))
             y = ops.conv3d_strided(a, _packed(weight, "convT", a.dtype), c_out=weight.shape[1],
@@ -333,8 +337,13 @@ class ResampleConv3dFn(torch.autograd.Function):
             dW = ops.conv3d_wgrad_strided(dy, a, ks, s3, p3)          # (C_in_T, C_out_T, k): ConvTranspose3d layout
         else:
             if ctx.needs_input_grad[0]:
-                da = ops.conv3d_strided(dy, _packed(weight, "conv_dgrad", dy.dtype),
-                                        c_out=weight.shape[1], kernel=ks, stride=s3, pad=p3, out_dims=in_dims, transposed=True)
+                even = all(i == 2 * o for i, o in zip(in_dims, dy.shape[1:4]))
+                if (ks == (3, 3, 3) and s3 == (2, 2, 2) and p3 == (1, 1, 1) and even
+                        and ops.convT3d_phase_supported(weight.shape[1], weight.shape[0], dy.dtype)):
+                    da = ops.convT3d_phase(dy, _packed(weight, "conv_dgrad_phase", dy.dtype), c_out=weight.shape[1], tag="conv3d_s_dgrad")
+                else:
+                    da = ops.conv3d_strided(dy, _packed(weight, "conv_dgrad", dy.dtype),
+                                            c_out=weight.shape[1], kernel=ks, stride=s3, pad=p3, out_dims=in_dims, transposed=True)
             dW = ops.conv3d_wgrad_strided(a, dy, ks, s3, p3)          # (C_out, C_in, k)
         db = ops.channel_stats(dy)[:, :, 0].sum((0, 1)).to(weight.dtype) if has_bias else None
         return da, dW.to(weight.dtype), db, None, None, None
