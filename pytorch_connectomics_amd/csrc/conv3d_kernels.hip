@@ -202,6 +202,96 @@ conv3d_thin_in_kernel(ConvParams p) {
   }
 }
 
+// ---- one input channel, 3 x 3 x 3, stride 1 or 2 (round 6) --------------------------------------------------------------------------------
+// The first conv of a U-Net (1 -> 32 / 64, stride 2 in the MONAI-style network) and the 1 -> 1 conv of its last residual unit are
+// stencils on a SCALAR field: 27 input loads and 27 x C_out FMAs per output voxel, HBM bound on the output.  On the MFMA gather kernel
+// the single channel is one of 32 K slots (conv3d_s_fwd[1 -> 32] 156 us, [1 -> 64] 258 us at 2 x 24 x 256 x 256), on the thin-input
+// kernel above a 1 -> 1 conv pays 16 output slots and a branch per tap (119 us).  Here: one thread = one output voxel x up to OCT
+// output channels, the 27 inputs loaded branch-free (clamped address, zeroed when outside) before any arithmetic, weights (the bf16 /
+// fp32 image the MFMA kernels read, tap-major layout) as fp32 in LDS with wave-uniform broadcast reads, 16-byte stores.
+template <typename T, int OCT>
+__global__ void __launch_bounds__(256)
+conv3d_c1_stencil_kernel(const T* __restrict__ x, const T* __restrict__ wp, const float* __restrict__ bias, T* __restrict__ y, int N,
+                         int Do, int Ho, int Wo, int Di, int Hi, int Wi, int C_out, int stride) {
+  constexpr int EPL = Mma<T>::EPL;
+  __shared__ float wl[27 * OCT];
+  const int oc0 = blockIdx.y * OCT;
+  for (int i = threadIdx.x; i < 27 * OCT; i += 256) {
+    const int o = oc0 + i % OCT, tap = i / OCT;
+    // [mtile][tap][kgroup = 0][lane = (kb = 0, r = o % 16)][j = 0]: input channel 0 of output channel o
+    wl[i] = o < C_out ? to_f32<T>(wp[(((long)(o >> 4) * 27 + tap) * 64 + (o & 15)) * EPL]) : 0.f;
+  }
+  __syncthreads();
+  const long rps = (long)Do * Ho * Wo;
+  const long v = (long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= rps * N) return;
+  const int n = (int)(v / rps);
+  const long row = v - (long)n * rps;
+  const int vx = (int)(row % Wo);
+  const long tq = row / Wo;
+  const int vy = (int)(tq % Ho), vz = (int)(tq / Ho);
+  const T* xn = x + (long)n * Di * Hi * Wi;
+  float in[27];
+#pragma unroll
+  for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int z = vz * stride + dz - 1, yy = vy * stride + dy - 1, xx = vx * stride + dx - 1;
+        const bool ok = z >= 0 && z < Di && yy >= 0 && yy < Hi && xx >= 0 && xx < Wi;
+        const float t = to_f32<T>(xn[((long)min(max(z, 0), Di - 1) * Hi + min(max(yy, 0), Hi - 1)) * Wi + min(max(xx, 0), Wi - 1)]);
+        in[(dz * 3 + dy) * 3 + dx] = ok ? t : 0.f;
+      }
+  T* yo = y + v * C_out + oc0;
+#pragma unroll
+  for (int ob = 0; ob < OCT; ob += 8) {
+    if (oc0 + ob >= C_out) break;
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = (bias && oc0 + ob + q < C_out) ? bias[oc0 + ob + q] : 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      if constexpr (OCT >= 8) {
+        const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(&wl[tap * OCT + ob]);
+        const f32x4_t w1 = *reinterpret_cast<const f32x4_t*>(&wl[tap * OCT + ob + 4]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { acc[q] = fmaf(in[tap], w0[q], acc[q]); acc[4 + q] = fmaf(in[tap], w1[q], acc[4 + q]); }
+      } else {
+#pragma unroll
+        for (int q = 0; q < OCT; ++q) acc[q] = fmaf(in[tap], wl[tap * OCT + q], acc[q]);
+      }
+    }
+    if (OCT >= 8 && (C_out % 8) == 0) {
+      VecIO<T, 8>::store(yo + ob, acc);
+    } else {
+#pragma unroll
+      for (int q = 0; q < (OCT < 8 ? OCT : 8); ++q)
+        if (oc0 + ob + q < C_out) yo[ob + q] = from_f32<T>(acc[q]);
+    }
+  }
+}
+
+// -> true when the launch was made: one input channel, 3^3 taps, stride 1 ('same') or 2 (pad 1), no fused pre-activation / residual
+bool conv_c1_stencil_try(const void* x, const void* wp, const float* bias, const float* ab, int act_in, const EpiParams& e, int N,
+                         int Do, int Ho, int Wo, int Di, int Hi, int Wi, int C_in, int C_out, int kd, int kh, int kw, int stride, int pad,
+                         int dtype, hipStream_t s) {
+  if (C_in != 1 || kd != 3 || kh != 3 || kw != 3 || pad != 1 || (stride != 1 && stride != 2) || ab || act_in != PYTC_ACT_NONE ||
+      e.res_mode != PYTC_RES_NONE || tuning_get("conv_c1_stencil", 1) == 0)
+    return false;
+  if (stride == 1 && (Do != Di || Ho != Hi || Wo != Wi)) return false;
+  if (stride == 2 && (Do != (Di + 1) / 2 || Ho != (Hi + 1) / 2 || Wo != (Wi + 1) / 2)) return false;
+  const long total = (long)N * Do * Ho * Wo;
+  const int oct = C_out >= 32 ? 32 : (C_out >= 8 ? 8 : (C_out > 1 ? 4 : 1));
+  dim3 grid((unsigned)((total + 255) / 256), (unsigned)((C_out + oct - 1) / oct));
+#define PYTC_C1(TT, OCTV) hipLaunchKernelGGL((conv3d_c1_stencil_kernel<TT, OCTV>), grid, dim3(256), 0, s, (const TT*)x, (const TT*)wp, bias, \
+                                             (TT*)e.y, N, Do, Ho, Wo, Di, Hi, Wi, C_out, stride)
+  if (dtype == PYTC_BF16) { if (oct == 32) PYTC_C1(bf16_t, 32); else if (oct == 8) PYTC_C1(bf16_t, 8); else if (oct == 4) PYTC_C1(bf16_t, 4); else PYTC_C1(bf16_t, 1); }
+  else { if (oct == 32) PYTC_C1(float, 32); else if (oct == 8) PYTC_C1(float, 8); else if (oct == 4) PYTC_C1(float, 4); else PYTC_C1(float, 1); }
+#undef PYTC_C1
+  return true;
+}
+
 // ---- LDS-tiled form (bf16, C_in % 8 == 0) ------------------------------------------------------------------------------
 // A workgroup owns a 4 x 8 x 16 (z, y, x) block of output voxels and MT*16 output channels.  Per chunk of KC input
 // channels it stages the haloed input block ONCE into LDS with the pre-activation f already applied (the direct kernel
@@ -630,7 +720,9 @@ extern "C" int pytc_conv3d_fwd(const pytc_conv3d_args* a, void* stream) {
   p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
   hipStream_t s = (hipStream_t)stream;
   ConvTile t; size_t lds_bytes;
-  if (conv_tile_plan(a->dtype, a->C_in, a->kd, a->kh, a->kw, t, lds_bytes)) launch_conv_tile(p, t, lds_bytes, s);
+  if (conv_c1_stencil_try(a->x, a->w_packed, a->bias, a->ab, a->act_in, p.e, a->N, a->D, a->H, a->W, a->D, a->H, a->W, a->C_in, a->C_out,
+                          a->kd, a->kh, a->kw, 1, 1, a->dtype, s)) {}
+  else if (conv_tile_plan(a->dtype, a->C_in, a->kd, a->kh, a->kw, t, lds_bytes)) launch_conv_tile(p, t, lds_bytes, s);
   else if (a->dtype == PYTC_F32) launch_conv<float, float, float>(p, s);
   else launch_conv<bf16_t, bf16_t, bf16_t>(p, s);
   PYTC_LAUNCH_CHECK("conv3d");

@@ -13,6 +13,11 @@
 
 namespace pytc {
 
+// conv3d_kernels.hip: the scalar-field stencil for one input channel (3^3 taps, stride 1 / 2)
+bool conv_c1_stencil_try(const void* x, const void* wp, const float* bias, const float* ab, int act_in, const EpiParams& e, int N,
+                         int Do, int Ho, int Wo, int Di, int Hi, int Wi, int C_in, int C_out, int kd, int kh, int kw, int stride, int pad,
+                         int dtype, hipStream_t s);
+
 struct SConvParams {
   const void* x;
   const void* wp;       // [mtile][tap][kgroup][lane][EPL]  (conv3d_pack_kernel layout)
@@ -812,7 +817,10 @@ extern "C" int pytc_conv3d_strided_fwd(const pytc_conv3d_args* a, const int32_t*
   p.e.rps_out = (long)a->D * a->H * a->W; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode; p.e.nt = 0;
   p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
   hipStream_t s = (hipStream_t)stream;
-  if (a->dtype == PYTC_F32) launch_sconv<float, float, float>(p, s);
+  if (!transposed && stride[0] == stride[1] && stride[1] == stride[2] && pad[0] == pad[1] && pad[1] == pad[2] &&
+      conv_c1_stencil_try(a->x, a->w_packed, a->bias, a->ab, a->act_in, p.e, a->N, a->D, a->H, a->W, p.Di, p.Hi, p.Wi, a->C_in, a->C_out,
+                          a->kd, a->kh, a->kw, stride[0], pad[0], a->dtype, s)) {}
+  else if (a->dtype == PYTC_F32) launch_sconv<float, float, float>(p, s);
   else launch_sconv<bf16_t, bf16_t, bf16_t>(p, s);
   PYTC_LAUNCH_CHECK("conv3d_strided");
   return PYTC_OK;
