@@ -707,6 +707,11 @@ int pytc_conv3d_pack_weight_direct(const float* w, int C_out, int C_in, int kd, 
  *   sub-taps of the phase, 2, 0, PHASE (4a + 2b + c), KC, chunks, groups, 0 } with element (o, c, tap) of the 27-tap conv at
  *   w[o*s_o + c*s_c + tap].
  * pytc_convT3d_phase_fwd: `a` as for pytc_conv3d_strided_fwd (a->D/H/W the OUTPUT grid = 2 x in_dims, kernel 3), a->w_packed the images. */
+/* pytc_convT3d_c1_fwd: the same transposed conv for ONE output channel (the last up-sampling layer of a single-class U-Net), input-centric:
+ * every input voxel forms its 27 tap products once (workspace: 27 * N * Di*Hi*Wi floats, planar), every output voxel sums the 1 .. 8 its
+ * parity selects.  w: ConvTranspose3d layout [C_in][1][27] fp32; C_in % 8 == 0. */
+int pytc_convT3d_c1_fwd(const void* x, const float* w, const float* bias, void* y, float* workspace, int N, const int32_t* in_dims,
+                        int C_in, int dtype, void* stream);
 int pytc_convT3d_phase_plan(int C_out, int C_in, int dtype, int64_t* out);
 int pytc_convT3d_phase_supported(int C_out, int C_in, int dtype);
 int pytc_convT3d_phase_fwd(const pytc_conv3d_args* a, const int32_t* in_dims, void* stream);

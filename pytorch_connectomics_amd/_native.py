@@ -192,6 +192,8 @@ _SIGS = {
                                                  C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "pytc_conv3d_strided_fwd": (C.c_int, [C.POINTER(Conv3dArgs), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                           C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
+    "pytc_convT3d_c1_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_int,
+                                      C.c_int, C.c_void_p]),
     "pytc_convT3d_phase_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pytc_convT3d_phase_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pytc_convT3d_phase_fwd": (C.c_int, [C.POINTER(Conv3dArgs), C.POINTER(C.c_int32), C.c_void_p]),

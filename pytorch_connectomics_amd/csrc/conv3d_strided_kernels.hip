@@ -491,6 +491,74 @@ static void launch_sconv(const SConvParams& p, hipStream_t s) {
 // axis an even coordinate has ONE contributing tap (t = 1, source o / 2) and an odd one two (t = 0 / 2, sources (o + 1) / 2 and
 // (o - 1) / 2), so 1 .. 8 of the 27 taps are visited; the source row is read in 16-byte channel chunks, the taps come from LDS
 // ([tap][o][c] fp32).  w: ConvTranspose3d layout [C_in][C_out][27] fp32.
+// ONE output channel (round 6): the output-voxel form below reads the full C_in-channel row of 1 .. 8 source voxels per output voxel
+// (3.4 on average, every source row fetched by up to 27 outputs: 304 us for 64 -> 1 at 2 x 24 x 256 x 256; the eight-phase tile kernel:
+// 180 us, bound by its staging).  Input-centric instead: (1) every INPUT voxel forms its 27 tap products once,
+// P[t][i] = sum_c w[c][t] * x[i][c] (planar fp32, 27 x rows), (2) every output voxel sums the 1 .. 8 entries its parity selects.
+template <typename T>
+__global__ void __launch_bounds__(256)
+convT3d_c1_dots_kernel(const T* __restrict__ x, const float* __restrict__ w, float* __restrict__ P, long rows, int C_in) {
+  extern __shared__ float wl[];                            // [27][C_in]
+  for (int i = threadIdx.x; i < 27 * C_in; i += 256) wl[i] = w[(long)(i % C_in) * 27 + i / C_in];
+  __syncthreads();
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+  const T* row = x + r * C_in;
+  for (int c = 0; c < C_in; c += 8) {
+    float xv[8];
+    VecIO<T, 8>::load(row + c, xv);
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(wl + t * C_in + c);
+      const f32x4_t w1 = *reinterpret_cast<const f32x4_t*>(wl + t * C_in + c + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[t] = fmaf(xv[j], w0[j], acc[t]); acc[t] = fmaf(xv[4 + j], w1[j], acc[t]); }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 27; ++t) P[(long)t * rows + r] = acc[t];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+convT3d_c1_gather_kernel(const float* __restrict__ P, const float* __restrict__ bias, T* __restrict__ y, int N, int Di, int Hi, int Wi) {
+  const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
+  const long total = (long)N * Do * Ho * Wo, rows = (long)N * Di * Hi * Wi;
+  const long v = (long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= total) return;
+  const int ox = (int)(v % Wo);
+  long t = v / Wo;
+  const int oy = (int)(t % Ho); t /= Ho;
+  const int oz = (int)(t % Do);
+  const long n = t / Do;
+  // per axis: even o -> (tap 1, source o / 2); odd o -> (tap 2, (o - 1) / 2) and (tap 0, (o + 1) / 2) when that source exists;
+  // accumulation in ascending tap order (the order of the gather form)
+  int tz[2], sz[2], ty[2], sy[2], tx[2], sx[2];
+  auto axis = [](int o, int n_in, int (&tp)[2], int (&sp)[2]) {
+    if ((o & 1) == 0) { tp[0] = 1; sp[0] = o >> 1; tp[1] = -1; sp[1] = 0; }
+    else {
+      tp[0] = 0; sp[0] = (o + 1) >> 1; tp[1] = 2; sp[1] = (o - 1) >> 1;
+      if (sp[0] >= n_in) tp[0] = -1;
+    }
+  };
+  axis(oz, Di, tz, sz); axis(oy, Hi, ty, sy); axis(ox, Wi, tx, sx);
+  float acc = bias ? bias[0] : 0.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (tz[a] < 0 || ty[b] < 0 || tx[c] < 0) continue;
+        const int tap = (tz[a] * 3 + ty[b]) * 3 + tx[c];
+        acc += P[(long)tap * rows + ((n * Di + sz[a]) * Hi + sy[b]) * Wi + sx[c]];
+      }
+  y[v] = from_f32<T>(acc);
+}
+
 constexpr int CT_OMAX = 4;
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -905,6 +973,30 @@ extern "C" int pytc_conv3d_wgrad_strided(const void* big, const void* small, flo
   const long nW = (long)taps * C_o * C_k;
   hipLaunchKernelGGL(sw_reduce_slots_kernel, dim3(ceil_div(nW, 16)), dim3(256), 0, s, workspace, dW, nW, slots);
   PYTC_LAUNCH_CHECK("conv3d_wgrad_strided");
+  return PYTC_OK;
+}
+
+/* ConvTranspose3d(k 3, s 2, p 1, output_padding 1) with ONE output channel, input-centric: workspace = 27 * N * Di * Hi * Wi floats */
+extern "C" int pytc_convT3d_c1_fwd(const void* x, const float* w, const float* bias, void* y, float* workspace, int N,
+                                   const int32_t* in_dims, int C_in, int dtype, void* stream) {
+  PYTC_REQUIRE(x && w && y && workspace && in_dims && N >= 1, "convT3d_c1: bad arguments");
+  PYTC_REQUIRE(C_in >= 8 && C_in % 8 == 0 && C_in <= 512, "convT3d_c1: C_in %% 8 == 0, <= 512 (got %d)", C_in);
+  const long rows = (long)N * in_dims[0] * in_dims[1] * in_dims[2];
+  const long total = rows * 8;
+  const size_t lds = (size_t)27 * C_in * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == PYTC_BF16) {
+    hipLaunchKernelGGL(convT3d_c1_dots_kernel<bf16_t>, dim3((unsigned)((rows + 255) / 256)), dim3(256), lds, s, (const bf16_t*)x, w, workspace, rows, C_in);
+    hipLaunchKernelGGL(convT3d_c1_gather_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, workspace, bias, (bf16_t*)y, N,
+                       in_dims[0], in_dims[1], in_dims[2]);
+  } else if (dtype == PYTC_F32) {
+    hipLaunchKernelGGL(convT3d_c1_dots_kernel<float>, dim3((unsigned)((rows + 255) / 256)), dim3(256), lds, s, (const float*)x, w, workspace, rows, C_in);
+    hipLaunchKernelGGL(convT3d_c1_gather_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, workspace, bias, (float*)y, N,
+                       in_dims[0], in_dims[1], in_dims[2]);
+  } else {
+    PYTC_REQUIRE(false, "convT3d_c1: bad dtype %d", dtype);
+  }
+  PYTC_LAUNCH_CHECK("convT3d_c1");
   return PYTC_OK;
 }
 

@@ -782,9 +782,21 @@ using namespace pytc;
 
 // launch plan shared by the workspace query and the launch
 struct CwPlan { bool mfma, rag_o, rag_k; int mt, nt, kp, tiles, slots; long per_slot; };
+// one input and one output channel, 3^3 taps (the last conv of a single-class U-Net): a 27-bin correlation of two scalar fields
+static bool cw_scalar(int C_in, int C_out, const int32_t* k, int dtype) {
+  return C_in == 1 && C_out == 1 && k[0] == 3 && k[1] == 3 && k[2] == 3 && (dtype == PYTC_BF16 || dtype == PYTC_F32) &&
+         tuning_get("conv_wgrad_scalar", 1) != 0;
+}
+
 static CwPlan cw_plan(int N, int D, int H, int W, int C_in, int C_out, const int32_t* k, int dtype) {
   CwPlan p{};
   const long rows_total = (long)N * D * H * W;
+  if (cw_scalar(C_in, C_out, k, dtype)) {
+    const long s = (rows_total + 4095) / 4096;          // 16 voxels per thread
+    p.slots = (int)(s < 1 ? 1 : (s > 1024 ? 1024 : s));
+    p.per_slot = (rows_total + p.slots - 1) / p.slots;
+    return p;
+  }
   p.rag_o = C_out < 16;
   p.rag_k = C_in < 16;
   p.kp = k[1];
@@ -810,6 +822,52 @@ static CwPlan cw_plan(int N, int D, int H, int W, int C_in, int C_out, const int
   return p;
 }
 
+// dW[t] = sum_v dy[v] * a[v + t - 1]: every thread walks its share of a slot's voxels with 27 accumulators (inputs loaded branch-free:
+// clamped address, zeroed outside the volume), the workgroup sums them in a fixed order (xor shuffles, then the four waves in LDS) ->
+// ws[slot][27]; reduce_slots2 finishes.  The MFMA kernel gave this 1 x 1 problem one lane of a 16 x 16 tile: 210 us at 2 x 24 x 256 x 256.
+template <typename T>
+__global__ void __launch_bounds__(256)
+conv3d_wgrad_scalar_kernel(const T* __restrict__ a, const T* __restrict__ dy, float* __restrict__ ws, int N, int D, int H, int W,
+                           long per_slot, long rows_total) {
+  __shared__ float red[4][27];
+  const long v0 = (long)blockIdx.x * per_slot;
+  const long v1 = v0 + per_slot < rows_total ? v0 + per_slot : rows_total;
+  const long rps = (long)D * H * W;
+  float acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+  for (long v = v0 + threadIdx.x; v < v1; v += 256) {
+    const int n = (int)(v / rps);
+    const long row = v - (long)n * rps;
+    const int x = (int)(row % W);
+    const long tq = row / W;
+    const int y = (int)(tq % H), z = (int)(tq / H);
+    const float g = to_f32<T>(dy[v]);
+    const T* an = a + (long)n * rps;
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+      for (int dyy = 0; dyy < 3; ++dyy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int zz = z + dz - 1, yy = y + dyy - 1, xx = x + dx - 1;
+          const bool ok = zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
+          const float t = to_f32<T>(an[((long)min(max(zz, 0), D - 1) * H + min(max(yy, 0), H - 1)) * W + min(max(xx, 0), W - 1)]);
+          acc[(dz * 3 + dyy) * 3 + dx] = fmaf(g, ok ? t : 0.f, acc[(dz * 3 + dyy) * 3 + dx]);
+        }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int t = 0; t < 27; ++t) {
+    float s = acc[t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) red[wave][t] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) ws[(long)blockIdx.x * 27 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
 extern "C" int64_t pytc_conv3d_wgrad_ws_elems(int N, int D, int H, int W, int C_in, int C_out, const int32_t* kernel,
                                               int dtype) {
   if (!kernel || N < 1) return -1;
@@ -827,7 +885,12 @@ extern "C" int pytc_conv3d_wgrad(const void* a, const void* dy, float* dW, float
   const int slots = p.slots;
   const int taps = g.kd * g.kh * g.kw;
   hipStream_t s = (hipStream_t)stream;
-  if (p.mfma) {
+  if (cw_scalar(C_in, C_out, kernel, dtype)) {
+    RS_DISPATCH(dtype,
+                hipLaunchKernelGGL(conv3d_wgrad_scalar_kernel<bf16_t>, dim3(slots), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)dy, workspace, N, D, H, W, p.per_slot, rows_total),
+                hipLaunchKernelGGL(conv3d_wgrad_scalar_kernel<float>, dim3(slots), dim3(256), 0, s, (const float*)a, (const float*)dy, workspace, N, D, H, W, p.per_slot, rows_total),
+                "conv3d_wgrad")
+  } else if (p.mfma) {
     const long blocks = (long)((slots + 7) / 8) * 8 * p.tiles * g.kd;
     const bf16_t* ap = (const bf16_t*)a;
     const bf16_t* dp = (const bf16_t*)dy;

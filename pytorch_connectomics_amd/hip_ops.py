@@ -1717,6 +1717,12 @@ def convT3d_thin(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor])
     if tuple(w.shape) != (ci, co, 3, 3, 3) or w.dtype != torch.float32 or not w.is_contiguous():
         raise ValueError(f"convT3d_thin: weight must be contiguous fp32 (C_in={ci}, C_out, 3, 3, 3), got {tuple(w.shape)} {w.dtype}")
     y = torch.empty((N, 2 * D, 2 * H, 2 * W, co), dtype=x.dtype, device=x.device)
+    if co == 1 and ci % 8 == 0 and ci <= 512:
+        # input-centric: 27 tap products per input voxel, then a 1 .. 8-term gather per output voxel (pytc_convT3d_c1_fwd)
+        ws = torch.empty((27 * N * D * H * W,), dtype=torch.float32, device=x.device)
+        _run(f"convT3d_fwd[{ci}->{co},k333]", _nbytes(x, y) + 2 * _nbytes(ws), nat.lib().pytc_convT3d_c1_fwd, _p(x), _p(w), _p(bias), _p(y), _p(ws),
+             N, _i3((D, H, W)), ci, dtype_code(x.dtype), _stream(), flops=int(2 * N * D * H * W * ci * 27))
+        return y
     _run(f"convT3d_fwd[{ci}->{co},k333]", _nbytes(x, y), nat.lib().pytc_convT3d_thin_fwd, _p(x), _p(w), _p(bias), _p(y), N,
          _i3((D, H, W)), ci, co, dtype_code(x.dtype), _stream())
     return y

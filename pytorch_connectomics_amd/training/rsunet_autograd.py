@@ -300,7 +300,7 @@ class ResampleConv3dFn(torch.autograd.Function):
             y = ops.conv3d(a, _packed(weight, "fwd", a.dtype), c_out=weight.shape[0], kernel=ks, bias=_f(bias))
         elif (transposed and ks == (3, 3, 3) and stride == 2 and pad == 1 and a.dtype in (torch.bfloat16, torch.float32)
               and ops.convT3d_thin_supported(weight.shape[0], weight.shape[1])
-              and not (os.environ.get("PYTC_CONVT_THIN_LAST", "1") == "0" and ops.convT3d_phase_supported(weight.shape[1], weight.shape[0], a.dtype))):
+              and (weight.shape[1] == 1 or not ops.convT3d_phase_supported(weight.shape[1], weight.shape[0], a.dtype))):
             # few output channels (the network's last up-sampling layer): one thread per output voxel instead of an MFMA tile
             # padded to 16 channels (csrc/conv3d_strided_kernels.hip convT3d_thin_kernel); the backward is unchanged
             y = ops.convT3d_thin(a.contiguous(), w32, _f(bias))

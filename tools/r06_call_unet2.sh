@@ -1,2 +1,2 @@
 timeout 600 python -m pytest tests/test_gpu_monai_unet.py tests/test_gpu_kernels.py tests/test_gpu_rsunet.py -x -q -k "strided or convT or monai or transposed or resample or conv3d or rsunet" 2>&1 | tail -4
-PYTC_CONVT_THIN_LAST=0 python tools/r06_unet_labels.py monai 14 2>&1 | grep -v amdgpu
+python tools/r06_unet_labels.py monai 14 2>&1 | grep -v amdgpu
