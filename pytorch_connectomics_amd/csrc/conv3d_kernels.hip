@@ -305,7 +305,7 @@ constexpr int CT_TZ = 4, CT_TY = 8, CT_TX = 16;
 struct ConvTile { int KC, nchunks, G, tzh, tyh, txh, tiles_z, tiles_y, tiles_x; };
 // the eight phases of a stride-2 transposed gather in ONE launch (blockIdx.z = phase = 4a + 2b + c): per phase the tap extents are
 // (1 + a, 1 + b, 1 + c), the groups per chunk G and the element offset of its weight image differ; n = 0: an ordinary conv
-struct ConvPhases { int n; int G[8]; long woff[8]; };
+struct ConvPhases { int n; };
 
 // channels per staged chunk: the whole (narrow) layer when it fits one chunk, else the widest divisor among 32 / 16 / 8
 static __host__ __device__ inline int conv_kc(int C_in) {
@@ -317,18 +317,25 @@ __global__ void __launch_bounds__(256, 2)
 conv3d_tile_kernel(ConvParams p, ConvTile t, ConvPhases ps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int NT = CT_TY;
+  // per-launch or per-phase geometry as wave-uniform scalars (a kernel argument indexed at run time would be copied to scratch)
+  int kd = p.kd, kh = p.kh, kw = p.kw, oz = p.oz, oy = p.oy, ox = p.ox, tG = t.G, tzh = t.tzh, tyh = t.tyh, txh = t.txh;
+  long woff = 0;
   if (ps.n) {
     const int phz = blockIdx.z, a = (phz >> 2) & 1, b = (phz >> 1) & 1, c = phz & 1;
-    p.kd = 1 + a; p.kh = 1 + b; p.kw = 1 + c;
-    p.oz = a; p.oy = b; p.ox = c;
-    p.wp = reinterpret_cast<const bf16_t*>(p.wp) + ps.woff[phz];
-    t.G = ps.G[phz];
-    t.tzh = CT_TZ + a; t.tyh = CT_TY + b; t.txh = CT_TX + c;
+    kd = 1 + a; kh = 1 + b; kw = 1 + c;
+    oz = a; oy = b; ox = c;
+    tzh = CT_TZ + a; tyh = CT_TY + b; txh = CT_TX + c;
+    // groups per chunk and image offset of the phase, from the rule of conv_tile_plan / pytc_convT3d_phase_plan (scalar arithmetic)
+    tG = (kd * kh * kw * t.KC + 31) / 32;
+    for (int k = 0; k < phz; ++k) {
+      const int gk = ((1 + ((k >> 2) & 1)) * (1 + ((k >> 1) & 1)) * (1 + (k & 1)) * t.KC + 31) / 32;
+      woff += (long)p.MTt * t.nchunks * gk * 64 * 8;
+    }
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = lane & 15, kb = lane >> 4;
   const int P = t.KC * 2;                                   // LDS bytes per staged voxel
-  const int tile_vox = t.tzh * t.tyh * t.txh;
+  const int tile_vox = tzh * tyh * txh;
   const int ZOFF = tile_vox * P;                            // 16 zero bytes: the operand of padded K slots
   int* koff = reinterpret_cast<int*>(lds + ZOFF + 16);      // [G][4]
   // block -> (n, z tile, y tile, x tile); blockIdx.y = group of MT output-channel tiles
@@ -340,19 +347,19 @@ conv3d_tile_kernel(ConvParams p, ConvTile t, ConvPhases ps) {
   const int z0 = bz * CT_TZ, y0 = by * CT_TY, x0 = bx * CT_TX;
   const int mt0 = blockIdx.y * MT;
   const int pd = p.pd, ph = p.ph, pw = p.pw;
-  const int ntap = p.kd * p.kh * p.kw;
+  const int ntap = kd * kh * kw;
   const long rps = (long)p.D * p.H * p.W;
   const bf16_t* xn = reinterpret_cast<const bf16_t*>(p.x) + (long)n * rps * p.C_in;
 
   if (threadIdx.x < 4) reinterpret_cast<int*>(lds + ZOFF)[threadIdx.x] = 0;
-  for (int i = threadIdx.x; i < t.G * 4; i += 256) {
+  for (int i = threadIdx.x; i < tG * 4; i += 256) {
     const int idx = i * 8;
     const int tap = idx / t.KC, c = idx % t.KC;
     int off = -1;
     if (tap < ntap) {
-      const int dx = tap % p.kw, tt = tap / p.kw;
-      const int dy = tt % p.kh, dz = tt / p.kh;
-      off = ((dz * t.tyh + dy) * t.txh + dx) * P + c * 2;
+      const int dx = tap % kw, tt = tap / kw;
+      const int dy = tt % kh, dz = tt / kh;
+      off = ((dz * tyh + dy) * txh + dx) * P + c * 2;
     }
     koff[i] = off;
   }
@@ -363,69 +370,138 @@ conv3d_tile_kernel(ConvParams p, ConvTile t, ConvPhases ps) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const bf16x8_t* wp = reinterpret_cast<const bf16x8_t*>(p.wp);
-  const int Gtot = t.nchunks * t.G;
+  const bf16x8_t* wp = reinterpret_cast<const bf16x8_t*>(reinterpret_cast<const bf16_t*>(p.wp) + woff);
+  const int Gtot = t.nchunks * tG;
   const int CH = t.KC / 8;                                  // 16-byte pieces per staged voxel
-  const int base0 = (wave * t.tyh * t.txh + r) * P;         // voxel (z = wave, y = 0, x = r) of the block
-  const int nt_step = t.txh * P;
+  const int base0 = (wave * tyh * txh + r) * P;         // voxel (z = wave, y = 0, x = r) of the block
+  const int nt_step = txh * P;
+
+  // Round 6: with MT = 1 (the deep, small layers: few workgroups, each a serial chain of chunks) the NEXT chunk's pieces are requested
+  // into registers before the matrix loop of the current one and written to LDS after it -- a chunk costs max(staging latency, matrix
+  // loop) instead of their sum (256 -> 256 at 2 x 3 x 32 x 32: 8 chunks of 17 loads + 216 matrix instructions each, 164 us).  The piece
+  // descriptors (global offset of chunk 0, validity) are formed ONCE per thread: no address arithmetic per chunk.  MT = 4 keeps the
+  // plain order: its 128 accumulator registers leave no room for 20 staged pieces, and those launches fill the chip.
+  constexpr bool PREF = false;      // measured (round 6): 167.6 against 164.5 us for 256 -> 256 -- the chunk's staging was not what the workgroup waited for
+  constexpr int MAXP = 20;                                  // 16-byte pieces per thread: the tile is <= 80 KB
+  typedef unsigned int cu4_t __attribute__((ext_vector_type(4)));      // (an array of HIP's uint4 struct goes to scratch: DESIGN.md 4.8)
+  cu4_t pf[PREF ? MAXP : 1];
+  int goff[PREF ? MAXP : 1];                                // element offset of the piece in chunk 0 (from xn); -1: outside the volume / the tile
+  const int npiece = tile_vox * CH;
+  if constexpr (PREF) {
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      goff[k] = -1;
+      if (i < npiece) {
+        const int vox = i / CH, piece = i % CH;
+        const int tx = vox % txh, tq = vox / txh;
+        const int ty = tq % tyh, tz = tq / tyh;
+        const int z = z0 + tz - pd, y = y0 + ty - ph, x = x0 + tx - pw;
+        if (z >= 0 && z < p.D && y >= 0 && y < p.H && x >= 0 && x < p.W) goff[k] = (int)((((long)z * p.H + y) * p.W + x) * p.C_in) + piece * 8;
+      }
+    }
+  }
+  auto fetch = [&](int ck) {                                // pieces of chunk ck -> registers (zero outside the volume)
+    if constexpr (PREF) {
+      const bf16_t* xc = xn + ck * t.KC;
+#pragma unroll
+      for (int k = 0; k < MAXP; ++k) {
+        cu4_t v = {0u, 0u, 0u, 0u};
+        if (goff[k] >= 0) v = *reinterpret_cast<const cu4_t*>(xc + goff[k]);
+        pf[k] = v;
+      }
+    }
+  };
+  auto preact = [&](cu4_t v, int c) -> cu4_t {              // the fused pre-activation of 8 channels starting at c
+    f32x8_t f = __builtin_convertvector(__builtin_bit_cast(bf16x8_t, v), f32x8_t);
+    if (p.ab != nullptr) {
+      const float* av = p.ab + ((long)n * 2 + 0) * p.C_in + c;
+      const float* bv = p.ab + ((long)n * 2 + 1) * p.C_in + c;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = fmaf(f[j], av[j], bv[j]);
+    }
+    if (p.act_in != PYTC_ACT_NONE) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = pre_act(f[j], p.act_in, p.act_param);
+    }
+    return __builtin_bit_cast(cu4_t, __builtin_convertvector(f, bf16x8_t));
+  };
+  const bool has_pre = p.ab != nullptr || p.act_in != PYTC_ACT_NONE;
+  fetch(0);
 
   for (int ck = 0; ck < t.nchunks; ++ck) {
     if (ck > 0) __syncthreads();                            // everyone is done reading the previous chunk
     const int c0 = ck * t.KC;
-    for (int i = threadIdx.x; i < tile_vox * CH; i += 256) {
-      const int vox = i / CH, piece = i % CH;
-      const int tx = vox % t.txh, tq = vox / t.txh;
-      const int ty = tq % t.tyh, tz = tq / t.tyh;
-      const int z = z0 + tz - pd, y = y0 + ty - ph, x = x0 + tx - pw;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (z >= 0 && z < p.D && y >= 0 && y < p.H && x >= 0 && x < p.W) {
-        const int c = c0 + piece * 8;
-        v = *reinterpret_cast<const uint4*>(xn + (((long)z * p.H + y) * p.W + x) * p.C_in + c);
-        if (p.ab != nullptr || p.act_in != PYTC_ACT_NONE) {
-          f32x8_t f = __builtin_convertvector(__builtin_bit_cast(bf16x8_t, v), f32x8_t);
-          if (p.ab != nullptr) {
-            const float* av = p.ab + ((long)n * 2 + 0) * p.C_in + c;
-            const float* bv = p.ab + ((long)n * 2 + 1) * p.C_in + c;
+    if constexpr (PREF) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = fmaf(f[j], av[j], bv[j]);
-          }
-          if (p.act_in != PYTC_ACT_NONE) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = pre_act(f[j], p.act_in, p.act_param);
-          }
-          v = __builtin_bit_cast(uint4, __builtin_convertvector(f, bf16x8_t));
+      for (int k = 0; k < MAXP; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < npiece) {
+          cu4_t v = pf[k];
+          // (zero padding applies to f(X): a voxel outside the volume stays zero)
+          if (has_pre && goff[k] >= 0) v = preact(v, c0 + (i % CH) * 8);
+          *reinterpret_cast<cu4_t*>(lds + i * 16) = v;      // = lds + vox * P + piece * 16
         }
       }
-      *reinterpret_cast<uint4*>(lds + vox * P + piece * 16) = v;
+      __syncthreads();
+      if (ck + 1 < t.nchunks) fetch(ck + 1);
+    } else {
+      for (int i = threadIdx.x; i < tile_vox * CH; i += 256) {
+        const int vox = i / CH, piece = i % CH;
+        const int tx = vox % txh, tq = vox / txh;
+        const int ty = tq % tyh, tz = tq / tyh;
+        const int z = z0 + tz - pd, y = y0 + ty - ph, x = x0 + tx - pw;
+        cu4_t v = {0u, 0u, 0u, 0u};
+        if (z >= 0 && z < p.D && y >= 0 && y < p.H && x >= 0 && x < p.W) {
+          const int c = c0 + piece * 8;
+          v = *reinterpret_cast<const cu4_t*>(xn + (((long)z * p.H + y) * p.W + x) * p.C_in + c);
+          if (has_pre) v = preact(v, c);
+        }
+        *reinterpret_cast<cu4_t*>(lds + vox * P + piece * 16) = v;
+      }
+      __syncthreads();
     }
-    __syncthreads();
 
-    bf16x8_t af[MT], afn[MT];
+    // Weight fragments stream from L1 / L2 (one 16-byte load per lane, group and output tile).  With ONE group in flight (rounds 1-5) a
+    // workgroup of the deep, small layers -- MT = 1: eight matrix instructions per fragment, ~50 ns -- waited a whole L2 round trip
+    // per group (256 -> 256 at 2 x 3 x 32 x 32: 1 728 groups per wave, 164 us for 12 us of matrix instructions).  A ring of AD groups ahead
+    // (6 / 3 / 1 for MT = 1 / 2 / 4: what the accumulators leave room for); ring slots are compile-time (the group loop advances AD at a time).
+    constexpr int AD = MT == 1 ? 6 : (MT == 2 ? 3 : 1);
+    bf16x8_t ring[AD][MT];
+    auto wfrag = [&](int mt, int g) -> bf16x8_t {
+      return (mt0 + mt < p.MTt && g < tG) ? wp[((long)(mt0 + mt) * Gtot + ck * tG + g) * 64 + lane] : bf16x8_t{};
+    };
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-      af[mt] = (mt0 + mt < p.MTt) ? wp[((long)(mt0 + mt) * Gtot + ck * t.G) * 64 + lane] : bf16x8_t{};
-    for (int g = 0; g < t.G; ++g) {
-      if (g + 1 < t.G) {
+    for (int d = 0; d < AD; ++d)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          afn[mt] = (mt0 + mt < p.MTt) ? wp[((long)(mt0 + mt) * Gtot + ck * t.G + g + 1) * 64 + lane] : bf16x8_t{};
+      for (int mt = 0; mt < MT; ++mt) ring[d][mt] = wfrag(mt, d);
+    for (int g0 = 0; g0 < tG; g0 += AD) {
+#pragma unroll
+      for (int d = 0; d < AD; ++d) {
+        const int g = g0 + d;
+        if (g < tG) {
+          bf16x8_t af[MT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) { af[mt] = ring[d][mt]; ring[d][mt] = wfrag(mt, g + AD); }
+          const int ko = koff[g * 4 + kb];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int addr = ko < 0 ? ZOFF : base0 + nt * nt_step + ko;
+            const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(lds + addr);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf, acc[mt][nt], 0, 0, 0);
+          }
+        }
       }
-      const int ko = koff[g * 4 + kb];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int addr = ko < 0 ? ZOFF : base0 + nt * nt_step + ko;
-        const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(lds + addr);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf, acc[mt][nt], 0, 0, 0);
-      }
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) af[mt] = afn[mt];
     }
   }
 
   const int z = z0 + wave;
   const int x = x0 + r;
   if (z >= p.D || x >= p.W) return;
+  // output row of (z, y0 + nt, x): one 64-bit base and a 32-bit step (the 2x output map of a phase launch steps two output rows)
+  const long row0 = p.om ? ((long)(2 * z + oz) * p.Ho + (2 * y0 + oy)) * p.Wo + (2 * x + ox) : ((long)z * p.H + y0) * p.W + x;
+  const int row_step = p.om ? 2 * p.Wo : p.W;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int o0 = (mt0 + mt) * 16 + kb * 4;
@@ -440,8 +516,7 @@ conv3d_tile_kernel(ConvParams p, ConvTile t, ConvPhases ps) {
       float v[4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) v[rr] = apply_act(acc[mt][nt][rr] + bo[rr], p.act_out);
-      const long row = p.om ? ((long)(2 * z + p.oz) * p.Ho + (2 * y + p.oy)) * p.Wo + (2 * x + p.ox) : ((long)z * p.H + y) * p.W + x;
-      finish_and_store<bf16_t, 4>(v, p.e, n, row, o0);
+      finish_and_store<bf16_t, 4>(v, p.e, n, row0 + (long)nt * row_step, o0);
     }
   }
 }
@@ -785,13 +860,9 @@ extern "C" int pytc_convT3d_phase_fwd(const pytc_conv3d_args* a, const int32_t* 
   p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
   ConvPhases ps;
   ps.n = 8;
-  long off = 0;
   size_t lds_max = 0;
-  for (int ph = 0; ph < 8; ++ph) {
-    ps.G[ph] = t[ph].G; ps.woff[ph] = off;
-    off += (long)p.MTt * t[ph].nchunks * t[ph].G * 64 * 8;
+  for (int ph = 0; ph < 8; ++ph)
     if (lds[ph] > lds_max) lds_max = lds[ph];
-  }
   ConvTile tt = t[7];
   tt.tiles_z = (p.D + CT_TZ - 1) / CT_TZ; tt.tiles_y = (p.H + CT_TY - 1) / CT_TY; tt.tiles_x = (p.W + CT_TX - 1) / CT_TX;
   int MT = p.MTt >= 4 ? 4 : (p.MTt >= 2 ? 2 : 1);
