@@ -305,7 +305,7 @@ constexpr int CT_TZ = 4, CT_TY = 8, CT_TX = 16;
 struct ConvTile { int KC, nchunks, G, tzh, tyh, txh, tiles_z, tiles_y, tiles_x; };
 // the eight phases of a stride-2 transposed gather in ONE launch (blockIdx.z = phase = 4a + 2b + c): per phase the tap extents are
 // (1 + a, 1 + b, 1 + c), the groups per chunk G and the element offset of its weight image differ; n = 0: an ordinary conv
-struct ConvPhases { int n; };
+struct ConvPhases { int n; int probe; };      // probe (measurements only, wrong results): 1 = no matrix loop, 2 = no staging loads
 
 // channels per staged chunk: the whole (narrow) layer when it fits one chunk, else the widest divisor among 32 / 16 / 8
 static __host__ __device__ inline int conv_kc(int C_in) {
@@ -452,7 +452,7 @@ conv3d_tile_kernel(ConvParams p, ConvTile t, ConvPhases ps) {
         const int ty = tq % tyh, tz = tq / tyh;
         const int z = z0 + tz - pd, y = y0 + ty - ph, x = x0 + tx - pw;
         cu4_t v = {0u, 0u, 0u, 0u};
-        if (z >= 0 && z < p.D && y >= 0 && y < p.H && x >= 0 && x < p.W) {
+        if (ps.probe != 2 && z >= 0 && z < p.D && y >= 0 && y < p.H && x >= 0 && x < p.W) {
           const int c = c0 + piece * 8;
           v = *reinterpret_cast<const cu4_t*>(xn + (((long)z * p.H + y) * p.W + x) * p.C_in + c);
           if (has_pre) v = preact(v, c);
@@ -466,16 +466,32 @@ conv3d_tile_kernel(ConvParams p, ConvTile t, ConvPhases ps) {
     // workgroup of the deep, small layers -- MT = 1: eight matrix instructions per fragment, ~50 ns -- waited a whole L2 round trip
     // per group (256 -> 256 at 2 x 3 x 32 x 32: 1 728 groups per wave, 164 us for 12 us of matrix instructions).  A ring of AD groups ahead
     // (6 / 3 / 1 for MT = 1 / 2 / 4: what the accumulators leave room for); ring slots are compile-time (the group loop advances AD at a time).
-    constexpr int AD = MT == 1 ? 6 : (MT == 2 ? 3 : 1);
+    constexpr int AD = MT == 1 ? 6 : (MT == 2 ? 4 : 1);
+    // ... and (MT <= 2) the B fragments of the NEXT group are read from LDS while the matrix instructions of the current one run: the
+    // small launches put ONE wave on a SIMD, so the koff -> address -> ds_read_b128 chain of a group (two LDS round trips) was paid in
+    // full 216 times per wave (matrix loop of 256 -> 256: 80 us for 12 us of matrix instructions, tools/r06_conv_tile_probe.py).  Buffer
+    // parity is the ring slot's (AD is even).
+    constexpr bool BDB = MT <= 2;
     bf16x8_t ring[AD][MT];
     auto wfrag = [&](int mt, int g) -> bf16x8_t {
       return (mt0 + mt < p.MTt && g < tG) ? wp[((long)(mt0 + mt) * Gtot + ck * tG + g) * 64 + lane] : bf16x8_t{};
+    };
+    auto bfrag = [&](int ko, int nt) -> bf16x8_t {
+      return *reinterpret_cast<const bf16x8_t*>(lds + (ko < 0 ? ZOFF : base0 + nt * nt_step + ko));
     };
 #pragma unroll
     for (int d = 0; d < AD; ++d)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) ring[d][mt] = wfrag(mt, d);
-    for (int g0 = 0; g0 < tG; g0 += AD) {
+    bf16x8_t bfb[BDB ? 2 : 1][NT];
+    int ko1 = 0;                                            // koff of group g + 1
+    if constexpr (BDB) {
+      const int ko0 = koff[kb];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bfb[0][nt] = bfrag(ko0, nt);
+      ko1 = tG > 1 ? koff[4 + kb] : -1;
+    }
+    for (int g0 = 0; g0 < (ps.probe == 1 ? 0 : tG); g0 += AD) {
 #pragma unroll
       for (int d = 0; d < AD; ++d) {
         const int g = g0 + d;
@@ -483,13 +499,26 @@ conv3d_tile_kernel(ConvParams p, ConvTile t, ConvPhases ps) {
           bf16x8_t af[MT];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) { af[mt] = ring[d][mt]; ring[d][mt] = wfrag(mt, g + AD); }
-          const int ko = koff[g * 4 + kb];
+          if constexpr (BDB) {
+            constexpr int cur = d & 1, nxt = cur ^ 1;
+            const int ko2 = g + 2 < tG ? koff[(g + 2) * 4 + kb] : -1;
+            if (g + 1 < tG) {
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const int addr = ko < 0 ? ZOFF : base0 + nt * nt_step + ko;
-            const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(lds + addr);
+              for (int nt = 0; nt < NT; ++nt) bfb[nxt][nt] = bfrag(ko1, nt);
+            }
+            ko1 = ko2;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf, acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfb[cur][nt], acc[mt][nt], 0, 0, 0);
+          } else {
+            const int ko = koff[g * 4 + kb];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const bf16x8_t bf = bfrag(ko, nt);
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf, acc[mt][nt], 0, 0, 0);
+            }
           }
         }
       }
@@ -650,7 +679,7 @@ template <int MT>
 static void launch_conv_tile_mt(const ConvParams& p, const ConvTile& t, size_t lds_bytes, dim3 grid, hipStream_t s) {
   // dynamic LDS above 64 KB needs the opt-in, once per kernel and device
   if (!ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3d_tile_kernel<MT>), 80 * 1024, "conv3d_tile")) return;
-  hipLaunchKernelGGL((conv3d_tile_kernel<MT>), grid, dim3(256), lds_bytes, s, p, t, ConvPhases{});
+  hipLaunchKernelGGL((conv3d_tile_kernel<MT>), grid, dim3(256), lds_bytes, s, p, t, ConvPhases{0, tuning_get("conv_tile_probe", 0)});
 }
 
 template <int MT>
@@ -859,7 +888,7 @@ extern "C" int pytc_convT3d_phase_fwd(const pytc_conv3d_args* a, const int32_t* 
   p.e.rps_out = (long)a->D * a->H * a->W; p.e.C_out = a->C_out; p.e.res_mode = a->res_mode; p.e.nt = 0;
   p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
   ConvPhases ps;
-  ps.n = 8;
+  ps.n = 8; ps.probe = 0;
   size_t lds_max = 0;
   for (int ph = 0; ph < 8; ++ph)
     if (lds[ph] > lds_max) lds_max = lds[ph];
