@@ -416,6 +416,10 @@ int pytc_groupnorm_fold_mlp(const float* stats, int slots, float count, const fl
 /* Training forward of the mixer: pytc_pw_mlp_fwd that also stores the hidden pre-activation W2*(a*t+b)+b2 as bf16
  * [N][rows][C_hid] (the GELU input the backward kernels differentiate); GELU is evaluated at that stored value. */
 int pytc_pw_mlp_train_fwd(const pytc_mlp_args* a, void* hidden_pre, void* stream);
+/* The training forward without the store (round 6): the hidden pre-activation is rounded to bf16 before the activation exactly as
+ * pytc_pw_mlp_train_fwd rounds it -- y carries the same bits -- but is not written; the block's backward rebuilds it from the
+ * depthwise output (pytc_mixer_bwd_rc).  128 of the 320 bytes per voxel the full-resolution 32 -> 64 -> 32 mixer moved. */
+int pytc_pw_mlp_train_fwd_nostore(const pytc_mlp_args* a, void* stream);
 /* Training backward of the mixer's data path in one launch: dX = W2^T ((W3^T dY) * GELU'(hidden_pre)); a->t = dY,
  * a->w2_packed = paired image of W3^T (C_out_fwd -> C_hid), a->w3_packed = paired image of W2^T (C_hid -> C_in_fwd),
  * a->ab = identity affine [N][2][C], a->b2 / a->b3 = zero vectors, a->res_mode = NONE, a->y = dX; d_hidden
@@ -547,6 +551,27 @@ int pytc_pw_wgrad_partial(const void* x, const float* ab, const void* dy, float*
 int pytc_pw_wgrad_dgrad_supported(int C_in, int C_out, int dtype);
 int pytc_pw_wgrad_dgrad_partial(const void* x, const void* dy, const void* w_t_paired, void* dx, float* workspace, int want_db, int N,
                                 int64_t rows_per_sample, int C_in, int C_out, int dtype, int* slots_out, void* stream);
+/* Backward of a full-resolution block's mixer with the hidden pre-activation REBUILT (round 6): from the depthwise output t
+ * [N][rows][32], the forward's GroupNorm affine ab [N][2][32], the output gradient dy [N][rows][32] and the block's weights (w2_paired /
+ * w3t_paired = pytc_pw_pack_weight_paired images of W2 (32 -> C_hid) and of W3^T; b2 [C_hid]) one pass gives
+ *   dhp [N][rows][C_hid] = bf16((W3^T dy) * gelu'(hp)),  hp = bf16(W2 bf16(a t + b) + b2) recomputed with the forward's arithmetic,
+ *   the weight-gradient partials of the projecting conv (dW3[o][k] = sum_r dy[r][o] gelu(hp[r][k]); db3 when want_db3), and, gn != 0,
+ *   what pytc_pw_wgrad_groupnorm returns for (t, dhp): s_out [N][2][32], coef [N][3][32], and the per-sample terms of dW2 / db2.
+ * workspace: pytc_mixer_bwd_rc_ws_elems(N, rows, C_hid, gn) floats, S = *slots_out = N * pytc_mixer_bwd_rc_sps(...) slots:
+ *   dW3 partials [S][32][C_hid] | db3 partials [S][32] | gn: M partials [S][C_hid][32] | q partials [S][C_hid] | term [N][C_hid][32] |
+ *   q [N][C_hid];  dW2 = sum_n term[n], db2 = sum_n q[n] and the dW3 / db3 slot sums are left to the caller's pytc_reduce_slots_multi.
+ * Same bits as pytc_pw_wgrad_dgrad_partial / pytc_pw_wgrad_groupnorm on the stored hidden tensor whenever those launches' slots do
+ * not straddle samples (they group rows by slot; this one never lets a slot straddle).  pytc_mixer_bwd_rc_supported: 0 = no,
+ * 1 = gn == 0 only, 2 = both (bf16, C = C_out = 32, C_hid in {32, 64, 96}).  Replaces, in the backward of MedNeXtBlock.forward
+ * (external nnunet_mednext; contract at mednext_models.py:99-126), autograd's saved hidden activation, the conv3 weight- and
+ * data-gradient nodes, the activation backward and the conv2 weight-gradient node. */
+int pytc_mixer_bwd_rc_supported(int C, int C_hid, int C_out, int dtype);
+int pytc_mixer_bwd_rc_sps(int N, int64_t rows_per_sample, int C_hid);
+int64_t pytc_mixer_bwd_rc_ws_elems(int N, int64_t rows_per_sample, int C_hid, int gn);
+int pytc_mixer_bwd_rc(const void* t, const float* ab, const float* mean_rstd, const void* dy, const void* w2_paired, const float* b2,
+                      const void* w3t_paired, const float* W2, const float* gamma, float count, void* dhp, float* workspace,
+                      float* s_out, float* coef, int want_db3, int gn, int N, int64_t rows_per_sample, int C, int C_hid, int C_out,
+                      int dtype, int* slots_out, void* stream);
 int pytc_dw_wgrad_partial(const void* g, const void* x, float* workspace, int want_db, int N, const int32_t* gdims,
                           const int32_t* xdims, int C, int K, int stride, int dtype, int* slots_out, void* stream);
 typedef struct {

@@ -149,6 +149,12 @@ _SIGS = {
     "pytc_pw_wgrad_dgrad_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pytc_pw_wgrad_dgrad_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64,
                                               C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
+    "pytc_mixer_bwd_rc_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pytc_mixer_bwd_rc_sps": (C.c_int, [C.c_int, C.c_int64, C.c_int]),
+    "pytc_mixer_bwd_rc_ws_elems": (C.c_int64, [C.c_int, C.c_int64, C.c_int, C.c_int]),
+    "pytc_mixer_bwd_rc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     "pytc_dw_wgrad_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     "pytc_reduce_slots_multi": (C.c_int, [C.POINTER(ReduceItem), C.c_int, C.c_void_p]),
@@ -255,6 +261,7 @@ _SIGS = {
     "pytc_stem_dwconv3d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pytc_pw_mlp_train_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p, C.c_void_p]),
+    "pytc_pw_mlp_train_fwd_nostore": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p]),
     "pytc_pw_mlp_bwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
     "pytc_pw_mlp_up_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pytc_pw_mlp_up_fwd": (C.c_int, [C.POINTER(MlpArgs), C.c_void_p, C.c_void_p, C.c_void_p]),

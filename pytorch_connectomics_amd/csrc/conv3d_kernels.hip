@@ -500,7 +500,7 @@ conv3d_tile_kernel(ConvParams p, ConvTile t, ConvPhases ps) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) { af[mt] = ring[d][mt]; ring[d][mt] = wfrag(mt, g + AD); }
           if constexpr (BDB) {
-            constexpr int cur = d & 1, nxt = cur ^ 1;
+            const int cur = d & 1, nxt = cur ^ 1;      // (d is an unrolled loop index: compile-time after unrolling)
             const int ko2 = g + 2 < tG ? koff[(g + 2) * 4 + kb] : -1;
             if (g + 1 < tG) {
 #pragma unroll

@@ -44,7 +44,10 @@ struct MlpParams {
   const float* stem_w;
   const float* stem_b;
   // STOREH kernels (training forward): the pre-activation of the hidden layer is also written, [N][rps][C_hid] bf16
+  // (round_h with hp == nullptr: rounded to bf16 exactly as the storing form rounds it, but not written -- the backward of the
+  // full-resolution blocks rebuilds it, mixer_bwd_rc_kernel)
   bf16_t* hp;
+  int round_h;
   // BWD kernels (training backward, data gradients of both GEMMs in one launch): the "activation" between the GEMMs is
   // the multiplication by GELU'(hp_in), and hp receives the product (d loss / d pre-activation) for the weight gradient
   const bf16_t* hp_in;
@@ -249,7 +252,7 @@ pw_mlp_kernel(MlpParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { pre[j] = acc1[0][nt][j]; pre[4 + j] = acc1[1][nt][j]; }
         const bf16x8_t hb = Mma<bf16_t>::from_floats(pre);
-        if (orow[nt] < p.rps)
+        if (p.hp && orow[nt] < p.rps)
           *reinterpret_cast<bf16x8_t*>(p.hp + ((long)n * p.rps + orow[nt]) * p.C_hid + hc * 32 + kb * 8) = hb;
         const f32x8_t hr = __builtin_convertvector(hb, f32x8_t);
 #pragma unroll
@@ -816,7 +819,7 @@ static void launch_mlp(const MlpParams& p, int N, hipStream_t s) {
     hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT, 1, false, false, false, true>), grid, block, 0, s, p);
     return;
   }
-  if (p.hp) {       // training forward: fast GELU (what the backward kernels differentiate), hidden pre-activation stored
+  if (p.hp || p.round_h) {       // training forward: fast GELU (what the backward kernels differentiate), hidden pre-activation stored / rounded
     if (p.w3_f16) hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT, 3, false, false, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((pw_mlp_kernel<KS_IN, MO, NT, 1, false, false, true>), grid, block, 0, s, p);
     return;
@@ -1047,7 +1050,7 @@ extern "C" int pytc_pw_mlp_proj_fwd(const pytc_mlp_args* a, const void* proj_w, 
   return PYTC_OK;
 }
 
-static int mlp_fwd_impl(const pytc_mlp_args* a, void* hp, void* stream, const void* hp_in = nullptr);
+static int mlp_fwd_impl(const pytc_mlp_args* a, void* hp, void* stream, const void* hp_in = nullptr, bool round_h = false);
 
 // a->t = dY [N][rows][C_in], a->w2_packed = W3^T image (C_in -> C_hid), a->w3_packed = W2^T image (C_hid -> C_out),
 // a->ab = identity affine, a->b2 / a->b3 = zeros, a->y = dX; hidden_pre = the forward's stored pre-activation,
@@ -1063,12 +1066,18 @@ extern "C" int pytc_pw_mlp_train_fwd(const pytc_mlp_args* a, void* hidden_pre, v
   return mlp_fwd_impl(a, hidden_pre, stream);
 }
 
+// the training forward without the store: the hidden pre-activation is rounded to bf16 before the activation exactly as
+// pytc_pw_mlp_train_fwd does, y carries the same bits, nothing is written besides y (pytc_mixer_bwd_rc rebuilds the hidden tensor)
+extern "C" int pytc_pw_mlp_train_fwd_nostore(const pytc_mlp_args* a, void* stream) {
+  return mlp_fwd_impl(a, nullptr, stream, nullptr, true);
+}
+
 extern "C" int pytc_pw_mlp_fwd(const pytc_mlp_args* a, void* stream) { return mlp_fwd_impl(a, nullptr, stream); }
 
-static int mlp_fwd_impl(const pytc_mlp_args* a, void* hp, void* stream, const void* hp_in) {
+static int mlp_fwd_impl(const pytc_mlp_args* a, void* hp, void* stream, const void* hp_in, bool round_h) {
   PYTC_REQUIRE(a && a->t && (a->ab || a->per_sample) && a->w2_packed && a->w3_packed && a->b2 && a->b3 && a->y, "pw_mlp: null pointer");
   PYTC_REQUIRE(!(a->ab && a->per_sample), "pw_mlp: per-sample (norm-folded) expand operands come without an affine");
-  PYTC_REQUIRE(!(a->per_sample && (hp || hp_in)), "pw_mlp: the training kernels take the shared expand image and the affine");
+  PYTC_REQUIRE(!(a->per_sample && (hp || hp_in || round_h)), "pw_mlp: the training kernels take the shared expand image and the affine");
   PYTC_REQUIRE(a->N >= 1 && a->rows_per_sample >= 1, "pw_mlp: bad shape");
   if (!mlp_shape_ok(a->C_in, a->C_hid, a->C_out)) {
     set_error("pw_mlp: no fused kernel for C_in=%d C_hid=%d C_out=%d", a->C_in, a->C_hid, a->C_out);
@@ -1088,6 +1097,7 @@ static int mlp_fwd_impl(const pytc_mlp_args* a, void* hp, void* stream, const vo
   p.e.Go_d = p.e.Go_h = p.e.Go_w = p.e.Gl_d = p.e.Gl_h = p.e.Gl_w = 0;
   p.hp = (bf16_t*)hp;
   p.hp_in = (const bf16_t*)hp_in;
+  p.round_h = round_h ? 1 : 0;
   p.w3_f16 = a->w3_format == PYTC_W3_F16 ? 1 : 0;
   PYTC_REQUIRE(!(p.w3_f16 && hp_in), "pw_mlp_bwd: the backward mixer takes bf16 weight images");
   if (a->res_mode == PYTC_RES_UPSAMPLE) {
@@ -1098,7 +1108,7 @@ static int mlp_fwd_impl(const pytc_mlp_args* a, void* hp, void* stream, const vo
     p.e.Gl_d = a->Di / 2; p.e.Gl_h = a->Hi / 2; p.e.Gl_w = a->Wi / 2;
   }
   // level-0 shapes of the inference mixers with per-sample operands: the DMA-prefetching form (pw_mlp_dma_kernel)
-  if (!hp && !hp_in && mlp_dma_applies(a, p)) {
+  if (!hp && !hp_in && !round_h && mlp_dma_applies(a, p)) {
     mlp_dma_launch<0>(a, p, (hipStream_t)stream);
     PYTC_LAUNCH_CHECK("pw_mlp_dma");
     return PYTC_OK;

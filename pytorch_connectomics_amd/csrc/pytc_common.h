@@ -148,6 +148,23 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// gelu_fast AND its derivative from one exponential and one reciprocal (round 6, mixer_bwd_rc_kernel: that kernel is bound by VALU issue,
+// and gelu_fast + gelu_erf_grad cost 21 VALU + 4 quarter-rate transcendentals per element).  With u = x p(x^2), e = 2^u, s = 1 / (1 + e):
+//     g = x s  (the bits of gelu_fast),     g' = s + x s (1 - s) (-ln 2) du/dx,     du/dx = p + 2 x^2 p'(x^2)
+// the derivative OF THE FUNCTION THE FORWARD EVALUATED; against the exact erf form |g' - gelu'| <= 1.1e-4 over the whole axis (max at
+// |x| = 0.93; bf16 rounding of g' ~ 1 is 2e-3).  1 - s, not e s: e = inf, s = 0 for x < -26 would give NaN.  15 VALU + 2 transcendentals.
+__device__ __forceinline__ void gelu_fast_with_grad(float x, float& g, float& gd) {
+  const float x2 = fminf(x * x, 64.0f);
+  float p = fmaf(x2, 1.0142630e-3f, -1.0677572e-1f);
+  p = fmaf(p, x2, -2.3011213f);
+  const float e = __builtin_amdgcn_exp2f(x * p);
+  const float s = __builtin_amdgcn_rcpf(1.0f + e);
+  g = x * s;
+  const float q = fmaf(x2, 2.0f * 1.0142630e-3f, -1.0677572e-1f);
+  const float du = fmaf(x2 + x2, q, p);
+  gd = fmaf(g * (1.0f - s), du * -0.69314718055994530942f, s);
+}
+
 // Packed-fp16 GELU for the fused mixers (round 2).  SQ counters put the bf16 mixers at ~70 % VALU busy with v_exp_f32 +
 // v_rcp_f32 (quarter rate) as 60 % of it; packed fp32 FMAs bring nothing on gfx950 (profiles/r02_gelu_valu_probe.txt), but
 // v_pk_*_f16 really does process two values per lane and instruction.  Transcendental-free form

@@ -368,6 +368,320 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
   }
 }
 
+// ---- level-0 mixer backward with the hidden pre-activation REBUILT from the depthwise output (round 6) ------------------------------
+// A block's training forward stored the hidden pre-activation hp = bf16(W2 bf16(a t + b) + b2) (2 C_hid bytes per voxel written, read
+// back once by the pass above).  At the full-resolution level, where every kernel is bound by its bytes, this kernel takes the
+// depthwise output t instead and rebuilds hp in registers with the forward's own arithmetic -- the paired image of W2 as the A operand,
+// the lane's 8 normalised channels of a row as the B operand, accumulators started from b2: one 16x16x32 MFMA per tile, bit-identical to
+// what pw_mlp_kernel<.., STOREH> rounded -- so the forward stores nothing (pytc_pw_mlp_train_fwd with a null hidden buffer) and the
+// backward reads 64 B per voxel where it read 128.  Per 32-row block of a wave:
+//   stage     dy rows -> wave-private LDS image (for the transposed weight-gradient fragments); t rows -> bf16(a t + b) in registers
+//             (GN: also xhat = (t - mean) rstd split into bf16 high and low parts -> two LDS images)
+//   rebuild   hp tile pair (lo, hi) = 2 MFMAs; g = bf16(gelu_fast(hp)) -> LDS image (the weight gradient's operand);
+//             dhp = bf16((W3^T dy) * gelu_fast'(hp)) = 2 more MFMAs on the dy rows still in registers -> 16-byte stores (the derivative of
+//             the function the forward evaluated, from the same exponential and reciprocal: gelu_fast_with_grad)
+//   dW3 += dy^T g, db3 += dy^T 1 through ds_read_tr16_b64 fragments, exactly as pw_wgrad_mfma_kernel
+//   GN        the dhp rows (kept in registers) replace g in its LDS image; dW2-partials M += dhp^T xhat_hi + dhp^T xhat_lo,
+//             q += dhp^T 1: the per-sample sums that norm_bwd_from_wgrad_kernel turns into the GroupNorm backward statistics, the
+//             norm-backward coefficients and dW2 / db2 -- the pass of pytc_pw_wgrad_groupnorm over (t, dhp) is not run at all.
+// Slots never straddle samples (`sps` per sample, as pytc_pw_wgrad_groupnorm), so the affine of a workgroup is one sample's.  With the
+// slot count of the launches it replaces the partial sums group the same rows in the same order: dW3 / db3 / M / q carry the bits of
+// pytc_pw_wgrad_dgrad_partial / pytc_pw_wgrad_groupnorm whenever those launches' slots do not straddle samples either.
+// C = C_out = 32, C_hid = 16 HT (HT even).
+struct MixBwd {
+  const bf16_t* t;          // [N][rows][32]
+  const float* ab;          // [N][2][32]
+  const float* mr;          // [N][2][32] (mean, rstd), GN
+  const bf16_t* dy;         // [N][rows][32]
+  const bf16x8_t* w2p;      // paired image of W2 (32 -> C_hid): HT tiles x 64 lanes
+  const float* b2;          // [C_hid]
+  const bf16x8_t* w3t;      // paired image of W3^T ([C_hid][32]): HT tiles x 64 lanes
+  float* dW3p; float* db3p; // [slots][32][C_hid], [slots][32]
+  float* dW2p; float* db2p; // GN: [slots][C_hid][32], [slots][C_hid]
+  bf16_t* dhp;              // [N][rows][C_hid]
+  long rows_per_sample, rows_per_slot;
+  int sps, want_db3;
+};
+
+template <int HT, bool GN>
+__global__ void __launch_bounds__(256, 2)
+mixer_bwd_rc_kernel(MixBwd p) {
+  static_assert(HT % 2 == 0 && HT >= 2 && HT <= 8, "hidden tiles come in pairs");
+  constexpr int CH = HT * 16;
+  constexpr int SG = 32 * 2 + 32, SX = CH * 2 + 32;            // LDS row pitches (bytes) of the 32-channel and the hidden images
+  constexpr int WAVE_BYTES = 32 * (SG + SX + (GN ? 2 * SG : 0));
+  constexpr int RED3 = (32 * CH + 32) * 4, RED2 = GN ? (CH * 32 + CH) * 4 : 0;
+  constexpr int TAB_BYTES = (CH + (GN ? 64 : 0)) * 4;           // b2 | xhat scale | xhat offset
+  constexpr int LDS_MAIN = 4 * WAVE_BYTES > RED3 + RED2 ? 4 * WAVE_BYTES : RED3 + RED2;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_MAIN + TAB_BYTES];
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+  typedef unsigned int q4_t __attribute__((ext_vector_type(4)));
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rr = lane & 15, kb = lane >> 4;
+  unsigned char* lg = lds + wave * WAVE_BYTES;      // dy rows
+  unsigned char* lx = lg + 32 * SG;                 // gelu(hp) rows, then (GN) dhp rows
+  unsigned char* lxh = lx + 32 * SX;                // GN: xhat high / low parts
+  unsigned char* lxl = lxh + 32 * SG;
+  float* tab = reinterpret_cast<float*>(lds + LDS_MAIN);
+
+  const int slot = blockIdx.x;
+  const long n = slot / p.sps;
+  const long sample_begin = n * p.rows_per_sample;
+  const long r_begin = sample_begin + (long)(slot % p.sps) * p.rows_per_slot;
+  const long r_end = r_begin + p.rows_per_slot < sample_begin + p.rows_per_sample ? r_begin + p.rows_per_slot : sample_begin + p.rows_per_sample;
+
+  for (int i = threadIdx.x; i < CH; i += 256) tab[i] = p.b2[i];
+  if constexpr (GN) {
+    if (threadIdx.x < 32) {
+      const float mean = p.mr[(n * 2 + 0) * 32 + threadIdx.x], rstd = p.mr[(n * 2 + 1) * 32 + threadIdx.x];
+      tab[CH + threadIdx.x] = rstd;
+      tab[CH + 32 + threadIdx.x] = -mean * rstd;
+    }
+  }
+  // the norm affine of the lane's 8 channels (one sample per workgroup)
+  float av[8], bv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { av[i] = p.ab[(n * 2 + 0) * 32 + kb * 8 + i]; bv[i] = p.ab[(n * 2 + 1) * 32 + kb * 8 + i]; }
+  bf16x8_t w2f[HT], w3f[HT];
+#pragma unroll
+  for (int t = 0; t < HT; ++t) { w2f[t] = p.w2p[t * 64 + lane]; w3f[t] = p.w3t[t * 64 + lane]; }
+  __syncthreads();
+
+  const q4_t zero4 = {0u, 0u, 0u, 0u};
+  q4_t rtA[2], rgA[2], rtB[2], rgB[2];
+  auto fetch = [&](long r0, q4_t (&rt)[2], q4_t (&rg)[2]) {
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const long r = r0 + t2 * 16 + rr;
+      rt[t2] = r < r_end ? *reinterpret_cast<const q4_t*>(p.t + r * 32 + kb * 8) : zero4;
+      rg[t2] = r < r_end ? *reinterpret_cast<const q4_t*>(p.dy + r * 32 + kb * 8) : zero4;
+    }
+  };
+  const int fr_row = (lane >> 4) * 4 + ((lane & 15) >> 2), fr_col = (lane & 3) * 8;
+  auto frag = [&](unsigned char* base, int pitch, int tile) -> bf16x8_t {
+    unsigned char* q = base + fr_row * pitch + tile * 32 + fr_col;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)q);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(q + 16 * pitch));
+    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, both);
+  };
+
+  f32x4_t acc3[2][HT], accb3[2];
+  f32x4_t acc2[GN ? HT : 1][2], accb2[GN ? HT : 1];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    accb3[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < HT; ++h) acc3[m][h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int h = 0; h < (GN ? HT : 1); ++h) {
+    accb2[h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    acc2[h][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    acc2[h][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  bf16x8_t ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
+
+  bf16x8_t tn[2], dyb[2];
+  auto stage = [&](long r0, q4_t (&rt)[2], q4_t (&rg)[2]) {
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      dyb[t2] = __builtin_bit_cast(bf16x8_t, rg[t2]);
+      *reinterpret_cast<q4_t*>(lg + (t2 * 16 + rr) * SG + kb * 16) = rg[t2];
+      const f32x8_t raw = __builtin_convertvector(__builtin_bit_cast(bf16x8_t, rt[t2]), f32x8_t);
+      f32x8_t f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = fmaf(raw[i], av[i], bv[i]);
+      tn[t2] = __builtin_convertvector(f, bf16x8_t);          // what the forward GEMM consumed
+      if constexpr (GN) {
+        const bool live = r0 + t2 * 16 + rr < r_end;
+        const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(tab + CH + kb * 8), s1 = *reinterpret_cast<const f32x4_t*>(tab + CH + kb * 8 + 4);
+        const f32x4_t o0 = *reinterpret_cast<const f32x4_t*>(tab + CH + 32 + kb * 8), o1 = *reinterpret_cast<const f32x4_t*>(tab + CH + 32 + kb * 8 + 4);
+        f32x8_t xh;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xh[i] = fmaf(raw[i], s0[i], o0[i]); xh[4 + i] = fmaf(raw[4 + i], s1[i], o1[i]); }
+        const bf16x8_t hi = __builtin_convertvector(xh, bf16x8_t);
+        const f32x8_t back = __builtin_convertvector(hi, f32x8_t);
+        const bf16x8_t lo = __builtin_convertvector(xh - back, bf16x8_t);
+        *reinterpret_cast<q4_t*>(lxh + (t2 * 16 + rr) * SG + kb * 16) = live ? __builtin_bit_cast(q4_t, hi) : zero4;
+        *reinterpret_cast<q4_t*>(lxl + (t2 * 16 + rr) * SG + kb * 16) = live ? __builtin_bit_cast(q4_t, lo) : zero4;
+      }
+    }
+  };
+  auto compute = [&](long r0) {
+    q4_t dq[GN ? 2 : 1][GN ? HT / 2 : 1];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const long row = r0 + t2 * 16 + rr;
+#pragma unroll
+      for (int pr = 0; pr < HT / 2; ++pr) {
+        const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(tab + pr * 32 + kb * 8), c1 = *reinterpret_cast<const f32x4_t*>(tab + pr * 32 + kb * 8 + 4);
+        const f32x4_t lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[2 * pr], tn[t2], c0, 0, 0, 0);
+        const f32x4_t hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[2 * pr + 1], tn[t2], c1, 0, 0, 0);
+        float pre[8], hv[8], g[8], gd[8], v[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { pre[i] = lo[i]; pre[4 + i] = hi[i]; }
+        const bf16x8_t hb = Mma<bf16_t>::from_floats(pre);      // the value the forward rounded (and used to store)
+        VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(&hb), hv);
+        // g = gelu_fast(hp) with gelu_fast's bits; g' = the derivative of that function (pytc_common.h: <= 1.1e-4 from the erf form's)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gelu_fast_with_grad(hv[i], g[i], gd[i]);
+        *reinterpret_cast<bf16x8_t*>(lx + (t2 * 16 + rr) * SX + (pr * 32 + kb * 8) * 2) = Mma<bf16_t>::from_floats(g);
+        const f32x4_t dlo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[2 * pr], dyb[t2], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const f32x4_t dhi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[2 * pr + 1], dyb[t2], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = dlo[i] * gd[i]; v[4 + i] = dhi[i] * gd[4 + i]; }
+        const bf16x8_t vb = Mma<bf16_t>::from_floats(v);
+        if (row < r_end) *reinterpret_cast<bf16x8_t*>(p.dhp + row * CH + pr * 32 + kb * 8) = vb;
+        if constexpr (GN) dq[t2][pr] = row < r_end ? __builtin_bit_cast(q4_t, vb) : zero4;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    bf16x8_t fa[2], fb[HT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) fa[m] = frag(lg, SG, m);
+#pragma unroll
+    for (int h = 0; h < HT; ++h) fb[h] = frag(lx, SX, h);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int h = 0; h < HT; ++h) acc3[m][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], fb[h], acc3[m][h], 0, 0, 0);
+      if (p.want_db3) accb3[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], ones, accb3[m], 0, 0, 0);
+    }
+    if constexpr (GN) {
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int pr = 0; pr < HT / 2; ++pr) *reinterpret_cast<q4_t*>(lx + (t2 * 16 + rr) * SX + (pr * 32 + kb * 8) * 2) = dq[t2][pr];
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+      bf16x8_t fh[2], fl[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) { fh[c] = frag(lxh, SG, c); fl[c] = frag(lxl, SG, c); }
+#pragma unroll
+      for (int h = 0; h < HT; ++h) {
+        const bf16x8_t fd = frag(lx, SX, h);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc2[h][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd, fh[c], acc2[h][c], 0, 0, 0);
+        accb2[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd, ones, accb2[h], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc2[h][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd, fl[c], acc2[h][c], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  long r0 = r_begin + wave * 32;
+  if (r0 < r_end) fetch(r0, rtA, rgA);
+  if (r0 + 128 < r_end) fetch(r0 + 128, rtB, rgB);
+  for (; r0 < r_end; r0 += 256) {                    // the block order per wave of pw_wgrad_mfma_kernel
+    stage(r0, rtA, rgA);
+    if (r0 + 256 < r_end) fetch(r0 + 256, rtA, rgA);
+    compute(r0);
+    if (r0 + 128 < r_end) {
+      stage(r0 + 128, rtB, rgB);
+      if (r0 + 384 < r_end) fetch(r0 + 384, rtB, rgB);
+      compute(r0 + 128);
+    }
+  }
+
+  // fixed-order cross-wave sums through LDS (wave 0 + 1 + 2 + 3), then wave 0 stores the slot partials
+  __syncthreads();
+  float* red3 = reinterpret_cast<float*>(lds);
+  float* red2 = reinterpret_cast<float*>(lds + RED3);
+  const int nn = lane & 15, mg = (lane >> 4) * 4;
+  for (int w = 1; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int h = 0; h < HT; ++h)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) red3[(m * 16 + mg + i) * CH + h * 16 + nn] = acc3[m][h][i];
+        if (nn == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) red3[32 * CH + m * 16 + mg + i] = accb3[m][i];
+        }
+      }
+      if constexpr (GN) {
+#pragma unroll
+        for (int h = 0; h < HT; ++h) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red2[(h * 16 + mg + i) * 32 + c * 16 + nn] = acc2[h][c][i];
+          if (nn == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red2[CH * 32 + h * 16 + mg + i] = accb2[h][i];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int h = 0; h < HT; ++h)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc3[m][h][i] += red3[(m * 16 + mg + i) * CH + h * 16 + nn];
+        if (nn == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) accb3[m][i] += red3[32 * CH + m * 16 + mg + i];
+        }
+      }
+      if constexpr (GN) {
+#pragma unroll
+        for (int h = 0; h < HT; ++h) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc2[h][c][i] += red2[(h * 16 + mg + i) * 32 + c * 16 + nn];
+          if (nn == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) accb2[h][i] += red2[CH * 32 + h * 16 + mg + i];
+          }
+        }
+      }
+    }
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int o = m * 16 + mg + i;
+#pragma unroll
+        for (int h = 0; h < HT; ++h) p.dW3p[((long)slot * 32 + o) * CH + h * 16 + nn] = acc3[m][h][i];
+        if (p.want_db3 && nn == 0) p.db3p[(long)slot * 32 + o] = accb3[m][i];
+      }
+    }
+    if constexpr (GN) {
+#pragma unroll
+      for (int h = 0; h < HT; ++h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int o = h * 16 + mg + i;
+#pragma unroll
+          for (int c = 0; c < 2; ++c) p.dW2p[((long)slot * CH + o) * 32 + c * 16 + nn] = acc2[h][c][i];
+          if (nn == 0) p.db2p[(long)slot * CH + o] = accb2[h][i];
+        }
+      }
+    }
+  }
+}
+
 // ---- thin pointwise weight gradient (C_in == 1: stem, or C_out == 1: one-channel heads; no prologue) --------------
 // dW[c] = sum_r big[r][c] * thin[r]: the column-sum lane map of colstats.h (16-byte loads of the wide operand).
 // big_is_dy: big = dY [rows][C_out], thin = X [rows][1], db[c] = sum big;  else big = X [rows][C_in], thin = dY, db[0].
@@ -1223,6 +1537,69 @@ extern "C" int pytc_pw_wgrad_groupnorm(const void* t, const float* mean_rstd, co
   hipLaunchKernelGGL(norm_bwd_from_wgrad_kernel, dim3((C + 15) / 16, N), dim3(256), 0, s, term, dbp, qv, W2, gamma, ab, mean_rstd,
                      s_out, coef, N, C, C_hid, sps, 1.0f / count);
   PYTC_LAUNCH_CHECK("pw_wgrad_groupnorm");
+  return PYTC_OK;
+}
+
+/* Level-0 mixer backward with the hidden pre-activation rebuilt (mixer_bwd_rc_kernel): from t, dy and the block's weights to
+   dhp = (W3^T dy) * gelu'(hp), the weight-gradient partials of the projecting conv and -- gn != 0 -- everything pytc_pw_wgrad_groupnorm
+   returns.  workspace (pytc_mixer_bwd_rc_ws_elems floats), S = N * sps slots:
+     dW3 partials [S][32][C_hid] | db3 partials [S][32] | gn: M partials [S][C_hid][32] | q partials [S][C_hid] | term [N][C_hid][32] | q [N][C_hid] */
+extern "C" int pytc_mixer_bwd_rc_supported(int C, int C_hid, int C_out, int dtype) {      // 0 no, 1 without the GroupNorm form, 2 both
+  if (!(dtype == PYTC_BF16 && C == 32 && C_out == 32 && (C_hid == 64 || C_hid == 32 || C_hid == 96)) || tuning_get("mixer_bwd_rc", 1) == 0) return 0;
+  return C_hid == 96 ? 1 : 2;          // 96: the GroupNorm form's accumulators do not fit 256 registers (68 spilled)
+}
+
+extern "C" int pytc_mixer_bwd_rc_sps(int N, int64_t rows_per_sample, int C_hid) {
+  const long rows_total = (long)N * rows_per_sample;
+  const int slots = wgrad_mfma_slots(rows_total, C_hid, 32, pytc_pw_wgrad_slots(rows_total));
+  const int sps = slots / N;
+  return sps < 1 ? 1 : sps;
+}
+
+extern "C" int64_t pytc_mixer_bwd_rc_ws_elems(int N, int64_t rows_per_sample, int C_hid, int gn) {
+  const long S = (long)N * pytc_mixer_bwd_rc_sps(N, rows_per_sample, C_hid);
+  const long per = 32L * C_hid;
+  return (int64_t)(S * (per + 32) + (gn ? S * (per + C_hid) + (long)N * (per + C_hid) : 0));
+}
+
+template <int HT>
+static void launch_mixer_bwd_rc(const MixBwd& q, int gn, int slots, hipStream_t s) {
+  if (gn) hipLaunchKernelGGL((mixer_bwd_rc_kernel<HT, true>), dim3(slots), dim3(256), 0, s, q);
+  else hipLaunchKernelGGL((mixer_bwd_rc_kernel<HT, false>), dim3(slots), dim3(256), 0, s, q);
+}
+
+extern "C" int pytc_mixer_bwd_rc(const void* t, const float* ab, const float* mean_rstd, const void* dy, const void* w2_paired,
+                                 const float* b2, const void* w3t_paired, const float* W2, const float* gamma, float count, void* dhp,
+                                 float* workspace, float* s_out, float* coef, int want_db3, int gn, int N, int64_t rows_per_sample,
+                                 int C, int C_hid, int C_out, int dtype, int* slots_out, void* stream) {
+  PYTC_REQUIRE(t && ab && dy && w2_paired && b2 && w3t_paired && dhp && workspace && slots_out && N >= 1 && N <= 65535 && rows_per_sample >= 1,
+               "mixer_bwd_rc: bad arguments");
+  PYTC_REQUIRE(pytc_mixer_bwd_rc_supported(C, C_hid, C_out, dtype) >= (gn ? 2 : 1),
+               "mixer_bwd_rc: bf16, C = C_out = 32, C_hid in {32, 64, 96} (96: gn = 0 only) (got %d, %d, %d, gn %d)", C, C_hid, C_out, gn);
+  PYTC_REQUIRE(!gn || (mean_rstd && W2 && s_out && coef && count > 0.f), "mixer_bwd_rc: the GroupNorm form needs mean_rstd, W2, s_out, coef, count");
+  const int sps = pytc_mixer_bwd_rc_sps(N, rows_per_sample, C_hid);
+  const long S = (long)N * sps, per = 32L * C_hid;
+  MixBwd q{};
+  q.t = (const bf16_t*)t; q.ab = ab; q.mr = mean_rstd; q.dy = (const bf16_t*)dy;
+  q.w2p = (const bf16x8_t*)w2_paired; q.b2 = b2; q.w3t = (const bf16x8_t*)w3t_paired;
+  q.dW3p = workspace; q.db3p = q.dW3p + S * per;
+  q.dW2p = q.db3p + S * 32; q.db2p = q.dW2p + S * per;
+  float* term = q.db2p + S * C_hid;
+  float* qv = term + (long)N * per;
+  q.dhp = (bf16_t*)dhp;
+  q.rows_per_sample = rows_per_sample; q.rows_per_slot = (rows_per_sample + sps - 1) / sps;
+  q.sps = sps; q.want_db3 = want_db3;
+  hipStream_t s = (hipStream_t)stream;
+  if (C_hid == 64) launch_mixer_bwd_rc<4>(q, gn, (int)S, s);
+  else if (C_hid == 96) hipLaunchKernelGGL((mixer_bwd_rc_kernel<6, false>), dim3((unsigned)S), dim3(256), 0, s, q);
+  else launch_mixer_bwd_rc<2>(q, gn, (int)S, s);
+  if (gn) {
+    hipLaunchKernelGGL(reduce_slots_batched_kernel, dim3(ceil_div(per, 16), N), dim3(256), 0, s, q.dW2p, term, per, sps);
+    hipLaunchKernelGGL(norm_bwd_from_wgrad_kernel, dim3(2, N), dim3(256), 0, s, term, q.db2p, qv, W2, gamma, ab, mean_rstd, s_out, coef, N, 32,
+                       C_hid, sps, 1.0f / count);
+  }
+  *slots_out = (int)S;
+  PYTC_LAUNCH_CHECK("mixer_bwd_rc");
   return PYTC_OK;
 }
 

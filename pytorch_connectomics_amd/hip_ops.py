@@ -621,11 +621,13 @@ def pw_mlp(t: torch.Tensor, ab: Optional[torch.Tensor], w2p: torch.Tensor, b2: t
            res: Optional[torch.Tensor] = None, res_mode: int = nat.RES_NONE, grid: Sequence[int] = (0, 0, 0),
            res_low: Optional[torch.Tensor] = None, res_bias: Optional[torch.Tensor] = None,
            y: Optional[torch.Tensor] = None, hidden_pre: Optional[torch.Tensor] = None, lds: bool = False,
-           chunked: bool = False) -> torch.Tensor:
+           chunked: bool = False, train_nostore: bool = False) -> torch.Tensor:
     """Fused norm-apply -> 1x1 expand -> GELU -> 1x1 project (+residual) on bf16 NDHWC rows.  hidden_pre (N, rows, c_hid)
     bf16: training forward, the hidden pre-activation is stored there as well.  lds: the persistent kernel with the weight images
     resident in LDS (pw_mlp_lds_supported shapes, fp16 projection image; bit-identical).  chunked: the kernel whose workgroups stream
-    the weight images through LDS one hidden chunk at a time (pw_mlp_chunk_supported shapes: wide hidden layers; bit-identical)."""
+    the weight images through LDS one hidden chunk at a time (pw_mlp_chunk_supported shapes: wide hidden layers; bit-identical).
+    train_nostore: the training forward's arithmetic (hidden pre-activation rounded to bf16 before the activation: y has the bits of the
+    hidden_pre form) without the store -- for blocks whose backward rebuilds the hidden tensor (mixer_bwd_rc)."""
     _dev(t, "t")
     if t.dtype != torch.bfloat16:
         raise TypeError("pw_mlp runs on bfloat16 activations")
@@ -649,6 +651,10 @@ def pw_mlp(t: torch.Tensor, ab: Optional[torch.Tensor], w2p: torch.Tensor, b2: t
         _dev(hidden_pre, "hidden_pre")
         _run(f"pw_mlp_train_fwd[{c_in}->{c_hid}->{c_out}]", nb + N * rows_per_sample * 2 * c_hid, nat.lib().pytc_pw_mlp_train_fwd,
              C.byref(a), _p(hidden_pre), _stream())
+        return y
+    if train_nostore:
+        _run(f"pw_mlp_train_fwd_nostore[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_train_fwd_nostore, C.byref(a), _stream(),
+             symbol=f"pw_mlp_kernel<{c_in // 32}, {c_out // 16}>")
         return y
     if lds:
         _run(f"pw_mlp_fwd[{c_in}->{c_hid}->{c_out}]", nb, nat.lib().pytc_pw_mlp_lds_fwd, C.byref(a), _stream(),
@@ -1572,6 +1578,60 @@ def pw_wgrad_dgrad(hp: torch.Tensor, dy: torch.Tensor, w_t_paired: torch.Tensor,
     if own:
         defer.flush()
     return dW, db, dhp
+
+
+def mixer_bwd_rc_supported(c: int, c_hid: int, c_out: int, dtype: torch.dtype) -> int:
+    """0: no; 1: the form without the GroupNorm sums; 2: both (pytc_mixer_bwd_rc_supported)."""
+    try:
+        return int(nat.lib().pytc_mixer_bwd_rc_supported(int(c), int(c_hid), int(c_out), dtype_code(dtype)))
+    except Exception:
+        return 0
+
+
+def mixer_bwd_rc(t: torch.Tensor, ab: torch.Tensor, dy: torch.Tensor, w2_paired: torch.Tensor, b2: torch.Tensor, w3t_paired: torch.Tensor,
+                 *, N: int, rows_per_sample: int, c: int, c_hid: int, c_out: int, want_bias: bool = True,
+                 mean_rstd: Optional[torch.Tensor] = None, w2: Optional[torch.Tensor] = None, gamma: Optional[torch.Tensor] = None,
+                 count: float = 0.0, defer: Optional["DeferredReduce"] = None):
+    """Backward of a full-resolution block's mixer with the hidden pre-activation rebuilt from the depthwise output t (N, rows, c)
+    (pytc_mixer_bwd_rc): -> (dW3 (c_out, c_hid), db3 (c_out) | None, dhp (N, rows, c_hid) bf16) and, when mean_rstd / w2 (fp32 (c_hid, c))
+    are given (the GroupNorm form), also (dW2 (c_hid, c), db2 (c_hid), s (N, 2, c), coef (N, 3, c)) as pw_wgrad_groupnorm returns them.
+    `defer` as in pw_wgrad: the slot sums join that object's reduction launch."""
+    _dev(t, "t"); _dev(dy, "dy"); _dev(w2_paired, "w2_paired"); _dev(w3t_paired, "w3t_paired")
+    if t.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16 or w2_paired.dtype != torch.bfloat16 or w3t_paired.dtype != torch.bfloat16:
+        raise TypeError("mixer_bwd_rc runs on bfloat16 operands and bf16 paired weight images")
+    gn = mean_rstd is not None
+    if gn and (w2 is None or count <= 0):
+        raise ValueError("mixer_bwd_rc: the GroupNorm form takes mean_rstd, w2 (fp32) and the voxel count of the statistics")
+    lib, dev = nat.lib(), t.device
+    sps = lib.pytc_mixer_bwd_rc_sps(N, rows_per_sample, c_hid)
+    S, nW3, nW2 = N * sps, c_out * c_hid, c_hid * c
+    ws = torch.empty((int(lib.pytc_mixer_bwd_rc_ws_elems(N, rows_per_sample, c_hid, int(gn))),), dtype=torch.float32, device=dev)
+    dhp = torch.empty((N, rows_per_sample, c_hid), dtype=torch.bfloat16, device=dev)
+    s = torch.empty((N, 2, c), dtype=torch.float32, device=dev) if gn else None
+    coef = torch.empty((N, 3, c), dtype=torch.float32, device=dev) if gn else None
+    used = C.c_int(0)
+    _run(f"mixer_bwd_rc[{c}->{c_hid}->{c_out}]" + ("+gn" if gn else ""), _nbytes(t, dy, dhp), lib.pytc_mixer_bwd_rc, _p(t), _p(ab),
+         _p(mean_rstd), _p(dy), _p(w2_paired), _p(b2), _p(w3t_paired), _p(w2), _p(gamma), float(count), _p(dhp), _p(ws), _p(s), _p(coef),
+         int(want_bias), int(gn), N, rows_per_sample, c, c_hid, c_out, dtype_code(t.dtype), C.byref(used), _stream(),
+         symbol="mixer_bwd_rc_kernel")
+    assert int(used.value) == S
+    dW3 = torch.empty((c_out, c_hid), dtype=torch.float32, device=dev)
+    db3 = torch.empty((c_out,), dtype=torch.float32, device=dev) if want_bias else None
+    own = defer if defer is not None else DeferredReduce()
+    own.add(ws[:S * nW3], dW3, nW3, S, keep=ws)
+    if want_bias:
+        own.add(ws[S * nW3:S * (nW3 + c_out)], db3, c_out, S)
+    out = (dW3, db3, dhp)
+    if gn:
+        term0 = S * (nW3 + c_out) + S * (nW2 + c_hid)
+        dW2 = torch.empty((c_hid, c), dtype=torch.float32, device=dev)
+        db2 = torch.empty((c_hid,), dtype=torch.float32, device=dev)
+        own.add(ws[term0:term0 + N * nW2], dW2, nW2, N)
+        own.add(ws[term0 + N * nW2:term0 + N * (nW2 + c_hid)], db2, c_hid, N)
+        out = out + (dW2, db2, s, coef)
+    if defer is None:
+        own.flush()
+    return out
 
 
 def dw_wgrad(g: torch.Tensor, x: torch.Tensor, *, K: int, stride: int = 1, want_bias: bool = True,

@@ -40,6 +40,10 @@ FUSED_WGRAD_DGRAD = os.environ.get("PYTC_FUSED_WGRAD_DGRAD", "1") != "0"
 # data gradient of a residual block, dx = conv_reversed(dt) + dy, with the "+ dy" inside the depthwise kernel (bf16, z-march
 # shapes) instead of a separate read-modify-write pass over dx
 FUSED_RESIDUAL_DGRAD = True
+# full-resolution blocks (32 -> c_hid -> 32): the forward does not store the hidden pre-activation (same arithmetic, same y bits) and the
+# backward rebuilds it from the depthwise output inside ONE pass that also yields dhp, dW3 / db3 and -- with NORM_STATS_FROM_WGRAD -- the
+# expand conv's weight gradient and the GroupNorm backward sums (csrc/train_kernels.hip mixer_bwd_rc_kernel; round 6)
+MIXER_BWD_RC = os.environ.get("PYTC_MIXER_BWD_RC", "1") != "0"
 # GroupNorm backward of a block without its two passes over (dtn, t): the statistics (sum dtn, sum dtn * xhat per sample and channel)
 # are contractions of the expand conv's PER-SAMPLE weight-gradient sums with its weights (pytc_pw_wgrad_groupnorm), and the
 # data-gradient GEMM applies dt = A*dtn + B*t + C to its own unrounded result in its epilogue (PYTC_RES_NORM_BWD); dtn is never
@@ -236,6 +240,13 @@ def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res,
     return dx, dW1, db1, dwres, dbres, dwres_m
 
 
+def _rc_level(kind, dt, C, c_hid, c_out, fused: bool) -> int:
+    """0: the block stores its hidden pre-activation; 1 / 2: it is rebuilt in the backward (2: with the GroupNorm sums in the same pass)."""
+    if not (MIXER_BWD_RC and fused and kind == "block" and dt == torch.bfloat16 and not FUSED_TRAIN_MIXER_BWD):
+        return 0
+    return ops.mixer_bwd_rc_supported(C, c_hid, c_out, dt)
+
+
 class BlockFn(torch.autograd.Function):
     """MedNeXt block / down block / up block.  `kind` in {"block", "down", "up"}.  `recompute` = the reference's
     `outside_block` activation checkpointing (mednext_models.py:386-393: torch.utils.checkpoint around every block): only the
@@ -249,9 +260,10 @@ class BlockFn(torch.autograd.Function):
         y, t, ab, mr, hp, taps, K, count = BlockFn._core(x, skip, w1, b1, gamma, beta, w2, b2, w3, b3, wres, bres, kind,
                                                          do_res, eps, None, packs)
         keep = x.new_zeros(0)
-        ctx.save_for_backward(x, keep if recompute else t, ab, mr, keep if recompute else hp, w1, gamma, w2, w3,
+        rc = hp is None                   # the hidden pre-activation was not stored: the backward rebuilds it (needs b2)
+        ctx.save_for_backward(x, keep if recompute else t, ab, mr, keep if (recompute or rc) else hp, w1, gamma, w2, w3,
                               wres if wres is not None else keep, skip if (recompute and skip is not None) else keep,
-                              b1 if (recompute and b1 is not None) else keep, b2 if recompute else keep, b3 if recompute else keep,
+                              b1 if (recompute and b1 is not None) else keep, b2 if (recompute or rc) else keep, b3 if recompute else keep,
                               bres if (recompute and bres is not None) else keep)
         ctx.meta = (kind, do_res, K, count, wres is not None, skip is not None, b1 is not None, bres is not None, recompute, eps,
                     b2 is not None, b3 is not None)
@@ -276,15 +288,16 @@ class BlockFn(torch.autograd.Function):
         c_hid, c_out = w2.shape[0], w3.shape[0]
         fused = (dt == torch.bfloat16 and b2 is not None and b3 is not None and ops.pw_mlp_supported(C, c_hid, c_out)
                  and FUSED_TRAIN_MIXER and N * rows >= FUSED_TRAIN_MIXER_MIN_ROWS)
+        rc = _rc_level(kind, dt, C, c_hid, c_out, fused)
         if fused:
             # one launch: norm affine -> expand -> (store pre-activation hp) -> GELU -> project -> residual epilogue
-            hp = torch.empty((N, rows, c_hid), dtype=dt, device=x.device)
+            hp = None if rc else torch.empty((N, rows, c_hid), dtype=dt, device=x.device)
             w2p = ops.packed_paired(_mat(w2), packs=packs)
             # bf16 image: the hidden-storing training forward measured FASTER with the bf16 sigmoid-form GELU than with the
             # packed-fp16 one (357 vs 395 us at 32->64->32: the stored pre-activation is rounded to bf16 and read back first,
             # and the extra conversions cost the kernel its 4th wave per SIMD), unlike the inference mixers
             w3p = ops.packed_paired(_mat(w3), packs=packs)
-            mk = dict(N=N, rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out, hidden_pre=hp)
+            mk = dict(N=N, rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out, hidden_pre=hp, train_nostore=bool(rc))
         else:
             hp = _pw(t, _mat(w2), _f(b2), c_out=c_hid, ab=ab, rows=rows, packs=packs)              # pre-activation (saved)
         h, G = hp, dict(pre_act=nat.ACT_GELU)       # GELU runs in the operand prologue of the projecting GEMM
@@ -349,10 +362,24 @@ class BlockFn(torch.autograd.Function):
         fused_bwd = (dy.dtype == torch.bfloat16 and FUSED_TRAIN_MIXER_BWD and ops.pw_mlp_supported(c_out, c_hid, C))
         # round 5: the projecting conv's weight gradient and the data gradient behind the activation in ONE pass over (hp, dy)
         # (pytc_pw_wgrad_dgrad_partial: level-0 shapes)
-        wg_dg = (FUSED_WGRAD_DGRAD and not fused_bwd and hp.dim() == 3 and ops.pw_wgrad_dgrad_supported(c_hid, c_out, dy.dtype)
+        rc = hp is None or hp.numel() == 0
+        wg_dg = (not rc and FUSED_WGRAD_DGRAD and not fused_bwd and hp.dim() == 3 and ops.pw_wgrad_dgrad_supported(c_hid, c_out, dy.dtype)
                  and hp.dtype == torch.bfloat16)
         dhp = None
-        if wg_dg:
+        rc_gn = None
+        if rc:
+            # full-resolution block: hp rebuilt from t inside the pass that forms dhp, dW3 / db3 (and, level 2, the GroupNorm form's sums)
+            lvl = _rc_level(kind, dy.dtype, C, c_hid, c_out, True)
+            assert lvl >= 1, "the forward dropped the hidden pre-activation of a block the backward cannot rebuild"
+            gn = (lvl >= 2 and NORM_STATS_FROM_WGRAD and not fused_bwd
+                  and ops.pw_conv_paired_supported(c_in=c_hid, c_out=C, in_dtype=dy.dtype, out_dtype=dy.dtype))
+            out = ops.mixer_bwd_rc(t.view(N, rows, C), ab, dcore.view(N, rows, c_out), ops.packed_paired(_mat(w2), packs=packs), _f(b2_s),
+                                   ops.packed_paired(_mat(w3), transposed=True, packs=packs), N=N, rows_per_sample=rows, c=C, c_hid=c_hid,
+                                   c_out=c_out, mean_rstd=mr if gn else None, w2=_mat(w2) if gn else None,
+                                   gamma=_f(gamma) if gn else None, count=count if gn else 0.0, defer=dr)
+            dW3, db3, dhp = out[:3]
+            rc_gn = out[3:] if gn else None
+        elif wg_dg:
             dW3, db3, dhp = ops.pw_wgrad_dgrad(hp, dcore.view(N, rows, c_out), ops.packed_paired(_mat(w3), transposed=True, packs=packs),
                                                N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, defer=dr)
         else:
@@ -364,7 +391,12 @@ class BlockFn(torch.autograd.Function):
         stats_from_wgrad = (NORM_STATS_FROM_WGRAD and not fused_bwd and kind != "up" and ops.pw_wgrad_groupnorm_supported(C, c_hid, dy.dtype)
                             and ops.pw_conv_paired_supported(c_in=c_hid, c_out=C, in_dtype=dy.dtype, out_dtype=dy.dtype))
         dtc = None
-        if fused_bwd:
+        if rc_gn is not None:
+            dW2, db2, s, coef = rc_gn
+            dt_ = _pw(dhp, _mat(w2), None, c_out=C, transposed=True, rows=rows, res=t.view(N, rows, C), res_mode=nat.RES_NORM_BWD,
+                      res_bias=coef, packs=packs)
+            del dhp
+        elif fused_bwd:
             # both data-gradient GEMMs in one launch: dtn = W2^T ((W3^T dy) * gelu'(hp)); dhp comes back for wgrad2
             dtn, dhp = ops.pw_mlp_bwd(dcore.view(N, rows, c_out), hp, ops.packed_paired(_mat(w3), transposed=True, packs=packs),
                                       ops.packed_paired(_mat(w2), transposed=True, packs=packs), N=N, rows_per_sample=rows,
@@ -372,7 +404,9 @@ class BlockFn(torch.autograd.Function):
         elif dhp is None:
             # dhp = (W3^T dy) * gelu'(hp): the GELU derivative is the epilogue of the data-gradient GEMM
             dhp = _pw(dcore, _mat(w3), None, c_out=c_hid, transposed=True, rows=rows, res=hp, res_mode=nat.RES_GELU_BWD, packs=packs)
-        if stats_from_wgrad:
+        if rc_gn is not None:
+            pass
+        elif stats_from_wgrad:
             dW2, db2, s, coef = ops.pw_wgrad_groupnorm(t, mr, ab, dhp, _mat(w2), _f(gamma), N=N, rows_per_sample=rows, c=C, c_hid=c_hid,
                                                        count=count, defer=dr)
             dt_ = _pw(dhp, _mat(w2), None, c_out=C, transposed=True, rows=rows, res=t.view(N, rows, C), res_mode=nat.RES_NORM_BWD,

@@ -384,9 +384,12 @@ def test_fused_training_mixer_matches_two_gemm_forward():
     # two-pass norm backward (the epilogue form of NORM_STATS_FROM_WGRAD belongs to the two-launch schedule only)
     # (round 5: with the weight-gradient + data-gradient pass of the level-0 blocks off as well -- that pass multiplies against the
     # PAIRED image of W3^T, the two-launch GEMM here against the plain one: same products, another summation order inside the MFMA)
-    stats_flag, wgdg_flag = AG.NORM_STATS_FROM_WGRAD, AG.FUSED_WGRAD_DGRAD
+    # (round 6: and with the hidden tensor STORED -- the full-resolution blocks' rebuilding backward multiplies by the derivative of the
+    # sigmoid-form GELU instead of the erf form's and has its own tests below)
+    stats_flag, wgdg_flag, rc_flag = AG.NORM_STATS_FROM_WGRAD, AG.FUSED_WGRAD_DGRAD, AG.MIXER_BWD_RC
     AG.NORM_STATS_FROM_WGRAD = False
     AG.FUSED_WGRAD_DGRAD = False
+    AG.MIXER_BWD_RC = False
     try:
         grads = []
         for fused_bwd in (False, True):
@@ -398,16 +401,19 @@ def test_fused_training_mixer_matches_two_gemm_forward():
         AG.FUSED_TRAIN_MIXER_BWD = False
         AG.NORM_STATS_FROM_WGRAD = stats_flag
         AG.FUSED_WGRAD_DGRAD = wgdg_flag
+        AG.MIXER_BWD_RC = rc_flag
     assert torch.equal(grads[0], grads[1])
     # the fused weight-gradient + data-gradient pass (default on) against the two launches: the same gradients to bf16 rounding
     both = []
     for flag in (False, True):
         AG.FUSED_WGRAD_DGRAD = flag
+        AG.MIXER_BWD_RC = False
         try:
             m.zero_grad()
             F.binary_cross_entropy_with_logits(m(x), y).backward()
         finally:
             AG.FUSED_WGRAD_DGRAD = wgdg_flag
+            AG.MIXER_BWD_RC = rc_flag
         both.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
     # (per tensor, with an absolute floor: the bias of a conv that feeds a GroupNorm has a gradient that is zero in exact arithmetic --
     # what is computed there is rounding noise of either schedule, 1e-5 per entry against 1e-1 for the weights)
@@ -933,3 +939,114 @@ def test_fused_weight_gradient_and_data_gradient_of_the_projecting_conv(N, rows,
     h = hp.float()
     ref = (dy.float() @ w3.bfloat16().float()) * (0.5 * (1 + torch.erf(h / 2 ** 0.5)) + h * torch.exp(-h * h / 2) / (2 * 3.141592653589793) ** 0.5)
     assert float((dhp1.float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,rows,c_hid,gn", [(4, 50176, 64, True), (2, 4096 + 37, 64, True), (1, 777, 64, False), (3, 2048, 32, True),
+                                             (2, 8192, 96, False)])
+def test_mixer_backward_with_the_hidden_pre_activation_rebuilt(N, rows, c_hid, gn):
+    """pytc_mixer_bwd_rc: the full-resolution mixer's backward from (t, dy) with hp = bf16(W2 bf16(a t + b) + b2) REBUILT in registers,
+    against the stored-hp schedule it replaces (pytc_pw_mlp_train_fwd -> pytc_pw_wgrad_dgrad_partial -> pytc_pw_wgrad_groupnorm):
+    the forward without the store gives the same y bits; dhp equal up to one bf16 ulp in a few outputs per million; dW3 / db3 with the
+    same bits where the two launches' slots group the same rows, to rounding elsewhere; the GroupNorm form's dW2 / db2 / sums /
+    coefficients likewise."""
+    from pytorch_connectomics_amd import _native as nat
+    from pytorch_connectomics_amd import hip_ops as ops
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(rows + c_hid)
+    C = c_out = 32
+    assert ops.mixer_bwd_rc_supported(C, c_hid, c_out, torch.bfloat16) >= (2 if gn else 1)
+    t = (torch.randn(N, rows, C, device=dev, generator=g) * 2 + 0.5).bfloat16()
+    x = torch.randn(N, rows, C, device=dev, generator=g).bfloat16()
+    dy = (torch.randn(N, rows, c_out, device=dev, generator=g) * 1e-3).bfloat16()
+    w2 = (torch.randn(c_hid, C, device=dev, generator=g) / C ** 0.5).contiguous()
+    w3 = (torch.randn(c_out, c_hid, device=dev, generator=g) / c_hid ** 0.5).contiguous()
+    b2 = torch.randn(c_hid, device=dev, generator=g) * 0.1
+    b3 = torch.randn(c_out, device=dev, generator=g) * 0.1
+    gamma = torch.rand(C, device=dev, generator=g) + 0.5
+    beta = torch.randn(C, device=dev, generator=g) * 0.1
+    mean = t.float().mean(1)                                   # (N, C)
+    rstd = 1.0 / (t.float().var(1, unbiased=False) + 1e-5).sqrt()
+    mr = torch.stack([mean, rstd], 1).contiguous()
+    a = gamma.view(1, C) * rstd
+    ab = torch.stack([a, beta.view(1, C) - mean * a], 1).contiguous()
+    w2p, w3p = ops.pw_pack_weight_paired(w2), ops.pw_pack_weight_paired(w3)
+    w3t = ops.pw_pack_weight_paired(w3, transposed=True)
+    mk = dict(N=N, rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out, res=x, res_mode=nat.RES_ADD)
+    hp = torch.empty(N, rows, c_hid, device=dev, dtype=torch.bfloat16)
+    y0 = ops.pw_mlp(t, ab, w2p, b2, w3p, b3, hidden_pre=hp, **mk)
+    y1 = ops.pw_mlp(t, ab, w2p, b2, w3p, b3, train_nostore=True, **mk)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    # the schedule it replaces
+    if ops.pw_wgrad_dgrad_supported(c_hid, c_out, torch.bfloat16):
+        dW3_0, db3_0, dhp0 = ops.pw_wgrad_dgrad(hp, dy, w3t, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out)
+    else:
+        dW3_0, db3_0 = ops.pw_wgrad(hp, dy, N=N, rows_per_sample=rows, c_in=c_hid, c_out=c_out, x_act=nat.ACT_GELU)
+        dhp0 = ops.pw_conv(dy, w3t, None, N=N, rows_per_sample=rows, c_in=c_out, c_out=c_hid, out_dtype=torch.bfloat16, res=hp,
+                           res_mode=nat.RES_GELU_BWD, w_paired=True).view(N, rows, c_hid)
+    count = float(rows)
+    if gn:
+        out = ops.mixer_bwd_rc(t, ab, dy, w2p, b2, w3t, N=N, rows_per_sample=rows, c=C, c_hid=c_hid, c_out=c_out, mean_rstd=mr, w2=w2,
+                               gamma=gamma, count=count)
+        dW3_1, db3_1, dhp1, dW2_1, db2_1, s1, coef1 = out
+    else:
+        dW3_1, db3_1, dhp1 = ops.mixer_bwd_rc(t, ab, dy, w2p, b2, w3t, N=N, rows_per_sample=rows, c=C, c_hid=c_hid, c_out=c_out)
+    torch.cuda.synchronize()
+    # dhp: the stored-hp schedule multiplies by the erf form's derivative, this kernel by the derivative of the sigmoid form the forward
+    # evaluated (<= 1.1e-4 apart, pytc_common.h gelu_fast_with_grad): bf16 neighbours at most, and close to fp32 torch (below)
+    p, q = dhp1.float(), dhp0.float()
+    neq = p != q
+    scale = float(q.abs().max())
+    assert bool(((p - q).abs() <= 2.0 ** -7 * q.abs() + 2e-4 * scale).all())         # one bf16 ulp + the derivative forms' distance
+    assert float(neq.float().mean()) < 0.2
+    hf = hp.float()
+    exact = (dy.float() @ w3.bfloat16().float()) * (0.5 * (1 + torch.erf(hf / 2 ** 0.5)) + hf * torch.exp(-hf * hf / 2) / (2 * 3.141592653589793) ** 0.5)
+    assert float((p - exact).abs().max()) <= 1.02 * float((q - exact).abs().max()) + 2e-4 * scale
+    same_slots = (N, rows) in ((4, 50176), (1, 777))          # the stored-hp launches' slots do not straddle samples there
+    if same_slots:
+        assert torch.equal(dW3_1, dW3_0) and torch.equal(db3_1, db3_0)
+    else:
+        assert float((dW3_1 - dW3_0).abs().max()) <= 2e-5 * float(dW3_0.abs().max())
+        assert float((db3_1 - db3_0).abs().max()) <= 2e-5 * float(db3_0.abs().max()) + 1e-9
+    if gn:
+        # the GroupNorm form against pytc_pw_wgrad_groupnorm fed with THIS kernel's dhp: same rows per slot, same operands -> same bits
+        dW2_0, db2_0, s0, coef0 = ops.pw_wgrad_groupnorm(t, mr, ab, dhp1, w2, gamma, N=N, rows_per_sample=rows, c=C, c_hid=c_hid, count=count)
+        torch.cuda.synchronize()
+        for u, v, name in ((dW2_1, dW2_0, "dW2"), (db2_1, db2_0, "db2"), (s1, s0, "s"), (coef1, coef0, "coef")):
+            assert torch.equal(u, v), name
+    # and against fp32 torch on the stored hidden tensor
+    h = hp.float()
+    gl = 0.5 * h * (1 + torch.erf(h / 2 ** 0.5))
+    ref = torch.einsum("nro,nrk->ok", dy.float(), gl.bfloat16().float())
+    assert float((dW3_1 - ref).abs().max()) <= 3e-3 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+def test_block_backward_with_rebuilt_hidden_tensor_gives_the_stored_schedule_gradients():
+    """MedNeXt trunk, bf16: PYTC_MIXER_BWD_RC on (full-resolution blocks drop the hidden pre-activation in the forward and rebuild it in
+    the backward) against off: same loss bits, gradients equal to the rounding of a handful of bf16 ulps in dhp."""
+    from pytorch_connectomics_amd.models.architectures.mednext import MedNeXt
+    from pytorch_connectomics_amd.training import autograd as AG
+    torch.manual_seed(5)
+    m = MedNeXt(1, 32, 1, exp_r=2, kernel_size=3, do_res=True, do_res_up_down=True, block_counts=[2] * 9).cuda().train()
+    m.compute_dtype = torch.bfloat16
+    x = torch.rand(2, 1, 48, 48, 48, device="cuda")
+    y = (torch.rand(2, 1, 48, 48, 48, device="cuda") > 0.8).float()
+    res = {}
+    flag0 = AG.MIXER_BWD_RC
+    for flag in (False, True):
+        AG.MIXER_BWD_RC = flag
+        try:
+            m.zero_grad()
+            loss = F.binary_cross_entropy_with_logits(m(x), y)
+            loss.backward()
+        finally:
+            AG.MIXER_BWD_RC = flag0
+        res[flag] = (float(loss.detach()), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert res[True][0] == res[False][0]
+    floor = 1e-3 * max(float(v.double().pow(2).mean().sqrt()) for v in res[False][1].values())
+    for k, a in res[False][1].items():
+        b = res[True][1][k]
+        a, b = a.flatten().double(), b.flatten().double()
+        assert float((a - b).norm()) <= 3e-3 * float(a.norm()) + floor * a.numel() ** 0.5, k
