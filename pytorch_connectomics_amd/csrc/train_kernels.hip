@@ -185,7 +185,10 @@ pw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
   // norm affine of the lane's 8 channels, cached per sample: a 32-row block never straddles two samples when
   // rows_per_sample % 32 == 0 (every MedNeXt level at 112^3), so the sample index is tracked per wave with a
   // compare instead of a 64-bit division per row, and (a, b) are reloaded only when it changes
-  const bool uniform_n = ab != nullptr && (sps > 0 || (rows_per_sample % 32) == 0);
+  // (... and every slot starts on a multiple of 32 rows: with rows_per_slot = 8232 and three samples of 112^3 rows the block at a sample
+  // boundary took the previous sample's affine for up to 31 rows -- found in round 6, tests/test_gpu_training.py
+  // test_pw_wgrad_mfma_affine_at_sample_boundaries)
+  const bool uniform_n = ab != nullptr && (sps > 0 || ((rows_per_sample % 32) == 0 && (rows_per_slot % 32) == 0));
   float av[8], bv[8];
   long n_cached = -1;
   auto load_ab = [&](long n) {

@@ -81,6 +81,29 @@ def test_pw_wgrad_mfma_bf16(ci, co, rows, N, use_ab):
     assert torch.equal(dW, dW3)                                                 # deterministic
 
 
+@pytest.mark.parametrize("ci,co,rows,N", [(64, 128, 6432, 3), (32, 64, 32 * 77, 5), (64, 128, 6400, 3)])
+def test_pw_wgrad_mfma_affine_at_sample_boundaries(ci, co, rows, N):
+    """Samples of a multiple of 32 rows with row slots that are NOT (6432 rows x 3: 258 rows per slot): a 32-row block of the MFMA kernel
+    can then straddle two samples and must take each row's own norm affine (round 6: it took the first row's).  Against the VALU kernel
+    (per-row sample index, same roundings) with per-sample affines that differ by an order of magnitude."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    torch.manual_seed(rows)
+    x = torch.randn(N, rows, ci).bfloat16().cuda()
+    dy = torch.randn(N, rows, co).bfloat16().cuda()
+    a = torch.tensor([1.0, -6.0, 11.0, 0.25, -3.0][:N]).view(N, 1) * (torch.rand(N, ci) + 0.5)
+    b = torch.tensor([0.0, 4.0, -9.0, 2.0, 7.0][:N]).view(N, 1) + torch.randn(N, ci)
+    ab = torch.stack([a, b], 1).contiguous().cuda()
+    dW, db = ops.pw_wgrad(x, dy, N=N, rows_per_sample=rows, c_in=ci, c_out=co, ab=ab)
+    ops.set_tuning("wgrad_valu", 1)
+    try:
+        dW2, db2 = ops.pw_wgrad(x, dy, N=N, rows_per_sample=rows, c_in=ci, c_out=co, ab=ab)
+    finally:
+        ops.set_tuning("wgrad_valu", 0)
+    scale = float(dW2.abs().max())
+    assert float((dW - dW2).abs().max()) < 2e-5 * scale
+    torch.testing.assert_close(db, db2, rtol=1e-5, atol=1e-3)
+
+
 @pytest.mark.parametrize("C,K,stride,shape", [(8, 3, 1, (6, 7, 9)), (16, 3, 2, (8, 8, 10)), (4, 5, 1, (6, 6, 7)), (32, 3, 1, (9, 17, 18)),
                                               (64, 3, 1, (30, 20, 24))])
 def test_depthwise_backward_kernels(C, K, stride, shape):
