@@ -67,7 +67,9 @@ extern "C" {
 #define PYTC_RES_UPSAMPLE 2   /* MedNeXt up block: front-pad + transposed 1x1 residual + skip     */
 #define PYTC_RES_GELU_BWD 3   /* y = f(x) * gelu'(R[row]): GELU backward fused into the data-gradient GEMM */
 #define PYTC_RES_NORM_BWD 4   /* y = A[n][o]*f(x) + B[n][o]*R[row][o] + C[n][o], (A, B, C) = res_bias [N][3][C_out]: the GroupNorm backward
-                               * apply pass fused into the data-gradient GEMM that produces its operand (w_paired kernel only) */
+                               * apply pass fused into the data-gradient GEMM that produces its operand (w_paired kernel only).
+                               * With (Di, Hi, Wi) != 0 (round 6, up blocks): the rows are the padded grid of a transposed conv's output,
+                               * y is the compact (Di - 1, Hi - 1, Wi - 1) grid -- rows on a front face are not written */
 
 int pytc_abi_version(void);
 const char* pytc_last_error(void);

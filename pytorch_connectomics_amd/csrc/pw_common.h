@@ -139,6 +139,23 @@ __device__ __forceinline__ void finish_and_store(float (&v)[NCH], const EpiParam
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
       if (o0 + i < C_out) v[i] = fmaf(cf[i], v[i], fmaf(cf[C_out + i], rv[i], cf[2 * C_out + i]));
+    if (e.Go_w > 0) {
+      // up blocks (round 6): the rows are the padded (Go_d, Go_h, Go_w) grid of a transposed conv's output, the front faces are not part
+      // of it -- dt goes to the compact (Go_d - 1, Go_h - 1, Go_w - 1) grid the transposed conv's backward reads, face rows are dropped
+      const unsigned ur = (unsigned)orow, gw = (unsigned)e.Go_w, gh = (unsigned)e.Go_h;
+      const unsigned tq = ur / gw;
+      const int px = (int)(ur - tq * gw), pz = (int)(tq / gh), py = (int)(tq - (unsigned)pz * gh);
+      if (px == 0 || py == 0 || pz == 0) return;
+      const long crow = ((long)(pz - 1) * (e.Go_h - 1) + (py - 1)) * (e.Go_w - 1) + (px - 1);
+      TO* yc = reinterpret_cast<TO*>(e.y) + ((long)n * (e.Go_d - 1) * (e.Go_h - 1) * (e.Go_w - 1) + crow) * C_out + o0;
+      if (full) VecIO<TO, NCH>::store(yc, v);
+      else {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+          if (o0 + i < C_out) yc[i] = from_f32<TO>(v[i]);
+      }
+      return;
+    }
   } else if (e.res_mode == PYTC_RES_UPSAMPLE) {
     int px, py, pz;
     if (pos) { pz = pos[0]; py = pos[1]; px = pos[2]; }

@@ -281,6 +281,12 @@ extern "C" int pytc_pw_conv_fwd(const pytc_pw_args* a, void* stream) {
     p.e.Go_d = a->Di; p.e.Go_h = a->Hi; p.e.Go_w = a->Wi;
     p.e.Gl_d = a->Di / 2; p.e.Gl_h = a->Hi / 2; p.e.Gl_w = a->Wi / 2;
   }
+  if (a->res_mode == PYTC_RES_NORM_BWD && (a->Di | a->Hi | a->Wi) != 0) {
+    // cropped form (up blocks): rows = the padded (Di, Hi, Wi) grid, y = the compact (Di - 1, Hi - 1, Wi - 1) grid (pw_common.h)
+    PYTC_REQUIRE(a->gather == 0 && a->Di >= 2 && a->Hi >= 2 && a->Wi >= 2 && (long)a->Di * a->Hi * a->Wi == a->rows_per_sample &&
+                 a->rows_per_sample < (1L << 31), "pw_conv: RES_NORM_BWD crop grid does not match the rows");
+    p.e.Go_d = a->Di; p.e.Go_h = a->Hi; p.e.Go_w = a->Wi;
+  }
   int MT = p.MTt >= 4 ? 4 : (p.MTt >= 2 ? 2 : 1);
   hipStream_t s = (hipStream_t)stream;
   const int ti = a->in_dtype, tw = a->w_dtype, to = a->out_dtype;

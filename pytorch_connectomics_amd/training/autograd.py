@@ -44,6 +44,10 @@ FUSED_RESIDUAL_DGRAD = True
 # backward rebuilds it from the depthwise output inside ONE pass that also yields dhp, dW3 / db3 and -- with NORM_STATS_FROM_WGRAD -- the
 # expand conv's weight gradient and the GroupNorm backward sums (csrc/train_kernels.hip mixer_bwd_rc_kernel; round 6)
 MIXER_BWD_RC = os.environ.get("PYTC_MIXER_BWD_RC", "1") != "0"
+# ... and the forward of those blocks with the packed-fp16 GELU + f16 projection of the inference mixers (pw_mlp_kernel<.., 3, .., STOREH> without
+# the store; the hidden pre-activation is still rounded to bf16 first): the backward's gelu_fast(hp) then differs from the forward's
+# activation by the polynomial's fit error (<= 1.1e-3, mean 1.5e-4: under the bf16 rounding of the activation)
+RC_FWD_F16_GELU = os.environ.get("PYTC_RC_FWD_F16_GELU", "0") == "1"
 # GroupNorm backward of a block without its two passes over (dtn, t): the statistics (sum dtn, sum dtn * xhat per sample and channel)
 # are contractions of the expand conv's PER-SAMPLE weight-gradient sums with its weights (pytc_pw_wgrad_groupnorm), and the
 # data-gradient GEMM applies dt = A*dtn + B*t + C to its own unrounded result in its epilogue (PYTC_RES_NORM_BWD); dtn is never
@@ -52,6 +56,7 @@ MIXER_BWD_RC = os.environ.get("PYTC_MIXER_BWD_RC", "1") != "0"
 # level-0 depthwise weight gradients moved from 4.6e-2 to 6.0e-2 relative L2 against the fp32 oracle at BASELINE width
 # (tests/test_gpu_baseline_sizes.py, gate 5e-2) -- hence the epilogue form.  False: pytc_norm_bwd.
 NORM_STATS_FROM_WGRAD = os.environ.get("PYTC_NORM_STATS_FROM_WGRAD", "1") != "0"
+UP_NORM_STATS_FROM_WGRAD = os.environ.get("PYTC_UP_NORM_STATS_FROM_WGRAD", "1") != "0"
 
 
 # every per-step weight re-layout (MFMA images, tap-major stencils) of a model is rebuilt by ONE launch: the StepPacks set of
@@ -296,7 +301,7 @@ class BlockFn(torch.autograd.Function):
             # bf16 image: the hidden-storing training forward measured FASTER with the bf16 sigmoid-form GELU than with the
             # packed-fp16 one (357 vs 395 us at 32->64->32: the stored pre-activation is rounded to bf16 and read back first,
             # and the extra conversions cost the kernel its 4th wave per SIMD), unlike the inference mixers
-            w3p = ops.packed_paired(_mat(w3), packs=packs)
+            w3p = ops.packed_paired(_mat(w3), f16=bool(rc and RC_FWD_F16_GELU), packs=packs)
             mk = dict(N=N, rows_per_sample=rows, c_in=C, c_hid=c_hid, c_out=c_out, hidden_pre=hp, train_nostore=bool(rc))
         else:
             hp = _pw(t, _mat(w2), _f(b2), c_out=c_hid, ab=ab, rows=rows, packs=packs)              # pre-activation (saved)
@@ -388,7 +393,10 @@ class BlockFn(torch.autograd.Function):
         # expand conv hp = W2 (a t + b) + b2.  NORM_STATS_FROM_WGRAD: its weight-gradient pass (against xhat, per-sample slots) also
         # yields the GroupNorm backward sums, and the data-gradient GEMM applies the norm backward to its own unrounded result in its
         # epilogue (RES_NORM_BWD): no statistics pass, no apply pass, dtn never stored.  Up blocks (cropped output) take the two-pass form.
-        stats_from_wgrad = (NORM_STATS_FROM_WGRAD and not fused_bwd and kind != "up" and ops.pw_wgrad_groupnorm_supported(C, c_hid, dy.dtype)
+        # (round 6: up blocks too -- dhp is zero on the padded front faces (dcore is), so the per-sample sums cover the transposed conv's
+        # (2D-1)^3 outputs exactly, and the epilogue writes the compact grid that conv's backward reads, dropping the face rows)
+        stats_from_wgrad = (NORM_STATS_FROM_WGRAD and not fused_bwd and (kind != "up" or UP_NORM_STATS_FROM_WGRAD)
+                            and ops.pw_wgrad_groupnorm_supported(C, c_hid, dy.dtype)
                             and ops.pw_conv_paired_supported(c_in=c_hid, c_out=C, in_dtype=dy.dtype, out_dtype=dy.dtype))
         dtc = None
         if rc_gn is not None:
@@ -409,8 +417,15 @@ class BlockFn(torch.autograd.Function):
         elif stats_from_wgrad:
             dW2, db2, s, coef = ops.pw_wgrad_groupnorm(t, mr, ab, dhp, _mat(w2), _f(gamma), N=N, rows_per_sample=rows, c=C, c_hid=c_hid,
                                                        count=count, defer=dr)
-            dt_ = _pw(dhp, _mat(w2), None, c_out=C, transposed=True, rows=rows, res=t.view(N, rows, C), res_mode=nat.RES_NORM_BWD,
-                      res_bias=coef, packs=packs)
+            if kind == "up":
+                gd, gh, gw = (int(v) for v in t.shape[1:4])
+                dtc = torch.empty((N, gd - 1, gh - 1, gw - 1, C), dtype=t.dtype, device=t.device)
+                _pw(dhp, _mat(w2), None, c_out=C, transposed=True, rows=rows, res=t.view(N, rows, C), res_mode=nat.RES_NORM_BWD,
+                    res_bias=coef, packs=packs, grid=(gd, gh, gw), y=dtc)
+                dt_ = None
+            else:
+                dt_ = _pw(dhp, _mat(w2), None, c_out=C, transposed=True, rows=rows, res=t.view(N, rows, C), res_mode=nat.RES_NORM_BWD,
+                          res_bias=coef, packs=packs)
             del dhp
         else:
             dW2, db2 = lane.run(lambda: ops.pw_wgrad(t, dhp, N=N, rows_per_sample=rows, c_in=C, c_out=c_hid, ab=ab, defer=dr), t, dhp, ab)
