@@ -547,7 +547,9 @@ int pytc_pw_wgrad_partial(const void* x, const float* ab, const void* dy, float*
  * projecting conv (dW[o][k] = sum_r dy[r][o] gelu(x[r][k]), bias partials when want_db) AND dx[r][k] = bf16((sum_o W[o][k] dy[r][o]) *
  * gelu'(x[r][k])), w_t_paired = pytc_pw_pack_weight_paired image of W^T ([C_in][C_out]).  Weight-gradient partials bit-identical to
  * pytc_pw_wgrad_partial; dx equal to pytc_pw_conv_fwd(that paired image, w_paired = 1, PYTC_RES_GELU_BWD) up to one bf16 ulp in a few outputs
- * per million (the GELU' expression is compiled into two kernels); bf16, C_out = 32, C_in in {32, 64}.  Replaces, in the
+ * per million (the GELU' expression is compiled into two kernels); bf16, C_out = 32, C_in in {32, 64}; C_in = 128 (round 6, the
+ * 64 -> 128 -> 32 up block: pw_wgrad_dgrad_wide_kernel) multiplies by the derivative of the sigmoid-form GELU the training forward
+ * evaluated instead of the erf form's (<= 1.1e-4 apart), weight-gradient partials bit-identical all the same.  Replaces, in the
  * backward of MedNeXtBlock.forward (external nnunet_mednext; contract at mednext_models.py:99-126), autograd's conv3 weight-gradient
  * and conv3 -> act data-gradient nodes. */
 int pytc_pw_wgrad_dgrad_supported(int C_in, int C_out, int dtype);

@@ -685,6 +685,171 @@ mixer_bwd_rc_kernel(MixBwd p) {
   }
 }
 
+// ---- the projecting conv's weight gradient + data gradient in one pass, WIDE hidden layer (round 6; the 64 -> 128 -> 32 up block) -----------
+// pw_wgrad_mfma_kernel<2, NT, true> keeps two LDS copies of the hidden rows per wave (gelu(x) for the weight gradient, x for GELU'): at 128
+// hidden channels 21.5 KB per wave, one workgroup per CU.  Here the lane's global loads ARE the MFMA result layout of the data gradient --
+// lane (row r, group kb) loads the 8 hidden channels pr * 32 + kb * 8 .. of its row for every tile pair pr -- so the pre-activation meets
+// (W^T dy) in registers, and only gelu(x) (weight-gradient operand) and the dy rows go through LDS (12.3 KB per wave).  One pass over
+// (x, dy) instead of pytc_pw_wgrad + pytc_pw_conv_fwd(RES_GELU_BWD): 3.2 GB instead of 5.0 GB per 4 x 112^3 step at 128 hidden channels.
+// dW / db: the rows per slot and the block order per wave of pytc_pw_wgrad_partial -> the same bits.  dx = bf16((W^T dy) * g'(x)) with g' the
+// derivative of gelu_fast (the function the training forward evaluated; gelu_fast_with_grad: <= 1.1e-4 from the erf form's).  C_out = 32.
+template <int HT>
+__global__ void __launch_bounds__(256, 2)
+pw_wgrad_dgrad_wide_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, const bf16x8_t* __restrict__ w_dg,
+                           float* __restrict__ dWp, float* __restrict__ dbp, bf16_t* __restrict__ dxo, long rows_total, long rows_per_slot) {
+  static_assert(HT % 2 == 0 && HT >= 2 && HT <= 8, "hidden tiles come in pairs");
+  constexpr int CH = HT * 16;
+  constexpr int SG = 32 * 2 + 32, SX = CH * 2 + 32;
+  constexpr int WAVE_BYTES = 32 * (SG + SX);
+  constexpr int RED = (32 * CH + 32) * 4;
+  constexpr int LDS_BYTES = 4 * WAVE_BYTES > RED ? 4 * WAVE_BYTES : RED;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+  typedef unsigned int q4_t __attribute__((ext_vector_type(4)));
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rr = lane & 15, kb = lane >> 4;
+  unsigned char* lg = lds + wave * WAVE_BYTES;
+  unsigned char* lx = lg + 32 * SG;
+  const int slot = blockIdx.x;
+  const long r_begin = (long)slot * rows_per_slot;
+  const long r_end = r_begin + rows_per_slot < rows_total ? r_begin + rows_per_slot : rows_total;
+  const bool want_db = dbp != nullptr;
+
+  bf16x8_t wf[HT];
+#pragma unroll
+  for (int t = 0; t < HT; ++t) wf[t] = w_dg[t * 64 + lane];
+  const q4_t zero4 = {0u, 0u, 0u, 0u};
+  q4_t rhA[2][HT / 2], rgA[2], rhB[2][HT / 2], rgB[2];
+  auto fetch = [&](long r0, q4_t (&rh)[2][HT / 2], q4_t (&rg)[2]) {
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const long r = r0 + t2 * 16 + rr;
+      rg[t2] = r < r_end ? *reinterpret_cast<const q4_t*>(dy + r * 32 + kb * 8) : zero4;
+#pragma unroll
+      for (int pr = 0; pr < HT / 2; ++pr)
+        rh[t2][pr] = r < r_end ? *reinterpret_cast<const q4_t*>(x + r * CH + pr * 32 + kb * 8) : zero4;
+    }
+  };
+  const int fr_row = (lane >> 4) * 4 + ((lane & 15) >> 2), fr_col = (lane & 3) * 8;
+  auto frag = [&](unsigned char* base, int pitch, int tile) -> bf16x8_t {
+    unsigned char* q = base + fr_row * pitch + tile * 32 + fr_col;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)q);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(q + 16 * pitch));
+    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, both);
+  };
+  f32x4_t acc[2][HT], accb[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    accb[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < HT; ++h) acc[m][h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  bf16x8_t ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
+
+  auto block = [&](long r0, q4_t (&rh)[2][HT / 2], q4_t (&rg)[2]) {
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const long row = r0 + t2 * 16 + rr;
+      *reinterpret_cast<q4_t*>(lg + (t2 * 16 + rr) * SG + kb * 16) = rg[t2];
+      const bf16x8_t dyb = __builtin_bit_cast(bf16x8_t, rg[t2]);
+#pragma unroll
+      for (int pr = 0; pr < HT / 2; ++pr) {
+        float hv[8], g[8], gd[8], v[8];
+        VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(&rh[t2][pr]), hv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gelu_fast_with_grad(hv[i], g[i], gd[i]);
+        *reinterpret_cast<bf16x8_t*>(lx + (t2 * 16 + rr) * SX + (pr * 32 + kb * 8) * 2) = Mma<bf16_t>::from_floats(g);
+        const f32x4_t dlo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * pr], dyb, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const f32x4_t dhi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * pr + 1], dyb, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = dlo[i] * gd[i]; v[4 + i] = dhi[i] * gd[4 + i]; }
+        if (row < r_end) *reinterpret_cast<bf16x8_t*>(dxo + row * CH + pr * 32 + kb * 8) = Mma<bf16_t>::from_floats(v);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    bf16x8_t fa[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) fa[m] = frag(lg, SG, m);
+#pragma unroll
+    for (int h = 0; h < HT; ++h) {
+      const bf16x8_t fb = frag(lx, SX, h);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], fb, acc[m][h], 0, 0, 0);
+    }
+    if (want_db) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], ones, accb[m], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  };
+  // a set's next loads are issued right after its block and land during the other set's block (the hidden rows stay in their registers
+  // through the block: no second copy)
+  long r0 = r_begin + wave * 32;
+  if (r0 < r_end) fetch(r0, rhA, rgA);
+  if (r0 + 128 < r_end) fetch(r0 + 128, rhB, rgB);
+  for (; r0 < r_end; r0 += 256) {                    // the block order per wave of pw_wgrad_mfma_kernel
+    block(r0, rhA, rgA);
+    if (r0 + 256 < r_end) fetch(r0 + 256, rhA, rgA);
+    if (r0 + 128 < r_end) {
+      block(r0 + 128, rhB, rgB);
+      if (r0 + 384 < r_end) fetch(r0 + 384, rhB, rgB);
+    }
+  }
+  float* red = reinterpret_cast<float*>(lds);
+  const int nn = lane & 15, mg = (lane >> 4) * 4;
+  for (int w = 1; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int h = 0; h < HT; ++h)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) red[(m * 16 + mg + i) * CH + h * 16 + nn] = acc[m][h][i];
+        if (nn == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) red[32 * CH + m * 16 + mg + i] = accb[m][i];
+        }
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int h = 0; h < HT; ++h)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[m][h][i] += red[(m * 16 + mg + i) * CH + h * 16 + nn];
+        if (nn == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) accb[m][i] += red[32 * CH + m * 16 + mg + i];
+        }
+      }
+    }
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int o = m * 16 + mg + i;
+#pragma unroll
+        for (int h = 0; h < HT; ++h) dWp[((long)slot * 32 + o) * CH + h * 16 + nn] = acc[m][h][i];
+        if (want_db && nn == 0) dbp[(long)slot * 32 + o] = accb[m][i];
+      }
+    }
+  }
+}
+
 // ---- thin pointwise weight gradient (C_in == 1: stem, or C_out == 1: one-channel heads; no prologue) --------------
 // dW[c] = sum_r big[r][c] * thin[r]: the column-sum lane map of colstats.h (16-byte loads of the wide operand).
 // big_is_dy: big = dY [rows][C_out], thin = X [rows][1], db[c] = sum big;  else big = X [rows][C_in], thin = dY, db[0].
@@ -1447,14 +1612,15 @@ extern "C" int pytc_pw_wgrad_partial(const void* x, const float* ab, const void*
 }
 
 extern "C" int pytc_pw_wgrad_dgrad_supported(int C_in, int C_out, int dtype) {
-  return (dtype == PYTC_BF16 && C_out == 32 && (C_in == 64 || C_in == 32) && tuning_get("wgrad_dgrad_fused", 1) != 0) ? 1 : 0;
+  return (dtype == PYTC_BF16 && C_out == 32 && (C_in == 64 || C_in == 32 || (C_in == 128 && tuning_get("wgrad_dgrad_wide", 1) != 0)) &&
+          tuning_get("wgrad_dgrad_fused", 1) != 0) ? 1 : 0;
 }
 
 extern "C" int pytc_pw_wgrad_dgrad_partial(const void* x, const void* dy, const void* w_t_paired, void* dx, float* workspace,
                                            int want_db, int N, int64_t rows_per_sample, int C_in, int C_out, int dtype,
                                            int* slots_out, void* stream) {
   PYTC_REQUIRE(x && dy && w_t_paired && dx && workspace && slots_out && N >= 1 && rows_per_sample >= 1, "pw_wgrad_dgrad: bad arguments");
-  PYTC_REQUIRE(pytc_pw_wgrad_dgrad_supported(C_in, C_out, dtype), "pw_wgrad_dgrad: bf16, C_out = 32, C_in in {32, 64} (C_in=%d C_out=%d)", C_in, C_out);
+  PYTC_REQUIRE(pytc_pw_wgrad_dgrad_supported(C_in, C_out, dtype), "pw_wgrad_dgrad: bf16, C_out = 32, C_in in {32, 64, 128} (C_in=%d C_out=%d)", C_in, C_out);
   const long rows_total = (long)N * rows_per_sample;
   int slots = wgrad_mfma_slots(rows_total, C_in, C_out, pytc_pw_wgrad_slots(rows_total));
   // one workgroup per row slot holds ALL channels here (the plain launch splits 32 x 64 into channel tiles only above 64 x 64: same grid)
@@ -1465,7 +1631,10 @@ extern "C" int pytc_pw_wgrad_dgrad_partial(const void* x, const void* dy, const 
   dim3 grid(slots, 1);
   const bf16_t* xp = (const bf16_t*)x;
   const bf16_t* dp = (const bf16_t*)dy;
-  if (C_in == 64)
+  if (C_in == 128)     // wide hidden layer (the 64 -> 128 -> 32 up block): pw_wgrad_dgrad_wide_kernel; g' = the derivative of gelu_fast
+    hipLaunchKernelGGL((pw_wgrad_dgrad_wide_kernel<8>), grid, dim3(256), 0, s, xp, dp, (const bf16x8_t*)w_t_paired, dWp, want_db ? dbp : nullptr,
+                       (bf16_t*)dx, rows_total, rps);
+  else if (C_in == 64)
     hipLaunchKernelGGL((pw_wgrad_mfma_kernel<2, 4, true>), grid, dim3(256), 0, s, xp, (const float*)nullptr, dp, dWp, want_db ? dbp : nullptr, rows_total,
                        (long)rows_per_sample, C_in, C_out, rps, PYTC_ACT_GELU, 0, 0, (const bf16x8_t*)w_t_paired, (bf16_t*)dx);
   else

@@ -930,7 +930,7 @@ def test_gradnorm_balancing_trains_through_the_hip_autograd_functions():
     assert "loss_weighter.task_weights" in ck["state_dict"]
 
 
-@pytest.mark.parametrize("N,rows,c_hid", [(2, 4096 + 37, 64), (1, 777, 64), (3, 2048, 32), (4, 50176, 64)])
+@pytest.mark.parametrize("N,rows,c_hid", [(2, 4096 + 37, 64), (1, 777, 64), (3, 2048, 32), (4, 50176, 64), (2, 6400 + 19, 128), (3, 12544, 128)])
 def test_fused_weight_gradient_and_data_gradient_of_the_projecting_conv(N, rows, c_hid):
     """pytc_pw_wgrad_dgrad_partial: one pass over (hp, dy) gives dW3 / db3 AND dhp = (W3^T dy) * gelu'(hp): dW3 / db3 with the same
     bits as pw_wgrad(x_act = GELU), dhp equal to the RES_GELU_BWD data-gradient GEMM on the PAIRED image of W3^T up to one bf16 ulp in
@@ -956,8 +956,14 @@ def test_fused_weight_gradient_and_data_gradient_of_the_projecting_conv(N, rows,
     # one bf16 ulp, at most 1e-5 of the elements (measured: 2 of 529 024, 13 of 12.8 M)
     a, b = dhp1.float(), dhp0.view(N, rows, c_hid).float()
     neq = a != b
-    assert float(neq.float().mean()) <= 1e-5
-    assert float(((a - b).abs() / b.abs().clamp_min(1e-30))[neq].max() if bool(neq.any()) else 0.0) <= 2.0 ** -7
+    if c_hid == 128:
+        # the wide-hidden-layer kernel (round 6) multiplies by the derivative of gelu_fast -- the function the training forward evaluated
+        # -- not by the erf form's (<= 1.1e-4 apart): bf16 neighbours at most
+        scale = float(b.abs().max())
+        assert bool(((a - b).abs() <= 2.0 ** -7 * b.abs() + 2e-4 * scale).all())
+    else:
+        assert float(neq.float().mean()) <= 1e-5
+        assert float(((a - b).abs() / b.abs().clamp_min(1e-30))[neq].max() if bool(neq.any()) else 0.0) <= 2.0 ** -7
     # and against fp32 torch
     h = hp.float()
     ref = (dy.float() @ w3.bfloat16().float()) * (0.5 * (1 + torch.erf(h / 2 ** 0.5)) + h * torch.exp(-h * h / 2) / (2 * 3.141592653589793) ** 0.5)
