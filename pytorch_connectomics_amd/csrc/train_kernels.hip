@@ -404,6 +404,7 @@ struct MixBwd {
   bf16_t* dhp;              // [N][rows][C_hid]
   long rows_per_sample, rows_per_slot;
   int sps, want_db3;
+  int probe;                // measurements only (wrong results): 1 = identity in the place of the activation and its derivative
 };
 
 template <int HT, bool GN>
@@ -535,6 +536,10 @@ mixer_bwd_rc_kernel(MixBwd p) {
         // g = gelu_fast(hp) with gelu_fast's bits; g' = the derivative of that function (pytc_common.h: <= 1.1e-4 from the erf form's)
 #pragma unroll
         for (int i = 0; i < 8; ++i) gelu_fast_with_grad(hv[i], g[i], gd[i]);
+        if (p.probe == 1) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { g[i] = hv[i]; gd[i] = 1.0f; }
+        }
         *reinterpret_cast<bf16x8_t*>(lx + (t2 * 16 + rr) * SX + (pr * 32 + kb * 8) * 2) = Mma<bf16_t>::from_floats(g);
         const f32x4_t dlo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[2 * pr], dyb[t2], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         const f32x4_t dhi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[2 * pr + 1], dyb[t2], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -1718,7 +1723,7 @@ extern "C" int pytc_pw_wgrad_groupnorm(const void* t, const float* mean_rstd, co
      dW3 partials [S][32][C_hid] | db3 partials [S][32] | gn: M partials [S][C_hid][32] | q partials [S][C_hid] | term [N][C_hid][32] | q [N][C_hid] */
 extern "C" int pytc_mixer_bwd_rc_supported(int C, int C_hid, int C_out, int dtype) {      // 0 no, 1 without the GroupNorm form, 2 both
   if (!(dtype == PYTC_BF16 && C == 32 && C_out == 32 && (C_hid == 64 || C_hid == 32 || C_hid == 96)) || tuning_get("mixer_bwd_rc", 1) == 0) return 0;
-  return C_hid == 96 ? 1 : 2;          // 96: the GroupNorm form's accumulators do not fit 256 registers (68 spilled)
+  return (C_hid == 96 || tuning_get("mixer_bwd_rc_gn", 1) == 0) ? 1 : 2;          // 96: the GroupNorm form's accumulators do not fit 256 registers (68 spilled)
 }
 
 extern "C" int pytc_mixer_bwd_rc_sps(int N, int64_t rows_per_sample, int C_hid) {
@@ -1760,7 +1765,7 @@ extern "C" int pytc_mixer_bwd_rc(const void* t, const float* ab, const float* me
   float* qv = term + (long)N * per;
   q.dhp = (bf16_t*)dhp;
   q.rows_per_sample = rows_per_sample; q.rows_per_slot = (rows_per_sample + sps - 1) / sps;
-  q.sps = sps; q.want_db3 = want_db3;
+  q.sps = sps; q.want_db3 = want_db3; q.probe = tuning_get("mixer_bwd_rc_probe", 0);
   hipStream_t s = (hipStream_t)stream;
   if (C_hid == 64) launch_mixer_bwd_rc<4>(q, gn, (int)S, s);
   else if (C_hid == 96) hipLaunchKernelGGL((mixer_bwd_rc_kernel<6, false>), dim3((unsigned)S), dim3(256), 0, s, q);
