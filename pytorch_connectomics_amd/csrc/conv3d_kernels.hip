@@ -302,10 +302,10 @@ bool conv_c1_stencil_try(const void* x, const void* wp, const float* bias, const
 // block, N tile = one 16-voxel x row.  Weights: packed [mtile][group][lane][8] (conv3d_pack_flat_kernel), streamed
 // from L1/L2 one group ahead of the MFMAs.
 constexpr int CT_TZ = 4, CT_TY = 8, CT_TX = 16;
-struct ConvTile { int KC, nchunks, G, tzh, tyh, txh, tiles_z, tiles_y, tiles_x; };
+struct ConvTile { int KC, nchunks, G, tzh, tyh, txh, tiles_z, tiles_y, tiles_x; int lds_total; };     // lds_total: dynamic LDS bytes of the launch
 // the eight phases of a stride-2 transposed gather in ONE launch (blockIdx.z = phase = 4a + 2b + c): per phase the tap extents are
 // (1 + a, 1 + b, 1 + c), the groups per chunk G and the element offset of its weight image differ; n = 0: an ordinary conv
-struct ConvPhases { int n; int probe; };      // probe (measurements only, wrong results): 1 = no matrix loop, 2 = no staging loads
+struct ConvPhases { int n; int probe; };      // probe (measurements only, wrong results): 1 = no matrix loop, 2 = no staging loads, 3 = no epilogue
 
 // channels per staged chunk: the whole (narrow) layer when it fits one chunk, else the widest divisor among 32 / 16 / 8
 static __host__ __device__ inline int conv_kc(int C_in) {
@@ -527,7 +527,66 @@ conv3d_tile_kernel(ConvParams p, ConvTile t, ConvPhases ps) {
 
   const int z = z0 + wave;
   const int x = x0 + r;
-  if (z >= p.D || x >= p.W) return;
+  // Round 6 (second session): narrow layers (MT <= 2: <= 32 output channels per workgroup) turn their results round in LDS.  A lane ends
+  // with 4 channels of one voxel -- 8-byte stores 2 * C_out bytes apart: at 24 -> 24 k133 on 2 x 18 x 256 x 256 (RSUNet's stock
+  // full-resolution layer) the epilogue was 93 of the launch's 183 us (probe 3 of tools/r06_conv_tile_probe.py) for 113 MB of output.
+  // Each wave writes its z plane's (bias + activation)-finished fp32 values into a wave-private [y][x][channel] image (row pitch
+  // CW + 4 floats: the 16 x positions of a float4 column fall on 16 distinct bank groups) over the input tile, which every wave is done
+  // with, and reads whole voxel rows back: a lane takes 8 consecutive channels, adds the residual's 16 bytes, rounds ONCE and stores 16
+  // bytes -- an x row of the tile is one contiguous 32 * C_out-byte run in HBM.  Same values, same single rounding as finish_and_store.
+  if constexpr (MT <= 2) {
+    const int CW = MT * 16;                                   // channels of this workgroup's tiles
+    const int c_base = mt0 * 16;
+    const int cw_live = p.C_out - c_base < CW ? p.C_out - c_base : CW;      // multiple of 8 (C_out is)
+    if (!p.om && (p.e.res_mode == PYTC_RES_NONE || p.e.res_mode == PYTC_RES_ADD) && (p.C_out % 8) == 0 && ps.probe != 3 &&
+        4 * NT * 16 * (CW + 4) * 4 <= t.lds_total) {
+      __syncthreads();                                        // the input tile is dead: every wave has left the matrix loop
+      float* img = reinterpret_cast<float*>(lds) + wave * (NT * 16 * (CW + 4));
+      const int zq = z0 + wave;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int o0 = (mt0 + mt) * 16 + kb * 4;
+        float bo[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) bo[rr] = (p.bias && o0 + rr < p.C_out) ? p.bias[o0 + rr] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          f32x4_t v;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) v[rr] = apply_act(acc[mt][nt][rr] + bo[rr], p.act_out);
+          *reinterpret_cast<f32x4_t*>(img + (nt * 16 + r) * (CW + 4) + mt * 16 + kb * 4) = v;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (zq >= p.D) return;
+      const int cpv = cw_live / 8;                            // 16-byte output chunks per voxel
+      const int nchunk = 16 * cpv;                            // ... per x row of the tile
+      bf16_t* yn = reinterpret_cast<bf16_t*>(p.e.y) + (long)n * rps * p.C_out;
+      const bf16_t* resn = p.e.res_mode == PYTC_RES_ADD ? reinterpret_cast<const bf16_t*>(p.e.res) + (long)n * rps * p.C_out : nullptr;
+      for (int q = lane; q < nchunk; q += 64) {
+        const int xq = q / cpv, cq = (q - xq * cpv) * 8;
+        if (x0 + xq >= p.W) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if (y0 + nt >= p.H) break;
+          const float* src = img + (nt * 16 + xq) * (CW + 4) + cq;
+          const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(src), hi = *reinterpret_cast<const f32x4_t*>(src + 4);
+          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const long off = ((((long)zq * p.H + (y0 + nt)) * p.W + (x0 + xq)) * p.C_out) + c_base + cq;
+          if (resn) {
+            float rv[8];
+            VecIO<bf16_t, 8>::load(resn + off, rv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += rv[i];
+          }
+          VecIO<bf16_t, 8>::store(yn + off, v);
+        }
+      }
+      return;
+    }
+  }
+  if (z >= p.D || x >= p.W || ps.probe == 3) return;      // (probe 3: no epilogue)
   // output row of (z, y0 + nt, x): one 64-bit base and a 32-bit step (the 2x output map of a phase launch steps two output rows)
   const long row0 = p.om ? ((long)(2 * z + oz) * p.Ho + (2 * y0 + oy)) * p.Wo + (2 * x + ox) : ((long)z * p.H + y0) * p.W + x;
   const int row_step = p.om ? 2 * p.Wo : p.W;
@@ -574,6 +633,7 @@ conv3d_pack_flat_kernel(const float* __restrict__ w, int C_out, int C_in, int nt
 static bool conv_tile_plan(int dtype, int C_in, int kd, int kh, int kw, ConvTile& t, size_t& lds_bytes) {
   if (dtype != PYTC_BF16 || C_in % 8 != 0) return false;
   t.KC = conv_kc(C_in);
+  t.lds_total = 0;
   t.nchunks = C_in / t.KC;
   t.G = (kd * kh * kw * t.KC + 31) / 32;
   t.tzh = CT_TZ + kd - 1; t.tyh = CT_TY + kh - 1; t.txh = CT_TX + kw - 1;
@@ -679,7 +739,17 @@ template <int MT>
 static void launch_conv_tile_mt(const ConvParams& p, const ConvTile& t, size_t lds_bytes, dim3 grid, hipStream_t s) {
   // dynamic LDS above 64 KB needs the opt-in, once per kernel and device
   if (!ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3d_tile_kernel<MT>), 80 * 1024, "conv3d_tile")) return;
-  hipLaunchKernelGGL((conv3d_tile_kernel<MT>), grid, dim3(256), lds_bytes, s, p, t, ConvPhases{0, tuning_get("conv_tile_probe", 0)});
+  ConvTile tt = t;
+  // narrow layers turn their results round in LDS (the kernel's epilogue): room for the waves' fp32 [8][16][MT * 16 + 4] images
+  size_t total = lds_bytes;
+  if (MT <= 2 && tuning_get("conv_tile_lds_epilogue", 1)) {
+    const size_t need = (size_t)4 * CT_TY * 16 * (MT * 16 + 4) * 4;
+    if (need <= 80 * 1024 && need > total) total = need;
+  } else if (MT <= 2) {
+    total = lds_bytes; tt.lds_total = 0;
+  }
+  tt.lds_total = (MT <= 2 && tuning_get("conv_tile_lds_epilogue", 1)) ? (int)total : 0;
+  hipLaunchKernelGGL((conv3d_tile_kernel<MT>), grid, dim3(256), total, s, p, tt, ConvPhases{0, tuning_get("conv_tile_probe", 0)});
 }
 
 template <int MT>
