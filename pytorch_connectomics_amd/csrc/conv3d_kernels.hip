@@ -527,60 +527,68 @@ conv3d_tile_kernel(ConvParams p, ConvTile t, ConvPhases ps) {
 
   const int z = z0 + wave;
   const int x = x0 + r;
-  // Round 6 (second session): narrow layers (MT <= 2: <= 32 output channels per workgroup) turn their results round in LDS.  A lane ends
+  // Round 6 (second session): the results turn round in LDS before they are stored.  A lane ends
   // with 4 channels of one voxel -- 8-byte stores 2 * C_out bytes apart: at 24 -> 24 k133 on 2 x 18 x 256 x 256 (RSUNet's stock
   // full-resolution layer) the epilogue was 93 of the launch's 183 us (probe 3 of tools/r06_conv_tile_probe.py) for 113 MB of output.
   // Each wave writes its z plane's (bias + activation)-finished fp32 values into a wave-private [y][x][channel] image (row pitch
   // CW + 4 floats: the 16 x positions of a float4 column fall on 16 distinct bank groups) over the input tile, which every wave is done
   // with, and reads whole voxel rows back: a lane takes 8 consecutive channels, adds the residual's 16 bytes, rounds ONCE and stores 16
   // bytes -- an x row of the tile is one contiguous 32 * C_out-byte run in HBM.  Same values, same single rounding as finish_and_store.
-  if constexpr (MT <= 2) {
-    const int CW = MT * 16;                                   // channels of this workgroup's tiles
-    const int c_base = mt0 * 16;
-    const int cw_live = p.C_out - c_base < CW ? p.C_out - c_base : CW;      // multiple of 8 (C_out is)
+  {
+    // (MT = 4: two passes of two channel tiles each through the same image -- 64-byte runs per voxel instead of four 8-byte pieces)
+    constexpr int TP = MT >= 2 ? 2 : 1;                       // channel tiles per pass
+    constexpr int CW = TP * 16;
     if (!p.om && (p.e.res_mode == PYTC_RES_NONE || p.e.res_mode == PYTC_RES_ADD) && (p.C_out % 8) == 0 && ps.probe != 3 &&
         4 * NT * 16 * (CW + 4) * 4 <= t.lds_total) {
       __syncthreads();                                        // the input tile is dead: every wave has left the matrix loop
       float* img = reinterpret_cast<float*>(lds) + wave * (NT * 16 * (CW + 4));
       const int zq = z0 + wave;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int o0 = (mt0 + mt) * 16 + kb * 4;
-        float bo[4];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) bo[rr] = (p.bias && o0 + rr < p.C_out) ? p.bias[o0 + rr] : 0.f;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          f32x4_t v;
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) v[rr] = apply_act(acc[mt][nt][rr] + bo[rr], p.act_out);
-          *reinterpret_cast<f32x4_t*>(img + (nt * 16 + r) * (CW + 4) + mt * 16 + kb * 4) = v;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (zq >= p.D) return;
-      const int cpv = cw_live / 8;                            // 16-byte output chunks per voxel
-      const int nchunk = 16 * cpv;                            // ... per x row of the tile
       bf16_t* yn = reinterpret_cast<bf16_t*>(p.e.y) + (long)n * rps * p.C_out;
       const bf16_t* resn = p.e.res_mode == PYTC_RES_ADD ? reinterpret_cast<const bf16_t*>(p.e.res) + (long)n * rps * p.C_out : nullptr;
-      for (int q = lane; q < nchunk; q += 64) {
-        const int xq = q / cpv, cq = (q - xq * cpv) * 8;
-        if (x0 + xq >= p.W) continue;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          if (y0 + nt >= p.H) break;
-          const float* src = img + (nt * 16 + xq) * (CW + 4) + cq;
-          const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(src), hi = *reinterpret_cast<const f32x4_t*>(src + 4);
-          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          const long off = ((((long)zq * p.H + (y0 + nt)) * p.W + (x0 + xq)) * p.C_out) + c_base + cq;
-          if (resn) {
-            float rv[8];
-            VecIO<bf16_t, 8>::load(resn + off, rv);
+      for (int ps_ = 0; ps_ < MT / TP; ++ps_) {
+        const int c_base = (mt0 + ps_ * TP) * 16;
+        if (c_base >= p.C_out) break;                         // (workgroup-uniform)
+        const int cw_live = p.C_out - c_base < CW ? p.C_out - c_base : CW;      // multiple of 8 (C_out is)
+        if (ps_ > 0) { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] += rv[i];
+        for (int tt = 0; tt < TP; ++tt) {
+          const int mt = ps_ * TP + tt;
+          const int o0 = (mt0 + mt) * 16 + kb * 4;
+          float bo[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) bo[rr] = (p.bias && o0 + rr < p.C_out) ? p.bias[o0 + rr] : 0.f;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            f32x4_t v;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) v[rr] = apply_act(acc[mt][nt][rr] + bo[rr], p.act_out);
+            *reinterpret_cast<f32x4_t*>(img + (nt * 16 + r) * (CW + 4) + tt * 16 + kb * 4) = v;
           }
-          VecIO<bf16_t, 8>::store(yn + off, v);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (zq >= p.D) continue;
+        const int cpv = cw_live / 8;                          // 16-byte output chunks per voxel
+        const int nchunk = 16 * cpv;                          // ... per x row of the tile
+        for (int q = lane; q < nchunk; q += 64) {
+          const int xq = q / cpv, cq = (q - xq * cpv) * 8;
+          if (x0 + xq >= p.W) continue;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            if (y0 + nt >= p.H) break;
+            const float* src = img + (nt * 16 + xq) * (CW + 4) + cq;
+            const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(src), hi = *reinterpret_cast<const f32x4_t*>(src + 4);
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const long off = ((((long)zq * p.H + (y0 + nt)) * p.W + (x0 + xq)) * p.C_out) + c_base + cq;
+            if (resn) {
+              float rv[8];
+              VecIO<bf16_t, 8>::load(resn + off, rv);
+#pragma unroll
+              for (int i = 0; i < 8; ++i) v[i] += rv[i];
+            }
+            VecIO<bf16_t, 8>::store(yn + off, v);
+          }
         }
       }
       return;
@@ -742,13 +750,13 @@ static void launch_conv_tile_mt(const ConvParams& p, const ConvTile& t, size_t l
   ConvTile tt = t;
   // narrow layers turn their results round in LDS (the kernel's epilogue): room for the waves' fp32 [8][16][MT * 16 + 4] images
   size_t total = lds_bytes;
-  if (MT <= 2 && tuning_get("conv_tile_lds_epilogue", 1)) {
-    const size_t need = (size_t)4 * CT_TY * 16 * (MT * 16 + 4) * 4;
+  const int knob = tuning_get("conv_tile_lds_epilogue", 3);      // bit 0: MT <= 2, bit 1: MT = 4 (two passes)
+  const bool on = MT <= 2 ? (knob & 1) != 0 : (knob & 2) != 0;
+  if (on) {
+    const size_t need = (size_t)4 * CT_TY * 16 * ((MT >= 2 ? 32 : 16) + 4) * 4;
     if (need <= 80 * 1024 && need > total) total = need;
-  } else if (MT <= 2) {
-    total = lds_bytes; tt.lds_total = 0;
   }
-  tt.lds_total = (MT <= 2 && tuning_get("conv_tile_lds_epilogue", 1)) ? (int)total : 0;
+  tt.lds_total = on ? (int)total : 0;
   hipLaunchKernelGGL((conv3d_tile_kernel<MT>), grid, dim3(256), total, s, p, tt, ConvPhases{0, tuning_get("conv_tile_probe", 0)});
 }
 
