@@ -1027,6 +1027,7 @@ reduce_slots_batched_kernel(const float* __restrict__ part, float* __restrict__ 
 struct DwWg {
   int N, Dg, Hg, Wg, Dx, Hx, Wx, C, K, stride, pad;
   int lpv, vs, iters, slots;
+  int kz_inner = 0;       // dw_wgrad_vec_kernel: kz as the fastest index of an XCD-aware 1-D grid
 };
 
 template <typename T, int VEC, int K>
@@ -1108,7 +1109,17 @@ dw_wgrad_vec_kernel(const T* __restrict__ g, const T* __restrict__ x, float* __r
                     DwWg q, long rows_per_slot) {
   constexpr int EPV = 16 / (int)sizeof(T), K = 3;
   __shared__ float lds[5 * 256 * EPV];             // [value][position lane][C], five parameter rows per round
-  const int slot = blockIdx.x, n = blockIdx.y, kz = blockIdx.z;
+  // Round 6: the three kz workgroups of a (slot, sample) read the same G rows and (stride 2) share the odd X planes.  As gridDim.z they
+  // were dispatched a whole grid apart; as the fastest index of an XCD-aware 1-D order they run back to back on ONE XCD and the second and
+  // third find those lines in its L2 (q.kz_inner; the sums do not depend on the order).
+  int slot = blockIdx.x, n = blockIdx.y, kz = blockIdx.z;
+  if (q.kz_inner) {
+    const int lb = xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+    kz = lb % 3;
+    const int sn = lb / 3;
+    slot = sn % q.slots;
+    n = sn / q.slots;
+  }
   const int C = q.C, Cw = C / EPV, PL = 256 / Cw;
   const int ck = threadIdx.x % Cw, pl = threadIdx.x / Cw;
   const long vg = (long)q.Dg * q.Hg * q.Wg;
@@ -1896,7 +1907,9 @@ static int dw_wgrad_impl(const void* g, const void* x, float* dW, float* db, flo
     float* dWv = workspace;
     float* dbv = workspace + (long)total * nWv;
     hipStream_t sv = (hipStream_t)stream;
+    q.kz_inner = tuning_get("dw_wgrad_vec_kz_inner", 1);
     dim3 grid(q.slots, N, 3), block(256);
+    if (q.kz_inner) grid = dim3((unsigned)(q.slots * N * 3), 1, 1);
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(dw_wgrad_vec_kernel<bf16_t>, grid, block, 0, sv, (const bf16_t*)g, (const bf16_t*)x, dWv, db ? dbv : nullptr, q, rps),
                hipLaunchKernelGGL(dw_wgrad_vec_kernel<float>, grid, block, 0, sv, (const float*)g, (const float*)x, dWv, db ? dbv : nullptr, q, rps),
