@@ -1739,7 +1739,10 @@ extern "C" int pytc_mixer_bwd_rc_supported(int C, int C_hid, int C_out, int dtyp
 
 extern "C" int pytc_mixer_bwd_rc_sps(int N, int64_t rows_per_sample, int C_hid) {
   const long rows_total = (long)N * rows_per_sample;
-  const int slots = wgrad_mfma_slots(rows_total, C_hid, 32, pytc_pw_wgrad_slots(rows_total));
+  int slots = wgrad_mfma_slots(rows_total, C_hid, 32, pytc_pw_wgrad_slots(rows_total));
+  // knob (measurement): fewer, longer slots -- halves the partials the block's reduction launch reads
+  const int div = tuning_get("mixer_bwd_rc_slot_div", 1);
+  if (div > 1 && slots / div >= 512) slots /= div;
   const int sps = slots / N;
   return sps < 1 ? 1 : sps;
 }
