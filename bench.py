@@ -471,7 +471,10 @@ def c4_chunked_leg(dev):
         return shapes
 
     with torch.no_grad():
-        fwd_cl(torch.rand(1, *roi, 1, device=dev))                              # warm-up: weight images, allocator pools
+        fwd_cl(torch.rand(1, *roi, 1, device=dev))                              # warm-up: weight images
+        one_chunk(chunks[0])                                                    # warm-up: the allocator pools of the window streams
+        windows.clear()
+        kept.clear()
         s, outs = timed(run_chunks)
     n_win = sum(windows)
     # the chunk FILE of the last chunk, as the chunked runner writes it (chunked.py: write_prediction_artifact, gzip, HDF5 chunks

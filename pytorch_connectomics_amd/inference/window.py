@@ -357,6 +357,18 @@ def _extract_padded_patch_batch(tensor: torch.Tensor, patch_slices, *, roi_size,
 _PIPELINE_STREAMS: dict = {}
 
 
+def pipeline_streams_for(dev, n: int):
+    """The process-wide set of `n` side streams of `dev` the window pipelines (eager engine, lazy region engine) share: the caching
+    allocator keeps a memory pool per stream, and an engine object that made its own streams would fault in ~10 GB of fresh
+    activations on its first pass."""
+    key = (str(dev), int(n))
+    hit = _PIPELINE_STREAMS.get(key)
+    if hit is None:
+        hit = [torch.cuda.Stream(device=dev) for _ in range(int(n))]
+        _PIPELINE_STREAMS[key] = hit
+    return hit
+
+
 class EagerSlidingWindowEngine:
     """``engine(inputs=(1,C,*spatial), network=fn) -> (1,C_out,*spatial)`` with everything in HBM.
 
@@ -540,14 +552,7 @@ class EagerSlidingWindowEngine:
             cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
             if free + cached < (n - 1) * self._probe_bytes * self.sw_batch_size:
                 return []
-        # one set of side streams per device for the whole process: the caching allocator keeps a memory pool per stream, and an
-        # engine object that made its own streams would fault in ~10 GB of fresh activations on its first pass
-        key = (str(dev), n)
-        hit = _PIPELINE_STREAMS.get(key)
-        if hit is None:
-            hit = [torch.cuda.Stream(device=dev) for _ in range(n)]
-            _PIPELINE_STREAMS[key] = hit
-        return hit
+        return pipeline_streams_for(dev, n)
 
     def shifted_weight(self, orig_size, shift, device) -> torch.Tensor:
         """Weight accumulator of the window grid restricted, per window, to the box a window displaced by `shift`
