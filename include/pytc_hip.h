@@ -583,6 +583,8 @@ typedef struct {
   float* out;          /* [n] */
   int64_t n;
   int32_t slots;
+  int32_t out_t;       /* 0: out[i]; > 0: the n sums are a [n / out_t][out_t] matrix and `out` receives its transpose (a depthwise
+                          weight gradient leaves tap-major [K^3][C] and the parameter is [C][K^3]); fills the struct's former padding */
 } pytc_reduce_item;
 int pytc_reduce_slots_multi(const pytc_reduce_item* items, int n_items, void* stream);
 /* GroupNorm(C,C) backward: dt = rstd*gamma*(dtn - mean_v(dtn) - xhat*mean_v(dtn*xhat)); s_out [N][2][C] holds

@@ -54,7 +54,7 @@ RAW_DTYPES = {"uint8": 0, "int8": 1, "uint16": 2, "int16": 3, "uint32": 4, "int3
 
 
 class ReduceItem(C.Structure):
-    _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("n", C.c_int64), ("slots", C.c_int32)]
+    _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("n", C.c_int64), ("slots", C.c_int32), ("out_t", C.c_int32)]
 
 
 class Conv3dArgs(C.Structure):

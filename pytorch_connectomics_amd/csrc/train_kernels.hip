@@ -974,6 +974,7 @@ struct ReduceMulti {
   float* out[REDUCE_MULTI_MAX];
   long n[REDUCE_MULTI_MAX];
   int slots[REDUCE_MULTI_MAX];
+  int out_t[REDUCE_MULTI_MAX];       // > 0: the n sums are a [n / out_t][out_t] matrix, written transposed ([out_t][n / out_t])
   int blk_end[REDUCE_MULTI_MAX];     // exclusive prefix end of each item's block range
   int count;
 };
@@ -997,7 +998,8 @@ reduce_slots_multi_kernel(ReduceMulti m) {
     float t = sm[0][e];
 #pragma unroll
     for (int q = 1; q < 16; ++q) t += sm[q][e];
-    m.out[k][i] = t;
+    const int ot = m.out_t[k];
+    m.out[k][ot > 0 ? (i % ot) * (n / ot) + i / ot : i] = t;
   }
 }
 
@@ -1346,8 +1348,20 @@ norm_bwd_from_wgrad_kernel(float* __restrict__ M, const float* __restrict__ dbp,
     {
       const int hh = threadIdx.x & 63, part = threadIdx.x >> 6;
       float a = 0.f;
-      if (h0 + hh < H)
-        for (int j = part; j < sps; j += 4) a += dbp[((long)n * sps + j) * H + h0 + hh];
+      if (h0 + hh < H) {
+        // same order of additions as the plain loop, eight loads in flight (a level-0 sample has 256 slots: 64 dependent round trips
+        // were 20 of this launch's 29 us)
+        const float* __restrict__ src = dbp + (long)n * sps * H + h0 + hh;
+        int j = part;
+        for (; j + 28 < sps; j += 32) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = src[(long)(j + 4 * u) * H];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; j < sps; j += 4) a += src[(long)j * H];
+      }
       sm_q[part][hh] = a;
     }
     __syncthreads();
@@ -1667,7 +1681,9 @@ extern "C" int pytc_reduce_slots_multi(const pytc_reduce_item* items, int n_item
   int blocks = 0;
   for (int k = 0; k < n_items; ++k) {
     PYTC_REQUIRE(items[k].part && items[k].out && items[k].n >= 1 && items[k].slots >= 1, "reduce_slots_multi: bad item %d", k);
+    PYTC_REQUIRE(items[k].out_t >= 0 && (items[k].out_t == 0 || items[k].n % items[k].out_t == 0), "reduce_slots_multi: item %d: out_t must divide n", k);
     m.part[k] = items[k].part; m.out[k] = items[k].out; m.n[k] = (long)items[k].n; m.slots[k] = items[k].slots;
+    m.out_t[k] = items[k].out_t;
     blocks += (int)((items[k].n + 15) / 16);
     m.blk_end[k] = blocks;
   }

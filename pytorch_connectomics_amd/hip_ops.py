@@ -1493,11 +1493,12 @@ class DeferredReduce:
     MAX_ITEMS = 12
 
     def __init__(self):
-        self.items = []       # (partials view, out, n, slots)
+        self.items = []       # (partials view, out, n, slots, out_t)
         self.keep = []        # workspaces the partial views live in
 
-    def add(self, part: torch.Tensor, out: torch.Tensor, n: int, slots: int, keep=None) -> None:
-        self.items.append((part, out, int(n), int(slots)))
+    def add(self, part: torch.Tensor, out: torch.Tensor, n: int, slots: int, keep=None, out_t: int = 0) -> None:
+        """out_t > 0: the n sums form a [n / out_t][out_t] matrix and `out` receives its transpose."""
+        self.items.append((part, out, int(n), int(slots), int(out_t)))
         if keep is not None:
             self.keep.append(keep)
 
@@ -1505,42 +1506,43 @@ class DeferredReduce:
         # partials / outputs may have been allocated on another stream (training/autograd.py _WgradLane): this launch, and
         # whoever reads the outputs afterwards, use them on the current stream
         cur = torch.cuda.current_stream()
-        for part, out, _n, _s in self.items:
+        for part, out, _n, _s, _t in self.items:
             part.record_stream(cur)
             out.record_stream(cur)
         for b0 in range(0, len(self.items), self.MAX_ITEMS):
             chunk = self.items[b0:b0 + self.MAX_ITEMS]
             arr = (nat.ReduceItem * len(chunk))()
-            for i, (part, out, n, slots) in enumerate(chunk):
-                arr[i].part, arr[i].out, arr[i].n, arr[i].slots = part.data_ptr(), out.data_ptr(), n, slots
-            _run("reduce_slots_multi", sum(4 * n * (s + 1) for _p0, _o, n, s in chunk), nat.lib().pytc_reduce_slots_multi, arr,
+            for i, (part, out, n, slots, out_t) in enumerate(chunk):
+                arr[i].part, arr[i].out, arr[i].n, arr[i].slots, arr[i].out_t = part.data_ptr(), out.data_ptr(), n, slots, out_t
+            _run("reduce_slots_multi", sum(4 * n * (s + 1) for _p0, _o, n, s, _t in chunk), nat.lib().pytc_reduce_slots_multi, arr,
                  len(chunk), _stream())
         self.items, self.keep = [], []
 
 
 def pw_wgrad(x: torch.Tensor, dy: torch.Tensor, *, N: int, rows_per_sample: int, c_in: int, c_out: int,
              ab: Optional[torch.Tensor] = None, want_bias: bool = True, x_act: int = nat.ACT_NONE,
-             defer: Optional[DeferredReduce] = None):
+             defer: Optional[DeferredReduce] = None, in_major: bool = False):
     """-> dW (c_out, c_in) fp32, db (c_out) fp32 | None;  x_act=ACT_GELU: the GEMM operand is gelu(x).  With `defer` the
-    slot reduction joins that object's single launch: dW / db hold their values only after defer.flush()."""
+    slot reduction joins that object's single launch: dW / db hold their values only after defer.flush().
+    in_major: dW arrives as (c_in, c_out) -- a ConvTranspose weight's layout (with `defer` the reduction launch writes it transposed)."""
     _dev(x, "x"); _dev(dy, "dy")
     slots = nat.lib().pytc_pw_wgrad_slots(N * rows_per_sample)
     nW = c_out * c_in
     ws = torch.empty((slots * (nW + c_out),), dtype=torch.float32, device=x.device)
-    dW = torch.empty((c_out, c_in), dtype=torch.float32, device=x.device)
+    dW = torch.empty((c_in, c_out) if (in_major and defer is not None) else (c_out, c_in), dtype=torch.float32, device=x.device)
     db = torch.empty((c_out,), dtype=torch.float32, device=x.device) if want_bias else None
     if defer is not None:
         used = C.c_int(0)
         _run(f"pw_wgrad[{c_in}->{c_out}]", _nbytes(x, dy), nat.lib().pytc_pw_wgrad_partial, _p(x), _p(ab), _p(dy), _p(ws),
              int(want_bias), N, rows_per_sample, c_in, c_out, dtype_code(x.dtype), int(x_act), C.byref(used), _stream())
         u = int(used.value)
-        defer.add(ws[:u * nW], dW, nW, u, keep=ws)
+        defer.add(ws[:u * nW], dW, nW, u, keep=ws, out_t=c_in if in_major else 0)
         if want_bias:
             defer.add(ws[u * nW:u * (nW + c_out)], db, c_out, u)
         return dW, db
     _run(f"pw_wgrad[{c_in}->{c_out}]", _nbytes(x, dy), nat.lib().pytc_pw_wgrad, _p(x), _p(ab), _p(dy), _p(dW), _p(db),
          _p(ws), N, rows_per_sample, c_in, c_out, dtype_code(x.dtype), int(x_act), _stream())
-    return dW, db
+    return (dW.t().contiguous() if in_major else dW), db
 
 
 def pw_wgrad_dgrad_supported(c_in: int, c_out: int, dtype: torch.dtype) -> bool:
@@ -1635,8 +1637,9 @@ def mixer_bwd_rc(t: torch.Tensor, ab: torch.Tensor, dy: torch.Tensor, w2_paired:
 
 
 def dw_wgrad(g: torch.Tensor, x: torch.Tensor, *, K: int, stride: int = 1, want_bias: bool = True,
-             defer: Optional[DeferredReduce] = None):
-    """g (N,*gdims,C), x (N,*xdims,C) -> dW (K^3, C) fp32, db (C) | None   (see pytc_dw_wgrad); `defer` as in pw_wgrad"""
+             defer: Optional[DeferredReduce] = None, channel_major: bool = False):
+    """g (N,*gdims,C), x (N,*xdims,C) -> dW (K^3, C) fp32, db (C) | None   (see pytc_dw_wgrad); `defer` as in pw_wgrad;
+    channel_major: dW arrives as (C, K^3), the parameter's own layout (with `defer` the reduction launch writes it transposed)"""
     _dev(g, "g"); _dev(x, "x")
     N, Cc = g.shape[0], g.shape[-1]
     gd, xd = _i3(g.shape[1:4]), _i3(x.shape[1:4])
@@ -1645,20 +1648,20 @@ def dw_wgrad(g: torch.Tensor, x: torch.Tensor, *, K: int, stride: int = 1, want_
         raise RuntimeError(f"dw_wgrad: unsupported channel count {Cc}")
     nW = K ** 3 * Cc
     ws = torch.empty((slots * (nW + Cc),), dtype=torch.float32, device=g.device)
-    dW = torch.empty((K ** 3, Cc), dtype=torch.float32, device=g.device)
+    dW = torch.empty((Cc, K ** 3) if (channel_major and defer is not None) else (K ** 3, Cc), dtype=torch.float32, device=g.device)
     db = torch.empty((Cc,), dtype=torch.float32, device=g.device) if want_bias else None
     if defer is not None:
         used = C.c_int(0)
         _run(f"dw_wgrad[C{Cc}_k{K}]", _nbytes(g, x), nat.lib().pytc_dw_wgrad_partial, _p(g), _p(x), _p(ws), int(want_bias), N,
              gd, xd, Cc, K, stride, dtype_code(g.dtype), C.byref(used), _stream())
         u = int(used.value)
-        defer.add(ws[:u * nW], dW, nW, u, keep=ws)
+        defer.add(ws[:u * nW], dW, nW, u, keep=ws, out_t=Cc if channel_major else 0)
         if want_bias:
             defer.add(ws[u * nW:u * (nW + Cc)], db, Cc, u)
         return dW, db
     _run(f"dw_wgrad[C{Cc}_k{K}]", _nbytes(g, x), nat.lib().pytc_dw_wgrad, _p(g), _p(x), _p(dW), _p(db), _p(ws), N, gd, xd,
          Cc, K, stride, dtype_code(g.dtype), _stream())
-    return dW, db
+    return (dW.t().contiguous() if channel_major else dW), db
 
 
 def norm_bwd(dtn: torch.Tensor, t: torch.Tensor, mean_rstd: torch.Tensor, gamma: Optional[torch.Tensor],

@@ -200,7 +200,7 @@ class PointwiseFn(torch.autograd.Function):
 
 def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res, dr, lane=None, dtc=None, norm_is_per_channel=False):
     """Depthwise-conv half of a block backward, shared by BlockFn and NormVariantBlockFn: from dt (gradient of the depthwise
-    output) to dx, dW1 (tap-major), db1 and the gradients of the resampling residual conv.  Slot reductions join `dr`."""
+    output) to dx, dW1 (channel-major (C, K^3): the reduction launch writes the parameter's layout), db1 and the gradients of the resampling residual conv.  Slot reductions join `dr`."""
     N, D, H, W, C = x.shape
     rows = _rows(t)
     c_out = dy.shape[-1]
@@ -208,7 +208,7 @@ def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res,
     dwres = dbres = None
     lane = lane or _WgradLane(torch.device("cpu"))
     if kind == "block":
-        dW1, db1 = lane.run(lambda: ops.dw_wgrad(dt_.view_as(t), x, K=K, stride=1, defer=dr), dt_, x)
+        dW1, db1 = lane.run(lambda: ops.dw_wgrad(dt_.view_as(t), x, K=K, stride=1, defer=dr, channel_major=True), dt_, x)
         flipped, _ = _taps(w1, packs, flipped=True)             # correlation with the reversed stencil
         gt = dt_.view_as(t)
         if do_res and FUSED_RESIDUAL_DGRAD and ops.dwconv3d_res_supported(gt, K, 1):
@@ -218,7 +218,7 @@ def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res,
             if do_res:
                 ops.add_(dx, dy)
     elif kind == "down":
-        dW1, db1 = lane.run(lambda: ops.dw_wgrad(dt_.view_as(t), x, K=K, stride=2, defer=dr), dt_, x)
+        dW1, db1 = lane.run(lambda: ops.dw_wgrad(dt_.view_as(t), x, K=K, stride=2, defer=dr, channel_major=True), dt_, x)
         dx = ops.dwconv3d_bwd_data(dt_.view_as(t), taps, (D, H, W), K=K, stride=2)
         if has_res:
             xg = x[:, ::2, ::2, ::2, :].contiguous()
@@ -228,7 +228,7 @@ def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res,
     else:
         if dtc is None:                                             # (given: the norm backward already wrote the compact grid)
             dtc = dt_.view_as(t)[:, 1:, 1:, 1:, :].contiguous()     # compact (2D-1)^3 grid of the transposed conv
-        dW1, _ = lane.run(lambda: ops.dw_wgrad(x, dtc, K=K, stride=2, want_bias=False, defer=dr), x, dtc)
+        dW1, _ = lane.run(lambda: ops.dw_wgrad(x, dtc, K=K, stride=2, want_bias=False, defer=dr, channel_major=True), x, dtc)
         if norm_is_per_channel:
             # GroupNorm(C, C) subtracts the per-(sample, channel) mean over exactly the voxels the bias reaches: its gradient
             # sum_r dt[r][c] = rstd*gamma * (S1 - count*S1/count - S2/count * sum_r xhat) is zero identically; what a pass over dt
@@ -240,7 +240,7 @@ def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res,
         if has_res:
             drl = dy[:, 1::2, 1::2, 1::2, :].contiguous()       # positions fed by the transposed 1x1 conv
             dwres_m, _ = lane.run(lambda: ops.pw_wgrad(x, drl, N=N, rows_per_sample=D * H * W, c_in=C, c_out=c_out, want_bias=False,
-                                                       defer=dr), x, drl)
+                                                       defer=dr, in_major=True), x, drl)        # ConvTranspose layout (C_in, C_out)
             ops.add_(dx, _pw(drl, _mat(wres), None, c_out=C, transposed=False, packs=packs).view_as(dx))
     return dx, dW1, db1, dwres, dbres, dwres_m
 
@@ -451,7 +451,7 @@ class BlockFn(torch.autograd.Function):
         lane.join()
         dr.flush()                       # all weight / bias / norm gradients of the block are final from here on
         if kind == "up" and has_res:
-            dwres = dwres_m.t().contiguous()                        # ConvTranspose layout (C_in, C_out)
+            dwres = dwres_m
             dbres = db3.clone()                                     # bias reaches every interior voxel exactly once
         # gradients in the parameter's own (contiguous) strides, which DDP's bucket views expect: a view when the kernel
         # output is already laid out that way (1x1x1 weights, norm vectors), a copy only for the transposed ones
@@ -461,7 +461,6 @@ class BlockFn(torch.autograd.Function):
             if v.is_contiguous() and like.is_contiguous():
                 return v.view(like.shape)
             return torch.empty_like(like).copy_(v.reshape(like.shape))
-        dW1 = dW1.t().contiguous()
         if w1.dim() == 4:                # dim='2d': only the centre z-plane of the embedded stencil is a parameter
             dW1 = dW1.view(C, 1, K, K, K)[:, :, K // 2].contiguous()
         return (dx, dskip, g(dW1, w1), (db1.to(w1.dtype) if has_b1 else None), g(dgamma, gamma),
@@ -636,9 +635,8 @@ class NormVariantBlockFn(torch.autograd.Function):
         dx, dW1, db1, dwres, dbres, dwres_m = _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res, dr)
         dr.flush()
         if kind == "up" and has_res:
-            dwres = dwres_m.t().contiguous()                        # ConvTranspose layout (C_in, C_out)
+            dwres = dwres_m
             dbres = db3.clone()                                     # bias reaches every interior voxel exactly once
-        dW1 = dW1.t().contiguous()
         if w1.dim() == 4:                # dim='2d': only the centre z-plane of the embedded stencil is a parameter
             dW1 = dW1.view(C, 1, K, K, K)[:, :, K // 2].contiguous()
         g = _grad_like

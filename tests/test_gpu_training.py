@@ -573,8 +573,8 @@ def test_batched_packs_and_deferred_reductions_are_bit_identical(dtype, monkeypa
     from pytorch_connectomics_amd.training import autograd as AG
 
     class _Immediate(ops.DeferredReduce):        # reduce every item at once, one launch each (the round-1 behaviour)
-        def add(self, part, out, n, slots, keep=None):
-            super().add(part, out, n, slots, keep)
+        def add(self, part, out, n, slots, keep=None, out_t=0):
+            super().add(part, out, n, slots, keep, out_t)
             self.flush()
 
     def run(batched: bool):
@@ -1079,3 +1079,23 @@ def test_block_backward_with_rebuilt_hidden_tensor_gives_the_stored_schedule_gra
         b = res[True][1][k]
         a, b = a.flatten().double(), b.flatten().double()
         assert float((a - b).norm()) <= 3e-3 * float(a.norm()) + floor * a.numel() ** 0.5, k
+
+
+def test_deferred_reduction_writes_transposed_outputs():
+    """pytc_reduce_item.out_t: a depthwise weight gradient leaves the reduction launch channel-major (C, K^3), a ConvTranspose 1x1x1
+    weight gradient as (C_in, C_out) -- the same bits as the plain outputs, transposed (no copy kernel per block)."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(3)
+    gt = torch.randn(2, 12, 12, 12, 32, generator=g).cuda().bfloat16()
+    x = torch.randn(2, 12, 12, 12, 32, generator=g).cuda().bfloat16()
+    d0, d1 = ops.DeferredReduce(), ops.DeferredReduce()
+    a, ab = ops.dw_wgrad(gt, x, K=3, stride=1, defer=d0)
+    b, bb = ops.dw_wgrad(gt, x, K=3, stride=1, defer=d1, channel_major=True)
+    d0.flush(); d1.flush()
+    assert b.shape == (32, 27) and torch.equal(b, a.t()) and torch.equal(ab, bb)
+    assert torch.equal(ops.dw_wgrad(gt, x, K=3, stride=1, channel_major=True)[0], a.t())
+    xr, dy = gt.view(2, -1, 32), torch.randn(2, 12 ** 3, 64, generator=g).cuda().bfloat16()
+    p, _ = ops.pw_wgrad(xr, dy, N=2, rows_per_sample=12 ** 3, c_in=32, c_out=64, want_bias=False, defer=d0)
+    q, _ = ops.pw_wgrad(xr, dy, N=2, rows_per_sample=12 ** 3, c_in=32, c_out=64, want_bias=False, defer=d1, in_major=True)
+    d0.flush(); d1.flush()
+    assert q.shape == (32, 64) and torch.equal(q, p.t())
