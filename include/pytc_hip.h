@@ -578,6 +578,9 @@ int pytc_mixer_bwd_rc(const void* t, const float* ab, const float* mean_rstd, co
                       int dtype, int* slots_out, void* stream);
 int pytc_dw_wgrad_partial(const void* g, const void* x, float* workspace, int want_db, int N, const int32_t* gdims,
                           const int32_t* xdims, int C, int K, int stride, int dtype, int* slots_out, void* stream);
+/* dst = src (N, D, H, W, C channels-last, dims = {D, H, W}) with the front faces (z, y or x == 0) zeroed: the output gradient of an up
+ * block's mixer (training/lightning/model.py:863-910 reaches it through autograd of the external block's F.pad(x, (1,0,1,0,1,0))). */
+int pytc_copy_zero_front(const void* src, void* dst, int N, const int32_t* dims, int C, int dtype, void* stream);
 typedef struct {
   const float* part;   /* [slots][n] fp32 partials */
   float* out;          /* [n] */
@@ -605,7 +608,8 @@ int pytc_norm_bwd(const void* dtn, const void* t, const float* mean_rstd, const 
  * pytc_norm_finalize_groups_mr, W2: fp32 [C_hid][C], count = voxels in the statistics.  bf16, C and C_hid multiples of 16
  * (pytc_pw_wgrad_groupnorm_supported).  workspace (pytc_pw_wgrad_groupnorm_ws_elems floats), sps = pytc_pw_wgrad_groupnorm_sps(...):
  *   [N*sps][C_hid*C] dW partials | [N*sps][C_hid] bias partials | term [N][C_hid*C] | q [N][C_hid]
- * the caller reduces term and q over their N slots (pytc_reduce_slots_multi).  Replaces autograd's separate Conv3d-weight and
+ * the caller reduces term and q over their N slots (pytc_reduce_slots_multi); with sps == 1 the samples' terms are left in the dW partials
+ * region instead (term unused: no reduction launch).  Replaces autograd's separate Conv3d-weight and
  * GroupNorm backward passes (reference: torch.nn.GroupNorm + Conv3d under connectomics/training/lightning/model.py:863-910).
  * pytc_norm_bwd_apply: the apply pass of pytc_norm_bwd with s given as [s_parts][N][2][C] (summed over the parts); crop_grid
  * (nullable int32[3], the (D,H,W) grid of the rows): rows on the front faces are dropped and dt is the compact (D-1,H-1,W-1)
@@ -622,6 +626,10 @@ int pytc_norm_bwd_apply(const void* dtn, const void* t, const float* mean_rstd, 
 /* depthwise conv backward-data, any stride: dx[i] = sum_k dy[(i + K/2 - k)/stride] * w[k] (w: forward taps [K^3][C]) */
 int pytc_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, int N, const int32_t* xdims,
                            const int32_t* ydims, int C, int K, int stride, int dtype, void* stream);
+/* the same with dx = conv^T(dy) + addend (addend shaped like dx, fp32 sum, one rounding): the gradient of a U-Net skip connection
+ * joins the down block's data gradient in this launch (autograd's accumulation of the two is a separate three-pass add). */
+int pytc_dwconv3d_bwd_data_add(const void* dy, const float* w, const void* addend, void* dx, int N, const int32_t* xdims,
+                               const int32_t* ydims, int C, int K, int stride, int dtype, void* stream);
 
 /* ---------------------------------------------------------------- dense-conv (RSUNet) training ---------- */
 /* Backward of the RSUNet building blocks (rsunet.py:73-259 through torch autograd in the reference).  The data

@@ -141,6 +141,7 @@ _SIGS = {
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pytc_gelu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "pytc_add_inplace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "pytc_copy_zero_front": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p]),
     "pytc_pw_wgrad_slots": (C.c_int, [C.c_int64]),
     "pytc_pw_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -175,6 +176,8 @@ _SIGS = {
                                 C.c_int, C.c_int64, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "pytc_dwconv3d_bwd_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32),
                                          C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pytc_dwconv3d_bwd_data_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pytc_conv3d_wgrad_ws_elems": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int]),
     "pytc_conv3d_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p]),

@@ -628,12 +628,22 @@ pw_pack_paired_kernel(const float* __restrict__ w, int C_out, int C_in, int tran
 __global__ void __launch_bounds__(256)
 pack_multi_kernel(const long* __restrict__ table, int n_items, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  int lo = 0, hi = n_items - 1;
-  while (lo < hi) {                                   // last item whose first element is <= i
-    const int mid = (lo + hi + 1) >> 1;
-    if (table[mid * 8 + 6] <= i) lo = mid; else hi = mid - 1;
+  // the item of the block's first element, found once per workgroup (every thread walking the table by itself was eight dependent
+  // loads per output element: 86 us per MedNeXt-S step); a thread then steps forward over the few item boundaries inside the block
+  __shared__ int s_lo;
+  if (threadIdx.x == 0) {
+    const long i0 = (long)blockIdx.x * blockDim.x;
+    int lo = 0, hi = n_items - 1;
+    while (lo < hi) {                                 // last item whose first element is <= i0
+      const int mid = (lo + hi + 1) >> 1;
+      if (table[mid * 8 + 6] <= i0) lo = mid; else hi = mid - 1;
+    }
+    s_lo = lo;
   }
+  __syncthreads();
+  if (i >= total) return;
+  int lo = s_lo;
+  while (lo + 1 < n_items && table[(lo + 1) * 8 + 6] <= i) ++lo;
   const long* it = table + lo * 8;
   const float* w = reinterpret_cast<const float*>(it[0]);
   const int kind = (int)it[2], C_out = (int)it[3], C_in = (int)it[4], aux = (int)it[5];

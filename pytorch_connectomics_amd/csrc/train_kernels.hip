@@ -34,6 +34,23 @@ add_kernel(T* __restrict__ y, const T* __restrict__ x, long n) {
   for (; i < n; i += stride) y[i] = from_f32<T>(to_f32<T>(y[i]) + to_f32<T>(x[i]));
 }
 
+// copy of a channels-last (N, D, H, W, C) tensor with the FRONT faces (z, y or x == 0) zeroed: the output gradient an up block's mixer
+// sees (those faces are the zero padding of its transposed conv, not outputs of the mixer); 16-byte pieces, one launch instead of
+// clone + three strided fills
+__global__ void __launch_bounds__(256)
+copy_zero_front_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long pieces, int pieces_per_voxel, int D, int H, int W) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < pieces; i += stride) {
+    const long v = i / pieces_per_voxel;
+    const int x = (int)(v % W);
+    const long q = v / W;
+    const int y = (int)(q % H);
+    const int z = (int)((q / H) % D);
+    dst[i] = (x == 0 || y == 0 || z == 0) ? uint4{0u, 0u, 0u, 0u} : src[i];
+  }
+}
+
 // ---- pointwise weight gradient: dWp[slot][o][k] = sum_{rows of slot} dY[r][o] * f(X[r][k]),  dbp[slot][o] ----------
 // workgroup = one (row slot, 64x64 (o,k) tile); rows staged in LDS as fp32 32 at a time; thread = 4x4 (o,k) block.
 constexpr int WG_TO = 64, WG_TK = 64, WG_TR = 32;
@@ -1401,6 +1418,101 @@ norm_bwd_from_wgrad_kernel(float* __restrict__ M, const float* __restrict__ dbp,
   }
 }
 
+// The same sums for H <= NBW_HMAX hidden channels with ONE pass over the q partials and no barrier inside the contraction loop (the
+// chunked kernel above paid three barriers and one exposed load round trip per 64 hidden channels: 22 us at C = 256, H = 512).  Same
+// order of additions everywhere (q: four interleaved slot partials, ((p0 + p1) + (p2 + p3)); s1 / s2: h ascending in steps of 16
+// per lane, the 16 lanes in order) -> bit-identical to norm_bwd_from_wgrad_kernel.
+constexpr int NBW_HMAX = 1024;
+__global__ void __launch_bounds__(256)
+norm_bwd_from_wgrad_flat_kernel(float* __restrict__ M, const float* __restrict__ dbp, float* __restrict__ q,
+                                const float* __restrict__ W2, const float* __restrict__ gamma, const float* __restrict__ ab,
+                                const float* __restrict__ mr, float* __restrict__ s_out, float* __restrict__ coef, int N, int C,
+                                int H, int sps, float inv_count) {
+  __shared__ float sm_q[4][NBW_HMAX];
+  __shared__ float sm[2][16][17];
+  const int n = blockIdx.y;
+  const int cl = threadIdx.x & 15, hl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const bool ok = c < C;
+  const float g = ok ? (gamma ? gamma[c] : 1.f) : 0.f;
+  const float mean = ok ? mr[((long)n * 2 + 0) * C + c] : 0.f, rstd = ok ? mr[((long)n * 2 + 1) * C + c] : 0.f;
+  const float beta = ok ? fmaf(mean, ab[((long)n * 2 + 0) * C + c], ab[((long)n * 2 + 1) * C + c]) : 0.f;
+  float* Mn = M + (long)n * H * C;
+  {
+    const int hh = threadIdx.x & 63, part = threadIdx.x >> 6;
+    for (int h = hh; h < H; h += 64) {
+      const float* __restrict__ src = dbp + (long)n * sps * H + h;
+      float a = 0.f;
+      int j = part;
+      for (; j + 28 < sps; j += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(long)(j + 4 * u) * H];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+      }
+      for (; j < sps; j += 4) a += src[(long)j * H];
+      sm_q[part][h] = a;
+    }
+  }
+  __syncthreads();
+  for (int h = threadIdx.x; h < H; h += 256) {
+    const float a = (sm_q[0][h] + sm_q[1][h]) + (sm_q[2][h] + sm_q[3][h]);
+    sm_q[0][h] = a;
+    if (blockIdx.x == 0) q[(long)n * H + h] = a;
+  }
+  __syncthreads();
+  float s1 = 0.f, s2 = 0.f;
+  if (ok) {
+    int h = hl;
+    for (; h + 48 < H; h += 64) {
+      float w[4], m[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        w[k] = W2[(long)(h + 16 * k) * C + c];
+        m[k] = Mn[(long)(h + 16 * k) * C + c];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float wb = to_f32<bf16_t>(from_f32<bf16_t>(w[k])), qq = sm_q[0][h + 16 * k];
+        s1 = fmaf(wb, qq, s1);
+        s2 = fmaf(wb, m[k], s2);
+        Mn[(long)(h + 16 * k) * C + c] = fmaf(g, m[k], beta * qq);
+      }
+    }
+    for (; h < H; h += 16) {
+      const float wb = to_f32<bf16_t>(from_f32<bf16_t>(W2[(long)h * C + c]));
+      const float m = Mn[(long)h * C + c], qq = sm_q[0][h];
+      s1 = fmaf(wb, qq, s1);
+      s2 = fmaf(wb, m, s2);
+      Mn[(long)h * C + c] = fmaf(g, m, beta * qq);
+    }
+  }
+  sm[0][hl][cl] = s1;
+  sm[1][hl][cl] = s2;
+  __syncthreads();
+  if (hl == 0 && ok) {
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { a1 += sm[0][j][cl]; a2 += sm[1][j][cl]; }
+    s_out[((long)n * 2 + 0) * C + c] = a1;
+    s_out[((long)n * 2 + 1) * C + c] = a2;
+    const float rg = rstd * g, m1 = a1 * inv_count, m2 = a2 * inv_count;
+    const float B = -rg * rstd * m2;
+    coef[((long)n * 3 + 0) * C + c] = rg;
+    coef[((long)n * 3 + 1) * C + c] = B;
+    coef[((long)n * 3 + 2) * C + c] = -rg * m1 - B * mean;
+  }
+}
+
+static void launch_norm_bwd_from_wgrad(dim3 grid, hipStream_t s, float* M, const float* dbp, float* q, const float* W2, const float* gamma,
+                                       const float* ab, const float* mr, float* s_out, float* coef, int N, int C, int H, int sps, float inv_count) {
+  if (H <= NBW_HMAX && tuning_get("norm_bwd_from_wgrad_flat", 1))
+    hipLaunchKernelGGL(norm_bwd_from_wgrad_flat_kernel, grid, dim3(256), 0, s, M, dbp, q, W2, gamma, ab, mr, s_out, coef, N, C, H, sps, inv_count);
+  else
+    hipLaunchKernelGGL(norm_bwd_from_wgrad_kernel, grid, dim3(256), 0, s, M, dbp, q, W2, gamma, ab, mr, s_out, coef, N, C, H, sps, inv_count);
+}
+
 // ---- strided depthwise backward-data (gather form): dx[i] = sum_k dy[(i + p - k)/s] * w[k] -------------------------
 struct DwBd {
   int D, H, W, Do, Ho, Wo, C, K, stride, pad;
@@ -1438,7 +1550,10 @@ dwconv_bwd_data_kernel(const T* __restrict__ dy, const float* __restrict__ w, T*
 // 16-byte form: lane = (input voxel, chunk of EPV channels)
 template <typename T>
 __global__ void __launch_bounds__(256)
-dwconv_bwd_data_vec_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, DwBd g, long total) {
+dwconv_bwd_data_vec_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, DwBd g, long total,
+                           const T* __restrict__ addend = nullptr) {
+  // addend (nullable, shaped like dx): dx = conv^T(dy) + addend in fp32, one rounding -- the skip connection's gradient joins the down
+  // block's data gradient here instead of in a separate three-pass add
   constexpr int EPV = 16 / (int)sizeof(T);
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -1477,6 +1592,12 @@ dwconv_bwd_data_vec_kernel(const T* __restrict__ dy, const float* __restrict__ w
 #pragma unroll
           for (int q = 0; q < EPV; ++q) acc[q] = fmaf(dv[q], wv[q], acc[q]);
         }
+    if (addend) {
+      float av[EPV];
+      VecIO<T, EPV>::load(addend + i * EPV, av);
+#pragma unroll
+      for (int q = 0; q < EPV; ++q) acc[q] += av[q];
+    }
     VecIO<T, EPV>::store(dx + i * EPV, acc);
     return;
   }
@@ -1498,6 +1619,12 @@ dwconv_bwd_data_vec_kernel(const T* __restrict__ dy, const float* __restrict__ w
         for (int q = 0; q < EPV; ++q) acc[q] = fmaf(dv[q], wv[q], acc[q]);
       }
     }
+  }
+  if (addend) {
+    float av[EPV];
+    VecIO<T, EPV>::load(addend + i * EPV, av);
+#pragma unroll
+    for (int q = 0; q < EPV; ++q) acc[q] += av[q];
   }
   VecIO<T, EPV>::store(dx + i * EPV, acc);
 }
@@ -1532,6 +1659,19 @@ extern "C" int pytc_add_inplace(void* y, const void* x, int64_t n, int dtype, vo
              hipLaunchKernelGGL(add_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (float*)y, (const float*)x, (long)n),
              "add_inplace")
   PYTC_LAUNCH_CHECK("add_inplace");
+  return PYTC_OK;
+}
+
+extern "C" int pytc_copy_zero_front(const void* src, void* dst, int N, const int32_t* dims, int C, int dtype, void* stream) {
+  PYTC_REQUIRE(src && dst && dims && N >= 1 && dims[0] >= 1 && dims[1] >= 1 && dims[2] >= 1 && C >= 1, "copy_zero_front: bad arguments");
+  const int esz = dtype == PYTC_BF16 ? 2 : 4;
+  PYTC_REQUIRE((C * esz) % 16 == 0, "copy_zero_front: a voxel's channels must be a multiple of 16 bytes (C = %d)", C);
+  const int ppv = C * esz / 16;
+  const long pieces = (long)N * dims[0] * dims[1] * dims[2] * ppv;
+  const long blocks = (pieces + 255) / 256;
+  hipLaunchKernelGGL(copy_zero_front_kernel, dim3((unsigned)(blocks < 262144 ? blocks : 262144)), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, pieces, ppv,
+                     dims[0], dims[1], dims[2]);
+  PYTC_LAUNCH_CHECK("copy_zero_front");
   return PYTC_OK;
 }
 
@@ -1696,8 +1836,8 @@ extern "C" int pytc_reduce_slots_multi(const pytc_reduce_item* items, int n_item
 /* GroupNorm-fed expand conv: weight-gradient sums AND the norm-backward statistics from one pass over (t, dhp) (see
    norm_bwd_from_wgrad_kernel).  bf16, C and C_hid multiples of 16.  workspace (pytc_pw_wgrad_groupnorm_ws_elems floats):
      [N*sps][C_hid*C] dW partials | [N*sps][C_hid] bias partials | term [N][C_hid*C] | q [N][C_hid]
-   with sps = pytc_pw_wgrad_groupnorm_sps.  On return  dW2 = sum_n term[n],  db2 = sum_n q[n]  (left to the caller's slot
-   reduction, N slots each), s_out [N][2][C] = (sum dtn, sum dtn * xhat) and coef [N][3][C] = (A, B, C) for the data-gradient
+   with sps = pytc_pw_wgrad_groupnorm_sps (sps == 1: the samples' terms are left IN the dW partials region, `term` stays unused).
+   On return  dW2 = sum_n term[n],  db2 = sum_n q[n]  (left to the caller's slot reduction, N slots each), s_out [N][2][C] = (sum dtn, sum dtn * xhat) and coef [N][3][C] = (A, B, C) for the data-gradient
    GEMM's PYTC_RES_NORM_BWD epilogue (count = voxels in the statistics). */
 extern "C" int pytc_pw_wgrad_groupnorm_sps(int N, int64_t rows_per_sample, int C, int C_hid) {
   const long rows_total = (long)N * rows_per_sample;
@@ -1737,9 +1877,11 @@ extern "C" int pytc_pw_wgrad_groupnorm(const void* t, const float* mean_rstd, co
   if (mt == 4) launch_wgrad_mfma<4>(nt, grid, s, xp, mean_rstd, dp, dWp, dbp, rows_total, (long)rows_per_sample, C, C_hid, rps, PYTC_ACT_NONE, sps, 1);
   else if (mt == 2) launch_wgrad_mfma<2>(nt, grid, s, xp, mean_rstd, dp, dWp, dbp, rows_total, (long)rows_per_sample, C, C_hid, rps, PYTC_ACT_NONE, sps, 1);
   else launch_wgrad_mfma<1>(nt, grid, s, xp, mean_rstd, dp, dWp, dbp, rows_total, (long)rows_per_sample, C, C_hid, rps, PYTC_ACT_NONE, sps, 1);
-  hipLaunchKernelGGL(reduce_slots_batched_kernel, dim3(ceil_div(nW, 16), N), dim3(256), 0, s, dWp, term, nW, sps);
-  hipLaunchKernelGGL(norm_bwd_from_wgrad_kernel, dim3((C + 15) / 16, N), dim3(256), 0, s, term, dbp, qv, W2, gamma, ab, mean_rstd,
-                     s_out, coef, N, C, C_hid, sps, 1.0f / count);
+  // one slot per sample (the 14^3 / 7^3 levels): the partials ARE the per-sample sums -- the epilogue kernel works on them in place and the
+  // samples' terms of dW2 stay in the partials region (no reduction launch: 12 us + a launch boundary per deep block)
+  float* M = sps == 1 ? dWp : term;
+  if (sps > 1) hipLaunchKernelGGL(reduce_slots_batched_kernel, dim3(ceil_div(nW, 16), N), dim3(256), 0, s, dWp, term, nW, sps);
+  launch_norm_bwd_from_wgrad(dim3((C + 15) / 16, N), s, M, dbp, qv, W2, gamma, ab, mean_rstd, s_out, coef, N, C, C_hid, sps, 1.0f / count);
   PYTC_LAUNCH_CHECK("pw_wgrad_groupnorm");
   return PYTC_OK;
 }
@@ -1802,8 +1944,7 @@ extern "C" int pytc_mixer_bwd_rc(const void* t, const float* ab, const float* me
   else launch_mixer_bwd_rc<2>(q, gn, (int)S, s);
   if (gn) {
     hipLaunchKernelGGL(reduce_slots_batched_kernel, dim3(ceil_div(per, 16), N), dim3(256), 0, s, q.dW2p, term, per, sps);
-    hipLaunchKernelGGL(norm_bwd_from_wgrad_kernel, dim3(2, N), dim3(256), 0, s, term, q.db2p, qv, W2, gamma, ab, mean_rstd, s_out, coef, N, 32,
-                       C_hid, sps, 1.0f / count);
+    launch_norm_bwd_from_wgrad(dim3(2, N), s, term, q.db2p, qv, W2, gamma, ab, mean_rstd, s_out, coef, N, 32, C_hid, sps, 1.0f / count);
   }
   *slots_out = (int)S;
   PYTC_LAUNCH_CHECK("mixer_bwd_rc");
@@ -1858,7 +1999,14 @@ static void make_wg_vec(DwWg& q, long& rps, int N, const int32_t* gd, const int3
   q.C = C; q.K = K; q.stride = stride; q.pad = K / 2; q.lpv = q.vs = q.iters = 0;
   const int PL = 256 / (C / (dtype == PYTC_BF16 ? 8 : 4));
   const long vg = (long)q.Dg * q.Hg * q.Wg;
-  long sl = (vg + (long)PL * 16 - 1) / ((long)PL * 16);
+  // positions per lane: 16 where that still gives the chip >= 1024 workgroups, down to 4 below (a 14^3 x 256 launch had 264 workgroups whose
+  // lanes walked 16 positions, one L2 round trip each: 50 us for 11 MB; knob dw_wgrad_vec_ppl forces a value)
+  long ppl = tuning_get("dw_wgrad_vec_ppl", 0);
+  if (ppl <= 0) {
+    ppl = vg * N * 3 / ((long)PL * 1024);
+    ppl = ppl < 4 ? 4 : (ppl > 16 ? 16 : ppl);
+  }
+  long sl = (vg + (long)PL * ppl - 1) / ((long)PL * ppl);
   q.slots = (int)(sl < 1 ? 1 : (sl > 1024 ? 1024 : sl));
   rps = (vg + q.slots - 1) / q.slots;
 }
@@ -2040,8 +2188,23 @@ extern "C" int pytc_norm_bwd_ws_elems(int N, int64_t rows, int C) {
   return (int)((long)N * slots * 2 * C);
 }
 
+static int dwconv3d_bwd_data_impl(const void* dy, const float* w, const void* addend, void* dx, int N, const int32_t* xdims,
+                                  const int32_t* ydims, int C, int K, int stride, int dtype, void* stream);
+
 extern "C" int pytc_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, int N, const int32_t* xdims,
                                       const int32_t* ydims, int C, int K, int stride, int dtype, void* stream) {
+  return dwconv3d_bwd_data_impl(dy, w, nullptr, dx, N, xdims, ydims, C, K, stride, dtype, stream);
+}
+
+/* dx = conv^T(dy) + addend (addend shaped like dx; 16-byte channel groups only) */
+extern "C" int pytc_dwconv3d_bwd_data_add(const void* dy, const float* w, const void* addend, void* dx, int N, const int32_t* xdims,
+                                          const int32_t* ydims, int C, int K, int stride, int dtype, void* stream) {
+  PYTC_REQUIRE(addend && C % (dtype == PYTC_BF16 ? 8 : 4) == 0, "dwconv3d_bwd_data_add: addend and 16-byte channel groups required (C = %d)", C);
+  return dwconv3d_bwd_data_impl(dy, w, addend, dx, N, xdims, ydims, C, K, stride, dtype, stream);
+}
+
+static int dwconv3d_bwd_data_impl(const void* dy, const float* w, const void* addend, void* dx, int N, const int32_t* xdims,
+                                  const int32_t* ydims, int C, int K, int stride, int dtype, void* stream) {
   PYTC_REQUIRE(dy && w && dx && xdims && ydims, "dwconv3d_bwd_data: null pointer");
   DwBd g;
   g.D = xdims[0]; g.H = xdims[1]; g.W = xdims[2]; g.Do = ydims[0]; g.Ho = ydims[1]; g.Wo = ydims[2];
@@ -2052,8 +2215,8 @@ extern "C" int pytc_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, 
   if (C % epv == 0) {
     const long tv = total / epv;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(dwconv_bwd_data_vec_kernel<bf16_t>, dim3(ceil_div(tv, 256)), dim3(256), 0, s, (const bf16_t*)dy, w, (bf16_t*)dx, g, tv),
-               hipLaunchKernelGGL(dwconv_bwd_data_vec_kernel<float>, dim3(ceil_div(tv, 256)), dim3(256), 0, s, (const float*)dy, w, (float*)dx, g, tv),
+               hipLaunchKernelGGL(dwconv_bwd_data_vec_kernel<bf16_t>, dim3(ceil_div(tv, 256)), dim3(256), 0, s, (const bf16_t*)dy, w, (bf16_t*)dx, g, tv, (const bf16_t*)addend),
+               hipLaunchKernelGGL(dwconv_bwd_data_vec_kernel<float>, dim3(ceil_div(tv, 256)), dim3(256), 0, s, (const float*)dy, w, (float*)dx, g, tv, (const float*)addend),
                "dwconv3d_bwd_data")
     PYTC_LAUNCH_CHECK("dwconv3d_bwd_data");
     return PYTC_OK;

@@ -1348,7 +1348,8 @@ def pw_wgrad_groupnorm(t: torch.Tensor, mean_rstd: torch.Tensor, ab: torch.Tenso
     dW = torch.empty((c_hid, c), dtype=torch.float32, device=dev)
     db = torch.empty((c_hid,), dtype=torch.float32, device=dev)
     own = defer if defer is not None else DeferredReduce()
-    own.add(ws[term0:term0 + N * nW], dW, nW, N, keep=ws)
+    tw = 0 if sps == 1 else term0            # one slot per sample: the samples' terms stay in the partials region (see pytc_pw_wgrad_groupnorm)
+    own.add(ws[tw:tw + N * nW], dW, nW, N, keep=ws)
     own.add(ws[term0 + N * nW:term0 + N * (nW + c_hid)], db, c_hid, N)
     if defer is None:
         own.flush()
@@ -1460,6 +1461,21 @@ def gelu(x: torch.Tensor, dy: Optional[torch.Tensor] = None) -> torch.Tensor:
 def add_(y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     _dev(y, "y"); _dev(x, "x")
     _run(f"add_inplace[C{x.shape[-1]}]", 3 * _nbytes(x), nat.lib().pytc_add_inplace, _p(y), _p(x), y.numel(), dtype_code(y.dtype), _stream())
+    return y
+
+
+def copy_zero_front(x: torch.Tensor) -> torch.Tensor:
+    """Copy of x (N, D, H, W, C) with the front faces (z, y or x == 0) zeroed -- one launch (pytc_copy_zero_front)."""
+    _dev(x, "x")
+    if x.dim() != 5 or not x.is_contiguous() or (x.shape[-1] * x.element_size()) % 16:
+        y = x.clone()
+        y[:, 0] = 0
+        y[:, :, 0] = 0
+        y[:, :, :, 0] = 0
+        return y
+    y = torch.empty_like(x)
+    _run(f"copy_zero_front[C{x.shape[-1]}]", 2 * _nbytes(x), nat.lib().pytc_copy_zero_front, _p(x), _p(y), int(x.shape[0]), _i3(x.shape[1:4]),
+         int(x.shape[-1]), dtype_code(x.dtype), _stream())
     return y
 
 
@@ -1678,10 +1694,17 @@ def norm_bwd(dtn: torch.Tensor, t: torch.Tensor, mean_rstd: torch.Tensor, gamma:
     return dt, s
 
 
-def dwconv3d_bwd_data(dy: torch.Tensor, w_taps: torch.Tensor, xdims, *, K: int, stride: int) -> torch.Tensor:
+def dwconv3d_bwd_data(dy: torch.Tensor, w_taps: torch.Tensor, xdims, *, K: int, stride: int, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Data gradient of a (strided) depthwise conv; add (shaped like the result): dx = conv^T(dy) + add in the same launch."""
     _dev(dy, "dy")
     N, Cc = dy.shape[0], dy.shape[-1]
     dx = torch.empty((N, *[int(v) for v in xdims], Cc), dtype=dy.dtype, device=dy.device)
+    if add is not None:
+        if tuple(add.shape) != tuple(dx.shape) or add.dtype != dx.dtype or not add.is_contiguous() or (Cc * dx.element_size()) % 16:
+            raise ValueError("dwconv3d_bwd_data: `add` must be a contiguous tensor shaped like the result with 16-byte channel groups")
+        _run(f"dwconv3d_bwd_data[C{Cc}_k{K}_s{stride}]+add", _nbytes(dy, dx, add), nat.lib().pytc_dwconv3d_bwd_data_add, _p(dy), _p(w_taps),
+             _p(add), _p(dx), N, _i3(xdims), _i3(dy.shape[1:4]), Cc, K, stride, dtype_code(dy.dtype), _stream())
+        return dx
     _run(f"dwconv3d_bwd_data[C{Cc}_k{K}_s{stride}]", _nbytes(dy, dx), nat.lib().pytc_dwconv3d_bwd_data, _p(dy), _p(w_taps),
          _p(dx), N, _i3(xdims), _i3(dy.shape[1:4]), Cc, K, stride, dtype_code(dy.dtype), _stream())
     return dx

@@ -73,6 +73,22 @@ SIDE_STREAM_WGRAD = False
 _SIDE_STREAMS = {}
 
 
+# U-Net skip connections: the encoder features of a level feed its down block AND the up block's skip input, so autograd adds two
+# gradients for them (a three-pass elementwise add per level: 0.24 ms of a 22 ms MedNeXt-S step).  With a _SkipBox shared by the two blocks of
+# a level the up block's backward leaves its skip gradient in the box (and returns none), and the down block's backward -- which always runs
+# later in the same pass: its output feeds the up block -- adds it inside its data-gradient launch (pytc_dwconv3d_bwd_data_add).
+FUSE_SKIP_GRAD = os.environ.get("PYTC_FUSE_SKIP_GRAD", "1") != "0"
+
+
+class _SkipBox:
+    """Mailbox between the up block (writer) and the down block (reader) of one level, alive for one forward / backward."""
+    __slots__ = ("grad", "armed")
+
+    def __init__(self):
+        self.grad = None
+        self.armed = False         # the down block has promised to collect: its forward ran with this box and its input needs a gradient
+
+
 class _WgradLane:
     """`run(fn, *deps)`: fn's launches go to the side stream once everything enqueued on the caller's stream so far is done
     (deps = tensors of the caller's stream fn reads: kept from being recycled under it); `join()`: the caller's stream waits for
@@ -198,7 +214,8 @@ class PointwiseFn(torch.autograd.Function):
                 None, None, None)
 
 
-def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res, dr, lane=None, dtc=None, norm_is_per_channel=False):
+def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res, dr, lane=None, dtc=None, norm_is_per_channel=False,
+                 skip_add=None):
     """Depthwise-conv half of a block backward, shared by BlockFn and NormVariantBlockFn: from dt (gradient of the depthwise
     output) to dx, dW1 (channel-major (C, K^3): the reduction launch writes the parameter's layout), db1 and the gradients of the resampling residual conv.  Slot reductions join `dr`."""
     N, D, H, W, C = x.shape
@@ -219,7 +236,12 @@ def _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res,
                 ops.add_(dx, dy)
     elif kind == "down":
         dW1, db1 = lane.run(lambda: ops.dw_wgrad(dt_.view_as(t), x, K=K, stride=2, defer=dr, channel_major=True), dt_, x)
-        dx = ops.dwconv3d_bwd_data(dt_.view_as(t), taps, (D, H, W), K=K, stride=2)
+        if skip_add is not None and tuple(skip_add.shape) == tuple(x.shape) and skip_add.dtype == dt_.dtype:
+            dx = ops.dwconv3d_bwd_data(dt_.view_as(t), taps, (D, H, W), K=K, stride=2, add=skip_add.contiguous())
+        else:
+            dx = ops.dwconv3d_bwd_data(dt_.view_as(t), taps, (D, H, W), K=K, stride=2)
+            if skip_add is not None:
+                dx = dx + skip_add.to(dx.dtype)
         if has_res:
             xg = x[:, ::2, ::2, ::2, :].contiguous()
             dwres, dbres = lane.run(lambda: ops.pw_wgrad(xg, dy, N=N, rows_per_sample=rows, c_in=C, c_out=c_out, defer=dr), xg, dy)
@@ -260,8 +282,11 @@ class BlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, skip, w1, b1, gamma, beta, w2, b2, w3, b3, wres, bres, kind: str, do_res: bool, eps: float,
-                recompute: bool = False, packs=None):
+                recompute: bool = False, packs=None, skip_box=None):
         ctx.packs = packs
+        ctx.skip_box = skip_box if FUSE_SKIP_GRAD else None
+        if ctx.skip_box is not None and kind == "down" and ctx.needs_input_grad[0]:
+            skip_box.armed = True        # this block's backward will collect the skip gradient of its level
         y, t, ab, mr, hp, taps, K, count = BlockFn._core(x, skip, w1, b1, gamma, beta, w2, b2, w3, b3, wres, bres, kind,
                                                          do_res, eps, None, packs)
         keep = x.new_zeros(0)
@@ -353,12 +378,15 @@ class BlockFn(torch.autograd.Function):
         c_hid, c_out = w2.shape[0], w3.shape[0]
         taps = ctx.taps
         dskip = dy if (kind == "up" and has_skip) else None
+        box = ctx.skip_box
+        if (dskip is not None and box is not None and box.armed and (dy.shape[-1] * dy.element_size()) % 16 == 0):
+            box.grad, dskip = dy, None   # collected by the level's down block inside its data-gradient launch
+        skip_add = None
+        if kind == "down" and box is not None and box.grad is not None:
+            skip_add, box.grad = box.grad, None
         dcore = dy
         if kind == "up":
-            dcore = dy.clone()      # the padded front faces are not outputs of the mixer
-            dcore[:, 0] = 0
-            dcore[:, :, 0] = 0
-            dcore[:, :, :, 0] = 0
+            dcore = ops.copy_zero_front(dy)      # the padded front faces are not outputs of the mixer
         # every slot reduction of this block's gradients (dW3/db3, dW2/db2, the norm sums, dW1/db1, the residual conv) joins
         # ONE launch at the end (ops.DeferredReduce): ~5 tiny launches per block become 1, bit-identical results
         dr = ops.DeferredReduce()
@@ -447,7 +475,7 @@ class BlockFn(torch.autograd.Function):
         dgamma, dbeta = ssum[1], ssum[0]
         # ---- depthwise conv
         dx, dW1, db1, dwres, dbres, dwres_m = _dw_backward(kind, dt_, t, x, dy, w1, wres, taps, K, packs, do_res, has_res, dr, lane,
-                                                           dtc=dtc, norm_is_per_channel=True)
+                                                           dtc=dtc, norm_is_per_channel=True, skip_add=skip_add)
         lane.join()
         dr.flush()                       # all weight / bias / norm gradients of the block are final from here on
         if kind == "up" and has_res:
@@ -467,7 +495,7 @@ class BlockFn(torch.autograd.Function):
                 g(dbeta, gamma), g(dW2, w2), (db2.to(w2.dtype) if has_b2 else None), g(dW3, w3),
                 (db3.to(w3.dtype) if has_b3 else None),
                 (g(dwres, wres) if has_res else None), (dbres.to(w3.dtype) if (has_res and has_bres) else None),
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 def _grad_like(v, like):
@@ -576,10 +604,7 @@ class NormVariantBlockFn(torch.autograd.Function):
         dskip = dy if (kind == "up" and has_skip) else None
         dcore = dy
         if kind == "up":
-            dcore = dy.clone()      # the padded front faces are not outputs of the mixer
-            dcore[:, 0] = 0
-            dcore[:, :, 0] = 0
-            dcore[:, :, :, 0] = 0
+            dcore = ops.copy_zero_front(dy)      # the padded front faces are not outputs of the mixer
         dr = ops.DeferredReduce()
         dgrn_g = dgrn_b = None
         if has_grn:
@@ -648,7 +673,7 @@ class NormVariantBlockFn(torch.autograd.Function):
                 None, None, None, None, None)
 
 
-def _block(m, x, skip=None, recompute: bool = False, packs=None):
+def _block(m, x, skip=None, recompute: bool = False, packs=None, skip_box=None):
     is_ln = not isinstance(m.norm, nn.GroupNorm)
     if is_ln and type(m.norm).__name__ != "_ChannelLayerNorm":
         raise NotImplementedError(f"no training kernels for MedNeXt norm module {type(m.norm).__name__}")
@@ -670,7 +695,8 @@ def _block(m, x, skip=None, recompute: bool = False, packs=None):
     else:
         y = BlockFn.apply(x, skip, m.conv1.weight, m.conv1.bias, m.norm.weight, m.norm.bias, m.conv2.weight,
                           m.conv2.bias, m.conv3.weight, m.conv3.bias, None if res is None else res.weight,
-                          None if res is None else res.bias, m.kind, bool(m.do_res), float(m.norm.eps), bool(recompute), packs)
+                          None if res is None else res.bias, m.kind, bool(m.do_res), float(m.norm.eps), bool(recompute), packs,
+                          None if (flat_up or m.dim == "2d") else skip_box)
     return y[:, 1:2].contiguous() if flat_up else y
 
 
@@ -719,16 +745,17 @@ def mednext_train_features(trunk, x_cl: torch.Tensor, compute_dtype: torch.dtype
         packs.refresh()          # ONE launch rebuilds every weight image / stencil whose parameter changed since the last step
     x = PointwiseFn.apply(x_cl, trunk.stem.weight, trunk.stem.bias, False, compute_dtype, packs)
     skips = []
+    boxes = [_SkipBox() if FUSE_SKIP_GRAD else None for _ in range(4)]      # one mailbox per level: up block -> down block (skip gradient)
     for lvl in range(4):
         for blk in getattr(trunk, f"enc_block_{lvl}"):
             x = _block(blk, x, recompute=rc, packs=packs)
         skips.append(x)
-        x = _block(getattr(trunk, f"down_{lvl}"), x, recompute=rc, packs=packs)
+        x = _block(getattr(trunk, f"down_{lvl}"), x, recompute=rc, packs=packs, skip_box=boxes[lvl])
     for blk in trunk.bottleneck:
         x = _block(blk, x, recompute=rc, packs=packs)
     feats = [x]
     for lvl in (3, 2, 1, 0):
-        x = _block(getattr(trunk, f"up_{lvl}"), x, skip=skips[lvl], recompute=rc, packs=packs)
+        x = _block(getattr(trunk, f"up_{lvl}"), x, skip=skips[lvl], recompute=rc, packs=packs, skip_box=boxes[lvl])
         for blk in getattr(trunk, f"dec_block_{lvl}"):
             x = _block(blk, x, recompute=rc, packs=packs)
         if lvl:

@@ -765,6 +765,15 @@ def test_groupnorm_backward_from_weight_gradient_sums_and_gemm_epilogue(C, H, ro
     ab, mr = ops.groupnorm_finalize_mr(ops.channel_stats(tc), float(rows), gamma.cuda(), beta.cuda(), 1e-5)
     dW, db, s, coef = ops.pw_wgrad_groupnorm(t.cuda(), mr, ab, dhp.cuda(), W2.cuda(), gamma.cuda(), N=N, rows_per_sample=rows, c=C,
                                              c_hid=H, count=float(rows))
+    # the flat form of the epilogue kernel (H <= 1024: one pass over the bias partials, no barrier in the contraction) and the chunked
+    # one add in the same order: identical bits
+    ops.set_tuning("norm_bwd_from_wgrad_flat", 0)
+    try:
+        dW_c, db_c, s_c, coef_c = ops.pw_wgrad_groupnorm(t.cuda(), mr, ab, dhp.cuda(), W2.cuda(), gamma.cuda(), N=N, rows_per_sample=rows,
+                                                         c=C, c_hid=H, count=float(rows))
+    finally:
+        ops.set_tuning("norm_bwd_from_wgrad_flat", 1)
+    assert torch.equal(dW, dW_c) and torch.equal(db, db_c) and torch.equal(s, s_c) and torch.equal(coef, coef_c)
     mean, rstd = mr[:, 0].double().cpu(), mr[:, 1].double().cpu()
     xhat = (t.double() - mean[:, None]) * rstd[:, None]
     d = dhp.double()
@@ -1099,3 +1108,56 @@ def test_deferred_reduction_writes_transposed_outputs():
     q, _ = ops.pw_wgrad(xr, dy, N=2, rows_per_sample=12 ** 3, c_in=32, c_out=64, want_bias=False, defer=d1, in_major=True)
     d0.flush(); d1.flush()
     assert q.shape == (32, 64) and torch.equal(q, p.t())
+
+
+@pytest.mark.parametrize("dt,C", [(torch.bfloat16, 32), (torch.bfloat16, 8), (torch.float32, 4), (torch.bfloat16, 12)])
+def test_copy_with_zeroed_front_faces(dt, C):
+    """pytc_copy_zero_front (the output gradient an up block's mixer sees) against clone + three slice fills; C = 12 bf16 is not a
+    multiple of 16 bytes per voxel and takes the torch form."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    x = torch.randn(2, 5, 6, 7, C, generator=torch.Generator().manual_seed(5)).cuda().to(dt)
+    ref = x.clone()
+    ref[:, 0] = 0
+    ref[:, :, 0] = 0
+    ref[:, :, :, 0] = 0
+    got = ops.copy_zero_front(x)
+    assert got.data_ptr() != x.data_ptr() and torch.equal(got, ref)
+
+
+def test_skip_gradient_joins_the_down_blocks_data_gradient(monkeypatch):
+    """FUSE_SKIP_GRAD: the up block leaves the skip connection's gradient in the level's mailbox and the down block adds it inside
+    pytc_dwconv3d_bwd_data_add (fp32 sum, one rounding) -- against autograd's own accumulation (two roundings): every parameter
+    gradient agrees to bf16 rounding, and the kernel itself equals conv^T(dy) + add."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    from pytorch_connectomics_amd.models.architectures.mednext import MedNeXt
+    from pytorch_connectomics_amd.training import autograd as AG
+    g = torch.Generator().manual_seed(2)
+    dy = torch.randn(2, 6, 6, 6, 16, generator=g).cuda().bfloat16()
+    add = torch.randn(2, 12, 12, 12, 16, generator=g).cuda().bfloat16()
+    taps = torch.randn(27, 16, generator=g).cuda()
+    plain = ops.dwconv3d_bwd_data(dy, taps, (12, 12, 12), K=3, stride=2)
+    fused = ops.dwconv3d_bwd_data(dy, taps, (12, 12, 12), K=3, stride=2, add=add)
+    assert (fused.float() - (plain.float() + add.float())).abs().max() <= 2.0 ** -7 * (plain.float() + add.float()).abs().max()
+
+    def run(flag):
+        monkeypatch.setattr(AG, "FUSE_SKIP_GRAD", flag)
+        torch.manual_seed(0)
+        m = MedNeXt(1, 16, 2, exp_r=2, kernel_size=3, do_res=True, do_res_up_down=True, block_counts=[1] * 9).cuda().train()
+        m.compute_dtype = torch.bfloat16
+        gg = torch.Generator().manual_seed(1)
+        x = torch.rand(2, 1, 32, 32, 32, generator=gg).cuda()
+        y = (torch.rand(2, 2, 32, 32, 32, generator=gg) > 0.7).float().cuda()
+        with ops.profiled() as prof:
+            F.binary_cross_entropy_with_logits(m(x), y).backward()
+        fused_launches = sum(v["launches"] for k, v in prof.summary().items() if k.endswith("+add"))
+        return {k: p.grad.detach().float().clone() for k, p in m.named_parameters() if p.grad is not None}, fused_launches
+
+    g1, n1 = run(True)
+    g0, n0 = run(False)
+    assert n1 == 4 and n0 == 0            # one fused launch per level
+    for k in g0:
+        if k.endswith("conv1.bias"):      # a depthwise bias in front of GroupNorm(C, C): its gradient is zero, both runs hold rounding noise
+            continue
+        den = g0[k].norm().item() + 1e-12
+        assert (g1[k] - g0[k]).norm().item() / den < 2e-2, k
+        assert torch.nn.functional.cosine_similarity(g1[k].flatten(), g0[k].flatten(), dim=0) > 0.999, k
