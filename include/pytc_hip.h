@@ -24,8 +24,10 @@ extern "C" {
 #endif
 
 /* 2 (round 5): pytc_mlp_args.per_sample (added in round 4 without a bump: ADVICE r04), pytc_dwconv3d_fwd with y = NULL, pytc_dwmix_*.
+ * 4 (round 6): pytc_reduce_item.out_t (in the struct's former padding: a caller built against 3 may pass garbage there),
+ * pytc_copy_zero_front, pytc_dwconv3d_bwd_data_add, pytc_pw_wgrad_groupnorm leaves the per-sample terms in the partials region at sps == 1.
  * Bumped whenever a struct layout or the meaning of an argument changes; _native.py refuses a library of another version. */
-#define PYTC_ABI_VERSION 3
+#define PYTC_ABI_VERSION 4
 
 #define PYTC_OK 0
 #define PYTC_ERR_INVALID 1     /* bad argument (shape, dtype, alignment) */

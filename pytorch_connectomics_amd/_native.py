@@ -11,7 +11,7 @@ import os
 from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libpytc_hip.so"
-ABI_VERSION = 3          # include/pytc_hip.h PYTC_ABI_VERSION
+ABI_VERSION = 4          # include/pytc_hip.h PYTC_ABI_VERSION
 
 F32, BF16 = 0, 1
 OK = 0
