@@ -30,8 +30,9 @@ FUSED_TRAIN_MIXER = True
 # levels of a 112^3 patch run it on 86 / 686 workgroups that each stream BOTH weight images; below this many rows (N * voxels) the
 # two single GEMMs, which also share out their output channels (pw_fast_kernels.hip: blockIdx.z), are faster
 FUSED_TRAIN_MIXER_MIN_ROWS = int(os.environ.get("PYTC_FUSED_MIXER_MIN_ROWS", "16384"))
-# ... and only below this hidden width: a 64-row workgroup of the fused mixer streams BOTH weight images (256 -> 512 -> 128: 384 KB per 64 rows)
-FUSED_TRAIN_MIXER_MAX_HID = int(os.environ.get("PYTC_FUSED_MIXER_MAX_HID", "1000000"))
+# ... and only below this hidden width: a 64-row workgroup of the fused mixer streams BOTH weight images (256 -> 512 -> 128: 384 KB per 64
+# rows; the up block at 28^3 ran 233 us fused against ~140 as two GEMMs: 21.95 -> 21.82 ms per 4 x 112^3 step; 256: 21.95)
+FUSED_TRAIN_MIXER_MAX_HID = int(os.environ.get("PYTC_FUSED_MIXER_MAX_HID", "512"))
 # the two data-gradient GEMMs of the mixer as one launch (pytc_pw_mlp_bwd): bit-identical results and 25 % less traffic,
 # but measured slower than the two launches it replaces (503 vs ~440 us at 4x112^3, level 0: the exact GELU' between the
 # GEMMs sits on the MFMA critical path instead of in a store epilogue) -> off
