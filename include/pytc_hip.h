@@ -714,6 +714,9 @@ int pytc_act_norm_bwd_stats(const void* da, const void* x, const float* ab, cons
                             float* p_ws, float* p_out, int N, int64_t rows, int C, int act, float prm, int dtype, void* stream);
 int pytc_act_norm_bwd_apply(const void* da, const void* x, const float* ab, const float* mean_rstd, const float* gamma,
                             const float* M, void* dx, int N, int64_t rows, int C, int act, float prm, int dtype, void* stream);
+/* the same with gamma holding C_gamma <= C entries (the norm's own channels next to channel-padded activations: no padded copy of gamma) */
+int pytc_act_norm_bwd_apply_cg(const void* da, const void* x, const float* ab, const float* mean_rstd, const float* gamma, int C_gamma,
+                               const float* M, void* dx, int N, int64_t rows, int C, int act, float prm, int dtype, void* stream);
 int pytc_maxpool3d_bwd(const void* x, const void* dy, void* dx, int N, int D, int H, int W, int C, int fz, int fy, int fx,
                        int dtype, void* stream);
 int pytc_dwconv3d_generic_fwd(const void* x, void* y, const float* w, int N, int D, int H, int W, int C,

@@ -189,6 +189,7 @@ _SIGS = {
                                       C.c_int, C.c_void_p]),
     "pytc_act_norm_bwd_stats": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "pytc_act_norm_bwd_apply": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "pytc_act_norm_bwd_apply_cg": (C.c_int, [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 2 + [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "pytc_norm_bwd_apply_general": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                               C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "pytc_maxpool3d_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

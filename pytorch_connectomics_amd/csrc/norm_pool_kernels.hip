@@ -62,7 +62,23 @@ norm_finalize_groups_kernel(const float* __restrict__ stats, int slots, float co
   }
   float a1 = 0.f, a2 = 0.f;
   const float* base = stats + (long)n * slots * 2 * C;
-  for (long i = threadIdx.x; i < (long)slots * cpg; i += blockDim.x) {
+  // same order of additions as the plain loop, eight slot rows in flight per thread (1 024 slots x 6 channels were 24 dependent round
+  // trips: 15 us for a launch that moves 50 KB; RSUNet runs 37 of them per training step)
+  const long total = (long)slots * cpg;
+  long i = threadIdx.x;
+  for (; i + 7L * blockDim.x < total; i += 8L * blockDim.x) {
+    float v1[8], v2[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long j = i + (long)u * blockDim.x;
+      const int s = (int)(j / cpg), c = g * cpg + (int)(j % cpg);
+      v1[u] = base[((long)s * 2 + 0) * C + c];
+      v2[u] = base[((long)s * 2 + 1) * C + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a1 += v1[u]; a2 += v2[u]; }
+  }
+  for (; i < total; i += blockDim.x) {
     const int s = (int)(i / cpg), c = g * cpg + (int)(i % cpg);
     a1 += base[((long)s * 2 + 0) * C + c];
     a2 += base[((long)s * 2 + 1) * C + c];

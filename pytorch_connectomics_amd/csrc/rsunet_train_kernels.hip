@@ -543,7 +543,8 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 act_norm_bwd_apply_kernel(const T* __restrict__ da, const T* __restrict__ x, const float* __restrict__ ab,
                           const float* __restrict__ mr, const float* __restrict__ gamma, const float* __restrict__ M,
-                          T* __restrict__ dx, long rows, int C, long rows_per_slot, int act, float prm) {
+                          T* __restrict__ dx, long rows, int C, long rows_per_slot, int act, float prm, int C_gamma) {
+  // C_gamma: entries of gamma (the norm's own channels); the channels from there on are alignment padding and take gamma = 0
   constexpr int EPV = 16 / (int)sizeof(T);
   const int n = blockIdx.y, slot = blockIdx.x;
   const long r0 = (long)slot * rows_per_slot;
@@ -561,7 +562,7 @@ act_norm_bwd_apply_kernel(const T* __restrict__ da, const T* __restrict__ x, con
     for (int i = 0; i < EPV; ++i) {
       mean[i] = mr[((long)n * 2 + 0) * C + c + i];
       rstd[i] = mr[((long)n * 2 + 1) * C + c + i];
-      g[i] = gamma ? gamma[c + i] : 1.f;
+      g[i] = gamma ? (c + i < C_gamma ? gamma[c + i] : 0.f) : 1.f;
       m1[i] = M[((long)n * 2 + 0) * C + c + i];
       m2[i] = M[((long)n * 2 + 1) * C + c + i];
       av[i] = ab ? ab[((long)n * 2 + 0) * C + c + i] : 1.f;
@@ -999,9 +1000,25 @@ extern "C" int pytc_act_norm_bwd_stats(const void* da, const void* x, const floa
 }
 
 /* act_bwd + norm_bwd_apply_general without the intermediate dt: dx = rstd * (gamma * dt - M1 - xhat * M2) */
+static int act_norm_bwd_apply_impl(const void* da, const void* x, const float* ab, const float* mean_rstd, const float* gamma, int C_gamma,
+                                   const float* M, void* dx, int N, int64_t rows, int C, int act, float prm, int dtype, void* stream);
+
 extern "C" int pytc_act_norm_bwd_apply(const void* da, const void* x, const float* ab, const float* mean_rstd, const float* gamma,
                                        const float* M, void* dx, int N, int64_t rows, int C, int act, float prm, int dtype,
                                        void* stream) {
+  return act_norm_bwd_apply_impl(da, x, ab, mean_rstd, gamma, C, M, dx, N, rows, C, act, prm, dtype, stream);
+}
+
+/* gamma holds C_gamma <= C entries (the norm's own channels next to channel-padded activations); the padding takes gamma = 0 */
+extern "C" int pytc_act_norm_bwd_apply_cg(const void* da, const void* x, const float* ab, const float* mean_rstd, const float* gamma,
+                                          int C_gamma, const float* M, void* dx, int N, int64_t rows, int C, int act, float prm, int dtype,
+                                          void* stream) {
+  PYTC_REQUIRE(C_gamma >= 0 && C_gamma <= C, "act_norm_bwd_apply: C_gamma = %d outside [0, %d]", C_gamma, C);
+  return act_norm_bwd_apply_impl(da, x, ab, mean_rstd, gamma, C_gamma, M, dx, N, rows, C, act, prm, dtype, stream);
+}
+
+static int act_norm_bwd_apply_impl(const void* da, const void* x, const float* ab, const float* mean_rstd, const float* gamma, int C_gamma,
+                                   const float* M, void* dx, int N, int64_t rows, int C, int act, float prm, int dtype, void* stream) {
   PYTC_REQUIRE(da && x && mean_rstd && M && dx, "act_norm_bwd_apply: null pointer");
   PYTC_REQUIRE((dtype == PYTC_BF16 && C % 8 == 0) || (dtype == PYTC_F32 && C % 4 == 0), "act_norm_bwd_apply: C %% (16 bytes) != 0");
   const int slots = act_norm_slots(rows, C, dtype == PYTC_BF16 ? 8 : 4);
@@ -1009,9 +1026,9 @@ extern "C" int pytc_act_norm_bwd_apply(const void* da, const void* x, const floa
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(slots, N), block(256);
   if (dtype == PYTC_BF16)
-    hipLaunchKernelGGL(act_norm_bwd_apply_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)da, (const bf16_t*)x, ab, mean_rstd, gamma, M, (bf16_t*)dx, (long)rows, C, rps, act, prm);
+    hipLaunchKernelGGL(act_norm_bwd_apply_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)da, (const bf16_t*)x, ab, mean_rstd, gamma, M, (bf16_t*)dx, (long)rows, C, rps, act, prm, C_gamma);
   else
-    hipLaunchKernelGGL(act_norm_bwd_apply_kernel<float>, grid, block, 0, s, (const float*)da, (const float*)x, ab, mean_rstd, gamma, M, (float*)dx, (long)rows, C, rps, act, prm);
+    hipLaunchKernelGGL(act_norm_bwd_apply_kernel<float>, grid, block, 0, s, (const float*)da, (const float*)x, ab, mean_rstd, gamma, M, (float*)dx, (long)rows, C, rps, act, prm, C_gamma);
   PYTC_LAUNCH_CHECK("act_norm_bwd_apply");
   return PYTC_OK;
 }

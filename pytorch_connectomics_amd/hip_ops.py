@@ -1403,8 +1403,9 @@ def act_norm_bwd_apply(da: torch.Tensor, x: torch.Tensor, ab: Optional[torch.Ten
     N, Cc = x.shape[0], x.shape[-1]
     rows = x.numel() // (N * Cc)
     dx = torch.empty_like(x)
-    _run(f"act_norm_bwd_apply[C{Cc}]", _nbytes(da, x, dx), nat.lib().pytc_act_norm_bwd_apply, _p(da), _p(x), _p(ab), _p(mean_rstd),
-         _p(gamma), _p(M), _p(dx), N, rows, Cc, int(act), float(prm), dtype_code(x.dtype), _stream())
+    cg = Cc if gamma is None else int(gamma.numel())      # fewer entries than channels: the rest of x is alignment padding (gamma = 0 there)
+    _run(f"act_norm_bwd_apply[C{Cc}]", _nbytes(da, x, dx), nat.lib().pytc_act_norm_bwd_apply_cg, _p(da), _p(x), _p(ab), _p(mean_rstd),
+         _p(gamma), cg, _p(M), _p(dx), N, rows, Cc, int(act), float(prm), dtype_code(x.dtype), _stream())
     return dx
 
 

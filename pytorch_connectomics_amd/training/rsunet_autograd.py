@@ -165,8 +165,11 @@ class NormActFn(torch.autograd.Function):
         # of x get it zero-extended, the parameter gradients are the leading c_real entries
         c_real = int(gamma.numel()) if has_g else C
         cpg = (c_real // groups) if (mode == "group" and c_real != C) else 0
-        g32 = _padded_vec(_f(gamma), C) if has_g else None
         grp = 0 if mode == "batch" else (groups if mode == "group" else c_real)
+        # the fused pair below takes the norm's own gamma next to padded activations (norm_bwd_means with groups reads the real channels only,
+        # act_norm_bwd_apply_cg zero-extends in the kernel): no padded copy per backward (a fill + a copy launch, 36 times per RSUNet step)
+        unpadded_ok = FUSED_ACT_NORM_BWD and grp > 0 and mode in ("group", "instance") and da.dtype == x.dtype and ops.act_norm_bwd_supported(x)
+        g32 = (_f(gamma) if unpadded_ok else _padded_vec(_f(gamma), C)) if has_g else None
         if mode == "instance" and c_real != C:
             cpg = 1
         cast = lambda v, like: None if v is None else v[:like.numel()].to(like.dtype).reshape(like.shape)      # noqa: E731
