@@ -313,12 +313,18 @@ typedef struct {
   int pre_act;          /* PYTC_ACT_NONE or PYTC_ACT_GELU applied to f(x) BEFORE the GEMM (the stored tensor is the
                          * pre-activation; training keeps only that one copy of the expanded tensor) */
   int w_paired;         /* 0: w_packed from pytc_pw_pack_weight; 1: from pytc_pw_pack_weight_paired (bf16) -- selects
-                         * the 16-byte-store kernel; allowed only when pytc_pw_conv_paired_supported(a) != 0 */
+                         * the 16-byte-store kernel; allowed only when pytc_pw_conv_paired_supported(a) != 0;
+                         * 2 (round 6): w_packed is the plain row-major bf16 matrix [C_out][C_in] (the conv weight cast, or its transpose
+                         * for a data gradient) and the launch is the LDS-tiled GEMM of pytc_pw_gemm_fwd with every prologue (ab, pre_act)
+                         * and epilogue (res_mode incl. PYTC_RES_GELU_BWD / PYTC_RES_NORM_BWD) of the paired-row kernel: the deep levels
+                         * of the training step; allowed only when pytc_pw_conv_rowmajor_supported(a) != 0 */
 } pytc_pw_args;
 
 int pytc_pw_conv_fwd(const pytc_pw_args* a, void* stream);
 /* 1 when the shape / dtypes / modes in `a` are covered by the paired-row kernel (pointers are not inspected) */
 int pytc_pw_conv_paired_supported(const pytc_pw_args* a);
+/* 1 when they are covered by the row-major LDS-tiled GEMM (w_paired = 2): bf16, C_in % 64 == 0, C_out % 128 == 0, no gather, no activation */
+int pytc_pw_conv_rowmajor_supported(const pytc_pw_args* a);
 
 /* Fused MedNeXt channel mixer (bf16 activations):
  *     y = W3 * gelu( W2 * (a*t + b) + b2 ) + b3   (+ residual per res_mode, as in pytc_pw_conv_fwd)

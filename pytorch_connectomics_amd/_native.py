@@ -124,6 +124,7 @@ _SIGS = {
                                         C.c_void_p, C.c_void_p]),
     "pytc_pw_conv_fwd": (C.c_int, [C.POINTER(PwArgs), C.c_void_p]),
     "pytc_pw_conv_paired_supported": (C.c_int, [C.POINTER(PwArgs)]),
+    "pytc_pw_conv_rowmajor_supported": (C.c_int, [C.POINTER(PwArgs)]),
     "pytc_conv3d_packed_elems": (C.c_int64, [C.c_int] * 6),
     "pytc_conv3d_pack_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                           C.c_void_p]),

@@ -27,6 +27,8 @@ struct GemmParams {
   EpiParams e;                // plain epilogue: bf16 output with the residual variants of finish_and_store
   long rps, rows_total;
   int C_in, C_out, gelu;
+  int pre_gelu;               // bf16 operand: x <- bf16(gelu_fast(x)) while staging (the training forward's projecting conv reads the
+                              // stored pre-activation; the same function pw_fast_kernel applies and the weight-gradient kernels recompute)
 };
 
 constexpr int GEMM_BN = 128;            // output channels per workgroup
@@ -35,7 +37,11 @@ constexpr int GEMM_KS = 64;             // k per staged step = two 16x16x32 MFMA
 // KS = 32 (round 5): half the LDS per workgroup (41 KB at BR = 128, 31 KB at BR = 64) -> 3 / 4 workgroups per CU instead of 2.  These launches
 // are latency bound, not MFMA bound (256 -> 2048 on 16 000 rows: a workgroup lives 12 us for 0.85 us of MFMAs -- every k step exposes a global
 // load round trip that one step of compute cannot cover), so resident workgroups are what hides it.  Same k order: bit-identical.
-template <bool F16, int BR, int KS = GEMM_KS>     // F16: fp16 operands (the projecting conv); BR rows per workgroup (64 or 128)
+// BWD (round 6: the deep-level GEMMs of the TRAINING step -- expand with the stored bf16 pre-activation as output, project with the GELU
+// in its operand prologue, and the two data-gradient GEMMs): the epilogue keeps finish_and_store's PYTC_RES_GELU_BWD / PYTC_RES_NORM_BWD
+// branches, the bias may be null.  pw_fast_kernel, which served these launches, keeps a wave's whole operand tile in registers and streams
+// EVERY weight fragment from L2 per 16-64 rows: 1024 -> 512 on 1 372 rows ran 43 us = 33 TFLOP/s.
+template <bool F16, int BR, int KS = GEMM_KS, bool BWD = false>     // F16: fp16 operands (the projecting conv); BR rows per workgroup (64 or 128)
 __global__ void __launch_bounds__(256, KS == 32 ? (BR == 64 ? 4 : 3) : 2)
 pw_gemm_lds_kernel(GemmParams p) {
   constexpr int GEMM_KS = KS;
@@ -109,13 +115,21 @@ pw_gemm_lds_kernel(GemmParams p) {
     for (int i = 0; i < B_CHUNKS; ++i) {
       q4_t v = rb[i];
       if constexpr (!F16) {
-        if (affine) {              // GroupNorm affine in fp32, rounded to bf16: what the fused mixer's prologue does
+        if (affine || (BWD && p.pre_gelu)) {   // GroupNorm affine in fp32, rounded to bf16: what the fused mixer's prologue does
           float f[8];
           VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(&v), f);
+          if (affine) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            f[j] = fmaf(f[j], rab[i][0][j], rab[i][2][j]);
-            f[4 + j] = fmaf(f[4 + j], rab[i][1][j], rab[i][3][j]);
+            for (int j = 0; j < 4; ++j) {
+              f[j] = fmaf(f[j], rab[i][0][j], rab[i][2][j]);
+              f[4 + j] = fmaf(f[4 + j], rab[i][1][j], rab[i][3][j]);
+            }
+          }
+          if constexpr (BWD) {
+            if (p.pre_gelu) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) f[j] = gelu_fast(f[j]);
+            }
           }
           v = __builtin_bit_cast(q4_t, Mma<bf16_t>::from_floats(f));
         }
@@ -128,10 +142,12 @@ pw_gemm_lds_kernel(GemmParams p) {
   f32x4_t acc[MT][NT];
 #pragma unroll
   for (int pr = 0; pr < MT / 2; ++pr) {
-    float b[8];
+    float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int ch = o0 + wm * 64 + pr * 32 + kb * 8;
-    VecIO<float, 4>::load(p.bias + ch, reinterpret_cast<float(&)[4]>(b[0]));
-    VecIO<float, 4>::load(p.bias + ch + 4, reinterpret_cast<float(&)[4]>(b[4]));
+    if (!BWD || p.bias) {
+      VecIO<float, 4>::load(p.bias + ch, reinterpret_cast<float(&)[4]>(b[0]));
+      VecIO<float, 4>::load(p.bias + ch + 4, reinterpret_cast<float(&)[4]>(b[4]));
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       acc[2 * pr][nt] = f32x4_t{b[0], b[1], b[2], b[3]};
@@ -190,9 +206,35 @@ pw_gemm_lds_kernel(GemmParams p) {
         *reinterpret_cast<h8_t*>(p.yh + row * p.C_out + ch) = g;
       } else {
         const int n = (int)(row / p.rps);
-        finish_and_store<bf16_t, 8>(v, p.e, n, row - (long)n * p.rps, ch);
+        finish_and_store<bf16_t, 8, BWD>(v, p.e, n, row - (long)n * p.rps, ch);
       }
     }
+  }
+}
+
+// pytc_pw_conv_fwd with w_paired == 2: the weight is a plain row-major bf16 [C_out][C_in] matrix and the launch is this kernel (bf16 in / out)
+bool pw_gemm_rowmajor_supported(const pytc_pw_args* a) {
+  return a->in_dtype == PYTC_BF16 && a->out_dtype == PYTC_BF16 && a->w_dtype == PYTC_BF16 && a->C_in % GEMM_KS == 0 && a->C_in >= GEMM_KS &&
+         a->C_out % GEMM_BN == 0 && a->C_out >= GEMM_BN && a->gather == 0 && a->act == PYTC_ACT_NONE;
+}
+
+void pw_gemm_rowmajor_launch(const pytc_pw_args* a, const EpiParams& e, hipStream_t s) {
+  GemmParams p{};
+  p.x = (const unsigned short*)a->x; p.w = (const unsigned short*)a->w_packed; p.bias = a->bias; p.ab = a->ab;
+  p.yh = nullptr; p.e = e;
+  p.rps = a->rows_per_sample; p.rows_total = (long)a->N * a->rows_per_sample; p.C_in = a->C_in; p.C_out = a->C_out; p.gelu = 0;
+  p.pre_gelu = a->pre_act == PYTC_ACT_GELU ? 1 : 0;
+  const long tiles128 = (p.rows_total + 127) / 128 * (a->C_out / GEMM_BN);
+  const bool big = tiles128 >= 512;
+  const bool ks32 = a->C_in <= 512;
+  if (big) {
+    dim3 grid((unsigned)((p.rows_total + 127) / 128 * (a->C_out / GEMM_BN)));
+    if (ks32) hipLaunchKernelGGL((pw_gemm_lds_kernel<false, 128, 32, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((pw_gemm_lds_kernel<false, 128, GEMM_KS, true>), grid, dim3(256), 0, s, p);
+  } else {
+    dim3 grid((unsigned)((p.rows_total + 63) / 64 * (a->C_out / GEMM_BN)));
+    if (ks32) hipLaunchKernelGGL((pw_gemm_lds_kernel<false, 64, 32, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((pw_gemm_lds_kernel<false, 64, GEMM_KS, true>), grid, dim3(256), 0, s, p);
   }
 }
 

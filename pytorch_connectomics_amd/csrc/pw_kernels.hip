@@ -214,12 +214,15 @@ static void launch_pw(const PwParams& p, int MT, hipStream_t s) {
 
 bool pw_fast_supported(const pytc_pw_args* a);
 void pw_fast_launch(const pytc_pw_args* a, const EpiParams& e, hipStream_t s);
+bool pw_gemm_rowmajor_supported(const pytc_pw_args* a);          // pw_gemm_kernels.hip
+void pw_gemm_rowmajor_launch(const pytc_pw_args* a, const EpiParams& e, hipStream_t s);
 
 }  // namespace pytc
 
 using namespace pytc;
 
 extern "C" int pytc_pw_conv_paired_supported(const pytc_pw_args* a) { return a && pw_fast_supported(a) ? 1 : 0; }
+extern "C" int pytc_pw_conv_rowmajor_supported(const pytc_pw_args* a) { return a && pw_gemm_rowmajor_supported(a) ? 1 : 0; }
 
 static int kstep_of(int dtype) { return dtype == PYTC_BF16 ? 32 : 16; }
 
@@ -305,6 +308,14 @@ extern "C" int pytc_pw_conv_fwd(const pytc_pw_args* a, void* stream) {
     const long work = rows_total * (a->C_in / 8);
     if (to == PYTC_F32) hipLaunchKernelGGL((pw_head_kernel<bf16_t, float>), dim3(ceil_div(work, 256)), dim3(256), 0, s, (const bf16_t*)a->x, (const bf16_t*)a->w_packed, a->bias, (float*)a->y, rows_total, a->C_in, a->act);
     else hipLaunchKernelGGL((pw_head_kernel<bf16_t, bf16_t>), dim3(ceil_div(work, 256)), dim3(256), 0, s, (const bf16_t*)a->x, (const bf16_t*)a->w_packed, a->bias, (bf16_t*)a->y, rows_total, a->C_in, a->act);
+    PYTC_LAUNCH_CHECK("pw_conv");
+    return PYTC_OK;
+  }
+  if (a->w_paired == 2) {
+    // plain row-major bf16 weight matrix [C_out][C_in]: the LDS-tiled GEMM (pw_gemm_kernels.hip), every prologue / epilogue of the paired-row kernel
+    PYTC_REQUIRE(pw_gemm_rowmajor_supported(a), "pw_conv: w_paired = 2 (row-major weights, LDS-tiled GEMM) needs bf16, C_in %% 64 == 0, C_out %% 128 == 0, "
+                 "no gather, no activation (got %d -> %d)", a->C_in, a->C_out);
+    pw_gemm_rowmajor_launch(a, p.e, s);
     PYTC_LAUNCH_CHECK("pw_conv");
     return PYTC_OK;
   }

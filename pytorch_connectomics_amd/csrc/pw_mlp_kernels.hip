@@ -625,6 +625,7 @@ pw_pack_paired_kernel(const float* __restrict__ w, int C_out, int C_in, int tran
 // table [n_items][8] int64: {src fp32, dst, kind, C_out, C_in, aux, first element, element count}
 //   kind 0 / 1: paired bf16 image of [C_out][C_in] / of a transposed source;  2 / 3: the same as fp16
 //   kind 4: depthwise taps [C][K3] -> [K3][C] fp32 (aux = K3, C_out = C);      5: the same with the stencil reversed
+//   kind 6 / 7: plain row-major bf16 [C_out][C_in] of the matrix / of a transposed source (pytc_pw_conv_fwd with w_paired = 2)
 __global__ void __launch_bounds__(256)
 pack_multi_kernel(const long* __restrict__ table, int n_items, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -648,6 +649,11 @@ pack_multi_kernel(const long* __restrict__ table, int n_items, long total) {
   const float* w = reinterpret_cast<const float*>(it[0]);
   const int kind = (int)it[2], C_out = (int)it[3], C_in = (int)it[4], aux = (int)it[5];
   const long e = i - it[6];
+  if (kind >= 6) {      // 6 / 7: plain row-major bf16 [C_out][C_in] of the matrix / of a transposed source (the LDS-tiled GEMM's weights)
+    const int o = (int)(e / C_in), k = (int)(e % C_in);
+    reinterpret_cast<bf16_t*>(it[1])[e] = from_f32<bf16_t>(kind == 7 ? w[(long)k * C_out + o] : w[e]);
+    return;
+  }
   if (kind >= 4) {
     const int K3 = aux, C = C_out;
     const int k = (int)(e / C), c = (int)(e % C);

@@ -445,7 +445,7 @@ def pw_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
             act: int = nat.ACT_NONE, res: Optional[torch.Tensor] = None, res_mode: int = nat.RES_NONE,
             gather: int = 0, grid: Sequence[int] = (0, 0, 0), res_low: Optional[torch.Tensor] = None,
             res_bias: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None,
-            pre_act: int = nat.ACT_NONE, w_paired: bool = False) -> torch.Tensor:
+            pre_act: int = nat.ACT_NONE, w_paired=False) -> torch.Tensor:
     _dev(x, "x"); _dev(w_packed, "w_packed")
     if y is None:
         y = torch.empty((N, rows_per_sample, c_out), dtype=out_dtype, device=x.device)
@@ -462,7 +462,8 @@ def pw_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
     a.res_bias = res_bias.data_ptr() if res_bias is not None else None
     rows_in = N * rows_per_sample * c_in * x.element_size()    # algorithmic: each operand once
     nb = rows_in + _nbytes(y) + (_nbytes(y) if res is not None else 0)
-    _run(f"pw_conv_fwd[{c_in}->{c_out}]", nb, nat.lib().pytc_pw_conv_fwd, C.byref(a), _stream())
+    _run(f"pw_conv_fwd[{c_in}->{c_out}]", nb, nat.lib().pytc_pw_conv_fwd, C.byref(a), _stream(),
+         **({"symbol": "pw_gemm_lds_kernel"} if int(w_paired) == 2 else {}))
     return y
 
 
@@ -512,7 +513,7 @@ def pw_pack_weight_paired(w: torch.Tensor, *, transposed: bool = False, f16: boo
     return packed
 
 
-PACK_PAIRED, PACK_PAIRED_T, PACK_PAIRED_F16, PACK_PAIRED_F16_T, PACK_TAPS, PACK_TAPS_FLIPPED = range(6)
+PACK_PAIRED, PACK_PAIRED_T, PACK_PAIRED_F16, PACK_PAIRED_F16_T, PACK_TAPS, PACK_TAPS_FLIPPED, PACK_ROWMAJOR, PACK_ROWMAJOR_T = range(8)
 
 
 class StepPacks:
@@ -574,6 +575,33 @@ def packed_paired(w_mat: torch.Tensor, *, transposed: bool = False, f16: bool = 
     c_out, c_in = (w_mat.shape[1], w_mat.shape[0]) if transposed else (w_mat.shape[0], w_mat.shape[1])
     packs.register(w_mat, kind, out, c_out, c_in, (c_in + 31) // 32)
     return out
+
+
+def packed_rowmajor(w_mat: torch.Tensor, *, transposed: bool = False, packs: Optional[StepPacks] = None) -> torch.Tensor:
+    """The plain row-major bf16 matrix [C_out][C_in] of a 1x1x1 conv weight (its transpose for a data gradient): the weights of
+    pw_conv(w_paired=2), through a StepPacks set when given (one pack launch per step for the whole model)."""
+    kind = PACK_ROWMAJOR_T if transposed else PACK_ROWMAJOR
+    if packs is not None:
+        hit = packs.lookup(w_mat, kind)
+        if hit is not None:
+            return hit
+    out = (w_mat.t() if transposed else w_mat).to(torch.bfloat16).contiguous()
+    if packs is not None:
+        c_out, c_in = (w_mat.shape[1], w_mat.shape[0]) if transposed else (w_mat.shape[0], w_mat.shape[1])
+        packs.register(w_mat, kind, out, c_out, c_in, 0)
+    return out
+
+
+def pw_conv_rowmajor_supported(*, c_in: int, c_out: int, in_dtype: torch.dtype, out_dtype: torch.dtype, act: int = nat.ACT_NONE,
+                               gather: int = 0) -> bool:
+    """True when pw_conv may run on the LDS-tiled GEMM with packed_rowmajor weights (w_paired=2)."""
+    a = nat.PwArgs()
+    a.C_in, a.C_out, a.act, a.gather = int(c_in), int(c_out), int(act), int(gather)
+    try:
+        a.in_dtype, a.out_dtype, a.w_dtype = dtype_code(in_dtype), dtype_code(out_dtype), dtype_code(torch.bfloat16)
+    except Exception:
+        return False
+    return bool(nat.lib().pytc_pw_conv_rowmajor_supported(C.byref(a)))
 
 
 def packed_taps(w: torch.Tensor, *, flipped: bool = False, packs: Optional[StepPacks] = None) -> torch.Tensor:

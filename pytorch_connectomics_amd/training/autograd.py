@@ -33,6 +33,9 @@ FUSED_TRAIN_MIXER_MIN_ROWS = int(os.environ.get("PYTC_FUSED_MIXER_MIN_ROWS", "16
 # ... and only below this hidden width: a 64-row workgroup of the fused mixer streams BOTH weight images (256 -> 512 -> 128: 384 KB per 64
 # rows; the up block at 28^3 ran 233 us fused against ~140 as two GEMMs: 21.95 -> 21.82 ms per 4 x 112^3 step; 256: 21.95)
 FUSED_TRAIN_MIXER_MAX_HID = int(os.environ.get("PYTC_FUSED_MIXER_MAX_HID", "512"))
+# single 1x1x1 GEMMs (expand / project / data gradients) with at most this many voxel rows in the batch and C_in % 64 == C_out % 128 == 0 run
+# on the LDS-tiled GEMM (pytc_pw_conv_fwd, w_paired = 2) instead of the paired-row kernel; 0 = off
+TRAIN_GEMM_MAX_ROWS = int(os.environ.get("PYTC_TRAIN_GEMM_MAX_ROWS", "100000"))
 # the two data-gradient GEMMs of the mixer as one launch (pytc_pw_mlp_bwd): bit-identical results and 25 % less traffic,
 # but measured slower than the two launches it replaces (503 vs ~440 us at 4x112^3, level 0: the exact GELU' between the
 # GEMMs sits on the MFMA critical path instead of in a store epilogue) -> off
@@ -167,9 +170,16 @@ def _pw(x, w_mat, bias, *, c_out, out_dtype=None, transposed=False, packs=None, 
     paired = wdt == torch.bfloat16 and ops.pw_conv_paired_supported(
         c_in=x.shape[-1], c_out=c_out, in_dtype=x.dtype, out_dtype=odt, act=kw.get("act", nat.ACT_NONE),
         gather=kw.get("gather", 0))
-    wp = ops.packed_paired(w_mat, transposed=transposed, packs=packs) if paired else ops.pw_pack_weight(w_mat, wdt, transposed=transposed)
     N = x.shape[0]
     rows = kw.pop("rows", None) or x.numel() // (N * x.shape[-1])
+    # deep levels (few voxel rows, wide channels): the LDS-tiled GEMM on plain row-major weights instead of the paired-row kernel, which
+    # streams every weight fragment from L2 per 16-64 rows (TRAIN_GEMM_MAX_ROWS; same prologues / epilogues through pytc_pw_conv_fwd)
+    if (paired and TRAIN_GEMM_MAX_ROWS and N * rows <= TRAIN_GEMM_MAX_ROWS and x.dtype == torch.bfloat16 and odt == torch.bfloat16
+            and ops.pw_conv_rowmajor_supported(c_in=x.shape[-1], c_out=c_out, in_dtype=x.dtype, out_dtype=odt,
+                                               act=kw.get("act", nat.ACT_NONE), gather=kw.get("gather", 0))):
+        wp = ops.packed_rowmajor(w_mat, transposed=transposed, packs=packs)
+        return ops.pw_conv(x, wp, bias, N=N, rows_per_sample=rows, c_in=x.shape[-1], c_out=c_out, out_dtype=odt, w_paired=2, **kw)
+    wp = ops.packed_paired(w_mat, transposed=transposed, packs=packs) if paired else ops.pw_pack_weight(w_mat, wdt, transposed=transposed)
     y = ops.pw_conv(x, wp, bias, N=N, rows_per_sample=rows, c_in=x.shape[-1], c_out=c_out,
                     out_dtype=odt, w_paired=paired, **kw)
     return y

@@ -1161,3 +1161,53 @@ def test_skip_gradient_joins_the_down_blocks_data_gradient(monkeypatch):
         den = g0[k].norm().item() + 1e-12
         assert (g1[k] - g0[k]).norm().item() / den < 2e-2, k
         assert torch.nn.functional.cosine_similarity(g1[k].flatten(), g0[k].flatten(), dim=0) > 0.999, k
+
+
+@pytest.mark.parametrize("c_in,c_out,rows,N", [(256, 512, 2744, 2), (1024, 512, 343, 4), (512, 128, 5000, 1), (128, 256, 21952, 2)])
+def test_rowmajor_gemm_route_of_pw_conv_matches_the_paired_row_kernel(c_in, c_out, rows, N):
+    """pytc_pw_conv_fwd with w_paired = 2 (plain row-major bf16 weights, LDS-tiled GEMM: the deep levels of the training step) against
+    w_paired = 1 (paired-row kernel) for every prologue / epilogue the training step uses: GroupNorm affine, GELU operand prologue + residual
+    add, GELU' epilogue, GroupNorm-backward epilogue (plain and cropped to the compact grid), transposed weights, null bias."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    from pytorch_connectomics_amd import _native as nat
+    g = torch.Generator().manual_seed(c_in + c_out + rows)
+    x = torch.randn(N, rows, c_in, generator=g).cuda().bfloat16()
+    W = (torch.randn(c_out, c_in, generator=g) / c_in ** 0.5).cuda()
+    b = torch.randn(c_out, generator=g).cuda()
+    ab = torch.stack([torch.rand(N, c_in, generator=g) + 0.5, torch.randn(N, c_in, generator=g) * 0.2], 1).cuda().contiguous()
+    res = torch.randn(N, rows, c_out, generator=g).cuda().bfloat16()
+    coef = torch.randn(N, 3, c_out, generator=g).cuda().contiguous()
+    wp, wr = ops.pw_pack_weight_paired(W), ops.packed_rowmajor(W)
+    assert ops.pw_conv_rowmajor_supported(c_in=c_in, c_out=c_out, in_dtype=torch.bfloat16, out_dtype=torch.bfloat16)
+    assert torch.equal(ops.packed_rowmajor(W.t().contiguous(), transposed=True), wr)
+
+    def both(**kw):
+        kw = dict(N=N, rows_per_sample=rows, c_in=c_in, c_out=c_out, out_dtype=torch.bfloat16, **kw)
+        a = ops.pw_conv(x, wp, kw.pop("bias", b), w_paired=True, **kw).float()
+        c = ops.pw_conv(x, wr, kw.pop("bias2", b), w_paired=2, **kw).float()
+        return a, c
+
+    def close(a, c, what):
+        den = a.abs().max().item() + 1e-12
+        assert (a - c).abs().max().item() <= 2.0 ** -7 * den, (what, (a - c).abs().max().item(), den)      # one bf16 rounding of the result
+
+    close(*both(ab=ab), "affine")
+    close(*both(pre_act=nat.ACT_GELU, res=res, res_mode=nat.RES_ADD), "gelu prologue + residual")
+    a = ops.pw_conv(x, wp, None, N=N, rows_per_sample=rows, c_in=c_in, c_out=c_out, out_dtype=torch.bfloat16, w_paired=True, res=res,
+                    res_mode=nat.RES_GELU_BWD).float()
+    c = ops.pw_conv(x, wr, None, N=N, rows_per_sample=rows, c_in=c_in, c_out=c_out, out_dtype=torch.bfloat16, w_paired=2, res=res,
+                    res_mode=nat.RES_GELU_BWD).float()
+    close(a, c, "gelu' epilogue, null bias")
+    a = ops.pw_conv(x, wp, None, N=N, rows_per_sample=rows, c_in=c_in, c_out=c_out, out_dtype=torch.bfloat16, w_paired=True, res=res,
+                    res_mode=nat.RES_NORM_BWD, res_bias=coef).float()
+    c = ops.pw_conv(x, wr, None, N=N, rows_per_sample=rows, c_in=c_in, c_out=c_out, out_dtype=torch.bfloat16, w_paired=2, res=res,
+                    res_mode=nat.RES_NORM_BWD, res_bias=coef).float()
+    close(a, c, "norm backward epilogue")
+    side = round(rows ** (1 / 3))
+    if side ** 3 == rows and side >= 2:
+        ya = torch.zeros(N, (side - 1) ** 3, c_out, dtype=torch.bfloat16, device="cuda")
+        yc = torch.zeros_like(ya)
+        for y_, w_, pf in ((ya, wp, True), (yc, wr, 2)):
+            ops.pw_conv(x, w_, None, N=N, rows_per_sample=rows, c_in=c_in, c_out=c_out, out_dtype=torch.bfloat16, w_paired=pf, res=res,
+                        res_mode=nat.RES_NORM_BWD, res_bias=coef, grid=(side, side, side), y=y_)
+        close(ya.float(), yc.float(), "norm backward epilogue, cropped grid")
