@@ -1211,3 +1211,40 @@ def test_rowmajor_gemm_route_of_pw_conv_matches_the_paired_row_kernel(c_in, c_ou
             ops.pw_conv(x, w_, None, N=N, rows_per_sample=rows, c_in=c_in, c_out=c_out, out_dtype=torch.bfloat16, w_paired=pf, res=res,
                         res_mode=nat.RES_NORM_BWD, res_bias=coef, grid=(side, side, side), y=y_)
         close(ya.float(), yc.float(), "norm backward epilogue, cropped grid")
+
+
+def test_training_steps_are_bit_reproducible_with_the_round6_schedule():
+    """Two runs from one seed -- skip-gradient mailbox, asynchronous optimizer tables (pinned ring, non-blocking copies), row-major deep
+    GEMMs, transposed reduction outputs -- give the same losses and the same weights bit for bit after four fused-AdamW steps."""
+    from pytorch_connectomics_amd.config import ConfigNode, schema_defaults
+    from pytorch_connectomics_amd.models import build_model as bm
+    from pytorch_connectomics_amd.training.fused import bce_dice_loss
+    from pytorch_connectomics_amd.training.module import build_optimizer, synthetic_batches
+
+    def run():
+        cfg = ConfigNode(schema_defaults())
+        cfg.model.arch.type, cfg.model.in_channels, cfg.model.out_channels = "mednext", 1, 1
+        cfg.model.mednext.size, cfg.model.mednext.kernel_size = "S", 3
+        cfg.optimization.optimizer.name, cfg.optimization.optimizer.lr = "AdamW", 1e-3
+        cfg.optimization.gradient_clip_val = 1.0
+        torch.manual_seed(0)
+        model = bm(cfg).cuda().train()
+        model.model.compute_dtype = torch.bfloat16
+        opt = build_optimizer(cfg, model)
+        it = synthetic_batches(3, (32, 32, 32), seed=5, device=torch.device("cuda"))
+        pool = [next(it) for _ in range(2)]
+        losses = []
+        for i in range(4):
+            b = pool[i % 2]
+            opt.zero_grad(set_to_none=True)
+            loss, _ = bce_dice_loss(model(b["image"]), b["label"])
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        return [float(v) for v in losses], [p.detach().clone() for p in model.parameters()]
+
+    l0, w0 = run()
+    l1, w1 = run()
+    assert l0 == l1 and all(v == v and abs(v) < 1e6 for v in l0) and l0[-1] < l0[0]
+    assert all(torch.equal(a, b) for a, b in zip(w0, w1))
