@@ -204,3 +204,26 @@ def test_window_pipeline_streams_do_not_change_the_result(dev, dtype):
     for n, ys in outs.items():
         for y in ys:
             assert torch.equal(ref, y), f"{n} streams changed the result (max |d| {float((ref - y).abs().max())})"
+
+
+@pytest.mark.parametrize("C,c0,c1,act", [(7, 0, 7, "sigmoid"), (7, 3, 6, "sigmoid"), (4, 0, 4, "tanh"), (3, 1, 2, "sigmoid"), (8, 0, 8, "none")])
+def test_channels_last_activation_flat_form_equals_the_per_voxel_form(C, c0, c1, act):
+    """pytc_channel_activation on channels-last predictions (the lazy loop's per-batch activation): the flat float4 kernel against the
+    per-voxel kernel (knob channel_act_flat) -- same expressions per element, identical bits; untouched channels stay untouched."""
+    from pytorch_connectomics_amd import hip_ops as ops
+    from pytorch_connectomics_amd import _native as nat
+    code = {"sigmoid": nat.ACT_SIGMOID, "tanh": nat.ACT_TANH, "none": nat.ACT_NONE}[act]
+    x = (torch.randn(2, 12, 10, 14, C, generator=torch.Generator().manual_seed(C + c0)) * 4).cuda()
+    a, b = x.clone(), x.clone()
+    ops.channel_activation(a, c0, c1, code, 1.5, channels_last=True)
+    ops.set_tuning("channel_act_flat", 0)
+    try:
+        ops.channel_activation(b, c0, c1, code, 1.5, channels_last=True)
+    finally:
+        ops.set_tuning("channel_act_flat", 1)
+    assert torch.equal(a, b)
+    keep = [c for c in range(C) if not (c0 <= c < c1)]
+    assert torch.equal(a[..., keep], x[..., keep])
+    ref = x[..., c0:c1] * 1.5
+    ref = torch.sigmoid(ref) if act == "sigmoid" else (torch.tanh(ref) if act == "tanh" else ref)
+    assert torch.allclose(a[..., c0:c1], ref, atol=1e-6, rtol=1e-5)
